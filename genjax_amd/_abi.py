@@ -1,0 +1,93 @@
+"""ctypes mirror of ``include/gjx.h`` (struct layouts, enums, prototypes).
+
+The same declarations serve the HIP library (``genjax_amd/csrc/libgjx_hip.so``) and, in the
+test-suite only, the CPU oracle (``oracle/libgjx_oracle.so``) — they share the *ABI*, never code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+ABI_VERSION = 1
+
+# status
+OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
+
+# distribution kinds
+NORMAL, FLIP, BERNOULLI_LOGITS, BETA, CATEGORICAL_LOGITS, CATEGORICAL_PROBS = 1, 2, 3, 4, 5, 6
+UNIFORM, MVNORMAL_DIAG, EXPONENTIAL, HALF_NORMAL, LAPLACE, LOG_NORMAL, CAUCHY, GAMMA = 7, 8, 9, 10, 11, 12, 13, 14
+KIND_NAMES = {
+    NORMAL: "normal", FLIP: "flip", BERNOULLI_LOGITS: "bernoulli", BETA: "beta",
+    CATEGORICAL_LOGITS: "categorical", CATEGORICAL_PROBS: "categorical(probs)", UNIFORM: "uniform",
+    MVNORMAL_DIAG: "mv_normal_diag", EXPONENTIAL: "exponential", HALF_NORMAL: "half_normal",
+    LAPLACE: "laplace", LOG_NORMAL: "log_normal", CAUCHY: "cauchy", GAMMA: "gamma",
+}
+DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS)
+
+# param forms / transforms / modes / flags / rng
+P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
+XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
+MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT = 0, 1, 2
+SITE_HMC_SELECTED = 1
+RNG_PACKED, RNG_JAX32 = 0, 1
+OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
+MAX_PARAMS = 2
+
+i32, i64, u32, u64, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
+vp = C.c_void_p
+
+
+class GjxParam(C.Structure):
+    _fields_ = [("op", i32), ("xf", i32), ("off", i32), ("len", i32), ("slot", i32), ("n", i32),
+                ("moff", i32), ("pad_", i32)]
+
+
+class GjxSite(C.Structure):
+    _fields_ = [("kind", i32), ("dim", i32), ("slot", i32), ("mode", i32), ("obs_off", i32),
+                ("ncat", i32), ("flags", i32), ("pad_", i32), ("p", GjxParam * MAX_PARAMS)]
+
+
+class GjxProgram(C.Structure):
+    _fields_ = [("n_sites", i32), ("n_slots", i32), ("n_tab", i32), ("rng_mode", i32),
+                ("sites", vp), ("sites_dev", vp), ("tab", vp), ("tab_dev", vp)]
+
+
+class GjxSsm(C.Structure):
+    _fields_ = [("dx", i32), ("dy", i32), ("A_dev", vp), ("H_dev", vp), ("q", f32), ("r", f32),
+                ("q0", f32)]
+
+
+assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 96
+
+PP = C.POINTER(GjxProgram)
+
+# name -> (restype, argtypes) for every symbol include/gjx.h declares
+PROTOTYPES = {
+    "gjx_version": (C.c_int, []),
+    "gjx_last_error": (C.c_char_p, []),
+    "gjx_program_engine": (C.c_int, [PP]),
+    "gjx_threefry2x32": (C.c_int, [u32, u32, u32, u32, i64, vp, vp]),
+    "gjx_run_program": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp,
+                                  C.c_size_t, vp]),
+    "gjx_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
+    "gjx_logsumexp": (C.c_int, [vp, i64, i64, vp, vp, C.c_size_t, vp]),
+    "gjx_lse_combine": (C.c_int, [vp, C.c_int, i64, vp, vp]),
+    "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),
+    "gjx_weight_cumsum": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
+    "gjx_resample_multinomial": (C.c_int, [vp, i64, vp, u32, u32, i64, i64, i64, vp, vp]),
+    "gjx_gather_rows": (C.c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
+    "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
+                               vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_hmc": (C.c_int, [PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp, vp,
+                          C.c_size_t, vp]),
+    "gjx_score_grad": (C.c_int, [PP, i64, vp, vp, vp, vp]),
+}
+
+
+def bind(lib: C.CDLL, prototypes=PROTOTYPES) -> C.CDLL:
+    """Attach restype/argtypes; raises AttributeError if a declared symbol is missing."""
+    for name, (res, args) in prototypes.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

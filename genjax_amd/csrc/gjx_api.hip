@@ -1,0 +1,48 @@
+// gjx_api.hip — library-level entry points: version, errors, workspace sizing, raw Threefry.
+#include "gjx_device.h"
+#include "gjx_host.h"
+
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+
+int gjx_fail(int status, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return status;
+}
+int gjx_fail_hip(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, (int)e, hipGetErrorString(e));
+  return GJX_EHIP;
+}
+
+extern "C" int gjx_version(void) { return GJX_ABI_VERSION; }
+extern "C" const char* gjx_last_error(void) { return g_err; }
+
+// One bound for every op: 16 bytes per 64 particles (block partials: {max,sum} floats, u64 block
+// sums, {value,index} argmax pairs) plus a fixed header.
+extern "C" size_t gjx_workspace_bytes(int op, int64_t K) {
+  (void)op;
+  if (K < 0) K = 0;
+  return (size_t)(16 * ((K + 63) / 64) + 65536);
+}
+
+namespace gjx {
+__global__ __launch_bounds__(256) void k_threefry(key2 key, uint32_t ctr_hi, uint32_t ctr_lo0, int64_t n, uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t c = (((uint64_t)ctr_hi << 32) | ctr_lo0) + (uint64_t)i;
+  const key2 h = threefry2x32(key, (uint32_t)(c >> 32), (uint32_t)c);
+  out[2 * i] = h.a;
+  out[2 * i + 1] = h.b;
+}
+}  // namespace gjx
+
+extern "C" int gjx_threefry2x32(uint32_t key0, uint32_t key1, uint32_t ctr_hi, uint32_t ctr_lo0, int64_t n,
+                                uint32_t* out_dev, void* stream) {
+  if (n < 0 || (n > 0 && !out_dev)) return gjx_fail(GJX_EINVAL, "gjx_threefry2x32: bad argument");
+  if (n == 0) return GJX_OK;
+  hipLaunchKernelGGL(gjx::k_threefry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     gjx::key2{key0, key1}, ctr_hi, ctr_lo0, n, out_dev);
+  GJX_CHECK_LAUNCH("gjx_threefry2x32");
+  return GJX_OK;
+}

@@ -1,0 +1,330 @@
+// gjx_device.h — device-side building blocks for the gfx950 kernels: Threefry-2x32, bits ->
+// uniform/normal/Gumbel, the primitive samplers and log-densities, parameter evaluation.
+//
+// Written for CDNA4 (wave64, no dual issue): integer hash work is plain VALU
+// (v_add_u32 / v_alignbit_b32 / v_xor_b32 — 3 ops per Threefry round), transcendentals use the
+// hardware v_log_f32 / v_exp_f32 / v_rcp_f32 / v_sqrt_f32 approximations (≈1 ulp), which is why
+// float parity with the CPU oracle is a tolerance, while every integer (hash words, indices,
+// fixed-point weights) is bit-exact.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gjx.h"
+
+#define GJX_DEV __device__ __forceinline__
+
+namespace gjx {
+
+struct key2 {
+  uint32_t a, b;
+};
+
+GJX_DEV uint32_t rotl32(uint32_t x, int r) { return __builtin_rotateleft32(x, r); }
+
+// Threefry-2x32, 20 rounds.  Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (2011);
+// the generator behind jax.random (jax/_src/prng.py threefry2x32).
+GJX_DEV key2 threefry2x32(key2 k, uint32_t c0, uint32_t c1) {
+  const uint32_t ks0 = k.a, ks1 = k.b, ks2 = k.a ^ k.b ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + ks0, x1 = c1 + ks1;
+#define GJX_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  GJX_R(13) GJX_R(15) GJX_R(26) GJX_R(6)
+  x0 += ks1; x1 += ks2 + 1u;
+  GJX_R(17) GJX_R(29) GJX_R(16) GJX_R(24)
+  x0 += ks2; x1 += ks0 + 2u;
+  GJX_R(13) GJX_R(15) GJX_R(26) GJX_R(6)
+  x0 += ks0; x1 += ks1 + 3u;
+  GJX_R(17) GJX_R(29) GJX_R(16) GJX_R(24)
+  x0 += ks1; x1 += ks2 + 4u;
+  GJX_R(13) GJX_R(15) GJX_R(26) GJX_R(6)
+  x0 += ks2; x1 += ks0 + 5u;
+#undef GJX_R
+  return key2{x0, x1};
+}
+
+// jax.random.fold_in(k, i) == jax.random.split(k, n)[i] with jax_threefry_partitionable=True
+GJX_DEV key2 fold_in(key2 k, uint32_t i) { return threefry2x32(k, 0u, i); }
+GJX_DEV key2 fold_in64(key2 k, uint64_t i) { return threefry2x32(k, (uint32_t)(i >> 32), (uint32_t)i); }
+
+// Sequential element-bit source for one site key.  PACKED: element c = word (c&1) of hash (c>>1);
+// JAX32: element c = x0^x1 of hash c.  get(c) may be called with any c; consecutive c reuse the
+// cached hash in PACKED mode.
+template <int RNG>
+struct BitStream {
+  key2 sk;
+  key2 cache;
+  uint32_t cached_h;
+  GJX_DEV explicit BitStream(key2 k) : sk(k), cache{0u, 0u}, cached_h(0xFFFFFFFFu) {}
+  GJX_DEV uint32_t get(uint32_t c) {
+    if (RNG == GJX_RNG_JAX32) {
+      key2 h = threefry2x32(sk, 0u, c);
+      return h.a ^ h.b;
+    }
+    const uint32_t hidx = c >> 1;
+    if (hidx != cached_h) {
+      cache = threefry2x32(sk, 0u, hidx);
+      cached_h = hidx;
+    }
+    return (c & 1u) ? cache.b : cache.a;
+  }
+};
+
+// ---- bits -> floats (jax/_src/random.py _uniform, _normal_real, gumbel) ------------------------
+GJX_DEV float bits_to_unit(uint32_t bits) { return __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f; }
+
+GJX_DEV float uniform_from_bits(uint32_t bits, float lo, float hi) {
+  const float v = bits_to_unit(bits) * (hi - lo) + lo;
+  return fmaxf(lo, v);
+}
+
+constexpr float kLn2 = 0.69314718056f;
+constexpr float kHalfLog2Pi = 0.918938533f;
+constexpr float kLogPi = 1.14472989f;
+constexpr float kSqrt2 = 1.41421356f;
+constexpr float kTiny = 1.17549435e-38f;
+constexpr float kNeg1PlusUlp = -0.99999994f;
+constexpr float kPi = 3.14159265f;
+
+GJX_DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }        // v_log_f32
+GJX_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); } // v_exp_f32
+GJX_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }               // v_rcp_f32
+GJX_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }             // v_sqrt_f32
+
+// log for arguments that can be denormal-small (uniform(tiny,1)): v_log_f32 flushes denormals,
+// so scale into the normal range first.
+GJX_DEV float safe_log(float x) {
+  const bool small = x < 1.0e-30f;
+  const float xs = small ? x * 1.8446744e19f /*2^64*/ : x;
+  const float l = __builtin_amdgcn_logf(xs);
+  return (small ? l - 64.0f : l) * kLn2;
+}
+
+GJX_DEV float log1p_acc(float x) {  // log(1+x), accurate near 0 (series below 2^-6)
+  const float u = 1.0f + x;
+  if (fabsf(x) < 0.015625f) {
+    // log1p(x) = x - x^2/2 + x^3/3 - x^4/4 + x^5/5   (|x| < 2^-6 -> rel. error < 1e-9)
+    return x * (1.0f + x * (-0.5f + x * (0.333333333f + x * (-0.25f + x * 0.2f))));
+  }
+  return fast_log(u);
+}
+
+// Giles (2010) single-precision erfinv (the polynomial of XLA's ErfInv32)
+GJX_DEV float erfinv_f32(float x) {
+  float w = -fast_log(fmaf(-x, x, 1.0f));
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f);
+    p = fmaf(p, w, -3.5233877e-06f);
+    p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f);
+    p = fmaf(p, w, -0.00125372503f);
+    p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f);
+    p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = fast_sqrt(w) - 3.0f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f);
+    p = fmaf(p, w, 0.00134934322f);
+    p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f);
+    p = fmaf(p, w, -0.0076224613f);
+    p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f);
+    p = fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+
+GJX_DEV float normal_from_bits(uint32_t bits) {
+  const float u = uniform_from_bits(bits, kNeg1PlusUlp, 1.0f);
+  return kSqrt2 * erfinv_f32(u);
+}
+GJX_DEV float gumbel_from_bits(uint32_t bits) {
+  const float u = uniform_from_bits(bits, kTiny, 1.0f);
+  return -fast_log(-safe_log(u));
+}
+
+GJX_DEV float softplus(float x) { return fmaxf(x, 0.0f) + log1p_acc(fast_exp(-fabsf(x))); }
+GJX_DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+// ---- parameter evaluation ------------------------------------------------------------------
+// `val(slot)` returns the current particle's value of a slot.
+template <class ValFn>
+GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val) {
+  switch (p.op) {
+    case GJX_P_CONST: return tab[p.off + (p.len == 1 ? 0 : d % p.len)];
+    case GJX_P_VALUE: return val(p.slot + (p.len == 1 ? 0 : d % p.len));
+    case GJX_P_GATHER: {
+      int idx = (int)val(p.slot);
+      idx = idx < 0 ? 0 : (idx > p.n - 1 ? p.n - 1 : idx);
+      return tab[p.off + idx * p.len + (p.len == 1 ? 0 : d % p.len)];
+    }
+    case GJX_P_AFFINE: {
+      float acc = tab[p.off + (p.len == 1 ? 0 : d % p.len)];
+      const float* row = tab + p.moff + d * p.n;
+      for (int e = 0; e < p.n; ++e) acc = fmaf(row[e], val(p.slot + e), acc);
+      return acc;
+    }
+    default: return __builtin_nanf("");
+  }
+}
+GJX_DEV float apply_xf(int xf, float v) {
+  switch (xf) {
+    case GJX_XF_EXP: return fast_exp(v);
+    case GJX_XF_SOFTPLUS: return softplus(v);
+    case GJX_XF_SIGMOID: return sigmoid(v);
+    default: return v;
+  }
+}
+template <class ValFn>
+GJX_DEV float eval_param(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val) {
+  return apply_xf(p.xf, eval_param_pre(p, d, tab, val));
+}
+
+// ---- log-densities of one scalar element (TFP 0.23 log_prob closed forms) --------------------
+GJX_DEV float normal_logpdf(float x, float mu, float sd) {
+  const float rs = fast_rcp(sd);
+  const float z = (x - mu) * rs;
+  return fmaf(-0.5f * z, z, -(kHalfLog2Pi + fast_log(sd)));
+}
+
+GJX_DEV float elem_logpdf(int kind, float x, float a, float b) {
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: return normal_logpdf(x, a, b);
+    case GJX_FLIP:
+      return (x != 0.0f ? fast_log(a) : 0.0f) + (x != 1.0f ? (1.0f - x) * log1p_acc(-a) : 0.0f);
+    case GJX_BERNOULLI_LOGITS:
+      return (x != 0.0f ? -softplus(-a) * x : 0.0f) + (x != 1.0f ? -softplus(a) * (1.0f - x) : 0.0f);
+    case GJX_BETA: {
+      const float t1 = (a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * fast_log(x);
+      const float t2 = (b - 1.0f) == 0.0f ? 0.0f : (b - 1.0f) * log1p_acc(-x);
+      return t1 + t2 - (lgammaf(a) + lgammaf(b) - lgammaf(a + b));
+    }
+    case GJX_UNIFORM: return (x < a || x > b) ? -INFINITY : -fast_log(b - a);
+    case GJX_EXPONENTIAL: return x < 0.0f ? -INFINITY : fast_log(a) - a * x;
+    case GJX_HALF_NORMAL: {
+      const float z = x * fast_rcp(a);
+      return x < 0.0f ? -INFINITY : (-0.225791353f /*0.5*log(2/pi)*/ - fast_log(a) - 0.5f * z * z);
+    }
+    case GJX_LAPLACE: return -fabsf(x - a) * fast_rcp(b) - fast_log(2.0f * b);
+    case GJX_LOG_NORMAL: {
+      const float lx = fast_log(x);
+      return normal_logpdf(lx, a, b) - lx;
+    }
+    case GJX_CAUCHY: {
+      const float z = (x - a) * fast_rcp(b);
+      return -(kLogPi + fast_log(b)) - log1p_acc(z * z);
+    }
+    case GJX_GAMMA: {
+      const float t0 = a == 0.0f ? 0.0f : a * fast_log(b);
+      const float t1 = (a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * fast_log(x);
+      return t0 + t1 - b * x - lgammaf(a);
+    }
+    default: return __builtin_nanf("");
+  }
+}
+
+// ---- samplers ----------------------------------------------------------------------------------
+constexpr int kGammaMaxIt = 32;
+constexpr int kGammaNDraw = 2 * kGammaMaxIt + 1;
+
+GJX_DEV int draws_per_elem(int kind) {
+  return kind == GJX_BETA ? 2 * kGammaNDraw : (kind == GJX_GAMMA ? kGammaNDraw : 1);
+}
+
+// Marsaglia & Tsang (2000), log space, fixed draw budget (same element schedule as the oracle)
+template <int RNG>
+GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
+  float boost = 0.0f, aa = a;
+  if (a < 1.0f) {
+    const float u = uniform_from_bits(bs.get(base + 2 * kGammaMaxIt), kTiny, 1.0f);
+    boost = safe_log(u) / a;
+    aa = a + 1.0f;
+  }
+  const float d = aa - (1.0f / 3.0f);
+  const float c = 1.0f / sqrtf(9.0f * d);
+  float res = fast_log(d);
+  for (int t = 0; t < kGammaMaxIt; ++t) {
+    const float x = normal_from_bits(bs.get(base + 2 * t));
+    const float u = uniform_from_bits(bs.get(base + 2 * t + 1), kTiny, 1.0f);
+    float v = fmaf(c, x, 1.0f);
+    if (v <= 0.0f) continue;
+    const float lv = 3.0f * fast_log(v);
+    v = v * v * v;
+    if (safe_log(u) < 0.5f * x * x + d - d * v + d * lv) {
+      res = fast_log(d) + lv;
+      break;
+    }
+  }
+  return res + boost;
+}
+
+template <int RNG>
+GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, float b) {
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: return fmaf(b, normal_from_bits(bs.get(c)), a);
+    case GJX_FLIP: return bits_to_unit(bs.get(c)) < a ? 1.0f : 0.0f;
+    case GJX_BERNOULLI_LOGITS: return bits_to_unit(bs.get(c)) < sigmoid(a) ? 1.0f : 0.0f;
+    case GJX_BETA: {
+      const float g1 = log_gamma_variate<RNG>(bs, c, a);
+      const float g2 = log_gamma_variate<RNG>(bs, c + kGammaNDraw, b);
+      return sigmoid(g1 - g2);
+    }
+    case GJX_UNIFORM: return fmaf(b - a, bits_to_unit(bs.get(c)), a);
+    case GJX_EXPONENTIAL: return -safe_log(uniform_from_bits(bs.get(c), kTiny, 1.0f)) / a;
+    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(bs.get(c))) * a;
+    case GJX_LAPLACE: {
+      const float u = uniform_from_bits(bs.get(c), kNeg1PlusUlp, 1.0f);
+      const float s = (float)((u > 0.0f) - (u < 0.0f));
+      return a - b * s * log1p_acc(-fabsf(u));
+    }
+    case GJX_LOG_NORMAL: return fast_exp(fmaf(b, normal_from_bits(bs.get(c)), a));
+    case GJX_CAUCHY: return fmaf(b, tanf(kPi * (bits_to_unit(bs.get(c)) - 0.5f)), a);
+    case GJX_GAMMA: return fast_exp(log_gamma_variate<RNG>(bs, c, a)) / b;
+    default: return __builtin_nanf("");
+  }
+}
+
+// ---- reductions --------------------------------------------------------------------------------
+GJX_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+GJX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide {max, sum exp(x - max)} of one value per thread; result valid in thread 0.
+// `red` is LDS scratch of >= 2 * (blockDim/64) floats.
+template <int THREADS>
+GJX_DEV void block_lse_partial(float x, bool valid, float* red, float& out_max, float& out_sum) {
+  constexpr int NW = THREADS / 64;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float xm = valid ? x : -INFINITY;
+  float m = wave_max(xm);
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  float bm = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
+  float e = (valid && bm > -INFINITY) ? fast_exp(x - bm) : 0.0f;
+  float s = wave_sum(e);
+  if (lane == 0) red[NW + wid] = s;
+  __syncthreads();
+  float bs = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bs += red[NW + w];
+  out_max = bm;
+  out_sum = bs;
+}
+
+}  // namespace gjx

@@ -1,0 +1,19 @@
+// gjx_host.h — host-side helpers shared by the launchers (error reporting only; no state).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/gjx.h"
+
+int gjx_fail(int status, const char* msg);           // records the thread-local message, returns status
+int gjx_fail_hip(hipError_t e, const char* where);   // same for a HIP error
+
+#define GJX_CHECK_LAUNCH(where)                                  \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) return gjx_fail_hip(e__, where);      \
+  } while (0)
+
+// {max,sumexp} block partials -> out[4] = {max, sumexp, lse, lse - log(K_total)}  (gjx_run.hip)
+int gjx_launch_lse_finish(const void* partials_float2, int n, int64_t K_total, float* out, hipStream_t st);

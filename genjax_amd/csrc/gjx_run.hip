@@ -1,0 +1,570 @@
+// gjx_run.hip — particle propagate + reweight kernels (gjx_run_program) for gfx950.
+//
+//   k_run_generic : site-list interpreter, one particle per lane.  Site descriptors are read
+//                   through wave-uniform addresses (scalar loads, SGPRs); particle values live in
+//                   the SoA rows of choices[][] (coalesced 256 B per wave per row).
+//   k_run_gmm     : hand-fused kernel for the mixture shape of BASELINE config 2
+//                   (categorical -> mv_normal_diag(gather) -> observed mv_normal_diag), PPT
+//                   particles per lane so that every SoA row is written with 16-byte stores; tables
+//                   staged in LDS with a padded row stride (conflict-free ds_read_b128); the
+//                   block's {max, sum-exp} of the log-weights reduced with wave shuffles + LDS.
+// Both produce identical random streams (same Threefry counters) — tests compare them bitwise on
+// the integer side and to float tolerance on the float side.
+#include "gjx_device.h"
+#include "gjx_host.h"
+
+namespace gjx {
+
+// ------------------------------------------------------------------------------------------
+// generic interpreter
+// ------------------------------------------------------------------------------------------
+struct RunArgs {
+  const gjx_site* sites;
+  const float* tab;
+  int n_sites, n_slots;
+  key2 key;
+  int64_t K, offset;
+  float* choices;
+  float* score;
+  float* weight;
+  float* logw;
+  const float* logw_in;
+  const float* sub;
+  float* site_scores;
+  float2* partials;  // per block {max, sumexp} of logw (or NULL)
+};
+
+template <int RNG>
+__global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
+  __shared__ float red[8];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.K;
+  const int64_t ii = active ? i : a.K - 1;  // inactive lanes shadow the last particle (no stores)
+  const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
+  const float* __restrict__ tab = a.tab;
+  float* ch = a.choices;
+  const int64_t K = a.K;
+  auto val = [&](int slot) -> float { return ch[(int64_t)slot * K + ii]; };
+
+  float score = 0.0f, weight = 0.0f;
+  for (int j = 0; j < a.n_sites; ++j) {
+    const gjx_site& s = a.sites[j];
+    const int kind = s.kind, mode = s.mode, slot = s.slot;
+    BitStream<RNG> bs(mode == GJX_MODE_SAMPLE ? fold_in(pk, (uint32_t)(j + 1)) : key2{0u, 0u});
+    float lp = 0.0f;
+    if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
+      const int n = s.ncat;
+      const bool probs = kind == GJX_CATEGORICAL_PROBS;
+      float mx = -INFINITY;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(s.p[0], c, tab, val);
+        if (probs) l = safe_log(l);
+        mx = fmaxf(mx, l);
+      }
+      float se = 0.0f;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(s.p[0], c, tab, val);
+        if (probs) l = safe_log(l);
+        se += fast_exp(l - mx);
+      }
+      const float lse = mx + fast_log(se);
+      float v;
+      if (mode == GJX_MODE_SAMPLE) {
+        int best = 0;
+        float bestv = -INFINITY;
+        for (int c = 0; c < n; ++c) {
+          float l = eval_param(s.p[0], c, tab, val);
+          if (probs) l = safe_log(l);
+          const float g = l + gumbel_from_bits(bs.get((uint32_t)c));
+          if (g > bestv) { bestv = g; best = c; }
+        }
+        v = (float)best;
+      } else if (mode == GJX_MODE_OBS_TAB) {
+        v = tab[s.obs_off];
+      } else {
+        v = val(slot);
+      }
+      const int k = (int)v;
+      if (k < 0 || k >= n) {
+        lp = -INFINITY;
+      } else {
+        float l = eval_param(s.p[0], k, tab, val);
+        if (probs) l = safe_log(l);
+        lp = l - lse;
+      }
+      if (slot >= 0 && active) ch[(int64_t)slot * K + i] = v;
+    } else {
+      const int nd = draws_per_elem(kind);
+      const int dim = s.dim;
+      for (int d = 0; d < dim; ++d) {
+        const float pa = eval_param(s.p[0], d, tab, val);
+        const float pb = eval_param(s.p[1], d, tab, val);
+        float v;
+        if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(kind, bs, (uint32_t)(d * nd), pa, pb);
+        else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
+        else v = val(slot + d);
+        lp += elem_logpdf(kind, v, pa, pb);
+        if (slot >= 0 && active && mode != GJX_MODE_OBS_SLOT) ch[(int64_t)(slot + d) * K + i] = v;
+      }
+    }
+    score += lp;
+    if (mode != GJX_MODE_SAMPLE) weight += lp;
+    if (a.site_scores && active) a.site_scores[(int64_t)j * K + i] = lp;
+  }
+  float lw = weight;
+  if (a.logw_in) lw += a.logw_in[ii];
+  if (a.sub) lw -= a.sub[ii];
+  if (active) {
+    if (a.score) a.score[i] = score;
+    if (a.weight) a.weight[i] = weight;
+    if (a.logw) a.logw[i] = lw;
+  }
+  if (a.partials) {
+    float bm, bsum;
+    block_lse_partial<256>(lw, active, red, bm, bsum);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = make_float2(bm, bsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused mixture kernel
+// ------------------------------------------------------------------------------------------
+struct GmmArgs {
+  const float* tab;
+  int C;
+  int logits_off, mu_off, sig_off;  // tab offsets; mu/sig tables are [C][D]
+  int r_off, r_len, y_off;
+  key2 key;
+  int64_t K, offset;
+  float* choices;  // row 0: z, rows 1..D: x
+  float* score;
+  float* weight;
+  float* logw;
+  const float* logw_in;
+  const float* sub;
+  float2* partials;
+};
+
+template <int PPT>
+struct VecStore;
+template <>
+struct VecStore<1> {
+  static GJX_DEV void st(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <>
+struct VecStore<2> {
+  static GJX_DEV void st(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <>
+struct VecStore<4> {
+  static GJX_DEV void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// Each lane owns PPT consecutive particles; ALIGNED: K % PPT == 0 (row bases stay PPT*4-byte aligned)
+template <int RNG, int D, int PPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
+  constexpr int DS = D + 4;  // padded LDS row stride: rows of different z land on different 16-B slots
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C;
+  float* s_mu = smem;                 // [C][DS]
+  float* s_sig = s_mu + C * DS;       // [C][DS]
+  float* s_rsig = s_sig + C * DS;     // [C][DS]   1/sigma
+  float* s_logit = s_rsig + C * DS;   // [C] raw logits
+  float* s_zlp = s_logit + C;         // [C] log_softmax(logits)[c] - sum_d log sigma[c][d] - D*0.5*log(2pi)
+  float* s_zonly = s_zlp + C;         // [C] log_softmax(logits)[c]
+  float* s_y = s_zonly + C;           // [D]
+  float* s_rr = s_y + D;              // [D] 1/r
+  float* s_misc = s_rr + D;           // [0]: -sum_d log r_d - D*0.5*log(2pi);  [8..]: reduction scratch
+  const float* __restrict__ tab = a.tab;
+
+  for (int t = threadIdx.x; t < C * D; t += THREADS) {
+    const int c = t / D, d = t % D;
+    const float sg = tab[a.sig_off + t];
+    s_mu[c * DS + d] = tab[a.mu_off + t];
+    s_sig[c * DS + d] = sg;
+    s_rsig[c * DS + d] = fast_rcp(sg);
+  }
+  for (int t = threadIdx.x; t < D; t += THREADS) {
+    s_y[t] = tab[a.y_off + t];
+    s_rr[t] = fast_rcp(tab[a.r_off + (a.r_len == 1 ? 0 : t)]);
+  }
+  for (int t = threadIdx.x; t < C; t += THREADS) s_logit[t] = tab[a.logits_off + t];
+  __syncthreads();
+  if (threadIdx.x < 64) {  // wave 0: log-softmax and per-component constants
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 64) mx = fmaxf(mx, s_logit[c]);
+    mx = wave_max(mx);
+    float se = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 64) se += fast_exp(s_logit[c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + fast_log(se);
+    for (int c = threadIdx.x; c < C; c += 64) {
+      float sl = 0.0f;
+      for (int d = 0; d < D; ++d) sl += fast_log(s_sig[c * DS + d]);
+      const float zl = s_logit[c] - lse;
+      s_zonly[c] = zl;
+      s_zlp[c] = zl - sl - (float)D * kHalfLog2Pi;
+    }
+    if (threadIdx.x == 0) {
+      float sl = 0.0f;
+      for (int d = 0; d < D; ++d) sl += fast_log(tab[a.r_off + (a.r_len == 1 ? 0 : d)]);
+      s_misc[0] = -sl - (float)D * kHalfLog2Pi;
+    }
+  }
+  __syncthreads();
+
+  const int64_t K = a.K;
+  const int64_t tile = (int64_t)THREADS * PPT;
+  const int64_t ntiles = (K + tile - 1) / tile;
+  float tmax = -INFINITY;   // running per-thread max / sum for the block's LSE partial
+  float tsum = 0.0f;
+  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;
+    key2 sk1[PPT], sk2[PPT];
+    bool act[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      act[p] = (i0 + p) < K;
+      const int64_t ii = act[p] ? i0 + p : K - 1;
+      const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
+      sk1[p] = fold_in(pk, 1u);
+      sk2[p] = fold_in(pk, 2u);
+    }
+    // ---- z ~ categorical(logits): Gumbel-max ----
+    int z[PPT];
+    float zf[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      float bestv = -INFINITY;
+      int best = 0;
+      if (RNG == GJX_RNG_JAX32) {
+        for (int c = 0; c < C; ++c) {
+          const key2 h = threefry2x32(sk1[p], 0u, (uint32_t)c);
+          const float g = s_logit[c] + gumbel_from_bits(h.a ^ h.b);
+          if (g > bestv) { bestv = g; best = c; }
+        }
+      } else {
+        for (int c = 0; c < C; c += 2) {
+          const key2 h = threefry2x32(sk1[p], 0u, (uint32_t)(c >> 1));
+          const float g0 = s_logit[c] + gumbel_from_bits(h.a);
+          if (g0 > bestv) { bestv = g0; best = c; }
+          if (c + 1 < C) {
+            const float g1 = s_logit[c + 1] + gumbel_from_bits(h.b);
+            if (g1 > bestv) { bestv = g1; best = c + 1; }
+          }
+        }
+      }
+      z[p] = best;
+      zf[p] = (float)best;
+    }
+    const bool full = (i0 + PPT) <= K;
+    float* ch = a.choices;
+    if (full) VecStore<PPT>::st(ch + i0, zf);
+    else {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) if (act[p]) ch[i0 + p] = zf[p];
+    }
+    // ---- x ~ N(mu[z], sigma[z]); y | x ~ N(x, r) observed ----
+    float qx[PPT], qy[PPT];  // sums of squared z-scores
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) { qx[p] = 0.0f; qy[p] = 0.0f; }
+#pragma unroll 2
+    for (int d0 = 0; d0 < D; d0 += 2) {
+      float xa[PPT], xb[PPT];
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        uint32_t b0, b1;
+        if (RNG == GJX_RNG_JAX32) {
+          const key2 h0 = threefry2x32(sk2[p], 0u, (uint32_t)d0);
+          b0 = h0.a ^ h0.b;
+          if (d0 + 1 < D) { const key2 h1 = threefry2x32(sk2[p], 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; } else b1 = 0u;
+        } else {
+          const key2 h = threefry2x32(sk2[p], 0u, (uint32_t)(d0 >> 1));
+          b0 = h.a; b1 = h.b;
+        }
+        const int zo = z[p] * DS;
+        {
+          const float mu = s_mu[zo + d0], sg = s_sig[zo + d0], rs = s_rsig[zo + d0];
+          const float x = fmaf(sg, normal_from_bits(b0), mu);
+          const float zx = (x - mu) * rs;
+          qx[p] = fmaf(zx, zx, qx[p]);
+          const float zy = (s_y[d0] - x) * s_rr[d0];
+          qy[p] = fmaf(zy, zy, qy[p]);
+          xa[p] = x;
+        }
+        if (d0 + 1 < D) {
+          const float mu = s_mu[zo + d0 + 1], sg = s_sig[zo + d0 + 1], rs = s_rsig[zo + d0 + 1];
+          const float x = fmaf(sg, normal_from_bits(b1), mu);
+          const float zx = (x - mu) * rs;
+          qx[p] = fmaf(zx, zx, qx[p]);
+          const float zy = (s_y[d0 + 1] - x) * s_rr[d0 + 1];
+          qy[p] = fmaf(zy, zy, qy[p]);
+          xb[p] = x;
+        } else xb[p] = 0.0f;
+      }
+      float* r0 = ch + (int64_t)(1 + d0) * K + i0;
+      if (full) {
+        VecStore<PPT>::st(r0, xa);
+        if (d0 + 1 < D) VecStore<PPT>::st(r0 + K, xb);
+      } else {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) if (act[p]) { r0[p] = xa[p]; if (d0 + 1 < D) r0[K + p] = xb[p]; }
+      }
+    }
+    float sc[PPT], wt[PPT], lw[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      wt[p] = fmaf(-0.5f, qy[p], s_misc[0]);
+      sc[p] = fmaf(-0.5f, qx[p], s_zlp[z[p]]) + wt[p];
+      float l = wt[p];
+      const int64_t ii = act[p] ? i0 + p : K - 1;
+      if (a.logw_in) l += a.logw_in[ii];
+      if (a.sub) l -= a.sub[ii];
+      lw[p] = l;
+    }
+    if (full) {
+      if (a.score) VecStore<PPT>::st(a.score + i0, sc);
+      if (a.weight) VecStore<PPT>::st(a.weight + i0, wt);
+      if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);
+    } else {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) if (act[p]) {
+        if (a.score) a.score[i0 + p] = sc[p];
+        if (a.weight) a.weight[i0 + p] = wt[p];
+        if (a.logw) a.logw[i0 + p] = lw[p];
+      }
+    }
+    // online {max, sum} per thread
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) if (act[p]) {
+      const float nm = fmaxf(tmax, lw[p]);
+      if (nm > -INFINITY) tsum = tsum * fast_exp(tmax - nm) + fast_exp(lw[p] - nm);
+      tmax = nm;
+    }
+  }
+  if (a.partials) {
+    constexpr int NW = THREADS / 64;
+    float* red = s_misc + 8;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float wm = wave_max(tmax);
+    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+    if (lane == 0) { red[wid] = wm; red[NW + wid] = ws; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float bm = red[0];
+      for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
+      float bsum = 0.0f;
+      for (int w = 0; w < NW; ++w) bsum += bm > -INFINITY ? red[NW + w] * fast_exp(red[w] - bm) : 0.0f;
+      a.partials[blockIdx.x] = make_float2(bm, bsum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LSE: partials -> {max, sumexp, lse, lse - log K_total}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lse_finish(const float2* partials, int n, float log_k_total, float* out) {
+  __shared__ float red[8];
+  float m = -INFINITY;
+  for (int t = threadIdx.x; t < n; t += 256) m = fmaxf(m, partials[t].x);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.0f;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const float2 p = partials[t];
+    if (p.x > -INFINITY) s += p.y * fast_exp(p.x - bm);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float bs = red[4] + red[5] + red[6] + red[7];
+    const float lse = bm > -INFINITY ? bm + logf(bs) : -INFINITY;
+    out[0] = bm; out[1] = bs; out[2] = lse; out[3] = lse - log_k_total;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lse_partial(const float* x, int64_t K, float2* partials) {
+  __shared__ float red[8];
+  float tmax = -INFINITY, tsum = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < K; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    const float nm = fmaxf(tmax, v);
+    if (nm > -INFINITY) tsum = tsum * fast_exp(tmax - nm) + fast_exp(v - nm);
+    tmax = nm;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float wm = wave_max(tmax);
+  const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+  if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float bs = 0.0f;
+    for (int w = 0; w < 4; ++w) bs += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;
+    partials[blockIdx.x] = make_float2(bm, bs);
+  }
+}
+
+}  // namespace gjx
+
+using namespace gjx;
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// engine ids reported by gjx_program_engine
+enum { ENGINE_GENERIC = 0, ENGINE_GMM = 1 };
+
+struct GmmShape {
+  int C, D, logits_off, mu_off, sig_off, r_off, r_len, y_off;
+};
+
+// Recognise: [categorical_logits(CONST) SAMPLE] -> [mvnormal_diag(GATHER(z), GATHER(z)) SAMPLE]
+//            -> [mvnormal_diag(VALUE(x), CONST) OBS_TAB], slots z=0, x=1..D.
+bool match_gmm(const gjx_program* p, GmmShape* g) {
+  if (p->n_sites != 3) return false;
+  const gjx_site& s0 = p->sites[0];
+  const gjx_site& s1 = p->sites[1];
+  const gjx_site& s2 = p->sites[2];
+  if (s0.kind != GJX_CATEGORICAL_LOGITS || s0.mode != GJX_MODE_SAMPLE || s0.slot != 0) return false;
+  if (s0.p[0].op != GJX_P_CONST || s0.p[0].xf != GJX_XF_NONE || s0.p[0].len != s0.ncat) return false;
+  if ((s1.kind != GJX_MVNORMAL_DIAG && s1.kind != GJX_NORMAL) || s1.mode != GJX_MODE_SAMPLE || s1.slot != 1) return false;
+  const int D = s1.dim, C = s0.ncat;
+  for (int k = 0; k < 2; ++k) {
+    const gjx_param& q = s1.p[k];
+    if (q.op != GJX_P_GATHER || q.xf != GJX_XF_NONE || q.slot != 0 || q.n != C || q.len != D) return false;
+  }
+  if ((s2.kind != GJX_MVNORMAL_DIAG && s2.kind != GJX_NORMAL) || s2.mode != GJX_MODE_OBS_TAB || s2.dim != D) return false;
+  if (s2.p[0].op != GJX_P_VALUE || s2.p[0].xf != GJX_XF_NONE || s2.p[0].slot != 1 || s2.p[0].len != D) return false;
+  if (s2.p[1].op != GJX_P_CONST || s2.p[1].xf != GJX_XF_NONE || (s2.p[1].len != 1 && s2.p[1].len != D)) return false;
+  if (p->n_slots != 1 + D) return false;
+  if (C < 1 || C > 64) return false;
+  if (!(D == 1 || D == 2 || D == 4 || D == 8 || D == 16 || D == 32 || D == 64)) return false;
+  g->C = C; g->D = D;
+  g->logits_off = s0.p[0].off; g->mu_off = s1.p[0].off; g->sig_off = s1.p[1].off;
+  g->r_off = s2.p[1].off; g->r_len = s2.p[1].len; g->y_off = s2.obs_off;
+  return true;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+template <int RNG, int D, int PPT>
+void launch_gmm_t(const GmmArgs& a, int grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_run_gmm<RNG, D, PPT, 256>), dim3(grid), dim3(256), lds, st, a);
+}
+template <int RNG, int D>
+void launch_gmm_d(const GmmArgs& a, int ppt, int grid, size_t lds, hipStream_t st) {
+  if (ppt == 4) launch_gmm_t<RNG, D, 4>(a, grid, lds, st);
+  else if (ppt == 2) launch_gmm_t<RNG, D, 2>(a, grid, lds, st);
+  else launch_gmm_t<RNG, D, 1>(a, grid, lds, st);
+}
+template <int RNG>
+void launch_gmm(const GmmArgs& a, int D, int ppt, int grid, size_t lds, hipStream_t st) {
+  switch (D) {
+    case 1: launch_gmm_d<RNG, 1>(a, ppt, grid, lds, st); break;
+    case 2: launch_gmm_d<RNG, 2>(a, ppt, grid, lds, st); break;
+    case 4: launch_gmm_d<RNG, 4>(a, ppt, grid, lds, st); break;
+    case 8: launch_gmm_d<RNG, 8>(a, ppt, grid, lds, st); break;
+    case 16: launch_gmm_d<RNG, 16>(a, ppt, grid, lds, st); break;
+    case 32: launch_gmm_d<RNG, 32>(a, ppt, grid, lds, st); break;
+    default: launch_gmm_d<RNG, 64>(a, ppt, grid, lds, st); break;
+  }
+}
+
+}  // namespace
+
+int gjx_launch_lse_finish(const void* partials, int n, int64_t K_total, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_lse_finish, dim3(1), dim3(256), 0, st, (const float2*)partials, n,
+                     (float)log((double)K_total), out);
+  GJX_CHECK_LAUNCH("lse_finish");
+  return GJX_OK;
+}
+
+extern "C" int gjx_program_engine(const gjx_program* prog) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  GmmShape g;
+  if (!env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g)) return ENGINE_GMM;
+  return ENGINE_GENERIC;
+}
+
+extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
+                               int64_t particle_offset, float* choices, float* score, float* weight,
+                               float* logw, const float* logw_in, const float* sub,
+                               float* site_scores, float* lse, int64_t K_total, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!prog || !prog->sites || !prog->sites_dev || !prog->tab_dev) return gjx_fail(GJX_EINVAL, "gjx_run_program: null program");
+  if (K < 0 || prog->n_sites < 0) return gjx_fail(GJX_EINVAL, "gjx_run_program: negative size");
+  if (K == 0) return GJX_OK;
+  if (prog->n_slots > 0 && !choices) return gjx_fail(GJX_EINVAL, "gjx_run_program: choices is null");
+  if (lse && !logw) return gjx_fail(GJX_EINVAL, "gjx_run_program: lse needs logw");
+  hipStream_t st = (hipStream_t)stream;
+  float2* partials = nullptr;
+  if (lse) {
+    if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RUN, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_run_program: workspace too small");
+    partials = (float2*)workspace;
+  }
+  int nblocks;
+  GmmShape g;
+  const bool fused = !site_scores && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g);
+  if (fused) {
+    int ppt = env_int("GJX_GMM_PPT", 4);
+    if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
+    if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned
+    const int64_t tile = 256 * (int64_t)ppt;
+    const int64_t ntiles = (K + tile - 1) / tile;
+    const int maxgrid = env_int("GJX_GMM_GRID", 2048);
+    nblocks = (int)(ntiles < maxgrid ? ntiles : maxgrid);
+    GmmArgs a;
+    a.tab = prog->tab_dev; a.C = g.C;
+    a.logits_off = g.logits_off; a.mu_off = g.mu_off; a.sig_off = g.sig_off;
+    a.r_off = g.r_off; a.r_len = g.r_len; a.y_off = g.y_off;
+    a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
+    a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
+    a.logw_in = logw_in; a.sub = sub; a.partials = partials;
+    const size_t lds = sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 3 * g.C + 2 * g.D + 8 + 16);
+    if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
+    else launch_gmm<GJX_RNG_PACKED>(a, g.D, ppt, nblocks, lds, st);
+  } else {
+    nblocks = (int)((K + 255) / 256);
+    RunArgs a;
+    a.sites = prog->sites_dev; a.tab = prog->tab_dev; a.n_sites = prog->n_sites; a.n_slots = prog->n_slots;
+    a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
+    a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
+    a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials;
+    if (prog->rng_mode == GJX_RNG_JAX32) hipLaunchKernelGGL(k_run_generic<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_run_generic<GJX_RNG_PACKED>, dim3(nblocks), dim3(256), 0, st, a);
+  }
+  GJX_CHECK_LAUNCH("gjx_run_program");
+  if (lse) {
+    const int rc = gjx_launch_lse_finish(partials, nblocks, K_total, lse, st);
+    if (rc) return rc;
+  }
+  return GJX_OK;
+}
+
+extern "C" int gjx_logsumexp(const float* x, int64_t K, int64_t K_total, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!x || !out || K <= 0) return gjx_fail(GJX_EINVAL, "gjx_logsumexp: bad argument");
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_LSE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_logsumexp: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (K + 1023) / 1024;
+  const int nblocks = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+  hipLaunchKernelGGL(k_lse_partial, dim3(nblocks), dim3(256), 0, st, x, K, (float2*)workspace);
+  GJX_CHECK_LAUNCH("gjx_logsumexp/partial");
+  return gjx_launch_lse_finish(workspace, nblocks, K_total, out, st);
+}
+
+extern "C" int gjx_lse_combine(const float* pairs, int G, int64_t K_total, float* out, void* stream) {
+  if (!pairs || !out || G <= 0) return gjx_fail(GJX_EINVAL, "gjx_lse_combine: bad argument");
+  return gjx_launch_lse_finish(pairs, G, K_total, out, (hipStream_t)stream);
+}

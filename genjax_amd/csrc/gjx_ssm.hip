@@ -1,0 +1,144 @@
+// gjx_ssm.hip — fused bootstrap-filter step for a linear-Gaussian state-space model
+// (BASELINE configs 3/4): ancestor gather + propagate x_t ~ N(A x_{t-1}, q) + reweight
+// log N(y_t; H x_t, r) + block {max, sum-exp} partials, one particle per lane.
+// A, H, y are wave-uniform (scalar loads into SGPRs); the previous state is read through the
+// ancestor index (systematic resampling yields monotone ancestors, so a wave's gathers touch a few
+// adjacent cache lines per row); the new state is written as SoA rows (256 B per wave per row).
+// Algorithmic HBM bytes per particle-step: 4 (ancestor) + 4*dx (gather) + 4*dx (state) + 4 (logw).
+#include "gjx_device.h"
+#include "gjx_host.h"
+
+namespace gjx {
+
+struct SsmArgs {
+  const float* A;
+  const float* H;
+  const float* y;
+  float q, r, q0;
+  int dy, t;
+  key2 key;
+  int64_t K, offset, prev_stride;
+  const float* x_prev;
+  const int32_t* anc;
+  float* x_out;
+  float* logw;
+  float2* partials;
+};
+
+template <int RNG, int DX>
+__global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
+  __shared__ float red[8];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.K;
+  const int64_t ii = active ? i : a.K - 1;
+  const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
+  const key2 sk = fold_in(pk, 1u);
+  float xn[DX];
+  if (a.t > 0) {
+    const int64_t src = a.anc ? (int64_t)a.anc[ii] : ii;
+    float xp[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < DX; ++e) acc = fmaf(a.A[d * DX + e], xp[e], acc);
+      xn[d] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) xn[d] = 0.0f;
+  }
+  const float sd = a.t > 0 ? a.q : a.q0;
+#pragma unroll
+  for (int d0 = 0; d0 < DX; d0 += 2) {
+    uint32_t b0, b1 = 0u;
+    if (RNG == GJX_RNG_JAX32) {
+      const key2 h0 = threefry2x32(sk, 0u, (uint32_t)d0);
+      b0 = h0.a ^ h0.b;
+      if (d0 + 1 < DX) { const key2 h1 = threefry2x32(sk, 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; }
+    } else {
+      const key2 h = threefry2x32(sk, 0u, (uint32_t)(d0 >> 1));
+      b0 = h.a; b1 = h.b;
+    }
+    xn[d0] = fmaf(sd, normal_from_bits(b0), xn[d0]);
+    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, normal_from_bits(b1), xn[d0 + 1]);
+  }
+  if (active) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) a.x_out[(int64_t)d * a.K + i] = xn[d];
+  }
+  const float rr = fast_rcp(a.r);
+  float qsum = 0.0f;
+  if (a.H) {
+    for (int o = 0; o < a.dy; ++o) {
+      float m = 0.0f;
+#pragma unroll
+      for (int e = 0; e < DX; ++e) m = fmaf(a.H[o * DX + e], xn[e], m);
+      const float z = (a.y[o] - m) * rr;
+      qsum = fmaf(z, z, qsum);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      const float z = (a.y[d] - xn[d]) * rr;
+      qsum = fmaf(z, z, qsum);
+    }
+  }
+  const float lw = fmaf(-0.5f, qsum, -(float)a.dy * (kHalfLog2Pi + fast_log(a.r)));
+  if (active) a.logw[i] = lw;
+  if (a.partials) {
+    float bm, bsum;
+    block_lse_partial<256>(lw, active, red, bm, bsum);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = make_float2(bm, bsum);
+  }
+}
+
+}  // namespace gjx
+
+using namespace gjx;
+
+namespace {
+template <int RNG>
+int launch_ssm(const SsmArgs& a, int dx, int nblocks, hipStream_t st) {
+  switch (dx) {
+    case 1: hipLaunchKernelGGL((k_ssm_step<RNG, 1>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL((k_ssm_step<RNG, 2>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL((k_ssm_step<RNG, 4>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 8: hipLaunchKernelGGL((k_ssm_step<RNG, 8>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 16: hipLaunchKernelGGL((k_ssm_step<RNG, 16>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 32: hipLaunchKernelGGL((k_ssm_step<RNG, 32>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    default: return -1;
+  }
+}
+}  // namespace
+
+extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
+                            int64_t particle_offset, const float* x_prev, int64_t prev_stride, const int32_t* anc,
+                            const float* y_dev, float* x_out, float* logw, float* lse, int64_t K_total,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !m->A_dev || !y_dev || !x_out || !logw || K <= 0 || t < 0) return gjx_fail(GJX_EINVAL, "gjx_ssm_step: bad argument");
+  if (t > 0 && !x_prev) return gjx_fail(GJX_EINVAL, "gjx_ssm_step: x_prev is null for t > 0");
+  if (!m->H_dev && m->dy != m->dx) return gjx_fail(GJX_EINVAL, "gjx_ssm_step: H == NULL needs dy == dx");
+  hipStream_t st = (hipStream_t)stream;
+  float2* partials = nullptr;
+  if (lse) {
+    if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_SSM, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_step: workspace too small");
+    partials = (float2*)workspace;
+  }
+  SsmArgs a;
+  a.A = m->A_dev; a.H = m->H_dev; a.y = y_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = t;
+  a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset; a.prev_stride = prev_stride;
+  a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials;
+  const int nblocks = (int)((K + 255) / 256);
+  const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
+                                           : launch_ssm<GJX_RNG_PACKED>(a, m->dx, nblocks, st);
+  if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step: dx must be one of 1,2,4,8,16,32");
+  GJX_CHECK_LAUNCH("gjx_ssm_step");
+  if (lse) {
+    const int rc2 = gjx_launch_lse_finish(partials, nblocks, K_total, lse, st);
+    if (rc2) return rc2;
+  }
+  return GJX_OK;
+}

@@ -1,0 +1,153 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of include/gjx.h).
+
+Every function launches asynchronously on torch's current HIP stream and returns device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _abi as A
+from ._lib import check, load
+from .program import PackedProgram
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(device=None):
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def workspace(op: int, K: int, device=None) -> torch.Tensor:
+    n = load().gjx_workspace_bytes(op, int(K))
+    return torch.empty(n, dtype=torch.uint8, device=_dev(device))
+
+
+def threefry2x32(key, n: int, ctr_lo0: int = 0, ctr_hi: int = 0, device=None) -> torch.Tensor:
+    out = torch.empty((n, 2), dtype=torch.int32, device=_dev(device))
+    check(load().gjx_threefry2x32(key[0], key[1], ctr_hi, ctr_lo0, n, _ptr(out), _stream()), "gjx_threefry2x32")
+    return out
+
+
+def program_engine(prog: PackedProgram) -> int:
+    cp = prog.c_program(None)
+    return int(load().gjx_program_engine(C.byref(cp)))
+
+
+def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
+                want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None):
+    """gjx_run_program.  Returns dict(choices, score, weight, logw, lse[, site_scores])."""
+    dev = _dev(device)
+    K = int(K)
+    f32 = torch.float32
+    if out is None:
+        out = {}
+    ch = choices if choices is not None else out.get("choices")
+    if ch is None:
+        ch = torch.empty((max(prog.n_slots, 1), K), dtype=f32, device=dev)
+    score = out.get("score") if out.get("score") is not None else torch.empty(K, dtype=f32, device=dev)
+    weight = out.get("weight") if out.get("weight") is not None else torch.empty(K, dtype=f32, device=dev)
+    logw = out.get("logw") if out.get("logw") is not None else torch.empty(K, dtype=f32, device=dev)
+    lse = (out.get("lse") if out.get("lse") is not None else torch.empty(4, dtype=f32, device=dev)) if want_lse else None
+    ss = torch.empty((max(prog.n_sites, 1), K), dtype=f32, device=dev) if want_site_scores else None
+    if ws is None:
+        ws = workspace(A.OP_RUN, K, dev)
+    cp = prog.c_program(dev)
+    rc = load().gjx_run_program(C.byref(cp), key[0], key[1], K, int(offset), _ptr(ch), _ptr(score), _ptr(weight),
+                                _ptr(logw), _ptr(logw_in), _ptr(sub), _ptr(ss), _ptr(lse), int(K_total or K),
+                                _ptr(ws), ws.numel(), _stream())
+    check(rc, "gjx_run_program")
+    res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws)
+    if ss is not None:
+        res["site_scores"] = ss
+    return res
+
+
+def logsumexp(x: torch.Tensor, K_total=None, ws=None) -> torch.Tensor:
+    K = x.numel()
+    out = torch.empty(4, dtype=torch.float32, device=x.device)
+    if ws is None:
+        ws = workspace(A.OP_LSE, K, x.device)
+    check(load().gjx_logsumexp(_ptr(x), K, int(K_total or K), _ptr(out), _ptr(ws), ws.numel(), _stream()), "gjx_logsumexp")
+    return out
+
+
+def lse_combine(pairs: torch.Tensor, K_total: int) -> torch.Tensor:
+    out = torch.empty(4, dtype=torch.float32, device=pairs.device)
+    G = pairs.numel() // 2
+    check(load().gjx_lse_combine(_ptr(pairs), G, int(K_total), _ptr(out), _stream()), "gjx_lse_combine")
+    return out
+
+
+def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_PACKED, offset=0, ws=None) -> torch.Tensor:
+    """Returns an int32[2] device tensor: [bitcast(best value), index]."""
+    K = logw.numel()
+    out = torch.empty(2, dtype=torch.int32, device=logw.device)
+    if ws is None:
+        ws = workspace(A.OP_PICK, K, logw.device)
+    check(load().gjx_categorical_pick(_ptr(logw), K, int(offset), _ptr(lse), key[0], key[1], rng_mode, _ptr(out),
+                                      _ptr(ws), ws.numel(), _stream()), "gjx_categorical_pick")
+    return out
+
+
+def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None):
+    K = x.numel()
+    cum = torch.empty(K, dtype=torch.int64, device=x.device)      # uint64 payload
+    total = torch.empty(1, dtype=torch.int64, device=x.device)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, x.device)
+    check(load().gjx_weight_cumsum(_ptr(x), K, int(is_log), _ptr(lse), _ptr(cum), _ptr(total), _ptr(ws), ws.numel(),
+                                   _stream()), "gjx_weight_cumsum")
+    return cum, total
+
+
+def resample_systematic(cum, base_total, u: float, N_total: int, out_begin=0, n_out=None) -> torch.Tensor:
+    n_out = int(N_total if n_out is None else n_out)
+    anc = torch.empty(n_out, dtype=torch.int32, device=cum.device)
+    check(load().gjx_resample_systematic(_ptr(cum), cum.numel(), _ptr(base_total), float(u), int(N_total),
+                                         int(out_begin), n_out, _ptr(anc), _stream()), "gjx_resample_systematic")
+    return anc
+
+
+def resample_multinomial(cum, base_total, key, N_total: int, out_begin=0, n_out=None) -> torch.Tensor:
+    n_out = int(N_total if n_out is None else n_out)
+    anc = torch.empty(n_out, dtype=torch.int32, device=cum.device)
+    check(load().gjx_resample_multinomial(_ptr(cum), cum.numel(), _ptr(base_total), key[0], key[1], int(N_total),
+                                          int(out_begin), n_out, _ptr(anc), _stream()), "gjx_resample_multinomial")
+    return anc
+
+
+def gather_rows(src: torch.Tensor, anc: torch.Tensor, dst: torch.Tensor | None = None) -> torch.Tensor:
+    rows, stride = src.shape
+    n = anc.numel()
+    if dst is None:
+        dst = torch.empty((rows, n), dtype=torch.float32, device=src.device)
+    check(load().gjx_gather_rows(_ptr(src), stride, _ptr(anc), n, rows, _ptr(dst), dst.shape[1], _stream()),
+          "gjx_gather_rows")
+    return dst
+
+
+def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, logw=None, lse=None, offset=0,
+             K_total=None, ws=None, device=None):
+    dev = _dev(device) if x_prev is None else x_prev.device
+    if x_out is None:
+        x_out = torch.empty((ssm.dx, K), dtype=torch.float32, device=dev)
+    if logw is None:
+        logw = torch.empty(K, dtype=torch.float32, device=dev)
+    if lse is None:
+        lse = torch.empty(4, dtype=torch.float32, device=dev)
+    if ws is None:
+        ws = workspace(A.OP_SSM, K, dev)
+    stride = 0 if x_prev is None else x_prev.shape[1]
+    check(load().gjx_ssm_step(C.byref(ssm), key[0], key[1], rng_mode, int(t), int(K), int(offset), _ptr(x_prev),
+                              stride, _ptr(anc), _ptr(y), _ptr(x_out), _ptr(logw), _ptr(lse), int(K_total or K),
+                              _ptr(ws), ws.numel(), _stream()), "gjx_ssm_step")
+    return x_out, logw, lse

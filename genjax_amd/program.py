@@ -1,0 +1,294 @@
+"""Model program: the explicit site list that replaces the reference's Jaxpr interpretation.
+
+The reference stages a ``@gen`` Python function to a Jaxpr and interprets it once per GFI call
+(generative_functions/static.py:340-399, core/compiler/interpreters/stateful.py:49-72).  Here a
+generative function is a straight-line list of *sites* whose distribution parameters are simple
+expression forms over earlier values and constants; that list is packed into the ``gjx_program``
+struct of ``include/gjx.h`` and handed to the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Sequence
+
+import numpy as np
+
+from . import _abi as A
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter expressions
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Param:
+    """One distribution parameter as a function of earlier choices (host-side description)."""
+
+    op: int
+    values: np.ndarray | None = None   # CONST: vector; GATHER: table [n][len]; AFFINE: bias
+    matrix: np.ndarray | None = None   # AFFINE: [dim][n]
+    src: str | None = None             # address of the source site (VALUE/AFFINE/GATHER index)
+    src_elem: int = 0                  # first element of the source site used
+    length: int = 1                    # VALUE: number of source elements (1 = broadcast)
+    xf: int = A.XF_NONE
+
+    @staticmethod
+    def const(v, xf=A.XF_NONE) -> "Param":
+        return Param(A.P_CONST, values=np.atleast_1d(np.asarray(v, np.float32)).ravel(), xf=xf)
+
+    @staticmethod
+    def value(src: str, length: int = 1, elem: int = 0, xf=A.XF_NONE) -> "Param":
+        return Param(A.P_VALUE, src=src, src_elem=elem, length=length, xf=xf)
+
+    @staticmethod
+    def gather(table, src: str, xf=A.XF_NONE) -> "Param":
+        t = np.asarray(table, np.float32)
+        if t.ndim == 1:
+            t = t[:, None]
+        return Param(A.P_GATHER, values=t, src=src, xf=xf)
+
+    @staticmethod
+    def affine(matrix, src: str, bias=0.0, elem: int = 0, xf=A.XF_NONE) -> "Param":
+        m = np.atleast_2d(np.asarray(matrix, np.float32))
+        return Param(A.P_AFFINE, values=np.atleast_1d(np.asarray(bias, np.float32)).ravel(),
+                     matrix=m, src=src, src_elem=elem, xf=xf)
+
+
+def as_param(p: Any) -> Param:
+    if isinstance(p, Param):
+        return p
+    if hasattr(p, "as_param"):
+        return p.as_param()
+    return Param.const(p)
+
+
+@dataclass
+class Site:
+    addr: str
+    kind: int
+    params: list[Param]
+    dim: int = 1
+    ncat: int = 0
+    slot: int = -1
+
+
+N_PARAMS = {
+    A.NORMAL: 2, A.FLIP: 1, A.BERNOULLI_LOGITS: 1, A.BETA: 2, A.CATEGORICAL_LOGITS: 1,
+    A.CATEGORICAL_PROBS: 1, A.UNIFORM: 2, A.MVNORMAL_DIAG: 2, A.EXPONENTIAL: 1, A.HALF_NORMAL: 1,
+    A.LAPLACE: 2, A.LOG_NORMAL: 2, A.CAUCHY: 2, A.GAMMA: 2,
+}
+
+
+class AddressReuse(Exception):
+    """Same address used twice in one program (reference: static.py:139)."""
+
+
+class MissingAddress(Exception):
+    """assess() without a value for a site (reference: static.py:147, 316-318)."""
+
+
+@dataclass
+class SiteList:
+    """Ordered sites of a generative function (program order == the reference's trace order)."""
+
+    sites: list[Site] = field(default_factory=list)
+    n_slots: int = 0
+
+    def add(self, addr: str, kind: int, params: Sequence[Any], dim: int | None = None) -> Site:
+        if any(s.addr == addr for s in self.sites):
+            raise AddressReuse(addr)
+        ps = [as_param(p) for p in params]
+        if len(ps) != N_PARAMS[kind]:
+            raise TypeError(f"{A.KIND_NAMES[kind]} takes {N_PARAMS[kind]} parameters, got {len(ps)}")
+        ncat = 0
+        if kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS):
+            p0 = ps[0]
+            if p0.op == A.P_CONST:
+                ncat = int(p0.values.size)
+            elif p0.op == A.P_GATHER:
+                ncat = int(p0.values.shape[1])
+            elif p0.op == A.P_AFFINE:
+                ncat = int(p0.matrix.shape[0])
+            else:
+                ncat = int(p0.length)
+            dim = 1
+        if dim is None:
+            dim = 1
+            for p in ps:
+                if p.op == A.P_CONST:
+                    dim = max(dim, int(p.values.size))
+                elif p.op == A.P_VALUE:
+                    dim = max(dim, int(p.length))
+                elif p.op == A.P_GATHER:
+                    dim = max(dim, int(p.values.shape[1]))
+                elif p.op == A.P_AFFINE:
+                    dim = max(dim, int(p.matrix.shape[0]))
+        site = Site(addr, kind, ps, int(dim), ncat, self.n_slots)
+        self.sites.append(site)
+        self.n_slots += int(dim)
+        return site
+
+    def __getitem__(self, addr: str) -> Site:
+        for s in self.sites:
+            if s.addr == addr:
+                return s
+        raise KeyError(addr)
+
+    def __contains__(self, addr: str) -> bool:
+        return any(s.addr == addr for s in self.sites)
+
+    def addresses(self) -> list[str]:
+        return [s.addr for s in self.sites]
+
+
+# ---------------------------------------------------------------------------------------------
+# packing
+# ---------------------------------------------------------------------------------------------
+class PackedProgram:
+    """A SiteList bound to per-site modes, packed into the C structs of ``include/gjx.h``.
+
+    ``modes`` maps address -> MODE_*; ``obs`` maps address -> observed value for MODE_OBS_TAB
+    sites (the Target's constraint, inference/sp.py:52-94).  Addresses absent from ``modes``
+    are MODE_SAMPLE.  ``selected`` flags sites for HMC.
+    """
+
+    def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
+                 obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
+                 rng_mode: int = A.RNG_PACKED):
+        self.site_list = sl
+        self.modes = dict(modes or {})
+        self.rng_mode = int(rng_mode)
+        obs = obs or {}
+        tab: list[np.ndarray] = []
+        self._tab_parts = tab
+        ntab = 0
+
+        def push(arr) -> int:
+            nonlocal ntab
+            a = np.asarray(arr, np.float32).ravel()
+            off = ntab
+            tab.append(a)
+            ntab += a.size
+            return off
+
+        n = len(sl.sites)
+        self.c_sites = (A.GjxSite * max(n, 1))()
+        self.obs_off: dict[str, int] = {}
+        self.slot_of: dict[str, int] = {}
+        self._derived: list[tuple[int, Param, str]] = []  # CONST blocks computed from observed values
+        # Sites constrained to one shared value (OBS_TAB) own no row of choices[][]: their value
+        # lives in tab and later sites read it from there.
+        n_slots = 0
+        for s in sl.sites:
+            if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_TAB:
+                if s.addr not in obs:
+                    raise MissingAddress(s.addr)
+                v = np.asarray(obs[s.addr], np.float32).ravel()
+                if v.size != s.dim:
+                    v = np.broadcast_to(v, (s.dim,))
+                self.obs_off[s.addr] = push(v)
+                self.slot_of[s.addr] = -1
+            else:
+                self.slot_of[s.addr] = n_slots
+                n_slots += s.dim
+        order = {s.addr: j for j, s in enumerate(sl.sites)}
+        for j, s in enumerate(sl.sites):
+            cs = self.c_sites[j]
+            cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
+            cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
+            cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
+            cs.obs_off = self.obs_off.get(s.addr, 0)
+            rows = s.ncat if s.ncat else s.dim
+            for k, p in enumerate(s.params):
+                cp = cs.p[k]
+                cp.op, cp.xf = p.op, p.xf
+                if p.op != A.P_CONST:
+                    if p.src not in order or order[p.src] >= j:
+                        raise ValueError(f"site {s.addr!r} reads {p.src!r} before it is traced")
+                src_obs = p.op != A.P_CONST and self.slot_of[p.src] < 0
+                if p.op == A.P_CONST:
+                    cp.off, cp.len = push(p.values), int(p.values.size)
+                elif p.op == A.P_VALUE and src_obs:
+                    cp.op = A.P_CONST  # read the observed value straight from tab
+                    cp.off, cp.len = self.obs_off[p.src] + p.src_elem, int(p.length)
+                elif src_obs:
+                    cp.op = A.P_CONST  # parameter is a function of observed data only: fold on the host
+                    vals = self._fold_observed(p, rows)
+                    cp.off, cp.len = push(vals), int(vals.size)
+                    self._derived.append((cp.off, p, s.addr))
+                elif p.op == A.P_VALUE:
+                    cp.slot, cp.len = self.slot_of[p.src] + p.src_elem, int(p.length)
+                elif p.op == A.P_GATHER:
+                    cp.slot = self.slot_of[p.src] + p.src_elem
+                    cp.n, cp.len = int(p.values.shape[0]), int(p.values.shape[1])
+                    cp.off = push(p.values)
+                elif p.op == A.P_AFFINE:
+                    m = p.matrix
+                    if m.shape[0] != rows:
+                        raise ValueError(f"affine matrix of {s.addr!r} has {m.shape[0]} rows, site dim {rows}")
+                    cp.slot, cp.n = self.slot_of[p.src] + p.src_elem, int(m.shape[1])
+                    cp.off, cp.len = push(p.values), int(p.values.size)
+                    cp.moff = push(m)
+                else:
+                    raise ValueError(p.op)
+        self.tab = np.concatenate(tab).astype(np.float32) if tab else np.zeros(1, np.float32)
+        self.n_sites = n
+        self.n_slots = n_slots
+        self._dev = None  # (sites tensor, tab tensor)
+
+    # -- observed values can be replaced in place (same program, new data) --
+    def _obs_value(self, addr: str) -> np.ndarray:
+        off = self.obs_off[addr]
+        return self._tab_view()[off:off + self.site_list[addr].dim]
+
+    def _tab_view(self) -> np.ndarray:
+        return self.tab if hasattr(self, "tab") else np.concatenate(self._tab_parts)
+
+    def _fold_observed(self, p: Param, rows: int) -> np.ndarray:
+        src = self._obs_value(p.src)[p.src_elem:]
+        if p.op == A.P_GATHER:
+            idx = int(np.clip(int(src[0]), 0, p.values.shape[0] - 1))
+            return p.values[idx].astype(np.float32).copy()
+        if p.op == A.P_AFFINE:
+            n = p.matrix.shape[1]
+            bias = np.broadcast_to(p.values, (rows,)) if p.values.size in (1, rows) else p.values
+            return (bias + p.matrix @ src[:n]).astype(np.float32)
+        raise ValueError(p.op)
+
+    def set_obs(self, addr: str, value) -> None:
+        """Replace an observed value in place (same program, new data)."""
+        off = self.obs_off[addr]
+        v = np.asarray(value, np.float32).ravel()
+        self.tab[off:off + v.size] = v
+        dirty = [(off, v.size)]
+        for doff, p, site_addr in self._derived:
+            if p.src == addr:
+                s = self.site_list[site_addr]
+                vals = self._fold_observed(p, s.ncat if s.ncat else s.dim)
+                self.tab[doff:doff + vals.size] = vals
+                dirty.append((doff, vals.size))
+        if self._dev is not None:
+            import torch
+            for o, n in dirty:
+                self._dev[1][o:o + n] = torch.from_numpy(self.tab[o:o + n].copy()).to(self._dev[1].device)
+
+    def sites_bytes(self) -> bytes:
+        return bytes(self.c_sites)[: self.n_sites * C.sizeof(A.GjxSite)]
+
+    def c_program(self, device=None) -> A.GjxProgram:
+        """Struct for a call.  With ``device`` (a torch device) the *_dev pointers are filled."""
+        p = A.GjxProgram()
+        p.n_sites, p.n_slots, p.n_tab, p.rng_mode = self.n_sites, self.n_slots, int(self.tab.size), self.rng_mode
+        p.sites = C.cast(self.c_sites, C.c_void_p)
+        p.tab = self.tab.ctypes.data_as(C.c_void_p)
+        if device is not None:
+            import torch
+            if self._dev is None or self._dev[1].device != torch.device(device):
+                sb = np.frombuffer(self.sites_bytes() or b"\0" * 96, dtype=np.uint8).copy()
+                self._dev = (torch.from_numpy(sb).to(device), torch.from_numpy(self.tab.copy()).to(device))
+            p.sites_dev = self._dev[0].data_ptr()
+            p.tab_dev = self._dev[1].data_ptr()
+        else:
+            p.sites_dev = p.sites
+            p.tab_dev = p.tab
+        return p

@@ -1,0 +1,251 @@
+/* gjx.h — C ABI of the MI355X-native inference-kernel backend (libgjx_hip.so).
+ *
+ * This is the drop-in boundary for the vmapped hot path of genjax.inference.smc and the
+ * per-chain MCMC step.  The reference (/root/reference, pure Python on JAX) has no FFI; the
+ * seams these entry points sit behind are its abstract Python interfaces, cited per function
+ * as  <file>:<line>  relative to  /root/reference/src/genjax/_src/ .
+ *
+ * Conventions
+ *   - return 0 (GJX_OK) on success, a negative gjx_status otherwise; gjx_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - the library never allocates or frees caller-visible memory: the caller owns every buffer
+ *     (torch tensors in the Python host layer); scratch is sized by gjx_workspace_bytes().
+ *   - every `*_dev` / output pointer is a DEVICE pointer; every call is asynchronous on the
+ *     given hipStream_t (passed as void*), re-entrant, and touches no global state.
+ *   - particle/chain state is SoA: choices[slot][K] — one contiguous f32[K] row per scalar of a
+ *     random choice, so a 64-lane wavefront reads/writes 256 contiguous bytes per row.
+ *   - all floating values are float32 (the reference's default, core/typing.py:42); integer and
+ *     boolean choices (categorical index, flip) are stored as exact float32 values.
+ *   - PRNG keys are Threefry-2x32 keys (two uint32 words), jax.random.key(seed) == (0, seed).
+ */
+#ifndef GJX_H
+#define GJX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJX_ABI_VERSION 1
+
+typedef enum gjx_status {
+  GJX_OK = 0,
+  GJX_EINVAL = -1,       /* bad argument (null pointer, negative size, malformed program) */
+  GJX_EUNSUPPORTED = -2, /* program uses a form this entry point cannot run */
+  GJX_EHIP = -3,         /* HIP runtime error (launch failure, no device) */
+  GJX_EWORKSPACE = -4    /* workspace too small */
+} gjx_status;
+
+/* ---- model program ---------------------------------------------------------------------
+ * A generative function in the reference is a Python function traced to a Jaxpr and
+ * interpreted site by site (generative_functions/static.py:340-399).  Here it is an explicit
+ * straight-line list of sites; "user code between sites" is restricted to the parameter
+ * expression forms below (enough for every configuration in BASELINE.json).
+ */
+
+/* primitive distribution kinds — generative_functions/distributions/tensorflow_probability/__init__.py */
+enum {
+  GJX_NORMAL = 1,             /* normal(loc, scale)            :259  (scale = std-dev)      */
+  GJX_FLIP = 2,               /* flip(p)  Bernoulli(probs=p)   :155                         */
+  GJX_BERNOULLI_LOGITS = 3,   /* bernoulli(logits)             :72                          */
+  GJX_BETA = 4,               /* beta(a, b)                    :82                          */
+  GJX_CATEGORICAL_LOGITS = 5, /* categorical(logits)           :102-104                     */
+  GJX_CATEGORICAL_PROBS = 6,  /* categorical(probs=...)        :102-104                     */
+  GJX_UNIFORM = 7,            /* uniform(low, high)            :294                         */
+  GJX_MVNORMAL_DIAG = 8,      /* mv_normal_diag(loc, scale)    :239  (one site, dim scalars)*/
+  GJX_EXPONENTIAL = 9,        /* exponential(rate)             :128                         */
+  GJX_HALF_NORMAL = 10,       /* half_normal(scale)            :171                         */
+  GJX_LAPLACE = 11,           /* laplace(loc, scale)           :200                         */
+  GJX_LOG_NORMAL = 12,        /* log_normal(loc, scale)        :220                         */
+  GJX_CAUCHY = 13,            /* cauchy(loc, scale)            :112                         */
+  GJX_GAMMA = 14,             /* gamma(concentration, rate)    :160                         */
+  GJX_KIND_MAX = 15
+};
+
+/* parameter expression forms (what the model body computes between sites) */
+enum {
+  GJX_P_CONST = 0,  /* tab[off + (d % len)]                                               */
+  GJX_P_VALUE = 1,  /* choices[slot + (d % len)][i]                                       */
+  GJX_P_GATHER = 2, /* tab[off + clamp((int)choices[slot][i], 0, n-1) * len + (d % len)]  */
+  GJX_P_AFFINE = 3  /* tab[off + (d % len)] + sum_{e<n} tab[moff + d*n + e] * choices[slot+e][i] */
+};
+/* unary transform applied to the evaluated parameter */
+enum { GJX_XF_NONE = 0, GJX_XF_EXP = 1, GJX_XF_SOFTPLUS = 2, GJX_XF_SIGMOID = 3 };
+
+/* how a site obtains its value in one run of the program
+ * (distribution.py:117-147 generate_choice_map; static.py:340-380 GenerateHandler) */
+enum {
+  GJX_MODE_SAMPLE = 0,   /* unconstrained: v ~ dist, score += logpdf(v), weight += 0           */
+  GJX_MODE_OBS_TAB = 1,  /* constrained, same value for every particle: v = tab[obs_off + d]   */
+  GJX_MODE_OBS_SLOT = 2  /* constrained per particle: v = choices[slot + d][i] (already there) */
+};
+
+enum { GJX_SITE_HMC_SELECTED = 1 }; /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */
+
+typedef struct gjx_param {
+  int32_t op;   /* GJX_P_*  */
+  int32_t xf;   /* GJX_XF_* */
+  int32_t off;  /* CONST: values; GATHER: table base; AFFINE: bias                 (into tab) */
+  int32_t len;  /* CONST/VALUE: vector length (1 = broadcast); GATHER: row length; AFFINE: bias length */
+  int32_t slot; /* VALUE/AFFINE: first source slot; GATHER: slot holding the index             */
+  int32_t n;    /* AFFINE: inner length; GATHER: number of rows                                */
+  int32_t moff; /* AFFINE: matrix [dim][n] row-major                               (into tab) */
+  int32_t pad_;
+} gjx_param; /* 32 bytes */
+
+#define GJX_MAX_PARAMS 2
+
+typedef struct gjx_site {
+  int32_t kind;    /* GJX_NORMAL ...                                                        */
+  int32_t dim;     /* event size: number of scalar slots this site owns (1 for scalars)     */
+  int32_t slot;    /* first slot of the value in choices[n_slots][K]                        */
+  int32_t mode;    /* GJX_MODE_*                                                            */
+  int32_t obs_off; /* OBS_TAB: offset of the observed value in tab                          */
+  int32_t ncat;    /* categorical: number of categories (length of params[0])               */
+  int32_t flags;   /* GJX_SITE_*                                                            */
+  int32_t pad_;
+  gjx_param p[GJX_MAX_PARAMS];
+} gjx_site; /* 96 bytes */
+
+enum {
+  GJX_RNG_PACKED = 0, /* element c of a site draws word (c & 1) of Threefry(site_key, (0, c >> 1)) */
+  GJX_RNG_JAX32 = 1   /* element c draws x0 ^ x1 of Threefry(site_key, (0, c))  — the layout of
+                         jax._src.prng._threefry_random_bits_partitionable (jax 0.5.2)          */
+};
+
+typedef struct gjx_program {
+  int32_t n_sites;
+  int32_t n_slots;          /* rows of choices[][] */
+  int32_t n_tab;            /* floats in tab */
+  int32_t rng_mode;         /* GJX_RNG_* */
+  const gjx_site* sites;    /* HOST copy of the site list (launcher inspects it) */
+  const gjx_site* sites_dev;/* DEVICE copy of the same bytes */
+  const float* tab;         /* HOST copy of the float table (constants, args, observations) */
+  const float* tab_dev;     /* DEVICE copy of the same floats */
+} gjx_program;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int gjx_version(void);
+const char* gjx_last_error(void);
+/* which engine a program will run on: 0 = generic site interpreter, >0 = id of a fused kernel */
+int gjx_program_engine(const gjx_program* prog);
+
+/* ---- counter-based RNG (jax.random.{split,fold_in,bits}; call sites smc.py:299-300,
+ *      static.py:349-352, scan.py:213,268) ------------------------------------------------ */
+/* out[i] = Threefry2x32(key, (ctr_hi, ctr_lo0 + i)), 2 words each: device uint32[n][2] */
+int gjx_threefry2x32(uint32_t key0, uint32_t key1, uint32_t ctr_hi, uint32_t ctr_lo0, int64_t n,
+                     uint32_t* out_dev, void* stream);
+
+/* ---- particle propagate + reweight ------------------------------------------------------
+ * Runs the program once per particle: the vmapped body of ImportanceK.run_smc
+ * (inference/smc.py:298-315  ->  sp.py:83-87  ->  static.py:340-399  ->  distribution.py:117-147).
+ * Particle i (global index particle_offset + i) uses key_i = Threefry(key, (0, offset+i))
+ * (== jax.random.split(key, K)[i]); site j (1-based, program order) uses Threefry(key_i, (0, j)).
+ *   choices   f32[n_slots][K]  in/out (OBS_SLOT sites read their value; all sites write it back)
+ *   score     f32[K]  out   sum of every site's logpdf            (static.py:102-105)
+ *   weight    f32[K]  out   sum of constrained sites' logpdf      (static.py:377)
+ *   logw      f32[K]  out   weight + (logw_in ? logw_in[i] : 0) - (sub ? sub[i] : 0)
+ *                           smc.py:313 (sub = proposal log-density) and smc.py:383
+ *                           (ChangeTarget: sub = previous score, logw_in = previous weight)
+ *   site_scores f32[n_sites][K] out or NULL
+ *   lse       f32[4]  out or NULL: {max, sum exp(logw-max), logsumexp, logsumexp - log(K_total)}
+ *                           over THIS call's K particles (smc.py:96-97 when K_total == K)
+ * `weight` or `logw` may be NULL.  workspace: gjx_workspace_bytes(GJX_OP_RUN, K).
+ */
+int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
+                    int64_t particle_offset, float* choices, float* score, float* weight,
+                    float* logw, const float* logw_in, const float* sub, float* site_scores,
+                    float* lse, int64_t K_total, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+enum { GJX_OP_RUN = 1, GJX_OP_LSE = 2, GJX_OP_PICK = 3, GJX_OP_RESAMPLE = 4, GJX_OP_HMC = 5,
+       GJX_OP_SSM = 6 };
+size_t gjx_workspace_bytes(int op, int64_t K);
+
+/* ---- log-sum-exp (smc.py:97,107,464) -----------------------------------------------------
+ * out[4] = {max, sum exp(x-max), logsumexp, logsumexp - log(K_total)} */
+int gjx_logsumexp(const float* x, int64_t K, int64_t K_total, float* out, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* combine G partial {max, sumexp} pairs (one per rank, gathered by the caller over RCCL) */
+int gjx_lse_combine(const float* pairs /*[G][2]*/, int G, int64_t K_total, float* out,
+                    void* stream);
+
+/* ---- 1-of-K categorical draw over the weights: ParticleCollection.sample_particle
+ * (smc.py:102-109): idx = argmax_i (logw[i] - lse) + Gumbel(bits(key, i)).
+ * out_dev: {float best_value, int32 idx (global index = particle_offset + i)} as 2 words */
+int gjx_categorical_pick(const float* logw, int64_t K, int64_t particle_offset, const float* lse,
+                         uint32_t key0, uint32_t key1, int32_t rng_mode, void* out_dev,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- N-of-K resampling (not in the reference library; the cookbook idiom is K independent
+ * categorical draws + gather, docs/cookbook/inactive/inference/importance_sampling.ipynb) ----
+ * Weights are turned into exact fixed-point integers q_i = (uint64)(w_i * 2^30),
+ * w_i = is_log ? exp(x_i - max) : x_i, so prefix sums and comb searches are exact integer work.
+ *   cum       u64[K] out : inclusive prefix sums of q
+ *   total_dev u64[1] out : sum q
+ */
+int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse /*max at [0]*/,
+                      uint64_t* cum, uint64_t* total_dev, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
+ * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
+ * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:
+ * ancestors[j - out_begin] = local index i, or -1 when slot j belongs to another rank.
+ * base_total_dev: u64[2] = {base, total_all} on the device. */
+int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,
+                            double u, int64_t N_total, int64_t out_begin, int64_t n_out,
+                            int32_t* ancestors, void* stream);
+/* multinomial: slot j draws u_j = uniform(bits(key, j)), ancestor = first i with cum_i > u_j * total */
+int gjx_resample_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,
+                             uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
+                             int64_t n_out, int32_t* ancestors, void* stream);
+/* dst[r][j] = src[r][anc[j]]  for r < rows, j < n_out (anc[j] < 0 leaves dst untouched);
+ * particle gather of smc.py:90-91 applied to every SoA row */
+int gjx_gather_rows(const float* src, int64_t src_stride, const int32_t* anc, int64_t n_out,
+                    int32_t rows, float* dst, int64_t dst_stride, void* stream);
+
+/* ---- linear-Gaussian state-space bootstrap-filter step (BASELINE config 3/4) --------------
+ * x_t ~ N(A x_{t-1}[anc], q), weight = log N(y_t; H x_t, r); fused ancestor gather + propagate
+ * + reweight + LSE partials.  Semantics are those of Scan.generate (combinators/scan.py:237-294)
+ * applied one step at a time with resampling in between; the step key is chained by the caller
+ * (key_t = fold_in(key_{t-1}, t), scan.py:268).
+ *   A f32[dx][dx], H f32[dy][dx] row-major, y f32[dy], on the device.
+ *   x_prev f32[dx][K_prev_stride], anc int32[K] or NULL (identity); t == 0 samples x_0 ~ N(0, I*q0)
+ *   x_out f32[dx][K], logw f32[K] (incremental weight), lse f32[4] as above.
+ */
+typedef struct gjx_ssm {
+  int32_t dx, dy;
+  const float* A_dev;
+  const float* H_dev; /* NULL = identity (dy == dx) */
+  float q, r, q0;
+} gjx_ssm;
+int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t,
+                 int64_t K, int64_t particle_offset, const float* x_prev, int64_t prev_stride,
+                 const int32_t* anc, const float* y_dev, float* x_out, float* logw, float* lse,
+                 int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
+ * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float
+ * sites only, hmc.py:49-65); every other site keeps its value (mode OBS_*).
+ *   chain key = Threefry(key, (0, chain_offset + i)); momenta: (key', sub) = split(chain key),
+ *   leaf l ~ N(0,1) from fold_in(sub, l) (hmc.py:120-130).
+ *   choices f32[n_slots][n] in/out, score f32[n] in/out, alpha f32[n] out (hmc.py:196-203).
+ *   stale_grad_compat != 0 reproduces hmc.py:186 (first half-kick always uses the INITIAL gradient).
+ *   accept != 0 additionally applies the caller-side MH rule of tests/inference/test_requests.py:134-137
+ *   with log U drawn from fold_in(key', 0x4d48) and reverts rejected chains; accepted f32[n] out or NULL.
+ */
+int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
+            float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
+            float* score, float* alpha, float* accepted, void* workspace, size_t workspace_bytes,
+            void* stream);
+/* d score / d choices for the selected slots: selection_gradient (hmc.py:70-96).
+ * grad f32[n_slots][n] (rows of unselected slots are written as 0). */
+int gjx_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score,
+                   float* grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GJX_H */

@@ -1,0 +1,136 @@
+"""float64 closed-form answers the hot path is checked against.  TEST INFRASTRUCTURE ONLY.
+
+NumPy only (no scipy at run time on the GPU box is assumed).  Sources of the cases:
+  - beta-bernoulli          /root/reference/README.md:89-123
+  - flip-flip               /root/reference/tests/inference/test_smc.py:32-87
+  - Gaussian mixture        SURVEY.md §8(d) config 2 (model shape from test_smc.py:89-98)
+  - linear-Gaussian SSM     SURVEY.md §8(d) config 3/4  (Kalman filter log-likelihood)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def log_normal_pdf(x, mu, sd):
+    x, mu, sd = np.asarray(x, np.float64), np.asarray(mu, np.float64), np.asarray(sd, np.float64)
+    z = (x - mu) / sd
+    return -0.5 * z * z - np.log(sd) - 0.5 * math.log(2 * math.pi)
+
+
+def logsumexp(a, axis=None):
+    a = np.asarray(a, np.float64)
+    m = np.max(a, axis=axis, keepdims=True)
+    out = np.log(np.sum(np.exp(a - m), axis=axis, keepdims=True)) + m
+    return np.squeeze(out, axis=axis) if axis is not None else float(out.ravel()[0])
+
+
+# ---- config 1 ------------------------------------------------------------------------------
+def beta_bernoulli_log_ml(a: float, b: float, obs: bool) -> float:
+    """p ~ beta(a,b); v ~ flip(p): P(v=True) = a/(a+b)."""
+    return math.log(a / (a + b)) if obs else math.log(b / (a + b))
+
+
+def beta_bernoulli_posterior_mean(a: float, b: float, obs: bool) -> float:
+    return (a + 1) / (a + b + 1) if obs else a / (a + b + 1)
+
+
+# ---- config 2 ------------------------------------------------------------------------------
+def gmm_problem(C: int = 8, D: int = 16, seed: int = 0, mu_range: float = 1.0, sigma: float = 1.0,
+                r: float = 4.0):
+    """Synthetic GMM of SURVEY §8(d): z~categorical(logits), x~N(mu[z], sigma), y~N(x, r)."""
+    rng = np.random.default_rng(seed)
+    logits = rng.standard_normal(C)
+    mu = rng.uniform(-mu_range, mu_range, size=(C, D))
+    sig = np.full((C, D), sigma)
+    rr = np.full(D, r)
+    z = rng.choice(C, p=np.exp(logits - logsumexp(logits)))
+    x = mu[z] + sig[z] * rng.standard_normal(D)
+    y = x + rr * rng.standard_normal(D)
+    f = np.float32
+    return dict(logits=logits.astype(f), mu=mu.astype(f), sigma=sig.astype(f), r=rr.astype(f), y=y.astype(f))
+
+
+def gmm_log_ml(logits, mu, sigma, r, y) -> float:
+    """log sum_c pi_c prod_d N(y_d; mu_cd, sqrt(sigma_cd^2 + r_d^2))."""
+    logits = np.asarray(logits, np.float64)
+    logpi = logits - logsumexp(logits)
+    sd = np.sqrt(np.asarray(sigma, np.float64) ** 2 + np.asarray(r, np.float64)[None, :] ** 2)
+    ll = log_normal_pdf(np.asarray(y, np.float64)[None, :], np.asarray(mu, np.float64), sd).sum(axis=1)
+    return float(logsumexp(logpi + ll))
+
+
+def gmm_posterior_z(logits, mu, sigma, r, y) -> np.ndarray:
+    logits = np.asarray(logits, np.float64)
+    logpi = logits - logsumexp(logits)
+    sd = np.sqrt(np.asarray(sigma, np.float64) ** 2 + np.asarray(r, np.float64)[None, :] ** 2)
+    ll = log_normal_pdf(np.asarray(y, np.float64)[None, :], np.asarray(mu, np.float64), sd).sum(axis=1)
+    lp = logpi + ll
+    return np.exp(lp - logsumexp(lp))
+
+
+# ---- config 3/4 ----------------------------------------------------------------------------
+def ssm_problem(dx: int = 8, T: int = 256, q: float = 0.5, r: float = 2.0, seed: int = 0):
+    """A = block-diag of 2x2 blocks 0.9*Rot(theta_i), theta_i = 0.3 + 0.1*i (i = block start), H = I."""
+    A = np.zeros((dx, dx))
+    for i in range(0, dx, 2):
+        th = 0.3 + 0.1 * i
+        c, s = math.cos(th), math.sin(th)
+        A[i:i + 2, i:i + 2] = 0.9 * np.array([[c, -s], [s, c]])
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(dx)
+    ys = np.zeros((T, dx))
+    for t in range(T):
+        if t > 0:
+            x = A @ x + q * rng.standard_normal(dx)
+        ys[t] = x + r * rng.standard_normal(dx)
+    return dict(A=A.astype(np.float32), y=ys.astype(np.float32), q=q, r=r, q0=1.0)
+
+
+def kalman_log_lik(A, y, q, r, q0=1.0, H=None):
+    """float64 Kalman filter: returns (total log-likelihood, per-step increments, filtered means)."""
+    A = np.asarray(A, np.float64)
+    y = np.asarray(y, np.float64)
+    T, dy = y.shape
+    dx = A.shape[0]
+    Hm = np.eye(dx)[:dy] if H is None else np.asarray(H, np.float64)
+    Q = q * q * np.eye(dx)
+    R = r * r * np.eye(dy)
+    m = np.zeros(dx)
+    P = q0 * q0 * np.eye(dx)
+    incs = np.zeros(T)
+    means = np.zeros((T, dx))
+    for t in range(T):
+        if t > 0:
+            m = A @ m
+            P = A @ P @ A.T + Q
+        S = Hm @ P @ Hm.T + R
+        v = y[t] - Hm @ m
+        Sinv = np.linalg.inv(S)
+        sign, logdet = np.linalg.slogdet(S)
+        incs[t] = -0.5 * (v @ Sinv @ v + logdet + dy * math.log(2 * math.pi))
+        Kg = P @ Hm.T @ Sinv
+        m = m + Kg @ v
+        P = (np.eye(dx) - Kg @ Hm) @ P
+        means[t] = m
+    return float(incs.sum()), incs, means
+
+
+# ---- config 5 ------------------------------------------------------------------------------
+def logreg_problem(N: int = 1024, P: int = 16, seed: int = 0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, P))
+    beta = rng.standard_normal(P)
+    y = (rng.uniform(size=N) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float32)
+    return dict(X=X.astype(np.float32), y=y, beta_true=beta.astype(np.float32))
+
+
+def logreg_log_joint(log_tau, beta, X, y):
+    """log p(log_tau, beta, y) of: log_tau~N(0,1); beta_p~N(0, exp(log_tau)); y_n~Bernoulli(logits=X beta)."""
+    log_tau = float(log_tau)
+    beta = np.asarray(beta, np.float64)
+    s = np.asarray(X, np.float64) @ beta
+    yy = np.asarray(y, np.float64)
+    ll = np.sum(yy * -np.logaddexp(0, -s) + (1 - yy) * -np.logaddexp(0, s))
+    return float(log_normal_pdf(log_tau, 0.0, 1.0) + log_normal_pdf(beta, 0.0, math.exp(log_tau)).sum() + ll)

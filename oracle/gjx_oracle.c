@@ -1,0 +1,766 @@
+/* gjx_oracle.c — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object.  The product (genjax_amd/) never imports, links or falls back to it.
+ *
+ * What it restates (paths relative to /root/reference/src/genjax/_src/):
+ *   - ImportanceK.run_smc's vmapped body           inference/smc.py:298-315
+ *   - Target.importance                            inference/sp.py:83-87
+ *   - GenerateHandler key rule / score / weight    generative_functions/static.py:340-399, 102-105
+ *   - Distribution.generate_choice_map             generative_functions/distributions/distribution.py:117-147
+ *   - ExactDensity.random_weighted/estimate_logpdf distribution.py:371-396 (shaped logpdf is summed)
+ *   - log-ML estimate, sample_particle             inference/smc.py:96-109
+ *   - ChangeTarget reweight                        inference/smc.py:378-391
+ *   - HMC.edit                                     inference/requests/hmc.py:70-211
+ * The arithmetic of the reference lives in un-vendored dependencies that cannot be imported in
+ * the build container: jax 0.5.2 / jaxlib 0.5.1 (poetry.lock:1627-1661) and
+ * tensorflow-probability 0.23.0 (poetry.lock:5015-5016).  Their published algorithms are
+ * restated here: Threefry-2x32 (Salmon et al. 2011, 20 rounds; checked against the Random123
+ * known-answer vectors), JAX's key derivation with jax_threefry_partitionable=True
+ * (split(k,n)[i] == fold_in(k,i) == Threefry(k,(0,i))), bits -> uniform -> normal via
+ * sqrt(2)*erfinv (Giles 2010 single-precision polynomial, as XLA), Gumbel-max categorical, and
+ * TFP's closed-form log_prob expressions.
+ *
+ * PARITY STATUS: bit-level parity with the reference's sample streams is UNPINNED — the
+ * reference holds no golden vectors or sampled-value assertions for this path
+ * and cannot run here.  This oracle is pinned by: the Random123 KATs, scipy.stats log-pdf
+ * tables (tests/golden/), and every closed-form / tolerance check the reference's own tests
+ * hold for the path (tests/inference/test_smc.py:32-87, test_requests.py:94-255, README.md:89-123).
+ *
+ * Plain C, float32 arithmetic exactly where the reference is float32; reductions that the
+ * reference leaves to XLA (logsumexp) are accumulated in double and rounded once.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gjx.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------------------------------
+ * Threefry-2x32, 20 rounds (Random123 threefry2x32_R(20,...)); JAX: jax/_src/prng.py
+ * threefry2x32 — rotations {13,15,26,6} {17,29,16,24}, key schedule parity 0x1BD11BDA.
+ * ------------------------------------------------------------------------------------- */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+void gjxo_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
+  static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    const int* r = (g & 1) ? R + 4 : R;
+    for (int j = 0; j < 4; ++j) {
+      x0 += x1;
+      x1 = rotl32(x1, r[j]);
+      x1 ^= x0;
+    }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  out[0] = x0;
+  out[1] = x1;
+}
+
+typedef struct { uint32_t a, b; } okey;
+
+/* jax.random.fold_in(key, i) == jax.random.split(key, n)[i]  (partitionable threefry) */
+static inline okey fold_in64(okey k, uint64_t i) {
+  uint32_t o[2];
+  gjxo_threefry2x32(k.a, k.b, (uint32_t)(i >> 32), (uint32_t)i, o);
+  okey r = {o[0], o[1]};
+  return r;
+}
+static inline okey fold_in(okey k, uint32_t i) { return fold_in64(k, i); }
+
+/* 32 random bits for element c of the array drawn with key k */
+static inline uint32_t elem_bits(okey k, uint32_t c, int rng_mode) {
+  uint32_t o[2];
+  if (rng_mode == GJX_RNG_JAX32) { /* _threefry_random_bits_partitionable: bits1 ^ bits2 */
+    gjxo_threefry2x32(k.a, k.b, 0u, c, o);
+    return o[0] ^ o[1];
+  }
+  gjxo_threefry2x32(k.a, k.b, 0u, c >> 1, o);
+  return o[c & 1];
+}
+
+static inline float bits_to_unit(uint32_t bits) { /* jax _uniform: [0,1) from 23 mantissa bits */
+  uint32_t u = (bits >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &u, 4);
+  return f - 1.0f;
+}
+static inline float uniform_from_bits(uint32_t bits, float lo, float hi) {
+  float f = bits_to_unit(bits);
+  float v = f * (hi - lo) + lo;
+  return v > lo ? v : lo; /* lax.max(minval, ...) */
+}
+
+/* Giles (2010) single-precision erfinv — the polynomial XLA's ErfInv32 uses */
+static float erfinv_f32(float x) {
+  float w = -log1pf(-x * x);
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  return p * x;
+}
+float gjxo_erfinv(float x) { return erfinv_f32(x); }
+
+#define NEG1_PLUS_ULP (-0.99999994f) /* nextafter(-1, 0) */
+#define F32_TINY 1.17549435e-38f
+#define SQRT2_F 1.41421356f
+#define HALF_LOG_2PI 0.918938533f
+#define LOG_PI 1.14472989f
+
+static inline float normal_from_bits(uint32_t bits) { /* jax _normal_real */
+  float u = uniform_from_bits(bits, NEG1_PLUS_ULP, 1.0f);
+  return SQRT2_F * erfinv_f32(u);
+}
+static inline float gumbel_from_bits(uint32_t bits) { /* jax.random.gumbel */
+  float u = uniform_from_bits(bits, F32_TINY, 1.0f);
+  return -logf(-logf(u));
+}
+
+float gjxo_normal_from_bits(uint32_t bits) { return normal_from_bits(bits); }
+float gjxo_gumbel_from_bits(uint32_t bits) { return gumbel_from_bits(bits); }
+float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
+
+/* Marsaglia & Tsang (2000) gamma sampler in log space; the draw budget per gamma variate is
+ * fixed so that element indices are a pure function of (variate, iteration). */
+#define GAMMA_MAXIT 32
+#define GAMMA_NDRAW (2 * GAMMA_MAXIT + 1)
+static float log_gamma_variate(okey sk, uint32_t base, float a, int rng_mode) {
+  float boost = 0.0f;
+  float aa = a;
+  if (a < 1.0f) {
+    float u = uniform_from_bits(elem_bits(sk, base + 2 * GAMMA_MAXIT, rng_mode), F32_TINY, 1.0f);
+    boost = logf(u) / a;
+    aa = a + 1.0f;
+  }
+  float d = aa - (1.0f / 3.0f);
+  float c = 1.0f / sqrtf(9.0f * d);
+  float res = logf(d);
+  for (int t = 0; t < GAMMA_MAXIT; ++t) {
+    float x = normal_from_bits(elem_bits(sk, base + 2 * t, rng_mode));
+    float u = uniform_from_bits(elem_bits(sk, base + 2 * t + 1, rng_mode), F32_TINY, 1.0f);
+    float v = 1.0f + c * x;
+    if (v <= 0.0f) continue;
+    float lv = 3.0f * logf(v);
+    v = v * v * v;
+    if (logf(u) < 0.5f * x * x + d - d * v + d * lv) {
+      res = logf(d) + lv;
+      break;
+    }
+  }
+  return res + boost;
+}
+
+/* --------------------------------------------------------------------------------------- */
+static inline float softplusf(float x) { /* log(1+exp(x)), stable */
+  return (x > 0.0f ? x : 0.0f) + log1pf(expf(-fabsf(x)));
+}
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+static inline float xlogyf(float x, float y) { return x == 0.0f ? 0.0f : x * logf(y); }
+static inline float xlog1pyf(float x, float y) { return x == 0.0f ? 0.0f : x * log1pf(y); }
+
+static float eval_param(const gjx_param* p, int d, const float* tab, const float* vals) {
+  float v;
+  switch (p->op) {
+    case GJX_P_CONST: v = tab[p->off + (d % p->len)]; break;
+    case GJX_P_VALUE: v = vals[p->slot + (d % p->len)]; break;
+    case GJX_P_GATHER: {
+      int idx = (int)vals[p->slot];
+      if (idx < 0) idx = 0;
+      if (idx > p->n - 1) idx = p->n - 1;
+      v = tab[p->off + idx * p->len + (d % p->len)];
+      break;
+    }
+    case GJX_P_AFFINE: {
+      float acc = tab[p->off + (d % p->len)];
+      for (int e = 0; e < p->n; ++e) acc += tab[p->moff + d * p->n + e] * vals[p->slot + e];
+      v = acc;
+      break;
+    }
+    default: v = NAN;
+  }
+  switch (p->xf) {
+    case GJX_XF_EXP: v = expf(v); break;
+    case GJX_XF_SOFTPLUS: v = softplusf(v); break;
+    case GJX_XF_SIGMOID: v = sigmoidf_(v); break;
+    default: break;
+  }
+  return v;
+}
+
+/* log-density of ONE scalar element (TFP 0.23 log_prob expressions) */
+static float elem_logpdf(int kind, float x, float a, float b) {
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: { /* tfd.Normal._log_prob */
+      float z = x / b - a / b;
+      return -0.5f * z * z - (HALF_LOG_2PI + logf(b));
+    }
+    case GJX_FLIP: /* tfd.Bernoulli(probs): multiply_no_nan(log p, x) + multiply_no_nan(log1p(-p), 1-x) */
+      return (x != 0.0f ? logf(a) : 0.0f) + (x != 1.0f ? (1.0f - x) * log1pf(-a) : 0.0f);
+    case GJX_BERNOULLI_LOGITS: /* -softplus(-l)*x - softplus(l)*(1-x) */
+      return (x != 0.0f ? -softplusf(-a) * x : 0.0f) + (x != 1.0f ? -softplusf(a) * (1.0f - x) : 0.0f);
+    case GJX_BETA: /* xlogy(a-1,x) + xlog1py(b-1,-x) - lbeta(a,b) */
+      return xlogyf(a - 1.0f, x) + xlog1pyf(b - 1.0f, -x) - (lgammaf(a) + lgammaf(b) - lgammaf(a + b));
+    case GJX_UNIFORM:
+      return (x < a || x > b) ? -INFINITY : -logf(b - a);
+    case GJX_EXPONENTIAL: /* a = rate */
+      return x < 0.0f ? -INFINITY : logf(a) - a * x;
+    case GJX_HALF_NORMAL: { /* a = scale */
+      float z = x / a;
+      return x < 0.0f ? -INFINITY : (0.5f * logf(2.0f / 3.14159265f) - logf(a) - 0.5f * z * z);
+    }
+    case GJX_LAPLACE:
+      return -fabsf(x - a) / b - logf(2.0f * b);
+    case GJX_LOG_NORMAL: {
+      float lx = logf(x);
+      float z = lx / b - a / b;
+      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - lx;
+    }
+    case GJX_CAUCHY: {
+      float z = (x - a) / b;
+      return -(LOG_PI + logf(b)) - log1pf(z * z);
+    }
+    case GJX_GAMMA: /* a = concentration, b = rate */
+      return xlogyf(a, b) + xlogyf(a - 1.0f, x) - b * x - lgammaf(a);
+    default: return NAN;
+  }
+}
+
+/* draws per scalar element, so that element indices are deterministic */
+static int draws_per_elem(int kind) {
+  switch (kind) {
+    case GJX_BETA: return 2 * GAMMA_NDRAW;
+    case GJX_GAMMA: return GAMMA_NDRAW;
+    default: return 1;
+  }
+}
+
+static float elem_sample(int kind, okey sk, uint32_t c, float a, float b, int rng_mode) {
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: return a + b * normal_from_bits(elem_bits(sk, c, rng_mode));
+    case GJX_FLIP: return bits_to_unit(elem_bits(sk, c, rng_mode)) < a ? 1.0f : 0.0f;
+    case GJX_BERNOULLI_LOGITS: return bits_to_unit(elem_bits(sk, c, rng_mode)) < sigmoidf_(a) ? 1.0f : 0.0f;
+    case GJX_BETA: {
+      float g1 = log_gamma_variate(sk, c, a, rng_mode);
+      float g2 = log_gamma_variate(sk, c + GAMMA_NDRAW, b, rng_mode);
+      return sigmoidf_(g1 - g2);
+    }
+    case GJX_UNIFORM: return a + (b - a) * bits_to_unit(elem_bits(sk, c, rng_mode));
+    case GJX_EXPONENTIAL: return -logf(uniform_from_bits(elem_bits(sk, c, rng_mode), F32_TINY, 1.0f)) / a;
+    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(elem_bits(sk, c, rng_mode))) * a;
+    case GJX_LAPLACE: {
+      float u = uniform_from_bits(elem_bits(sk, c, rng_mode), NEG1_PLUS_ULP, 1.0f);
+      float s = (u > 0.0f) - (u < 0.0f);
+      return a - b * s * log1pf(-fabsf(u));
+    }
+    case GJX_LOG_NORMAL: return expf(a + b * normal_from_bits(elem_bits(sk, c, rng_mode)));
+    case GJX_CAUCHY: return a + b * tanf(3.14159265f * (bits_to_unit(elem_bits(sk, c, rng_mode)) - 0.5f));
+    case GJX_GAMMA: return expf(log_gamma_variate(sk, c, a, rng_mode)) / b;
+    default: return NAN;
+  }
+}
+
+/* One particle through the site list.  vals[n_slots] in/out.  Returns via pointers. */
+static void run_particle(const gjx_program* prog, okey pk, float* vals, float* score_out,
+                         float* weight_out, float* site_scores, int64_t ss_stride) {
+  const float* tab = prog->tab;
+  float score = 0.0f, weight = 0.0f;
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site* s = &prog->sites[j];
+    okey sk = fold_in(pk, (uint32_t)(j + 1)); /* static.py:349-352, counter starts at 1 */
+    float lp = 0.0f;
+    if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
+      /* logits (probs -> log p), log_softmax; sample = argmax(logits + Gumbel) */
+      int n = s->ncat;
+      float mx = -INFINITY;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        if (l > mx) mx = l;
+      }
+      double se = 0.0;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        se += exp((double)l - (double)mx);
+      }
+      float lse = mx + (float)log(se);
+      float v;
+      if (s->mode == GJX_MODE_SAMPLE) {
+        int best = 0;
+        float bestv = -INFINITY;
+        for (int c = 0; c < n; ++c) {
+          float l = eval_param(&s->p[0], c, tab, vals);
+          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+          float g = l + gumbel_from_bits(elem_bits(sk, (uint32_t)c, prog->rng_mode));
+          if (g > bestv) { bestv = g; best = c; }
+        }
+        v = (float)best;
+      } else if (s->mode == GJX_MODE_OBS_TAB) {
+        v = tab[s->obs_off];
+      } else {
+        v = vals[s->slot];
+      }
+      int k = (int)v;
+      if (k < 0 || k >= n) {
+        lp = -INFINITY;
+      } else {
+        float l = eval_param(&s->p[0], k, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        lp = l - lse;
+      }
+      if (s->slot >= 0) vals[s->slot] = v;
+    } else {
+      int nd = draws_per_elem(s->kind);
+      for (int d = 0; d < s->dim; ++d) {
+        float a = eval_param(&s->p[0], d, tab, vals);
+        float b = eval_param(&s->p[1], d, tab, vals);
+        float v;
+        if (s->mode == GJX_MODE_SAMPLE) v = elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b, prog->rng_mode);
+        else if (s->mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
+        else v = vals[s->slot + d];
+        lp += elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
+        if (s->slot >= 0) vals[s->slot + d] = v;
+      }
+    }
+    score += lp;
+    if (s->mode != GJX_MODE_SAMPLE) weight += lp; /* static.py:377 with distribution.py:127/147 */
+    if (site_scores) site_scores[(int64_t)j * ss_stride] = lp;
+  }
+  *score_out = score;
+  *weight_out = weight;
+}
+
+static void lse4(const float* x, int64_t K, int64_t K_total, float* out) {
+  float mx = -INFINITY;
+  for (int64_t i = 0; i < K; ++i)
+    if (x[i] > mx) mx = x[i];
+  double s = 0.0;
+  if (mx > -INFINITY)
+    for (int64_t i = 0; i < K; ++i) s += exp((double)x[i] - (double)mx);
+  out[0] = mx;
+  out[1] = (float)s;
+  out[2] = (mx > -INFINITY) ? (float)((double)mx + log(s)) : -INFINITY;
+  out[3] = (float)((double)out[2] - log((double)K_total));
+}
+
+int gjxo_logsumexp(const float* x, int64_t K, int64_t K_total, float* out) {
+  lse4(x, K, K_total, out);
+  return 0;
+}
+
+int gjxo_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
+                     int64_t particle_offset, float* choices, float* score, float* weight,
+                     float* logw, const float* logw_in, const float* sub, float* site_scores,
+                     float* lse, int64_t K_total) {
+  if (!prog || K < 0) return GJX_EINVAL;
+  const okey key = {key0, key1};
+  const int ns = prog->n_slots;
+#pragma omp parallel
+  {
+    float* vals = (float*)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < K; ++i) {
+      okey pk = fold_in64(key, (uint64_t)(particle_offset + i)); /* smc.py:300 split(sub_key, K)[i] */
+      for (int s = 0; s < ns; ++s) vals[s] = choices[(int64_t)s * K + i];
+      float sc, w;
+      run_particle(prog, pk, vals, &sc, &w, site_scores ? site_scores + i : NULL, K);
+      for (int s = 0; s < ns; ++s) choices[(int64_t)s * K + i] = vals[s];
+      if (score) score[i] = sc;
+      if (weight) weight[i] = w;
+      if (logw) {
+        float lw = w;
+        if (logw_in) lw = lw + logw_in[i];
+        if (sub) lw = lw - sub[i];
+        logw[i] = lw;
+      }
+    }
+    free(vals);
+  }
+  if (lse && logw) lse4(logw, K, K_total, lse);
+  return 0;
+}
+
+/* ParticleCollection.sample_particle (smc.py:102-109) */
+int gjxo_categorical_pick(const float* logw, int64_t K, int64_t particle_offset, const float* lse,
+                          uint32_t key0, uint32_t key1, int32_t rng_mode, float* best_val,
+                          int64_t* best_idx) {
+  okey key = {key0, key1};
+  float bv = -INFINITY;
+  int64_t bi = 0;
+  for (int64_t i = 0; i < K; ++i) {
+    uint64_t gi = (uint64_t)(particle_offset + i);
+    float g;
+    if (rng_mode == GJX_RNG_JAX32) {
+      uint32_t o[2];
+      gjxo_threefry2x32(key.a, key.b, (uint32_t)(gi >> 32), (uint32_t)gi, o);
+      g = gumbel_from_bits(o[0] ^ o[1]);
+    } else {
+      uint32_t o[2];
+      uint64_t h = gi >> 1;
+      gjxo_threefry2x32(key.a, key.b, (uint32_t)(h >> 32), (uint32_t)h, o);
+      g = gumbel_from_bits(o[gi & 1]);
+    }
+    float v = (logw[i] - lse[2]) + g;
+    if (v > bv) { bv = v; bi = particle_offset + i; }
+  }
+  *best_val = bv;
+  *best_idx = bi;
+  return 0;
+}
+
+/* ---- resampling: exact integer work on fixed-point weights -------------------------------- */
+#define GJX_WEIGHT_SCALE 1073741824.0f /* 2^30 */
+
+int gjxo_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, uint64_t* cum,
+                       uint64_t* total) {
+  uint64_t acc = 0;
+  for (int64_t i = 0; i < K; ++i) {
+    float w = is_log ? expf(x[i] - lse[0]) : x[i];
+    if (!(w > 0.0f)) w = 0.0f;
+    acc += (uint64_t)(w * GJX_WEIGHT_SCALE);
+    cum[i] = acc;
+  }
+  *total = acc;
+  return 0;
+}
+
+/* Systematic comb: output slot j sits at p_j = (j + u) * total_all / N_total on the weight line;
+ * its integer threshold is T_j = floor(p_j) (clamped below total_all) and its ancestor is the
+ * first particle whose inclusive prefix sum exceeds T_j.  The double arithmetic (one add, one
+ * multiply, one truncation per slot) is IEEE-exact, so a GPU evaluating the same expression gets
+ * the same T_j. */
+int gjxo_resample_systematic(const uint64_t* cum, int64_t K, uint64_t base, uint64_t total_all,
+                             double u, int64_t N_total, int64_t out_begin, int64_t n_out,
+                             int32_t* ancestors) {
+  const double step = (double)total_all / (double)N_total;
+  int64_t i = 0; /* thresholds are non-decreasing in j: walk the prefix sums once */
+  for (int64_t j = 0; j < n_out; ++j) {
+    const double pj = ((double)(out_begin + j) + u) * step;
+    uint64_t T = (uint64_t)pj;
+    if (total_all > 0 && T > total_all - 1) T = total_all - 1;
+    int32_t a = -1;
+    if (K > 0 && T >= base && T < base + cum[K - 1]) {
+      const uint64_t tl = T - base;
+      while (i < K - 1 && !(cum[i] > tl)) ++i;
+      a = (int32_t)i;
+    }
+    ancestors[j] = a;
+  }
+  return 0;
+}
+
+int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uint64_t total_all,
+                              uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
+                              int64_t n_out, int32_t* ancestors) {
+  (void)N_total;
+  okey key = {key0, key1};
+  for (int64_t j = 0; j < n_out; ++j) {
+    uint64_t gj = (uint64_t)(out_begin + j);
+    uint32_t o[2];
+    gjxo_threefry2x32(key.a, key.b, (uint32_t)(gj >> 32), (uint32_t)gj, o);
+    /* 53-bit uniform from both words: exact integer target on the weight line */
+    uint64_t r = (((uint64_t)o[0] << 32) | o[1]) >> 11;
+    double uj = (double)r * (1.0 / 9007199254740992.0);
+    uint64_t target = (uint64_t)(uj * (double)total_all);
+    int32_t a = -1;
+    if (target >= base && K > 0 && target < base + cum[K - 1]) {
+      uint64_t tl = target - base;
+      int64_t lo = 0, hi = K - 1; /* first i with cum[i] > tl */
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (cum[mid] > tl) hi = mid; else lo = mid + 1;
+      }
+      a = (int32_t)lo;
+    }
+    ancestors[j] = a;
+  }
+  return 0;
+}
+
+int gjxo_gather_rows(const float* src, int64_t src_stride, const int32_t* anc, int64_t n_out,
+                     int32_t rows, float* dst, int64_t dst_stride) {
+  for (int r = 0; r < rows; ++r)
+    for (int64_t j = 0; j < n_out; ++j)
+      if (anc[j] >= 0) dst[(int64_t)r * dst_stride + j] = src[(int64_t)r * src_stride + anc[j]];
+  return 0;
+}
+
+/* ---- linear-Gaussian SSM bootstrap step ---------------------------------------------------- */
+int gjxo_ssm_step(int32_t dx, int32_t dy, const float* A, const float* H, float q, float r, float q0,
+                  uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
+                  int64_t particle_offset, const float* x_prev, int64_t prev_stride,
+                  const int32_t* anc, const float* y, float* x_out, float* logw, float* lse,
+                  int64_t K_total) {
+  okey key = {key0, key1};
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < K; ++i) {
+    okey pk = fold_in64(key, (uint64_t)(particle_offset + i));
+    okey sk = fold_in(pk, 1u); /* site 1: the latent state; site 2 (y) is observed */
+    float xp[64], xn[64];
+    if (t > 0) {
+      int64_t a = anc ? anc[i] : i;
+      for (int d = 0; d < dx; ++d) xp[d] = x_prev[(int64_t)d * prev_stride + a];
+    }
+    for (int d = 0; d < dx; ++d) {
+      float mu = 0.0f, sd = q0;
+      if (t > 0) {
+        float acc = 0.0f;
+        for (int e = 0; e < dx; ++e) acc += A[d * dx + e] * xp[e];
+        mu = acc;
+        sd = q;
+      }
+      xn[d] = mu + sd * normal_from_bits(elem_bits(sk, (uint32_t)d, rng_mode));
+      x_out[(int64_t)d * K + i] = xn[d];
+    }
+    float lw = 0.0f;
+    for (int o = 0; o < dy; ++o) {
+      float m;
+      if (H) {
+        float acc = 0.0f;
+        for (int e = 0; e < dx; ++e) acc += H[o * dx + e] * xn[e];
+        m = acc;
+      } else {
+        m = xn[o];
+      }
+      float z = y[o] / r - m / r;
+      lw += -0.5f * z * z - (HALF_LOG_2PI + logf(r));
+    }
+    logw[i] = lw;
+  }
+  if (lse) lse4(logw, K, K_total, lse);
+  return 0;
+}
+
+/* ---- HMC.edit (hmc.py:156-211) ---------------------------------------------------------------
+ * score and its gradient w.r.t. the selected slots by a reverse sweep over the site list
+ * (what jax.grad of gen_fn.assess computes, hmc.py:83-94).  All sites are evaluated at their
+ * current value (assess semantics: every site constrained, static.py:297-321). */
+static void dlogpdf(int kind, float x, float a, float b, float* dx, float* da, float* db) {
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: {
+      float z = (x - a) / b;
+      *dx = -z / b; *da = z / b; *db = (z * z - 1.0f) / b;
+      return;
+    }
+    case GJX_BERNOULLI_LOGITS: *dx = 0.0f; *da = x - sigmoidf_(a); *db = 0.0f; return;
+    case GJX_FLIP: *dx = 0.0f; *da = (x != 0.0f ? 1.0f / a : 0.0f) - (x != 1.0f ? (1.0f - x) / (1.0f - a) : 0.0f); *db = 0.0f; return;
+    case GJX_HALF_NORMAL: { float z = x / a; *dx = -z / a; *da = (z * z - 1.0f) / a; *db = 0.0f; return; }
+    case GJX_EXPONENTIAL: *dx = -a; *da = 1.0f / a - x; *db = 0.0f; return;
+    case GJX_LAPLACE: { float s = (x > a) - (x < a); *dx = -s / b; *da = s / b; *db = fabsf(x - a) / (b * b) - 1.0f / b; return; }
+    case GJX_CAUCHY: { float z = (x - a) / b; float g = 2.0f * z / (1.0f + z * z); *dx = -g / b; *da = g / b; *db = (g * z - 1.0f) / b; return; }
+    case GJX_LOG_NORMAL: { float lx = logf(x); float z = (lx - a) / b; *dx = (-z / b - 1.0f) / x; *da = z / b; *db = (z * z - 1.0f) / b; return; }
+    case GJX_BETA: *dx = (a - 1.0f) / x - (b - 1.0f) / (1.0f - x); *da = NAN; *db = NAN; return;
+    case GJX_GAMMA: *dx = (a - 1.0f) / x - b; *da = NAN; *db = x == x ? (a / b - x) : NAN; return;
+    case GJX_UNIFORM: *dx = 0.0f; *da = 1.0f / (b - a); *db = -1.0f / (b - a); return;
+    default: *dx = *da = *db = 0.0f;
+  }
+}
+
+static float xf_deriv(int xf, float pre) { /* d xf(v) / d v at pre-transform value */
+  switch (xf) {
+    case GJX_XF_EXP: return expf(pre);
+    case GJX_XF_SOFTPLUS: return sigmoidf_(pre);
+    case GJX_XF_SIGMOID: { float s = sigmoidf_(pre); return s * (1.0f - s); }
+    default: return 1.0f;
+  }
+}
+static float eval_param_pre(const gjx_param* p, int d, const float* tab, const float* vals) {
+  gjx_param q = *p;
+  q.xf = GJX_XF_NONE;
+  return eval_param(&q, d, tab, vals);
+}
+static void param_backprop(const gjx_param* p, int d, float g, const float* tab, const float* vals,
+                           float* grad) {
+  if (g == 0.0f) return;
+  if (p->xf != GJX_XF_NONE) g *= xf_deriv(p->xf, eval_param_pre(p, d, tab, vals));
+  switch (p->op) {
+    case GJX_P_VALUE: grad[p->slot + (d % p->len)] += g; break;
+    case GJX_P_AFFINE:
+      for (int e = 0; e < p->n; ++e) grad[p->slot + e] += g * tab[p->moff + d * p->n + e];
+      break;
+    default: break; /* CONST, GATHER: no float dependence */
+  }
+}
+
+/* score + gradient for one chain; grad[n_slots] (all slots; caller masks by selection) */
+static float score_and_grad(const gjx_program* prog, const float* vals, float* grad) {
+  const float* tab = prog->tab;
+  float score = 0.0f;
+  for (int s = 0; s < prog->n_slots; ++s) grad[s] = 0.0f;
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site* s = &prog->sites[j];
+    if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
+      int n = s->ncat;
+      float mx = -INFINITY;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        if (l > mx) mx = l;
+      }
+      double se = 0.0;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        se += exp((double)l - (double)mx);
+      }
+      int k = (int)vals[s->slot];
+      float l = eval_param(&s->p[0], k, tab, vals);
+      if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+      score += l - (mx + (float)log(se));
+      continue; /* integer site: no gradient through it (hmc.py:49-65) */
+    }
+    for (int d = 0; d < s->dim; ++d) {
+      float a = eval_param(&s->p[0], d, tab, vals);
+      float b = eval_param(&s->p[1], d, tab, vals);
+      float x = vals[s->slot + d];
+      score += elem_logpdf(s->kind, x, a, b);
+      float gx, ga, gb;
+      dlogpdf(s->kind, x, a, b, &gx, &ga, &gb);
+      grad[s->slot + d] += gx;
+      param_backprop(&s->p[0], d, ga, tab, vals, grad);
+      param_backprop(&s->p[1], d, gb, tab, vals, grad);
+    }
+  }
+  return score;
+}
+
+int gjxo_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score,
+                    float* grad) {
+  const int ns = prog->n_slots;
+  char* sel = (char*)calloc((size_t)ns + 1, 1);
+  for (int j = 0; j < prog->n_sites; ++j)
+    if (prog->sites[j].flags & GJX_SITE_HMC_SELECTED)
+      for (int d = 0; d < prog->sites[j].dim; ++d) sel[prog->sites[j].slot + d] = 1;
+#pragma omp parallel
+  {
+    float* vals = (float*)malloc(sizeof(float) * (size_t)ns);
+    float* g = (float*)malloc(sizeof(float) * (size_t)ns);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      for (int s = 0; s < ns; ++s) vals[s] = choices[(int64_t)s * n + i];
+      float sc = score_and_grad(prog, vals, g);
+      if (score) score[i] = sc;
+      for (int s = 0; s < ns; ++s) grad[(int64_t)s * n + i] = sel[s] ? g[s] : 0.0f;
+    }
+    free(vals);
+    free(g);
+  }
+  free(sel);
+  return 0;
+}
+
+int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
+             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
+             float* score, float* alpha, float* accepted) {
+  const int ns = prog->n_slots;
+  const okey key = {key0, key1};
+  int* selslot = (int*)malloc(sizeof(int) * (size_t)(ns + 1));
+  int* leaf_of = (int*)malloc(sizeof(int) * (size_t)(ns + 1));
+  int* elem_of = (int*)malloc(sizeof(int) * (size_t)(ns + 1));
+  int nsel = 0, leaf = 0;
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site* s = &prog->sites[j];
+    if (!(s->flags & GJX_SITE_HMC_SELECTED)) continue;
+    for (int d = 0; d < s->dim; ++d) {
+      selslot[nsel] = s->slot + d;
+      leaf_of[nsel] = leaf; /* one momentum leaf per selected address, in program order */
+      elem_of[nsel] = d;
+      ++nsel;
+    }
+    ++leaf;
+  }
+#pragma omp parallel
+  {
+    float* vals = (float*)malloc(sizeof(float) * (size_t)ns);
+    float* old = (float*)malloc(sizeof(float) * (size_t)ns);
+    float* g = (float*)malloc(sizeof(float) * (size_t)ns);
+    float* g0 = (float*)malloc(sizeof(float) * (size_t)ns);
+    float* p = (float*)malloc(sizeof(float) * (size_t)(nsel + 1));
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      okey ck = fold_in64(key, (uint64_t)(chain_offset + i));
+      okey knew = fold_in(ck, 0u), sub = fold_in(ck, 1u); /* key, sub_key = split(key)  hmc.py:167 */
+      for (int s = 0; s < ns; ++s) old[s] = vals[s] = choices[(int64_t)s * n + i];
+      float score0 = score_and_grad(prog, vals, g0); /* hmc.py:165-166 */
+      float k0 = 0.0f;
+      for (int m = 0; m < nsel; ++m) { /* sample_momenta hmc.py:120-130 */
+        okey lk = fold_in(sub, (uint32_t)leaf_of[m]);
+        p[m] = normal_from_bits(elem_bits(lk, (uint32_t)elem_of[m], prog->rng_mode));
+        k0 += -0.5f * p[m] * p[m] - HALF_LOG_2PI;
+      }
+      for (int s = 0; s < ns; ++s) g[s] = g0[s];
+      float sc = score0;
+      for (int t = 1; t <= L; ++t) { /* hmc.py:170-194 */
+        const float* gfirst = stale_grad_compat ? g0 : g; /* hmc.py:186 carries the received gradient */
+        for (int m = 0; m < nsel; ++m) p[m] = p[m] + (eps / 2.0f) * gfirst[selslot[m]];
+        for (int m = 0; m < nsel; ++m) vals[selslot[m]] = vals[selslot[m]] + eps * p[m];
+        sc = score_and_grad(prog, vals, g);
+        for (int m = 0; m < nsel; ++m) p[m] = p[m] + (eps / 2.0f) * g[selslot[m]];
+      }
+      float k1 = 0.0f;
+      for (int m = 0; m < nsel; ++m) { float q = -1.0f * p[m]; k1 += -0.5f * q * q - HALF_LOG_2PI; }
+      float al = sc - score0 + k1 - k0; /* hmc.py:196-203 */
+      int acc = 1;
+      if (accept) {
+        okey ak = fold_in(knew, 0x4d48u);
+        float lu = logf(bits_to_unit(elem_bits(ak, 0u, prog->rng_mode)));
+        acc = lu < al; /* tests/inference/test_requests.py:134-137 */
+      }
+      if (!acc) { for (int s = 0; s < ns; ++s) vals[s] = old[s]; sc = score0; }
+      for (int s = 0; s < ns; ++s) choices[(int64_t)s * n + i] = vals[s];
+      if (score) score[i] = sc;
+      if (alpha) alpha[i] = al;
+      if (accepted) accepted[i] = (float)acc;
+    }
+    free(vals); free(old); free(g); free(g0); free(p);
+  }
+  free(selslot); free(leaf_of); free(elem_of);
+  return 0;
+}
+
+int gjxo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void gjxo_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
