@@ -1,1 +1,18 @@
-"""genjax_amd — MI355X-native inference-kernel backend with the GenJAX API shape."""
+"""genjax_amd — MI355X-native inference-kernel backend with the GenJAX API shape.
+
+Host-side Python keeps the reference's surface (``gen``, ``Target``, ``ChoiceMap``/``C``,
+``Selection``/``S``, ``ImportanceK``, ``HMC`` ...); everything per-particle runs in hand-written HIP
+kernels behind the C ABI of ``include/gjx.h`` (``genjax_amd/csrc/libgjx_hip.so``).  There is no CPU
+fallback: compute entry points raise ``GjxError`` if the library is missing.
+"""
+from . import config, inference  # noqa: F401
+from .core import (C, ChoiceMap, ChoiceMapBuilder, S, Selection, SelectionBuilder, fold_in, key,  # noqa: F401
+                   split)
+from .gen import (Distribution, Marginal, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
+                  cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
+                  mv_normal_diag, normal, sigmoid, softplus, take, uniform, where)
+from .inference import (HMC, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
+                        ParticleCollection, Regenerate, SafeHMC, SMCAlgorithm, Target, Update)
+from .program import AddressReuse, MissingAddress  # noqa: F401
+
+__version__ = "0.1.0"

@@ -28,7 +28,8 @@ P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
 MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT = 0, 1, 2
 SITE_HMC_SELECTED = 1
-RNG_PACKED, RNG_JAX32 = 0, 1
+RNG_FLAT, RNG_JAX32 = 0, 1
+FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
 MAX_PARAMS = 2
 
@@ -78,6 +79,7 @@ PROTOTYPES = {
     "gjx_gather_rows": (C.c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
                                vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc": (C.c_int, [PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp, vp,
                           C.c_size_t, vp]),
     "gjx_score_grad": (C.c_int, [PP, i64, vp, vp, vp, vp]),

@@ -1,0 +1,260 @@
+"""Host-side data types with the reference's names: PRNG keys, ChoiceMap, Selection.
+
+Only the static-address forms that the hot path needs are restated:
+  - ChoiceMap / ChoiceMapBuilder ``C``      core/generative/choice_map.py:847-1395
+  - Selection / SelectionBuilder ``S``      core/generative/choice_map.py:124-361
+  - key / split / fold_in                   jax.random (Threefry-2x32, partitionable layout)
+Values are Python scalars, NumPy arrays or torch tensors; a leading batch axis means "one value per
+particle".  No arithmetic happens here — this is trace bookkeeping.
+"""
+from __future__ import annotations
+
+from typing import Any, Iterable
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------
+# PRNG keys (host side).  key(seed) == (0, seed); split(k, n)[i] == fold_in(k, i) == Threefry(k, (0, i))
+# (jax 0.5.2, jax_threefry_partitionable=True).  The same function runs on the device for per-particle
+# keys; this host copy only serves the few scalar splits of the inference drivers (smc.py:154, 299).
+# ---------------------------------------------------------------------------------------------
+_M = 0xFFFFFFFF
+_ROT = (13, 15, 26, 6, 17, 29, 16, 24)
+
+
+def threefry2x32(k0: int, k1: int, c0: int, c1: int) -> tuple[int, int]:
+    ks = (k0 & _M, k1 & _M, (k0 ^ k1 ^ 0x1BD11BDA) & _M)
+    x0, x1 = (c0 + ks[0]) & _M, (c1 + ks[1]) & _M
+    for g in range(5):
+        rs = _ROT[4:] if g & 1 else _ROT[:4]
+        for r in rs:
+            x0 = (x0 + x1) & _M
+            x1 = ((x1 << r) | (x1 >> (32 - r))) & _M
+            x1 ^= x0
+        x0 = (x0 + ks[(g + 1) % 3]) & _M
+        x1 = (x1 + ks[(g + 2) % 3] + g + 1) & _M
+    return x0, x1
+
+
+Key = tuple  # (uint32, uint32)
+
+
+def key(seed: int) -> Key:
+    seed = int(seed)
+    return ((seed >> 32) & _M, seed & _M)
+
+
+def fold_in(k: Key, data: int) -> Key:
+    data = int(data)
+    return threefry2x32(k[0], k[1], (data >> 32) & _M, data & _M)
+
+
+def split(k: Key, num: int = 2) -> list[Key]:
+    return [fold_in(k, i) for i in range(num)]
+
+
+# ---------------------------------------------------------------------------------------------
+# Selection
+# ---------------------------------------------------------------------------------------------
+class Selection:
+    """Set of addresses (choice_map.py:124-361): ``S["x"] | S["y"]``, ``~sel``, ``Selection.all()``."""
+
+    def __init__(self, addrs: Iterable[str] = (), complement: bool = False):
+        self.addrs = frozenset(addrs)
+        self.complement = bool(complement)
+
+    @staticmethod
+    def all() -> "Selection":
+        return Selection((), True)
+
+    @staticmethod
+    def none() -> "Selection":
+        return Selection((), False)
+
+    class _At:
+        def __getitem__(self, addr) -> "Selection":
+            if isinstance(addr, tuple):
+                addr = addr[0] if len(addr) == 1 else addr
+            return Selection((addr,))
+
+    at = _At()
+
+    def check(self, addr=None) -> bool:
+        return (addr in self.addrs) != self.complement
+
+    def __contains__(self, addr) -> bool:
+        return self.check(addr)
+
+    def __call__(self, addr) -> bool:
+        return self.check(addr)
+
+    def __invert__(self) -> "Selection":
+        return Selection(self.addrs, not self.complement)
+
+    def __or__(self, other: "Selection") -> "Selection":
+        if not self.complement and not other.complement:
+            return Selection(self.addrs | other.addrs)
+        if self.complement and other.complement:
+            return Selection(self.addrs & other.addrs, True)
+        c, p = (self, other) if self.complement else (other, self)
+        return Selection(c.addrs - p.addrs, True)
+
+    def __and__(self, other: "Selection") -> "Selection":
+        return ~((~self) | (~other))
+
+    def __repr__(self) -> str:
+        return ("~" if self.complement else "") + "S" + repr(sorted(map(str, self.addrs)))
+
+
+class _SelectionBuilder:
+    def __getitem__(self, addr) -> Selection:
+        return Selection.at[addr]
+
+
+SelectionBuilder = S = _SelectionBuilder()
+
+
+# ---------------------------------------------------------------------------------------------
+# ChoiceMap
+# ---------------------------------------------------------------------------------------------
+class ChoiceMapNoValueAtAddress(KeyError):
+    """choice_map.py:672"""
+
+
+_VALUE = ()  # address of a bare value (C.v(x)), as in the reference's `()` address
+
+
+class ChoiceMap:
+    """Static-address choice map: ``{addr: value}`` (choice_map.py:847-1395, Static 1535)."""
+
+    def __init__(self, entries: dict | None = None):
+        self._d: dict = dict(entries or {})
+
+    # -- builders (ChoiceMapBuilder C) ------------------------------------------------------
+    @staticmethod
+    def empty() -> "ChoiceMap":
+        return ChoiceMap()
+
+    n = empty
+
+    @staticmethod
+    def kw(**kwargs) -> "ChoiceMap":
+        return ChoiceMap(kwargs)
+
+    @staticmethod
+    def d(entries: dict) -> "ChoiceMap":
+        return ChoiceMap(entries)
+
+    @staticmethod
+    def v(value) -> "ChoiceMap":
+        return ChoiceMap({_VALUE: value})
+
+    choice = v
+
+    class _AtSetter:
+        def __init__(self, base: "ChoiceMap", addr):
+            self.base, self.addr = base, addr
+
+        def set(self, value) -> "ChoiceMap":
+            d = dict(self.base._d)
+            d[self.addr] = value.get_value() if isinstance(value, ChoiceMap) and value.has_value() else value
+            return ChoiceMap(d)
+
+    class _At:
+        def __init__(self, base: "ChoiceMap"):
+            self.base = base
+
+        def __getitem__(self, addr) -> "ChoiceMap._AtSetter":
+            if isinstance(addr, tuple) and len(addr) == 1:
+                addr = addr[0]
+            return ChoiceMap._AtSetter(self.base, addr)
+
+    @property
+    def at(self) -> "ChoiceMap._At":
+        return ChoiceMap._At(self)
+
+    # -- queries ------------------------------------------------------------------------------
+    def has_value(self) -> bool:
+        return _VALUE in self._d
+
+    def get_value(self):
+        return self._d.get(_VALUE)
+
+    def static_is_empty(self) -> bool:
+        return not self._d
+
+    def __contains__(self, addr) -> bool:
+        return addr in self._d
+
+    def __getitem__(self, addr):
+        if addr not in self._d:
+            raise ChoiceMapNoValueAtAddress(addr)
+        return self._d[addr]
+
+    def get(self, addr, default=None):
+        return self._d.get(addr, default)
+
+    def __call__(self, addr):
+        return self.get_submap(addr)
+
+    def get_submap(self, addr) -> "ChoiceMap":
+        return ChoiceMap.v(self._d[addr]) if addr in self._d else ChoiceMap()
+
+    def addresses(self) -> list:
+        return [a for a in self._d if a != _VALUE]
+
+    def items(self):
+        return [(a, v) for a, v in self._d.items() if a != _VALUE]
+
+    def __len__(self) -> int:
+        return len(self._d)
+
+    # -- algebra ------------------------------------------------------------------------------
+    def merge(self, other: "ChoiceMap") -> "ChoiceMap":
+        """``self | other`` — left-biased union (choice_map.py:1227-1251)."""
+        d = dict(other._d)
+        d.update(self._d)
+        return ChoiceMap(d)
+
+    __or__ = merge
+
+    def filter(self, selection: Selection) -> "ChoiceMap":
+        return ChoiceMap({a: v for a, v in self._d.items() if selection.check(a)})
+
+    def get_selection(self) -> Selection:
+        return Selection(self._d.keys())
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, ChoiceMap) or set(self._d) != set(other._d):
+            return False
+        return all(np.array_equal(_np(self._d[a]), _np(other._d[a])) for a in self._d)
+
+    def __repr__(self) -> str:
+        return "ChoiceMap(" + ", ".join(f"{a!r}: {_short(v)}" for a, v in self._d.items()) + ")"
+
+
+def _np(v) -> np.ndarray:
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _short(v: Any) -> str:
+    a = _np(v)
+    return repr(a.item()) if a.ndim == 0 else f"array{a.shape}"
+
+
+class _ChoiceMapBuilder:
+    """``C["y"].set(v)``, ``C.kw(y=3.0)``, ``C.d({...})``, ``C.v(x)``, ``C.n()`` (choice_map.py builders)."""
+
+    def __getitem__(self, addr):
+        return ChoiceMap().at[addr]
+
+    kw = staticmethod(ChoiceMap.kw)
+    d = staticmethod(ChoiceMap.d)
+    v = staticmethod(ChoiceMap.v)
+    n = staticmethod(ChoiceMap.empty)
+    choice = staticmethod(ChoiceMap.v)
+
+
+ChoiceMapBuilder = C = _ChoiceMapBuilder()

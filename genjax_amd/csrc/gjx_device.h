@@ -47,26 +47,41 @@ GJX_DEV key2 threefry2x32(key2 k, uint32_t c0, uint32_t c1) {
 GJX_DEV key2 fold_in(key2 k, uint32_t i) { return threefry2x32(k, 0u, i); }
 GJX_DEV key2 fold_in64(key2 k, uint64_t i) { return threefry2x32(k, (uint32_t)(i >> 32), (uint32_t)i); }
 
-// Sequential element-bit source for one site key.  PACKED: element c = word (c&1) of hash (c>>1);
-// JAX32: element c = x0^x1 of hash c.  get(c) may be called with any c; consecutive c reuse the
-// cached hash in PACKED mode.
+// Element-bit source for one (particle, site) stream; layouts documented at GJX_RNG_* in gjx.h.
 template <int RNG>
-struct BitStream {
-  key2 sk;
-  key2 cache;
-  uint32_t cached_h;
-  GJX_DEV explicit BitStream(key2 k) : sk(k), cache{0u, 0u}, cached_h(0xFFFFFFFFu) {}
+struct BitStream;
+
+template <>
+struct BitStream<GJX_RNG_FLAT> {
+  key2 key, cache;
+  uint32_t c0, site_hi, cached;
+  GJX_DEV BitStream() : key{0u, 0u}, cache{0u, 0u}, c0(0u), site_hi(0u), cached(0xFFFFFFFFu) {}
+  GJX_DEV void open(key2 run_key, uint64_t idx, uint32_t site) {
+    key = (idx >> 32) ? threefry2x32(run_key, 0xFFFFFFFFu, (uint32_t)(idx >> 32)) : run_key;
+    c0 = (uint32_t)idx;
+    site_hi = site << GJX_FLAT_SITE_SHIFT;
+    cached = 0xFFFFFFFFu;
+  }
+  GJX_DEV void open_site_key(key2) {}
   GJX_DEV uint32_t get(uint32_t c) {
-    if (RNG == GJX_RNG_JAX32) {
-      key2 h = threefry2x32(sk, 0u, c);
-      return h.a ^ h.b;
-    }
-    const uint32_t hidx = c >> 1;
-    if (hidx != cached_h) {
-      cache = threefry2x32(sk, 0u, hidx);
-      cached_h = hidx;
+    const uint32_t pair = c >> 1;
+    if (pair != cached) {
+      cache = threefry2x32(key, c0, site_hi | pair);
+      cached = pair;
     }
     return (c & 1u) ? cache.b : cache.a;
+  }
+};
+
+template <>
+struct BitStream<GJX_RNG_JAX32> {
+  key2 sk;
+  GJX_DEV BitStream() : sk{0u, 0u} {}
+  GJX_DEV void open(key2 run_key, uint64_t idx, uint32_t site) { sk = fold_in(fold_in64(run_key, idx), site); }
+  GJX_DEV void open_site_key(key2 k) { sk = k; }
+  GJX_DEV uint32_t get(uint32_t c) {
+    const key2 h = threefry2x32(sk, 0u, c);
+    return h.a ^ h.b;
   }
 };
 
@@ -137,6 +152,41 @@ GJX_DEV float erfinv_f32(float x) {
     p = fmaf(p, w, 2.83297682f);
   }
   return p * x;
+}
+
+// Hot-path variant of normal_from_bits: same Giles polynomial with sqrt(2) and ln(2) folded into
+// the constants, (bits >> 9) | 0x3F800000 as one v_alignbit_b32, and the redundant max() dropped
+// (f*2 is exact and rounding is monotone, so f*2 + lo >= lo).  Differs from normal_from_bits by
+// float rounding only.
+GJX_DEV float normal_from_bits_fast(uint32_t bits) {
+  const float f = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, bits, 9)) - 1.0f;
+  const float u = fmaf(f, 2.0f, kNeg1PlusUlp);
+  const float L = __builtin_amdgcn_logf(fmaf(-u, u, 1.0f));
+  float w = fmaf(L, -kLn2, -2.5f);  // (-ln(1-u^2)) - 2.5
+  float p;
+  if (w < 2.5f) {
+    p = 3.9742602098158386e-08f;
+    p = fmaf(p, w, 4.854626354244829e-07f);
+    p = fmaf(p, w, -4.982822702004341e-06f);
+    p = fmaf(p, w, -6.2105282268021256e-06f);
+    p = fmaf(p, w, 0.0003091200196649879f);
+    p = fmaf(p, w, -0.0017730349209159613f);
+    p = fmaf(p, w, -0.005908133927732706f);
+    p = fmaf(p, w, 0.3488026559352875f);
+    p = fmaf(p, w, 2.1233136653900146f);
+  } else {
+    w = fast_sqrt(w + 2.5f) - 3.0f;
+    p = -0.0002831457240972668f;
+    p = fmaf(p, w, 0.00014276565343607217f);
+    p = fmaf(p, w, 0.001908259466290474f);
+    p = fmaf(p, w, -0.00519501231610775f);
+    p = fmaf(p, w, 0.008116889744997025f);
+    p = fmaf(p, w, -0.01077978778630495f);
+    p = fmaf(p, w, 0.013348578475415707f);
+    p = fmaf(p, w, 1.4165810346603394f);
+    p = fmaf(p, w, 4.006434440612793f);
+  }
+  return p * u;
 }
 
 GJX_DEV float normal_from_bits(uint32_t bits) {

@@ -234,7 +234,7 @@ extern "C" int gjx_categorical_pick(const float* logw, int64_t K, int64_t partic
   if (rng_mode == GJX_RNG_JAX32)
     hipLaunchKernelGGL(k_pick_partial<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, logw, K, particle_offset, lse, key2{key0, key1}, partials);
   else
-    hipLaunchKernelGGL(k_pick_partial<GJX_RNG_PACKED>, dim3(nblocks), dim3(256), 0, st, logw, K, particle_offset, lse, key2{key0, key1}, partials);
+    hipLaunchKernelGGL(k_pick_partial<GJX_RNG_FLAT>, dim3(nblocks), dim3(256), 0, st, logw, K, particle_offset, lse, key2{key0, key1}, partials);
   GJX_CHECK_LAUNCH("gjx_categorical_pick/partial");
   hipLaunchKernelGGL(k_pick_finish, dim3(1), dim3(256), 0, st, (const PickPair*)partials, nblocks, (PickPair*)out_dev);
   GJX_CHECK_LAUNCH("gjx_categorical_pick/finish");

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.K;
   const int64_t ii = active ? i : a.K - 1;  // inactive lanes shadow the last particle (no stores)
-  const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
+  const uint64_t gidx = (uint64_t)(a.offset + ii);
   const float* __restrict__ tab = a.tab;
   float* ch = a.choices;
   const int64_t K = a.K;
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   for (int j = 0; j < a.n_sites; ++j) {
     const gjx_site& s = a.sites[j];
     const int kind = s.kind, mode = s.mode, slot = s.slot;
-    BitStream<RNG> bs(mode == GJX_MODE_SAMPLE ? fold_in(pk, (uint32_t)(j + 1)) : key2{0u, 0u});
+    BitStream<RNG> bs;
+    if (mode == GJX_MODE_SAMPLE) bs.open(a.key, gidx, (uint32_t)(j + 1));
     float lp = 0.0f;
     if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
       const int n = s.ncat;
@@ -162,7 +163,13 @@ struct VecStore<4> {
   }
 };
 
-// Each lane owns PPT consecutive particles; ALIGNED: K % PPT == 0 (row bases stay PPT*4-byte aligned)
+// Each lane owns PPT consecutive particles (so every SoA row is written with PPT*4-byte stores);
+// a block walks tiles of THREADS*PPT particles.  K % PPT == 0 is required by the launcher when PPT > 1.
+//
+// VALU budget (measured on MI355X, cycles per wave-instruction): v_add_u32 / v_xor_b32 / fp32
+// add,mul,fma = 2; v_alignbit_b32 and every other VOP3 integer op = 4; v_log/v_exp/v_rcp/v_sqrt = 8.
+// One Threefry hash is therefore ~190 cycles per wave and yields two draws; a normal costs ~50 more.
+// The kernel is bound by that integer work, not by HBM — DESIGN.md §roofline.
 template <int RNG, int D, int PPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
   constexpr int DS = D + 4;  // padded LDS row stride: rows of different z land on different 16-B slots
@@ -170,27 +177,28 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
   const int C = a.C;
   float* s_mu = smem;                 // [C][DS]
   float* s_sig = s_mu + C * DS;       // [C][DS]
-  float* s_rsig = s_sig + C * DS;     // [C][DS]   1/sigma
-  float* s_logit = s_rsig + C * DS;   // [C] raw logits
-  float* s_zlp = s_logit + C;         // [C] log_softmax(logits)[c] - sum_d log sigma[c][d] - D*0.5*log(2pi)
-  float* s_zonly = s_zlp + C;         // [C] log_softmax(logits)[c]
-  float* s_y = s_zonly + C;           // [D]
+  float* s_logit = s_sig + C * DS;    // [C] raw logits
+  float* s_race = s_logit + C;        // [C] ln2 * exp(-logit): exponential-race rate^-1
+  float* s_zlp = s_race + C;          // [C] log_softmax(logits)[c] - sum_d log sigma[c][d] - D*0.5*log(2pi)
+  float* s_y = s_zlp + C;             // [D]
   float* s_rr = s_y + D;              // [D] 1/r
   float* s_misc = s_rr + D;           // [0]: -sum_d log r_d - D*0.5*log(2pi);  [8..]: reduction scratch
   const float* __restrict__ tab = a.tab;
 
   for (int t = threadIdx.x; t < C * D; t += THREADS) {
     const int c = t / D, d = t % D;
-    const float sg = tab[a.sig_off + t];
     s_mu[c * DS + d] = tab[a.mu_off + t];
-    s_sig[c * DS + d] = sg;
-    s_rsig[c * DS + d] = fast_rcp(sg);
+    s_sig[c * DS + d] = tab[a.sig_off + t];
   }
   for (int t = threadIdx.x; t < D; t += THREADS) {
     s_y[t] = tab[a.y_off + t];
     s_rr[t] = fast_rcp(tab[a.r_off + (a.r_len == 1 ? 0 : t)]);
   }
-  for (int t = threadIdx.x; t < C; t += THREADS) s_logit[t] = tab[a.logits_off + t];
+  for (int t = threadIdx.x; t < C; t += THREADS) {
+    const float l = tab[a.logits_off + t];
+    s_logit[t] = l;
+    s_race[t] = kLn2 * fast_exp(-l);
+  }
   __syncthreads();
   if (threadIdx.x < 64) {  // wave 0: log-softmax and per-component constants
     float mx = -INFINITY;
@@ -203,9 +211,7 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
     for (int c = threadIdx.x; c < C; c += 64) {
       float sl = 0.0f;
       for (int d = 0; d < D; ++d) sl += fast_log(s_sig[c * DS + d]);
-      const float zl = s_logit[c] - lse;
-      s_zonly[c] = zl;
-      s_zlp[c] = zl - sl - (float)D * kHalfLog2Pi;
+      s_zlp[c] = (s_logit[c] - lse) - sl - (float)D * kHalfLog2Pi;
     }
     if (threadIdx.x == 0) {
       float sl = 0.0f;
@@ -218,42 +224,53 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
   const int64_t K = a.K;
   const int64_t tile = (int64_t)THREADS * PPT;
   const int64_t ntiles = (K + tile - 1) / tile;
+  const uint64_t goff = (uint64_t)a.offset;
+  // FLAT: the launcher guarantees that all particles of this launch share the high index word
+  const key2 fkey = (RNG == GJX_RNG_FLAT && (goff >> 32)) ? threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(goff >> 32)) : a.key;
   float tmax = -INFINITY;   // running per-thread max / sum for the block's LSE partial
   float tsum = 0.0f;
   for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;
-    key2 sk1[PPT], sk2[PPT];
     bool act[PPT];
+    uint32_t c0[PPT];          // FLAT: low word of the global particle index
+    key2 sk1[PPT], sk2[PPT];   // JAX32: site keys
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
       act[p] = (i0 + p) < K;
-      const int64_t ii = act[p] ? i0 + p : K - 1;
-      const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
-      sk1[p] = fold_in(pk, 1u);
-      sk2[p] = fold_in(pk, 2u);
+      const uint64_t gi = goff + (uint64_t)(act[p] ? i0 + p : K - 1);
+      c0[p] = (uint32_t)gi;
+      if (RNG == GJX_RNG_JAX32) {
+        const key2 pk = fold_in64(a.key, gi);
+        sk1[p] = fold_in(pk, 1u);
+        sk2[p] = fold_in(pk, 2u);
+      }
     }
-    // ---- z ~ categorical(logits): Gumbel-max ----
+    // ---- z ~ categorical(logits).  Gumbel-max argmax_c (l_c - log(-log u_c)) evaluated as the
+    //      equivalent exponential race argmin_c (-log u_c) * exp(-l_c): one log per category. ----
     int z[PPT];
     float zf[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
-      float bestv = -INFINITY;
+      float bestv = INFINITY;
       int best = 0;
-      if (RNG == GJX_RNG_JAX32) {
-        for (int c = 0; c < C; ++c) {
-          const key2 h = threefry2x32(sk1[p], 0u, (uint32_t)c);
-          const float g = s_logit[c] + gumbel_from_bits(h.a ^ h.b);
-          if (g > bestv) { bestv = g; best = c; }
+      for (int c = 0; c < C; c += 2) {
+        uint32_t b0, b1 = 0u;
+        if (RNG == GJX_RNG_JAX32) {
+          const key2 h0 = threefry2x32(sk1[p], 0u, (uint32_t)c);
+          b0 = h0.a ^ h0.b;
+          if (c + 1 < C) { const key2 h1 = threefry2x32(sk1[p], 0u, (uint32_t)(c + 1)); b1 = h1.a ^ h1.b; }
+        } else {
+          const key2 h = threefry2x32(fkey, c0[p], (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(c >> 1));
+          b0 = h.a; b1 = h.b;
         }
-      } else {
-        for (int c = 0; c < C; c += 2) {
-          const key2 h = threefry2x32(sk1[p], 0u, (uint32_t)(c >> 1));
-          const float g0 = s_logit[c] + gumbel_from_bits(h.a);
-          if (g0 > bestv) { bestv = g0; best = c; }
-          if (c + 1 < C) {
-            const float g1 = s_logit[c + 1] + gumbel_from_bits(h.b);
-            if (g1 > bestv) { bestv = g1; best = c + 1; }
-          }
+        // u = uniform(tiny, 1) = f + tiny (f*(1-tiny) == f in fp32; max(tiny, .) is a no-op)
+        const float u0 = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, b0, 9)) - 1.0f) + kTiny;
+        const float e0 = -__builtin_amdgcn_logf(u0) * s_race[c];
+        if (e0 < bestv) { bestv = e0; best = c; }
+        if (c + 1 < C) {
+          const float u1 = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, b1, 9)) - 1.0f) + kTiny;
+          const float e1 = -__builtin_amdgcn_logf(u1) * s_race[c + 1];
+          if (e1 < bestv) { bestv = e1; best = c + 1; }
         }
       }
       z[p] = best;
@@ -275,30 +292,28 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
       float xa[PPT], xb[PPT];
 #pragma unroll
       for (int p = 0; p < PPT; ++p) {
-        uint32_t b0, b1;
+        uint32_t b0, b1 = 0u;
         if (RNG == GJX_RNG_JAX32) {
           const key2 h0 = threefry2x32(sk2[p], 0u, (uint32_t)d0);
           b0 = h0.a ^ h0.b;
-          if (d0 + 1 < D) { const key2 h1 = threefry2x32(sk2[p], 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; } else b1 = 0u;
+          if (d0 + 1 < D) { const key2 h1 = threefry2x32(sk2[p], 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; }
         } else {
-          const key2 h = threefry2x32(sk2[p], 0u, (uint32_t)(d0 >> 1));
+          const key2 h = threefry2x32(fkey, c0[p], (2u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(d0 >> 1));
           b0 = h.a; b1 = h.b;
         }
-        const int zo = z[p] * DS;
+        const int zo = z[p] * DS + d0;
         {
-          const float mu = s_mu[zo + d0], sg = s_sig[zo + d0], rs = s_rsig[zo + d0];
-          const float x = fmaf(sg, normal_from_bits(b0), mu);
-          const float zx = (x - mu) * rs;
-          qx[p] = fmaf(zx, zx, qx[p]);
+          const float n = normal_from_bits_fast(b0);
+          const float x = fmaf(s_sig[zo], n, s_mu[zo]);
+          qx[p] = fmaf(n, n, qx[p]);  // ((x - mu)/sigma)^2 up to rounding
           const float zy = (s_y[d0] - x) * s_rr[d0];
           qy[p] = fmaf(zy, zy, qy[p]);
           xa[p] = x;
         }
         if (d0 + 1 < D) {
-          const float mu = s_mu[zo + d0 + 1], sg = s_sig[zo + d0 + 1], rs = s_rsig[zo + d0 + 1];
-          const float x = fmaf(sg, normal_from_bits(b1), mu);
-          const float zx = (x - mu) * rs;
-          qx[p] = fmaf(zx, zx, qx[p]);
+          const float n = normal_from_bits_fast(b1);
+          const float x = fmaf(s_sig[zo + 1], n, s_mu[zo + 1]);
+          qx[p] = fmaf(n, n, qx[p]);
           const float zy = (s_y[d0 + 1] - x) * s_rr[d0 + 1];
           qy[p] = fmaf(zy, zy, qy[p]);
           xb[p] = x;
@@ -507,6 +522,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   if (K == 0) return GJX_OK;
   if (prog->n_slots > 0 && !choices) return gjx_fail(GJX_EINVAL, "gjx_run_program: choices is null");
   if (lse && !logw) return gjx_fail(GJX_EINVAL, "gjx_run_program: lse needs logw");
+  if (prog->rng_mode == GJX_RNG_FLAT && prog->n_sites > GJX_FLAT_MAX_SITES) return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: FLAT stream supports at most 1023 sites");
   hipStream_t st = (hipStream_t)stream;
   float2* partials = nullptr;
   if (lse) {
@@ -515,7 +531,8 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   }
   int nblocks;
   GmmShape g;
-  const bool fused = !site_scores && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g);
+  const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
+  const bool fused = !site_scores && same_hi && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g);
   if (fused) {
     int ppt = env_int("GJX_GMM_PPT", 4);
     if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
@@ -531,9 +548,9 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.partials = partials;
-    const size_t lds = sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 3 * g.C + 2 * g.D + 8 + 16);
+    const size_t lds = sizeof(float) * (size_t)(2 * g.C * (g.D + 4) + 3 * g.C + 2 * g.D + 8 + 16);
     if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
-    else launch_gmm<GJX_RNG_PACKED>(a, g.D, ppt, nblocks, lds, st);
+    else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
   } else {
     nblocks = (int)((K + 255) / 256);
     RunArgs a;
@@ -542,7 +559,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials;
     if (prog->rng_mode == GJX_RNG_JAX32) hipLaunchKernelGGL(k_run_generic<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_run_generic<GJX_RNG_PACKED>, dim3(nblocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_run_generic<GJX_RNG_FLAT>, dim3(nblocks), dim3(256), 0, st, a);
   }
   GJX_CHECK_LAUNCH("gjx_run_program");
   if (lse) {

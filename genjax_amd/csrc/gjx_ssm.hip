@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.K;
   const int64_t ii = active ? i : a.K - 1;
-  const key2 pk = fold_in64(a.key, (uint64_t)(a.offset + ii));
-  const key2 sk = fold_in(pk, 1u);
+  const uint64_t gidx = (uint64_t)(a.offset + ii);
+  key2 sk = a.key;  // JAX32: site key; FLAT: run key (high index word folded in when needed)
+  if (RNG == GJX_RNG_JAX32) sk = fold_in(fold_in64(a.key, gidx), 1u);
+  else if (gidx >> 32) sk = threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
   float xn[DX];
   if (a.t > 0) {
     const int64_t src = a.anc ? (int64_t)a.anc[ii] : ii;
@@ -59,11 +61,11 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
       b0 = h0.a ^ h0.b;
       if (d0 + 1 < DX) { const key2 h1 = threefry2x32(sk, 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; }
     } else {
-      const key2 h = threefry2x32(sk, 0u, (uint32_t)(d0 >> 1));
+      const key2 h = threefry2x32(sk, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(d0 >> 1));
       b0 = h.a; b1 = h.b;
     }
-    xn[d0] = fmaf(sd, normal_from_bits(b0), xn[d0]);
-    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, normal_from_bits(b1), xn[d0 + 1]);
+    xn[d0] = fmaf(sd, normal_from_bits_fast(b0), xn[d0]);
+    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, normal_from_bits_fast(b1), xn[d0 + 1]);
   }
   if (active) {
 #pragma unroll
@@ -133,7 +135,7 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials;
   const int nblocks = (int)((K + 255) / 256);
   const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
-                                           : launch_ssm<GJX_RNG_PACKED>(a, m->dx, nblocks, st);
+                                           : launch_ssm<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
   if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step: dx must be one of 1,2,4,8,16,32");
   GJX_CHECK_LAUNCH("gjx_ssm_step");
   if (lse) {

@@ -1,0 +1,653 @@
+"""``@gen`` modelling language, primitive distributions and traces — host side.
+
+The reference stages a Python function to a Jaxpr and re-interprets it for every GFI method
+(generative_functions/static.py:725-1049).  Here the function body is run ONCE per argument tuple
+with symbolic values; every ``dist(*params) @ "addr"`` appends a site to a SiteList
+(program.py) and the GFI methods become launches of the HIP site interpreter / fused kernels
+with per-site modes:
+
+    simulate   all sites SAMPLE                                   static.py:254-278, 787-793
+    assess     all sites constrained, MissingAddress otherwise    static.py:297-321, 983-989
+    generate / importance   constrained sites OBS, rest SAMPLE    static.py:340-399, 795-810
+    update     all sites keep/replace their value, w = new - old  static.py:827-865
+
+Batched execution (the reference's ``jax.vmap`` over particles or chains) is the native mode: a
+Trace holds choices[n_slots][K] on the device; K == 1 is the un-vmapped case.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import _abi as A
+from .core import ChoiceMap, Key, Selection, _VALUE, fold_in, split
+from .program import AddressReuse, MissingAddress, PackedProgram, Param, SiteList
+
+__all__ = [
+    "gen", "StaticGenerativeFunction", "Trace", "Distribution", "take", "where", "cond", "const", "exp",
+    "softplus", "sigmoid", "normal", "flip", "bernoulli", "beta", "categorical", "uniform", "mv_normal_diag",
+    "exponential", "half_normal", "laplace", "log_normal", "cauchy", "gamma", "Marginal",
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# symbolic values seen by the model body while it is traced
+# ---------------------------------------------------------------------------------------------
+class NotSupportedInModelBody(TypeError):
+    """The model body computed something the parameter-expression forms cannot express."""
+
+
+class Sym:
+    __array_ufunc__ = None  # numpy binary operators defer to our reflected methods
+    __array_priority__ = 1000
+
+    def as_param(self) -> Param:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    # arithmetic is defined on Affine; everything else lifts itself first
+    def _affine(self) -> "Affine":
+        raise NotSupportedInModelBody(f"arithmetic on {type(self).__name__} is not supported in a model body")
+
+    def __add__(self, o): return self._affine().add(o)
+    def __radd__(self, o): return self._affine().add(o)
+    def __sub__(self, o): return self._affine().add(_neg(o))
+    def __rsub__(self, o): return self._affine().scale(-1.0).add(o)
+    def __mul__(self, o): return self._affine().mul(o)
+    def __rmul__(self, o): return self._affine().mul(o)
+    def __truediv__(self, o): return self._affine().mul(1.0 / np.asarray(o, np.float64))
+    def __neg__(self): return self._affine().scale(-1.0)
+    def __rmatmul__(self, o): return self._affine().lmatmul(o)
+
+
+def _neg(o):
+    return -o if isinstance(o, Sym) else -np.asarray(o, np.float64)
+
+
+class HostExpr(Sym):
+    """An expression of several choices: fine as a RETURN value (evaluated from the trace on demand),
+    not expressible as a distribution parameter."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def as_param(self):
+        raise NotSupportedInModelBody("a distribution parameter may depend on ONE earlier site (plus constants)")
+
+    def _bin(self, o, op):
+        return HostExpr(lambda ev: op(ev(self), ev(o) if isinstance(o, Sym) else o))
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    __radd__ = __add__
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    __rmul__ = __mul__
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    def __neg__(self): return HostExpr(lambda ev: -ev(self))
+
+
+class Affine(Sym):
+    """``M @ value(src) + b`` with M over ALL elements of the source site; optional outer transform."""
+
+    def __init__(self, src: "SiteVal", M: np.ndarray, b: np.ndarray, xf: int = A.XF_NONE):
+        self.src, self.M, self.b, self.xf = src, np.atleast_2d(np.asarray(M, np.float64)), np.atleast_1d(np.asarray(b, np.float64)), xf
+        self.dim = self.M.shape[0]
+
+    def _affine(self):
+        if self.xf != A.XF_NONE:
+            raise NotSupportedInModelBody("arithmetic after exp/softplus/sigmoid is not supported")
+        return self
+
+    def _bcast(self, m: int) -> "Affine":
+        if self.dim == m:
+            return self
+        if self.dim != 1:
+            raise NotSupportedInModelBody(f"cannot broadcast a length-{self.dim} expression to {m}")
+        return Affine(self.src, np.repeat(self.M, m, 0), np.repeat(self.b, m))
+
+    def add(self, o):
+        if isinstance(o, Sym):
+            o = o._affine()
+            if o.src is not self.src:
+                a0, o0 = self, o
+                return HostExpr(lambda ev: ev(a0) + ev(o0))
+            m = max(self.dim, o.dim)
+            a, c = self._bcast(m), o._bcast(m)
+            return Affine(self.src, a.M + c.M, a.b + c.b)
+        o = np.atleast_1d(np.asarray(o, np.float64)).ravel()
+        a = self._bcast(max(self.dim, o.size))
+        return Affine(self.src, a.M, a.b + o)
+
+    def scale(self, s: float):
+        return Affine(self.src, self.M * s, self.b * s)
+
+    def mul(self, o):
+        if isinstance(o, Sym):
+            a0 = self
+            return HostExpr(lambda ev: ev(a0) * ev(o))
+        o = np.atleast_1d(np.asarray(o, np.float64)).ravel()
+        a = self._bcast(max(self.dim, o.size))
+        return Affine(self.src, a.M * o[:, None], a.b * o)
+
+    def lmatmul(self, o):
+        o = np.atleast_2d(np.asarray(o, np.float64))
+        return Affine(self.src, o @ self.M, o @ self.b)
+
+    def with_xf(self, xf: int) -> "Affine":
+        self._affine()
+        return Affine(self.src, self.M, self.b, xf)
+
+    def __getitem__(self, i):
+        self._affine()
+        return Affine(self.src, self.M[i], self.b[i])
+
+    def as_param(self) -> Param:
+        M, b = self.M, self.b
+        n = self.src.dim
+        # identity on a prefix (or a single broadcast element) is a plain VALUE read
+        if not b.any():
+            if M.shape == (n, n) and np.array_equal(M, np.eye(n)):
+                return Param.value(self.src.addr, length=n, xf=self.xf)
+            nz = np.nonzero(M.any(axis=0))[0]
+            if M.shape[0] == 1 and nz.size == 1 and M[0, nz[0]] == 1.0:
+                return Param.value(self.src.addr, length=1, elem=int(nz[0]), xf=self.xf)
+        nz = np.nonzero(M.any(axis=0))[0]
+        c0, c1 = (int(nz[0]), int(nz[-1]) + 1) if nz.size else (0, 1)
+        return Param.affine(M[:, c0:c1], self.src.addr, bias=b, elem=c0, xf=self.xf)
+
+
+class SiteVal(Sym):
+    """The value of a traced site (what ``dist(...) @ addr`` returns inside a model body)."""
+
+    def __init__(self, addr, dim: int, kind: int):
+        self.addr, self.dim, self.kind = addr, dim, kind
+
+    def _affine(self) -> Affine:
+        if self.kind in A.DISCRETE_KINDS and self.kind not in (A.FLIP, A.BERNOULLI_LOGITS):
+            raise NotSupportedInModelBody("arithmetic on a categorical index; use take(table, idx)")
+        return Affine(self, np.eye(self.dim), np.zeros(self.dim))
+
+    def __getitem__(self, i):
+        return self._affine()[i]
+
+    def as_param(self) -> Param:
+        return Param.value(self.addr, length=self.dim)
+
+    def __repr__(self):
+        return f"<choice {self.addr!r}>"
+
+
+class Gather(Sym):
+    def __init__(self, table: np.ndarray, idx: SiteVal, xf: int = A.XF_NONE):
+        t = np.asarray(table, np.float32)
+        self.table, self.idx, self.xf = (t[:, None] if t.ndim == 1 else t.reshape(t.shape[0], -1)), idx, xf
+        self.dim = self.table.shape[1]
+
+    def as_param(self) -> Param:
+        return Param.gather(self.table, self.idx.addr, xf=self.xf)
+
+
+class const:
+    """Wrap a constant table so that it can be indexed by a random choice: ``const(means)[idx]``."""
+
+    def __init__(self, table):
+        self.table = np.asarray(table, np.float32)
+
+    def __getitem__(self, idx):
+        return take(self.table, idx) if isinstance(idx, Sym) else self.table[idx]
+
+
+def take(table, idx) -> Gather:
+    """``table[idx]`` for a categorical / boolean choice ``idx`` (rows of a constant table)."""
+    if not isinstance(idx, SiteVal):
+        raise NotSupportedInModelBody("take(table, idx): idx must be a random choice")
+    return Gather(np.asarray(table, np.float32), idx)
+
+
+def where(flag, if_true, if_false) -> Gather:
+    """``jnp.where(flag, a, b)`` / ``jax.lax.cond(flag, lambda: a, lambda: b)`` on constants."""
+    a, b = np.atleast_1d(np.asarray(if_true, np.float32)), np.atleast_1d(np.asarray(if_false, np.float32))
+    return take(np.stack([np.broadcast_to(b, np.broadcast(a, b).shape), np.broadcast_to(a, np.broadcast(a, b).shape)]), flag)
+
+
+def cond(flag, true_fn, false_fn) -> Gather:
+    t = true_fn() if callable(true_fn) else true_fn
+    f = false_fn() if callable(false_fn) else false_fn
+    return where(flag, t, f)
+
+
+def _xf(x, code: int, fn: Callable):
+    if isinstance(x, Gather):
+        if x.xf != A.XF_NONE:
+            raise NotSupportedInModelBody("nested transforms")
+        return Gather(x.table, x.idx, code)
+    if isinstance(x, Sym):
+        return x._affine().with_xf(code)
+    return fn(np.asarray(x, np.float64))
+
+
+def exp(x): return _xf(x, A.XF_EXP, np.exp)
+def softplus(x): return _xf(x, A.XF_SOFTPLUS, lambda v: np.logaddexp(0.0, v))
+def sigmoid(x): return _xf(x, A.XF_SIGMOID, lambda v: 1.0 / (1.0 + np.exp(-v)))
+
+
+# ---------------------------------------------------------------------------------------------
+# tracer
+# ---------------------------------------------------------------------------------------------
+class _Tracer:
+    stack: list["_Tracer"] = []
+
+    def __init__(self):
+        self.sites = SiteList()
+
+    def __enter__(self):
+        _Tracer.stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _Tracer.stack.pop()
+
+    @staticmethod
+    def current() -> "_Tracer":
+        if not _Tracer.stack:
+            raise RuntimeError("`dist(...) @ addr` is only meaningful inside a @gen function")
+        return _Tracer.stack[-1]
+
+
+class DistCall:
+    def __init__(self, dist: "Distribution", kind: int, params: list, dim):
+        self.dist, self.kind, self.params, self.dim = dist, kind, params, dim
+
+    def __matmul__(self, addr):
+        site = _Tracer.current().sites.add(addr, self.kind, self.params, self.dim)
+        return SiteVal(addr, site.dim, self.kind)
+
+
+# ---------------------------------------------------------------------------------------------
+# traces
+# ---------------------------------------------------------------------------------------------
+def _to_device_value(kind: int, t):
+    import torch
+    if kind in (A.FLIP, A.BERNOULLI_LOGITS):
+        return t != 0
+    if kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS):
+        return t.to(torch.int32)
+    return t
+
+
+class Trace:
+    """Batched execution record (static.py:80-119 StaticTrace, distribution.py:59-82).
+
+    ``choices`` f32[n_slots][K] and ``score`` f32[K] live on the device; constrained-to-a-shared-value
+    sites (the Target's constraint) are kept once in ``shared``.  ``batched`` False means the trace was
+    produced by an un-vmapped call and accessors drop the particle axis.
+    """
+
+    def __init__(self, gen_fn, args, prog: PackedProgram, choices, score, shared: dict, batched: bool,
+                 retval_sym=None):
+        self.gen_fn, self.args, self.prog = gen_fn, args, prog
+        self.choices, self.score, self.shared, self.batched = choices, score, dict(shared), batched
+        self.retval_sym = retval_sym
+
+    @property
+    def K(self) -> int:
+        return int(self.score.shape[0])
+
+    def get_gen_fn(self): return self.gen_fn
+    def get_args(self): return self.args
+
+    def get_score(self):
+        return self.score if self.batched else self.score[0]
+
+    def _site_value(self, addr):
+        import torch
+        s = self.prog.site_list[addr]
+        slot = self.prog.slot_of[addr]
+        if slot < 0:
+            v = torch.as_tensor(np.asarray(self.shared[addr], np.float32).reshape(-1)[: s.dim].copy(), device=self.score.device)
+            v = v[0] if s.dim == 1 else v
+            if self.batched:
+                v = v.expand(self.K, *v.shape)
+            return _to_device_value(s.kind, v)
+        rows = self.choices[slot:slot + s.dim]                      # [dim][K]
+        v = rows[0] if s.dim == 1 else rows.t()                      # [K] or [K][dim]
+        if not self.batched:
+            v = v[0]
+        return _to_device_value(s.kind, v)
+
+    def get_choices(self) -> ChoiceMap:
+        return ChoiceMap({s.addr: self._site_value(s.addr) for s in self.prog.site_list.sites})
+
+    def get_retval(self):
+        r = self.retval_sym
+        import torch
+
+        def ev(x):
+            if isinstance(x, SiteVal):
+                return self._site_value(x.addr)
+            if isinstance(x, Affine):
+                v = self._site_value(x.src.addr).float()
+                v = v[..., None] if x.src.dim == 1 else v
+                M = torch.as_tensor(x.M, dtype=torch.float32, device=v.device)
+                out = v @ M.t() + torch.as_tensor(x.b, dtype=torch.float32, device=v.device)
+                out = out[..., 0] if x.dim == 1 else out
+                return {A.XF_EXP: torch.exp, A.XF_SOFTPLUS: torch.nn.functional.softplus,
+                        A.XF_SIGMOID: torch.sigmoid}.get(x.xf, lambda t: t)(out)
+            if isinstance(x, Gather):
+                idx = self._site_value(x.idx.addr).long()
+                out = torch.as_tensor(x.table, device=idx.device)[idx]
+                return out[..., 0] if x.dim == 1 else out
+            if isinstance(x, HostExpr):
+                return x.fn(ev)
+            if isinstance(x, (tuple, list)):
+                return type(x)(ev(e) for e in x)
+            return x
+        return ev(r)
+
+    def get_particle(self, idx) -> "Trace":
+        """Row gather of every leaf (smc.py:90-91)."""
+        i = int(idx)
+        return Trace(self.gen_fn, self.args, self.prog, self.choices[:, i:i + 1].contiguous(),
+                     self.score[i:i + 1].contiguous(), self.shared, False, self.retval_sym)
+
+    # -- edits ---------------------------------------------------------------------------------
+    def update(self, key: Key, constraint: ChoiceMap, argdiffs=None):
+        from .inference.requests import Update
+        return Update(constraint).edit(key, self, argdiffs)
+
+    def edit(self, key: Key, request, argdiffs=None):
+        return request.edit(key, self, argdiffs)
+
+    def full_choice_rows(self) -> dict:
+        """addr -> device rows [dim][K] for every site (shared values broadcast)."""
+        import torch
+        out = {}
+        for s in self.prog.site_list.sites:
+            slot = self.prog.slot_of[s.addr]
+            if slot >= 0:
+                out[s.addr] = self.choices[slot:slot + s.dim]
+            else:
+                v = torch.as_tensor(np.broadcast_to(np.asarray(self.shared[s.addr], np.float32).ravel(), (s.dim,)).copy(),
+                                    device=self.score.device)
+                out[s.addr] = v[:, None].expand(s.dim, self.K)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# generative functions
+# ---------------------------------------------------------------------------------------------
+def _value_rows(v, dim: int):
+    """Constraint value -> (np [dim] shared, or torch/np [dim][K] per particle)."""
+    if hasattr(v, "detach"):
+        t = v.float()
+        if t.ndim == 0:
+            return np.asarray([float(t)], np.float32), None
+        if dim == 1 and t.ndim == 1 and t.shape[0] != 1:
+            return None, t[None, :]
+        if dim > 1 and t.ndim == 1:
+            return t.detach().cpu().numpy().astype(np.float32), None
+        if t.ndim == 2:
+            return None, t.t()
+        return t.detach().cpu().numpy().astype(np.float32).ravel(), None
+    a = np.asarray(v, np.float32)
+    if a.ndim == 0:
+        return a.reshape(1), None
+    if a.ndim == 1 and (dim > 1 or a.shape[0] == 1) and a.shape[0] == dim:
+        return a, None
+    if a.ndim == 1:
+        return None, a[None, :]
+    if a.ndim == 2:
+        return None, a.T
+    raise ValueError(f"constraint of shape {a.shape} for a site of dimension {dim}")
+
+
+class GenerativeFunction:
+    """GFI surface (core/generative/generative_function.py:238-689), restated for sited programs."""
+
+    def site_list(self, args) -> tuple[SiteList, Any]:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    # -- program construction -------------------------------------------------------------------
+    def pack(self, args, constraint: ChoiceMap, sample_rest: bool, selected: Sequence = (), rng_mode=None,
+             per_particle: Sequence = ()):
+        """-> (PackedProgram, shared dict, per-particle dict addr -> rows).  Sites in ``constraint`` are
+        OBS_TAB (shared value) or OBS_SLOT (value per particle); sites in ``per_particle`` are OBS_SLOT with
+        rows supplied later; the rest are SAMPLE when ``sample_rest`` else MissingAddress."""
+        from . import config
+        sl, _ = self.site_list(args)
+        modes, shared, pp = {}, {}, {}
+        for s in sl.sites:
+            if s.addr in constraint:
+                sv, rows = _value_rows(constraint[s.addr], s.dim)
+                if rows is None:
+                    modes[s.addr] = A.MODE_OBS_TAB
+                    shared[s.addr] = np.broadcast_to(sv, (s.dim,)).astype(np.float32)
+                else:
+                    modes[s.addr] = A.MODE_OBS_SLOT
+                    pp[s.addr] = rows
+            elif s.addr in per_particle:
+                modes[s.addr] = A.MODE_OBS_SLOT
+            elif not sample_rest:
+                raise MissingAddress(s.addr)
+        prog = PackedProgram(sl, modes, shared, selected=tuple(selected),
+                             rng_mode=config.rng_mode() if rng_mode is None else rng_mode)
+        return prog, shared, pp
+
+    def _run(self, key: Key, K: int, args, constraint: ChoiceMap, sample_rest: bool, batched: bool,
+             prev_rows: dict | None = None, logw_in=None, sub=None, want_lse=False, device=None, offset=0,
+             K_total=None):
+        import torch
+        from . import kernels
+        prog, shared, pp = self.pack(args, constraint, sample_rest, per_particle=tuple(prev_rows or ()))
+        _, retval = self.site_list(args)
+        dev = kernels._dev(device)
+        rows = dict(prev_rows or {})
+        rows.update(pp)
+        for r in rows.values():
+            if r.shape[-1] not in (1, K):
+                raise ValueError(f"per-particle constraint has {r.shape[-1]} particles, expected {K}")
+        choices = torch.empty((max(prog.n_slots, 1), K), dtype=torch.float32, device=dev)
+        for addr, r in rows.items():
+            slot = prog.slot_of[addr]
+            dim = prog.site_list[addr].dim
+            choices[slot:slot + dim] = torch.as_tensor(r, dtype=torch.float32, device=dev).expand(dim, K)
+        out = kernels.run_program(prog, key, K, offset=offset, choices=choices, logw_in=logw_in, sub=sub,
+                                  want_lse=want_lse, K_total=K_total, device=dev)
+        tr = Trace(self, args, prog, out["choices"], out["score"], shared, batched, retval)
+        return tr, out
+
+    # -- GFI ------------------------------------------------------------------------------------
+    def simulate(self, key: Key, args=(), K: int | None = None) -> Trace:
+        tr, _ = self._run(key, K or 1, args, ChoiceMap.empty(), True, K is not None)
+        return tr
+
+    def generate(self, key: Key, constraint: ChoiceMap, args=(), K: int | None = None):
+        kk = K or 1
+        tr, out = self._run(key, kk, args, constraint, True, K is not None)
+        w = out["weight"]
+        return tr, (w if K is not None else w[0])
+
+    importance = generate
+
+    def assess(self, chm: ChoiceMap, args=()):
+        K = 1
+        batched = False
+        sl, _ = self.site_list(args)
+        for s in sl.sites:
+            if s.addr in chm:
+                _, rows = _value_rows(chm[s.addr], s.dim)
+                if rows is not None:
+                    K, batched = int(rows.shape[-1]), True
+        tr, out = self._run((0, 0), K, args, chm, False, batched)
+        return (out["score"] if batched else out["score"][0]), tr.get_retval()
+
+    def propose(self, key: Key, args=(), K: int | None = None):
+        tr = self.simulate(key, args, K)
+        return tr.get_choices(), tr.get_score(), tr.get_retval()
+
+    def marginal(self, selection: Selection | None = None, algorithm=None) -> "Marginal":
+        return Marginal(self, selection or Selection.all(), algorithm)
+
+
+class StaticGenerativeFunction(GenerativeFunction):
+    """``@gen`` function (static.py:725-1036)."""
+
+    def __init__(self, source: Callable):
+        self.source = source
+        self.__name__ = getattr(source, "__name__", "gen_fn")
+        self.__doc__ = getattr(source, "__doc__", None)
+        self._cache: dict = {}
+
+    def site_list(self, args):
+        k = _args_key(args)
+        if k not in self._cache:
+            with _Tracer() as t:
+                retval = self.source(*args)
+            self._cache[k] = (t.sites, retval)
+        return self._cache[k]
+
+    def __call__(self, *args):
+        raise NotSupportedInModelBody("calling a @gen function inside another model body is not supported; "
+                                      "use simulate/importance/assess")
+
+    def __repr__(self):
+        return f"<gen {self.__name__}>"
+
+
+def gen(fn: Callable) -> StaticGenerativeFunction:
+    """static.py:1044-1049"""
+    return StaticGenerativeFunction(fn)
+
+
+def _args_key(args) -> tuple:
+    out = []
+    for a in args:
+        if isinstance(a, (int, float, str, bool, type(None))):
+            out.append(a)
+        elif isinstance(a, (np.ndarray, list, tuple)) or hasattr(a, "detach"):
+            arr = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+            out.append((arr.shape, arr.tobytes()))
+        else:
+            out.append(id(a))
+    return tuple(out)
+
+
+class Marginal(GenerativeFunction):
+    """inference/sp.py:207-252 — only constructed so that Target can reject it (sp.py:46-49)."""
+
+    def __init__(self, gen_fn, selection, algorithm=None):
+        self.gen_fn, self.selection, self.algorithm = gen_fn, selection, algorithm
+
+
+# ---------------------------------------------------------------------------------------------
+# primitive distributions (distribution.py:359-476 ExactDensity; tfp/__init__.py wrappers)
+# ---------------------------------------------------------------------------------------------
+class Distribution(GenerativeFunction):
+    def __init__(self, name: str, kind: int, param_names: Sequence[str]):
+        self.name, self.kind, self.param_names = name, kind, tuple(param_names)
+
+    def _params(self, args, kwargs) -> tuple[int, list]:
+        if kwargs:
+            args = tuple(args) + tuple(kwargs[n] for n in self.param_names[len(args):])
+        if len(args) != len(self.param_names):
+            raise TypeError(f"{self.name}() takes parameters {self.param_names}")
+        return self.kind, list(args)
+
+    def _dim(self, params):
+        return None
+
+    def __call__(self, *args, **kwargs) -> DistCall:
+        kind, params = self._params(args, kwargs)
+        return DistCall(self, kind, params, self._dim(params))
+
+    # one-site program for the stand-alone API
+    def _as_gen(self, args, kwargs=None) -> StaticGenerativeFunction:
+        d = self
+        def body():
+            return d(*args, **(kwargs or {})) @ _VALUE
+        return StaticGenerativeFunction(body)
+
+    def site_list(self, args):
+        return self._as_gen(args).site_list(())
+
+    def simulate(self, key, args=(), K=None):
+        return self._as_gen(args).simulate(key, (), K)
+
+    def sample(self, key, *args, **kwargs):
+        return self._as_gen(args, kwargs).simulate(key, ()).get_choices()[_VALUE]
+
+    def logpdf(self, v, *args, **kwargs):
+        return self._as_gen(args, kwargs).assess(ChoiceMap.v(v), ())[0]
+
+    def assess(self, chm: ChoiceMap, args=()):
+        g = self._as_gen(args)
+        v = chm.get_value() if chm.has_value() else chm[_VALUE]
+        return g.assess(ChoiceMap.v(v), ())
+
+    def generate(self, key, constraint: ChoiceMap, args=(), K=None):
+        return self._as_gen(args).generate(key, constraint, (), K)
+
+    importance = generate
+
+    def random_weighted(self, key, *args):
+        tr = self.simulate(key, args)
+        return tr.get_score(), tr.get_choices()[_VALUE]
+
+    def estimate_logpdf(self, key, v, *args):
+        return self.logpdf(v, *args)
+
+    def __repr__(self):
+        return f"genjax_amd.{self.name}"
+
+
+class _VectorDist(Distribution):
+    def _dim(self, params):
+        d = 1
+        for p in params:
+            if isinstance(p, Sym):
+                d = max(d, getattr(p, "dim", 1))
+            else:
+                d = max(d, int(np.asarray(p).size))
+        return d
+
+
+class _Categorical(Distribution):
+    def _params(self, args, kwargs):
+        if "probs" in kwargs:
+            return A.CATEGORICAL_PROBS, [kwargs["probs"]]
+        if "logits" in kwargs:
+            return A.CATEGORICAL_LOGITS, [kwargs["logits"]]
+        if len(args) != 1:
+            raise TypeError("categorical(logits) / categorical(probs=...) / categorical(logits=...)")
+        warnings.warn("bare argument to categorical is interpreted as logits (distribution.py:479-500)",
+                      DeprecationWarning, stacklevel=3)
+        return A.CATEGORICAL_LOGITS, [args[0]]
+
+
+class _Bernoulli(Distribution):
+    def _params(self, args, kwargs):
+        if "probs" in kwargs:
+            return A.FLIP, [kwargs["probs"]]
+        if "logits" in kwargs:
+            return A.BERNOULLI_LOGITS, [kwargs["logits"]]
+        if len(args) != 1:
+            raise TypeError("bernoulli(logits) / bernoulli(probs=...) / bernoulli(logits=...)")
+        return A.BERNOULLI_LOGITS, [args[0]]
+
+
+normal = _VectorDist("normal", A.NORMAL, ("loc", "scale"))
+mv_normal_diag = _VectorDist("mv_normal_diag", A.MVNORMAL_DIAG, ("loc", "scale_diag"))
+flip = _VectorDist("flip", A.FLIP, ("p",))
+bernoulli = _Bernoulli("bernoulli", A.BERNOULLI_LOGITS, ("logits",))
+beta = Distribution("beta", A.BETA, ("concentration1", "concentration0"))
+categorical = _Categorical("categorical", A.CATEGORICAL_LOGITS, ("logits",))
+uniform = _VectorDist("uniform", A.UNIFORM, ("low", "high"))
+exponential = _VectorDist("exponential", A.EXPONENTIAL, ("rate",))
+half_normal = _VectorDist("half_normal", A.HALF_NORMAL, ("scale",))
+laplace = _VectorDist("laplace", A.LAPLACE, ("loc", "scale"))
+log_normal = _VectorDist("log_normal", A.LOG_NORMAL, ("loc", "scale"))
+cauchy = _VectorDist("cauchy", A.CAUCHY, ("loc", "scale"))
+gamma = Distribution("gamma", A.GAMMA, ("concentration", "rate"))

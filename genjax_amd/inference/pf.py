@@ -1,0 +1,117 @@
+"""Bootstrap particle filter for a linear-Gaussian state-space model (BASELINE configs 3 and 4) and
+N-of-K resampling.  The reference library has neither: it supplies the ingredients
+(Scan.generate's chained keys and per-step weights, scan.py:237-294; the cookbook's categorical-draw +
+gather idiom) and closed-form answers come from a Kalman filter.  Per step and per particle the HIP
+path does: resample-index (prefix sum + comb search) then ONE fused kernel (ancestor gather +
+propagate + reweight + LSE partials).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _abi as A
+from .. import config
+from ..core import Key, fold_in, split, threefry2x32
+
+
+def _unit_from_key(k: Key) -> float:
+    """uniform [0,1) from one key: 23 mantissa bits of x0^x1 of Threefry(k, (0,0)) (jax _uniform)."""
+    a, b = threefry2x32(k[0], k[1], 0, 0)
+    bits = (a ^ b) >> 9
+    return float(bits) / float(1 << 23)
+
+
+def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None):
+    """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N])."""
+    from .. import kernels
+    K = logw.numel()
+    N = int(n_out or K)
+    if lse is None:
+        lse = kernels.logsumexp(logw)
+    cum, total = kernels.weight_cumsum(logw, True, lse)
+    bt = torch.cat([torch.zeros(1, dtype=torch.int64, device=logw.device), total.reshape(1)])
+    if method == "systematic":
+        anc = kernels.resample_systematic(cum, bt, _unit_from_key(key), N)
+    elif method == "multinomial":
+        anc = kernels.resample_multinomial(cum, bt, key, N)
+    else:
+        raise ValueError(method)
+    return kernels.gather_rows(rows, anc), anc
+
+
+class LinearGaussianSSM:
+    """x_0 ~ N(0, q0^2 I); x_t ~ N(A x_{t-1}, q^2 I); y_t ~ N(H x_t, r^2 I)."""
+
+    def __init__(self, A_mat, q: float, r: float, H=None, q0: float = 1.0):
+        self.A = np.ascontiguousarray(A_mat, np.float32)
+        self.H = None if H is None else np.ascontiguousarray(H, np.float32)
+        self.q, self.r, self.q0 = float(q), float(r), float(q0)
+        self.dx = self.A.shape[0]
+        self.dy = self.dx if self.H is None else self.H.shape[0]
+        self._dev = None
+
+    def c_struct(self, device) -> A.GjxSsm:
+        if self._dev is None or self._dev[0].device != torch.device(device):
+            Ad = torch.from_numpy(self.A).to(device)
+            Hd = None if self.H is None else torch.from_numpy(self.H).to(device)
+            self._dev = (Ad, Hd)
+        s = A.GjxSsm()
+        s.dx, s.dy, s.q, s.r, s.q0 = self.dx, self.dy, self.q, self.r, self.q0
+        s.A_dev = self._dev[0].data_ptr()
+        s.H_dev = None if self._dev[1] is None else self._dev[1].data_ptr()
+        return s
+
+
+class BootstrapFilter:
+    """SMC with the prior as proposal and systematic resampling before every propagate step."""
+
+    def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None):
+        self.ssm, self.K = ssm, int(k_particles)
+        self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
+
+    def run(self, key: Key, ys, device=None, rank: int = 0, world: int = 1, keep_means: bool = False):
+        """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?).
+        With world > 1 the K particles are sharded (distributed.py) and ``ys`` is the same on all ranks."""
+        from .. import kernels
+        from .. import distributed as D
+        dev = kernels._dev(device)
+        ys_d = torch.as_tensor(np.asarray(ys, np.float32), device=dev) if not torch.is_tensor(ys) else ys.to(dev)
+        T = ys_d.shape[0]
+        off, K = D.shard(self.K, rank, world)
+        cs = self.ssm.c_struct(dev)
+        ws = kernels.workspace(A.OP_SSM, K, dev)
+        bufs = [torch.empty((self.ssm.dx, K), dtype=torch.float32, device=dev) for _ in range(2)]
+        logw = torch.empty(K, dtype=torch.float32, device=dev)
+        incs = torch.empty(T, dtype=torch.float32, device=dev)
+        lse = torch.empty(4, dtype=torch.float32, device=dev)
+        zero = torch.zeros(1, dtype=torch.int64, device=dev)
+        means = torch.empty((T, self.ssm.dx), dtype=torch.float32, device=dev) if keep_means else None
+        x_prev, anc = None, None
+        k = key
+        for t in range(T):
+            k = fold_in(k, t)                      # chained step key (scan.py:268)
+            k_prop, k_res = split(k)
+            if t > 0:
+                if world == 1:
+                    cum, total = kernels.weight_cumsum(logw, True, lse)
+                    anc = kernels.resample_systematic(cum, torch.cat([zero, total.reshape(1)]), _unit_from_key(k_res), self.K)
+                else:
+                    x_prev, _ = D.resample_exchange(x_prev, logw, lse, _unit_from_key(k_res), self.K)
+                    anc = None
+            x_out = bufs[t & 1]
+            kernels.ssm_step(cs, k_prop, self.rng_mode, t, K, x_prev, anc, ys_d[t], x_out=x_out, logw=logw, lse=lse,
+                             offset=off, K_total=self.K, ws=ws)
+            if world > 1:
+                lse = D.global_lse(lse, self.K)
+            incs[t] = lse[3]
+            if keep_means:
+                w = torch.exp(logw - lse[2])
+                m = (x_out * w).sum(dim=1)
+                if world > 1:
+                    torch.distributed.all_reduce(m)
+                means[t] = m
+            x_prev = x_out
+            if world > 1:
+                lse = lse.clone()
+        return dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means)

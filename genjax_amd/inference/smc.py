@@ -1,0 +1,252 @@
+"""Importance sampling / SMC drivers with the reference's class names (inference/smc.py, sp.py).
+
+Host code here only does what the reference does at trace time: key splits, constraint merging,
+choosing site modes.  Every per-particle operation is one launch of the HIP kernels:
+  run_smc            -> gjx_run_program (propagate + reweight + fused LSE partials)   smc.py:298-315
+  log-ML estimate    -> 4-float device result of the LSE finish                       smc.py:96-97
+  sample_particle    -> gjx_categorical_pick (Gumbel-max argmax reduce) + column read smc.py:102-109
+  ChangeTarget       -> gjx_run_program with every site constrained                   smc.py:370-396
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from .. import _abi as A
+from ..core import ChoiceMap, Key, fold_in, split
+from ..gen import GenerativeFunction, Marginal, Trace
+
+
+class Target:
+    """Unnormalised posterior: generative function + args + constraint (sp.py:52-94)."""
+
+    def __init__(self, p: GenerativeFunction, args: tuple, constraint: ChoiceMap):
+        if isinstance(p, Marginal):
+            raise TypeError("Target does not support Marginal generative functions.")  # sp.py:46-49
+        if not isinstance(p, GenerativeFunction):
+            raise TypeError("Target needs a generative function")
+        self.p, self.args, self.constraint = p, tuple(args), constraint
+
+    def importance(self, key: Key, constraint: ChoiceMap, K: int | None = None):
+        merged = self.constraint.merge(constraint)
+        return self.p.importance(key, merged, self.args, K)
+
+    def filter_to_unconstrained(self, choice_map: ChoiceMap) -> ChoiceMap:
+        return choice_map.filter(~self.constraint.get_selection())
+
+    def __getitem__(self, addr):
+        return self.constraint[addr]
+
+    def same_as(self, other: "Target") -> bool:
+        return self.p is other.p and self.args == other.args and self.constraint == other.constraint
+
+
+class ParticleCollection:
+    """Weighted particles (smc.py:76-109): a batched Trace + log-weights, all on the device."""
+
+    def __init__(self, particles: Trace, log_weights, is_valid=True, lse=None, offset: int = 0, K_total=None):
+        self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
+        self._lse = lse            # device f32[4] = {max, sumexp, lse, lse - log K} when already reduced
+        self.offset = offset
+        self.K_total = K_total or int(log_weights.shape[0])
+
+    def get_particles(self) -> Trace:
+        return self.particles
+
+    def get_particle(self, idx) -> Trace:
+        return self.particles.get_particle(idx)
+
+    def get_log_weights(self):
+        return self.log_weights
+
+    def __len__(self):
+        return int(self.log_weights.shape[0])
+
+    def __getitem__(self, idx):
+        return self.get_particle(idx), self.log_weights[idx]
+
+    def lse(self):
+        if self._lse is None:
+            from .. import kernels
+            self._lse = kernels.logsumexp(self.log_weights, self.K_total)
+        return self._lse
+
+    def get_log_marginal_likelihood_estimate(self):
+        """logsumexp(log_weights) - log K  (smc.py:96-97), a 0-d device tensor."""
+        return self.lse()[3]
+
+    def sample_particle(self, key: Key) -> Trace:
+        """1-of-K categorical draw over the weights + gather (smc.py:102-109)."""
+        from .. import kernels
+        out = kernels.categorical_pick(self.log_weights, self.lse(), key, self.particles.prog.rng_mode, self.offset)
+        idx = int(out[1].item()) - self.offset
+        return self.get_particle(idx)
+
+
+class SMCAlgorithm:
+    """smc.py:117-225"""
+
+    def get_num_particles(self) -> int:
+        raise NotImplementedError
+
+    def get_final_target(self) -> Target:
+        raise NotImplementedError
+
+    def run_smc(self, key: Key) -> ParticleCollection:
+        raise NotImplementedError
+
+    def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
+        raise NotImplementedError
+
+    def log_marginal_likelihood_estimate(self, key: Key, target: Target | None = None):
+        algorithm = ChangeTarget(self, target) if target else self
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+    # GenSP interface
+    def random_weighted(self, key: Key, *args: Any):
+        target = args[0]
+        assert isinstance(target, Target)
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        pc = algorithm.run_smc(key)
+        particle = pc.sample_particle(sub_key)
+        log_density_estimate = particle.get_score() - pc.get_log_marginal_likelihood_estimate()
+        chm = target.filter_to_unconstrained(particle.get_choices())
+        return log_density_estimate, chm
+
+    def estimate_logpdf(self, key: Key, v: ChoiceMap, *args: Any):
+        target = args[0]
+        assert isinstance(target, Target)
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        pc = algorithm.run_csmc(key, v)
+        particle = pc.sample_particle(sub_key)
+        return particle.get_score() - pc.get_log_marginal_likelihood_estimate()
+
+    def estimate_normalizing_constant(self, key: Key, target: Target):
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+    def simulate(self, key: Key, args: tuple):
+        """Distribution.simulate of an Algorithm (distribution.py:108-115): (score, choices) as a pair."""
+        w, chm = self.random_weighted(key, *args)
+        return w, chm
+
+
+def _propose(q, key: Key, target: Target, K: int):
+    """q.random_weighted vmapped over particles: -> (log_q f32[K], per-particle rows addr -> [dim][K]).
+    Properly weighted (log_q = the proposal's full density), unlike the reference's
+    Marginal.random_weighted path (sp.py:226-230)."""
+    gf = q.gen_fn if isinstance(q, Marginal) else q
+    tr, out = gf._run(key, K, (target,), ChoiceMap.empty(), True, True)
+    return out["score"], {a: r for a, r in tr.full_choice_rows().items()}
+
+
+class ImportanceK(SMCAlgorithm):
+    """K-particle importance sampling (smc.py:282-351)."""
+
+    def __init__(self, target: Target, q=None, k_particles: int = 2):
+        self.target, self.q, self.k_particles = target, q, int(k_particles)
+
+    def get_num_particles(self):
+        return self.k_particles
+
+    def get_final_target(self):
+        return self.target
+
+    def run_smc(self, key: Key, offset: int = 0, K_local: int | None = None) -> ParticleCollection:
+        """``offset``/``K_local`` select this rank's shard of the K particles (global indices
+        [offset, offset + K_local)); the default is the whole collection."""
+        K = self.k_particles if K_local is None else int(K_local)
+        key, sub_key = split(key)                    # smc.py:299
+        # sub_keys = split(sub_key, K) happens on the device: particle i <-> Threefry(sub_key, (0, i))
+        if self.q is not None:
+            log_q, rows = _propose(self.q, sub_key, self.target, K)     # smc.py:302-304
+            tr, out = self.target.p._run(sub_key, K, self.target.args, self.target.constraint, True, True,
+                                         prev_rows=rows, sub=log_q, want_lse=True, offset=offset,
+                                         K_total=self.k_particles)
+        else:
+            tr, out = self.target.p._run(sub_key, K, self.target.args, self.target.constraint, True, True,
+                                         want_lse=True, offset=offset, K_total=self.k_particles)
+        return ParticleCollection(tr, out["logw"], True, out["lse"], offset, self.k_particles)
+
+    def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
+        """K-1 fresh particles plus the retained choice map stacked last (smc.py:317-351)."""
+        import torch
+        K = self.k_particles
+        key, sub_key = split(key)
+        tgt = self.target
+        if self.q is not None:
+            log_q, rows = _propose(self.q, sub_key, tgt, K - 1) if K > 1 else (None, {})
+            gf = self.q.gen_fn if isinstance(self.q, Marginal) else self.q
+            ret_score, _ = gf.assess(retained, (tgt,))
+            sl, _ = gf.site_list((tgt,))
+            stacked = {}
+            for s in sl.sites:
+                rv = torch.as_tensor(np.asarray(_host(retained[s.addr]), np.float32).reshape(s.dim, 1), device=ret_score.device)
+                stacked[s.addr] = torch.cat([rows[s.addr], rv], dim=1) if K > 1 else rv
+            sub = torch.cat([log_q, ret_score.reshape(1)]) if K > 1 else ret_score.reshape(1)
+            tr, out = tgt.p._run(key, K, tgt.args, tgt.constraint, True, True, prev_rows=stacked, sub=sub, want_lse=True)
+            return ParticleCollection(tr, out["logw"], True, out["lse"])
+        # no proposal: K-1 fresh particles from the prior; the retained choices enter as per-particle
+        # constraints of a 1-particle run, so both runs share one slot layout and are stacked column-wise
+        ret_rows = {}
+        sl, _ = tgt.p.site_list(tgt.args)
+        for s in sl.sites:
+            if s.addr in retained:
+                ret_rows[s.addr] = torch.as_tensor(np.asarray(_host(retained[s.addr]), np.float32).reshape(s.dim, 1))
+        tr_r, out_r = tgt.p._run(key, 1, tgt.args, tgt.constraint, True, True, prev_rows=ret_rows)
+        if K == 1:
+            return ParticleCollection(tr_r, out_r["weight"], True)
+        tr_f, out_f = tgt.p._run(sub_key, K - 1, tgt.args, tgt.constraint, True, True)
+        pf = {a: r for a, r in tr_f.full_choice_rows().items() if tr_r.prog.slot_of[a] >= 0}
+        ch = torch.cat([torch.cat([pf[s.addr] for s in sl.sites if tr_r.prog.slot_of[s.addr] >= 0], dim=0), tr_r.choices], dim=1)
+        tr = Trace(tgt.p, tgt.args, tr_r.prog, ch.contiguous(), torch.cat([tr_f.score, tr_r.score]), tr_r.shared, True,
+                   tr_r.retval_sym)
+        return ParticleCollection(tr, torch.cat([out_f["weight"], out_r["weight"]]), True)
+
+
+class Importance(ImportanceK):
+    """1-particle special case (smc.py:233-279)."""
+
+    def __init__(self, target: Target, q=None):
+        super().__init__(target, q, 1)
+
+
+class ChangeTarget(SMCAlgorithm):
+    """Reweight an existing collection to a new target (smc.py:359-465)."""
+
+    def __init__(self, prev: SMCAlgorithm, target: Target):
+        self.prev, self.target = prev, target
+
+    def get_num_particles(self):
+        return self.prev.get_num_particles()
+
+    def get_final_target(self):
+        return self.target
+
+    def _reweight(self, key: Key, collection: ParticleCollection) -> ParticleCollection:
+        prev_target = self.prev.get_final_target()
+        particles = collection.get_particles()
+        if self.target.same_as(prev_target):
+            # every site would be re-assessed to the same score: this_weight == weight
+            return collection
+        rows = particles.full_choice_rows()
+        latents = {a: r for a, r in rows.items() if a not in prev_target.constraint}   # sp.py:89-91
+        K = particles.K
+        tr, out = self.target.p._run(key, K, self.target.args, self.target.constraint, True, True, prev_rows=latents,
+                                     logw_in=collection.get_log_weights(), sub=particles.score, want_lse=True)
+        return ParticleCollection(tr, out["logw"], True, out["lse"])          # smc.py:383: w' - score + w
+
+    def run_smc(self, key: Key) -> ParticleCollection:
+        return self._reweight(key, self.prev.run_smc(key))
+
+    def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
+        return self._reweight(key, self.prev.run_csmc(key, retained))
+
+
+def _host(v):
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else v

@@ -87,7 +87,7 @@ def lse_combine(pairs: torch.Tensor, K_total: int) -> torch.Tensor:
     return out
 
 
-def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_PACKED, offset=0, ws=None) -> torch.Tensor:
+def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_FLAT, offset=0, ws=None) -> torch.Tensor:
     """Returns an int32[2] device tensor: [bitcast(best value), index]."""
     K = logw.numel()
     out = torch.empty(2, dtype=torch.int32, device=logw.device)
@@ -151,3 +151,31 @@ def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, log
                               stride, _ptr(anc), _ptr(y), _ptr(x_out), _ptr(logw), _ptr(lse), int(K_total or K),
                               _ptr(ws), ws.numel(), _stream()), "gjx_ssm_step")
     return x_out, logw, lse
+
+
+def hmc(prog: PackedProgram, key, choices: torch.Tensor, eps: float, L: int, stale=False, accept=False, offset=0,
+        ws=None):
+    """gjx_hmc: in-place HMC move of every chain column.  Returns dict(choices, score, alpha, accepted)."""
+    n = choices.shape[1]
+    dev = choices.device
+    cp = prog.c_program(dev)
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    alpha = torch.empty(n, dtype=torch.float32, device=dev)
+    acc = torch.empty(n, dtype=torch.float32, device=dev)
+    need = load().gjx_hmc_workspace_bytes(C.byref(cp), n)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(load().gjx_hmc(C.byref(cp), key[0], key[1], n, int(offset), float(eps), int(L), int(bool(stale)),
+                         int(bool(accept)), _ptr(choices), _ptr(score), _ptr(alpha), _ptr(acc), _ptr(ws), ws.numel(),
+                         _stream()), "gjx_hmc")
+    return dict(choices=choices, score=score, alpha=alpha, accepted=acc, _ws=ws)
+
+
+def score_grad(prog: PackedProgram, choices: torch.Tensor):
+    n = choices.shape[1]
+    dev = choices.device
+    cp = prog.c_program(dev)
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(choices)
+    check(load().gjx_score_grad(C.byref(cp), n, _ptr(choices), _ptr(score), _ptr(grad), _stream()), "gjx_score_grad")
+    return score, grad

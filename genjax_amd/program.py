@@ -154,7 +154,7 @@ class PackedProgram:
 
     def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
                  obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
-                 rng_mode: int = A.RNG_PACKED):
+                 rng_mode: int = A.RNG_FLAT):
         self.site_list = sl
         self.modes = dict(modes or {})
         self.rng_mode = int(rng_mode)
@@ -199,6 +199,8 @@ class PackedProgram:
             cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
             cs.obs_off = self.obs_off.get(s.addr, 0)
             rows = s.ncat if s.ncat else s.dim
+            for k in range(len(s.params), A.MAX_PARAMS):   # unused parameter slots read tab[0]
+                cs.p[k].op, cs.p[k].len, cs.p[k].off = A.P_CONST, 1, 0
             for k, p in enumerate(s.params):
                 cp = cs.p[k]
                 cp.op, cp.xf = p.op, p.xf

@@ -55,12 +55,12 @@ enum {
   GJX_CATEGORICAL_PROBS = 6,  /* categorical(probs=...)        :102-104                     */
   GJX_UNIFORM = 7,            /* uniform(low, high)            :294                         */
   GJX_MVNORMAL_DIAG = 8,      /* mv_normal_diag(loc, scale)    :239  (one site, dim scalars)*/
-  GJX_EXPONENTIAL = 9,        /* exponential(rate)             :128                         */
-  GJX_HALF_NORMAL = 10,       /* half_normal(scale)            :171                         */
-  GJX_LAPLACE = 11,           /* laplace(loc, scale)           :200                         */
-  GJX_LOG_NORMAL = 12,        /* log_normal(loc, scale)        :220                         */
-  GJX_CAUCHY = 13,            /* cauchy(loc, scale)            :112                         */
-  GJX_GAMMA = 14,             /* gamma(concentration, rate)    :160                         */
+  GJX_EXPONENTIAL = 9,        /* exponential(rate)             :150                         */
+  GJX_HALF_NORMAL = 10,       /* half_normal(scale)            :184                         */
+  GJX_LAPLACE = 11,           /* laplace(loc, scale)           :214                         */
+  GJX_LOG_NORMAL = 12,        /* log_normal(loc, scale)        :219                         */
+  GJX_CAUCHY = 13,            /* cauchy(loc, scale)            :110                         */
+  GJX_GAMMA = 14,             /* gamma(concentration, rate)    :164                         */
   GJX_KIND_MAX = 15
 };
 
@@ -109,11 +109,20 @@ typedef struct gjx_site {
   gjx_param p[GJX_MAX_PARAMS];
 } gjx_site; /* 96 bytes */
 
-enum {
-  GJX_RNG_PACKED = 0, /* element c of a site draws word (c & 1) of Threefry(site_key, (0, c >> 1)) */
-  GJX_RNG_JAX32 = 1   /* element c draws x0 ^ x1 of Threefry(site_key, (0, c))  — the layout of
-                         jax._src.prng._threefry_random_bits_partitionable (jax 0.5.2)          */
-};
+/* random-stream layouts.  Both are Threefry-2x32-20 counter streams and both give results that are
+ * independent of how particles are sharded over GPUs (the counter carries the GLOBAL particle index).
+ *   GJX_RNG_FLAT  (default, the MI355X-first layout): no per-particle or per-site key derivation.
+ *       bits(particle i, site j (1-based), element c) = word (c & 1) of
+ *       Threefry(key, (i, (j << 22) | (c >> 1)))              [i < 2^32, j < 1024, c < 2^23]
+ *       -> 1 hash per TWO 32-bit draws, key schedule wave-uniform (SGPRs).
+ *   GJX_RNG_JAX32 (the reference's layout, jax 0.5.2 with jax_threefry_partitionable=True):
+ *       particle key = Threefry(key, (0, i))   (jax.random.split(key, K)[i], smc.py:300)
+ *       site key     = Threefry(particle key, (0, j))          (fold_in(key, counter), static.py:349-352)
+ *       bits(c)      = x0 ^ x1 of Threefry(site key, (0, c))   (prng._threefry_random_bits_partitionable)
+ *       -> 1 hash per 32-bit draw plus 1 + n_sites hashes per particle. */
+enum { GJX_RNG_FLAT = 0, GJX_RNG_JAX32 = 1 };
+#define GJX_FLAT_SITE_SHIFT 22
+#define GJX_FLAT_MAX_SITES 1023
 
 typedef struct gjx_program {
   int32_t n_sites;
@@ -141,8 +150,7 @@ int gjx_threefry2x32(uint32_t key0, uint32_t key1, uint32_t ctr_hi, uint32_t ctr
 /* ---- particle propagate + reweight ------------------------------------------------------
  * Runs the program once per particle: the vmapped body of ImportanceK.run_smc
  * (inference/smc.py:298-315  ->  sp.py:83-87  ->  static.py:340-399  ->  distribution.py:117-147).
- * Particle i (global index particle_offset + i) uses key_i = Threefry(key, (0, offset+i))
- * (== jax.random.split(key, K)[i]); site j (1-based, program order) uses Threefry(key_i, (0, j)).
+ * Particle i has GLOBAL index particle_offset + i; its draws follow prog->rng_mode (above).
  *   choices   f32[n_slots][K]  in/out (OBS_SLOT sites read their value; all sites write it back)
  *   score     f32[K]  out   sum of every site's logpdf            (static.py:102-105)
  *   weight    f32[K]  out   sum of constrained sites' logpdf      (static.py:377)
@@ -229,13 +237,15 @@ int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mod
 /* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
  * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float
  * sites only, hmc.py:49-65); every other site keeps its value (mode OBS_*).
- *   chain key = Threefry(key, (0, chain_offset + i)); momenta: (key', sub) = split(chain key),
- *   leaf l ~ N(0,1) from fold_in(sub, l) (hmc.py:120-130).
+ *   JAX32 stream: chain key = Threefry(key, (0, chain_offset + i)); (key', sub) = split(chain key);
+ *   momentum leaf l ~ N(0,1) from fold_in(sub, l) (hmc.py:120-130).  FLAT stream: leaf l is site l+1.
  *   choices f32[n_slots][n] in/out, score f32[n] in/out, alpha f32[n] out (hmc.py:196-203).
  *   stale_grad_compat != 0 reproduces hmc.py:186 (first half-kick always uses the INITIAL gradient).
+ *   workspace: gjx_hmc_workspace_bytes(prog, n).
  *   accept != 0 additionally applies the caller-side MH rule of tests/inference/test_requests.py:134-137
- *   with log U drawn from fold_in(key', 0x4d48) and reverts rejected chains; accepted f32[n] out or NULL.
+ *   with log U drawn from fold_in(key', 0x4d48) (FLAT: site 1023) and reverts rejected chains; accepted f32[n] out or NULL.
  */
+size_t gjx_hmc_workspace_bytes(const gjx_program* prog, int64_t n);
 int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
             float* score, float* alpha, float* accepted, void* workspace, size_t workspace_bytes,

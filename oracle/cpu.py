@@ -114,7 +114,7 @@ def logsumexp(x, K_total=None):
     return out
 
 
-def categorical_pick(logw, lse, key, rng_mode=A.RNG_PACKED, offset=0):
+def categorical_pick(logw, lse, key, rng_mode=A.RNG_FLAT, offset=0):
     logw = np.ascontiguousarray(logw, np.float32)
     lse = np.ascontiguousarray(lse, np.float32)
     bv = C.c_float()

@@ -76,14 +76,41 @@ static inline okey fold_in64(okey k, uint64_t i) {
 }
 static inline okey fold_in(okey k, uint32_t i) { return fold_in64(k, i); }
 
-/* 32 random bits for element c of the array drawn with key k */
-static inline uint32_t elem_bits(okey k, uint32_t c, int rng_mode) {
+/* A random stream = all draws of (particle idx, site) under one run key; see GJX_RNG_* in gjx.h. */
+typedef struct {
+  int mode;
+  okey key;      /* FLAT: run key (with the high index word folded in when idx >= 2^32) */
+  uint32_t c0;   /* FLAT: low 32 bits of the global particle index */
+  uint32_t site; /* FLAT: 1-based site index */
+  okey sk;       /* JAX32: site key */
+} ostream;
+
+static inline ostream stream_open(int mode, okey run_key, uint64_t idx, uint32_t site) {
+  ostream s;
+  s.mode = mode; s.key = run_key; s.c0 = (uint32_t)idx; s.site = site; s.sk = run_key;
+  if (mode == GJX_RNG_JAX32) {
+    okey pk = fold_in64(run_key, idx); /* jax.random.split(key, K)[idx]   smc.py:300 */
+    s.sk = fold_in(pk, site);          /* fold_in(key, counter)           static.py:349-352 */
+  } else if (idx >> 32) {
+    uint32_t o[2];
+    gjxo_threefry2x32(run_key.a, run_key.b, 0xFFFFFFFFu, (uint32_t)(idx >> 32), o);
+    s.key.a = o[0]; s.key.b = o[1];
+  }
+  return s;
+}
+static inline ostream stream_from_site_key(okey sk) { /* JAX32 stream with an explicit site key */
+  ostream s;
+  s.mode = GJX_RNG_JAX32; s.key = sk; s.c0 = 0; s.site = 0; s.sk = sk;
+  return s;
+}
+/* 32 random bits for element c of the stream */
+static inline uint32_t elem_bits(const ostream* s, uint32_t c) {
   uint32_t o[2];
-  if (rng_mode == GJX_RNG_JAX32) { /* _threefry_random_bits_partitionable: bits1 ^ bits2 */
-    gjxo_threefry2x32(k.a, k.b, 0u, c, o);
+  if (s->mode == GJX_RNG_JAX32) { /* _threefry_random_bits_partitionable: bits1 ^ bits2 */
+    gjxo_threefry2x32(s->sk.a, s->sk.b, 0u, c, o);
     return o[0] ^ o[1];
   }
-  gjxo_threefry2x32(k.a, k.b, 0u, c >> 1, o);
+  gjxo_threefry2x32(s->key.a, s->key.b, s->c0, (s->site << GJX_FLAT_SITE_SHIFT) | (c >> 1), o);
   return o[c & 1];
 }
 
@@ -153,11 +180,11 @@ float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
  * fixed so that element indices are a pure function of (variate, iteration). */
 #define GAMMA_MAXIT 32
 #define GAMMA_NDRAW (2 * GAMMA_MAXIT + 1)
-static float log_gamma_variate(okey sk, uint32_t base, float a, int rng_mode) {
+static float log_gamma_variate(const ostream* sk, uint32_t base, float a) {
   float boost = 0.0f;
   float aa = a;
   if (a < 1.0f) {
-    float u = uniform_from_bits(elem_bits(sk, base + 2 * GAMMA_MAXIT, rng_mode), F32_TINY, 1.0f);
+    float u = uniform_from_bits(elem_bits(sk, base + 2 * GAMMA_MAXIT), F32_TINY, 1.0f);
     boost = logf(u) / a;
     aa = a + 1.0f;
   }
@@ -165,8 +192,8 @@ static float log_gamma_variate(okey sk, uint32_t base, float a, int rng_mode) {
   float c = 1.0f / sqrtf(9.0f * d);
   float res = logf(d);
   for (int t = 0; t < GAMMA_MAXIT; ++t) {
-    float x = normal_from_bits(elem_bits(sk, base + 2 * t, rng_mode));
-    float u = uniform_from_bits(elem_bits(sk, base + 2 * t + 1, rng_mode), F32_TINY, 1.0f);
+    float x = normal_from_bits(elem_bits(sk, base + 2 * t));
+    float u = uniform_from_bits(elem_bits(sk, base + 2 * t + 1), F32_TINY, 1.0f);
     float v = 1.0f + c * x;
     if (v <= 0.0f) continue;
     float lv = 3.0f * logf(v);
@@ -264,40 +291,41 @@ static int draws_per_elem(int kind) {
   }
 }
 
-static float elem_sample(int kind, okey sk, uint32_t c, float a, float b, int rng_mode) {
+static float elem_sample(int kind, const ostream* sk, uint32_t c, float a, float b) {
   switch (kind) {
     case GJX_NORMAL:
-    case GJX_MVNORMAL_DIAG: return a + b * normal_from_bits(elem_bits(sk, c, rng_mode));
-    case GJX_FLIP: return bits_to_unit(elem_bits(sk, c, rng_mode)) < a ? 1.0f : 0.0f;
-    case GJX_BERNOULLI_LOGITS: return bits_to_unit(elem_bits(sk, c, rng_mode)) < sigmoidf_(a) ? 1.0f : 0.0f;
+    case GJX_MVNORMAL_DIAG: return a + b * normal_from_bits(elem_bits(sk, c));
+    case GJX_FLIP: return bits_to_unit(elem_bits(sk, c)) < a ? 1.0f : 0.0f;
+    case GJX_BERNOULLI_LOGITS: return bits_to_unit(elem_bits(sk, c)) < sigmoidf_(a) ? 1.0f : 0.0f;
     case GJX_BETA: {
-      float g1 = log_gamma_variate(sk, c, a, rng_mode);
-      float g2 = log_gamma_variate(sk, c + GAMMA_NDRAW, b, rng_mode);
+      float g1 = log_gamma_variate(sk, c, a);
+      float g2 = log_gamma_variate(sk, c + GAMMA_NDRAW, b);
       return sigmoidf_(g1 - g2);
     }
-    case GJX_UNIFORM: return a + (b - a) * bits_to_unit(elem_bits(sk, c, rng_mode));
-    case GJX_EXPONENTIAL: return -logf(uniform_from_bits(elem_bits(sk, c, rng_mode), F32_TINY, 1.0f)) / a;
-    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(elem_bits(sk, c, rng_mode))) * a;
+    case GJX_UNIFORM: return a + (b - a) * bits_to_unit(elem_bits(sk, c));
+    case GJX_EXPONENTIAL: return -logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)) / a;
+    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(elem_bits(sk, c))) * a;
     case GJX_LAPLACE: {
-      float u = uniform_from_bits(elem_bits(sk, c, rng_mode), NEG1_PLUS_ULP, 1.0f);
+      float u = uniform_from_bits(elem_bits(sk, c), NEG1_PLUS_ULP, 1.0f);
       float s = (u > 0.0f) - (u < 0.0f);
       return a - b * s * log1pf(-fabsf(u));
     }
-    case GJX_LOG_NORMAL: return expf(a + b * normal_from_bits(elem_bits(sk, c, rng_mode)));
-    case GJX_CAUCHY: return a + b * tanf(3.14159265f * (bits_to_unit(elem_bits(sk, c, rng_mode)) - 0.5f));
-    case GJX_GAMMA: return expf(log_gamma_variate(sk, c, a, rng_mode)) / b;
+    case GJX_LOG_NORMAL: return expf(a + b * normal_from_bits(elem_bits(sk, c)));
+    case GJX_CAUCHY: return a + b * tanf(3.14159265f * (bits_to_unit(elem_bits(sk, c)) - 0.5f));
+    case GJX_GAMMA: return expf(log_gamma_variate(sk, c, a)) / b;
     default: return NAN;
   }
 }
 
 /* One particle through the site list.  vals[n_slots] in/out.  Returns via pointers. */
-static void run_particle(const gjx_program* prog, okey pk, float* vals, float* score_out,
+static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, float* vals, float* score_out,
                          float* weight_out, float* site_scores, int64_t ss_stride) {
   const float* tab = prog->tab;
   float score = 0.0f, weight = 0.0f;
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
-    okey sk = fold_in(pk, (uint32_t)(j + 1)); /* static.py:349-352, counter starts at 1 */
+    const ostream st = stream_open(prog->rng_mode, run_key, idx, (uint32_t)(j + 1)); /* counter starts at 1 */
+    const ostream* sk = &st;
     float lp = 0.0f;
     if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
       /* logits (probs -> log p), log_softmax; sample = argmax(logits + Gumbel) */
@@ -322,7 +350,7 @@ static void run_particle(const gjx_program* prog, okey pk, float* vals, float* s
         for (int c = 0; c < n; ++c) {
           float l = eval_param(&s->p[0], c, tab, vals);
           if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-          float g = l + gumbel_from_bits(elem_bits(sk, (uint32_t)c, prog->rng_mode));
+          float g = l + gumbel_from_bits(elem_bits(sk, (uint32_t)c));
           if (g > bestv) { bestv = g; best = c; }
         }
         v = (float)best;
@@ -346,7 +374,7 @@ static void run_particle(const gjx_program* prog, okey pk, float* vals, float* s
         float a = eval_param(&s->p[0], d, tab, vals);
         float b = eval_param(&s->p[1], d, tab, vals);
         float v;
-        if (s->mode == GJX_MODE_SAMPLE) v = elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b, prog->rng_mode);
+        if (s->mode == GJX_MODE_SAMPLE) v = elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
         else if (s->mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
         else v = vals[s->slot + d];
         lp += elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
@@ -391,10 +419,9 @@ int gjxo_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int6
     float* vals = (float*)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < K; ++i) {
-      okey pk = fold_in64(key, (uint64_t)(particle_offset + i)); /* smc.py:300 split(sub_key, K)[i] */
       for (int s = 0; s < ns; ++s) vals[s] = choices[(int64_t)s * K + i];
       float sc, w;
-      run_particle(prog, pk, vals, &sc, &w, site_scores ? site_scores + i : NULL, K);
+      run_particle(prog, key, (uint64_t)(particle_offset + i), vals, &sc, &w, site_scores ? site_scores + i : NULL, K);
       for (int s = 0; s < ns; ++s) choices[(int64_t)s * K + i] = vals[s];
       if (score) score[i] = sc;
       if (weight) weight[i] = w;
@@ -427,7 +454,7 @@ int gjxo_categorical_pick(const float* logw, int64_t K, int64_t particle_offset,
       g = gumbel_from_bits(o[0] ^ o[1]);
     } else {
       uint32_t o[2];
-      uint64_t h = gi >> 1;
+      uint64_t h = gi >> 1; /* FLAT: index pairs share one hash */
       gjxo_threefry2x32(key.a, key.b, (uint32_t)(h >> 32), (uint32_t)h, o);
       g = gumbel_from_bits(o[gi & 1]);
     }
@@ -525,8 +552,8 @@ int gjxo_ssm_step(int32_t dx, int32_t dy, const float* A, const float* H, float 
   okey key = {key0, key1};
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < K; ++i) {
-    okey pk = fold_in64(key, (uint64_t)(particle_offset + i));
-    okey sk = fold_in(pk, 1u); /* site 1: the latent state; site 2 (y) is observed */
+    const ostream st = stream_open(rng_mode, key, (uint64_t)(particle_offset + i), 1u); /* site 1: the latent state; site 2 (y) is observed */
+    const ostream* sk = &st;
     float xp[64], xn[64];
     if (t > 0) {
       int64_t a = anc ? anc[i] : i;
@@ -540,7 +567,7 @@ int gjxo_ssm_step(int32_t dx, int32_t dy, const float* A, const float* H, float 
         mu = acc;
         sd = q;
       }
-      xn[d] = mu + sd * normal_from_bits(elem_bits(sk, (uint32_t)d, rng_mode));
+      xn[d] = mu + sd * normal_from_bits(elem_bits(sk, (uint32_t)d));
       x_out[(int64_t)d * K + i] = xn[d];
     }
     float lw = 0.0f;
@@ -635,7 +662,9 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
         if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
         se += exp((double)l - (double)mx);
       }
-      int k = (int)vals[s->slot];
+      int k = (int)(s->slot >= 0 ? vals[s->slot] : tab[s->obs_off]);
+      if (k < 0) k = 0;
+      if (k > n - 1) k = n - 1;
       float l = eval_param(&s->p[0], k, tab, vals);
       if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
       score += l - (mx + (float)log(se));
@@ -644,11 +673,11 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
     for (int d = 0; d < s->dim; ++d) {
       float a = eval_param(&s->p[0], d, tab, vals);
       float b = eval_param(&s->p[1], d, tab, vals);
-      float x = vals[s->slot + d];
+      float x = s->slot >= 0 ? vals[s->slot + d] : tab[s->obs_off + d];
       score += elem_logpdf(s->kind, x, a, b);
       float gx, ga, gb;
       dlogpdf(s->kind, x, a, b, &gx, &ga, &gb);
-      grad[s->slot + d] += gx;
+      if (s->slot >= 0) grad[s->slot + d] += gx;
       param_backprop(&s->p[0], d, ga, tab, vals, grad);
       param_backprop(&s->p[1], d, gb, tab, vals, grad);
     }
@@ -661,7 +690,7 @@ int gjxo_score_grad(const gjx_program* prog, int64_t n, const float* choices, fl
   const int ns = prog->n_slots;
   char* sel = (char*)calloc((size_t)ns + 1, 1);
   for (int j = 0; j < prog->n_sites; ++j)
-    if (prog->sites[j].flags & GJX_SITE_HMC_SELECTED)
+    if ((prog->sites[j].flags & GJX_SITE_HMC_SELECTED) && prog->sites[j].slot >= 0)
       for (int d = 0; d < prog->sites[j].dim; ++d) sel[prog->sites[j].slot + d] = 1;
 #pragma omp parallel
   {
@@ -692,7 +721,7 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
   int nsel = 0, leaf = 0;
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
-    if (!(s->flags & GJX_SITE_HMC_SELECTED)) continue;
+    if (!(s->flags & GJX_SITE_HMC_SELECTED) || s->slot < 0) continue;
     for (int d = 0; d < s->dim; ++d) {
       selslot[nsel] = s->slot + d;
       leaf_of[nsel] = leaf; /* one momentum leaf per selected address, in program order */
@@ -710,14 +739,16 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
     float* p = (float*)malloc(sizeof(float) * (size_t)(nsel + 1));
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
-      okey ck = fold_in64(key, (uint64_t)(chain_offset + i));
+      const uint64_t gidx = (uint64_t)(chain_offset + i);
+      okey ck = fold_in64(key, gidx);
       okey knew = fold_in(ck, 0u), sub = fold_in(ck, 1u); /* key, sub_key = split(key)  hmc.py:167 */
       for (int s = 0; s < ns; ++s) old[s] = vals[s] = choices[(int64_t)s * n + i];
       float score0 = score_and_grad(prog, vals, g0); /* hmc.py:165-166 */
       float k0 = 0.0f;
       for (int m = 0; m < nsel; ++m) { /* sample_momenta hmc.py:120-130 */
-        okey lk = fold_in(sub, (uint32_t)leaf_of[m]);
-        p[m] = normal_from_bits(elem_bits(lk, (uint32_t)elem_of[m], prog->rng_mode));
+        const ostream ms = prog->rng_mode == GJX_RNG_JAX32 ? stream_from_site_key(fold_in(sub, (uint32_t)leaf_of[m]))
+                                                           : stream_open(GJX_RNG_FLAT, key, gidx, (uint32_t)leaf_of[m] + 1u);
+        p[m] = normal_from_bits(elem_bits(&ms, (uint32_t)elem_of[m]));
         k0 += -0.5f * p[m] * p[m] - HALF_LOG_2PI;
       }
       for (int s = 0; s < ns; ++s) g[s] = g0[s];
@@ -734,8 +765,9 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
       float al = sc - score0 + k1 - k0; /* hmc.py:196-203 */
       int acc = 1;
       if (accept) {
-        okey ak = fold_in(knew, 0x4d48u);
-        float lu = logf(bits_to_unit(elem_bits(ak, 0u, prog->rng_mode)));
+        const ostream as = prog->rng_mode == GJX_RNG_JAX32 ? stream_from_site_key(fold_in(knew, 0x4d48u))
+                                                           : stream_open(GJX_RNG_FLAT, key, gidx, GJX_FLAT_MAX_SITES);
+        float lu = logf(bits_to_unit(elem_bits(&as, 0u)));
         acc = lu < al; /* tests/inference/test_requests.py:134-137 */
       }
       if (!acc) { for (int s = 0; s < ns; ++s) vals[s] = old[s]; sc = score0; }

@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np, torch, ctypes
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genjax_amd import _abi as A, kernels as Kn
 from genjax_amd.program import SiteList, Param, PackedProgram
 from oracle import cpu, closed_form as cf
@@ -11,7 +11,7 @@ print("threefry", [hex(x) for x in t[0]], "expect c4923a9c 483df7a0")
 ref = np.array([cpu.threefry2x32(0x13198a2e, 0x03707344, 0x243f6a88, 0x85a308d3 + i) for i in range(4)], np.uint32)
 assert (t == ref).all()
 
-def gmm_prog(D=16, C=8, rng=A.RNG_PACKED):
+def gmm_prog(D=16, C=8, rng=A.RNG_FLAT):
     g = cf.gmm_problem(C=C, D=D)
     sl = SiteList()
     sl.add("z", A.CATEGORICAL_LOGITS, [g["logits"]])
@@ -25,7 +25,7 @@ def cmp(name, a, b, rtol=1e-4, atol=1e-4):
     print(f"  {name}: max err ratio {err.max():.3g}  maxabs {np.abs(a-b).max():.3g}")
     return err.max()
 
-for rng in (A.RNG_PACKED, A.RNG_JAX32):
+for rng in (A.RNG_FLAT, A.RNG_JAX32):
   for D in (16, 1):
     prog, g = gmm_prog(D=D, rng=rng)
     K = 10007

@@ -1,0 +1,85 @@
+"""Program builders shared by the CPU and GPU tests."""
+import numpy as np
+
+from genjax_amd import _abi as A
+from genjax_amd.program import PackedProgram, Param, SiteList
+from oracle import closed_form as cf
+
+KIND = dict(normal=A.NORMAL, flip=A.FLIP, bernoulli_logits=A.BERNOULLI_LOGITS, beta=A.BETA, uniform=A.UNIFORM,
+            exponential=A.EXPONENTIAL, half_normal=A.HALF_NORMAL, laplace=A.LAPLACE, log_normal=A.LOG_NORMAL,
+            cauchy=A.CAUCHY, gamma=A.GAMMA, mv_normal_diag=A.MVNORMAL_DIAG)
+NPAR = dict(normal=2, flip=1, bernoulli_logits=1, beta=2, uniform=2, exponential=1, half_normal=1, laplace=2,
+            log_normal=2, cauchy=2, gamma=2, mv_normal_diag=2)
+
+
+def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT):
+    sl = SiteList()
+    params = [a] if NPAR[kind] == 1 else [a, b]
+    sl.add("v", KIND[kind], params)
+    if obs is None:
+        return PackedProgram(sl, rng_mode=rng)
+    return PackedProgram(sl, {"v": A.MODE_OBS_TAB}, {"v": obs}, rng_mode=rng)
+
+
+def gmm(D=16, C=8, rng=A.RNG_FLAT, seed=0):
+    g = cf.gmm_problem(C=C, D=D, seed=seed)
+    sl = SiteList()
+    sl.add("z", A.CATEGORICAL_LOGITS, [g["logits"]])
+    sl.add("x", A.MVNORMAL_DIAG, [Param.gather(g["mu"], "z"), Param.gather(g["sigma"], "z")], dim=D)
+    sl.add("y", A.MVNORMAL_DIAG, [Param.value("x", D), Param.const(g["r"])], dim=D)
+    return PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": g["y"]}, rng_mode=rng), g
+
+
+def flip_flip(trivial: bool, rng=A.RNG_FLAT):
+    """tests/inference/test_smc.py:32-87 of the reference."""
+    sl = SiteList()
+    sl.add("x", A.FLIP, [0.5])
+    sl.add("y", A.FLIP, [0.7] if trivial else [Param.gather(np.array([0.3, 0.9], np.float32), "x")])
+    return PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": 1.0}, rng_mode=rng)
+
+
+def beta_bernoulli(obs: bool, rng=A.RNG_FLAT):
+    """README.md:89-102 of the reference."""
+    sl = SiteList()
+    sl.add("p", A.BETA, [2.0, 2.0])
+    sl.add("v", A.FLIP, [Param.value("p")])
+    return PackedProgram(sl, {"v": A.MODE_OBS_TAB}, {"v": float(obs)}, rng_mode=rng)
+
+
+def zoo(rng=A.RNG_FLAT, observed=()):
+    """One site of every distribution kind, chained through every parameter-expression form."""
+    sl = SiteList()
+    sl.add("n0", A.NORMAL, [0.5, 2.0])
+    sl.add("f0", A.FLIP, [0.3])
+    sl.add("c0", A.CATEGORICAL_PROBS, [np.array([0.2, 0.5, 0.3], np.float32)])
+    sl.add("n1", A.NORMAL, [Param.gather(np.array([-1.0, 0.0, 4.0], np.float32), "c0"), Param.value("n0", xf=A.XF_EXP)])
+    sl.add("b0", A.BETA, [2.0, 3.5])
+    sl.add("f1", A.FLIP, [Param.value("b0")])
+    sl.add("u0", A.UNIFORM, [-1.0, 3.0])
+    sl.add("bl", A.BERNOULLI_LOGITS, [Param.affine(np.array([[0.7]], np.float32), "u0", bias=-0.2)])
+    sl.add("mv", A.MVNORMAL_DIAG, [np.array([0.0, 1.0, 2.0], np.float32), np.array([1.0, 0.5, 2.0], np.float32)], dim=3)
+    sl.add("mv2", A.MVNORMAL_DIAG, [Param.affine(np.array([[1, 0, 1], [0, 2, 0]], np.float32), "mv", bias=[0.1, -0.1]),
+                                    Param.const([0.7])], dim=2)
+    sl.add("e0", A.EXPONENTIAL, [1.5])
+    sl.add("h0", A.HALF_NORMAL, [Param.value("e0", xf=A.XF_SOFTPLUS)])
+    sl.add("l0", A.LAPLACE, [Param.value("h0"), 0.8])
+    sl.add("ln", A.LOG_NORMAL, [0.2, 0.4])
+    sl.add("ca", A.CAUCHY, [Param.value("ln"), 2.0])
+    sl.add("g0", A.GAMMA, [2.5, 1.5])
+    sl.add("g1", A.GAMMA, [0.6, 2.0])
+    sl.add("cl", A.CATEGORICAL_LOGITS, [Param.affine(np.array([[1.0], [0.0], [-1.0], [0.5]], np.float32), "n0")])
+    sl.add("n2", A.NORMAL, [Param.value("ca", xf=A.XF_SIGMOID), 0.3])
+    obs_vals = dict(n2=0.4, mv2=[0.3, 1.9], f1=1.0, l0=0.9)
+    modes = {a: A.MODE_OBS_TAB for a in observed}
+    return PackedProgram(sl, modes, {a: obs_vals[a] for a in observed}, rng_mode=rng)
+
+
+def logreg(N=64, P=4, rng=A.RNG_FLAT, seed=0):
+    """BASELINE config 5 shape: log_tau ~ N(0,1); beta ~ N(0, exp(log_tau)); y ~ bernoulli(logits = X beta)."""
+    pr = cf.logreg_problem(N, P, seed)
+    sl = SiteList()
+    sl.add("log_tau", A.NORMAL, [0.0, 1.0])
+    sl.add("beta", A.NORMAL, [Param.const(0.0), Param.value("log_tau", xf=A.XF_EXP)], dim=P)
+    sl.add("y", A.BERNOULLI_LOGITS, [Param.affine(pr["X"], "beta")], dim=N)
+    modes = {"y": A.MODE_OBS_TAB, "log_tau": A.MODE_OBS_SLOT, "beta": A.MODE_OBS_SLOT}
+    return PackedProgram(sl, modes, {"y": pr["y"]}, selected=("log_tau", "beta"), rng_mode=rng), pr

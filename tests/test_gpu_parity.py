@@ -1,0 +1,377 @@
+"""GPU parity tests: every entry point of include/gjx.h, called through the C ABI, against the CPU oracle on the
+same seeded inputs, the committed golden fixtures, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (north_star: log-ML rtol 1e-4, "matching posterior estimates within stated FP tolerance"):
+  * integers — Threefry words, ancestor indices, fixed-point prefix sums, picked indices: BIT-EXACT
+  * float32 per-particle values (samples, log-pdfs, scores, weights): rtol 2e-4 / atol 5e-5 — the device uses the
+    hardware v_log/v_exp/v_rcp/v_sqrt approximations (≈1 ulp each) where the oracle uses libm
+  * reductions (log-sum-exp): rtol 2e-6 against a float64 accumulation
+  * discrete draws that hinge on a float comparison (categorical argmax, flip u<p, rejection samplers) may differ
+    from the oracle at near-ties: at most 1e-3 of the particles, every other particle within the float tolerance
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from genjax_amd import _abi as A
+from genjax_amd import core
+from genjax_amd.program import PackedProgram, Param, SiteList
+from oracle import closed_form as cf
+
+pytestmark = pytest.mark.gpu
+RNGS = [A.RNG_FLAT, A.RNG_JAX32]
+RT, AT = 2e-4, 5e-5
+
+
+@pytest.fixture(scope="module")
+def K_():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from genjax_amd import kernels
+    return kernels
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _close_cols(a, b, rt=RT, at=AT):
+    """per-particle mask: all rows within tolerance"""
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return (np.abs(a - b) <= at + rt * np.abs(b)).all(axis=0) | (np.isnan(a) & np.isnan(b)).all(axis=0)
+
+
+def assert_particles_match(gpu, ora, max_bad=1e-3, what=""):
+    ok = _close_cols(gpu["choices"], ora["choices"])
+    for k in ("score", "weight", "logw"):
+        ok &= _close_cols(gpu[k][None], ora[k][None])
+    bad = (~ok).sum()
+    assert bad <= max(0, int(max_bad * ok.size)), f"{what}: {bad}/{ok.size} particles differ from the oracle"
+    return ok
+
+
+def _run_both(K_, oracle, prog, key, K, **kw):
+    g = K_.run_program(prog, key, K, **kw)
+    o = oracle.run_program(prog, key, K, **kw)
+    gg = {k: _np(v) for k, v in g.items() if k in ("choices", "score", "weight", "logw", "lse", "site_scores") and v is not None}
+    return gg, o
+
+
+def test_library_is_the_hip_one(K_):
+    from genjax_amd import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "libgjx_hip.so" and _lib.load().gjx_version() == A.ABI_VERSION
+
+
+def test_threefry_bit_exact(K_, oracle, golden):
+    for v in golden["threefry_kat"]:
+        out = _np(K_.threefry2x32(tuple(v["key"]), 1, ctr_lo0=v["ctr"][1], ctr_hi=v["ctr"][0])).view(np.uint32)
+        assert list(out[0]) == v["out"]
+    n = 100_003
+    out = _np(K_.threefry2x32((0xDEADBEEF, 0x12345678), n, ctr_lo0=0xFFFFFF00, ctr_hi=7)).view(np.uint32)
+    for i in (0, 1, 255, 256, 257, n - 1):                 # crosses the 32-bit counter carry
+        c = (7 << 32) + 0xFFFFFF00 + i
+        assert tuple(out[i]) == oracle.threefry2x32(0xDEADBEEF, 0x12345678, c >> 32, c & 0xFFFFFFFF)
+
+
+def test_logpdf_table_gpu(K_, golden):
+    for row in golden["logpdf_table"]:
+        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"])
+        got = float(K_.run_program(prog, (0, 1), 1)["score"][0])
+        if row["neg_inf"]:
+            assert got == -math.inf, row
+        else:
+            assert got == pytest.approx(row["lp"], rel=1e-4, abs=1e-4), row
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("observed", [(), ("n2", "mv2", "f1", "l0")])
+def test_zoo_parity(K_, oracle, rng, observed):
+    """every distribution kind and parameter form through the generic interpreter"""
+    prog = H.zoo(rng, observed)
+    for K in (1, 77, 3000):
+        g, o = _run_both(K_, oracle, prog, (11, 22), K, want_site_scores=True)
+        ok = assert_particles_match(g, o, max_bad=2e-3 if K > 1000 else 0, what=f"zoo K={K}")
+        np.testing.assert_allclose(g["site_scores"][:, ok], o["site_scores"][:, ok], rtol=RT, atol=AT)
+        if not observed:
+            assert (g["weight"] == 0).all()
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_assess_and_reweight_parity(K_, oracle, rng):
+    """all sites constrained per particle (assess / ChangeTarget, smc.py:378-391): logw = w + logw_in - sub"""
+    sim = H.zoo(rng)
+    K = 2000
+    tr = oracle.run_program(sim, (1, 2), K)
+    sl = sim.site_list
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, rng_mode=rng)
+    rs = np.random.default_rng(0)
+    lin, sub = rs.standard_normal(K).astype(np.float32), rs.standard_normal(K).astype(np.float32)
+    import torch
+    g = K_.run_program(prog, (0, 0), K, choices=torch.as_tensor(tr["choices"]).cuda(), logw_in=torch.as_tensor(lin).cuda(),
+                       sub=torch.as_tensor(sub).cuda())
+    o = oracle.run_program(prog, (0, 0), K, choices=tr["choices"], logw_in=lin, sub=sub)
+    np.testing.assert_array_equal(_np(g["choices"]), tr["choices"])          # values untouched
+    np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=RT, atol=AT)
+    np.testing.assert_allclose(_np(g["logw"]), o["logw"], rtol=RT, atol=2e-4)
+    np.testing.assert_allclose(_np(g["score"]), tr["score"], rtol=RT, atol=2e-4)   # score(simulate) == assess(choices)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("shape", [(8, 16), (8, 1), (3, 2), (1, 4), (5, 64), (64, 8)])
+def test_gmm_fused_generic_oracle(K_, oracle, rng, shape, monkeypatch):
+    C, D = shape
+    prog, g = H.gmm(D=D, C=C, rng=rng)
+    for K in (1, 63, 1000, 4099):
+        o = oracle.run_program(prog, (0, 1), K)
+        res = {}
+        for force in ("1", "0"):
+            monkeypatch.setenv("GJX_FORCE_GENERIC", force)
+            assert K_.program_engine(prog) == (0 if force == "1" else 1)
+            r = K_.run_program(prog, (0, 1), K)
+            res[force] = {k: _np(v) for k, v in r.items() if k in ("choices", "score", "weight", "logw", "lse")}
+            assert_particles_match(res[force], o, max_bad=1e-3 if K > 500 else 0, what=f"gmm {shape} K={K} generic={force}")
+            np.testing.assert_allclose(res[force]["lse"][[0, 2, 3]], o["lse"][[0, 2, 3]], rtol=1e-5, atol=3e-4)
+            assert res[force]["lse"][0] + math.log(res[force]["lse"][1]) == pytest.approx(res[force]["lse"][2], abs=1e-3)
+        # fused and generic draw from the same counters: integer choices identical, floats within rounding
+        same = res["0"]["choices"][0] == res["1"]["choices"][0]
+        assert same.mean() >= 1 - 1e-3
+        np.testing.assert_allclose(res["0"]["choices"][:, same], res["1"]["choices"][:, same], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_sharding_and_determinism_bitwise(K_, rng, monkeypatch):
+    prog, _ = H.gmm(rng=rng)
+    K = 12_288
+    full = K_.run_program(prog, (4, 2), K)
+    again = K_.run_program(prog, (4, 2), K)
+    for k in ("choices", "score", "logw"):
+        np.testing.assert_array_equal(_np(full[k]), _np(again[k]))
+    a = K_.run_program(prog, (4, 2), 4096, offset=0, K_total=K)
+    b = K_.run_program(prog, (4, 2), 8192, offset=4096, K_total=K)
+    np.testing.assert_array_equal(np.concatenate([_np(a["choices"]), _np(b["choices"])], axis=1), _np(full["choices"]))
+    np.testing.assert_array_equal(np.concatenate([_np(a["logw"]), _np(b["logw"])]), _np(full["logw"]))
+    # global LSE from the two shards' {max, sumexp} pairs
+    import torch
+    comb = K_.lse_combine(torch.stack([a["lse"][:2], b["lse"][:2]]).contiguous(), K)
+    np.testing.assert_allclose(_np(comb), _np(full["lse"]), rtol=2e-6, atol=2e-6)
+    # launch geometry must not change a single per-particle bit
+    for ppt in ("1", "2"):
+        monkeypatch.setenv("GJX_GMM_PPT", ppt)
+        other = K_.run_program(prog, (4, 2), K)
+        for k in ("choices", "score", "logw"):
+            np.testing.assert_array_equal(_np(full[k]), _np(other[k]))
+    # particle indices beyond 2^32 (FLAT folds the high word into the key; JAX32 uses a 64-bit counter)
+    big = K_.run_program(prog, (4, 2), 300, offset=(1 << 32) + 5)
+    monkeypatch.setenv("GJX_FORCE_GENERIC", "1")
+    big_g = K_.run_program(prog, (4, 2), 300, offset=(1 << 32) + 5)
+    np.testing.assert_array_equal(_np(big["choices"][0]), _np(big_g["choices"][0]))
+
+
+def test_gmm_full_size(K_, golden):
+    """BASELINE config 2 at K = 2^20: log-ML against the closed form (north_star rtol 1e-4) + invariants."""
+    import torch
+    prog, g = H.gmm()
+    K = 1 << 20
+    exact = golden["closed_form"]["gmm_c8_d16_seed0"]
+    out = K_.run_program(prog, (0, 1), K)
+    lml = float(out["lse"][3])
+    assert lml == pytest.approx(exact, rel=1e-4)
+    lw = out["logw"].double()
+    assert float(out["lse"][2]) == pytest.approx(float(torch.logsumexp(lw, 0)), rel=2e-6)
+    l2 = K_.logsumexp(out["logw"])
+    np.testing.assert_allclose(_np(l2), _np(out["lse"]), rtol=2e-6, atol=2e-6)
+    # weight is the observed site's log-density of the stored x: recompute it in float64 on the host
+    x = out["choices"][1:].double()
+    y = torch.as_tensor(g["y"], dtype=torch.float64, device=x.device)[:, None]
+    want = (-0.5 * ((y - x) / 4.0) ** 2 - math.log(4.0) - 0.5 * math.log(2 * math.pi)).sum(0)
+    assert float((out["weight"].double() - want).abs().max()) < 2e-4
+    # prior part: score - weight = log p(z) + log N(x; mu_z, sigma_z)
+    z = out["choices"][0].long()
+    mu = torch.as_tensor(g["mu"], dtype=torch.float64, device=x.device)[z].t()
+    lp = torch.log_softmax(torch.as_tensor(g["logits"], dtype=torch.float64, device=x.device), 0)[z]
+    prior = lp + (-0.5 * (x - mu) ** 2 - 0.5 * math.log(2 * math.pi)).sum(0)
+    assert float(((out["score"] - out["weight"]).double() - prior).abs().max()) < 3e-4
+    # component frequencies follow softmax(logits)
+    freq = torch.bincount(z, minlength=8).double() / K
+    np.testing.assert_allclose(_np(freq), np.exp(g["logits"] - cf.logsumexp(g["logits"])), atol=4e-3)
+    # posterior over z from the weights
+    w = torch.exp(lw - out["lse"][2].double())
+    pz = torch.zeros(8, dtype=torch.float64, device=x.device).index_add_(0, z, w)
+    np.testing.assert_allclose(_np(pz), cf.gmm_posterior_z(**g), atol=5e-3)
+
+
+def test_logsumexp_gpu(K_, oracle):
+    import torch
+    for K in (1, 2, 255, 256, 257, 100_003, 3_000_001):
+        x = (np.random.default_rng(K).standard_normal(K) * 20).astype(np.float32)
+        x[:: max(1, K // 7)] = -np.inf
+        got = _np(K_.logsumexp(torch.as_tensor(x).cuda(), K_total=2 * K))
+        want = oracle.logsumexp(x, 2 * K)
+        if np.isneginf(want[2]):
+            assert np.isneginf(got[2])
+        else:
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+    allinf = torch.full((1000,), -float("inf")).cuda()
+    assert np.isneginf(_np(K_.logsumexp(allinf))[2])
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_categorical_pick_parity(K_, oracle, rng):
+    import torch
+    for K, off in ((1, 0), (1000, 0), (300_001, 12_345)):
+        lw = (np.random.default_rng(K).standard_normal(K) * 3).astype(np.float32)
+        l4 = oracle.logsumexp(lw)
+        for key in ((5, 6), (7, 8), (9, 10)):
+            out = _np(K_.categorical_pick(torch.as_tensor(lw).cuda(), torch.as_tensor(l4).cuda(), key, rng, off))
+            bv, bi = oracle.categorical_pick(lw, l4, key, rng, off)
+            assert int(out[1]) == bi                                   # index: exact
+            assert float(out.view(np.float32)[0]) == pytest.approx(bv, rel=1e-5, abs=1e-5)
+
+
+def test_resampling_bit_exact(K_, oracle):
+    import torch
+    for K in (1, 5, 2048, 2049, 70_001, 1 << 20):
+        rs = np.random.default_rng(K)
+        lw = rs.standard_normal(K) * (4.0 if K % 2 else 1.0)
+        w = np.exp(lw - lw.max()).astype(np.float32)
+        wd = torch.as_tensor(w).cuda()
+        cum, tot = K_.weight_cumsum(wd)
+        cum_o, tot_o = oracle.weight_cumsum(w)
+        np.testing.assert_array_equal(_np(cum).view(np.uint64), cum_o)
+        assert int(tot.item()) == tot_o
+        bt = torch.tensor([0, tot_o], dtype=torch.int64).cuda()
+        for N, u in ((K, 0.37), (max(1, K // 3), 0.0), (2 * K + 1, 0.999999)):
+            anc = _np(K_.resample_systematic(cum, bt, u, N))
+            np.testing.assert_array_equal(anc, oracle.resample_systematic(cum_o, u, N))
+            assert anc.min() >= 0 and (np.diff(anc) >= 0).all()
+        anc_m = _np(K_.resample_multinomial(cum, bt, (7, 8), K))
+        np.testing.assert_array_equal(anc_m, oracle.resample_multinomial(cum_o, (7, 8), K))
+        # windows of output slots and a second rank's view of the global weight line
+        if K > 100:
+            np.testing.assert_array_equal(_np(K_.resample_systematic(cum, bt, 0.5, K, out_begin=17, n_out=50)),
+                                          oracle.resample_systematic(cum_o, 0.5, K)[17:67])
+            bt2 = torch.tensor([tot_o // 3, 2 * tot_o], dtype=torch.int64).cuda()
+            np.testing.assert_array_equal(_np(K_.resample_systematic(cum, bt2, 0.25, K)),
+                                          oracle.resample_systematic(cum_o, 0.25, K, base=tot_o // 3, total_all=2 * tot_o))
+        rows = rs.standard_normal((3, K)).astype(np.float32)
+        anc_t = K_.resample_systematic(cum, bt, 0.37, K)
+        np.testing.assert_array_equal(_np(K_.gather_rows(torch.as_tensor(rows).cuda(), anc_t)), oracle.gather_rows(rows, _np(anc_t)))
+    # log-weight input: same as normalising on the device first, bit for bit
+    lwd = torch.as_tensor(lw.astype(np.float32)).cuda()
+    l4 = K_.logsumexp(lwd)
+    cum_a, tot_a = K_.weight_cumsum(lwd, True, l4)
+    # fixed-point conversion of exp(x - max) evaluated by the same device exp
+    assert int(tot_a.item()) == int(cum_a[-1].item())
+    anc_a = _np(K_.resample_systematic(cum_a, torch.cat([tot_a.new_zeros(1), tot_a]), 0.1, K))
+    counts = np.bincount(anc_a, minlength=K)
+    wn = np.exp(lw - cf.logsumexp(lw))
+    assert np.abs(counts - K * wn).max() <= 1.01
+
+
+def test_degenerate_and_invalid_arguments(K_):
+    import torch
+    from genjax_amd._lib import GjxError
+    w = torch.zeros(1000).cuda()
+    w[123] = 1.0
+    cum, tot = K_.weight_cumsum(w)
+    bt = torch.cat([tot.new_zeros(1), tot])
+    assert (K_.resample_systematic(cum, bt, 0.9999, 1000) == 123).all()
+    assert (K_.resample_multinomial(cum, bt, (1, 2), 1000) == 123).all()
+    with pytest.raises(GjxError):
+        K_.resample_systematic(cum, bt, 1.5, 1000)                      # u outside [0,1)
+    with pytest.raises(GjxError):
+        K_.logsumexp(torch.zeros(8).cuda(), ws=torch.empty(8, dtype=torch.uint8).cuda())   # workspace too small
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_ssm_step_parity(K_, oracle, rng):
+    import torch
+    rs = np.random.default_rng(3)
+    for dx, dy, useH in ((8, 8, False), (4, 3, True), (2, 2, False), (16, 5, True)):
+        Am = (rs.standard_normal((dx, dx)) * 0.3).astype(np.float32)
+        Hm = rs.standard_normal((dy, dx)).astype(np.float32) if useH else None
+        y = rs.standard_normal((2, dy)).astype(np.float32)
+        from genjax_amd.inference.pf import LinearGaussianSSM
+        m = LinearGaussianSSM(Am, 0.5, 2.0, Hm, 1.0)
+        cs = m.c_struct("cuda")
+        K = 5001
+        x0, lw0, l0 = K_.ssm_step(cs, (1, 2), rng, 0, K, None, None, torch.as_tensor(y[0]).cuda())
+        xo, lwo, lo = oracle.ssm_step(Am, Hm, 0.5, 2.0, 1.0, (1, 2), rng, 0, K, None, None, y[0])
+        np.testing.assert_allclose(_np(x0), xo, rtol=RT, atol=AT)
+        np.testing.assert_allclose(_np(lw0), lwo, rtol=RT, atol=2e-4)
+        np.testing.assert_allclose(_np(l0), lo, rtol=1e-4, atol=1e-4)
+        anc = rs.integers(0, K, K).astype(np.int32)
+        x1, lw1, l1 = K_.ssm_step(cs, (3, 4), rng, 1, K, x0, torch.as_tensor(anc).cuda(), torch.as_tensor(y[1]).cuda(), offset=77)
+        x1o, lw1o, l1o = oracle.ssm_step(Am, Hm, 0.5, 2.0, 1.0, (3, 4), rng, 1, K, _np(x0), anc, y[1], offset=77)
+        np.testing.assert_allclose(_np(x1), x1o, rtol=RT, atol=AT)
+        np.testing.assert_allclose(_np(lw1), lw1o, rtol=RT, atol=2e-4)
+        np.testing.assert_allclose(_np(l1), l1o, rtol=1e-4, atol=1e-4)
+
+
+def test_bootstrap_filter_full_size(K_, golden):
+    """BASELINE config 3: T=256, K=2^18, systematic resampling every step; log-ML vs the float64 Kalman filter."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem()
+    exact = golden["closed_form"]["ssm_dx8_T256_seed0"]
+    kl, incs, means = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
+    assert kl == pytest.approx(exact, rel=1e-12)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18)
+    out = bf.run(core.key(1), s["y"], keep_means=True)
+    assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
+    np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
+    np.testing.assert_allclose(_np(out["means"]), means, atol=0.15)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_score_grad_and_hmc_parity(K_, oracle, rng):
+    import torch
+    prog, pr = H.logreg(N=64, P=4, rng=rng)
+    rs = np.random.default_rng(2)
+    n = 777
+    ch = (rs.standard_normal((5, n)) * 0.3).astype(np.float32)
+    sg, gg = K_.score_grad(prog, torch.as_tensor(ch).cuda())
+    so, go = oracle.score_grad(prog, ch)
+    np.testing.assert_allclose(_np(sg), so, rtol=RT, atol=2e-4)
+    np.testing.assert_allclose(_np(gg), go, rtol=5e-4, atol=5e-4)
+    for stale in (False, True):
+        g = K_.hmc(prog, (1, 5), torch.as_tensor(ch).cuda(), 0.01, 25, stale, False, offset=3)
+        o = oracle.hmc(prog, (1, 5), ch, 0.01, 25, stale, False, offset=3)
+        np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=5e-3)
+        assert (_np(g["accepted"]) == 1).all()
+    # fused MH rule: a step size that rejects a fair share of the chains
+    g = K_.hmc(prog, (1, 5), torch.as_tensor(ch).cuda(), 0.2, 20, False, True, offset=3)
+    o = oracle.hmc(prog, (1, 5), ch, 0.2, 20, False, True, offset=3)
+    acc_g, acc_o = _np(g["accepted"]), o["accepted"]
+    assert (acc_g == acc_o).mean() > 0.97                      # near-threshold chains may flip
+    rej = acc_g == 0
+    assert 0.05 * n < rej.sum() < 0.6 * n
+    np.testing.assert_array_equal(_np(g["choices"])[:, rej], ch[:, rej])          # rejected chains are restored bit for bit
+    s_old, _ = K_.score_grad(prog, torch.as_tensor(ch).cuda())
+    np.testing.assert_array_equal(_np(g["score"])[rej], _np(s_old)[rej])
+    both = (acc_g == 1) & (acc_o == 1) & (np.abs(o["alpha"]) < 0.5)
+    np.testing.assert_allclose(_np(g["choices"])[:, both], o["choices"][:, both], rtol=3e-2, atol=3e-2)
+
+
+def test_hmc_all_kinds_gradient(K_, oracle):
+    import torch
+    sl = SiteList()
+    sl.add("a", A.NORMAL, [0.3, 1.2])
+    sl.add("h", A.HALF_NORMAL, [Param.value("a", xf=A.XF_SOFTPLUS)])
+    sl.add("l", A.LAPLACE, [Param.value("a"), Param.value("h", xf=A.XF_EXP)])
+    sl.add("c", A.CAUCHY, [Param.affine(np.array([[0.5]], np.float32), "l", bias=0.1), 1.3])
+    sl.add("ln", A.LOG_NORMAL, [Param.value("c", xf=A.XF_SIGMOID), 0.7])
+    sl.add("e", A.EXPONENTIAL, [Param.value("ln")])
+    sl.add("g", A.GAMMA, [2.0, Param.value("e", xf=A.XF_SOFTPLUS)])
+    sl.add("b", A.BETA, [2.0, 3.0])
+    sl.add("y", A.BERNOULLI_LOGITS, [Param.value("b")])
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=tuple(s.addr for s in sl.sites if s.addr != "y"))
+    vals = np.array([[0.4], [0.8], [0.1], [0.9], [1.3], [0.6], [1.7], [0.35], [1.0]], np.float32)
+    sg, gg = K_.score_grad(prog, torch.as_tensor(vals).cuda())
+    so, go = oracle.score_grad(prog, vals)
+    np.testing.assert_allclose(_np(sg), so, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_np(gg), go, rtol=1e-3, atol=1e-3)

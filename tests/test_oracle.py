@@ -1,0 +1,441 @@
+"""CPU tests of the oracle itself: it must be pinned before anything is compared with it.
+
+Pins: Random123 KATs, scipy.stats log-pdf tables, scipy erfinv, and the closed-form / tolerance checks
+the reference's own tests hold for this path (tests/inference/test_smc.py:32-87,
+tests/generative_functions/test_distributions.py:25-60, test_static_gen_fn.py:441-490, README.md:89-123).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import helpers as H
+from genjax_amd import _abi as A
+from genjax_amd import core
+from genjax_amd.program import PackedProgram, Param, SiteList
+from oracle import closed_form as cf
+
+RNGS = [A.RNG_FLAT, A.RNG_JAX32]
+
+
+def test_threefry_kat(oracle, golden):
+    for v in golden["threefry_kat"]:
+        assert list(oracle.threefry2x32(*v["key"], *v["ctr"])) == v["out"]
+        assert list(core.threefry2x32(*v["key"], *v["ctr"])) == v["out"]   # host-side key splits use the same hash
+
+
+def test_key_derivation_matches_jax_layout(oracle):
+    # key(seed) == (0, seed); split(k, n)[i] == fold_in(k, i) == Threefry(k, (0, i))
+    k = core.key(314159)
+    assert k == (0, 314159)
+    assert core.split(k, 3) == [core.fold_in(k, i) for i in range(3)]
+    assert core.fold_in(k, 7) == oracle.threefry2x32(k[0], k[1], 0, 7)
+
+
+def test_logpdf_table(oracle, golden):
+    for row in golden["logpdf_table"]:
+        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"])
+        out = oracle.run_program(prog, (0, 1), 1)
+        got = float(out["score"][0])
+        if row["neg_inf"]:
+            assert got == -math.inf, row
+        else:
+            assert got == pytest.approx(row["lp"], rel=3e-5, abs=3e-5), row
+        # constrained site: weight == score (distribution.py:144-147)
+        assert out["weight"][0] == out["score"][0]
+
+
+def test_categorical_log_softmax(oracle, golden):
+    for row in golden["categorical_table"]:
+        for kind, par in ((A.CATEGORICAL_LOGITS, row["logits"]), (A.CATEGORICAL_PROBS, np.exp(row["log_softmax"]))):
+            for k, want in enumerate(row["log_softmax"]):
+                sl = SiteList()
+                sl.add("c", kind, [np.asarray(par, np.float32)])
+                prog = PackedProgram(sl, {"c": A.MODE_OBS_TAB}, {"c": float(k)})
+                assert float(oracle.run_program(prog, (0, 1), 1)["score"][0]) == pytest.approx(want, rel=2e-5, abs=2e-5)
+
+
+def test_erfinv_table(oracle, golden):
+    t = golden["erfinv_table"]
+    for x, y in zip(t["x"], t["y"]):
+        assert float(np.float32(x)) == x                     # table inputs are exact float32 values
+        got = float(oracle.lib().gjxo_erfinv(np.float32(x)))
+        # Giles' polynomial: ~3e-7 relative in the centre; float32 cancellation in 1 - x*x costs more in the tails
+        assert got == pytest.approx(y, rel=2e-6 if abs(x) < 0.99 else 3e-5, abs=1e-9)
+
+
+def test_uniform_bits_mapping(oracle):
+    L = oracle.lib()
+    assert L.gjxo_unit_from_bits(0) == 0.0
+    assert L.gjxo_unit_from_bits(0xFFFFFFFF) == pytest.approx(1.0 - 2.0 ** -23)
+    assert L.gjxo_unit_from_bits(1 << 31) == 0.5
+    assert math.isfinite(L.gjxo_normal_from_bits(0)) and math.isfinite(L.gjxo_normal_from_bits(0xFFFFFFFF))
+    assert math.isfinite(L.gjxo_gumbel_from_bits(0)) and math.isfinite(L.gjxo_gumbel_from_bits(0xFFFFFFFF))
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_sampler_moments(oracle, rng):
+    K = 200_000
+    cases = [
+        ("normal", 1.5, 2.0, 1.5, 4.0), ("flip", 0.3, None, 0.3, 0.21), ("bernoulli_logits", 0.4, None, 1 / (1 + math.exp(-0.4)), None),
+        ("beta", 2.0, 3.5, 2 / 5.5, 2 * 3.5 / (5.5 ** 2 * 6.5)), ("beta", 0.5, 0.5, 0.5, 0.125), ("uniform", -1.0, 3.0, 1.0, 16 / 12),
+        ("exponential", 1.5, None, 1 / 1.5, 1 / 2.25), ("half_normal", 2.0, None, 2.0 * math.sqrt(2 / math.pi), 4 * (1 - 2 / math.pi)),
+        ("laplace", 0.5, 0.8, 0.5, 2 * 0.64), ("log_normal", 0.2, 0.4, math.exp(0.2 + 0.08), None),
+        ("gamma", 2.5, 1.5, 2.5 / 1.5, 2.5 / 2.25), ("gamma", 0.6, 2.0, 0.3, 0.15),
+    ]
+    for kind, a, b, mean, var in cases:
+        out = oracle.run_program(H.one_site(kind, a, b, rng=rng), (3, 4), K)
+        v = out["choices"][0].astype(np.float64)
+        sd = math.sqrt(var) if var else v.std()
+        assert abs(v.mean() - mean) < 5 * sd / math.sqrt(K) + 1e-6, (kind, a, b, v.mean(), mean)
+        if var:
+            assert v.var() == pytest.approx(var, rel=0.03), (kind, a, b)
+        assert (out["weight"] == 0).all()          # unconstrained: weight 0 (distribution.py:125-127)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_streams_are_shard_independent(oracle, rng):
+    prog = H.zoo(rng, observed=("n2",))
+    full = oracle.run_program(prog, (9, 9), 1000)
+    a = oracle.run_program(prog, (9, 9), 400, offset=0)
+    b = oracle.run_program(prog, (9, 9), 600, offset=400)
+    np.testing.assert_array_equal(np.concatenate([a["choices"], b["choices"]], axis=1), full["choices"])
+    np.testing.assert_array_equal(np.concatenate([a["logw"], b["logw"]]), full["logw"])
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_score_of_simulate_equals_assess(oracle, rng):
+    """tests/generative_functions/test_distributions.py:25-28; test_static_gen_fn.py:441-490."""
+    sim = H.zoo(rng)
+    tr = oracle.run_program(sim, (1, 2), 500, want_site_scores=True)
+    assert (tr["weight"] == 0).all()
+    # assess: every site constrained per particle to the simulated values
+    sl = sim.site_list
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, rng_mode=rng)
+    ass = oracle.run_program(prog, (0, 0), 500, choices=tr["choices"], want_site_scores=True)
+    np.testing.assert_allclose(ass["score"], tr["score"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ass["weight"], ass["score"], rtol=0, atol=0)
+    np.testing.assert_array_equal(ass["choices"], tr["choices"])
+    # importance: weight is the sum of the constrained sites' scores only
+    obs = ("n2", "mv2", "f1")
+    imp = oracle.run_program(H.zoo(rng, observed=obs), (1, 2), 500, want_site_scores=True)
+    idx = [j for j, s in enumerate(sl.sites) if s.addr in obs]
+    np.testing.assert_allclose(imp["weight"], imp["site_scores"][idx].sum(axis=0), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(imp["score"], imp["site_scores"].sum(axis=0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_flip_flip_trivial_log_ml(oracle, golden, rng):
+    """reference tests/inference/test_smc.py:32-57 — every weight is exactly log 0.7."""
+    exact = golden["closed_form"]["flip_flip_trivial"]
+    for K in (1, 1000):
+        out = oracle.run_program(H.flip_flip(True, rng), core.key(314159), K)
+        assert float(out["lse"][3]) == pytest.approx(exact, rel=1e-3 if K > 1 else 1e-1)
+        assert np.allclose(out["logw"], exact, rtol=1e-6)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_flip_flip_log_ml(oracle, golden, rng):
+    """reference tests/inference/test_smc.py:59-87 (K=2000, rel 1e-1) and a tighter large-K check."""
+    exact = golden["closed_form"]["flip_flip"]
+    out = oracle.run_program(H.flip_flip(False, rng), core.key(314159), 2000)
+    assert float(out["lse"][3]) == pytest.approx(exact, rel=1e-1)
+    out = oracle.run_program(H.flip_flip(False, rng), core.key(314159), 1 << 18)
+    assert float(out["lse"][3]) == pytest.approx(exact, rel=5e-3)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("obs", [True, False])
+def test_beta_bernoulli(oracle, golden, rng, obs):
+    """README.md:89-123: log-ML -> log 1/2, posterior mean of p -> 0.6 / 0.4."""
+    K = 1 << 18
+    out = oracle.run_program(H.beta_bernoulli(obs, rng), core.key(314159), K)
+    assert float(out["lse"][3]) == pytest.approx(math.log(0.5), rel=5e-3)
+    w = np.exp(out["logw"].astype(np.float64) - out["lse"][2])
+    post = float((w * out["choices"][0]).sum())
+    assert post == pytest.approx(0.6 if obs else 0.4, abs=5e-3)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_gmm_log_ml(oracle, golden, rng):
+    prog, g = H.gmm(rng=rng)
+    exact = golden["closed_form"]["gmm_c8_d16_seed0"]
+    assert cf.gmm_log_ml(**g) == pytest.approx(exact, rel=1e-12)
+    K = 1 << 18
+    out = oracle.run_program(prog, (0, 1), K)
+    assert float(out["lse"][3]) == pytest.approx(exact, rel=3e-4)        # MC error ~ 1.15/sqrt(K)/43.8 = 5e-5
+    # posterior over the component index
+    w = np.exp(out["logw"].astype(np.float64) - out["lse"][2])
+    pz = np.bincount(out["choices"][0].astype(int), weights=w, minlength=8)
+    np.testing.assert_allclose(pz, cf.gmm_posterior_z(**g), atol=0.01)
+
+
+def test_logsumexp_edge_cases(oracle):
+    x = np.array([-np.inf, -np.inf], np.float32)
+    assert oracle.logsumexp(x)[2] == -np.inf
+    x = np.array([1000.0, 1000.0, -np.inf], np.float32)
+    assert oracle.logsumexp(x)[2] == pytest.approx(1000.0 + math.log(2.0))
+    x = np.random.default_rng(0).standard_normal(100_003).astype(np.float32) * 30
+    assert oracle.logsumexp(x)[2] == pytest.approx(cf.logsumexp(x), rel=1e-6)
+
+
+# ---- resampling ------------------------------------------------------------------------------
+def _weights(K, seed=0, heavy=False):
+    r = np.random.default_rng(seed)
+    lw = r.standard_normal(K) * (6.0 if heavy else 1.0)
+    w = np.exp(lw - lw.max()).astype(np.float32)
+    return w
+
+
+def test_weight_cumsum_exact(oracle):
+    for K in (1, 7, 2048, 2049, 100_000):
+        w = _weights(K, K)
+        cum, tot = oracle.weight_cumsum(w)
+        q = (w.astype(np.float32) * np.float32(2 ** 30)).astype(np.uint64)
+        np.testing.assert_array_equal(cum, np.cumsum(q, dtype=np.uint64))
+        assert tot == int(q.sum())
+    w = np.array([0.0, -1.0, np.nan, 0.5], np.float32)          # non-positive / NaN weights count as zero
+    cum, tot = oracle.weight_cumsum(w)
+    assert list(cum) == [0, 0, 0, 2 ** 29] and tot == 2 ** 29
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_systematic_properties(oracle, heavy):
+    K = 50_000
+    w = _weights(K, 3, heavy)
+    cum, tot = oracle.weight_cumsum(w)
+    for N in (K, 1234, 3 * K):
+        anc = oracle.resample_systematic(cum, 0.37, N)
+        assert anc.min() >= 0 and anc.max() < K and (np.diff(anc) >= 0).all()      # all assigned, sorted
+        counts = np.bincount(anc, minlength=K)
+        expect = N * (w.astype(np.float64) * 2 ** 30).astype(np.uint64) / tot
+        assert np.abs(counts - expect).max() <= 1.0 + 1e-6                          # systematic: |n_i - N w_i| <= 1
+    # sharding: two ranks on the global weight line reproduce the global answer
+    k0 = 20_000
+    c0, t0 = oracle.weight_cumsum(w[:k0])
+    c1, t1 = oracle.weight_cumsum(w[k0:])
+    assert t0 + t1 == tot
+    glob = oracle.resample_systematic(cum, 0.91, K)
+    a0 = oracle.resample_systematic(c0, 0.91, K, base=0, total_all=tot)
+    a1 = oracle.resample_systematic(c1, 0.91, K, base=t0, total_all=tot)
+    assert ((a0 >= 0) ^ (a1 >= 0)).all()
+    merged = np.where(a0 >= 0, a0, a1 + k0)
+    np.testing.assert_array_equal(merged, glob)
+    # a window of output slots equals the same window of the full answer
+    np.testing.assert_array_equal(oracle.resample_systematic(cum, 0.91, K, out_begin=777, n_out=5000), glob[777:5777])
+
+
+def test_degenerate_weights(oracle):
+    w = np.zeros(1000, np.float32)
+    w[123] = 1.0
+    cum, tot = oracle.weight_cumsum(w)
+    assert (oracle.resample_systematic(cum, 0.999999, 1000) == 123).all()
+    assert (oracle.resample_multinomial(cum, (1, 2), 1000) == 123).all()
+
+
+def test_multinomial_chi2(oracle):
+    K, N = 64, 400_000
+    w = _weights(K, 5)
+    cum, tot = oracle.weight_cumsum(w)
+    anc = oracle.resample_multinomial(cum, (11, 12), N)
+    assert anc.min() >= 0
+    p = (w.astype(np.float64) * 2 ** 30).astype(np.uint64) / tot
+    counts = np.bincount(anc, minlength=K)
+    chi2 = ((counts - N * p) ** 2 / (N * p)).sum()
+    assert chi2 < 63 + 6 * math.sqrt(2 * 63)
+    np.testing.assert_array_equal(oracle.resample_multinomial(cum, (11, 12), N, out_begin=1000, n_out=500), anc[1000:1500])
+
+
+def test_categorical_pick_distribution(oracle):
+    K = 16
+    lw = np.log(_weights(K, 8).astype(np.float64) + 1e-3).astype(np.float32)
+    l4 = oracle.logsumexp(lw)
+    p = np.exp(lw.astype(np.float64) - l4[2])
+    for rng in RNGS:
+        counts = np.zeros(K)
+        T = 20000
+        for t in range(T):
+            _, idx = oracle.categorical_pick(lw, l4, (t, 77), rng)
+            counts[idx] += 1
+        chi2 = ((counts - T * p) ** 2 / (T * p)).sum()
+        assert chi2 < 15 + 6 * math.sqrt(30), rng
+
+
+def test_gather_rows(oracle):
+    src = np.arange(12, dtype=np.float32).reshape(3, 4)
+    out = oracle.gather_rows(src, np.array([3, 3, 0, -1], np.int32))
+    np.testing.assert_array_equal(out, [[3, 3, 0, 0], [7, 7, 4, 0], [11, 11, 8, 0]])
+
+
+# ---- state-space model -------------------------------------------------------------------------
+@pytest.mark.parametrize("rng", RNGS)
+def test_bootstrap_filter_vs_kalman(oracle, rng):
+    s = cf.ssm_problem(T=24)
+    exact, incs, means = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
+    K = 1 << 15
+    key = core.key(1)
+    x, lw, lse, total = None, None, None, 0.0
+    for t in range(24):
+        key = core.fold_in(key, t)
+        kp, kr = core.split(key)
+        anc = None
+        if t > 0:
+            cum, _ = oracle.weight_cumsum(lw, True, lse)
+            anc = oracle.resample_systematic(cum, 0.5, K)
+        x, lw, lse = oracle.ssm_step(s["A"], None, s["q"], s["r"], 1.0, kp, rng, t, K, x, anc, s["y"][t])
+        total += float(lse[3])
+    assert total == pytest.approx(exact, rel=3e-3)
+    w = np.exp(lw.astype(np.float64) - lse[2])
+    np.testing.assert_allclose((x * w).sum(axis=1), means[-1], atol=0.08)
+
+
+def test_ssm_step_general_H_matches_program(oracle):
+    """The fused SSM step is the two-site program  x ~ N(A x_prev, q), y ~ N(H x, r)  (JAX32 stream: same keys)."""
+    rs = np.random.default_rng(0)
+    dx, dy, K = 4, 3, 257
+    Am = rs.standard_normal((dx, dx)).astype(np.float32) * 0.4
+    Hm = rs.standard_normal((dy, dx)).astype(np.float32)
+    y = rs.standard_normal(dy).astype(np.float32)
+    xprev = rs.standard_normal((dx, K)).astype(np.float32)
+    for rng in RNGS:
+        x1, lw1, _ = oracle.ssm_step(Am, Hm, 0.5, 2.0, 1.0, (5, 6), rng, 1, K, xprev, None, y)
+        sl = SiteList()
+        sl.add("xp", A.MVNORMAL_DIAG, [np.zeros(dx, np.float32), np.ones(dx, np.float32)], dim=dx)
+        sl.add("x", A.MVNORMAL_DIAG, [Param.affine(Am, "xp"), Param.const([0.5])], dim=dx)
+        sl.add("y", A.MVNORMAL_DIAG, [Param.affine(Hm, "x"), Param.const([2.0])], dim=dy)
+        # site "x" must be site 1 for the stream to line up, so constrain xp per particle and re-index: build
+        # the equivalent program with x first instead
+        sl2 = SiteList()
+        sl2.add("x", A.MVNORMAL_DIAG, [Param.const(np.zeros(dx, np.float32)), Param.const([0.5])], dim=dx)
+        prog = PackedProgram(sl2, rng_mode=rng)
+        eps = oracle.run_program(prog, (5, 6), K)["choices"]           # x - A xprev, same draws
+        np.testing.assert_allclose(x1, Am @ xprev + eps, rtol=2e-6, atol=2e-6)
+        want = cf.log_normal_pdf(y[:, None], Hm.astype(np.float64) @ x1.astype(np.float64), 2.0).sum(axis=0)
+        np.testing.assert_allclose(lw1, want, rtol=2e-5, atol=2e-5)
+
+
+# ---- HMC -----------------------------------------------------------------------------------------
+def test_score_grad_vs_finite_differences(oracle):
+    prog, pr = H.logreg(N=32, P=3)
+    rs = np.random.default_rng(1)
+    n = 5
+    ch = rs.standard_normal((4, n)).astype(np.float32) * 0.5
+    score, grad = oracle.score_grad(prog, ch)
+    for i in range(n):
+        want = cf.logreg_log_joint(ch[0, i], ch[1:, i], pr["X"], pr["y"])
+        assert float(score[i]) == pytest.approx(want, rel=2e-5, abs=2e-5)
+        for s in range(4):
+            h = 1e-4
+            cp, cm = ch[:, i].astype(np.float64).copy(), ch[:, i].astype(np.float64).copy()
+            cp[s] += h
+            cm[s] -= h
+            fd = (cf.logreg_log_joint(cp[0], cp[1:], pr["X"], pr["y"]) - cf.logreg_log_joint(cm[0], cm[1:], pr["X"], pr["y"])) / (2 * h)
+            assert float(grad[s, i]) == pytest.approx(fd, rel=2e-3, abs=2e-3)
+
+
+def test_score_grad_all_kinds(oracle):
+    """Analytic d logpdf / d value and / d params against float64 finite differences of the oracle's own score."""
+    sl = SiteList()
+    sl.add("a", A.NORMAL, [0.3, 1.2])
+    sl.add("h", A.HALF_NORMAL, [Param.value("a", xf=A.XF_SOFTPLUS)])
+    sl.add("l", A.LAPLACE, [Param.value("a"), Param.value("h", xf=A.XF_EXP)])
+    sl.add("c", A.CAUCHY, [Param.affine(np.array([[0.5]], np.float32), "l", bias=0.1), 1.3])
+    sl.add("ln", A.LOG_NORMAL, [Param.value("c", xf=A.XF_SIGMOID), 0.7])
+    sl.add("e", A.EXPONENTIAL, [Param.value("ln")])
+    sl.add("g", A.GAMMA, [2.0, Param.value("e", xf=A.XF_SOFTPLUS)])
+    sl.add("b", A.BETA, [2.0, 3.0])
+    sl.add("y", A.BERNOULLI_LOGITS, [Param.value("b")])
+    modes = {s.addr: A.MODE_OBS_SLOT for s in sl.sites}
+    prog = PackedProgram(sl, modes, selected=tuple(s.addr for s in sl.sites if s.addr != "y"))
+    vals = np.array([[0.4], [0.8], [0.1], [0.9], [1.3], [0.6], [1.7], [0.35], [1.0]], np.float32)
+    score, grad = oracle.score_grad(prog, vals)
+    for s in range(8):
+        h = 2e-3
+        vp, vm = vals.copy(), vals.copy()
+        vp[s] += h
+        vm[s] -= h
+        fd = (float(oracle.score_grad(prog, vp)[0][0]) - float(oracle.score_grad(prog, vm)[0][0])) / (float(vp[s, 0]) - float(vm[s, 0]))
+        assert float(grad[s, 0]) == pytest.approx(fd, rel=2e-2, abs=2e-2), s
+    assert grad[8, 0] == 0.0          # unselected / integer site: zero (hmc.py:90-96)
+
+
+def test_hmc_gaussian_trajectory(oracle):
+    """N(0,1) target: leapfrog is a rotation; compare with the exact float64 recurrence, both variants
+    (hmc.py:186 stale-gradient carry and the standard integrator).  SURVEY.md §9 H1."""
+    sl = SiteList()
+    sl.add("x", A.NORMAL, [0.0, 1.0])
+    prog = PackedProgram(sl, {"x": A.MODE_OBS_SLOT}, selected=("x",))
+    q0 = np.array([[1.0]], np.float32)
+    eps = 0.01
+    for L in (10, 1000):
+        for stale in (False, True):
+            out = oracle.hmc(prog, (7, 7), q0, eps, L, stale=stale)
+            # reproduce: the momentum draw is unknown to the test, recover it from alpha identity instead:
+            # run the float64 recurrence for a grid of p0 and match the final position.
+            def run(p0):
+                q, p, g0 = 1.0, p0, -1.0
+                g = g0
+                for _ in range(L):
+                    p += eps / 2 * (g0 if stale else g)
+                    q += eps * p
+                    g = -q
+                    p += eps / 2 * g
+                return q, p
+            # solve for p0 by bisection on the final q (monotone in p0)
+            lo, hi = -10.0, 10.0
+            for _ in range(200):
+                mid = 0.5 * (lo + hi)
+                if (run(mid)[0] - float(out["choices"][0, 0])) * (run(hi)[0] - run(lo)[0]) > 0:
+                    hi = mid
+                else:
+                    lo = mid
+            p0 = 0.5 * (lo + hi)
+            qf, pf = run(p0)
+            alpha = (-0.5 * qf * qf) - (-0.5) + (-0.5 * pf * pf) - (-0.5 * p0 * p0)
+            assert float(out["alpha"][0]) == pytest.approx(alpha, abs=5e-4 if L == 10 else 5e-3)
+            assert float(out["score"][0]) == pytest.approx(-0.5 * qf * qf - 0.918938533, abs=1e-4 if L == 10 else 2e-3)
+    # the two variants agree at small L and diverge at large L
+    a = oracle.hmc(prog, (7, 7), q0, eps, 10, stale=False)["choices"][0, 0]
+    b = oracle.hmc(prog, (7, 7), q0, eps, 10, stale=True)["choices"][0, 0]
+    assert a == pytest.approx(b, abs=1e-3)
+    a = oracle.hmc(prog, (7, 7), q0, eps, 1000, stale=False)["choices"][0, 0]
+    b = oracle.hmc(prog, (7, 7), q0, eps, 1000, stale=True)["choices"][0, 0]
+    assert abs(a - b) > 0.1
+
+
+def test_hmc_energy_and_accept(oracle):
+    prog, pr = H.logreg(N=64, P=4)
+    rs = np.random.default_rng(2)
+    n = 512
+    ch = (rs.standard_normal((5, n)) * 0.3).astype(np.float32)
+    out = oracle.hmc(prog, (1, 5), ch, 0.01, 50)
+    assert np.abs(out["alpha"]).max() < 0.05            # |dH| small for a well-resolved trajectory
+    s_new, _ = oracle.score_grad(prog, out["choices"])
+    np.testing.assert_allclose(out["score"], s_new, rtol=1e-5, atol=1e-4)
+    acc = oracle.hmc(prog, (1, 5), ch, 0.3, 20, accept=True)
+    rej = acc["accepted"] == 0
+    assert 0 < rej.sum() < n
+    np.testing.assert_array_equal(acc["choices"][:, rej], ch[:, rej])      # rejected chains are restored
+    s_old, _ = oracle.score_grad(prog, ch)
+    np.testing.assert_allclose(acc["score"][rej], s_old[rej], rtol=1e-6, atol=1e-5)
+
+
+def test_hmc_converges_like_reference_test(oracle):
+    """reference tests/inference/test_requests.py:196-235: x~N(0,1), y~N(x,0.01), y=3: 20 always-accepted moves
+    (eps 1e-2, L 10) move x -> 3 (rel 5e-3)."""
+    sl = SiteList()
+    sl.add("x", A.NORMAL, [0.0, 1.0])
+    sl.add("y", A.NORMAL, [Param.value("x"), 0.01])
+    prog = PackedProgram(sl, {"x": A.MODE_OBS_SLOT, "y": A.MODE_OBS_TAB}, {"y": 3.0}, selected=("x",))
+    for stale in (True, False):
+        x = np.array([[0.3]], np.float32)
+        key = core.key(0)
+        for _ in range(20):
+            key, sub = core.split(key)
+            o = oracle.hmc(prog, sub, x, 1e-2, 10, stale=stale)
+            # Delta score identity (test_requests.py:224-226)
+            old = cf.log_normal_pdf(x[0, 0], 0, 1) + cf.log_normal_pdf(3.0, x[0, 0], 0.01)
+            new = cf.log_normal_pdf(o["choices"][0, 0], 0, 1) + cf.log_normal_pdf(3.0, o["choices"][0, 0], 0.01)
+            assert float(o["score"][0]) - float(oracle.score_grad(prog, x)[0][0]) == pytest.approx(new - old, rel=1e-3, abs=0.5)
+            x = o["choices"]
+        assert float(x[0, 0]) == pytest.approx(3.0, rel=5e-3)
