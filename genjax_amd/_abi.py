@@ -1,7 +1,7 @@
 """ctypes mirror of ``include/gjx.h`` (struct layouts, enums, prototypes).
 
 The same declarations serve the HIP library (``genjax_amd/csrc/libgjx_hip.so``) and, in the
-test-suite only, the CPU oracle (``oracle/libgjx_oracle.so``) — they share the *ABI*, never code.
+test-suite only, the CPU checker under ``oracle/`` — they share the *ABI*, never code.
 """
 from __future__ import annotations
 

@@ -230,7 +230,7 @@ extern "C" int gjx_categorical_pick(const float* logw, int64_t K, int64_t partic
   hipStream_t st = (hipStream_t)stream;
   const int64_t want = (K + 1023) / 1024;
   const int nblocks = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
-  PickPair* partials = (PickPair*)workspace;
+  PickPair* partials = (PickPair*)((char*)workspace + kWsHeaderBytes);
   if (rng_mode == GJX_RNG_JAX32)
     hipLaunchKernelGGL(k_pick_partial<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, logw, K, particle_offset, lse, key2{key0, key1}, partials);
   else
@@ -247,7 +247,7 @@ extern "C" int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, cons
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_weight_cumsum: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblocks = (int)((K + kScanTile - 1) / kScanTile);
-  uint64_t* bs = (uint64_t*)workspace;
+  uint64_t* bs = (uint64_t*)((char*)workspace + kWsHeaderBytes);
   hipLaunchKernelGGL(k_wsum_blocks, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, bs);
   GJX_CHECK_LAUNCH("gjx_weight_cumsum/sum");
   hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(256), 0, st, bs, nblocks, total_dev);

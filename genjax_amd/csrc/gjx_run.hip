@@ -31,12 +31,15 @@ struct RunArgs {
   const float* logw_in;
   const float* sub;
   float* site_scores;
-  float2* partials;  // per block {max, sumexp} of logw (or NULL)
+  unsigned long long* partials;  // per block {max, sumexp} of logw (or NULL)
+  unsigned* ticket;
+  float* lse;
+  float log_k_total;
 };
 
 template <int RNG>
 __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
-  __shared__ float red[8];
+  __shared__ float red[16];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.K;
   const int64_t ii = active ? i : a.K - 1;  // inactive lanes shadow the last particle (no stores)
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   if (a.partials) {
     float bm, bsum;
     block_lse_partial<256>(lw, active, red, bm, bsum);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = make_float2(bm, bsum);
+    lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
   }
 }
 
@@ -143,7 +146,10 @@ struct GmmArgs {
   float* logw;
   const float* logw_in;
   const float* sub;
-  float2* partials;
+  unsigned long long* partials;
+  unsigned* ticket;
+  float* lse;
+  float log_k_total;
 };
 
 template <int PPT>
@@ -367,13 +373,11 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
     const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
     if (lane == 0) { red[wid] = wm; red[NW + wid] = ws; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float bm = red[0];
-      for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
-      float bsum = 0.0f;
-      for (int w = 0; w < NW; ++w) bsum += bm > -INFINITY ? red[NW + w] * fast_exp(red[w] - bm) : 0.0f;
-      a.partials[blockIdx.x] = make_float2(bm, bsum);
-    }
+    float bm = red[0];
+    for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
+    float bsum = 0.0f;
+    for (int w = 0; w < NW; ++w) bsum += bm > -INFINITY ? red[NW + w] * fast_exp(red[w] - bm) : 0.0f;
+    lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
   }
 }
 
@@ -524,11 +528,14 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   if (lse && !logw) return gjx_fail(GJX_EINVAL, "gjx_run_program: lse needs logw");
   if (prog->rng_mode == GJX_RNG_FLAT && prog->n_sites > GJX_FLAT_MAX_SITES) return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: FLAT stream supports at most 1023 sites");
   hipStream_t st = (hipStream_t)stream;
-  float2* partials = nullptr;
+  unsigned long long* partials = nullptr;
+  unsigned* ticket = nullptr;
   if (lse) {
     if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RUN, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_run_program: workspace too small");
-    partials = (float2*)workspace;
+    ticket = (unsigned*)workspace;
+    partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   }
+  const float log_k_total = (float)log((double)K_total);
   int nblocks;
   GmmShape g;
   const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
@@ -547,7 +554,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.r_off = g.r_off; a.r_len = g.r_len; a.y_off = g.y_off;
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
-    a.logw_in = logw_in; a.sub = sub; a.partials = partials;
+    a.logw_in = logw_in; a.sub = sub; a.partials = partials; a.ticket = ticket; a.lse = lse; a.log_k_total = log_k_total;
     const size_t lds = sizeof(float) * (size_t)(2 * g.C * (g.D + 4) + 3 * g.C + 2 * g.D + 8 + 16);
     if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
     else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
@@ -557,15 +564,13 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.sites = prog->sites_dev; a.tab = prog->tab_dev; a.n_sites = prog->n_sites; a.n_slots = prog->n_slots;
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
-    a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials;
+    a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials; a.ticket = ticket; a.lse = lse;
+    a.log_k_total = log_k_total;
     if (prog->rng_mode == GJX_RNG_JAX32) hipLaunchKernelGGL(k_run_generic<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_run_generic<GJX_RNG_FLAT>, dim3(nblocks), dim3(256), 0, st, a);
   }
   GJX_CHECK_LAUNCH("gjx_run_program");
-  if (lse) {
-    const int rc = gjx_launch_lse_finish(partials, nblocks, K_total, lse, st);
-    if (rc) return rc;
-  }
+  (void)nblocks;
   return GJX_OK;
 }
 
@@ -576,9 +581,10 @@ extern "C" int gjx_logsumexp(const float* x, int64_t K, int64_t K_total, float* 
   hipStream_t st = (hipStream_t)stream;
   const int64_t want = (K + 1023) / 1024;
   const int nblocks = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
-  hipLaunchKernelGGL(k_lse_partial, dim3(nblocks), dim3(256), 0, st, x, K, (float2*)workspace);
+  float2* parts = (float2*)((char*)workspace + kWsHeaderBytes);
+  hipLaunchKernelGGL(k_lse_partial, dim3(nblocks), dim3(256), 0, st, x, K, parts);
   GJX_CHECK_LAUNCH("gjx_logsumexp/partial");
-  return gjx_launch_lse_finish(workspace, nblocks, K_total, out, st);
+  return gjx_launch_lse_finish(parts, nblocks, K_total, out, st);
 }
 
 extern "C" int gjx_lse_combine(const float* pairs, int G, int64_t K_total, float* out, void* stream) {

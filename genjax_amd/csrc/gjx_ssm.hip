@@ -22,12 +22,15 @@ struct SsmArgs {
   const int32_t* anc;
   float* x_out;
   float* logw;
-  float2* partials;
+  unsigned long long* partials;
+  unsigned* ticket;
+  float* lse;
+  float log_k_total;
 };
 
 template <int RNG, int DX>
 __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
-  __shared__ float red[8];
+  __shared__ float red[16];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.K;
   const int64_t ii = active ? i : a.K - 1;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   if (a.partials) {
     float bm, bsum;
     block_lse_partial<256>(lw, active, red, bm, bsum);
-    if (threadIdx.x == 0) a.partials[blockIdx.x] = make_float2(bm, bsum);
+    lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
   }
 }
 
@@ -124,23 +127,22 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   if (t > 0 && !x_prev) return gjx_fail(GJX_EINVAL, "gjx_ssm_step: x_prev is null for t > 0");
   if (!m->H_dev && m->dy != m->dx) return gjx_fail(GJX_EINVAL, "gjx_ssm_step: H == NULL needs dy == dx");
   hipStream_t st = (hipStream_t)stream;
-  float2* partials = nullptr;
+  unsigned long long* partials = nullptr;
+  unsigned* ticket = nullptr;
   if (lse) {
     if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_SSM, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_step: workspace too small");
-    partials = (float2*)workspace;
+    ticket = (unsigned*)workspace;
+    partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   }
   SsmArgs a;
   a.A = m->A_dev; a.H = m->H_dev; a.y = y_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = t;
   a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset; a.prev_stride = prev_stride;
-  a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials;
+  a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials; a.ticket = ticket; a.lse = lse;
+  a.log_k_total = (float)log((double)K_total);
   const int nblocks = (int)((K + 255) / 256);
   const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
                                            : launch_ssm<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
   if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step: dx must be one of 1,2,4,8,16,32");
   GJX_CHECK_LAUNCH("gjx_ssm_step");
-  if (lse) {
-    const int rc2 = gjx_launch_lse_finish(partials, nblocks, K_total, lse, st);
-    if (rc2) return rc2;
-  }
   return GJX_OK;
 }

@@ -70,9 +70,9 @@ def global_lse(local_lse: torch.Tensor, K_total: int, backend=None, group=None) 
     if world == 1:
         return local_lse
     backend = backend or HipBackend()
-    pairs = torch.empty((world, 2), dtype=torch.float32, device=local_lse.device)
+    pairs = torch.empty(world * 2, dtype=torch.float32, device=local_lse.device)
     dist.all_gather_into_tensor(pairs, local_lse[:2].contiguous(), group=group)
-    return backend.lse_combine(pairs, K_total)
+    return backend.lse_combine(pairs.view(world, 2), K_total)
 
 
 def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global: torch.Tensor, u: float, N_total: int,

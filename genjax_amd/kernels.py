@@ -28,7 +28,7 @@ def _dev(device=None):
 
 def workspace(op: int, K: int, device=None) -> torch.Tensor:
     n = load().gjx_workspace_bytes(op, int(K))
-    return torch.empty(n, dtype=torch.uint8, device=_dev(device))
+    return torch.zeros(n, dtype=torch.uint8, device=_dev(device))   # control block must start zeroed (gjx.h)
 
 
 def threefry2x32(key, n: int, ctr_lo0: int = 0, ctr_hi: int = 0, device=None) -> torch.Tensor:
@@ -43,7 +43,8 @@ def program_engine(prog: PackedProgram) -> int:
 
 
 def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
-                want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None):
+                want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None,
+                want_weight=True):
     """gjx_run_program.  Returns dict(choices, score, weight, logw, lse[, site_scores])."""
     dev = _dev(device)
     K = int(K)
@@ -54,7 +55,7 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     if ch is None:
         ch = torch.empty((max(prog.n_slots, 1), K), dtype=f32, device=dev)
     score = out.get("score") if out.get("score") is not None else torch.empty(K, dtype=f32, device=dev)
-    weight = out.get("weight") if out.get("weight") is not None else torch.empty(K, dtype=f32, device=dev)
+    weight = (out.get("weight") if out.get("weight") is not None else torch.empty(K, dtype=f32, device=dev)) if want_weight else None
     logw = out.get("logw") if out.get("logw") is not None else torch.empty(K, dtype=f32, device=dev)
     lse = (out.get("lse") if out.get("lse") is not None else torch.empty(4, dtype=f32, device=dev)) if want_lse else None
     ss = torch.empty((max(prog.n_sites, 1), K), dtype=f32, device=dev) if want_site_scores else None

@@ -170,6 +170,9 @@ int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64
 
 enum { GJX_OP_RUN = 1, GJX_OP_LSE = 2, GJX_OP_PICK = 3, GJX_OP_RESAMPLE = 4, GJX_OP_HMC = 5,
        GJX_OP_SSM = 6 };
+/* Scratch for one call.  The first 256 bytes are a control block (completion tickets of the fused
+ * log-sum-exp): the caller zero-fills a workspace ONCE after allocating it; every entry point leaves the
+ * control block zeroed again, so a workspace can be reused by any sequence of calls on one stream. */
 size_t gjx_workspace_bytes(int op, int64_t K);
 
 /* ---- log-sum-exp (smc.py:97,107,464) -----------------------------------------------------

@@ -1,0 +1,187 @@
+"""CPU tests of the host logic: data types, model tracing, program packing, the C-ABI library's exports.
+No compute call is made here (there is no GPU in the build container and no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import genjax_amd as genjax
+from genjax_amd import C, S, ChoiceMap, Selection
+from genjax_amd import _abi as A
+from genjax_amd.inference import Target
+from genjax_amd.program import PackedProgram, Param, SiteList
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/gjx.h <-> libgjx_hip.so <-> genjax_amd/_abi.py agree on the symbol set."""
+    hdr = open(os.path.join(ROOT, "include", "gjx.h")).read()
+    declared = set(re.findall(r"\b(gjx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"gjx_status"}
+    assert declared == set(A.PROTOTYPES), (declared ^ set(A.PROTOTYPES))
+    from genjax_amd import _lib
+    lib = _lib.load()                                   # binds all of them; AttributeError if one is missing
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.gjx_version() == A.ABI_VERSION
+    assert lib.gjx_workspace_bytes(A.OP_RUN, 1 << 20) >= 8 * (1 << 20) // 256 + 256
+    assert ctypes.sizeof(A.GjxSite) == 96 and ctypes.sizeof(A.GjxParam) == 32
+
+
+def test_abi_struct_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "gjx.h")).read()
+    for name, val in (("GJX_NORMAL", A.NORMAL), ("GJX_GAMMA", A.GAMMA), ("GJX_P_AFFINE", A.P_AFFINE), ("GJX_XF_SIGMOID", A.XF_SIGMOID),
+                      ("GJX_MODE_OBS_SLOT", A.MODE_OBS_SLOT), ("GJX_RNG_JAX32", A.RNG_JAX32), ("GJX_OP_SSM", A.OP_SSM)):
+        m = re.search(name + r"\s*=\s*(\d+)", hdr)
+        assert m and int(m.group(1)) == val, name
+    assert f"#define GJX_FLAT_SITE_SHIFT {A.FLAT_SITE_SHIFT}" in hdr
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from genjax_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgjx_hip.so"))
+    with pytest.raises(_lib.GjxError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "genjax_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "gjx_oracle" not in src, f
+
+
+def test_choice_map_and_selection_algebra():
+    chm = C["y"].set(3.0)
+    assert "y" in chm and chm["y"] == 3.0 and "x" not in chm
+    assert C.kw(y=3.0) == chm and C.d({"y": 3.0}) == chm
+    assert chm.get_submap("y").get_value() == 3.0 and chm.get_submap("zz").static_is_empty()
+    both = chm | C["x"].set(1.0)
+    assert set(both.addresses()) == {"x", "y"}
+    assert (C["y"].set(1.0) | C["y"].set(2.0))["y"] == 1.0            # left-biased merge (choice_map.py:1227)
+    assert both.at["z"].set(5.0)["z"] == 5.0 and "z" not in both
+    assert C.v(2.5).get_value() == 2.5 and C.n().static_is_empty()
+    with pytest.raises(KeyError):
+        chm["nope"]
+    sel = S["x"] | S["y"]
+    assert "x" in sel and "z" not in sel and "z" in ~sel and "x" not in ~sel
+    assert Selection.all().check("anything") and not Selection.none().check("anything")
+    assert both.filter(S["x"]).addresses() == ["x"] and both.filter(~S["x"]).addresses() == ["y"]
+    assert ((~S["x"]) | S["x"]).check("x") and ((~S["x"]) & (~S["y"])).check("z") and not ((~S["x"]) & (~S["y"])).check("y")
+    assert Selection.at["x"].check("x")
+    assert set(both.get_selection().addrs) == {"x", "y"}
+
+
+def test_keys():
+    k = genjax.key(314159)
+    assert k == (0, 314159)
+    a, b = genjax.split(k)
+    assert a == genjax.fold_in(k, 0) and b == genjax.fold_in(k, 1) and a != b
+    assert len(genjax.split(k, 50)) == 50
+
+
+def test_tracing_builds_the_expected_program():
+    @genjax.gen
+    def model(scale):
+        z = genjax.categorical(probs=[0.2, 0.8]) @ "z"
+        mu = genjax.const([[0.0, 1.0], [5.0, 6.0]])[z]
+        x = genjax.mv_normal_diag(mu, np.array([1.0, 2.0])) @ "x"
+        t = genjax.normal(0.0, 1.0) @ "t"
+        y = genjax.normal(np.array([[1.0, -1.0]]) @ x + 0.5, genjax.exp(t) ) @ "y"
+        b = genjax.flip(genjax.where(z, 0.9, 0.3)) @ "b"
+        w = genjax.normal(2.0 * x[1] - 1.0, scale) @ "w"
+        return y
+
+    sl, ret = model.site_list((3.0,))
+    assert sl.addresses() == ["z", "x", "t", "y", "b", "w"]
+    assert [s.dim for s in sl.sites] == [1, 2, 1, 1, 1, 1] and sl["z"].ncat == 2
+    prog, shared, pp = model.pack((3.0,), C["y"].set(0.25), True)
+    assert prog.slot_of == {"z": 0, "x": 1, "t": 3, "y": -1, "b": 4, "w": 5} and prog.n_slots == 6
+    s = {a: prog.c_sites[j] for j, a in enumerate(sl.addresses())}
+    assert s["x"].p[0].op == A.P_GATHER and s["x"].p[0].n == 2 and s["x"].p[0].len == 2 and s["x"].p[0].slot == 0
+    assert s["y"].mode == A.MODE_OBS_TAB and prog.tab[s["y"].obs_off] == 0.25
+    assert s["y"].p[0].op == A.P_AFFINE and s["y"].p[0].n == 2 and s["y"].p[0].slot == 1
+    np.testing.assert_array_equal(prog.tab[s["y"].p[0].moff: s["y"].p[0].moff + 2], [1.0, -1.0])
+    assert prog.tab[s["y"].p[0].off] == 0.5
+    assert s["y"].p[1].op == A.P_VALUE and s["y"].p[1].xf == A.XF_EXP and s["y"].p[1].slot == 3
+    assert s["b"].p[0].op == A.P_GATHER and list(prog.tab[s["b"].p[0].off: s["b"].p[0].off + 2]) == pytest.approx([0.3, 0.9])
+    assert s["w"].p[0].op == A.P_AFFINE and s["w"].p[0].slot == 2 and s["w"].p[0].n == 1       # trimmed to x[1]
+    assert prog.tab[s["w"].p[0].moff] == 2.0 and prog.tab[s["w"].p[0].off] == -1.0 and prog.tab[s["w"].p[1].off] == 3.0
+    assert model.site_list((3.0,))[0] is sl and model.site_list((4.0,))[0] is not sl            # cached per args
+
+
+def test_observed_parents_fold_into_constants():
+    sl = SiteList()
+    sl.add("x", A.MVNORMAL_DIAG, [np.zeros(2, np.float32), np.ones(2, np.float32)], dim=2)
+    sl.add("k", A.CATEGORICAL_PROBS, [np.array([0.5, 0.5], np.float32)])
+    sl.add("y", A.NORMAL, [Param.affine(np.array([[2.0, 3.0]], np.float32), "x", bias=1.0), Param.gather([0.1, 0.2], "k")])
+    prog = PackedProgram(sl, {"x": A.MODE_OBS_TAB, "k": A.MODE_OBS_TAB}, {"x": [1.0, -1.0], "k": 1.0})
+    y = prog.c_sites[2]
+    assert prog.n_slots == 1 and y.slot == 0
+    assert y.p[0].op == A.P_CONST and prog.tab[y.p[0].off] == 0.0            # 2*1 + 3*(-1) + 1
+    assert y.p[1].op == A.P_CONST and prog.tab[y.p[1].off] == pytest.approx(0.2)
+    prog.set_obs("x", [2.0, 2.0])
+    assert prog.tab[y.p[0].off] == 11.0
+
+
+def test_errors_mirror_the_reference():
+    @genjax.gen
+    def dup():
+        _ = genjax.normal(0.0, 1.0) @ "a"
+        _ = genjax.normal(0.0, 1.0) @ "a"
+
+    with pytest.raises(genjax.AddressReuse):                 # static.py:139
+        dup.site_list(())
+
+    @genjax.gen
+    def model():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        _ = genjax.normal(x, 1.0) @ "y"
+
+    with pytest.raises(genjax.MissingAddress):               # static.py:316-318
+        model.pack((), C["x"].set(0.0), False)
+    with pytest.raises(TypeError):                           # sp.py:46-49, tests/inference/test_smc.py:89-106
+        Target(model.marginal(selection=S["x"]), (), C["x"].set(1.0))
+    t = Target(model, (), C["y"].set(3.0))
+    assert t["y"] == 3.0 and t.constraint.get_submap("y").get_value() == 3.0
+    assert t.filter_to_unconstrained(C.d({"x": 1.0, "y": 3.0})).addresses() == ["x"]
+
+    @genjax.gen
+    def nonlinear():
+        a = genjax.normal(0.0, 1.0) @ "a"
+        b = genjax.normal(0.0, 1.0) @ "b"
+        _ = genjax.normal(a * b, 1.0) @ "c"
+
+    with pytest.raises(TypeError):
+        nonlinear.site_list(())
+    with pytest.warns(DeprecationWarning):                   # distribution.py:479-500
+        genjax.categorical([0.0, 1.0])
+    with pytest.raises(RuntimeError):
+        genjax.normal(0.0, 1.0) @ "outside"
+
+
+def test_defaults_mirror_the_reference():
+    from genjax_amd.inference import HMC, ImportanceK
+
+    @genjax.gen
+    def m():
+        _ = genjax.normal(0.0, 1.0) @ "x"
+
+    t = Target(m, (), C.n())
+    assert ImportanceK(t).get_num_particles() == 2            # smc.py:290
+    assert HMC(S["x"], 0.1).L == 10                           # hmc.py:154
+    assert ImportanceK(t, k_particles=7).get_final_target() is t
+
+
+def test_shard_arithmetic():
+    from genjax_amd.distributed import shard
+    for K in (1, 7, 1 << 20, (1 << 20) + 3):
+        for G in (1, 2, 3, 8):
+            parts = [shard(K, r, G) for r in range(G)]
+            assert parts[0][0] == 0 and sum(k for _, k in parts) == K
+            assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(G - 1))
