@@ -4,8 +4,9 @@
 A "step" is one pass of the path over one batch of synthetic input, per GPU:
     propagate + reweight + fused log-sum-exp (ONE kernel, gjx_run_program)
       -> [N > 1: 8-byte all-gather of {max, sumexp} + combine]
-      -> systematic resampling (fixed-point prefix sum, comb search [, all-to-all-v of surplus rows])
-      -> gather of the SoA rows by ancestor
+      -> fixed-point prefix sum of the weights (2 kernels)
+      -> systematic ancestors by per-particle slot-range expansion (no search), row gather by ancestor
+         [N > 1: search, all-to-all-v of the rows whose slot another rank owns]
 on BASELINE.json configs[1]: the Gaussian-mixture Target (C = 8 components, D = 16 latent dims),
 ImportanceK with k_particles = 2^20 PER GPU (weak scaling: the collection grows with N and is
 sharded by particle index; results are independent of N because streams are indexed globally).
@@ -93,7 +94,9 @@ def main():
     ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
     out = kernels.run_program(prog, (0, 1), K, offset=off, K_total=K_total, ws=ws, want_weight=False)
     rows = torch.empty_like(out["choices"])
-    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    cum = torch.empty(K, dtype=torch.int64, device=dev)
+    bt = torch.empty(2, dtype=torch.int64, device=dev)
+    anc = torch.empty(K, dtype=torch.int32, device=dev)
     n_samp = max(1, min(args.event_samples, args.steps))
     sample_at = {int(round(j * (args.steps - 1) / max(n_samp - 1, 1))): j for j in range(n_samp)}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
@@ -108,9 +111,8 @@ def main():
             ev[j][1].record()
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
         if world == 1:
-            cum, total = kernels.weight_cumsum(out["logw"], True, out["lse"], ws=ws2)
-            anc = kernels.resample_systematic(cum, torch.cat([zero, total]), u, K_total)
-            kernels.gather_rows(out["choices"], anc, rows)
+            kernels.weight_cumsum(out["logw"], True, out["lse"], ws=ws2, out=(cum, bt))
+            kernels.resample_gather_systematic(cum, bt, u, K_total, out["choices"], rows, anc=anc)
             return out["lse"]
         lse = DD.global_lse(out["lse"], K_total)
         DD.resample_exchange(out["choices"], out["logw"], lse, u, K_total)

@@ -75,10 +75,12 @@ PROTOTYPES = {
     "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),
     "gjx_weight_cumsum": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
+    "gjx_resample_gather_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, i64, i32, vp, i64, vp, vp]),
     "gjx_resample_multinomial": (C.c_int, [vp, i64, vp, u32, u32, i64, i64, i64, vp, vp]),
     "gjx_gather_rows": (C.c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
                                vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc": (C.c_int, [PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp, vp,
                           C.c_size_t, vp]),

@@ -193,6 +193,26 @@ GJX_DEV float normal_from_bits(uint32_t bits) {
   const float u = uniform_from_bits(bits, kNeg1PlusUlp, 1.0f);
   return kSqrt2 * erfinv_f32(u);
 }
+// Box-Muller pair from the two words of one hash (FLAT layout): (r cos 2πu2, r sin 2πu2), u1 in (0,1].
+// v_sin_f32 / v_cos_f32 take their argument in revolutions, so u2 feeds them directly.
+GJX_DEV void box_muller(uint32_t wa, uint32_t wb, float& n0, float& n1) {
+  const float u1 = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wa, 9));  // 1 - unit, (0,1]
+  const float u2 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9)) - 1.0f;
+  const float r = fast_sqrt(__builtin_amdgcn_logf(u1) * (-2.0f * kLn2));
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// standard normal for element e of a stream (see stream_normal in the oracle)
+template <int RNG>
+GJX_DEV float stream_normal(BitStream<RNG>& bs, uint32_t e) {
+  if (RNG == GJX_RNG_JAX32) return normal_from_bits(bs.get(e));
+  const uint32_t wa = bs.get(e & ~1u), wb = bs.get(e | 1u);
+  float n0, n1;
+  box_muller(wa, wb, n0, n1);
+  return (e & 1u) ? n1 : n0;
+}
+
 GJX_DEV float gumbel_from_bits(uint32_t bits) {
   const float u = uniform_from_bits(bits, kTiny, 1.0f);
   return -fast_log(-safe_log(u));
@@ -281,7 +301,7 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b) {
 
 // ---- samplers ----------------------------------------------------------------------------------
 constexpr int kGammaMaxIt = 32;
-constexpr int kGammaNDraw = 2 * kGammaMaxIt + 1;
+constexpr int kGammaNDraw = 4 * kGammaMaxIt + 2;  // draw schedule: see GAMMA_NDRAW in the oracle
 
 GJX_DEV int draws_per_elem(int kind) {
   return kind == GJX_BETA ? 2 * kGammaNDraw : (kind == GJX_GAMMA ? kGammaNDraw : 1);
@@ -292,7 +312,7 @@ template <int RNG>
 GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
   float boost = 0.0f, aa = a;
   if (a < 1.0f) {
-    const float u = uniform_from_bits(bs.get(base + 2 * kGammaMaxIt), kTiny, 1.0f);
+    const float u = uniform_from_bits(bs.get(base + 4 * kGammaMaxIt), kTiny, 1.0f);
     boost = safe_log(u) / a;
     aa = a + 1.0f;
   }
@@ -300,8 +320,8 @@ GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
   const float c = 1.0f / sqrtf(9.0f * d);
   float res = fast_log(d);
   for (int t = 0; t < kGammaMaxIt; ++t) {
-    const float x = normal_from_bits(bs.get(base + 2 * t));
-    const float u = uniform_from_bits(bs.get(base + 2 * t + 1), kTiny, 1.0f);
+    const float x = stream_normal<RNG>(bs, base + 4 * t);
+    const float u = uniform_from_bits(bs.get(base + 4 * t + 2), kTiny, 1.0f);
     float v = fmaf(c, x, 1.0f);
     if (v <= 0.0f) continue;
     const float lv = 3.0f * fast_log(v);
@@ -318,7 +338,7 @@ template <int RNG>
 GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, float b) {
   switch (kind) {
     case GJX_NORMAL:
-    case GJX_MVNORMAL_DIAG: return fmaf(b, normal_from_bits(bs.get(c)), a);
+    case GJX_MVNORMAL_DIAG: return fmaf(b, stream_normal<RNG>(bs, c), a);
     case GJX_FLIP: return bits_to_unit(bs.get(c)) < a ? 1.0f : 0.0f;
     case GJX_BERNOULLI_LOGITS: return bits_to_unit(bs.get(c)) < sigmoid(a) ? 1.0f : 0.0f;
     case GJX_BETA: {
@@ -328,13 +348,13 @@ GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, flo
     }
     case GJX_UNIFORM: return fmaf(b - a, bits_to_unit(bs.get(c)), a);
     case GJX_EXPONENTIAL: return -safe_log(uniform_from_bits(bs.get(c), kTiny, 1.0f)) / a;
-    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(bs.get(c))) * a;
+    case GJX_HALF_NORMAL: return fabsf(stream_normal<RNG>(bs, c)) * a;
     case GJX_LAPLACE: {
       const float u = uniform_from_bits(bs.get(c), kNeg1PlusUlp, 1.0f);
       const float s = (float)((u > 0.0f) - (u < 0.0f));
       return a - b * s * log1p_acc(-fabsf(u));
     }
-    case GJX_LOG_NORMAL: return fast_exp(fmaf(b, normal_from_bits(bs.get(c)), a));
+    case GJX_LOG_NORMAL: return fast_exp(fmaf(b, stream_normal<RNG>(bs, c), a));
     case GJX_CAUCHY: return fmaf(b, tanf(kPi * (bits_to_unit(bs.get(c)) - 0.5f)), a);
     case GJX_GAMMA: return fast_exp(log_gamma_variate<RNG>(bs, c, a)) / b;
     default: return __builtin_nanf("");

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
       if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, (uint32_t)leaf));
       else bs.open(a.key, gidx, (uint32_t)leaf + 1u);
       for (int d = 0; d < s.dim; ++d, ++m) {
-        const float p = normal_from_bits(bs.get((uint32_t)d));
+        const float p = stream_normal<RNG>(bs, (uint32_t)d);
         a.ws_p[(int64_t)m * n + i] = p;
         k0 += -0.5f * p * p - kHalfLog2Pi;
       }

@@ -107,39 +107,20 @@ __global__ __launch_bounds__(256) void k_wsum_blocks(const float* x, int64_t K, 
   if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// exclusive scan of the block sums in place (single block, sequential carry over chunks of 256)
-__global__ __launch_bounds__(256) void k_scan_block_sums(uint64_t* block_sums, int n, uint64_t* total) {
-  __shared__ uint64_t wsum[4];
-  __shared__ uint64_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += 256) {
-    const int t = c0 + threadIdx.x;
-    const uint64_t v = t < n ? block_sums[t] : 0;
-    uint64_t inc = v;  // inclusive wave scan
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-      if ((threadIdx.x & 63) >= o) inc += up;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint64_t woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    const uint64_t carry = carry_s;
-    if (t < n) block_sums[t] = carry + woff + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry_s = carry + woff + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = carry_s;
-}
-
+// Second (final) pass: every block sums the totals of the blocks before it (nblocks u64 values, L2-resident:
+// K/2048 of them) instead of waiting for a separate single-block scan kernel, then scans its own tile.
+// The last block also publishes base_total = {0, sum of all weights}.
 __global__ __launch_bounds__(256) void k_wscan_write(const float* x, int64_t K, int is_log, const float* lse,
-                                                    const uint64_t* block_offsets, uint64_t* cum) {
+                                                    const uint64_t* block_sums, uint64_t* cum, uint64_t* base_total) {
   __shared__ uint64_t wsum[4];
+  __shared__ uint64_t red[4];
   const float mx = is_log ? lse[0] : 0.0f;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  // offset of this block = sum of block_sums[0 .. blockIdx.x)
+  uint64_t pre = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) pre += block_sums[t];
+  pre = wave_sum_u64(pre);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
   uint64_t q[kScanItems];
   uint64_t s = 0;
 #pragma unroll
@@ -156,11 +137,15 @@ __global__ __launch_bounds__(256) void k_wscan_write(const float* x, int64_t K, 
   }
   if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
-  uint64_t off = block_offsets[blockIdx.x] + inc - s;
+  uint64_t off = red[0] + red[1] + red[2] + red[3] + inc - s;
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
     if (base + k < K) cum[base + k] = off + q[k];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+    base_total[0] = 0;
+    base_total[1] = off + s;
+  }
 }
 
 // first i in [0, K) with cum[i] > t   (requires t < cum[K-1])
@@ -173,22 +158,100 @@ GJX_DEV int64_t upper_search(const uint64_t* __restrict__ cum, int64_t K, uint64
   return lo;
 }
 
-__global__ __launch_bounds__(256) void k_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total,
-                                                   double u, int64_t N_total, int64_t out_begin, int64_t n_out,
-                                                   int32_t* ancestors) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_out) return;
+// first i in [lo, hi] with cum[i] > t   (requires cum[hi] > t)
+GJX_DEV int64_t upper_search_in(const uint64_t* __restrict__ cum, int64_t lo, int64_t hi, uint64_t t) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cum[mid] > t) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// comb threshold of output slot j (identical double arithmetic in the oracle)
+GJX_DEV uint64_t comb_threshold(int64_t j, double u, double step, uint64_t total) {
+  uint64_t T = (uint64_t)(((double)j + u) * step);
+  if (total > 0 && T > total - 1) T = total - 1;
+  return T;
+}
+
+// number of output slots whose comb threshold lies strictly below c (0 <= c <= total):
+// J(c) = #{j in [0, N) : T_j < c}.  T_j is non-decreasing in j, so J is found from the real-valued guess
+// ceil(c/step - u) and corrected with the EXACT integer predicate (the same T_j the per-slot search uses).
+GJX_DEV int64_t slots_below(uint64_t c, double u, double step, double inv_step, uint64_t total, int64_t N) {
+  if (c == 0) return 0;
+  if (c >= total) return N;
+  double gd = ceil((double)c * inv_step - u);  // any guess works: the loops below make the result exact
+  int64_t g = gd < 0.0 ? 0 : (gd > (double)N ? N : (int64_t)gd);
+  while (g > 0 && comb_threshold(g - 1, u, step, total) >= c) --g;
+  while (g < N && comb_threshold(g, u, step, total) < c) ++g;
+  return g;
+}
+
+// Systematic resampling, particle-oriented ("expand"): particle i owns the output slots
+// [J(base + cum[i-1]), J(base + cum[i])) — a few consecutive slots, usually 0..3 — so one lane per particle
+// reads two prefix sums (coalesced), computes its slot range in O(1), and writes its index (and, with
+// GATHER, its SoA rows) to those slots.  Consecutive particles own consecutive slot runs, so the writes
+// coalesce; particles without offspring read nothing.  Particles with many offspring (degenerate weights)
+// are filled cooperatively by the whole block.  No binary search, no dependent-load chain.
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_systematic_expand(const uint64_t* __restrict__ cum, int64_t K,
+                                                          const uint64_t* base_total, double u, int64_t N_total,
+                                                          int64_t out_begin, int64_t n_out, int32_t* ancestors,
+                                                          const float* __restrict__ src, int64_t src_stride, int rows,
+                                                          float* __restrict__ dst, int64_t dst_stride) {
+  constexpr int kOwn = 8;  // offspring a lane writes by itself
+  __shared__ int n_heavy;
+  __shared__ int32_t h_i[256];
+  __shared__ int64_t h_lo[256], h_hi[256];
+  if (threadIdx.x == 0) n_heavy = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t base = base_total[0], total = base_total[1];
   const double step = (double)total / (double)N_total;
-  const double pj = ((double)(out_begin + j) + u) * step;
-  uint64_t T = (uint64_t)pj;
-  if (total > 0 && T > total - 1) T = total - 1;
-  int32_t a = -1;
-  if (K > 0) {
-    const uint64_t local = cum[K - 1];
-    if (T >= base && T < base + local) a = (int32_t)upper_search(cum, K, T - base);
+  const double inv_step = (double)N_total / (double)total;
+  // J(base + cum[i]) once per lane; the lower end of a particle's run is its left neighbour's upper end
+  const bool in = i < K && total > 0;
+  const uint64_t c_cur = in ? base + cum[i] : 0;
+  const int64_t j_cur = in ? slots_below(c_cur, u, step, inv_step, total, N_total) : 0;
+  int64_t j_prev = __shfl_up((long long)j_cur, 1, 64);
+  uint64_t c_prev = __shfl_up((unsigned long long)c_cur, 1, 64);
+  if ((threadIdx.x & 63) == 0) {
+    c_prev = base + ((in && i > 0) ? cum[i - 1] : 0);
+    j_prev = in ? slots_below(c_prev, u, step, inv_step, total, N_total) : 0;
   }
-  ancestors[j] = a;
+  if (in) {
+    if (c_cur > c_prev) {
+      int64_t lo = j_prev - out_begin;
+      int64_t hi = j_cur - out_begin;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > n_out ? n_out : hi;
+      if (hi - lo > kOwn) {
+        const int h = atomicAdd(&n_heavy, 1);
+        h_i[h] = (int32_t)i; h_lo[h] = lo; h_hi[h] = hi;
+      } else if (hi > lo) {
+        if (ancestors) for (int64_t j = lo; j < hi; ++j) ancestors[j] = (int32_t)i;
+        if (GATHER) {
+          for (int r = 0; r < rows; ++r) {
+            const float v = src[(int64_t)r * src_stride + i];
+            for (int64_t j = lo; j < hi; ++j) dst[(int64_t)r * dst_stride + j] = v;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nh = n_heavy;
+  for (int h = 0; h < nh; ++h) {
+    const int32_t pi = h_i[h];
+    const int64_t lo = h_lo[h], hi = h_hi[h];
+    if (ancestors) for (int64_t j = lo + threadIdx.x; j < hi; j += 256) ancestors[j] = pi;
+    if (GATHER) {
+      for (int r = 0; r < rows; ++r) {
+        const float v = src[(int64_t)r * src_stride + pi];
+        for (int64_t j = lo + threadIdx.x; j < hi; j += 256) dst[(int64_t)r * dst_stride + j] = v;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total,
@@ -242,17 +305,15 @@ extern "C" int gjx_categorical_pick(const float* logw, int64_t K, int64_t partic
 }
 
 extern "C" int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, uint64_t* cum,
-                                 uint64_t* total_dev, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !cum || !total_dev || K <= 0 || (is_log && !lse)) return gjx_fail(GJX_EINVAL, "gjx_weight_cumsum: bad argument");
+                                 uint64_t* base_total_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !cum || !base_total_dev || K <= 0 || (is_log && !lse)) return gjx_fail(GJX_EINVAL, "gjx_weight_cumsum: bad argument");
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_weight_cumsum: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblocks = (int)((K + kScanTile - 1) / kScanTile);
   uint64_t* bs = (uint64_t*)((char*)workspace + kWsHeaderBytes);
   hipLaunchKernelGGL(k_wsum_blocks, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, bs);
   GJX_CHECK_LAUNCH("gjx_weight_cumsum/sum");
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(256), 0, st, bs, nblocks, total_dev);
-  GJX_CHECK_LAUNCH("gjx_weight_cumsum/scan");
-  hipLaunchKernelGGL(k_wscan_write, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, (const uint64_t*)bs, cum);
+  hipLaunchKernelGGL(k_wscan_write, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, (const uint64_t*)bs, cum, base_total_dev);
   GJX_CHECK_LAUNCH("gjx_weight_cumsum/write");
   return GJX_OK;
 }
@@ -263,10 +324,25 @@ extern "C" int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uin
   if (!cum || !base_total_dev || !ancestors || K <= 0 || N_total <= 0 || n_out < 0 || !(u >= 0.0 && u < 1.0))
     return gjx_fail(GJX_EINVAL, "gjx_resample_systematic: bad argument");
   if (n_out == 0) return GJX_OK;
-  hipLaunchKernelGGL(k_systematic, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cum, K,
-                     base_total_dev, u, N_total, out_begin, n_out, ancestors);
+  hipLaunchKernelGGL(k_systematic_expand<false>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cum, K,
+                     base_total_dev, u, N_total, out_begin, n_out, ancestors, (const float*)nullptr, (int64_t)0, 0,
+                     (float*)nullptr, (int64_t)0);
   GJX_CHECK_LAUNCH("gjx_resample_systematic");
   return GJX_OK;
+}
+
+extern "C" int gjx_resample_gather_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev, double u,
+                                              int64_t N_total, int64_t out_begin, int64_t n_out, const float* src,
+                                              int64_t src_stride, int32_t rows, float* dst, int64_t dst_stride,
+                                              int32_t* ancestors, void* stream) {
+  if (!cum || !base_total_dev || !src || !dst || !ancestors || K <= 0 || N_total <= 0 || n_out < 0 || rows < 0 ||
+      !(u >= 0.0 && u < 1.0))
+    return gjx_fail(GJX_EINVAL, "gjx_resample_gather_systematic: bad argument");
+  if (n_out == 0) return GJX_OK;
+  // particle-oriented expand of the ancestor indices (no search), then the slot-oriented, fully coalesced row copy
+  const int rc = gjx_resample_systematic(cum, K, base_total_dev, u, N_total, out_begin, n_out, ancestors, stream);
+  if (rc) return rc;
+  return gjx_gather_rows(src, src_stride, ancestors, n_out, rows, dst, dst_stride, stream);
 }
 
 extern "C" int gjx_resample_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,

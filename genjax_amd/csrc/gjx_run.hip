@@ -73,7 +73,20 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       }
       const float lse = mx + fast_log(se);
       float v;
-      if (mode == GJX_MODE_SAMPLE) {
+      if (mode == GJX_MODE_SAMPLE && RNG == GJX_RNG_FLAT) {
+        // inverse CDF on one uniform (se is the float32 running total in category order)
+        const float target = bits_to_unit(bs.get(0u)) * se;
+        float run = 0.0f;
+        int zc = n - 1;
+        bool found = false;
+        for (int c = 0; c < n; ++c) {
+          float l = eval_param(s.p[0], c, tab, val);
+          if (probs) l = safe_log(l);
+          run += fast_exp(l - mx);
+          if (!found && run > target) { zc = c; found = true; }
+        }
+        v = (float)zc;
+      } else if (mode == GJX_MODE_SAMPLE) {
         int best = 0;
         float bestv = -INFINITY;
         for (int c = 0; c < n; ++c) {
@@ -186,7 +199,8 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
   float* s_logit = s_sig + C * DS;    // [C] raw logits
   float* s_race = s_logit + C;        // [C] ln2 * exp(-logit): exponential-race rate^-1
   float* s_zlp = s_race + C;          // [C] log_softmax(logits)[c] - sum_d log sigma[c][d] - D*0.5*log(2pi)
-  float* s_y = s_zlp + C;             // [D]
+  float* s_cdf = s_zlp + C;           // [C] running sums of exp(logit - max) (FLAT: inverse-CDF draw)
+  float* s_y = s_cdf + C;             // [D]
   float* s_rr = s_y + D;              // [D] 1/r
   float* s_misc = s_rr + D;           // [0]: -sum_d log r_d - D*0.5*log(2pi);  [8..]: reduction scratch
   const float* __restrict__ tab = a.tab;
@@ -223,6 +237,8 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
       float sl = 0.0f;
       for (int d = 0; d < D; ++d) sl += fast_log(tab[a.r_off + (a.r_len == 1 ? 0 : d)]);
       s_misc[0] = -sl - (float)D * kHalfLog2Pi;
+      float run = 0.0f;  // same float32 order as the generic interpreter and the oracle
+      for (int c = 0; c < C; ++c) { run += fast_exp(s_logit[c] - mx); s_cdf[c] = run; }
     }
   }
   __syncthreads();
@@ -251,32 +267,27 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
         sk2[p] = fold_in(pk, 2u);
       }
     }
-    // ---- z ~ categorical(logits).  Gumbel-max argmax_c (l_c - log(-log u_c)) evaluated as the
-    //      equivalent exponential race argmin_c (-log u_c) * exp(-l_c): one log per category. ----
+    // ---- z ~ categorical(logits).
+    //   FLAT : inverse CDF on one uniform (first c whose running sum exceeds u * total).
+    //   JAX32: Gumbel-max argmax_c (l_c - log(-log u_c)), evaluated as the equivalent exponential race
+    //          argmin_c (-log u_c) * exp(-l_c): one log per category.
     int z[PPT];
     float zf[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
-      float bestv = INFINITY;
       int best = 0;
-      for (int c = 0; c < C; c += 2) {
-        uint32_t b0, b1 = 0u;
-        if (RNG == GJX_RNG_JAX32) {
-          const key2 h0 = threefry2x32(sk1[p], 0u, (uint32_t)c);
-          b0 = h0.a ^ h0.b;
-          if (c + 1 < C) { const key2 h1 = threefry2x32(sk1[p], 0u, (uint32_t)(c + 1)); b1 = h1.a ^ h1.b; }
-        } else {
-          const key2 h = threefry2x32(fkey, c0[p], (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(c >> 1));
-          b0 = h.a; b1 = h.b;
-        }
-        // u = uniform(tiny, 1) = f + tiny (f*(1-tiny) == f in fp32; max(tiny, .) is a no-op)
-        const float u0 = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, b0, 9)) - 1.0f) + kTiny;
-        const float e0 = -__builtin_amdgcn_logf(u0) * s_race[c];
-        if (e0 < bestv) { bestv = e0; best = c; }
-        if (c + 1 < C) {
-          const float u1 = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, b1, 9)) - 1.0f) + kTiny;
-          const float e1 = -__builtin_amdgcn_logf(u1) * s_race[c + 1];
-          if (e1 < bestv) { bestv = e1; best = c + 1; }
+      if (RNG == GJX_RNG_FLAT) {
+        const key2 h = threefry2x32(fkey, c0[p], (1u << GJX_FLAT_SITE_SHIFT));
+        const float target = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, h.a, 9)) - 1.0f) * s_cdf[C - 1];
+        for (int c = 0; c < C - 1; ++c) best += (s_cdf[c] > target) ? 0 : 1;
+      } else {
+        float bestv = INFINITY;
+        for (int c = 0; c < C; ++c) {
+          const key2 h = threefry2x32(sk1[p], 0u, (uint32_t)c);
+          // u = uniform(tiny, 1) = f + tiny (f*(1-tiny) == f in fp32; max(tiny, .) is a no-op)
+          const float u = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, h.a ^ h.b, 9)) - 1.0f) + kTiny;
+          const float e = -__builtin_amdgcn_logf(u) * s_race[c];
+          if (e < bestv) { bestv = e; best = c; }
         }
       }
       z[p] = best;
@@ -308,18 +319,19 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
           b0 = h.a; b1 = h.b;
         }
         const int zo = z[p] * DS + d0;
+        float n0, n1;
+        if (RNG == GJX_RNG_FLAT) box_muller(b0, b1, n0, n1);
+        else { n0 = normal_from_bits_fast(b0); n1 = (d0 + 1 < D) ? normal_from_bits_fast(b1) : 0.0f; }
         {
-          const float n = normal_from_bits_fast(b0);
-          const float x = fmaf(s_sig[zo], n, s_mu[zo]);
-          qx[p] = fmaf(n, n, qx[p]);  // ((x - mu)/sigma)^2 up to rounding
+          const float x = fmaf(s_sig[zo], n0, s_mu[zo]);
+          qx[p] = fmaf(n0, n0, qx[p]);  // ((x - mu)/sigma)^2 up to rounding
           const float zy = (s_y[d0] - x) * s_rr[d0];
           qy[p] = fmaf(zy, zy, qy[p]);
           xa[p] = x;
         }
         if (d0 + 1 < D) {
-          const float n = normal_from_bits_fast(b1);
-          const float x = fmaf(s_sig[zo + 1], n, s_mu[zo + 1]);
-          qx[p] = fmaf(n, n, qx[p]);
+          const float x = fmaf(s_sig[zo + 1], n1, s_mu[zo + 1]);
+          qx[p] = fmaf(n1, n1, qx[p]);
           const float zy = (s_y[d0 + 1] - x) * s_rr[d0 + 1];
           qy[p] = fmaf(zy, zy, qy[p]);
           xb[p] = x;
@@ -555,7 +567,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.partials = partials; a.ticket = ticket; a.lse = lse; a.log_k_total = log_k_total;
-    const size_t lds = sizeof(float) * (size_t)(2 * g.C * (g.D + 4) + 3 * g.C + 2 * g.D + 8 + 16);
+    const size_t lds = sizeof(float) * (size_t)(2 * g.C * (g.D + 4) + 4 * g.C + 2 * g.D + 8 + 16);
     if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
     else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
   } else {

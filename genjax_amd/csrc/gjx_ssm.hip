@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
       const key2 h = threefry2x32(sk, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(d0 >> 1));
       b0 = h.a; b1 = h.b;
     }
-    xn[d0] = fmaf(sd, normal_from_bits_fast(b0), xn[d0]);
-    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, normal_from_bits_fast(b1), xn[d0 + 1]);
+    float n0, n1;
+    if (RNG == GJX_RNG_FLAT) box_muller(b0, b1, n0, n1);
+    else { n0 = normal_from_bits_fast(b0); n1 = (d0 + 1 < DX) ? normal_from_bits_fast(b1) : 0.0f; }
+    xn[d0] = fmaf(sd, n0, xn[d0]);
+    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
   }
   if (active) {
 #pragma unroll
@@ -144,5 +147,62 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
                                            : launch_ssm<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
   if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step: dx must be one of 1,2,4,8,16,32");
   GJX_CHECK_LAUNCH("gjx_ssm_step");
+  return GJX_OK;
+}
+
+
+// ---- whole bootstrap filter on one GPU: the T-step loop runs in C++ so that the per-step launches
+// (prefix sum x2, ancestor expansion, fused step) are issued back to back without Python in between.
+// Key discipline as in inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t);
+// the systematic comb offset is uniform(k_res).
+extern "C" int gjx_weight_cumsum(const float*, int64_t, int32_t, const float*, uint64_t*, uint64_t*, void*, size_t, void*);
+extern "C" int gjx_resample_systematic(const uint64_t*, int64_t, const uint64_t*, double, int64_t, int64_t, int64_t, int32_t*, void*);
+
+static void host_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
+  static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    const int* r = (g & 1) ? R + 4 : R;
+    for (int j = 0; j < 4; ++j) { x0 += x1; x1 = (x1 << r[j]) | (x1 >> (32 - r[j])); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  out[0] = x0; out[1] = x1;
+}
+
+extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                              const float* ys_dev /*[T][dy]*/, float* x_a, float* x_b /*[dx][K] ping-pong*/, float* logw,
+                              uint64_t* cum, int32_t* ancestors, float* lse_steps /*[T][4]*/, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!m || !ys_dev || !x_a || !x_b || !logw || !cum || !ancestors || !lse_steps || T <= 0 || K <= 0)
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_filter: bad argument");
+  const size_t need = gjx_workspace_bytes(GJX_OP_SSM, K);
+  if (!workspace || workspace_bytes < 2 * need + 64) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_filter: workspace too small (2x OP_SSM + 64)");
+  char* ws1 = (char*)workspace;
+  char* ws2 = ws1 + need;
+  uint64_t* bt = (uint64_t*)(ws2 + need);
+  uint32_t k[2] = {key0, key1};
+  for (int t = 0; t < T; ++t) {
+    uint32_t kt[2], kp[2], kr[2], b[2];
+    host_threefry(k[0], k[1], 0u, (uint32_t)t, kt);
+    k[0] = kt[0]; k[1] = kt[1];
+    host_threefry(k[0], k[1], 0u, 0u, kp);
+    host_threefry(k[0], k[1], 0u, 1u, kr);
+    float* x_out = (t & 1) ? x_b : x_a;
+    const float* x_prev = (t & 1) ? x_a : x_b;
+    float* lse = lse_steps + 4 * (size_t)t;
+    if (t > 0) {
+      host_threefry(kr[0], kr[1], 0u, 0u, b);
+      const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
+      int rc = gjx_weight_cumsum(logw, K, 1, lse - 4, cum, bt, ws2, need, stream);
+      if (rc) return rc;
+      rc = gjx_resample_systematic(cum, K, bt, u, K, 0, K, ancestors, stream);
+      if (rc) return rc;
+    }
+    const int rc = gjx_ssm_step(m, kp[0], kp[1], rng_mode, t, K, 0, t > 0 ? x_prev : nullptr, K, t > 0 ? ancestors : nullptr,
+                                ys_dev + (size_t)t * m->dy, x_out, logw, lse, K, ws1, need, stream);
+    if (rc) return rc;
+  }
   return GJX_OK;
 }

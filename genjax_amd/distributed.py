@@ -87,13 +87,12 @@ def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global: torch.
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = rows.device
-    cum, total = backend.weight_cumsum(logw, is_log, lse_global)
+    cum, bt_local = backend.weight_cumsum(logw, is_log, lse_global)      # bt_local = {0, local total}
     if world == 1:
-        bt = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), total.reshape(1)])
-        anc = backend.resample_systematic(cum, bt, u, N_total, 0, N_total)
+        anc = backend.resample_systematic(cum, bt_local, u, N_total, 0, N_total)
         return backend.gather_rows(rows, anc), dict(sent=0, ancestors=anc)
     totals = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(totals, total.reshape(1).contiguous(), group=group)
+    dist.all_gather_into_tensor(totals, bt_local[1:2].contiguous(), group=group)
     tot_host = [int(t) for t in totals.cpu().tolist()]           # G integers: the only host sync per step
     total_all = sum(tot_host)
     base = sum(tot_host[:rank])

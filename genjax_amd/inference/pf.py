@@ -29,15 +29,13 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
     N = int(n_out or K)
     if lse is None:
         lse = kernels.logsumexp(logw)
-    cum, total = kernels.weight_cumsum(logw, True, lse)
-    bt = torch.cat([torch.zeros(1, dtype=torch.int64, device=logw.device), total.reshape(1)])
+    cum, bt = kernels.weight_cumsum(logw, True, lse)
     if method == "systematic":
-        anc = kernels.resample_systematic(cum, bt, _unit_from_key(key), N)
-    elif method == "multinomial":
+        return kernels.resample_gather_systematic(cum, bt, _unit_from_key(key), N, rows, want_ancestors=True)
+    if method == "multinomial":
         anc = kernels.resample_multinomial(cum, bt, key, N)
-    else:
-        raise ValueError(method)
-    return kernels.gather_rows(rows, anc), anc
+        return kernels.gather_rows(rows, anc), anc
+    raise ValueError(method)
 
 
 class LinearGaussianSSM:
@@ -70,14 +68,20 @@ class BootstrapFilter:
         self.ssm, self.K = ssm, int(k_particles)
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
 
-    def run(self, key: Key, ys, device=None, rank: int = 0, world: int = 1, keep_means: bool = False):
+    def run(self, key: Key, ys, device=None, rank: int = 0, world: int = 1, keep_means: bool = False,
+            step_by_step: bool = False):
         """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?).
         With world > 1 the K particles are sharded (distributed.py) and ``ys`` is the same on all ranks."""
         from .. import kernels
         from .. import distributed as D
         dev = kernels._dev(device)
         ys_d = torch.as_tensor(np.asarray(ys, np.float32), device=dev) if not torch.is_tensor(ys) else ys.to(dev)
+        ys_d = ys_d.contiguous()
         T = ys_d.shape[0]
+        if world == 1 and not keep_means and not step_by_step:
+            out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K)
+            incs = out["lse_steps"][:, 3]
+            return dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
         off, K = D.shard(self.K, rank, world)
         cs = self.ssm.c_struct(dev)
         ws = kernels.workspace(A.OP_SSM, K, dev)
@@ -85,7 +89,9 @@ class BootstrapFilter:
         logw = torch.empty(K, dtype=torch.float32, device=dev)
         incs = torch.empty(T, dtype=torch.float32, device=dev)
         lse = torch.empty(4, dtype=torch.float32, device=dev)
-        zero = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
+        cum_buf = torch.empty(K, dtype=torch.int64, device=dev)
+        bt_buf = torch.empty(2, dtype=torch.int64, device=dev)
         means = torch.empty((T, self.ssm.dx), dtype=torch.float32, device=dev) if keep_means else None
         x_prev, anc = None, None
         k = key
@@ -94,8 +100,8 @@ class BootstrapFilter:
             k_prop, k_res = split(k)
             if t > 0:
                 if world == 1:
-                    cum, total = kernels.weight_cumsum(logw, True, lse)
-                    anc = kernels.resample_systematic(cum, torch.cat([zero, total.reshape(1)]), _unit_from_key(k_res), self.K)
+                    cum, bt = kernels.weight_cumsum(logw, True, lse, ws=ws2, out=(cum_buf, bt_buf))
+                    anc = kernels.resample_systematic(cum, bt, _unit_from_key(k_res), self.K, prefill=False)
                 else:
                     x_prev, _ = D.resample_exchange(x_prev, logw, lse, _unit_from_key(k_res), self.K)
                     anc = None

@@ -99,23 +99,41 @@ def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_
     return out
 
 
-def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None):
+def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None):
     K = x.numel()
-    cum = torch.empty(K, dtype=torch.int64, device=x.device)      # uint64 payload
-    total = torch.empty(1, dtype=torch.int64, device=x.device)
+    """-> (cum uint64[K] as int64 payload, base_total int64[2] = {0, total})"""
+    cum = torch.empty(K, dtype=torch.int64, device=x.device) if out is None else out[0]
+    bt = torch.empty(2, dtype=torch.int64, device=x.device) if out is None else out[1]
     if ws is None:
         ws = workspace(A.OP_RESAMPLE, K, x.device)
-    check(load().gjx_weight_cumsum(_ptr(x), K, int(is_log), _ptr(lse), _ptr(cum), _ptr(total), _ptr(ws), ws.numel(),
+    check(load().gjx_weight_cumsum(_ptr(x), K, int(is_log), _ptr(lse), _ptr(cum), _ptr(bt), _ptr(ws), ws.numel(),
                                    _stream()), "gjx_weight_cumsum")
-    return cum, total
+    return cum, bt
 
 
-def resample_systematic(cum, base_total, u: float, N_total: int, out_begin=0, n_out=None) -> torch.Tensor:
+def resample_systematic(cum, base_total, u: float, N_total: int, out_begin=0, n_out=None, prefill=True) -> torch.Tensor:
+    """Slots that fall on another rank's particles are left untouched by the kernel; ``prefill`` marks them -1."""
     n_out = int(N_total if n_out is None else n_out)
-    anc = torch.empty(n_out, dtype=torch.int32, device=cum.device)
+    anc = (torch.full((n_out,), -1, dtype=torch.int32, device=cum.device) if prefill
+           else torch.empty(n_out, dtype=torch.int32, device=cum.device))
     check(load().gjx_resample_systematic(_ptr(cum), cum.numel(), _ptr(base_total), float(u), int(N_total),
                                          int(out_begin), n_out, _ptr(anc), _stream()), "gjx_resample_systematic")
     return anc
+
+
+def resample_gather_systematic(cum, base_total, u: float, N_total: int, src: torch.Tensor, dst=None, out_begin=0,
+                               n_out=None, want_ancestors=False, anc=None):
+    """Systematic ancestors + SoA row gather in one call.  -> (dst [rows][n_out], ancestors)"""
+    n_out = int(N_total if n_out is None else n_out)
+    rows, stride = src.shape
+    if dst is None:
+        dst = torch.empty((rows, n_out), dtype=torch.float32, device=src.device)
+    if anc is None:
+        anc = torch.empty(n_out, dtype=torch.int32, device=src.device)
+    check(load().gjx_resample_gather_systematic(_ptr(cum), cum.numel(), _ptr(base_total), float(u), int(N_total),
+                                                int(out_begin), n_out, _ptr(src), stride, rows, _ptr(dst), dst.shape[1],
+                                                _ptr(anc), _stream()), "gjx_resample_gather_systematic")
+    return dst, anc
 
 
 def resample_multinomial(cum, base_total, key, N_total: int, out_begin=0, n_out=None) -> torch.Tensor:
@@ -180,3 +198,22 @@ def score_grad(prog: PackedProgram, choices: torch.Tensor):
     grad = torch.empty_like(choices)
     check(load().gjx_score_grad(C.byref(cp), n, _ptr(choices), _ptr(score), _ptr(grad), _stream()), "gjx_score_grad")
     return score, grad
+
+
+def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None):
+    """gjx_ssm_filter: the whole T-step bootstrap filter in one native call.
+    -> dict(lse_steps [T][4], x (final state rows), logw, ancestors)"""
+    dev = ys.device
+    T = ys.shape[0]
+    if bufs is None:
+        need = load().gjx_workspace_bytes(A.OP_SSM, K)
+        bufs = dict(xa=torch.empty((ssm.dx, K), dtype=torch.float32, device=dev),
+                    xb=torch.empty((ssm.dx, K), dtype=torch.float32, device=dev),
+                    logw=torch.empty(K, dtype=torch.float32, device=dev), cum=torch.empty(K, dtype=torch.int64, device=dev),
+                    anc=torch.empty(K, dtype=torch.int32, device=dev), lse=torch.empty((T, 4), dtype=torch.float32, device=dev),
+                    ws=torch.zeros(2 * need + 64, dtype=torch.uint8, device=dev))
+    check(load().gjx_ssm_filter(C.byref(ssm), key[0], key[1], rng_mode, T, int(K), _ptr(ys), _ptr(bufs["xa"]), _ptr(bufs["xb"]),
+                                _ptr(bufs["logw"]), _ptr(bufs["cum"]), _ptr(bufs["anc"]), _ptr(bufs["lse"]), _ptr(bufs["ws"]),
+                                bufs["ws"].numel(), _stream()), "gjx_ssm_filter")
+    return dict(lse_steps=bufs["lse"], x=bufs["xa"] if (T - 1) % 2 == 0 else bufs["xb"], logw=bufs["logw"],
+                ancestors=bufs["anc"], _bufs=bufs)

@@ -194,20 +194,28 @@ int gjx_categorical_pick(const float* logw, int64_t K, int64_t particle_offset, 
  * categorical draws + gather, docs/cookbook/inactive/inference/importance_sampling.ipynb) ----
  * Weights are turned into exact fixed-point integers q_i = (uint64)(w_i * 2^30),
  * w_i = is_log ? exp(x_i - max) : x_i, so prefix sums and comb searches are exact integer work.
- *   cum       u64[K] out : inclusive prefix sums of q
- *   total_dev u64[1] out : sum q
+ *   cum            u64[K] out : inclusive prefix sums of q
+ *   base_total_dev u64[2] out : {0, sum q} — ready to pass to the resamplers on one GPU; with several ranks the
+ *                               caller overwrites it with {sum of lower ranks' totals, sum over all ranks}
  */
 int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse /*max at [0]*/,
-                      uint64_t* cum, uint64_t* total_dev, void* workspace, size_t workspace_bytes,
+                      uint64_t* cum, uint64_t* base_total_dev, void* workspace, size_t workspace_bytes,
                       void* stream);
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:
- * ancestors[j - out_begin] = local index i, or -1 when slot j belongs to another rank.
+ * ancestors[j - out_begin] = local index i; slots that belong to another rank's particles are LEFT UNTOUCHED
+ * (a caller that needs markers pre-fills the buffer with -1; on one GPU every slot is written).
  * base_total_dev: u64[2] = {base, total_all} on the device. */
 int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,
                             double u, int64_t N_total, int64_t out_begin, int64_t n_out,
                             int32_t* ancestors, void* stream);
+/* the same search fused with the row gather: dst[r][j - out_begin] = src[r][ancestor(j)] for r < rows
+ * (slots owned by another rank are left untouched in dst and in ancestors); ancestors int32[n_out] is scratch/output */
+int gjx_resample_gather_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev, double u,
+                                   int64_t N_total, int64_t out_begin, int64_t n_out, const float* src,
+                                   int64_t src_stride, int32_t rows, float* dst, int64_t dst_stride,
+                                   int32_t* ancestors, void* stream);
 /* multinomial: slot j draws u_j = uniform(bits(key, j)), ancestor = first i with cum_i > u_j * total */
 int gjx_resample_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,
                              uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
@@ -236,6 +244,16 @@ int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mod
                  int64_t K, int64_t particle_offset, const float* x_prev, int64_t prev_stride,
                  const int32_t* anc, const float* y_dev, float* x_out, float* logw, float* lse,
                  int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The whole T-step bootstrap filter on ONE GPU, looped in C++ (4 launches per step, no host round trip):
+ * step keys k_t = fold_in(k_{t-1}, t), (k_prop, k_res) = split(k_t), systematic resampling before every
+ * propagate step with comb offset uniform(k_res) — identical to issuing the per-step calls from the host.
+ *   ys_dev f32[T][dy]; x_a, x_b f32[dx][K] (step t writes x_a for even t, x_b for odd t); logw f32[K];
+ *   cum u64[K], ancestors i32[K] scratch; lse_steps f32[T][4] out (log-ML estimate = sum_t lse_steps[t][3]).
+ *   workspace: 2 * gjx_workspace_bytes(GJX_OP_SSM, K) + 64 bytes, zero-filled once. */
+int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                   const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
+                   float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
  * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float

@@ -172,6 +172,20 @@ static inline float gumbel_from_bits(uint32_t bits) { /* jax.random.gumbel */
   return -logf(-logf(u));
 }
 
+/* Standard normal for element e of a stream.
+ *   JAX32: sqrt(2) * erfinv(uniform(-1,1)) of the element's 32 bits (jax.random.normal).
+ *   FLAT : Box-Muller on the TWO words of the element's hash: u1 = 1 - unit(word a) in (0,1],
+ *          u2 = unit(word b); even elements take r*cos(2 pi u2), odd ones r*sin(2 pi u2).  An exact
+ *          sampler that needs one log, one sqrt and one sin/cos per PAIR instead of an erfinv per draw. */
+static float stream_normal(const ostream* s, uint32_t e) {
+  if (s->mode == GJX_RNG_JAX32) return normal_from_bits(elem_bits(s, e));
+  const float u1 = 1.0f - bits_to_unit(elem_bits(s, e & ~1u));
+  const float u2 = bits_to_unit(elem_bits(s, e | 1u));
+  const float r = sqrtf(-2.0f * logf(u1));
+  const float ang = 6.28318530718f * u2;
+  return r * ((e & 1u) ? sinf(ang) : cosf(ang));
+}
+
 float gjxo_normal_from_bits(uint32_t bits) { return normal_from_bits(bits); }
 float gjxo_gumbel_from_bits(uint32_t bits) { return gumbel_from_bits(bits); }
 float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
@@ -179,12 +193,15 @@ float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
 /* Marsaglia & Tsang (2000) gamma sampler in log space; the draw budget per gamma variate is
  * fixed so that element indices are a pure function of (variate, iteration). */
 #define GAMMA_MAXIT 32
-#define GAMMA_NDRAW (2 * GAMMA_MAXIT + 1)
+#define GAMMA_NDRAW (4 * GAMMA_MAXIT + 2)
+/* draw schedule of one gamma variate (element indices relative to `base`): iteration t takes its normal
+ * from element 4t and its uniform from element 4t+2 (different hash pairs in the FLAT layout, where a
+ * normal consumes both words of its pair); the a < 1 boost uniform is element 4*MAXIT. */
 static float log_gamma_variate(const ostream* sk, uint32_t base, float a) {
   float boost = 0.0f;
   float aa = a;
   if (a < 1.0f) {
-    float u = uniform_from_bits(elem_bits(sk, base + 2 * GAMMA_MAXIT), F32_TINY, 1.0f);
+    float u = uniform_from_bits(elem_bits(sk, base + 4 * GAMMA_MAXIT), F32_TINY, 1.0f);
     boost = logf(u) / a;
     aa = a + 1.0f;
   }
@@ -192,8 +209,8 @@ static float log_gamma_variate(const ostream* sk, uint32_t base, float a) {
   float c = 1.0f / sqrtf(9.0f * d);
   float res = logf(d);
   for (int t = 0; t < GAMMA_MAXIT; ++t) {
-    float x = normal_from_bits(elem_bits(sk, base + 2 * t));
-    float u = uniform_from_bits(elem_bits(sk, base + 2 * t + 1), F32_TINY, 1.0f);
+    float x = stream_normal(sk, base + 4 * t);
+    float u = uniform_from_bits(elem_bits(sk, base + 4 * t + 2), F32_TINY, 1.0f);
     float v = 1.0f + c * x;
     if (v <= 0.0f) continue;
     float lv = 3.0f * logf(v);
@@ -294,7 +311,7 @@ static int draws_per_elem(int kind) {
 static float elem_sample(int kind, const ostream* sk, uint32_t c, float a, float b) {
   switch (kind) {
     case GJX_NORMAL:
-    case GJX_MVNORMAL_DIAG: return a + b * normal_from_bits(elem_bits(sk, c));
+    case GJX_MVNORMAL_DIAG: return a + b * stream_normal(sk, c);
     case GJX_FLIP: return bits_to_unit(elem_bits(sk, c)) < a ? 1.0f : 0.0f;
     case GJX_BERNOULLI_LOGITS: return bits_to_unit(elem_bits(sk, c)) < sigmoidf_(a) ? 1.0f : 0.0f;
     case GJX_BETA: {
@@ -304,13 +321,13 @@ static float elem_sample(int kind, const ostream* sk, uint32_t c, float a, float
     }
     case GJX_UNIFORM: return a + (b - a) * bits_to_unit(elem_bits(sk, c));
     case GJX_EXPONENTIAL: return -logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)) / a;
-    case GJX_HALF_NORMAL: return fabsf(normal_from_bits(elem_bits(sk, c))) * a;
+    case GJX_HALF_NORMAL: return fabsf(stream_normal(sk, c)) * a;
     case GJX_LAPLACE: {
       float u = uniform_from_bits(elem_bits(sk, c), NEG1_PLUS_ULP, 1.0f);
       float s = (u > 0.0f) - (u < 0.0f);
       return a - b * s * log1pf(-fabsf(u));
     }
-    case GJX_LOG_NORMAL: return expf(a + b * normal_from_bits(elem_bits(sk, c)));
+    case GJX_LOG_NORMAL: return expf(a + b * stream_normal(sk, c));
     case GJX_CAUCHY: return a + b * tanf(3.14159265f * (bits_to_unit(elem_bits(sk, c)) - 0.5f));
     case GJX_GAMMA: return expf(log_gamma_variate(sk, c, a)) / b;
     default: return NAN;
@@ -344,7 +361,25 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
       }
       float lse = mx + (float)log(se);
       float v;
-      if (s->mode == GJX_MODE_SAMPLE) {
+      if (s->mode == GJX_MODE_SAMPLE && prog->rng_mode == GJX_RNG_FLAT) {
+        /* FLAT layout: inverse CDF on ONE uniform (float32 running sum of exp(l - max), category order) */
+        float tot = 0.0f;
+        for (int c = 0; c < n; ++c) {
+          float l = eval_param(&s->p[0], c, tab, vals);
+          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+          tot += expf(l - mx);
+        }
+        const float target = bits_to_unit(elem_bits(sk, 0u)) * tot;
+        float run = 0.0f;
+        int zc = n - 1;
+        for (int c = 0; c < n; ++c) {
+          float l = eval_param(&s->p[0], c, tab, vals);
+          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+          run += expf(l - mx);
+          if (run > target) { zc = c; break; }
+        }
+        v = (float)zc;
+      } else if (s->mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
         int best = 0;
         float bestv = -INFINITY;
         for (int c = 0; c < n; ++c) {
@@ -567,7 +602,7 @@ int gjxo_ssm_step(int32_t dx, int32_t dy, const float* A, const float* H, float 
         mu = acc;
         sd = q;
       }
-      xn[d] = mu + sd * normal_from_bits(elem_bits(sk, (uint32_t)d));
+      xn[d] = mu + sd * stream_normal(sk, (uint32_t)d);
       x_out[(int64_t)d * K + i] = xn[d];
     }
     float lw = 0.0f;
@@ -748,7 +783,7 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
       for (int m = 0; m < nsel; ++m) { /* sample_momenta hmc.py:120-130 */
         const ostream ms = prog->rng_mode == GJX_RNG_JAX32 ? stream_from_site_key(fold_in(sub, (uint32_t)leaf_of[m]))
                                                            : stream_open(GJX_RNG_FLAT, key, gidx, (uint32_t)leaf_of[m] + 1u);
-        p[m] = normal_from_bits(elem_bits(&ms, (uint32_t)elem_of[m]));
+        p[m] = stream_normal(&ms, (uint32_t)elem_of[m]);
         k0 += -0.5f * p[m] * p[m] - HALF_LOG_2PI;
       }
       for (int s = 0; s < ns; ++s) g[s] = g0[s];

@@ -19,7 +19,7 @@ class OracleBackend:
     def weight_cumsum(self, x, is_log, lse):
         from oracle import cpu
         cum, tot = cpu.weight_cumsum(x.numpy(), is_log, None if lse is None else lse.numpy())
-        return torch.from_numpy(cum.view(np.int64)), torch.tensor([tot], dtype=torch.int64)
+        return torch.from_numpy(cum.view(np.int64)), torch.tensor([0, tot], dtype=torch.int64)
 
     def resample_systematic(self, cum, base_total, u, N_total, out_begin, n_out):
         from oracle import cpu

@@ -238,11 +238,10 @@ def test_resampling_bit_exact(K_, oracle):
         lw = rs.standard_normal(K) * (4.0 if K % 2 else 1.0)
         w = np.exp(lw - lw.max()).astype(np.float32)
         wd = torch.as_tensor(w).cuda()
-        cum, tot = K_.weight_cumsum(wd)
+        cum, bt = K_.weight_cumsum(wd)
         cum_o, tot_o = oracle.weight_cumsum(w)
         np.testing.assert_array_equal(_np(cum).view(np.uint64), cum_o)
-        assert int(tot.item()) == tot_o
-        bt = torch.tensor([0, tot_o], dtype=torch.int64).cuda()
+        assert _np(bt).tolist() == [0, tot_o]
         for N, u in ((K, 0.37), (max(1, K // 3), 0.0), (2 * K + 1, 0.999999)):
             anc = _np(K_.resample_systematic(cum, bt, u, N))
             np.testing.assert_array_equal(anc, oracle.resample_systematic(cum_o, u, N))
@@ -259,13 +258,15 @@ def test_resampling_bit_exact(K_, oracle):
         rows = rs.standard_normal((3, K)).astype(np.float32)
         anc_t = K_.resample_systematic(cum, bt, 0.37, K)
         np.testing.assert_array_equal(_np(K_.gather_rows(torch.as_tensor(rows).cuda(), anc_t)), oracle.gather_rows(rows, _np(anc_t)))
+        fused, anc_f = K_.resample_gather_systematic(cum, bt, 0.37, K, torch.as_tensor(rows).cuda(), want_ancestors=True)
+        np.testing.assert_array_equal(_np(anc_f), _np(anc_t))
+        np.testing.assert_array_equal(_np(fused), oracle.gather_rows(rows, _np(anc_t)))
     # log-weight input: same as normalising on the device first, bit for bit
     lwd = torch.as_tensor(lw.astype(np.float32)).cuda()
     l4 = K_.logsumexp(lwd)
-    cum_a, tot_a = K_.weight_cumsum(lwd, True, l4)
-    # fixed-point conversion of exp(x - max) evaluated by the same device exp
-    assert int(tot_a.item()) == int(cum_a[-1].item())
-    anc_a = _np(K_.resample_systematic(cum_a, torch.cat([tot_a.new_zeros(1), tot_a]), 0.1, K))
+    cum_a, bt_a = K_.weight_cumsum(lwd, True, l4)
+    assert int(bt_a[1].item()) == int(cum_a[-1].item()) and int(bt_a[0].item()) == 0
+    anc_a = _np(K_.resample_systematic(cum_a, bt_a, 0.1, K))
     counts = np.bincount(anc_a, minlength=K)
     wn = np.exp(lw - cf.logsumexp(lw))
     assert np.abs(counts - K * wn).max() <= 1.01
@@ -276,8 +277,7 @@ def test_degenerate_and_invalid_arguments(K_):
     from genjax_amd._lib import GjxError
     w = torch.zeros(1000).cuda()
     w[123] = 1.0
-    cum, tot = K_.weight_cumsum(w)
-    bt = torch.cat([tot.new_zeros(1), tot])
+    cum, bt = K_.weight_cumsum(w)
     assert (K_.resample_systematic(cum, bt, 0.9999, 1000) == 123).all()
     assert (K_.resample_multinomial(cum, bt, (1, 2), 1000) == 123).all()
     with pytest.raises(GjxError):
@@ -323,6 +323,19 @@ def test_bootstrap_filter_full_size(K_, golden):
     assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
     np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
     np.testing.assert_allclose(_np(out["means"]), means, atol=0.15)
+
+
+def test_native_filter_loop_equals_step_by_step(K_):
+    """gjx_ssm_filter (C++ loop) issues exactly the launches of the host-driven loop: bit-identical results."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem(T=40)
+    for rng in RNGS:
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 10_000, rng_mode=rng)
+        a = bf.run(core.key(7), s["y"])
+        b = bf.run(core.key(7), s["y"], step_by_step=True)
+        np.testing.assert_array_equal(_np(a["increments"]), _np(b["increments"]))
+        np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+        np.testing.assert_array_equal(_np(a["logw"]), _np(b["logw"]))
 
 
 @pytest.mark.parametrize("rng", RNGS)
