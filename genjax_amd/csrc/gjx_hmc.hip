@@ -210,9 +210,241 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
   if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------
+// fused kernel for hierarchical logistic regression (BASELINE config 5):
+//   log_tau ~ N(m0, s0);  beta_p ~ N(mu_p, exp(log_tau)), p < P;  y_n ~ Bernoulli(logits = b_n + X_n . beta), n < N
+// The whole chain state (log_tau, beta[P], momenta, gradient) stays in VGPRs for all L leapfrog steps.  A block
+// stages X (N*P floats), y and the bias ONCE into LDS; inside the trajectory there is no global-memory traffic.
+// Per chain-leapfrog: 2*N*P FMA for X beta and X^T r plus N sigmoids — FP32 VALU bound, ≈0 HBM bytes; the score
+// (softplus) is only needed at the two ends of the trajectory.  Random streams and results match
+// k_hmc_generic on the same program.
+struct LogregArgs {
+  const float* tab;
+  int N;
+  int x_off, b_off, b_len, y_off;      // X[N][P] row-major, bias, observed y
+  int mu_off, mu_len;                  // prior mean of beta
+  float m0, s0;                        // prior of log_tau
+  key2 key;
+  int64_t n, offset;
+  float eps;
+  int L, stale, accept;
+  float* choices;                      // row 0: log_tau, rows 1..P: beta
+  float* score;
+  float* alpha;
+  float* accepted;
+};
+
+// Work split: FOUR lanes per chain.  Lane (c, k) handles the observations n ≡ k (mod 4); the four partial
+// gradients are summed with two quad butterflies (DPP), after which all four lanes hold the same full
+// gradient and take the identical leapfrog update.  That gives 4x the waves of a lane-per-chain layout
+// (2^16 chains -> 4096 waves, 4 per SIMD), which is what hides the LDS latency; each ds_read_b128 serves four
+// different rows (k = 0..3) broadcast over the 16 chains of the wave — conflict-free.
+// LDS image: sX[Npad][P], sY[Npad], sB[Npad]  (Npad = N rounded up to 8; padded rows are zero with y = 0.5,
+// bias 0, so their residual y - sigmoid(0) is exactly 0 and they add nothing to the gradient)
+GJX_DEV float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+template <int P>
+GJX_DEV void logreg_grad(const LogregArgs& a, const float* __restrict__ sX, const float* __restrict__ sY,
+                         const float* __restrict__ sB, int Npad, int k, float lt, const float (&beta)[P], float (&g)[P],
+                         float& glt) {
+  const float* __restrict__ tab = a.tab;
+  float gp[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) gp[p] = 0.0f;
+  for (int n = k; n < Npad; n += 8) {  // two observations of this lane per iteration (n and n + 4)
+    float x0[P], x1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { x0[p] = sX[n * P + p]; x1[p] = sX[(n + 4) * P + p]; }
+    float s0 = sB[n], s1 = sB[n + 4];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { s0 = fmaf(x0[p], beta[p], s0); s1 = fmaf(x1[p], beta[p], s1); }
+    const float r0 = sY[n] - sigmoid(s0), r1 = sY[n + 4] - sigmoid(s1);
+#pragma unroll
+    for (int p = 0; p < P; ++p) { gp[p] = fmaf(x0[p], r0, gp[p]); gp[p] = fmaf(x1[p], r1, gp[p]); }
+  }
+  const float t2i = fast_exp(-2.0f * lt);  // 1 / tau^2
+  float acc = 0.0f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const float z = beta[p] - tab[a.mu_off + (a.mu_len == 1 ? 0 : p)];
+    g[p] = quad_sum(gp[p]) - z * t2i;
+    acc = fmaf(z * z, t2i, acc);
+  }
+  const float rs0 = fast_rcp(a.s0);
+  glt = -(lt - a.m0) * rs0 * rs0 + acc - (float)P;
+}
+
+template <int P>
+GJX_DEV float logreg_score(const LogregArgs& a, const float* __restrict__ sX, const float* __restrict__ sY,
+                           const float* __restrict__ sB, int k, float lt, const float (&beta)[P]) {
+  const float* __restrict__ tab = a.tab;
+  float part = 0.0f;
+  for (int n = k; n < a.N; n += 4) {
+    float sl = sB[n];
+#pragma unroll
+    for (int p = 0; p < P; ++p) sl = fmaf(sX[n * P + p], beta[p], sl);
+    part += elem_logpdf(GJX_BERNOULLI_LOGITS, sY[n], sl, 0.0f);
+  }
+  float sc = quad_sum(part) + normal_logpdf(lt, a.m0, a.s0);
+  const float tau = fast_exp(lt);
+#pragma unroll
+  for (int p = 0; p < P; ++p) sc += normal_logpdf(beta[p], tab[a.mu_off + (a.mu_len == 1 ? 0 : p)], tau);
+  return sc;
+}
+
+constexpr int kLogregThreads = 512;  // 128 chains per block; two blocks (2 x ~72 KB of LDS) per CU -> 4 waves per SIMD
+
+template <int RNG, int P, bool STALE>
+__global__ __launch_bounds__(kLogregThreads) void k_hmc_logreg(LogregArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, Npad = (N + 7) & ~7;
+  float* sX = smem;
+  float* sY = sX + Npad * P;
+  float* sB = sY + Npad;
+  for (int t = threadIdx.x; t < Npad * P; t += kLogregThreads) sX[t] = t < N * P ? a.tab[a.x_off + t] : 0.0f;
+  for (int t = threadIdx.x; t < Npad; t += kLogregThreads) {
+    sY[t] = t < N ? a.tab[a.y_off + t] : 0.5f;
+    sB[t] = t < N ? a.tab[a.b_off + (a.b_len == 1 ? 0 : t)] : 0.0f;
+  }
+  __syncthreads();
+  const int k = threadIdx.x & 3;
+  const int64_t n = a.n;
+  int64_t i = (int64_t)blockIdx.x * (kLogregThreads / 4) + (threadIdx.x >> 2);
+  const bool live = i < n;
+  if (!live) i = n - 1;  // keep the quad complete for the butterflies; no stores from shadow lanes
+  float* ch = a.choices;
+  const uint64_t gidx = (uint64_t)(a.offset + i);
+  float lt = ch[i];
+  float beta[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) beta[p] = ch[(int64_t)(1 + p) * n + i];
+  const float score0 = logreg_score<P>(a, sX, sY, sB, k, lt, beta);
+  float g[P], glt, g0[STALE ? P : 1], glt0 = 0.0f;
+  logreg_grad<P>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
+  if (STALE) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) g0[STALE ? p : 0] = g[p];
+    glt0 = glt;
+  }
+  // momenta: leaf 0 = log_tau, leaf 1 = beta (same streams as k_hmc_generic; the 4 lanes of a chain agree)
+  key2 knew{0u, 0u}, sub{0u, 0u};
+  if (RNG == GJX_RNG_JAX32) {
+    const key2 ck = fold_in64(a.key, gidx);
+    knew = fold_in(ck, 0u);
+    sub = fold_in(ck, 1u);
+  }
+  float plt, pb[P], k0 = 0.0f;
+  {
+    BitStream<RNG> bs;
+    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 0u)); else bs.open(a.key, gidx, 1u);
+    plt = stream_normal<RNG>(bs, 0u);
+    k0 += -0.5f * plt * plt - kHalfLog2Pi;
+    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 1u)); else bs.open(a.key, gidx, 2u);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      pb[p] = stream_normal<RNG>(bs, (uint32_t)p);
+      k0 += -0.5f * pb[p] * pb[p] - kHalfLog2Pi;
+    }
+  }
+  const float he = 0.5f * a.eps;
+  for (int t = 1; t <= a.L; ++t) {
+    plt = plt + he * (STALE ? glt0 : glt);
+    lt = lt + a.eps * plt;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      pb[p] = pb[p] + he * (STALE ? g0[STALE ? p : 0] : g[p]);
+      beta[p] = beta[p] + a.eps * pb[p];
+    }
+    logreg_grad<P>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
+    plt += he * glt;
+#pragma unroll
+    for (int p = 0; p < P; ++p) pb[p] += he * g[p];
+  }
+  float sc = a.L > 0 ? logreg_score<P>(a, sX, sY, sB, k, lt, beta) : score0;
+  float k1 = -0.5f * plt * plt - kHalfLog2Pi;
+#pragma unroll
+  for (int p = 0; p < P; ++p) k1 += -0.5f * pb[p] * pb[p] - kHalfLog2Pi;
+  const float al = sc - score0 + k1 - k0;
+  bool acc = true;
+  if (a.accept) {
+    BitStream<RNG> bs;
+    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(knew, 0x4d48u)); else bs.open(a.key, gidx, GJX_FLAT_MAX_SITES);
+    acc = safe_log(bits_to_unit(bs.get(0u))) < al;
+  }
+  if (live && k == 0) {
+    if (acc) {  // rejected chains keep the values already in choices[][]
+      ch[i] = lt;
+#pragma unroll
+      for (int p = 0; p < P; ++p) ch[(int64_t)(1 + p) * n + i] = beta[p];
+    }
+    if (a.score) a.score[i] = acc ? sc : score0;
+    if (a.alpha) a.alpha[i] = al;
+    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;
+  }
+}
+
 }  // namespace gjx
 
 using namespace gjx;
+
+// [normal(CONST,CONST) dim 1, selected] -> [normal(CONST, exp(VALUE slot 0)) dim P, selected]
+//   -> [bernoulli_logits(AFFINE X[N][P] of slots 1..P) dim N, OBS_TAB]
+static bool match_logreg(const gjx_program* p, LogregArgs* a, int* P_out) {
+  if (p->n_sites != 3 || !p->tab) return false;
+  const gjx_site& s0 = p->sites[0];
+  const gjx_site& s1 = p->sites[1];
+  const gjx_site& s2 = p->sites[2];
+  if (s0.kind != GJX_NORMAL || s0.dim != 1 || s0.slot != 0 || s0.mode != GJX_MODE_OBS_SLOT || !(s0.flags & GJX_SITE_HMC_SELECTED)) return false;
+  if (s0.p[0].op != GJX_P_CONST || s0.p[1].op != GJX_P_CONST || s0.p[0].xf || s0.p[1].xf) return false;
+  if ((s1.kind != GJX_NORMAL && s1.kind != GJX_MVNORMAL_DIAG) || s1.slot != 1 || s1.mode != GJX_MODE_OBS_SLOT || !(s1.flags & GJX_SITE_HMC_SELECTED)) return false;
+  const int P = s1.dim;
+  if (s1.p[0].op != GJX_P_CONST || s1.p[0].xf || (s1.p[0].len != 1 && s1.p[0].len != P)) return false;
+  if (s1.p[1].op != GJX_P_VALUE || s1.p[1].xf != GJX_XF_EXP || s1.p[1].slot != 0 || s1.p[1].len != 1) return false;
+  if (s2.kind != GJX_BERNOULLI_LOGITS || s2.mode != GJX_MODE_OBS_TAB || s2.slot >= 0) return false;
+  const gjx_param& q = s2.p[0];
+  if (q.op != GJX_P_AFFINE || q.xf || q.slot != 1 || q.n != P || (q.len != 1 && q.len != s2.dim)) return false;
+  if (p->n_slots != 1 + P) return false;
+  if (!(P == 2 || P == 4 || P == 8 || P == 16 || P == 32)) return false;
+  if (sizeof(float) * ((size_t)((s2.dim + 7) & ~7) * (P + 2)) > 160 * 1024) return false;  // X, y, bias must fit the 160 KB LDS
+  a->N = s2.dim; a->x_off = q.moff; a->b_off = q.off; a->b_len = q.len; a->y_off = s2.obs_off;
+  a->mu_off = s1.p[0].off; a->mu_len = s1.p[0].len;
+  a->m0 = p->tab[s0.p[0].off]; a->s0 = p->tab[s0.p[1].off];
+  *P_out = P;
+  return true;
+}
+
+template <int RNG>
+static int launch_logreg(const LogregArgs& a, int P, hipStream_t st) {
+  const int chains_per_block = kLogregThreads / 4;
+  const unsigned nb = (unsigned)((a.n + chains_per_block - 1) / chains_per_block);
+  const int Npad = (a.N + 7) & ~7;
+  const size_t lds = sizeof(float) * ((size_t)Npad * P + 2 * (size_t)Npad);
+#define GJX_LR2(PP, ST)                                                                                          \
+  {                                                                                                              \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg<RNG, PP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_hmc_logreg<RNG, PP, ST>), dim3(nb), dim3(kLogregThreads), lds, st, a);                 \
+  }
+#define GJX_LR(PP) case PP: if (a.stale) GJX_LR2(PP, true) else GJX_LR2(PP, false) break;
+  switch (P) {
+    GJX_LR(2) GJX_LR(4) GJX_LR(8) GJX_LR(16) GJX_LR(32)
+    default: return -1;
+  }
+#undef GJX_LR
+#undef GJX_LR2
+  return 0;
+}
+
+extern "C" int gjx_hmc_engine(const gjx_program* prog) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  LogregArgs a; int P;
+  const char* f = getenv("GJX_FORCE_GENERIC");
+  if (!(f && atoi(f)) && match_logreg(prog, &a, &P)) return 2;
+  return 0;
+}
 
 static int count_selected(const gjx_program* prog) {
   int nsel = 0;
@@ -239,6 +471,18 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS))
       return gjx_fail(GJX_EINVAL, "gjx_hmc: only float32 sites can be selected (hmc.py:49-65)");
+  }
+  {
+    LogregArgs la; int P;
+    const char* f = getenv("GJX_FORCE_GENERIC");
+    if (!(f && atoi(f)) && match_logreg(prog, &la, &P)) {
+      la.tab = prog->tab_dev; la.key = key2{key0, key1}; la.n = n; la.offset = chain_offset; la.eps = eps; la.L = L;
+      la.stale = stale_grad_compat; la.accept = accept; la.choices = choices; la.score = score; la.alpha = alpha; la.accepted = accepted;
+      if (prog->rng_mode == GJX_RNG_JAX32) launch_logreg<GJX_RNG_JAX32>(la, P, (hipStream_t)stream);
+      else launch_logreg<GJX_RNG_FLAT>(la, P, (hipStream_t)stream);
+      GJX_CHECK_LAUNCH("gjx_hmc/logreg");
+      return GJX_OK;
+    }
   }
   if (!workspace || workspace_bytes < gjx_hmc_workspace_bytes(prog, n)) return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small");
   HmcArgs a;

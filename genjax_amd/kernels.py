@@ -190,6 +190,11 @@ def hmc(prog: PackedProgram, key, choices: torch.Tensor, eps: float, L: int, sta
     return dict(choices=choices, score=score, alpha=alpha, accepted=acc, _ws=ws)
 
 
+def hmc_engine(prog: PackedProgram) -> int:
+    cp = prog.c_program(None)
+    return int(load().gjx_hmc_engine(C.byref(cp)))
+
+
 def score_grad(prog: PackedProgram, choices: torch.Tensor):
     n = choices.shape[1]
     dev = choices.device

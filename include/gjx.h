@@ -267,6 +267,8 @@ int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_m
  *   with log U drawn from fold_in(key', 0x4d48) (FLAT: site 1023) and reverts rejected chains; accepted f32[n] out or NULL.
  */
 size_t gjx_hmc_workspace_bytes(const gjx_program* prog, int64_t n);
+/* which engine gjx_hmc will use: 0 = generic site interpreter, 2 = fused hierarchical-logistic-regression kernel */
+int gjx_hmc_engine(const gjx_program* prog);
 int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
             float* score, float* alpha, float* accepted, void* workspace, size_t workspace_bytes,
