@@ -255,16 +255,16 @@ GJX_DEV void logreg_grad(const LogregArgs& a, const float* __restrict__ sX, cons
   float gp[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) gp[p] = 0.0f;
-  for (int n = k; n < Npad; n += 8) {  // two observations of this lane per iteration (n and n + 4)
-    float x0[P], x1[P];
+  for (int n = k; n < Npad; n += 4) {  // one observation of this lane per iteration; 4 waves per SIMD hide the latency
+    float x0[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { x0[p] = sX[n * P + p]; x1[p] = sX[(n + 4) * P + p]; }
-    float s0 = sB[n], s1 = sB[n + 4];
+    for (int p = 0; p < P; ++p) x0[p] = sX[n * P + p];
+    float s0 = sB[n];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { s0 = fmaf(x0[p], beta[p], s0); s1 = fmaf(x1[p], beta[p], s1); }
-    const float r0 = sY[n] - sigmoid(s0), r1 = sY[n + 4] - sigmoid(s1);
+    for (int p = 0; p < P; ++p) s0 = fmaf(x0[p], beta[p], s0);
+    const float r0 = sY[n] - sigmoid(s0);
 #pragma unroll
-    for (int p = 0; p < P; ++p) { gp[p] = fmaf(x0[p], r0, gp[p]); gp[p] = fmaf(x1[p], r1, gp[p]); }
+    for (int p = 0; p < P; ++p) gp[p] = fmaf(x0[p], r0, gp[p]);
   }
   const float t2i = fast_exp(-2.0f * lt);  // 1 / tau^2
   float acc = 0.0f;
@@ -299,7 +299,7 @@ GJX_DEV float logreg_score(const LogregArgs& a, const float* __restrict__ sX, co
 constexpr int kLogregThreads = 512;  // 128 chains per block; two blocks (2 x ~72 KB of LDS) per CU -> 4 waves per SIMD
 
 template <int RNG, int P, bool STALE>
-__global__ __launch_bounds__(kLogregThreads) void k_hmc_logreg(LogregArgs a) {
+__global__ __launch_bounds__(kLogregThreads, 4) void k_hmc_logreg(LogregArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, Npad = (N + 7) & ~7;
   float* sX = smem;
