@@ -81,7 +81,7 @@ def main():
     rank, world = DD.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -133,7 +133,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

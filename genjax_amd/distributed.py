@@ -14,6 +14,7 @@ exercised on CPU tensors in the gloo tests.
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -28,11 +29,34 @@ def init_from_env(backend: str | None = None) -> tuple[int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("GJX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+def _host_staged(group=None) -> bool:
+    """gloo moves host memory: device tensors are staged through the CPU (debug / single-GPU dry runs only)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    if inp.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None) -> None:
+    if inp.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
 def shard(K_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -41,6 +65,27 @@ def shard(K_total: int, rank: int, world: int) -> tuple[int, int]:
     k = base + (1 if rank < rem else 0)
     off = rank * base + min(rank, rem)
     return off, k
+
+
+def comb_threshold(j: int, u: float, step: float, total: int) -> int:
+    """floor((j + u) * step) clamped below total — the kernels' IEEE-double expression, bit for bit."""
+    t = int((float(j) + u) * step)
+    return min(t, total - 1) if total > 0 else t
+
+
+def slots_below(c: int, u: float, total: int, N: int) -> int:
+    """#{j in [0, N): comb_threshold(j) < c}  (host twin of slots_below() in csrc/gjx_resample.hip)."""
+    if c <= 0 or total <= 0:
+        return 0
+    if c >= total:
+        return N
+    step = float(total) / float(N)
+    g = int(min(max(math.ceil(c * (float(N) / float(total)) - u), 0), N))
+    while g > 0 and comb_threshold(g - 1, u, step, total) >= c:
+        g -= 1
+    while g < N and comb_threshold(g, u, step, total) < c:
+        g += 1
+    return g
 
 
 class HipBackend:
@@ -52,7 +97,7 @@ class HipBackend:
 
     def resample_systematic(self, cum, base_total, u, N_total, out_begin, n_out):
         from . import kernels
-        return kernels.resample_systematic(cum, base_total, u, N_total, out_begin, n_out)
+        return kernels.resample_systematic(cum, base_total, u, N_total, out_begin, n_out, prefill=False)
 
     def gather_rows(self, src, anc):
         from . import kernels
@@ -71,7 +116,7 @@ def global_lse(local_lse: torch.Tensor, K_total: int, backend=None, group=None) 
         return local_lse
     backend = backend or HipBackend()
     pairs = torch.empty(world * 2, dtype=torch.float32, device=local_lse.device)
-    dist.all_gather_into_tensor(pairs, local_lse[:2].contiguous(), group=group)
+    _all_gather(pairs, local_lse[:2].contiguous(), group)
     return backend.lse_combine(pairs.view(world, 2), K_total)
 
 
@@ -92,40 +137,31 @@ def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global: torch.
         anc = backend.resample_systematic(cum, bt_local, u, N_total, 0, N_total)
         return backend.gather_rows(rows, anc), dict(sent=0, ancestors=anc)
     totals = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(totals, bt_local[1:2].contiguous(), group=group)
-    tot_host = [int(t) for t in totals.cpu().tolist()]           # G integers: the only host sync per step
+    _all_gather(totals, bt_local[1:2].contiguous(), group)
+    tot_host = [int(t) for t in totals.cpu().tolist()]           # G integers: the ONE host sync of the step
     total_all = sum(tot_host)
     base = sum(tot_host[:rank])
     bt = torch.tensor([base, total_all], dtype=torch.int64, device=dev)
-    # output slots whose comb threshold lands on my particles form one contiguous run; bracket it with the
-    # same double arithmetic the kernel uses, padded by one slot, and let the -1 markers trim the ends.
-    step = float(total_all) / float(N_total)
-    if tot_host[rank] == 0 or step == 0.0:
-        j0, j1 = 0, 0
-    else:
-        j0 = max(0, int(base / step - u) - 1)
-        j1 = min(N_total, int((base + tot_host[rank]) / step - u) + 2)
-    anc = backend.resample_systematic(cum, bt, u, N_total, j0, j1 - j0)
-    mine = anc >= 0
-    n_valid = int(mine.sum())
-    first = int(torch.nonzero(mine)[0]) if n_valid else 0
-    anc = anc[first:first + n_valid]
-    slot0 = j0 + first                                            # my children occupy slots [slot0, slot0+n_valid)
-    # split my run by destination rank (slot owner)
-    send_counts = []
-    for d in range(world):
-        lo, k = shard(N_total, d, world)
-        a, b = max(slot0, lo), min(slot0 + n_valid, lo + k)
-        send_counts.append(max(0, b - a))
+    # Every rank's run of output slots follows from the totals alone (same IEEE-double comb arithmetic as the
+    # kernels), so all send/receive counts are known on the host without another round trip.
+    bounds = [0]
+    for r in range(world):
+        bounds.append(slots_below(sum(tot_host[:r + 1]), u, total_all, N_total))
+    slot0, n_valid = bounds[rank], bounds[rank + 1] - bounds[rank]
+    anc = backend.resample_systematic(cum, bt, u, N_total, slot0, n_valid)
+
+    def overlap(a0, a1, b0, b1):
+        return max(0, min(a1, b1) - max(a0, b0))
+
+    owners = [shard(N_total, d, world) for d in range(world)]
+    send_counts = [overlap(slot0, slot0 + n_valid, lo, lo + k) for lo, k in owners]
+    my_lo, my_k = owners[rank]
+    recv_counts = [overlap(bounds[s_], bounds[s_ + 1], my_lo, my_lo + my_k) for s_ in range(world)]
     children = backend.gather_rows(rows, anc)                     # [R][n_valid], slot order
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-    rc = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(c) for c in rc.cpu().tolist()]
     R = rows.shape[0]
     send = children.t().contiguous()                              # [n_valid][R]: splits run along dim 0
     recv = torch.empty((sum(recv_counts), R), dtype=rows.dtype, device=dev)
-    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+    _all_to_all(recv, send, recv_counts, send_counts, group)
     off_mine, n_mine = shard(N_total, rank, world)
     assert recv.shape[0] == n_mine, (recv.shape, n_mine)
     return recv.t().contiguous(), dict(sent=n_valid - send_counts[rank], slot_off=off_mine, ancestors=anc)
