@@ -2,7 +2,7 @@
 """bench.py — whole-job throughput of the ImportanceK hot path on N MI355X GPUs of one node.
 
 A "step" is one pass of the path over one batch of synthetic input, per GPU:
-    propagate + reweight + fused log-sum-exp (ONE kernel, gjx_run_program)
+    propagate + reweight + per-block log-sum-exp partials (ONE kernel, gjx_run_program)
       -> [N > 1: 8-byte all-gather of {max, sumexp} + combine]
       -> fixed-point prefix sum of the weights (2 kernels)
       -> systematic ancestors by per-particle slot-range expansion (no search), row gather by ancestor
@@ -97,6 +97,8 @@ def main():
     cum = torch.empty(K, dtype=torch.int64, device=dev)
     bt = torch.empty(2, dtype=torch.int64, device=dev)
     anc = torch.empty(K, dtype=torch.int32, device=dev)
+    lse_rec = torch.empty(4, dtype=torch.float32, device=dev)
+    n_part = kernels.run_partials_count(prog, K, off)
     n_samp = max(1, min(args.event_samples, args.steps))
     sample_at = {int(round(j * (args.steps - 1) / max(n_samp - 1, 1))): j for j in range(n_samp)}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
@@ -106,14 +108,16 @@ def main():
         j = sample_at.get(i) if timed else None
         if j is not None:
             ev[j][0].record()
-        kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False)
+        kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
+                            want_lse=(world > 1))
         if j is not None:
             ev[j][1].record()
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
         if world == 1:
-            kernels.weight_cumsum(out["logw"], True, out["lse"], ws=ws2, out=(cum, bt))
+            # single GPU: the LSE reduction is finished by the prefix-sum kernels' prologue (no serial tail)
+            kernels.weight_cumsum(out["logw"], ws=ws2, out=(cum, bt), partials=(ws, n_part), lse_out=lse_rec, K_total=K_total)
             kernels.resample_gather_systematic(cum, bt, u, K_total, out["choices"], rows, anc=anc)
-            return out["lse"]
+            return lse_rec
         lse = DD.global_lse(out["lse"], K_total)
         DD.resample_exchange(out["choices"], out["logw"], lse, u, K_total)
         return lse

@@ -86,6 +86,36 @@ GJX_DEV uint64_t weight_q(const float* x, int64_t i, int is_log, float mx) {
   return (uint64_t)(w * kWeightScale);
 }
 
+// reference maximum of the log-weights for the fixed-point conversion.
+//   mode 1: lse[0] of a finished LSE record.
+//   mode 2: `lse` points at n_partials per-block {max, sumexp} pairs left by the producing kernel
+//           (gjx_run_program with lse == NULL): every block reduces them itself (a few KB from L2) — the LSE
+//           "finish" rides in the consumer's prologue instead of being a serial tail of the producer.
+// Block-uniform result; `red` is LDS scratch of >= 8 floats; ends with a barrier.
+GJX_DEV float block_ref_max(int mode, const float* lse, int n_partials, float* red, float* sum_out) {
+  if (mode != 2) { if (sum_out) *sum_out = 0.0f; return mode == 1 ? lse[0] : 0.0f; }
+  const float2* parts = (const float2*)lse;
+  float tmax = -INFINITY, tsum = 0.0f;
+  for (int t = threadIdx.x; t < n_partials; t += 256) {
+    const float2 p = parts[t];
+    const float nm = fmaxf(tmax, p.x);
+    if (nm > -INFINITY) tsum = tsum * fast_exp(tmax - nm) + p.y * fast_exp(p.x - nm);
+    tmax = nm;
+  }
+  const float wm = wave_max(tmax);
+  const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[4 + (threadIdx.x >> 6)] = ws; }
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (sum_out) {
+    float sm = 0.0f;
+    for (int w = 0; w < 4; ++w) sm += m > -INFINITY ? red[4 + w] * fast_exp(red[w] - m) : 0.0f;
+    *sum_out = sm;
+  }
+  return m;
+}
+
 GJX_DEV uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o, 64);
@@ -93,9 +123,16 @@ GJX_DEV uint64_t wave_sum_u64(uint64_t v) {
 }
 
 __global__ __launch_bounds__(256) void k_wsum_blocks(const float* x, int64_t K, int is_log, const float* lse,
+                                                    int n_partials, float* lse_out, float log_k_total,
                                                     uint64_t* block_sums) {
   __shared__ uint64_t red[4];
-  const float mx = is_log ? lse[0] : 0.0f;
+  __shared__ float fred[8];
+  float sm;
+  const float mx = block_ref_max(is_log, lse, n_partials, fred, &sm);
+  if (is_log == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float l = mx > -INFINITY ? mx + logf(sm) : -INFINITY;
+    lse_out[0] = mx; lse_out[1] = sm; lse_out[2] = l; lse_out[3] = l - log_k_total;
+  }
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   uint64_t s = 0;
 #pragma unroll
@@ -111,10 +148,12 @@ __global__ __launch_bounds__(256) void k_wsum_blocks(const float* x, int64_t K, 
 // K/2048 of them) instead of waiting for a separate single-block scan kernel, then scans its own tile.
 // The last block also publishes base_total = {0, sum of all weights}.
 __global__ __launch_bounds__(256) void k_wscan_write(const float* x, int64_t K, int is_log, const float* lse,
-                                                    const uint64_t* block_sums, uint64_t* cum, uint64_t* base_total) {
+                                                    int n_partials, const uint64_t* block_sums, uint64_t* cum,
+                                                    uint64_t* base_total) {
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t red[4];
-  const float mx = is_log ? lse[0] : 0.0f;
+  __shared__ float fred[8];
+  const float mx = block_ref_max(is_log, lse, n_partials, fred, nullptr);
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   // offset of this block = sum of block_sums[0 .. blockIdx.x)
   uint64_t pre = 0;
@@ -304,16 +343,19 @@ extern "C" int gjx_categorical_pick(const float* logw, int64_t K, int64_t partic
   return GJX_OK;
 }
 
-extern "C" int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, uint64_t* cum,
-                                 uint64_t* base_total_dev, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !cum || !base_total_dev || K <= 0 || (is_log && !lse)) return gjx_fail(GJX_EINVAL, "gjx_weight_cumsum: bad argument");
+extern "C" int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials,
+                                 uint64_t* cum, uint64_t* base_total_dev, float* lse_out, int64_t K_total,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !cum || !base_total_dev || K <= 0 || is_log < 0 || is_log > 2 || (is_log && !lse) || (is_log == 2 && n_partials <= 0))
+    return gjx_fail(GJX_EINVAL, "gjx_weight_cumsum: bad argument");
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_weight_cumsum: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nblocks = (int)((K + kScanTile - 1) / kScanTile);
   uint64_t* bs = (uint64_t*)((char*)workspace + kWsHeaderBytes);
-  hipLaunchKernelGGL(k_wsum_blocks, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, bs);
+  const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
+  hipLaunchKernelGGL(k_wsum_blocks, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, (int)n_partials, lse_out, log_k, bs);
   GJX_CHECK_LAUNCH("gjx_weight_cumsum/sum");
-  hipLaunchKernelGGL(k_wscan_write, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, (const uint64_t*)bs, cum, base_total_dev);
+  hipLaunchKernelGGL(k_wscan_write, dim3(nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, (int)n_partials, (const uint64_t*)bs, cum, base_total_dev);
   GJX_CHECK_LAUNCH("gjx_weight_cumsum/write");
   return GJX_OK;
 }

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   if (a.partials) {
     float bm, bsum;
     block_lse_partial<256>(lw, active, red, bm, bsum);
-    lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // consumer finishes (gjx_weight_cumsum mode 2)
   }
 }
 
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
     for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
     float bsum = 0.0f;
     for (int w = 0; w < NW; ++w) bsum += bm > -INFINITY ? red[NW + w] * fast_exp(red[w] - bm) : 0.0f;
-    lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    if (a.lse) lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // consumer finishes (gjx_weight_cumsum mode 2)
   }
 }
 
@@ -528,6 +530,28 @@ extern "C" int gjx_program_engine(const gjx_program* prog) {
   return ENGINE_GENERIC;
 }
 
+// number of thread blocks (== LSE partial pairs) gjx_run_program launches for this program and K
+static int run_grid(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores, int* ppt_out, bool* fused_out, GmmShape* g) {
+  const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
+  const bool fused = !want_site_scores && same_hi && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, g);
+  if (fused_out) *fused_out = fused;
+  if (!fused) return (int)((K + 255) / 256);
+  int ppt = env_int("GJX_GMM_PPT", 4);
+  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
+  if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned
+  if (ppt_out) *ppt_out = ppt;
+  const int64_t tile = 256 * (int64_t)ppt;
+  const int64_t ntiles = (K + tile - 1) / tile;
+  const int maxgrid = env_int("GJX_GMM_GRID", 2048);
+  return (int)(ntiles < maxgrid ? ntiles : maxgrid);
+}
+
+extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_offset) {
+  if (!prog || !prog->sites || K <= 0) return GJX_EINVAL;
+  GmmShape g;
+  return run_grid(prog, K, particle_offset, false, nullptr, nullptr, &g);
+}
+
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                                int64_t particle_offset, float* choices, float* score, float* weight,
                                float* logw, const float* logw_in, const float* sub,
@@ -542,24 +566,17 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* partials = nullptr;
   unsigned* ticket = nullptr;
-  if (lse) {
+  if (lse || (workspace && logw)) {  // lse == NULL with a workspace: leave the per-block partials for the consumer
     if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RUN, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_run_program: workspace too small");
     ticket = (unsigned*)workspace;
     partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   }
   const float log_k_total = (float)log((double)K_total);
-  int nblocks;
   GmmShape g;
-  const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
-  const bool fused = !site_scores && same_hi && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g);
+  int ppt = 1;
+  bool fused = false;
+  const int nblocks = run_grid(prog, K, particle_offset, site_scores != nullptr, &ppt, &fused, &g);
   if (fused) {
-    int ppt = env_int("GJX_GMM_PPT", 4);
-    if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
-    if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned
-    const int64_t tile = 256 * (int64_t)ppt;
-    const int64_t ntiles = (K + tile - 1) / tile;
-    const int maxgrid = env_int("GJX_GMM_GRID", 2048);
-    nblocks = (int)(ntiles < maxgrid ? ntiles : maxgrid);
     GmmArgs a;
     a.tab = prog->tab_dev; a.C = g.C;
     a.logits_off = g.logits_off; a.mu_off = g.mu_off; a.sig_off = g.sig_off;
@@ -571,7 +588,6 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
     else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
   } else {
-    nblocks = (int)((K + 255) / 256);
     RunArgs a;
     a.sites = prog->sites_dev; a.tab = prog->tab_dev; a.n_sites = prog->n_sites; a.n_slots = prog->n_slots;
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;

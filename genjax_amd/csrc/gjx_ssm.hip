@@ -155,7 +155,7 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
 // (prefix sum x2, ancestor expansion, fused step) are issued back to back without Python in between.
 // Key discipline as in inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t);
 // the systematic comb offset is uniform(k_res).
-extern "C" int gjx_weight_cumsum(const float*, int64_t, int32_t, const float*, uint64_t*, uint64_t*, void*, size_t, void*);
+extern "C" int gjx_weight_cumsum(const float*, int64_t, int32_t, const float*, int32_t, uint64_t*, uint64_t*, float*, int64_t, void*, size_t, void*);
 extern "C" int gjx_resample_systematic(const uint64_t*, int64_t, const uint64_t*, double, int64_t, int64_t, int64_t, int32_t*, void*);
 
 static void host_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
@@ -195,7 +195,7 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
     if (t > 0) {
       host_threefry(kr[0], kr[1], 0u, 0u, b);
       const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
-      int rc = gjx_weight_cumsum(logw, K, 1, lse - 4, cum, bt, ws2, need, stream);
+      int rc = gjx_weight_cumsum(logw, K, 1, lse - 4, 0, cum, bt, nullptr, K, ws2, need, stream);
       if (rc) return rc;
       rc = gjx_resample_systematic(cum, K, bt, u, K, 0, K, ancestors, stream);
       if (rc) return rc;

@@ -99,16 +99,28 @@ def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_
     return out
 
 
-def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None):
+def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, partials=None, lse_out=None, K_total=None):
+    """-> (cum uint64[K] as int64 payload, base_total int64[2] = {0, total}).
+    ``partials=(run_workspace, n)`` selects mode 2: the max comes from the per-block pairs a preceding
+    run_program(want_lse=False) left in its workspace, and ``lse_out`` (f32[4]) receives the finished record."""
     K = x.numel()
-    """-> (cum uint64[K] as int64 payload, base_total int64[2] = {0, total})"""
     cum = torch.empty(K, dtype=torch.int64, device=x.device) if out is None else out[0]
     bt = torch.empty(2, dtype=torch.int64, device=x.device) if out is None else out[1]
     if ws is None:
         ws = workspace(A.OP_RESAMPLE, K, x.device)
-    check(load().gjx_weight_cumsum(_ptr(x), K, int(is_log), _ptr(lse), _ptr(cum), _ptr(bt), _ptr(ws), ws.numel(),
-                                   _stream()), "gjx_weight_cumsum")
+    if partials is not None:
+        run_ws, n = partials
+        mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
+    else:
+        mode, lp, npart = int(bool(is_log)), _ptr(lse), 0
+    check(load().gjx_weight_cumsum(_ptr(x), K, mode, lp, npart, _ptr(cum), _ptr(bt), _ptr(lse_out), int(K_total or K),
+                                   _ptr(ws), ws.numel(), _stream()), "gjx_weight_cumsum")
     return cum, bt
+
+
+def run_partials_count(prog: PackedProgram, K: int, offset: int = 0) -> int:
+    cp = prog.c_program(None)
+    return int(load().gjx_run_partials_count(C.byref(cp), int(K), int(offset)))
 
 
 def resample_systematic(cum, base_total, u: float, N_total: int, out_begin=0, n_out=None, prefill=True) -> torch.Tensor:

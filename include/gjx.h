@@ -161,6 +161,8 @@ int gjx_threefry2x32(uint32_t key0, uint32_t key1, uint32_t ctr_hi, uint32_t ctr
  *   lse       f32[4]  out or NULL: {max, sum exp(logw-max), logsumexp, logsumexp - log(K_total)}
  *                           over THIS call's K particles (smc.py:96-97 when K_total == K)
  * `weight` or `logw` may be NULL.  workspace: gjx_workspace_bytes(GJX_OP_RUN, K).
+ * With lse == NULL and a workspace, the kernel still leaves its per-block {max, sumexp} pairs at workspace + 256
+ * (gjx_run_partials_count() of them) for a consumer that finishes the reduction itself (gjx_weight_cumsum, is_log 2).
  */
 int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                     int64_t particle_offset, float* choices, float* score, float* weight,
@@ -198,9 +200,16 @@ int gjx_categorical_pick(const float* logw, int64_t K, int64_t particle_offset, 
  *   base_total_dev u64[2] out : {0, sum q} — ready to pass to the resamplers on one GPU; with several ranks the
  *                               caller overwrites it with {sum of lower ranks' totals, sum over all ranks}
  */
-int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse /*max at [0]*/,
-                      uint64_t* cum, uint64_t* base_total_dev, void* workspace, size_t workspace_bytes,
-                      void* stream);
+int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials,
+                      uint64_t* cum, uint64_t* base_total_dev, float* lse_out, int64_t K_total,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/*   is_log = 0 : x are linear weights.
+ *   is_log = 1 : x are log-weights, lse[0] holds their maximum (a finished LSE record).
+ *   is_log = 2 : x are log-weights and `lse` points at the n_partials per-block {max, sumexp} pairs that
+ *                gjx_run_program leaves at workspace + 256 when called with lse == NULL; the reduction of the
+ *                pairs rides in this call's prologue (no serial tail in the producing kernel) and, if lse_out is
+ *                not NULL, the finished record {max, sumexp, lse, lse - log K_total} is written there. */
+int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_offset);
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:

@@ -203,6 +203,27 @@ def test_gmm_full_size(K_, golden):
     np.testing.assert_allclose(_np(pz), cf.gmm_posterior_z(**g), atol=5e-3)
 
 
+def test_consumer_side_lse_finish(K_):
+    """run_program(want_lse=False) leaves per-block {max, sumexp} pairs; gjx_weight_cumsum (mode 2) finishes the
+    reduction in its prologue: same prefix sums bit for bit, same LSE record to rounding."""
+    import torch
+    for rng in RNGS:
+        for K in (1000, 4099, 1 << 18):
+            prog, _ = H.gmm(rng=rng)
+            full = K_.run_program(prog, (3, 1), K)
+            ws = K_.workspace(A.OP_RUN, K)
+            part = K_.run_program(prog, (3, 1), K, want_lse=False, ws=ws)
+            np.testing.assert_array_equal(_np(part["logw"]), _np(full["logw"]))
+            n = K_.run_partials_count(prog, K)
+            lse_out = torch.empty(4, device="cuda")
+            cum2, bt2 = K_.weight_cumsum(part["logw"], partials=(ws, n), lse_out=lse_out)
+            cum1, bt1 = K_.weight_cumsum(full["logw"], True, full["lse"])
+            np.testing.assert_allclose(_np(lse_out), _np(full["lse"]), rtol=2e-6, atol=2e-6)
+            assert float(lse_out[0]) == float(full["lse"][0])                     # the max is exact
+            np.testing.assert_array_equal(_np(cum2), _np(cum1))
+            np.testing.assert_array_equal(_np(bt2), _np(bt1))
+
+
 def test_logsumexp_gpu(K_, oracle):
     import torch
     for K in (1, 2, 255, 256, 257, 100_003, 3_000_001):
