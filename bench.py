@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — whole-job throughput of the ImportanceK hot path on N MI355X GPUs of one node.
+"""bench.py — whole-job throughput of the inference hot path on N MI355X GPUs of one node.
 
-A "step" is one pass of the path over one batch of synthetic input, per GPU:
+Default workload (the one BASELINE.json's metric is quoted on, configs[1]): the Gaussian-mixture
+Target (C = 8 components, D = 16 latent dims), ImportanceK with k_particles = 2^20 PER GPU (weak
+scaling: the collection grows with N and is sharded by particle index; results are independent of N
+because random streams are indexed by the global particle index).  A "step" is one pass of the path
+over one batch of synthetic input, per GPU:
     propagate + reweight + per-block log-sum-exp partials (ONE kernel, gjx_run_program)
       -> [N > 1: 8-byte all-gather of {max, sumexp} + combine]
-      -> fixed-point prefix sum of the weights (2 kernels)
+      -> fixed-point prefix sum of the weights (2 kernels; on one GPU their prologue finishes the LSE)
       -> systematic ancestors by per-particle slot-range expansion (no search), row gather by ancestor
-         [N > 1: search, all-to-all-v of the rows whose slot another rank owns]
-on BASELINE.json configs[1]: the Gaussian-mixture Target (C = 8 components, D = 16 latent dims),
-ImportanceK with k_particles = 2^20 PER GPU (weak scaling: the collection grows with N and is
-sharded by particle index; results are independent of N because streams are indexed globally).
+         [N > 1: all-to-all-v of the rows whose output slot another rank owns]
 
 Prints ONE JSON line (rank 0).  value = K_total * steps / wall time of the timed region (max over
 ranks), inputs resident in HBM.  roofline.achieved = algorithmic bytes of the propagate+reweight
 kernel (4*D + 12 = 76 B per particle, 0 read) / its average duration measured with
 HIP events on the launch stream inside the timed region.
+
+Other §8 rows can be measured with --workload ssm (config 3: bootstrap filter, T = 256, K = 2^18) and
+--workload hmc (config 5: 2^16 chains x L = 1000 leapfrog steps); they print the same JSON shape.
 """
 from __future__ import annotations
 
@@ -27,7 +31,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -37,10 +40,19 @@ K_PER_GPU = 1 << 20
 D, C = 16, 8
 ALGO_BYTES_PER_PARTICLE = 4 * D + 12          # z + x[D] + score + log_weight, written once; nothing read
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP32_PEAK_TFLOPS = 157.3                       # vector / f32-MFMA peak
 
 
-def cpu_baseline(prog, K, budget_s=12.0):
-    """The CPU restatement (oracle/, OpenMP over all host cores) on a bounded sample of the same step."""
+def golden(name):
+    with open(os.path.join(ROOT, "tests", "golden", "closed_form.json")) as f:
+        return json.load(f)[name]
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baselines: the oracle (oracle/, a C restatement with OpenMP) on a bounded sample of the same step.
+# This is the only place bench.py touches oracle/.
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline_gmm(prog, K, budget_s=12.0):
     from oracle import cpu
     threads = cpu.num_threads()
     t0 = time.perf_counter()
@@ -59,36 +71,59 @@ def cpu_baseline(prog, K, budget_s=12.0):
                        f"propagate+reweight+LSE on {threads} OpenMP threads, resample+gather single-threaded")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--k-per-gpu", type=int, default=K_PER_GPU)
-    ap.add_argument("--event-samples", type=int, default=16,
-                    help="number of timed steps whose propagate+reweight kernel is bracketed with HIP events "
-                         "(timing events are not free on ROCm — hundreds of live ones slow every launch — so the "
-                         "kernel duration is sampled at evenly spaced steps INSIDE the timed region)")
-    args = ap.parse_args()
+def cpu_baseline_ssm(s, K, T, budget_s=12.0):
+    from genjax_amd import core
+    from oracle import cpu
+    threads = cpu.num_threads()
+    t0 = time.perf_counter()
+    key = core.key(1)
+    x = lw = lse = None
+    steps = 0
+    for t in range(T):
+        key = core.fold_in(key, t)
+        kp, _ = core.split(key)
+        anc = None
+        if t > 0:
+            cum, _ = cpu.weight_cumsum(lw, True, lse)
+            anc = cpu.resample_systematic(cum, 0.5, K)
+        x, lw, lse = cpu.ssm_step(s["A"], None, s["q"], s["r"], 1.0, kp, 0, t, K, x, anc, s["y"][t])
+        steps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=K * steps / dt, unit="particle-steps/s", cores=threads, kind="port",
+                sample=f"first {steps} of {T} filter steps at K=2^{int(math.log2(K))}; propagate on {threads} OpenMP threads, "
+                       "prefix sum + comb single-threaded")
 
+
+def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
+    from oracle import cpu
+    threads = cpu.num_threads()
+    n = max(threads * 4, 256)
+    ch = (np.random.default_rng(0).standard_normal((P + 1, n)) * 0.1).astype(np.float32)
+    Lc = min(L, 50)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        cpu.hmc(prog, (1, 2 + reps), ch, 0.01, Lc, False, True)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n * Lc * reps / dt, unit="chain-leapfrogs/s", cores=threads, kind="port",
+                sample=f"{reps} moves of {n} chains x {Lc} leapfrog steps on {threads} OpenMP threads")
+
+
+# ---------------------------------------------------------------------------------------------
+def run_gmm(args, rank, world, dev):
     from genjax_amd import _abi as A
     from genjax_amd import distributed as DD
-    from genjax_amd import kernels
-    import helpers as H
-    from oracle import closed_form as cf
-
-    rank, world = DD.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    from genjax_amd import kernels, workloads
 
     K = args.k_per_gpu
     K_total = K * world
     off = rank * K
-    prog, g = H.gmm(D=D, C=C)
+    prog, g = workloads.gmm_program(D=D, C=C)
     assert kernels.program_engine(prog) == 1, "fused mixture kernel not selected"
     ws = kernels.workspace(A.OP_RUN, K, dev)
     ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
@@ -122,6 +157,117 @@ def main():
         DD.resample_exchange(out["choices"], out["logw"], lse, u, K_total)
         return lse
 
+    dt, lse = timed_loop(args, world, dev, step)
+    if rank != 0:
+        return None
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    achieved = ALGO_BYTES_PER_PARTICLE * K / (kern_ms * 1e-3) / 1e9
+    exact = golden("gmm_c8_d16_seed0")
+    lml = float(lse[3])
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_run_gmm.json")
+    if os.path.exists(tp):
+        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+    res = dict(
+        metric="particle_steps_per_sec", value=K_total * args.steps / dt, unit="particle-steps/s",
+        n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload="gmm_c8_d16 ImportanceK: propagate+reweight+LSE, systematic resample, gather "
+                             "(BASELINE.json configs[1])",
+                    k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}"),
+        roofline=dict(bound="hbm", kernel="gjx::k_run_gmm<FLAT,16,4,256>", achieved=achieved, peak=HBM_PEAK_GBS,
+                      unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                      kernel_us=kern_ms * 1e3, algorithmic_bytes_per_launch=ALGO_BYTES_PER_PARTICLE * K,
+                      note="binding resource is integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),
+        log_ml=lml, log_ml_exact=exact, log_ml_rel_err=abs(lml - exact) / abs(exact),
+    )
+    if not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline_gmm(prog, min(K, 1 << 20))
+    return res
+
+
+def run_ssm(args, rank, world, dev):
+    """config 3: linear-Gaussian SSM d=8, T=256, bootstrap filter K=2^18, systematic resampling every step."""
+    from genjax_amd import core, workloads
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    if world != 1:
+        raise SystemExit("--workload ssm is the single-GPU configuration (config 3)")
+    s = workloads.ssm_problem()
+    K, T = 1 << 18, 256
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
+    ys = torch.as_tensor(s["y"], device=dev)
+    last = {}
+
+    def step(i, timed):                      # one "step" here = one whole T-step filter run (T*K particle-steps)
+        last["out"] = bf.run(core.key(1 + i), ys)
+        return last["out"]["log_ml"]
+
+    dt, lml = timed_loop(args, world, dev, step)
+    exact = golden("ssm_dx8_T256_seed0")
+    per_step_us = dt / args.steps / T * 1e6
+    algo = (8 * 8 + 24) * K                  # SURVEY §8(d): 8*d_x + 16..24 B per particle-step
+    res = dict(
+        metric="particle_steps_per_sec", value=K * T * args.steps / dt, unit="particle-steps/s", n_gpus=1,
+        steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[2]); "
+                             "one bench step = one T=256 filter run", k_particles=K, T=T, rng_stream="flat"),
+        roofline=dict(bound="hbm", kernel="filter step = k_wsum_blocks + k_wscan_write + k_systematic_expand + k_ssm_step",
+                      achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
+                      algorithmic_bytes_per_launch=algo,
+                      note="8 MB working set is cache resident and each of the 4 launches per step is latency-bound at K=2^18"),
+        log_ml=float(lml), log_ml_exact=exact, log_ml_rel_err=abs(float(lml) - exact) / abs(exact),
+    )
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_ssm(s, K, T)
+    return res
+
+
+def run_hmc(args, rank, world, dev):
+    """config 5: hierarchical logistic regression N=1024, P=16; HMC 2^16 chains x L=1000, eps 0.01 (chains shard by rank)."""
+    from genjax_amd import kernels, workloads
+    N, P, L = 1024, 16, args.leapfrog
+    n = (1 << 16)
+    prog, pr = workloads.logreg_program(N=N, P=P)
+    assert kernels.hmc_engine(prog) == 2, "fused logistic-regression HMC kernel not selected"
+    ch0 = torch.as_tensor((np.random.default_rng(rank).standard_normal((P + 1, n)) * 0.1).astype(np.float32), device=dev)
+    state = {"ch": ch0.clone(), "ws": None}
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 8))]
+
+    def step(i, timed):
+        j = i if (timed and i < len(ev)) else None
+        if j is not None:
+            ev[j][0].record()
+        out = kernels.hmc(prog, (1, 2 + i), state["ch"], 0.01, L, False, True, offset=rank * n, ws=state["ws"])
+        if j is not None:
+            ev[j][1].record()
+        state["ws"] = out["_ws"]
+        return out["accepted"]
+
+    dt, acc = timed_loop(args, world, dev, step)
+    if rank != 0:
+        return None
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    flops = n * L * (2 * 2 * N * P + 10 * N)            # X beta and X^T r (2 flop per FMA) + sigmoid
+    tf = flops / (kern_ms * 1e-3) / 1e12
+    res = dict(
+        metric="chain_leapfrogs_per_sec", value=n * world * L * args.steps / dt, unit="chain-leapfrogs/s", n_gpus=world,
+        steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload="hier_logreg_N1024_P16 HMC with fused MH accept (BASELINE.json configs[4]); one bench step = "
+                             f"one move of L={L} leapfrog steps", chains_per_gpu=n, leapfrog=L, eps=0.01, rng_stream="flat"),
+        roofline=dict(bound="mfma", kernel="gjx::k_hmc_logreg<FLAT,16,false>", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                      frac=tf / FP32_PEAK_TFLOPS, traffic=None, kernel_us=kern_ms * 1e3,
+                      note="FP32 VALU-bound (the f32 MFMA peak equals the f32 vector peak on gfx950, no MFMA used); ~0 HBM bytes"),
+        accept_rate=float(acc.mean()),
+    )
+    if not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline_hmc(prog, P, L)
+    return res
+
+
+def timed_loop(args, world, dev, step):
     def barrier():
         if world > 1:
             dist.barrier()
@@ -131,40 +277,45 @@ def main():
         step(i % max(args.steps, 1), False)
     barrier()
     t0 = time.perf_counter()
-    lse = None
+    last = None
     for i in range(args.steps):
-        lse = step(i, True)
+        last = step(i, True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, last
 
-    if rank == 0:
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-        achieved = ALGO_BYTES_PER_PARTICLE * K / (kern_ms * 1e-3) / 1e9
-        exact = cf.gmm_log_ml(**g)
-        lml = float(lse[3])
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_run_gmm.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-        res = dict(
-            metric="particle_steps_per_sec", value=K_total * args.steps / dt, unit="particle-steps/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload="gmm_c8_d16 ImportanceK: propagate+reweight+LSE, systematic resample, gather "
-                                 "(BASELINE.json configs[1])",
-                        k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}"),
-            roofline=dict(bound="hbm", kernel="gjx::k_run_gmm<FLAT,16,4,256>", achieved=achieved, peak=HBM_PEAK_GBS,
-                          unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                          kernel_us=kern_ms * 1e3, algorithmic_bytes_per_launch=ALGO_BYTES_PER_PARTICLE * K,
-                          note="kernel is VALU-bound by Threefry-2x32-20 integer work (DESIGN.md); frac is vs HBM"),
-            log_ml=lml, log_ml_exact=exact, log_ml_rel_err=abs(lml - exact) / abs(exact),
-        )
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(prog, min(K, 1 << 20))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["gmm", "ssm", "hmc"], default="gmm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-per-gpu", type=int, default=K_PER_GPU)
+    ap.add_argument("--leapfrog", type=int, default=1000)
+    ap.add_argument("--event-samples", type=int, default=16,
+                    help="number of timed steps whose propagate+reweight kernel is bracketed with HIP events "
+                         "(timing events are not free on ROCm — hundreds of live ones slow every launch — so the "
+                         "kernel duration is sampled at evenly spaced steps INSIDE the timed region)")
+    args = ap.parse_args()
+    dflt = {"gmm": (200, 20), "ssm": (10, 2), "hmc": (5, 1)}[args.workload]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+
+    from genjax_amd import distributed as DD
+    rank, world = DD.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    res = {"gmm": run_gmm, "ssm": run_ssm, "hmc": run_hmc}[args.workload](args, rank, world, dev)
+    if rank == 0 and res is not None:
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

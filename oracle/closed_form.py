@@ -12,6 +12,8 @@ import math
 
 import numpy as np
 
+from genjax_amd.workloads import gmm_problem, logreg_problem, ssm_problem  # noqa: F401  (workload definitions)
+
 
 def log_normal_pdf(x, mu, sd):
     x, mu, sd = np.asarray(x, np.float64), np.asarray(mu, np.float64), np.asarray(sd, np.float64)
@@ -37,21 +39,6 @@ def beta_bernoulli_posterior_mean(a: float, b: float, obs: bool) -> float:
 
 
 # ---- config 2 ------------------------------------------------------------------------------
-def gmm_problem(C: int = 8, D: int = 16, seed: int = 0, mu_range: float = 1.0, sigma: float = 1.0,
-                r: float = 4.0):
-    """Synthetic GMM of SURVEY §8(d): z~categorical(logits), x~N(mu[z], sigma), y~N(x, r)."""
-    rng = np.random.default_rng(seed)
-    logits = rng.standard_normal(C)
-    mu = rng.uniform(-mu_range, mu_range, size=(C, D))
-    sig = np.full((C, D), sigma)
-    rr = np.full(D, r)
-    z = rng.choice(C, p=np.exp(logits - logsumexp(logits)))
-    x = mu[z] + sig[z] * rng.standard_normal(D)
-    y = x + rr * rng.standard_normal(D)
-    f = np.float32
-    return dict(logits=logits.astype(f), mu=mu.astype(f), sigma=sig.astype(f), r=rr.astype(f), y=y.astype(f))
-
-
 def gmm_log_ml(logits, mu, sigma, r, y) -> float:
     """log sum_c pi_c prod_d N(y_d; mu_cd, sqrt(sigma_cd^2 + r_d^2))."""
     logits = np.asarray(logits, np.float64)
@@ -71,23 +58,6 @@ def gmm_posterior_z(logits, mu, sigma, r, y) -> np.ndarray:
 
 
 # ---- config 3/4 ----------------------------------------------------------------------------
-def ssm_problem(dx: int = 8, T: int = 256, q: float = 0.5, r: float = 2.0, seed: int = 0):
-    """A = block-diag of 2x2 blocks 0.9*Rot(theta_i), theta_i = 0.3 + 0.1*i (i = block start), H = I."""
-    A = np.zeros((dx, dx))
-    for i in range(0, dx, 2):
-        th = 0.3 + 0.1 * i
-        c, s = math.cos(th), math.sin(th)
-        A[i:i + 2, i:i + 2] = 0.9 * np.array([[c, -s], [s, c]])
-    rng = np.random.default_rng(seed)
-    x = rng.standard_normal(dx)
-    ys = np.zeros((T, dx))
-    for t in range(T):
-        if t > 0:
-            x = A @ x + q * rng.standard_normal(dx)
-        ys[t] = x + r * rng.standard_normal(dx)
-    return dict(A=A.astype(np.float32), y=ys.astype(np.float32), q=q, r=r, q0=1.0)
-
-
 def kalman_log_lik(A, y, q, r, q0=1.0, H=None):
     """float64 Kalman filter: returns (total log-likelihood, per-step increments, filtered means)."""
     A = np.asarray(A, np.float64)
@@ -118,14 +88,6 @@ def kalman_log_lik(A, y, q, r, q0=1.0, H=None):
 
 
 # ---- config 5 ------------------------------------------------------------------------------
-def logreg_problem(N: int = 1024, P: int = 16, seed: int = 0):
-    rng = np.random.default_rng(seed)
-    X = rng.standard_normal((N, P))
-    beta = rng.standard_normal(P)
-    y = (rng.uniform(size=N) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float32)
-    return dict(X=X.astype(np.float32), y=y, beta_true=beta.astype(np.float32))
-
-
 def logreg_log_joint(log_tau, beta, X, y):
     """log p(log_tau, beta, y) of: log_tau~N(0,1); beta_p~N(0, exp(log_tau)); y_n~Bernoulli(logits=X beta)."""
     log_tau = float(log_tau)

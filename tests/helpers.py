@@ -3,7 +3,7 @@ import numpy as np
 
 from genjax_amd import _abi as A
 from genjax_amd.program import PackedProgram, Param, SiteList
-from oracle import closed_form as cf
+from genjax_amd import workloads as W
 
 KIND = dict(normal=A.NORMAL, flip=A.FLIP, bernoulli_logits=A.BERNOULLI_LOGITS, beta=A.BETA, uniform=A.UNIFORM,
             exponential=A.EXPONENTIAL, half_normal=A.HALF_NORMAL, laplace=A.LAPLACE, log_normal=A.LOG_NORMAL,
@@ -22,12 +22,7 @@ def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT):
 
 
 def gmm(D=16, C=8, rng=A.RNG_FLAT, seed=0):
-    g = cf.gmm_problem(C=C, D=D, seed=seed)
-    sl = SiteList()
-    sl.add("z", A.CATEGORICAL_LOGITS, [g["logits"]])
-    sl.add("x", A.MVNORMAL_DIAG, [Param.gather(g["mu"], "z"), Param.gather(g["sigma"], "z")], dim=D)
-    sl.add("y", A.MVNORMAL_DIAG, [Param.value("x", D), Param.const(g["r"])], dim=D)
-    return PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": g["y"]}, rng_mode=rng), g
+    return W.gmm_program(D, C, rng, seed)
 
 
 def flip_flip(trivial: bool, rng=A.RNG_FLAT):
@@ -75,11 +70,4 @@ def zoo(rng=A.RNG_FLAT, observed=()):
 
 
 def logreg(N=64, P=4, rng=A.RNG_FLAT, seed=0):
-    """BASELINE config 5 shape: log_tau ~ N(0,1); beta ~ N(0, exp(log_tau)); y ~ bernoulli(logits = X beta)."""
-    pr = cf.logreg_problem(N, P, seed)
-    sl = SiteList()
-    sl.add("log_tau", A.NORMAL, [0.0, 1.0])
-    sl.add("beta", A.NORMAL, [Param.const(0.0), Param.value("log_tau", xf=A.XF_EXP)], dim=P)
-    sl.add("y", A.BERNOULLI_LOGITS, [Param.affine(pr["X"], "beta")], dim=N)
-    modes = {"y": A.MODE_OBS_TAB, "log_tau": A.MODE_OBS_SLOT, "beta": A.MODE_OBS_SLOT}
-    return PackedProgram(sl, modes, {"y": pr["y"]}, selected=("log_tau", "beta"), rng_mode=rng), pr
+    return W.logreg_program(N, P, rng, seed)
