@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   if (a.partials) {
     float bm, bsum;
     block_lse_partial<256>(lw, active, red, bm, bsum);
-    lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // finished by gjx_weight_cumsum (is_log 2)
   }
 }
 
@@ -132,7 +133,7 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* partials = nullptr;
   unsigned* ticket = nullptr;
-  if (lse) {
+  if (lse || workspace) {  // lse == NULL with a workspace: leave ceil(K/256) per-block partial pairs at workspace + 256
     if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_SSM, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_step: workspace too small");
     ticket = (unsigned*)workspace;
     partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
@@ -195,13 +196,15 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
     if (t > 0) {
       host_threefry(kr[0], kr[1], 0u, 0u, b);
       const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
-      int rc = gjx_weight_cumsum(logw, K, 1, lse - 4, 0, cum, bt, nullptr, K, ws2, need, stream);
+      // the previous step left its per-block LSE partials in ws1; the prefix-sum prologue reduces them and
+      // block 0 writes the finished record of step t-1
+      int rc = gjx_weight_cumsum(logw, K, 2, (const float*)(ws1 + 256), (int32_t)((K + 255) / 256), cum, bt, lse - 4, K, ws2, need, stream);
       if (rc) return rc;
       rc = gjx_resample_systematic(cum, K, bt, u, K, 0, K, ancestors, stream);
       if (rc) return rc;
     }
     const int rc = gjx_ssm_step(m, kp[0], kp[1], rng_mode, t, K, 0, t > 0 ? x_prev : nullptr, K, t > 0 ? ancestors : nullptr,
-                                ys_dev + (size_t)t * m->dy, x_out, logw, lse, K, ws1, need, stream);
+                                ys_dev + (size_t)t * m->dy, x_out, logw, t == T - 1 ? lse : nullptr, K, ws1, need, stream);
     if (rc) return rc;
   }
   return GJX_OK;

@@ -241,7 +241,8 @@ int gjx_gather_rows(const float* src, int64_t src_stride, const int32_t* anc, in
  * (key_t = fold_in(key_{t-1}, t), scan.py:268).
  *   A f32[dx][dx], H f32[dy][dx] row-major, y f32[dy], on the device.
  *   x_prev f32[dx][K_prev_stride], anc int32[K] or NULL (identity); t == 0 samples x_0 ~ N(0, I*q0)
- *   x_out f32[dx][K], logw f32[K] (incremental weight), lse f32[4] as above.
+ *   x_out f32[dx][K], logw f32[K] (incremental weight), lse f32[4] as above; lse == NULL with a workspace leaves
+ *   ceil(K/256) per-block {max, sumexp} pairs at workspace + 256 (finished by gjx_weight_cumsum, is_log 2).
  */
 typedef struct gjx_ssm {
   int32_t dx, dy;

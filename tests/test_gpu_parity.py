@@ -354,7 +354,7 @@ def test_native_filter_loop_equals_step_by_step(K_):
         bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 10_000, rng_mode=rng)
         a = bf.run(core.key(7), s["y"])
         b = bf.run(core.key(7), s["y"], step_by_step=True)
-        np.testing.assert_array_equal(_np(a["increments"]), _np(b["increments"]))
+        np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-6)   # LSE finish order differs
         np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
         np.testing.assert_array_equal(_np(a["logw"]), _np(b["logw"]))
 
