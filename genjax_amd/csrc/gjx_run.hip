@@ -13,6 +13,8 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 
+#include <type_traits>
+
 namespace gjx {
 
 // ------------------------------------------------------------------------------------------
@@ -35,19 +37,34 @@ struct RunArgs {
   unsigned* ticket;
   float* lse;
   float log_k_total;
+  int preload, n_tab;
 };
 
-template <int RNG>
+// LDSV: the particle's values are mirrored in LDS (vals[slot][lane], conflict-free) so that parameter
+// expressions read earlier choices at LDS latency instead of re-reading the SoA rows through L1/L2; used
+// whenever n_slots * 1 KB fits (the launcher decides).  The SoA rows in HBM are still written once.
+// TABL: the float table (constants, observations) is small enough to be copied into LDS as well, so GATHER /
+// AFFINE parameters (per-lane table reads) stop being dependent global loads.
+template <int RNG, bool LDSV, bool TABL>
 __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   __shared__ float red[16];
+  extern __shared__ __attribute__((aligned(16))) float vals_s[];
+  float* tab_s = vals_s + (LDSV ? a.n_slots * 256 : 0);
+  if (TABL) {
+    for (int t = threadIdx.x; t < a.n_tab; t += 256) tab_s[t] = a.tab[t];
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.K;
   const int64_t ii = active ? i : a.K - 1;  // inactive lanes shadow the last particle (no stores)
   const uint64_t gidx = (uint64_t)(a.offset + ii);
-  const float* __restrict__ tab = a.tab;
+  const float* __restrict__ tab = TABL ? tab_s : a.tab;
   float* ch = a.choices;
   const int64_t K = a.K;
-  auto val = [&](int slot) -> float { return ch[(int64_t)slot * K + ii]; };
+  if (LDSV && a.preload) {  // some site reads its value from choices[][] (OBS_SLOT): stage every row once, coalesced
+    for (int s = 0; s < a.n_slots; ++s) vals_s[s * 256 + threadIdx.x] = ch[(int64_t)s * K + ii];
+  }
+  auto val = [&](int slot) -> float { return LDSV ? vals_s[slot * 256 + threadIdx.x] : ch[(int64_t)slot * K + ii]; };
 
   float score = 0.0f, weight = 0.0f;
   for (int j = 0; j < a.n_sites; ++j) {
@@ -109,20 +126,40 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         if (probs) l = safe_log(l);
         lp = l - lse;
       }
-      if (slot >= 0 && active) ch[(int64_t)slot * K + i] = v;
-    } else {
-      const int nd = draws_per_elem(kind);
-      const int dim = s.dim;
-      for (int d = 0; d < dim; ++d) {
-        const float pa = eval_param(s.p[0], d, tab, val);
-        const float pb = eval_param(s.p[1], d, tab, val);
-        float v;
-        if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(kind, bs, (uint32_t)(d * nd), pa, pb);
-        else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
-        else v = val(slot + d);
-        lp += elem_logpdf(kind, v, pa, pb);
-        if (slot >= 0 && active && mode != GJX_MODE_OBS_SLOT) ch[(int64_t)(slot + d) * K + i] = v;
+      if (slot >= 0) {
+        if (LDSV) vals_s[slot * 256 + threadIdx.x] = v;
+        if (active) ch[(int64_t)slot * K + i] = v;
       }
+    } else {
+      // the element loop is instantiated per distribution kind so that the sampler / density switches fold away
+      auto elems = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const int nd = draws_per_elem(KIND);
+        const int dim = s.dim;
+        const bool b_inv = s.p[1].op == GJX_P_CONST && s.p[1].len == 1 && s.p[1].xf == GJX_XF_NONE;  // wave-uniform
+        const float pb0 = b_inv ? tab[s.p[1].off] : 0.0f;
+        for (int d = 0; d < dim; ++d) {
+          const float pa = eval_param(s.p[0], d, tab, val);
+          const float pb = b_inv ? pb0 : eval_param(s.p[1], d, tab, val);
+          float v;
+          if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb);
+          else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
+          else v = val(slot + d);
+          lp += elem_logpdf(KIND, v, pa, pb);
+          if (slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
+            if (LDSV) vals_s[(slot + d) * 256 + threadIdx.x] = v;
+            if (active) ch[(int64_t)(slot + d) * K + i] = v;
+          }
+        }
+      };
+#define GJX_KIND(K_) case K_: elems(std::integral_constant<int, K_>{}); break;
+      switch (kind) {
+        GJX_KIND(GJX_NORMAL) GJX_KIND(GJX_MVNORMAL_DIAG) GJX_KIND(GJX_FLIP) GJX_KIND(GJX_BERNOULLI_LOGITS) GJX_KIND(GJX_BETA)
+        GJX_KIND(GJX_UNIFORM) GJX_KIND(GJX_EXPONENTIAL) GJX_KIND(GJX_HALF_NORMAL) GJX_KIND(GJX_LAPLACE) GJX_KIND(GJX_LOG_NORMAL)
+        GJX_KIND(GJX_CAUCHY) GJX_KIND(GJX_GAMMA)
+        default: lp = __builtin_nanf(""); break;
+      }
+#undef GJX_KIND
     }
     score += lp;
     if (mode != GJX_MODE_SAMPLE) weight += lp;
@@ -594,8 +631,23 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials; a.ticket = ticket; a.lse = lse;
     a.log_k_total = log_k_total;
-    if (prog->rng_mode == GJX_RNG_JAX32) hipLaunchKernelGGL(k_run_generic<GJX_RNG_JAX32>, dim3(nblocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_run_generic<GJX_RNG_FLAT>, dim3(nblocks), dim3(256), 0, st, a);
+    a.preload = 0;
+    for (int j = 0; j < prog->n_sites; ++j) a.preload |= prog->sites[j].mode == GJX_MODE_OBS_SLOT;
+    a.n_tab = prog->n_tab;
+    const size_t vbytes = sizeof(float) * 256 * (size_t)prog->n_slots;
+    const bool ldsv = prog->n_slots > 0 && vbytes <= 48 * 1024 && !env_int("GJX_GENERIC_NO_LDS", 0);
+    const size_t tbytes = sizeof(float) * (size_t)prog->n_tab;
+    const bool tabl = tbytes <= 16 * 1024 && !env_int("GJX_GENERIC_NO_LDS", 0);
+    const size_t lds = (ldsv ? vbytes : 0) + (tabl ? tbytes : 0);
+#define GJX_GEN(R, L, T) hipLaunchKernelGGL((k_run_generic<R, L, T>), dim3(nblocks), dim3(256), lds, st, a)
+    if (prog->rng_mode == GJX_RNG_JAX32) {
+      if (ldsv && tabl) GJX_GEN(GJX_RNG_JAX32, true, true); else if (ldsv) GJX_GEN(GJX_RNG_JAX32, true, false);
+      else if (tabl) GJX_GEN(GJX_RNG_JAX32, false, true); else GJX_GEN(GJX_RNG_JAX32, false, false);
+    } else {
+      if (ldsv && tabl) GJX_GEN(GJX_RNG_FLAT, true, true); else if (ldsv) GJX_GEN(GJX_RNG_FLAT, true, false);
+      else if (tabl) GJX_GEN(GJX_RNG_FLAT, false, true); else GJX_GEN(GJX_RNG_FLAT, false, false);
+    }
+#undef GJX_GEN
   }
   GJX_CHECK_LAUNCH("gjx_run_program");
   (void)nblocks;
