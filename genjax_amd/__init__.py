@@ -12,7 +12,7 @@ from .gen import (Distribution, Marginal, StaticGenerativeFunction, Trace, berno
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   mv_normal_diag, normal, sigmoid, softplus, take, uniform, where)
 from .inference import (HMC, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
-                        ParticleCollection, Regenerate, SafeHMC, SMCAlgorithm, Target, Update)
+                        ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, Update)
 from .program import AddressReuse, MissingAddress  # noqa: F401
 
 __version__ = "0.1.0"

@@ -80,7 +80,8 @@ class Selection:
     at = _At()
 
     def check(self, addr=None) -> bool:
-        return (addr in self.addrs) != self.complement
+        hit = addr in self.addrs or (isinstance(addr, tuple) and len(addr) == 2 and addr[0] in self.addrs)
+        return hit != self.complement
 
     def __contains__(self, addr) -> bool:
         return self.check(addr)
@@ -187,6 +188,15 @@ class ChoiceMap:
         return addr in self._d
 
     def __getitem__(self, addr):
+        # scan-style addressing: chm[:, "x"] is the stacked value, chm[t, "x"] one step (scan.py:56-97)
+        if isinstance(addr, tuple) and len(addr) == 2 and not isinstance(addr[1], int):
+            idx, name = addr
+            if isinstance(idx, slice) or idx is Ellipsis:
+                addr = name
+            elif (name, idx) in self._d:
+                addr = (name, idx)
+            elif name in self._d:
+                return self._d[name][..., idx]
         if addr not in self._d:
             raise ChoiceMapNoValueAtAddress(addr)
         return self._d[addr]

@@ -29,7 +29,7 @@ from .program import AddressReuse, MissingAddress, PackedProgram, Param, SiteLis
 __all__ = [
     "gen", "StaticGenerativeFunction", "Trace", "Distribution", "take", "where", "cond", "const", "exp",
     "softplus", "sigmoid", "normal", "flip", "bernoulli", "beta", "categorical", "uniform", "mv_normal_diag",
-    "exponential", "half_normal", "laplace", "log_normal", "cauchy", "gamma", "Marginal",
+    "exponential", "half_normal", "laplace", "log_normal", "cauchy", "gamma", "Marginal", "ScanCombinator",
 ]
 
 
@@ -242,6 +242,7 @@ class _Tracer:
 
     def __init__(self):
         self.sites = SiteList()
+        self.step = None   # inside a scan: the iteration index, appended to every address as (addr, step)
 
     def __enter__(self):
         _Tracer.stack.append(self)
@@ -262,7 +263,10 @@ class DistCall:
         self.dist, self.kind, self.params, self.dim = dist, kind, params, dim
 
     def __matmul__(self, addr):
-        site = _Tracer.current().sites.add(addr, self.kind, self.params, self.dim)
+        t = _Tracer.current()
+        if t.step is not None:
+            addr = (addr, t.step)
+        site = t.sites.add(addr, self.kind, self.params, self.dim)
         return SiteVal(addr, site.dim, self.kind)
 
 
@@ -319,7 +323,16 @@ class Trace:
         return _to_device_value(s.kind, v)
 
     def get_choices(self) -> ChoiceMap:
-        return ChoiceMap({s.addr: self._site_value(s.addr) for s in self.prog.site_list.sites})
+        import torch
+        d = {s.addr: self._site_value(s.addr) for s in self.prog.site_list.sites}
+        # scan sites ("x", t): also expose the stacked sequence under "x" (leading axes: particles, then steps)
+        seqs: dict = {}
+        for s in self.prog.site_list.sites:
+            if isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], int):
+                seqs.setdefault(s.addr[0], []).append(d[s.addr])
+        for name, vals in seqs.items():
+            d[name] = torch.stack(vals, dim=1 if self.batched else 0)
+        return ChoiceMap(d)
 
     def get_retval(self):
         r = self.retval_sym
@@ -404,6 +417,17 @@ def _value_rows(v, dim: int):
     raise ValueError(f"constraint of shape {a.shape} for a site of dimension {dim}")
 
 
+def _constraint_value(constraint: ChoiceMap, addr):
+    """(found, value) for a site address; a scan site ("x", t) also matches a whole-sequence entry "x"."""
+    if addr in constraint:
+        return True, constraint[addr]
+    if isinstance(addr, tuple) and len(addr) == 2 and addr[0] in constraint:
+        v = constraint[addr[0]]
+        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        return True, v[addr[1]]
+    return False, None
+
+
 class GenerativeFunction:
     """GFI surface (core/generative/generative_function.py:238-689), restated for sited programs."""
 
@@ -420,8 +444,9 @@ class GenerativeFunction:
         sl, _ = self.site_list(args)
         modes, shared, pp = {}, {}, {}
         for s in sl.sites:
-            if s.addr in constraint:
-                sv, rows = _value_rows(constraint[s.addr], s.dim)
+            found, cval = _constraint_value(constraint, s.addr)
+            if found:
+                sv, rows = _value_rows(cval, s.dim)
                 if rows is None:
                     modes[s.addr] = A.MODE_OBS_TAB
                     shared[s.addr] = np.broadcast_to(sv, (s.dim,)).astype(np.float32)
@@ -438,7 +463,7 @@ class GenerativeFunction:
 
     def _run(self, key: Key, K: int, args, constraint: ChoiceMap, sample_rest: bool, batched: bool,
              prev_rows: dict | None = None, logw_in=None, sub=None, want_lse=False, device=None, offset=0,
-             K_total=None):
+             K_total=None, want_site_scores=False):
         import torch
         from . import kernels
         prog, shared, pp = self.pack(args, constraint, sample_rest, per_particle=tuple(prev_rows or ()))
@@ -455,7 +480,7 @@ class GenerativeFunction:
             dim = prog.site_list[addr].dim
             choices[slot:slot + dim] = torch.as_tensor(r, dtype=torch.float32, device=dev).expand(dim, K)
         out = kernels.run_program(prog, key, K, offset=offset, choices=choices, logw_in=logw_in, sub=sub,
-                                  want_lse=want_lse, K_total=K_total, device=dev)
+                                  want_lse=want_lse, K_total=K_total, device=dev, want_site_scores=want_site_scores)
         tr = Trace(self, args, prog, out["choices"], out["score"], shared, batched, retval)
         return tr, out
 
@@ -477,8 +502,9 @@ class GenerativeFunction:
         batched = False
         sl, _ = self.site_list(args)
         for s in sl.sites:
-            if s.addr in chm:
-                _, rows = _value_rows(chm[s.addr], s.dim)
+            found, cval = _constraint_value(chm, s.addr)
+            if found:
+                _, rows = _value_rows(cval, s.dim)
                 if rows is not None:
                     K, batched = int(rows.shape[-1]), True
         tr, out = self._run((0, 0), K, args, chm, False, batched)
@@ -513,8 +539,38 @@ class StaticGenerativeFunction(GenerativeFunction):
         raise NotSupportedInModelBody("calling a @gen function inside another model body is not supported; "
                                       "use simulate/importance/assess")
 
+    def scan(self, n: int) -> "ScanCombinator":
+        """``kernel.scan(n=T)`` (combinators/scan.py): the kernel ``(carry, x) -> (carry, out)`` unrolled T times."""
+        return ScanCombinator(self, int(n))
+
     def __repr__(self):
         return f"<gen {self.__name__}>"
+
+
+class ScanCombinator(GenerativeFunction):
+    """Time recursion of a kernel generative function (combinators/scan.py:200-294), lowered by unrolling:
+    step t's sites get the addresses ``(addr, t)``, its parameters read step t-1's choices through the carry.
+    Scores and weights add over steps (scan.py:283-294); whole-sequence constraints / selections use the bare
+    address (``C["y"].set(vector)``, ``Selection.at["x"]``, ``chm[:, "x"]``)."""
+
+    def __init__(self, kernel: StaticGenerativeFunction, n: int):
+        self.kernel, self.n = kernel, n
+        self._cache: dict = {}
+
+    def site_list(self, args):
+        k = _args_key(tuple(a for a in args if a is not None)) + (len(args),)
+        if k not in self._cache:
+            carry = args[0]
+            xs = args[1] if len(args) > 1 else None
+            outs = []
+            with _Tracer() as t:
+                for i in range(self.n):
+                    t.step = i
+                    carry, out = self.kernel.source(carry, None if xs is None else xs[i])
+                    outs.append(out)
+                t.step = None
+            self._cache[k] = (t.sites, (carry, outs))
+        return self._cache[k]
 
 
 def gen(fn: Callable) -> StaticGenerativeFunction:

@@ -105,3 +105,74 @@ class HMC(EditRequest):
 def SafeHMC(selection: Selection, eps, L: int = 10) -> HMC:
     """hmc.py:214-223 — the retdiff assertion is vacuous here (argdiffs are always no-change)."""
     return HMC(selection, eps, L)
+
+
+class Rejuvenate(EditRequest):
+    """Metropolis-Hastings proposal move without the accept step (inference/requests/rejuvenate.py:70-94):
+    propose z' ~ q(. | argument_mapping(old choices)), apply it as an Update (weight w), score the reverse
+    proposal, return w + log q(z_old | args(z')) - log q(z' | args(z_old)).  Used through
+    ``StaticRequest({addr: Rejuvenate(dist, argument_mapping)})``; ``argument_mapping`` receives a value
+    ChoiceMap (``chm.get_value()`` is the current choice) and is traced symbolically once."""
+
+    def __init__(self, proposal, argument_mapping):
+        self.proposal, self.argument_mapping = proposal, argument_mapping
+        self._gf = None
+
+    def _proposal_gf(self):
+        if self._gf is None:
+            from ..gen import StaticGenerativeFunction, normal
+            prop, amap = self.proposal, self.argument_mapping
+
+            def body():
+                cur = normal(0.0, 1.0) @ "cur"          # carrier of the current value (its score is not used)
+                args = amap(ChoiceMap.v(cur))
+                _ = prop(*args) @ "new"
+            self._gf = StaticGenerativeFunction(body)
+        return self._gf
+
+    def edit_at(self, key: Key, tr: Trace, addr):
+        from ..core import split
+        gf = self._proposal_gf()
+        site = tr.prog.site_list[addr]
+        if site.dim != 1 or tr.prog.slot_of[addr] < 0:
+            raise NotImplementedError("Rejuvenate is implemented for scalar, unconstrained addresses")
+        old = tr.choices[tr.prog.slot_of[addr]: tr.prog.slot_of[addr] + 1]          # [1][K]
+        key, sub_key = split(key)
+        fwd_tr, fwd_out = gf._run(sub_key, tr.K, (), ChoiceMap.empty(), True, True, prev_rows={"cur": old},
+                                  want_site_scores=True)
+        new = fwd_tr.choices[fwd_tr.prog.slot_of["new"]: fwd_tr.prog.slot_of["new"] + 1]
+        fwd = fwd_out["site_scores"][1]
+        new_tr, w, _, bwd_req = Update(ChoiceMap({addr: new[0] if tr.batched else new[0, 0]})).edit(key, tr, None)
+        _, bwd_out = gf._run(sub_key, tr.K, (), ChoiceMap.empty(), False, True, prev_rows={"cur": new, "new": old},
+                             want_site_scores=True)
+        bwd = bwd_out["site_scores"][1]
+        final = (w if tr.batched else w.reshape(1)) + bwd - fwd
+        return new_tr, (final if tr.batched else final[0]), None, Rejuvenate(self.proposal, self.argument_mapping)
+
+    def edit(self, key: Key, tr: Trace, argdiffs=None):
+        raise NotImplementedError("address a Rejuvenate move through StaticRequest({addr: Rejuvenate(...)})")
+
+
+class StaticRequest(EditRequest):
+    """Address-wise composition of requests (generative_functions/static.py:130-131): ``{addr: request}``."""
+
+    def __init__(self, addressed: dict):
+        self.addressed = dict(addressed)
+
+    def edit(self, key: Key, tr: Trace, argdiffs=None):
+        from ..core import fold_in
+        total, bwd = None, {}
+        for n, (addr, req) in enumerate(self.addressed.items()):
+            k = fold_in(key, n + 1)
+            if isinstance(req, Rejuvenate):
+                tr, w, _, b = req.edit_at(k, tr, addr)
+            elif isinstance(req, Regenerate):
+                tr, w, _, b = Regenerate(Selection((addr,))).edit(k, tr, argdiffs)
+            elif isinstance(req, Update):
+                v = req.constraint.get_value() if req.constraint.has_value() else req.constraint[addr]
+                tr, w, _, b = Update(ChoiceMap({addr: v})).edit(k, tr, argdiffs)
+            else:
+                raise NotImplementedError(type(req).__name__)
+            total = w if total is None else total + w
+            bwd[addr] = b
+        return tr, total, None, StaticRequest(bwd)

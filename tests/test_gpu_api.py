@@ -10,7 +10,8 @@ import genjax_amd as genjax
 from genjax_amd import ChoiceMap, Selection
 from genjax_amd import ChoiceMapBuilder as C
 from genjax_amd import SelectionBuilder as S
-from genjax_amd.inference import HMC, ChangeTarget, Importance, ImportanceK, Regenerate, Target, Update
+from genjax_amd.inference import (HMC, ChangeTarget, Importance, ImportanceK, Regenerate, Rejuvenate, StaticRequest, Target,
+                                  Update)
 
 pytestmark = pytest.mark.gpu
 
@@ -285,6 +286,97 @@ class TestRegenerate:
         y1 = tr.get_choices()["y1"][acc_any]
         assert acc_any.float().mean() > 0.5
         assert float((y1 - 3.0).abs().median()) < 0.03     # posterior sd is 0.01; single chains in the reference: rel 1e-2
+
+
+class TestRejuvenate:
+    def test_simple_normal_correctness(self):
+        """reference tests/inference/test_requests.py:142-166: a symmetric prior proposal gives weight 0."""
+        @genjax.gen
+        def simple_normal():
+            _ = genjax.normal(0.0, 1.0) @ "y1"
+
+        key, sub_key = genjax.split(genjax.key(314159))
+        tr = simple_normal.simulate(sub_key, ())
+        old_v = tr.get_choices()["y1"]
+        request = StaticRequest({"y1": Rejuvenate(genjax.normal, lambda chm: (0.0, 1.0))})
+        new_tr, w, _, _ = request.edit(sub_key, tr, ())
+        assert f(old_v) != f(new_tr.get_choices()["y1"])
+        assert f(w) == pytest.approx(0.0, abs=2e-5)
+
+    def test_linked_normal_rejuvenate_convergence(self):
+        """reference tests/inference/test_requests.py:168-193 (random-walk proposal, 100 MH steps -> 3.0), run
+        on 2048 chains at once."""
+        import torch
+
+        @genjax.gen
+        def linked_normal():
+            y1 = genjax.normal(0.0, 3.0) @ "y1"
+            _ = genjax.normal(y1, 0.001) @ "y2"
+
+        key, sub_key = genjax.split(genjax.key(314159))
+        n = 2048
+        tr, _ = linked_normal.importance(sub_key, C.kw(y2=3.0), (), K=n)
+        request = StaticRequest({"y1": Rejuvenate(genjax.normal, lambda chm: (chm.get_value(), 0.3))})
+        for _ in range(100):
+            key, sub_key = genjax.split(key)
+            new_tr, w, _, _ = request.edit(sub_key, tr, ())
+            key, sub_key = genjax.split(key)
+            check = torch.log(genjax.uniform.simulate(sub_key, (0.0, 1.0), K=n).get_choices()[()]) < w
+            tr.choices = torch.where(check[None, :], new_tr.choices, tr.choices)
+            tr.score = torch.where(check, new_tr.score, tr.score)
+        y1 = tr.get_choices()["y1"]
+        # a +-0.3 random walk hits the 0.001-wide posterior rarely, as in the reference; chains move monotonically closer
+        assert float((y1 - 3.0).abs().median()) < 0.1
+        assert float(((y1 - 3.0).abs() < 5e-3 * 3).float().mean()) > 0.05
+
+    def test_detailed_balance_weight(self):
+        """w + log q(old | new) - log q(new | old) with an asymmetric proposal, checked against the closed form."""
+        @genjax.gen
+        def model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            _ = genjax.normal(x, 0.5) @ "y"
+
+        tr, _ = model.importance(genjax.key(1), C.kw(y=1.0), (), K=1000)
+        req = StaticRequest({"x": Rejuvenate(genjax.normal, lambda chm: (0.5 * chm.get_value() + 0.2, 0.4))})
+        new_tr, w, _, _ = req.edit(genjax.key(2), tr, ())
+        xo, xn = tr.get_choices()["x"].double(), new_tr.get_choices()["x"].double()
+        lp = lambda x: -0.5 * x * x - 0.5 * ((1.0 - x) / 0.5) ** 2
+        lq = lambda a, b: -0.5 * ((a - (0.5 * b + 0.2)) / 0.4) ** 2            # log q(a | b) up to a constant
+        want = lp(xn) - lp(xo) + lq(xo, xn) - lq(xn, xo)
+        assert float((w.double() - want).abs().max()) < 2e-3
+
+
+class TestScan:
+    def test_simple_scan_hmc(self):
+        """reference tests/inference/test_requests.py:237-255: kernel.scan(n=10), y_t = 3 for all t, 50 always-accepted
+        HMC moves over every "x" (eps 1e-2, L 10) bring all x_t to 3 (rel 8e-3)."""
+        import torch
+
+        @genjax.gen
+        def kernel(z, scanned_in):
+            z = genjax.normal(z, 1.0) @ "x"
+            _ = genjax.normal(z, 0.01) @ "y"
+            return z, None
+
+        key, sub_key = genjax.split(genjax.key(0))
+        model = kernel.scan(n=10)
+        vchm = ChoiceMap.empty().at["y"].set(3.0 * np.ones(10, np.float32))
+        tr, w = model.importance(sub_key, vchm, (0.0, None))
+        chm = tr.get_choices()
+        assert chm[:, "x"].shape == (10,) and chm[:, "y"].shape == (10,) and f(chm[3, "y"]) == 3.0
+        # importance weight = sum_t log N(3; x_t, 0.01); score adds the transition terms (scan.py:283-294)
+        x = chm[:, "x"].double()
+        ll = (-0.5 * ((3.0 - x) / 0.01) ** 2 - math.log(0.01) - 0.5 * math.log(2 * math.pi)).sum()
+        assert f(w) == pytest.approx(f(ll), rel=1e-4)
+        prev = torch.cat([torch.zeros(1, dtype=torch.float64, device=x.device), x[:-1]])
+        lt = (-0.5 * (x - prev) ** 2 - 0.5 * math.log(2 * math.pi)).sum()
+        assert f(tr.get_score()) == pytest.approx(f(ll + lt), rel=1e-4)
+        request = HMC(Selection.at["x"], 1e-2, stale_gradient_compat=True)
+        new_tr = tr
+        for _ in range(50):
+            key, sub_key = genjax.split(key)
+            new_tr, *_ = request.edit(sub_key, new_tr, None)
+        np.testing.assert_allclose(new_tr.get_choices()[:, "x"].cpu().numpy(), 3.0, rtol=8e-3)
 
 
 class TestHMC:

@@ -185,3 +185,24 @@ def test_shard_arithmetic():
             parts = [shard(K, r, G) for r in range(G)]
             assert parts[0][0] == 0 and sum(k for _, k in parts) == K
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(G - 1))
+
+
+def test_scan_unrolls_into_chained_sites():
+    @genjax.gen
+    def kernel(z, scanned_in):
+        z = genjax.normal(z, 1.0) @ "x"
+        _ = genjax.normal(2.0 * z + scanned_in, 0.01) @ "y"
+        return z, None
+
+    model = kernel.scan(n=4)
+    sl, (carry, outs) = model.site_list((0.5, np.arange(4, dtype=np.float32)))
+    assert sl.addresses() == [("x", 0), ("y", 0), ("x", 1), ("y", 1), ("x", 2), ("y", 2), ("x", 3), ("y", 3)]
+    prog, shared, _ = model.pack((0.5, np.arange(4, dtype=np.float32)), C["y"].set(np.full(4, 3.0, np.float32)), True)
+    assert prog.n_slots == 4 and all(prog.slot_of[("y", t)] == -1 for t in range(4))
+    x0, x1, y1 = prog.c_sites[0], prog.c_sites[2], prog.c_sites[3]
+    assert x0.p[0].op == A.P_CONST and prog.tab[x0.p[0].off] == 0.5                    # initial carry
+    assert x1.p[0].op == A.P_VALUE and x1.p[0].slot == prog.slot_of[("x", 0)]            # x_1 ~ N(x_0, 1)
+    assert y1.p[0].op == A.P_AFFINE and prog.tab[y1.p[0].moff] == 2.0 and prog.tab[y1.p[0].off] == 1.0   # 2 x_1 + xs[1]
+    assert Selection.at["x"].check(("x", 2)) and not Selection.at["x"].check(("y", 2))
+    chm = C.d({("x", 1): 7.0, "x": np.array([5.0, 7.0])})
+    assert chm[1, "x"] == 7.0 and chm[:, "x"][0] == 5.0
