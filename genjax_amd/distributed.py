@@ -103,6 +103,11 @@ class HipBackend:
         from . import kernels
         return kernels.gather_rows(src, anc)
 
+    def gather_rows_into(self, src, anc, dst, col0):
+        """dst[:, col0 : col0 + len(anc)] = src[:, anc]"""
+        from . import kernels
+        kernels.gather_rows(src, anc, dst[:, col0: col0 + anc.numel()])
+
     def lse_combine(self, pairs, K_total):
         from . import kernels
         return kernels.lse_combine(pairs, K_total)
@@ -157,11 +162,27 @@ def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global: torch.
     send_counts = [overlap(slot0, slot0 + n_valid, lo, lo + k) for lo, k in owners]
     my_lo, my_k = owners[rank]
     recv_counts = [overlap(bounds[s_], bounds[s_ + 1], my_lo, my_lo + my_k) for s_ in range(world)]
-    children = backend.gather_rows(rows, anc)                     # [R][n_valid], slot order
+    # Children whose output slot this rank owns are gathered straight into place (SoA, one pass); only the
+    # surplus rows that belong to other ranks' slots travel, as small [n][R] blocks in one all-to-all-v.
     R = rows.shape[0]
-    send = children.t().contiguous()                              # [n_valid][R]: splits run along dim 0
+    new_rows = torch.empty((R, my_k), dtype=rows.dtype, device=dev)
+    lo_l, hi_l = max(slot0, my_lo), min(slot0 + n_valid, my_lo + my_k)
+    if hi_l > lo_l:
+        backend.gather_rows_into(rows, anc[lo_l - slot0: hi_l - slot0], new_rows, lo_l - my_lo)
+    send_counts[rank] = 0
+    recv_counts[rank] = 0
+    parts, pos = [], 0
+    for d, (lo, k) in enumerate(owners):
+        a0, a1 = max(slot0, lo), min(slot0 + n_valid, lo + k)
+        if d != rank and a1 > a0:
+            parts.append(backend.gather_rows(rows, anc[a0 - slot0: a1 - slot0]).t())
+    send = torch.cat(parts, dim=0).contiguous() if parts else torch.empty((0, R), dtype=rows.dtype, device=dev)
     recv = torch.empty((sum(recv_counts), R), dtype=rows.dtype, device=dev)
     _all_to_all(recv, send, recv_counts, send_counts, group)
-    off_mine, n_mine = shard(N_total, rank, world)
-    assert recv.shape[0] == n_mine, (recv.shape, n_mine)
-    return recv.t().contiguous(), dict(sent=n_valid - send_counts[rank], slot_off=off_mine, ancestors=anc)
+    for s_ in range(world):
+        if recv_counts[s_]:
+            a0 = max(bounds[s_], my_lo) - my_lo
+            new_rows[:, a0: a0 + recv_counts[s_]] = recv[pos: pos + recv_counts[s_]].t()
+            pos += recv_counts[s_]
+    return new_rows, dict(sent=int(send.shape[0]), slot_off=my_lo, ancestors=anc)
+

@@ -157,11 +157,12 @@ def resample_multinomial(cum, base_total, key, N_total: int, out_begin=0, n_out=
 
 
 def gather_rows(src: torch.Tensor, anc: torch.Tensor, dst: torch.Tensor | None = None) -> torch.Tensor:
-    rows, stride = src.shape
+    rows = src.shape[0]
     n = anc.numel()
     if dst is None:
         dst = torch.empty((rows, n), dtype=torch.float32, device=src.device)
-    check(load().gjx_gather_rows(_ptr(src), stride, _ptr(anc), n, rows, _ptr(dst), dst.shape[1], _stream()),
+    # dst may be a column window of a wider SoA buffer: its row stride is what the kernel needs
+    check(load().gjx_gather_rows(_ptr(src), src.stride(0), _ptr(anc), n, rows, _ptr(dst), dst.stride(0), _stream()),
           "gjx_gather_rows")
     return dst
 

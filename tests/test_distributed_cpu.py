@@ -30,6 +30,9 @@ class OracleBackend:
         from oracle import cpu
         return torch.from_numpy(cpu.gather_rows(src.numpy(), anc.numpy()))
 
+    def gather_rows_into(self, src, anc, dst, col0):
+        dst[:, col0: col0 + anc.numel()] = self.gather_rows(src, anc)
+
     def lse_combine(self, pairs, K_total):
         m = pairs[:, 0].max()
         s = (pairs[:, 1].double() * torch.exp((pairs[:, 0] - m).double())).sum()
