@@ -181,6 +181,22 @@ def run_gmm(args, rank, world, dev):
                       note="binding resource is integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),
         log_ml=lml, log_ml_exact=exact, log_ml_rel_err=abs(lml - exact) / abs(exact),
     )
+    if world == 1:
+        # the same propagate+reweight kernel on the reference's stream layout and samplers (GJX_RNG_JAX32:
+        # key per particle, key per site, one 32-bit word per draw, erfinv normals, Gumbel-max categorical)
+        prog_j, _ = workloads.gmm_program(D=D, C=C, rng=A.RNG_JAX32)
+        oj = kernels.run_program(prog_j, (0, 1), K, ws=ws, want_weight=False, want_lse=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            kernels.run_program(prog_j, (0, 1 + i), K, ws=ws, out=oj, want_weight=False, want_lse=False)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        res["roofline_jax32_stream"] = dict(kernel="gjx::k_run_gmm<JAX32,16,4,256>", kernel_us=us,
+                                            achieved=ALGO_BYTES_PER_PARTICLE * K / (us * 1e-6) / 1e9, unit="GB/s",
+                                            frac=ALGO_BYTES_PER_PARTICLE * K / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_gmm(prog, min(K, 1 << 20))
     return res
