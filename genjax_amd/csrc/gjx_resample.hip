@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pick_finish(const PickPair* partials, i
 
 // ---- fixed-point weights ---------------------------------------------------------------------
 constexpr float kWeightScale = 1073741824.0f;  // 2^30
-constexpr int kScanItems = 8;                  // items per thread
+constexpr int kScanItems = 4;                  // items per thread
 constexpr int kScanTile = 256 * kScanItems;    // items per block
 
 GJX_DEV uint64_t weight_q(const float* x, int64_t i, int is_log, float mx) {

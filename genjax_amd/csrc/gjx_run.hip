@@ -243,14 +243,22 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
   float* s_misc = s_rr + D;           // [0]: -sum_d log r_d - D*0.5*log(2pi);  [8..]: reduction scratch
   const float* __restrict__ tab = a.tab;
 
+  // prologue, spread over the whole block: every transcendental of the per-component constants is computed by a
+  // different lane; only short LDS sums stay serial
+  float* s_lsig = s_misc + 32;        // [C][DS] log sigma
+  float* s_lr = s_lsig + C * DS;      // [D] log r
   for (int t = threadIdx.x; t < C * D; t += THREADS) {
     const int c = t / D, d = t % D;
+    const float sg = tab[a.sig_off + t];
     s_mu[c * DS + d] = tab[a.mu_off + t];
-    s_sig[c * DS + d] = tab[a.sig_off + t];
+    s_sig[c * DS + d] = sg;
+    s_lsig[c * DS + d] = fast_log(sg);
   }
   for (int t = threadIdx.x; t < D; t += THREADS) {
+    const float r = tab[a.r_off + (a.r_len == 1 ? 0 : t)];
     s_y[t] = tab[a.y_off + t];
-    s_rr[t] = fast_rcp(tab[a.r_off + (a.r_len == 1 ? 0 : t)]);
+    s_rr[t] = fast_rcp(r);
+    s_lr[t] = fast_log(r);
   }
   for (int t = threadIdx.x; t < C; t += THREADS) {
     const float l = tab[a.logits_off + t];
@@ -268,13 +276,15 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
     const float lse = mx + fast_log(se);
     for (int c = threadIdx.x; c < C; c += 64) {
       float sl = 0.0f;
-      for (int d = 0; d < D; ++d) sl += fast_log(s_sig[c * DS + d]);
+      for (int d = 0; d < D; ++d) sl += s_lsig[c * DS + d];
       s_zlp[c] = (s_logit[c] - lse) - sl - (float)D * kHalfLog2Pi;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 63) {
       float sl = 0.0f;
-      for (int d = 0; d < D; ++d) sl += fast_log(tab[a.r_off + (a.r_len == 1 ? 0 : d)]);
+      for (int d = 0; d < D; ++d) sl += s_lr[d];
       s_misc[0] = -sl - (float)D * kHalfLog2Pi;
+    }
+    if (threadIdx.x == 0) {
       float run = 0.0f;  // same float32 order as the generic interpreter and the oracle
       for (int c = 0; c < C; ++c) { run += fast_exp(s_logit[c] - mx); s_cdf[c] = run; }
     }
@@ -621,7 +631,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.partials = partials; a.ticket = ticket; a.lse = lse; a.log_k_total = log_k_total;
-    const size_t lds = sizeof(float) * (size_t)(2 * g.C * (g.D + 4) + 4 * g.C + 2 * g.D + 8 + 16);
+    const size_t lds = sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
     if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
     else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
   } else {
