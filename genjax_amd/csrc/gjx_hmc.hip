@@ -247,35 +247,51 @@ GJX_DEV float quad_sum(float v) {
   return v;
 }
 
-template <int P>
+// CPL chains per lane-quad member: each X row fetched from LDS feeds CPL independent chains, which halves
+// (CPL = 2) the LDS traffic per FLOP and gives the two logit chains of ILP the single quad needs.
+template <int P, int CPL>
 GJX_DEV void logreg_grad(const LogregArgs& a, const float* __restrict__ sX, const float* __restrict__ sY,
-                         const float* __restrict__ sB, int Npad, int k, float lt, const float (&beta)[P], float (&g)[P],
-                         float& glt) {
+                         const float* __restrict__ sB, int Npad, int k, const float (&lt)[CPL], const float (&beta)[CPL][P],
+                         float (&g)[CPL][P], float (&glt)[CPL]) {
   const float* __restrict__ tab = a.tab;
-  float gp[P];
+  float gp[CPL][P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) gp[p] = 0.0f;
-  for (int n = k; n < Npad; n += 4) {  // one observation of this lane per iteration; 4 waves per SIMD hide the latency
+  for (int c = 0; c < CPL; ++c)
+#pragma unroll
+    for (int p = 0; p < P; ++p) gp[c][p] = 0.0f;
+  for (int n = k; n < Npad; n += 4) {
     float x0[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) x0[p] = sX[n * P + p];
-    float s0 = sB[n];
+    const float b0 = sB[n], y0 = sY[n];
+    float s0[CPL];
 #pragma unroll
-    for (int p = 0; p < P; ++p) s0 = fmaf(x0[p], beta[p], s0);
-    const float r0 = sY[n] - sigmoid(s0);
+    for (int c = 0; c < CPL; ++c) s0[c] = b0;
 #pragma unroll
-    for (int p = 0; p < P; ++p) gp[p] = fmaf(x0[p], r0, gp[p]);
-  }
-  const float t2i = fast_exp(-2.0f * lt);  // 1 / tau^2
-  float acc = 0.0f;
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const float z = beta[p] - tab[a.mu_off + (a.mu_len == 1 ? 0 : p)];
-    g[p] = quad_sum(gp[p]) - z * t2i;
-    acc = fmaf(z * z, t2i, acc);
+      for (int c = 0; c < CPL; ++c) s0[c] = fmaf(x0[p], beta[c][p], s0[c]);
+    float r0[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) r0[c] = y0 - sigmoid(s0[c]);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) gp[c][p] = fmaf(x0[p], r0[c], gp[c][p]);
   }
   const float rs0 = fast_rcp(a.s0);
-  glt = -(lt - a.m0) * rs0 * rs0 + acc - (float)P;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const float t2i = fast_exp(-2.0f * lt[c]);  // 1 / tau^2
+    float acc = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float z = beta[c][p] - tab[a.mu_off + (a.mu_len == 1 ? 0 : p)];
+      g[c][p] = quad_sum(gp[c][p]) - z * t2i;
+      acc = fmaf(z * z, t2i, acc);
+    }
+    glt[c] = -(lt[c] - a.m0) * rs0 * rs0 + acc - (float)P;
+  }
 }
 
 template <int P>
@@ -296,10 +312,10 @@ GJX_DEV float logreg_score(const LogregArgs& a, const float* __restrict__ sX, co
   return sc;
 }
 
-constexpr int kLogregThreads = 512;  // 128 chains per block; two blocks (2 x ~72 KB of LDS) per CU -> 4 waves per SIMD
+constexpr int kLogregThreads = 512;  // (128 * CPL) chains per block; X, y, bias (~72 KB at N=1024, P=16) once per block
 
-template <int RNG, int P, bool STALE>
-__global__ __launch_bounds__(kLogregThreads, 4) void k_hmc_logreg(LogregArgs a) {
+template <int RNG, int P, bool STALE, int CPL>
+__global__ __launch_bounds__(kLogregThreads, CPL == 1 ? 4 : 2) void k_hmc_logreg(LogregArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, Npad = (N + 7) & ~7;
   float* sX = smem;
@@ -313,77 +329,99 @@ __global__ __launch_bounds__(kLogregThreads, 4) void k_hmc_logreg(LogregArgs a) 
   __syncthreads();
   const int k = threadIdx.x & 3;
   const int64_t n = a.n;
-  int64_t i = (int64_t)blockIdx.x * (kLogregThreads / 4) + (threadIdx.x >> 2);
-  const bool live = i < n;
-  if (!live) i = n - 1;  // keep the quad complete for the butterflies; no stores from shadow lanes
   float* ch = a.choices;
-  const uint64_t gidx = (uint64_t)(a.offset + i);
-  float lt = ch[i];
-  float beta[P];
+  int64_t idx[CPL];
+  bool live[CPL];
+  float lt[CPL], beta[CPL][P], score0[CPL];
 #pragma unroll
-  for (int p = 0; p < P; ++p) beta[p] = ch[(int64_t)(1 + p) * n + i];
-  const float score0 = logreg_score<P>(a, sX, sY, sB, k, lt, beta);
-  float g[P], glt, g0[STALE ? P : 1], glt0 = 0.0f;
-  logreg_grad<P>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
-  if (STALE) {
+  for (int c = 0; c < CPL; ++c) {
+    idx[c] = ((int64_t)blockIdx.x * (kLogregThreads / 4) + (threadIdx.x >> 2)) * CPL + c;
+    live[c] = idx[c] < n;
+    if (!live[c]) idx[c] = n - 1;  // keep the quad complete for the butterflies; no stores from shadow chains
+    lt[c] = ch[idx[c]];
 #pragma unroll
-    for (int p = 0; p < P; ++p) g0[STALE ? p : 0] = g[p];
-    glt0 = glt;
+    for (int p = 0; p < P; ++p) beta[c][p] = ch[(int64_t)(1 + p) * n + idx[c]];
+    score0[c] = logreg_score<P>(a, sX, sY, sB, k, lt[c], beta[c]);
+  }
+  float g[CPL][P], glt[CPL], g0[STALE ? CPL : 1][STALE ? P : 1], glt0[CPL];
+  logreg_grad<P, CPL>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    glt0[c] = glt[c];
+    if (STALE) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) g0[STALE ? c : 0][STALE ? p : 0] = g[c][p];
+    }
   }
   // momenta: leaf 0 = log_tau, leaf 1 = beta (same streams as k_hmc_generic; the 4 lanes of a chain agree)
-  key2 knew{0u, 0u}, sub{0u, 0u};
-  if (RNG == GJX_RNG_JAX32) {
-    const key2 ck = fold_in64(a.key, gidx);
-    knew = fold_in(ck, 0u);
-    sub = fold_in(ck, 1u);
-  }
-  float plt, pb[P], k0 = 0.0f;
-  {
+  float plt[CPL], pb[CPL][P], k0[CPL];
+  key2 knew[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const uint64_t gidx = (uint64_t)(a.offset + idx[c]);
+    key2 sub{0u, 0u};
+    knew[c] = key2{0u, 0u};
+    if (RNG == GJX_RNG_JAX32) {
+      const key2 ck = fold_in64(a.key, gidx);
+      knew[c] = fold_in(ck, 0u);
+      sub = fold_in(ck, 1u);
+    }
     BitStream<RNG> bs;
     if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 0u)); else bs.open(a.key, gidx, 1u);
-    plt = stream_normal<RNG>(bs, 0u);
-    k0 += -0.5f * plt * plt - kHalfLog2Pi;
+    plt[c] = stream_normal<RNG>(bs, 0u);
+    k0[c] = -0.5f * plt[c] * plt[c] - kHalfLog2Pi;
     if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 1u)); else bs.open(a.key, gidx, 2u);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      pb[p] = stream_normal<RNG>(bs, (uint32_t)p);
-      k0 += -0.5f * pb[p] * pb[p] - kHalfLog2Pi;
+      pb[c][p] = stream_normal<RNG>(bs, (uint32_t)p);
+      k0[c] += -0.5f * pb[c][p] * pb[c][p] - kHalfLog2Pi;
     }
   }
   const float he = 0.5f * a.eps;
   for (int t = 1; t <= a.L; ++t) {
-    plt = plt + he * (STALE ? glt0 : glt);
-    lt = lt + a.eps * plt;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      pb[p] = pb[p] + he * (STALE ? g0[STALE ? p : 0] : g[p]);
-      beta[p] = beta[p] + a.eps * pb[p];
+    for (int c = 0; c < CPL; ++c) {
+      plt[c] = plt[c] + he * (STALE ? glt0[c] : glt[c]);
+      lt[c] = lt[c] + a.eps * plt[c];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        pb[c][p] = pb[c][p] + he * (STALE ? g0[STALE ? c : 0][STALE ? p : 0] : g[c][p]);
+        beta[c][p] = beta[c][p] + a.eps * pb[c][p];
+      }
     }
-    logreg_grad<P>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
-    plt += he * glt;
+    logreg_grad<P, CPL>(a, sX, sY, sB, Npad, k, lt, beta, g, glt);
 #pragma unroll
-    for (int p = 0; p < P; ++p) pb[p] += he * g[p];
-  }
-  float sc = a.L > 0 ? logreg_score<P>(a, sX, sY, sB, k, lt, beta) : score0;
-  float k1 = -0.5f * plt * plt - kHalfLog2Pi;
+    for (int c = 0; c < CPL; ++c) {
+      plt[c] += he * glt[c];
 #pragma unroll
-  for (int p = 0; p < P; ++p) k1 += -0.5f * pb[p] * pb[p] - kHalfLog2Pi;
-  const float al = sc - score0 + k1 - k0;
-  bool acc = true;
-  if (a.accept) {
-    BitStream<RNG> bs;
-    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(knew, 0x4d48u)); else bs.open(a.key, gidx, GJX_FLAT_MAX_SITES);
-    acc = safe_log(bits_to_unit(bs.get(0u))) < al;
-  }
-  if (live && k == 0) {
-    if (acc) {  // rejected chains keep the values already in choices[][]
-      ch[i] = lt;
-#pragma unroll
-      for (int p = 0; p < P; ++p) ch[(int64_t)(1 + p) * n + i] = beta[p];
+      for (int p = 0; p < P; ++p) pb[c][p] += he * g[c][p];
     }
-    if (a.score) a.score[i] = acc ? sc : score0;
-    if (a.alpha) a.alpha[i] = al;
-    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const float sc = a.L > 0 ? logreg_score<P>(a, sX, sY, sB, k, lt[c], beta[c]) : score0[c];
+    float k1 = -0.5f * plt[c] * plt[c] - kHalfLog2Pi;
+#pragma unroll
+    for (int p = 0; p < P; ++p) k1 += -0.5f * pb[c][p] * pb[c][p] - kHalfLog2Pi;
+    const float al = sc - score0[c] + k1 - k0[c];
+    bool acc = true;
+    if (a.accept) {
+      BitStream<RNG> bs;
+      if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(knew[c], 0x4d48u));
+      else bs.open(a.key, (uint64_t)(a.offset + idx[c]), GJX_FLAT_MAX_SITES);
+      acc = safe_log(bits_to_unit(bs.get(0u))) < al;
+    }
+    if (live[c] && k == 0) {
+      const int64_t i = idx[c];
+      if (acc) {  // rejected chains keep the values already in choices[][]
+        ch[i] = lt[c];
+#pragma unroll
+        for (int p = 0; p < P; ++p) ch[(int64_t)(1 + p) * n + i] = beta[c][p];
+      }
+      if (a.score) a.score[i] = acc ? sc : score0[c];
+      if (a.alpha) a.alpha[i] = al;
+      if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;
+    }
   }
 }
 
@@ -419,15 +457,20 @@ static bool match_logreg(const gjx_program* p, LogregArgs* a, int* P_out) {
 
 template <int RNG>
 static int launch_logreg(const LogregArgs& a, int P, hipStream_t st) {
-  const int chains_per_block = kLogregThreads / 4;
+  // GJX_HMC_CPL=2 puts two chains on each lane (half the LDS traffic per FLOP); measured equal to 1 at 2^16 chains
+  // (the kernel is bound by v_fma issue at ~2.9 cycles with three distinct VGPR sources, not by LDS), so 1 is the default
+  const char* e = getenv("GJX_HMC_CPL");
+  const int cpl = e ? atoi(e) : 1;
+  const int chains_per_block = kLogregThreads / 4 * (cpl == 2 ? 2 : 1);
   const unsigned nb = (unsigned)((a.n + chains_per_block - 1) / chains_per_block);
   const int Npad = (a.N + 7) & ~7;
   const size_t lds = sizeof(float) * ((size_t)Npad * P + 2 * (size_t)Npad);
-#define GJX_LR2(PP, ST)                                                                                          \
+#define GJX_LR3(PP, ST, CP)                                                                                      \
   {                                                                                                              \
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg<RNG, PP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_hmc_logreg<RNG, PP, ST>), dim3(nb), dim3(kLogregThreads), lds, st, a);                 \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg<RNG, PP, ST, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_hmc_logreg<RNG, PP, ST, CP>), dim3(nb), dim3(kLogregThreads), lds, st, a);             \
   }
+#define GJX_LR2(PP, ST) { if (cpl == 2) GJX_LR3(PP, ST, 2) else GJX_LR3(PP, ST, 1) }
 #define GJX_LR(PP) case PP: if (a.stale) GJX_LR2(PP, true) else GJX_LR2(PP, false) break;
   switch (P) {
     GJX_LR(2) GJX_LR(4) GJX_LR(8) GJX_LR(16) GJX_LR(32)
@@ -435,6 +478,7 @@ static int launch_logreg(const LogregArgs& a, int P, hipStream_t st) {
   }
 #undef GJX_LR
 #undef GJX_LR2
+#undef GJX_LR3
   return 0;
 }
 
