@@ -8,9 +8,10 @@ because random streams are indexed by the global particle index).  A "step" is o
 over one batch of synthetic input, per GPU:
     propagate + reweight + per-block log-sum-exp partials (ONE kernel, gjx_run_program)
       -> [N > 1: 8-byte all-gather of {max, sumexp} + combine]
-      -> fixed-point prefix sum of the weights (2 kernels; on one GPU their prologue finishes the LSE)
-      -> systematic ancestors by per-particle slot-range expansion (no search), row gather by ancestor
-         [N > 1: all-to-all-v of the rows whose output slot another rank owns]
+      -> resampling indices: fixed-point prefix sum of the weights + systematic ancestors by per-particle
+         slot-range expansion (no search) — ONE co-resident kernel on one GPU (its prologue also finishes the
+         LSE); with N > 1 the prefix sum, an 8-byte all-gather of totals and the expansion are separate launches
+      -> row gather by ancestor [N > 1: all-to-all-v of the rows whose output slot another rank owns]
 
 Prints ONE JSON line (rank 0).  value = K_total * steps / wall time of the timed region (max over
 ranks), inputs resident in HBM.  roofline.achieved = algorithmic bytes of the propagate+reweight
@@ -150,8 +151,8 @@ def run_gmm(args, rank, world, dev):
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
         if world == 1:
             # single GPU: the LSE reduction is finished by the prefix-sum kernels' prologue (no serial tail)
-            kernels.weight_cumsum(out["logw"], ws=ws2, out=(cum, bt), partials=(ws, n_part), lse_out=lse_rec, K_total=K_total)
-            kernels.resample_gather_systematic(cum, bt, u, K_total, out["choices"], rows, anc=anc)
+            kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
+            kernels.gather_rows(out["choices"], anc, rows)
             return lse_rec
         lse = DD.global_lse(out["lse"], K_total)
         DD.resample_exchange(out["choices"], out["logw"], lse, u, K_total)

@@ -293,6 +293,127 @@ __global__ __launch_bounds__(256) void k_systematic_expand(const uint64_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-launch resampling indices for a single GPU: fixed-point weights, their prefix sums and the systematic
+// ancestor expansion in ONE kernel.  Each block scans its tile in registers, publishes the tile total as one
+// tagged 8-byte agent-scope granule, and then reads EVERY block's granule (spinning until the tag of this call
+// appears) to get both its own offset and the grand total — an all-gather of ≤1024 words instead of two kernel
+// boundaries and a 16 MB round trip of the prefix-sum array.  Requires all blocks co-resident (the launcher caps
+// the grid at 1024 blocks of 256 threads; 256 CUs hold at least twice that at this kernel's register count).
+// Tags: granule = (tag << 50) | total, tag = (epoch mod 16383) + 1 != 0; `epoch` lives in the workspace control
+// block and is bumped by block 0 once it has seen every granule (by then every block has read the old epoch),
+// so consecutive calls never mistake each other's granules and the workspace needs zeroing only once.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long kAggMask = (1ull << 50) - 1;
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict__ x, int64_t K, int mode,
+                                                       const float* lse, int n_partials, float* lse_out,
+                                                       float log_k_total, double u, int64_t N, int32_t* ancestors,
+                                                       uint64_t* cum_out, uint64_t* base_total_out,
+                                                       unsigned long long* agg, unsigned* ctrl) {
+  constexpr int kOwn = 8;
+  __shared__ float fred[8];
+  __shared__ uint64_t wsum[4], red2[8];
+  __shared__ int64_t jlast[256];
+  __shared__ int n_heavy;
+  __shared__ int32_t h_i[256];
+  __shared__ int64_t h_lo[256], h_hi[256];
+  const unsigned epoch = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long tag = (unsigned long long)(epoch % 16383u) + 1ull;
+  if (threadIdx.x == 0) n_heavy = 0;
+  float sm;
+  const float mx = block_ref_max(mode, lse, n_partials, fred, &sm);
+  if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float l = mx > -INFINITY ? mx + logf(sm) : -INFINITY;
+    lse_out[0] = mx; lse_out[1] = sm; lse_out[2] = l; lse_out[3] = l - log_k_total;
+  }
+  // ---- tile scan in registers ----
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
+  uint64_t q[ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    s += (i0 + k < K) ? weight_q(x, i0 + k, mode, mx) : 0;
+    q[k] = s;  // thread-local inclusive
+  }
+  uint64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+    if ((threadIdx.x & 63) >= o) inc += up;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint64_t off = inc - s;  // exclusive offset of this thread inside the block
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&agg[blockIdx.x], (tag << 50) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- all-gather of the tile totals ----
+  uint64_t pre = 0, tot = 0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
+    unsigned long long v = 0;
+    for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+      v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 50) == tag) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if ((v >> 50) != tag) { __hip_atomic_store(&ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
+    const uint64_t val = v & kAggMask;
+    tot += val;
+    if (b < (int)blockIdx.x) pre += val;
+  }
+  pre = wave_sum_u64(pre);
+  tot = wave_sum_u64(tot);
+  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6] = pre; red2[4 + (threadIdx.x >> 6)] = tot; }
+  __syncthreads();
+  const uint64_t prefix = red2[0] + red2[1] + red2[2] + red2[3];
+  const uint64_t total = red2[4] + red2[5] + red2[6] + red2[7];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(&ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every block has read `epoch` by now
+    if (base_total_out) { base_total_out[0] = 0; base_total_out[1] = total; }
+  }
+  if (cum_out) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) cum_out[i0 + k] = prefix + off + q[k];
+  }
+  // ---- systematic ancestors by slot-range expansion (see k_systematic_expand) ----
+  if (!ancestors) return;
+  const double step = (double)total / (double)N;
+  const double inv_step = (double)N / (double)total;
+  const bool any = total > 0;
+  const uint64_t c_last = prefix + off + s;  // inclusive prefix of this thread's last item
+  const int64_t j_mine = any ? slots_below(c_last, u, step, inv_step, total, N) : 0;
+  jlast[threadIdx.x] = j_mine;
+  __syncthreads();
+  int64_t j_prev = threadIdx.x > 0 ? jlast[threadIdx.x - 1] : (any ? slots_below(prefix, u, step, inv_step, total, N) : 0);
+  uint64_t c_prev = prefix + off;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t i = i0 + k;
+    const uint64_t c_cur = prefix + off + q[k];
+    const int64_t j_cur = (k == ITEMS - 1) ? j_mine : ((any && c_cur > c_prev) ? slots_below(c_cur, u, step, inv_step, total, N) : j_prev);
+    if (i < K && c_cur > c_prev) {
+      const int64_t lo = j_prev, hi = j_cur > N ? N : j_cur;
+      if (hi - lo > kOwn) {
+        const int h = atomicAdd(&n_heavy, 1);
+        h_i[h] = (int32_t)i; h_lo[h] = lo; h_hi[h] = hi;
+      } else {
+        for (int64_t j = lo; j < hi; ++j) ancestors[j] = (int32_t)i;
+      }
+    }
+    j_prev = j_cur;
+    c_prev = c_cur;
+  }
+  __syncthreads();
+  const int nh = n_heavy < 256 ? n_heavy : 256;
+  for (int h = 0; h < nh; ++h) {
+    const int32_t pi = h_i[h];
+    for (int64_t j = h_lo[h] + threadIdx.x; j < h_hi[h]; j += 256) ancestors[j] = pi;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total,
                                                     key2 key, int64_t out_begin, int64_t n_out, int32_t* ancestors) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -370,6 +491,35 @@ extern "C" int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uin
                      base_total_dev, u, N_total, out_begin, n_out, ancestors, (const float*)nullptr, (int64_t)0, 0,
                      (float*)nullptr, (int64_t)0);
   GJX_CHECK_LAUNCH("gjx_resample_systematic");
+  return GJX_OK;
+}
+
+extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials,
+                                    double u, int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev,
+                                    float* lse_out, int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || K <= 0 || N <= 0 || is_log < 0 || is_log > 2 || (is_log && !lse) || (is_log == 2 && n_partials <= 0) ||
+      !(u >= 0.0 && u < 1.0) || (!ancestors && !cum))
+    return gjx_fail(GJX_EINVAL, "gjx_resample_indices: bad argument");
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_resample_indices: workspace too small");
+  // one co-resident grid of at most 1024 blocks; otherwise fall back to the three-launch path
+  int items = 4;
+  while (items < 64 && (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items *= 4;
+  const int64_t nblocks = (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items);
+  hipStream_t st = (hipStream_t)stream;
+  if (nblocks > 1024 || !ancestors) {
+    if (!cum || !base_total_dev) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_indices: K too large for the fused path and no cum/base_total buffers for the fallback");
+    int rc = gjx_weight_cumsum(x, K, is_log, lse, n_partials, cum, base_total_dev, lse_out, K_total, workspace, workspace_bytes, stream);
+    if (rc || !ancestors) return rc;
+    return gjx_resample_systematic(cum, K, base_total_dev, u, N, 0, N, ancestors, stream);
+  }
+  unsigned* ctrl = (unsigned*)workspace + 8;  // control block words 8..10: epoch, -, error (0..7 belong to the LSE ticket)
+  unsigned long long* agg = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
+  const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
+#define GJX_RF(IT) hipLaunchKernelGGL((k_resample_fused<IT>), dim3((unsigned)nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, \
+                                      (int)n_partials, lse_out, log_k, u, N, ancestors, cum, base_total_dev, agg, ctrl)
+  if (items == 4) GJX_RF(4); else if (items == 16) GJX_RF(16); else GJX_RF(64);
+#undef GJX_RF
+  GJX_CHECK_LAUNCH("gjx_resample_indices");
   return GJX_OK;
 }
 

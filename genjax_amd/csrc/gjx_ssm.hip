@@ -153,11 +153,12 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
 
 
 // ---- whole bootstrap filter on one GPU: the T-step loop runs in C++ so that the per-step launches
-// (prefix sum x2, ancestor expansion, fused step) are issued back to back without Python in between.
+// (one-launch resampling indices, fused step) are issued back to back without Python in between.
 // Key discipline as in inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t);
 // the systematic comb offset is uniform(k_res).
 extern "C" int gjx_weight_cumsum(const float*, int64_t, int32_t, const float*, int32_t, uint64_t*, uint64_t*, float*, int64_t, void*, size_t, void*);
 extern "C" int gjx_resample_systematic(const uint64_t*, int64_t, const uint64_t*, double, int64_t, int64_t, int64_t, int32_t*, void*);
+extern "C" int gjx_resample_indices(const float*, int64_t, int32_t, const float*, int32_t, double, int64_t, int32_t*, uint64_t*, uint64_t*, float*, int64_t, void*, size_t, void*);
 
 static void host_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
   static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
@@ -198,9 +199,8 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
       // the previous step left its per-block LSE partials in ws1; the prefix-sum prologue reduces them and
       // block 0 writes the finished record of step t-1
-      int rc = gjx_weight_cumsum(logw, K, 2, (const float*)(ws1 + 256), (int32_t)((K + 255) / 256), cum, bt, lse - 4, K, ws2, need, stream);
-      if (rc) return rc;
-      rc = gjx_resample_systematic(cum, K, bt, u, K, 0, K, ancestors, stream);
+      const int rc = gjx_resample_indices(logw, K, 2, (const float*)(ws1 + 256), (int32_t)((K + 255) / 256), u, K, ancestors, cum, bt,
+                                          lse - 4, K, ws2, need, stream);
       if (rc) return rc;
     }
     const int rc = gjx_ssm_step(m, kp[0], kp[1], rng_mode, t, K, 0, t > 0 ? x_prev : nullptr, K, t > 0 ? ancestors : nullptr,

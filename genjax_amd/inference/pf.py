@@ -100,8 +100,7 @@ class BootstrapFilter:
             k_prop, k_res = split(k)
             if t > 0:
                 if world == 1:
-                    cum, bt = kernels.weight_cumsum(logw, True, lse, ws=ws2, out=(cum_buf, bt_buf))
-                    anc = kernels.resample_systematic(cum, bt, _unit_from_key(k_res), self.K, prefill=False)
+                    anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
                 else:
                     x_prev, _ = D.resample_exchange(x_prev, logw, lse, _unit_from_key(k_res), self.K)
                     anc = None

@@ -118,6 +118,28 @@ def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, pa
     return cum, bt
 
 
+def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=True, lse=None, partials=None, lse_out=None,
+                     K_total=None, anc=None, cum=None, bt=None, ws=None) -> torch.Tensor:
+    """gjx_resample_indices: weights -> systematic ancestors in one launch (single GPU).  -> ancestors int32[N]"""
+    K = x.numel()
+    N = int(N or K)
+    if anc is None:
+        anc = torch.empty(N, dtype=torch.int32, device=x.device)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, x.device)
+    if partials is not None:
+        run_ws, n = partials
+        mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
+    else:
+        mode, lp, npart = int(bool(is_log)), _ptr(lse), 0
+    if K > (1 << 24) and (cum is None or bt is None):      # beyond the co-resident grid: fallback needs the buffers
+        cum = torch.empty(K, dtype=torch.int64, device=x.device)
+        bt = torch.empty(2, dtype=torch.int64, device=x.device)
+    check(load().gjx_resample_indices(_ptr(x), K, mode, lp, npart, float(u), N, _ptr(anc), _ptr(cum), _ptr(bt), _ptr(lse_out),
+                                      int(K_total or K), _ptr(ws), ws.numel(), _stream()), "gjx_resample_indices")
+    return anc
+
+
 def run_partials_count(prog: PackedProgram, K: int, offset: int = 0) -> int:
     cp = prog.c_program(None)
     return int(load().gjx_run_partials_count(C.byref(cp), int(K), int(offset)))

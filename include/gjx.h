@@ -219,6 +219,14 @@ int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_
 int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev,
                             double u, int64_t N_total, int64_t out_begin, int64_t n_out,
                             int32_t* ancestors, void* stream);
+/* Single-GPU resampling indices in ONE launch: fixed-point weights (is_log / lse / n_partials as in
+ * gjx_weight_cumsum), their prefix sums and the systematic ancestors ancestors[j], j < N (every slot is written).
+ * cum u64[K] and base_total_dev u64[2] are optional outputs (NULL = not materialised; they are required only when K
+ * is too large for the co-resident fused kernel and the call falls back to the three-launch path).  Results are
+ * bit-identical to gjx_weight_cumsum + gjx_resample_systematic. */
+int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
+                         int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev, float* lse_out,
+                         int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
 /* the same search fused with the row gather: dst[r][j - out_begin] = src[r][ancestor(j)] for r < rows
  * (slots owned by another rank are left untouched in dst and in ancestors); ancestors int32[n_out] is scratch/output */
 int gjx_resample_gather_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev, double u,
@@ -255,7 +263,7 @@ int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mod
                  const int32_t* anc, const float* y_dev, float* x_out, float* logw, float* lse,
                  int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The whole T-step bootstrap filter on ONE GPU, looped in C++ (4 launches per step, no host round trip):
+/* The whole T-step bootstrap filter on ONE GPU, looped in C++ (2 launches per step, no host round trip):
  * step keys k_t = fold_in(k_{t-1}, t), (k_prop, k_res) = split(k_t), systematic resampling before every
  * propagate step with comb offset uniform(k_res) — identical to issuing the per-step calls from the host.
  *   ys_dev f32[T][dy]; x_a, x_b f32[dx][K] (step t writes x_a for even t, x_b for odd t); logw f32[K];

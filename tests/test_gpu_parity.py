@@ -293,6 +293,37 @@ def test_resampling_bit_exact(K_, oracle):
     assert np.abs(counts - K * wn).max() <= 1.01
 
 
+def test_one_launch_resample_indices(K_, oracle):
+    """gjx_resample_indices (prefix sums + ancestors in one co-resident kernel) == the three-launch path, bit for
+    bit, for every tile configuration, repeated calls on one workspace (epoch tags) and degenerate weights."""
+    import torch
+    ws = None
+    for K in (1, 300, 1024, 1025, 70_001, 1 << 20, (1 << 20) + 77, 3_000_000):
+        rs = np.random.default_rng(K)
+        lw = (rs.standard_normal(K) * (5.0 if K % 2 else 1.0)).astype(np.float32)
+        lwd = torch.as_tensor(lw).cuda()
+        l4 = K_.logsumexp(lwd)
+        cum, bt = K_.weight_cumsum(lwd, True, l4)
+        ws = K_.workspace(A.OP_RESAMPLE, K)
+        for rep, (N, u) in enumerate(((K, 0.37), (K, 0.0), (max(1, K // 3), 0.999999), (2 * K + 1, 0.5))):
+            want = K_.resample_systematic(cum, bt, u, N)
+            cum2 = torch.empty_like(cum)
+            bt2 = torch.empty_like(bt)
+            got = K_.resample_indices(lwd, u, N, True, l4, ws=ws, cum=cum2, bt=bt2)
+            np.testing.assert_array_equal(_np(got), _np(want))
+            np.testing.assert_array_equal(_np(cum2), _np(cum))
+            np.testing.assert_array_equal(_np(bt2), _np(bt))
+        assert int(ws[40:44].view(torch.int32)) == 0                              # no spin timeout was flagged
+    w = torch.zeros(5000).cuda()
+    w[4321] = 2.0
+    assert (K_.resample_indices(w, 0.7, 5000, is_log=False) == 4321).all()
+    # linear weights against the oracle
+    wl = np.random.default_rng(1).random(9999).astype(np.float32)
+    cum_o, _ = oracle.weight_cumsum(wl)
+    np.testing.assert_array_equal(_np(K_.resample_indices(torch.as_tensor(wl).cuda(), 0.123, 9999, is_log=False)),
+                                  oracle.resample_systematic(cum_o, 0.123, 9999))
+
+
 def test_degenerate_and_invalid_arguments(K_):
     import torch
     from genjax_amd._lib import GjxError
