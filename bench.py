@@ -139,25 +139,31 @@ def run_gmm(args, rank, world, dev):
     sample_at = {int(round(j * (args.steps - 1) / max(n_samp - 1, 1))): j for j in range(n_samp)}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
 
+    sharded = world > 1 or os.environ.get("GJX_FORCE_DIST", "0") == "1"
+
     def step(i, timed):
         key = (0, 1 + i)
         j = sample_at.get(i) if timed else None
         if j is not None:
             ev[j][0].record()
         kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
-                            want_lse=(world > 1))
+                            want_lse=sharded)
         if j is not None:
             ev[j][1].record()
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
-        if world == 1:
+        if world == 1 and not sharded:
             # single GPU: the LSE reduction is finished by the prefix-sum kernels' prologue (no serial tail)
             kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
             kernels.gather_rows(out["choices"], anc, rows)
             return lse_rec
-        lse = DD.global_lse(out["lse"], K_total)
-        DD.resample_exchange(out["choices"], out["logw"], lse, u, K_total)
-        return lse
+        # sharded: 8-byte all-gather of per-rank {max, sumexp} (reduced in the prefix-sum prologue), 8-byte
+        # all-gather of weight totals, device-side plan, local gather + all-to-all-v of the surplus children
+        _, info = DD.resample_exchange(out["choices"], out["logw"], None, u, K_total, pairs=DD.gather_lse_pairs(out["lse"]))
+        return info["lse"]
 
+    if sharded:
+        for i in range(30):     # RCCL sets up channels lazily per collective: keep that out of W and the timed region
+            step(i, False)
     dt, lse = timed_loop(args, world, dev, step)
     if rank != 0:
         return None
@@ -286,7 +292,7 @@ def run_hmc(args, rank, world, dev):
 
 def timed_loop(args, world, dev, step):
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -299,7 +305,7 @@ def timed_loop(args, world, dev, step):
         last = step(i, True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -334,7 +340,7 @@ def main():
     res = {"gmm": run_gmm, "ssm": run_ssm, "hmc": run_hmc}[args.workload](args, rank, world, dev)
     if rank == 0 and res is not None:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -57,7 +57,16 @@ class GjxSsm(C.Structure):
                 ("q0", f32)]
 
 
-assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 96
+MAX_RANKS = 64
+
+
+class GjxShardPlan(C.Structure):
+    _fields_ = [("base", C.c_uint64), ("total", C.c_uint64), ("slot0", i64), ("n_valid", i64), ("own_lo", i64),
+                ("own_n", i64), ("keep_lo", i64), ("keep_hi", i64), ("n_ranks", i64), ("status", i64),
+                ("seq", i64), ("reserved", i64), ("bounds", i64 * (MAX_RANKS + 1))]
+
+
+assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 96 and C.sizeof(GjxShardPlan) == 8 * (12 + MAX_RANKS + 1)
 
 PP = C.POINTER(GjxProgram)
 
@@ -80,6 +89,11 @@ PROTOTYPES = {
     "gjx_resample_gather_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, i64, i32, vp, i64, vp, vp]),
     "gjx_resample_multinomial": (C.c_int, [vp, i64, vp, u32, u32, i64, i64, i64, vp, vp]),
     "gjx_gather_rows": (C.c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
+    "gjx_shard_plan_build": (C.c_int, [vp, i32, i32, f64, i64, i64, vp, vp, vp]),
+    "gjx_shard_pack": (C.c_int, [vp, i64, i32, vp, i64, i64, i64, vp, vp]),
+    "gjx_shard_unpack": (C.c_int, [vp, i64, i64, i32, vp, i64, i64, vp]),
+    "gjx_shard_resample": (C.c_int, [vp, i64, vp, f64, i64, vp, i64, vp, i64, i32, vp, i64, i64, vp]),
+    "gjx_gather_rows_strided": (C.c_int, [vp, i64, i64, vp, i64, i32, vp, i64, i64, vp]),
     "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
                                vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),

@@ -237,8 +237,14 @@ __global__ __launch_bounds__(256) void k_systematic_expand(const uint64_t* __res
                                                           const uint64_t* base_total, double u, int64_t N_total,
                                                           int64_t out_begin, int64_t n_out, int32_t* ancestors,
                                                           const float* __restrict__ src, int64_t src_stride, int rows,
-                                                          float* __restrict__ dst, int64_t dst_stride) {
+                                                          float* __restrict__ dst, int64_t dst_stride,
+                                                          const int64_t* range_dev = nullptr) {
   constexpr int kOwn = 8;  // offspring a lane writes by itself
+  if (range_dev) {         // sharded plan: {first slot, slot count} of this rank's run live on the device
+    out_begin = range_dev[0];
+    const int64_t n = range_dev[1];
+    n_out = n < n_out ? n : n_out;   // n_out carries the capacity of ancestors[]
+  }
   __shared__ int n_heavy;
   __shared__ int32_t h_i[256];
   __shared__ int64_t h_lo[256], h_hi[256];
@@ -441,6 +447,106 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
   for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + j] = src[(int64_t)r * src_stride + a];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Sharded resampling plan.  Every rank holds the G per-rank weight totals (one 8-byte all-gather) and derives
+// the same slot bounds B_r = J(total_0 + ... + total_{r-1}): rank r's particles produce exactly the output
+// slots [B_r, B_{r+1}).  One wave computes the G+1 bounds; the plan goes to device memory (read by the
+// expansion / gather kernels queued behind it) and to a pinned host copy (read by the host only to size the
+// all-to-all, while those kernels run).
+__global__ __launch_bounds__(64) void k_shard_plan(const uint64_t* __restrict__ totals, int G, int rank, double u,
+                                                  int64_t N_total, int64_t seq, gjx_shard_plan* plan_dev,
+                                                  gjx_shard_plan* plan_host) {
+  __shared__ gjx_shard_plan p;
+  const int t = threadIdx.x;
+  uint64_t total = 0, below = 0;
+  for (int r = 0; r < G; ++r) {
+    if (r < t) below += totals[r];
+    total += totals[r];
+  }
+  if (t <= G) {
+    const double step = (double)total / (double)N_total;
+    const double inv_step = (double)N_total / (double)total;
+    p.bounds[t] = total > 0 ? slots_below(below, u, step, inv_step, total, N_total) : 0;
+    if (t == rank) p.base = below;
+  }
+  __syncthreads();
+  if (t == 0) {
+    p.total = total;
+    p.slot0 = p.bounds[rank];
+    p.n_valid = p.bounds[rank + 1] - p.bounds[rank];
+    const int64_t q = N_total / G, rem = N_total % G;
+    p.own_lo = rank * q + (rank < rem ? rank : rem);
+    p.own_n = q + (rank < rem ? 1 : 0);
+    const int64_t lo = p.slot0 > p.own_lo ? p.slot0 : p.own_lo;
+    int64_t hi = p.slot0 + p.n_valid < p.own_lo + p.own_n ? p.slot0 + p.n_valid : p.own_lo + p.own_n;
+    p.keep_lo = lo;
+    p.keep_hi = hi > lo ? hi : lo;
+    p.n_ranks = G;
+    p.status = total > 0 ? 0 : 1;
+    p.seq = seq;
+    p.reserved = 0;
+  }
+  __syncthreads();
+  constexpr int kWords = sizeof(gjx_shard_plan) / 8;
+  constexpr int kSeqWord = offsetof(gjx_shard_plan, seq) / 8;
+  const uint64_t* sp = reinterpret_cast<const uint64_t*>(&p);
+  for (int w = t; w < kWords; w += 64) {
+    reinterpret_cast<uint64_t*>(plan_dev)[w] = sp[w];
+    if (plan_host && w != kSeqWord) reinterpret_cast<uint64_t*>(plan_host)[w] = sp[w];
+  }
+  if (plan_host) {         // one wave: every lane's stores are ordered before lane 0's release of the sequence word
+    __threadfence_system();
+    if (t == 0) __hip_atomic_store(&plan_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// pack: msg[j][r] = src[r][anc[idx(j)]]; unpack: dst[r][col(j)] = msg[j][r]  (lanes along r: messages are row-major)
+__global__ __launch_bounds__(256) void k_shard_pack(const float* __restrict__ src, int64_t src_stride, int rows,
+                                                   const int32_t* __restrict__ anc, int64_t n_valid, int64_t n_pre,
+                                                   int64_t n_suf, float* __restrict__ msg) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (n_pre + n_suf) * rows) return;
+  const int64_t j = e / rows, r = e % rows;
+  const int32_t a = anc[j < n_pre ? j : n_valid - n_suf + (j - n_pre)];
+  msg[e] = src[r * src_stride + a];
+}
+
+__global__ __launch_bounds__(256) void k_shard_unpack(const float* __restrict__ msg, int64_t n_lo, int64_t n_hi, int rows,
+                                                     float* __restrict__ dst, int64_t dst_stride, int64_t own_n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (n_lo + n_hi) * rows) return;
+  const int64_t r = e / (n_lo + n_hi), j = e % (n_lo + n_hi);   // lanes along j: coalesced stores into the SoA rows
+  const int64_t col = j < n_lo ? j : own_n - n_hi + (j - n_lo);
+  dst[r * dst_stride + col] = msg[j * rows + r];
+}
+
+// children that stay on this rank: dst[r][j - own_lo] = src[r][anc[j - slot0]] for the slots j this rank both
+// produces and owns, keep_lo <= j < keep_hi (all four read from the device plan)
+__global__ __launch_bounds__(256) void k_gather_kept(const gjx_shard_plan* __restrict__ plan, const float* __restrict__ src,
+                                                    int64_t src_stride, const int32_t* __restrict__ anc, int rows,
+                                                    float* __restrict__ dst, int64_t dst_stride) {
+  const int64_t j = plan->keep_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= plan->keep_hi) return;
+  const int32_t a = anc[j - plan->slot0];
+  const int64_t o = j - plan->own_lo;
+  for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + o] = src[(int64_t)r * src_stride + a];
+}
+
+// general strided form: dst[r*drs + j*dcs] = src[r*srs + idx(j)*scs]; packs children into [n][rows] messages
+// and unpacks received ones.  Lanes run along r when the destination is row-contiguous.
+__global__ __launch_bounds__(256) void k_gather_rows_strided(const float* __restrict__ src, int64_t srs, int64_t scs,
+                                                            const int32_t* __restrict__ anc, int64_t n, int rows,
+                                                            float* __restrict__ dst, int64_t drs, int64_t dcs) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * rows) return;
+  int64_t j, r;
+  if (drs == 1) { j = e / rows; r = e % rows; } else { r = e / n; j = e % n; }
+  const int64_t a = anc ? anc[j] : j;
+  if (a < 0) return;
+  dst[r * drs + j * dcs] = src[r * srs + a * scs];
+}
+
 }  // namespace gjx
 
 using namespace gjx;
@@ -556,5 +662,77 @@ extern "C" int gjx_gather_rows(const float* src, int64_t src_stride, const int32
   hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                      src_stride, anc, n_out, (int)rows, dst, dst_stride);
   GJX_CHECK_LAUNCH("gjx_gather_rows");
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_plan_build(const uint64_t* totals_dev, int32_t n_ranks, int32_t rank, double u, int64_t N_total,
+                                    int64_t seq, gjx_shard_plan* plan_dev, gjx_shard_plan* plan_host_pinned, void* stream) {
+  if (!totals_dev || !plan_dev || n_ranks < 1 || n_ranks > GJX_MAX_RANKS || rank < 0 || rank >= n_ranks || N_total <= 0 ||
+      !(u >= 0.0 && u < 1.0))
+    return gjx_fail(GJX_EINVAL, "gjx_shard_plan_build: bad argument");
+  gjx_shard_plan* mapped = nullptr;
+  if (plan_host_pinned && hipHostGetDevicePointer((void**)&mapped, plan_host_pinned, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return gjx_fail(GJX_EINVAL, "gjx_shard_plan_build: plan_host_pinned is not pinned (device-mapped) host memory");
+  }
+  hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, totals_dev, (int)n_ranks, (int)rank, u, N_total,
+                     seq, plan_dev, mapped);
+  GJX_CHECK_LAUNCH("gjx_shard_plan_build");
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_resample(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
+                                  int32_t* ancestors, int64_t anc_capacity, const float* src, int64_t src_stride,
+                                  int32_t rows, float* dst, int64_t dst_stride, int64_t own_n, void* stream) {
+  if (!cum || !plan_dev || !ancestors || K <= 0 || N_total <= 0 || anc_capacity < 0 || rows < 0 || own_n < 0 ||
+      (rows > 0 && own_n > 0 && (!src || !dst)) || !(u >= 0.0 && u < 1.0))
+    return gjx_fail(GJX_EINVAL, "gjx_shard_resample: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t* bt = reinterpret_cast<const uint64_t*>(plan_dev);                       // {base, total}
+  const int64_t* range = reinterpret_cast<const int64_t*>(plan_dev) + 2;                  // {slot0, n_valid}
+  hipLaunchKernelGGL(k_systematic_expand<false>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cum, K, bt, u, N_total,
+                     (int64_t)0, anc_capacity, ancestors, (const float*)nullptr, (int64_t)0, 0, (float*)nullptr, (int64_t)0,
+                     range);
+  GJX_CHECK_LAUNCH("gjx_shard_resample(expand)");
+  if (rows > 0 && own_n > 0) {
+    hipLaunchKernelGGL(k_gather_kept, dim3((unsigned)((own_n + 255) / 256)), dim3(256), 0, st, plan_dev, src, src_stride,
+                       (const int32_t*)ancestors, (int)rows, dst, dst_stride);
+    GJX_CHECK_LAUNCH("gjx_shard_resample(gather)");
+  }
+  return GJX_OK;
+}
+
+extern "C" int gjx_gather_rows_strided(const float* src, int64_t src_row_stride, int64_t src_col_stride, const int32_t* anc,
+                                       int64_t n, int32_t rows, float* dst, int64_t dst_row_stride, int64_t dst_col_stride,
+                                       void* stream) {
+  if (!src || !dst || n < 0 || rows < 0) return gjx_fail(GJX_EINVAL, "gjx_gather_rows_strided: bad argument");
+  if (n == 0 || rows == 0) return GJX_OK;
+  hipLaunchKernelGGL(k_gather_rows_strided, dim3((unsigned)((n * rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_row_stride, src_col_stride, anc, n, (int)rows, dst, dst_row_stride, dst_col_stride);
+  GJX_CHECK_LAUNCH("gjx_gather_rows_strided");
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_pack(const float* src, int64_t src_stride, int32_t rows, const int32_t* ancestors, int64_t n_valid,
+                              int64_t n_pre, int64_t n_suf, float* msg, void* stream) {
+  if (n_pre < 0 || n_suf < 0 || rows < 0 || n_pre + n_suf > n_valid) return gjx_fail(GJX_EINVAL, "gjx_shard_pack: bad argument");
+  const int64_t n = (n_pre + n_suf) * rows;
+  if (n == 0) return GJX_OK;
+  if (!src || !ancestors || !msg) return gjx_fail(GJX_EINVAL, "gjx_shard_pack: bad argument");
+  hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_stride, (int)rows,
+                     ancestors, n_valid, n_pre, n_suf, msg);
+  GJX_CHECK_LAUNCH("gjx_shard_pack");
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_unpack(const float* msg, int64_t n_lo, int64_t n_hi, int32_t rows, float* dst, int64_t dst_stride,
+                                int64_t own_n, void* stream) {
+  if (n_lo < 0 || n_hi < 0 || rows < 0 || n_lo + n_hi > own_n) return gjx_fail(GJX_EINVAL, "gjx_shard_unpack: bad argument");
+  const int64_t n = (n_lo + n_hi) * rows;
+  if (n == 0) return GJX_OK;
+  if (!msg || !dst) return gjx_fail(GJX_EINVAL, "gjx_shard_unpack: bad argument");
+  hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, msg, n_lo, n_hi, (int)rows,
+                     dst, dst_stride, own_n);
+  GJX_CHECK_LAUNCH("gjx_shard_unpack");
   return GJX_OK;
 }

@@ -21,11 +21,17 @@ import torch
 import torch.distributed as dist
 
 
+def _forced() -> bool:
+    """GJX_FORCE_DIST=1: take the sharded code path (process group, collectives, plan, all-to-all) even with a
+    single rank — how the RCCL plumbing is exercised on a 1-GPU box."""
+    return os.environ.get("GJX_FORCE_DIST", "0") == "1"
+
+
 def init_from_env(backend: str | None = None) -> tuple[int, int]:
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun contract). -> (rank, world)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -88,12 +94,72 @@ def slots_below(c: int, u: float, total: int, N: int) -> int:
     return g
 
 
-class HipBackend:
-    """Compute steps on the HIP kernels (device tensors)."""
+class HostPlan:
+    """Host-computed gjx_shard_plan (same fields), for backends without the plan kernel (CPU dry runs)."""
 
-    def weight_cumsum(self, x, is_log, lse):
+    def __init__(self, totals: list[int], rank: int, u: float, N_total: int):
+        world = len(totals)
+        self.total = sum(totals)
+        self.base = sum(totals[:rank])
+        self.bounds = [slots_below(sum(totals[:r]), u, self.total, N_total) for r in range(world + 1)]
+        self.slot0, self.n_valid = self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank]
+        self.own_lo, self.own_n = shard(N_total, rank, world)
+        self.keep_lo = max(self.slot0, self.own_lo)
+        self.keep_hi = max(self.keep_lo, min(self.slot0 + self.n_valid, self.own_lo + self.own_n))
+        self.status = 0 if self.total > 0 else 1
+
+    def wait(self):
+        return self
+
+
+class HipBackend:
+    """Compute steps on the HIP kernels (device tensors).  Internal temporaries (zeroed workspace, prefix sums,
+    plan) are kept per (K, device); everything handed back to the caller is freshly allocated."""
+
+    def __init__(self):
+        self._plan = None
+        self._tmp = {}
+
+    def _buffers(self, K, dev):
+        from . import _abi as A
         from . import kernels
-        return kernels.weight_cumsum(x, is_log, lse)
+        b = self._tmp.get((K, dev))
+        if b is None:
+            b = (kernels.workspace(A.OP_RESAMPLE, K, dev), torch.empty(K, dtype=torch.int64, device=dev),
+                 torch.empty(2, dtype=torch.int64, device=dev))
+            self._tmp = {(K, dev): b}
+        return b
+
+    def weight_cumsum(self, x, is_log, lse=None, pairs=None, K_total=None):
+        """-> (cum, {0, local total}, global LSE record or None).  ``pairs`` = the all-gathered per-rank
+        {max, sumexp}: the kernels' prologue reduces them, so no separate combine launch."""
+        from . import kernels
+        ws, cum, bt = self._buffers(x.numel(), x.device)
+        rec = None
+        if pairs is not None:
+            rec = torch.empty(4, dtype=torch.float32, device=x.device)
+            kernels.weight_cumsum(x, True, pairs=pairs, lse_out=rec, K_total=K_total, ws=ws, out=(cum, bt))
+        else:
+            kernels.weight_cumsum(x, is_log, lse, ws=ws, out=(cum, bt))
+        return cum, bt, rec
+
+    def plan(self, totals, rank, u, N_total):
+        from . import kernels
+        if self._plan is None or self._plan.dev.device != totals.device:
+            self._plan = kernels.ShardPlan(totals.device)
+        return self._plan.build(totals, rank, u, N_total)
+
+    def shard_resample(self, cum, plan, u, N_total, rows, own_n):
+        from . import kernels
+        return kernels.shard_resample(cum, plan, u, N_total, rows, own_n)
+
+    def pack(self, rows, anc, n_valid, n_pre, n_suf):
+        from . import kernels
+        return kernels.shard_pack(rows, anc, n_valid, n_pre, n_suf)
+
+    def unpack(self, msg, n_lo, n_hi, dst):
+        from . import kernels
+        kernels.shard_unpack(msg, n_lo, n_hi, dst)
 
     def resample_systematic(self, cum, base_total, u, N_total, out_begin, n_out):
         from . import kernels
@@ -103,14 +169,31 @@ class HipBackend:
         from . import kernels
         return kernels.gather_rows(src, anc)
 
-    def gather_rows_into(self, src, anc, dst, col0):
-        """dst[:, col0 : col0 + len(anc)] = src[:, anc]"""
-        from . import kernels
-        kernels.gather_rows(src, anc, dst[:, col0: col0 + anc.numel()])
-
     def lse_combine(self, pairs, K_total):
         from . import kernels
         return kernels.lse_combine(pairs, K_total)
+
+
+_default_backend = None
+
+
+def _backend(backend):
+    global _default_backend
+    if backend is not None:
+        return backend
+    if _default_backend is None:
+        _default_backend = HipBackend()
+    return _default_backend
+
+
+def gather_lse_pairs(local_lse: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of the per-rank {max, sumexp} (first two floats of an LSE record): f32[world][2]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not _forced():
+        return local_lse[:2].reshape(1, 2)
+    pairs = torch.empty(world * 2, dtype=torch.float32, device=local_lse.device)
+    _all_gather(pairs, local_lse[:2].contiguous(), group)
+    return pairs.view(world, 2)
 
 
 def global_lse(local_lse: torch.Tensor, K_total: int, backend=None, group=None) -> torch.Tensor:
@@ -119,70 +202,62 @@ def global_lse(local_lse: torch.Tensor, K_total: int, backend=None, group=None) 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_lse
-    backend = backend or HipBackend()
-    pairs = torch.empty(world * 2, dtype=torch.float32, device=local_lse.device)
-    _all_gather(pairs, local_lse[:2].contiguous(), group)
-    return backend.lse_combine(pairs.view(world, 2), K_total)
+    return _backend(backend).lse_combine(gather_lse_pairs(local_lse, group), K_total)
 
 
-def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global: torch.Tensor, u: float, N_total: int,
-                      backend=None, group=None, is_log: bool = True):
+def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global, u: float, N_total: int,
+                      backend=None, group=None, is_log: bool = True, pairs=None):
     """Systematic resampling of a sharded collection.
 
-    rows f32[R][K_local] (SoA), logw f32[K_local], lse_global the GLOBAL record (its max scales the
-    fixed-point weights identically on every rank).  Returns (new_rows f32[R][n_mine], info) where this
-    rank ends up with the particles of its output-slot range [slot_off, slot_off + n_mine).
+    rows f32[R][K_local] (SoA), logw f32[K_local].  The fixed-point weight scale is the GLOBAL maximum, given
+    either as ``lse_global`` (the combined record) or as ``pairs`` (gather_lse_pairs: the combine then happens
+    in the prefix-sum kernels' prologue and the record comes back in info["lse"]).
+    Returns (new_rows f32[R][own_n], info): this rank ends up with the particles of its output-slot range.
+
+    Stream order per rank (2 collectives + 1 all-to-all-v, one host wait that does not drain the GPU):
+      prefix sums -> all-gather totals -> plan (device + pinned host) -> expand ancestors -> gather kept children
+      [host reads the plan while those run] -> pack surplus -> all-to-all-v -> unpack.
     """
-    backend = backend or HipBackend()
+    backend = _backend(backend)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = rows.device
-    cum, bt_local = backend.weight_cumsum(logw, is_log, lse_global)      # bt_local = {0, local total}
-    if world == 1:
+    R = rows.shape[0]
+    cum, bt_local, rec = backend.weight_cumsum(logw, is_log, lse_global, pairs=pairs, K_total=N_total)
+    if world == 1 and not _forced():
         anc = backend.resample_systematic(cum, bt_local, u, N_total, 0, N_total)
-        return backend.gather_rows(rows, anc), dict(sent=0, ancestors=anc)
+        return backend.gather_rows(rows, anc), dict(sent=0, ancestors=anc, lse=rec)
     totals = torch.empty(world, dtype=torch.int64, device=dev)
     _all_gather(totals, bt_local[1:2].contiguous(), group)
-    tot_host = [int(t) for t in totals.cpu().tolist()]           # G integers: the ONE host sync of the step
-    total_all = sum(tot_host)
-    base = sum(tot_host[:rank])
-    bt = torch.tensor([base, total_all], dtype=torch.int64, device=dev)
-    # Every rank's run of output slots follows from the totals alone (same IEEE-double comb arithmetic as the
-    # kernels), so all send/receive counts are known on the host without another round trip.
-    bounds = [0]
-    for r in range(world):
-        bounds.append(slots_below(sum(tot_host[:r + 1]), u, total_all, N_total))
-    slot0, n_valid = bounds[rank], bounds[rank + 1] - bounds[rank]
-    anc = backend.resample_systematic(cum, bt, u, N_total, slot0, n_valid)
+    own_lo, own_n = shard(N_total, rank, world)
+    plan = backend.plan(totals, rank, u, N_total)
+    anc, new_rows = backend.shard_resample(cum, plan, u, N_total, rows, own_n)
+    p = plan.wait()                                   # the expansion and the local gather are already queued
+    if p.status:
+        raise ValueError("resample_exchange: all weights are zero")
+    b = list(p.bounds[: world + 1])
+    slot0, n_valid = int(p.slot0), int(p.n_valid)
 
     def overlap(a0, a1, b0, b1):
         return max(0, min(a1, b1) - max(a0, b0))
 
     owners = [shard(N_total, d, world) for d in range(world)]
-    send_counts = [overlap(slot0, slot0 + n_valid, lo, lo + k) for lo, k in owners]
-    my_lo, my_k = owners[rank]
-    recv_counts = [overlap(bounds[s_], bounds[s_ + 1], my_lo, my_lo + my_k) for s_ in range(world)]
-    # Children whose output slot this rank owns are gathered straight into place (SoA, one pass); only the
-    # surplus rows that belong to other ranks' slots travel, as small [n][R] blocks in one all-to-all-v.
-    R = rows.shape[0]
-    new_rows = torch.empty((R, my_k), dtype=rows.dtype, device=dev)
-    lo_l, hi_l = max(slot0, my_lo), min(slot0 + n_valid, my_lo + my_k)
-    if hi_l > lo_l:
-        backend.gather_rows_into(rows, anc[lo_l - slot0: hi_l - slot0], new_rows, lo_l - my_lo)
-    send_counts[rank] = 0
-    recv_counts[rank] = 0
-    parts, pos = [], 0
-    for d, (lo, k) in enumerate(owners):
-        a0, a1 = max(slot0, lo), min(slot0 + n_valid, lo + k)
-        if d != rank and a1 > a0:
-            parts.append(backend.gather_rows(rows, anc[a0 - slot0: a1 - slot0]).t())
-    send = torch.cat(parts, dim=0).contiguous() if parts else torch.empty((0, R), dtype=rows.dtype, device=dev)
+    send_counts = [0 if d == rank else overlap(slot0, slot0 + n_valid, lo, lo + k) for d, (lo, k) in enumerate(owners)]
+    recv_counts = [0 if s_ == rank else overlap(b[s_], b[s_ + 1], own_lo, own_lo + own_n) for s_ in range(world)]
+    # My slot run minus the window I keep is a prefix piece (slots owned by lower ranks) and a suffix piece
+    # (higher ranks); in slot order both are already sorted by destination, so the message buffer is two packs.
+    own_hi, run_hi = own_lo + own_n, slot0 + n_valid
+    n_pre = max(0, min(run_hi, own_lo) - slot0)
+    n_suf = max(0, run_hi - max(slot0, own_hi))
+    assert n_pre == sum(send_counts[:rank]) and n_suf == sum(send_counts[rank + 1:]), (n_pre, n_suf, send_counts)
+    send = backend.pack(rows, anc, n_valid, n_pre, n_suf)
     recv = torch.empty((sum(recv_counts), R), dtype=rows.dtype, device=dev)
     _all_to_all(recv, send, recv_counts, send_counts, group)
-    for s_ in range(world):
-        if recv_counts[s_]:
-            a0 = max(bounds[s_], my_lo) - my_lo
-            new_rows[:, a0: a0 + recv_counts[s_]] = recv[pos: pos + recv_counts[s_]].t()
-            pos += recv_counts[s_]
-    return new_rows, dict(sent=int(send.shape[0]), slot_off=my_lo, ancestors=anc)
-
+    # received blocks arrive in source-rank order = slot order: lower ranks fill the head of my slot range,
+    # higher ranks its tail
+    n_lo = max(0, min(own_hi, slot0) - own_lo)
+    n_hi = max(0, own_hi - max(own_lo, run_hi))
+    assert n_lo == sum(recv_counts[:rank]) and n_hi == sum(recv_counts[rank + 1:]), (n_lo, n_hi, recv_counts)
+    if n_lo + n_hi:
+        backend.unpack(recv, n_lo, n_hi, new_rows)
+    return new_rows, dict(sent=int(send.shape[0]), slot_off=own_lo, ancestors=anc, lse=rec, bounds=b)

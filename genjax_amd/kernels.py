@@ -6,11 +6,12 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 
 import torch
 
 from . import _abi as A
-from ._lib import check, load
+from ._lib import GjxError, check, load
 from .program import PackedProgram
 
 
@@ -99,7 +100,8 @@ def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_
     return out
 
 
-def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, partials=None, lse_out=None, K_total=None):
+def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, partials=None, lse_out=None, K_total=None,
+                  pairs=None):
     """-> (cum uint64[K] as int64 payload, base_total int64[2] = {0, total}).
     ``partials=(run_workspace, n)`` selects mode 2: the max comes from the per-block pairs a preceding
     run_program(want_lse=False) left in its workspace, and ``lse_out`` (f32[4]) receives the finished record."""
@@ -108,7 +110,9 @@ def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, pa
     bt = torch.empty(2, dtype=torch.int64, device=x.device) if out is None else out[1]
     if ws is None:
         ws = workspace(A.OP_RESAMPLE, K, x.device)
-    if partials is not None:
+    if pairs is not None:                                  # raw {max, sumexp} pairs, e.g. one per rank
+        mode, lp, npart = 2, _ptr(pairs), pairs.numel() // 2
+    elif partials is not None:
         run_ws, n = partials
         mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
     else:
@@ -187,6 +191,86 @@ def gather_rows(src: torch.Tensor, anc: torch.Tensor, dst: torch.Tensor | None =
     check(load().gjx_gather_rows(_ptr(src), src.stride(0), _ptr(anc), n, rows, _ptr(dst), dst.stride(0), _stream()),
           "gjx_gather_rows")
     return dst
+
+
+class ShardPlan:
+    """Device plan of one rank's part of a sharded resampling + its pinned host mirror (gjx_shard_plan)."""
+    _SEQ = A.GjxShardPlan.seq.offset // 8
+
+    def __init__(self, device):
+        n = C.sizeof(A.GjxShardPlan)
+        self.dev = torch.empty(n, dtype=torch.uint8, device=device)
+        self.host = torch.zeros(n, dtype=torch.uint8).pin_memory()
+        self._words = self.host.numpy().view("int64")
+        self._struct = A.GjxShardPlan.from_buffer(self.host.numpy())     # live view of the pinned bytes
+        self.seq = 0
+
+    def build(self, totals: torch.Tensor, rank: int, u: float, N_total: int) -> "ShardPlan":
+        self.seq += 1
+        check(load().gjx_shard_plan_build(_ptr(totals), totals.numel(), int(rank), float(u), int(N_total), self.seq,
+                                          _ptr(self.dev), C.c_void_p(self.host.data_ptr()), _stream()), "gjx_shard_plan_build")
+        return self
+
+    def wait(self, timeout_s: float = 60.0) -> A.GjxShardPlan:
+        """Spin until the plan kernel of the last build() has published its sequence number in the pinned mirror
+        (no stream or event synchronisation: kernels queued behind the plan keep running).  The returned struct
+        is a live view, valid until the next build()."""
+        w, k, s = self._words, self._SEQ, self.seq
+        if w[k] != s:
+            t0 = time.perf_counter()
+            while w[k] != s:
+                if time.perf_counter() - t0 > timeout_s:
+                    raise GjxError("gjx_shard_plan: the plan kernel did not complete within %.0f s" % timeout_s)
+        return self._struct
+
+
+def shard_resample(cum, plan: ShardPlan, u: float, N_total: int, src: torch.Tensor, own_n: int, anc=None, dst=None):
+    """gjx_shard_resample: this rank's ancestors (device-planned slot run) + in-place gather of the kept children.
+    -> (ancestors int32[N_total] scratch, dst f32[R][own_n])"""
+    R = src.shape[0]
+    if anc is None:
+        anc = torch.empty(int(N_total), dtype=torch.int32, device=src.device)
+    if dst is None:
+        dst = torch.empty((R, own_n), dtype=src.dtype, device=src.device)
+    check(load().gjx_shard_resample(_ptr(cum), cum.numel(), _ptr(plan.dev), float(u), int(N_total), _ptr(anc), anc.numel(),
+                                    _ptr(src), src.stride(0), R, _ptr(dst), dst.stride(0) if own_n else 0, int(own_n),
+                                    _stream()), "gjx_shard_resample")
+    return anc, dst
+
+
+def shard_pack(src: torch.Tensor, anc: torch.Tensor, n_valid: int, n_pre: int, n_suf: int) -> torch.Tensor:
+    """gjx_shard_pack: the surplus children of this rank's slot run as [n_pre + n_suf][R] messages (one launch)"""
+    R = src.shape[0]
+    msg = torch.empty((n_pre + n_suf, R), dtype=src.dtype, device=src.device)
+    check(load().gjx_shard_pack(_ptr(src), src.stride(0), R, _ptr(anc), int(n_valid), int(n_pre), int(n_suf), _ptr(msg),
+                                _stream()), "gjx_shard_pack")
+    return msg
+
+
+def shard_unpack(msg: torch.Tensor, n_lo: int, n_hi: int, dst: torch.Tensor) -> None:
+    """gjx_shard_unpack: received [n_lo + n_hi][R] messages into the head / tail columns of dst f32[R][own_n]"""
+    R, own_n = dst.shape
+    check(load().gjx_shard_unpack(_ptr(msg), int(n_lo), int(n_hi), R, _ptr(dst), dst.stride(0), own_n, _stream()),
+          "gjx_shard_unpack")
+
+
+def pack_rows(src: torch.Tensor, anc: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[j][r] = src[r][anc[j]] (gjx_gather_rows_strided)"""
+    R, n = src.shape[0], anc.numel()
+    if out is None:
+        out = torch.empty((n, R), dtype=src.dtype, device=src.device)
+    if n:
+        check(load().gjx_gather_rows_strided(_ptr(src), src.stride(0), 1, _ptr(anc), n, R, _ptr(out), 1, R, _stream()),
+              "gjx_gather_rows_strided")
+    return out
+
+
+def unpack_rows(msg: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[r][j] = msg[j][r] for a [n][R] block; dst is an SoA column window (gjx_gather_rows_strided)"""
+    n, R = msg.shape
+    if n:
+        check(load().gjx_gather_rows_strided(_ptr(msg), 1, R, None, n, R, _ptr(dst), dst.stride(0), 1, _stream()),
+              "gjx_gather_rows_strided")
 
 
 def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, logw=None, lse=None, offset=0,

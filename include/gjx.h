@@ -242,6 +242,46 @@ int gjx_resample_multinomial(const uint64_t* cum, int64_t K, const uint64_t* bas
 int gjx_gather_rows(const float* src, int64_t src_stride, const int32_t* anc, int64_t n_out,
                     int32_t rows, float* dst, int64_t dst_stride, void* stream);
 
+/* ---- sharded collections: one rank's part of a global systematic resampling -----------------
+ * The reference has no multi-device path; this is the build's own extension of
+ * smc.py:90-101 to a collection split over ranks in contiguous particle ranges.  Every rank all-gathers
+ * the per-rank fixed-point totals (gjx_weight_cumsum's base_total[1]) and builds the same plan. */
+#define GJX_MAX_RANKS 64
+typedef struct gjx_shard_plan {
+  uint64_t base, total;       /* weight mass on lower ranks; mass on all ranks                       */
+  int64_t slot0, n_valid;     /* this rank's particles produce the output slots [slot0, slot0+n_valid) */
+  int64_t own_lo, own_n;      /* this rank stores the output slots [own_lo, own_lo+own_n)             */
+  int64_t keep_lo, keep_hi;   /* produced AND stored here (no traffic)                                */
+  int64_t n_ranks, status;    /* status 1: all weights are zero                                       */
+  int64_t seq, reserved;      /* caller's sequence number, stored LAST (system-scope release)         */
+  int64_t bounds[GJX_MAX_RANKS + 1]; /* rank r produces [bounds[r], bounds[r+1])                      */
+} gjx_shard_plan;
+/* one tiny launch: totals_dev u64[n_ranks] -> plan_dev, and (optional) the same bytes into pinned host
+ * memory so the host can size the exchange without draining the stream: it polls plan_host_pinned->seq
+ * until it reads the seq of this call (written after all other words), while the kernels queued behind
+ * the plan keep running */
+int gjx_shard_plan_build(const uint64_t* totals_dev, int32_t n_ranks, int32_t rank, double u, int64_t N_total,
+                         int64_t seq, gjx_shard_plan* plan_dev, gjx_shard_plan* plan_host_pinned, void* stream);
+/* ancestors[j - slot0] = local index of slot j's ancestor for this rank's run (capacity anc_capacity >= n_valid;
+ * N_total always suffices), then the children that stay: dst[r][j - own_lo] = src[r][ancestor(j)],
+ * keep_lo <= j < keep_hi.  Slot ranges are read from plan_dev; own_n (host-known) sizes the launch. */
+int gjx_shard_resample(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
+                       int32_t* ancestors, int64_t anc_capacity, const float* src, int64_t src_stride, int32_t rows,
+                       float* dst, int64_t dst_stride, int64_t own_n, void* stream);
+/* surplus children as [n_pre + n_suf][rows] messages: message j < n_pre is the child of ancestors[j] (slots below
+ * own_lo, bound for lower ranks), the others of ancestors[n_valid - n_suf + (j - n_pre)] (higher ranks) */
+int gjx_shard_pack(const float* src, int64_t src_stride, int32_t rows, const int32_t* ancestors, int64_t n_valid,
+                   int64_t n_pre, int64_t n_suf, float* msg, void* stream);
+/* received [n_lo + n_hi][rows] messages into the head and the tail of this rank's slot range:
+ * dst[r][j] = msg[j][r] (j < n_lo), dst[r][own_n - n_hi + t] = msg[n_lo + t][r] */
+int gjx_shard_unpack(const float* msg, int64_t n_lo, int64_t n_hi, int32_t rows, float* dst, int64_t dst_stride,
+                     int64_t own_n, void* stream);
+/* dst[r*dst_row_stride + j*dst_col_stride] = src[r*src_row_stride + idx(j)*src_col_stride], idx = anc[j] or j
+ * when anc is NULL: packs children into [n][rows] messages and unpacks received ones */
+int gjx_gather_rows_strided(const float* src, int64_t src_row_stride, int64_t src_col_stride, const int32_t* anc,
+                            int64_t n, int32_t rows, float* dst, int64_t dst_row_stride, int64_t dst_col_stride,
+                            void* stream);
+
 /* ---- linear-Gaussian state-space bootstrap-filter step (BASELINE config 3/4) --------------
  * x_t ~ N(A x_{t-1}[anc], q), weight = log N(y_t; H x_t, r); fused ancestor gather + propagate
  * + reweight + LSE partials.  Semantics are those of Scan.generate (combinators/scan.py:237-294)

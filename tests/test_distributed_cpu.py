@@ -14,12 +14,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleBackend:
-    """Same interface as distributed.HipBackend, on CPU tensors, computed by the C oracle (test-only)."""
+    """Same interface as distributed.HipBackend, on CPU tensors, computed by the C oracle (test-only).
+    The plan comes from distributed.HostPlan (the host twin of the plan kernel)."""
 
-    def weight_cumsum(self, x, is_log, lse):
+    def weight_cumsum(self, x, is_log, lse=None, pairs=None, K_total=None):
         from oracle import cpu
+        rec = None
+        if pairs is not None:
+            rec = lse = self.lse_combine(pairs, K_total)
+            is_log = True
         cum, tot = cpu.weight_cumsum(x.numpy(), is_log, None if lse is None else lse.numpy())
-        return torch.from_numpy(cum.view(np.int64)), torch.tensor([0, tot], dtype=torch.int64)
+        return torch.from_numpy(cum.view(np.int64)), torch.tensor([0, tot], dtype=torch.int64), rec
+
+    def plan(self, totals, rank, u, N_total):
+        from genjax_amd.distributed import HostPlan
+        return HostPlan([int(t) for t in totals.tolist()], rank, u, N_total)
+
+    def shard_resample(self, cum, plan, u, N_total, rows, own_n):
+        from oracle import cpu
+        anc = torch.from_numpy(cpu.resample_systematic(cum.numpy().view(np.uint64), u, N_total, base=plan.base, total_all=plan.total,
+                                                       out_begin=plan.slot0, n_out=plan.n_valid))
+        new_rows = torch.full((rows.shape[0], own_n), float("nan"), dtype=rows.dtype)
+        if plan.keep_hi > plan.keep_lo:
+            a = anc[plan.keep_lo - plan.slot0: plan.keep_hi - plan.slot0]
+            new_rows[:, plan.keep_lo - plan.own_lo: plan.keep_hi - plan.own_lo] = self.gather_rows(rows, a)
+        return anc, new_rows
+
+    def pack(self, rows, anc, n_valid, n_pre, n_suf):
+        idx = torch.cat([anc[:n_pre], anc[n_valid - n_suf: n_valid]])
+        return self.gather_rows(rows, idx).t().contiguous()
+
+    def unpack(self, msg, n_lo, n_hi, dst):
+        dst[:, :n_lo] = msg[:n_lo].t()
+        if n_hi:
+            dst[:, dst.shape[1] - n_hi:] = msg[n_lo:].t()
 
     def resample_systematic(self, cum, base_total, u, N_total, out_begin, n_out):
         from oracle import cpu
@@ -30,14 +58,21 @@ class OracleBackend:
         from oracle import cpu
         return torch.from_numpy(cpu.gather_rows(src.numpy(), anc.numpy()))
 
-    def gather_rows_into(self, src, anc, dst, col0):
-        dst[:, col0: col0 + anc.numel()] = self.gather_rows(src, anc)
-
     def lse_combine(self, pairs, K_total):
         m = pairs[:, 0].max()
         s = (pairs[:, 1].double() * torch.exp((pairs[:, 0] - m).double())).sum()
         lse = m.double() + torch.log(s)
         return torch.tensor([m, s, lse, lse - np.log(K_total)], dtype=torch.float32)
+
+
+def _weights(rs, K, heavy):
+    """heavy: False = mild, True = wide spread, "first"/"last" = (nearly) all mass on the first / last few particles"""
+    logw = (rs.standard_normal(K) * (5.0 if heavy else 1.0)).astype(np.float32)
+    if heavy == "first":
+        logw[7:] -= 80.0
+    elif heavy == "last":
+        logw[:-5] -= 80.0
+    return logw
 
 
 def _worker(rank, world, port, K, R, heavy, out_q):
@@ -48,27 +83,32 @@ def _worker(rank, world, port, K, R, heavy, out_q):
     r, w = D.init_from_env("gloo")
     assert (r, w) == (rank, world)
     rs = np.random.default_rng(0)
-    logw = (rs.standard_normal(K) * (5.0 if heavy else 1.0)).astype(np.float32)
+    logw = _weights(rs, K, heavy)
     rows = rs.standard_normal((R, K)).astype(np.float32)
     off, k = D.shard(K, rank, world)
     be = OracleBackend()
     local = torch.from_numpy(cpu.logsumexp(logw[off:off + k], K))
     glob = D.global_lse(local, K, backend=be)
-    new_rows, info = D.resample_exchange(torch.from_numpy(rows[:, off:off + k].copy()), torch.from_numpy(logw[off:off + k].copy()),
-                                         glob, 0.37, K, backend=be)
+    if heavy:        # the gathered-pairs entry: the combine happens inside the prefix-sum step
+        new_rows, info = D.resample_exchange(torch.from_numpy(rows[:, off:off + k].copy()), torch.from_numpy(logw[off:off + k].copy()),
+                                             None, 0.37, K, backend=be, pairs=D.gather_lse_pairs(local))
+        np.testing.assert_array_equal(info["lse"].numpy(), glob.numpy())
+    else:
+        new_rows, info = D.resample_exchange(torch.from_numpy(rows[:, off:off + k].copy()), torch.from_numpy(logw[off:off + k].copy()),
+                                             glob, 0.37, K, backend=be)
     out_q.put((rank, glob.numpy(), new_rows.numpy(), info["sent"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("heavy", [False, True])
-@pytest.mark.parametrize("K", [1000, 4097])
-def test_sharded_resampling_equals_single_process(K, heavy):
+@pytest.mark.parametrize("heavy", [False, True, "first", "last"])
+@pytest.mark.parametrize("K,world", [(1000, 2), (4097, 2), (1001, 3)])
+def test_sharded_resampling_equals_single_process(K, world, heavy):
     from oracle import cpu
-    world, R = 2, 3
+    R = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + (1 if heavy else 0) + (2 if K > 2000 else 0)
+    port = 29600 + (os.getpid() % 300) + [False, True, 'first', 'last'].index(heavy) * 16 + (2 if K > 2000 else 0) + 4 * world
     procs = [ctx.Process(target=_worker, args=(r, world, port, K, R, heavy, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -78,7 +118,7 @@ def test_sharded_resampling_equals_single_process(K, heavy):
         assert p.exitcode == 0
     # single-process answer
     rs = np.random.default_rng(0)
-    logw = (rs.standard_normal(K) * (5.0 if heavy else 1.0)).astype(np.float32)
+    logw = _weights(rs, K, heavy)
     rows = rs.standard_normal((R, K)).astype(np.float32)
     lse = cpu.logsumexp(logw, K)
     cum, tot = cpu.weight_cumsum(logw, True, lse)
