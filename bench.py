@@ -140,6 +140,7 @@ def run_gmm(args, rank, world, dev):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
 
     sharded = world > 1 or os.environ.get("GJX_FORCE_DIST", "0") == "1"
+    resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if sharded else None
 
     def step(i, timed):
         key = (0, 1 + i)
@@ -158,12 +159,16 @@ def run_gmm(args, rank, world, dev):
             return lse_rec
         # sharded: 8-byte all-gather of per-rank {max, sumexp} (reduced in the prefix-sum prologue), 8-byte
         # all-gather of weight totals, device-side plan, local gather + all-to-all-v of the surplus children
-        _, info = DD.resample_exchange(out["choices"], out["logw"], None, u, K_total, pairs=DD.gather_lse_pairs(out["lse"]))
-        return info["lse"]
+        _, lse_g = resampler.step(out["choices"], out["logw"], out["lse"], u)
+        return lse_g
 
-    if sharded:
-        for i in range(30):     # RCCL sets up channels lazily per collective: keep that out of W and the timed region
-            step(i, False)
+    # One-off costs that belong to neither W nor the timed region: RCCL sets up channels lazily per collective, and
+    # the HIP runtime grows its signal / kernel-argument pools the first time the launch queue gets deep — a single
+    # 35-45 ms host stall inside one launch call (scratch/hiccup.py), 2-3x the whole default timed region.  A deep
+    # un-synchronised burst here triggers it before the clock starts.
+    for i in range(300):
+        step(i, False)
+    torch.cuda.synchronize()
     dt, lse = timed_loop(args, world, dev, step)
     if rank != 0:
         return None
@@ -181,7 +186,8 @@ def run_gmm(args, rank, world, dev):
         higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload="gmm_c8_d16 ImportanceK: propagate+reweight+LSE, systematic resample, gather "
                              "(BASELINE.json configs[1])",
-                    k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}"),
+                    k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}",
+                    exchange=(resampler.transport if resampler else "none")),
         roofline=dict(bound="hbm", kernel="gjx::k_run_gmm<FLAT,16,4,256>", achieved=achieved, peak=HBM_PEAK_GBS,
                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel_us=kern_ms * 1e3, algorithmic_bytes_per_launch=ALGO_BYTES_PER_PARTICLE * K,

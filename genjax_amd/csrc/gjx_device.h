@@ -447,4 +447,25 @@ GJX_DEV void lse_publish_and_finish(float bm, float bsum, unsigned long long* pa
   }
 }
 
+// ---- systematic-resampling comb on the fixed-point weight line (shared by gjx_resample.hip / gjx_shard.hip) ----
+// comb threshold of output slot j (identical double arithmetic in the oracle)
+GJX_DEV uint64_t comb_threshold(int64_t j, double u, double step, uint64_t total) {
+  uint64_t T = (uint64_t)(((double)j + u) * step);
+  if (total > 0 && T > total - 1) T = total - 1;
+  return T;
+}
+
+// number of output slots whose comb threshold lies strictly below c (0 <= c <= total):
+// J(c) = #{j in [0, N) : T_j < c}.  T_j is non-decreasing in j, so J is found from the real-valued guess
+// ceil(c/step - u) and corrected with the EXACT integer predicate (the same T_j the per-slot search uses).
+GJX_DEV int64_t slots_below(uint64_t c, double u, double step, double inv_step, uint64_t total, int64_t N) {
+  if (c == 0) return 0;
+  if (c >= total) return N;
+  double gd = ceil((double)c * inv_step - u);  // any guess works: the loops below make the result exact
+  int64_t g = gd < 0.0 ? 0 : (gd > (double)N ? N : (int64_t)gd);
+  while (g > 0 && comb_threshold(g - 1, u, step, total) >= c) --g;
+  while (g < N && comb_threshold(g, u, step, total) < c) ++g;
+  return g;
+}
+
 }  // namespace gjx

@@ -17,3 +17,9 @@ int gjx_fail_hip(hipError_t e, const char* where);   // same for a HIP error
 
 // {max,sumexp} block partials -> out[4] = {max, sumexp, lse, lse - log(K_total)}  (gjx_run.hip)
 int gjx_launch_lse_finish(const void* partials_float2, int n, int64_t K_total, float* out, hipStream_t st);
+
+namespace gjx {
+// systematic ancestor expansion with the slot run {slot0, n_valid} read from a device plan (gjx_resample.hip)
+int launch_expand_planned(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
+                          int32_t* ancestors, int64_t anc_capacity, hipStream_t st);
+}  // namespace gjx

@@ -206,26 +206,6 @@ GJX_DEV int64_t upper_search_in(const uint64_t* __restrict__ cum, int64_t lo, in
   return lo;
 }
 
-// comb threshold of output slot j (identical double arithmetic in the oracle)
-GJX_DEV uint64_t comb_threshold(int64_t j, double u, double step, uint64_t total) {
-  uint64_t T = (uint64_t)(((double)j + u) * step);
-  if (total > 0 && T > total - 1) T = total - 1;
-  return T;
-}
-
-// number of output slots whose comb threshold lies strictly below c (0 <= c <= total):
-// J(c) = #{j in [0, N) : T_j < c}.  T_j is non-decreasing in j, so J is found from the real-valued guess
-// ceil(c/step - u) and corrected with the EXACT integer predicate (the same T_j the per-slot search uses).
-GJX_DEV int64_t slots_below(uint64_t c, double u, double step, double inv_step, uint64_t total, int64_t N) {
-  if (c == 0) return 0;
-  if (c >= total) return N;
-  double gd = ceil((double)c * inv_step - u);  // any guess works: the loops below make the result exact
-  int64_t g = gd < 0.0 ? 0 : (gd > (double)N ? N : (int64_t)gd);
-  while (g > 0 && comb_threshold(g - 1, u, step, total) >= c) --g;
-  while (g < N && comb_threshold(g, u, step, total) < c) ++g;
-  return g;
-}
-
 // Systematic resampling, particle-oriented ("expand"): particle i owns the output slots
 // [J(base + cum[i-1]), J(base + cum[i])) — a few consecutive slots, usually 0..3 — so one lane per particle
 // reads two prefix sums (coalesced), computes its slot range in O(1), and writes its index (and, with
@@ -448,103 +428,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Sharded resampling plan.  Every rank holds the G per-rank weight totals (one 8-byte all-gather) and derives
-// the same slot bounds B_r = J(total_0 + ... + total_{r-1}): rank r's particles produce exactly the output
-// slots [B_r, B_{r+1}).  One wave computes the G+1 bounds; the plan goes to device memory (read by the
-// expansion / gather kernels queued behind it) and to a pinned host copy (read by the host only to size the
-// all-to-all, while those kernels run).
-__global__ __launch_bounds__(64) void k_shard_plan(const uint64_t* __restrict__ totals, int G, int rank, double u,
-                                                  int64_t N_total, int64_t seq, gjx_shard_plan* plan_dev,
-                                                  gjx_shard_plan* plan_host) {
-  __shared__ gjx_shard_plan p;
-  const int t = threadIdx.x;
-  uint64_t total = 0, below = 0;
-  for (int r = 0; r < G; ++r) {
-    if (r < t) below += totals[r];
-    total += totals[r];
-  }
-  if (t <= G) {
-    const double step = (double)total / (double)N_total;
-    const double inv_step = (double)N_total / (double)total;
-    p.bounds[t] = total > 0 ? slots_below(below, u, step, inv_step, total, N_total) : 0;
-    if (t == rank) p.base = below;
-  }
-  __syncthreads();
-  if (t == 0) {
-    p.total = total;
-    p.slot0 = p.bounds[rank];
-    p.n_valid = p.bounds[rank + 1] - p.bounds[rank];
-    const int64_t q = N_total / G, rem = N_total % G;
-    p.own_lo = rank * q + (rank < rem ? rank : rem);
-    p.own_n = q + (rank < rem ? 1 : 0);
-    const int64_t lo = p.slot0 > p.own_lo ? p.slot0 : p.own_lo;
-    int64_t hi = p.slot0 + p.n_valid < p.own_lo + p.own_n ? p.slot0 + p.n_valid : p.own_lo + p.own_n;
-    p.keep_lo = lo;
-    p.keep_hi = hi > lo ? hi : lo;
-    p.n_ranks = G;
-    p.status = total > 0 ? 0 : 1;
-    p.seq = seq;
-    p.reserved = 0;
-  }
-  __syncthreads();
-  constexpr int kWords = sizeof(gjx_shard_plan) / 8;
-  constexpr int kSeqWord = offsetof(gjx_shard_plan, seq) / 8;
-  const uint64_t* sp = reinterpret_cast<const uint64_t*>(&p);
-  for (int w = t; w < kWords; w += 64) {
-    reinterpret_cast<uint64_t*>(plan_dev)[w] = sp[w];
-    if (plan_host && w != kSeqWord) reinterpret_cast<uint64_t*>(plan_host)[w] = sp[w];
-  }
-  if (plan_host) {         // one wave: every lane's stores are ordered before lane 0's release of the sequence word
-    __threadfence_system();
-    if (t == 0) __hip_atomic_store(&plan_host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-// pack: msg[j][r] = src[r][anc[idx(j)]]; unpack: dst[r][col(j)] = msg[j][r]  (lanes along r: messages are row-major)
-__global__ __launch_bounds__(256) void k_shard_pack(const float* __restrict__ src, int64_t src_stride, int rows,
-                                                   const int32_t* __restrict__ anc, int64_t n_valid, int64_t n_pre,
-                                                   int64_t n_suf, float* __restrict__ msg) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (n_pre + n_suf) * rows) return;
-  const int64_t j = e / rows, r = e % rows;
-  const int32_t a = anc[j < n_pre ? j : n_valid - n_suf + (j - n_pre)];
-  msg[e] = src[r * src_stride + a];
-}
-
-__global__ __launch_bounds__(256) void k_shard_unpack(const float* __restrict__ msg, int64_t n_lo, int64_t n_hi, int rows,
-                                                     float* __restrict__ dst, int64_t dst_stride, int64_t own_n) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (n_lo + n_hi) * rows) return;
-  const int64_t r = e / (n_lo + n_hi), j = e % (n_lo + n_hi);   // lanes along j: coalesced stores into the SoA rows
-  const int64_t col = j < n_lo ? j : own_n - n_hi + (j - n_lo);
-  dst[r * dst_stride + col] = msg[j * rows + r];
-}
-
-// children that stay on this rank: dst[r][j - own_lo] = src[r][anc[j - slot0]] for the slots j this rank both
-// produces and owns, keep_lo <= j < keep_hi (all four read from the device plan)
-__global__ __launch_bounds__(256) void k_gather_kept(const gjx_shard_plan* __restrict__ plan, const float* __restrict__ src,
-                                                    int64_t src_stride, const int32_t* __restrict__ anc, int rows,
-                                                    float* __restrict__ dst, int64_t dst_stride) {
-  const int64_t j = plan->keep_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= plan->keep_hi) return;
-  const int32_t a = anc[j - plan->slot0];
-  const int64_t o = j - plan->own_lo;
-  for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + o] = src[(int64_t)r * src_stride + a];
-}
-
-// general strided form: dst[r*drs + j*dcs] = src[r*srs + idx(j)*scs]; packs children into [n][rows] messages
-// and unpacks received ones.  Lanes run along r when the destination is row-contiguous.
-__global__ __launch_bounds__(256) void k_gather_rows_strided(const float* __restrict__ src, int64_t srs, int64_t scs,
-                                                            const int32_t* __restrict__ anc, int64_t n, int rows,
-                                                            float* __restrict__ dst, int64_t drs, int64_t dcs) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n * rows) return;
-  int64_t j, r;
-  if (drs == 1) { j = e / rows; r = e % rows; } else { r = e / n; j = e % n; }
-  const int64_t a = anc ? anc[j] : j;
-  if (a < 0) return;
-  dst[r * drs + j * dcs] = src[r * srs + a * scs];
+// planned expansion for a sharded collection (gjx_shard.hip): slot run read from the device plan
+int launch_expand_planned(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
+                          int32_t* ancestors, int64_t anc_capacity, hipStream_t st) {
+  const uint64_t* bt = reinterpret_cast<const uint64_t*>(plan_dev);                       // {base, total}
+  const int64_t* range = reinterpret_cast<const int64_t*>(plan_dev) + 2;                  // {slot0, n_valid}
+  hipLaunchKernelGGL(k_systematic_expand<false>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cum, K, bt, u, N_total,
+                     (int64_t)0, anc_capacity, ancestors, (const float*)nullptr, (int64_t)0, 0, (float*)nullptr, (int64_t)0,
+                     range);
+  GJX_CHECK_LAUNCH("gjx_shard_resample(expand)");
+  return GJX_OK;
 }
 
 }  // namespace gjx
@@ -665,74 +558,3 @@ extern "C" int gjx_gather_rows(const float* src, int64_t src_stride, const int32
   return GJX_OK;
 }
 
-extern "C" int gjx_shard_plan_build(const uint64_t* totals_dev, int32_t n_ranks, int32_t rank, double u, int64_t N_total,
-                                    int64_t seq, gjx_shard_plan* plan_dev, gjx_shard_plan* plan_host_pinned, void* stream) {
-  if (!totals_dev || !plan_dev || n_ranks < 1 || n_ranks > GJX_MAX_RANKS || rank < 0 || rank >= n_ranks || N_total <= 0 ||
-      !(u >= 0.0 && u < 1.0))
-    return gjx_fail(GJX_EINVAL, "gjx_shard_plan_build: bad argument");
-  gjx_shard_plan* mapped = nullptr;
-  if (plan_host_pinned && hipHostGetDevicePointer((void**)&mapped, plan_host_pinned, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return gjx_fail(GJX_EINVAL, "gjx_shard_plan_build: plan_host_pinned is not pinned (device-mapped) host memory");
-  }
-  hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, totals_dev, (int)n_ranks, (int)rank, u, N_total,
-                     seq, plan_dev, mapped);
-  GJX_CHECK_LAUNCH("gjx_shard_plan_build");
-  return GJX_OK;
-}
-
-extern "C" int gjx_shard_resample(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
-                                  int32_t* ancestors, int64_t anc_capacity, const float* src, int64_t src_stride,
-                                  int32_t rows, float* dst, int64_t dst_stride, int64_t own_n, void* stream) {
-  if (!cum || !plan_dev || !ancestors || K <= 0 || N_total <= 0 || anc_capacity < 0 || rows < 0 || own_n < 0 ||
-      (rows > 0 && own_n > 0 && (!src || !dst)) || !(u >= 0.0 && u < 1.0))
-    return gjx_fail(GJX_EINVAL, "gjx_shard_resample: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  const uint64_t* bt = reinterpret_cast<const uint64_t*>(plan_dev);                       // {base, total}
-  const int64_t* range = reinterpret_cast<const int64_t*>(plan_dev) + 2;                  // {slot0, n_valid}
-  hipLaunchKernelGGL(k_systematic_expand<false>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cum, K, bt, u, N_total,
-                     (int64_t)0, anc_capacity, ancestors, (const float*)nullptr, (int64_t)0, 0, (float*)nullptr, (int64_t)0,
-                     range);
-  GJX_CHECK_LAUNCH("gjx_shard_resample(expand)");
-  if (rows > 0 && own_n > 0) {
-    hipLaunchKernelGGL(k_gather_kept, dim3((unsigned)((own_n + 255) / 256)), dim3(256), 0, st, plan_dev, src, src_stride,
-                       (const int32_t*)ancestors, (int)rows, dst, dst_stride);
-    GJX_CHECK_LAUNCH("gjx_shard_resample(gather)");
-  }
-  return GJX_OK;
-}
-
-extern "C" int gjx_gather_rows_strided(const float* src, int64_t src_row_stride, int64_t src_col_stride, const int32_t* anc,
-                                       int64_t n, int32_t rows, float* dst, int64_t dst_row_stride, int64_t dst_col_stride,
-                                       void* stream) {
-  if (!src || !dst || n < 0 || rows < 0) return gjx_fail(GJX_EINVAL, "gjx_gather_rows_strided: bad argument");
-  if (n == 0 || rows == 0) return GJX_OK;
-  hipLaunchKernelGGL(k_gather_rows_strided, dim3((unsigned)((n * rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     src_row_stride, src_col_stride, anc, n, (int)rows, dst, dst_row_stride, dst_col_stride);
-  GJX_CHECK_LAUNCH("gjx_gather_rows_strided");
-  return GJX_OK;
-}
-
-extern "C" int gjx_shard_pack(const float* src, int64_t src_stride, int32_t rows, const int32_t* ancestors, int64_t n_valid,
-                              int64_t n_pre, int64_t n_suf, float* msg, void* stream) {
-  if (n_pre < 0 || n_suf < 0 || rows < 0 || n_pre + n_suf > n_valid) return gjx_fail(GJX_EINVAL, "gjx_shard_pack: bad argument");
-  const int64_t n = (n_pre + n_suf) * rows;
-  if (n == 0) return GJX_OK;
-  if (!src || !ancestors || !msg) return gjx_fail(GJX_EINVAL, "gjx_shard_pack: bad argument");
-  hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_stride, (int)rows,
-                     ancestors, n_valid, n_pre, n_suf, msg);
-  GJX_CHECK_LAUNCH("gjx_shard_pack");
-  return GJX_OK;
-}
-
-extern "C" int gjx_shard_unpack(const float* msg, int64_t n_lo, int64_t n_hi, int32_t rows, float* dst, int64_t dst_stride,
-                                int64_t own_n, void* stream) {
-  if (n_lo < 0 || n_hi < 0 || rows < 0 || n_lo + n_hi > own_n) return gjx_fail(GJX_EINVAL, "gjx_shard_unpack: bad argument");
-  const int64_t n = (n_lo + n_hi) * rows;
-  if (n == 0) return GJX_OK;
-  if (!msg || !dst) return gjx_fail(GJX_EINVAL, "gjx_shard_unpack: bad argument");
-  hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, msg, n_lo, n_hi, (int)rows,
-                     dst, dst_stride, own_n);
-  GJX_CHECK_LAUNCH("gjx_shard_unpack");
-  return GJX_OK;
-}

@@ -261,3 +261,90 @@ def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global, u: flo
     if n_lo + n_hi:
         backend.unpack(recv, n_lo, n_hi, new_rows)
     return new_rows, dict(sent=int(send.shape[0]), slot_off=own_lo, ancestors=anc, lse=rec, bounds=b)
+
+
+class ShardedResampler:
+    """Systematic resampling of a collection sharded over the ranks of a group, for a fixed shape
+    (K_local particles x ``rows`` SoA rows per rank, N_total output slots).
+
+    transport "rccl": the whole exchange is one host call (gjx_shard_resample_step: RCCL all-gathers and grouped
+    send/recv issued from C on the caller's stream, local gather overlapped on a second stream).
+    transport "torch": the same kernels driven from Python with torch.distributed collectives
+    (resample_exchange) — the only choice for gloo dry runs and CPU tests.
+    "auto" (default, or GJX_SHARD_TRANSPORT) takes "rccl" when the group's backend is nccl, after a one-off
+    self-check that both transports return identical bits on a synthetic uneven collection; otherwise "torch".
+    """
+
+    def __init__(self, K_local: int, rows: int, N_total: int, device, transport: str | None = None, backend=None,
+                 group=None):
+        self.K, self.rows, self.N_total, self.group, self.backend = int(K_local), int(rows), int(N_total), group, backend
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        transport = transport or os.environ.get("GJX_SHARD_TRANSPORT", "auto")
+        if transport not in ("auto", "rccl", "torch"):
+            raise ValueError(f"unknown transport {transport!r}")
+        self.ctx = None
+        nccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and self.device.type == "cuda"
+        if transport == "rccl" and not nccl:
+            raise ValueError('transport "rccl" needs an initialised nccl (RCCL) process group')
+        if transport != "torch" and nccl:
+            self._open_rccl(strict=(transport == "rccl"))
+        self.transport = "rccl" if self.ctx is not None else "torch"
+
+    def _open_rccl(self, strict: bool) -> None:
+        from . import kernels
+        from ._lib import GjxError
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            uid.copy_(torch.tensor(list(kernels.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0, group=self.group)
+        err = None
+        try:
+            ctx = kernels.ShardContext(bytes(uid.cpu().tolist()), self.world, self.rank, self.K, self.rows, self.N_total)
+        except GjxError as e:        # symmetric failures only (missing library / symbols); comm init itself is collective
+            ctx, err = None, e
+        ok = torch.tensor([1 if ctx is not None else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 1:
+            self.ctx = ctx
+            ok = torch.tensor([1 if self._self_check() else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 1:
+                return
+            err = "the RCCL transport and the torch.distributed transport disagree on the self-check collection"
+        if ctx is not None:
+            ctx.close()
+        self.ctx = None
+        if strict:
+            raise RuntimeError(f"ShardedResampler: RCCL transport unavailable: {err}")
+        import warnings
+        warnings.warn(f"ShardedResampler: falling back to the torch.distributed transport ({err})")
+
+    def _self_check(self) -> bool:
+        """Both transports on a deterministic collection whose weights lean towards the high ranks (so children
+        cross rank boundaries in both directions of the slot order)."""
+        off, k = shard(self.K * self.world, self.rank, self.world)
+        i = torch.arange(off, off + self.K, device=self.device, dtype=torch.float32)
+        logw = 2.0 * torch.sin(i * 0.37) + 3.0 * (i / float(self.K * self.world)) ** 2 - (3.0 if self.rank % 2 else 0.0)
+        rows = (i[None, :] + torch.arange(self.rows, device=self.device, dtype=torch.float32)[:, None] * 0.25).contiguous()
+        from . import kernels
+        local = kernels.logsumexp(logw, self.K * self.world)
+        a, rec_a = self.ctx.step(rows, logw, local, 0.4321)
+        b, info = resample_exchange(rows, logw, None, 0.4321, self.N_total, self.backend, self.group,
+                                    pairs=gather_lse_pairs(local, self.group))
+        torch.cuda.synchronize()
+        return bool(torch.equal(a, b)) and bool(torch.equal(rec_a, info["lse"]))
+
+    def step(self, rows: torch.Tensor, logw: torch.Tensor, local_lse: torch.Tensor, u: float):
+        """-> (new_rows f32[rows][own_n], global LSE record f32[4])"""
+        if self.ctx is not None:
+            return self.ctx.step(rows, logw, local_lse, u)
+        new_rows, info = resample_exchange(rows, logw, None, u, self.N_total, self.backend, self.group,
+                                           pairs=gather_lse_pairs(local_lse, self.group))
+        return new_rows, info["lse"]
+
+    def close(self) -> None:
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None

@@ -238,6 +238,60 @@ def shard_resample(cum, plan: ShardPlan, u: float, N_total: int, src: torch.Tens
     return anc, dst
 
 
+def rccl_library_path() -> str:
+    """The RCCL build this process already uses (torch's), so there is a single RCCL instance per process."""
+    import os
+    return os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+
+
+def rccl_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    check(load().gjx_rccl_unique_id(rccl_library_path().encode(), C.cast(buf, C.c_void_p)), "gjx_rccl_unique_id")
+    return bytes(buf)
+
+
+class ShardContext:
+    """gjx_shard_ctx: RCCL communicator + scratch for the one-call sharded resampling of a fixed shape."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, K_local: int, rows: int, N_total: int):
+        self._h = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(load().gjx_shard_ctx_create(rccl_library_path().encode(), C.cast(idb, C.c_void_p), world, rank, int(K_local),
+                                          int(rows), int(N_total), C.byref(self._h)), "gjx_shard_ctx_create")
+        self.world, self.rank, self.K, self.rows, self.N_total = world, rank, int(K_local), int(rows), int(N_total)
+        q, rem = divmod(self.N_total, world)
+        self.own_n = q + (1 if rank < rem else 0)
+        self._info = (C.c_int64 * 4)()
+
+    def step(self, rows: torch.Tensor, logw: torch.Tensor, local_lse: torch.Tensor, u: float, out=None, lse_out=None):
+        """-> (new_rows f32[R][own_n], global LSE record f32[4]); info in .last_info after the call"""
+        assert rows.shape == (self.rows, self.K) and logw.numel() == self.K and rows.stride(1) == 1
+        if out is None:
+            out = torch.empty((self.rows, self.own_n), dtype=rows.dtype, device=rows.device)
+        if lse_out is None:
+            lse_out = torch.empty(4, dtype=torch.float32, device=rows.device)
+        check(load().gjx_shard_resample_step(self._h, _ptr(logw), _ptr(local_lse), _ptr(rows), rows.stride(0), _ptr(out),
+                                             out.stride(0), float(u), _ptr(lse_out), C.cast(self._info, C.c_void_p), _stream()),
+              "gjx_shard_resample_step")
+        return out, lse_out
+
+    @property
+    def last_info(self) -> dict:
+        i = self._info
+        return dict(sent=int(i[0]), received=int(i[1]), slot0=int(i[2]), n_valid=int(i[3]))
+
+    def close(self):
+        if self._h:
+            load().gjx_shard_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_pack(src: torch.Tensor, anc: torch.Tensor, n_valid: int, n_pre: int, n_suf: int) -> torch.Tensor:
     """gjx_shard_pack: the surplus children of this rank's slot run as [n_pre + n_suf][R] messages (one launch)"""
     R = src.shape[0]

@@ -276,6 +276,24 @@ int gjx_shard_pack(const float* src, int64_t src_stride, int32_t rows, const int
  * dst[r][j] = msg[j][r] (j < n_lo), dst[r][own_n - n_hi + t] = msg[n_lo + t][r] */
 int gjx_shard_unpack(const float* msg, int64_t n_lo, int64_t n_hi, int32_t rows, float* dst, int64_t dst_stride,
                      int64_t own_n, void* stream);
+/* The same exchange as ONE host call over RCCL (xGMI): all-gather of the per-rank {max, sumexp} (local_lse[0..1]),
+ * fixed-point prefix sums, all-gather of the totals, plan, ancestors, children that stay gathered in place,
+ * the surplus as grouped ncclSend/ncclRecv, unpack — everything on `stream`.  The context owns the
+ * communicator and all scratch; RCCL is dlopen'ed from rccl_library_path (pass the library the process already
+ * uses, e.g. torch/lib/librccl.so) and rank 0's gjx_rccl_unique_id bytes must be handed to every rank.
+ *   rows_in  f32[rows][K_local] (stride in_stride), rows_out f32[rows][own_n] (must not alias rows_in), where
+ *   own_n = this rank's share of N_total output slots (N_total/n_ranks, remainder to the low ranks);
+ *   lse_out device f32[4] = global {max, sumexp, lse, lse - log N_total};
+ *   info_host (optional) int64[4] = {children sent, received, first slot produced, slots produced}.
+ * Blocks the host only until the plan kernel has run (the G+1 slot bounds size the messages). */
+typedef struct gjx_shard_ctx gjx_shard_ctx;
+int gjx_rccl_unique_id(const char* rccl_library_path, uint8_t* out128);
+int gjx_shard_ctx_create(const char* rccl_library_path, const uint8_t* unique_id128, int32_t n_ranks, int32_t rank,
+                         int64_t K_local, int32_t rows, int64_t N_total, gjx_shard_ctx** out);
+int gjx_shard_ctx_destroy(gjx_shard_ctx* ctx);
+int gjx_shard_resample_step(gjx_shard_ctx* ctx, const float* logw, const float* local_lse, const float* rows_in,
+                            int64_t in_stride, float* rows_out, int64_t out_stride, double u, float* lse_out,
+                            int64_t* info_host, void* stream);
 /* dst[r*dst_row_stride + j*dst_col_stride] = src[r*src_row_stride + idx(j)*src_col_stride], idx = anc[j] or j
  * when anc is NULL: packs children into [n][rows] messages and unpacks received ones */
 int gjx_gather_rows_strided(const float* src, int64_t src_row_stride, int64_t src_col_stride, const int32_t* anc,

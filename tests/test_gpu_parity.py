@@ -619,3 +619,43 @@ def test_sharded_exchange_two_processes_one_gpu(oracle, spread):
         np.testing.assert_allclose(r[2][2:], lse[2:], rtol=2e-6)
     if spread == "wide":
         assert sum(r[3] for r in res) > 0
+
+
+def _rccl_one_rank_worker(port, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", GJX_FORCE_DIST="1")
+    from genjax_amd import distributed as D
+    from genjax_amd import kernels
+    D.init_from_env("nccl")
+    K, R = 70_001, 5
+    rs = np.random.default_rng(3)
+    lw = torch.as_tensor((rs.standard_normal(K) * 2).astype(np.float32)).cuda()
+    rows = torch.as_tensor(rs.standard_normal((R, K)).astype(np.float32)).cuda()
+    local = kernels.logsumexp(lw, K)
+    res = D.ShardedResampler(K, R, K, "cuda", transport="rccl")
+    got, rec = res.step(rows, lw, local, 0.77)
+    anc = kernels.resample_indices(lw, 0.77, K, lse=local)
+    want = kernels.gather_rows(rows, anc)
+    torch.cuda.synchronize()
+    q.put((res.transport, bool(torch.equal(got, want)), rec.cpu().numpy(), local.cpu().numpy(), res.ctx.last_info))
+    res.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_transport_single_rank():
+    """The one-call RCCL exchange (gjx_shard_resample_step) with a 1-rank communicator: RCCL resolves and
+    initialises, the all-gathers run, and the result equals the single-GPU path bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(29950 + os.getpid() % 40, q))
+    p.start()
+    transport, same, rec, local, info = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert transport == "rccl" and same
+    np.testing.assert_allclose(rec, local, rtol=1e-6)
+    assert info["sent"] == 0 and info["n_valid"] == 70_001
