@@ -241,7 +241,7 @@ def run_ssm(args, rank, world, dev):
         vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[2]); "
                              "one bench step = one T=256 filter run", k_particles=K, T=T, rng_stream="flat"),
-        roofline=dict(bound="hbm", kernel="filter step = k_wsum_blocks + k_wscan_write + k_systematic_expand + k_ssm_step",
+        roofline=dict(bound="hbm", kernel="filter step = k_resample_fused + k_ssm_step",
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
                       algorithmic_bytes_per_launch=algo,
