@@ -219,36 +219,38 @@ def run_ssm(args, rank, world, dev):
     """config 3: linear-Gaussian SSM d=8, T=256, bootstrap filter K=2^18, systematic resampling every step."""
     from genjax_amd import core, workloads
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
-    if world != 1:
-        raise SystemExit("--workload ssm is the single-GPU configuration (config 3)")
     s = workloads.ssm_problem()
-    K, T = 1 << 18, 256
+    K_local, T = 1 << 18, 256                # config 3; with N ranks the collection is N x 2^18 (config 4 shape, weak scaling)
+    K = K_local * world
     bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
     ys = torch.as_tensor(s["y"], device=dev)
     last = {}
 
     def step(i, timed):                      # one "step" here = one whole T-step filter run (T*K particle-steps)
-        last["out"] = bf.run(core.key(1 + i), ys)
+        last["out"] = bf.run(core.key(1 + i), ys, device=dev, rank=rank, world=world)
         return last["out"]["log_ml"]
 
     dt, lml = timed_loop(args, world, dev, step)
+    if rank != 0:
+        return None
     exact = golden("ssm_dx8_T256_seed0")
     per_step_us = dt / args.steps / T * 1e6
-    algo = (8 * 8 + 24) * K                  # SURVEY §8(d): 8*d_x + 16..24 B per particle-step
+    algo = (8 * 8 + 24) * K_local            # SURVEY §8(d): 8*d_x + 16..24 B per particle-step
     res = dict(
-        metric="particle_steps_per_sec", value=K * T * args.steps / dt, unit="particle-steps/s", n_gpus=1,
+        metric="particle_steps_per_sec", value=K * T * args.steps / dt, unit="particle-steps/s", n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
         vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[2]); "
-                             "one bench step = one T=256 filter run", k_particles=K, T=T, rng_stream="flat"),
+                             "one bench step = one T=256 filter run", k_particles_per_gpu=K_local, k_particles_total=K, T=T,
+                    rng_stream="flat", sharding=f"particles x{world}"),
         roofline=dict(bound="hbm", kernel="filter step = k_resample_fused + k_ssm_step",
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
                       algorithmic_bytes_per_launch=algo,
-                      note="8 MB working set is cache resident and each of the 4 launches per step is latency-bound at K=2^18"),
+                      note="8 MB working set is cache resident and both launches of a step are latency-bound at K=2^18"),
         log_ml=float(lml), log_ml_exact=exact, log_ml_rel_err=abs(float(lml) - exact) / abs(exact),
     )
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_ssm(s, K, T)
     return res
 

@@ -436,3 +436,15 @@ extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, cons
   }
   return GJX_OK;
 }
+
+extern "C" int gjx_shard_ctx_shape(const gjx_shard_ctx* c, int64_t* out5) {
+  if (!c || !out5) return gjx_fail(GJX_EINVAL, "gjx_shard_ctx_shape: bad argument");
+  out5[0] = c->K; out5[1] = c->rows; out5[2] = c->N_total; out5[3] = c->world; out5[4] = c->rank;
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_global_lse(gjx_shard_ctx* c, const float* local_lse, float* lse_out, void* stream) {
+  if (!c || !local_lse || !lse_out) return gjx_fail(GJX_EINVAL, "gjx_shard_global_lse: bad argument");
+  GJX_NCCL(c, c->api.AllGather(local_lse, c->pairs, 2, ncclFloat, c->comm, (hipStream_t)stream), "all-gather lse pairs");
+  return gjx_lse_combine(c->pairs, c->world, c->N_total, lse_out, stream);
+}

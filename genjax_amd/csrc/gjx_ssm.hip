@@ -209,3 +209,44 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
   }
   return GJX_OK;
 }
+
+extern "C" int gjx_ssm_filter_sharded(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T,
+                                      gjx_shard_ctx* ctx, int64_t particle_offset, const float* ys_dev, float* x_a, float* x_b,
+                                      float* logw, float* lse_steps, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !ctx || !ys_dev || !x_a || !x_b || !logw || !lse_steps || T <= 0)
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_sharded: bad argument");
+  int64_t shape[5];
+  int rc = gjx_shard_ctx_shape(ctx, shape);
+  if (rc) return rc;
+  const int64_t K = shape[0], N_total = shape[2];
+  if (shape[1] != m->dx || N_total != K * shape[3])
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_sharded: context shape must be (K_local, dx, n_ranks * K_local)");
+  const size_t need = gjx_workspace_bytes(GJX_OP_SSM, K);
+  if (!workspace || workspace_bytes < need + 64) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_filter_sharded: workspace too small (OP_SSM + 64)");
+  float* lse_local = (float*)((char*)workspace + need);
+  uint32_t k[2] = {key0, key1};
+  uint32_t kt[2], kp[2], kr[2], b[2];
+  host_threefry(k[0], k[1], 0u, 0u, kt);       // k_0 = fold_in(key, 0)
+  k[0] = kt[0]; k[1] = kt[1];
+  for (int t = 0; t < T; ++t) {
+    host_threefry(k[0], k[1], 0u, 0u, kp);
+    rc = gjx_ssm_step(m, kp[0], kp[1], rng_mode, t, K, particle_offset, t > 0 ? x_b : nullptr, K, nullptr,
+                      ys_dev + (size_t)t * m->dy, x_a, logw, lse_local, N_total, workspace, need, stream);
+    if (rc) return rc;
+    float* rec = lse_steps + 4 * (size_t)t;
+    if (t + 1 < T) {
+      // step t+1's key gives the comb offset of the resampling that precedes it; the exchange also yields the
+      // global LSE record of step t
+      host_threefry(k[0], k[1], 0u, (uint32_t)(t + 1), kt);
+      k[0] = kt[0]; k[1] = kt[1];
+      host_threefry(k[0], k[1], 0u, 1u, kr);
+      host_threefry(kr[0], kr[1], 0u, 0u, b);
+      const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
+      rc = gjx_shard_resample_step(ctx, logw, lse_local, x_a, K, x_b, K, u, rec, nullptr, stream);
+    } else {
+      rc = gjx_shard_global_lse(ctx, lse_local, rec, stream);
+    }
+    if (rc) return rc;
+  }
+  return GJX_OK;
+}

@@ -78,45 +78,60 @@ class BootstrapFilter:
         ys_d = torch.as_tensor(np.asarray(ys, np.float32), device=dev) if not torch.is_tensor(ys) else ys.to(dev)
         ys_d = ys_d.contiguous()
         T = ys_d.shape[0]
-        if world == 1 and not keep_means and not step_by_step:
+        if world == 1 and not keep_means and not step_by_step and not D._forced():
             out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K)
             incs = out["lse_steps"][:, 3]
             return dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
         off, K = D.shard(self.K, rank, world)
+        sharded = world > 1 or D._forced()
         cs = self.ssm.c_struct(dev)
         ws = kernels.workspace(A.OP_SSM, K, dev)
         bufs = [torch.empty((self.ssm.dx, K), dtype=torch.float32, device=dev) for _ in range(2)]
         logw = torch.empty(K, dtype=torch.float32, device=dev)
         incs = torch.empty(T, dtype=torch.float32, device=dev)
         lse = torch.empty(4, dtype=torch.float32, device=dev)
-        ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
-        cum_buf = torch.empty(K, dtype=torch.int64, device=dev)
-        bt_buf = torch.empty(2, dtype=torch.int64, device=dev)
         means = torch.empty((T, self.ssm.dx), dtype=torch.float32, device=dev) if keep_means else None
+        if sharded:
+            # equal shards only: every rank keeps K/world particles through every resampling
+            if self.K % world:
+                raise ValueError("sharded bootstrap filter: k_particles must be a multiple of the world size")
+            key_ = (K, self.ssm.dx, self.K, str(dev))
+            if getattr(self, "_resampler_key", None) != key_:
+                self._resampler, self._resampler_key = D.ShardedResampler(K, self.ssm.dx, self.K, dev), key_
+            resampler = self._resampler
+            if resampler.transport == "rccl" and not keep_means and not step_by_step:
+                out = kernels.ssm_filter_sharded(cs, key, self.rng_mode, ys_d, resampler.ctx, off)
+                incs = out["lse_steps"][:, 3]
+                return dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
+        else:
+            ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
+            cum_buf = torch.empty(K, dtype=torch.int64, device=dev)
+            bt_buf = torch.empty(2, dtype=torch.int64, device=dev)
         x_prev, anc = None, None
         k = key
         for t in range(T):
             k = fold_in(k, t)                      # chained step key (scan.py:268)
             k_prop, k_res = split(k)
-            if t > 0:
-                if world == 1:
-                    anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
-                else:
-                    x_prev, _ = D.resample_exchange(x_prev, logw, lse, _unit_from_key(k_res), self.K)
-                    anc = None
+            if t > 0 and not sharded:
+                anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
             x_out = bufs[t & 1]
             kernels.ssm_step(cs, k_prop, self.rng_mode, t, K, x_prev, anc, ys_d[t], x_out=x_out, logw=logw, lse=lse,
                              offset=off, K_total=self.K, ws=ws)
-            if world > 1:
-                lse = D.global_lse(lse, self.K)
-            incs[t] = lse[3]
+            rec = lse
+            if sharded:
+                if t + 1 < T:
+                    # resampling for step t+1 (its u comes from step t+1's key, as in the unsharded loop) also
+                    # yields the global LSE record of step t
+                    k_next = split(fold_in(k, t + 1))[1]
+                    x_res, rec = resampler.step(x_out, logw, lse, _unit_from_key(k_next))
+                else:
+                    rec = D.global_lse(lse, self.K)
+            incs[t] = rec[3]
             if keep_means:
-                w = torch.exp(logw - lse[2])
+                w = torch.exp(logw - rec[2])
                 m = (x_out * w).sum(dim=1)
                 if world > 1:
                     torch.distributed.all_reduce(m)
                 means[t] = m
-            x_prev = x_out
-            if world > 1:
-                lse = lse.clone()
+            x_prev = x_res if (sharded and t + 1 < T) else x_out
         return dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means)

@@ -345,6 +345,23 @@ def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, log
     return x_out, logw, lse
 
 
+def ssm_filter_sharded(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, ctx: "ShardContext", offset: int, bufs=None):
+    """gjx_ssm_filter_sharded: this rank's part of the T-step bootstrap filter over a gjx_shard_ctx, looped in C++.
+    -> dict(lse_steps [T][4] global records, x (propagated particles of the last step), logw)"""
+    dev = ys.device
+    T, K = ys.shape[0], ctx.K
+    if bufs is None:
+        need = load().gjx_workspace_bytes(A.OP_SSM, K)
+        bufs = dict(xa=torch.empty((ssm.dx, K), dtype=torch.float32, device=dev),
+                    xb=torch.empty((ssm.dx, K), dtype=torch.float32, device=dev),
+                    logw=torch.empty(K, dtype=torch.float32, device=dev), lse=torch.empty((T, 4), dtype=torch.float32, device=dev),
+                    ws=torch.zeros(need + 64, dtype=torch.uint8, device=dev))
+    check(load().gjx_ssm_filter_sharded(C.byref(ssm), key[0], key[1], rng_mode, T, ctx._h, int(offset), _ptr(ys), _ptr(bufs["xa"]),
+                                        _ptr(bufs["xb"]), _ptr(bufs["logw"]), _ptr(bufs["lse"]), _ptr(bufs["ws"]),
+                                        bufs["ws"].numel(), _stream()), "gjx_ssm_filter_sharded")
+    return dict(lse_steps=bufs["lse"], x=bufs["xa"], logw=bufs["logw"], _bufs=bufs)
+
+
 def hmc(prog: PackedProgram, key, choices: torch.Tensor, eps: float, L: int, stale=False, accept=False, offset=0,
         ws=None):
     """gjx_hmc: in-place HMC move of every chain column.  Returns dict(choices, score, alpha, accepted)."""

@@ -331,6 +331,21 @@ int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_m
                    const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                    float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same filter on a collection sharded over the ranks of a gjx_shard_ctx (BASELINE config 4): every rank
+ * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles
+ * (streams indexed by the global particle index particle_offset + i, so results do not depend on the number
+ * of ranks) and one gjx_shard_resample_step.  ctx must have been created for (K_local, rows = dx,
+ * N_total = n_ranks * K_local).  x_a (propagated) and x_b (resampled) f32[dx][K_local]; lse_steps f32[T][4]
+ * receives the GLOBAL record of every step; workspace: gjx_workspace_bytes(GJX_OP_SSM, K_local) + 64 bytes,
+ * zero-filled once. */
+int gjx_ssm_filter_sharded(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T,
+                           gjx_shard_ctx* ctx, int64_t particle_offset, const float* ys_dev, float* x_a, float* x_b,
+                           float* logw, float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
+/* shape of a context {K_local, rows, N_total, n_ranks, rank}; global LSE record from this rank's local one
+ * (8-byte all-gather + combine) */
+int gjx_shard_ctx_shape(const gjx_shard_ctx* ctx, int64_t out5[5]);
+int gjx_shard_global_lse(gjx_shard_ctx* ctx, const float* local_lse, float* lse_out, void* stream);
+
 /* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
  * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float
  * sites only, hmc.py:49-65); every other site keeps its value (mode OBS_*).

@@ -622,6 +622,15 @@ def test_sharded_exchange_two_processes_one_gpu(oracle, spread):
 
 
 def _rccl_one_rank_worker(port, q):
+    try:
+        _rccl_one_rank_body(port, q)
+    except BaseException as e:          # report instead of leaving the parent to time out
+        import traceback
+        q.put(("error", traceback.format_exc(), None, None, None, None))
+        raise
+
+
+def _rccl_one_rank_body(port, q):
     import sys
     import torch
     import torch.distributed as dist
@@ -640,7 +649,19 @@ def _rccl_one_rank_worker(port, q):
     anc = kernels.resample_indices(lw, 0.77, K, lse=local)
     want = kernels.gather_rows(rows, anc)
     torch.cuda.synchronize()
-    q.put((res.transport, bool(torch.equal(got, want)), rec.cpu().numpy(), local.cpu().numpy(), res.ctx.last_info))
+    # the sharded bootstrap filter (per-step exchange through the same transport) against the native one-GPU loop
+    from genjax_amd import core, workloads
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = workloads.ssm_problem(T=24)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 14)
+    os.environ["GJX_FORCE_DIST"] = "0"
+    a = bf.run(core.key(5), s["y"])
+    os.environ["GJX_FORCE_DIST"] = "1"
+    b = bf.run(core.key(5), s["y"])
+    c = bf.run(core.key(5), s["y"], step_by_step=True)          # same exchange, one host call per stage
+    assert torch.equal(b["x"], c["x"]) and torch.allclose(b["increments"], c["increments"], rtol=2e-6, atol=1e-6)
+    filt = (a["increments"].cpu().numpy(), b["increments"].cpu().numpy(), bool(torch.equal(a["x"], b["x"])), bf._resampler.transport)
+    q.put((res.transport, bool(torch.equal(got, want)), rec.cpu().numpy(), local.cpu().numpy(), res.ctx.last_info, filt))
     res.close()
     dist.destroy_process_group()
 
@@ -653,9 +674,13 @@ def test_rccl_transport_single_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_one_rank_worker, args=(29950 + os.getpid() % 40, q))
     p.start()
-    transport, same, rec, local, info = q.get(timeout=300)
+    transport, same, rec, local, info, filt = q.get(timeout=180)
+    assert transport != "error", same
     p.join(timeout=60)
     assert p.exitcode == 0
     assert transport == "rccl" and same
     np.testing.assert_allclose(rec, local, rtol=1e-6)
     assert info["sent"] == 0 and info["n_valid"] == 70_001
+    inc_native, inc_sharded, same_x, tr2 = filt
+    assert tr2 == "rccl" and same_x                       # same ancestors every step -> identical final particles
+    np.testing.assert_allclose(inc_sharded, inc_native, rtol=2e-6, atol=1e-6)
