@@ -331,7 +331,7 @@ int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_m
                    const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                    float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same filter on a collection sharded over the ranks of a gjx_shard_ctx (BASELINE config 4): every rank
+/* The same filter on a collection sharded over the ranks of a shard context, BASELINE config 4: every rank
  * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles
  * (streams indexed by the global particle index particle_offset + i, so results do not depend on the number
  * of ranks) and one gjx_shard_resample_step.  ctx must have been created for (K_local, rows = dx,
