@@ -8,9 +8,9 @@ fallback: compute entry points raise ``GjxError`` if the library is missing.
 from . import config, inference  # noqa: F401
 from .core import (C, ChoiceMap, ChoiceMapBuilder, S, Selection, SelectionBuilder, fold_in, key,  # noqa: F401
                    split)
-from .gen import (Distribution, Marginal, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
+from .gen import (Distribution, Marginal, array, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
-                  mv_normal_diag, normal, sigmoid, softplus, take, uniform, where)
+                  mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .inference import (HMC, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
                         ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, Update)
 from .program import AddressReuse, MissingAddress  # noqa: F401

@@ -54,6 +54,57 @@ def split(k: Key, num: int = 2) -> list[Key]:
 
 
 # ---------------------------------------------------------------------------------------------
+# Addresses.  The reference addresses a choice by a path of strings with at most one index component for a
+# Scan/Vmap level: "x", ("sub", "x"), ("tracks", 3, "pos"), ("tracks", slice(None), "pos"), (3, "x")
+# (choice_map.py:847-1395, scan.py:56-97).  Internally a site is keyed by ``name`` or ``(name, i)`` where
+# ``name`` is a string or a tuple of strings and ``i`` the step / instance index.
+# ---------------------------------------------------------------------------------------------
+ALL = "<all indices>"
+
+
+def norm_addr(addr):
+    """user or internal address -> (name, idx); idx is None, an int, or ALL (slice / Ellipsis)."""
+    if not isinstance(addr, tuple) or addr == ():
+        return addr, None
+    names, idx = [], [None]
+
+    def walk(c):
+        if isinstance(c, str):
+            names.append(c)
+        elif isinstance(c, tuple):
+            for e in c:
+                walk(e)
+        elif isinstance(c, slice) or c is Ellipsis:
+            if idx[0] is not None:
+                raise KeyError(f"address {addr!r} has more than one index component")
+            idx[0] = ALL
+        elif isinstance(c, (int, np.integer)) and not isinstance(c, bool):
+            if idx[0] is not None:
+                raise KeyError(f"address {addr!r} has more than one index component")
+            idx[0] = int(c)
+        else:
+            raise KeyError(f"unsupported address component {c!r} in {addr!r}")
+
+    walk(addr)
+    if not names:
+        raise KeyError(f"address {addr!r} has no name component")
+    return (names[0] if len(names) == 1 else tuple(names)), idx[0]
+
+
+def key_of(addr):
+    """canonical dictionary key of an address: name, or (name, i) for one step / instance"""
+    name, idx = norm_addr(addr)
+    return name if idx is None or idx is ALL else (name, idx)
+
+
+def _prefixes(name):
+    """proper prefixes of a name path, as keys ("a" for ("a", "b"), ("a", "b") for ("a", "b", "c"))"""
+    if not isinstance(name, tuple):
+        return []
+    return [name[0] if n == 1 else name[:n] for n in range(1, len(name))]
+
+
+# ---------------------------------------------------------------------------------------------
 # Selection
 # ---------------------------------------------------------------------------------------------
 class Selection:
@@ -73,15 +124,29 @@ class Selection:
 
     class _At:
         def __getitem__(self, addr) -> "Selection":
-            if isinstance(addr, tuple):
-                addr = addr[0] if len(addr) == 1 else addr
-            return Selection((addr,))
+            return Selection((key_of(addr),))
 
     at = _At()
 
     def check(self, addr=None) -> bool:
-        hit = addr in self.addrs or (isinstance(addr, tuple) and len(addr) == 2 and addr[0] in self.addrs)
+        """a site is selected by its own key, by its whole sequence (name), or by any prefix of its path"""
+        name, idx = norm_addr(addr)
+        hit = key_of(addr) in self.addrs or name in self.addrs or any(p in self.addrs for p in _prefixes(name))
         return hit != self.complement
+
+    def prefixed(self, prefix) -> "Selection":
+        """the same selection seen from an enclosing generative function that calls this one at ``prefix``"""
+        pre = tuple(prefix) if isinstance(prefix, tuple) else (prefix,)
+
+        def join(a):
+            name, idx = norm_addr(a)
+            full = pre + (name if isinstance(name, tuple) else (name,))
+            return full if idx is None or idx is ALL else (full, idx)
+        if self.complement and not self.addrs:          # all() under a prefix = the prefix itself
+            return Selection((pre[0] if len(pre) == 1 else pre,))
+        if self.complement:
+            raise NotImplementedError("complement selections cannot be re-rooted under a prefix")
+        return Selection(join(a) for a in self.addrs)
 
     def __contains__(self, addr) -> bool:
         return self.check(addr)
@@ -158,7 +223,7 @@ class ChoiceMap:
 
         def set(self, value) -> "ChoiceMap":
             d = dict(self.base._d)
-            d[self.addr] = value.get_value() if isinstance(value, ChoiceMap) and value.has_value() else value
+            d[key_of(self.addr)] = value.get_value() if isinstance(value, ChoiceMap) and value.has_value() else value
             return ChoiceMap(d)
 
     class _At:
@@ -185,30 +250,55 @@ class ChoiceMap:
         return not self._d
 
     def __contains__(self, addr) -> bool:
-        return addr in self._d
+        try:
+            name, idx = norm_addr(addr)
+        except KeyError:
+            return False
+        return key_of(addr) in self._d or (isinstance(idx, int) and name in self._d)
+
+    def _n_steps(self, name) -> int:
+        return sum(1 for k in self._d if isinstance(k, tuple) and len(k) == 2 and k[0] == name and isinstance(k[1], int))
 
     def __getitem__(self, addr):
-        # scan-style addressing: chm[:, "x"] is the stacked value, chm[t, "x"] one step (scan.py:56-97)
-        if isinstance(addr, tuple) and len(addr) == 2 and not isinstance(addr[1], int):
-            idx, name = addr
-            if isinstance(idx, slice) or idx is Ellipsis:
-                addr = name
-            elif (name, idx) in self._d:
-                addr = (name, idx)
-            elif name in self._d:
-                return self._d[name][..., idx]
-        if addr not in self._d:
+        # chm["x"], chm["sub", "x"], chm[t, "x"] / chm["tracks", t, "pos"] (one step), chm[:, "x"] (stacked)
+        name, idx = norm_addr(addr)
+        if isinstance(idx, int):
+            if idx < 0:
+                n = self._n_steps(name)
+                idx = idx + n if n else idx
+            if (name, idx) in self._d:
+                return self._d[(name, idx)]
+            if name in self._d:                       # a whole-sequence value set by the user: leading axis = steps
+                return self._d[name][idx]
             raise ChoiceMapNoValueAtAddress(addr)
-        return self._d[addr]
+        if name not in self._d:
+            raise ChoiceMapNoValueAtAddress(addr)
+        return self._d[name]
 
     def get(self, addr, default=None):
-        return self._d.get(addr, default)
+        try:
+            return self[addr]
+        except (KeyError, IndexError):
+            return default
 
     def __call__(self, addr):
         return self.get_submap(addr)
 
     def get_submap(self, addr) -> "ChoiceMap":
-        return ChoiceMap.v(self._d[addr]) if addr in self._d else ChoiceMap()
+        """value at a leaf address, or the choices below a path prefix with the prefix removed"""
+        k = key_of(addr)
+        if k in self._d:
+            return ChoiceMap.v(self._d[k])
+        pre = k if isinstance(k, tuple) and all(isinstance(c, str) for c in k) else (k,)
+        out = {}
+        for a, v in self._d.items():
+            name, idx = norm_addr(a)
+            path = name if isinstance(name, tuple) else (name,)
+            if a != _VALUE and len(path) > len(pre) and path[: len(pre)] == pre:
+                rest = path[len(pre):]
+                rest = rest[0] if len(rest) == 1 else rest
+                out[rest if idx is None else (rest, idx)] = v
+        return ChoiceMap(out)
 
     def addresses(self) -> list:
         return [a for a in self._d if a != _VALUE]

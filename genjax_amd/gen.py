@@ -219,6 +219,28 @@ def cond(flag, true_fn, false_fn) -> Gather:
     return where(flag, t, f)
 
 
+def array(items) -> "Affine | np.ndarray":
+    """``jnp.array([0.0, y])`` inside a model body: a vector whose entries are numbers and scalar expressions of
+    ONE earlier site (the parameter forms of the site program are affine in a single source)."""
+    items = list(items)
+    syms = [it for it in items if isinstance(it, Sym)]
+    if not syms:
+        return np.asarray(items, np.float32)
+    affs = [it._affine() if isinstance(it, Sym) else None for it in items]
+    src = next(a for a in affs if a is not None).src
+    n_src = src.dim
+    M = np.zeros((len(items), n_src), np.float64)
+    b = np.zeros(len(items), np.float64)
+    for r, (it, a) in enumerate(zip(items, affs)):
+        if a is None:
+            b[r] = float(it)
+            continue
+        if a.src.addr != src.addr or a.xf != A.XF_NONE or a.M.shape[0] != 1:
+            raise NotSupportedInModelBody("array([...]): entries must be scalars that depend on one and the same site")
+        M[r], b[r] = a.M[0], a.b[0]
+    return Affine(src, M, b)
+
+
 def _xf(x, code: int, fn: Callable):
     if isinstance(x, Gather):
         if x.xf != A.XF_NONE:
@@ -242,7 +264,8 @@ class _Tracer:
 
     def __init__(self):
         self.sites = SiteList()
-        self.step = None   # inside a scan: the iteration index, appended to every address as (addr, step)
+        self.step = None   # inside a scan / vmap: the iteration index, appended to every address as (name, step)
+        self.prefix = ()   # inside `callee(...) @ "addr"`: the path of enclosing call addresses
 
     def __enter__(self):
         _Tracer.stack.append(self)
@@ -264,10 +287,29 @@ class DistCall:
 
     def __matmul__(self, addr):
         t = _Tracer.current()
+        path = t.prefix + (tuple(addr) if isinstance(addr, tuple) else (addr,))
+        addr = path[0] if len(path) == 1 else path
         if t.step is not None:
             addr = (addr, t.step)
         site = t.sites.add(addr, self.kind, self.params, self.dim)
         return SiteVal(addr, site.dim, self.kind)
+
+
+class GenCall:
+    """``callee(*args)`` inside a model body; ``@ "addr"`` inlines the callee's sites under that address
+    (static.py:340-399: the handler recurses into the callee with the sub-choicemap at ``addr``)."""
+
+    def __init__(self, inline: Callable):
+        self._inline = inline
+
+    def __matmul__(self, addr):
+        t = _Tracer.current()
+        old = t.prefix
+        t.prefix = old + (tuple(addr) if isinstance(addr, tuple) else (addr,))
+        try:
+            return self._inline(t)
+        finally:
+            t.prefix = old
 
 
 # ---------------------------------------------------------------------------------------------
@@ -418,13 +460,10 @@ def _value_rows(v, dim: int):
 
 
 def _constraint_value(constraint: ChoiceMap, addr):
-    """(found, value) for a site address; a scan site ("x", t) also matches a whole-sequence entry "x"."""
+    """(found, value) for a site key ``name`` or ``(name, t)``; a scan / vmap site also matches a whole-sequence
+    entry under its name (ChoiceMap.__getitem__ indexes the leading axis)."""
     if addr in constraint:
         return True, constraint[addr]
-    if isinstance(addr, tuple) and len(addr) == 2 and addr[0] in constraint:
-        v = constraint[addr[0]]
-        v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
-        return True, v[addr[1]]
     return False, None
 
 
@@ -536,8 +575,16 @@ class StaticGenerativeFunction(GenerativeFunction):
         return self._cache[k]
 
     def __call__(self, *args):
-        raise NotSupportedInModelBody("calling a @gen function inside another model body is not supported; "
-                                      "use simulate/importance/assess")
+        return GenCall(lambda t: self.source(*args))
+
+    def vmap(self, in_axes=0) -> "VmapCombinator":
+        """``kernel.vmap(in_axes=...)`` (combinators/vmap.py:193-218): one independent instance per index of the
+        mapped (host-data) arguments."""
+        return VmapCombinator(self, in_axes)
+
+    def repeat(self, n: int) -> "VmapCombinator":
+        """``kernel.repeat(n=...)`` (combinators/repeat.py): n i.i.d. instances with the same arguments."""
+        return VmapCombinator(self, None, n=int(n))
 
     def scan(self, n: int) -> "ScanCombinator":
         """``kernel.scan(n=T)`` (combinators/scan.py): the kernel ``(carry, x) -> (carry, out)`` unrolled T times."""
@@ -557,20 +604,103 @@ class ScanCombinator(GenerativeFunction):
         self.kernel, self.n = kernel, n
         self._cache: dict = {}
 
+    def _unroll(self, t: _Tracer, carry, xs):
+        if t.step is not None:
+            raise NotSupportedInModelBody("a scan / vmap nested inside another scan / vmap is not supported")
+        outs = []
+        try:
+            for i in range(self.n):
+                t.step = i
+                carry, out = self.kernel.source(carry, None if xs is None else xs[i])
+                outs.append(out)
+        finally:
+            t.step = None
+        return carry, outs
+
+    def __call__(self, carry, xs=None):
+        return GenCall(lambda t: self._unroll(t, carry, xs))
+
     def site_list(self, args):
         k = _args_key(tuple(a for a in args if a is not None)) + (len(args),)
         if k not in self._cache:
-            carry = args[0]
-            xs = args[1] if len(args) > 1 else None
-            outs = []
             with _Tracer() as t:
-                for i in range(self.n):
-                    t.step = i
-                    carry, out = self.kernel.source(carry, None if xs is None else xs[i])
-                    outs.append(out)
-                t.step = None
-            self._cache[k] = (t.sites, (carry, outs))
+                ret = self._unroll(t, args[0], args[1] if len(args) > 1 else None)
+            self._cache[k] = (t.sites, ret)
         return self._cache[k]
+
+
+class VmapCombinator(GenerativeFunction):
+    """Plate over a kernel generative function (combinators/vmap.py:193-218), lowered by unrolling like
+    ``ScanCombinator``: instance i's sites get the addresses ``(addr, i)``; whole-plate constraints / selections
+    use the bare address (``C["y"].set(vector)``, ``chm[:, "y"]``, ``chm[i, "y"]``); scores and weights add
+    (vmap.py:206-218 sums the per-instance weights).  Mapped arguments are host data (arrays indexed on the
+    mapped axis at trace time); ``in_axes`` follows jax.vmap: an int for every argument, or a tuple with
+    ``None`` for broadcast arguments.  The reference derives instance keys by ``split(key, n)`` (vmap.py:186);
+    here every site has its own counter-based stream, which is the same independence structure."""
+
+    def __init__(self, kernel: StaticGenerativeFunction, in_axes=0, n: int | None = None):
+        self.kernel, self.in_axes, self.n = kernel, in_axes, n
+        self._cache: dict = {}
+
+    def _axes(self, args) -> tuple:
+        if self.n is not None:
+            return (None,) * len(args)
+        ax = self.in_axes
+        if isinstance(ax, (int, type(None))):
+            ax = (ax,) * len(args)
+        ax = tuple(ax) + (None,) * (len(args) - len(ax))
+        if len(ax) != len(args):
+            raise ValueError(f"vmap in_axes {self.in_axes!r} does not match {len(args)} argument(s)")
+        return ax
+
+    def _unroll(self, t: _Tracer, args):
+        if t.step is not None:
+            raise NotSupportedInModelBody("a scan / vmap nested inside another scan / vmap is not supported")
+        axes = self._axes(args)
+        moved = [a if ax is None else np.moveaxis(_np_arg(a), ax, 0) for a, ax in zip(args, axes)]
+        lens = {m.shape[0] for m, ax in zip(moved, axes) if ax is not None}
+        if self.n is None and len(lens) != 1:
+            raise ValueError(f"vmap: mapped arguments must share one axis length, got {sorted(lens)}")
+        n = self.n if self.n is not None else lens.pop()
+        outs = []
+        try:
+            for i in range(n):
+                t.step = i
+                outs.append(self.kernel.source(*[m if ax is None else m[i] for m, ax in zip(moved, axes)]))
+        finally:
+            t.step = None
+        return outs
+
+    def __call__(self, *args):
+        return GenCall(lambda t: self._unroll(t, args))
+
+    def site_list(self, args):
+        k = _args_key(args)
+        if k not in self._cache:
+            with _Tracer() as t:
+                outs = self._unroll(t, args)
+            self._cache[k] = (t.sites, outs)
+        return self._cache[k]
+
+
+def _np_arg(a) -> np.ndarray:
+    if isinstance(a, Sym):
+        raise NotSupportedInModelBody("vmap over a traced value is not supported: mapped arguments must be host data")
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
+def vmap(in_axes=0) -> Callable:
+    """``@genjax.vmap(in_axes=...)`` decorator form (combinators/vmap.py:115)."""
+    return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).vmap(in_axes)
+
+
+def repeat(n: int) -> Callable:
+    return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).repeat(n)
+
+
+def scan(n: int) -> Callable:
+    """``@genjax.scan(n=T)`` decorator form (combinators/scan.py)."""
+    return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).scan(n)
 
 
 def gen(fn: Callable) -> StaticGenerativeFunction:

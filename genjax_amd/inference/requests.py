@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _abi as A
-from ..core import ChoiceMap, Key, Selection
+from ..core import ChoiceMap, Key, Selection, key_of
 from ..gen import Trace, _value_rows
 
 
@@ -159,11 +159,37 @@ class StaticRequest(EditRequest):
     def __init__(self, addressed: dict):
         self.addressed = dict(addressed)
 
+    @staticmethod
+    def _join(prefix, addr):
+        pre = tuple(prefix) if isinstance(prefix, tuple) else (prefix,)
+        return pre + (tuple(addr) if isinstance(addr, tuple) else (addr,))
+
+    @classmethod
+    def _reroot(cls, req, prefix):
+        """the request ``req`` addressed to the callee at ``prefix``, as a request on the enclosing trace"""
+        if isinstance(req, HMC):
+            return HMC(req.selection.prefixed(prefix), req.eps, req.L, req.stale_gradient_compat, req.accept)
+        if isinstance(req, Regenerate):
+            return Regenerate(req.selection.prefixed(prefix))
+        if isinstance(req, Update):
+            return Update(ChoiceMap({key_of(cls._join(prefix, a)): v for a, v in req.constraint.items()}))
+        if isinstance(req, StaticRequest):
+            return StaticRequest({key_of(cls._join(prefix, a)): r for a, r in req.addressed.items()})
+        raise NotImplementedError(f"{type(req).__name__} addressed to a sub-generative-function")
+
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         from ..core import fold_in
         total, bwd = None, {}
         for n, (addr, req) in enumerate(self.addressed.items()):
             k = fold_in(key, n + 1)
+            if key_of(addr) not in tr.prog.site_list:          # the address of a callee: recurse with re-rooted request
+                if isinstance(req, Update) and req.constraint.has_value():
+                    raise KeyError(f"Update(C.choice(v)) addressed to {addr!r}, which is not a leaf choice")
+                tr, w, _, b = self._reroot(req, addr).edit(k, tr, argdiffs)
+                total = w if total is None else total + w
+                bwd[addr] = b
+                continue
+            addr = key_of(addr)
             if isinstance(req, Rejuvenate):
                 tr, w, _, b = req.edit_at(k, tr, addr)
             elif isinstance(req, Regenerate):
@@ -171,6 +197,8 @@ class StaticRequest(EditRequest):
             elif isinstance(req, Update):
                 v = req.constraint.get_value() if req.constraint.has_value() else req.constraint[addr]
                 tr, w, _, b = Update(ChoiceMap({addr: v})).edit(k, tr, argdiffs)
+            elif isinstance(req, HMC):
+                tr, w, _, b = HMC(Selection((addr,)), req.eps, req.L, req.stale_gradient_compat, req.accept).edit(k, tr, argdiffs)
             else:
                 raise NotImplementedError(type(req).__name__)
             total = w if total is None else total + w

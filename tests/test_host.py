@@ -206,3 +206,71 @@ def test_scan_unrolls_into_chained_sites():
     assert Selection.at["x"].check(("x", 2)) and not Selection.at["x"].check(("y", 2))
     chm = C.d({("x", 1): 7.0, "x": np.array([5.0, 7.0])})
     assert chm[1, "x"] == 7.0 and chm[:, "x"][0] == 5.0
+
+
+def test_hierarchical_addresses_and_nested_calls():
+    """`callee(...) @ "addr"`, `kernel.scan(n)(...) @ "tracks"`, `kernel.vmap(...)(...) @ "ys"` inline the callee's
+    sites under a path prefix; ChoiceMap / Selection accept the reference's address forms
+    (tests/inference/test_requests.py:257-420: ["tracks", :, "obs_pos"], ["x", "x"], Selection.at["tracks", ..., "pos"])."""
+    import genjax_amd as genjax
+    from genjax_amd import C, ChoiceMap, S, Selection
+    from genjax_amd.core import key_of, norm_addr, ALL
+
+    assert norm_addr(("tracks", 3, "pos")) == (("tracks", "pos"), 3)
+    assert norm_addr(("tracks", slice(None), "pos")) == (("tracks", "pos"), ALL)
+    assert norm_addr((2, "x")) == ("x", 2) and key_of(("x", "x")) == ("x", "x") and key_of("x") == "x"
+    with pytest.raises(KeyError):
+        norm_addr(("a", 1, 2, "b"))
+
+    @genjax.gen
+    def submodel():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        y = genjax.normal(x, 0.01) @ "y"
+        return y
+
+    @genjax.gen
+    def step(carry, _):
+        pos = genjax.mv_normal_diag(carry, np.array([0.1, 0.1])) @ "pos"
+        genjax.mv_normal_diag(pos, np.array([0.2, 0.2])) @ "obs_pos"
+        return pos, pos
+
+    @genjax.gen
+    def noisy(x, w):
+        return genjax.normal(w * x, 0.5) @ "y"
+
+    @genjax.gen
+    def model(xs):
+        a = submodel() @ "a"
+        _ = submodel() @ "b"
+        y0 = genjax.normal(0.5, 0.01) @ "init_pos"
+        _, tracks = step.scan(n=3)(genjax.array([0.0, y0]), None) @ "tracks"
+        w = genjax.normal(0.0, 1.0) @ "w"
+        ys = noisy.vmap(in_axes=(0, None))(xs, w) @ "ys"
+        return a
+
+    sl, _ = model.site_list((np.arange(4.0),))
+    addrs = [s.addr for s in sl.sites]
+    assert addrs[:5] == [("a", "x"), ("a", "y"), ("b", "x"), ("b", "y"), "init_pos"]
+    assert (("tracks", "pos"), 0) in addrs and (("tracks", "obs_pos"), 2) in addrs and (("ys", "y"), 3) in addrs and "w" in addrs
+    # the scan's initial carry [0, y0] is an affine read of init_pos
+    p0 = sl[(("tracks", "pos"), 0)].params[0]
+    assert p0.src == "init_pos"
+    # address reuse across callees is detected on the full path only
+    @genjax.gen
+    def bad():
+        submodel() @ "a"
+        submodel() @ "a"
+    with pytest.raises(genjax.AddressReuse):
+        bad.site_list(())
+
+    obs = ChoiceMap.empty().at["tracks", :, "obs_pos"].set(np.arange(6.0).reshape(3, 2)).at["a", "y"].set(3.0)
+    assert ("tracks", 1, "obs_pos") in obs and ("a", "y") in obs and "a" not in obs
+    np.testing.assert_array_equal(obs["tracks", 2, "obs_pos"], [4.0, 5.0])
+    assert obs.get_submap("a")["y"] == 3.0 and obs("a")["y"] == 3.0
+    sel = Selection.at["tracks", ..., "pos"]
+    assert sel.check((("tracks", "pos"), 1)) and not sel.check((("tracks", "obs_pos"), 1)) and not sel.check("pos")
+    assert S["a"].check(("a", "x")) and not S["a"].check(("b", "x")) and (S["a"] | S["w"]).check("w")
+    assert Selection.at["x"].prefixed("b").check(("b", "x")) and Selection.all().prefixed("b").check(("b", "y"))
+    # packing with a hierarchical constraint: observed sites leave the slot table
+    prog, shared, pp = model.pack((np.arange(4.0),), obs, True)
+    assert prog.slot_of[("a", "y")] == -1 and prog.slot_of[(("tracks", "obs_pos"), 1)] == -1 and prog.slot_of[("a", "x")] >= 0
