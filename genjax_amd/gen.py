@@ -90,39 +90,64 @@ class HostExpr(Sym):
 
 
 class Affine(Sym):
-    """``M @ value(src) + b`` with M over ALL elements of the source site; optional outer transform."""
+    """``sum_s M_s @ value(s) + b`` over one or more earlier sites s (M_s over ALL elements of s); optional outer
+    transform.  One source lowers to a VALUE / AFFINE parameter on that site; several lower to one AFFINE
+    parameter over the slot range that spans them (observed sources fold into the bias at pack time)."""
 
-    def __init__(self, src: "SiteVal", M: np.ndarray, b: np.ndarray, xf: int = A.XF_NONE):
-        self.src, self.M, self.b, self.xf = src, np.atleast_2d(np.asarray(M, np.float64)), np.atleast_1d(np.asarray(b, np.float64)), xf
-        self.dim = self.M.shape[0]
+    def __init__(self, src, M=None, b=None, xf: int = A.XF_NONE):
+        if isinstance(src, dict):                         # {addr: (SiteVal, M)}
+            self.terms = {a: (sv, np.atleast_2d(np.asarray(m, np.float64))) for a, (sv, m) in src.items()}
+        else:
+            self.terms = {src.addr: (src, np.atleast_2d(np.asarray(M, np.float64)))}
+        self.b, self.xf = np.atleast_1d(np.asarray(b, np.float64)), xf
+        self.dim = next(iter(self.terms.values()))[1].shape[0] if self.terms else self.b.size
+
+    # single-source views (most expressions)
+    @property
+    def src(self) -> "SiteVal":
+        if len(self.terms) != 1:
+            raise NotSupportedInModelBody("this expression depends on several sites")
+        return next(iter(self.terms.values()))[0]
+
+    @property
+    def M(self) -> np.ndarray:
+        if len(self.terms) != 1:
+            raise NotSupportedInModelBody("this expression depends on several sites")
+        return next(iter(self.terms.values()))[1]
 
     def _affine(self):
         if self.xf != A.XF_NONE:
             raise NotSupportedInModelBody("arithmetic after exp/softplus/sigmoid is not supported")
         return self
 
+    def _map(self, f, b) -> "Affine":
+        return Affine({a: (sv, f(m)) for a, (sv, m) in self.terms.items()}, b=b)
+
     def _bcast(self, m: int) -> "Affine":
         if self.dim == m:
             return self
         if self.dim != 1:
             raise NotSupportedInModelBody(f"cannot broadcast a length-{self.dim} expression to {m}")
-        return Affine(self.src, np.repeat(self.M, m, 0), np.repeat(self.b, m))
+        return self._map(lambda M: np.repeat(M, m, 0), np.repeat(self.b, m))
 
     def add(self, o):
         if isinstance(o, Sym):
+            if isinstance(o, HostExpr):
+                a0 = self
+                return HostExpr(lambda ev: ev(a0) + ev(o))
             o = o._affine()
-            if o.src is not self.src:
-                a0, o0 = self, o
-                return HostExpr(lambda ev: ev(a0) + ev(o0))
             m = max(self.dim, o.dim)
             a, c = self._bcast(m), o._bcast(m)
-            return Affine(self.src, a.M + c.M, a.b + c.b)
+            terms = dict(a.terms)
+            for addr, (sv, M) in c.terms.items():
+                terms[addr] = (sv, terms[addr][1] + M) if addr in terms else (sv, M)
+            return Affine(terms, b=a.b + c.b)
         o = np.atleast_1d(np.asarray(o, np.float64)).ravel()
         a = self._bcast(max(self.dim, o.size))
-        return Affine(self.src, a.M, a.b + o)
+        return Affine(a.terms, b=a.b + o)
 
     def scale(self, s: float):
-        return Affine(self.src, self.M * s, self.b * s)
+        return self._map(lambda M: M * s, self.b * s)
 
     def mul(self, o):
         if isinstance(o, Sym):
@@ -130,21 +155,23 @@ class Affine(Sym):
             return HostExpr(lambda ev: ev(a0) * ev(o))
         o = np.atleast_1d(np.asarray(o, np.float64)).ravel()
         a = self._bcast(max(self.dim, o.size))
-        return Affine(self.src, a.M * o[:, None], a.b * o)
+        return a._map(lambda M: M * o[:, None], a.b * o)
 
     def lmatmul(self, o):
         o = np.atleast_2d(np.asarray(o, np.float64))
-        return Affine(self.src, o @ self.M, o @ self.b)
+        return self._map(lambda M: o @ M, o @ self.b)
 
     def with_xf(self, xf: int) -> "Affine":
         self._affine()
-        return Affine(self.src, self.M, self.b, xf)
+        return Affine(self.terms, b=self.b, xf=xf)
 
     def __getitem__(self, i):
         self._affine()
-        return Affine(self.src, self.M[i], self.b[i])
+        return self._map(lambda M: M[i], self.b[i])
 
     def as_param(self) -> Param:
+        if len(self.terms) > 1:
+            return Param.affine_multi([(a, m) for a, (sv, m) in self.terms.items()], bias=self.b, xf=self.xf)
         M, b = self.M, self.b
         n = self.src.dim
         # identity on a prefix (or a single broadcast element) is a plain VALUE read
@@ -220,25 +247,27 @@ def cond(flag, true_fn, false_fn) -> Gather:
 
 
 def array(items) -> "Affine | np.ndarray":
-    """``jnp.array([0.0, y])`` inside a model body: a vector whose entries are numbers and scalar expressions of
-    ONE earlier site (the parameter forms of the site program are affine in a single source)."""
+    """``jnp.array([0.0, y])`` inside a model body: a vector whose entries are numbers and scalar affine
+    expressions of earlier sites."""
     items = list(items)
-    syms = [it for it in items if isinstance(it, Sym)]
-    if not syms:
+    if not any(isinstance(it, Sym) for it in items):
         return np.asarray(items, np.float32)
-    affs = [it._affine() if isinstance(it, Sym) else None for it in items]
-    src = next(a for a in affs if a is not None).src
-    n_src = src.dim
-    M = np.zeros((len(items), n_src), np.float64)
-    b = np.zeros(len(items), np.float64)
-    for r, (it, a) in enumerate(zip(items, affs)):
-        if a is None:
+    n = len(items)
+    terms: dict = {}
+    b = np.zeros(n, np.float64)
+    for r, it in enumerate(items):
+        if not isinstance(it, Sym):
             b[r] = float(it)
             continue
-        if a.src.addr != src.addr or a.xf != A.XF_NONE or a.M.shape[0] != 1:
-            raise NotSupportedInModelBody("array([...]): entries must be scalars that depend on one and the same site")
-        M[r], b[r] = a.M[0], a.b[0]
-    return Affine(src, M, b)
+        a = it._affine()
+        if a.dim != 1:
+            raise NotSupportedInModelBody("array([...]): entries must be scalars")
+        b[r] = a.b[0]
+        for addr, (sv, M) in a.terms.items():
+            if addr not in terms:
+                terms[addr] = (sv, np.zeros((n, sv.dim), np.float64))
+            terms[addr][1][r] = M[0]
+    return Affine(terms, b=b)
 
 
 def _xf(x, code: int, fn: Callable):
@@ -384,10 +413,11 @@ class Trace:
             if isinstance(x, SiteVal):
                 return self._site_value(x.addr)
             if isinstance(x, Affine):
-                v = self._site_value(x.src.addr).float()
-                v = v[..., None] if x.src.dim == 1 else v
-                M = torch.as_tensor(x.M, dtype=torch.float32, device=v.device)
-                out = v @ M.t() + torch.as_tensor(x.b, dtype=torch.float32, device=v.device)
+                out = torch.as_tensor(x.b, dtype=torch.float32, device=self.score.device)
+                for addr, (sv, Mx) in x.terms.items():
+                    v = self._site_value(addr).float()
+                    v = v[..., None] if sv.dim == 1 else v
+                    out = out + v @ torch.as_tensor(Mx, dtype=torch.float32, device=v.device).t()
                 out = out[..., 0] if x.dim == 1 else out
                 return {A.XF_EXP: torch.exp, A.XF_SOFTPLUS: torch.nn.functional.softplus,
                         A.XF_SIGMOID: torch.sigmoid}.get(x.xf, lambda t: t)(out)
@@ -410,8 +440,8 @@ class Trace:
 
     # -- edits ---------------------------------------------------------------------------------
     def update(self, key: Key, constraint: ChoiceMap, argdiffs=None):
-        from .inference.requests import Update
-        return Update(constraint).edit(key, self, argdiffs)
+        """-> (new trace, weight, retdiff, discard ChoiceMap)  (generative_function.py:168-183, 611-627)"""
+        return self.gen_fn.update(key, self, constraint, argdiffs)
 
     def edit(self, key: Key, request, argdiffs=None):
         return request.edit(key, self, argdiffs)
@@ -549,6 +579,13 @@ class GenerativeFunction:
         tr, out = self._run((0, 0), K, args, chm, False, batched)
         return (out["score"] if batched else out["score"][0]), tr.get_retval()
 
+    def update(self, key: Key, trace: "Trace", constraint: ChoiceMap, argdiffs=None):
+        """generative_function.py:611-627: ``Update(constraint).edit`` with the backward request's choice map as the
+        discard."""
+        from .inference.requests import Update
+        tr, w, rd, bwd = Update(constraint).edit(key, trace, argdiffs)
+        return tr, w, rd, bwd.constraint
+
     def propose(self, key: Key, args=(), K: int | None = None):
         tr = self.simulate(key, args, K)
         return tr.get_choices(), tr.get_score(), tr.get_retval()
@@ -576,6 +613,13 @@ class StaticGenerativeFunction(GenerativeFunction):
 
     def __call__(self, *args):
         return GenCall(lambda t: self.source(*args))
+
+    def partial_apply(self, *args) -> "StaticGenerativeFunction":
+        """static.py:1011-1036: the same function with its leading arguments pre-filled."""
+        src = self.source
+        g = StaticGenerativeFunction(lambda *rest: src(*args, *rest))
+        g.__name__ = self.__name__
+        return g
 
     def vmap(self, in_axes=0) -> "VmapCombinator":
         """``kernel.vmap(in_axes=...)`` (combinators/vmap.py:193-218): one independent instance per index of the

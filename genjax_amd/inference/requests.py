@@ -156,8 +156,9 @@ class Rejuvenate(EditRequest):
 class StaticRequest(EditRequest):
     """Address-wise composition of requests (generative_functions/static.py:130-131): ``{addr: request}``."""
 
-    def __init__(self, addressed: dict):
+    def __init__(self, addressed: dict, absolute=()):
         self.addressed = dict(addressed)
+        self.absolute = list(absolute)      # requests already expressed on the enclosing trace (backward of re-rooted ones)
 
     @staticmethod
     def _join(prefix, addr):
@@ -179,7 +180,11 @@ class StaticRequest(EditRequest):
 
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         from ..core import fold_in
-        total, bwd = None, {}
+        total, bwd, bwd_abs = None, {}, []
+        for n, req in enumerate(self.absolute):
+            tr, w, _, b = req.edit(fold_in(key, 1000 + n), tr, argdiffs)
+            total = w if total is None else total + w
+            bwd_abs.append(b)
         for n, (addr, req) in enumerate(self.addressed.items()):
             k = fold_in(key, n + 1)
             if key_of(addr) not in tr.prog.site_list:          # the address of a callee: recurse with re-rooted request
@@ -187,7 +192,7 @@ class StaticRequest(EditRequest):
                     raise KeyError(f"Update(C.choice(v)) addressed to {addr!r}, which is not a leaf choice")
                 tr, w, _, b = self._reroot(req, addr).edit(k, tr, argdiffs)
                 total = w if total is None else total + w
-                bwd[addr] = b
+                bwd_abs.append(b)                              # its addresses are already those of this trace
                 continue
             addr = key_of(addr)
             if isinstance(req, Rejuvenate):
@@ -203,4 +208,4 @@ class StaticRequest(EditRequest):
                 raise NotImplementedError(type(req).__name__)
             total = w if total is None else total + w
             bwd[addr] = b
-        return tr, total, None, StaticRequest(bwd)
+        return tr, total, None, StaticRequest(bwd, bwd_abs)

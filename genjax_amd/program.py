@@ -31,6 +31,7 @@ class Param:
     src_elem: int = 0                  # first element of the source site used
     length: int = 1                    # VALUE: number of source elements (1 = broadcast)
     xf: int = A.XF_NONE
+    terms: list | None = None          # AFFINE over several sites: [(addr, matrix [dim][site dim]), ...]
 
     @staticmethod
     def const(v, xf=A.XF_NONE) -> "Param":
@@ -52,6 +53,16 @@ class Param:
         m = np.atleast_2d(np.asarray(matrix, np.float32))
         return Param(A.P_AFFINE, values=np.atleast_1d(np.asarray(bias, np.float32)).ravel(),
                      matrix=m, src=src, src_elem=elem, xf=xf)
+
+
+def _affine_multi(terms, bias=0.0, xf=A.XF_NONE) -> Param:
+    """bias + sum_t M_t @ value(site t): one P_AFFINE over the slot range spanning the latent sources; observed
+    sources fold into the bias when the program is packed."""
+    ts = [(a, np.atleast_2d(np.asarray(m, np.float32))) for a, m in terms]
+    return Param(A.P_AFFINE, values=np.atleast_1d(np.asarray(bias, np.float32)).ravel(), src=ts[0][0], xf=xf, terms=ts)
+
+
+Param.affine_multi = staticmethod(_affine_multi)
 
 
 def as_param(p: Any) -> Param:
@@ -205,8 +216,12 @@ class PackedProgram:
                 cp = cs.p[k]
                 cp.op, cp.xf = p.op, p.xf
                 if p.op != A.P_CONST:
-                    if p.src not in order or order[p.src] >= j:
-                        raise ValueError(f"site {s.addr!r} reads {p.src!r} before it is traced")
+                    for a_src in ([t[0] for t in p.terms] if p.terms else [p.src]):
+                        if a_src not in order or order[a_src] >= j:
+                            raise ValueError(f"site {s.addr!r} reads {a_src!r} before it is traced")
+                if p.terms:
+                    self._pack_affine_multi(cp, p, s, rows, push)
+                    continue
                 src_obs = p.op != A.P_CONST and self.slot_of[p.src] < 0
                 if p.op == A.P_CONST:
                     cp.off, cp.len = push(p.values), int(p.values.size)
@@ -246,7 +261,34 @@ class PackedProgram:
     def _tab_view(self) -> np.ndarray:
         return self.tab if hasattr(self, "tab") else np.concatenate(self._tab_parts)
 
+    def _pack_affine_multi(self, cp, p: Param, s: Site, rows: int, push) -> None:
+        latent = [(a, m) for a, m in p.terms if self.slot_of[a] >= 0]
+        for a, m in p.terms:
+            if m.shape[0] != rows or m.shape[1] != self.site_list[a].dim:
+                raise ValueError(f"affine term of {s.addr!r} on {a!r} has shape {m.shape}, want ({rows}, {self.site_list[a].dim})")
+        bias = self._fold_observed(p, rows)
+        if not latent:
+            cp.op = A.P_CONST
+            cp.off, cp.len = push(bias), int(bias.size)
+        else:
+            lo = min(self.slot_of[a] for a, _ in latent)
+            hi = max(self.slot_of[a] + m.shape[1] for a, m in latent)
+            dense = np.zeros((rows, hi - lo), np.float32)
+            for a, m in latent:
+                dense[:, self.slot_of[a] - lo: self.slot_of[a] - lo + m.shape[1]] += m
+            cp.slot, cp.n = lo, hi - lo
+            cp.off, cp.len = push(bias), int(bias.size)
+            cp.moff = push(dense)
+        if len(latent) < len(p.terms):
+            self._derived.append((cp.off, p, s.addr))
+
     def _fold_observed(self, p: Param, rows: int) -> np.ndarray:
+        if p.terms:
+            bias = np.broadcast_to(p.values, (rows,)).astype(np.float32).copy() if p.values.size in (1, rows) else p.values.astype(np.float32).copy()
+            for a, m in p.terms:
+                if self.slot_of[a] < 0:
+                    bias = bias + m @ self._obs_value(a)[: m.shape[1]]
+            return bias.astype(np.float32)
         src = self._obs_value(p.src)[p.src_elem:]
         if p.op == A.P_GATHER:
             idx = int(np.clip(int(src[0]), 0, p.values.shape[0] - 1))
@@ -264,7 +306,7 @@ class PackedProgram:
         self.tab[off:off + v.size] = v
         dirty = [(off, v.size)]
         for doff, p, site_addr in self._derived:
-            if p.src == addr:
+            if p.src == addr or (p.terms and any(a == addr for a, _ in p.terms)):
                 s = self.site_list[site_addr]
                 vals = self._fold_observed(p, s.ncat if s.ncat else s.dim)
                 self.tab[doff:doff + vals.size] = vals

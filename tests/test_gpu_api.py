@@ -434,7 +434,9 @@ class TestHMC:
             _ = genjax.normal(x, 0.5) @ "y"
 
         tr, _ = model.importance(genjax.key(1), C.kw(y=1.0), ())
-        new_tr, w, _, bwd = tr.update(genjax.key(2), C["x"].set(0.25))
+        new_tr, w, _, discard = tr.update(genjax.key(2), C["x"].set(0.25))       # discard = old values (ChoiceMap)
+        assert f(discard["x"]) == f(tr.get_choices()["x"])
+        new_tr, w, _, bwd = tr.edit(genjax.key(2), Update(C["x"].set(0.25)))      # request form: backward request
         old_x = f(tr.get_choices()["x"])
         lp = lambda x: -0.5 * x * x - 0.5 * ((1.0 - x) / 0.5) ** 2
         assert f(new_tr.get_choices()["x"]) == 0.25

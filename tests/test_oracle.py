@@ -439,3 +439,51 @@ def test_hmc_converges_like_reference_test(oracle):
             assert float(o["score"][0]) - float(oracle.score_grad(prog, x)[0][0]) == pytest.approx(new - old, rel=1e-3, abs=0.5)
             x = o["choices"]
         assert float(x[0, 0]) == pytest.approx(3.0, rel=5e-3)
+
+
+def test_multi_source_affine_parameters(oracle):
+    """A parameter that is affine in SEVERAL earlier sites (reference models such as
+    tests/generative_functions/test_static_gen_fn.py:552-581, `normal(y1 + y2, 1.0)`, or a regression line
+    `a * x + b`) packs into one P_AFFINE over the slot range that spans the latent sources; observed sources
+    fold into the bias."""
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMap
+
+    @genjax.gen
+    def linked():
+        y1 = genjax.normal(0.0, 1.0) @ "y1"
+        mid = genjax.normal(5.0, 2.0) @ "mid"
+        y2 = genjax.normal(y1, 1.0) @ "y2"
+        y3 = genjax.normal(y1 + 2.0 * y2 - 0.5, 1.0) @ "y3"
+        v = genjax.mv_normal_diag(genjax.array([y1 + y3, 1.0, mid - y2]), np.array([0.5, 1.0, 2.0])) @ "v"
+        return y1 + y2 + y3
+
+    K = 4096
+    for constraint in (ChoiceMap.empty(), ChoiceMap.empty().at["y2"].set(0.7), ChoiceMap.empty().at["y1"].set(-0.3).at["y3"].set(1.1)):
+        prog, shared, _ = linked.pack((), constraint, True)
+        out = oracle.run_program(prog, (3, 4), K)
+        val = {}
+        for s in prog.site_list.sites:
+            sl = prog.slot_of[s.addr]
+            val[s.addr] = (np.broadcast_to(np.asarray(shared[s.addr], np.float64)[:, None], (s.dim, K)) if sl < 0
+                           else out["choices"][sl:sl + s.dim].astype(np.float64))
+        lp = lambda x, m, sd: -0.5 * ((x - m) / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)
+        y1, mid, y2, y3, v = val["y1"][0], val["mid"][0], val["y2"][0], val["y3"][0], val["v"]
+        want = (lp(y1, 0, 1) + lp(mid, 5, 2) + lp(y2, y1, 1) + lp(y3, y1 + 2 * y2 - 0.5, 1)
+                + lp(v[0], y1 + y3, 0.5) + lp(v[1], 1.0, 1.0) + lp(v[2], mid - y2, 2.0))
+        np.testing.assert_allclose(out["score"], want, rtol=2e-4, atol=2e-4)
+        # the sampled children really follow their parents
+        if "y3" not in constraint:
+            assert abs(np.mean(y3 - (y1 + 2 * y2 - 0.5))) < 0.08
+        assert abs(np.mean(v[2] - (mid - y2))) < 0.15
+    # structure: y3's location is one AFFINE over the slots y1..y2 (mid lies in between and gets a zero column)
+    prog, _, _ = linked.pack((), ChoiceMap.empty(), True)
+    cs = prog.c_sites[3]
+    assert cs.p[0].op == A.P_AFFINE and cs.p[0].slot == 0 and cs.p[0].n == 3
+    np.testing.assert_array_equal(prog.tab[cs.p[0].moff: cs.p[0].moff + 3], [1.0, 0.0, 2.0])
+    # all sources observed -> constant; replacing the observation recomputes the folded constant
+    prog, _, _ = linked.pack((), ChoiceMap.empty().at["y1"].set(1.0).at["y2"].set(2.0), True)
+    cs = prog.c_sites[3]
+    assert cs.p[0].op == A.P_CONST and prog.tab[cs.p[0].off] == pytest.approx(1.0 + 4.0 - 0.5)
+    prog.set_obs("y2", 3.0)
+    assert prog.tab[cs.p[0].off] == pytest.approx(1.0 + 6.0 - 0.5)
