@@ -24,8 +24,10 @@
  * PARITY STATUS: bit-level parity with the reference's sample streams is UNPINNED — the
  * reference holds no golden vectors or sampled-value assertions for this path
  * and cannot run here.  This oracle is pinned by: the Random123 KATs, scipy.stats log-pdf
- * tables (tests/golden/), and every closed-form / tolerance check the reference's own tests
- * hold for the path (tests/inference/test_smc.py:32-87, test_requests.py:94-255, README.md:89-123).
+ * tables (tests/golden/), the one literal value the reference's tests hold on this path
+ * (tests/generative_functions/test_static_gen_fn.py:318, assess == -2.837877; tests/golden/reference_kat.json),
+ * and every closed-form / tolerance check the reference's own tests hold for the path
+ * (tests/inference/test_smc.py:32-87, test_requests.py:94-255, test_static_gen_fn.py:208-731, README.md:89-123).
  *
  * Plain C, float32 arithmetic exactly where the reference is float32; reductions that the
  * reference leaves to XLA (logsumexp) are accumulated in double and rounded once.

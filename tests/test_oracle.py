@@ -5,6 +5,7 @@ the reference's own tests hold for this path (tests/inference/test_smc.py:32-87,
 tests/generative_functions/test_distributions.py:25-60, test_static_gen_fn.py:441-490, README.md:89-123).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -487,3 +488,26 @@ def test_multi_source_affine_parameters(oracle):
     assert cs.p[0].op == A.P_CONST and prog.tab[cs.p[0].off] == pytest.approx(1.0 + 4.0 - 0.5)
     prog.set_obs("y2", 3.0)
     assert prog.tab[cs.p[0].off] == pytest.approx(1.0 + 6.0 - 0.5)
+
+
+def test_reference_literal_kat(oracle):
+    """The one literal value in the reference's own tests for this path (test_static_gen_fn.py:318):
+    assess(y1=1.0, y2=-1.0) of two standard normals == -2.837877 (float32 print, so rel 1e-6)."""
+    import json
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMap
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat.json")))
+
+    @genjax.gen
+    def model():
+        y1 = genjax.normal(0.0, 1.0) @ "y1"
+        y2 = genjax.normal(0.0, 1.0) @ "y2"
+        return y1 + y2
+
+    chm = ChoiceMap.empty()
+    for a, v in kat["choices"].items():
+        chm = chm.at[a].set(v)
+    prog, _, _ = model.pack((), chm, False)
+    out = oracle.run_program(prog, (0, 0), 1)
+    assert float(out["score"][0]) == pytest.approx(kat["score"], rel=1e-6)
+    assert float(np.float32(out["score"][0])) == float(np.float32(kat["score"]))      # the same float32 the reference prints
