@@ -8,7 +8,8 @@ fallback: compute entry points raise ``GjxError`` if the library is missing.
 from . import config, inference  # noqa: F401
 from .core import (C, ChoiceMap, ChoiceMapBuilder, S, Selection, SelectionBuilder, fold_in, key,  # noqa: F401
                    split)
-from .gen import (Distribution, Marginal, array, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
+from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gumbel, half_cauchy, inverse_gamma,
+                  logit_normal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .inference import (HMC, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401

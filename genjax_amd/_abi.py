@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -15,13 +15,19 @@ OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
 # distribution kinds
 NORMAL, FLIP, BERNOULLI_LOGITS, BETA, CATEGORICAL_LOGITS, CATEGORICAL_PROBS = 1, 2, 3, 4, 5, 6
 UNIFORM, MVNORMAL_DIAG, EXPONENTIAL, HALF_NORMAL, LAPLACE, LOG_NORMAL, CAUCHY, GAMMA = 7, 8, 9, 10, 11, 12, 13, 14
+STUDENT_T, TRUNCATED_NORMAL, POISSON, GEOMETRIC, DIRICHLET, GUMBEL, HALF_CAUCHY, INVERSE_GAMMA = 15, 16, 17, 18, 19, 20, 21, 22
+WEIBULL, LOGIT_NORMAL, CHI2 = 23, 24, 25
 KIND_NAMES = {
     NORMAL: "normal", FLIP: "flip", BERNOULLI_LOGITS: "bernoulli", BETA: "beta",
     CATEGORICAL_LOGITS: "categorical", CATEGORICAL_PROBS: "categorical(probs)", UNIFORM: "uniform",
     MVNORMAL_DIAG: "mv_normal_diag", EXPONENTIAL: "exponential", HALF_NORMAL: "half_normal",
     LAPLACE: "laplace", LOG_NORMAL: "log_normal", CAUCHY: "cauchy", GAMMA: "gamma",
+    STUDENT_T: "student_t", TRUNCATED_NORMAL: "truncated_normal", POISSON: "poisson", GEOMETRIC: "geometric",
+    DIRICHLET: "dirichlet", GUMBEL: "gumbel", HALF_CAUCHY: "half_cauchy", INVERSE_GAMMA: "inverse_gamma",
+    WEIBULL: "weibull", LOGIT_NORMAL: "logit_normal", CHI2: "chi2",
 }
-DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS)
+DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS, POISSON, GEOMETRIC)
+NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move (integers; simplex-constrained)
 
 # param forms / transforms / modes / flags / rng
 P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
@@ -31,7 +37,7 @@ SITE_HMC_SELECTED = 1
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
-MAX_PARAMS = 2
+MAX_PARAMS = 4
 
 i32, i64, u32, u64, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 vp = C.c_void_p
@@ -66,7 +72,7 @@ class GjxShardPlan(C.Structure):
                 ("seq", i64), ("reserved", i64), ("bounds", i64 * (MAX_RANKS + 1))]
 
 
-assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 96 and C.sizeof(GjxShardPlan) == 8 * (12 + MAX_RANKS + 1)
+assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 160 and C.sizeof(GjxShardPlan) == 8 * (12 + MAX_RANKS + 1)
 
 PP = C.POINTER(GjxProgram)
 

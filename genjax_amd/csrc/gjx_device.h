@@ -262,8 +262,54 @@ GJX_DEV float normal_logpdf(float x, float mu, float sd) {
   return fmaf(-0.5f * z, z, -(kHalfLog2Pi + fast_log(sd)));
 }
 
-GJX_DEV float elem_logpdf(int kind, float x, float a, float b) {
+// standard normal CDF differences for the truncated normal: log(Phi(hi) - Phi(lo)), evaluated in the tail that
+// keeps precision (erfc of a positive argument)
+GJX_DEV float normal_cdf(float z) { return 0.5f * erfcf(-z * 0.70710678f); }
+GJX_DEV float normal_interval_mass(float lo, float hi) {
+  if (lo > 0.0f) return normal_cdf(-lo) - normal_cdf(-hi);
+  return normal_cdf(hi) - normal_cdf(lo);
+}
+
+GJX_DEV int params_of(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : 2); }
+
+GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, float d = 0.0f) {
   switch (kind) {
+    case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
+      const float y = (x - b) * fast_rcp(c);
+      return -0.5f * (a + 1.0f) * log1p_acc(y * y * fast_rcp(a)) - fast_log(c) - 0.5f * fast_log(a) - 0.5f * kLogPi +
+             lgammaf(0.5f * (a + 1.0f)) - lgammaf(0.5f * a);
+    }
+    case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
+      if (x < c || x > d) return -INFINITY;
+      const float rs = fast_rcp(b);
+      return normal_logpdf(x, a, b) - fast_log(normal_interval_mass((c - a) * rs, (d - a) * rs));
+    }
+    case GJX_POISSON: return (x < 0.0f || x != floorf(x)) ? -INFINITY : ((x == 0.0f ? 0.0f : x * fast_log(a)) - a - lgammaf(x + 1.0f));
+    case GJX_GEOMETRIC: return (x < 0.0f || x != floorf(x)) ? -INFINITY : ((x == 0.0f ? 0.0f : x * log1p_acc(-a)) + fast_log(a));
+    case GJX_GUMBEL: {
+      const float z = (x - a) * fast_rcp(b);
+      return -(z + fast_exp(-z)) - fast_log(b);
+    }
+    case GJX_HALF_CAUCHY: {
+      const float z = (x - a) * fast_rcp(b);
+      return x < a ? -INFINITY : (-0.451582705f /*log(2/pi)*/ - fast_log(b) - log1p_acc(z * z));
+    }
+    case GJX_INVERSE_GAMMA:  // a = concentration, b = scale
+      return x <= 0.0f ? -INFINITY : (a * fast_log(b) - lgammaf(a) - (a + 1.0f) * fast_log(x) - b * fast_rcp(x));
+    case GJX_WEIBULL: {  // a = concentration k, b = scale
+      if (x < 0.0f) return -INFINITY;
+      const float lr = fast_log(x * fast_rcp(b));
+      return fast_log(a * fast_rcp(b)) + ((a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * lr) - fast_exp(a * lr);
+    }
+    case GJX_LOGIT_NORMAL: {
+      if (!(x > 0.0f && x < 1.0f)) return -INFINITY;
+      const float lx = fast_log(x), l1 = log1p_acc(-x);
+      return normal_logpdf(lx - l1, a, b) - lx - l1;
+    }
+    case GJX_CHI2: {  // a = df
+      const float h = 0.5f * a;
+      return x <= 0.0f ? -INFINITY : (((h - 1.0f) == 0.0f ? 0.0f : (h - 1.0f) * fast_log(x)) - 0.5f * x - h * kLn2 - lgammaf(h));
+    }
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: return normal_logpdf(x, a, b);
     case GJX_FLIP:
@@ -303,8 +349,19 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b) {
 constexpr int kGammaMaxIt = 32;
 constexpr int kGammaNDraw = 4 * kGammaMaxIt + 2;  // draw schedule: see GAMMA_NDRAW in the oracle
 
+constexpr int kPoissonTries = 16;
+
 GJX_DEV int draws_per_elem(int kind) {
-  return kind == GJX_BETA ? 2 * kGammaNDraw : (kind == GJX_GAMMA ? kGammaNDraw : 1);
+  switch (kind) {
+    case GJX_BETA: return 2 * kGammaNDraw;
+    case GJX_GAMMA:
+    case GJX_DIRICHLET:
+    case GJX_INVERSE_GAMMA:
+    case GJX_CHI2: return kGammaNDraw;
+    case GJX_STUDENT_T: return kGammaNDraw + 2;
+    case GJX_POISSON: return 2 * kPoissonTries + 2;
+    default: return 1;
+  }
 }
 
 // Marsaglia & Tsang (2000), log space, fixed draw budget (same element schedule as the oracle)
@@ -334,9 +391,66 @@ GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
   return res + boost;
 }
 
+// Poisson: inversion by sequential search on one uniform for rate < 10, Hörmann's transformed rejection (PTRS,
+// 1993) with a fixed budget of tries above (same element schedule as the oracle: try t uses elements c+2+2t, +1)
 template <int RNG>
-GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, float b) {
+GJX_DEV float poisson_variate(BitStream<RNG>& bs, uint32_t c, float lam) {
+  if (lam < 10.0f) {
+    const float u = bits_to_unit(bs.get(c));
+    float p = fast_exp(-lam), cdf = p;
+    int k = 0;
+    while (u > cdf && k < 96) {
+      ++k;
+      p *= lam / (float)k;
+      cdf += p;
+    }
+    return (float)k;
+  }
+  const float slam = sqrtf(lam), loglam = fast_log(lam);
+  const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+  const float inv_alpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.0f);
+  for (int t = 0; t < kPoissonTries; ++t) {
+    const float U = bits_to_unit(bs.get(c + 2 + 2 * t)) - 0.5f;
+    const float V = uniform_from_bits(bs.get(c + 3 + 2 * t), kTiny, 1.0f);
+    const float us = 0.5f - fabsf(U);
+    const float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
+    if (us >= 0.07f && V <= vr) return k;
+    if (k < 0.0f || (us < 0.013f && V > us)) continue;
+    if (fast_log(V) + fast_log(inv_alpha) - fast_log(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;
+  }
+  return floorf(lam);
+}
+
+template <int RNG>
+GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, float b, float p3 = 0.0f, float p4 = 0.0f) {
   switch (kind) {
+    case GJX_STUDENT_T: {  // a = df, b = loc, p3 = scale: z * sqrt(df / chi2_df), chi2_df = 2 * Gamma(df/2)
+      const float z = stream_normal<RNG>(bs, c);
+      const float lg = log_gamma_variate<RNG>(bs, c + 2, 0.5f * a);
+      return fmaf(p3 * z, fast_exp(0.5f * (fast_log(0.5f * a) - lg)), b);
+    }
+    case GJX_TRUNCATED_NORMAL: {  // inverse CDF inside [low, high], in the tail that keeps precision
+      const float rs = fast_rcp(b);
+      const float lo = (p3 - a) * rs, hi = (p4 - a) * rs;
+      const float u = bits_to_unit(bs.get(c));
+      float z;
+      if (lo > 0.0f) {
+        const float q = fmaf(-u, normal_cdf(-lo) - normal_cdf(-hi), normal_cdf(-lo));   // upper-tail mass
+        z = -kSqrt2 * erfinv_f32(fmaf(2.0f, q, -1.0f));
+      } else {
+        const float q = fmaf(u, normal_cdf(hi) - normal_cdf(lo), normal_cdf(lo));
+        z = kSqrt2 * erfinv_f32(fmaf(2.0f, q, -1.0f));
+      }
+      return fminf(fmaxf(fmaf(b, z, a), p3), p4);
+    }
+    case GJX_POISSON: return poisson_variate<RNG>(bs, c, a);
+    case GJX_GEOMETRIC: return floorf(safe_log(uniform_from_bits(bs.get(c), kTiny, 1.0f)) / log1p_acc(-a));
+    case GJX_GUMBEL: return a - b * safe_log(-safe_log(uniform_from_bits(bs.get(c), kTiny, 1.0f)));
+    case GJX_HALF_CAUCHY: return fmaf(b, tanf(0.5f * kPi * bits_to_unit(bs.get(c))), a);
+    case GJX_INVERSE_GAMMA: return b * fast_exp(-log_gamma_variate<RNG>(bs, c, a));
+    case GJX_WEIBULL: return b * fast_exp(safe_log(-log1p_acc(-bits_to_unit(bs.get(c)))) / a);
+    case GJX_LOGIT_NORMAL: return sigmoid(fmaf(b, stream_normal<RNG>(bs, c), a));
+    case GJX_CHI2: return 2.0f * fast_exp(log_gamma_variate<RNG>(bs, c, 0.5f * a));
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: return fmaf(b, stream_normal<RNG>(bs, c), a);
     case GJX_FLIP: return bits_to_unit(bs.get(c)) < a ? 1.0f : 0.0f;

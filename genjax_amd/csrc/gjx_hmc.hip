@@ -27,28 +27,88 @@ struct HmcArgs {
   float* ws_old;  // [n_slots][n] pre-move values
 };
 
-GJX_DEV void dlogpdf(int kind, float x, float a, float b, float& dx, float& da, float& db) {
-  dx = da = db = 0.0f;
+// gradient of elem_logpdf w.r.t. the value and the parameters; g[0..3] = d/d(a, b, c, d).  NaN marks a parameter
+// gradient that would need digamma (shape parameters): HMC through such a parameter is unsupported.
+GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, float& dx, float* gpar) {
+  float da = 0.0f, db = 0.0f, dc = 0.0f, dd = 0.0f;
+  dx = 0.0f;
+  auto done = [&]() { gpar[0] = da; gpar[1] = db; gpar[2] = dc; gpar[3] = dd; };
+  switch (kind) {
+    case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
+      const float rc = fast_rcp(c);
+      const float y = (x - b) * rc;
+      const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
+      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc; da = __builtin_nanf("");
+      done(); return;
+    }
+    case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb, lo = (c - a) * rb, hi = (d - a) * rb;
+      const float rZ = fast_rcp(normal_interval_mass(lo, hi));
+      const float plo = 0.39894228f * fast_exp(-0.5f * lo * lo) * rZ * rb, phi = 0.39894228f * fast_exp(-0.5f * hi * hi) * rZ * rb;
+      dx = -z * rb;
+      da = z * rb + (phi - plo);
+      db = (z * z - 1.0f) * rb + (hi * phi - lo * plo);
+      dc = plo; dd = -phi;
+      done(); return;
+    }
+    case GJX_POISSON: da = x * fast_rcp(a) - 1.0f; done(); return;
+    case GJX_GEOMETRIC: da = fast_rcp(a) - x * fast_rcp(1.0f - a); done(); return;
+    case GJX_GUMBEL: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float e1 = 1.0f - fast_exp(-z);
+      dx = -e1 * rb; da = e1 * rb; db = (e1 * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_HALF_CAUCHY: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float gq = 2.0f * z * fast_rcp(1.0f + z * z);
+      dx = -gq * rb; da = gq * rb; db = (gq * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_INVERSE_GAMMA: {
+      const float rx = fast_rcp(x);
+      dx = -(a + 1.0f) * rx + b * rx * rx; db = a * fast_rcp(b) - rx; da = __builtin_nanf("");
+      done(); return;
+    }
+    case GJX_WEIBULL: {
+      const float lr = fast_log(x * fast_rcp(b));
+      const float t = fast_exp(a * lr);
+      dx = ((a - 1.0f) - a * t) * fast_rcp(x); db = a * (t - 1.0f) * fast_rcp(b); da = fast_rcp(a) + lr * (1.0f - t);
+      done(); return;
+    }
+    case GJX_LOGIT_NORMAL: {
+      const float rb = fast_rcp(b);
+      const float z = (fast_log(x) - log1p_acc(-x) - a) * rb;
+      dx = -z * rb * fast_rcp(x * (1.0f - x)) - fast_rcp(x) + fast_rcp(1.0f - x); da = z * rb; db = (z * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_CHI2: dx = (0.5f * a - 1.0f) * fast_rcp(x) - 0.5f; da = __builtin_nanf(""); done(); return;
+    default: break;
+  }
   switch (kind) {
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: {
       const float rb = fast_rcp(b);
       const float z = (x - a) * rb;
       dx = -z * rb; da = z * rb; db = (z * z - 1.0f) * rb;
-      return;
+      break;
     }
-    case GJX_BERNOULLI_LOGITS: da = x - sigmoid(a); return;
-    case GJX_FLIP: da = (x != 0.0f ? fast_rcp(a) : 0.0f) - (x != 1.0f ? (1.0f - x) * fast_rcp(1.0f - a) : 0.0f); return;
-    case GJX_HALF_NORMAL: { const float ra = fast_rcp(a); const float z = x * ra; dx = -z * ra; da = (z * z - 1.0f) * ra; return; }
-    case GJX_EXPONENTIAL: dx = -a; da = fast_rcp(a) - x; return;
-    case GJX_LAPLACE: { const float s = (float)((x > a) - (x < a)); const float rb = fast_rcp(b); dx = -s * rb; da = s * rb; db = fabsf(x - a) * rb * rb - rb; return; }
-    case GJX_CAUCHY: { const float rb = fast_rcp(b); const float z = (x - a) * rb; const float g = 2.0f * z * fast_rcp(1.0f + z * z); dx = -g * rb; da = g * rb; db = (g * z - 1.0f) * rb; return; }
-    case GJX_LOG_NORMAL: { const float lx = fast_log(x); const float rb = fast_rcp(b); const float z = (lx - a) * rb; dx = (-z * rb - 1.0f) * fast_rcp(x); da = z * rb; db = (z * z - 1.0f) * rb; return; }
-    case GJX_BETA: dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x); da = __builtin_nanf(""); db = __builtin_nanf(""); return;
-    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = __builtin_nanf(""); db = a * fast_rcp(b) - x; return;
-    case GJX_UNIFORM: { const float r = fast_rcp(b - a); da = r; db = -r; return; }
-    default: return;
+    case GJX_BERNOULLI_LOGITS: da = x - sigmoid(a); break;
+    case GJX_FLIP: da = (x != 0.0f ? fast_rcp(a) : 0.0f) - (x != 1.0f ? (1.0f - x) * fast_rcp(1.0f - a) : 0.0f); break;
+    case GJX_HALF_NORMAL: { const float ra = fast_rcp(a); const float z = x * ra; dx = -z * ra; da = (z * z - 1.0f) * ra; break; }
+    case GJX_EXPONENTIAL: dx = -a; da = fast_rcp(a) - x; break;
+    case GJX_LAPLACE: { const float s = (float)((x > a) - (x < a)); const float rb = fast_rcp(b); dx = -s * rb; da = s * rb; db = fabsf(x - a) * rb * rb - rb; break; }
+    case GJX_CAUCHY: { const float rb = fast_rcp(b); const float z = (x - a) * rb; const float g = 2.0f * z * fast_rcp(1.0f + z * z); dx = -g * rb; da = g * rb; db = (g * z - 1.0f) * rb; break; }
+    case GJX_LOG_NORMAL: { const float lx = fast_log(x); const float rb = fast_rcp(b); const float z = (lx - a) * rb; dx = (-z * rb - 1.0f) * fast_rcp(x); da = z * rb; db = (z * z - 1.0f) * rb; break; }
+    case GJX_BETA: dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x); da = __builtin_nanf(""); db = __builtin_nanf(""); break;
+    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = __builtin_nanf(""); db = a * fast_rcp(b) - x; break;
+    case GJX_UNIFORM: { const float r = fast_rcp(b - a); da = r; db = -r; break; }
+    default: break;
   }
+  done();
 }
 
 GJX_DEV float xf_deriv(int xf, float pre) {
@@ -84,21 +144,36 @@ GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, co
       score += l - (mx + fast_log(se));
       continue;  // integer site: no gradient through it (hmc.py:49-65)
     }
+    if (kind == GJX_DIRICHLET) {  // simplex-valued: scored, never moved (the host refuses to select it)
+      float sa = 0.0f;
+      for (int d = 0; d < s.dim; ++d) {
+        const float al = eval_param(s.p[0], d, tab, val);
+        const float x = s.slot >= 0 ? val(s.slot + d) : tab[s.obs_off + d];
+        sa += al;
+        score += ((al - 1.0f) == 0.0f ? 0.0f : (al - 1.0f) * fast_log(x)) - lgammaf(al);
+      }
+      score += lgammaf(sa);
+      continue;
+    }
     for (int d = 0; d < s.dim; ++d) {
       const float pa_pre = eval_param_pre(s.p[0], d, tab, val);
       const float pb_pre = eval_param_pre(s.p[1], d, tab, val);
       const float pa = apply_xf(s.p[0].xf, pa_pre), pb = apply_xf(s.p[1].xf, pb_pre);
+      const int np = params_of(kind);
+      const float pc_pre = np > 2 ? eval_param_pre(s.p[2], d, tab, val) : 0.0f;
+      const float pd_pre = np > 3 ? eval_param_pre(s.p[3], d, tab, val) : 0.0f;
+      const float pc = np > 2 ? apply_xf(s.p[2].xf, pc_pre) : 0.0f, pd = np > 3 ? apply_xf(s.p[3].xf, pd_pre) : 0.0f;
       const float x = s.slot >= 0 ? val(s.slot + d) : tab[s.obs_off + d];
-      score += elem_logpdf(kind, x, pa, pb);
-      float gx, ga, gb;
-      dlogpdf(kind, x, pa, pb, gx, ga, gb);
+      score += elem_logpdf(kind, x, pa, pb, pc, pd);
+      float gx, gpar[4];
+      dlogpdf(kind, x, pa, pb, pc, pd, gx, gpar);
       if (s.slot >= 0) g[(int64_t)(s.slot + d) * n + i] += gx;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      const float pre[4] = {pa_pre, pb_pre, pc_pre, pd_pre};
+      for (int q = 0; q < np; ++q) {
         const gjx_param& p = s.p[q];
-        float gp = q == 0 ? ga : gb;
+        float gp = gpar[q];
         if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE)) continue;
-        if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, q == 0 ? pa_pre : pb_pre);
+        if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, pre[q]);
         if (p.op == GJX_P_VALUE) {
           g[(int64_t)(p.slot + (p.len == 1 ? 0 : d % p.len)) * n + i] += gp;
         } else {
@@ -513,8 +588,9 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     const gjx_site& s = prog->sites[j];
     if (s.mode == GJX_MODE_SAMPLE) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_*)");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
-                                              s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS))
-      return gjx_fail(GJX_EINVAL, "gjx_hmc: only float32 sites can be selected (hmc.py:49-65)");
+                                              s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
+                                              s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))
+      return gjx_fail(GJX_EINVAL, "gjx_hmc: only unconstrained float32 sites can be selected (hmc.py:49-65)");
   }
   {
     LogregArgs la; int P;

@@ -130,10 +130,45 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         if (LDSV) vals_s[slot * 256 + threadIdx.x] = v;
         if (active) ch[(int64_t)slot * K + i] = v;
       }
+    } else if (kind == GJX_DIRICHLET) {
+      // one site, dim values on the simplex: x = softmax(log-gamma variates); density couples all elements
+      const int n = s.dim;
+      auto put = [&](int d, float v) {
+        if (slot >= 0) {
+          if (LDSV) vals_s[(slot + d) * 256 + threadIdx.x] = v;
+          else if (active) ch[(int64_t)(slot + d) * K + i] = v;
+        }
+      };
+      auto get = [&](int d) -> float {
+        if (mode == GJX_MODE_OBS_TAB) return tab[s.obs_off + d];
+        return LDSV ? vals_s[(slot + d) * 256 + threadIdx.x] : ch[(int64_t)(slot + d) * K + ii];
+      };
+      if (mode == GJX_MODE_SAMPLE) {
+        float mx = -INFINITY;
+        for (int d = 0; d < n; ++d) {
+          const float lg = log_gamma_variate<RNG>(bs, (uint32_t)(d * kGammaNDraw), eval_param(s.p[0], d, tab, val));
+          put(d, lg);
+          mx = fmaxf(mx, lg);
+        }
+        float se = 0.0f;
+        for (int d = 0; d < n; ++d) se += fast_exp(get(d) - mx);
+        const float lse = mx + fast_log(se);
+        for (int d = 0; d < n; ++d) put(d, fast_exp(get(d) - lse));
+      }
+      float sa = 0.0f;
+      for (int d = 0; d < n; ++d) {
+        const float al = eval_param(s.p[0], d, tab, val);
+        const float v = get(d);
+        sa += al;
+        lp += ((al - 1.0f) == 0.0f ? 0.0f : (al - 1.0f) * fast_log(v)) - lgammaf(al);
+        if (LDSV && slot >= 0 && mode != GJX_MODE_OBS_SLOT && active) ch[(int64_t)(slot + d) * K + i] = v;
+      }
+      lp += lgammaf(sa);
     } else {
       // the element loop is instantiated per distribution kind so that the sampler / density switches fold away
       auto elems = [&](auto kind_c) {
         constexpr int KIND = decltype(kind_c)::value;
+        constexpr int NP = KIND == GJX_TRUNCATED_NORMAL ? 4 : (KIND == GJX_STUDENT_T ? 3 : 2);
         const int nd = draws_per_elem(KIND);
         const int dim = s.dim;
         const bool b_inv = s.p[1].op == GJX_P_CONST && s.p[1].len == 1 && s.p[1].xf == GJX_XF_NONE;  // wave-uniform
@@ -141,11 +176,13 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         for (int d = 0; d < dim; ++d) {
           const float pa = eval_param(s.p[0], d, tab, val);
           const float pb = b_inv ? pb0 : eval_param(s.p[1], d, tab, val);
+          const float pc = NP > 2 ? eval_param(s.p[2], d, tab, val) : 0.0f;
+          const float pd = NP > 3 ? eval_param(s.p[3], d, tab, val) : 0.0f;
           float v;
-          if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb);
+          if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
           else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
           else v = val(slot + d);
-          lp += elem_logpdf(KIND, v, pa, pb);
+          lp += elem_logpdf(KIND, v, pa, pb, pc, pd);
           if (slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
             if (LDSV) vals_s[(slot + d) * 256 + threadIdx.x] = v;
             if (active) ch[(int64_t)(slot + d) * K + i] = v;
@@ -156,7 +193,9 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       switch (kind) {
         GJX_KIND(GJX_NORMAL) GJX_KIND(GJX_MVNORMAL_DIAG) GJX_KIND(GJX_FLIP) GJX_KIND(GJX_BERNOULLI_LOGITS) GJX_KIND(GJX_BETA)
         GJX_KIND(GJX_UNIFORM) GJX_KIND(GJX_EXPONENTIAL) GJX_KIND(GJX_HALF_NORMAL) GJX_KIND(GJX_LAPLACE) GJX_KIND(GJX_LOG_NORMAL)
-        GJX_KIND(GJX_CAUCHY) GJX_KIND(GJX_GAMMA)
+        GJX_KIND(GJX_CAUCHY) GJX_KIND(GJX_GAMMA) GJX_KIND(GJX_STUDENT_T) GJX_KIND(GJX_TRUNCATED_NORMAL) GJX_KIND(GJX_POISSON)
+        GJX_KIND(GJX_GEOMETRIC) GJX_KIND(GJX_GUMBEL) GJX_KIND(GJX_HALF_CAUCHY) GJX_KIND(GJX_INVERSE_GAMMA) GJX_KIND(GJX_WEIBULL)
+        GJX_KIND(GJX_LOGIT_NORMAL) GJX_KIND(GJX_CHI2)
         default: lp = __builtin_nanf(""); break;
       }
 #undef GJX_KIND

@@ -193,7 +193,7 @@ class SiteVal(Sym):
         self.addr, self.dim, self.kind = addr, dim, kind
 
     def _affine(self) -> Affine:
-        if self.kind in A.DISCRETE_KINDS and self.kind not in (A.FLIP, A.BERNOULLI_LOGITS):
+        if self.kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS):
             raise NotSupportedInModelBody("arithmetic on a categorical index; use take(table, idx)")
         return Affine(self, np.eye(self.dim), np.zeros(self.dim))
 
@@ -868,6 +868,26 @@ class _Bernoulli(Distribution):
         return A.BERNOULLI_LOGITS, [args[0]]
 
 
+class _Geometric(_VectorDist):
+    """tfd.Geometric(logits=None, probs=None): a bare argument is LOGITS (the reference passes tfd.Geometric through
+    unwrapped, tensorflow_probability/__init__.py:169)."""
+
+    def _params(self, args, kwargs):
+        if "probs" in kwargs:
+            return self.kind, [kwargs["probs"]]
+        l = kwargs["logits"] if "logits" in kwargs else (args[0] if len(args) == 1 else None)
+        if l is None:
+            raise TypeError("geometric(logits) / geometric(probs=...) / geometric(logits=...)")
+        return self.kind, [sigmoid(l)]
+
+
+class _Poisson(_VectorDist):
+    def _params(self, args, kwargs):
+        if "log_rate" in kwargs:
+            return self.kind, [exp(kwargs["log_rate"])]
+        return super()._params(args, kwargs)
+
+
 normal = _VectorDist("normal", A.NORMAL, ("loc", "scale"))
 mv_normal_diag = _VectorDist("mv_normal_diag", A.MVNORMAL_DIAG, ("loc", "scale_diag"))
 flip = _VectorDist("flip", A.FLIP, ("p",))
@@ -881,3 +901,14 @@ laplace = _VectorDist("laplace", A.LAPLACE, ("loc", "scale"))
 log_normal = _VectorDist("log_normal", A.LOG_NORMAL, ("loc", "scale"))
 cauchy = _VectorDist("cauchy", A.CAUCHY, ("loc", "scale"))
 gamma = Distribution("gamma", A.GAMMA, ("concentration", "rate"))
+student_t = _VectorDist("student_t", A.STUDENT_T, ("df", "loc", "scale"))
+truncated_normal = _VectorDist("truncated_normal", A.TRUNCATED_NORMAL, ("loc", "scale", "low", "high"))
+poisson = _Poisson("poisson", A.POISSON, ("rate",))
+geometric = _Geometric("geometric", A.GEOMETRIC, ("probs",))
+dirichlet = _VectorDist("dirichlet", A.DIRICHLET, ("concentration",))
+gumbel = _VectorDist("gumbel", A.GUMBEL, ("loc", "scale"))
+half_cauchy = _VectorDist("half_cauchy", A.HALF_CAUCHY, ("loc", "scale"))
+inverse_gamma = _VectorDist("inverse_gamma", A.INVERSE_GAMMA, ("concentration", "scale"))
+weibull = _VectorDist("weibull", A.WEIBULL, ("concentration", "scale"))
+logit_normal = _VectorDist("logit_normal", A.LOGIT_NORMAL, ("loc", "scale"))
+chi2 = _VectorDist("chi2", A.CHI2, ("df",))

@@ -90,7 +90,8 @@ class HMC(EditRequest):
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         from .. import kernels
         shared, rows = _rows_and_shared(tr)
-        sel = [s.addr for s in tr.prog.site_list.sites if self.selection.check(s.addr)]
+        # float leaves only, as the reference's selection_gradient (hmc.py:49-65, 90-96)
+        sel = [s.addr for s in tr.prog.site_list.sites if self.selection.check(s.addr) and s.kind not in A.NO_GRADIENT_KINDS]
         prog, _, _ = tr.gen_fn.pack(tr.args, shared, False, selected=sel, rng_mode=tr.prog.rng_mode,
                                     per_particle=tuple(rows))
         assert prog.slot_of == tr.prog.slot_of

@@ -87,6 +87,8 @@ N_PARAMS = {
     A.NORMAL: 2, A.FLIP: 1, A.BERNOULLI_LOGITS: 1, A.BETA: 2, A.CATEGORICAL_LOGITS: 1,
     A.CATEGORICAL_PROBS: 1, A.UNIFORM: 2, A.MVNORMAL_DIAG: 2, A.EXPONENTIAL: 1, A.HALF_NORMAL: 1,
     A.LAPLACE: 2, A.LOG_NORMAL: 2, A.CAUCHY: 2, A.GAMMA: 2,
+    A.STUDENT_T: 3, A.TRUNCATED_NORMAL: 4, A.POISSON: 1, A.GEOMETRIC: 1, A.DIRICHLET: 1, A.GUMBEL: 2, A.HALF_CAUCHY: 2,
+    A.INVERSE_GAMMA: 2, A.WEIBULL: 2, A.LOGIT_NORMAL: 2, A.CHI2: 1,
 }
 
 
@@ -119,7 +121,7 @@ class SiteList:
             elif p0.op == A.P_GATHER:
                 ncat = int(p0.values.shape[1])
             elif p0.op == A.P_AFFINE:
-                ncat = int(p0.matrix.shape[0])
+                ncat = int((p0.terms[0][1] if p0.terms else p0.matrix).shape[0])
             else:
                 ncat = int(p0.length)
             dim = 1
@@ -133,7 +135,7 @@ class SiteList:
                 elif p.op == A.P_GATHER:
                     dim = max(dim, int(p.values.shape[1]))
                 elif p.op == A.P_AFFINE:
-                    dim = max(dim, int(p.matrix.shape[0]))
+                    dim = max(dim, int((p.terms[0][1] if p.terms else p.matrix).shape[0]))
         site = Site(addr, kind, ps, int(dim), ncat, self.n_slots)
         self.sites.append(site)
         self.n_slots += int(dim)

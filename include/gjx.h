@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 1
+#define GJX_ABI_VERSION 2
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -61,7 +61,18 @@ enum {
   GJX_LOG_NORMAL = 12,        /* log_normal(loc, scale)        :219                         */
   GJX_CAUCHY = 13,            /* cauchy(loc, scale)            :110                         */
   GJX_GAMMA = 14,             /* gamma(concentration, rate)    :164                         */
-  GJX_KIND_MAX = 15
+  GJX_STUDENT_T = 15,         /* student_t(df, loc, scale)     :279                         */
+  GJX_TRUNCATED_NORMAL = 16,  /* truncated_normal(loc, scale, low, high) :289               */
+  GJX_POISSON = 17,           /* poisson(rate)                 :264  (value stored as float) */
+  GJX_GEOMETRIC = 18,         /* geometric(probs)              :169  (failures before success)*/
+  GJX_DIRICHLET = 19,         /* dirichlet(concentration[dim]) :125  (one site, dim scalars) */
+  GJX_GUMBEL = 20,            /* gumbel(loc, scale)            :174                         */
+  GJX_HALF_CAUCHY = 21,       /* half_cauchy(loc, scale)       :179                         */
+  GJX_INVERSE_GAMMA = 22,     /* inverse_gamma(concentration, scale) :194                   */
+  GJX_WEIBULL = 23,           /* weibull(concentration, scale) :309                         */
+  GJX_LOGIT_NORMAL = 24,      /* logit_normal(loc, scale)      :224                         */
+  GJX_CHI2 = 25,              /* chi2(df)                      :120                         */
+  GJX_KIND_MAX = 26
 };
 
 /* parameter expression forms (what the model body computes between sites) */
@@ -95,7 +106,7 @@ typedef struct gjx_param {
   int32_t pad_;
 } gjx_param; /* 32 bytes */
 
-#define GJX_MAX_PARAMS 2
+#define GJX_MAX_PARAMS 4
 
 typedef struct gjx_site {
   int32_t kind;    /* GJX_NORMAL ...                                                        */
@@ -107,7 +118,7 @@ typedef struct gjx_site {
   int32_t flags;   /* GJX_SITE_*                                                            */
   int32_t pad_;
   gjx_param p[GJX_MAX_PARAMS];
-} gjx_site; /* 96 bytes */
+} gjx_site; /* 160 bytes */
 
 /* random-stream layouts.  Both are Threefry-2x32-20 counter streams and both give results that are
  * independent of how particles are sharded over GPUs (the counter carries the GLOBAL particle index).

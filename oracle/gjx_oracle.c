@@ -194,6 +194,7 @@ float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
 
 /* Marsaglia & Tsang (2000) gamma sampler in log space; the draw budget per gamma variate is
  * fixed so that element indices are a pure function of (variate, iteration). */
+#define POISSON_TRIES 16
 #define GAMMA_MAXIT 32
 #define GAMMA_NDRAW (4 * GAMMA_MAXIT + 2)
 /* draw schedule of one gamma variate (element indices relative to `base`): iteration t takes its normal
@@ -263,6 +264,60 @@ static float eval_param(const gjx_param* p, int d, const float* tab, const float
 }
 
 /* log-density of ONE scalar element (TFP 0.23 log_prob expressions) */
+static float std_normal_cdf(float z) { return 0.5f * erfcf(-z / 1.41421356f); }
+/* Phi(hi) - Phi(lo), through the upper tail when both bounds are positive */
+static float normal_interval_mass(float lo, float hi) {
+  if (lo > 0.0f) return std_normal_cdf(-lo) - std_normal_cdf(-hi);
+  return std_normal_cdf(hi) - std_normal_cdf(lo);
+}
+static int params_of(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : 2); }
+
+/* parameter order follows the reference's constructor arguments (tfp wrappers, tensorflow_probability/__init__.py) */
+static float elem_logpdf4(int kind, float x, float a, float b, float c, float d) {
+  switch (kind) {
+    case GJX_STUDENT_T: { /* tfd.StudentT(df=a, loc=b, scale=c) */
+      float y = (x - b) / c;
+      return -0.5f * (a + 1.0f) * log1pf(y * y / a) - logf(c) - 0.5f * logf(a) - 0.5f * LOG_PI +
+             lgammaf(0.5f * (a + 1.0f)) - lgammaf(0.5f * a);
+    }
+    case GJX_TRUNCATED_NORMAL: { /* tfd.TruncatedNormal(loc=a, scale=b, low=c, high=d) */
+      if (x < c || x > d) return -INFINITY;
+      float z = (x - a) / b;
+      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - logf(normal_interval_mass((c - a) / b, (d - a) / b));
+    }
+    case GJX_POISSON: /* tfd.Poisson(rate=a) */
+      return (x < 0.0f || x != floorf(x)) ? -INFINITY : (xlogyf(x, a) - a - lgammaf(x + 1.0f));
+    case GJX_GEOMETRIC: /* tfd.Geometric(probs=a): number of failures before the first success */
+      return (x < 0.0f || x != floorf(x)) ? -INFINITY : (xlog1pyf(x, -a) + logf(a));
+    case GJX_GUMBEL: {
+      float z = (x - a) / b;
+      return -(z + expf(-z)) - logf(b);
+    }
+    case GJX_HALF_CAUCHY: {
+      float z = (x - a) / b;
+      return x < a ? -INFINITY : (logf(2.0f / 3.14159265f) - logf(b) - log1pf(z * z));
+    }
+    case GJX_INVERSE_GAMMA: /* concentration a, scale b */
+      return x <= 0.0f ? -INFINITY : (a * logf(b) - lgammaf(a) - (a + 1.0f) * logf(x) - b / x);
+    case GJX_WEIBULL: { /* concentration a, scale b */
+      if (x < 0.0f) return -INFINITY;
+      float lr = logf(x / b);
+      return logf(a / b) + xlogyf(a - 1.0f, x / b) - expf(a * lr);
+    }
+    case GJX_LOGIT_NORMAL: {
+      if (!(x > 0.0f && x < 1.0f)) return -INFINITY;
+      float lx = logf(x), l1 = log1pf(-x);
+      float z = ((lx - l1) - a) / b;
+      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - lx - l1;
+    }
+    case GJX_CHI2: { /* df a: gamma(a/2, rate 1/2) */
+      float h = 0.5f * a;
+      return x <= 0.0f ? -INFINITY : (xlogyf(h - 1.0f, x) - 0.5f * x - h * logf(2.0f) - lgammaf(h));
+    }
+    default: return NAN;
+  }
+}
+
 static float elem_logpdf(int kind, float x, float a, float b) {
   switch (kind) {
     case GJX_NORMAL:
@@ -305,8 +360,75 @@ static float elem_logpdf(int kind, float x, float a, float b) {
 static int draws_per_elem(int kind) {
   switch (kind) {
     case GJX_BETA: return 2 * GAMMA_NDRAW;
-    case GJX_GAMMA: return GAMMA_NDRAW;
+    case GJX_GAMMA:
+    case GJX_DIRICHLET:
+    case GJX_INVERSE_GAMMA:
+    case GJX_CHI2: return GAMMA_NDRAW;
+    case GJX_STUDENT_T: return GAMMA_NDRAW + 2;
+    case GJX_POISSON: return 2 * POISSON_TRIES + 2;
     default: return 1;
+  }
+}
+
+/* Poisson(lam): inversion by sequential search on one uniform below 10; Hormann's PTRS (1993) with a fixed
+ * budget of tries above.  Element schedule: c for the inversion uniform, c+2+2t / c+3+2t for try t. */
+static float poisson_variate(const ostream* sk, uint32_t c, float lam) {
+  if (lam < 10.0f) {
+    float u = bits_to_unit(elem_bits(sk, c));
+    float p = expf(-lam), cdf = p;
+    int k = 0;
+    while (u > cdf && k < 96) {
+      ++k;
+      p *= lam / (float)k;
+      cdf += p;
+    }
+    return (float)k;
+  }
+  float slam = sqrtf(lam), loglam = logf(lam);
+  float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+  float inv_alpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.0f);
+  for (int t = 0; t < POISSON_TRIES; ++t) {
+    float U = bits_to_unit(elem_bits(sk, c + 2 + 2 * t)) - 0.5f;
+    float V = uniform_from_bits(elem_bits(sk, c + 3 + 2 * t), F32_TINY, 1.0f);
+    float us = 0.5f - fabsf(U);
+    float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
+    if (us >= 0.07f && V <= vr) return k;
+    if (k < 0.0f || (us < 0.013f && V > us)) continue;
+    if (logf(V) + logf(inv_alpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;
+  }
+  return floorf(lam);
+}
+
+static float elem_sample4(int kind, const ostream* sk, uint32_t c, float a, float b, float p3, float p4) {
+  switch (kind) {
+    case GJX_STUDENT_T: { /* z * sqrt(df / chi2_df), chi2_df = 2 Gamma(df/2, 1) */
+      float z = stream_normal(sk, c);
+      float lg = log_gamma_variate(sk, c + 2, 0.5f * a);
+      return b + p3 * z * expf(0.5f * (logf(0.5f * a) - lg));
+    }
+    case GJX_TRUNCATED_NORMAL: {
+      float lo = (p3 - a) / b, hi = (p4 - a) / b;
+      float u = bits_to_unit(elem_bits(sk, c));
+      float z;
+      if (lo > 0.0f) {
+        float q = std_normal_cdf(-lo) - u * (std_normal_cdf(-lo) - std_normal_cdf(-hi));
+        z = -1.41421356f * erfinv_f32(2.0f * q - 1.0f);
+      } else {
+        float q = std_normal_cdf(lo) + u * (std_normal_cdf(hi) - std_normal_cdf(lo));
+        z = 1.41421356f * erfinv_f32(2.0f * q - 1.0f);
+      }
+      float x = a + b * z;
+      return x < p3 ? p3 : (x > p4 ? p4 : x);
+    }
+    case GJX_POISSON: return poisson_variate(sk, c, a);
+    case GJX_GEOMETRIC: return floorf(logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)) / log1pf(-a));
+    case GJX_GUMBEL: return a - b * logf(-logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)));
+    case GJX_HALF_CAUCHY: return a + b * tanf(0.5f * 3.14159265f * bits_to_unit(elem_bits(sk, c)));
+    case GJX_INVERSE_GAMMA: return b * expf(-log_gamma_variate(sk, c, a));
+    case GJX_WEIBULL: return b * expf(logf(-log1pf(-bits_to_unit(elem_bits(sk, c)))) / a);
+    case GJX_LOGIT_NORMAL: return sigmoidf_(a + b * stream_normal(sk, c));
+    case GJX_CHI2: return 2.0f * expf(log_gamma_variate(sk, c, 0.5f * a));
+    default: return NAN;
   }
 }
 
@@ -405,16 +527,43 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
         lp = l - lse;
       }
       if (s->slot >= 0) vals[s->slot] = v;
+    } else if (s->kind == GJX_DIRICHLET) { /* tfd.Dirichlet(concentration): gamma variates normalised; joint density */
+      int n = s->dim;
+      float x[256];
+      if (n > 256) n = 256;
+      if (s->mode == GJX_MODE_SAMPLE) {
+        float mx = -INFINITY, se = 0.0f;
+        for (int d = 0; d < n; ++d) {
+          x[d] = log_gamma_variate(sk, (uint32_t)(d * GAMMA_NDRAW), eval_param(&s->p[0], d, tab, vals));
+          if (x[d] > mx) mx = x[d];
+        }
+        for (int d = 0; d < n; ++d) se += expf(x[d] - mx);
+        for (int d = 0; d < n; ++d) x[d] = expf(x[d] - (mx + logf(se)));
+      } else {
+        for (int d = 0; d < n; ++d) x[d] = s->mode == GJX_MODE_OBS_TAB ? tab[s->obs_off + d] : vals[s->slot + d];
+      }
+      float sa = 0.0f;
+      for (int d = 0; d < n; ++d) {
+        float al = eval_param(&s->p[0], d, tab, vals);
+        sa += al;
+        lp += xlogyf(al - 1.0f, x[d]) - lgammaf(al);
+        if (s->slot >= 0) vals[s->slot + d] = x[d];
+      }
+      lp += lgammaf(sa);
     } else {
       int nd = draws_per_elem(s->kind);
+      int np = s->kind >= GJX_STUDENT_T ? params_of(s->kind) : 2;
       for (int d = 0; d < s->dim; ++d) {
         float a = eval_param(&s->p[0], d, tab, vals);
         float b = eval_param(&s->p[1], d, tab, vals);
+        float c = np > 2 ? eval_param(&s->p[2], d, tab, vals) : 0.0f;
+        float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
+        int wide = s->kind >= GJX_STUDENT_T;
         float v;
-        if (s->mode == GJX_MODE_SAMPLE) v = elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
+        if (s->mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
         else if (s->mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
         else v = vals[s->slot + d];
-        lp += elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
+        lp += wide ? elem_logpdf4(s->kind, v, a, b, c, e) : elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
         if (s->slot >= 0) vals[s->slot + d] = v;
       }
     }
@@ -652,6 +801,36 @@ static void dlogpdf(int kind, float x, float a, float b, float* dx, float* da, f
   }
 }
 
+/* gradients of the four-parameter forms; g[0..3] = d/d(a,b,c,d); NAN where a digamma would be needed */
+static void dlogpdf4(int kind, float x, float a, float b, float c, float d, float* dx, float* g) {
+  g[0] = g[1] = g[2] = g[3] = 0.0f;
+  *dx = 0.0f;
+  switch (kind) {
+    case GJX_STUDENT_T: {
+      float y = (x - b) / c;
+      float w = (a + 1.0f) * y / (a + y * y);
+      *dx = -w / c; g[1] = w / c; g[2] = (w * y - 1.0f) / c; g[0] = NAN;
+      return;
+    }
+    case GJX_TRUNCATED_NORMAL: {
+      float z = (x - a) / b, lo = (c - a) / b, hi = (d - a) / b;
+      float Z = normal_interval_mass(lo, hi);
+      float plo = 0.39894228f * expf(-0.5f * lo * lo) / (Z * b), phi = 0.39894228f * expf(-0.5f * hi * hi) / (Z * b);
+      *dx = -z / b; g[0] = z / b + (phi - plo); g[1] = (z * z - 1.0f) / b + (hi * phi - lo * plo); g[2] = plo; g[3] = -phi;
+      return;
+    }
+    case GJX_POISSON: g[0] = x / a - 1.0f; return;
+    case GJX_GEOMETRIC: g[0] = 1.0f / a - x / (1.0f - a); return;
+    case GJX_GUMBEL: { float z = (x - a) / b; float e1 = 1.0f - expf(-z); *dx = -e1 / b; g[0] = e1 / b; g[1] = (e1 * z - 1.0f) / b; return; }
+    case GJX_HALF_CAUCHY: { float z = (x - a) / b; float q = 2.0f * z / (1.0f + z * z); *dx = -q / b; g[0] = q / b; g[1] = (q * z - 1.0f) / b; return; }
+    case GJX_INVERSE_GAMMA: *dx = -(a + 1.0f) / x + b / (x * x); g[1] = a / b - 1.0f / x; g[0] = NAN; return;
+    case GJX_WEIBULL: { float lr = logf(x / b); float t = expf(a * lr); *dx = ((a - 1.0f) - a * t) / x; g[1] = a * (t - 1.0f) / b; g[0] = 1.0f / a + lr * (1.0f - t); return; }
+    case GJX_LOGIT_NORMAL: { float z = (logf(x) - log1pf(-x) - a) / b; *dx = -z / b / (x * (1.0f - x)) - 1.0f / x + 1.0f / (1.0f - x); g[0] = z / b; g[1] = (z * z - 1.0f) / b; return; }
+    case GJX_CHI2: *dx = (0.5f * a - 1.0f) / x - 0.5f; g[0] = NAN; return;
+    default: return;
+  }
+}
+
 static float xf_deriv(int xf, float pre) { /* d xf(v) / d v at pre-transform value */
   switch (xf) {
     case GJX_XF_EXP: return expf(pre);
@@ -707,10 +886,32 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
       score += l - (mx + (float)log(se));
       continue; /* integer site: no gradient through it (hmc.py:49-65) */
     }
+    if (s->kind == GJX_DIRICHLET) { /* scored, never differentiated (simplex-constrained value) */
+      float sa = 0.0f;
+      for (int d = 0; d < s->dim; ++d) {
+        float al = eval_param(&s->p[0], d, tab, vals);
+        float x = s->slot >= 0 ? vals[s->slot + d] : tab[s->obs_off + d];
+        sa += al;
+        score += xlogyf(al - 1.0f, x) - lgammaf(al);
+      }
+      score += lgammaf(sa);
+      continue;
+    }
     for (int d = 0; d < s->dim; ++d) {
       float a = eval_param(&s->p[0], d, tab, vals);
       float b = eval_param(&s->p[1], d, tab, vals);
       float x = s->slot >= 0 ? vals[s->slot + d] : tab[s->obs_off + d];
+      if (s->kind >= GJX_STUDENT_T) {
+        int np = params_of(s->kind);
+        float c = np > 2 ? eval_param(&s->p[2], d, tab, vals) : 0.0f;
+        float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
+        float gx, g4[4];
+        score += elem_logpdf4(s->kind, x, a, b, c, e);
+        dlogpdf4(s->kind, x, a, b, c, e, &gx, g4);
+        if (s->slot >= 0) grad[s->slot + d] += gx;
+        for (int q = 0; q < np; ++q) param_backprop(&s->p[q], d, g4[q], tab, vals, grad);
+        continue;
+      }
       score += elem_logpdf(s->kind, x, a, b);
       float gx, ga, gb;
       dlogpdf(s->kind, x, a, b, &gx, &ga, &gb);

@@ -73,7 +73,57 @@ def main():
     for a, rate in [(0.5, 1), (1, 2), (3, 0.5), (20, 4)]:
         for x in [0.01, 0.7, 3.0, 12.0]:
             add("gamma", x, a, rate, st.gamma.logpdf(x, a, scale=1 / rate))
+    # ---- wider set: three/four-parameter forms carry "c", "d" ----
+    def add4(kind, x, a, b, c, d, lp):
+        rows.append(dict(kind=kind, x=float(x), a=float(a), b=float(b), c=float(c), d=float(d),
+                         lp=(None if not np.isfinite(lp) else float(lp)), neg_inf=bool(np.isneginf(lp))))
+    for df, loc, sc in [(1.0, 0.0, 1.0), (3.5, -1.0, 2.0), (30.0, 2.0, 0.1)]:
+        for x in [loc - 6 * sc, loc - sc, loc, loc + 0.4 * sc, loc + 20 * sc]:
+            x, df_, l_, s_ = f32(x), f32(df), f32(loc), f32(sc)
+            add4("student_t", x, df_, l_, s_, 0, st.t.logpdf(x, df_, l_, s_))
+    for loc, sc, lo, hi in [(0.0, 1.0, -1.0, 2.0), (1.0, 2.0, 2.0, 7.0), (-3.0, 0.5, -10.0, -3.5), (0.0, 1.0, 3.0, 5.0)]:
+        for x in [lo - 0.1, lo, 0.5 * (lo + hi), lo + 0.9 * (hi - lo), hi, hi + 0.1]:
+            x, l_, s_, lo_, hi_ = f32(x), f32(loc), f32(sc), f32(lo), f32(hi)
+            add4("truncated_normal", x, l_, s_, lo_, hi_, st.truncnorm.logpdf(x, (lo_ - l_) / s_, (hi_ - l_) / s_, l_, s_))
+    for rate in [0.3, 4.0, 60.0]:
+        for x in [-1.0, 0.0, 1.0, 5.0, 70.0, 2.5]:
+            lp = st.poisson.logpmf(x, f32(rate)) if x == int(x) else -np.inf
+            add("poisson", x, f32(rate), 0, lp)
+    for pr in [0.05, 0.5, 0.9]:
+        for x in [-1.0, 0.0, 1.0, 7.0, 40.0]:
+            add("geometric", x, f32(pr), 0, st.geom.logpmf(x + 1, f32(pr)))        # scipy counts trials, TFP failures
+    for loc, sc in [(0.0, 1.0), (2.0, 0.3)]:
+        for x in [loc - 2 * sc, loc, loc + 5 * sc]:
+            add("gumbel", f32(x), f32(loc), f32(sc), st.gumbel_r.logpdf(f32(x), f32(loc), f32(sc)))
+    for loc, sc in [(0.0, 1.0), (1.0, 4.0)]:
+        for x in [loc - 0.5, loc, loc + 0.2 * sc, loc + 30 * sc]:
+            add("half_cauchy", f32(x), f32(loc), f32(sc), st.halfcauchy.logpdf(f32(x), f32(loc), f32(sc)))
+    for a, b in [(0.7, 1.0), (3.0, 2.0), (12.0, 0.5)]:
+        for x in [0.02, 0.5, 3.0]:
+            add("inverse_gamma", f32(x), f32(a), f32(b), st.invgamma.logpdf(f32(x), f32(a), scale=f32(b)))
+    for k, lam in [(0.8, 1.0), (1.0, 2.0), (3.5, 0.5)]:
+        for x in [-0.1, 0.05, 0.7, 4.0]:
+            add("weibull", f32(x), f32(k), f32(lam), st.weibull_min.logpdf(f32(x), f32(k), scale=f32(lam)))
+    for mu, sd in [(0.0, 1.0), (1.5, 0.4)]:
+        for x in [0.001, 0.3, 0.5, 0.97]:
+            x_ = float(f32(x))
+            lg = math.log(x_) - math.log1p(-x_)
+            add("logit_normal", x_, f32(mu), f32(sd), st.norm.logpdf(lg, f32(mu), f32(sd)) - math.log(x_) - math.log1p(-x_))
+    for df in [1.0, 2.0, 7.5, 40.0]:
+        for x in [0.05, 1.0, 9.0, 60.0]:
+            add("chi2", f32(x), f32(df), 0, st.chi2.logpdf(f32(x), f32(df)))
     dump("logpdf_table.json", rows)
+
+    dr = []
+    rng_d = np.random.default_rng(5)
+    for alpha in [[1.0, 1.0, 1.0], [0.5, 2.0, 3.0, 0.7], [10.0, 20.0], [2.0] * 8]:
+        al = np.asarray(alpha, np.float32).astype(np.float64)
+        for _ in range(3):
+            x = rng_d.dirichlet(al)
+            x = x.astype(np.float32).astype(np.float64)
+            x = x / x.sum()                                 # scipy insists on the simplex; the kernels see float32(x)
+            dr.append(dict(alpha=al.tolist(), x=x.tolist(), lp=float(st.dirichlet.logpdf(x, al))))
+    dump("dirichlet_table.json", dr)
 
     cat = []
     rng = np.random.default_rng(0)

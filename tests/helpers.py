@@ -7,14 +7,17 @@ from genjax_amd import workloads as W
 
 KIND = dict(normal=A.NORMAL, flip=A.FLIP, bernoulli_logits=A.BERNOULLI_LOGITS, beta=A.BETA, uniform=A.UNIFORM,
             exponential=A.EXPONENTIAL, half_normal=A.HALF_NORMAL, laplace=A.LAPLACE, log_normal=A.LOG_NORMAL,
-            cauchy=A.CAUCHY, gamma=A.GAMMA, mv_normal_diag=A.MVNORMAL_DIAG)
+            cauchy=A.CAUCHY, gamma=A.GAMMA, mv_normal_diag=A.MVNORMAL_DIAG, student_t=A.STUDENT_T,
+            truncated_normal=A.TRUNCATED_NORMAL, poisson=A.POISSON, geometric=A.GEOMETRIC, dirichlet=A.DIRICHLET, gumbel=A.GUMBEL,
+            half_cauchy=A.HALF_CAUCHY, inverse_gamma=A.INVERSE_GAMMA, weibull=A.WEIBULL, logit_normal=A.LOGIT_NORMAL, chi2=A.CHI2)
 NPAR = dict(normal=2, flip=1, bernoulli_logits=1, beta=2, uniform=2, exponential=1, half_normal=1, laplace=2,
-            log_normal=2, cauchy=2, gamma=2, mv_normal_diag=2)
+            log_normal=2, cauchy=2, gamma=2, mv_normal_diag=2, student_t=3, truncated_normal=4, poisson=1, geometric=1,
+            dirichlet=1, gumbel=2, half_cauchy=2, inverse_gamma=2, weibull=2, logit_normal=2, chi2=1)
 
 
-def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT):
+def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT, c=None, d=None):
     sl = SiteList()
-    params = [a] if NPAR[kind] == 1 else [a, b]
+    params = [a, b, c, d][: NPAR[kind]]
     sl.add("v", KIND[kind], params)
     if obs is None:
         return PackedProgram(sl, rng_mode=rng)
@@ -71,3 +74,27 @@ def zoo(rng=A.RNG_FLAT, observed=()):
 
 def logreg(N=64, P=4, rng=A.RNG_FLAT, seed=0):
     return W.logreg_program(N, P, rng, seed)
+
+
+def zoo2(rng=A.RNG_FLAT, observed=()):
+    """The wider distribution set, one site per kind, chained through parameter forms."""
+    sl = SiteList()
+    sl.add("t0", A.STUDENT_T, [4.0, 0.5, 1.5])
+    sl.add("tn", A.TRUNCATED_NORMAL, [Param.value("t0", xf=A.XF_SIGMOID), 0.8, -0.5, 2.0])
+    sl.add("po", A.POISSON, [3.5])
+    sl.add("pl", A.POISSON, [Param.value("tn", xf=A.XF_EXP)])
+    sl.add("pb", A.POISSON, [40.0])                                    # transformed-rejection branch
+    sl.add("ge", A.GEOMETRIC, [0.3])
+    sl.add("di", A.DIRICHLET, [np.array([0.8, 2.0, 3.0], np.float32)], dim=3)
+    sl.add("gu", A.GUMBEL, [Param.value("di", length=1, elem=1), 0.7])
+    sl.add("hc", A.HALF_CAUCHY, [0.0, Param.value("gu", xf=A.XF_SOFTPLUS)])
+    sl.add("ig", A.INVERSE_GAMMA, [3.0, 2.0])
+    sl.add("we", A.WEIBULL, [1.5, Param.value("ig")])
+    sl.add("lo", A.LOGIT_NORMAL, [Param.affine(np.array([[0.1]], np.float32), "po"), 0.6])
+    sl.add("c2", A.CHI2, [5.0])
+    sl.add("t1", A.STUDENT_T, [3.0, Param.value("lo"), Param.value("c2", xf=A.XF_SOFTPLUS)])
+    sl.add("tr", A.TRUNCATED_NORMAL, [0.0, 1.0, 2.5, 6.0])            # far upper tail
+    sl.add("n9", A.NORMAL, [Param.value("t1", xf=A.XF_SIGMOID), 0.3])
+    obs_vals = dict(n9=0.4, di=[0.2, 0.3, 0.5], po=2.0, tn=0.7)
+    modes = {a: A.MODE_OBS_TAB for a in observed}
+    return PackedProgram(sl, modes, {a: obs_vals[a] for a in observed}, rng_mode=rng)

@@ -571,3 +571,52 @@ class TestNestedCalls:
         sign, logdet = np.linalg.slogdet(cov)
         want = -0.5 * (ys.astype(np.float64) @ np.linalg.solve(cov, ys.astype(np.float64)) + logdet + 6 * math.log(2 * math.pi))
         assert lml == pytest.approx(want, abs=2e-2)
+
+
+class TestWiderDistributions:
+    def test_primitive_api(self):
+        """tests/generative_functions/test_distributions.py:194-230 shape (test_using_primitive_distributions): every
+        wrapper samples, scores its own sample consistently (simulate score == assess), and has weight 0 unconstrained."""
+        cases = [
+            (genjax.student_t, (4.0, 0.5, 1.5)), (genjax.truncated_normal, (0.0, 1.0, -1.0, 2.0)), (genjax.poisson, (3.5,)),
+            (genjax.geometric, (0.2,)), (genjax.dirichlet, (np.array([1.0, 2.0, 3.0], np.float32),)), (genjax.gumbel, (0.0, 1.0)),
+            (genjax.half_cauchy, (0.0, 2.0)), (genjax.inverse_gamma, (3.0, 2.0)), (genjax.weibull, (1.5, 2.0)),
+            (genjax.logit_normal, (0.0, 1.0)), (genjax.chi2, (5.0,)), (genjax.gamma, (2.0, 1.5)), (genjax.exponential, (1.5,)),
+        ]
+        for i, (dist, args) in enumerate(cases):
+            tr = dist.simulate(genjax.key(10 + i), args)
+            v = tr.get_choices()[()]
+            score, _ = dist.assess(C.v(v), args)
+            assert f(score) == pytest.approx(f(tr.get_score()), rel=1e-5, abs=1e-5), dist
+            tr2, w = dist.importance(genjax.key(10 + i), C.n(), args)
+            assert f(w) == 0.0
+            tr3, w3 = dist.importance(genjax.key(3), C.v(v), args)
+            assert f(w3) == pytest.approx(f(score), rel=1e-6, abs=1e-6)
+
+    def test_student_t_regression_posterior(self):
+        """a model over the wider set end to end: robust regression with Student-t noise and a truncated-normal prior;
+        ImportanceK posterior mean against a fine grid."""
+        xs = np.linspace(-2.0, 2.0, 9).astype(np.float32)
+        ys = (1.3 * xs + np.array([0.1, -0.2, 0.05, 3.0, -0.1, 0.0, 0.2, -0.15, 0.1], np.float32)).astype(np.float32)
+
+        @genjax.gen
+        def model(xs):
+            w = genjax.truncated_normal(0.0, 2.0, -1.0, 4.0) @ "w"
+            _ = genjax.student_t(3.0, w * xs, 0.3) @ "ys"
+            return w
+
+        target = Target(model, (xs,), C["ys"].set(ys))
+        alg = ImportanceK(target, k_particles=1 << 18)
+        pc = alg.run_smc(genjax.key(4))
+        w = pc.get_particles().get_choices()["w"].double()
+        lw = pc.get_log_weights().double()
+        post_mean = f(((lw - lw.max()).exp() * w).sum() / (lw - lw.max()).exp().sum())
+        import scipy.stats as st
+        grid = np.linspace(-1.0, 4.0, 20001)
+        logp = st.truncnorm.logpdf(grid, -0.5, 2.0, 0.0, 2.0) + st.t.logpdf(ys[None, :], 3.0, grid[:, None] * xs[None, :], 0.3).sum(1)
+        p = np.exp(logp - logp.max())
+        want = float((grid * p).sum() / p.sum())
+        assert post_mean == pytest.approx(want, abs=5e-3)
+        lml = f(pc.get_log_marginal_likelihood_estimate())
+        want_lml = float(np.log(np.trapezoid(np.exp(logp - logp.max()), grid)) + logp.max())
+        assert lml == pytest.approx(want_lml, abs=2e-2)

@@ -78,12 +78,15 @@ def test_threefry_bit_exact(K_, oracle, golden):
 
 def test_logpdf_table_gpu(K_, golden):
     for row in golden["logpdf_table"]:
-        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"])
+        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"], c=row.get("c"), d=row.get("d"))
         got = float(K_.run_program(prog, (0, 1), 1)["score"][0])
         if row["neg_inf"]:
             assert got == -math.inf, row
         else:
             assert got == pytest.approx(row["lp"], rel=1e-4, abs=1e-4), row
+    for row in golden["dirichlet_table"]:
+        prog = H.one_site("dirichlet", np.asarray(row["alpha"], np.float32), obs=np.asarray(row["x"], np.float32))
+        assert float(K_.run_program(prog, (0, 1), 1)["score"][0]) == pytest.approx(row["lp"], rel=2e-4, abs=2e-4), row
 
 
 @pytest.mark.parametrize("rng", RNGS)
@@ -97,6 +100,43 @@ def test_zoo_parity(K_, oracle, rng, observed):
         np.testing.assert_allclose(g["site_scores"][:, ok], o["site_scores"][:, ok], rtol=RT, atol=AT)
         if not observed:
             assert (g["weight"] == 0).all()
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("observed", [(), ("n9", "di", "po", "tn")])
+def test_zoo2_parity(K_, oracle, rng, observed):
+    """the wider distribution set (student_t, truncated_normal, poisson, geometric, dirichlet, gumbel, half_cauchy,
+    inverse_gamma, weibull, logit_normal, chi2) through the generic interpreter: samples, scores, weights.
+    Rejection samplers (gamma family, poisson above rate 10) and floor()-ed draws may part ways with the oracle on a
+    near-tie, so up to 1% of the particles are allowed to differ; the rest must match to the float tolerance."""
+    prog = H.zoo2(rng, observed)
+    for K in (1, 77, 3000):
+        g, o = _run_both(K_, oracle, prog, (31, 32), K, want_site_scores=True)
+        ok = _close_cols(g["choices"], o["choices"], rt=5e-4, at=2e-4)
+        for k in ("score", "weight", "logw"):
+            ok &= _close_cols(g[k][None], o[k][None], rt=5e-4, at=5e-4)
+        assert (~ok).sum() <= (0.01 * K if K > 1000 else (1 if K > 1 else 0)), f"zoo2 K={K}: {(~ok).sum()} particles differ"
+        np.testing.assert_allclose(g["site_scores"][:, ok], o["site_scores"][:, ok], rtol=1e-3, atol=5e-4)
+        if not observed:
+            assert (g["weight"] == 0).all()
+        else:
+            assert np.isfinite(g["logw"]).all()
+
+
+def test_zoo2_gradient_parity(K_, oracle):
+    """analytic gradients of the wider set: device == oracle (the oracle's are checked by finite differences in
+    tests/test_oracle.py)"""
+    import torch
+    sl = H.zoo2().site_list
+    cont = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS)
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=cont)
+    base = oracle.run_program(H.zoo2(), (9, 9), 512)["choices"].astype(np.float32)
+    sg, gg = K_.score_grad(prog, torch.as_tensor(base).cuda())
+    so, go = oracle.score_grad(prog, base)
+    np.testing.assert_allclose(_np(sg), so, rtol=2e-4, atol=5e-4)
+    big = np.abs(go) > 1e3                                    # near-singular points (x -> 0): compare relatively only
+    np.testing.assert_allclose(_np(gg)[~big], go[~big], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(gg)[big], go[big], rtol=1e-2)
 
 
 @pytest.mark.parametrize("rng", RNGS)

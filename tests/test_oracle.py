@@ -35,7 +35,7 @@ def test_key_derivation_matches_jax_layout(oracle):
 
 def test_logpdf_table(oracle, golden):
     for row in golden["logpdf_table"]:
-        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"])
+        prog = H.one_site(row["kind"], row["a"], row["b"], obs=row["x"], c=row.get("c"), d=row.get("d"))
         out = oracle.run_program(prog, (0, 1), 1)
         got = float(out["score"][0])
         if row["neg_inf"]:
@@ -44,6 +44,13 @@ def test_logpdf_table(oracle, golden):
             assert got == pytest.approx(row["lp"], rel=3e-5, abs=3e-5), row
         # constrained site: weight == score (distribution.py:144-147)
         assert out["weight"][0] == out["score"][0]
+
+
+def test_dirichlet_table(oracle, golden):
+    for row in golden["dirichlet_table"]:
+        prog = H.one_site("dirichlet", np.asarray(row["alpha"], np.float32), obs=np.asarray(row["x"], np.float32))
+        out = oracle.run_program(prog, (0, 1), 1)
+        assert float(out["score"][0]) == pytest.approx(row["lp"], rel=1e-4, abs=1e-4), row
 
 
 def test_categorical_log_softmax(oracle, golden):
@@ -511,3 +518,75 @@ def test_reference_literal_kat(oracle):
     out = oracle.run_program(prog, (0, 0), 1)
     assert float(out["score"][0]) == pytest.approx(kat["score"], rel=1e-6)
     assert float(np.float32(out["score"][0])) == float(np.float32(kat["score"]))      # the same float32 the reference prints
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_wider_samplers_match_scipy_moments(oracle, rng):
+    """The samplers of the wider set against scipy.stats moments / quantiles (the reference's samplers are TFP's;
+    bit parity is unpinned, the distributions are not)."""
+    import scipy.stats as st
+    K = 200_000
+    out = oracle.run_program(H.zoo2(rng), (5, 6), K)
+    prog = H.zoo2(rng)
+    v = {s.addr: out["choices"][prog.slot_of[s.addr]: prog.slot_of[s.addr] + s.dim].astype(np.float64) for s in prog.site_list.sites}
+    se = lambda sd: 5.0 * sd / math.sqrt(K)
+    # student_t(4, 0.5, 1.5): median and interquartile range (heavy tails: avoid moments)
+    q = np.quantile(v["t0"][0], [0.25, 0.5, 0.75])
+    np.testing.assert_allclose(q, st.t.ppf([0.25, 0.5, 0.75], 4.0, 0.5, 1.5), atol=0.03)
+    assert (v["tn"][0] >= -0.5).all() and (v["tn"][0] <= 2.0).all()
+    assert abs(v["po"][0].mean() - 3.5) < se(math.sqrt(3.5)) and abs(v["po"][0].var() - 3.5) < 0.1
+    assert abs(v["pb"][0].mean() - 40.0) < se(math.sqrt(40.0)) and abs(v["pb"][0].var() - 40.0) < 1.0
+    assert (v["po"][0] == np.floor(v["po"][0])).all() and (v["pb"][0] >= 0).all()
+    # poisson with a per-particle rate: mean of (count - rate) is 0
+    assert abs((v["pl"][0] - np.exp(v["tn"][0])).mean()) < se(3.0)
+    assert abs(v["ge"][0].mean() - 0.7 / 0.3) < se(math.sqrt(0.7) / 0.3)
+    np.testing.assert_allclose(v["di"].sum(axis=0), 1.0, atol=1e-5)
+    np.testing.assert_allclose(v["di"].mean(axis=1), np.array([0.8, 2.0, 3.0]) / 5.8, atol=se(0.2))
+    np.testing.assert_allclose(v["di"].var(axis=1), st.dirichlet.var([0.8, 2.0, 3.0]), rtol=0.05)
+    assert abs((v["gu"][0] - v["di"][1]).mean() - 0.7 * np.euler_gamma) < se(0.7 * math.pi / math.sqrt(6))
+    assert abs(np.median(v["hc"][0] / np.logaddexp(0.0, v["gu"][0])) - 1.0) < 0.02          # half-Cauchy median = scale
+    assert abs(v["ig"][0].mean() - 2.0 / (3.0 - 1.0)) < 0.03                                  # var is 1: se 0.011
+    r = v["we"][0] / v["ig"][0]
+    assert abs(r.mean() - st.weibull_min.mean(1.5)) < se(st.weibull_min.std(1.5))
+    lg = np.log(v["lo"][0]) - np.log1p(-v["lo"][0])
+    assert abs((lg - 0.1 * v["po"][0]).mean()) < se(0.6) and abs((lg - 0.1 * v["po"][0]).std() - 0.6) < 0.01
+    assert abs(v["c2"][0].mean() - 5.0) < se(math.sqrt(10.0)) and abs(v["c2"][0].var() - 10.0) < 0.3
+    z = (v["t1"][0] - v["lo"][0]) / np.logaddexp(0.0, v["c2"][0])
+    np.testing.assert_allclose(np.quantile(z, [0.1, 0.5, 0.9]), st.t.ppf([0.1, 0.5, 0.9], 3.0), atol=0.03)
+    # truncated to [2.5, 6] sigma: mean of the tail
+    assert (v["tr"][0] >= 2.5).all() and (v["tr"][0] <= 6.0).all()
+    assert abs(v["tr"][0].mean() - st.truncnorm.mean(2.5, 6.0)) < 0.01
+    tn_m = st.truncnorm.mean((-0.5 - 0.5) / 0.8, (2.0 - 0.5) / 0.8, 0.5, 0.8)   # loc = sigmoid(t0) varies; loose sanity only
+    assert abs(v["tn"][0].mean() - tn_m) < 0.15
+    # simulate: score == sum of the site scores, weight == 0
+    assert (out["weight"] == 0).all()
+
+
+def test_wider_gradients_by_finite_differences(oracle):
+    """dlogpdf of the wider set (value and parameter gradients through VALUE / xf chains) against central differences
+    of the oracle's own score in float64-ish steps."""
+    prog0 = H.zoo2()
+    sl = prog0.site_list
+    cont = [s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS]
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=tuple(cont))
+    base = oracle.run_program(H.zoo2(), (9, 9), 64)["choices"].astype(np.float32)
+    sc, gr = oracle.score_grad(prog, base)
+    n_checked = 0
+    for s in sl.sites:
+        if s.addr not in cont:
+            assert (gr[prog.slot_of[s.addr]: prog.slot_of[s.addr] + s.dim] == 0).all()
+            continue
+        slot = prog.slot_of[s.addr]
+        h = 2e-3 * np.maximum(1.0, np.abs(base[slot]))
+        up, dn = base.copy(), base.copy()
+        up[slot] += h
+        dn[slot] -= h
+        su, _ = oracle.score_grad(prog, up)
+        sd, _ = oracle.score_grad(prog, dn)
+        fd = (su.astype(np.float64) - sd.astype(np.float64)) / (2 * h)
+        ok = np.isfinite(fd) & np.isfinite(gr[slot]) & (np.abs(fd) < 50)
+        # the inverse-gamma / chi2 / student-t shape parameters are constants here, so no NaN gradient may appear
+        assert np.isfinite(gr[slot]).all(), s.addr
+        np.testing.assert_allclose(gr[slot][ok], fd[ok], rtol=0.05, atol=0.05, err_msg=str(s.addr))
+        n_checked += int(ok.sum())
+    assert n_checked > 400
