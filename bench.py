@@ -261,7 +261,8 @@ def run_hmc(args, rank, world, dev):
     N, P, L = 1024, 16, args.leapfrog
     n = (1 << 16)
     prog, pr = workloads.logreg_program(N=N, P=P)
-    assert kernels.hmc_engine(prog) == 2, "fused logistic-regression HMC kernel not selected"
+    engine = kernels.hmc_engine(prog)
+    assert engine in (2, 3), "fused logistic-regression HMC kernel not selected"
     ch0 = torch.as_tensor((np.random.default_rng(rank).standard_normal((P + 1, n)) * 0.1).astype(np.float32), device=dev)
     state = {"ch": ch0.clone(), "ws": None}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 8))]
@@ -288,9 +289,10 @@ def run_hmc(args, rank, world, dev):
         vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload="hier_logreg_N1024_P16 HMC with fused MH accept (BASELINE.json configs[4]); one bench step = "
                              f"one move of L={L} leapfrog steps", chains_per_gpu=n, leapfrog=L, eps=0.01, rng_stream="flat"),
-        roofline=dict(bound="mfma", kernel="gjx::k_hmc_logreg<FLAT,16,false>", achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+        roofline=dict(bound="mfma", kernel=("gjx::k_hmc_logreg_mfma<FLAT,false>" if engine == 3 else "gjx::k_hmc_logreg<FLAT,16,false>"), achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
                       frac=tf / FP32_PEAK_TFLOPS, traffic=None, kernel_us=kern_ms * 1e3,
-                      note="FP32 VALU-bound (the f32 MFMA peak equals the f32 vector peak on gfx950, no MFMA used); ~0 HBM bytes"),
+                      note="both contractions on v_mfma_f32_16x16x4_f32 (exact f32; its peak equals the f32 vector peak on gfx950 and the two "
+                           "do not overlap: what is left beside the MFMAs is the sigmoid VALU work); ~0 HBM bytes"),
         accept_rate=float(acc.mean()),
     )
     if not args.no_cpu_baseline and world == 1:

@@ -500,6 +500,202 @@ __global__ __launch_bounds__(kLogregThreads, CPL == 1 ? 4 : 2) void k_hmc_logreg
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// P = 16 on the matrix cores.  The two contractions of a leapfrog step are [chains x 16] x [16 x N] (logits) and
+// [chains x N] x [N x 16] (gradient): f32-input MFMA (v_mfma_f32_16x16x4_f32, exact f32, the f32 VALU rate) takes
+// them off the vector pipe, which keeps only the sigmoids and the leapfrog update — the two pipes overlap.
+//
+// One wave = 16 chains.  Lane l: chain c = l & 15, group q = l >> 4.  Every per-coefficient quantity (beta, momentum,
+// gradient) lives in the MFMA C layout: register i of lane (c, q) holds coefficient p = 4q + i of chain c.  With that
+// choice no operand ever needs a transpose:
+//   logits tile S[n0 + 4q + r][c] (C layout, r = 0..3) = bias + sum_i MFMA(A = X[n0 + (l&15)][4q + i], B = beta[i])
+//       (step i contracts the coefficient set {4k + i : k = 0..3}; A[row][k] <-> X[n0 + row][4k + i])
+//   gradient G[4q + i][c] += sum_r MFMA(A = X[n0 + 4k + r][p = l&15] = XT[l&15][n0 + 4q + r], B = resid[r])
+// LDS holds X TRANSPOSED, XT[16][Npad + 4] (row pad 4 floats: the b128 reads of 16 rows hit 64 distinct banks; the
+// forward b32 reads of 4 row groups are 16 banks apart), plus y and bias (plain and pre-scaled): 78 KB at N = 1024 -> 2 blocks per CU.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaThreads = 512;  // 8 waves = 128 chains per block
+
+GJX_DEV float group_sum(float v) {  // over the 4 lanes (q = 0..3) that share a chain
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct LogregLds {
+  const float* xt;  // [16][ld]
+  const float* y;   // [Npad]
+  const float* b;   // [Npad]
+  const float* bs;  // [Npad]  bias * -log2(e): the gradient pass accumulates -log2(e) * logits, so that
+                    //         sigmoid = rcp(1 + exp2(acc)) needs no multiply per element
+  int ld, Npad, N;
+};
+constexpr float kNegLog2e = -1.44269504f;
+
+// gradient of the log-likelihood w.r.t. beta (C layout) for the 16 chains of the wave
+GJX_DEV v4f logreg_mfma_grad(const LogregLds& s, int c16, int q, const v4f& beta_in) {
+  const v4f beta = beta_in * kNegLog2e;
+  v4f g0 = {0.0f, 0.0f, 0.0f, 0.0f}, g1 = g0;
+  const float* xrow = s.xt + c16 * s.ld + 4 * q;   // backward A operand: XT[l&15][n0 + 4q + r]
+  const float* xcol = s.xt + (4 * q) * s.ld + c16; // forward  A operand: XT[4q + i][n0 + (l&15)]
+  for (int n0 = 0; n0 < s.Npad; n0 += 32) {        // two independent tiles per trip: two accumulator chains
+    v4f s0 = *reinterpret_cast<const v4f*>(s.bs + n0 + 4 * q);
+    v4f s1 = *reinterpret_cast<const v4f*>(s.bs + n0 + 16 + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xcol[i * s.ld + n0], beta[i], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xcol[i * s.ld + n0 + 16], beta[i], s1, 0, 0, 0);
+    }
+    const v4f y0 = *reinterpret_cast<const v4f*>(s.y + n0 + 4 * q);
+    const v4f y1 = *reinterpret_cast<const v4f*>(s.y + n0 + 16 + 4 * q);
+    const v4f a0 = *reinterpret_cast<const v4f*>(xrow + n0);
+    const v4f a1 = *reinterpret_cast<const v4f*>(xrow + n0 + 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], y0[r] - fast_rcp(1.0f + __builtin_amdgcn_exp2f(s0[r])), g0, 0, 0, 0);
+      g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], y1[r] - fast_rcp(1.0f + __builtin_amdgcn_exp2f(s1[r])), g1, 0, 0, 0);
+    }
+  }
+  return g0 + g1;
+}
+
+// log-likelihood sum_n log Bernoulli(y_n; logits) of the wave's 16 chains (all 4 lanes of a chain get the total)
+GJX_DEV float logreg_mfma_loglik(const LogregLds& s, int c16, int q, const v4f& beta) {
+  const float* xcol = s.xt + (4 * q) * s.ld + c16;
+  float part = 0.0f;
+  for (int n0 = 0; n0 < s.Npad; n0 += 16) {
+    v4f sl = *reinterpret_cast<const v4f*>(s.b + n0 + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sl = __builtin_amdgcn_mfma_f32_16x16x4f32(xcol[i * s.ld + n0], beta[i], sl, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n0 + 4 * q + r < s.N) part += elem_logpdf(GJX_BERNOULLI_LOGITS, s.y[n0 + 4 * q + r], sl[r], 0.0f);
+  }
+  return group_sum(part);
+}
+
+template <int RNG, bool STALE>
+__global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs a) {
+  constexpr int P = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, Npad = (N + 31) & ~31, ld = Npad + 4;
+  float* sXT = smem;
+  float* sY = sXT + P * ld;
+  float* sB = sY + Npad;
+  float* sBs = sB + Npad;
+  for (int t = threadIdx.x; t < P * ld; t += kMfmaThreads) {
+    const int p = t / ld, nn = t - p * ld;
+    sXT[t] = nn < N ? a.tab[a.x_off + nn * P + p] : 0.0f;
+  }
+  for (int t = threadIdx.x; t < Npad; t += kMfmaThreads) {
+    sY[t] = t < N ? a.tab[a.y_off + t] : 0.5f;      // padded rows: residual y - sigmoid(0) is exactly 0
+    sB[t] = t < N ? a.tab[a.b_off + (a.b_len == 1 ? 0 : t)] : 0.0f;
+    sBs[t] = sB[t] * kNegLog2e;
+  }
+  __syncthreads();
+  const LogregLds lds{sXT, sY, sB, sBs, ld, Npad, N};
+  const float* __restrict__ tab = a.tab;
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
+  const int64_t n = a.n;
+  float* ch = a.choices;
+  int64_t idx = ((int64_t)blockIdx.x * (kMfmaThreads / 64) + (threadIdx.x >> 6)) * 16 + c16;
+  const bool live = idx < n;
+  if (!live) idx = n - 1;                             // shadow chains keep the wave's matrices full; they never store
+  float lt = ch[idx];
+  v4f beta, mu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    beta[i] = ch[(int64_t)(1 + 4 * q + i) * n + idx];
+    mu[i] = tab[a.mu_off + (a.mu_len == 1 ? 0 : 4 * q + i)];
+  }
+  const float rs0 = fast_rcp(a.s0);
+  auto prior_score = [&](float l, const v4f& be) {
+    const float tau = fast_exp(l);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += normal_logpdf(be[i], mu[i], tau);
+    return normal_logpdf(l, a.m0, a.s0) + group_sum(acc);
+  };
+  auto full_grad = [&](float l, const v4f& be, v4f& g, float& gl) {
+    g = logreg_mfma_grad(lds, c16, q, be);
+    const float t2i = fast_exp(-2.0f * l);            // 1 / tau^2
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float z = be[i] - mu[i];
+      g[i] -= z * t2i;
+      acc = fmaf(z * z, t2i, acc);
+    }
+    gl = -(l - a.m0) * rs0 * rs0 + group_sum(acc) - (float)P;
+  };
+  const float score0 = logreg_mfma_loglik(lds, c16, q, beta) + prior_score(lt, beta);
+  v4f g, g0;
+  float glt, glt0;
+  full_grad(lt, beta, g, glt);
+  g0 = g; glt0 = glt;
+  // momenta: leaf 0 = log_tau, leaf 1 = beta — the streams of k_hmc_generic / k_hmc_logreg; each lane draws its 4
+  const uint64_t gidx = (uint64_t)(a.offset + idx);
+  key2 sub{0u, 0u}, knew{0u, 0u};
+  if (RNG == GJX_RNG_JAX32) {
+    const key2 ck = fold_in64(a.key, gidx);
+    knew = fold_in(ck, 0u);
+    sub = fold_in(ck, 1u);
+  }
+  BitStream<RNG> bs;
+  if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 0u)); else bs.open(a.key, gidx, 1u);
+  float plt = stream_normal<RNG>(bs, 0u);
+  if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 1u)); else bs.open(a.key, gidx, 2u);
+  v4f pb;
+  float ksum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pb[i] = stream_normal<RNG>(bs, (uint32_t)(4 * q + i));
+    ksum += -0.5f * pb[i] * pb[i] - kHalfLog2Pi;
+  }
+  const float k0 = -0.5f * plt * plt - kHalfLog2Pi + group_sum(ksum);
+  const float he = 0.5f * a.eps;
+  for (int t = 1; t <= a.L; ++t) {
+    plt += he * (STALE ? glt0 : glt);
+    lt += a.eps * plt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pb[i] += he * (STALE ? g0[i] : g[i]);
+      beta[i] += a.eps * pb[i];
+    }
+    full_grad(lt, beta, g, glt);
+    plt += he * glt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] += he * g[i];
+  }
+  const float sc = a.L > 0 ? logreg_mfma_loglik(lds, c16, q, beta) + prior_score(lt, beta) : score0;
+  ksum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ksum += -0.5f * pb[i] * pb[i] - kHalfLog2Pi;
+  const float k1 = -0.5f * plt * plt - kHalfLog2Pi + group_sum(ksum);
+  const float al = sc - score0 + k1 - k0;
+  bool acc = true;
+  if (a.accept) {
+    BitStream<RNG> bs2;
+    if (RNG == GJX_RNG_JAX32) bs2.open_site_key(fold_in(knew, 0x4d48u));
+    else bs2.open(a.key, gidx, GJX_FLAT_MAX_SITES);
+    acc = safe_log(bits_to_unit(bs2.get(0u))) < al;
+  }
+  if (live) {
+    if (acc) {  // rejected chains keep the values already in choices[][]
+      if (q == 0) ch[idx] = lt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ch[(int64_t)(1 + 4 * q + i) * n + idx] = beta[i];
+    }
+    if (q == 0) {
+      if (a.score) a.score[idx] = acc ? sc : score0;
+      if (a.alpha) a.alpha[idx] = al;
+      if (a.accepted) a.accepted[idx] = acc ? 1.0f : 0.0f;
+    }
+  }
+}
+
 }  // namespace gjx
 
 using namespace gjx;
@@ -530,8 +726,34 @@ static bool match_logreg(const gjx_program* p, LogregArgs* a, int* P_out) {
   return true;
 }
 
+// 3 = matrix-core kernel (P == 16), 2 = vector kernel
+static int logreg_engine(const LogregArgs& a, int P) {
+  const char* e = getenv("GJX_HMC_MFMA");
+  if (e && !atoi(e)) return 2;
+  const int Npad = (a.N + 31) & ~31;
+  if (P == 16 && sizeof(float) * ((size_t)16 * (Npad + 4) + 3 * (size_t)Npad) <= 160 * 1024) return 3;
+  return 2;
+}
+
+template <int RNG>
+static int launch_logreg_mfma(const LogregArgs& a, hipStream_t st) {
+  const int Npad = (a.N + 31) & ~31;
+  const size_t lds = sizeof(float) * ((size_t)16 * (Npad + 4) + 3 * (size_t)Npad);
+  const int chains_per_block = kMfmaThreads / 64 * 16;
+  const unsigned nb = (unsigned)((a.n + chains_per_block - 1) / chains_per_block);
+#define GJX_LM(ST)                                                                                                   \
+  {                                                                                                                  \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg_mfma<RNG, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_hmc_logreg_mfma<RNG, ST>), dim3(nb), dim3(kMfmaThreads), lds, st, a);                      \
+  }
+  if (a.stale) GJX_LM(true) else GJX_LM(false)
+#undef GJX_LM
+  return 0;
+}
+
 template <int RNG>
 static int launch_logreg(const LogregArgs& a, int P, hipStream_t st) {
+  if (logreg_engine(a, P) == 3) return launch_logreg_mfma<RNG>(a, st);
   // GJX_HMC_CPL=2 puts two chains on each lane (half the LDS traffic per FLOP); measured equal to 1 at 2^16 chains
   // (the kernel is bound by v_fma issue at ~2.9 cycles with three distinct VGPR sources, not by LDS), so 1 is the default
   const char* e = getenv("GJX_HMC_CPL");
@@ -561,7 +783,7 @@ extern "C" int gjx_hmc_engine(const gjx_program* prog) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   LogregArgs a; int P;
   const char* f = getenv("GJX_FORCE_GENERIC");
-  if (!(f && atoi(f)) && match_logreg(prog, &a, &P)) return 2;
+  if (!(f && atoi(f)) && match_logreg(prog, &a, &P)) return logreg_engine(a, P);
   return 0;
 }
 
