@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
   const unsigned epoch = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long tag = (unsigned long long)(epoch % 16383u) + 1ull;
   if (threadIdx.x == 0) n_heavy = 0;
+  // the weights are requested before the reference maximum is reduced: their latency overlaps the reduction
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
+  float xv[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) xv[k] = (i0 + k < K) ? x[i0 + k] : 0.0f;
   float sm;
   const float mx = block_ref_max(mode, lse, n_partials, fred, &sm);
   if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -315,12 +320,11 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
     lse_out[0] = mx; lse_out[1] = sm; lse_out[2] = l; lse_out[3] = l - log_k_total;
   }
   // ---- tile scan in registers ----
-  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
   uint64_t q[ITEMS];
   uint64_t s = 0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
-    s += (i0 + k < K) ? weight_q(x, i0 + k, mode, mx) : 0;
+    s += (i0 + k < K) ? weight_q(&xv[k], 0, mode, mx) : 0;
     q[k] = s;  // thread-local inclusive
   }
   uint64_t inc = s;

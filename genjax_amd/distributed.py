@@ -308,9 +308,15 @@ class ShardedResampler:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 1:
             self.ctx = ctx
-            ok = torch.tensor([1 if self._self_check() else 0], dtype=torch.int32, device=self.device)
+            try:
+                verdict = 1 if self._self_check() else 0
+            except Exception as e:           # the reference transport itself failed: nothing to compare against
+                import warnings
+                warnings.warn(f"ShardedResampler: self-check of the RCCL transport could not run ({e!r}); keeping RCCL")
+                verdict = 2
+            ok = torch.tensor([verdict], dtype=torch.int32, device=self.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-            if int(ok.item()) == 1:
+            if int(ok.item()) >= 1:
                 return
             err = "the RCCL transport and the torch.distributed transport disagree on the self-check collection"
         if ctx is not None:
