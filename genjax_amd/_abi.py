@@ -100,6 +100,7 @@ PROTOTYPES = {
     "gjx_shard_ctx_create": (C.c_int, [C.c_char_p, vp, i32, i32, i64, i32, i64, C.POINTER(vp)]),
     "gjx_shard_ctx_destroy": (C.c_int, [vp]),
     "gjx_shard_resample_step": (C.c_int, [vp, vp, vp, vp, i64, vp, i64, f64, vp, vp, vp]),
+    "gjx_shard_message_counts": (C.c_int, [vp, i32, i64, vp, vp, vp]),
     "gjx_shard_pack": (C.c_int, [vp, i64, i32, vp, i64, i64, i64, vp, vp]),
     "gjx_shard_unpack": (C.c_int, [vp, i64, i64, i32, vp, i64, i64, vp]),
     "gjx_shard_resample": (C.c_int, [vp, i64, vp, f64, i64, vp, i64, vp, i64, i32, vp, i64, i64, vp]),

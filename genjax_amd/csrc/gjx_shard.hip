@@ -342,6 +342,40 @@ static int grow(float** buf, size_t* cap, size_t need, hipStream_t st) {
   return GJX_OK;
 }
 
+// Message sizes of one rank, from the plan alone (host arithmetic, no device access).  Rank r produces the output
+// slots [bounds[r], bounds[r+1]) and stores the slots of its own shard of N_total; what it produces outside its
+// shard goes to the owners (send_counts), what others produce inside it comes in (recv_counts).  Every rank calls
+// this with the same bounds, so send_counts[d] on rank r equals recv_counts[r] on rank d by construction.
+extern "C" int gjx_shard_message_counts(const gjx_shard_plan* plan, int32_t rank, int64_t N_total, int64_t* send_counts,
+                                        int64_t* recv_counts, int64_t* parts4) {
+  if (!plan || !send_counts || !recv_counts || plan->n_ranks < 1 || plan->n_ranks > GJX_MAX_RANKS || rank < 0 ||
+      rank >= plan->n_ranks || N_total <= 0)
+    return gjx_fail(GJX_EINVAL, "gjx_shard_message_counts: bad argument");
+  const int G = (int)plan->n_ranks;
+  const int64_t q = N_total / G, rem = N_total % G;
+  auto lo_of = [&](int d) { return d * q + (d < rem ? d : rem); };
+  const int64_t slot0 = plan->bounds[rank], run_hi = plan->bounds[rank + 1];
+  const int64_t own_lo = lo_of(rank), own_hi = lo_of(rank + 1);
+  auto overlap = [](int64_t a0, int64_t a1, int64_t b0, int64_t b1) {
+    const int64_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
+    return hi > lo ? hi - lo : (int64_t)0;
+  };
+  int64_t n_pre = 0, n_suf = 0, n_lo = 0, n_hi = 0;
+  for (int d = 0; d < G; ++d) {
+    send_counts[d] = d == rank ? 0 : overlap(slot0, run_hi, lo_of(d), lo_of(d + 1));
+    recv_counts[d] = d == rank ? 0 : overlap(plan->bounds[d], plan->bounds[d + 1], own_lo, own_hi);
+    (d < rank ? n_pre : n_suf) += send_counts[d];
+    (d < rank ? n_lo : n_hi) += recv_counts[d];
+  }
+  // the two pieces of the run outside the shard / of the shard outside the run, as intervals (cross-check)
+  auto clamp0 = [](int64_t v) { return v > 0 ? v : (int64_t)0; };
+  if (n_pre != clamp0((run_hi < own_lo ? run_hi : own_lo) - slot0) || n_suf != clamp0(run_hi - (slot0 > own_hi ? slot0 : own_hi)) ||
+      n_lo != clamp0((own_hi < slot0 ? own_hi : slot0) - own_lo) || n_hi != clamp0(own_hi - (own_lo > run_hi ? own_lo : run_hi)))
+    return gjx_fail(GJX_EINVAL, "gjx_shard_message_counts: the plan's bounds are not monotone");
+  if (parts4) { parts4[0] = n_pre; parts4[1] = n_suf; parts4[2] = n_lo; parts4[3] = n_hi; }
+  return GJX_OK;
+}
+
 extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, const float* local_lse, const float* rows_in,
                                        int64_t in_stride, float* rows_out, int64_t out_stride, double u, float* lse_out,
                                        int64_t* info_host, void* stream) {
@@ -378,18 +412,15 @@ extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, cons
   }
   const gjx_shard_plan* p = c->plan_host;
   if (p->status) return gjx_fail(GJX_EINVAL, "gjx_shard_resample_step: all weights are zero");
-  const int64_t slot0 = p->slot0, n_valid = p->n_valid, run_hi = slot0 + n_valid;
-  const int64_t own_lo = c->own_lo, own_hi = c->own_lo + c->own_n;
-  auto clamp0 = [](int64_t v) { return v > 0 ? v : 0; };
-  const int64_t n_pre = clamp0((run_hi < own_lo ? run_hi : own_lo) - slot0);
-  const int64_t n_suf = clamp0(run_hi - (slot0 > own_hi ? slot0 : own_hi));
-  const int64_t n_lo = clamp0((own_hi < slot0 ? own_hi : slot0) - own_lo);
-  const int64_t n_hi = clamp0(own_hi - (own_lo > run_hi ? own_lo : run_hi));
+  int64_t send_counts[GJX_MAX_RANKS], recv_counts[GJX_MAX_RANKS], parts[4];
+  rc = gjx_shard_message_counts(p, rank, c->N_total, send_counts, recv_counts, parts);
+  if (rc != GJX_OK) return rc;
+  const int64_t n_pre = parts[0], n_suf = parts[1], n_lo = parts[2], n_hi = parts[3];
   if (info_host) {
     info_host[0] = n_pre + n_suf;  // children sent
     info_host[1] = n_lo + n_hi;    // children received
-    info_host[2] = slot0;
-    info_host[3] = n_valid;
+    info_host[2] = p->slot0;
+    info_host[3] = p->n_valid;
   }
   if (R > 0 && G > 1) {
     rc = grow(&c->send, &c->send_cap, (size_t)(n_pre + n_suf) * R, st);
@@ -399,34 +430,24 @@ extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, cons
     if (n_pre + n_suf) {
       const int64_t n = (n_pre + n_suf) * R;
       hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows_in, in_stride, R, (const int32_t*)c->anc,
-                         n_valid, n_pre, n_suf, c->send);
+                         p->n_valid, n_pre, n_suf, c->send);
       GJX_CHECK_LAUNCH("gjx_shard_resample_step(pack)");
     }
-    // all-to-all-v as grouped send/recv.  Messages are in slot order, so the block for rank d starts where the
-    // slots below d's range end; every rank derives every count from the same bounds.
+    // all-to-all-v as grouped send/recv.  Messages are in slot order, so the block for rank d follows the blocks
+    // of the lower ranks; every rank derives every count from the same bounds (gjx_shard_message_counts).
     GJX_NCCL(c, c->api.GroupStart(), "group");
     int64_t s_off = 0, r_off = 0;
-    const int64_t q = c->N_total / G, rem = c->N_total % G;
     for (int d = 0; d < G; ++d) {
-      const int64_t lo_d = d * q + (d < rem ? d : rem), hi_d = lo_d + q + (d < rem ? 1 : 0);
-      if (d != rank) {
-        // I produce [slot0, run_hi): what falls into d's slots goes to d
-        const int64_t a = slot0 > lo_d ? slot0 : lo_d, b = run_hi < hi_d ? run_hi : hi_d;
-        if (b > a) {
-          GJX_NCCL(c, c->api.Send(c->send + s_off * R, (size_t)(b - a) * R, ncclFloat, d, c->comm, st), "send");
-          s_off += b - a;
-        }
-        // d produces [bounds[d], bounds[d+1]): what falls into my slots comes from d
-        const int64_t a2 = p->bounds[d] > own_lo ? p->bounds[d] : own_lo, b2 = p->bounds[d + 1] < own_hi ? p->bounds[d + 1] : own_hi;
-        if (b2 > a2) {
-          GJX_NCCL(c, c->api.Recv(c->recv + r_off * R, (size_t)(b2 - a2) * R, ncclFloat, d, c->comm, st), "recv");
-          r_off += b2 - a2;
-        }
+      if (send_counts[d]) {
+        GJX_NCCL(c, c->api.Send(c->send + s_off * R, (size_t)send_counts[d] * R, ncclFloat, d, c->comm, st), "send");
+        s_off += send_counts[d];
+      }
+      if (recv_counts[d]) {
+        GJX_NCCL(c, c->api.Recv(c->recv + r_off * R, (size_t)recv_counts[d] * R, ncclFloat, d, c->comm, st), "recv");
+        r_off += recv_counts[d];
       }
     }
     GJX_NCCL(c, c->api.GroupEnd(), "group");
-    if (s_off != n_pre + n_suf || r_off != n_lo + n_hi)
-      return gjx_fail(GJX_EINVAL, "gjx_shard_resample_step: internal error (message counts do not match the plan)");
     if (n_lo + n_hi) {
       const int64_t n = (n_lo + n_hi) * R;
       hipLaunchKernelGGL(k_shard_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)c->recv, n_lo, n_hi, R, rows_out,

@@ -305,6 +305,11 @@ int gjx_shard_ctx_destroy(gjx_shard_ctx* ctx);
 int gjx_shard_resample_step(gjx_shard_ctx* ctx, const float* logw, const float* local_lse, const float* rows_in,
                             int64_t in_stride, float* rows_out, int64_t out_stride, double u, float* lse_out,
                             int64_t* info_host, void* stream);
+/* host arithmetic only: one rank's message sizes from the plan.  send_counts / recv_counts int64[n_ranks];
+ * parts4 (optional) = {children sent to lower ranks, to higher ranks, received from lower, from higher}.
+ * send_counts[d] on rank r == recv_counts[r] on rank d for every pair, because all ranks hold the same bounds. */
+int gjx_shard_message_counts(const gjx_shard_plan* plan, int32_t rank, int64_t N_total, int64_t* send_counts,
+                             int64_t* recv_counts, int64_t* parts4);
 /* dst[r*dst_row_stride + j*dst_col_stride] = src[r*src_row_stride + idx(j)*src_col_stride], idx = anc[j] or j
  * when anc is NULL: packs children into [n][rows] messages and unpacks received ones */
 int gjx_gather_rows_strided(const float* src, int64_t src_row_stride, int64_t src_col_stride, const int32_t* anc,

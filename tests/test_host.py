@@ -274,3 +274,57 @@ def test_hierarchical_addresses_and_nested_calls():
     # packing with a hierarchical constraint: observed sites leave the slot table
     prog, shared, pp = model.pack((np.arange(4.0),), obs, True)
     assert prog.slot_of[("a", "y")] == -1 and prog.slot_of[(("tracks", "obs_pos"), 1)] == -1 and prog.slot_of[("a", "x")] >= 0
+
+
+def test_shard_message_counts_are_pairwise_consistent():
+    """The C++ message-size arithmetic that drives the grouped ncclSend/ncclRecv (gjx_shard_message_counts, host
+    only): for random and degenerate weight totals and 1..8 ranks, what rank r sends to d is exactly what d expects
+    from r (the no-hang condition of the exchange), every output slot is produced once and stored once, and the
+    counts equal the Python exchange's (distributed.resample_exchange uses the same plan)."""
+    import ctypes as C
+    from genjax_amd import _lib
+    from genjax_amd.distributed import HostPlan, shard
+    lib = _lib.load()
+    rs = np.random.default_rng(0)
+    cases = 0
+    for G in (1, 2, 3, 4, 7, 8):
+        for trial in range(40):
+            N = int(rs.integers(G, 5000)) if trial % 3 else G * 1024
+            kind = trial % 5
+            if kind == 0:
+                tot = rs.integers(1, 1 << 40, G)
+            elif kind == 1:
+                tot = np.zeros(G, np.int64); tot[rs.integers(0, G)] = 12345            # all mass on one rank
+            elif kind == 2:
+                tot = rs.integers(0, 3, G) * rs.integers(1, 1 << 30, G); tot[0] += (tot.sum() == 0)
+            elif kind == 3:
+                tot = np.full(G, 1 << 30, np.int64) + rs.integers(-1000, 1000, G)      # nearly balanced
+            else:
+                tot = (rs.random(G) ** 6 * (1 << 35)).astype(np.int64) + 1             # a few dominant ranks
+            totals = [int(t) for t in tot]
+            u = float(rs.random())
+            send = np.zeros((G, G), np.int64)
+            recv = np.zeros((G, G), np.int64)
+            for r in range(G):
+                hp = HostPlan(totals, r, u, N)
+                p = A.GjxShardPlan()
+                p.base, p.total, p.slot0, p.n_valid = hp.base, hp.total, hp.slot0, hp.n_valid
+                p.own_lo, p.own_n, p.keep_lo, p.keep_hi, p.n_ranks, p.status = hp.own_lo, hp.own_n, hp.keep_lo, hp.keep_hi, G, hp.status
+                for k, b in enumerate(hp.bounds):
+                    p.bounds[k] = b
+                sc, rc_, parts = (C.c_int64 * G)(), (C.c_int64 * G)(), (C.c_int64 * 4)()
+                assert lib.gjx_shard_message_counts(C.byref(p), r, N, C.cast(sc, C.c_void_p), C.cast(rc_, C.c_void_p),
+                                                    C.cast(parts, C.c_void_p)) == 0, lib.gjx_last_error()
+                send[r], recv[r] = list(sc), list(rc_)
+                # the Python exchange's counts (resample_exchange): overlaps of runs and shards
+                owners = [shard(N, d, G) for d in range(G)]
+                ov = lambda a0, a1, b0, b1: max(0, min(a1, b1) - max(a0, b0))
+                want_s = [0 if d == r else ov(hp.slot0, hp.slot0 + hp.n_valid, lo, lo + k) for d, (lo, k) in enumerate(owners)]
+                want_r = [0 if s_ == r else ov(hp.bounds[s_], hp.bounds[s_ + 1], hp.own_lo, hp.own_lo + hp.own_n) for s_ in range(G)]
+                assert list(sc) == want_s and list(rc_) == want_r
+                assert parts[0] + parts[1] == sum(want_s) and parts[2] + parts[3] == sum(want_r)
+                assert hp.keep_hi - hp.keep_lo + sum(want_r) == hp.own_n          # every stored slot arrives exactly once
+            np.testing.assert_array_equal(send, recv.T)                            # pairwise agreement: no rank waits for bytes nobody sends
+            assert send.sum() + sum(HostPlan(totals, r, u, N).keep_hi - HostPlan(totals, r, u, N).keep_lo for r in range(G)) == N
+            cases += 1
+    assert cases == 240
