@@ -11,8 +11,8 @@ from .core import (C, ChoiceMap, ChoiceMapBuilder, S, Selection, SelectionBuilde
 from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gumbel, half_cauchy, inverse_gamma,
                   logit_normal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
-                  mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
-from .inference import (HMC, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
+                  iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
+from .inference import (HMC, IndexRequest, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
                         ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, Update)
 from .program import AddressReuse, MissingAddress  # noqa: F401
 

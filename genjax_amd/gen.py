@@ -317,7 +317,7 @@ class DistCall:
     def __matmul__(self, addr):
         t = _Tracer.current()
         path = t.prefix + (tuple(addr) if isinstance(addr, tuple) else (addr,))
-        addr = path[0] if len(path) == 1 else path
+        addr = path[0] if len(path) == 1 else (path if path else _VALUE)
         if t.step is not None:
             addr = (addr, t.step)
         site = t.sites.add(addr, self.kind, self.params, self.dim)
@@ -445,6 +445,19 @@ class Trace:
 
     def edit(self, key: Key, request, argdiffs=None):
         return request.edit(key, self, argdiffs)
+
+    def project(self, key: Key, selection: Selection):
+        """Sum of the scores of the selected choices (generative_function.py:184-194; static.py project: the
+        per-site score of every selected site).  One assess launch with per-site scores."""
+        import torch
+        from . import kernels
+        from .inference.requests import _rows_and_shared
+        shared, rows = _rows_and_shared(self)
+        prog, _, _ = self.gen_fn.pack(self.args, shared, False, rng_mode=self.prog.rng_mode, per_particle=tuple(rows))
+        out = kernels.run_program(prog, (0, 0), self.K, choices=self.choices.clone(), want_site_scores=True, want_lse=False)
+        sel = [j for j, s in enumerate(prog.site_list.sites) if selection.check(s.addr)]
+        tot = out["site_scores"][sel].sum(dim=0) if sel else torch.zeros(self.K, device=self.score.device)
+        return tot if self.batched else tot[0]
 
     def full_choice_rows(self) -> dict:
         """addr -> device rows [dim][K] for every site (shared values broadcast)."""
@@ -742,6 +755,44 @@ def repeat(n: int) -> Callable:
     return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).repeat(n)
 
 
+def iterate(n: int) -> Callable:
+    """``@genjax.iterate(n=T)`` (combinators/scan.py:916-990): ``a -> a`` applied T times; all traced values nested
+    under the step index; returns [init, f(init), f(f(init)), ...]."""
+    def deco(f):
+        g = f if isinstance(f, StaticGenerativeFunction) else gen(f)
+
+        def kernel(carry, _):
+            out = g.source(carry)
+            return out, out
+        sc = ScanCombinator(StaticGenerativeFunction(kernel), int(n))
+        return _Iterate(sc, final=False)
+    return deco
+
+
+def iterate_final(n: int) -> Callable:
+    """``@genjax.iterate_final(n=T)``: as iterate, returning only the final value."""
+    def deco(f):
+        it = iterate(n)(f)
+        it.final = True
+        return it
+    return deco
+
+
+class _Iterate(GenerativeFunction):
+    def __init__(self, sc: "ScanCombinator", final: bool):
+        self.sc, self.final = sc, final
+
+    def site_list(self, args):
+        sl, (carry, outs) = self.sc.site_list((args[0], None))
+        return sl, (carry if self.final else [args[0]] + list(outs))
+
+    def __call__(self, init):
+        def inline(t):
+            carry, outs = self.sc._unroll(t, init, None)
+            return carry if self.final else [init] + list(outs)
+        return GenCall(inline)
+
+
 def scan(n: int) -> Callable:
     """``@genjax.scan(n=T)`` decorator form (combinators/scan.py)."""
     return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).scan(n)
@@ -821,6 +872,11 @@ class Distribution(GenerativeFunction):
         return self._as_gen(args).generate(key, constraint, (), K)
 
     importance = generate
+
+    def vmap(self, in_axes=0) -> "VmapCombinator":
+        """``genjax.normal.vmap()(locs, scales) @ "a"``: one independent draw per index, addressed ["a", i]."""
+        d = self
+        return VmapCombinator(StaticGenerativeFunction(lambda *a: d(*a) @ _VALUE), in_axes)
 
     def random_weighted(self, key, *args):
         tr = self.simulate(key, args)

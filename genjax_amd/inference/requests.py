@@ -154,6 +154,14 @@ class Rejuvenate(EditRequest):
         raise NotImplementedError("address a Rejuvenate move through StaticRequest({addr: Rejuvenate(...)})")
 
 
+class IndexRequest(EditRequest):
+    """A request for ONE instance of a vmap / scan level (concepts.py:154-165); used inside a StaticRequest as
+    ``{"a": IndexRequest(idx, Regenerate(S.all()))}``."""
+
+    def __init__(self, idx, request: EditRequest):
+        self.idx, self.request = int(np.asarray(idx)), request
+
+
 class StaticRequest(EditRequest):
     """Address-wise composition of requests (generative_functions/static.py:130-131): ``{addr: request}``."""
 
@@ -177,10 +185,42 @@ class StaticRequest(EditRequest):
             return Update(ChoiceMap({key_of(cls._join(prefix, a)): v for a, v in req.constraint.items()}))
         if isinstance(req, StaticRequest):
             return StaticRequest({key_of(cls._join(prefix, a)): r for a, r in req.addressed.items()})
+        if isinstance(req, IndexRequest):
+            return cls._reroot_indexed(req, prefix)
         raise NotImplementedError(f"{type(req).__name__} addressed to a sub-generative-function")
+
+    _sites = None   # set per edit: the trace's site keys, for IndexRequest resolution
+
+    @classmethod
+    def _reroot_indexed(cls, req: "IndexRequest", prefix):
+        """instance ``idx`` of the vmap / scan level at ``prefix``: its sites are the keys (name, idx) whose name path
+        starts with the prefix; the sub-request's addresses are relative to the instance"""
+        from ..core import norm_addr
+        pre = tuple(prefix) if isinstance(prefix, tuple) else (prefix,)
+        inst = []
+        for k in cls._sites or ():
+            name, idx = norm_addr(k)
+            path = name if isinstance(name, tuple) else (name,)
+            if idx == req.idx and path[: len(pre)] == pre:
+                rel = path[len(pre):]
+                inst.append((k, rel[0] if len(rel) == 1 else rel))      # rel == () for a vmapped distribution
+        if not inst:
+            raise KeyError(f"IndexRequest({req.idx}) addressed to {prefix!r}: no such instance")
+        sub = req.request
+        if isinstance(sub, Regenerate):
+            return Regenerate(Selection(k for k, rel in inst if sub.selection.check(rel)))
+        if isinstance(sub, Update):
+            if sub.constraint.has_value():
+                (k, _), = [x for x in inst if x[1] == ()]
+                return Update(ChoiceMap({k: sub.constraint.get_value()}))
+            return Update(ChoiceMap({k: sub.constraint[rel] for k, rel in inst if rel in sub.constraint}))
+        if isinstance(sub, HMC):
+            return HMC(Selection(k for k, rel in inst if sub.selection.check(rel)), sub.eps, sub.L, sub.stale_gradient_compat, sub.accept)
+        raise NotImplementedError(f"IndexRequest around {type(sub).__name__}")
 
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         from ..core import fold_in
+        StaticRequest._sites = [s.addr for s in tr.prog.site_list.sites]
         total, bwd, bwd_abs = None, {}, []
         for n, req in enumerate(self.absolute):
             tr, w, _, b = req.edit(fold_in(key, 1000 + n), tr, argdiffs)
