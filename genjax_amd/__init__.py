@@ -6,7 +6,7 @@ kernels behind the C ABI of ``include/gjx.h`` (``genjax_amd/csrc/libgjx_hip.so``
 fallback: compute entry points raise ``GjxError`` if the library is missing.
 """
 from . import config, inference  # noqa: F401
-from .core import (C, ChoiceMap, ChoiceMapBuilder, S, Selection, SelectionBuilder, fold_in, key,  # noqa: F401
+from .core import (C, ChoiceMap, ChoiceMapBuilder, Diff, NoChange, S, Selection, SelectionBuilder, UnknownChange, fold_in, key,  # noqa: F401
                    split)
 from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gumbel, half_cauchy, inverse_gamma,
                   logit_normal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401

@@ -54,6 +54,42 @@ def split(k: Key, num: int = 2) -> list[Key]:
 
 
 # ---------------------------------------------------------------------------------------------
+# Argument change tags (core/interpreters/incremental.py:  Diff, NoChange, UnknownChange).  The kernels always
+# recompute every visited density, so the tag only matters as API surface: ``Diff.tree_primal`` strips it.
+# ---------------------------------------------------------------------------------------------
+class _ChangeTag:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return self.name
+
+
+NoChange, UnknownChange = _ChangeTag("NoChange"), _ChangeTag("UnknownChange")
+
+
+class Diff:
+    def __init__(self, primal, tangent=UnknownChange):
+        self.primal, self.tangent = primal, tangent
+
+    @staticmethod
+    def no_change(v):
+        return tuple(Diff(x, NoChange) for x in v) if isinstance(v, tuple) else Diff(v, NoChange)
+
+    @staticmethod
+    def unknown_change(v):
+        return tuple(Diff(x, UnknownChange) for x in v) if isinstance(v, tuple) else Diff(v, UnknownChange)
+
+    @staticmethod
+    def tree_primal(v):
+        if isinstance(v, Diff):
+            return Diff.tree_primal(v.primal)
+        if isinstance(v, (tuple, list)):
+            return type(v)(Diff.tree_primal(x) for x in v)
+        return v
+
+
+# ---------------------------------------------------------------------------------------------
 # Addresses.  The reference addresses a choice by a path of strings with at most one index component for a
 # Scan/Vmap level: "x", ("sub", "x"), ("tracks", 3, "pos"), ("tracks", slice(None), "pos"), (3, "x")
 # (choice_map.py:847-1395, scan.py:56-97).  Internally a site is keyed by ``name`` or ``(name, i)`` where
@@ -317,6 +353,14 @@ class ChoiceMap:
         return ChoiceMap(d)
 
     __or__ = merge
+
+    def mask(self, flag) -> "ChoiceMap":
+        """``chm.mask(flag)`` (choice_map.py Mask): present when the flag is true.  Host booleans only — a
+        per-particle flag would have to mix constrained and sampled particles in one site."""
+        f = np.asarray(flag.detach().cpu() if hasattr(flag, "detach") else flag)
+        if f.ndim != 0:
+            raise NotImplementedError("ChoiceMap.mask with a per-particle flag")
+        return self if bool(f) else ChoiceMap()
 
     def filter(self, selection: Selection) -> "ChoiceMap":
         return ChoiceMap({a: v for a, v in self._d.items() if selection.check(a)})

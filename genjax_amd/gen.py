@@ -324,6 +324,20 @@ class DistCall:
         return SiteVal(addr, site.dim, self.kind)
 
 
+def _distcall_api(cls):
+    """``genjax.normal(0.0, 1.0).simulate(key, ())``: a distribution applied to its parameters is itself a generative
+    function without arguments (distribution.py:108-147)."""
+    def bound(self):
+        return self.dist._as_gen_with_args(), tuple(self.params)
+    cls.simulate = lambda self, key, args=(), K=None: bound(self)[0].simulate(key, bound(self)[1], K)
+    cls.assess = lambda self, chm, args=(): self.dist.assess(chm, bound(self)[1])
+    cls.importance = cls.generate = lambda self, key, chm, args=(), K=None: bound(self)[0].generate(key, chm, bound(self)[1], K)
+    return cls
+
+
+_distcall_api(DistCall)
+
+
 class GenCall:
     """``callee(*args)`` inside a model body; ``@ "addr"`` inlines the callee's sites under that address
     (static.py:340-399: the handler recurses into the callee with the sub-choicemap at ``addr``)."""
@@ -851,11 +865,23 @@ class Distribution(GenerativeFunction):
             return d(*args, **(kwargs or {})) @ _VALUE
         return StaticGenerativeFunction(body)
 
+    def _as_gen_with_args(self) -> StaticGenerativeFunction:
+        """one-site @gen function that takes the distribution's parameters as ITS arguments, so that a trace can be
+        updated under new arguments (distribution.py:179-244)"""
+        if getattr(self, "_argful", None) is None:
+            d = self
+            self._argful = StaticGenerativeFunction(lambda *a: d(*a) @ _VALUE)
+            self._argful.__name__ = self.name
+        return self._argful
+
     def site_list(self, args):
         return self._as_gen(args).site_list(())
 
     def simulate(self, key, args=(), K=None):
-        return self._as_gen(args).simulate(key, (), K)
+        return self._as_gen_with_args().simulate(key, tuple(args), K)
+
+    def update(self, key, trace, constraint: ChoiceMap, argdiffs=None):
+        return self._as_gen_with_args().update(key, trace, constraint, argdiffs)
 
     def sample(self, key, *args, **kwargs):
         return self._as_gen(args, kwargs).simulate(key, ()).get_choices()[_VALUE]
@@ -869,7 +895,7 @@ class Distribution(GenerativeFunction):
         return g.assess(ChoiceMap.v(v), ())
 
     def generate(self, key, constraint: ChoiceMap, args=(), K=None):
-        return self._as_gen(args).generate(key, constraint, (), K)
+        return self._as_gen_with_args().generate(key, constraint, tuple(args), K)
 
     importance = generate
 

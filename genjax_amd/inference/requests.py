@@ -24,6 +24,18 @@ def _rows_and_shared(tr: Trace):
     return shared, rows
 
 
+def _new_args(tr: Trace, argdiffs):
+    """arguments of the edited trace: the primals of ``argdiffs`` (Diff-tagged or plain), or the old ones"""
+    from ..core import Diff
+    if argdiffs is None or (isinstance(argdiffs, tuple) and len(argdiffs) == 0 and len(tr.args) != 0):
+        return tr.args
+    args = Diff.tree_primal(argdiffs)
+    args = tuple(args) if isinstance(args, (tuple, list)) else (args,)
+    if len(args) != len(tr.args):
+        raise ValueError(f"argdiffs has {len(args)} entries, the trace's generative function takes {len(tr.args)}")
+    return args
+
+
 class Update(EditRequest):
     """Replace the values at the constrained addresses, keep the rest; weight = new score - old score
     (generative_function.py:1687-1689, distribution.py:179-244, static.py:827-865)."""
@@ -33,8 +45,9 @@ class Update(EditRequest):
 
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         shared, rows = _rows_and_shared(tr)
+        args = _new_args(tr, argdiffs)
         discard = {}
-        for addr, v in self.constraint.items():
+        for addr, v in self.constraint._d.items():          # including the bare-value address () of a distribution trace
             s = tr.prog.site_list[addr]
             discard[addr] = tr._site_value(addr)
             sv, r = _value_rows(v, s.dim)
@@ -45,7 +58,7 @@ class Update(EditRequest):
                 if r is not None:
                     raise ValueError(f"{addr!r} is constrained to one shared value in this trace")
                 shared = ChoiceMap({**dict(shared.items()), addr: sv})
-        new_tr, out = tr.gen_fn._run(key, tr.K, tr.args, shared, False, tr.batched, prev_rows=rows)
+        new_tr, out = tr.gen_fn._run(key, tr.K, args, shared, False, tr.batched, prev_rows=rows)
         w = out["score"] - tr.score
         return new_tr, (w if tr.batched else w[0]), None, Update(ChoiceMap(discard))
 
@@ -68,7 +81,7 @@ class Regenerate(EditRequest):
                     del rows[s.addr]
                 else:
                     shared = ChoiceMap({a: v for a, v in shared.items() if a != s.addr})
-        new_tr, out = tr.gen_fn._run(key, tr.K, tr.args, shared, True, tr.batched, prev_rows=rows)
+        new_tr, out = tr.gen_fn._run(key, tr.K, _new_args(tr, argdiffs), shared, True, tr.batched, prev_rows=rows)
         w = out["score"] - tr.score
         return new_tr, (w if tr.batched else w[0]), None, Update(ChoiceMap(old))
 

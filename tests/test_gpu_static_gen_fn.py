@@ -320,3 +320,80 @@ class TestStaticGenFnAddresses:
         assert f(w) == pytest.approx(want, rel=1e-4, abs=1e-4)
         back, w2, _, _ = bwd.edit(genjax.key(7), new_tr, ())
         assert f(back.get_choices()["x", "a"]) == pytest.approx(f(old["x", "a"]))
+
+
+class TestDistributions:
+    """tests/generative_functions/test_distributions.py:22-190 (per-site semantics of distribution.py:117-244);
+    masks with host booleans only."""
+
+    def test_simulate(self):                                                 # :23-26
+        tr = genjax.normal(0.0, 1.0).simulate(genjax.key(314159), ())
+        assert f(tr.get_score()) == f(genjax.normal(0.0, 1.0).assess(tr.get_choices(), ())[0])
+
+    def test_importance(self):                                               # :28-58
+        key = genjax.key(314159)
+        (tr, w) = genjax.normal.importance(key, C.n(), (0.0, 1.0))
+        assert f(w) == 0.0
+        (tr, w) = genjax.normal.importance(key, C.v(1.0), (0.0, 1.0))
+        assert f(w) == f(genjax.normal(0.0, 1.0).assess(tr.get_choices(), ())[0])
+        (tr, w) = genjax.normal.importance(key, C.v(1.0).mask(np.array(True)), (0.0, 1.0))
+        v = f(tr.get_choices().get_value())
+        assert v == 1.0 and f(w) == f(genjax.normal.assess(C.v(v), (0.0, 1.0))[0])
+        (tr, w) = genjax.normal.importance(key, C.v(1.0).mask(np.array(False)), (0.0, 1.0))
+        assert f(tr.get_choices().get_value()) != 1.0 and f(w) == 0.0
+
+    def test_update(self):                                                   # :60-190
+        from genjax_amd import Diff, NoChange, UnknownChange
+        key, sub_key = genjax.split(genjax.key(314159))
+        tr = genjax.normal.simulate(sub_key, (0.0, 1.0))
+        old = tr.get_choices()
+        a = lambda chm, args: f(genjax.normal.assess(chm, args)[0])
+        same = (Diff(0.0, NoChange), Diff(1.0, NoChange))
+        # no constraint, no change to arguments
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.n(), same)
+        assert f(new_tr.get_choices().get_value()) == f(old.get_value())
+        assert f(new_tr.get_score()) == pytest.approx(a(old, (0.0, 1.0)), rel=1e-6) and f(w) == 0.0
+        # constraint, no change to arguments
+        (new_tr, w, _, discard) = genjax.normal.update(sub_key, tr, C.v(1.0), same)
+        assert f(new_tr.get_choices().get_value()) == 1.0 and f(discard.get_value()) == f(old.get_value())
+        assert f(new_tr.get_score()) == pytest.approx(a(C.v(1.0), (0.0, 1.0)), rel=1e-6)
+        assert f(w) == pytest.approx(a(C.v(1.0), (0.0, 1.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+        # no constraint, change to arguments
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.n(), (Diff(1.0, UnknownChange), Diff(1.0, NoChange)))
+        assert f(new_tr.get_choices().get_value()) == f(old.get_value())
+        assert f(new_tr.get_score()) == pytest.approx(a(old, (1.0, 1.0)), rel=1e-6)
+        assert f(w) == pytest.approx(a(old, (1.0, 1.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+        # constraint, change to arguments
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.v(1.0), (Diff(1.0, UnknownChange), Diff(2.0, UnknownChange)))
+        assert f(new_tr.get_choices().get_value()) == 1.0
+        assert f(new_tr.get_score()) == pytest.approx(a(C.v(1.0), (1.0, 2.0)), rel=1e-6)
+        assert f(w) == pytest.approx(a(C.v(1.0), (1.0, 2.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+        # masked constraints (True / False), with and without argument changes
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.v(1.0).mask(np.array(True)), same)
+        assert f(new_tr.get_choices().get_value()) == 1.0
+        assert f(w) == pytest.approx(a(C.v(1.0), (0.0, 1.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.v(1.0).mask(True), (Diff(1.0, UnknownChange), Diff(1.0, NoChange)))
+        assert f(new_tr.get_choices().get_value()) == 1.0
+        assert f(w) == pytest.approx(a(C.v(1.0), (1.0, 1.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.v(1.0).mask(False), same)
+        assert f(new_tr.get_choices().get_value()) == f(old.get_value()) and f(w) == 0.0
+        (new_tr, w, _, _) = genjax.normal.update(sub_key, tr, C.v(1.0).mask(False), (Diff(1.0, UnknownChange), Diff(1.0, NoChange)))
+        assert f(new_tr.get_choices().get_value()) == f(old.get_value())
+        assert f(w) == pytest.approx(a(old, (1.0, 1.0)) - a(old, (0.0, 1.0)), rel=1e-5, abs=1e-6)
+
+    def test_update_with_changed_model_arguments(self):
+        """static.py:827-865 with argdiffs: an @gen function re-scored under new arguments, choices kept."""
+        from genjax_amd import Diff
+
+        @genjax.gen
+        def model(mu, sd):
+            x = genjax.normal(mu, sd) @ "x"
+            y = genjax.normal(x, 0.5) @ "y"
+            return y
+
+        tr = model.simulate(genjax.key(2), (0.0, 1.0))
+        ch = tr.get_choices()
+        new_tr, w, _, _ = model.update(genjax.key(3), tr, C.n(), Diff.unknown_change((1.0, 2.0)))
+        assert f(new_tr.get_choices()["x"]) == f(ch["x"]) and new_tr.get_args() == (1.0, 2.0)
+        lpn = lambda v, m, s: -0.5 * ((v - m) / s) ** 2 - math.log(s) - 0.5 * math.log(2 * math.pi)
+        assert f(w) == pytest.approx(lpn(f(ch["x"]), 1.0, 2.0) - lpn(f(ch["x"]), 0.0, 1.0), rel=1e-4, abs=1e-5)
