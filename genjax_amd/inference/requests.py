@@ -188,8 +188,9 @@ class StaticRequest(EditRequest):
         return pre + (tuple(addr) if isinstance(addr, tuple) else (addr,))
 
     @classmethod
-    def _reroot(cls, req, prefix):
-        """the request ``req`` addressed to the callee at ``prefix``, as a request on the enclosing trace"""
+    def _reroot(cls, req, prefix, sites=()):
+        """the request ``req`` addressed to the callee at ``prefix``, as a request on the enclosing trace whose site
+        keys are ``sites``"""
         if isinstance(req, HMC):
             return HMC(req.selection.prefixed(prefix), req.eps, req.L, req.stale_gradient_compat, req.accept)
         if isinstance(req, Regenerate):
@@ -199,19 +200,17 @@ class StaticRequest(EditRequest):
         if isinstance(req, StaticRequest):
             return StaticRequest({key_of(cls._join(prefix, a)): r for a, r in req.addressed.items()})
         if isinstance(req, IndexRequest):
-            return cls._reroot_indexed(req, prefix)
+            return cls._reroot_indexed(req, prefix, sites)
         raise NotImplementedError(f"{type(req).__name__} addressed to a sub-generative-function")
 
-    _sites = None   # set per edit: the trace's site keys, for IndexRequest resolution
-
     @classmethod
-    def _reroot_indexed(cls, req: "IndexRequest", prefix):
+    def _reroot_indexed(cls, req: "IndexRequest", prefix, sites):
         """instance ``idx`` of the vmap / scan level at ``prefix``: its sites are the keys (name, idx) whose name path
         starts with the prefix; the sub-request's addresses are relative to the instance"""
         from ..core import norm_addr
         pre = tuple(prefix) if isinstance(prefix, tuple) else (prefix,)
         inst = []
-        for k in cls._sites or ():
+        for k in sites:
             name, idx = norm_addr(k)
             path = name if isinstance(name, tuple) else (name,)
             if idx == req.idx and path[: len(pre)] == pre:
@@ -233,7 +232,7 @@ class StaticRequest(EditRequest):
 
     def edit(self, key: Key, tr: Trace, argdiffs=None):
         from ..core import fold_in
-        StaticRequest._sites = [s.addr for s in tr.prog.site_list.sites]
+        sites = [s.addr for s in tr.prog.site_list.sites]
         total, bwd, bwd_abs = None, {}, []
         for n, req in enumerate(self.absolute):
             tr, w, _, b = req.edit(fold_in(key, 1000 + n), tr, argdiffs)
@@ -244,7 +243,7 @@ class StaticRequest(EditRequest):
             if key_of(addr) not in tr.prog.site_list:          # the address of a callee: recurse with re-rooted request
                 if isinstance(req, Update) and req.constraint.has_value():
                     raise KeyError(f"Update(C.choice(v)) addressed to {addr!r}, which is not a leaf choice")
-                tr, w, _, b = self._reroot(req, addr).edit(k, tr, argdiffs)
+                tr, w, _, b = self._reroot(req, addr, sites).edit(k, tr, argdiffs)
                 total = w if total is None else total + w
                 bwd_abs.append(b)                              # its addresses are already those of this trace
                 continue
