@@ -247,6 +247,22 @@ class ChangeTarget(SMCAlgorithm):
     def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
         return self._reweight(key, self.prev.run_csmc(key, retained))
 
+    def run_csmc_for_normalizing_constant(self, key: Key, latent_choices: ChoiceMap, w):
+        """smc.py:432-465: reciprocal-normalising-constant estimate used by the variational interface — the K-1 fresh
+        particles are reweighted to this target, the retained one keeps the caller's weight ``w``."""
+        import math
+        import torch
+        from .. import kernels
+        from ..core import split
+        key, sub_key = split(key)
+        coll = self.prev.run_csmc(sub_key, latent_choices)
+        lw = self._reweight(key, coll).get_log_weights().clone()
+        retained_score = coll.get_particles().score[-1]
+        retained_weight = coll.get_log_weights()[-1]
+        lw[-1] = torch.as_tensor(w, dtype=lw.dtype, device=lw.device) - retained_score + retained_weight
+        total = kernels.logsumexp(lw.contiguous())[2]
+        return retained_score - (total - math.log(self.get_num_particles()))
+
 
 def _host(v):
     return v.detach().cpu().numpy() if hasattr(v, "detach") else v

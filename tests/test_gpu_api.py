@@ -178,6 +178,14 @@ class TestSMC:
         # smc.py:181-199 scores the SAMPLED particle: an estimate of log p(x* | y) at a posterior draw x*,
         # bounded by the density at the mode of N(0.8, sqrt(.2))
         assert math.isfinite(f(lp)) and f(lp) < -0.5 * math.log(2 * math.pi * 0.2) + 0.05
+        # smc.py:432-465: returns retained_score - log-mean-weight, where the retained particle's score is taken under
+        # the PREVIOUS target (y = 1) and the weights are those of the new one (their log-mean estimates log p(y = 2))
+        ct = ChangeTarget(alg, t2)
+        xs = 1.6
+        joint = (-0.5 * xs * xs - 0.5 * math.log(2 * math.pi)) + (-0.5 * ((2.0 - xs) / 0.5) ** 2 - math.log(0.5) - 0.5 * math.log(2 * math.pi))
+        est = f(ct.run_csmc_for_normalizing_constant(genjax.key(6), C["x"].set(xs), joint))
+        score_t1 = (-0.5 * xs * xs - 0.5 * math.log(2 * math.pi)) + (-0.5 * ((1.0 - xs) / 0.5) ** 2 - math.log(0.5) - 0.5 * math.log(2 * math.pi))
+        assert est == pytest.approx(score_t1 - exact2, abs=0.05)
 
 
 class TestGFI:
