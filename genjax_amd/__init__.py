@@ -9,7 +9,7 @@ from . import config, inference  # noqa: F401
 from .core import (C, ChoiceMap, ChoiceMapBuilder, Diff, NoChange, S, Selection, SelectionBuilder, UnknownChange, fold_in, key,  # noqa: F401
                    split)
 from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gumbel, half_cauchy, inverse_gamma,
-                  logit_normal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
+                  logit_normal, marginal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .inference import (HMC, IndexRequest, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401

@@ -831,10 +831,42 @@ def _args_key(args) -> tuple:
 
 
 class Marginal(GenerativeFunction):
-    """inference/sp.py:207-252 — only constructed so that Target can reject it (sp.py:46-49)."""
+    """The marginal of a generative function over a selection of addresses, as a sample distribution
+    (inference/sp.py:207-252).  ``Target`` refuses it as a model (sp.py:46-49); as a PROPOSAL it is what
+    ``gen_fn.marginal()`` hands to ``ImportanceK(target, q=...)``."""
 
     def __init__(self, gen_fn, selection, algorithm=None):
         self.gen_fn, self.selection, self.algorithm = gen_fn, selection, algorithm
+
+    def random_weighted(self, key: Key, *args):
+        """-> (score estimate, choices of the selection)  (sp.py:216-238): simulate, keep the selected choices; the
+        weight is the projection on the UNSELECTED choices, or, with an inference algorithm, its estimate of the
+        reciprocal normalising constant of Target(gen_fn, args, selected choices)."""
+        from .inference.smc import Target
+        key, sub_key = split(key)
+        tr = self.gen_fn.simulate(sub_key, args)
+        choices = tr.get_choices()
+        latent_choices = choices.filter(self.selection)
+        key, sub_key = split(key)
+        weight = tr.project(sub_key, ~self.selection)
+        if self.algorithm is None:
+            return weight, latent_choices
+        target = Target(self.gen_fn, args, latent_choices)
+        other_choices = choices.filter(~self.selection)
+        return self.algorithm.estimate_reciprocal_normalizing_constant(key, target, other_choices, weight), latent_choices
+
+    def estimate_logpdf(self, key: Key, v: ChoiceMap, *args):
+        """sp.py:240-252: importance weight of the given choices, or the algorithm's normalising-constant estimate"""
+        from .inference.smc import Target
+        if self.algorithm is None:
+            _, weight = self.gen_fn.importance(key, v, args)
+            return weight
+        return self.algorithm.estimate_normalizing_constant(key, Target(self.gen_fn, args, v))
+
+
+def marginal(selection: Selection | None = None, algorithm=None) -> Callable:
+    """``@genjax.marginal(selection, algorithm)`` (sp.py:260-275)"""
+    return lambda gen_fn: Marginal(gen_fn, selection or Selection.all(), algorithm)
 
 
 # ---------------------------------------------------------------------------------------------

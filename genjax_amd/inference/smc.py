@@ -130,6 +130,11 @@ class SMCAlgorithm:
         key, sub_key = split(key)
         return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
 
+    def estimate_reciprocal_normalizing_constant(self, key: Key, target: Target, latent_choices: ChoiceMap, w):
+        """smc.py:213-225: ``w`` with ``latent_choices`` is already properly weighted for ``target``, so the retained
+        particle skips the reweighting step (ChangeTarget.run_csmc_for_normalizing_constant)."""
+        return ChangeTarget(self, target).run_csmc_for_normalizing_constant(key, latent_choices, w)
+
     def simulate(self, key: Key, args: tuple):
         """Distribution.simulate of an Algorithm (distribution.py:108-115): (score, choices) as a pair."""
         w, chm = self.random_weighted(key, *args)

@@ -628,3 +628,51 @@ class TestWiderDistributions:
         lml = f(pc.get_log_marginal_likelihood_estimate())
         want_lml = float(np.log(np.trapezoid(np.exp(logp - logp.max()), grid)) + logp.max())
         assert lml == pytest.approx(want_lml, abs=2e-2)
+
+
+class TestMarginal:
+    def test_marginal_without_algorithm(self):
+        """sp.py:216-252: Marginal over a selection, no inference algorithm: random_weighted returns the selected choices
+        with the projection on the rest as weight; estimate_logpdf is the importance weight of the given choices."""
+        @genjax.gen
+        def model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = genjax.normal(x, 0.5) @ "y"
+            return y
+
+        m = model.marginal(S["y"])
+        w, chm = m.random_weighted(genjax.key(3))
+        assert "y" in chm and "x" not in chm
+        # the weight is log p(x) of the unselected choice that was simulated alongside; finite and <= its mode
+        assert math.isfinite(f(w)) and f(w) <= -0.5 * math.log(2 * math.pi) + 1e-6
+        lp = m.estimate_logpdf(genjax.key(4), C["y"].set(0.7))
+        # one-sample importance weight log N(0.7; x, 0.5) with x ~ prior
+        assert math.isfinite(f(lp)) and f(lp) <= -math.log(0.5) - 0.5 * math.log(2 * math.pi) + 1e-6
+
+    def test_marginal_with_importance_k(self):
+        """sp.py:240-252 with an algorithm: the density estimate of the marginal p(y) through ImportanceK, and the
+        random_weighted path through estimate_reciprocal_normalizing_constant (smc.py:213-225, 432-465)."""
+        @genjax.gen
+        def model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = genjax.normal(x, 0.5) @ "y"
+            return y
+
+        K = 1 << 14
+        alg = ImportanceK(Target(model, (), C["y"].set(0.0)), k_particles=K)      # proposal: the prior over x
+        m = genjax.marginal(S["y"], alg)(model)
+        est = f(m.estimate_logpdf(genjax.key(5), C["y"].set(0.7)))
+        exact = -0.5 * 0.49 / 1.25 - 0.5 * math.log(2 * math.pi * 1.25)            # y ~ N(0, sqrt(1.25))
+        assert est == pytest.approx(exact, abs=0.03)
+        w, chm = m.random_weighted(genjax.key(6))
+        y = f(chm["y"])
+        # the reference's formula, term by term (sp.py:226-236 -> smc.py:213-225 -> 432-465): the simulated x* is the
+        # retained particle of a conditional run of `alg` (whose own target has y = 0), the K-1 fresh particles are
+        # reweighted to Target(y = sampled y), the retained one gets w - retained_score + retained_weight = 0, and
+        # the result is retained_score - log-mean-weight
+        _, sub_key = genjax.split(genjax.key(6))
+        xs = f(model.simulate(sub_key, ()).get_choices()["x"])
+        lpn = lambda v, mu, sd: -0.5 * ((v - mu) / sd) ** 2 - math.log(sd) - 0.5 * math.log(2 * math.pi)
+        retained_score = lpn(xs, 0.0, 1.0) + lpn(0.0, xs, 0.5)
+        log_p_y = -0.5 * y * y / 1.25 - 0.5 * math.log(2 * math.pi * 1.25)
+        assert f(w) == pytest.approx(retained_score - log_p_y, abs=0.05)
