@@ -364,6 +364,46 @@ def test_one_launch_resample_indices(K_, oracle):
                                   oracle.resample_systematic(cum_o, 0.123, 9999))
 
 
+def test_resampling_fuzz_against_oracle(K_, oracle):
+    """Randomised shapes and weight patterns (zeros, a few giants, many ties, subnormal-scale weights, N != K) through
+    the one-launch resampler and the gather, against the oracle's integer arithmetic: bit-exact every time."""
+    import torch
+    rs = np.random.default_rng(2024)
+    ws = {}
+    for trial in range(60):
+        K = int(rs.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097, 33_333, 131_072, 262_145]))
+        kind = trial % 6
+        if kind == 0:
+            w = rs.random(K)
+        elif kind == 1:
+            w = rs.random(K) * (rs.random(K) < 0.1)                   # mostly zeros
+            w[rs.integers(0, K)] += 1e-3
+        elif kind == 2:
+            w = np.full(K, 0.25)                                      # all ties
+        elif kind == 3:
+            w = rs.random(K) * 1e-6
+            w[rs.integers(0, K, size=max(1, K // 500))] = 1.0         # a few giants
+        elif kind == 4:
+            w = np.exp(rs.standard_normal(K) * 6.0)
+            w /= w.max()
+        else:
+            w = np.zeros(K); w[rs.integers(0, K)] = 1.0               # one survivor
+        w = w.astype(np.float32)
+        N = int(rs.choice([K, max(1, K // 2), 2 * K + 3, 1]))
+        u = float(rs.choice([0.0, 0.5, 0.999999, rs.random()]))
+        cum_o, tot = oracle.weight_cumsum(w)
+        want = oracle.resample_systematic(cum_o, u, N)
+        wd = torch.as_tensor(w).cuda()
+        if K not in ws:
+            ws[K] = K_.workspace(A.OP_RESAMPLE, K)
+        got = K_.resample_indices(wd, u, N, is_log=False, ws=ws[K])
+        np.testing.assert_array_equal(_np(got), want, err_msg=f"trial {trial} K={K} N={N} kind={kind} u={u}")
+        rows = rs.standard_normal((3, K)).astype(np.float32)
+        np.testing.assert_array_equal(_np(K_.gather_rows(torch.as_tensor(rows).cuda(), got)), rows[:, want])
+        counts = np.bincount(want, minlength=K)
+        assert counts[w == 0].sum() == 0                              # weightless particles never survive
+
+
 def test_degenerate_and_invalid_arguments(K_):
     import torch
     from genjax_amd._lib import GjxError
