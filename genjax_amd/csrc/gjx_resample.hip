@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
   __shared__ uint64_t wsum[4], red2[8];
   __shared__ int64_t jlast[256];
   __shared__ int n_heavy;
-  __shared__ int32_t h_i[256];
-  __shared__ int64_t h_lo[256], h_hi[256];
+  constexpr int kHeavyCap = 1024;   // particles with more than kOwn offspring, filled cooperatively; a block holds 256 * ITEMS
+  __shared__ int32_t h_i[kHeavyCap];
+  __shared__ int64_t h_lo[kHeavyCap], h_hi[kHeavyCap];
   const unsigned epoch = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long tag = (unsigned long long)(epoch % 16383u) + 1ull;
   if (threadIdx.x == 0) n_heavy = 0;
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
     const int64_t j_cur = (k == ITEMS - 1) ? j_mine : ((any && c_cur > c_prev) ? slots_below(c_cur, u, step, inv_step, total, N) : j_prev);
     if (i < K && c_cur > c_prev) {
       const int64_t lo = j_prev, hi = j_cur > N ? N : j_cur;
-      if (hi - lo > kOwn) {
-        const int h = atomicAdd(&n_heavy, 1);
+      const int h = (hi - lo > kOwn) ? atomicAdd(&n_heavy, 1) : kHeavyCap;
+      if (h < kHeavyCap) {
         h_i[h] = (int32_t)i; h_lo[h] = lo; h_hi[h] = hi;
-      } else {
+      } else {   // few offspring, or the cooperative list is full (ITEMS > 4 with collapsed weights): write them here
         for (int64_t j = lo; j < hi; ++j) ancestors[j] = (int32_t)i;
       }
     }
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
     c_prev = c_cur;
   }
   __syncthreads();
-  const int nh = n_heavy < 256 ? n_heavy : 256;
+  const int nh = n_heavy < kHeavyCap ? n_heavy : kHeavyCap;
   for (int h = 0; h < nh; ++h) {
     const int32_t pi = h_i[h];
     for (int64_t j = h_lo[h] + threadIdx.x; j < h_hi[h]; j += 256) ancestors[j] = pi;

@@ -370,9 +370,9 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
     import torch
     rs = np.random.default_rng(2024)
     ws = {}
-    for trial in range(60):
+    for trial in range(70):
         K = int(rs.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097, 33_333, 131_072, 262_145]))
-        kind = trial % 6
+        kind = trial % 7
         if kind == 0:
             w = rs.random(K)
         elif kind == 1:
@@ -386,8 +386,14 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
         elif kind == 4:
             w = np.exp(rs.standard_normal(K) * 6.0)
             w /= w.max()
-        else:
+        elif kind == 5:
             w = np.zeros(K); w[rs.integers(0, K)] = 1.0               # one survivor
+        else:
+            # a contiguous stretch of particles with 9..40 offspring EACH: more "heavy" particles in one tile than
+            # threads in the block (found by the 4-process exchange test: the cooperative list used to hold 256)
+            w = np.zeros(K); n_live = max(1, K // int(rs.integers(9, 40)))
+            a0 = int(rs.integers(0, K - n_live + 1))
+            w[a0:a0 + n_live] = 0.5 + rs.random(n_live)
         w = w.astype(np.float32)
         N = int(rs.choice([K, max(1, K // 2), 2 * K + 3, 1]))
         u = float(rs.choice([0.0, 0.5, 0.999999, rs.random()]))
@@ -653,6 +659,8 @@ def _two_rank_worker(rank, world, port, K, R, spread, q):
     D.init_from_env("gloo")
     rs = np.random.default_rng(11)
     lw = (rs.standard_normal(K) * (5.0 if spread == "wide" else 1.0)).astype(np.float32)
+    if spread == "first":
+        lw[K // 7:] -= 60.0           # nearly all the mass on the first rank: every other rank only receives
     rows = rs.standard_normal((R, K)).astype(np.float32)
     off, k = D.shard(K, rank, world)
     lw_d = torch.as_tensor(lw[off:off + k]).cuda()
@@ -664,15 +672,15 @@ def _two_rank_worker(rank, world, port, K, R, spread, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("spread", ["mild", "wide"])
-def test_sharded_exchange_two_processes_one_gpu(oracle, spread):
+@pytest.mark.parametrize("spread,world", [("mild", 2), ("wide", 2), ("first", 4)])
+def test_sharded_exchange_two_processes_one_gpu(oracle, spread, world):
     """genjax_amd.distributed end to end with the HIP backend: 2 processes share the GPU, gloo carries the
     collectives (device tensors staged through the host).  Result == unsharded oracle, bit for bit."""
     import torch.multiprocessing as mp
-    K, R, world = 50_001, 4, 2
+    K, R = 50_001, 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 150) + (1 if spread == "wide" else 0)
+    port = 29800 + (os.getpid() % 150) + ["mild", "wide", "first"].index(spread)
     procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, K, R, spread, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -682,6 +690,8 @@ def test_sharded_exchange_two_processes_one_gpu(oracle, spread):
         assert p.exitcode == 0
     rs = np.random.default_rng(11)
     lw = (rs.standard_normal(K) * (5.0 if spread == "wide" else 1.0)).astype(np.float32)
+    if spread == "first":
+        lw[K // 7:] -= 60.0
     rows = rs.standard_normal((R, K)).astype(np.float32)
     lse = oracle.logsumexp(lw, K)
     # unsharded run on the device (log weights go through the device exp, so the device is its own reference
@@ -697,8 +707,10 @@ def test_sharded_exchange_two_processes_one_gpu(oracle, spread):
     assert (anc.cpu().numpy() != oracle.resample_systematic(cum, 0.37, K)).mean() <= 1e-3
     for r in res:
         np.testing.assert_allclose(r[2][2:], lse[2:], rtol=2e-6)
-    if spread == "wide":
+    if spread != "mild":
         assert sum(r[3] for r in res) > 0
+    if spread == "first":
+        assert res[0][3] > K // 2 and all(r[3] == 0 for r in res[2:])     # rank 0 feeds everyone; the tail ranks send nothing
 
 
 def _rccl_one_rank_worker(port, q):
