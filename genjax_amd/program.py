@@ -136,6 +136,8 @@ class SiteList:
                     dim = max(dim, int(p.values.shape[1]))
                 elif p.op == A.P_AFFINE:
                     dim = max(dim, int((p.terms[0][1] if p.terms else p.matrix).shape[0]))
+        if kind == A.DIRICHLET and int(dim) > 256:
+            raise ValueError("dirichlet: at most 256 components per site")
         site = Site(addr, kind, ps, int(dim), ncat, self.n_slots)
         self.sites.append(site)
         self.n_slots += int(dim)
