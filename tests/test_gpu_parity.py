@@ -509,7 +509,7 @@ def test_score_grad_and_hmc_parity(K_, oracle, rng):
 
 
 @pytest.mark.parametrize("rng", RNGS)
-@pytest.mark.parametrize("shape", [(64, 4), (200, 8), (1024, 16)])
+@pytest.mark.parametrize("shape", [(64, 4), (200, 8), (1024, 16), (1000, 16), (33, 16)])
 def test_hmc_logreg_fused_vs_generic_vs_oracle(K_, oracle, rng, shape, monkeypatch):
     """BASELINE config 5 shape: the fused kernel and the site interpreter run the same program, same streams."""
     import torch
