@@ -408,6 +408,14 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
         np.testing.assert_array_equal(_np(K_.gather_rows(torch.as_tensor(rows).cuda(), got)), rows[:, want])
         counts = np.bincount(want, minlength=K)
         assert counts[w == 0].sum() == 0                              # weightless particles never survive
+    # the same stretch pattern where a lane holds 16 particles (more many-offspring particles per tile than the
+    # cooperative list holds: the overflow is written by the owning lanes)
+    K = 3_000_000
+    w = np.zeros(K, np.float32)
+    w[1_000_000:1_000_000 + K // 20] = (0.5 + rs.random(K // 20)).astype(np.float32)
+    cum_o, _ = oracle.weight_cumsum(w)
+    got = K_.resample_indices(torch.as_tensor(w).cuda(), 0.25, K, is_log=False)
+    np.testing.assert_array_equal(_np(got), oracle.resample_systematic(cum_o, 0.25, K))
 
 
 def test_degenerate_and_invalid_arguments(K_):
