@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_systematic_expand(const uint64_t* __res
 // tagged 8-byte agent-scope granule, and then reads EVERY block's granule (spinning until the tag of this call
 // appears) to get both its own offset and the grand total — an all-gather of ≤1024 words instead of two kernel
 // boundaries and a 16 MB round trip of the prefix-sum array.  Requires all blocks co-resident (the launcher caps
-// the grid at 1024 blocks of 256 threads; 256 CUs hold at least twice that at this kernel's register count).
+// the grid at 1024 blocks of 256 threads, 4 per CU).
 // Tags: granule = (tag << 50) | total, tag = (epoch mod 16383) + 1 != 0; `epoch` lives in the workspace control
 // block and is bumped by block 0 once it has seen every granule (by then every block has read the old epoch),
 // so consecutive calls never mistake each other's granules and the workspace needs zeroing only once.
@@ -343,11 +343,13 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
     __hip_atomic_store(&agg[blockIdx.x], (tag << 50) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- all-gather of the tile totals ----
   uint64_t pre = 0, tot = 0;
+  unsigned budget = 1u << 22;   // polls this lane may spend in total (~1 s): a grid that is not co-resident must not hang
   for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
     unsigned long long v = 0;
-    for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+    while (budget) {
       v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((v >> 50) == tag) break;
+      --budget;
       __builtin_amdgcn_s_sleep(1);
     }
     if ((v >> 50) != tag) { __hip_atomic_store(&ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
@@ -505,9 +507,11 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
       !(u >= 0.0 && u < 1.0) || (!ancestors && !cum))
     return gjx_fail(GJX_EINVAL, "gjx_resample_indices: bad argument");
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_resample_indices: workspace too small");
-  // one co-resident grid of at most 1024 blocks; otherwise fall back to the three-launch path
+  // one co-resident grid of at most 1024 blocks (4 per CU: 70 / 118 registers per lane at 4 / 16 items, 23 KB of
+  // LDS); larger K (> 2^22) falls back to the three-launch path — 64 items per lane would need 312 registers, one
+  // block per CU, and a grid that cannot be co-resident deadlocks in the granule all-gather
   int items = 4;
-  while (items < 64 && (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items *= 4;
+  if ((K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items = 16;
   const int64_t nblocks = (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items);
   hipStream_t st = (hipStream_t)stream;
   if (nblocks > 1024 || !ancestors) {
@@ -521,7 +525,7 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
 #define GJX_RF(IT) hipLaunchKernelGGL((k_resample_fused<IT>), dim3((unsigned)nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, \
                                       (int)n_partials, lse_out, log_k, u, N, ancestors, cum, base_total_dev, agg, ctrl)
-  if (items == 4) GJX_RF(4); else if (items == 16) GJX_RF(16); else GJX_RF(64);
+  if (items == 4) GJX_RF(4); else GJX_RF(16);
 #undef GJX_RF
   GJX_CHECK_LAUNCH("gjx_resample_indices");
   return GJX_OK;

@@ -136,7 +136,7 @@ def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=Tru
         mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
     else:
         mode, lp, npart = int(bool(is_log)), _ptr(lse), 0
-    if K > (1 << 24) and (cum is None or bt is None):      # beyond the co-resident grid: fallback needs the buffers
+    if K > (1 << 22) and (cum is None or bt is None):      # beyond the co-resident grid: fallback needs the buffers
         cum = torch.empty(K, dtype=torch.int64, device=x.device)
         bt = torch.empty(2, dtype=torch.int64, device=x.device)
     check(load().gjx_resample_indices(_ptr(x), K, mode, lp, npart, float(u), N, _ptr(anc), _ptr(cum), _ptr(bt), _ptr(lse_out),

@@ -338,7 +338,7 @@ def test_one_launch_resample_indices(K_, oracle):
     bit, for every tile configuration, repeated calls on one workspace (epoch tags) and degenerate weights."""
     import torch
     ws = None
-    for K in (1, 300, 1024, 1025, 70_001, 1 << 20, (1 << 20) + 77, 3_000_000):
+    for K in (1, 300, 1024, 1025, 70_001, 1 << 20, (1 << 20) + 77, 3_000_000, 1 << 22, (1 << 22) + 5):
         rs = np.random.default_rng(K)
         lw = (rs.standard_normal(K) * (5.0 if K % 2 else 1.0)).astype(np.float32)
         lwd = torch.as_tensor(lw).cuda()
