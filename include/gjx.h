@@ -233,8 +233,11 @@ int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base
 /* Single-GPU resampling indices in ONE launch: fixed-point weights (is_log / lse / n_partials as in
  * gjx_weight_cumsum), their prefix sums and the systematic ancestors ancestors[j], j < N (every slot is written).
  * cum u64[K] and base_total_dev u64[2] are optional outputs (NULL = not materialised; they are required only when K
- * is too large for the co-resident fused kernel and the call falls back to the three-launch path).  Results are
- * bit-identical to gjx_weight_cumsum + gjx_resample_systematic. */
+ * is too large for the co-resident fused kernel, K > 2^22, and the call falls back to the three-launch path).
+ * Results are bit-identical to gjx_weight_cumsum + gjx_resample_systematic.
+ * The fused kernel's blocks exchange their totals inside the launch, so its whole grid (<= 1024 blocks) must be
+ * resident: do not run two of these launches concurrently on one device (two streams).  A block that cannot collect
+ * the totals within its poll budget (~1 s) sets workspace word 10 to 1 and the output of that call is undefined. */
 int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
                          int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev, float* lse_out,
                          int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
