@@ -749,6 +749,14 @@ def _rccl_one_rank_body(port, q):
     anc = kernels.resample_indices(lw, 0.77, K, lse=local)
     want = kernels.gather_rows(rows, anc)
     torch.cuda.synchronize()
+    # collapsed weights (a stretch of many-offspring particles, the rest dead) through the same context
+    lw2 = torch.full((K,), -200.0, device="cuda")
+    lw2[20_000:23_000] = torch.as_tensor(rs.standard_normal(3000).astype(np.float32)).cuda()
+    local2 = kernels.logsumexp(lw2, K)
+    got2, _ = res.step(rows, lw2, local2, 0.31)
+    want2 = kernels.gather_rows(rows, kernels.resample_indices(lw2, 0.31, K, lse=local2))
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want2), "collapsed weights: RCCL path differs from the single-GPU path"
     # the sharded bootstrap filter (per-step exchange through the same transport) against the native one-GPU loop
     from genjax_amd import core, workloads
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
