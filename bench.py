@@ -230,6 +230,11 @@ def run_ssm(args, rank, world, dev):
         last["out"] = bf.run(core.key(1 + i), ys, device=dev, rank=rank, world=world)
         return last["out"]["log_ml"]
 
+    # see run_gmm: the HIP runtime's one-off pool-growth stalls (35-45 ms each, two or three of them over the first
+    # ~10^4 launches when the queue is kept this deep) must not land between the barriers of a 60 ms timed region
+    for i in range(20):
+        step(i, False)
+    torch.cuda.synchronize()
     dt, lml = timed_loop(args, world, dev, step)
     if rank != 0:
         return None
