@@ -32,7 +32,7 @@ NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move 
 # param forms / transforms / modes / flags / rng
 P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
-MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT = 0, 1, 2
+MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK = 0, 1, 2, 3
 SITE_HMC_SELECTED = 1
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023

@@ -219,6 +219,16 @@ SelectionBuilder = S = _SelectionBuilder()
 # ---------------------------------------------------------------------------------------------
 # ChoiceMap
 # ---------------------------------------------------------------------------------------------
+class Masked:
+    """A value with one validity flag per particle (core/generative/functional_types.py Mask, batched flag)."""
+
+    def __init__(self, value, flag: np.ndarray):
+        self.value, self.flag = value, np.asarray(flag, bool)
+
+    def __repr__(self):
+        return f"Masked({int(self.flag.sum())}/{self.flag.size} valid)"
+
+
 class ChoiceMapNoValueAtAddress(KeyError):
     """choice_map.py:672"""
 
@@ -355,12 +365,15 @@ class ChoiceMap:
     __or__ = merge
 
     def mask(self, flag) -> "ChoiceMap":
-        """``chm.mask(flag)`` (choice_map.py Mask): present when the flag is true.  Host booleans only — a
-        per-particle flag would have to mix constrained and sampled particles in one site."""
+        """``chm.mask(flag)`` (choice_map.py Mask).  A scalar flag keeps or drops the choices on the host; a flag per
+        particle (length-K array) wraps every value in ``Masked``: the kernels then apply the constrained rule to the
+        flagged particles and sample the others (distribution.py:129-143)."""
         f = np.asarray(flag.detach().cpu() if hasattr(flag, "detach") else flag)
-        if f.ndim != 0:
-            raise NotImplementedError("ChoiceMap.mask with a per-particle flag")
-        return self if bool(f) else ChoiceMap()
+        if f.ndim == 0:
+            return self if bool(f) else ChoiceMap()
+        if f.ndim != 1:
+            raise ValueError("ChoiceMap.mask: the flag is a scalar or one boolean per particle")
+        return ChoiceMap({a: Masked(v, f.astype(bool)) for a, v in self._d.items()})
 
     def filter(self, selection: Selection) -> "ChoiceMap":
         return ChoiceMap({a: v for a, v in self._d.items() if selection.check(a)})

@@ -808,7 +808,7 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     return gjx_fail(GJX_EINVAL, "gjx_hmc: bad argument");
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
-    if (s.mode == GJX_MODE_SAMPLE) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_*)");
+    if (s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_TAB / OBS_SLOT)");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
                                               s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
     const gjx_site& s = a.sites[j];
     const int kind = s.kind, mode = s.mode, slot = s.slot;
     BitStream<RNG> bs;
-    if (mode == GJX_MODE_SAMPLE) bs.open(a.key, gidx, (uint32_t)(j + 1));
+    const bool masked = mode == GJX_MODE_OBS_MASK;
+    const bool draws = mode == GJX_MODE_SAMPLE || masked;           // wave-uniform
+    const bool given = masked ? (val(s.obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
+    if (draws) bs.open(a.key, gidx, (uint32_t)(j + 1));
     float lp = 0.0f;
     if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
       const int n = s.ncat;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       }
       const float lse = mx + fast_log(se);
       float v;
-      if (mode == GJX_MODE_SAMPLE && RNG == GJX_RNG_FLAT) {
+      if (draws && RNG == GJX_RNG_FLAT) {
         // inverse CDF on one uniform (se is the float32 running total in category order)
         const float target = bits_to_unit(bs.get(0u)) * se;
         float run = 0.0f;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
           if (!found && run > target) { zc = c; found = true; }
         }
         v = (float)zc;
-      } else if (mode == GJX_MODE_SAMPLE) {
+      } else if (draws) {
         int best = 0;
         float bestv = -INFINITY;
         for (int c = 0; c < n; ++c) {
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       } else {
         v = val(slot);
       }
+      if (masked && given) v = val(slot);
       const int k = (int)v;
       if (k < 0 || k >= n) {
         lp = -INFINITY;
@@ -179,9 +183,10 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
           const float pc = NP > 2 ? eval_param(s.p[2], d, tab, val) : 0.0f;
           const float pd = NP > 3 ? eval_param(s.p[3], d, tab, val) : 0.0f;
           float v;
-          if (mode == GJX_MODE_SAMPLE) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
+          if (draws) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
           else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
           else v = val(slot + d);
+          if (masked && given) v = val(slot + d);
           lp += elem_logpdf(KIND, v, pa, pb, pc, pd);
           if (slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
             if (LDSV) vals_s[(slot + d) * 256 + threadIdx.x] = v;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
 #undef GJX_KIND
     }
     score += lp;
-    if (mode != GJX_MODE_SAMPLE) weight += lp;
+    if (given) weight += lp;
     if (a.site_scores && active) a.site_scores[(int64_t)j * K + i] = lp;
   }
   float lw = weight;
@@ -649,6 +654,12 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   if (prog->n_slots > 0 && !choices) return gjx_fail(GJX_EINVAL, "gjx_run_program: choices is null");
   if (lse && !logw) return gjx_fail(GJX_EINVAL, "gjx_run_program: lse needs logw");
   if (prog->rng_mode == GJX_RNG_FLAT && prog->n_sites > GJX_FLAT_MAX_SITES) return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: FLAT stream supports at most 1023 sites");
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site& sj = prog->sites[j];
+    if (sj.mode != GJX_MODE_OBS_MASK) continue;
+    if (sj.kind == GJX_DIRICHLET) return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: a dirichlet site cannot be masked per particle");
+    if (sj.slot < 0 || sj.obs_off < 0 || sj.obs_off >= prog->n_slots) return gjx_fail(GJX_EINVAL, "gjx_run_program: OBS_MASK needs a value slot and a flag slot");
+  }
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* partials = nullptr;
   unsigned* ticket = nullptr;
@@ -681,7 +692,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.logw_in = logw_in; a.sub = sub; a.site_scores = site_scores; a.partials = partials; a.ticket = ticket; a.lse = lse;
     a.log_k_total = log_k_total;
     a.preload = 0;
-    for (int j = 0; j < prog->n_sites; ++j) a.preload |= prog->sites[j].mode == GJX_MODE_OBS_SLOT;
+    for (int j = 0; j < prog->n_sites; ++j) a.preload |= prog->sites[j].mode == GJX_MODE_OBS_SLOT || prog->sites[j].mode == GJX_MODE_OBS_MASK;
     a.n_tab = prog->n_tab;
     const size_t vbytes = sizeof(float) * 256 * (size_t)prog->n_slots;
     const bool ldsv = prog->n_slots > 0 && vbytes <= 48 * 1024 && !env_int("GJX_GENERIC_NO_LDS", 0);

@@ -23,7 +23,7 @@ from typing import Any, Callable, Sequence
 import numpy as np
 
 from . import _abi as A
-from .core import ChoiceMap, Key, Selection, _VALUE, fold_in, split
+from .core import ChoiceMap, Key, Masked, Selection, _VALUE, fold_in, split
 from .program import AddressReuse, MissingAddress, PackedProgram, Param, SiteList
 
 __all__ = [
@@ -538,10 +538,18 @@ class GenerativeFunction:
         rows supplied later; the rest are SAMPLE when ``sample_rest`` else MissingAddress."""
         from . import config
         sl, _ = self.site_list(args)
-        modes, shared, pp = {}, {}, {}
+        modes, shared, pp, mask_rows = {}, {}, {}, {}
         for s in sl.sites:
             found, cval = _constraint_value(constraint, s.addr)
-            if found:
+            if found and isinstance(cval, Masked):
+                K = cval.flag.size
+                sv, rows = _value_rows(cval.value, s.dim)
+                if rows is None:
+                    rows = np.broadcast_to(np.asarray(sv, np.float32).reshape(s.dim, 1), (s.dim, K)).copy()
+                modes[s.addr] = A.MODE_OBS_MASK
+                pp[s.addr] = rows
+                mask_rows[s.addr] = cval.flag.astype(np.float32)
+            elif found:
                 sv, rows = _value_rows(cval, s.dim)
                 if rows is None:
                     modes[s.addr] = A.MODE_OBS_TAB
@@ -555,6 +563,7 @@ class GenerativeFunction:
                 raise MissingAddress(s.addr)
         prog = PackedProgram(sl, modes, shared, selected=tuple(selected),
                              rng_mode=config.rng_mode() if rng_mode is None else rng_mode)
+        prog.mask_flags = mask_rows          # addr -> f32[K] validity flags of Mask(value, flag) constraints
         return prog, shared, pp
 
     def _run(self, key: Key, K: int, args, constraint: ChoiceMap, sample_rest: bool, batched: bool,
@@ -575,6 +584,11 @@ class GenerativeFunction:
             slot = prog.slot_of[addr]
             dim = prog.site_list[addr].dim
             choices[slot:slot + dim] = torch.as_tensor(r, dtype=torch.float32, device=dev).expand(dim, K)
+        for addr, fslot in prog.flag_slot_of.items():
+            fl = torch.as_tensor(prog.mask_flags[addr], dtype=torch.float32, device=dev).reshape(-1)
+            if fl.numel() != K:
+                raise ValueError(f"mask of {addr!r} has {fl.numel()} flags, expected one per particle ({K})")
+            choices[fslot] = fl
         out = kernels.run_program(prog, key, K, offset=offset, choices=choices, logw_in=logw_in, sub=sub,
                                   want_lse=want_lse, K_total=K_total, device=dev, want_site_scores=want_site_scores)
         tr = Trace(self, args, prog, out["choices"], out["score"], shared, batched, retval)

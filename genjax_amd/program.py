@@ -206,13 +206,19 @@ class PackedProgram:
             else:
                 self.slot_of[s.addr] = n_slots
                 n_slots += s.dim
+        # Mask(value, flag) per particle: one extra row of choices[][] per masked site holds its flags
+        self.flag_slot_of: dict[str, int] = {}
+        for s in sl.sites:
+            if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_MASK:
+                self.flag_slot_of[s.addr] = n_slots
+                n_slots += 1
         order = {s.addr: j for j, s in enumerate(sl.sites)}
         for j, s in enumerate(sl.sites):
             cs = self.c_sites[j]
             cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
             cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
             cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
-            cs.obs_off = self.obs_off.get(s.addr, 0)
+            cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)
             rows = s.ncat if s.ncat else s.dim
             for k in range(len(s.params), A.MAX_PARAMS):   # unused parameter slots read tab[0]
                 cs.p[k].op, cs.p[k].len, cs.p[k].off = A.P_CONST, 1, 0

@@ -90,7 +90,10 @@ enum { GJX_XF_NONE = 0, GJX_XF_EXP = 1, GJX_XF_SOFTPLUS = 2, GJX_XF_SIGMOID = 3 
 enum {
   GJX_MODE_SAMPLE = 0,   /* unconstrained: v ~ dist, score += logpdf(v), weight += 0           */
   GJX_MODE_OBS_TAB = 1,  /* constrained, same value for every particle: v = tab[obs_off + d]   */
-  GJX_MODE_OBS_SLOT = 2  /* constrained per particle: v = choices[slot + d][i] (already there) */
+  GJX_MODE_OBS_SLOT = 2, /* constrained per particle: v = choices[slot + d][i] (already there) */
+  GJX_MODE_OBS_MASK = 3  /* Mask(value, flag) per particle (distribution.py:129-143): flag = choices[obs_off][i];
+                            flag != 0: as OBS_SLOT; flag == 0: as SAMPLE (the draw overwrites the slot).
+                            Not accepted by dirichlet sites, gjx_hmc or gjx_score_grad. */
 };
 
 enum { GJX_SITE_HMC_SELECTED = 1 }; /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */

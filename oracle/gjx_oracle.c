@@ -465,6 +465,10 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
   float score = 0.0f, weight = 0.0f;
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
+    /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
+     * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
+    int mode = s->mode;
+    if (mode == GJX_MODE_OBS_MASK) mode = vals[s->obs_off] != 0.0f ? GJX_MODE_OBS_SLOT : GJX_MODE_SAMPLE;
     const ostream st = stream_open(prog->rng_mode, run_key, idx, (uint32_t)(j + 1)); /* counter starts at 1 */
     const ostream* sk = &st;
     float lp = 0.0f;
@@ -485,7 +489,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
       }
       float lse = mx + (float)log(se);
       float v;
-      if (s->mode == GJX_MODE_SAMPLE && prog->rng_mode == GJX_RNG_FLAT) {
+      if (mode == GJX_MODE_SAMPLE && prog->rng_mode == GJX_RNG_FLAT) {
         /* FLAT layout: inverse CDF on ONE uniform (float32 running sum of exp(l - max), category order) */
         float tot = 0.0f;
         for (int c = 0; c < n; ++c) {
@@ -503,7 +507,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
           if (run > target) { zc = c; break; }
         }
         v = (float)zc;
-      } else if (s->mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
+      } else if (mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
         int best = 0;
         float bestv = -INFINITY;
         for (int c = 0; c < n; ++c) {
@@ -513,7 +517,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
           if (g > bestv) { bestv = g; best = c; }
         }
         v = (float)best;
-      } else if (s->mode == GJX_MODE_OBS_TAB) {
+      } else if (mode == GJX_MODE_OBS_TAB) {
         v = tab[s->obs_off];
       } else {
         v = vals[s->slot];
@@ -531,7 +535,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
       int n = s->dim;
       float x[256];
       if (n > 256) n = 256;
-      if (s->mode == GJX_MODE_SAMPLE) {
+      if (mode == GJX_MODE_SAMPLE) {
         float mx = -INFINITY, se = 0.0f;
         for (int d = 0; d < n; ++d) {
           x[d] = log_gamma_variate(sk, (uint32_t)(d * GAMMA_NDRAW), eval_param(&s->p[0], d, tab, vals));
@@ -540,7 +544,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
         for (int d = 0; d < n; ++d) se += expf(x[d] - mx);
         for (int d = 0; d < n; ++d) x[d] = expf(x[d] - (mx + logf(se)));
       } else {
-        for (int d = 0; d < n; ++d) x[d] = s->mode == GJX_MODE_OBS_TAB ? tab[s->obs_off + d] : vals[s->slot + d];
+        for (int d = 0; d < n; ++d) x[d] = mode == GJX_MODE_OBS_TAB ? tab[s->obs_off + d] : vals[s->slot + d];
       }
       float sa = 0.0f;
       for (int d = 0; d < n; ++d) {
@@ -560,15 +564,15 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
         float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
         int wide = s->kind >= GJX_STUDENT_T;
         float v;
-        if (s->mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
-        else if (s->mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
+        if (mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
+        else if (mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
         else v = vals[s->slot + d];
         lp += wide ? elem_logpdf4(s->kind, v, a, b, c, e) : elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
         if (s->slot >= 0) vals[s->slot + d] = v;
       }
     }
     score += lp;
-    if (s->mode != GJX_MODE_SAMPLE) weight += lp; /* static.py:377 with distribution.py:127/147 */
+    if (mode != GJX_MODE_SAMPLE) weight += lp; /* static.py:377 with distribution.py:127/147 */
     if (site_scores) site_scores[(int64_t)j * ss_stride] = lp;
   }
   *score_out = score;

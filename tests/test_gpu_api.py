@@ -676,3 +676,31 @@ class TestMarginal:
         retained_score = lpn(xs, 0.0, 1.0) + lpn(0.0, xs, 0.5)
         log_p_y = -0.5 * y * y / 1.25 - 0.5 * math.log(2 * math.pi * 1.25)
         assert f(w) == pytest.approx(retained_score - log_p_y, abs=0.05)
+
+
+class TestMask:
+    def test_per_particle_mask_importance(self):
+        """distribution.py:129-143 with a flag per particle (the batched form of test_distributions.py:40-58):
+        `C.v(1.0).mask(flags)` constrains the flagged particles only."""
+        K = 2048
+        flags = np.arange(K) % 3 == 0
+        tr, w = genjax.normal.importance(genjax.key(1), C.v(1.0).mask(flags), (0.0, 1.0), K=K)
+        v = tr.get_choices().get_value().cpu().numpy()
+        assert (v[flags] == 1.0).all() and (v[~flags] != 1.0).all()
+        lp1 = f(genjax.normal.assess(C.v(1.0), (0.0, 1.0))[0])
+        np.testing.assert_allclose(w.cpu().numpy()[flags], lp1, rtol=1e-5)
+        assert (w.cpu().numpy()[~flags] == 0.0).all()
+
+        @genjax.gen
+        def model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            _ = genjax.normal(x, 0.5) @ "y"
+
+        xs = np.linspace(-1, 1, K).astype(np.float32)
+        chm = C["x"].set(xs).mask(flags) | C["y"].set(0.2)
+        tr, w = model.importance(genjax.key(2), chm, (), K=K)
+        x = tr.get_choices()["x"].double().cpu().numpy()
+        np.testing.assert_array_equal(x[flags].astype(np.float32), xs[flags])
+        lpn = lambda v, m, s: -0.5 * ((v - m) / s) ** 2 - np.log(s) - 0.5 * np.log(2 * np.pi)
+        want = lpn(0.2, x, 0.5) + np.where(flags, lpn(x, 0.0, 1.0), 0.0)
+        np.testing.assert_allclose(w.cpu().numpy(), want, rtol=2e-4, atol=2e-4)

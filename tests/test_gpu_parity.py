@@ -792,3 +792,32 @@ def test_rccl_transport_single_rank():
     inc_native, inc_sharded, same_x, tr2 = filt
     assert tr2 == "rccl" and same_x                       # same ancestors every step -> identical final particles
     np.testing.assert_allclose(inc_sharded, inc_native, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_masked_constraints_parity(K_, oracle, rng):
+    """GJX_MODE_OBS_MASK (Mask(value, flag) per particle, distribution.py:129-143): device == oracle; flagged particles
+    keep their value and are weighted, the others draw exactly what an unconstrained run draws."""
+    import torch
+    sl = H.zoo(rng).site_list
+    K = 3000
+    rs = np.random.default_rng(8)
+    masked = {"n0": rs.random(K) < 0.5, "c0": rs.random(K) < 0.3, "mv": rs.random(K) < 0.7, "g0": rs.random(K) < 0.5}
+    vals = {"n0": rs.standard_normal((1, K)), "c0": rs.integers(0, 3, (1, K)), "mv": rs.standard_normal((3, K)), "g0": rs.random((1, K)) + 0.5}
+    prog = PackedProgram(sl, {a: A.MODE_OBS_MASK for a in masked}, rng_mode=rng)
+    ch = np.zeros((prog.n_slots, K), np.float32)
+    for a in masked:
+        s0 = prog.slot_of[a]
+        ch[s0:s0 + sl[a].dim] = vals[a]
+        ch[prog.flag_slot_of[a]] = masked[a]
+    g = K_.run_program(prog, (6, 7), K, choices=torch.as_tensor(ch).cuda(), want_site_scores=True)
+    o = oracle.run_program(prog, (6, 7), K, choices=ch.copy(), want_site_scores=True)
+    gg = {k: _np(v) for k, v in g.items() if k in ("choices", "score", "weight", "logw")}
+    assert_particles_match(gg, o, max_bad=2e-3, what="masked zoo")
+    free = K_.run_program(PackedProgram(sl, rng_mode=rng), (6, 7), K)
+    for a, fl in masked.items():
+        s0 = prog.slot_of[a]
+        np.testing.assert_array_equal(gg["choices"][s0:s0 + sl[a].dim][:, fl], ch[s0:s0 + sl[a].dim][:, fl])
+        if a == "n0":        # first site: nothing upstream differs, so unflagged draws equal the unconstrained run's
+            np.testing.assert_array_equal(gg["choices"][s0][~fl], _np(free["choices"])[s0][~fl])
+    assert (gg["weight"] != 0).mean() > 0.8

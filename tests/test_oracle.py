@@ -590,3 +590,46 @@ def test_wider_gradients_by_finite_differences(oracle):
         np.testing.assert_allclose(gr[slot][ok], fd[ok], rtol=0.05, atol=0.05, err_msg=str(s.addr))
         n_checked += int(ok.sum())
     assert n_checked > 400
+
+
+def test_masked_constraints_per_particle(oracle):
+    """Mask(value, flag) with one flag per particle (distribution.py:129-143, a lax.cond per particle): flagged
+    particles follow the constrained rule (value kept, weight += log-pdf), the others the unconstrained one."""
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMap
+
+    @genjax.gen
+    def model():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        c = genjax.categorical(probs=np.array([0.2, 0.5, 0.3], np.float32)) @ "c"
+        y = genjax.normal(x, 0.5) @ "y"
+        return y
+
+    K = 4000
+    rs = np.random.default_rng(0)
+    fx, fc = rs.random(K) < 0.4, rs.random(K) < 0.6
+    xv = rs.standard_normal(K).astype(np.float32)
+    chm = (ChoiceMap.empty().at["x"].set(xv).mask(fx)
+           | ChoiceMap.empty().at["c"].set(np.float32(2.0)).mask(fc)
+           | ChoiceMap.empty().at["y"].set(0.3))
+    prog, shared, pp = model.pack((), chm, True)
+    assert prog.n_slots == 2 + 2 and prog.flag_slot_of == {"x": 2, "c": 3}
+    ch = np.zeros((prog.n_slots, K), np.float32)
+    ch[prog.slot_of["x"]] = pp["x"]
+    ch[prog.slot_of["c"]] = pp["c"]
+    ch[2], ch[3] = fx, fc
+    out = oracle.run_program(prog, (4, 5), K, choices=ch)
+    x, c = out["choices"][0].astype(np.float64), out["choices"][1]
+    np.testing.assert_array_equal(x[fx].astype(np.float32), xv[fx])                 # kept where flagged
+    assert (c[fc] == 2.0).all()
+    assert abs(x[~fx].mean()) < 0.08 and abs(x[~fx].std() - 1.0) < 0.05               # drawn elsewhere
+    assert abs((c[~fc] == 1.0).mean() - 0.5) < 0.05
+    lp = lambda v, m, s: -0.5 * ((v - m) / s) ** 2 - np.log(s) - 0.5 * np.log(2 * np.pi)
+    want_w = lp(0.3, x, 0.5) + np.where(fx, lp(x, 0.0, 1.0), 0.0) + np.where(fc, np.log(0.3), 0.0)
+    np.testing.assert_allclose(out["weight"], want_w, rtol=2e-4, atol=2e-4)
+    lpc = np.log(np.array([0.2, 0.5, 0.3]))[c.astype(int)]
+    np.testing.assert_allclose(out["score"], lp(0.3, x, 0.5) + lp(x, 0.0, 1.0) + lpc, rtol=2e-4, atol=2e-4)
+    # unflagged particles draw exactly what an unconstrained run draws (same counter streams)
+    prog0, _, _ = model.pack((), ChoiceMap.empty().at["y"].set(0.3), True)
+    free = oracle.run_program(prog0, (4, 5), K)
+    np.testing.assert_array_equal(out["choices"][0][~fx], free["choices"][0][~fx])
