@@ -55,12 +55,15 @@ template <>
 struct BitStream<GJX_RNG_FLAT> {
   key2 key, cache;
   uint32_t c0, site_hi, cached;
-  GJX_DEV BitStream() : key{0u, 0u}, cache{0u, 0u}, c0(0u), site_hi(0u), cached(0xFFFFFFFFu) {}
+  float n0, n1;         // Box-Muller pair of hash `npair` (stream_normal): the odd element reuses the even one's work
+  uint32_t npair;
+  GJX_DEV BitStream() : key{0u, 0u}, cache{0u, 0u}, c0(0u), site_hi(0u), cached(0xFFFFFFFFu), n0(0.0f), n1(0.0f), npair(0xFFFFFFFFu) {}
   GJX_DEV void open(key2 run_key, uint64_t idx, uint32_t site) {
     key = (idx >> 32) ? threefry2x32(run_key, 0xFFFFFFFFu, (uint32_t)(idx >> 32)) : run_key;
     c0 = (uint32_t)idx;
     site_hi = site << GJX_FLAT_SITE_SHIFT;
     cached = 0xFFFFFFFFu;
+    npair = 0xFFFFFFFFu;
   }
   GJX_DEV void open_site_key(key2) {}
   GJX_DEV uint32_t get(uint32_t c) {
@@ -206,11 +209,16 @@ GJX_DEV void box_muller(uint32_t wa, uint32_t wb, float& n0, float& n1) {
 // standard normal for element e of a stream (see stream_normal in the oracle)
 template <int RNG>
 GJX_DEV float stream_normal(BitStream<RNG>& bs, uint32_t e) {
-  if (RNG == GJX_RNG_JAX32) return normal_from_bits(bs.get(e));
-  const uint32_t wa = bs.get(e & ~1u), wb = bs.get(e | 1u);
-  float n0, n1;
-  box_muller(wa, wb, n0, n1);
-  return (e & 1u) ? n1 : n0;
+  if constexpr (RNG == GJX_RNG_JAX32) {
+    return normal_from_bits(bs.get(e));
+  } else {
+    if ((e >> 1) != bs.npair) {
+      const uint32_t wa = bs.get(e & ~1u), wb = bs.get(e | 1u);
+      box_muller(wa, wb, bs.n0, bs.n1);
+      bs.npair = e >> 1;
+    }
+    return (e & 1u) ? bs.n1 : bs.n0;
+  }
 }
 
 GJX_DEV float gumbel_from_bits(uint32_t bits) {
