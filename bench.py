@@ -170,6 +170,10 @@ def run_gmm(args, rank, world, dev):
         step(i, False)
     torch.cuda.synchronize()
     dt, lse = timed_loop(args, world, dev, step)
+    if resampler is not None:
+        lse = lse.clone()
+        torch.cuda.synchronize()
+        resampler.close()            # communicator torn down on every rank while the process group is still up
     if rank != 0:
         return None
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
