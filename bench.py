@@ -240,6 +240,9 @@ def run_ssm(args, rank, world, dev):
         step(i, False)
     torch.cuda.synchronize()
     dt, lml = timed_loop(args, world, dev, step)
+    lml = float(lml)
+    if getattr(bf, "_resampler", None) is not None:
+        bf._resampler.close()
     if rank != 0:
         return None
     exact = golden("ssm_dx8_T256_seed0")
