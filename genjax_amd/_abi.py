@@ -89,6 +89,10 @@ PROTOTYPES = {
     "gjx_lse_combine": (C.c_int, [vp, C.c_int, i64, vp, vp]),
     "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),
     "gjx_weight_cumsum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_event_create": (C.c_int, [C.POINTER(vp)]),
+    "gjx_event_destroy": (C.c_int, [vp]),
+    "gjx_event_elapsed_us": (C.c_int, [vp, vp, C.POINTER(f32)]),
+    "gjx_profile_next_run": (C.c_int, [vp, vp]),
     "gjx_run_partials_count": (C.c_int, [PP, i64, i64]),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
     "gjx_resample_indices": (C.c_int, [vp, i64, i32, vp, i32, f64, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),

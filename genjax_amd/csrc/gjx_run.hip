@@ -10,6 +10,8 @@
 //                   block's {max, sum-exp} of the log-weights reduced with wave shuffles + LDS.
 // Both produce identical random streams (same Threefry counters) — tests compare them bitwise on
 // the integer side and to float tolerance on the float side.
+#include <hip/hip_ext.h>
+
 #include "gjx_device.h"
 #include "gjx_host.h"
 
@@ -582,8 +584,17 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// measurement hook (gjx_profile_next_run): HIP events attached to the DISPATCH of the next propagate kernel launched
+// from this thread — they take the kernel's own begin / end timestamps, not those of markers around it
+thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+
 template <int RNG, int D, int PPT>
 void launch_gmm_t(const GmmArgs& a, int grid, size_t lds, hipStream_t st) {
+  if (t_prof_start && t_prof_stop) {
+    hipExtLaunchKernelGGL((k_run_gmm<RNG, D, PPT, 256>), dim3(grid), dim3(256), (uint32_t)lds, st, t_prof_start, t_prof_stop, 0, a);
+    t_prof_start = t_prof_stop = nullptr;
+    return;
+  }
   hipLaunchKernelGGL((k_run_gmm<RNG, D, PPT, 256>), dim3(grid), dim3(256), lds, st, a);
 }
 template <int RNG, int D>
@@ -611,6 +622,34 @@ int gjx_launch_lse_finish(const void* partials, int n, int64_t K_total, float* o
   hipLaunchKernelGGL(k_lse_finish, dim3(1), dim3(256), 0, st, (const float2*)partials, n,
                      (float)log((double)K_total), out);
   GJX_CHECK_LAUNCH("lse_finish");
+  return GJX_OK;
+}
+
+extern "C" int gjx_event_create(void** ev) {
+  if (!ev) return gjx_fail(GJX_EINVAL, "gjx_event_create: bad argument");
+  hipEvent_t e;
+  const hipError_t r = hipEventCreate(&e);
+  if (r != hipSuccess) return gjx_fail_hip(r, "gjx_event_create");
+  *ev = (void*)e;
+  return GJX_OK;
+}
+extern "C" int gjx_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+  return GJX_OK;
+}
+extern "C" int gjx_event_elapsed_us(void* start, void* stop, float* us) {
+  if (!start || !stop || !us) return gjx_fail(GJX_EINVAL, "gjx_event_elapsed_us: bad argument");
+  hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+  if (r != hipSuccess) return gjx_fail_hip(r, "gjx_event_elapsed_us");
+  float ms = 0.0f;
+  r = hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop);
+  if (r != hipSuccess) return gjx_fail_hip(r, "gjx_event_elapsed_us");
+  *us = ms * 1000.0f;
+  return GJX_OK;
+}
+extern "C" int gjx_profile_next_run(void* start, void* stop) {
+  t_prof_start = (hipEvent_t)start;
+  t_prof_stop = (hipEvent_t)stop;
   return GJX_OK;
 }
 

@@ -38,6 +38,27 @@ def threefry2x32(key, n: int, ctr_lo0: int = 0, ctr_hi: int = 0, device=None) ->
     return out
 
 
+class DispatchTimer:
+    """A pair of HIP events attached to the dispatch of the next fused propagate kernel (gjx_profile_next_run)."""
+
+    def __init__(self):
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        check(load().gjx_event_create(C.byref(self.a)), "gjx_event_create")
+        check(load().gjx_event_create(C.byref(self.b)), "gjx_event_create")
+
+    def arm(self) -> None:
+        check(load().gjx_profile_next_run(self.a, self.b), "gjx_profile_next_run")
+
+    def elapsed_us(self) -> float:
+        us = C.c_float()
+        check(load().gjx_event_elapsed_us(self.a, self.b, C.byref(us)), "gjx_event_elapsed_us")
+        return float(us.value)
+
+    def close(self) -> None:
+        load().gjx_event_destroy(self.a)
+        load().gjx_event_destroy(self.b)
+
+
 def program_engine(prog: PackedProgram) -> int:
     cp = prog.c_program(None)
     return int(load().gjx_program_engine(C.byref(cp)))

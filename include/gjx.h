@@ -199,6 +199,15 @@ int gjx_logsumexp(const float* x, int64_t K, int64_t K_total, float* out, void* 
 int gjx_lse_combine(const float* pairs /*[G][2]*/, int G, int64_t K_total, float* out,
                     void* stream);
 
+/* ---- measurement aid (bench.py's roofline figure): HIP events attached to the dispatch of the NEXT fused
+ * propagate+reweight kernel that gjx_run_program launches from the calling thread, so that the kernel's own begin
+ * and end are timed inside a running loop (an event pair recorded around the call also times the dispatch hand-offs
+ * on both sides).  Events are created / read / destroyed through the library so that the caller needs no HIP. */
+int gjx_event_create(void** event_out);
+int gjx_event_destroy(void* event);
+int gjx_event_elapsed_us(void* start_event, void* stop_event, float* us_out); /* waits for stop_event */
+int gjx_profile_next_run(void* start_event, void* stop_event);
+
 /* ---- 1-of-K categorical draw over the weights: ParticleCollection.sample_particle
  * (smc.py:102-109): idx = argmax_i (logw[i] - lse) + Gumbel(bits(key, i)).
  * out_dev: {float best_value, int32 idx (global index = particle_offset + i)} as 2 words */
