@@ -821,3 +821,92 @@ def test_masked_constraints_parity(K_, oracle, rng):
         if a == "n0":        # first site: nothing upstream differs, so unflagged draws equal the unconstrained run's
             np.testing.assert_array_equal(gg["choices"][s0][~fl], _np(free["choices"])[s0][~fl])
     assert (gg["weight"] != 0).mean() > 0.8
+
+
+def _random_program(rs, rng_mode):
+    """A random valid site program: every kind, parameters drawn from the four expression forms over earlier sites
+    (positive / probability parameters go through exp / softplus / sigmoid), random constraint modes."""
+    POS, PROB, REAL = "pos", "prob", "real"
+    spec = {  # kind -> parameter domains
+        A.NORMAL: (REAL, POS), A.FLIP: (PROB,), A.BERNOULLI_LOGITS: (REAL,), A.BETA: (POS, POS), A.UNIFORM: None,
+        A.EXPONENTIAL: (POS,), A.HALF_NORMAL: (POS,), A.LAPLACE: (REAL, POS), A.LOG_NORMAL: (REAL, POS), A.CAUCHY: (REAL, POS),
+        A.GAMMA: (POS, POS), A.STUDENT_T: (POS, REAL, POS), A.POISSON: (POS,), A.GEOMETRIC: (PROB,), A.GUMBEL: (REAL, POS),
+        A.HALF_CAUCHY: (REAL, POS), A.INVERSE_GAMMA: (POS, POS), A.WEIBULL: (POS, POS), A.LOGIT_NORMAL: (REAL, POS), A.CHI2: (POS,),
+        A.MVNORMAL_DIAG: (REAL, POS),
+    }
+    kinds = [k for k in spec if spec[k] is not None]
+    sl = SiteList()
+    cont, cats = [], []           # (addr, dim) of continuous sites; (addr, ncat) of categorical sites
+    n_sites = int(rs.integers(2, 9))
+    for j in range(n_sites):
+        addr = f"s{j}"
+        if rs.random() < 0.15:
+            n = int(rs.integers(2, 6))
+            sl.add(addr, A.CATEGORICAL_PROBS if rs.random() < 0.5 else A.CATEGORICAL_LOGITS,
+                   [(rs.random(n) + 0.1).astype(np.float32)])
+            cats.append((addr, n))
+            continue
+        kind = int(rs.choice(kinds))
+        dim = int(rs.integers(2, 5)) if kind == A.MVNORMAL_DIAG else 1
+
+        def param(dom):
+            xf = {POS: int(rs.choice([A.XF_EXP, A.XF_SOFTPLUS])), PROB: A.XF_SIGMOID, REAL: A.XF_NONE}[dom]
+            form = rs.random()
+            base = rs.standard_normal(dim).astype(np.float32) * 0.5
+            if form < 0.35 or not cont:
+                v = {POS: np.abs(base) + 0.3, PROB: 1 / (1 + np.exp(-base)), REAL: base}[dom]
+                return Param.const(v.astype(np.float32))
+            if form < 0.6 and cats:
+                a, n = cats[int(rs.integers(len(cats)))]
+                tab = rs.standard_normal((n, dim)).astype(np.float32) * 0.5
+                return Param.gather(tab, a, xf=xf)
+            a, d = cont[int(rs.integers(len(cont)))]
+            if form < 0.8:
+                return Param.value(a, length=1, elem=int(rs.integers(d)), xf=xf)
+            return Param.affine((rs.standard_normal((dim, d)) * 0.3).astype(np.float32), a, bias=base * 0.2, xf=xf)
+
+        sl.add(addr, kind, [param(dom) for dom in spec[kind]], dim=dim)
+        # bounded-magnitude continuous values only feed later parameters (heavy tails would overflow exp())
+        if kind in (A.NORMAL, A.MVNORMAL_DIAG, A.LAPLACE, A.GUMBEL, A.LOGIT_NORMAL, A.BETA, A.HALF_NORMAL, A.EXPONENTIAL):
+            cont.append((addr, dim))
+    return sl
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_random_programs_against_oracle(K_, oracle, rng):
+    """Differential test of the site interpreter: 40 random programs, simulate, then re-run with a random subset of
+    sites constrained per particle (assess / importance semantics).  Device == oracle up to the stated tolerances."""
+    import torch
+    rs = np.random.default_rng(77 + rng)
+    K = 600
+    for trial in range(40):
+        sl = _random_program(rs, rng)
+        prog = PackedProgram(sl, rng_mode=rng)
+        key = (int(rs.integers(1 << 30)), int(rs.integers(1 << 30)))
+        g, o = _run_both(K_, oracle, prog, key, K, want_site_scores=True)
+        fin = np.isfinite(o["score"]) & (np.abs(o["score"]) < 1e4)
+        ok = _close_cols(g["choices"], o["choices"], rt=1e-3, at=5e-4) & _close_cols(g["score"][None], o["score"][None], rt=2e-3, at=2e-3)
+        assert (~ok & fin).sum() <= 0.02 * K, f"trial {trial}: {(~ok & fin).sum()} of {K} particles differ ({[A.KIND_NAMES[s.kind] for s in sl.sites]})"
+        # analytic gradients of the same program at the oracle's draws (every site constrained, float sites selected)
+        sel = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS and s.kind not in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS))
+        if sel:
+            prog3 = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=sel, rng_mode=rng)
+            sg, gg = K_.score_grad(prog3, torch.as_tensor(o["choices"]).cuda())
+            so, go = oracle.score_grad(prog3, o["choices"])
+            okg = np.isfinite(go) & (np.abs(go) < 1e3) & fin[None, :]
+            np.testing.assert_allclose(_np(gg)[okg], go[okg], rtol=5e-3, atol=5e-3, err_msg=f"trial {trial} gradients")
+        # constrain a random subset of sites to the oracle's own draws: values untouched, weights = their log-pdfs
+        sub = [s.addr for s in sl.sites if rs.random() < 0.5]
+        if not sub:
+            continue
+        prog2 = PackedProgram(sl, {a: A.MODE_OBS_SLOT for a in sub}, rng_mode=rng)
+        ch = o["choices"].copy()
+        g2 = K_.run_program(prog2, key, K, choices=torch.as_tensor(ch).cuda(), want_site_scores=True)
+        o2 = oracle.run_program(prog2, key, K, choices=ch.copy(), want_site_scores=True)
+        idx = [j for j, s in enumerate(sl.sites) if s.addr in sub]
+        gs, os_ = _np(g2["site_scores"])[idx], o2["site_scores"][idx]
+        good = np.isfinite(os_) & (np.abs(os_) < 1e4)
+        np.testing.assert_allclose(gs[good], os_[good], rtol=2e-3, atol=2e-3, err_msg=f"trial {trial}")
+        for a in sub:
+            s0 = prog2.slot_of[a]
+            np.testing.assert_array_equal(_np(g2["choices"])[s0:s0 + sl[a].dim], ch[s0:s0 + sl[a].dim])
