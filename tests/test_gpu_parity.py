@@ -436,7 +436,7 @@ def test_degenerate_and_invalid_arguments(K_):
 def test_ssm_step_parity(K_, oracle, rng):
     import torch
     rs = np.random.default_rng(3)
-    for dx, dy, useH in ((8, 8, False), (4, 3, True), (2, 2, False), (16, 5, True)):
+    for dx, dy, useH in ((8, 8, False), (4, 3, True), (2, 2, False), (16, 5, True), (32, 7, True), (1, 1, False)):
         Am = (rs.standard_normal((dx, dx)) * 0.3).astype(np.float32)
         Hm = rs.standard_normal((dy, dx)).astype(np.float32) if useH else None
         y = rs.standard_normal((2, dy)).astype(np.float32)
