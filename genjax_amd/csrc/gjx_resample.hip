@@ -500,6 +500,12 @@ extern "C" int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uin
   return GJX_OK;
 }
 
+static int env_items() {
+  const char* e = getenv("GJX_RESAMPLE_ITEMS");
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 4 || v == 16) ? v : 0;
+}
+
 extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials,
                                     double u, int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev,
                                     float* lse_out, int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
@@ -510,7 +516,9 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
   // one co-resident grid of at most 1024 blocks (4 per CU: 70 / 118 registers per lane at 4 / 16 items, 23 KB of
   // LDS); larger K (> 2^22) falls back to the three-launch path — 64 items per lane would need 312 registers, one
   // block per CU, and a grid that cannot be co-resident deadlocks in the granule all-gather
-  int items = 4;
+  int items = env_items();   // 1 particle per lane while that still fits 1024 blocks (K <= 2^18): 4x the waves to hide the
+  if (items == 0) items = (K + 255) / 256 <= 1024 ? 1 : 4;   // round trips; 4, then 16 above
+  if ((K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items = items < 4 ? 4 : 16;
   if ((K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items = 16;
   const int64_t nblocks = (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items);
   hipStream_t st = (hipStream_t)stream;
@@ -525,7 +533,7 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
 #define GJX_RF(IT) hipLaunchKernelGGL((k_resample_fused<IT>), dim3((unsigned)nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, \
                                       (int)n_partials, lse_out, log_k, u, N, ancestors, cum, base_total_dev, agg, ctrl)
-  if (items == 4) GJX_RF(4); else GJX_RF(16);
+  if (items == 1) GJX_RF(1); else if (items == 4) GJX_RF(4); else GJX_RF(16);
 #undef GJX_RF
   GJX_CHECK_LAUNCH("gjx_resample_indices");
   return GJX_OK;
