@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -55,7 +55,8 @@ class GjxSite(C.Structure):
 
 class GjxProgram(C.Structure):
     _fields_ = [("n_sites", i32), ("n_slots", i32), ("n_tab", i32), ("rng_mode", i32),
-                ("sites", vp), ("sites_dev", vp), ("tab", vp), ("tab_dev", vp)]
+                ("sites", vp), ("sites_dev", vp), ("tab", vp), ("tab_dev", vp), ("aux_dev", vp), ("n_aux", i32),
+                ("pad_", i32)]
 
 
 class GjxSsm(C.Structure):
@@ -81,6 +82,8 @@ PROTOTYPES = {
     "gjx_version": (C.c_int, []),
     "gjx_last_error": (C.c_char_p, []),
     "gjx_program_engine": (C.c_int, [PP]),
+    "gjx_program_aux_floats": (C.c_int, [PP]),
+    "gjx_program_prepare": (C.c_int, [PP, vp, i32, vp]),
     "gjx_threefry2x32": (C.c_int, [u32, u32, u32, u32, i64, vp, vp]),
     "gjx_run_program": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp,
                                   C.c_size_t, vp]),

@@ -51,30 +51,47 @@ GJX_DEV key2 fold_in64(key2 k, uint64_t i) { return threefry2x32(k, (uint32_t)(i
 template <int RNG>
 struct BitStream;
 
+// FLAT: the (particle, site) stream is the concatenation of the 64-bit blocks Threefry(key, (i, site<<22 | h)),
+// h = 0, 1, ..., read as 32-bit words; element c is the 32-bit window starting at stream bit 23*c (consumers use
+// its top 23 bits), so consecutive draws use consecutive disjoint 23-bit fields: 2.78 draws per hash.
+// The two most recent blocks are cached (slot = h & 1), which makes a sequential reader compute every hash once.
 template <>
 struct BitStream<GJX_RNG_FLAT> {
-  key2 key, cache;
-  uint32_t c0, site_hi, cached;
-  float n0, n1;         // Box-Muller pair of hash `npair` (stream_normal): the odd element reuses the even one's work
+  key2 key, blk0, blk1;
+  uint32_t c0, site_hi, h0, h1;   // h0 / h1: block index held in blk0 (even h) / blk1 (odd h), ~0u when empty
+  float n0, n1;         // Box-Muller pair of elements (2*npair, 2*npair+1) (stream_normal): the odd element reuses the even one's work
   uint32_t npair;
-  GJX_DEV BitStream() : key{0u, 0u}, cache{0u, 0u}, c0(0u), site_hi(0u), cached(0xFFFFFFFFu), n0(0.0f), n1(0.0f), npair(0xFFFFFFFFu) {}
+  GJX_DEV BitStream() : key{0u, 0u}, blk0{0u, 0u}, blk1{0u, 0u}, c0(0u), site_hi(0u), h0(0xFFFFFFFFu), h1(0xFFFFFFFFu), n0(0.0f), n1(0.0f), npair(0xFFFFFFFFu) {}
   GJX_DEV void open(key2 run_key, uint64_t idx, uint32_t site) {
     key = (idx >> 32) ? threefry2x32(run_key, 0xFFFFFFFFu, (uint32_t)(idx >> 32)) : run_key;
     c0 = (uint32_t)idx;
     site_hi = site << GJX_FLAT_SITE_SHIFT;
-    cached = 0xFFFFFFFFu;
+    h0 = h1 = 0xFFFFFFFFu;
     npair = 0xFFFFFFFFu;
   }
   GJX_DEV void open_site_key(key2) {}
-  GJX_DEV uint32_t get(uint32_t c) {
-    const uint32_t pair = c >> 1;
-    if (pair != cached) {
-      cache = threefry2x32(key, c0, site_hi | pair);
-      cached = pair;
+  GJX_DEV uint32_t word(uint32_t n) {
+    const uint32_t h = n >> 1;
+    if (h & 1u) {
+      if (h1 != h) { blk1 = threefry2x32(key, c0, site_hi | h); h1 = h; }
+      return (n & 1u) ? blk1.b : blk1.a;
     }
-    return (c & 1u) ? cache.b : cache.a;
+    if (h0 != h) { blk0 = threefry2x32(key, c0, site_hi | h); h0 = h; }
+    return (n & 1u) ? blk0.b : blk0.a;
+  }
+  GJX_DEV uint32_t get(uint32_t c) {
+    const uint32_t bit = 23u * c, n = bit >> 5, sh = bit & 31u;
+    const uint32_t lo = word(n);
+    if (sh == 0u) return lo;
+    return __builtin_amdgcn_alignbit(word(n + 1u), lo, sh);
   }
 };
+
+// 32-bit window of FLAT element c in the word array w[] (word 2h = x0, word 2h+1 = x1 of block h); for fused kernels
+// whose c is a constant after unrolling
+#define GJX_FIELD(w, c) ((((23 * (c)) & 31) == 0) ? (w)[(23 * (c)) >> 5] : __builtin_amdgcn_alignbit((w)[((23 * (c)) >> 5) + 1], (w)[(23 * (c)) >> 5], (23 * (c)) & 31))
+// number of 64-bit blocks the first n elements of a FLAT stream touch
+#define GJX_FLAT_BLOCKS(n) ((9 + 23 * (n) + 63) / 64)
 
 template <>
 struct BitStream<GJX_RNG_JAX32> {
@@ -196,7 +213,7 @@ GJX_DEV float normal_from_bits(uint32_t bits) {
   const float u = uniform_from_bits(bits, kNeg1PlusUlp, 1.0f);
   return kSqrt2 * erfinv_f32(u);
 }
-// Box-Muller pair from the two words of one hash (FLAT layout): (r cos 2πu2, r sin 2πu2), u1 in (0,1].
+// Box-Muller pair from two consecutive FLAT elements: (r cos 2πu2, r sin 2πu2), u1 in (0,1].
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so u2 feeds them directly.
 GJX_DEV void box_muller(uint32_t wa, uint32_t wb, float& n0, float& n1) {
   const float u1 = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wa, 9));  // 1 - unit, (0,1]

@@ -247,6 +247,7 @@ struct GmmArgs {
   unsigned* ticket;
   float* lse;
   float log_k_total;
+  const float* aux;  // prepared constants (gjx_program_prepare), FLAT kernel only
 };
 
 template <int PPT>
@@ -489,6 +490,259 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// fused mixture kernel, FLAT stream (the headline kernel of BASELINE config 2)
+//
+// What bounds it (measured on MI355X, scratch/ub4.hip, whole-SIMD throughput in shader cycles per wave-instruction):
+// v_add/xor/sub/and/or/lshr/mov and fp32 add/mul/fma 2.3; every VOP3 integer op, v_lshlrev, v_max_f32, v_cvt, v_cmp,
+// v_pk_* and any VOP2 with an SGPR source 4.2; v_log/exp/sqrt/rcp/sin/cos 8.3; and a stream that alternates the two
+// integer classes pays ~2.3 extra per Threefry round: one Threefry-2x32-20 hash = 272 cycles however it is ordered,
+// placed or interleaved (1-8 waves per SIMD, ILP 1-8, same or different register banks).  The kernel therefore spends
+// its time in the hash and everything here serves to need fewer VALU cycles per particle:
+//   * the bit-packed FLAT stream (23 bits per draw): 1 + ceil((9 + 23 D) / 64) hashes per particle instead of 1 + D/2;
+//   * every per-component constant comes precomputed from gjx_program_prepare (the prologue is one global -> LDS copy
+//     whose latency hides behind the first tile's categorical hash);
+//   * z by counting sign bits of (target - cdf[c]) (sub, lshr, add: three full-rate ops instead of cmp + cndmask/addc);
+//   * x = mu + sigma n and the observed z-score a - b n (a = (y - mu) / r, b = sigma / r) are one fma each, and
+//     sum_d n_d^2 of a Box-Muller pair is its squared radius -2 ln u1, which is already there.
+// Aux layout (floats): T[C][4 D + 4] with T[c][4 d .. 4 d + 3] = {mu, sigma, a, b} of (c, d) — one ds_read_b128 per
+// (particle, dimension), one address register per particle with the dimension in the instruction's offset field, rows
+// of different z on different LDS banks — then zlp[C], cdf[C], misc[8].
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline int gmm_aux_floats(int C, int D) { return C * (4 * D + 4) + 2 * C + 8; }
+
+__global__ __launch_bounds__(256) void k_gmm_prepare(GmmArgs a, int D, float* aux) {
+  const int C = a.C, RS = 4 * D + 4;
+  const float* __restrict__ tab = a.tab;
+  float* s_t = aux; float* s_zlp = s_t + C * RS; float* s_cdf = s_zlp + C; float* s_misc = s_cdf + C;
+  for (int t = threadIdx.x; t < C * (D + 1); t += 256) {
+    const int c = t / (D + 1), d = t % (D + 1);
+    float mu = 0.0f, sg = 0.0f, av = 0.0f, bv = 0.0f;
+    if (d < D) {
+      mu = tab[a.mu_off + c * D + d];
+      sg = tab[a.sig_off + c * D + d];
+      const float rr = fast_rcp(tab[a.r_off + (a.r_len == 1 ? 0 : d)]);
+      av = (tab[a.y_off + d] - mu) * rr;
+      bv = sg * rr;
+    }
+    float* q = s_t + c * RS + 4 * d;
+    q[0] = mu; q[1] = sg; q[2] = av; q[3] = bv;
+  }
+  if (threadIdx.x < 64) {  // wave 0: log-softmax, per-component log-sigma sums, running CDF (float32 category order)
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 64) mx = fmaxf(mx, tab[a.logits_off + c]);
+    mx = wave_max(mx);
+    float se = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 64) se += fast_exp(tab[a.logits_off + c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + fast_log(se);
+    for (int c = threadIdx.x; c < C; c += 64) {
+      float sl = 0.0f;
+      for (int d = 0; d < D; ++d) sl += fast_log(tab[a.sig_off + c * D + d]);
+      s_zlp[c] = (tab[a.logits_off + c] - lse) - sl - (float)D * kHalfLog2Pi;
+    }
+    if (threadIdx.x == 63) {
+      float sl = 0.0f;
+      for (int d = 0; d < D; ++d) sl += fast_log(tab[a.r_off + (a.r_len == 1 ? 0 : d)]);
+      s_misc[0] = -sl - (float)D * kHalfLog2Pi;
+      for (int j = 1; j < 8; ++j) s_misc[j] = 0.0f;
+    }
+    if (threadIdx.x == 0) {
+      float run = 0.0f;  // same float32 order as the generic interpreter and the oracle
+      for (int c = 0; c < C; ++c) { run += fast_exp(tab[a.logits_off + c] - mx); s_cdf[c] = run; }
+    }
+  }
+}
+
+template <int D, int PPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
+  constexpr int RS = 4 * D + 4;       // LDS row stride of one component (floats)
+  constexpr int NPAIR = (D + 1) / 2;
+  constexpr int NHASH = (9 + 23 * (D == 1 ? 2 : D) + 63) / 64;   // blocks of the x site's stream the draws touch
+  constexpr bool UNROLLED = D <= 16;                 // larger D: rolled loop over pairs through BitStream (code size)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C;
+  float* s_t = smem; float* s_zlp = s_t + C * RS; float* s_cdf = s_zlp + C; float* s_misc = s_cdf + C;
+  const int64_t K = a.K;
+  const int64_t tile = (int64_t)THREADS * PPT;
+  const int64_t ntiles = (K + tile - 1) / tile;
+  const uint64_t goff = (uint64_t)a.offset;
+  // the launcher guarantees that all particles of this launch share the high index word
+  const key2 fkey = (goff >> 32) ? threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(goff >> 32)) : a.key;
+
+  // ---- prologue: request the prepared table, hash while it is in flight, then fill LDS ----
+  const int naux = gmm_aux_floats(C, D);
+  constexpr int NPRE = 4;
+  float pre[NPRE];
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) {
+    const int t = threadIdx.x + j * THREADS;
+    pre[j] = t < naux ? a.aux[t] : 0.0f;
+  }
+  int64_t tix = blockIdx.x;
+  uint32_t hz[PPT];   // categorical draw of the next tile (element 0 of site 1)
+  auto cat_bits = [&](int64_t t) {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      int64_t i = t * tile + (int64_t)threadIdx.x * PPT + p;
+      i = i < K ? i : K - 1;
+      hz[p] = threefry2x32(fkey, (uint32_t)(goff + (uint64_t)i), (1u << GJX_FLAT_SITE_SHIFT)).a;
+    }
+  };
+  if (tix < ntiles) cat_bits(tix);
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) {
+    const int t = threadIdx.x + j * THREADS;
+    if (t < naux) smem[t] = pre[j];
+  }
+  for (int t = threadIdx.x + NPRE * THREADS; t < naux; t += THREADS) smem[t] = a.aux[t];
+  __syncthreads();
+
+  float tmax = -INFINITY;   // running per-thread max / sum for the block's LSE partial
+  float tsum = 0.0f;
+  const float cdf_total = s_cdf[C - 1];
+  for (; tix < ntiles; tix += gridDim.x) {
+    const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;
+    // K % PPT == 0 (launcher), so a lane's PPT particles are all inside or all outside; lanes past the end are done
+    // (their later tiles lie past the end too) and take no part in anything but the final reduction
+    if (i0 >= K) break;
+    uint32_t c0[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) c0[p] = (uint32_t)(goff + (uint64_t)(i0 + p));
+    // ---- z ~ categorical(logits): inverse CDF on one uniform = number of c < C-1 with cdf[c] <= target ----
+    int z[PPT];
+    float zf[PPT], target[PPT];
+    uint32_t neg[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      target[p] = (__uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, hz[p], 9)) - 1.0f) * cdf_total;
+      neg[p] = 0u;
+    }
+    for (int c = 0; c < C - 1; ++c) {
+      const float cd = s_cdf[c];
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) neg[p] += __float_as_uint(target[p] - cd) >> 31;   // cdf[c] > target
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) { z[p] = (C - 1) - (int)neg[p]; zf[p] = (float)z[p]; }
+    float* ch = a.choices;
+    VecStore<PPT>::st(ch + i0, zf);
+    // ---- x ~ N(mu[z], sigma[z]); y | x ~ N(x, r) observed ----
+    float qx[PPT], qy[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) { qx[p] = 0.0f; qy[p] = 0.0f; }
+    uint32_t w[PPT][UNROLLED ? 2 * NHASH : 2];
+    BitStream<GJX_RNG_FLAT> bs[UNROLLED ? 1 : PPT];
+    if (!UNROLLED) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) { bs[p].key = fkey; bs[p].c0 = c0[p]; bs[p].site_hi = 2u << GJX_FLAT_SITE_SHIFT; bs[p].h0 = bs[p].h1 = 0xFFFFFFFFu; }
+    }
+    constexpr int UF = UNROLLED ? NPAIR : 1;
+#pragma unroll UF
+    for (int k = 0; k < NPAIR; ++k) {            // k is a constant after unrolling when UNROLLED
+      const int d0 = 2 * k;
+      float xa[PPT], xb[PPT];
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        uint32_t wa, wb;
+        if constexpr (UNROLLED) {
+          const int last = D == 1 ? 1 : 2 * k + 1;                           // highest element this pair reads
+          const int need = (((23 * last) >> 5) + ((((23 * last) & 31) != 0) ? 1 : 0)) >> 1;   // highest block it touches
+          const int prev_last = 2 * (k - 1) + 1;
+          const int have = k == 0 ? -1 : ((((23 * prev_last) >> 5) + ((((23 * prev_last) & 31) != 0) ? 1 : 0)) >> 1);
+#pragma unroll
+          for (int h = 0; h < NHASH; ++h) if (h > have && h <= need) {
+            const key2 hh = threefry2x32(fkey, c0[p], (2u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+            w[p][2 * h] = hh.a; w[p][2 * h + 1] = hh.b;
+          }
+          wa = GJX_FIELD(w[p], 2 * k);
+          wb = GJX_FIELD(w[p], 2 * k + 1);
+        } else {
+          wa = bs[p].get((uint32_t)d0);
+          wb = bs[p].get((uint32_t)d0 + 1u);
+        }
+        // Box-Muller: u1 = 2 - [1,2) in (0,1]; v_sin/v_cos take revolutions and are periodic, so [1,2) feeds them as is
+        const float u1 = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wa, 9));
+        const float rsq = __builtin_amdgcn_logf(u1) * (-2.0f * kLn2);
+        const float r = fast_sqrt(rsq);
+        const float4* row = reinterpret_cast<const float4*>(s_t + z[p] * RS) + d0;   // {mu, sigma, a, b} of (z, d0)
+        if (D == 1) {
+          // one draw: the cosine branch of the pair whose angle is element 1 of the stream (the generic rule)
+          const float u2 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9));
+          const float n0 = r * __builtin_amdgcn_cosf(u2);
+          const float4 t0 = row[0];
+          const float x = fmaf(t0.y, n0, t0.x);
+          qx[p] = fmaf(n0, n0, qx[p]);
+          const float zy = fmaf(-t0.w, n0, t0.z);
+          qy[p] = fmaf(zy, zy, qy[p]);
+          xa[p] = x; xb[p] = 0.0f;
+        } else {
+          const float u2 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9));
+          const float n0 = r * __builtin_amdgcn_cosf(u2), n1 = r * __builtin_amdgcn_sinf(u2);
+          const float4 t0 = row[0], t1 = row[1];
+          xa[p] = fmaf(t0.y, n0, t0.x);
+          xb[p] = fmaf(t1.y, n1, t1.x);
+          qx[p] += rsq;                                   // n0^2 + n1^2 = r^2
+          const float zy0 = fmaf(-t0.w, n0, t0.z), zy1 = fmaf(-t1.w, n1, t1.z);
+          qy[p] = fmaf(zy0, zy0, qy[p]);
+          qy[p] = fmaf(zy1, zy1, qy[p]);
+        }
+      }
+      float* r0 = ch + (int64_t)(1 + d0) * K + i0;
+      VecStore<PPT>::st(r0, xa);
+      if (D > 1) VecStore<PPT>::st(r0 + K, xb);
+      // keeps the work of pair k+1 out of pair k.  Without the scheduling barrier every hash of the tile moves to the
+      // top (170+ VGPRs); without pinning the two accumulators here instruction selection parks the whole
+      // z-score / sum-of-squares chain (it has no side effect until the tile's last store) behind the last barrier and
+      // keeps a, b and n of all D dimensions alive until then (250 VGPRs, 1-2 waves per SIMD)
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) asm volatile("" : "+v"(qx[p]), "+v"(qy[p]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float sc[PPT], wt[PPT], lw[PPT];
+    const float wconst = s_misc[0];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      wt[p] = fmaf(-0.5f, qy[p], wconst);
+      sc[p] = fmaf(-0.5f, qx[p], s_zlp[z[p]]) + wt[p];
+      float l = wt[p];
+      if (a.logw_in) l += a.logw_in[i0 + p];
+      if (a.sub) l -= a.sub[i0 + p];
+      lw[p] = l;
+    }
+    if (a.score) VecStore<PPT>::st(a.score + i0, sc);
+    if (a.weight) VecStore<PPT>::st(a.weight + i0, wt);
+    if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);
+    // online {max, sum} per thread: one rescale per tile
+    float m4 = tmax;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) m4 = fmaxf(m4, lw[p]);
+    if (m4 > -INFINITY) {
+      float s4 = tsum * fast_exp(tmax - m4);
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) s4 += fast_exp(lw[p] - m4);
+      tsum = s4;
+    }
+    tmax = m4;
+    if (tix + gridDim.x < ntiles) cat_bits(tix + gridDim.x);
+  }
+  if (a.partials) {
+    constexpr int NW = THREADS / 64;
+    __shared__ float red[2 * NW + 2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float wm = wave_max(tmax);
+    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+    if (lane == 0) { red[wid] = wm; red[NW + wid] = ws; }
+    __syncthreads();
+    float bm = red[0];
+    for (int w2 = 1; w2 < NW; ++w2) bm = fmaxf(bm, red[w2]);
+    float bsum = 0.0f;
+    for (int w2 = 0; w2 < NW; ++w2) bsum += bm > -INFINITY ? red[NW + w2] * fast_exp(red[w2] - bm) : 0.0f;
+    if (a.lse) lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // consumer finishes (gjx_weight_cumsum mode 2)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LSE: partials -> {max, sumexp, lse, lse - log K_total}
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lse_finish(const float2* partials, int n, float log_k_total, float* out) {
@@ -588,32 +842,51 @@ int env_int(const char* name, int dflt) {
 // from this thread — they take the kernel's own begin / end timestamps, not those of markers around it
 thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
 
-template <int RNG, int D, int PPT>
-void launch_gmm_t(const GmmArgs& a, int grid, size_t lds, hipStream_t st) {
+template <class KERN>
+void launch_gmm_kernel(KERN kern, const GmmArgs& a, int grid, size_t lds, hipStream_t st) {
   if (t_prof_start && t_prof_stop) {
-    hipExtLaunchKernelGGL((k_run_gmm<RNG, D, PPT, 256>), dim3(grid), dim3(256), (uint32_t)lds, st, t_prof_start, t_prof_stop, 0, a);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)lds, st, t_prof_start, t_prof_stop, 0, a);
     t_prof_start = t_prof_stop = nullptr;
     return;
   }
-  hipLaunchKernelGGL((k_run_gmm<RNG, D, PPT, 256>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
-template <int RNG, int D>
-void launch_gmm_d(const GmmArgs& a, int ppt, int grid, size_t lds, hipStream_t st) {
-  if (ppt == 4) launch_gmm_t<RNG, D, 4>(a, grid, lds, st);
-  else if (ppt == 2) launch_gmm_t<RNG, D, 2>(a, grid, lds, st);
-  else launch_gmm_t<RNG, D, 1>(a, grid, lds, st);
-}
-template <int RNG>
-void launch_gmm(const GmmArgs& a, int D, int ppt, int grid, size_t lds, hipStream_t st) {
-  switch (D) {
-    case 1: launch_gmm_d<RNG, 1>(a, ppt, grid, lds, st); break;
-    case 2: launch_gmm_d<RNG, 2>(a, ppt, grid, lds, st); break;
-    case 4: launch_gmm_d<RNG, 4>(a, ppt, grid, lds, st); break;
-    case 8: launch_gmm_d<RNG, 8>(a, ppt, grid, lds, st); break;
-    case 16: launch_gmm_d<RNG, 16>(a, ppt, grid, lds, st); break;
-    case 32: launch_gmm_d<RNG, 32>(a, ppt, grid, lds, st); break;
-    default: launch_gmm_d<RNG, 64>(a, ppt, grid, lds, st); break;
+template <int D>
+void launch_gmm_d(const GmmArgs& a, bool flat, int ppt, int grid, size_t lds, hipStream_t st) {
+  if (flat) {
+    if (ppt == 4) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256>, a, grid, lds, st);
+    else if (ppt == 2) launch_gmm_kernel(k_run_gmm_flat<D, 2, 256>, a, grid, lds, st);
+    else launch_gmm_kernel(k_run_gmm_flat<D, 1, 256>, a, grid, lds, st);
+  } else {
+    if (ppt == 4) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 4, 256>, a, grid, lds, st);
+    else if (ppt == 2) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 2, 256>, a, grid, lds, st);
+    else launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 1, 256>, a, grid, lds, st);
   }
+}
+void launch_gmm(const GmmArgs& a, bool flat, int D, int ppt, int grid, size_t lds, hipStream_t st) {
+  switch (D) {
+    case 1: launch_gmm_d<1>(a, flat, ppt, grid, lds, st); break;
+    case 2: launch_gmm_d<2>(a, flat, ppt, grid, lds, st); break;
+    case 4: launch_gmm_d<4>(a, flat, ppt, grid, lds, st); break;
+    case 8: launch_gmm_d<8>(a, flat, ppt, grid, lds, st); break;
+    case 16: launch_gmm_d<16>(a, flat, ppt, grid, lds, st); break;
+    case 32: launch_gmm_d<32>(a, flat, ppt, grid, lds, st); break;
+    default: launch_gmm_d<64>(a, flat, ppt, grid, lds, st); break;
+  }
+}
+
+void fill_gmm_args(GmmArgs& a, const gjx_program* prog, const GmmShape& g) {
+  a.tab = prog->tab_dev; a.C = g.C;
+  a.logits_off = g.logits_off; a.mu_off = g.mu_off; a.sig_off = g.sig_off;
+  a.r_off = g.r_off; a.r_len = g.r_len; a.y_off = g.y_off;
+  a.aux = prog->aux_dev;
+}
+
+// the fused mixture kernel needs the prepared constants when the stream is FLAT
+bool gmm_usable(const gjx_program* p, GmmShape* g) {
+  if (env_int("GJX_FORCE_GENERIC", 0) || !match_gmm(p, g)) return false;
+  if (p->rng_mode == GJX_RNG_JAX32) return true;
+  return p->aux_dev != nullptr && p->n_aux >= gmm_aux_floats(g->C, g->D);
 }
 
 }  // namespace
@@ -656,14 +929,36 @@ extern "C" int gjx_profile_next_run(void* start, void* stop) {
 extern "C" int gjx_program_engine(const gjx_program* prog) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   GmmShape g;
-  if (!env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, &g)) return ENGINE_GMM;
+  if (gmm_usable(prog, &g)) return ENGINE_GMM;
   return ENGINE_GENERIC;
+}
+
+// ---- prepared constants -------------------------------------------------------------------------
+extern "C" int gjx_program_aux_floats(const gjx_program* prog) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  GmmShape g;
+  if (prog->rng_mode == GJX_RNG_FLAT && match_gmm(prog, &g)) return gmm_aux_floats(g.C, g.D);
+  return 0;
+}
+
+extern "C" int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int32_t n_aux, void* stream) {
+  if (!prog || !prog->sites || !prog->tab_dev) return gjx_fail(GJX_EINVAL, "gjx_program_prepare: null program");
+  const int need = gjx_program_aux_floats(prog);
+  if (need <= 0) return GJX_OK;
+  if (!aux_dev || n_aux < need) return gjx_fail(GJX_EINVAL, "gjx_program_prepare: aux buffer too small (gjx_program_aux_floats)");
+  GmmShape g;
+  match_gmm(prog, &g);
+  GmmArgs a = {};
+  fill_gmm_args(a, prog, g);
+  hipLaunchKernelGGL(k_gmm_prepare, dim3(1), dim3(256), 0, (hipStream_t)stream, a, g.D, aux_dev);
+  GJX_CHECK_LAUNCH("gjx_program_prepare");
+  return GJX_OK;
 }
 
 // number of thread blocks (== LSE partial pairs) gjx_run_program launches for this program and K
 static int run_grid(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores, int* ppt_out, bool* fused_out, GmmShape* g) {
   const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
-  const bool fused = !want_site_scores && same_hi && !env_int("GJX_FORCE_GENERIC", 0) && match_gmm(prog, g);
+  const bool fused = !want_site_scores && same_hi && gmm_usable(prog, g);
   if (fused_out) *fused_out = fused;
   if (!fused) return (int)((K + 255) / 256);
   int ppt = env_int("GJX_GMM_PPT", 4);
@@ -714,15 +1009,14 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   const int nblocks = run_grid(prog, K, particle_offset, site_scores != nullptr, &ppt, &fused, &g);
   if (fused) {
     GmmArgs a;
-    a.tab = prog->tab_dev; a.C = g.C;
-    a.logits_off = g.logits_off; a.mu_off = g.mu_off; a.sig_off = g.sig_off;
-    a.r_off = g.r_off; a.r_len = g.r_len; a.y_off = g.y_off;
+    fill_gmm_args(a, prog, g);
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.partials = partials; a.ticket = ticket; a.lse = lse; a.log_k_total = log_k_total;
-    const size_t lds = sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
-    if (prog->rng_mode == GJX_RNG_JAX32) launch_gmm<GJX_RNG_JAX32>(a, g.D, ppt, nblocks, lds, st);
-    else launch_gmm<GJX_RNG_FLAT>(a, g.D, ppt, nblocks, lds, st);
+    const bool flat = prog->rng_mode != GJX_RNG_JAX32;
+    const size_t lds = flat ? sizeof(float) * (size_t)gmm_aux_floats(g.C, g.D)
+                            : sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
+    launch_gmm(a, flat, g.D, ppt, nblocks, lds, st);
   } else {
     RunArgs a;
     a.sites = prog->sites_dev; a.tab = prog->tab_dev; a.n_sites = prog->n_sites; a.n_slots = prog->n_slots;

@@ -56,22 +56,33 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
     for (int d = 0; d < DX; ++d) xn[d] = 0.0f;
   }
   const float sd = a.t > 0 ? a.q : a.q0;
+  if (RNG == GJX_RNG_FLAT) {
+    // site 1 of the FLAT stream: DX elements of 23 bits (an odd DX reads the partner element DX of its last pair)
+    constexpr int NE = DX + (DX & 1);
+    constexpr int NB = GJX_FLAT_BLOCKS(NE);
+    uint32_t w[2 * NB];
 #pragma unroll
-  for (int d0 = 0; d0 < DX; d0 += 2) {
-    uint32_t b0, b1 = 0u;
-    if (RNG == GJX_RNG_JAX32) {
-      const key2 h0 = threefry2x32(sk, 0u, (uint32_t)d0);
-      b0 = h0.a ^ h0.b;
-      if (d0 + 1 < DX) { const key2 h1 = threefry2x32(sk, 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; }
-    } else {
-      const key2 h = threefry2x32(sk, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)(d0 >> 1));
-      b0 = h.a; b1 = h.b;
+    for (int h = 0; h < NB; ++h) {
+      const key2 hh = threefry2x32(sk, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+      w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
     }
-    float n0, n1;
-    if (RNG == GJX_RNG_FLAT) box_muller(b0, b1, n0, n1);
-    else { n0 = normal_from_bits_fast(b0); n1 = (d0 + 1 < DX) ? normal_from_bits_fast(b1) : 0.0f; }
-    xn[d0] = fmaf(sd, n0, xn[d0]);
-    if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
+#pragma unroll
+    for (int d0 = 0; d0 < DX; d0 += 2) {
+      float n0, n1;
+      box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
+      xn[d0] = fmaf(sd, n0, xn[d0]);
+      if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int d0 = 0; d0 < DX; d0 += 2) {
+      const key2 h0 = threefry2x32(sk, 0u, (uint32_t)d0);
+      const uint32_t b0 = h0.a ^ h0.b;
+      uint32_t b1 = 0u;
+      if (d0 + 1 < DX) { const key2 h1 = threefry2x32(sk, 0u, (uint32_t)(d0 + 1)); b1 = h1.a ^ h1.b; }
+      xn[d0] = fmaf(sd, normal_from_bits_fast(b0), xn[d0]);
+      if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, normal_from_bits_fast(b1), xn[d0 + 1]);
+    }
   }
   if (active) {
 #pragma unroll

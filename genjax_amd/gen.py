@@ -831,17 +831,38 @@ def gen(fn: Callable) -> StaticGenerativeFunction:
     return StaticGenerativeFunction(fn)
 
 
+class _IdKey:
+    """Cache-key component for an argument that has no value identity: compares by object identity and keeps the
+    object alive, so its id() cannot be recycled for a different object while the cache entry exists."""
+    __slots__ = ("obj",)
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __hash__(self):
+        return id(self.obj)
+
+    def __eq__(self, other):
+        return isinstance(other, _IdKey) and other.obj is self.obj
+
+
+def _value_key(a):
+    """Content key of one argument / constraint value (arrays by shape + bytes)."""
+    if isinstance(a, (int, float, str, bool, type(None))):
+        return a
+    if isinstance(a, (np.ndarray, np.generic, list, tuple)) or hasattr(a, "detach"):
+        arr = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        if arr.dtype == object:
+            return tuple(_value_key(x) for x in a)
+        return (arr.shape, arr.dtype.str, arr.tobytes())
+    ck = getattr(a, "_cache_key", None)
+    if ck is not None:
+        return ck()
+    return _IdKey(a)
+
+
 def _args_key(args) -> tuple:
-    out = []
-    for a in args:
-        if isinstance(a, (int, float, str, bool, type(None))):
-            out.append(a)
-        elif isinstance(a, (np.ndarray, list, tuple)) or hasattr(a, "detach"):
-            arr = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
-            out.append((arr.shape, arr.tobytes()))
-        else:
-            out.append(id(a))
-    return tuple(out)
+    return tuple(_value_key(a) for a in args)
 
 
 class Marginal(GenerativeFunction):

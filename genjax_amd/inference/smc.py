@@ -39,7 +39,17 @@ class Target:
         return self.constraint[addr]
 
     def same_as(self, other: "Target") -> bool:
-        return self.p is other.p and self.args == other.args and self.constraint == other.constraint
+        from ..gen import _args_key
+        return self.p is other.p and _args_key(self.args) == _args_key(other.args) and self.constraint == other.constraint
+
+    def _cache_key(self):
+        """Content identity for trace caches (a proposal ``q(target)`` is traced once per distinct target)."""
+        from ..gen import _IdKey, _args_key, _value_key
+        items = []
+        from ..core import Masked
+        for addr, v in self.constraint._d.items():
+            items.append((repr(addr), (_value_key(v.value), _value_key(v.flag)) if isinstance(v, Masked) else _value_key(v)))
+        return ("Target", _IdKey(self.p), _args_key(self.args), tuple(items))
 
 
 class ParticleCollection:
@@ -141,12 +151,13 @@ class SMCAlgorithm:
         return w, chm
 
 
-def _propose(q, key: Key, target: Target, K: int):
+def _propose(q, key: Key, target: Target, K: int, offset: int = 0, K_total=None):
     """q.random_weighted vmapped over particles: -> (log_q f32[K], per-particle rows addr -> [dim][K]).
     Properly weighted (log_q = the proposal's full density), unlike the reference's
-    Marginal.random_weighted path (sp.py:226-230)."""
+    Marginal.random_weighted path (sp.py:226-230).  ``offset`` is the global index of this
+    rank's first particle: a shard proposes from the same streams the unsharded run would use."""
     gf = q.gen_fn if isinstance(q, Marginal) else q
-    tr, out = gf._run(key, K, (target,), ChoiceMap.empty(), True, True)
+    tr, out = gf._run(key, K, (target,), ChoiceMap.empty(), True, True, offset=offset, K_total=K_total)
     return out["score"], {a: r for a, r in tr.full_choice_rows().items()}
 
 
@@ -169,7 +180,7 @@ class ImportanceK(SMCAlgorithm):
         key, sub_key = split(key)                    # smc.py:299
         # sub_keys = split(sub_key, K) happens on the device: particle i <-> Threefry(sub_key, (0, i))
         if self.q is not None:
-            log_q, rows = _propose(self.q, sub_key, self.target, K)     # smc.py:302-304
+            log_q, rows = _propose(self.q, sub_key, self.target, K, offset, self.k_particles)     # smc.py:302-304
             tr, out = self.target.p._run(sub_key, K, self.target.args, self.target.constraint, True, True,
                                          prev_rows=rows, sub=log_q, want_lse=True, offset=offset,
                                          K_total=self.k_particles)

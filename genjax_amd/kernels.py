@@ -59,8 +59,14 @@ class DispatchTimer:
         load().gjx_event_destroy(self.b)
 
 
-def program_engine(prog: PackedProgram) -> int:
-    cp = prog.c_program(None)
+def _cp_for_query(prog: PackedProgram, device=None):
+    """Program struct for engine / grid queries: the device form (with the prepared constants the fused engines need)
+    whenever a GPU is there, the host form otherwise (struct checks on a CPU-only box)."""
+    return prog.c_program(_dev(device) if (device is not None or torch.cuda.is_available()) else None)
+
+
+def program_engine(prog: PackedProgram, device=None) -> int:
+    cp = _cp_for_query(prog, device)
     return int(load().gjx_program_engine(C.byref(cp)))
 
 
@@ -165,8 +171,8 @@ def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=Tru
     return anc
 
 
-def run_partials_count(prog: PackedProgram, K: int, offset: int = 0) -> int:
-    cp = prog.c_program(None)
+def run_partials_count(prog: PackedProgram, K: int, offset: int = 0, device=None) -> int:
+    cp = _cp_for_query(prog, device)
     return int(load().gjx_run_partials_count(C.byref(cp), int(K), int(offset)))
 
 

@@ -262,6 +262,8 @@ class PackedProgram:
         self.n_sites = n
         self.n_slots = n_slots
         self._dev = None  # (sites tensor, tab tensor)
+        self._aux = None  # device floats of gjx_program_prepare (None: not prepared yet)
+        self._aux_n = 0
 
     # -- observed values can be replaced in place (same program, new data) --
     def _obs_value(self, addr: str) -> np.ndarray:
@@ -325,6 +327,7 @@ class PackedProgram:
             import torch
             for o, n in dirty:
                 self._dev[1][o:o + n] = torch.from_numpy(self.tab[o:o + n].copy()).to(self._dev[1].device)
+            self._aux = None                             # derived constants follow the table
 
     def sites_bytes(self) -> bytes:
         return bytes(self.c_sites)[: self.n_sites * C.sizeof(A.GjxSite)]
@@ -340,8 +343,22 @@ class PackedProgram:
             if self._dev is None or self._dev[1].device != torch.device(device):
                 sb = np.frombuffer(self.sites_bytes() or b"\0" * 96, dtype=np.uint8).copy()
                 self._dev = (torch.from_numpy(sb).to(device), torch.from_numpy(self.tab.copy()).to(device))
+                self._aux = None
             p.sites_dev = self._dev[0].data_ptr()
             p.tab_dev = self._dev[1].data_ptr()
+            if self._dev[1].is_cuda:
+                if self._aux is None:                    # constants derived from tab, computed once per upload
+                    from ._lib import check, load
+                    lib = load()
+                    n = int(lib.gjx_program_aux_floats(C.byref(p)))
+                    self._aux = torch.empty(max(n, 1), dtype=torch.float32, device=device) if n >= 0 else False
+                    if n > 0:
+                        check(lib.gjx_program_prepare(C.byref(p), C.c_void_p(self._aux.data_ptr()), n,
+                                                      C.c_void_p(torch.cuda.current_stream(self._aux.device).cuda_stream)),
+                              "gjx_program_prepare")
+                    self._aux_n = max(n, 0)
+                if self._aux is not False and self._aux_n > 0:
+                    p.aux_dev, p.n_aux = self._aux.data_ptr(), self._aux_n
         else:
             p.sites_dev = p.sites
             p.tab_dev = p.tab

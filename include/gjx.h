@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 2
+#define GJX_ABI_VERSION 3
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -125,10 +125,13 @@ typedef struct gjx_site {
 
 /* random-stream layouts.  Both are Threefry-2x32-20 counter streams and both give results that are
  * independent of how particles are sharded over GPUs (the counter carries the GLOBAL particle index).
- *   GJX_RNG_FLAT  (default, the MI355X-first layout): no per-particle or per-site key derivation.
- *       bits(particle i, site j (1-based), element c) = word (c & 1) of
- *       Threefry(key, (i, (j << 22) | (c >> 1)))              [i < 2^32, j < 1024, c < 2^23]
- *       -> 1 hash per TWO 32-bit draws, key schedule wave-uniform (SGPRs).
+ *   GJX_RNG_FLAT  (default, the MI355X-first layout): no per-particle or per-site key derivation, and no
+ *       random bit is thrown away.  The stream of (particle i, site j (1-based)) is the concatenation of the
+ *       64-bit blocks Threefry(key, (i, (j << 22) | h)), h = 0, 1, ... read as 32-bit words (x0 first); every
+ *       draw consumes 23 bits (a float32 mantissa): element c is the 32-bit window starting at stream bit
+ *       23*c, of which the consumers use the top 23 bits, i.e. stream bits [23c + 9, 23c + 32).
+ *                                                              [i < 2^32, j < 1024, h < 2^22]
+ *       -> 1 hash per 2.78 draws (16 normals = 6 hashes), key schedule wave-uniform.
  *   GJX_RNG_JAX32 (the reference's layout, jax 0.5.2 with jax_threefry_partitionable=True):
  *       particle key = Threefry(key, (0, i))   (jax.random.split(key, K)[i], smc.py:300)
  *       site key     = Threefry(particle key, (0, j))          (fold_in(key, counter), static.py:349-352)
@@ -147,6 +150,9 @@ typedef struct gjx_program {
   const gjx_site* sites_dev;/* DEVICE copy of the same bytes */
   const float* tab;         /* HOST copy of the float table (constants, args, observations) */
   const float* tab_dev;     /* DEVICE copy of the same floats */
+  const float* aux_dev;     /* DEVICE: constants derived from tab by gjx_program_prepare (or NULL) */
+  int32_t n_aux;            /* floats in aux_dev */
+  int32_t pad_;
 } gjx_program;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -154,6 +160,14 @@ int gjx_version(void);
 const char* gjx_last_error(void);
 /* which engine a program will run on: 0 = generic site interpreter, >0 = id of a fused kernel */
 int gjx_program_engine(const gjx_program* prog);
+/* Constants a fused kernel would otherwise recompute in every block (log-softmax of constant logits, running CDF,
+ * sums of log sigma, reciprocal scales, ...) are computed ONCE per program: the reference gets the same effect from
+ * XLA's constant folding of the traced model body (core/compiler/staging.py:286-298).  gjx_program_aux_floats
+ * returns how many floats the program's engine wants (0: none); gjx_program_prepare fills a caller-owned device
+ * buffer of that size from tab_dev (call it again after changing tab_dev); the program then carries the buffer in
+ * aux_dev / n_aux.  A program without aux_dev still runs (generic interpreter). */
+int gjx_program_aux_floats(const gjx_program* prog);
+int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int32_t n_aux, void* stream);
 
 /* ---- counter-based RNG (jax.random.{split,fold_in,bits}; call sites smc.py:299-300,
  *      static.py:349-352, scan.py:213,268) ------------------------------------------------ */

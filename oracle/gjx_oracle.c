@@ -105,15 +105,27 @@ static inline ostream stream_from_site_key(okey sk) { /* JAX32 stream with an ex
   s.mode = GJX_RNG_JAX32; s.key = sk; s.c0 = 0; s.site = 0; s.sk = sk;
   return s;
 }
-/* 32 random bits for element c of the stream */
+/* 32 random bits for element c of the stream (every consumer uses the TOP 23 of them: bits >> 9).
+ *   JAX32: x0 ^ x1 of Threefry(site key, (0, c))   (_threefry_random_bits_partitionable).
+ *   FLAT : the site's stream is the concatenation of the 64-bit blocks Threefry(key, (i, (site << 22) | h)),
+ *          h = 0, 1, ..., read as 32-bit words (word 2h = x0, word 2h+1 = x1, little end first).  Element c is the
+ *          32-bit window that starts at stream bit 23*c, so its top 23 bits are stream bits [23c + 9, 23c + 32):
+ *          consecutive elements use consecutive, disjoint 23-bit fields — 64 / 23 = 2.78 draws per hash. */
+static inline uint32_t flat_word(const ostream* s, uint32_t n) {
+  uint32_t o[2];
+  gjxo_threefry2x32(s->key.a, s->key.b, s->c0, (s->site << GJX_FLAT_SITE_SHIFT) | (n >> 1), o);
+  return o[n & 1];
+}
 static inline uint32_t elem_bits(const ostream* s, uint32_t c) {
   uint32_t o[2];
-  if (s->mode == GJX_RNG_JAX32) { /* _threefry_random_bits_partitionable: bits1 ^ bits2 */
+  if (s->mode == GJX_RNG_JAX32) {
     gjxo_threefry2x32(s->sk.a, s->sk.b, 0u, c, o);
     return o[0] ^ o[1];
   }
-  gjxo_threefry2x32(s->key.a, s->key.b, s->c0, (s->site << GJX_FLAT_SITE_SHIFT) | (c >> 1), o);
-  return o[c & 1];
+  const uint32_t bit = 23u * c, n = bit >> 5, sh = bit & 31u;
+  const uint32_t lo = flat_word(s, n);
+  if (sh == 0) return lo;
+  return (lo >> sh) | (flat_word(s, n + 1) << (32u - sh));
 }
 
 static inline float bits_to_unit(uint32_t bits) { /* jax _uniform: [0,1) from 23 mantissa bits */
@@ -176,8 +188,8 @@ static inline float gumbel_from_bits(uint32_t bits) { /* jax.random.gumbel */
 
 /* Standard normal for element e of a stream.
  *   JAX32: sqrt(2) * erfinv(uniform(-1,1)) of the element's 32 bits (jax.random.normal).
- *   FLAT : Box-Muller on the TWO words of the element's hash: u1 = 1 - unit(word a) in (0,1],
- *          u2 = unit(word b); even elements take r*cos(2 pi u2), odd ones r*sin(2 pi u2).  An exact
+ *   FLAT : Box-Muller on the elements (e & ~1, e | 1) of the stream: u1 = 1 - unit(even element) in (0,1],
+ *          u2 = unit(odd element); even elements take r*cos(2 pi u2), odd ones r*sin(2 pi u2).  An exact
  *          sampler that needs one log, one sqrt and one sin/cos per PAIR instead of an erfinv per draw. */
 static float stream_normal(const ostream* s, uint32_t e) {
   if (s->mode == GJX_RNG_JAX32) return normal_from_bits(elem_bits(s, e));
@@ -198,8 +210,8 @@ float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
 #define GAMMA_MAXIT 32
 #define GAMMA_NDRAW (4 * GAMMA_MAXIT + 2)
 /* draw schedule of one gamma variate (element indices relative to `base`): iteration t takes its normal
- * from element 4t and its uniform from element 4t+2 (different hash pairs in the FLAT layout, where a
- * normal consumes both words of its pair); the a < 1 boost uniform is element 4*MAXIT. */
+ * from element 4t and its uniform from element 4t+2 (a FLAT normal consumes the element pair (4t, 4t+1));
+ * the a < 1 boost uniform is element 4*MAXIT. */
 static float log_gamma_variate(const ostream* sk, uint32_t base, float a) {
   float boost = 0.0f;
   float aa = a;
