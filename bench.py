@@ -177,9 +177,11 @@ def run_gmm(args, rank, world, dev):
         step(i, False)
     torch.cuda.synchronize()
     dt, lse = timed_loop(args, world, dev, step)
+    exch = dict(transport="none")
     if resampler is not None:
         lse = lse.clone()
         torch.cuda.synchronize()
+        exch = resampler.stats()
         resampler.close()            # communicator torn down on every rank while the process group is still up
     if rank != 0:
         return None
@@ -203,7 +205,7 @@ def run_gmm(args, rank, world, dev):
         config=dict(workload="gmm_c8_d16 ImportanceK: propagate+reweight+LSE, systematic resample, gather "
                              "(BASELINE.json configs[1])",
                     k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}",
-                    exchange=(resampler.transport if resampler else "none")),
+                    exchange=exch["transport"], exchange_stats=exch),
         roofline=dict(bound="hbm", kernel="gjx::k_run_gmm<FLAT,16,4,256>", achieved=achieved, peak=HBM_PEAK_GBS,
                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel_us=kern_ms * 1e3, kernel_us_event_pair_around_call=bracket_us,
@@ -238,8 +240,17 @@ def run_ssm(args, rank, world, dev):
     from genjax_amd import core, workloads
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
     s = workloads.ssm_problem()
-    K_local, T = 1 << 18, 256                # config 3; with N ranks the collection is N x 2^18 (config 4 shape, weak scaling)
-    K = K_local * world
+    T = 256
+    # N = 1: config 3 (K = 2^18).  N > 1: config 4, K = 2^22 in total however many ranks share it (strong scaling;
+    # 2^19 per GPU at N = 8); --weak keeps 2^19 per GPU instead (K = N * 2^19).
+    if args.ssm_k_total:
+        K = int(args.ssm_k_total)
+    elif world == 1:
+        K = 1 << 18
+    else:
+        K = (world << 19) if args.weak else (1 << 22)
+    K_local = K // world
+    scaling = "weak" if (args.weak or world == 1) else "strong"
     bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
     ys = torch.as_tensor(s["y"], device=dev)
     last = {}
@@ -250,12 +261,15 @@ def run_ssm(args, rank, world, dev):
 
     # see run_gmm: the HIP runtime's one-off pool-growth stalls (35-45 ms each, two or three of them over the first
     # ~10^4 launches when the queue is kept this deep) must not land between the barriers of a 60 ms timed region
-    for i in range(20):
+    for i in range(20 if world == 1 else 2):
         step(i, False)
     torch.cuda.synchronize()
     dt, lml = timed_loop(args, world, dev, step)
     lml = float(lml)
+    exch = dict(transport="none")
     if getattr(bf, "_resampler", None) is not None:
+        torch.cuda.synchronize()
+        exch = bf._resampler.stats()
         bf._resampler.close()
     if rank != 0:
         return None
@@ -264,11 +278,12 @@ def run_ssm(args, rank, world, dev):
     algo = (8 * 8 + 24) * K_local            # 8*d_x + 16..24 B per particle-step
     res = dict(
         metric="particle_steps_per_sec", value=K * T * args.steps / dt, unit="particle-steps/s", n_gpus=world,
-        steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak",
+        steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling=scaling,
         vs_baseline=None, dtype="f32", data="synthetic",
-        config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[2]); "
-                             "one bench step = one T=256 filter run", k_particles_per_gpu=K_local, k_particles_total=K, T=T,
-                    rng_stream="flat", sharding=f"particles x{world}"),
+        config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[%d]); "
+                             "one bench step = one T=256 filter run" % (2 if world == 1 else 3), k_particles_per_gpu=K_local,
+                    k_particles_total=K, T=T, rng_stream="flat", sharding=f"particles x{world}",
+                    exchange=exch["transport"], exchange_stats=exch),
         roofline=dict(bound="hbm", kernel="filter step = k_resample_fused + k_ssm_step",
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
@@ -326,6 +341,21 @@ def run_hmc(args, rank, world, dev):
     return res
 
 
+def respawn(n: int) -> None:
+    """Replace this process by `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`
+    (one rank per GPU over RCCL; rendezvous on 127.0.0.1 and a free port)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this stack
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def timed_loop(args, world, dev, step):
     def barrier():
         if dist.is_initialized():
@@ -357,6 +387,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k-per-gpu", type=int, default=K_PER_GPU)
     ap.add_argument("--leapfrog", type=int, default=1000)
+    ap.add_argument("--weak", action="store_true", help="ssm with --gpus N > 1: 2^19 particles per GPU instead of 2^22 in total")
+    ap.add_argument("--ssm-k-total", type=int, default=0, help="ssm: total number of particles (overrides the config-3/4 sizes)")
+    ap.add_argument("--no-extra", action="store_true", help="gmm on one GPU: skip the short ssm / hmc / API runs reported under extra")
     ap.add_argument("--event-samples", type=int, default=16,
                     help="number of timed steps whose propagate+reweight kernel is bracketed with HIP events "
                          "(timing events are not free on ROCm — hundreds of live ones slow every launch — so the "
@@ -366,6 +399,8 @@ def main():
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        respawn(args.gpus)                   # plain `python bench.py --gpus N`: become N ranks, one per GPU
     from genjax_amd import distributed as DD
     rank, world = DD.init_from_env()
     if world != args.gpus and world > 1:
@@ -374,6 +409,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     res = {"gmm": run_gmm, "ssm": run_ssm, "hmc": run_hmc}[args.workload](args, rank, world, dev)
+    if args.workload == "gmm" and world == 1 and res is not None and not args.no_extra:
+        # the other single-GPU rows of BASELINE.json, short runs, so that the driver's one line carries them too
+        extra = {}
+        for name, fn, st in (("ssm", run_ssm, 3), ("hmc", run_hmc, 2)):
+            a2 = argparse.Namespace(**vars(args))
+            a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, st, 1, True
+            r2 = fn(a2, rank, world, dev)
+            extra[name] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in r2}
+            for k in ("log_ml_rel_err", "accept_rate"):
+                if k in r2:
+                    extra[name][k] = r2[k]
+        res["extra"] = extra
     if rank == 0 and res is not None:
         print(json.dumps(res))
     if dist.is_initialized():

@@ -117,6 +117,8 @@ PROTOTYPES = {
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),
+    "gjx_shard_ctx_stats": (C.c_int, [vp, vp]),
+    "gjx_shard_resample_multinomial_step": (C.c_int, [vp, vp, vp, vp, i64, vp, i64, u32, u32, vp, vp, vp]),
     "gjx_shard_global_lse": (C.c_int, [vp, vp, vp, vp]),
     "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc_engine": (C.c_int, [PP]),

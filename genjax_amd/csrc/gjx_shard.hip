@@ -30,16 +30,15 @@ __global__ __launch_bounds__(64) void k_shard_plan(const uint64_t* __restrict__ 
                                                   gjx_shard_plan* plan_host) {
   __shared__ gjx_shard_plan p;
   const int t = threadIdx.x;
-  uint64_t total = 0, below = 0;
-  for (int r = 0; r < G; ++r) {
-    if (r < t) below += totals[r];
-    total += totals[r];
-  }
-  if (t <= G) {
+  uint64_t total = 0;
+  for (int r = 0; r < G; ++r) total += totals[r];
+  for (int b = t; b <= G; b += 64) {          // G + 1 bounds, G <= GJX_MAX_RANKS = 64: lane 0 also takes bound 64
+    uint64_t below = 0;
+    for (int r = 0; r < b; ++r) below += totals[r];
     const double step = (double)total / (double)N_total;
     const double inv_step = (double)N_total / (double)total;
-    p.bounds[t] = total > 0 ? slots_below(below, u, step, inv_step, total, N_total) : 0;
-    if (t == rank) p.base = below;
+    p.bounds[b] = total > 0 ? slots_below(below, u, step, inv_step, total, N_total) : 0;
+    if (b == rank) p.base = below;
   }
   __syncthreads();
   if (t == 0) {
@@ -118,6 +117,107 @@ __global__ __launch_bounds__(256) void k_gather_rows_strided(const float* __rest
   dst[r * drs + j * dcs] = src[r * srs + a * scs];
 }
 
+
+// first i in [0, K) with cum[i] > t   (requires t < cum[K-1])
+GJX_DEV int64_t upper_search_u64(const uint64_t* __restrict__ cum, int64_t K, uint64_t t) {
+  int64_t lo = 0, hi = K - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cum[mid] > t) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// ---- sharded multinomial resampling --------------------------------------------------------------------------
+// Output slot j of N_total draws its own uniform (hash of the GLOBAL slot index, as k_multinomial), so the result
+// does not depend on the number of ranks.  The slots that land on a rank's particles are scattered over [0, N_total):
+// every rank scans all N_total thresholds (one hash each), keeps those inside its stretch of the global weight line,
+// and ships each child to the rank that owns the slot — a true all-to-all (systematic resampling only talks to
+// neighbours in slot order).  Two passes over the thresholds: count per owner, then fill the messages; children are
+// tagged with their slot, so the order inside a message does not matter and the fill can use atomics.
+struct MultiArgs {
+  const uint64_t* cum;       // local inclusive prefix sums [K]
+  int64_t K;
+  const uint64_t* totals;    // [G] all-gathered local totals
+  int G, rank;
+  key2 key;
+  int64_t N_total;
+};
+
+GJX_DEV int owner_of(int64_t j, int64_t q, int64_t rem) {   // contiguous shards, remainder to the low ranks
+  const int64_t cut = rem * (q + 1);
+  return (int)(j < cut ? j / (q + 1) : rem + (j - cut) / (q > 0 ? q : 1));
+}
+GJX_DEV int64_t shard_lo(int d, int64_t q, int64_t rem) { return d * q + (d < rem ? d : rem); }
+
+GJX_DEV bool multi_threshold(const MultiArgs& a, int64_t j, uint64_t base, uint64_t local, uint64_t total, uint64_t* t_local) {
+  const key2 h = fold_in64(a.key, (uint64_t)j);
+  const uint64_t r = (((uint64_t)h.a << 32) | h.b) >> 11;
+  const double uj = (double)r * (1.0 / 9007199254740992.0);
+  const uint64_t T = (uint64_t)(uj * (double)total);
+  if (T < base || T >= base + local) return false;
+  *t_local = T - base;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_multi_count(MultiArgs a, unsigned long long* counts /*[G], zeroed*/) {
+  __shared__ unsigned cnt[GJX_MAX_RANKS];
+  for (int t = threadIdx.x; t < a.G; t += 256) cnt[t] = 0u;
+  __syncthreads();
+  uint64_t total = 0, base = 0;
+  for (int r = 0; r < a.G; ++r) { if (r < a.rank) base += a.totals[r]; total += a.totals[r]; }
+  const uint64_t local = a.totals[a.rank];
+  const int64_t q = a.N_total / a.G, rem = a.N_total % a.G;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < a.N_total; j += (int64_t)gridDim.x * 256) {
+    uint64_t tl;
+    if (total > 0 && multi_threshold(a, j, base, local, total, &tl)) atomicAdd(&cnt[owner_of(j, q, rem)], 1u);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.G; t += 256) if (cnt[t]) atomicAdd(&counts[t], (unsigned long long)cnt[t]);
+}
+
+// counts matrix [G][G] (row = source rank) -> pinned host mirror, sequence word last (as the systematic plan)
+__global__ __launch_bounds__(64) void k_multi_publish(const unsigned long long* matrix, int n, int64_t seq, unsigned long long* host) {
+  for (int t = threadIdx.x; t < n; t += 64) host[1 + t] = matrix[t];
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(&host[0], (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_multi_fill(MultiArgs a, const unsigned long long* my_counts /*[G]: row `rank` of the matrix*/,
+                                                   unsigned long long* cursor /*[G], zeroed*/, const float* __restrict__ src,
+                                                   int64_t src_stride, int rows, float* __restrict__ msg /*[n][rows+1]*/,
+                                                   float* __restrict__ dst, int64_t dst_stride) {
+  uint64_t total = 0, base = 0;
+  for (int r = 0; r < a.G; ++r) { if (r < a.rank) base += a.totals[r]; total += a.totals[r]; }
+  const uint64_t local = a.totals[a.rank];
+  const int64_t q = a.N_total / a.G, rem = a.N_total % a.G;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < a.N_total; j += (int64_t)gridDim.x * 256) {
+    uint64_t tl;
+    if (!(total > 0 && multi_threshold(a, j, base, local, total, &tl))) continue;
+    const int64_t anc = upper_search_u64(a.cum, a.K, tl);
+    const int d = owner_of(j, q, rem);
+    const int64_t slot = j - shard_lo(d, q, rem);
+    if (d == a.rank) {
+      for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + slot] = src[(int64_t)r * src_stride + anc];
+    } else {
+      uint64_t off = 0;
+      for (int e = 0; e < d; ++e) if (e != a.rank) off += my_counts[e];
+      const uint64_t pos = off + atomicAdd(&cursor[d], 1ull);
+      float* m = msg + pos * (uint64_t)(rows + 1);
+      for (int r = 0; r < rows; ++r) m[r] = src[(int64_t)r * src_stride + anc];
+      m[rows] = __uint_as_float((uint32_t)slot);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_multi_unpack(const float* __restrict__ msg, int64_t n, int rows, float* __restrict__ dst,
+                                                     int64_t dst_stride) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float* m = msg + e * (int64_t)(rows + 1);
+  const int64_t slot = (int64_t)__float_as_uint(m[rows]);
+  for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + slot] = m[r];
+}
 
 }  // namespace gjx
 
@@ -249,6 +349,11 @@ struct gjx_shard_ctx {
   float* send = nullptr;
   float* recv = nullptr;
   size_t send_cap = 0, recv_cap = 0;     // in floats
+  int64_t stat_steps = 0, stat_sent = 0, stat_received = 0;   // since creation (gjx_shard_ctx_stats)
+  unsigned long long* mcounts = nullptr;   // [G] this rank's children per owner + [G] fill cursors
+  unsigned long long* mmatrix = nullptr;   // [G][G] all-gathered counts (row = source)
+  unsigned long long* mhost = nullptr;     // pinned: {seq, matrix[G*G]}
+  unsigned long long* mhost_mapped = nullptr;
 };
 
 #define GJX_HIP(call, where)                                   \
@@ -279,10 +384,11 @@ extern "C" int gjx_shard_ctx_destroy(gjx_shard_ctx* c) {
   if (!c) return GJX_OK;
   (void)hipDeviceSynchronize();
   if (c->comm) c->api.CommDestroy(c->comm);
-  void* dev_bufs[] = {c->ws, c->cum, c->bt, c->pairs, c->totals, c->plan_dev, c->anc, c->send, c->recv};
+  void* dev_bufs[] = {c->ws, c->cum, c->bt, c->pairs, c->totals, c->plan_dev, c->anc, c->send, c->recv, c->mcounts, c->mmatrix};
   for (void* b : dev_bufs)
     if (b) (void)hipFree(b);
   if (c->plan_host) (void)hipHostFree(c->plan_host);
+  if (c->mhost) (void)hipHostFree(c->mhost);
   delete c;
   return GJX_OK;
 }
@@ -318,6 +424,21 @@ extern "C" int gjx_shard_ctx_create(const char* rccl_library_path, const uint8_t
   GJX_TRY(hipHostMalloc((void**)&c->plan_host, sizeof(gjx_shard_plan), hipHostMallocMapped), "shard ctx: pinned plan");
   memset(c->plan_host, 0, sizeof(gjx_shard_plan));
   GJX_TRY(hipHostGetDevicePointer((void**)&c->plan_host_mapped, c->plan_host, 0), "shard ctx: pinned plan");
+  GJX_TRY(hipMalloc((void**)&c->mcounts, sizeof(unsigned long long) * 2 * n_ranks), "shard ctx: multinomial counts");
+  GJX_TRY(hipMalloc((void**)&c->mmatrix, sizeof(unsigned long long) * n_ranks * n_ranks), "shard ctx: multinomial matrix");
+  GJX_TRY(hipHostMalloc((void**)&c->mhost, sizeof(unsigned long long) * (1 + n_ranks * n_ranks), hipHostMallocMapped), "shard ctx: pinned counts");
+  memset(c->mhost, 0, sizeof(unsigned long long) * (1 + n_ranks * n_ranks));
+  GJX_TRY(hipHostGetDevicePointer((void**)&c->mhost_mapped, c->mhost, 0), "shard ctx: pinned counts");
+  if (rows > 0 && n_ranks > 1) {
+    // message buffers for the worst case (every child this rank produces leaves it / every slot it owns is filled
+    // from elsewhere), capped at 1 GiB each: nothing is allocated or freed inside the resampling loop below that
+    const size_t cap = (size_t)1 << 28;
+    // (rows + 1 floats per child: the multinomial exchange tags each child with its slot)
+    size_t s_need = (size_t)(N_total - c->own_n) * (rows + 1), r_need = (size_t)c->own_n * (rows + 1);
+    s_need = s_need < cap ? s_need : cap; r_need = r_need < cap ? r_need : cap;
+    if (s_need) { GJX_TRY(hipMalloc((void**)&c->send, s_need * sizeof(float)), "shard ctx: send buffer"); c->send_cap = s_need; }
+    if (r_need) { GJX_TRY(hipMalloc((void**)&c->recv, r_need * sizeof(float)), "shard ctx: recv buffer"); c->recv_cap = r_need; }
+  }
   GJX_TRY(hipDeviceSynchronize(), "shard ctx: init");
 #undef GJX_TRY
   ncclUniqueId id;
@@ -416,6 +537,7 @@ extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, cons
   rc = gjx_shard_message_counts(p, rank, c->N_total, send_counts, recv_counts, parts);
   if (rc != GJX_OK) return rc;
   const int64_t n_pre = parts[0], n_suf = parts[1], n_lo = parts[2], n_hi = parts[3];
+  c->stat_steps += 1; c->stat_sent += n_pre + n_suf; c->stat_received += n_lo + n_hi;
   if (info_host) {
     info_host[0] = n_pre + n_suf;  // children sent
     info_host[1] = n_lo + n_hi;    // children received
@@ -455,6 +577,80 @@ extern "C" int gjx_shard_resample_step(gjx_shard_ctx* c, const float* logw, cons
       GJX_CHECK_LAUNCH("gjx_shard_resample_step(unpack)");
     }
   }
+  return GJX_OK;
+}
+
+
+extern "C" int gjx_shard_resample_multinomial_step(gjx_shard_ctx* c, const float* logw, const float* local_lse, const float* rows_in,
+                                                   int64_t in_stride, float* rows_out, int64_t out_stride, uint32_t key0, uint32_t key1,
+                                                   float* lse_out, int64_t* info_host, void* stream) {
+  if (!c || !logw || !local_lse || !lse_out || (c->rows > 0 && (!rows_in || !rows_out)))
+    return gjx_fail(GJX_EINVAL, "gjx_shard_resample_multinomial_step: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = c->world, rank = c->rank, R = c->rows;
+  GJX_NCCL(c, c->api.AllGather(local_lse, c->pairs, 2, ncclFloat, c->comm, st), "all-gather lse pairs");
+  int rc = gjx_weight_cumsum(logw, c->K, 2, c->pairs, G, c->cum, c->bt, lse_out, c->N_total, c->ws, c->ws_bytes, st);
+  if (rc != GJX_OK) return rc;
+  GJX_NCCL(c, c->api.AllGather(c->bt + 1, c->totals, 1, ncclUint64, c->comm, st), "all-gather totals");
+  GJX_HIP(hipMemsetAsync(c->mcounts, 0, sizeof(unsigned long long) * 2 * G, st), "multinomial step: counters");
+  MultiArgs a;
+  a.cum = c->cum; a.K = c->K; a.totals = c->totals; a.G = G; a.rank = rank; a.key = key2{key0, key1}; a.N_total = c->N_total;
+  const int64_t want = (c->N_total + 255) / 256;
+  const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(k_multi_count, dim3(grid), dim3(256), 0, st, a, c->mcounts);
+  GJX_CHECK_LAUNCH("gjx_shard_resample_multinomial_step(count)");
+  GJX_NCCL(c, c->api.AllGather(c->mcounts, c->mmatrix, (size_t)G, ncclUint64, c->comm, st), "all-gather counts");
+  const int64_t seq = ++c->seq;
+  hipLaunchKernelGGL(k_multi_publish, dim3(1), dim3(64), 0, st, (const unsigned long long*)c->mmatrix, G * G, seq, c->mhost_mapped);
+  GJX_CHECK_LAUNCH("gjx_shard_resample_multinomial_step(publish)");
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (__atomic_load_n(&c->mhost[0], __ATOMIC_ACQUIRE) != (unsigned long long)seq) {
+      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+        return gjx_fail(GJX_EHIP, "gjx_shard_resample_multinomial_step: the count kernels did not complete within 60 s");
+    }
+  }
+  const unsigned long long* M = c->mhost + 1;
+  int64_t n_send = 0, n_recv = 0, n_all = 0;
+  for (int s = 0; s < G; ++s)
+    for (int d = 0; d < G; ++d) n_all += (int64_t)M[s * G + d];
+  if (n_all != c->N_total) return gjx_fail(GJX_EINVAL, n_all == 0 ? "gjx_shard_resample_multinomial_step: all weights are zero"
+                                                                  : "gjx_shard_resample_multinomial_step: the ranks' counts do not add up to N_total");
+  for (int d = 0; d < G; ++d) if (d != rank) { n_send += (int64_t)M[rank * G + d]; n_recv += (int64_t)M[d * G + rank]; }
+  c->stat_steps += 1; c->stat_sent += n_send; c->stat_received += n_recv;
+  if (info_host) { info_host[0] = n_send; info_host[1] = n_recv; info_host[2] = (int64_t)M[rank * G + rank]; info_host[3] = c->N_total; }
+  if (R > 0) {
+    rc = grow(&c->send, &c->send_cap, (size_t)n_send * (R + 1), st);
+    if (rc != GJX_OK) return rc;
+    rc = grow(&c->recv, &c->recv_cap, (size_t)n_recv * (R + 1), st);
+    if (rc != GJX_OK) return rc;
+    hipLaunchKernelGGL(k_multi_fill, dim3(grid), dim3(256), 0, st, a, (const unsigned long long*)(c->mmatrix + (size_t)rank * G),
+                       c->mcounts + G, rows_in, in_stride, R, c->send, rows_out, out_stride);
+    GJX_CHECK_LAUNCH("gjx_shard_resample_multinomial_step(fill)");
+    if (G > 1) {
+      GJX_NCCL(c, c->api.GroupStart(), "group");
+      int64_t s_off = 0, r_off = 0;
+      for (int d = 0; d < G; ++d) {
+        if (d == rank) continue;
+        const int64_t ns = (int64_t)M[rank * G + d], nr = (int64_t)M[d * G + rank];
+        if (ns) { GJX_NCCL(c, c->api.Send(c->send + s_off * (R + 1), (size_t)ns * (R + 1), ncclFloat, d, c->comm, st), "send"); s_off += ns; }
+        if (nr) { GJX_NCCL(c, c->api.Recv(c->recv + r_off * (R + 1), (size_t)nr * (R + 1), ncclFloat, d, c->comm, st), "recv"); r_off += nr; }
+      }
+      GJX_NCCL(c, c->api.GroupEnd(), "group");
+      if (n_recv) {
+        hipLaunchKernelGGL(k_multi_unpack, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, st, (const float*)c->recv, n_recv, R,
+                           rows_out, out_stride);
+        GJX_CHECK_LAUNCH("gjx_shard_resample_multinomial_step(unpack)");
+      }
+    }
+  }
+  return GJX_OK;
+}
+
+extern "C" int gjx_shard_ctx_stats(const gjx_shard_ctx* c, int64_t* out4) {
+  if (!c || !out4) return gjx_fail(GJX_EINVAL, "gjx_shard_ctx_stats: bad argument");
+  out4[0] = c->stat_steps; out4[1] = c->stat_sent; out4[2] = c->stat_received; out4[3] = c->world;
   return GJX_OK;
 }
 

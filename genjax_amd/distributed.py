@@ -165,6 +165,10 @@ class HipBackend:
         from . import kernels
         return kernels.resample_systematic(cum, base_total, u, N_total, out_begin, n_out, prefill=False)
 
+    def resample_multinomial(self, cum, base_total, key, N_total):
+        from . import kernels
+        return kernels.resample_multinomial(cum, base_total, key, N_total)
+
     def gather_rows(self, src, anc):
         from . import kernels
         return kernels.gather_rows(src, anc)
@@ -263,6 +267,56 @@ def resample_exchange(rows: torch.Tensor, logw: torch.Tensor, lse_global, u: flo
     return new_rows, dict(sent=int(send.shape[0]), slot_off=own_lo, ancestors=anc, lse=rec, bounds=b)
 
 
+def resample_exchange_multinomial(rows: torch.Tensor, logw: torch.Tensor, key, N_total: int, pairs, backend=None, group=None):
+    """Multinomial resampling of a sharded collection over torch.distributed (the reference transport of
+    gjx_shard_resample_multinomial_step; gloo dry runs and CPU tests).  Slot j draws from the hash of its global index;
+    every rank finds the slots that land on its particles and an all-to-all-v carries each child to the slot's owner.
+    -> (new_rows f32[R][own_n], info)"""
+    backend = _backend(backend)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = rows.device
+    R = rows.shape[0]
+    cum, bt_local, rec = backend.weight_cumsum(logw, True, None, pairs=pairs, K_total=N_total)
+    totals = torch.empty(world, dtype=torch.int64, device=dev)
+    if world > 1 or _forced():
+        _all_gather(totals, bt_local[1:2].contiguous(), group)
+    else:
+        totals.copy_(bt_local[1:2])
+    tl = [int(t) for t in totals.tolist()]
+    if sum(tl) <= 0:
+        raise ValueError("resample_exchange_multinomial: all weights are zero")
+    bt = torch.tensor([sum(tl[:rank]), sum(tl)], dtype=torch.int64, device=dev)
+    anc = backend.resample_multinomial(cum, bt, key, N_total)            # int32[N_total], -1 where the slot is not mine
+    sel = torch.nonzero(anc >= 0).flatten()                              # slots, ascending = sorted by owner
+    lows = torch.tensor([shard(N_total, d, world)[0] for d in range(world)] + [N_total], dtype=torch.int64, device=dev)
+    owner = torch.bucketize(sel, lows[1:], right=True)
+    counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    matrix = torch.empty(world * world, dtype=torch.int64, device=dev)
+    if world > 1 or _forced():
+        _all_gather(matrix, counts, group)
+    else:
+        matrix.copy_(counts)
+    M = matrix.view(world, world).tolist()
+    own_lo, own_n = shard(N_total, rank, world)
+    new_rows = torch.empty((R, own_n), dtype=rows.dtype, device=dev)
+    picked = backend.gather_rows(rows, anc[sel].contiguous()) if sel.numel() else torch.empty((R, 0), dtype=rows.dtype, device=dev)
+    mine = owner == rank
+    new_rows[:, (sel[mine] - own_lo)] = picked[:, mine]
+    send_counts = [0 if d == rank else int(M[rank][d]) for d in range(world)]
+    recv_counts = [0 if s_ == rank else int(M[s_][rank]) for s_ in range(world)]
+    if world > 1:
+        away = ~mine
+        slot_local = (sel[away] - lows[owner[away]]).to(torch.int32)
+        send = torch.cat([picked[:, away].t().contiguous(), slot_local.view(torch.float32).unsqueeze(1)], dim=1).contiguous()
+        recv = torch.empty((sum(recv_counts), R + 1), dtype=rows.dtype, device=dev)
+        _all_to_all(recv, send, recv_counts, send_counts, group)
+        if recv.shape[0]:
+            slots = recv[:, R].contiguous().view(torch.int32).to(torch.int64)
+            new_rows[:, slots] = recv[:, :R].t()
+    return new_rows, dict(sent=sum(send_counts), received=sum(recv_counts), lse=rec, ancestors=anc)
+
+
 class ShardedResampler:
     """Systematic resampling of a collection sharded over the ranks of a group, for a fixed shape
     (K_local particles x ``rows`` SoA rows per rank, N_total output slots).
@@ -349,6 +403,21 @@ class ShardedResampler:
         new_rows, info = resample_exchange(rows, logw, None, u, self.N_total, self.backend, self.group,
                                            pairs=gather_lse_pairs(local_lse, self.group))
         return new_rows, info["lse"]
+
+    def step_multinomial(self, rows: torch.Tensor, logw: torch.Tensor, local_lse: torch.Tensor, key):
+        """multinomial resampling with the slots' uniforms from ``key`` -> (new_rows f32[rows][own_n], global LSE record)"""
+        if self.ctx is not None:
+            return self.ctx.step_multinomial(rows, logw, local_lse, key)
+        new_rows, info = resample_exchange_multinomial(rows, logw, key, self.N_total, gather_lse_pairs(local_lse, self.group),
+                                                       self.backend, self.group)
+        return new_rows, info["lse"]
+
+    def stats(self) -> dict:
+        """transport, communicator size and (RCCL transport) children sent / received by this rank since creation"""
+        d = dict(transport=self.transport, ranks=self.world)
+        if self.ctx is not None:
+            d.update(self.ctx.stats())
+        return d
 
     def close(self) -> None:
         if self.ctx is not None:

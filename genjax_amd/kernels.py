@@ -302,6 +302,25 @@ class ShardContext:
               "gjx_shard_resample_step")
         return out, lse_out
 
+    def step_multinomial(self, rows: torch.Tensor, logw: torch.Tensor, local_lse: torch.Tensor, key, out=None, lse_out=None):
+        """gjx_shard_resample_multinomial_step -> (new_rows f32[R][own_n], global LSE record f32[4])"""
+        assert rows.shape == (self.rows, self.K) and logw.numel() == self.K and rows.stride(1) == 1
+        if out is None:
+            out = torch.empty((self.rows, self.own_n), dtype=rows.dtype, device=rows.device)
+        if lse_out is None:
+            lse_out = torch.empty(4, dtype=torch.float32, device=rows.device)
+        check(load().gjx_shard_resample_multinomial_step(self._h, _ptr(logw), _ptr(local_lse), _ptr(rows), rows.stride(0), _ptr(out),
+                                                         out.stride(0), key[0], key[1], _ptr(lse_out),
+                                                         C.cast(self._info, C.c_void_p), _stream()),
+              "gjx_shard_resample_multinomial_step")
+        return out, lse_out
+
+    def stats(self) -> dict:
+        """counters since creation: resampling steps, children sent / received by this rank, communicator size"""
+        o = (C.c_int64 * 4)()
+        check(load().gjx_shard_ctx_stats(self._h, C.cast(o, C.c_void_p)), "gjx_shard_ctx_stats")
+        return dict(steps=int(o[0]), sent=int(o[1]), received=int(o[2]), rccl_ranks=int(o[3]))
+
     @property
     def last_info(self) -> dict:
         i = self._info

@@ -388,6 +388,17 @@ int gjx_ssm_filter_sharded(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32
                            float* logw, float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
 /* shape of a context {K_local, rows, N_total, n_ranks, rank}; global LSE record from this rank's local one
  * (8-byte all-gather + combine) */
+/* Multinomial resampling of the sharded collection (the all-to-all of north_star): output slot j draws its uniform
+ * from the hash of its GLOBAL index (as gjx_resample_multinomial), every rank keeps the slots whose threshold lands
+ * on its particles and ships each child, tagged with its slot, to the slot's owner.  Collectives per call: the two
+ * 8-byte all-gathers of the systematic step, an all-gather of G counts per rank, grouped send/recv between every
+ * pair of ranks with children to exchange.  Result == gjx_resample_multinomial + gjx_gather_rows on the unsharded
+ * collection, bit for bit, for any number of ranks.  info_host[4] = {sent, received, kept, N_total}. */
+int gjx_shard_resample_multinomial_step(gjx_shard_ctx* ctx, const float* logw, const float* local_lse, const float* rows_in,
+                                        int64_t in_stride, float* rows_out, int64_t out_stride, uint32_t key0, uint32_t key1,
+                                        float* lse_out, int64_t* info_host, void* stream);
+/* counters since creation: out4 = {resampling steps, children sent, children received, ranks of the communicator} */
+int gjx_shard_ctx_stats(const gjx_shard_ctx* ctx, int64_t* out4);
 int gjx_shard_ctx_shape(const gjx_shard_ctx* ctx, int64_t out5[5]);
 int gjx_shard_global_lse(gjx_shard_ctx* ctx, const float* local_lse, float* lse_out, void* stream);
 

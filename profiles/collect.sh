@@ -1,0 +1,38 @@
+#!/bin/bash
+# Profile collection on the GPU box (run through gpurun): bench JSON lines, rocprofv3 kernel stats, PMC passes.
+# usage: bash profiles/collect.sh r02 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
+TAG=${1:-r02}; shift; WL=${@:-gmm ssm hmc}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd $R
+for w in $WL; do
+  python bench.py --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
+done
+cd /tmp; export TMPDIR=/tmp
+for w in $WL; do
+  st=100; [ $w != gmm ] && st=3
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --steps $st --warmup 1 > $OUT/prof_$w.log 2>&1
+  cp $(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${w}_kernel_stats.csv
+done
+# PMC passes for the default bench (counters only: no tracing domains alongside --pmc); FETCH_SIZE and WRITE_SIZE in separate passes
+if echo $WL | grep -q gmm; then
+  CMD="python $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 --event-samples 2"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
+  python - <<PY
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+for sub in ("fetch", "write", "sq"):
+    for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % sub, recursive=True):
+        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            d[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in d.items():
+            for c, v in cs.items():
+                res[k][c] = sum(v) / len(v)
+                res[k]["launches_" + sub] = len(v)
+json.dump({k: v for k, v in res.items() if "gjx" in k}, open("$OUT/${TAG}_pmc_summary.json", "w"), indent=1)
+PY
+fi
+rm -rf $OUT/prof_*/ $OUT/pmc_*/
+ls $OUT

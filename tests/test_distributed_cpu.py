@@ -54,6 +54,11 @@ class OracleBackend:
         return torch.from_numpy(cpu.resample_systematic(cum.numpy().view(np.uint64), u, N_total, base=int(base_total[0]),
                                                         total_all=int(base_total[1]), out_begin=out_begin, n_out=n_out))
 
+    def resample_multinomial(self, cum, base_total, key, N_total):
+        from oracle import cpu
+        return torch.from_numpy(cpu.resample_multinomial(cum.numpy().view(np.uint64), key, N_total, base=int(base_total[0]),
+                                                         total_all=int(base_total[1])))
+
     def gather_rows(self, src, anc):
         from oracle import cpu
         return torch.from_numpy(cpu.gather_rows(src.numpy(), anc.numpy()))
@@ -129,3 +134,49 @@ def test_sharded_resampling_equals_single_process(K, world, heavy):
         np.testing.assert_allclose(r[1][2:], lse[2:], rtol=1e-6, atol=1e-6)
     if heavy:
         assert sum(r[3] for r in res) > 0                          # uneven weights force a real exchange
+
+
+def _multinomial_worker(rank, world, port, K, R, heavy, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from genjax_amd import distributed as D
+    from oracle import cpu
+    D.init_from_env("gloo")
+    rs = np.random.default_rng(0)
+    logw = _weights(rs, K, heavy)
+    rows = rs.standard_normal((R, K)).astype(np.float32)
+    off, k = D.shard(K, rank, world)
+    be = OracleBackend()
+    local = torch.from_numpy(cpu.logsumexp(logw[off:off + k], K))
+    new_rows, info = D.resample_exchange_multinomial(torch.from_numpy(rows[:, off:off + k].copy()), torch.from_numpy(logw[off:off + k].copy()),
+                                                     (5, 6), K, D.gather_lse_pairs(local), backend=be)
+    out_q.put((rank, new_rows.numpy(), info["sent"], info["received"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("heavy", [False, True, "first"])
+@pytest.mark.parametrize("K,world", [(1000, 2), (1001, 3)])
+def test_sharded_multinomial_equals_single_process(K, world, heavy):
+    """all-to-all multinomial resampling over gloo == the unsharded multinomial draw, bit for bit"""
+    from oracle import cpu
+    R = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 300) + [False, True, 'first'].index(heavy) * 8 + 4 * world
+    procs = [ctx.Process(target=_multinomial_worker, args=(r, world, port, K, R, heavy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.default_rng(0)
+    logw = _weights(rs, K, heavy)
+    rows = rs.standard_normal((R, K)).astype(np.float32)
+    lse = cpu.logsumexp(logw, K)
+    cum, tot = cpu.weight_cumsum(logw, True, lse)
+    want = cpu.gather_rows(rows, cpu.resample_multinomial(cum, (5, 6), K))
+    got = np.concatenate([r[1] for r in res], axis=1)
+    np.testing.assert_array_equal(got, want)
+    assert sum(r[2] for r in res) == sum(r[3] for r in res) > 0          # children crossed ranks, nothing lost

@@ -757,6 +757,14 @@ def _rccl_one_rank_body(port, q):
     want2 = kernels.gather_rows(rows, kernels.resample_indices(lw2, 0.31, K, lse=local2))
     torch.cuda.synchronize()
     assert torch.equal(got2, want2), "collapsed weights: RCCL path differs from the single-GPU path"
+    # multinomial (all-to-all) step through the same context: == unsharded multinomial draw + gather
+    got3, rec3 = res.step_multinomial(rows, lw, local, (9, 10))
+    cum3, bt3 = kernels.weight_cumsum(lw, True, local)
+    want3 = kernels.gather_rows(rows, kernels.resample_multinomial(cum3, bt3, (9, 10), K))
+    torch.cuda.synchronize()
+    assert torch.equal(got3, want3), "multinomial: RCCL path differs from the single-GPU path"
+    assert res.ctx.last_info["sent"] == 0
+    got, rec = res.step(rows, lw, local, 0.77)       # last_info below is that of a systematic step
     # the sharded bootstrap filter (per-step exchange through the same transport) against the native one-GPU loop
     from genjax_amd import core, workloads
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
