@@ -144,6 +144,16 @@ def run_gmm(args, rank, world, dev):
     timers = [kernels.DispatchTimer() for _ in range(n_samp)]
 
     sharded = world > 1 or os.environ.get("GJX_FORCE_DIST", "0") == "1"
+    # one GPU: the whole step is one launch when the grid is co-resident (K % 1024 == 0, K / 1024 blocks fit the device)
+    step_out = dict(choices=out["choices"], score=out["score"], logw=out["logw"], rows=rows, ancestors=anc, lse=lse_rec, _ws=ws)
+    fused_step = False
+    # (measured slower than the three launches on MI355X — 77-90 us vs 70 us per step, DESIGN.md §5 — so it is opt-in)
+    if not sharded and os.environ.get("GJX_FUSED_STEP", "0") == "1":
+        try:
+            kernels.importance_step(prog, (0, 1), K, 0.5, out=step_out, allow_fallback=False)
+            fused_step = True
+        except Exception:
+            fused_step = False
     resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if sharded else None
 
     def step(i, timed):
@@ -154,11 +164,18 @@ def run_gmm(args, rank, world, dev):
                 timers[j].arm()
             else:
                 ev[j][0].record()
-        kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
-                            want_lse=sharded)
-        if j is not None and j % 2 == 1:
-            ev[j][1].record()
+        if not fused_step:
+            kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
+                                want_lse=sharded)
+            if j is not None and j % 2 == 1:
+                ev[j][1].record()
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
+        if fused_step:
+            # one launch: propagate + reweight + LSE + prefix sums + systematic ancestors + gather (gjx_importance_step)
+            kernels.importance_step(prog, key, K, u, out=step_out, allow_fallback=False)
+            if j is not None and j % 2 == 1:
+                ev[j][1].record()
+            return step_out["lse"]
         if world == 1 and not sharded:
             # single GPU: the LSE reduction is finished by the prefix-sum kernels' prologue (no serial tail)
             kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
@@ -191,13 +208,18 @@ def run_gmm(args, rank, world, dev):
     bracket_us = sum(brk) / len(brk) if brk else None
     for t in timers:
         t.close()
-    achieved = ALGO_BYTES_PER_PARTICLE * K / (kern_ms * 1e-3) / 1e9
+    # algorithmic bytes per particle: propagate+reweight 4 D + 12 = 76 written; resampling 4 + 4
+    # (ancestor written, ancestor read; the log-weight is not re-read when the step is one launch); gather 8 (D + 1) = 136
+    step_bytes = ALGO_BYTES_PER_PARTICLE + 8 + 8 * (D + 1)
+    algo_bytes = (step_bytes if fused_step else ALGO_BYTES_PER_PARTICLE) * K
+    kernel_name = "gjx::k_run_gmm_flat<16,4,256,STEP>" if fused_step else "gjx::k_run_gmm_flat<16,4,256>"
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     exact = golden("gmm_c8_d16_seed0")
     lml = float(lse[3])
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_run_gmm.json")
+    tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")      # FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/README.md)
     if os.path.exists(tp):
-        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        traffic = json.load(open(tp)).get(kernel_name)
     res = dict(
         metric="particle_steps_per_sec", value=K_total * args.steps / dt, unit="particle-steps/s",
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
@@ -206,14 +228,35 @@ def run_gmm(args, rank, world, dev):
                              "(BASELINE.json configs[1])",
                     k_particles_per_gpu=K, k_particles_total=K_total, rng_stream="flat", sharding=f"particles x{world}",
                     exchange=exch["transport"], exchange_stats=exch),
-        roofline=dict(bound="hbm", kernel="gjx::k_run_gmm<FLAT,16,4,256>", achieved=achieved, peak=HBM_PEAK_GBS,
+        roofline=dict(bound="hbm", kernel=kernel_name, achieved=achieved, peak=HBM_PEAK_GBS,
                       unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                       kernel_us=kern_ms * 1e3, kernel_us_event_pair_around_call=bracket_us,
                       timing="HIP events attached to the kernel dispatch on %d steps spread over the timed region" % len(disp),
-                      algorithmic_bytes_per_launch=ALGO_BYTES_PER_PARTICLE * K,
-                      note="binding resource is integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),
+                      algorithmic_bytes_per_launch=algo_bytes,
+                      launches_per_step=1 if fused_step else 3,
+                      note=("the whole importance step is this one launch: propagate+reweight (76 B/particle), resampling (8), "
+                            "gather of 17 rows (136); " if fused_step else "") +
+                           "the propagate+reweight phase is bound by integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),
         log_ml=lml, log_ml_exact=exact, log_ml_rel_err=abs(lml - exact) / abs(exact),
     )
+    if fused_step:
+        # the propagate+reweight kernel on its own (what the step's first phase costs as a separate launch), measured
+        # with dispatch events outside the timed region, alternating with the other two kernels of the three-launch step
+        tm = [kernels.DispatchTimer() for _ in range(8)]
+        for i in range(40):
+            if i % 5 == 0:
+                tm[i // 5].arm()
+            kernels.run_program(prog, (0, 1 + i), K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False, want_lse=False)
+            kernels.resample_indices(out["logw"], 0.5, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
+            kernels.gather_rows(out["choices"], anc, rows)
+        torch.cuda.synchronize()
+        us = sum(t.elapsed_us() for t in tm) / len(tm)
+        for t in tm:
+            t.close()
+        res["roofline_propagate_kernel"] = dict(kernel="gjx::k_run_gmm_flat<16,4,256>", kernel_us=us, achieved=ALGO_BYTES_PER_PARTICLE * K / (us * 1e-6) / 1e9,
+                                                unit="GB/s", frac=ALGO_BYTES_PER_PARTICLE * K / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                algorithmic_bytes_per_launch=ALGO_BYTES_PER_PARTICLE * K,
+                                                timing="dispatch events on 8 of 40 three-launch steps run after the timed region")
     if world == 1:
         # the same propagate+reweight kernel on the reference's stream layout and samplers (GJX_RNG_JAX32:
         # key per particle, key per site, one 32-bit word per draw, erfinv normals, Gumbel-max categorical)

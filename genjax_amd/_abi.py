@@ -87,7 +87,9 @@ PROTOTYPES = {
     "gjx_threefry2x32": (C.c_int, [u32, u32, u32, u32, i64, vp, vp]),
     "gjx_run_program": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp,
                                   C.c_size_t, vp]),
+    "gjx_importance_step": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, f64, vp, vp, vp, C.c_size_t, vp]),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
+    "gjx_workspace_status": (C.c_int, [vp, C.POINTER(i32), vp]),
     "gjx_logsumexp": (C.c_int, [vp, i64, i64, vp, vp, C.c_size_t, vp]),
     "gjx_lse_combine": (C.c_int, [vp, C.c_int, i64, vp, vp]),
     "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),

@@ -18,6 +18,12 @@ int gjx_fail_hip(hipError_t e, const char* where);   // same for a HIP error
 // {max,sumexp} block partials -> out[4] = {max, sumexp, lse, lse - log(K_total)}  (gjx_run.hip)
 int gjx_launch_lse_finish(const void* partials_float2, int n, int64_t K_total, float* out, hipStream_t st);
 
+// Number of thread blocks of `kernel` (block size `threads`, `dyn_lds` bytes of dynamic LDS) that are resident on the
+// current device AT THE SAME TIME: occupancy query x CU count, cached per (kernel, device).  Kernels that synchronise
+// their blocks through memory (granule all-gathers) must not be launched with a larger grid.  GJX_CORESIDENT_BLOCKS
+// overrides the answer (tests of the fallback paths).  Returns 0 when the query fails.
+int gjx_coresident_blocks(const void* kernel, int threads, size_t dyn_lds);
+
 namespace gjx {
 // systematic ancestor expansion with the slot run {slot0, n_valid} read from a device plan (gjx_resample.hip)
 int launch_expand_planned(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,

@@ -8,6 +8,7 @@
 // binary-search probes); gather 4 B read + 4 B write per row.
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include "gjx_scan.h"
 
 namespace gjx {
 
@@ -73,53 +74,6 @@ __global__ __launch_bounds__(256) void k_pick_finish(const PickPair* partials, i
     for (int w = 1; w < 4; ++w) pick_better(bv, bi, rv[w], ri[w]);
     *out = PickPair{bv, bi};
   }
-}
-
-// ---- fixed-point weights ---------------------------------------------------------------------
-constexpr float kWeightScale = 1073741824.0f;  // 2^30
-constexpr int kScanItems = 4;                  // items per thread
-constexpr int kScanTile = 256 * kScanItems;    // items per block
-
-GJX_DEV uint64_t weight_q(const float* x, int64_t i, int is_log, float mx) {
-  float w = is_log ? fast_exp(x[i] - mx) : x[i];
-  w = w > 0.0f ? w : 0.0f;
-  return (uint64_t)(w * kWeightScale);
-}
-
-// reference maximum of the log-weights for the fixed-point conversion.
-//   mode 1: lse[0] of a finished LSE record.
-//   mode 2: `lse` points at n_partials per-block {max, sumexp} pairs left by the producing kernel
-//           (gjx_run_program with lse == NULL): every block reduces them itself (a few KB from L2) — the LSE
-//           "finish" rides in the consumer's prologue instead of being a serial tail of the producer.
-// Block-uniform result; `red` is LDS scratch of >= 8 floats; ends with a barrier.
-GJX_DEV float block_ref_max(int mode, const float* lse, int n_partials, float* red, float* sum_out) {
-  if (mode != 2) { if (sum_out) *sum_out = 0.0f; return mode == 1 ? lse[0] : 0.0f; }
-  const float2* parts = (const float2*)lse;
-  float tmax = -INFINITY, tsum = 0.0f;
-  for (int t = threadIdx.x; t < n_partials; t += 256) {
-    const float2 p = parts[t];
-    const float nm = fmaxf(tmax, p.x);
-    if (nm > -INFINITY) tsum = tsum * fast_exp(tmax - nm) + p.y * fast_exp(p.x - nm);
-    tmax = nm;
-  }
-  const float wm = wave_max(tmax);
-  const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[4 + (threadIdx.x >> 6)] = ws; }
-  __syncthreads();
-  const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  if (sum_out) {
-    float sm = 0.0f;
-    for (int w = 0; w < 4; ++w) sm += m > -INFINITY ? red[4 + w] * fast_exp(red[w] - m) : 0.0f;
-    *sum_out = sm;
-  }
-  return m;
-}
-
-GJX_DEV uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o, 64);
-  return v;
 }
 
 __global__ __launch_bounds__(256) void k_wsum_blocks(const float* x, int64_t K, int is_log, const float* lse,
@@ -281,130 +235,33 @@ __global__ __launch_bounds__(256) void k_systematic_expand(const uint64_t* __res
 
 // ------------------------------------------------------------------------------------------
 // One-launch resampling indices for a single GPU: fixed-point weights, their prefix sums and the systematic
-// ancestor expansion in ONE kernel.  Each block scans its tile in registers, publishes the tile total as one
-// tagged 8-byte agent-scope granule, and then reads EVERY block's granule (spinning until the tag of this call
-// appears) to get both its own offset and the grand total — an all-gather of ≤1024 words instead of two kernel
-// boundaries and a 16 MB round trip of the prefix-sum array.  Requires all blocks co-resident (the launcher caps
-// the grid at 1024 blocks of 256 threads, 4 per CU).
-// Tags: granule = (tag << 50) | total, tag = (epoch mod 16383) + 1 != 0; `epoch` lives in the workspace control
-// block and is bumped by block 0 once it has seen every granule (by then every block has read the old epoch),
-// so consecutive calls never mistake each other's granules and the workspace needs zeroing only once.
+// ancestor expansion in ONE kernel (gjx_scan.h: tile_scan_expand).  Each block scans its tile in registers, publishes
+// the tile total as one tagged 8-byte agent-scope granule, and then reads EVERY block's granule to get both its own
+// offset and the grand total — an all-gather of <= 1024 words instead of two kernel boundaries and a 16 MB round trip
+// of the prefix-sum array.  Requires all blocks co-resident: the launcher sizes the grid with the occupancy query.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned long long kAggMask = (1ull << 50) - 1;
-
 template <int ITEMS>
 __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict__ x, int64_t K, int mode,
                                                        const float* lse, int n_partials, float* lse_out,
                                                        float log_k_total, double u, int64_t N, int32_t* ancestors,
                                                        uint64_t* cum_out, uint64_t* base_total_out,
                                                        unsigned long long* agg, unsigned* ctrl) {
-  constexpr int kOwn = 8;
   __shared__ float fred[8];
-  __shared__ uint64_t wsum[4], red2[8];
-  __shared__ int64_t jlast[256];
-  __shared__ int n_heavy;
-  constexpr int kHeavyCap = 1024;   // particles with more than kOwn offspring, filled cooperatively; a block holds 256 * ITEMS
-  __shared__ int32_t h_i[kHeavyCap];
-  __shared__ int64_t h_lo[kHeavyCap], h_hi[kHeavyCap];
-  const unsigned epoch = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long tag = (unsigned long long)(epoch % 16383u) + 1ull;
-  if (threadIdx.x == 0) n_heavy = 0;
+  __shared__ ScanSmem sm;
+  unsigned epoch;
+  const unsigned long long tag = grid_tag(ctrl, &epoch);
   // the weights are requested before the reference maximum is reduced: their latency overlaps the reduction
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
   float xv[ITEMS];
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) xv[k] = (i0 + k < K) ? x[i0 + k] : 0.0f;
-  float sm;
-  const float mx = block_ref_max(mode, lse, n_partials, fred, &sm);
+  float sm_sum;
+  const float mx = block_ref_max(mode, lse, n_partials, fred, &sm_sum);
   if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
-    const float l = mx > -INFINITY ? mx + logf(sm) : -INFINITY;
-    lse_out[0] = mx; lse_out[1] = sm; lse_out[2] = l; lse_out[3] = l - log_k_total;
+    const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
+    lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;
   }
-  // ---- tile scan in registers ----
-  uint64_t q[ITEMS];
-  uint64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    s += (i0 + k < K) ? weight_q(&xv[k], 0, mode, mx) : 0;
-    q[k] = s;  // thread-local inclusive
-  }
-  uint64_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-    if ((threadIdx.x & 63) >= o) inc += up;
-  }
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  uint64_t off = inc - s;  // exclusive offset of this thread inside the block
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
-  const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&agg[blockIdx.x], (tag << 50) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- all-gather of the tile totals ----
-  uint64_t pre = 0, tot = 0;
-  unsigned budget = 1u << 22;   // polls this lane may spend in total (~1 s): a grid that is not co-resident must not hang
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
-    unsigned long long v = 0;
-    while (budget) {
-      v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v >> 50) == tag) break;
-      --budget;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if ((v >> 50) != tag) { __hip_atomic_store(&ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
-    const uint64_t val = v & kAggMask;
-    tot += val;
-    if (b < (int)blockIdx.x) pre += val;
-  }
-  pre = wave_sum_u64(pre);
-  tot = wave_sum_u64(tot);
-  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6] = pre; red2[4 + (threadIdx.x >> 6)] = tot; }
-  __syncthreads();
-  const uint64_t prefix = red2[0] + red2[1] + red2[2] + red2[3];
-  const uint64_t total = red2[4] + red2[5] + red2[6] + red2[7];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    __hip_atomic_store(&ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every block has read `epoch` by now
-    if (base_total_out) { base_total_out[0] = 0; base_total_out[1] = total; }
-  }
-  if (cum_out) {
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) cum_out[i0 + k] = prefix + off + q[k];
-  }
-  // ---- systematic ancestors by slot-range expansion (see k_systematic_expand) ----
-  if (!ancestors) return;
-  const double step = (double)total / (double)N;
-  const double inv_step = (double)N / (double)total;
-  const bool any = total > 0;
-  const uint64_t c_last = prefix + off + s;  // inclusive prefix of this thread's last item
-  const int64_t j_mine = any ? slots_below(c_last, u, step, inv_step, total, N) : 0;
-  jlast[threadIdx.x] = j_mine;
-  __syncthreads();
-  int64_t j_prev = threadIdx.x > 0 ? jlast[threadIdx.x - 1] : (any ? slots_below(prefix, u, step, inv_step, total, N) : 0);
-  uint64_t c_prev = prefix + off;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const int64_t i = i0 + k;
-    const uint64_t c_cur = prefix + off + q[k];
-    const int64_t j_cur = (k == ITEMS - 1) ? j_mine : ((any && c_cur > c_prev) ? slots_below(c_cur, u, step, inv_step, total, N) : j_prev);
-    if (i < K && c_cur > c_prev) {
-      const int64_t lo = j_prev, hi = j_cur > N ? N : j_cur;
-      const int h = (hi - lo > kOwn) ? atomicAdd(&n_heavy, 1) : kHeavyCap;
-      if (h < kHeavyCap) {
-        h_i[h] = (int32_t)i; h_lo[h] = lo; h_hi[h] = hi;
-      } else {   // few offspring, or the cooperative list is full (ITEMS > 4 with collapsed weights): write them here
-        for (int64_t j = lo; j < hi; ++j) ancestors[j] = (int32_t)i;
-      }
-    }
-    j_prev = j_cur;
-    c_prev = c_cur;
-  }
-  __syncthreads();
-  const int nh = n_heavy < kHeavyCap ? n_heavy : kHeavyCap;
-  for (int h = 0; h < nh; ++h) {
-    const int32_t pi = h_i[h];
-    for (int64_t j = h_lo[h] + threadIdx.x; j < h_hi[h]; j += 256) ancestors[j] = pi;
-  }
+  tile_scan_expand<ITEMS, false>(xv, mode, mx, i0, K, u, N, ancestors, cum_out, base_total_out, agg, tag, ctrl, epoch, true, sm);
 }
 
 __global__ __launch_bounds__(256) void k_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total,
@@ -513,17 +370,24 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
       !(u >= 0.0 && u < 1.0) || (!ancestors && !cum))
     return gjx_fail(GJX_EINVAL, "gjx_resample_indices: bad argument");
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_resample_indices: workspace too small");
-  // one co-resident grid of at most 1024 blocks (4 per CU: 70 / 118 registers per lane at 4 / 16 items, 23 KB of
-  // LDS); larger K (> 2^22) falls back to the three-launch path — 64 items per lane would need 312 registers, one
-  // block per CU, and a grid that cannot be co-resident deadlocks in the granule all-gather
-  int items = env_items();   // 1 particle per lane while that still fits 1024 blocks (K <= 2^18): 4x the waves to hide the
-  if (items == 0) items = (K + 255) / 256 <= 1024 ? 1 : 4;   // round trips; 4, then 16 above
-  if ((K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items = items < 4 ? 4 : 16;
-  if ((K + 256 * (int64_t)items - 1) / (256 * (int64_t)items) > 1024) items = 16;
-  const int64_t nblocks = (K + 256 * (int64_t)items - 1) / (256 * (int64_t)items);
+  // One co-resident grid: the blocks all-gather their tile totals through memory, so every block must be running.
+  // The capacity comes from the occupancy query (70 / 118 registers per lane at 4 / 16 particles per lane, 30 KB of
+  // LDS: 4 blocks per CU on a full MI355X, fewer on a partitioned device); 1 particle per lane while the grid fits
+  // (4x the waves to hide the round trips), then 4, then 16; beyond that the three-launch path runs.
+  int items = env_items();
+  int64_t nblocks = 0;
+  const int cand[3] = {1, 4, 16};
+  bool fits = false;
+  for (int c = 0; c < 3 && !fits; ++c) {
+    if (items && cand[c] != items) continue;
+    const void* fn = cand[c] == 1 ? (const void*)k_resample_fused<1> : cand[c] == 4 ? (const void*)k_resample_fused<4> : (const void*)k_resample_fused<16>;
+    const int cap = gjx_coresident_blocks(fn, 256, 0);
+    nblocks = (K + 256 * (int64_t)cand[c] - 1) / (256 * (int64_t)cand[c]);
+    if (nblocks <= cap) { items = cand[c]; fits = true; }
+  }
   hipStream_t st = (hipStream_t)stream;
-  if (nblocks > 1024 || !ancestors) {
-    if (!cum || !base_total_dev) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_indices: K too large for the fused path and no cum/base_total buffers for the fallback");
+  if (!fits || !ancestors) {
+    if (!cum || !base_total_dev) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_indices: the grid would not be co-resident on this device and there are no cum/base_total buffers for the three-launch path");
     int rc = gjx_weight_cumsum(x, K, is_log, lse, n_partials, cum, base_total_dev, lse_out, K_total, workspace, workspace_bytes, stream);
     if (rc || !ancestors) return rc;
     return gjx_resample_systematic(cum, K, base_total_dev, u, N, 0, N, ancestors, stream);

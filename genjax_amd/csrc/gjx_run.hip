@@ -14,6 +14,7 @@
 
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include "gjx_scan.h"
 
 #include <type_traits>
 
@@ -248,6 +249,13 @@ struct GmmArgs {
   float* lse;
   float log_k_total;
   const float* aux;  // prepared constants (gjx_program_prepare), FLAT kernel only
+  // one-launch importance step (STEP kernels): systematic comb offset, outputs, granule areas, control words
+  double u;
+  float* rows_out;              // [1 + D][K] resampled particles
+  int32_t* ancestors;           // [K]
+  unsigned long long* agg;      // 4 granule arrays of gridDim.x words each
+  unsigned* ctrl;
+  unsigned long long* timeline; // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block
 };
 
 template <int PPT>
@@ -266,6 +274,28 @@ struct VecStore<4> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
+
+// Write-through (sc1) 16-byte stores and L1-bypassing loads for data that other blocks of the SAME launch read or wrote
+// (MI355X guide, G16 form R1).  Raw buffer accesses: base in a resource descriptor, the row offset in an SGPR, one
+// 32-bit lane offset for all rows (the array must be smaller than 4 GiB; the launcher checks).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;   // cache-policy bits of the buffer builtins on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1
+GJX_DEV __amdgpu_buffer_rsrc_t buffer_of(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+GJX_DEV void store4_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t lane_off, uint32_t row_off, const float (&v)[4]) {
+  const u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)lane_off, (int)row_off, kAuxSc1);
+  // A buffer store of more than 8 bytes whose soffset is an SGPR reads its data late: a VALU write of the data
+  // registers needs 2 wait states behind it.  The compiler's hazard recogniser inserts them, but not across the inline
+  // asm / scheduling barrier that closes a pair iteration (seen as lanes 12-15 of every 16 storing the next
+  // iteration's values), so they are spelled out here.
+  asm volatile("s_nop 1");
+}
+GJX_DEV float load_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t lane_off, uint32_t row_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_off, (int)row_off, kAuxSc1));
+}
+GJX_DEV int32_t load_sc1(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Each lane owns PPT consecutive particles (so every SoA row is written with PPT*4-byte stores);
 // a block walks tiles of THREADS*PPT particles.  K % PPT == 0 is required by the launcher when PPT > 1.
@@ -553,10 +583,16 @@ __global__ __launch_bounds__(256) void k_gmm_prepare(GmmArgs a, int D, float* au
   }
 }
 
-template <int D, int PPT, int THREADS>
+template <int D, int PPT, int THREADS, bool STEP = false>
 __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
+  static_assert(!STEP || (PPT == 4 && THREADS == 256), "the one-launch step works on tiles of 256 x 4 particles");
   constexpr int RS = 4 * D + 4;       // LDS row stride of one component (floats)
   constexpr int NPAIR = (D + 1) / 2;
+  unsigned epoch = 0;
+  unsigned long long tag = 0;
+  if (STEP && a.timeline && threadIdx.x == 0) a.timeline[blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
+  if (STEP) tag = grid_tag(a.ctrl, &epoch);   // before anything is published: block 0 bumps it once every block is known to run
+  const __amdgpu_buffer_rsrc_t rs_ch = buffer_of(a.choices, STEP ? (uint32_t)((1 + D) * a.K * 4) : 0u);
   constexpr int NHASH = (9 + 23 * (D == 1 ? 2 : D) + 63) / 64;   // blocks of the x site's stream the draws touch
   constexpr bool UNROLLED = D <= 16;                 // larger D: rolled loop over pairs through BitStream (code size)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -599,6 +635,9 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
 
   float tmax = -INFINITY;   // running per-thread max / sum for the block's LSE partial
   float tsum = 0.0f;
+  float lw_tile[PPT];       // STEP: the tile's log-weights stay in registers for the resampling phases
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) lw_tile[p] = -INFINITY;
   const float cdf_total = s_cdf[C - 1];
   for (; tix < ntiles; tix += gridDim.x) {
     const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;
@@ -625,7 +664,7 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
 #pragma unroll
     for (int p = 0; p < PPT; ++p) { z[p] = (C - 1) - (int)neg[p]; zf[p] = (float)z[p]; }
     float* ch = a.choices;
-    VecStore<PPT>::st(ch + i0, zf);
+    if constexpr (STEP) store4_sc1(rs_ch, (uint32_t)i0 * 4u, 0u, zf); else VecStore<PPT>::st(ch + i0, zf);
     // ---- x ~ N(mu[z], sigma[z]); y | x ~ N(x, r) observed ----
     float qx[PPT], qy[PPT];
 #pragma unroll
@@ -688,8 +727,11 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
         }
       }
       float* r0 = ch + (int64_t)(1 + d0) * K + i0;
-      VecStore<PPT>::st(r0, xa);
-      if (D > 1) VecStore<PPT>::st(r0 + K, xb);
+      if constexpr (STEP) {
+        store4_sc1(rs_ch, (uint32_t)i0 * 4u, (uint32_t)(1 + d0) * (uint32_t)K * 4u, xa);
+        if (D > 1) store4_sc1(rs_ch, (uint32_t)i0 * 4u, (uint32_t)(2 + d0) * (uint32_t)K * 4u, xb);
+      }
+      else { VecStore<PPT>::st(r0, xa); if (D > 1) VecStore<PPT>::st(r0 + K, xb); }
       // keeps the work of pair k+1 out of pair k.  Without the scheduling barrier every hash of the tile moves to the
       // top (170+ VGPRs); without pinning the two accumulators here instruction selection parks the whole
       // z-score / sum-of-squares chain (it has no side effect until the tile's last store) behind the last barrier and
@@ -712,6 +754,10 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
     if (a.score) VecStore<PPT>::st(a.score + i0, sc);
     if (a.weight) VecStore<PPT>::st(a.weight + i0, wt);
     if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);
+    if (STEP) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) lw_tile[p] = lw[p];
+    }
     // online {max, sum} per thread: one rescale per tile
     float m4 = tmax;
 #pragma unroll
@@ -725,20 +771,100 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
     tmax = m4;
     if (tix + gridDim.x < ntiles) cat_bits(tix + gridDim.x);
   }
-  if (a.partials) {
-    constexpr int NW = THREADS / 64;
-    __shared__ float red[2 * NW + 2];
+  constexpr int NW = THREADS / 64;
+  __shared__ float red[2 * NW + 2];
+  float bm = -INFINITY, bsum = 0.0f;
+  if (a.partials || STEP) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float wm = wave_max(tmax);
     const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
     if (lane == 0) { red[wid] = wm; red[NW + wid] = ws; }
     __syncthreads();
-    float bm = red[0];
+    bm = red[0];
     for (int w2 = 1; w2 < NW; ++w2) bm = fmaxf(bm, red[w2]);
-    float bsum = 0.0f;
     for (int w2 = 0; w2 < NW; ++w2) bsum += bm > -INFINITY ? red[NW + w2] * fast_exp(red[w2] - bm) : 0.0f;
-    if (a.lse) lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
-    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // consumer finishes (gjx_weight_cumsum mode 2)
+  }
+  if constexpr (!STEP) {
+    if (a.partials) {
+      if (a.lse) lse_publish_and_finish<THREADS>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);
+      else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);  // consumer finishes (gjx_weight_cumsum mode 2)
+    }
+  } else {
+    // =================== one-launch importance step: resample + gather without leaving the kernel ===================
+    // Preconditions (launcher): one full tile per block (gridDim.x * 1024 == K), grid co-resident, N == K.
+    // Every rendezvous is a tagged-granule all-gather (gjx_scan.h); bulk data that crosses blocks (the particle rows
+    // written above, the ancestors) is stored write-through and read past L1 (sc1 on both sides: no fences).
+    __shared__ ScanSmem sm;
+#define GJX_STAMP(n) do { if (a.timeline && threadIdx.x == 0) a.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    GJX_STAMP(1);
+    unsigned long long* aggA0 = a.agg;
+    unsigned long long* aggA1 = aggA0 + gridDim.x;
+    unsigned long long* aggB = aggA1 + gridDim.x;
+    unsigned long long* aggC = aggB + gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * tile + (int64_t)threadIdx.x * PPT;
+    // -- A: global {max, sumexp} of the log-weights (same reduction order as block_ref_max over per-block partials)
+    if (threadIdx.x == 0) {
+      grid_publish(aggA0, tag, (unsigned long long)__float_as_uint(bm));
+      grid_publish(aggA1, tag, (unsigned long long)__float_as_uint(bsum));
+    }
+    // thread t combines blocks t, t + 256, ... in that order, then waves and block as block_ref_max does (same bits as
+    // the three-launch path, whose prefix-sum kernel reduces the per-block partials the same way)
+    float gmax = -INFINITY, gsum = 0.0f;
+    {
+      float pm[8];              // gridDim.x <= 2048 (launcher)
+      int np = 0;
+      grid_gather(aggA0, tag, a.ctrl, [&](int, unsigned long long v) { pm[np++] = __uint_as_float((uint32_t)v); });
+      np = 0;
+      grid_gather(aggA1, tag, a.ctrl, [&](int, unsigned long long v) {
+        const float px = pm[np++], py = __uint_as_float((uint32_t)v);
+        const float nm = fmaxf(gmax, px);
+        if (nm > -INFINITY) gsum = gsum * fast_exp(gmax - nm) + py * fast_exp(px - nm);
+        gmax = nm;
+      });
+    }
+    {
+      const float wm = wave_max(gmax);
+      const float ws = wave_sum(wm > -INFINITY ? gsum * fast_exp(gmax - wm) : 0.0f);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[NW + (threadIdx.x >> 6)] = ws; }
+      __syncthreads();
+      gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      gsum = 0.0f;
+      for (int w2 = 0; w2 < 4; ++w2) gsum += gmax > -INFINITY ? red[NW + w2] * fast_exp(red[w2] - gmax) : 0.0f;
+    }
+    if (a.lse && blockIdx.x == 0 && threadIdx.x == 0) {
+      const float l = gmax > -INFINITY ? gmax + logf(gsum) : -INFINITY;
+      a.lse[0] = gmax; a.lse[1] = gsum; a.lse[2] = l; a.lse[3] = l - a.log_k_total;
+    }
+    GJX_STAMP(2);
+    // -- B: fixed-point weights, tile scan, all-gather of the tile totals, ancestors of the slots this tile owns
+    tile_scan_expand<PPT, true>(lw_tile, 1, gmax, i0, K, a.u, K, a.ancestors, nullptr, nullptr, aggB, tag, a.ctrl, epoch, false, sm);
+    GJX_STAMP(3);
+    // -- C: every block's ancestors are out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) grid_publish(aggC, tag, 1ull);
+    grid_gather(aggC, tag, a.ctrl, [&](int, unsigned long long) {});
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(&a.ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has read `epoch` long ago
+    GJX_STAMP(4);
+    // -- D: slot-oriented copy of this block's 1024 output slots (coalesced 16-byte stores; monotone ancestors make
+    //       the reads of neighbouring lanes touch neighbouring particles)
+    int32_t an[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) an[p] = load_sc1(a.ancestors + i0 + p);
+    constexpr int R = 1 + D;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+      float v[PPT];
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) v[p] = load_sc1(rs_ch, (uint32_t)an[p] * 4u, (uint32_t)r * (uint32_t)K * 4u);
+      VecStore<PPT>::st(a.rows_out + (int64_t)r * K + i0, v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GJX_STAMP(5);
+#undef GJX_STAMP
   }
 }
 
@@ -1044,6 +1170,58 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   }
   GJX_CHECK_LAUNCH("gjx_run_program");
   (void)nblocks;
+  return GJX_OK;
+}
+
+// ---- one-launch importance step -------------------------------------------------------------------------------
+namespace {
+template <int D>
+const void* step_kernel() { return (const void*)k_run_gmm_flat<D, 4, 256, true>; }
+const void* step_kernel_for(int D) {
+  switch (D) {
+    case 1: return step_kernel<1>(); case 2: return step_kernel<2>(); case 4: return step_kernel<4>(); case 8: return step_kernel<8>();
+    case 16: return step_kernel<16>(); default: return nullptr;
+  }
+}
+template <int D>
+void launch_step_d(const GmmArgs& a, int grid, size_t lds, hipStream_t st) { launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, true>, a, grid, lds, st); }
+}  // namespace
+
+extern "C" int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
+                                   float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
+                                   int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!prog || !prog->sites || !prog->sites_dev || !prog->tab_dev) return gjx_fail(GJX_EINVAL, "gjx_importance_step: null program");
+  if (K <= 0 || !choices || !logw || !rows_out || !ancestors || !(u >= 0.0 && u < 1.0))
+    return gjx_fail(GJX_EINVAL, "gjx_importance_step: bad argument");
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RUN, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_importance_step: workspace too small");
+  GmmShape g;
+  const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
+  if (env_int("GJX_NO_FUSED_STEP", 0) || prog->rng_mode != GJX_RNG_FLAT || !same_hi || !gmm_usable(prog, &g) || g.D > 16 || K % 1024 != 0)
+    return gjx_fail(GJX_EUNSUPPORTED, "gjx_importance_step: no one-launch kernel for this program / size (use gjx_run_program + gjx_resample_indices + gjx_gather_rows)");
+  const int64_t nblocks = K / 1024;
+  const size_t lds = sizeof(float) * (size_t)gmm_aux_floats(g.C, g.D);
+  const int cap = gjx_coresident_blocks(step_kernel_for(g.D), 256, lds);
+  if (nblocks > cap || nblocks > 2048 || (uint64_t)(1 + g.D) * (uint64_t)K * 4ull >= (1ull << 32))
+    return gjx_fail(GJX_EUNSUPPORTED, "gjx_importance_step: the grid would not be co-resident on this device");
+  GmmArgs a = {};
+  fill_gmm_args(a, prog, g);
+  a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;
+  a.choices = choices; a.score = score; a.weight = nullptr; a.logw = logw;
+  a.logw_in = nullptr; a.sub = nullptr; a.partials = nullptr; a.ticket = nullptr; a.lse = lse;
+  a.log_k_total = (float)log((double)K);
+  a.u = u; a.rows_out = rows_out; a.ancestors = ancestors;
+  a.agg = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
+  a.ctrl = (unsigned*)workspace + 8;
+  if (const char* e = getenv("GJX_STEP_TIMELINE_PTR")) a.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+  hipStream_t st = (hipStream_t)stream;
+  switch (g.D) {
+    case 1: launch_step_d<1>(a, (int)nblocks, lds, st); break;
+    case 2: launch_step_d<2>(a, (int)nblocks, lds, st); break;
+    case 4: launch_step_d<4>(a, (int)nblocks, lds, st); break;
+    case 8: launch_step_d<8>(a, (int)nblocks, lds, st); break;
+    default: launch_step_d<16>(a, (int)nblocks, lds, st); break;
+  }
+  GJX_CHECK_LAUNCH("gjx_importance_step");
   return GJX_OK;
 }
 

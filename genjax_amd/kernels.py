@@ -32,6 +32,18 @@ def workspace(op: int, K: int, device=None) -> torch.Tensor:
     return torch.zeros(n, dtype=torch.uint8, device=_dev(device))   # control block must start zeroed (gjx.h)
 
 
+def workspace_status(ws: torch.Tensor, raise_on_error: bool = True) -> int:
+    """Read and clear the status word of a workspace (synchronises the stream).  Bit 0: a co-resident kernel ran out of
+    its poll budget (its output is undefined); bit 1: a resampling call saw a zero total weight (identity ancestors)."""
+    st = C.c_int32(0)
+    check(load().gjx_workspace_status(_ptr(ws), C.byref(st), _stream()), "gjx_workspace_status")
+    if raise_on_error and st.value:
+        what = [m for b, m in ((1, "a co-resident kernel timed out waiting for its peers (grid not co-resident?)"),
+                               (2, "all weights are zero / -inf / NaN: nothing to resample from")) if st.value & b]
+        raise GjxError("workspace status %d: %s" % (st.value, "; ".join(what)))
+    return int(st.value)
+
+
 def threefry2x32(key, n: int, ctr_lo0: int = 0, ctr_hi: int = 0, device=None) -> torch.Tensor:
     out = torch.empty((n, 2), dtype=torch.int32, device=_dev(device))
     check(load().gjx_threefry2x32(key[0], key[1], ctr_hi, ctr_lo0, n, _ptr(out), _stream()), "gjx_threefry2x32")
@@ -98,6 +110,43 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     if ss is not None:
         res["site_scores"] = ss
     return res
+
+
+def importance_step(prog: PackedProgram, key, K: int, u: float, offset: int = 0, out=None, ws=None, device=None,
+                    allow_fallback: bool = True):
+    """One importance step (propagate + reweight + LSE + systematic resample + gather).  One launch when the program has
+    a fused engine and the grid is co-resident (gjx_importance_step), otherwise the three calls it replaces.
+    -> dict(choices, score, logw, lse, rows (resampled), ancestors, fused: bool)"""
+    dev = _dev(device)
+    K = int(K)
+    f32 = torch.float32
+    out = {} if out is None else out
+    n = max(prog.n_slots, 1)
+    for name, shape, dt in (("choices", (n, K), f32), ("score", (K,), f32), ("logw", (K,), f32), ("lse", (4,), f32),
+                            ("rows", (n, K), f32), ("ancestors", (K,), torch.int32)):
+        if out.get(name) is None:
+            out[name] = torch.empty(shape, dtype=dt, device=dev)
+    if ws is None:
+        ws = out.get("_ws")
+    if ws is None:
+        ws = workspace(A.OP_RUN, K, dev)
+    out["_ws"] = ws
+    cp = prog.c_program(dev)
+    rc = load().gjx_importance_step(C.byref(cp), key[0], key[1], K, int(offset), _ptr(out["choices"]), _ptr(out["score"]),
+                                    _ptr(out["logw"]), _ptr(out["lse"]), float(u), _ptr(out["rows"]), _ptr(out["ancestors"]),
+                                    _ptr(ws), ws.numel(), _stream())
+    if rc == A.EUNSUPPORTED and allow_fallback:
+        run_program(prog, key, K, offset=offset, ws=ws, out=out, want_weight=False, want_lse=False)
+        if out.get("_ws2") is None:
+            out["_ws2"] = workspace(A.OP_RESAMPLE, K, dev)
+        resample_indices(out["logw"], u, K, partials=(ws, run_partials_count(prog, K, offset)), lse_out=out["lse"], K_total=K,
+                         anc=out["ancestors"], ws=out["_ws2"])
+        gather_rows(out["choices"], out["ancestors"], out["rows"])
+        out["fused"] = False
+        return out
+    check(rc, "gjx_importance_step")
+    out["fused"] = True
+    return out
 
 
 def logsumexp(x: torch.Tensor, K_total=None, ws=None) -> torch.Tensor:

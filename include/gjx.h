@@ -204,6 +204,24 @@ enum { GJX_OP_RUN = 1, GJX_OP_LSE = 2, GJX_OP_PICK = 3, GJX_OP_RESAMPLE = 4, GJX
  * log-sum-exp): the caller zero-fills a workspace ONCE after allocating it; every entry point leaves the
  * control block zeroed again, so a workspace can be reused by any sequence of calls on one stream. */
 size_t gjx_workspace_bytes(int op, int64_t K);
+/* status word of a workspace: 0, or GJX_STATUS_* bits left by the kernels that synchronise their blocks through
+ * memory (one-launch resampling, one-launch importance / filter steps).  Synchronises the stream; clears the word. */
+enum { GJX_STATUS_POLL_TIMEOUT = 1, GJX_STATUS_ZERO_TOTAL = 2 };
+int gjx_workspace_status(void* workspace, int32_t* status_host, void* stream);
+
+/* One SMC importance step in ONE launch on one GPU (smc.py:298-315 + 96-97 + the cookbook's resample-and-gather):
+ * propagate + reweight every particle, global log-sum-exp, fixed-point prefix sums of the weights, systematic
+ * ancestors (comb offset u) and the gather of the resampled particles — the blocks of one co-resident grid meet at
+ * three tagged-granule all-gathers instead of three kernel boundaries; log-weights never leave registers between
+ * propagate and the prefix sum, ancestors live only as scratch.  Outputs: choices f32[n_slots][K], score, logw f32[K]
+ * (the collection BEFORE resampling), lse f32[4], rows_out f32[n_slots][K] (the resampled collection), ancestors i32[K].
+ * Same bits as gjx_run_program -> gjx_resample_indices -> gjx_gather_rows.  Returns GJX_EUNSUPPORTED when the program
+ * has no fused engine, K is not a multiple of 1024, or K/1024 blocks would not be co-resident on the device: callers
+ * then use the three calls.  workspace: gjx_workspace_bytes(GJX_OP_RUN, K), zero-filled once; check
+ * gjx_workspace_status after a batch of steps. */
+int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
+                        float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
+                        int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- log-sum-exp (smc.py:97,107,464) -----------------------------------------------------
  * out[4] = {max, sum exp(x-max), logsumexp, logsumexp - log(K_total)} */
@@ -263,7 +281,9 @@ int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base
  * Results are bit-identical to gjx_weight_cumsum + gjx_resample_systematic.
  * The fused kernel's blocks exchange their totals inside the launch, so its whole grid (<= 1024 blocks) must be
  * resident: do not run two of these launches concurrently on one device (two streams).  A block that cannot collect
- * the totals within its poll budget (~1 s) sets workspace word 10 to 1 and the output of that call is undefined. */
+ * the totals within its poll budget (~1 s) sets bit 0 of workspace word 10 and the output of that call is undefined;
+ * a zero grand total (every weight -inf, NaN or 0) sets bit 1 and yields the identity ancestors (in bounds for any
+ * later gather).  Read and clear the word with gjx_workspace_status after a batch of calls. */
 int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
                          int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev, float* lse_out,
                          int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
