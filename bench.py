@@ -384,6 +384,61 @@ def run_hmc(args, rank, world, dev):
     return res
 
 
+def run_codegen(dev):
+    """Kernels generated from the site list (hipRTC, csrc/gjx_codegen.hip) at K = 2^20: the mixture program through its
+    generated kernel next to the hand-fused one, and two programs that have no hand-written kernel.  Kernel time from
+    HIP events attached to the dispatch; `frac` = algorithmic bytes (4 B per stored scalar + score + log-weight) / time
+    against 8 TB/s; `bound` says what actually limits each."""
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels, workloads
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    K = 1 << 20
+
+    def timed(prog, engine):
+        old = os.environ.get("GJX_ENGINE")
+        os.environ["GJX_ENGINE"] = engine
+        try:
+            eng = kernels.program_engine(prog)
+            ws = kernels.workspace(A.OP_RUN, K, dev)
+            out = kernels.run_program(prog, (0, 1), K, ws=ws, want_weight=False)
+            tm = [kernels.DispatchTimer() for _ in range(5)]
+            for i, t in enumerate(tm):
+                if eng != 0:
+                    t.arm()
+                kernels.run_program(prog, (0, 2 + i), K, ws=ws, out=out, want_weight=False)
+            torch.cuda.synchronize()
+            us = sorted(t.elapsed_us() for t in tm)[2] if eng != 0 else None
+            for t in tm:
+                t.close()
+        finally:
+            if old is None:
+                del os.environ["GJX_ENGINE"]
+            else:
+                os.environ["GJX_ENGINE"] = old
+        b = (4 * prog.n_slots + 8) * K
+        return dict(engine=eng, kernel_us=us, algorithmic_bytes=b, frac=(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us else None,
+                    log_ml=float(out["lse"][3]))
+
+    res = {}
+    gmm, _ = workloads.gmm_program(D=D, C=C)
+    res["gmm_hand_fused"] = timed(gmm, "auto")
+    res["gmm_generated"] = timed(gmm, "gen")
+    res["gmm_generated"]["vs_hand_fused"] = res["gmm_generated"]["kernel_us"] / res["gmm_hand_fused"]["kernel_us"]
+    sl = SiteList()
+    sl.add("p", A.BETA, [np.float32(2.0), np.float32(2.0)])
+    sl.add("v", A.FLIP, [Param.value("p", 1)])
+    bb = PackedProgram(sl, {"v": A.MODE_OBS_TAB}, {"v": np.float32(1.0)})
+    res["beta_bernoulli"] = dict(timed(bb, "auto"), log_ml_exact=math.log(0.5),
+                                 bound="VALU: two Marsaglia-Tsang log-gamma variates per particle for 12 B of output")
+    lr, _ = workloads.logreg_importance_program(N=1024, P=16)
+    r = timed(lr, "auto")
+    r["flops"] = K * (2 * 1024 * 16 + 10 * 1024)
+    r["tflops"] = r["flops"] / (r["kernel_us"] * 1e-6) / 1e12 if r["kernel_us"] else None
+    r["bound"] = "fp32 VALU: 16 K FMA + 1 K softplus per particle for 76 B of output (the X beta contraction, not HBM)"
+    res["hier_logreg_prior_likelihood"] = r
+    return res
+
+
 def respawn(n: int) -> None:
     """Replace this process by `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`
     (one rank per GPU over RCCL; rendezvous on 127.0.0.1 and a free port)."""
@@ -463,6 +518,7 @@ def main():
             for k in ("log_ml_rel_err", "accept_rate"):
                 if k in r2:
                     extra[name][k] = r2[k]
+        extra["codegen"] = run_codegen(dev)
         res["extra"] = extra
     if rank == 0 and res is not None:
         print(json.dumps(res))

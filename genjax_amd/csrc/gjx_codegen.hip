@@ -1,0 +1,583 @@
+// gjx_codegen.hip — per-program fused propagate+reweight kernels.
+//
+// The reference stages ANY @gen body into a Jaxpr and lets XLA fuse it (generative_functions/static.py:383-399,
+// core/compiler/staging.py:286-298).  The counterpart here: the site list of a gjx_program is turned into the HIP
+// source of ONE straight-line kernel — every site's kind, mode, event size, parameter forms, table offsets and slot
+// numbers are literals, every element loop is unrolled, particle values live in registers, tables in LDS, and whatever
+// depends on the float table only (log-softmax / running CDF of constant logits, log and reciprocal of constant
+// scales) is computed once per block in the prologue instead of once per particle — compiled with hipRTC for gfx950
+// and cached per structure (in memory, and as a code object next to this library so that a build step can pre-populate
+// the cache; the table VALUES are run-time data, so new observations do not recompile).  The site interpreter
+// (k_run_generic) stays as the fallback for what the emitter does not cover (dirichlet sites, vector values wider than
+// 32 that later sites read, non-table categorical logits).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <hip/hiprtc.h>
+#include <unistd.h>
+#include <stdarg.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gjx_device.h"
+#include "gjx_host.h"
+
+namespace {
+
+const char* kDeviceHeader =
+#include "build/gjx_device_h.inc"
+    ;
+const char* kApiHeader =
+#include "build/gjx_h.inc"
+    ;
+
+// ---------------------------------------------------------------------------------------------------------
+// emitter
+// ---------------------------------------------------------------------------------------------------------
+struct Emit {
+  std::string s;
+  void f(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    s += buf;
+  }
+};
+
+struct Companion {   // derived constants in LDS behind the table
+  int kind;          // 0: log of tab[off .. off+n)   1: reciprocal   2: categorical {cdf[n], lse}
+  int off, n, at;    // table range; offset of the result in comp[]
+};
+
+struct Plan {
+  const gjx_program* prog;
+  int ppt;
+  bool tab_lds;
+  std::vector<Companion> comps;
+  int comp_floats = 0;
+  int find(int kind, int off, int n) {
+    for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n) return c.at;
+    Companion c{kind, off, n, comp_floats};
+    comp_floats += kind == 2 ? n + 1 : n;
+    comps.push_back(c);
+    return c.at;
+  }
+};
+
+constexpr int kMaxExpandDim = 32;
+constexpr int kMaxLdsTab = 12288;   // floats of the table copied to LDS (48 KB)
+
+bool is_normal(int k) { return k == GJX_NORMAL || k == GJX_MVNORMAL_DIAG; }
+bool is_categorical(int k) { return k == GJX_CATEGORICAL_LOGITS || k == GJX_CATEGORICAL_PROBS; }
+bool table_param(const gjx_param& p) { return (p.op == GJX_P_CONST || p.op == GJX_P_GATHER) && p.xf == GJX_XF_NONE; }
+int table_range(const gjx_param& p) { return p.op == GJX_P_CONST ? p.len : p.n * p.len; }
+
+int n_params(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : (is_categorical(kind) ? 1 : 2)); }
+
+// what the emitter covers; everything else runs on the interpreter
+bool supported(const gjx_program* p) {
+  if (p->n_sites < 1 || p->n_sites > 48 || p->n_slots > 160) return false;
+  int total = 0;
+  for (int j = 0; j < p->n_sites; ++j) {
+    const gjx_site& s = p->sites[j];
+    if (s.kind == GJX_DIRICHLET || s.kind < 1 || s.kind > GJX_CHI2) return false;
+    if (is_categorical(s.kind)) {
+      if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
+      if (s.ncat < 1 || s.ncat > 64) return false;
+      total += s.ncat;
+      continue;
+    }
+    if (s.dim < 1) return false;
+    if (s.dim > kMaxExpandDim && s.mode != GJX_MODE_OBS_TAB) return false;
+    for (int k = 0; k < n_params(s.kind); ++k) {
+      const gjx_param& q = s.p[k];
+      if (q.op < GJX_P_CONST || q.op > GJX_P_AFFINE) return false;
+      if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
+      if (s.dim > kMaxExpandDim && q.op == GJX_P_VALUE && q.len != 1) return false;
+    }
+    total += s.dim > kMaxExpandDim ? 8 : s.dim;
+  }
+  return total <= 320;
+}
+
+// index into the float table of parameter q at element `d` (a C expression; `dx` is the element index expression)
+std::string tab_index(const gjx_param& q, const std::string& dx, int site, int k) {
+  char b[256];
+  const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
+  if (q.op == GJX_P_CONST) snprintf(b, sizeof(b), "%d + %s", q.off, e.c_str());
+  else snprintf(b, sizeof(b), "%d + gi_%d_%d[p] * %d + %s", q.off, site, k, q.len, e.c_str());
+  return b;
+}
+
+// value of parameter q at element dx for particle p (before the transform)
+std::string param_expr(const gjx_param& q, const std::string& dx, int site, int k) {
+  char b[512];
+  switch (q.op) {
+    case GJX_P_CONST:
+    case GJX_P_GATHER: return "TAB(" + tab_index(q, dx, site, k) + ")";
+    case GJX_P_VALUE:
+      if (q.len == 1) snprintf(b, sizeof(b), "v[%d][p]", q.slot);
+      else snprintf(b, sizeof(b), "v[%d + (%s) %% %d][p]", q.slot, dx.c_str(), q.len);
+      return b;
+    default: snprintf(b, sizeof(b), "aff_%d_%d", site, k); return b;   // computed into a local just before use
+  }
+}
+std::string xf_wrap(int xf, const std::string& e) {
+  switch (xf) {
+    case GJX_XF_EXP: return "fast_exp(" + e + ")";
+    case GJX_XF_SOFTPLUS: return "softplus(" + e + ")";
+    case GJX_XF_SIGMOID: return "sigmoid(" + e + ")";
+    default: return e;
+  }
+}
+
+// statements that must precede the use of param_expr for element dx (affine accumulations)
+void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind) {
+  if (q.op != GJX_P_AFFINE) return;
+  const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
+  o.f("%sfloat aff_%d_%d = TAB(%d + %s);\n", ind, site, k, q.off, e.c_str());
+  o.f("%s{ const int r_ = %d + (%s) * %d;\n", ind, q.moff, dx.c_str(), q.n);
+  o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) aff_%d_%d = fmaf(TAB(r_ + e_), v[%d + e_][p], aff_%d_%d); }\n", ind, q.n, site,
+      k, q.slot, site, k);
+}
+
+void emit_gather_index(Emit& o, const gjx_site& s, int site, int np) {
+  for (int k = 0; k < np; ++k) {
+    const gjx_param& q = s.p[k];
+    if (q.op != GJX_P_GATHER) continue;
+    o.f("      int gi_%d_%d[PPT];\n", site, k);
+    o.f("      PLOOP { int g_ = (int)v[%d][p]; gi_%d_%d[p] = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", q.slot, site, k, q.n - 1, q.n - 1);
+  }
+}
+
+void emit_site(Emit& o, Plan& pl, int j) {
+  const gjx_program* prog = pl.prog;
+  const gjx_site& s = prog->sites[j];
+  const int mode = s.mode, kind = s.kind;
+  const bool masked = mode == GJX_MODE_OBS_MASK;
+  const bool draws = mode == GJX_MODE_SAMPLE || masked;
+  const int np = n_params(kind);
+  o.f("    { // ---- site %d: kind %d, dim %d, mode %d, slot %d\n", j, kind, is_categorical(kind) ? s.ncat : s.dim, mode, s.slot);
+  o.f("      float lp[PPT];\n      PLOOP lp[p] = 0.0f;\n");
+  if (draws) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", j + 1);
+  if (masked) o.f("      bool given[PPT];\n      PLOOP given[p] = v[%d][p] != 0.0f;\n", s.obs_off);
+  emit_gather_index(o, s, j, np);
+  if (is_categorical(kind)) {
+    const gjx_param& q = s.p[0];
+    const int n = s.ncat;
+    const bool probs = kind == GJX_CATEGORICAL_PROBS;
+    const bool fast = q.op == GJX_P_CONST && q.xf == GJX_XF_NONE && !probs && q.len == n;
+    // L(c): logit of category c for particle p
+    std::string L = xf_wrap(q.xf, param_expr(q, "c_", j, 0));
+    if (probs) L = "safe_log(" + L + ")";
+    if (fast) {
+      const int at = pl.find(2, q.off, n);
+      o.f("      PLOOP {\n        float val;\n");
+      if (draws) {
+        o.f("        if (RNG == GJX_RNG_FLAT) {\n");
+        o.f("          const float target = bits_to_unit(bs[p].get(0u)) * COMP(%d);\n          unsigned neg = 0u;\n", at + n - 1);
+        o.f("          _Pragma(\"unroll\") for (int c_ = 0; c_ < %d; ++c_) neg += __float_as_uint(target - COMP(%d + c_)) >> 31;\n", n - 1, at);
+        o.f("          val = (float)(%d - (int)neg);\n        } else {\n", n - 1);
+        o.f("          int best = 0; float bestv = -INFINITY;\n");
+        o.f("          for (int c_ = 0; c_ < %d; ++c_) { const float g_ = %s + gumbel_from_bits(bs[p].get((uint32_t)c_)); if (g_ > bestv) { bestv = g_; best = c_; } }\n", n, L.c_str());
+        o.f("          val = (float)best;\n        }\n");
+      }
+      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%d);\n", s.obs_off);
+      if (mode == GJX_MODE_OBS_SLOT) o.f("        val = v[%d][p];\n", s.slot);
+      if (masked) o.f("        if (given[p]) val = v[%d][p];\n", s.slot);
+      o.f("        const int k_ = (int)val;\n");
+      o.f("        lp[p] = (k_ < 0 || k_ >= %d) ? -INFINITY : TAB(%d + k_) - COMP(%d);\n", n, q.off, at + n);
+      if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) o.f("        v[%d][p] = val;\n", s.slot);
+      o.f("      }\n");
+    } else {
+      o.f("      PLOOP {\n        float mx = -INFINITY;\n");
+      o.f("        for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, %s);\n", n, L.c_str());
+      o.f("        float se = 0.0f;\n        for (int c_ = 0; c_ < %d; ++c_) se += fast_exp(%s - mx);\n", n, L.c_str());
+      o.f("        const float lse_ = mx + fast_log(se);\n        float val;\n");
+      if (draws) {
+        o.f("        if (RNG == GJX_RNG_FLAT) {\n          const float target = bits_to_unit(bs[p].get(0u)) * se; float run = 0.0f; int zc = %d; bool found = false;\n", n - 1);
+        o.f("          for (int c_ = 0; c_ < %d; ++c_) { run += fast_exp(%s - mx); if (!found && run > target) { zc = c_; found = true; } }\n", n, L.c_str());
+        o.f("          val = (float)zc;\n        } else {\n          int best = 0; float bestv = -INFINITY;\n");
+        o.f("          for (int c_ = 0; c_ < %d; ++c_) { const float g_ = %s + gumbel_from_bits(bs[p].get((uint32_t)c_)); if (g_ > bestv) { bestv = g_; best = c_; } }\n", n, L.c_str());
+        o.f("          val = (float)best;\n        }\n");
+      }
+      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%d);\n", s.obs_off);
+      if (mode == GJX_MODE_OBS_SLOT) o.f("        val = v[%d][p];\n", s.slot);
+      if (masked) o.f("        if (given[p]) val = v[%d][p];\n", s.slot);
+      o.f("        const int k_ = (int)val;\n");
+      o.f("        if (k_ < 0 || k_ >= %d) lp[p] = -INFINITY; else { const int c_ = k_; lp[p] = %s - lse_; }\n", n, L.c_str());
+      if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) o.f("        v[%d][p] = val;\n", s.slot);
+      o.f("      }\n");
+    }
+  } else {
+    const int dim = s.dim;
+    const bool expand = dim <= kMaxExpandDim;
+    const int nd = kind == GJX_BETA ? 2 * gjx::kGammaNDraw
+                   : (kind == GJX_GAMMA || kind == GJX_INVERSE_GAMMA || kind == GJX_CHI2) ? gjx::kGammaNDraw
+                   : kind == GJX_STUDENT_T ? gjx::kGammaNDraw + 2
+                   : kind == GJX_POISSON ? 2 * gjx::kPoissonTries + 2 : 1;
+    // the scale of a normal that comes straight from the table has its log and reciprocal in the prologue's companions
+    const bool norm = is_normal(kind);
+    const gjx_param& qb = s.p[1];
+    const bool comp_scale = norm && table_param(qb);
+    int at_log = -1, at_rcp = -1;
+    if (comp_scale) {
+      at_log = pl.find(0, qb.off, table_range(qb));
+      if (mode != GJX_MODE_SAMPLE) at_rcp = pl.find(1, qb.off, table_range(qb));
+    }
+    auto element = [&](const std::string& dx, const char* ind) {
+      o.f("%sPLOOP {\n", ind);
+      std::string in2 = std::string(ind) + "  ";
+      std::string pe[4];
+      for (int k = 0; k < np; ++k) {
+        emit_param_pre(o, s.p[k], dx, j, k, in2.c_str());
+        pe[k] = xf_wrap(s.p[k].xf, param_expr(s.p[k], dx, j, k));
+      }
+      for (int k = np; k < 4; ++k) pe[k] = "0.0f";
+      const std::string vslot = "v[" + std::to_string(s.slot) + " + (" + dx + ")][p]";
+      o.f("%sconst float pa = %s;\n", in2.c_str(), pe[0].c_str());
+      if (norm) {
+        std::string logb, rcpb;
+        if (comp_scale) {
+          const std::string idx = "(" + tab_index(qb, dx, j, 1) + ") - " + std::to_string(qb.off);
+          logb = "COMP(" + std::to_string(at_log) + " + " + idx + ")";
+          if (at_rcp >= 0) rcpb = "COMP(" + std::to_string(at_rcp) + " + " + idx + ")";
+        }
+        o.f("%sconst float pb = %s;\n", in2.c_str(), pe[1].c_str());
+        if (logb.empty()) logb = "fast_log(pb)";
+        if (rcpb.empty()) rcpb = "fast_rcp(pb)";
+        o.f("%sfloat val;\n", in2.c_str());
+        if (mode == GJX_MODE_SAMPLE) {
+          o.f("%sconst float n_ = stream_normal<RNG>(bs[p], (uint32_t)(%s));\n", in2.c_str(), dx.c_str());
+          o.f("%sval = fmaf(pb, n_, pa);\n%slp[p] += fmaf(-0.5f * n_, n_, -(kHalfLog2Pi + %s));\n", in2.c_str(), in2.c_str(), logb.c_str());
+        } else {
+          if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), dx.c_str());
+          else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%d + (%s));\n", in2.c_str(), s.obs_off, dx.c_str());
+          else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
+          o.f("%s{ const float z_ = (val - pa) * %s; lp[p] += fmaf(-0.5f * z_, z_, -(kHalfLog2Pi + %s)); }\n", in2.c_str(), rcpb.c_str(), logb.c_str());
+        }
+      } else {
+        o.f("%sconst float pb = %s, pc = %s, pd = %s;\n%sfloat val;\n", in2.c_str(), pe[1].c_str(), pe[2].c_str(), pe[3].c_str(), in2.c_str());
+        const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
+        if (mode == GJX_MODE_SAMPLE) o.f("%sval = %s;\n", in2.c_str(), smp.c_str());
+        else if (masked) o.f("%s{ const float smp_ = %s; val = given[p] ? %s : smp_; }\n", in2.c_str(), smp.c_str(), vslot.c_str());
+        else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%d + (%s));\n", in2.c_str(), s.obs_off, dx.c_str());
+        else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
+        o.f("%slp[p] += elem_logpdf(%d, val, pa, pb, pc, pd);\n", in2.c_str(), kind);
+      }
+      if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) o.f("%s%s = val;\n", in2.c_str(), vslot.c_str());
+      o.f("%s}\n", ind);
+    };
+    if (expand) {
+      for (int d = 0; d < dim; ++d) {
+        element(std::to_string(d), "      ");
+        if ((d & 1) == 1 && d + 1 < dim) o.f("      PLOOP asm volatile(\"\" : \"+v\"(lp[p]));\n      __builtin_amdgcn_sched_barrier(0);\n");
+      }
+    } else {
+      o.f("      for (int d_ = 0; d_ < %d; ++d_) {\n", dim);
+      element("d_", "        ");
+      o.f("      }\n");
+    }
+  }
+  // bookkeeping: score, weight, per-site scores, store the site's rows
+  o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
+  o.f("      if (a.site_scores) { float t_[PPT]; PLOOP t_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, t_); }\n", j);
+  if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
+    const int nrow = is_categorical(kind) ? 1 : s.dim;
+    for (int d = 0; d < nrow; ++d) o.f("      VecStore<PPT>::st(a.choices + (int64_t)%d * K + i0, v[%d]);\n", s.slot + d, s.slot + d);
+  }
+  o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
+}
+
+std::string generate(const gjx_program* prog, int ppt) {
+  Plan pl;
+  pl.prog = prog;
+  pl.ppt = ppt;
+  pl.tab_lds = prog->n_tab <= kMaxLdsTab;
+  Emit body;
+  for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
+  Emit o;
+  o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
+      prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
+  o.f("#define NTAB %d\n#define NCOMP %d\n", prog->n_tab, pl.comp_floats);
+  if (pl.tab_lds) o.f("#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n");
+  else o.f("#define TAB(i) a.tab[i]\n#define COMP(i) tab_s[i]\n");
+  o.f("template <int N> struct VecStore;\n"
+      "template <> struct VecStore<1> { static GJX_DEV void st(float* q, const float (&x)[1]) { *q = x[0]; } };\n"
+      "template <> struct VecStore<2> { static GJX_DEV void st(float* q, const float (&x)[2]) { *reinterpret_cast<float2*>(q) = make_float2(x[0], x[1]); } };\n"
+      "template <> struct VecStore<4> { static GJX_DEV void st(float* q, const float (&x)[4]) { *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]); } };\n");
+  o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
+      "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n");
+  if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
+  // companions: one pass per entry, spread over the block
+  for (auto& c : pl.comps) {
+    if (c.kind == 0) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_log(TAB(%d + t));\n", c.n, c.at, c.off);
+    else if (c.kind == 1) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_rcp(TAB(%d + t));\n", c.n, c.at, c.off);
+    else {
+      o.f("  if (threadIdx.x == 0) {   // running CDF (float32, category order) and log-sum-exp of constant logits\n"
+          "    float mx = -INFINITY;\n    for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, TAB(%d + c_));\n"
+          "    float run = 0.0f;\n    for (int c_ = 0; c_ < %d; ++c_) { run += fast_exp(TAB(%d + c_) - mx); COMP(%d + c_) = run; }\n"
+          "    COMP(%d) = mx + fast_log(run);\n  }\n", c.n, c.off, c.n, c.off, c.at, c.at + c.n);
+    }
+  }
+  if (!pl.comps.empty()) o.f("  __syncthreads();\n");
+  o.f("  const int64_t K = a.K;\n  const int64_t tile = 256 * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
+      "  float tmax = -INFINITY, tsum = 0.0f;\n"
+      "  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {\n"
+      "    const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;\n    if (i0 >= K) break;   // K %% PPT == 0 (launcher)\n"
+      "    uint64_t gidx[PPT];\n    PLOOP gidx[p] = (uint64_t)(a.offset + i0 + p);\n"
+      "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n");
+  o.f("    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
+  // rows that already hold values (per-particle constraints, mask flags)
+  std::vector<char> pre(prog->n_slots > 0 ? prog->n_slots : 1, 0);
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) {
+      const int n = is_categorical(s.kind) ? 1 : s.dim;
+      for (int d = 0; d < n; ++d) pre[s.slot + d] = 1;
+      if (s.mode == GJX_MODE_OBS_MASK) pre[s.obs_off] = 1;
+    }
+  }
+  for (int r = 0; r < prog->n_slots; ++r)
+    if (pre[r]) o.f("    PLOOP v[%d][p] = a.choices[(int64_t)%d * K + i0 + p];\n", r, r);
+  o.s += body.s;
+  o.f("    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
+      "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
+      "    if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);\n"
+      "    float m4 = tmax;\n    PLOOP m4 = fmaxf(m4, lw[p]);\n"
+      "    if (m4 > -INFINITY) { float s4 = tsum * fast_exp(tmax - m4); PLOOP s4 += fast_exp(lw[p] - m4); tsum = s4; }\n    tmax = m4;\n  }\n");
+  o.f("  if (a.partials) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
+      "    const float wm = wave_max(tmax);\n    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);\n"
+      "    if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }\n    __syncthreads();\n"
+      "    float bm = red[0];\n    for (int w = 1; w < 4; ++w) bm = fmaxf(bm, red[w]);\n    float bsum = 0.0f;\n"
+      "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
+      "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
+      "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
+  // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
+  o.f("// LDS_FLOATS %d\n", (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
+  return o.s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hipRTC (resolved at run time: the library must not need it when no program is ever generated)
+// ---------------------------------------------------------------------------------------------------------
+struct Rtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) Create = nullptr;
+  decltype(&hiprtcCompileProgram) Compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) LogSize = nullptr;
+  decltype(&hiprtcGetProgramLog) Log = nullptr;
+  decltype(&hiprtcGetCodeSize) CodeSize = nullptr;
+  decltype(&hiprtcGetCode) Code = nullptr;
+  decltype(&hiprtcDestroyProgram) Destroy = nullptr;
+  bool ok = false;
+};
+
+Rtc& rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {getenv("GJX_HIPRTC"), "libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) {
+      if (!n) continue;
+      r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); ok = ok && p; return p; };
+    r.Create = (decltype(r.Create))sym("hiprtcCreateProgram");
+    r.Compile = (decltype(r.Compile))sym("hiprtcCompileProgram");
+    r.LogSize = (decltype(r.LogSize))sym("hiprtcGetProgramLogSize");
+    r.Log = (decltype(r.Log))sym("hiprtcGetProgramLog");
+    r.CodeSize = (decltype(r.CodeSize))sym("hiprtcGetCodeSize");
+    r.Code = (decltype(r.Code))sym("hiprtcGetCode");
+    r.Destroy = (decltype(r.Destroy))sym("hiprtcDestroyProgram");
+    r.ok = ok;
+  });
+  return r;
+}
+
+uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char* e = getenv("GJX_JIT_CACHE")) return e;
+  Dl_info info;
+  if (dladdr((void*)&fnv1a, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
+  }
+  return "/tmp/gjx_jit_cache";
+}
+
+struct Compiled {
+  std::vector<char> code;   // code object
+  int lds_floats = 0;
+  std::string error;        // non-empty: this structure cannot be generated / compiled
+};
+
+std::mutex g_mu;
+std::map<uint64_t, Compiled> g_compiled;                                 // by structure key
+std::map<std::pair<uint64_t, int>, std::pair<hipModule_t, hipFunction_t>> g_loaded;   // by (key, device)
+
+uint64_t structure_key(const gjx_program* p, int ppt) {
+  uint64_t h = fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites);
+  const int32_t extra[5] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt};
+  h = fnv1a(extra, sizeof(extra), h);
+  static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
+  return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
+}
+
+const Compiled& compile(const gjx_program* prog, int ppt) {
+  const uint64_t key = structure_key(prog, ppt);
+  auto it = g_compiled.find(key);
+  if (it != g_compiled.end()) return it->second;
+  Compiled& c = g_compiled[key];
+  const std::string src = generate(prog, ppt);
+  const size_t m = src.rfind("// LDS_FLOATS ");
+  c.lds_floats = atoi(src.c_str() + m + 14);
+  if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
+  char name[64];
+  snprintf(name, sizeof(name), "%016llx", (unsigned long long)key);
+  const std::string dir = cache_dir(), path = dir + "/" + name + ".hsaco";
+  if (!getenv("GJX_JIT_NO_DISK")) {
+    if (FILE* f = fopen(path.c_str(), "rb")) {
+      fseek(f, 0, SEEK_END);
+      const long n = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      c.code.resize((size_t)n);
+      const size_t got = fread(c.code.data(), 1, (size_t)n, f);
+      fclose(f);
+      if (got == (size_t)n && n > 0) return c;
+      c.code.clear();
+    }
+  }
+  if (getenv("GJX_JIT_DUMP")) {
+    if (FILE* f = fopen((std::string(getenv("GJX_JIT_DUMP")) + "/" + name + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+  }
+  Rtc& r = rtc();
+  if (!r.ok) { c.error = "hipRTC is not available (libhiprtc.so)"; return c; }
+  hiprtcProgram p;
+  const char* hn[] = {"gjx_device.h", "../../include/gjx.h"};
+  const char* hs[] = {kDeviceHeader, kApiHeader};
+  if (r.Create(&p, src.c_str(), "gjx_gen.hip", 2, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const hiprtcResult rc = r.Compile(p, 3, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    r.LogSize(p, &ls);
+    std::string log(ls, 0);
+    if (ls) r.Log(p, &log[0]);
+    c.error = "hipRTC: " + log.substr(0, 1500);
+    r.Destroy(&p);
+    return c;
+  }
+  size_t cs = 0;
+  r.CodeSize(p, &cs);
+  c.code.resize(cs);
+  r.Code(p, c.code.data());
+  r.Destroy(&p);
+  if (!getenv("GJX_JIT_NO_DISK")) {
+    mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+      fwrite(c.code.data(), 1, c.code.size(), f);
+      fclose(f);
+      rename(tmp.c_str(), path.c_str());
+    }
+  }
+  return c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// interface used by gjx_run.hip
+// ---------------------------------------------------------------------------------------------------------
+namespace gjx {
+
+int gen_pick_ppt(const gjx_program* prog, int64_t K) {
+  int ppt = prog->n_slots <= 6 ? 4 : (prog->n_slots <= 24 ? 2 : 1);
+  if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
+  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;
+  while (ppt > 1 && K % ppt != 0) ppt >>= 1;
+  return ppt;
+}
+
+// 0: a generated kernel exists (compiled now if need be); otherwise the reason is in gjx_last_error
+int gen_available(const gjx_program* prog, int ppt) {
+  if (!supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the emitter's coverage");
+  std::lock_guard<std::mutex> lock(g_mu);
+  const Compiled& c = compile(prog, ppt);
+  if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+  return GJX_OK;
+}
+
+int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  hipFunction_t fn = nullptr;
+  int lds_floats = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    const Compiled& c = compile(prog, ppt);
+    if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+    lds_floats = c.lds_floats;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
+    const auto lk = std::make_pair(structure_key(prog, ppt), dev);
+    auto it = g_loaded.find(lk);
+    if (it == g_loaded.end()) {
+      hipModule_t mod;
+      hipError_t e = hipModuleLoadData(&mod, c.code.data());
+      if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleLoadData");
+      e = hipModuleGetFunction(&fn, mod, "gjx_gen");
+      if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleGetFunction");
+      g_loaded[lk] = std::make_pair(mod, fn);
+    } else {
+      fn = it->second.second;
+    }
+  }
+  GenArgs a = args;
+  size_t sz = sizeof(a);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  hipError_t e;
+  if (ev0 && ev1) e = hipExtModuleLaunchKernel(fn, (uint32_t)grid * 256u, 1, 1, 256, 1, 1, (size_t)lds_floats * 4, st, nullptr, config, ev0, ev1, 0);
+  else e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
+  if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch");
+  return GJX_OK;
+}
+
+}  // namespace gjx
+
+// the generated source of a program (debugging, tests, docs): returns the length, copies at most cap - 1 characters
+extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  if (!supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the emitter's coverage");
+  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = gjx::gen_pick_ppt(prog, 4);
+  const std::string src = generate(prog, ppt);
+  if (out && cap > 0) {
+    const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
+    memcpy(out, src.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)src.size();
+}
+
+// compile (or load from the disk cache) the kernel of a program without launching it — build steps pre-populate the
+// cache with this on machines without a GPU (hipRTC cross-compiles)
+extern "C" int gjx_program_precompile(const gjx_program* prog, int32_t ppt) {
+  if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: null program");
+  if (ppt != 1 && ppt != 2 && ppt != 4) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2 or 4");
+  return gjx::gen_available(prog, ppt);
+}

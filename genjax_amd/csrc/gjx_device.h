@@ -8,8 +8,13 @@
 // fixed-point weights) is bit-exact.
 #pragma once
 
+#ifndef __HIPCC_RTC__   /* hipRTC (generated kernels, gjx_codegen.hip) brings its own runtime header and integer types */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
+#ifndef INFINITY
+#define INFINITY __builtin_huge_valf()
+#endif
 
 #include "../../include/gjx.h"
 
@@ -102,6 +107,33 @@ struct BitStream<GJX_RNG_JAX32> {
   GJX_DEV uint32_t get(uint32_t c) {
     const key2 h = threefry2x32(sk, 0u, c);
     return h.a ^ h.b;
+  }
+};
+
+// Run-time element indices (the site interpreter, rolled loops): the same stream with ONE inlined copy of the hash per
+// get() instead of four — with two dozen distribution kinds instantiated in one kernel the fully inlined form is
+// several hundred KB of code and thrashes the instruction cache (interpreter 147 us -> 850 us on the headline model).
+template <int RNG>
+struct BitStreamRT : BitStream<RNG> {};
+template <>
+struct BitStreamRT<GJX_RNG_FLAT> : BitStream<GJX_RNG_FLAT> {
+  GJX_DEV uint32_t get(uint32_t c) {
+    const uint32_t bit = 23u * c, n = bit >> 5, sh = bit & 31u;
+    uint32_t lo = 0u, hi = 0u;
+    const int nw = sh ? 2 : 1;
+#pragma nounroll
+    for (int k = 0; k < nw; ++k) {
+      const uint32_t m = n + (uint32_t)k, h = m >> 1;
+      const bool odd = (h & 1u) != 0u;
+      if ((odd ? h1 : h0) != h) {
+        const key2 b = threefry2x32(key, c0, site_hi | h);
+        if (odd) { blk1 = b; h1 = h; } else { blk0 = b; h0 = h; }
+      }
+      const key2 b = odd ? blk1 : blk0;
+      const uint32_t w = (m & 1u) ? b.b : b.a;
+      if (k == 0) lo = w; else hi = w;
+    }
+    return sh ? __builtin_amdgcn_alignbit(hi, lo, sh) : lo;
   }
 };
 
@@ -224,8 +256,8 @@ GJX_DEV void box_muller(uint32_t wa, uint32_t wb, float& n0, float& n1) {
 }
 
 // standard normal for element e of a stream (see stream_normal in the oracle)
-template <int RNG>
-GJX_DEV float stream_normal(BitStream<RNG>& bs, uint32_t e) {
+template <int RNG, class BS>
+GJX_DEV float stream_normal(BS& bs, uint32_t e) {
   if constexpr (RNG == GJX_RNG_JAX32) {
     return normal_from_bits(bs.get(e));
   } else {
@@ -390,8 +422,8 @@ GJX_DEV int draws_per_elem(int kind) {
 }
 
 // Marsaglia & Tsang (2000), log space, fixed draw budget (same element schedule as the oracle)
-template <int RNG>
-GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
+template <int RNG, class BS>
+GJX_DEV float log_gamma_variate(BS& bs, uint32_t base, float a) {
   float boost = 0.0f, aa = a;
   if (a < 1.0f) {
     const float u = uniform_from_bits(bs.get(base + 4 * kGammaMaxIt), kTiny, 1.0f);
@@ -418,8 +450,8 @@ GJX_DEV float log_gamma_variate(BitStream<RNG>& bs, uint32_t base, float a) {
 
 // Poisson: inversion by sequential search on one uniform for rate < 10, Hörmann's transformed rejection (PTRS,
 // 1993) with a fixed budget of tries above (same element schedule as the oracle: try t uses elements c+2+2t, +1)
-template <int RNG>
-GJX_DEV float poisson_variate(BitStream<RNG>& bs, uint32_t c, float lam) {
+template <int RNG, class BS>
+GJX_DEV float poisson_variate(BS& bs, uint32_t c, float lam) {
   if (lam < 10.0f) {
     const float u = bits_to_unit(bs.get(c));
     float p = fast_exp(-lam), cdf = p;
@@ -446,8 +478,8 @@ GJX_DEV float poisson_variate(BitStream<RNG>& bs, uint32_t c, float lam) {
   return floorf(lam);
 }
 
-template <int RNG>
-GJX_DEV float elem_sample(int kind, BitStream<RNG>& bs, uint32_t c, float a, float b, float p3 = 0.0f, float p4 = 0.0f) {
+template <int RNG, class BS>
+GJX_DEV float elem_sample(int kind, BS& bs, uint32_t c, float a, float b, float p3 = 0.0f, float p4 = 0.0f) {
   switch (kind) {
     case GJX_STUDENT_T: {  // a = df, b = loc, p3 = scale: z * sqrt(df / chi2_df), chi2_df = 2 * Gamma(df/2)
       const float z = stream_normal<RNG>(bs, c);
@@ -585,6 +617,24 @@ GJX_DEV void lse_publish_and_finish(float bm, float bsum, unsigned long long* pa
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+// ---- arguments of a generated per-program kernel (gjx_codegen.hip emits `extern "C" __global__ void gjx_gen(GenArgs)`) ----
+struct GenArgs {
+  const float* tab;
+  key2 key;
+  int64_t K, offset;
+  float* choices;
+  float* score;
+  float* weight;
+  float* logw;
+  const float* logw_in;
+  const float* sub;
+  float* site_scores;
+  unsigned long long* partials;  // per block {max, sumexp} of logw (or NULL)
+  unsigned* ticket;
+  float* lse;
+  float log_k_total;
+};
 
 // ---- systematic-resampling comb on the fixed-point weight line (shared by gjx_resample.hip / gjx_shard.hip) ----
 // comb threshold of output slot j (identical double arithmetic in the oracle)

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
     for (int j = 0; j < a.n_sites; ++j) {
       const gjx_site& s = a.sites[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
-      BitStream<RNG> bs;
+      BitStreamRT<RNG> bs;
       if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, (uint32_t)leaf));
       else bs.open(a.key, gidx, (uint32_t)leaf + 1u);
       for (int d = 0; d < s.dim; ++d, ++m) {

@@ -16,6 +16,7 @@
 #include "gjx_host.h"
 #include "gjx_scan.h"
 
+#include <string.h>
 #include <type_traits>
 
 namespace gjx {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   for (int j = 0; j < a.n_sites; ++j) {
     const gjx_site& s = a.sites[j];
     const int kind = s.kind, mode = s.mode, slot = s.slot;
-    BitStream<RNG> bs;
+    BitStreamRT<RNG> bs;
     const bool masked = mode == GJX_MODE_OBS_MASK;
     const bool draws = mode == GJX_MODE_SAMPLE || masked;           // wave-uniform
     const bool given = masked ? (val(s.obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       lp += lgammaf(sa);
     } else {
       // the element loop is instantiated per distribution kind so that the sampler / density switches fold away
-      auto elems = [&](auto kind_c) {
+      auto elems = [&](auto kind_c) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr int NP = KIND == GJX_TRUNCATED_NORMAL ? 4 : (KIND == GJX_STUDENT_T ? 3 : 2);
         const int nd = draws_per_elem(KIND);
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
 #pragma unroll
     for (int p = 0; p < PPT; ++p) { qx[p] = 0.0f; qy[p] = 0.0f; }
     uint32_t w[PPT][UNROLLED ? 2 * NHASH : 2];
-    BitStream<GJX_RNG_FLAT> bs[UNROLLED ? 1 : PPT];
+    BitStreamRT<GJX_RNG_FLAT> bs[UNROLLED ? 1 : PPT];
     if (!UNROLLED) {
 #pragma unroll
       for (int p = 0; p < PPT; ++p) { bs[p].key = fkey; bs[p].c0 = c0[p]; bs[p].site_hi = 2u << GJX_FLAT_SITE_SHIFT; bs[p].h0 = bs[p].h1 = 0xFFFFFFFFu; }
@@ -926,7 +927,7 @@ using namespace gjx;
 namespace {
 
 // engine ids reported by gjx_program_engine
-enum { ENGINE_GENERIC = 0, ENGINE_GMM = 1 };
+enum { ENGINE_GENERIC = 0, ENGINE_GMM = 1, ENGINE_GEN = 4 };   // 2, 3: the HMC engines (gjx_hmc_engine)
 
 struct GmmShape {
   int C, D, logits_off, mu_off, sig_off, r_off, r_len, y_off;
@@ -1052,12 +1053,6 @@ extern "C" int gjx_profile_next_run(void* start, void* stop) {
   return GJX_OK;
 }
 
-extern "C" int gjx_program_engine(const gjx_program* prog) {
-  if (!prog || !prog->sites) return GJX_EINVAL;
-  GmmShape g;
-  if (gmm_usable(prog, &g)) return ENGINE_GMM;
-  return ENGINE_GENERIC;
-}
 
 // ---- prepared constants -------------------------------------------------------------------------
 extern "C" int gjx_program_aux_floats(const gjx_program* prog) {
@@ -1081,26 +1076,53 @@ extern "C" int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int3
   return GJX_OK;
 }
 
-// number of thread blocks (== LSE partial pairs) gjx_run_program launches for this program and K
-static int run_grid(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores, int* ppt_out, bool* fused_out, GmmShape* g) {
+// Which engine runs a program: the hand-fused mixture kernel, the kernel generated from the site list (hipRTC), or the
+// site interpreter.  GJX_ENGINE = auto (default: mixture kernel if the program has that shape, else generated, else
+// interpreter) | gen (generated first) | interp; GJX_FORCE_GENERIC=1 is the older spelling of interp.
+struct EnginePlan {
+  int engine, ppt, grid;
+  GmmShape g;
+};
+
+static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores) {
+  EnginePlan e;
+  e.engine = ENGINE_GENERIC; e.ppt = 1; e.grid = (int)((K + 255) / 256);
+  const char* env = getenv("GJX_ENGINE");
+  const bool interp = env_int("GJX_FORCE_GENERIC", 0) || (env && !strcmp(env, "interp"));
+  if (interp) return e;
+  const bool gen_first = env && !strcmp(env, "gen");
   const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
-  const bool fused = !want_site_scores && same_hi && gmm_usable(prog, g);
-  if (fused_out) *fused_out = fused;
-  if (!fused) return (int)((K + 255) / 256);
-  int ppt = env_int("GJX_GMM_PPT", 4);
-  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
-  if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned
-  if (ppt_out) *ppt_out = ppt;
-  const int64_t tile = 256 * (int64_t)ppt;
-  const int64_t ntiles = (K + tile - 1) / tile;
-  const int maxgrid = env_int("GJX_GMM_GRID", 2048);
-  return (int)(ntiles < maxgrid ? ntiles : maxgrid);
+  auto try_gmm = [&]() {
+    if (want_site_scores || !same_hi || !gmm_usable(prog, &e.g)) return false;
+    int ppt = env_int("GJX_GMM_PPT", 4);
+    if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
+    if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned
+    const int64_t tile = 256 * (int64_t)ppt, ntiles = (K + tile - 1) / tile;
+    const int maxgrid = env_int("GJX_GMM_GRID", 2048);
+    e.engine = ENGINE_GMM; e.ppt = ppt; e.grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
+    return true;
+  };
+  auto try_gen = [&]() {
+    if (env_int("GJX_NO_CODEGEN", 0)) return false;
+    const int ppt = gen_pick_ppt(prog, K);
+    if (gen_available(prog, ppt) != GJX_OK) return false;
+    const int64_t tile = 256 * (int64_t)ppt, ntiles = (K + tile - 1) / tile;
+    e.engine = ENGINE_GEN; e.ppt = ppt; e.grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    return true;
+  };
+  if (gen_first) { if (!try_gen()) try_gmm(); }
+  else if (!try_gmm()) try_gen();
+  return e;
+}
+
+extern "C" int gjx_program_engine(const gjx_program* prog) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  return plan_engine(prog, 1024, 0, false).engine;
 }
 
 extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_offset) {
   if (!prog || !prog->sites || K <= 0) return GJX_EINVAL;
-  GmmShape g;
-  return run_grid(prog, K, particle_offset, false, nullptr, nullptr, &g);
+  return plan_engine(prog, K, particle_offset, false).grid;
 }
 
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
@@ -1129,11 +1151,19 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   }
   const float log_k_total = (float)log((double)K_total);
-  GmmShape g;
-  int ppt = 1;
-  bool fused = false;
-  const int nblocks = run_grid(prog, K, particle_offset, site_scores != nullptr, &ppt, &fused, &g);
-  if (fused) {
+  const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr);
+  const GmmShape& g = ep.g;
+  const int ppt = ep.ppt, nblocks = ep.grid;
+  if (ep.engine == ENGINE_GEN) {
+    GenArgs ga;
+    ga.tab = prog->tab_dev; ga.key = key2{key0, key1}; ga.K = K; ga.offset = particle_offset;
+    ga.choices = choices; ga.score = score; ga.weight = weight; ga.logw = logw; ga.logw_in = logw_in; ga.sub = sub;
+    ga.site_scores = site_scores; ga.partials = partials; ga.ticket = ticket; ga.lse = lse; ga.log_k_total = log_k_total;
+    hipEvent_t e0 = t_prof_start, e1 = t_prof_stop;
+    t_prof_start = t_prof_stop = nullptr;
+    return gen_launch(prog, ppt, ga, nblocks, st, e0, e1);
+  }
+  if (ep.engine == ENGINE_GMM) {
     GmmArgs a;
     fill_gmm_args(a, prog, g);
     a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset;

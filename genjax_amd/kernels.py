@@ -82,6 +82,23 @@ def program_engine(prog: PackedProgram, device=None) -> int:
     return int(load().gjx_program_engine(C.byref(cp)))
 
 
+def program_source(prog: PackedProgram, ppt: int = 0) -> str:
+    """HIP source of the kernel gjx_codegen generates for this program (raises GjxError if the emitter does not cover it)."""
+    cp = prog.c_program(None)
+    n = load().gjx_program_source(C.byref(cp), int(ppt), None, 0)
+    if n < 0:
+        check(int(n), "gjx_program_source")
+    buf = C.create_string_buffer(int(n) + 1)
+    load().gjx_program_source(C.byref(cp), int(ppt), buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def program_precompile(prog: PackedProgram, ppt: int) -> None:
+    """Compile the program's generated kernel with hipRTC (works without a GPU) into the in-memory and on-disk caches."""
+    cp = prog.c_program(None)
+    check(load().gjx_program_precompile(C.byref(cp), int(ppt)), "gjx_program_precompile")
+
+
 def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
                 want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None,
                 want_weight=True):

@@ -85,3 +85,14 @@ def logreg_program(N=1024, P=16, rng=A.RNG_FLAT, seed=0):
     sl.add("y", A.BERNOULLI_LOGITS, [Param.affine(pr["X"], "beta")], dim=N)
     modes = {"y": A.MODE_OBS_TAB, "log_tau": A.MODE_OBS_SLOT, "beta": A.MODE_OBS_SLOT}
     return PackedProgram(sl, modes, {"y": pr["y"]}, selected=("log_tau", "beta"), rng_mode=rng), pr
+
+
+def logreg_importance_program(N=1024, P=16, rng=A.RNG_FLAT, seed=0):
+    """The config-5 model as an ImportanceK target: log_tau and beta sampled from the prior, y observed (prior as
+    proposal; the likelihood X beta is a [N x P] contraction per particle)."""
+    pr = logreg_problem(N, P, seed)
+    sl = SiteList()
+    sl.add("log_tau", A.NORMAL, [0.0, 1.0])
+    sl.add("beta", A.NORMAL, [Param.const(0.0), Param.value("log_tau", xf=A.XF_EXP)], dim=P)
+    sl.add("y", A.BERNOULLI_LOGITS, [Param.affine(pr["X"], "beta")], dim=N)
+    return PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": pr["y"]}, rng_mode=rng), pr

@@ -21,8 +21,17 @@
 #ifndef GJX_H
 #define GJX_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else   /* hipRTC has no libc headers: its runtime header keeps the fixed-width types in a namespace */
+typedef __hip_internal::int32_t int32_t;
+typedef __hip_internal::uint32_t uint32_t;
+typedef __hip_internal::int64_t int64_t;
+typedef __hip_internal::uint64_t uint64_t;
+typedef __hip_internal::uint8_t uint8_t;
+typedef unsigned long size_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -166,6 +175,11 @@ int gjx_program_engine(const gjx_program* prog);
  * returns how many floats the program's engine wants (0: none); gjx_program_prepare fills a caller-owned device
  * buffer of that size from tab_dev (call it again after changing tab_dev); the program then carries the buffer in
  * aux_dev / n_aux.  A program without aux_dev still runs (generic interpreter). */
+/* Generated kernels (gjx_codegen.hip): the HIP source emitted for a program (returns its length; copies at most
+ * cap - 1 characters), and compilation without a launch — hipRTC cross-compiles for gfx950 without a GPU, so a build
+ * step can fill the on-disk cache (GJX_JIT_CACHE, default jit_cache/ next to the library).  ppt = particles per lane. */
+int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap);
+int gjx_program_precompile(const gjx_program* prog, int32_t ppt);
 int gjx_program_aux_floats(const gjx_program* prog);
 int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int32_t n_aux, void* stream);
 
