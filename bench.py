@@ -54,22 +54,37 @@ def golden(name):
 # This is the only place bench.py touches oracle/.
 # ---------------------------------------------------------------------------------------------
 def cpu_baseline_gmm(prog, K, budget_s=12.0):
+    """the same step (propagate + reweight + LSE, prefix sum, systematic ancestors, gather) through the C oracle: on all
+    host cores (every stage OpenMP-parallel) and on ONE thread"""
     from oracle import cpu
+
+    def run(budget):
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            o = cpu.run_program(prog, (0, 1 + reps), K)
+            cum, _ = cpu.weight_cumsum(o["logw"], True, o["lse"])
+            anc = cpu.resample_systematic(cum, 0.5, K)
+            cpu.gather_rows(o["choices"], anc)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= 64:
+                return reps, dt
+
     threads = cpu.num_threads()
+    reps, dt = run(budget_s)
+    cpu.set_threads(1)
+    K1 = min(K, 1 << 17)
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        o = cpu.run_program(prog, (0, 1 + reps), K)
-        cum, _ = cpu.weight_cumsum(o["logw"], True, o["lse"])
-        anc = cpu.resample_systematic(cum, 0.5, K)
-        cpu.gather_rows(o["choices"], anc)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 64:
-            break
+    o = cpu.run_program(prog, (0, 1), K1)
+    cum, _ = cpu.weight_cumsum(o["logw"], True, o["lse"])
+    cpu.gather_rows(o["choices"], cpu.resample_systematic(cum, 0.5, K1))
+    dt1 = time.perf_counter() - t0
+    cpu.set_threads(threads)
     return dict(value=K * reps / dt, unit="particle-steps/s", cores=threads, kind="port",
-                sample=f"{reps} steps of K=2^{int(math.log2(K))} particles of the same workload, "
-                       f"propagate+reweight+LSE on {threads} OpenMP threads, resample+gather single-threaded")
+                sample=f"{reps} steps of K=2^{int(math.log2(K))} particles of the same workload on {threads} OpenMP threads "
+                       "(all stages parallel)",
+                single_thread=dict(value=K1 / dt1, unit="particle-steps/s", cores=1, sample=f"1 step of K=2^{int(math.log2(K1))}"))
 
 
 def cpu_baseline_ssm(s, K, T, budget_s=12.0):
@@ -93,8 +108,7 @@ def cpu_baseline_ssm(s, K, T, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     return dict(value=K * steps / dt, unit="particle-steps/s", cores=threads, kind="port",
-                sample=f"first {steps} of {T} filter steps at K=2^{int(math.log2(K))}; propagate on {threads} OpenMP threads, "
-                       "prefix sum + comb single-threaded")
+                sample=f"first {steps} of {T} filter steps at K=2^{int(math.log2(K))} on {threads} OpenMP threads (all stages parallel)")
 
 
 def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
@@ -384,6 +398,47 @@ def run_hmc(args, rank, world, dev):
     return res
 
 
+def run_api(dev, K, steps=100):
+    """The gmm step through the public API instead of a hand-built program: @gen body -> Target -> ImportanceK.run_smc
+    -> N-of-K systematic resampling (inference.pf.resample).  The traced site list and the packed program (table on the
+    device, engine chosen) are cached per (gen fn, arguments, constraint content), so a step costs the same launches
+    as the kernel-level loop plus the Python of the API objects.  -> dict(ms_per_step, particle_steps_per_sec, engine)"""
+    import genjax_amd as genjax
+    from genjax_amd import C, kernels, workloads
+    from genjax_amd.inference import ImportanceK, Target
+    from genjax_amd.inference.pf import resample
+    g = workloads.gmm_problem(C=8, D=D)
+
+    @genjax.gen
+    def model():
+        z = genjax.categorical(g["logits"]) @ "z"
+        mu, sig = genjax.const(g["mu"]), genjax.const(g["sigma"])
+        x = genjax.mv_normal_diag(mu[z], sig[z]) @ "x"
+        genjax.mv_normal_diag(x, g["r"]) @ "y"
+        return x
+
+    target = Target(model, (), C["y"].set(g["y"]))
+    alg = ImportanceK(target, k_particles=K)
+    keys = genjax.split(genjax.key(7), steps + 10)
+
+    def step(k):
+        pc = alg.run_smc(k)
+        tr = pc.get_particles()
+        rows, anc = resample(tr.choices, pc.get_log_weights(), k, lse=pc.lse())
+        return pc, rows
+
+    for k in keys[:10]:
+        pc, rows = step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in keys[10:]:
+        pc, rows = step(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(ms_per_step=dt / steps * 1e3, particle_steps_per_sec=K * steps / dt, engine=kernels.program_engine(pc.get_particles().prog),
+                log_ml=float(pc.get_log_marginal_likelihood_estimate()), steps=steps)
+
+
 def run_codegen(dev):
     """Kernels generated from the site list (hipRTC, csrc/gjx_codegen.hip) at K = 2^20: the mixture program through its
     generated kernel next to the hand-fused one, and two programs that have no hand-written kernel.  Kernel time from
@@ -487,6 +542,7 @@ def main():
     ap.add_argument("--leapfrog", type=int, default=1000)
     ap.add_argument("--weak", action="store_true", help="ssm with --gpus N > 1: 2^19 particles per GPU instead of 2^22 in total")
     ap.add_argument("--ssm-k-total", type=int, default=0, help="ssm: total number of particles (overrides the config-3/4 sizes)")
+    ap.add_argument("--api", action="store_true", help="gmm on one GPU: print only the API-level measurement (extra.api)")
     ap.add_argument("--no-extra", action="store_true", help="gmm on one GPU: skip the short ssm / hmc / API runs reported under extra")
     ap.add_argument("--event-samples", type=int, default=16,
                     help="number of timed steps whose propagate+reweight kernel is bracketed with HIP events "
@@ -506,6 +562,9 @@ def main():
     local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.api:
+        print(json.dumps(dict(metric="particle_steps_per_sec_api", **run_api(dev, args.k_per_gpu))))
+        return
     res = {"gmm": run_gmm, "ssm": run_ssm, "hmc": run_hmc}[args.workload](args, rank, world, dev)
     if args.workload == "gmm" and world == 1 and res is not None and not args.no_extra:
         # the other single-GPU rows of BASELINE.json, short runs, so that the driver's one line carries them too
@@ -519,6 +578,9 @@ def main():
                 if k in r2:
                     extra[name][k] = r2[k]
         extra["codegen"] = run_codegen(dev)
+        api = run_api(dev, args.k_per_gpu)
+        api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
+        extra["api"] = api
         res["extra"] = extra
     if rank == 0 and res is not None:
         print(json.dumps(res))

@@ -537,6 +537,27 @@ class GenerativeFunction:
         OBS_TAB (shared value) or OBS_SLOT (value per particle); sites in ``per_particle`` are OBS_SLOT with
         rows supplied later; the rest are SAMPLE when ``sample_rest`` else MissingAddress."""
         from . import config
+        # Packed programs are kept per (arguments, constraint content, flags): the same Target used again — every step of
+        # an SMC loop, every call of the GenSP interface — finds its program with the table already on the device and
+        # its engine already chosen, instead of re-tracing the body, re-packing and re-uploading (the reference gets the
+        # same effect from jax.jit's trace cache).  Constraints that carry one value per particle are not cached.
+        ckey = None
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        try:
+            items = []
+            for addr, v in constraint._d.items():
+                if isinstance(v, Masked) or np.size(_np_value(v)) > 4096:
+                    items = None
+                    break
+                items.append((repr(addr), _value_key(v)))
+            if items is not None:
+                ckey = (_args_key(args), tuple(items), bool(sample_rest), tuple(selected),
+                        config.rng_mode() if rng_mode is None else rng_mode, tuple(per_particle))
+                hit = cache.get(ckey)
+                if hit is not None and not hit[2]:
+                    return hit[0], hit[1], {}
+        except TypeError:
+            ckey = None
         sl, _ = self.site_list(args)
         modes, shared, pp, mask_rows = {}, {}, {}, {}
         for s in sl.sites:
@@ -564,6 +585,10 @@ class GenerativeFunction:
         prog = PackedProgram(sl, modes, shared, selected=tuple(selected),
                              rng_mode=config.rng_mode() if rng_mode is None else rng_mode)
         prog.mask_flags = mask_rows          # addr -> f32[K] validity flags of Mask(value, flag) constraints
+        if ckey is not None and not pp and not mask_rows:
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            cache[ckey] = (prog, shared, False)
         return prog, shared, pp
 
     def _run(self, key: Key, K: int, args, constraint: ChoiceMap, sample_rest: bool, batched: bool,
@@ -590,7 +615,8 @@ class GenerativeFunction:
                 raise ValueError(f"mask of {addr!r} has {fl.numel()} flags, expected one per particle ({K})")
             choices[fslot] = fl
         out = kernels.run_program(prog, key, K, offset=offset, choices=choices, logw_in=logw_in, sub=sub,
-                                  want_lse=want_lse, K_total=K_total, device=dev, want_site_scores=want_site_scores)
+                                  want_lse=want_lse, K_total=K_total, device=dev, want_site_scores=want_site_scores,
+                                  ws=kernels.shared_workspace(A.OP_RUN, K, dev))
         tr = Trace(self, args, prog, out["choices"], out["score"], shared, batched, retval)
         return tr, out
 
@@ -859,6 +885,10 @@ def _value_key(a):
     if ck is not None:
         return ck()
     return _IdKey(a)
+
+
+def _np_value(v):
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
 
 
 def _args_key(args) -> tuple:

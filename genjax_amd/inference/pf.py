@@ -28,10 +28,12 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
     K = logw.numel()
     N = int(n_out or K)
     if lse is None:
-        lse = kernels.logsumexp(logw)
-    cum, bt = kernels.weight_cumsum(logw, True, lse)
+        lse = kernels.logsumexp(logw, ws=kernels.shared_workspace(A.OP_LSE, K, logw.device))
     if method == "systematic":
-        return kernels.resample_gather_systematic(cum, bt, _unit_from_key(key), N, rows, want_ancestors=True)
+        # weights -> ancestors in one launch, then the slot-oriented row copy
+        anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, ws=kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device))
+        return kernels.gather_rows(rows, anc), anc
+    cum, bt = kernels.weight_cumsum(logw, True, lse, ws=kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device))
     if method == "multinomial":
         anc = kernels.resample_multinomial(cum, bt, key, N)
         return kernels.gather_rows(rows, anc), anc

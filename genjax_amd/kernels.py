@@ -32,6 +32,23 @@ def workspace(op: int, K: int, device=None) -> torch.Tensor:
     return torch.zeros(n, dtype=torch.uint8, device=_dev(device))   # control block must start zeroed (gjx.h)
 
 
+_shared_ws: dict = {}
+
+
+def shared_workspace(op: int, K: int, device=None) -> torch.Tensor:
+    """A zero-initialised workspace kept per (size, device, stream) for callers that hand nothing of it on (every entry
+    point leaves the control block zeroed, so one allocation + one memset serves all later calls on that stream)."""
+    dev = _dev(device)
+    n = load().gjx_workspace_bytes(op, int(K))
+    k = (n, dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _shared_ws.get(k)
+    if ws is None:
+        if len(_shared_ws) >= 16:
+            _shared_ws.pop(next(iter(_shared_ws)))
+        ws = _shared_ws[k] = torch.zeros(n, dtype=torch.uint8, device=dev)
+    return ws
+
+
 def workspace_status(ws: torch.Tensor, raise_on_error: bool = True) -> int:
     """Read and clear the status word of a workspace (synchronises the stream).  Bit 0: a co-resident kernel ran out of
     its poll budget (its output is undefined); bit 1: a resampling call saw a zero total weight (identity ancestors)."""

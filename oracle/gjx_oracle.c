@@ -673,14 +673,37 @@ int gjxo_categorical_pick(const float* logw, int64_t K, int64_t particle_offset,
 
 int gjxo_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* lse, uint64_t* cum,
                        uint64_t* total) {
-  uint64_t acc = 0;
-  for (int64_t i = 0; i < K; ++i) {
-    float w = is_log ? expf(x[i] - lse[0]) : x[i];
-    if (!(w > 0.0f)) w = 0.0f;
-    acc += (uint64_t)(w * GJX_WEIGHT_SCALE);
-    cum[i] = acc;
+  /* two passes over contiguous chunks, one chunk per thread: uint64 adds are associative, so the prefix sums are the
+   * same bits for any number of threads (and equal to the device's, whatever its block decomposition) */
+  int nt = 1;
+#ifdef _OPENMP
+  nt = omp_get_max_threads();
+#endif
+  if (nt > 256) nt = 256;
+  if (K < 65536) nt = 1;
+  uint64_t part[257];
+  const int64_t chunk = (K + nt - 1) / nt;
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+  for (int t = 0; t < nt; ++t) {
+    const int64_t lo = t * chunk, hi = lo + chunk < K ? lo + chunk : K;
+    uint64_t acc = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      float w = is_log ? expf(x[i] - lse[0]) : x[i];
+      if (!(w > 0.0f)) w = 0.0f;
+      acc += (uint64_t)(w * GJX_WEIGHT_SCALE);
+      cum[i] = acc;
+    }
+    part[t + 1] = acc;
   }
-  *total = acc;
+  part[0] = 0;
+  for (int t = 1; t <= nt; ++t) part[t] += part[t - 1];
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+  for (int t = 1; t < nt; ++t) {
+    const int64_t lo = t * chunk, hi = lo + chunk < K ? lo + chunk : K;
+    const uint64_t off = part[t];
+    for (int64_t i = lo; i < hi; ++i) cum[i] += off;
+  }
+  *total = part[nt];
   return 0;
 }
 
@@ -693,18 +716,34 @@ int gjxo_resample_systematic(const uint64_t* cum, int64_t K, uint64_t base, uint
                              double u, int64_t N_total, int64_t out_begin, int64_t n_out,
                              int32_t* ancestors) {
   const double step = (double)total_all / (double)N_total;
-  int64_t i = 0; /* thresholds are non-decreasing in j: walk the prefix sums once */
-  for (int64_t j = 0; j < n_out; ++j) {
-    const double pj = ((double)(out_begin + j) + u) * step;
-    uint64_t T = (uint64_t)pj;
-    if (total_all > 0 && T > total_all - 1) T = total_all - 1;
-    int32_t a = -1;
-    if (K > 0 && T >= base && T < base + cum[K - 1]) {
-      const uint64_t tl = T - base;
-      while (i < K - 1 && !(cum[i] > tl)) ++i;
-      a = (int32_t)i;
+  /* thresholds are non-decreasing in j: every thread walks the prefix sums once over its own stretch of slots,
+   * starting from a binary search for its first threshold */
+#pragma omp parallel
+  {
+    int nt = 1, tid = 0;
+#ifdef _OPENMP
+    nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+    const int64_t chunk = (n_out + nt - 1) / nt;
+    const int64_t j0 = tid * chunk, j1 = j0 + chunk < n_out ? j0 + chunk : n_out;
+    int64_t i = -1;
+    for (int64_t j = j0; j < j1; ++j) {
+      const double pj = ((double)(out_begin + j) + u) * step;
+      uint64_t T = (uint64_t)pj;
+      if (total_all > 0 && T > total_all - 1) T = total_all - 1;
+      int32_t a = -1;
+      if (K > 0 && T >= base && T < base + cum[K - 1]) {
+        const uint64_t tl = T - base;
+        if (i < 0) { /* first i with cum[i] > tl */
+          int64_t lo = 0, hi = K - 1;
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cum[mid] > tl) hi = mid; else lo = mid + 1; }
+          i = lo;
+        }
+        while (i < K - 1 && !(cum[i] > tl)) ++i;
+        a = (int32_t)i;
+      }
+      ancestors[j] = a;
     }
-    ancestors[j] = a;
   }
   return 0;
 }
@@ -714,6 +753,7 @@ int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uin
                               int64_t n_out, int32_t* ancestors) {
   (void)N_total;
   okey key = {key0, key1};
+#pragma omp parallel for schedule(static)
   for (int64_t j = 0; j < n_out; ++j) {
     uint64_t gj = (uint64_t)(out_begin + j);
     uint32_t o[2];
@@ -739,9 +779,10 @@ int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uin
 
 int gjxo_gather_rows(const float* src, int64_t src_stride, const int32_t* anc, int64_t n_out,
                      int32_t rows, float* dst, int64_t dst_stride) {
-  for (int r = 0; r < rows; ++r)
-    for (int64_t j = 0; j < n_out; ++j)
-      if (anc[j] >= 0) dst[(int64_t)r * dst_stride + j] = src[(int64_t)r * src_stride + anc[j]];
+#pragma omp parallel for schedule(static) collapse(1)
+  for (int64_t j = 0; j < n_out; ++j)
+    if (anc[j] >= 0)
+      for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + j] = src[(int64_t)r * src_stride + anc[j]];
   return 0;
 }
 
