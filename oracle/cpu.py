@@ -52,6 +52,7 @@ def lib() -> C.CDLL:
         for n in ("gjxo_normal_from_bits", "gjxo_gumbel_from_bits", "gjxo_unit_from_bits"):
             getattr(L, n).argtypes = [u32]
             getattr(L, n).restype = f32
+        L.gjxo_set_margin_buffer.argtypes = [vp, i64]
         L.gjxo_num_threads.restype = C.c_int
         L.gjxo_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -85,8 +86,10 @@ def num_threads() -> int:
 
 
 def run_program(prog: PackedProgram, key, K, offset=0, choices=None, logw_in=None, sub=None,
-                want_site_scores=False, K_total=None):
-    """Returns dict(choices [n_slots,K], score, weight, logw, lse[4], site_scores?)."""
+                want_site_scores=False, K_total=None, want_margin=False):
+    """Returns dict(choices [n_slots,K], score, weight, logw, lse[4], site_scores?, margin?).
+    margin[i]: the smallest relative distance between the two sides of any float comparison that decided a DISCRETE
+    outcome for particle i (category, accept / reject, floor); 3e38 when the particle took no such decision."""
     K = int(K)
     ns = max(prog.n_slots, 1)
     ch = np.zeros((ns, K), np.float32) if choices is None else np.ascontiguousarray(choices, np.float32).copy()
@@ -98,10 +101,19 @@ def run_program(prog: PackedProgram, key, K, offset=0, choices=None, logw_in=Non
     cp = prog.c_program(None)
     li = None if logw_in is None else np.ascontiguousarray(logw_in, np.float32)
     sb = None if sub is None else np.ascontiguousarray(sub, np.float32)
-    rc = lib().gjxo_run_program(C.byref(cp), key[0], key[1], K, int(offset), _p(ch), _p(score), _p(weight),
-                                _p(logw), _p(li), _p(sb), _p(ss), _p(lse), int(K_total or K))
+    margin = np.full(K, 3.0e38, np.float32) if want_margin else None
+    if want_margin:
+        lib().gjxo_set_margin_buffer(_p(margin), K)
+    try:
+        rc = lib().gjxo_run_program(C.byref(cp), key[0], key[1], K, int(offset), _p(ch), _p(score), _p(weight),
+                                    _p(logw), _p(li), _p(sb), _p(ss), _p(lse), int(K_total or K))
+    finally:
+        if want_margin:
+            lib().gjxo_set_margin_buffer(None, 0)
     assert rc == 0, rc
     out = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse)
+    if margin is not None:
+        out["margin"] = margin
     if ss is not None:
         out["site_scores"] = ss
     return out

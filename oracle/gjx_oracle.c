@@ -69,6 +69,24 @@ void gjxo_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
 
 typedef struct { uint32_t a, b; } okey;
 
+/* ---- decision margins ---------------------------------------------------------------------------------
+ * Every place where a float comparison decides a DISCRETE outcome (which category, accept / reject, which side of a
+ * floor) records how close the two sides were, relative to their size.  gjxo_run_program keeps the smallest margin of
+ * each particle (gjxo_set_margin_buffer).  The device uses hardware exp / log / rcp (about 1 ulp), so a device
+ * particle may legitimately take the other branch ONLY where the margin is tiny: the parity tests require every
+ * particle that differs from the oracle to have a margin below their stated bound, instead of allowing a blanket
+ * fraction of mismatches. */
+static _Thread_local float t_margin = 3.0e38f;
+static float* g_margin_buf = 0;
+static int64_t g_margin_n = 0;
+void gjxo_set_margin_buffer(float* buf, int64_t n) { g_margin_buf = buf; g_margin_n = n; }
+static inline void decide(float lhs, float rhs) {
+  float m = fabsf(lhs - rhs), sc = fabsf(lhs) > fabsf(rhs) ? fabsf(lhs) : fabsf(rhs);
+  if (sc > 1.0f) m /= sc;
+  if (!(m >= 0.0f)) m = 0.0f; /* NaN on either side: anything goes */
+  if (m < t_margin) t_margin = m;
+}
+
 /* jax.random.fold_in(key, i) == jax.random.split(key, n)[i]  (partitionable threefry) */
 static inline okey fold_in64(okey k, uint64_t i) {
   uint32_t o[2];
@@ -227,9 +245,11 @@ static float log_gamma_variate(const ostream* sk, uint32_t base, float a) {
     float x = stream_normal(sk, base + 4 * t);
     float u = uniform_from_bits(elem_bits(sk, base + 4 * t + 2), F32_TINY, 1.0f);
     float v = 1.0f + c * x;
+    decide(v, 0.0f);
     if (v <= 0.0f) continue;
     float lv = 3.0f * logf(v);
     v = v * v * v;
+    decide(logf(u), 0.5f * x * x + d - d * v + d * lv);
     if (logf(u) < 0.5f * x * x + d - d * v + d * lv) {
       res = logf(d) + lv;
       break;
@@ -389,10 +409,12 @@ static float poisson_variate(const ostream* sk, uint32_t c, float lam) {
     float u = bits_to_unit(elem_bits(sk, c));
     float p = expf(-lam), cdf = p;
     int k = 0;
+    decide(u, cdf);
     while (u > cdf && k < 96) {
       ++k;
       p *= lam / (float)k;
       cdf += p;
+      decide(u, cdf);
     }
     return (float)k;
   }
@@ -404,8 +426,12 @@ static float poisson_variate(const ostream* sk, uint32_t c, float lam) {
     float V = uniform_from_bits(elem_bits(sk, c + 3 + 2 * t), F32_TINY, 1.0f);
     float us = 0.5f - fabsf(U);
     float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
+    { const float kraw = (2.0f * a / us + b) * U + lam + 0.43f; decide(kraw, floorf(kraw)); decide(kraw, floorf(kraw) + 1.0f); }
+    decide(us, 0.07f); decide(V, vr);
     if (us >= 0.07f && V <= vr) return k;
+    decide(us, 0.013f); decide(V, us);
     if (k < 0.0f || (us < 0.013f && V > us)) continue;
+    decide(logf(V) + logf(inv_alpha) - logf(a / (us * us) + b), -lam + k * loglam - lgammaf(k + 1.0f));
     if (logf(V) + logf(inv_alpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;
   }
   return floorf(lam);
@@ -433,7 +459,11 @@ static float elem_sample4(int kind, const ostream* sk, uint32_t c, float a, floa
       return x < p3 ? p3 : (x > p4 ? p4 : x);
     }
     case GJX_POISSON: return poisson_variate(sk, c, a);
-    case GJX_GEOMETRIC: return floorf(logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)) / log1pf(-a));
+    case GJX_GEOMETRIC: {
+      const float raw = logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)) / log1pf(-a);
+      decide(raw, floorf(raw)); decide(raw, floorf(raw) + 1.0f);
+      return floorf(raw);
+    }
     case GJX_GUMBEL: return a - b * logf(-logf(uniform_from_bits(elem_bits(sk, c), F32_TINY, 1.0f)));
     case GJX_HALF_CAUCHY: return a + b * tanf(0.5f * 3.14159265f * bits_to_unit(elem_bits(sk, c)));
     case GJX_INVERSE_GAMMA: return b * expf(-log_gamma_variate(sk, c, a));
@@ -448,8 +478,8 @@ static float elem_sample(int kind, const ostream* sk, uint32_t c, float a, float
   switch (kind) {
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: return a + b * stream_normal(sk, c);
-    case GJX_FLIP: return bits_to_unit(elem_bits(sk, c)) < a ? 1.0f : 0.0f;
-    case GJX_BERNOULLI_LOGITS: return bits_to_unit(elem_bits(sk, c)) < sigmoidf_(a) ? 1.0f : 0.0f;
+    case GJX_FLIP: decide(bits_to_unit(elem_bits(sk, c)), a); return bits_to_unit(elem_bits(sk, c)) < a ? 1.0f : 0.0f;
+    case GJX_BERNOULLI_LOGITS: decide(bits_to_unit(elem_bits(sk, c)), sigmoidf_(a)); return bits_to_unit(elem_bits(sk, c)) < sigmoidf_(a) ? 1.0f : 0.0f;
     case GJX_BETA: {
       float g1 = log_gamma_variate(sk, c, a);
       float g2 = log_gamma_variate(sk, c + GAMMA_NDRAW, b);
@@ -516,18 +546,20 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
           float l = eval_param(&s->p[0], c, tab, vals);
           if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
           run += expf(l - mx);
+          if (c < n - 1) decide(run, target);
           if (run > target) { zc = c; break; }
         }
         v = (float)zc;
       } else if (mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
         int best = 0;
-        float bestv = -INFINITY;
+        float bestv = -INFINITY, second = -INFINITY;
         for (int c = 0; c < n; ++c) {
           float l = eval_param(&s->p[0], c, tab, vals);
           if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
           float g = l + gumbel_from_bits(elem_bits(sk, (uint32_t)c));
-          if (g > bestv) { bestv = g; best = c; }
+          if (g > bestv) { second = bestv; bestv = g; best = c; } else if (g > second) second = g;
         }
+        if (n > 1) decide(bestv, second);
         v = (float)best;
       } else if (mode == GJX_MODE_OBS_TAB) {
         v = tab[s->obs_off];
@@ -623,7 +655,9 @@ int gjxo_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int6
     for (int64_t i = 0; i < K; ++i) {
       for (int s = 0; s < ns; ++s) vals[s] = choices[(int64_t)s * K + i];
       float sc, w;
+      t_margin = 3.0e38f;
       run_particle(prog, key, (uint64_t)(particle_offset + i), vals, &sc, &w, site_scores ? site_scores + i : NULL, K);
+      if (g_margin_buf && i < g_margin_n) g_margin_buf[i] = t_margin;
       for (int s = 0; s < ns; ++s) choices[(int64_t)s * K + i] = vals[s];
       if (score) score[i] = sc;
       if (weight) weight[i] = w;

@@ -44,18 +44,34 @@ def _close_cols(a, b, rt=RT, at=AT):
     return (np.abs(a - b) <= at + rt * np.abs(b)).all(axis=0) | (np.isnan(a) & np.isnan(b)).all(axis=0)
 
 
-def assert_particles_match(gpu, ora, max_bad=1e-3, what=""):
+NEAR_TIE = 3e-4   # relative margin of a discrete decision below which the device (v_exp / v_log / v_rcp, ~1 ulp, and
+                  # float32 sums in another order) may land on the other side of the oracle's comparison
+
+
+def assert_near_ties_only(bad, ora, what="", cap=0.02):
+    """Particles that differ from the oracle must be NEAR TIES of a discrete decision the oracle took for them (which
+    category, accept / reject, which side of a floor): the oracle reports each particle's smallest decision margin
+    (oracle/gjx_oracle.c `decide`), and only margins below NEAR_TIE excuse a mismatch.  `cap` bounds their share."""
+    bad = np.asarray(bad, bool)
+    if not bad.any():
+        return
+    m = ora["margin"][bad]
+    assert (m < NEAR_TIE).all(), (f"{what}: {int((m >= NEAR_TIE).sum())} of {int(bad.sum())} differing particles are NOT near ties "
+                                   f"(largest decision margin among them {float(m.max()):.3g}, bound {NEAR_TIE})")
+    assert bad.sum() <= max(1, int(cap * bad.size)), f"{what}: {int(bad.sum())}/{bad.size} near-tie particles (cap {cap})"
+
+
+def assert_particles_match(gpu, ora, max_bad=None, what=""):
     ok = _close_cols(gpu["choices"], ora["choices"])
     for k in ("score", "weight", "logw"):
         ok &= _close_cols(gpu[k][None], ora[k][None])
-    bad = (~ok).sum()
-    assert bad <= max(0, int(max_bad * ok.size)), f"{what}: {bad}/{ok.size} particles differ from the oracle"
+    assert_near_ties_only(~ok, ora, what)
     return ok
 
 
 def _run_both(K_, oracle, prog, key, K, **kw):
     g = K_.run_program(prog, key, K, **kw)
-    o = oracle.run_program(prog, key, K, **kw)
+    o = oracle.run_program(prog, key, K, want_margin=True, **kw)
     gg = {k: _np(v) for k, v in g.items() if k in ("choices", "score", "weight", "logw", "lse", "site_scores") and v is not None}
     return gg, o
 
@@ -107,15 +123,15 @@ def test_zoo_parity(K_, oracle, rng, observed):
 def test_zoo2_parity(K_, oracle, rng, observed):
     """the wider distribution set (student_t, truncated_normal, poisson, geometric, dirichlet, gumbel, half_cauchy,
     inverse_gamma, weibull, logit_normal, chi2) through the generic interpreter: samples, scores, weights.
-    Rejection samplers (gamma family, poisson above rate 10) and floor()-ed draws may part ways with the oracle on a
-    near-tie, so up to 1% of the particles are allowed to differ; the rest must match to the float tolerance."""
+    Rejection samplers (gamma family, poisson above rate 10) and floor()-ed draws may part ways with the oracle only
+    on a near-tie of the deciding comparison (assert_near_ties_only); the rest must match to the float tolerance."""
     prog = H.zoo2(rng, observed)
     for K in (1, 77, 3000):
         g, o = _run_both(K_, oracle, prog, (31, 32), K, want_site_scores=True)
         ok = _close_cols(g["choices"], o["choices"], rt=5e-4, at=2e-4)
         for k in ("score", "weight", "logw"):
             ok &= _close_cols(g[k][None], o[k][None], rt=5e-4, at=5e-4)
-        assert (~ok).sum() <= (0.01 * K if K > 1000 else (1 if K > 1 else 0)), f"zoo2 K={K}: {(~ok).sum()} particles differ"
+        assert_near_ties_only(~ok, o, f"zoo2 K={K}")
         np.testing.assert_allclose(g["site_scores"][:, ok], o["site_scores"][:, ok], rtol=1e-3, atol=5e-4)
         if not observed:
             assert (g["weight"] == 0).all()
@@ -165,7 +181,7 @@ def test_gmm_fused_generic_oracle(K_, oracle, rng, shape, monkeypatch):
     C, D = shape
     prog, g = H.gmm(D=D, C=C, rng=rng)
     for K in (1, 63, 1000, 4099):
-        o = oracle.run_program(prog, (0, 1), K)
+        o = oracle.run_program(prog, (0, 1), K, want_margin=True)
         res = {}
         for force in ("1", "0"):
             monkeypatch.setenv("GJX_FORCE_GENERIC", force)
@@ -819,7 +835,7 @@ def test_masked_constraints_parity(K_, oracle, rng):
         ch[s0:s0 + sl[a].dim] = vals[a]
         ch[prog.flag_slot_of[a]] = masked[a]
     g = K_.run_program(prog, (6, 7), K, choices=torch.as_tensor(ch).cuda(), want_site_scores=True)
-    o = oracle.run_program(prog, (6, 7), K, choices=ch.copy(), want_site_scores=True)
+    o = oracle.run_program(prog, (6, 7), K, choices=ch.copy(), want_site_scores=True, want_margin=True)
     gg = {k: _np(v) for k, v in g.items() if k in ("choices", "score", "weight", "logw")}
     assert_particles_match(gg, o, max_bad=2e-3, what="masked zoo")
     free = K_.run_program(PackedProgram(sl, rng_mode=rng), (6, 7), K)
@@ -894,7 +910,7 @@ def test_random_programs_against_oracle(K_, oracle, rng):
         g, o = _run_both(K_, oracle, prog, key, K, want_site_scores=True)
         fin = np.isfinite(o["score"]) & (np.abs(o["score"]) < 1e4)
         ok = _close_cols(g["choices"], o["choices"], rt=1e-3, at=5e-4) & _close_cols(g["score"][None], o["score"][None], rt=2e-3, at=2e-3)
-        assert (~ok & fin).sum() <= 0.02 * K, f"trial {trial}: {(~ok & fin).sum()} of {K} particles differ ({[A.KIND_NAMES[s.kind] for s in sl.sites]})"
+        assert_near_ties_only(~ok & fin, o, f"trial {trial} ({[A.KIND_NAMES[s.kind] for s in sl.sites]})")
         # analytic gradients of the same program at the oracle's draws (every site constrained, float sites selected)
         sel = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS and s.kind not in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS))
         if sel:
