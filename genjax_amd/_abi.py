@@ -118,6 +118,8 @@ PROTOTYPES = {
     "gjx_gather_rows_strided": (C.c_int, [vp, i64, i64, vp, i64, i32, vp, i64, i64, vp]),
     "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
                                vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_ssm_step_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32, vp, vp,
+                                    vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),

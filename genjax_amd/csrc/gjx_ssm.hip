@@ -26,9 +26,16 @@ struct SsmArgs {
   unsigned* ticket;
   float* lse;
   float log_k_total;
+  // resample-move (MOVE kernels): Metropolis-Hastings rejuvenation of the resampled x_{t-1} before it is propagated
+  const float* m_prev;   // [DX][K] E[x_{t-1} | parent] of every particle of step t-1 (NULL at t-1 == 0: prior mean 0)
+  float* m_out;          // [DX][K] A x_{t-1} of the particles of this step
+  const float* y_prev;   // y_{t-1}
+  int n_moves;
+  float move_scale;
+  float* accepted;       // [K] number of accepted moves (or NULL)
 };
 
-template <int RNG, int DX>
+template <int RNG, int DX, bool MOVE = false>
 __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   __shared__ float red[16];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -44,6 +51,53 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
     float xp[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
+    if constexpr (MOVE) {
+      // The resampled particle x_{t-1} (equal weights) is a draw from p(x_{t-1} | parent, y_{t-1}) up to the filter's
+      // approximation; n_moves random-walk Metropolis steps with that conditional as invariant density restore the
+      // diversity the resampling removed (the reference's ingredients: Regenerate / Rejuvenate + the caller-side accept
+      // of tests/inference/test_requests.py:131-137; the kernel fuses proposal, both densities and the accept).
+      // Draws: site 2 of this step's stream, element n (DX + 2) + d for the proposal, n (DX + 2) + DX for the uniform.
+      float mp[DX];
+#pragma unroll
+      for (int d = 0; d < DX; ++d) mp[d] = a.m_prev ? a.m_prev[(int64_t)d * a.prev_stride + src] : 0.0f;
+      const float sdp = a.t > 1 ? a.q : a.q0;
+      const float rq = fast_rcp(sdp), rr0 = fast_rcp(a.r);
+      auto logpi = [&](const float (&x)[DX]) {
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) { const float z = (x[d] - mp[d]) * rq; s = fmaf(z, z, s); }
+        if (a.H) {
+          for (int o = 0; o < a.dy; ++o) {
+            float m = 0.0f;
+#pragma unroll
+            for (int e = 0; e < DX; ++e) m = fmaf(a.H[o * DX + e], x[e], m);
+            const float z = (a.y_prev[o] - m) * rr0;
+            s = fmaf(z, z, s);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < DX; ++d) { const float z = (a.y_prev[d] - x[d]) * rr0; s = fmaf(z, z, s); }
+        }
+        return -0.5f * s;
+      };
+      BitStreamRT<RNG> bm;
+      bm.open(a.key, gidx, 2u);
+      float cur = logpi(xp), nacc = 0.0f;
+      for (int n = 0; n < a.n_moves; ++n) {
+        float xq[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) xq[d] = fmaf(a.move_scale, stream_normal<RNG>(bm, (uint32_t)(n * (DX + 2) + d)), xp[d]);
+        const float prop = logpi(xq);
+        const float lu = safe_log(uniform_from_bits(bm.get((uint32_t)(n * (DX + 2) + DX)), kTiny, 1.0f));
+        if (lu < prop - cur) {
+#pragma unroll
+          for (int d = 0; d < DX; ++d) xp[d] = xq[d];
+          cur = prop;
+          nacc += 1.0f;
+        }
+      }
+      if (a.accepted && active) a.accepted[i] = nacc;
+    }
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
       float acc = 0.0f;
@@ -54,6 +108,10 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   } else {
 #pragma unroll
     for (int d = 0; d < DX; ++d) xn[d] = 0.0f;
+  }
+  if (MOVE && a.m_out && active) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) a.m_out[(int64_t)d * a.K + i] = xn[d];
   }
   const float sd = a.t > 0 ? a.q : a.q0;
   if (RNG == GJX_RNG_FLAT) {
@@ -121,6 +179,16 @@ using namespace gjx;
 
 namespace {
 template <int RNG>
+int launch_ssm_move(const SsmArgs& a, int dx, int nblocks, hipStream_t st) {
+  switch (dx) {
+    case 2: hipLaunchKernelGGL((k_ssm_step<RNG, 2, true>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL((k_ssm_step<RNG, 4, true>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 8: hipLaunchKernelGGL((k_ssm_step<RNG, 8, true>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    case 16: hipLaunchKernelGGL((k_ssm_step<RNG, 16, true>), dim3(nblocks), dim3(256), 0, st, a); return 0;
+    default: return -1;
+  }
+}
+template <int RNG>
 int launch_ssm(const SsmArgs& a, int dx, int nblocks, hipStream_t st) {
   switch (dx) {
     case 1: hipLaunchKernelGGL((k_ssm_step<RNG, 1>), dim3(nblocks), dim3(256), 0, st, a); return 0;
@@ -154,11 +222,45 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset; a.prev_stride = prev_stride;
   a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials; a.ticket = ticket; a.lse = lse;
   a.log_k_total = (float)log((double)K_total);
+  a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
   const int nblocks = (int)((K + 255) / 256);
   const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
                                            : launch_ssm<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
   if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step: dx must be one of 1,2,4,8,16,32");
   GJX_CHECK_LAUNCH("gjx_ssm_step");
+  return GJX_OK;
+}
+
+extern "C" int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
+                                 int64_t particle_offset, const float* x_prev, const float* m_prev, int64_t prev_stride,
+                                 const int32_t* anc, const float* y_prev_dev, const float* y_dev, int32_t n_moves,
+                                 float move_scale, float* x_out, float* m_out, float* logw, float* accepted, float* lse,
+                                 int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !m->A_dev || !y_dev || !x_out || !m_out || !logw || K <= 0 || t < 0 || n_moves < 0)
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: bad argument");
+  if (t > 0 && (!x_prev || !y_prev_dev)) return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: x_prev / y_prev are null for t > 0");
+  if (t > 1 && !m_prev) return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: m_prev is null for t > 1");
+  if (!m->H_dev && m->dy != m->dx) return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: H == NULL needs dy == dx");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* partials = nullptr;
+  unsigned* ticket = nullptr;
+  if (lse || workspace) {
+    if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_SSM, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_step_move: workspace too small");
+    ticket = (unsigned*)workspace;
+    partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
+  }
+  SsmArgs a;
+  a.A = m->A_dev; a.H = m->H_dev; a.y = y_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = t;
+  a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset; a.prev_stride = prev_stride;
+  a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials; a.ticket = ticket; a.lse = lse;
+  a.log_k_total = (float)log((double)K_total);
+  a.m_prev = t > 1 ? m_prev : nullptr; a.m_out = m_out; a.y_prev = y_prev_dev; a.n_moves = t > 0 ? n_moves : 0;
+  a.move_scale = move_scale; a.accepted = accepted;
+  const int nblocks = (int)((K + 255) / 256);
+  const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm_move<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
+                                           : launch_ssm_move<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
+  if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_step_move: dx must be one of 2,4,8,16");
+  GJX_CHECK_LAUNCH("gjx_ssm_step_move");
   return GJX_OK;
 }
 

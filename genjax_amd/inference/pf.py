@@ -63,15 +63,61 @@ class LinearGaussianSSM:
         return s
 
 
+class ParticleHistory:
+    """Append-only record of a filter run: the particles of every step (SoA rows) and the ancestor indices of every
+    resampling.  The reference's ScanTrace keeps the whole stacked trace per particle and its resampling idiom gathers
+    whole particles (scan.py:56-97; O(T^2) copies over a run); here a trajectory is reconstructed lazily by following
+    the ancestors back from the last step — one row gather per step."""
+
+    def __init__(self):
+        self.states: list = []      # x_t f32[dx][K], the particles as propagated at step t (before the next resampling)
+        self.ancestors: list = []   # a_t i32[K] for t >= 1: particle i of step t descends from particle a_t[i] of step t-1
+        self.logw = None            # log-weights of the last step
+
+    def append(self, x, anc):
+        self.states.append(x.clone())
+        if anc is not None:
+            self.ancestors.append(anc.clone())
+
+    def __len__(self):
+        return len(self.states)
+
+    def paths(self, idx=None):
+        """-> f32[T][dx][n]: the trajectories that end in particles ``idx`` (int32 device tensor; default all) of the last step"""
+        import torch
+        from .. import kernels
+        T = len(self.states)
+        K = self.states[-1].shape[1]
+        cur = torch.arange(K, dtype=torch.int32, device=self.states[-1].device) if idx is None else idx.to(torch.int32).contiguous()
+        out = [None] * T
+        for t in range(T - 1, -1, -1):
+            out[t] = kernels.gather_rows(self.states[t], cur)
+            if t > 0:
+                a = self.ancestors[t - 1]
+                cur = kernels.gather_rows(a.view(torch.float32).reshape(1, -1), cur).reshape(-1).view(torch.int32).contiguous()
+        return torch.stack(out)
+
+    def smoothed_means(self):
+        """E[x_t | y_{1:T}] estimated from the reconstructed trajectories, weighted by the last step's weights: f32[T][dx]"""
+        import torch
+        w = torch.softmax(self.logw.double(), dim=0)
+        return (self.paths().double() * w).sum(dim=2).float()
+
+
 class BootstrapFilter:
     """SMC with the prior as proposal and systematic resampling before every propagate step."""
 
-    def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None):
+    def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None, rejuvenate: dict | None = None):
+        """``rejuvenate=dict(n_moves=.., scale=..)``: resample-move — after every resampling each particle takes n_moves
+        random-walk Metropolis steps (proposal scale ``scale``) that leave p(x_{t-1} | parent, y_{t-1}) invariant, fused
+        into the propagate kernel (gjx_ssm_step_move)."""
         self.ssm, self.K = ssm, int(k_particles)
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
+        self.rejuvenate = dict(rejuvenate) if rejuvenate else None
+        self.last_accept_rate = None
 
     def run(self, key: Key, ys, device=None, rank: int = 0, world: int = 1, keep_means: bool = False,
-            step_by_step: bool = False):
+            step_by_step: bool = False, keep_history: bool = False):
         """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?).
         With world > 1 the K particles are sharded (distributed.py) and ``ys`` is the same on all ranks."""
         from .. import kernels
@@ -80,7 +126,11 @@ class BootstrapFilter:
         ys_d = torch.as_tensor(np.asarray(ys, np.float32), device=dev) if not torch.is_tensor(ys) else ys.to(dev)
         ys_d = ys_d.contiguous()
         T = ys_d.shape[0]
-        if world == 1 and not keep_means and not step_by_step and not D._forced():
+        if keep_history and (world > 1 or D._forced()):
+            raise NotImplementedError("keep_history: the ancestor history is kept per process; run the filter on one GPU")
+        if self.rejuvenate and (world > 1 or D._forced()):
+            raise NotImplementedError("resample-move rejuvenation runs on one GPU")
+        if world == 1 and not keep_means and not step_by_step and not keep_history and not self.rejuvenate and not D._forced():
             out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K)
             incs = out["lse_steps"][:, 3]
             return dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
@@ -110,6 +160,7 @@ class BootstrapFilter:
             cum_buf = torch.empty(K, dtype=torch.int64, device=dev)
             bt_buf = torch.empty(2, dtype=torch.int64, device=dev)
         x_prev, anc = None, None
+        hist = ParticleHistory() if keep_history else None
         k = key
         for t in range(T):
             k = fold_in(k, t)                      # chained step key (scan.py:268)
@@ -117,8 +168,20 @@ class BootstrapFilter:
             if t > 0 and not sharded:
                 anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
             x_out = bufs[t & 1]
-            kernels.ssm_step(cs, k_prop, self.rng_mode, t, K, x_prev, anc, ys_d[t], x_out=x_out, logw=logw, lse=lse,
-                             offset=off, K_total=self.K, ws=ws)
+            if self.rejuvenate:
+                if t == 0:
+                    mbufs = [torch.empty((self.ssm.dx, K), dtype=torch.float32, device=dev) for _ in range(2)]
+                    acc_buf = torch.zeros(K, dtype=torch.float32, device=dev)
+                    acc_sum = torch.zeros((), dtype=torch.float64, device=dev)
+                kernels.ssm_step_move(cs, k_prop, self.rng_mode, t, K, x_prev, mbufs[(t + 1) & 1] if t > 1 else None, anc,
+                                      ys_d[t - 1] if t > 0 else None, ys_d[t], int(self.rejuvenate.get("n_moves", 1)),
+                                      float(self.rejuvenate.get("scale", 0.5)), x_out=x_out, m_out=mbufs[t & 1], logw=logw,
+                                      accepted=acc_buf, lse=lse, offset=off, K_total=self.K, ws=ws)
+                if t > 0:
+                    acc_sum += acc_buf.double().mean()
+            else:
+                kernels.ssm_step(cs, k_prop, self.rng_mode, t, K, x_prev, anc, ys_d[t], x_out=x_out, logw=logw, lse=lse,
+                                 offset=off, K_total=self.K, ws=ws)
             rec = lse
             if sharded:
                 if t + 1 < T:
@@ -129,6 +192,8 @@ class BootstrapFilter:
                 else:
                     rec = D.global_lse(lse, self.K)
             incs[t] = rec[3]
+            if hist is not None:
+                hist.append(x_out, anc if t > 0 else None)
             if keep_means:
                 w = torch.exp(logw - rec[2])
                 m = (x_out * w).sum(dim=1)
@@ -136,4 +201,8 @@ class BootstrapFilter:
                     torch.distributed.all_reduce(m)
                 means[t] = m
             x_prev = x_res if (sharded and t + 1 < T) else x_out
-        return dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means)
+        if self.rejuvenate and T > 1:
+            self.last_accept_rate = float(acc_sum) / ((T - 1) * max(int(self.rejuvenate.get("n_moves", 1)), 1))
+        if hist is not None:
+            hist.logw = logw.clone()
+        return dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means, history=hist)

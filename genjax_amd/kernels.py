@@ -474,6 +474,25 @@ def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, log
     return x_out, logw, lse
 
 
+def ssm_step_move(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, m_prev, anc, y_prev, y, n_moves, move_scale, x_out=None,
+                  m_out=None, logw=None, accepted=None, lse=None, offset=0, K_total=None, ws=None, device=None):
+    """gjx_ssm_step_move: resample-move rejuvenation of x_{t-1} fused in front of the propagate + reweight step"""
+    dev = _dev(device) if x_prev is None else x_prev.device
+    f32 = torch.float32
+    x_out = torch.empty((ssm.dx, K), dtype=f32, device=dev) if x_out is None else x_out
+    m_out = torch.empty((ssm.dx, K), dtype=f32, device=dev) if m_out is None else m_out
+    logw = torch.empty(K, dtype=f32, device=dev) if logw is None else logw
+    lse = torch.empty(4, dtype=f32, device=dev) if lse is None else lse
+    if ws is None:
+        ws = workspace(A.OP_SSM, K, dev)
+    stride = 0 if x_prev is None else x_prev.shape[1]
+    check(load().gjx_ssm_step_move(C.byref(ssm), key[0], key[1], rng_mode, int(t), int(K), int(offset), _ptr(x_prev), _ptr(m_prev),
+                                   stride, _ptr(anc), _ptr(y_prev), _ptr(y), int(n_moves), float(move_scale), _ptr(x_out),
+                                   _ptr(m_out), _ptr(logw), _ptr(accepted), _ptr(lse), int(K_total or K), _ptr(ws), ws.numel(),
+                                   _stream()), "gjx_ssm_step_move")
+    return x_out, m_out, logw, lse
+
+
 def ssm_filter_sharded(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, ctx: "ShardContext", offset: int, bufs=None):
     """gjx_ssm_filter_sharded: this rank's part of the T-step bootstrap filter over a gjx_shard_ctx, looped in C++.
     -> dict(lse_steps [T][4] global records, x (propagated particles of the last step), logw)"""

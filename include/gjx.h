@@ -399,6 +399,17 @@ int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mod
                  int64_t K, int64_t particle_offset, const float* x_prev, int64_t prev_stride,
                  const int32_t* anc, const float* y_dev, float* x_out, float* logw, float* lse,
                  int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
+/* The same step with a resample-move rejuvenation in front of the propagation (the reference's
+ * ingredients are Regenerate / Rejuvenate, distribution.py:258-300, rejuvenate.py:70-94, and the caller-side accept of
+ * tests/inference/test_requests.py:131-137): the resampled x_{t-1} takes n_moves random-walk Metropolis steps (scale
+ * move_scale) that leave p(x_{t-1} | its parent, y_{t-1}) invariant — proposal, both densities and the accept fused into
+ * the step kernel — and is then propagated.  m_prev f32[dx][K] = E[x_{t-1} | parent] written by the previous call as its
+ * m_out (ignored at t <= 1: the prior mean is 0); accepted f32[K] = accepted moves per particle, or NULL. */
+int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
+                      int64_t particle_offset, const float* x_prev, const float* m_prev, int64_t prev_stride,
+                      const int32_t* anc, const float* y_prev_dev, const float* y_dev, int32_t n_moves, float move_scale,
+                      float* x_out, float* m_out, float* logw, float* accepted, float* lse, int64_t K_total,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* The whole T-step bootstrap filter on ONE GPU, looped in C++ (2 launches per step, no host round trip):
  * step keys k_t = fold_in(k_{t-1}, t), (k_prop, k_res) = split(k_t), systematic resampling before every

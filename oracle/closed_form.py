@@ -87,6 +87,39 @@ def kalman_log_lik(A, y, q, r, q0=1.0, H=None):
     return float(incs.sum()), incs, means
 
 
+def rts_smoother(A, y, q, r, q0=1.0, H=None):
+    """float64 Rauch-Tung-Striebel smoother of the same model: E[x_t | y_{1:T}] for every t (and the covariances).
+    The yardstick for trajectories reconstructed from the particle filter's ancestor history (scan.py:56-97 keeps the
+    whole stacked trace; the build keeps per-step states + ancestors and follows them back)."""
+    A = np.asarray(A, np.float64)
+    y = np.asarray(y, np.float64)
+    T, dy = y.shape
+    dx = A.shape[0]
+    Hm = np.eye(dx)[:dy] if H is None else np.asarray(H, np.float64)
+    Q = q * q * np.eye(dx)
+    R = r * r * np.eye(dy)
+    m = np.zeros(dx)
+    P = q0 * q0 * np.eye(dx)
+    mf, Pf, mp, Pp = [], [], [], []
+    for t in range(T):
+        if t > 0:
+            m = A @ m
+            P = A @ P @ A.T + Q
+        mp.append(m.copy()); Pp.append(P.copy())
+        S = Hm @ P @ Hm.T + R
+        Kg = P @ Hm.T @ np.linalg.inv(S)
+        m = m + Kg @ (y[t] - Hm @ m)
+        P = (np.eye(dx) - Kg @ Hm) @ P
+        mf.append(m.copy()); Pf.append(P.copy())
+    ms, Ps = [None] * T, [None] * T
+    ms[-1], Ps[-1] = mf[-1], Pf[-1]
+    for t in range(T - 2, -1, -1):
+        G = Pf[t] @ A.T @ np.linalg.inv(Pp[t + 1])
+        ms[t] = mf[t] + G @ (ms[t + 1] - mp[t + 1])
+        Ps[t] = Pf[t] + G @ (Ps[t + 1] - Pp[t + 1]) @ G.T
+    return np.stack(ms), np.stack(Ps)
+
+
 # ---- config 5 ------------------------------------------------------------------------------
 def logreg_log_joint(log_tau, beta, X, y):
     """log p(log_tau, beta, y) of: log_tau~N(0,1); beta_p~N(0, exp(log_tau)); y_n~Bernoulli(logits=X beta)."""

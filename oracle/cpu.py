@@ -44,6 +44,8 @@ def lib() -> C.CDLL:
         L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
         L.gjxo_ssm_step.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp,
                                     i64, vp, vp, vp, vp, vp, i64]
+        L.gjxo_ssm_step_move.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32,
+                                         vp, vp, vp, vp, vp, i64]
         L.gjxo_score_grad.argtypes = [A.PP, i64, vp, vp, vp]
         L.gjxo_hmc.argtypes = [A.PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp]
         for n in ("gjxo_erfinv",):
@@ -188,6 +190,30 @@ def ssm_step(A_, H, q, r, q0, key, rng_mode, t, K, x_prev, anc, y, offset=0, K_t
                         _p(xp), 0 if xp is None else xp.shape[1], _p(an), _p(y), _p(xo), _p(lw), _p(lse),
                         int(K_total or K))
     return xo, lw, lse
+
+
+def ssm_step_move(A_, H, q, r, q0, key, rng_mode, t, K, x_prev, m_prev, anc, y_prev, y, n_moves, move_scale, offset=0):
+    """-> (x_out, m_out, logw, accepted, lse, margin): the step with the resample-move rejuvenation in front"""
+    A_ = np.ascontiguousarray(A_, np.float32)
+    dx = A_.shape[0]
+    Hc = None if H is None else np.ascontiguousarray(H, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    yp = None if y_prev is None else np.ascontiguousarray(y_prev, np.float32)
+    xp = None if x_prev is None else np.ascontiguousarray(x_prev, np.float32)
+    mp = None if m_prev is None else np.ascontiguousarray(m_prev, np.float32)
+    an = None if anc is None else np.ascontiguousarray(anc, np.int32)
+    x_out, m_out = np.zeros((dx, K), np.float32), np.zeros((dx, K), np.float32)
+    logw, acc, lse = np.zeros(K, np.float32), np.zeros(K, np.float32), np.zeros(4, np.float32)
+    margin = np.full(K, 3.0e38, np.float32)
+    lib().gjxo_set_margin_buffer(_p(margin), K)
+    try:
+        rc = lib().gjxo_ssm_step_move(dx, y.size, _p(A_), _p(Hc), q, r, q0, key[0], key[1], rng_mode, int(t), int(K), int(offset), _p(xp),
+                                      _p(mp), 0 if xp is None else xp.shape[1], _p(an), _p(yp), _p(y), int(n_moves), float(move_scale),
+                                      _p(x_out), _p(m_out), _p(logw), _p(acc), _p(lse), int(K))
+    finally:
+        lib().gjxo_set_margin_buffer(None, 0)
+    assert rc == 0
+    return x_out, m_out, logw, acc, lse, margin
 
 
 def score_grad(prog: PackedProgram, choices):

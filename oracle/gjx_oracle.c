@@ -866,6 +866,76 @@ int gjxo_ssm_step(int32_t dx, int32_t dy, const float* A, const float* H, float 
   return 0;
 }
 
+/* Resample-move variant: before x_{t-1} (gathered through its ancestor) is propagated it takes
+ * n_moves random-walk Metropolis steps whose invariant density is p(x_{t-1} | parent, y_{t-1}) ~ N(x; m_prev, sd^2)
+ * N(y_{t-1}; H x, r^2) — the reference's Regenerate / Rejuvenate ingredients with the caller-side accept of
+ * tests/inference/test_requests.py:131-137 (log u < w).  Draws come from site 2 of the step's stream: element
+ * n (dx + 2) + d for the proposal of move n, n (dx + 2) + dx for its uniform. */
+int gjxo_ssm_step_move(int32_t dx, int32_t dy, const float* A, const float* H, float q, float r, float q0,
+                       uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K, int64_t particle_offset,
+                       const float* x_prev, const float* m_prev, int64_t prev_stride, const int32_t* anc,
+                       const float* y_prev, const float* y, int32_t n_moves, float move_scale, float* x_out,
+                       float* m_out, float* logw, float* accepted, float* lse, int64_t K_total) {
+  okey key = {key0, key1};
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < K; ++i) {
+    const uint64_t gi = (uint64_t)(particle_offset + i);
+    const ostream st = stream_open(rng_mode, key, gi, 1u);
+    float xp[64], xn[64], mp[64], xq[64];
+    float nacc = 0.0f;
+    t_margin = 3.0e38f;
+    if (t > 0) {
+      int64_t a = anc ? anc[i] : i;
+      for (int d = 0; d < dx; ++d) xp[d] = x_prev[(int64_t)d * prev_stride + a];
+      for (int d = 0; d < dx; ++d) mp[d] = (t > 1 && m_prev) ? m_prev[(int64_t)d * prev_stride + a] : 0.0f;
+      const float sdp = t > 1 ? q : q0;
+      const ostream sm = stream_open(rng_mode, key, gi, 2u);
+      float cur = 0.0f;
+      for (int pass = 0; pass <= n_moves; ++pass) { /* pass 0 scores the current state */
+        const float* x = pass == 0 ? xp : xq;
+        if (pass > 0) for (int d = 0; d < dx; ++d) xq[d] = xp[d] + move_scale * stream_normal(&sm, (uint32_t)((pass - 1) * (dx + 2) + d));
+        float s2 = 0.0f;
+        for (int d = 0; d < dx; ++d) { float z = (x[d] - mp[d]) / sdp; s2 += z * z; }
+        for (int o = 0; o < dy; ++o) {
+          float m;
+          if (H) { float acc = 0.0f; for (int e = 0; e < dx; ++e) acc += H[o * dx + e] * x[e]; m = acc; } else m = x[o];
+          float z = (y_prev[o] - m) / r;
+          s2 += z * z;
+        }
+        const float lp = -0.5f * s2;
+        if (pass == 0) { cur = lp; continue; }
+        const float lu = logf(uniform_from_bits(elem_bits(&sm, (uint32_t)((pass - 1) * (dx + 2) + dx)), F32_TINY, 1.0f));
+        decide(lu, lp - cur);
+        if (lu < lp - cur) { for (int d = 0; d < dx; ++d) xp[d] = xq[d]; cur = lp; nacc += 1.0f; }
+      }
+    }
+    for (int d = 0; d < dx; ++d) {
+      float mu = 0.0f, sd = q0;
+      if (t > 0) {
+        float acc = 0.0f;
+        for (int e = 0; e < dx; ++e) acc += A[d * dx + e] * xp[e];
+        mu = acc;
+        sd = q;
+      }
+      m_out[(int64_t)d * K + i] = mu;
+      xn[d] = mu + sd * stream_normal(&st, (uint32_t)d);
+      x_out[(int64_t)d * K + i] = xn[d];
+    }
+    float lw = 0.0f;
+    for (int o = 0; o < dy; ++o) {
+      float m;
+      if (H) { float acc = 0.0f; for (int e = 0; e < dx; ++e) acc += H[o * dx + e] * xn[e]; m = acc; } else m = xn[o];
+      float z = y[o] / r - m / r;
+      lw += -0.5f * z * z - (HALF_LOG_2PI + logf(r));
+    }
+    logw[i] = lw;
+    if (accepted) accepted[i] = nacc;
+    if (g_margin_buf && i < g_margin_n) g_margin_buf[i] = t_margin;
+  }
+  if (lse) lse4(logw, K, K_total, lse);
+  return 0;
+}
+
 /* ---- HMC.edit (hmc.py:156-211) ---------------------------------------------------------------
  * score and its gradient w.r.t. the selected slots by a reverse sweep over the site list
  * (what jax.grad of gen_fn.assess computes, hmc.py:83-94).  All sites are evaluated at their
