@@ -275,6 +275,16 @@ GJX_DEV float gumbel_from_bits(uint32_t bits) {
   return -fast_log(-safe_log(u));
 }
 
+// digamma: recurrence up to x >= 6, then the asymptotic series (|error| < 1e-6 for x > 1e-3)
+GJX_DEV float digamma_f(float x) {
+  float acc = 0.0f;
+  for (int k = 0; k < 6; ++k) {
+    if (x < 6.0f) { acc -= fast_rcp(x); x += 1.0f; }
+  }
+  const float r = fast_rcp(x), r2 = r * r;
+  return acc + fast_log(x) - 0.5f * r - r2 * (0.0833333333f - r2 * (0.00833333333f - r2 * 0.00396825397f));
+}
+
 GJX_DEV float softplus(float x) { return fmaxf(x, 0.0f) + log1p_acc(fast_exp(-fabsf(x))); }
 GJX_DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 

@@ -27,8 +27,9 @@ struct HmcArgs {
   float* ws_old;  // [n_slots][n] pre-move values
 };
 
-// gradient of elem_logpdf w.r.t. the value and the parameters; g[0..3] = d/d(a, b, c, d).  NaN marks a parameter
-// gradient that would need digamma (shape parameters): HMC through such a parameter is unsupported.
+// gradient of elem_logpdf w.r.t. the value and the parameters; g[0..3] = d/d(a, b, c, d).  Shape parameters (gamma / beta
+// concentrations, student-t / chi2 degrees of freedom, inverse-gamma concentration) go through digamma, so HMC over
+// hierarchical shape parameters works as it does under jax.grad (hmc.py:70-96).
 GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, float& dx, float* gpar) {
   float da = 0.0f, db = 0.0f, dc = 0.0f, dd = 0.0f;
   dx = 0.0f;
@@ -38,7 +39,9 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
       const float rc = fast_rcp(c);
       const float y = (x - b) * rc;
       const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
-      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc; da = __builtin_nanf("");
+      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc;
+      da = -0.5f * log1p_acc(y * y * fast_rcp(a)) + 0.5f * (a + 1.0f) * y * y * fast_rcp(a * (a + y * y)) - 0.5f * fast_rcp(a) +
+           0.5f * (digamma_f(0.5f * (a + 1.0f)) - digamma_f(0.5f * a));
       done(); return;
     }
     case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
@@ -70,7 +73,7 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
     }
     case GJX_INVERSE_GAMMA: {
       const float rx = fast_rcp(x);
-      dx = -(a + 1.0f) * rx + b * rx * rx; db = a * fast_rcp(b) - rx; da = __builtin_nanf("");
+      dx = -(a + 1.0f) * rx + b * rx * rx; db = a * fast_rcp(b) - rx; da = fast_log(b) - digamma_f(a) - fast_log(x);
       done(); return;
     }
     case GJX_WEIBULL: {
@@ -85,7 +88,7 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
       dx = -z * rb * fast_rcp(x * (1.0f - x)) - fast_rcp(x) + fast_rcp(1.0f - x); da = z * rb; db = (z * z - 1.0f) * rb;
       done(); return;
     }
-    case GJX_CHI2: dx = (0.5f * a - 1.0f) * fast_rcp(x) - 0.5f; da = __builtin_nanf(""); done(); return;
+    case GJX_CHI2: dx = (0.5f * a - 1.0f) * fast_rcp(x) - 0.5f; da = 0.5f * (fast_log(x) - kLn2 - digamma_f(0.5f * a)); done(); return;
     default: break;
   }
   switch (kind) {
@@ -103,8 +106,13 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
     case GJX_LAPLACE: { const float s = (float)((x > a) - (x < a)); const float rb = fast_rcp(b); dx = -s * rb; da = s * rb; db = fabsf(x - a) * rb * rb - rb; break; }
     case GJX_CAUCHY: { const float rb = fast_rcp(b); const float z = (x - a) * rb; const float g = 2.0f * z * fast_rcp(1.0f + z * z); dx = -g * rb; da = g * rb; db = (g * z - 1.0f) * rb; break; }
     case GJX_LOG_NORMAL: { const float lx = fast_log(x); const float rb = fast_rcp(b); const float z = (lx - a) * rb; dx = (-z * rb - 1.0f) * fast_rcp(x); da = z * rb; db = (z * z - 1.0f) * rb; break; }
-    case GJX_BETA: dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x); da = __builtin_nanf(""); db = __builtin_nanf(""); break;
-    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = __builtin_nanf(""); db = a * fast_rcp(b) - x; break;
+    case GJX_BETA: {
+      const float pab = digamma_f(a + b);
+      dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x);
+      da = fast_log(x) - digamma_f(a) + pab; db = log1p_acc(-x) - digamma_f(b) + pab;
+      break;
+    }
+    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = fast_log(b) + fast_log(x) - digamma_f(a); db = a * fast_rcp(b) - x; break;
     case GJX_UNIFORM: { const float r = fast_rcp(b - a); da = r; db = -r; break; }
     default: break;
   }

@@ -940,6 +940,14 @@ int gjxo_ssm_step_move(int32_t dx, int32_t dy, const float* A, const float* H, f
  * score and its gradient w.r.t. the selected slots by a reverse sweep over the site list
  * (what jax.grad of gen_fn.assess computes, hmc.py:83-94).  All sites are evaluated at their
  * current value (assess semantics: every site constrained, static.py:297-321). */
+/* digamma in double precision: recurrence to x >= 10, then the asymptotic series */
+static double digamma_d(double x) {
+  double acc = 0.0;
+  while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
+  const double r = 1.0 / x, r2 = r * r;
+  return acc + log(x) - 0.5 * r - r2 * (1.0 / 12 - r2 * (1.0 / 120 - r2 * (1.0 / 252 - r2 * (1.0 / 240 - r2 / 132))));
+}
+
 static void dlogpdf(int kind, float x, float a, float b, float* dx, float* da, float* db) {
   switch (kind) {
     case GJX_NORMAL:
@@ -955,14 +963,18 @@ static void dlogpdf(int kind, float x, float a, float b, float* dx, float* da, f
     case GJX_LAPLACE: { float s = (x > a) - (x < a); *dx = -s / b; *da = s / b; *db = fabsf(x - a) / (b * b) - 1.0f / b; return; }
     case GJX_CAUCHY: { float z = (x - a) / b; float g = 2.0f * z / (1.0f + z * z); *dx = -g / b; *da = g / b; *db = (g * z - 1.0f) / b; return; }
     case GJX_LOG_NORMAL: { float lx = logf(x); float z = (lx - a) / b; *dx = (-z / b - 1.0f) / x; *da = z / b; *db = (z * z - 1.0f) / b; return; }
-    case GJX_BETA: *dx = (a - 1.0f) / x - (b - 1.0f) / (1.0f - x); *da = NAN; *db = NAN; return;
-    case GJX_GAMMA: *dx = (a - 1.0f) / x - b; *da = NAN; *db = x == x ? (a / b - x) : NAN; return;
+    case GJX_BETA:
+      *dx = (a - 1.0f) / x - (b - 1.0f) / (1.0f - x);
+      *da = (float)(log((double)x) - digamma_d(a) + digamma_d((double)a + b));
+      *db = (float)(log1p(-(double)x) - digamma_d(b) + digamma_d((double)a + b));
+      return;
+    case GJX_GAMMA: *dx = (a - 1.0f) / x - b; *da = (float)(log((double)b) + log((double)x) - digamma_d(a)); *db = a / b - x; return;
     case GJX_UNIFORM: *dx = 0.0f; *da = 1.0f / (b - a); *db = -1.0f / (b - a); return;
     default: *dx = *da = *db = 0.0f;
   }
 }
 
-/* gradients of the four-parameter forms; g[0..3] = d/d(a,b,c,d); NAN where a digamma would be needed */
+/* gradients of the four-parameter forms; g[0..3] = d/d(a,b,c,d) */
 static void dlogpdf4(int kind, float x, float a, float b, float c, float d, float* dx, float* g) {
   g[0] = g[1] = g[2] = g[3] = 0.0f;
   *dx = 0.0f;
@@ -970,7 +982,9 @@ static void dlogpdf4(int kind, float x, float a, float b, float c, float d, floa
     case GJX_STUDENT_T: {
       float y = (x - b) / c;
       float w = (a + 1.0f) * y / (a + y * y);
-      *dx = -w / c; g[1] = w / c; g[2] = (w * y - 1.0f) / c; g[0] = NAN;
+      *dx = -w / c; g[1] = w / c; g[2] = (w * y - 1.0f) / c;
+      g[0] = (float)(-0.5 * log1p((double)y * y / a) + 0.5 * (a + 1.0) * y * y / (a * (a + (double)y * y)) - 0.5 / a +
+                     0.5 * (digamma_d(0.5 * (a + 1.0)) - digamma_d(0.5 * a)));
       return;
     }
     case GJX_TRUNCATED_NORMAL: {
@@ -984,10 +998,10 @@ static void dlogpdf4(int kind, float x, float a, float b, float c, float d, floa
     case GJX_GEOMETRIC: g[0] = 1.0f / a - x / (1.0f - a); return;
     case GJX_GUMBEL: { float z = (x - a) / b; float e1 = 1.0f - expf(-z); *dx = -e1 / b; g[0] = e1 / b; g[1] = (e1 * z - 1.0f) / b; return; }
     case GJX_HALF_CAUCHY: { float z = (x - a) / b; float q = 2.0f * z / (1.0f + z * z); *dx = -q / b; g[0] = q / b; g[1] = (q * z - 1.0f) / b; return; }
-    case GJX_INVERSE_GAMMA: *dx = -(a + 1.0f) / x + b / (x * x); g[1] = a / b - 1.0f / x; g[0] = NAN; return;
+    case GJX_INVERSE_GAMMA: *dx = -(a + 1.0f) / x + b / (x * x); g[1] = a / b - 1.0f / x; g[0] = (float)(log((double)b) - digamma_d(a) - log((double)x)); return;
     case GJX_WEIBULL: { float lr = logf(x / b); float t = expf(a * lr); *dx = ((a - 1.0f) - a * t) / x; g[1] = a * (t - 1.0f) / b; g[0] = 1.0f / a + lr * (1.0f - t); return; }
     case GJX_LOGIT_NORMAL: { float z = (logf(x) - log1pf(-x) - a) / b; *dx = -z / b / (x * (1.0f - x)) - 1.0f / x + 1.0f / (1.0f - x); g[0] = z / b; g[1] = (z * z - 1.0f) / b; return; }
-    case GJX_CHI2: *dx = (0.5f * a - 1.0f) / x - 0.5f; g[0] = NAN; return;
+    case GJX_CHI2: *dx = (0.5f * a - 1.0f) / x - 0.5f; g[0] = (float)(0.5 * (log((double)x) - 0.6931471805599453 - digamma_d(0.5 * a))); return;
     default: return;
   }
 }

@@ -98,3 +98,19 @@ def zoo2(rng=A.RNG_FLAT, observed=()):
     obs_vals = dict(n9=0.4, di=[0.2, 0.3, 0.5], po=2.0, tn=0.7)
     modes = {a: A.MODE_OBS_TAB for a in observed}
     return PackedProgram(sl, modes, {a: obs_vals[a] for a in observed}, rng_mode=rng)
+
+
+def shape_hierarchy(rng=A.RNG_FLAT):
+    """a model whose SHAPE parameters are latent (gradients through them need digamma): log-normal hyper-parameters
+    feeding gamma / beta concentrations, student-t / chi2 degrees of freedom and the inverse-gamma concentration"""
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    sl = SiteList()
+    sl.add("la", A.NORMAL, [0.3, 0.25])
+    sl.add("lb", A.NORMAL, [0.1, 0.25])
+    a, b = Param.value("la", xf=A.XF_EXP), Param.value("lb", xf=A.XF_EXP)
+    sl.add("g", A.GAMMA, [a, b])
+    sl.add("be", A.BETA, [a, b])
+    sl.add("t", A.STUDENT_T, [Param.value("la", xf=A.XF_SOFTPLUS), 0.2, b])
+    sl.add("ig", A.INVERSE_GAMMA, [a, 1.5])
+    sl.add("c2", A.CHI2, [Param.value("lb", xf=A.XF_SOFTPLUS)])
+    return sl

@@ -155,6 +155,25 @@ def test_zoo2_gradient_parity(K_, oracle):
     np.testing.assert_allclose(_np(gg)[big], go[big], rtol=1e-2)
 
 
+def test_shape_parameter_gradient_parity_and_hmc(K_, oracle):
+    """digamma-based gradients w.r.t. latent shape parameters: device == oracle, and an HMC move over the
+    hyper-parameters of a gamma / beta / student-t hierarchy runs (finite, energy error small at small eps)"""
+    import torch
+    sl = H.shape_hierarchy()
+    base = oracle.run_program(PackedProgram(sl), (3, 4), 2048)["choices"].astype(np.float32)
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=tuple(s.addr for s in sl.sites))
+    sg, gg = K_.score_grad(prog, torch.as_tensor(base).cuda())
+    so, go = oracle.score_grad(prog, base)
+    assert np.isfinite(_np(gg)).all()
+    np.testing.assert_allclose(_np(sg), so, rtol=3e-4, atol=1e-3)
+    big = np.abs(go) > 1e3
+    np.testing.assert_allclose(_np(gg)[~big], go[~big], rtol=3e-3, atol=3e-3)
+    prog_h = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=("la", "lb"))
+    out = K_.hmc(prog_h, (1, 2), torch.as_tensor(base).cuda(), 0.002, 20, False, False)
+    al = _np(out["alpha"])
+    assert np.isfinite(al).all() and np.abs(np.median(al)) < 0.05
+
+
 @pytest.mark.parametrize("rng", RNGS)
 def test_assess_and_reweight_parity(K_, oracle, rng):
     """all sites constrained per particle (assess / ChangeTarget, smc.py:378-391): logw = w + logw_in - sub"""

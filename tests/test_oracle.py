@@ -633,3 +633,27 @@ def test_masked_constraints_per_particle(oracle):
     prog0, _, _ = model.pack((), ChoiceMap.empty().at["y"].set(0.3), True)
     free = oracle.run_program(prog0, (4, 5), K)
     np.testing.assert_array_equal(out["choices"][0][~fx], free["choices"][0][~fx])
+
+
+def test_shape_parameter_gradients_by_finite_differences(oracle):
+    """d log p / d (gamma / beta concentration, student-t / chi2 degrees of freedom, inverse-gamma concentration) goes
+    through digamma; the reference gets it from jax.grad of gen_fn.assess (hmc.py:70-96).  Central differences of the
+    oracle's own score through the latent hyper-parameters."""
+    sl = H.shape_hierarchy()
+    sim = PackedProgram(sl)
+    base = oracle.run_program(sim, (3, 4), 200)["choices"].astype(np.float32)
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=tuple(s.addr for s in sl.sites))
+    sc, gr = oracle.score_grad(prog, base)
+    assert np.isfinite(gr).all()                       # no NaN placeholders left
+    for addr in ("la", "lb"):
+        slot = prog.slot_of[addr]
+        h = 1e-3
+        up, dn = base.copy(), base.copy()
+        up[slot] += h
+        dn[slot] -= h
+        su, _ = oracle.score_grad(prog, up)
+        sd, _ = oracle.score_grad(prog, dn)
+        fd = (su.astype(np.float64) - sd.astype(np.float64)) / (2 * h)
+        ok = np.abs(fd) < 200
+        assert ok.mean() > 0.9
+        np.testing.assert_allclose(gr[slot][ok], fd[ok], rtol=0.03, atol=0.05, err_msg=addr)
