@@ -7,6 +7,7 @@
 // Algorithmic HBM bytes per particle-step: 4 (ancestor) + 4*dx (gather) + 4*dx (state) + 4 (logw).
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include "gjx_scan.h"
 
 namespace gjx {
 
@@ -173,6 +174,220 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// One launch per filter step (t >= 1): resample + propagate + reweight with ONE rendezvous.
+//
+// The two-launch step (k_resample_fused, k_ssm_step) is latency-bound at K = 2^18: 10 us + 10 us for 23 MB.  Here the
+// block that OWNS a particle also propagates its children: after the tile scan and the all-gather of the tile totals
+// (the one rendezvous) every lane knows the run of output slots its particle owns, the block's runs together are one
+// contiguous stretch of slots, their ancestors are staged in LDS, and the block's lanes walk that stretch slot by slot:
+// gather x_{t-1} of the ancestor (the block's own tile: its cache lines), draw with the stream of the SLOT's global
+// index, write x_t and log w_t of the slot.  Ancestors never go to memory (unless asked for), nobody waits for another
+// block's ancestors, and the previous step's {max, sumexp} block partials are reduced in the prologue as before.
+// Every slot is produced exactly once, by the owner of its ancestor; values are the same bits as the two-launch step
+// (same ancestors, same streams), only the LSE partials are grouped by producing block instead of by slot tile.
+// A block whose particles own more slots than the staging window (collapsed weights) walks its stretch window by
+// window: correct, just not balanced.
+// ------------------------------------------------------------------------------------------------------------
+struct SsmFusedArgs {
+  SsmArgs s;                       // model, key, K, x_prev / x_out, y, t; logw = output of THIS step
+  const float* logw_prev;          // [K] log-weights of step t-1
+  const float* partials_prev;      // per-block {max, sumexp} pairs of step t-1
+  int n_partials_prev;
+  float* lse_prev_out;             // [4] finished record of step t-1 (block 0)
+  float log_k_total_prev;
+  double u;
+  int32_t* ancestors;              // [K] or NULL
+  unsigned long long* agg;
+  unsigned* ctrl;
+  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block
+};
+
+template <int RNG, int DX>
+__global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
+#define GJX_STAMP(n) do { if (f.timeline && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GJX_STAMP(0);
+  const SsmArgs& a = f.s;
+  constexpr int kWin = 2048;
+  __shared__ float fred[16];
+  __shared__ uint64_t wsum[4], red2[8];
+  __shared__ int64_t jlast[256];
+  __shared__ int64_t s_run[2];
+  __shared__ int32_t stage[kWin];
+  unsigned epoch;
+  const unsigned long long tag = grid_tag(f.ctrl, &epoch);
+  const int64_t K = a.K;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float xv[1];
+  xv[0] = i < K ? f.logw_prev[i] : 0.0f;
+  float sm_sum;
+  const float mx = block_ref_max(2, f.partials_prev, f.n_partials_prev, fred, &sm_sum);
+  if (f.lse_prev_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
+    f.lse_prev_out[0] = mx; f.lse_prev_out[1] = sm_sum; f.lse_prev_out[2] = l; f.lse_prev_out[3] = l - f.log_k_total_prev;
+  }
+  GJX_STAMP(1);
+  // ---- tile scan, all-gather of the tile totals ----
+  const uint64_t qv = i < K ? weight_q(xv, 0, 1, mx) : 0;
+  uint64_t inc = qv;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+    if ((threadIdx.x & 63) >= o) inc += up;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint64_t off = inc - qv;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (threadIdx.x == 0) grid_publish(f.agg, tag, tile_total);
+  GJX_STAMP(2);
+  uint64_t pre = 0, tot = 0;
+  grid_gather(f.agg, tag, f.ctrl, [&](int b, unsigned long long val) {
+    tot += val;
+    if (b < (int)blockIdx.x) pre += val;
+  });
+  pre = wave_sum_u64(pre);
+  tot = wave_sum_u64(tot);
+  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6] = pre; red2[4 + (threadIdx.x >> 6)] = tot; }
+  __syncthreads();
+  GJX_STAMP(3);
+  const uint64_t prefix = red2[0] + red2[1] + red2[2] + red2[3];
+  const uint64_t total = red2[4] + red2[5] + red2[6] + red2[7];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(&f.ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (total == 0) __hip_atomic_fetch_or(&f.ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- this particle's run of output slots [lo, hi) ----
+  const int64_t N = K;
+  int64_t lo = 0, hi = 0;
+  if (total > 0) {
+    const double step = (double)total / (double)N, inv_step = (double)N / (double)total;
+    const uint64_t c_cur = prefix + off + qv;
+    const int64_t j_mine = slots_below(c_cur, f.u, step, inv_step, total, N);
+    jlast[threadIdx.x] = j_mine;
+    if (threadIdx.x == 0) s_run[0] = slots_below(prefix, f.u, step, inv_step, total, N);
+    __syncthreads();
+    lo = threadIdx.x > 0 ? jlast[threadIdx.x - 1] : s_run[0];
+    hi = j_mine > N ? N : j_mine;
+    if (qv == 0) hi = lo;
+    if (threadIdx.x == 255) s_run[1] = hi > lo ? hi : lo;
+    __syncthreads();
+  } else {   // dead collection: every slot keeps its own particle (identity), flagged above
+    lo = i < K ? i : 0; hi = i < K ? i + 1 : 0;
+    if (threadIdx.x == 0) s_run[0] = (int64_t)blockIdx.x * 256;
+    if (threadIdx.x == 255) s_run[1] = ((int64_t)blockIdx.x * 256 + 256) < K ? ((int64_t)blockIdx.x * 256 + 256) : K;
+    __syncthreads();
+  }
+  // the block's stretch ends where its last particle WITH offspring ends: take the maximum over the lanes
+  {
+    int64_t h = hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int64_t v = __shfl_xor((long long)h, o, 64); h = v > h ? v : h; }
+    if ((threadIdx.x & 63) == 0) jlast[threadIdx.x >> 6] = h;    // jlast is free again after the barrier above
+    __syncthreads();
+    if (threadIdx.x == 0) { int64_t m = jlast[0]; for (int w = 1; w < 4; ++w) m = jlast[w] > m ? jlast[w] : m; s_run[1] = m > s_run[0] ? m : s_run[0]; }
+    __syncthreads();
+  }
+  const int64_t run_lo = s_run[0], run_hi = s_run[1];
+  GJX_STAMP(4);
+  // ---- walk the stretch: stage ancestors, then one lane per slot ----
+  key2 sk = a.key;
+  float tmax = -INFINITY, tsum = 0.0f;
+  const float sd = a.q;
+  const float rr = fast_rcp(a.r);
+  const float lconst = -(float)a.dy * (kHalfLog2Pi + fast_log(a.r));
+  for (int64_t w0 = run_lo; w0 < run_hi; w0 += kWin) {
+    const int64_t w1 = w0 + kWin < run_hi ? w0 + kWin : run_hi;
+    __syncthreads();
+    {
+      const int64_t l2 = lo > w0 ? lo : w0, h2 = hi < w1 ? hi : w1;
+      for (int64_t j = l2; j < h2; ++j) stage[j - w0] = (int32_t)threadIdx.x;
+    }
+    __syncthreads();
+    for (int64_t j = w0 + threadIdx.x; j < w1; j += 256) {
+      const int64_t src = (int64_t)blockIdx.x * 256 + stage[j - w0];
+      if (f.ancestors) f.ancestors[j] = (int32_t)src;
+      const uint64_t gidx = (uint64_t)(a.offset + j);
+      key2 skj = sk;
+      if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(a.key, gidx), 1u);
+      else if (gidx >> 32) skj = threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
+      float xp[DX], xn[DX];
+#pragma unroll
+      for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
+#pragma unroll
+      for (int d = 0; d < DX; ++d) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < DX; ++e) acc = fmaf(a.A[d * DX + e], xp[e], acc);
+        xn[d] = acc;
+      }
+      if (RNG == GJX_RNG_FLAT) {
+        constexpr int NE = DX + (DX & 1);
+        constexpr int NB = GJX_FLAT_BLOCKS(NE);
+        uint32_t w[2 * NB];
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+          const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+          w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+        }
+#pragma unroll
+        for (int d0 = 0; d0 < DX; d0 += 2) {
+          float n0, n1;
+          box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
+          xn[d0] = fmaf(sd, n0, xn[d0]);
+          if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int d0 = 0; d0 < DX; ++d0) {
+          const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
+          xn[d0] = fmaf(sd, normal_from_bits_fast(h0.a ^ h0.b), xn[d0]);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < DX; ++d) a.x_out[(int64_t)d * K + j] = xn[d];
+      float qsum = 0.0f;
+      if (a.H) {
+        for (int o = 0; o < a.dy; ++o) {
+          float m = 0.0f;
+#pragma unroll
+          for (int e = 0; e < DX; ++e) m = fmaf(a.H[o * DX + e], xn[e], m);
+          const float z = (a.y[o] - m) * rr;
+          qsum = fmaf(z, z, qsum);
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < DX; ++d) { const float z = (a.y[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
+      }
+      const float lw = fmaf(-0.5f, qsum, lconst);
+      a.logw[j] = lw;
+      const float nm = fmaxf(tmax, lw);
+      tsum = tsum * fast_exp(tmax - nm) + fast_exp(lw - nm);
+      tmax = nm;
+    }
+  }
+  GJX_STAMP(5);
+  // ---- this block's {max, sumexp} over the slots it produced ----
+  {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float wm = wave_max(tmax);
+    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+    __syncthreads();
+    if (lane == 0) { fred[wid] = wm; fred[4 + wid] = ws; }
+    __syncthreads();
+    float bm = fred[0];
+    for (int w2 = 1; w2 < 4; ++w2) bm = fmaxf(bm, fred[w2]);
+    float bsum = 0.0f;
+    for (int w2 = 0; w2 < 4; ++w2) bsum += bm > -INFINITY ? fred[4 + w2] * fast_exp(fred[w2] - bm) : 0.0f;
+    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, fred);
+    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);
+  }
+  GJX_STAMP(6);
+#undef GJX_STAMP
+}
+
 }  // namespace gjx
 
 using namespace gjx;
@@ -298,6 +513,67 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
   char* ws2 = ws1 + need;
   uint64_t* bt = (uint64_t*)(ws2 + need);
   uint32_t k[2] = {key0, key1};
+  // one launch per step when the grid of K / 256 blocks is co-resident (k_ssm_fused_step); GJX_SSM_TWO_LAUNCH=1 keeps
+  // the resample + step pair
+  const int64_t nblk = (K + 255) / 256;
+  const void* fused_fn = nullptr;
+  if (!getenv("GJX_SSM_TWO_LAUNCH") || atoi(getenv("GJX_SSM_TWO_LAUNCH")) == 0) {
+    const bool jax = rng_mode == GJX_RNG_JAX32;
+    switch (m->dx) {
+      case 2: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 2> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 2>; break;
+      case 4: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 4> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 4>; break;
+      case 8: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 8> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 8>; break;
+      case 16: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 16> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 16>; break;
+      default: break;
+    }
+    if (fused_fn && (nblk > gjx_coresident_blocks(fused_fn, 256, 0) || 256 + 16 * (size_t)nblk > need)) fused_fn = nullptr;
+  }
+  if (fused_fn) {
+    hipStream_t st = (hipStream_t)stream;
+    float* lw_alt = (float*)cum;                     // the prefix-sum buffer is free on this path: second log-weight buffer
+    auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };   // the last step writes the caller's logw
+    auto part_of = [&](int t) { return (unsigned long long*)(ws1 + kWsHeaderBytes) + (size_t)(t & 1) * nblk; };
+    for (int t = 0; t < T; ++t) {
+      uint32_t kt[2], kp[2], kr[2], b[2];
+      host_threefry(k[0], k[1], 0u, (uint32_t)t, kt);
+      k[0] = kt[0]; k[1] = kt[1];
+      host_threefry(k[0], k[1], 0u, 0u, kp);
+      host_threefry(k[0], k[1], 0u, 1u, kr);
+      float* x_out = (t & 1) ? x_b : x_a;
+      const float* x_prev = (t & 1) ? x_a : x_b;
+      SsmArgs a;
+      a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev + (size_t)t * m->dy; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = t;
+      a.key = key2{kp[0], kp[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
+      a.x_prev = t > 0 ? x_prev : nullptr; a.anc = nullptr; a.x_out = x_out; a.logw = lw_of(t);
+      a.partials = part_of(t); a.ticket = (unsigned*)ws1; a.lse = t == T - 1 ? lse_steps + 4 * (size_t)t : nullptr;
+      a.log_k_total = (float)log((double)K);
+      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+      if (t == 0) {
+        const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
+        if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
+        GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
+        continue;
+      }
+      host_threefry(kr[0], kr[1], 0u, 0u, b);
+      SsmFusedArgs f;
+      f.s = a;
+      f.logw_prev = lw_of(t - 1);
+      f.partials_prev = (const float*)part_of(t - 1);
+      f.n_partials_prev = (int)nblk;
+      f.lse_prev_out = lse_steps + 4 * (size_t)(t - 1);
+      f.log_k_total_prev = (float)log((double)K);
+      f.u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
+      f.ancestors = t == T - 1 ? ancestors : nullptr;
+      f.agg = (unsigned long long*)(ws2 + kWsHeaderBytes);
+      f.ctrl = (unsigned*)ws2 + 8;
+      f.timeline = nullptr;
+      if (const char* e = getenv("GJX_STEP_TIMELINE_PTR")) f.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+      void* args[] = {&f};
+      const hipError_t e = hipLaunchKernel(fused_fn, dim3((unsigned)nblk), dim3(256), args, 0, st);
+      if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(fused step)");
+    }
+    return GJX_OK;
+  }
   for (int t = 0; t < T; ++t) {
     uint32_t kt[2], kp[2], kr[2], b[2];
     host_threefry(k[0], k[1], 0u, (uint32_t)t, kt);
