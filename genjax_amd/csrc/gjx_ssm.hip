@@ -178,17 +178,16 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // One launch per filter step (t >= 1): resample + propagate + reweight with ONE rendezvous.
 //
-// The two-launch step (k_resample_fused, k_ssm_step) is latency-bound at K = 2^18: 10 us + 10 us for 23 MB.  Here the
-// block that OWNS a particle also propagates its children: after the tile scan and the all-gather of the tile totals
-// (the one rendezvous) every lane knows the run of output slots its particle owns, the block's runs together are one
-// contiguous stretch of slots, their ancestors are staged in LDS, and the block's lanes walk that stretch slot by slot:
-// gather x_{t-1} of the ancestor (the block's own tile: its cache lines), draw with the stream of the SLOT's global
-// index, write x_t and log w_t of the slot.  Ancestors never go to memory (unless asked for), nobody waits for another
-// block's ancestors, and the previous step's {max, sumexp} block partials are reduced in the prologue as before.
-// Every slot is produced exactly once, by the owner of its ancestor; values are the same bits as the two-launch step
-// (same ancestors, same streams), only the LSE partials are grouped by producing block instead of by slot tile.
-// A block whose particles own more slots than the staging window (collapsed weights) walks its stretch window by
-// window: correct, just not balanced.
+// The two-launch step (k_resample_fused, k_ssm_step) is latency-bound at K = 2^18: 10 us + 10 us for 23 MB.  Here
+// block b scans its own tile of fixed-point weights, the tile totals are all-gathered (the one rendezvous), and then the
+// block is the CONSUMER of output slots [256 b, 256 b + 256): every lane computes the comb threshold T_j of its slot,
+// finds the source tile by binary search in the prefix of the tile totals (LDS), the block re-scans the few distinct
+// source tiles its 256 thresholds fall into (their log-weights come from L2; one wave per tile), and each lane finds its
+// ancestor by binary search in that tile's cumulative weights.  Ancestors never go to memory (unless asked for), the
+// propagation is one slot per lane — balanced whatever the weights are — and the step's {max, sumexp} block partials
+// are grouped by slot tile exactly as in k_ssm_step.  Same ancestors as the slot-run expansion of k_resample_fused:
+// particle i owns slot j  <=>  cum_excl(i) <= T_j < cum_incl(i)  (slots_below counts the T_j below a boundary).
+// A window whose thresholds touch more than kChunk distinct tiles (collapsed weights) walks them kChunk at a time.
 // ------------------------------------------------------------------------------------------------------------
 struct SsmFusedArgs {
   SsmArgs s;                       // model, key, K, x_prev / x_out, y, t; logw = output of THIS step
@@ -204,23 +203,29 @@ struct SsmFusedArgs {
   unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block
 };
 
+constexpr int kSsmFusedMaxTiles = 2048;
+
 template <int RNG, int DX>
 __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
 #define GJX_STAMP(n) do { if (f.timeline && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GJX_STAMP(0);
   const SsmArgs& a = f.s;
-  constexpr int kWin = 2048;
+  constexpr int kChunk = 4;        // source tiles re-scanned together: one per wave
   __shared__ float fred[16];
-  __shared__ uint64_t wsum[4], red2[8];
-  __shared__ int64_t jlast[256];
-  __shared__ int64_t s_run[2];
-  __shared__ int32_t stage[kWin];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t P[kSsmFusedMaxTiles + 1];   // P[t] = total weight of tiles < t; P[nb] = grand total
+  __shared__ uint64_t cumL[kChunk * 256];         // inclusive cumulative weights of the loaded tiles (absolute)
+  __shared__ int32_t s_tof[256], s_tiles[256];
+  __shared__ int s_cnt[4];
   unsigned epoch;
   const unsigned long long tag = grid_tag(f.ctrl, &epoch);
   const int64_t K = a.K;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nb = (int)gridDim.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;     // the slot this lane produces (and the particle it scans)
+  const bool active = j < K;
   float xv[1];
-  xv[0] = i < K ? f.logw_prev[i] : 0.0f;
+  xv[0] = active ? f.logw_prev[j] : 0.0f;
   float sm_sum;
   const float mx = block_ref_max(2, f.partials_prev, f.n_partials_prev, fred, &sm_sum);
   if (f.lse_prev_out && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -228,163 +233,178 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
     f.lse_prev_out[0] = mx; f.lse_prev_out[1] = sm_sum; f.lse_prev_out[2] = l; f.lse_prev_out[3] = l - f.log_k_total_prev;
   }
   GJX_STAMP(1);
-  // ---- tile scan, all-gather of the tile totals ----
-  const uint64_t qv = i < K ? weight_q(xv, 0, 1, mx) : 0;
-  uint64_t inc = qv;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-    if ((threadIdx.x & 63) >= o) inc += up;
+  // ---- own tile total -> all-gather ----
+  {
+    const uint64_t qv = active ? weight_q(xv, 0, 1, mx) : 0;
+    const uint64_t wt = wave_sum_u64(qv);
+    if (lane == 0) wsum[wid] = wt;
+    __syncthreads();
+    if (threadIdx.x == 0) grid_publish(f.agg, tag, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   }
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  uint64_t off = inc - qv;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
-  const uint64_t tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  if (threadIdx.x == 0) grid_publish(f.agg, tag, tile_total);
   GJX_STAMP(2);
-  uint64_t pre = 0, tot = 0;
-  grid_gather(f.agg, tag, f.ctrl, [&](int b, unsigned long long val) {
-    tot += val;
-    if (b < (int)blockIdx.x) pre += val;
-  });
-  pre = wave_sum_u64(pre);
-  tot = wave_sum_u64(tot);
-  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6] = pre; red2[4 + (threadIdx.x >> 6)] = tot; }
+  grid_gather(f.agg, tag, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
+  if (threadIdx.x == 0) P[0] = 0;
   __syncthreads();
+  // ---- prefix of the tile totals, in place: lane t owns entries [t per, (t+1) per) ----
+  {
+    const int per = (nb + 255) >> 8;
+    const int e0 = threadIdx.x * per, e1 = (e0 + per) < nb ? (e0 + per) : nb;
+    uint64_t loc = 0;
+    for (int e = e0; e < e1; ++e) loc += P[e + 1];
+    uint64_t inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    __syncthreads();            // wsum of the publish above has been read by thread 0
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint64_t run = inc - loc;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+    __syncthreads();
+  }
+  const uint64_t total = P[nb];
   GJX_STAMP(3);
-  const uint64_t prefix = red2[0] + red2[1] + red2[2] + red2[3];
-  const uint64_t total = red2[4] + red2[5] + red2[6] + red2[7];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     __hip_atomic_store(&f.ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (total == 0) __hip_atomic_fetch_or(&f.ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ---- this particle's run of output slots [lo, hi) ----
-  const int64_t N = K;
-  int64_t lo = 0, hi = 0;
-  if (total > 0) {
-    const double step = (double)total / (double)N, inv_step = (double)N / (double)total;
-    const uint64_t c_cur = prefix + off + qv;
-    const int64_t j_mine = slots_below(c_cur, f.u, step, inv_step, total, N);
-    jlast[threadIdx.x] = j_mine;
-    if (threadIdx.x == 0) s_run[0] = slots_below(prefix, f.u, step, inv_step, total, N);
-    __syncthreads();
-    lo = threadIdx.x > 0 ? jlast[threadIdx.x - 1] : s_run[0];
-    hi = j_mine > N ? N : j_mine;
-    if (qv == 0) hi = lo;
-    if (threadIdx.x == 255) s_run[1] = hi > lo ? hi : lo;
-    __syncthreads();
-  } else {   // dead collection: every slot keeps its own particle (identity), flagged above
-    lo = i < K ? i : 0; hi = i < K ? i + 1 : 0;
-    if (threadIdx.x == 0) s_run[0] = (int64_t)blockIdx.x * 256;
-    if (threadIdx.x == 255) s_run[1] = ((int64_t)blockIdx.x * 256 + 256) < K ? ((int64_t)blockIdx.x * 256 + 256) : K;
-    __syncthreads();
-  }
-  // the block's stretch ends where its last particle WITH offspring ends: take the maximum over the lanes
-  {
-    int64_t h = hi;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int64_t v = __shfl_xor((long long)h, o, 64); h = v > h ? v : h; }
-    if ((threadIdx.x & 63) == 0) jlast[threadIdx.x >> 6] = h;    // jlast is free again after the barrier above
-    __syncthreads();
-    if (threadIdx.x == 0) { int64_t m = jlast[0]; for (int w = 1; w < 4; ++w) m = jlast[w] > m ? jlast[w] : m; s_run[1] = m > s_run[0] ? m : s_run[0]; }
-    __syncthreads();
-  }
-  const int64_t run_lo = s_run[0], run_hi = s_run[1];
-  GJX_STAMP(4);
-  // ---- walk the stretch: stage ancestors, then one lane per slot ----
-  key2 sk = a.key;
-  float tmax = -INFINITY, tsum = 0.0f;
-  const float sd = a.q;
-  const float rr = fast_rcp(a.r);
-  const float lconst = -(float)a.dy * (kHalfLog2Pi + fast_log(a.r));
-  for (int64_t w0 = run_lo; w0 < run_hi; w0 += kWin) {
-    const int64_t w1 = w0 + kWin < run_hi ? w0 + kWin : run_hi;
-    __syncthreads();
-    {
-      const int64_t l2 = lo > w0 ? lo : w0, h2 = hi < w1 ? hi : w1;
-      for (int64_t j = l2; j < h2; ++j) stage[j - w0] = (int32_t)threadIdx.x;
+  // ---- ancestor of slot j ----
+  int64_t src = j;               // dead collection (total == 0): every slot keeps its own particle, flagged above
+  if (total > 0) {               // block-uniform
+    const double step = (double)total / (double)K;
+    const uint64_t T = comb_threshold(active ? j : K - 1, f.u, step, total);
+    int lo = 0, hi = nb - 1;     // first tile t with P[t + 1] > T
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (P[mid + 1] > T) hi = mid; else lo = mid + 1;
     }
+    const int tile = lo;
+    s_tof[threadIdx.x] = tile;
     __syncthreads();
-    for (int64_t j = w0 + threadIdx.x; j < w1; j += 256) {
-      const int64_t src = (int64_t)blockIdx.x * 256 + stage[j - w0];
-      if (f.ancestors) f.ancestors[j] = (int32_t)src;
-      const uint64_t gidx = (uint64_t)(a.offset + j);
-      key2 skj = sk;
-      if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(a.key, gidx), 1u);
-      else if (gidx >> 32) skj = threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
-      float xp[DX], xn[DX];
+    // distinct source tiles of the window (tile is non-decreasing in the slot index)
+    const bool first = threadIdx.x == 0 || s_tof[threadIdx.x - 1] != tile;
+    const unsigned long long bal = __ballot(first);
+    if (lane == 0) s_cnt[wid] = __popcll(bal);
+    __syncthreads();
+    int kpos = __popcll(bal & ((2ull << lane) - 1ull)) - 1;      // index of this lane's tile in the distinct list
+    for (int w = 0; w < wid; ++w) kpos += s_cnt[w];
+    const int ntiles = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (first) s_tiles[kpos] = tile;
+    GJX_STAMP(4);
+    for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
+      __syncthreads();           // s_tiles written / previous chunk's cumL consumed
+      if (c0 + wid < ntiles) {   // wave-uniform: this wave re-scans tile s_tiles[c0 + wid], 4 particles per lane
+        const int tsrc = s_tiles[c0 + wid];
+        const int64_t p0 = (int64_t)tsrc * 256 + lane * 4;
+        float lw4[4];
+        if (p0 + 4 <= K) {
+          const float4 v = *(const float4*)(f.logw_prev + p0);
+          lw4[0] = v.x; lw4[1] = v.y; lw4[2] = v.z; lw4[3] = v.w;
+        } else {
 #pragma unroll
-      for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
+          for (int k = 0; k < 4; ++k) lw4[k] = p0 + k < K ? f.logw_prev[p0 + k] : -INFINITY;
+        }
+        uint64_t qi[4], sacc = 0;
 #pragma unroll
-      for (int d = 0; d < DX; ++d) {
-        float acc = 0.0f;
+        for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? weight_q(lw4, k, 1, mx) : 0; qi[k] = sacc; }
+        uint64_t inc = sacc;
 #pragma unroll
-        for (int e = 0; e < DX; ++e) acc = fmaf(a.A[d * DX + e], xp[e], acc);
-        xn[d] = acc;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+          if (lane >= o) inc += up;
+        }
+        const uint64_t base = P[tsrc] + (inc - sacc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cumL[wid * 256 + lane * 4 + k] = base + qi[k];
       }
-      if (RNG == GJX_RNG_FLAT) {
-        constexpr int NE = DX + (DX & 1);
-        constexpr int NB = GJX_FLAT_BLOCKS(NE);
-        uint32_t w[2 * NB];
-#pragma unroll
-        for (int h = 0; h < NB; ++h) {
-          const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
-          w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+      __syncthreads();
+      if (kpos >= c0 && kpos < c0 + kChunk) {
+        const uint64_t* cm = cumL + (kpos - c0) * 256;
+        int l2 = 0, h2 = 255;    // first particle p of the tile with cum_incl(p) > T
+        while (l2 < h2) {
+          const int mid = (l2 + h2) >> 1;
+          if (cm[mid] > T) h2 = mid; else l2 = mid + 1;
         }
-#pragma unroll
-        for (int d0 = 0; d0 < DX; d0 += 2) {
-          float n0, n1;
-          box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
-          xn[d0] = fmaf(sd, n0, xn[d0]);
-          if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
-        }
-      } else {
-#pragma unroll
-        for (int d0 = 0; d0 < DX; ++d0) {
-          const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
-          xn[d0] = fmaf(sd, normal_from_bits_fast(h0.a ^ h0.b), xn[d0]);
-        }
+        src = (int64_t)tile * 256 + l2;
       }
-#pragma unroll
-      for (int d = 0; d < DX; ++d) a.x_out[(int64_t)d * K + j] = xn[d];
-      float qsum = 0.0f;
-      if (a.H) {
-        for (int o = 0; o < a.dy; ++o) {
-          float m = 0.0f;
-#pragma unroll
-          for (int e = 0; e < DX; ++e) m = fmaf(a.H[o * DX + e], xn[e], m);
-          const float z = (a.y[o] - m) * rr;
-          qsum = fmaf(z, z, qsum);
-        }
-      } else {
-#pragma unroll
-        for (int d = 0; d < DX; ++d) { const float z = (a.y[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
-      }
-      const float lw = fmaf(-0.5f, qsum, lconst);
-      a.logw[j] = lw;
-      const float nm = fmaxf(tmax, lw);
-      tsum = tsum * fast_exp(tmax - nm) + fast_exp(lw - nm);
-      tmax = nm;
     }
+  } else {
+    GJX_STAMP(4);
   }
   GJX_STAMP(5);
-  // ---- this block's {max, sumexp} over the slots it produced ----
+  // ---- propagate + reweight slot j from its ancestor (k_ssm_step's arithmetic, same streams) ----
+  if (active && f.ancestors) f.ancestors[j] = (int32_t)src;
+  if (!active) src = 0;
+  const uint64_t gidx = (uint64_t)(a.offset + j);
+  key2 skj = a.key;
+  if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(a.key, gidx), 1u);
+  else if (gidx >> 32) skj = threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
+  const float sd = a.q;
+  const float rr = fast_rcp(a.r);
+  float xp[DX], xn[DX];
+#pragma unroll
+  for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
+#pragma unroll
+  for (int d = 0; d < DX; ++d) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < DX; ++e) acc = fmaf(a.A[d * DX + e], xp[e], acc);
+    xn[d] = acc;
+  }
+  if (f.timeline) { asm volatile("" :: "v"(xn[0])); GJX_STAMP(6); }
+  if (RNG == GJX_RNG_FLAT) {
+    constexpr int NE = DX + (DX & 1);
+    constexpr int NB = GJX_FLAT_BLOCKS(NE);
+    uint32_t w[2 * NB];
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+      const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+      w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+    }
+#pragma unroll
+    for (int d0 = 0; d0 < DX; d0 += 2) {
+      float n0, n1;
+      box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
+      xn[d0] = fmaf(sd, n0, xn[d0]);
+      if (d0 + 1 < DX) xn[d0 + 1] = fmaf(sd, n1, xn[d0 + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int d0 = 0; d0 < DX; ++d0) {
+      const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
+      xn[d0] = fmaf(sd, normal_from_bits_fast(h0.a ^ h0.b), xn[d0]);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) a.x_out[(int64_t)d * K + j] = xn[d];
+  }
+  if (f.timeline) { asm volatile("" :: "v"(xn[0])); GJX_STAMP(7); }
+  float qsum = 0.0f;
+  if (a.H) {
+    for (int o = 0; o < a.dy; ++o) {
+      float m = 0.0f;
+#pragma unroll
+      for (int e = 0; e < DX; ++e) m = fmaf(a.H[o * DX + e], xn[e], m);
+      const float z = (a.y[o] - m) * rr;
+      qsum = fmaf(z, z, qsum);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) { const float z = (a.y[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
+  }
+  const float lw = fmaf(-0.5f, qsum, -(float)a.dy * (kHalfLog2Pi + fast_log(a.r)));
+  if (active) a.logw[j] = lw;
   {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const float wm = wave_max(tmax);
-    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
-    __syncthreads();
-    if (lane == 0) { fred[wid] = wm; fred[4 + wid] = ws; }
-    __syncthreads();
-    float bm = fred[0];
-    for (int w2 = 1; w2 < 4; ++w2) bm = fmaxf(bm, fred[w2]);
-    float bsum = 0.0f;
-    for (int w2 = 0; w2 < 4; ++w2) bsum += bm > -INFINITY ? fred[4 + w2] * fast_exp(fred[w2] - bm) : 0.0f;
+    float bm, bsum;
+    block_lse_partial<256>(lw, active, fred, bm, bsum);
     if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, fred);
     else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);
   }
-  GJX_STAMP(6);
+  if (f.timeline && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();   // end (reuses slot 1)
 #undef GJX_STAMP
 }
 
@@ -526,7 +546,7 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       case 16: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 16> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 16>; break;
       default: break;
     }
-    if (fused_fn && (nblk > gjx_coresident_blocks(fused_fn, 256, 0) || 256 + 16 * (size_t)nblk > need)) fused_fn = nullptr;
+    if (fused_fn && (nblk > kSsmFusedMaxTiles || nblk > gjx_coresident_blocks(fused_fn, 256, 0) || 256 + 16 * (size_t)nblk > need)) fused_fn = nullptr;
   }
   if (fused_fn) {
     hipStream_t st = (hipStream_t)stream;
@@ -567,7 +587,6 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       f.agg = (unsigned long long*)(ws2 + kWsHeaderBytes);
       f.ctrl = (unsigned*)ws2 + 8;
       f.timeline = nullptr;
-      if (const char* e = getenv("GJX_STEP_TIMELINE_PTR")) f.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
       void* args[] = {&f};
       const hipError_t e = hipLaunchKernel(fused_fn, dim3((unsigned)nblk), dim3(256), args, 0, st);
       if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(fused step)");
