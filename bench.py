@@ -168,6 +168,17 @@ def run_gmm(args, rank, world, dev):
             fused_step = True
         except Exception:
             fused_step = False
+    # two launches per step: propagate+reweight, then resampling + gather in one co-resident launch (K <= 2^20 on a full
+    # MI355X; GJX_THREE_LAUNCH=1 keeps resample_indices + gather_rows)
+    two_launch = False
+    if not sharded and not fused_step and os.environ.get("GJX_THREE_LAUNCH", "0") != "1":
+        try:
+            kernels.run_program(prog, (0, 1), K, ws=ws, out=out, want_weight=False, want_lse=False)
+            kernels.resample_gather(out["logw"], 0.5, out["choices"], partials=(ws, n_part), lse_out=lse_rec, K_total=K_total,
+                                    out=rows, ws=ws2, allow_fallback=False)
+            two_launch = True
+        except Exception:
+            two_launch = False
     resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if sharded else None
 
     def step(i, timed):
@@ -192,8 +203,12 @@ def run_gmm(args, rank, world, dev):
             return step_out["lse"]
         if world == 1 and not sharded:
             # single GPU: the LSE reduction is finished by the prefix-sum kernels' prologue (no serial tail)
-            kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
-            kernels.gather_rows(out["choices"], anc, rows)
+            if two_launch:      # weights -> ancestors -> children in one launch (ancestors stay on chip)
+                kernels.resample_gather(out["logw"], u, out["choices"], partials=(ws, n_part), lse_out=lse_rec, K_total=K_total,
+                                        out=rows, ws=ws2, allow_fallback=False)
+            else:
+                kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
+                kernels.gather_rows(out["choices"], anc, rows)
             return lse_rec
         # sharded: 8-byte all-gather of per-rank {max, sumexp} (reduced in the prefix-sum prologue), 8-byte
         # all-gather of weight totals, device-side plan, local gather + all-to-all-v of the surplus children
@@ -232,8 +247,10 @@ def run_gmm(args, rank, world, dev):
     lml = float(lse[3])
     traffic = None
     tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")      # FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/README.md)
-    if os.path.exists(tp):
-        traffic = json.load(open(tp)).get(kernel_name)
+    if os.path.exists(tp):                                           # keys: rocprofv3 kernel names without "void " and blanks
+        want = "gjx::k_run_gmm_flat<%d,4,256," % D
+        traffic = next((v for k, v in json.load(open(tp)).items()
+                        if k.startswith(want) and k.endswith("true>") == bool(fused_step)), None)
     res = dict(
         metric="particle_steps_per_sec", value=K_total * args.steps / dt, unit="particle-steps/s",
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
@@ -247,7 +264,7 @@ def run_gmm(args, rank, world, dev):
                       kernel_us=kern_ms * 1e3, kernel_us_event_pair_around_call=bracket_us,
                       timing="HIP events attached to the kernel dispatch on %d steps spread over the timed region" % len(disp),
                       algorithmic_bytes_per_launch=algo_bytes,
-                      launches_per_step=1 if fused_step else 3,
+                      launches_per_step=1 if fused_step else (2 if two_launch else 3),
                       note=("the whole importance step is this one launch: propagate+reweight (76 B/particle), resampling (8), "
                             "gather of 17 rows (136); " if fused_step else "") +
                            "the propagate+reweight phase is bound by integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "gjx_run_partials_count": (C.c_int, [PP, i64, i64]),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
     "gjx_resample_indices": (C.c_int, [vp, i64, i32, vp, i32, f64, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),
+    "gjx_resample_gather": (C.c_int, [vp, i64, i32, vp, i32, f64, vp, i64, i32, vp, i64, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_resample_gather_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, i64, i32, vp, i64, vp, vp]),
     "gjx_resample_multinomial": (C.c_int, [vp, i64, vp, u32, u32, i64, i64, i64, vp, vp]),
     "gjx_gather_rows": (C.c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),

@@ -264,6 +264,255 @@ __global__ __launch_bounds__(256) void k_resample_fused(const float* __restrict_
   tile_scan_expand<ITEMS, false>(xv, mode, mx, i0, K, u, N, ancestors, cum_out, base_total_out, agg, tag, ctrl, epoch, true, sm);
 }
 
+// ------------------------------------------------------------------------------------------
+// One-launch resampling + gather for a single GPU (N = K): weights -> systematic ancestors -> rows of the children,
+// the ancestors never written to memory unless asked for.  Block b scans its own tile of 256 ITEMS fixed-point weights,
+// the tile totals are all-gathered (the one rendezvous, as in k_resample_fused), and then the block is the CONSUMER of
+// the output slots [b TILE, (b+1) TILE): each lane takes ITEMS consecutive slots, computes their comb thresholds T_j,
+// finds the source tile of each by binary search in the prefix of the tile totals (LDS), and the block re-scans the few
+// distinct source tiles its thresholds fall into (log-weights from L2, the next tile's loads in flight while the current
+// one is searched); ancestor = first particle of the tile with inclusive cumulative weight > T_j.  Same ancestors as
+// the slot-run expansion: particle i owns slot j  <=>  cum_excl(i) <= T_j < cum_incl(i).  Then the rows are copied,
+// ITEMS slots per lane (16-byte stores at ITEMS = 4).  Balanced whatever the weights are; a window that touches many
+// source tiles (collapsed weights) just loops longer.
+// ------------------------------------------------------------------------------------------
+constexpr int kGatherMaxTiles = 1024;
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict__ x, int64_t K, int mode,
+                                                        const float* lse, int n_partials, float* lse_out,
+                                                        float log_k_total, double u, const float* __restrict__ src,
+                                                        int64_t src_stride, int rows, float* __restrict__ dst,
+                                                        int64_t dst_stride, int32_t* ancestors,
+                                                        unsigned long long* agg, unsigned* ctrl,
+                                                        unsigned long long* timeline) {
+#define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GJX_STAMP(0);
+  constexpr int TILE = 256 * ITEMS;
+  __shared__ float fred[8];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t P[kGatherMaxTiles + 1];   // P[t] = total weight of tiles < t; P[nb] = grand total
+  constexpr int CH = 3;                          // source tiles re-scanned per round
+  __shared__ uint64_t cumL[CH * TILE];          // inclusive cumulative weights (absolute) of the tiles being searched
+  __shared__ uint64_t s_wtot[CH][4];
+  __shared__ int32_t s_tiles[TILE];             // distinct source tiles of this block's slots, in slot order
+  __shared__ int32_t s_last[256];
+  __shared__ int s_cnt[4];
+  unsigned epoch;
+  const unsigned long long tag = grid_tag(ctrl, &epoch);
+  const int nb = (int)gridDim.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;   // first particle this lane scans
+  auto load_tile = [&](int64_t p0, float (&v)[ITEMS]) {
+    if (ITEMS == 4 && p0 + 4 <= K) {
+      const float4 q4 = *(const float4*)(x + p0);
+      v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? x[p0 + k] : 0.0f;
+    }
+  };
+  float xv[ITEMS];
+  load_tile(i0, xv);
+  float sm_sum;
+  const float mx = block_ref_max(mode, lse, n_partials, fred, &sm_sum);
+  if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
+    lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;
+  }
+  // ---- own tile total -> all-gather ----
+  {
+    uint64_t qs = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) qs += (i0 + k < K) ? weight_q(xv, k, mode, mx) : 0;
+    const uint64_t wt = wave_sum_u64(qs);
+    if (lane == 0) wsum[wid] = wt;
+    __syncthreads();
+    if (threadIdx.x == 0) grid_publish(agg, tag, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  }
+  GJX_STAMP(1);
+  grid_gather(agg, tag, ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
+  if (threadIdx.x == 0) P[0] = 0;
+  __syncthreads();
+  GJX_STAMP(2);
+  {   // prefix of the tile totals, in place: lane t owns entries [t per, (t+1) per)
+    const int per = (nb + 255) >> 8;
+    const int e0 = threadIdx.x * per, e1 = (e0 + per) < nb ? (e0 + per) : nb;
+    uint64_t loc = 0;
+    for (int e = e0; e < e1; ++e) loc += P[e + 1];
+    uint64_t inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wid] = inc;     // the publish above read wsum before the barrier after the gather
+    __syncthreads();
+    uint64_t run = inc - loc;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+    __syncthreads();
+  }
+  const uint64_t total = P[nb];
+  GJX_STAMP(6);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(&ctrl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (total == 0) __hip_atomic_fetch_or(&ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- ancestors of slots i0 .. i0 + ITEMS - 1 (consecutive slots per lane: 16-byte row stores at ITEMS = 4; the
+  //      striped assignment, 64 consecutive slots per wave instruction, measured 1.3 us slower at K = 2^20) ----
+  int32_t anc[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((i0 + k < K) ? i0 + k : 0);   // dead collection: identity (flagged)
+  if (total > 0) {   // block-uniform
+    const double step = (double)total / (double)K;
+    uint64_t T[ITEMS];
+    int tile[ITEMS], kpos[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int64_t j = (i0 + k < K) ? i0 + k : K - 1;
+      T[k] = comb_threshold(j, u, step, total);
+      tile[k] = 0;
+    }
+    // first tile t with P[t + 1] > T = number of tiles with inclusive prefix <= T: fixed-trip binary descent for the
+    // lane's first and last slot together (independent LDS reads per round); the slots between them are in the same
+    // tile unless the lane straddles a tile boundary (then they are searched too)
+    auto descend = [&](int k0, int k1) {
+#pragma unroll
+      for (int sft = kGatherMaxTiles >> 1; sft >= 1; sft >>= 1) {
+        const int pa = tile[k0] + sft, pb = tile[k1] + sft;     // P[probe] = inclusive prefix of tile probe - 1
+        if (pa <= nb - 1 && P[pa] <= T[k0]) tile[k0] = pa;
+        if (k1 != k0 && pb <= nb - 1 && P[pb] <= T[k1]) tile[k1] = pb;
+      }
+    };
+    descend(0, ITEMS - 1);
+    if (ITEMS > 2) {
+      if (tile[0] == tile[ITEMS - 1]) {
+#pragma unroll
+        for (int k = 1; k < ITEMS - 1; ++k) tile[k] = tile[0];
+      } else {
+        descend(1, ITEMS > 3 ? 2 : 1);
+      }
+    }
+    if (timeline) { asm volatile("" :: "v"(tile[0]), "v"(tile[ITEMS - 1])); GJX_STAMP(7); }
+    // distinct source tiles in slot order (the tile index is non-decreasing in the slot index)
+    s_last[threadIdx.x] = tile[ITEMS - 1];
+    __syncthreads();
+    const int prev = threadIdx.x > 0 ? s_last[threadIdx.x - 1] : -1;
+    int cnt = 0;
+    bool first[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) { first[k] = tile[k] != (k ? tile[k - 1] : prev); cnt += first[k]; }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_cnt[wid] = incl;
+    __syncthreads();
+    int at = incl - cnt;
+    for (int w = 0; w < wid; ++w) at += s_cnt[w];
+    const int ntiles = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      if (first[k]) s_tiles[at++] = tile[k];
+      kpos[k] = at - 1;
+    }
+    __syncthreads();
+    GJX_STAMP(3);
+    // re-scan the source tiles, CH at a time (a window of TILE slots rarely touches more than 3)
+    float nv[CH][ITEMS];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < ntiles) load_tile((int64_t)s_tiles[c] * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);
+    for (int idx = 0; idx < ntiles; idx += CH) {
+      uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
+      int tsrc[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const bool on = idx + c < ntiles;
+        tsrc[c] = on ? s_tiles[idx + c] : 0;
+        const int64_t p0 = (int64_t)tsrc[c] * TILE + (int64_t)threadIdx.x * ITEMS;
+        sacc[c] = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { sacc[c] += (on && p0 + k < K) ? weight_q(nv[c], k, mode, mx) : 0; qi[c][k] = sacc[c]; }
+        if (idx + CH + c < ntiles) load_tile((int64_t)s_tiles[idx + CH + c] * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);   // next round, in flight
+        inc[c] = sacc[c];
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const uint64_t up = __shfl_up((unsigned long long)inc[c], o, 64);
+          if (lane >= o) inc[c] += up;
+        }
+      }
+      if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];
+      }
+      __syncthreads();           // also: every lane is done searching the previous round's cumL
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        uint64_t base = P[tsrc[c]] + (inc[c] - sacc[c]);
+        for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
+      }
+      __syncthreads();
+      // first particle p of the slot's tile with cum_incl(p) > T: the same fixed-trip descent
+      int pos[ITEMS];
+      const uint64_t* cm[ITEMS];
+      bool mine[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        mine[k] = kpos[k] >= idx && kpos[k] < idx + CH;
+        cm[k] = cumL + (mine[k] ? (kpos[k] - idx) * TILE : 0);
+        pos[k] = 0;
+      }
+#pragma unroll
+      for (int sft = TILE >> 1; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k)
+          if (cm[k][pos[k] + sft - 1] <= T[k]) pos[k] += sft;
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k)
+        if (mine[k]) anc[k] = (int32_t)((int64_t)tile[k] * TILE + pos[k]);
+    }
+  }
+  GJX_STAMP(4);
+  // ---- children: rows of the ancestors, ITEMS consecutive slots per lane ----
+  const bool whole = i0 + ITEMS <= K;
+  if (ancestors) {
+    if (ITEMS == 4 && whole) *(int4*)(ancestors + i0) = make_int4(anc[0], anc[1], anc[2], anc[3]);
+    else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) ancestors[i0 + k] = anc[k];
+    }
+  }
+  const bool vec = ITEMS == 4 && whole && (dst_stride & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
+  if (vec) {
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const float* sr = src + (int64_t)r * src_stride;
+      float4 v;
+      v.x = sr[anc[0]]; v.y = sr[anc[ITEMS > 1 ? 1 : 0]]; v.z = sr[anc[ITEMS > 2 ? 2 : 0]]; v.w = sr[anc[ITEMS > 3 ? 3 : 0]];
+      *(float4*)(dst + (int64_t)r * dst_stride + i0) = v;
+    }
+  } else {
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const float* sr = src + (int64_t)r * src_stride;
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) dst[(int64_t)r * dst_stride + i0 + k] = sr[anc[k]];
+    }
+  }
+  GJX_STAMP(5);
+#undef GJX_STAMP
+}
+
 __global__ __launch_bounds__(256) void k_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total,
                                                     key2 key, int64_t out_begin, int64_t n_out, int32_t* ancestors) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -400,6 +649,40 @@ extern "C" int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, c
   if (items == 1) GJX_RF(1); else if (items == 4) GJX_RF(4); else GJX_RF(16);
 #undef GJX_RF
   GJX_CHECK_LAUNCH("gjx_resample_indices");
+  return GJX_OK;
+}
+
+extern "C" int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
+                                   const float* src, int64_t src_stride, int32_t rows, float* dst, int64_t dst_stride,
+                                   int32_t* ancestors, float* lse_out, int64_t K_total, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (!x || K <= 0 || is_log < 0 || is_log > 2 || (is_log && !lse) || (is_log == 2 && n_partials <= 0) ||
+      !(u >= 0.0 && u < 1.0) || rows < 0 || (rows > 0 && (!src || !dst)) || K > 0x7fffffffLL)
+    return gjx_fail(GJX_EINVAL, "gjx_resample_gather: bad argument");
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K)) return gjx_fail(GJX_EWORKSPACE, "gjx_resample_gather: workspace too small");
+  int items = 0;
+  int64_t nblocks = 0;
+  const int cand[2] = {1, 4};
+  const int forced = env_items();
+  for (int c = 0; c < 2 && !items; ++c) {
+    if (forced && cand[c] != forced) continue;
+    const void* fn = cand[c] == 1 ? (const void*)k_resample_gather<1> : (const void*)k_resample_gather<4>;
+    const int cap = gjx_coresident_blocks(fn, 256, 0);
+    nblocks = (K + 256 * (int64_t)cand[c] - 1) / (256 * (int64_t)cand[c]);
+    if (nblocks <= cap && nblocks <= kGatherMaxTiles) items = cand[c];
+  }
+  if (!items) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_gather: K is too large for one co-resident grid on this device (use gjx_resample_indices + gjx_gather_rows)");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ctrl = (unsigned*)workspace + 8;
+  unsigned long long* agg = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
+  const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
+  unsigned long long* timeline = nullptr;   // debug: per-block phase stamps (profiles/microbench/gather_timeline.py)
+  if (const char* e = getenv("GJX_GATHER_TIMELINE_PTR")) timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+#define GJX_RG(IT) hipLaunchKernelGGL((k_resample_gather<IT>), dim3((unsigned)nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, \
+                                      (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride, ancestors, agg, ctrl, timeline)
+  if (items == 1) GJX_RG(1); else GJX_RG(4);
+#undef GJX_RG
+  GJX_CHECK_LAUNCH("gjx_resample_gather");
   return GJX_OK;
 }
 

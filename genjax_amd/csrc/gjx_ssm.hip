@@ -586,7 +586,8 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       f.ancestors = t == T - 1 ? ancestors : nullptr;
       f.agg = (unsigned long long*)(ws2 + kWsHeaderBytes);
       f.ctrl = (unsigned*)ws2 + 8;
-      f.timeline = nullptr;
+      f.timeline = nullptr;   // debug: phase stamps of the middle step (profiles/microbench/ssm_timeline.py)
+      if (const char* e = t == T / 2 ? getenv("GJX_STEP_TIMELINE_PTR") : nullptr) f.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
       void* args[] = {&f};
       const hipError_t e = hipLaunchKernel(fused_fn, dim3((unsigned)nblk), dim3(256), args, 0, st);
       if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(fused step)");

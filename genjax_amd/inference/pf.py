@@ -30,6 +30,11 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
     if lse is None:
         lse = kernels.logsumexp(logw, ws=kernels.shared_workspace(A.OP_LSE, K, logw.device))
     if method == "systematic":
+        ws = kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device)
+        if N == K and rows.stride(1) == 1:
+            # weights -> ancestors -> children in one launch (falls back to two beyond the co-resident grid)
+            anc = torch.empty(K, dtype=torch.int32, device=logw.device)
+            return kernels.resample_gather(logw, _unit_from_key(key), rows, True, lse, anc=anc, ws=ws), anc
         # weights -> ancestors in one launch, then the slot-oriented row copy
         anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, ws=kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device))
         return kernels.gather_rows(rows, anc), anc

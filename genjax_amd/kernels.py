@@ -254,6 +254,31 @@ def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=Tru
     return anc
 
 
+def resample_gather(x: torch.Tensor, u: float, rows: torch.Tensor, is_log=True, lse=None, partials=None, lse_out=None,
+                    K_total=None, out=None, anc=None, ws=None, allow_fallback=True) -> torch.Tensor:
+    """gjx_resample_gather: weights -> systematic ancestors -> out[r, j] = rows[r, ancestor(j)] in ONE launch (N = K);
+    `anc` (int32[K]) receives the ancestors when given.  Falls back to resample_indices + gather_rows when the grid
+    would not be co-resident (K > 2^20 on a full MI355X) unless allow_fallback is False."""
+    K = x.numel()
+    assert rows.dim() == 2 and rows.shape[1] == K and rows.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(rows)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, x.device)
+    if partials is not None:
+        run_ws, n = partials
+        mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
+    else:
+        mode, lp, npart = int(bool(is_log)), _ptr(lse), 0
+    rc = load().gjx_resample_gather(_ptr(x), K, mode, lp, npart, float(u), _ptr(rows), rows.stride(0), rows.shape[0], _ptr(out),
+                                    out.stride(0), _ptr(anc), _ptr(lse_out), int(K_total or K), _ptr(ws), ws.numel(), _stream())
+    if rc == A.EUNSUPPORTED and allow_fallback:
+        a = resample_indices(x, u, K, is_log=is_log, lse=lse, partials=partials, lse_out=lse_out, K_total=K_total, anc=anc, ws=ws)
+        return gather_rows(rows, a, dst=out)
+    check(rc, "gjx_resample_gather")
+    return out
+
+
 def run_partials_count(prog: PackedProgram, K: int, offset: int = 0, device=None) -> int:
     cp = _cp_for_query(prog, device)
     return int(load().gjx_run_partials_count(C.byref(cp), int(K), int(offset)))

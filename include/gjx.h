@@ -301,6 +301,19 @@ int gjx_resample_systematic(const uint64_t* cum, int64_t K, const uint64_t* base
 int gjx_resample_indices(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
                          int64_t N, int32_t* ancestors, uint64_t* cum, uint64_t* base_total_dev, float* lse_out,
                          int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
+/* Resampling AND the row gather in ONE launch on one GPU (N = K): dst[r][j] = src[r][ancestor(j)], r < rows, j < K,
+ * with the ancestors of gjx_resample_indices (bit-identical), which are written to `ancestors` (int32[K]) only when it
+ * is not NULL.  Weights as in gjx_resample_indices (is_log / lse / n_partials / lse_out / K_total).  Every block produces
+ * the slots of its own index range and finds their ancestors by binary search (prefix of the tile totals, then the
+ * re-scanned source tile), so the work is balanced for any weights.  Co-residency, status bits and the workspace are
+ * those of gjx_resample_indices; returns GJX_EUNSUPPORTED when K / 1024 blocks would not be co-resident on the device
+ * (K > 2^20 on a full MI355X): use gjx_resample_indices + gjx_gather_rows then.
+ * Replaces the resample-and-index idiom of the reference's SMC cookbook (docs/cookbook/inactive/inference/
+ * importance_sampling.ipynb: jax.random.categorical over the log-weights + jtu.tree_map(lambda v: v[idx], ...)). */
+int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, const float* lse, int32_t n_partials, double u,
+                        const float* src, int64_t src_stride, int32_t rows, float* dst, int64_t dst_stride,
+                        int32_t* ancestors, float* lse_out, int64_t K_total, void* workspace, size_t workspace_bytes,
+                        void* stream);
 /* the same search fused with the row gather: dst[r][j - out_begin] = src[r][ancestor(j)] for r < rows
  * (slots owned by another rank are left untouched in dst and in ancestors); ancestors int32[n_out] is scratch/output */
 int gjx_resample_gather_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev, double u,

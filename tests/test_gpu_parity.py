@@ -441,6 +441,11 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
         np.testing.assert_array_equal(_np(got), want, err_msg=f"trial {trial} K={K} N={N} kind={kind} u={u}")
         rows = rs.standard_normal((3, K)).astype(np.float32)
         np.testing.assert_array_equal(_np(K_.gather_rows(torch.as_tensor(rows).cuda(), got)), rows[:, want])
+        if N == K:      # resampling + gather in one launch: same ancestors, same children
+            anc1 = torch.empty(K, dtype=torch.int32, device="cuda")
+            ch = K_.resample_gather(wd, u, torch.as_tensor(rows).cuda(), is_log=False, anc=anc1, ws=ws[K], allow_fallback=False)
+            np.testing.assert_array_equal(_np(anc1), want, err_msg=f"one-launch gather: trial {trial} K={K} kind={kind} u={u}")
+            np.testing.assert_array_equal(_np(ch), rows[:, want])
         counts = np.bincount(want, minlength=K)
         assert counts[w == 0].sum() == 0                              # weightless particles never survive
     # the same stretch pattern where a lane holds 16 particles (more many-offspring particles per tile than the
@@ -451,6 +456,49 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
     cum_o, _ = oracle.weight_cumsum(w)
     got = K_.resample_indices(torch.as_tensor(w).cuda(), 0.25, K, is_log=False)
     np.testing.assert_array_equal(_np(got), oracle.resample_systematic(cum_o, 0.25, K))
+
+
+@pytest.mark.parametrize("K", [1, 255, 4096, 65_537, 1 << 18, (1 << 18) + 1024, 999_999, 1 << 20])
+@pytest.mark.parametrize("kind", ["normal", "wide", "two_ends", "one", "stretch"])
+def test_one_launch_resample_gather(K_, oracle, K, kind):
+    """gjx_resample_gather (weights -> ancestors -> children in one co-resident launch, consumer side: binary search
+    in the tile prefix and in the re-scanned source tiles) == oracle ancestors and rows, bit for bit, for log-weights
+    with a finished LSE record, odd K, collapsed weights (all slots from one tile / from the two ends: every block's
+    thresholds fall into one or two source tiles far away) and 17 rows (the bench shape)."""
+    import torch
+    rs = np.random.default_rng(K % 1000 + len(kind))
+    lw = rs.standard_normal(K).astype(np.float32)
+    if kind == "wide":
+        lw *= 6.0
+    if kind == "two_ends" and K > 8:
+        lw[3:K - 3] = -np.inf
+    if kind == "one":
+        lw[:] = -np.inf; lw[K // 3] = 0.25
+    if kind == "stretch":
+        lw[: K // 2] -= 60.0; lw[K // 2 + K // 16:] -= 60.0
+    rows = rs.standard_normal((17, K)).astype(np.float32)
+    lwd, rd = torch.as_tensor(lw).cuda(), torch.as_tensor(rows).cuda()
+    lse = K_.logsumexp(lwd, K)
+    ws = K_.workspace(A.OP_RESAMPLE, K)
+    for u in (0.0, 0.37, 0.999999):
+        want = _np(K_.resample_indices(lwd, u, K, lse=lse))             # itself oracle-exact (test_one_launch_resample_indices)
+        anc = torch.empty(K, dtype=torch.int32, device="cuda")
+        ch = K_.resample_gather(lwd, u, rd, lse=lse, anc=anc, ws=ws, allow_fallback=False)
+        np.testing.assert_array_equal(_np(anc), want)
+        np.testing.assert_array_equal(_np(ch), rows[:, want])
+        ch2 = K_.resample_gather(lwd, u, rd, lse=lse, ws=ws, allow_fallback=False)   # ancestors not asked for
+        assert torch.equal(ch, ch2)
+    assert K_.workspace_status(ws) == 0
+    # plain (non-log) weights straight against the oracle
+    w = np.exp(lw - np.max(lw)).astype(np.float32)
+    cum_o, _ = oracle.weight_cumsum(w)
+    want = oracle.resample_systematic(cum_o, 0.61, K)
+    ch = K_.resample_gather(torch.as_tensor(w).cuda(), 0.61, rd, is_log=False, ws=ws, allow_fallback=False)
+    np.testing.assert_array_equal(_np(ch), rows[:, want])
+    # a dead collection keeps every particle (identity) and says so
+    dead = torch.full((K,), -np.inf, device="cuda")
+    ch = K_.resample_gather(dead, 0.5, rd, lse=K_.logsumexp(dead, K), ws=ws, allow_fallback=False)
+    assert torch.equal(ch, rd) and K_.workspace_status(ws, raise_on_error=False) == 2
 
 
 def test_degenerate_and_invalid_arguments(K_):
