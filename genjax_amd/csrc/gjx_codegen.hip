@@ -53,7 +53,10 @@ struct Emit {
 
 struct Companion {   // derived constants in LDS behind the table
   int kind;          // 0: log of tab[off .. off+n)   1: reciprocal   2: categorical {cdf[n], lse}
+                     // 3: per-row normaliser of a diagonal normal, sum_e (log sqrt(2 pi) + log tab[off + r len + e % len]), r < n
+                     // 4: observed value over scale, tab[dim + e] / tab[off + e % len], e < n (dim = offset of the observation)
   int off, n, at;    // table range; offset of the result in comp[]
+  int len = 0, dim = 0;
 };
 
 struct Plan {
@@ -62,9 +65,9 @@ struct Plan {
   bool tab_lds;
   std::vector<Companion> comps;
   int comp_floats = 0;
-  int find(int kind, int off, int n) {
-    for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n) return c.at;
-    Companion c{kind, off, n, comp_floats};
+  int find(int kind, int off, int n, int len = 0, int dim = 0) {
+    for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n && c.len == len && c.dim == dim) return c.at;
+    Companion c{kind, off, n, comp_floats, len, dim};
     comp_floats += kind == 2 ? n + 1 : n;
     comps.push_back(c);
     return c.at;
@@ -227,11 +230,16 @@ void emit_site(Emit& o, Plan& pl, int j) {
     const bool norm = is_normal(kind);
     const gjx_param& qb = s.p[1];
     const bool comp_scale = norm && table_param(qb);
-    int at_log = -1, at_rcp = -1;
+    int at_rcp = -1, at_sum = -1;
     if (comp_scale) {
-      at_log = pl.find(0, qb.off, table_range(qb));
       if (mode != GJX_MODE_SAMPLE) at_rcp = pl.find(1, qb.off, table_range(qb));
+      at_sum = pl.find(3, qb.off, qb.op == GJX_P_CONST ? 1 : qb.n, qb.len, dim);
     }
+    // observed in the table under a constant scale: z = y/sigma - mean/sigma with y/sigma precomputed
+    const int at_ys = (comp_scale && mode == GJX_MODE_OBS_TAB && qb.op == GJX_P_CONST) ? pl.find(4, qb.off, dim, qb.len, s.obs_off) : -1;
+    // diagonal normals accumulate the squared z-scores; the normaliser is one constant per (gathered) row of the
+    // scale table, or summed alongside when the scale is not a plain table entry
+    if (norm) o.f("      float q2[PPT], ls[PPT];\n      PLOOP { q2[p] = 0.0f; ls[p] = 0.0f; }\n");
     auto element = [&](const std::string& dx, const char* ind) {
       o.f("%sPLOOP {\n", ind);
       std::string in2 = std::string(ind) + "  ";
@@ -247,7 +255,6 @@ void emit_site(Emit& o, Plan& pl, int j) {
         std::string logb, rcpb;
         if (comp_scale) {
           const std::string idx = "(" + tab_index(qb, dx, j, 1) + ") - " + std::to_string(qb.off);
-          logb = "COMP(" + std::to_string(at_log) + " + " + idx + ")";
           if (at_rcp >= 0) rcpb = "COMP(" + std::to_string(at_rcp) + " + " + idx + ")";
         }
         o.f("%sconst float pb = %s;\n", in2.c_str(), pe[1].c_str());
@@ -256,13 +263,15 @@ void emit_site(Emit& o, Plan& pl, int j) {
         o.f("%sfloat val;\n", in2.c_str());
         if (mode == GJX_MODE_SAMPLE) {
           o.f("%sconst float n_ = stream_normal<RNG>(bs[p], (uint32_t)(%s));\n", in2.c_str(), dx.c_str());
-          o.f("%sval = fmaf(pb, n_, pa);\n%slp[p] += fmaf(-0.5f * n_, n_, -(kHalfLog2Pi + %s));\n", in2.c_str(), in2.c_str(), logb.c_str());
+          o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
           if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), dx.c_str());
           else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%d + (%s));\n", in2.c_str(), s.obs_off, dx.c_str());
           else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
-          o.f("%s{ const float z_ = (val - pa) * %s; lp[p] += fmaf(-0.5f * z_, z_, -(kHalfLog2Pi + %s)); }\n", in2.c_str(), rcpb.c_str(), logb.c_str());
+          if (at_ys >= 0) o.f("%s{ const float z_ = fmaf(-%s, pa, COMP(%d + (%s))); q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str(), at_ys, dx.c_str());
+          else o.f("%s{ const float z_ = (val - pa) * %s; q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str());
         }
+        if (at_sum < 0) o.f("%sls[p] += kHalfLog2Pi + %s;\n", in2.c_str(), logb.c_str());
       } else {
         o.f("%sconst float pb = %s, pc = %s, pd = %s;\n%sfloat val;\n", in2.c_str(), pe[1].c_str(), pe[2].c_str(), pe[3].c_str(), in2.c_str());
         const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
@@ -278,12 +287,17 @@ void emit_site(Emit& o, Plan& pl, int j) {
     if (expand) {
       for (int d = 0; d < dim; ++d) {
         element(std::to_string(d), "      ");
-        if ((d & 1) == 1 && d + 1 < dim) o.f("      PLOOP asm volatile(\"\" : \"+v\"(lp[p]));\n      __builtin_amdgcn_sched_barrier(0);\n");
+        if ((d & 1) == 1 && d + 1 < dim) o.f("      PLOOP asm volatile(\"\" : \"+v\"(%s[p]));\n      __builtin_amdgcn_sched_barrier(0);\n", norm ? "q2" : "lp");
       }
     } else {
       o.f("      for (int d_ = 0; d_ < %d; ++d_) {\n", dim);
       element("d_", "        ");
       o.f("      }\n");
+    }
+    if (norm) {
+      if (at_sum < 0) o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -ls[p]);\n");
+      else if (qb.op == GJX_P_CONST) o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -COMP(%d));\n", at_sum);
+      else o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -COMP(%d + gi_%d_1[p]));\n", at_sum, j);
     }
   }
   // bookkeeping: score, weight, per-site scores, store the site's rows
@@ -320,6 +334,22 @@ std::string generate(const gjx_program* prog, int ppt) {
   for (auto& c : pl.comps) {
     if (c.kind == 0) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_log(TAB(%d + t));\n", c.n, c.at, c.off);
     else if (c.kind == 1) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_rcp(TAB(%d + t));\n", c.n, c.at, c.off);
+    else if (c.kind == 4)
+      o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = TAB(%d + t) * fast_rcp(TAB(%d + t %% %d));\n", c.n, c.at, c.dim, c.off, c.len);
+    else if (c.kind == 3) {
+      int p2 = 1;
+      while (p2 < c.dim) p2 <<= 1;
+      if (p2 <= 64) {   // one (row, element) per lane, rows are aligned groups of p2 lanes: sum by xor-shuffles
+        o.f("  for (int t0 = 0; t0 < %d; t0 += 256) {\n    const int t = t0 + threadIdx.x, r_ = t / %d, e_ = t %% %d;\n"
+            "    float s_ = (r_ < %d && e_ < %d) ? kHalfLog2Pi + fast_log(TAB(%d + r_ * %d + e_ %% %d)) : 0.0f;\n",
+            c.n * p2, p2, p2, c.n, c.dim, c.off, c.len, c.len);
+        for (int o2 = p2 >> 1; o2 >= 1; o2 >>= 1) o.f("    s_ += __shfl_xor(s_, %d, 64);\n", o2);
+        o.f("    if (r_ < %d && e_ == 0) COMP(%d + r_) = s_;\n  }\n", c.n, c.at);
+      } else {
+        o.f("  for (int t = threadIdx.x; t < %d; t += 256) { float s_ = 0.0f; for (int e_ = 0; e_ < %d; ++e_) s_ += kHalfLog2Pi + fast_log(TAB(%d + t * %d + e_ %% %d)); COMP(%d + t) = s_; }\n",
+            c.n, c.dim, c.off, c.len, c.len, c.at);
+      }
+    }
     else {
       o.f("  if (threadIdx.x == 0) {   // running CDF (float32, category order) and log-sum-exp of constant logits\n"
           "    float mx = -INFINITY;\n    for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, TAB(%d + c_));\n"
@@ -449,8 +479,10 @@ const Compiled& compile(const gjx_program* prog, int ppt) {
   const size_t m = src.rfind("// LDS_FLOATS ");
   c.lds_floats = atoi(src.c_str() + m + 14);
   if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
+  // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
+  // can never pick up a stale file
   char name[64];
-  snprintf(name, sizeof(name), "%016llx", (unsigned long long)key);
+  snprintf(name, sizeof(name), "%016llx", (unsigned long long)(fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader))));
   const std::string dir = cache_dir(), path = dir + "/" + name + ".hsaco";
   if (!getenv("GJX_JIT_NO_DISK")) {
     if (FILE* f = fopen(path.c_str(), "rb")) {

@@ -1107,7 +1107,11 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
     const int ppt = gen_pick_ppt(prog, K);
     if (gen_available(prog, ppt) != GJX_OK) return false;
     const int64_t tile = 256 * (int64_t)ppt, ntiles = (K + tile - 1) / tile;
-    e.engine = ENGINE_GEN; e.ppt = ppt; e.grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    // the per-block prologue (table copy + derived constants) is paid once per block: no more blocks than can be resident
+    // at 4 per CU, each looping over its tiles
+    static const int resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * (cus > 0 ? cus : 256); }();
+    const int maxgrid = env_int("GJX_GEN_GRID", resident);
+    e.engine = ENGINE_GEN; e.ppt = ppt; e.grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
     return true;
   };
   if (gen_first) { if (!try_gen()) try_gmm(); }
