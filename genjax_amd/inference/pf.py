@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import _abi as A
+from .._lib import GjxError
 from .. import config
 from ..core import Key, fold_in, split, threefry2x32
 
@@ -22,8 +23,11 @@ def _unit_from_key(k: Key) -> float:
     return float(bits) / float(1 << 23)
 
 
-def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None):
-    """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N])."""
+def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None,
+             check: bool = False):
+    """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N]).
+    check=True reads the status word of the co-resident kernel afterwards (one stream synchronisation): raises GjxError
+    on a time-out (grid not co-resident: results undefined) or a dead collection (all weights zero)."""
     from .. import kernels
     K = logw.numel()
     N = int(n_out or K)
@@ -34,10 +38,14 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
         if N == K and rows.stride(1) == 1:
             # weights -> ancestors -> children in one launch (falls back to two beyond the co-resident grid)
             anc = torch.empty(K, dtype=torch.int32, device=logw.device)
-            return kernels.resample_gather(logw, _unit_from_key(key), rows, True, lse, anc=anc, ws=ws), anc
-        # weights -> ancestors in one launch, then the slot-oriented row copy
-        anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, ws=kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device))
-        return kernels.gather_rows(rows, anc), anc
+            out = kernels.resample_gather(logw, _unit_from_key(key), rows, True, lse, anc=anc, ws=ws)
+        else:
+            # weights -> ancestors in one launch, then the slot-oriented row copy
+            anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, ws=ws)
+            out = kernels.gather_rows(rows, anc)
+        if check:
+            kernels.workspace_status(ws)
+        return out, anc
     cum, bt = kernels.weight_cumsum(logw, True, lse, ws=kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device))
     if method == "multinomial":
         anc = kernels.resample_multinomial(cum, bt, key, N)
@@ -121,9 +129,22 @@ class BootstrapFilter:
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
         self.last_accept_rate = None
 
+    @staticmethod
+    def _checked(res, ws, check_status):
+        """Read (and clear) the status word of the co-resident resampling kernels: a time-out means the grid was not
+        co-resident and the results are undefined (raises); a step whose weights were all zero kept its particles and
+        the run is flagged ``degenerate``.  One stream synchronisation per run."""
+        from .. import kernels
+        if check_status and ws is not None:
+            st = kernels.workspace_status(ws, raise_on_error=False)
+            if st & 1:
+                raise GjxError("bootstrap filter: a co-resident resampling kernel timed out waiting for its peers; results are undefined")
+            res["degenerate"] = bool(st & 2)
+        return res
+
     def run(self, key: Key, ys, device=None, rank: int = 0, world: int = 1, keep_means: bool = False,
-            step_by_step: bool = False, keep_history: bool = False):
-        """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?).
+            step_by_step: bool = False, keep_history: bool = False, check_status: bool = True):
+        """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?, degenerate?).
         With world > 1 the K particles are sharded (distributed.py) and ``ys`` is the same on all ranks."""
         from .. import kernels
         from .. import distributed as D
@@ -138,7 +159,8 @@ class BootstrapFilter:
         if world == 1 and not keep_means and not step_by_step and not keep_history and not self.rejuvenate and not D._forced():
             out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K)
             incs = out["lse_steps"][:, 3]
-            return dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
+            res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
+            return self._checked(res, out["_status_ws"], check_status)
         off, K = D.shard(self.K, rank, world)
         sharded = world > 1 or D._forced()
         cs = self.ssm.c_struct(dev)
@@ -210,4 +232,5 @@ class BootstrapFilter:
             self.last_accept_rate = float(acc_sum) / ((T - 1) * max(int(self.rejuvenate.get("n_moves", 1)), 1))
         if hist is not None:
             hist.logw = logw.clone()
-        return dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means, history=hist)
+        res = dict(log_ml=incs.sum(), increments=incs, x=x_prev, logw=logw, means=means, history=hist)
+        return self._checked(res, None if sharded else ws2, check_status)

@@ -583,5 +583,7 @@ def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None
     check(load().gjx_ssm_filter(C.byref(ssm), key[0], key[1], rng_mode, T, int(K), _ptr(ys), _ptr(bufs["xa"]), _ptr(bufs["xb"]),
                                 _ptr(bufs["logw"]), _ptr(bufs["cum"]), _ptr(bufs["anc"]), _ptr(bufs["lse"]), _ptr(bufs["ws"]),
                                 bufs["ws"].numel(), _stream()), "gjx_ssm_filter")
+    # the resampling half of the workspace (status word of the co-resident step kernels): second OP_SSM-sized block
+    need = load().gjx_workspace_bytes(A.OP_SSM, K)
     return dict(lse_steps=bufs["lse"], x=bufs["xa"] if (T - 1) % 2 == 0 else bufs["xb"], logw=bufs["logw"],
-                ancestors=bufs["anc"], _bufs=bufs)
+                ancestors=bufs["anc"], _bufs=bufs, _status_ws=bufs["ws"][need:])

@@ -19,10 +19,11 @@ if echo $WL | grep -q gmm; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_sq2 -o pmc -- $CMD > $OUT/pmc_sq2.log 2>&1
   python - <<PY
 import csv, glob, collections, json
 res = collections.defaultdict(dict)
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % sub, recursive=True):
         d = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -37,8 +38,22 @@ json.dump(res, open("$OUT/${TAG}_pmc_summary.json", "w"), indent=1)
 traffic = {k.replace("void ", "").replace(" ", ""): (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
            for k, v in res.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
 json.dump(traffic, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
+# VALU issue utilisation = cycles the VALU pipes were executing / cycles the shader engines were busy.
+# SQ_ACTIVE_INST_VALU is summed over the 1024 SIMDs in units of 4 cycles (MI355X_MICROARCH.md, PMC units); SQ_BUSY_CYCLES is
+# summed over the 32 shader engines in cycles (cross-check: SQ_BUSY_CYCLES / 32 / kernel duration = the shader clock).
+util = {}
+for k, v in res.items():
+    if "SQ_ACTIVE_INST_VALU" in v and "SQ_BUSY_CYCLES" in v and v["SQ_BUSY_CYCLES"] > 0:
+        valu_cyc = 4.0 * v["SQ_ACTIVE_INST_VALU"] / 1024.0
+        busy_cyc = v["SQ_BUSY_CYCLES"] / 32.0
+        util[k.replace("void ", "").replace(" ", "")] = dict(
+            valu_busy_cycles_per_simd=valu_cyc, se_busy_cycles=busy_cyc, valu_issue_utilisation=valu_cyc / busy_cyc,
+            valu_instr_per_wave=v.get("SQ_INSTS_VALU", 0) / max(v.get("SQ_WAVES", 1), 1),
+            cycles_per_valu_instr=4.0 * v["SQ_ACTIVE_INST_VALU"] / max(v.get("SQ_INSTS_VALU", 1), 1))
+json.dump(util, open("$OUT/${TAG}_valu_utilisation.json", "w"), indent=1)
 PY
 fi
-python $R/profiles/microbench/ssm_timeline.py > $OUT/${TAG}_ssm_step_timeline.txt 2>/dev/null
+python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
+python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT
