@@ -50,7 +50,7 @@ class GjxParam(C.Structure):
 
 class GjxSite(C.Structure):
     _fields_ = [("kind", i32), ("dim", i32), ("slot", i32), ("mode", i32), ("obs_off", i32),
-                ("ncat", i32), ("flags", i32), ("pad_", i32), ("p", GjxParam * MAX_PARAMS)]
+                ("ncat", i32), ("flags", i32), ("scan", i32), ("p", GjxParam * MAX_PARAMS)]
 
 
 class GjxProgram(C.Structure):

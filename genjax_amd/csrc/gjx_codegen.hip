@@ -59,10 +59,14 @@ struct Companion {   // derived constants in LDS behind the table
   int len = 0, dim = 0;
 };
 
+struct SiteStream { std::string key_var; unsigned site_no; };   // "" = the run key
+
 struct Plan {
   const gjx_program* prog;
   int ppt;
   bool tab_lds;
+  std::vector<SiteStream> stream;   // per site
+  std::string key_decls;            // definitions of the chained step keys, in order
   std::vector<Companion> comps;
   int comp_floats = 0;
   int find(int kind, int off, int n, int len = 0, int dim = 0) {
@@ -169,7 +173,11 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const int np = n_params(kind);
   o.f("    { // ---- site %d: kind %d, dim %d, mode %d, slot %d\n", j, kind, is_categorical(kind) ? s.ncat : s.dim, mode, s.slot);
   o.f("      float lp[PPT];\n      PLOOP lp[p] = 0.0f;\n");
-  if (draws) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", j + 1);
+  // stream key and site number (gjx.h "Scan steps"): chained step keys are wave-uniform locals emitted on first use
+  if (draws) {
+    if (prog->rng_mode != GJX_RNG_FLAT || pl.stream[j].key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", pl.stream[j].site_no);
+    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", pl.stream[j].key_var.c_str(), pl.stream[j].site_no);
+  }
   if (masked) o.f("      bool given[PPT];\n      PLOOP given[p] = v[%d][p] != 0.0f;\n", s.obs_off);
   emit_gather_index(o, s, j, np);
   if (is_categorical(kind)) {
@@ -315,6 +323,31 @@ std::string generate(const gjx_program* prog, int ppt) {
   pl.prog = prog;
   pl.ppt = ppt;
   pl.tab_lds = prog->n_tab <= kMaxLdsTab;
+  {   // stream keys and site numbers, as SiteStreamWalk (gjx_device.h) walks them
+    int tag = 0, nkey = 0;
+    unsigned local = 0, plain = 0;
+    std::string cur;
+    for (int j = 0; j < prog->n_sites; ++j) {
+      const int sc = prog->sites[j].scan;
+      if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", (unsigned)(j + 1)}); continue; }
+      if (sc == 0) { tag = 0; pl.stream.push_back({"", ++plain}); continue; }
+      if (sc != tag) {
+        const unsigned id = (unsigned)sc >> 20;
+        const int step = (int)((unsigned)sc & 0xFFFFFu) - 1;
+        const bool follows = tag != 0 && ((unsigned)tag >> 20) == id && (int)((unsigned)tag & 0xFFFFFu) - 1 == step - 1;
+        char b[256];
+        const std::string nm = "sk" + std::to_string(nkey++);
+        if (follows) snprintf(b, sizeof(b), "  const key2 %s = fold_in(%s, %du);\n", nm.c_str(), cur.c_str(), (unsigned)step);
+        else snprintf(b, sizeof(b), "  key2 %s = fold_in(a.key, %uu); for (int t_ = 0; t_ <= %d; ++t_) %s = fold_in(%s, (uint32_t)t_);\n", nm.c_str(),
+                      0x80000000u | id, step, nm.c_str(), nm.c_str());
+        pl.key_decls += b;
+        cur = nm;
+        tag = sc;
+        local = 0;
+      }
+      pl.stream.push_back({cur, ++local});
+    }
+  }
   Emit body;
   for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
   Emit o;
@@ -358,6 +391,7 @@ std::string generate(const gjx_program* prog, int ppt) {
     }
   }
   if (!pl.comps.empty()) o.f("  __syncthreads();\n");
+  o.f("%s", pl.key_decls.c_str());
   o.f("  const int64_t K = a.K;\n  const int64_t tile = 256 * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
       "  float tmax = -INFINITY, tsum = 0.0f;\n"
       "  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {\n"

@@ -110,6 +110,32 @@ struct BitStream<GJX_RNG_JAX32> {
   }
 };
 
+// Which key and which site number the FLAT stream of a site uses (gjx.h "Scan steps"): walked in site order.
+struct SiteStreamWalk {
+  key2 run_key, key;
+  int32_t tag;       // scan tag of the previous site
+  uint32_t local;    // sites seen in the current step
+  uint32_t plain;    // non-Scan sites seen
+  GJX_DEV explicit SiteStreamWalk(key2 k) : run_key(k), key(k), tag(0), local(0u), plain(0u) {}
+  // -> site number; `key` is the key to open the stream with
+  GJX_DEV uint32_t next(int32_t scan) {
+    if (scan == 0) { key = run_key; tag = 0; return ++plain; }
+    if (scan != tag) {
+      const uint32_t id = (uint32_t)scan >> 20;
+      const int32_t step = (int32_t)((uint32_t)scan & 0xFFFFFu) - 1;
+      const bool follows = tag != 0 && ((uint32_t)tag >> 20) == id && (int32_t)((uint32_t)tag & 0xFFFFFu) - 1 == step - 1;
+      if (follows) key = fold_in(key, (uint32_t)step);
+      else {
+        key = fold_in(run_key, 0x80000000u | id);
+        for (int32_t t = 0; t <= step; ++t) key = fold_in(key, (uint32_t)t);
+      }
+      tag = scan;
+      local = 0u;
+    }
+    return ++local;
+  }
+};
+
 // Run-time element indices (the site interpreter, rolled loops): the same stream with ONE inlined copy of the hash per
 // get() instead of four — with two dozen distribution kinds instantiated in one kernel the fully inlined form is
 // several hundred KB of code and thrashes the instruction cache (interpreter 147 us -> 850 us on the headline model).

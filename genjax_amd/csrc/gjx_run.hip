@@ -71,14 +71,16 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   auto val = [&](int slot) -> float { return LDSV ? vals_s[slot * 256 + threadIdx.x] : ch[(int64_t)slot * K + ii]; };
 
   float score = 0.0f, weight = 0.0f;
+  SiteStreamWalk walk(a.key);     // wave-uniform: chained step keys of Scan sites (gjx.h "Scan steps")
   for (int j = 0; j < a.n_sites; ++j) {
     const gjx_site& s = a.sites[j];
     const int kind = s.kind, mode = s.mode, slot = s.slot;
+    const uint32_t site_no = RNG == GJX_RNG_FLAT ? walk.next(s.scan) : (uint32_t)(j + 1);
     BitStreamRT<RNG> bs;
     const bool masked = mode == GJX_MODE_OBS_MASK;
     const bool draws = mode == GJX_MODE_SAMPLE || masked;           // wave-uniform
     const bool given = masked ? (val(s.obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
-    if (draws) bs.open(a.key, gidx, (uint32_t)(j + 1));
+    if (draws) bs.open(RNG == GJX_RNG_FLAT ? walk.key : a.key, gidx, site_no);
     float lp = 0.0f;
     if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
       const int n = s.ncat;
@@ -1139,7 +1141,16 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   if (K == 0) return GJX_OK;
   if (prog->n_slots > 0 && !choices) return gjx_fail(GJX_EINVAL, "gjx_run_program: choices is null");
   if (lse && !logw) return gjx_fail(GJX_EINVAL, "gjx_run_program: lse needs logw");
-  if (prog->rng_mode == GJX_RNG_FLAT && prog->n_sites > GJX_FLAT_MAX_SITES) return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: FLAT stream supports at most 1023 sites");
+  if (prog->rng_mode == GJX_RNG_FLAT) {   // 1023 site numbers per Scan step and for the sites outside Scans
+    int plain = 0, local = 0, tag = 0;
+    for (int j = 0; j < prog->n_sites; ++j) {
+      const int sc = prog->sites[j].scan;
+      if (sc == 0) { ++plain; tag = 0; }
+      else { if (sc != tag) { tag = sc; local = 0; } ++local; }
+      if (plain > GJX_FLAT_MAX_SITES || local > GJX_FLAT_MAX_SITES)
+        return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program: FLAT stream supports at most 1023 sites per Scan step and 1023 outside Scans");
+    }
+  }
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& sj = prog->sites[j];
     if (sj.mode != GJX_MODE_OBS_MASK) continue;

@@ -294,6 +294,8 @@ class _Tracer:
     def __init__(self):
         self.sites = SiteList()
         self.step = None   # inside a scan / vmap: the iteration index, appended to every address as (name, step)
+        self.scan = 0      # inside a scan: gjx_site.scan tag of the current step (chained step keys, gjx.h)
+        self.n_scans = 0
         self.prefix = ()   # inside `callee(...) @ "addr"`: the path of enclosing call addresses
 
     def __enter__(self):
@@ -321,6 +323,7 @@ class DistCall:
         if t.step is not None:
             addr = (addr, t.step)
         site = t.sites.add(addr, self.kind, self.params, self.dim)
+        site.scan = t.scan
         return SiteVal(addr, site.dim, self.kind)
 
 
@@ -719,13 +722,19 @@ class ScanCombinator(GenerativeFunction):
         if t.step is not None:
             raise NotSupportedInModelBody("a scan / vmap nested inside another scan / vmap is not supported")
         outs = []
+        sid = t.n_scans
+        t.n_scans += 1
+        if self.n >= (1 << 20) - 1 or sid >= 2048:
+            raise NotSupportedInModelBody("scan: at most 2^20 - 2 steps and 2048 scans per model")
         try:
             for i in range(self.n):
                 t.step = i
+                t.scan = (sid << 20) | (i + 1)      # step keys chain on the device: key_t = fold_in(key_{t-1}, t) (scan.py:268)
                 carry, out = self.kernel.source(carry, None if xs is None else xs[i])
                 outs.append(out)
         finally:
             t.step = None
+            t.scan = 0
         return carry, outs
 
     def __call__(self, carry, xs=None):

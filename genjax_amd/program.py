@@ -81,6 +81,7 @@ class Site:
     dim: int = 1
     ncat: int = 0
     slot: int = -1
+    scan: int = 0     # gjx_site.scan: (scan_id << 20) | (step + 1) for the sites of a Scan step, else 0
 
 
 N_PARAMS = {
@@ -218,6 +219,7 @@ class PackedProgram:
             cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
             cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
             cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
+            cs.scan = int(s.scan)
             cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)
             rows = s.ncat if s.ncat else s.dim
             for k in range(len(s.params), A.MAX_PARAMS):   # unused parameter slots read tab[0]

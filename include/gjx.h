@@ -128,9 +128,21 @@ typedef struct gjx_site {
   int32_t obs_off; /* OBS_TAB: offset of the observed value in tab                          */
   int32_t ncat;    /* categorical: number of categories (length of params[0])               */
   int32_t flags;   /* GJX_SITE_*                                                            */
-  int32_t pad_;
+  int32_t scan;    /* 0: not inside a Scan; else (scan_id << 20) | (step + 1): see "Scan steps" below */
   gjx_param p[GJX_MAX_PARAMS];
 } gjx_site; /* 160 bytes */
+
+/* Scan steps (combinators/scan.py:237-294).  The sites of step t of a Scan are consecutive and carry the same `scan`
+ * tag.  Their random streams follow the reference's CHAINED key rule (scan.py:268, key_t = fold_in(key_{t-1}, t)):
+ *   base   = fold_in(run key, 0x80000000 | scan_id)       (the key the Scan call itself receives)
+ *   key_t  = fold_in(key_{t-1}, t),  key_{-1} = base       (fold_in(k, i) = Threefry(k, (0, i)))
+ * and site number = position of the site within its step, from 1 — so a Scan of any length never runs out of the
+ * 1023 site numbers of the FLAT layout; the site loop is a device loop over the steps' descriptors.  Sites outside
+ * any Scan use the run key and their position among the non-Scan sites, from 1.  (GJX_RNG_JAX32 keeps
+ * fold_in(particle key, global site index) for every site.) */
+#define GJX_SCAN_TAG(scan_id, step) ((int32_t)(((uint32_t)(scan_id) << 20) | (uint32_t)((step) + 1)))
+#define GJX_SCAN_ID(tag) ((uint32_t)(tag) >> 20)
+#define GJX_SCAN_STEP(tag) ((int32_t)((uint32_t)(tag) & 0xFFFFFu) - 1)
 
 /* random-stream layouts.  Both are Threefry-2x32-20 counter streams and both give results that are
  * independent of how particles are sharded over GPUs (the counter carries the GLOBAL particle index).

@@ -505,13 +505,37 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
                          float* weight_out, float* site_scores, int64_t ss_stride) {
   const float* tab = prog->tab;
   float score = 0.0f, weight = 0.0f;
+  /* stream key and site number of every site (gjx.h "Scan steps"): sites of a Scan step use the chained step key
+   * key_t = fold_in(key_{t-1}, t) (scan.py:268) and their position within the step; the others the run key and their
+   * position among the non-Scan sites */
+  okey skey = run_key;
+  int32_t tag = 0;
+  uint32_t local = 0u, plain = 0u;
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
+    uint32_t site_no = (uint32_t)(j + 1);
+    if (prog->rng_mode == GJX_RNG_FLAT) {
+      if (s->scan == 0) { skey = run_key; tag = 0; site_no = ++plain; }
+      else {
+        if (s->scan != tag) {
+          const uint32_t id = GJX_SCAN_ID(s->scan);
+          const int32_t step = GJX_SCAN_STEP(s->scan);
+          if (tag != 0 && GJX_SCAN_ID(tag) == id && GJX_SCAN_STEP(tag) == step - 1) skey = fold_in(skey, (uint32_t)step);
+          else {
+            skey = fold_in(run_key, 0x80000000u | id);
+            for (int32_t t = 0; t <= step; ++t) skey = fold_in(skey, (uint32_t)t);
+          }
+          tag = s->scan;
+          local = 0u;
+        }
+        site_no = ++local;
+      }
+    }
     /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
      * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
     int mode = s->mode;
     if (mode == GJX_MODE_OBS_MASK) mode = vals[s->obs_off] != 0.0f ? GJX_MODE_OBS_SLOT : GJX_MODE_SAMPLE;
-    const ostream st = stream_open(prog->rng_mode, run_key, idx, (uint32_t)(j + 1)); /* counter starts at 1 */
+    const ostream st = stream_open(prog->rng_mode, prog->rng_mode == GJX_RNG_FLAT ? skey : run_key, idx, site_no); /* counter starts at 1 */
     const ostream* sk = &st;
     float lp = 0.0f;
     if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {

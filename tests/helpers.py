@@ -114,3 +114,23 @@ def shape_hierarchy(rng=A.RNG_FLAT):
     sl.add("ig", A.INVERSE_GAMMA, [a, 1.5])
     sl.add("c2", A.CHI2, [Param.value("lb", xf=A.XF_SOFTPLUS)])
     return sl
+
+
+def scan_chain(T, rng=A.RNG_FLAT, carry=True, observe=False, sigma=0.1, r=0.5, seed=0, scan_id=0):
+    """A Scan of T steps laid out as the host tracer does (gen.py ScanCombinator): step t holds x_t ~ N(x_{t-1}, sigma)
+    (x_{-1} = 0; independent N(0, 1) draws without `carry`) and, with `observe`, y_t ~ N(x_t, r) constrained to data;
+    every site of step t carries the tag GJX_SCAN_TAG(scan_id, t)."""
+    rs = np.random.default_rng(seed)
+    sl = SiteList()
+    modes, obs = {}, {}
+    ys = rs.standard_normal(T).astype(np.float32)
+    for t in range(T):
+        loc = Param.value(("x", t - 1)) if (carry and t > 0) else Param.const(0.0)
+        sx = sl.add(("x", t), A.NORMAL, [loc, Param.const(sigma if carry else 1.0)])
+        sx.scan = (scan_id << 20) | (t + 1)
+        if observe:
+            sy = sl.add(("y", t), A.NORMAL, [Param.value(("x", t)), Param.const(r)])
+            sy.scan = (scan_id << 20) | (t + 1)
+            modes[("y", t)] = A.MODE_OBS_TAB
+            obs[("y", t)] = ys[t]
+    return PackedProgram(sl, modes, obs, rng_mode=rng), ys

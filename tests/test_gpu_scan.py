@@ -1,0 +1,112 @@
+"""Scan steps on the device: the site loop is a device loop over the steps' descriptors, step keys chain as in
+combinators/scan.py:268 (include/gjx.h "Scan steps"), and a Scan may be longer than the 1023 site numbers of one FLAT
+stream.  Checked against the oracle, against single-site programs run under the host-computed chained keys, and
+between the interpreter and the generated kernels."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from genjax_amd import _abi as A
+from genjax_amd import core
+from test_scan_keys import chain_keys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K_():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from genjax_amd import kernels
+    return kernels
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class engine:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.old = os.environ.get("GJX_ENGINE")
+        os.environ["GJX_ENGINE"] = self.name
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            del os.environ["GJX_ENGINE"]
+        else:
+            os.environ["GJX_ENGINE"] = self.old
+
+
+@pytest.mark.parametrize("eng", ["interp", "gen"])
+def test_step_streams_follow_the_chained_key_rule(K_, eng):
+    T, K, key = 7, 4096, (1234, 5678)
+    one = H.one_site("normal", 0.0, 1.0)
+    for scan_id in (0, 5):
+        prog, _ = H.scan_chain(T, carry=False, scan_id=scan_id)
+        with engine(eng):
+            assert K_.program_engine(prog) == (4 if eng == "gen" else 0)
+            got = _np(K_.run_program(prog, key, K)["choices"])
+            for t, kt in enumerate(chain_keys(key, T, scan_id)):
+                want = _np(K_.run_program(one, kt, K)["choices"][0])
+                np.testing.assert_array_equal(got[t], want)
+
+
+def test_long_scan_on_the_device_equals_the_oracle(K_, oracle):
+    """1500 steps = 1500 sites: more than one FLAT stream has site numbers; the interpreter's site loop walks the step
+    descriptors on the device, chaining the step keys."""
+    T, K = 1500, 2048
+    prog, _ = H.scan_chain(T, carry=True, sigma=0.1)
+    out = K_.run_program(prog, (7, 9), K)
+    ora = oracle.run_program(prog, (7, 9), K)
+    np.testing.assert_allclose(_np(out["choices"]), ora["choices"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(_np(out["score"]), ora["score"], rtol=2e-4)
+    # an observed chain: weights accumulate over the steps
+    prog, _ = H.scan_chain(600, carry=True, observe=True, sigma=0.3, r=0.7)
+    out = K_.run_program(prog, (3, 4), K)
+    ora = oracle.run_program(prog, (3, 4), K)
+    np.testing.assert_allclose(_np(out["logw"]), ora["logw"], rtol=3e-4)
+    np.testing.assert_allclose(_np(out["lse"])[2:], ora["lse"][2:], rtol=1e-4)
+
+
+def test_generated_kernel_of_a_scan_equals_the_interpreter(K_, oracle):
+    T, K = 20, 1 << 14
+    prog, _ = H.scan_chain(T, carry=True, observe=True, sigma=0.3, r=0.7)
+    with engine("gen"):
+        assert K_.program_engine(prog) == 4
+        g = K_.run_program(prog, (5, 6), K)
+    with engine("interp"):
+        i = K_.run_program(prog, (5, 6), K)
+    np.testing.assert_array_equal(_np(g["choices"]), _np(i["choices"]))     # same streams, same sampler arithmetic
+    np.testing.assert_allclose(_np(g["logw"]), _np(i["logw"]), rtol=1e-4, atol=1e-4)
+    ora = oracle.run_program(prog, (5, 6), K)
+    np.testing.assert_allclose(_np(g["choices"]), ora["choices"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(_np(g["logw"]), ora["logw"], rtol=2e-4, atol=2e-4)
+
+
+def test_gen_scan_api_with_more_steps_than_site_numbers(K_):
+    """`kernel.scan(n=T)` through the API with T > 1023: simulate, then the score is the sum of the step log-densities of
+    the returned choices (scan.py:283-294)."""
+    import genjax_amd as genjax
+
+    @genjax.gen
+    def step(carry, _):
+        x = genjax.normal(carry, 0.25) @ "x"
+        return x, x
+
+    T, K = 1200, 256
+    tr = step.scan(n=T).simulate(genjax.key(11), (0.0, None), K=K)
+    xs = np.stack([_np(tr.get_choices()[t, "x"]) for t in (0, 1, 599, T - 1)])
+    assert np.isfinite(xs).all() and xs.shape == (4, K)
+    allx = _np(tr.get_choices()[:, "x"]) if hasattr(tr.get_choices(), "__getitem__") else None
+    x = np.asarray(allx, np.float64)
+    if x.shape[0] != T:
+        x = x.T
+    inc = np.diff(np.vstack([np.zeros((1, K)), x]), axis=0) / 0.25
+    want = (-0.5 * inc ** 2 - 0.5 * np.log(2 * np.pi) - np.log(0.25)).sum(axis=0)
+    np.testing.assert_allclose(_np(tr.get_score()), want, rtol=1e-4)
