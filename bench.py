@@ -417,6 +417,38 @@ def run_hmc(args, rank, world, dev):
     return res
 
 
+def run_hmc_generic(dev):
+    """The same config-5 model through the GENERIC per-chain HMC kernel (k_hmc_generic: forward sweep over the site list
+    with analytic d logpdf / d(value, params), any program) instead of the fused logistic-regression kernel: what a model
+    without a dedicated kernel gets.  Same 2^16 chains, L = 5, same eps."""
+    from genjax_amd import kernels, workloads
+    N, P, L, n = 1024, 16, 5, 1 << 16
+    prog, _ = workloads.logreg_program(N=N, P=P)
+    old = os.environ.get("GJX_FORCE_GENERIC")
+    os.environ["GJX_FORCE_GENERIC"] = "1"
+    try:
+        eng = kernels.hmc_engine(prog)
+        ch = torch.as_tensor((np.random.default_rng(0).standard_normal((P + 1, n)) * 0.1).astype(np.float32), device=dev)
+        out = kernels.hmc(prog, (1, 2), ch, 0.01, L, False, True)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(3):
+            out = kernels.hmc(prog, (1, 3 + i), ch, 0.01, L, False, True, ws=out["_ws"])
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+    finally:
+        if old is None:
+            del os.environ["GJX_FORCE_GENERIC"]
+        else:
+            os.environ["GJX_FORCE_GENERIC"] = old
+    flops = n * L * (2 * 2 * N * P + 10 * N)
+    return dict(engine=eng, chains=n, leapfrog=L, ms_per_move=ms, chain_leapfrogs_per_sec=n * L / (ms * 1e-3),
+                tflops=flops / (ms * 1e-3) / 1e12, accept_rate=float(out["accepted"].mean()),
+                note="generic site-list HMC kernel on the config-5 model (the fused MFMA kernel is extra.hmc)")
+
+
 def run_api(dev, K, steps=100):
     """The gmm step through the public API instead of a hand-built program: @gen body -> Target -> ImportanceK.run_smc
     -> N-of-K systematic resampling (inference.pf.resample).  The traced site list and the packed program (table on the
@@ -597,6 +629,7 @@ def main():
                 if k in r2:
                     extra[name][k] = r2[k]
         extra["codegen"] = run_codegen(dev)
+        extra["hmc_generic"] = run_hmc_generic(dev)
         api = run_api(dev, args.k_per_gpu)
         api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
         extra["api"] = api

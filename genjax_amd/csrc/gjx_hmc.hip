@@ -128,11 +128,21 @@ GJX_DEV float xf_deriv(int xf, float pre) {
   }
 }
 
-// score and gradient rows g[n_slots][n] for chain i (rows are zeroed here)
-template <class ValFn>
+// where a chain's gradient row lives: column i of rows g[n_slots][n] in memory, or column threadIdx.x of LDS rows
+struct GlobalRows {
+  float* g; int64_t n, i;
+  GJX_DEV float& at(int slot) const { return g[(int64_t)slot * n + i]; }
+};
+struct LdsRows {
+  float* g;
+  GJX_DEV float& at(int slot) const { return g[slot * 256 + threadIdx.x]; }
+};
+
+// score and gradient of chain i; the gradient rows G.at(slot) are zeroed here
+template <class ValFn, class Rows>
 GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, const float* __restrict__ tab,
-                             ValFn&& val, float* g, int64_t n, int64_t i) {
-  for (int s = 0; s < n_slots; ++s) g[(int64_t)s * n + i] = 0.0f;
+                             ValFn&& val, Rows G) {
+  for (int s = 0; s < n_slots; ++s) G.at(s) = 0.0f;
   float score = 0.0f;
   for (int j = 0; j < n_sites; ++j) {
     const gjx_site& s = sites[j];
@@ -175,7 +185,7 @@ GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, co
       score += elem_logpdf(kind, x, pa, pb, pc, pd);
       float gx, gpar[4];
       dlogpdf(kind, x, pa, pb, pc, pd, gx, gpar);
-      if (s.slot >= 0) g[(int64_t)(s.slot + d) * n + i] += gx;
+      if (s.slot >= 0) G.at(s.slot + d) += gx;
       const float pre[4] = {pa_pre, pb_pre, pc_pre, pd_pre};
       for (int q = 0; q < np; ++q) {
         const gjx_param& p = s.p[q];
@@ -183,10 +193,10 @@ GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, co
         if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE)) continue;
         if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, pre[q]);
         if (p.op == GJX_P_VALUE) {
-          g[(int64_t)(p.slot + (p.len == 1 ? 0 : d % p.len)) * n + i] += gp;
+          G.at(p.slot + (p.len == 1 ? 0 : d % p.len)) += gp;
         } else {
           const float* row = tab + p.moff + d * p.n;
-          for (int e = 0; e < p.n; ++e) g[(int64_t)(p.slot + e) * n + i] += gp * row[e];
+          for (int e = 0; e < p.n; ++e) G.at(p.slot + e) += gp * row[e];
         }
       }
     }
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256) void k_score_grad(const gjx_site* sites, const
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   auto val = [&](int slot) -> float { return choices[(int64_t)slot * n + i]; };
-  const float sc = score_and_grad(sites, n_sites, n_slots, tab, val, grad, n, i);
+  const float sc = score_and_grad(sites, n_sites, n_slots, tab, val, GlobalRows{grad, n, i});
   if (score) score[i] = sc;
   // zero rows of unselected slots (selection_gradient returns zeros for them, hmc.py:90-96)
   for (int j = 0; j < n_sites; ++j) {
@@ -209,17 +219,34 @@ __global__ __launch_bounds__(256) void k_score_grad(const gjx_site* sites, const
   }
 }
 
-template <int RNG>
+// Generic per-chain HMC move over any site list.  LDSM: the chain's values and its gradient live in LDS columns
+// ([slot][lane], 2 n_slots KB per block) for the whole trajectory — a site with an affine parameter reads every source
+// value and adds to every source gradient once per element, which from memory costs two round trips per (element, source)
+// pair (the config-5 model: 2 x 16 K per gradient).  Momenta and the stale-gradient copy stay in the workspace.
+template <int RNG, bool LDSM>
 __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float hmc_lds[];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= a.n) return;      // no barriers below: every lane works on its own columns
   const int64_t n = a.n;
   float* ch = a.choices;
-  auto val = [&](int slot) -> float { return ch[(int64_t)slot * n + i]; };
+  float* v_s = hmc_lds;
+  float* g_s = hmc_lds + (LDSM ? a.n_slots * 256 : 0);
+  auto val = [&](int slot) -> float { return LDSM ? v_s[slot * 256 + threadIdx.x] : ch[(int64_t)slot * n + i]; };
+  auto setv = [&](int slot, float x) { if (LDSM) v_s[slot * 256 + threadIdx.x] = x; else ch[(int64_t)slot * n + i] = x; };
+  auto grad_of = [&](int slot) -> float { return LDSM ? g_s[slot * 256 + threadIdx.x] : a.ws_g[(int64_t)slot * n + i]; };
+  auto gradient = [&]() -> float {
+    if (LDSM) return score_and_grad(a.sites, a.n_sites, a.n_slots, a.tab, val, LdsRows{g_s});
+    return score_and_grad(a.sites, a.n_sites, a.n_slots, a.tab, val, GlobalRows{a.ws_g, n, i});
+  };
   const uint64_t gidx = (uint64_t)(a.offset + i);
-  for (int s = 0; s < a.n_slots; ++s) a.ws_old[(int64_t)s * n + i] = ch[(int64_t)s * n + i];
-  const float score0 = score_and_grad(a.sites, a.n_sites, a.n_slots, a.tab, val, a.ws_g0, n, i);  // hmc.py:165-166
-  for (int s = 0; s < a.n_slots; ++s) a.ws_g[(int64_t)s * n + i] = a.ws_g0[(int64_t)s * n + i];
+  for (int s = 0; s < a.n_slots; ++s) {
+    const float x = ch[(int64_t)s * n + i];
+    a.ws_old[(int64_t)s * n + i] = x;
+    if (LDSM) v_s[s * 256 + threadIdx.x] = x;
+  }
+  const float score0 = gradient();  // hmc.py:165-166
+  if (a.stale) for (int s = 0; s < a.n_slots; ++s) a.ws_g0[(int64_t)s * n + i] = grad_of(s);
   // momenta (hmc.py:120-130): leaf l = l-th selected address in program order
   key2 knew{0u, 0u}, sub{0u, 0u};
   if (RNG == GJX_RNG_JAX32) {
@@ -247,27 +274,25 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
   const float he = 0.5f * a.eps;
   float sc = score0;
   for (int t = 1; t <= a.L; ++t) {  // hmc.py:170-194
-    const float* gfirst = a.stale ? a.ws_g0 : a.ws_g;  // hmc.py:186 keeps the received gradient in the carry
     int m = 0;
     for (int j = 0; j < a.n_sites; ++j) {
       const gjx_site& s = a.sites[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
       for (int d = 0; d < s.dim; ++d, ++m) {
-        const int64_t si = (int64_t)(s.slot + d) * n + i;
-        const float p = a.ws_p[(int64_t)m * n + i] + he * gfirst[si];
+        const int sl = s.slot + d;
+        // hmc.py:186 keeps the received gradient in the carry (stale): every first half-kick uses it
+        const float gf = a.stale ? a.ws_g0[(int64_t)sl * n + i] : grad_of(sl);
+        const float p = a.ws_p[(int64_t)m * n + i] + he * gf;
         a.ws_p[(int64_t)m * n + i] = p;
-        ch[si] = ch[si] + a.eps * p;
+        setv(sl, val(sl) + a.eps * p);
       }
     }
-    sc = score_and_grad(a.sites, a.n_sites, a.n_slots, a.tab, val, a.ws_g, n, i);
+    sc = gradient();
     m = 0;
     for (int j = 0; j < a.n_sites; ++j) {
       const gjx_site& s = a.sites[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
-      for (int d = 0; d < s.dim; ++d, ++m) {
-        const int64_t si = (int64_t)(s.slot + d) * n + i;
-        a.ws_p[(int64_t)m * n + i] += he * a.ws_g[si];
-      }
+      for (int d = 0; d < s.dim; ++d, ++m) a.ws_p[(int64_t)m * n + i] += he * grad_of(s.slot + d);
     }
   }
   float k1 = 0.0f;
@@ -284,9 +309,9 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
     const float lu = safe_log(bits_to_unit(bs.get(0u)));
     acc = lu < al;  // tests/inference/test_requests.py:134-137
   }
-  if (!acc) {
-    for (int s = 0; s < a.n_slots; ++s) ch[(int64_t)s * n + i] = a.ws_old[(int64_t)s * n + i];
-    sc = score0;
+  if (!acc) sc = score0;
+  if (LDSM || !acc) {
+    for (int s = 0; s < a.n_slots; ++s) ch[(int64_t)s * n + i] = acc ? val(s) : a.ws_old[(int64_t)s * n + i];
   }
   if (a.score) a.score[i] = sc;
   if (a.alpha) a.alpha[i] = al;
@@ -846,8 +871,17 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
   a.ws_g0 = w; w += (size_t)a.n_slots * n;
   a.ws_old = w;
   const unsigned nb = (unsigned)((n + 255) / 256);
-  if (prog->rng_mode == GJX_RNG_JAX32) hipLaunchKernelGGL(k_hmc_generic<GJX_RNG_JAX32>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_hmc_generic<GJX_RNG_FLAT>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+  // values + gradient in LDS columns when they fit (2 n_slots KB per block, at most 64 KB)
+  const size_t lds = (size_t)2 * a.n_slots * 256 * sizeof(float);
+  const bool ldsm = lds <= 64 * 1024 && !getenv("GJX_HMC_NO_LDS");
+  const bool jax = prog->rng_mode == GJX_RNG_JAX32;
+  if (ldsm) {
+    if (jax) hipLaunchKernelGGL((k_hmc_generic<GJX_RNG_JAX32, true>), dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_hmc_generic<GJX_RNG_FLAT, true>), dim3(nb), dim3(256), lds, (hipStream_t)stream, a);
+  } else {
+    if (jax) hipLaunchKernelGGL((k_hmc_generic<GJX_RNG_JAX32, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_hmc_generic<GJX_RNG_FLAT, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+  }
   GJX_CHECK_LAUNCH("gjx_hmc");
   return GJX_OK;
 }
