@@ -61,11 +61,28 @@ struct Companion {   // derived constants in LDS behind the table
 
 struct SiteStream { std::string key_var; unsigned site_no; };   // "" = the run key
 
+// Where an emitted site's rows and table entries really are.  Outside a rolled Scan everything is static (the site's own
+// fields); inside the loop over t_ (steps 1 .. T-1 of a rolled Scan) the site is emitted ONCE, from step 1's descriptor,
+// and every step-dependent quantity is `value at step 1 + (t_ - 1) * stride`.
+struct RollInfo {
+  int row = -1, d_row = 0;              // first row of the site's value in choices[][]
+  int score_row = 0, d_score_row = 0;   // row of the site in site_scores[][]
+  int d_obs = 0;                        // stride of obs_off
+  int d_off[4] = {0, 0, 0, 0}, d_moff[4] = {0, 0, 0, 0};   // strides of the parameters' table offsets
+};
+
+// "off" or "(off + (t_ - 1) * stride)"
+std::string toff(int off, int stride) {
+  if (stride == 0) return std::to_string(off);
+  return "(" + std::to_string(off) + " + (t_ - 1) * " + std::to_string(stride) + ")";
+}
+
 struct Plan {
   const gjx_program* prog;
   int ppt;
   bool tab_lds;
-  std::vector<SiteStream> stream;   // per site
+  std::vector<SiteStream> stream;   // per emitted site
+  std::vector<RollInfo> info;       // per emitted site
   std::string key_decls;            // definitions of the chained step keys, in order
   std::vector<Companion> comps;
   int comp_floats = 0;
@@ -88,12 +105,132 @@ int table_range(const gjx_param& p) { return p.op == GJX_P_CONST ? p.len : p.n *
 
 int n_params(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : (is_categorical(kind) ? 1 : 2)); }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Rolled Scans.  A program whose tail is a Scan of T >= 4 steps (gjx_site.scan tags, include/gjx.h "Scan steps") whose
+// step descriptors are PERIODIC from step 1 on — same kinds / shapes / modes, and every slot, row and table offset of
+// step t equal to step 1's plus (t - 1) times a fixed stride — is emitted as: the sites before the Scan, step 0, then
+// ONE loop over t_ = 1 .. T-1 around step 1's sites.  Values of the previous and of the current step live in registers
+// (slots n_pre .. n_pre + S - 1 and n_pre + S .. n_pre + 2 S - 1 of the kernel's value array); rows and table offsets
+// advance with t_; the step key chains, skt = fold_in(skt, t_) (scan.py:268).  The emitted program `sites` holds the
+// pre-Scan sites, step 0 and step 1 with their slots remapped to those registers.
+// ---------------------------------------------------------------------------------------------------------
+struct Roll {
+  bool ok = false;
+  int i0 = 0, m = 0, T = 0, S = 0, n_pre = 0;
+  unsigned scan_id = 0;
+  std::vector<gjx_site> sites;      // emitted sites: [0, i0) pre, [i0, i0 + m) step 0, [i0 + m, i0 + 2 m) step 1 (loop body)
+  std::vector<RollInfo> info;
+};
+
+bool slot_op(int op) { return op == GJX_P_VALUE || op == GJX_P_GATHER || op == GJX_P_AFFINE; }
+int ref_span(const gjx_param& q) { return q.op == GJX_P_AFFINE ? q.n : (q.op == GJX_P_VALUE ? q.len : 1); }
+
+Roll detect_roll(const gjx_program* p) {
+  Roll r;
+  if (p->rng_mode != GJX_RNG_FLAT || getenv("GJX_GEN_NO_ROLL")) return r;
+  const int n = p->n_sites;
+  int i0 = 0;
+  while (i0 < n && p->sites[i0].scan == 0) ++i0;
+  if (i0 == n || GJX_SCAN_STEP(p->sites[i0].scan) != 0) return r;
+  const unsigned id = GJX_SCAN_ID(p->sites[i0].scan);
+  int m = 0;
+  while (i0 + m < n && p->sites[i0 + m].scan == p->sites[i0].scan) ++m;
+  if ((n - i0) % m != 0) return r;
+  const int T = (n - i0) / m;
+  if (T < 4) return r;
+  auto at = [&](int t, int l) -> const gjx_site& { return p->sites[i0 + t * m + l]; };
+  for (int t = 0; t < T; ++t)
+    for (int l = 0; l < m; ++l) {
+      const gjx_site& s = at(t, l);
+      if (s.scan != GJX_SCAN_TAG(id, t)) return r;
+      if (s.mode != GJX_MODE_SAMPLE && s.mode != GJX_MODE_OBS_TAB) return r;
+    }
+  auto width = [&](const gjx_site& s) { return is_categorical(s.kind) ? 1 : s.dim; };
+  // slots: steps are laid out back to back, S slots each, step 0 right behind the pre-Scan slots
+  int S = 0, base0 = -1;
+  for (int l = 0; l < m; ++l) if (at(0, l).slot >= 0) { S += width(at(0, l)); if (base0 < 0 || at(0, l).slot < base0) base0 = at(0, l).slot; }
+  if (S <= 0 || base0 < 0 || p->n_slots != base0 + T * S) return r;
+  for (int j = 0; j < i0; ++j) if (p->sites[j].slot >= 0 && p->sites[j].slot + width(p->sites[j]) > base0) return r;
+  const int n_pre = base0;
+  auto base = [&](int t) { return base0 + t * S; };
+  // every step has step 1's shape; step 0 may differ in its parameters only (the initial carry is constant)
+  for (int t = 0; t < T; ++t)
+    for (int l = 0; l < m; ++l) {
+      const gjx_site &a = at(t, l), &b = at(1, l);
+      if (a.kind != b.kind || a.dim != b.dim || a.mode != b.mode || a.ncat != b.ncat || a.flags != b.flags) return r;
+      if ((a.slot < 0) != (b.slot < 0) || (a.slot >= 0 && a.slot - base(t) != b.slot - base(1))) return r;
+      if (a.slot >= 0 && (a.slot < base(t) || a.slot + width(a) > base(t) + S)) return r;
+    }
+  // strides from steps 1 and 2, checked on every later step
+  std::vector<RollInfo> st(m);
+  for (int l = 0; l < m; ++l) {
+    const gjx_site &a = at(1, l), &b = at(2, l);
+    st[l].d_obs = a.mode == GJX_MODE_OBS_TAB ? b.obs_off - a.obs_off : 0;
+    for (int k = 0; k < n_params(a.kind); ++k) { st[l].d_off[k] = b.p[k].off - a.p[k].off; st[l].d_moff[k] = b.p[k].moff - a.p[k].moff; }
+  }
+  for (int t = 1; t < T; ++t)
+    for (int l = 0; l < m; ++l) {
+      const gjx_site &a = at(1, l), &b = at(t, l);
+      if (a.mode == GJX_MODE_OBS_TAB && b.obs_off != a.obs_off + (t - 1) * st[l].d_obs) return r;
+      for (int k = 0; k < n_params(a.kind); ++k) {
+        const gjx_param &qa = a.p[k], &qb = b.p[k];
+        if (qa.op != qb.op || qa.xf != qb.xf || qa.len != qb.len || qa.n != qb.n) return r;
+        if (qa.op != GJX_P_VALUE && qb.off != qa.off + (t - 1) * st[l].d_off[k]) return r;
+        if (qa.op == GJX_P_AFFINE && qb.moff != qa.moff + (t - 1) * st[l].d_moff[k]) return r;
+        if (slot_op(qa.op)) {
+          const bool pre = qa.slot + ref_span(qa) <= n_pre;
+          if (pre ? qb.slot != qa.slot : qb.slot != qa.slot + (t - 1) * S) return r;
+          // a reference that moves with the step stays inside the previous or inside the current step
+          if (!pre) {
+            const bool in_prev = qa.slot >= base(0) && qa.slot + ref_span(qa) <= base(0) + S;
+            const bool in_cur = qa.slot >= base(1) && qa.slot + ref_span(qa) <= base(1) + S;
+            if (!in_prev && !in_cur) return r;
+          }
+        }
+      }
+    }
+  // step 0's references: pre-Scan slots or its own step
+  for (int l = 0; l < m; ++l)
+    for (int k = 0; k < n_params(at(0, l).kind); ++k) {
+      const gjx_param& q = at(0, l).p[k];
+      if (!slot_op(q.op)) continue;
+      const bool pre = q.slot + ref_span(q) <= n_pre;
+      const bool own = q.slot >= base(0) && q.slot + ref_span(q) <= base(0) + S;
+      if (!pre && !own) return r;
+    }
+  // ---- the emitted program
+  auto remap = [&](int ref, int tau) -> int {     // a slot referenced from step tau -> register slot
+    if (ref < n_pre) return ref;
+    if (ref >= base(tau) && ref < base(tau) + S) return n_pre + S + (ref - base(tau));   // current step
+    return n_pre + (ref - base(tau - 1));                                                 // previous step
+  };
+  for (int j = 0; j < i0; ++j) {
+    r.sites.push_back(p->sites[j]);
+    RollInfo ri; ri.row = p->sites[j].slot; ri.score_row = j;
+    r.info.push_back(ri);
+  }
+  for (int tau = 0; tau < 2; ++tau)
+    for (int l = 0; l < m; ++l) {
+      gjx_site s = at(tau, l);
+      RollInfo ri = tau ? st[l] : RollInfo();
+      ri.row = s.slot; ri.score_row = i0 + tau * m + l;
+      if (tau) { ri.d_row = S; ri.d_score_row = m; }
+      if (s.slot >= 0) s.slot = remap(s.slot, tau);
+      for (int k = 0; k < n_params(s.kind); ++k) if (slot_op(s.p[k].op)) s.p[k].slot = remap(s.p[k].slot, tau);
+      r.sites.push_back(s);
+      r.info.push_back(ri);
+    }
+  r.ok = true; r.i0 = i0; r.m = m; r.T = T; r.S = S; r.n_pre = n_pre; r.scan_id = id;
+  return r;
+}
+
 // what the emitter covers; everything else runs on the interpreter
-bool supported(const gjx_program* p) {
-  if (p->n_sites < 1 || p->n_sites > 48 || p->n_slots > 160) return false;
+bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
+  if (n_sites < 1 || n_sites > 48 || n_slots > 160) return false;
   int total = 0;
-  for (int j = 0; j < p->n_sites; ++j) {
-    const gjx_site& s = p->sites[j];
+  for (int j = 0; j < n_sites; ++j) {
+    const gjx_site& s = sites[j];
     if (s.kind == GJX_DIRICHLET || s.kind < 1 || s.kind > GJX_CHI2) return false;
     if (is_categorical(s.kind)) {
       if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
@@ -114,21 +251,28 @@ bool supported(const gjx_program* p) {
   return total <= 320;
 }
 
+bool supported(const gjx_program* p) {
+  if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots)) return true;
+  const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
+  return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_pre + 2 * r.S);
+}
+
 // index into the float table of parameter q at element `d` (a C expression; `dx` is the element index expression)
-std::string tab_index(const gjx_param& q, const std::string& dx, int site, int k) {
+std::string tab_index(const gjx_param& q, const std::string& dx, int site, int k, int d_off = 0) {
   char b[256];
   const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
-  if (q.op == GJX_P_CONST) snprintf(b, sizeof(b), "%d + %s", q.off, e.c_str());
-  else snprintf(b, sizeof(b), "%d + gi_%d_%d[p] * %d + %s", q.off, site, k, q.len, e.c_str());
+  const std::string off = toff(q.off, d_off);
+  if (q.op == GJX_P_CONST) snprintf(b, sizeof(b), "%s + %s", off.c_str(), e.c_str());
+  else snprintf(b, sizeof(b), "%s + gi_%d_%d[p] * %d + %s", off.c_str(), site, k, q.len, e.c_str());
   return b;
 }
 
 // value of parameter q at element dx for particle p (before the transform)
-std::string param_expr(const gjx_param& q, const std::string& dx, int site, int k) {
+std::string param_expr(const gjx_param& q, const std::string& dx, int site, int k, int d_off = 0) {
   char b[512];
   switch (q.op) {
     case GJX_P_CONST:
-    case GJX_P_GATHER: return "TAB(" + tab_index(q, dx, site, k) + ")";
+    case GJX_P_GATHER: return "TAB(" + tab_index(q, dx, site, k, d_off) + ")";
     case GJX_P_VALUE:
       if (q.len == 1) snprintf(b, sizeof(b), "v[%d][p]", q.slot);
       else snprintf(b, sizeof(b), "v[%d + (%s) %% %d][p]", q.slot, dx.c_str(), q.len);
@@ -146,11 +290,11 @@ std::string xf_wrap(int xf, const std::string& e) {
 }
 
 // statements that must precede the use of param_expr for element dx (affine accumulations)
-void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind) {
+void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, int d_off = 0, int d_moff = 0) {
   if (q.op != GJX_P_AFFINE) return;
   const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
-  o.f("%sfloat aff_%d_%d = TAB(%d + %s);\n", ind, site, k, q.off, e.c_str());
-  o.f("%s{ const int r_ = %d + (%s) * %d;\n", ind, q.moff, dx.c_str(), q.n);
+  o.f("%sfloat aff_%d_%d = TAB(%s + %s);\n", ind, site, k, toff(q.off, d_off).c_str(), e.c_str());
+  o.f("%s{ const int r_ = %s + (%s) * %d;\n", ind, toff(q.moff, d_moff).c_str(), dx.c_str(), q.n);
   o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) aff_%d_%d = fmaf(TAB(r_ + e_), v[%d + e_][p], aff_%d_%d); }\n", ind, q.n, site,
       k, q.slot, site, k);
 }
@@ -167,6 +311,7 @@ void emit_gather_index(Emit& o, const gjx_site& s, int site, int np) {
 void emit_site(Emit& o, Plan& pl, int j) {
   const gjx_program* prog = pl.prog;
   const gjx_site& s = prog->sites[j];
+  const RollInfo& ri = pl.info[j];
   const int mode = s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
@@ -184,9 +329,9 @@ void emit_site(Emit& o, Plan& pl, int j) {
     const gjx_param& q = s.p[0];
     const int n = s.ncat;
     const bool probs = kind == GJX_CATEGORICAL_PROBS;
-    const bool fast = q.op == GJX_P_CONST && q.xf == GJX_XF_NONE && !probs && q.len == n;
+    const bool fast = q.op == GJX_P_CONST && q.xf == GJX_XF_NONE && !probs && q.len == n && ri.d_off[0] == 0;
     // L(c): logit of category c for particle p
-    std::string L = xf_wrap(q.xf, param_expr(q, "c_", j, 0));
+    std::string L = xf_wrap(q.xf, param_expr(q, "c_", j, 0, ri.d_off[0]));
     if (probs) L = "safe_log(" + L + ")";
     if (fast) {
       const int at = pl.find(2, q.off, n);
@@ -200,7 +345,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         o.f("          for (int c_ = 0; c_ < %d; ++c_) { const float g_ = %s + gumbel_from_bits(bs[p].get((uint32_t)c_)); if (g_ > bestv) { bestv = g_; best = c_; } }\n", n, L.c_str());
         o.f("          val = (float)best;\n        }\n");
       }
-      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%d);\n", s.obs_off);
+      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%s);\n", toff(s.obs_off, ri.d_obs).c_str());
       if (mode == GJX_MODE_OBS_SLOT) o.f("        val = v[%d][p];\n", s.slot);
       if (masked) o.f("        if (given[p]) val = v[%d][p];\n", s.slot);
       o.f("        const int k_ = (int)val;\n");
@@ -219,7 +364,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         o.f("          for (int c_ = 0; c_ < %d; ++c_) { const float g_ = %s + gumbel_from_bits(bs[p].get((uint32_t)c_)); if (g_ > bestv) { bestv = g_; best = c_; } }\n", n, L.c_str());
         o.f("          val = (float)best;\n        }\n");
       }
-      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%d);\n", s.obs_off);
+      if (mode == GJX_MODE_OBS_TAB) o.f("        val = TAB(%s);\n", toff(s.obs_off, ri.d_obs).c_str());
       if (mode == GJX_MODE_OBS_SLOT) o.f("        val = v[%d][p];\n", s.slot);
       if (masked) o.f("        if (given[p]) val = v[%d][p];\n", s.slot);
       o.f("        const int k_ = (int)val;\n");
@@ -237,14 +382,14 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // the scale of a normal that comes straight from the table has its log and reciprocal in the prologue's companions
     const bool norm = is_normal(kind);
     const gjx_param& qb = s.p[1];
-    const bool comp_scale = norm && table_param(qb);
+    const bool comp_scale = norm && table_param(qb) && ri.d_off[1] == 0;   // companions are built once: time-invariant scales only
     int at_rcp = -1, at_sum = -1;
     if (comp_scale) {
       if (mode != GJX_MODE_SAMPLE) at_rcp = pl.find(1, qb.off, table_range(qb));
       at_sum = pl.find(3, qb.off, qb.op == GJX_P_CONST ? 1 : qb.n, qb.len, dim);
     }
     // observed in the table under a constant scale: z = y/sigma - mean/sigma with y/sigma precomputed
-    const int at_ys = (comp_scale && mode == GJX_MODE_OBS_TAB && qb.op == GJX_P_CONST) ? pl.find(4, qb.off, dim, qb.len, s.obs_off) : -1;
+    const int at_ys = (comp_scale && mode == GJX_MODE_OBS_TAB && qb.op == GJX_P_CONST && ri.d_obs == 0) ? pl.find(4, qb.off, dim, qb.len, s.obs_off) : -1;
     // diagonal normals accumulate the squared z-scores; the normaliser is one constant per (gathered) row of the
     // scale table, or summed alongside when the scale is not a plain table entry
     if (norm) o.f("      float q2[PPT], ls[PPT];\n      PLOOP { q2[p] = 0.0f; ls[p] = 0.0f; }\n");
@@ -253,8 +398,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
       std::string in2 = std::string(ind) + "  ";
       std::string pe[4];
       for (int k = 0; k < np; ++k) {
-        emit_param_pre(o, s.p[k], dx, j, k, in2.c_str());
-        pe[k] = xf_wrap(s.p[k].xf, param_expr(s.p[k], dx, j, k));
+        emit_param_pre(o, s.p[k], dx, j, k, in2.c_str(), ri.d_off[k], ri.d_moff[k]);
+        pe[k] = xf_wrap(s.p[k].xf, param_expr(s.p[k], dx, j, k, ri.d_off[k]));
       }
       for (int k = np; k < 4; ++k) pe[k] = "0.0f";
       const std::string vslot = "v[" + std::to_string(s.slot) + " + (" + dx + ")][p]";
@@ -262,7 +407,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
       if (norm) {
         std::string logb, rcpb;
         if (comp_scale) {
-          const std::string idx = "(" + tab_index(qb, dx, j, 1) + ") - " + std::to_string(qb.off);
+          const std::string idx = "(" + tab_index(qb, dx, j, 1) + ") - " + std::to_string(qb.off);   // d_off[1] == 0 here
           if (at_rcp >= 0) rcpb = "COMP(" + std::to_string(at_rcp) + " + " + idx + ")";
         }
         o.f("%sconst float pb = %s;\n", in2.c_str(), pe[1].c_str());
@@ -274,7 +419,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
           o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
           if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), dx.c_str());
-          else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%d + (%s));\n", in2.c_str(), s.obs_off, dx.c_str());
+          else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
           else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
           if (at_ys >= 0) o.f("%s{ const float z_ = fmaf(-%s, pa, COMP(%d + (%s))); q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str(), at_ys, dx.c_str());
           else o.f("%s{ const float z_ = (val - pa) * %s; q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str());
@@ -285,7 +430,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
         if (mode == GJX_MODE_SAMPLE) o.f("%sval = %s;\n", in2.c_str(), smp.c_str());
         else if (masked) o.f("%s{ const float smp_ = %s; val = given[p] ? %s : smp_; }\n", in2.c_str(), smp.c_str(), vslot.c_str());
-        else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%d + (%s));\n", in2.c_str(), s.obs_off, dx.c_str());
+        else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
         else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
         o.f("%slp[p] += elem_logpdf(%d, val, pa, pb, pc, pd);\n", in2.c_str(), kind);
       }
@@ -310,24 +455,44 @@ void emit_site(Emit& o, Plan& pl, int j) {
   }
   // bookkeeping: score, weight, per-site scores, store the site's rows
   o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
-  o.f("      if (a.site_scores) { float t_[PPT]; PLOOP t_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, t_); }\n", j);
+  o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
+      toff(ri.score_row, ri.d_score_row).c_str());
   if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
-    for (int d = 0; d < nrow; ++d) o.f("      VecStore<PPT>::st(a.choices + (int64_t)%d * K + i0, v[%d]);\n", s.slot + d, s.slot + d);
+    for (int d = 0; d < nrow; ++d) o.f("      VecStore<PPT>::st(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
   }
   o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
 }
 
-std::string generate(const gjx_program* prog, int ppt) {
+bool want_roll() { const char* e = getenv("GJX_GEN_ROLL"); return e && atoi(e) != 0; }
+
+std::string generate(const gjx_program* prog_in, int ppt) {
+  // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
+  Roll roll;
+  if (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots)) roll = detect_roll(prog_in);
+  gjx_program eprog = *prog_in;
+  if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_pre + 2 * roll.S; }
+  const gjx_program* prog = &eprog;
   Plan pl;
   pl.prog = prog;
   pl.ppt = ppt;
   pl.tab_lds = prog->n_tab <= kMaxLdsTab;
-  {   // stream keys and site numbers, as SiteStreamWalk (gjx_device.h) walks them
+  if (roll.ok) {
+    pl.info = roll.info;
+    unsigned plain = 0;
+    for (int j = 0; j < roll.i0; ++j) pl.stream.push_back({"", ++plain});
+    for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"sk0", (unsigned)(l + 1)});
+    for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"skt", (unsigned)(l + 1)});
+    char b[256];
+    snprintf(b, sizeof(b), "  const key2 sk0 = fold_in(fold_in(a.key, %uu), 0u);\n", 0x80000000u | roll.scan_id);
+    pl.key_decls = b;
+  } else {   // stream keys and site numbers, as SiteStreamWalk (gjx_device.h) walks them
     int tag = 0, nkey = 0;
     unsigned local = 0, plain = 0;
     std::string cur;
     for (int j = 0; j < prog->n_sites; ++j) {
+      RollInfo ri; ri.row = prog->sites[j].slot; ri.score_row = j;
+      pl.info.push_back(ri);
       const int sc = prog->sites[j].scan;
       if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", (unsigned)(j + 1)}); continue; }
       if (sc == 0) { tag = 0; pl.stream.push_back({"", ++plain}); continue; }
@@ -349,7 +514,22 @@ std::string generate(const gjx_program* prog, int ppt) {
     }
   }
   Emit body;
-  for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
+  if (roll.ok) {
+    auto carry = [&]() {   // the step just produced becomes the previous step
+      body.f("      PLOOP { ");
+      for (int l = 0; l < roll.S; ++l) body.f("v[%d][p] = v[%d][p]; ", roll.n_pre + l, roll.n_pre + roll.S + l);
+      body.f("}\n");
+    };
+    for (int j = 0; j < roll.i0 + roll.m; ++j) emit_site(body, pl, j);
+    carry();
+    body.f("    key2 skt = sk0;\n    for (int t_ = 1; t_ < %d; ++t_) {   // steps 1 .. T-1: one emitted body, rows and table offsets advance with t_\n"
+           "      skt = fold_in(skt, (uint32_t)t_);\n", roll.T);
+    for (int j = roll.i0 + roll.m; j < roll.i0 + 2 * roll.m; ++j) emit_site(body, pl, j);
+    carry();
+    body.f("    }\n");
+  } else {
+    for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
+  }
   Emit o;
   o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
@@ -498,7 +678,7 @@ std::map<std::pair<uint64_t, int>, std::pair<hipModule_t, hipFunction_t>> g_load
 
 uint64_t structure_key(const gjx_program* p, int ppt) {
   uint64_t h = fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites);
-  const int32_t extra[5] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt};
+  const int32_t extra[6] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
@@ -575,7 +755,12 @@ const Compiled& compile(const gjx_program* prog, int ppt) {
 namespace gjx {
 
 int gen_pick_ppt(const gjx_program* prog, int64_t K) {
-  int ppt = prog->n_slots <= 6 ? 4 : (prog->n_slots <= 24 ? 2 : 1);
+  int slots = prog->n_slots;      // values a lane keeps in registers: for a rolled Scan only two steps' worth
+  if (want_roll() || !supported_sites(prog->sites, prog->n_sites, prog->n_slots)) {
+    const Roll r = detect_roll(prog);
+    if (r.ok) slots = r.n_pre + 2 * r.S;
+  }
+  int ppt = slots <= 6 ? 4 : (slots <= 24 ? 2 : 1);
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;
   while (ppt > 1 && K % ppt != 0) ppt >>= 1;

@@ -89,6 +89,47 @@ def test_generated_kernel_of_a_scan_equals_the_interpreter(K_, oracle):
     np.testing.assert_allclose(_np(g["logw"]), ora["logw"], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("T,observe", [(20, True), (7, False), (300, True), (1500, True)])
+def test_rolled_scan_kernel_equals_the_interpreter_and_the_oracle(K_, oracle, T, observe):
+    """A periodic Scan is emitted as ONE loop over its steps (gjx_codegen.hip "Rolled Scans": previous / current step in
+    registers, rows and table offsets advancing with t, chained step key): same values as the interpreter's walk over
+    the T step descriptors, bit for bit (same streams, same sampler arithmetic), same weights to float rounding."""
+    K = 1 << 13
+    prog, _ = H.scan_chain(T, carry=True, observe=observe, sigma=0.3, r=0.7)
+    old = os.environ.get("GJX_GEN_ROLL")
+    os.environ["GJX_GEN_ROLL"] = "1"
+    try:
+        with engine("gen"):
+            assert K_.program_engine(prog) == 4
+            src = K_.program_source(prog)
+            assert "for (int t_ = 1; t_ < %d; ++t_)" % T in src and "skt = fold_in(skt, (uint32_t)t_)" in src
+            g = K_.run_program(prog, (5, 6), K, want_site_scores=True)
+    finally:
+        if old is None:
+            del os.environ["GJX_GEN_ROLL"]
+        else:
+            os.environ["GJX_GEN_ROLL"] = old
+    with engine("interp"):
+        i = K_.run_program(prog, (5, 6), K, want_site_scores=True)
+    np.testing.assert_array_equal(_np(g["choices"]), _np(i["choices"]))
+    np.testing.assert_allclose(_np(g["site_scores"]), _np(i["site_scores"]), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_np(g["logw"]), _np(i["logw"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(_np(g["lse"])[2:], _np(i["lse"])[2:], rtol=1e-4)
+    if T <= 300:
+        ora = oracle.run_program(prog, (5, 6), K)
+        np.testing.assert_allclose(_np(g["choices"]), ora["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(g["logw"]), ora["logw"], rtol=3e-4, atol=3e-4)
+
+
+def test_long_scan_picks_the_rolled_kernel_by_itself(K_):
+    """Too long to unroll (the generator takes 48 sites): the engine choice rolls the Scan instead of falling back to the
+    interpreter."""
+    prog, _ = H.scan_chain(400, carry=True, observe=True, sigma=0.3, r=0.7)
+    assert K_.program_engine(prog) == 4
+    short, _ = H.scan_chain(3, carry=True, observe=True)          # fewer than 4 steps: plain unrolled kernel
+    assert "for (int t_ = 1;" not in K_.program_source(short)
+
+
 def test_gen_scan_api_with_more_steps_than_site_numbers(K_):
     """`kernel.scan(n=T)` through the API with T > 1023: simulate, then the score is the sum of the step log-densities of
     the returned choices (scan.py:283-294)."""
