@@ -151,3 +151,30 @@ def test_gen_scan_api_with_more_steps_than_site_numbers(K_):
     inc = np.diff(np.vstack([np.zeros((1, K)), x]), axis=0) / 0.25
     want = (-0.5 * inc ** 2 - 0.5 * np.log(2 * np.pi) - np.log(0.25)).sum(axis=0)
     np.testing.assert_allclose(_np(tr.get_score()), want, rtol=1e-4)
+
+
+def test_observed_scan_through_the_api_runs_the_rolled_kernel(K_):
+    """`@gen` step kernel -> `.scan(n=T)` -> Target with a whole-sequence constraint -> ImportanceK: the packed program
+    is periodic, so the engine is the rolled generated kernel; the importance weights are the observation log-densities
+    of the sampled trajectories (static.py:377 summed over the steps, scan.py:283-294)."""
+    import genjax_amd as genjax
+    from genjax_amd import C
+    from genjax_amd.inference import ImportanceK, Target
+
+    @genjax.gen
+    def step(carry, _):
+        x = genjax.normal(carry, 0.25) @ "x"
+        genjax.normal(x, 0.5) @ "y"
+        return x, x
+
+    T, K = 300, 1 << 12
+    ys = np.random.default_rng(0).standard_normal(T).astype(np.float32) * 0.3
+    model = step.scan(n=T)
+    prog, _, _ = model.pack((0.0, None), C["y"].set(ys), True)
+    assert K_.program_engine(prog) == 4 and "for (int t_ = 1;" in K_.program_source(prog)
+    pc = ImportanceK(Target(model, (0.0, None), C["y"].set(ys)), k_particles=K).run_smc(genjax.key(5))
+    x = np.asarray(_np(pc.get_particles().get_choices()[:, "x"]), np.float64)
+    if x.shape[0] != T:
+        x = x.T
+    want = (-0.5 * ((ys[:, None] - x) / 0.5) ** 2 - 0.5 * np.log(2 * np.pi) - np.log(0.5)).sum(axis=0)
+    np.testing.assert_allclose(_np(pc.get_log_weights()), want, rtol=2e-4)
