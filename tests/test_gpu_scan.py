@@ -178,3 +178,43 @@ def test_observed_scan_through_the_api_runs_the_rolled_kernel(K_):
         x = x.T
     want = (-0.5 * ((ys[:, None] - x) / 0.5) ** 2 - 0.5 * np.log(2 * np.pi) - np.log(0.5)).sum(axis=0)
     np.testing.assert_allclose(_np(pc.get_log_weights()), want, rtol=2e-4)
+
+
+def test_rolled_scan_with_a_hyper_site_vector_state_and_affine_transition(K_, oracle):
+    """The general shapes: a site BEFORE the Scan that every step reads (scale of the transition noise), a vector state
+    with an affine transition x_t ~ N(A x_{t-1}, s), a categorical regime per step that gathers the observation scale,
+    and vector observations — rolled kernel vs interpreter (bitwise values) vs oracle."""
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    rs = np.random.default_rng(3)
+    T, D, K = 60, 3, 1 << 12
+    Amat = (0.9 * np.eye(D) + 0.05 * rs.standard_normal((D, D))).astype(np.float32)
+    ys = rs.standard_normal((T, D)).astype(np.float32)
+    sl = SiteList()
+    modes, obs = {}, {}
+    sl.add("s", A.HALF_NORMAL, [Param.const(0.5)])
+    for t in range(T):
+        tag = (0 << 20) | (t + 1)
+        loc = Param.affine(Amat, ("x", t - 1)) if t > 0 else Param.const(np.zeros(D, np.float32))
+        sx = sl.add(("x", t), A.MVNORMAL_DIAG, [loc, Param.value("s", 1)], dim=D)
+        sz = sl.add(("z", t), A.CATEGORICAL_LOGITS, [np.array([0.2, -0.1, 0.4], np.float32)])
+        sy = sl.add(("y", t), A.MVNORMAL_DIAG, [Param.value(("x", t), D), Param.gather(np.array([[0.5], [1.0], [2.0]], np.float32), ("z", t))], dim=D)
+        for s_ in (sx, sz, sy):
+            s_.scan = tag
+        modes[("y", t)] = A.MODE_OBS_TAB
+        obs[("y", t)] = ys[t]
+    prog = PackedProgram(sl, modes, obs, rng_mode=A.RNG_FLAT)
+    with engine("gen"):
+        assert K_.program_engine(prog) == 4                      # 181 sites: only the rolled form fits the generator
+        assert "for (int t_ = 1;" in K_.program_source(prog)
+        g = K_.run_program(prog, (8, 9), K, want_site_scores=True)
+    with engine("interp"):
+        i = K_.run_program(prog, (8, 9), K, want_site_scores=True)
+    gc, ic = _np(g["choices"]), _np(i["choices"])
+    np.testing.assert_array_equal(gc, ic)
+    np.testing.assert_allclose(_np(g["site_scores"]), _np(i["site_scores"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(_np(g["logw"]), _np(i["logw"]), rtol=3e-4, atol=3e-4)
+    ora = oracle.run_program(prog, (8, 9), K, want_margin=True)
+    bad = (np.abs(gc - ora["choices"]) > 5e-5 + 2e-4 * np.abs(ora["choices"])).any(axis=0)
+    assert bad.mean() < 0.02                                   # regime flips at near ties propagate down the chain
+    good = ~bad
+    np.testing.assert_allclose(_np(g["logw"])[good], ora["logw"][good], rtol=5e-4, atol=5e-4)
