@@ -56,7 +56,7 @@ class GjxSite(C.Structure):
 class GjxProgram(C.Structure):
     _fields_ = [("n_sites", i32), ("n_slots", i32), ("n_tab", i32), ("rng_mode", i32),
                 ("sites", vp), ("sites_dev", vp), ("tab", vp), ("tab_dev", vp), ("aux_dev", vp), ("n_aux", i32),
-                ("pad_", i32)]
+                ("uid", i32)]
 
 
 class GjxSsm(C.Structure):

@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 
 #include <map>
+#include <unordered_map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -251,7 +252,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
   return total <= 320;
 }
 
-bool supported(const gjx_program* p) {
+bool supported_uncached(const gjx_program* p) {
   if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
   return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_pre + 2 * r.S);
@@ -676,8 +677,49 @@ std::mutex g_mu;
 std::map<uint64_t, Compiled> g_compiled;                                 // by structure key
 std::map<std::pair<uint64_t, int>, std::pair<hipModule_t, hipFunction_t>> g_loaded;   // by (key, device)
 
+// per-program analysis cached under gjx_program.uid (0 = no caching): the site-list hash, the emitter's verdict and the
+// register footprint that decides PPT — each of them a walk over the whole site list
+struct ProgMeta { bool roll_pref; uint64_t sites_hash; int supported; int slots; };   // supported / slots: -1 = not computed yet
+std::mutex g_meta_mu;
+std::unordered_map<int32_t, ProgMeta> g_meta;
+
+ProgMeta* meta_of(const gjx_program* p) {      // call with g_meta_mu held; nullptr when the program has no uid
+  if (p->uid == 0) return nullptr;
+  ProgMeta& m = g_meta[p->uid];
+  if (m.sites_hash == 0 || m.roll_pref != want_roll()) m = ProgMeta{want_roll(), fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites) | 1ull, -1, -1};
+  return &m;
+}
+
+uint64_t sites_hash(const gjx_program* p) {
+  std::lock_guard<std::mutex> lock(g_meta_mu);
+  if (ProgMeta* m = meta_of(p)) return m->sites_hash;
+  return fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites) | 1ull;
+}
+
+bool supported(const gjx_program* p) {
+  std::lock_guard<std::mutex> lock(g_meta_mu);
+  ProgMeta* m = meta_of(p);
+  if (!m) return supported_uncached(p);
+  if (m->supported < 0) m->supported = supported_uncached(p) ? 1 : 0;
+  return m->supported == 1;
+}
+
+// values a lane keeps in registers: all slots, or two steps' worth (+ the pre-Scan slots) when the program is rolled
+int register_slots(const gjx_program* p) {
+  std::lock_guard<std::mutex> lock(g_meta_mu);
+  ProgMeta* m = meta_of(p);
+  if (m && m->slots >= 0) return m->slots;
+  int slots = p->n_slots;
+  if (want_roll() || !supported_sites(p->sites, p->n_sites, p->n_slots)) {
+    const Roll r = detect_roll(p);
+    if (r.ok) slots = r.n_pre + 2 * r.S;
+  }
+  if (m) m->slots = slots;
+  return slots;
+}
+
 uint64_t structure_key(const gjx_program* p, int ppt) {
-  uint64_t h = fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites);
+  uint64_t h = sites_hash(p);
   const int32_t extra[6] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
@@ -755,11 +797,7 @@ const Compiled& compile(const gjx_program* prog, int ppt) {
 namespace gjx {
 
 int gen_pick_ppt(const gjx_program* prog, int64_t K) {
-  int slots = prog->n_slots;      // values a lane keeps in registers: for a rolled Scan only two steps' worth
-  if (want_roll() || !supported_sites(prog->sites, prog->n_sites, prog->n_slots)) {
-    const Roll r = detect_roll(prog);
-    if (r.ok) slots = r.n_pre + 2 * r.S;
-  }
+  const int slots = register_slots(prog);
   int ppt = slots <= 6 ? 4 : (slots <= 24 ? 2 : 1);
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;

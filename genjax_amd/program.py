@@ -9,6 +9,7 @@ struct of ``include/gjx.h`` and handed to the HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -101,6 +102,9 @@ class MissingAddress(Exception):
     """assess() without a value for a site (reference: static.py:147, 316-318)."""
 
 
+_UIDS = itertools.count(1)     # gjx_program.uid of every PackedProgram of this process
+
+
 @dataclass
 class SiteList:
     """Ordered sites of a generative function (program order == the reference's trace order)."""
@@ -189,6 +193,7 @@ class PackedProgram:
 
         n = len(sl.sites)
         self.c_sites = (A.GjxSite * max(n, 1))()
+        self._uid = next(_UIDS)     # gjx_program.uid: names this site list for the library's per-program caches
         self.obs_off: dict[str, int] = {}
         self.slot_of: dict[str, int] = {}
         self._derived: list[tuple[int, Param, str]] = []  # CONST blocks computed from observed values
@@ -339,6 +344,7 @@ class PackedProgram:
         p = A.GjxProgram()
         p.n_sites, p.n_slots, p.n_tab, p.rng_mode = self.n_sites, self.n_slots, int(self.tab.size), self.rng_mode
         p.sites = C.cast(self.c_sites, C.c_void_p)
+        p.uid = self._uid
         p.tab = self.tab.ctypes.data_as(C.c_void_p)
         if device is not None:
             import torch

@@ -173,7 +173,9 @@ typedef struct gjx_program {
   const float* tab_dev;     /* DEVICE copy of the same floats */
   const float* aux_dev;     /* DEVICE: constants derived from tab by gjx_program_prepare (or NULL) */
   int32_t n_aux;            /* floats in aux_dev */
-  int32_t pad_;
+  int32_t uid;              /* 0, or a caller-chosen id that names THIS site list (and n_tab, rng_mode) for the lifetime of the
+                             * process: lets the library cache its per-program analysis (engine choice, kernel lookup) instead of
+                             * walking the site list on every call — matters for long Scans.  Table VALUES may change under one id. */
 } gjx_program;
 
 /* ---- library ---------------------------------------------------------------------------- */
