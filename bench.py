@@ -358,13 +358,14 @@ def run_ssm(args, rank, world, dev):
                              "one bench step = one T=256 filter run" % (2 if world == 1 else 3), k_particles_per_gpu=K_local,
                     k_particles_total=K, T=T, rng_stream="flat", sharding=f"particles x{world}",
                     exchange=exch["transport"], exchange_stats=exch),
-        roofline=dict(bound="hbm", kernel=("gjx::k_ssm_fused_step<FLAT,8> (one launch per filter step: resample + propagate + reweight)"
+        roofline=dict(bound="hbm", kernel=("gjx::k_ssm_persistent<FLAT,8,1024> (steps 1..T-1 of the filter in ONE launch: two grid "
+                                           "rendezvous per step, resample + propagate + reweight)"
                                            if world == 1 else "sharded filter step: k_ssm_step + exchange"),
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
                       algorithmic_bytes_per_launch=algo,
-                      note="latency-bound at K=2^18: one grid rendezvous (~4.5 us), ~3 dependent memory round trips and a ~4 us "
-                           "kernel boundary per step (phase timeline: profiles/, DESIGN.md section 5); kernel_us = wall time per filter step"),
+                      note="latency-bound at K=2^18: two grid rendezvous (~3 + ~4 us) and ~8 us of VALU work per step, no kernel "
+                           "boundary (phase timeline: profiles/, DESIGN.md section 5); kernel_us = wall time per filter step"),
         log_ml=float(lml), log_ml_exact=exact, log_ml_rel_err=abs(float(lml) - exact) / abs(exact),
     )
     if not args.no_cpu_baseline and world == 1:

@@ -64,7 +64,7 @@ enum { kStatusPollTimeout = 1u, kStatusZeroTotal = 2u };
 // all-gather (by then every block has read the old epoch), so consecutive calls never mistake each other's granules
 // and the workspace needs zeroing only once.  Every lane carries a poll budget (~1 s): a grid that is not co-resident
 // must not hang — it sets kStatusPollTimeout and carries on with zeros.
-// `visit(b, value)` is called by lane (b mod 256) for every block b.
+// `visit(b, value)` is called by thread (b mod blockDim.x) for every block b.
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long kAggMask = (1ull << 50) - 1;
 
@@ -84,7 +84,7 @@ GJX_DEV void grid_publish(unsigned long long* agg, unsigned long long tag, unsig
 template <class Visit>
 GJX_DEV void grid_gather(const unsigned long long* agg, unsigned long long tag, unsigned* ctrl, Visit&& visit) {
   unsigned budget = 1u << 22;   // polls this lane may spend in total (~1 s): a grid that is not co-resident must not hang
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += (int)blockDim.x) {
     unsigned long long v = 0;
     while (budget) {
       v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

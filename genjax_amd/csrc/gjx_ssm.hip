@@ -8,6 +8,7 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 #include "gjx_scan.h"
+#include <vector>
 
 namespace gjx {
 
@@ -408,6 +409,305 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
 #undef GJX_STAMP
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The whole filter in ONE launch (steps 1 .. T-1; step 0 is k_ssm_step).  Per step the blocks of the co-resident grid
+// meet twice — all-gather of the block maxima of log w_{t-1} (the fixed point needs the exact global maximum), then of
+// the tile totals — and there is no kernel boundary: a block keeps the log-weights of the slots it produced (they are
+// the particles it scans next), the ancestors are found on the consumer side exactly as in k_ssm_fused_step, and the
+// state and log-weights other blocks read cross the chip through write-through (agent-scope) stores and loads, ordered
+// by a release fence before a block publishes its granule.  Ping-pong buffers are safe without further fences: a block
+// can only overwrite the buffer of step t-1 in step t+1, after every block has published its granule of step t+1, i.e.
+// has finished reading it.  The LSE record of step t-1 is finished by block (t-1) mod gridDim.x from the gathered
+// maxima and the per-block sums.  Same ancestors, same streams, same values as the per-step kernels.
+// ------------------------------------------------------------------------------------------------------------
+struct SsmPersistArgs {
+  const float* A; const float* H; const float* ys;   // ys [T][dy]
+  float q, r;
+  int dy, T;
+  int64_t K;
+  float* x_a; float* x_b;          // [DX][K]: step t writes x_b when t is odd
+  float* lw_even; float* lw_odd;   // log-weights of step t in lw_odd when (T - 1 - t) is odd (the last step writes the caller's)
+  const uint32_t* keys;            // [T][2] propagation key of every step
+  const double* us;                // [T]    comb offset of every step
+  float* lse_steps;                // [T][4]
+  int32_t* ancestors;              // [K]: of the last step
+  unsigned long long* aggA; unsigned long long* aggB;
+  float* bsum;                     // [gridDim.x] per-block sum of exp(log w - block max)
+  unsigned* ctrl;
+  float log_k;
+  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block for step T / 2
+};
+
+GJX_DEV float load_agent(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int RNG, int DX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
+  // THREADS = 1024 (one block per CU, 256 blocks at K = 2^18) quarters the granules of each all-gather: a rendezvous
+  // among 256 blocks measures 3.5 us, among 1024 blocks 5.4 us
+  constexpr int NW = THREADS / 64;               // waves per block
+  constexpr int WPT = THREADS / 256;             // waves that re-scan one source tile together (256 particles each)
+  constexpr int kChunk = NW / WPT;               // source tiles re-scanned per round (= 4)
+  constexpr int kPer = (kSsmFusedMaxTiles + THREADS - 1) / THREADS;
+  __shared__ float fred[2 * NW];
+  __shared__ uint64_t wsum[NW];
+  __shared__ uint64_t P[kSsmFusedMaxTiles + 1];
+  __shared__ uint64_t cumL[kChunk * THREADS];
+  __shared__ int32_t s_tof[THREADS], s_tiles[THREADS];
+  __shared__ int s_cnt[NW];
+  const unsigned epoch = __hip_atomic_load(&f.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t K = f.K;
+  const int nb = (int)gridDim.x, T = f.T;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * THREADS + threadIdx.x;  // the slot this lane produces = the particle it scans
+  const bool active = j < K;
+  auto lw_buf = [&](int t) { return ((T - 1 - t) & 1) ? f.lw_odd : f.lw_even; };
+  auto x_buf = [&](int t) { return (t & 1) ? f.x_b : f.x_a; };
+  const float rr = fast_rcp(f.r);
+  const float lconst = -(float)f.dy * (kHalfLog2Pi + fast_log(f.r));
+  float lw_own = active ? lw_buf(0)[j] : -INFINITY;               // step 0 ran in the previous launch
+#define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  for (int t = 1; t <= T; ++t) {
+    GJX_PSTAMP(0);
+    // ---- rendezvous A: exact global maximum of log w_{t-1} (nothing else rides on it: published as early as possible) ----
+    const unsigned long long tagA = (unsigned long long)((epoch + 2u * (unsigned)(t - 1)) % 16383u) + 1ull;
+    const unsigned long long tagB = (unsigned long long)((epoch + 2u * (unsigned)(t - 1) + 1u) % 16383u) + 1ull;
+    float bm;
+    {
+      const float wm = wave_max(active ? lw_own : -INFINITY);
+      __syncthreads();
+      if (lane == 0) fred[wid] = wm;
+      __syncthreads();
+      bm = fred[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
+      if (threadIdx.x == 0) grid_publish(f.aggA, tagA, (unsigned long long)__float_as_uint(bm));
+    }
+    GJX_PSTAMP(1);
+    // while the granules travel: this block's sum of exp(log w - block max), for the LSE record (read after rendezvous B)
+    {
+      const float e = (active && bm > -INFINITY) ? fast_exp(lw_own - bm) : 0.0f;
+      const float ws = wave_sum(e);
+      if (lane == 0) fred[NW + wid] = ws;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float bs = 0.0f;
+        for (int w = 0; w < NW; ++w) bs += fred[NW + w];
+        store_agent(&f.bsum[blockIdx.x], bs);
+      }
+    }
+    float pm[kPer];
+    int np = 0;
+    float mx = -INFINITY;
+    grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
+      const float m = __uint_as_float((uint32_t)v);
+      pm[np++] = m;
+      mx = fmaxf(mx, m);
+    });
+    mx = wave_max(mx);     // (no acquire fence: everything read from other blocks goes through agent-scope loads)
+    __syncthreads();
+    if (lane == 0) fred[wid] = mx;
+    __syncthreads();
+    mx = fred[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[w]);
+    GJX_PSTAMP(2);
+    // ---- rendezvous B: tile totals of the fixed-point weights.  The granule goes out only after this lane's
+    //      write-through (sc1) stores of step t-1 — x, log w, the block sum — have completed; readers use sc1 loads: no
+    //      cache maintenance on either side (MI355X guide G16 form R2; a release fence per wave cost 60 us per step).
+    //      At t == T only the ordering matters (the last LSE record is finished behind it). ----
+    {
+      float xv[1] = {lw_own};
+      const uint64_t qv = (active && t < T) ? weight_q(xv, 0, 1, mx) : 0;
+      const uint64_t wt = wave_sum_u64(qv);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (lane == 0) wsum[wid] = wt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint64_t tt = 0;
+        for (int w = 0; w < NW; ++w) tt += wsum[w];
+        grid_publish(f.aggB, tagB, tt);
+      }
+    }
+    GJX_PSTAMP(3);
+    grid_gather(f.aggB, tagB, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
+    if (threadIdx.x == 0) P[0] = 0;
+    __syncthreads();
+    {
+      const int per = (nb + THREADS - 1) / THREADS;
+      const int e0 = threadIdx.x * per < nb ? threadIdx.x * per : nb, e1 = (e0 + per) < nb ? (e0 + per) : nb;
+      uint64_t loc = 0;
+      for (int e = e0; e < e1; ++e) loc += P[e + 1];
+      uint64_t inc = loc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      __syncthreads();
+      if (lane == 63) wsum[wid] = inc;
+      __syncthreads();
+      uint64_t run = inc - loc;
+      for (int w = 0; w < wid; ++w) run += wsum[w];
+      for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+      __syncthreads();
+    }
+    const uint64_t total = P[nb];
+    GJX_PSTAMP(4);
+    if ((int)blockIdx.x == (t - 1) % nb) {                        // block-uniform: finish the LSE record of step t-1
+      float sacc = 0.0f;
+      int k = 0;
+      for (int b = threadIdx.x; b < nb; b += THREADS, ++k) sacc += mx > -INFINITY ? load_agent(&f.bsum[b]) * fast_exp(pm[k] - mx) : 0.0f;
+      sacc = wave_sum(sacc);
+      __syncthreads();
+      if (lane == 0) fred[NW + wid] = sacc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float se = 0.0f;
+        for (int w = 0; w < NW; ++w) se += fred[NW + w];
+        const float l = mx > -INFINITY ? mx + logf(se) : -INFINITY;
+        float* rec = f.lse_steps + 4 * (size_t)(t - 1);
+        rec[0] = mx; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
+      }
+    }
+    if (t == T) break;
+    if (total == 0 && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_or(&f.ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- ancestor of slot j (k_ssm_fused_step's search; foreign log-weights through agent-scope loads) ----
+    const float* lw_prev = lw_buf(t - 1);
+    int64_t src = j;
+    if (total > 0) {
+      const double step = (double)total / (double)K;
+      const uint64_t Tj = comb_threshold(active ? j : K - 1, f.us[t], step, total);
+      int lo = 0, hi = nb - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (P[mid + 1] > Tj) hi = mid; else lo = mid + 1;
+      }
+      const int tile = lo;
+      s_tof[threadIdx.x] = tile;
+      __syncthreads();
+      const bool first = threadIdx.x == 0 || s_tof[threadIdx.x - 1] != tile;
+      const unsigned long long bal = __ballot(first);
+      if (lane == 0) s_cnt[wid] = __popcll(bal);
+      __syncthreads();
+      int kpos = __popcll(bal & ((2ull << lane) - 1ull)) - 1;
+      int ntiles = 0;
+      for (int w = 0; w < NW; ++w) { if (w < wid) kpos += s_cnt[w]; ntiles += s_cnt[w]; }
+      if (first) s_tiles[kpos] = tile;
+      for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
+        __syncthreads();
+        const int tl = wid / WPT, part = wid % WPT;               // this wave: quarter `part` of source tile c0 + tl
+        const bool on = c0 + tl < ntiles;
+        uint64_t qi[4], sacc = 0, inc = 0;
+        int tsrc = 0;
+        if (on) {
+          tsrc = s_tiles[c0 + tl];
+          const int64_t p0 = (int64_t)tsrc * THREADS + part * 256 + lane * 4;
+          float lw4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) lw4[k] = p0 + k < K ? load_agent(lw_prev + p0 + k) : -INFINITY;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? weight_q(lw4, k, 1, mx) : 0; qi[k] = sacc; }
+          inc = sacc;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+            if (lane >= o) inc += up;
+          }
+          if (WPT > 1 && lane == 63) wsum[wid] = inc;             // the wave's total: offset of the next quarter
+        }
+        if (WPT > 1) __syncthreads();
+        if (on) {
+          uint64_t base = P[tsrc] + (inc - sacc);
+          for (int w = 0; w < part; ++w) base += wsum[tl * WPT + w];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cumL[tl * THREADS + part * 256 + lane * 4 + k] = base + qi[k];
+        }
+        __syncthreads();
+        if (kpos >= c0 && kpos < c0 + kChunk) {
+          const uint64_t* cm = cumL + (kpos - c0) * THREADS;
+          int l2 = 0, h2 = THREADS - 1;
+          while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            if (cm[mid] > Tj) h2 = mid; else l2 = mid + 1;
+          }
+          src = (int64_t)tile * THREADS + l2;
+        }
+      }
+    }
+    GJX_PSTAMP(5);
+    if (active && t == T - 1 && f.ancestors) f.ancestors[j] = (int32_t)src;
+    if (!active) src = 0;
+    // ---- propagate + reweight slot j (k_ssm_step's arithmetic and streams) ----
+    const float* x_prev = x_buf(t - 1);
+    float* x_out = x_buf(t);
+    const uint64_t gidx = (uint64_t)j;
+    key2 skj{f.keys[2 * t], f.keys[2 * t + 1]};
+    if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
+    else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
+    float xp[DX], xn[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) xp[d] = load_agent(x_prev + (int64_t)d * K + src);
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < DX; ++e) acc = fmaf(f.A[d * DX + e], xp[e], acc);
+      xn[d] = acc;
+    }
+    if (RNG == GJX_RNG_FLAT) {
+      constexpr int NE = DX + (DX & 1);
+      constexpr int NB = GJX_FLAT_BLOCKS(NE);
+      uint32_t w[2 * NB];
+#pragma unroll
+      for (int h = 0; h < NB; ++h) {
+        const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+        w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+      }
+#pragma unroll
+      for (int d0 = 0; d0 < DX; d0 += 2) {
+        float n0, n1;
+        box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
+        xn[d0] = fmaf(f.q, n0, xn[d0]);
+        if (d0 + 1 < DX) xn[d0 + 1] = fmaf(f.q, n1, xn[d0 + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int d0 = 0; d0 < DX; ++d0) {
+        const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
+        xn[d0] = fmaf(f.q, normal_from_bits_fast(h0.a ^ h0.b), xn[d0]);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int d = 0; d < DX; ++d) store_agent(x_out + (int64_t)d * K + j, xn[d]);
+    }
+    const float* y = f.ys + (size_t)t * f.dy;
+    float qsum = 0.0f;
+    if (f.H) {
+      for (int o = 0; o < f.dy; ++o) {
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < DX; ++e) m = fmaf(f.H[o * DX + e], xn[e], m);
+        const float z = (y[o] - m) * rr;
+        qsum = fmaf(z, z, qsum);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DX; ++d) { const float z = (y[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
+    }
+    const float lw = fmaf(-0.5f, qsum, lconst);
+    if (active) store_agent(lw_buf(t) + j, lw);
+    lw_own = active ? lw : -INFINITY;
+    GJX_PSTAMP(6);
+  }
+#undef GJX_PSTAMP
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(&f.ctrl[0], epoch + 2u * (unsigned)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace gjx
 
 using namespace gjx;
@@ -547,6 +847,79 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       default: break;
     }
     if (fused_fn && (nblk > kSsmFusedMaxTiles || nblk > gjx_coresident_blocks(fused_fn, 256, 0) || 256 + 16 * (size_t)nblk > need)) fused_fn = nullptr;
+  }
+  // the whole filter in one launch (k_ssm_persistent) when everything fits: GJX_SSM_PERSISTENT=0 keeps one launch per step
+  const void* pers_fn = nullptr;
+  int pthreads = 256;
+  int64_t pblk = nblk;
+  if (fused_fn && T > 1 && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
+    const bool jax = rng_mode == GJX_RNG_JAX32;
+    // 1024-thread blocks (one per CU) once the grid would have more than 256 blocks of 256: fewer, cheaper rendezvous
+    pthreads = (nblk > 256 && (!getenv("GJX_SSM_THREADS") || atoi(getenv("GJX_SSM_THREADS")) == 1024)) ? 1024 : 256;
+#define GJX_PERS(DXV) (pthreads == 1024 ? (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 1024> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 1024>) \
+                                        : (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 256> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 256>))
+    switch (m->dx) {
+      case 2: pers_fn = GJX_PERS(2); break;
+      case 4: pers_fn = GJX_PERS(4); break;
+      case 8: pers_fn = GJX_PERS(8); break;
+      case 16: pers_fn = GJX_PERS(16); break;
+      default: break;
+    }
+#undef GJX_PERS
+    pblk = (K + pthreads - 1) / pthreads;
+    if (pers_fn && (pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 24 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+  }
+  if (pers_fn) {
+    hipStream_t st = (hipStream_t)stream;
+    float* lw_alt = (float*)cum;
+    auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
+    static thread_local std::vector<uint32_t> h_keys;
+    static thread_local std::vector<double> h_us;
+    h_keys.assign(2 * (size_t)T, 0u);
+    h_us.assign((size_t)T, 0.0);
+    uint32_t kp0[2] = {0u, 0u};
+    for (int t = 0; t < T; ++t) {
+      uint32_t kt[2], kp[2], kr[2], b[2];
+      host_threefry(k[0], k[1], 0u, (uint32_t)t, kt);
+      k[0] = kt[0]; k[1] = kt[1];
+      host_threefry(k[0], k[1], 0u, 0u, kp);
+      host_threefry(k[0], k[1], 0u, 1u, kr);
+      host_threefry(kr[0], kr[1], 0u, 0u, b);
+      h_keys[2 * t] = kp[0]; h_keys[2 * t + 1] = kp[1];
+      h_us[t] = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
+      if (t == 0) { kp0[0] = kp[0]; kp0[1] = kp[1]; }
+    }
+    // ws2: [256 B control][aggA 8 nb][aggB 8 nb][bsum 4 nb (padded to 8 nb)][us 8 T][keys 8 T]
+    unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
+    unsigned long long* aggB = aggA + pblk;
+    float* bsum = (float*)(aggB + pblk);
+    double* us_dev = (double*)(aggB + 2 * pblk);
+    uint32_t* keys_dev = (uint32_t*)(us_dev + T);
+    hipError_t e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
+    {   // step 0: from the prior
+      SsmArgs a;
+      a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;
+      a.key = key2{kp0[0], kp0[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
+      a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
+      a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
+      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+      const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
+      if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
+      GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
+    }
+    SsmPersistArgs f;
+    f.A = m->A_dev; f.H = m->H_dev; f.ys = ys_dev; f.q = m->q; f.r = m->r; f.dy = m->dy; f.T = T; f.K = K;
+    f.x_a = x_a; f.x_b = x_b; f.lw_even = logw; f.lw_odd = lw_alt;
+    f.keys = keys_dev; f.us = us_dev; f.lse_steps = lse_steps; f.ancestors = ancestors;
+    f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
+    f.timeline = nullptr;
+    if (const char* e2 = getenv("GJX_STEP_TIMELINE_PTR")) f.timeline = (unsigned long long*)strtoull(e2, nullptr, 0);
+    void* args[] = {&f};
+    e = hipLaunchKernel(pers_fn, dim3((unsigned)pblk), dim3((unsigned)pthreads), args, 0, st);
+    if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(persistent)");
+    return GJX_OK;
   }
   if (fused_fn) {
     hipStream_t st = (hipStream_t)stream;

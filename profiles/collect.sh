@@ -53,7 +53,8 @@ for k, v in res.items():
 json.dump(util, open("$OUT/${TAG}_valu_utilisation.json", "w"), indent=1)
 PY
 fi
-python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
+GJX_SSM_PERSISTENT=0 python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
+python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_ssm_persistent_timeline.txt
 python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT

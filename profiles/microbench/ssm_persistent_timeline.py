@@ -11,9 +11,9 @@ os.environ["GJX_STEP_TIMELINE_PTR"] = hex(tl.data_ptr())
 bf.run(core.key(2), ys)
 torch.cuda.synchronize()
 t = tl.cpu().numpy().astype(np.float64)
-t = t[t[:, 0] > 0]          # blocks that ran (K / 256)
+t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
-names = [(0,"start"), (2,"tile total published"), (3,"totals gathered+prefix"), (4,"tile list known"), (5,"ancestors known"), (6,"x_prev gathered+A x"), (7,"noise drawn, x stored"), (1,"end")]
-for j, n in names:
+print("persistent filter, step T/2, %d blocks" % len(t))
+for j, n in [(0, "step start"), (1, "block max published"), (2, "global max known"), (3, "tile total published"), (4, "totals gathered + prefix"), (5, "ancestors known"), (6, "step end (stores issued)")]:
     c = (t[:, j] - t0) * 0.01
-    print(f"{n:24s} min {c.min():7.2f}  median {np.median(c):7.2f}  max {c.max():7.2f} us")
+    print(f"{n:26s} min {c.min():7.2f}  median {np.median(c):7.2f}  max {c.max():7.2f} us")
