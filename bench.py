@@ -325,7 +325,10 @@ def run_ssm(args, rank, world, dev):
         K = (world << 19) if args.weak else (1 << 22)
     K_local = K // world
     scaling = "weak" if (args.weak or world == 1) else "strong"
-    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
+    # fixed-point scheme of the resampler (include/gjx.h): tile-scaled = one grid rendezvous per step instead of two;
+    # the sharded exchange quantises against the global maximum
+    scheme = "global_max" if world > 1 else args.ssm_weights
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights=scheme)
     ys = torch.as_tensor(s["y"], device=dev)
     last = {}
 
@@ -340,6 +343,18 @@ def run_ssm(args, rank, world, dev):
     torch.cuda.synchronize()
     dt, lml = timed_loop(args, world, dev, step)
     lml = float(lml)
+    other = None
+    if world == 1:                           # the other weight scheme beside it, same keys, untimed warm-up then 3 runs
+        o_name = "global_max" if scheme == "tile_scaled" else "tile_scaled"
+        bo = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights=o_name)
+        for i in range(3):
+            bo.run(core.key(1 + i), ys, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3):
+            lo = bo.run(core.key(args.warmup + args.steps + i - 2), ys, device=dev)["log_ml"]
+        torch.cuda.synchronize()
+        other = dict(weights=o_name, us_per_filter_step=(time.perf_counter() - t0) / 3 / T * 1e6, log_ml=float(lo))
     exch = dict(transport="none")
     if getattr(bf, "_resampler", None) is not None:
         torch.cuda.synchronize()
@@ -357,17 +372,21 @@ def run_ssm(args, rank, world, dev):
         config=dict(workload="lgssm_d8_T256 bootstrap filter, systematic resampling every step (BASELINE.json configs[%d]); "
                              "one bench step = one T=256 filter run" % (2 if world == 1 else 3), k_particles_per_gpu=K_local,
                     k_particles_total=K, T=T, rng_stream="flat", sharding=f"particles x{world}",
-                    exchange=exch["transport"], exchange_stats=exch),
-        roofline=dict(bound="hbm", kernel=("gjx::k_ssm_persistent<FLAT,8,1024> (steps 1..T-1 of the filter in ONE launch: two grid "
+                    resampler_weights=scheme, exchange=exch["transport"], exchange_stats=exch),
+        roofline=dict(bound="hbm", kernel=("gjx::k_ssm_persistent<FLAT,8,1024,%s> (steps 1..T-1 of the filter in ONE launch: %s grid "
                                            "rendezvous per step, resample + propagate + reweight)"
+                                           % (("true", "one") if scheme == "tile_scaled" else ("false", "two"))
                                            if world == 1 else "sharded filter step: k_ssm_step + exchange"),
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
                       algorithmic_bytes_per_launch=algo,
-                      note="latency-bound at K=2^18: two grid rendezvous (~3 + ~4 us) and ~8 us of VALU work per step, no kernel "
-                           "boundary (phase timeline: profiles/, DESIGN.md section 5); kernel_us = wall time per filter step"),
+                      note="latency-bound at K=2^18: grid rendezvous (~3.5 us each) + the ancestor search + the propagate phase per "
+                           "step, no kernel boundary (phase timeline: profiles/, DESIGN.md section 5); kernel_us = wall time per filter step"),
         log_ml=float(lml), log_ml_exact=exact, log_ml_rel_err=abs(float(lml) - exact) / abs(exact),
     )
+    if other is not None:
+        other["log_ml_rel_err"] = abs(other["log_ml"] - exact) / abs(exact)
+        res["other_weight_scheme"] = other
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_ssm(s, K, T)
     return res
@@ -593,6 +612,8 @@ def main():
     ap.add_argument("--k-per-gpu", type=int, default=K_PER_GPU)
     ap.add_argument("--leapfrog", type=int, default=1000)
     ap.add_argument("--weak", action="store_true", help="ssm with --gpus N > 1: 2^19 particles per GPU instead of 2^22 in total")
+    ap.add_argument("--ssm-weights", choices=["tile_scaled", "global_max"], default="tile_scaled",
+                    help="ssm on one GPU: fixed-point scheme of the filter's systematic resampler (include/gjx.h)")
     ap.add_argument("--ssm-k-total", type=int, default=0, help="ssm: total number of particles (overrides the config-3/4 sizes)")
     ap.add_argument("--api", action="store_true", help="gmm on one GPU: print only the API-level measurement (extra.api)")
     ap.add_argument("--no-extra", action="store_true", help="gmm on one GPU: skip the short ssm / hmc / API runs reported under extra")
@@ -626,7 +647,7 @@ def main():
             a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, st, 1, True
             r2 = fn(a2, rank, world, dev)
             extra[name] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in r2}
-            for k in ("log_ml_rel_err", "accept_rate"):
+            for k in ("log_ml_rel_err", "accept_rate", "other_weight_scheme"):
                 if k in r2:
                     extra[name][k] = r2[k]
         extra["codegen"] = run_codegen(dev)

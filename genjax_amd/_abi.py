@@ -37,6 +37,7 @@ SITE_HMC_SELECTED = 1
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
+WEIGHTS_GLOBAL_MAX, WEIGHTS_TILE_SCALED = 0, 1      # gjx.h: fixed-point weight schemes of the filter's resampler
 MAX_PARAMS = 4
 
 i32, i64, u32, u64, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
@@ -122,6 +123,8 @@ PROTOTYPES = {
     "gjx_ssm_step_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32, vp, vp,
                                     vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_ssm_filter_scheme": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
+    "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),
     "gjx_shard_ctx_stats": (C.c_int, [vp, vp]),

@@ -411,15 +411,27 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
 
 
 // ------------------------------------------------------------------------------------------------------------
-// The whole filter in ONE launch (steps 1 .. T-1; step 0 is k_ssm_step).  Per step the blocks of the co-resident grid
-// meet twice — all-gather of the block maxima of log w_{t-1} (the fixed point needs the exact global maximum), then of
-// the tile totals — and there is no kernel boundary: a block keeps the log-weights of the slots it produced (they are
-// the particles it scans next), the ancestors are found on the consumer side exactly as in k_ssm_fused_step, and the
-// state and log-weights other blocks read cross the chip through write-through (agent-scope) stores and loads, ordered
-// by a release fence before a block publishes its granule.  Ping-pong buffers are safe without further fences: a block
-// can only overwrite the buffer of step t-1 in step t+1, after every block has published its granule of step t+1, i.e.
-// has finished reading it.  The LSE record of step t-1 is finished by block (t-1) mod gridDim.x from the gathered
-// maxima and the per-block sums.  Same ancestors, same streams, same values as the per-step kernels.
+// The whole filter in ONE launch (steps 1 .. T-1; step 0 is k_ssm_step).  No kernel boundary: a block keeps the
+// log-weights of the slots it produced (they are the particles it scans next), the ancestors are found on the consumer
+// side exactly as in k_ssm_fused_step, and the state and log-weights other blocks read cross the chip through
+// write-through (sc1) stores and sc1 loads, ordered by `s_waitcnt vmcnt(0)` before a block publishes its granule.
+// Ping-pong buffers are safe without further fences: a block can only overwrite the buffer of step t-1 in step t+1,
+// after every block has published its granule of step t+1, i.e. has finished reading it.  The standard-normal draws of
+// step t depend on (key_t, slot) only, not on the ancestor: they are generated while the granules travel.
+//
+// TILED == false — the fixed point of gjx_resample_indices (every weight against the exact GLOBAL maximum): the blocks
+//   meet twice per step, all-gather of the block maxima of log w_{t-1}, then of the tile totals.  Same ancestors, same
+//   streams, same values as the per-step kernels.
+// TILED == true — TILE-SCALED fixed point (GJX_WEIGHTS_TILE_SCALED, include/gjx.h): a tile of kTileQ = 1024 consecutive
+//   particles is quantised against its OWN power-of-two reference 2^e_b, e_b = ceil(max_tile(log w) * log2 e):
+//   q_i = floor(2^29 * exp2(log w_i * log2 e - e_b)), S_b = sum of the tile's q_i.  One granule {e_b, S_b} per block, ONE
+//   rendezvous per step; then E = max e_b, the tile counts G_b = S_b >> (E - e_b) units of 2^(E-29) on the global weight
+//   line, comb thresholds T_j on the prefix of the G_b, and inside the source tile the residual (T_j - P_b) << (E - e_b)
+//   is looked up in the tile's own cumulative q.  A tile loses less than one global unit (< 2^-28 of the largest
+//   weight); nothing else is approximated.  Restated by the test oracle (gjxo_resample_systematic_tiled); the
+//   multi-launch form is gjx_resample_indices_tiled (bit-identical ancestors).
+// The LSE record of step t-1 needs the exact float maximum: blocks leave {block max, block sum-exp} in a 3-deep ring
+// (TILED) and block (t-1) mod gridDim finishes the record inside the NEXT step's granule wait, off the critical path.
 // ------------------------------------------------------------------------------------------------------------
 struct SsmPersistArgs {
   const float* A; const float* H; const float* ys;   // ys [T][dy]
@@ -433,7 +445,9 @@ struct SsmPersistArgs {
   float* lse_steps;                // [T][4]
   int32_t* ancestors;              // [K]: of the last step
   unsigned long long* aggA; unsigned long long* aggB;
-  float* bsum;                     // [gridDim.x] per-block sum of exp(log w - block max)
+  float* bsum;                     // [3][gridDim.x] per-block sum of exp(log w - block max) (ring over steps)
+  float* bmax;                     // [3][gridDim.x] per-block max (TILED)
+  unsigned* ready;                 // [gridDim.x] TILED: epoch + t once the block's stores of step t-1 have completed
   unsigned* ctrl;
   float log_k;
   unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block for step T / 2
@@ -442,17 +456,75 @@ struct SsmPersistArgs {
 GJX_DEV float load_agent(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int RNG, int DX, int THREADS>
+// standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams)
+template <int RNG, int DX>
+GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX]) {
+  if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
+  else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
+  if (RNG == GJX_RNG_FLAT) {
+    constexpr int NE = DX + (DX & 1);
+    constexpr int NB = GJX_FLAT_BLOCKS(NE);
+    uint32_t w[2 * NB];
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+      const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
+      w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+    }
+#pragma unroll
+    for (int d0 = 0; d0 < DX; d0 += 2) {
+      float n0, n1;
+      box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
+      nz[d0] = n0;
+      if (d0 + 1 < DX) nz[d0 + 1] = n1;
+    }
+  } else {
+#pragma unroll
+    for (int d0 = 0; d0 < DX; ++d0) {
+      const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
+      nz[d0] = normal_from_bits_fast(h0.a ^ h0.b);
+    }
+  }
+}
+
+// ---- tile-scaled fixed point (shared by k_ssm_persistent<TILED> and the gjx_resample_indices_tiled kernels) ----
+constexpr int kTileQ = 1024;                       // particles per quantisation tile
+constexpr float kTileScale = 536870912.0f;         // 2^29
+constexpr int kTileDead = -524288;                 // exponent of a tile without a finite positive weight (-2^19)
+constexpr float kLog2e = 1.44269504f;
+
+GJX_DEV int tile_exponent(float tile_max) {        // e_b = ceil(max * log2 e), clamped to 20 bits; tile_max never NaN (fmaxf)
+  if (!(tile_max > -INFINITY)) return kTileDead;
+  const float t = ceilf(tile_max * kLog2e);
+  return t < -524287.0f ? -524287 : (t > 524287.0f ? 524287 : (int)t);
+}
+GJX_DEV uint64_t tile_q(float lw, int e) {         // floor(2^29 * min(1, 2^(lw * log2 e - e))); NaN / -inf / dead tile -> 0
+  if (e == kTileDead) return 0;
+  float w = __builtin_amdgcn_exp2f(fmaf(lw, kLog2e, -(float)e));   // one rounding: the oracle uses fmaf too
+  w = w > 0.0f ? w : 0.0f;
+  w = w < 1.0f ? w : 1.0f;
+  return (uint64_t)(w * kTileScale);
+}
+// granule of the tiled rendezvous: tag (4 bits, != 0) | e_b + 2^19 (20 bits) | S_b (40 bits, S_b <= 2^39).  Four tag
+// bits are plenty: a block rewrites its granule of one parity every second step, so a reader can only ever meet the
+// tag of step t or of step t - 2
+GJX_DEV unsigned long long tile_granule(unsigned long long tag, int e, uint64_t S) {
+  return (tag << 60) | ((unsigned long long)(unsigned)(e - kTileDead) << 40) | (S & ((1ull << 40) - 1));
+}
+
+template <int RNG, int DX, int THREADS, bool TILED>
 __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   // THREADS = 1024 (one block per CU, 256 blocks at K = 2^18) quarters the granules of each all-gather: a rendezvous
   // among 256 blocks measures 3.5 us, among 1024 blocks 5.4 us
+  static_assert(!TILED || THREADS == kTileQ, "the tile-scaled fixed point quantises per 1024-particle tile");
   constexpr int NW = THREADS / 64;               // waves per block
   constexpr int WPT = THREADS / 256;             // waves that re-scan one source tile together (256 particles each)
   constexpr int kChunk = NW / WPT;               // source tiles re-scanned per round (= 4)
   constexpr int kPer = (kSsmFusedMaxTiles + THREADS - 1) / THREADS;
   __shared__ float fred[2 * NW];
+  __shared__ float lse_pm[NW], lse_ps[NW];       // finisher: per-wave {max, sumexp} of the ring entries it read
   __shared__ uint64_t wsum[NW];
   __shared__ uint64_t P[kSsmFusedMaxTiles + 1];
+  __shared__ int32_t Eb[TILED ? kSsmFusedMaxTiles : 1];
   __shared__ uint64_t cumL[kChunk * THREADS];
   __shared__ int32_t s_tof[THREADS], s_tiles[THREADS];
   __shared__ int s_cnt[NW];
@@ -467,87 +539,218 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   const float rr = fast_rcp(f.r);
   const float lconst = -(float)f.dy * (kHalfLog2Pi + fast_log(f.r));
   float lw_own = active ? lw_buf(0)[j] : -INFINITY;               // step 0 ran in the previous launch
+  // finisher of the LSE record of step s from ring slot s % 3 (TILED): all threads read, per-wave partials to LDS
+  auto lse_ring_partials = [&](int s) {
+    const float* rm = f.bmax + (size_t)(s % 3) * nb;
+    const float* rs = f.bsum + (size_t)(s % 3) * nb;
+    float m = -INFINITY, sm = 0.0f;
+    for (int b = (threadIdx.x + THREADS / 2) % THREADS; b < nb; b += THREADS) {   // the non-polling half of the block first
+      const float pm = load_agent(rm + b), ps = load_agent(rs + b);
+      const float nm = fmaxf(m, pm);
+      if (nm > -INFINITY) sm = sm * fast_exp(m - nm) + ps * fast_exp(pm - nm);
+      m = nm;
+    }
+    const float wm = wave_max_dpp(m);
+    const float ws = wave_sum_dpp(wm > -INFINITY ? sm * fast_exp(m - wm) : 0.0f);
+    if (lane == 0) { lse_pm[wid] = wm; lse_ps[wid] = ws; }
+  };
+  auto lse_ring_write = [&](int s) {             // thread 0, after a barrier behind lse_ring_partials(s)
+    float m = lse_pm[0];
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, lse_pm[w]);
+    float se = 0.0f;
+    for (int w = 0; w < NW; ++w) se += m > -INFINITY ? lse_ps[w] * fast_exp(lse_pm[w] - m) : 0.0f;
+    const float l = m > -INFINITY ? m + logf(se) : -INFINITY;
+    float* rec = f.lse_steps + 4 * (size_t)s;
+    rec[0] = m; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
+  };
 #define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = 1; t <= T; ++t) {
     GJX_PSTAMP(0);
-    // ---- rendezvous A: exact global maximum of log w_{t-1} (nothing else rides on it: published as early as possible) ----
-    const unsigned long long tagA = (unsigned long long)((epoch + 2u * (unsigned)(t - 1)) % 16383u) + 1ull;
-    const unsigned long long tagB = (unsigned long long)((epoch + 2u * (unsigned)(t - 1) + 1u) % 16383u) + 1ull;
+    float nz[DX];
+    float mx = -INFINITY;
+    float pm[kPer];
+    int eb = kTileDead, Emax = kTileDead;
+    unsigned rdy[kPer];
+    const unsigned rtag = epoch + (unsigned)t;                // `ready` word of this step: never repeats, the epoch advances by 2 T per launch
+    auto check_ready = [&]() {                                // every block's stores of step t-1 have completed (TILED)
+      unsigned budget = 1u << 22;
+      for (int b = threadIdx.x, k = 0; b < nb; b += THREADS, ++k) {
+        unsigned r = rdy[k];
+        while (r != rtag && budget) {
+          __builtin_amdgcn_s_sleep(1);
+          r = __hip_atomic_load(&f.ready[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          --budget;
+        }
+        if (r != rtag) __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    // ---- block maximum of log w_{t-1} ----
     float bm;
     {
-      const float wm = wave_max(active ? lw_own : -INFINITY);
+      const float wm = wave_max_dpp(active ? lw_own : -INFINITY);
       __syncthreads();
+      GJX_PSTAMP(7);         // every wave of the block has finished the previous step
       if (lane == 0) fred[wid] = wm;
       __syncthreads();
       bm = fred[0];
 #pragma unroll
       for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
+    }
+    if constexpr (!TILED) {
+      // ---- rendezvous A: exact global maximum (nothing else rides on it: published as early as possible) ----
+      const unsigned long long tagA = (unsigned long long)((epoch + 2u * (unsigned)(t - 1)) % 16383u) + 1ull;
       if (threadIdx.x == 0) grid_publish(f.aggA, tagA, (unsigned long long)__float_as_uint(bm));
-    }
-    GJX_PSTAMP(1);
-    // while the granules travel: this block's sum of exp(log w - block max), for the LSE record (read after rendezvous B)
-    {
-      const float e = (active && bm > -INFINITY) ? fast_exp(lw_own - bm) : 0.0f;
-      const float ws = wave_sum(e);
-      if (lane == 0) fred[NW + wid] = ws;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float bs = 0.0f;
-        for (int w = 0; w < NW; ++w) bs += fred[NW + w];
-        store_agent(&f.bsum[blockIdx.x], bs);
+      GJX_PSTAMP(1);
+      // while the granules travel: this block's sum of exp(log w - block max), for the LSE record (read after
+      // rendezvous B; ring of 2: a block rewrites its entry only after the finisher published its next granule A),
+      // and the draws of step t
+      {
+        const float e = (active && bm > -INFINITY) ? fast_exp(lw_own - bm) : 0.0f;
+        const float ws = wave_sum_dpp(e);
+        if (lane == 0) fred[NW + wid] = ws;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float bs = 0.0f;
+          for (int w = 0; w < NW; ++w) bs += fred[NW + w];
+          store_agent(&f.bsum[(size_t)(t & 1) * nb + blockIdx.x], bs);
+        }
       }
-    }
-    float pm[kPer];
-    int np = 0;
-    float mx = -INFINITY;
-    grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
-      const float m = __uint_as_float((uint32_t)v);
-      pm[np++] = m;
-      mx = fmaxf(mx, m);
-    });
-    mx = wave_max(mx);     // (no acquire fence: everything read from other blocks goes through agent-scope loads)
-    __syncthreads();
-    if (lane == 0) fred[wid] = mx;
-    __syncthreads();
-    mx = fred[0];
+      if (t < T) ssm_noise<RNG, DX>(key2{f.keys[2 * t], f.keys[2 * t + 1]}, (uint64_t)j, nz);
+      int np = 0;
+      grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
+        const float m = __uint_as_float((uint32_t)v);
+        pm[np++] = m;
+        mx = fmaxf(mx, m);
+      });
+      mx = wave_max_dpp(mx);     // (no acquire fence: everything read from other blocks goes through agent-scope loads)
+      __syncthreads();
+      if (lane == 0) fred[wid] = mx;
+      __syncthreads();
+      mx = fred[0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[w]);
-    GJX_PSTAMP(2);
-    // ---- rendezvous B: tile totals of the fixed-point weights.  The granule goes out only after this lane's
-    //      write-through (sc1) stores of step t-1 — x, log w, the block sum — have completed; readers use sc1 loads: no
-    //      cache maintenance on either side (MI355X guide G16 form R2; a release fence per wave cost 60 us per step).
-    //      At t == T only the ordering matters (the last LSE record is finished behind it). ----
-    {
-      float xv[1] = {lw_own};
-      const uint64_t qv = (active && t < T) ? weight_q(xv, 0, 1, mx) : 0;
-      const uint64_t wt = wave_sum_u64(qv);
+      for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[w]);
+      GJX_PSTAMP(2);
+      // ---- rendezvous B: tile totals of the fixed-point weights.  The granule goes out only after this lane's
+      //      write-through (sc1) stores of step t-1 — x, log w, the block sum — have completed; readers use sc1 loads: no
+      //      cache maintenance on either side (MI355X guide G16 form R2; a release fence per wave cost 60 us per step).
+      //      At t == T only the ordering matters (the last LSE record is finished behind it). ----
+      const unsigned long long tagB = (unsigned long long)((epoch + 2u * (unsigned)(t - 1) + 1u) % 16383u) + 1ull;
+      {
+        float xv[1] = {lw_own};
+        const uint64_t qv = (active && t < T) ? weight_q(xv, 0, 1, mx) : 0;
+        const uint64_t wt = wave_total_u64(qv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) wsum[wid] = wt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          uint64_t tt = 0;
+          for (int w = 0; w < NW; ++w) tt += wsum[w];
+          grid_publish(f.aggB, tagB, tt);
+        }
+      }
+      GJX_PSTAMP(3);
+      grid_gather(f.aggB, tagB, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
+    } else {
+      // ---- the ONE rendezvous: {e_b, S_b}.  The granule depends on registers only and goes out at once; that the block's
+      //      sc1 stores of step t-1 (x, log w, its ring entry) have completed is signalled separately (`ready`), behind
+      //      the granule and off the rendezvous' critical path: consumers look at it only right before their first
+      //      foreign read, several microseconds later ----
+      const unsigned long long tag = (unsigned long long)((epoch + (unsigned)t) % 15u) + 1ull;
+      unsigned long long* agg = (t & 1) ? f.aggA : f.aggB;   // alternate: a slow block may still poll step t-1's granules
+      eb = tile_exponent(bm);
+      {
+        const uint64_t qv = (active && t < T) ? tile_q(lw_own, eb) : 0;
+        const float e = (active && bm > -INFINITY) ? fast_exp(lw_own - bm) : 0.0f;
+        const uint64_t wt = wave_total_u64(qv);
+        const float ws = wave_sum_dpp(e);
+        if (lane == 0) { wsum[wid] = wt; fred[NW + wid] = ws; }
+        __syncthreads();
+        if (wid == 0) {                    // the NW wave partials, summed across the first lanes of wave 0
+          static_assert(NW <= 16, "the wave partials fit one DPP row");
+          uint64_t tt = row_scan_u64(lane < NW ? wsum[lane] : 0);       // lane 15 = sum of lanes 0..15
+          float bs = row_sum_to_lane15(lane < NW ? fred[NW + lane] : 0.0f);
+          if (lane == 15) {
+            __hip_atomic_store(&agg[blockIdx.x], tile_granule(tag, eb, tt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const size_t slot = (size_t)((t - 1) % 3) * nb + blockIdx.x;
+            store_agent(&f.bsum[slot], bs);
+            store_agent(&f.bmax[slot], bm);
+          }
+        }
+      }
+      GJX_PSTAMP(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the record of step t-2 if this block is its finisher: its ring entries were complete before the `ready` words
+      // this block checked in step t-1; the loads go out here and are consumed behind the draws
+      const bool fin = t >= 2 && (int)blockIdx.x == (t - 2) % nb;
+      float rpm[kPer], rps[kPer];
+      if (fin) {
+        const float* rm = f.bmax + (size_t)((t - 2) % 3) * nb;
+        const float* rs = f.bsum + (size_t)((t - 2) % 3) * nb;
+        int k = 0;
+        for (int b = (threadIdx.x + THREADS / 2) % THREADS; b < nb; b += THREADS, ++k) { rpm[k] = load_agent(rm + b); rps[k] = load_agent(rs + b); }
+      }
       __syncthreads();
-      if (lane == 0) wsum[wid] = wt;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint64_t tt = 0;
-        for (int w = 0; w < NW; ++w) tt += wsum[w];
-        grid_publish(f.aggB, tagB, tt);
+      if (threadIdx.x == 0) __hip_atomic_store(&f.ready[blockIdx.x], rtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // while the granules travel: the draws of step t
+      if (t < T) ssm_noise<RNG, DX>(key2{f.keys[2 * t], f.keys[2 * t + 1]}, (uint64_t)j, nz);
+      if (fin) {
+        float m = -INFINITY, sm = 0.0f;
+        int k = 0;
+        for (int b = (threadIdx.x + THREADS / 2) % THREADS; b < nb; b += THREADS, ++k) {
+          const float nm = fmaxf(m, rpm[k]);
+          if (nm > -INFINITY) sm = sm * fast_exp(m - nm) + rps[k] * fast_exp(rpm[k] - nm);
+          m = nm;
+        }
+        const float wm = wave_max_dpp(m);
+        const float wsm = wave_sum_dpp(wm > -INFINITY ? sm * fast_exp(m - wm) : 0.0f);
+        if (lane == 0) { lse_pm[wid] = wm; lse_ps[wid] = wsm; }
+      }
+      GJX_PSTAMP(2);
+      {
+        unsigned budget = 1u << 22;
+        float em = (float)kTileDead;
+        for (int b = threadIdx.x; b < nb; b += THREADS) {
+          unsigned long long v = 0;
+          while (budget) {
+            v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 60) == tag) break;
+            --budget;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if ((v >> 60) != tag) { __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
+          const uint64_t S = v & ((1ull << 40) - 1);
+          const int e = S ? (int)((v >> 40) & 0xFFFFFu) + kTileDead : kTileDead;
+          P[b + 1] = S;
+          Eb[b] = e;
+          em = fmaxf(em, (float)e);
+        }
+        // the `ready` words: loads issued now, looked at after the tile search
+        for (int b = threadIdx.x, k = 0; b < nb; b += THREADS, ++k) rdy[k] = __hip_atomic_load(&f.ready[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        em = wave_max_dpp(em);
+        if (lane == 0) fred[wid] = em;   // (fred[0..NW) was last read for the block maximum, two barriers ago)
       }
     }
-    GJX_PSTAMP(3);
-    grid_gather(f.aggB, tagB, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
     if (threadIdx.x == 0) P[0] = 0;
     __syncthreads();
+    if constexpr (TILED) {
+      float em = fred[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) em = fmaxf(em, fred[w]);
+      Emax = (int)em;
+      if (t >= 2 && (int)blockIdx.x == (t - 2) % nb && threadIdx.x == 0) lse_ring_write(t - 2);
+      GJX_PSTAMP(3);
+    }
     {
       const int per = (nb + THREADS - 1) / THREADS;
       const int e0 = threadIdx.x * per < nb ? threadIdx.x * per : nb, e1 = (e0 + per) < nb ? (e0 + per) : nb;
       uint64_t loc = 0;
-      for (int e = e0; e < e1; ++e) loc += P[e + 1];
-      uint64_t inc = loc;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-        if (lane >= o) inc += up;
+      for (int e = e0; e < e1; ++e) {
+        if constexpr (TILED) { const int sh = Emax - Eb[e]; P[e + 1] = sh < 64 ? P[e + 1] >> sh : 0; }
+        loc += P[e + 1];
       }
-      __syncthreads();
-      if (lane == 63) wsum[wid] = inc;
+      const uint64_t inc = wave_scan_u64(loc);
+      if (lane == 63) wsum[wid] = inc;   // (wsum was last read by thread 0 before its publish, at least one barrier ago)
       __syncthreads();
       uint64_t run = inc - loc;
       for (int w = 0; w < wid; ++w) run += wsum[w];
@@ -556,20 +759,31 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     }
     const uint64_t total = P[nb];
     GJX_PSTAMP(4);
-    if ((int)blockIdx.x == (t - 1) % nb) {                        // block-uniform: finish the LSE record of step t-1
-      float sacc = 0.0f;
-      int k = 0;
-      for (int b = threadIdx.x; b < nb; b += THREADS, ++k) sacc += mx > -INFINITY ? load_agent(&f.bsum[b]) * fast_exp(pm[k] - mx) : 0.0f;
-      sacc = wave_sum(sacc);
+    if constexpr (!TILED) {
+      if ((int)blockIdx.x == (t - 1) % nb) {                        // block-uniform: finish the LSE record of step t-1
+        float sacc = 0.0f;
+        int k = 0;
+        const float* rs = f.bsum + (size_t)(t & 1) * nb;
+        for (int b = threadIdx.x; b < nb; b += THREADS, ++k) sacc += mx > -INFINITY ? load_agent(&rs[b]) * fast_exp(pm[k] - mx) : 0.0f;
+        sacc = wave_sum_dpp(sacc);
+        __syncthreads();
+        if (lane == 0) fred[NW + wid] = sacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float se = 0.0f;
+          for (int w = 0; w < NW; ++w) se += fred[NW + w];
+          const float l = mx > -INFINITY ? mx + logf(se) : -INFINITY;
+          float* rec = f.lse_steps + 4 * (size_t)(t - 1);
+          rec[0] = mx; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
+        }
+      }
+    } else if (t == T) {                                            // the last record, once every block's ring entry is complete
+      check_ready();
       __syncthreads();
-      if (lane == 0) fred[NW + wid] = sacc;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float se = 0.0f;
-        for (int w = 0; w < NW; ++w) se += fred[NW + w];
-        const float l = mx > -INFINITY ? mx + logf(se) : -INFINITY;
-        float* rec = f.lse_steps + 4 * (size_t)(t - 1);
-        rec[0] = mx; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
+      if ((int)blockIdx.x == (T - 1) % nb) {
+        lse_ring_partials(T - 1);
+        __syncthreads();
+        if (threadIdx.x == 0) lse_ring_write(T - 1);
       }
     }
     if (t == T) break;
@@ -579,13 +793,17 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     int64_t src = j;
     if (total > 0) {
       const double step = (double)total / (double)K;
-      const uint64_t Tj = comb_threshold(active ? j : K - 1, f.us[t], step, total);
+      uint64_t Tj = comb_threshold(active ? j : K - 1, f.us[t], step, total);
       int lo = 0, hi = nb - 1;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (P[mid + 1] > Tj) hi = mid; else lo = mid + 1;
       }
       const int tile = lo;
+      if constexpr (TILED) {
+        Tj = (Tj - P[tile]) << (Emax - Eb[tile]);                      // residual in the source tile's own units (< S_tile)
+        check_ready();                                                // before the barrier in front of the first foreign read
+      }
       s_tof[threadIdx.x] = tile;
       __syncthreads();
       const bool first = threadIdx.x == 0 || s_tof[threadIdx.x - 1] != tile;
@@ -608,19 +826,19 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           float lw4[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) lw4[k] = p0 + k < K ? load_agent(lw_prev + p0 + k) : -INFINITY;
+          const int es = TILED ? Eb[tsrc] : 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? weight_q(lw4, k, 1, mx) : 0; qi[k] = sacc; }
-          inc = sacc;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-            if (lane >= o) inc += up;
+          for (int k = 0; k < 4; ++k) {
+            if constexpr (TILED) sacc += p0 + k < K ? tile_q(lw4[k], es) : 0;
+            else sacc += p0 + k < K ? weight_q(lw4, k, 1, mx) : 0;
+            qi[k] = sacc;
           }
+          inc = wave_scan_u64(sacc);
           if (WPT > 1 && lane == 63) wsum[wid] = inc;             // the wave's total: offset of the next quarter
         }
         if (WPT > 1) __syncthreads();
         if (on) {
-          uint64_t base = P[tsrc] + (inc - sacc);
+          uint64_t base = (TILED ? 0 : P[tsrc]) + (inc - sacc);
           for (int w = 0; w < part; ++w) base += wsum[tl * WPT + w];
 #pragma unroll
           for (int k = 0; k < 4; ++k) cumL[tl * THREADS + part * 256 + lane * 4 + k] = base + qi[k];
@@ -636,6 +854,8 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           src = (int64_t)tile * THREADS + l2;
         }
       }
+    } else if constexpr (TILED) {
+      check_ready();              // (a dead step reads nothing foreign, but the ring entries count on every step's check)
     }
     GJX_PSTAMP(5);
     if (active && t == T - 1 && f.ancestors) f.ancestors[j] = (int32_t)src;
@@ -643,10 +863,6 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     // ---- propagate + reweight slot j (k_ssm_step's arithmetic and streams) ----
     const float* x_prev = x_buf(t - 1);
     float* x_out = x_buf(t);
-    const uint64_t gidx = (uint64_t)j;
-    key2 skj{f.keys[2 * t], f.keys[2 * t + 1]};
-    if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
-    else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
     float xp[DX], xn[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) xp[d] = load_agent(x_prev + (int64_t)d * K + src);
@@ -655,30 +871,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       float acc = 0.0f;
 #pragma unroll
       for (int e = 0; e < DX; ++e) acc = fmaf(f.A[d * DX + e], xp[e], acc);
-      xn[d] = acc;
-    }
-    if (RNG == GJX_RNG_FLAT) {
-      constexpr int NE = DX + (DX & 1);
-      constexpr int NB = GJX_FLAT_BLOCKS(NE);
-      uint32_t w[2 * NB];
-#pragma unroll
-      for (int h = 0; h < NB; ++h) {
-        const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
-        w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
-      }
-#pragma unroll
-      for (int d0 = 0; d0 < DX; d0 += 2) {
-        float n0, n1;
-        box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
-        xn[d0] = fmaf(f.q, n0, xn[d0]);
-        if (d0 + 1 < DX) xn[d0 + 1] = fmaf(f.q, n1, xn[d0 + 1]);
-      }
-    } else {
-#pragma unroll
-      for (int d0 = 0; d0 < DX; ++d0) {
-        const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
-        xn[d0] = fmaf(f.q, normal_from_bits_fast(h0.a ^ h0.b), xn[d0]);
-      }
+      xn[d] = fmaf(f.q, nz[d], acc);
     }
     if (active) {
 #pragma unroll
@@ -706,6 +899,106 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
 #undef GJX_PSTAMP
   if (blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(&f.ctrl[0], epoch + 2u * (unsigned)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the tile-scaled systematic resampler as three plain launches (gjx_resample_indices_tiled): the step-by-step
+//      form of what k_ssm_persistent<TILED> does inside its loop; bit-identical ancestors ----
+__global__ __launch_bounds__(kTileQ) void k_tiled_quantise(const float* logw, int64_t K, uint64_t* cq, uint64_t* S, int32_t* E,
+                                                           uint32_t* q_out, int32_t* e_out) {
+  constexpr int NW = kTileQ / 64;
+  __shared__ float fred[NW];
+  __shared__ uint64_t wsum[NW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kTileQ + threadIdx.x;
+  const bool active = i < K;
+  const float lw = active ? logw[i] : -INFINITY;
+  const float wm = wave_max(lw);
+  if (lane == 0) fred[wid] = wm;
+  __syncthreads();
+  float bm = fred[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
+  const int e = tile_exponent(bm);
+  const uint64_t q = active ? tile_q(lw, e) : 0;
+  uint64_t inc = q;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  for (int w = 0; w < NW; ++w) { if (w < wid) base += wsum[w]; tot += wsum[w]; }
+  if (active) { cq[i] = base + inc; if (q_out) q_out[i] = (uint32_t)q; }
+  if (threadIdx.x == 0) {
+    const int es = tot ? e : kTileDead;
+    S[blockIdx.x] = tot; E[blockIdx.x] = es;
+    if (e_out) e_out[blockIdx.x] = es;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_tiled_plan(const uint64_t* S, const int32_t* E, int nt, uint64_t* P, int32_t* sh, unsigned* ctrl) {
+  __shared__ float fred[16];
+  __shared__ uint64_t wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float em = (float)kTileDead;
+  for (int b = threadIdx.x; b < nt; b += 1024) em = fmaxf(em, (float)E[b]);
+  em = wave_max(em);
+  if (lane == 0) fred[wid] = em;
+  __syncthreads();
+  em = fred[0];
+  for (int w = 1; w < 16; ++w) em = fmaxf(em, fred[w]);
+  const int Emax = (int)em;
+  uint64_t carry = 0;
+  if (threadIdx.x == 0) P[0] = 0;
+  for (int b0 = 0; b0 < nt; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    uint64_t g = 0;
+    if (b < nt) {
+      const int s = Emax - E[b];
+      g = s < 64 ? S[b] >> s : 0;
+      sh[b] = s < 64 ? s : 64;
+    }
+    uint64_t inc = g;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint64_t base = carry, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wid) base += wsum[w]; tot += wsum[w]; }
+    if (b < nt) P[b + 1] = base + inc;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && carry == 0 && ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_tiled_ancestors(const uint64_t* P, const int32_t* sh, const uint64_t* cq, int nt, int64_t K,
+                                                         double u, int64_t N, int32_t* anc) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const uint64_t total = P[nt];
+  if (total == 0) { anc[j] = (int32_t)(j < K ? j : K - 1); return; }   // dead collection: identity, flagged by the plan
+  const double step = (double)total / (double)N;
+  const uint64_t Tj = comb_threshold(j, u, step, total);
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (P[mid + 1] > Tj) hi = mid; else lo = mid + 1;
+  }
+  const uint64_t r = (Tj - P[lo]) << sh[lo];
+  const uint64_t* cm = cq + (int64_t)lo * kTileQ;
+  const int64_t left = K - (int64_t)lo * kTileQ;
+  int l2 = 0, h2 = (int)(left < kTileQ ? left : kTileQ) - 1;
+  while (l2 < h2) {
+    const int mid = (l2 + h2) >> 1;
+    if (cm[mid] > r) h2 = mid; else l2 = mid + 1;
+  }
+  anc[j] = (int32_t)((int64_t)lo * kTileQ + l2);
 }
 
 }  // namespace gjx
@@ -821,12 +1114,47 @@ static void host_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, ui
   out[0] = x0; out[1] = x1;
 }
 
+extern "C" int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N, int32_t* ancestors, uint64_t* cum,
+                                          uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logw || !ancestors || !cum || K <= 0 || N <= 0 || K > (int64_t)1 << 31) return gjx_fail(GJX_EINVAL, "gjx_resample_indices_tiled: bad argument");
+  const int64_t nt = (K + kTileQ - 1) / kTileQ;
+  // workspace: [256 B control][S u64 nt][P u64 nt + 1][E i32 nt][shift i32 nt]
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K) || 256 + 24 * (size_t)nt + 8 > workspace_bytes)
+    return gjx_fail(GJX_EWORKSPACE, "gjx_resample_indices_tiled: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t* S = (uint64_t*)((char*)workspace + kWsHeaderBytes);
+  uint64_t* P = S + nt;
+  int32_t* E = (int32_t*)(P + nt + 1);
+  int32_t* sh = E + nt;
+  hipLaunchKernelGGL(k_tiled_quantise, dim3((unsigned)nt), dim3(kTileQ), 0, st, logw, K, cum, S, E, q_out, e_out);
+  hipLaunchKernelGGL(k_tiled_plan, dim3(1), dim3(1024), 0, st, (const uint64_t*)S, (const int32_t*)E, (int)nt, P, sh, (unsigned*)workspace + 8);
+  hipLaunchKernelGGL(k_tiled_ancestors, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const uint64_t*)P, (const int32_t*)sh,
+                     (const uint64_t*)cum, (int)nt, K, u, N, ancestors);
+  GJX_CHECK_LAUNCH("gjx_resample_indices_tiled");
+  return GJX_OK;
+}
+
+extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                                     const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
+                                     float* lse_steps, int32_t weight_scheme, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
                               const float* ys_dev /*[T][dy]*/, float* x_a, float* x_b /*[dx][K] ping-pong*/, float* logw,
                               uint64_t* cum, int32_t* ancestors, float* lse_steps /*[T][4]*/, void* workspace,
                               size_t workspace_bytes, void* stream) {
+  return gjx_ssm_filter_scheme(m, key0, key1, rng_mode, T, K, ys_dev, x_a, x_b, logw, cum, ancestors, lse_steps,
+                               GJX_WEIGHTS_GLOBAL_MAX, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                                     const float* ys_dev /*[T][dy]*/, float* x_a, float* x_b /*[dx][K] ping-pong*/, float* logw,
+                                     uint64_t* cum, int32_t* ancestors, float* lse_steps /*[T][4]*/, int32_t weight_scheme,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !ys_dev || !x_a || !x_b || !logw || !cum || !ancestors || !lse_steps || T <= 0 || K <= 0)
     return gjx_fail(GJX_EINVAL, "gjx_ssm_filter: bad argument");
+  if (weight_scheme != GJX_WEIGHTS_GLOBAL_MAX && weight_scheme != GJX_WEIGHTS_TILE_SCALED)
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_filter: weight_scheme must be GJX_WEIGHTS_GLOBAL_MAX or GJX_WEIGHTS_TILE_SCALED");
+  const bool tiled = weight_scheme == GJX_WEIGHTS_TILE_SCALED;
   const size_t need = gjx_workspace_bytes(GJX_OP_SSM, K);
   if (!workspace || workspace_bytes < 2 * need + 64) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_filter: workspace too small (2x OP_SSM + 64)");
   char* ws1 = (char*)workspace;
@@ -837,7 +1165,7 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
   // the resample + step pair
   const int64_t nblk = (K + 255) / 256;
   const void* fused_fn = nullptr;
-  if (!getenv("GJX_SSM_TWO_LAUNCH") || atoi(getenv("GJX_SSM_TWO_LAUNCH")) == 0) {
+  if (!tiled && (!getenv("GJX_SSM_TWO_LAUNCH") || atoi(getenv("GJX_SSM_TWO_LAUNCH")) == 0)) {
     const bool jax = rng_mode == GJX_RNG_JAX32;
     switch (m->dx) {
       case 2: fused_fn = jax ? (const void*)k_ssm_fused_step<GJX_RNG_JAX32, 2> : (const void*)k_ssm_fused_step<GJX_RNG_FLAT, 2>; break;
@@ -852,12 +1180,14 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
   const void* pers_fn = nullptr;
   int pthreads = 256;
   int64_t pblk = nblk;
-  if (fused_fn && T > 1 && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
+  if ((fused_fn || tiled) && T > 1 && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
     const bool jax = rng_mode == GJX_RNG_JAX32;
-    // 1024-thread blocks (one per CU) once the grid would have more than 256 blocks of 256: fewer, cheaper rendezvous
-    pthreads = (nblk > 256 && (!getenv("GJX_SSM_THREADS") || atoi(getenv("GJX_SSM_THREADS")) == 1024)) ? 1024 : 256;
-#define GJX_PERS(DXV) (pthreads == 1024 ? (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 1024> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 1024>) \
-                                        : (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 256> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 256>))
+    // 1024-thread blocks (one per CU) once the grid would have more than 256 blocks of 256: fewer, cheaper rendezvous;
+    // always for the tile-scaled scheme (its quantisation tile is 1024 particles)
+    pthreads = (tiled || (nblk > 256 && (!getenv("GJX_SSM_THREADS") || atoi(getenv("GJX_SSM_THREADS")) == 1024))) ? 1024 : 256;
+#define GJX_PERS(DXV) (tiled ? (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 1024, true> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 1024, true>) \
+                     : pthreads == 1024 ? (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 1024, false> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 1024, false>) \
+                                        : (jax ? (const void*)k_ssm_persistent<GJX_RNG_JAX32, DXV, 256, false> : (const void*)k_ssm_persistent<GJX_RNG_FLAT, DXV, 256, false>))
     switch (m->dx) {
       case 2: pers_fn = GJX_PERS(2); break;
       case 4: pers_fn = GJX_PERS(4); break;
@@ -867,7 +1197,7 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
     }
 #undef GJX_PERS
     pblk = (K + pthreads - 1) / pthreads;
-    if (pers_fn && (pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 24 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+    if (pers_fn && (pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 48 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
   }
   if (pers_fn) {
     hipStream_t st = (hipStream_t)stream;
@@ -889,13 +1219,18 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       h_us[t] = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
       if (t == 0) { kp0[0] = kp[0]; kp0[1] = kp[1]; }
     }
-    // ws2: [256 B control][aggA 8 nb][aggB 8 nb][bsum 4 nb (padded to 8 nb)][us 8 T][keys 8 T]
+    // ws2: [256 B control][aggA 8 nb][aggB 8 nb][bsum ring 12 nb][bmax ring 12 nb][ready 4 nb + 4 nb pad][us 8 T][keys 8 T]
     unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
     unsigned long long* aggB = aggA + pblk;
     float* bsum = (float*)(aggB + pblk);
-    double* us_dev = (double*)(aggB + 2 * pblk);
+    float* bmax = bsum + 3 * pblk;
+    unsigned* ready = (unsigned*)(bmax + 3 * pblk);
+    double* us_dev = (double*)(aggB + 5 * pblk);
     uint32_t* keys_dev = (uint32_t*)(us_dev + T);
-    hipError_t e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+    // the two schemes (and k_ssm_fused_step) tag their granules differently: no stale granule of another kernel may pass for
+    // one of this launch
+    hipError_t e = hipMemsetAsync(aggA, 0, 48 * (size_t)pblk, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
     {   // step 0: from the prior
@@ -913,7 +1248,7 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
     f.A = m->A_dev; f.H = m->H_dev; f.ys = ys_dev; f.q = m->q; f.r = m->r; f.dy = m->dy; f.T = T; f.K = K;
     f.x_a = x_a; f.x_b = x_b; f.lw_even = logw; f.lw_odd = lw_alt;
     f.keys = keys_dev; f.us = us_dev; f.lse_steps = lse_steps; f.ancestors = ancestors;
-    f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
+    f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
     f.timeline = nullptr;
     if (const char* e2 = getenv("GJX_STEP_TIMELINE_PTR")) f.timeline = (unsigned long long*)strtoull(e2, nullptr, 0);
     void* args[] = {&f};
@@ -923,6 +1258,10 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
   }
   if (fused_fn) {
     hipStream_t st = (hipStream_t)stream;
+    {
+      const hipError_t e0 = hipMemsetAsync(ws2 + kWsHeaderBytes, 0, 8 * (size_t)nblk, st);   // see the persistent path
+      if (e0 != hipSuccess) return gjx_fail_hip(e0, "gjx_ssm_filter(granules)");
+    }
     float* lw_alt = (float*)cum;                     // the prefix-sum buffer is free on this path: second log-weight buffer
     auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };   // the last step writes the caller's logw
     auto part_of = [&](int t) { return (unsigned long long*)(ws1 + kWsHeaderBytes) + (size_t)(t & 1) * nblk; };
@@ -981,12 +1320,14 @@ extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, in
       const double u = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
       // the previous step left its per-block LSE partials in ws1; the prefix-sum prologue reduces them and
       // block 0 writes the finished record of step t-1
-      const int rc = gjx_resample_indices(logw, K, 2, (const float*)(ws1 + 256), (int32_t)((K + 255) / 256), u, K, ancestors, cum, bt,
-                                          lse - 4, K, ws2, need, stream);
+      const int rc = tiled ? gjx_resample_indices_tiled(logw, K, u, K, ancestors, cum, nullptr, nullptr, ws2, need, stream)
+                           : gjx_resample_indices(logw, K, 2, (const float*)(ws1 + 256), (int32_t)((K + 255) / 256), u, K, ancestors, cum, bt,
+                                                  lse - 4, K, ws2, need, stream);
       if (rc) return rc;
     }
+    // tile-scaled scheme: the resampler does not touch the LSE partials, every step finishes its own record
     const int rc = gjx_ssm_step(m, kp[0], kp[1], rng_mode, t, K, 0, t > 0 ? x_prev : nullptr, K, t > 0 ? ancestors : nullptr,
-                                ys_dev + (size_t)t * m->dy, x_out, logw, t == T - 1 ? lse : nullptr, K, ws1, need, stream);
+                                ys_dev + (size_t)t * m->dy, x_out, logw, (tiled || t == T - 1) ? lse : nullptr, K, ws1, need, stream);
     if (rc) return rc;
   }
   return GJX_OK;

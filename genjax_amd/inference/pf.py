@@ -120,10 +120,17 @@ class ParticleHistory:
 class BootstrapFilter:
     """SMC with the prior as proposal and systematic resampling before every propagate step."""
 
-    def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None, rejuvenate: dict | None = None):
+    def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None, rejuvenate: dict | None = None,
+                 weights: str = "global_max"):
         """``rejuvenate=dict(n_moves=.., scale=..)``: resample-move — after every resampling each particle takes n_moves
         random-walk Metropolis steps (proposal scale ``scale``) that leave p(x_{t-1} | parent, y_{t-1}) invariant, fused
-        into the propagate kernel (gjx_ssm_step_move)."""
+        into the propagate kernel (gjx_ssm_step_move).
+        ``weights``: fixed-point scheme of the systematic resampler (include/gjx.h): ``"global_max"`` quantises every
+        weight against the exact global maximum, ``"tile_scaled"`` against a power of two per 1024-particle tile — one
+        grid-wide exchange per step instead of two in the one-launch filter (one GPU, no rejuvenation)."""
+        if weights not in ("global_max", "tile_scaled"):
+            raise ValueError("weights must be 'global_max' or 'tile_scaled'")
+        self.weights = A.WEIGHTS_TILE_SCALED if weights == "tile_scaled" else A.WEIGHTS_GLOBAL_MAX
         self.ssm, self.K = ssm, int(k_particles)
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
@@ -156,8 +163,10 @@ class BootstrapFilter:
             raise NotImplementedError("keep_history: the ancestor history is kept per process; run the filter on one GPU")
         if self.rejuvenate and (world > 1 or D._forced()):
             raise NotImplementedError("resample-move rejuvenation runs on one GPU")
+        if self.weights == A.WEIGHTS_TILE_SCALED and (world > 1 or D._forced()):
+            raise NotImplementedError("the tile-scaled weight scheme runs on one GPU (the sharded exchange quantises against the global maximum)")
         if world == 1 and not keep_means and not step_by_step and not keep_history and not self.rejuvenate and not D._forced():
-            out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K)
+            out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, weights=self.weights)
             incs = out["lse_steps"][:, 3]
             res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)
             return self._checked(res, out["_status_ws"], check_status)
@@ -193,7 +202,10 @@ class BootstrapFilter:
             k = fold_in(k, t)                      # chained step key (scan.py:268)
             k_prop, k_res = split(k)
             if t > 0 and not sharded:
-                anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
+                if self.weights == A.WEIGHTS_TILE_SCALED:
+                    anc = kernels.resample_indices_tiled(logw, _unit_from_key(k_res), self.K, ws=ws2, cum=cum_buf)
+                else:
+                    anc = kernels.resample_indices(logw, _unit_from_key(k_res), self.K, True, lse, ws=ws2, cum=cum_buf, bt=bt_buf)
             x_out = bufs[t & 1]
             if self.rejuvenate:
                 if t == 0:

@@ -254,6 +254,25 @@ def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=Tru
     return anc
 
 
+def resample_indices_tiled(logw: torch.Tensor, u: float, N: int | None = None, anc=None, cum=None, ws=None, want_q=False):
+    """gjx_resample_indices_tiled: log-weights -> systematic ancestors under the tile-scaled fixed point (gjx.h,
+    GJX_WEIGHTS_TILE_SCALED).  -> ancestors int32[N], or (ancestors, q int32[K], e int32[ceil(K/1024)]) with want_q"""
+    K = logw.numel()
+    N = int(N or K)
+    dev = logw.device
+    if anc is None:
+        anc = torch.empty(N, dtype=torch.int32, device=dev)
+    if cum is None:
+        cum = torch.empty(K, dtype=torch.int64, device=dev)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, dev)
+    q = torch.empty(K, dtype=torch.int32, device=dev) if want_q else None
+    e = torch.empty((K + 1023) // 1024, dtype=torch.int32, device=dev) if want_q else None
+    check(load().gjx_resample_indices_tiled(_ptr(logw), K, float(u), N, _ptr(anc), _ptr(cum), _ptr(q), _ptr(e), _ptr(ws), ws.numel(),
+                                            _stream()), "gjx_resample_indices_tiled")
+    return (anc, q, e) if want_q else anc
+
+
 def resample_gather(x: torch.Tensor, u: float, rows: torch.Tensor, is_log=True, lse=None, partials=None, lse_out=None,
                     K_total=None, out=None, anc=None, ws=None, allow_fallback=True) -> torch.Tensor:
     """gjx_resample_gather: weights -> systematic ancestors -> out[r, j] = rows[r, ancestor(j)] in ONE launch (N = K);
@@ -568,8 +587,9 @@ def score_grad(prog: PackedProgram, choices: torch.Tensor):
     return score, grad
 
 
-def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None):
-    """gjx_ssm_filter: the whole T-step bootstrap filter in one native call.
+def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None, weights: int = A.WEIGHTS_GLOBAL_MAX):
+    """gjx_ssm_filter_scheme: the whole T-step bootstrap filter in one native call; ``weights`` picks the fixed-point
+    scheme of its resampler (A.WEIGHTS_GLOBAL_MAX | A.WEIGHTS_TILE_SCALED).
     -> dict(lse_steps [T][4], x (final state rows), logw, ancestors)"""
     dev = ys.device
     T = ys.shape[0]
@@ -580,9 +600,9 @@ def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None
                     logw=torch.empty(K, dtype=torch.float32, device=dev), cum=torch.empty(K, dtype=torch.int64, device=dev),
                     anc=torch.empty(K, dtype=torch.int32, device=dev), lse=torch.empty((T, 4), dtype=torch.float32, device=dev),
                     ws=torch.zeros(2 * need + 64, dtype=torch.uint8, device=dev))
-    check(load().gjx_ssm_filter(C.byref(ssm), key[0], key[1], rng_mode, T, int(K), _ptr(ys), _ptr(bufs["xa"]), _ptr(bufs["xb"]),
-                                _ptr(bufs["logw"]), _ptr(bufs["cum"]), _ptr(bufs["anc"]), _ptr(bufs["lse"]), _ptr(bufs["ws"]),
-                                bufs["ws"].numel(), _stream()), "gjx_ssm_filter")
+    check(load().gjx_ssm_filter_scheme(C.byref(ssm), key[0], key[1], rng_mode, T, int(K), _ptr(ys), _ptr(bufs["xa"]),
+                                       _ptr(bufs["xb"]), _ptr(bufs["logw"]), _ptr(bufs["cum"]), _ptr(bufs["anc"]), _ptr(bufs["lse"]),
+                                       int(weights), _ptr(bufs["ws"]), bufs["ws"].numel(), _stream()), "gjx_ssm_filter_scheme")
     # the resampling half of the workspace (status word of the co-resident step kernels): second OP_SSM-sized block
     need = load().gjx_workspace_bytes(A.OP_SSM, K)
     return dict(lse_steps=bufs["lse"], x=bufs["xa"] if (T - 1) % 2 == 0 else bufs["xb"], logw=bufs["logw"],

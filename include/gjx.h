@@ -448,6 +448,34 @@ int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_m
                    const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                    float* lse_steps, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fixed-point weight schemes of the systematic resampler inside the filter loop.
+ *   GJX_WEIGHTS_GLOBAL_MAX (what gjx_resample_indices does): q_i = floor(2^30 exp(log w_i - max_all log w)).  The exact
+ *     global maximum is a grid-wide dependency of its own: two rendezvous per step in the one-launch filter.
+ *   GJX_WEIGHTS_TILE_SCALED: every tile of 1024 consecutive particles is quantised against its own power of two,
+ *     e_b = ceil(max_tile(log w) * log2 e) (float32 multiply, clamped to +-524287, i.e. |log w| < 3.6e5; a tile without a
+ *     finite positive weight is dead), q_i = floor(2^29 min(1, exp2(fma(log w_i, log2 e, -e_b)))), S_b = sum of the tile's q_i.  With E = max e_b over
+ *     the live tiles, tile b covers G_b = S_b >> (E - e_b) units of the global weight line (0 when the shift is >= 64),
+ *     the comb thresholds T_j = floor((j + u) total / N) are taken on the prefix P of the G_b exactly as before, and
+ *     inside its source tile b slot j takes the first particle whose tile-local cumulative q exceeds
+ *     (T_j - P_b) << (E - e_b).  One exchange of {e_b, S_b} per step instead of two; a tile loses less than one unit of
+ *     2^(E-29) (under 2^-28 of the largest weight), nothing else is approximated; the result does not depend on the
+ *     launch geometry (the tile is part of the scheme).  Same systematic comb, same key discipline, same propagation
+ *     streams; the ancestors differ from GLOBAL_MAX's only where a threshold falls within the quantisation step of a
+ *     particle boundary.  Oracle: gjxo_resample_systematic_tiled.
+ * gjx_ssm_filter == gjx_ssm_filter_scheme(..., GJX_WEIGHTS_GLOBAL_MAX, ...). */
+enum { GJX_WEIGHTS_GLOBAL_MAX = 0, GJX_WEIGHTS_TILE_SCALED = 1 };
+int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                          const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
+                          float* lse_steps, int32_t weight_scheme, void* workspace, size_t workspace_bytes, void* stream);
+/* The tile-scaled systematic resampler on its own (three plain launches; what the filter's one-launch form computes
+ * between two steps, bit for bit): log-weights f32[K] -> ancestors i32[N].  cum u64[K] scratch (tile-local cumulative q);
+ * q_out u32[K] / e_out i32[ceil(K/1024)] receive the quantised weights and tile exponents when not NULL (the oracle
+ * checks the integer logic from them, the exp2 separately).  A dead collection yields identity ancestors and
+ * GJX_STATUS_ZERO_TOTAL.  workspace: gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once.  There is no counterpart
+ * in the reference (its SMC does not resample); the comb is that of gjx_resample_systematic. */
+int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N, int32_t* ancestors, uint64_t* cum,
+                               uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same filter on a collection sharded over the ranks of a shard context, BASELINE config 4: every rank
  * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles
  * (streams indexed by the global particle index particle_offset + i, so results do not depend on the number

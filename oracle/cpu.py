@@ -41,6 +41,7 @@ def lib() -> C.CDLL:
         L.gjxo_weight_cumsum.argtypes = [vp, i64, i32, vp, vp, vp]
         L.gjxo_resample_systematic.argtypes = [vp, i64, u64, u64, f64, i64, i64, i64, vp]
         L.gjxo_resample_multinomial.argtypes = [vp, i64, u64, u64, u32, u32, i64, i64, i64, vp]
+        L.gjxo_resample_systematic_tiled.argtypes = [vp, i64, f64, i64, vp, vp, vp, vp]
         L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
         L.gjxo_ssm_step.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp,
                                     i64, vp, vp, vp, vp, vp, i64]
@@ -155,6 +156,20 @@ def resample_systematic(cum, u, N_total, base=0, total_all=None, out_begin=0, n_
     lib().gjxo_resample_systematic(_p(cum), cum.size, int(base), total_all, float(u), int(N_total),
                                    int(out_begin), n_out, _p(anc))
     return anc
+
+
+def resample_systematic_tiled(logw, u, N=None, q=None):
+    """-> (ancestors int32[N], q uint32[K], e int32[ceil(K/1024)], dead bool): the tile-scaled fixed-point scheme;
+    ``q`` = quantised weights to use instead of the oracle's own exp2f (the device's)."""
+    logw = np.ascontiguousarray(logw, np.float32)
+    K = logw.size
+    N = int(K if N is None else N)
+    anc = np.zeros(N, np.int32)
+    q_out = np.zeros(K, np.uint32)
+    e_out = np.zeros((K + 1023) // 1024, np.int32)
+    qi = None if q is None else np.ascontiguousarray(q, np.uint32)
+    rc = lib().gjxo_resample_systematic_tiled(_p(logw), K, float(u), N, _p(qi), _p(anc), _p(q_out), _p(e_out))
+    return anc, q_out, e_out, bool(rc)
 
 
 def resample_multinomial(cum, key, N_total, base=0, total_all=None, out_begin=0, n_out=None):

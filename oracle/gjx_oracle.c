@@ -806,6 +806,83 @@ int gjxo_resample_systematic(const uint64_t* cum, int64_t K, uint64_t base, uint
   return 0;
 }
 
+/* Systematic resampling under the TILE-SCALED fixed point (include/gjx.h GJX_WEIGHTS_TILE_SCALED; device:
+ * genjax_amd/csrc/gjx_ssm.hip k_ssm_persistent<TILED> / gjx_resample_indices_tiled).  No counterpart in the reference
+ * (its SMC never resamples); the comb is gjxo_resample_systematic's.  Sequential on purpose.
+ *   tile b = particles [1024 b, 1024 b + 1024): e_b = ceil(max(log w) * log2 e) in float32, clamped to +-524287,
+ *   q_i = floor(2^29 min(1, exp2f(fmaf(log w_i, log2 e, -e_b)))), S_b = sum q_i; a tile with S_b == 0 is dead.
+ *   E = max e_b over live tiles; G_b = S_b >> (E - e_b); P = exclusive prefix of G; T_j = comb threshold on total = sum G;
+ *   slot j -> tile b with P_b <= T_j < P_{b+1}; ancestor = first i in the tile with cumulative q > (T_j - P_b) << (E - e_b).
+ * q_in != NULL: use these quantised weights (the device's, so that everything but the exp2 is compared bit for bit;
+ * the exponents are still recomputed from logw).  q_out / e_out (optional) receive the oracle's own q and e_b.
+ * All weights dead: identity ancestors (min(j, K - 1)), returns 1. */
+#define GJXO_TILE_Q 1024
+#define GJXO_TILE_DEAD (-524288)
+int gjxo_resample_systematic_tiled(const float* logw, int64_t K, double u, int64_t N, const uint32_t* q_in,
+                                   int32_t* ancestors, uint32_t* q_out, int32_t* e_out) {
+  const float log2e = 1.44269504f;
+  const int64_t nt = (K + GJXO_TILE_Q - 1) / GJXO_TILE_Q;
+  uint64_t* S = (uint64_t*)calloc((size_t)nt + 1, sizeof(uint64_t));
+  uint64_t* P = (uint64_t*)calloc((size_t)nt + 1, sizeof(uint64_t));
+  int32_t* E = (int32_t*)calloc((size_t)nt, sizeof(int32_t));
+  uint32_t* q = (uint32_t*)calloc((size_t)K, sizeof(uint32_t));
+  int Emax = GJXO_TILE_DEAD;
+  for (int64_t b = 0; b < nt; ++b) {
+    const int64_t lo = b * GJXO_TILE_Q, hi = lo + GJXO_TILE_Q < K ? lo + GJXO_TILE_Q : K;
+    float m = -INFINITY;
+    for (int64_t i = lo; i < hi; ++i) if (logw[i] > m) m = logw[i]; /* NaN never wins, as fmaxf on the device */
+    int e = GJXO_TILE_DEAD;
+    if (m > -INFINITY) {
+      const float t = ceilf(m * log2e);
+      e = t < -524287.0f ? -524287 : (t > 524287.0f ? 524287 : (int)t);
+    }
+    uint64_t acc = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      uint32_t qi = 0;
+      if (q_in) qi = q_in[i];
+      else if (e != GJXO_TILE_DEAD) {
+        float w = exp2f(fmaf(logw[i], log2e, -(float)e));
+        if (!(w > 0.0f)) w = 0.0f;
+        if (!(w < 1.0f)) w = 1.0f;
+        qi = (uint32_t)(w * 536870912.0f);
+      }
+      q[i] = qi;
+      acc += qi;
+    }
+    S[b] = acc;
+    E[b] = acc ? e : GJXO_TILE_DEAD;
+    if (acc && e > Emax) Emax = e;
+    if (e_out) e_out[b] = E[b];
+  }
+  if (q_out) memcpy(q_out, q, (size_t)K * sizeof(uint32_t));
+  for (int64_t b = 0; b < nt; ++b) {
+    const int sh = Emax - E[b];
+    P[b + 1] = P[b] + (sh < 64 ? S[b] >> sh : 0);
+  }
+  const uint64_t total = P[nt];
+  int rc = 0;
+  if (total == 0) {
+    for (int64_t j = 0; j < N; ++j) ancestors[j] = (int32_t)(j < K ? j : K - 1);
+    rc = 1;
+  } else {
+    const double step = (double)total / (double)N;
+    int64_t b = 0;
+    for (int64_t j = 0; j < N; ++j) {
+      uint64_t T = (uint64_t)(((double)j + u) * step);
+      if (T > total - 1) T = total - 1;
+      while (!(P[b + 1] > T)) ++b;            /* thresholds are non-decreasing */
+      const uint64_t r = (T - P[b]) << (Emax - E[b]);
+      const int64_t lo = b * GJXO_TILE_Q, hi = lo + GJXO_TILE_Q < K ? lo + GJXO_TILE_Q : K;
+      uint64_t c = 0;
+      int64_t i = lo;
+      for (; i < hi - 1; ++i) { c += q[i]; if (c > r) break; }
+      ancestors[j] = (int32_t)i;
+    }
+  }
+  free(S); free(P); free(E); free(q);
+  return rc;
+}
+
 int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uint64_t total_all,
                               uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
                               int64_t n_out, int32_t* ancestors) {

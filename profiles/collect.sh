@@ -55,6 +55,7 @@ PY
 fi
 GJX_SSM_PERSISTENT=0 python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
 python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_ssm_persistent_timeline.txt
+SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
 python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT

@@ -1,0 +1,133 @@
+"""Tile-scaled fixed-point weights (include/gjx.h GJX_WEIGHTS_TILE_SCALED): the multi-launch resampler against the
+oracle's restatement (integer logic bit for bit from the device's quantised weights, the exp2 within float32 bounds),
+the one-launch filter against the step-by-step loop (bit-identical), and the filter's log-ML against the Kalman filter."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from genjax_amd import _abi as A       # noqa: E402
+from genjax_amd import core            # noqa: E402
+from oracle import closed_form as cf   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from genjax_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu
+    return cpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _weight_shapes(K, rs):
+    lw = rs.standard_normal(K).astype(np.float32)
+    yield "normal", lw
+    yield "wide", (lw * 12.0 - 300.0).astype(np.float32)
+    spiky = np.full(K, -80.0, np.float32)
+    spiky[rs.integers(0, K, max(1, K // 500))] = 0.0
+    yield "spiky", spiky
+    holes = lw.copy()
+    holes[rs.random(K) < 0.3] = -np.inf
+    holes[rs.random(K) < 0.01] = np.nan
+    if K > 2048:
+        holes[1024:2048] = -np.inf                     # a dead tile
+        holes[2048:3072] -= 150.0                      # a tile that is shifted out
+    yield "holes", holes
+    one = np.full(K, -np.inf, np.float32)
+    one[K // 3] = -1234.5
+    yield "one_live", one
+    yield "ramp", np.linspace(-60000.0, 0.0, K).astype(np.float32)   # tile exponents span the whole shift range
+
+
+@pytest.mark.parametrize("K,N", [(1, 1), (777, 777), (1024, 1024), (1025, 3000), (10_000, 10_000), (1 << 18, 1 << 18), ((1 << 20) + 5, 1 << 19)])
+def test_tiled_resampler_against_oracle(K_, oracle, K, N):
+    import torch
+    rs = np.random.default_rng(K)
+    for name, lw in _weight_shapes(K, rs):
+        for u in (0.0, 0.3718, 0.999999):
+            anc, q, e = K_.resample_indices_tiled(torch.as_tensor(lw).cuda(), u, N, want_q=True)
+            anc, q, e = _np(anc), _np(q).view(np.uint32), _np(e)
+            # (1) everything but the exp2: the oracle run on the device's quantised weights -> the same ancestors, bit for bit
+            anc_o, q_same, e_o, dead = oracle.resample_systematic_tiled(lw, u, N, q=q)
+            assert not dead, name
+            np.testing.assert_array_equal(e, e_o, err_msg=name)
+            np.testing.assert_array_equal(anc, anc_o, err_msg=f"{name} u={u}")
+            if u != 0.3718:
+                continue
+            # (2) the exp2: device v_exp_f32 vs libm exp2f on the same fma argument, a few float32 ulps of the weight
+            _, q_o, _, _ = oracle.resample_systematic_tiled(lw, u, N)
+            np.testing.assert_allclose(q.astype(np.float64), q_o.astype(np.float64), rtol=4e-7, atol=1.0, err_msg=name)
+            assert q.max() <= (1 << 29)
+
+
+def test_tiled_dead_collection_sets_status(K_):
+    import torch
+    lw = torch.full((5000,), float("-inf"), device="cuda")
+    ws = K_.workspace(A.OP_RESAMPLE, 5000, lw.device)
+    anc = K_.resample_indices_tiled(lw, 0.5, ws=ws)
+    assert (_np(anc) == np.arange(5000)).all()
+    assert K_.workspace_status(ws, raise_on_error=False) & 2
+    assert K_.workspace_status(ws, raise_on_error=False) == 0            # read and cleared
+
+
+@pytest.mark.parametrize("K", [10_000, 1 << 16, (1 << 18) - 77])
+def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
+    """k_ssm_persistent<TILED> (one rendezvous per step, everything in registers / LDS) == gjx_ssm_step +
+    gjx_resample_indices_tiled issued from the host: same ancestors, hence bit-identical particles and weights."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem(T=24)
+    for rng in (A.RNG_FLAT, A.RNG_JAX32):
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, rng_mode=rng, weights="tile_scaled")
+        a = bf.run(core.key(7), s["y"])
+        b = bf.run(core.key(7), s["y"], step_by_step=True)
+        assert not a["degenerate"]
+        np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+        np.testing.assert_array_equal(_np(a["logw"]), _np(b["logw"]))
+        np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-6)   # LSE finish order differs
+        # the multi-launch fallback of the native loop (no co-resident grid): the same again
+        os.environ["GJX_SSM_PERSISTENT"] = "0"
+        try:
+            c = bf.run(core.key(7), s["y"])
+        finally:
+            del os.environ["GJX_SSM_PERSISTENT"]
+        np.testing.assert_array_equal(_np(a["x"]), _np(c["x"]))
+        np.testing.assert_allclose(_np(a["increments"]), _np(c["increments"]), rtol=2e-6, atol=2e-6)
+
+
+def test_tiled_filter_close_to_global_max_filter(K_):
+    """Same comb, same streams: the two weight schemes pick the same ancestor except where a threshold falls within the
+    quantisation step of a particle boundary — after one resampling almost all particles agree bit for bit."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem(T=2)
+    K = 1 << 16
+    m = LinearGaussianSSM(s["A"], s["q"], s["r"])
+    a = BootstrapFilter(m, K, weights="tile_scaled").run(core.key(3), s["y"])
+    b = BootstrapFilter(m, K).run(core.key(3), s["y"])
+    same = (_np(a["x"]) == _np(b["x"])).all(axis=0)
+    assert same.mean() > 0.995
+    np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=1e-3, atol=1e-3)
+
+
+def test_tiled_bootstrap_filter_full_size(K_):
+    """BASELINE config 3 (T=256, K=2^18) under the tile-scaled scheme: log-ML vs the float64 Kalman filter, rtol 1e-4."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem()
+    exact, incs, _ = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18, weights="tile_scaled")
+    out = bf.run(core.key(1), s["y"])
+    assert not out["degenerate"]
+    assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
+    np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
