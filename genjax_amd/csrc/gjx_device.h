@@ -569,16 +569,50 @@ GJX_DEV float elem_sample(int kind, BS& bs, uint32_t c, float a, float b, float 
 }
 
 // ---- reductions --------------------------------------------------------------------------------
-GJX_DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// `__shfl_*` compiles to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles each): a 64-lane u64 scan is 12 of them
+// in a dependent chain, and the latency-bound co-resident kernels run half a dozen such chains per step.  The same
+// scan as 6 DPP steps (MI355X guide, DPP idioms): row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into rows 2 and 3; lanes without a source keep the identity (`old`).
+template <unsigned CTRL, unsigned ROW_MASK>
+GJX_DEV uint32_t dpp_mov(uint32_t identity, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr unsigned kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+template <unsigned CTRL, unsigned ROW_MASK>
+GJX_DEV float dpp_max_f32(float v) {
+  return fmaxf(v, __uint_as_float(dpp_mov<CTRL, ROW_MASK>(0xFF800000u /* -inf */, __float_as_uint(v))));
+}
+template <unsigned CTRL, unsigned ROW_MASK>
+GJX_DEV float dpp_add_f32(float v) { return v + __uint_as_float(dpp_mov<CTRL, ROW_MASK>(0u, __float_as_uint(v))); }
+GJX_DEV float wave_max_dpp(float v) {        // maximum over the wave, in every lane (NaN never wins, as fmaxf)
+  v = dpp_max_f32<kDppShr1, 0xf>(v);
+  v = dpp_max_f32<kDppShr2, 0xf>(v);
+  v = dpp_max_f32<kDppShr4, 0xf>(v);
+  v = dpp_max_f32<kDppShr8, 0xf>(v);
+  v = dpp_max_f32<kDppBcast15, 0xa>(v);
+  v = dpp_max_f32<kDppBcast31, 0xc>(v);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+GJX_DEV float wave_sum_dpp(float v) {        // sum over the wave, in every lane (a fixed order, not wave_sum's butterfly)
+  v = dpp_add_f32<kDppShr1, 0xf>(v);
+  v = dpp_add_f32<kDppShr2, 0xf>(v);
+  v = dpp_add_f32<kDppShr4, 0xf>(v);
+  v = dpp_add_f32<kDppShr8, 0xf>(v);
+  v = dpp_add_f32<kDppBcast15, 0xa>(v);
+  v = dpp_add_f32<kDppBcast31, 0xc>(v);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+GJX_DEV float row_sum_to_lane15(float v) {
+  v = dpp_add_f32<kDppShr1, 0xf>(v);
+  v = dpp_add_f32<kDppShr2, 0xf>(v);
+  v = dpp_add_f32<kDppShr4, 0xf>(v);
+  v = dpp_add_f32<kDppShr8, 0xf>(v);
   return v;
 }
-GJX_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+
+GJX_DEV float wave_max(float v) { return wave_max_dpp(v); }
+GJX_DEV float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // Block-wide {max, sum exp(x - max)} of one value per thread; result valid in thread 0.
 // `red` is LDS scratch of >= 2 * (blockDim/64) floats.

@@ -122,12 +122,7 @@ __global__ __launch_bounds__(256) void k_wscan_write(const float* x, int64_t K, 
     s += q[k];
     q[k] = s;  // thread-local inclusive
   }
-  uint64_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-    if ((threadIdx.x & 63) >= o) inc += up;
-  }
+  uint64_t inc = wave_scan_u64(s);
   if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
   uint64_t off = red[0] + red[1] + red[2] + red[3] + inc - s;
@@ -340,12 +335,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
     const int e0 = threadIdx.x * per, e1 = (e0 + per) < nb ? (e0 + per) : nb;
     uint64_t loc = 0;
     for (int e = e0; e < e1; ++e) loc += P[e + 1];
-    uint64_t inc = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-      if (lane >= o) inc += up;
-    }
+    uint64_t inc = wave_scan_u64(loc);
     if (lane == 63) wsum[wid] = inc;     // the publish above read wsum before the barrier after the gather
     __syncthreads();
     uint64_t run = inc - loc;
@@ -403,12 +393,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
     bool first[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) { first[k] = tile[k] != (k ? tile[k - 1] : prev); cnt += first[k]; }
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
+    const int incl = (int)wave_scan_u32((uint32_t)cnt);
     if (lane == 63) s_cnt[wid] = incl;
     __syncthreads();
     int at = incl - cnt;
@@ -441,13 +426,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
         inc[c] = sacc[c];
       }
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const uint64_t up = __shfl_up((unsigned long long)inc[c], o, 64);
-          if (lane >= o) inc[c] += up;
-        }
-      }
+      for (int c = 0; c < CH; ++c) inc[c] = wave_scan_u64(inc[c]);     // three independent DPP chains
       if (lane == 63) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];

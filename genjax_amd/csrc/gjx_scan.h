@@ -47,17 +47,7 @@ GJX_DEV float block_ref_max(int mode, const float* lse, int n_partials, float* r
   return m;
 }
 
-// ---- wave scans and reductions on the DPP network -----------------------------------------------------------
-// `__shfl_*` compiles to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles each): a 64-lane u64 scan is 12 of them
-// in a dependent chain, and the latency-bound co-resident kernels run half a dozen such chains per step.  The same
-// scan as 6 DPP steps (MI355X guide, DPP idioms): row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15
-// into rows 1 and 3 and row_bcast:31 into rows 2 and 3; lanes without a source keep the identity (`old`).
-template <unsigned CTRL, unsigned ROW_MASK>
-GJX_DEV uint32_t dpp_mov(uint32_t identity, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-constexpr unsigned kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
-
+// ---- u64 wave scans on the DPP network (dpp_mov and the float forms: gjx_device.h) ----
 template <unsigned CTRL, unsigned ROW_MASK>
 GJX_DEV uint64_t dpp_add_u64(uint64_t v) {
   const uint32_t lo = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)v), hi = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
@@ -73,6 +63,15 @@ GJX_DEV uint64_t wave_scan_u64(uint64_t v) {
   v = dpp_add_u64<kDppBcast31, 0xc>(v);
   return v;
 }
+GJX_DEV uint32_t wave_scan_u32(uint32_t v) {
+  v += dpp_mov<kDppShr1, 0xf>(0u, v);
+  v += dpp_mov<kDppShr2, 0xf>(0u, v);
+  v += dpp_mov<kDppShr4, 0xf>(0u, v);
+  v += dpp_mov<kDppShr8, 0xf>(0u, v);
+  v += dpp_mov<kDppBcast15, 0xa>(0u, v);
+  v += dpp_mov<kDppBcast31, 0xc>(0u, v);
+  return v;
+}
 GJX_DEV uint64_t lane63_u64(uint64_t v) {
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
@@ -85,43 +84,7 @@ GJX_DEV uint64_t row_scan_u64(uint64_t v) {
   v = dpp_add_u64<kDppShr8, 0xf>(v);
   return v;
 }
-template <unsigned CTRL, unsigned ROW_MASK>
-GJX_DEV float dpp_max_f32(float v) {
-  return fmaxf(v, __uint_as_float(dpp_mov<CTRL, ROW_MASK>(0xFF800000u /* -inf */, __float_as_uint(v))));
-}
-template <unsigned CTRL, unsigned ROW_MASK>
-GJX_DEV float dpp_add_f32(float v) { return v + __uint_as_float(dpp_mov<CTRL, ROW_MASK>(0u, __float_as_uint(v))); }
-GJX_DEV float wave_max_dpp(float v) {        // maximum over the wave, in every lane (NaN never wins, as fmaxf)
-  v = dpp_max_f32<kDppShr1, 0xf>(v);
-  v = dpp_max_f32<kDppShr2, 0xf>(v);
-  v = dpp_max_f32<kDppShr4, 0xf>(v);
-  v = dpp_max_f32<kDppShr8, 0xf>(v);
-  v = dpp_max_f32<kDppBcast15, 0xa>(v);
-  v = dpp_max_f32<kDppBcast31, 0xc>(v);
-  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
-}
-GJX_DEV float wave_sum_dpp(float v) {        // sum over the wave, in every lane (a fixed order, not wave_sum's butterfly)
-  v = dpp_add_f32<kDppShr1, 0xf>(v);
-  v = dpp_add_f32<kDppShr2, 0xf>(v);
-  v = dpp_add_f32<kDppShr4, 0xf>(v);
-  v = dpp_add_f32<kDppShr8, 0xf>(v);
-  v = dpp_add_f32<kDppBcast15, 0xa>(v);
-  v = dpp_add_f32<kDppBcast31, 0xc>(v);
-  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
-}
-GJX_DEV float row_sum_to_lane15(float v) {
-  v = dpp_add_f32<kDppShr1, 0xf>(v);
-  v = dpp_add_f32<kDppShr2, 0xf>(v);
-  v = dpp_add_f32<kDppShr4, 0xf>(v);
-  v = dpp_add_f32<kDppShr8, 0xf>(v);
-  return v;
-}
-
-GJX_DEV uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o, 64);
-  return v;
-}
+GJX_DEV uint64_t wave_sum_u64(uint64_t v) { return wave_total_u64(v); }   // the total, in every lane
 
 
 // status bits a co-resident kernel leaves in workspace word 10 (read and cleared by gjx_workspace_status)
@@ -203,12 +166,7 @@ GJX_DEV void tile_scan_expand(const float (&xv)[ITEMS], int mode, float mx, int6
     s += (i0 + k < K) ? weight_q(&xv[k], 0, mode, mx) : 0;
     q[k] = s;  // thread-local inclusive
   }
-  uint64_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-    if ((threadIdx.x & 63) >= o) inc += up;
-  }
+  uint64_t inc = wave_scan_u64(s);
   if ((threadIdx.x & 63) == 63) sm.wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
   uint64_t off = inc - s;  // exclusive offset of this thread inside the block

@@ -252,12 +252,7 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
     const int e0 = threadIdx.x * per, e1 = (e0 + per) < nb ? (e0 + per) : nb;
     uint64_t loc = 0;
     for (int e = e0; e < e1; ++e) loc += P[e + 1];
-    uint64_t inc = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-      if (lane >= o) inc += up;
-    }
+    uint64_t inc = wave_scan_u64(loc);
     __syncthreads();            // wsum of the publish above has been read by thread 0
     if (lane == 63) wsum[wid] = inc;
     __syncthreads();
@@ -311,12 +306,7 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
         uint64_t qi[4], sacc = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? weight_q(lw4, k, 1, mx) : 0; qi[k] = sacc; }
-        uint64_t inc = sacc;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-          if (lane >= o) inc += up;
-        }
+        uint64_t inc = wave_scan_u64(sacc);
         const uint64_t base = P[tsrc] + (inc - sacc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) cumL[wid * 256 + lane * 4 + k] = base + qi[k];
@@ -920,12 +910,7 @@ __global__ __launch_bounds__(kTileQ) void k_tiled_quantise(const float* logw, in
   for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
   const int e = tile_exponent(bm);
   const uint64_t q = active ? tile_q(lw, e) : 0;
-  uint64_t inc = q;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-    if (lane >= o) inc += up;
-  }
+  uint64_t inc = wave_scan_u64(q);
   if (lane == 63) wsum[wid] = inc;
   __syncthreads();
   uint64_t base = 0, tot = 0;
@@ -960,12 +945,7 @@ __global__ __launch_bounds__(1024) void k_tiled_plan(const uint64_t* S, const in
       g = s < 64 ? S[b] >> s : 0;
       sh[b] = s < 64 ? s : 64;
     }
-    uint64_t inc = g;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t up = __shfl_up((unsigned long long)inc, o, 64);
-      if (lane >= o) inc += up;
-    }
+    uint64_t inc = wave_scan_u64(g);
     __syncthreads();
     if (lane == 63) wsum[wid] = inc;
     __syncthreads();

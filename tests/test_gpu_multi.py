@@ -145,7 +145,9 @@ def test_bench_launcher_config4_ssm():
     of the same K to LSE rounding (small K and T here; the full size is bench.py --workload ssm --gpus 8)."""
     multi = _n_gpus() >= 2
     env = {} if multi else {"GJX_ALL_ON_DEVICE0": "1", "GJX_DIST_BACKEND": "gloo"}
-    one = _run_bench(["--workload", "ssm", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total", str(1 << 14)])
+    # (the sharded exchange quantises against the global maximum: compare with the one-GPU run under the same scheme)
+    one = _run_bench(["--workload", "ssm", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total", str(1 << 14),
+                      "--ssm-weights", "global_max"])
     two = _run_bench(["--workload", "ssm", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total",
                       str(1 << 14)], env)
     assert two["n_gpus"] == 2 and two["config"]["k_particles_total"] == 1 << 14 and two["config"]["k_particles_per_gpu"] == 1 << 13
