@@ -205,6 +205,7 @@ struct SsmFusedArgs {
 };
 
 constexpr int kSsmFusedMaxTiles = 2048;
+constexpr int kSsmPersistMaxDy = 32;              // observation dimension the one-launch filter stages in LDS
 
 template <int RNG, int DX>
 __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
@@ -440,15 +441,16 @@ struct SsmPersistArgs {
   unsigned* ready;                 // [gridDim.x] TILED: epoch + t once the block's stores of step t-1 have completed
   unsigned* ctrl;
   float log_k;
-  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block for step T / 2
+  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 16 realtime stamps per block for step T / 2
 };
 
 GJX_DEV float load_agent(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams)
-template <int RNG, int DX>
-GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX]) {
+// `between()` runs between the segments (one hash / one Box-Muller pair each): the caller's look at its granule loads
+template <int RNG, int DX, class Between>
+GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX], Between&& between) {
   if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
   else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
   if (RNG == GJX_RNG_FLAT) {
@@ -459,6 +461,7 @@ GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX]) {
     for (int h = 0; h < NB; ++h) {
       const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
       w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
+      between();
     }
 #pragma unroll
     for (int d0 = 0; d0 < DX; d0 += 2) {
@@ -466,12 +469,14 @@ GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX]) {
       box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
       nz[d0] = n0;
       if (d0 + 1 < DX) nz[d0 + 1] = n1;
+      if ((d0 & 2) && d0 + 2 < DX) between();
     }
   } else {
 #pragma unroll
     for (int d0 = 0; d0 < DX; ++d0) {
       const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
       nz[d0] = normal_from_bits_fast(h0.a ^ h0.b);
+      if (d0 + 1 < DX) between();
     }
   }
 }
@@ -518,6 +523,13 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   __shared__ uint64_t cumL[kChunk * THREADS];
   __shared__ int32_t s_tof[THREADS], s_tiles[THREADS];
   __shared__ int s_cnt[NW];
+  // model constants in LDS: inside the step loop the compiler must assume the kernel's own stores may alias A, H, ys, us
+  // and re-reads them with VECTOR loads every step (16 dependent global_load_dwordx4 for A alone: 1.6 us per step)
+  __shared__ float sA[DX * DX], sH[kSsmPersistMaxDy * DX], sY[kSsmPersistMaxDy];
+  __shared__ double sU;
+  __shared__ uint32_t sKey[2][2];
+  for (int e = threadIdx.x; e < DX * DX; e += THREADS) sA[e] = f.A[e];
+  if (f.H) for (int e = threadIdx.x; e < f.dy * DX; e += THREADS) sH[e] = f.H[e];
   const unsigned epoch = __hip_atomic_load(&f.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t K = f.K;
   const int nb = (int)gridDim.x, T = f.T;
@@ -553,7 +565,18 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     float* rec = f.lse_steps + 4 * (size_t)s;
     rec[0] = m; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
   };
-#define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  // y_t and the comb offset of step t into LDS, by lanes of the second wave, while the granules travel (read several
+  // barriers later; the previous step's values were last read before this step's first barrier)
+  auto stage_step_constants = [&](int t) {
+    if (t < T && wid == (NW > 1 ? 1 : 0)) {
+      if (lane < f.dy) sY[lane] = f.ys[(size_t)t * f.dy + lane];
+      if (lane == 63) sU = f.us[t];
+      if (lane >= 61 && lane < 63 && t + 1 < T) sKey[(t + 1) & 1][lane - 61] = f.keys[2 * (t + 1) + (lane - 61)];   // next step's key
+    }
+  };
+  if (threadIdx.x < 2) sKey[1][threadIdx.x] = f.keys[2 + threadIdx.x];        // step 1's key (T > 1)
+  __syncthreads();
+#define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = 1; t <= T; ++t) {
     GJX_PSTAMP(0);
     float nz[DX];
@@ -564,7 +587,10 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     const unsigned rtag = epoch + (unsigned)t;                // `ready` word of this step: never repeats, the epoch advances by 2 T per launch
     auto check_ready = [&]() {                                // every block's stores of step t-1 have completed (TILED)
       unsigned budget = 1u << 22;
-      for (int b = threadIdx.x, k = 0; b < nb; b += THREADS, ++k) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int b = threadIdx.x + k * THREADS;
+        if (b >= nb) break;
         unsigned r = rdy[k];
         while (r != rtag && budget) {
           __builtin_amdgcn_s_sleep(1);
@@ -605,7 +631,8 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           store_agent(&f.bsum[(size_t)(t & 1) * nb + blockIdx.x], bs);
         }
       }
-      if (t < T) ssm_noise<RNG, DX>(key2{f.keys[2 * t], f.keys[2 * t + 1]}, (uint64_t)j, nz);
+      stage_step_constants(t);
+      if (t < T) ssm_noise<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nz, [] {});
       int np = 0;
       grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
         const float m = __uint_as_float((uint32_t)v);
@@ -677,17 +704,32 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       if (fin) {
         const float* rm = f.bmax + (size_t)((t - 2) % 3) * nb;
         const float* rs = f.bsum + (size_t)((t - 2) % 3) * nb;
-        int k = 0;
-        for (int b = (threadIdx.x + THREADS / 2) % THREADS; b < nb; b += THREADS, ++k) { rpm[k] = load_agent(rm + b); rps[k] = load_agent(rs + b); }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          const int b = (threadIdx.x + THREADS / 2) % THREADS + k * THREADS;     // the non-polling half of the block first
+          rpm[k] = b < nb ? load_agent(rm + b) : -INFINITY;
+          rps[k] = b < nb ? load_agent(rs + b) : 0.0f;
+        }
       }
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(&f.ready[blockIdx.x], rtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // while the granules travel: the draws of step t
-      if (t < T) ssm_noise<RNG, DX>(key2{f.keys[2 * t], f.keys[2 * t + 1]}, (uint64_t)j, nz);
+      stage_step_constants(t);
+      // a first look at the granules goes out BEFORE the draws: for the block that is last to publish (the one everybody
+      // else is waiting for, hence the one whose own chain sets the step time) they are all there already, and the load
+      // latency hides behind the draws
+      unsigned long long gv[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {         // (fixed trip count: the loads stay in flight, in registers)
+        const int b = threadIdx.x + k * THREADS;
+        gv[k] = b < nb ? __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+      // while the granules travel: the draws of step t.  (Looking at the missing granules again between the hashes was
+      // measured and dropped: the polling waves then stall inside the draws, 13.5 -> 14.1 us per step.)
+      if (t < T) ssm_noise<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nz, [] {});
       if (fin) {
         float m = -INFINITY, sm = 0.0f;
-        int k = 0;
-        for (int b = (threadIdx.x + THREADS / 2) % THREADS; b < nb; b += THREADS, ++k) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
           const float nm = fmaxf(m, rpm[k]);
           if (nm > -INFINITY) sm = sm * fast_exp(m - nm) + rps[k] * fast_exp(rpm[k] - nm);
           m = nm;
@@ -700,13 +742,15 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       {
         unsigned budget = 1u << 22;
         float em = (float)kTileDead;
-        for (int b = threadIdx.x; b < nb; b += THREADS) {
-          unsigned long long v = 0;
-          while (budget) {
-            v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((v >> 60) == tag) break;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          const int b = threadIdx.x + k * THREADS;
+          if (b >= nb) break;
+          unsigned long long v = gv[k];
+          while ((v >> 60) != tag && budget) {
             --budget;
             __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if ((v >> 60) != tag) { __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
           const uint64_t S = v & ((1ull << 40) - 1);
@@ -716,7 +760,11 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           em = fmaxf(em, (float)e);
         }
         // the `ready` words: loads issued now, looked at after the tile search
-        for (int b = threadIdx.x, k = 0; b < nb; b += THREADS, ++k) rdy[k] = __hip_atomic_load(&f.ready[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          const int b = threadIdx.x + k * THREADS;
+          rdy[k] = b < nb ? __hip_atomic_load(&f.ready[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rtag;
+        }
         em = wave_max_dpp(em);
         if (lane == 0) fred[wid] = em;   // (fred[0..NW) was last read for the block maximum, two barriers ago)
       }
@@ -783,7 +831,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     int64_t src = j;
     if (total > 0) {
       const double step = (double)total / (double)K;
-      uint64_t Tj = comb_threshold(active ? j : K - 1, f.us[t], step, total);
+      uint64_t Tj = comb_threshold(active ? j : K - 1, sU, step, total);
       int lo = 0, hi = nb - 1;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -794,6 +842,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         Tj = (Tj - P[tile]) << (Emax - Eb[tile]);                      // residual in the source tile's own units (< S_tile)
         check_ready();                                                // before the barrier in front of the first foreign read
       }
+      GJX_PSTAMP(9);
       s_tof[threadIdx.x] = tile;
       __syncthreads();
       const bool first = threadIdx.x == 0 || s_tof[threadIdx.x - 1] != tile;
@@ -816,6 +865,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           float lw4[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) lw4[k] = p0 + k < K ? load_agent(lw_prev + p0 + k) : -INFINITY;
+          if (f.timeline && c0 == 0) { asm volatile("" :: "v"(lw4[0]), "v"(lw4[3])); GJX_PSTAMP(10); }
           const int es = TILED ? Eb[tsrc] : 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -834,6 +884,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           for (int k = 0; k < 4; ++k) cumL[tl * THREADS + part * 256 + lane * 4 + k] = base + qi[k];
         }
         __syncthreads();
+        if (c0 == 0) GJX_PSTAMP(11);
         if (kpos >= c0 && kpos < c0 + kChunk) {
           const uint64_t* cm = cumL + (kpos - c0) * THREADS;
           int l2 = 0, h2 = THREADS - 1;
@@ -856,30 +907,30 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     float xp[DX], xn[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) xp[d] = load_agent(x_prev + (int64_t)d * K + src);
+    if (f.timeline) { asm volatile("" :: "v"(xp[0]), "v"(xp[DX - 1])); GJX_PSTAMP(8); }
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
       float acc = 0.0f;
 #pragma unroll
-      for (int e = 0; e < DX; ++e) acc = fmaf(f.A[d * DX + e], xp[e], acc);
+      for (int e = 0; e < DX; ++e) acc = fmaf(sA[d * DX + e], xp[e], acc);
       xn[d] = fmaf(f.q, nz[d], acc);
     }
     if (active) {
 #pragma unroll
       for (int d = 0; d < DX; ++d) store_agent(x_out + (int64_t)d * K + j, xn[d]);
     }
-    const float* y = f.ys + (size_t)t * f.dy;
     float qsum = 0.0f;
     if (f.H) {
       for (int o = 0; o < f.dy; ++o) {
         float m = 0.0f;
 #pragma unroll
-        for (int e = 0; e < DX; ++e) m = fmaf(f.H[o * DX + e], xn[e], m);
-        const float z = (y[o] - m) * rr;
+        for (int e = 0; e < DX; ++e) m = fmaf(sH[o * DX + e], xn[e], m);
+        const float z = (sY[o] - m) * rr;
         qsum = fmaf(z, z, qsum);
       }
     } else {
 #pragma unroll
-      for (int d = 0; d < DX; ++d) { const float z = (y[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
+      for (int d = 0; d < DX; ++d) { const float z = (sY[d] - xn[d]) * rr; qsum = fmaf(z, z, qsum); }
     }
     const float lw = fmaf(-0.5f, qsum, lconst);
     if (active) store_agent(lw_buf(t) + j, lw);
@@ -1177,7 +1228,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     }
 #undef GJX_PERS
     pblk = (K + pthreads - 1) / pthreads;
-    if (pers_fn && (pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 48 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+    if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 48 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
   }
   if (pers_fn) {
     hipStream_t st = (hipStream_t)stream;
