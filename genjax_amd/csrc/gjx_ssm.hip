@@ -445,6 +445,14 @@ struct SsmPersistArgs {
 };
 
 GJX_DEV float load_agent(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+// four consecutive floats through ONE 16-byte sc1 load (4-byte sc1 accesses run at a fraction of the 16-byte rate); the
+// wait sits inside the asm because the compiler does not count an asm's memory operations
+GJX_DEV void load_agent_x4(const float* p, float (&v)[4]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+}
 GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams)
@@ -521,13 +529,12 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   __shared__ uint64_t P[kSsmFusedMaxTiles + 1];
   __shared__ int32_t Eb[TILED ? kSsmFusedMaxTiles : 1];
   __shared__ uint64_t cumL[kChunk * THREADS];
-  __shared__ int32_t s_tof[THREADS], s_tiles[THREADS];
-  __shared__ int s_cnt[NW];
   // model constants in LDS: inside the step loop the compiler must assume the kernel's own stores may alias A, H, ys, us
   // and re-reads them with VECTOR loads every step (16 dependent global_load_dwordx4 for A alone: 1.6 us per step)
   __shared__ float sA[DX * DX], sH[kSsmPersistMaxDy * DX], sY[kSsmPersistMaxDy];
   __shared__ double sU;
   __shared__ uint32_t sKey[2][2];
+  __shared__ int s_range[2];
   for (int e = threadIdx.x; e < DX * DX; e += THREADS) sA[e] = f.A[e];
   if (f.H) for (int e = threadIdx.x; e < f.dy * DX; e += THREADS) sH[e] = f.H[e];
   const unsigned epoch = __hip_atomic_load(&f.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -831,40 +838,43 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     int64_t src = j;
     if (total > 0) {
       const double step = (double)total / (double)K;
+      // the slot's source tile: first tile t with P[t + 1] > T = number of tiles whose inclusive prefix is <= T (fixed-trip
+      // descent in the LDS prefix).  The tile index is non-decreasing in the slot index, so the block's source tiles are
+      // the range between its first and its last slot's tile: no list to build, the two ends travel through LDS behind
+      // the one barrier the `ready` check needs anyway
       uint64_t Tj = comb_threshold(active ? j : K - 1, sU, step, total);
-      int lo = 0, hi = nb - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (P[mid + 1] > Tj) hi = mid; else lo = mid + 1;
+      int tile = 0;
+      for (int sft = 1 << (31 - __builtin_clz((unsigned)nb)); sft >= 1; sft >>= 1) {
+        const int p = tile + sft;                                       // P[p] = inclusive prefix of tile p - 1
+        if (p <= nb - 1 && P[p] <= Tj) tile = p;
       }
-      const int tile = lo;
+      if (threadIdx.x == 0) s_range[0] = tile;
+      if (threadIdx.x == THREADS - 1) s_range[1] = tile;                // (inactive lanes searched slot K - 1)
       if constexpr (TILED) {
         Tj = (Tj - P[tile]) << (Emax - Eb[tile]);                      // residual in the source tile's own units (< S_tile)
         check_ready();                                                // before the barrier in front of the first foreign read
       }
       GJX_PSTAMP(9);
-      s_tof[threadIdx.x] = tile;
       __syncthreads();
-      const bool first = threadIdx.x == 0 || s_tof[threadIdx.x - 1] != tile;
-      const unsigned long long bal = __ballot(first);
-      if (lane == 0) s_cnt[wid] = __popcll(bal);
-      __syncthreads();
-      int kpos = __popcll(bal & ((2ull << lane) - 1ull)) - 1;
-      int ntiles = 0;
-      for (int w = 0; w < NW; ++w) { if (w < wid) kpos += s_cnt[w]; ntiles += s_cnt[w]; }
-      if (first) s_tiles[kpos] = tile;
+      const int tmin = s_range[0], ntiles = s_range[1] - tmin + 1;    // (tiles without weight inside the range are scanned for nothing)
+      const int kpos = tile - tmin;
       for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
-        __syncthreads();
+        if (c0) __syncthreads();                                      // previous chunk's cumL consumed
         const int tl = wid / WPT, part = wid % WPT;               // this wave: quarter `part` of source tile c0 + tl
         const bool on = c0 + tl < ntiles;
         uint64_t qi[4], sacc = 0, inc = 0;
         int tsrc = 0;
         if (on) {
-          tsrc = s_tiles[c0 + tl];
+          tsrc = tmin + c0 + tl;
           const int64_t p0 = (int64_t)tsrc * THREADS + part * 256 + lane * 4;
           float lw4[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) lw4[k] = p0 + k < K ? load_agent(lw_prev + p0 + k) : -INFINITY;
+          for (int k = 0; k < 4; ++k) lw4[k] = -INFINITY;
+          if (p0 + 4 <= K) load_agent_x4(lw_prev + p0, lw4);            // (p0 is a multiple of 4, the buffer 16-byte aligned)
+          else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (p0 + k < K) lw4[k] = load_agent(lw_prev + p0 + k);
+          }
           if (f.timeline && c0 == 0) { asm volatile("" :: "v"(lw4[0]), "v"(lw4[3])); GJX_PSTAMP(10); }
           const int es = TILED ? Eb[tsrc] : 0;
 #pragma unroll
