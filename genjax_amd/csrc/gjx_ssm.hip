@@ -455,37 +455,45 @@ GJX_DEV void load_agent_x4(const float* p, float (&v)[4]) {
 }
 GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams)
-// `between()` runs between the segments (one hash / one Box-Muller pair each): the caller's look at its granule loads
-template <int RNG, int DX, class Between>
-GJX_DEV void ssm_noise(key2 skj, uint64_t gidx, float (&nz)[DX], Between&& between) {
+// standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams), in two halves: the random
+// words (the hashes: most of the VALU work, done inside the granule wait) and the normals from them (Box-Muller, done
+// behind the loads of the ancestor's state).  A block's window work must stay below the ~1 us of slack the LAST block
+// to publish has over the others, or that block is late again in the next step and its chain sets the step time.
+template <int RNG, int DX>
+struct SsmNoiseBits { uint32_t w[RNG == GJX_RNG_FLAT ? 2 * GJX_FLAT_BLOCKS(DX + (DX & 1)) : DX]; };
+
+template <int RNG, int DX>
+GJX_DEV void ssm_noise_bits(key2 skj, uint64_t gidx, SsmNoiseBits<RNG, DX>& nb) {
   if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
   else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
   if (RNG == GJX_RNG_FLAT) {
-    constexpr int NE = DX + (DX & 1);
-    constexpr int NB = GJX_FLAT_BLOCKS(NE);
-    uint32_t w[2 * NB];
+    constexpr int NB = GJX_FLAT_BLOCKS(DX + (DX & 1));
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
       const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
-      w[2 * h] = hh.a; w[2 * h + 1] = hh.b;
-      between();
-    }
-#pragma unroll
-    for (int d0 = 0; d0 < DX; d0 += 2) {
-      float n0, n1;
-      box_muller(GJX_FIELD(w, d0), GJX_FIELD(w, d0 + 1), n0, n1);
-      nz[d0] = n0;
-      if (d0 + 1 < DX) nz[d0 + 1] = n1;
-      if ((d0 & 2) && d0 + 2 < DX) between();
+      nb.w[2 * h] = hh.a; nb.w[2 * h + 1] = hh.b;
     }
   } else {
 #pragma unroll
     for (int d0 = 0; d0 < DX; ++d0) {
       const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
-      nz[d0] = normal_from_bits_fast(h0.a ^ h0.b);
-      if (d0 + 1 < DX) between();
+      nb.w[d0] = h0.a ^ h0.b;
     }
+  }
+}
+template <int RNG, int DX>
+GJX_DEV void ssm_noise_normals(const SsmNoiseBits<RNG, DX>& nb, float (&nz)[DX]) {
+  if (RNG == GJX_RNG_FLAT) {
+#pragma unroll
+    for (int d0 = 0; d0 < DX; d0 += 2) {
+      float n0, n1;
+      box_muller(GJX_FIELD(nb.w, d0), GJX_FIELD(nb.w, d0 + 1), n0, n1);
+      nz[d0] = n0;
+      if (d0 + 1 < DX) nz[d0 + 1] = n1;
+    }
+  } else {
+#pragma unroll
+    for (int d0 = 0; d0 < DX; ++d0) nz[d0] = normal_from_bits_fast(nb.w[d0]);
   }
 }
 
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
 #define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = 1; t <= T; ++t) {
     GJX_PSTAMP(0);
-    float nz[DX];
+    SsmNoiseBits<RNG, DX> nbits;
     float mx = -INFINITY;
     float pm[kPer];
     int eb = kTileDead, Emax = kTileDead;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         }
       }
       stage_step_constants(t);
-      if (t < T) ssm_noise<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nz, [] {});
+      if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
       int np = 0;
       grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
         const float m = __uint_as_float((uint32_t)v);
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       }
       // while the granules travel: the draws of step t.  (Looking at the missing granules again between the hashes was
       // measured and dropped: the polling waves then stall inside the draws, 13.5 -> 14.1 us per step.)
-      if (t < T) ssm_noise<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nz, [] {});
+      if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
       if (fin) {
         float m = -INFINITY, sm = 0.0f;
 #pragma unroll
@@ -917,6 +925,8 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     float xp[DX], xn[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) xp[d] = load_agent(x_prev + (int64_t)d * K + src);
+    float nz[DX];
+    ssm_noise_normals<RNG, DX>(nbits, nz);          // behind the loads above
     if (f.timeline) { asm volatile("" :: "v"(xp[0]), "v"(xp[DX - 1])); GJX_PSTAMP(8); }
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
