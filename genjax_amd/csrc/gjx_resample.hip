@@ -290,9 +290,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
   constexpr int CH = 3;                          // source tiles re-scanned per round
   __shared__ uint64_t cumL[CH * TILE];          // inclusive cumulative weights (absolute) of the tiles being searched
   __shared__ uint64_t s_wtot[CH][4];
-  __shared__ int32_t s_tiles[TILE];             // distinct source tiles of this block's slots, in slot order
-  __shared__ int32_t s_last[256];
-  __shared__ int s_cnt[4];
+  __shared__ int s_range[2];                    // first and last source tile of this block's slots
   unsigned epoch;
   const unsigned long long tag = grid_tag(ctrl, &epoch);
   const int nb = (int)gridDim.x;
@@ -385,44 +383,36 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
       }
     }
     if (timeline) { asm volatile("" :: "v"(tile[0]), "v"(tile[ITEMS - 1])); GJX_STAMP(7); }
-    // distinct source tiles in slot order (the tile index is non-decreasing in the slot index)
-    s_last[threadIdx.x] = tile[ITEMS - 1];
+    // the block's source tiles: the tile index is non-decreasing in the slot index, so they are the range between the
+    // first and the last slot's tile — no list to build, the two ends travel through LDS behind one barrier.  A round
+    // starts at a tile that has weight (block-uniform skip; the range's last tile always has), so collapsed weights far
+    // apart cost as many rounds as there are live tiles
+    if (threadIdx.x == 0) s_range[0] = tile[0];
+    if (threadIdx.x == 255) s_range[1] = tile[ITEMS - 1];
     __syncthreads();
-    const int prev = threadIdx.x > 0 ? s_last[threadIdx.x - 1] : -1;
-    int cnt = 0;
-    bool first[ITEMS];
+    const int tmin = s_range[0], ntiles = s_range[1] - tmin + 1;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) { first[k] = tile[k] != (k ? tile[k - 1] : prev); cnt += first[k]; }
-    const int incl = (int)wave_scan_u32((uint32_t)cnt);
-    if (lane == 63) s_cnt[wid] = incl;
-    __syncthreads();
-    int at = incl - cnt;
-    for (int w = 0; w < wid; ++w) at += s_cnt[w];
-    const int ntiles = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      if (first[k]) s_tiles[at++] = tile[k];
-      kpos[k] = at - 1;
-    }
-    __syncthreads();
+    for (int k = 0; k < ITEMS; ++k) kpos[k] = tile[k] - tmin;
+    auto next_live = [&](int at) { while (at < ntiles && P[tmin + at + 1] == P[tmin + at]) ++at; return at; };
     GJX_STAMP(3);
     // re-scan the source tiles, CH at a time (a window of TILE slots rarely touches more than 3)
     float nv[CH][ITEMS];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if (c < ntiles) load_tile((int64_t)s_tiles[c] * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);
-    for (int idx = 0; idx < ntiles; idx += CH) {
+      if (c < ntiles) load_tile((int64_t)(tmin + c) * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);
+    for (int idx = 0; idx < ntiles;) {
+      const int nidx = next_live(idx + CH);
       uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
       int tsrc[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const bool on = idx + c < ntiles;
-        tsrc[c] = on ? s_tiles[idx + c] : 0;
+        tsrc[c] = on ? tmin + idx + c : 0;
         const int64_t p0 = (int64_t)tsrc[c] * TILE + (int64_t)threadIdx.x * ITEMS;
         sacc[c] = 0;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) { sacc[c] += (on && p0 + k < K) ? weight_q(nv[c], k, mode, mx) : 0; qi[c][k] = sacc[c]; }
-        if (idx + CH + c < ntiles) load_tile((int64_t)s_tiles[idx + CH + c] * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);   // next round, in flight
+        if (nidx + c < ntiles) load_tile((int64_t)(tmin + nidx + c) * TILE + (int64_t)threadIdx.x * ITEMS, nv[c]);   // next round, in flight
         inc[c] = sacc[c];
       }
 #pragma unroll
@@ -459,6 +449,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
 #pragma unroll
       for (int k = 0; k < ITEMS; ++k)
         if (mine[k]) anc[k] = (int32_t)((int64_t)tile[k] * TILE + pos[k]);
+      idx = nidx;
     }
   }
   GJX_STAMP(4);

@@ -866,8 +866,13 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       __syncthreads();
       const int tmin = s_range[0], ntiles = s_range[1] - tmin + 1;    // (tiles without weight inside the range are scanned for nothing)
       const int kpos = tile - tmin;
+      bool again = false;
       for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
-        if (c0) __syncthreads();                                      // previous chunk's cumL consumed
+        // a round starts at a tile that has weight (block-uniform; the range's last tile always has): collapsed weights
+        // far apart cost as many rounds as there are live tiles, not as the range is long
+        while (P[tmin + c0 + 1] == P[tmin + c0]) ++c0;
+        if (again) __syncthreads();                                   // previous round's cumL consumed
+        again = true;
         const int tl = wid / WPT, part = wid % WPT;               // this wave: quarter `part` of source tile c0 + tl
         const bool on = c0 + tl < ntiles;
         uint64_t qi[4], sacc = 0, inc = 0;

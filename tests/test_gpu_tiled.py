@@ -107,6 +107,32 @@ def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
         np.testing.assert_allclose(_np(a["increments"]), _np(c["increments"]), rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("weights", ["tile_scaled", "global_max"])
+def test_collapsed_weights_one_launch_equals_step_by_step(K_, weights):
+    """A very informative observation (r = 0.02): almost every tile is dead, the few live particles lie far apart, a
+    block's source tiles are a long range of mostly empty tiles.  The one-launch filter still equals the host-driven
+    loop bit for bit (and does not crawl through the empty tiles round by round)."""
+    import time
+    import torch
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem(T=10)
+    for K in (1 << 16, (1 << 18) - 3):
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], 0.02), K, weights=weights)
+        a = bf.run(core.key(11), s["y"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a = bf.run(core.key(11), s["y"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        b = bf.run(core.key(11), s["y"], step_by_step=True)
+        lw = _np(a["logw"])
+        assert np.isfinite(lw).all() and (lw.max() - np.median(lw)) > 200.0          # collapsed indeed
+        np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+        np.testing.assert_array_equal(lw, _np(b["logw"]))
+        np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-5)
+        assert dt < 0.02, dt                                                        # 10 steps: well under a millisecond each
+
+
 def test_tiled_filter_close_to_global_max_filter(K_):
     """Same comb, same streams: the two weight schemes pick the same ancestor except where a threshold falls within the
     quantisation step of a particle boundary — after one resampling almost all particles agree bit for bit."""
