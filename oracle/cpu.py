@@ -242,12 +242,20 @@ def score_grad(prog: PackedProgram, choices):
 
 
 def hmc(prog: PackedProgram, key, choices, eps, L, stale=False, accept=False, offset=0):
+    """-> dict(choices, score, alpha, accepted, margin): margin[i] = |log u - alpha| of chain i's accept decision (with
+    ``accept``; 3e38 otherwise) — a device chain may take the other branch only where this is below the tolerance to
+    which its alpha matches the oracle's"""
     ch = np.ascontiguousarray(choices, np.float32).copy()
     n = ch.shape[1]
     score = np.zeros(n, np.float32)
     alpha = np.zeros(n, np.float32)
     acc = np.zeros(n, np.float32)
+    margin = np.full(n, 3.0e38, np.float32)
     cp = prog.c_program(None)
-    lib().gjxo_hmc(C.byref(cp), key[0], key[1], n, int(offset), float(eps), int(L), int(stale), int(accept),
-                   _p(ch), _p(score), _p(alpha), _p(acc))
-    return dict(choices=ch, score=score, alpha=alpha, accepted=acc)
+    lib().gjxo_set_margin_buffer(_p(margin), n)
+    try:
+        lib().gjxo_hmc(C.byref(cp), key[0], key[1], n, int(offset), float(eps), int(L), int(stale), int(accept),
+                       _p(ch), _p(score), _p(alpha), _p(acc))
+    finally:
+        lib().gjxo_set_margin_buffer(None, 0)
+    return dict(choices=ch, score=score, alpha=alpha, accepted=acc, margin=margin)

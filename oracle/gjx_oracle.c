@@ -1283,6 +1283,9 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
                                                            : stream_open(GJX_RNG_FLAT, key, gidx, GJX_FLAT_MAX_SITES);
         float lu = logf(bits_to_unit(elem_bits(&as, 0u)));
         acc = lu < al; /* tests/inference/test_requests.py:134-137 */
+        /* decision margin of the accept (gjxo_set_margin_buffer): |log u - alpha|, absolute — alpha is a difference of
+         * scores that the device's trajectory reproduces to an absolute tolerance, not a relative one */
+        if (g_margin_buf && i < g_margin_n) g_margin_buf[i] = fabsf(lu - al);
       }
       if (!acc) { for (int s = 0; s < ns; ++s) vals[s] = old[s]; sc = score0; }
       for (int s = 0; s < ns; ++s) choices[(int64_t)s * n + i] = vals[s];
