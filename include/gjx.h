@@ -438,7 +438,8 @@ int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rn
                       float* x_out, float* m_out, float* logw, float* accepted, float* lse, int64_t K_total,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* The whole T-step bootstrap filter on ONE GPU, looped in C++ (2 launches per step, no host round trip):
+/* The whole T-step bootstrap filter on ONE GPU: step 0, then steps 1 .. T-1 in ONE launch when the grid of K / 1024 blocks
+ * is co-resident (otherwise one or two launches per step, looped in C++; no host round trip either way):
  * step keys k_t = fold_in(k_{t-1}, t), (k_prop, k_res) = split(k_t), systematic resampling before every
  * propagate step with comb offset uniform(k_res) — identical to issuing the per-step calls from the host.
  *   ys_dev f32[T][dy]; x_a, x_b f32[dx][K] (step t writes x_a for even t, x_b for odd t); logw f32[K];
