@@ -37,7 +37,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 3
+#define GJX_ABI_VERSION 4
 
 typedef enum gjx_status {
   GJX_OK = 0,
