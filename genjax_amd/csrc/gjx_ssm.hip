@@ -619,10 +619,9 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     float bm;
     {
       const float wm = wave_max_dpp(active ? lw_own : -INFINITY);
+      if (lane == 0) fred[wid] = wm;     // (fred[0..NW) was last read at least two barriers ago)
       __syncthreads();
       GJX_PSTAMP(7);         // every wave of the block has finished the previous step
-      if (lane == 0) fred[wid] = wm;
-      __syncthreads();
       bm = fred[0];
 #pragma unroll
       for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
@@ -794,22 +793,20 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       if (t >= 2 && (int)blockIdx.x == (t - 2) % nb && threadIdx.x == 0) lse_ring_write(t - 2);
       GJX_PSTAMP(3);
     }
-    {
-      const int per = (nb + THREADS - 1) / THREADS;
-      const int e0 = threadIdx.x * per < nb ? threadIdx.x * per : nb, e1 = (e0 + per) < nb ? (e0 + per) : nb;
+    if (wid == 0) {
+      // prefix of the (shifted) tile totals by ONE wave — ceil(nb / 64) entries per lane, one DPP scan — instead of four
+      // waves and a barrier between their partial sums
+      const int per = (nb + 63) >> 6;
+      const int e0 = lane * per < nb ? lane * per : nb, e1 = (e0 + per) < nb ? (e0 + per) : nb;
       uint64_t loc = 0;
       for (int e = e0; e < e1; ++e) {
         if constexpr (TILED) { const int sh = Emax - Eb[e]; P[e + 1] = sh < 64 ? P[e + 1] >> sh : 0; }
         loc += P[e + 1];
       }
-      const uint64_t inc = wave_scan_u64(loc);
-      if (lane == 63) wsum[wid] = inc;   // (wsum was last read by thread 0 before its publish, at least one barrier ago)
-      __syncthreads();
-      uint64_t run = inc - loc;
-      for (int w = 0; w < wid; ++w) run += wsum[w];
+      uint64_t run = wave_scan_u64(loc) - loc;
       for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
-      __syncthreads();
     }
+    __syncthreads();
     const uint64_t total = P[nb];
     GJX_PSTAMP(4);
     if constexpr (!TILED) {
