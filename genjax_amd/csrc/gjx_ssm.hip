@@ -848,10 +848,23 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       // the range between its first and its last slot's tile: no list to build, the two ends travel through LDS behind
       // the one barrier the `ready` check needs anyway
       uint64_t Tj = comb_threshold(active ? j : K - 1, sU, step, total);
-      int tile = 0;
-      for (int sft = 1 << (31 - __builtin_clz((unsigned)nb)); sft >= 1; sft >>= 1) {
-        const int p = tile + sft;                                       // P[p] = inclusive prefix of tile p - 1
-        if (p <= nb - 1 && P[p] <= Tj) tile = p;
+      // A block's slots draw from tiles near its own index (equal tile totals would make it exactly its own): the nine
+      // boundaries of the eight tiles around blockIdx.x are read together (one LDS latency, same addresses in every lane)
+      // and the tile is counted off; a threshold outside that window takes the fixed-trip descent (nine dependent reads)
+      const int wlo = (int)blockIdx.x - 4 < 0 ? 0 : ((int)blockIdx.x - 4 > nb - 8 ? (nb - 8 < 0 ? 0 : nb - 8) : (int)blockIdx.x - 4);
+      uint64_t Pw[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Pw[k] = P[wlo + k < nb ? wlo + k : nb];
+      int tile = wlo;
+      if (Tj >= Pw[0] && Tj < Pw[8]) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tile += Pw[k] <= Tj ? 1 : 0;
+      } else {
+        tile = 0;
+        for (int sft = 1 << (31 - __builtin_clz((unsigned)nb)); sft >= 1; sft >>= 1) {
+          const int p = tile + sft;                                     // P[p] = inclusive prefix of tile p - 1
+          if (p <= nb - 1 && P[p] <= Tj) tile = p;
+        }
       }
       if (threadIdx.x == 0) s_range[0] = tile;
       if (threadIdx.x == THREADS - 1) s_range[1] = tile;                // (inactive lanes searched slot K - 1)
@@ -907,10 +920,13 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         if (c0 == 0) GJX_PSTAMP(11);
         if (kpos >= c0 && kpos < c0 + kChunk) {
           const uint64_t* cm = cumL + (kpos - c0) * THREADS;
-          int l2 = 0, h2 = THREADS - 1;
-          while (l2 < h2) {
-            const int mid = (l2 + h2) >> 1;
-            if (cm[mid] > Tj) h2 = mid; else l2 = mid + 1;
+          // first particle whose cumulative weight exceeds the threshold = number of entries <= it: a 4-ary descent, three
+          // independent probes per level (5 LDS latencies for 1024 entries instead of 10)
+          int l2 = 0;
+#pragma unroll
+          for (int q = THREADS >> 2; q >= 1; q >>= 2) {
+            const uint64_t pa = cm[l2 + q - 1], pb = cm[l2 + 2 * q - 1], pc = cm[l2 + 3 * q - 1];
+            l2 += (pa <= Tj ? q : 0) + (pb <= Tj ? q : 0) + (pc <= Tj ? q : 0);
           }
           src = (int64_t)tile * THREADS + l2;
         }
