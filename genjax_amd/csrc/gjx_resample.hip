@@ -373,13 +373,30 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
         if (k1 != k0 && pb <= nb - 1 && P[pb] <= T[k1]) tile[k1] = pb;
       }
     };
-    descend(0, ITEMS - 1);
-    if (ITEMS > 2) {
-      if (tile[0] == tile[ITEMS - 1]) {
+    // A block's slots draw from tiles near its own index (equal tile totals would make it exactly its own): the nine
+    // boundaries of the eight tiles around blockIdx.x are read together (one LDS latency, the same addresses in every
+    // lane) and the tile of each slot is counted off; only a lane with a threshold outside that window descends
+    const int wlo = (int)blockIdx.x - 4 < 0 ? 0 : ((int)blockIdx.x - 4 > nb - 8 ? (nb - 8 < 0 ? 0 : nb - 8) : (int)blockIdx.x - 4);
+    uint64_t Pw[9];
 #pragma unroll
-        for (int k = 1; k < ITEMS - 1; ++k) tile[k] = tile[0];
-      } else {
-        descend(1, ITEMS > 3 ? 2 : 1);
+    for (int k = 0; k < 9; ++k) Pw[k] = P[wlo + k < nb ? wlo + k : nb];
+    if (T[0] >= Pw[0] && T[ITEMS - 1] < Pw[8]) {            // thresholds are non-decreasing in the slot index
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        int tl = wlo;
+#pragma unroll
+        for (int w = 1; w < 8; ++w) tl += Pw[w] <= T[k] ? 1 : 0;
+        tile[k] = tl;
+      }
+    } else {
+      descend(0, ITEMS - 1);
+      if (ITEMS > 2) {
+        if (tile[0] == tile[ITEMS - 1]) {
+#pragma unroll
+          for (int k = 1; k < ITEMS - 1; ++k) tile[k] = tile[0];
+        } else {
+          descend(1, ITEMS > 3 ? 2 : 1);
+        }
       }
     }
     if (timeline) { asm volatile("" :: "v"(tile[0]), "v"(tile[ITEMS - 1])); GJX_STAMP(7); }
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
         for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
       }
       __syncthreads();
-      // first particle p of the slot's tile with cum_incl(p) > T: the same fixed-trip descent
+      // first particle p of the slot's tile with cum_incl(p) > T
       int pos[ITEMS];
       const uint64_t* cm[ITEMS];
       bool mine[ITEMS];
@@ -440,11 +457,14 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
         cm[k] = cumL + (mine[k] ? (kpos[k] - idx) * TILE : 0);
         pos[k] = 0;
       }
+      // (number of entries <= T, 4-ary: three independent probes per level and slot, 5 LDS latencies for 1024 entries)
 #pragma unroll
-      for (int sft = TILE >> 1; sft >= 1; sft >>= 1) {
+      for (int q = TILE >> 2; q >= 1; q >>= 2) {
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k)
-          if (cm[k][pos[k] + sft - 1] <= T[k]) pos[k] += sft;
+        for (int k = 0; k < ITEMS; ++k) {
+          const uint64_t pa = cm[k][pos[k] + q - 1], pb = cm[k][pos[k] + 2 * q - 1], pc = cm[k][pos[k] + 3 * q - 1];
+          pos[k] += (pa <= T[k] ? q : 0) + (pb <= T[k] ? q : 0) + (pc <= T[k] ? q : 0);
+        }
       }
 #pragma unroll
       for (int k = 0; k < ITEMS; ++k)
