@@ -495,7 +495,7 @@ def run_api(dev, K, steps=100):
     def step(k):
         pc = alg.run_smc(k)
         tr = pc.get_particles()
-        rows, anc = resample(tr.choices, pc.get_log_weights(), k, lse=pc.lse())
+        rows, anc = resample(tr.choices, pc.get_log_weights(), k, collection=pc)
         return pc, rows
 
     for k in keys[:10]:

@@ -24,25 +24,37 @@ def _unit_from_key(k: Key) -> float:
 
 
 def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None,
-             check: bool = False):
+             check: bool = False, collection=None):
     """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N]).
     check=True reads the status word of the co-resident kernel afterwards (one stream synchronisation): raises GjxError
-    on a time-out (grid not co-resident: results undefined) or a dead collection (all weights zero)."""
+    on a time-out (grid not co-resident: results undefined) or a dead collection (all weights zero).
+    ``collection``: the ParticleCollection the weights come from — if its producing run's block partials are still in
+    place, the resampling kernel reduces them in its prologue and hands the finished LSE record back to the collection
+    (no separate LSE launch anywhere on the path)."""
     from .. import kernels
     K = logw.numel()
     N = int(n_out or K)
-    if lse is None:
-        lse = kernels.logsumexp(logw, ws=kernels.shared_workspace(A.OP_LSE, K, logw.device))
+    part = collection.lse_partials() if (collection is not None and lse is None and method == "systematic") else None
+    lse_out = None
+    if part is not None and collection.K_total == K:
+        lse_out = torch.empty(4, dtype=torch.float32, device=logw.device)
+    else:
+        part = None
+        if lse is None:
+            lse = collection.lse() if collection is not None else kernels.logsumexp(logw, ws=kernels.shared_workspace(A.OP_LSE, K, logw.device))
     if method == "systematic":
         ws = kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device)
+        pa = None if part is None else part.as_arg()
         if N == K and rows.stride(1) == 1:
             # weights -> ancestors -> children in one launch (falls back to two beyond the co-resident grid)
             anc = torch.empty(K, dtype=torch.int32, device=logw.device)
-            out = kernels.resample_gather(logw, _unit_from_key(key), rows, True, lse, anc=anc, ws=ws)
+            out = kernels.resample_gather(logw, _unit_from_key(key), rows, True, lse, partials=pa, lse_out=lse_out, K_total=K, anc=anc, ws=ws)
         else:
             # weights -> ancestors in one launch, then the slot-oriented row copy
-            anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, ws=ws)
+            anc = kernels.resample_indices(logw, _unit_from_key(key), N, True, lse, partials=pa, lse_out=lse_out, K_total=K, ws=ws)
             out = kernels.gather_rows(rows, anc)
+        if lse_out is not None:
+            collection._lse = lse_out
         if check:
             kernels.workspace_status(ws)
         return out, anc

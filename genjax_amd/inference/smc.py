@@ -55,9 +55,10 @@ class Target:
 class ParticleCollection:
     """Weighted particles (smc.py:76-109): a batched Trace + log-weights, all on the device."""
 
-    def __init__(self, particles: Trace, log_weights, is_valid=True, lse=None, offset: int = 0, K_total=None):
+    def __init__(self, particles: Trace, log_weights, is_valid=True, lse=None, offset: int = 0, K_total=None, partials=None):
         self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
         self._lse = lse            # device f32[4] = {max, sumexp, lse, lse - log K} when already reduced
+        self._partials = partials  # kernels.RunPartials of the producing run (block {max, sumexp} pairs), or None
         self.offset = offset
         self.K_total = K_total or int(log_weights.shape[0])
 
@@ -77,10 +78,21 @@ class ParticleCollection:
         return self.get_particle(idx), self.log_weights[idx]
 
     def lse(self):
+        """The LSE record, reduced on first use: from the producing run's block partials while they are still in its
+        workspace (one small launch), otherwise from the log-weights."""
         if self._lse is None:
             from .. import kernels
-            self._lse = kernels.logsumexp(self.log_weights, self.K_total)
+            p = self._partials
+            if p is not None and p.valid():
+                self._lse = p.finish(self.K_total)
+            else:
+                self._lse = kernels.logsumexp(self.log_weights, self.K_total)
         return self._lse
+
+    def lse_partials(self):
+        """kernels.RunPartials of the producing run if still valid (for ``inference.pf.resample(..., collection=)``)"""
+        p = self._partials
+        return p if (self._lse is None and p is not None and p.valid()) else None
 
     def get_log_marginal_likelihood_estimate(self):
         """logsumexp(log_weights) - log K  (smc.py:96-97), a 0-d device tensor."""
@@ -185,9 +197,11 @@ class ImportanceK(SMCAlgorithm):
                                          prev_rows=rows, sub=log_q, want_lse=True, offset=offset,
                                          K_total=self.k_particles)
         else:
+            # no LSE tail in the producing kernel: its block partials stay in the workspace and are reduced by whoever
+            # needs the record first (the resampler's prologue, or one small launch)
             tr, out = self.target.p._run(sub_key, K, self.target.args, self.target.constraint, True, True,
-                                         want_lse=True, offset=offset, K_total=self.k_particles)
-        return ParticleCollection(tr, out["logw"], True, out["lse"], offset, self.k_particles)
+                                         want_lse=False, offset=offset, K_total=self.k_particles)
+        return ParticleCollection(tr, out["logw"], True, out["lse"], offset, self.k_particles, partials=out.get("_partials"))
 
     def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
         """K-1 fresh particles plus the retained choice map stacked last (smc.py:317-351)."""

@@ -116,6 +116,34 @@ def program_precompile(prog: PackedProgram, ppt: int) -> None:
     check(load().gjx_program_precompile(C.byref(cp), int(ppt)), "gjx_program_precompile")
 
 
+class RunPartials:
+    """The per-block {max, sumexp} pairs a run with ``want_lse=False`` left in its workspace: the consumers that can
+    reduce them in their own prologue (resample_gather / resample_indices, ``partials=``) save the producer's serial
+    LSE tail.  Valid only until the same workspace is used by another run."""
+
+    def __init__(self, ws, gen, prog, K, offset):
+        self.ws, self.gen, self.prog, self.K, self.offset = ws, gen, prog, K, offset
+        self._n = None
+
+    def valid(self) -> bool:
+        return getattr(self.ws, "_gjx_gen", None) == self.gen
+
+    def count(self) -> int:
+        if self._n is None:
+            self._n = run_partials_count(self.prog, self.K, self.offset, self.ws.device)
+        return self._n
+
+    def as_arg(self):
+        """(workspace, n) for the ``partials=`` argument of the resampling wrappers"""
+        return (self.ws, self.count())
+
+    def finish(self, K_total) -> torch.Tensor:
+        """-> the finished LSE record f32[4] (one small launch over the pairs)"""
+        n = self.count()
+        pairs = self.ws[256:256 + 8 * n].view(torch.float32)
+        return lse_combine(pairs, K_total)
+
+
 def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
                 want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None,
                 want_weight=True):
@@ -140,7 +168,12 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
                                 _ptr(logw), _ptr(logw_in), _ptr(sub), _ptr(ss), _ptr(lse), int(K_total or K),
                                 _ptr(ws), ws.numel(), _stream())
     check(rc, "gjx_run_program")
+    # generation stamp of the workspace: with lse == None the kernel leaves per-block {max, sumexp} partials at ws + 256,
+    # valid until the next run through the same workspace (RunPartials.valid)
+    ws._gjx_gen = getattr(ws, "_gjx_gen", 0) + 1
     res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws)
+    if lse is None:
+        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset))
     if ss is not None:
         res["site_scores"] = ss
     return res

@@ -28,6 +28,42 @@ def rng_mode(request):
 
 
 class TestSMC:
+    def test_lazy_lse_record(self):
+        """run_smc leaves no LSE tail in the producing kernel: the record comes from the run's block partials while they
+        are in its workspace (one small launch, or the resampler's prologue), from the log-weights afterwards."""
+        import torch
+        from genjax_amd import kernels
+        from genjax_amd.inference.pf import resample
+
+        @genjax.gen
+        def model():
+            z = genjax.categorical(np.array([0.2, -0.4, 0.9], np.float32)) @ "z"
+            x = genjax.normal(genjax.const(np.array([-1.0, 0.5, 2.0], np.float32))[z], 1.5) @ "x"
+            genjax.normal(x, 0.7) @ "y"
+
+        alg = ImportanceK(Target(model, (), C["y"].set(0.3)), k_particles=300_000)
+        pc = alg.run_smc(genjax.key(3))
+        assert pc.lse_partials() is not None
+        ref = kernels.logsumexp(pc.get_log_weights(), pc.K_total).cpu().numpy()
+        # (a) through the resampler's prologue: same children as with an explicit record, and the record handed back
+        rows_a, anc_a = resample(pc.get_particles().choices, pc.get_log_weights(), genjax.key(9), collection=pc)
+        assert pc.lse_partials() is None and pc._lse is not None
+        np.testing.assert_allclose(pc.lse().cpu().numpy(), ref, rtol=2e-6)
+        assert float(pc.lse()[0]) == float(ref[0])
+        rows_b, anc_b = resample(pc.get_particles().choices, pc.get_log_weights(), genjax.key(9), lse=torch.as_tensor(ref).cuda())
+        assert torch.equal(anc_a, anc_b) and torch.equal(rows_a, rows_b)
+        # (b) on demand from the partials
+        pc2 = alg.run_smc(genjax.key(4))
+        ref2 = kernels.logsumexp(pc2.get_log_weights(), pc2.K_total).cpu().numpy()
+        np.testing.assert_allclose(pc2.lse().cpu().numpy(), ref2, rtol=2e-6)
+        # (c) a later run through the same workspace invalidates an older collection's partials: it falls back to its weights
+        pc3 = alg.run_smc(genjax.key(5))
+        pc4 = alg.run_smc(genjax.key(6))
+        assert pc3.lse_partials() is None and pc4.lse_partials() is not None
+        ref3 = kernels.logsumexp(pc3.get_log_weights(), pc3.K_total).cpu().numpy()
+        np.testing.assert_allclose(pc3.lse().cpu().numpy(), ref3, rtol=2e-6)
+        assert f(pc3.get_log_marginal_likelihood_estimate()) == pytest.approx(float(ref3[3]), rel=1e-6)
+
     def test_exact_flip_flip_trivial(self):
         """reference tests/inference/test_smc.py:32-57"""
         @genjax.gen
