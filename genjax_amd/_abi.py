@@ -81,6 +81,7 @@ PP = C.POINTER(GjxProgram)
 # name -> (restype, argtypes) for every symbol include/gjx.h declares
 PROTOTYPES = {
     "gjx_version": (C.c_int, []),
+    "gjx_host_threefry2x32": (C.c_uint64, [u32, u32, u32, u32]),
     "gjx_last_error": (C.c_char_p, []),
     "gjx_program_engine": (C.c_int, [PP]),
     "gjx_program_source": (i64, [PP, i32, C.c_char_p, i64]),

@@ -58,6 +58,21 @@ extern "C" int gjx_workspace_status(void* workspace, int32_t* status_host, void*
 }
 
 extern "C" int gjx_version(void) { return GJX_ABI_VERSION; }
+
+// Threefry-2x32-20 on the HOST: the scalar key operations of the drivers (split / fold_in of the run key, smc.py:154,299;
+// the comb offset of a resampling) — a few per step, but 3-4 us each in Python, which made the API-level step host-bound.
+extern "C" uint64_t gjx_host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1) {
+  static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    const int* r = (g & 1) ? R + 4 : R;
+    for (int j = 0; j < 4; ++j) { x0 += x1; x1 = (x1 << r[j]) | (x1 >> (32 - r[j])); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  return ((uint64_t)x0 << 32) | x1;
+}
 extern "C" const char* gjx_last_error(void) { return g_err; }
 
 // One bound for every op: 16 bytes per 64 particles (block partials: {max,sum} floats, u64 block

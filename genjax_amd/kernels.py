@@ -19,8 +19,19 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_handle(device_index=None) -> int:
+    """torch's current HIP stream of the device as a raw handle (the C-level query when torch has it: building a
+    torch.cuda.Stream object per kernel call was a fifth of the API step's host time)"""
+    if _raw_stream is not None:
+        return int(_raw_stream(torch.cuda.current_device() if device_index is None else device_index))
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_handle())
 
 
 def _dev(device=None):
@@ -36,11 +47,11 @@ _shared_ws: dict = {}
 
 
 def shared_workspace(op: int, K: int, device=None) -> torch.Tensor:
-    """A zero-initialised workspace kept per (size, device, stream) for callers that hand nothing of it on (every entry
+    """A zero-initialised workspace kept per (op, size, device, stream) for callers that hand nothing of it on (every entry
     point leaves the control block zeroed, so one allocation + one memset serves all later calls on that stream)."""
     dev = _dev(device)
     n = load().gjx_workspace_bytes(op, int(K))
-    k = (n, dev, torch.cuda.current_stream(dev).cuda_stream)
+    k = (int(op), n, dev, _stream_handle(dev.index))   # per op: a run's block partials must survive the resampler's granules
     ws = _shared_ws.get(k)
     if ws is None:
         if len(_shared_ws) >= 16:

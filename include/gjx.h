@@ -180,6 +180,10 @@ typedef struct gjx_program {
 
 /* ---- library ---------------------------------------------------------------------------- */
 int gjx_version(void);
+/* Threefry-2x32-20 of one counter on the HOST (no device work): (x0 << 32) | x1.  jax.random.fold_in(k, i) ==
+ * split(k, n)[i] == gjx_host_threefry2x32(k0, k1, i >> 32, i) (jax/_src/prng.py, jax_threefry_partitionable=True) — the
+ * scalar key operations of the inference drivers (smc.py:154,299; scan.py:268). */
+uint64_t gjx_host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1);
 const char* gjx_last_error(void);
 /* which engine a program will run on: 0 = generic site interpreter, >0 = id of a fused kernel */
 int gjx_program_engine(const gjx_program* prog);
