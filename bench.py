@@ -556,6 +556,27 @@ def run_codegen(dev):
     bb = PackedProgram(sl, {"v": A.MODE_OBS_TAB}, {"v": np.float32(1.0)})
     res["beta_bernoulli"] = dict(timed(bb, "auto"), log_ml_exact=math.log(0.5),
                                  bound="VALU: two Marsaglia-Tsang log-gamma variates per particle for 12 B of output")
+    # two programs no hand-written kernel or matcher knows, HBM-shaped like the headline model (cheap samplers, 16 stored
+    # scalars per particle): a conjugate normal-normal model and an observed random-walk chain (every site depends on the
+    # previous one); exact log-ML of both from the Gaussian marginal
+    g = workloads.gmm_problem(C=C, D=D)
+    sl = SiteList()
+    sl.add("x", A.MVNORMAL_DIAG, [Param.const(np.zeros(D, np.float32)), Param.const(np.full(D, 1.5, np.float32))], dim=D)
+    sl.add("y", A.MVNORMAL_DIAG, [Param.value("x", D), Param.const(g["r"])], dim=D)
+    nn = PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": g["y"]})
+    var = 1.5 ** 2 + np.asarray(g["r"], np.float64) ** 2
+    nn_exact = float(np.sum(-0.5 * np.asarray(g["y"], np.float64) ** 2 / var - 0.5 * np.log(2 * np.pi * var)))
+    res["normal_normal_d16"] = dict(timed(nn, "auto"), log_ml_exact=nn_exact)
+    T = 16
+    ys = (np.cumsum(np.random.default_rng(3).standard_normal(T)) * 0.7).astype(np.float32)
+    sl = SiteList()
+    for t in range(T):
+        sl.add(f"x{t}", A.NORMAL, [Param.const(0.0) if t == 0 else Param.value(f"x{t - 1}", 1), Param.const(1.0)])
+        sl.add(f"y{t}", A.NORMAL, [Param.value(f"x{t}", 1), Param.const(2.0)])
+    rw = PackedProgram(sl, {f"y{t}": A.MODE_OBS_TAB for t in range(T)}, {f"y{t}": ys[t] for t in range(T)})
+    cov = np.minimum.outer(np.arange(1, T + 1), np.arange(1, T + 1)).astype(np.float64) + 4.0 * np.eye(T)
+    rw_exact = float(-0.5 * ys.astype(np.float64) @ np.linalg.solve(cov, ys.astype(np.float64)) - 0.5 * np.linalg.slogdet(2 * np.pi * cov)[1])
+    res["random_walk_T16"] = dict(timed(rw, "auto"), log_ml_exact=rw_exact)
     lr, _ = workloads.logreg_importance_program(N=1024, P=16)
     r = timed(lr, "auto")
     r["flops"] = K * (2 * 1024 * 16 + 10 * 1024)
