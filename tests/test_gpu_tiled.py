@@ -108,6 +108,22 @@ def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
 
 
 @pytest.mark.parametrize("weights", ["tile_scaled", "global_max"])
+def test_one_launch_filter_tiny_and_ragged_sizes(K_, weights):
+    """One particle, one wave, one tile, one particle past a tile; two-step and three-step filters: the one-launch filter
+    still equals the host-driven loop bit for bit."""
+    import torch
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    for T in (2, 3, 7):
+        s = cf.ssm_problem(T=T)
+        for K in (1, 2, 63, 64, 65, 1023, 1024, 1025, 2049, 4097):
+            bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights=weights)
+            a = bf.run(core.key(3), s["y"])
+            b = bf.run(core.key(3), s["y"], step_by_step=True)
+            assert torch.equal(a["x"], b["x"]) and torch.equal(a["logw"], b["logw"]), (T, K)
+            np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("weights", ["tile_scaled", "global_max"])
 @pytest.mark.parametrize("dx,dy", [(2, 2), (4, 3), (8, 5), (16, 16), (16, 7)])
 def test_one_launch_filter_other_shapes(K_, weights, dx, dy):
     """State dimensions 2 .. 16, with and without an observation matrix H (dy != dx): the one-launch filter (model
