@@ -671,13 +671,12 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         const uint64_t qv = (active && t < T) ? weight_q(xv, 0, 1, mx) : 0;
         const uint64_t wt = wave_total_u64(qv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) wsum[wid] = wt;     // (wsum was last read in the previous step's re-scan, barriers ago)
         __syncthreads();
-        if (lane == 0) wsum[wid] = wt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          uint64_t tt = 0;
-          for (int w = 0; w < NW; ++w) tt += wsum[w];
-          grid_publish(f.aggB, tagB, tt);
+        if (wid == 0) {
+          static_assert(NW <= 16, "the wave partials fit one DPP row");
+          const uint64_t tt = row_scan_u64(lane < NW ? wsum[lane] : 0);   // lane 15 = sum of lanes 0..15
+          if (lane == 15) __hip_atomic_store(&f.aggB[blockIdx.x], (tagB << 50) | (tt & kAggMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       GJX_PSTAMP(3);
