@@ -571,6 +571,30 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     const float ws = wave_sum_dpp(wm > -INFINITY ? sm * fast_exp(m - wm) : 0.0f);
     if (lane == 0) { lse_pm[wid] = wm; lse_ps[wid] = ws; }
   };
+  // the same in two halves around other work: the loads go out (fixed trip count: they stay in flight, in registers) ...
+  auto lse_ring_issue = [&](int s, float (&rpm)[kPer], float (&rps)[kPer]) {
+    const float* rm = f.bmax + (size_t)(s % 3) * nb;
+    const float* rs = f.bsum + (size_t)(s % 3) * nb;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int b = (threadIdx.x + THREADS / 2) % THREADS + k * THREADS;     // the non-polling half of the block first
+      rpm[k] = b < nb ? load_agent(rm + b) : -INFINITY;
+      rps[k] = b < nb ? load_agent(rs + b) : 0.0f;
+    }
+  };
+  // ... and are reduced to per-wave partials in LDS (block-uniform call: every wave takes part)
+  auto lse_ring_reduce = [&](const float (&rpm)[kPer], const float (&rps)[kPer]) {
+    float m = -INFINITY, sm = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const float nm = fmaxf(m, rpm[k]);
+      if (nm > -INFINITY) sm = sm * fast_exp(m - nm) + rps[k] * fast_exp(rpm[k] - nm);
+      m = nm;
+    }
+    const float wm = wave_max_dpp(m);
+    const float wsm = wave_sum_dpp(wm > -INFINITY ? sm * fast_exp(m - wm) : 0.0f);
+    if (lane == 0) { lse_pm[wid] = wm; lse_ps[wid] = wsm; }
+  };
   auto lse_ring_write = [&](int s) {             // thread 0, after a barrier behind lse_ring_partials(s)
     float m = lse_pm[0];
     for (int w = 1; w < NW; ++w) m = fmaxf(m, lse_pm[w]);
@@ -596,7 +620,6 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     GJX_PSTAMP(0);
     SsmNoiseBits<RNG, DX> nbits;
     float mx = -INFINITY;
-    float pm[kPer];
     int eb = kTileDead, Emax = kTileDead;
     unsigned rdy[kPer];
     const unsigned rtag = epoch + (unsigned)t;                // `ready` word of this step: never repeats, the epoch advances by 2 T per launch
@@ -642,17 +665,21 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         if (threadIdx.x == 0) {
           float bs = 0.0f;
           for (int w = 0; w < NW; ++w) bs += fred[NW + w];
-          store_agent(&f.bsum[(size_t)(t & 1) * nb + blockIdx.x], bs);
+          const size_t slot = (size_t)((t - 1) % 3) * nb + blockIdx.x;   // ring over steps (complete before granule B goes out)
+          store_agent(&f.bsum[slot], bs);
+          store_agent(&f.bmax[slot], bm);
         }
       }
       stage_step_constants(t);
+      // the record of step t-2, if this block is its finisher, off the critical path: ring loads out before the hashes,
+      // reduced behind them, written by thread 0 behind the next barrier (every block's entry of step t-2 was complete
+      // before its granule B of step t-1, which this block has gathered)
+      const bool fin = t >= 2 && (int)blockIdx.x == (t - 2) % nb;
+      float rpm[kPer], rps[kPer];
+      if (fin) lse_ring_issue(t - 2, rpm, rps);
       if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
-      int np = 0;
-      grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) {
-        const float m = __uint_as_float((uint32_t)v);
-        pm[np++] = m;
-        mx = fmaxf(mx, m);
-      });
+      if (fin) lse_ring_reduce(rpm, rps);
+      grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) { mx = fmaxf(mx, __uint_as_float((uint32_t)v)); });
       mx = wave_max_dpp(mx);     // (no acquire fence: everything read from other blocks goes through agent-scope loads)
       __syncthreads();
       if (lane == 0) fred[wid] = mx;
@@ -660,6 +687,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       mx = fred[0];
 #pragma unroll
       for (int w = 1; w < NW; ++w) mx = fmaxf(mx, fred[w]);
+      if (fin && threadIdx.x == 0) lse_ring_write(t - 2);
       GJX_PSTAMP(2);
       // ---- rendezvous B: tile totals of the fixed-point weights.  The granule goes out only after this lane's
       //      write-through (sc1) stores of step t-1 — x, log w, the block sum — have completed; readers use sc1 loads: no
@@ -714,16 +742,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       // this block checked in step t-1; the loads go out here and are consumed behind the draws
       const bool fin = t >= 2 && (int)blockIdx.x == (t - 2) % nb;
       float rpm[kPer], rps[kPer];
-      if (fin) {
-        const float* rm = f.bmax + (size_t)((t - 2) % 3) * nb;
-        const float* rs = f.bsum + (size_t)((t - 2) % 3) * nb;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-          const int b = (threadIdx.x + THREADS / 2) % THREADS + k * THREADS;     // the non-polling half of the block first
-          rpm[k] = b < nb ? load_agent(rm + b) : -INFINITY;
-          rps[k] = b < nb ? load_agent(rs + b) : 0.0f;
-        }
-      }
+      if (fin) lse_ring_issue(t - 2, rpm, rps);
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(&f.ready[blockIdx.x], rtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       stage_step_constants(t);
@@ -739,18 +758,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       // while the granules travel: the draws of step t.  (Looking at the missing granules again between the hashes was
       // measured and dropped: the polling waves then stall inside the draws, 13.5 -> 14.1 us per step.)
       if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
-      if (fin) {
-        float m = -INFINITY, sm = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-          const float nm = fmaxf(m, rpm[k]);
-          if (nm > -INFINITY) sm = sm * fast_exp(m - nm) + rps[k] * fast_exp(rpm[k] - nm);
-          m = nm;
-        }
-        const float wm = wave_max_dpp(m);
-        const float wsm = wave_sum_dpp(wm > -INFINITY ? sm * fast_exp(m - wm) : 0.0f);
-        if (lane == 0) { lse_pm[wid] = wm; lse_ps[wid] = wsm; }
-      }
+      if (fin) lse_ring_reduce(rpm, rps);
       GJX_PSTAMP(2);
       {
         unsigned budget = 1u << 22;
@@ -809,22 +817,10 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     const uint64_t total = P[nb];
     GJX_PSTAMP(4);
     if constexpr (!TILED) {
-      if ((int)blockIdx.x == (t - 1) % nb) {                        // block-uniform: finish the LSE record of step t-1
-        float sacc = 0.0f;
-        int k = 0;
-        const float* rs = f.bsum + (size_t)(t & 1) * nb;
-        for (int b = threadIdx.x; b < nb; b += THREADS, ++k) sacc += mx > -INFINITY ? load_agent(&rs[b]) * fast_exp(pm[k] - mx) : 0.0f;
-        sacc = wave_sum_dpp(sacc);
+      if (t == T && (int)blockIdx.x == (T - 1) % nb) {             // the last record: its ring entries preceded granule B of this step
+        lse_ring_partials(T - 1);
         __syncthreads();
-        if (lane == 0) fred[NW + wid] = sacc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          float se = 0.0f;
-          for (int w = 0; w < NW; ++w) se += fred[NW + w];
-          const float l = mx > -INFINITY ? mx + logf(se) : -INFINITY;
-          float* rec = f.lse_steps + 4 * (size_t)(t - 1);
-          rec[0] = mx; rec[1] = se; rec[2] = l; rec[3] = l - f.log_k;
-        }
+        if (threadIdx.x == 0) lse_ring_write(T - 1);
       }
     } else if (t == T) {                                            // the last record, once every block's ring entry is complete
       check_ready();
