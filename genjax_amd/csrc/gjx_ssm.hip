@@ -8,6 +8,9 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 #include "gjx_scan.h"
+#include "gjx_tile.h"
+#include "gjx_pfilter_host.h"
+#include <string.h>
 #include <vector>
 
 namespace gjx {
@@ -205,7 +208,6 @@ struct SsmFusedArgs {
 };
 
 constexpr int kSsmFusedMaxTiles = 2048;
-constexpr int kSsmPersistMaxDy = 32;              // observation dimension the one-launch filter stages in LDS
 
 template <int RNG, int DX>
 __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
@@ -443,84 +445,6 @@ struct SsmPersistArgs {
   float log_k;
   unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 16 realtime stamps per block for step T / 2
 };
-
-GJX_DEV float load_agent(const float* p) { return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-// four consecutive floats through ONE 16-byte sc1 load (4-byte sc1 accesses run at a fraction of the 16-byte rate); the
-// wait sits inside the asm because the compiler does not count an asm's memory operations
-GJX_DEV void load_agent_x4(const float* p, float (&v)[4]) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 r;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-}
-GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// standard-normal draws of slot gidx under the step's propagation key (k_ssm_step's streams), in two halves: the random
-// words (the hashes: most of the VALU work, done inside the granule wait) and the normals from them (Box-Muller, done
-// behind the loads of the ancestor's state).  A block's window work must stay below the ~1 us of slack the LAST block
-// to publish has over the others, or that block is late again in the next step and its chain sets the step time.
-template <int RNG, int DX>
-struct SsmNoiseBits { uint32_t w[RNG == GJX_RNG_FLAT ? 2 * GJX_FLAT_BLOCKS(DX + (DX & 1)) : DX]; };
-
-template <int RNG, int DX>
-GJX_DEV void ssm_noise_bits(key2 skj, uint64_t gidx, SsmNoiseBits<RNG, DX>& nb) {
-  if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(skj, gidx), 1u);
-  else if (gidx >> 32) skj = threefry2x32(skj, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
-  if (RNG == GJX_RNG_FLAT) {
-    constexpr int NB = GJX_FLAT_BLOCKS(DX + (DX & 1));
-#pragma unroll
-    for (int h = 0; h < NB; ++h) {
-      const key2 hh = threefry2x32(skj, (uint32_t)gidx, (1u << GJX_FLAT_SITE_SHIFT) | (uint32_t)h);
-      nb.w[2 * h] = hh.a; nb.w[2 * h + 1] = hh.b;
-    }
-  } else {
-#pragma unroll
-    for (int d0 = 0; d0 < DX; ++d0) {
-      const key2 h0 = threefry2x32(skj, 0u, (uint32_t)d0);
-      nb.w[d0] = h0.a ^ h0.b;
-    }
-  }
-}
-template <int RNG, int DX>
-GJX_DEV void ssm_noise_normals(const SsmNoiseBits<RNG, DX>& nb, float (&nz)[DX]) {
-  if (RNG == GJX_RNG_FLAT) {
-#pragma unroll
-    for (int d0 = 0; d0 < DX; d0 += 2) {
-      float n0, n1;
-      box_muller(GJX_FIELD(nb.w, d0), GJX_FIELD(nb.w, d0 + 1), n0, n1);
-      nz[d0] = n0;
-      if (d0 + 1 < DX) nz[d0 + 1] = n1;
-    }
-  } else {
-#pragma unroll
-    for (int d0 = 0; d0 < DX; ++d0) nz[d0] = normal_from_bits_fast(nb.w[d0]);
-  }
-}
-
-// ---- tile-scaled fixed point (shared by k_ssm_persistent<TILED> and the gjx_resample_indices_tiled kernels) ----
-constexpr int kTileQ = 1024;                       // particles per quantisation tile
-constexpr float kTileScale = 536870912.0f;         // 2^29
-constexpr int kTileDead = -524288;                 // exponent of a tile without a finite positive weight (-2^19)
-constexpr float kLog2e = 1.44269504f;
-
-GJX_DEV int tile_exponent(float tile_max) {        // e_b = ceil(max * log2 e), clamped to 20 bits; tile_max never NaN (fmaxf)
-  if (!(tile_max > -INFINITY)) return kTileDead;
-  const float t = ceilf(tile_max * kLog2e);
-  return t < -524287.0f ? -524287 : (t > 524287.0f ? 524287 : (int)t);
-}
-GJX_DEV uint64_t tile_q(float lw, int e) {         // floor(2^29 * min(1, 2^(lw * log2 e - e))); NaN / -inf / dead tile -> 0
-  if (e == kTileDead) return 0;
-  float w = __builtin_amdgcn_exp2f(fmaf(lw, kLog2e, -(float)e));   // one rounding: the oracle uses fmaf too
-  w = w > 0.0f ? w : 0.0f;
-  w = w < 1.0f ? w : 1.0f;
-  return (uint64_t)(w * kTileScale);
-}
-// granule of the tiled rendezvous: tag (4 bits, != 0) | e_b + 2^19 (20 bits) | S_b (40 bits, S_b <= 2^39).  Four tag
-// bits are plenty: a block rewrites its granule of one parity every second step, so a reader can only ever meet the
-// tag of step t or of step t - 2
-GJX_DEV unsigned long long tile_granule(unsigned long long tag, int e, uint64_t S) {
-  return (tag << 60) | ((unsigned long long)(unsigned)(e - kTileDead) << 40) | (S & ((1ull << 40) - 1));
-}
 
 template <int RNG, int DX, int THREADS, bool TILED>
 __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
@@ -1262,6 +1186,57 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
 #undef GJX_PERS
     pblk = (K + pthreads - 1) / pthreads;
     if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 48 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+  }
+  // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
+  if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
+      (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
+    PfPlan pf;
+    if (pf_plan(rng_mode, m->dx, m->dy, K, 1, 1, &pf) == GJX_OK &&
+        256 + 40 * (size_t)pf.nt + 8 * (size_t)pf.grid + 16 * (size_t)T + 64 <= need) {
+      hipStream_t st = (hipStream_t)stream;
+      float* lw_alt = (float*)cum;
+      auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
+      static thread_local std::vector<uint32_t> h_keys;
+      static thread_local std::vector<double> h_us;
+      pf_step_keys(key0, key1, T, h_keys, h_us);
+      const size_t NT = (size_t)pf.nt;
+      // ws2: [256 B control][aggA 8 NT][aggB 8 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
+      unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
+      unsigned long long* aggB = aggA + NT;
+      float* bsum = (float*)(aggB + NT);
+      float* bmax = bsum + 3 * NT;
+      unsigned* ready = (unsigned*)(bmax + 3 * NT);
+      double* us_dev = (double*)(ready + 2 * (((size_t)pf.grid + 1) / 2));
+      uint32_t* keys_dev = (uint32_t*)(us_dev + T);
+      hipError_t e = hipMemsetAsync(aggA, 0, 40 * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
+      if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
+      {   // step 0: from the prior
+        SsmArgs a;
+        a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;
+        a.key = key2{h_keys[0], h_keys[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
+        a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
+        a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
+        a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+        const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
+        if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
+        GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
+      }
+      PfArgs f;
+      memset(&f, 0, sizeof(f));
+      f.A = m->A_dev; f.H = m->H_dev; f.ys = ys_dev; f.q = m->q; f.r = m->r; f.dy = m->dy; f.T = T;
+      f.K = K; f.K_total = K; f.offset = 0; f.G = 1; f.rank = 0; f.nt = pf.nt; f.NT = pf.nt;
+      f.x_a = x_a; f.x_b = x_b; f.lw_even = logw; f.lw_odd = lw_alt;
+      f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready;
+      f.peer_data = nullptr; f.peer_flag = nullptr; f.keys = keys_dev; f.us = us_dev;
+      f.lse_steps = lse_steps; f.ancestors = ancestors; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
+      f.first_budget = 1u << 17; f.zero_ptr = nullptr; f.zero_n = 0;
+      void* args[] = {&f};
+      e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
+      if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(k_pf_persistent)");
+      return GJX_OK;
+    }
   }
   if (pers_fn) {
     hipStream_t st = (hipStream_t)stream;
