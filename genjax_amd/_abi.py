@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -131,6 +131,13 @@ PROTOTYPES = {
     "gjx_shard_ctx_stats": (C.c_int, [vp, vp]),
     "gjx_shard_resample_multinomial_step": (C.c_int, [vp, vp, vp, vp, i64, vp, i64, u32, u32, vp, vp, vp]),
     "gjx_shard_global_lse": (C.c_int, [vp, vp, vp, vp]),
+    "gjx_peer_ctx_create": (C.c_int, [i32, i32, i64, i32, i32, C.POINTER(vp)]),
+    "gjx_peer_ctx_export": (C.c_int, [vp, vp]),
+    "gjx_peer_ctx_connect": (C.c_int, [vp, vp]),
+    "gjx_peer_ctx_buffers": (C.c_int, [vp, vp]),
+    "gjx_peer_ctx_status": (C.c_int, [vp, C.POINTER(i32), vp]),
+    "gjx_peer_ctx_destroy": (C.c_int, [vp]),
+    "gjx_ssm_filter_peer": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, vp, vp, vp, vp]),
     "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc_engine": (C.c_int, [PP]),
     "gjx_hmc": (C.c_int, [PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp, vp,

@@ -509,6 +509,95 @@ class ShardContext:
             pass
 
 
+class _RawDevice:
+    """__cuda_array_interface__ view of library-owned device memory (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=3, strides=None)
+        self._owner = owner
+
+
+class PeerContext:
+    """gjx_peer_ctx: this rank's peer-mapped exchange windows of a collection sharded over the ranks of a process group
+    (one process per GPU).  ``rows[p]`` f32[rows][K_local] and ``logw[p]`` f32[K_local] (p = 0, 1) are torch views of the
+    DATA window: kernels write their particles there, other ranks read them through hipIpc mappings.  The handles travel
+    through one all-gather on ``group`` (any backend) at construction; nothing else ever goes through the host."""
+
+    def __init__(self, K_local: int, rows: int, device=None, group=None, ranks_on_device: int | None = None):
+        import torch.distributed as dist
+        self.group = group
+        self.device = _dev(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.K, self.nrows = int(K_local), int(rows)
+        self._h = C.c_void_p()
+        host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        if ranks_on_device is None:
+            ranks_on_device = 1
+            if self.world > 1:      # ranks that share this physical device (dry runs on one GPU) split its co-resident capacity
+                props = torch.cuda.get_device_properties(self.device)
+                ident = str(getattr(props, "uuid", "")) or "index-%d" % self.device.index
+                mine = torch.tensor(list(ident.encode()[:64].ljust(64, b" ")), dtype=torch.uint8)
+                allv = torch.empty(self.world * 64, dtype=torch.uint8)
+                if host_staged:
+                    dist.all_gather_into_tensor(allv, mine, group=group)
+                else:
+                    allv_d = allv.to(self.device)
+                    dist.all_gather_into_tensor(allv_d, mine.to(self.device), group=group)
+                    allv = allv_d.cpu()
+                ranks_on_device = sum(1 for g in range(self.world) if bytes(allv[64 * g:64 * g + 64].tolist()) == bytes(mine.tolist()))
+        self.ranks_on_device = int(ranks_on_device)
+        with torch.cuda.device(self.device):
+            check(load().gjx_peer_ctx_create(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, C.byref(self._h)),
+                  "gjx_peer_ctx_create")
+            if self.world > 1:
+                buf = (C.c_uint8 * 128)()
+                check(load().gjx_peer_ctx_export(self._h, C.cast(buf, C.c_void_p)), "gjx_peer_ctx_export")
+                mine = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+                allh = torch.empty(self.world * 128, dtype=torch.uint8)
+                if host_staged:
+                    dist.all_gather_into_tensor(allh, mine, group=group)
+                else:
+                    allh_d = allh.to(self.device)
+                    dist.all_gather_into_tensor(allh_d, mine.to(self.device), group=group)
+                    allh = allh_d.cpu()
+                hb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(bytes(allh.tolist()))
+                check(load().gjx_peer_ctx_connect(self._h, C.cast(hb, C.c_void_p)), "gjx_peer_ctx_connect")
+            o = (C.c_uint64 * 6)()
+            check(load().gjx_peer_ctx_buffers(self._h, C.cast(o, C.c_void_p)), "gjx_peer_ctx_buffers")
+        self.rows = [torch.as_tensor(_RawDevice(o[p], (self.nrows, self.K), "<f4", self), device=self.device) for p in (0, 1)]
+        self.logw = [torch.as_tensor(_RawDevice(o[2 + p], (self.K,), "<f4", self), device=self.device) for p in (0, 1)]
+        self.window_bytes = (int(o[4]), int(o[5]))
+        if self.world > 1:
+            dist.barrier(group=group)      # every rank has mapped every window before anyone launches into them
+
+    def ssm_filter(self, ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, want_ancestors: bool = False):
+        """gjx_ssm_filter_peer -> dict(lse_steps [T][4] global records, x (particles of the last step: a view of the window),
+        logw, ancestors?)"""
+        T = ys.shape[0]
+        lse = torch.empty((T, 4), dtype=torch.float32, device=self.device)
+        anc = torch.empty(self.K, dtype=torch.int32, device=self.device) if want_ancestors else None
+        check(load().gjx_ssm_filter_peer(C.byref(ssm), key[0], key[1], rng_mode, int(T), self._h, _ptr(ys), _ptr(lse), _ptr(anc), _stream()),
+              "gjx_ssm_filter_peer")
+        return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
+
+    def status(self) -> int:
+        """bit 0: a rendezvous timed out (results undefined), bit 1: a step had zero total weight; read and cleared"""
+        st = C.c_int32(0)
+        check(load().gjx_peer_ctx_status(self._h, C.byref(st), _stream()), "gjx_peer_ctx_status")
+        return int(st.value)
+
+    def close(self) -> None:
+        if self._h:
+            import torch.distributed as dist
+            torch.cuda.synchronize(self.device)
+            if self.world > 1 and dist.is_initialized():
+                dist.barrier(group=self.group)      # nobody unmaps a window a peer's kernel may still read
+            self.rows, self.logw = [], []
+            load().gjx_peer_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 def shard_pack(src: torch.Tensor, anc: torch.Tensor, n_valid: int, n_pre: int, n_suf: int) -> torch.Tensor:
     """gjx_shard_pack: the surplus children of this rank's slot run as [n_pre + n_suf][R] messages (one launch)"""
     R = src.shape[0]

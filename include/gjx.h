@@ -37,7 +37,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 4
+#define GJX_ABI_VERSION 5
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -506,6 +506,43 @@ int gjx_shard_resample_multinomial_step(gjx_shard_ctx* ctx, const float* logw, c
 int gjx_shard_ctx_stats(const gjx_shard_ctx* ctx, int64_t* out4);
 int gjx_shard_ctx_shape(const gjx_shard_ctx* ctx, int64_t out5[5]);
 int gjx_shard_global_lse(gjx_shard_ctx* ctx, const float* local_lse, float* lse_out, void* stream);
+
+/* ---- sharded collections without the host in the loop: peer-mapped exchange windows --------------------------
+ * (build's own design for north_star's config 4; nothing in the reference.)  One process per GPU.
+ * Every rank owns two windows — DATA (particle rows x2 and log-weights x2: what other ranks READ) and FLAG (tagged
+ * granules, the LSE ring, `ready` words: what other ranks WRITE) — exports them as hipIpc handles and maps everybody
+ * else's (xGMI peer access between GPUs).  The kernels below then exchange everything themselves: granules are pushed
+ * with system-scope stores, source tiles and ancestors' rows are pulled with system-scope loads.  No collective call,
+ * no host synchronisation and no allocation inside any loop.
+ *   create:  K_local particles and `rows` SoA rows per rank; n_ranks > 1 needs K_local % 1024 == 0;
+ *            ranks_on_this_device > 1 declares that so many ranks share ONE device (dry runs): grids are sized so
+ *            that all of them stay co-resident.
+ *   export:  out128 = the two 64-byte hipIpcMemHandle_t (data, flag); hand every rank's 128 bytes to
+ *   connect: in rank order (n_ranks x 128 bytes; a rank's own entry is ignored).  One rank: connected from the start.
+ *   buffers: out6 = device pointers of this rank's rows[0], rows[1] (f32[rows][K_local]), logw[0], logw[1] (f32[K_local])
+ *            and the byte sizes of the two windows.  The caller's kernels write their particles THERE.
+ *   status:  bit 0 a rendezvous timed out (a peer is missing: results undefined), bit 1 a collection had zero total
+ *            weight; read and cleared, synchronises the stream.
+ *   destroy: only after every rank has finished using the context (the caller's barrier). */
+typedef struct gjx_peer_ctx gjx_peer_ctx;
+int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device,
+                        gjx_peer_ctx** out);
+int gjx_peer_ctx_export(gjx_peer_ctx* ctx, uint8_t* out128);
+int gjx_peer_ctx_connect(gjx_peer_ctx* ctx, const uint8_t* handles);
+int gjx_peer_ctx_buffers(gjx_peer_ctx* ctx, uint64_t* out6);
+int gjx_peer_ctx_status(gjx_peer_ctx* ctx, int32_t* status_host, void* stream);
+int gjx_peer_ctx_destroy(gjx_peer_ctx* ctx);
+/* BASELINE config 4 — the bootstrap filter of gjx_ssm_filter_scheme(GJX_WEIGHTS_TILE_SCALED) on a collection sharded
+ * over the ranks of a peer context created with rows == dx; every rank calls this with the same key and ys (T >= 2).
+ * TWO launches per rank whatever T is: step 0, then steps 1 .. T-1 in one launch in which the ranks meet once per step
+ * through their flag windows (Scan.generate's step recursion, combinators/scan.py:237-294, with systematic resampling
+ * in front of every step).  Streams are indexed by the global particle index and every integer of the resampling comes
+ * from the same K_total / 1024 granules on every rank, so particles, weights and log-ML do not depend on n_ranks.
+ * The particles of the last step are left in rows[(T - 1) & 1], their log-weights in logw[0]; lse_steps f32[T][4] =
+ * the GLOBAL record of every step (on every rank); ancestors (or NULL) int32[K_local] = global index of every slot's
+ * ancestor at the last resampling. */
+int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
+                        const float* ys_dev, float* lse_steps, int32_t* ancestors, void* stream);
 
 /* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
  * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float
