@@ -325,9 +325,9 @@ def run_ssm(args, rank, world, dev):
         K = (world << 19) if args.weak else (1 << 22)
     K_local = K // world
     scaling = "weak" if (args.weak or world == 1) else "strong"
-    # fixed-point scheme of the resampler (include/gjx.h): tile-scaled = one grid rendezvous per step instead of two;
-    # the sharded exchange quantises against the global maximum
-    scheme = "global_max" if world > 1 else args.ssm_weights
+    # fixed-point scheme of the resampler (include/gjx.h): tile-scaled = one rendezvous per step (among the blocks of one
+    # GPU, or among the ranks through peer-mapped windows); global_max on a sharded collection = the collective transport
+    scheme = args.ssm_weights
     bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights=scheme)
     ys = torch.as_tensor(s["y"], device=dev)
     last = {}
@@ -356,10 +356,13 @@ def run_ssm(args, rank, world, dev):
         torch.cuda.synchronize()
         other = dict(weights=o_name, us_per_filter_step=(time.perf_counter() - t0) / 3 / T * 1e6, log_ml=float(lo))
     exch = dict(transport="none")
-    if getattr(bf, "_resampler", None) is not None:
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    if getattr(bf, "_peer", None) is not None:
+        exch = dict(transport="peer", ranks=world, ranks_on_this_device=bf._peer.ranks_on_device,
+                    note="peer-mapped windows (hipIpc): granules pushed, source tiles and ancestors pulled inside one launch; no collective calls")
+    elif getattr(bf, "_resampler", None) is not None:
         exch = bf._resampler.stats()
-        bf._resampler.close()
+    bf.close()
     if rank != 0:
         return None
     exact = golden("ssm_dx8_T256_seed0")
@@ -373,10 +376,14 @@ def run_ssm(args, rank, world, dev):
                              "one bench step = one T=256 filter run" % (2 if world == 1 else 3), k_particles_per_gpu=K_local,
                     k_particles_total=K, T=T, rng_stream="flat", sharding=f"particles x{world}",
                     resampler_weights=scheme, exchange=exch["transport"], exchange_stats=exch),
-        roofline=dict(bound="hbm", kernel=("gjx::k_ssm_persistent<FLAT,8,1024,%s> (steps 1..T-1 of the filter in ONE launch: %s grid "
-                                           "rendezvous per step, resample + propagate + reweight)"
-                                           % (("true", "one") if scheme == "tile_scaled" else ("false", "two"))
-                                           if world == 1 else "sharded filter step: k_ssm_step + exchange"),
+        roofline=dict(bound="hbm", kernel=(("gjx::k_ssm_persistent<FLAT,8,1024,%s> (steps 1..T-1 of the filter in ONE launch: %s grid "
+                                            "rendezvous per step, resample + propagate + reweight)"
+                                            % (("true", "one") if scheme == "tile_scaled" else ("false", "two")))
+                                           if exch["transport"] == "none" and K_local <= (1 << 18) else
+                                           "gjx::k_pf_persistent<FLAT,8,SPL> (steps 1..T-1 in ONE launch, SPL 1024-slot tiles per block, one rendezvous per step"
+                                           + (" among all ranks through peer-mapped windows)" if exch["transport"] == "peer" else ")")
+                                           if (exch["transport"] == "peer" or (exch["transport"] == "none" and scheme == "tile_scaled")) else
+                                           "sharded filter step: k_ssm_step + collective exchange"),
                       achieved=algo / (per_step_us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=algo / (per_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_us=per_step_us,
                       algorithmic_bytes_per_launch=algo,

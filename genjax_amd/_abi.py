@@ -138,6 +138,7 @@ PROTOTYPES = {
     "gjx_peer_ctx_status": (C.c_int, [vp, C.POINTER(i32), vp]),
     "gjx_peer_ctx_destroy": (C.c_int, [vp]),
     "gjx_ssm_filter_peer": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, vp, vp, vp, vp]),
+    "gjx_peer_resample_gather": (C.c_int, [vp, i32, vp, i32, f64, vp, i64, vp, vp, vp]),
     "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc_engine": (C.c_int, [PP]),
     "gjx_hmc": (C.c_int, [PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp, vp,

@@ -93,7 +93,7 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   for (int p = 0; p < 2; ++p) { c->off_lw[p] = o; o = align_up(o + sizeof(float) * (size_t)K_local); }
   c->data_bytes = o;
   // FLAG window: [256 B control][region 0][region 1]; a region: granules A, B [NT] | ring sum, max [3][NT] | ready words |
-  // the words of the one-launch resampling step (gmm: 4 x [world] u64 + this rank's tile granules [nt])
+  // the words of the one-launch resampling step (twice, for alternating calls: 4 x [MAX_RANKS] u64 + this rank's tile granules [nt])
   const size_t NT = (size_t)c->NT;
   size_t r = 0;
   c->r_aggA = r; r = align_up(r + 8 * NT);
@@ -101,7 +101,7 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   c->r_bsum = r; r = align_up(r + 12 * NT);
   c->r_bmax = r; r = align_up(r + 12 * NT);
   c->r_ready = r; r = align_up(r + 4 * (size_t)kPfHostMaxTiles);
-  c->r_gmm = r; r = align_up(r + 8 * (4 * (size_t)GJX_MAX_RANKS + (size_t)c->nt));
+  c->r_gmm = r; r = align_up(r + 2 * 8 * (4 * (size_t)GJX_MAX_RANKS + (size_t)c->nt));   // x2: alternating calls
   c->region_bytes = r;
   c->off_region[0] = kAlign;
   c->off_region[1] = kAlign + r;
@@ -249,5 +249,436 @@ extern "C" int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key
   void* args[] = {&f};
   const hipError_t e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
   if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter_peer(k_pf_persistent)");
+  return GJX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// One sharded ImportanceK resampling step in ONE launch per rank: log-weights -> systematic ancestors over the WHOLE
+// collection -> this rank's children, pulled from whichever rank holds the ancestor.  k_resample_gather's consumer-side
+// scheme (gjx_resample.hip) under the tile-scaled fixed point (GJX_WEIGHTS_TILE_SCALED): a block quantises its own tile
+// of 1024 particles against the tile's power of two, the blocks of a rank all-gather their {e_b, S_b} granules locally,
+// and the ranks meet twice through their flag windows — hop 1: the largest tile exponent E of the collection, hop 2:
+// the rank totals at that exponent (G words each) — after which every block knows the global comb, finds the source
+// rank of its slots from the G + 1 rank bounds, and searches that rank's tile prefix (its own: already in LDS; another
+// rank's: that rank's granule array, pulled through the mapping).  Same integers as gjx_resample_indices_tiled on the
+// unsharded collection: G_b = S_b >> (E - e_b), prefix over all tiles in rank order, thresholds floor((j + u) total / N),
+// residual << (E - e_b) looked up in the tile's own cumulative q.  One rank: both hops vanish.
+// ------------------------------------------------------------------------------------------------------------
+namespace gjx {
+
+struct PrgArgs {
+  const float* x;                  // [K] log-weights of this rank (DATA window: other ranks read them)
+  int64_t K, K_total, offset;      // particles here / in total; global index of this rank's first particle
+  int G, rank, nt;                 // ranks, this rank, tiles per rank (= gridDim.x)
+  int mode;                        // 2: `lse` = n_partials per-block {max, sumexp} pairs of the producing kernel; 0: no LSE record
+  const float* lse;
+  int n_partials;
+  float* lse_out;                  // [4] global record (every rank), or NULL
+  float log_k_total;
+  double u;
+  const float* src;                // [rows][src_stride] this rank's particle rows (DATA window)
+  int64_t src_stride;
+  int rows;
+  float* dst;                      // [rows][dst_stride] children of this rank's slots (private)
+  int64_t dst_stride;
+  int32_t* ancestors;              // [K] global ancestor index (or NULL)
+  unsigned long long* agg;         // [nt] this rank's tile granules (FLAG window: other ranks read them)
+  unsigned long long* wE;          // [G] hop 1: tagged max tile exponent of every rank (this rank's copy)
+  unsigned long long* wR;          // [G] hop 2: tagged rank total at the global exponent
+  unsigned long long* wP;          // [G] {max, sumexp} of every rank's log-weights (lands before its hop-1 word)
+  const long long* peer_data;      // [G] byte distances to the other ranks' windows (NULL: one rank)
+  const long long* peer_flag;
+  unsigned* ctrl;
+  unsigned seq;                    // call counter of the context (same on every rank): the tags
+  unsigned first_budget;
+};
+
+constexpr int kPrgMaxTiles = 1024;
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
+  constexpr int TILE = 256 * ITEMS;
+  static_assert(TILE == kTileQ, "a block owns one quantisation tile");
+  constexpr int CH = 3;                          // source tiles re-scanned per round
+  __shared__ float fred[8], s_tm[4], s_em[4];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t P[kPrgMaxTiles + 1];
+  __shared__ int32_t Eb[kPrgMaxTiles];
+  __shared__ uint64_t cumL[CH * TILE];
+  __shared__ uint64_t s_wtot[CH][4];
+  __shared__ uint64_t RB[GJX_MAX_RANKS + 1];
+  __shared__ long long sPD[GJX_MAX_RANKS], sPF[GJX_MAX_RANKS];
+  __shared__ int s_range[2], s_dead;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool sys = a.G > 1;
+  const int nb = (int)gridDim.x, G = a.G;
+  const int64_t K = a.K;
+  const unsigned long long tag4 = (unsigned long long)(a.seq % 15u) + 1ull;
+  const unsigned long long tag14 = (unsigned long long)(a.seq % 16383u) + 1ull;
+  if (tid < GJX_MAX_RANKS) {
+    sPD[tid] = (a.peer_data && tid < G) ? a.peer_data[tid] : 0;
+    sPF[tid] = (a.peer_flag && tid < G) ? a.peer_flag[tid] : 0;
+  }
+  if (tid == 0) s_dead = 0;
+  unsigned budget = a.first_budget;
+  auto timed_out = [&]() {
+    __hip_atomic_fetch_or(&a.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dead = 1;
+    budget = 0;
+  };
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + tid) * ITEMS;   // first particle this lane scans = first slot it produces
+  float xv[ITEMS];
+  if (ITEMS == 4 && i0 + 4 <= K) {
+    const float4 q4 = *(const float4*)(a.x + i0);
+    xv[0] = q4.x; xv[1] = q4.y; xv[2] = q4.z; xv[3] = q4.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) xv[k] = (i0 + k < K) ? a.x[i0 + k] : -INFINITY;
+  }
+  float sm_sum = 0.0f, mx_r = -INFINITY;
+  if (a.mode == 2) mx_r = block_ref_max(2, a.lse, a.n_partials, fred, &sm_sum);      // this rank's {max, sumexp} (ends with a barrier)
+  else __syncthreads();                                                             // (sPF / s_dead visible)
+  // ---- own tile: exponent, fixed-point weights, total -> local granule ----
+  {
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) m = fmaxf(m, xv[k]);
+    const float wm = wave_max_dpp(m);
+    if (lane == 0) s_tm[wid] = wm;
+  }
+  __syncthreads();
+  const int eb = tile_exponent(fmaxf(fmaxf(s_tm[0], s_tm[1]), fmaxf(s_tm[2], s_tm[3])));
+  {
+    uint64_t qs = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) qs += (i0 + k < K) ? tile_q(xv[k], eb) : 0;
+    const uint64_t wt = wave_sum_u64(qs);
+    if (lane == 0) wsum[wid] = wt;
+  }
+  __syncthreads();
+  if (tid == 0) store_scoped_u64(&a.agg[blockIdx.x], tile_granule(tag4, eb, wsum[0] + wsum[1] + wsum[2] + wsum[3]), sys);
+  if (blockIdx.x == 0 && a.mode == 2 && sys && tid < G)          // this rank's LSE pair, to every rank (ordered before the hop-1 word below)
+    store_scoped_u64(peer_ptr(a.wP + a.rank, sPF[tid]), pack_f2(mx_r, sm_sum), true);
+  // ---- all-gather of this rank's granules (local) ----
+  auto read_granules = [&](const unsigned long long* arr, bool wait_tag) {
+    float em = (float)kTileDead;
+    for (int b = tid; b < nb; b += 256) {
+      unsigned long long v = load_scoped_u64(&arr[b], sys);
+      if (wait_tag) {
+        while ((v >> 60) != tag4 && budget) {
+          --budget;
+          __builtin_amdgcn_s_sleep(1);
+          v = load_scoped_u64(&arr[b], sys);
+        }
+        if ((v >> 60) != tag4) { timed_out(); v = 0; }
+      }
+      const uint64_t S = v & ((1ull << 40) - 1);
+      const int e = S ? (int)((v >> 40) & 0xFFFFFu) + kTileDead : kTileDead;
+      P[b + 1] = S;
+      Eb[b] = e;
+      em = fmaxf(em, (float)e);
+    }
+    em = wave_max_dpp(em);
+    if (lane == 0) s_em[wid] = em;
+    if (tid == 0) P[0] = 0;
+    __syncthreads();
+    return (int)fmaxf(fmaxf(s_em[0], s_em[1]), fmaxf(s_em[2], s_em[3]));
+  };
+  // P[b + 1] = S_b >> (E - e_b), then the inclusive prefix in place: thread t owns the entries [t per, (t + 1) per)
+  auto shift_and_prefix = [&](int E) {
+    const int per = (nb + 255) >> 8;
+    const int e0 = tid * per < nb ? tid * per : nb, e1 = (e0 + per) < nb ? (e0 + per) : nb;
+    uint64_t loc = 0;
+    for (int e = e0; e < e1; ++e) {
+      const int sh = E - Eb[e];
+      const uint64_t g = sh < 64 ? P[e + 1] >> sh : 0;
+      P[e + 1] = g;
+      loc += g;
+    }
+    const uint64_t inc = wave_scan_u64(loc);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint64_t run = inc - loc;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+    __syncthreads();
+  };
+  budget = 1u << 17;                             // the local gather: blocks of one launch
+  int E = read_granules(a.agg, true);
+  // ---- hop 1: the largest tile exponent over all ranks ----
+  if (sys) {
+    budget = s_dead ? 0u : a.first_budget;       // the other ranks' launches may start later than this one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (block 0: the LSE pair has landed before the hop-1 word goes out)
+    if (blockIdx.x == 0 && tid < G)
+      store_scoped_u64(peer_ptr(a.wE + a.rank, sPF[tid]), (tag14 << 50) | (unsigned long long)(unsigned)(E - kTileDead), true);
+    float em = (float)kTileDead;
+    if (tid < G) {
+      unsigned long long v = load_scoped_u64(&a.wE[tid], true);
+      while ((v >> 50) != tag14 && budget) {
+        --budget;
+        __builtin_amdgcn_s_sleep(1);
+        v = load_scoped_u64(&a.wE[tid], true);
+      }
+      if ((v >> 50) != tag14) { timed_out(); v = 0; }
+      em = (float)((int)(v & 0xFFFFFu) + kTileDead);
+    }
+    em = wave_max_dpp(em);
+    __syncthreads();                             // s_em of read_granules has been read by everybody
+    if (lane == 0) s_em[wid] = em;
+    __syncthreads();
+    E = (int)fmaxf(fmaxf(s_em[0], s_em[1]), fmaxf(s_em[2], s_em[3]));
+  }
+  E = __builtin_amdgcn_readfirstlane(E);
+  shift_and_prefix(E);
+  const uint64_t R_own = P[nb];
+  // ---- hop 2: the rank totals at that exponent -> rank bounds on the global weight line ----
+  if (sys) {
+    budget = s_dead ? 0u : (1u << 17);
+    if (blockIdx.x == 0 && tid < G)
+      store_scoped_u64(peer_ptr(a.wR + a.rank, sPF[tid]), (tag14 << 50) | (R_own & kAggMask), true);
+    if (tid < G) {
+      unsigned long long v = load_scoped_u64(&a.wR[tid], true);
+      while ((v >> 50) != tag14 && budget) {
+        --budget;
+        __builtin_amdgcn_s_sleep(1);
+        v = load_scoped_u64(&a.wR[tid], true);
+      }
+      if ((v >> 50) != tag14) { timed_out(); v = 0; }
+      RB[tid + 1] = v & kAggMask;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t run = 0;
+      RB[0] = 0;
+      for (int g = 0; g < G; ++g) { run += RB[g + 1]; RB[g + 1] = run; }
+    }
+    __syncthreads();
+  } else {
+    if (tid == 0) { RB[0] = 0; RB[1] = R_own; }
+    __syncthreads();
+  }
+  const uint64_t total = RB[G];
+  // the global LSE record (every rank writes its own copy): the G pairs landed before the hop-1 words this block has seen
+  if (a.mode == 2 && a.lse_out && blockIdx.x == 0 && tid == 0) {
+    float m = mx_r, s = sm_sum;
+    if (sys) {
+      m = -INFINITY; s = 0.0f;
+      for (int g = 0; g < G; ++g) {
+        const unsigned long long pr = g == a.rank ? pack_f2(mx_r, sm_sum) : load_scoped_u64(&a.wP[g], true);
+        const float pm = __uint_as_float((uint32_t)pr), ps = __uint_as_float((uint32_t)(pr >> 32));
+        const float nm = fmaxf(m, pm);
+        if (nm > -INFINITY) s = s * fast_exp(m - nm) + ps * fast_exp(pm - nm);
+        m = nm;
+      }
+    }
+    const float l = m > -INFINITY ? m + logf(s) : -INFINITY;
+    a.lse_out[0] = m; a.lse_out[1] = s; a.lse_out[2] = l; a.lse_out[3] = l - a.log_k_total;
+  }
+  if (total == 0 && blockIdx.x == 0 && tid == 0) __hip_atomic_fetch_or(&a.ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- ancestors of slots i0 .. i0 + ITEMS - 1, in TILE space: (global tile) * 1024 + index in the tile ----
+  const int kpad = nb * TILE;
+  int anc[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) anc[k] = a.rank * kpad + (int)((i0 + k < K) ? i0 + k : 0);   // dead collection: identity (flagged)
+  if (total > 0) {                               // block-uniform
+    const double step = (double)total / (double)a.K_total;
+    const double inv_step = (double)a.K_total / (double)total;
+    uint64_t T[ITEMS];
+    int gk[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int64_t j = a.offset + ((i0 + k < K) ? i0 + k : K - 1);
+      T[k] = comb_threshold(j, a.u, step, total);
+      int g = a.rank;                            // source rank: the one whose stretch [RB[g], RB[g + 1]) holds the threshold
+      if (T[k] < RB[g] || T[k] >= RB[g + 1]) {
+        g = 0;
+        for (int h = 1; h < G; ++h) g += RB[h] <= T[k] ? 1 : 0;
+      }
+      gk[k] = g;
+    }
+    if (tid == 0) s_range[0] = gk[0];
+    if (tid == 255) s_range[1] = gk[ITEMS - 1];
+    __syncthreads();
+    const int gmin = __builtin_amdgcn_readfirstlane(s_range[0]), gmax = __builtin_amdgcn_readfirstlane(s_range[1]);
+    bool own_prefix = true;                      // P / Eb hold this rank's tiles
+    const int64_t blk0 = a.offset + (int64_t)blockIdx.x * TILE;      // first global slot of the block
+    for (int gs = gmin; gs <= gmax; ++gs) {
+      if (RB[gs + 1] == RB[gs]) continue;        // a rank without weight produces no slot
+      // the block's slots that fall on rank gs: [J(RB[gs]), J(RB[gs + 1])) cut to the block
+      const int64_t jlo = slots_below(RB[gs], a.u, step, inv_step, total, a.K_total);
+      const int64_t jhi = slots_below(RB[gs + 1], a.u, step, inv_step, total, a.K_total);
+      const int64_t sb0 = jlo > blk0 ? jlo : blk0, sb1 = jhi < blk0 + TILE ? jhi : blk0 + TILE;
+      if (sb1 <= sb0) continue;                  // block-uniform
+      __syncthreads();                           // the previous rank's search is over (P, Eb, cumL, s_range free)
+      if (gs != a.rank || !own_prefix) {         // that rank's granules: complete since its hop-2 word was seen
+        const int Eg = read_granules(peer_ptr(a.agg, sPF[gs]), false);
+        (void)Eg;
+        shift_and_prefix(E);
+        own_prefix = false;
+      }
+      uint64_t Tl[ITEMS];
+      int tile[ITEMS];
+      bool in[ITEMS];
+      // rank-local thresholds; a block's slots draw from tiles near its own index when the source is its own rank: the nine
+      // boundaries of the eight tiles around blockIdx.x are read together, otherwise (and outside the window) a descent
+      const int wlo = (int)blockIdx.x - 4 < 0 ? 0 : ((int)blockIdx.x - 4 > nb - 8 ? (nb - 8 < 0 ? 0 : nb - 8) : (int)blockIdx.x - 4);
+      uint64_t Pw[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Pw[k] = P[wlo + k < nb ? wlo + k : nb];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        in[k] = gk[k] == gs;
+        Tl[k] = in[k] ? T[k] - RB[gs] : 0;
+        int tl = wlo;
+        if (Tl[k] >= Pw[0] && Tl[k] < Pw[8]) {
+#pragma unroll
+          for (int w = 1; w < 8; ++w) tl += Pw[w] <= Tl[k] ? 1 : 0;
+        } else {
+          tl = 0;
+#pragma unroll
+          for (int sft = kPrgMaxTiles >> 1; sft >= 1; sft >>= 1) {
+            const int p = tl + sft;              // P[p] = inclusive prefix of tile p - 1
+            if (p <= nb - 1 && P[p] <= Tl[k]) tl = p;
+          }
+        }
+        tile[k] = tl;
+        Tl[k] = (Tl[k] - P[tl]) << (E - Eb[tl]);                  // residual in the source tile's own units
+        const int64_t jslot = a.offset + i0 + k;
+        if (in[k] && jslot == sb0) s_range[0] = tl;
+        if (in[k] && jslot == sb1 - 1) s_range[1] = tl;
+      }
+      __syncthreads();
+      const int tmin = __builtin_amdgcn_readfirstlane(s_range[0]), ntiles = __builtin_amdgcn_readfirstlane(s_range[1]) - tmin + 1;
+      auto next_live = [&](int at) { while (at < ntiles && P[tmin + at + 1] == P[tmin + at]) ++at; return at; };
+      const float* xg = peer_ptr(a.x, sPD[gs]);
+      auto load_tile = [&](int t, float (&v)[ITEMS]) {
+        const int64_t p0 = (int64_t)t * TILE + (int64_t)tid * ITEMS;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) v[k] = -INFINITY;
+        if (ITEMS == 4 && p0 + 4 <= K) load_scoped_x4(xg + p0, v, sys);
+        else {
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) if (p0 + k < K) v[k] = load_scoped(xg + p0 + k, sys);
+        }
+      };
+      for (int idx = next_live(0); idx < ntiles;) {
+        const int nidx = next_live(idx + CH);
+        uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const bool on = idx + c < ntiles;
+          float nv[ITEMS];
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) nv[k] = -INFINITY;
+          if (on) load_tile(tmin + idx + c, nv);
+          const int es = on ? Eb[tmin + idx + c] : kTileDead;
+          sacc[c] = 0;
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) { sacc[c] += on ? tile_q(nv[k], es) : 0; qi[c][k] = sacc[c]; }
+          inc[c] = sacc[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) inc[c] = wave_scan_u64(inc[c]);
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];
+        }
+        __syncthreads();                         // also: every lane is done searching the previous round's cumL
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          uint64_t base = inc[c] - sacc[c];
+          for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + tid * ITEMS + k] = base + qi[c][k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+          const int kpos = tile[k] - tmin;
+          if (in[k] && kpos >= idx && kpos < idx + CH) {
+            const uint64_t* cm = cumL + (kpos - idx) * TILE;
+            int pos = 0;                           // number of entries <= the residual, 4-ary
+#pragma unroll
+            for (int q = TILE >> 2; q >= 1; q >>= 2) {
+              const uint64_t pa = cm[pos + q - 1], pb = cm[pos + 2 * q - 1], pc = cm[pos + 3 * q - 1];
+              pos += (pa <= Tl[k] ? q : 0) + (pb <= Tl[k] ? q : 0) + (pc <= Tl[k] ? q : 0);
+            }
+            anc[k] = (gs * nb + tile[k]) * TILE + pos;
+          }
+        }
+        idx = nidx;
+      }
+    }
+  }
+  // ---- children: rows of the ancestors, pulled from the rank that holds them ----
+  int sl[ITEMS];
+  long long dl[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int sg = anc[k] / kpad;
+    sl[k] = anc[k] - sg * kpad;
+    dl[k] = sPD[sg];
+    if (a.ancestors && i0 + k < K) a.ancestors[i0 + k] = (int32_t)((int64_t)sg * K + sl[k]);
+  }
+  const bool whole = i0 + ITEMS <= K;
+  const bool vec = ITEMS == 4 && whole && (a.dst_stride & 3) == 0 && (((uintptr_t)a.dst) & 15) == 0;
+#pragma unroll 4
+  for (int r = 0; r < a.rows; ++r) {
+    const float* sr = a.src + (int64_t)r * a.src_stride;
+    float v[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) v[k] = sys ? load_scoped(peer_ptr(sr, dl[k]) + sl[k], true) : sr[sl[k]];
+    if (vec) *(float4*)(a.dst + (int64_t)r * a.dst_stride + i0) = make_float4(v[0], v[ITEMS > 1 ? 1 : 0], v[ITEMS > 2 ? 2 : 0], v[ITEMS > 3 ? 3 : 0]);
+    else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) a.dst[(int64_t)r * a.dst_stride + i0 + k] = v[k];
+    }
+  }
+}
+
+}  // namespace gjx
+
+// One resampling step of a sharded collection (every rank calls it with the same u): this rank's log-weights logw[p]
+// and particle rows rows[p] (p = parity: the buffers of the context's DATA window the producing kernel wrote) -> the
+// children of this rank's K_local output slots in rows_out f32[rows][out_stride] (caller's memory).  Alternate p from
+// call to call: a rank that is one call ahead then never overwrites what a slower rank still reads.
+//   partials / n_partials: the per-block {max, sumexp} pairs gjx_run_program left in ITS workspace (workspace + 256) — the
+//   global LSE record then comes out in lse_out f32[4] on every rank; partials == NULL: no record.
+//   ancestors (or NULL): int32[K_local], global ancestor index of every slot.
+// One launch, no collective call, no host synchronisation.  GJX_EUNSUPPORTED when K_local / 1024 blocks are not
+// co-resident (K_local <= 2^20 on a full MI355X).
+extern "C" int gjx_peer_resample_gather(gjx_peer_ctx* c, int32_t parity, const float* partials, int32_t n_partials, double u,
+                                        float* rows_out, int64_t out_stride, int32_t* ancestors, float* lse_out, void* stream) {
+  if (!c || parity < 0 || parity > 1 || !rows_out || !(u >= 0.0 && u < 1.0) || (partials && n_partials <= 0))
+    return gjx_fail(GJX_EINVAL, "gjx_peer_resample_gather: bad argument");
+  if (!c->connected) return gjx_fail(GJX_EINVAL, "gjx_peer_resample_gather: the context is not connected (gjx_peer_ctx_connect)");
+  const void* fn = (const void*)k_peer_resample_gather<4>;
+  int cap = gjx_coresident_blocks(fn, 256, 0);
+  if (c->share > 1) cap /= c->share;
+  if (c->nt > cap || c->nt > kPrgMaxTiles)
+    return gjx_fail(GJX_EUNSUPPORTED, "gjx_peer_resample_gather: K_local / 1024 blocks are not co-resident on this device");
+  // the exchange words alternate between two sets from call to call: a rank that is already one call ahead (nothing stops
+  // it once it has seen everybody's hop-2 word) must not overwrite granules or LSE pairs a slower rank still reads; it
+  // cannot be two calls ahead (its next hop 1 needs the slower rank's next hop-1 word)
+  char* gm = c->flag + c->off_region[0] + c->r_gmm + (size_t)(c->n_gmm & 1) * 8 * (4 * (size_t)GJX_MAX_RANKS + (size_t)c->nt);
+  PrgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const float*)(c->data + c->off_lw[parity]);
+  a.K = c->K; a.K_total = c->K * c->world; a.offset = (int64_t)c->rank * c->K; a.G = c->world; a.rank = c->rank; a.nt = c->nt;
+  a.mode = partials ? 2 : 0; a.lse = partials; a.n_partials = n_partials; a.lse_out = lse_out;
+  a.log_k_total = (float)log((double)a.K_total);
+  a.u = u;
+  a.src = (const float*)(c->data + c->off_rows[parity]); a.src_stride = c->K; a.rows = c->rows;
+  a.dst = rows_out; a.dst_stride = out_stride; a.ancestors = ancestors;
+  a.wE = (unsigned long long*)gm; a.wR = a.wE + GJX_MAX_RANKS; a.wP = a.wR + GJX_MAX_RANKS;
+  a.agg = a.wP + 2 * GJX_MAX_RANKS;
+  a.peer_data = c->world > 1 ? c->delta_dev : nullptr;
+  a.peer_flag = c->world > 1 ? c->delta_dev + c->world : nullptr;
+  a.ctrl = (unsigned*)c->flag + 8;
+  a.seq = (unsigned)(c->n_gmm++);
+  a.first_budget = c->world > 1 ? (1u << 24) : (1u << 17);
+  void* args[] = {&a};
+  const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)c->nt), dim3(256), args, 0, (hipStream_t)stream);
+  if (e != hipSuccess) return gjx_fail_hip(e, "gjx_peer_resample_gather");
   return GJX_OK;
 }

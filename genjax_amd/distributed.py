@@ -423,3 +423,75 @@ class ShardedResampler:
         if self.ctx is not None:
             self.ctx.close()
             self.ctx = None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Peer-mapped exchange (csrc/gjx_peer.hip): the sharded kernels talk to each other through hipIpc-mapped windows, no
+# host in the loop.  Opened once per process after a self-check; the collective transports above stay as the fallback.
+# ---------------------------------------------------------------------------------------------------------------
+_peer_verdict: dict = {}
+
+
+def _peer_self_check(device, group) -> bool:
+    """A small sharded tile-scaled filter through the peer windows against the same filter run unsharded on this rank:
+    this rank's slice of the particles and log-weights must match bit for bit and no rendezvous may time out.  Collective:
+    every rank gets the same verdict."""
+    import numpy as np
+    from . import _abi as A
+    from . import kernels
+    from .inference.pf import LinearGaussianSSM
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    host = _host_staged(group) if dist.is_initialized() else True
+    ok = 0
+    pc = None
+    try:
+        pc = kernels.PeerContext(2048, 4, device, group)
+    except Exception as e:                 # symmetric: PeerContext raises on every rank or on none
+        import warnings
+        warnings.warn(f"peer-mapped exchange unavailable: {e}")
+        return False
+    try:
+        th = 0.3 + 0.1 * np.arange(2)
+        Am = np.zeros((4, 4), np.float32)
+        for i, t in enumerate(th):
+            c, s_ = 0.9 * np.cos(t), 0.9 * np.sin(t)
+            Am[2 * i:2 * i + 2, 2 * i:2 * i + 2] = [[c, -s_], [s_, c]]
+        ssm = LinearGaussianSSM(Am, 0.5, 2.0)
+        ys = torch.as_tensor(np.random.default_rng(5).standard_normal((5, 4)).astype(np.float32), device=device)
+        cs = ssm.c_struct(device)
+        got = pc.ssm_filter(cs, (0, 77), A.RNG_FLAT, ys)
+        torch.cuda.synchronize(device)
+        st = pc.status()
+        ref = kernels.ssm_filter(cs, (0, 77), A.RNG_FLAT, ys, 2048 * world, weights=A.WEIGHTS_TILE_SCALED)
+        sl = slice(rank * 2048, (rank + 1) * 2048)
+        same = torch.equal(got["x"], ref["x"][:, sl]) and torch.equal(got["logw"], ref["logw"][sl])
+        ok = 1 if (same and st == 0) else 0
+    except Exception as e:
+        import warnings
+        warnings.warn(f"peer-mapped exchange: self-check raised {e!r}")
+        ok = 0
+    if world > 1:
+        t = torch.tensor([ok], dtype=torch.int32, device="cpu" if host else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        ok = int(t.item())
+    try:
+        pc.close()
+    except Exception:
+        pass
+    return bool(ok)
+
+
+def peer_available(device, group=None) -> bool:
+    """True when the peer-mapped exchange works between the ranks of ``group`` (checked once per process and device;
+    GJX_PEER=0 switches it off, GJX_PEER=1 skips the check)."""
+    mode = os.environ.get("GJX_PEER", "auto")
+    if mode == "0":
+        return False
+    key = (str(torch.device(device)), id(group))
+    if key not in _peer_verdict:
+        _peer_verdict[key] = True if mode == "1" else _peer_self_check(torch.device(device), group)
+        if not _peer_verdict[key]:
+            import warnings
+            warnings.warn("peer-mapped exchange failed its self-check: sharded collections fall back to the collective transports")
+    return _peer_verdict[key]

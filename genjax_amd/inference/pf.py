@@ -148,6 +148,33 @@ class BootstrapFilter:
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
         self.last_accept_rate = None
 
+    def _run_peer(self, key, ys_d, dev, world, check_status):
+        from .. import kernels
+        K_local = self.K // world
+        k_ = (K_local, self.ssm.dx, world, str(dev))
+        if getattr(self, "_peer_key", None) != k_:
+            if getattr(self, "_peer", None) is not None:
+                self._peer.close()
+            self._peer, self._peer_key = kernels.PeerContext(K_local, self.ssm.dx, dev), k_
+        out = self._peer.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d)
+        incs = out["lse_steps"][:, 3]
+        res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None, transport="peer")
+        if check_status:
+            st = self._peer.status()
+            if st & 1:
+                raise GjxError("sharded bootstrap filter: a rendezvous between the ranks timed out; results are undefined")
+            res["degenerate"] = bool(st & 2)
+        return res
+
+    def close(self):
+        """release the exchange contexts of a sharded filter (collective: every rank calls it)"""
+        if getattr(self, "_peer", None) is not None:
+            self._peer.close()
+            self._peer, self._peer_key = None, None
+        if getattr(self, "_resampler", None) is not None:
+            self._resampler.close()
+            self._resampler, self._resampler_key = None, None
+
     @staticmethod
     def _checked(res, ws, check_status):
         """Read (and clear) the status word of the co-resident resampling kernels: a time-out means the grid was not
@@ -175,8 +202,19 @@ class BootstrapFilter:
             raise NotImplementedError("keep_history: the ancestor history is kept per process; run the filter on one GPU")
         if self.rejuvenate and (world > 1 or D._forced()):
             raise NotImplementedError("resample-move rejuvenation runs on one GPU")
-        if self.weights == A.WEIGHTS_TILE_SCALED and (world > 1 or D._forced()):
-            raise NotImplementedError("the tile-scaled weight scheme runs on one GPU (the sharded exchange quantises against the global maximum)")
+        sharded_ = world > 1 or D._forced()
+        if self.weights == A.WEIGHTS_TILE_SCALED and sharded_:
+            # the whole sharded filter in two launches per rank through peer-mapped windows (gjx_ssm_filter_peer); the
+            # collective transport (global-maximum scheme, one exchange call per step) only if that is not available
+            plain = not keep_means and not step_by_step and T >= 2
+            if plain and self.K % world == 0 and (self.K // world) % 1024 == 0 and D.peer_available(dev):
+                return self._run_peer(key, ys_d, dev, world, check_status)
+            if not plain or not getattr(self, "_allow_collective_fallback", True):
+                raise NotImplementedError("sharded tile-scaled filter: needs the peer-mapped exchange (K / world a multiple of 1024, "
+                                          "no keep_means / step_by_step)")
+            import warnings
+            warnings.warn("sharded bootstrap filter: peer-mapped exchange unavailable, using the collective transport with "
+                          "global-maximum weights")
         if world == 1 and not keep_means and not step_by_step and not keep_history and not self.rejuvenate and not D._forced():
             out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, weights=self.weights)
             incs = out["lse_steps"][:, 3]

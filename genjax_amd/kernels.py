@@ -547,22 +547,47 @@ class PeerContext:
                     allv = allv_d.cpu()
                 ranks_on_device = sum(1 for g in range(self.world) if bytes(allv[64 * g:64 * g + 64].tolist()) == bytes(mine.tolist()))
         self.ranks_on_device = int(ranks_on_device)
+        def agree(ok: bool) -> bool:
+            """every rank learns whether ALL ranks succeeded (a rank that failed alone must not leave the others in a collective)"""
+            if self.world == 1:
+                return ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if host_staged else self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        def gather_bytes(mine: bytes, n: int) -> bytes:
+            m = torch.tensor(list(mine), dtype=torch.uint8)
+            allv = torch.empty(self.world * n, dtype=torch.uint8)
+            if host_staged:
+                dist.all_gather_into_tensor(allv, m, group=group)
+            else:
+                d = allv.to(self.device)
+                dist.all_gather_into_tensor(d, m.to(self.device), group=group)
+                allv = d.cpu()
+            return bytes(allv.tolist())
+
+        err = None
         with torch.cuda.device(self.device):
-            check(load().gjx_peer_ctx_create(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, C.byref(self._h)),
-                  "gjx_peer_ctx_create")
+            rc = load().gjx_peer_ctx_create(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, C.byref(self._h))
+            buf = (C.c_uint8 * 128)()
+            if rc == 0 and self.world > 1:
+                rc = load().gjx_peer_ctx_export(self._h, C.cast(buf, C.c_void_p))
+            if rc != 0:
+                err = load().gjx_last_error().decode("utf-8", "replace")
+            if not agree(rc == 0):
+                self._destroy_now()
+                raise GjxError("PeerContext: windows could not be created / exported on every rank: %s" % (err or "another rank failed"))
             if self.world > 1:
-                buf = (C.c_uint8 * 128)()
-                check(load().gjx_peer_ctx_export(self._h, C.cast(buf, C.c_void_p)), "gjx_peer_ctx_export")
-                mine = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
-                allh = torch.empty(self.world * 128, dtype=torch.uint8)
-                if host_staged:
-                    dist.all_gather_into_tensor(allh, mine, group=group)
-                else:
-                    allh_d = allh.to(self.device)
-                    dist.all_gather_into_tensor(allh_d, mine.to(self.device), group=group)
-                    allh = allh_d.cpu()
-                hb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(bytes(allh.tolist()))
-                check(load().gjx_peer_ctx_connect(self._h, C.cast(hb, C.c_void_p)), "gjx_peer_ctx_connect")
+                allh = gather_bytes(bytes(buf), 128)
+                hb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(allh)
+                rc = load().gjx_peer_ctx_connect(self._h, C.cast(hb, C.c_void_p))
+                if rc != 0:
+                    err = load().gjx_last_error().decode("utf-8", "replace")
+                if not agree(rc == 0):      # (no peer access between two of the devices, IPC disabled, ...)
+                    if rc == 0:
+                        dist.barrier(group=group)
+                    self._destroy_now()
+                    raise GjxError("PeerContext: the windows could not be mapped on every rank: %s" % (err or "another rank failed"))
             o = (C.c_uint64 * 6)()
             check(load().gjx_peer_ctx_buffers(self._h, C.cast(o, C.c_void_p)), "gjx_peer_ctx_buffers")
         self.rows = [torch.as_tensor(_RawDevice(o[p], (self.nrows, self.K), "<f4", self), device=self.device) for p in (0, 1)]
@@ -570,6 +595,11 @@ class PeerContext:
         self.window_bytes = (int(o[4]), int(o[5]))
         if self.world > 1:
             dist.barrier(group=group)      # every rank has mapped every window before anyone launches into them
+
+    def _destroy_now(self) -> None:
+        if self._h:
+            load().gjx_peer_ctx_destroy(self._h)
+            self._h = C.c_void_p()
 
     def ssm_filter(self, ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, want_ancestors: bool = False):
         """gjx_ssm_filter_peer -> dict(lse_steps [T][4] global records, x (particles of the last step: a view of the window),
@@ -580,6 +610,21 @@ class PeerContext:
         check(load().gjx_ssm_filter_peer(C.byref(ssm), key[0], key[1], rng_mode, int(T), self._h, _ptr(ys), _ptr(lse), _ptr(anc), _stream()),
               "gjx_ssm_filter_peer")
         return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
+
+    def resample_gather(self, parity: int, u: float, partials=None, out=None, anc=None, lse_out=None):
+        """gjx_peer_resample_gather: logw[parity], rows[parity] -> the children of this rank's slots (one launch).
+        ``partials=(run_workspace, n)``: the block pairs of the producing run -> lse_out receives the global record."""
+        if out is None:
+            out = torch.empty((self.nrows, self.K), dtype=torch.float32, device=self.device)
+        lp, npart = (None, 0)
+        if partials is not None:
+            run_ws, n = partials
+            lp, npart = C.c_void_p(run_ws.data_ptr() + 256), int(n)
+            if lse_out is None:
+                lse_out = torch.empty(4, dtype=torch.float32, device=self.device)
+        check(load().gjx_peer_resample_gather(self._h, int(parity), lp, npart, float(u), _ptr(out), out.stride(0), _ptr(anc),
+                                              _ptr(lse_out), _stream()), "gjx_peer_resample_gather")
+        return out, lse_out
 
     def status(self) -> int:
         """bit 0: a rendezvous timed out (results undefined), bit 1: a step had zero total weight; read and cleared"""

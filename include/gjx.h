@@ -543,6 +543,19 @@ int gjx_peer_ctx_destroy(gjx_peer_ctx* ctx);
  * ancestor at the last resampling. */
 int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
                         const float* ys_dev, float* lse_steps, int32_t* ancestors, void* stream);
+/* BASELINE configs 2 / 4 on a sharded collection — one systematic resampling step over the WHOLE collection in ONE
+ * launch per rank (ParticleCollection resampling, the N-of-K form of smc.py:102-109): this rank's log-weights logw[parity]
+ * and rows rows[parity] (the buffers of the DATA window the producing kernel wrote) -> the children of this rank's
+ * K_local output slots in rows_out f32[rows][out_stride] (caller's memory), pulled from whichever rank holds the
+ * ancestor.  Tile-scaled fixed point; the ranks meet twice through their flag windows (largest tile exponent, then the
+ * rank totals at that exponent: G words each).  Ancestors == gjx_resample_indices_tiled on the unsharded collection, bit
+ * for bit, for any number of ranks.  Alternate `parity` from call to call (a rank may be one call ahead of another).
+ *   partials / n_partials: the per-block {max, sumexp} pairs gjx_run_program(lse == NULL) left at its workspace + 256:
+ *   lse_out f32[4] then receives the GLOBAL record on every rank; partials == NULL: no record.
+ *   ancestors (or NULL) int32[K_local]: global ancestor index of every slot.
+ * GJX_EUNSUPPORTED when K_local / 1024 blocks are not co-resident (K_local <= 2^20 on a full MI355X). */
+int gjx_peer_resample_gather(gjx_peer_ctx* ctx, int32_t parity, const float* partials, int32_t n_partials, double u,
+                             float* rows_out, int64_t out_stride, int32_t* ancestors, float* lse_out, void* stream);
 
 /* ---- HMC move: HMC.edit (inference/requests/hmc.py:156-211) -------------------------------
  * One chain per particle column.  Moves the slots of sites flagged GJX_SITE_HMC_SELECTED (float

@@ -92,3 +92,101 @@ def test_peer_filter_equals_unsharded(world, K_total, dx):
             np.testing.assert_allclose(r[1][rep][2][:, 2:], ref["lse_steps"].cpu().numpy()[:, 2:], rtol=2e-6, atol=2e-6)
     assert all(r[2] == 0 for r in res), [r[2] for r in res]       # no rendezvous timed out, no dead step
     assert all(r[3] == world for r in res)                         # the ranks noticed that they share one device
+
+
+def _weights(shape, K, seed=11):
+    rs = np.random.default_rng(seed)
+    lw = (rs.standard_normal(K) * (5.0 if shape == "wide" else 1.0)).astype(np.float32)
+    if shape == "first":
+        lw[K // 7:] -= 60.0                      # nearly all the mass on the first rank: every rank pulls from it
+    if shape == "dead_tiles":
+        lw[2048:9000] = -np.inf                  # whole tiles without weight, a rank boundary inside the stretch
+        lw[K - 3000:] = -300.0                   # tiles that are shifted out entirely
+    if shape == "spiky":
+        lw[:] = -40.0
+        lw[rs.integers(0, K, 40)] = rs.standard_normal(40).astype(np.float32) * 3.0   # a few particles with many children
+    return lw
+
+
+def _resample_worker(rank, world, port, K_total, R, shape, q):
+    try:
+        import sys
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        from genjax_amd import distributed as D
+        from genjax_amd import kernels
+        D.init_from_env("gloo")
+        torch.cuda.set_device(0)
+        K = K_total // world
+        ctx = kernels.PeerContext(K, R, "cuda")
+        rows = np.random.default_rng(3).standard_normal((R, K_total)).astype(np.float32)
+        outs = []
+        for call in range(4):                    # consecutive calls alternate the buffers and the exchange words
+            p = call & 1
+            lw = _weights(shape, K_total, seed=11 + call)
+            sl = slice(rank * K, (rank + 1) * K)
+            ctx.logw[p].copy_(torch.as_tensor(lw[sl]))
+            ctx.rows[p].copy_(torch.as_tensor(rows[:, sl] + call))
+            # the producer's per-block {max, sumexp} pairs, as gjx_run_program leaves them at workspace + 256
+            t = torch.as_tensor(lw[sl]).cuda().view(-1, 256)
+            m = t.max(dim=1).values
+            se = torch.where(torch.isfinite(m), torch.exp(t - torch.where(torch.isfinite(m), m, torch.zeros_like(m))[:, None]).sum(dim=1), torch.zeros_like(m))
+            ws = torch.zeros(256 + 8 * m.numel(), dtype=torch.uint8, device="cuda")
+            ws[256:].view(torch.float32).view(-1, 2).copy_(torch.stack([m, se], dim=1))
+            anc = torch.empty(K, dtype=torch.int32, device="cuda")
+            out, rec = ctx.resample_gather(p, 0.37 + 0.1 * call, partials=(ws, m.numel()), anc=anc)
+            torch.cuda.synchronize()
+            outs.append((out.cpu().numpy(), anc.cpu().numpy(), rec.cpu().numpy()))
+        q.put((rank, outs, ctx.status(), None))
+        ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+        raise
+
+
+@pytest.mark.parametrize("world,shape", [(1, "mild"), (2, "mild"), (2, "wide"), (4, "first"), (4, "dead_tiles"), (2, "spiky")])
+def test_peer_resample_gather_equals_unsharded(world, shape):
+    """gjx_peer_resample_gather on `world` ranks == gjx_resample_indices_tiled + gjx_gather_rows on the whole collection:
+    ancestors and children bit for bit (children crossing rank boundaries in both directions, dead and shifted-out tiles,
+    many-offspring particles), global LSE record on every rank."""
+    import torch
+    import torch.multiprocessing as mp
+    from genjax_amd import kernels
+    K_total, R = 1 << 15, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 200) + world + 10 * ["mild", "wide", "first", "dead_tiles", "spiky"].index(shape)
+    procs = [ctx.Process(target=_resample_worker, args=(r, world, port, K_total, R, shape, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = np.random.default_rng(3).standard_normal((R, K_total)).astype(np.float32)
+    crossing = 0
+    K = K_total // world
+    for call in range(4):
+        lw = _weights(shape, K_total, seed=11 + call)
+        lw_d = torch.as_tensor(lw).cuda()
+        anc = kernels.resample_indices_tiled(lw_d, 0.37 + 0.1 * call)
+        want = kernels.gather_rows(torch.as_tensor(rows + call).cuda(), anc).cpu().numpy()
+        got_anc = np.concatenate([r[1][call][1] for r in res])
+        np.testing.assert_array_equal(got_anc, anc.cpu().numpy())
+        np.testing.assert_array_equal(np.concatenate([r[1][call][0] for r in res], axis=1), want)
+        lse = float(torch.logsumexp(lw_d.double(), dim=0))
+        for r in res:
+            np.testing.assert_allclose(r[1][call][2][2], lse, rtol=3e-6)
+        crossing += int((got_anc // K != np.arange(K_total) // K).sum())
+    assert all(r[2] in (0,) for r in res), [r[2] for r in res]
+    if world > 1:
+        assert crossing > 0                     # children did cross rank boundaries
