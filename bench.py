@@ -179,7 +179,15 @@ def run_gmm(args, rank, world, dev):
             two_launch = True
         except Exception:
             two_launch = False
-    resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if sharded else None
+    # sharded: peer-mapped windows (the producing kernel writes its particles into the context's buffers, alternating
+    # from step to step; one resampling launch per rank, no collective call) — or, if the ranks cannot map each other's
+    # memory, the collective transport (RCCL all-gathers + host-sized all-to-all-v)
+    peer = None
+    if sharded and K % 1024 == 0 and os.environ.get("GJX_SHARD_TRANSPORT", "auto") in ("auto", "peer") and DD.peer_available(dev):
+        peer = kernels.PeerContext(K, out["choices"].shape[0], dev)
+        peer_out = [dict(choices=peer.rows[p], score=out["score"], logw=peer.logw[p], _ws=ws) for p in (0, 1)]
+        peer_calls = [0]                         # buffer parity: strictly alternating from call to call on every rank
+    resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if (sharded and peer is None) else None
 
     def step(i, timed):
         key = (0, 1 + i)
@@ -189,7 +197,13 @@ def run_gmm(args, rank, world, dev):
                 timers[j].arm()
             else:
                 ev[j][0].record()
-        if not fused_step:
+        if peer is not None:
+            par = peer_calls[0] & 1
+            peer_calls[0] += 1
+            kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=peer_out[par], want_weight=False, want_lse=False)
+            if j is not None and j % 2 == 1:
+                ev[j][1].record()
+        elif not fused_step:
             kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
                                 want_lse=sharded)
             if j is not None and j % 2 == 1:
@@ -210,7 +224,11 @@ def run_gmm(args, rank, world, dev):
                 kernels.resample_indices(out["logw"], u, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
                 kernels.gather_rows(out["choices"], anc, rows)
             return lse_rec
-        # sharded: 8-byte all-gather of per-rank {max, sumexp} (reduced in the prefix-sum prologue), 8-byte
+        if peer is not None:
+            # one launch: tile granules, two G-word hops between the ranks, ancestors, children pulled from their owners
+            peer.resample_gather(par, u, partials=(ws, n_part), out=rows, lse_out=lse_rec)
+            return lse_rec
+        # collective transport: 8-byte all-gather of per-rank {max, sumexp} (reduced in the prefix-sum prologue), 8-byte
         # all-gather of weight totals, device-side plan, local gather + all-to-all-v of the surplus children
         _, lse_g = resampler.step(out["choices"], out["logw"], out["lse"], u)
         return lse_g
@@ -224,6 +242,12 @@ def run_gmm(args, rank, world, dev):
     torch.cuda.synchronize()
     dt, lse = timed_loop(args, world, dev, step)
     exch = dict(transport="none")
+    if peer is not None:
+        lse = lse.clone()
+        torch.cuda.synchronize()
+        exch = dict(transport="peer", ranks=world, ranks_on_this_device=peer.ranks_on_device, status=peer.status(),
+                    note="peer-mapped windows (hipIpc): one resampling launch per rank, two G-word hops, children pulled from their owners")
+        peer.close()
     if resampler is not None:
         lse = lse.clone()
         torch.cuda.synchronize()
@@ -264,7 +288,7 @@ def run_gmm(args, rank, world, dev):
                       kernel_us=kern_ms * 1e3, kernel_us_event_pair_around_call=bracket_us,
                       timing="HIP events attached to the kernel dispatch on %d steps spread over the timed region" % len(disp),
                       algorithmic_bytes_per_launch=algo_bytes,
-                      launches_per_step=1 if fused_step else (2 if two_launch else 3),
+                      launches_per_step=1 if fused_step else (2 if (two_launch or peer is not None) else 3),
                       note=("the whole importance step is this one launch: propagate+reweight (76 B/particle), resampling (8), "
                             "gather of 17 rows (136); " if fused_step else "") +
                            "the propagate+reweight phase is bound by integer VALU issue (Threefry-2x32-20), see DESIGN.md §5; frac is vs HBM"),
