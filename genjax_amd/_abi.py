@@ -94,6 +94,7 @@ PROTOTYPES = {
     "gjx_importance_step": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, f64, vp, vp, vp, C.c_size_t, vp]),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
     "gjx_workspace_status": (C.c_int, [vp, C.POINTER(i32), vp]),
+    "gjx_debug_timeline": (C.c_int, [vp, C.c_size_t]),
     "gjx_logsumexp": (C.c_int, [vp, i64, i64, vp, vp, C.c_size_t, vp]),
     "gjx_lse_combine": (C.c_int, [vp, C.c_int, i64, vp, vp]),
     "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "gjx_event_elapsed_us": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "gjx_profile_next_run": (C.c_int, [vp, vp]),
     "gjx_run_partials_count": (C.c_int, [PP, i64, i64]),
+    "gjx_last_run_partials": (C.c_int, []),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
     "gjx_resample_indices": (C.c_int, [vp, i64, i32, vp, i32, f64, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_resample_gather": (C.c_int, [vp, i64, i32, vp, i32, f64, vp, i64, i32, vp, i64, vp, vp, i64, vp, C.c_size_t, vp]),
@@ -122,7 +124,7 @@ PROTOTYPES = {
     "gjx_ssm_step": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, i64, vp, vp, vp,
                                vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_step_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32, vp, vp,
-                                    vp, vp, vp, i64, vp, C.c_size_t, vp]),
+                                    vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_scheme": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),

@@ -77,6 +77,20 @@ extern "C" const char* gjx_last_error(void) { return g_err; }
 
 // One bound for every op: 16 bytes per 64 particles (block partials: {max,sum} floats, u64 block
 // sums, {value,index} argmax pairs) plus a fixed header.
+// Phase stamps for profiles/microbench/*_timeline.py: an EXPLICIT registration (a device buffer and its size) instead of an
+// environment variable holding a raw pointer — a stale variable would have made every block of every later run write
+// through it.  The co-resident kernels stamp into it only while it is registered and large enough for their grid.
+static unsigned long long* g_timeline = nullptr;
+static size_t g_timeline_bytes = 0;
+extern "C" int gjx_debug_timeline(void* device_buffer, size_t bytes) {
+  g_timeline = (unsigned long long*)device_buffer;
+  g_timeline_bytes = device_buffer ? bytes : 0;
+  return GJX_OK;
+}
+namespace gjx {
+unsigned long long* debug_timeline(size_t need) { return (g_timeline && g_timeline_bytes >= need) ? g_timeline : nullptr; }
+}  // namespace gjx
+
 extern "C" size_t gjx_workspace_bytes(int op, int64_t K) {
   (void)op;
   if (K < 0) K = 0;

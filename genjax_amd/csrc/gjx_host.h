@@ -25,6 +25,8 @@ int gjx_launch_lse_finish(const void* partials_float2, int n, int64_t K_total, f
 int gjx_coresident_blocks(const void* kernel, int threads, size_t dyn_lds);
 
 namespace gjx {
+// phase-stamp buffer of the profiling scripts (gjx_debug_timeline): the registered device buffer if it holds `need` bytes
+unsigned long long* debug_timeline(size_t need);
 struct GenArgs;
 // per-program generated kernels (gjx_codegen.hip)
 int gen_pick_ppt(const gjx_program* prog, int64_t K);

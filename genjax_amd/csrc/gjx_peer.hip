@@ -243,7 +243,7 @@ extern "C" int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key
   f.keys = c->keys_dev; f.us = c->us_dev; f.lse_steps = lse_steps; f.ancestors = ancestors;
   f.ctrl = (unsigned*)c->flag + 8; f.log_k = (float)log((double)K_total);
   // the other ranks' launches may be queued behind host work of their own: the first rendezvous waits for seconds, later ones ~0.1 s
-  f.first_budget = c->world > 1 ? (1u << 24) : (1u << 17);
+  f.first_budget = c->world > 1 ? (1u << 24) : (1u << 16);
   f.zero_ptr = (unsigned long long*)(c->flag + c->off_region[other] + c->r_aggA);
   f.zero_n = (int)((c->r_bsum - c->r_aggA) / 8);
   void* args[] = {&f};
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
     for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
     __syncthreads();
   };
-  budget = 1u << 17;                             // the local gather: blocks of one launch
+  budget = kPollBudget;                          // the local gather: blocks of one launch
   int E = read_granules(a.agg, true);
   // ---- hop 1: the largest tile exponent over all ranks ----
   if (sys) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
   const uint64_t R_own = P[nb];
   // ---- hop 2: the rank totals at that exponent -> rank bounds on the global weight line ----
   if (sys) {
-    budget = s_dead ? 0u : (1u << 17);
+    budget = s_dead ? 0u : kPollBudget;
     if (blockIdx.x == 0 && tid < G)
       store_scoped_u64(peer_ptr(a.wR + a.rank, sPF[tid]), (tag14 << 50) | (R_own & kAggMask), true);
     if (tid < G) {
@@ -676,7 +676,7 @@ extern "C" int gjx_peer_resample_gather(gjx_peer_ctx* c, int32_t parity, const f
   a.peer_flag = c->world > 1 ? c->delta_dev + c->world : nullptr;
   a.ctrl = (unsigned*)c->flag + 8;
   a.seq = (unsigned)(c->n_gmm++);
-  a.first_budget = c->world > 1 ? (1u << 24) : (1u << 17);
+  a.first_budget = c->world > 1 ? (1u << 24) : (1u << 16);
   void* args[] = {&a};
   const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)c->nt), dim3(256), args, 0, (hipStream_t)stream);
   if (e != hipSuccess) return gjx_fail_hip(e, "gjx_peer_resample_gather");

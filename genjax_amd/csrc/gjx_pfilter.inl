@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
     unsigned rdy0;
     const unsigned rtag = epoch + (unsigned)t;   // `ready` word of this step: never repeats, the epoch advances by 2 T per launch
     const int nready = G * nb;
-    unsigned step_budget = s_dead ? 0u : (t == 1 ? f.first_budget : (1u << 17));   // sticky: a launch that timed out once stops waiting
+    // sticky: a launch in which one rendezvous timed out (a rank is missing, the grid is not co-resident) stops waiting
+    const bool flagged = (__hip_atomic_load(&f.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout) != 0;
+    unsigned step_budget = (s_dead || flagged) ? 0u : (t == 1 ? f.first_budget : kPollBudget);
     auto timed_out = [&]() {
       __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_dead = 1;

@@ -667,7 +667,7 @@ extern "C" int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, co
   unsigned long long* agg = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
   unsigned long long* timeline = nullptr;   // debug: per-block phase stamps (profiles/microbench/gather_timeline.py)
-  if (const char* e = getenv("GJX_GATHER_TIMELINE_PTR")) timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+  timeline = gjx::debug_timeline(64 * (size_t)nblocks);
 #define GJX_RG(IT) hipLaunchKernelGGL((k_resample_gather<IT>), dim3((unsigned)nblocks), dim3(256), 0, st, x, K, (int)is_log, lse, \
                                       (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride, ancestors, agg, ctrl, timeline)
   if (items == 1) GJX_RG(1); else GJX_RG(4);

@@ -258,7 +258,7 @@ struct GmmArgs {
   int32_t* ancestors;           // [K]
   unsigned long long* agg;      // 4 granule arrays of gridDim.x words each
   unsigned* ctrl;
-  unsigned long long* timeline; // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block
+  unsigned long long* timeline; // debug (gjx_debug_timeline): 8 realtime stamps per block
 };
 
 template <int PPT>
@@ -1131,6 +1131,11 @@ extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_
   return plan_engine(prog, K, particle_offset, false).grid;
 }
 
+// the grid the LAST gjx_run_program of this thread actually launched (= the number of {max, sumexp} block pairs it left in
+// its workspace): what a consumer of the pairs must use — a re-derived plan can differ (site scores, environment)
+static thread_local int g_last_run_grid = 0;
+extern "C" int gjx_last_run_partials(void) { return g_last_run_grid; }
+
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                                int64_t particle_offset, float* choices, float* score, float* weight,
                                float* logw, const float* logw_in, const float* sub,
@@ -1167,6 +1172,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   }
   const float log_k_total = (float)log((double)K_total);
   const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr);
+  g_last_run_grid = ep.grid;
   const GmmShape& g = ep.g;
   const int ppt = ep.ppt, nblocks = ep.grid;
   if (ep.engine == ENGINE_GEN) {
@@ -1257,7 +1263,7 @@ extern "C" int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint3
   a.u = u; a.rows_out = rows_out; a.ancestors = ancestors;
   a.agg = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   a.ctrl = (unsigned*)workspace + 8;
-  if (const char* e = getenv("GJX_STEP_TIMELINE_PTR")) a.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+  a.timeline = gjx::debug_timeline(64 * (size_t)((K + 1023) / 1024));
   hipStream_t st = (hipStream_t)stream;
   switch (g.D) {
     case 1: launch_step_d<1>(a, (int)nblocks, lds, st); break;

@@ -95,11 +95,14 @@ enum { kStatusPollTimeout = 1u, kStatusZeroTotal = 2u };
 // MI355X guide, G16 form R2).  granule = (tag << 50) | value, value < 2^50, tag = (epoch mod 16383) + 1 != 0; `epoch`
 // lives in the workspace control block and is bumped by block 0 once it has seen every granule of the call's LAST
 // all-gather (by then every block has read the old epoch), so consecutive calls never mistake each other's granules
-// and the workspace needs zeroing only once.  Every lane carries a poll budget (~1 s): a grid that is not co-resident
+// and the workspace needs zeroing only once.  Every lane carries a poll budget (~0.1 s): a grid that is not co-resident
 // must not hang — it sets kStatusPollTimeout and carries on with zeros.
 // `visit(b, value)` is called by thread (b mod blockDim.x) for every block b.
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long kAggMask = (1ull << 50) - 1;
+// polls (sleep + one L2-bypassing load: ~1 us each) a lane spends on ONE rendezvous before it gives up and flags
+// kStatusPollTimeout; the host side then repeats the call on the plain multi-launch path (inference/pf.py)
+constexpr unsigned kPollBudget = 1u << 16;
 
 GJX_DEV unsigned long long grid_tag(const unsigned* ctrl, unsigned* epoch_out) {
   const unsigned epoch = __hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -116,7 +119,9 @@ GJX_DEV void grid_publish(unsigned long long* agg, unsigned long long tag, unsig
 // several microseconds and the re-issued batches crowd the L2) and `visit(b, value)` runs on thread (b mod 256).
 template <class Visit>
 GJX_DEV void grid_gather(const unsigned long long* agg, unsigned long long tag, unsigned* ctrl, Visit&& visit) {
-  unsigned budget = 1u << 22;   // polls this lane may spend in total (~1 s): a grid that is not co-resident must not hang
+  unsigned budget = kPollBudget;   // polls this lane may spend in total (~0.1 s): a grid that is not co-resident must not hang
+  // (sticky: blocks that start after the flag went up — the grid never was co-resident — do not wait at all)
+  if (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout) budget = 0;
   for (int b = threadIdx.x; b < (int)gridDim.x; b += (int)blockDim.x) {
     unsigned long long v = 0;
     while (budget) {

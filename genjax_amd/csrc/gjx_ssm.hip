@@ -38,6 +38,7 @@ struct SsmArgs {
   int n_moves;
   float move_scale;
   float* accepted;       // [K] number of accepted moves (or NULL)
+  float* x_moved;        // [DX][K] the moved x_{t-1} each slot was propagated from (or NULL)
 };
 
 template <int RNG, int DX, bool MOVE = false>
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
         }
       }
       if (a.accepted && active) a.accepted[i] = nacc;
+      if (a.x_moved && active) {
+#pragma unroll
+        for (int d = 0; d < DX; ++d) a.x_moved[(int64_t)d * a.K + i] = xp[d];
+      }
     }
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
@@ -204,7 +209,7 @@ struct SsmFusedArgs {
   int32_t* ancestors;              // [K] or NULL
   unsigned long long* agg;
   unsigned* ctrl;
-  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 8 realtime stamps per block
+  unsigned long long* timeline;    // debug (gjx_debug_timeline): 8 realtime stamps per block
 };
 
 constexpr int kSsmFusedMaxTiles = 2048;
@@ -443,7 +448,7 @@ struct SsmPersistArgs {
   unsigned* ready;                 // [gridDim.x] TILED: epoch + t once the block's stores of step t-1 have completed
   unsigned* ctrl;
   float log_k;
-  unsigned long long* timeline;    // debug (GJX_STEP_TIMELINE_PTR): 16 realtime stamps per block for step T / 2
+  unsigned long long* timeline;    // debug (gjx_debug_timeline): 16 realtime stamps per block for step T / 2
 };
 
 template <int RNG, int DX, int THREADS, bool TILED>
@@ -541,6 +546,9 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   __syncthreads();
 #define GJX_PSTAMP(n) do { if (f.timeline && t == T / 2 && threadIdx.x == 0) f.timeline[blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int t = 1; t <= T; ++t) {
+    // a rendezvous that timed out once (the grid is not co-resident: another kernel holds CUs) ends the launch: every block
+    // sees the flag at its next step and leaves; the host repeats the run on the multi-launch path
+    if (__hip_atomic_load(&f.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout) break;
     GJX_PSTAMP(0);
     SsmNoiseBits<RNG, DX> nbits;
     float mx = -INFINITY;
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     unsigned rdy[kPer];
     const unsigned rtag = epoch + (unsigned)t;                // `ready` word of this step: never repeats, the epoch advances by 2 T per launch
     auto check_ready = [&]() {                                // every block's stores of step t-1 have completed (TILED)
-      unsigned budget = 1u << 22;
+      unsigned budget = kPollBudget;
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         const int b = threadIdx.x + k * THREADS;
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       if (fin) lse_ring_reduce(rpm, rps);
       GJX_PSTAMP(2);
       {
-        unsigned budget = 1u << 22;
+        unsigned budget = kPollBudget;
         float em = (float)kTileDead;
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
@@ -1038,7 +1046,7 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   a.key = key2{key0, key1}; a.K = K; a.offset = particle_offset; a.prev_stride = prev_stride;
   a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials; a.ticket = ticket; a.lse = lse;
   a.log_k_total = (float)log((double)K_total);
-  a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+  a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
   const int nblocks = (int)((K + 255) / 256);
   const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
                                            : launch_ssm<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
@@ -1050,8 +1058,8 @@ extern "C" int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
 extern "C" int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
                                  int64_t particle_offset, const float* x_prev, const float* m_prev, int64_t prev_stride,
                                  const int32_t* anc, const float* y_prev_dev, const float* y_dev, int32_t n_moves,
-                                 float move_scale, float* x_out, float* m_out, float* logw, float* accepted, float* lse,
-                                 int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float move_scale, float* x_out, float* m_out, float* logw, float* accepted, float* x_moved_out,
+                                 float* lse, int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !m->A_dev || !y_dev || !x_out || !m_out || !logw || K <= 0 || t < 0 || n_moves < 0)
     return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: bad argument");
   if (t > 0 && (!x_prev || !y_prev_dev)) return gjx_fail(GJX_EINVAL, "gjx_ssm_step_move: x_prev / y_prev are null for t > 0");
@@ -1071,7 +1079,7 @@ extern "C" int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1,
   a.x_prev = x_prev; a.anc = anc; a.x_out = x_out; a.logw = logw; a.partials = partials; a.ticket = ticket; a.lse = lse;
   a.log_k_total = (float)log((double)K_total);
   a.m_prev = t > 1 ? m_prev : nullptr; a.m_out = m_out; a.y_prev = y_prev_dev; a.n_moves = t > 0 ? n_moves : 0;
-  a.move_scale = move_scale; a.accepted = accepted;
+  a.move_scale = move_scale; a.accepted = accepted; a.x_moved = t > 0 ? x_moved_out : nullptr;
   const int nblocks = (int)((K + 255) / 256);
   const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm_move<GJX_RNG_JAX32>(a, m->dx, nblocks, st)
                                            : launch_ssm_move<GJX_RNG_FLAT>(a, m->dx, nblocks, st);
@@ -1218,7 +1226,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
         a.key = key2{h_keys[0], h_keys[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
         a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
         a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
-        a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+        a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
         const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
         if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
         GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
@@ -1231,7 +1239,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready;
       f.peer_data = nullptr; f.peer_flag = nullptr; f.keys = keys_dev; f.us = us_dev;
       f.lse_steps = lse_steps; f.ancestors = ancestors; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
-      f.first_budget = 1u << 17; f.zero_ptr = nullptr; f.zero_n = 0;
+      f.first_budget = 1u << 16; f.zero_ptr = nullptr; f.zero_n = 0;
       void* args[] = {&f};
       e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
       if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(k_pf_persistent)");
@@ -1278,7 +1286,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       a.key = key2{kp0[0], kp0[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
       a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
       a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
-      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
       const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
       if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
       GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
@@ -1289,7 +1297,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     f.keys = keys_dev; f.us = us_dev; f.lse_steps = lse_steps; f.ancestors = ancestors;
     f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
     f.timeline = nullptr;
-    if (const char* e2 = getenv("GJX_STEP_TIMELINE_PTR")) f.timeline = (unsigned long long*)strtoull(e2, nullptr, 0);
+    f.timeline = gjx::debug_timeline(128 * (size_t)pblk);
     void* args[] = {&f};
     e = hipLaunchKernel(pers_fn, dim3((unsigned)pblk), dim3((unsigned)pthreads), args, 0, st);
     if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(persistent)");
@@ -1318,7 +1326,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       a.x_prev = t > 0 ? x_prev : nullptr; a.anc = nullptr; a.x_out = x_out; a.logw = lw_of(t);
       a.partials = part_of(t); a.ticket = (unsigned*)ws1; a.lse = t == T - 1 ? lse_steps + 4 * (size_t)t : nullptr;
       a.log_k_total = (float)log((double)K);
-      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr;
+      a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
       if (t == 0) {
         const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
         if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
@@ -1338,7 +1346,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       f.agg = (unsigned long long*)(ws2 + kWsHeaderBytes);
       f.ctrl = (unsigned*)ws2 + 8;
       f.timeline = nullptr;   // debug: phase stamps of the middle step (profiles/microbench/ssm_timeline.py)
-      if (const char* e = t == T / 2 ? getenv("GJX_STEP_TIMELINE_PTR") : nullptr) f.timeline = (unsigned long long*)strtoull(e, nullptr, 0);
+      if (t == T / 2) f.timeline = gjx::debug_timeline(64 * (size_t)nblk);
       void* args[] = {&f};
       const hipError_t e = hipLaunchKernel(fused_fn, dim3((unsigned)nblk), dim3(256), args, 0, st);
       if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(fused step)");

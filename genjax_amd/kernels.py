@@ -132,9 +132,9 @@ class RunPartials:
     reduce them in their own prologue (resample_gather / resample_indices, ``partials=``) save the producer's serial
     LSE tail.  Valid only until the same workspace is used by another run."""
 
-    def __init__(self, ws, gen, prog, K, offset):
+    def __init__(self, ws, gen, prog, K, offset, n=None):
         self.ws, self.gen, self.prog, self.K, self.offset = ws, gen, prog, K, offset
-        self._n = None
+        self._n = n                     # the grid the run actually launched (recorded right after the call)
 
     def valid(self) -> bool:
         return getattr(self.ws, "_gjx_gen", None) == self.gen
@@ -184,7 +184,7 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     ws._gjx_gen = getattr(ws, "_gjx_gen", 0) + 1
     res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws)
     if lse is None:
-        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset))
+        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset), int(load().gjx_last_run_partials()))
     if ss is not None:
         res["site_scores"] = ss
     return res
@@ -290,11 +290,17 @@ def resample_indices(x: torch.Tensor, u: float, N: int | None = None, is_log=Tru
         mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
     else:
         mode, lp, npart = int(bool(is_log)), _ptr(lse), 0
-    if K > (1 << 22) and (cum is None or bt is None):      # beyond the co-resident grid: fallback needs the buffers
-        cum = torch.empty(K, dtype=torch.int64, device=x.device)
-        bt = torch.empty(2, dtype=torch.int64, device=x.device)
-    check(load().gjx_resample_indices(_ptr(x), K, mode, lp, npart, float(u), N, _ptr(anc), _ptr(cum), _ptr(bt), _ptr(lse_out),
-                                      int(K_total or K), _ptr(ws), ws.numel(), _stream()), "gjx_resample_indices")
+    def call(cum_, bt_):
+        return load().gjx_resample_indices(_ptr(x), K, mode, lp, npart, float(u), N, _ptr(anc), _ptr(cum_), _ptr(bt_), _ptr(lse_out),
+                                           int(K_total or K), _ptr(ws), ws.numel(), _stream())
+
+    rc = call(cum, bt)
+    if rc == A.EUNSUPPORTED and (cum is None or bt is None):
+        # the grid would not be co-resident on THIS device (its capacity is the library's to know: a partitioned or smaller
+        # GPU holds fewer blocks than a full MI355X): the three-launch path needs the prefix-sum buffers
+        rc = call(torch.empty(K, dtype=torch.int64, device=x.device) if cum is None else cum,
+                  torch.empty(2, dtype=torch.int64, device=x.device) if bt is None else bt)
+    check(rc, "gjx_resample_indices")
     return anc
 
 
@@ -697,7 +703,7 @@ def ssm_step(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, anc, y, x_out=None, log
 
 
 def ssm_step_move(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, m_prev, anc, y_prev, y, n_moves, move_scale, x_out=None,
-                  m_out=None, logw=None, accepted=None, lse=None, offset=0, K_total=None, ws=None, device=None):
+                  m_out=None, logw=None, accepted=None, lse=None, offset=0, K_total=None, ws=None, device=None, x_moved=None):
     """gjx_ssm_step_move: resample-move rejuvenation of x_{t-1} fused in front of the propagate + reweight step"""
     dev = _dev(device) if x_prev is None else x_prev.device
     f32 = torch.float32
@@ -710,7 +716,7 @@ def ssm_step_move(ssm: A.GjxSsm, key, rng_mode, t, K, x_prev, m_prev, anc, y_pre
     stride = 0 if x_prev is None else x_prev.shape[1]
     check(load().gjx_ssm_step_move(C.byref(ssm), key[0], key[1], rng_mode, int(t), int(K), int(offset), _ptr(x_prev), _ptr(m_prev),
                                    stride, _ptr(anc), _ptr(y_prev), _ptr(y), int(n_moves), float(move_scale), _ptr(x_out),
-                                   _ptr(m_out), _ptr(logw), _ptr(accepted), _ptr(lse), int(K_total or K), _ptr(ws), ws.numel(),
+                                   _ptr(m_out), _ptr(logw), _ptr(accepted), _ptr(x_moved), _ptr(lse), int(K_total or K), _ptr(ws), ws.numel(),
                                    _stream()), "gjx_ssm_step_move")
     return x_out, m_out, logw, lse
 

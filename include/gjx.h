@@ -240,6 +240,10 @@ size_t gjx_workspace_bytes(int op, int64_t K);
  * memory (one-launch resampling, one-launch importance / filter steps).  Synchronises the stream; clears the word. */
 enum { GJX_STATUS_POLL_TIMEOUT = 1, GJX_STATUS_ZERO_TOTAL = 2 };
 int gjx_workspace_status(void* workspace, int32_t* status_host, void* stream);
+/* profiling hook of profiles/microbench/: registers a device buffer into which the co-resident kernels write per-block
+ * phase stamps (s_memrealtime) while it is registered and large enough for their grid (8 or 16 u64 per block);
+ * (NULL, 0) unregisters.  Not for production runs. */
+int gjx_debug_timeline(void* device_buffer, size_t bytes);
 
 /* One SMC importance step in ONE launch on one GPU (smc.py:298-315 + 96-97 + the cookbook's resample-and-gather):
  * propagate + reweight every particle, global log-sum-exp, fixed-point prefix sums of the weights, systematic
@@ -297,6 +301,9 @@ int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* ls
  *                pairs rides in this call's prologue (no serial tail in the producing kernel) and, if lse_out is
  *                not NULL, the finished record {max, sumexp, lse, lse - log K_total} is written there. */
 int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_offset);
+/* the number of block pairs the LAST gjx_run_program call of the calling thread left in its workspace (the grid it
+ * actually launched): record it right after the call; gjx_run_partials_count re-derives a plan and is for sizing only */
+int gjx_last_run_partials(void);
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:
@@ -435,12 +442,14 @@ int gjx_ssm_step(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mod
  * tests/inference/test_requests.py:131-137): the resampled x_{t-1} takes n_moves random-walk Metropolis steps (scale
  * move_scale) that leave p(x_{t-1} | its parent, y_{t-1}) invariant — proposal, both densities and the accept fused into
  * the step kernel — and is then propagated.  m_prev f32[dx][K] = E[x_{t-1} | parent] written by the previous call as its
- * m_out (ignored at t <= 1: the prior mean is 0); accepted f32[K] = accepted moves per particle, or NULL. */
+ * m_out (ignored at t <= 1: the prior mean is 0); accepted f32[K] = accepted moves per particle, or NULL;
+ * x_moved_out f32[dx][K] (or NULL) = the moved x_{t-1} every slot was propagated from, in slot order (t >= 1) — the
+ * parents a trajectory store must keep instead of the resampled, un-moved ones. */
 int gjx_ssm_step_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t t, int64_t K,
                       int64_t particle_offset, const float* x_prev, const float* m_prev, int64_t prev_stride,
                       const int32_t* anc, const float* y_prev_dev, const float* y_dev, int32_t n_moves, float move_scale,
-                      float* x_out, float* m_out, float* logw, float* accepted, float* lse, int64_t K_total,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      float* x_out, float* m_out, float* logw, float* accepted, float* x_moved_out, float* lse,
+                      int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The whole T-step bootstrap filter on ONE GPU: step 0, then steps 1 .. T-1 in ONE launch when the grid of K / 1024 blocks
  * is co-resident (otherwise one or two launches per step, looped in C++; no host round trip either way):

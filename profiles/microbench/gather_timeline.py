@@ -12,7 +12,9 @@ def go():
     kernels.resample_gather(out["logw"], 0.37, out["choices"], partials=(ws, n_part), lse_out=lse, out=rows, ws=ws2, allow_fallback=False)
 for _ in range(20): go()
 tl = torch.zeros((1024, 8), dtype=torch.int64, device="cuda")
-os.environ["GJX_GATHER_TIMELINE_PTR"] = hex(tl.data_ptr())
+from genjax_amd._lib import load as _load
+import ctypes as _C
+_load().gjx_debug_timeline(_C.c_void_p(tl.data_ptr()), tl.numel() * tl.element_size())
 go(); torch.cuda.synchronize()
 t = tl.cpu().numpy().astype(np.float64); t0 = t[:, 0].min()
 for j, n in [(0, "start"), (1, "tile total published"), (2, "totals gathered"), (6, "prefix of totals"), (7, "source tiles found"), (3, "tile list known"), (4, "ancestors known"), (5, "rows copied (end)")]:

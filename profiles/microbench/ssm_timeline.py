@@ -7,7 +7,9 @@ bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), int(os.environ.g
 ys = torch.as_tensor(s["y"]).cuda()
 bf.run(core.key(1), ys)
 tl = torch.zeros((4096, 8), dtype=torch.int64, device="cuda")
-os.environ["GJX_STEP_TIMELINE_PTR"] = hex(tl.data_ptr())
+from genjax_amd._lib import load as _load
+import ctypes as _C
+_load().gjx_debug_timeline(_C.c_void_p(tl.data_ptr()), tl.numel() * tl.element_size())
 bf.run(core.key(2), ys)
 torch.cuda.synchronize()
 t = tl.cpu().numpy().astype(np.float64)

@@ -5,7 +5,9 @@ prog, _ = workloads.gmm_program(D=16, C=8)
 K = 1 << 20
 out = K_.importance_step(prog, (0, 7), K, 0.3718, allow_fallback=False)
 tl = torch.zeros((1024, 8), dtype=torch.int64, device="cuda")
-os.environ["GJX_STEP_TIMELINE_PTR"] = hex(tl.data_ptr())
+from genjax_amd._lib import load as _load
+import ctypes as _C
+_load().gjx_debug_timeline(_C.c_void_p(tl.data_ptr()), tl.numel() * tl.element_size())
 for i in range(3):
     K_.importance_step(prog, (0, 7 + i), K, 0.3718, out=out, allow_fallback=False)
 torch.cuda.synchronize()

@@ -133,9 +133,12 @@ def test_bench_launcher_spawns_its_own_ranks():
     one = _run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--k-per-gpu", str(1 << 17)])
     two = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--k-per-gpu", str(1 << 16)], env)
     assert two["n_gpus"] == 2 and two["config"]["k_particles_total"] == 1 << 17
-    assert two["config"]["exchange"] == ("rccl" if multi else "torch")
-    if multi:
+    # peer-mapped windows when the ranks can map each other's memory (always on one shared GPU), else the collective transport
+    assert two["config"]["exchange"] in (("peer", "rccl") if multi else ("peer",))
+    if two["config"]["exchange"] == "rccl":
         assert two["config"]["exchange_stats"]["rccl_ranks"] == 2
+    else:
+        assert two["config"]["exchange_stats"]["status"] == 0
     # same global collection, same global stream: the log-ML estimates agree to LSE rounding
     assert abs(two["log_ml"] - one["log_ml"]) <= 2e-5 * abs(one["log_ml"])
 
@@ -145,10 +148,18 @@ def test_bench_launcher_config4_ssm():
     of the same K to LSE rounding (small K and T here; the full size is bench.py --workload ssm --gpus 8)."""
     multi = _n_gpus() >= 2
     env = {} if multi else {"GJX_ALL_ON_DEVICE0": "1", "GJX_DIST_BACKEND": "gloo"}
-    # (the sharded exchange quantises against the global maximum: compare with the one-GPU run under the same scheme)
-    one = _run_bench(["--workload", "ssm", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total", str(1 << 14),
-                      "--ssm-weights", "global_max"])
+    # default scheme on both sides: tile-scaled weights, on two ranks through the peer-mapped windows (same granules, same
+    # integers: the log-ML differs only by the summation order of the LSE records); then the collective transport with
+    # global-maximum weights against the one-GPU run under that scheme
+    one = _run_bench(["--workload", "ssm", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total", str(1 << 14)])
     two = _run_bench(["--workload", "ssm", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total",
                       str(1 << 14)], env)
     assert two["n_gpus"] == 2 and two["config"]["k_particles_total"] == 1 << 14 and two["config"]["k_particles_per_gpu"] == 1 << 13
+    assert two["config"]["exchange"] in (("peer", "rccl") if multi else ("peer",))
     assert abs(two["log_ml"] - one["log_ml"]) <= 1e-5 * abs(one["log_ml"])
+    one_g = _run_bench(["--workload", "ssm", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total", str(1 << 14),
+                        "--ssm-weights", "global_max"])
+    two_g = _run_bench(["--workload", "ssm", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--ssm-k-total",
+                        str(1 << 14), "--ssm-weights", "global_max"], env)
+    assert two_g["config"]["exchange"] in (("rccl", "torch") if multi else ("torch",))
+    assert abs(two_g["log_ml"] - one_g["log_ml"]) <= 1e-5 * abs(one_g["log_ml"])

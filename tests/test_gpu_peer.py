@@ -190,3 +190,58 @@ def test_peer_resample_gather_equals_unsharded(world, shape):
     assert all(r[2] in (0,) for r in res), [r[2] for r in res]
     if world > 1:
         assert crossing > 0                     # children did cross rank boundaries
+
+
+_TRACE_SCRIPT = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from genjax_amd import core, workloads
+from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+T = int(sys.argv[1])
+s = workloads.ssm_problem(T=T)
+bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 15, weights="tile_scaled")
+ys = torch.as_tensor(np.asarray(s["y"], np.float32)).cuda()
+for rep in range(3):
+    out = bf._run_peer(core.key(3 + rep), ys, torch.device("cuda", 0), 1, True)     # the sharded path, one rank
+print("LOGML", float(out["log_ml"]))
+bf.close()
+'''
+
+
+def _hip_api_counts(tmp, T):
+    import csv
+    import glob
+    import subprocess
+    import sys
+    d = os.path.join(tmp, "trace_T%d" % T)
+    script = os.path.join(tmp, "run_T%d.py" % T)
+    with open(script, "w") as f:
+        f.write(_TRACE_SCRIPT % dict(root=ROOT))
+    env = dict(os.environ, TMPDIR=tmp, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["rocprofv3", "--hip-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, script, str(T)],
+                       cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LOGML" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    files = glob.glob(os.path.join(d, "**", "*hip_api_stats.csv"), recursive=True)
+    assert files, os.listdir(d)
+    counts = {}
+    for row in csv.DictReader(open(files[0])):
+        counts[row["Name"]] = counts.get(row["Name"], 0) + int(row["Calls"])
+    return counts
+
+
+def test_sharded_filter_host_calls_do_not_depend_on_T(tmp_path):
+    """Zero host involvement inside the T loop of the sharded filter, shown with a HIP-API trace (rocprofv3 --hip-trace):
+    the number of kernel launches, synchronisations, copies and allocations of a process that runs the sharded filter
+    three times is THE SAME for T = 8 and T = 128 steps."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    a = _hip_api_counts(str(tmp_path), 8)
+    b = _hip_api_counts(str(tmp_path), 128)
+    watched = [n for n in set(a) | set(b) if any(k in n for k in ("Synchronize", "Memcpy", "Memset", "Launch", "Malloc", "Free", "EventQuery", "StreamWait"))]
+    assert any("Launch" in n for n in watched) and any("Synchronize" in n for n in watched), sorted(a)
+    diff = {n: (a.get(n, 0), b.get(n, 0)) for n in watched if a.get(n, 0) != b.get(n, 0)}
+    assert not diff, diff
+    launches = sum(v for n, v in b.items() if "LaunchKernel" in n)
+    assert launches < 200, launches               # 3 runs x 2 launches + torch's own fills / copies, not 3 x 128 x anything

@@ -100,4 +100,21 @@ def test_resample_move_filter_keeps_the_estimate_and_restores_diversity():
     # the parents actually used at the last step: plain filter duplicates them, the moved filter does not
     pa = a["history"].states[-2][0][a["history"].ancestors[-1].long()]
     assert int(torch.unique(pa).numel()) < K * 0.9
-    assert b["history"] is not None
+    # the moved filter's history holds the parents that were actually propagated (the MOVED x_{t-1}, with their lineage):
+    # along every reconstructed trajectory x_t - A x_{t-1} is the propagation noise (std a little under q: the surviving
+    # trajectories are selected by the later observations) exactly as in the plain filter — with the un-moved parents it
+    # would carry the move's displacement on top — and the smoothed means agree with the RTS smoother like the plain filter's
+    ms, Ps = cf.rts_smoother(s["A"], s["y"], s["q"], s["r"])
+    sd = np.sqrt(np.stack([np.diag(P) for P in Ps]))
+    Am = torch.as_tensor(np.asarray(s["A"], np.float32)).cuda()
+    stds = {}
+    for out, name in ((a, "plain"), (b, "moved")):
+        h = out["history"]
+        paths = h.paths()                                            # [T][dx][K]
+        resid = paths[1:] - torch.einsum("de,tek->tdk", Am, paths[:-1])
+        stds[name] = float(resid.std())
+        assert 0.9 * s["q"] < stds[name] < 1.02 * s["q"], stds
+        got = _np(h.smoothed_means()).astype(np.float64)
+        assert np.abs(got[-4:] - ms[-4:]).max() < 0.05 * sd.max(), name
+        assert np.abs(got - ms).max() < 0.25 * sd.max(), name
+    assert abs(stds["moved"] - stds["plain"]) < 0.02 * s["q"], stds

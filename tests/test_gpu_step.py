@@ -92,6 +92,14 @@ def test_importance_step_unsupported_sizes_fall_back(K_):
         del os.environ["GJX_CORESIDENT_BLOCKS"]
     anc2 = K_.resample_indices(lw, 0.25, lse=K_.logsumexp(lw))
     assert torch.equal(anc, anc2)
+    # a device that holds even fewer blocks (a partition, a smaller GPU): the wrapper asks the library, gets GJX_EUNSUPPORTED
+    # for the one-launch form and retries on the three-launch path with prefix-sum buffers of its own (no size constant)
+    os.environ["GJX_CORESIDENT_BLOCKS"] = "4"
+    try:
+        anc3 = K_.resample_indices(lw, 0.25, lse=K_.logsumexp(lw))
+    finally:
+        del os.environ["GJX_CORESIDENT_BLOCKS"]
+    assert torch.equal(anc3, anc2)
 
 
 def test_one_launch_resampler_under_concurrent_load(K_, oracle):
@@ -143,3 +151,34 @@ def test_dead_collection_gives_identity_ancestors_and_status(K_):
     lw[17] = 0.0
     anc = K_.resample_indices(lw, 0.5, lse=K_.logsumexp(lw), ws=ws)
     assert int((anc != 17).sum()) == 0 and K_.workspace_status(ws) == 0
+
+
+def test_filter_and_resampler_fail_soft_when_the_grid_is_not_coresident(K_):
+    """A co-resident kernel whose grid does not fit (here: the launcher is told the device holds far more blocks than it
+    does; in production: another stream holds compute units) runs out of its ~0.1 s poll budget and flags the workspace.
+    BootstrapFilter.run and inference.pf.resample(check=True) then repeat the call on the plain multi-launch path, warn
+    once, and return the SAME result as an undisturbed call — they do not raise."""
+    import warnings
+    import torch
+    from genjax_amd import core, workloads
+    from genjax_amd.inference import pf
+    s = workloads.ssm_problem(T=10)
+    K = 1 << 20
+    bf = pf.BootstrapFilter(pf.LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights="tile_scaled")
+    ref = bf.run(core.key(5), s["y"])
+    rows = torch.randn(2, 1 << 22, device="cuda")
+    lw = torch.randn(1 << 22, device="cuda") * 1.5
+    ref_rows, ref_anc = pf.resample(rows, lw, core.key(8), check=True)
+    pf._warned_timeout[0] = False
+    os.environ["GJX_CORESIDENT_BLOCKS"] = "100000"
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = bf.run(core.key(5), s["y"])
+            got_rows, got_anc = pf.resample(rows, lw, core.key(8), check=True)
+        assert sum("timed out" in str(x.message) for x in w) == 1          # logged once
+    finally:
+        del os.environ["GJX_CORESIDENT_BLOCKS"]
+    assert torch.equal(got["x"], ref["x"]) and torch.equal(got["logw"], ref["logw"]) and not got["degenerate"]
+    np.testing.assert_allclose(_np(got["increments"]), _np(ref["increments"]), rtol=2e-6, atol=2e-6)
+    assert torch.equal(got_anc, ref_anc) and torch.equal(got_rows, ref_rows)
