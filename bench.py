@@ -525,6 +525,66 @@ def run_hmc_generic(dev):
                 note="generic site-list HMC kernel on the config-5 model (the fused MFMA kernel is extra.hmc)")
 
 
+def run_hmc_generated(dev):
+    """HMC kernels GENERATED from the site list (gjx_hmc engine 4) at 2^16 chains: the config-5 model through the generated
+    kernel next to the hand-written matrix-core kernel, and two targets that have no hand-written kernel — a hierarchy with
+    latent shape parameters (digamma gradients) and a 16-step observed random-walk Scan — generated vs site interpreter."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels, workloads
+    from genjax_amd.program import PackedProgram
+    n = 1 << 16
+
+    def timed(prog, ch0, eps, L, engine, reps=3):
+        old = os.environ.get("GJX_HMC_ENGINE")
+        os.environ["GJX_HMC_ENGINE"] = engine
+        try:
+            eng = kernels.hmc_engine(prog)
+            ch = ch0.clone()
+            out = kernels.hmc(prog, (1, 2), ch, eps, L, False, True)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(reps):
+                out = kernels.hmc(prog, (1, 3 + i), ch, eps, L, False, True, ws=out["_ws"])
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / reps
+        finally:
+            if old is None:
+                del os.environ["GJX_HMC_ENGINE"]
+            else:
+                os.environ["GJX_HMC_ENGINE"] = old
+        return dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=n * L / (ms * 1e-3), accept_rate=float(out["accepted"].mean()))
+
+    res = {}
+    N, P = 1024, 16
+    prog, _ = workloads.logreg_program(N=N, P=P)
+    ch = torch.as_tensor((np.random.default_rng(0).standard_normal((P + 1, n)) * 0.1).astype(np.float32), device=dev)
+    g = timed(prog, ch, 0.01, 100, "gen")
+    f = timed(prog, ch, 0.01, 100, "fused")
+    flops = n * 100 * (2 * 2 * N * P + 10 * N)
+    g["tflops"] = flops / (g["ms_per_move"] * 1e-3) / 1e12
+    g["vs_hand_written_mfma_kernel"] = g["chain_leapfrogs_per_sec"] / f["chain_leapfrogs_per_sec"]
+    res["hier_logreg_N1024_P16_L100"] = dict(generated=g, hand_written=f)
+    sl = H.shape_hierarchy()
+    hp = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=("la", "lb"))
+    from oracle import cpu                      # (start states only: a draw from the prior through the CPU checker, outside any timing)
+    base = cpu.run_program(PackedProgram(sl), (3, 4), 4096)["choices"].astype(np.float32)
+    ch = torch.as_tensor(np.tile(base, (1, n // 4096)), device=dev)
+    gi, ii = timed(hp, ch, 0.002, 200, "gen"), timed(hp, ch, 0.002, 200, "interp", reps=1)
+    res["shape_hierarchy_L200"] = dict(generated=gi, interpreter=ii, speedup=ii["ms_per_move"] / gi["ms_per_move"])
+    sp, ys = H.scan_chain(16, carry=True, observe=True, sigma=0.3, r=0.5)
+    ssl = sp.site_list
+    modes = {s.addr: (A.MODE_OBS_TAB if s.addr[0] == "y" else A.MODE_OBS_SLOT) for s in ssl.sites}
+    scp = PackedProgram(ssl, modes, {("y", t): ys[t] for t in range(16)}, selected=tuple(("x", t) for t in range(16)))
+    ch = torch.as_tensor((np.random.default_rng(6).standard_normal((16, n)) * 0.3).astype(np.float32), device=dev)
+    gi, ii = timed(scp, ch, 0.02, 200, "gen"), timed(scp, ch, 0.02, 200, "interp", reps=1)
+    res["scan_T16_L200"] = dict(generated=gi, interpreter=ii, speedup=ii["ms_per_move"] / gi["ms_per_move"])
+    return res
+
+
 def run_api(dev, K, steps=100):
     """The gmm step through the public API instead of a hand-built program: @gen body -> Target -> ImportanceK.run_smc
     -> N-of-K systematic resampling (inference.pf.resample).  The traced site list and the packed program (table on the
@@ -812,6 +872,10 @@ def main():
             extra["sharded_one_rank"] = dict(error=repr(e))
         extra["codegen"] = run_codegen(dev)
         extra["hmc_generic"] = run_hmc_generic(dev)
+        try:
+            extra["hmc_generated"] = run_hmc_generated(dev)
+        except Exception as e:
+            extra["hmc_generated"] = dict(error=repr(e))
         api = run_api(dev, args.k_per_gpu)
         api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
         extra["api"] = api

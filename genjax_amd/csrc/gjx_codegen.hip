@@ -611,6 +611,230 @@ std::string generate(const gjx_program* prog_in, int ppt) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Generated HMC kernels.  The reference differentiates ANY model with jax.grad over gen_fn.assess and lets XLA fuse the
+// leapfrog loop (inference/requests/hmc.py:70-96, 156-211).  Here the site list becomes ONE straight-line kernel
+// `gjx_hmc_gen`: the chain's values, gradient, momenta and (compat mode) initial gradient live in registers for the
+// whole trajectory; a sweep over the sites computes the score and its ANALYTIC gradient in one forward pass (every
+// parameter form reads value slots directly, so d score / d slot is a sum of per-site terms: dlogpdf x the parameter's
+// transform derivative x the affine row) and is emitted twice — with and without the score, which only the two ends of the
+// trajectory need; the float table sits in LDS; L leapfrog steps and the MH accept run inside the kernel.  A site with
+// more than kMaxExpandDim elements (an observed plate: the N rows of a regression likelihood) is a rolled loop whose
+// elements are dealt round-robin to the CPL = 4 lanes that share a chain — each lane accumulates its part of the score and
+// of the gradient rows, joined by two DPP butterflies per accumulator at the end of the site — so a program with a big
+// likelihood runs 4 waves per SIMD instead of 1.  Streams, semantics and results: k_hmc_generic's (gjx_hmc.hip), to
+// float summation order.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHmcMaxSel = 48, kHmcMaxSlots = 96, kHmcMaxTab = 36864;   // 144 KB of LDS for the table
+
+struct HmcPlan {
+  int nsel = 0;
+  std::vector<int> sel_of_slot;    // slot -> index among the selected slots, or -1
+  std::vector<int> slot_of_sel;
+  bool looped = false;             // some site is a rolled loop (CPL = 4)
+};
+
+bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIRICHLET; }
+
+bool hmc_plan(const gjx_program* p, HmcPlan* out) {
+  if (p->n_sites < 1 || p->n_sites > 64 || p->n_slots < 1 || p->n_slots > kHmcMaxSlots || p->n_tab > kHmcMaxTab) return false;
+  HmcPlan pl;
+  pl.sel_of_slot.assign(p->n_slots, -1);
+  int unrolled = 0;
+  for (int j = 0; j < p->n_sites; ++j) {
+    const gjx_site& s = p->sites[j];
+    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
+    if (s.mode != GJX_MODE_OBS_TAB && s.mode != GJX_MODE_OBS_SLOT) return false;
+    if (is_categorical(s.kind)) {
+      if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
+      if (s.ncat < 1 || s.ncat > 64 || (s.flags & GJX_SITE_HMC_SELECTED)) return false;
+      continue;
+    }
+    if (s.dim < 1) return false;
+    const bool big = s.dim > kMaxExpandDim;
+    if (big && (s.slot >= 0 || (s.flags & GJX_SITE_HMC_SELECTED))) return false;   // a rolled site reads its values from the table
+    for (int k = 0; k < n_params(s.kind); ++k) {
+      const gjx_param& q = s.p[k];
+      if (q.op < GJX_P_CONST || q.op > GJX_P_AFFINE) return false;
+      if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
+      if (big && q.op == GJX_P_VALUE && q.len != 1) return false;
+    }
+    if (big) pl.looped = true; else unrolled += s.dim;
+    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0)
+      for (int d = 0; d < s.dim; ++d) { pl.sel_of_slot[s.slot + d] = pl.nsel++; pl.slot_of_sel.push_back(s.slot + d); }
+  }
+  if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
+  *out = pl;
+  return true;
+}
+
+// one element of site j: parameters, (score,) gradient terms.  dx: element index expression (a literal, or "d_" in a rolled
+// site); acc: name of the gradient accumulator array indexed by SELECTED-slot index ("g" or the site's partial "ga")
+void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j, const std::string& dx, bool dyn, const char* acc,
+                      const char* sc, const char* ind) {
+  const gjx_site& s = prog->sites[j];
+  const int np = n_params(s.kind);
+  const bool tab_lds = true;
+  (void)tab_lds;
+  o.f("%s{\n", ind);
+  for (int k = 0; k < 4; ++k) {
+    if (k >= np) { o.f("%s  const float par_%d = 0.0f;\n", ind, k); continue; }
+    const gjx_param& q = s.p[k];
+    const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
+    switch (q.op) {
+      case GJX_P_CONST: o.f("%s  const float pre_%d = TAB(%d + %s);\n", ind, k, q.off, e.c_str()); break;
+      case GJX_P_GATHER: o.f("%s  const float pre_%d = TAB(%d + gi_%d_%d * %d + %s);\n", ind, k, q.off, j, k, q.len, e.c_str()); break;
+      case GJX_P_VALUE:
+        if (q.len == 1) o.f("%s  const float pre_%d = v[%d];\n", ind, k, q.slot);
+        else o.f("%s  const float pre_%d = v[%d + %s];\n", ind, k, q.slot, e.c_str());   // (unrolled sites only: literal index)
+        break;
+      default: {   // AFFINE: the row stays in registers for the gradient
+        o.f("%s  float row_%d[%d];\n", ind, k, q.n);
+        if (q.moff % 4 == 0 && q.n % 4 == 0)
+          o.f("%s  { const float4* r4_ = (const float4*)&TAB(%d + (%s) * %d); _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) { const float4 t_ = r4_[e_]; "
+              "row_%d[4 * e_] = t_.x; row_%d[4 * e_ + 1] = t_.y; row_%d[4 * e_ + 2] = t_.z; row_%d[4 * e_ + 3] = t_.w; } }\n",
+              ind, q.moff, dx.c_str(), q.n, q.n / 4, k, k, k, k);
+        else
+          o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) row_%d[e_] = TAB(%d + (%s) * %d + e_);\n", ind, q.n, k, q.moff, dx.c_str(), q.n);
+        o.f("%s  float pre_%d = TAB(%d + %s);\n", ind, k, q.off, e.c_str());
+        o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) pre_%d = fmaf(row_%d[e_], v[%d + e_], pre_%d);\n", ind, q.n, k, k, q.slot, k);
+      }
+    }
+    o.f("%s  const float par_%d = %s;\n", ind, k, xf_wrap(q.xf, "pre_" + std::to_string(k)).c_str());
+  }
+  if (s.slot >= 0) o.f("%s  const float x_ = v[%d + %s];\n", ind, s.slot, dx.c_str());
+  else o.f("%s  const float x_ = TAB(%d + %s);\n", ind, s.obs_off, dx.c_str());
+  o.f("%s  if (SC) %s += elem_logpdf(%d, x_, par_0, par_1, par_2, par_3);\n", ind, sc, s.kind);
+  o.f("%s  float gx_, gp_[4];\n%s  dlogpdf(%d, x_, par_0, par_1, par_2, par_3, gx_, gp_);\n", ind, ind, s.kind);
+  if (s.slot >= 0 && !dyn) {
+    const int m = hp.sel_of_slot[s.slot + atoi(dx.c_str())];
+    if (m >= 0) o.f("%s  %s[%d] += gx_;\n", ind, acc, m);
+  }
+  for (int k = 0; k < np; ++k) {
+    const gjx_param& q = s.p[k];
+    if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE) continue;
+    const std::string w = q.xf == GJX_XF_NONE ? "gp_[" + std::to_string(k) + "]"
+                                              : "(gp_[" + std::to_string(k) + "] * xf_deriv(" + std::to_string(q.xf) + ", pre_" + std::to_string(k) + "))";
+    if (q.op == GJX_P_VALUE) {
+      const int src = q.slot + (q.len == 1 ? 0 : atoi(dx.c_str()) % q.len);
+      const int m = hp.sel_of_slot[src];
+      if (m >= 0) o.f("%s  %s[%d] += %s;\n", ind, acc, m, w.c_str());
+    } else {
+      bool any = false;
+      for (int e = 0; e < q.n; ++e) any = any || hp.sel_of_slot[q.slot + e] >= 0;
+      if (!any) continue;
+      o.f("%s  { const float w_ = %s;\n", ind, w.c_str());
+      for (int e = 0; e < q.n; ++e) {
+        const int m = hp.sel_of_slot[q.slot + e];
+        if (m >= 0) o.f("%s    %s[%d] = fmaf(w_, row_%d[%d], %s[%d]);\n", ind, acc, m, k, e, acc, m);
+      }
+      o.f("%s  }\n", ind);
+    }
+  }
+  o.f("%s}\n", ind);
+}
+
+std::string generate_hmc(const gjx_program* prog) {
+  HmcPlan hp;
+  if (!hmc_plan(prog, &hp)) return "";
+  const int cpl = hp.looped ? 4 : 1;
+  const int NS = prog->n_slots, NSEL = hp.nsel;
+  Emit o;
+  o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define CPL %d\n#define NS %d\n#define NSEL %d\n#define NTAB %d\n",
+      prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, cpl, NS, NSEL, prog->n_tab);
+  o.f("#define TAB(i) tab_s[i]\n");
+  // ---- the sweep: score (SC) and gradient of the selected slots
+  o.f("template <bool SC>\nGJX_DEV float sweep(const float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const int q_) {\n"
+      "  float sc_ = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
+  for (int j = 0; j < prog->n_sites; ++j) {
+    const gjx_site& s = prog->sites[j];
+    const int np = n_params(s.kind);
+    o.f("  { // ---- site %d: kind %d, dim %d, slot %d\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot);
+    for (int k = 0; k < np; ++k) {
+      const gjx_param& q = s.p[k];
+      if (q.op == GJX_P_GATHER)
+        o.f("    int gi_%d_%d; { const int g_ = (int)v[%d]; gi_%d_%d = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", j, k, q.slot, j, k, q.n - 1, q.n - 1);
+    }
+    if (is_categorical(s.kind)) {   // an integer site: scored, no gradient through it (hmc.py:49-65; k_hmc_generic)
+      const gjx_param& q = s.p[0];
+      const bool probs = s.kind == GJX_CATEGORICAL_PROBS;
+      std::string L = "TAB(" + std::to_string(q.off) + (q.op == GJX_P_GATHER ? " + gi_" + std::to_string(j) + "_0 * " + std::to_string(q.len) : "") +
+                      " + (c_) % " + std::to_string(q.len) + ")";
+      L = xf_wrap(q.xf, L);
+      if (probs) L = "safe_log(" + L + ")";
+      o.f("    if (SC) {\n      float mx = -INFINITY;\n      for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, %s);\n", s.ncat, L.c_str());
+      o.f("      float se = 0.0f;\n      for (int c_ = 0; c_ < %d; ++c_) se += fast_exp(%s - mx);\n", s.ncat, L.c_str());
+      if (s.slot >= 0) o.f("      const float val_ = v[%d];\n", s.slot);
+      else o.f("      const float val_ = TAB(%d);\n", s.obs_off);
+      o.f("      int k_ = (int)val_;\n      k_ = k_ < 0 ? 0 : (k_ > %d ? %d : k_);\n      { const int c_ = k_; sc_ += %s - (mx + fast_log(se)); }\n    }\n",
+          s.ncat - 1, s.ncat - 1, L.c_str());
+    } else if (s.dim <= kMaxExpandDim) {
+      for (int d = 0; d < s.dim; ++d) hmc_emit_element(o, prog, hp, j, std::to_string(d), false, "g", "sc_", "    ");
+    } else {
+      // a rolled site: elements dealt round-robin to the CPL lanes of the chain, partial score and gradient rows joined at the end
+      o.f("    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n    float scp_ = 0.0f;\n");
+      o.f("    _Pragma(\"unroll 2\") for (int d_ = q_; d_ < %d; d_ += CPL) {\n", s.dim);
+      hmc_emit_element(o, prog, hp, j, "d_", true, "ga", "scp_", "      ");
+      o.f("    }\n");
+      // which accumulators the site touches
+      std::vector<char> touched(NSEL, 0);
+      for (int k = 0; k < np; ++k) {
+        const gjx_param& q = s.p[k];
+        if (q.op == GJX_P_VALUE && hp.sel_of_slot[q.slot] >= 0) touched[hp.sel_of_slot[q.slot]] = 1;
+        if (q.op == GJX_P_AFFINE) for (int e = 0; e < q.n; ++e) if (hp.sel_of_slot[q.slot + e] >= 0) touched[hp.sel_of_slot[q.slot + e]] = 1;
+      }
+      for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? quad_sum(ga[%d]) : ga[%d];\n", m, m, m);
+      o.f("    if (SC) sc_ += CPL > 1 ? quad_sum(scp_) : scp_;\n");
+    }
+    o.f("  }\n");
+  }
+  o.f("  return sc_;\n}\n\n");
+  // ---- the kernel
+  o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_hmc_gen(HmcGenArgs a) {\n"
+      "  __shared__ __attribute__((aligned(16))) float tab_s[NTAB > 0 ? ((NTAB + 3) & ~3) : 4];\n"
+      "  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n"
+      "  const int q_ = (int)threadIdx.x %% CPL;\n"
+      "  const int64_t i_raw = ((int64_t)blockIdx.x * 256 + threadIdx.x) / CPL;\n"
+      "  const bool live = i_raw < a.n;\n  const int64_t n = a.n, i = live ? i_raw : a.n - 1;   // (every lane runs: the quads reduce across lanes)\n"
+      "  const uint64_t gidx = (uint64_t)(a.offset + i);\n"
+      "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
+      "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = a.choices[(int64_t)s_ * n + i];\n"
+      "  const float score0 = sweep<true>(v, g, tab_s, q_);   // hmc.py:165-166\n"
+      "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g0[m_] = g[m_];\n"
+      "  key2 knew{0u, 0u}, sub{0u, 0u};\n"
+      "  if (RNG == GJX_RNG_JAX32) { const key2 ck = fold_in64(a.key, gidx); knew = fold_in(ck, 0u); sub = fold_in(ck, 1u); }   // hmc.py:167\n"
+      "  float k0 = 0.0f;\n");
+  {   // momenta (hmc.py:120-130): leaf l = l-th selected address in program order
+    int leaf = 0, m = 0;
+    for (int j = 0; j < prog->n_sites; ++j) {
+      const gjx_site& s = prog->sites[j];
+      if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
+      o.f("  { BitStreamRT<RNG> bs;\n    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, %du)); else bs.open(a.key, gidx, %du);\n", leaf, leaf + 1);
+      for (int d = 0; d < s.dim; ++d, ++m)
+        o.f("    p[%d] = stream_normal<RNG>(bs, %du); k0 += -0.5f * p[%d] * p[%d] - kHalfLog2Pi;\n", m, d, m, m);
+      o.f("  }\n");
+      ++leaf;
+    }
+  }
+  o.f("  const float he = 0.5f * a.eps;\n  float sc = score0;\n"
+      "  for (int t = 1; t <= a.L; ++t) {   // hmc.py:170-194\n"
+      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * (a.stale ? g0[m_] : g[m_]);   // hmc.py:186: the carry keeps the received gradient\n");
+  for (int m = 0; m < NSEL; ++m) o.f("    v[%d] += a.eps * p[%d];\n", hp.slot_of_sel[m], m);
+  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, q_); else (void)sweep<false>(v, g, tab_s, q_);\n"
+      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * g[m_];\n  }\n"
+      "  float k1 = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) { const float q2_ = -1.0f * p[m_]; k1 += -0.5f * q2_ * q2_ - kHalfLog2Pi; }\n"
+      "  const float al = sc - score0 + k1 - k0;   // hmc.py:196-203\n"
+      "  bool acc = true;\n"
+      "  if (a.accept) {\n    BitStream<RNG> bs;\n    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(knew, 0x4d48u)); else bs.open(a.key, gidx, GJX_FLAT_MAX_SITES);\n"
+      "    acc = safe_log(bits_to_unit(bs.get(0u))) < al;   // tests/inference/test_requests.py:134-137\n  }\n"
+      "  if (!acc) sc = score0;\n"
+      "  if (live && q_ == 0) {\n    if (acc) {\n");
+  for (int m = 0; m < NSEL; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", hp.slot_of_sel[m], hp.slot_of_sel[m]);
+  o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n}\n");
+  o.f("// CPL %d\n// LDS_FLOATS 0\n", cpl);
+  return o.s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // hipRTC (resolved at run time: the library must not need it when no program is ever generated)
 // ---------------------------------------------------------------------------------------------------------
 struct Rtc {
@@ -670,6 +894,7 @@ std::string cache_dir() {
 struct Compiled {
   std::vector<char> code;   // code object
   int lds_floats = 0;
+  int cpl = 1;              // generated HMC kernels: lanes per chain
   std::string error;        // non-empty: this structure cannot be generated / compiled
 };
 
@@ -718,22 +943,25 @@ int register_slots(const gjx_program* p) {
   return slots;
 }
 
-uint64_t structure_key(const gjx_program* p, int ppt) {
+uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // flavour 0: propagate+reweight kernel, 1: HMC kernel
   uint64_t h = sites_hash(p);
-  const int32_t extra[6] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0};
+  const int32_t extra[7] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
 }
 
-const Compiled& compile(const gjx_program* prog, int ppt) {
-  const uint64_t key = structure_key(prog, ppt);
+const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
+  const uint64_t key = structure_key(prog, ppt, flavour);
   auto it = g_compiled.find(key);
   if (it != g_compiled.end()) return it->second;
   Compiled& c = g_compiled[key];
-  const std::string src = generate(prog, ppt);
+  const std::string src = flavour == 1 ? generate_hmc(prog) : generate(prog, ppt);
+  if (src.empty()) { c.error = "codegen: program outside the emitter's coverage"; return c; }
   const size_t m = src.rfind("// LDS_FLOATS ");
   c.lds_floats = atoi(src.c_str() + m + 14);
+  const size_t mc = src.rfind("// CPL ");
+  if (mc != std::string::npos) c.cpl = atoi(src.c_str() + mc + 7);
   if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
@@ -760,7 +988,7 @@ const Compiled& compile(const gjx_program* prog, int ppt) {
   hiprtcProgram p;
   const char* hn[] = {"gjx_device.h", "../../include/gjx.h"};
   const char* hs[] = {kDeviceHeader, kApiHeader};
-  if (r.Create(&p, src.c_str(), "gjx_gen.hip", 2, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
+  if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : "gjx_gen.hip", 2, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
   const hiprtcResult rc = r.Compile(p, 3, opts);
   if (rc != HIPRTC_SUCCESS) {
@@ -847,7 +1075,69 @@ int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, 
   return GJX_OK;
 }
 
+// ---- generated HMC kernels (gjx_hmc.hip) ----
+int hmc_gen_available(const gjx_program* prog) {
+  HmcPlan hp;
+  if (!hmc_plan(prog, &hp)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the HMC emitter's coverage");
+  std::lock_guard<std::mutex> lock(g_mu);
+  const Compiled& c = compile(prog, 0, 1);
+  if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+  return GJX_OK;
+}
+
+int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t st) {
+  hipFunction_t fn = nullptr;
+  int cpl = 1;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    const Compiled& c = compile(prog, 0, 1);
+    if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+    cpl = c.cpl;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
+    const auto lk = std::make_pair(structure_key(prog, 0, 1), dev);
+    auto it = g_loaded.find(lk);
+    if (it == g_loaded.end()) {
+      hipModule_t mod;
+      hipError_t e = hipModuleLoadData(&mod, c.code.data());
+      if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleLoadData");
+      e = hipModuleGetFunction(&fn, mod, "gjx_hmc_gen");
+      if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleGetFunction");
+      g_loaded[lk] = std::make_pair(mod, fn);
+    } else {
+      fn = it->second.second;
+    }
+  }
+  HmcGenArgs a = args;
+  size_t sz = sizeof(a);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  const int64_t threads = a.n * cpl;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  const hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, st, nullptr, config);
+  if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch (HMC kernel)");
+  return GJX_OK;
+}
+
 }  // namespace gjx
+
+// source of the generated HMC kernel of a program (GJX_EUNSUPPORTED when the emitter does not cover it)
+extern "C" int64_t gjx_program_hmc_source(const gjx_program* prog, char* out, int64_t cap) {
+  if (!prog || !prog->sites) return GJX_EINVAL;
+  const std::string src = generate_hmc(prog);
+  if (src.empty()) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the HMC emitter's coverage");
+  if (out && cap > 0) {
+    const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
+    memcpy(out, src.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)src.size();
+}
+
+// compile (or load from the disk cache) the generated HMC kernel of a program without launching it
+extern "C" int gjx_program_hmc_precompile(const gjx_program* prog) {
+  if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_hmc_precompile: null program");
+  return gjx::hmc_gen_available(prog);
+}
 
 // the generated source of a program (debugging, tests, docs): returns the length, copies at most cap - 1 characters
 extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap) {

@@ -706,6 +706,128 @@ struct GenArgs {
   float log_k_total;
 };
 
+// ---- arguments of a generated per-program HMC kernel (gjx_codegen.hip emits `extern "C" __global__ void gjx_hmc_gen(HmcGenArgs)`) ----
+struct HmcGenArgs {
+  const float* tab;
+  key2 key;
+  int64_t n, offset;
+  float eps;
+  int L, stale, accept;
+  float* choices;   // [n_slots][n] in / out
+  float* score;     // [n] or NULL
+  float* alpha;     // [n] or NULL
+  float* accepted;  // [n] or NULL
+};
+
+// ---- analytic gradients of the element log-densities (gjx_hmc.hip, generated HMC kernels) ----
+// gradient of elem_logpdf w.r.t. the value and the parameters; g[0..3] = d/d(a, b, c, d).  Shape parameters (gamma / beta
+// concentrations, student-t / chi2 degrees of freedom, inverse-gamma concentration) go through digamma, so HMC over
+// hierarchical shape parameters works as it does under jax.grad (hmc.py:70-96).
+GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, float& dx, float* gpar) {
+  float da = 0.0f, db = 0.0f, dc = 0.0f, dd = 0.0f;
+  dx = 0.0f;
+  auto done = [&]() { gpar[0] = da; gpar[1] = db; gpar[2] = dc; gpar[3] = dd; };
+  switch (kind) {
+    case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
+      const float rc = fast_rcp(c);
+      const float y = (x - b) * rc;
+      const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
+      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc;
+      da = -0.5f * log1p_acc(y * y * fast_rcp(a)) + 0.5f * (a + 1.0f) * y * y * fast_rcp(a * (a + y * y)) - 0.5f * fast_rcp(a) +
+           0.5f * (digamma_f(0.5f * (a + 1.0f)) - digamma_f(0.5f * a));
+      done(); return;
+    }
+    case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb, lo = (c - a) * rb, hi = (d - a) * rb;
+      const float rZ = fast_rcp(normal_interval_mass(lo, hi));
+      const float plo = 0.39894228f * fast_exp(-0.5f * lo * lo) * rZ * rb, phi = 0.39894228f * fast_exp(-0.5f * hi * hi) * rZ * rb;
+      dx = -z * rb;
+      da = z * rb + (phi - plo);
+      db = (z * z - 1.0f) * rb + (hi * phi - lo * plo);
+      dc = plo; dd = -phi;
+      done(); return;
+    }
+    case GJX_POISSON: da = x * fast_rcp(a) - 1.0f; done(); return;
+    case GJX_GEOMETRIC: da = fast_rcp(a) - x * fast_rcp(1.0f - a); done(); return;
+    case GJX_GUMBEL: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float e1 = 1.0f - fast_exp(-z);
+      dx = -e1 * rb; da = e1 * rb; db = (e1 * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_HALF_CAUCHY: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float gq = 2.0f * z * fast_rcp(1.0f + z * z);
+      dx = -gq * rb; da = gq * rb; db = (gq * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_INVERSE_GAMMA: {
+      const float rx = fast_rcp(x);
+      dx = -(a + 1.0f) * rx + b * rx * rx; db = a * fast_rcp(b) - rx; da = fast_log(b) - digamma_f(a) - fast_log(x);
+      done(); return;
+    }
+    case GJX_WEIBULL: {
+      const float lr = fast_log(x * fast_rcp(b));
+      const float t = fast_exp(a * lr);
+      dx = ((a - 1.0f) - a * t) * fast_rcp(x); db = a * (t - 1.0f) * fast_rcp(b); da = fast_rcp(a) + lr * (1.0f - t);
+      done(); return;
+    }
+    case GJX_LOGIT_NORMAL: {
+      const float rb = fast_rcp(b);
+      const float z = (fast_log(x) - log1p_acc(-x) - a) * rb;
+      dx = -z * rb * fast_rcp(x * (1.0f - x)) - fast_rcp(x) + fast_rcp(1.0f - x); da = z * rb; db = (z * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_CHI2: dx = (0.5f * a - 1.0f) * fast_rcp(x) - 0.5f; da = 0.5f * (fast_log(x) - kLn2 - digamma_f(0.5f * a)); done(); return;
+    default: break;
+  }
+  switch (kind) {
+    case GJX_NORMAL:
+    case GJX_MVNORMAL_DIAG: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      dx = -z * rb; da = z * rb; db = (z * z - 1.0f) * rb;
+      break;
+    }
+    case GJX_BERNOULLI_LOGITS: da = x - sigmoid(a); break;
+    case GJX_FLIP: da = (x != 0.0f ? fast_rcp(a) : 0.0f) - (x != 1.0f ? (1.0f - x) * fast_rcp(1.0f - a) : 0.0f); break;
+    case GJX_HALF_NORMAL: { const float ra = fast_rcp(a); const float z = x * ra; dx = -z * ra; da = (z * z - 1.0f) * ra; break; }
+    case GJX_EXPONENTIAL: dx = -a; da = fast_rcp(a) - x; break;
+    case GJX_LAPLACE: { const float s = (float)((x > a) - (x < a)); const float rb = fast_rcp(b); dx = -s * rb; da = s * rb; db = fabsf(x - a) * rb * rb - rb; break; }
+    case GJX_CAUCHY: { const float rb = fast_rcp(b); const float z = (x - a) * rb; const float g = 2.0f * z * fast_rcp(1.0f + z * z); dx = -g * rb; da = g * rb; db = (g * z - 1.0f) * rb; break; }
+    case GJX_LOG_NORMAL: { const float lx = fast_log(x); const float rb = fast_rcp(b); const float z = (lx - a) * rb; dx = (-z * rb - 1.0f) * fast_rcp(x); da = z * rb; db = (z * z - 1.0f) * rb; break; }
+    case GJX_BETA: {
+      const float pab = digamma_f(a + b);
+      dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x);
+      da = fast_log(x) - digamma_f(a) + pab; db = log1p_acc(-x) - digamma_f(b) + pab;
+      break;
+    }
+    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = fast_log(b) + fast_log(x) - digamma_f(a); db = a * fast_rcp(b) - x; break;
+    case GJX_UNIFORM: { const float r = fast_rcp(b - a); da = r; db = -r; break; }
+    default: break;
+  }
+  done();
+}
+
+GJX_DEV float xf_deriv(int xf, float pre) {
+  switch (xf) {
+    case GJX_XF_EXP: return fast_exp(pre);
+    case GJX_XF_SOFTPLUS: return sigmoid(pre);
+    case GJX_XF_SIGMOID: { const float s = sigmoid(pre); return s * (1.0f - s); }
+    default: return 1.0f;
+  }
+}
+
+// sum over the 4 lanes of an aligned lane quad, in every lane of it
+GJX_DEV float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
 // ---- systematic-resampling comb on the fixed-point weight line (shared by gjx_resample.hip / gjx_shard.hip) ----
 // comb threshold of output slot j (identical double arithmetic in the oracle)
 GJX_DEV uint64_t comb_threshold(int64_t j, double u, double step, uint64_t total) {

@@ -6,6 +6,7 @@
 // (what jax.grad of gen_fn.assess computes, without a tape).
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include <string.h>
 
 namespace gjx {
 
@@ -26,107 +27,6 @@ struct HmcArgs {
   float* ws_g0;   // [n_slots][n] gradient at the initial position
   float* ws_old;  // [n_slots][n] pre-move values
 };
-
-// gradient of elem_logpdf w.r.t. the value and the parameters; g[0..3] = d/d(a, b, c, d).  Shape parameters (gamma / beta
-// concentrations, student-t / chi2 degrees of freedom, inverse-gamma concentration) go through digamma, so HMC over
-// hierarchical shape parameters works as it does under jax.grad (hmc.py:70-96).
-GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, float& dx, float* gpar) {
-  float da = 0.0f, db = 0.0f, dc = 0.0f, dd = 0.0f;
-  dx = 0.0f;
-  auto done = [&]() { gpar[0] = da; gpar[1] = db; gpar[2] = dc; gpar[3] = dd; };
-  switch (kind) {
-    case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
-      const float rc = fast_rcp(c);
-      const float y = (x - b) * rc;
-      const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
-      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc;
-      da = -0.5f * log1p_acc(y * y * fast_rcp(a)) + 0.5f * (a + 1.0f) * y * y * fast_rcp(a * (a + y * y)) - 0.5f * fast_rcp(a) +
-           0.5f * (digamma_f(0.5f * (a + 1.0f)) - digamma_f(0.5f * a));
-      done(); return;
-    }
-    case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
-      const float rb = fast_rcp(b);
-      const float z = (x - a) * rb, lo = (c - a) * rb, hi = (d - a) * rb;
-      const float rZ = fast_rcp(normal_interval_mass(lo, hi));
-      const float plo = 0.39894228f * fast_exp(-0.5f * lo * lo) * rZ * rb, phi = 0.39894228f * fast_exp(-0.5f * hi * hi) * rZ * rb;
-      dx = -z * rb;
-      da = z * rb + (phi - plo);
-      db = (z * z - 1.0f) * rb + (hi * phi - lo * plo);
-      dc = plo; dd = -phi;
-      done(); return;
-    }
-    case GJX_POISSON: da = x * fast_rcp(a) - 1.0f; done(); return;
-    case GJX_GEOMETRIC: da = fast_rcp(a) - x * fast_rcp(1.0f - a); done(); return;
-    case GJX_GUMBEL: {
-      const float rb = fast_rcp(b);
-      const float z = (x - a) * rb;
-      const float e1 = 1.0f - fast_exp(-z);
-      dx = -e1 * rb; da = e1 * rb; db = (e1 * z - 1.0f) * rb;
-      done(); return;
-    }
-    case GJX_HALF_CAUCHY: {
-      const float rb = fast_rcp(b);
-      const float z = (x - a) * rb;
-      const float gq = 2.0f * z * fast_rcp(1.0f + z * z);
-      dx = -gq * rb; da = gq * rb; db = (gq * z - 1.0f) * rb;
-      done(); return;
-    }
-    case GJX_INVERSE_GAMMA: {
-      const float rx = fast_rcp(x);
-      dx = -(a + 1.0f) * rx + b * rx * rx; db = a * fast_rcp(b) - rx; da = fast_log(b) - digamma_f(a) - fast_log(x);
-      done(); return;
-    }
-    case GJX_WEIBULL: {
-      const float lr = fast_log(x * fast_rcp(b));
-      const float t = fast_exp(a * lr);
-      dx = ((a - 1.0f) - a * t) * fast_rcp(x); db = a * (t - 1.0f) * fast_rcp(b); da = fast_rcp(a) + lr * (1.0f - t);
-      done(); return;
-    }
-    case GJX_LOGIT_NORMAL: {
-      const float rb = fast_rcp(b);
-      const float z = (fast_log(x) - log1p_acc(-x) - a) * rb;
-      dx = -z * rb * fast_rcp(x * (1.0f - x)) - fast_rcp(x) + fast_rcp(1.0f - x); da = z * rb; db = (z * z - 1.0f) * rb;
-      done(); return;
-    }
-    case GJX_CHI2: dx = (0.5f * a - 1.0f) * fast_rcp(x) - 0.5f; da = 0.5f * (fast_log(x) - kLn2 - digamma_f(0.5f * a)); done(); return;
-    default: break;
-  }
-  switch (kind) {
-    case GJX_NORMAL:
-    case GJX_MVNORMAL_DIAG: {
-      const float rb = fast_rcp(b);
-      const float z = (x - a) * rb;
-      dx = -z * rb; da = z * rb; db = (z * z - 1.0f) * rb;
-      break;
-    }
-    case GJX_BERNOULLI_LOGITS: da = x - sigmoid(a); break;
-    case GJX_FLIP: da = (x != 0.0f ? fast_rcp(a) : 0.0f) - (x != 1.0f ? (1.0f - x) * fast_rcp(1.0f - a) : 0.0f); break;
-    case GJX_HALF_NORMAL: { const float ra = fast_rcp(a); const float z = x * ra; dx = -z * ra; da = (z * z - 1.0f) * ra; break; }
-    case GJX_EXPONENTIAL: dx = -a; da = fast_rcp(a) - x; break;
-    case GJX_LAPLACE: { const float s = (float)((x > a) - (x < a)); const float rb = fast_rcp(b); dx = -s * rb; da = s * rb; db = fabsf(x - a) * rb * rb - rb; break; }
-    case GJX_CAUCHY: { const float rb = fast_rcp(b); const float z = (x - a) * rb; const float g = 2.0f * z * fast_rcp(1.0f + z * z); dx = -g * rb; da = g * rb; db = (g * z - 1.0f) * rb; break; }
-    case GJX_LOG_NORMAL: { const float lx = fast_log(x); const float rb = fast_rcp(b); const float z = (lx - a) * rb; dx = (-z * rb - 1.0f) * fast_rcp(x); da = z * rb; db = (z * z - 1.0f) * rb; break; }
-    case GJX_BETA: {
-      const float pab = digamma_f(a + b);
-      dx = (a - 1.0f) * fast_rcp(x) - (b - 1.0f) * fast_rcp(1.0f - x);
-      da = fast_log(x) - digamma_f(a) + pab; db = log1p_acc(-x) - digamma_f(b) + pab;
-      break;
-    }
-    case GJX_GAMMA: dx = (a - 1.0f) * fast_rcp(x) - b; da = fast_log(b) + fast_log(x) - digamma_f(a); db = a * fast_rcp(b) - x; break;
-    case GJX_UNIFORM: { const float r = fast_rcp(b - a); da = r; db = -r; break; }
-    default: break;
-  }
-  done();
-}
-
-GJX_DEV float xf_deriv(int xf, float pre) {
-  switch (xf) {
-    case GJX_XF_EXP: return fast_exp(pre);
-    case GJX_XF_SOFTPLUS: return sigmoid(pre);
-    case GJX_XF_SIGMOID: { const float s = sigmoid(pre); return s * (1.0f - s); }
-    default: return 1.0f;
-  }
-}
 
 // where a chain's gradient row lives: column i of rows g[n_slots][n] in memory, or column threadIdx.x of LDS rows
 struct GlobalRows {
@@ -349,11 +249,6 @@ struct LogregArgs {
 // different rows (k = 0..3) broadcast over the 16 chains of the wave — conflict-free.
 // LDS image: sX[Npad][P], sY[Npad], sB[Npad]  (Npad = N rounded up to 8; padded rows are zero with y = 0.5,
 // bias 0, so their residual y - sigmoid(0) is exactly 0 and they add nothing to the gradient)
-GJX_DEV float quad_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  return v;
-}
 
 // CPL chains per lane-quad member: each X row fetched from LDS feeds CPL independent chains, which halves
 // (CPL = 2) the LDS traffic per FLOP and gives the two logit chains of ILP the single quad needs.
@@ -812,11 +707,25 @@ static int launch_logreg(const LogregArgs& a, int P, hipStream_t st) {
   return 0;
 }
 
+// which engines may run: GJX_HMC_ENGINE = auto (default) | fused (hand-written kernels only) | gen (generated kernel, skipping the
+// hand-written match) | interp (site interpreter); GJX_FORCE_GENERIC=1 == interp
+static int hmc_engine_pref() {
+  const char* f = getenv("GJX_FORCE_GENERIC");
+  if (f && atoi(f)) return 3;
+  const char* e = getenv("GJX_HMC_ENGINE");
+  if (!e || !strcmp(e, "auto")) return 0;
+  if (!strcmp(e, "fused")) return 1;
+  if (!strcmp(e, "gen")) return 2;
+  if (!strcmp(e, "interp")) return 3;
+  return 0;
+}
+
 extern "C" int gjx_hmc_engine(const gjx_program* prog) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   LogregArgs a; int P;
-  const char* f = getenv("GJX_FORCE_GENERIC");
-  if (!(f && atoi(f)) && match_logreg(prog, &a, &P)) return logreg_engine(a, P);
+  const int pref = hmc_engine_pref();
+  if ((pref == 0 || pref == 1) && match_logreg(prog, &a, &P)) return logreg_engine(a, P);
+  if ((pref == 0 || pref == 2) && hmc_gen_available(prog) == GJX_OK) return 4;
   return 0;
 }
 
@@ -847,10 +756,10 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
                                               s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))
       return gjx_fail(GJX_EINVAL, "gjx_hmc: only unconstrained float32 sites can be selected (hmc.py:49-65)");
   }
+  const int pref = hmc_engine_pref();
   {
     LogregArgs la; int P;
-    const char* f = getenv("GJX_FORCE_GENERIC");
-    if (!(f && atoi(f)) && match_logreg(prog, &la, &P)) {
+    if ((pref == 0 || pref == 1) && match_logreg(prog, &la, &P)) {
       la.tab = prog->tab_dev; la.key = key2{key0, key1}; la.n = n; la.offset = chain_offset; la.eps = eps; la.L = L;
       la.stale = stale_grad_compat; la.accept = accept; la.choices = choices; la.score = score; la.alpha = alpha; la.accepted = accepted;
       if (prog->rng_mode == GJX_RNG_JAX32) launch_logreg<GJX_RNG_JAX32>(la, P, (hipStream_t)stream);
@@ -858,6 +767,13 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
       GJX_CHECK_LAUNCH("gjx_hmc/logreg");
       return GJX_OK;
     }
+  }
+  // a kernel generated from the site list (gjx_codegen.hip): chain state in registers, table in LDS, no workspace
+  if ((pref == 0 || pref == 2) && hmc_gen_available(prog) == GJX_OK) {
+    HmcGenArgs ga;
+    ga.tab = prog->tab_dev; ga.key = key2{key0, key1}; ga.n = n; ga.offset = chain_offset; ga.eps = eps; ga.L = L;
+    ga.stale = stale_grad_compat; ga.accept = accept; ga.choices = choices; ga.score = score; ga.alpha = alpha; ga.accepted = accepted;
+    return hmc_gen_launch(prog, ga, (hipStream_t)stream);
   }
   if (!workspace || workspace_bytes < gjx_hmc_workspace_bytes(prog, n)) return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small");
   HmcArgs a;

@@ -32,6 +32,10 @@ struct GenArgs;
 int gen_pick_ppt(const gjx_program* prog, int64_t K);
 int gen_available(const gjx_program* prog, int ppt);
 int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// per-program generated HMC kernels (gjx_codegen.hip)
+struct HmcGenArgs;
+int hmc_gen_available(const gjx_program* prog);
+int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t st);
 // systematic ancestor expansion with the slot run {slot0, n_valid} read from a device plan (gjx_resample.hip)
 int launch_expand_planned(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
                           int32_t* ancestors, int64_t anc_capacity, hipStream_t st);

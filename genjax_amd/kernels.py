@@ -127,6 +127,23 @@ def program_precompile(prog: PackedProgram, ppt: int) -> None:
     check(load().gjx_program_precompile(C.byref(cp), int(ppt)), "gjx_program_precompile")
 
 
+def program_hmc_source(prog: PackedProgram) -> str:
+    """HIP source of the HMC kernel gjx_codegen generates for this program (raises GjxError if the emitter does not cover it)."""
+    cp = prog.c_program(None)
+    n = load().gjx_program_hmc_source(C.byref(cp), None, 0)
+    if n < 0:
+        check(int(n), "gjx_program_hmc_source")
+    buf = C.create_string_buffer(int(n) + 1)
+    load().gjx_program_hmc_source(C.byref(cp), buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def program_hmc_precompile(prog: PackedProgram) -> None:
+    """Compile the program's generated HMC kernel with hipRTC (works without a GPU) into the in-memory and on-disk caches."""
+    cp = prog.c_program(None)
+    check(load().gjx_program_hmc_precompile(C.byref(cp)), "gjx_program_hmc_precompile")
+
+
 class RunPartials:
     """The per-block {max, sumexp} pairs a run with ``want_lse=False`` left in its workspace: the consumers that can
     reduce them in their own prologue (resample_gather / resample_indices, ``partials=``) save the producer's serial

@@ -198,6 +198,11 @@ int gjx_program_engine(const gjx_program* prog);
  * step can fill the on-disk cache (GJX_JIT_CACHE, default jit_cache/ next to the library).  ppt = particles per lane. */
 int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap);
 int gjx_program_precompile(const gjx_program* prog, int32_t ppt);
+/* the same for the HMC kernel generated from the program's site list (gjx_hmc engine 4: chain values, gradient and momenta
+ * in registers, analytic gradient sweep, L leapfrog steps and the accept in one launch): its HIP source, and a compile
+ * without launch.  GJX_EUNSUPPORTED when the emitter does not cover the program (the site interpreter runs it). */
+int64_t gjx_program_hmc_source(const gjx_program* prog, char* out, int64_t cap);
+int gjx_program_hmc_precompile(const gjx_program* prog);
 int gjx_program_aux_floats(const gjx_program* prog);
 int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int32_t n_aux, void* stream);
 
@@ -578,7 +583,8 @@ int gjx_peer_resample_gather(gjx_peer_ctx* ctx, int32_t parity, const float* par
  *   with log U drawn from fold_in(key', 0x4d48) (FLAT: site 1023) and reverts rejected chains; accepted f32[n] out or NULL.
  */
 size_t gjx_hmc_workspace_bytes(const gjx_program* prog, int64_t n);
-/* which engine gjx_hmc will use: 0 = generic site interpreter, 2 = fused hierarchical-logistic-regression kernel */
+/* which engine gjx_hmc will use: 0 = generic site interpreter, 2 / 3 = fused hierarchical-logistic-regression kernels (vector /
+ * matrix-core), 4 = a kernel generated from the site list; GJX_HMC_ENGINE = auto | fused | gen | interp restricts the choice */
 int gjx_hmc_engine(const gjx_program* prog);
 int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,

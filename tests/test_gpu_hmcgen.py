@@ -1,0 +1,137 @@
+"""Generated HMC kernels (csrc/gjx_codegen.hip `gjx_hmc_gen`, gjx_hmc engine 4): the kernel emitted from a program's site
+list against the oracle's HMC.edit restatement (oracle/gjx_oracle.c, hmc.py:156-211) and against the site interpreter
+(k_hmc_generic) on the same streams — same tolerances as the hand-written kernels' tests in test_gpu_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import helpers as H  # noqa: E402
+from genjax_amd import _abi as A  # noqa: E402
+from genjax_amd.program import PackedProgram, Param, SiteList  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RNGS = [A.RNG_FLAT, A.RNG_JAX32]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def K_():
+    from genjax_amd import kernels
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu
+    return cpu
+
+
+def _scan_target(T, rng):
+    """an observed random-walk Scan of T steps with every x_t selected: x_t ~ N(x_{t-1}, 0.3), y_t ~ N(x_t, 0.5)"""
+    prog, ys = H.scan_chain(T, rng=rng, carry=True, observe=True, sigma=0.3, r=0.5)
+    sl = prog.site_list
+    modes = {s.addr: (A.MODE_OBS_TAB if s.addr[0] == "y" else A.MODE_OBS_SLOT) for s in sl.sites}
+    obs = {("y", t): ys[t] for t in range(T)}
+    return PackedProgram(sl, modes, obs, selected=tuple(("x", t) for t in range(T)), rng_mode=rng), T
+
+
+def _hierarchy_target(rng):
+    sl = H.shape_hierarchy(rng)
+    return PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=("la", "lb"), rng_mode=rng)
+
+
+def _mixed_target(rng):
+    """gather through a discrete (unselected) site, an affine over two selected vectors, transforms on value parameters"""
+    rs = np.random.default_rng(4)
+    sl = SiteList()
+    sl.add("z", A.CATEGORICAL_LOGITS, [np.array([0.2, -0.3, 0.5], np.float32)])
+    sl.add("mu", A.MVNORMAL_DIAG, [Param.gather(rs.standard_normal((3, 4)).astype(np.float32), "z"), Param.const(np.full(4, 0.8, np.float32))], dim=4)
+    sl.add("ls", A.NORMAL, [-0.5, 0.3])
+    sl.add("w", A.MVNORMAL_DIAG, [Param.value("mu", 4), Param.value("ls", xf=A.XF_EXP)], dim=4)
+    sl.add("y", A.NORMAL, [Param.affine(rs.standard_normal((6, 4)).astype(np.float32), "w", bias=rs.standard_normal(6).astype(np.float32)),
+                           Param.value("ls", xf=A.XF_SOFTPLUS)], dim=6)
+    sl.add("k", A.POISSON, [Param.affine(np.abs(rs.standard_normal((1, 4))).astype(np.float32) * 0.2, "mu", bias=np.float32(1.0), xf=A.XF_SOFTPLUS)])
+    modes = {"z": A.MODE_OBS_SLOT, "mu": A.MODE_OBS_SLOT, "ls": A.MODE_OBS_SLOT, "w": A.MODE_OBS_SLOT, "y": A.MODE_OBS_TAB, "k": A.MODE_OBS_TAB}
+    obs = {"y": rs.standard_normal(6).astype(np.float32), "k": np.float32(2.0)}
+    # (second program: the same sites with the latents sampled — a start state in which the discrete site holds valid values)
+    sim = PackedProgram(sl, {"y": A.MODE_OBS_TAB, "k": A.MODE_OBS_TAB}, obs, rng_mode=rng)
+    return PackedProgram(sl, modes, obs, selected=("mu", "ls", "w"), rng_mode=rng), sim
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("which", ["logreg_small", "logreg_cfg5", "hierarchy", "scan16", "mixed"])
+def test_generated_hmc_kernel_against_oracle_and_interpreter(K_, oracle, rng, which, monkeypatch):
+    import torch
+    n = 500
+    if which == "logreg_small":
+        prog, _ = H.logreg(N=64, P=4, rng=rng)
+        ch = (np.random.default_rng(2).standard_normal((5, n)) * 0.3).astype(np.float32)
+        eps, L = 0.01, 25
+    elif which == "logreg_cfg5":
+        prog, _ = H.logreg(N=1024, P=16, rng=rng)
+        ch = (np.random.default_rng(5).standard_normal((17, n)) * 0.2).astype(np.float32)
+        eps, L = 0.004, 20
+    elif which == "hierarchy":
+        prog = _hierarchy_target(rng)
+        ch = oracle.run_program(PackedProgram(H.shape_hierarchy(rng), rng_mode=rng), (3, 4), n)["choices"].astype(np.float32)
+        eps, L = 0.002, 20
+    elif which == "scan16":
+        prog, T = _scan_target(16, rng)
+        ch = (np.random.default_rng(6).standard_normal((16, n)) * 0.3).astype(np.float32)
+        eps, L = 0.02, 15
+    else:
+        prog, sim = _mixed_target(rng)
+        ch = oracle.run_program(sim, (3, 1), n)["choices"].astype(np.float32)
+        eps, L = 0.01, 12
+    monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+    assert K_.hmc_engine(prog) == 4, "the emitter does not cover this program"
+    for stale, accept in ((False, False), (True, False), (False, True)):
+        e = eps * (4 if accept else 1)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        g = K_.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), e, L, stale, accept, offset=11)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        assert K_.hmc_engine(prog) == 0
+        it = K_.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), e, L, stale, accept, offset=11)
+        o = oracle.hmc(prog, (2, 9), ch, e, L, stale, accept, offset=11)
+        gc, ic = _np(g["choices"]), _np(it["choices"])
+        assert np.isfinite(gc).all() and np.isfinite(_np(g["alpha"])).all()
+        if not accept:
+            # generated vs interpreter: same streams, same arithmetic up to the order of the sums
+            np.testing.assert_allclose(gc, ic, rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), _np(it["alpha"]), rtol=5e-3, atol=5e-3)
+            np.testing.assert_allclose(gc, o["choices"], rtol=3e-3, atol=3e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
+            np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=6e-3)
+            assert (_np(g["accepted"]) == 1).all()
+        else:
+            acc_g, acc_o = _np(g["accepted"]), o["accepted"]
+            flip = acc_g != acc_o
+            # a chain may decide differently from the oracle only if log u lies within the alpha tolerance of the boundary
+            assert (o["margin"][flip] < 6e-3 + 6e-3 * np.abs(o["alpha"][flip])).all()
+            assert flip.mean() < 0.03
+            rej = acc_g == 0
+            np.testing.assert_array_equal(gc[:, rej], ch[:, rej])              # rejected chains are untouched, bit for bit
+            both = (acc_g == 1) & (acc_o == 1) & (np.abs(o["alpha"]) < 0.5)
+            np.testing.assert_allclose(gc[:, both], o["choices"][:, both], rtol=3e-2, atol=3e-2)
+
+
+def test_generated_hmc_is_the_default_engine_for_unmatched_programs(K_, oracle):
+    """engine selection: the hand-written kernels for the config-5 shape, the generated kernel for everything else the
+    emitter covers, the interpreter for the rest (a dirichlet site)"""
+    prog, _ = H.logreg(N=64, P=4)
+    assert K_.hmc_engine(prog) in (2, 3)
+    assert K_.hmc_engine(_hierarchy_target(A.RNG_FLAT)) == 4
+    assert K_.hmc_engine(_scan_target(16, A.RNG_FLAT)[0]) == 4
+    sl = SiteList()
+    sl.add("th", A.DIRICHLET, [np.array([1.0, 2.0, 3.0], np.float32)], dim=3)
+    sl.add("x", A.NORMAL, [0.0, 1.0])
+    pd = PackedProgram(sl, {"th": A.MODE_OBS_SLOT, "x": A.MODE_OBS_SLOT}, selected=("x",))
+    assert K_.hmc_engine(pd) == 0
+    src = K_.program_hmc_source(_scan_target(16, A.RNG_FLAT)[0])
+    assert "gjx_hmc_gen" in src and "sweep<false>" in src
