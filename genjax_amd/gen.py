@@ -470,11 +470,24 @@ class Trace:
         from . import kernels
         from .inference.requests import _rows_and_shared
         shared, rows = _rows_and_shared(self)
-        prog, _, _ = self.gen_fn.pack(self.args, shared, False, rng_mode=self.prog.rng_mode, per_particle=tuple(rows))
-        out = kernels.run_program(prog, (0, 0), self.K, choices=self.choices.clone(), want_site_scores=True, want_lse=False)
+        prog, _, _ = self.gen_fn.pack(self.args, shared, False, rng_mode=self.prog.rng_mode, per_particle=tuple(rows), plates=False)
+        out = kernels.run_program(prog, (0, 0), self.K, choices=self.rows_for(prog), want_site_scores=True, want_lse=False)
         sel = [j for j, s in enumerate(prog.site_list.sites) if selection.check(s.addr)]
         tot = out["site_scores"][sel].sum(dim=0) if sel else torch.zeros(self.K, device=self.score.device)
         return tot if self.batched else tot[0]
+
+    def rows_for(self, prog: PackedProgram):
+        """this trace's values laid out for ANOTHER packing of the same site list (a program packed with / without plates,
+        or with other modes, orders its rows differently): f32[prog.n_slots][K]"""
+        import torch
+        if prog.slot_of == self.prog.slot_of and prog.n_slots == self.prog.n_slots:
+            return self.choices.clone()
+        out = torch.zeros((max(prog.n_slots, 1), self.K), dtype=torch.float32, device=self.score.device)
+        for s in self.prog.site_list.sites:
+            src, dst = self.prog.slot_of[s.addr], prog.slot_of.get(s.addr, -1)
+            if src >= 0 and dst >= 0:
+                out[dst:dst + s.dim] = self.choices[src:src + s.dim]
+        return out
 
     def full_choice_rows(self) -> dict:
         """addr -> device rows [dim][K] for every site (shared values broadcast)."""
@@ -535,10 +548,12 @@ class GenerativeFunction:
 
     # -- program construction -------------------------------------------------------------------
     def pack(self, args, constraint: ChoiceMap, sample_rest: bool, selected: Sequence = (), rng_mode=None,
-             per_particle: Sequence = ()):
+             per_particle: Sequence = (), plates: bool = True):
         """-> (PackedProgram, shared dict, per-particle dict addr -> rows).  Sites in ``constraint`` are
         OBS_TAB (shared value) or OBS_SLOT (value per particle); sites in ``per_particle`` are OBS_SLOT with
-        rows supplied later; the rest are SAMPLE when ``sample_rest`` else MissingAddress."""
+        rows supplied later; the rest are SAMPLE when ``sample_rest`` else MissingAddress.
+        ``plates``: the instances of vmapped kernels become one vector site per kernel site on the device (program.py
+        compact_plates; the logical addresses stay per instance); off for callers that need one score per instance."""
         from . import config
         # Packed programs are kept per (arguments, constraint content, flags): the same Target used again — every step of
         # an SMC loop, every call of the GenSP interface — finds its program with the table already on the device and
@@ -555,7 +570,7 @@ class GenerativeFunction:
                 items.append((repr(addr), _value_key(v)))
             if items is not None:
                 ckey = (_args_key(args), tuple(items), bool(sample_rest), tuple(selected),
-                        config.rng_mode() if rng_mode is None else rng_mode, tuple(per_particle))
+                        config.rng_mode() if rng_mode is None else rng_mode, tuple(per_particle), bool(plates))
                 hit = cache.get(ckey)
                 if hit is not None and not hit[2]:
                     return hit[0], hit[1], {}
@@ -585,8 +600,8 @@ class GenerativeFunction:
                 modes[s.addr] = A.MODE_OBS_SLOT
             elif not sample_rest:
                 raise MissingAddress(s.addr)
-        prog = PackedProgram(sl, modes, shared, selected=tuple(selected),
-                             rng_mode=config.rng_mode() if rng_mode is None else rng_mode)
+        rm = config.rng_mode() if rng_mode is None else rng_mode
+        prog = PackedProgram(sl, modes, shared, selected=tuple(selected), rng_mode=rm, plates=bool(plates))
         prog.mask_flags = mask_rows          # addr -> f32[K] validity flags of Mask(value, flag) constraints
         if ckey is not None and not pp and not mask_rows:
             if len(cache) >= 64:
@@ -596,10 +611,10 @@ class GenerativeFunction:
 
     def _run(self, key: Key, K: int, args, constraint: ChoiceMap, sample_rest: bool, batched: bool,
              prev_rows: dict | None = None, logw_in=None, sub=None, want_lse=False, device=None, offset=0,
-             K_total=None, want_site_scores=False):
+             K_total=None, want_site_scores=False, plates: bool = True):
         import torch
         from . import kernels
-        prog, shared, pp = self.pack(args, constraint, sample_rest, per_particle=tuple(prev_rows or ()))
+        prog, shared, pp = self.pack(args, constraint, sample_rest, per_particle=tuple(prev_rows or ()), plates=plates)
         _, retval = self.site_list(args)
         dev = kernels._dev(device)
         rows = dict(prev_rows or {})

@@ -24,6 +24,18 @@ def _rows_and_shared(tr: Trace):
     return shared, rows
 
 
+def _unrolled_score(tr: Trace):
+    """The trace's score with the SAME order of summation as an edit's re-run: edits run on the unrolled lowering (one site
+    per plate instance — a move may treat instances differently), and their weight is a difference of two float32 sums of
+    all site scores, exact only if the unchanged terms are added in the same order on both sides.  A trace that came from
+    a program with plates (vector sites: per-plate partial sums) is therefore re-assessed once on the unrolled program."""
+    if not getattr(tr.prog, "plate_of", None):
+        return tr.score
+    shared, rows = _rows_and_shared(tr)
+    _, out = tr.gen_fn._run((0, 0), tr.K, tr.args, shared, False, tr.batched, prev_rows=rows, plates=False)
+    return out["score"]
+
+
 def _new_args(tr: Trace, argdiffs):
     """arguments of the edited trace: the primals of ``argdiffs`` (Diff-tagged or plain), or the old ones"""
     from ..core import Diff
@@ -58,8 +70,9 @@ class Update(EditRequest):
                 if r is not None:
                     raise ValueError(f"{addr!r} is constrained to one shared value in this trace")
                 shared = ChoiceMap({**dict(shared.items()), addr: sv})
-        new_tr, out = tr.gen_fn._run(key, tr.K, args, shared, False, tr.batched, prev_rows=rows)
-        w = out["score"] - tr.score
+        old_score = _unrolled_score(tr)
+        new_tr, out = tr.gen_fn._run(key, tr.K, args, shared, False, tr.batched, prev_rows=rows, plates=False)
+        w = out["score"] - old_score
         return new_tr, (w if tr.batched else w[0]), None, Update(ChoiceMap(discard))
 
 
@@ -81,8 +94,9 @@ class Regenerate(EditRequest):
                     del rows[s.addr]
                 else:
                     shared = ChoiceMap({a: v for a, v in shared.items() if a != s.addr})
-        new_tr, out = tr.gen_fn._run(key, tr.K, _new_args(tr, argdiffs), shared, True, tr.batched, prev_rows=rows)
-        w = out["score"] - tr.score
+        old_score = _unrolled_score(tr)
+        new_tr, out = tr.gen_fn._run(key, tr.K, _new_args(tr, argdiffs), shared, True, tr.batched, prev_rows=rows, plates=False)
+        w = out["score"] - old_score
         return new_tr, (w if tr.batched else w[0]), None, Update(ChoiceMap(old))
 
 
@@ -107,9 +121,12 @@ class HMC(EditRequest):
         sel = [s.addr for s in tr.prog.site_list.sites if self.selection.check(s.addr) and s.kind not in A.NO_GRADIENT_KINDS]
         prog, _, _ = tr.gen_fn.pack(tr.args, shared, False, selected=sel, rng_mode=tr.prog.rng_mode,
                                     per_particle=tuple(rows))
-        assert prog.slot_of == tr.prog.slot_of
-        out = kernels.hmc(prog, key, tr.choices.clone(), self.eps, self.L, self.stale_gradient_compat, self.accept)
-        new_tr = Trace(tr.gen_fn, tr.args, tr.prog, out["choices"], out["score"], tr.shared, tr.batched, tr.retval_sym)
+        # (the move's program may lay its rows out differently from the trace's: other modes, plates; the new trace is bound
+        # to the program its rows follow)
+        self.last_program = prog             # the move's program (every site constrained, the selected ones flagged): tests, engine queries
+        out = kernels.hmc(prog, key, tr.rows_for(prog), self.eps, self.L, self.stale_gradient_compat, self.accept)
+        new_tr = Trace(tr.gen_fn, tr.args, prog if prog.slot_of != tr.prog.slot_of else tr.prog, out["choices"], out["score"], tr.shared,
+                       tr.batched, tr.retval_sym)
         alpha = out["alpha"]
         bwd = HMC(self.selection, self.eps, self.L, self.stale_gradient_compat, self.accept)
         bwd.last_accepted = self.last_accepted = out["accepted"] if self.accept else None

@@ -162,6 +162,150 @@ class SiteList:
 
 
 # ---------------------------------------------------------------------------------------------
+# plates: the instances of a vmapped kernel as ONE vector site per kernel site
+# ---------------------------------------------------------------------------------------------
+PLATE_MIN = 8     # fewer instances stay unrolled (nothing to gain)
+
+
+def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, draws_ok: bool = True) -> tuple[SiteList, dict, dict, tuple, dict]:
+    """The host tracer unrolls ``kernel.vmap(...)(args)`` into n instances of the kernel's m sites, addressed
+    ``(name, i)`` (combinators/vmap.py:193-218: per-instance sub-traces, summed weights).  For the device a plate of n
+    i.i.d.-structured instances is ONE site per kernel site with n * d elements — element i * d + c is element c of
+    instance i — whose log-density is the sum over the instances (distribution.py:392-396 sums a shaped log-pdf): the
+    N rows of a regression likelihood become one site with an [N x P] affine parameter, not N sites.
+
+    A run of instance-major sites is compacted when, for every kernel site, all instances agree on kind / dimension /
+    mode / selection and every parameter is: a constant (stacked per element when it differs between instances), the
+    value of a site outside the plate (broadcast, or elementwise over the event), the value of an earlier site of the SAME
+    instance with the same dimension (elementwise between the two vector sites), or an affine form over a site outside
+    the plate (matrices stacked to [n d x m]).  Anything else — categorical sites, gathers, per-instance masks, an instance
+    constrained on its own — leaves that plate unrolled, which is always correct.
+
+    ``draws_ok`` False (GJX_RNG_JAX32, whose streams follow the reference's key structure site by site): only plates whose
+    sites are all constrained — nothing is drawn inside them, so no stream changes — are compacted.
+
+    -> (device site list, its modes / obs / selected, {logical addr: (device addr, element offset)})"""
+    sel = set(selected)
+    out = SiteList()
+    dmodes, dobs, dsel, where = {}, {}, [], {}
+    sites = sl.sites
+    j = 0
+
+    def is_inst(s, i=None):
+        return (s.scan == 0 and isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], (int, np.integer))
+                and (i is None or s.addr[1] == i))
+
+    def copy_plain(s):
+        ns = Site(s.addr, s.kind, s.params, s.dim, s.ncat, out.n_slots, s.scan)
+        out.sites.append(ns)
+        out.n_slots += s.dim
+        if s.addr in modes:
+            dmodes[s.addr] = modes[s.addr]
+        if s.addr in obs:
+            dobs[s.addr] = obs[s.addr]
+        if s.addr in sel:
+            dsel.append(s.addr)
+
+    while j < len(sites):
+        s0 = sites[j]
+        if not is_inst(s0, 0):
+            copy_plain(s0)
+            j += 1
+            continue
+        # instance 0: the kernel's sites; then count the instances that repeat its names
+        m = 0
+        while j + m < len(sites) and is_inst(sites[j + m], 0):
+            m += 1
+        names = [sites[j + l].addr[0] for l in range(m)]
+        n = 1
+        while j + (n + 1) * m <= len(sites) and all(is_inst(sites[j + n * m + l], n) and sites[j + n * m + l].addr[0] == names[l] for l in range(m)):
+            n += 1
+        group = [[sites[j + i * m + l] for i in range(n)] for l in range(m)]      # [kernel site][instance]
+        plate = _try_compact(group, names, n, modes, obs, sel) if n >= PLATE_MIN else None
+        if plate is not None and not draws_ok and any(mode not in (A.MODE_OBS_TAB, A.MODE_OBS_SLOT) for _, mode, _, _ in plate):
+            plate = None
+        if plate is None:
+            for i in range(n):
+                for l in range(m):
+                    copy_plain(sites[j + i * m + l])
+        else:
+            for l, (ns, mode, ov, is_sel) in enumerate(plate):
+                ns.slot = out.n_slots
+                out.sites.append(ns)
+                out.n_slots += ns.dim
+                if mode is not None:
+                    dmodes[ns.addr] = mode
+                if ov is not None:
+                    dobs[ns.addr] = ov
+                if is_sel:
+                    dsel.append(ns.addr)
+                d = group[l][0].dim
+                for i in range(n):
+                    where[group[l][i].addr] = (ns.addr, i * d)
+        j += n * m
+    return out, dmodes, dobs, tuple(dsel), where
+
+
+def _try_compact(group, names, n: int, modes: dict, obs: dict, sel: set):
+    """-> [(vector Site, mode or None, observed values or None, selected)] per kernel site, or None"""
+    inside = {s.addr: (l, i) for l, col in enumerate(group) for i, s in enumerate(col)}
+    res = []
+    for l, col in enumerate(group):
+        s0 = col[0]
+        d = s0.dim
+        if s0.kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS, A.DIRICHLET) or s0.ncat:
+            return None
+        mode0 = modes.get(s0.addr)
+        if mode0 == A.MODE_OBS_MASK:
+            return None
+        for s in col:
+            if s.kind != s0.kind or s.dim != d or len(s.params) != len(s0.params) or modes.get(s.addr) != mode0 or (s.addr in sel) != (s0.addr in sel):
+                return None
+        params = []
+        for k, p0 in enumerate(s0.params):
+            ps = [s.params[k] for s in col]
+            if any(q.op != p0.op or q.xf != p0.xf or bool(q.terms) for q in ps):
+                return None
+            if p0.op == A.P_CONST:
+                if any(q.values.size not in (1, d) for q in ps):
+                    return None
+                if all(q.values.size == p0.values.size and np.array_equal(q.values, p0.values) for q in ps):
+                    params.append(Param.const(p0.values, xf=p0.xf))
+                else:
+                    params.append(Param.const(np.concatenate([np.broadcast_to(q.values, (d,)) for q in ps]), xf=p0.xf))
+            elif p0.op == A.P_VALUE:
+                if p0.src in inside:          # an earlier site of the same instance, elementwise
+                    ls, _ = inside[p0.src]
+                    if ls >= l or group[ls][0].dim != d or p0.length != d or p0.src_elem != 0:
+                        return None
+                    if any(q.src != group[ls][i].addr or q.length != d or q.src_elem != 0 for i, q in enumerate(ps)):
+                        return None
+                    params.append(Param.value(("@plate", names[ls]), length=n * d, xf=p0.xf))
+                else:                         # a site outside the plate: the same read in every instance
+                    if any(q.src != p0.src or q.length != p0.length or q.src_elem != p0.src_elem for q in ps) or p0.length not in (1, d):
+                        return None
+                    params.append(Param.value(p0.src, length=p0.length, elem=p0.src_elem, xf=p0.xf))
+            elif p0.op == A.P_AFFINE:
+                if p0.src in inside or any(q.src != p0.src or q.src_elem != p0.src_elem or q.matrix.shape != p0.matrix.shape for q in ps):
+                    return None
+                if p0.matrix.shape[0] != d or any(q.values.size not in (1, d) for q in ps):
+                    return None
+                M = np.concatenate([q.matrix for q in ps], axis=0)
+                b = np.concatenate([np.broadcast_to(q.values, (d,)) for q in ps])
+                params.append(Param.affine(M, p0.src, bias=b, elem=p0.src_elem, xf=p0.xf))
+            else:
+                return None
+        ns = Site(("@plate", names[l]), s0.kind, params, n * d, 0, -1, 0)
+        ov = None
+        if mode0 == A.MODE_OBS_TAB:
+            if any(s.addr not in obs for s in col):
+                return None
+            ov = np.concatenate([np.broadcast_to(np.asarray(obs[s.addr], np.float32).ravel(), (d,)) for s in col])
+        res.append((ns, mode0, ov, s0.addr in sel))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------
 # packing
 # ---------------------------------------------------------------------------------------------
 class PackedProgram:
@@ -174,11 +318,23 @@ class PackedProgram:
 
     def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
                  obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
-                 rng_mode: int = A.RNG_FLAT):
+                 rng_mode: int = A.RNG_FLAT, plates: bool = False):
+        """``plates``: lower the instances of vmapped kernels to vector sites (compact_plates).  The LOGICAL view stays
+        per instance — ``site_list``, ``slot_of`` and ``obs_off`` answer for the addresses ``(name, i)`` — while the
+        device program (``c_sites``, ``n_sites``) holds one site per kernel site; per-site scores are then per plate,
+        so callers that need one score per instance pack without it."""
+        self.logical_site_list = sl
+        self.logical_modes = dict(modes or {})
+        self.plate_of: dict = {}
+        obs = obs or {}
+        if plates:
+            sl, modes, obs, selected, self.plate_of = compact_plates(sl, dict(modes or {}), dict(obs), tuple(selected),
+                                                                     draws_ok=int(rng_mode) == A.RNG_FLAT)
+            if not self.plate_of:
+                sl = self.logical_site_list
         self.site_list = sl
         self.modes = dict(modes or {})
         self.rng_mode = int(rng_mode)
-        obs = obs or {}
         tab: list[np.ndarray] = []
         self._tab_parts = tab
         ntab = 0
@@ -268,6 +424,17 @@ class PackedProgram:
         self.tab = np.concatenate(tab).astype(np.float32) if tab else np.zeros(1, np.float32)
         self.n_sites = n
         self.n_slots = n_slots
+        if self.plate_of:
+            # the logical view: instance i of a compacted kernel site lives at element offset i * d of the vector site
+            self.device_site_list = self.site_list
+            for addr, (daddr, off) in self.plate_of.items():
+                self.slot_of[addr] = self.slot_of[daddr] + off if self.slot_of[daddr] >= 0 else -1
+                if daddr in self.obs_off:
+                    self.obs_off[addr] = self.obs_off[daddr] + off
+            self.site_list = self.logical_site_list
+            self.modes = self.logical_modes
+        else:
+            self.device_site_list = self.site_list
         self._dev = None  # (sites tensor, tab tensor)
         self._aux = None  # device floats of gjx_program_prepare (None: not prepared yet)
         self._aux_n = 0
@@ -324,9 +491,10 @@ class PackedProgram:
         v = np.asarray(value, np.float32).ravel()
         self.tab[off:off + v.size] = v
         dirty = [(off, v.size)]
+        daddr = self.plate_of.get(addr, (addr, 0))[0]
         for doff, p, site_addr in self._derived:
-            if p.src == addr or (p.terms and any(a == addr for a, _ in p.terms)):
-                s = self.site_list[site_addr]
+            if p.src in (addr, daddr) or (p.terms and any(a in (addr, daddr) for a, _ in p.terms)):
+                s = self.device_site_list[site_addr]
                 vals = self._fold_observed(p, s.ncat if s.ncat else s.dim)
                 self.tab[doff:doff + vals.size] = vals
                 dirty.append((doff, vals.size))

@@ -186,3 +186,144 @@ class TestIterateSimpleNormal:
         want = (lp(f(new[4, "z"]), z3) + lp(z5, f(new[4, "z"]))) - (lp(f(old[4, "z"]), z3) + lp(z5, f(old[4, "z"])))
         assert f(w) == pytest.approx(want, rel=1e-4, abs=1e-5)
         assert f(new_tr.get_score()) == pytest.approx(f(tr.get_score()) + want, rel=1e-4, abs=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device plates (program.py compact_plates): the instances of a vmapped kernel as ONE vector site per kernel site, against
+# the ORACLE (oracle/gjx_oracle.c restates the site semantics of distribution.py:117-147 / static.py:340-399) on the very
+# program the device ran, and against the unrolled lowering of the same model.
+# ---------------------------------------------------------------------------------------------------------------
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _hier_logreg(N=1024, P=16, seed=0):
+    rs = np.random.default_rng(seed)
+    X = rs.standard_normal((N, P)).astype(np.float32)
+    beta = rs.standard_normal(P)
+    y = (rs.uniform(size=N) < 1.0 / (1.0 + np.exp(-X @ beta))).astype(np.float32)
+
+    @genjax.gen
+    def obs(x_row, b):
+        return genjax.bernoulli(x_row @ b) @ "y"
+
+    @genjax.gen
+    def model(Xd):
+        lt = genjax.normal(0.0, 1.0) @ "log_tau"
+        b = genjax.normal(np.zeros(P, np.float32), genjax.exp(lt)) @ "beta"
+        obs.vmap(in_axes=(0, None))(Xd, b) @ "ys"
+        return b
+
+    return model, X, y
+
+
+class TestVmapPlates:
+    def test_vmapped_hierarchical_logreg_is_three_sites_and_matches_the_oracle(self):
+        """vmap.py:193-218 with N = 1024 observed instances + 2 latents: the device program has 3 sites (the plate is one
+        bernoulli site with a [1024 x 16] affine parameter), runs on a GENERATED kernel, and its particles, scores and
+        weights equal the oracle's on that program and the unrolled lowering's on the same key."""
+        from genjax_amd import kernels
+        from oracle import cpu
+        model, X, y = _hier_logreg()
+        chm = C["ys", "y"].set(y)
+        prog, _, _ = model.pack((X,), chm, True)
+        assert len(prog.site_list.sites) == 1026 and prog.n_sites == 3 and len(prog.plate_of) == 1024
+        assert kernels.program_engine(prog) == 4                                  # a kernel generated from the 3-site list
+        K = 4096
+        tr, w = model.importance(genjax.key(7), chm, (X,), K=K)
+        assert tr.prog.n_sites == 3
+        o = cpu.run_program(tr.prog, genjax.key(7), K)
+        ch = _np(tr.choices)
+        np.testing.assert_allclose(ch, o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(w), o["weight"], rtol=3e-4, atol=2e-2)        # a sum of 1024 log-densities around -700
+        np.testing.assert_allclose(_np(tr.get_score()), o["score"], rtol=3e-4, atol=2e-2)
+        # the unrolled lowering of the same model under the same key (at N = 256: 1026 sites are more than the FLAT stream's
+        # 1023 site numbers, which is one of the things the plate removes): the latents come from the same streams (they
+        # precede the plate), the weight is the same sum
+        model_s, Xs, ys_ = _hier_logreg(N=256)
+        chm_s = C["ys", "y"].set(ys_)
+        prog_p, _, _ = model_s.pack((Xs,), chm_s, True)
+        prog_u, _, _ = model_s.pack((Xs,), chm_s, True, plates=False)
+        assert prog_p.n_sites == 3 and prog_u.n_sites == 258
+        op, ou = kernels.run_program(prog_p, genjax.key(7), 512), kernels.run_program(prog_u, genjax.key(7), 512)
+        np.testing.assert_allclose(_np(ou["choices"]), _np(op["choices"]), rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(ou["weight"]), _np(op["weight"]), rtol=3e-4, atol=5e-3)
+        # logical addressing is unchanged: every instance's value is there
+        got = tr.get_choices()
+        assert got["ys", 5, "y"].shape == (K,) and bool((got["ys", 5, "y"] == bool(y[5])).all())
+
+    def test_plate_with_a_latent_per_instance_matches_the_oracle(self):
+        """a kernel with two sites, the second reading the first of the SAME instance, and a latent outside the plate:
+        z_i ~ normal(mu, 1), y_i ~ normal(z_i, 0.5) observed -> vector sites z[n], y[n] with an elementwise VALUE link"""
+        from oracle import cpu
+        n = 64
+        ys = np.random.default_rng(1).standard_normal(n).astype(np.float32) + 1.0
+
+        @genjax.gen
+        def kernel(mu):
+            z = genjax.normal(mu, 1.0) @ "z"
+            return genjax.normal(z, 0.5) @ "y"
+
+        @genjax.gen
+        def model():
+            mu = genjax.normal(0.0, 2.0) @ "mu"
+            kernel.repeat(n=n)(mu) @ "k"
+            return mu
+
+        chm = C["k", "y"].set(ys)
+        K = 3000
+        tr, w = model.importance(genjax.key(11), chm, (), K=K)
+        assert tr.prog.n_sites == 3 and len(tr.prog.site_list.sites) == 1 + 2 * n
+        o = cpu.run_program(tr.prog, genjax.key(11), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(w), o["weight"], rtol=2e-4, atol=2e-3)
+        z = tr.get_choices()["k", :, "z"]                                          # [K][n]
+        assert tuple(z.shape) == (K, n)
+        lw = sum(genjax.normal.assess(C.v(float(ys[i])), (float(z[0, i]), 0.5))[0] for i in range(n))
+        assert f(w[0]) == pytest.approx(f(lw), rel=1e-4)
+        # through the inference layer: ImportanceK on the plate program == logsumexp of these weights - log K
+        from genjax_amd.inference import ImportanceK, Target
+        pc = ImportanceK(Target(model, (), chm), k_particles=K).run_smc(genjax.key(3))
+        lw = _np(pc.get_log_weights()).astype(np.float64)
+        assert f(pc.get_log_marginal_likelihood_estimate()) == pytest.approx(float(np.log(np.exp(lw - lw.max()).sum()) + lw.max() - np.log(K)), rel=1e-5)
+
+    def test_hmc_on_a_vmapped_model_uses_the_fused_kernel_and_matches_the_oracle(self):
+        """HMC.edit (hmc.py:156-211) on the .vmap-written config-5 model: the plate lowering gives the hand-written
+        matrix-core kernel its shape back; alpha and the moved values equal the oracle's HMC on the same program"""
+        from genjax_amd import HMC, kernels
+        from oracle import cpu
+        model, X, y = _hier_logreg()
+        chm = C["ys", "y"].set(y)
+        K = 256
+        tr, _ = model.importance(genjax.key(2), chm, (X,), K=K)
+        req = HMC(Selection.at["log_tau"] | Selection.at["beta"], 0.004, 20)
+        new_tr, alpha, _, _ = req.edit(genjax.key(9), tr, None)
+        shared_prog = req.last_program
+        assert shared_prog.n_sites == 3 and kernels.hmc_engine(shared_prog) in (2, 3)     # the hand-written config-5 kernels
+        o = cpu.hmc(shared_prog, genjax.key(9), _np(tr.rows_for(shared_prog)), 0.004, 20, False, False)
+        # alpha is a difference of two scores of size |score| (a sum of 1024 log-densities; chains started from the prior reach
+        # several thousand): the tolerance carries the float32 resolution of those sums
+        tol = 6e-3 + 6e-3 * np.abs(o["alpha"]) + 2e-5 * np.abs(o["score"])
+        assert (np.abs(_np(alpha) - o["alpha"]) <= tol).all(), float(np.abs(_np(alpha) - o["alpha"]).max())
+        np.testing.assert_allclose(_np(new_tr.choices), o["choices"], rtol=3e-3, atol=3e-3)
+
+    def test_simple_vmap_simulate_and_assess_match_the_oracle(self):
+        """test_vmap_combinator.py:29-40, 158-170 with the oracle as the checker instead of the device itself"""
+        from oracle import cpu
+
+        @genjax.vmap(in_axes=(0,))
+        @genjax.gen
+        def model(x):
+            return genjax.normal(x, 1.0) @ "z"
+
+        map_over = np.arange(0, 50, dtype=np.float32)
+        tr = model.simulate(genjax.key(314159), (map_over,), K=1000)
+        assert tr.prog.n_sites == 1 and len(tr.prog.site_list.sites) == 50
+        o = cpu.run_program(tr.prog, genjax.key(314159), 1000)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(tr.get_score()), o["score"], rtol=2e-4, atol=2e-3)
+        z = tr.get_choices()[:, "z"]
+        want = (-0.5 * (z.double().cpu() - np.arange(50)) ** 2 - 0.5 * np.log(2 * np.pi)).sum(dim=1)
+        np.testing.assert_allclose(_np(tr.get_score()), want.numpy(), rtol=1e-4, atol=1e-3)
+        sc, _ = model.assess(tr.get_particle(3).get_choices(), (map_over,))
+        assert f(sc) == pytest.approx(f(tr.get_score()[3]), rel=1e-5)
