@@ -60,7 +60,34 @@ struct Companion {   // derived constants in LDS behind the table
   int len = 0, dim = 0;
 };
 
-struct SiteStream { std::string key_var; unsigned site_no; };   // "" = the run key
+struct SiteStream {
+  std::string key_var; unsigned site_no;   // "" = the run key
+  int run = -1;                            // scalar-normal run the site belongs to (gjx.h "Scalar-normal runs"), -1: none
+  unsigned elem = 0;                       // its element in the run's stream
+  bool opens = false;                      // the run's head: declares and opens the stream
+};
+
+// Scalar-normal runs over a segment of emitted sites [j0, j1) that share one stream key and one numbering
+// (SiteStreamWalk::run_elem in gjx_device.h walks the same rule): fills run / elem / opens and points the members'
+// site_no at their head's
+void assign_runs(const gjx_program* prog, std::vector<SiteStream>& st, int j0, int j1, int& n_runs) {
+  if (prog->rng_mode != GJX_RNG_FLAT) return;
+  int head = -1;
+  unsigned next = 0;
+  int32_t tag = j0 < j1 ? prog->sites[j0].scan : 0;
+  for (int j = j0; j < j1; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.scan != tag) { head = -1; tag = s.scan; }
+    const bool draws = s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK;
+    if (GJX_FLAT_JOINS(prog->rng_mode, s.kind, s.dim, s.mode)) {
+      if (head < 0 || next >= (unsigned)GJX_FLAT_RUN_MAX) { head = j; next = 0; st[j].opens = true; st[j].run = n_runs++; }
+      else { st[j].run = st[head].run; st[j].site_no = st[head].site_no; }
+      st[j].elem = next++;
+    } else if (draws) {
+      head = -1;
+    }
+  }
+}
 
 // Where an emitted site's rows and table entries really are.  Outside a rolled Scan everything is static (the site's own
 // fields); inside the loop over t_ (steps 1 .. T-1 of a rolled Scan) the site is emitted ONCE, from step 1's descriptor,
@@ -317,12 +344,22 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
   const int np = n_params(kind);
+  if (pl.stream[j].opens) {
+    const SiteStream& hs = pl.stream[j];
+    o.f("    BitStream<RNG> rs%d[PPT];\n    PLOOP rs%d[p].open(%s, gidx[p], %du);\n", hs.run, hs.run,
+        hs.key_var.empty() ? "a.key" : hs.key_var.c_str(), hs.site_no);
+  }
   o.f("    { // ---- site %d: kind %d, dim %d, mode %d, slot %d\n", j, kind, is_categorical(kind) ? s.ncat : s.dim, mode, s.slot);
   o.f("      float lp[PPT];\n      PLOOP lp[p] = 0.0f;\n");
   // stream key and site number (gjx.h "Scan steps"): chained step keys are wave-uniform locals emitted on first use
-  if (draws) {
-    if (prog->rng_mode != GJX_RNG_FLAT || pl.stream[j].key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", pl.stream[j].site_no);
-    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", pl.stream[j].key_var.c_str(), pl.stream[j].site_no);
+  const SiteStream& ss = pl.stream[j];
+  if (draws && ss.run >= 0) {
+    // member of a scalar-normal run: the run's stream lives OUTSIDE the site's block (declared by the head, in the
+    // enclosing scope), members 2k and 2k+1 share one Box-Muller evaluation through its pair cache
+    o.f("      BitStream<RNG> (&bs)[PPT] = rs%d;\n", ss.run);
+  } else if (draws) {
+    if (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", ss.site_no);
+    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", ss.key_var.c_str(), ss.site_no);
   }
   if (masked) o.f("      bool given[PPT];\n      PLOOP given[p] = v[%d][p] != 0.0f;\n", s.obs_off);
   emit_gather_index(o, s, j, np);
@@ -416,7 +453,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (rcpb.empty()) rcpb = "fast_rcp(pb)";
         o.f("%sfloat val;\n", in2.c_str());
         if (mode == GJX_MODE_SAMPLE) {
-          o.f("%sconst float n_ = stream_normal<RNG>(bs[p], (uint32_t)(%s));\n", in2.c_str(), dx.c_str());
+          o.f("%sconst float n_ = stream_normal<RNG>(bs[p], (uint32_t)(%u + (%s)));\n", in2.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
           o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
           if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), dx.c_str());
@@ -484,6 +521,10 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     for (int j = 0; j < roll.i0; ++j) pl.stream.push_back({"", ++plain});
     for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"sk0", (unsigned)(l + 1)});
     for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"skt", (unsigned)(l + 1)});
+    int n_runs = 0;   // runs never cross the three segments (the Scan tag changes at each boundary)
+    assign_runs(prog, pl.stream, 0, roll.i0, n_runs);
+    assign_runs(prog, pl.stream, roll.i0, roll.i0 + roll.m, n_runs);
+    assign_runs(prog, pl.stream, roll.i0 + roll.m, roll.i0 + 2 * roll.m, n_runs);
     char b[256];
     snprintf(b, sizeof(b), "  const key2 sk0 = fold_in(fold_in(a.key, %uu), 0u);\n", 0x80000000u | roll.scan_id);
     pl.key_decls = b;
@@ -513,6 +554,8 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       }
       pl.stream.push_back({cur, ++local});
     }
+    int n_runs = 0;
+    assign_runs(prog, pl.stream, 0, prog->n_sites, n_runs);
   }
   Emit body;
   if (roll.ok) {

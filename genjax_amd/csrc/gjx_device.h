@@ -116,11 +116,27 @@ struct SiteStreamWalk {
   int32_t tag;       // scan tag of the previous site
   uint32_t local;    // sites seen in the current step
   uint32_t plain;    // non-Scan sites seen
-  GJX_DEV explicit SiteStreamWalk(key2 k) : run_key(k), key(k), tag(0), local(0u), plain(0u) {}
+  uint32_t run_head, run_next;   // open scalar-normal run (gjx.h "Scalar-normal runs"): its head's site number (0 = none), next element
+  GJX_DEV explicit SiteStreamWalk(key2 k) : run_key(k), key(k), tag(0), local(0u), plain(0u), run_head(0u), run_next(0u) {}
+  // Scalar-normal runs: call after next() with the site's number.  `joins`: the site is a sampled scalar normal
+  // (GJX_FLAT_JOINS); `draws`: it consumes random bits at all.  -> the element of the stream at which the site's draws
+  // start; `site` becomes the site number of the stream (the run's head for a member of a run); `opens` tells a member
+  // that it is the head (the stream is to be opened).
+  GJX_DEV uint32_t run_elem(uint32_t& site, bool joins, bool draws, bool& opens) {
+    opens = false;
+    if (joins) {
+      if (run_head == 0u || run_next >= (uint32_t)GJX_FLAT_RUN_MAX) { run_head = site; run_next = 0u; opens = true; }
+      site = run_head;
+      return run_next++;
+    }
+    if (draws) run_head = 0u;
+    return 0u;
+  }
   // -> site number; `key` is the key to open the stream with
   GJX_DEV uint32_t next(int32_t scan) {
-    if (scan == 0) { key = run_key; tag = 0; return ++plain; }
+    if (scan == 0) { if (tag != 0) run_head = 0u; key = run_key; tag = 0; return ++plain; }
     if (scan != tag) {
+      run_head = 0u;
       const uint32_t id = (uint32_t)scan >> 20;
       const int32_t step = (int32_t)((uint32_t)scan & 0xFFFFFu) - 1;
       const bool follows = tag != 0 && ((uint32_t)tag >> 20) == id && (int32_t)((uint32_t)tag & 0xFFFFFu) - 1 == step - 1;

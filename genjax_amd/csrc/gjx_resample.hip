@@ -305,8 +305,18 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
       for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? x[p0 + k] : 0.0f;
     }
   };
-  float xv[ITEMS];
+  // the block's own tile and its two neighbours: with weights that are not collapsed the slots of block b draw from
+  // tiles b - 1 .. b + 1, so their cumulative weights are laid out in LDS while the tile totals travel (below)
+  const int w0 = (int)blockIdx.x - 1;            // first tile of the prefetched window
+  float xv[ITEMS], xn[2][ITEMS];
   load_tile(i0, xv);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tc = w0 + 2 * c;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) xn[c][k] = 0.0f;
+    if (tc >= 0 && tc < nb) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xn[c]);
+  }
   float sm_sum;
   const float mx = block_ref_max(mode, lse, n_partials, fred, &sm_sum);
   if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -314,16 +324,40 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
     lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;
   }
   // ---- own tile total -> all-gather ----
+  uint64_t qown[ITEMS], sown = 0, incown;
   {
-    uint64_t qs = 0;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) qs += (i0 + k < K) ? weight_q(xv, k, mode, mx) : 0;
-    const uint64_t wt = wave_sum_u64(qs);
-    if (lane == 0) wsum[wid] = wt;
+    for (int k = 0; k < ITEMS; ++k) { sown += (i0 + k < K) ? weight_q(xv, k, mode, mx) : 0; qown[k] = sown; }
+    incown = wave_scan_u64(sown);
+    if (lane == 63) { wsum[wid] = incown; s_wtot[1][wid] = incown; }
     __syncthreads();
     if (threadIdx.x == 0) grid_publish(agg, tag, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   }
   GJX_STAMP(1);
+  // ---- while the totals are in flight: cumulative weights of tiles b - 1, b, b + 1 RELATIVE to each tile's start ----
+  {
+    uint64_t qn[2][ITEMS], sn[2], incn[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int tc = w0 + 2 * c;
+      const bool on = tc >= 0 && tc < nb;
+      const int64_t p0 = (int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS;
+      sn[c] = 0;
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) { sn[c] += (on && p0 + k < K) ? weight_q(xn[c], k, mode, mx) : 0; qn[c][k] = sn[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) incn[c] = wave_scan_u64(sn[c]);
+    if (lane == 63) { s_wtot[0][wid] = incn[0]; s_wtot[2][wid] = incn[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uint64_t base = c == 1 ? incown - sown : incn[c >> 1] - sn[c >> 1];
+      for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + (c == 1 ? qown[k] : qn[c >> 1][k]);
+    }
+  }
   grid_gather(agg, tag, ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
   if (threadIdx.x == 0) P[0] = 0;
   __syncthreads();
@@ -408,6 +442,24 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
     if (threadIdx.x == 255) s_range[1] = tile[ITEMS - 1];
     __syncthreads();
     const int tmin = s_range[0], ntiles = s_range[1] - tmin + 1;
+    if (tmin >= w0 && s_range[1] <= w0 + 2) {       // block-uniform: every source tile is in the prefetched window
+      GJX_STAMP(3);
+      int pos[ITEMS];
+      const uint64_t* cm[ITEMS];
+      uint64_t Tr[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) { cm[k] = cumL + (tile[k] - w0) * TILE; Tr[k] = T[k] - P[tile[k]]; pos[k] = 0; }
+#pragma unroll
+      for (int q = TILE >> 2; q >= 1; q >>= 2) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+          const uint64_t pa = cm[k][pos[k] + q - 1], pb = cm[k][pos[k] + 2 * q - 1], pc = cm[k][pos[k] + 3 * q - 1];
+          pos[k] += (pa <= Tr[k] ? q : 0) + (pb <= Tr[k] ? q : 0) + (pc <= Tr[k] ? q : 0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((int64_t)tile[k] * TILE + pos[k]);
+    } else {
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) kpos[k] = tile[k] - tmin;
     auto next_live = [&](int at) { while (at < ntiles && P[tmin + at + 1] == P[tmin + at]) ++at; return at; };
@@ -471,8 +523,13 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
         if (mine[k]) anc[k] = (int32_t)((int64_t)tile[k] * TILE + pos[k]);
       idx = nidx;
     }
+    }
   }
   GJX_STAMP(4);
+  // if a rendezvous timed out (grid not co-resident) the totals are partial and the ancestors undefined (the caller
+  // repeats the call): keep them inside the rows whatever happened — one v_med3_i32 per slot
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) anc[k] = max(0, min(anc[k], (int32_t)(K - 1)));
   // ---- children: rows of the ancestors, ITEMS consecutive slots per lane ----
   const bool whole = i0 + ITEMS <= K;
   if (ancestors) {
@@ -526,7 +583,9 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_out) return;
   const int32_t a = anc[j];
-  if (a < 0) return;
+  // a < 0: a slot another rank fills (prefilled -1).  a >= src_stride cannot come from a completed resampling, but the
+  // ancestors of a co-resident kernel that timed out are undefined (the caller repeats the call): never read outside the rows
+  if ((uint64_t)(int64_t)a >= (uint64_t)src_stride) return;
   for (int r = 0; r < rows; ++r) dst[(int64_t)r * dst_stride + j] = src[(int64_t)r * src_stride + a];
 }
 

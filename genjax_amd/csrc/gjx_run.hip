@@ -72,15 +72,20 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
 
   float score = 0.0f, weight = 0.0f;
   SiteStreamWalk walk(a.key);     // wave-uniform: chained step keys of Scan sites (gjx.h "Scan steps")
+  BitStreamRT<RNG> rs;            // stream of the open scalar-normal run (gjx.h "Scalar-normal runs"): lives across sites
   for (int j = 0; j < a.n_sites; ++j) {
     const gjx_site& s = a.sites[j];
     const int kind = s.kind, mode = s.mode, slot = s.slot;
-    const uint32_t site_no = RNG == GJX_RNG_FLAT ? walk.next(s.scan) : (uint32_t)(j + 1);
+    uint32_t site_no = RNG == GJX_RNG_FLAT ? walk.next(s.scan) : (uint32_t)(j + 1);
     BitStreamRT<RNG> bs;
     const bool masked = mode == GJX_MODE_OBS_MASK;
     const bool draws = mode == GJX_MODE_SAMPLE || masked;           // wave-uniform
     const bool given = masked ? (val(s.obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
-    if (draws) bs.open(RNG == GJX_RNG_FLAT ? walk.key : a.key, gidx, site_no);
+    const bool joins = GJX_FLAT_JOINS(RNG, kind, s.dim, mode);      // wave-uniform
+    bool opens = false;
+    const uint32_t e0 = RNG == GJX_RNG_FLAT ? walk.run_elem(site_no, joins, draws, opens) : 0u;
+    if (joins) { if (opens) rs.open(walk.key, gidx, site_no); }
+    else if (draws) bs.open(RNG == GJX_RNG_FLAT ? walk.key : a.key, gidx, site_no);
     float lp = 0.0f;
     if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
       const int n = s.ncat;
@@ -189,7 +194,8 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
           const float pc = NP > 2 ? eval_param(s.p[2], d, tab, val) : 0.0f;
           const float pd = NP > 3 ? eval_param(s.p[3], d, tab, val) : 0.0f;
           float v;
-          if (draws) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
+          if (KIND == GJX_NORMAL && joins) v = fmaf(pb, stream_normal<RNG>(rs, e0), pa);     // member e0 of its run
+          else if (draws) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
           else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
           else v = val(slot + d);
           if (masked && given) v = val(slot + d);

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_ssm_step(SsmArgs a) {
   else if (gidx >> 32) sk = threefry2x32(a.key, 0xFFFFFFFFu, (uint32_t)(gidx >> 32));
   float xn[DX];
   if (a.t > 0) {
-    const int64_t src = a.anc ? (int64_t)a.anc[ii] : ii;
+    // (ancestors left by a co-resident resampler that timed out are undefined — the caller repeats the run —: stay inside the rows)
+    const int64_t src = a.anc ? (int64_t)max(0, min(a.anc[ii], (int32_t)(a.prev_stride - 1))) : ii;
     float xp[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) xp[d] = a.x_prev[(int64_t)d * a.prev_stride + src];
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void k_ssm_fused_step(SsmFusedArgs f) {
   // ---- propagate + reweight slot j from its ancestor (k_ssm_step's arithmetic, same streams) ----
   if (active && f.ancestors) f.ancestors[j] = (int32_t)src;
   if (!active) src = 0;
+  if (src >= a.K) src = a.K - 1;    // only after a timed-out rendezvous (undefined totals): stay inside the rows
   const uint64_t gidx = (uint64_t)(a.offset + j);
   key2 skj = a.key;
   if (RNG == GJX_RNG_JAX32) skj = fold_in(fold_in64(a.key, gidx), 1u);

@@ -161,6 +161,18 @@ typedef struct gjx_site {
 enum { GJX_RNG_FLAT = 0, GJX_RNG_JAX32 = 1 };
 #define GJX_FLAT_SITE_SHIFT 22
 #define GJX_FLAT_MAX_SITES 1023
+/* Scalar-normal runs (GJX_RNG_FLAT only).  A model written as a chain of scalar normal sites (x_t ~ normal(x_{t-1}, s),
+ * one address per step) would spend one hash and one half-used Box-Muller pair per site.  Instead, walking the sites in
+ * order, the sampled scalar normal sites (kind GJX_NORMAL, dim 1, mode GJX_MODE_SAMPLE) form RUNS: a run starts at such
+ * a site when none is open; every following such site joins it; sites that draw nothing (OBS_TAB, OBS_SLOT) are
+ * transparent; any other drawing site, a change of the Scan tag, or GJX_FLAT_RUN_MAX members close it.  All members of
+ * a run read the stream of the run's HEAD (its key and site number): member number e (from 0) takes stream element e,
+ * so members 2k and 2k+1 are the two outputs of ONE Box-Muller evaluation and 16 members cost 6 hashes — exactly the
+ * stream of a 16-wide mv_normal_diag site at the head's position.  A run of one member is the plain per-site stream.
+ * The site numbers of the members are not reused.  (Interpreter, generated kernels and the oracle walk the same rule:
+ * SiteStreamWalk::run_elem in csrc/gjx_device.h, run_particle in oracle/gjx_oracle.c.) */
+#define GJX_FLAT_RUN_MAX 32
+#define GJX_FLAT_JOINS(rng_mode, kind, dim, mode) ((rng_mode) == GJX_RNG_FLAT && (kind) == GJX_NORMAL && (dim) == 1 && (mode) == GJX_MODE_SAMPLE)
 
 typedef struct gjx_program {
   int32_t n_sites;

@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
             getattr(L, n).argtypes = [u32]
             getattr(L, n).restype = f32
         L.gjxo_set_margin_buffer.argtypes = [vp, i64]
+        L.gjxo_set_momenta_buffer.argtypes = [vp, i64]
         L.gjxo_num_threads.restype = C.c_int
         L.gjxo_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -241,12 +242,15 @@ def score_grad(prog: PackedProgram, choices):
     return score, grad
 
 
-def hmc(prog: PackedProgram, key, choices, eps, L, stale=False, accept=False, offset=0):
+def hmc(prog: PackedProgram, key, choices, eps, L, stale=False, accept=False, offset=0, want_momenta=False):
     """-> dict(choices, score, alpha, accepted, margin): margin[i] = |log u - alpha| of chain i's accept decision (with
     ``accept``; 3e38 otherwise) — a device chain may take the other branch only where this is below the tolerance to
-    which its alpha matches the oracle's"""
+    which its alpha matches the oracle's.  ``want_momenta``: also "momenta" [selected scalars, n], the initial draw."""
     ch = np.ascontiguousarray(choices, np.float32).copy()
     n = ch.shape[1]
+    mom = np.zeros((prog.n_slots, n), np.float32) if want_momenta else None
+    if want_momenta:
+        lib().gjxo_set_momenta_buffer(_p(mom), n)
     score = np.zeros(n, np.float32)
     alpha = np.zeros(n, np.float32)
     acc = np.zeros(n, np.float32)
@@ -258,4 +262,8 @@ def hmc(prog: PackedProgram, key, choices, eps, L, stale=False, accept=False, of
                        _p(ch), _p(score), _p(alpha), _p(acc))
     finally:
         lib().gjxo_set_margin_buffer(None, 0)
-    return dict(choices=ch, score=score, alpha=alpha, accepted=acc, margin=margin)
+        lib().gjxo_set_momenta_buffer(None, 0)
+    out = dict(choices=ch, score=score, alpha=alpha, accepted=acc, margin=margin)
+    if want_momenta:
+        out["momenta"] = mom
+    return out

@@ -80,6 +80,11 @@ static _Thread_local float t_margin = 3.0e38f;
 static float* g_margin_buf = 0;
 static int64_t g_margin_n = 0;
 void gjxo_set_margin_buffer(float* buf, int64_t n) { g_margin_buf = buf; g_margin_n = n; }
+/* optional [n_selected_scalars][n] buffer that gjxo_hmc fills with the initial momenta it drew (tests integrate the same
+ * trajectory in float64 from them to size the float32 tolerance) */
+static float* g_momenta_buf = 0;
+static int64_t g_momenta_n = 0;
+void gjxo_set_momenta_buffer(float* buf, int64_t n) { g_momenta_buf = buf; g_momenta_n = n; }
 static inline void decide(float lhs, float rhs) {
   float m = fabsf(lhs - rhs), sc = fabsf(lhs) > fabsf(rhs) ? fabsf(lhs) : fabsf(rhs);
   if (sc > 1.0f) m /= sc;
@@ -511,13 +516,16 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
   okey skey = run_key;
   int32_t tag = 0;
   uint32_t local = 0u, plain = 0u;
+  uint32_t run_head = 0u, run_next = 0u; /* open scalar-normal run (gjx.h "Scalar-normal runs"): head's site number, next element */
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
     uint32_t site_no = (uint32_t)(j + 1);
+    uint32_t e0 = 0u; /* element of the stream at which this site's draws start */
     if (prog->rng_mode == GJX_RNG_FLAT) {
-      if (s->scan == 0) { skey = run_key; tag = 0; site_no = ++plain; }
+      if (s->scan == 0) { if (tag != 0) run_head = 0u; skey = run_key; tag = 0; site_no = ++plain; }
       else {
         if (s->scan != tag) {
+          run_head = 0u;
           const uint32_t id = GJX_SCAN_ID(s->scan);
           const int32_t step = GJX_SCAN_STEP(s->scan);
           if (tag != 0 && GJX_SCAN_ID(tag) == id && GJX_SCAN_STEP(tag) == step - 1) skey = fold_in(skey, (uint32_t)step);
@@ -529,6 +537,14 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
           local = 0u;
         }
         site_no = ++local;
+      }
+      /* the STATIC mode decides membership (a masked site draws per particle: it closes the run) */
+      if (GJX_FLAT_JOINS(prog->rng_mode, s->kind, s->dim, s->mode)) {
+        if (run_head == 0u || run_next >= (uint32_t)GJX_FLAT_RUN_MAX) { run_head = site_no; run_next = 0u; }
+        site_no = run_head;
+        e0 = run_next++;
+      } else if (s->mode == GJX_MODE_SAMPLE || s->mode == GJX_MODE_OBS_MASK) {
+        run_head = 0u;
       }
     }
     /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
@@ -632,7 +648,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
         float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
         int wide = s->kind >= GJX_STUDENT_T;
         float v;
-        if (mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, (uint32_t)(d * nd), a, b);
+        if (mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, e0 + (uint32_t)(d * nd), a, b);
         else if (mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
         else v = vals[s->slot + d];
         lp += wide ? elem_logpdf4(s->kind, v, a, b, c, e) : elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
@@ -1264,6 +1280,7 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
                                                            : stream_open(GJX_RNG_FLAT, key, gidx, (uint32_t)leaf_of[m] + 1u);
         p[m] = stream_normal(&ms, (uint32_t)elem_of[m]);
         k0 += -0.5f * p[m] * p[m] - HALF_LOG_2PI;
+        if (g_momenta_buf && i < g_momenta_n) g_momenta_buf[(int64_t)m * g_momenta_n + i] = p[m];
       }
       for (int s = 0; s < ns; ++s) g[s] = g0[s];
       float sc = score0;

@@ -48,7 +48,7 @@ NEAR_TIE = 3e-4   # relative margin of a discrete decision below which the devic
                   # float32 sums in another order) may land on the other side of the oracle's comparison
 
 
-def assert_near_ties_only(bad, ora, what="", cap=0.02):
+def assert_near_ties_only(bad, ora, what="", cap=0.005):
     """Particles that differ from the oracle must be NEAR TIES of a discrete decision the oracle took for them (which
     category, accept / reject, which side of a floor): the oracle reports each particle's smallest decision margin
     (oracle/gjx_oracle.c `decide`), and only margins below NEAR_TIE excuse a mismatch.  `cap` bounds their share."""
@@ -551,7 +551,34 @@ def test_bootstrap_filter_full_size(K_, golden):
     out = bf.run(core.key(1), s["y"], keep_means=True)
     assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
     np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
-    np.testing.assert_allclose(_np(out["means"]), means, atol=0.15)
+    # filtered mean vs Kalman mean at full size (posterior sd ~1, min ESS ~0.05 K: sigma_MC ~0.01)
+    np.testing.assert_allclose(_np(out["means"]), means, atol=0.08)
+    assert float(np.sqrt(np.mean((_np(out["means"]) - means) ** 2))) < 0.015
+
+
+@pytest.mark.parametrize("weights", ["global_max", "tile_scaled"])
+def test_bootstrap_filter_seeds_vs_float64_filter(K_, weights):
+    """Is the device filter's log-ML error Monte-Carlo spread or fixed-point quantisation?  32 seeds at config 3 full size
+    on the device, against the spread of an IDEAL float64 bootstrap filter (NumPy) over 16 seeds at the same size
+    (tests/golden/ssm_pf_float64.json, written by tests/golden/make_ssm_pf_float64.py).  The ideal filter's own rms
+    relative error at K = 2^18 is 8e-5 (some of its seeds exceed 1e-4), so single runs at 9e-5 are Monte-Carlo spread;
+    asserted: the device rms is within 1.5x the ideal filter's, no device run is beyond 3.5x that rms, and the mean
+    error (bias) is within the spread of a mean of 32."""
+    import json
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ssm_pf_float64.json")))
+    s = cf.ssm_problem()
+    exact, _, _ = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
+    assert exact == pytest.approx(fx["kalman_log_lik"], rel=1e-12)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18, weights=weights)
+    rel = np.array([(float(bf.run(core.key(100 + sd), s["y"])["log_ml"]) - exact) / abs(exact) for sd in range(32)])
+    rms, ideal = float(np.sqrt(np.mean(rel ** 2))), fx["rms_rel_err"]
+    print(f"{weights}: device rms rel-err {rms:.3g} (mean {rel.mean():.3g}, max |.| {np.abs(rel).max():.3g}, "
+          f"{int((np.abs(rel) <= 1e-4).sum())}/32 within 1e-4); ideal float64 filter rms {ideal:.3g} "
+          f"({sum(abs(r) <= 1e-4 for r in fx['rel_err'])}/{len(fx['rel_err'])} within 1e-4)")
+    assert rms <= 1.5 * ideal
+    assert np.abs(rel).max() <= 3.5 * ideal
+    assert abs(rel.mean() - np.mean(fx["rel_err"])) <= 3.0 * ideal * math.sqrt(1 / 32 + 1 / len(fx["rel_err"]))
 
 
 def test_native_filter_loop_equals_step_by_step(K_):
@@ -636,7 +663,6 @@ def test_hmc_logreg_fused_vs_generic_vs_oracle(K_, oracle, rng, shape, monkeypat
         # decisions differ from the oracle's only where log u lies between the two alphas
         assert_accept_flips_explained(_np(f["accepted"]) != o["accepted"], _np(f["alpha"]), o)
         assert_accept_flips_explained(_np(g["accepted"]) != o["accepted"], _np(g["alpha"]), o)
-        assert same.mean() > 0.97
         tol = dict(rtol=3e-3, atol=3e-3)
         np.testing.assert_allclose(_np(f["choices"])[:, same], _np(g["choices"])[:, same], **tol)
         np.testing.assert_allclose(_np(f["choices"])[:, same], o["choices"][:, same], **tol)
@@ -648,14 +674,43 @@ def test_hmc_logreg_fused_vs_generic_vs_oracle(K_, oracle, rng, shape, monkeypat
             np.testing.assert_array_equal(_np(f["choices"])[:, rej], ch[:, rej])
 
 
+def _logreg_leapfrog_f64(pr, q0, p0, eps, L):
+    """The config-5 trajectory in float64 (NumPy; closed-form gradient of log_tau ~ N(0,1), beta ~ N(0, e^log_tau),
+    y ~ bernoulli_logits(X beta)) from the SAME initial state and momenta: hmc.py:170-203 without the stale carry.
+    -> (q_L [17, n], alpha [n])."""
+    X, y = pr["X"].astype(np.float64), pr["y"].astype(np.float64)[:, None]
+    P = X.shape[1]
+
+    def lpg(q):
+        lt, b = q[0], q[1:]
+        s2, bb, z = np.exp(-2.0 * lt), (b * b).sum(0), X @ b
+        lp = -0.5 * lt * lt - P * lt - 0.5 * bb * s2 + (y * z - np.logaddexp(0.0, z)).sum(0)
+        g = np.empty_like(q)
+        g[0] = -lt - P + bb * s2
+        g[1:] = -b * s2 + X.T @ (y - 1.0 / (1.0 + np.exp(-z)))
+        return lp, g
+
+    q, p = q0.astype(np.float64), p0.astype(np.float64)
+    eps = float(np.float32(eps))
+    lp0, g = lpg(q)
+    k0 = -0.5 * (p * p).sum(0)
+    for _ in range(L):
+        p += 0.5 * eps * g
+        q += eps * p
+        lp, g = lpg(q)
+        p += 0.5 * eps * g
+    return q, lp - lp0 - 0.5 * (p * p).sum(0) - k0
+
+
 def test_hmc_logreg_long_trajectory_energy(K_, oracle):
-    """config 5 integrator settings (eps 0.01, L 1000, N 1024, P 16).  (1) the fused kernel follows the oracle's
-    float32 trajectory for 1000 steps; (2) the energy error alpha is the leapfrog's O(eps^2) discretisation
-    error: quartering eps at fixed trajectory length shrinks it ~16x."""
+    """config 5 integrator settings (eps 0.01, L 1000, N 1024, P 16).  (1) 256 chains of the fused kernel against the
+    SAME trajectories integrated in float64 (same initial states, same momenta), with the tolerance DERIVED from how far
+    the float32 oracle itself drifts from float64 over the 1000 steps — no flat number; (2) the energy error alpha is
+    the leapfrog's O(eps^2) discretisation error: quartering eps at fixed trajectory length shrinks it ~16x."""
     import torch
     prog, pr = H.logreg(N=1024, P=16)
     rs = np.random.default_rng(6)
-    n = 2048
+    n, nc = 2048, 256
     ch0 = (rs.standard_normal((17, n)) * 0.1).astype(np.float32)
     out = K_.hmc(prog, (3, 3), torch.as_tensor(ch0).cuda(), 0.01, 1000, False, False)
     al = _np(out["alpha"])
@@ -663,12 +718,50 @@ def test_hmc_logreg_long_trajectory_energy(K_, oracle):
     s1, _ = K_.score_grad(prog, out["choices"])
     np.testing.assert_allclose(_np(out["score"]), _np(s1), rtol=1e-4, atol=5e-2)
     assert float((out["choices"].cpu() - torch.as_tensor(ch0)).abs().mean()) > 0.05        # the chains moved
-    o = oracle.hmc(prog, (3, 3), ch0[:, :8].copy(), 0.01, 1000, False, False)      # chains 0..7 (same global indices)
-    np.testing.assert_allclose(_np(out["choices"])[:, :8], o["choices"], rtol=2e-2, atol=2e-2)
-    np.testing.assert_allclose(al[:8], o["alpha"], atol=5e-2)
+    o = oracle.hmc(prog, (3, 3), ch0[:, :nc].copy(), 0.01, 1000, False, False, want_momenta=True)   # chains 0..255 (same global indices)
+    q64, al64 = _logreg_leapfrog_f64(pr, ch0[:, :nc], o["momenta"][:17], 0.01, 1000)
+    d_o = np.abs(o["choices"] - q64).max(axis=0)                 # per chain: float32 oracle vs float64
+    d_g = np.abs(_np(out["choices"])[:, :nc] - q64).max(axis=0)  # per chain: device vs float64
+    a_o, a_g = np.abs(o["alpha"] - al64), np.abs(al[:nc] - al64)
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    print(f"L=1000 drift from float64, 256 chains: oracle f32 rms {rms(d_o):.3g} median {np.median(d_o):.3g} max {d_o.max():.3g}; "
+          f"device rms {rms(d_g):.3g} median {np.median(d_g):.3g} max {d_g.max():.3g}; "
+          f"alpha: oracle rms {rms(a_o):.3g} max {a_o.max():.3g}, device rms {rms(a_g):.3g} max {a_g.max():.3g}")
+    # the device (MFMA contraction order, v_exp/v_rcp) may drift as far as the float32 oracle does, times a small factor
+    assert np.median(d_g) <= 3.0 * np.median(d_o)
+    assert rms(d_g) <= 3.0 * rms(d_o)
+    assert d_g.max() <= 4.0 * d_o.max()
+    assert rms(a_g) <= 3.0 * rms(a_o) and a_g.max() <= 4.0 * a_o.max()
     fine = K_.hmc(prog, (3, 3), torch.as_tensor(ch0).cuda(), 0.0025, 4000, False, False)
     ratio = np.abs(al).mean() / np.abs(_np(fine["alpha"])).mean()
     assert 8.0 < ratio < 32.0, ratio                                               # second-order integrator
+
+
+def test_hmc_logreg_posterior_mean_vs_float64_long_run(K_):
+    """posterior mean of (log_tau, beta) of the config-5 model from the device chains — 2^14
+    chains, moves of L = 1000 leapfrogs at eps = 0.01 with the fused Metropolis accept — against a LONG float64 run
+    (tests/golden/logreg_posterior.json, written by tests/golden/make_logreg_posterior.py: an independent NumPy sampler),
+    tolerance 3 sigma_MC per coordinate, sigma_MC^2 = posterior variance / chains + (the fixture's own standard error)^2."""
+    import json
+    import torch
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "logreg_posterior.json")))
+    mean, sd, se = (np.array(fx[k]) for k in ("mean", "sd", "mc_se"))
+    prog, pr = H.logreg(N=1024, P=16)
+    n = 1 << 14
+    rs = np.random.default_rng(11)
+    ch = torch.as_tensor((rs.standard_normal((17, n)) * 0.1).astype(np.float32)).cuda()
+    acc = []
+    for mv in range(4):                 # trajectory length 10 per move >> the posterior scale (~0.1): a few moves forget the start
+        out = K_.hmc(prog, (5, 100 + mv), ch, 0.01, 1000, False, True)
+        ch = out["choices"]
+        acc.append(float(out["accepted"].mean()))
+    got = _np(ch).astype(np.float64)
+    sig = np.sqrt(sd ** 2 / n + se ** 2)
+    z = (got.mean(axis=1) - mean) / sig
+    print("accept rates", np.round(acc, 3), "z-scores", np.round(z, 2))
+    assert min(acc) > 0.6
+    assert np.abs(z).max() < 3.0 * 1.35, z          # 17 coordinates: 3 sigma each, widened for the maximum of 17 (P(|z|max > 4.05) ~ 1e-3)
+    np.testing.assert_allclose(got.std(axis=1), sd, rtol=0.05)
 
 
 def test_hmc_all_kinds_gradient(K_, oracle):

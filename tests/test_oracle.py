@@ -657,3 +657,39 @@ def test_shape_parameter_gradients_by_finite_differences(oracle):
         ok = np.abs(fd) < 200
         assert ok.mean() > 0.9
         np.testing.assert_allclose(gr[slot][ok], fd[ok], rtol=0.03, atol=0.05, err_msg=addr)
+
+
+def test_scalar_normal_run_is_the_stream_of_a_vector_site_at_its_head_oracle():
+    """gjx.h "Scalar-normal runs" in the oracle: 16 sampled scalar N(0, 1) sites in a row (observed sites between them are
+    transparent) draw exactly what one 16-wide mv_normal_diag(0, 1) site at the head's position draws; a drawing site of
+    another kind closes the run; JAX32 streams are per site as before."""
+    from genjax_amd import _abi as A
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    from oracle import cpu
+    a, b = SiteList(), SiteList()
+    a.add("pre", A.FLIP, [0.5])
+    b.add("pre", A.FLIP, [0.5])
+    modes, obs = {}, {}
+    for t in range(16):
+        a.add(("z", t), A.NORMAL, [Param.const(0.0), Param.const(1.0)])
+        a.add(("y", t), A.NORMAL, [Param.value(("z", t)), Param.const(1.0)])
+        modes[("y", t)] = A.MODE_OBS_TAB
+        obs[("y", t)] = np.float32(0.25)
+    b.add("z", A.MVNORMAL_DIAG, [np.zeros(16, np.float32), np.ones(16, np.float32)], dim=16)
+    K = 500
+    oa = cpu.run_program(PackedProgram(a, modes, obs), (0, 5), K)["choices"]
+    ob = cpu.run_program(PackedProgram(b), (0, 5), K)["choices"]
+    np.testing.assert_array_equal(oa, ob)
+    # closing: z0, z1 | flip | z2: z2 heads a new run at ITS site number = element 0 of site 4's stream
+    c, d = SiteList(), SiteList()
+    for sl in (c, d):
+        sl.add("z0", A.NORMAL, [Param.const(0.0), Param.const(1.0)])
+        sl.add("z1", A.NORMAL, [Param.const(0.0), Param.const(1.0)])
+        sl.add("f", A.FLIP, [0.5])
+    c.add("z2", A.NORMAL, [Param.const(0.0), Param.const(1.0)])
+    d.add("z2", A.MVNORMAL_DIAG, [np.zeros(1, np.float32), np.ones(1, np.float32)], dim=1)
+    np.testing.assert_array_equal(cpu.run_program(PackedProgram(c), (0, 5), K)["choices"], cpu.run_program(PackedProgram(d), (0, 5), K)["choices"])
+    # the reference's key structure is untouched: every site its own fold_in
+    ja = cpu.run_program(PackedProgram(a, modes, obs, rng_mode=A.RNG_JAX32), (0, 5), K)["choices"]
+    jb = cpu.run_program(PackedProgram(b, rng_mode=A.RNG_JAX32), (0, 5), K)["choices"]
+    assert not np.array_equal(ja[1:], jb[1:])
