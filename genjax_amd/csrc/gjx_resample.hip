@@ -9,6 +9,7 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 #include "gjx_scan.h"
+#include "gjx_tile.h"
 
 namespace gjx {
 
@@ -310,13 +311,6 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
   const int w0 = (int)blockIdx.x - 1;            // first tile of the prefetched window
   float xv[ITEMS], xn[2][ITEMS];
   load_tile(i0, xv);
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int tc = w0 + 2 * c;
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) xn[c][k] = 0.0f;
-    if (tc >= 0 && tc < nb) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xn[c]);
-  }
   float sm_sum;
   const float mx = block_ref_max(mode, lse, n_partials, fred, &sm_sum);
   if (mode == 2 && lse_out && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -334,7 +328,16 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
     if (threadIdx.x == 0) grid_publish(agg, tag, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   }
   GJX_STAMP(1);
-  // ---- while the totals are in flight: cumulative weights of tiles b - 1, b, b + 1 RELATIVE to each tile's start ----
+  // ---- while the totals are in flight: cumulative weights of tiles b - 1, b, b + 1 RELATIVE to each tile's start
+  //      (the neighbours' log-weights are requested only now: nothing may delay the publication above, every block waits
+  //      for the last one) ----
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tc = w0 + 2 * c;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) xn[c][k] = 0.0f;
+    if (tc >= 0 && tc < nb) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xn[c]);
+  }
   {
     uint64_t qn[2][ITEMS], sn[2], incn[2];
 #pragma unroll
@@ -560,6 +563,307 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
 #undef GJX_STAMP
 }
 
+// ------------------------------------------------------------------------------------------
+// Resampling + gather under the TILE-SCALED scheme (GJX_WEIGHTS_TILE_SCALED, include/gjx.h), N = K: a PLAIN kernel — no
+// rendezvous, no co-resident grid, any K up to kGatherTiledMaxTiles tiles.  The {e_b, S_b} of every 1024-particle tile
+// exist before the launch: the propagate kernel leaves them beside its LSE partials when a block of it covers whole
+// tiles (gjx_run_program, k_run_gmm_flat<.., TILES>), otherwise k_tile_totals computes them (one small launch).  Every
+// block reads all of them (12 B per tile), takes the maximum exponent, shifts, prefixes, and is the consumer of the
+// output slots [b 1024, (b+1) 1024) exactly as k_resample_gather: thresholds, source tile in a window of the prefix,
+// cumulative q of tiles b-1 .. b+1 laid out in LDS from the log-weights (quantised against each tile's OWN exponent),
+// 4-ary search of the residual, rows copied.  Every load the head needs is issued at the top: the head is one memory
+// latency plus LDS work instead of two fabric round trips.  Ancestors are those of gjx_resample_indices_tiled bit for bit.
+// ------------------------------------------------------------------------------------------
+constexpr int kGatherTiledMaxTiles = 4096;
+
+// {S_b, E_b} of every tile from the log-weights (what k_tiled_quantise computes, without the cumulative array)
+__global__ __launch_bounds__(kTileQ) void k_tile_totals(const float* __restrict__ logw, int64_t K, uint64_t* S, int32_t* E) {
+  constexpr int NW = kTileQ / 64;
+  __shared__ float fred[NW];
+  __shared__ uint64_t wsum[NW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kTileQ + threadIdx.x;
+  const float lw = i < K ? logw[i] : -INFINITY;
+  const float wm = wave_max(lw);
+  if (lane == 0) fred[wid] = wm;
+  __syncthreads();
+  float bm = fred[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) bm = fmaxf(bm, fred[w]);
+  const int e = tile_exponent(bm);
+  const uint64_t tot_w = wave_total_u64(i < K ? tile_q(lw, e) : 0);
+  if (lane == 0) wsum[wid] = tot_w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t tot = 0;
+    for (int w = 0; w < NW; ++w) tot += wsum[w];
+    S[blockIdx.x] = tot;
+    E[blockIdx.x] = tot ? e : kTileDead;
+  }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __restrict__ x, int64_t K, const uint64_t* __restrict__ S,
+                                                              const int32_t* __restrict__ E, int lse_mode, const float* lse,
+                                                              int n_partials, float* lse_out, float log_k_total, double u,
+                                                              const float* __restrict__ src, int64_t src_stride, int rows,
+                                                              float* __restrict__ dst, int64_t dst_stride, int32_t* ancestors,
+                                                              unsigned* ctrl, unsigned long long* timeline) {
+#define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GJX_STAMP(0);
+  static_assert(ITEMS == 4, "a block consumes one quantisation tile: 256 lanes x 4 slots");
+  constexpr int TILE = 256 * ITEMS;
+  constexpr int CH = 3;
+  extern __shared__ __align__(16) unsigned char gt_dyn[];
+  const int nt = (int)gridDim.x;
+  uint64_t* const P = (uint64_t*)gt_dyn;                       // [nt + 1] prefix of the shifted tile totals
+  int32_t* const Eb = (int32_t*)(P + ((nt + 2) & ~1));         // [nt] tile exponents
+  __shared__ float fred[8];
+  __shared__ uint64_t wsum[4];
+  __shared__ uint64_t cumL[CH * TILE];                         // cumulative q of the tiles being searched, relative to the tile's start
+  __shared__ uint64_t s_wtot[CH][4];
+  __shared__ int s_range[2];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
+  auto load_tile = [&](int64_t p0, float (&v)[ITEMS]) {
+    if (p0 + 4 <= K) {
+      const float4 q4 = *(const float4*)(x + p0);
+      v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? x[p0 + k] : -INFINITY;
+    }
+  };
+  // ---- every load of the head, at once: the three tiles of log-weights around the block, all tile totals ----
+  const int w0 = (int)blockIdx.x - 1;
+  float xw[CH][ITEMS];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) xw[c][k] = -INFINITY;
+    const int tc = w0 + c;
+    if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
+  }
+  float em = (float)kTileDead;
+  for (int b = threadIdx.x; b < nt; b += 256) {
+    const uint64_t sv = S[b];
+    const int e = sv ? E[b] : kTileDead;
+    P[b + 1] = sv;
+    Eb[b] = e;
+    em = fmaxf(em, (float)e);
+  }
+  em = wave_max(em);
+  if (lane == 0) fred[wid] = em;
+  if (threadIdx.x == 0) P[0] = 0;
+  __syncthreads();
+  const int Emax = (int)fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+  GJX_STAMP(1);
+  {   // shifted totals and their prefix, in place: lane t owns entries [t per, (t+1) per)
+    const int per = (nt + 255) >> 8;
+    const int e0 = threadIdx.x * per < nt ? threadIdx.x * per : nt, e1 = (e0 + per) < nt ? (e0 + per) : nt;
+    uint64_t loc = 0;
+    for (int e = e0; e < e1; ++e) {
+      const int sh = Emax - Eb[e];
+      const uint64_t g = sh < 64 ? P[e + 1] >> sh : 0;
+      P[e + 1] = g;
+      loc += g;
+    }
+    const uint64_t inc = wave_scan_u64(loc);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint64_t run = inc - loc;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+    __syncthreads();
+  }
+  const uint64_t total = P[nt];
+  GJX_STAMP(2);
+  if (blockIdx.x == 0) {   // block-uniform: the LSE record of the producing run (its block partials), the dead-collection flag
+    if (lse_mode == 2 && lse_out) {
+      float sm_sum;
+      const float mx = block_ref_max(2, lse, n_partials, fred, &sm_sum);
+      if (threadIdx.x == 0) {
+        const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
+        lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;
+      }
+    }
+    if (threadIdx.x == 0 && total == 0 && ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int32_t anc[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((i0 + k < K) ? i0 + k : K - 1);   // dead collection: identity (flagged)
+  if (total > 0) {   // block-uniform
+    const double step = (double)total / (double)K;
+    uint64_t T[ITEMS];
+    int tile[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int64_t j = (i0 + k < K) ? i0 + k : K - 1;
+      T[k] = comb_threshold(j, u, step, total);
+      tile[k] = 0;
+    }
+    auto descend = [&](int k0, int k1) {   // first tile t with P[t + 1] > T (fixed trip count; two slots per pass)
+      for (int sft = 1 << (31 - __builtin_clz((unsigned)nt)); sft >= 1; sft >>= 1) {
+        const int pa = tile[k0] + sft, pb = tile[k1] + sft;
+        if (pa <= nt - 1 && P[pa] <= T[k0]) tile[k0] = pa;
+        if (k1 != k0 && pb <= nt - 1 && P[pb] <= T[k1]) tile[k1] = pb;
+      }
+    };
+    const int wlo = (int)blockIdx.x - 4 < 0 ? 0 : ((int)blockIdx.x - 4 > nt - 8 ? (nt - 8 < 0 ? 0 : nt - 8) : (int)blockIdx.x - 4);
+    uint64_t Pw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Pw[k] = P[wlo + k < nt ? wlo + k : nt];
+    if (T[0] >= Pw[0] && T[ITEMS - 1] < Pw[8]) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        int tl = wlo;
+#pragma unroll
+        for (int w = 1; w < 8; ++w) tl += Pw[w] <= T[k] ? 1 : 0;
+        tile[k] = tl;
+      }
+    } else {
+      descend(0, ITEMS - 1);
+      if (tile[0] == tile[ITEMS - 1]) {
+#pragma unroll
+        for (int k = 1; k < ITEMS - 1; ++k) tile[k] = tile[0];
+      } else {
+        descend(1, 2);
+      }
+    }
+    // residual of every slot in its source tile's own units (< S of that tile)
+    uint64_t Tr[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) Tr[k] = (T[k] - P[tile[k]]) << (Emax - Eb[tile[k]]);
+    if (threadIdx.x == 0) s_range[0] = tile[0];
+    if (threadIdx.x == 255) s_range[1] = tile[ITEMS - 1];
+    __syncthreads();
+    const int tmin = s_range[0], tmax = s_range[1];
+    GJX_STAMP(3);
+    const bool windowed = tmin >= w0 && tmax <= w0 + 2;       // block-uniform: every source tile is among the three loaded at the top
+    if (windowed) {
+      // cumulative q of the window tiles the slots fall into (usually two), each against its own exponent, relative to
+      // the tile's start: cumL[c] for tile w0 + c
+      uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int tc = w0 + c;
+        sacc[c] = 0; inc[c] = 0;
+        if (tc < tmin || tc > tmax) continue;                 // block-uniform
+        const int es = Eb[tc];
+        const int64_t p0 = (int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS;
+        if (p0 + ITEMS <= K) {
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) { sacc[c] += tile_q(xw[c][k], es); qi[c][k] = sacc[c]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) { sacc[c] += p0 + k < K ? tile_q(xw[c][k], es) : 0; qi[c][k] = sacc[c]; }
+        }
+        inc[c] = wave_scan_u64(sacc[c]);
+        if (lane == 63) s_wtot[c][wid] = inc[c];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int tc = w0 + c;
+        if (tc < tmin || tc > tmax) continue;
+        uint64_t base = inc[c] - sacc[c];
+        for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
+      }
+      __syncthreads();
+    }
+    auto search = [&](const uint64_t* cm, uint64_t r) {   // entries <= r among TILE (4-ary: three independent probes per level)
+      int pos = 0;
+#pragma unroll
+      for (int q = TILE >> 2; q >= 1; q >>= 2) {
+        const uint64_t pa = cm[pos + q - 1], pb = cm[pos + 2 * q - 1], pc = cm[pos + 3 * q - 1];
+        pos += (pa <= r ? q : 0) + (pb <= r ? q : 0) + (pc <= r ? q : 0);
+      }
+      return pos;
+    };
+    if (windowed) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((int64_t)tile[k] * TILE + search(cumL + (tile[k] - w0) * TILE, Tr[k]));
+    } else {
+      // collapsed or strongly drifting weights: re-scan the source tiles CH at a time (tiles without weight are skipped)
+      const int ntiles = tmax - tmin + 1;
+      auto next_live = [&](int at) { while (at < ntiles && P[tmin + at + 1] == P[tmin + at]) ++at; return at; };
+      for (int idx = 0; idx < ntiles;) {
+        const int nidx = next_live(idx + CH);
+        uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
+        __syncthreads();         // every lane is done searching the previous contents of cumL
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const bool on = idx + c < ntiles;
+          const int tsrc = on ? tmin + idx + c : 0;
+          const int64_t p0 = (int64_t)tsrc * TILE + (int64_t)threadIdx.x * ITEMS;
+          float nv[ITEMS];
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) nv[k] = -INFINITY;
+          if (on) load_tile(p0, nv);
+          const int es = Eb[tsrc];
+          sacc[c] = 0;
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) { sacc[c] += (on && p0 + k < K) ? tile_q(nv[k], es) : 0; qi[c][k] = sacc[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) inc[c] = wave_scan_u64(sacc[c]);
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          uint64_t base = inc[c] - sacc[c];
+          for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
+#pragma unroll
+          for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+          const int kp = tile[k] - tmin;
+          if (kp >= idx && kp < idx + CH) anc[k] = (int32_t)((int64_t)tile[k] * TILE + search(cumL + (kp - idx) * TILE, Tr[k]));
+        }
+        idx = nidx;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) anc[k] = anc[k] < K ? anc[k] : (int32_t)(K - 1);
+  }
+  GJX_STAMP(4);
+  // ---- children: rows of the ancestors, ITEMS consecutive slots per lane ----
+  const bool whole = i0 + ITEMS <= K;
+  if (ancestors) {
+    if (whole) *(int4*)(ancestors + i0) = make_int4(anc[0], anc[1], anc[2], anc[3]);
+    else {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) ancestors[i0 + k] = anc[k];
+    }
+  }
+  const bool vec = whole && (dst_stride & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
+  if (vec) {
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const float* sr = src + (int64_t)r * src_stride;
+      float4 v;
+      v.x = sr[anc[0]]; v.y = sr[anc[1]]; v.z = sr[anc[2]]; v.w = sr[anc[3]];
+      *(float4*)(dst + (int64_t)r * dst_stride + i0) = v;
+    }
+  } else {
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const float* sr = src + (int64_t)r * src_stride;
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) dst[(int64_t)r * dst_stride + i0 + k] = sr[anc[k]];
+    }
+  }
+  GJX_STAMP(5);
+#undef GJX_STAMP
+}
+
 __global__ __launch_bounds__(256) void k_multinomial(const uint64_t* cum, int64_t K, const uint64_t* base_total,
                                                     key2 key, int64_t out_begin, int64_t n_out, int32_t* ancestors) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -732,6 +1036,42 @@ extern "C" int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, co
   if (items == 1) GJX_RG(1); else GJX_RG(4);
 #undef GJX_RG
   GJX_CHECK_LAUNCH("gjx_resample_gather");
+  return GJX_OK;
+}
+
+extern "C" int gjx_resample_gather_tiled(const float* logw, int64_t K, const uint64_t* tile_S, const int32_t* tile_E, int32_t lse_mode,
+                                         const float* lse, int32_t n_partials, double u, const float* src, int64_t src_stride,
+                                         int32_t rows, float* dst, int64_t dst_stride, int32_t* ancestors, float* lse_out,
+                                         int64_t K_total, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logw || K <= 0 || !(u >= 0.0 && u < 1.0) || rows < 0 || (rows > 0 && (!src || !dst)) || K > 0x7fffffffLL ||
+      (lse_mode != 0 && lse_mode != 2) || (lse_mode == 2 && (!lse || n_partials <= 0)) || ((tile_S == nullptr) != (tile_E == nullptr)))
+    return gjx_fail(GJX_EINVAL, "gjx_resample_gather_tiled: bad argument");
+  const int64_t nt = (K + kTileQ - 1) / kTileQ;
+  if (nt > kGatherTiledMaxTiles) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_gather_tiled: more than 4096 tiles (K > 2^22): use gjx_resample_indices_tiled + gjx_gather_rows");
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K) || kWsHeaderBytes + 12 * (size_t)nt > workspace_bytes)
+    return gjx_fail(GJX_EWORKSPACE, "gjx_resample_gather_tiled: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ctrl = (unsigned*)workspace + 8;
+  if (!tile_S) {   // the producer left no tile totals: one small launch over the log-weights
+    uint64_t* S = (uint64_t*)((char*)workspace + kWsHeaderBytes);
+    int32_t* E = (int32_t*)(S + nt);
+    hipLaunchKernelGGL(k_tile_totals, dim3((unsigned)nt), dim3(kTileQ), 0, st, logw, K, S, E);
+    tile_S = S; tile_E = E;
+  }
+  const size_t lds = 8 * (size_t)((nt + 2) & ~1) + 4 * (size_t)nt;
+  if (lds > 32 * 1024) {   // static + dynamic LDS above the 64 KB default (K > 2^21): raise the kernel's limit once
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)k_resample_gather_tiled<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (kGatherTiledMaxTiles + 2) + 4 * kGatherTiledMaxTiles) != hipSuccess)
+        (void)hipGetLastError();
+      raised = true;
+    }
+  }
+  const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
+  unsigned long long* timeline = gjx::debug_timeline(64 * (size_t)nt);
+  hipLaunchKernelGGL((k_resample_gather_tiled<4>), dim3((unsigned)nt), dim3(256), lds, st, logw, K, tile_S, tile_E, (int)lse_mode, lse,
+                     (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride, ancestors, ctrl, timeline);
+  GJX_CHECK_LAUNCH("gjx_resample_gather_tiled");
   return GJX_OK;
 }
 

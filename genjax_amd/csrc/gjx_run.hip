@@ -15,6 +15,7 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 #include "gjx_scan.h"
+#include "gjx_tile.h"
 
 #include <string.h>
 #include <type_traits>
@@ -265,6 +266,9 @@ struct GmmArgs {
   unsigned long long* agg;      // 4 granule arrays of gridDim.x words each
   unsigned* ctrl;
   unsigned long long* timeline; // debug (gjx_debug_timeline): 8 realtime stamps per block
+  // TILES kernels: {S_b, e_b} of every 1024-particle tile under GJX_WEIGHTS_TILE_SCALED, for gjx_resample_gather_tiled
+  unsigned long long* tile_S;   // [K / 1024]
+  int32_t* tile_E;              // [K / 1024]
 };
 
 template <int PPT>
@@ -592,9 +596,12 @@ __global__ __launch_bounds__(256) void k_gmm_prepare(GmmArgs a, int D, float* au
   }
 }
 
-template <int D, int PPT, int THREADS, bool STEP = false>
+template <int D, int PPT, int THREADS, bool STEP = false, bool TILES = false>
 __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
   static_assert(!STEP || (PPT == 4 && THREADS == 256), "the one-launch step works on tiles of 256 x 4 particles");
+  static_assert(!TILES || (PPT == 4 && THREADS == 256 && !STEP), "tile totals: a block's tile is one quantisation tile of 1024 particles");
+  __shared__ float red_tm[4];
+  __shared__ uint64_t red_tq[4];
   constexpr int RS = 4 * D + 4;       // LDS row stride of one component (floats)
   constexpr int NPAIR = (D + 1) / 2;
   unsigned epoch = 0;
@@ -778,6 +785,29 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm_flat(GmmArgs a) {
       tsum = s4;
     }
     tmax = m4;
+    if constexpr (TILES) {
+      // {e_b, S_b} of this tile (GJX_WEIGHTS_TILE_SCALED, include/gjx.h; K % 1024 == 0: every wave of the block is here):
+      // the resampling kernel that follows needs no grid-wide exchange of its own (gjx_resample_gather_tiled)
+      const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+      float m = lw[0];
+#pragma unroll
+      for (int p = 1; p < PPT; ++p) m = fmaxf(m, lw[p]);
+      const float wm = wave_max(m);
+      if (lane == 0) red_tm[wid] = wm;
+      __syncthreads();
+      const int e = tile_exponent(fmaxf(fmaxf(red_tm[0], red_tm[1]), fmaxf(red_tm[2], red_tm[3])));
+      uint64_t q = 0;
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) q += tile_q(lw[p], e);
+      const uint64_t wq = wave_total_u64(q);
+      if (lane == 0) red_tq[wid] = wq;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint64_t tot = red_tq[0] + red_tq[1] + red_tq[2] + red_tq[3];
+        a.tile_S[tix] = tot;
+        a.tile_E[tix] = tot ? e : kTileDead;
+      }
+    }
     if (tix + gridDim.x < ntiles) cat_bits(tix + gridDim.x);
   }
   constexpr int NW = THREADS / 64;
@@ -989,7 +1019,8 @@ void launch_gmm_kernel(KERN kern, const GmmArgs& a, int grid, size_t lds, hipStr
 template <int D>
 void launch_gmm_d(const GmmArgs& a, bool flat, int ppt, int grid, size_t lds, hipStream_t st) {
   if (flat) {
-    if (ppt == 4) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256>, a, grid, lds, st);
+    if (ppt == 4 && a.tile_S) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, false, true>, a, grid, lds, st);
+    else if (ppt == 4) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256>, a, grid, lds, st);
     else if (ppt == 2) launch_gmm_kernel(k_run_gmm_flat<D, 2, 256>, a, grid, lds, st);
     else launch_gmm_kernel(k_run_gmm_flat<D, 1, 256>, a, grid, lds, st);
   } else {
@@ -1141,6 +1172,11 @@ extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_
 // its workspace): what a consumer of the pairs must use — a re-derived plan can differ (site scores, environment)
 static thread_local int g_last_run_grid = 0;
 extern "C" int gjx_last_run_partials(void) { return g_last_run_grid; }
+// byte offset, in the workspace of the LAST gjx_run_program of this thread, of the tile totals it left for
+// gjx_resample_gather_tiled — uint64 S[nt] then int32 E[nt], nt = K / 1024 — or 0 when it left none (the engine's blocks do
+// not cover whole quantisation tiles, K is not a multiple of 1024, lse was requested)
+static thread_local int64_t g_last_run_tiles = 0;
+extern "C" int64_t gjx_last_run_tiles(void) { return g_last_run_tiles; }
 
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                                int64_t particle_offset, float* choices, float* score, float* weight,
@@ -1179,6 +1215,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   const float log_k_total = (float)log((double)K_total);
   const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr);
   g_last_run_grid = ep.grid;
+  g_last_run_tiles = 0;
   const GmmShape& g = ep.g;
   const int ppt = ep.ppt, nblocks = ep.grid;
   if (ep.engine == ENGINE_GEN) {
@@ -1197,6 +1234,18 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.choices = choices; a.score = score; a.weight = weight; a.logw = logw;
     a.logw_in = logw_in; a.sub = sub; a.partials = partials; a.ticket = ticket; a.lse = lse; a.log_k_total = log_k_total;
     const bool flat = prog->rng_mode != GJX_RNG_JAX32;
+    a.tile_S = nullptr; a.tile_E = nullptr;
+    // consumer-finishes mode (lse == NULL) on the 1024-particles-per-block kernel: leave the tile totals of the tile-scaled
+    // resampler behind the block partials (which take at most 8 bytes per 256 particles)
+    if (flat && ppt == 4 && !lse && partials && K % 1024 == 0 && !env_int("GJX_NO_RUN_TILES", 0)) {
+      const size_t off = (kWsHeaderBytes + 8 * (size_t)((K + 255) / 256) + 15) & ~(size_t)15;
+      const size_t nt = (size_t)(K / 1024);
+      if (off + 12 * nt <= workspace_bytes) {
+        a.tile_S = (unsigned long long*)((char*)workspace + off);
+        a.tile_E = (int32_t*)(a.tile_S + nt);
+        g_last_run_tiles = (int64_t)off;
+      }
+    }
     const size_t lds = flat ? sizeof(float) * (size_t)gmm_aux_floats(g.C, g.D)
                             : sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
     launch_gmm(a, flat, g.D, ppt, nblocks, lds, st);

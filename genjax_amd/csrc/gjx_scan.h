@@ -14,7 +14,9 @@ constexpr int kScanTile = 256 * kScanItems;    // items per block
 GJX_DEV uint64_t weight_q(const float* x, int64_t i, int is_log, float mx) {
   float w = is_log ? fast_exp(x[i] - mx) : x[i];
   w = w > 0.0f ? w : 0.0f;
-  return (uint64_t)(w * kWeightScale);
+  // log-weights: w <= 1 up to the rounding of v_exp_f32, the product fits 32 bits (one v_cvt_u32_f32; a float -> u64
+  // conversion is eight instructions); linear weights may be anything
+  return is_log ? (uint64_t)(uint32_t)(w * kWeightScale) : (uint64_t)(w * kWeightScale);
 }
 
 // reference maximum of the log-weights for the fixed-point conversion.

@@ -113,7 +113,7 @@ GJX_DEV uint64_t tile_q(float lw, int e) {         // floor(2^29 * min(1, 2^(lw 
   float w = __builtin_amdgcn_exp2f(fmaf(lw, kLog2e, -(float)e));   // one rounding: the oracle uses fmaf too
   w = w > 0.0f ? w : 0.0f;
   w = w < 1.0f ? w : 1.0f;
-  return (uint64_t)(w * kTileScale);
+  return (uint64_t)(uint32_t)(w * kTileScale);    // <= 2^29: one v_cvt_u32_f32 (a float -> u64 conversion is eight instructions)
 }
 // granule of the tiled rendezvous: tag (4 bits, != 0) | e_b + 2^19 (20 bits) | S_b (40 bits, S_b <= 2^39).  Four tag
 // bits are plenty: a block rewrites its granule of one parity every second step, so a reader can only ever meet the

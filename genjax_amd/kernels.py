@@ -149,9 +149,10 @@ class RunPartials:
     reduce them in their own prologue (resample_gather / resample_indices, ``partials=``) save the producer's serial
     LSE tail.  Valid only until the same workspace is used by another run."""
 
-    def __init__(self, ws, gen, prog, K, offset, n=None):
+    def __init__(self, ws, gen, prog, K, offset, n=None, tiles=0):
         self.ws, self.gen, self.prog, self.K, self.offset = ws, gen, prog, K, offset
         self._n = n                     # the grid the run actually launched (recorded right after the call)
+        self.tiles = int(tiles)         # byte offset of the tile totals the run left for resample_gather_tiled (0: none)
 
     def valid(self) -> bool:
         return getattr(self.ws, "_gjx_gen", None) == self.gen
@@ -201,7 +202,8 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     ws._gjx_gen = getattr(ws, "_gjx_gen", 0) + 1
     res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws)
     if lse is None:
-        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset), int(load().gjx_last_run_partials()))
+        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset), int(load().gjx_last_run_partials()),
+                                       int(load().gjx_last_run_tiles()))
     if ss is not None:
         res["site_scores"] = ss
     return res
@@ -362,6 +364,31 @@ def resample_gather(x: torch.Tensor, u: float, rows: torch.Tensor, is_log=True, 
         a = resample_indices(x, u, K, is_log=is_log, lse=lse, partials=partials, lse_out=lse_out, K_total=K_total, anc=anc, ws=ws)
         return gather_rows(rows, a, dst=out)
     check(rc, "gjx_resample_gather")
+    return out
+
+
+def resample_gather_tiled(logw: torch.Tensor, u: float, rows: torch.Tensor, partials=None, tiles: int = 0, lse_out=None,
+                          K_total=None, out=None, anc=None, ws=None) -> torch.Tensor:
+    """gjx_resample_gather_tiled: the tile-scaled systematic resampler + row gather (N = K) as a PLAIN launch (no
+    co-resident grid).  ``partials=(run_workspace, n)``: the block pairs of the producing run (lse_out receives the finished
+    record); ``tiles``: byte offset of the tile totals that run left in the same workspace (RunPartials.tiles; 0: they are
+    computed by one extra small launch).  Ancestors == resample_indices_tiled's, bit for bit."""
+    K = logw.numel()
+    assert rows.dim() == 2 and rows.shape[1] == K and rows.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(rows)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, logw.device)
+    mode, lp, npart, S, E = 0, None, 0, None, None
+    if partials is not None:
+        run_ws, n = partials
+        mode, lp, npart = 2, C.c_void_p(run_ws.data_ptr() + 256), int(n)
+        if tiles:
+            S = C.c_void_p(run_ws.data_ptr() + int(tiles))
+            E = C.c_void_p(run_ws.data_ptr() + int(tiles) + 8 * ((K + 1023) // 1024))
+    check(load().gjx_resample_gather_tiled(_ptr(logw), K, S, E, mode, lp, npart, float(u), _ptr(rows), rows.stride(0), rows.shape[0],
+                                           _ptr(out), out.stride(0), _ptr(anc), _ptr(lse_out), int(K_total or K), _ptr(ws),
+                                           ws.numel(), _stream()), "gjx_resample_gather_tiled")
     return out
 
 

@@ -37,7 +37,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 5
+#define GJX_ABI_VERSION 6
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -321,6 +321,11 @@ int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_
 /* the number of block pairs the LAST gjx_run_program call of the calling thread left in its workspace (the grid it
  * actually launched): record it right after the call; gjx_run_partials_count re-derives a plan and is for sizing only */
 int gjx_last_run_partials(void);
+/* byte offset, inside the workspace of the LAST gjx_run_program call of the calling thread, of the tile totals that run
+ * left for gjx_resample_gather_tiled: uint64 S[nt] followed by int32 E[nt], nt = K / 1024 — or 0 when it left none.  A run
+ * leaves them when it is called with lse == NULL (consumer-finishes mode), K is a multiple of 1024 and a block of its
+ * kernel covers whole 1024-particle tiles (the hand-fused mixture kernel with 4 particles per lane). */
+int64_t gjx_last_run_tiles(void);
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:
@@ -356,6 +361,19 @@ int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, const float* 
                         const float* src, int64_t src_stride, int32_t rows, float* dst, int64_t dst_stride,
                         int32_t* ancestors, float* lse_out, int64_t K_total, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* Resampling and the row gather (N = K) under GJX_WEIGHTS_TILE_SCALED (below, at gjx_ssm_filter_scheme) as a PLAIN launch:
+ * no block waits for another one, so there is no co-residency requirement, no poll budget and no limit from the device's
+ * capacity (K <= 2^22: 4096 tiles).  tile_S / tile_E: the {S_b, e_b} of every 1024-particle tile of logw, as the producing
+ * gjx_run_program left them (gjx_last_run_tiles) — both NULL: computed here by one extra small launch into the workspace.
+ * lse_mode 2: `lse` points at n_partials block pairs of the producing run and lse_out receives the finished record
+ * (reduced by block 0, off the critical path); lse_mode 0: no record.  Ancestors (written to `ancestors` when not NULL)
+ * are those of gjx_resample_indices_tiled bit for bit (oracle: gjxo_resample_systematic_tiled).  A dead collection
+ * yields the identity and bit 1 of the status word.  workspace: gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zeroed once.
+ * Same reference idiom as gjx_resample_gather (categorical draw over the weights + gather of every leaf). */
+int gjx_resample_gather_tiled(const float* logw, int64_t K, const uint64_t* tile_S, const int32_t* tile_E, int32_t lse_mode,
+                              const float* lse, int32_t n_partials, double u, const float* src, int64_t src_stride,
+                              int32_t rows, float* dst, int64_t dst_stride, int32_t* ancestors, float* lse_out,
+                              int64_t K_total, void* workspace, size_t workspace_bytes, void* stream);
 /* the same search fused with the row gather: dst[r][j - out_begin] = src[r][ancestor(j)] for r < rows
  * (slots owned by another rank are left untouched in dst and in ancestors); ancestors int32[n_out] is scratch/output */
 int gjx_resample_gather_systematic(const uint64_t* cum, int64_t K, const uint64_t* base_total_dev, double u,

@@ -195,3 +195,56 @@ def test_tiled_bootstrap_filter_full_size(K_):
     assert not out["degenerate"]
     assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
     np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
+
+
+@pytest.mark.parametrize("K", [1, 777, 1024, 4096 + 3, 100_000, 1 << 20, (1 << 22) - 5])
+def test_plain_launch_resample_gather_equals_the_three_launch_tiled_resampler(K_, K):
+    """gjx_resample_gather_tiled (ONE plain launch: tile totals read, no block waits for another) gives the ancestors of
+    gjx_resample_indices_tiled — itself compared with the oracle above — bit for bit, for every weight shape (collapsed
+    weights take the re-scan loop, balanced ones the window of three tiles), and the children are the gathered rows."""
+    import torch
+    rs = np.random.default_rng(K + 1)
+    rows = torch.as_tensor(rs.standard_normal((3, K)).astype(np.float32)).cuda()
+    ws = K_.workspace(A.OP_RESAMPLE, K, "cuda")
+    for name, lw in _weight_shapes(K, rs):
+        lwd = torch.as_tensor(lw).cuda()
+        for u in (0.0, 0.3718, 0.999999):
+            want = K_.resample_indices_tiled(lwd, u, K)
+            anc = torch.empty(K, dtype=torch.int32, device="cuda")
+            out = K_.resample_gather_tiled(lwd, u, rows, anc=anc, ws=ws)
+            np.testing.assert_array_equal(_np(anc), _np(want), err_msg=f"{name} u={u}")
+            assert torch.equal(out, K_.gather_rows(rows, want)), name
+        assert K_.workspace_status(ws, raise_on_error=False) == 0, name
+    dead = torch.full((K,), float("-inf"), device="cuda")
+    anc = torch.empty(K, dtype=torch.int32, device="cuda")
+    K_.resample_gather_tiled(dead, 0.5, rows, anc=anc, ws=ws)
+    assert (_np(anc) == np.arange(K)).all() and K_.workspace_status(ws, raise_on_error=False) == 2
+
+
+@pytest.mark.parametrize("K", [1 << 20, 1 << 14, 3 * 1024])
+def test_run_program_leaves_the_tile_totals_for_the_resampler(K_, K):
+    """the hand-fused mixture kernel, called without an LSE record, leaves {S_b, e_b} of every 1024-particle tile beside its
+    block partials: identical to what the resampler computes from the log-weights itself; resampling from them gives the
+    same ancestors, the same children and the finished LSE record."""
+    import torch
+    from genjax_amd import workloads
+    prog, _ = workloads.gmm_program()
+    out = K_.run_program(prog, (0, 3), K, want_lse=False)
+    part = out["_partials"]
+    assert part.tiles > 0
+    nt = K // 1024
+    S = out["_ws"][part.tiles:part.tiles + 8 * nt].view(torch.int64)
+    E = out["_ws"][part.tiles + 8 * nt:part.tiles + 12 * nt].view(torch.int32)
+    _, q, e = K_.resample_indices_tiled(out["logw"], 0.25, K, want_q=True)
+    np.testing.assert_array_equal(_np(E), _np(e))
+    np.testing.assert_array_equal(_np(S), _np(q).view(np.uint32).astype(np.int64).reshape(nt, 1024).sum(axis=1))
+    a1 = torch.empty(K, dtype=torch.int32, device="cuda")
+    a2 = torch.empty(K, dtype=torch.int32, device="cuda")
+    lse = torch.empty(4, device="cuda")
+    r1 = K_.resample_gather_tiled(out["logw"], 0.25, out["choices"], partials=part.as_arg(), tiles=part.tiles, lse_out=lse, anc=a1)
+    r2 = K_.resample_gather_tiled(out["logw"], 0.25, out["choices"], anc=a2)
+    assert torch.equal(a1, a2) and torch.equal(r1, r2)
+    assert torch.equal(a1, K_.resample_indices_tiled(out["logw"], 0.25, K))
+    full = K_.run_program(prog, (0, 3), K)                    # the same run with its own LSE tail
+    np.testing.assert_allclose(_np(lse)[2:], _np(full["lse"])[2:], rtol=1e-6, atol=1e-5)
+    assert K_.run_program(prog, (0, 3), K + 4, want_lse=False)["_partials"].tiles == 0      # K % 1024 != 0: no tiles
