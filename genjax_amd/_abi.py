@@ -131,6 +131,8 @@ PROTOTYPES = {
                                     vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_ssm_filter": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_scheme": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
+    "gjx_ssm_filter_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp,
+                                      C.c_size_t, vp]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),
@@ -144,6 +146,7 @@ PROTOTYPES = {
     "gjx_peer_ctx_status": (C.c_int, [vp, C.POINTER(i32), vp]),
     "gjx_peer_ctx_destroy": (C.c_int, [vp]),
     "gjx_ssm_filter_peer": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, vp, vp, vp, vp]),
+    "gjx_ssm_filter_peer_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]),
     "gjx_peer_resample_gather": (C.c_int, [vp, i32, vp, i32, f64, vp, i64, vp, vp, vp]),
     "gjx_hmc_workspace_bytes": (C.c_size_t, [PP, i64]),
     "gjx_hmc_engine": (C.c_int, [PP]),

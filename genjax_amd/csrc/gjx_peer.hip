@@ -36,7 +36,7 @@ struct gjx_peer_ctx {
   char* data = nullptr;                // this rank's DATA window
   char* flag = nullptr;                // this rank's FLAG window
   size_t data_bytes = 0, flag_bytes = 0;
-  size_t off_rows[2] = {0, 0}, off_lw[2] = {0, 0};
+  size_t off_rows[2] = {0, 0}, off_lw[2] = {0, 0}, off_m[2] = {0, 0};   // off_m: transition means of the resample-move filter
   size_t off_region[2] = {0, 0}, region_bytes = 0;
   // inside a flag region
   size_t r_aggA = 0, r_aggB = 0, r_bsum = 0, r_bmax = 0, r_ready = 0, r_gmm = 0;
@@ -91,6 +91,7 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   size_t o = 0;
   for (int p = 0; p < 2; ++p) { c->off_rows[p] = o; o = align_up(o + sizeof(float) * (size_t)rows * (size_t)K_local); }
   for (int p = 0; p < 2; ++p) { c->off_lw[p] = o; o = align_up(o + sizeof(float) * (size_t)K_local); }
+  for (int p = 0; p < 2; ++p) { c->off_m[p] = o; o = align_up(o + sizeof(float) * (size_t)rows * (size_t)K_local); }
   c->data_bytes = o;
   // FLAG window: [256 B control][region 0][region 1]; a region: granules A, B [NT] | ring sum, max [3][NT] | ready words |
   // the words of the one-launch resampling step (twice, for alternating calls: 4 x [MAX_RANKS] u64 + this rank's tile granules [nt])
@@ -194,8 +195,25 @@ extern "C" int gjx_ssm_step(const gjx_ssm*, uint32_t, uint32_t, int32_t, int32_t
 // on the number of ranks.  The particles of the last step end up in rows[(T - 1) & 1] of the context, their log-weights
 // in logw[0]; lse_steps f32[T][4] receives the GLOBAL record of every step on every rank; ancestors (optional) int32[K_local]
 // the GLOBAL ancestor index of every slot at the last resampling.
+static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* c, const float* ys_dev,
+                       float* lse_steps, int32_t* ancestors, bool move, int n_moves, float move_scale, unsigned long long* acc_total,
+                       void* stream);
 extern "C" int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* c,
                                    const float* ys_dev, float* lse_steps, int32_t* ancestors, void* stream) {
+  return filter_peer(m, key0, key1, rng_mode, T, c, ys_dev, lse_steps, ancestors, false, 0, 0.0f, nullptr, stream);
+}
+// the sharded filter with resample-move rejuvenation (gjx_ssm_filter_move on a sharded collection): the transition means
+// live in the DATA window like the states, a moved particle's parent mean is pulled from the rank that holds the ancestor
+extern "C" int gjx_ssm_filter_peer_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* c,
+                                        const float* ys_dev, float* lse_steps, int32_t* ancestors, int32_t n_moves, float move_scale,
+                                        uint64_t* accepted_total, void* stream) {
+  if (n_moves < 0) return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_peer_move: bad argument");
+  return filter_peer(m, key0, key1, rng_mode, T, c, ys_dev, lse_steps, ancestors, true, (int)n_moves, move_scale,
+                     (unsigned long long*)accepted_total, stream);
+}
+static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* c, const float* ys_dev,
+                       float* lse_steps, int32_t* ancestors, bool move, int n_moves, float move_scale, unsigned long long* acc_total,
+                       void* stream) {
   if (!m || !c || !ys_dev || !lse_steps || T < 2) return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_peer: bad argument (T >= 2)");
   if (!c->connected) return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_peer: the context is not connected (gjx_peer_ctx_connect)");
   if (c->rows != m->dx) return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_peer: the context must have rows == dx");
@@ -203,7 +221,7 @@ extern "C" int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key
   hipStream_t st = (hipStream_t)stream;
   const int64_t K = c->K, K_total = K * c->world;
   PfPlan pf;
-  if (pf_plan(rng_mode, m->dx, m->dy, K, c->world, c->share, &pf) != GJX_OK)
+  if (pf_plan(rng_mode, m->dx, m->dy, K, c->world, c->share, &pf, move) != GJX_OK)
     return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_peer: this shape does not fit the one-launch filter (dx in {2,4,8,16}, dy <= 32, "
                                        "K_total <= 2^22, K_local / 1024 tiles co-resident at <= 8 tiles per block)");
   if (T > c->t_cap) {   // (per-run scratch grows outside every loop)
@@ -246,6 +264,12 @@ extern "C" int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key
   f.first_budget = c->world > 1 ? (1u << 24) : (1u << 16);
   f.zero_ptr = (unsigned long long*)(c->flag + c->off_region[other] + c->r_aggA);
   f.zero_n = (int)((c->r_bsum - c->r_aggA) / 8);
+  f.q0 = m->q0;
+  if (move) {
+    f.m_a = (float*)(c->data + c->off_m[0]); f.m_b = (float*)(c->data + c->off_m[1]);
+    f.n_moves = n_moves; f.move_scale = move_scale; f.acc_total = acc_total;
+    if (acc_total) GJX_HIP(hipMemsetAsync(acc_total, 0, sizeof(unsigned long long), st), "gjx_ssm_filter_peer_move(accept counter)");
+  }
   void* args[] = {&f};
   const hipError_t e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
   if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter_peer(k_pf_persistent)");

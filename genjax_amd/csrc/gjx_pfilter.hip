@@ -10,10 +10,10 @@
 
 namespace gjx {
 
-const void* pf_kernel_flat(int dx, int spl);   // gjx_pfilter_flat.hip
-const void* pf_kernel_jax(int dx, int spl);    // gjx_pfilter_jax.hip
+const void* pf_kernel_flat(int dx, int spl, bool move);   // gjx_pfilter_flat.hip
+const void* pf_kernel_jax(int dx, int spl, bool move);    // gjx_pfilter_jax.hip
 
-int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int share, PfPlan* out) {
+int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int share, PfPlan* out, bool move) {
   if (K_local <= 0 || n_ranks < 1 || n_ranks > GJX_MAX_RANKS || dy > 32) return GJX_EUNSUPPORTED;
   const int64_t nt = (K_local + kPfHostThreads - 1) / kPfHostThreads;
   if (n_ranks > 1 && K_local % kPfHostThreads) return GJX_EUNSUPPORTED;   // sharded: whole tiles per rank
@@ -22,7 +22,7 @@ int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int shar
   const int spls[4] = {1, 2, 4, 8};
   for (int i = 0; i < 4; ++i) {
     const int spl = spls[i];
-    const void* fn = rng_mode == GJX_RNG_JAX32 ? pf_kernel_jax(dx, spl) : pf_kernel_flat(dx, spl);
+    const void* fn = rng_mode == GJX_RNG_JAX32 ? pf_kernel_jax(dx, spl, move) : pf_kernel_flat(dx, spl, move);
     if (!fn) continue;
     // (static + dynamic LDS is above the 64 KB default once NT > 2048)
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); }

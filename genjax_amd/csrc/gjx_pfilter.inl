@@ -32,7 +32,7 @@ GJX_DEV uint64_t uni_u64(uint64_t v) {
 GJX_DEV double uni_f64(double v) { return __longlong_as_double((long long)uni_u64((uint64_t)__double_as_longlong(v))); }
 GJX_DEV float uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-template <int RNG, int DX, int SPL>
+template <int RNG, int DX, int SPL, bool MOVE = false>
 __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
   constexpr int THREADS = kPfThreads;
   constexpr int NW = THREADS / 64;               // waves per block
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
   __shared__ uint64_t wtot[SPL][NW], wq[NW];
   __shared__ float lse_pm[NW], lse_ps[NW];
   __shared__ float sA[DX * DX], sH[kSsmPersistMaxDy * DX], sY[kSsmPersistMaxDy];
+  __shared__ float sYp[MOVE ? kSsmPersistMaxDy : 1];       // MOVE: y_{t-1}, the observation the moved particle is conditioned on
   __shared__ double sU;
   __shared__ uint32_t sKey[2][2];
   __shared__ int s_range[2], s_dead;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
 #define ton(s) ((tonm >> (s)) & 1u)
   auto lw_buf = [&](int t) { return ((T - 1 - t) & 1) ? f.lw_odd : f.lw_even; };
   auto x_buf = [&](int t) { return (t & 1) ? f.x_b : f.x_a; };
+  auto m_buf = [&](int t) { return (t & 1) ? f.m_b : f.m_a; };   // MOVE: A x'_{t-1} of step t (step 0: the prior mean, zero — never read)
   const float rr = fast_rcp(f.r);
   const float lconst = -(float)f.dy * (kHalfLog2Pi + fast_log(f.r));
   float lw_own[SPL];
@@ -121,12 +123,14 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
   auto stage_step_constants = [&](int t) {
     if (t < T && wid == 1) {
       if (lane < f.dy) sY[lane] = f.ys[(size_t)t * f.dy + lane];
+      if (MOVE && lane < f.dy) sYp[lane] = f.ys[(size_t)(t - 1) * f.dy + lane];
       if (lane == 63) sU = f.us[t];
       if (lane >= 61 && lane < 63 && t + 1 < T) sKey[(t + 1) & 1][lane - 61] = f.keys[2 * (t + 1) + (lane - 61)];
     }
   };
   if (tid < 2) sKey[1][tid] = f.keys[2 + tid];   // step 1's key (T > 1)
   __syncthreads();
+  unsigned acc_lane = 0u;                         // MOVE: accepted Metropolis moves of this lane's slots, all steps
   for (int t = 1; t <= T; ++t) {
     SsmNoiseBits<RNG, DX> nbits;
     int eb[SPL], Emax = kTileDead;
@@ -367,6 +371,52 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
       float xp[DX], nz[DX], xn[DX];
 #pragma unroll
       for (int d = 0; d < DX; ++d) xp[d] = load_scoped(xs + (int64_t)d * K, sys);
+      if constexpr (MOVE) {
+        // resample-move: n_moves random-walk Metropolis steps on the gathered x_{t-1} with p(x_{t-1} | parent, y_{t-1}) as
+        // invariant density — k_ssm_step<.., MOVE>'s arithmetic and draws (site 2 of the step's stream), so the one-launch
+        // filter equals the step-by-step one bit for bit.  The parent's transition mean A x'_{t-2} was stored by the
+        // previous step; step 1 moves x_0 under the prior N(0, q0^2 I).
+        float mp[DX];
+        const float* ms = peer_ptr((const float*)m_buf(t - 1), sPD[sg]) + sl;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) mp[d] = t > 1 ? load_scoped(ms + (int64_t)d * K, sys) : 0.0f;
+        const float rq = fast_rcp(t > 1 ? f.q : f.q0);
+        auto logpi = [&](const float (&xx)[DX]) {
+          float sq = 0.0f;
+#pragma unroll
+          for (int d = 0; d < DX; ++d) { const float z = (xx[d] - mp[d]) * rq; sq = fmaf(z, z, sq); }
+          if (f.H) {
+            for (int o = 0; o < f.dy; ++o) {
+              float m = 0.0f;
+#pragma unroll
+              for (int e = 0; e < DX; ++e) m = fmaf(sH[o * DX + e], xx[e], m);
+              const float z = (sYp[o] - m) * rr;
+              sq = fmaf(z, z, sq);
+            }
+          } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) { const float z = (sYp[d] - xx[d]) * rr; sq = fmaf(z, z, sq); }
+          }
+          return -0.5f * sq;
+        };
+        BitStreamRT<RNG> bmv;
+        bmv.open(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)(f.offset + j), 2u);
+        float cur = logpi(xp), nacc = 0.0f;
+        for (int n = 0; n < f.n_moves; ++n) {
+          float xq[DX];
+#pragma unroll
+          for (int d = 0; d < DX; ++d) xq[d] = fmaf(f.move_scale, stream_normal<RNG>(bmv, (uint32_t)(n * (DX + 2) + d)), xp[d]);
+          const float prop = logpi(xq);
+          const float lu = safe_log(uniform_from_bits(bmv.get((uint32_t)(n * (DX + 2) + DX)), kTiny, 1.0f));
+          if (lu < prop - cur) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) xp[d] = xq[d];
+            cur = prop;
+            nacc += 1.0f;
+          }
+        }
+        if (a) acc_lane += (unsigned)nacc;       // summed over the launch: one atomic per block at the very end
+      }
       if (s == 0) ssm_noise_normals<RNG, DX>(nbits, nz);             // behind the loads above
       else {
         SsmNoiseBits<RNG, DX> late;                                 // (tiles after the first hash here)
@@ -378,6 +428,7 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < DX; ++e) acc = fmaf(sA[d * DX + e], xp[e], acc);
+        if (MOVE && a) store_scoped(m_buf(t) + (int64_t)d * K + j, acc, sys);
         xn[d] = fmaf(f.q, nz[d], acc);
       }
       if (a) {
@@ -405,6 +456,12 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
   }
   if (blockIdx.x == 0 && tid == 0)
     __hip_atomic_store(&f.ctrl[0], epoch + 2u * (unsigned)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (MOVE) {
+    if (f.acc_total) {
+      const unsigned wacc = wave_scan_u32(acc_lane);     // lane 63: the wave's total (< 2^32: 64 lanes x SPL x T x n_moves)
+      if (lane == 63 && wacc) atomicAdd(f.acc_total, (unsigned long long)wacc);
+    }
+  }
 #undef jl
 #undef act
 #undef ton
@@ -412,8 +469,8 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
 
 // kernel of one (dx, spl) for this translation unit's RNG; NULL when the combination is not instantiated
 template <int RNG>
-const void* pf_kernel_of(int dx, int spl) {
-#define GJX_PF(DXV, SPLV) if (dx == DXV && spl == SPLV) return (const void*)k_pf_persistent<RNG, DXV, SPLV>;
+const void* pf_kernel_of(int dx, int spl, bool move) {
+#define GJX_PF(DXV, SPLV) if (dx == DXV && spl == SPLV) return move ? (const void*)k_pf_persistent<RNG, DXV, SPLV, true> : (const void*)k_pf_persistent<RNG, DXV, SPLV, false>;
   GJX_PF(2, 1) GJX_PF(2, 2) GJX_PF(2, 4) GJX_PF(2, 8)
   GJX_PF(4, 1) GJX_PF(4, 2) GJX_PF(4, 4) GJX_PF(4, 8)
   GJX_PF(8, 1) GJX_PF(8, 2) GJX_PF(8, 4) GJX_PF(8, 8)

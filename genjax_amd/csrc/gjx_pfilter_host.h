@@ -40,6 +40,13 @@ struct PfArgs {
   unsigned first_budget;                                 // polls a lane may spend in the FIRST rendezvous (peers launch later)
   unsigned long long* zero_ptr;                          // sharded: the granule arrays of the NEXT launch's flag region, cleared here
   int zero_n;
+  // resample-move rejuvenation (MOVE kernels; requests/rejuvenate.py:70-94, k_ssm_step<.., MOVE>): after the ancestor gather
+  // every particle takes n_moves random-walk Metropolis steps that leave p(x_{t-1} | parent, y_{t-1}) invariant
+  float* m_a; float* m_b;                                // [DX][K] ping-pong like x: A x'_{t-1}, the mean step t propagated from
+  float q0;                                              // prior scale (the transition that produced x_0)
+  int n_moves;
+  float move_scale;
+  unsigned long long* acc_total;                         // [1] accepted moves of this rank's particles over the launch (or NULL)
 };
 
 constexpr int kPfHostThreads = kPfThreads;
@@ -56,7 +63,7 @@ struct PfPlan {
 };
 // Picks the smallest number of tiles per block whose grid is co-resident on the current device (`share` ranks on one
 // device split its capacity: dry runs).  GJX_EUNSUPPORTED when the shape does not fit this kernel.
-int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int share, PfPlan* out);
+int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int share, PfPlan* out, bool move = false);
 void host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]);
 void pf_step_keys(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& keys, std::vector<double>& us);
 

@@ -1132,9 +1132,84 @@ extern "C" int gjx_resample_indices_tiled(const float* logw, int64_t K, double u
   return GJX_OK;
 }
 
+
+// ---- k_pf_persistent on one GPU: step 0 as a plain launch, then steps 1 .. T-1 in ONE launch (gjx_pfilter.inl) ----
+struct PfMove { float* m_a; float* m_b; int n_moves; float move_scale; unsigned long long* acc_total; };
+// GJX_EUNSUPPORTED when the shape does not fit the kernel or its grid would not be co-resident (the caller falls back)
+static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K, const float* ys_dev,
+                            float* x_a, float* x_b, float* logw, float* lw_alt, int32_t* ancestors, float* lse_steps, char* ws1, char* ws2,
+                            size_t need, void* stream, const PfMove* mv) {
+  const int64_t nblk = (K + 255) / 256;
+  PfPlan pf;
+  if (pf_plan(rng_mode, m->dx, m->dy, K, 1, 1, &pf, mv != nullptr) != GJX_OK ||
+      256 + 40 * (size_t)pf.nt + 8 * (size_t)pf.grid + 16 * (size_t)T + 64 > need)
+    return GJX_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
+  static thread_local std::vector<uint32_t> h_keys;
+  static thread_local std::vector<double> h_us;
+  pf_step_keys(key0, key1, T, h_keys, h_us);
+  const size_t NT = (size_t)pf.nt;
+  // ws2: [256 B control][aggA 8 NT][aggB 8 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
+  unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
+  unsigned long long* aggB = aggA + NT;
+  float* bsum = (float*)(aggB + NT);
+  float* bmax = bsum + 3 * NT;
+  unsigned* ready = (unsigned*)(bmax + 3 * NT);
+  double* us_dev = (double*)(ready + 2 * (((size_t)pf.grid + 1) / 2));
+  uint32_t* keys_dev = (uint32_t*)(us_dev + T);
+  hipError_t e = hipMemsetAsync(aggA, 0, 40 * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
+  if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && mv && mv->acc_total) e = hipMemsetAsync(mv->acc_total, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
+  {   // step 0: from the prior (no move: there is nothing to rejuvenate yet)
+    SsmArgs a;
+    a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;
+    a.key = key2{h_keys[0], h_keys[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
+    a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
+    a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
+    a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
+    const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
+    if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
+    GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
+  }
+  PfArgs f;
+  memset(&f, 0, sizeof(f));
+  f.A = m->A_dev; f.H = m->H_dev; f.ys = ys_dev; f.q = m->q; f.r = m->r; f.dy = m->dy; f.T = T;
+  f.K = K; f.K_total = K; f.offset = 0; f.G = 1; f.rank = 0; f.nt = pf.nt; f.NT = pf.nt;
+  f.x_a = x_a; f.x_b = x_b; f.lw_even = logw; f.lw_odd = lw_alt;
+  f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready;
+  f.peer_data = nullptr; f.peer_flag = nullptr; f.keys = keys_dev; f.us = us_dev;
+  f.lse_steps = lse_steps; f.ancestors = ancestors; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
+  f.first_budget = 1u << 16; f.zero_ptr = nullptr; f.zero_n = 0;
+  f.q0 = m->q0;
+  if (mv) { f.m_a = mv->m_a; f.m_b = mv->m_b; f.n_moves = mv->n_moves; f.move_scale = mv->move_scale; f.acc_total = mv->acc_total; }
+  void* args[] = {&f};
+  e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
+  if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(k_pf_persistent)");
+  return GJX_OK;
+}
 extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
                                      const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                                      float* lse_steps, int32_t weight_scheme, void* workspace, size_t workspace_bytes, void* stream);
+
+extern "C" int gjx_ssm_filter_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                                   const float* ys_dev, float* x_a, float* x_b, float* m_a, float* m_b, float* logw, float* logw_alt,
+                                   int32_t* ancestors, float* lse_steps, int32_t n_moves, float move_scale, uint64_t* accepted_total,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !ys_dev || !x_a || !x_b || !m_a || !m_b || !logw || !logw_alt || !lse_steps || T <= 1 || K <= 0 || n_moves < 0)
+    return gjx_fail(GJX_EINVAL, "gjx_ssm_filter_move: bad argument");
+  const size_t need = gjx_workspace_bytes(GJX_OP_SSM, K);
+  if (!workspace || workspace_bytes < 2 * need + 64) return gjx_fail(GJX_EWORKSPACE, "gjx_ssm_filter_move: workspace too small (2x OP_SSM + 64)");
+  if (getenv("GJX_SSM_PERSISTENT") && atoi(getenv("GJX_SSM_PERSISTENT")) == 0)
+    return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_move: one-launch filters are disabled (GJX_SSM_PERSISTENT=0)");
+  PfMove mv{m_a, m_b, (int)n_moves, move_scale, (unsigned long long*)accepted_total};
+  const int rc = pf_filter_launch(m, key0, key1, rng_mode, T, K, ys_dev, x_a, x_b, logw, logw_alt, ancestors, lse_steps, (char*)workspace,
+                                  (char*)workspace + need, need, stream, &mv);
+  if (rc == GJX_EUNSUPPORTED) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_move: shape or size outside the one-launch filter (use gjx_ssm_step_move per step)");
+  return rc;
+}
 
 extern "C" int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
                               const float* ys_dev /*[T][dy]*/, float* x_a, float* x_b /*[dx][K] ping-pong*/, float* logw,
@@ -1200,53 +1275,9 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
   // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
   if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
       (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
-    PfPlan pf;
-    if (pf_plan(rng_mode, m->dx, m->dy, K, 1, 1, &pf) == GJX_OK &&
-        256 + 40 * (size_t)pf.nt + 8 * (size_t)pf.grid + 16 * (size_t)T + 64 <= need) {
-      hipStream_t st = (hipStream_t)stream;
-      float* lw_alt = (float*)cum;
-      auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
-      static thread_local std::vector<uint32_t> h_keys;
-      static thread_local std::vector<double> h_us;
-      pf_step_keys(key0, key1, T, h_keys, h_us);
-      const size_t NT = (size_t)pf.nt;
-      // ws2: [256 B control][aggA 8 NT][aggB 8 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
-      unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
-      unsigned long long* aggB = aggA + NT;
-      float* bsum = (float*)(aggB + NT);
-      float* bmax = bsum + 3 * NT;
-      unsigned* ready = (unsigned*)(bmax + 3 * NT);
-      double* us_dev = (double*)(ready + 2 * (((size_t)pf.grid + 1) / 2));
-      uint32_t* keys_dev = (uint32_t*)(us_dev + T);
-      hipError_t e = hipMemsetAsync(aggA, 0, 40 * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
-      if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
-      if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
-      {   // step 0: from the prior
-        SsmArgs a;
-        a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;
-        a.key = key2{h_keys[0], h_keys[1]}; a.K = K; a.offset = 0; a.prev_stride = K;
-        a.x_prev = nullptr; a.anc = nullptr; a.x_out = x_a; a.logw = lw_of(0);
-        a.partials = nullptr; a.ticket = (unsigned*)ws1; a.lse = nullptr; a.log_k_total = (float)log((double)K);
-        a.m_prev = nullptr; a.m_out = nullptr; a.y_prev = nullptr; a.n_moves = 0; a.move_scale = 0.0f; a.accepted = nullptr; a.x_moved = nullptr;
-        const int rc = rng_mode == GJX_RNG_JAX32 ? launch_ssm<GJX_RNG_JAX32>(a, m->dx, (int)nblk, st) : launch_ssm<GJX_RNG_FLAT>(a, m->dx, (int)nblk, st);
-        if (rc) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter: dx must be one of 1,2,4,8,16,32");
-        GJX_CHECK_LAUNCH("gjx_ssm_filter(step 0)");
-      }
-      PfArgs f;
-      memset(&f, 0, sizeof(f));
-      f.A = m->A_dev; f.H = m->H_dev; f.ys = ys_dev; f.q = m->q; f.r = m->r; f.dy = m->dy; f.T = T;
-      f.K = K; f.K_total = K; f.offset = 0; f.G = 1; f.rank = 0; f.nt = pf.nt; f.NT = pf.nt;
-      f.x_a = x_a; f.x_b = x_b; f.lw_even = logw; f.lw_odd = lw_alt;
-      f.aggA = aggA; f.aggB = aggB; f.bsum = bsum; f.bmax = bmax; f.ready = ready;
-      f.peer_data = nullptr; f.peer_flag = nullptr; f.keys = keys_dev; f.us = us_dev;
-      f.lse_steps = lse_steps; f.ancestors = ancestors; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
-      f.first_budget = 1u << 16; f.zero_ptr = nullptr; f.zero_n = 0;
-      void* args[] = {&f};
-      e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
-      if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(k_pf_persistent)");
-      return GJX_OK;
-    }
+    const int rc_pf = pf_filter_launch(m, key0, key1, rng_mode, T, K, ys_dev, x_a, x_b, logw, (float*)cum, ancestors, lse_steps, ws1, ws2, need,
+                                       stream, nullptr);
+    if (rc_pf != GJX_EUNSUPPORTED) return rc_pf;
   }
   if (pers_fn) {
     hipStream_t st = (hipStream_t)stream;

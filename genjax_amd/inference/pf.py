@@ -209,9 +209,17 @@ class BootstrapFilter:
             if getattr(self, "_peer", None) is not None:
                 self._peer.close()
             self._peer, self._peer_key = kernels.PeerContext(K_local, self.ssm.dx, dev), k_
-        out = self._peer.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d)
+        mv = None
+        if self.rejuvenate:
+            mv = (int(self.rejuvenate.get("n_moves", 1)), float(self.rejuvenate.get("scale", 0.5)))
+        out = self._peer.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, move=mv)
         incs = out["lse_steps"][:, 3]
         res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None, transport="peer")
+        if mv is not None:
+            acc = out["accepted_total"].double()
+            if world > 1:
+                torch.distributed.all_reduce(acc)
+            self.last_accept_rate = float(acc[0]) / (self.K * (ys_d.shape[0] - 1) * max(mv[0], 1))
         if check_status:
             st = self._peer.status()
             if st & 1:
@@ -253,8 +261,8 @@ class BootstrapFilter:
         T = ys_d.shape[0]
         if keep_history and (world > 1 or D._forced()):
             raise NotImplementedError("keep_history: the ancestor history is kept per process; run the filter on one GPU")
-        if self.rejuvenate and (world > 1 or D._forced()):
-            raise NotImplementedError("resample-move rejuvenation runs on one GPU")
+        if self.rejuvenate and (world > 1 or D._forced()) and self.weights != A.WEIGHTS_TILE_SCALED:
+            raise NotImplementedError("sharded resample-move rejuvenation needs weights='tile_scaled' (the peer-mapped one-launch filter)")
         sharded_ = world > 1 or D._forced()
         if self.weights == A.WEIGHTS_TILE_SCALED and sharded_:
             # the whole sharded filter in two launches per rank through peer-mapped windows (gjx_ssm_filter_peer); the
@@ -268,6 +276,23 @@ class BootstrapFilter:
             import warnings
             warnings.warn("sharded bootstrap filter: peer-mapped exchange unavailable, using the collective transport with "
                           "global-maximum weights")
+            if self.rejuvenate:
+                raise NotImplementedError("sharded resample-move rejuvenation needs the peer-mapped exchange")
+        if (self.rejuvenate and self.weights == A.WEIGHTS_TILE_SCALED and world == 1 and not keep_means and not step_by_step
+                and not keep_history and not D._forced() and T >= 2):
+            # resample-move inside the one-launch filter (gjx_ssm_filter_move); None: outside that kernel -> the loop below
+            nm, sc = int(self.rejuvenate.get("n_moves", 1)), float(self.rejuvenate.get("scale", 0.5))
+            out = kernels.ssm_filter_move(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, nm, sc)
+            if out is not None:
+                st = kernels.workspace_status(out["_status_ws"], raise_on_error=False) if check_status else 0
+                if not (st & 1):
+                    incs = out["lse_steps"][:, 3]
+                    self.last_accept_rate = float(out["accepted_total"][0]) / (self.K * (T - 1) * max(nm, 1))
+                    res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None, history=None)
+                    if check_status:
+                        res["degenerate"] = bool(st & 2)
+                    return res
+                _note_timeout("bootstrap filter (resample-move)")      # the grid was not co-resident: the loop below, plain launches
         if world == 1 and not keep_means and not step_by_step and not keep_history and not self.rejuvenate and not D._forced():
             out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, weights=self.weights)
             st = kernels.workspace_status(out["_status_ws"], raise_on_error=False) if check_status else 0

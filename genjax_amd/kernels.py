@@ -651,12 +651,18 @@ class PeerContext:
             load().gjx_peer_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
-    def ssm_filter(self, ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, want_ancestors: bool = False):
+    def ssm_filter(self, ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, want_ancestors: bool = False, move=None):
         """gjx_ssm_filter_peer -> dict(lse_steps [T][4] global records, x (particles of the last step: a view of the window),
-        logw, ancestors?)"""
+        logw, ancestors?).  ``move=(n_moves, scale)``: gjx_ssm_filter_peer_move (resample-move rejuvenation inside the
+        launch), adds accepted_total int64[1] (this rank's accepted moves)."""
         T = ys.shape[0]
         lse = torch.empty((T, 4), dtype=torch.float32, device=self.device)
         anc = torch.empty(self.K, dtype=torch.int32, device=self.device) if want_ancestors else None
+        if move is not None:
+            acc = torch.zeros(1, dtype=torch.int64, device=self.device)
+            check(load().gjx_ssm_filter_peer_move(C.byref(ssm), key[0], key[1], rng_mode, int(T), self._h, _ptr(ys), _ptr(lse), _ptr(anc),
+                                                  int(move[0]), float(move[1]), _ptr(acc), _stream()), "gjx_ssm_filter_peer_move")
+            return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc, accepted_total=acc)
         check(load().gjx_ssm_filter_peer(C.byref(ssm), key[0], key[1], rng_mode, int(T), self._h, _ptr(ys), _ptr(lse), _ptr(anc), _stream()),
               "gjx_ssm_filter_peer")
         return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
@@ -835,3 +841,27 @@ def ssm_filter(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, bufs=None
     need = load().gjx_workspace_bytes(A.OP_SSM, K)
     return dict(lse_steps=bufs["lse"], x=bufs["xa"] if (T - 1) % 2 == 0 else bufs["xb"], logw=bufs["logw"],
                 ancestors=bufs["anc"], _bufs=bufs, _status_ws=bufs["ws"][need:])
+
+
+def ssm_filter_move(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, K: int, n_moves: int, move_scale: float):
+    """gjx_ssm_filter_move: the bootstrap filter WITH resample-move rejuvenation (n_moves random-walk Metropolis steps on
+    every resampled particle, tile-scaled resampler) — step 0 and then steps 1 .. T-1 in ONE launch.
+    -> dict(lse_steps [T][4], x, logw, ancestors, accepted_total int64[1] (accepted moves over the run), _status_ws), or None
+    when the shape / size is outside the one-launch kernel (the caller runs the step-by-step loop)."""
+    dev = ys.device
+    T = ys.shape[0]
+    need = load().gjx_workspace_bytes(A.OP_SSM, K)
+    f32 = torch.float32
+    b = dict(xa=torch.empty((ssm.dx, K), dtype=f32, device=dev), xb=torch.empty((ssm.dx, K), dtype=f32, device=dev),
+             ma=torch.empty((ssm.dx, K), dtype=f32, device=dev), mb=torch.empty((ssm.dx, K), dtype=f32, device=dev),
+             logw=torch.empty(K, dtype=f32, device=dev), lw2=torch.empty(K, dtype=f32, device=dev),
+             anc=torch.empty(K, dtype=torch.int32, device=dev), lse=torch.empty((T, 4), dtype=f32, device=dev),
+             acc=torch.zeros(1, dtype=torch.int64, device=dev), ws=torch.zeros(2 * need + 64, dtype=torch.uint8, device=dev))
+    rc = load().gjx_ssm_filter_move(C.byref(ssm), key[0], key[1], rng_mode, T, int(K), _ptr(ys), _ptr(b["xa"]), _ptr(b["xb"]),
+                                    _ptr(b["ma"]), _ptr(b["mb"]), _ptr(b["logw"]), _ptr(b["lw2"]), _ptr(b["anc"]), _ptr(b["lse"]),
+                                    int(n_moves), float(move_scale), _ptr(b["acc"]), _ptr(b["ws"]), b["ws"].numel(), _stream())
+    if rc == A.EUNSUPPORTED:
+        return None
+    check(rc, "gjx_ssm_filter_move")
+    return dict(lse_steps=b["lse"], x=b["xa"] if (T - 1) % 2 == 0 else b["xb"], logw=b["logw"], ancestors=b["anc"],
+                accepted_total=b["acc"], _bufs=b, _status_ws=b["ws"][need:])

@@ -516,6 +516,18 @@ enum { GJX_WEIGHTS_GLOBAL_MAX = 0, GJX_WEIGHTS_TILE_SCALED = 1 };
 int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
                           const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                           float* lse_steps, int32_t weight_scheme, void* workspace, size_t workspace_bytes, void* stream);
+/* The same filter WITH resample-move rejuvenation inside the one launch (requests/rejuvenate.py:70-94 fused into the
+ * filter, as gjx_ssm_step_move does per step): after every resampling each particle takes n_moves random-walk Metropolis
+ * steps of scale move_scale that leave p(x_{t-1} | parent, y_{t-1}) invariant, then propagates.  GJX_WEIGHTS_TILE_SCALED
+ * resampler; the same draws and arithmetic as the per-step calls (gjx_resample_indices_tiled + gjx_ssm_step_move), so
+ * particles and weights are bit-identical to that loop.  m_a, m_b f32[dx][K]: the transition means (ping-pong like x_a,
+ * x_b); logw_alt f32[K]: the second log-weight buffer; accepted_total u64[1] (or NULL): accepted moves over the run.
+ * GJX_EUNSUPPORTED when the shape (dx not in 2, 4, 8, 16; dy > 32) or the size (grid not co-resident) is outside the
+ * one-launch kernel: loop over gjx_ssm_step_move then.  workspace as gjx_ssm_filter. */
+int gjx_ssm_filter_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
+                        const float* ys_dev, float* x_a, float* x_b, float* m_a, float* m_b, float* logw, float* logw_alt,
+                        int32_t* ancestors, float* lse_steps, int32_t n_moves, float move_scale, uint64_t* accepted_total,
+                        void* workspace, size_t workspace_bytes, void* stream);
 /* The tile-scaled systematic resampler on its own (three plain launches; what the filter's one-launch form computes
  * between two steps, bit for bit): log-weights f32[K] -> ancestors i32[N].  cum u64[K] scratch (tile-local cumulative q);
  * q_out u32[K] / e_out i32[ceil(K/1024)] receive the quantised weights and tile exponents when not NULL (the oracle
@@ -587,6 +599,12 @@ int gjx_peer_ctx_destroy(gjx_peer_ctx* ctx);
  * ancestor at the last resampling. */
 int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
                         const float* ys_dev, float* lse_steps, int32_t* ancestors, void* stream);
+/* the sharded filter with resample-move rejuvenation: gjx_ssm_filter_move on a collection sharded over the ranks of a peer
+ * context (the transition means travel through the DATA windows like the states).  accepted_total u64[1] (or NULL): accepted
+ * moves of THIS rank's particles over the run.  Results do not depend on the number of ranks. */
+int gjx_ssm_filter_peer_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
+                             const float* ys_dev, float* lse_steps, int32_t* ancestors, int32_t n_moves, float move_scale,
+                             uint64_t* accepted_total, void* stream);
 /* BASELINE configs 2 / 4 on a sharded collection — one systematic resampling step over the WHOLE collection in ONE
  * launch per rank (ParticleCollection resampling, the N-of-K form of smc.py:102-109): this rank's log-weights logw[parity]
  * and rows rows[parity] (the buffers of the DATA window the producing kernel wrote) -> the children of this rank's

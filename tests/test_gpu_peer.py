@@ -19,7 +19,7 @@ def _problem(dx, T):
     return workloads.ssm_problem(dx=dx, T=T)
 
 
-def _filter_worker(rank, world, port, K_total, T, dx, rng, q):
+def _filter_worker(rank, world, port, K_total, T, dx, rng, q, move=None):
     try:
         import sys
         import torch
@@ -38,10 +38,10 @@ def _filter_worker(rank, world, port, K_total, T, dx, rng, q):
         ctx = kernels.PeerContext(K_total // world, dx, "cuda")
         outs = []
         for rep in range(3):                      # consecutive runs alternate the flag regions of the context
-            o = ctx.ssm_filter(ssm.c_struct("cuda"), (0, 5 + rep), rng, ys, want_ancestors=True)
+            o = ctx.ssm_filter(ssm.c_struct("cuda"), (0, 5 + rep), rng, ys, want_ancestors=True, move=move)
             torch.cuda.synchronize()
             outs.append((o["x"].cpu().numpy().copy(), o["logw"].cpu().numpy().copy(), o["lse_steps"].cpu().numpy().copy(),
-                         o["ancestors"].cpu().numpy().copy()))
+                         o["ancestors"].cpu().numpy().copy(), int(o["accepted_total"][0]) if move else 0))
         st = ctx.status()
         q.put((rank, outs, st, ctx.ranks_on_device))
         ctx.close()
@@ -92,6 +92,45 @@ def test_peer_filter_equals_unsharded(world, K_total, dx):
             np.testing.assert_allclose(r[1][rep][2][:, 2:], ref["lse_steps"].cpu().numpy()[:, 2:], rtol=2e-6, atol=2e-6)
     assert all(r[2] == 0 for r in res), [r[2] for r in res]       # no rendezvous timed out, no dead step
     assert all(r[3] == world for r in res)                         # the ranks noticed that they share one device
+
+
+@pytest.mark.parametrize("world,K_total,dx", [(1, 1 << 15, 8), (2, 1 << 15, 8), (4, 1 << 16, 4)])
+def test_peer_move_filter_equals_unsharded(world, K_total, dx):
+    """the sharded filter WITH resample-move rejuvenation (gjx_ssm_filter_peer_move: the parent means of the Metropolis
+    target are pulled through the peer windows like the states) == gjx_ssm_filter_move on one rank: particles, weights
+    and the number of accepted moves, bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels
+    from genjax_amd.inference.pf import LinearGaussianSSM
+    T, move = 12, (2, 0.4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 200) + world
+    procs = [ctx.Process(target=_filter_worker, args=(r, world, port, K_total, T, dx, A.RNG_FLAT, q, move)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s = _problem(dx, T)
+    ssm = LinearGaussianSSM(s["A"], s["q"], s["r"])
+    ys = torch.as_tensor(np.asarray(s["y"], np.float32)).cuda()
+    for rep in range(3):
+        ref = kernels.ssm_filter_move(ssm.c_struct("cuda"), (0, 5 + rep), A.RNG_FLAT, ys, K_total, move[0], move[1])
+        torch.cuda.synchronize()
+        assert ref is not None
+        np.testing.assert_array_equal(np.concatenate([r[1][rep][0] for r in res], axis=1), ref["x"].cpu().numpy())
+        np.testing.assert_array_equal(np.concatenate([r[1][rep][1] for r in res]), ref["logw"].cpu().numpy())
+        assert sum(r[1][rep][4] for r in res) == int(ref["accepted_total"][0]) > 0
+        for r in res:
+            np.testing.assert_allclose(r[1][rep][2][:, 2:], ref["lse_steps"].cpu().numpy()[:, 2:], rtol=2e-6, atol=2e-6)
+    assert all(r[2] == 0 for r in res), [r[2] for r in res]
 
 
 def _weights(shape, K, seed=11):

@@ -118,3 +118,34 @@ def test_resample_move_filter_keeps_the_estimate_and_restores_diversity():
         assert np.abs(got[-4:] - ms[-4:]).max() < 0.05 * sd.max(), name
         assert np.abs(got - ms).max() < 0.25 * sd.max(), name
     assert abs(stds["moved"] - stds["plain"]) < 0.02 * s["q"], stds
+
+
+@pytest.mark.parametrize("rng", [0, 1])
+@pytest.mark.parametrize("K,dx,useH", [(1 << 16, 8, False), ((1 << 15) - 70, 4, True), (1 << 19, 8, False)])
+def test_move_filter_in_one_launch_equals_the_step_by_step_loop(rng, K, dx, useH):
+    """Resample-move INSIDE the one-launch filter (gjx_ssm_filter_move, k_pf_persistent<.., MOVE>): the same draws and
+    arithmetic as gjx_resample_indices_tiled + gjx_ssm_step_move issued per step from the host — bit-identical particles
+    and weights, the same accept count — and the estimate still agrees with the Kalman filter."""
+    import torch
+    from genjax_amd import core, workloads
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    from oracle import closed_form as cf
+    if K > (1 << 18) and rng == 1:
+        pytest.skip("one size of the large grid is enough")
+    s = workloads.ssm_problem(dx=dx, T=20, r=1.0)
+    Hm = np.random.default_rng(3).standard_normal((3, dx)).astype(np.float32) if useH else None
+    ys = s["y"] if not useH else (s["y"] @ Hm.T).astype(np.float32)
+    m = LinearGaussianSSM(s["A"], s["q"], 1.0, Hm)
+    bf = BootstrapFilter(m, K, rng_mode=rng, rejuvenate=dict(n_moves=2, scale=0.4), weights="tile_scaled")
+    a = bf.run(core.key(21), ys)
+    rate_a = bf.last_accept_rate
+    assert a.get("history", None) is None and not a["degenerate"]
+    b = bf.run(core.key(21), ys, step_by_step=True)
+    rate_b = bf.last_accept_rate
+    np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+    np.testing.assert_array_equal(_np(a["logw"]), _np(b["logw"]))
+    np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-5)
+    assert rate_a == pytest.approx(rate_b, rel=1e-6) and 0.05 < rate_a < 0.95
+    if not useH:
+        exact, _, _ = cf.kalman_log_lik(s["A"], ys, s["q"], 1.0)
+        assert abs(float(a["log_ml"]) - exact) < 3e-3 * abs(exact)
