@@ -96,6 +96,10 @@ struct RollInfo {
   int row = -1, d_row = 0;              // first row of the site's value in choices[][]
   int score_row = 0, d_score_row = 0;   // row of the site in site_scores[][]
   int d_obs = 0;                        // stride of obs_off
+  bool load_here = false;               // the site's own rows (OBS_SLOT / OBS_MASK values, the mask flags) are loaded in front of
+                                        // the site instead of at the top of the kernel: their rows move with t_, or the
+                                        // register that holds them is not the row number (rolled programs)
+  int flag_row = -1, d_flag_row = 0;    // OBS_MASK: row of the site's flags in choices[][] (the register is gjx_site.obs_off)
   int d_off[4] = {0, 0, 0, 0}, d_moff[4] = {0, 0, 0, 0};   // strides of the parameters' table offsets
 };
 
@@ -146,6 +150,8 @@ int n_params(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_
 struct Roll {
   bool ok = false;
   int i0 = 0, m = 0, T = 0, S = 0, n_pre = 0;
+  int n_post = 0;                   // sites behind the Scan (emitted after the loop)
+  int n_regs = 0;                   // value registers of the emitted kernel
   unsigned scan_id = 0;
   std::vector<gjx_site> sites;      // emitted sites: [0, i0) pre, [i0, i0 + m) step 0, [i0 + m, i0 + 2 m) step 1 (loop body)
   std::vector<RollInfo> info;
@@ -164,32 +170,54 @@ Roll detect_roll(const gjx_program* p) {
   const unsigned id = GJX_SCAN_ID(p->sites[i0].scan);
   int m = 0;
   while (i0 + m < n && p->sites[i0 + m].scan == p->sites[i0].scan) ++m;
-  if ((n - i0) % m != 0) return r;
-  const int T = (n - i0) / m;
+  int i1 = i0;                                              // end of the Scan: the sites behind it carry no Scan tag
+  while (i1 < n && p->sites[i1].scan != 0 && GJX_SCAN_ID(p->sites[i1].scan) == id) ++i1;
+  for (int j = i1; j < n; ++j) if (p->sites[j].scan != 0) return r;     // one Scan per rolled program
+  if ((i1 - i0) % m != 0) return r;
+  const int T = (i1 - i0) / m, n_post = n - i1;
   if (T < 4) return r;
   auto at = [&](int t, int l) -> const gjx_site& { return p->sites[i0 + t * m + l]; };
+  auto mode_ok = [](int md) { return md == GJX_MODE_SAMPLE || md == GJX_MODE_OBS_TAB || md == GJX_MODE_OBS_SLOT || md == GJX_MODE_OBS_MASK; };
   for (int t = 0; t < T; ++t)
     for (int l = 0; l < m; ++l) {
       const gjx_site& s = at(t, l);
       if (s.scan != GJX_SCAN_TAG(id, t)) return r;
-      if (s.mode != GJX_MODE_SAMPLE && s.mode != GJX_MODE_OBS_TAB) return r;
+      if (!mode_ok(s.mode)) return r;
     }
   auto width = [&](const gjx_site& s) { return is_categorical(s.kind) ? 1 : s.dim; };
-  // slots: steps are laid out back to back, S slots each, step 0 right behind the pre-Scan slots
+  // value slots: steps are laid out back to back, S slots each, step 0 right behind the pre-Scan slots; then the slots of
+  // the sites behind the Scan; then one flag row per OBS_MASK site, in site order (program.py)
   int S = 0, base0 = -1;
   for (int l = 0; l < m; ++l) if (at(0, l).slot >= 0) { S += width(at(0, l)); if (base0 < 0 || at(0, l).slot < base0) base0 = at(0, l).slot; }
-  if (S <= 0 || base0 < 0 || p->n_slots != base0 + T * S) return r;
+  if (S <= 0 || base0 < 0) return r;
+  int post_slots = 0, nf_pre = 0, mk = 0, nf_post = 0;
+  for (int j = i1; j < n; ++j) if (p->sites[j].slot >= 0) post_slots += width(p->sites[j]);
+  for (int j = 0; j < i0; ++j) nf_pre += p->sites[j].mode == GJX_MODE_OBS_MASK;
+  for (int l = 0; l < m; ++l) mk += at(0, l).mode == GJX_MODE_OBS_MASK;
+  for (int j = i1; j < n; ++j) nf_post += p->sites[j].mode == GJX_MODE_OBS_MASK;
+  const int post0 = base0 + T * S;                  // first slot of the sites behind the Scan
+  const int F0 = post0 + post_slots;                // first flag row
+  if (p->n_slots != F0 + nf_pre + T * mk + nf_post) return r;
   for (int j = 0; j < i0; ++j) if (p->sites[j].slot >= 0 && p->sites[j].slot + width(p->sites[j]) > base0) return r;
   const int n_pre = base0;
   auto base = [&](int t) { return base0 + t * S; };
   // every step has step 1's shape; step 0 may differ in its parameters only (the initial carry is constant)
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < T; ++t) {
+    int fi = 0;
     for (int l = 0; l < m; ++l) {
       const gjx_site &a = at(t, l), &b = at(1, l);
       if (a.kind != b.kind || a.dim != b.dim || a.mode != b.mode || a.ncat != b.ncat || a.flags != b.flags) return r;
       if ((a.slot < 0) != (b.slot < 0) || (a.slot >= 0 && a.slot - base(t) != b.slot - base(1))) return r;
       if (a.slot >= 0 && (a.slot < base(t) || a.slot + width(a) > base(t) + S)) return r;
+      if (a.mode == GJX_MODE_OBS_MASK && a.obs_off != F0 + nf_pre + t * mk + fi++) return r;
     }
+  }
+  {   // flags of the sites in front of and behind the Scan
+    int fi = 0;
+    for (int j = 0; j < i0; ++j) if (p->sites[j].mode == GJX_MODE_OBS_MASK && p->sites[j].obs_off != F0 + fi++) return r;
+    fi = 0;
+    for (int j = i1; j < n; ++j) if (p->sites[j].mode == GJX_MODE_OBS_MASK && p->sites[j].obs_off != F0 + nf_pre + T * mk + fi++) return r;
+  }
   // strides from steps 1 and 2, checked on every later step
   std::vector<RollInfo> st(m);
   for (int l = 0; l < m; ++l) {
@@ -227,29 +255,74 @@ Roll detect_roll(const gjx_program* p) {
       const bool own = q.slot >= base(0) && q.slot + ref_span(q) <= base(0) + S;
       if (!pre && !own) return r;
     }
-  // ---- the emitted program
+  // the sites behind the Scan: their own slots follow the Scan's; they read pre-Scan slots, the LAST step (still in
+  // registers when the loop ends) or each other
+  for (int j = i1; j < n; ++j) {
+    const gjx_site& sj = p->sites[j];
+    if (!mode_ok(sj.mode)) return r;
+    if (sj.slot >= 0 && (sj.slot < post0 || sj.slot + width(sj) > F0)) return r;
+    for (int k = 0; k < n_params(sj.kind); ++k) {
+      const gjx_param& q = sj.p[k];
+      if (!slot_op(q.op)) continue;
+      const bool pre = q.slot + ref_span(q) <= n_pre;
+      const bool last = q.slot >= base(T - 1) && q.slot + ref_span(q) <= base(T - 1) + S;
+      const bool post = q.slot >= post0 && q.slot + ref_span(q) <= F0;
+      if (!pre && !last && !post) return r;
+    }
+  }
+  // ---- the emitted program.  Registers: [0, n_pre) pre-Scan values | [n_pre, n_pre + S) previous step | [.., n_pre + 2 S)
+  //      current step | post-Scan values | flags: pre-Scan sites, the current step's, post-Scan sites
+  const int reg_post0 = n_pre + 2 * S, reg_f0 = reg_post0 + post_slots;
   auto remap = [&](int ref, int tau) -> int {     // a slot referenced from step tau -> register slot
     if (ref < n_pre) return ref;
     if (ref >= base(tau) && ref < base(tau) + S) return n_pre + S + (ref - base(tau));   // current step
     return n_pre + (ref - base(tau - 1));                                                 // previous step
   };
-  for (int j = 0; j < i0; ++j) {
-    r.sites.push_back(p->sites[j]);
-    RollInfo ri; ri.row = p->sites[j].slot; ri.score_row = j;
-    r.info.push_back(ri);
+  auto remap_post = [&](int ref) -> int {         // a slot referenced from behind the Scan
+    if (ref < n_pre) return ref;
+    if (ref >= post0) return reg_post0 + (ref - post0);
+    return n_pre + (ref - base(T - 1));           // the last step: the loop's final carry left it in the "previous" registers
+  };
+  {
+    int fi = 0;
+    for (int j = 0; j < i0; ++j) {
+      gjx_site s = p->sites[j];
+      RollInfo ri; ri.row = s.slot; ri.score_row = j;
+      if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; s.obs_off = reg_f0 + fi++; ri.load_here = true; }
+      r.sites.push_back(s);
+      r.info.push_back(ri);
+    }
   }
-  for (int tau = 0; tau < 2; ++tau)
+  for (int tau = 0; tau < 2; ++tau) {
+    int fi = 0;
     for (int l = 0; l < m; ++l) {
       gjx_site s = at(tau, l);
       RollInfo ri = tau ? st[l] : RollInfo();
       ri.row = s.slot; ri.score_row = i0 + tau * m + l;
       if (tau) { ri.d_row = S; ri.d_score_row = m; }
+      if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) ri.load_here = true;
+      if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = tau ? mk : 0; s.obs_off = reg_f0 + nf_pre + fi++; }
       if (s.slot >= 0) s.slot = remap(s.slot, tau);
       for (int k = 0; k < n_params(s.kind); ++k) if (slot_op(s.p[k].op)) s.p[k].slot = remap(s.p[k].slot, tau);
       r.sites.push_back(s);
       r.info.push_back(ri);
     }
-  r.ok = true; r.i0 = i0; r.m = m; r.T = T; r.S = S; r.n_pre = n_pre; r.scan_id = id;
+  }
+  {
+    int fi = 0;
+    for (int j = i1; j < n; ++j) {
+      gjx_site s = p->sites[j];
+      RollInfo ri; ri.row = s.slot; ri.score_row = j;
+      if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) ri.load_here = true;
+      if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; s.obs_off = reg_f0 + nf_pre + mk + fi++; }
+      if (s.slot >= 0) s.slot = remap_post(s.slot);
+      for (int k = 0; k < n_params(s.kind); ++k) if (slot_op(s.p[k].op)) s.p[k].slot = remap_post(s.p[k].slot);
+      r.sites.push_back(s);
+      r.info.push_back(ri);
+    }
+  }
+  r.ok = true; r.i0 = i0; r.m = m; r.T = T; r.S = S; r.n_pre = n_pre; r.scan_id = id; r.n_post = n_post;
+  r.n_regs = reg_f0 + nf_pre + mk + nf_post;
   return r;
 }
 
@@ -282,7 +355,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
 bool supported_uncached(const gjx_program* p) {
   if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
-  return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_pre + 2 * r.S);
+  return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs);
 }
 
 // index into the float table of parameter q at element `d` (a C expression; `dx` is the element index expression)
@@ -360,6 +433,12 @@ void emit_site(Emit& o, Plan& pl, int j) {
   } else if (draws) {
     if (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", ss.site_no);
     else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", ss.key_var.c_str(), ss.site_no);
+  }
+  if (ri.load_here) {   // per-particle constraint rows / mask flags whose row moves with t_ or differs from the register number
+    const int nrow_ = is_categorical(kind) ? 1 : s.dim;
+    if (mode == GJX_MODE_OBS_SLOT || masked)
+      for (int d = 0; d < nrow_; ++d) o.f("      PLOOP v[%d][p] = a.choices[(int64_t)%s * K + i0 + p];\n", s.slot + d, toff(ri.row + d, ri.d_row).c_str());
+    if (masked) o.f("      PLOOP v[%d][p] = a.choices[(int64_t)%s * K + i0 + p];\n", s.obs_off, toff(ri.flag_row, ri.d_flag_row).c_str());
   }
   if (masked) o.f("      bool given[PPT];\n      PLOOP given[p] = v[%d][p] != 0.0f;\n", s.obs_off);
   emit_gather_index(o, s, j, np);
@@ -509,7 +588,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
   Roll roll;
   if (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots)) roll = detect_roll(prog_in);
   gjx_program eprog = *prog_in;
-  if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_pre + 2 * roll.S; }
+  if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_regs; }
   const gjx_program* prog = &eprog;
   Plan pl;
   pl.prog = prog;
@@ -521,10 +600,12 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     for (int j = 0; j < roll.i0; ++j) pl.stream.push_back({"", ++plain});
     for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"sk0", (unsigned)(l + 1)});
     for (int l = 0; l < roll.m; ++l) pl.stream.push_back({"skt", (unsigned)(l + 1)});
-    int n_runs = 0;   // runs never cross the three segments (the Scan tag changes at each boundary)
+    for (int j = 0; j < roll.n_post; ++j) pl.stream.push_back({"", ++plain});      // behind the Scan: the run key again, numbering continues
+    int n_runs = 0;   // runs never cross the segments (the Scan tag changes at each boundary)
     assign_runs(prog, pl.stream, 0, roll.i0, n_runs);
     assign_runs(prog, pl.stream, roll.i0, roll.i0 + roll.m, n_runs);
     assign_runs(prog, pl.stream, roll.i0 + roll.m, roll.i0 + 2 * roll.m, n_runs);
+    assign_runs(prog, pl.stream, roll.i0 + 2 * roll.m, roll.i0 + 2 * roll.m + roll.n_post, n_runs);
     char b[256];
     snprintf(b, sizeof(b), "  const key2 sk0 = fold_in(fold_in(a.key, %uu), 0u);\n", 0x80000000u | roll.scan_id);
     pl.key_decls = b;
@@ -571,6 +652,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     for (int j = roll.i0 + roll.m; j < roll.i0 + 2 * roll.m; ++j) emit_site(body, pl, j);
     carry();
     body.f("    }\n");
+    for (int j = roll.i0 + 2 * roll.m; j < roll.i0 + 2 * roll.m + roll.n_post; ++j) emit_site(body, pl, j);   // the last step sits in the "previous" registers
   } else {
     for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
   }
@@ -627,6 +709,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
   std::vector<char> pre(prog->n_slots > 0 ? prog->n_slots : 1, 0);
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
+    if (pl.info[j].load_here) continue;
     if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) {
       const int n = is_categorical(s.kind) ? 1 : s.dim;
       for (int d = 0; d < n; ++d) pre[s.slot + d] = 1;

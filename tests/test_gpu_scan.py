@@ -218,3 +218,103 @@ def test_rolled_scan_with_a_hyper_site_vector_state_and_affine_transition(K_, or
     assert bad.mean() < 0.02                                   # regime flips at near ties propagate down the chain
     good = ~bad
     np.testing.assert_allclose(_np(g["logw"])[good], ora["logw"][good], rtol=5e-4, atol=5e-4)
+
+
+def _scan_with_extras(T, x_mode, post=True, pre_masked=False, seed=0):
+    """mu ~ N(0, 1) in front of a Scan of T steps {x_t ~ N(x_{t-1}, 0.3) (x_{-1} = mu), y_t ~ N(x_t, 0.7) observed}, and behind
+    it z ~ N(x_{T-1}, 1), v ~ N(mu, 2), w ~ N(z, 0.5) observed.  x_mode: the constraint mode of every x_t (per-particle values /
+    per-particle masks live in rows of choices[][])."""
+    from genjax_amd import _abi as A
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    rs = np.random.default_rng(seed)
+    sl = SiteList()
+    modes, obs = {}, {}
+    sl.add("mu", A.NORMAL, [0.0, 1.0])
+    if pre_masked:
+        modes["mu"] = A.MODE_OBS_MASK
+    for t in range(T):
+        loc = Param.value(("x", t - 1)) if t else Param.value("mu")          # step 0 starts at the pre-Scan site
+        sx = sl.add(("x", t), A.NORMAL, [loc, Param.const(0.3)])
+        sy = sl.add(("y", t), A.NORMAL, [Param.value(("x", t)), Param.const(0.7)])
+        sx.scan = sy.scan = (3 << 20) | (t + 1)
+        modes[("y", t)] = A.MODE_OBS_TAB
+        obs[("y", t)] = np.float32(rs.standard_normal())
+        if x_mode != A.MODE_SAMPLE:
+            modes[("x", t)] = x_mode
+    if post:
+        sl.add("z", A.NORMAL, [Param.value(("x", T - 1)), Param.const(1.0)])
+        sl.add("v", A.NORMAL, [Param.value("mu"), Param.const(2.0)])
+        sl.add("w", A.NORMAL, [Param.value("z"), Param.const(0.5)])
+        modes["w"] = A.MODE_OBS_TAB
+        obs["w"] = np.float32(0.3)
+    return PackedProgram(sl, modes, obs)
+
+
+def _rolled_vs_interp_vs_oracle(K_, oracle, prog, K, T, ch=None):
+    import torch
+    old = os.environ.get("GJX_GEN_ROLL")
+    os.environ["GJX_GEN_ROLL"] = "1"
+    try:
+        with engine("gen"):
+            assert K_.program_engine(prog) == 4
+            src = K_.program_source(prog)
+            assert "for (int t_ = 1; t_ < %d; ++t_)" % T in src
+            g = K_.run_program(prog, (5, 6), K, choices=None if ch is None else torch.as_tensor(ch).cuda(), want_site_scores=True)
+    finally:
+        if old is None:
+            del os.environ["GJX_GEN_ROLL"]
+        else:
+            os.environ["GJX_GEN_ROLL"] = old
+    with engine("interp"):
+        i = K_.run_program(prog, (5, 6), K, choices=None if ch is None else torch.as_tensor(ch).cuda(), want_site_scores=True)
+    np.testing.assert_array_equal(_np(g["choices"]), _np(i["choices"]))
+    np.testing.assert_allclose(_np(g["site_scores"]), _np(i["site_scores"]), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_np(g["logw"]), _np(i["logw"]), rtol=2e-4, atol=3e-4)
+    np.testing.assert_allclose(_np(g["score"]), _np(i["score"]), rtol=2e-4, atol=3e-4)
+    ora = oracle.run_program(prog, (5, 6), K, choices=None if ch is None else ch.copy())
+    np.testing.assert_allclose(_np(g["choices"]), ora["choices"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(_np(g["logw"]), ora["logw"], rtol=3e-4, atol=5e-4)
+    return g
+
+
+@pytest.mark.parametrize("T", [12, 300])
+def test_rolled_scan_with_sites_behind_the_scan(K_, oracle, T):
+    """sites after the Scan (a final latent and an observation) are emitted behind the loop and read the LAST step from
+    the registers the final carry left it in"""
+    from genjax_amd import _abi as A
+    prog = _scan_with_extras(T, A.MODE_SAMPLE, post=True)
+    g = _rolled_vs_interp_vs_oracle(K_, oracle, prog, 4096, T)
+    z = _np(g["choices"])[prog.slot_of["z"]]
+    xl = _np(g["choices"])[prog.slot_of[("x", T - 1)]]
+    assert 0.8 < np.std(z - xl) < 1.2                                  # z ~ N(x_{T-1}, 1)
+
+
+@pytest.mark.parametrize("T,post", [(10, False), (200, True)])
+def test_rolled_scan_with_per_particle_constraints(K_, oracle, T, post):
+    """every x_t constrained to the particle's OWN value (GJX_MODE_OBS_SLOT: what assess / ChangeTarget / Update run over a
+    Scan trace): the rolled loop loads the step's rows as t advances; the weight is the whole score"""
+    from genjax_amd import _abi as A
+    prog = _scan_with_extras(T, A.MODE_OBS_SLOT, post=post)
+    K = 2048
+    rs = np.random.default_rng(4)
+    ch = (rs.standard_normal((prog.n_slots, K)) * 0.5).astype(np.float32)
+    g = _rolled_vs_interp_vs_oracle(K_, oracle, prog, K, T, ch)
+    for t in (0, T // 2, T - 1):
+        np.testing.assert_array_equal(_np(g["choices"])[prog.slot_of[("x", t)]], ch[prog.slot_of[("x", t)]])   # untouched
+
+
+@pytest.mark.parametrize("T,post,pre_masked", [(9, True, True), (150, False, False)])
+def test_rolled_scan_with_per_particle_masks(K_, oracle, T, post, pre_masked):
+    """Mask(value, flag) per particle and step (GJX_MODE_OBS_MASK): flag rows advance with t like the value rows"""
+    from genjax_amd import _abi as A
+    prog = _scan_with_extras(T, A.MODE_OBS_MASK, post=post, pre_masked=pre_masked)
+    K = 2048
+    rs = np.random.default_rng(5)
+    ch = (rs.standard_normal((prog.n_slots, K)) * 0.5).astype(np.float32)
+    for a, fs in prog.flag_slot_of.items():
+        ch[fs] = rs.random(K) < 0.4
+    g = _rolled_vs_interp_vs_oracle(K_, oracle, prog, K, T, ch)
+    a = ("x", T // 2)
+    fl = ch[prog.flag_slot_of[a]] != 0
+    np.testing.assert_array_equal(_np(g["choices"])[prog.slot_of[a]][fl], ch[prog.slot_of[a]][fl])
+    assert (_np(g["choices"])[prog.slot_of[a]][~fl] != ch[prog.slot_of[a]][~fl]).mean() > 0.99
