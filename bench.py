@@ -277,7 +277,9 @@ def run_gmm(args, rank, world, dev):
         tp = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")   # FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/README.md)
         if os.path.exists(tp):                                           # keys: rocprofv3 kernel names without "void " and blanks
             want = "gjx::k_run_gmm_flat<%d,4,256," % D
-            v = next((v for k, v in json.load(open(tp)).items() if k.startswith(want) and k.endswith("true>") == bool(fused_step)), None)
+            # template arguments: <D, particles per lane, threads, STEP (the one-launch importance step), TILES (tile totals left for the tile-scaled resampler)>
+            v = next((v for k, v in json.load(open(tp)).items()
+                      if k.startswith(want) and k[len(want):].startswith("true") == bool(fused_step)), None)
             if v is not None:
                 traffic_prof = dict(bytes_per_launch=v, file="profiles/%s_pmc_traffic.json" % tag,
                                     note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run")
@@ -772,6 +774,102 @@ def run_sharded_one_rank(dev):
                          ratio=s_shard / s_plain, log_ml_unsharded=l_plain, log_ml_sharded=l_shard))
 
 
+def run_round3(dev):
+    """Round-3 paths, short runs: (1) the ImportanceK step with the PLAIN-launch tile-scaled resampler
+    (gjx_resample_gather_tiled: no co-resident grid) next to the one-launch global-maximum resampler, at K = 2^20 and at
+    the sizes the latter cannot run in one launch; (2) the bootstrap filter with resample-move rejuvenation inside the
+    one-launch filter vs the step-by-step loop; (3) assess of a T = 256 Scan trace (every latent constrained to the
+    particle's own value) on the rolled generated kernel vs the site interpreter."""
+    from genjax_amd import _abi as A
+    from genjax_amd import core, kernels, workloads
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    res = {}
+    prog, _ = workloads.gmm_program(D=D, C=C)
+
+    def timed(fn, n=300):
+        for i in range(30):
+            fn(i)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / n * 1e6)
+        return sorted(ts)[1]
+
+    steps = {}
+    for K in (1 << 20, 1 << 21, 1 << 22):
+        ws = kernels.workspace(A.OP_RUN, K, dev)
+        ws2 = kernels.workspace(A.OP_RESAMPLE, K, dev)
+        out = kernels.run_program(prog, (0, 1), K, ws=ws, want_weight=False, want_lse=False, want_tiles=True)
+        part = out["_partials"]
+        rows = torch.empty_like(out["choices"])
+        rec = torch.empty(4, dtype=torch.float32, device=dev)
+
+        def tiled(i):
+            kernels.run_program(prog, (0, 1 + i), K, ws=ws, out=out, want_weight=False, want_lse=False, want_tiles=True)
+            kernels.resample_gather_tiled(out["logw"], 0.5, out["choices"], partials=(ws, part.count()), tiles=part.tiles, lse_out=rec,
+                                          K_total=K, out=rows, ws=ws2)
+
+        def gmax(i):
+            kernels.run_program(prog, (0, 1 + i), K, ws=ws, out=out, want_weight=False, want_lse=False)
+            kernels.resample_gather(out["logw"], 0.5, out["choices"], partials=(ws, part.count()), lse_out=rec, K_total=K, out=rows, ws=ws2)
+
+        n = 300 if K == 1 << 20 else 100
+        t_t, t_g = timed(tiled, n), timed(gmax, n)
+        steps[str(K)] = dict(us_per_step_tile_scaled_plain_launch=t_t, us_per_step_global_max=t_g,
+                             particle_steps_per_sec_tile_scaled=K / t_t * 1e6, tiles_from_the_propagate_kernel=bool(part.tiles),
+                             log_ml=float(rec[3]))
+        del out, rows
+    res["importance_step_tile_scaled_resampler"] = dict(
+        note="global_max = gjx_resample_gather (one co-resident launch up to K = 2^20 on a full MI355X, beyond that "
+             "gjx_resample_indices + gjx_gather_rows); tile_scaled = gjx_resample_gather_tiled, a plain launch at every size", **steps)
+    s = workloads.ssm_problem()
+    ys = torch.as_tensor(s["y"], device=dev)
+    T = ys.shape[0]
+    mv = {}
+    for K in (1 << 18, 1 << 19):
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, rejuvenate=dict(n_moves=1, scale=0.4), weights="tile_scaled")
+        row = {}
+        for name, sbs in (("one_launch", False), ("step_by_step", True)):
+            bf.run(core.key(1), ys, device=dev, step_by_step=sbs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2):
+                o = bf.run(core.key(2 + i), ys, device=dev, step_by_step=sbs)
+            torch.cuda.synchronize()
+            row["us_per_filter_step_" + name] = (time.perf_counter() - t0) / 2 / T * 1e6
+            row["log_ml_" + name] = float(o["log_ml"])
+        row["accept_rate"] = bf.last_accept_rate
+        mv[str(K)] = row
+    res["resample_move_filter"] = dict(note="lgssm_d8_T256, one random-walk Metropolis move per particle and step, tile-scaled resampler", **mv)
+    # assess of a Scan trace: x_t ~ N(x_{t-1}, 0.3) constrained per particle, y_t observed
+    Ts, Ka = 256, 1 << 16
+    sl = SiteList()
+    modes, obs = {}, {}
+    for t in range(Ts):
+        sx = sl.add(("x", t), A.NORMAL, [Param.value(("x", t - 1)) if t else Param.const(0.0), Param.const(0.3)])
+        sy = sl.add(("y", t), A.NORMAL, [Param.value(("x", t)), Param.const(0.7)])
+        sx.scan = sy.scan = (1 << 20) | (t + 1)
+        modes[("x", t)], modes[("y", t)], obs[("y", t)] = A.MODE_OBS_SLOT, A.MODE_OBS_TAB, np.float32(0.1)
+    pa = PackedProgram(sl, modes, obs)
+    ch = torch.randn((pa.n_slots, Ka), device=dev) * 0.5
+    row = {}
+    for name in ("gen", "interp"):
+        os.environ["GJX_ENGINE"] = name
+        try:
+            row["engine_" + name] = kernels.program_engine(pa)
+            row["us_" + name] = timed(lambda i: kernels.run_program(pa, (0, 1), Ka, choices=ch, want_weight=False), 20)
+        finally:
+            del os.environ["GJX_ENGINE"]
+    row["speedup"] = row["us_interp"] / row["us_gen"]
+    res["scan_trace_assess_T256"] = dict(k_particles=Ka, note="every x_t constrained to the particle's own value (OBS_SLOT): rolled generated kernel vs site interpreter", **row)
+    return res
+
+
 def respawn(n: int) -> None:
     """Replace this process by `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`
     (one rank per GPU over RCCL; rendezvous on 127.0.0.1 and a free port)."""
@@ -876,6 +974,10 @@ def main():
             extra["hmc_generated"] = run_hmc_generated(dev)
         except Exception as e:
             extra["hmc_generated"] = dict(error=repr(e))
+        try:
+            extra["round3"] = run_round3(dev)
+        except Exception as e:
+            extra["round3"] = dict(error=repr(e))
         api = run_api(dev, args.k_per_gpu)
         api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
         extra["api"] = api

@@ -39,4 +39,7 @@ int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t 
 // systematic ancestor expansion with the slot run {slot0, n_valid} read from a device plan (gjx_resample.hip)
 int launch_expand_planned(const uint64_t* cum, int64_t K, const gjx_shard_plan* plan_dev, double u, int64_t N_total,
                           int32_t* ancestors, int64_t anc_capacity, hipStream_t st);
+// maximum tile exponent, shifts and prefix of the shifted tile totals for the tile-scaled resampler (k_tiled_plan, gjx_ssm.hip):
+// P u64[nt + 1], sh i32[nt]
+int launch_tiled_plan(const uint64_t* S, const int32_t* E, int nt, uint64_t* P, int32_t* sh, unsigned* ctrl, hipStream_t st);
 }  // namespace gjx

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_resample_gather(const float* __restrict
 // 4-ary search of the residual, rows copied.  Every load the head needs is issued at the top: the head is one memory
 // latency plus LDS work instead of two fabric round trips.  Ancestors are those of gjx_resample_indices_tiled bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int kGatherTiledMaxTiles = 4096;
+constexpr int kGatherTiledMaxTiles = 65536;
 
 // {S_b, E_b} of every tile from the log-weights (what k_tiled_quantise computes, without the cumulative array)
 __global__ __launch_bounds__(kTileQ) void k_tile_totals(const float* __restrict__ logw, int64_t K, uint64_t* S, int32_t* E) {
@@ -602,9 +602,13 @@ __global__ __launch_bounds__(kTileQ) void k_tile_totals(const float* __restrict_
   }
 }
 
-template <int ITEMS>
+// PLANNED (more than 1024 tiles): the maximum exponent, the shifts and the prefix were computed ONCE by k_tiled_plan (one
+// small launch) and are read from memory — a block touches the nine prefix entries around its own index — instead of
+// every block reducing all nt granules again (O(nt^2) reads and 72 KB of LDS at nt = 4096).
+template <int ITEMS, bool PLANNED>
 __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __restrict__ x, int64_t K, const uint64_t* __restrict__ S,
-                                                              const int32_t* __restrict__ E, int lse_mode, const float* lse,
+                                                              const int32_t* __restrict__ E, const uint64_t* __restrict__ Pg,
+                                                              const int32_t* __restrict__ shg, int lse_mode, const float* lse,
                                                               int n_partials, float* lse_out, float log_k_total, double u,
                                                               const float* __restrict__ src, int64_t src_stride, int rows,
                                                               float* __restrict__ dst, int64_t dst_stride, int32_t* ancestors,
@@ -616,8 +620,10 @@ __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __re
   constexpr int CH = 3;
   extern __shared__ __align__(16) unsigned char gt_dyn[];
   const int nt = (int)gridDim.x;
-  uint64_t* const P = (uint64_t*)gt_dyn;                       // [nt + 1] prefix of the shifted tile totals
-  int32_t* const Eb = (int32_t*)(P + ((nt + 2) & ~1));         // [nt] tile exponents
+  uint64_t* const Pl = (uint64_t*)gt_dyn;                      // [nt + 1] prefix of the shifted tile totals (!PLANNED)
+  int32_t* const Ebl = (int32_t*)(Pl + ((nt + 2) & ~1));       // [nt] tile exponents (!PLANNED)
+  const uint64_t* const P = PLANNED ? Pg : Pl;
+  const int32_t* const Eb = PLANNED ? E : Ebl;
   __shared__ float fred[8];
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t cumL[CH * TILE];                         // cumulative q of the tiles being searched, relative to the tile's start
@@ -644,28 +650,30 @@ __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __re
     const int tc = w0 + c;
     if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
   }
+  int Emax = 0;
+  if constexpr (!PLANNED) {
   float em = (float)kTileDead;
   for (int b = threadIdx.x; b < nt; b += 256) {
     const uint64_t sv = S[b];
     const int e = sv ? E[b] : kTileDead;
-    P[b + 1] = sv;
-    Eb[b] = e;
+    Pl[b + 1] = sv;
+    Ebl[b] = e;
     em = fmaxf(em, (float)e);
   }
   em = wave_max(em);
   if (lane == 0) fred[wid] = em;
-  if (threadIdx.x == 0) P[0] = 0;
+  if (threadIdx.x == 0) Pl[0] = 0;
   __syncthreads();
-  const int Emax = (int)fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+  Emax = (int)fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
   GJX_STAMP(1);
   {   // shifted totals and their prefix, in place: lane t owns entries [t per, (t+1) per)
     const int per = (nt + 255) >> 8;
     const int e0 = threadIdx.x * per < nt ? threadIdx.x * per : nt, e1 = (e0 + per) < nt ? (e0 + per) : nt;
     uint64_t loc = 0;
     for (int e = e0; e < e1; ++e) {
-      const int sh = Emax - Eb[e];
-      const uint64_t g = sh < 64 ? P[e + 1] >> sh : 0;
-      P[e + 1] = g;
+      const int sh = Emax - Ebl[e];
+      const uint64_t g = sh < 64 ? Pl[e + 1] >> sh : 0;
+      Pl[e + 1] = g;
       loc += g;
     }
     const uint64_t inc = wave_scan_u64(loc);
@@ -673,9 +681,11 @@ __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __re
     __syncthreads();
     uint64_t run = inc - loc;
     for (int w = 0; w < wid; ++w) run += wsum[w];
-    for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+    for (int e = e0; e < e1; ++e) { run += Pl[e + 1]; Pl[e + 1] = run; }
     __syncthreads();
   }
+  }
+  auto shift_of = [&](int t) { return PLANNED ? shg[t] : Emax - Eb[t]; };   // (a tile shifted out entirely is never a source)
   const uint64_t total = P[nt];
   GJX_STAMP(2);
   if (blockIdx.x == 0) {   // block-uniform: the LSE record of the producing run (its block partials), the dead-collection flag
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __re
     // residual of every slot in its source tile's own units (< S of that tile)
     uint64_t Tr[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) Tr[k] = (T[k] - P[tile[k]]) << (Emax - Eb[tile[k]]);
+    for (int k = 0; k < ITEMS; ++k) Tr[k] = (T[k] - P[tile[k]]) << shift_of(tile[k]);
     if (threadIdx.x == 0) s_range[0] = tile[0];
     if (threadIdx.x == 255) s_range[1] = tile[ITEMS - 1];
     __syncthreads();
@@ -1047,7 +1057,7 @@ extern "C" int gjx_resample_gather_tiled(const float* logw, int64_t K, const uin
       (lse_mode != 0 && lse_mode != 2) || (lse_mode == 2 && (!lse || n_partials <= 0)) || ((tile_S == nullptr) != (tile_E == nullptr)))
     return gjx_fail(GJX_EINVAL, "gjx_resample_gather_tiled: bad argument");
   const int64_t nt = (K + kTileQ - 1) / kTileQ;
-  if (nt > kGatherTiledMaxTiles) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_gather_tiled: more than 4096 tiles (K > 2^22): use gjx_resample_indices_tiled + gjx_gather_rows");
+  if (nt > kGatherTiledMaxTiles) return gjx_fail(GJX_EUNSUPPORTED, "gjx_resample_gather_tiled: more than 65536 tiles (K > 2^26): use gjx_resample_indices_tiled + gjx_gather_rows");
   if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K) || kWsHeaderBytes + 12 * (size_t)nt > workspace_bytes)
     return gjx_fail(GJX_EWORKSPACE, "gjx_resample_gather_tiled: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -1058,19 +1068,25 @@ extern "C" int gjx_resample_gather_tiled(const float* logw, int64_t K, const uin
     hipLaunchKernelGGL(k_tile_totals, dim3((unsigned)nt), dim3(kTileQ), 0, st, logw, K, S, E);
     tile_S = S; tile_E = E;
   }
-  const size_t lds = 8 * (size_t)((nt + 2) & ~1) + 4 * (size_t)nt;
-  if (lds > 32 * 1024) {   // static + dynamic LDS above the 64 KB default (K > 2^21): raise the kernel's limit once
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute((const void*)k_resample_gather_tiled<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (kGatherTiledMaxTiles + 2) + 4 * kGatherTiledMaxTiles) != hipSuccess)
-        (void)hipGetLastError();
-      raised = true;
-    }
-  }
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
   unsigned long long* timeline = gjx::debug_timeline(64 * (size_t)nt);
-  hipLaunchKernelGGL((k_resample_gather_tiled<4>), dim3((unsigned)nt), dim3(256), lds, st, logw, K, tile_S, tile_E, (int)lse_mode, lse,
-                     (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride, ancestors, ctrl, timeline);
+  if (nt > 1024 || getenv("GJX_TILED_PLANNED")) {
+    // many tiles: maximum exponent, shifts and prefix once (k_tiled_plan), behind the tile totals in the workspace
+    uint64_t* Pg = (uint64_t*)((char*)workspace + kWsHeaderBytes + 12 * (size_t)nt + 16);
+    Pg = (uint64_t*)(((uintptr_t)Pg + 15) & ~(uintptr_t)15);
+    int32_t* shg = (int32_t*)(Pg + nt + 1);
+    if ((char*)(shg + nt) > (char*)workspace + workspace_bytes) return gjx_fail(GJX_EWORKSPACE, "gjx_resample_gather_tiled: workspace too small");
+    const int rc = gjx::launch_tiled_plan(tile_S, tile_E, (int)nt, Pg, shg, ctrl, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_resample_gather_tiled<4, true>), dim3((unsigned)nt), dim3(256), 0, st, logw, K, tile_S, tile_E, (const uint64_t*)Pg,
+                       (const int32_t*)shg, (int)lse_mode, lse, (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride,
+                       ancestors, ctrl, timeline);
+  } else {
+    const size_t lds = 8 * (size_t)((nt + 2) & ~1) + 4 * (size_t)nt;
+    hipLaunchKernelGGL((k_resample_gather_tiled<4, false>), dim3((unsigned)nt), dim3(256), lds, st, logw, K, tile_S, tile_E, (const uint64_t*)nullptr,
+                       (const int32_t*)nullptr, (int)lse_mode, lse, (int)n_partials, lse_out, log_k, u, src, src_stride, (int)rows, dst, dst_stride,
+                       ancestors, ctrl, timeline);
+  }
   GJX_CHECK_LAUNCH("gjx_resample_gather_tiled");
   return GJX_OK;
 }

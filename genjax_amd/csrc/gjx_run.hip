@@ -1177,6 +1177,10 @@ extern "C" int gjx_last_run_partials(void) { return g_last_run_grid; }
 // not cover whole quantisation tiles, K is not a multiple of 1024, lse was requested)
 static thread_local int64_t g_last_run_tiles = 0;
 extern "C" int64_t gjx_last_run_tiles(void) { return g_last_run_tiles; }
+// one-shot request (like gjx_profile_next_run): the NEXT gjx_run_program of this thread leaves the tile totals if it can.
+// Off by default: the per-tile block reduction costs the propagate kernel ~1 % and only gjx_resample_gather_tiled reads them.
+static thread_local int g_want_tiles = 0;
+extern "C" int gjx_run_want_tiles(int32_t on) { g_want_tiles = on ? 1 : 0; return GJX_OK; }
 
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                                int64_t particle_offset, float* choices, float* score, float* weight,
@@ -1237,7 +1241,9 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.tile_S = nullptr; a.tile_E = nullptr;
     // consumer-finishes mode (lse == NULL) on the 1024-particles-per-block kernel: leave the tile totals of the tile-scaled
     // resampler behind the block partials (which take at most 8 bytes per 256 particles)
-    if (flat && ppt == 4 && !lse && partials && K % 1024 == 0 && !env_int("GJX_NO_RUN_TILES", 0)) {
+    const bool want_tiles = g_want_tiles || env_int("GJX_RUN_TILES", 0);
+    g_want_tiles = 0;
+    if (want_tiles && flat && ppt == 4 && !lse && partials && K % 1024 == 0) {
       const size_t off = (kWsHeaderBytes + 8 * (size_t)((K + 255) / 256) + 15) & ~(size_t)15;
       const size_t nt = (size_t)(K / 1024);
       if (off + 12 * nt <= workspace_bytes) {

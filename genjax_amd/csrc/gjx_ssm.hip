@@ -999,6 +999,12 @@ __global__ __launch_bounds__(256) void k_tiled_ancestors(const uint64_t* P, cons
   anc[j] = (int32_t)((int64_t)lo * kTileQ + l2);
 }
 
+int launch_tiled_plan(const uint64_t* S, const int32_t* E, int nt, uint64_t* P, int32_t* sh, unsigned* ctrl, hipStream_t st) {
+  hipLaunchKernelGGL(k_tiled_plan, dim3(1), dim3(1024), 0, st, S, E, nt, P, sh, ctrl);
+  GJX_CHECK_LAUNCH("k_tiled_plan");
+  return GJX_OK;
+}
+
 }  // namespace gjx
 
 using namespace gjx;

@@ -175,8 +175,10 @@ class RunPartials:
 
 def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
                 want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None,
-                want_weight=True):
-    """gjx_run_program.  Returns dict(choices, score, weight, logw, lse[, site_scores])."""
+                want_weight=True, want_tiles=False):
+    """gjx_run_program.  Returns dict(choices, score, weight, logw, lse[, site_scores]).  ``want_tiles`` (with
+    ``want_lse=False``): ask the kernel to leave the tile totals of the tile-scaled resampler beside its block partials
+    (RunPartials.tiles; 0 when this engine / size cannot)."""
     dev = _dev(device)
     K = int(K)
     f32 = torch.float32
@@ -193,6 +195,8 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     if ws is None:
         ws = workspace(A.OP_RUN, K, dev)
     cp = prog.c_program(dev)
+    if want_tiles:
+        load().gjx_run_want_tiles(1)
     rc = load().gjx_run_program(C.byref(cp), key[0], key[1], K, int(offset), _ptr(ch), _ptr(score), _ptr(weight),
                                 _ptr(logw), _ptr(logw_in), _ptr(sub), _ptr(ss), _ptr(lse), int(K_total or K),
                                 _ptr(ws), ws.numel(), _stream())

@@ -323,9 +323,13 @@ int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_
 int gjx_last_run_partials(void);
 /* byte offset, inside the workspace of the LAST gjx_run_program call of the calling thread, of the tile totals that run
  * left for gjx_resample_gather_tiled: uint64 S[nt] followed by int32 E[nt], nt = K / 1024 — or 0 when it left none.  A run
- * leaves them when it is called with lse == NULL (consumer-finishes mode), K is a multiple of 1024 and a block of its
+ * leaves them when gjx_run_want_tiles(1) preceded it, it is called with lse == NULL (consumer-finishes mode), K is a multiple
+ * of 1024 and a block of its
  * kernel covers whole 1024-particle tiles (the hand-fused mixture kernel with 4 particles per lane). */
 int64_t gjx_last_run_tiles(void);
+/* one-shot: ask the NEXT gjx_run_program call of the calling thread to leave those tile totals (off by default: the
+ * per-tile reduction costs the propagate kernel about 1 %, and only gjx_resample_gather_tiled reads them) */
+int gjx_run_want_tiles(int32_t on);
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:

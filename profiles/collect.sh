@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile collection on the GPU box (run through gpurun): bench JSON lines, rocprofv3 kernel stats, PMC passes.
-# usage: bash profiles/collect.sh r02 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
-TAG=${1:-r02}; shift; WL=${@:-gmm ssm hmc}
+# usage: bash profiles/collect.sh r03 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
+TAG=${1:-r03}; shift; WL=${@:-gmm ssm hmc}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 for w in $WL; do
@@ -9,10 +9,16 @@ for w in $WL; do
 done
 cd /tmp; export TMPDIR=/tmp
 for w in $WL; do
-  st=100; [ $w != gmm ] && st=3
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --steps $st --warmup 1 > $OUT/prof_$w.log 2>&1
+  # gmm: the headline command WITHOUT the extra workloads (they launch the same kernels at other sizes, which would mix into
+  # the per-kernel averages); the extras get their own trace below
+  st=100; xf=--no-extra; [ $w != gmm ] && st=3 && xf=
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline $xf --steps $st --warmup 1 > $OUT/prof_$w.log 2>&1
   cp $(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${w}_kernel_stats.csv
 done
+if echo $WL | grep -q gmm; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extra -o extra -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 1 > $OUT/prof_extra.log 2>&1
+  cp $(find $OUT/prof_extra -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_gmm_with_extras_kernel_stats.csv
+fi
 # PMC passes for the default bench (counters only: no tracing domains alongside --pmc); FETCH_SIZE and WRITE_SIZE in separate passes
 if echo $WL | grep -q gmm; then
   CMD="python $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 --event-samples 2"
@@ -25,9 +31,17 @@ import csv, glob, collections, json
 res = collections.defaultdict(dict)
 for sub in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % sub, recursive=True):
-        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        # the extra workloads launch some kernels at several sizes: a kernel's launches are grouped by grid size and the
+        # most frequent grid is the one reported (the headline kernel: 1024 blocks = K 2^20)
+        g = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
         for r in csv.DictReader(open(f)):
-            d[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            g[r["Kernel_Name"].split("(")[0][:60]][r.get("Grid_Size", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d = {}
+        for k, grids in g.items():
+            best = max(grids, key=lambda gs: max(len(v) for v in grids[gs].values()))
+            d[k] = grids[best]
+            if len(grids) > 1:
+                res[k]["grid_size_reported"] = best
         for k, cs in d.items():
             for c, v in cs.items():
                 res[k][c] = sum(v) / len(v)
@@ -57,5 +71,7 @@ GJX_SSM_PERSISTENT=0 python $R/profiles/microbench/ssm_timeline.py 2>/dev/null |
 python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_ssm_persistent_timeline.txt
 SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
 python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
+python $R/profiles/microbench/gather_tiled_timeline.py 2>/dev/null | grep -E " us" > $OUT/${TAG}_resample_gather_tiled_timeline.txt
+bash $R/profiles/gputests.sh $TAG > /dev/null 2>&1; cp $OUT/gputest_summary.txt $OUT/${TAG}_gputest_summary.txt; rm -f $OUT/gputest_test_*.txt $OUT/gputest_summary.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT

@@ -221,6 +221,23 @@ def test_plain_launch_resample_gather_equals_the_three_launch_tiled_resampler(K_
     assert (_np(anc) == np.arange(K)).all() and K_.workspace_status(ws, raise_on_error=False) == 2
 
 
+@pytest.mark.parametrize("K", [777, 100_000, 1 << 20])
+def test_plain_launch_resample_gather_planned_form(K_, K, monkeypatch):
+    """the form for many tiles (prefix and shifts computed once by k_tiled_plan and read from memory; what K > 2^20 runs),
+    forced at small sizes: the same ancestors"""
+    import torch
+    monkeypatch.setenv("GJX_TILED_PLANNED", "1")
+    rs = np.random.default_rng(K + 2)
+    rows = torch.as_tensor(rs.standard_normal((2, K)).astype(np.float32)).cuda()
+    for name, lw in _weight_shapes(K, rs):
+        lwd = torch.as_tensor(lw).cuda()
+        want = K_.resample_indices_tiled(lwd, 0.3718, K)
+        anc = torch.empty(K, dtype=torch.int32, device="cuda")
+        out = K_.resample_gather_tiled(lwd, 0.3718, rows, anc=anc)
+        np.testing.assert_array_equal(_np(anc), _np(want), err_msg=name)
+        assert torch.equal(out, K_.gather_rows(rows, want)), name
+
+
 @pytest.mark.parametrize("K", [1 << 20, 1 << 14, 3 * 1024])
 def test_run_program_leaves_the_tile_totals_for_the_resampler(K_, K):
     """the hand-fused mixture kernel, called without an LSE record, leaves {S_b, e_b} of every 1024-particle tile beside its
@@ -229,9 +246,10 @@ def test_run_program_leaves_the_tile_totals_for_the_resampler(K_, K):
     import torch
     from genjax_amd import workloads
     prog, _ = workloads.gmm_program()
-    out = K_.run_program(prog, (0, 3), K, want_lse=False)
+    out = K_.run_program(prog, (0, 3), K, want_lse=False, want_tiles=True)
     part = out["_partials"]
     assert part.tiles > 0
+    assert K_.run_program(prog, (0, 3), K, want_lse=False)["_partials"].tiles == 0          # only on request
     nt = K // 1024
     S = out["_ws"][part.tiles:part.tiles + 8 * nt].view(torch.int64)
     E = out["_ws"][part.tiles + 8 * nt:part.tiles + 12 * nt].view(torch.int32)
@@ -247,4 +265,4 @@ def test_run_program_leaves_the_tile_totals_for_the_resampler(K_, K):
     assert torch.equal(a1, K_.resample_indices_tiled(out["logw"], 0.25, K))
     full = K_.run_program(prog, (0, 3), K)                    # the same run with its own LSE tail
     np.testing.assert_allclose(_np(lse)[2:], _np(full["lse"])[2:], rtol=1e-6, atol=1e-5)
-    assert K_.run_program(prog, (0, 3), K + 4, want_lse=False)["_partials"].tiles == 0      # K % 1024 != 0: no tiles
+    assert K_.run_program(prog, (0, 3), K + 4, want_lse=False, want_tiles=True)["_partials"].tiles == 0      # K % 1024 != 0: no tiles
