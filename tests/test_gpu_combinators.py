@@ -327,3 +327,38 @@ class TestVmapPlates:
         np.testing.assert_allclose(_np(tr.get_score()), want.numpy(), rtol=1e-4, atol=1e-3)
         sc, _ = model.assess(tr.get_particle(3).get_choices(), (map_over,))
         assert f(sc) == pytest.approx(f(tr.get_score()[3]), rel=1e-5)
+
+
+class TestRepeatAndIterateAgainstTheOracle:
+    """the repeat / iterate (Scan) lowerings checked by the ORACLE run on the very program the API traced, not by the
+    device itself: values of every step, per-particle weight and score"""
+
+    def test_repeat_importance_matches_the_oracle(self):                     # test_repeat_combinator.py:23-30
+        from oracle import cpu
+
+        @genjax.gen
+        def model():
+            return genjax.normal(0.0, 1.0) @ "x"
+
+        K = 2048
+        tr, w = model.repeat(n=10).importance(genjax.key(314), C[1, "x"].set(3.0), (), K=K)
+        o = cpu.run_program(tr.prog, genjax.key(314), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(w), o["weight"], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(_np(tr.get_score()), o["score"], rtol=2e-4, atol=2e-4)
+        assert np.allclose(o["weight"], lp(3.0, 0.0), rtol=1e-6)              # and the oracle agrees with the closed form
+
+    def test_iterate_simulate_and_importance_match_the_oracle(self):         # test_scan_combinator.py:41-61
+        from oracle import cpu
+        K = 2048
+        tr = scanner.simulate(genjax.key(314159), (0.01,), K=K)
+        o = cpu.run_program(tr.prog, genjax.key(314159), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(tr.get_score()), o["score"], rtol=2e-4, atol=3e-4)
+        tr2, w2 = scanner.importance(genjax.key(5), C[3, "z"].set(0.5), (0.01,), K=K)
+        o2 = cpu.run_program(tr2.prog, genjax.key(5), K)
+        np.testing.assert_allclose(_np(tr2.choices), o2["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(w2), o2["weight"], rtol=2e-4, atol=3e-4)
+        # the chained step keys (scan.py:268): step t's draw differs from a run in which the steps shared one key
+        z = _np(tr.choices)
+        assert np.abs(np.diff(z, axis=0)).mean() > 0.5
