@@ -281,17 +281,25 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
     const int kpad = nt * THREADS;               // ancestors live in TILE space: (global tile) * 1024 + index in the tile
     const double step = total > 0 ? (double)total / (double)f.K_total : 0.0;
     const double u_t = uni_f64(sU);
-    bool again = false;
-    if (total == 0) check_ready();               // (a dead step reads nothing foreign, but the ring entries count on every step's check)
-#pragma unroll 1
-    for (int s = 0; s < SPL; ++s) {
-      if (!ton(s)) break;                        // block-uniform: the rank's last block may own fewer tiles
-      const bool a = act(s);
-      const int j = jl(s);
-      int src = f.rank * kpad + (a ? j : 0);     // dead collection: every slot keeps its own particle (flagged)
-      if (total > 0) {
+    // ---- ancestors of ALL the block's tiles together: the SPL slot tiles of a block draw from a common, contiguous range
+    //      of source tiles (thresholds ascend with the slot index, so tile s+1's sources start where tile s's end): that
+    //      range is re-scanned ONCE, kChunk tiles per round — a source tile shared by two slot tiles is quantised once, and
+    //      the barriers of a round are paid per round, not per slot tile ----
+    int nton = 0;                                // tiles this block owns (block-uniform: the rank's last block may own fewer)
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) nton += ton(s) ? 1 : 0;
+    int srcs[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) srcs[s] = f.rank * kpad + (act(s) ? jl(s) : 0);     // dead collection: every slot keeps its own particle (flagged)
+    if (total > 0) {
+      uint64_t Tjs[SPL];
+      int tiles[SPL];
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        tiles[s] = 0; Tjs[s] = 0;
+        if (!ton(s)) continue;
         // slots past the rank's last particle search that particle's threshold (thresholds stay non-decreasing in the tile)
-        uint64_t Tj = comb_threshold(f.offset + (a ? (int64_t)j : K - 1), u_t, step, total);
+        uint64_t Tj = comb_threshold(f.offset + (act(s) ? (int64_t)jl(s) : K - 1), u_t, step, total);
         // a tile's slots draw from tiles near its own index: the nine boundaries around it are read together (one LDS
         // latency, the same addresses in every lane); a threshold outside that window takes the fixed-trip descent
         const int own = gt0 + s;
@@ -310,60 +318,79 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
             if (p <= NT - 1 && P[p] <= Tj) tile = p;
           }
         }
-        Tj = (Tj - P[tile]) << (Emax - Eb[tile]);                     // residual in the source tile's own units (< S_tile)
-        if (tid == 0) s_range[0] = tile;
-        if (tid == THREADS - 1) s_range[1] = tile;
-        if (s == 0) check_ready();                                    // before the barrier in front of the first foreign read
-        __syncthreads();                                              // (also: the previous tile's cumL has been searched)
-        const int tmin = uni_i32(s_range[0]), ntiles = uni_i32(s_range[1]) - tmin + 1;
-        const int kpos = tile - tmin;
-        for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
-          // a round starts at a tile that has weight (block-uniform; the range's last tile always has)
-          while (P[tmin + c0 + 1] == P[tmin + c0]) ++c0;
-          if (again) __syncthreads();                                 // previous round's cumL consumed
-          again = true;
-          const int tl = wid / WPT, part = wid % WPT;                 // this wave: quarter `part` of source tile c0 + tl
-          const bool on = c0 + tl < ntiles;
-          uint64_t qi[4], sacc = 0, inc = 0;
-          if (on) {
-            const int tsrc = tmin + c0 + tl;
-            const int g = tsrc / nt;
-            const int64_t p0 = (int64_t)(tsrc - g * nt) * THREADS + part * 256 + lane * 4;
-            const float* lwp = peer_ptr(lw_prev, sPD[g]);
-            float lw4[4];
+        Tjs[s] = (Tj - P[tile]) << (Emax - Eb[tile]);                 // residual in the source tile's own units (< S_tile)
+        tiles[s] = tile;
+      }
+      if (tid == 0) s_range[0] = tiles[0];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lw4[k] = -INFINITY;
-            if (p0 + 4 <= K) load_scoped_x4(lwp + p0, lw4, sys);      // (p0 is a multiple of 4, the buffer 16-byte aligned)
-            else {
+      for (int s = 0; s < SPL; ++s) if (s == nton - 1 && tid == THREADS - 1) s_range[1] = tiles[s];
+      check_ready();                                                  // before the barrier in front of the first foreign read
+      __syncthreads();                                                // (also: the previous step's cumL has been searched)
+      const int tmin = uni_i32(s_range[0]), ntiles = uni_i32(s_range[1]) - tmin + 1;
+      bool again = false;
+      for (int c0 = 0; c0 < ntiles; c0 += kChunk) {
+        // a round starts at a tile that has weight (block-uniform; the range's last tile always has)
+        while (P[tmin + c0 + 1] == P[tmin + c0]) ++c0;
+        if (again) __syncthreads();                                   // previous round's cumL consumed
+        again = true;
+        const int tl = wid / WPT, part = wid % WPT;                   // this wave: quarter `part` of source tile c0 + tl
+        const bool on = c0 + tl < ntiles;
+        uint64_t qi[4], sacc = 0, inc = 0;
+        if (on) {
+          const int tsrc = tmin + c0 + tl;
+          const int g = tsrc / nt;
+          const int64_t p0 = (int64_t)(tsrc - g * nt) * THREADS + part * 256 + lane * 4;
+          const float* lwp = peer_ptr(lw_prev, sPD[g]);
+          float lw4[4];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) if (p0 + k < K) lw4[k] = load_scoped(lwp + p0 + k, sys);
-            }
-            const int es = Eb[tsrc];
+          for (int k = 0; k < 4; ++k) lw4[k] = -INFINITY;
+          if (p0 + 4 <= K) load_scoped_x4(lwp + p0, lw4, sys);        // (p0 is a multiple of 4, the buffer 16-byte aligned)
+          else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? tile_q(lw4[k], es) : 0; qi[k] = sacc; }
-            inc = wave_scan_u64(sacc);
-            if (lane == 63) wq[wid] = inc;                            // the wave's total: offset of the next quarter
+            for (int k = 0; k < 4; ++k) if (p0 + k < K) lw4[k] = load_scoped(lwp + p0 + k, sys);
           }
-          __syncthreads();
-          if (on) {
-            uint64_t base = inc - sacc;
-            for (int w = 0; w < part; ++w) base += wq[tl * WPT + w];
+          const int es = Eb[tsrc];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cumL[tl * THREADS + part * 256 + lane * 4 + k] = base + qi[k];
-          }
-          __syncthreads();
-          if (kpos >= c0 && kpos < c0 + kChunk) {
+          for (int k = 0; k < 4; ++k) { sacc += p0 + k < K ? tile_q(lw4[k], es) : 0; qi[k] = sacc; }
+          inc = wave_scan_u64(sacc);
+          if (lane == 63) wq[wid] = inc;                              // the wave's total: offset of the next quarter
+        }
+        __syncthreads();
+        if (on) {
+          uint64_t base = inc - sacc;
+          for (int w = 0; w < part; ++w) base += wq[tl * WPT + w];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cumL[tl * THREADS + part * 256 + lane * 4 + k] = base + qi[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          const int kpos = tiles[s] - tmin;
+          if (ton(s) && kpos >= c0 && kpos < c0 + kChunk) {
             const uint64_t* cm = cumL + (kpos - c0) * THREADS;
+            const uint64_t Tj = Tjs[s];
             int l2 = 0;                                               // number of entries <= the residual, 4-ary descent
 #pragma unroll
             for (int q = THREADS >> 2; q >= 1; q >>= 2) {
               const uint64_t pa = cm[l2 + q - 1], pb = cm[l2 + 2 * q - 1], pc = cm[l2 + 3 * q - 1];
               l2 += (pa <= Tj ? q : 0) + (pb <= Tj ? q : 0) + (pc <= Tj ? q : 0);
             }
-            src = tile * THREADS + l2;
+            srcs[s] = tiles[s] * THREADS + l2;
           }
         }
       }
+    } else {
+      check_ready();               // (a dead step reads nothing foreign, but the ring entries count on every step's check)
+    }
+    // ---- per tile of the block, one after the other (a rolled loop: 128 VGPRs hold one slot's propagation) ----
+#pragma unroll 1
+    for (int s = 0; s < SPL; ++s) {
+      if (!ton(s)) break;                        // block-uniform
+      const bool a = act(s);
+      const int j = jl(s);
+      int src = srcs[0];
+#pragma unroll
+      for (int k = 1; k < SPL; ++k) if (k == s) src = srcs[k];
       // ---- propagate + reweight the slot (k_ssm_step's arithmetic and streams) ----
       const int sg = src / kpad, sl = src - sg * kpad;
       if (a && t == T - 1 && f.ancestors) f.ancestors[j] = (int32_t)((int64_t)sg * K + sl);
