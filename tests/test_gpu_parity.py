@@ -1078,13 +1078,19 @@ def _random_program(rs, rng_mode):
 
 
 @pytest.mark.parametrize("rng", RNGS)
-def test_random_programs_against_oracle(K_, oracle, rng):
-    """Differential test of the site interpreter: 40 random programs, simulate, then re-run with a random subset of
-    sites constrained per particle (assess / importance semantics).  Device == oracle up to the stated tolerances."""
+def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
+    """Differential test of the engines: 40 random programs, simulate, then re-run with a random subset of sites
+    constrained per particle (assess / importance semantics).  Device == oracle up to the stated tolerances.  Even trials
+    run on the engine the library picks (a kernel generated for the program, compiled on the spot), odd trials on the site
+    interpreter (which also halves the time the test spends in hipRTC)."""
     import torch
     rs = np.random.default_rng(77 + rng)
     K = 600
     for trial in range(40):
+        if trial & 1:
+            monkeypatch.setenv("GJX_ENGINE", "interp")
+        else:
+            monkeypatch.delenv("GJX_ENGINE", raising=False)
         sl = _random_program(rs, rng)
         prog = PackedProgram(sl, rng_mode=rng)
         key = (int(rs.integers(1 << 30)), int(rs.integers(1 << 30)))
