@@ -163,3 +163,47 @@ def test_bench_launcher_config4_ssm():
                         str(1 << 14), "--ssm-weights", "global_max"], env)
     assert two_g["config"]["exchange"] in (("rccl", "torch") if multi else ("torch",))
     assert abs(two_g["log_ml"] - one_g["log_ml"]) <= 1e-5 * abs(one_g["log_ml"])
+
+
+@pytest.mark.parametrize("move", [None, (1, 0.4)])
+def test_peer_filter_on_real_peers_equals_unsharded(move):
+    """the peer-mapped sharded filter (gjx_ssm_filter_peer[_move], csrc/gjx_peer.hip) with ONE GPU PER RANK — the windows
+    are mapped over xGMI — against the unsharded one-launch filter: particles and weights bit for bit.  Needs >= 2 GPUs
+    (tests/test_gpu_peer.py runs the same ranks on one shared GPU)."""
+    n = _n_gpus()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_peer as TP
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels
+    from genjax_amd.inference.pf import LinearGaussianSSM
+    world, K_total, T, dx = min(n, 4), 1 << 17, 12, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=TP._filter_worker, args=(r, world, port, K_total, T, dx, A.RNG_FLAT, q, move, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s = TP._problem(dx, T)
+    ssm = LinearGaussianSSM(s["A"], s["q"], s["r"])
+    ys = torch.as_tensor(np.asarray(s["y"], np.float32)).cuda()
+    for rep in range(3):
+        if move is None:
+            ref = kernels.ssm_filter(ssm.c_struct("cuda"), (0, 5 + rep), A.RNG_FLAT, ys, K_total, weights=A.WEIGHTS_TILE_SCALED)
+        else:
+            ref = kernels.ssm_filter_move(ssm.c_struct("cuda"), (0, 5 + rep), A.RNG_FLAT, ys, K_total, move[0], move[1])
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(np.concatenate([r[1][rep][0] for r in res], axis=1), ref["x"].cpu().numpy())
+        np.testing.assert_array_equal(np.concatenate([r[1][rep][1] for r in res]), ref["logw"].cpu().numpy())
+    assert all(r[2] == 0 for r in res), [r[2] for r in res]
+    assert all(r[3] == 1 for r in res)                             # every rank had its device to itself

@@ -19,7 +19,7 @@ def _problem(dx, T):
     return workloads.ssm_problem(dx=dx, T=T)
 
 
-def _filter_worker(rank, world, port, K_total, T, dx, rng, q, move=None):
+def _filter_worker(rank, world, port, K_total, T, dx, rng, q, move=None, device_per_rank=False):
     try:
         import sys
         import torch
@@ -31,7 +31,7 @@ def _filter_worker(rank, world, port, K_total, T, dx, rng, q, move=None):
         from genjax_amd import kernels
         from genjax_amd.inference.pf import LinearGaussianSSM
         D.init_from_env("gloo")
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(rank if device_per_rank else 0)       # device_per_rank: one GPU per rank, windows mapped over xGMI
         s = _problem(dx, T)
         ssm = LinearGaussianSSM(s["A"], s["q"], s["r"])
         ys = torch.as_tensor(np.asarray(s["y"], np.float32)).cuda()
