@@ -188,6 +188,22 @@ def run_gmm(args, rank, world, dev):
         peer = kernels.PeerContext(K, out["choices"].shape[0], dev)
         peer_out = [dict(choices=peer.rows[p], score=out["score"], logw=peer.logw[p], _ws=ws) for p in (0, 1)]
         peer_calls = [0]                         # buffer parity: strictly alternating from call to call on every rank
+        # one trial step: the one-launch resampler needs K / 1024 blocks co-resident per rank (ranks that SHARE a device —
+        # a dry run of the multi-rank path on one GPU — split its capacity); if any rank cannot, all take the collective transport
+        from genjax_amd._lib import GjxError
+        try:
+            for _ in range(4):
+                par = peer_calls[0] & 1
+                peer_calls[0] += 1
+                kernels.run_program(prog, (0, 1), K, offset=off, K_total=K_total, ws=ws, out=peer_out[par], want_weight=False, want_lse=False)
+                peer.resample_gather(par, 0.5, partials=(ws, n_part), out=rows, lse_out=lse_rec)
+            torch.cuda.synchronize()
+            ok = not (peer.status() & 1)         # a rendezvous between the ranks timed out: their grids do not run side by side
+        except GjxError:
+            ok = False
+        if not DD.all_agree(ok, dev):
+            peer.close()
+            peer = None
     resampler = DD.ShardedResampler(K, out["choices"].shape[0], K_total, dev) if (sharded and peer is None) else None
 
     def step(i, timed):
@@ -946,7 +962,8 @@ def main():
     rank, world = DD.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank))
+    # one GPU per rank; with fewer visible devices than ranks (a dry run of the multi-rank path on one GPU) the ranks share them
+    local = 0 if os.environ.get("GJX_ALL_ON_DEVICE0") else int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.api:

@@ -35,11 +35,26 @@ def init_from_env(backend: str | None = None) -> tuple[int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = os.environ.get("GJX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # RCCL needs a device per local rank: with fewer visible devices (a dry run of the multi-rank path on one GPU) the
+            # ranks share devices and gloo carries the host-side collectives
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            enough = torch.cuda.is_available() and torch.cuda.device_count() >= local_world and not os.environ.get("GJX_ALL_ON_DEVICE0")
+            backend = os.environ.get("GJX_DIST_BACKEND") or ("nccl" if enough else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+            # (more ranks than visible devices never reaches this branch: RCCL needs one device per rank)
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+def all_agree(ok: bool, device=None, group=None) -> bool:
+    """True when `ok` is True on EVERY rank (one small all-reduce; True at once without a process group)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    staged = dist.get_backend(group) == "gloo"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if staged else (device or torch.device("cuda", torch.cuda.current_device())))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t[0]))
 
 
 def _host_staged(group=None) -> bool:

@@ -269,8 +269,19 @@ class BootstrapFilter:
             # collective transport (global-maximum scheme, one exchange call per step) only if that is not available
             plain = not keep_means and not step_by_step and T >= 2
             if plain and self.K % world == 0 and (self.K // world) % 1024 == 0 and D.peer_available(dev):
-                return self._run_peer(key, ys_d, dev, world, check_status)
-            if not plain or not getattr(self, "_allow_collective_fallback", True):
+                try:
+                    res, ok = self._run_peer(key, ys_d, dev, world, check_status), True
+                except GjxError:
+                    # a rendezvous between the ranks timed out: their grids do not run side by side (ranks sharing one
+                    # device in a dry run, a device held by something else)
+                    res, ok = None, False
+                if D.all_agree(ok, dev):
+                    return res
+                if self.rejuvenate or not getattr(self, "_allow_collective_fallback", True):
+                    raise GjxError("sharded bootstrap filter: the peer-mapped launch timed out and there is no collective form of this run")
+                _note_timeout("sharded bootstrap filter (peer-mapped)")
+                plain = False      # -> the collective transport below
+            if (not plain and (keep_means or step_by_step or T < 2)) or not getattr(self, "_allow_collective_fallback", True):
                 raise NotImplementedError("sharded tile-scaled filter: needs the peer-mapped exchange (K / world a multiple of 1024, "
                                           "no keep_means / step_by_step)")
             import warnings
