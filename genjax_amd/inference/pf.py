@@ -55,8 +55,11 @@ def _unit_from_key(k: Key) -> float:
 
 
 def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None,
-             check: bool = False, collection=None):
+             check: bool = False, collection=None, weights: str = "global_max"):
     """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N]).
+    ``weights="tile_scaled"`` (systematic, N = K): the tile-scaled fixed point of include/gjx.h through
+    gjx_resample_gather_tiled — ONE plain launch at any K (no co-resident grid, nothing to time out), the tile totals
+    taken from the collection's producing run when it left them.
     check=True reads the status word of the co-resident kernel afterwards (one stream synchronisation): raises GjxError
     on a time-out (grid not co-resident: results undefined) or a dead collection (all weights zero).
     ``collection``: the ParticleCollection the weights come from — if its producing run's block partials are still in
@@ -65,6 +68,22 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
     from .. import kernels
     K = logw.numel()
     N = int(n_out or K)
+    if weights not in ("global_max", "tile_scaled"):
+        raise ValueError("weights must be 'global_max' or 'tile_scaled'")
+    if weights == "tile_scaled":
+        if method != "systematic" or N != K or rows.stride(1) != 1:
+            raise ValueError("weights='tile_scaled' resamples N = K particles systematically from contiguous rows")
+        part = collection.lse_partials() if (collection is not None and lse is None) else None
+        ws = kernels.shared_workspace(A.OP_RESAMPLE, K, logw.device)
+        anc = torch.empty(K, dtype=torch.int32, device=logw.device)
+        lse_out = torch.empty(4, dtype=torch.float32, device=logw.device) if (part is not None and collection.K_total == K) else None
+        out = kernels.resample_gather_tiled(logw, _unit_from_key(key), rows, partials=None if lse_out is None else part.as_arg(),
+                                            tiles=0 if lse_out is None else part.tiles, lse_out=lse_out, K_total=K, anc=anc, ws=ws)
+        if check and kernels.workspace_status(ws, raise_on_error=False) & 2:
+            raise GjxError("resample: all weights are zero / -inf / NaN: nothing to resample from")
+        if lse_out is not None:
+            collection._lse = lse_out
+        return out, anc
     part = collection.lse_partials() if (collection is not None and lse is None and method == "systematic") else None
     lse_out = None
     if part is not None and collection.K_total == K:

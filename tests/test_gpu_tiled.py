@@ -266,3 +266,37 @@ def test_run_program_leaves_the_tile_totals_for_the_resampler(K_, K):
     full = K_.run_program(prog, (0, 3), K)                    # the same run with its own LSE tail
     np.testing.assert_allclose(_np(lse)[2:], _np(full["lse"])[2:], rtol=1e-6, atol=1e-5)
     assert K_.run_program(prog, (0, 3), K + 4, want_lse=False, want_tiles=True)["_partials"].tiles == 0      # K % 1024 != 0: no tiles
+
+
+def test_api_resample_with_tile_scaled_weights(K_):
+    """inference.pf.resample(..., weights="tile_scaled"): one plain launch at a size the co-resident resampler cannot take
+    in one launch (K = 2^21); ancestors of gjx_resample_indices_tiled, children gathered, the collection's LSE record
+    finished by the same launch when the weights come from an ImportanceK run"""
+    import torch
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMapBuilder as C
+    from genjax_amd.inference import ImportanceK, Target
+    from genjax_amd.inference import pf
+    K = 1 << 21
+    rs = np.random.default_rng(9)
+    rows = torch.as_tensor(rs.standard_normal((3, K)).astype(np.float32)).cuda()
+    lw = torch.as_tensor((rs.standard_normal(K) * 2.0).astype(np.float32)).cuda()
+    key = core.key(12)
+    out, anc = pf.resample(rows, lw, key, weights="tile_scaled", check=True)
+    want = K_.resample_indices_tiled(lw, pf._unit_from_key(key), K)
+    assert torch.equal(anc, want) and torch.equal(out, K_.gather_rows(rows, want))
+    with pytest.raises(ValueError):
+        pf.resample(rows, lw, key, weights="tile_scaled", n_out=K // 2)
+
+    @genjax.gen
+    def model():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        genjax.normal(x, 0.5) @ "y"
+
+    pc = ImportanceK(Target(model, (), C["y"].set(0.7)), k_particles=1 << 16).run_smc(genjax.key(3))
+    ch = pc.particles.choices
+    new_rows, a2 = pf.resample(ch, pc.log_weights, core.key(4), collection=pc, weights="tile_scaled")
+    assert torch.equal(a2, K_.resample_indices_tiled(pc.log_weights, pf._unit_from_key(core.key(4)), 1 << 16))
+    lml = float(pc.get_log_marginal_likelihood_estimate())                      # finished by the resampling launch (or on demand)
+    want_lml = float(torch.logsumexp(pc.log_weights.double(), 0) - np.log(1 << 16))
+    assert abs(lml - want_lml) < 1e-4
