@@ -180,3 +180,32 @@ def test_sharded_multinomial_equals_single_process(K, world, heavy):
     got = np.concatenate([r[1] for r in res], axis=1)
     np.testing.assert_array_equal(got, want)
     assert sum(r[2] for r in res) == sum(r[3] for r in res) > 0          # children crossed ranks, nothing lost
+
+
+def _agree_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from genjax_amd import distributed as D
+    r, w = D.init_from_env("gloo")
+    res = (D.all_agree(True), D.all_agree(rank != 1), D.all_agree(False))
+    out_q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_all_agree_is_a_logical_and_over_the_ranks():
+    """distributed.all_agree: what bench.py and BootstrapFilter use to leave the peer-mapped transport TOGETHER when one rank's
+    launch cannot be co-resident or timed out (a rank that went on alone would wait for granules nobody publishes)"""
+    from genjax_amd import distributed as D
+    assert D.all_agree(True) and not D.all_agree(False)              # no process group: the local answer
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 100
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert all(v == (True, False, False) for v in res.values()), res
