@@ -300,3 +300,27 @@ def test_api_resample_with_tile_scaled_weights(K_):
     lml = float(pc.get_log_marginal_likelihood_estimate())                      # finished by the resampling launch (or on demand)
     want_lml = float(torch.logsumexp(pc.log_weights.double(), 0) - np.log(1 << 16))
     assert abs(lml - want_lml) < 1e-4
+
+
+def test_plain_launch_resampler_properties_at_full_size(K_):
+    """size-independent properties of systematic resampling at K = 2^22 (the largest single-GPU collection of BASELINE.json's
+    configs): ancestors are sorted, every particle's offspring count is within one of K w_i (float64 weights), uniform
+    weights reproduce the collection (idempotence), and the children are the ancestors' rows"""
+    import torch
+    K = 1 << 22
+    rs = np.random.default_rng(23)
+    lw = (rs.standard_normal(K) * 1.5).astype(np.float32)
+    rows = torch.as_tensor(rs.standard_normal((2, K)).astype(np.float32)).cuda()
+    anc = torch.empty(K, dtype=torch.int32, device="cuda")
+    out = K_.resample_gather_tiled(torch.as_tensor(lw).cuda(), 0.61803, rows, anc=anc)
+    a = _np(anc).astype(np.int64)
+    assert a.min() >= 0 and a.max() < K and (np.diff(a) >= 0).all()
+    w = np.exp(lw.astype(np.float64) - lw.max())
+    expect = K * w / w.sum()
+    counts = np.bincount(a, minlength=K)
+    # the fixed point truncates each weight by < 2^-29 of its tile's largest and each tile by < 2^-28 of the largest weight
+    assert np.abs(counts - expect).max() < 1.0 + 2e-3 * expect.max()
+    assert torch.equal(out, rows[:, anc.long()])
+    flat = torch.zeros(K, device="cuda")
+    K_.resample_gather_tiled(flat, 0.5, rows, anc=anc)
+    assert torch.equal(anc, torch.arange(K, dtype=torch.int32, device="cuda"))
