@@ -119,10 +119,11 @@ ALL = "<all indices>"
 
 
 def norm_addr(addr):
-    """user or internal address -> (name, idx); idx is None, an int, or ALL (slice / Ellipsis)."""
+    """user or internal address -> (name, idx); idx is None, an int, ALL (slice / Ellipsis), or — for a site inside nested
+    combinators (a vmap inside a scan step, a scan inside a vmap instance, ...) — a tuple of ints / ALL, outermost first."""
     if not isinstance(addr, tuple) or addr == ():
         return addr, None
-    names, idx = [], [None]
+    names, idx = [], []
 
     def walk(c):
         if isinstance(c, str):
@@ -131,26 +132,29 @@ def norm_addr(addr):
             for e in c:
                 walk(e)
         elif isinstance(c, slice) or c is Ellipsis:
-            if idx[0] is not None:
-                raise KeyError(f"address {addr!r} has more than one index component")
-            idx[0] = ALL
+            idx.append(ALL)
         elif isinstance(c, (int, np.integer)) and not isinstance(c, bool):
-            if idx[0] is not None:
-                raise KeyError(f"address {addr!r} has more than one index component")
-            idx[0] = int(c)
+            idx.append(int(c))
         else:
             raise KeyError(f"unsupported address component {c!r} in {addr!r}")
 
     walk(addr)
     if not names:
         raise KeyError(f"address {addr!r} has no name component")
-    return (names[0] if len(names) == 1 else tuple(names)), idx[0]
+    if len(idx) > 3:
+        raise KeyError(f"address {addr!r} has more than three index components")
+    return (names[0] if len(names) == 1 else tuple(names)), (None if not idx else (idx[0] if len(idx) == 1 else tuple(idx)))
+
+
+def _has_all(idx) -> bool:
+    return idx is ALL or (isinstance(idx, tuple) and any(c is ALL for c in idx))
 
 
 def key_of(addr):
-    """canonical dictionary key of an address: name, or (name, i) for one step / instance"""
+    """canonical dictionary key of an address: name, or (name, i) for one step / instance ((name, (i, j)) nested); an
+    address with a wildcard component stands for the whole sequence: name"""
     name, idx = norm_addr(addr)
-    return name if idx is None or idx is ALL else (name, idx)
+    return name if idx is None or _has_all(idx) else (name, idx)
 
 
 def _prefixes(name):
@@ -197,7 +201,7 @@ class Selection:
         def join(a):
             name, idx = norm_addr(a)
             full = pre + (name if isinstance(name, tuple) else (name,))
-            return full if idx is None or idx is ALL else (full, idx)
+            return full if idx is None or _has_all(idx) else (full, idx)
         if self.complement and not self.addrs:          # all() under a prefix = the prefix itself
             return Selection((pre[0] if len(pre) == 1 else pre,))
         if self.complement:
@@ -320,14 +324,29 @@ class ChoiceMap:
             name, idx = norm_addr(addr)
         except KeyError:
             return False
-        return key_of(addr) in self._d or (isinstance(idx, int) and name in self._d)
+        return key_of(addr) in self._d or (idx is not None and not _has_all(idx) and name in self._d)
 
     def _n_steps(self, name) -> int:
         return sum(1 for k in self._d if isinstance(k, tuple) and len(k) == 2 and k[0] == name and isinstance(k[1], int))
 
     def __getitem__(self, addr):
-        # chm["x"], chm["sub", "x"], chm[t, "x"] / chm["tracks", t, "pos"] (one step), chm[:, "x"] (stacked)
+        # chm["x"], chm["sub", "x"], chm[t, "x"] / chm["tracks", t, "pos"] (one step), chm[:, "x"] (stacked);
+        # nested combinators: chm[i, t, "x"] (one instance, one step), chm[:, :, "x"] (stacked over both), chm[i, :, "x"]
         name, idx = norm_addr(addr)
+        if isinstance(idx, tuple):
+            if not _has_all(idx):
+                if (name, idx) in self._d:
+                    return self._d[(name, idx)]
+                if name in self._d:                   # a whole-array value set by the user: leading axes = the indices
+                    return self._d[name][idx]
+                raise ChoiceMapNoValueAtAddress(addr)
+            if name not in self._d:
+                raise ChoiceMapNoValueAtAddress(addr)
+            whole = self._d[name]
+            if all(c is ALL for c in idx):
+                return whole
+            lead = getattr(self, "_lead_axes", 0)     # a batched trace's stacked values carry the particle axis in front
+            return whole[(slice(None),) * lead + tuple(slice(None) if c is ALL else c for c in idx)]
         if isinstance(idx, int):
             if idx < 0:
                 n = self._n_steps(name)

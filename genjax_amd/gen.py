@@ -293,7 +293,9 @@ class _Tracer:
 
     def __init__(self):
         self.sites = SiteList()
-        self.step = None   # inside a scan / vmap: the iteration index, appended to every address as (name, step)
+        self.step = None   # inside a scan / vmap: the iteration index, appended to every address as (name, step); nested
+                           # combinators: the tuple of indices, outermost first
+        self.in_scan = False
         self.scan = 0      # inside a scan: gjx_site.scan tag of the current step (chained step keys, gjx.h)
         self.n_scans = 0
         self.prefix = ()   # inside `callee(...) @ "addr"`: the path of enclosing call addresses
@@ -415,12 +417,24 @@ class Trace:
         d = {s.addr: self._site_value(s.addr) for s in self.prog.site_list.sites}
         # scan sites ("x", t): also expose the stacked sequence under "x" (leading axes: particles, then steps)
         seqs: dict = {}
+        nested: dict = {}
         for s in self.prog.site_list.sites:
             if isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], int):
                 seqs.setdefault(s.addr[0], []).append(d[s.addr])
+            elif isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], tuple):
+                nested.setdefault(s.addr[0], {})[s.addr[1]] = d[s.addr]
+        lead = 1 if self.batched else 0
         for name, vals in seqs.items():
-            d[name] = torch.stack(vals, dim=1 if self.batched else 0)
-        return ChoiceMap(d)
+            d[name] = torch.stack(vals, dim=lead)
+        for name, by_idx in nested.items():
+            # nested combinators: the full grid of indices (a rectangular nest) stacks to [particles?][n0][n1](...)
+            shape = tuple(max(ix[k] for ix in by_idx) + 1 for k in range(len(next(iter(by_idx)))))
+            if len(by_idx) == int(np.prod(shape)):
+                flat = torch.stack([by_idx[ix] for ix in sorted(by_idx)], dim=lead)
+                d[name] = flat.reshape(flat.shape[:lead] + shape + flat.shape[lead + 1:])
+        chm = ChoiceMap(d)
+        chm._lead_axes = lead
+        return chm
 
     def get_retval(self):
         r = self.retval_sym
@@ -723,6 +737,13 @@ class StaticGenerativeFunction(GenerativeFunction):
         return f"<gen {self.__name__}>"
 
 
+def _nest(outer, i: int):
+    """index of iteration i under the enclosing combinators' index `outer` (None, an int, or a tuple)"""
+    if outer is None:
+        return i
+    return (outer if isinstance(outer, tuple) else (outer,)) + (i,)
+
+
 class ScanCombinator(GenerativeFunction):
     """Time recursion of a kernel generative function (combinators/scan.py:200-294), lowered by unrolling:
     step t's sites get the addresses ``(addr, t)``, its parameters read step t-1's choices through the carry.
@@ -734,22 +755,27 @@ class ScanCombinator(GenerativeFunction):
         self._cache: dict = {}
 
     def _unroll(self, t: _Tracer, carry, xs):
-        if t.step is not None:
-            raise NotSupportedInModelBody("a scan / vmap nested inside another scan / vmap is not supported")
+        # a scan inside a vmap instance is a scan of its own (its own id, its own chained keys); a scan inside a scan step
+        # would interleave two key chains within one step's site numbering: not supported
+        if t.in_scan:
+            raise NotSupportedInModelBody("a scan nested inside another scan's step is not supported")
+        outer = t.step
         outs = []
         sid = t.n_scans
         t.n_scans += 1
         if self.n >= (1 << 20) - 1 or sid >= 2048:
             raise NotSupportedInModelBody("scan: at most 2^20 - 2 steps and 2048 scans per model")
         try:
+            t.in_scan = True
             for i in range(self.n):
-                t.step = i
+                t.step = _nest(outer, i)
                 t.scan = (sid << 20) | (i + 1)      # step keys chain on the device: key_t = fold_in(key_{t-1}, t) (scan.py:268)
                 carry, out = self.kernel.source(carry, None if xs is None else xs[i])
                 outs.append(out)
         finally:
-            t.step = None
+            t.step = outer
             t.scan = 0
+            t.in_scan = False
         return carry, outs
 
     def __call__(self, carry, xs=None):
@@ -789,8 +815,9 @@ class VmapCombinator(GenerativeFunction):
         return ax
 
     def _unroll(self, t: _Tracer, args):
-        if t.step is not None:
-            raise NotSupportedInModelBody("a scan / vmap nested inside another scan / vmap is not supported")
+        outer = t.step                      # nested in a scan step or another vmap: the indices stack, outermost first
+        if isinstance(outer, tuple) and len(outer) >= 3:
+            raise NotSupportedInModelBody("combinators nest at most three deep")
         axes = self._axes(args)
         moved = [a if ax is None else np.moveaxis(_np_arg(a), ax, 0) for a, ax in zip(args, axes)]
         lens = {m.shape[0] for m, ax in zip(moved, axes) if ax is not None}
@@ -800,10 +827,10 @@ class VmapCombinator(GenerativeFunction):
         outs = []
         try:
             for i in range(n):
-                t.step = i
+                t.step = _nest(outer, i)
                 outs.append(self.kernel.source(*[m if ax is None else m[i] for m, ax in zip(moved, axes)]))
         finally:
-            t.step = None
+            t.step = outer
         return outs
 
     def __call__(self, *args):

@@ -1,6 +1,6 @@
 """The reference's combinator tests (tests/generative_functions/test_vmap_combinator.py, test_repeat_combinator.py,
-test_scan_combinator.py) restated against genjax_amd, for the forms the site-program lowering supports (one index
-level; mapped arguments are host data).  Line numbers of the originals are cited."""
+test_scan_combinator.py) restated against genjax_amd, for the forms the site-program lowering supports (mapped
+arguments are host data; nesting up to three index levels, TestNestedCombinators).  Line numbers of the originals are cited."""
 import numpy as np
 import pytest
 
@@ -362,3 +362,117 @@ class TestRepeatAndIterateAgainstTheOracle:
         # the chained step keys (scan.py:268): step t's draw differs from a run in which the steps shared one key
         z = _np(tr.choices)
         assert np.abs(np.diff(z, axis=0)).mean() > 0.5
+
+
+class TestNestedCombinators:
+    """combinators nested in each other (combinators/vmap.py:193-218 and scan.py:237-294 compose freely in the reference):
+    a vmap inside a vmap, a scan inside every vmap instance, a vmap inside every scan step.  Addresses carry the indices
+    outermost first (``chm[i, j, "x"]``); values, weights and scores are checked by the ORACLE on the traced program."""
+
+    def test_vmap_in_vmap(self):
+        from oracle import cpu
+
+        @genjax.gen
+        def cell(mu):
+            return genjax.normal(mu, 0.5) @ "x"
+
+        @genjax.gen
+        def row(mus):
+            return cell.vmap(in_axes=0)(mus) @ "cells"
+
+        mus = np.arange(12, dtype=np.float32).reshape(3, 4)
+        grid = row.vmap(in_axes=0)
+        K = 1024
+        tr = grid.simulate(genjax.key(5), (mus,), K=K)
+        o = cpu.run_program(tr.prog, genjax.key(5), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(tr.get_score()), o["score"], rtol=2e-4, atol=3e-4)
+        ch = tr.get_choices()
+        whole = ch[:, :, "cells", "x"]
+        assert whole.shape == (K, 3, 4)
+        assert np.array_equal(_np(ch[2, 1, "cells", "x"]), _np(whole[:, 2, 1]))
+        assert np.array_equal(_np(ch[1, :, "cells", "x"]), _np(whole[:, 1, :]))
+        assert abs(float(whole[:, 2, 3].mean()) - 11.0) < 0.1                         # instance (2, 3) has mean mus[2, 3]
+        # one instance constrained: the weight is its log-density, every other instance is sampled
+        tr2, w = grid.importance(genjax.key(6), C[1, 2, "cells", "x"].set(6.5), (mus,), K=K)
+        o2 = cpu.run_program(tr2.prog, genjax.key(6), K)
+        np.testing.assert_allclose(_np(w), o2["weight"], rtol=2e-4, atol=1e-5)
+        want = -0.5 * ((6.5 - 6.0) / 0.5) ** 2 - np.log(0.5) - 0.5 * np.log(2 * np.pi)
+        assert np.allclose(_np(w), want, rtol=1e-5)
+        assert float(tr2.get_choices()[1, 2, "cells", "x"][0]) == 6.5
+        # the whole grid constrained at once: assess == the sum of the 12 log-densities
+        vals = (mus + 0.25).astype(np.float32)
+        sc, _ = grid.assess(C["cells", "x"].set(vals), (mus,))
+        assert f(sc) == pytest.approx(12 * (-0.5 * 0.25 - np.log(0.5) - 0.5 * np.log(2 * np.pi)), rel=1e-5)
+
+    def test_scan_in_vmap(self):
+        from oracle import cpu
+
+        @genjax.gen
+        def step(x, _):
+            z = genjax.normal(x, 0.3) @ "z"
+            return z, z
+
+        @genjax.gen
+        def chain(x0):
+            return step.scan(n=6)(x0, None) @ "walk"
+
+        x0s = np.array([0.0, 10.0, -5.0], np.float32)
+        K = 2048
+        tr = chain.vmap(in_axes=0).simulate(genjax.key(8), (x0s,), K=K)
+        o = cpu.run_program(tr.prog, genjax.key(8), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        z = tr.get_choices()[:, :, "walk", "z"]                                       # [K][instance][step]
+        assert z.shape == (K, 3, 6)
+        zz = _np(z)
+        assert np.allclose(zz[:, :, 0].mean(axis=0), x0s, atol=0.05)                  # every chain starts at its own x0
+        inc = np.diff(zz, axis=2)
+        assert 0.27 < inc.std() < 0.33
+        # the instances are separate scans with their own chained keys: their increments are uncorrelated
+        c = np.corrcoef(inc[:, 0, :].ravel(), inc[:, 1, :].ravel())[0, 1]
+        assert abs(c) < 0.05
+        # a constraint on one step of one instance
+        tr2, w = chain.vmap(in_axes=0).importance(genjax.key(9), C[2, 3, "walk", "z"].set(-4.0), (x0s,), K=K)
+        o2 = cpu.run_program(tr2.prog, genjax.key(9), K)
+        np.testing.assert_allclose(_np(w), o2["weight"], rtol=3e-4, atol=3e-4)
+
+    def test_vmap_in_scan(self):
+        from oracle import cpu
+
+        @genjax.gen
+        def obs(x, off):
+            return genjax.normal(x + off, 1.0) @ "y"
+
+        @genjax.gen
+        def step(x, _):
+            z = genjax.normal(x, 0.5) @ "z"
+            ys = obs.vmap(in_axes=(None, 0))(z, np.array([0.0, 1.0, 2.0], np.float32)) @ "sensors"
+            return z, z
+
+        T, K = 8, 2048
+        model = step.scan(n=T)
+        yobs = np.linspace(-1.0, 1.0, T * 3).astype(np.float32).reshape(T, 3)
+        tr, w = model.importance(genjax.key(4), C["sensors", "y"].set(yobs), (0.0, None), K=K)
+        o = cpu.run_program(tr.prog, genjax.key(4), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(w), o["weight"], rtol=3e-4, atol=2e-3)
+        z = _np(tr.get_choices()[:, "z"])                                             # [K][T]
+        want = sum((-0.5 * (yobs[t, i] - (z[:, t] + i)) ** 2 - 0.5 * np.log(2 * np.pi)) for t in range(T) for i in range(3))
+        np.testing.assert_allclose(_np(w), want, rtol=3e-4, atol=2e-3)
+        assert float(tr.get_choices()[5, 1, "sensors", "y"][0]) == pytest.approx(float(yobs[5, 1]))
+
+    def test_scan_in_scan_is_refused(self):
+        from genjax_amd.gen import NotSupportedInModelBody
+
+        @genjax.gen
+        def inner(x, _):
+            z = genjax.normal(x, 1.0) @ "z"
+            return z, z
+
+        @genjax.gen
+        def outer(x, _):
+            c, _zs = inner.scan(n=3)(x, None) @ "in"
+            return c, c
+
+        with pytest.raises(NotSupportedInModelBody):
+            outer.scan(n=2).simulate(genjax.key(1), (0.0, None))

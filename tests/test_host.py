@@ -229,8 +229,16 @@ def test_hierarchical_addresses_and_nested_calls():
     assert norm_addr(("tracks", 3, "pos")) == (("tracks", "pos"), 3)
     assert norm_addr(("tracks", slice(None), "pos")) == (("tracks", "pos"), ALL)
     assert norm_addr((2, "x")) == ("x", 2) and key_of(("x", "x")) == ("x", "x") and key_of("x") == "x"
+    # nested combinators: the indices stack, outermost first (a vmap inside a scan step, a scan inside a vmap instance)
+    assert norm_addr(("a", 1, 2, "b")) == (("a", "b"), (1, 2)) and key_of((1, 2, "x")) == ("x", (1, 2))
+    assert key_of((slice(None), 2, "x")) == "x"                       # a wildcard component: the whole array
     with pytest.raises(KeyError):
-        norm_addr(("a", 1, 2, "b"))
+        norm_addr(("a", 1, 2, 3, 4, "b"))
+    nested = C[1, 2, "x"].set(5.0)
+    assert (1, 2, "x") in nested and nested[1, 2, "x"] == 5.0 and (1, 3, "x") not in nested
+    grid = C["x"].set(np.arange(6.0).reshape(2, 3))
+    assert (1, 2, "x") in grid and grid[1, 2, "x"] == 5.0 and np.array_equal(grid[:, :, "x"], np.arange(6.0).reshape(2, 3))
+    assert np.array_equal(grid[1, :, "x"], np.array([3.0, 4.0, 5.0]))
 
     @genjax.gen
     def submodel():
