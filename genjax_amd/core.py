@@ -263,8 +263,9 @@ _VALUE = ()  # address of a bare value (C.v(x)), as in the reference's `()` addr
 class ChoiceMap:
     """Static-address choice map: ``{addr: value}`` (choice_map.py:847-1395, Static 1535)."""
 
-    def __init__(self, entries: dict | None = None):
+    def __init__(self, entries: dict | None = None, lead_axes: int = 0):
         self._d: dict = dict(entries or {})
+        self._lead_axes = int(lead_axes)   # stacked values of a batched trace carry the particle axis in front of the indices
 
     # -- builders (ChoiceMapBuilder C) ------------------------------------------------------
     @staticmethod
@@ -345,7 +346,7 @@ class ChoiceMap:
             whole = self._d[name]
             if all(c is ALL for c in idx):
                 return whole
-            lead = getattr(self, "_lead_axes", 0)     # a batched trace's stacked values carry the particle axis in front
+            lead = self._lead_axes                    # a batched trace's stacked values carry the particle axis in front
             return whole[(slice(None),) * lead + tuple(slice(None) if c is ALL else c for c in idx)]
         if isinstance(idx, int):
             if idx < 0:
@@ -399,7 +400,7 @@ class ChoiceMap:
         """``self | other`` — left-biased union (choice_map.py:1227-1251)."""
         d = dict(other._d)
         d.update(self._d)
-        return ChoiceMap(d)
+        return ChoiceMap(d, max(self._lead_axes, getattr(other, "_lead_axes", 0)))
 
     __or__ = merge
 
@@ -415,7 +416,7 @@ class ChoiceMap:
         return ChoiceMap({a: Masked(v, f.astype(bool)) for a, v in self._d.items()})
 
     def filter(self, selection: Selection) -> "ChoiceMap":
-        return ChoiceMap({a: v for a, v in self._d.items() if selection.check(a)})
+        return ChoiceMap({a: v for a, v in self._d.items() if selection.check(a)}, self._lead_axes)
 
     def get_selection(self) -> Selection:
         return Selection(self._d.keys())

@@ -432,9 +432,7 @@ class Trace:
             if len(by_idx) == int(np.prod(shape)):
                 flat = torch.stack([by_idx[ix] for ix in sorted(by_idx)], dim=lead)
                 d[name] = flat.reshape(flat.shape[:lead] + shape + flat.shape[lead + 1:])
-        chm = ChoiceMap(d)
-        chm._lead_axes = lead
-        return chm
+        return ChoiceMap(d, lead)
 
     def get_retval(self):
         r = self.retval_sym
