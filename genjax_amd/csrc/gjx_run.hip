@@ -1220,6 +1220,8 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr);
   g_last_run_grid = ep.grid;
   g_last_run_tiles = 0;
+  const bool tiles_requested = g_want_tiles != 0;      // one-shot, whatever engine runs
+  g_want_tiles = 0;
   const GmmShape& g = ep.g;
   const int ppt = ep.ppt, nblocks = ep.grid;
   if (ep.engine == ENGINE_GEN) {
@@ -1241,8 +1243,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.tile_S = nullptr; a.tile_E = nullptr;
     // consumer-finishes mode (lse == NULL) on the 1024-particles-per-block kernel: leave the tile totals of the tile-scaled
     // resampler behind the block partials (which take at most 8 bytes per 256 particles)
-    const bool want_tiles = g_want_tiles || env_int("GJX_RUN_TILES", 0);
-    g_want_tiles = 0;
+    const bool want_tiles = tiles_requested || env_int("GJX_RUN_TILES", 0);
     if (want_tiles && flat && ppt == 4 && !lse && partials && K % 1024 == 0) {
       const size_t off = (kWsHeaderBytes + 8 * (size_t)((K + 255) / 256) + 15) & ~(size_t)15;
       const size_t nt = (size_t)(K / 1024);
