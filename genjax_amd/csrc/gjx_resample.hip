@@ -1070,7 +1070,7 @@ extern "C" int gjx_resample_gather_tiled(const float* logw, int64_t K, const uin
   }
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));
   unsigned long long* timeline = gjx::debug_timeline(64 * (size_t)nt);
-  if (nt > 1024 || getenv("GJX_TILED_PLANNED")) {
+  if (nt > 1024 || getenv("GJX_TILED_PLANNED")) {       // (the variable: tests run the planned form at small sizes)
     // many tiles: maximum exponent, shifts and prefix once (k_tiled_plan), behind the tile totals in the workspace
     uint64_t* Pg = (uint64_t*)((char*)workspace + kWsHeaderBytes + 12 * (size_t)nt + 16);
     Pg = (uint64_t*)(((uintptr_t)Pg + 15) & ~(uintptr_t)15);

@@ -1243,7 +1243,8 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.tile_S = nullptr; a.tile_E = nullptr;
     // consumer-finishes mode (lse == NULL) on the 1024-particles-per-block kernel: leave the tile totals of the tile-scaled
     // resampler behind the block partials (which take at most 8 bytes per 256 particles)
-    const bool want_tiles = tiles_requested || env_int("GJX_RUN_TILES", 0);
+    static const bool tiles_env = env_int("GJX_RUN_TILES", 0) != 0;
+    const bool want_tiles = tiles_requested || tiles_env;
     if (want_tiles && flat && ppt == 4 && !lse && partials && K % 1024 == 0) {
       const size_t off = (kWsHeaderBytes + 8 * (size_t)((K + 255) / 256) + 15) & ~(size_t)15;
       const size_t nt = (size_t)(K / 1024);
