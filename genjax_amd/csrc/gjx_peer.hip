@@ -97,8 +97,8 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   // the words of the one-launch resampling step (twice, for alternating calls: 4 x [MAX_RANKS] u64 + this rank's tile granules [nt])
   const size_t NT = (size_t)c->NT;
   size_t r = 0;
-  c->r_aggA = r; r = align_up(r + 8 * NT);
-  c->r_aggB = r; r = align_up(r + 8 * NT);
+  c->r_aggA = r; r = align_up(r + 8 * NT * kPfGranulePad);   // (one granule per 64-byte line)
+  c->r_aggB = r; r = align_up(r + 8 * NT * kPfGranulePad);
   c->r_bsum = r; r = align_up(r + 12 * NT);
   c->r_bmax = r; r = align_up(r + 12 * NT);
   c->r_ready = r; r = align_up(r + 4 * (size_t)kPfHostMaxTiles);

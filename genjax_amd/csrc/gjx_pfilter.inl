@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
         const float bs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_sum_to_lane15(lane < NW ? fsum[s][lane] : 0.0f)), 15));
         if (ton(s) && lane < G) {
           const long long d = sPF[lane];
-          store_scoped_u64(peer_ptr(agg + gt0 + s, d), tile_granule(tag, eb[s], tt), sys);
+          store_scoped_u64(peer_ptr(agg + (size_t)(gt0 + s) * kPfGranulePad, d), tile_granule(tag, eb[s], tt), sys);
           const size_t slot = (size_t)((t - 1) % 3) * NT + gt0 + s;
           store_scoped(peer_ptr(f.bsum + slot, d), bs, sys);
           store_scoped(peer_ptr(f.bmax + slot, d), bm[s], sys);
@@ -206,17 +206,17 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
     if (tid < G) store_scoped_u32(peer_ptr(f.ready + f.rank * nb + (int)blockIdx.x, sPF[tid]), rtag, sys);
     stage_step_constants(t);
     // a first look at the granules goes out before the draws (for the last block to publish they are all there already)
-    const unsigned long long gv0 = tid < NT ? load_scoped_u64(&agg[tid], sys) : 0ull;
+    const unsigned long long gv0 = tid < NT ? load_scoped_u64(&agg[(size_t)tid * kPfGranulePad], sys) : 0ull;
     if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)(f.offset + jl(0)), nbits);
     if (fin) lse_ring_reduce(t - 2, rpm, rps);
     {
       float em = (float)kTileDead;
       for (int b = tid; b < NT; b += THREADS) {
-        unsigned long long v = b == tid ? gv0 : load_scoped_u64(&agg[b], sys);
+        unsigned long long v = b == tid ? gv0 : load_scoped_u64(&agg[(size_t)b * kPfGranulePad], sys);
         while ((v >> 60) != tag && step_budget) {
           --step_budget;
           __builtin_amdgcn_s_sleep(1);
-          v = load_scoped_u64(&agg[b], sys);
+          v = load_scoped_u64(&agg[(size_t)b * kPfGranulePad], sys);
         }
         if ((v >> 60) != tag) { timed_out(); v = 0; }
         const uint64_t S = v & ((1ull << 40) - 1);

@@ -11,6 +11,7 @@
 namespace gjx {
 
 constexpr int kPfThreads = 1024;
+constexpr int kPfGranulePad = 8;                         // granules one per 64-byte line (as k_ssm_persistent: gjx_ssm.hip kGranulePad)
 constexpr int kPfMaxTiles = 4096;                        // quantisation tiles over all ranks (K_total <= 2^22)
 constexpr int kPfPer = kPfMaxTiles / kPfThreads;         // granules / ring entries / ready words a thread looks at
 
@@ -26,7 +27,7 @@ struct PfArgs {
   int NT;                                                // G * nt
   float* x_a; float* x_b;                                // [DX][K] ping-pong: step t writes x_b when t is odd
   float* lw_even; float* lw_odd;                         // log-weights of step t in lw_odd when (T - 1 - t) is odd
-  unsigned long long* aggA; unsigned long long* aggB;    // [NT] this rank's copy of the granules (alternating steps)
+  unsigned long long* aggA; unsigned long long* aggB;    // [NT * kPfGranulePad] this rank's copy of the granules (alternating steps), one per 64-byte line
   float* bsum; float* bmax;                              // [3][NT] LSE ring: per tile {max, sum exp(lw - max)}
   unsigned* ready;                                       // [G * gridDim.x]
   const long long* peer_data;                            // [G] byte distance from this rank's data window to rank g's mapping (NULL: one rank)

@@ -453,6 +453,9 @@ struct SsmPersistArgs {
   unsigned long long* timeline;    // debug (gjx_debug_timeline): 16 realtime stamps per block for step T / 2
 };
 
+// granules of the tile-scaled rendezvous sit one per 64-byte line: 256 blocks storing into 32 shared lines serialise in the
+// L2 (11.6 -> 11.0 us per filter step; 128-byte spacing and padding the `ready` words as well measured the same)
+constexpr int kGranulePad = 8;
 template <int RNG, int DX, int THREADS, bool TILED>
 __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   // THREADS = 1024 (one block per CU, 256 blocks at K = 2^18) quarters the granules of each all-gather: a rendezvous
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           uint64_t tt = row_scan_u64(lane < NW ? wsum[lane] : 0);       // lane 15 = sum of lanes 0..15
           float bs = row_sum_to_lane15(lane < NW ? fred[NW + lane] : 0.0f);
           if (lane == 15) {
-            __hip_atomic_store(&agg[blockIdx.x], tile_granule(tag, eb, tt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&agg[(size_t)blockIdx.x * kGranulePad], tile_granule(tag, eb, tt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const size_t slot = (size_t)((t - 1) % 3) * nb + blockIdx.x;
             store_agent(&f.bsum[slot], bs);
             store_agent(&f.bmax[slot], bm);
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {         // (fixed trip count: the loads stay in flight, in registers)
         const int b = threadIdx.x + k * THREADS;
-        gv[k] = b < nb ? __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        gv[k] = b < nb ? __hip_atomic_load(&agg[(size_t)b * kGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       }
       // while the granules travel: the draws of step t.  (Looking at the missing granules again between the hashes was
       // measured and dropped: the polling waves then stall inside the draws, 13.5 -> 14.1 us per step.)
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
           while ((v >> 60) != tag && budget) {
             --budget;
             __builtin_amdgcn_s_sleep(1);
-            v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(&agg[(size_t)b * kGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if ((v >> 60) != tag) { __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
           const uint64_t S = v & ((1ull << 40) - 1);
@@ -1148,7 +1151,7 @@ static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   const int64_t nblk = (K + 255) / 256;
   PfPlan pf;
   if (pf_plan(rng_mode, m->dx, m->dy, K, 1, 1, &pf, mv != nullptr) != GJX_OK ||
-      256 + 40 * (size_t)pf.nt + 8 * (size_t)pf.grid + 16 * (size_t)T + 64 > need)
+      256 + (16 * (size_t)kPfGranulePad + 24) * (size_t)pf.nt + 8 * (size_t)pf.grid + 16 * (size_t)T + 64 > need)
     return GJX_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
@@ -1156,15 +1159,15 @@ static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   static thread_local std::vector<double> h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);
   const size_t NT = (size_t)pf.nt;
-  // ws2: [256 B control][aggA 8 NT][aggB 8 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
+  // ws2: [256 B control][aggA 64 NT][aggB 64 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
   unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
-  unsigned long long* aggB = aggA + NT;
-  float* bsum = (float*)(aggB + NT);
+  unsigned long long* aggB = aggA + NT * kPfGranulePad;
+  float* bsum = (float*)(aggB + NT * kPfGranulePad);
   float* bmax = bsum + 3 * NT;
   unsigned* ready = (unsigned*)(bmax + 3 * NT);
   double* us_dev = (double*)(ready + 2 * (((size_t)pf.grid + 1) / 2));
   uint32_t* keys_dev = (uint32_t*)(us_dev + T);
-  hipError_t e = hipMemsetAsync(aggA, 0, 40 * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
+  hipError_t e = hipMemsetAsync(aggA, 0, (16 * kPfGranulePad + 24) * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
   if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
   if (e == hipSuccess && mv && mv->acc_total) e = hipMemsetAsync(mv->acc_total, 0, sizeof(unsigned long long), st);
@@ -1276,7 +1279,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     }
 #undef GJX_PERS
     pblk = (K + pthreads - 1) / pthreads;
-    if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + 48 * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+    if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + (16 * (size_t)(tiled ? kGranulePad : 1) + 32) * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
   }
   // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
   if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
@@ -1305,17 +1308,18 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       h_us[t] = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
       if (t == 0) { kp0[0] = kp[0]; kp0[1] = kp[1]; }
     }
-    // ws2: [256 B control][aggA 8 nb][aggB 8 nb][bsum ring 12 nb][bmax ring 12 nb][ready 4 nb + 4 nb pad][us 8 T][keys 8 T]
+    // ws2: [256 B control][aggA 8 gp nb][aggB 8 gp nb][bsum ring 12 nb][bmax ring 12 nb][ready 4 nb + 4 nb pad][us 8 T][keys 8 T]
+    const size_t gp = tiled ? (size_t)kGranulePad : 1;        // tile-scaled scheme: one 64-byte line per granule
     unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
-    unsigned long long* aggB = aggA + pblk;
-    float* bsum = (float*)(aggB + pblk);
+    unsigned long long* aggB = aggA + gp * pblk;
+    float* bsum = (float*)(aggB + gp * pblk);
     float* bmax = bsum + 3 * pblk;
     unsigned* ready = (unsigned*)(bmax + 3 * pblk);
-    double* us_dev = (double*)(aggB + 5 * pblk);
+    double* us_dev = (double*)(ready + 2 * pblk);
     uint32_t* keys_dev = (uint32_t*)(us_dev + T);
     // the two schemes (and k_ssm_fused_step) tag their granules differently: no stale granule of another kernel may pass for
     // one of this launch
-    hipError_t e = hipMemsetAsync(aggA, 0, 48 * (size_t)pblk, st);
+    hipError_t e = hipMemsetAsync(aggA, 0, (16 * gp + 32) * (size_t)pblk, st);
     if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
