@@ -112,14 +112,17 @@ GJX_DEV unsigned long long grid_tag(const unsigned* ctrl, unsigned* epoch_out) {
   return (unsigned long long)(epoch % 16383u) + 1ull;
 }
 
+// PAD: one granule every PAD words (PAD = 8: one per 64-byte line).  Blocks that store into a shared line serialise in the
+// L2, readers pay PAD times the lines: worth it for the 256-block grids of the one-launch filters, not for 1024 blocks.
+template <int PAD = 1>
 GJX_DEV void grid_publish(unsigned long long* agg, unsigned long long tag, unsigned long long value) {
-  __hip_atomic_store(&agg[blockIdx.x], (tag << 50) | (value & kAggMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&agg[(size_t)blockIdx.x * PAD], (tag << 50) | (value & kAggMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Called by every thread of the block; thread t polls the granules of blocks t, t + 256, ... one after the other (a
 // variant with all of a lane's loads in flight together measured 2 us SLOWER per all-gather: the blocks arrive over
 // several microseconds and the re-issued batches crowd the L2) and `visit(b, value)` runs on thread (b mod 256).
-template <class Visit>
+template <int PAD = 1, class Visit>
 GJX_DEV void grid_gather(const unsigned long long* agg, unsigned long long tag, unsigned* ctrl, Visit&& visit) {
   unsigned budget = kPollBudget;   // polls this lane may spend in total (~0.1 s): a grid that is not co-resident must not hang
   // (sticky: blocks that start after the flag went up — the grid never was co-resident — do not wait at all)
@@ -127,7 +130,7 @@ GJX_DEV void grid_gather(const unsigned long long* agg, unsigned long long tag, 
   for (int b = threadIdx.x; b < (int)gridDim.x; b += (int)blockDim.x) {
     unsigned long long v = 0;
     while (budget) {
-      v = __hip_atomic_load(&agg[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load(&agg[(size_t)b * PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((v >> 50) == tag) break;
       --budget;
       __builtin_amdgcn_s_sleep(1);

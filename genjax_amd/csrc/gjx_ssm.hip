@@ -453,7 +453,7 @@ struct SsmPersistArgs {
   unsigned long long* timeline;    // debug (gjx_debug_timeline): 16 realtime stamps per block for step T / 2
 };
 
-// granules of the tile-scaled rendezvous sit one per 64-byte line: 256 blocks storing into 32 shared lines serialise in the
+// granules of the persistent filter's rendezvous (both weight schemes) sit one per 64-byte line: 256 blocks storing into 32 shared lines serialise in the
 // L2 (11.6 -> 11.0 us per filter step; 128-byte spacing and padding the `ready` words as well measured the same)
 constexpr int kGranulePad = 8;
 template <int RNG, int DX, int THREADS, bool TILED>
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
     if constexpr (!TILED) {
       // ---- rendezvous A: exact global maximum (nothing else rides on it: published as early as possible) ----
       const unsigned long long tagA = (unsigned long long)((epoch + 2u * (unsigned)(t - 1)) % 16383u) + 1ull;
-      if (threadIdx.x == 0) grid_publish(f.aggA, tagA, (unsigned long long)__float_as_uint(bm));
+      if (threadIdx.x == 0) grid_publish<kGranulePad>(f.aggA, tagA, (unsigned long long)__float_as_uint(bm));
       GJX_PSTAMP(1);
       // while the granules travel: this block's sum of exp(log w - block max), for the LSE record (read after
       // rendezvous B; ring of 2: a block rewrites its entry only after the finisher published its next granule A),
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       if (fin) lse_ring_issue(t - 2, rpm, rps);
       if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
       if (fin) lse_ring_reduce(rpm, rps);
-      grid_gather(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) { mx = fmaxf(mx, __uint_as_float((uint32_t)v)); });
+      grid_gather<kGranulePad>(f.aggA, tagA, f.ctrl, [&](int, unsigned long long v) { mx = fmaxf(mx, __uint_as_float((uint32_t)v)); });
       mx = wave_max_dpp(mx);     // (no acquire fence: everything read from other blocks goes through agent-scope loads)
       __syncthreads();
       if (lane == 0) fred[wid] = mx;
@@ -641,11 +641,11 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
         if (wid == 0) {
           static_assert(NW <= 16, "the wave partials fit one DPP row");
           const uint64_t tt = row_scan_u64(lane < NW ? wsum[lane] : 0);   // lane 15 = sum of lanes 0..15
-          if (lane == 15) __hip_atomic_store(&f.aggB[blockIdx.x], (tagB << 50) | (tt & kAggMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 15) __hip_atomic_store(&f.aggB[(size_t)blockIdx.x * kGranulePad], (tagB << 50) | (tt & kAggMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       GJX_PSTAMP(3);
-      grid_gather(f.aggB, tagB, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
+      grid_gather<kGranulePad>(f.aggB, tagB, f.ctrl, [&](int b, unsigned long long val) { P[b + 1] = val; });
     } else {
       // ---- the ONE rendezvous: {e_b, S_b}.  The granule depends on registers only and goes out at once; that the block's
       //      sc1 stores of step t-1 (x, log w, its ring entry) have completed is signalled separately (`ready`), behind
@@ -1279,7 +1279,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     }
 #undef GJX_PERS
     pblk = (K + pthreads - 1) / pthreads;
-    if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + (16 * (size_t)(tiled ? kGranulePad : 1) + 32) * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
+    if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + (16 * (size_t)kGranulePad + 32) * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
   }
   // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
   if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
@@ -1309,7 +1309,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
       if (t == 0) { kp0[0] = kp[0]; kp0[1] = kp[1]; }
     }
     // ws2: [256 B control][aggA 8 gp nb][aggB 8 gp nb][bsum ring 12 nb][bmax ring 12 nb][ready 4 nb + 4 nb pad][us 8 T][keys 8 T]
-    const size_t gp = tiled ? (size_t)kGranulePad : 1;        // tile-scaled scheme: one 64-byte line per granule
+    const size_t gp = (size_t)kGranulePad;                    // one 64-byte line per granule, both schemes
     unsigned long long* aggA = (unsigned long long*)(ws2 + kWsHeaderBytes);
     unsigned long long* aggB = aggA + gp * pblk;
     float* bsum = (float*)(aggB + gp * pblk);
