@@ -1066,6 +1066,7 @@ extern "C" int gjx_resample_gather_tiled(const float* logw, int64_t K, const uin
     uint64_t* S = (uint64_t*)((char*)workspace + kWsHeaderBytes);
     int32_t* E = (int32_t*)(S + nt);
     hipLaunchKernelGGL(k_tile_totals, dim3((unsigned)nt), dim3(kTileQ), 0, st, logw, K, S, E);
+    GJX_CHECK_LAUNCH("gjx_resample_gather_tiled/totals");
     tile_S = S; tile_E = E;
   }
   const float log_k = (float)log((double)(K_total > 0 ? K_total : K));

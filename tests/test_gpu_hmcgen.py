@@ -135,3 +135,46 @@ def test_generated_hmc_is_the_default_engine_for_unmatched_programs(K_, oracle):
     assert K_.hmc_engine(pd) == 0
     src = K_.program_hmc_source(_scan_target(16, A.RNG_FLAT)[0])
     assert "gjx_hmc_gen" in src and "sweep<false>" in src
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_random_programs_generated_hmc_vs_interpreter_and_oracle(K_, oracle, rng, monkeypatch):
+    """Differential test of the HMC emitter: random site programs (test_gpu_parity._random_program: every kind, the four
+    parameter forms, transforms), every site constrained to the oracle's own draws, every differentiable site selected,
+    a short trajectory without the accept step — generated kernel == site interpreter == oracle on the chains whose
+    oracle result is well conditioned.  GJX_FUZZ_TRIALS / GJX_FUZZ_SEED widen the campaign (profiles/gputests.sh)."""
+    import torch
+    from test_gpu_parity import _random_program
+    trials = int(os.environ.get("GJX_FUZZ_TRIALS", "24"))
+    rs = np.random.default_rng(int(os.environ.get("GJX_FUZZ_SEED", "311")) + rng)
+    n, covered = 256, 0
+    for trial in range(trials):
+        sl = _random_program(rs, rng)
+        sel = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS and s.kind not in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS))
+        key = (int(rs.integers(1 << 30)), int(rs.integers(1 << 30)))
+        if not sel:
+            continue
+        ch = oracle.run_program(PackedProgram(sl, rng_mode=rng), key, n)["choices"].astype(np.float32)
+        prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=sel, rng_mode=rng)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        if K_.hmc_engine(prog) != 4:
+            continue
+        covered += 1
+        what = f"trial {trial} ({[A.KIND_NAMES[s.kind] for s in sl.sites]})"
+        eps, L = 1e-3, 6
+        o = oracle.hmc(prog, key, ch, eps, L, False, False, offset=3)
+        o2 = oracle.hmc(prog, key, ch, eps * 1.01, L, False, False, offset=3)
+        g = K_.hmc(prog, key, torch.as_tensor(ch).cuda(), eps, L, False, False, offset=3)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        it = K_.hmc(prog, key, torch.as_tensor(ch).cuda(), eps, L, False, False, offset=3)
+        gc, ic, ga, ia = _np(g["choices"]), _np(it["choices"]), _np(g["alpha"]), _np(it["alpha"])
+        # well-conditioned chains: the oracle's own result is finite, moderate, and moves by less than 1e-3 when the step
+        # size changes by 1 % (a chain that sits next to a pole of its density amplifies every rounding difference)
+        well = (np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o["choices"]).max(0) < 1e3) & (np.abs(o["alpha"]) < 10.0)
+                & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o2["alpha"] - o["alpha"]) < 1e-2))
+        assert well.mean() > 0.5, what
+        np.testing.assert_allclose(gc[:, well], ic[:, well], rtol=2e-3, atol=2e-3, err_msg=what + " generated vs interpreter")
+        np.testing.assert_allclose(gc[:, well], o["choices"][:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs oracle")
+        np.testing.assert_allclose(ga[well], ia[well], rtol=5e-3, atol=5e-3, err_msg=what + " alpha generated vs interpreter")
+        np.testing.assert_allclose(ga[well], o["alpha"][well], rtol=6e-3, atol=6e-3, err_msg=what + " alpha generated vs oracle")
+    assert covered >= trials // 3, f"the emitter covered {covered} of {trials} random programs"

@@ -53,7 +53,8 @@ def _filter_worker(rank, world, port, K_total, T, dx, rng, q, move=None, device_
         raise
 
 
-@pytest.mark.parametrize("world,K_total,dx", [(1, 1 << 15, 8), (2, 1 << 15, 8), (4, 1 << 15, 4), (2, 1 << 17, 8)])
+@pytest.mark.parametrize("world,K_total,dx", [(1, 1 << 15, 8), (2, 1 << 15, 8), (4, 1 << 15, 4), (2, 1 << 17, 8),
+                                              (4, 1 << 21, 8)])     # the last: config 4's shard (2^19 particles per rank, d_x = 8)
 def test_peer_filter_equals_unsharded(world, K_total, dx):
     """gjx_ssm_filter_peer on `world` ranks (processes sharing the GPU) == gjx_ssm_filter_scheme(tile-scaled) on one rank:
     particles, log-weights and ancestors bit for bit, the LSE records to summation order."""

@@ -107,6 +107,28 @@ def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
         np.testing.assert_allclose(_np(a["increments"]), _np(c["increments"]), rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("K,force", [((1 << 18) + 1, False), (300_001, False), (1 << 19, False), (1 << 20, False), (1, True), (2049, True), (70_001, True)])
+def test_any_size_one_launch_filter_equals_step_by_step(K_, K, force, monkeypatch):
+    """k_pf_persistent (the one-launch filter beyond one slot per lane: several quantisation tiles per block, any K; what
+    config 4's 2^19 particles per GPU run; GJX_PF=1 takes it at small sizes too) == the host-driven loop, bit for bit,
+    on both stream layouts and with an observation matrix."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    if force:
+        monkeypatch.setenv("GJX_PF", "1")
+    for rng, dx in ((A.RNG_FLAT, 8), (A.RNG_JAX32, 4)):
+        s = cf.ssm_problem(dx=dx, T=9)
+        rs = np.random.default_rng(K % 97)
+        H = None if rng == A.RNG_FLAT else (rs.standard_normal((3, dx)) / np.sqrt(dx)).astype(np.float32)
+        y = s["y"] if H is None else (s["y"] @ H.T + 0.3 * rs.standard_normal((9, 3))).astype(np.float32)
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], H=H), K, rng_mode=rng, weights="tile_scaled")
+        a = bf.run(core.key(11), y)
+        b = bf.run(core.key(11), y, step_by_step=True)
+        assert not a["degenerate"]
+        np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+        np.testing.assert_array_equal(_np(a["logw"]), _np(b["logw"]))
+        np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-5)
+
+
 @pytest.mark.parametrize("weights", ["tile_scaled", "global_max"])
 def test_one_launch_filter_tiny_and_ragged_sizes(K_, weights):
     """One particle, one wave, one tile, one particle past a tile; two-step and three-step filters: the one-launch filter
