@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
 // k_hmc_generic on the same program.
 struct LogregArgs {
   const float* tab;
+  const float* tab_host;               // host copy of the same table (launcher only)
   int N;
   int x_off, b_off, b_len, y_off;      // X[N][P] row-major, bias, observed y
   int mu_off, mu_len;                  // prior mean of beta
@@ -432,7 +433,11 @@ __global__ __launch_bounds__(kLogregThreads, CPL == 1 ? 4 : 2) void k_hmc_logreg
 // ------------------------------------------------------------------------------------------
 // P = 16 on the matrix cores.  The two contractions of a leapfrog step are [chains x 16] x [16 x N] (logits) and
 // [chains x N] x [N x 16] (gradient): f32-input MFMA (v_mfma_f32_16x16x4_f32, exact f32, the f32 VALU rate) takes
-// them off the vector pipe, which keeps only the sigmoids and the leapfrog update — the two pipes overlap.
+// them off the vector instructions, which keep only the sigmoids and the leapfrog update.  The f32 MFMA runs on the SIMD's
+// own f32 lanes: a v_fma / v_exp issued beside it costs its full time on top of the MFMA's 32 cycles, at any number of
+// waves per SIMD, and alternating MFMAs with vector instructions costs a further ~10 % over issuing each kind in groups
+// of 8 (profiles/microbench/ub_mfma.hip, profiles/r03_mfma_valu_overlap_microbench.txt) — so the gradient loop issues 8
+// forward MFMAs, then the 8 x 3 sigmoid instructions, then 8 backward MFMAs, and keeps every other instruction out.
 //
 // One wave = 16 chains.  Lane l: chain c = l & 15, group q = l >> 4.  Every per-coefficient quantity (beta, momentum,
 // gradient) lives in the MFMA C layout: register i of lane (c, q) holds coefficient p = 4q + i of chain c.  With that
@@ -489,7 +494,55 @@ GJX_DEV v4f logreg_mfma_grad(const LogregLds& s, int c16, int q, const v4f& beta
   return g0 + g1;
 }
 
+// The same for observations that are all 0 or 1 (BIN): with s_n = 2 y_n - 1 the residual y_n - sigmoid(z_n) is
+// s_n sigmoid(-s_n z_n), so LDS holds the rows X'_n = s_n X_n (and the bias s_n b_n log2(e)), the forward pass accumulates
+// log2(e) s_n z_n, the residual is rcp(1 + exp2(acc)) — no y, no subtraction — and the backward pass contracts X' again.
+// LD > 0: the row stride is a compile-time constant (config 5: N = 1024), every LDS address is base + immediate.
+// The three phases are fenced (sched_barrier): the machine scheduler would interleave them to hide latencies, which the
+// other waves of the SIMD do for free, and the interleaved order is the slow one (see the header of this section).
+template <int LD>
+GJX_DEV v4f logreg_mfma_grad_bin(const LogregLds& s, int c16, int q, const v4f& beta_in) {
+  const int ld = LD > 0 ? LD : s.ld;
+  const v4f beta = beta_in * (-kNegLog2e);
+  v4f g0 = {0.0f, 0.0f, 0.0f, 0.0f}, g1 = g0;
+  const float* xrow = s.xt + c16 * ld + 4 * q;
+  const float* xcol = s.xt + (4 * q) * ld + c16;
+  const float* bsq = s.bs + 4 * q;
+  for (int n0 = 0; n0 < s.Npad; n0 += 32) {
+    float xa[4], xb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xa[i] = xcol[i * ld + n0]; xb[i] = xcol[i * ld + n0 + 16]; }
+    v4f s0 = *reinterpret_cast<const v4f*>(bsq + n0);
+    v4f s1 = *reinterpret_cast<const v4f*>(bsq + n0 + 16);
+    const v4f a0 = *reinterpret_cast<const v4f*>(xrow + n0);
+    const v4f a1 = *reinterpret_cast<const v4f*>(xrow + n0 + 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], beta[i], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i], beta[i], s1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    v4f e0, e1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e0[r] = __builtin_amdgcn_exp2f(s0[r]); e1[r] = __builtin_amdgcn_exp2f(s1[r]); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e0[r] = 1.0f + e0[r]; e1[r] = 1.0f + e1[r]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e0[r] = fast_rcp(e0[r]); e1[r] = fast_rcp(e1[r]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], e0[r], g0, 0, 0, 0);
+      g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], e1[r], g1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return g0 + g1;
+}
+
 // log-likelihood sum_n log Bernoulli(y_n; logits) of the wave's 16 chains (all 4 lanes of a chain get the total)
+template <bool BIN>
 GJX_DEV float logreg_mfma_loglik(const LogregLds& s, int c16, int q, const v4f& beta) {
   const float* xcol = s.xt + (4 * q) * s.ld + c16;
   float part = 0.0f;
@@ -499,28 +552,32 @@ GJX_DEV float logreg_mfma_loglik(const LogregLds& s, int c16, int q, const v4f& 
     for (int i = 0; i < 4; ++i) sl = __builtin_amdgcn_mfma_f32_16x16x4f32(xcol[i * s.ld + n0], beta[i], sl, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n0 + 4 * q + r < s.N) part += elem_logpdf(GJX_BERNOULLI_LOGITS, s.y[n0 + 4 * q + r], sl[r], 0.0f);
+      if (n0 + 4 * q + r < s.N)    // BIN: the rows and the bias carry s_n, so sl = s_n z_n and log p = log sigmoid(s_n z_n)
+        part += elem_logpdf(GJX_BERNOULLI_LOGITS, BIN ? 1.0f : s.y[n0 + 4 * q + r], sl[r], 0.0f);
   }
   return group_sum(part);
 }
 
-template <int RNG, bool STALE>
+// BIN: every observation is 0 or 1 (checked by the launcher); NP > 0: Npad is this compile-time constant
+template <int RNG, bool STALE, bool BIN, int NP>
 __global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs a) {
   constexpr int P = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = a.N, Npad = (N + 31) & ~31, ld = Npad + 4;
+  const int N = a.N, Npad = NP > 0 ? NP : (N + 31) & ~31, ld = Npad + 4;
   float* sXT = smem;
   float* sY = sXT + P * ld;
   float* sB = sY + Npad;
   float* sBs = sB + Npad;
   for (int t = threadIdx.x; t < P * ld; t += kMfmaThreads) {
     const int p = t / ld, nn = t - p * ld;
-    sXT[t] = nn < N ? a.tab[a.x_off + nn * P + p] : 0.0f;
+    const float sgn = BIN && nn < N ? 2.0f * a.tab[a.y_off + nn] - 1.0f : 1.0f;
+    sXT[t] = nn < N ? sgn * a.tab[a.x_off + nn * P + p] : 0.0f;
   }
   for (int t = threadIdx.x; t < Npad; t += kMfmaThreads) {
-    sY[t] = t < N ? a.tab[a.y_off + t] : 0.5f;      // padded rows: residual y - sigmoid(0) is exactly 0
-    sB[t] = t < N ? a.tab[a.b_off + (a.b_len == 1 ? 0 : t)] : 0.0f;
-    sBs[t] = sB[t] * kNegLog2e;
+    sY[t] = t < N ? a.tab[a.y_off + t] : 0.5f;      // padded rows: residual y - sigmoid(0) is exactly 0 (BIN: their X' row is 0)
+    const float sgn = BIN && t < N ? 2.0f * sY[t] - 1.0f : 1.0f;
+    sB[t] = t < N ? sgn * a.tab[a.b_off + (a.b_len == 1 ? 0 : t)] : 0.0f;
+    sBs[t] = sB[t] * (BIN ? -kNegLog2e : kNegLog2e);
   }
   __syncthreads();
   const LogregLds lds{sXT, sY, sB, sBs, ld, Npad, N};
@@ -547,7 +604,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs 
     return normal_logpdf(l, a.m0, a.s0) + group_sum(acc);
   };
   auto full_grad = [&](float l, const v4f& be, v4f& g, float& gl) {
-    g = logreg_mfma_grad(lds, c16, q, be);
+    g = BIN ? logreg_mfma_grad_bin<(NP > 0 ? NP + 4 : 0)>(lds, c16, q, be) : logreg_mfma_grad(lds, c16, q, be);
     const float t2i = fast_exp(-2.0f * l);            // 1 / tau^2
     float acc = 0.0f;
 #pragma unroll
@@ -558,7 +615,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs 
     }
     gl = -(l - a.m0) * rs0 * rs0 + group_sum(acc) - (float)P;
   };
-  const float score0 = logreg_mfma_loglik(lds, c16, q, beta) + prior_score(lt, beta);
+  const float score0 = logreg_mfma_loglik<BIN>(lds, c16, q, beta) + prior_score(lt, beta);
   v4f g, g0;
   float glt, glt0;
   full_grad(lt, beta, g, glt);
@@ -597,7 +654,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) pb[i] += he * g[i];
   }
-  const float sc = a.L > 0 ? logreg_mfma_loglik(lds, c16, q, beta) + prior_score(lt, beta) : score0;
+  const float sc = a.L > 0 ? logreg_mfma_loglik<BIN>(lds, c16, q, beta) + prior_score(lt, beta) : score0;
   ksum = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) ksum += -0.5f * pb[i] * pb[i] - kHalfLog2Pi;
@@ -669,12 +726,17 @@ static int launch_logreg_mfma(const LogregArgs& a, hipStream_t st) {
   const size_t lds = sizeof(float) * ((size_t)16 * (Npad + 4) + 3 * (size_t)Npad);
   const int chains_per_block = kMfmaThreads / 64 * 16;
   const unsigned nb = (unsigned)((a.n + chains_per_block - 1) / chains_per_block);
-#define GJX_LM(ST)                                                                                                   \
+  // observations all 0 or 1 (what a Bernoulli site holds): the sign-folded gradient loop; anything else keeps y - sigmoid
+  bool bin = !getenv("GJX_HMC_NO_BIN");
+  for (int i = 0; i < a.N && bin; ++i) bin = a.tab_host[a.y_off + i] == 0.0f || a.tab_host[a.y_off + i] == 1.0f;
+#define GJX_LM(ST, BN, NP)                                                                                           \
   {                                                                                                                  \
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg_mfma<RNG, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_hmc_logreg_mfma<RNG, ST>), dim3(nb), dim3(kMfmaThreads), lds, st, a);                      \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)k_hmc_logreg_mfma<RNG, ST, BN, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_hmc_logreg_mfma<RNG, ST, BN, NP>), dim3(nb), dim3(kMfmaThreads), lds, st, a);              \
   }
-  if (a.stale) GJX_LM(true) else GJX_LM(false)
+#define GJX_LM2(ST) { if (!bin) GJX_LM(ST, false, 0) else if (Npad == 1024) GJX_LM(ST, true, 1024) else GJX_LM(ST, true, 0) }
+  if (a.stale) GJX_LM2(true) else GJX_LM2(false)
+#undef GJX_LM2
 #undef GJX_LM
   return 0;
 }
@@ -760,7 +822,7 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
   {
     LogregArgs la; int P;
     if ((pref == 0 || pref == 1) && match_logreg(prog, &la, &P)) {
-      la.tab = prog->tab_dev; la.key = key2{key0, key1}; la.n = n; la.offset = chain_offset; la.eps = eps; la.L = L;
+      la.tab = prog->tab_dev; la.tab_host = prog->tab; la.key = key2{key0, key1}; la.n = n; la.offset = chain_offset; la.eps = eps; la.L = L;
       la.stale = stale_grad_compat; la.accept = accept; la.choices = choices; la.score = score; la.alpha = alpha; la.accepted = accepted;
       if (prog->rng_mode == GJX_RNG_JAX32) launch_logreg<GJX_RNG_JAX32>(la, P, (hipStream_t)stream);
       else launch_logreg<GJX_RNG_FLAT>(la, P, (hipStream_t)stream);

@@ -164,17 +164,33 @@ def test_random_programs_generated_hmc_vs_interpreter_and_oracle(K_, oracle, rng
         eps, L = 1e-3, 6
         o = oracle.hmc(prog, key, ch, eps, L, False, False, offset=3)
         o2 = oracle.hmc(prog, key, ch, eps * 1.01, L, False, False, offset=3)
+        ch3 = ch.copy()                                       # the selected values moved by a few float32 ulps
+        for a_ in sel:
+            ch3[prog.slot_of[a_]:prog.slot_of[a_] + sl[a_].dim] *= np.float32(1.0 + 4e-6)
+        o3 = oracle.hmc(prog, key, ch3, eps, L, False, False, offset=3)
         g = K_.hmc(prog, key, torch.as_tensor(ch).cuda(), eps, L, False, False, offset=3)
         monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
         it = K_.hmc(prog, key, torch.as_tensor(ch).cuda(), eps, L, False, False, offset=3)
         gc, ic, ga, ia = _np(g["choices"]), _np(it["choices"]), _np(g["alpha"]), _np(it["alpha"])
-        # well-conditioned chains: the oracle's own result is finite, moderate, and moves by less than 1e-3 when the step
-        # size changes by 1 % (a chain that sits next to a pole of its density amplifies every rounding difference)
-        well = (np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o["choices"]).max(0) < 1e3) & (np.abs(o["alpha"]) < 10.0)
-                & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o2["alpha"] - o["alpha"]) < 1e-2))
+        # well-conditioned chains: the oracle's own result is finite, moderate, moves by less than 1e-3 when the step size
+        # changes by 1 %, and does not notice a start that is a few float32 ulps away (a chain that sits next to a pole of
+        # its density amplifies every rounding difference: device and oracle round differently)
+        with np.errstate(invalid="ignore"):
+            # (|alpha| < 1e-3: with eps = 1e-3 and 6 steps the energy error of a smooth chain is ~1e-6; an alpha of 1e-2 that
+            # does not shrink with eps is the float32 rounding of the score itself, e.g. lgamma((nu+1)/2) - lgamma(nu/2) of a
+            # student-t with nu = exp(10): one ulp of lgamma(16000) is 0.016)
+            well = (np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o["choices"]).max(0) < 1e3) & (np.abs(o["alpha"]) < 1e-3)
+                    & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o2["alpha"] - o["alpha"]) < 5e-4)
+                    & (np.abs(o3["choices"] - o["choices"]).max(0) < 2e-4) & (np.abs(o3["alpha"] - o["alpha"]) < 5e-4))
         assert well.mean() > 0.5, what
         np.testing.assert_allclose(gc[:, well], ic[:, well], rtol=2e-3, atol=2e-3, err_msg=what + " generated vs interpreter")
         np.testing.assert_allclose(gc[:, well], o["choices"][:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs oracle")
-        np.testing.assert_allclose(ga[well], ia[well], rtol=5e-3, atol=5e-3, err_msg=what + " alpha generated vs interpreter")
-        np.testing.assert_allclose(ga[well], o["alpha"][well], rtol=6e-3, atol=6e-3, err_msg=what + " alpha generated vs oracle")
+        # alpha is a difference of two scores: its float32 rounding error grows with their magnitude (summation order and the
+        # hardware log / exp differ between the device and the oracle's libm)
+        mag = 5e-6 * np.maximum(np.abs(o["score"]), np.abs(o["score"] - o["alpha"]))[well]
+        assert (np.abs(ga[well] - ia[well]) <= 5e-3 + 5e-3 * np.abs(ia[well]) + mag).all(), what + " alpha generated vs interpreter"
+        err = np.abs(ga[well] - o["alpha"][well]) - (6e-3 + 6e-3 * np.abs(o["alpha"][well]) + mag)
+        w = int(np.argmax(err))
+        assert err[w] <= 0, (f"{what} alpha generated vs oracle: chain {np.flatnonzero(well)[w]} generated {ga[well][w]} interpreter {ia[well][w]} "
+                             f"oracle {o['alpha'][well][w]} score {o['score'][well][w]} start {ch[:, np.flatnonzero(well)[w]]}")
     assert covered >= trials // 3, f"the emitter covered {covered} of {trials} random programs"
