@@ -104,6 +104,55 @@ static void runmix(const char* name, unsigned long long* d) {
   }
 }
 
+// LDS reads beside the MFMAs: per 8 MFMAs, R reads of kind W (0: ds_read_b32, 1: ds_read2_b32, 2: ds_read_b128); M = 0: reads alone
+template <int R, int W, int M>
+__global__ __launch_bounds__(1024) void klds(unsigned long long* out, float seed) {
+  __shared__ float sm[16384];
+  for (int t = threadIdx.x; t < 16384; t += blockDim.x) sm[t] = seed * (float)t;
+  __syncthreads();
+  v4f c0 = {seed, 0.f, 1.f, 2.f}, c1 = {1.f, seed, 0.f, 3.f};
+  float a = seed + (float)(threadIdx.x & 15), b = seed * 0.5f;
+  const unsigned addr = (unsigned)(uintptr_t)(sm) + (threadIdx.x & 63) * (W == 2 ? 16 : 4);
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (M) {
+        if (u & 1) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
+      }
+      if (u < R) {
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (W == 0) asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(v[0]) : "v"(addr));
+        else if (W == 1) { float2 w; asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:20" : "=v"(w) : "v"(addr)); v[0] = w.x; v[1] = w.y; }
+        else asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v) : "v"(addr));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        acc += v;
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = c0[0] + c0[1] + c0[2] + c0[3] + c1[0] + c1[1] + c1[2] + c1[3] + acc[0] + acc[1] + acc[2] + acc[3];
+  if (s == 12345.678f) out[4096] = 1;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int R, int W, int M>
+static void runlds(const char* name, unsigned long long* d) {
+  for (int threads : {256, 512, 1024}) {
+    CK(hipMemset(d, 0, 8 * 8192));
+    hipLaunchKernelGGL((klds<R, W, M>), dim3(8), dim3(threads), 0, 0, d, 1.25f);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(8 * 16);
+    CK(hipMemcpy(h.data(), d, 8 * 16 * 8, hipMemcpyDeviceToHost));
+    double mx = 0;
+    for (int b = 0; b < 8; ++b) for (int w = 0; w < threads / 64; ++w) mx = std::max(mx, (double)h[b * 16 + w]);
+    printf("%-34s waves/SIMD %d: %7.1f cycles of SIMD time per 8 MFMA slots (256 for the MFMAs)\n", name, threads / 256, mx / ITER / (threads / 256));
+  }
+}
+
 template <int F, int KIND, int M>
 static void run(const char* name, unsigned long long* d) {
   for (int threads : {256, 512, 1024}) {
@@ -137,5 +186,11 @@ int main() {
   runmix<0>("mix interleaved", d);
   runmix<1>("mix batched 8", d);
   runmix<2>("mix batched 4", d);
+  runlds<8, 0, 1>("8 mfma + 8 ds_read_b32 (+wait+4 add)", d);
+  runlds<4, 1, 1>("8 mfma + 4 ds_read2_b32", d);
+  runlds<4, 2, 1>("8 mfma + 4 ds_read_b128", d);
+  runlds<8, 2, 1>("8 mfma + 8 ds_read_b128", d);
+  runlds<8, 2, 0>("8 ds_read_b128 alone", d);
+  runlds<8, 0, 0>("8 ds_read_b32 alone", d);
   return 0;
 }

