@@ -500,10 +500,12 @@ def run_hmc(args, rank, world, dev):
         vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload="hier_logreg_N1024_P16 HMC with fused MH accept (BASELINE.json configs[4]); one bench step = "
                              f"one move of L={L} leapfrog steps", chains_per_gpu=n, leapfrog=L, eps=0.01, rng_stream="flat"),
-        roofline=dict(bound="mfma", kernel=("gjx::k_hmc_logreg_mfma<FLAT,false>" if engine == 3 else "gjx::k_hmc_logreg<FLAT,16,false>"), achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+        roofline=dict(bound="mfma", kernel=("gjx::k_hmc_logreg_mfma2<FLAT,false,1024>" if engine == 3 else "gjx::k_hmc_logreg<FLAT,16,false>"), achieved=tf, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
                       frac=tf / FP32_PEAK_TFLOPS, traffic=None, kernel_us=kern_ms * 1e3,
-                      note="both contractions on v_mfma_f32_16x16x4_f32 (exact f32; its peak equals the f32 vector peak on gfx950 and the two "
-                           "do not overlap: what is left beside the MFMAs is the sigmoid VALU work); ~0 HBM bytes"),
+                      note="both contractions on v_mfma_f32_16x16x4_f32 (exact f32).  The f32 MFMA occupies the SIMD's own f32 lanes: vector "
+                           "instructions beside it cost their full issue time on top of its 32 cycles (profiles/r03_mfma_valu_overlap_microbench.txt), "
+                           "so per 32 observations a wave needs 32 MFMAs (1024 cycles) + 48 sigmoid instructions (~330) + ~80 of LDS reads and loop: "
+                           "MFMA busy 0.72 by SQ_VALU_MFMA_BUSY_CYCLES; ~0 HBM bytes"),
         accept_rate=float(acc.mean()),
     )
     if not args.no_cpu_baseline and world == 1:

@@ -686,6 +686,234 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void k_hmc_logreg_mfma(LogregArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same kernel for the shape the benchmark runs (0/1 observations, no bias), two steps further: one wave carries TWO groups
+// of 16 chains, so every X operand fetched from LDS feeds two MFMAs, and LDS holds X' twice — row-major XR[N][16] for the
+// forward A operand (the 4 coefficients a lane needs are one 16-byte read) and transposed XT[16][N + 4] for the backward one —
+// so a trip of 32 observations is 4 ds_read_b128 + 32 MFMAs + 48 sigmoid instructions (before: 12 LDS reads per 32 MFMAs; an
+// LDS read costs the SIMD ~9 cycles of issue).  130 KB of LDS: one 512-thread block per CU, two waves per SIMD (as fast per
+// wave as four: the SIMD is busy either way).
+constexpr int kMfma2Chains = kMfmaThreads / 64 * 32;   // 256 chains per block
+
+// gradient for the wave's two chain groups; NP = Npad (compile-time) or 0
+template <int NP>
+GJX_DEV void logreg_mfma2_grad(const float* xr, const float* xt, int Npad_rt, int c16, int q, const v4f (&beta_in)[2], v4f (&g)[2]) {
+  const int Npad = NP > 0 ? NP : Npad_rt, ld = Npad + 4;
+  v4f beta[2] = {beta_in[0] * (-kNegLog2e), beta_in[1] * (-kNegLog2e)};
+  v4f ga[2], gb[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { ga[c] = v4f{0.0f, 0.0f, 0.0f, 0.0f}; gb[c] = ga[c]; }
+  const float* xrow = xt + c16 * ld + 4 * q;       // backward A operand: XT[l&15][n0 + 4q + r]
+  const float* xfw = xr + c16 * 16 + 4 * q;        // forward  A operand: XR[n0 + (l&15)][4q + i]
+  // the operands of the next trip are fetched a phase ahead (X' for the forward MFMAs behind this trip's forward MFMAs, the
+  // transposed rows behind its backward MFMAs): with two waves per SIMD nothing else hides the LDS latency
+  v4f x0 = *reinterpret_cast<const v4f*>(xfw);
+  v4f x1 = *reinterpret_cast<const v4f*>(xfw + 16 * 16);
+  v4f a0 = *reinterpret_cast<const v4f*>(xrow);
+  v4f a1 = *reinterpret_cast<const v4f*>(xrow + 16);
+  for (int n0 = 0; n0 < Npad; n0 += 32) {
+    const int nn = n0 + 32 < Npad ? n0 + 32 : 0;    // (the last trip fetches the first tile again: unused)
+    v4f s0[2], s1[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { s0[c] = v4f{0.0f, 0.0f, 0.0f, 0.0f}; s1[c] = s0[c]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        s0[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i], beta[c][i], s0[c], 0, 0, 0);
+        s1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i], beta[c][i], s1[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    x0 = *reinterpret_cast<const v4f*>(xfw + nn * 16);
+    x1 = *reinterpret_cast<const v4f*>(xfw + (nn + 16) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[c][r] = __builtin_amdgcn_exp2f(s0[c][r]); s1[c][r] = __builtin_amdgcn_exp2f(s1[c][r]); }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[c][r] = 1.0f + s0[c][r]; s1[c][r] = 1.0f + s1[c][r]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[c][r] = fast_rcp(s0[c][r]); s1[c][r] = fast_rcp(s1[c][r]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        ga[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], s0[c][r], ga[c], 0, 0, 0);
+        gb[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], s1[c][r], gb[c], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = *reinterpret_cast<const v4f*>(xrow + nn);
+    a1 = *reinterpret_cast<const v4f*>(xrow + nn + 16);
+  }
+  g[0] = ga[0] + gb[0];
+  g[1] = ga[1] + gb[1];
+}
+
+// log-likelihood of one chain group from the row-major copy (rows carry s_n: log p = log sigmoid(s_n z_n))
+GJX_DEV float logreg_mfma2_loglik(const float* xr, int N, int Npad, int c16, int q, const v4f& beta) {
+  const float* xfw = xr + c16 * 16 + 4 * q;
+  float part = 0.0f;
+  for (int n0 = 0; n0 < Npad; n0 += 16) {
+    const v4f x0 = *reinterpret_cast<const v4f*>(xfw + n0 * 16);
+    v4f sl = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sl = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i], beta[i], sl, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n0 + 4 * q + r < N) part += elem_logpdf(GJX_BERNOULLI_LOGITS, 1.0f, sl[r], 0.0f);
+  }
+  return group_sum(part);
+}
+
+template <int RNG, bool STALE, int NP>
+__global__ __launch_bounds__(kMfmaThreads, 1) void k_hmc_logreg_mfma2(LogregArgs a) {
+  constexpr int P = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, Npad = NP > 0 ? NP : (N + 31) & ~31, ld = Npad + 4;
+  float* sXT = smem;               // [16][ld]   X' transposed
+  float* sXR = sXT + P * ld;       // [Npad][16] X' row-major
+  for (int t = threadIdx.x; t < P * ld; t += kMfmaThreads) {
+    const int p = t / ld, nn = t - p * ld;
+    sXT[t] = nn < N ? (2.0f * a.tab[a.y_off + nn] - 1.0f) * a.tab[a.x_off + nn * P + p] : 0.0f;
+  }
+  for (int t = threadIdx.x; t < Npad * P; t += kMfmaThreads) {
+    const int nn = t / P;
+    sXR[t] = nn < N ? (2.0f * a.tab[a.y_off + nn] - 1.0f) * a.tab[a.x_off + t] : 0.0f;
+  }
+  __syncthreads();
+  const float* __restrict__ tab = a.tab;
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
+  const int64_t n = a.n;
+  float* ch = a.choices;
+  int64_t idx[2];
+  bool live[2];
+  float lt[2];
+  v4f beta[2], mu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mu[i] = tab[a.mu_off + (a.mu_len == 1 ? 0 : 4 * q + i)];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    idx[c] = ((int64_t)blockIdx.x * (kMfmaThreads / 64) + (threadIdx.x >> 6)) * 32 + c * 16 + c16;
+    live[c] = idx[c] < n;
+    if (!live[c]) idx[c] = n - 1;                   // shadow chains keep the wave's matrices full; they never store
+    lt[c] = ch[idx[c]];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) beta[c][i] = ch[(int64_t)(1 + 4 * q + i) * n + idx[c]];
+  }
+  const float rs0 = fast_rcp(a.s0);
+  auto prior_score = [&](float l, const v4f& be) {
+    const float tau = fast_exp(l);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += normal_logpdf(be[i], mu[i], tau);
+    return normal_logpdf(l, a.m0, a.s0) + group_sum(acc);
+  };
+  v4f g[2], g0[2];
+  float glt[2], glt0[2];
+  auto full_grad = [&]() {
+    logreg_mfma2_grad<NP>(sXR, sXT, Npad, c16, q, beta, g);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float t2i = fast_exp(-2.0f * lt[c]);      // 1 / tau^2
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float z = beta[c][i] - mu[i];
+        g[c][i] -= z * t2i;
+        acc = fmaf(z * z, t2i, acc);
+      }
+      glt[c] = -(lt[c] - a.m0) * rs0 * rs0 + group_sum(acc) - (float)P;
+    }
+  };
+  float score0[2], k0[2], plt[2];
+  v4f pb[2];
+  key2 knew[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) score0[c] = logreg_mfma2_loglik(sXR, N, Npad, c16, q, beta[c]) + prior_score(lt[c], beta[c]);
+  full_grad();
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    g0[c] = g[c]; glt0[c] = glt[c];
+    // momenta: leaf 0 = log_tau, leaf 1 = beta — the streams of k_hmc_generic / k_hmc_logreg; each lane draws its 4
+    const uint64_t gidx = (uint64_t)(a.offset + idx[c]);
+    key2 sub{0u, 0u};
+    knew[c] = key2{0u, 0u};
+    if (RNG == GJX_RNG_JAX32) {
+      const key2 ck = fold_in64(a.key, gidx);
+      knew[c] = fold_in(ck, 0u);
+      sub = fold_in(ck, 1u);
+    }
+    BitStream<RNG> bs;
+    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 0u)); else bs.open(a.key, gidx, 1u);
+    plt[c] = stream_normal<RNG>(bs, 0u);
+    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, 1u)); else bs.open(a.key, gidx, 2u);
+    float ksum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pb[c][i] = stream_normal<RNG>(bs, (uint32_t)(4 * q + i));
+      ksum += -0.5f * pb[c][i] * pb[c][i] - kHalfLog2Pi;
+    }
+    k0[c] = -0.5f * plt[c] * plt[c] - kHalfLog2Pi + group_sum(ksum);
+  }
+  const float he = 0.5f * a.eps;
+  for (int t = 1; t <= a.L; ++t) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      plt[c] += he * (STALE ? glt0[c] : glt[c]);
+      lt[c] += a.eps * plt[c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pb[c][i] += he * (STALE ? g0[c][i] : g[c][i]);
+        beta[c][i] += a.eps * pb[c][i];
+      }
+    }
+    full_grad();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      plt[c] += he * glt[c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pb[c][i] += he * g[c][i];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float sc = a.L > 0 ? logreg_mfma2_loglik(sXR, N, Npad, c16, q, beta[c]) + prior_score(lt[c], beta[c]) : score0[c];
+    float ksum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ksum += -0.5f * pb[c][i] * pb[c][i] - kHalfLog2Pi;
+    const float k1 = -0.5f * plt[c] * plt[c] - kHalfLog2Pi + group_sum(ksum);
+    const float al = sc - score0[c] + k1 - k0[c];
+    bool acc = true;
+    if (a.accept) {
+      BitStream<RNG> bs2;
+      if (RNG == GJX_RNG_JAX32) bs2.open_site_key(fold_in(knew[c], 0x4d48u));
+      else bs2.open(a.key, (uint64_t)(a.offset + idx[c]), GJX_FLAT_MAX_SITES);
+      acc = safe_log(bits_to_unit(bs2.get(0u))) < al;
+    }
+    if (live[c]) {
+      if (acc) {  // rejected chains keep the values already in choices[][]
+        if (q == 0) ch[idx[c]] = lt[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ch[(int64_t)(1 + 4 * q + i) * n + idx[c]] = beta[c][i];
+      }
+      if (q == 0) {
+        if (a.score) a.score[idx[c]] = acc ? sc : score0[c];
+        if (a.alpha) a.alpha[idx[c]] = al;
+        if (a.accepted) a.accepted[idx[c]] = acc ? 1.0f : 0.0f;
+      }
+    }
+  }
+}
+
 }  // namespace gjx
 
 using namespace gjx;
@@ -741,6 +969,20 @@ static int launch_logreg_mfma(const LogregArgs& a, hipStream_t st) {
   }
   bool zero_bias = true;
   for (int i = 0; i < (a.b_len == 1 ? 1 : a.N) && zero_bias; ++i) zero_bias = a.tab_host[a.b_off + i] == 0.0f;
+  // 0/1 observations, no bias, both copies of X' fit the LDS: the two-group kernel
+  const size_t lds2 = sizeof(float) * ((size_t)16 * (Npad + 4) + (size_t)16 * Npad);
+  if (bin && zero_bias && lds2 <= 160 * 1024 && !getenv("GJX_HMC_NO_MFMA2")) {
+    const unsigned nb2 = (unsigned)((a.n + kMfma2Chains - 1) / kMfma2Chains);
+#define GJX_LM3(ST, NP)                                                                                              \
+  {                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)k_hmc_logreg_mfma2<RNG, ST, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+    hipLaunchKernelGGL((k_hmc_logreg_mfma2<RNG, ST, NP>), dim3(nb2), dim3(kMfmaThreads), lds2, st, a);               \
+  }
+    if (a.stale) { if (Npad == 1024) GJX_LM3(true, 1024) else GJX_LM3(true, 0) }
+    else { if (Npad == 1024) GJX_LM3(false, 1024) else GJX_LM3(false, 0) }
+#undef GJX_LM3
+    return 0;
+  }
 #define GJX_LM2(ST) { if (!bin) GJX_LM(ST, false, 0) else if (Npad == 1024 && zero_bias) GJX_LM(ST, true, 1024) else GJX_LM(ST, true, 0) }
   if (a.stale) GJX_LM2(true) else GJX_LM2(false)
 #undef GJX_LM2

@@ -153,6 +153,77 @@ static void runlds(const char* name, unsigned long long* d) {
   }
 }
 
+// the gradient trip of k_hmc_logreg_mfma2 without its LDS reads: 16 forward MFMAs on 4 accumulators, 16 exp + 16 add + 16 rcp on
+// their results, 16 backward MFMAs that take the sigmoids as B.  DROP bit 0: no exp, bit 1: no add, bit 2: no rcp
+template <int DROP>
+__global__ __launch_bounds__(1024) void khmc(unsigned long long* out, float seed) {
+  v4f g[4], beta[2], x0, x1, a0, a1;
+  for (int j = 0; j < 4; ++j) g[j] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < 2; ++c) beta[c] = v4f{seed * 1e-3f, -seed * 1e-3f, 2e-3f, -1e-3f} * (float)(c + 1);
+  x0 = v4f{seed, 1.f, -1.f, 0.5f}; x1 = x0 * 0.5f; a0 = x0 * 0.25f; a1 = x0 * 0.125f;
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < ITER; ++i) {
+    v4f s0[2], s1[2];
+    for (int c = 0; c < 2; ++c) { s0[c] = v4f{0.f, 0.f, 0.f, 0.f}; s1[c] = s0[c]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        s0[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k], beta[c][k], s0[c], 0, 0, 0);
+        s1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k], beta[c][k], s1[c], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DROP & 1)) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[c][r] = __builtin_amdgcn_exp2f(s0[c][r]); s1[c][r] = __builtin_amdgcn_exp2f(s1[c][r]); }
+    }
+    if (!(DROP & 2)) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[c][r] = 1.0f + s0[c][r]; s1[c][r] = 1.0f + s1[c][r]; }
+    }
+    if (!(DROP & 4)) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[c][r] = __builtin_amdgcn_rcpf(s0[c][r]); s1[c][r] = __builtin_amdgcn_rcpf(s1[c][r]); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        g[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], s0[c][r], g[c], 0, 0, 0);
+        g[2 + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], s1[c][r], g[2 + c], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) s += g[j][0] + g[j][1] + g[j][2] + g[j][3];
+  if (s == 12345.678f) out[4096] = 1;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int DROP>
+static void runhmc(const char* name, unsigned long long* d) {
+  for (int threads : {256, 512, 1024}) {
+    CK(hipMemset(d, 0, 8 * 8192));
+    hipLaunchKernelGGL((khmc<DROP>), dim3(8), dim3(threads), 0, 0, d, 1.25f);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(8 * 16);
+    CK(hipMemcpy(h.data(), d, 8 * 16 * 8, hipMemcpyDeviceToHost));
+    double mx = 0;
+    for (int b = 0; b < 8; ++b) for (int w = 0; w < threads / 64; ++w) mx = std::max(mx, (double)h[b * 16 + w]);
+    printf("%-34s waves/SIMD %d: %7.1f cycles of SIMD time per trip (32 MFMAs = 1024)\n", name, threads / 256, mx / ITER / (threads / 256));
+  }
+}
+
 template <int F, int KIND, int M>
 static void run(const char* name, unsigned long long* d) {
   for (int threads : {256, 512, 1024}) {
@@ -192,5 +263,10 @@ int main() {
   runlds<8, 2, 1>("8 mfma + 8 ds_read_b128", d);
   runlds<8, 2, 0>("8 ds_read_b128 alone", d);
   runlds<8, 0, 0>("8 ds_read_b32 alone", d);
+  runhmc<0>("hmc trip: 32 mfma + 16 exp,add,rcp", d);
+  runhmc<4>("hmc trip without the rcp", d);
+  runhmc<1>("hmc trip without the exp", d);
+  runhmc<2>("hmc trip without the add", d);
+  runhmc<7>("hmc trip: the 32 mfma only", d);
   return 0;
 }

@@ -640,11 +640,18 @@ def test_score_grad_and_hmc_parity(K_, oracle, rng):
 
 
 @pytest.mark.parametrize("rng", RNGS)
-@pytest.mark.parametrize("shape", [(64, 4), (200, 8), (1024, 16), (1000, 16), (33, 16)])
+@pytest.mark.parametrize("shape", [(64, 4), (200, 8), (1024, 16), (1000, 16), (33, 16), (1024, 16, "GJX_HMC_NO_MFMA2"), (33, 16, "GJX_HMC_NO_MFMA2"),
+                                   (1024, 16, "GJX_HMC_NO_BIN"), (1000, 16, "GJX_HMC_NO_BIN")])
 def test_hmc_logreg_fused_vs_generic_vs_oracle(K_, oracle, rng, shape, monkeypatch):
-    """BASELINE config 5 shape: the fused kernel and the site interpreter run the same program, same streams."""
+    """BASELINE config 5 shape: the fused kernel and the site interpreter run the same program, same streams.  P = 16 runs on
+    the matrix cores — by default the two-group kernel for 0/1 observations without a bias (k_hmc_logreg_mfma2); the variables
+    step down to the one-group sign-folded kernel and to the general y - sigmoid kernel."""
     import torch
-    N, P = shape
+    N, P = shape[:2]
+    if len(shape) > 2:
+        monkeypatch.setenv(shape[2], "1")
+        if shape[2] == "GJX_HMC_NO_BIN":
+            monkeypatch.setenv("GJX_HMC_NO_MFMA2", "1")
     prog, pr = H.logreg(N=N, P=P, rng=rng)
     assert K_.hmc_engine(prog) in (2, 3)
     rs = np.random.default_rng(5)
