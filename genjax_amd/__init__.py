@@ -13,7 +13,7 @@ from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gum
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .inference import (HMC, IndexRequest, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
-                        ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, Update)
+                        ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, TrialCollections, Update)
 from .program import AddressReuse, MissingAddress  # noqa: F401
 
 __version__ = "0.1.0"

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "gjx_logsumexp": (C.c_int, [vp, i64, i64, vp, vp, C.c_size_t, vp]),
     "gjx_lse_combine": (C.c_int, [vp, C.c_int, i64, vp, vp]),
     "gjx_categorical_pick": (C.c_int, [vp, i64, i64, vp, u32, u32, i32, vp, vp, C.c_size_t, vp]),
+    "gjx_trials_lse_pick": (C.c_int, [vp, i64, i64, i64, u32, u32, i32, vp, vp, vp]),
     "gjx_weight_cumsum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_event_create": (C.c_int, [C.POINTER(vp)]),
     "gjx_event_destroy": (C.c_int, [vp]),

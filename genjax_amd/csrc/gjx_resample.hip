@@ -77,6 +77,64 @@ __global__ __launch_bounds__(256) void k_pick_finish(const PickPair* partials, i
   }
 }
 
+// Independent trials (jax.vmap(alg.run_smc)(split(key, n)), README.md:110-113): trial t owns particles [t K, (t + 1) K) of one
+// n K-particle run.  One block per trial: its LSE record {max, sumexp, lse, lse - log K} and, if asked, its 1-of-K draw
+// argmax_i (logw_i - lse_t) + Gumbel(bits(key, global index)) — the same rule as k_pick_partial with particle_offset = t K.
+template <int RNG>
+__global__ __launch_bounds__(256) void k_trials_lse_pick(const float* logw, int64_t K, int64_t offset, key2 key, int want_pick,
+                                                        float* lse_out, int32_t* pick_out) {
+  __shared__ float red[8];
+  __shared__ float rv[4];
+  __shared__ int32_t ri[4];
+  const int64_t t = blockIdx.x;
+  const float* lw = logw + t * K;
+  float m = -INFINITY;
+  for (int64_t i = threadIdx.x; i < K; i += 256) m = fmaxf(m, lw[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sm = 0.0f;
+  if (bm > -INFINITY)
+    for (int64_t i = threadIdx.x; i < K; i += 256) sm += fast_exp(lw[i] - bm);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sm;
+  __syncthreads();
+  const float bs = (red[4] + red[5]) + (red[6] + red[7]);
+  const float l = bm > -INFINITY ? bm + fast_log(bs) : -INFINITY;
+  if (threadIdx.x == 0) {
+    float* o = lse_out + 4 * t;
+    o[0] = bm; o[1] = bs; o[2] = l; o[3] = l - (float)log((double)K);
+  }
+  if (!want_pick) return;
+  float bv = -INFINITY;
+  int32_t bi = 0x7FFFFFFF;
+  for (int64_t i = threadIdx.x; i < K; i += 256) {
+    const uint64_t gi = (uint64_t)(offset + t * K + i);
+    uint32_t bits;
+    if (RNG == GJX_RNG_JAX32) {
+      const key2 h = fold_in64(key, gi);
+      bits = h.a ^ h.b;
+    } else {
+      const key2 h = fold_in64(key, gi >> 1);
+      bits = (gi & 1u) ? h.b : h.a;
+    }
+    pick_better(bv, bi, (lw[i] - l) + gumbel_from_bits(bits), (int32_t)gi);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int32_t oi = __shfl_xor(bi, o, 64);
+    pick_better(bv, bi, ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = bv; ri[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) pick_better(bv, bi, rv[w], ri[w]);
+    pick_out[t] = bi;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_wsum_blocks(const float* x, int64_t K, int is_log, const float* lse,
                                                     int n_partials, float* lse_out, float log_k_total,
                                                     uint64_t* block_sums) {
@@ -936,6 +994,22 @@ extern "C" int gjx_categorical_pick(const float* logw, int64_t K, int64_t partic
   GJX_CHECK_LAUNCH("gjx_categorical_pick/partial");
   hipLaunchKernelGGL(k_pick_finish, dim3(1), dim3(256), 0, st, (const PickPair*)partials, nblocks, (PickPair*)out_dev);
   GJX_CHECK_LAUNCH("gjx_categorical_pick/finish");
+  return GJX_OK;
+}
+
+extern "C" int gjx_trials_lse_pick(const float* logw, int64_t n_trials, int64_t K, int64_t particle_offset, uint32_t key0, uint32_t key1,
+                                   int32_t rng_mode, float* lse_out, int32_t* pick_out, void* stream) {
+  if (!logw || !lse_out || n_trials <= 0 || K <= 0 || n_trials > 0x7fffffffLL || particle_offset < 0 ||
+      (pick_out && particle_offset + n_trials * K > 0x7fffffffLL))
+    return gjx_fail(GJX_EINVAL, "gjx_trials_lse_pick: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (rng_mode == GJX_RNG_JAX32)
+    hipLaunchKernelGGL(k_trials_lse_pick<GJX_RNG_JAX32>, dim3((unsigned)n_trials), dim3(256), 0, st, logw, K, particle_offset, key2{key0, key1},
+                       pick_out ? 1 : 0, lse_out, pick_out);
+  else
+    hipLaunchKernelGGL(k_trials_lse_pick<GJX_RNG_FLAT>, dim3((unsigned)n_trials), dim3(256), 0, st, logw, K, particle_offset, key2{key0, key1},
+                       pick_out ? 1 : 0, lse_out, pick_out);
+  GJX_CHECK_LAUNCH("gjx_trials_lse_pick");
   return GJX_OK;
 }
 

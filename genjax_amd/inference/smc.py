@@ -106,6 +106,51 @@ class ParticleCollection:
         return self.get_particle(idx)
 
 
+class TrialCollections:
+    """n independent particle collections of K particles each, produced by ONE launch over n K particles: what the reference
+    gets from ``jax.vmap(alg.run_smc)(jax.random.split(key, n))`` (README.md:108-113).  Trial t owns the global particle
+    indices [t K, (t + 1) K); its weights are those of ``alg.run_smc(key, offset=t K, K_local=K)`` of an n K-particle run,
+    normalised on their own."""
+
+    def __init__(self, particles: Trace, log_weights, n_trials: int, K: int):
+        self.particles, self.log_weights, self.n_trials, self.K = particles, log_weights, int(n_trials), int(K)
+        self._lse = None
+
+    def __len__(self):
+        return self.n_trials
+
+    def lse(self):
+        """f32[n_trials][4] = {max, sumexp, lse, lse - log K} per trial (one launch, gjx_trials_lse_pick)"""
+        if self._lse is None:
+            from .. import kernels
+            self._lse, _ = kernels.trials_lse_pick(self.log_weights, self.n_trials, self.K, None, self.particles.prog.rng_mode)
+        return self._lse
+
+    def get_log_weights(self):
+        return self.log_weights.view(self.n_trials, self.K)
+
+    def get_log_marginal_likelihood_estimates(self):
+        """f32[n_trials]: logsumexp(log_weights of the trial) - log K  (smc.py:96-97 per trial)"""
+        return self.lse()[:, 3]
+
+    def trial(self, t: int) -> ParticleCollection:
+        """trial t as a ParticleCollection (a copy of its columns)"""
+        a, b = t * self.K, (t + 1) * self.K
+        tr = self.particles
+        sub = Trace(tr.gen_fn, tr.args, tr.prog, tr.choices[:, a:b].contiguous(), tr.score[a:b].contiguous(), tr.shared, True, tr.retval_sym)
+        return ParticleCollection(sub, self.log_weights[a:b].contiguous(), True, self.lse()[t], a, self.K)
+
+    def sample_particles(self, key: Key) -> Trace:
+        """one particle per trial, drawn 1-of-K over the trial's weights (smc.py:102-109 per trial): a batched Trace of
+        n_trials particles"""
+        from .. import kernels
+        tr = self.particles
+        self._lse, pick = kernels.trials_lse_pick(self.log_weights, self.n_trials, self.K, key, tr.prog.rng_mode)
+        ch = kernels.gather_rows(tr.choices, pick)
+        sc = kernels.gather_rows(tr.score.reshape(1, -1), pick).reshape(-1)
+        return Trace(tr.gen_fn, tr.args, tr.prog, ch, sc, tr.shared, True, tr.retval_sym)
+
+
 class SMCAlgorithm:
     """smc.py:117-225"""
 
@@ -202,6 +247,37 @@ class ImportanceK(SMCAlgorithm):
             tr, out = self.target.p._run(sub_key, K, self.target.args, self.target.constraint, True, True,
                                          want_lse=False, offset=offset, K_total=self.k_particles)
         return ParticleCollection(tr, out["logw"], True, out["lse"], offset, self.k_particles, partials=out.get("_partials"))
+
+    def run_smc_trials(self, key: Key, n_trials: int) -> TrialCollections:
+        """``n_trials`` independent runs of this algorithm in one launch — the device form of the reference idiom
+        ``jax.vmap(alg.run_smc)(jax.random.split(key, n_trials))`` (README.md:108-113).  The trials are the consecutive
+        K-particle shards of ONE n_trials * K-particle run under ``key`` (counter-based streams: disjoint particle
+        indices are independent), each normalised on its own."""
+        n, K = int(n_trials), self.k_particles
+        key, sub_key = split(key)
+        if self.q is not None:
+            log_q, rows = _propose(self.q, sub_key, self.target, n * K, 0, n * K)
+            tr, out = self.target.p._run(sub_key, n * K, self.target.args, self.target.constraint, True, True,
+                                         prev_rows=rows, sub=log_q, want_lse=False, K_total=n * K)
+        else:
+            tr, out = self.target.p._run(sub_key, n * K, self.target.args, self.target.constraint, True, True,
+                                         want_lse=False, K_total=n * K)
+        return TrialCollections(tr, out["logw"], n, K)
+
+    def random_weighted_trials(self, key: Key, n_trials: int, *args: Any):
+        """``jax.vmap(alg.random_weighted, in_axes=(0, None))(jax.random.split(key, n_trials), target)`` (README.md:110-113)
+        in three launches: -> (log-density estimates f32[n_trials], ChoiceMap of the unconstrained choices with a leading
+        trial axis)."""
+        target = args[0]
+        assert isinstance(target, Target)
+        key, sub_key = split(key)
+        tc = self.run_smc_trials(key, n_trials)
+        if not target.same_as(self.target):
+            pc = ChangeTarget(self, target)._reweight(key, ParticleCollection(tc.particles, tc.log_weights, True))
+            tc = TrialCollections(pc.get_particles(), pc.get_log_weights(), tc.n_trials, tc.K)
+        picked = tc.sample_particles(sub_key)
+        est = picked.get_score() - tc.get_log_marginal_likelihood_estimates()
+        return est, target.filter_to_unconstrained(picked.get_choices())
 
     def run_csmc(self, key: Key, retained: ChoiceMap) -> ParticleCollection:
         """K-1 fresh particles plus the retained choice map stacked last (smc.py:317-351)."""

@@ -277,6 +277,18 @@ def categorical_pick(logw: torch.Tensor, lse: torch.Tensor, key, rng_mode=A.RNG_
     return out
 
 
+def trials_lse_pick(logw: torch.Tensor, n_trials: int, K: int, key=None, rng_mode=A.RNG_FLAT, offset=0):
+    """gjx_trials_lse_pick: per-trial LSE records f32[n_trials][4] and (with ``key``) per-trial 1-of-K draws int32[n_trials]
+    (global indices) of n_trials * K log-weights laid out trial after trial."""
+    assert logw.numel() == n_trials * K
+    lse = torch.empty((n_trials, 4), dtype=torch.float32, device=logw.device)
+    pick = torch.empty(n_trials, dtype=torch.int32, device=logw.device) if key is not None else None
+    k = key if key is not None else (0, 0)
+    check(load().gjx_trials_lse_pick(_ptr(logw), int(n_trials), int(K), int(offset), k[0], k[1], rng_mode, _ptr(lse),
+                                     _ptr(pick) if pick is not None else None, _stream()), "gjx_trials_lse_pick")
+    return lse, pick
+
+
 def weight_cumsum(x: torch.Tensor, is_log=False, lse=None, ws=None, out=None, partials=None, lse_out=None, K_total=None,
                   pairs=None):
     """-> (cum uint64[K] as int64 payload, base_total int64[2] = {0, total}).

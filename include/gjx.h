@@ -284,6 +284,15 @@ int gjx_logsumexp(const float* x, int64_t K, int64_t K_total, float* out, void* 
 int gjx_lse_combine(const float* pairs /*[G][2]*/, int G, int64_t K_total, float* out,
                     void* stream);
 
+/* ---- independent trials in one launch: jax.vmap(alg.run_smc / alg.random_weighted)(jax.random.split(key, n)) of the
+ * reference's README (README.md:108-113).  Trial t owns the global particle indices [particle_offset + t K,
+ * particle_offset + (t + 1) K) of ONE n K-particle run of gjx_run_program (so trial t is exactly the K_local = K shard at
+ * that offset of the sharded run, normalised on its own): lse_out f32[n_trials][4] = {max, sumexp, lse, lse - log K} per
+ * trial; pick_out (or NULL) int32[n_trials] = the trial's 1-of-K draw as a GLOBAL index, by the rule of
+ * gjx_categorical_pick (smc.py:102-109) with that trial's offset. */
+int gjx_trials_lse_pick(const float* logw, int64_t n_trials, int64_t K, int64_t particle_offset, uint32_t key0,
+                        uint32_t key1, int32_t rng_mode, float* lse_out, int32_t* pick_out, void* stream);
+
 /* ---- measurement aid (bench.py's roofline figure): HIP events attached to the dispatch of the NEXT fused
  * propagate+reweight kernel that gjx_run_program launches from the calling thread, so that the kernel's own begin
  * and end are timed inside a running loop (an event pair recorded around the call also times the dispatch hand-offs

@@ -139,6 +139,48 @@ class TestSMC:
         est = f(ImportanceK(Target(model, (), C["v"].set(True)), k_particles=1 << 16).log_marginal_likelihood_estimate(genjax.key(2)))
         assert est == pytest.approx(math.log(0.5), rel=1e-2)
 
+    def test_readme_trials_in_one_launch(self):
+        """reference README.md:108-116: jax.vmap(alg.random_weighted)(split(key, 50), target) — here random_weighted_trials:
+        the 50 trials are the K-particle shards of one 2500-particle run.  (1) every trial equals the sharded run_smc at its
+        offset bit for bit, its LSE record and its 1-of-K draw equal the oracle's; (2) the README's estimates."""
+        import torch
+        from oracle import cpu as oracle
+
+        @genjax.gen
+        def model():
+            p = genjax.beta(2.0, 2.0) @ "p"
+            v = genjax.flip(p) @ "v"
+            return v
+
+        n, K = 50, 50
+        for obs, want in ((True, 0.6039314), (False, 0.3679334)):      # the reference's printed estimates (README.md:121)
+            target = Target(model, (), C["v"].set(obs))
+            alg = ImportanceK(target, k_particles=K)
+            key = genjax.key(314159)
+            tc = alg.run_smc_trials(key, n)
+            lw = tc.get_log_weights().cpu().numpy()
+            assert lw.shape == (n, K)
+            big = ImportanceK(target, k_particles=n * K)
+            k_pick = genjax.key(7)
+            picked = tc.sample_particles(k_pick)
+            lse = tc.lse().cpu().numpy()
+            for t in (0, 1, 17, 49):
+                shard = big.run_smc(key, offset=t * K, K_local=K)
+                np.testing.assert_array_equal(shard.get_log_weights().cpu().numpy(), lw[t])
+                want_lse = oracle.logsumexp(lw[t])
+                np.testing.assert_allclose(lse[t], want_lse, rtol=2e-6, atol=2e-6)
+                _, idx = oracle.categorical_pick(lw[t], lse[t], k_pick, tc.particles.prog.rng_mode, offset=t * K)
+                assert f(picked.get_choices()["p"][t]) == f(tc.particles.get_choices()["p"][idx])
+                assert f(tc.trial(t).get_log_marginal_likelihood_estimate()) == pytest.approx(float(want_lse[3]), abs=1e-5)
+            est, p_chm = alg.random_weighted_trials(key, n, target)
+            assert est.shape == (n,) and "p" in p_chm and "v" not in p_chm
+            ps = p_chm["p"].cpu().numpy()
+            assert ps.shape == (n,) and np.isfinite(est.cpu().numpy()).all()
+            assert ps.mean() == pytest.approx(want, abs=3 * 0.2 / math.sqrt(n))
+            # many trials: the mean of the SIR draws is the posterior mean of p, 3/5 or 2/5
+            _, many = alg.random_weighted_trials(genjax.key(5), 20_000, target)
+            assert f(many["p"].mean()) == pytest.approx(0.6 if obs else 0.4, abs=5e-3)
+
     def test_particle_collection_api(self):
         @genjax.gen
         def model():

@@ -403,9 +403,9 @@ def test_resampling_fuzz_against_oracle(K_, oracle):
     """Randomised shapes and weight patterns (zeros, a few giants, many ties, subnormal-scale weights, N != K) through
     the one-launch resampler and the gather, against the oracle's integer arithmetic: bit-exact every time."""
     import torch
-    rs = np.random.default_rng(2024)
+    rs = np.random.default_rng(int(os.environ.get("GJX_FUZZ_SEED", "2024")))
     ws = {}
-    for trial in range(70):
+    for trial in range(int(os.environ.get("GJX_FUZZ_TRIALS", "70"))):
         K = int(rs.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097, 33_333, 131_072, 262_145]))
         kind = trial % 7
         if kind == 0:
@@ -1091,9 +1091,9 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
     run on the engine the library picks (a kernel generated for the program, compiled on the spot), odd trials on the site
     interpreter (which also halves the time the test spends in hipRTC)."""
     import torch
-    rs = np.random.default_rng(77 + rng)
+    rs = np.random.default_rng(int(os.environ.get("GJX_FUZZ_SEED", "77")) + rng)
     K = 600
-    for trial in range(40):
+    for trial in range(int(os.environ.get("GJX_FUZZ_TRIALS", "40"))):
         if trial & 1:
             monkeypatch.setenv("GJX_ENGINE", "interp")
         else:
@@ -1103,6 +1103,21 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
         key = (int(rs.integers(1 << 30)), int(rs.integers(1 << 30)))
         g, o = _run_both(K_, oracle, prog, key, K, want_site_scores=True)
         fin = np.isfinite(o["score"]) & (np.abs(o["score"]) < 1e4)
+        # float32 conditioning of the particle: (1) a draw in the denormal range (the device flushes it to zero, the oracle's
+        # libm does not); (2) a score that the oracle itself moves by more than the tolerance when its continuous inputs move
+        # by a few ulps — a parameter like exp(13) makes a log-density a difference of terms of 1e6 whose last bit is 0.25
+        # (found by profiles/fuzz.sh, seeds 1001 / 1002)
+        cont_sites = [s_ for s_ in sl.sites if s_.kind not in A.NO_GRADIENT_KINDS and s_.kind not in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS)]
+        denorm = ((o["choices"] != 0) & (np.abs(o["choices"]) < 1.2e-38)).any(axis=0)
+        prog_c = PackedProgram(sl, {s_.addr: A.MODE_OBS_SLOT for s_ in sl.sites}, rng_mode=rng)
+        ch_p = o["choices"].copy()
+        for s_ in cont_sites:
+            ch_p[prog_c.slot_of[s_.addr]:prog_c.slot_of[s_.addr] + s_.dim] *= np.float32(1.0 + 2e-6)
+        s_a = oracle.run_program(prog_c, key, K, choices=o["choices"].copy())["score"]
+        s_b = oracle.run_program(prog_c, key, K, choices=ch_p)["score"]
+        with np.errstate(invalid="ignore"):
+            fin &= ~denorm & (np.abs(s_b - s_a) <= 5e-4 + 5e-4 * np.abs(s_a))
+        assert fin.mean() > 0.3, f"trial {trial}: {fin.mean():.2f} of the particles are well conditioned"
         ok = _close_cols(g["choices"], o["choices"], rt=1e-3, at=5e-4) & _close_cols(g["score"][None], o["score"][None], rt=2e-3, at=2e-3)
         assert_near_ties_only(~ok & fin, o, f"trial {trial} ({[A.KIND_NAMES[s.kind] for s in sl.sites]})")
         # analytic gradients of the same program at the oracle's draws (every site constrained, float sites selected)
@@ -1123,7 +1138,7 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
         o2 = oracle.run_program(prog2, key, K, choices=ch.copy(), want_site_scores=True)
         idx = [j for j, s in enumerate(sl.sites) if s.addr in sub]
         gs, os_ = _np(g2["site_scores"])[idx], o2["site_scores"][idx]
-        good = np.isfinite(os_) & (np.abs(os_) < 1e4)
+        good = np.isfinite(os_) & (np.abs(os_) < 1e4) & fin[None, :]
         np.testing.assert_allclose(gs[good], os_[good], rtol=2e-3, atol=2e-3, err_msg=f"trial {trial}")
         for a in sub:
             s0 = prog2.slot_of[a]
