@@ -885,6 +885,31 @@ def run_round3(dev):
             del os.environ["GJX_ENGINE"]
     row["speedup"] = row["us_interp"] / row["us_gen"]
     res["scan_trace_assess_T256"] = dict(k_particles=Ka, note="every x_t constrained to the particle's own value (OBS_SLOT): rolled generated kernel vs site interpreter", **row)
+    # (4) BASELINE configs[0] (README quick example: 50 SIR trials x K = 50 through random_weighted): one call per trial vs
+    # all trials as the shards of one launch (ImportanceK.random_weighted_trials), and the same at 4096 trials
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMap as Cm
+
+    @genjax.gen
+    def beta_bernoulli():
+        p = genjax.beta(2.0, 2.0) @ "p"
+        v = genjax.flip(p) @ "v"
+        return v
+
+    target = genjax.Target(beta_bernoulli, (), Cm.d({"v": True}))
+    alg = genjax.ImportanceK(target, k_particles=50)
+    k0 = genjax.key(314159)
+
+    def loop50(i):
+        return [alg.random_weighted(sk, target) for sk in genjax.split(genjax.fold_in(k0, i), 50)]
+
+    tr = dict(note="beta_bernoulli, K = 50 particles per trial, wall time of the Python call incl. trace bookkeeping")
+    tr["us_50_trials_one_call_each"] = timed(loop50, n=3)
+    tr["us_50_trials_one_launch"] = timed(lambda i: alg.random_weighted_trials(genjax.fold_in(k0, i), 50, target), n=30)
+    tr["us_4096_trials_one_launch"] = timed(lambda i: alg.random_weighted_trials(genjax.fold_in(k0, i), 4096, target), n=30)
+    _, pch = alg.random_weighted_trials(k0, 4096, target)
+    tr["posterior_mean_p_4096_trials"] = float(pch["p"].mean())
+    res["readme_trials"] = tr
     return res
 
 
