@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_trials_lse_pick(const float* logw, int6
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w) pick_better(bv, bi, rv[w], ri[w]);
-    pick_out[t] = bi;
+    pick_out[t] = bi == 0x7FFFFFFF ? (int32_t)(offset + t * K) : bi;   // a dead trial (all weights zero, lse = -inf): its first particle
   }
 }
 

@@ -289,7 +289,8 @@ int gjx_lse_combine(const float* pairs /*[G][2]*/, int G, int64_t K_total, float
  * particle_offset + (t + 1) K) of ONE n K-particle run of gjx_run_program (so trial t is exactly the K_local = K shard at
  * that offset of the sharded run, normalised on its own): lse_out f32[n_trials][4] = {max, sumexp, lse, lse - log K} per
  * trial; pick_out (or NULL) int32[n_trials] = the trial's 1-of-K draw as a GLOBAL index, by the rule of
- * gjx_categorical_pick (smc.py:102-109) with that trial's offset. */
+ * gjx_categorical_pick (smc.py:102-109) with that trial's offset (a trial whose weights are all zero: lse = -inf, and the
+ * index of its first particle). */
 int gjx_trials_lse_pick(const float* logw, int64_t n_trials, int64_t K, int64_t particle_offset, uint32_t key0,
                         uint32_t key1, int32_t rng_mode, float* lse_out, int32_t* pick_out, void* stream);
 
