@@ -317,6 +317,18 @@ GJX_DEV float gumbel_from_bits(uint32_t bits) {
   return -fast_log(-safe_log(u));
 }
 
+// digamma(x + 1/2) - digamma(x) without the cancellation of two digamma calls (the student-t's d/d(df) at large df: the two
+// values agree to all 24 bits from df ~ 1e7 on, and the gradient would keep a spurious -1/(2 df)): recurrence up to x >= 8
+// — every term 1 / (2 (x + k)(x + k + 1/2)) is positive — then 1/(2x) + 1/(8x^2) - 1/(64x^4) + 1/(128x^6); relative error < 2e-7
+GJX_DEV float digamma_half_step(float x) {
+  float acc = 0.0f;
+  for (int k = 0; k < 8; ++k) {
+    if (x < 8.0f) { acc += 0.5f * fast_rcp(x * (x + 0.5f)); x += 1.0f; }
+  }
+  const float r = fast_rcp(x), r2 = r * r;
+  return acc + r * (0.5f + r * (0.125f + r2 * (-0.015625f + r2 * 0.0078125f)));
+}
+
 // digamma: recurrence up to x >= 6, then the asymptotic series (|error| < 1e-6 for x > 1e-3)
 GJX_DEV float digamma_f(float x) {
   float acc = 0.0f;
@@ -750,7 +762,7 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
       const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
       dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc;
       da = -0.5f * log1p_acc(y * y * fast_rcp(a)) + 0.5f * (a + 1.0f) * y * y * fast_rcp(a * (a + y * y)) - 0.5f * fast_rcp(a) +
-           0.5f * (digamma_f(0.5f * (a + 1.0f)) - digamma_f(0.5f * a));
+           0.5f * digamma_half_step(0.5f * a);
       done(); return;
     }
     case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
