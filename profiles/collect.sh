@@ -67,6 +67,7 @@ for k, v in res.items():
 json.dump(util, open("$OUT/${TAG}_valu_utilisation.json", "w"), indent=1)
 PY
 fi
+if echo $WL | grep -q hmc; then bash $R/profiles/hmc_pmc.sh $TAG > /dev/null 2>&1; fi
 GJX_SSM_PERSISTENT=0 python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
 python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_ssm_persistent_timeline.txt
 SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
