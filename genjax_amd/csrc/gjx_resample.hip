@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_pick_finish(const PickPair* partials, i
 // n K-particle run.  One block per trial: its LSE record {max, sumexp, lse, lse - log K} and, if asked, its 1-of-K draw
 // argmax_i (logw_i - lse_t) + Gumbel(bits(key, global index)) — the same rule as k_pick_partial with particle_offset = t K.
 template <int RNG>
-__global__ __launch_bounds__(256) void k_trials_lse_pick(const float* logw, int64_t K, int64_t offset, key2 key, int want_pick,
+__global__ __launch_bounds__(256) void k_trials_lse_pick(const float* logw, int64_t K, int64_t offset, key2 key, int want_pick, float log_k,
                                                         float* lse_out, int32_t* pick_out) {
   __shared__ float red[8];
   __shared__ float rv[4];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_trials_lse_pick(const float* logw, int6
   const float l = bm > -INFINITY ? bm + fast_log(bs) : -INFINITY;
   if (threadIdx.x == 0) {
     float* o = lse_out + 4 * t;
-    o[0] = bm; o[1] = bs; o[2] = l; o[3] = l - (float)log((double)K);
+    o[0] = bm; o[1] = bs; o[2] = l; o[3] = l - log_k;
   }
   if (!want_pick) return;
   float bv = -INFINITY;
@@ -1003,12 +1003,13 @@ extern "C" int gjx_trials_lse_pick(const float* logw, int64_t n_trials, int64_t 
       (pick_out && particle_offset + n_trials * K > 0x7fffffffLL))
     return gjx_fail(GJX_EINVAL, "gjx_trials_lse_pick: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  const float log_k = (float)log((double)K);
   if (rng_mode == GJX_RNG_JAX32)
     hipLaunchKernelGGL(k_trials_lse_pick<GJX_RNG_JAX32>, dim3((unsigned)n_trials), dim3(256), 0, st, logw, K, particle_offset, key2{key0, key1},
-                       pick_out ? 1 : 0, lse_out, pick_out);
+                       pick_out ? 1 : 0, log_k, lse_out, pick_out);
   else
     hipLaunchKernelGGL(k_trials_lse_pick<GJX_RNG_FLAT>, dim3((unsigned)n_trials), dim3(256), 0, st, logw, K, particle_offset, key2{key0, key1},
-                       pick_out ? 1 : 0, lse_out, pick_out);
+                       pick_out ? 1 : 0, log_k, lse_out, pick_out);
   GJX_CHECK_LAUNCH("gjx_trials_lse_pick");
   return GJX_OK;
 }

@@ -229,6 +229,16 @@ class TestSMC:
         lw = pc.get_log_weights()
         assert f(lw.std()) < 0.02                              # near-optimal proposal: almost constant weights
         assert f(pc.get_log_marginal_likelihood_estimate()) == pytest.approx(exact, abs=2e-3)
+        # the same algorithm as 64 independent trials of 256 particles in one launch: every trial is the shard of the
+        # 64 * 256-particle run at its offset, and every trial's estimate is the exact evidence (a near-optimal proposal)
+        alg = ImportanceK(target, q=proposal, k_particles=256)
+        tc = alg.run_smc_trials(genjax.key(3), 64)
+        big = ImportanceK(target, q=proposal, k_particles=64 * 256)
+        for t in (0, 63):
+            shard = big.run_smc(genjax.key(3), offset=t * 256, K_local=256)
+            np.testing.assert_array_equal(shard.get_log_weights().cpu().numpy(), tc.get_log_weights()[t].cpu().numpy())
+        est = tc.get_log_marginal_likelihood_estimates().cpu().numpy()
+        assert est.shape == (64,) and np.abs(est - exact).max() < 5e-3
 
     def test_change_target_and_csmc(self):
         @genjax.gen
