@@ -205,16 +205,20 @@ class BootstrapFilter:
     """SMC with the prior as proposal and systematic resampling before every propagate step."""
 
     def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None, rejuvenate: dict | None = None,
-                 weights: str = "global_max"):
+                 weights: str | None = None):
         """``rejuvenate=dict(n_moves=.., scale=..)``: resample-move — after every resampling each particle takes n_moves
         random-walk Metropolis steps (proposal scale ``scale``) that leave p(x_{t-1} | parent, y_{t-1}) invariant, fused
         into the propagate kernel (gjx_ssm_step_move).
         ``weights``: fixed-point scheme of the systematic resampler (include/gjx.h): ``"global_max"`` quantises every
         weight against the exact global maximum, ``"tile_scaled"`` against a power of two per 1024-particle tile — one
-        grid-wide exchange per step instead of two in the one-launch filter (one GPU, no rejuvenation)."""
-        if weights not in ("global_max", "tile_scaled"):
+        grid-wide exchange per step instead of two in the one-launch filter, resample-move inside the launch, and the
+        peer-mapped exchange when sharded.  Default (None): tile-scaled wherever that path exists, i.e. everywhere except a
+        sharded run that cannot use the peer-mapped exchange (keep_means / step_by_step, ranks that are not peers, shards that
+        are not whole tiles), which runs the global-maximum scheme over the collective transport."""
+        if weights not in (None, "global_max", "tile_scaled"):
             raise ValueError("weights must be 'global_max' or 'tile_scaled'")
-        self.weights = A.WEIGHTS_TILE_SCALED if weights == "tile_scaled" else A.WEIGHTS_GLOBAL_MAX
+        self._auto_weights = weights is None
+        self.weights = A.WEIGHTS_GLOBAL_MAX if weights == "global_max" else A.WEIGHTS_TILE_SCALED
         self.ssm, self.K = ssm, int(k_particles)
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
@@ -272,6 +276,23 @@ class BootstrapFilter:
             step_by_step: bool = False, keep_history: bool = False, check_status: bool = True):
         """-> dict(log_ml 0-d device tensor, increments f32[T], x f32[dx][K_local], logw, means?, degenerate?).
         With world > 1 the K particles are sharded (distributed.py) and ``ys`` is the same on all ranks."""
+        from .. import kernels
+        from .. import distributed as D
+        if self._auto_weights and (world > 1 or D._forced()):
+            # default scheme, sharded: tile-scaled only where the peer-mapped filter can run (the test is rank-symmetric)
+            dev_ = kernels._dev(device)
+            T_ = ys.shape[0] if hasattr(ys, "shape") else len(ys)
+            peer_ok = (not keep_means and not step_by_step and not keep_history and T_ >= 2 and self.K % world == 0
+                       and (self.K // world) % 1024 == 0 and D.peer_available(dev_))
+            if not peer_ok and not self.rejuvenate:
+                self.weights = A.WEIGHTS_GLOBAL_MAX
+                try:
+                    return self._run(key, ys, device, rank, world, keep_means, step_by_step, keep_history, check_status)
+                finally:
+                    self.weights = A.WEIGHTS_TILE_SCALED
+        return self._run(key, ys, device, rank, world, keep_means, step_by_step, keep_history, check_status)
+
+    def _run(self, key: Key, ys, device, rank, world, keep_means, step_by_step, keep_history, check_status):
         from .. import kernels
         from .. import distributed as D
         dev = kernels._dev(device)

@@ -574,7 +574,7 @@ def test_bootstrap_filter_full_size(K_, golden):
     exact = golden["closed_form"]["ssm_dx8_T256_seed0"]
     kl, incs, means = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
     assert kl == pytest.approx(exact, rel=1e-12)
-    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18, weights="global_max")
     out = bf.run(core.key(1), s["y"], keep_means=True)
     assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
     np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
@@ -613,7 +613,7 @@ def test_native_filter_loop_equals_step_by_step(K_):
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
     s = cf.ssm_problem(T=40)
     for rng in RNGS:
-        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 10_000, rng_mode=rng)
+        bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 10_000, rng_mode=rng, weights="global_max")
         a = bf.run(core.key(7), s["y"])
         b = bf.run(core.key(7), s["y"], step_by_step=True)
         np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=2e-6, atol=2e-6)   # LSE finish order differs
@@ -1000,13 +1000,18 @@ def _rccl_one_rank_body(port, q):
     from genjax_amd import core, workloads
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
     s = workloads.ssm_problem(T=24)
-    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 14)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 14, weights="global_max")
     os.environ["GJX_FORCE_DIST"] = "0"
     a = bf.run(core.key(5), s["y"])
     os.environ["GJX_FORCE_DIST"] = "1"
     b = bf.run(core.key(5), s["y"])
     c = bf.run(core.key(5), s["y"], step_by_step=True)          # same exchange, one host call per stage
     assert torch.equal(b["x"], c["x"]) and torch.allclose(b["increments"], c["increments"], rtol=2e-6, atol=1e-6)
+    # the default scheme, sharded, with an option the peer-mapped filter does not have: global maximum over the collective
+    # transport instead of an error
+    d = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 14).run(core.key(5), s["y"], keep_means=True)
+    e = bf.run(core.key(5), s["y"], keep_means=True)
+    assert torch.equal(d["x"], e["x"]) and torch.equal(d["means"], e["means"])
     filt = (a["increments"].cpu().numpy(), b["increments"].cpu().numpy(), bool(torch.equal(a["x"], b["x"])), bf._resampler.transport)
     q.put((res.transport, bool(torch.equal(got, want)), rec.cpu().numpy(), local.cpu().numpy(), res.ctx.last_info, filt))
     res.close()

@@ -21,7 +21,7 @@ def test_ancestor_history_reconstructs_smoothed_trajectories():
     from oracle import closed_form as cf
     s = workloads.ssm_problem(dx=4, T=12, r=2.0)
     K = 1 << 18
-    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights="global_max")
     out = bf.run(core.key(3), s["y"], keep_history=True)
     h = out["history"]
     assert len(h) == 12 and len(h.ancestors) == 11
@@ -85,8 +85,8 @@ def test_resample_move_filter_keeps_the_estimate_and_restores_diversity():
     s = workloads.ssm_problem(dx=4, T=24, r=0.7)         # informative observations: heavy resampling
     K = 1 << 16
     exact, _, means = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
-    plain = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K)
-    moved = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, rejuvenate=dict(n_moves=2, scale=0.35))
+    plain = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, weights="global_max")
+    moved = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, rejuvenate=dict(n_moves=2, scale=0.35), weights="global_max")
     a = plain.run(core.key(9), s["y"], keep_means=True, keep_history=True)
     b = moved.run(core.key(9), s["y"], keep_means=True, keep_history=True)
     for out in (a, b):

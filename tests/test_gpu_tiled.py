@@ -201,10 +201,26 @@ def test_tiled_filter_close_to_global_max_filter(K_):
     K = 1 << 16
     m = LinearGaussianSSM(s["A"], s["q"], s["r"])
     a = BootstrapFilter(m, K, weights="tile_scaled").run(core.key(3), s["y"])
-    b = BootstrapFilter(m, K).run(core.key(3), s["y"])
+    b = BootstrapFilter(m, K, weights="global_max").run(core.key(3), s["y"])
     same = (_np(a["x"]) == _np(b["x"])).all(axis=0)
     assert same.mean() > 0.995
     np.testing.assert_allclose(_np(a["increments"]), _np(b["increments"]), rtol=1e-3, atol=1e-3)
+
+
+def test_default_weights_are_the_tile_scaled_paths(K_):
+    """BootstrapFilter() without a scheme runs the tile-scaled one-launch filter (also with resample-move), bit for bit what
+    weights="tile_scaled" runs (the sharded side of the default: test_gpu_parity's one-rank RCCL worker)."""
+    from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
+    s = cf.ssm_problem(T=12)
+    m = LinearGaussianSSM(s["A"], s["q"], s["r"])
+    K = 1 << 15
+    for rej in (None, dict(n_moves=1, scale=0.4)):
+        a = BootstrapFilter(m, K, rejuvenate=rej).run(core.key(3), s["y"])
+        b = BootstrapFilter(m, K, rejuvenate=rej, weights="tile_scaled").run(core.key(3), s["y"])
+        c = BootstrapFilter(m, K, rejuvenate=rej, weights="global_max").run(core.key(3), s["y"])
+        np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
+        np.testing.assert_array_equal(_np(a["increments"]), _np(b["increments"]))
+        assert not np.array_equal(_np(a["x"]), _np(c["x"]))
 
 
 def test_tiled_bootstrap_filter_full_size(K_):
