@@ -72,7 +72,7 @@ def cpu_baseline_gmm(prog, K, budget_s=12.0):
             if dt > budget or reps >= 64:
                 return reps, dt
 
-    threads = cpu.num_threads()
+    threads = baseline_threads(cpu)
     reps, dt = run(budget_s)
     cpu.set_threads(1)
     K1 = min(K, 1 << 17)
@@ -84,14 +84,41 @@ def cpu_baseline_gmm(prog, K, budget_s=12.0):
     cpu.set_threads(threads)
     return dict(value=K * reps / dt, unit="particle-steps/s", cores=threads, kind="port",
                 sample=f"{reps} steps of K=2^{int(math.log2(K))} particles of the same workload on {threads} OpenMP threads "
-                       "(all stages parallel)",
+                       f"(all stages parallel; {usable_cpus()} usable CPUs: affinity mask capped by the cgroup quota)",
                 single_thread=dict(value=K1 / dt1, unit="particle-steps/s", cores=1, sample=f"1 step of K=2^{int(math.log2(K1))}"))
+
+
+def usable_cpus() -> int:
+    """CPUs this process can actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows 256 logical
+    CPUs and grants 16 CPUs of time: 128 OpenMP threads there run 2.5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                 # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def baseline_threads(cpu) -> int:
+    """OpenMP threads of the CPU baseline = usable CPUs (never more than the runtime's own default)"""
+    n = max(1, min(usable_cpus(), cpu.num_threads()))
+    cpu.set_threads(n)
+    return n
 
 
 def cpu_baseline_ssm(s, K, T, budget_s=12.0):
     from genjax_amd import core
     from oracle import cpu
-    threads = cpu.num_threads()
+    threads = baseline_threads(cpu)
     t0 = time.perf_counter()
     key = core.key(1)
     x = lw = lse = None
@@ -114,7 +141,7 @@ def cpu_baseline_ssm(s, K, T, budget_s=12.0):
 
 def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
     from oracle import cpu
-    threads = cpu.num_threads()
+    threads = baseline_threads(cpu)
     n = max(threads * 4, 256)
     ch = (np.random.default_rng(0).standard_normal((P + 1, n)) * 0.1).astype(np.float32)
     Lc = min(L, 50)
