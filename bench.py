@@ -279,7 +279,7 @@ def run_gmm(args, rank, world, dev):
 
     # One-off costs that belong to neither W nor the timed region: RCCL sets up channels lazily per collective, and
     # the HIP runtime grows its signal / kernel-argument pools the first time the launch queue gets deep — a single
-    # 35-45 ms host stall inside one launch call (scratch/hiccup.py), 2-3x the whole default timed region.  A deep
+    # 35-45 ms host stall inside one launch call (seen with a per-call timer around the launches), 2-3x the whole default timed region.  A deep
     # un-synchronised burst here triggers it before the clock starts.
     for i in range(300):
         step(i, False)

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(THREADS) void k_run_gmm(GmmArgs a) {
 // ------------------------------------------------------------------------------------------
 // fused mixture kernel, FLAT stream (the headline kernel of BASELINE config 2)
 //
-// What bounds it (measured on MI355X, scratch/ub4.hip, whole-SIMD throughput in shader cycles per wave-instruction):
+// What bounds it (measured on MI355X, profiles/microbench/ub4.hip, whole-SIMD throughput in shader cycles per wave-instruction):
 // v_add/xor/sub/and/or/lshr/mov and fp32 add/mul/fma 2.3; every VOP3 integer op, v_lshlrev, v_max_f32, v_cvt, v_cmp,
 // v_pk_* and any VOP2 with an SGPR source 4.2; v_log/exp/sqrt/rcp/sin/cos 8.3; and a stream that alternates the two
 // integer classes pays ~2.3 extra per Threefry round: one Threefry-2x32-20 hash = 272 cycles however it is ordered,
