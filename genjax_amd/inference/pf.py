@@ -55,8 +55,11 @@ def _unit_from_key(k: Key) -> float:
 
 
 def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "systematic", lse=None, n_out=None,
-             check: bool = False, collection=None, weights: str = "global_max"):
+             check: bool = False, collection=None, weights: str | None = None):
     """N-of-K resampling of SoA rows by log-weights.  -> (new_rows, ancestors int32[N]).
+    ``weights`` picks the fixed-point scheme of include/gjx.h; default: ``"global_max"`` (weights -> ancestors -> children in
+    one co-resident launch) up to K = 2^20, ``"tile_scaled"`` beyond, where that launch no longer fits the device and the
+    global-maximum scheme would take three launches (K = 2^21: 104 vs 127 us per ImportanceK step).
     ``weights="tile_scaled"`` (systematic, N = K): the tile-scaled fixed point of include/gjx.h through
     gjx_resample_gather_tiled — ONE plain launch at any K (no co-resident grid, nothing to time out), the tile totals
     taken from the collection's producing run when it left them.
@@ -68,6 +71,8 @@ def resample(rows: torch.Tensor, logw: torch.Tensor, key: Key, method: str = "sy
     from .. import kernels
     K = logw.numel()
     N = int(n_out or K)
+    if weights is None:
+        weights = "tile_scaled" if (K > (1 << 20) and method == "systematic" and N == K and rows.stride(1) == 1) else "global_max"
     if weights not in ("global_max", "tile_scaled"):
         raise ValueError("weights must be 'global_max' or 'tile_scaled'")
     if weights == "tile_scaled":

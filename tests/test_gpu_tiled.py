@@ -325,6 +325,12 @@ def test_api_resample_with_tile_scaled_weights(K_):
     assert torch.equal(anc, want) and torch.equal(out, K_.gather_rows(rows, want))
     with pytest.raises(ValueError):
         pf.resample(rows, lw, key, weights="tile_scaled", n_out=K // 2)
+    # without a scheme: tile-scaled above 2^20 (where the co-resident launch does not fit), global maximum up to there
+    out_d, anc_d = pf.resample(rows, lw, key)
+    assert torch.equal(anc_d, want) and torch.equal(out_d, out)
+    Ks = 1 << 16
+    out_s, anc_s = pf.resample(rows[:, :Ks].contiguous(), lw[:Ks].contiguous(), key)
+    assert torch.equal(anc_s, K_.resample_indices(lw[:Ks].contiguous(), pf._unit_from_key(key), Ks, lse=K_.logsumexp(lw[:Ks].contiguous(), Ks)))
 
     @genjax.gen
     def model():
