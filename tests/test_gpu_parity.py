@@ -1154,12 +1154,20 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
         s_b = oracle.run_program(prog_c, key, K, choices=ch_p)["score"]
         with np.errstate(invalid="ignore"):
             fin &= ~denorm & (np.abs(s_b - s_a) <= 5e-4 + 5e-4 * np.abs(s_a))
-        assert fin.mean() > 0.3, f"trial {trial}: {fin.mean():.2f} of the particles are well conditioned"
+            if loose:
+                # campaign mode also keeps to moderate draws: a value of 15 behind an exp() transform is a parameter of 3e6, and
+                # a log-density built from terms of 1e7 is piecewise constant in float32 (steps of 0.25: the perturbation test
+                # above does not see it)
+                cs = np.concatenate([np.arange(prog_c.slot_of[s_.addr], prog_c.slot_of[s_.addr] + s_.dim) for s_ in cont_sites]) if cont_sites else np.zeros(0, int)
+                if cs.size:
+                    v_ = np.abs(o["choices"][cs])
+                    fin &= (v_ < 8.0).all(axis=0) & ((v_ > 1e-4) | (v_ == 0)).all(axis=0)
+        assert fin.mean() > (0.05 if loose else 0.3), f"trial {trial}: {fin.mean():.2f} of the particles are well conditioned"
         ok = _close_cols(g["choices"], o["choices"], rt=1e-3, at=5e-4) & _close_cols(g["score"][None], o["score"][None], rt=2e-3, at=2e-3)
         miss = ~ok & fin
         if loose and 0 < (miss & (o["margin"] >= NEAR_TIE)).sum() <= 2:
             miss &= o["margin"] < NEAR_TIE
-        assert_near_ties_only(miss, o, f"trial {trial} ({[A.KIND_NAMES[s.kind] for s in sl.sites]})")
+        assert_near_ties_only(miss, o, f"trial {trial} ({[A.KIND_NAMES[s.kind] for s in sl.sites]})", cap=0.02 if loose else 0.005)
         # analytic gradients of the same program at the oracle's draws (every site constrained, float sites selected)
         sel = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS and s.kind not in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS))
         if sel:
