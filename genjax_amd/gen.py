@@ -16,15 +16,14 @@ Trace holds choices[n_slots][K] on the device; K == 1 is the un-vmapped case.
 """
 from __future__ import annotations
 
-import math
 import warnings
 from typing import Any, Callable, Sequence
 
 import numpy as np
 
 from . import _abi as A
-from .core import ChoiceMap, Key, Masked, Selection, _VALUE, fold_in, split
-from .program import AddressReuse, MissingAddress, PackedProgram, Param, SiteList
+from .core import ChoiceMap, Key, Masked, Selection, _VALUE, split
+from .program import MissingAddress, PackedProgram, Param, SiteList
 
 __all__ = [
     "gen", "StaticGenerativeFunction", "Trace", "Distribution", "take", "where", "cond", "const", "exp",

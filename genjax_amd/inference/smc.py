@@ -13,8 +13,7 @@ from typing import Any
 
 import numpy as np
 
-from .. import _abi as A
-from ..core import ChoiceMap, Key, fold_in, split
+from ..core import ChoiceMap, Key, split
 from ..gen import GenerativeFunction, Marginal, Trace
 
 

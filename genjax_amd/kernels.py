@@ -5,7 +5,6 @@ Every function launches asynchronously on torch's current HIP stream and returns
 from __future__ import annotations
 
 import ctypes as C
-import math
 import time
 
 import torch
