@@ -214,6 +214,26 @@ class Selection:
     def __call__(self, addr) -> bool:
         return self.check(addr)
 
+    def __getitem__(self, addr) -> bool:
+        """``sel["x"]``, ``sel["z", "y"]``: is the address selected (choice_map.py:262-290)"""
+        return True if addr == () and self.complement and not self.addrs else (False if addr == () else self.check(addr))
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, Selection) and self.addrs == other.addrs and self.complement == other.complement
+
+    def __hash__(self) -> int:
+        return hash((self.addrs, self.complement))
+
+    def extend(self, *addrs) -> "Selection":
+        """the same selection below the path ``addrs`` (choice_map.py:291-318); ``none`` stays ``none``"""
+        if not self.addrs and not self.complement:
+            return self
+        return self.prefixed(tuple(addrs))
+
+    def filter(self, chm: "ChoiceMap") -> "ChoiceMap":
+        """``sel.filter(chm)`` == ``chm.filter(sel)`` (choice_map.py:319-361)"""
+        return chm.filter(self)
+
     def __invert__(self) -> "Selection":
         return Selection(self.addrs, not self.complement)
 
@@ -235,6 +255,14 @@ class Selection:
 class _SelectionBuilder:
     def __getitem__(self, addr) -> Selection:
         return Selection.at[addr]
+
+    @property
+    def all(self) -> Selection:
+        return Selection.all()
+
+    @property
+    def none(self) -> Selection:
+        return Selection.none()
 
 
 SelectionBuilder = S = _SelectionBuilder()
@@ -260,6 +288,37 @@ class ChoiceMapNoValueAtAddress(KeyError):
 _VALUE = ()  # address of a bare value (C.v(x)), as in the reference's `()` address
 
 
+def _rekey(prefix: tuple, key):
+    """the canonical key of ``key`` seen below the path ``prefix`` (a tuple of strings)"""
+    if isinstance(key, tuple) and key == ():
+        name, idx = (), None
+    else:
+        name, idx = norm_addr(key)
+        name = name if isinstance(name, tuple) else (name,)
+    full = tuple(prefix) + name
+    if not full:
+        return _VALUE
+    k = full[0] if len(full) == 1 else full
+    return k if idx is None or _has_all(idx) else (k, idx)
+
+
+def _flat_into(out: dict, prefix: tuple, value) -> None:
+    """nested dictionaries and choice maps become path keys (choice_map.py `d` / `kw` / `from_mapping`: dict values are
+    converted into choice maps)"""
+    if isinstance(value, dict):
+        for k, v in value.items():
+            name, idx = norm_addr(k) if not (isinstance(k, tuple) and k == ()) else ((), None)
+            if idx is None:
+                _flat_into(out, tuple(prefix) + (name if isinstance(name, tuple) else (name,)), v)
+            else:
+                out[_rekey(prefix, k)] = v
+    elif isinstance(value, ChoiceMap):
+        for k, v in value._d.items():
+            out[_rekey(prefix, k)] = v
+    else:
+        out[_rekey(prefix, ())] = value
+
+
 class ChoiceMap:
     """Static-address choice map: ``{addr: value}`` (choice_map.py:847-1395, Static 1535)."""
 
@@ -276,11 +335,22 @@ class ChoiceMap:
 
     @staticmethod
     def kw(**kwargs) -> "ChoiceMap":
-        return ChoiceMap(kwargs)
+        return ChoiceMap.d(kwargs)
 
     @staticmethod
     def d(entries: dict) -> "ChoiceMap":
-        return ChoiceMap(entries)
+        """nested dictionaries (and choice maps) as values nest below their key (choice_map.py:1023-1056)"""
+        out: dict = {}
+        _flat_into(out, (), entries)
+        return ChoiceMap(out)
+
+    @staticmethod
+    def from_mapping(pairs) -> "ChoiceMap":
+        """``[(addr, value), ...]`` with string or tuple addresses (choice_map.py:1057-1085)"""
+        out: dict = {}
+        for a, v in pairs:
+            _flat_into(out, a if isinstance(a, tuple) else (a,), v)
+        return ChoiceMap(out)
 
     @staticmethod
     def v(value) -> "ChoiceMap":
@@ -292,10 +362,49 @@ class ChoiceMap:
         def __init__(self, base: "ChoiceMap", addr):
             self.base, self.addr = base, addr
 
+        def _path(self) -> tuple | None:
+            """the address as a pure path of strings, or None when it carries an index"""
+            if isinstance(self.addr, tuple) and self.addr == ():
+                return ()
+            name, idx = norm_addr(self.addr)
+            return None if idx is not None else (name if isinstance(name, tuple) else (name,))
+
         def set(self, value) -> "ChoiceMap":
             d = dict(self.base._d)
-            d[key_of(self.addr)] = value.get_value() if isinstance(value, ChoiceMap) and value.has_value() else value
-            return ChoiceMap(d)
+            if isinstance(value, ChoiceMap) and value.has_value():
+                value = value.get_value()
+            pre = self._path()
+            if pre is not None and isinstance(value, (dict, ChoiceMap)):
+                _flat_into(d, pre, value)              # a choice map / dict nests below the address
+            else:
+                d[key_of(self.addr) if self.addr != () else _VALUE] = value
+            return ChoiceMap(d, self.base._lead_axes)
+
+        def v(self, value) -> "ChoiceMap":
+            return self.set(value)
+
+        def n(self) -> "ChoiceMap":
+            return ChoiceMap.empty()
+
+        def d(self, entries: dict) -> "ChoiceMap":
+            return self.set(ChoiceMap.d(entries))
+
+        def kw(self, **kwargs) -> "ChoiceMap":
+            return self.set(ChoiceMap.d(kwargs))
+
+        def from_mapping(self, pairs) -> "ChoiceMap":
+            return self.set(ChoiceMap.from_mapping(pairs))
+
+        def update(self, f) -> "ChoiceMap":
+            """replace what sits at the address by ``f`` of it: of the value for a leaf, of the sub-map otherwise
+            (choice_map.py builder `update`); an empty spot hands ``f`` the empty choice map"""
+            k = key_of(self.addr)
+            if k in self.base._d:
+                return self.set(f(self.base._d[k]))
+            sub = self.base.get_submap(self.addr)
+            pre = self._path() or ()
+            keep = {a: v for a, v in self.base._d.items() if not (a != _VALUE and _starts_with(a, pre))}
+            return ChoiceMap._AtSetter(ChoiceMap(keep, self.base._lead_axes), self.addr).set(f(sub))
 
     class _At:
         def __init__(self, base: "ChoiceMap"):
@@ -370,8 +479,12 @@ class ChoiceMap:
     def __call__(self, addr):
         return self.get_submap(addr)
 
-    def get_submap(self, addr) -> "ChoiceMap":
-        """value at a leaf address, or the choices below a path prefix with the prefix removed"""
+    def get_submap(self, *addr) -> "ChoiceMap":
+        """value at a leaf address, or the choices below a path prefix with the prefix removed; the path may be given as one
+        tuple or splatted (choice_map.py:1170-1202)"""
+        addr = addr[0] if len(addr) == 1 else tuple(addr)
+        if isinstance(addr, tuple) and addr == ():
+            return self
         k = key_of(addr)
         if k in self._d:
             return ChoiceMap.v(self._d[k])
@@ -404,6 +517,25 @@ class ChoiceMap:
 
     __or__ = merge
 
+    def __xor__(self, other: "ChoiceMap") -> "ChoiceMap":
+        """disjoint union: the two maps may not hold a value at the same address (choice_map.py Xor)"""
+        both = set(self._d) & set(other._d)
+        if both:
+            raise ValueError(f"ChoiceMap ^: both sides hold a value at {sorted(map(str, both))}")
+        return self.merge(other)
+
+    def __and__(self, other: "ChoiceMap") -> "ChoiceMap":
+        """the addresses both maps hold, with the RIGHT side's values (choice_map.py And)"""
+        return ChoiceMap({a: v for a, v in other._d.items() if a in self._d}, max(self._lead_axes, other._lead_axes))
+
+    def extend(self, *addrs) -> "ChoiceMap":
+        """the same choices below the path ``addrs`` (choice_map.py:1203-1226)"""
+        return ChoiceMap({_rekey(tuple(addrs), a): v for a, v in self._d.items()}, self._lead_axes)
+
+    def simplify(self) -> "ChoiceMap":
+        """this representation is always flat: nothing to push down (choice_map.py `simplify`)"""
+        return self
+
     def mask(self, flag) -> "ChoiceMap":
         """``chm.mask(flag)`` (choice_map.py Mask).  A scalar flag keeps or drops the choices on the host; a flag per
         particle (length-K array) wraps every value in ``Masked``: the kernels then apply the constrained rule to the
@@ -430,6 +562,12 @@ class ChoiceMap:
         return "ChoiceMap(" + ", ".join(f"{a!r}: {_short(v)}" for a, v in self._d.items()) + ")"
 
 
+def _starts_with(key, pre: tuple) -> bool:
+    name, _ = norm_addr(key)
+    path = name if isinstance(name, tuple) else (name,)
+    return len(path) > len(pre) and path[: len(pre)] == tuple(pre)
+
+
 def _np(v) -> np.ndarray:
     if hasattr(v, "detach"):
         v = v.detach().cpu().numpy()
@@ -452,6 +590,7 @@ class _ChoiceMapBuilder:
     v = staticmethod(ChoiceMap.v)
     n = staticmethod(ChoiceMap.empty)
     choice = staticmethod(ChoiceMap.v)
+    from_mapping = staticmethod(ChoiceMap.from_mapping)
 
 
 ChoiceMapBuilder = C = _ChoiceMapBuilder()

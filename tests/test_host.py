@@ -346,3 +346,118 @@ def test_shard_message_counts_are_pairwise_consistent():
             assert send.sum() + sum(HostPlan(totals, r, u, N).keep_hi - HostPlan(totals, r, u, N).keep_lo for r in range(G)) == N
             cases += 1
     assert cases == 240
+
+
+class TestChoiceMapAlgebra:
+    """The reference's ChoiceMap / Selection unit tests on the host mirror (genjax_amd/core.py), restated from
+    /root/reference/tests/core/test_choice_maps.py (line numbers per case).  Out of scope there: Switch / dynamic-index
+    choice maps, pytree validation."""
+
+    def test_builder_set_and_membership(self):      # :295-310
+        from genjax_amd.core import ChoiceMapBuilder as C
+        chm = C["a", "b"].set(1)
+        assert chm["a", "b"] == 1
+        assert ("a", "b") in chm and "a" not in chm and "b" in chm("a")
+        nested = C["x"].set(C["y"].set(2))
+        assert nested["x", "y"] == 2 and ("x", "y") in nested and "y" not in nested
+        assert C[()].set(1.0).get_value() == 1.0
+
+    def test_builder_update(self):                  # :312-329
+        from genjax_amd.core import ChoiceMapBuilder as C
+        chm = C["x", "y"].set(2)
+        assert chm.at["x"].update(lambda m: C["z"].set(m))["x", "z", "y"] == 2
+        assert chm.at["x", "y"].update(lambda v: v * v)["x", "y"] == 4
+        assert chm.at["q"].update(lambda m: C["z"].set(m))(("q", "z")).static_is_empty()
+        assert chm.at["q"].update(lambda m: C["z"].set(2))["q", "z"] == 2
+
+    def test_builder_empty_v_from_mapping_d_kw(self):   # :331-375
+        from genjax_amd.core import ChoiceMap, ChoiceMapBuilder as C
+        assert C.n() == ChoiceMap.empty() and C["x", "y"].n() == ChoiceMap.empty()
+        assert C["a", "b"].set(1) == C["a", "b"].v(1)
+        chm = C["base"].from_mapping([("a", 1.0), (("b", "c"), 2.0), (("b", "d", "e"), {"f": 3.0})])
+        assert chm["base", "a"] == 1 and chm["base", "b", "c"] == 2 and chm["base", "b", "d", "e", "f"] == 3
+        assert ("base", "a") in chm and ("base", "b", "c") in chm and ("b", "c") in chm("base")
+        d = C["top"].d({"x": 3, "y": {"z": 4, "w": C["bottom"].d({"v": 5})}})
+        assert d["top", "x"] == 3 and d["top", "y", "z"] == 4 and d["top", "y", "w", "bottom", "v"] == 5
+        kw = C["root"].kw(a=1, b=C["nested"].kw(c=2, d={"deep": 3}))
+        assert kw["root", "a"] == 1 and kw["root", "b", "nested", "c"] == 2 and kw["root", "b", "nested", "d", "deep"] == 3
+
+    def test_extend_through_at(self):               # :465-499
+        from genjax_amd.core import ChoiceMap
+        initial = ChoiceMap.kw(x=1, y={"z": 2})
+        ext = initial.at["y", "w"].set(3)
+        assert ext["x"] == 1 and ext["y", "z"] == 2 and ext["y", "w"] == 3
+        multi = initial.at["y", "w"].set(3).at["a", "b", "c"].set(4)
+        assert multi["y", "w"] == 3 and multi["a", "b", "c"] == 4 and multi["x"] == 1
+        assert initial.at["y", "z"].set(5)["y", "z"] == 5
+        nested = initial.at["nested"].set(ChoiceMap.kw(a=6, b=7))
+        assert nested["nested", "a"] == 6 and nested["nested", "b"] == 7 and nested["y", "z"] == 2
+
+    def test_filter_mask_extend(self):              # :501-523
+        from genjax_amd.core import ChoiceMap, SelectionBuilder as S
+        chm = ChoiceMap.kw(x=1, y=2, z=3)
+        f = (S["x"] | S["y"]).filter(chm)
+        assert f["x"] == 1 and f["y"] == 2 and "z" not in f
+        assert ChoiceMap.kw(x=1, y=2).mask(True) == ChoiceMap.kw(x=1, y=2)
+        assert ChoiceMap.kw(x=1, y=2).mask(False).static_is_empty()
+        e = ChoiceMap.choice(1).extend("a", "b")
+        assert e["a", "b"] == 1 and e.get_value() is None and e.get_submap("a", "b").get_value() == 1
+        assert ChoiceMap.empty().extend("a", "b").static_is_empty()
+
+    def test_merge_xor_or_and(self):                # :709-793
+        from genjax_amd.core import ChoiceMap
+        a, b = ChoiceMap.kw(x=1), ChoiceMap.kw(y=2)
+        m = a.merge(b)
+        assert m["x"] == 1 and m["y"] == 2 and m == (a | b)
+        x = a ^ b
+        assert x["x"] == 1 and x["y"] == 2
+        assert (ChoiceMap.empty() ^ ChoiceMap.empty()).static_is_empty()
+        assert (a ^ ChoiceMap.empty()) == a and (ChoiceMap.empty() ^ a) == a
+        with pytest.raises(ValueError):
+            ChoiceMap.kw(x=1) ^ ChoiceMap.kw(x=2)
+        o = a | b
+        assert o.get_value() is None and (a | ChoiceMap.empty()) == a and (ChoiceMap.empty() | a) == a
+        assert (ChoiceMap.kw(x=1) | ChoiceMap.kw(x=2))["x"] == 1          # left-biased
+        c1, c2 = ChoiceMap.kw(x=1, y=2, z=3), ChoiceMap.kw(y=20, z=30, w=40)
+        n = c1 & c2
+        assert "x" not in n and "w" not in n and n["y"] == 20 and n["z"] == 30
+        assert (c1 & ChoiceMap.empty()).static_is_empty() and (ChoiceMap.empty() & c1).static_is_empty()
+        n1, n2 = ChoiceMap.kw(a={"b": 1, "c": 2}, d=3), ChoiceMap.kw(a={"b": 10, "d": 20}, d=30)
+        nn = n1 & n2
+        assert nn["a", "b"] == 10 and "c" not in nn("a") and "d" not in nn("a") and nn["d"] == 30
+
+    def test_call_getitem_contains_selection(self):     # :719-724, :795-810
+        from genjax_amd.core import ChoiceMap, ChoiceMapNoValueAtAddress
+        chm = ChoiceMap.kw(x={"y": 1})
+        assert chm("x")("y") == ChoiceMap.choice(1)
+        assert "x" not in chm and "y" in chm("x") and ("x", "y") in chm and "z" not in chm
+        with pytest.raises(ChoiceMapNoValueAtAddress, match="y"):
+            ChoiceMap.kw(x=1)["y"]
+        sel = ChoiceMap.kw(x=1, y=2).get_selection()
+        assert sel["x"] and sel["y"] and not sel["z"]
+        assert ChoiceMap.empty().static_is_empty() and not ChoiceMap.kw(x=1).static_is_empty()
+
+    def test_submap_path_can_be_split_or_splatted(self):    # :1170-1202
+        from genjax_amd.core import ChoiceMap
+        chm = ChoiceMap.from_mapping([(("a", "b", "c"), 1.0), (("a", "d"), 2.0)])
+        assert chm.get_submap("a", "b", "c") == chm.get_submap(("a", "b", "c")) == chm("a")("b")("c")
+        assert chm.get_submap("a").get_submap("b", "c").get_value() == 1.0
+        assert chm.get_submap("a", "d").get_value() == 2.0
+
+    def test_selections(self):                      # :40-53, :62-79, :118-181, :228-253
+        from genjax_amd.core import Selection, SelectionBuilder as S
+        new = S["x"] | S["z", "y"]
+        assert new["x"] and new["z", "y"] and new["z", "y", "tail"]
+        assert S["x"]["x", "y", "z"] and S["x", "y", "z"]["x", "y", "z"] and not S["x", "y", "z"]["x"] and not S["x", "y", "z"]["x", "y"]
+        all_sel, none_sel = Selection.all(), Selection.none()
+        assert all_sel == ~~all_sel and all_sel["x"] and all_sel["y", "z"] and all_sel[()]
+        assert none_sel == ~~none_sel and not none_sel["x"] and not none_sel["y", "z"] and not none_sel[()]
+        assert Selection.none().extend("a", "b") == Selection.none()
+        assert S.all == Selection.all() and S.none == Selection.none() and ~all_sel == none_sel and ~none_sel == all_sel
+        sel = S["x"] | S["y"]
+        assert not (~sel)["x"] and not (~sel)["y"] and (~sel)["z"] and ~~sel == sel
+        both = (S["x"] | S["y"]) & (S["y"] | S["z"])
+        assert both["y"] and not both["x"] and not both["z"]
+        assert "x" in S["x"] and ("x", "y") in S["x", "y"] and "y" not in S["x"]
+        ext = S["x"].extend("a", "b")
+        assert ext["a", "b", "x"] and not ext["x"]
