@@ -487,6 +487,22 @@ class Trace:
         tot = out["site_scores"][sel].sum(dim=0) if sel else torch.zeros(self.K, device=self.score.device)
         return tot if self.batched else tot[0]
 
+    def _site_scores(self):
+        """(sites, f32[n_sites][K]) per-site scores of this trace: one assess launch with every site constrained to its value"""
+        from . import kernels
+        from .inference.requests import _rows_and_shared
+        shared, rows = _rows_and_shared(self)
+        prog, _, _ = self.gen_fn.pack(self.args, shared, False, rng_mode=self.prog.rng_mode, per_particle=tuple(rows), plates=False)
+        out = kernels.run_program(prog, (0, 0), self.K, choices=self.rows_for(prog), want_site_scores=True, want_lse=False)
+        return prog.site_list.sites, out["site_scores"]
+
+    def get_subtrace(self, *addrs) -> "SubTrace":
+        """the part of this trace below an address path (generative_function.py get_subtrace; tests/core/generative/
+        test_core.py:57-170): ``tr.get_subtrace("f", "x")`` == ``tr.get_subtrace("f").get_subtrace("x")``; its score is the
+        sum of the scores of the sites below the path — one score per step / instance when the path names the sites of a
+        Scan or Vmap."""
+        return SubTrace(self, _flat_path(addrs))
+
     def rows_for(self, prog: PackedProgram):
         """this trace's values laid out for ANOTHER packing of the same site list (a program packed with / without plates,
         or with other modes, orders its rows differently): f32[prog.n_slots][K]"""
@@ -513,6 +529,52 @@ class Trace:
                                     device=self.score.device)
                 out[s.addr] = v[:, None].expand(s.dim, self.K)
         return out
+
+
+def _flat_path(addrs) -> tuple:
+    out = []
+    for a in addrs:
+        out.extend(_flat_path(a) if isinstance(a, tuple) else [a])
+    return tuple(out)
+
+
+class SubTrace:
+    """View of a trace below an address path: ``get_score``, ``get_choices``, ``get_subtrace`` (static.py:80-119: the
+    reference keeps one sub-trace object per address; here it is a view that assesses the parent's sites on demand)."""
+
+    def __init__(self, trace: Trace, prefix: tuple):
+        self.trace, self.prefix = trace, tuple(prefix)
+
+    def get_subtrace(self, *addrs) -> "SubTrace":
+        return SubTrace(self.trace, self.prefix + _flat_path(addrs))
+
+    def _members(self):
+        from .core import norm_addr
+        sites, scores = self.trace._site_scores()
+        mem = []
+        for j, st in enumerate(sites):
+            name, idx = norm_addr(st.addr)
+            path = name if isinstance(name, tuple) else (name,)
+            if path[: len(self.prefix)] == self.prefix:
+                mem.append((j, idx))
+        if not mem:
+            raise KeyError(f"no choices below {self.prefix!r}")
+        return mem, scores
+
+    def get_score(self):
+        import torch
+        mem, scores = self._members()
+        tr = self.trace
+        if all(idx is None for _, idx in mem):
+            tot = scores[[j for j, _ in mem]].sum(dim=0)
+            return tot if tr.batched else tot[0]
+        order = sorted({idx for _, idx in mem if idx is not None}, key=lambda i: i if isinstance(i, tuple) else (i,))
+        per = [scores[[j for j, idx in mem if idx == i]].sum(dim=0) for i in order]       # one row per step / instance
+        st = torch.stack(per, dim=-1)                                                    # [K][n]
+        return st if tr.batched else st[0]
+
+    def get_choices(self):
+        return self.trace.get_choices().get_submap(self.prefix) if self.prefix else self.trace.get_choices()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -792,3 +792,79 @@ class TestMask:
         lpn = lambda v, m, s: -0.5 * ((v - m) / s) ** 2 - np.log(s) - 0.5 * np.log(2 * np.pi)
         want = lpn(0.2, x, 0.5) + np.where(flags, lpn(x, 0.0, 1.0), 0.0)
         np.testing.assert_allclose(w.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
+
+
+class TestGetSubtrace:
+    """reference tests/core/generative/test_core.py:28-39, 57-119, 149-170 (project and get_subtrace)"""
+
+    def test_tupled_address_and_project(self):
+        @genjax.gen
+        def fn():
+            x = genjax.normal(0.0, 1.0) @ ("x", "x0")
+            y = genjax.normal(x, 1.0) @ "y"
+            return y
+
+        tr = fn.simulate(genjax.key(0), ())
+        chm = tr.get_choices()
+        x_score, _ = genjax.normal.assess(C.v(chm["x", "x0"]), (0.0, 1.0))
+        assert f(x_score) == pytest.approx(f(tr.project(genjax.key(1), S["x", "x0"])), abs=1e-6)
+        assert f(tr.get_subtrace("x", "x0").get_score()) == pytest.approx(f(x_score), abs=1e-6)
+
+    def test_project_and_subtrace_scores_add_up(self):
+        @genjax.gen
+        def fn():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = genjax.normal(0.0, 1.0) @ "y"
+            return x, y
+
+        tr = fn.simulate(genjax.key(0), ())
+        xs, ys = tr.project(genjax.key(1), S["x"]), tr.project(genjax.key(1), S["y"])
+        assert f(xs) == pytest.approx(f(tr.get_subtrace("x").get_score()), abs=1e-6)
+        assert f(xs) == pytest.approx(f(tr.get_subtrace(("x",)).get_score()), abs=1e-6)      # the deprecated tuple form
+        assert f(ys) == pytest.approx(f(tr.get_subtrace("y").get_score()), abs=1e-6)
+        assert f(tr.get_score()) == pytest.approx(f(xs) + f(ys), abs=1e-5)
+
+    def test_nested_subtraces(self):
+        @genjax.gen
+        def inner():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = genjax.normal(0.0, 1.0) @ "y"
+            return x, y
+
+        @genjax.gen
+        def g():
+            x, y = inner() @ "f"
+            return x + y
+
+        @genjax.gen
+        def h():
+            return g() @ "g"
+
+        tr = g.simulate(genjax.key(1), ())
+        f_tr = tr.get_subtrace("f")
+        for a in ("x", "y"):
+            assert f(tr.get_subtrace("f", a).get_score()) == pytest.approx(f(f_tr.get_subtrace(a).get_score()), abs=1e-6)
+        assert f(f_tr.get_score()) == pytest.approx(f(tr.get_score()), abs=1e-5)
+        assert "x" in f_tr.get_choices() and "y" in f_tr.get_choices()
+        tr = h.simulate(genjax.key(2), ())
+        want = f(tr.get_subtrace("g", "f", "x").get_score())
+        assert f(tr.get_subtrace("g").get_subtrace("f").get_subtrace("x").get_score()) == pytest.approx(want, abs=1e-6)
+        assert f(tr.get_subtrace("g").get_subtrace("f", "x").get_score()) == pytest.approx(want, abs=1e-6)
+        assert f(tr.get_subtrace("g", "f").get_subtrace("x").get_score()) == pytest.approx(want, abs=1e-6)
+
+    def test_subtrace_of_vmap_and_scan_has_one_score_per_instance(self):
+        @genjax.gen
+        def fv(x):
+            return genjax.normal(x, 0.01) @ "y"
+
+        tr = fv.vmap().simulate(genjax.key(0), (np.arange(5.0, dtype=np.float32),))
+        sc = tr.get_subtrace("y").get_score()
+        assert tuple(sc.shape) == (5,) and f(tr.get_score()) == pytest.approx(f(sc.sum()), abs=1e-4)
+
+        @genjax.gen
+        def fs(state, step):
+            return state + genjax.normal(step, 0.01) @ "y", None
+
+        tr = fs.scan(n=3).simulate(genjax.key(0), (5.0, np.arange(3.0, dtype=np.float32)))
+        sc = tr.get_subtrace("y").get_score()
+        assert tuple(sc.shape) == (3,) and f(tr.get_score()) == pytest.approx(f(sc.sum()), abs=1e-4)
