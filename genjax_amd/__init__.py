@@ -6,8 +6,8 @@ kernels behind the C ABI of ``include/gjx.h`` (``genjax_amd/csrc/libgjx_hip.so``
 fallback: compute entry points raise ``GjxError`` if the library is missing.
 """
 from . import config, inference  # noqa: F401
-from .core import (C, ChoiceMap, ChoiceMapBuilder, Diff, NoChange, S, Selection, SelectionBuilder, UnknownChange, fold_in, key,  # noqa: F401
-                   split)
+from .core import (C, ChoiceMap, ChoiceMapBuilder, ChoiceMapNoValueAtAddress, Diff, Mask, NoChange, S, Selection, SelectionBuilder,  # noqa: F401
+                   UnknownChange, fold_in, key, split)
 from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gumbel, half_cauchy, inverse_gamma,
                   logit_normal, marginal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,

@@ -272,13 +272,105 @@ SelectionBuilder = S = _SelectionBuilder()
 # ChoiceMap
 # ---------------------------------------------------------------------------------------------
 class Masked:
-    """A value with one validity flag per particle (core/generative/functional_types.py Mask, batched flag)."""
+    """``Mask(value, flag)`` (core/generative/functional_types.py:40-330): a value that is only meaningful where its flag is
+    set.  A Python-bool flag is decided on the host (a constraint under ``Mask(v, False)`` is no constraint); a flag array
+    holds one flag per particle and goes to the kernels as GJX_MODE_OBS_MASK (distribution.py:129-143)."""
 
-    def __init__(self, value, flag: np.ndarray):
-        self.value, self.flag = value, np.asarray(flag, bool)
+    def __init__(self, value, flag=True):
+        self.value = value
+        self.flag = bool(flag) if isinstance(flag, (bool, np.bool_)) else np.asarray(_np(flag), bool)
+
+    # -- the reference's constructors ---------------------------------------------------------
+    @staticmethod
+    def build(value, flag=True) -> "Masked":
+        """flattens a nested mask: the flags combine with AND (functional_types.py `build`)"""
+        if isinstance(value, Masked):
+            return Masked(value.value, _flag_and(value.flag, flag if isinstance(flag, (bool, np.bool_)) else np.asarray(_np(flag), bool)))
+        return Masked(value, flag)
+
+    @staticmethod
+    def maybe_mask(value, flag):
+        """the bare value for a concrete True flag, None for a concrete False one, a mask otherwise"""
+        if isinstance(flag, (bool, np.bool_)):
+            if not flag:
+                return None
+            return value.unmask() if isinstance(value, Masked) and value.flag is True else value
+        return Masked.build(value, flag)
+
+    def primal_flag(self):
+        return self.flag
+
+    def unmask(self, default=None):
+        """the value; invalid entries are replaced by ``default`` (without a default an invalid scalar mask raises)"""
+        if isinstance(self.flag, bool):
+            if self.flag:
+                return self.value
+            if default is None:
+                raise ValueError("Mask.unmask: the mask is invalid and no default was given")
+            return default
+        if default is None:
+            if not self.flag.all():
+                raise ValueError("Mask.unmask: some entries are invalid and no default was given")
+            return self.value
+        v = _np(self.value)
+        f = self.flag.reshape(self.flag.shape + (1,) * (v.ndim - self.flag.ndim))
+        return np.where(f, v, _np(default))
+
+    def __invert__(self) -> "Masked":
+        return Masked(self.value, (not self.flag) if isinstance(self.flag, bool) else ~self.flag)
+
+    def _pick(self, other: "Masked", flag):
+        """value of ``self`` where it is valid, ``other``'s elsewhere"""
+        if isinstance(self.flag, bool) and isinstance(other.flag, bool):
+            return Masked(self.value if self.flag else other.value, flag)
+        a, b = _np(self.value), _np(other.value)
+        f = np.broadcast_to(np.asarray(self.flag), np.broadcast(np.asarray(self.flag), np.asarray(other.flag)).shape)
+        fe = f.reshape(f.shape + (1,) * (max(a.ndim, b.ndim) - f.ndim))
+        return Masked(np.where(fe, a, b), flag)
+
+    def __or__(self, other: "Masked") -> "Masked":
+        return self._pick(other, _flag_or(self.flag, other.flag))
+
+    def __xor__(self, other: "Masked") -> "Masked":
+        return self._pick(other, _flag_xor(self.flag, other.flag))
+
+    def __getitem__(self, idx) -> "Masked":
+        """index the value; a flag array is indexed by as many leading components as it has axes"""
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        v = _np(self.value)[idx]
+        if isinstance(self.flag, bool):
+            return Masked(v, self.flag)
+        fl = self.flag[idx[: self.flag.ndim]]
+        return Masked(v, bool(fl) if np.ndim(fl) == 0 else fl)
+
+    def __eq__(self, other) -> bool:
+        return (isinstance(other, Masked) and np.array_equal(np.asarray(self.flag), np.asarray(other.flag))
+                and np.array_equal(_np(self.value), _np(other.value)))
+
+    __hash__ = None
 
     def __repr__(self):
-        return f"Masked({int(self.flag.sum())}/{self.flag.size} valid)"
+        if isinstance(self.flag, bool):
+            return f"Mask({self.value!r}, {self.flag})"
+        return f"Mask({int(self.flag.sum())}/{self.flag.size} valid)"
+
+
+def _flag_and(a, b):
+    r = np.logical_and(a, b)
+    return bool(r) if np.ndim(r) == 0 and isinstance(a, bool) and isinstance(b, (bool, np.bool_)) else np.asarray(r, bool)
+
+
+def _flag_or(a, b):
+    r = np.logical_or(a, b)
+    return bool(r) if isinstance(a, bool) and isinstance(b, bool) else np.asarray(r, bool)
+
+
+def _flag_xor(a, b):
+    r = np.logical_xor(a, b)
+    return bool(r) if isinstance(a, bool) and isinstance(b, bool) else np.asarray(r, bool)
+
+
+Mask = Masked
 
 
 class ChoiceMapNoValueAtAddress(KeyError):

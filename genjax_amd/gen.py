@@ -653,6 +653,8 @@ class GenerativeFunction:
         modes, shared, pp, mask_rows = {}, {}, {}, {}
         for s in sl.sites:
             found, cval = _constraint_value(constraint, s.addr)
+            if found and isinstance(cval, Masked) and isinstance(cval.flag, bool):
+                found, cval = cval.flag, cval.value         # a concrete flag is decided here: a plain constraint, or none
             if found and isinstance(cval, Masked):
                 K = cval.flag.size
                 sv, rows = _value_rows(cval.value, s.dim)

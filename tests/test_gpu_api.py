@@ -868,3 +868,22 @@ class TestGetSubtrace:
         tr = fs.scan(n=3).simulate(genjax.key(0), (5.0, np.arange(3.0, dtype=np.float32)))
         sc = tr.get_subtrace("y").get_score()
         assert tuple(sc.shape) == (3,) and f(tr.get_score()) == pytest.approx(f(sc.sum()), abs=1e-4)
+
+
+def test_concrete_mask_flags_are_decided_on_the_host():
+    """a constraint under Mask(v, True) is the constraint v, under Mask(v, False) no constraint (functional_types.py:40-110,
+    distribution.py:129-143 with a concrete flag)"""
+    from genjax_amd import Mask
+
+    @genjax.gen
+    def model():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        _ = genjax.normal(x, 0.5) @ "y"
+
+    k = genjax.key(4)
+    tr_c, w_c = model.importance(k, C["y"].set(1.0), ())
+    tr_t, w_t = model.importance(k, C["y"].set(Mask(1.0, True)), ())
+    tr_f, w_f = model.importance(k, C["y"].set(Mask(1.0, False)), ())
+    tr_n, w_n = model.importance(k, ChoiceMap.empty(), ())
+    assert f(w_t) == f(w_c) and f(tr_t.get_choices()["y"]) == 1.0 and f(tr_t.get_choices()["x"]) == f(tr_c.get_choices()["x"])
+    assert f(w_f) == f(w_n) == 0.0 and f(tr_f.get_choices()["y"]) == f(tr_n.get_choices()["y"])

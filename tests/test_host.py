@@ -461,3 +461,48 @@ class TestChoiceMapAlgebra:
         assert "x" in S["x"] and ("x", "y") in S["x", "y"] and "y" not in S["x"]
         ext = S["x"].extend("a", "b")
         assert ext["a", "b", "x"] and not ext["x"]
+
+
+class TestMask:
+    """reference tests/core/generative/test_functional_types.py:28-63, 65-75, 139-150, 154-227, 329-366 on the host type
+    (genjax_amd.Mask): concrete flags are Python bools, flag arrays hold one flag per leading index."""
+
+    def test_constructor_unmask_build_maybe(self):
+        from genjax_amd import Mask
+        m = Mask(value=42, flag=True)
+        assert m.value == 42 and m.flag is True and Mask(value=42).flag is True
+        assert Mask(42, True).unmask() == 42 and Mask(42, True).unmask(default=0) == 42 and Mask(42, False).unmask(default=0) == 0
+        with pytest.raises(Exception):
+            Mask(42, False).unmask()
+        tree = {"a": 1, "b": [2, 3], "c": {"d": 4}}
+        assert Mask(tree, True).unmask() == tree
+        default = {"a": 0, "b": [0, 0], "c": {"d": 0}}
+        assert Mask(tree, False).unmask(default=default) == default
+        b = Mask.build(42, True)
+        assert isinstance(b, Mask) and b.flag is True and b.value == 42
+        nested = Mask.build(Mask.build(42, True), False)
+        assert isinstance(nested, Mask) and nested.flag is False and nested.value == 42
+        v = Mask.build(np.arange(10), np.ones(10, bool))
+        n2 = Mask.build(v, False)
+        assert np.array_equal(n2.value, np.arange(10)) and np.array_equal(n2.primal_flag(), np.zeros(10, bool))
+        assert Mask.maybe_mask(42, True) == 42 and Mask.maybe_mask(42, False) is None
+        assert Mask.maybe_mask(Mask(42, True), True) == 42 and Mask.maybe_mask(Mask(42, True), False) is None
+
+    def test_or_xor_not_indexing(self):
+        from genjax_amd import Mask
+        for fa, fb, flag, val in ((True, True, True, 42), (True, False, True, 42), (False, True, True, 43), (False, False, False, None)):
+            r = Mask(42, fa) | Mask(43, fb)
+            assert r.primal_flag() is flag and (val is None or r.value == val)
+        for fa, fb, flag, val in ((True, True, False, None), (True, False, True, 42), (False, True, True, 43), (False, False, False, None)):
+            r = Mask(42, fa) ^ Mask(43, fb)
+            assert r.primal_flag() is flag and (val is None or r.value == val)
+        a = Mask(np.array([42, 42, 42, 42]), np.array([True, True, False, False]))
+        b = Mask(np.array([43, 43, 43, 43]), np.array([False, True, False, True]))
+        assert np.array_equal((a | b).primal_flag(), [True, True, False, True]) and np.array_equal((a | b).value[[0, 3]], [42, 43])
+        assert np.array_equal((a ^ b).primal_flag(), [True, False, False, True]) and np.array_equal((a ^ b).value[[0, 3]], [42, 43])
+        assert ~Mask(1.0, True) == Mask(1.0, False) and ~Mask(2.0, False) == Mask(2.0, True)
+        assert ~Mask(np.array([1.0, 2.0]), np.array([True, False])) == Mask(np.array([1.0, 2.0]), np.array([False, True]))
+        s_ = Mask(np.array([[1, 2], [3, 4]]), True)
+        assert s_[0, 1].value == 2 and s_[0, 1].primal_flag() is True
+        v = Mask(np.array([[1, 2], [3, 4]]), np.array([True, False]))
+        assert v[0, 1].value == 2 and v[0, 1].primal_flag() is True and v[1, 0].value == 3 and v[1, 0].primal_flag() is False
