@@ -465,6 +465,17 @@ class ChoiceMap:
             d = dict(self.base._d)
             if isinstance(value, ChoiceMap) and value.has_value():
                 value = value.get_value()
+            comps = self.addr if isinstance(self.addr, tuple) else (self.addr,)
+            if comps and not any(isinstance(c, str) for c in comps) and isinstance(value, (dict, ChoiceMap)):
+                # C[:].set({"x": xs}) / C[0].set({"x": 1.0}): the index applies to every address of the value
+                flat: dict = {}
+                _flat_into(flat, (), value)
+                for k, v in flat.items():
+                    name, idx = norm_addr(k)
+                    if idx is not None:
+                        raise KeyError(f"{k!r} already carries an index")
+                    d[key_of(tuple(comps) + (name if isinstance(name, tuple) else (name,)))] = v
+                return ChoiceMap(d, self.base._lead_axes)
             pre = self._path()
             if pre is not None and isinstance(value, (dict, ChoiceMap)):
                 _flat_into(d, pre, value)              # a choice map / dict nests below the address

@@ -48,6 +48,26 @@ def _new_args(tr: Trace, argdiffs):
     return args
 
 
+def _per_site(constraint: ChoiceMap, site_list) -> dict:
+    """the constraint keyed by site address: a whole-sequence entry (``C[:].set({"x": xs})``, ``C["x"].set(xs)`` for the sites
+    ("x", i) of a Scan / Vmap / repeat) is dealt to its instances, leading axis = instance index"""
+    from ..core import norm_addr
+    addrs = {st.addr for st in site_list.sites}
+    out = {}
+    for addr, v in constraint._d.items():
+        if addr in addrs or addr == ():
+            out[addr] = v
+            continue
+        members = [a for a in addrs if isinstance(a, tuple) and len(a) == 2 and a[0] == addr and norm_addr(a)[1] is not None]
+        if not members:
+            out[addr] = v                                   # unknown address: reported by the lookup below
+            continue
+        arr = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        for a in members:
+            out[a] = arr[a[1]]
+    return out
+
+
 class Update(EditRequest):
     """Replace the values at the constrained addresses, keep the rest; weight = new score - old score
     (generative_function.py:1687-1689, distribution.py:179-244, static.py:827-865)."""
@@ -59,7 +79,7 @@ class Update(EditRequest):
         shared, rows = _rows_and_shared(tr)
         args = _new_args(tr, argdiffs)
         discard = {}
-        for addr, v in self.constraint._d.items():          # including the bare-value address () of a distribution trace
+        for addr, v in _per_site(self.constraint, tr.prog.site_list).items():   # including the bare-value address () of a distribution trace
             s = tr.prog.site_list[addr]
             discard[addr] = tr._site_value(addr)
             sv, r = _value_rows(v, s.dim)

@@ -887,3 +887,24 @@ def test_concrete_mask_flags_are_decided_on_the_host():
     tr_n, w_n = model.importance(k, ChoiceMap.empty(), ())
     assert f(w_t) == f(w_c) and f(tr_t.get_choices()["y"]) == 1.0 and f(tr_t.get_choices()["x"]) == f(tr_c.get_choices()["x"])
     assert f(w_f) == f(w_n) == 0.0 and f(tr_f.get_choices()["y"]) == f(tr_n.get_choices()["y"])
+
+
+def test_filtered_choice_map_update_of_a_repeat():
+    """reference tests/core/test_choice_maps.py:836-862: C[:].set({...}) filtered by a selection constrains only the selected
+    address of every instance in Trace.update"""
+    @genjax.gen
+    def fn():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        y = genjax.normal(10.0, 1.0) @ "y"
+        return x, y
+
+    tr = fn.repeat(n=4).simulate(genjax.key(0), ())
+    xs, ys = np.ones(4, np.float32), 5 * np.ones(4, np.float32)
+    constraint = C[:].set({"x": xs, "y": ys})
+    only_xs, only_ys = constraint.filter(S["x"]), constraint.filter(S["y"])
+    new_tr, _, _, _ = tr.update(genjax.key(1), only_xs)
+    ch = new_tr.get_choices()
+    assert np.array_equal(ch[:, "x"].cpu().numpy(), xs) and not np.array_equal(ch[:, "y"].cpu().numpy(), ys)
+    new_tr2, _, _, _ = tr.update(genjax.key(2), only_ys)
+    ch2 = new_tr2.get_choices()
+    assert not np.array_equal(ch2[:, "x"].cpu().numpy(), xs) and np.array_equal(ch2[:, "y"].cpu().numpy(), ys)

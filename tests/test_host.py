@@ -444,6 +444,17 @@ class TestChoiceMapAlgebra:
         assert chm.get_submap("a").get_submap("b", "c").get_value() == 1.0
         assert chm.get_submap("a", "d").get_value() == 2.0
 
+    def test_index_only_addresses(self):            # :812-834, :864-869
+        from genjax_amd.core import ChoiceMapBuilder as C, ChoiceMapNoValueAtAddress, SelectionBuilder as S
+        xs, ys = np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0])
+        chm = C[:].set({"x": xs, "y": ys})
+        only_x = chm.filter(S["x"])
+        assert (only_x[:, "x"] == xs).all() and only_x[0, "x"] == 1.0 and only_x[1, "x"] == 2.0 and only_x[2, "x"] == 3.0
+        with pytest.raises(ChoiceMapNoValueAtAddress):
+            only_x[:, "y"]
+        c0 = C[0].set({"x": 1.0, "y": 2.0})
+        assert c0[0, "x"] == 1.0 and c0[0, "y"] == 2.0
+
     def test_selections(self):                      # :40-53, :62-79, :118-181, :228-253
         from genjax_amd.core import Selection, SelectionBuilder as S
         new = S["x"] | S["z", "y"]
