@@ -790,9 +790,27 @@ class StaticGenerativeFunction(GenerativeFunction):
         """``kernel.repeat(n=...)`` (combinators/repeat.py): n i.i.d. instances with the same arguments."""
         return VmapCombinator(self, None, n=int(n))
 
-    def scan(self, n: int) -> "ScanCombinator":
-        """``kernel.scan(n=T)`` (combinators/scan.py): the kernel ``(carry, x) -> (carry, out)`` unrolled T times."""
-        return ScanCombinator(self, int(n))
+    def scan(self, n: int | None = None) -> "ScanCombinator":
+        """``kernel.scan(n=T)`` (combinators/scan.py): the kernel ``(carry, x) -> (carry, out)`` unrolled T times; without ``n``
+        the length is the leading axis of the scanned argument (scan.py:380-400)."""
+        return ScanCombinator(self, None if n is None else int(n))
+
+    def iterate(self, n: int) -> "_Iterate":
+        """``f.iterate(n=T)`` (scan.py:916-990): ``a -> a`` applied T times, returns [init, f(init), ..., f^T(init)]"""
+        return iterate(n)(self)
+
+    def iterate_final(self, n: int) -> "_Iterate":
+        """``f.iterate_final(n=T)``: as iterate, returning only f^T(init)"""
+        return iterate_final(n)(self)
+
+    def accumulate(self) -> "_Accumulate":
+        """``f.accumulate()`` (scan.py:992-1064): ``(acc, v) -> acc`` folded over the leading axis of ``vs``; returns
+        [init, acc_1, ..., acc_T]"""
+        return _Accumulate(self, final=False)
+
+    def reduce(self) -> "_Accumulate":
+        """``f.reduce()`` (scan.py:1066-1130): as accumulate, returning only the final accumulator"""
+        return _Accumulate(self, final=True)
 
     def __repr__(self):
         return f"<gen {self.__name__}>"
@@ -811,9 +829,19 @@ class ScanCombinator(GenerativeFunction):
     Scores and weights add over steps (scan.py:283-294); whole-sequence constraints / selections use the bare
     address (``C["y"].set(vector)``, ``Selection.at["x"]``, ``chm[:, "x"]``)."""
 
-    def __init__(self, kernel: StaticGenerativeFunction, n: int):
+    def __init__(self, kernel: StaticGenerativeFunction, n: int | None):
         self.kernel, self.n = kernel, n
         self._cache: dict = {}
+
+    def _length(self, xs) -> int:
+        """the number of steps: ``n``, or the common leading axis of the scanned argument's leaves (scan.py:380-400, 422-438)"""
+        if self.n is not None:
+            return self.n
+        lens = sorted({int(np.shape(_np_arg(v))[0]) for v in _leaves(xs) if np.ndim(_np_arg(v)) > 0})
+        if len(lens) != 1:
+            raise ValueError("scan got values with different leading axis sizes: " + ", ".join(map(str, lens)) + "."
+                             if lens else "scan without n needs a scanned argument with a leading axis")
+        return lens[0]
 
     def _unroll(self, t: _Tracer, carry, xs):
         # a scan inside a vmap instance is a scan of its own (its own id, its own chained keys); a scan inside a scan step
@@ -824,14 +852,15 @@ class ScanCombinator(GenerativeFunction):
         outs = []
         sid = t.n_scans
         t.n_scans += 1
-        if self.n >= (1 << 20) - 1 or sid >= 2048:
+        n = self._length(xs)
+        if n >= (1 << 20) - 1 or sid >= 2048:
             raise NotSupportedInModelBody("scan: at most 2^20 - 2 steps and 2048 scans per model")
         try:
             t.in_scan = True
-            for i in range(self.n):
+            for i in range(n):
                 t.step = _nest(outer, i)
                 t.scan = (sid << 20) | (i + 1)      # step keys chain on the device: key_t = fold_in(key_{t-1}, t) (scan.py:268)
-                carry, out = self.kernel.source(carry, None if xs is None else xs[i])
+                carry, out = self.kernel.source(carry, None if xs is None else _step_of(xs, i))
                 outs.append(out)
         finally:
             t.step = outer
@@ -942,6 +971,48 @@ def iterate_final(n: int) -> Callable:
         it.final = True
         return it
     return deco
+
+
+def _leaves(x):
+    if isinstance(x, dict):
+        for v in x.values():
+            yield from _leaves(v)
+    elif isinstance(x, (tuple, list)):
+        for v in x:
+            yield from _leaves(v)
+    elif x is not None:
+        yield x
+
+
+def _step_of(xs, i: int):
+    """element i of the scanned argument: arrays are indexed on their leading axis, containers leaf by leaf"""
+    if isinstance(xs, dict):
+        return {k: _step_of(v, i) for k, v in xs.items()}
+    if isinstance(xs, tuple):
+        return tuple(_step_of(v, i) for v in xs)
+    return xs[i]
+
+
+class _Accumulate(GenerativeFunction):
+    """``f.accumulate()`` / ``f.reduce()``: the kernel ``(acc, v) -> acc`` as a Scan over ``vs`` (scan.py:992-1130)"""
+
+    def __init__(self, f: "StaticGenerativeFunction", final: bool):
+        src = f.source
+
+        def kernel(carry, v):
+            out = src(carry, v)
+            return out, out
+        self.sc, self.final = ScanCombinator(StaticGenerativeFunction(kernel), None), final
+
+    def site_list(self, args):
+        sl, (carry, outs) = self.sc.site_list((args[0], args[1]))
+        return sl, (carry if self.final else [args[0]] + list(outs))
+
+    def __call__(self, init, vs):
+        def inline(t):
+            carry, outs = self.sc._unroll(t, init, vs)
+            return carry if self.final else [init] + list(outs)
+        return GenCall(inline)
 
 
 class _Iterate(GenerativeFunction):

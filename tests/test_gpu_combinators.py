@@ -476,3 +476,89 @@ class TestNestedCombinators:
 
         with pytest.raises(NotSupportedInModelBody):
             outer.scan(n=2).simulate(genjax.key(1), (0.0, None))
+
+
+class TestIterateAccumulateReduceMethods:
+    """reference tests/generative_functions/test_scan_combinator.py:95-123, 212-247 (the method forms) and :324-438 (scan with
+    parameters, inferred length, zero length, validation)"""
+
+    def test_iterate_and_iterate_final(self):                                # :99-123
+        @genjax.gen
+        def inc(x):
+            return x + 1
+
+        assert f(inc.simulate(genjax.key(314159), (0,)).get_retval()) == 1
+        rv = inc.iterate(n=4).simulate(genjax.key(314159), (0,)).get_retval()
+        assert [f(v) for v in rv] == [0, 1, 2, 3, 4]
+        assert f(inc.iterate_final(n=10).simulate(genjax.key(314159), (0,)).get_retval()) == 10
+
+    def test_accumulate_and_reduce(self):                                    # :217-247
+        @genjax.gen
+        def add(x, y):
+            return x + y
+
+        assert f(add.simulate(genjax.key(314159), (0, 2)).get_retval()) == 2
+        rv = add.accumulate().simulate(genjax.key(314159), (0, np.ones(4, np.float32))).get_retval()
+        assert [f(v) for v in rv] == [0, 1, 2, 3, 4]
+        assert f(add.reduce().simulate(genjax.key(314159), (0, np.ones(10, np.float32))).get_retval()) == 10
+
+    def test_scan_update_below_an_address(self):                             # :324-349 (the Pytree argument as a dict)
+        @genjax.gen
+        def step(b, a):
+            return genjax.normal(b + a["x"], 1e-6) @ "b", None
+
+        @genjax.gen
+        def model(k):
+            return step.scan(n=3)(k, {"x": np.array([1.0, 2.0, 3.0], np.float32)}) @ "steps"
+
+        tr = model.simulate(genjax.key(1), (1.0,))
+        u, w, _, _ = tr.update(genjax.key(2), C["steps", 1, "b"].set(99.0))
+        got = u.get_choices()["steps", :, "b"].cpu().numpy()
+        np.testing.assert_allclose(got, [2.0, 99.0, 7.0], atol=0.1)
+        assert f(w) < -100.0
+
+    def test_scan_with_parameters(self):                                     # :357-378
+        @genjax.gen
+        def step(data, state, update):
+            new_state = state + genjax.normal(update, data["noise"]) @ "state"
+            return new_state, new_state
+
+        @genjax.gen
+        def model(data):
+            stepper = step.partial_apply(data)
+            return stepper.scan(n=3)(data["initial"], data["updates"]) @ "s"
+
+        tr = model.simulate(genjax.key(314159), ({"initial": 3.0, "updates": np.array([5.0, 6.0, 7.0], np.float32), "noise": 1e-6},))
+        end, steps = tr.get_retval()
+        np.testing.assert_allclose([f(v) for v in steps], [8.0, 14.0, 21.0], atol=0.1)
+        assert f(end) == pytest.approx(21.0, abs=0.1)
+
+    def test_scan_length_inferred_zero_length_and_validation(self):          # :380-438
+        @genjax.gen
+        def walk_step(x, std):
+            new_x = genjax.normal(x, std) @ "x"
+            return new_x, new_x
+
+        args = (0.0, np.array([2.0, 4.0, 3.0, 5.0, 1.0], np.float32))
+        tr = walk_step.scan(n=5).simulate(genjax.key(314159), args)
+        _, expected = tr.get_retval()
+        np.testing.assert_allclose(tr.get_choices()[:, "x"].cpu().numpy(), [f(v) for v in expected], rtol=1e-6)
+        tr2 = walk_step.scan().simulate(genjax.key(314159), args)
+        np.testing.assert_array_equal(tr2.get_choices()[:, "x"].cpu().numpy(), tr.get_choices()[:, "x"].cpu().numpy())
+
+        @genjax.gen
+        def step(state, sigma):
+            new_x = genjax.normal(state, sigma) @ "x"
+            return (new_x, new_x + 1)
+
+        empty = step.scan(n=0).simulate(genjax.key(1), (2.0, np.zeros(0, np.float32)))
+        assert empty.get_choices().static_is_empty()
+        step.scan().importance(genjax.key(2), empty.get_choices(), (2.0, np.zeros(0, np.float32)))
+
+        @genjax.gen
+        def foo(shift, d):
+            x = genjax.normal(d["loc"], d["scale"]) @ "x"
+            return x + shift, None
+
+        with pytest.raises(ValueError, match="scan got values with different leading axis sizes: 1, 2."):
+            foo.scan().simulate(genjax.key(3), (1.0, {"loc": np.array([10.0, 12.0], np.float32), "scale": np.array([1.0], np.float32)}))
