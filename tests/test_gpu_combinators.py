@@ -562,3 +562,32 @@ class TestIterateAccumulateReduceMethods:
 
         with pytest.raises(ValueError, match="scan got values with different leading axis sizes: 1, 2."):
             foo.scan().simulate(genjax.key(3), (1.0, {"loc": np.array([10.0, 12.0], np.float32), "scale": np.array([1.0], np.float32)}))
+
+
+class TestVmapRemaining:
+    """reference tests/generative_functions/test_vmap_combinator.py:103-119, 230-243"""
+
+    def test_nested_indexed_choice_map_importance(self):                     # :103-119
+        @genjax.vmap(in_axes=(0,))
+        @genjax.gen
+        def model(x):
+            z = genjax.normal(x, 1.0) @ "z"
+            return z
+
+        @genjax.vmap(in_axes=(0,))
+        @genjax.gen
+        def higher_model(x):
+            return model(x) @ "outer"
+
+        chm = C[0, "outer", 1, "z"].set(1.0)
+        _, w = higher_model.importance(genjax.key(314159), chm, (np.ones((3, 3), np.float32),))
+        assert f(w) == pytest.approx(f(genjax.normal.assess(C.v(1.0), (1.0, 1.0))[0]), abs=1e-6)
+
+    def test_zero_length_vmap(self):                                         # :230-243
+        @genjax.gen
+        def step(state, sigma):
+            new_x = genjax.normal(state, sigma) @ "x"
+            return (new_x, new_x + 1)
+
+        tr = step.vmap(in_axes=(None, 0)).simulate(genjax.key(20), (2.0, np.zeros(0, np.float32)))
+        assert tr.get_choices().static_is_empty()
