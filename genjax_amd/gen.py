@@ -359,6 +359,36 @@ class GenCall:
             t.prefix = old
 
 
+class GenClosure(GenCall):
+    """``model(*args, **kwargs)``: inlines under an address inside a body (GenCall), and outside one behaves as the generative
+    function with its arguments filled in — ``gfc.simulate(key, ())``, ``gfc.importance(key, chm, ())``, ``gfc.assess(chm, ())``,
+    ``gfc(key)`` -> return value, keyword arguments overridable per call (tests/generative_functions/test_static_gen_fn.py:824-885)."""
+
+    def __init__(self, gen_fn, args: tuple, kwargs: dict):
+        super().__init__(lambda t: gen_fn.source(*args, **kwargs))
+        self.gen_fn, self.args, self.kwargs = gen_fn, tuple(args), dict(kwargs)
+
+    def _bound(self, **over):
+        src, a, kw = self.gen_fn.source, self.args, {**self.kwargs, **over}
+        g = StaticGenerativeFunction(lambda: src(*a, **kw))
+        g.__name__ = getattr(self.gen_fn, "__name__", "gen_fn")
+        return g
+
+    def simulate(self, key, args=()):
+        return self._bound().simulate(key, ())
+
+    def importance(self, key, constraint, args=()):
+        return self._bound().importance(key, constraint, ())
+
+    generate = importance
+
+    def assess(self, chm, args=()):
+        return self._bound().assess(chm, ())
+
+    def __call__(self, key, **over):
+        return self._bound(**over).simulate(key, ()).get_retval()
+
+
 # ---------------------------------------------------------------------------------------------
 # traces
 # ---------------------------------------------------------------------------------------------
@@ -761,6 +791,13 @@ class StaticGenerativeFunction(GenerativeFunction):
         self.source = source
         self.__name__ = getattr(source, "__name__", "gen_fn")
         self.__doc__ = getattr(source, "__doc__", None)
+        for a in ("__module__", "__qualname__"):              # static.py:1044-1049 (functools.wraps)
+            if hasattr(source, a):
+                try:
+                    setattr(self, a, getattr(source, a))
+                except (AttributeError, TypeError):
+                    pass
+        self.__wrapped__ = source
         self._cache: dict = {}
 
     def site_list(self, args):
@@ -771,8 +808,10 @@ class StaticGenerativeFunction(GenerativeFunction):
             self._cache[k] = (t.sites, retval)
         return self._cache[k]
 
-    def __call__(self, *args):
-        return GenCall(lambda t: self.source(*args))
+    def __call__(self, *args, **kwargs):
+        """``callee(*args) @ "addr"`` inside a model body; outside one, the result is also a closure over the arguments
+        with the generative-function interface taking ``()`` (generative_function.py GenerativeFunctionClosure)."""
+        return GenClosure(self, args, kwargs)
 
     def partial_apply(self, *args) -> "StaticGenerativeFunction":
         """static.py:1011-1036: the same function with its leading arguments pre-filled."""

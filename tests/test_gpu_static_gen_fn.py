@@ -397,3 +397,66 @@ class TestDistributions:
         assert f(new_tr.get_choices()["x"]) == f(ch["x"]) and new_tr.get_args() == (1.0, 2.0)
         lpn = lambda v, m, s: -0.5 * ((v - m) / s) ** 2 - math.log(s) - 0.5 * math.log(2 * math.pi)
         assert f(w) == pytest.approx(lpn(f(ch["x"]), 1.0, 2.0) - lpn(f(ch["x"]), 0.0, 1.0), rel=1e-4, abs=1e-5)
+
+
+class TestNoChoicesForwardRefClosure:
+    """reference test_static_gen_fn.py:197-206, 274-285 (no choices), :803-821 (forward reference), :825-885 (closures)"""
+
+    def test_simulate_and_assess_with_no_choices(self):
+        @genjax.gen
+        def empty(x):
+            return (x - 3.0) * (x - 3.0)
+
+        tr = empty.simulate(genjax.key(314159), (1.0,))
+        assert f(tr.get_score()) == 0.0 and f(tr.get_retval()) == 4.0
+        score, _ = empty.assess(tr.get_choices(), (1.0,))
+        assert f(score) == f(tr.get_score())
+
+    def test_forward_ref(self):
+        def make_gen_fn():
+            @genjax.gen
+            def proposal(x):
+                x = outlier(x) @ "x"
+                return x
+
+            @genjax.gen
+            def outlier(prob):
+                is_outlier = genjax.bernoulli(probs=prob) @ "is_outlier"
+                return is_outlier
+
+            return proposal
+
+        tr = make_gen_fn().simulate(genjax.key(314159), (0.3,))
+        want = math.log(0.3) if bool(tr.get_retval()) else math.log(0.7)
+        assert f(tr.get_score()) == pytest.approx(want, abs=1e-6)
+
+    def test_gen_fn_closure(self):
+        @genjax.gen
+        def model():
+            return genjax.normal(1.0, 0.001) @ "x"
+
+        gfc = model()
+        tr = gfc.simulate(genjax.key(0), ())
+        lp = lambda v: f(genjax.normal.assess(C.v(v), (1.0, 0.001))[0])
+        assert f(tr.get_score()) == pytest.approx(lp(f(tr.get_retval())), rel=1e-5, abs=1e-4)
+        tr_u, w = gfc.importance(genjax.key(1), C.kw(x=1.1), ())
+        assert f(tr_u.get_score()) == pytest.approx(lp(1.1), rel=1e-5) and f(w) == f(tr_u.get_score())
+
+    def test_gen_fn_closure_with_kwargs(self):
+        @genjax.gen
+        def model(x, y, z=None):
+            if z is None:
+                raise ValueError("z must be provided")
+            _sampled = genjax.normal(x + y, z) @ "sampled"
+            return z
+
+        key = genjax.key(0)
+        with pytest.raises(ValueError, match="z must be provided"):
+            model(1.0, 2.0)(key)
+        gfc = model(1.0, 2.0, z=3.0)
+        assert f(gfc(key)) == 3.0 and f(gfc(key, z=10.0)) == 10.0
+        arg_tuple = (1.0, 2.0, 3.0)
+        assert gfc.simulate(key, ()).get_choices() == model.simulate(key, arg_tuple).get_choices()
+        chm = C.kw(sampled=3.5)
+        assert f(gfc.assess(chm, ())[0]) == f(model.assess(chm, arg_tuple)[0])
+        assert f(gfc.importance(key, C.kw(sampled=3.0), ())[1]) == f(model.importance(key, C.kw(sampled=3.0), arg_tuple)[1])

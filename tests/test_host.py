@@ -517,3 +517,17 @@ class TestMask:
         assert s_[0, 1].value == 2 and s_[0, 1].primal_flag() is True
         v = Mask(np.array([[1, 2], [3, 4]]), np.array([True, False]))
         assert v[0, 1].value == 2 and v[0, 1].primal_flag() is True and v[1, 0].value == 3 and v[1, 0].primal_flag() is False
+
+
+def test_gen_transfers_the_function_metadata():
+    """reference tests/generative_functions/test_static_gen_fn.py:39-84"""
+    import genjax_amd as genjax
+
+    def original_function(x: float, y: float) -> float:
+        """This is a test function that adds two numbers."""
+        return x + y
+
+    w = genjax.gen(original_function)
+    assert w.__doc__ == original_function.__doc__ and w.__name__ == original_function.__name__
+    assert w.__module__ == original_function.__module__ and w.__qualname__ == original_function.__qualname__
+    assert getattr(w, "__wrapped__") == original_function
