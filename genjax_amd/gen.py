@@ -798,6 +798,7 @@ class StaticGenerativeFunction(GenerativeFunction):
                 except (AttributeError, TypeError):
                     pass
         self.__wrapped__ = source
+        self.partial_args: tuple = ()      # arguments filled in by partial_apply / method binding (static.py:1011-1036)
         self._cache: dict = {}
 
     def site_list(self, args):
@@ -814,11 +815,22 @@ class StaticGenerativeFunction(GenerativeFunction):
         return GenClosure(self, args, kwargs)
 
     def partial_apply(self, *args) -> "StaticGenerativeFunction":
-        """static.py:1011-1036: the same function with its leading arguments pre-filled."""
+        """static.py:1011-1036: the same function with its leading arguments pre-filled (``partial_args`` lists them)."""
         src = self.source
-        g = StaticGenerativeFunction(lambda *rest: src(*args, *rest))
+        g = StaticGenerativeFunction(lambda *rest, **kw: src(*args, *rest, **kw))
         g.__name__ = self.__name__
+        g.partial_args = self.partial_args + tuple(args)
         return g
+
+    def __get__(self, obj, objtype=None):
+        """``@gen`` on a method: ``instance.method`` is the generative function with ``self`` filled in (static.py gen on
+        methods; tests/generative_functions/test_static_gen_fn.py:1116-1145)"""
+        return self if obj is None else self.partial_apply(obj)
+
+    def inline(self, *args, **kwargs):
+        """inside a model body: the callee's choices at the CALLER's address level, no prefix (static.py `inline`)"""
+        _Tracer.current()                     # (only meaningful while a body is traced)
+        return self.source(*args, **kwargs)
 
     def vmap(self, in_axes=0) -> "VmapCombinator":
         """``kernel.vmap(in_axes=...)`` (combinators/vmap.py:193-218): one independent instance per index of the

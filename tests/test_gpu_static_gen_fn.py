@@ -460,3 +460,67 @@ class TestNoChoicesForwardRefClosure:
         chm = C.kw(sampled=3.5)
         assert f(gfc.assess(chm, ())[0]) == f(model.assess(chm, arg_tuple)[0])
         assert f(gfc.importance(key, C.kw(sampled=3.0), ())[1]) == f(model.importance(key, C.kw(sampled=3.0), arg_tuple)[1])
+
+
+class TestInlineMethodsPartialApply:
+    """reference test_static_gen_fn.py:987-1114 (inline), :1116-1145 (gen on a method), :1147-1165 (partial_apply)"""
+
+    @staticmethod
+    def _models():
+        @genjax.gen
+        def simple_normal():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+
+        @genjax.gen
+        def higher_model():
+            return simple_normal.inline()
+
+        @genjax.gen
+        def higher_higher_model():
+            return higher_model.inline()
+
+        return higher_model, higher_higher_model
+
+    def test_inline_simulate_importance_update_assess(self):
+        lp = lambda v: f(genjax.normal.assess(C.v(v), (0.0, 1.0))[0])
+        for m in self._models():
+            tr = m.simulate(genjax.key(314159), ())
+            ch = tr.get_choices()
+            assert "y1" in ch and "y2" in ch
+            tr_i, w = m.importance(genjax.key(1), C["y1"].set(3.0), ())
+            assert f(w) == pytest.approx(lp(3.0), rel=1e-6)
+            old = f(ch["y1"])
+            tr_u, w_u, _, _ = m.update(genjax.key(2), tr, C["y1"].set(3.0), ())
+            assert f(w_u) == pytest.approx(lp(3.0) - lp(old), rel=1e-4, abs=1e-5)
+            score, _ = m.assess(C["y1"].set(3.0).at["y2"].set(3.0), ())
+            assert f(score) == pytest.approx(2 * lp(3.0), rel=1e-6)
+
+    def test_gen_method(self):
+        class Model:
+            def __init__(self, foo, bar):
+                self.foo, self.bar = foo, bar
+
+            @genjax.gen
+            def run(self, x):
+                y = genjax.normal(self.foo, self.bar) @ "y"
+                z = genjax.normal(x, 1.0) @ "z"
+                return y + z
+
+        m = Model(4.0, 6.0)
+        tr = m.run.simulate(genjax.key(0), (1.0,))
+        chm = tr.get_choices()
+        assert tr.get_args() == (1.0,)                     # the curried `self` is not among the arguments
+        assert tr.gen_fn.partial_args[0] is m
+        assert "y" in chm and "z" in chm and "q" not in chm
+
+    def test_partial_apply(self):
+        @genjax.gen
+        def model(x, y, z):
+            return genjax.normal(x, y + z) @ "x"
+
+        double_curry = model.partial_apply(1.0).partial_apply(1.0)
+        tr = double_curry.simulate(genjax.key(0), (2.0,))
+        assert tr.get_args() == (2.0,) and tr.gen_fn.partial_args == (1.0, 1.0)
+        assert f(tr.get_score()) == pytest.approx(f(genjax.normal.assess(C.v(tr.get_retval()), (1.0, 3.0))[0]), rel=1e-5)
