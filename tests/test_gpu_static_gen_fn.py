@@ -524,3 +524,44 @@ class TestInlineMethodsPartialApply:
         tr = double_curry.simulate(genjax.key(0), (2.0,))
         assert tr.get_args() == (2.0,) and tr.gen_fn.partial_args == (1.0, 1.0)
         assert f(tr.get_score()) == pytest.approx(f(genjax.normal.assess(C.v(tr.get_retval()), (1.0, 3.0))[0]), rel=1e-5)
+
+
+class TestStaticRetvalAndEditRequests:
+    """reference test_static_gen_fn.py:139-151 (literal return value), :401-415 (assess == score), :889-932 (StaticRequest
+    composition, also at a tupled address)"""
+
+    def test_static_retval(self):
+        @genjax.gen
+        def fn():
+            return 1
+
+        tr = fn.simulate(genjax.key(0), ())
+        tr.update(genjax.key(0), C.n(), ())
+        assert tr.get_retval() == 1
+
+    def test_assess_of_own_choices_is_the_score(self):
+        @genjax.gen
+        def simple_normal():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+
+        tr = simple_normal.simulate(genjax.key(314159), ())
+        score, _ = simple_normal.assess(tr.get_choices(), ())
+        assert f(score) == pytest.approx(f(tr.get_score()), rel=1e-6)
+
+    @pytest.mark.parametrize("first", ["y1", ("y1", "y3")])
+    def test_static_edit_request_composition(self, first):
+        @genjax.gen
+        def simple_normal():
+            y1 = genjax.normal(0.0, 1.0) @ first
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+
+        tr = simple_normal.simulate(genjax.key(0), ())
+        request = StaticRequest({first: Regenerate(Selection.all()), "y2": Update(C.v(3.0))})
+        new_tr, w, _, bwd_request = request.edit(genjax.key(1), tr, ())
+        assert f(new_tr.get_choices()["y2"]) == 3.0 and f(w) != 0.0
+        old_tr, w_, _, _ = bwd_request.edit(genjax.key(2), new_tr, ())
+        assert f(old_tr.get_choices()["y2"]) == f(tr.get_choices()["y2"]) and f(w_) != 0.0
+        assert f(w) + f(w_) == pytest.approx(0.0, abs=1e-5)
