@@ -116,6 +116,7 @@ class Diff:
 # ``name`` is a string or a tuple of strings and ``i`` the step / instance index.
 # ---------------------------------------------------------------------------------------------
 ALL = "<all indices>"
+_ANY = "<any component>"
 
 
 def norm_addr(addr):
@@ -182,16 +183,43 @@ class Selection:
     def none() -> "Selection":
         return Selection((), False)
 
+    @staticmethod
+    def leaf() -> "Selection":
+        """exactly the address ``()``; extended, exactly that path and nothing below it (choice_map.py:203-230)"""
+        return Selection((("=", ()),))
+
     class _At:
         def __getitem__(self, addr) -> "Selection":
+            if isinstance(addr, tuple) and addr == ():
+                return Selection.leaf()
+            comps = addr if isinstance(addr, tuple) else (addr,)
+            if any(c is Ellipsis for c in comps) and any(isinstance(c, str) for c in comps):
+                # S[..., "y"]: any one component, then "y" — a name wildcard (choice_map.py:55-60) and, because a step /
+                # instance index is a component of the reference's addresses, also the whole sequence "y"
+                names = tuple(_ANY if c is Ellipsis else c for c in comps if c is Ellipsis or isinstance(c, str))
+                return Selection((("*", names), key_of(addr)))
             return Selection((key_of(addr),))
 
     at = _At()
 
     def check(self, addr=None) -> bool:
-        """a site is selected by its own key, by its whole sequence (name), or by any prefix of its path"""
+        """a site is selected by its own key, by its whole sequence (name), by any prefix of its path, by an exact-path
+        entry equal to its path, or by a wildcard entry matching a prefix of its path"""
+        if isinstance(addr, tuple) and addr == ():
+            hit = ("=", ()) in self.addrs
+            return hit != self.complement if (self.addrs or not self.complement) else True
         name, idx = norm_addr(addr)
+        path = name if isinstance(name, tuple) else (name,)
         hit = key_of(addr) in self.addrs or name in self.addrs or any(p in self.addrs for p in _prefixes(name))
+        if not hit:
+            for e in self.addrs:
+                if isinstance(e, tuple) and len(e) == 2 and e[0] == "=" and isinstance(e[1], tuple):
+                    hit = e[1] == path and e[1] != ()
+                elif isinstance(e, tuple) and len(e) == 2 and e[0] == "*" and isinstance(e[1], tuple):
+                    pat = e[1]
+                    hit = len(path) >= len(pat) and all(pc is _ANY or pc == c for pc, c in zip(pat, path))
+                if hit:
+                    break
         return hit != self.complement
 
     def prefixed(self, prefix) -> "Selection":
@@ -199,6 +227,8 @@ class Selection:
         pre = tuple(prefix) if isinstance(prefix, tuple) else (prefix,)
 
         def join(a):
+            if isinstance(a, tuple) and len(a) == 2 and a[0] in ("=", "*") and isinstance(a[1], tuple):
+                return (a[0], pre + a[1])                   # exact-path and wildcard entries move below the prefix
             name, idx = norm_addr(a)
             full = pre + (name if isinstance(name, tuple) else (name,))
             return full if idx is None or _has_all(idx) else (full, idx)
@@ -215,8 +245,10 @@ class Selection:
         return self.check(addr)
 
     def __getitem__(self, addr) -> bool:
-        """``sel["x"]``, ``sel["z", "y"]``: is the address selected (choice_map.py:262-290)"""
-        return True if addr == () and self.complement and not self.addrs else (False if addr == () else self.check(addr))
+        """``sel["x"]``, ``sel["z", "y"]``: is the address selected (choice_map.py:262-290); a query holds no wildcard"""
+        if addr is Ellipsis or (isinstance(addr, tuple) and any(c is Ellipsis for c in addr)):
+            raise TypeError("a selection is queried with a concrete address: `...` is only meaningful when building one")
+        return self.check(addr)
 
     def __eq__(self, other) -> bool:
         return isinstance(other, Selection) and self.addrs == other.addrs and self.complement == other.complement
@@ -263,6 +295,10 @@ class _SelectionBuilder:
     @property
     def none(self) -> Selection:
         return Selection.none()
+
+    @property
+    def leaf(self) -> Selection:
+        return Selection.leaf()
 
 
 SelectionBuilder = S = _SelectionBuilder()

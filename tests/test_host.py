@@ -455,6 +455,22 @@ class TestChoiceMapAlgebra:
         c0 = C[0].set({"x": 1.0, "y": 2.0})
         assert c0[0, "x"] == 1.0 and c0[0, "y"] == 2.0
 
+    def test_wildcard_and_leaf_selections(self):    # :55-60, :81-116
+        from genjax_amd.core import Selection, SelectionBuilder as S
+        sel = S["x"] | S[..., "y"]
+        assert sel["x"] and sel["any_address", "y"] and sel["rando", "y", "tail"] and not sel["q"]
+        assert S.all == Selection.all() and S.all["x"] and S.all["y", "z"] and S.all[()]
+        assert S.none == Selection.none() and not S.none["x"] and not S.none["y", "z"] and not S.none[()]
+        leaf = S.leaf
+        assert leaf == Selection.leaf()
+        leaf = leaf.extend("a", "b")
+        assert leaf["a", "b"] and not leaf["a"] and not leaf["a", "b", "c"]
+        assert S[()] == Selection.leaf() and () in S[()]
+        exact = Selection.leaf().extend("x", "y")
+        assert not exact["x"] and exact["x", "y"] and not exact["x", "y", "z"]
+        with pytest.raises(TypeError):
+            exact[..., "y"]
+
     def test_selections(self):                      # :40-53, :62-79, :118-181, :228-253
         from genjax_amd.core import Selection, SelectionBuilder as S
         new = S["x"] | S["z", "y"]
