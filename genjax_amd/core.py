@@ -202,10 +202,10 @@ class Selection:
 
     at = _At()
 
-    def check(self, addr=None) -> bool:
+    def check(self, addr=()) -> bool:
         """a site is selected by its own key, by its whole sequence (name), by any prefix of its path, by an exact-path
-        entry equal to its path, or by a wildcard entry matching a prefix of its path"""
-        if isinstance(addr, tuple) and addr == ():
+        entry equal to its path, or by a wildcard entry matching a prefix of its path; without an address: is ``()``"""
+        if addr is None or (isinstance(addr, tuple) and addr == ()):
             hit = ("=", ()) in self.addrs
             return hit != self.complement if (self.addrs or not self.complement) else True
         name, idx = norm_addr(addr)
@@ -241,8 +241,36 @@ class Selection:
     def __contains__(self, addr) -> bool:
         return self.check(addr)
 
-    def __call__(self, addr) -> bool:
-        return self.check(addr)
+    def __call__(self, *addr) -> "Selection":
+        """the selection seen from below the path ``addr`` (choice_map.py:262-290): ``S["a", "b", "c"]("a")("b")["c"]``"""
+        a = tuple(c for x in addr for c in (x if isinstance(x, tuple) else (x,)))
+        if not a:
+            return self
+        out, everything = set(), False
+        for e in self.addrs:
+            if isinstance(e, tuple) and len(e) == 2 and e[0] == "=" and isinstance(e[1], tuple):
+                if e[1][: len(a)] == a:
+                    out.add(("=", e[1][len(a):]))
+                continue
+            if isinstance(e, tuple) and len(e) == 2 and e[0] == "*" and isinstance(e[1], tuple):
+                pat = e[1]
+                n = min(len(a), len(pat))
+                if all(pc is _ANY or pc == c for pc, c in zip(pat[:n], a[:n])):
+                    if len(a) >= len(pat):
+                        everything = True
+                    else:
+                        out.add(("*", pat[len(a):]))
+                continue
+            name, idx = norm_addr(e)
+            path = name if isinstance(name, tuple) else (name,)
+            if path[: len(a)] == a and len(path) > len(a):
+                rest = path[len(a):]
+                rest = rest[0] if len(rest) == 1 else rest
+                out.add(rest if idx is None or _has_all(idx) else (rest, idx))
+            elif a[: len(path)] == path:                     # the entry is the path itself or one of its prefixes
+                everything = True
+        sub = Selection.all() if everything else Selection(out)
+        return ~sub if self.complement else sub
 
     def __getitem__(self, addr) -> bool:
         """``sel["x"]``, ``sel["z", "y"]``: is the address selected (choice_map.py:262-290); a query holds no wildcard"""

@@ -471,6 +471,31 @@ class TestChoiceMapAlgebra:
         with pytest.raises(TypeError):
             exact[..., "y"]
 
+    def test_selection_filter_combination_contains_subselection(self):   # :183-292
+        from genjax_amd.core import ChoiceMap, ChoiceMapBuilder as C, Selection, SelectionBuilder as S
+        chm = ChoiceMap.kw(x=1, y=2, z=3)
+        f_ = (S["x"] | S["y"]).filter(chm)
+        assert "x" in f_ and "y" in f_ and "z" not in f_ and f_["x"] == 1 and f_["y"] == 2
+        assert Selection.none().filter(chm).static_is_empty() and Selection.all().filter(chm) == chm
+        nf = (S["a", "b"] | S["d"]).filter(ChoiceMap.kw(a={"b": 1, "c": 2}, d=3))
+        assert "d" in nf and "b" in nf("a") and "c" not in nf("a")
+        comb = ((S["x"] | S["y"]) & (S["y"] | S["z"])) | S["w"]
+        assert not comb["x"] and comb["y"] and not comb["z"] and comb["w"]
+        sel = S["x"] | S["y", "z"]
+        assert "x" in sel and sel["x"] and ("y", "z") in sel and sel["y", "z"] and "y" not in sel and not sel["y"] and "w" not in sel
+        nested = S["c"].extend("a", "b")
+        assert ("a", "b", "c") in nested and nested["a", "b", "c"] and ("a", "b") not in nested and not nested["a", "b"]
+        assert not nested("a")("b").check() and nested("a")("b")("c").check()
+        with pytest.raises(TypeError):
+            (S["a", "b", "c"] | S["x", "y", "z"])["a", ..., ...]
+        xy = Selection.at["x", "y"]
+        assert not xy[()] and xy["x", "y"] and not xy["other_address"]
+        n = Selection.at["x"].extend("y")
+        assert n["y", "x"] and not n["y"]
+        cs = (C["x", "y"].set(3.0) | C["z"].set(5.0)).get_selection()
+        assert cs["x", "y"] and cs["z"] and not cs["w"] and cs("x")["y"]
+        assert ChoiceMap.empty().get_selection() == Selection.none()
+
     def test_selections(self):                      # :40-53, :62-79, :118-181, :228-253
         from genjax_amd.core import Selection, SelectionBuilder as S
         new = S["x"] | S["z", "y"]
