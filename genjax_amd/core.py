@@ -510,6 +510,12 @@ class ChoiceMap:
 
     @staticmethod
     def v(value) -> "ChoiceMap":
+        """a bare value (choice_map.py `choice`): a concrete-False mask or an empty array is no choice at all, a concrete-True
+        mask is its value"""
+        if isinstance(value, Masked) and isinstance(value.flag, bool):
+            return ChoiceMap.v(value.value) if value.flag else ChoiceMap()
+        if not isinstance(value, (Masked, dict, ChoiceMap)) and value is not None and hasattr(value, "shape") and int(np.prod(value.shape)) == 0:
+            return ChoiceMap()
         return ChoiceMap({_VALUE: value})
 
     choice = v
@@ -597,6 +603,8 @@ class ChoiceMap:
         return not self._d
 
     def __contains__(self, addr) -> bool:
+        if isinstance(addr, tuple) and addr == ():
+            return self.has_value()
         try:
             name, idx = norm_addr(addr)
         except KeyError:

@@ -444,6 +444,34 @@ class TestChoiceMapAlgebra:
         assert chm.get_submap("a").get_submap("b", "c").get_value() == 1.0
         assert chm.get_submap("a", "d").get_value() == 2.0
 
+    def test_choice_kv_d_from_mapping_simplify(self):   # :412-463, :662-687
+        from genjax_amd import Mask
+        from genjax_amd.core import ChoiceMap, ChoiceMapBuilder as C, ChoiceMapNoValueAtAddress, SelectionBuilder as S
+        assert ChoiceMap.empty().static_is_empty()
+        choice = ChoiceMap.choice(42.0)
+        assert choice.get_value() == 42.0 and choice.has_value() and () in choice
+        assert ChoiceMap.choice(Mask(42.0, False)).static_is_empty()
+        assert ChoiceMap.choice(Mask(42.0, True)) == ChoiceMap.choice(42.0)
+        mv = Mask(42.0, np.array(False))
+        assert ChoiceMap.choice(mv).get_value() == mv
+        assert ChoiceMap.choice(np.ones((0,))).static_is_empty()
+        kv = ChoiceMap.kw(x=1, y=2)
+        assert kv["x"] == 1 and kv["y"] == 2 and "x" in kv and "y" in kv and "other_value" not in kv
+        d = ChoiceMap.d({"a": 1, "b": {"c": 2, "d": {"e": 3}}})
+        assert d["a"] == 1 and d["b", "c"] == 2 and d["b", "d", "e"] == 3 and "a" in d and ("b", "c") in d and ("b", "d", "e") in d
+        fm = ChoiceMap.from_mapping([("x", 1), (("y", "z"), 2), (("w", "v", "u"), 3)])
+        assert fm["x"] == 1 and fm["y", "z"] == 2 and fm["w", "v", "u"] == 3 and ("w", "v", "u") in fm
+        outer = ChoiceMap.kw(x=ChoiceMap.kw(a=1, b=2), y=3)
+        assert outer["x", "a"] == 1 and outer["x", "b"] == 2 and outer["y"] == 3
+        root = ChoiceMap.kw(r=ChoiceMap.kw(p=ChoiceMap.kw(m=4, n=5), q=6), s=7)
+        assert root["r", "p", "m"] == 4 and root["r", "p", "n"] == 5 and root["r", "q"] == 6 and root["s"] == 7
+        xyz = ChoiceMap.d({"x": 1, "y": 2, "z": 3})
+        or_chm, xor_chm = xyz.filter(S["x"]) | xyz.filter(S["y"]), xyz.filter(S["x"]) ^ xyz.filter(S["y"])
+        assert or_chm.simplify() == xor_chm.simplify() == ChoiceMap.d({"x": 1, "y": 2})
+        assert or_chm["x"] == 1 and or_chm["y"] == 2
+        with pytest.raises(ChoiceMapNoValueAtAddress, match="z"):
+            or_chm["z"]
+
     def test_index_only_addresses(self):            # :812-834, :864-869
         from genjax_amd.core import ChoiceMapBuilder as C, ChoiceMapNoValueAtAddress, SelectionBuilder as S
         xs, ys = np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0])
