@@ -707,6 +707,19 @@ class ChoiceMap:
         """the same choices below the path ``addrs`` (choice_map.py:1203-1226)"""
         return ChoiceMap({_rekey(tuple(addrs), a): v for a, v in self._d.items()}, self._lead_axes)
 
+    def invalid_subset(self, gen_fn, args: tuple):
+        """the choices of this map at addresses ``gen_fn(*args)`` does not produce, or None when every address is one of the
+        function's (choice_map.py `invalid_subset`; a missing address is fine).  A whole-sequence entry (``C["x"].set(xs)``)
+        is valid when the function has sites ``("x", i)``."""
+        sl, _ = gen_fn.site_list(tuple(args))
+        known = set()
+        for st in sl.sites:
+            known.add(st.addr)
+            name, idx = norm_addr(st.addr) if st.addr != _VALUE else (_VALUE, None)
+            known.add(name)
+        bad = {a: v for a, v in self._d.items() if a not in known}
+        return ChoiceMap(bad, self._lead_axes) if bad else None
+
     def simplify(self) -> "ChoiceMap":
         """this representation is always flat: nothing to push down (choice_map.py `simplify`)"""
         return self

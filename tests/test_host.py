@@ -472,6 +472,38 @@ class TestChoiceMapAlgebra:
         with pytest.raises(ChoiceMapNoValueAtAddress, match="z"):
             or_chm["z"]
 
+    def test_choicemap_validation(self):            # :875-927
+        import genjax_amd as genjax
+        from genjax_amd.core import ChoiceMap
+
+        @genjax.gen
+        def model(x):
+            y = genjax.normal(x, 1.0) @ "y"
+            z = genjax.bernoulli(probs=0.5) @ "z"
+            return y + z
+
+        assert ChoiceMap.kw(y=1.0, z=1).invalid_subset(model, (0.0,)) is None
+        bad1 = ChoiceMap.kw(x=1.0)
+        assert bad1.invalid_subset(model, (0.0,)) == bad1
+        assert ChoiceMap.kw(y=1.0, z=1, extra=0.5).invalid_subset(model, (0.0,)) == ChoiceMap.kw(extra=0.5)
+
+        @genjax.gen
+        def inner_model():
+            a = genjax.normal(0.0, 1.0) @ "a"
+            b = genjax.bernoulli(probs=0.5) @ "b"
+            return a + b
+
+        @genjax.gen
+        def outer_model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = inner_model() @ "y"
+            return x + y
+
+        assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5, b=1)).invalid_subset(outer_model, ()) is None
+        assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5)).invalid_subset(outer_model, ()) is None          # a missing address is fine
+        assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5, b=1, c=2.0)).invalid_subset(outer_model, ()) == ChoiceMap.kw(y=ChoiceMap.kw(c=2.0))
+        assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5, b=1), z=3.0).invalid_subset(outer_model, ()) == ChoiceMap.kw(z=3.0)
+
     def test_index_only_addresses(self):            # :812-834, :864-869
         from genjax_amd.core import ChoiceMapBuilder as C, ChoiceMapNoValueAtAddress, SelectionBuilder as S
         xs, ys = np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0])
