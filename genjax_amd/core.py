@@ -536,6 +536,8 @@ class ChoiceMap:
             if isinstance(value, ChoiceMap) and value.has_value():
                 value = value.get_value()
             comps = self.addr if isinstance(self.addr, tuple) else (self.addr,)
+            if any(isinstance(c, slice) and c != slice(None) for c in comps):
+                raise ValueError("a choice map is set at whole sequences ([:]) or single indices, not at partial slices")
             if comps and not any(isinstance(c, str) for c in comps) and isinstance(value, (dict, ChoiceMap)):
                 # C[:].set({"x": xs}) / C[0].set({"x": 1.0}): the index applies to every address of the value
                 flat: dict = {}
@@ -617,6 +619,13 @@ class ChoiceMap:
     def __getitem__(self, addr):
         # chm["x"], chm["sub", "x"], chm[t, "x"] / chm["tracks", t, "pos"] (one step), chm[:, "x"] (stacked);
         # nested combinators: chm[i, t, "x"] (one instance, one step), chm[:, :, "x"] (stacked over both), chm[i, :, "x"]
+        if isinstance(addr, tuple) and any(isinstance(c, slice) and c != slice(None) for c in addr):
+            # a partial slice of a sequence (chm[0:4, "x"], choice_map.py slices): the whole sequence, then the slice on the
+            # axis of that index component
+            full = tuple(slice(None) if isinstance(c, slice) else c for c in addr)
+            whole = self[full]
+            cut = tuple(c for c in addr if isinstance(c, slice) or c is Ellipsis)
+            return whole[(slice(None),) * self._lead_axes + tuple(slice(None) if c is Ellipsis else c for c in cut)]
         name, idx = norm_addr(addr)
         if isinstance(idx, tuple):
             if not _has_all(idx):

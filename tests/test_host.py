@@ -504,6 +504,47 @@ class TestChoiceMapAlgebra:
         assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5, b=1, c=2.0)).invalid_subset(outer_model, ()) == ChoiceMap.kw(y=ChoiceMap.kw(c=2.0))
         assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=0.5, b=1), z=3.0).invalid_subset(outer_model, ()) == ChoiceMap.kw(z=3.0)
 
+    def test_validation_of_sequences_and_slices(self):   # :929-979, :1025-1081
+        import genjax_amd as genjax
+        from genjax_amd.core import ChoiceMap, ChoiceMapBuilder as C
+
+        @genjax.gen
+        def inner_model(x):
+            a = genjax.normal(x, 1.0) @ "a"
+            b = genjax.bernoulli(probs=0.5) @ "b"
+            return a + b
+
+        @genjax.gen
+        def outer_model():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            y = inner_model.vmap(in_axes=(0,))(np.array([1.0, 2.0, 3.0], np.float32)) @ "y"
+            return x
+
+        a_, b_ = np.array([0.5, 1.5, 2.5]), np.array([1, 0, 1])
+        assert ChoiceMap.kw(x=1.0, y=C[:].set(ChoiceMap.kw(a=a_, b=b_))).invalid_subset(outer_model, ()) is None
+        assert ChoiceMap.kw(x=1.0, y=ChoiceMap.kw(a=a_, b=b_)).invalid_subset(outer_model, ()) is None    # the index layer is optional
+        c_ = np.array([0.1, 0.2, 0.3])
+        bad = ChoiceMap.kw(x=1.0, y=C[:].set(ChoiceMap.kw(a=a_, b=b_, c=c_))).invalid_subset(outer_model, ())
+        assert bad == C["y", :, "c"].set(c_)
+
+        @genjax.gen
+        def step(mean):
+            return genjax.normal(mean, 1.0) @ "x"
+
+        chain = step.iterate(n=4)
+        xs = np.array([0.5, 1.2, 0.8, 0.9])
+        assert C[:, "x"].set(xs).invalid_subset(chain, (1.0,)) is None
+        assert C["x"].set(xs).invalid_subset(chain, (1.0,)) is None
+        assert C[:].set({"x": xs, "z": xs}).invalid_subset(chain, (1.0,)) == C[:, "z"].set(xs)
+
+        for partial in (slice(None, 3), slice(0, 3), slice(0, 3, 1)):
+            with pytest.raises(ValueError):
+                C[partial, "x"].set(np.array([1, 2]))
+        vals = np.arange(10)
+        chm = C[:, "x"].set(vals)
+        assert np.array_equal(chm[:, "x"], vals) and chm[1, "x"] == vals[1] and chm[np.int64(5), "x"] == vals[5]
+        assert np.array_equal(chm[0:4, "x"], vals[0:4])
+
     def test_index_only_addresses(self):            # :812-834, :864-869
         from genjax_amd.core import ChoiceMapBuilder as C, ChoiceMapNoValueAtAddress, SelectionBuilder as S
         xs, ys = np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0])
