@@ -12,6 +12,9 @@ from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gum
                   logit_normal, marginal, poisson, student_t, truncated_normal, weibull, StaticGenerativeFunction, Trace, bernoulli, beta, categorical,  # noqa: F401
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
+from .gen import Scan, Vmap, accumulate, reduce  # noqa: F401
+from .inference import requests, smc  # noqa: F401  (the reference's genjax.smc / genjax.requests modules)
+from .inference.smc import SMCAlgorithm as Algorithm  # noqa: F401
 from .inference import (HMC, IndexRequest, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401
                         ParticleCollection, Regenerate, Rejuvenate, SafeHMC, SMCAlgorithm, StaticRequest, Target, TrialCollections, Update)
 from .program import AddressReuse, MissingAddress  # noqa: F401

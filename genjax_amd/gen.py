@@ -1081,9 +1081,22 @@ class _Iterate(GenerativeFunction):
         return GenCall(inline)
 
 
-def scan(n: int) -> Callable:
+def scan(n: int | None = None) -> Callable:
     """``@genjax.scan(n=T)`` decorator form (combinators/scan.py)."""
     return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).scan(n)
+
+
+def accumulate() -> Callable:
+    """``@genjax.accumulate()`` decorator form (combinators/scan.py:791-852)"""
+    return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).accumulate()
+
+
+def reduce() -> Callable:
+    """``@genjax.reduce()`` decorator form (combinators/scan.py:854-914)"""
+    return lambda f: (f if isinstance(f, StaticGenerativeFunction) else gen(f)).reduce()
+
+
+Scan, Vmap = ScanCombinator, VmapCombinator          # the reference's class names (scan.py:110, vmap.py:98)
 
 
 def gen(fn: Callable) -> StaticGenerativeFunction:

@@ -673,3 +673,15 @@ def test_gen_transfers_the_function_metadata():
     assert w.__doc__ == original_function.__doc__ and w.__name__ == original_function.__name__
     assert w.__module__ == original_function.__module__ and w.__qualname__ == original_function.__qualname__
     assert getattr(w, "__wrapped__") == original_function
+
+
+def test_reference_names_are_importable():
+    """names a reference user imports from `genjax` for this path (src/genjax/{core,generative_functions,inference}/__init__.py)"""
+    import genjax_amd as g
+    for n in ("gen", "ChoiceMap", "ChoiceMapBuilder", "Selection", "SelectionBuilder", "Mask", "Diff", "NoChange", "UnknownChange",
+              "normal", "beta", "flip", "bernoulli", "categorical", "mv_normal_diag", "gamma", "exponential", "laplace", "poisson",
+              "scan", "vmap", "repeat", "iterate", "iterate_final", "accumulate", "reduce", "Scan", "Vmap",
+              "Target", "ImportanceK", "Importance", "ChangeTarget", "Algorithm", "SMCAlgorithm", "ParticleCollection",
+              "Update", "Regenerate", "Rejuvenate", "HMC", "SafeHMC", "StaticRequest", "IndexRequest", "smc", "requests", "marginal"):
+        assert hasattr(g, n), n
+    assert g.smc.ImportanceK is g.ImportanceK and g.requests.HMC is g.HMC
