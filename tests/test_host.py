@@ -685,3 +685,62 @@ def test_reference_names_are_importable():
               "Update", "Regenerate", "Rejuvenate", "HMC", "SafeHMC", "StaticRequest", "IndexRequest", "smc", "requests", "marginal"):
         assert hasattr(g, n), n
     assert g.smc.ImportanceK is g.ImportanceK and g.requests.HMC is g.HMC
+
+
+def test_tracing_of_inline_methods_closures_and_scan_lengths():
+    """host-side lowering of the forms added for the reference's static / scan tests: the site lists (no device needed)"""
+    import genjax_amd as genjax
+
+    @genjax.gen
+    def simple_normal():
+        y1 = genjax.normal(0.0, 1.0) @ "y1"
+        y2 = genjax.normal(0.0, 1.0) @ "y2"
+        return y1 + y2
+
+    @genjax.gen
+    def higher():
+        return simple_normal.inline()
+
+    @genjax.gen
+    def nested():
+        return simple_normal() @ "sub"
+
+    addrs = lambda g, args=(): [s.addr for s in g.site_list(args)[0].sites]
+    assert addrs(higher) == ["y1", "y2"] and addrs(nested) == [("sub", "y1"), ("sub", "y2")]
+
+    class Model:
+        def __init__(self, loc):
+            self.loc = loc
+
+        @genjax.gen
+        def run(self, x):
+            return genjax.normal(self.loc, 1.0) @ "y" + genjax.normal(x, 1.0) @ "z"
+
+    m = Model(4.0)
+    assert addrs(m.run, (1.0,)) == ["y", "z"] and m.run.partial_args == (m,) and Model.run.partial_args == ()
+
+    @genjax.gen
+    def model3(x, y, z):
+        return genjax.normal(x, y + z) @ "x"
+
+    assert model3.partial_apply(1.0).partial_apply(1.0).partial_args == (1.0, 1.0)
+
+    @genjax.gen
+    def walk(x, std):
+        nx = genjax.normal(x, std) @ "x"
+        return nx, nx
+
+    xs = np.array([2.0, 4.0, 3.0], np.float32)
+    assert addrs(walk.scan(), (0.0, xs)) == [("x", 0), ("x", 1), ("x", 2)] == addrs(walk.scan(n=3), (0.0, xs))
+    assert addrs(walk.scan(n=0), (0.0, np.zeros(0, np.float32))) == []
+    with pytest.raises(ValueError, match="different leading axis sizes: 1, 2"):
+        @genjax.gen
+        def foo(shift, d):
+            return genjax.normal(d["loc"], d["scale"]) @ "x" + shift, None
+        foo.scan().site_list((1.0, {"loc": np.array([10.0, 12.0], np.float32), "scale": np.array([1.0], np.float32)}))
+
+    @genjax.gen
+    def add(acc, v):
+        return acc + genjax.normal(v, 1.0) @ "n"
+
+    assert addrs(add.accumulate(), (0.0, xs)) == [("n", 0), ("n", 1), ("n", 2)] == addrs(add.reduce(), (0.0, xs))
