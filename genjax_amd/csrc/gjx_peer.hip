@@ -37,6 +37,12 @@ struct gjx_peer_ctx {
   char* flag = nullptr;                // this rank's FLAG window
   size_t data_bytes = 0, flag_bytes = 0;
   size_t off_rows[2] = {0, 0}, off_lw[2] = {0, 0}, off_m[2] = {0, 0};   // off_m: transition means of the resample-move filter
+  size_t off_chk[2] = {0, 0};          // verify mode: one check word per particle row (u32[K], ping-pong like the rows)
+  bool verify = false;                 // GJX_PEER_VERIFY=1 when the context was created
+  bool verify_fault = false;           // GJX_PEER_VERIFY_FAULT=<this rank>: publish wrong check words (test hook)
+  bool data_fine = false;              // DATA window in fine-grained memory (GJX_PEER_DATA=fine)
+  std::vector<uint32_t> h_keys;        // host scratch of a filter run (step keys, comb offsets)
+  std::vector<double> h_us;
   size_t off_region[2] = {0, 0}, region_bytes = 0;
   // inside a flag region
   size_t r_aggA = 0, r_aggB = 0, r_bsum = 0, r_bmax = 0, r_ready = 0, r_gmm = 0;
@@ -59,12 +65,11 @@ struct gjx_peer_ctx {
 extern "C" int gjx_peer_ctx_destroy(gjx_peer_ctx* c) {
   if (!c) return GJX_OK;
   (void)hipDeviceSynchronize();
-  if (c->connected) {
-    for (int g = 0; g < c->world; ++g) {
-      if (g == c->rank) continue;
-      if (c->peer_data[g]) (void)hipIpcCloseMemHandle(c->peer_data[g]);
-      if (c->peer_flag[g]) (void)hipIpcCloseMemHandle(c->peer_flag[g]);
-    }
+  for (int g = 0; g < c->world; ++g) {   // (whatever `connected` says: a connect that failed half-way has opened some of them)
+    if (g == c->rank) continue;
+    if (c->peer_data[g]) (void)hipIpcCloseMemHandle(c->peer_data[g]);
+    if (c->peer_flag[g]) (void)hipIpcCloseMemHandle(c->peer_flag[g]);
+    c->peer_data[g] = nullptr; c->peer_flag[g] = nullptr;
   }
   void* bufs[] = {c->data, c->flag, c->delta_dev, c->us_dev, c->keys_dev};
   for (void* b : bufs)
@@ -92,7 +97,12 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   for (int p = 0; p < 2; ++p) { c->off_rows[p] = o; o = align_up(o + sizeof(float) * (size_t)rows * (size_t)K_local); }
   for (int p = 0; p < 2; ++p) { c->off_lw[p] = o; o = align_up(o + sizeof(float) * (size_t)K_local); }
   for (int p = 0; p < 2; ++p) { c->off_m[p] = o; o = align_up(o + sizeof(float) * (size_t)rows * (size_t)K_local); }
+  for (int p = 0; p < 2; ++p) { c->off_chk[p] = o; o = align_up(o + sizeof(uint32_t) * (size_t)K_local); }
   c->data_bytes = o;
+  { const char* v = getenv("GJX_PEER_VERIFY"); c->verify = v && atoi(v) != 0; }
+  { const char* v = getenv("GJX_PEER_DATA"); c->data_fine = v && !strcmp(v, "fine"); }
+  // test hook of the verify mode: this rank publishes check words that do not belong to its rows (tests/test_gpu_config4.py)
+  { const char* v = getenv("GJX_PEER_VERIFY_FAULT"); c->verify_fault = c->verify && v && atoi(v) == rank; }
   // FLAG window: [256 B control][region 0][region 1]; a region: granules A, B [NT] | ring sum, max [3][NT] | ready words |
   // the words of the one-launch resampling step (twice, for alternating calls: 4 x [MAX_RANKS] u64 + this rank's tile granules [nt])
   const size_t NT = (size_t)c->NT;
@@ -108,7 +118,18 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   c->off_region[1] = kAlign + r;
   c->flag_bytes = kAlign + 2 * r;
   auto fail = [&](int code) { gjx_peer_ctx_destroy(c); return code; };
-  if (hipMalloc((void**)&c->data, c->data_bytes) != hipSuccess) return fail(gjx_fail(GJX_EHIP, "gjx_peer_ctx_create: data window"));
+  // DATA window.  Default: ordinary (coarse-grained) device memory — every access another rank can observe carries its scope
+  // in the instruction (sc0 sc1 write-through stores, sc0 sc1 loads: DESIGN.md §8 "memory model of the peer windows").
+  // GJX_PEER_DATA=fine: fine-grained device memory (hipDeviceMallocFinegrained) — coherent between agents by its memory
+  // type, whatever the instructions say; the fallback for a fabric on which the coarse window shows stale rows
+  // (GJX_PEER_VERIFY=1 raises GJX_STATUS_VERIFY_MISMATCH then).  Every rank of a run must use the same setting.
+  if (c->data_fine) {
+    if (hipExtMallocWithFlags((void**)&c->data, c->data_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      c->data = nullptr;
+      return fail(gjx_fail(GJX_EHIP, "gjx_peer_ctx_create: fine-grained data window (GJX_PEER_DATA=fine)"));
+    }
+  } else if (hipMalloc((void**)&c->data, c->data_bytes) != hipSuccess) return fail(gjx_fail(GJX_EHIP, "gjx_peer_ctx_create: data window"));
   // flags are polled while other devices write them: uncached device memory (what RCCL uses for its own flags); plain
   // device memory as the fallback (every access to it carries its scope in the instruction anyway)
   if (hipExtMallocWithFlags((void**)&c->flag, c->flag_bytes, hipDeviceMallocUncached) != hipSuccess) {
@@ -120,6 +141,11 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
       hipMalloc((void**)&c->delta_dev, sizeof(long long) * 2 * (size_t)n_ranks) != hipSuccess ||
       hipMemset(c->delta_dev, 0, sizeof(long long) * 2 * (size_t)n_ranks) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
     return fail(gjx_fail(GJX_EHIP, "gjx_peer_ctx_create: initialisation"));
+  // per-run scratch of the filter (step keys, comb offsets): sized here for T <= 4096 so that no call allocates
+  c->t_cap = 4096;
+  if (hipMalloc((void**)&c->us_dev, sizeof(double) * (size_t)c->t_cap) != hipSuccess ||
+      hipMalloc((void**)&c->keys_dev, sizeof(uint32_t) * 2 * (size_t)c->t_cap) != hipSuccess)
+    return fail(gjx_fail(GJX_EHIP, "gjx_peer_ctx_create: step-key scratch"));
   c->peer_data[rank] = c->data;
   c->peer_flag[rank] = c->flag;
   c->connected = n_ranks == 1;
@@ -224,7 +250,7 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
   if (pf_plan(rng_mode, m->dx, m->dy, K, c->world, c->share, &pf, move) != GJX_OK)
     return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_peer: this shape does not fit the one-launch filter (dx in {2,4,8,16}, dy <= 32, "
                                        "K_total <= 2^22, K_local / 1024 tiles co-resident at <= 8 tiles per block)");
-  if (T > c->t_cap) {   // (per-run scratch grows outside every loop)
+  if (T > c->t_cap) {   // longer than the 4096 steps the context was sized for: the scratch grows here, once, outside every loop
     if (c->us_dev) (void)hipFree(c->us_dev);
     if (c->keys_dev) (void)hipFree(c->keys_dev);
     c->us_dev = nullptr; c->keys_dev = nullptr; c->t_cap = 0;
@@ -232,8 +258,8 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
     GJX_HIP(hipMalloc((void**)&c->keys_dev, sizeof(uint32_t) * 2 * (size_t)T), "gjx_ssm_filter_peer: step keys");
     c->t_cap = T;
   }
-  static thread_local std::vector<uint32_t> h_keys;
-  static thread_local std::vector<double> h_us;
+  std::vector<uint32_t>& h_keys = c->h_keys;
+  std::vector<double>& h_us = c->h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);
   GJX_HIP(hipMemcpyAsync(c->us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st), "gjx_ssm_filter_peer(step offsets)");
   GJX_HIP(hipMemcpyAsync(c->keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st), "gjx_ssm_filter_peer(step keys)");
@@ -265,6 +291,8 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
   f.zero_ptr = (unsigned long long*)(c->flag + c->off_region[other] + c->r_aggA);
   f.zero_n = (int)((c->r_bsum - c->r_aggA) / 8);
   f.q0 = m->q0;
+  f.verify = c->verify ? (c->verify_fault ? 2 : 1) : 0;
+  f.chk_a = (unsigned*)(c->data + c->off_chk[0]); f.chk_b = (unsigned*)(c->data + c->off_chk[1]);
   if (move) {
     f.m_a = (float*)(c->data + c->off_m[0]); f.m_b = (float*)(c->data + c->off_m[1]);
     f.n_moves = n_moves; f.move_scale = move_scale; f.acc_total = acc_total;
@@ -315,6 +343,8 @@ struct PrgArgs {
   unsigned* ctrl;
   unsigned seq;                    // call counter of the context (same on every rank): the tags
   unsigned first_budget;
+  int verify;                      // GJX_PEER_VERIFY=1: check words per particle row + tile totals against the granules
+  unsigned* chk;                   // [K] this rank's check words of the rows of this call (DATA window)
 };
 
 constexpr int kPrgMaxTiles = 1024;
@@ -380,6 +410,21 @@ __global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
     if (lane == 0) wsum[wid] = wt;
   }
   __syncthreads();
+  const bool verify = a.verify != 0;
+  auto verify_failed = [&]() { __hip_atomic_fetch_or(&a.ctrl[2], kStatusVerifyMismatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  if (verify) {
+    // the rows of this block's own particles (the caller's kernels wrote them) get their check words before the block's
+    // granule goes out: a remote reader pulls a row of this rank only after this rank's hop-2 word, which follows every granule
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      if (i0 + k >= K) continue;
+      uint32_t h = row_check_init((int)a.seq, (uint32_t)(a.offset + i0 + k));
+      for (int r = 0; r < a.rows; ++r) h = row_check_mix(h, a.src[(int64_t)r * a.src_stride + i0 + k]);
+      store_scoped_u32(a.chk + i0 + k, a.verify == 2 ? h ^ 1u : h, sys);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (tid == 0) store_scoped_u64(&a.agg[blockIdx.x], tile_granule(tag4, eb, wsum[0] + wsum[1] + wsum[2] + wsum[3]), sys);
   if (blockIdx.x == 0 && a.mode == 2 && sys && tid < G)          // this rank's LSE pair, to every rank (ordered before the hop-1 word below)
     store_scoped_u64(peer_ptr(a.wP + a.rank, sPF[tid]), pack_f2(mx_r, sm_sum), true);
@@ -608,6 +653,12 @@ __global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
           for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];
         }
         __syncthreads();                         // also: every lane is done searching the previous round's cumL
+        if (verify && tid < CH && idx + tid < ntiles) {
+          // the log-weights just pulled must quantise to the total their owner published in the tile's granule
+          const int ts = tmin + idx + tid, sh = E - Eb[ts];
+          const uint64_t tot = s_wtot[tid][0] + s_wtot[tid][1] + s_wtot[tid][2] + s_wtot[tid][3];
+          if ((sh < 64 ? tot >> sh : 0) != P[ts + 1] - P[ts]) verify_failed();
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           uint64_t base = inc[c] - sacc[c];
@@ -646,16 +697,30 @@ __global__ __launch_bounds__(256) void k_peer_resample_gather(PrgArgs a) {
   }
   const bool whole = i0 + ITEMS <= K;
   const bool vec = ITEMS == 4 && whole && (a.dst_stride & 3) == 0 && (((uintptr_t)a.dst) & 15) == 0;
+  uint32_t hk[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) hk[k] = row_check_init((int)a.seq, (uint32_t)((int64_t)(anc[k] / kpad) * K + sl[k]));
 #pragma unroll 4
   for (int r = 0; r < a.rows; ++r) {
     const float* sr = a.src + (int64_t)r * a.src_stride;
     float v[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) v[k] = sys ? load_scoped(peer_ptr(sr, dl[k]) + sl[k], true) : sr[sl[k]];
+    if (verify) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) hk[k] = row_check_mix(hk[k], v[k]);
+    }
     if (vec) *(float4*)(a.dst + (int64_t)r * a.dst_stride + i0) = make_float4(v[0], v[ITEMS > 1 ? 1 : 0], v[ITEMS > 2 ? 2 : 0], v[ITEMS > 3 ? 3 : 0]);
     else {
 #pragma unroll
       for (int k = 0; k < ITEMS; ++k) if (i0 + k < K) a.dst[(int64_t)r * a.dst_stride + i0 + k] = v[k];
+    }
+  }
+  if (verify && !s_dead) {                       // every pulled row against its owner's check word
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const unsigned want = load_scoped_u32(peer_ptr((const unsigned*)a.chk, dl[k]) + sl[k], sys);
+      if (i0 + k < K && want != hk[k]) verify_failed();
     }
   }
 }
@@ -700,6 +765,8 @@ extern "C" int gjx_peer_resample_gather(gjx_peer_ctx* c, int32_t parity, const f
   a.peer_flag = c->world > 1 ? c->delta_dev + c->world : nullptr;
   a.ctrl = (unsigned*)c->flag + 8;
   a.seq = (unsigned)(c->n_gmm++);
+  a.verify = c->verify ? (c->verify_fault ? 2 : 1) : 0;
+  a.chk = (unsigned*)(c->data + c->off_chk[parity]);
   a.first_budget = c->world > 1 ? (1u << 24) : (1u << 16);
   void* args[] = {&a};
   const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)c->nt), dim3(256), args, 0, (hipStream_t)stream);

@@ -19,8 +19,8 @@ int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int shar
   if (n_ranks > 1 && K_local % kPfHostThreads) return GJX_EUNSUPPORTED;   // sharded: whole tiles per rank
   if (nt * n_ranks > kPfHostMaxTiles) return GJX_EUNSUPPORTED;
   const size_t lds = pf_host_dyn_lds((int)(nt * n_ranks));
-  const int spls[4] = {1, 2, 4, 8};
-  for (int i = 0; i < 4; ++i) {
+  const int spls[5] = {1, 2, 4, 8, 16};
+  for (int i = 0; i < 5; ++i) {
     const int spl = spls[i];
     const void* fn = rng_mode == GJX_RNG_JAX32 ? pf_kernel_jax(dx, spl, move) : pf_kernel_flat(dx, spl, move);
     if (!fn) continue;

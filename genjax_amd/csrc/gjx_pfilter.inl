@@ -86,11 +86,24 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
   auto lw_buf = [&](int t) { return ((T - 1 - t) & 1) ? f.lw_odd : f.lw_even; };
   auto x_buf = [&](int t) { return (t & 1) ? f.x_b : f.x_a; };
   auto m_buf = [&](int t) { return (t & 1) ? f.m_b : f.m_a; };   // MOVE: A x'_{t-1} of step t (step 0: the prior mean, zero — never read)
+  auto chk_buf = [&](int t) { return (t & 1) ? f.chk_b : f.chk_a; };   // verify mode: check words of the rows of step t
+  const bool verify = f.verify != 0;             // (wave-uniform: scalar branches)
+  auto verify_failed = [&]() { __hip_atomic_fetch_or(&f.ctrl[2], kStatusVerifyMismatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const float rr = fast_rcp(f.r);
   const float lconst = -(float)f.dy * (kHalfLog2Pi + fast_log(f.r));
   float lw_own[SPL];
 #pragma unroll
   for (int s = 0; s < SPL; ++s) lw_own[s] = act(s) ? lw_buf(0)[jl(s)] : -INFINITY;    // step 0 ran in the previous launch
+  if (verify) {                                  // step 0's rows (written by the previous launch) get their check words here:
+#pragma unroll 1                                  // complete before this block's first `ready` word, like every store of a step
+    for (int s = 0; s < SPL; ++s) {
+      if (!act(s)) continue;
+      uint32_t h = row_check_init(0, (uint32_t)(f.offset + jl(s)));
+#pragma unroll
+      for (int d = 0; d < DX; ++d) h = row_check_mix(h, x_buf(0)[(int64_t)d * K + jl(s)]);
+      store_scoped_u32(chk_buf(0) + jl(s), f.verify == 2 ? h ^ 1u : h, sys);
+    }
+  }
   // ---- LSE record of step s from ring slot s % 3: loads out (fixed trip count), reduced later, written by thread 0 ----
   auto lse_ring_issue = [&](int s, float& rpm, float& rps) {       // the first entry of this thread: stays in flight
     const int b = (tid + THREADS / 2) % THREADS;
@@ -356,6 +369,14 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
           if (lane == 63) wq[wid] = inc;                              // the wave's total: offset of the next quarter
         }
         __syncthreads();
+        if (verify && on && part == 0 && lane == 0) {
+          // the log-weights this block just pulled must quantise to the total their owner published in the tile's granule
+          const int tsrc = tmin + c0 + tl;
+          uint64_t tot = 0;
+          for (int w = 0; w < WPT; ++w) tot += wq[tl * WPT + w];
+          const int sh = Emax - Eb[tsrc];
+          if ((sh < 64 ? tot >> sh : 0) != P[tsrc + 1] - P[tsrc]) verify_failed();
+        }
         if (on) {
           uint64_t base = inc - sacc;
           for (int w = 0; w < part; ++w) base += wq[tl * WPT + w];
@@ -398,6 +419,13 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
       float xp[DX], nz[DX], xn[DX];
 #pragma unroll
       for (int d = 0; d < DX; ++d) xp[d] = load_scoped(xs + (int64_t)d * K, sys);
+      if (verify) {                              // the pulled row against its owner's check word (step t - 1, global index)
+        const unsigned want = load_scoped_u32(peer_ptr((const unsigned*)chk_buf(t - 1), sPD[sg]) + sl, sys);
+        uint32_t h = row_check_init(t - 1, (uint32_t)((int64_t)sg * K + sl));
+#pragma unroll
+        for (int d = 0; d < DX; ++d) h = row_check_mix(h, xp[d]);
+        if (a && total > 0 && h != want) verify_failed();
+      }
       if constexpr (MOVE) {
         // resample-move: n_moves random-walk Metropolis steps on the gathered x_{t-1} with p(x_{t-1} | parent, y_{t-1}) as
         // invariant density — k_ssm_step<.., MOVE>'s arithmetic and draws (site 2 of the step's stream), so the one-launch
@@ -461,6 +489,12 @@ __global__ __launch_bounds__(kPfThreads) void k_pf_persistent(PfArgs f) {
       if (a) {
 #pragma unroll
         for (int d = 0; d < DX; ++d) store_scoped(x_out + (int64_t)d * K + j, xn[d], sys);
+        if (verify) {
+          uint32_t h = row_check_init(t, (uint32_t)(f.offset + j));
+#pragma unroll
+          for (int d = 0; d < DX; ++d) h = row_check_mix(h, xn[d]);
+          store_scoped_u32(chk_buf(t) + j, f.verify == 2 ? h ^ 1u : h, sys);
+        }
       }
       float qsum = 0.0f;
       if (f.H) {
@@ -500,7 +534,7 @@ const void* pf_kernel_of(int dx, int spl, bool move) {
 #define GJX_PF(DXV, SPLV) if (dx == DXV && spl == SPLV) return move ? (const void*)k_pf_persistent<RNG, DXV, SPLV, true> : (const void*)k_pf_persistent<RNG, DXV, SPLV, false>;
   GJX_PF(2, 1) GJX_PF(2, 2) GJX_PF(2, 4) GJX_PF(2, 8)
   GJX_PF(4, 1) GJX_PF(4, 2) GJX_PF(4, 4) GJX_PF(4, 8)
-  GJX_PF(8, 1) GJX_PF(8, 2) GJX_PF(8, 4) GJX_PF(8, 8)
+  GJX_PF(8, 1) GJX_PF(8, 2) GJX_PF(8, 4) GJX_PF(8, 8) GJX_PF(8, 16)   // 16: config 4's dry run (8 ranks share ONE device's blocks)
   GJX_PF(16, 1) GJX_PF(16, 2) GJX_PF(16, 4)
 #undef GJX_PF
   return nullptr;

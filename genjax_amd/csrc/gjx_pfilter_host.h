@@ -48,6 +48,11 @@ struct PfArgs {
   int n_moves;
   float move_scale;
   unsigned long long* acc_total;                         // [1] accepted moves of this rank's particles over the launch (or NULL)
+  // verify mode (GJX_PEER_VERIFY=1, gjx_peer.hip): every propagated particle leaves a check word beside its row (gjx_tile.h
+  // row_check_*), every reader of a row recomputes it; the re-scanned total of a source tile is compared with the tile's
+  // granule.  A mismatch raises GJX_STATUS_VERIFY_MISMATCH.  chk_a / chk_b ping-pong like x_a / x_b (DATA window).
+  int verify;
+  unsigned* chk_a; unsigned* chk_b;                      // [K]
 };
 
 constexpr int kPfHostThreads = kPfThreads;

@@ -90,7 +90,7 @@ GJX_DEV uint64_t wave_sum_u64(uint64_t v) { return wave_total_u64(v); }   // the
 
 
 // status bits a co-resident kernel leaves in workspace word 10 (read and cleared by gjx_workspace_status)
-enum { kStatusPollTimeout = 1u, kStatusZeroTotal = 2u };
+enum { kStatusPollTimeout = 1u, kStatusZeroTotal = 2u, kStatusVerifyMismatch = 4u };
 
 // ------------------------------------------------------------------------------------------
 // All-gather of one 8-byte granule per block among the blocks of a CO-RESIDENT grid (no kernel boundary, no fence:

@@ -51,6 +51,16 @@ GJX_DEV void store_scoped_u32(unsigned* p, unsigned v, bool sys) {
 GJX_DEV unsigned load_scoped_u32(const unsigned* p, bool sys) {
   return sys ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- verify mode of the sharded kernels (GJX_PEER_VERIFY=1, gjx_peer.hip): a check word per particle row, stored by the
+// owner beside the row and recomputed by every reader that pulls the row.  It folds in the STEP the row belongs to and the
+// particle's global index, so a reader that is served an older generation of the same addresses (the buffers ping-pong:
+// the previous occupant is the row of step t - 2), a torn row, or a row of another particle cannot pass.
+GJX_DEV uint32_t row_check_init(int t, uint32_t gslot) { return (0x9E3779B9u * (uint32_t)(t + 1)) ^ (gslot * 0x85EBCA6Bu); }
+GJX_DEV uint32_t row_check_mix(uint32_t h, float v) {
+  h ^= __float_as_uint(v);
+  h *= 0x01000193u;
+  return h ^ (h >> 15);
+}
 // pointer into rank g's copy of a window: this rank's pointer + the byte distance between the two mappings (0 for g == rank)
 template <class Tp>
 GJX_DEV Tp* peer_ptr(Tp* local, long long delta) { return (Tp*)((char*)local + delta); }

@@ -649,8 +649,8 @@ class PeerContext:
                 if rc != 0:
                     err = load().gjx_last_error().decode("utf-8", "replace")
                 if not agree(rc == 0):      # (no peer access between two of the devices, IPC disabled, ...)
-                    if rc == 0:
-                        dist.barrier(group=group)
+                    # agree() is a collective every rank has just left: nobody maps anything new from here on, every rank
+                    # (failed or not) tears its context down and raises — no further collective that some ranks would skip
                     self._destroy_now()
                     raise GjxError("PeerContext: the windows could not be mapped on every rank: %s" % (err or "another rank failed"))
             o = (C.c_uint64 * 6)()
@@ -698,7 +698,8 @@ class PeerContext:
         return out, lse_out
 
     def status(self) -> int:
-        """bit 0: a rendezvous timed out (results undefined), bit 1: a step had zero total weight; read and cleared"""
+        """bit 0: a rendezvous timed out (results undefined), bit 1: a step had zero total weight, bit 2 (GJX_PEER_VERIFY=1): a
+        pulled row or source tile did not match its owner's check word / granule total; read and cleared"""
         st = C.c_int32(0)
         check(load().gjx_peer_ctx_status(self._h, C.byref(st), _stream()), "gjx_peer_ctx_status")
         return int(st.value)

@@ -255,7 +255,7 @@ enum { GJX_OP_RUN = 1, GJX_OP_LSE = 2, GJX_OP_PICK = 3, GJX_OP_RESAMPLE = 4, GJX
 size_t gjx_workspace_bytes(int op, int64_t K);
 /* status word of a workspace: 0, or GJX_STATUS_* bits left by the kernels that synchronise their blocks through
  * memory (one-launch resampling, one-launch importance / filter steps).  Synchronises the stream; clears the word. */
-enum { GJX_STATUS_POLL_TIMEOUT = 1, GJX_STATUS_ZERO_TOTAL = 2 };
+enum { GJX_STATUS_POLL_TIMEOUT = 1, GJX_STATUS_ZERO_TOTAL = 2, GJX_STATUS_VERIFY_MISMATCH = 4 /* gjx_peer_ctx, GJX_PEER_VERIFY=1 */ };
 int gjx_workspace_status(void* workspace, int32_t* status_host, void* stream);
 /* profiling hook of profiles/microbench/: registers a device buffer into which the co-resident kernels write per-block
  * phase stamps (s_memrealtime) while it is registered and large enough for their grid (8 or 16 u64 per block);
@@ -592,7 +592,17 @@ int gjx_shard_global_lse(gjx_shard_ctx* ctx, const float* local_lse, float* lse_
  *   buffers: out6 = device pointers of this rank's rows[0], rows[1] (f32[rows][K_local]), logw[0], logw[1] (f32[K_local])
  *            and the byte sizes of the two windows.  The caller's kernels write their particles THERE.
  *   status:  bit 0 a rendezvous timed out (a peer is missing: results undefined), bit 1 a collection had zero total
- *            weight; read and cleared, synchronises the stream.
+ *            weight, bit 2 (verify mode) a pulled row or source tile did not match its owner's check; read and cleared,
+ *            synchronises the stream.
+ *   Environment, read by create (the same on every rank of a run):
+ *     GJX_PEER_VERIFY=1   every kernel that writes particle rows other ranks read leaves a 32-bit check word per row beside
+ *                         it (a hash of the row's floats, of the STEP / call it belongs to and of the particle's global index),
+ *                         every reader recomputes it from what it pulled; the fixed-point total of every re-scanned source
+ *                         tile is compared with the total in the tile's granule.  A stale, torn or misdirected read raises
+ *                         GJX_STATUS_VERIFY_MISMATCH instead of going unnoticed.  Results are unchanged bit for bit.
+ *     GJX_PEER_DATA=fine  the DATA window is fine-grained device memory (hipDeviceMallocFinegrained) instead of ordinary
+ *                         device memory: coherent between agents by memory type — the fallback if a fabric shows mismatches
+ *                         with the default (coarse) window, whose visibility rests on sc0 sc1 accesses.
  *   destroy: only after every rank has finished using the context (the caller's barrier). */
 typedef struct gjx_peer_ctx gjx_peer_ctx;
 int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device,
