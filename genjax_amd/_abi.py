@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -46,12 +46,13 @@ vp = C.c_void_p
 
 class GjxParam(C.Structure):
     _fields_ = [("op", i32), ("xf", i32), ("off", i32), ("len", i32), ("slot", i32), ("n", i32),
-                ("moff", i32), ("pad_", i32)]
+                ("moff", i32), ("d_off", i32), ("d_slot", i32), ("d_moff", i32), ("pad_", i32 * 2)]
 
 
 class GjxSite(C.Structure):
     _fields_ = [("kind", i32), ("dim", i32), ("slot", i32), ("mode", i32), ("obs_off", i32),
-                ("ncat", i32), ("flags", i32), ("scan", i32), ("p", GjxParam * MAX_PARAMS)]
+                ("ncat", i32), ("flags", i32), ("scan", i32), ("plate", i32), ("plate_n", i32), ("d_obs", i32), ("pad_", i32),
+                ("p", GjxParam * MAX_PARAMS)]
 
 
 class GjxProgram(C.Structure):
@@ -74,7 +75,7 @@ class GjxShardPlan(C.Structure):
                 ("seq", i64), ("reserved", i64), ("bounds", i64 * (MAX_RANKS + 1))]
 
 
-assert C.sizeof(GjxParam) == 32 and C.sizeof(GjxSite) == 160 and C.sizeof(GjxShardPlan) == 8 * (12 + MAX_RANKS + 1)
+assert C.sizeof(GjxParam) == 48 and C.sizeof(GjxSite) == 240 and C.sizeof(GjxShardPlan) == 8 * (12 + MAX_RANKS + 1)
 
 PP = C.POINTER(GjxProgram)
 

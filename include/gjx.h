@@ -37,7 +37,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 6
+#define GJX_ABI_VERSION 7
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -115,8 +115,11 @@ typedef struct gjx_param {
   int32_t slot; /* VALUE/AFFINE: first source slot; GATHER: slot holding the index             */
   int32_t n;    /* AFFINE: inner length; GATHER: number of rows                                */
   int32_t moff; /* AFFINE: matrix [dim][n] row-major                               (into tab) */
-  int32_t pad_;
-} gjx_param; /* 32 bytes */
+  /* plate strides (sites with gjx_site.plate != 0, see "Plates" below): instance i evaluates the parameter with
+   * off + i * d_off, slot + i * d_slot, moff + i * d_moff.  All 0 outside plates and for what the instances share. */
+  int32_t d_off, d_slot, d_moff;
+  int32_t pad_[2];
+} gjx_param; /* 48 bytes */
 
 #define GJX_MAX_PARAMS 4
 
@@ -129,8 +132,35 @@ typedef struct gjx_site {
   int32_t ncat;    /* categorical: number of categories (length of params[0])               */
   int32_t flags;   /* GJX_SITE_*                                                            */
   int32_t scan;    /* 0: not inside a Scan; else (scan_id << 20) | (step + 1): see "Scan steps" below */
+  int32_t plate;   /* 0: not inside a plate; else the plate's id (from 1): see "Plates" below          */
+  int32_t plate_n; /* number of instances of the plate                                                */
+  int32_t d_obs;   /* plate stride of obs_off: OBS_TAB dim (one observed value per instance), OBS_MASK 1 (one flag row per
+                      instance)                                                                       */
+  int32_t pad_;
   gjx_param p[GJX_MAX_PARAMS];
-} gjx_site; /* 160 bytes */
+} gjx_site; /* 240 bytes */
+
+/* Plates (combinators/vmap.py:180-218: Vmap.simulate / generate over n instances of a kernel generative function).
+ * The m sites of a kernel body that is vmapped over n instances are m CONSECUTIVE sites that carry the same `plate` id and
+ * `plate_n` = n; the engines run ONE instance loop over them:
+ *     for i in [0, n):  for each body site, in order:  the site with
+ *         value rows      slot + i * dim .. slot + (i + 1) * dim - 1     (site-major: a body site owns n * dim rows;
+ *                                                                        categorical sites: dim = 1)
+ *         observed value  tab[obs_off + i * d_obs ...]   (OBS_TAB)  /  flag row obs_off + i * d_obs   (OBS_MASK)
+ *         parameters      off + i * d_off,  slot + i * d_slot,  moff + i * d_moff
+ * A parameter reads an earlier site of the SAME instance with d_slot = that site's dim, a site outside the plate with
+ * d_slot = 0, instance i of an EARLIER plate with that plate's dim; tables are shared (d_off = 0) or stacked per instance.
+ * The score of a body site is the sum over its instances (vmap.py:206-218 sums the instances' weights); site_scores holds
+ * one row per body site.  The body counts m — not n m — towards the site numbers of the FLAT layout.
+ * Streams.  GJX_RNG_FLAT: a body site has ONE site number (its position, like any other site) and instance i draws at the
+ *     elements a vector site of n * dim elements would use: element (i * dim + c) * draws_per_element + k; categorical
+ *     sites: element i.  Body sites never join scalar-normal runs (a drawing body site closes an open run).
+ *   GJX_RNG_JAX32 — the reference's key rule:  plate key P = fold_in(particle key, J), J = the (1-based) index of the
+ *     plate's first site in the program (the Vmap call is ONE traced site of its caller, static.py:349-352);
+ *     instance key = Threefry(P, (0, i)) = jax.random.split(P, n)[i] (vmap.py:186, 201);  site key = fold_in(instance key,
+ *     l), l = 1-based position of the site in the body (static.py:349-352 inside the kernel); elements from 0 per instance.
+ * A plate may sit inside a Scan step (its sites carry both tags); plates do not nest on the device (the host unrolls the
+ * outer one). */
 
 /* Scan steps (combinators/scan.py:237-294).  The sites of step t of a Scan are consecutive and carry the same `scan`
  * tag.  Their random streams follow the reference's CHAINED key rule (scan.py:268, key_t = fold_in(key_{t-1}, t)):

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name)
     assert lib.gjx_version() == A.ABI_VERSION
     assert lib.gjx_workspace_bytes(A.OP_RUN, 1 << 20) >= 8 * (1 << 20) // 256 + 256
-    assert ctypes.sizeof(A.GjxSite) == 160 and ctypes.sizeof(A.GjxParam) == 32
+    assert ctypes.sizeof(A.GjxSite) == 240 and ctypes.sizeof(A.GjxParam) == 48
 
 
 def test_abi_struct_layout_matches_header():
