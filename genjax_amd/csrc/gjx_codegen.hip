@@ -79,7 +79,7 @@ void assign_runs(const gjx_program* prog, std::vector<SiteStream>& st, int j0, i
     const gjx_site& s = prog->sites[j];
     if (s.scan != tag) { head = -1; tag = s.scan; }
     const bool draws = s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK;
-    if (GJX_FLAT_JOINS(prog->rng_mode, s.kind, s.dim, s.mode)) {
+    if (s.plate == 0 && GJX_FLAT_JOINS(prog->rng_mode, s.kind, s.dim, s.mode)) {
       if (head < 0 || next >= (unsigned)GJX_FLAT_RUN_MAX) { head = j; next = 0; st[j].opens = true; st[j].run = n_runs++; }
       else { st[j].run = st[head].run; st[j].site_no = st[head].site_no; }
       st[j].elem = next++;
@@ -101,12 +101,27 @@ struct RollInfo {
                                         // register that holds them is not the row number (rolled programs)
   int flag_row = -1, d_flag_row = 0;    // OBS_MASK: row of the site's flags in choices[][] (the register is gjx_site.obs_off)
   int d_off[4] = {0, 0, 0, 0}, d_moff[4] = {0, 0, 0, 0};   // strides of the parameters' table offsets
+  // plates (gjx.h "Plates"): the site is emitted once inside `for (i_ ...)`; its loop variable is i_ instead of (t_ - 1)
+  bool plate = false;
+  int plate_n = 0, plate_l = 0, plate_j0 = 0;   // instances, position in the body, program index of the plate's first site
+  // a parameter whose source rows are not in registers (instances of ANOTHER plate, one instance of a plate read from outside
+  // it): read from choices[][] — rows mem_slot + i_ * d_mem + element; -1: a register source
+  int mem_slot[4] = {-1, -1, -1, -1}, d_mem[4] = {0, 0, 0, 0};
 };
 
-// "off" or "(off + (t_ - 1) * stride)"
+// loop variable of the site being emitted: steps of a rolled Scan, or instances of a plate
+thread_local const char* g_loop_var = "(t_ - 1)";
+
+// "off" or "(off + <loop variable> * stride)"
 std::string toff(int off, int stride) {
   if (stride == 0) return std::to_string(off);
-  return "(" + std::to_string(off) + " + (t_ - 1) * " + std::to_string(stride) + ")";
+  return "(" + std::to_string(off) + " + " + g_loop_var + " * " + std::to_string(stride) + ")";
+}
+
+// value of source element `elem` (an expression) of parameter k: a register, or a row of choices[][] (RollInfo::mem_slot)
+std::string src_val(const gjx_param& q, const RollInfo& ri, int k, const std::string& elem) {
+  if (ri.mem_slot[k] < 0) return "v[" + std::to_string(q.slot) + " + (" + elem + ")][p]";
+  return "a.choices[(int64_t)(" + toff(ri.mem_slot[k], ri.d_mem[k]) + " + (" + elem + ")) * K + i0 + p]";
 }
 
 struct Plan {
@@ -164,6 +179,7 @@ Roll detect_roll(const gjx_program* p) {
   Roll r;
   if (p->rng_mode != GJX_RNG_FLAT || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
+  for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
   int i0 = 0;
   while (i0 < n && p->sites[i0].scan == 0) ++i0;
   if (i0 == n || GJX_SCAN_STEP(p->sites[i0].scan) != 0) return r;
@@ -326,6 +342,88 @@ Roll detect_roll(const gjx_program* p) {
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Plates (gjx.h "Plates").  The m body sites of a plate are emitted ONCE, inside `for (i_ = 0; i_ < n; ++i_)`: the values of
+// the CURRENT instance live in registers, their rows in choices[][] / offsets in the table advance with i_.  The emitted
+// program holds every site with its slots remapped to registers (a body site owns one instance's worth); a parameter whose
+// source is not in a register — instances of an earlier plate, one instance of a plate read from outside it — reads
+// choices[][] (written earlier by the same lane).
+// ---------------------------------------------------------------------------------------------------------
+struct PlateXf {
+  bool any = false, ok = false;
+  std::vector<gjx_site> sites;
+  std::vector<RollInfo> info;
+  int n_regs = 0;
+};
+
+PlateXf plate_program(const gjx_program* p) {
+  PlateXf x;
+  const int n = p->n_sites;
+  for (int j = 0; j < n; ++j) x.any = x.any || p->sites[j].plate != 0;
+  if (!x.any) return x;
+  auto width = [&](const gjx_site& s) { return is_categorical(s.kind) ? 1 : s.dim; };
+  auto rows = [&](const gjx_site& s) { return width(s) * (s.plate ? s.plate_n : 1); };
+  std::vector<int> reg(n, -1), flag(n, -1), first(n, 0), pos(n, 0);
+  int next = 0;
+  for (int j = 0; j < n; ++j) {
+    const gjx_site& s = p->sites[j];
+    if (s.plate && (s.plate_n < 1 || s.kind == GJX_DIRICHLET)) return x;
+    if (s.plate) { first[j] = (j > 0 && p->sites[j - 1].plate == s.plate) ? first[j - 1] : j; pos[j] = j - first[j]; }
+    if (s.slot >= 0) { reg[j] = next; next += width(s); }
+  }
+  for (int j = 0; j < n; ++j) if (p->sites[j].mode == GJX_MODE_OBS_MASK) flag[j] = next++;
+  x.n_regs = next;
+  auto owner_of = [&](int slot, int before) {
+    for (int o = 0; o < before; ++o) { const gjx_site& so = p->sites[o]; if (so.slot >= 0 && slot >= so.slot && slot < so.slot + rows(so)) return o; }
+    return -1;
+  };
+  for (int j = 0; j < n; ++j) {
+    gjx_site s = p->sites[j];
+    RollInfo ri;
+    ri.row = s.slot; ri.score_row = j;
+    if (s.plate) {
+      ri.plate = true; ri.plate_n = s.plate_n; ri.plate_l = pos[j]; ri.plate_j0 = first[j];
+      ri.d_row = width(s); ri.d_obs = s.mode == GJX_MODE_OBS_TAB ? s.d_obs : 0;
+      for (int k = 0; k < n_params(s.kind); ++k) { ri.d_off[k] = s.p[k].d_off; ri.d_moff[k] = s.p[k].d_moff; }
+    }
+    if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) ri.load_here = true;   // (registers are not row numbers here)
+    if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = s.plate ? s.d_obs : 0; s.obs_off = flag[j]; }
+    for (int k = 0; k < n_params(s.kind); ++k) {
+      gjx_param& q = s.p[k];
+      if (!slot_op(q.op)) continue;
+      const int span = ref_span(q);
+      const int o = owner_of(q.slot, j);
+      if (o < 0) return x;
+      const gjx_site& so = p->sites[o];
+      const int off = q.slot - so.slot;
+      if (so.plate == 0 && q.d_slot != 0) {
+        // element i_ of a VECTOR site outside the plate (an earlier plate in its vector form): registers cannot be indexed by
+        // i_, the rows in choices[][] can (the site stored them before this plate started)
+        ri.mem_slot[k] = q.slot; ri.d_mem[k] = q.d_slot;
+        q.slot = 0;
+      } else if (so.plate == 0) {
+        // a span may run over several consecutive non-plate sites (an affine form over several sites): registers must follow
+        for (int e = 0; e < span; ++e) {
+          const int oe = owner_of(q.slot + e, j);
+          if (oe < 0 || p->sites[oe].plate != 0 || reg[oe] + (q.slot + e - p->sites[oe].slot) != reg[o] + off + e) return x;
+        }
+        q.slot = reg[o] + off;
+      } else if (s.plate == so.plate && q.d_slot == width(so) && off + span <= width(so)) {
+        q.slot = reg[o] + off;                     // an earlier site of the SAME instance
+      } else {
+        if (off % width(so) + span > width(so) && q.op != GJX_P_AFFINE) return x;
+        ri.mem_slot[k] = q.slot; ri.d_mem[k] = s.plate ? q.d_slot : 0;
+        q.slot = 0;
+      }
+    }
+    if (s.slot >= 0) s.slot = reg[j];
+    x.sites.push_back(s);
+    x.info.push_back(ri);
+  }
+  x.ok = true;
+  return x;
+}
+
 // what the emitter covers; everything else runs on the interpreter
 bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
   if (n_sites < 1 || n_sites > 48 || n_slots > 160) return false;
@@ -353,6 +451,8 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
 }
 
 bool supported_uncached(const gjx_program* p) {
+  const PlateXf px = plate_program(p);
+  if (px.any) return px.ok && supported_sites(px.sites.data(), (int)px.sites.size(), px.n_regs);
   if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
   return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs);
@@ -369,15 +469,14 @@ std::string tab_index(const gjx_param& q, const std::string& dx, int site, int k
 }
 
 // value of parameter q at element dx for particle p (before the transform)
-std::string param_expr(const gjx_param& q, const std::string& dx, int site, int k, int d_off = 0) {
+std::string param_expr(const gjx_param& q, const std::string& dx, int site, int k, const RollInfo& ri) {
   char b[512];
   switch (q.op) {
     case GJX_P_CONST:
-    case GJX_P_GATHER: return "TAB(" + tab_index(q, dx, site, k, d_off) + ")";
+    case GJX_P_GATHER: return "TAB(" + tab_index(q, dx, site, k, ri.d_off[k]) + ")";
     case GJX_P_VALUE:
-      if (q.len == 1) snprintf(b, sizeof(b), "v[%d][p]", q.slot);
-      else snprintf(b, sizeof(b), "v[%d + (%s) %% %d][p]", q.slot, dx.c_str(), q.len);
-      return b;
+      if (q.len == 1) return src_val(q, ri, k, "0");
+      return src_val(q, ri, k, "(" + dx + ") % " + std::to_string(q.len));
     default: snprintf(b, sizeof(b), "aff_%d_%d", site, k); return b;   // computed into a local just before use
   }
 }
@@ -391,21 +490,21 @@ std::string xf_wrap(int xf, const std::string& e) {
 }
 
 // statements that must precede the use of param_expr for element dx (affine accumulations)
-void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, int d_off = 0, int d_moff = 0) {
+void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, const RollInfo& ri) {
   if (q.op != GJX_P_AFFINE) return;
   const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
-  o.f("%sfloat aff_%d_%d = TAB(%s + %s);\n", ind, site, k, toff(q.off, d_off).c_str(), e.c_str());
-  o.f("%s{ const int r_ = %s + (%s) * %d;\n", ind, toff(q.moff, d_moff).c_str(), dx.c_str(), q.n);
-  o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) aff_%d_%d = fmaf(TAB(r_ + e_), v[%d + e_][p], aff_%d_%d); }\n", ind, q.n, site,
-      k, q.slot, site, k);
+  o.f("%sfloat aff_%d_%d = TAB(%s + %s);\n", ind, site, k, toff(q.off, ri.d_off[k]).c_str(), e.c_str());
+  o.f("%s{ const int r_ = %s + (%s) * %d;\n", ind, toff(q.moff, ri.d_moff[k]).c_str(), dx.c_str(), q.n);
+  o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) aff_%d_%d = fmaf(TAB(r_ + e_), %s, aff_%d_%d); }\n", ind, q.n, site,
+      k, src_val(q, ri, k, "e_").c_str(), site, k);
 }
 
-void emit_gather_index(Emit& o, const gjx_site& s, int site, int np) {
+void emit_gather_index(Emit& o, const gjx_site& s, int site, int np, const RollInfo& ri) {
   for (int k = 0; k < np; ++k) {
     const gjx_param& q = s.p[k];
     if (q.op != GJX_P_GATHER) continue;
     o.f("      int gi_%d_%d[PPT];\n", site, k);
-    o.f("      PLOOP { int g_ = (int)v[%d][p]; gi_%d_%d[p] = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", q.slot, site, k, q.n - 1, q.n - 1);
+    o.f("      PLOOP { int g_ = (int)%s; gi_%d_%d[p] = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", src_val(q, ri, k, "0").c_str(), site, k, q.n - 1, q.n - 1);
   }
 }
 
@@ -413,6 +512,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const gjx_program* prog = pl.prog;
   const gjx_site& s = prog->sites[j];
   const RollInfo& ri = pl.info[j];
+  g_loop_var = ri.plate ? "i_" : "(t_ - 1)";
   const int mode = s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
@@ -426,7 +526,20 @@ void emit_site(Emit& o, Plan& pl, int j) {
   o.f("      float lp[PPT];\n      PLOOP lp[p] = 0.0f;\n");
   // stream key and site number (gjx.h "Scan steps"): chained step keys are wave-uniform locals emitted on first use
   const SiteStream& ss = pl.stream[j];
-  if (draws && ss.run >= 0) {
+  // element at which this (site, instance) starts drawing (gjx.h "Plates": the elements of a vector site of n * dim elements)
+  std::string ebase = "0u";
+  if (ri.plate && prog->rng_mode == GJX_RNG_FLAT) {
+    const int per = is_categorical(kind) ? 1 : s.dim * (kind == GJX_BETA ? 2 * gjx::kGammaNDraw
+                   : (kind == GJX_GAMMA || kind == GJX_INVERSE_GAMMA || kind == GJX_CHI2) ? gjx::kGammaNDraw
+                   : kind == GJX_STUDENT_T ? gjx::kGammaNDraw + 2 : kind == GJX_POISSON ? 2 * gjx::kPoissonTries + 2 : 1);
+    ebase = "(uint32_t)(i_ * " + std::to_string(per) + ")";
+  }
+  if (draws && ri.plate) {
+    // FLAT: the body site's stream lives outside the instance loop (its hash blocks are shared by consecutive instances);
+    // JAX32: site key = fold_in(instance key, position in the body) (static.py:349-352 inside the vmapped kernel)
+    if (prog->rng_mode == GJX_RNG_FLAT) o.f("      BitStream<RNG> (&bs)[PPT] = ps%d;\n", j);
+    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open_site_key(fold_in(ik_[p], %du));\n", ri.plate_l + 1);
+  } else if (draws && ss.run >= 0) {
     // member of a scalar-normal run: the run's stream lives OUTSIDE the site's block (declared by the head, in the
     // enclosing scope), members 2k and 2k+1 share one Box-Muller evaluation through its pair cache
     o.f("      BitStream<RNG> (&bs)[PPT] = rs%d;\n", ss.run);
@@ -441,21 +554,21 @@ void emit_site(Emit& o, Plan& pl, int j) {
     if (masked) o.f("      PLOOP v[%d][p] = a.choices[(int64_t)%s * K + i0 + p];\n", s.obs_off, toff(ri.flag_row, ri.d_flag_row).c_str());
   }
   if (masked) o.f("      bool given[PPT];\n      PLOOP given[p] = v[%d][p] != 0.0f;\n", s.obs_off);
-  emit_gather_index(o, s, j, np);
+  emit_gather_index(o, s, j, np, ri);
   if (is_categorical(kind)) {
     const gjx_param& q = s.p[0];
     const int n = s.ncat;
     const bool probs = kind == GJX_CATEGORICAL_PROBS;
     const bool fast = q.op == GJX_P_CONST && q.xf == GJX_XF_NONE && !probs && q.len == n && ri.d_off[0] == 0;
     // L(c): logit of category c for particle p
-    std::string L = xf_wrap(q.xf, param_expr(q, "c_", j, 0, ri.d_off[0]));
+    std::string L = xf_wrap(q.xf, param_expr(q, "c_", j, 0, ri));
     if (probs) L = "safe_log(" + L + ")";
     if (fast) {
       const int at = pl.find(2, q.off, n);
       o.f("      PLOOP {\n        float val;\n");
       if (draws) {
         o.f("        if (RNG == GJX_RNG_FLAT) {\n");
-        o.f("          const float target = bits_to_unit(bs[p].get(0u)) * COMP(%d);\n          unsigned neg = 0u;\n", at + n - 1);
+        o.f("          const float target = bits_to_unit(bs[p].get(%s)) * COMP(%d);\n          unsigned neg = 0u;\n", ebase.c_str(), at + n - 1);
         o.f("          _Pragma(\"unroll\") for (int c_ = 0; c_ < %d; ++c_) neg += __float_as_uint(target - COMP(%d + c_)) >> 31;\n", n - 1, at);
         o.f("          val = (float)(%d - (int)neg);\n        } else {\n", n - 1);
         o.f("          int best = 0; float bestv = -INFINITY;\n");
@@ -475,7 +588,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
       o.f("        float se = 0.0f;\n        for (int c_ = 0; c_ < %d; ++c_) se += fast_exp(%s - mx);\n", n, L.c_str());
       o.f("        const float lse_ = mx + fast_log(se);\n        float val;\n");
       if (draws) {
-        o.f("        if (RNG == GJX_RNG_FLAT) {\n          const float target = bits_to_unit(bs[p].get(0u)) * se; float run = 0.0f; int zc = %d; bool found = false;\n", n - 1);
+        o.f("        if (RNG == GJX_RNG_FLAT) {\n          const float target = bits_to_unit(bs[p].get(%s)) * se; float run = 0.0f; int zc = %d; bool found = false;\n", ebase.c_str(), n - 1);
         o.f("          for (int c_ = 0; c_ < %d; ++c_) { run += fast_exp(%s - mx); if (!found && run > target) { zc = c_; found = true; } }\n", n, L.c_str());
         o.f("          val = (float)zc;\n        } else {\n          int best = 0; float bestv = -INFINITY;\n");
         o.f("          for (int c_ = 0; c_ < %d; ++c_) { const float g_ = %s + gumbel_from_bits(bs[p].get((uint32_t)c_)); if (g_ > bestv) { bestv = g_; best = c_; } }\n", n, L.c_str());
@@ -515,8 +628,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
       std::string in2 = std::string(ind) + "  ";
       std::string pe[4];
       for (int k = 0; k < np; ++k) {
-        emit_param_pre(o, s.p[k], dx, j, k, in2.c_str(), ri.d_off[k], ri.d_moff[k]);
-        pe[k] = xf_wrap(s.p[k].xf, param_expr(s.p[k], dx, j, k, ri.d_off[k]));
+        emit_param_pre(o, s.p[k], dx, j, k, in2.c_str(), ri);
+        pe[k] = xf_wrap(s.p[k].xf, param_expr(s.p[k], dx, j, k, ri));
       }
       for (int k = np; k < 4; ++k) pe[k] = "0.0f";
       const std::string vslot = "v[" + std::to_string(s.slot) + " + (" + dx + ")][p]";
@@ -532,10 +645,10 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (rcpb.empty()) rcpb = "fast_rcp(pb)";
         o.f("%sfloat val;\n", in2.c_str());
         if (mode == GJX_MODE_SAMPLE) {
-          o.f("%sconst float n_ = stream_normal<RNG>(bs[p], (uint32_t)(%u + (%s)));\n", in2.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
+          o.f("%sconst float n_ = stream_normal<RNG>(bs[p], %s + (uint32_t)(%u + (%s)));\n", in2.c_str(), ebase.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
           o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
-          if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), dx.c_str());
+          if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], %s + (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), ebase.c_str(), dx.c_str());
           else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
           else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
           if (at_ys >= 0) o.f("%s{ const float z_ = fmaf(-%s, pa, COMP(%d + (%s))); q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str(), at_ys, dx.c_str());
@@ -544,7 +657,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (at_sum < 0) o.f("%sls[p] += kHalfLog2Pi + %s;\n", in2.c_str(), logb.c_str());
       } else {
         o.f("%sconst float pb = %s, pc = %s, pd = %s;\n%sfloat val;\n", in2.c_str(), pe[1].c_str(), pe[2].c_str(), pe[3].c_str(), in2.c_str());
-        const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
+        const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], " + ebase + " + (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
         if (mode == GJX_MODE_SAMPLE) o.f("%sval = %s;\n", in2.c_str(), smp.c_str());
         else if (masked) o.f("%s{ const float smp_ = %s; val = given[p] ? %s : smp_; }\n", in2.c_str(), smp.c_str(), vslot.c_str());
         else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
@@ -572,8 +685,9 @@ void emit_site(Emit& o, Plan& pl, int j) {
   }
   // bookkeeping: score, weight, per-site scores, store the site's rows
   o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
-  o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
-      toff(ri.score_row, ri.d_score_row).c_str());
+  if (ri.plate) o.f("      PLOOP pacc%d[p] += lp[p];\n", j);      // a plate's body site: the sum over its instances
+  else o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
+           toff(ri.score_row, ri.d_score_row).c_str());
   if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
     for (int d = 0; d < nrow; ++d) o.f("      VecStore<PPT>::st(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
@@ -586,9 +700,11 @@ bool want_roll() { const char* e = getenv("GJX_GEN_ROLL"); return e && atoi(e) !
 std::string generate(const gjx_program* prog_in, int ppt) {
   // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
   Roll roll;
-  if (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots)) roll = detect_roll(prog_in);
+  const PlateXf px = plate_program(prog_in);
+  if (!px.any && (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots))) roll = detect_roll(prog_in);
   gjx_program eprog = *prog_in;
   if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_regs; }
+  if (px.any) { eprog.sites = px.sites.data(); eprog.n_sites = (int)px.sites.size(); eprog.n_slots = px.n_regs; }
   const gjx_program* prog = &eprog;
   Plan pl;
   pl.prog = prog;
@@ -615,7 +731,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     std::string cur;
     for (int j = 0; j < prog->n_sites; ++j) {
       RollInfo ri; ri.row = prog->sites[j].slot; ri.score_row = j;
-      pl.info.push_back(ri);
+      pl.info.push_back(px.any ? px.info[j] : ri);
       const int sc = prog->sites[j].scan;
       if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", (unsigned)(j + 1)}); continue; }
       if (sc == 0) { tag = 0; pl.stream.push_back({"", ++plain}); continue; }
@@ -654,7 +770,32 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     body.f("    }\n");
     for (int j = roll.i0 + 2 * roll.m; j < roll.i0 + 2 * roll.m + roll.n_post; ++j) emit_site(body, pl, j);   // the last step sits in the "previous" registers
   } else {
-    for (int j = 0; j < prog->n_sites; ++j) emit_site(body, pl, j);
+    for (int j = 0; j < prog->n_sites;) {
+      if (!pl.info[j].plate) { emit_site(body, pl, j++); continue; }
+      // ---- a plate: prologue, ONE instance loop over the body, epilogue (gjx.h "Plates"; vmap.py:180-218)
+      int m = 1;
+      while (j + m < prog->n_sites && pl.info[j + m].plate && pl.info[j + m].plate_j0 == pl.info[j].plate_j0) ++m;
+      const bool flat = prog->rng_mode == GJX_RNG_FLAT;
+      body.f("    { // ---- plate of %d instances x %d sites\n", pl.info[j].plate_n, m);
+      for (int l = 0; l < m; ++l) {
+        const gjx_site& sl = prog->sites[j + l];
+        body.f("    float pacc%d[PPT];\n    PLOOP pacc%d[p] = 0.0f;\n", j + l, j + l);
+        const bool draws = sl.mode == GJX_MODE_SAMPLE || sl.mode == GJX_MODE_OBS_MASK;
+        if (flat && draws) {
+          const SiteStream& ss = pl.stream[j + l];
+          body.f("    BitStream<RNG> ps%d[PPT];\n    PLOOP ps%d[p].open(%s, gidx[p], %du);\n", j + l, j + l, ss.key_var.empty() ? "a.key" : ss.key_var.c_str(), ss.site_no);
+        }
+      }
+      // JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J); instance key = split(plate key, n)[i]
+      if (!flat) body.f("    key2 pk_[PPT];\n    PLOOP pk_[p] = fold_in(fold_in64(a.key, gidx[p]), %du);\n", pl.info[j].plate_j0 + 1);
+      body.f("    _Pragma(\"nounroll\") for (int i_ = 0; i_ < %d; ++i_) {\n", pl.info[j].plate_n);
+      if (!flat) body.f("    key2 ik_[PPT];\n    PLOOP ik_[p] = fold_in(pk_[p], (uint32_t)i_);\n");
+      for (int l = 0; l < m; ++l) emit_site(body, pl, j + l);
+      body.f("    }\n    if (a.site_scores) {\n");
+      for (int l = 0; l < m; ++l) body.f("      VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, pacc%d);\n", j + l, j + l);
+      body.f("    }\n    }\n");
+      j += m;
+    }
   }
   Emit o;
   o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
@@ -768,7 +909,7 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
   int unrolled = 0;
   for (int j = 0; j < p->n_sites; ++j) {
     const gjx_site& s = p->sites[j];
-    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
+    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET || s.plate != 0) return false;
     if (s.mode != GJX_MODE_OBS_TAB && s.mode != GJX_MODE_OBS_SLOT) return false;
     if (is_categorical(s.kind)) {
       if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
@@ -1061,7 +1202,9 @@ int register_slots(const gjx_program* p) {
   ProgMeta* m = meta_of(p);
   if (m && m->slots >= 0) return m->slots;
   int slots = p->n_slots;
-  if (want_roll() || !supported_sites(p->sites, p->n_sites, p->n_slots)) {
+  const PlateXf px = plate_program(p);
+  if (px.any) slots = px.n_regs;
+  else if (want_roll() || !supported_sites(p->sites, p->n_sites, p->n_slots)) {
     const Roll r = detect_roll(p);
     if (r.ok) slots = r.n_pre + 2 * r.S;
   }

@@ -344,20 +344,22 @@ GJX_DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
 // ---- parameter evaluation ------------------------------------------------------------------
 // `val(slot)` returns the current particle's value of a slot.
+// `inst`: instance of the site's plate (gjx.h "Plates": off + inst * d_off, slot + inst * d_slot, moff + inst * d_moff); 0 elsewhere
 template <class ValFn>
-GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val) {
+GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst = 0) {
+  const int off = p.off + inst * p.d_off, slot = p.slot + inst * p.d_slot;
   switch (p.op) {
-    case GJX_P_CONST: return tab[p.off + (p.len == 1 ? 0 : d % p.len)];
-    case GJX_P_VALUE: return val(p.slot + (p.len == 1 ? 0 : d % p.len));
+    case GJX_P_CONST: return tab[off + (p.len == 1 ? 0 : d % p.len)];
+    case GJX_P_VALUE: return val(slot + (p.len == 1 ? 0 : d % p.len));
     case GJX_P_GATHER: {
-      int idx = (int)val(p.slot);
+      int idx = (int)val(slot);
       idx = idx < 0 ? 0 : (idx > p.n - 1 ? p.n - 1 : idx);
-      return tab[p.off + idx * p.len + (p.len == 1 ? 0 : d % p.len)];
+      return tab[off + idx * p.len + (p.len == 1 ? 0 : d % p.len)];
     }
     case GJX_P_AFFINE: {
-      float acc = tab[p.off + (p.len == 1 ? 0 : d % p.len)];
-      const float* row = tab + p.moff + d * p.n;
-      for (int e = 0; e < p.n; ++e) acc = fmaf(row[e], val(p.slot + e), acc);
+      float acc = tab[off + (p.len == 1 ? 0 : d % p.len)];
+      const float* row = tab + p.moff + inst * p.d_moff + d * p.n;
+      for (int e = 0; e < p.n; ++e) acc = fmaf(row[e], val(slot + e), acc);
       return acc;
     }
     default: return __builtin_nanf("");
@@ -372,8 +374,8 @@ GJX_DEV float apply_xf(int xf, float v) {
   }
 }
 template <class ValFn>
-GJX_DEV float eval_param(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val) {
-  return apply_xf(p.xf, eval_param_pre(p, d, tab, val));
+GJX_DEV float eval_param(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst = 0) {
+  return apply_xf(p.xf, eval_param_pre(p, d, tab, val, inst));
 }
 
 // ---- log-densities of one scalar element (TFP 0.23 log_prob closed forms) --------------------

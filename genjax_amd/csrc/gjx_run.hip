@@ -74,47 +74,82 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   float score = 0.0f, weight = 0.0f;
   SiteStreamWalk walk(a.key);     // wave-uniform: chained step keys of Scan sites (gjx.h "Scan steps")
   BitStreamRT<RNG> rs;            // stream of the open scalar-normal run (gjx.h "Scalar-normal runs"): lives across sites
-  for (int j = 0; j < a.n_sites; ++j) {
+  for (int j0 = 0; j0 < a.n_sites;) {
+    // a plate (gjx.h "Plates"; vmap.py:180-218): m consecutive body sites, n instances, ONE instance loop over the body;
+    // any other site: m = n = 1
+    int m = 1, ninst = 1;
+    const int plate = a.sites[j0].plate;
+    if (plate != 0) {
+      while (j0 + m < a.n_sites && a.sites[j0 + m].plate == plate) ++m;
+      ninst = a.sites[j0].plate_n;
+    }
+    // site numbers: the body's are consecutive (one scan tag, no run members); a drawing body site closes an open run
+    uint32_t no0 = 0u, e0_single = 0u;
+    bool opens_single = false, joins_single = false;
+    for (int l = 0; l < m; ++l) {
+      const gjx_site& sl = a.sites[j0 + l];
+      uint32_t no = RNG == GJX_RNG_FLAT ? walk.next(sl.scan) : (uint32_t)(j0 + l + 1);
+      const bool draws_l = sl.mode == GJX_MODE_SAMPLE || sl.mode == GJX_MODE_OBS_MASK;
+      const bool joins_l = plate == 0 && GJX_FLAT_JOINS(RNG, sl.kind, sl.dim, sl.mode);
+      bool op = false;
+      const uint32_t e = RNG == GJX_RNG_FLAT ? walk.run_elem(no, joins_l, draws_l, op) : 0u;
+      if (l == 0) { no0 = no; e0_single = e; opens_single = op; joins_single = joins_l; }
+    }
+    key2 plate_key{0u, 0u};       // JAX32: fold_in(particle key, J), J = 1-based index of the plate's first site
+    if (RNG == GJX_RNG_JAX32 && plate != 0) plate_key = fold_in(fold_in64(a.key, gidx), (uint32_t)(j0 + 1));
+    for (int inst = 0; inst < ninst; ++inst) {
+    key2 inst_key{0u, 0u};
+    if (RNG == GJX_RNG_JAX32 && plate != 0) inst_key = fold_in(plate_key, (uint32_t)inst);     // split(plate key, n)[inst] (vmap.py:186)
+    for (int l = 0; l < m; ++l) {
+    const int j = j0 + l;
     const gjx_site& s = a.sites[j];
-    const int kind = s.kind, mode = s.mode, slot = s.slot;
-    uint32_t site_no = RNG == GJX_RNG_FLAT ? walk.next(s.scan) : (uint32_t)(j + 1);
+    const int kind = s.kind, mode = s.mode;
+    const int width = (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) ? 1 : s.dim;
+    const int slot = s.slot >= 0 ? s.slot + inst * width : s.slot;
+    const int obs_off = s.obs_off + inst * s.d_obs;
+    const uint32_t site_no = no0 + (uint32_t)l;
     BitStreamRT<RNG> bs;
     const bool masked = mode == GJX_MODE_OBS_MASK;
     const bool draws = mode == GJX_MODE_SAMPLE || masked;           // wave-uniform
-    const bool given = masked ? (val(s.obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
-    const bool joins = GJX_FLAT_JOINS(RNG, kind, s.dim, mode);      // wave-uniform
-    bool opens = false;
-    const uint32_t e0 = RNG == GJX_RNG_FLAT ? walk.run_elem(site_no, joins, draws, opens) : 0u;
-    if (joins) { if (opens) rs.open(walk.key, gidx, site_no); }
-    else if (draws) bs.open(RNG == GJX_RNG_FLAT ? walk.key : a.key, gidx, site_no);
+    const bool given = masked ? (val(obs_off) != 0.0f) : (mode != GJX_MODE_SAMPLE);   // per lane under a mask
+    const bool joins = joins_single && plate == 0;                  // wave-uniform
+    const uint32_t e0 = e0_single;
+    // element at which this (site, instance) starts drawing: FLAT = the elements a vector site of n * dim elements would use
+    const bool is_cat = kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS;
+    const uint32_t eb = (RNG == GJX_RNG_FLAT && plate != 0) ? (uint32_t)inst * (uint32_t)(is_cat ? 1 : s.dim * draws_per_elem(kind)) : 0u;
+    if (joins) { if (opens_single) rs.open(walk.key, gidx, site_no); }
+    else if (draws) {
+      if (RNG == GJX_RNG_JAX32 && plate != 0) bs.open_site_key(fold_in(inst_key, (uint32_t)(l + 1)));   // static.py:349-352 inside the kernel
+      else bs.open(RNG == GJX_RNG_FLAT ? walk.key : a.key, gidx, site_no);
+    }
     float lp = 0.0f;
     if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
       const int n = s.ncat;
       const bool probs = kind == GJX_CATEGORICAL_PROBS;
       float mx = -INFINITY;
       for (int c = 0; c < n; ++c) {
-        float l = eval_param(s.p[0], c, tab, val);
-        if (probs) l = safe_log(l);
-        mx = fmaxf(mx, l);
+        float l2 = eval_param(s.p[0], c, tab, val, inst);
+        if (probs) l2 = safe_log(l2);
+        mx = fmaxf(mx, l2);
       }
       float se = 0.0f;
       for (int c = 0; c < n; ++c) {
-        float l = eval_param(s.p[0], c, tab, val);
-        if (probs) l = safe_log(l);
-        se += fast_exp(l - mx);
+        float l2 = eval_param(s.p[0], c, tab, val, inst);
+        if (probs) l2 = safe_log(l2);
+        se += fast_exp(l2 - mx);
       }
       const float lse = mx + fast_log(se);
       float v;
       if (draws && RNG == GJX_RNG_FLAT) {
         // inverse CDF on one uniform (se is the float32 running total in category order)
-        const float target = bits_to_unit(bs.get(0u)) * se;
+        const float target = bits_to_unit(bs.get(eb)) * se;
         float run = 0.0f;
         int zc = n - 1;
         bool found = false;
         for (int c = 0; c < n; ++c) {
-          float l = eval_param(s.p[0], c, tab, val);
-          if (probs) l = safe_log(l);
-          run += fast_exp(l - mx);
+          float l2 = eval_param(s.p[0], c, tab, val, inst);
+          if (probs) l2 = safe_log(l2);
+          run += fast_exp(l2 - mx);
           if (!found && run > target) { zc = c; found = true; }
         }
         v = (float)zc;
@@ -122,14 +157,14 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         int best = 0;
         float bestv = -INFINITY;
         for (int c = 0; c < n; ++c) {
-          float l = eval_param(s.p[0], c, tab, val);
-          if (probs) l = safe_log(l);
-          const float g = l + gumbel_from_bits(bs.get((uint32_t)c));
+          float l2 = eval_param(s.p[0], c, tab, val, inst);
+          if (probs) l2 = safe_log(l2);
+          const float g = l2 + gumbel_from_bits(bs.get((uint32_t)c));
           if (g > bestv) { bestv = g; best = c; }
         }
         v = (float)best;
       } else if (mode == GJX_MODE_OBS_TAB) {
-        v = tab[s.obs_off];
+        v = tab[obs_off];
       } else {
         v = val(slot);
       }
@@ -138,9 +173,9 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       if (k < 0 || k >= n) {
         lp = -INFINITY;
       } else {
-        float l = eval_param(s.p[0], k, tab, val);
-        if (probs) l = safe_log(l);
-        lp = l - lse;
+        float l2 = eval_param(s.p[0], k, tab, val, inst);
+        if (probs) l2 = safe_log(l2);
+        lp = l2 - lse;
       }
       if (slot >= 0) {
         if (LDSV) vals_s[slot * 256 + threadIdx.x] = v;
@@ -156,7 +191,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         }
       };
       auto get = [&](int d) -> float {
-        if (mode == GJX_MODE_OBS_TAB) return tab[s.obs_off + d];
+        if (mode == GJX_MODE_OBS_TAB) return tab[obs_off + d];
         return LDSV ? vals_s[(slot + d) * 256 + threadIdx.x] : ch[(int64_t)(slot + d) * K + ii];
       };
       if (mode == GJX_MODE_SAMPLE) {
@@ -187,17 +222,17 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         constexpr int NP = KIND == GJX_TRUNCATED_NORMAL ? 4 : (KIND == GJX_STUDENT_T ? 3 : 2);
         const int nd = draws_per_elem(KIND);
         const int dim = s.dim;
-        const bool b_inv = s.p[1].op == GJX_P_CONST && s.p[1].len == 1 && s.p[1].xf == GJX_XF_NONE;  // wave-uniform
+        const bool b_inv = s.p[1].op == GJX_P_CONST && s.p[1].len == 1 && s.p[1].xf == GJX_XF_NONE && s.p[1].d_off == 0;  // wave-uniform
         const float pb0 = b_inv ? tab[s.p[1].off] : 0.0f;
         for (int d = 0; d < dim; ++d) {
-          const float pa = eval_param(s.p[0], d, tab, val);
-          const float pb = b_inv ? pb0 : eval_param(s.p[1], d, tab, val);
-          const float pc = NP > 2 ? eval_param(s.p[2], d, tab, val) : 0.0f;
-          const float pd = NP > 3 ? eval_param(s.p[3], d, tab, val) : 0.0f;
+          const float pa = eval_param(s.p[0], d, tab, val, inst);
+          const float pb = b_inv ? pb0 : eval_param(s.p[1], d, tab, val, inst);
+          const float pc = NP > 2 ? eval_param(s.p[2], d, tab, val, inst) : 0.0f;
+          const float pd = NP > 3 ? eval_param(s.p[3], d, tab, val, inst) : 0.0f;
           float v;
           if (KIND == GJX_NORMAL && joins) v = fmaf(pb, stream_normal<RNG>(rs, e0), pa);     // member e0 of its run
-          else if (draws) v = elem_sample<RNG>(KIND, bs, (uint32_t)(d * nd), pa, pb, pc, pd);
-          else if (mode == GJX_MODE_OBS_TAB) v = tab[s.obs_off + d];
+          else if (draws) v = elem_sample<RNG>(KIND, bs, eb + (uint32_t)(d * nd), pa, pb, pc, pd);
+          else if (mode == GJX_MODE_OBS_TAB) v = tab[obs_off + d];
           else v = val(slot + d);
           if (masked && given) v = val(slot + d);
           lp += elem_logpdf(KIND, v, pa, pb, pc, pd);
@@ -220,7 +255,13 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
     }
     score += lp;
     if (given) weight += lp;
-    if (a.site_scores && active) a.site_scores[(int64_t)j * K + i] = lp;
+    if (a.site_scores && active) {      // a plate's body site: the sum over its instances
+      float* ss = a.site_scores + (int64_t)j * K + i;
+      *ss = inst == 0 ? lp : *ss + lp;
+    }
+    }   // body sites
+    }   // instances
+    j0 += m;
   }
   float lw = weight;
   if (a.logw_in) lw += a.logw_in[ii];

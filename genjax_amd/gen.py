@@ -673,7 +673,7 @@ class GenerativeFunction:
                 items.append((repr(addr), _value_key(v)))
             if items is not None:
                 ckey = (_args_key(args), tuple(items), bool(sample_rest), tuple(selected),
-                        config.rng_mode() if rng_mode is None else rng_mode, tuple(per_particle), bool(plates))
+                        config.rng_mode() if rng_mode is None else rng_mode, tuple(per_particle), plates if isinstance(plates, str) else bool(plates))
                 hit = cache.get(ckey)
                 if hit is not None and not hit[2]:
                     return hit[0], hit[1], {}
@@ -706,7 +706,7 @@ class GenerativeFunction:
             elif not sample_rest:
                 raise MissingAddress(s.addr)
         rm = config.rng_mode() if rng_mode is None else rng_mode
-        prog = PackedProgram(sl, modes, shared, selected=tuple(selected), rng_mode=rm, plates=bool(plates))
+        prog = PackedProgram(sl, modes, shared, selected=tuple(selected), rng_mode=rm, plates=plates if isinstance(plates, str) else bool(plates))
         prog.mask_flags = mask_rows          # addr -> f32[K] validity flags of Mask(value, flag) constraints
         if ckey is not None and not pp and not mask_rows:
             if len(cache) >= 64:

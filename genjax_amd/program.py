@@ -9,6 +9,7 @@ struct of ``include/gjx.h`` and handed to the HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import itertools
 from dataclasses import dataclass, field
 from typing import Any, Sequence
@@ -33,6 +34,11 @@ class Param:
     length: int = 1                    # VALUE: number of source elements (1 = broadcast)
     xf: int = A.XF_NONE
     terms: list | None = None          # AFFINE over several sites: [(addr, matrix [dim][site dim]), ...]
+    # inside a plate (gjx.h "Plates"): the source element advances by d_elem per instance; `values` / `matrix` (and the
+    # matrices of `terms`) carry a leading instance axis when inst_values / inst_matrix is set
+    d_elem: int = 0
+    inst_values: bool = False
+    inst_matrix: bool = False
 
     @staticmethod
     def const(v, xf=A.XF_NONE) -> "Param":
@@ -83,6 +89,13 @@ class Site:
     ncat: int = 0
     slot: int = -1
     scan: int = 0     # gjx_site.scan: (scan_id << 20) | (step + 1) for the sites of a Scan step, else 0
+    plate: int = 0    # gjx_site.plate / plate_n: body site of a device plate of plate_n instances (dim = ONE instance's size)
+    plate_n: int = 0
+
+    @property
+    def rows(self) -> int:
+        """rows of choices[][] the site owns"""
+        return self.dim * (self.plate_n if self.plate else 1)
 
 
 N_PARAMS = {
@@ -111,9 +124,15 @@ class SiteList:
 
     sites: list[Site] = field(default_factory=list)
     n_slots: int = 0
+    _index: dict = field(default_factory=dict, repr=False, compare=False)     # addr -> position (hashable addresses)
+
+    def _pos(self, addr):
+        if len(self._index) != len(self.sites):
+            self._index = {s.addr: j for j, s in enumerate(self.sites)}
+        return self._index.get(addr)
 
     def add(self, addr: str, kind: int, params: Sequence[Any], dim: int | None = None) -> Site:
-        if any(s.addr == addr for s in self.sites):
+        if self._pos(addr) is not None:
             raise AddressReuse(addr)
         ps = [as_param(p) for p in params]
         if len(ps) != N_PARAMS[kind]:
@@ -145,44 +164,52 @@ class SiteList:
             raise ValueError("dirichlet: at most 256 components per site")
         site = Site(addr, kind, ps, int(dim), ncat, self.n_slots)
         self.sites.append(site)
+        self._index[addr] = len(self.sites) - 1
         self.n_slots += int(dim)
         return site
 
     def __getitem__(self, addr: str) -> Site:
-        for s in self.sites:
-            if s.addr == addr:
-                return s
-        raise KeyError(addr)
+        j = self._pos(addr)
+        if j is None:
+            raise KeyError(addr)
+        return self.sites[j]
 
     def __contains__(self, addr: str) -> bool:
-        return any(s.addr == addr for s in self.sites)
+        return self._pos(addr) is not None
 
     def addresses(self) -> list[str]:
         return [s.addr for s in self.sites]
 
 
 # ---------------------------------------------------------------------------------------------
-# plates: the instances of a vmapped kernel as ONE vector site per kernel site
+# plates: the instances of a vmapped kernel as ONE device site per kernel site
 # ---------------------------------------------------------------------------------------------
 PLATE_MIN = 8     # fewer instances stay unrolled (nothing to gain)
 
 
-def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, draws_ok: bool = True) -> tuple[SiteList, dict, dict, tuple, dict]:
+def _is_cat(kind: int) -> bool:
+    return kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS)
+
+
+def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, draws_ok: bool = True,
+                   tagged: bool = True) -> tuple[SiteList, dict, dict, tuple, dict]:
     """The host tracer unrolls ``kernel.vmap(...)(args)`` into n instances of the kernel's m sites, addressed
-    ``(name, i)`` (combinators/vmap.py:193-218: per-instance sub-traces, summed weights).  For the device a plate of n
-    i.i.d.-structured instances is ONE site per kernel site with n * d elements — element i * d + c is element c of
-    instance i — whose log-density is the sum over the instances (distribution.py:392-396 sums a shaped log-pdf): the
-    N rows of a regression likelihood become one site with an [N x P] affine parameter, not N sites.
+    ``(name, i)`` (combinators/vmap.py:193-218: per-instance sub-traces, summed weights).  The device gets ONE site per
+    kernel site, in one of two forms (both lay a kernel site's values out instance after instance — element i * d + c is
+    element c of instance i — so the logical addresses ``(name, i)`` map to the same rows either way):
 
-    A run of instance-major sites is compacted when, for every kernel site, all instances agree on kind / dimension /
-    mode / selection and every parameter is: a constant (stacked per element when it differs between instances), the
-    value of a site outside the plate (broadcast, or elementwise over the event), the value of an earlier site of the SAME
-    instance with the same dimension (elementwise between the two vector sites), or an affine form over a site outside
-    the plate (matrices stacked to [n d x m]).  Anything else — categorical sites, gathers, per-instance masks, an instance
-    constrained on its own — leaves that plate unrolled, which is always correct.
+    * VECTOR form (``_try_compact``): a plain site with n * d elements whose log-density is the sum over the instances
+      (distribution.py:392-396 sums a shaped log-pdf) — the N rows of a regression likelihood become one site with an
+      [N x P] affine parameter.  Possible when every parameter is a constant, the value of a site outside the plate, the
+      value of an earlier site of the SAME instance with the same dimension, or an affine form over a site outside the
+      plate; not for categorical sites, gathers, masks.  It is what the hand-written and the generated HMC kernels see.
+    * PLATE form (``_try_plate``, ``tagged``): the m sites carry ``gjx_site.plate`` and the engines run ONE instance loop
+      over them (include/gjx.h "Plates") with per-instance rows, observations, masks, tables and sources — categorical
+      sites, gathers on an index of the same instance, per-instance masks, sources in an earlier plate.
 
-    ``draws_ok`` False (GJX_RNG_JAX32, whose streams follow the reference's key structure site by site): only plates whose
-    sites are all constrained — nothing is drawn inside them, so no stream changes — are compacted.
+    Anything neither form covers (instances that differ in structure or mode) stays unrolled, which is always correct.
+    ``draws_ok`` False (GJX_RNG_JAX32, whose streams follow the reference's key structure site by site): the vector form is
+    used only for plates in which nothing is drawn; the plate form follows the reference's instance-key rule and may draw.
 
     -> (device site list, its modes / obs / selected, {logical addr: (device addr, element offset)})"""
     sel = set(selected)
@@ -190,13 +217,27 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
     dmodes, dobs, dsel, where = {}, {}, [], {}
     sites = sl.sites
     j = 0
+    n_plates = 0
 
     def is_inst(s, i=None):
-        return (s.scan == 0 and isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], (int, np.integer))
+        return (isinstance(s.addr, tuple) and len(s.addr) == 2 and isinstance(s.addr[1], (int, np.integer))
                 and (i is None or s.addr[1] == i))
 
+    def resolve_param(p: Param) -> Param:
+        """a parameter of a site OUTSIDE the plates that reads a compacted instance: read the device site at the instance's offset"""
+        if p.op == A.P_CONST:
+            return p
+        if p.terms:
+            if not any(a_ in where for a_, _ in p.terms):
+                return p
+            raise _Unrollable()         # (an affine form over several sites, one of them a compacted instance)
+        if p.src in where:
+            daddr, off = where[p.src]
+            return dataclasses.replace(p, src=daddr, src_elem=p.src_elem + off)
+        return p
+
     def copy_plain(s):
-        ns = Site(s.addr, s.kind, s.params, s.dim, s.ncat, out.n_slots, s.scan)
+        ns = Site(s.addr, s.kind, [resolve_param(p) for p in s.params], s.dim, s.ncat, out.n_slots, s.scan)
         out.sites.append(ns)
         out.n_slots += s.dim
         if s.addr in modes:
@@ -214,16 +255,24 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
             continue
         # instance 0: the kernel's sites; then count the instances that repeat its names
         m = 0
-        while j + m < len(sites) and is_inst(sites[j + m], 0):
+        while j + m < len(sites) and is_inst(sites[j + m], 0) and sites[j + m].scan == s0.scan:
             m += 1
         names = [sites[j + l].addr[0] for l in range(m)]
         n = 1
-        while j + (n + 1) * m <= len(sites) and all(is_inst(sites[j + n * m + l], n) and sites[j + n * m + l].addr[0] == names[l] for l in range(m)):
+        while j + (n + 1) * m <= len(sites) and all(is_inst(sites[j + n * m + l], n) and sites[j + n * m + l].addr[0] == names[l]
+                                                    and sites[j + n * m + l].scan == s0.scan for l in range(m)):
             n += 1
         group = [[sites[j + i * m + l] for i in range(n)] for l in range(m)]      # [kernel site][instance]
-        plate = _try_compact(group, names, n, modes, obs, sel) if n >= PLATE_MIN else None
-        if plate is not None and not draws_ok and any(mode not in (A.MODE_OBS_TAB, A.MODE_OBS_SLOT) for _, mode, _, _ in plate):
-            plate = None
+        plate = None
+        if n >= PLATE_MIN:
+            if s0.scan == 0:
+                plate = _try_compact(group, names, n, modes, obs, sel, where)
+                if plate is not None and not draws_ok and any(mode not in (A.MODE_OBS_TAB, A.MODE_OBS_SLOT) for _, mode, _, _ in plate):
+                    plate = None
+            if plate is None and tagged and m <= 48:
+                plate = _try_plate(group, names, n, modes, obs, sel, where, n_plates + 1)
+                if plate is not None:
+                    n_plates += 1
         if plate is None:
             for i in range(n):
                 for l in range(m):
@@ -231,8 +280,9 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
         else:
             for l, (ns, mode, ov, is_sel) in enumerate(plate):
                 ns.slot = out.n_slots
+                ns.scan = s0.scan
                 out.sites.append(ns)
-                out.n_slots += ns.dim
+                out.n_slots += ns.rows
                 if mode is not None:
                     dmodes[ns.addr] = mode
                 if ov is not None:
@@ -246,15 +296,117 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
     return out, dmodes, dobs, tuple(dsel), where
 
 
-def _try_compact(group, names, n: int, modes: dict, obs: dict, sel: set):
+class _Unrollable(Exception):
+    """a site outside the plates reads compacted instances in a form the device sites cannot express: pack without plates"""
+
+
+def _same(arrs) -> bool:
+    a0 = arrs[0]
+    return all(a.shape == a0.shape and np.array_equal(a, a0) for a in arrs[1:])
+
+
+def _try_plate(group, names, n: int, modes: dict, obs: dict, sel: set, where: dict, pid: int):
+    """PLATE form -> [(body Site, mode or None, observed values [n * d] or None, selected)] per kernel site, or None.
+    Every parameter must have the same form in all instances; what differs between them is per-instance DATA: constants,
+    gather tables, affine bias / matrices (stacked along a leading instance axis) and the source element, which must
+    advance by a fixed number of elements per instance (an earlier site of the same instance: its dimension; a site
+    outside the plate: 0; instance i of an earlier plate: that site's dimension)."""
+    inside = {s.addr: (l, i) for l, col in enumerate(group) for i, s in enumerate(col)}
+    res = []
+
+    def source(addr, l, i):
+        """-> (device addr, element offset) of a source address as instance i of kernel site l sees it, or None"""
+        if addr in inside:
+            ls, isrc = inside[addr]
+            if ls >= l or isrc != i:
+                return None
+            return ("@plate", names[ls]), i * group[ls][0].dim
+        if addr in where:
+            return where[addr]
+        return addr, 0
+
+    for l, col in enumerate(group):
+        s0 = col[0]
+        d = s0.dim
+        if s0.kind == A.DIRICHLET:
+            return None
+        mode0 = modes.get(s0.addr)
+        for s in col:
+            if (s.kind != s0.kind or s.dim != d or s.ncat != s0.ncat or len(s.params) != len(s0.params) or modes.get(s.addr) != mode0
+                    or (s.addr in sel) != (s0.addr in sel)):
+                return None
+        params = []
+        for k, p0 in enumerate(s0.params):
+            ps = [s.params[k] for s in col]
+            if any(q.op != p0.op or q.xf != p0.xf or bool(q.terms) != bool(p0.terms) for q in ps):
+                return None
+            d_elem, src, elem0 = 0, None, 0
+            if p0.op != A.P_CONST and not p0.terms:
+                rs = [source(q.src, l, i) for i, q in enumerate(ps)]
+                if any(r is None for r in rs) or any(r[0] != rs[0][0] for r in rs):
+                    return None
+                el = [r[1] + q.src_elem for r, q in zip(rs, ps)]
+                d_elem = el[1] - el[0]
+                if any(el[i] != el[0] + i * d_elem for i in range(n)) or any(q.length != p0.length for q in ps):
+                    return None
+                src, elem0 = rs[0][0], el[0]
+            if p0.op == A.P_CONST:
+                vs = [q.values for q in ps]
+                if any(v.size != p0.values.size for v in vs):
+                    return None
+                params.append(Param.const(p0.values, xf=p0.xf) if _same(vs) else Param(A.P_CONST, values=np.stack(vs), xf=p0.xf, inst_values=True))
+            elif p0.op == A.P_VALUE:
+                params.append(Param(A.P_VALUE, src=src, src_elem=elem0, length=p0.length, xf=p0.xf, d_elem=d_elem))
+            elif p0.op == A.P_GATHER:
+                vs = [q.values for q in ps]
+                if any(v.shape != p0.values.shape for v in vs):
+                    return None
+                share = _same(vs)
+                params.append(Param(A.P_GATHER, values=p0.values if share else np.stack(vs), src=src, src_elem=elem0, xf=p0.xf,
+                                    d_elem=d_elem, inst_values=not share))
+            elif p0.op == A.P_AFFINE and not p0.terms:
+                if any(q.matrix.shape != p0.matrix.shape or q.values.size != p0.values.size for q in ps):
+                    return None
+                sb, sm = _same([q.values for q in ps]), _same([q.matrix for q in ps])
+                params.append(Param(A.P_AFFINE, values=p0.values if sb else np.stack([q.values for q in ps]),
+                                    matrix=p0.matrix if sm else np.stack([q.matrix for q in ps]), src=src, src_elem=elem0, xf=p0.xf,
+                                    d_elem=d_elem, inst_values=not sb, inst_matrix=not sm))
+            elif p0.op == A.P_AFFINE:
+                # an affine form over several sites: every source outside this plate and the same in all instances
+                t0 = [a_ for a_, _ in p0.terms]
+                if any([a_ for a_, _ in q.terms] != t0 or q.values.size != p0.values.size for q in ps) or any(a_ in inside or a_ in where for a_ in t0):
+                    return None
+                if any(any(mq.shape != m0.shape for (_, mq), (_, m0) in zip(q.terms, p0.terms)) for q in ps):
+                    return None
+                sb = _same([q.values for q in ps])
+                sm = all(_same([q.terms[t][1] for q in ps]) for t in range(len(t0)))
+                terms = p0.terms if sm else [(a_, np.stack([q.terms[t][1] for q in ps])) for t, a_ in enumerate(t0)]
+                params.append(Param(A.P_AFFINE, values=p0.values if sb else np.stack([q.values for q in ps]), src=t0[0], xf=p0.xf,
+                                    terms=terms, inst_values=not sb, inst_matrix=not sm))
+            else:
+                return None
+        ns = Site(("@plate", names[l]), s0.kind, params, d, s0.ncat, -1, 0, pid, n)
+        ov = None
+        if mode0 == A.MODE_OBS_TAB:
+            if any(s.addr not in obs for s in col):
+                return None
+            ov = np.concatenate([np.broadcast_to(np.asarray(obs[s.addr], np.float32).ravel(), (d,)) for s in col])
+        res.append((ns, mode0, ov, s0.addr in sel))
+    return res
+
+
+def _try_compact(group, names, n: int, modes: dict, obs: dict, sel: set, where: dict | None = None):
     """-> [(vector Site, mode or None, observed values or None, selected)] per kernel site, or None"""
     inside = {s.addr: (l, i) for l, col in enumerate(group) for i, s in enumerate(col)}
+    where = where or {}
     res = []
     for l, col in enumerate(group):
         s0 = col[0]
         d = s0.dim
         if s0.kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS, A.DIRICHLET) or s0.ncat:
             return None
+        if any(q.op != A.P_CONST and (q.src in where or (q.terms and any(a_ in where for a_, _ in q.terms))) for s in col for q in s.params):
+            return None                     # reads instances of an earlier plate: the plate form expresses that
         mode0 = modes.get(s0.addr)
         if mode0 == A.MODE_OBS_MASK:
             return None
@@ -318,7 +470,7 @@ class PackedProgram:
 
     def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
                  obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
-                 rng_mode: int = A.RNG_FLAT, plates: bool = False):
+                 rng_mode: int = A.RNG_FLAT, plates: bool | str = False):
         """``plates``: lower the instances of vmapped kernels to vector sites (compact_plates).  The LOGICAL view stays
         per instance — ``site_list``, ``slot_of`` and ``obs_off`` answer for the addresses ``(name, i)`` — while the
         device program (``c_sites``, ``n_sites``) holds one site per kernel site; per-site scores are then per plate,
@@ -328,8 +480,13 @@ class PackedProgram:
         self.plate_of: dict = {}
         obs = obs or {}
         if plates:
-            sl, modes, obs, selected, self.plate_of = compact_plates(sl, dict(modes or {}), dict(obs), tuple(selected),
-                                                                     draws_ok=int(rng_mode) == A.RNG_FLAT)
+            # True: vector form where it applies, else the plate form (gjx_site.plate); "vector": vector form only (the HMC
+            # engines and gjx_score_grad take no plate-tagged sites)
+            try:
+                sl, modes, obs, selected, self.plate_of = compact_plates(sl, dict(modes or {}), dict(obs), tuple(selected),
+                                                                         draws_ok=int(rng_mode) == A.RNG_FLAT, tagged=plates is True)
+            except _Unrollable:
+                sl, modes, self.plate_of = self.logical_site_list, self.logical_modes, {}
             if not self.plate_of:
                 sl = self.logical_site_list
         self.site_list = sl
@@ -361,19 +518,19 @@ class PackedProgram:
                 if s.addr not in obs:
                     raise MissingAddress(s.addr)
                 v = np.asarray(obs[s.addr], np.float32).ravel()
-                if v.size != s.dim:
-                    v = np.broadcast_to(v, (s.dim,))
+                if v.size != s.rows:
+                    v = np.broadcast_to(v, (s.rows,))
                 self.obs_off[s.addr] = push(v)
                 self.slot_of[s.addr] = -1
             else:
                 self.slot_of[s.addr] = n_slots
-                n_slots += s.dim
-        # Mask(value, flag) per particle: one extra row of choices[][] per masked site holds its flags
+                n_slots += s.rows
+        # Mask(value, flag) per particle: one extra row of choices[][] per masked site (per instance of a plate) holds its flags
         self.flag_slot_of: dict[str, int] = {}
         for s in sl.sites:
             if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_MASK:
                 self.flag_slot_of[s.addr] = n_slots
-                n_slots += 1
+                n_slots += s.plate_n if s.plate else 1
         order = {s.addr: j for j, s in enumerate(sl.sites)}
         for j, s in enumerate(sl.sites):
             cs = self.c_sites[j]
@@ -381,7 +538,10 @@ class PackedProgram:
             cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
             cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
             cs.scan = int(s.scan)
+            cs.plate, cs.plate_n = int(s.plate), int(s.plate_n)
             cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)
+            if s.plate:
+                cs.d_obs = 1 if cs.mode == A.MODE_OBS_MASK else (s.dim if cs.mode == A.MODE_OBS_TAB else 0)
             rows = s.ncat if s.ncat else s.dim
             for k in range(len(s.params), A.MAX_PARAMS):   # unused parameter slots read tab[0]
                 cs.p[k].op, cs.p[k].len, cs.p[k].off = A.P_CONST, 1, 0
@@ -396,29 +556,43 @@ class PackedProgram:
                     self._pack_affine_multi(cp, p, s, rows, push)
                     continue
                 src_obs = p.op != A.P_CONST and self.slot_of[p.src] < 0
+                ninst = s.plate_n if s.plate else 1
                 if p.op == A.P_CONST:
-                    cp.off, cp.len = push(p.values), int(p.values.size)
+                    cp.off, cp.len = push(p.values), int(p.values.size // (ninst if p.inst_values else 1))
+                    cp.d_off = cp.len if p.inst_values else 0
                 elif p.op == A.P_VALUE and src_obs:
                     cp.op = A.P_CONST  # read the observed value straight from tab
                     cp.off, cp.len = self.obs_off[p.src] + p.src_elem, int(p.length)
+                    cp.d_off = int(p.d_elem)
                 elif src_obs:
-                    cp.op = A.P_CONST  # parameter is a function of observed data only: fold on the host
-                    vals = self._fold_observed(p, rows)
-                    cp.off, cp.len = push(vals), int(vals.size)
+                    cp.op = A.P_CONST  # parameter is a function of observed data only: fold on the host (per instance in a plate)
+                    if s.plate:
+                        vals = np.stack([self._fold_observed(p, rows, i) for i in range(ninst)])
+                        cp.off, cp.len, cp.d_off = push(vals), int(vals.shape[1]), int(vals.shape[1])
+                    else:
+                        vals = self._fold_observed(p, rows)
+                        cp.off, cp.len = push(vals), int(vals.size)
                     self._derived.append((cp.off, p, s.addr))
                 elif p.op == A.P_VALUE:
                     cp.slot, cp.len = self.slot_of[p.src] + p.src_elem, int(p.length)
+                    cp.d_slot = int(p.d_elem)
                 elif p.op == A.P_GATHER:
                     cp.slot = self.slot_of[p.src] + p.src_elem
-                    cp.n, cp.len = int(p.values.shape[0]), int(p.values.shape[1])
+                    cp.d_slot = int(p.d_elem)
+                    tshape = p.values.shape[1:] if p.inst_values else p.values.shape
+                    cp.n, cp.len = int(tshape[0]), int(tshape[1])
                     cp.off = push(p.values)
+                    cp.d_off = cp.n * cp.len if p.inst_values else 0
                 elif p.op == A.P_AFFINE:
-                    m = p.matrix
-                    if m.shape[0] != rows:
-                        raise ValueError(f"affine matrix of {s.addr!r} has {m.shape[0]} rows, site dim {rows}")
-                    cp.slot, cp.n = self.slot_of[p.src] + p.src_elem, int(m.shape[1])
-                    cp.off, cp.len = push(p.values), int(p.values.size)
-                    cp.moff = push(m)
+                    mshape = p.matrix.shape[1:] if p.inst_matrix else p.matrix.shape
+                    if mshape[0] != rows:
+                        raise ValueError(f"affine matrix of {s.addr!r} has {mshape[0]} rows, site dim {rows}")
+                    cp.slot, cp.n = self.slot_of[p.src] + p.src_elem, int(mshape[1])
+                    cp.d_slot = int(p.d_elem)
+                    cp.off, cp.len = push(p.values), int(p.values.size // (ninst if p.inst_values else 1))
+                    cp.d_off = cp.len if p.inst_values else 0
+                    cp.moff = push(p.matrix)
+                    cp.d_moff = int(mshape[0] * mshape[1]) if p.inst_matrix else 0
                 else:
                     raise ValueError(p.op)
         self.tab = np.concatenate(tab).astype(np.float32) if tab else np.zeros(1, np.float32)
@@ -431,6 +605,10 @@ class PackedProgram:
                 self.slot_of[addr] = self.slot_of[daddr] + off if self.slot_of[daddr] >= 0 else -1
                 if daddr in self.obs_off:
                     self.obs_off[addr] = self.obs_off[daddr] + off
+                if daddr in self.flag_slot_of:      # a masked plate site: one flag row per instance
+                    self.flag_slot_of[addr] = self.flag_slot_of[daddr] + off // max(self.device_site_list[daddr].dim, 1)
+            for daddr in {d for d, _ in self.plate_of.values()}:
+                self.flag_slot_of.pop(daddr, None)
             self.site_list = self.logical_site_list
             self.modes = self.logical_modes
         else:
@@ -442,47 +620,64 @@ class PackedProgram:
     # -- observed values can be replaced in place (same program, new data) --
     def _obs_value(self, addr: str) -> np.ndarray:
         off = self.obs_off[addr]
-        return self._tab_view()[off:off + self.site_list[addr].dim]
+        return self._tab_view()[off:off + self.site_list[addr].rows]
 
     def _tab_view(self) -> np.ndarray:
         return self.tab if hasattr(self, "tab") else np.concatenate(self._tab_parts)
 
     def _pack_affine_multi(self, cp, p: Param, s: Site, rows: int, push) -> None:
+        ninst = s.plate_n if s.plate else 1
+        per_inst = bool(s.plate) and (p.inst_matrix or p.inst_values)
+        def mat(m, i):
+            return m[i] if p.inst_matrix else m
         latent = [(a, m) for a, m in p.terms if self.slot_of[a] >= 0]
         for a, m in p.terms:
-            if m.shape[0] != rows or m.shape[1] != self.site_list[a].dim:
-                raise ValueError(f"affine term of {s.addr!r} on {a!r} has shape {m.shape}, want ({rows}, {self.site_list[a].dim})")
-        bias = self._fold_observed(p, rows)
+            m0 = mat(m, 0)
+            if m0.shape[0] != rows or m0.shape[1] != self.site_list[a].dim:
+                raise ValueError(f"affine term of {s.addr!r} on {a!r} has shape {m0.shape}, want ({rows}, {self.site_list[a].dim})")
+        observed = len(latent) < len(p.terms)
+        per_inst = per_inst or (bool(s.plate) and observed and p.inst_matrix)
+        insts = range(ninst) if per_inst else range(1)
+        bias = np.stack([self._fold_observed(p, rows, i) for i in insts])
         if not latent:
             cp.op = A.P_CONST
-            cp.off, cp.len = push(bias), int(bias.size)
+            cp.off, cp.len = push(bias), int(bias.shape[1])
+            cp.d_off = cp.len if per_inst else 0
         else:
             lo = min(self.slot_of[a] for a, _ in latent)
-            hi = max(self.slot_of[a] + m.shape[1] for a, m in latent)
-            dense = np.zeros((rows, hi - lo), np.float32)
-            for a, m in latent:
-                dense[:, self.slot_of[a] - lo: self.slot_of[a] - lo + m.shape[1]] += m
+            hi = max(self.slot_of[a] + mat(m, 0).shape[1] for a, m in latent)
+            dense = np.zeros((len(insts), rows, hi - lo), np.float32)
+            for i in insts:
+                for a, m in latent:
+                    mi = mat(m, i)
+                    dense[i, :, self.slot_of[a] - lo: self.slot_of[a] - lo + mi.shape[1]] += mi
             cp.slot, cp.n = lo, hi - lo
-            cp.off, cp.len = push(bias), int(bias.size)
+            cp.off, cp.len = push(bias), int(bias.shape[1])
             cp.moff = push(dense)
-        if len(latent) < len(p.terms):
+            if per_inst:
+                cp.d_off, cp.d_moff = cp.len, rows * (hi - lo)
+        if observed:
             self._derived.append((cp.off, p, s.addr))
 
-    def _fold_observed(self, p: Param, rows: int) -> np.ndarray:
+    def _fold_observed(self, p: Param, rows: int, inst: int = 0) -> np.ndarray:
+        """the part of a parameter that depends on observed data only, evaluated on the host (for instance `inst` of a plate)"""
+        vals = p.values[inst] if p.inst_values else p.values
         if p.terms:
-            bias = np.broadcast_to(p.values, (rows,)).astype(np.float32).copy() if p.values.size in (1, rows) else p.values.astype(np.float32).copy()
+            bias = np.broadcast_to(vals, (rows,)).astype(np.float32).copy() if vals.size in (1, rows) else vals.astype(np.float32).copy()
             for a, m in p.terms:
                 if self.slot_of[a] < 0:
-                    bias = bias + m @ self._obs_value(a)[: m.shape[1]]
+                    mi = m[inst] if p.inst_matrix else m
+                    bias = bias + mi @ self._obs_value(a)[: mi.shape[1]]
             return bias.astype(np.float32)
-        src = self._obs_value(p.src)[p.src_elem:]
+        src = self._obs_value(p.src)[p.src_elem + inst * p.d_elem:]
         if p.op == A.P_GATHER:
-            idx = int(np.clip(int(src[0]), 0, p.values.shape[0] - 1))
-            return p.values[idx].astype(np.float32).copy()
+            idx = int(np.clip(int(src[0]), 0, vals.shape[0] - 1))
+            return vals[idx].astype(np.float32).copy()
         if p.op == A.P_AFFINE:
-            n = p.matrix.shape[1]
-            bias = np.broadcast_to(p.values, (rows,)) if p.values.size in (1, rows) else p.values
-            return (bias + p.matrix @ src[:n]).astype(np.float32)
+            mi = p.matrix[inst] if p.inst_matrix else p.matrix
+            n = mi.shape[1]
+            bias = np.broadcast_to(vals, (rows,)) if vals.size in (1, rows) else vals
+            return (bias + mi @ src[:n]).astype(np.float32)
         raise ValueError(p.op)
 
     def set_obs(self, addr: str, value) -> None:
@@ -495,7 +690,9 @@ class PackedProgram:
         for doff, p, site_addr in self._derived:
             if p.src in (addr, daddr) or (p.terms and any(a in (addr, daddr) for a, _ in p.terms)):
                 s = self.device_site_list[site_addr]
-                vals = self._fold_observed(p, s.ncat if s.ncat else s.dim)
+                r_ = s.ncat if s.ncat else s.dim
+                per = s.plate and (p.inst_values or p.inst_matrix or p.d_elem)
+                vals = np.stack([self._fold_observed(p, r_, i) for i in range(s.plate_n)]).ravel() if per else self._fold_observed(p, r_)
                 self.tab[doff:doff + vals.size] = vals
                 dirty.append((doff, vals.size))
         if self._dev is not None:

@@ -505,159 +505,225 @@ static float elem_sample(int kind, const ostream* sk, uint32_t c, float a, float
   }
 }
 
+/* stream key and site number of every site (gjx.h "Scan steps"): sites of a Scan step use the chained step key
+ * key_t = fold_in(key_{t-1}, t) (scan.py:268) and their position within the step; the others the run key and their
+ * position among the non-Scan sites.  Scalar-normal runs: gjx.h. */
+typedef struct {
+  okey run_key, skey;
+  int32_t tag;
+  uint32_t local, plain;
+  uint32_t run_head, run_next; /* open scalar-normal run: head's site number, next element */
+} site_walk;
+
+/* -> site number of site s (FLAT numbering); *e0 = element of the stream at which the site's draws start */
+static uint32_t walk_next(site_walk* w, const gjx_program* prog, const gjx_site* s, int j, uint32_t* e0) {
+  uint32_t site_no = (uint32_t)(j + 1);
+  *e0 = 0u;
+  if (prog->rng_mode != GJX_RNG_FLAT) return site_no;
+  if (s->scan == 0) { if (w->tag != 0) w->run_head = 0u; w->skey = w->run_key; w->tag = 0; site_no = ++w->plain; }
+  else {
+    if (s->scan != w->tag) {
+      w->run_head = 0u;
+      const uint32_t id = GJX_SCAN_ID(s->scan);
+      const int32_t step = GJX_SCAN_STEP(s->scan);
+      if (w->tag != 0 && GJX_SCAN_ID(w->tag) == id && GJX_SCAN_STEP(w->tag) == step - 1) w->skey = fold_in(w->skey, (uint32_t)step);
+      else {
+        w->skey = fold_in(w->run_key, 0x80000000u | id);
+        for (int32_t t = 0; t <= step; ++t) w->skey = fold_in(w->skey, (uint32_t)t);
+      }
+      w->tag = s->scan;
+      w->local = 0u;
+    }
+    site_no = ++w->local;
+  }
+  /* the STATIC mode decides membership (a masked site draws per particle: it closes the run); sites of a plate never join */
+  if (s->plate == 0 && GJX_FLAT_JOINS(prog->rng_mode, s->kind, s->dim, s->mode)) {
+    if (w->run_head == 0u || w->run_next >= (uint32_t)GJX_FLAT_RUN_MAX) { w->run_head = site_no; w->run_next = 0u; }
+    site_no = w->run_head;
+    *e0 = w->run_next++;
+  } else if (s->mode == GJX_MODE_SAMPLE || s->mode == GJX_MODE_OBS_MASK) {
+    w->run_head = 0u;
+  }
+  return site_no;
+}
+
+/* One site (instance `inst` of it when the site belongs to a plate: gjx.h "Plates") for one particle.  `sk`: the site's
+ * stream; ebase: element at which this (site, instance) starts drawing.  -> log-density; *given: the value was constrained */
+static float run_site(const gjx_program* prog, const gjx_site* s0, int inst, const ostream* sk, uint32_t ebase, float* vals, int* given) {
+  const float* tab = prog->tab;
+  gjx_site sv = *s0;                   /* the site with its per-instance offsets applied */
+  gjx_site* s = &sv;
+  if (s0->plate && inst) {
+    const int w = (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) ? 1 : s->dim;
+    if (s->slot >= 0) s->slot += inst * w;
+    s->obs_off += inst * s->d_obs;
+    for (int k = 0; k < GJX_MAX_PARAMS; ++k) { s->p[k].off += inst * s->p[k].d_off; s->p[k].slot += inst * s->p[k].d_slot; s->p[k].moff += inst * s->p[k].d_moff; }
+  }
+  /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
+   * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
+  int mode = s->mode;
+  if (mode == GJX_MODE_OBS_MASK) mode = vals[s->obs_off] != 0.0f ? GJX_MODE_OBS_SLOT : GJX_MODE_SAMPLE;
+  *given = mode != GJX_MODE_SAMPLE;
+  float lp = 0.0f;
+  if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
+    /* logits (probs -> log p), log_softmax; sample = argmax(logits + Gumbel) */
+    int n = s->ncat;
+    float mx = -INFINITY;
+    for (int c = 0; c < n; ++c) {
+      float l = eval_param(&s->p[0], c, tab, vals);
+      if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+      if (l > mx) mx = l;
+    }
+    double se = 0.0;
+    for (int c = 0; c < n; ++c) {
+      float l = eval_param(&s->p[0], c, tab, vals);
+      if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+      se += exp((double)l - (double)mx);
+    }
+    float lse = mx + (float)log(se);
+    float v;
+    if (mode == GJX_MODE_SAMPLE && prog->rng_mode == GJX_RNG_FLAT) {
+      /* FLAT layout: inverse CDF on ONE uniform (float32 running sum of exp(l - max), category order) */
+      float tot = 0.0f;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        tot += expf(l - mx);
+      }
+      const float target = bits_to_unit(elem_bits(sk, ebase)) * tot;
+      float run = 0.0f;
+      int zc = n - 1;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        run += expf(l - mx);
+        if (c < n - 1) decide(run, target);
+        if (run > target) { zc = c; break; }
+      }
+      v = (float)zc;
+    } else if (mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
+      int best = 0;
+      float bestv = -INFINITY, second = -INFINITY;
+      for (int c = 0; c < n; ++c) {
+        float l = eval_param(&s->p[0], c, tab, vals);
+        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+        float g = l + gumbel_from_bits(elem_bits(sk, ebase + (uint32_t)c));
+        if (g > bestv) { second = bestv; bestv = g; best = c; } else if (g > second) second = g;
+      }
+      if (n > 1) decide(bestv, second);
+      v = (float)best;
+    } else if (mode == GJX_MODE_OBS_TAB) {
+      v = tab[s->obs_off];
+    } else {
+      v = vals[s->slot];
+    }
+    int k = (int)v;
+    if (k < 0 || k >= n) {
+      lp = -INFINITY;
+    } else {
+      float l = eval_param(&s->p[0], k, tab, vals);
+      if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
+      lp = l - lse;
+    }
+    if (s->slot >= 0) vals[s->slot] = v;
+  } else if (s->kind == GJX_DIRICHLET) { /* tfd.Dirichlet(concentration): gamma variates normalised; joint density */
+    int n = s->dim;
+    float x[256];
+    if (n > 256) n = 256;
+    if (mode == GJX_MODE_SAMPLE) {
+      float mx = -INFINITY, se = 0.0f;
+      for (int d = 0; d < n; ++d) {
+        x[d] = log_gamma_variate(sk, ebase + (uint32_t)(d * GAMMA_NDRAW), eval_param(&s->p[0], d, tab, vals));
+        if (x[d] > mx) mx = x[d];
+      }
+      for (int d = 0; d < n; ++d) se += expf(x[d] - mx);
+      for (int d = 0; d < n; ++d) x[d] = expf(x[d] - (mx + logf(se)));
+    } else {
+      for (int d = 0; d < n; ++d) x[d] = mode == GJX_MODE_OBS_TAB ? tab[s->obs_off + d] : vals[s->slot + d];
+    }
+    float sa = 0.0f;
+    for (int d = 0; d < n; ++d) {
+      float al = eval_param(&s->p[0], d, tab, vals);
+      sa += al;
+      lp += xlogyf(al - 1.0f, x[d]) - lgammaf(al);
+      if (s->slot >= 0) vals[s->slot + d] = x[d];
+    }
+    lp += lgammaf(sa);
+  } else {
+    int nd = draws_per_elem(s->kind);
+    int np = s->kind >= GJX_STUDENT_T ? params_of(s->kind) : 2;
+    for (int d = 0; d < s->dim; ++d) {
+      float a = eval_param(&s->p[0], d, tab, vals);
+      float b = eval_param(&s->p[1], d, tab, vals);
+      float c = np > 2 ? eval_param(&s->p[2], d, tab, vals) : 0.0f;
+      float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
+      int wide = s->kind >= GJX_STUDENT_T;
+      float v;
+      if (mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, ebase + (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, ebase + (uint32_t)(d * nd), a, b);
+      else if (mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
+      else v = vals[s->slot + d];
+      lp += wide ? elem_logpdf4(s->kind, v, a, b, c, e) : elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
+      if (s->slot >= 0) vals[s->slot + d] = v;
+    }
+  }
+  return lp;
+}
+
 /* One particle through the site list.  vals[n_slots] in/out.  Returns via pointers. */
 static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, float* vals, float* score_out,
                          float* weight_out, float* site_scores, int64_t ss_stride) {
-  const float* tab = prog->tab;
   float score = 0.0f, weight = 0.0f;
-  /* stream key and site number of every site (gjx.h "Scan steps"): sites of a Scan step use the chained step key
-   * key_t = fold_in(key_{t-1}, t) (scan.py:268) and their position within the step; the others the run key and their
-   * position among the non-Scan sites */
-  okey skey = run_key;
-  int32_t tag = 0;
-  uint32_t local = 0u, plain = 0u;
-  uint32_t run_head = 0u, run_next = 0u; /* open scalar-normal run (gjx.h "Scalar-normal runs"): head's site number, next element */
-  for (int j = 0; j < prog->n_sites; ++j) {
+  site_walk w = {run_key, run_key, 0, 0u, 0u, 0u, 0u};
+  const int flat = prog->rng_mode == GJX_RNG_FLAT;
+  for (int j = 0; j < prog->n_sites;) {
     const gjx_site* s = &prog->sites[j];
-    uint32_t site_no = (uint32_t)(j + 1);
-    uint32_t e0 = 0u; /* element of the stream at which this site's draws start */
-    if (prog->rng_mode == GJX_RNG_FLAT) {
-      if (s->scan == 0) { if (tag != 0) run_head = 0u; skey = run_key; tag = 0; site_no = ++plain; }
-      else {
-        if (s->scan != tag) {
-          run_head = 0u;
-          const uint32_t id = GJX_SCAN_ID(s->scan);
-          const int32_t step = GJX_SCAN_STEP(s->scan);
-          if (tag != 0 && GJX_SCAN_ID(tag) == id && GJX_SCAN_STEP(tag) == step - 1) skey = fold_in(skey, (uint32_t)step);
-          else {
-            skey = fold_in(run_key, 0x80000000u | id);
-            for (int32_t t = 0; t <= step; ++t) skey = fold_in(skey, (uint32_t)t);
-          }
-          tag = s->scan;
-          local = 0u;
+    if (s->plate == 0) {
+      uint32_t e0;
+      const uint32_t site_no = walk_next(&w, prog, s, j, &e0);
+      const ostream st = stream_open(prog->rng_mode, flat ? w.skey : run_key, idx, site_no); /* counter starts at 1 */
+      int given;
+      const float lp = run_site(prog, s, 0, &st, e0, vals, &given);
+      score += lp;
+      if (given) weight += lp; /* static.py:377 with distribution.py:127/147 */
+      if (site_scores) site_scores[(int64_t)j * ss_stride] = lp;
+      ++j;
+      continue;
+    }
+    /* a plate (gjx.h "Plates"; vmap.py:180-218): m body sites, n instances, ONE instance loop over the body */
+    int m = 1;
+    while (j + m < prog->n_sites && prog->sites[j + m].plate == s->plate) ++m;
+    const int n = s->plate_n;
+    uint32_t site_no[64];
+    float acc[64];
+    if (m > 64) m = 64; /* (the host never emits more) */
+    for (int l = 0; l < m; ++l) { uint32_t e0; site_no[l] = walk_next(&w, prog, &prog->sites[j + l], j + l, &e0); acc[l] = 0.0f; }
+    /* JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J), J = 1-based index of the
+     * plate's first site; instance key = split(plate key, n)[i] (vmap.py:186, 201) */
+    okey pkey = run_key;
+    if (!flat) pkey = fold_in(fold_in64(run_key, idx), (uint32_t)(j + 1));
+    for (int i = 0; i < n; ++i) {
+      okey ikey = pkey;
+      if (!flat) ikey = fold_in(pkey, (uint32_t)i);
+      for (int l = 0; l < m; ++l) {
+        const gjx_site* sl = &prog->sites[j + l];
+        ostream st;
+        uint32_t ebase = 0u;
+        if (flat) {
+          st = stream_open(prog->rng_mode, w.skey, idx, site_no[l]);
+          const int cat = sl->kind == GJX_CATEGORICAL_LOGITS || sl->kind == GJX_CATEGORICAL_PROBS;
+          ebase = cat ? (uint32_t)i : (uint32_t)i * (uint32_t)sl->dim * (uint32_t)draws_per_elem(sl->kind);
+        } else {
+          st = stream_from_site_key(fold_in(ikey, (uint32_t)(l + 1))); /* static.py:349-352 inside the kernel */
         }
-        site_no = ++local;
-      }
-      /* the STATIC mode decides membership (a masked site draws per particle: it closes the run) */
-      if (GJX_FLAT_JOINS(prog->rng_mode, s->kind, s->dim, s->mode)) {
-        if (run_head == 0u || run_next >= (uint32_t)GJX_FLAT_RUN_MAX) { run_head = site_no; run_next = 0u; }
-        site_no = run_head;
-        e0 = run_next++;
-      } else if (s->mode == GJX_MODE_SAMPLE || s->mode == GJX_MODE_OBS_MASK) {
-        run_head = 0u;
+        int given;
+        const float lp = run_site(prog, sl, i, &st, ebase, vals, &given);
+        score += lp;
+        if (given) weight += lp;
+        acc[l] += lp;
       }
     }
-    /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
-     * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
-    int mode = s->mode;
-    if (mode == GJX_MODE_OBS_MASK) mode = vals[s->obs_off] != 0.0f ? GJX_MODE_OBS_SLOT : GJX_MODE_SAMPLE;
-    const ostream st = stream_open(prog->rng_mode, prog->rng_mode == GJX_RNG_FLAT ? skey : run_key, idx, site_no); /* counter starts at 1 */
-    const ostream* sk = &st;
-    float lp = 0.0f;
-    if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
-      /* logits (probs -> log p), log_softmax; sample = argmax(logits + Gumbel) */
-      int n = s->ncat;
-      float mx = -INFINITY;
-      for (int c = 0; c < n; ++c) {
-        float l = eval_param(&s->p[0], c, tab, vals);
-        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-        if (l > mx) mx = l;
-      }
-      double se = 0.0;
-      for (int c = 0; c < n; ++c) {
-        float l = eval_param(&s->p[0], c, tab, vals);
-        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-        se += exp((double)l - (double)mx);
-      }
-      float lse = mx + (float)log(se);
-      float v;
-      if (mode == GJX_MODE_SAMPLE && prog->rng_mode == GJX_RNG_FLAT) {
-        /* FLAT layout: inverse CDF on ONE uniform (float32 running sum of exp(l - max), category order) */
-        float tot = 0.0f;
-        for (int c = 0; c < n; ++c) {
-          float l = eval_param(&s->p[0], c, tab, vals);
-          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-          tot += expf(l - mx);
-        }
-        const float target = bits_to_unit(elem_bits(sk, 0u)) * tot;
-        float run = 0.0f;
-        int zc = n - 1;
-        for (int c = 0; c < n; ++c) {
-          float l = eval_param(&s->p[0], c, tab, vals);
-          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-          run += expf(l - mx);
-          if (c < n - 1) decide(run, target);
-          if (run > target) { zc = c; break; }
-        }
-        v = (float)zc;
-      } else if (mode == GJX_MODE_SAMPLE) { /* JAX32 layout: Gumbel-max (jax.random.categorical) */
-        int best = 0;
-        float bestv = -INFINITY, second = -INFINITY;
-        for (int c = 0; c < n; ++c) {
-          float l = eval_param(&s->p[0], c, tab, vals);
-          if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-          float g = l + gumbel_from_bits(elem_bits(sk, (uint32_t)c));
-          if (g > bestv) { second = bestv; bestv = g; best = c; } else if (g > second) second = g;
-        }
-        if (n > 1) decide(bestv, second);
-        v = (float)best;
-      } else if (mode == GJX_MODE_OBS_TAB) {
-        v = tab[s->obs_off];
-      } else {
-        v = vals[s->slot];
-      }
-      int k = (int)v;
-      if (k < 0 || k >= n) {
-        lp = -INFINITY;
-      } else {
-        float l = eval_param(&s->p[0], k, tab, vals);
-        if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
-        lp = l - lse;
-      }
-      if (s->slot >= 0) vals[s->slot] = v;
-    } else if (s->kind == GJX_DIRICHLET) { /* tfd.Dirichlet(concentration): gamma variates normalised; joint density */
-      int n = s->dim;
-      float x[256];
-      if (n > 256) n = 256;
-      if (mode == GJX_MODE_SAMPLE) {
-        float mx = -INFINITY, se = 0.0f;
-        for (int d = 0; d < n; ++d) {
-          x[d] = log_gamma_variate(sk, (uint32_t)(d * GAMMA_NDRAW), eval_param(&s->p[0], d, tab, vals));
-          if (x[d] > mx) mx = x[d];
-        }
-        for (int d = 0; d < n; ++d) se += expf(x[d] - mx);
-        for (int d = 0; d < n; ++d) x[d] = expf(x[d] - (mx + logf(se)));
-      } else {
-        for (int d = 0; d < n; ++d) x[d] = mode == GJX_MODE_OBS_TAB ? tab[s->obs_off + d] : vals[s->slot + d];
-      }
-      float sa = 0.0f;
-      for (int d = 0; d < n; ++d) {
-        float al = eval_param(&s->p[0], d, tab, vals);
-        sa += al;
-        lp += xlogyf(al - 1.0f, x[d]) - lgammaf(al);
-        if (s->slot >= 0) vals[s->slot + d] = x[d];
-      }
-      lp += lgammaf(sa);
-    } else {
-      int nd = draws_per_elem(s->kind);
-      int np = s->kind >= GJX_STUDENT_T ? params_of(s->kind) : 2;
-      for (int d = 0; d < s->dim; ++d) {
-        float a = eval_param(&s->p[0], d, tab, vals);
-        float b = eval_param(&s->p[1], d, tab, vals);
-        float c = np > 2 ? eval_param(&s->p[2], d, tab, vals) : 0.0f;
-        float e = np > 3 ? eval_param(&s->p[3], d, tab, vals) : 0.0f;
-        int wide = s->kind >= GJX_STUDENT_T;
-        float v;
-        if (mode == GJX_MODE_SAMPLE) v = wide ? elem_sample4(s->kind, sk, (uint32_t)(d * nd), a, b, c, e) : elem_sample(s->kind, sk, e0 + (uint32_t)(d * nd), a, b);
-        else if (mode == GJX_MODE_OBS_TAB) v = tab[s->obs_off + d];
-        else v = vals[s->slot + d];
-        lp += wide ? elem_logpdf4(s->kind, v, a, b, c, e) : elem_logpdf(s->kind, v, a, b); /* distribution.py:392-396: summed over the event */
-        if (s->slot >= 0) vals[s->slot + d] = v;
-      }
-    }
-    score += lp;
-    if (mode != GJX_MODE_SAMPLE) weight += lp; /* static.py:377 with distribution.py:127/147 */
-    if (site_scores) site_scores[(int64_t)j * ss_stride] = lp;
+    if (site_scores) for (int l = 0; l < m; ++l) site_scores[(int64_t)(j + l) * ss_stride] = acc[l];
+    j += m;
   }
   *score_out = score;
   *weight_out = weight;
