@@ -32,7 +32,8 @@ NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move 
 # param forms / transforms / modes / flags / rng
 P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
-MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK = 0, 1, 2, 3
+MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK, MODE_INPUT = 0, 1, 2, 3, 4
+RUN_LEAVE_TILES, RUN_TIME_DISPATCH, RUN_STORE_INPUTS = 1, 2, 4
 SITE_HMC_SELECTED = 1
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
@@ -59,6 +60,15 @@ class GjxProgram(C.Structure):
     _fields_ = [("n_sites", i32), ("n_slots", i32), ("n_tab", i32), ("rng_mode", i32),
                 ("sites", vp), ("sites_dev", vp), ("tab", vp), ("tab_dev", vp), ("aux_dev", vp), ("n_aux", i32),
                 ("uid", i32)]
+
+
+class GjxRunOpts(C.Structure):
+    _fields_ = [("flags", i32), ("pad_", i32), ("start_event", vp), ("stop_event", vp), ("in_rows", vp), ("in_stride", i64),
+                ("in_ancestors", vp)]
+
+
+class GjxRunInfo(C.Structure):
+    _fields_ = [("n_partials", i32), ("engine", i32), ("tiles_offset", i64)]
 
 
 class GjxSsm(C.Structure):
@@ -94,6 +104,8 @@ PROTOTYPES = {
     "gjx_threefry2x32": (C.c_int, [u32, u32, u32, u32, i64, vp, vp]),
     "gjx_run_program": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp,
                                   C.c_size_t, vp]),
+    "gjx_run_program_ex": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp,
+                                     C.POINTER(GjxRunOpts), C.POINTER(GjxRunInfo)]),
     "gjx_importance_step": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, f64, vp, vp, vp, C.c_size_t, vp]),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
     "gjx_workspace_status": (C.c_int, [vp, C.POINTER(i32), vp]),
@@ -136,6 +148,7 @@ PROTOTYPES = {
     "gjx_ssm_filter_scheme": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp,
                                       C.c_size_t, vp]),
+    "gjx_scan_filter": (C.c_int, [vp, i32, u32, u32, i64, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),

@@ -36,6 +36,12 @@ const char* kDeviceHeader =
 const char* kApiHeader =
 #include "build/gjx_h.inc"
     ;
+const char* kScanHeader =
+#include "build/gjx_scan_h.inc"
+    ;
+const char* kTileHeader =
+#include "build/gjx_tile_h.inc"
+    ;
 
 // ---------------------------------------------------------------------------------------------------------
 // emitter
@@ -361,7 +367,7 @@ PlateXf plate_program(const gjx_program* p) {
   const int n = p->n_sites;
   for (int j = 0; j < n; ++j) x.any = x.any || p->sites[j].plate != 0;
   if (!x.any) return x;
-  auto width = [&](const gjx_site& s) { return is_categorical(s.kind) ? 1 : s.dim; };
+  auto width = [&](const gjx_site& s) { return (is_categorical(s.kind) && s.mode != GJX_MODE_INPUT) ? 1 : s.dim; };
   auto rows = [&](const gjx_site& s) { return width(s) * (s.plate ? s.plate_n : 1); };
   std::vector<int> reg(n, -1), flag(n, -1), first(n, 0), pos(n, 0);
   int next = 0;
@@ -388,7 +394,7 @@ PlateXf plate_program(const gjx_program* p) {
     }
     if (s.mode == GJX_MODE_OBS_SLOT || s.mode == GJX_MODE_OBS_MASK) ri.load_here = true;   // (registers are not row numbers here)
     if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = s.plate ? s.d_obs : 0; s.obs_off = flag[j]; }
-    for (int k = 0; k < n_params(s.kind); ++k) {
+    for (int k = 0; k < (s.mode == GJX_MODE_INPUT ? 0 : n_params(s.kind)); ++k) {
       gjx_param& q = s.p[k];
       if (!slot_op(q.op)) continue;
       const int span = ref_span(q);
@@ -430,6 +436,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
   int total = 0;
   for (int j = 0; j < n_sites; ++j) {
     const gjx_site& s = sites[j];
+    if (s.mode == GJX_MODE_INPUT) { if (s.dim < 1 || s.dim > kMaxExpandDim || s.slot < 0) return false; total += s.dim; continue; }
     if (s.kind == GJX_DIRICHLET || s.kind < 1 || s.kind > GJX_CHI2) return false;
     if (is_categorical(s.kind)) {
       if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
@@ -513,6 +520,18 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const gjx_site& s = prog->sites[j];
   const RollInfo& ri = pl.info[j];
   g_loop_var = ri.plate ? "i_" : "(t_ - 1)";
+  if (s.mode == GJX_MODE_INPUT) {
+    // the carry of a Scan step / an argument: rows that are already there, or the rows of the ancestor the resampling step
+    // picked for this slot (gjx_run_program_ex: the particle gather fused into the read side); no draw, no score
+    o.f("    { // ---- site %d: INPUT, %d rows, slot %d\n", j, s.dim, s.slot);
+    for (int d = 0; d < s.dim; ++d)
+      o.f("      PLOOP v[%d][p] = a.in_rows ? a.in_rows[(int64_t)%d * a.in_stride + src_[p]] : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
+          s.obs_off + d, ri.row + d);
+    o.f("      if (a.in_rows && a.store_inputs) {\n");
+    for (int d = 0; d < s.dim; ++d) o.f("        VecStore<PPT>::st(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
+    o.f("      }\n      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
+    return;
+  }
   const int mode = s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
@@ -727,13 +746,14 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     pl.key_decls = b;
   } else {   // stream keys and site numbers, as SiteStreamWalk (gjx_device.h) walks them
     int tag = 0, nkey = 0;
-    unsigned local = 0, plain = 0;
+    unsigned local = 0, plain = 0, jn = 0;
     std::string cur;
     for (int j = 0; j < prog->n_sites; ++j) {
       RollInfo ri; ri.row = prog->sites[j].slot; ri.score_row = j;
       pl.info.push_back(px.any ? px.info[j] : ri);
       const int sc = prog->sites[j].scan;
-      if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", (unsigned)(j + 1)}); continue; }
+      if (prog->sites[j].mode == GJX_MODE_INPUT) { pl.stream.push_back({"", 0u}); continue; }      // (takes no site number)
+      if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", ++jn}); continue; }
       if (sc == 0) { tag = 0; pl.stream.push_back({"", ++plain}); continue; }
       if (sc != tag) {
         const unsigned id = (unsigned)sc >> 20;
@@ -787,7 +807,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
         }
       }
       // JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J); instance key = split(plate key, n)[i]
-      if (!flat) body.f("    key2 pk_[PPT];\n    PLOOP pk_[p] = fold_in(fold_in64(a.key, gidx[p]), %du);\n", pl.info[j].plate_j0 + 1);
+      if (!flat) body.f("    key2 pk_[PPT];\n    PLOOP pk_[p] = fold_in(fold_in64(a.key, gidx[p]), %uu);\n", pl.stream[j].site_no);
       body.f("    _Pragma(\"nounroll\") for (int i_ = 0; i_ < %d; ++i_) {\n", pl.info[j].plate_n);
       if (!flat) body.f("    key2 ik_[PPT];\n    PLOOP ik_[p] = fold_in(pk_[p], (uint32_t)i_);\n");
       for (int l = 0; l < m; ++l) emit_site(body, pl, j + l);
@@ -798,7 +818,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
     }
   }
   Emit o;
-  o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
+  o.f("#include \"gjx_device.h\"\n#include \"gjx_tile.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
   o.f("#define NTAB %d\n#define NCOMP %d\n", prog->n_tab, pl.comp_floats);
   if (pl.tab_lds) o.f("#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n");
@@ -808,7 +828,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       "template <> struct VecStore<2> { static GJX_DEV void st(float* q, const float (&x)[2]) { *reinterpret_cast<float2*>(q) = make_float2(x[0], x[1]); } };\n"
       "template <> struct VecStore<4> { static GJX_DEV void st(float* q, const float (&x)[4]) { *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]); } };\n");
   o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
-      "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n");
+      "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
   // companions: one pass per entry, spread over the block
   for (auto& c : pl.comps) {
@@ -846,6 +866,11 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       "    uint64_t gidx[PPT];\n    PLOOP gidx[p] = (uint64_t)(a.offset + i0 + p);\n"
       "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n");
   o.f("    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
+  {
+    bool has_input = false;
+    for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
+    if (has_input) o.f("    int64_t src_[PPT];\n    PLOOP src_[p] = a.anc ? (int64_t)a.anc[i0 + p] : i0 + p;\n");
+  }
   // rows that already hold values (per-particle constraints, mask flags)
   std::vector<char> pre(prog->n_slots > 0 ? prog->n_slots : 1, 0);
   for (int j = 0; j < prog->n_sites; ++j) {
@@ -864,7 +889,17 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
       "    if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);\n"
       "    float m4 = tmax;\n    PLOOP m4 = fmaxf(m4, lw[p]);\n"
-      "    if (m4 > -INFINITY) { float s4 = tsum * fast_exp(tmax - m4); PLOOP s4 += fast_exp(lw[p] - m4); tsum = s4; }\n    tmax = m4;\n  }\n");
+      "    if (m4 > -INFINITY) { float s4 = tsum * fast_exp(tmax - m4); PLOOP s4 += fast_exp(lw[p] - m4); tsum = s4; }\n    tmax = m4;\n");
+  // {e_b, S_b} of this block-tile under GJX_WEIGHTS_TILE_SCALED (include/gjx.h) when it IS a quantisation tile (PPT == 4,
+  // K % 1024 == 0: the launcher checks): the resampling kernel that follows needs no pass of its own over the weights
+  o.f("    if (PPT == 4 && a.tile_S) {\n      const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
+      "      float m_ = lw[0];\n      PLOOP m_ = fmaxf(m_, lw[p]);\n      const float wm_ = wave_max(m_);\n"
+      "      __syncthreads();\n      if (lane == 0) red[8 + wid] = wm_;\n      __syncthreads();\n"
+      "      const int e_ = tile_exponent(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])));\n"
+      "      uint64_t q_ = 0;\n      PLOOP q_ += tile_q(lw[p], e_);\n      const uint64_t wq_ = wave_total_u64(q_);\n"
+      "      if (lane == 0) red_q[wid] = wq_;\n      __syncthreads();\n"
+      "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
+      "    }\n  }\n");
   o.f("  if (a.partials) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
       "    const float wm = wave_max(tmax);\n    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);\n"
       "    if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }\n    __syncthreads();\n"
@@ -1235,7 +1270,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
   char name[64];
-  snprintf(name, sizeof(name), "%016llx", (unsigned long long)(fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader))));
+  snprintf(name, sizeof(name), "%016llx", (unsigned long long)(fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader)) ^
+                                                               fnv1a(kScanHeader, strlen(kScanHeader)) ^ (fnv1a(kTileHeader, strlen(kTileHeader)) << 1)));
   const std::string dir = cache_dir(), path = dir + "/" + name + ".hsaco";
   if (!getenv("GJX_JIT_NO_DISK")) {
     if (FILE* f = fopen(path.c_str(), "rb")) {
@@ -1255,9 +1291,9 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   Rtc& r = rtc();
   if (!r.ok) { c.error = "hipRTC is not available (libhiprtc.so)"; return c; }
   hiprtcProgram p;
-  const char* hn[] = {"gjx_device.h", "../../include/gjx.h"};
-  const char* hs[] = {kDeviceHeader, kApiHeader};
-  if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : "gjx_gen.hip", 2, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
+  const char* hn[] = {"gjx_device.h", "../../include/gjx.h", "gjx_scan.h", "gjx_tile.h"};
+  const char* hs[] = {kDeviceHeader, kApiHeader, kScanHeader, kTileHeader};
+  if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : "gjx_gen.hip", 4, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
   const hiprtcResult rc = r.Compile(p, 3, opts);
   if (rc != HIPRTC_SUCCESS) {
@@ -1293,9 +1329,10 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
 // ---------------------------------------------------------------------------------------------------------
 namespace gjx {
 
-int gen_pick_ppt(const gjx_program* prog, int64_t K) {
+int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {
   const int slots = register_slots(prog);
   int ppt = slots <= 6 ? 4 : (slots <= 24 ? 2 : 1);
+  if (prefer4 && slots <= 40) ppt = 4;     // a block-tile of 1024 particles = one quantisation tile (tile totals, GJX_RUN_LEAVE_TILES)
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;
   while (ppt > 1 && K % ppt != 0) ppt >>= 1;

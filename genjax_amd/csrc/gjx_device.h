@@ -734,6 +734,14 @@ struct GenArgs {
   unsigned* ticket;
   float* lse;
   float log_k_total;
+  // GJX_MODE_INPUT sites (gjx_run_program_ex): in_rows[(obs_off + d) * in_stride + ancestor(i)], or their rows of choices
+  const float* in_rows;
+  int64_t in_stride;
+  const int32_t* anc;
+  int store_inputs;
+  // with lse == NULL: {S_b, e_b} of every 1024-particle tile of logw (tile-scaled fixed point) for gjx_resample_gather_tiled
+  unsigned long long* tile_S;
+  int32_t* tile_E;
 };
 
 // ---- arguments of a generated per-program HMC kernel (gjx_codegen.hip emits `extern "C" __global__ void gjx_hmc_gen(HmcGenArgs)`) ----

@@ -29,7 +29,7 @@ namespace gjx {
 unsigned long long* debug_timeline(size_t need);
 struct GenArgs;
 // per-program generated kernels (gjx_codegen.hip)
-int gen_pick_ppt(const gjx_program* prog, int64_t K);
+int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4 = false);
 int gen_available(const gjx_program* prog, int ppt);
 int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // per-program generated HMC kernels (gjx_codegen.hip)

@@ -43,6 +43,10 @@ struct RunArgs {
   float* lse;
   float log_k_total;
   int preload, n_tab;
+  const float* in_rows;          // GJX_MODE_INPUT sites: in_rows[(obs_off + d) * in_stride + ancestor(i)] (NULL: their rows of choices)
+  int64_t in_stride;
+  const int32_t* anc;
+  int store_inputs;
 };
 
 // LDSV: the particle's values are mirrored in LDS (vals[slot][lane], conflict-free) so that parameter
@@ -74,7 +78,22 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
   float score = 0.0f, weight = 0.0f;
   SiteStreamWalk walk(a.key);     // wave-uniform: chained step keys of Scan sites (gjx.h "Scan steps")
   BitStreamRT<RNG> rs;            // stream of the open scalar-normal run (gjx.h "Scalar-normal runs"): lives across sites
+  uint32_t jn = 0u;               // sites seen that are not GJX_MODE_INPUT (those take no site number)
   for (int j0 = 0; j0 < a.n_sites;) {
+    if (a.sites[j0].mode == GJX_MODE_INPUT) {
+      // the carry of a Scan step / an argument of the kernel: rows that are already there — or the rows of the ancestor the
+      // resampling step picked for this slot (the particle gather fused into the read side); no draw, no score
+      const gjx_site& s = a.sites[j0];
+      const int64_t src_i = a.anc ? (int64_t)a.anc[ii] : ii;
+      for (int d = 0; d < s.dim; ++d) {
+        const float v = a.in_rows ? a.in_rows[(int64_t)(s.obs_off + d) * a.in_stride + src_i] : ch[(int64_t)(s.slot + d) * K + ii];
+        if (LDSV) vals_s[(s.slot + d) * 256 + threadIdx.x] = v;
+        if (a.in_rows && active && (!LDSV || a.store_inputs)) ch[(int64_t)(s.slot + d) * K + i] = v;
+      }
+      if (a.site_scores && active) a.site_scores[(int64_t)j0 * K + i] = 0.0f;
+      ++j0;
+      continue;
+    }
     // a plate (gjx.h "Plates"; vmap.py:180-218): m consecutive body sites, n instances, ONE instance loop over the body;
     // any other site: m = n = 1
     int m = 1, ninst = 1;
@@ -88,7 +107,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
     bool opens_single = false, joins_single = false;
     for (int l = 0; l < m; ++l) {
       const gjx_site& sl = a.sites[j0 + l];
-      uint32_t no = RNG == GJX_RNG_FLAT ? walk.next(sl.scan) : (uint32_t)(j0 + l + 1);
+      uint32_t no = RNG == GJX_RNG_FLAT ? walk.next(sl.scan) : jn + (uint32_t)(l + 1);
       const bool draws_l = sl.mode == GJX_MODE_SAMPLE || sl.mode == GJX_MODE_OBS_MASK;
       const bool joins_l = plate == 0 && GJX_FLAT_JOINS(RNG, sl.kind, sl.dim, sl.mode);
       bool op = false;
@@ -96,7 +115,8 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       if (l == 0) { no0 = no; e0_single = e; opens_single = op; joins_single = joins_l; }
     }
     key2 plate_key{0u, 0u};       // JAX32: fold_in(particle key, J), J = 1-based index of the plate's first site
-    if (RNG == GJX_RNG_JAX32 && plate != 0) plate_key = fold_in(fold_in64(a.key, gidx), (uint32_t)(j0 + 1));
+    if (RNG == GJX_RNG_JAX32 && plate != 0) plate_key = fold_in(fold_in64(a.key, gidx), jn + 1u);
+    jn += (uint32_t)m;
     for (int inst = 0; inst < ninst; ++inst) {
     key2 inst_key{0u, 0u};
     if (RNG == GJX_RNG_JAX32 && plate != 0) inst_key = fold_in(plate_key, (uint32_t)inst);     // split(plate key, n)[inst] (vmap.py:186)
@@ -1164,7 +1184,7 @@ struct EnginePlan {
   GmmShape g;
 };
 
-static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores) {
+static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t particle_offset, bool want_site_scores, bool want_tiles = false) {
   EnginePlan e;
   e.engine = ENGINE_GENERIC; e.ppt = 1; e.grid = (int)((K + 255) / 256);
   const char* env = getenv("GJX_ENGINE");
@@ -1184,7 +1204,7 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
   };
   auto try_gen = [&]() {
     if (env_int("GJX_NO_CODEGEN", 0)) return false;
-    const int ppt = gen_pick_ppt(prog, K);
+    const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);
     if (gen_available(prog, ppt) != GJX_OK) return false;
     const int64_t tile = 256 * (int64_t)ppt, ntiles = (K + tile - 1) / tile;
     // the per-block prologue (table copy + derived constants) is paid once per block: no more blocks than can be resident
@@ -1209,17 +1229,10 @@ extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_
   return plan_engine(prog, K, particle_offset, false).grid;
 }
 
-// the grid the LAST gjx_run_program of this thread actually launched (= the number of {max, sumexp} block pairs it left in
-// its workspace): what a consumer of the pairs must use — a re-derived plan can differ (site scores, environment)
-static thread_local int g_last_run_grid = 0;
-extern "C" int gjx_last_run_partials(void) { return g_last_run_grid; }
-// byte offset, in the workspace of the LAST gjx_run_program of this thread, of the tile totals it left for
-// gjx_resample_gather_tiled — uint64 S[nt] then int32 E[nt], nt = K / 1024 — or 0 when it left none (the engine's blocks do
-// not cover whole quantisation tiles, K is not a multiple of 1024, lse was requested)
-static thread_local int64_t g_last_run_tiles = 0;
-extern "C" int64_t gjx_last_run_tiles(void) { return g_last_run_tiles; }
-// one-shot request (like gjx_profile_next_run): the NEXT gjx_run_program of this thread leaves the tile totals if it can.
-// Off by default: the per-tile block reduction costs the propagate kernel ~1 % and only gjx_resample_gather_tiled reads them.
+// ---- deprecated per-thread one-shot state: wrappers around gjx_run_program_ex's explicit options / record ----
+static thread_local gjx_run_info g_last_info = {0, 0, 0};
+extern "C" int gjx_last_run_partials(void) { return g_last_info.n_partials; }
+extern "C" int64_t gjx_last_run_tiles(void) { return g_last_info.tiles_offset; }
 static thread_local int g_want_tiles = 0;
 extern "C" int gjx_run_want_tiles(int32_t on) { g_want_tiles = on ? 1 : 0; return GJX_OK; }
 
@@ -1228,6 +1241,28 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
                                float* logw, const float* logw_in, const float* sub,
                                float* site_scores, float* lse, int64_t K_total, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  gjx_run_opts o;
+  memset(&o, 0, sizeof(o));
+  if (g_want_tiles) o.flags |= GJX_RUN_LEAVE_TILES;
+  g_want_tiles = 0;
+  if (t_prof_start && t_prof_stop) { o.flags |= GJX_RUN_TIME_DISPATCH; o.start_event = (void*)t_prof_start; o.stop_event = (void*)t_prof_stop; }
+  t_prof_start = t_prof_stop = nullptr;
+  return gjx_run_program_ex(prog, key0, key1, K, particle_offset, choices, score, weight, logw, logw_in, sub, site_scores, lse, K_total,
+                            workspace, workspace_bytes, stream, &o, &g_last_info);
+}
+
+extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
+                                  int64_t particle_offset, float* choices, float* score, float* weight,
+                                  float* logw, const float* logw_in, const float* sub,
+                                  float* site_scores, float* lse, int64_t K_total, void* workspace,
+                                  size_t workspace_bytes, void* stream, const gjx_run_opts* opts, gjx_run_info* info_out) {
+  gjx_run_opts no_opts;
+  memset(&no_opts, 0, sizeof(no_opts));
+  const gjx_run_opts& op = opts ? *opts : no_opts;
+  gjx_run_info info = {0, 0, 0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (op.flags & GJX_RUN_TIME_DISPATCH) { ev0 = (hipEvent_t)op.start_event; ev1 = (hipEvent_t)op.stop_event; }
+  if (info_out) *info_out = info;
   if (!prog || !prog->sites || !prog->sites_dev || !prog->tab_dev) return gjx_fail(GJX_EINVAL, "gjx_run_program: null program");
   if (K < 0 || prog->n_sites < 0) return gjx_fail(GJX_EINVAL, "gjx_run_program: negative size");
   if (K == 0) return GJX_OK;
@@ -1258,21 +1293,35 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     partials = (unsigned long long*)((char*)workspace + kWsHeaderBytes);
   }
   const float log_k_total = (float)log((double)K_total);
-  const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr);
-  g_last_run_grid = ep.grid;
-  g_last_run_tiles = 0;
-  const bool tiles_requested = g_want_tiles != 0;      // one-shot, whatever engine runs
-  g_want_tiles = 0;
+  bool has_input = false;
+  for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
+  if (op.in_rows && op.in_stride <= 0) return gjx_fail(GJX_EINVAL, "gjx_run_program_ex: in_rows needs in_stride");
+  const EnginePlan ep = plan_engine(prog, K, particle_offset, site_scores != nullptr, (op.flags & GJX_RUN_LEAVE_TILES) != 0 && !lse);
+  info.n_partials = ep.grid; info.engine = ep.engine; info.tiles_offset = 0;
+  const bool tiles_requested = (op.flags & GJX_RUN_LEAVE_TILES) != 0;
   const GmmShape& g = ep.g;
   const int ppt = ep.ppt, nblocks = ep.grid;
+  (void)has_input;
   if (ep.engine == ENGINE_GEN) {
     GenArgs ga;
     ga.tab = prog->tab_dev; ga.key = key2{key0, key1}; ga.K = K; ga.offset = particle_offset;
     ga.choices = choices; ga.score = score; ga.weight = weight; ga.logw = logw; ga.logw_in = logw_in; ga.sub = sub;
     ga.site_scores = site_scores; ga.partials = partials; ga.ticket = ticket; ga.lse = lse; ga.log_k_total = log_k_total;
-    hipEvent_t e0 = t_prof_start, e1 = t_prof_stop;
-    t_prof_start = t_prof_stop = nullptr;
-    return gen_launch(prog, ppt, ga, nblocks, st, e0, e1);
+    ga.in_rows = op.in_rows; ga.in_stride = op.in_stride; ga.anc = op.in_ancestors; ga.store_inputs = (op.flags & GJX_RUN_STORE_INPUTS) ? 1 : 0;
+    ga.tile_S = nullptr; ga.tile_E = nullptr;
+    if (tiles_requested && !lse && partials && K % 1024 == 0 && ppt == 4) {
+      // tile totals of the tile-scaled resampler behind the block pairs: every block of the generated kernel walks whole
+      // 1024-particle tiles only when 256 * ppt divides 1024 and its tile loop is tile-aligned (gjx_codegen.hip)
+      const size_t off = (kWsHeaderBytes + 8 * (size_t)((K + 255) / 256) + 15) & ~(size_t)15;
+      const size_t nt = (size_t)(K / 1024);
+      if (off + 12 * nt <= workspace_bytes) {
+        ga.tile_S = (unsigned long long*)((char*)workspace + off);
+        ga.tile_E = (int32_t*)(ga.tile_S + nt);
+        info.tiles_offset = (int64_t)off;
+      }
+    }
+    if (info_out) *info_out = info;
+    return gen_launch(prog, ppt, ga, nblocks, st, ev0, ev1);
   }
   if (ep.engine == ENGINE_GMM) {
     GmmArgs a;
@@ -1292,9 +1341,10 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
       if (off + 12 * nt <= workspace_bytes) {
         a.tile_S = (unsigned long long*)((char*)workspace + off);
         a.tile_E = (int32_t*)(a.tile_S + nt);
-        g_last_run_tiles = (int64_t)off;
+        info.tiles_offset = (int64_t)off;
       }
     }
+    t_prof_start = ev0; t_prof_stop = ev1;      // (consumed by the launch below: transient inside this call)
     const size_t lds = flat ? sizeof(float) * (size_t)gmm_aux_floats(g.C, g.D)
                             : sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
     launch_gmm(a, flat, g.D, ppt, nblocks, lds, st);
@@ -1308,6 +1358,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
     a.preload = 0;
     for (int j = 0; j < prog->n_sites; ++j) a.preload |= prog->sites[j].mode == GJX_MODE_OBS_SLOT || prog->sites[j].mode == GJX_MODE_OBS_MASK;
     a.n_tab = prog->n_tab;
+    a.in_rows = op.in_rows; a.in_stride = op.in_stride; a.anc = op.in_ancestors; a.store_inputs = (op.flags & GJX_RUN_STORE_INPUTS) ? 1 : 0;
     const size_t vbytes = sizeof(float) * 256 * (size_t)prog->n_slots;
     const bool ldsv = prog->n_slots > 0 && vbytes <= 48 * 1024 && !env_int("GJX_GENERIC_NO_LDS", 0);
     const size_t tbytes = sizeof(float) * (size_t)prog->n_tab;
@@ -1325,6 +1376,7 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
   }
   GJX_CHECK_LAUNCH("gjx_run_program");
   (void)nblocks;
+  if (info_out) *info_out = info;
   return GJX_OK;
 }
 

@@ -1,0 +1,69 @@
+// gjx_scanfilter.hip — bootstrap filter for ANY Scan kernel (gjx_scan_filter): the step recursion of Scan.generate
+// (combinators/scan.py:237-294: step t receives the carry of step t-1, weights add over steps) with systematic resampling in
+// front of every step.  Host code only: per step TWO plain launches, issued back to back from this loop —
+//   1. the tile-scaled systematic resampler's search (gjx_resample_gather_tiled with no rows to copy): log-weights of step
+//      t-1 -> ancestors; the block pairs and tile totals come from the producing kernel, so this launch reads 4 B per particle
+//      and writes 4 B; it also finishes the LSE record of step t-1;
+//   2. the step's generated propagate + reweight kernel (gjx_run_program_ex) whose GJX_MODE_INPUT sites read the carry through
+//      the ancestors — the particle gather is fused into the read side, the resampled collection is never materialised —
+//      and which leaves the {max, sumexp} block pairs and the tile totals of ITS log-weights for the next search.
+// The hand-written linear-Gaussian filters (gjx_ssm.hip, gjx_pfilter.inl) stay the fast path for that one model.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "gjx_device.h"
+#include "gjx_host.h"
+#include "gjx_pfilter_host.h"
+
+using namespace gjx;
+
+extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
+                               float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!steps || T < 1 || K <= 0 || !rows_a || !rows_b || !logw || !ancestors || !lse_steps)
+    return gjx_fail(GJX_EINVAL, "gjx_scan_filter: bad argument");
+  const size_t need_run = gjx_workspace_bytes(GJX_OP_RUN, K), need_res = gjx_workspace_bytes(GJX_OP_RESAMPLE, K);
+  if (!workspace || workspace_bytes < need_run + need_res) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter: workspace too small (OP_RUN + OP_RESAMPLE)");
+  char* ws_run = (char*)workspace;
+  char* ws_res = ws_run + need_run;
+  // key discipline of inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t); comb offset = uniform(k_res)
+  std::vector<uint32_t> keys;
+  std::vector<double> us;
+  pf_step_keys(key0, key1, T, keys, us);
+  auto input_rows = [](const gjx_program& p) {   // rows of the program's INPUT sites (they come first and in order)
+    int n = 0;
+    for (int j = 0; j < p.n_sites; ++j) if (p.sites[j].mode == GJX_MODE_INPUT) n += p.sites[j].dim;
+    return n;
+  };
+  gjx_run_opts o;
+  gjx_run_info info = {0, 0, 0}, prev = {0, 0, 0};
+  for (int t = 0; t < T; ++t) {
+    const gjx_program& pr = steps[t];
+    float* out = (t & 1) ? rows_b : rows_a;
+    const float* in = (t & 1) ? rows_a : rows_b;
+    memset(&o, 0, sizeof(o));
+    o.flags = GJX_RUN_LEAVE_TILES;
+    if (t > 0) {
+      if (input_rows(pr) > steps[t - 1].n_slots - input_rows(steps[t - 1]))
+        return gjx_fail(GJX_EINVAL, "gjx_scan_filter: a step reads more carry rows than the step before it produced");
+      const bool tiles = prev.tiles_offset != 0;
+      const uint64_t* tS = tiles ? (const uint64_t*)(ws_run + prev.tiles_offset) : nullptr;
+      const int32_t* tE = tiles ? (const int32_t*)(tS + (K / 1024)) : nullptr;
+      int32_t* anc_t = ancestors_all ? ancestors_all + (size_t)(t - 1) * (size_t)K : ancestors;
+      int rc = gjx_resample_gather_tiled(logw, K, tS, tE, 2, (const float*)(ws_run + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
+                                         anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
+      if (rc) return rc;
+      o.in_rows = in + (size_t)input_rows(steps[t - 1]) * (size_t)K;      // the rows the previous step's OWN sites wrote
+      o.in_stride = K;
+      o.in_ancestors = anc_t;
+    }
+    int rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, logw, nullptr, nullptr, nullptr, nullptr, K,
+                                ws_run, need_run, stream, &o, &info);
+    if (rc) return rc;
+    prev = info;
+  }
+  // the record of the last step: its block pairs are still in the run workspace
+  return gjx_launch_lse_finish(ws_run + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);
+}

@@ -207,7 +207,16 @@ class ParticleHistory:
 
 
 class BootstrapFilter:
-    """SMC with the prior as proposal and systematic resampling before every propagate step."""
+    """SMC with the prior as proposal and systematic resampling before every propagate step.
+    ``BootstrapFilter(LinearGaussianSSM(...), K)``: the hand-written kernels of BASELINE configs 3 / 4;
+    ``BootstrapFilter(kernel.scan(n=T), K)``: any Scan kernel (inference/scan_filter.py, gjx_scan_filter)."""
+
+    def __new__(cls, model, *args, **kwargs):
+        from ..gen import ScanCombinator
+        if isinstance(model, ScanCombinator):
+            from .scan_filter import ScanBootstrapFilter
+            return ScanBootstrapFilter(model, *args, **kwargs)
+        return super().__new__(cls)
 
     def __init__(self, ssm: LinearGaussianSSM, k_particles: int, rng_mode: int | None = None, rejuvenate: dict | None = None,
                  weights: str | None = None):

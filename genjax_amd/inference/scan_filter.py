@@ -1,0 +1,136 @@
+"""Bootstrap particle filter for ANY Scan kernel (SURVEY.md §8 R-2 beyond the one hand-coded linear-Gaussian model).
+
+The reference supplies the ingredients and no filter: ``Scan.generate`` runs a kernel ``(carry, x) ->
+(carry, out)`` T times, step t receiving the carry of step t-1, keys chained ``key_t = fold_in(key_{t-1}, t)``, weights added
+over steps (combinators/scan.py:237-294); ``Scan.edit_index`` / ``IndexRequest`` extend a trace by one step (scan.py:325-416).
+Here the unrolled trace of ``kernel.scan(n=T)`` is cut into T one-step programs — the sites of step t plus GJX_MODE_INPUT
+sites standing for the choices of step t-1 it reads — and the C loop ``gjx_scan_filter`` runs, per step, the tile-scaled
+systematic resampler's search and the step's generated propagate + reweight kernel, which reads its carry through the
+ancestors (include/gjx.h).  Periodic Scans give T-1 programs of one structure: one kernel is generated, only the tables
+(the step's observation) differ.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _abi as A
+from .. import config
+from .._lib import check, load
+from ..core import ChoiceMap, Key
+from ..gen import MissingAddress, ScanCombinator, _constraint_value, _value_rows
+from ..program import PackedProgram, Site, SiteList, fold_known
+
+
+def _step_of(site) -> int:
+    return (int(site.scan) & 0xFFFFF) - 1
+
+
+class ScanBootstrapFilter:
+    """``ScanBootstrapFilter(kernel.scan(n=T), k_particles).run(key, constraint, (carry0, xs))``: SMC with the prior as proposal
+    and systematic resampling in front of every step.  ``constraint`` holds the observations of every step (``C["y"].set(ys)``
+    with a leading step axis, or ``C[t, "y"]`` per step); the sites it names are the observed ones (the SAME sites in every
+    step), the others are propagated."""
+
+    def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None):
+        if not isinstance(scan, ScanCombinator):
+            raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T)")
+        self.scan, self.K = scan, int(k_particles)
+        self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
+        self._cache: dict = {}
+
+    # -- the T one-step programs -------------------------------------------------------------------------------
+    def step_programs(self, constraint: ChoiceMap, args) -> list[PackedProgram]:
+        sl, _ = self.scan.site_list(tuple(args))
+        steps: list[list[Site]] = []
+        for s in sl.sites:
+            t = _step_of(s)
+            if t < 0:
+                raise NotImplementedError("ScanBootstrapFilter: the model must be the Scan itself (no sites outside it)")
+            while len(steps) <= t:
+                steps.append([])
+            steps[t].append(s)
+        progs = []
+        prev_latent: list[Site] = []
+        known: dict = {}                      # observed sites of the previous step: address -> value
+        for t, cur in enumerate(steps):
+            step_sl = SiteList()
+            modes, obs = {}, {}
+            for ps in prev_latent:            # the carry: what this step may read of step t-1, in that step's slot order
+                w = ps.dim
+                step_sl.sites.append(Site(ps.addr, ps.kind, [], w, 0, step_sl.n_slots, 0))
+                step_sl.n_slots += w
+                modes[ps.addr] = A.MODE_INPUT
+            now_known, latent = {}, []
+            for s in cur:
+                rows = s.ncat if s.ncat else s.dim
+                ns = Site(s.addr, s.kind, [fold_known(p, known, rows) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
+                for p in ns.params:
+                    for a_ in ([a for a, _ in p.terms] if p.terms else ([p.src] if p.op != A.P_CONST else [])):
+                        if a_ not in step_sl:
+                            raise NotImplementedError(f"ScanBootstrapFilter: site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
+                step_sl.sites.append(ns)
+                step_sl.n_slots += s.dim
+                found, cval = _constraint_value(constraint, s.addr)
+                if found:
+                    sv, per = _value_rows(cval, s.dim)
+                    if per is not None:
+                        raise NotImplementedError("ScanBootstrapFilter: observations are shared by the particles")
+                    modes[s.addr] = A.MODE_OBS_TAB
+                    obs[s.addr] = now_known[s.addr] = np.broadcast_to(sv, (s.dim,)).astype(np.float32)
+                else:
+                    latent.append(s)
+            progs.append(PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False))
+            prev_latent, known = latent, now_known
+        return progs
+
+    def run(self, key: Key, constraint: ChoiceMap, args=(None, None), device=None, keep_ancestors: bool = False):
+        """-> dict(log_ml, increments f32[T], choices f32[n_slots][K] of the last step (its INPUT rows unused), logw,
+        programs, ancestors (the last resampling's, or int32[T-1][K] with keep_ancestors), degenerate)"""
+        from .. import kernels
+        dev = kernels._dev(device)
+        ck = (tuple(sorted((repr(a), np.asarray(kernels_np(v)).tobytes()) for a, v in constraint._d.items())), repr(args), str(dev))
+        if self._cache.get("key") != ck:
+            progs = self.step_programs(constraint, args)
+            cps = (A.GjxProgram * len(progs))()
+            for t, p in enumerate(progs):
+                cps[t] = p.c_program(dev)
+            self._cache = dict(key=ck, progs=progs, cps=cps)
+        progs, cps = self._cache["progs"], self._cache["cps"]
+        T, K = len(progs), self.K
+        n_rows = max(max(p.n_slots for p in progs), 1)
+        f32 = torch.float32
+        b = self._cache.get("bufs")
+        if b is None or b["rows_a"].shape != (n_rows, K):
+            need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
+            b = self._cache["bufs"] = dict(rows_a=torch.empty((n_rows, K), dtype=f32, device=dev), rows_b=torch.empty((n_rows, K), dtype=f32, device=dev),
+                                           logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
+                                           ws=torch.zeros(need, dtype=torch.uint8, device=dev))
+        lse = torch.empty((T, 4), dtype=f32, device=dev)
+        anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev) if keep_ancestors else None
+        check(load().gjx_scan_filter(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(b["rows_a"]), kernels._ptr(b["rows_b"]),
+                                     kernels._ptr(b["logw"]), kernels._ptr(b["anc"]), kernels._ptr(anc_all), kernels._ptr(lse),
+                                     kernels._ptr(b["ws"]), b["ws"].numel(), kernels._stream()), "gjx_scan_filter")
+        incs = lse[:, 3]
+        last = progs[-1]
+        ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
+        return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=ch, logw=b["logw"], programs=progs,
+                    ancestors=anc_all if keep_ancestors else b["anc"])
+
+    def latent(self, out: dict, name) -> torch.Tensor:
+        """rows of the last step's choice ``name``: f32[dim][K]"""
+        p = out["programs"][-1]
+        for s in p.site_list.sites:
+            if _name(s.addr) == name and p.modes.get(s.addr) != A.MODE_INPUT and p.slot_of[s.addr] >= 0:
+                return out["choices"][p.slot_of[s.addr]: p.slot_of[s.addr] + s.dim]
+        raise KeyError(name)
+
+
+def _name(addr):
+    return addr[0] if isinstance(addr, tuple) and len(addr) == 2 and isinstance(addr[1], (int, np.integer)) else addr
+
+
+def kernels_np(v):
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)

@@ -86,6 +86,7 @@ class DispatchTimer:
         check(load().gjx_event_create(C.byref(self.b)), "gjx_event_create")
 
     def arm(self) -> None:
+        """(deprecated form: per-thread one-shot; run_program(timer=...) passes the events explicitly)"""
         check(load().gjx_profile_next_run(self.a, self.b), "gjx_profile_next_run")
 
     def elapsed_us(self) -> float:
@@ -174,10 +175,12 @@ class RunPartials:
 
 def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None, logw_in=None, sub=None,
                 want_site_scores=False, want_lse=True, K_total=None, device=None, ws=None, out=None,
-                want_weight=True, want_tiles=False):
+                want_weight=True, want_tiles=False, in_rows=None, ancestors=None, store_inputs=False, timer=None):
     """gjx_run_program.  Returns dict(choices, score, weight, logw, lse[, site_scores]).  ``want_tiles`` (with
     ``want_lse=False``): ask the kernel to leave the tile totals of the tile-scaled resampler beside its block partials
-    (RunPartials.tiles; 0 when this engine / size cannot)."""
+    (RunPartials.tiles; 0 when this engine / size cannot).  ``in_rows`` f32[rows][stride] (+ ``ancestors`` int32[K]): the
+    program's INPUT sites read in_rows[obs_off + d][ancestors[i]] — the particle gather of a resampling step fused into this
+    propagate step (gjx_run_program_ex)."""
     dev = _dev(device)
     K = int(K)
     f32 = torch.float32
@@ -194,19 +197,25 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
     if ws is None:
         ws = workspace(A.OP_RUN, K, dev)
     cp = prog.c_program(dev)
-    if want_tiles:
-        load().gjx_run_want_tiles(1)
-    rc = load().gjx_run_program(C.byref(cp), key[0], key[1], K, int(offset), _ptr(ch), _ptr(score), _ptr(weight),
-                                _ptr(logw), _ptr(logw_in), _ptr(sub), _ptr(ss), _ptr(lse), int(K_total or K),
-                                _ptr(ws), ws.numel(), _stream())
-    check(rc, "gjx_run_program")
+    opts = A.GjxRunOpts()
+    opts.flags = (A.RUN_LEAVE_TILES if want_tiles else 0) | (A.RUN_STORE_INPUTS if store_inputs else 0)
+    if timer is not None:                     # DispatchTimer: HIP events attached to the propagate kernel's dispatch
+        opts.flags |= A.RUN_TIME_DISPATCH
+        opts.start_event, opts.stop_event = timer.a, timer.b
+    if in_rows is not None:
+        opts.in_rows, opts.in_stride = in_rows.data_ptr(), int(in_rows.stride(0))
+        opts.in_ancestors = None if ancestors is None else ancestors.data_ptr()
+    info = A.GjxRunInfo()
+    rc = load().gjx_run_program_ex(C.byref(cp), key[0], key[1], K, int(offset), _ptr(ch), _ptr(score), _ptr(weight),
+                                   _ptr(logw), _ptr(logw_in), _ptr(sub), _ptr(ss), _ptr(lse), int(K_total or K),
+                                   _ptr(ws), ws.numel(), _stream(), C.byref(opts), C.byref(info))
+    check(rc, "gjx_run_program_ex")
     # generation stamp of the workspace: with lse == None the kernel leaves per-block {max, sumexp} partials at ws + 256,
     # valid until the next run through the same workspace (RunPartials.valid)
     ws._gjx_gen = getattr(ws, "_gjx_gen", 0) + 1
-    res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws)
+    res = dict(choices=ch, score=score, weight=weight, logw=logw, lse=lse, _ws=ws, _engine=int(info.engine))
     if lse is None:
-        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset), int(load().gjx_last_run_partials()),
-                                       int(load().gjx_last_run_tiles()))
+        res["_partials"] = RunPartials(ws, ws._gjx_gen, prog, K, int(offset), int(info.n_partials), int(info.tiles_offset))
     if ss is not None:
         res["site_scores"] = ss
     return res

@@ -296,6 +296,40 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
     return out, dmodes, dobs, tuple(dsel), where
 
 
+def fold_known(p: Param, known: dict, rows: int) -> Param:
+    """a parameter with the sources whose values are KNOWN constants (observed sites of an earlier Scan step) folded in:
+    VALUE -> the constant slice, GATHER -> the row, AFFINE -> bias + M v; an affine form over several sites keeps its unknown
+    terms.  ``rows``: the reading site's event size."""
+    if p.op == A.P_CONST:
+        return p
+    if p.terms:
+        if not any(a_ in known for a_, _ in p.terms):
+            return p
+        bias = np.broadcast_to(p.values.astype(np.float64), (rows,)).copy() if p.values.size in (1, rows) else p.values.astype(np.float64).copy()
+        rest = []
+        for a_, m in p.terms:
+            if a_ in known:
+                bias = bias + m.astype(np.float64) @ np.asarray(known[a_], np.float64).ravel()[: m.shape[1]]
+            else:
+                rest.append((a_, m))
+        if not rest:
+            return Param.const(bias, xf=p.xf)
+        return Param(A.P_AFFINE, values=bias.astype(np.float32), src=rest[0][0], xf=p.xf, terms=rest)
+    if p.src not in known:
+        return p
+    v = np.asarray(known[p.src], np.float64).ravel()[p.src_elem:]
+    if p.op == A.P_VALUE:
+        return Param.const(v[: p.length], xf=p.xf)
+    if p.op == A.P_GATHER:
+        idx = int(np.clip(int(v[0]), 0, p.values.shape[0] - 1))
+        return Param.const(p.values[idx], xf=p.xf)
+    if p.op == A.P_AFFINE:
+        n = p.matrix.shape[1]
+        bias = np.broadcast_to(p.values, (rows,)) if p.values.size in (1, rows) else p.values
+        return Param.const(bias + p.matrix.astype(np.float64) @ v[:n], xf=p.xf)
+    raise ValueError(p.op)
+
+
 class _Unrollable(Exception):
     """a site outside the plates reads compacted instances in a form the device sites cannot express: pack without plates"""
 
@@ -532,6 +566,8 @@ class PackedProgram:
                 self.flag_slot_of[s.addr] = n_slots
                 n_slots += s.plate_n if s.plate else 1
         order = {s.addr: j for j, s in enumerate(sl.sites)}
+        self.input_row: dict = {}
+        self.n_input_rows = 0
         for j, s in enumerate(sl.sites):
             cs = self.c_sites[j]
             cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
@@ -540,6 +576,10 @@ class PackedProgram:
             cs.scan = int(s.scan)
             cs.plate, cs.plate_n = int(s.plate), int(s.plate_n)
             cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)
+            if cs.mode == A.MODE_INPUT:          # row of the site in the INPUT rows of gjx_run_program_ex (in_rows): inputs in site order
+                cs.obs_off = self.n_input_rows
+                self.input_row[s.addr] = self.n_input_rows
+                self.n_input_rows += s.dim
             if s.plate:
                 cs.d_obs = 1 if cs.mode == A.MODE_OBS_MASK else (s.dim if cs.mode == A.MODE_OBS_TAB else 0)
             rows = s.ncat if s.ncat else s.dim

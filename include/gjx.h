@@ -100,9 +100,15 @@ enum {
   GJX_MODE_SAMPLE = 0,   /* unconstrained: v ~ dist, score += logpdf(v), weight += 0           */
   GJX_MODE_OBS_TAB = 1,  /* constrained, same value for every particle: v = tab[obs_off + d]   */
   GJX_MODE_OBS_SLOT = 2, /* constrained per particle: v = choices[slot + d][i] (already there) */
-  GJX_MODE_OBS_MASK = 3  /* Mask(value, flag) per particle (distribution.py:129-143): flag = choices[obs_off][i];
+  GJX_MODE_OBS_MASK = 3, /* Mask(value, flag) per particle (distribution.py:129-143): flag = choices[obs_off][i];
                             flag != 0: as OBS_SLOT; flag == 0: as SAMPLE (the draw overwrites the slot).
                             Not accepted by dirichlet sites, gjx_hmc or gjx_score_grad. */
+  GJX_MODE_INPUT = 4     /* not a random choice: `dim` rows that hold a per-particle INPUT of the program — the carry a Scan step
+                            receives from the step before it (scan.py:237-294), the arguments of a kernel.  The value is read
+                            (from choices[slot + d][i], or through the ancestor gather of gjx_run_program_ex:
+                            in_rows[obs_off + d][ancestor(i)]), never drawn and never scored; the site takes NO site number in
+                            either stream layout (the sites behind it are numbered as if it were not there); kind and
+                            parameters are ignored.  Accepted by gjx_run_program[_ex] only. */
 };
 
 enum { GJX_SITE_HMC_SELECTED = 1 }; /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */
@@ -276,6 +282,37 @@ int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64
                     float* logw, const float* logw_in, const float* sub, float* site_scores,
                     float* lse, int64_t K_total, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* The same call with its options and its record as explicit arguments — no per-thread one-shot state (gjx_run_want_tiles,
+ * gjx_profile_next_run, gjx_last_run_partials, gjx_last_run_tiles are wrappers around this form and will go away).
+ *   opts (or NULL):
+ *     flags  GJX_RUN_LEAVE_TILES   with lse == NULL: leave the {S_b, e_b} of every 1024-particle tile of logw (tile-scaled
+ *                                  fixed point, below) behind the block pairs for gjx_resample_gather_tiled
+ *            GJX_RUN_TIME_DISPATCH attach start_event / stop_event (gjx_event_create) to the dispatch of the propagate kernel
+ *            GJX_RUN_STORE_INPUTS  with in_rows: also write the gathered inputs into their rows of choices[][]
+ *     in_rows / in_stride / in_ancestors   the program's GJX_MODE_INPUT sites read in_rows[(obs_off + d) * in_stride + a(i)],
+ *            a(i) = in_ancestors ? in_ancestors[i] : i — the particle gather of a resampling step (smc.py:90-91 applied to the
+ *            carry) fused into the read side of the next propagate step: the resampled collection is never materialised.
+ *   info_out (or NULL): n_partials = the block pairs left at workspace + 256 (the grid launched); tiles_offset = byte offset of
+ *            the tile totals in the workspace (uint64 S[nt] then int32 E[nt], nt = K / 1024), 0 when none were left;
+ *            engine = 0 interpreter, 1 hand-fused mixture kernel, 4 generated kernel. */
+enum { GJX_RUN_LEAVE_TILES = 1, GJX_RUN_TIME_DISPATCH = 2, GJX_RUN_STORE_INPUTS = 4 };
+typedef struct gjx_run_opts {
+  int32_t flags, pad_;
+  void* start_event;
+  void* stop_event;
+  const float* in_rows;
+  int64_t in_stride;
+  const int32_t* in_ancestors;
+} gjx_run_opts;
+typedef struct gjx_run_info {
+  int32_t n_partials, engine;
+  int64_t tiles_offset;
+} gjx_run_info;
+int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset, float* choices,
+                       float* score, float* weight, float* logw, const float* logw_in, const float* sub, float* site_scores,
+                       float* lse, int64_t K_total, void* workspace, size_t workspace_bytes, void* stream,
+                       const gjx_run_opts* opts, gjx_run_info* info_out);
 
 enum { GJX_OP_RUN = 1, GJX_OP_LSE = 2, GJX_OP_PICK = 3, GJX_OP_RESAMPLE = 4, GJX_OP_HMC = 5,
        GJX_OP_SSM = 6 };
@@ -580,6 +617,27 @@ int gjx_ssm_filter_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t 
  * in the reference (its SMC does not resample); the comb is that of gjx_resample_systematic. */
 int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N, int32_t* ancestors, uint64_t* cum,
                                uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- bootstrap filter for ANY Scan kernel (SURVEY.md §8 R-2 beyond the linear-Gaussian model).  The reference's
+ * ingredients: Scan.generate's step recursion (combinators/scan.py:237-294 — step t receives the carry of step t-1, weights
+ * add over steps) and the cookbook's resample-and-index idiom; there is no filter in the reference.
+ *   steps[T]: one program per step (host array).  steps[0] is step 0 (it reads no carry); the sites of steps[t], t >= 1, that
+ *   stand for the choices of step t-1 have mode GJX_MODE_INPUT, come FIRST, and their obs_off numbers the rows the OWN
+ *   (non-INPUT) sites of steps[t-1] wrote, in order.  Periodic Scans give T - 1 programs of one structure (one generated
+ *   kernel) that differ in their tables (the step's observation).  Keys: k_t = fold_in(k_{t-1}, t), (k_prop, k_res) =
+ *   split(k_t); step t runs under k_prop with its sites numbered from 1 (INPUT sites take no number); systematic
+ *   resampling (GJX_WEIGHTS_TILE_SCALED) with comb offset uniform(k_res) in front of every step t >= 1.
+ * Per step two plain launches: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the
+ * producing kernel) and the step's generated propagate + reweight kernel, which reads its carry THROUGH the ancestors
+ * (the particle gather of smc.py:90-91 fused into the read side).  No co-resident grid, nothing to time out, any K <= 2^26.
+ *   rows_a / rows_b f32[max_t n_slots][K]: choices of even / odd steps (the last step's end up in rows_[(T-1)&1]);
+ *   logw f32[K] the last step's incremental log-weights; ancestors int32[K] scratch / the last resampling's ancestors;
+ *   ancestors_all (or NULL) int32[T-1][K]: the ancestors of every resampling (trajectory reconstruction);
+ *   lse_steps f32[T][4]: log-ML estimate = sum_t lse_steps[t][3];
+ *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once. */
+int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
+                    float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* The same filter on a collection sharded over the ranks of a shard context, BASELINE config 4: every rank
  * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles

@@ -513,11 +513,13 @@ typedef struct {
   int32_t tag;
   uint32_t local, plain;
   uint32_t run_head, run_next; /* open scalar-normal run: head's site number, next element */
+  uint32_t jn;                 /* sites seen that are not GJX_MODE_INPUT (those take no site number) */
 } site_walk;
 
 /* -> site number of site s (FLAT numbering); *e0 = element of the stream at which the site's draws start */
 static uint32_t walk_next(site_walk* w, const gjx_program* prog, const gjx_site* s, int j, uint32_t* e0) {
-  uint32_t site_no = (uint32_t)(j + 1);
+  (void)j;
+  uint32_t site_no = ++w->jn;
   *e0 = 0u;
   if (prog->rng_mode != GJX_RNG_FLAT) return site_no;
   if (s->scan == 0) { if (w->tag != 0) w->run_head = 0u; w->skey = w->run_key; w->tag = 0; site_no = ++w->plain; }
@@ -673,10 +675,15 @@ static float run_site(const gjx_program* prog, const gjx_site* s0, int inst, con
 static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, float* vals, float* score_out,
                          float* weight_out, float* site_scores, int64_t ss_stride) {
   float score = 0.0f, weight = 0.0f;
-  site_walk w = {run_key, run_key, 0, 0u, 0u, 0u, 0u};
+  site_walk w = {run_key, run_key, 0, 0u, 0u, 0u, 0u, 0u};
   const int flat = prog->rng_mode == GJX_RNG_FLAT;
   for (int j = 0; j < prog->n_sites;) {
     const gjx_site* s = &prog->sites[j];
+    if (s->mode == GJX_MODE_INPUT) { /* the carry / arguments: rows that are already there; no draw, no score, no site number */
+      if (site_scores) site_scores[(int64_t)j * ss_stride] = 0.0f;
+      ++j;
+      continue;
+    }
     if (s->plate == 0) {
       uint32_t e0;
       const uint32_t site_no = walk_next(&w, prog, s, j, &e0);
@@ -700,7 +707,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
     /* JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J), J = 1-based index of the
      * plate's first site; instance key = split(plate key, n)[i] (vmap.py:186, 201) */
     okey pkey = run_key;
-    if (!flat) pkey = fold_in(fold_in64(run_key, idx), (uint32_t)(j + 1));
+    if (!flat) pkey = fold_in(fold_in64(run_key, idx), site_no[0]);
     for (int i = 0; i < n; ++i) {
       okey ikey = pkey;
       if (!flat) ikey = fold_in(pkey, (uint32_t)i);

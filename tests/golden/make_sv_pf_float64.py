@@ -1,0 +1,62 @@
+"""Generates tests/golden/sv_pf_float64.json: a stochastic-volatility model
+
+    x_0 ~ N(0, sigma),  x_t ~ N(phi x_{t-1}, sigma),  y_t ~ N(0, exp(x_t / 2)),      phi = 0.95, sigma = 0.3, T = 256
+
+its data (seed 7) and the log-marginal-likelihood estimates of an ideal (float64, NumPy) bootstrap particle filter with
+K = 2^18 particles and systematic resampling before every step, over 16 seeds.  There is no closed form for this model: the
+device filter for ANY Scan kernel (genjax_amd/inference/scan_filter.py, gjx_scan_filter) is checked against the MEAN and the
+SPREAD recorded here (tests/test_gpu_scan_filter.py).  No code or stream is shared with the device path.
+
+    python tests/golden/make_sv_pf_float64.py             (about 2 minutes on 8 cores)
+"""
+import json
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PHI, SIGMA, T = 0.95, 0.3, 256
+
+
+def data():
+    rs = np.random.default_rng(7)
+    x = np.zeros(T)
+    prev = 0.0
+    for t in range(T):
+        prev = PHI * prev + SIGMA * rs.standard_normal()
+        x[t] = prev
+    return (np.exp(x / 2) * rs.standard_normal(T)).astype(np.float32)
+
+
+def run(seed, K=1 << 18):
+    y = data().astype(np.float64)
+    rs = np.random.default_rng(2000 + seed)
+    x = np.zeros(K)
+    log_ml = 0.0
+    for t in range(T):
+        x = PHI * x + SIGMA * rs.standard_normal(K)
+        lw = -0.5 * np.log(2 * np.pi) - 0.5 * x - 0.5 * y[t] ** 2 * np.exp(-x)
+        m = lw.max()
+        w = np.exp(lw - m)
+        tot = w.sum()
+        log_ml += m + np.log(tot) - np.log(K)
+        cum = np.cumsum(w)
+        u = (np.arange(K) + rs.uniform()) * (tot / K)
+        x = x[np.minimum(np.searchsorted(cum, u, side="right"), K - 1)]
+    return log_ml
+
+
+def main():
+    with mp.Pool(8) as pool:
+        est = pool.map(run, range(16))
+    out = dict(config="stochastic volatility phi=0.95 sigma=0.3 T=256, data seed 7; bootstrap PF K=2^18, systematic resampling before every step",
+               filter="NumPy float64, seeds 2000..2015", phi=PHI, sigma=SIGMA, y=[float(v) for v in data()], log_ml=est,
+               log_ml_mean=float(np.mean(est)), log_ml_std=float(np.std(est, ddof=1)))
+    with open(os.path.join(HERE, "sv_pf_float64.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print({k: v for k, v in out.items() if k != "y"})
+
+
+if __name__ == "__main__":
+    main()

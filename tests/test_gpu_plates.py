@@ -184,7 +184,9 @@ def test_plate_with_per_instance_masks_tables_and_affine_rows(rng):
     yobs = rs.standard_normal(n).astype(np.float32)
     mvals = rs.standard_normal((K, n)).astype(np.float32)
     flags = rs.uniform(size=(K, n)) < 0.5
-    chm = C["k", "y"].set(yobs) | C["k", "m"].set(Mask(mvals, flags))
+    chm = C["k", "y"].set(yobs)
+    for i in range(n):                       # Mask(value, flag) per instance AND particle (distribution.py:129-143)
+        chm = chm | C["k", i, "m"].set(Mask(mvals[:, i], flags[:, i]))
     tr, w = model.importance(genjax.key(9), chm, (), K=K)
     prog = tr.prog
     assert prog.n_sites == 5 and sum(1 for j in range(5) if prog.c_sites[j].plate) == 3
