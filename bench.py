@@ -236,20 +236,23 @@ def run_gmm(args, rank, world, dev):
     def step(i, timed):
         key = (0, 1 + i)
         j = sample_at.get(i) if timed else None
+        tmr = None
         if j is not None:
             if j % 2 == 0:
-                timers[j].arm()
+                tmr = timers[j]             # events attached to the kernel's dispatch (gjx_run_program_ex, GJX_RUN_TIME_DISPATCH)
+                if fused_step:
+                    tmr.arm()
             else:
                 ev[j][0].record()
         if peer is not None:
             par = peer_calls[0] & 1
             peer_calls[0] += 1
-            kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=peer_out[par], want_weight=False, want_lse=False)
+            kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=peer_out[par], want_weight=False, want_lse=False, timer=tmr)
             if j is not None and j % 2 == 1:
                 ev[j][1].record()
         elif not fused_step:
             kernels.run_program(prog, key, K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False,
-                                want_lse=sharded)
+                                want_lse=sharded, timer=tmr)
             if j is not None and j % 2 == 1:
                 ev[j][1].record()
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
@@ -358,9 +361,8 @@ def run_gmm(args, rank, world, dev):
     if not fused_step:
         tm = [kernels.DispatchTimer() for _ in range(8)]
         for i in range(64):
-            if i % 8 == 4:
-                tm[i // 8].arm()
-            kernels.run_program(prog, (0, 1 + i), K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False, want_lse=False)
+            kernels.run_program(prog, (0, 1 + i), K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False, want_lse=False,
+                                timer=tm[i // 8] if i % 8 == 4 else None)
         torch.cuda.synchronize()
         us = sorted(t.elapsed_us() for t in tm)[len(tm) // 2]
         for t in tm:
@@ -372,9 +374,8 @@ def run_gmm(args, rank, world, dev):
         # with dispatch events outside the timed region, alternating with the other two kernels of the three-launch step
         tm = [kernels.DispatchTimer() for _ in range(8)]
         for i in range(40):
-            if i % 5 == 0:
-                tm[i // 5].arm()
-            kernels.run_program(prog, (0, 1 + i), K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False, want_lse=False)
+            kernels.run_program(prog, (0, 1 + i), K, offset=off, K_total=K_total, ws=ws, out=out, want_weight=False, want_lse=False,
+                                timer=tm[i // 5] if i % 5 == 0 else None)
             kernels.resample_indices(out["logw"], 0.5, K_total, partials=(ws, n_part), lse_out=lse_rec, K_total=K_total, anc=anc, ws=ws2)
             kernels.gather_rows(out["choices"], anc, rows)
         torch.cuda.synchronize()
@@ -695,9 +696,7 @@ def run_codegen(dev):
             out = kernels.run_program(prog, (0, 1), K, ws=ws, want_weight=False)
             tm = [kernels.DispatchTimer() for _ in range(5)]
             for i, t in enumerate(tm):
-                if eng != 0:
-                    t.arm()
-                kernels.run_program(prog, (0, 2 + i), K, ws=ws, out=out, want_weight=False)
+                kernels.run_program(prog, (0, 2 + i), K, ws=ws, out=out, want_weight=False, timer=t if eng != 0 else None)
             torch.cuda.synchronize()
             us = sorted(t.elapsed_us() for t in tm)[2] if eng != 0 else None
             for t in tm:
@@ -943,6 +942,132 @@ def run_round3(dev):
     return res
 
 
+def _kalman_log_lik(A_, y, q, r, q0):
+    """float64 Kalman log-likelihood of x_0 ~ N(0, q0^2 I), x_t ~ N(A x_{t-1}, q^2 I), y_t ~ N(x_t, r^2 I)"""
+    A_ = np.asarray(A_, np.float64)
+    y = np.asarray(y, np.float64)
+    dx = A_.shape[0]
+    m, P, ll = np.zeros(dx), q0 * q0 * np.eye(dx), 0.0
+    for t in range(y.shape[0]):
+        if t > 0:
+            m, P = A_ @ m, A_ @ P @ A_.T + q * q * np.eye(dx)
+        S = P + r * r * np.eye(dx)
+        v = y[t] - m
+        Si = np.linalg.inv(S)
+        ll += -0.5 * (v @ Si @ v + np.linalg.slogdet(S)[1] + dx * math.log(2 * math.pi))
+        Kg = P @ Si
+        m, P = m + Kg @ v, (np.eye(dx) - Kg) @ P
+    return float(ll)
+
+
+def run_round4(dev):
+    """Round-4 paths, short runs: (1) the bootstrap filter for ANY Scan kernel (gjx_scan_filter: two plain launches per step,
+    ancestor gather fused into the generated propagate kernel) on config 3's model written as @gen + .scan, next to the
+    hand-written one-launch filter, and on a stochastic-volatility model; (2) a vmapped mixture (N = 4096 data: two plate-tagged
+    device sites, one instance loop) on its generated kernel and on the site interpreter."""
+    import genjax_amd as genjax
+    from genjax_amd import C as CM
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels, workloads
+    from genjax_amd.inference import BootstrapFilter, LinearGaussianSSM
+    res = {}
+    s = workloads.ssm_problem()
+    T, K, q, r = 256, 1 << 18, float(s["q"]), float(s["r"])
+    Am = np.asarray(s["A"], np.float32)
+    dx = Am.shape[0]
+
+    @genjax.gen
+    def lg_step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(dx, q, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(dx, r, np.float32)) @ "y"
+        return x, None
+
+    def time_filter(bf, chm, args, n=5):
+        for i in range(2):
+            bf.run(genjax.key(i), chm, args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            out = bf.run(genjax.key(10 + i), chm, args)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, float(out["log_ml"])
+
+    bf = BootstrapFilter(lg_step.scan(n=T), K)
+    dt, lml = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None))
+    hand = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], q0=q), K, weights="tile_scaled")
+    ys_d = torch.as_tensor(s["y"], device=dev)
+    for i in range(3):
+        hand.run(genjax.key(i), ys_d, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(5):
+        hand.run(genjax.key(10 + i), ys_d, device=dev)
+    torch.cuda.synchronize()
+    dth = (time.perf_counter() - t0) / 5
+    exact = _kalman_log_lik(s["A"], s["y"], q, r, q)          # float64 closed form (x_0 ~ N(0, q^2 I): the Scan's step 0)
+    res["scan_filter_lgssm_d8_T256_K2e18"] = dict(us_per_step=dt / T * 1e6, particle_steps_per_sec=K * T / dt, log_ml=lml,
+                                                  log_ml_rel_err=abs(lml - exact) / abs(exact), launches_per_step=2,
+                                                  hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
+                                                  algorithmic_bytes_per_particle_step=8 * dx + 24,
+                                                  achieved_GBs=(8 * dx + 24) * K / (dt / T) / 1e9, frac_of_hbm=(8 * dx + 24) * K / (dt / T) / 1e9 / HBM_PEAK_GBS,
+                                                  engine="gjx_gen (generated, INPUT rows through the ancestors) + k_resample_gather_tiled<rows = 0>")
+    with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
+        fx = json.load(f)
+    phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
+
+    @genjax.gen
+    def sv_step(x_prev, _):
+        x = genjax.normal(phi * x_prev, sigma) @ "x"
+        genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+        return x, None
+
+    bsv = BootstrapFilter(sv_step.scan(n=len(ysv)), K)
+    dts, lsv = time_filter(bsv, CM["y"].set(ysv), (0.0, None))
+    res["scan_filter_stochastic_volatility_T256_K2e18"] = dict(us_per_step=dts / len(ysv) * 1e6, log_ml=lsv, float64_filter_mean=fx["log_ml_mean"],
+                                                               float64_filter_std=fx["log_ml_std"], z=(lsv - fx["log_ml_mean"]) / fx["log_ml_std"])
+    # (2) the vmapped mixture
+    N, Kp = 4096, 1 << 17
+    rs = np.random.default_rng(0)
+    mu = np.array([-2.0, 0.5, 3.0], np.float32)
+    yv = (mu[rs.integers(0, 3, N)] + 0.7 * rs.standard_normal(N)).astype(np.float32)
+
+    @genjax.gen
+    def mk(lg):
+        z = genjax.categorical(logits=lg) @ "z"
+        return genjax.normal(genjax.take(mu, z), 0.7) @ "x"
+
+    @genjax.gen
+    def mix():
+        mk.repeat(n=N)(np.array([0.2, -0.3, 0.1], np.float32)) @ "k"
+
+    prog, _, _ = mix.pack((), CM["k", "x"].set(yv), True)
+    row = dict(device_sites=prog.n_sites, logical_sites=len(prog.site_list.sites), K=Kp, N=N)
+    for engine in ("gen", "interp"):
+        old = os.environ.get("GJX_ENGINE")
+        os.environ["GJX_ENGINE"] = engine
+        try:
+            ws = kernels.workspace(A.OP_RUN, Kp, dev)
+            o = kernels.run_program(prog, (0, 1), Kp, ws=ws, want_weight=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                kernels.run_program(prog, (0, 2 + i), Kp, ws=ws, out=o, want_weight=False)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 5 * 1e3
+            row[engine] = dict(engine=o["_engine"], kernel_us=us, particle_instances_per_sec=Kp * N / (us * 1e-6), bytes=4.0 * N * Kp,
+                               achieved_GBs=4.0 * N * Kp / (us * 1e-6) / 1e9)
+        finally:
+            if old is None:
+                os.environ.pop("GJX_ENGINE", None)
+            else:
+                os.environ["GJX_ENGINE"] = old
+    row["generated_vs_interpreter"] = row["interp"]["kernel_us"] / row["gen"]["kernel_us"]
+    res["vmapped_mixture_plate"] = row
+    return res
+
+
 def _config4_worker(rank, world, port, K_total, T, dx, out_dir, verify):
     """one rank of the config-4 dry run (processes sharing ONE device): the sharded filter over peer-mapped windows"""
     import hashlib
@@ -1153,6 +1278,10 @@ def main():
             extra["hmc_generated"] = run_hmc_generated(dev)
         except Exception as e:
             extra["hmc_generated"] = dict(error=repr(e))
+        try:
+            extra["round4"] = run_round4(dev)
+        except Exception as e:
+            extra["round4"] = dict(error=repr(e))
         try:
             extra["config4_dry_run"] = run_config4_dry_run(dev)
         except Exception as e:
