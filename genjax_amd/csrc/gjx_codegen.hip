@@ -133,6 +133,8 @@ std::string src_val(const gjx_param& q, const RollInfo& ri, int k, const std::st
 struct Plan {
   const gjx_program* prog;
   int ppt;
+  bool mfma = false;                // flavour: big affine sites on the matrix cores (static LDS, PPT = 1, K % 256 == 0)
+  int mfma_floats = 0;              // floats of the transpose patches (4 waves x 64 particles x inner length)
   bool tab_lds;
   std::vector<SiteStream> stream;   // per emitted site
   std::vector<RollInfo> info;       // per emitted site
@@ -515,6 +517,92 @@ void emit_gather_index(Emit& o, const gjx_site& s, int site, int np, const RollI
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Big affine sites on the matrix cores.  An observed site with more than kMaxExpandDim elements whose first parameter is an
+// AFFINE form over n = 16, 32, 48 or 64 values (the N rows of a regression likelihood: logits = X beta) is a [dim x n] x
+// [n x particles] contraction: emitted on v_mfma_f32_16x16x4_f32 with the particles of a wave as 4 column groups of 16.
+// The reference gets any model's contraction fused by XLA (inference/requests/hmc.py:70-96, smc.py:298-315 under jit).
+//   layout (as the hand-written k_hmc_logreg_mfma2, gjx_hmc.hip): lane l = (c = l & 15, q = l >> 4); for group g the B operand
+//   of step s is coefficient (n/4) q + s of particle 16 g + c — fetched once per site from a per-wave LDS patch into which
+//   every lane wrote its particle's n values; the A operand of step s is X[n0 + c][(n/4) q + s], one b128 LDS read per four
+//   steps, SHARED by the four groups; the result tile (C layout) is logits[n0 + 4 q + r][particle 16 g + c], r = 0..3.
+//   The elementwise log-density is then taken in that layout and the four lanes of a column add up their partial sums.
+// ---------------------------------------------------------------------------------------------------------
+bool mfma_site_ok(const gjx_site& s, const RollInfo& ri) {
+  if (s.mode != GJX_MODE_OBS_TAB || s.dim <= kMaxExpandDim || s.dim < 64 || is_categorical(s.kind) || s.kind == GJX_DIRICHLET) return false;
+  if (ri.plate || ri.d_obs || ri.d_row || ri.mem_slot[0] >= 0) return false;
+  const gjx_param& q = s.p[0];
+  if (q.op != GJX_P_AFFINE || q.xf != GJX_XF_NONE || q.n < 16 || q.n > 64 || (q.n & 15) || (q.moff & 3) || ri.d_off[0] || ri.d_moff[0]) return false;
+  if (q.len != 1 && q.len != s.dim) return false;
+  for (int k = 1; k < n_params(s.kind); ++k) if (s.p[k].op != GJX_P_CONST || ri.d_off[k]) return false;
+  return true;
+}
+
+bool has_mfma_site(const gjx_program* p) {
+  if (getenv("GJX_GEN_NO_MFMA") || p->n_tab > 30000) return false;      // table + patches in static LDS (<= 150 KB)
+  for (int j = 0; j < p->n_sites; ++j) { RollInfo ri; if (p->sites[j].plate == 0 && mfma_site_ok(p->sites[j], ri)) return true; }
+  return false;
+}
+
+void emit_mfma_site(Emit& o, Plan& pl, int j) {
+  const gjx_site& s = pl.prog->sites[j];
+  const RollInfo& ri = pl.info[j];
+  const gjx_param& q = s.p[0];
+  const int n = q.n, M = n / 4, dim = s.dim, np = n_params(s.kind);
+  if (64 * 4 * n > pl.mfma_floats) pl.mfma_floats = 64 * 4 * n;
+  o.f("    { // ---- site %d: kind %d, %d rows x %d coefficients on the matrix cores (v_mfma_f32_16x16x4_f32)\n", j, s.kind, dim, n);
+  o.f("      float lp[PPT];\n      const int lane_ = threadIdx.x & 63, c_ = lane_ & 15, q_ = lane_ >> 4;\n"
+      "      float* tb_ = mfma_s + (threadIdx.x >> 6) * %d;\n", 64 * n);
+  // (1) lane = particle -> C layout, through this wave's LDS patch (LDS operations of one wave execute in order; the asm is
+  //     the compiler-level fence between the writes and the reads of OTHER lanes' values)
+  for (int e4 = 0; e4 < n / 4; ++e4)
+    o.f("      *(v4f_*)(tb_ + lane_ * %d + %d) = v4f_{v[%d][0], v[%d][0], v[%d][0], v[%d][0]};\n", n, 4 * e4, q.slot + 4 * e4, q.slot + 4 * e4 + 1,
+        q.slot + 4 * e4 + 2, q.slot + 4 * e4 + 3);
+  o.f("      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      float bg_[4][%d];\n", M);
+  o.f("      _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) _Pragma(\"unroll\") for (int s4_ = 0; s4_ < %d; ++s4_) {\n"
+      "        const v4f_ t_ = *(const v4f_*)(tb_ + (16 * g_ + c_) * %d + %d * q_ + 4 * s4_);\n"
+      "        bg_[g_][4 * s4_] = t_[0]; bg_[g_][4 * s4_ + 1] = t_[1]; bg_[g_][4 * s4_ + 2] = t_[2]; bg_[g_][4 * s4_ + 3] = t_[3];\n      }\n",
+      M / 4, n, M);
+  o.f("      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      float part_[4] = {0.0f, 0.0f, 0.0f, 0.0f};\n");
+  std::string pc[4] = {"0.0f", "0.0f", "0.0f", "0.0f"};
+  for (int k = 1; k < np; ++k) {
+    const gjx_param& qk = s.p[k];
+    pc[k] = xf_wrap(qk.xf, "TAB(" + std::to_string(qk.off) + (qk.len == 1 ? "" : " + row_ % " + std::to_string(qk.len)) + ")");
+  }
+  const bool y128 = (s.obs_off & 3) == 0 && (dim & 15) == 0;
+  const bool b128 = q.len == dim && (q.off & 3) == 0 && (dim & 15) == 0;
+  o.f("      for (int n0_ = 0; n0_ < %d; n0_ += 16) {\n", (dim + 15) & ~15);
+  o.f("        const int ra_ = n0_ + c_ < %d ? n0_ + c_ : %d;\n        float xa_[%d];\n", dim, dim - 1, M);
+  o.f("        _Pragma(\"unroll\") for (int s4_ = 0; s4_ < %d; ++s4_) {\n          const v4f_ t_ = *(const v4f_*)&TAB(%d + ra_ * %d + %d * q_ + 4 * s4_);\n"
+      "          xa_[4 * s4_] = t_[0]; xa_[4 * s4_ + 1] = t_[1]; xa_[4 * s4_ + 2] = t_[2]; xa_[4 * s4_ + 3] = t_[3];\n        }\n", M / 4, q.moff, n, M);
+  if (q.len == 1) o.f("        const float b0_ = TAB(%d);\n        const v4f_ bias_ = {b0_, b0_, b0_, b0_};\n", q.off);
+  else if (b128) o.f("        const v4f_ bias_ = *(const v4f_*)&TAB(%d + n0_ + 4 * q_);\n", q.off);
+  else o.f("        v4f_ bias_;\n        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = n0_ + 4 * q_ + r_; bias_[r_] = TAB(%d + (row_ < %d ? row_ : %d)); }\n",
+           q.off, dim, dim - 1);
+  if (y128) o.f("        const v4f_ y_ = *(const v4f_*)&TAB(%d + n0_ + 4 * q_);\n", s.obs_off);
+  else o.f("        v4f_ y_;\n        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = n0_ + 4 * q_ + r_; y_[r_] = TAB(%d + (row_ < %d ? row_ : %d)); }\n",
+           s.obs_off, dim, dim - 1);
+  o.f("        v4f_ acc_[4] = {bias_, bias_, bias_, bias_};\n        __builtin_amdgcn_sched_barrier(0);\n");
+  o.f("        _Pragma(\"unroll\") for (int s_ = 0; s_ < %d; ++s_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_)\n"
+      "          acc_[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_[s_], bg_[g_][s_], acc_[g_], 0, 0, 0);\n        __builtin_amdgcn_sched_barrier(0);\n", M);
+  o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n          const int row_ = n0_ + 4 * q_ + r_; (void)row_;\n");
+  o.f("          const float pb_ = %s, pc_ = %s, pd_ = %s;\n", pc[1].c_str(), pc[2].c_str(), pc[3].c_str());
+  o.f("          _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n            const float a_ = acc_[g_][r_];\n");
+  if (s.kind == GJX_BERNOULLI_LOGITS)   // y a - softplus(a): the same value as TFP's -softplus(-a) y - softplus(a) (1 - y) for any y
+    o.f("            const float e_ = fmaf(y_[r_], a_, -(fmaxf(a_, 0.0f) + kLn2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * fabsf(a_)))));\n");
+  else
+    o.f("            const float e_ = elem_logpdf(%d, y_[r_], a_, pb_, pc_, pd_);\n", s.kind);
+  if (dim & 15) o.f("            part_[g_] += row_ < %d ? e_ : 0.0f;\n", dim);
+  else o.f("            part_[g_] += e_;\n");
+  o.f("          }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n");
+  // (3) the four lanes of a column hold partial sums of ONE particle; lane q == g keeps group g's total (it IS that particle's lane)
+  o.f("      float tot_ = 0.0f;\n      _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n        float t_ = part_[g_];\n"
+      "        t_ += __shfl_xor(t_, 16, 64);\n        t_ += __shfl_xor(t_, 32, 64);\n        if (q_ == g_) tot_ = t_;\n      }\n      lp[0] = tot_;\n");
+  o.f("      PLOOP { score[p] += lp[p]; weight[p] += lp[p]; }\n");
+  o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n", ri.score_row);
+  o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
+}
+
 void emit_site(Emit& o, Plan& pl, int j) {
   const gjx_program* prog = pl.prog;
   const gjx_site& s = prog->sites[j];
@@ -532,6 +620,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
     o.f("      }\n      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
     return;
   }
+  if (pl.mfma && mfma_site_ok(s, ri)) { emit_mfma_site(o, pl, j); return; }
   const int mode = s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
@@ -716,7 +805,9 @@ void emit_site(Emit& o, Plan& pl, int j) {
 
 bool want_roll() { const char* e = getenv("GJX_GEN_ROLL"); return e && atoi(e) != 0; }
 
-std::string generate(const gjx_program* prog_in, int ppt) {
+std::string generate(const gjx_program* prog_in, int ppt_code) {
+  const int ppt = ppt_code & 255;
+  const bool mfma = (ppt_code >> 8) != 0 && ppt == 1;
   // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
   Roll roll;
   const PlateXf px = plate_program(prog_in);
@@ -728,7 +819,8 @@ std::string generate(const gjx_program* prog_in, int ppt) {
   Plan pl;
   pl.prog = prog;
   pl.ppt = ppt;
-  pl.tab_lds = prog->n_tab <= kMaxLdsTab;
+  pl.mfma = mfma;
+  pl.tab_lds = mfma || prog->n_tab <= kMaxLdsTab;
   if (roll.ok) {
     pl.info = roll.info;
     unsigned plain = 0;
@@ -827,6 +919,12 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       "template <> struct VecStore<1> { static GJX_DEV void st(float* q, const float (&x)[1]) { *q = x[0]; } };\n"
       "template <> struct VecStore<2> { static GJX_DEV void st(float* q, const float (&x)[2]) { *reinterpret_cast<float2*>(q) = make_float2(x[0], x[1]); } };\n"
       "template <> struct VecStore<4> { static GJX_DEV void st(float* q, const float (&x)[4]) { *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]); } };\n");
+  o.f("typedef float v4f_ __attribute__((ext_vector_type(4)));\n");
+  if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
+    o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
+        "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n  __shared__ __attribute__((aligned(16))) float mfma_s[%d];\n"
+        "  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4, pl.mfma_floats > 0 ? pl.mfma_floats : 4);
+  else
   o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
@@ -908,7 +1006,7 @@ std::string generate(const gjx_program* prog_in, int ppt) {
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
       "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
-  o.f("// LDS_FLOATS %d\n", (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
+  o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
   return o.s;
 }
 
@@ -1333,6 +1431,8 @@ int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {
   const int slots = register_slots(prog);
   int ppt = slots <= 6 ? 4 : (slots <= 24 ? 2 : 1);
   if (prefer4 && slots <= 40) ppt = 4;     // a block-tile of 1024 particles = one quantisation tile (tile totals, GJX_RUN_LEAVE_TILES)
+  // a big affine site goes to the matrix cores: one particle per lane, whole waves (code = ppt | 256: see generate())
+  if (K % 256 == 0 && !getenv("GJX_GEN_PPT") && has_mfma_site(prog)) return 1 | 256;
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;
   while (ppt > 1 && K % ppt != 0) ppt >>= 1;
@@ -1449,7 +1549,7 @@ extern "C" int gjx_program_hmc_precompile(const gjx_program* prog) {
 extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   if (!supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the emitter's coverage");
-  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = gjx::gen_pick_ppt(prog, 4);
+  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256)) ppt = gjx::gen_pick_ppt(prog, 4);
   const std::string src = generate(prog, ppt);
   if (out && cap > 0) {
     const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
@@ -1463,6 +1563,6 @@ extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char
 // cache with this on machines without a GPU (hipRTC cross-compiles)
 extern "C" int gjx_program_precompile(const gjx_program* prog, int32_t ppt) {
   if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: null program");
-  if (ppt != 1 && ppt != 2 && ppt != 4) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2 or 4");
+  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256)) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4 or 257 (1 | 256: big affine sites on the matrix cores)");
   return gjx::gen_available(prog, ppt);
 }

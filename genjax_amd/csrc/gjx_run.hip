@@ -1204,9 +1204,9 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
   };
   auto try_gen = [&]() {
     if (env_int("GJX_NO_CODEGEN", 0)) return false;
-    const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);
+    const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);     // (ppt | 256: the matrix-core flavour, gjx_codegen.hip)
     if (gen_available(prog, ppt) != GJX_OK) return false;
-    const int64_t tile = 256 * (int64_t)ppt, ntiles = (K + tile - 1) / tile;
+    const int64_t tile = 256 * (int64_t)(ppt & 255), ntiles = (K + tile - 1) / tile;
     // the per-block prologue (table copy + derived constants) is paid once per block: no more blocks than can be resident
     // at 4 per CU, each looping over its tiles
     static const int resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * (cus > 0 ? cus : 256); }();

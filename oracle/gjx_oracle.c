@@ -29,8 +29,9 @@
  * and every closed-form / tolerance check the reference's own tests hold for the path
  * (tests/inference/test_smc.py:32-87, test_requests.py:94-255, test_static_gen_fn.py:208-731, README.md:89-123).
  *
- * Plain C, float32 arithmetic exactly where the reference is float32; reductions that the
- * reference leaves to XLA (logsumexp) are accumulated in double and rounded once.
+ * Plain C.  Samplers, parameter expressions and the per-particle sums run in float32 like the reference; the closed-form
+ * log-densities (elem_logpdf*) and the reductions the reference leaves to XLA (logsumexp) are evaluated in double and
+ * rounded once.
  */
 #include <math.h>
 #include <stdint.h>
@@ -310,85 +311,95 @@ static float normal_interval_mass(float lo, float hi) {
 static int params_of(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : 2); }
 
 /* parameter order follows the reference's constructor arguments (tfp wrappers, tensorflow_probability/__init__.py) */
-static float elem_logpdf4(int kind, float x, float a, float b, float c, float d) {
+/* The closed-form log-densities are evaluated in DOUBLE from the float32 inputs and rounded once: the oracle is the
+ * correctly rounded value of TFP's formula at these inputs.  (A float32 evaluation has rounding of its own — a gamma log-pdf at
+ * concentration 1e6 is a difference of terms of 1e7 and moves in steps of 0.25 — which would make the checker wrong in its own
+ * way where the device is wrong in another; and the conditioning probe of the differential tests, which perturbs the inputs by
+ * a few ulps, can only see ill-conditioning in a function that is not piecewise constant.) */
+static inline double xlogy_d(double x, double y) { return x == 0.0 ? 0.0 : x * log(y); }
+static inline double xlog1py_d(double x, double y) { return x == 0.0 ? 0.0 : x * log1p(y); }
+static inline double softplus_d(double x) { return (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x))); }
+
+static float elem_logpdf4(int kind, float xf, float af, float bf, float cf, float df) {
+  const double x = xf, a = af, b = bf, c = cf, d = df;
   switch (kind) {
     case GJX_STUDENT_T: { /* tfd.StudentT(df=a, loc=b, scale=c) */
-      float y = (x - b) / c;
-      return -0.5f * (a + 1.0f) * log1pf(y * y / a) - logf(c) - 0.5f * logf(a) - 0.5f * LOG_PI +
-             lgammaf(0.5f * (a + 1.0f)) - lgammaf(0.5f * a);
+      double y = (x - b) / c;
+      return (float)(-0.5 * (a + 1.0) * log1p(y * y / a) - log(c) - 0.5 * log(a) - 0.5 * (double)LOG_PI + lgamma(0.5 * (a + 1.0)) - lgamma(0.5 * a));
     }
     case GJX_TRUNCATED_NORMAL: { /* tfd.TruncatedNormal(loc=a, scale=b, low=c, high=d) */
       if (x < c || x > d) return -INFINITY;
-      float z = (x - a) / b;
-      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - logf(normal_interval_mass((c - a) / b, (d - a) / b));
+      double z = (x - a) / b;
+      return (float)(-0.5 * z * z - ((double)HALF_LOG_2PI + log(b)) - log((double)normal_interval_mass((float)((c - a) / b), (float)((d - a) / b))));
     }
     case GJX_POISSON: /* tfd.Poisson(rate=a) */
-      return (x < 0.0f || x != floorf(x)) ? -INFINITY : (xlogyf(x, a) - a - lgammaf(x + 1.0f));
+      return (x < 0.0 || x != floor(x)) ? -INFINITY : (float)(xlogy_d(x, a) - a - lgamma(x + 1.0));
     case GJX_GEOMETRIC: /* tfd.Geometric(probs=a): number of failures before the first success */
-      return (x < 0.0f || x != floorf(x)) ? -INFINITY : (xlog1pyf(x, -a) + logf(a));
+      return (x < 0.0 || x != floor(x)) ? -INFINITY : (float)(xlog1py_d(x, -a) + log(a));
     case GJX_GUMBEL: {
-      float z = (x - a) / b;
-      return -(z + expf(-z)) - logf(b);
+      double z = (x - a) / b;
+      return (float)(-(z + exp(-z)) - log(b));
     }
     case GJX_HALF_CAUCHY: {
-      float z = (x - a) / b;
-      return x < a ? -INFINITY : (logf(2.0f / 3.14159265f) - logf(b) - log1pf(z * z));
+      double z = (x - a) / b;
+      return x < a ? -INFINITY : (float)(log(2.0 / 3.14159265358979323846) - log(b) - log1p(z * z));
     }
     case GJX_INVERSE_GAMMA: /* concentration a, scale b */
-      return x <= 0.0f ? -INFINITY : (a * logf(b) - lgammaf(a) - (a + 1.0f) * logf(x) - b / x);
+      return x <= 0.0 ? -INFINITY : (float)(a * log(b) - lgamma(a) - (a + 1.0) * log(x) - b / x);
     case GJX_WEIBULL: { /* concentration a, scale b */
-      if (x < 0.0f) return -INFINITY;
-      float lr = logf(x / b);
-      return logf(a / b) + xlogyf(a - 1.0f, x / b) - expf(a * lr);
+      if (x < 0.0) return -INFINITY;
+      double lr = log(x / b);
+      return (float)(log(a / b) + xlogy_d(a - 1.0, x / b) - exp(a * lr));
     }
     case GJX_LOGIT_NORMAL: {
-      if (!(x > 0.0f && x < 1.0f)) return -INFINITY;
-      float lx = logf(x), l1 = log1pf(-x);
-      float z = ((lx - l1) - a) / b;
-      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - lx - l1;
+      if (!(x > 0.0 && x < 1.0)) return -INFINITY;
+      double lx = log(x), l1 = log1p(-x);
+      double z = ((lx - l1) - a) / b;
+      return (float)(-0.5 * z * z - ((double)HALF_LOG_2PI + log(b)) - lx - l1);
     }
     case GJX_CHI2: { /* df a: gamma(a/2, rate 1/2) */
-      float h = 0.5f * a;
-      return x <= 0.0f ? -INFINITY : (xlogyf(h - 1.0f, x) - 0.5f * x - h * logf(2.0f) - lgammaf(h));
+      double h = 0.5 * a;
+      return x <= 0.0 ? -INFINITY : (float)(xlogy_d(h - 1.0, x) - 0.5 * x - h * log(2.0) - lgamma(h));
     }
     default: return NAN;
   }
 }
 
-static float elem_logpdf(int kind, float x, float a, float b) {
+static float elem_logpdf(int kind, float xf, float af, float bf) {
+  const double x = xf, a = af, b = bf;
   switch (kind) {
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: { /* tfd.Normal._log_prob */
-      float z = x / b - a / b;
-      return -0.5f * z * z - (HALF_LOG_2PI + logf(b));
+      double z = x / b - a / b;
+      return (float)(-0.5 * z * z - ((double)HALF_LOG_2PI + log(b)));
     }
     case GJX_FLIP: /* tfd.Bernoulli(probs): multiply_no_nan(log p, x) + multiply_no_nan(log1p(-p), 1-x) */
-      return (x != 0.0f ? logf(a) : 0.0f) + (x != 1.0f ? (1.0f - x) * log1pf(-a) : 0.0f);
+      return (float)((x != 0.0 ? log(a) : 0.0) + (x != 1.0 ? (1.0 - x) * log1p(-a) : 0.0));
     case GJX_BERNOULLI_LOGITS: /* -softplus(-l)*x - softplus(l)*(1-x) */
-      return (x != 0.0f ? -softplusf(-a) * x : 0.0f) + (x != 1.0f ? -softplusf(a) * (1.0f - x) : 0.0f);
+      return (float)((x != 0.0 ? -softplus_d(-a) * x : 0.0) + (x != 1.0 ? -softplus_d(a) * (1.0 - x) : 0.0));
     case GJX_BETA: /* xlogy(a-1,x) + xlog1py(b-1,-x) - lbeta(a,b) */
-      return xlogyf(a - 1.0f, x) + xlog1pyf(b - 1.0f, -x) - (lgammaf(a) + lgammaf(b) - lgammaf(a + b));
+      return (float)(xlogy_d(a - 1.0, x) + xlog1py_d(b - 1.0, -x) - (lgamma(a) + lgamma(b) - lgamma(a + b)));
     case GJX_UNIFORM:
-      return (x < a || x > b) ? -INFINITY : -logf(b - a);
+      return (x < a || x > b) ? -INFINITY : (float)(-log(b - a));
     case GJX_EXPONENTIAL: /* a = rate */
-      return x < 0.0f ? -INFINITY : logf(a) - a * x;
+      return x < 0.0 ? -INFINITY : (float)(log(a) - a * x);
     case GJX_HALF_NORMAL: { /* a = scale */
-      float z = x / a;
-      return x < 0.0f ? -INFINITY : (0.5f * logf(2.0f / 3.14159265f) - logf(a) - 0.5f * z * z);
+      double z = x / a;
+      return x < 0.0 ? -INFINITY : (float)(0.5 * log(2.0 / 3.14159265358979323846) - log(a) - 0.5 * z * z);
     }
     case GJX_LAPLACE:
-      return -fabsf(x - a) / b - logf(2.0f * b);
+      return (float)(-fabs(x - a) / b - log(2.0 * b));
     case GJX_LOG_NORMAL: {
-      float lx = logf(x);
-      float z = lx / b - a / b;
-      return -0.5f * z * z - (HALF_LOG_2PI + logf(b)) - lx;
+      double lx = log(x);
+      double z = lx / b - a / b;
+      return (float)(-0.5 * z * z - ((double)HALF_LOG_2PI + log(b)) - lx);
     }
     case GJX_CAUCHY: {
-      float z = (x - a) / b;
-      return -(LOG_PI + logf(b)) - log1pf(z * z);
+      double z = (x - a) / b;
+      return (float)(-((double)LOG_PI + log(b)) - log1p(z * z));
     }
     case GJX_GAMMA: /* a = concentration, b = rate */
-      return xlogyf(a, b) + xlogyf(a - 1.0f, x) - b * x - lgammaf(a);
+      return (float)(xlogy_d(a, b) + xlogy_d(a - 1.0, x) - b * x - lgamma(a));
     default: return NAN;
   }
 }

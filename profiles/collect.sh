@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile collection on the GPU box (run through gpurun): bench JSON lines, rocprofv3 kernel stats, PMC passes.
 # usage: bash profiles/collect.sh r03 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
-TAG=${1:-r03}; shift; WL=${@:-gmm ssm hmc}
+TAG=${1:-r04}; shift; WL=${@:-gmm ssm hmc}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 for w in $WL; do

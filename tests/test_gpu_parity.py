@@ -1155,13 +1155,15 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
         with np.errstate(invalid="ignore"):
             fin &= ~denorm & (np.abs(s_b - s_a) <= 5e-4 + 5e-4 * np.abs(s_a))
             if loose:
-                # campaign mode also keeps to moderate draws: a value of 15 behind an exp() transform is a parameter of 3e6, and
-                # a log-density built from terms of 1e7 is piecewise constant in float32 (steps of 0.25: the perturbation test
-                # above does not see it)
+                # campaign mode keeps away from draws so small that a log() of them loses the value's own float32 rounding.
+                # (A cap |v| < 8 used to sit here as well: the oracle's float32 log-densities were piecewise constant at
+                # parameters of 1e6 and hid their own ill-conditioning from the probe above.  The oracle now evaluates the closed
+                # forms in double, the probe sees every ill-conditioned particle, and the device takes lgamma DIFFERENCES from
+                # their asymptotic series: the cap is gone.)
                 cs = np.concatenate([np.arange(prog_c.slot_of[s_.addr], prog_c.slot_of[s_.addr] + s_.dim) for s_ in cont_sites]) if cont_sites else np.zeros(0, int)
                 if cs.size:
                     v_ = np.abs(o["choices"][cs])
-                    fin &= (v_ < 8.0).all(axis=0) & ((v_ > 1e-4) | (v_ == 0)).all(axis=0)
+                    fin &= ((v_ > 1e-4) | (v_ == 0)).all(axis=0)
         assert fin.mean() > (0.05 if loose else 0.3), f"trial {trial}: {fin.mean():.2f} of the particles are well conditioned"
         ok = _close_cols(g["choices"], o["choices"], rt=1e-3, at=5e-4) & _close_cols(g["score"][None], o["score"][None], rt=2e-3, at=2e-3)
         miss = ~ok & fin

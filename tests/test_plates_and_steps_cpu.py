@@ -1,0 +1,196 @@
+"""CPU checks (no GPU, no compute call into the product library) of round 4's program constructs: plate-tagged sites
+(include/gjx.h "Plates"; reference combinators/vmap.py:180-218), GJX_MODE_INPUT sites and the one-step programs of the
+bootstrap filter for any Scan kernel (scan.py:237-294), the matrix-core flavour of the generated kernels.  The ORACLE runs the
+packed programs (it is the checker); the product side is exercised as far as it goes without a device: tracing, packing, the
+emitted HIP source and its hipRTC cross-compilation for gfx950."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import genjax_amd as genjax
+from genjax_amd import C
+from genjax_amd import _abi as A
+
+
+def _mixture(N):
+    rs = np.random.default_rng(0)
+    mu = np.array([-2.0, 0.5, 3.0], np.float32)
+    ys = (mu[rs.integers(0, 3, N)] + 0.7 * rs.standard_normal(N)).astype(np.float32)
+    logits = np.array([0.2, -0.3, 0.1], np.float32)
+
+    @genjax.gen
+    def kernel(lg):
+        z = genjax.categorical(logits=lg) @ "z"
+        return genjax.normal(genjax.take(mu, z), 0.7) @ "x"
+
+    @genjax.gen
+    def model():
+        kernel.repeat(n=N)(logits) @ "k"
+
+    return model, C["k", "x"].set(ys), ys, mu, logits
+
+
+def test_abi7_structs():
+    assert ctypes.sizeof(A.GjxParam) == 48 and ctypes.sizeof(A.GjxSite) == 240
+    assert A.GjxSite.plate.offset == 32 and A.GjxSite.p.offset == 48 and A.GjxParam.d_off.offset == 28
+    assert ctypes.sizeof(A.GjxRunOpts) == 48 and ctypes.sizeof(A.GjxRunInfo) == 16
+    hdr = open(__file__.rsplit("/tests/", 1)[0] + "/include/gjx.h").read()
+    assert "#define GJX_ABI_VERSION 7" in hdr and "GJX_MODE_INPUT = 4" in hdr and "GJX_STATUS_VERIFY_MISMATCH = 4" in hdr
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_vmapped_mixture_lowers_to_two_plate_sites_and_the_oracle_scores_it(rng):
+    from oracle import cpu
+    N, K = 600, 400                                  # 1200 logical sites: more than the 1023 site numbers of the FLAT layout
+    model, chm, ys, mu, logits = _mixture(N)
+    prog, _, _ = model.pack((), chm, True, rng_mode=rng)
+    assert prog.n_sites == 2 and prog.n_slots == N and len(prog.site_list.sites) == 2 * N
+    z_site, x_site = prog.c_sites[0], prog.c_sites[1]
+    assert (z_site.plate, z_site.plate_n, z_site.dim, z_site.slot) == (1, N, 1, 0)
+    assert (x_site.plate, x_site.plate_n, x_site.mode, x_site.d_obs, x_site.slot) == (1, N, A.MODE_OBS_TAB, 1, -1)
+    assert (x_site.p[0].op, x_site.p[0].slot, x_site.p[0].d_slot, x_site.p[0].d_off) == (A.P_GATHER, 0, 1, 0)
+    assert prog.slot_of[(("k", "z"), 17)] == 17 and prog.obs_off[(("k", "x"), 17)] == prog.obs_off[("@plate", ("k", "x"))] + 17
+    o = cpu.run_program(prog, (0, 5), K, want_site_scores=True)
+    z = o["choices"][:N].astype(int)
+    p = np.exp(logits - logits.max())
+    p /= p.sum()
+    lz = np.log(p)[z].sum(axis=0)
+    lx = (-0.5 * ((ys[:, None] - mu[z]) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(o["weight"], lx, rtol=2e-5, atol=5e-3)
+    np.testing.assert_allclose(o["score"], lx + lz, rtol=2e-5, atol=5e-3)
+    np.testing.assert_allclose(o["site_scores"][0], lz, rtol=2e-5, atol=5e-3)       # one row per BODY site: the sum over its instances
+    assert np.abs(np.bincount(z.ravel(), minlength=3) / z.size - p).max() < 5e-3
+
+
+def test_plate_assess_equals_the_unrolled_program():
+    """no randomness: a trace's score on the plate lowering == on the unrolled one (per-instance tables, observations, masks,
+    an affine row per instance over two latent sites outside the plate)"""
+    from oracle import cpu
+    from genjax_amd.core import Mask
+    n, P, K = 24, 3, 300
+    rs = np.random.default_rng(5)
+    X = rs.standard_normal((n, P)).astype(np.float32)
+    tabs = rs.standard_normal((n, 2)).astype(np.float32)
+
+    @genjax.gen
+    def kernel(x_row, tab, beta, b0):
+        c = genjax.flip(0.4) @ "c"
+        genjax.normal(genjax.take(tab, c), 1.0) @ "m"
+        return genjax.normal(x_row @ beta + b0, 0.8) @ "y"
+
+    @genjax.gen
+    def model():
+        beta = genjax.normal(np.zeros(P, np.float32), 1.0) @ "beta"
+        b0 = genjax.normal(0.0, 2.0) @ "b0"
+        kernel.vmap(in_axes=(0, 0, None, None))(X, tabs, beta, b0) @ "k"
+
+    chm = C["k", "y"].set(rs.standard_normal(n).astype(np.float32))
+    prog_p, _, _ = model.pack((), chm, True)
+    prog_u, _, _ = model.pack((), chm, True, plates=False)
+    assert prog_p.n_sites == 5 and prog_u.n_sites == 2 + 3 * n and [prog_p.c_sites[j].plate for j in range(5)] == [0, 0, 1, 1, 1]
+    y_site = prog_p.c_sites[4]
+    assert (y_site.p[0].op, y_site.p[0].d_moff, y_site.p[0].d_slot, y_site.p[0].n) == (A.P_AFFINE, P + 1, 0, P + 1)   # [beta, b0] span, a row per instance
+    drawn = cpu.run_program(prog_p, (0, 9), K)
+    # the same values on the unrolled program, every latent constrained per particle
+    lat = [s.addr for s in prog_u.site_list.sites if prog_u.slot_of[s.addr] >= 0]
+    prog_a, _, _ = model.pack((), chm, False, per_particle=tuple(lat), plates=False)
+    ch = np.zeros((prog_a.n_slots, K), np.float32)
+    for a_ in lat:
+        d = prog_a.site_list[a_].dim
+        ch[prog_a.slot_of[a_]:prog_a.slot_of[a_] + d] = drawn["choices"][prog_p.slot_of[a_]:prog_p.slot_of[a_] + d]
+    again = cpu.run_program(prog_a, (0, 0), K, choices=ch)
+    np.testing.assert_allclose(again["score"], drawn["score"], rtol=3e-6, atol=2e-4)
+
+
+def test_reads_of_plate_instances_from_outside_and_from_a_later_plate_pack():
+    """`zs = k.vmap()(xs); y ~ normal(zs[3], 1)` and `ws = k2.vmap()(zs)` crashed at pack time with plates on"""
+    from oracle import cpu
+    n = 16
+    xs = np.linspace(-1.0, 1.0, n).astype(np.float32)
+
+    @genjax.gen
+    def k1(x):
+        return genjax.normal(x, 1.0) @ "z"
+
+    @genjax.gen
+    def k2(z):
+        c = genjax.categorical(logits=np.array([0.0, 0.5], np.float32)) @ "c"
+        return genjax.normal(z, genjax.take(np.array([0.5, 1.5], np.float32), c)) @ "w"
+
+    @genjax.gen
+    def model():
+        zs = k1.vmap()(xs) @ "zs"
+        k2.vmap()(zs) @ "ws"
+        return genjax.normal(zs[3], 1.0) @ "y"
+
+    for rng in (A.RNG_FLAT, A.RNG_JAX32):
+        prog, _, _ = model.pack((), C.n(), True, rng_mode=rng)
+        assert prog.n_sites == 4
+        o = cpu.run_program(prog, (0, 4), 4000)
+        ch = o["choices"]
+        z, w = ch[prog.slot_of[(("zs", "z"), 5)]], ch[prog.slot_of[(("ws", "w"), 5)]]
+        assert abs(np.corrcoef(z, w)[0, 1]) > 0.5                                   # w_5 ~ N(z_5, .) reads instance 5 of the first plate
+        assert abs(np.corrcoef(ch[prog.slot_of[(("zs", "z"), 3)]], ch[prog.slot_of["y"]])[0, 1] - 2 ** -0.5) < 0.05
+
+
+def test_generated_sources_compile_for_gfx950():
+    """hipRTC cross-compiles without a GPU: the plate loop, the INPUT / ancestor-gather read side with tile totals, and the
+    matrix-core flavour of a big affine site"""
+    from genjax_amd import kernels, workloads
+    from genjax_amd.inference.scan_filter import ScanBootstrapFilter
+    model, chm, *_ = _mixture(64)
+    for rng in (A.RNG_FLAT, A.RNG_JAX32):
+        prog, _, _ = model.pack((), chm, True, rng_mode=rng)
+        src = kernels.program_source(prog, 2)
+        assert "for (int i_ = 0; i_ < 64; ++i_)" in src and ("ik_[p]" in src) == (rng == A.RNG_JAX32)
+        kernels.program_precompile(prog, 2)
+    s = workloads.ssm_problem(dx=4, T=3)
+    Am = np.asarray(s["A"], np.float32)
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(4, 0.5, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(4, 2.0, np.float32)) @ "y"
+        return x, None
+
+    progs = ScanBootstrapFilter(step.scan(n=3), 1024).step_programs(C["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(4, np.float32), None))
+    assert [p.n_input_rows for p in progs] == [0, 4, 4] and progs[1].c_sites[0].mode == A.MODE_INPUT
+    assert bytes(progs[1].c_sites)[:3 * 240] == bytes(progs[2].c_sites)[:3 * 240]      # periodic steps: ONE generated kernel
+    src = kernels.program_source(progs[1], 4)
+    assert "a.in_rows ? a.in_rows[" in src and "a.tile_S[tix]" in src
+    kernels.program_precompile(progs[1], 4)
+    lr, _ = workloads.logreg_importance_program()
+    src = kernels.program_source(lr, 257)
+    assert "__builtin_amdgcn_mfma_f32_16x16x4f32" in src and "mfma_s" in src
+    kernels.program_precompile(lr, 257)
+
+
+def test_scan_step_program_on_the_oracle():
+    """the oracle treats INPUT sites as rows that are already there (no draw, no score, no site number): x_t - A x_in has the
+    transition's spread, the weight is the observation's log-density"""
+    from genjax_amd import workloads
+    from genjax_amd.inference.scan_filter import ScanBootstrapFilter
+    from oracle import cpu
+    s = workloads.ssm_problem(dx=8, T=3)
+    Am, q, r = np.asarray(s["A"], np.float32), float(s["q"]), float(s["r"])
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(8, q, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(8, r, np.float32)) @ "y"
+        return x, None
+
+    ys = np.asarray(s["y"], np.float32)
+    progs = ScanBootstrapFilter(step.scan(n=3), 64).step_programs(C["y"].set(ys), (np.zeros(8, np.float32), None))
+    K = 20000
+    ch = np.random.default_rng(0).standard_normal((progs[1].n_slots, K)).astype(np.float32)
+    o = cpu.run_program(progs[1], (1, 2), K, choices=ch, want_site_scores=True)
+    x_in, x = ch[:8], o["choices"][8:16]
+    np.testing.assert_array_equal(o["choices"][:8], x_in)
+    assert abs(np.std(x - Am @ x_in) - q) < 0.01 and (o["site_scores"][0] == 0).all()
+    lw = (-0.5 * ((ys[1][:, None] - x) / r) ** 2 - np.log(r) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(o["weight"], lw, rtol=2e-5, atol=2e-4)
+    # the same draws as a program WITHOUT the input site would make at site number 1 (INPUT sites take no number)
+    o0 = cpu.run_program(progs[0], (1, 2), K)
+    np.testing.assert_allclose(o0["choices"][:8], x - Am @ x_in, rtol=0, atol=2e-6)
