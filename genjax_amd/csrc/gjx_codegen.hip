@@ -549,21 +549,20 @@ void emit_mfma_site(Emit& o, Plan& pl, int j) {
   const RollInfo& ri = pl.info[j];
   const gjx_param& q = s.p[0];
   const int n = q.n, M = n / 4, dim = s.dim, np = n_params(s.kind);
-  if (64 * 4 * n > pl.mfma_floats) pl.mfma_floats = 64 * 4 * n;
   o.f("    { // ---- site %d: kind %d, %d rows x %d coefficients on the matrix cores (v_mfma_f32_16x16x4_f32)\n", j, s.kind, dim, n);
-  o.f("      float lp[PPT];\n      const int lane_ = threadIdx.x & 63, c_ = lane_ & 15, q_ = lane_ >> 4;\n"
-      "      float* tb_ = mfma_s + (threadIdx.x >> 6) * %d;\n", 64 * n);
-  // (1) lane = particle -> C layout, through this wave's LDS patch (LDS operations of one wave execute in order; the asm is
-  //     the compiler-level fence between the writes and the reads of OTHER lanes' values)
-  for (int e4 = 0; e4 < n / 4; ++e4)
-    o.f("      *(v4f_*)(tb_ + lane_ * %d + %d) = v4f_{v[%d][0], v[%d][0], v[%d][0], v[%d][0]};\n", n, 4 * e4, q.slot + 4 * e4, q.slot + 4 * e4 + 1,
-        q.slot + 4 * e4 + 2, q.slot + 4 * e4 + 3);
-  o.f("      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      float bg_[4][%d];\n", M);
-  o.f("      _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) _Pragma(\"unroll\") for (int s4_ = 0; s4_ < %d; ++s4_) {\n"
-      "        const v4f_ t_ = *(const v4f_*)(tb_ + (16 * g_ + c_) * %d + %d * q_ + 4 * s4_);\n"
-      "        bg_[g_][4 * s4_] = t_[0]; bg_[g_][4 * s4_ + 1] = t_[1]; bg_[g_][4 * s4_ + 2] = t_[2]; bg_[g_][4 * s4_ + 3] = t_[3];\n      }\n",
-      M / 4, n, M);
-  o.f("      asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n      float part_[4] = {0.0f, 0.0f, 0.0f, 0.0f};\n");
+  o.f("      float lp[PPT];\n      const int lane_ = threadIdx.x & 63, c_ = lane_ & 15, q_ = lane_ >> 4;\n");
+  // (1) lane = particle -> C layout: group g, step s needs coefficient M q + s of particle 16 g + c, i.e. register (M q + s) of lane
+  //     16 g + c — one cross-lane read (ds_bpermute: no LDS allocation, the table needs the space) per candidate q, the lane keeps
+  //     its own q's.  Once per particle and site: 4 n reads against dim / 16 tiles of 4 n / 4 matrix instructions each.
+  o.f("      float bg_[4][%d];\n", M);
+  const bool bern = s.kind == GJX_BERNOULLI_LOGITS;
+  for (int g = 0; g < 4; ++g)
+    for (int st = 0; st < M; ++st) {
+      o.f("      { float t_ = 0.0f;");
+      for (int qq = 0; qq < 4; ++qq) o.f(" { const float u_ = __shfl(v[%d][0], %d + c_, 64); if (q_ == %d) t_ = u_; }", q.slot + M * qq + st, 16 * g, qq);
+      o.f(" bg_[%d][%d] = t_%s; }\n", g, st, bern ? " * 1.44269504f" : "");     // (bernoulli: the tile is accumulated in log2 units)
+    }
+  o.f("      float part_[4] = {0.0f, 0.0f, 0.0f, 0.0f};\n");
   std::string pc[4] = {"0.0f", "0.0f", "0.0f", "0.0f"};
   for (int k = 1; k < np; ++k) {
     const gjx_param& qk = s.p[k];
@@ -571,33 +570,62 @@ void emit_mfma_site(Emit& o, Plan& pl, int j) {
   }
   const bool y128 = (s.obs_off & 3) == 0 && (dim & 15) == 0;
   const bool b128 = q.len == dim && (q.off & 3) == 0 && (dim & 15) == 0;
-  o.f("      for (int n0_ = 0; n0_ < %d; n0_ += 16) {\n", (dim + 15) & ~15);
-  o.f("        const int ra_ = n0_ + c_ < %d ? n0_ + c_ : %d;\n        float xa_[%d];\n", dim, dim - 1, M);
-  o.f("        _Pragma(\"unroll\") for (int s4_ = 0; s4_ < %d; ++s4_) {\n          const v4f_ t_ = *(const v4f_*)&TAB(%d + ra_ * %d + %d * q_ + 4 * s4_);\n"
-      "          xa_[4 * s4_] = t_[0]; xa_[4 * s4_ + 1] = t_[1]; xa_[4 * s4_ + 2] = t_[2]; xa_[4 * s4_ + 3] = t_[3];\n        }\n", M / 4, q.moff, n, M);
-  if (q.len == 1) o.f("        const float b0_ = TAB(%d);\n        const v4f_ bias_ = {b0_, b0_, b0_, b0_};\n", q.off);
-  else if (b128) o.f("        const v4f_ bias_ = *(const v4f_*)&TAB(%d + n0_ + 4 * q_);\n", q.off);
-  else o.f("        v4f_ bias_;\n        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = n0_ + 4 * q_ + r_; bias_[r_] = TAB(%d + (row_ < %d ? row_ : %d)); }\n",
-           q.off, dim, dim - 1);
-  if (y128) o.f("        const v4f_ y_ = *(const v4f_*)&TAB(%d + n0_ + 4 * q_);\n", s.obs_off);
-  else o.f("        v4f_ y_;\n        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = n0_ + 4 * q_ + r_; y_[r_] = TAB(%d + (row_ < %d ? row_ : %d)); }\n",
-           s.obs_off, dim, dim - 1);
-  o.f("        v4f_ acc_[4] = {bias_, bias_, bias_, bias_};\n        __builtin_amdgcn_sched_barrier(0);\n");
-  o.f("        _Pragma(\"unroll\") for (int s_ = 0; s_ < %d; ++s_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_)\n"
-      "          acc_[g_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_[s_], bg_[g_][s_], acc_[g_], 0, 0, 0);\n        __builtin_amdgcn_sched_barrier(0);\n", M);
-  o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n          const int row_ = n0_ + 4 * q_ + r_; (void)row_;\n");
-  o.f("          const float pb_ = %s, pc_ = %s, pd_ = %s;\n", pc[1].c_str(), pc[2].c_str(), pc[3].c_str());
-  o.f("          _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n            const float a_ = acc_[g_][r_];\n");
-  if (s.kind == GJX_BERNOULLI_LOGITS)   // y a - softplus(a): the same value as TFP's -softplus(-a) y - softplus(a) (1 - y) for any y
-    o.f("            const float e_ = fmaf(y_[r_], a_, -(fmaxf(a_, 0.0f) + kLn2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * fabsf(a_)))));\n");
+  // profiling variants (GJX_GEN_MFMA_DEBUG, part of the cache key): 1 = no matrix instructions, 2 = no elementwise phase,
+  // 4 = no scheduling barrier behind the matrix phase, 8 = dependent matrix-instruction order, 16 / 32 = one / two row tiles per trip
+  const int dbg_all = getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0;
+  const int dbg = dbg_all & 3;
+  const char* bsc = bern ? " * 1.44269504f" : "";
+  // TB row tiles of 16 per trip: their matrix instructions are issued as ONE batch (4 TB accumulators), then their elementwise
+  // phase — the f32 matrix unit and the vector ALU of a SIMD do not overlap, and every switch between the two kinds costs
+  // (profiles/r03_mfma_valu_overlap_microbench.txt), so the batches are as long as the registers allow
+  const int TB = (dbg_all & 16) ? 1 : (((dbg_all & 32) || (dim % 64)) ? ((dim % 32) == 0 ? 2 : 1) : 4);
+  o.f("      for (int n0_ = 0; n0_ < %d; n0_ += %d) {\n", (dim + 15) & ~15, 16 * TB);
+  o.f("        float xa_[%d][%d];\n        v4f_ bias_[%d], y_[%d];\n", TB, M, TB, TB);
+  for (int tb = 0; tb < TB; ++tb) {
+    const std::string n0 = tb ? "(n0_ + " + std::to_string(16 * tb) + ")" : "n0_";
+    o.f("        { const int ra_ = %s + c_ < %d ? %s + c_ : %d;\n", n0.c_str(), dim, n0.c_str(), dim - 1);
+    o.f("          _Pragma(\"unroll\") for (int s4_ = 0; s4_ < %d; ++s4_) {\n            const v4f_ t_ = *(const v4f_*)&TAB(%d + ra_ * %d + %d * q_ + 4 * s4_);\n"
+        "            xa_[%d][4 * s4_] = t_[0]; xa_[%d][4 * s4_ + 1] = t_[1]; xa_[%d][4 * s4_ + 2] = t_[2]; xa_[%d][4 * s4_ + 3] = t_[3];\n          }\n",
+        M / 4, q.moff, n, M, tb, tb, tb, tb);
+    if (q.len == 1) o.f("          { const float b0_ = TAB(%d)%s; bias_[%d] = v4f_{b0_, b0_, b0_, b0_}; }\n", q.off, bsc, tb);
+    else if (b128) o.f("          bias_[%d] = *(const v4f_*)&TAB(%d + %s + 4 * q_)%s;\n", tb, q.off, n0.c_str(), bsc);
+    else o.f("          _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = %s + 4 * q_ + r_; bias_[%d][r_] = TAB(%d + (row_ < %d ? row_ : %d))%s; }\n",
+             n0.c_str(), tb, q.off, dim, dim - 1, bsc);
+    if (y128) o.f("          y_[%d] = *(const v4f_*)&TAB(%d + %s + 4 * q_);\n", tb, s.obs_off, n0.c_str());
+    else o.f("          _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) { const int row_ = %s + 4 * q_ + r_; y_[%d][r_] = TAB(%d + (row_ < %d ? row_ : %d)); }\n",
+             n0.c_str(), tb, s.obs_off, dim, dim - 1);
+    o.f("        }\n");
+  }
+  if (bern) o.f("        v4f_ yh_[%d];\n        _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) yh_[tb_] = y_[tb_] - 0.5f;\n", TB, TB);
+  o.f("        v4f_ acc_[%d][4];\n        _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) acc_[tb_][g_] = bias_[tb_];\n"
+      "        __builtin_amdgcn_sched_barrier(0);\n", TB, TB);
+  if (dbg == 1)
+    o.f("        _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) acc_[tb_][g_] += xa_[tb_][g_ %% %d] * bg_[g_][0];\n"
+        "        __builtin_amdgcn_sched_barrier(0);\n", TB, M);
+  else if (dbg_all & 8)
+    o.f("        _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) _Pragma(\"unroll\") for (int s_ = 0; s_ < %d; ++s_)\n"
+        "          acc_[tb_][g_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_[tb_][s_], bg_[g_][s_], acc_[tb_][g_], 0, 0, 0);\n        __builtin_amdgcn_sched_barrier(0);\n", TB, M);
   else
-    o.f("            const float e_ = elem_logpdf(%d, y_[r_], a_, pb_, pc_, pd_);\n", s.kind);
+    o.f("        _Pragma(\"unroll\") for (int s_ = 0; s_ < %d; ++s_) _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_)\n"
+        "          acc_[tb_][g_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_[tb_][s_], bg_[g_][s_], acc_[tb_][g_], 0, 0, 0);\n        %s\n", M, TB,
+        (dbg_all & 4) ? "" : "__builtin_amdgcn_sched_barrier(0);");
+  o.f("        _Pragma(\"unroll\") for (int tb_ = 0; tb_ < %d; ++tb_) _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n"
+      "          const int row_ = n0_ + 16 * tb_ + 4 * q_ + r_; (void)row_;\n", TB);
+  o.f("          const float pb_ = %s, pc_ = %s, pd_ = %s;\n", pc[1].c_str(), pc[2].c_str(), pc[3].c_str());
+  o.f("          _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n            const float a_ = acc_[tb_][g_][r_];\n");
+  if (dbg == 2) o.f("            const float e_ = a_ + y_[tb_][r_];\n");
+  else if (bern)   // y a - softplus(a) — the value of TFP's -softplus(-a) y - softplus(a) (1 - y) for any y — in log2 units (a_ = a log2 e)
+    // with max(a_, 0) = (a_ + |a_|) / 2:  (y - 1/2) a_ - |a_| / 2 - log2(1 + exp2(-|a_|))   (two fused multiply-adds beside the exp2 / log2);
+    // the factor ln 2 is applied once to the particle's sum
+    o.f("            const float e_ = fmaf(yh_[tb_][r_], a_, fmaf(-0.5f, fabsf(a_), -__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a_)))));\n");
+  else
+    o.f("            const float e_ = elem_logpdf(%d, y_[tb_][r_], a_, pb_, pc_, pd_);\n", s.kind);
   if (dim & 15) o.f("            part_[g_] += row_ < %d ? e_ : 0.0f;\n", dim);
   else o.f("            part_[g_] += e_;\n");
   o.f("          }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n");
   // (3) the four lanes of a column hold partial sums of ONE particle; lane q == g keeps group g's total (it IS that particle's lane)
   o.f("      float tot_ = 0.0f;\n      _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n        float t_ = part_[g_];\n"
-      "        t_ += __shfl_xor(t_, 16, 64);\n        t_ += __shfl_xor(t_, 32, 64);\n        if (q_ == g_) tot_ = t_;\n      }\n      lp[0] = tot_;\n");
+      "        t_ += __shfl_xor(t_, 16, 64);\n        t_ += __shfl_xor(t_, 32, 64);\n        if (q_ == g_) tot_ = t_;\n      }\n      lp[0] = tot_%s;\n", bern ? " * kLn2" : "");
   o.f("      PLOOP { score[p] += lp[p]; weight[p] += lp[p]; }\n");
   o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n", ri.score_row);
   o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
@@ -921,7 +949,9 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "template <> struct VecStore<4> { static GJX_DEV void st(float* q, const float (&x)[4]) { *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]); } };\n");
   o.f("typedef float v4f_ __attribute__((ext_vector_type(4)));\n");
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
-    o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
+    // (two blocks per CU by launch bounds: with at most 256 VGPRs per lane the compiler keeps the matrix-core accumulators in
+    // VGPRs — the elementwise phase reads them there; the AGPR form it picks otherwise ran the loop at HALF the matrix rate)
+    o.f("extern \"C\" __global__ __launch_bounds__(256, 2) void gjx_gen(GenArgs a) {\n"
         "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n  __shared__ __attribute__((aligned(16))) float mfma_s[%d];\n"
         "  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4, pl.mfma_floats > 0 ? pl.mfma_floats : 4);
   else
@@ -1347,7 +1377,8 @@ int register_slots(const gjx_program* p) {
 
 uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // flavour 0: propagate+reweight kernel, 1: HMC kernel
   uint64_t h = sites_hash(p);
-  const int32_t extra[7] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour};
+  const int32_t extra[8] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour,
+                            getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
@@ -1392,6 +1423,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   const char* hn[] = {"gjx_device.h", "../../include/gjx.h", "gjx_scan.h", "gjx_tile.h"};
   const char* hs[] = {kDeviceHeader, kApiHeader, kScanHeader, kTileHeader};
   if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : "gjx_gen.hip", 4, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
+  // (offline clang takes -mllvm -amdgpu-mfma-vgpr-form=1, which would keep matrix-core results out of the AGPRs; this hipRTC's LLVM
+  // does not know the option, so the generated kernels pay 16 v_accvgpr_read per tile: about 3 %)
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
   const hiprtcResult rc = r.Compile(p, 3, opts);
   if (rc != HIPRTC_SUCCESS) {

@@ -530,9 +530,14 @@ class PackedProgram:
         self._tab_parts = tab
         ntab = 0
 
-        def push(arr) -> int:
+        def push(arr, align: int = 1) -> int:
+            """append to the float table; ``align`` (in floats): 16-byte alignment for what a kernel reads with b128 loads"""
             nonlocal ntab
             a = np.asarray(arr, np.float32).ravel()
+            if align > 1 and ntab % align:
+                pad = align - ntab % align
+                tab.append(np.zeros(pad, np.float32))
+                ntab += pad
             off = ntab
             tab.append(a)
             ntab += a.size
@@ -554,7 +559,7 @@ class PackedProgram:
                 v = np.asarray(obs[s.addr], np.float32).ravel()
                 if v.size != s.rows:
                     v = np.broadcast_to(v, (s.rows,))
-                self.obs_off[s.addr] = push(v)
+                self.obs_off[s.addr] = push(v, 4 if v.size >= 64 else 1)
                 self.slot_of[s.addr] = -1
             else:
                 self.slot_of[s.addr] = n_slots
@@ -629,9 +634,9 @@ class PackedProgram:
                         raise ValueError(f"affine matrix of {s.addr!r} has {mshape[0]} rows, site dim {rows}")
                     cp.slot, cp.n = self.slot_of[p.src] + p.src_elem, int(mshape[1])
                     cp.d_slot = int(p.d_elem)
-                    cp.off, cp.len = push(p.values), int(p.values.size // (ninst if p.inst_values else 1))
+                    cp.off, cp.len = push(p.values, 4 if p.values.size >= 64 else 1), int(p.values.size // (ninst if p.inst_values else 1))
                     cp.d_off = cp.len if p.inst_values else 0
-                    cp.moff = push(p.matrix)
+                    cp.moff = push(p.matrix, 4 if mshape[1] % 4 == 0 else 1)      # (rows of a matrix with 4 k columns: b128 loads)
                     cp.d_moff = int(mshape[0] * mshape[1]) if p.inst_matrix else 0
                 else:
                     raise ValueError(p.op)
