@@ -39,6 +39,7 @@ RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
 WEIGHTS_GLOBAL_MAX, WEIGHTS_TILE_SCALED = 0, 1      # gjx.h: fixed-point weight schemes of the filter's resampler
+WEIGHTS_PLAIN_LAUNCHES = 256                        # OR-ed into the scheme: plain launches only (the repeat after a poll time-out)
 MAX_PARAMS = 4
 
 i32, i64, u32, u64, f32, f64 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double

@@ -194,10 +194,11 @@ class Selection:
                 return Selection.leaf()
             comps = addr if isinstance(addr, tuple) else (addr,)
             if any(c is Ellipsis for c in comps) and any(isinstance(c, str) for c in comps):
-                # S[..., "y"]: any one component, then "y" — a name wildcard (choice_map.py:55-60) and, because a step /
-                # instance index is a component of the reference's addresses, also the whole sequence "y"
+                # S[..., "y"]: any ONE component, then "y" (choice_map.py:55-60).  A step / instance index is a component of
+                # the reference's addresses (chm[3, "y"]), so the wildcard also stands for the index of a sequence "y" —
+                # check() matches the pattern against the index-first form of an address; a bare "y" is NOT selected
                 names = tuple(_ANY if c is Ellipsis else c for c in comps if c is Ellipsis or isinstance(c, str))
-                return Selection((("*", names), key_of(addr)))
+                return Selection((("*", names),))
             return Selection((key_of(addr),))
 
     at = _At()
@@ -218,6 +219,15 @@ class Selection:
                 elif isinstance(e, tuple) and len(e) == 2 and e[0] == "*" and isinstance(e[1], tuple):
                     pat = e[1]
                     hit = len(path) >= len(pat) and all(pc is _ANY or pc == c for pc, c in zip(pat, path))
+                    if not hit and idx is not None and not _has_all(idx):
+                        # the reference's form of the same address carries the index components in front of one of the names
+                        # (chm[3, "y"], chm["tracks", 1, "pos"]); only a wildcard matches an index
+                        blk = (_ANY,) * (len(idx) if isinstance(idx, tuple) else 1)
+                        for at in range(len(path)):
+                            ipath = path[:at] + blk + path[at:]
+                            if len(ipath) >= len(pat) and all(pc is _ANY or (c is not _ANY and pc == c) for pc, c in zip(pat, ipath)):
+                                hit = True
+                                break
                 if hit:
                     break
         return hit != self.complement

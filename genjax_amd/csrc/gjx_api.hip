@@ -19,7 +19,13 @@ int gjx_fail_hip(hipError_t e, const char* where) {
 #include <mutex>
 #include <tuple>
 
+static thread_local int g_plain_depth = 0;
+gjx_plain_launch_scope::gjx_plain_launch_scope(bool on) : on_(on) { if (on_) ++g_plain_depth; }
+gjx_plain_launch_scope::~gjx_plain_launch_scope() { if (on_) --g_plain_depth; }
+bool gjx_plain_launches_forced() { return g_plain_depth > 0; }
+
 int gjx_coresident_blocks(const void* kernel, int threads, size_t dyn_lds) {
+  if (g_plain_depth > 0) return 0;
   if (const char* e = getenv("GJX_CORESIDENT_BLOCKS")) return atoi(e);
   static std::mutex mu;
   static std::map<std::tuple<const void*, int, int, size_t>, int> cache;

@@ -1061,7 +1061,26 @@ struct HmcPlan {
   std::vector<int> sel_of_slot;    // slot -> index among the selected slots, or -1
   std::vector<int> slot_of_sel;
   bool looped = false;             // some site is a rolled loop (CPL = 4)
+  // rolled sites whose AFFINE parameter runs on the matrix cores (hmc_emit_mfma_site): parameter index or -1 per site, offset
+  // of the site's transposed matrix in the second LDS array, and what the layout needs from the launch
+  bool mfma = false;
+  std::vector<int> mf_k, xt_off;
+  int xt_floats = 0, block = 256;
 };
+
+// a rolled site for the matrix cores: exactly one AFFINE parameter over n = 16, 32, 48 or 64 values with 16-byte aligned rows,
+// rows in multiples of 16
+int hmc_mfma_param(const gjx_site& s) {
+  if (s.dim <= kMaxExpandDim || (s.dim & 15) || is_categorical(s.kind) || s.kind == GJX_DIRICHLET) return -1;
+  int k_aff = -1;
+  for (int k = 0; k < n_params(s.kind); ++k) {
+    const gjx_param& q = s.p[k];
+    if (q.op != GJX_P_AFFINE) continue;
+    if (k_aff >= 0 || q.n < 16 || q.n > 64 || (q.n & 15) || (q.moff & 3) || (q.len != 1 && q.len != s.dim)) return -1;
+    k_aff = k;
+  }
+  return k_aff;
+}
 
 bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIRICHLET; }
 
@@ -1093,23 +1112,52 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
       for (int d = 0; d < s.dim; ++d) { pl.sel_of_slot[s.slot + d] = pl.nsel++; pl.slot_of_sel.push_back(s.slot + d); }
   }
   if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
+  pl.mf_k.assign(p->n_sites, -1);
+  pl.xt_off.assign(p->n_sites, 0);
+  if (pl.looped && !getenv("GJX_HMC_GEN_NO_MFMA")) {
+    const int tab_pad = (p->n_tab + 3) & ~3;
+    for (int j = 0; j < p->n_sites; ++j) {
+      const gjx_site& s = p->sites[j];
+      const int k = hmc_mfma_param(s);
+      if (k < 0) continue;
+      const int need = s.p[k].n * (s.dim + 4);
+      if (tab_pad + pl.xt_floats + need > 40000) continue;           // 160 KB of LDS: table + transposed matrices (+ nothing else)
+      pl.mf_k[j] = k;
+      pl.xt_off[j] = pl.xt_floats;
+      pl.xt_floats += need;
+      pl.mfma = true;
+    }
+    if (pl.mfma) {
+      // the LDS footprint decides how many blocks a CU holds; the block is sized so that a CU still runs 8 waves — two per
+      // SIMD with 256 registers each: chain state (4 NSEL + NS values) and four row tiles of operands do not fit 128
+      const int bytes = 4 * (tab_pad + pl.xt_floats), per_cu = bytes > 0 ? (160 * 1024) / bytes : 8;
+      pl.block = per_cu >= 2 ? 256 : 512;
+      if (const char* e = getenv("GJX_HMC_GEN_BT")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) pl.block = b; }
+    }
+  }
   *out = pl;
   return true;
 }
 
 // one element of site j: parameters, (score,) gradient terms.  dx: element index expression (a literal, or "d_" in a rolled
 // site); acc: name of the gradient accumulator array indexed by SELECTED-slot index ("g" or the site's partial "ga")
+// mf (matrix-core sites): parameter mf->k arrives finished in `pre` (bias + contraction, the tile's C layout) and its
+// gradient weight leaves through `wout` for the backward contraction; `x` (optional) names the element's value
+struct HmcMf { int k; std::string pre, wout, x; };
+
 void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j, const std::string& dx, bool dyn, const char* acc,
-                      const char* sc, const char* ind) {
+                      const char* sc, const char* ind, const HmcMf* mf = nullptr) {
   const gjx_site& s = prog->sites[j];
   const int np = n_params(s.kind);
-  const bool tab_lds = true;
-  (void)tab_lds;
   o.f("%s{\n", ind);
   for (int k = 0; k < 4; ++k) {
     if (k >= np) { o.f("%s  const float par_%d = 0.0f;\n", ind, k); continue; }
     const gjx_param& q = s.p[k];
     const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
+    if (mf && k == mf->k) {
+      o.f("%s  const float pre_%d = %s;\n%s  const float par_%d = %s;\n", ind, k, mf->pre.c_str(), ind, k, xf_wrap(q.xf, "pre_" + std::to_string(k)).c_str());
+      continue;
+    }
     switch (q.op) {
       case GJX_P_CONST: o.f("%s  const float pre_%d = TAB(%d + %s);\n", ind, k, q.off, e.c_str()); break;
       case GJX_P_GATHER: o.f("%s  const float pre_%d = TAB(%d + gi_%d_%d * %d + %s);\n", ind, k, q.off, j, k, q.len, e.c_str()); break;
@@ -1131,7 +1179,8 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
     }
     o.f("%s  const float par_%d = %s;\n", ind, k, xf_wrap(q.xf, "pre_" + std::to_string(k)).c_str());
   }
-  if (s.slot >= 0) o.f("%s  const float x_ = v[%d + %s];\n", ind, s.slot, dx.c_str());
+  if (mf && !mf->x.empty()) o.f("%s  const float x_ = %s;\n", ind, mf->x.c_str());
+  else if (s.slot >= 0) o.f("%s  const float x_ = v[%d + %s];\n", ind, s.slot, dx.c_str());
   else o.f("%s  const float x_ = TAB(%d + %s);\n", ind, s.obs_off, dx.c_str());
   o.f("%s  if (SC) %s += elem_logpdf(%d, x_, par_0, par_1, par_2, par_3);\n", ind, sc, s.kind);
   o.f("%s  float gx_, gp_[4];\n%s  dlogpdf(%d, x_, par_0, par_1, par_2, par_3, gx_, gp_);\n", ind, ind, s.kind);
@@ -1144,7 +1193,9 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
     if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE) continue;
     const std::string w = q.xf == GJX_XF_NONE ? "gp_[" + std::to_string(k) + "]"
                                               : "(gp_[" + std::to_string(k) + "] * xf_deriv(" + std::to_string(q.xf) + ", pre_" + std::to_string(k) + "))";
-    if (q.op == GJX_P_VALUE) {
+    if (mf && k == mf->k) {
+      o.f("%s  %s = %s;\n", ind, mf->wout.c_str(), w.c_str());
+    } else if (q.op == GJX_P_VALUE) {
       const int src = q.slot + (q.len == 1 ? 0 : atoi(dx.c_str()) % q.len);
       const int m = hp.sel_of_slot[src];
       if (m >= 0) o.f("%s  %s[%d] += %s;\n", ind, acc, m, w.c_str());
@@ -1163,6 +1214,74 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
   o.f("%s}\n", ind);
 }
 
+// A rolled site with an AFFINE parameter on v_mfma_f32_16x16x4_f32 (the layout of the hand-written k_hmc_logreg_mfma2,
+// gjx_hmc.hip, for any such site): a wave holds 16 chains, lane l = (c = l & 15, q = l >> 4) is one of the four lanes of chain c.
+//   forward   pre[n0 + 4 q + r][c] = bias + sum_k X[n0 + ..][k] v[k][c]:  A = X[n0 + c][16 b + 4 q + s] (one b128 LDS read of the
+//             row-major table per four instructions), B = v[16 b + 4 q + s] of chain c (registers: every lane keeps its chain's values);
+//   the element log-densities' derivatives are taken in the result layout — 4 elements per lane, no lane idle or redundant —
+//   backward  d/dv[16 b + 4 q + r][c] = sum_rows X[row][..] w[row][c]:  A = XT[16 b + c][n0 + 4 q + r] (one b128 read of the
+//             transposed copy made in the kernel's prologue), B = w of row n0 + 4 q + r, which is what this lane just computed;
+//   after the site the four lanes of a chain exchange their quarters of the gradient (n lane permutes).
+void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j) {
+  const gjx_site& s = prog->sites[j];
+  const int k = hp.mf_k[j], np = n_params(s.kind);
+  const gjx_param& q = s.p[k];
+  const int n = q.n, NB = n / 16, dim = s.dim, LD = dim + 4;
+  const int TB = dim % 64 == 0 ? 4 : (dim % 32 == 0 ? 2 : 1);
+  bool any_in = false;
+  for (int e = 0; e < n; ++e) any_in = any_in || hp.sel_of_slot[q.slot + e] >= 0;
+  o.f("    // %d rows x %d inputs on the matrix cores, %d row tiles per trip\n", dim, n, TB);
+  o.f("    float bq_[%d][4];\n", NB);
+  for (int b = 0; b < NB; ++b)
+    for (int st = 0; st < 4; ++st) {
+      const int v0 = q.slot + 16 * b + st;
+      o.f("    bq_[%d][%d] = q_ == 0 ? v[%d] : (q_ == 1 ? v[%d] : (q_ == 2 ? v[%d] : v[%d]));\n", b, st, v0, v0 + 4, v0 + 8, v0 + 12);
+    }
+  o.f("    v4f_ gacc_[%d][%d];\n    _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) gacc_[t_][b_] = v4f_{0.0f, 0.0f, 0.0f, 0.0f};\n",
+      TB, NB, TB, NB);
+  o.f("    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n    float scp_ = 0.0f;\n");
+  o.f("    const float* xf_ = &TAB(%d) + c16_ * %d + 4 * q_;\n    const float* xb_ = xt_s + %d + c16_ * %d + 4 * q_;\n", q.moff, n, hp.xt_off[j], LD);
+  o.f("    _Pragma(\"nounroll\") for (int n0_ = 0; n0_ < %d; n0_ += %d) {\n", dim, 16 * TB);
+  o.f("      v4f_ s_[%d], xa_[%d][%d];\n", TB, TB, NB);
+  o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) {\n", TB);
+  if (q.len == 1) o.f("        { const float b0_ = TAB(%d); s_[t_] = v4f_{b0_, b0_, b0_, b0_}; }\n", q.off);
+  else if ((q.off & 3) == 0) o.f("        s_[t_] = *(const v4f_*)&TAB(%d + n0_ + 16 * t_ + 4 * q_);\n", q.off);
+  else o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) s_[t_][r_] = TAB(%d + n0_ + 16 * t_ + 4 * q_ + r_);\n", q.off);
+  o.f("        _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) xa_[t_][b_] = *(const v4f_*)(xf_ + (n0_ + 16 * t_) * %d + 16 * b_);\n      }\n", NB, n);
+  o.f("      __builtin_amdgcn_sched_barrier(0);\n");
+  o.f("      _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) _Pragma(\"unroll\") for (int st_ = 0; st_ < 4; ++st_) _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_)\n"
+      "        s_[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa_[t_][b_][st_], bq_[b_][st_], s_[t_], 0, 0, 0);\n      __builtin_amdgcn_sched_barrier(0);\n", NB, TB);
+  // the transposed rows of the backward phase are fetched here, behind the forward instructions
+  if (any_in) o.f("      v4f_ xc_[%d][%d];\n      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) xc_[t_][b_] = *(const v4f_*)(xb_ + b_ * %d + n0_ + 16 * t_);\n",
+                  TB, NB, TB, NB, 16 * LD);
+  const bool y128 = s.slot < 0 && (s.obs_off & 3) == 0;
+  o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) {\n", TB);
+  if (y128) o.f("        const v4f_ y4_ = *(const v4f_*)&TAB(%d + n0_ + 16 * t_ + 4 * q_);\n", s.obs_off);
+  o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n          const int d_ = n0_ + 16 * t_ + 4 * q_ + r_; (void)d_;\n");
+  const HmcMf mf{k, "s_[t_][r_]", "s_[t_][r_]", y128 ? "y4_[r_]" : ""};
+  hmc_emit_element(o, prog, hp, j, "d_", true, "ga", "scp_", "          ", &mf);
+  o.f("        }\n      }\n      __builtin_amdgcn_sched_barrier(0);\n");
+  if (any_in)
+    o.f("      _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_)\n"
+        "        gacc_[t_][b_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc_[t_][b_][r_], s_[t_][r_], gacc_[t_][b_], 0, 0, 0);\n      __builtin_amdgcn_sched_barrier(0);\n", TB, NB);
+  o.f("    }\n");
+  // the lane (c, qq) holds d/dv[16 b + 4 qq + r] of chain c in gacc_[.][b][r]: every lane of the chain fetches all of them
+  if (any_in) {
+    o.f("    _Pragma(\"unroll\") for (int t_ = 1; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) gacc_[0][b_] += gacc_[t_][b_];\n", TB, NB);
+    for (int e = 0; e < n; ++e) {
+      const int m = hp.sel_of_slot[q.slot + e];
+      if (m >= 0) o.f("    g[%d] += __shfl(gacc_[0][%d][%d], c16_ + %d, 64);\n", m, e / 16, e % 4, 16 * ((e % 16) / 4));
+    }
+  }
+  std::vector<char> touched(hp.nsel, 0);
+  for (int kk = 0; kk < np; ++kk) {
+    const gjx_param& qq = s.p[kk];
+    if (kk != k && qq.op == GJX_P_VALUE && hp.sel_of_slot[qq.slot] >= 0) touched[hp.sel_of_slot[qq.slot]] = 1;
+  }
+  for (int m = 0; m < hp.nsel; ++m) if (touched[m]) o.f("    g[%d] += QSUM(ga[%d]);\n", m, m);
+  o.f("    if (SC) sc_ += QSUM(scp_);\n");
+}
+
 std::string generate_hmc(const gjx_program* prog) {
   HmcPlan hp;
   if (!hmc_plan(prog, &hp)) return "";
@@ -1171,10 +1290,13 @@ std::string generate_hmc(const gjx_program* prog) {
   Emit o;
   o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define CPL %d\n#define NS %d\n#define NSEL %d\n#define NTAB %d\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, cpl, NS, NSEL, prog->n_tab);
-  o.f("#define TAB(i) tab_s[i]\n");
+  o.f("#define TAB(i) tab_s[i]\n#define BT %d\n#define XTF %d\ntypedef float v4f_ __attribute__((ext_vector_type(4)));\n", hp.block, hp.xt_floats);
+  // the lanes of a chain: an aligned quad, or with a matrix-core site the four 16-lane rows of the wave (lane & 15 = chain)
+  if (hp.mfma) o.f("GJX_DEV float QSUM(float x) { x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); return x; }\n");
+  else o.f("#define QSUM(x) quad_sum(x)\n");
   // ---- the sweep: score (SC) and gradient of the selected slots
-  o.f("template <bool SC>\nGJX_DEV float sweep(const float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const int q_) {\n"
-      "  float sc_ = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
+  o.f("template <bool SC>\nGJX_DEV float sweep(const float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_) {\n"
+      "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
     const int np = n_params(s.kind);
@@ -1199,6 +1321,8 @@ std::string generate_hmc(const gjx_program* prog) {
           s.ncat - 1, s.ncat - 1, L.c_str());
     } else if (s.dim <= kMaxExpandDim) {
       for (int d = 0; d < s.dim; ++d) hmc_emit_element(o, prog, hp, j, std::to_string(d), false, "g", "sc_", "    ");
+    } else if (hp.mf_k[j] >= 0) {
+      hmc_emit_mfma_site(o, prog, hp, j);
     } else {
       // a rolled site: elements dealt round-robin to the CPL lanes of the chain, partial score and gradient rows joined at the end
       o.f("    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n    float scp_ = 0.0f;\n");
@@ -1212,23 +1336,37 @@ std::string generate_hmc(const gjx_program* prog) {
         if (q.op == GJX_P_VALUE && hp.sel_of_slot[q.slot] >= 0) touched[hp.sel_of_slot[q.slot]] = 1;
         if (q.op == GJX_P_AFFINE) for (int e = 0; e < q.n; ++e) if (hp.sel_of_slot[q.slot + e] >= 0) touched[hp.sel_of_slot[q.slot + e]] = 1;
       }
-      for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? quad_sum(ga[%d]) : ga[%d];\n", m, m, m);
-      o.f("    if (SC) sc_ += CPL > 1 ? quad_sum(scp_) : scp_;\n");
+      for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? QSUM(ga[%d]) : ga[%d];\n", m, m, m);
+      o.f("    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n");
     }
     o.f("  }\n");
   }
   o.f("  return sc_;\n}\n\n");
   // ---- the kernel
-  o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_hmc_gen(HmcGenArgs a) {\n"
+  o.f("extern \"C\" __global__ __launch_bounds__(BT) void gjx_hmc_gen(HmcGenArgs a) {\n"
       "  __shared__ __attribute__((aligned(16))) float tab_s[NTAB > 0 ? ((NTAB + 3) & ~3) : 4];\n"
-      "  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n"
-      "  const int q_ = (int)threadIdx.x %% CPL;\n"
-      "  const int64_t i_raw = ((int64_t)blockIdx.x * 256 + threadIdx.x) / CPL;\n"
+      "  __shared__ __attribute__((aligned(16))) float xt_s[XTF > 0 ? XTF : 4];\n"
+      "  for (int t = threadIdx.x; t < NTAB; t += BT) tab_s[t] = a.tab[t];\n");
+  for (int j = 0; j < prog->n_sites; ++j) {
+    if (hp.mf_k[j] < 0) continue;
+    const gjx_site& s = prog->sites[j];
+    const gjx_param& q = s.p[hp.mf_k[j]];
+    o.f("  for (int t = threadIdx.x; t < %d; t += BT) { const int k_ = t / %d, r_ = t - k_ * %d; xt_s[%d + k_ * %d + r_] = a.tab[%d + r_ * %d + k_]; }   // site %d: X transposed\n",
+        q.n * s.dim, s.dim, s.dim, hp.xt_off[j], s.dim + 4, q.moff, q.n, j);
+  }
+  o.f("  __syncthreads();\n");
+  if (hp.mfma)
+    o.f("  const int q_ = (int)(threadIdx.x & 63u) >> 4;\n"
+        "  const int64_t i_raw = ((((int64_t)blockIdx.x * BT + threadIdx.x) >> 6) << 4) + (int64_t)(threadIdx.x & 15u);\n");
+  else
+    o.f("  const int q_ = (int)threadIdx.x %% CPL;\n"
+        "  const int64_t i_raw = ((int64_t)blockIdx.x * BT + threadIdx.x) / CPL;\n");
+  o.f(
       "  const bool live = i_raw < a.n;\n  const int64_t n = a.n, i = live ? i_raw : a.n - 1;   // (every lane runs: the quads reduce across lanes)\n"
       "  const uint64_t gidx = (uint64_t)(a.offset + i);\n"
       "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
       "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = a.choices[(int64_t)s_ * n + i];\n"
-      "  const float score0 = sweep<true>(v, g, tab_s, q_);   // hmc.py:165-166\n"
+      "  const float score0 = sweep<true>(v, g, tab_s, xt_s, q_);   // hmc.py:165-166\n"
       "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g0[m_] = g[m_];\n"
       "  key2 knew{0u, 0u}, sub{0u, 0u};\n"
       "  if (RNG == GJX_RNG_JAX32) { const key2 ck = fold_in64(a.key, gidx); knew = fold_in(ck, 0u); sub = fold_in(ck, 1u); }   // hmc.py:167\n"
@@ -1249,7 +1387,7 @@ std::string generate_hmc(const gjx_program* prog) {
       "  for (int t = 1; t <= a.L; ++t) {   // hmc.py:170-194\n"
       "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * (a.stale ? g0[m_] : g[m_]);   // hmc.py:186: the carry keeps the received gradient\n");
   for (int m = 0; m < NSEL; ++m) o.f("    v[%d] += a.eps * p[%d];\n", hp.slot_of_sel[m], m);
-  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, q_); else (void)sweep<false>(v, g, tab_s, q_);\n"
+  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, xt_s, q_); else (void)sweep<false>(v, g, tab_s, xt_s, q_);\n"
       "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * g[m_];\n  }\n"
       "  float k1 = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) { const float q2_ = -1.0f * p[m_]; k1 += -0.5f * q2_ * q2_ - kHalfLog2Pi; }\n"
       "  const float al = sc - score0 + k1 - k0;   // hmc.py:196-203\n"
@@ -1260,7 +1398,7 @@ std::string generate_hmc(const gjx_program* prog) {
       "  if (live && q_ == 0) {\n    if (acc) {\n");
   for (int m = 0; m < NSEL; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", hp.slot_of_sel[m], hp.slot_of_sel[m]);
   o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n}\n");
-  o.f("// CPL %d\n// LDS_FLOATS 0\n", cpl);
+  o.f("// CPL %d\n// BT %d\n// LDS_FLOATS 0\n", cpl, hp.block);
   return o.s;
 }
 
@@ -1324,7 +1462,7 @@ std::string cache_dir() {
 struct Compiled {
   std::vector<char> code;   // code object
   int lds_floats = 0;
-  int cpl = 1;              // generated HMC kernels: lanes per chain
+  int cpl = 1, block = 256; // generated HMC kernels: lanes per chain, threads per block
   std::string error;        // non-empty: this structure cannot be generated / compiled
 };
 
@@ -1378,7 +1516,9 @@ int register_slots(const gjx_program* p) {
 uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // flavour 0: propagate+reweight kernel, 1: HMC kernel
   uint64_t h = sites_hash(p);
   const int32_t extra[8] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour,
-                            getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0};
+                            (getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0) ^
+                                (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
+                                (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0)};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
@@ -1395,6 +1535,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   c.lds_floats = atoi(src.c_str() + m + 14);
   const size_t mc = src.rfind("// CPL ");
   if (mc != std::string::npos) c.cpl = atoi(src.c_str() + mc + 7);
+  const size_t mb = src.rfind("// BT ");
+  if (mb != std::string::npos) c.block = atoi(src.c_str() + mb + 6);
   if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
@@ -1526,12 +1668,13 @@ int hmc_gen_available(const gjx_program* prog) {
 
 int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t st) {
   hipFunction_t fn = nullptr;
-  int cpl = 1;
+  int cpl = 1, block = 256;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     const Compiled& c = compile(prog, 0, 1);
     if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
     cpl = c.cpl;
+    block = c.block;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
     const auto lk = std::make_pair(structure_key(prog, 0, 1), dev);
@@ -1551,8 +1694,8 @@ int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t 
   size_t sz = sizeof(a);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const int64_t threads = a.n * cpl;
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  const hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, st, nullptr, config);
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  const hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, (unsigned)block, 1, 1, 0, st, nullptr, config);
   if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch (HMC kernel)");
   return GJX_OK;
 }

@@ -1062,6 +1062,10 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
     if (s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_TAB / OBS_SLOT)");
+    // the HMC engines walk plain site lists: a plate-tagged body or an INPUT site would be read as an ordinary site (wrong rows,
+    // wrong strides) — the host lowers a vmapped kernel to the vector form for HMC (PackedProgram(plates="vector"))
+    if (s.plate != 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_hmc: plate-tagged sites are not supported (pack the program with the vector form of its plates)");
+    if (s.mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_hmc: GJX_MODE_INPUT sites are not supported");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
                                               s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))
@@ -1116,6 +1120,10 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
 extern "C" int gjx_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score, float* grad,
                               void* stream) {
   if (!prog || !prog->sites_dev || !prog->tab_dev || !choices || !grad || n <= 0) return gjx_fail(GJX_EINVAL, "gjx_score_grad: bad argument");
+  for (int j = 0; prog->sites && j < prog->n_sites; ++j) {
+    if (prog->sites[j].plate != 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_score_grad: plate-tagged sites are not supported (pack the program with the vector form of its plates)");
+    if (prog->sites[j].mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_score_grad: GJX_MODE_INPUT sites are not supported");
+  }
   hipLaunchKernelGGL(k_score_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prog->sites_dev,
                      prog->tab_dev, prog->n_sites, prog->n_slots, n, choices, score, grad);
   GJX_CHECK_LAUNCH("gjx_score_grad");

@@ -23,6 +23,14 @@ int gjx_launch_lse_finish(const void* partials_float2, int n, int64_t K_total, f
 // their blocks through memory (granule all-gathers) must not be launched with a larger grid.  GJX_CORESIDENT_BLOCKS
 // overrides the answer (tests of the fallback paths).  Returns 0 when the query fails.
 int gjx_coresident_blocks(const void* kernel, int threads, size_t dyn_lds);
+// While one of these lives on a thread, gjx_coresident_blocks answers 0 on that thread: every launcher below it takes its
+// plain multi-launch path (GJX_WEIGHTS_PLAIN_LAUNCHES of gjx_ssm_filter_scheme: the repeat after a poll time-out).
+struct gjx_plain_launch_scope {
+  explicit gjx_plain_launch_scope(bool on);
+  ~gjx_plain_launch_scope();
+  bool on_;
+};
+bool gjx_plain_launches_forced();
 
 namespace gjx {
 // phase-stamp buffer of the profiling scripts (gjx_debug_timeline): the registered device buffer if it holds `need` bytes

@@ -1234,6 +1234,9 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
                                      void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !ys_dev || !x_a || !x_b || !logw || !cum || !ancestors || !lse_steps || T <= 0 || K <= 0)
     return gjx_fail(GJX_EINVAL, "gjx_ssm_filter: bad argument");
+  // GJX_WEIGHTS_PLAIN_LAUNCHES: no kernel of this call may wait for its own blocks (the caller repeats a timed-out run)
+  const gjx_plain_launch_scope plain_scope((weight_scheme & GJX_WEIGHTS_PLAIN_LAUNCHES) != 0);
+  weight_scheme &= ~GJX_WEIGHTS_PLAIN_LAUNCHES;
   if (weight_scheme != GJX_WEIGHTS_GLOBAL_MAX && weight_scheme != GJX_WEIGHTS_TILE_SCALED)
     return gjx_fail(GJX_EINVAL, "gjx_ssm_filter: weight_scheme must be GJX_WEIGHTS_GLOBAL_MAX or GJX_WEIGHTS_TILE_SCALED");
   const bool tiled = weight_scheme == GJX_WEIGHTS_TILE_SCALED;
@@ -1262,7 +1265,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
   const void* pers_fn = nullptr;
   int pthreads = 256;
   int64_t pblk = nblk;
-  if ((fused_fn || tiled) && T > 1 && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
+  if ((fused_fn || tiled) && T > 1 && (!gjx_plain_launches_forced() && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0))) {
     const bool jax = rng_mode == GJX_RNG_JAX32;
     // 1024-thread blocks (one per CU) once the grid would have more than 256 blocks of 256: fewer, cheaper rendezvous;
     // always for the tile-scaled scheme (its quantisation tile is 1024 particles)
@@ -1283,7 +1286,7 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
   }
   // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
   if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
-      (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0)) {
+      (!gjx_plain_launches_forced() && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0))) {
     const int rc_pf = pf_filter_launch(m, key0, key1, rng_mode, T, K, ys_dev, x_a, x_b, logw, (float*)cum, ancestors, lse_steps, ws1, ws2, need,
                                        stream, nullptr);
     if (rc_pf != GJX_EUNSUPPORTED) return rc_pf;

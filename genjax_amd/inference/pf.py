@@ -19,26 +19,6 @@ from ..core import Key, fold_in, split, threefry2x32
 _warned_timeout = [False]
 
 
-class _plain_launches:
-    """Run the enclosed calls on the plain multi-launch paths: no kernel whose blocks wait for each other (the library's
-    launchers size co-resident grids from GJX_CORESIDENT_BLOCKS when it is set: 0 = nothing is co-resident)."""
-
-    def __enter__(self):
-        import os
-        self._old = {k: os.environ.get(k) for k in ("GJX_CORESIDENT_BLOCKS", "GJX_SSM_PERSISTENT")}
-        os.environ["GJX_CORESIDENT_BLOCKS"] = "0"
-        os.environ["GJX_SSM_PERSISTENT"] = "0"
-
-    def __exit__(self, *exc):
-        import os
-        for k, v in self._old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        return False
-
-
 def _note_timeout(what: str) -> None:
     if not _warned_timeout[0]:
         import warnings
@@ -365,8 +345,7 @@ class BootstrapFilter:
                 # the one-launch filter needs its whole grid resident; something else held compute units.  Same filter, same
                 # keys, as one plain launch per stage (bit-identical results: tests/test_gpu_tiled.py) — log once, do not raise
                 _note_timeout("bootstrap filter")
-                with _plain_launches():
-                    out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, weights=self.weights)
+                out = kernels.ssm_filter(self.ssm.c_struct(dev), key, self.rng_mode, ys_d, self.K, weights=self.weights | A.WEIGHTS_PLAIN_LAUNCHES)
                 st = kernels.workspace_status(out["_status_ws"], raise_on_error=False)
             incs = out["lse_steps"][:, 3]
             res = dict(log_ml=incs.sum(), increments=incs, x=out["x"], logw=out["logw"], means=None)

@@ -593,7 +593,10 @@ int gjx_ssm_filter(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_m
  *     streams; the ancestors differ from GLOBAL_MAX's only where a threshold falls within the quantisation step of a
  *     particle boundary.  Oracle: gjxo_resample_systematic_tiled.
  * gjx_ssm_filter == gjx_ssm_filter_scheme(..., GJX_WEIGHTS_GLOBAL_MAX, ...). */
-enum { GJX_WEIGHTS_GLOBAL_MAX = 0, GJX_WEIGHTS_TILE_SCALED = 1 };
+enum { GJX_WEIGHTS_GLOBAL_MAX = 0, GJX_WEIGHTS_TILE_SCALED = 1,
+       /* OR-ed into weight_scheme: run the filter as plain launches only — no kernel whose blocks wait for each other.  Same
+        * keys, bit-identical results; what a caller passes when it repeats a run whose status word shows GJX_STATUS_POLL_TIMEOUT */
+       GJX_WEIGHTS_PLAIN_LAUNCHES = 256 };
 int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, int64_t K,
                           const float* ys_dev, float* x_a, float* x_b, float* logw, uint64_t* cum, int32_t* ancestors,
                           float* lse_steps, int32_t weight_scheme, void* workspace, size_t workspace_bytes, void* stream);

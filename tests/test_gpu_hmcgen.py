@@ -121,6 +121,73 @@ def test_generated_hmc_kernel_against_oracle_and_interpreter(K_, oracle, rng, wh
             np.testing.assert_allclose(gc[:, both], o["choices"][:, both], rtol=3e-2, atol=3e-2)
 
 
+def _regression_target(which, rng):
+    """big likelihood sites whose AFFINE parameter the emitter puts on the matrix cores (hmc_emit_mfma_site): other row / input
+    counts than config 5's, a vector bias, a transform on the contraction, a second (value) parameter with a gradient of its
+    own, two such sites over the same coefficients"""
+    rs = np.random.default_rng(17)
+    sl = SiteList()
+    if which == "normal_96x32":
+        N, P = 96, 32
+        sl.add("ls", A.NORMAL, [-0.3, 0.4])
+        sl.add("w", A.MVNORMAL_DIAG, [Param.const(np.zeros(P, np.float32)), Param.const(np.full(P, 0.7, np.float32))], dim=P)
+        X = (rs.standard_normal((N, P)) * 0.4).astype(np.float32)
+        sl.add("y", A.NORMAL, [Param.affine(X, "w", bias=rs.standard_normal(N).astype(np.float32)), Param.value("ls", xf=A.XF_EXP)], dim=N)
+        obs = {"y": rs.standard_normal(N).astype(np.float32)}
+        sel = ("ls", "w")
+    elif which == "poisson_48x32":
+        N, P = 48, 32
+        sl.add("w", A.MVNORMAL_DIAG, [Param.const(np.zeros(P, np.float32)), Param.const(np.full(P, 0.5, np.float32))], dim=P)
+        X = (rs.standard_normal((N, P)) * 0.2).astype(np.float32)
+        sl.add("k", A.POISSON, [Param.affine(X, "w", bias=np.float32(1.0), xf=A.XF_SOFTPLUS)], dim=N)
+        obs = {"k": rs.poisson(1.5, N).astype(np.float32)}
+        sel = ("w",)
+    else:
+        N, P = 128, 16
+        sl.add("w", A.MVNORMAL_DIAG, [Param.const(np.zeros(P, np.float32)), Param.const(np.full(P, 1.0, np.float32))], dim=P)
+        X1, X2 = (rs.standard_normal((N, P)) * 0.5).astype(np.float32), (rs.standard_normal((64, P)) * 0.5).astype(np.float32)
+        sl.add("b", A.BERNOULLI_LOGITS, [Param.affine(X1, "w", bias=np.float32(0.2))], dim=N)
+        sl.add("y", A.NORMAL, [Param.affine(X2, "w", bias=np.float32(-0.1)), Param.const(np.float32(0.8))], dim=64)
+        obs = {"b": (rs.random(N) < 0.5).astype(np.float32), "y": rs.standard_normal(64).astype(np.float32)}
+        sel = ("w",)
+    modes = {s.addr: (A.MODE_OBS_TAB if s.addr in obs else A.MODE_OBS_SLOT) for s in sl.sites}
+    return PackedProgram(sl, modes, obs, selected=sel, rng_mode=rng)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("which", ["normal_96x32", "poisson_48x32", "two_sites_16"])
+def test_generated_hmc_matrix_core_sites(K_, oracle, rng, which, monkeypatch):
+    """the matrix-core flavour of the generated HMC kernel (16 chains per wave, forward and backward contraction on
+    v_mfma_f32_16x16x4_f32) == the same program with the flavour switched off (scalar rolled loop) == interpreter == oracle"""
+    import torch
+    prog = _regression_target(which, rng)
+    n = 1000                                                              # (not a multiple of 16: shadow chains in the last wave)
+    ch = (np.random.default_rng(8).standard_normal((prog.n_slots, n)) * 0.2).astype(np.float32)
+    eps, L = 0.004, 12
+    monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+    assert K_.hmc_engine(prog) == 4
+    src = K_.program_hmc_source(prog)
+    assert src.count("on the matrix cores") == (2 if which == "two_sites_16" else 1) and "mfma_f32_16x16x4f32" in src
+    for stale in (False, True):
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        monkeypatch.delenv("GJX_HMC_GEN_NO_MFMA", raising=False)
+        g = K_.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), eps, L, stale, False, offset=5)
+        monkeypatch.setenv("GJX_HMC_GEN_NO_MFMA", "1")
+        assert "on the matrix cores" not in K_.program_hmc_source(prog)
+        gs = K_.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), eps, L, stale, False, offset=5)
+        monkeypatch.delenv("GJX_HMC_GEN_NO_MFMA")
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        it = K_.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), eps, L, stale, False, offset=5)
+        o = oracle.hmc(prog, (4, 1), ch, eps, L, stale, False, offset=5)
+        gc = _np(g["choices"])
+        assert np.isfinite(gc).all()
+        np.testing.assert_allclose(gc, _np(gs["choices"]), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(gc, _np(it["choices"]), rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(gc, o["choices"], rtol=3e-3, atol=3e-3)
+        np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
+        np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=6e-3)
+
+
 def test_generated_hmc_is_the_default_engine_for_unmatched_programs(K_, oracle):
     """engine selection: the hand-written kernels for the config-5 shape, the generated kernel for everything else the
     emitter covers, the interpreter for the rest (a dirichlet site)"""

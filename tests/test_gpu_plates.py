@@ -236,3 +236,22 @@ def test_flat_plate_draws_equal_the_vector_form():
     b = kernels.run_program(prog_p, (0, 3), 4096)
     np.testing.assert_allclose(_np(a["choices"]), _np(b["choices"]), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(_np(a["weight"]), _np(b["weight"]), rtol=1e-5, atol=1e-4)
+
+
+def test_hmc_entry_points_refuse_plate_tagged_and_input_sites():
+    """gjx_hmc / gjx_score_grad walk plain site lists: a plate-tagged program (or one with INPUT sites) is refused with
+    GJX_EUNSUPPORTED instead of being read with the wrong rows (the host's HMC packs vmapped kernels in the vector form)"""
+    import torch
+    from genjax_amd import kernels
+    from genjax_amd._lib import GjxError
+    model, chm, ys, mu, logits = _mixture(64)
+    prog, _, _ = model.pack((), chm, True)
+    assert prog.c_sites[0].plate == 1
+    ch = torch.zeros((max(prog.n_slots, 1), 32), device="cuda")
+    with pytest.raises(GjxError, match="plate-tagged"):
+        kernels.score_grad(prog, ch)
+    # every site constrained (what gjx_hmc asks for first), still plate-tagged
+    p2, _, _ = model.pack((), chm ^ C["k", "z"].set(np.zeros(64, np.float32)), True)
+    assert p2.c_sites[0].plate == 1 and all(p2.c_sites[j].mode == A.MODE_OBS_TAB for j in range(p2.n_sites))
+    with pytest.raises(GjxError, match="plate-tagged"):
+        kernels.hmc(p2, (1, 2), torch.zeros((max(p2.n_slots, 1), 32), device="cuda"), 0.01, 2, False, False)

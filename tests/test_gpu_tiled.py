@@ -105,6 +105,16 @@ def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
             del os.environ["GJX_SSM_PERSISTENT"]
         np.testing.assert_array_equal(_np(a["x"]), _np(c["x"]))
         np.testing.assert_allclose(_np(a["increments"]), _np(c["increments"]), rtol=2e-6, atol=2e-6)
+        # and the flag the host layer passes when it repeats a timed-out run (GJX_WEIGHTS_PLAIN_LAUNCHES: per call, no environment)
+        import torch
+        ys_d = torch.as_tensor(np.asarray(s["y"], np.float32)).cuda()
+        for w in (A.WEIGHTS_TILE_SCALED, A.WEIGHTS_GLOBAL_MAX):
+            one = K_.ssm_filter(bf.ssm.c_struct("cuda"), core.key(7), rng, ys_d, K, weights=w)
+            x1, l1 = _np(one["x"]).copy(), _np(one["lse_steps"]).copy()
+            pl = K_.ssm_filter(bf.ssm.c_struct("cuda"), core.key(7), rng, ys_d, K, weights=w | A.WEIGHTS_PLAIN_LAUNCHES)
+            np.testing.assert_array_equal(x1, _np(pl["x"]))
+            np.testing.assert_allclose(l1[:, 3], _np(pl["lse_steps"])[:, 3], rtol=2e-6, atol=2e-6)
+            assert K_.workspace_status(pl["_status_ws"], raise_on_error=False) == 0
 
 
 @pytest.mark.parametrize("K,force", [((1 << 18) + 1, False), (300_001, False), (1 << 19, False), (1 << 20, False), (1, True), (2049, True), (70_001, True)])

@@ -560,6 +560,11 @@ class TestChoiceMapAlgebra:
         from genjax_amd.core import Selection, SelectionBuilder as S
         sel = S["x"] | S[..., "y"]
         assert sel["x"] and sel["any_address", "y"] and sel["rando", "y", "tail"] and not sel["q"]
+        # the wildcard consumes exactly ONE component (the reference's StaticSel with an Ellipsis component): a top-level "y"
+        # is not selected, step 3 of a sequence "y" (the reference's chm[3, "y"]) is
+        wild = S[..., "y"]
+        assert not wild["y"] and wild.check(("y", 3)) and not wild.check(("x", 3)) and wild["z", "y"]
+        assert S["tracks", ..., "pos"].check((("tracks", "pos"), 1)) and not S["tracks", ..., "pos"].check(("tracks", "pos"))
         assert S.all == Selection.all() and S.all["x"] and S.all["y", "z"] and S.all[()]
         assert S.none == Selection.none() and not S.none["x"] and not S.none["y", "z"] and not S.none[()]
         leaf = S.leaf
