@@ -63,9 +63,14 @@ class GjxProgram(C.Structure):
                 ("uid", i32)]
 
 
+class GjxRunResample(C.Structure):
+    _fields_ = [("logw", vp), ("tile_S", vp), ("tile_E", vp), ("lse_partials", vp), ("n_partials", i32), ("pad_", i32), ("lse_out", vp),
+                ("u", C.c_double), ("ancestors_out", vp), ("status_ws", vp)]
+
+
 class GjxRunOpts(C.Structure):
     _fields_ = [("flags", i32), ("pad_", i32), ("start_event", vp), ("stop_event", vp), ("in_rows", vp), ("in_stride", i64),
-                ("in_ancestors", vp)]
+                ("in_ancestors", vp), ("resample", C.POINTER(GjxRunResample))]
 
 
 class GjxRunInfo(C.Structure):

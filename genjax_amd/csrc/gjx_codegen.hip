@@ -998,6 +998,15 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
     if (has_input) o.f("    int64_t src_[PPT];\n    PLOOP src_[p] = a.anc ? (int64_t)a.anc[i0 + p] : i0 + p;\n");
+    if (has_input && ppt == 4)
+      // gjx_run_resample: the search of the tile-scaled systematic resampler for this block's tile, in front of the reads of the
+      // carry (tiled_search_tile, gjx_tile.h: the body of k_resample_gather_tiled) — resample + gather + propagate + reweight in one launch
+      o.f("    if (a.rs_logw) {\n      __shared__ TiledSearchShared rs_sh_;\n      __shared__ uint64_t rs_pl_[1026];\n      __shared__ int32_t rs_eb_[1024];\n"
+          "      int32_t anc_[4];\n      __syncthreads();\n"
+          "      tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
+          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_);\n"
+          "      PLOOP src_[p] = (int64_t)anc_[p];\n"
+          "      if (a.rs_anc_out) *reinterpret_cast<int4*>(a.rs_anc_out + i0) = make_int4(anc_[0], anc_[1], anc_[2], anc_[3]);\n    }\n");
   }
   // rows that already hold values (per-particle constraints, mask flags)
   std::vector<char> pre(prog->n_slots > 0 ? prog->n_slots : 1, 0);

@@ -763,6 +763,16 @@ struct GenArgs {
   // with lse == NULL: {S_b, e_b} of every 1024-particle tile of logw (tile-scaled fixed point) for gjx_resample_gather_tiled
   unsigned long long* tile_S;
   int32_t* tile_E;
+  // gjx_run_resample: the tile-scaled systematic search over the PREVIOUS collection in the prologue (rs_logw != NULL)
+  const float* rs_logw;
+  const unsigned long long* rs_S;
+  const int32_t* rs_E;
+  const float* rs_lse;
+  int rs_n_partials;
+  float* rs_lse_out;
+  double rs_u;
+  int32_t* rs_anc_out;
+  unsigned* rs_ctrl;
 };
 
 // ---- arguments of a generated per-program HMC kernel (gjx_codegen.hip emits `extern "C" __global__ void gjx_hmc_gen(HmcGenArgs)`) ----

@@ -674,233 +674,14 @@ __global__ __launch_bounds__(256) void k_resample_gather_tiled(const float* __re
 #define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GJX_STAMP(0);
   static_assert(ITEMS == 4, "a block consumes one quantisation tile: 256 lanes x 4 slots");
-  constexpr int TILE = 256 * ITEMS;
-  constexpr int CH = 3;
   extern __shared__ __align__(16) unsigned char gt_dyn[];
   const int nt = (int)gridDim.x;
   uint64_t* const Pl = (uint64_t*)gt_dyn;                      // [nt + 1] prefix of the shifted tile totals (!PLANNED)
   int32_t* const Ebl = (int32_t*)(Pl + ((nt + 2) & ~1));       // [nt] tile exponents (!PLANNED)
-  const uint64_t* const P = PLANNED ? Pg : Pl;
-  const int32_t* const Eb = PLANNED ? E : Ebl;
-  __shared__ float fred[8];
-  __shared__ uint64_t wsum[4];
-  __shared__ uint64_t cumL[CH * TILE];                         // cumulative q of the tiles being searched, relative to the tile's start
-  __shared__ uint64_t s_wtot[CH][4];
-  __shared__ int s_range[2];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __shared__ TiledSearchShared sh;
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ITEMS;
-  auto load_tile = [&](int64_t p0, float (&v)[ITEMS]) {
-    if (p0 + 4 <= K) {
-      const float4 q4 = *(const float4*)(x + p0);
-      v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? x[p0 + k] : -INFINITY;
-    }
-  };
-  // ---- every load of the head, at once: the three tiles of log-weights around the block, all tile totals ----
-  const int w0 = (int)blockIdx.x - 1;
-  float xw[CH][ITEMS];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) xw[c][k] = -INFINITY;
-    const int tc = w0 + c;
-    if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
-  }
-  int Emax = 0;
-  if constexpr (!PLANNED) {
-  float em = (float)kTileDead;
-  for (int b = threadIdx.x; b < nt; b += 256) {
-    const uint64_t sv = S[b];
-    const int e = sv ? E[b] : kTileDead;
-    Pl[b + 1] = sv;
-    Ebl[b] = e;
-    em = fmaxf(em, (float)e);
-  }
-  em = wave_max(em);
-  if (lane == 0) fred[wid] = em;
-  if (threadIdx.x == 0) Pl[0] = 0;
-  __syncthreads();
-  Emax = (int)fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
-  GJX_STAMP(1);
-  {   // shifted totals and their prefix, in place: lane t owns entries [t per, (t+1) per)
-    const int per = (nt + 255) >> 8;
-    const int e0 = threadIdx.x * per < nt ? threadIdx.x * per : nt, e1 = (e0 + per) < nt ? (e0 + per) : nt;
-    uint64_t loc = 0;
-    for (int e = e0; e < e1; ++e) {
-      const int sh = Emax - Ebl[e];
-      const uint64_t g = sh < 64 ? Pl[e + 1] >> sh : 0;
-      Pl[e + 1] = g;
-      loc += g;
-    }
-    const uint64_t inc = wave_scan_u64(loc);
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    uint64_t run = inc - loc;
-    for (int w = 0; w < wid; ++w) run += wsum[w];
-    for (int e = e0; e < e1; ++e) { run += Pl[e + 1]; Pl[e + 1] = run; }
-    __syncthreads();
-  }
-  }
-  auto shift_of = [&](int t) { return PLANNED ? shg[t] : Emax - Eb[t]; };   // (a tile shifted out entirely is never a source)
-  const uint64_t total = P[nt];
-  GJX_STAMP(2);
-  if (blockIdx.x == 0) {   // block-uniform: the LSE record of the producing run (its block partials), the dead-collection flag
-    if (lse_mode == 2 && lse_out) {
-      float sm_sum;
-      const float mx = block_ref_max(2, lse, n_partials, fred, &sm_sum);
-      if (threadIdx.x == 0) {
-        const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
-        lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;
-      }
-    }
-    if (threadIdx.x == 0 && total == 0 && ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusZeroTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   int32_t anc[ITEMS];
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((i0 + k < K) ? i0 + k : K - 1);   // dead collection: identity (flagged)
-  if (total > 0) {   // block-uniform
-    const double step = (double)total / (double)K;
-    uint64_t T[ITEMS];
-    int tile[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      const int64_t j = (i0 + k < K) ? i0 + k : K - 1;
-      T[k] = comb_threshold(j, u, step, total);
-      tile[k] = 0;
-    }
-    auto descend = [&](int k0, int k1) {   // first tile t with P[t + 1] > T (fixed trip count; two slots per pass)
-      for (int sft = 1 << (31 - __builtin_clz((unsigned)nt)); sft >= 1; sft >>= 1) {
-        const int pa = tile[k0] + sft, pb = tile[k1] + sft;
-        if (pa <= nt - 1 && P[pa] <= T[k0]) tile[k0] = pa;
-        if (k1 != k0 && pb <= nt - 1 && P[pb] <= T[k1]) tile[k1] = pb;
-      }
-    };
-    const int wlo = (int)blockIdx.x - 4 < 0 ? 0 : ((int)blockIdx.x - 4 > nt - 8 ? (nt - 8 < 0 ? 0 : nt - 8) : (int)blockIdx.x - 4);
-    uint64_t Pw[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Pw[k] = P[wlo + k < nt ? wlo + k : nt];
-    if (T[0] >= Pw[0] && T[ITEMS - 1] < Pw[8]) {
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k) {
-        int tl = wlo;
-#pragma unroll
-        for (int w = 1; w < 8; ++w) tl += Pw[w] <= T[k] ? 1 : 0;
-        tile[k] = tl;
-      }
-    } else {
-      descend(0, ITEMS - 1);
-      if (tile[0] == tile[ITEMS - 1]) {
-#pragma unroll
-        for (int k = 1; k < ITEMS - 1; ++k) tile[k] = tile[0];
-      } else {
-        descend(1, 2);
-      }
-    }
-    // residual of every slot in its source tile's own units (< S of that tile)
-    uint64_t Tr[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) Tr[k] = (T[k] - P[tile[k]]) << shift_of(tile[k]);
-    if (threadIdx.x == 0) s_range[0] = tile[0];
-    if (threadIdx.x == 255) s_range[1] = tile[ITEMS - 1];
-    __syncthreads();
-    const int tmin = s_range[0], tmax = s_range[1];
-    GJX_STAMP(3);
-    const bool windowed = tmin >= w0 && tmax <= w0 + 2;       // block-uniform: every source tile is among the three loaded at the top
-    if (windowed) {
-      // cumulative q of the window tiles the slots fall into (usually two), each against its own exponent, relative to
-      // the tile's start: cumL[c] for tile w0 + c
-      uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int tc = w0 + c;
-        sacc[c] = 0; inc[c] = 0;
-        if (tc < tmin || tc > tmax) continue;                 // block-uniform
-        const int es = Eb[tc];
-        const int64_t p0 = (int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS;
-        if (p0 + ITEMS <= K) {
-#pragma unroll
-          for (int k = 0; k < ITEMS; ++k) { sacc[c] += tile_q(xw[c][k], es); qi[c][k] = sacc[c]; }
-        } else {
-#pragma unroll
-          for (int k = 0; k < ITEMS; ++k) { sacc[c] += p0 + k < K ? tile_q(xw[c][k], es) : 0; qi[c][k] = sacc[c]; }
-        }
-        inc[c] = wave_scan_u64(sacc[c]);
-        if (lane == 63) s_wtot[c][wid] = inc[c];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int tc = w0 + c;
-        if (tc < tmin || tc > tmax) continue;
-        uint64_t base = inc[c] - sacc[c];
-        for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
-      }
-      __syncthreads();
-    }
-    auto search = [&](const uint64_t* cm, uint64_t r) {   // entries <= r among TILE (4-ary: three independent probes per level)
-      int pos = 0;
-#pragma unroll
-      for (int q = TILE >> 2; q >= 1; q >>= 2) {
-        const uint64_t pa = cm[pos + q - 1], pb = cm[pos + 2 * q - 1], pc = cm[pos + 3 * q - 1];
-        pos += (pa <= r ? q : 0) + (pb <= r ? q : 0) + (pc <= r ? q : 0);
-      }
-      return pos;
-    };
-    if (windowed) {
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k) anc[k] = (int32_t)((int64_t)tile[k] * TILE + search(cumL + (tile[k] - w0) * TILE, Tr[k]));
-    } else {
-      // collapsed or strongly drifting weights: re-scan the source tiles CH at a time (tiles without weight are skipped)
-      const int ntiles = tmax - tmin + 1;
-      auto next_live = [&](int at) { while (at < ntiles && P[tmin + at + 1] == P[tmin + at]) ++at; return at; };
-      for (int idx = 0; idx < ntiles;) {
-        const int nidx = next_live(idx + CH);
-        uint64_t qi[CH][ITEMS], sacc[CH], inc[CH];
-        __syncthreads();         // every lane is done searching the previous contents of cumL
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const bool on = idx + c < ntiles;
-          const int tsrc = on ? tmin + idx + c : 0;
-          const int64_t p0 = (int64_t)tsrc * TILE + (int64_t)threadIdx.x * ITEMS;
-          float nv[ITEMS];
-#pragma unroll
-          for (int k = 0; k < ITEMS; ++k) nv[k] = -INFINITY;
-          if (on) load_tile(p0, nv);
-          const int es = Eb[tsrc];
-          sacc[c] = 0;
-#pragma unroll
-          for (int k = 0; k < ITEMS; ++k) { sacc[c] += (on && p0 + k < K) ? tile_q(nv[k], es) : 0; qi[c][k] = sacc[c]; }
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) inc[c] = wave_scan_u64(sacc[c]);
-        if (lane == 63) {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) s_wtot[c][wid] = inc[c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          uint64_t base = inc[c] - sacc[c];
-          for (int w = 0; w < wid; ++w) base += s_wtot[c][w];
-#pragma unroll
-          for (int k = 0; k < ITEMS; ++k) cumL[c * TILE + threadIdx.x * ITEMS + k] = base + qi[c][k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-          const int kp = tile[k] - tmin;
-          if (kp >= idx && kp < idx + CH) anc[k] = (int32_t)((int64_t)tile[k] * TILE + search(cumL + (kp - idx) * TILE, Tr[k]));
-        }
-        idx = nidx;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) anc[k] = anc[k] < K ? anc[k] : (int32_t)(K - 1);
-  }
+  tiled_search_tile<PLANNED>(x, K, S, E, Pg, shg, nt, (int)blockIdx.x, Pl, Ebl, sh, lse_mode, lse, n_partials, lse_out, log_k_total, u, ctrl, timeline, anc);
   GJX_STAMP(4);
   // ---- children: rows of the ancestors, ITEMS consecutive slots per lane ----
   const bool whole = i0 + ITEMS <= K;

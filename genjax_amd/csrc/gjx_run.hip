@@ -1303,7 +1303,15 @@ extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32
   const bool tiles_requested = (op.flags & GJX_RUN_LEAVE_TILES) != 0;
   const GmmShape& g = ep.g;
   const int ppt = ep.ppt, nblocks = ep.grid;
-  (void)has_input;
+  if (op.resample) {
+    // the resampling search in the prologue of the generated kernel (gjx_run_resample): only where a block IS a quantisation tile
+    const gjx_run_resample& rs = *op.resample;
+    if (!rs.logw || !rs.tile_S || !rs.tile_E || !(rs.u >= 0.0 && rs.u < 1.0) || (rs.lse_out && (!rs.lse_partials || rs.n_partials <= 0)) || !op.in_rows)
+      return gjx_fail(GJX_EINVAL, "gjx_run_program_ex: resample needs logw, tile totals, u in [0, 1), in_rows (and block pairs with lse_out)");
+    if (rs.logw == logw) return gjx_fail(GJX_EINVAL, "gjx_run_program_ex: resample.logw must not be this run's logw");
+    if (ep.engine != ENGINE_GEN || ep.ppt != 4 || !has_input || K % 1024 != 0 || K > (1 << 20) || particle_offset != 0)
+      return gjx_fail(GJX_EUNSUPPORTED, "gjx_run_program_ex: resample needs a generated kernel with 4 particles per lane, INPUT sites, K % 1024 == 0, K <= 2^20");
+  }
   if (ep.engine == ENGINE_GEN) {
     GenArgs ga;
     ga.tab = prog->tab_dev; ga.key = key2{key0, key1}; ga.K = K; ga.offset = particle_offset;
@@ -1311,6 +1319,13 @@ extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32
     ga.site_scores = site_scores; ga.partials = partials; ga.ticket = ticket; ga.lse = lse; ga.log_k_total = log_k_total;
     ga.in_rows = op.in_rows; ga.in_stride = op.in_stride; ga.anc = op.in_ancestors; ga.store_inputs = (op.flags & GJX_RUN_STORE_INPUTS) ? 1 : 0;
     ga.tile_S = nullptr; ga.tile_E = nullptr;
+    ga.rs_logw = nullptr; ga.rs_S = nullptr; ga.rs_E = nullptr; ga.rs_lse = nullptr; ga.rs_n_partials = 0; ga.rs_lse_out = nullptr; ga.rs_u = 0.0;
+    ga.rs_anc_out = nullptr; ga.rs_ctrl = nullptr;
+    if (op.resample) {
+      const gjx_run_resample& rs = *op.resample;
+      ga.rs_logw = rs.logw; ga.rs_S = (const unsigned long long*)rs.tile_S; ga.rs_E = rs.tile_E; ga.rs_lse = rs.lse_partials; ga.rs_n_partials = rs.n_partials;
+      ga.rs_lse_out = rs.lse_out; ga.rs_u = rs.u; ga.rs_anc_out = rs.ancestors_out; ga.rs_ctrl = rs.status_ws ? (unsigned*)rs.status_ws + 8 : nullptr;
+    }
     if (tiles_requested && !lse && partials && K % 1024 == 0 && ppt == 4) {
       // tile totals of the tile-scaled resampler behind the block pairs: every block of the generated kernel walks whole
       // 1024-particle tiles only when 256 * ppt divides 1024 and its tile loop is tile-aligned (gjx_codegen.hip)

@@ -1,6 +1,9 @@
 // gjx_scanfilter.hip — bootstrap filter for ANY Scan kernel (gjx_scan_filter): the step recursion of Scan.generate
 // (combinators/scan.py:237-294: step t receives the carry of step t-1, weights add over steps) with systematic resampling in
-// front of every step.  Host code only: per step TWO plain launches, issued back to back from this loop —
+// front of every step.  Host code only.  Per step ONE plain launch where the step's generated kernel can resample in its
+// prologue (gjx_run_resample: 4 particles per lane, K a multiple of 1024 up to 2^20 — every block searches the ancestors of
+// its own tile from the previous step's log-weights and tile totals, which therefore alternate between two buffers / two
+// run workspaces), otherwise TWO, issued back to back from this loop —
 //   1. the tile-scaled systematic resampler's search (gjx_resample_gather_tiled with no rows to copy): log-weights of step
 //      t-1 -> ancestors; the block pairs and tile totals come from the producing kernel, so this launch reads 4 B per particle
 //      and writes 4 B; it also finishes the LSE record of step t-1;
@@ -28,6 +31,18 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
   if (!workspace || workspace_bytes < need_run + need_res) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter: workspace too small (OP_RUN + OP_RESAMPLE)");
   char* ws_run = (char*)workspace;
   char* ws_res = ws_run + need_run;
+  // the one-launch step needs a second run workspace and a second log-weight buffer behind the two the call must have
+  const size_t logw_off = (need_run + need_res + need_run + 255) & ~(size_t)255;
+  const bool room = workspace_bytes >= logw_off + sizeof(float) * (size_t)K;
+  char* ws_run2 = room ? ws_res + need_res : nullptr;
+  float* logw2 = room ? (float*)((char*)workspace + logw_off) : nullptr;
+  const bool no_fuse = getenv("GJX_SCAN_FILTER_TWO_LAUNCH") && atoi(getenv("GJX_SCAN_FILTER_TWO_LAUNCH")) != 0;
+  bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
+  if (fused && T > 1) {
+    // the second run workspace's control block must be zero like the first one's (the caller zero-fills the workspace once; be safe)
+    const hipError_t e = hipMemsetAsync(ws_run2, 0, kWsHeaderBytes, (hipStream_t)stream);
+    if (e != hipSuccess) return gjx_fail_hip(e, "gjx_scan_filter(workspace)");
+  }
   // key discipline of inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t); comb offset = uniform(k_res)
   std::vector<uint32_t> keys;
   std::vector<double> us;
@@ -38,32 +53,59 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
     return n;
   };
   gjx_run_opts o;
+  gjx_run_resample rs;
   gjx_run_info info = {0, 0, 0}, prev = {0, 0, 0};
+  // fused form: step t writes the log-weights / block pairs / tile totals of parity (T - 1 - t) & 1, so that the last step's land
+  // in `logw` and in the first run workspace; the two-launch form uses one buffer throughout
+  auto lw_of = [&](int t) { return (fused && ((T - 1 - t) & 1)) ? logw2 : logw; };
+  auto ws_of = [&](int t) { return (fused && ((T - 1 - t) & 1)) ? ws_run2 : ws_run; };
   for (int t = 0; t < T; ++t) {
     const gjx_program& pr = steps[t];
     float* out = (t & 1) ? rows_b : rows_a;
     const float* in = (t & 1) ? rows_a : rows_b;
     memset(&o, 0, sizeof(o));
     o.flags = GJX_RUN_LEAVE_TILES;
+    int rc = GJX_EUNSUPPORTED;
     if (t > 0) {
       if (input_rows(pr) > steps[t - 1].n_slots - input_rows(steps[t - 1]))
         return gjx_fail(GJX_EINVAL, "gjx_scan_filter: a step reads more carry rows than the step before it produced");
+      const char* pws = ws_of(t - 1);
       const bool tiles = prev.tiles_offset != 0;
-      const uint64_t* tS = tiles ? (const uint64_t*)(ws_run + prev.tiles_offset) : nullptr;
+      const uint64_t* tS = tiles ? (const uint64_t*)(pws + prev.tiles_offset) : nullptr;
       const int32_t* tE = tiles ? (const int32_t*)(tS + (K / 1024)) : nullptr;
       int32_t* anc_t = ancestors_all ? ancestors_all + (size_t)(t - 1) * (size_t)K : ancestors;
-      int rc = gjx_resample_gather_tiled(logw, K, tS, tE, 2, (const float*)(ws_run + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
-                                         anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
-      if (rc) return rc;
       o.in_rows = in + (size_t)input_rows(steps[t - 1]) * (size_t)K;      // the rows the previous step's OWN sites wrote
       o.in_stride = K;
-      o.in_ancestors = anc_t;
+      if (fused && tiles) {
+        memset(&rs, 0, sizeof(rs));
+        rs.logw = lw_of(t - 1); rs.tile_S = tS; rs.tile_E = tE; rs.lse_partials = (const float*)(pws + kWsHeaderBytes); rs.n_partials = prev.n_partials;
+        rs.lse_out = lse_steps + 4 * (size_t)(t - 1); rs.u = us[t]; rs.ancestors_out = anc_t; rs.status_ws = ws_res;
+        o.resample = &rs;
+        rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, lw_of(t), nullptr, nullptr, nullptr, nullptr, K,
+                                ws_of(t), need_run, stream, &o, &info);
+        o.resample = nullptr;
+        if (rc != GJX_OK && rc != GJX_EUNSUPPORTED) return rc;
+      }
+      if (rc != GJX_OK) {
+        if (fused && lw_of(t) != lw_of(t - 1)) {
+          // a step whose kernel cannot resample in its prologue: this step (and the rest) in the two-launch form, which keeps one
+          // buffer — the run continues on the buffers step t - 1 wrote
+          if (t > 1) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the steps' kernels differ in whether they can resample in their prologue");
+          fused = false;
+        }
+        rc = gjx_resample_gather_tiled(lw_of(t - 1), K, tS, tE, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
+                                       anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
+        if (rc) return rc;
+        o.in_ancestors = anc_t;
+      }
     }
-    int rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, logw, nullptr, nullptr, nullptr, nullptr, K,
-                                ws_run, need_run, stream, &o, &info);
-    if (rc) return rc;
+    if (rc != GJX_OK || t == 0) {
+      rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, lw_of(t), nullptr, nullptr, nullptr, nullptr, K,
+                              ws_of(t), need_run, stream, &o, &info);
+      if (rc) return rc;
+    }
     prev = info;
   }
-  // the record of the last step: its block pairs are still in the run workspace
-  return gjx_launch_lse_finish(ws_run + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);
+  // the record of the last step: its block pairs are still in its run workspace
+  return gjx_launch_lse_finish(ws_of(T - 1) + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);
 }

@@ -4,9 +4,9 @@ The reference supplies the ingredients and no filter: ``Scan.g
 (carry, out)`` T times, step t receiving the carry of step t-1, keys chained ``key_t = fold_in(key_{t-1}, t)``, weights added
 over steps (combinators/scan.py:237-294); ``Scan.edit_index`` / ``IndexRequest`` extend a trace by one step (scan.py:325-416).
 Here the unrolled trace of ``kernel.scan(n=T)`` is cut into T one-step programs — the sites of step t plus GJX_MODE_INPUT
-sites standing for the choices of step t-1 it reads — and the C loop ``gjx_scan_filter`` runs, per step, the tile-scaled
-systematic resampler's search and the step's generated propagate + reweight kernel, which reads its carry through the
-ancestors (include/gjx.h).  Periodic Scans give T-1 programs of one structure: one kernel is generated, only the tables
+sites standing for the choices of step t-1 it reads — and the C loop ``gjx_scan_filter`` runs, per step, the step's generated
+propagate + reweight kernel with the tile-scaled systematic resampler's search in its prologue (one launch per step; two where
+the kernel's shape does not allow it), reading its carry through the ancestors (include/gjx.h).  Periodic Scans give T-1 programs of one structure: one kernel is generated, only the tables
 (the step's observation) differ.
 """
 from __future__ import annotations
@@ -104,7 +104,9 @@ class ScanBootstrapFilter:
         f32 = torch.float32
         b = self._cache.get("bufs")
         if b is None or b["rows_a"].shape != (n_rows, K):
-            need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
+            # two run workspaces and a second log-weight buffer: the one-launch step (resampling in the generated kernel's
+            # prologue, include/gjx.h gjx_run_resample) alternates between them; OP_RUN + OP_RESAMPLE is the minimum
+            need = 2 * load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K) + 4 * K + 512
             b = self._cache["bufs"] = dict(rows_a=torch.empty((n_rows, K), dtype=f32, device=dev), rows_b=torch.empty((n_rows, K), dtype=f32, device=dev),
                                            logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))

@@ -293,10 +293,31 @@ int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64
  *     in_rows / in_stride / in_ancestors   the program's GJX_MODE_INPUT sites read in_rows[(obs_off + d) * in_stride + a(i)],
  *            a(i) = in_ancestors ? in_ancestors[i] : i — the particle gather of a resampling step (smc.py:90-91 applied to the
  *            carry) fused into the read side of the next propagate step: the resampled collection is never materialised.
+ *     resample (or NULL)   the tile-scaled systematic resampling of the PREVIOUS collection (GJX_WEIGHTS_TILE_SCALED, N = K) in
+ *            the prologue of this run's kernel: every block searches the ancestors of its own 1024 particles from the previous
+ *            log-weights and their tile totals (what gjx_resample_gather_tiled does with rows = 0 — one body, the same
+ *            ancestors bit for bit) and reads its GJX_MODE_INPUT rows through them — resampling, gather, propagate and reweight
+ *            of an SMC step in ONE plain launch.  logw / tile_S / tile_E / lse_partials: what the previous run left (its logw,
+ *            the tile totals and block pairs in ITS workspace — which must not be this run's workspace, nor logw this run's
+ *            logw: blocks of this launch still read them while others write); u: comb offset in [0, 1); lse_out f32[4] or NULL:
+ *            the previous run's LSE record, finished by one block; ancestors_out int32[K] or NULL; status_ws: a workspace whose
+ *            status word takes GJX_STATUS_ZERO_TOTAL.  Needs a generated kernel that gives a lane 4 particles, INPUT sites,
+ *            K % 1024 == 0, K <= 2^20 and in_rows (in_ancestors ignored); otherwise GJX_EUNSUPPORTED and nothing is launched.
  *   info_out (or NULL): n_partials = the block pairs left at workspace + 256 (the grid launched); tiles_offset = byte offset of
  *            the tile totals in the workspace (uint64 S[nt] then int32 E[nt], nt = K / 1024), 0 when none were left;
  *            engine = 0 interpreter, 1 hand-fused mixture kernel, 4 generated kernel. */
 enum { GJX_RUN_LEAVE_TILES = 1, GJX_RUN_TIME_DISPATCH = 2, GJX_RUN_STORE_INPUTS = 4 };
+typedef struct gjx_run_resample {
+  const float* logw;               /* f32[K]: log-weights of the collection being resampled */
+  const uint64_t* tile_S;          /* [K / 1024] */
+  const int32_t* tile_E;           /* [K / 1024] */
+  const float* lse_partials;       /* the producing run's block pairs (its workspace + 256) */
+  int32_t n_partials, pad_;
+  float* lse_out;                  /* f32[4] or NULL */
+  double u;
+  int32_t* ancestors_out;          /* int32[K] or NULL */
+  void* status_ws;                 /* workspace whose status word is written, or NULL */
+} gjx_run_resample;
 typedef struct gjx_run_opts {
   int32_t flags, pad_;
   void* start_event;
@@ -304,6 +325,7 @@ typedef struct gjx_run_opts {
   const float* in_rows;
   int64_t in_stride;
   const int32_t* in_ancestors;
+  const gjx_run_resample* resample;
 } gjx_run_opts;
 typedef struct gjx_run_info {
   int32_t n_partials, engine;
@@ -630,14 +652,17 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  *   kernel) that differ in their tables (the step's observation).  Keys: k_t = fold_in(k_{t-1}, t), (k_prop, k_res) =
  *   split(k_t); step t runs under k_prop with its sites numbered from 1 (INPUT sites take no number); systematic
  *   resampling (GJX_WEIGHTS_TILE_SCALED) with comb offset uniform(k_res) in front of every step t >= 1.
- * Per step two plain launches: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the
- * producing kernel) and the step's generated propagate + reweight kernel, which reads its carry THROUGH the ancestors
- * (the particle gather of smc.py:90-91 fused into the read side).  No co-resident grid, nothing to time out, any K <= 2^26.
+ * Per step ONE plain launch when the workspace has room for the alternating buffers (below), K % 1024 == 0, K <= 2^20 and
+ * the step's generated kernel gives a lane 4 particles: the kernel searches the ancestors of its own tile in its prologue
+ * (gjx_run_resample) and reads its carry THROUGH them (the particle gather of smc.py:90-91 fused into the read side).
+ * Otherwise two: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the producing
+ * kernel), then the step's kernel.  Same ancestors either way, bit for bit.  No co-resident grid, nothing to time out, any K <= 2^26.
  *   rows_a / rows_b f32[max_t n_slots][K]: choices of even / odd steps (the last step's end up in rows_[(T-1)&1]);
  *   logw f32[K] the last step's incremental log-weights; ancestors int32[K] scratch / the last resampling's ancestors;
  *   ancestors_all (or NULL) int32[T-1][K]: the ancestors of every resampling (trajectory reconstruction);
  *   lse_steps f32[T][4]: log-ML estimate = sum_t lse_steps[t][3];
- *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once. */
+ *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once; with
+ *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the one-launch step is used (a second run workspace and log-weight buffer). */
 int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                     float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
                     void* stream);

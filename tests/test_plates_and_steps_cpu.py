@@ -34,7 +34,8 @@ def _mixture(N):
 def test_abi7_structs():
     assert ctypes.sizeof(A.GjxParam) == 48 and ctypes.sizeof(A.GjxSite) == 240
     assert A.GjxSite.plate.offset == 32 and A.GjxSite.p.offset == 48 and A.GjxParam.d_off.offset == 28
-    assert ctypes.sizeof(A.GjxRunOpts) == 48 and ctypes.sizeof(A.GjxRunInfo) == 16
+    assert ctypes.sizeof(A.GjxRunOpts) == 56 and ctypes.sizeof(A.GjxRunInfo) == 16 and ctypes.sizeof(A.GjxRunResample) == 72
+    assert A.GjxRunResample.u.offset == 48 and A.GjxRunOpts.resample.offset == 48
     hdr = open(__file__.rsplit("/tests/", 1)[0] + "/include/gjx.h").read()
     assert "#define GJX_ABI_VERSION 7" in hdr and "GJX_MODE_INPUT = 4" in hdr and "GJX_STATUS_VERIFY_MISMATCH = 4" in hdr
 
