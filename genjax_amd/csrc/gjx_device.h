@@ -350,6 +350,25 @@ GJX_DEV float lbeta_f(float a, float b) {
   return lgammaf(lo) - lgamma_step(hi, lo);
 }
 
+// ---- gamma-family log-densities at large shape parameters.  a log z - z - lgamma(a) is a difference of terms of size a log a that
+// leaves O(1): in float32 the closed form is piecewise constant from a ~ 1e5 (steps of 0.25 at a = 1e7).  From a >= 8 the same
+// value in the deviance form  1/2 log a - 1/2 log 2 pi - S(a) + a (log1p(d) - d),  d = (z - a) / a,  S = Stirling's correction:
+// nothing large is subtracted — the caller forms z - a with ONE rounding (fma), log1p(d) - d comes from a series.
+// log1p(t) - t: below |t| = 1/4, log1p(t) = 2 atanh(s) with s = t / (2 + t), and 2 s - t = -s t exactly
+GJX_DEV float log1p_minus(float t) {
+  if (!(fabsf(t) < 0.25f)) return log1p_acc(t) - t;
+  const float s = t * fast_rcp(2.0f + t), s2 = s * s;
+  return fmaf(-s, t, 2.0f * s * s2 * (0.333333333f + s2 * (0.2f + s2 * (0.142857143f + s2 * (0.111111111f + s2 * 0.0909090909f)))));
+}
+GJX_DEV float stirling_corr(float a) {      // lgamma(a) - ((a - 1/2) log a - a + 1/2 log 2 pi), a >= 8
+  const float r = fast_rcp(a), r2 = r * r;
+  return r * (0.0833333333f - r2 * (2.7777778e-3f - r2 * 7.9365079e-4f));
+}
+// a log z - z - lgamma(a) for a >= 8; num = z - a
+GJX_DEV float gamma_kernel_big(float a, float num) {
+  return fmaf(a, log1p_minus(num * fast_rcp(a)), 0.5f * fast_log(a) - kHalfLog2Pi - stirling_corr(a));
+}
+
 // digamma: recurrence up to x >= 6, then the asymptotic series (|error| < 1e-6 for x > 1e-3)
 GJX_DEV float digamma_f(float x) {
   float acc = 0.0f;
@@ -428,7 +447,10 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
       const float rs = fast_rcp(b);
       return normal_logpdf(x, a, b) - fast_log(normal_interval_mass((c - a) * rs, (d - a) * rs));
     }
-    case GJX_POISSON: return (x < 0.0f || x != floorf(x)) ? -INFINITY : ((x == 0.0f ? 0.0f : x * fast_log(a)) - a - lgammaf(x + 1.0f));
+    case GJX_POISSON:
+      if (x < 0.0f || x != floorf(x)) return -INFINITY;
+      if (x >= 7.0f) return gamma_kernel_big(x + 1.0f, a - (x + 1.0f)) - fast_log(a);     // (x + 1) log a - a - lgamma(x + 1) - log a
+      return (x == 0.0f ? 0.0f : x * fast_log(a)) - a - lgammaf(x + 1.0f);
     case GJX_GEOMETRIC: return (x < 0.0f || x != floorf(x)) ? -INFINITY : ((x == 0.0f ? 0.0f : x * log1p_acc(-a)) + fast_log(a));
     case GJX_GUMBEL: {
       const float z = (x - a) * fast_rcp(b);
@@ -439,7 +461,9 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
       return x < a ? -INFINITY : (-0.451582705f /*log(2/pi)*/ - fast_log(b) - log1p_acc(z * z));
     }
     case GJX_INVERSE_GAMMA:  // a = concentration, b = scale
-      return x <= 0.0f ? -INFINITY : (a * fast_log(b) - lgammaf(a) - (a + 1.0f) * fast_log(x) - b * fast_rcp(x));
+      if (x <= 0.0f) return -INFINITY;
+      if (a >= 8.0f) return gamma_kernel_big(a, fmaf(-a, x, b) * fast_rcp(x)) - fast_log(x);   // z = b / x: a log z - z - lgamma(a) - log x
+      return a * fast_log(b) - lgammaf(a) - (a + 1.0f) * fast_log(x) - b * fast_rcp(x);
     case GJX_WEIBULL: {  // a = concentration k, b = scale
       if (x < 0.0f) return -INFINITY;
       const float lr = fast_log(x * fast_rcp(b));
@@ -452,7 +476,9 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
     }
     case GJX_CHI2: {  // a = df
       const float h = 0.5f * a;
-      return x <= 0.0f ? -INFINITY : (((h - 1.0f) == 0.0f ? 0.0f : (h - 1.0f) * fast_log(x)) - 0.5f * x - h * kLn2 - lgammaf(h));
+      if (x <= 0.0f) return -INFINITY;
+      if (h >= 8.0f) return gamma_kernel_big(h, 0.5f * (x - a)) - fast_log(x);                  // gamma(h, rate 1/2): z = x / 2
+      return ((h - 1.0f) == 0.0f ? 0.0f : (h - 1.0f) * fast_log(x)) - 0.5f * x - h * kLn2 - lgammaf(h);
     }
     case GJX_NORMAL:
     case GJX_MVNORMAL_DIAG: return normal_logpdf(x, a, b);
@@ -461,6 +487,16 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
     case GJX_BERNOULLI_LOGITS:
       return (x != 0.0f ? -softplus(-a) * x : 0.0f) + (x != 1.0f ? -softplus(a) * (1.0f - x) : 0.0f);
     case GJX_BETA: {
+      if (a >= 8.0f && b >= 8.0f && x > 0.0f && x < 1.0f) {
+        // both shapes large: (a - 1) log x + (b - 1) log(1 - x) and log B(a, b) are each of size n = a + b.  With the mode's
+        // neighbour p = a / n:  a log(x / p) + b log((1 - x) / (1 - p)) = a L(u) + b L(w),  L(t) = log1p(t) - t,  u = t_ / a,
+        // w = -t_ / b,  t_ = n x - a (the linear terms a u + b w cancel identically), and the rest of Stirling is O(log n).
+        // t_ = b x - a (1 - x) from two fused multiply-adds: the rounding of n = a + b (up to 16 at n = 3e8) never enters it
+        const float n = a + b, t_ = fmaf(b, x, fmaf(a, x, -a));
+        const float dev = fmaf(a, log1p_minus(t_ * fast_rcp(a)), b * log1p_minus(-t_ * fast_rcp(b)));
+        return dev + 0.5f * (fast_log(a) + fast_log(b) - fast_log(n)) - kHalfLog2Pi - stirling_corr(a) - stirling_corr(b) + stirling_corr(n)
+               - fast_log(x) - log1p_acc(-x);
+      }
       const float t1 = (a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * fast_log(x);
       const float t2 = (b - 1.0f) == 0.0f ? 0.0f : (b - 1.0f) * log1p_acc(-x);
       return t1 + t2 - lbeta_f(a, b);
@@ -481,6 +517,7 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
       return -(kLogPi + fast_log(b)) - log1p_acc(z * z);
     }
     case GJX_GAMMA: {
+      if (a >= 8.0f && x > 0.0f) return gamma_kernel_big(a, fmaf(b, x, -a)) - fast_log(x);     // z = b x: a log z - z - lgamma(a) - log x
       const float t0 = a == 0.0f ? 0.0f : a * fast_log(b);
       const float t1 = (a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * fast_log(x);
       return t0 + t1 - b * x - lgammaf(a);

@@ -66,10 +66,12 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
     memset(&o, 0, sizeof(o));
     o.flags = GJX_RUN_LEAVE_TILES;
     int rc = GJX_EUNSUPPORTED;
+    bool ran = false;
     if (t > 0) {
       if (input_rows(pr) > steps[t - 1].n_slots - input_rows(steps[t - 1]))
         return gjx_fail(GJX_EINVAL, "gjx_scan_filter: a step reads more carry rows than the step before it produced");
       const char* pws = ws_of(t - 1);
+      const float* lw_prev = lw_of(t - 1);
       const bool tiles = prev.tiles_offset != 0;
       const uint64_t* tS = tiles ? (const uint64_t*)(pws + prev.tiles_offset) : nullptr;
       const int32_t* tE = tiles ? (const int32_t*)(tS + (K / 1024)) : nullptr;
@@ -78,28 +80,26 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
       o.in_stride = K;
       if (fused && tiles) {
         memset(&rs, 0, sizeof(rs));
-        rs.logw = lw_of(t - 1); rs.tile_S = tS; rs.tile_E = tE; rs.lse_partials = (const float*)(pws + kWsHeaderBytes); rs.n_partials = prev.n_partials;
+        rs.logw = lw_prev; rs.tile_S = tS; rs.tile_E = tE; rs.lse_partials = (const float*)(pws + kWsHeaderBytes); rs.n_partials = prev.n_partials;
         rs.lse_out = lse_steps + 4 * (size_t)(t - 1); rs.u = us[t]; rs.ancestors_out = anc_t; rs.status_ws = ws_res;
         o.resample = &rs;
         rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, lw_of(t), nullptr, nullptr, nullptr, nullptr, K,
                                 ws_of(t), need_run, stream, &o, &info);
         o.resample = nullptr;
         if (rc != GJX_OK && rc != GJX_EUNSUPPORTED) return rc;
+        ran = rc == GJX_OK;
       }
-      if (rc != GJX_OK) {
-        if (fused && lw_of(t) != lw_of(t - 1)) {
-          // a step whose kernel cannot resample in its prologue: this step (and the rest) in the two-launch form, which keeps one
-          // buffer — the run continues on the buffers step t - 1 wrote
-          if (t > 1) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the steps' kernels differ in whether they can resample in their prologue");
-          fused = false;
-        }
-        rc = gjx_resample_gather_tiled(lw_of(t - 1), K, tS, tE, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
+      if (!ran) {
+        // a step whose kernel cannot resample in its prologue: this step and the rest in the two-launch form, which writes one
+        // buffer throughout (this step still reads what step t - 1 left where it left it)
+        fused = false;
+        rc = gjx_resample_gather_tiled(lw_prev, K, tS, tE, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
                                        anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
         if (rc) return rc;
         o.in_ancestors = anc_t;
       }
     }
-    if (rc != GJX_OK || t == 0) {
+    if (!ran) {
       rc = gjx_run_program_ex(&pr, keys[2 * t], keys[2 * t + 1], K, 0, out, nullptr, nullptr, lw_of(t), nullptr, nullptr, nullptr, nullptr, K,
                               ws_of(t), need_run, stream, &o, &info);
       if (rc) return rc;
