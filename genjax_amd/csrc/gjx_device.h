@@ -439,8 +439,10 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
   switch (kind) {
     case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
       const float y = (x - b) * fast_rcp(c);
-      return -0.5f * (a + 1.0f) * log1p_acc(y * y * fast_rcp(a)) - fast_log(c) - 0.5f * fast_log(a) - 0.5f * kLogPi +
-             lgamma_half_step(0.5f * a);
+      // log1p(y^2 / df): a draw with df << 1 reaches 1e30 and y^2 leaves float32 — there log(y^2 / df) stands for it (the 1 is below 1e-30 of it)
+      const float q = y * y * fast_rcp(a);
+      const float l1p = q < 1e30f ? log1p_acc(q) : 2.0f * fast_log(fabsf(y)) - fast_log(a);
+      return -0.5f * (a + 1.0f) * l1p - fast_log(c) - 0.5f * fast_log(a) - 0.5f * kLogPi + lgamma_half_step(0.5f * a);
     }
     case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
       if (x < c || x > d) return -INFINITY;

@@ -324,8 +324,12 @@ static float elem_logpdf4(int kind, float xf, float af, float bf, float cf, floa
   const double x = xf, a = af, b = bf, c = cf, d = df;
   switch (kind) {
     case GJX_STUDENT_T: { /* tfd.StudentT(df=a, loc=b, scale=c) */
-      double y = (x - b) / c;
-      return (float)(-0.5 * (a + 1.0) * log1p(y * y / a) - log(c) - 0.5 * log(a) - 0.5 * (double)LOG_PI + lgamma(0.5 * (a + 1.0)) - lgamma(0.5 * a));
+      double y = (x - b) / c, h = 0.5 * a, lgd;
+      /* lgamma(h + 1/2) - lgamma(h) on its own (added to the small terms one lgamma at a time, a df of 1e20 absorbs them: the result
+       * was exactly 0), and from the asymptotic series where the two values agree to within their own rounding */
+      if (h < 1e6) lgd = lgamma(h + 0.5) - lgamma(h);
+      else { double r = 1.0 / h; lgd = 0.5 * log(h) - r * (0.125 - r * r / 192.0); }
+      return (float)(-0.5 * (a + 1.0) * log1p(y * y / a) - log(c) - 0.5 * log(a) - 0.5 * (double)LOG_PI + lgd);
     }
     case GJX_TRUNCATED_NORMAL: { /* tfd.TruncatedNormal(loc=a, scale=b, low=c, high=d) */
       if (x < c || x > d) return -INFINITY;
