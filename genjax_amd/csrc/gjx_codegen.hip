@@ -1075,7 +1075,38 @@ struct HmcPlan {
   bool mfma = false;
   std::vector<int> mf_k, xt_off;
   int xt_floats = 0, block = 256;
+  // bernoulli(logits = X v + b) with every observation 0 or 1: rows of X (both copies) and the bias are folded with the sign
+  // s = 2 y - 1 and log2 e in the kernel's prologue — log p = log sigmoid(s a), d/da = s sigmoid(-s a): the element costs
+  // exp2, add, rcp and needs neither y nor a subtraction (what the hand-written k_hmc_logreg_mfma2 does for its one shape)
+  std::vector<char> fold;
+  std::vector<int> bs_off;         // the folded bias vector of a fold site, behind its transposed matrix
 };
+
+// may site j's matrix (parameter k) be folded with the observations' signs IN the kernel's LDS copy of the table?  A bernoulli-logits
+// site without a transform, observed from the table with values 0 / 1 only (the host copy of the table is read: the answer is part
+// of the kernel's cache key, hmc_variant), and a matrix no other parameter or observation of the program shares storage with
+bool hmc_fold_ok(const gjx_program* p, int j, int k) {
+  const gjx_site& s = p->sites[j];
+  if (getenv("GJX_HMC_GEN_NO_FOLD") || s.kind != GJX_BERNOULLI_LOGITS || k != 0 || s.p[0].xf != GJX_XF_NONE || s.slot >= 0 || s.mode != GJX_MODE_OBS_TAB || !p->tab) return false;
+  for (int d = 0; d < s.dim; ++d) { const float y = p->tab[s.obs_off + d]; if (y != 0.0f && y != 1.0f) return false; }
+  const int lo = s.p[0].moff, hi = lo + s.dim * s.p[0].n;
+  auto hits = [&](int a, int n) { return n > 0 && a < hi && a + n > lo; };
+  for (int jj = 0; jj < p->n_sites; ++jj) {
+    const gjx_site& t = p->sites[jj];
+    const int rows = is_categorical(t.kind) ? t.ncat : t.dim;
+    if (t.mode == GJX_MODE_OBS_TAB && hits(t.obs_off, is_categorical(t.kind) ? 1 : t.dim)) return false;
+    for (int kk = 0; kk < (is_categorical(t.kind) ? 1 : n_params(t.kind)); ++kk) {
+      const gjx_param& q = t.p[kk];
+      if (q.op == GJX_P_CONST && hits(q.off, q.len)) return false;
+      if (q.op == GJX_P_GATHER && hits(q.off, q.n * q.len)) return false;
+      if (q.op == GJX_P_AFFINE) {
+        if (hits(q.off, q.len)) return false;
+        if (!(jj == j && kk == k) && hits(q.moff, rows * q.n)) return false;
+      }
+    }
+  }
+  return true;
+}
 
 // a rolled site for the matrix cores: exactly one AFFINE parameter over n = 16, 32, 48 or 64 values with 16-byte aligned rows,
 // rows in multiples of 16
@@ -1123,16 +1154,21 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
   if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
   pl.mf_k.assign(p->n_sites, -1);
   pl.xt_off.assign(p->n_sites, 0);
+  pl.fold.assign(p->n_sites, 0);
+  pl.bs_off.assign(p->n_sites, 0);
   if (pl.looped && !getenv("GJX_HMC_GEN_NO_MFMA")) {
     const int tab_pad = (p->n_tab + 3) & ~3;
     for (int j = 0; j < p->n_sites; ++j) {
       const gjx_site& s = p->sites[j];
       const int k = hmc_mfma_param(s);
       if (k < 0) continue;
-      const int need = s.p[k].n * (s.dim + 4);
+      const bool fold = hmc_fold_ok(p, j, k);
+      const int need = s.p[k].n * (s.dim + 4) + (fold ? s.dim : 0);
       if (tab_pad + pl.xt_floats + need > 40000) continue;           // 160 KB of LDS: table + transposed matrices (+ nothing else)
       pl.mf_k[j] = k;
       pl.xt_off[j] = pl.xt_floats;
+      pl.fold[j] = fold ? 1 : 0;
+      pl.bs_off[j] = pl.xt_floats + s.p[k].n * (s.dim + 4);
       pl.xt_floats += need;
       pl.mfma = true;
     }
@@ -1237,9 +1273,11 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
   const gjx_param& q = s.p[k];
   const int n = q.n, NB = n / 16, dim = s.dim, LD = dim + 4;
   const int TB = dim % 64 == 0 ? 4 : (dim % 32 == 0 ? 2 : 1);
+  const bool fold = hp.fold[j] != 0;
   bool any_in = false;
   for (int e = 0; e < n; ++e) any_in = any_in || hp.sel_of_slot[q.slot + e] >= 0;
-  o.f("    // %d rows x %d inputs on the matrix cores, %d row tiles per trip\n", dim, n, TB);
+  o.f("    // %d rows x %d inputs on the matrix cores, %d row tiles per trip%s\n", dim, n, TB,
+      fold ? "; rows and bias carry the observation's sign and log2 e (folded in the prologue)" : "");
   o.f("    float bq_[%d][4];\n", NB);
   for (int b = 0; b < NB; ++b)
     for (int st = 0; st < 4; ++st) {
@@ -1253,7 +1291,8 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
   o.f("    _Pragma(\"nounroll\") for (int n0_ = 0; n0_ < %d; n0_ += %d) {\n", dim, 16 * TB);
   o.f("      v4f_ s_[%d], xa_[%d][%d];\n", TB, TB, NB);
   o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) {\n", TB);
-  if (q.len == 1) o.f("        { const float b0_ = TAB(%d); s_[t_] = v4f_{b0_, b0_, b0_, b0_}; }\n", q.off);
+  if (fold) o.f("        s_[t_] = *(const v4f_*)(xt_s + %d + n0_ + 16 * t_ + 4 * q_);\n", hp.bs_off[j]);
+  else if (q.len == 1) o.f("        { const float b0_ = TAB(%d); s_[t_] = v4f_{b0_, b0_, b0_, b0_}; }\n", q.off);
   else if ((q.off & 3) == 0) o.f("        s_[t_] = *(const v4f_*)&TAB(%d + n0_ + 16 * t_ + 4 * q_);\n", q.off);
   else o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) s_[t_][r_] = TAB(%d + n0_ + 16 * t_ + 4 * q_ + r_);\n", q.off);
   o.f("        _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) xa_[t_][b_] = *(const v4f_*)(xf_ + (n0_ + 16 * t_) * %d + 16 * b_);\n      }\n", NB, n);
@@ -1264,12 +1303,22 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
   if (any_in) o.f("      v4f_ xc_[%d][%d];\n      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) xc_[t_][b_] = *(const v4f_*)(xb_ + b_ * %d + n0_ + 16 * t_);\n",
                   TB, NB, TB, NB, 16 * LD);
   const bool y128 = s.slot < 0 && (s.obs_off & 3) == 0;
-  o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) {\n", TB);
-  if (y128) o.f("        const v4f_ y4_ = *(const v4f_*)&TAB(%d + n0_ + 16 * t_ + 4 * q_);\n", s.obs_off);
-  o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n          const int d_ = n0_ + 16 * t_ + 4 * q_ + r_; (void)d_;\n");
-  const HmcMf mf{k, "s_[t_][r_]", "s_[t_][r_]", y128 ? "y4_[r_]" : ""};
-  hmc_emit_element(o, prog, hp, j, "d_", true, "ga", "scp_", "          ", &mf);
-  o.f("        }\n      }\n      __builtin_amdgcn_sched_barrier(0);\n");
+  if (fold) {
+    // s_ = log2 e * s a: log p = -ln 2 * log2(1 + 2^(-s_)) (accumulated in log2 units), d log p / d(s a) = 1 / (1 + 2^(s_))
+    o.f("      if (SC) {\n        _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n"
+        "          const float m_ = -s_[t_][r_];\n          scp_ += fmaxf(m_, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(m_)));\n        }\n      }\n", TB);
+    o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) s_[t_][r_] = __builtin_amdgcn_exp2f(s_[t_][r_]);\n"
+        "      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) s_[t_][r_] = 1.0f + s_[t_][r_];\n"
+        "      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) s_[t_][r_] = fast_rcp(s_[t_][r_]);\n"
+        "      __builtin_amdgcn_sched_barrier(0);\n", TB, TB, TB);
+  } else {
+    o.f("      _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) {\n", TB);
+    if (y128) o.f("        const v4f_ y4_ = *(const v4f_*)&TAB(%d + n0_ + 16 * t_ + 4 * q_);\n", s.obs_off);
+    o.f("        _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) {\n          const int d_ = n0_ + 16 * t_ + 4 * q_ + r_; (void)d_;\n");
+    const HmcMf mf{k, "s_[t_][r_]", "s_[t_][r_]", y128 ? "y4_[r_]" : ""};
+    hmc_emit_element(o, prog, hp, j, "d_", true, "ga", "scp_", "          ", &mf);
+    o.f("        }\n      }\n      __builtin_amdgcn_sched_barrier(0);\n");
+  }
   if (any_in)
     o.f("      _Pragma(\"unroll\") for (int r_ = 0; r_ < 4; ++r_) _Pragma(\"unroll\") for (int t_ = 0; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_)\n"
         "        gacc_[t_][b_] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc_[t_][b_][r_], s_[t_][r_], gacc_[t_][b_], 0, 0, 0);\n      __builtin_amdgcn_sched_barrier(0);\n", TB, NB);
@@ -1279,7 +1328,7 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
     o.f("    _Pragma(\"unroll\") for (int t_ = 1; t_ < %d; ++t_) _Pragma(\"unroll\") for (int b_ = 0; b_ < %d; ++b_) gacc_[0][b_] += gacc_[t_][b_];\n", TB, NB);
     for (int e = 0; e < n; ++e) {
       const int m = hp.sel_of_slot[q.slot + e];
-      if (m >= 0) o.f("    g[%d] += __shfl(gacc_[0][%d][%d], c16_ + %d, 64);\n", m, e / 16, e % 4, 16 * ((e % 16) / 4));
+      if (m >= 0) o.f("    g[%d] += %s__shfl(gacc_[0][%d][%d], c16_ + %d, 64);\n", m, fold ? "kLn2 * " : "", e / 16, e % 4, 16 * ((e % 16) / 4));
     }
   }
   std::vector<char> touched(hp.nsel, 0);
@@ -1287,8 +1336,8 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
     const gjx_param& qq = s.p[kk];
     if (kk != k && qq.op == GJX_P_VALUE && hp.sel_of_slot[qq.slot] >= 0) touched[hp.sel_of_slot[qq.slot]] = 1;
   }
-  for (int m = 0; m < hp.nsel; ++m) if (touched[m]) o.f("    g[%d] += QSUM(ga[%d]);\n", m, m);
-  o.f("    if (SC) sc_ += QSUM(scp_);\n");
+  for (int m = 0; m < hp.nsel; ++m) if (touched[m] && !fold) o.f("    g[%d] += QSUM(ga[%d]);\n", m, m);
+  o.f("    if (SC) sc_ += %sQSUM(scp_);\n", fold ? "-kLn2 * " : "");
 }
 
 std::string generate_hmc(const gjx_program* prog) {
@@ -1360,6 +1409,16 @@ std::string generate_hmc(const gjx_program* prog) {
     if (hp.mf_k[j] < 0) continue;
     const gjx_site& s = prog->sites[j];
     const gjx_param& q = s.p[hp.mf_k[j]];
+    if (hp.fold[j]) {
+      // the LDS copy of the matrix takes the sign of its row's observation and log2 e IN PLACE (no other parameter shares the
+      // storage: hmc_fold_ok), then the transposed copy and the bias vector are made from it
+      o.f("  __syncthreads();\n  for (int t = threadIdx.x; t < %d; t += BT) tab_s[%d + t] *= (2.0f * tab_s[%d + t / %d] - 1.0f) * 1.44269504f;   // site %d: rows folded\n",
+          q.n * s.dim, q.moff, s.obs_off, q.n, j);
+      o.f("  for (int t = threadIdx.x; t < %d; t += BT) xt_s[%d + t] = (2.0f * tab_s[%d + t] - 1.0f) * 1.44269504f * tab_s[%d + %s];\n",
+          s.dim, hp.bs_off[j], s.obs_off, q.off, q.len == 1 ? "0" : "t");
+      o.f("  __syncthreads();\n  for (int t = threadIdx.x; t < %d; t += BT) { const int k_ = t / %d, r_ = t - k_ * %d; xt_s[%d + k_ * %d + r_] = tab_s[%d + r_ * %d + k_]; }\n",
+          q.n * s.dim, s.dim, s.dim, hp.xt_off[j], s.dim + 4, q.moff, q.n);
+    } else
     o.f("  for (int t = threadIdx.x; t < %d; t += BT) { const int k_ = t / %d, r_ = t - k_ * %d; xt_s[%d + k_ * %d + r_] = a.tab[%d + r_ * %d + k_]; }   // site %d: X transposed\n",
         q.n * s.dim, s.dim, s.dim, hp.xt_off[j], s.dim + 4, q.moff, q.n, j);
   }
@@ -1524,6 +1583,10 @@ int register_slots(const gjx_program* p) {
 
 uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // flavour 0: propagate+reweight kernel, 1: HMC kernel
   uint64_t h = sites_hash(p);
+  if (flavour == 1) {   // the HMC emitter's data-dependent choice (hmc_fold_ok reads the observations): part of the kernel's identity
+    HmcPlan hp;
+    if (hmc_plan(p, &hp)) h = fnv1a(hp.fold.data(), hp.fold.size(), h);
+  }
   const int32_t extra[8] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour,
                             (getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0) ^
                                 (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
