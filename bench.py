@@ -965,9 +965,9 @@ def _kalman_log_lik(A_, y, q, r, q0):
 
 
 def run_round4(dev):
-    """Round-4 paths, short runs: (1) the bootstrap filter for ANY Scan kernel (gjx_scan_filter: two plain launches per step,
-    ancestor gather fused into the generated propagate kernel) on config 3's model written as @gen + .scan, next to the
-    hand-written one-launch filter, and on a stochastic-volatility model; (2) a vmapped mixture (N = 4096 data: two plate-tagged
+    """Round-4 paths, short runs: (1) the bootstrap filter for ANY Scan kernel (gjx_scan_filter: one plain launch per step —
+    resampling search, ancestor gather, propagate, reweight in the step's generated kernel) on config 3's model written as
+    @gen + .scan, next to the hand-written one-launch filter at 2^18 and 2^20 particles, and on a stochastic-volatility model; (2) a vmapped mixture (N = 4096 data: two plate-tagged
     device sites, one instance loop) on its generated kernel and on the site interpreter."""
     import genjax_amd as genjax
     from genjax_amd import C as CM
@@ -996,25 +996,28 @@ def run_round4(dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n, float(out["log_ml"])
 
-    bf = BootstrapFilter(lg_step.scan(n=T), K)
-    dt, lml = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None))
-    hand = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], q0=q), K, weights="tile_scaled")
-    ys_d = torch.as_tensor(s["y"], device=dev)
-    for i in range(3):
-        hand.run(genjax.key(i), ys_d, device=dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(5):
-        hand.run(genjax.key(10 + i), ys_d, device=dev)
-    torch.cuda.synchronize()
-    dth = (time.perf_counter() - t0) / 5
     exact = _kalman_log_lik(s["A"], s["y"], q, r, q)          # float64 closed form (x_0 ~ N(0, q^2 I): the Scan's step 0)
-    res["scan_filter_lgssm_d8_T256_K2e18"] = dict(us_per_step=dt / T * 1e6, particle_steps_per_sec=K * T / dt, log_ml=lml,
-                                                  log_ml_rel_err=abs(lml - exact) / abs(exact), launches_per_step=2,
-                                                  hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
-                                                  algorithmic_bytes_per_particle_step=8 * dx + 24,
-                                                  achieved_GBs=(8 * dx + 24) * K / (dt / T) / 1e9, frac_of_hbm=(8 * dx + 24) * K / (dt / T) / 1e9 / HBM_PEAK_GBS,
-                                                  engine="gjx_gen (generated, INPUT rows through the ancestors) + k_resample_gather_tiled<rows = 0>")
+    ys_d = torch.as_tensor(s["y"], device=dev)
+    two_launch = bool(int(os.environ.get("GJX_SCAN_FILTER_TWO_LAUNCH", "0") or 0))
+    for Kf, tag in ((K, "2e18"), (1 << 20, "2e20")):
+        bf = BootstrapFilter(lg_step.scan(n=T), Kf)
+        dt, lml = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=5 if Kf == K else 3)
+        hand = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], q0=q), Kf, weights="tile_scaled")
+        for i in range(3):
+            hand.run(genjax.key(i), ys_d, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            hand.run(genjax.key(10 + i), ys_d, device=dev)
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t0) / 5
+        res[f"scan_filter_lgssm_d8_T256_K{tag}"] = dict(
+            us_per_step=dt / T * 1e6, particle_steps_per_sec=Kf * T / dt, log_ml=lml, log_ml_rel_err=abs(lml - exact) / abs(exact),
+            launches_per_step=2 if two_launch else 1, hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
+            algorithmic_bytes_per_particle_step=8 * dx + 24, achieved_GBs=(8 * dx + 24) * Kf / (dt / T) / 1e9,
+            frac_of_hbm=(8 * dx + 24) * Kf / (dt / T) / 1e9 / HBM_PEAK_GBS,
+            engine=("k_resample_gather_tiled<rows = 0> + gjx_gen (generated, INPUT rows through the ancestors)" if two_launch else
+                    "gjx_gen: the tile-scaled resampler's search in the prologue of the step's generated kernel (gjx_run_resample), INPUT rows through the ancestors"))
     with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
         fx = json.load(f)
     phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
