@@ -656,7 +656,7 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  * the step's generated kernel gives a lane 4 particles: the kernel searches the ancestors of its own tile in its prologue
  * (gjx_run_resample) and reads its carry THROUGH them (the particle gather of smc.py:90-91 fused into the read side).
  * Otherwise two: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the producing
- * kernel), then the step's kernel.  Same ancestors either way, bit for bit.  No co-resident grid, nothing to time out, any K <= 2^26.
+ * kernel), then the step's kernel (GJX_SCAN_FILTER_TWO_LAUNCH=1 forces this form).  Same ancestors either way, bit for bit.  No co-resident grid, nothing to time out, any K <= 2^26.
  *   rows_a / rows_b f32[max_t n_slots][K]: choices of even / odd steps (the last step's end up in rows_[(T-1)&1]);
  *   logw f32[K] the last step's incremental log-weights; ancestors int32[K] scratch / the last resampling's ancestors;
  *   ancestors_all (or NULL) int32[T-1][K]: the ancestors of every resampling (trajectory reconstruction);
@@ -772,7 +772,11 @@ int gjx_peer_resample_gather(gjx_peer_ctx* ctx, int32_t parity, const float* par
  */
 size_t gjx_hmc_workspace_bytes(const gjx_program* prog, int64_t n);
 /* which engine gjx_hmc will use: 0 = generic site interpreter, 2 / 3 = fused hierarchical-logistic-regression kernels (vector /
- * matrix-core), 4 = a kernel generated from the site list; GJX_HMC_ENGINE = auto | fused | gen | interp restricts the choice */
+ * matrix-core), 4 = a kernel generated from the site list; GJX_HMC_ENGINE = auto | fused | gen | interp restricts the choice.
+ * A generated kernel runs both contractions of a rolled site with an affine parameter (n = 16 .. 64 inputs, rows a multiple of
+ * 16: the likelihood of a regression) on the matrix cores, and folds 0 / 1 observations of a bernoulli-logits site into its
+ * copies of the matrix; profiling variants of the emitter: GJX_HMC_GEN_NO_MFMA=1 (scalar rolled loop), GJX_HMC_GEN_NO_FOLD=1,
+ * GJX_HMC_GEN_BT=256|512|1024 (threads per block).  Plate-tagged and GJX_MODE_INPUT sites: GJX_EUNSUPPORTED (gjx_score_grad too). */
 int gjx_hmc_engine(const gjx_program* prog);
 int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
