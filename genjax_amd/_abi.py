@@ -155,6 +155,7 @@ PROTOTYPES = {
     "gjx_ssm_filter_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp,
                                       C.c_size_t, vp]),
     "gjx_scan_filter": (C.c_int, [vp, i32, u32, u32, i64, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_scan_filter_history": (C.c_int, [vp, i32, u32, u32, i64, vp, i32, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),

@@ -22,11 +22,11 @@
 
 using namespace gjx;
 
-extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
-                               float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-  if (!steps || T < 1 || K <= 0 || !rows_a || !rows_b || !logw || !ancestors || !lse_steps)
-    return gjx_fail(GJX_EINVAL, "gjx_scan_filter: bad argument");
+// rows_of(t): the buffer step t writes its choices into (two alternating buffers, or one per step when the run is recorded)
+template <class RowsOf>
+static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, RowsOf&& rows_of,
+                            float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   const size_t need_run = gjx_workspace_bytes(GJX_OP_RUN, K), need_res = gjx_workspace_bytes(GJX_OP_RESAMPLE, K);
   if (!workspace || workspace_bytes < need_run + need_res) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter: workspace too small (OP_RUN + OP_RESAMPLE)");
   char* ws_run = (char*)workspace;
@@ -61,8 +61,8 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
   auto ws_of = [&](int t) { return (fused && ((T - 1 - t) & 1)) ? ws_run2 : ws_run; };
   for (int t = 0; t < T; ++t) {
     const gjx_program& pr = steps[t];
-    float* out = (t & 1) ? rows_b : rows_a;
-    const float* in = (t & 1) ? rows_a : rows_b;
+    float* out = rows_of(t);
+    const float* in = t > 0 ? rows_of(t - 1) : nullptr;
     memset(&o, 0, sizeof(o));
     o.flags = GJX_RUN_LEAVE_TILES;
     int rc = GJX_EUNSUPPORTED;
@@ -108,4 +108,27 @@ extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key
   }
   // the record of the last step: its block pairs are still in its run workspace
   return gjx_launch_lse_finish(ws_of(T - 1) + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);
+}
+
+extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
+                               float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!steps || T < 1 || K <= 0 || !rows_a || !rows_b || !logw || !ancestors || !lse_steps)
+    return gjx_fail(GJX_EINVAL, "gjx_scan_filter: bad argument");
+  return scan_filter_impl(steps, T, key0, key1, K, [&](int t) { return (t & 1) ? rows_b : rows_a; }, logw, ancestors, ancestors_all, lse_steps,
+                          workspace, workspace_bytes, stream);
+}
+
+// the same run with the choices of EVERY step kept (rows_all f32[T][rows_per_step][K]) and every resampling's ancestors: what a
+// trajectory reconstruction needs (the reference's ScanTrace stacks the whole trace per particle, scan.py:56-97)
+extern "C" int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_all,
+                                       int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  if (!steps || T < 1 || K <= 0 || !rows_all || rows_per_step < 1 || !logw || (T > 1 && !ancestors_all) || !lse_steps)
+    return gjx_fail(GJX_EINVAL, "gjx_scan_filter_history: bad argument");
+  for (int t = 0; t < T; ++t)
+    if (steps[t].n_slots > rows_per_step) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_history: a step has more rows than rows_per_step");
+  int32_t* anc = ancestors_all ? ancestors_all : (int32_t*)rows_all;     // (T == 1: never written)
+  return scan_filter_impl(steps, T, key0, key1, K, [&](int t) { return rows_all + (size_t)t * (size_t)rows_per_step * (size_t)K; }, logw, anc,
+                          ancestors_all, lse_steps, workspace, workspace_bytes, stream);
 }

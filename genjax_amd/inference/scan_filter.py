@@ -86,9 +86,11 @@ class ScanBootstrapFilter:
             prev_latent, known = latent, now_known
         return progs
 
-    def run(self, key: Key, constraint: ChoiceMap, args=(None, None), device=None, keep_ancestors: bool = False):
+    def run(self, key: Key, constraint: ChoiceMap, args=(None, None), device=None, keep_ancestors: bool = False, keep_history: bool = False):
         """-> dict(log_ml, increments f32[T], choices f32[n_slots][K] of the last step (its INPUT rows unused), logw,
-        programs, ancestors (the last resampling's, or int32[T-1][K] with keep_ancestors), degenerate)"""
+        programs, ancestors (the last resampling's, or int32[T-1][K] with keep_ancestors), degenerate).
+        ``keep_history``: every step's choices and every resampling's ancestors are kept (gjx_scan_filter_history) and
+        ``out["history"]`` (a ScanHistory) reconstructs trajectories from them."""
         from .. import kernels
         dev = kernels._dev(device)
         ck = (tuple(sorted((repr(a), np.asarray(kernels_np(v)).tobytes()) for a, v in constraint._d.items())), repr(args), str(dev))
@@ -111,6 +113,16 @@ class ScanBootstrapFilter:
                                            logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))
         lse = torch.empty((T, 4), dtype=f32, device=dev)
+        if keep_history:
+            rows_all = torch.empty((T, n_rows, K), dtype=f32, device=dev)
+            anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev)
+            check(load().gjx_scan_filter_history(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(rows_all), n_rows, kernels._ptr(b["logw"]),
+                                                 kernels._ptr(anc_all), kernels._ptr(lse), kernels._ptr(b["ws"]), b["ws"].numel(), kernels._stream()),
+                  "gjx_scan_filter_history")
+            incs = lse[:, 3]
+            hist = ScanHistory(progs, rows_all, anc_all[: T - 1], b["logw"])
+            return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=b["logw"],
+                        programs=progs, ancestors=anc_all[: T - 1], history=hist)
         anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev) if keep_ancestors else None
         check(load().gjx_scan_filter(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(b["rows_a"]), kernels._ptr(b["rows_b"]),
                                      kernels._ptr(b["logw"]), kernels._ptr(b["anc"]), kernels._ptr(anc_all), kernels._ptr(lse),
@@ -128,6 +140,48 @@ class ScanBootstrapFilter:
             if _name(s.addr) == name and p.modes.get(s.addr) != A.MODE_INPUT and p.slot_of[s.addr] >= 0:
                 return out["choices"][p.slot_of[s.addr]: p.slot_of[s.addr] + s.dim]
         raise KeyError(name)
+
+
+class ScanHistory:
+    """Record of a filter run over a Scan: the choices of every step (SoA rows of the step's program) and the ancestors of every
+    resampling.  The reference's ScanTrace stacks the whole trace per particle and a resampling gathers whole traces
+    (scan.py:56-97); here the trajectory that ends in particle i of the last step is read back lazily: i_{t-1} =
+    ancestors[t-1][i_t], one row gather per step."""
+
+    def __init__(self, programs, rows_all, ancestors, logw):
+        self.programs, self.rows_all, self.ancestors, self.logw = programs, rows_all, ancestors, logw
+
+    def __len__(self):
+        return len(self.programs)
+
+    def _rows_of(self, t, name):
+        p = self.programs[t]
+        for s in p.site_list.sites:
+            if _name(s.addr) == name and p.modes.get(s.addr) != A.MODE_INPUT and p.slot_of[s.addr] >= 0:
+                return p.slot_of[s.addr], s.dim
+        raise KeyError(name)
+
+    def step(self, t, name) -> torch.Tensor:
+        """the particles of step t as propagated (before the next resampling): f32[dim][K]"""
+        r0, d = self._rows_of(t, name)
+        return self.rows_all[t, r0:r0 + d]
+
+    def paths(self, name, idx=None) -> torch.Tensor:
+        """-> f32[T][dim][n]: the trajectories of choice ``name`` that end in particles ``idx`` (default: all) of the last step"""
+        T = len(self.programs)
+        K = self.rows_all.shape[2]
+        cur = torch.arange(K, device=self.rows_all.device) if idx is None else idx.to(torch.int64)
+        out = [None] * T
+        for t in range(T - 1, -1, -1):
+            out[t] = self.step(t, name)[:, cur]
+            if t > 0:
+                cur = self.ancestors[t - 1][cur].to(torch.int64)
+        return torch.stack(out)
+
+    def smoothed_means(self, name) -> torch.Tensor:
+        """E[x_t | y_{1:T}] from the reconstructed trajectories, weighted by the last step's weights: f32[T][dim]"""
+        w = torch.softmax(self.logw.double(), dim=0)
+        return (self.paths(name).double() * w).sum(dim=2).float()
 
 
 def _name(addr):

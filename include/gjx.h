@@ -666,6 +666,14 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
 int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                     float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* The same run with the choices of EVERY step kept: rows_all f32[T][rows_per_step][K] (step t's program writes its rows into
+ * block t, rows_per_step >= every step's n_slots) and ancestors_all int32[T-1][K] (required for T > 1).  The trajectory that
+ * ends in particle i of the last step is read back by following the ancestors: i_{t-1} = ancestors_all[t-1][i_t] — one row
+ * gather per step instead of the reference's stacked per-particle trace (ScanTrace, scan.py:56-97, re-gathered whole at every
+ * resampling).  Everything else as gjx_scan_filter. */
+int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_all,
+                            int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* The same filter on a collection sharded over the ranks of a shard context, BASELINE config 4: every rank
  * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles
