@@ -68,6 +68,10 @@ json.dump(util, open("$OUT/${TAG}_valu_utilisation.json", "w"), indent=1)
 PY
 fi
 if echo $WL | grep -q hmc; then bash $R/profiles/hmc_pmc.sh $TAG > /dev/null 2>&1; fi
+# the generic Scan filter alone (config 3's model as @gen + .scan, K = 2^18, T = 256): its step IS one launch of gjx_gen
+python $R/profiles/microbench/scan_filter_run.py 2>/dev/null | grep "us per step" > $OUT/${TAG}_scan_filter_kernel_stats.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scanf -o scanf -- python $R/profiles/microbench/scan_filter_run.py > /dev/null 2>&1
+grep -E "Name|gjx" $(find $OUT/prof_scanf -name "*kernel_stats.csv" | head -1) >> $OUT/${TAG}_scan_filter_kernel_stats.txt
 GJX_SSM_PERSISTENT=0 python $R/profiles/microbench/ssm_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_ssm_step_timeline.txt
 python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_ssm_persistent_timeline.txt
 SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
