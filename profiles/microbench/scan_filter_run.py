@@ -1,7 +1,7 @@
 """the generic Scan filter on config 3's model, a few runs (for rocprofv3 --kernel-trace --stats)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, torch
 import genjax_amd as genjax
 from genjax_amd import C, workloads
