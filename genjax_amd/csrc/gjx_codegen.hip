@@ -858,7 +858,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   pl.prog = prog;
   pl.ppt = ppt;
   pl.mfma = mfma;
-  pl.tab_lds = mfma || prog->n_tab <= kMaxLdsTab;
+  pl.tab_lds = mfma || (prog->n_tab <= kMaxLdsTab && !getenv("GJX_GEN_TAB_GLOBAL"));   // (the variable: profiling variant, part of the cache key)
   if (roll.ok) {
     pl.info = roll.info;
     unsigned plain = 0;
@@ -1623,7 +1623,8 @@ uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // fl
   const int32_t extra[8] = {p->n_sites, p->n_slots, p->n_tab, p->rng_mode, ppt, want_roll() ? 1 : 0, flavour,
                             (getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0) ^
                                 (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
-                                (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0)};
+                                (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0) ^ (getenv("GJX_GEN_TAB_GLOBAL") ? 1 << 24 : 0) ^
+                                (getenv("GJX_GEN_NO_HOIST") ? 1 << 25 : 0)};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);

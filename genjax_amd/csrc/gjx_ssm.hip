@@ -11,6 +11,14 @@
 #include "gjx_tile.h"
 #include "gjx_pfilter_host.h"
 #include <string.h>
+// pollers per granule in the one-launch filter's rendezvous (tile-scaled scheme, up to 256 blocks) and the stagger between their
+// first looks in units of s_sleep (64 cycles): see k_ssm_persistent
+#ifndef GJX_POLLERS
+#define GJX_POLLERS 4
+#endif
+#ifndef GJX_POLL_STAGGER
+#define GJX_POLL_STAGGER 12
+#endif
 #include <vector>
 
 namespace gjx {
@@ -477,6 +485,11 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
   __shared__ double sU;
   __shared__ uint32_t sKey[2][2];
   __shared__ int s_range[2];
+  // TILED, nb <= 256: every granule has kPollers pollers — lanes b, b + 256, ... of the block — whose loads leave a quarter of a
+  // round trip apart; whoever sees the tag first publishes the granule in LDS and sets seen[b], the others leave their loop at their
+  // next look.  A poll is one fabric round trip (~1.7 us): with one poller a block learns of the last granule up to a round trip
+  // after it landed, and that block is then the last to publish in the NEXT step — the skew feeds itself.
+  __shared__ unsigned seen[256];
   for (int e = threadIdx.x; e < DX * DX; e += THREADS) sA[e] = f.A[e];
   if (f.H) for (int e = threadIdx.x; e < f.dy * DX; e += THREADS) sH[e] = f.H[e];
   const unsigned epoch = __hip_atomic_load(&f.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -675,6 +688,9 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       }
       GJX_PSTAMP(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      constexpr int kPollers = (THREADS == 1024 && GJX_POLLERS > 1) ? GJX_POLLERS : 1;
+      const bool multi = kPollers > 1 && nb <= 256;                      // block-uniform
+      if (multi && threadIdx.x < 256) seen[threadIdx.x] = 0u;           // (the previous step's pollers are barriers behind; this step's start behind the next barrier)
       // the record of step t-2 if this block is its finisher: its ring entries were complete before the `ready` words
       // this block checked in step t-1; the loads go out here and are consumed behind the draws
       const bool fin = t >= 2 && (int)blockIdx.x == (t - 2) % nb;
@@ -697,7 +713,47 @@ __global__ __launch_bounds__(THREADS) void k_ssm_persistent(SsmPersistArgs f) {
       if (t < T) ssm_noise_bits<RNG, DX>(key2{sKey[t & 1][0], sKey[t & 1][1]}, (uint64_t)j, nbits);
       if (fin) lse_ring_reduce(rpm, rps);
       GJX_PSTAMP(2);
-      {
+      if (multi) {
+        unsigned budget = kPollBudget;
+        float em = (float)kTileDead;
+        const int b = threadIdx.x & 255, grp = threadIdx.x >> 8;
+        if (b < nb && grp < kPollers) {
+          unsigned long long v = gv[0];
+          if (grp > 0) {                                  // the later pollers: first look a fraction of a round trip behind the one before
+            v = 0ull;
+            __builtin_amdgcn_s_sleep(1);
+            for (int w = 0; w < grp; ++w) __builtin_amdgcn_s_sleep(GJX_POLL_STAGGER);
+            if (!__hip_atomic_load(&seen[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+              v = __hip_atomic_load(&agg[(size_t)b * kGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          bool other = false;
+          while ((v >> 60) != tag && budget) {
+            if (__hip_atomic_load(&seen[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { other = true; break; }
+            --budget;
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&agg[(size_t)b * kGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if ((v >> 60) == tag) {
+            const uint64_t S = v & ((1ull << 40) - 1);
+            const int e = S ? (int)((v >> 40) & 0xFFFFFu) + kTileDead : kTileDead;
+            P[b + 1] = S;
+            Eb[b] = e;
+            em = (float)e;
+            __hip_atomic_store(&seen[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else if (!other && grp == 0) {                // (only the first poller reports: it runs the whole budget)
+            __hip_atomic_fetch_or(&f.ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            P[b + 1] = 0;
+            Eb[b] = kTileDead;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+          const int bb = threadIdx.x + k * THREADS;
+          rdy[k] = bb < nb ? __hip_atomic_load(&f.ready[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rtag;
+        }
+        em = wave_max_dpp(em);
+        if (lane == 0) fred[wid] = em;
+      } else {
         unsigned budget = kPollBudget;
         float em = (float)kTileDead;
 #pragma unroll
