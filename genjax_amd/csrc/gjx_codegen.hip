@@ -139,11 +139,6 @@ struct Plan {
   std::vector<SiteStream> stream;   // per emitted site
   std::vector<RollInfo> info;       // per emitted site
   std::string key_decls;            // definitions of the chained step keys, in order
-  // kernels that resample in their prologue (gjx_run_resample): the standard-normal draws of sampled normal sites do not depend
-  // on the carry, so they are taken IN FRONT of the search — their hashes and Box-Muller evaluations fill the search's memory
-  // waits (a block is one tile and a CU holds one or two blocks: nothing else would) — and the site uses them from registers
-  std::vector<char> hoist;
-  std::string hoist_code;
   std::vector<Companion> comps;
   int comp_floats = 0;
   int find(int kind, int off, int n, int len = 0, int dim = 0) {
@@ -684,8 +679,6 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // member of a scalar-normal run: the run's stream lives OUTSIDE the site's block (declared by the head, in the
     // enclosing scope), members 2k and 2k+1 share one Box-Muller evaluation through its pair cache
     o.f("      BitStream<RNG> (&bs)[PPT] = rs%d;\n", ss.run);
-  } else if (draws && pl.hoist[j]) {
-    // (the draws were taken at the top of the tile: pl.hoist_code)
   } else if (draws) {
     if (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", ss.site_no);
     else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", ss.key_var.c_str(), ss.site_no);
@@ -787,10 +780,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (logb.empty()) logb = "fast_log(pb)";
         if (rcpb.empty()) rcpb = "fast_rcp(pb)";
         o.f("%sfloat val;\n", in2.c_str());
-        if (mode == GJX_MODE_SAMPLE && pl.hoist[j]) {
-          o.f("%sconst float n_ = zh%d[%s][p];\n", in2.c_str(), j, dx.c_str());
-          o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
-        } else if (mode == GJX_MODE_SAMPLE) {
+        if (mode == GJX_MODE_SAMPLE) {
           o.f("%sconst float n_ = stream_normal<RNG>(bs[p], %s + (uint32_t)(%u + (%s)));\n", in2.c_str(), ebase.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
           o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
@@ -904,28 +894,6 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     int n_runs = 0;
     assign_runs(prog, pl.stream, 0, prog->n_sites, n_runs);
   }
-  pl.hoist.assign(prog->n_sites, 0);
-  {
-    bool has_input = false;
-    for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
-    if (has_input && ppt == 4 && !roll.ok && !getenv("GJX_GEN_NO_HOIST")) {
-      Emit h, hd;
-      int regs = 0;
-      for (int j = 0; j < prog->n_sites; ++j) {
-        const gjx_site& s = prog->sites[j];
-        const SiteStream& ss = pl.stream[j];
-        if (s.mode != GJX_MODE_SAMPLE || !is_normal(s.kind) || pl.info[j].plate || ss.run >= 0 || s.dim > kMaxExpandDim || regs + s.dim > 24) continue;
-        pl.hoist[j] = 1;
-        regs += s.dim;
-        hd.f("    float zh%d[%d][PPT];\n", j, s.dim);
-        h.f("      { BitStream<RNG> bs[PPT];\n        PLOOP bs[p].open(%s, gidx[p], %du);\n", 
-            (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) ? "a.key" : ss.key_var.c_str(), ss.site_no);
-        for (int d = 0; d < s.dim; ++d) h.f("        PLOOP zh%d[%d][p] = stream_normal<RNG>(bs[p], %uu);\n", j, d, (unsigned)d);
-        h.f("      }\n");
-      }
-      pl.hoist_code = hd.s + "    auto hoist_ = [&]() {\n" + h.s + "    };\n";
-    }
-  }
   Emit body;
   if (roll.ok) {
     auto carry = [&]() {   // the step just produced becomes the previous step
@@ -1030,16 +998,15 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
     if (has_input) o.f("    int64_t src_[PPT];\n    PLOOP src_[p] = a.anc ? (int64_t)a.anc[i0 + p] : i0 + p;\n");
-    if (has_input && ppt == 4) o.f("%s", pl.hoist_code.c_str());
     if (has_input && ppt == 4)
       // gjx_run_resample: the search of the tile-scaled systematic resampler for this block's tile, in front of the reads of the
       // carry (tiled_search_tile, gjx_tile.h: the body of k_resample_gather_tiled) — resample + gather + propagate + reweight in one launch
       o.f("    if (a.rs_logw) {\n      __shared__ TiledSearchShared rs_sh_;\n      __shared__ uint64_t rs_pl_[1026];\n      __shared__ int32_t rs_eb_[1024];\n"
           "      int32_t anc_[4];\n      __syncthreads();\n"
           "      tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
-          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_, hoist_);\n"
+          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_);\n"
           "      PLOOP src_[p] = (int64_t)anc_[p];\n"
-          "      if (a.rs_anc_out) *reinterpret_cast<int4*>(a.rs_anc_out + i0) = make_int4(anc_[0], anc_[1], anc_[2], anc_[3]);\n    } else hoist_();\n");
+          "      if (a.rs_anc_out) *reinterpret_cast<int4*>(a.rs_anc_out + i0) = make_int4(anc_[0], anc_[1], anc_[2], anc_[3]);\n    }\n");
   }
   // rows that already hold values (per-particle constraints, mask flags)
   std::vector<char> pre(prog->n_slots > 0 ? prog->n_slots : 1, 0);

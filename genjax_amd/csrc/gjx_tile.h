@@ -147,12 +147,11 @@ struct TiledSearchShared {
   int s_range[2];
 };
 
-struct TiledNoOverlap { GJX_DEV void operator()() const {} };
-template <bool PLANNED, class Overlap = TiledNoOverlap>
+template <bool PLANNED>
 GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uint64_t* __restrict__ S, const int32_t* __restrict__ E,
                                const uint64_t* __restrict__ Pg, const int32_t* __restrict__ shg, const int nt, const int tix, uint64_t* const Pl,
                                int32_t* const Ebl, TiledSearchShared& sh, int lse_mode, const float* lse, int n_partials, float* lse_out,
-                               float log_k_total, double u, unsigned* ctrl, unsigned long long* timeline, int32_t (&anc)[4], Overlap&& overlap = Overlap()) {
+                               float log_k_total, double u, unsigned* ctrl, unsigned long long* timeline, int32_t (&anc)[4]) {
 #define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[tix * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   constexpr int ITEMS = 4, TILE = 256 * ITEMS, CH = 3;
   const uint64_t* const P = PLANNED ? Pg : Pl;
@@ -179,40 +178,14 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
     if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
   }
   int Emax = 0;
-  if constexpr (PLANNED) overlap();
   if constexpr (!PLANNED) {
   float em = (float)kTileDead;
-  if (nt <= 1024) {
-    // (the usual case: a fixed trip count keeps the loads in flight, in registers, while `overlap` runs — work of the caller that
-    // needs nothing from the search, e.g. the random draws of the step a generated kernel is about to propagate)
-    uint64_t sv[4];
-    int ev[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int b = threadIdx.x + 256 * k;
-      sv[k] = b < nt ? S[b] : 0;
-      ev[k] = b < nt ? E[b] : kTileDead;
-    }
-    overlap();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int b = threadIdx.x + 256 * k;
-      if (b < nt) {
-        const int e = sv[k] ? ev[k] : kTileDead;
-        Pl[b + 1] = sv[k];
-        Ebl[b] = e;
-        em = fmaxf(em, (float)e);
-      }
-    }
-  } else {
-    overlap();
-    for (int b = threadIdx.x; b < nt; b += 256) {
-      const uint64_t sv = S[b];
-      const int e = sv ? E[b] : kTileDead;
-      Pl[b + 1] = sv;
-      Ebl[b] = e;
-      em = fmaxf(em, (float)e);
-    }
+  for (int b = threadIdx.x; b < nt; b += 256) {
+    const uint64_t sv = S[b];
+    const int e = sv ? E[b] : kTileDead;
+    Pl[b + 1] = sv;
+    Ebl[b] = e;
+    em = fmaxf(em, (float)e);
   }
   em = wave_max(em);
   if (lane == 0) sh.fred[wid] = em;
