@@ -109,6 +109,8 @@ class ScanBootstrapFilter:
             # two run workspaces and a second log-weight buffer: the one-launch step (resampling in the generated kernel's
             # prologue, include/gjx.h gjx_run_resample) alternates between them; OP_RUN + OP_RESAMPLE is the minimum
             need = 2 * load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K) + 4 * K + 512
+            if getattr(self, "_minimal_workspace", False):        # (tests: the library then runs the two-launch step by itself)
+                need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
             b = self._cache["bufs"] = dict(rows_a=torch.empty((n_rows, K), dtype=f32, device=dev), rows_b=torch.empty((n_rows, K), dtype=f32, device=dev),
                                            logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))
