@@ -641,10 +641,10 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // picked for this slot (gjx_run_program_ex: the particle gather fused into the read side); no draw, no score
     o.f("    { // ---- site %d: INPUT, %d rows, slot %d\n", j, s.dim, s.slot);
     for (int d = 0; d < s.dim; ++d)
-      o.f("      PLOOP v[%d][p] = a.in_rows ? a.in_rows[(int64_t)%d * a.in_stride + src_[p]] : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
+      o.f("      PLOOP v[%d][p] = a.in_rows ? LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]) : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
           s.obs_off + d, ri.row + d);
     o.f("      if (a.in_rows && a.store_inputs) {\n");
-    for (int d = 0; d < s.dim; ++d) o.f("        VecStore<PPT>::st(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
+    for (int d = 0; d < s.dim; ++d) o.f("        VSTORE(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
     o.f("      }\n      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
     return;
   }
@@ -826,7 +826,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
            toff(ri.score_row, ri.d_score_row).c_str());
   if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
-    for (int d = 0; d < nrow; ++d) o.f("      VecStore<PPT>::st(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
+    for (int d = 0; d < nrow; ++d) o.f("      VSTORE(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
   }
   o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
 }
@@ -948,15 +948,21 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "template <> struct VecStore<2> { static GJX_DEV void st(float* q, const float (&x)[2]) { *reinterpret_cast<float2*>(q) = make_float2(x[0], x[1]); } };\n"
       "template <> struct VecStore<4> { static GJX_DEV void st(float* q, const float (&x)[4]) { *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]); } };\n");
   o.f("typedef float v4f_ __attribute__((ext_vector_type(4)));\n");
+  // steps kernel (gjx_gen_steps): what other blocks of the launch read next step leaves at agent scope, write-through
+  o.f("template <int N> GJX_DEV void vec_store_live(float* q, const float (&x)[N]) { _Pragma(\"unroll\") for (int k = 0; k < N; ++k) store_agent(q + k, x[k]); }\n"
+      "template <> GJX_DEV void vec_store_live<4>(float* q, const float (&x)[4]) { store_agent_x4(q, x); }\n"
+      "#define VSTORE(q, x) do { if (live_) vec_store_live<PPT>(q, x); else VecStore<PPT>::st(q, x); } while (0)\n"
+      "#define LDIN(q) (live_ ? load_agent(q) : *(q))\n");
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
     // (two blocks per CU by launch bounds: with at most 256 VGPRs per lane the compiler keeps the matrix-core accumulators in
     // VGPRs — the elementwise phase reads them there; the AGPR form it picks otherwise ran the loop at HALF the matrix rate)
-    o.f("extern \"C\" __global__ __launch_bounds__(256, 2) void gjx_gen(GenArgs a) {\n"
+    o.f("static __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
         "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n  __shared__ __attribute__((aligned(16))) float mfma_s[%d];\n"
         "  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4, pl.mfma_floats > 0 ? pl.mfma_floats : 4);
   else
-  o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen(GenArgs a) {\n"
+  o.f("static __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
+  o.f("  const bool live_ = a.st_tag != 0ull; (void)live_;\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
   // companions: one pass per entry, spread over the block
   for (auto& c : pl.comps) {
@@ -1003,7 +1009,9 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       // carry (tiled_search_tile, gjx_tile.h: the body of k_resample_gather_tiled) — resample + gather + propagate + reweight in one launch
       o.f("    if (a.rs_logw) {\n      __shared__ TiledSearchShared rs_sh_;\n      __shared__ uint64_t rs_pl_[1026];\n      __shared__ int32_t rs_eb_[1024];\n"
           "      int32_t anc_[4];\n      __syncthreads();\n"
-          "      tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
+          "      if (live_) tiled_search_tile<false, true>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
+          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_, a.st_rtag);\n"
+          "      else tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
           "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_);\n"
           "      PLOOP src_[p] = (int64_t)anc_[p];\n"
           "      if (a.rs_anc_out) *reinterpret_cast<int4*>(a.rs_anc_out + i0) = make_int4(anc_[0], anc_[1], anc_[2], anc_[3]);\n    }\n");
@@ -1024,7 +1032,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   o.s += body.s;
   o.f("    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
       "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
-      "    if (a.logw) VecStore<PPT>::st(a.logw + i0, lw);\n"
+      "    if (a.logw) VSTORE(a.logw + i0, lw);\n"
       "    float m4 = tmax;\n    PLOOP m4 = fmaxf(m4, lw[p]);\n"
       "    if (m4 > -INFINITY) { float s4 = tsum * fast_exp(tmax - m4); PLOOP s4 += fast_exp(lw[p] - m4); tsum = s4; }\n    tmax = m4;\n");
   // {e_b, S_b} of this block-tile under GJX_WEIGHTS_TILE_SCALED (include/gjx.h) when it IS a quantisation tile (PPT == 4,
@@ -1034,16 +1042,52 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "      __syncthreads();\n      if (lane == 0) red[8 + wid] = wm_;\n      __syncthreads();\n"
       "      const int e_ = tile_exponent(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])));\n"
       "      uint64_t q_ = 0;\n      PLOOP q_ += tile_q(lw[p], e_);\n      const uint64_t wq_ = wave_total_u64(q_);\n"
-      "      if (lane == 0) red_q[wid] = wq_;\n      __syncthreads();\n"
+      "      if (lane == 0) red_q[wid] = wq_;\n"
+      "      if (live_) {\n"
+      "        // steps kernel: this tile's block pair and then — once every wave's write-through stores of the step have completed —\n"
+      "        // its granule {tag, e_b, S_b}: the next step of every block waits for it (one tile per block: the launcher checks)\n"
+      "        const float tm_ = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));\n"
+      "        float se_ = 0.0f;\n        PLOOP se_ += tm_ > -INFINITY ? fast_exp(lw[p] - tm_) : 0.0f;\n        const float wse_ = wave_sum(se_);\n"
+      "        if (lane == 0) red[12 + wid] = wse_;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n"
+      "        if (threadIdx.x == 0) {\n          const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3];\n"
+      "          __hip_atomic_store(&a.partials[tix], pack_f2(tm_, red[12] + red[13] + red[14] + red[15]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+      "          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+      "          __hip_atomic_store(&a.tile_S[tix], tile_granule(a.st_tag, tot_ ? e_ : kTileDead, tot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+      "        }\n      } else {\n      __syncthreads();\n"
       "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
-      "    }\n  }\n");
-  o.f("  if (a.partials) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
+      "      }\n    }\n  }\n");
+  o.f("  if (a.partials && !live_) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
       "    const float wm = wave_max(tmax);\n    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);\n"
       "    if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }\n    __syncthreads();\n"
       "    float bm = red[0];\n    for (int w = 1; w < 4; ++w) bm = fmaxf(bm, red[w]);\n    float bsum = 0.0f;\n"
       "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
       "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
+  o.f("extern \"C\" __global__ __launch_bounds__(256%s) void gjx_gen(GenArgs a) { gjx_step_(a); }\n", mfma ? ", 2" : "");
+  {
+    bool has_input = false;
+    for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
+    if (has_input && ppt == 4 && !mfma)
+      // every step t = T0 .. T-1 of a filter in ONE launch: the step programs share this structure and differ in their tables, keys and
+      // comb offsets; a step's kernel boundary is replaced by the granules its blocks publish (co-resident grid: the launcher checks)
+      o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen_steps(GenStepsArgs s) {\n"
+          "  const int64_t K = s.base.K;\n"
+          "  for (int t = s.T0; t < s.T; ++t) {\n"
+          "    if (__hip_atomic_load(&s.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout) break;   // a rendezvous timed out: the host repeats the run step by step\n"
+          "    GenArgs a = s.base;\n"
+          "    const bool odd = (t & 1) != 0, lodd = ((s.T - 1 - t) & 1) != 0;\n"
+          "    a.tab = s.tabs[t];\n    a.key = key2{s.keys[2 * t], s.keys[2 * t + 1]};\n"
+          "    a.choices = s.rows_all ? s.rows_all + (int64_t)t * s.rows_step : (odd ? s.rows_b : s.rows_a);\n"
+          "    a.in_rows = (s.rows_all ? s.rows_all + (int64_t)(t - 1) * s.rows_step : (odd ? s.rows_a : s.rows_b)) + (t == s.T0 ? s.in_row0_first : s.in_row0);\n"
+          "    a.in_stride = K;\n    a.anc = nullptr;\n"
+          "    a.logw = lodd ? s.logw_b : s.logw_a;\n    a.rs_logw = lodd ? s.logw_a : s.logw_b;\n"
+          "    a.tile_S = odd ? s.gran_b : s.gran_a;\n    a.tile_E = nullptr;\n    a.partials = odd ? s.part_b : s.part_a;\n"
+          "    a.rs_S = odd ? s.gran_a : s.gran_b;\n    a.rs_E = nullptr;\n    a.rs_lse = (const float*)(odd ? s.part_a : s.part_b);\n"
+          "    a.rs_n_partials = (int)(K >> 10);\n    a.rs_lse_out = s.lse_steps + 4 * (int64_t)(t - 1);\n    a.rs_u = s.us[t];\n"
+          "    a.rs_anc_out = s.anc_all ? s.anc_all + (int64_t)(t - 1) * K : s.anc;\n    a.rs_ctrl = s.ctrl;\n"
+          "    a.st_tag = (unsigned long long)((s.epoch + (unsigned)t) %% 15u) + 1ull;\n    a.st_rtag = (unsigned long long)((s.epoch + (unsigned)t - 1u) %% 15u) + 1ull;\n"
+          "    gjx_step_(a);\n  }\n}\n");
+  }
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
   o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
   return o.s;
@@ -1726,6 +1770,69 @@ int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, 
   if (ev0 && ev1) e = hipExtModuleLaunchKernel(fn, (uint32_t)grid * 256u, 1, 1, 256, 1, 1, (size_t)lds_floats * 4, st, nullptr, config, ev0, ev1, 0);
   else e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
   if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch");
+  return GJX_OK;
+}
+
+// ---- the steps kernel of a generated filter (gjx_scanfilter.hip): gjx_gen_steps of the module generated for `prog` ----
+// two programs run through one steps kernel only if they ARE one kernel: same structure key (sites, table size, stream layout)
+bool gen_same_kernel(const gjx_program* p, const gjx_program* q, int ppt) { return structure_key(p, ppt) == structure_key(q, ppt); }
+
+// blocks of gjx_gen_steps that are resident at the same time on the current device, or 0 (no such kernel / query failed)
+static int gen_steps_function(const gjx_program* prog, int ppt, hipFunction_t* fn_out, int* lds_floats) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  const Compiled& c = compile(prog, ppt);
+  if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+  *lds_floats = c.lds_floats;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
+  static std::map<std::pair<uint64_t, int>, hipFunction_t> steps_fn;
+  const auto lk = std::make_pair(structure_key(prog, ppt), dev);
+  auto sit = steps_fn.find(lk);
+  if (sit != steps_fn.end()) { *fn_out = sit->second; return *fn_out ? GJX_OK : GJX_EUNSUPPORTED; }
+  hipModule_t mod;
+  auto it = g_loaded.find(lk);
+  if (it == g_loaded.end()) {
+    hipFunction_t fn;
+    hipError_t e = hipModuleLoadData(&mod, c.code.data());
+    if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleLoadData");
+    e = hipModuleGetFunction(&fn, mod, "gjx_gen");
+    if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleGetFunction");
+    g_loaded[lk] = std::make_pair(mod, fn);
+  } else {
+    mod = it->second.first;
+  }
+  hipFunction_t sf = nullptr;
+  if (hipModuleGetFunction(&sf, mod, "gjx_gen_steps") != hipSuccess) { (void)hipGetLastError(); sf = nullptr; }
+  steps_fn[lk] = sf;
+  *fn_out = sf;
+  return sf ? GJX_OK : GJX_EUNSUPPORTED;
+}
+
+int gen_steps_resident_blocks(const gjx_program* prog, int ppt) {
+  hipFunction_t fn = nullptr;
+  int lds_floats = 0;
+  if (gen_steps_function(prog, ppt, &fn, &lds_floats) != GJX_OK) return 0;
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, (size_t)lds_floats * 4) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (gjx_plain_launches_forced()) return 0;
+  if (const char* e = getenv("GJX_CORESIDENT_BLOCKS")) return atoi(e);
+  return (per_cu > 6 ? 6 : per_cu) * cus;        // (as gjx_coresident_blocks: answers above 6 per CU are not exact)
+}
+
+int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st) {
+  hipFunction_t fn = nullptr;
+  int lds_floats = 0;
+  const int rc = gen_steps_function(prog, ppt, &fn, &lds_floats);
+  if (rc) return rc;
+  GenStepsArgs a = args;
+  size_t sz = sizeof(a);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
+  if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch (steps kernel)");
   return GJX_OK;
 }
 

@@ -812,6 +812,29 @@ struct GenArgs {
   double rs_u;
   int32_t* rs_anc_out;
   unsigned* rs_ctrl;
+  // steps kernel (gjx_gen_steps: every step of a filter run in ONE launch).  st_tag != 0: rows, log-weights and the block pair
+  // are stored write-through at agent scope and the tile's {e_b, S_b} goes out LAST, as a granule tagged st_tag in tile_S[tix]
+  // (tile_E unused); the resampling side polls rs_S for granules tagged st_rtag and reads the previous step at agent scope
+  unsigned long long st_tag, st_rtag;
+};
+
+// ---- arguments of `gjx_gen_steps`: steps T0 .. T-1 of a filter whose step programs share one structure (a periodic Scan) ----
+struct GenStepsArgs {
+  GenArgs base;                       // what every step shares: K, log_k_total, ... (per-step fields are filled in by the kernel)
+  int T0, T;
+  const float* const* tabs;           // [T] the step programs' tables (they differ in their observations)
+  const uint32_t* keys;               // [T][2]
+  const double* us;                   // [T]
+  float* rows_a; float* rows_b;       // choices of even / odd steps ...
+  float* rows_all; int64_t rows_step; // ... or, when the run is recorded, step t at rows_all + t * rows_step
+  int64_t in_row0_first, in_row0;     // floats in front of the OWN rows of step T0-1 / of the later steps in their buffer
+  float* logw_a; float* logw_b;       // log-weights of step t in logw_b when (T - 1 - t) is odd
+  unsigned long long* gran_a; unsigned long long* gran_b;   // [K / 1024] granules of even / odd steps
+  unsigned long long* part_a; unsigned long long* part_b;   // [K / 1024] block pairs {max, sumexp} of even / odd steps
+  float* lse_steps;                   // [T][4]
+  int32_t* anc; int32_t* anc_all;     // ancestors of the last resampling / of every resampling [T-1][K]
+  unsigned* ctrl;                     // control block of a workspace (status word at [2])
+  unsigned epoch;                     // granule tags: (epoch + t) % 15 + 1
 };
 
 // ---- arguments of a generated per-program HMC kernel (gjx_codegen.hip emits `extern "C" __global__ void gjx_hmc_gen(HmcGenArgs)`) ----

@@ -49,6 +49,29 @@ GJX_DEV float block_ref_max(int mode, const float* lse, int n_partials, float* r
   return m;
 }
 
+// the same reduction over block pairs that other blocks of THIS launch stored (agent-scope 8-byte stores of pack_f2)
+GJX_DEV float block_ref_max_live(const float* lse, int n_partials, float* red, float* sum_out) {
+  const unsigned long long* parts = (const unsigned long long*)lse;
+  float tmax = -INFINITY, tsum = 0.0f;
+  for (int t = threadIdx.x; t < n_partials; t += 256) {
+    const unsigned long long w = __hip_atomic_load(&parts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float px = __uint_as_float((unsigned)w), py = __uint_as_float((unsigned)(w >> 32));
+    const float nm = fmaxf(tmax, px);
+    if (nm > -INFINITY) tsum = tsum * fast_exp(tmax - nm) + py * fast_exp(px - nm);
+    tmax = nm;
+  }
+  const float wm = wave_max(tmax);
+  const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[4 + (threadIdx.x >> 6)] = ws; }
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sm = 0.0f;
+  for (int w = 0; w < 4; ++w) sm += m > -INFINITY ? red[4 + w] * fast_exp(red[w] - m) : 0.0f;
+  if (sum_out) *sum_out = sm;
+  return m;
+}
+
 // ---- u64 wave scans on the DPP network (dpp_mov and the float forms: gjx_device.h) ----
 template <unsigned CTRL, unsigned ROW_MASK>
 GJX_DEV uint64_t dpp_add_u64(uint64_t v) {

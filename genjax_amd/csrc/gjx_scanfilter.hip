@@ -18,9 +18,21 @@
 
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include "gjx_tile.h"
 #include "gjx_pfilter_host.h"
 
 using namespace gjx;
+
+// tile totals {S_b, e_b} and block pairs of a step that ran as its own launch -> the tagged granules and the pair array the steps
+// kernel's first step polls / reads (gjx_gen_steps)
+__global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_t* __restrict__ E, const unsigned long long* __restrict__ pairs,
+                                    unsigned long long* gran, unsigned long long* part, int nt, unsigned long long tag) {
+  const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (b >= nt) return;
+  const uint64_t sv = S[b];
+  gran[b] = tile_granule(tag, sv ? E[b] : kTileDead, sv);
+  part[b] = pairs[b];
+}
 
 // rows_of(t): the buffer step t writes its choices into (two alternating buffers, or one per step when the run is recorded)
 template <class RowsOf>
@@ -36,6 +48,11 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const bool room = workspace_bytes >= logw_off + sizeof(float) * (size_t)K;
   char* ws_run2 = room ? ws_res + need_res : nullptr;
   float* logw2 = room ? (float*)((char*)workspace + logw_off) : nullptr;
+  // ... and the steps kernel (every step from the third in one launch) an area for its granules, pair arrays and per-step arguments
+  const int64_t nt = K / 1024;
+  const size_t steps_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
+  const size_t steps_bytes = 32 * (size_t)nt + 24 * (size_t)T + 64;
+  char* steps_area = (room && K % 1024 == 0 && workspace_bytes >= steps_off + steps_bytes) ? (char*)workspace + steps_off : nullptr;
   const bool no_fuse = getenv("GJX_SCAN_FILTER_TWO_LAUNCH") && atoi(getenv("GJX_SCAN_FILTER_TWO_LAUNCH")) != 0;
   bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
   if (fused && T > 1) {
@@ -105,6 +122,54 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       if (rc) return rc;
     }
     prev = info;
+    // ---- steps 2 .. T-1 in ONE launch (gjx_gen_steps) when step 1 ran with the search in its prologue, the remaining step programs are
+    //      the same kernel (a periodic Scan: they differ in tables, keys, comb offsets), the grid of K / 1024 blocks is co-resident
+    //      and the workspace has the room (granules, pair arrays, the per-step arguments) ----
+    if (t == 1 && ran && T >= 4 && steps_area && info.engine == 4 && prev.tiles_offset != 0 && prev.n_partials == (int)nt &&
+        !(getenv("GJX_SCAN_FILTER_PERSISTENT") && atoi(getenv("GJX_SCAN_FILTER_PERSISTENT")) == 0)) {
+      bool same = true;
+      for (int u = 2; u < T && same; ++u)
+        same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
+               steps[u].tab_dev != nullptr && gen_same_kernel(&steps[1], &steps[u], 4);
+      if (same && (int64_t)gen_steps_resident_blocks(&steps[1], 4) >= nt) {
+        hipStream_t st = (hipStream_t)stream;
+        unsigned long long* gran_a = (unsigned long long*)steps_area;           // even steps
+        unsigned long long* gran_b = gran_a + nt;
+        unsigned long long* part_a = gran_b + nt;
+        unsigned long long* part_b = part_a + nt;
+        const float** tabs_dev = (const float**)(part_b + nt);
+        uint32_t* keys_dev = (uint32_t*)(tabs_dev + T);
+        double* us_dev = (double*)(keys_dev + 2 * (size_t)T);
+        static thread_local std::vector<const float*> h_tabs;
+        h_tabs.assign((size_t)T, nullptr);
+        for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
+        hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)nt, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(tabs_dev, h_tabs.data(), sizeof(float*) * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(us_dev, us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return gjx_fail_hip(e, "gjx_scan_filter(step arguments)");
+        const char* w1 = ws_of(1);
+        const uint64_t* tS = (const uint64_t*)(w1 + prev.tiles_offset);
+        hipLaunchKernelGGL(k_tiles_to_granules, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tS, (const int32_t*)(tS + nt),
+                           (const unsigned long long*)(w1 + kWsHeaderBytes), gran_b, part_b, (int)nt, (unsigned long long)(1u % 15u) + 1ull);
+        GJX_CHECK_LAUNCH("gjx_scan_filter(granules of step 1)");
+        GenStepsArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.base.K = K; sa.base.offset = 0; sa.base.log_k_total = (float)log((double)K);
+        sa.T0 = 2; sa.T = T; sa.tabs = tabs_dev; sa.keys = keys_dev; sa.us = us_dev;
+        float* r0 = rows_of(0); float* r1 = rows_of(1); float* r2 = rows_of(2);
+        if (r2 == r0) { sa.rows_a = r0; sa.rows_b = r1; sa.rows_all = nullptr; sa.rows_step = 0; }
+        else { sa.rows_a = nullptr; sa.rows_b = nullptr; sa.rows_all = r0; sa.rows_step = (int64_t)(r1 - r0); }
+        sa.in_row0_first = sa.in_row0 = (int64_t)input_rows(steps[1]) * K;
+        sa.logw_a = logw; sa.logw_b = logw2;
+        sa.gran_a = gran_a; sa.gran_b = gran_b; sa.part_a = part_a; sa.part_b = part_b;
+        sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
+        const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)nt, st);
+        if (rc2 == GJX_OK)
+          return gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st);
+        if (rc2 != GJX_EUNSUPPORTED) return rc2;
+      }
+    }
   }
   // the record of the last step: its block pairs are still in its run workspace
   return gjx_launch_lse_finish(ws_of(T - 1) + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);

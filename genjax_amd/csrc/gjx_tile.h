@@ -18,6 +18,13 @@ GJX_DEV void load_agent_x4(const float* p, float (&v)[4]) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
   v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
 }
+// four consecutive floats through ONE 16-byte write-through store (completion: the caller's s_waitcnt vmcnt(0) — the compiler
+// does not count an asm's memory operations)
+GJX_DEV void store_agent_x4(float* p, const float (&v)[4]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 r = {v[0], v[1], v[2], v[3]};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
+}
 GJX_DEV void store_agent(float* p, float v) { __hip_atomic_store((int*)p, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The same accesses with the scope as a (wave-uniform) argument: `sys` selects SYSTEM scope (sc0 sc1) for memory that
@@ -147,11 +154,17 @@ struct TiledSearchShared {
   int s_range[2];
 };
 
-template <bool PLANNED>
+// LIVE: the collection being resampled was written by other blocks of THIS launch (the steps kernel of a generated filter,
+// gjx_codegen.hip): S holds one tagged granule {rtag, e_b, S_b} per tile (tile_granule), published by its block once the block's
+// write-through stores of the step had completed; this block polls them — the rendezvous of the step — and reads everything else
+// of the previous step (log-weights, block pairs) with agent-scope loads.  E is unused.
+template <bool PLANNED, bool LIVE = false>
 GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uint64_t* __restrict__ S, const int32_t* __restrict__ E,
                                const uint64_t* __restrict__ Pg, const int32_t* __restrict__ shg, const int nt, const int tix, uint64_t* const Pl,
                                int32_t* const Ebl, TiledSearchShared& sh, int lse_mode, const float* lse, int n_partials, float* lse_out,
-                               float log_k_total, double u, unsigned* ctrl, unsigned long long* timeline, int32_t (&anc)[4]) {
+                               float log_k_total, double u, unsigned* ctrl, unsigned long long* timeline, int32_t (&anc)[4],
+                               unsigned long long rtag = 0ull) {
+  static_assert(!(PLANNED && LIVE), "the live form reduces the granules itself");
 #define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[tix * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   constexpr int ITEMS = 4, TILE = 256 * ITEMS, CH = 3;
   const uint64_t* const P = PLANNED ? Pg : Pl;
@@ -159,7 +172,10 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t i0 = ((int64_t)tix * 256 + threadIdx.x) * ITEMS;
   auto load_tile = [&](int64_t p0, float (&v)[ITEMS]) {
-    if (p0 + 4 <= K) {
+    if constexpr (LIVE) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? load_agent(x + p0 + k) : -INFINITY;
+    } else if (p0 + 4 <= K) {
       const float4 q4 = *(const float4*)(x + p0);
       v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
     } else {
@@ -167,25 +183,49 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
       for (int k = 0; k < ITEMS; ++k) v[k] = (p0 + k < K) ? x[p0 + k] : -INFINITY;
     }
   };
-  // ---- every load of the head, at once: the three tiles of log-weights around the block, all tile totals ----
+  // ---- every load of the head, at once: the three tiles of log-weights around the block, all tile totals (LIVE: the granules
+  //      first — a tile's log-weights are complete only once its granule is there) ----
   const int w0 = tix - 1;
   float xw[CH][ITEMS];
+  auto load_window = [&]() {
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
+    for (int c = 0; c < CH; ++c) {
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) xw[c][k] = -INFINITY;
-    const int tc = w0 + c;
-    if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
-  }
+      for (int k = 0; k < ITEMS; ++k) xw[c][k] = -INFINITY;
+      const int tc = w0 + c;
+      if (tc >= 0 && tc < nt) load_tile((int64_t)tc * TILE + (int64_t)threadIdx.x * ITEMS, xw[c]);
+    }
+  };
+  if constexpr (!LIVE) load_window();
   int Emax = 0;
   if constexpr (!PLANNED) {
   float em = (float)kTileDead;
+  if constexpr (LIVE) {
+    unsigned budget = (ctrl && (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout)) ? 0u : kPollBudget;
+    for (int b = threadIdx.x; b < nt; b += 256) {
+      unsigned long long v = __hip_atomic_load((const unsigned long long*)&S[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((v >> 60) != rtag && budget) {
+        --budget;
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load((const unsigned long long*)&S[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((v >> 60) != rtag) { if (ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
+      const uint64_t sv = v & ((1ull << 40) - 1);
+      const int e = sv ? (int)((v >> 40) & 0xFFFFFu) + kTileDead : kTileDead;
+      Pl[b + 1] = sv;
+      Ebl[b] = e;
+      em = fmaxf(em, (float)e);
+    }
+    __syncthreads();        // every granule of the step has been seen by some lane of this block: the whole previous step is readable
+    load_window();
+  } else {
   for (int b = threadIdx.x; b < nt; b += 256) {
     const uint64_t sv = S[b];
     const int e = sv ? E[b] : kTileDead;
     Pl[b + 1] = sv;
     Ebl[b] = e;
     em = fmaxf(em, (float)e);
+  }
   }
   em = wave_max(em);
   if (lane == 0) sh.fred[wid] = em;
@@ -218,7 +258,7 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
   if (tix == 0) {   // block-uniform: the LSE record of the producing run (its block partials), the dead-collection flag
     if (lse_mode == 2 && lse_out) {
       float sm_sum;
-      const float mx = block_ref_max(2, lse, n_partials, sh.fred, &sm_sum);
+      const float mx = LIVE ? block_ref_max_live(lse, n_partials, sh.fred, &sm_sum) : block_ref_max(2, lse, n_partials, sh.fred, &sm_sum);
       if (threadIdx.x == 0) {
         const float l = mx > -INFINITY ? mx + logf(sm_sum) : -INFINITY;
         lse_out[0] = mx; lse_out[1] = sm_sum; lse_out[2] = l; lse_out[3] = l - log_k_total;

@@ -109,18 +109,30 @@ class ScanBootstrapFilter:
             # two run workspaces and a second log-weight buffer: the one-launch step (resampling in the generated kernel's
             # prologue, include/gjx.h gjx_run_resample) alternates between them; OP_RUN + OP_RESAMPLE is the minimum
             need = 2 * load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K) + 4 * K + 512
+            # ... and behind them the area of the steps kernel (every step from the third in ONE launch: granules, pair arrays, the
+            # per-step tables / keys / comb offsets); the size of the workspace handed over selects the form (include/gjx.h)
+            self._ws_one_launch_per_step = need
+            need += 32 * (K // 1024) + 24 * 4096 + 1024
             if getattr(self, "_minimal_workspace", False):        # (tests: the library then runs the two-launch step by itself)
                 need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
+                self._ws_one_launch_per_step = need
             b = self._cache["bufs"] = dict(rows_a=torch.empty((n_rows, K), dtype=f32, device=dev), rows_b=torch.empty((n_rows, K), dtype=f32, device=dev),
                                            logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))
         lse = torch.empty((T, 4), dtype=f32, device=dev)
+        ws_bytes = b["ws"].numel() if T <= 4096 and not getattr(self, "_no_steps_kernel", False) else min(b["ws"].numel(), self._ws_one_launch_per_step)
         if keep_history:
             rows_all = torch.empty((T, n_rows, K), dtype=f32, device=dev)
             anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev)
             check(load().gjx_scan_filter_history(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(rows_all), n_rows, kernels._ptr(b["logw"]),
-                                                 kernels._ptr(anc_all), kernels._ptr(lse), kernels._ptr(b["ws"]), b["ws"].numel(), kernels._stream()),
+                                                 kernels._ptr(anc_all), kernels._ptr(lse), kernels._ptr(b["ws"]), ws_bytes, kernels._stream()),
                   "gjx_scan_filter_history")
+            if self._timed_out(b):
+                self._no_steps_kernel = True
+                try:
+                    return self.run(key, constraint, args, device, keep_ancestors, keep_history)
+                finally:
+                    self._no_steps_kernel = False
             incs = lse[:, 3]
             hist = ScanHistory(progs, rows_all, anc_all[: T - 1], b["logw"])
             return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=b["logw"],
@@ -128,12 +140,28 @@ class ScanBootstrapFilter:
         anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev) if keep_ancestors else None
         check(load().gjx_scan_filter(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(b["rows_a"]), kernels._ptr(b["rows_b"]),
                                      kernels._ptr(b["logw"]), kernels._ptr(b["anc"]), kernels._ptr(anc_all), kernels._ptr(lse),
-                                     kernels._ptr(b["ws"]), b["ws"].numel(), kernels._stream()), "gjx_scan_filter")
+                                     kernels._ptr(b["ws"]), ws_bytes, kernels._stream()), "gjx_scan_filter")
+        if self._timed_out(b):
+            # the steps kernel needs its whole grid resident and something else held compute units: the same run, same keys, one
+            # launch per step (bit-identical results)
+            self._no_steps_kernel = True
+            try:
+                return self.run(key, constraint, args, device, keep_ancestors, keep_history)
+            finally:
+                self._no_steps_kernel = False
         incs = lse[:, 3]
         last = progs[-1]
         ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=ch, logw=b["logw"], programs=progs,
                     ancestors=anc_all if keep_ancestors else b["anc"])
+
+    def _timed_out(self, b) -> bool:
+        """status word of the run (one stream synchronisation, only when the steps kernel may have run): GJX_STATUS_POLL_TIMEOUT"""
+        from .. import kernels
+        if getattr(self, "_no_steps_kernel", False) or getattr(self, "_minimal_workspace", False) or not getattr(self, "check_status", True):
+            return False
+        off = load().gjx_workspace_bytes(A.OP_RUN, self.K)
+        return bool(kernels.workspace_status(b["ws"][off:], raise_on_error=False) & 1)
 
     def latent(self, out: dict, name) -> torch.Tensor:
         """rows of the last step's choice ``name``: f32[dim][K]"""

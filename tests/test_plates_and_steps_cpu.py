@@ -159,7 +159,7 @@ def test_generated_sources_compile_for_gfx950():
     assert [p.n_input_rows for p in progs] == [0, 4, 4] and progs[1].c_sites[0].mode == A.MODE_INPUT
     assert bytes(progs[1].c_sites)[:3 * 240] == bytes(progs[2].c_sites)[:3 * 240]      # periodic steps: ONE generated kernel
     src = kernels.program_source(progs[1], 4)
-    assert "a.in_rows ? a.in_rows[" in src and "a.tile_S[tix]" in src
+    assert "a.in_rows ? LDIN(a.in_rows + " in src and "a.tile_S[tix]" in src and "gjx_gen_steps" in src and "tiled_search_tile<false, true>" in src
     kernels.program_precompile(progs[1], 4)
     lr, _ = workloads.logreg_importance_program()
     src = kernels.program_source(lr, 257)
