@@ -956,13 +956,13 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
     // (two blocks per CU by launch bounds: with at most 256 VGPRs per lane the compiler keeps the matrix-core accumulators in
     // VGPRs — the elementwise phase reads them there; the AGPR form it picks otherwise ran the loop at HALF the matrix rate)
-    o.f("static __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
+    o.f("template <bool LIVE_>\nstatic __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
         "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n  __shared__ __attribute__((aligned(16))) float mfma_s[%d];\n"
         "  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4, pl.mfma_floats > 0 ? pl.mfma_floats : 4);
   else
-  o.f("static __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
+  o.f("template <bool LIVE_>\nstatic __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
-  o.f("  const bool live_ = a.st_tag != 0ull; (void)live_;\n");
+  o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
   // companions: one pass per entry, spread over the block
   for (auto& c : pl.comps) {
@@ -1063,7 +1063,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
       "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
-  o.f("extern \"C\" __global__ __launch_bounds__(256%s) void gjx_gen(GenArgs a) { gjx_step_(a); }\n", mfma ? ", 2" : "");
+  o.f("extern \"C\" __global__ __launch_bounds__(256%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", mfma ? ", 2" : "");
   {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
@@ -1086,7 +1086,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
           "    a.rs_n_partials = (int)(K >> 10);\n    a.rs_lse_out = s.lse_steps + 4 * (int64_t)(t - 1);\n    a.rs_u = s.us[t];\n"
           "    a.rs_anc_out = s.anc_all ? s.anc_all + (int64_t)(t - 1) * K : s.anc;\n    a.rs_ctrl = s.ctrl;\n"
           "    a.st_tag = (unsigned long long)((s.epoch + (unsigned)t) %% 15u) + 1ull;\n    a.st_rtag = (unsigned long long)((s.epoch + (unsigned)t - 1u) %% 15u) + 1ull;\n"
-          "    gjx_step_(a);\n  }\n}\n");
+          "    gjx_step_<true>(a);\n  }\n}\n");
   }
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
   o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
