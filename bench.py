@@ -999,6 +999,7 @@ def run_round4(dev):
     exact = _kalman_log_lik(s["A"], s["y"], q, r, q)          # float64 closed form (x_0 ~ N(0, q^2 I): the Scan's step 0)
     ys_d = torch.as_tensor(s["y"], device=dev)
     two_launch = bool(int(os.environ.get("GJX_SCAN_FILTER_TWO_LAUNCH", "0") or 0))
+    per_step = os.environ.get("GJX_SCAN_FILTER_PERSISTENT", "1") == "0"
     for Kf, tag in ((K, "2e18"), (1 << 20, "2e20")):
         bf = BootstrapFilter(lg_step.scan(n=T), Kf)
         dt, lml = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=5 if Kf == K else 3)
@@ -1013,11 +1014,16 @@ def run_round4(dev):
         dth = (time.perf_counter() - t0) / 5
         res[f"scan_filter_lgssm_d8_T256_K{tag}"] = dict(
             us_per_step=dt / T * 1e6, particle_steps_per_sec=Kf * T / dt, log_ml=lml, log_ml_rel_err=abs(lml - exact) / abs(exact),
-            launches_per_step=2 if two_launch else 1, hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
+            launches_per_step=2 if two_launch else 1,
+            launches_per_run=(2 * T if two_launch else (T + 1 if per_step else 5)),
+            form=("search launch + step launch per step" if two_launch else
+                  "one launch per step (search in the prologue of the step's generated kernel)" if per_step else
+                  "steps 0 and 1 one launch each, steps 2 .. T-1 in ONE launch (gjx_gen_steps: granules instead of kernel boundaries)"),
+            hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
             algorithmic_bytes_per_particle_step=8 * dx + 24, achieved_GBs=(8 * dx + 24) * Kf / (dt / T) / 1e9,
             frac_of_hbm=(8 * dx + 24) * Kf / (dt / T) / 1e9 / HBM_PEAK_GBS,
             engine=("k_resample_gather_tiled<rows = 0> + gjx_gen (generated, INPUT rows through the ancestors)" if two_launch else
-                    "gjx_gen: the tile-scaled resampler's search in the prologue of the step's generated kernel (gjx_run_resample), INPUT rows through the ancestors"))
+                    "gjx_gen / gjx_gen_steps: the tile-scaled resampler's search in the prologue of the step's generated code, INPUT rows through the ancestors"))
     with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
         fx = json.load(f)
     phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)

@@ -1052,7 +1052,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "        if (threadIdx.x == 0) {\n          const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3];\n"
       "          __hip_atomic_store(&a.partials[tix], pack_f2(tm_, red[12] + red[13] + red[14] + red[15]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
       "          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
-      "          __hip_atomic_store(&a.tile_S[tix], tile_granule(a.st_tag, tot_ ? e_ : kTileDead, tot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+      "          __hip_atomic_store(&a.tile_S[tix * kLiveGranulePad], tile_granule(a.st_tag, tot_ ? e_ : kTileDead, tot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
       "        }\n      } else {\n      __syncthreads();\n"
       "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
       "      }\n    }\n  }\n");

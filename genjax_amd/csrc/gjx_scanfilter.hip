@@ -30,7 +30,7 @@ __global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_
   const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (b >= nt) return;
   const uint64_t sv = S[b];
-  gran[b] = tile_granule(tag, sv ? E[b] : kTileDead, sv);
+  gran[(size_t)b * kLiveGranulePad] = tile_granule(tag, sv ? E[b] : kTileDead, sv);
   part[b] = pairs[b];
 }
 
@@ -51,7 +51,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   // ... and the steps kernel (every step from the third in one launch) an area for its granules, pair arrays and per-step arguments
   const int64_t nt = K / 1024;
   const size_t steps_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
-  const size_t steps_bytes = 32 * (size_t)nt + 24 * (size_t)T + 64;
+  const size_t steps_bytes = (16 * (size_t)kLiveGranulePad + 16) * (size_t)nt + 24 * (size_t)T + 64;
   char* steps_area = (room && K % 1024 == 0 && workspace_bytes >= steps_off + steps_bytes) ? (char*)workspace + steps_off : nullptr;
   const bool no_fuse = getenv("GJX_SCAN_FILTER_TWO_LAUNCH") && atoi(getenv("GJX_SCAN_FILTER_TWO_LAUNCH")) != 0;
   bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
@@ -134,8 +134,8 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       if (same && (int64_t)gen_steps_resident_blocks(&steps[1], 4) >= nt) {
         hipStream_t st = (hipStream_t)stream;
         unsigned long long* gran_a = (unsigned long long*)steps_area;           // even steps
-        unsigned long long* gran_b = gran_a + nt;
-        unsigned long long* part_a = gran_b + nt;
+        unsigned long long* gran_b = gran_a + nt * kLiveGranulePad;
+        unsigned long long* part_a = gran_b + nt * kLiveGranulePad;
         unsigned long long* part_b = part_a + nt;
         const float** tabs_dev = (const float**)(part_b + nt);
         uint32_t* keys_dev = (uint32_t*)(tabs_dev + T);
@@ -143,7 +143,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         static thread_local std::vector<const float*> h_tabs;
         h_tabs.assign((size_t)T, nullptr);
         for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
-        hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)nt, st);
+        hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)kLiveGranulePad * (size_t)nt, st);
         if (e == hipSuccess) e = hipMemcpyAsync(tabs_dev, h_tabs.data(), sizeof(float*) * (size_t)T, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(us_dev, us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);

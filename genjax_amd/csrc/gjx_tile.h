@@ -146,6 +146,7 @@ GJX_DEV unsigned long long tile_granule(unsigned long long tag, int e, uint64_t 
 // every tile; !PLANNED: Pl [nt + 2], Ebl [nt] are block-shared scratch (every block reduces all nt totals), PLANNED: Pg, shg
 // hold the prefix and the shifts (k_tiled_plan).  tix == 0 also finishes the LSE record of the producing run (lse_mode 2) and
 // flags a dead collection.  Every thread of the block must call it (block barriers inside).
+constexpr int kLiveGranulePad = 8;         // words between the granules of the steps kernel (gjx_gen_steps)
 struct TiledSearchShared {
   float fred[8];
   uint64_t wsum[4];
@@ -203,11 +204,12 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
   if constexpr (LIVE) {
     unsigned budget = (ctrl && (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout)) ? 0u : kPollBudget;
     for (int b = threadIdx.x; b < nt; b += 256) {
-      unsigned long long v = __hip_atomic_load((const unsigned long long*)&S[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (one granule per 64-byte line, kLiveGranulePad: blocks that store into a shared line serialise in the L2)
+      unsigned long long v = __hip_atomic_load((const unsigned long long*)&S[(size_t)b * kLiveGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       while ((v >> 60) != rtag && budget) {
         --budget;
         __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load((const unsigned long long*)&S[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load((const unsigned long long*)&S[(size_t)b * kLiveGranulePad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if ((v >> 60) != rtag) { if (ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 0; }
       const uint64_t sv = v & ((1ull << 40) - 1);

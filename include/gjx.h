@@ -656,13 +656,23 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  * the step's generated kernel gives a lane 4 particles: the kernel searches the ancestors of its own tile in its prologue
  * (gjx_run_resample) and reads its carry THROUGH them (the particle gather of smc.py:90-91 fused into the read side).
  * Otherwise two: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the producing
- * kernel), then the step's kernel (GJX_SCAN_FILTER_TWO_LAUNCH=1 forces this form).  Same ancestors either way, bit for bit.  No co-resident grid, nothing to time out, any K <= 2^26.
+ * kernel), then the step's kernel (GJX_SCAN_FILTER_TWO_LAUNCH=1 forces this form).  Same ancestors either way, bit for bit.  No
+ * co-resident grid, nothing to time out, any K <= 2^26.
+ * Every step from the third in ONE launch (the steps kernel gjx_gen_steps) when, beyond that, the step programs 1 .. T-1 are one
+ * kernel (same sites: a periodic Scan — tables, keys and comb offsets are per-step arguments), T >= 4, the grid of K / 1024 blocks
+ * is co-resident on the device and the workspace has the room below: a step's kernel boundary is replaced by the granules
+ * {tag, e_b, S_b} its blocks publish once their write-through stores have completed, the search of the next step polls them and
+ * reads the previous step at agent scope.  Bit-identical to the per-step forms.  A grid that turns out not to be co-resident
+ * (another kernel holds compute units) sets GJX_STATUS_POLL_TIMEOUT in the status word of the OP_RESAMPLE part of the workspace
+ * (workspace + gjx_workspace_bytes(GJX_OP_RUN, K)) and ends the launch: the caller repeats the run with a workspace size below
+ * the steps kernel's (the size of the workspace handed over selects the form).  GJX_SCAN_FILTER_PERSISTENT=0 switches it off.
  *   rows_a / rows_b f32[max_t n_slots][K]: choices of even / odd steps (the last step's end up in rows_[(T-1)&1]);
  *   logw f32[K] the last step's incremental log-weights; ancestors int32[K] scratch / the last resampling's ancestors;
  *   ancestors_all (or NULL) int32[T-1][K]: the ancestors of every resampling (trajectory reconstruction);
  *   lse_steps f32[T][4]: log-ML estimate = sum_t lse_steps[t][3];
  *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once; with
- *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the one-launch step is used (a second run workspace and log-weight buffer). */
+ *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the one-launch step is used (a second run workspace and log-weight buffer); with
+ *   144 (K / 1024) + 24 T + 1024 bytes more, the steps kernel. */
 int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                     float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
                     void* stream);
