@@ -144,6 +144,9 @@ class ScanBootstrapFilter:
         if self._timed_out(b):
             # the steps kernel needs its whole grid resident and something else held compute units: the same run, same keys, one
             # launch per step (bit-identical results)
+            import warnings
+            warnings.warn("generic filter: the steps kernel timed out waiting for its peer blocks (another kernel holds compute units); "
+                          "the run was repeated with one launch per step")
             self._no_steps_kernel = True
             try:
                 return self.run(key, constraint, args, device, keep_ancestors, keep_history)
