@@ -1070,8 +1070,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     if (has_input && ppt == 4 && !mfma)
       // every step t = T0 .. T-1 of a filter in ONE launch: the step programs share this structure and differ in their tables, keys and
       // comb offsets; a step's kernel boundary is replaced by the granules its blocks publish (co-resident grid: the launcher checks)
-      for (int variant = 0; variant < 2; ++variant)
-      o.f("extern \"C\" __global__ __launch_bounds__(256%s) void gjx_gen_steps%s(GenStepsArgs s) {\n"
+      o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen_steps(GenStepsArgs s) {\n"
           "  const int64_t K = s.base.K;\n"
           "  for (int t = s.T0; t < s.T; ++t) {\n"
           "    if (__hip_atomic_load(&s.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout) break;   // a rendezvous timed out: the host repeats the run step by step\n"
@@ -1087,7 +1086,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
           "    a.rs_n_partials = (int)(K >> 10);\n    a.rs_lse_out = s.lse_steps + 4 * (int64_t)(t - 1);\n    a.rs_u = s.us[t];\n"
           "    a.rs_anc_out = s.anc_all ? s.anc_all + (int64_t)(t - 1) * K : s.anc;\n    a.rs_ctrl = s.ctrl;\n"
           "    a.st_tag = (unsigned long long)((s.epoch + (unsigned)t) %% 15u) + 1ull;\n    a.st_rtag = (unsigned long long)((s.epoch + (unsigned)t - 1u) %% 15u) + 1ull;\n"
-          "    gjx_step_<true>(a);\n  }\n}\n", variant ? ", 4" : "", variant ? "4" : "");
+          "    gjx_step_<true>(a);\n  }\n}\n");
   }
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
   o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
@@ -1779,17 +1778,17 @@ int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, 
 bool gen_same_kernel(const gjx_program* p, const gjx_program* q, int ppt) { return structure_key(p, ppt) == structure_key(q, ppt); }
 
 // blocks of gjx_gen_steps that are resident at the same time on the current device, or 0 (no such kernel / query failed)
-static int gen_steps_function(const gjx_program* prog, int ppt, hipFunction_t* fn_out, int* lds_floats, int variant = 0) {
+static int gen_steps_function(const gjx_program* prog, int ppt, hipFunction_t* fn_out, int* lds_floats) {
   std::lock_guard<std::mutex> lock(g_mu);
   const Compiled& c = compile(prog, ppt);
   if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
   *lds_floats = c.lds_floats;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
-  static std::map<std::pair<uint64_t, int>, hipFunction_t> steps_fn[2];
+  static std::map<std::pair<uint64_t, int>, hipFunction_t> steps_fn;
   const auto lk = std::make_pair(structure_key(prog, ppt), dev);
-  auto sit = steps_fn[variant].find(lk);
-  if (sit != steps_fn[variant].end()) { *fn_out = sit->second; return *fn_out ? GJX_OK : GJX_EUNSUPPORTED; }
+  auto sit = steps_fn.find(lk);
+  if (sit != steps_fn.end()) { *fn_out = sit->second; return *fn_out ? GJX_OK : GJX_EUNSUPPORTED; }
   hipModule_t mod;
   auto it = g_loaded.find(lk);
   if (it == g_loaded.end()) {
@@ -1803,17 +1802,16 @@ static int gen_steps_function(const gjx_program* prog, int ppt, hipFunction_t* f
     mod = it->second.first;
   }
   hipFunction_t sf = nullptr;
-  if (hipModuleGetFunction(&sf, mod, variant ? "gjx_gen_steps4" : "gjx_gen_steps") != hipSuccess) { (void)hipGetLastError(); sf = nullptr; }
-  steps_fn[variant][lk] = sf;
+  if (hipModuleGetFunction(&sf, mod, "gjx_gen_steps") != hipSuccess) { (void)hipGetLastError(); sf = nullptr; }
+  steps_fn[lk] = sf;
   *fn_out = sf;
   return sf ? GJX_OK : GJX_EUNSUPPORTED;
 }
 
-// variant 0: the compiler's register budget; 1: at most 128 VGPRs (four blocks per CU, spills: for grids the first cannot hold)
-int gen_steps_resident_blocks(const gjx_program* prog, int ppt, int variant) {
+int gen_steps_resident_blocks(const gjx_program* prog, int ppt) {
   hipFunction_t fn = nullptr;
   int lds_floats = 0;
-  if (gen_steps_function(prog, ppt, &fn, &lds_floats, variant) != GJX_OK) return 0;
+  if (gen_steps_function(prog, ppt, &fn, &lds_floats) != GJX_OK) return 0;
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, (size_t)lds_floats * 4) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
@@ -1825,10 +1823,10 @@ int gen_steps_resident_blocks(const gjx_program* prog, int ppt, int variant) {
   return (per_cu > 6 ? 6 : per_cu) * cus;        // (as gjx_coresident_blocks: answers above 6 per CU are not exact)
 }
 
-int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st, int variant) {
+int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st) {
   hipFunction_t fn = nullptr;
   int lds_floats = 0;
-  const int rc = gen_steps_function(prog, ppt, &fn, &lds_floats, variant);
+  const int rc = gen_steps_function(prog, ppt, &fn, &lds_floats);
   if (rc) return rc;
   GenStepsArgs a = args;
   size_t sz = sizeof(a);

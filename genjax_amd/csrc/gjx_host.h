@@ -43,8 +43,8 @@ int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, 
 // the steps kernel of a generated filter (gjx_gen_steps, gjx_codegen.hip): every step of a run in one launch
 struct GenStepsArgs;
 bool gen_same_kernel(const gjx_program* p, const gjx_program* q, int ppt);
-int gen_steps_resident_blocks(const gjx_program* prog, int ppt, int variant = 0);
-int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st, int variant = 0);
+int gen_steps_resident_blocks(const gjx_program* prog, int ppt);
+int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st);
 // per-program generated HMC kernels (gjx_codegen.hip)
 struct HmcGenArgs;
 int hmc_gen_available(const gjx_program* prog);
