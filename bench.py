@@ -1015,9 +1015,9 @@ def run_round4(dev):
         res[f"scan_filter_lgssm_d8_T256_K{tag}"] = dict(
             us_per_step=dt / T * 1e6, particle_steps_per_sec=Kf * T / dt, log_ml=lml, log_ml_rel_err=abs(lml - exact) / abs(exact),
             launches_per_step=2 if two_launch else 1,
-            launches_per_run=(2 * T if two_launch else (T + 1 if (per_step or Kf > (1 << 19)) else 5)),     # (the steps kernel holds 2 blocks per CU: K <= 2^19)
+            launches_per_run=(2 * T if two_launch else (T + 1 if per_step else 5)),
             form=("search launch + step launch per step" if two_launch else
-                  "one launch per step (search in the prologue of the step's generated kernel)" if (per_step or Kf > (1 << 19)) else
+                  "one launch per step (search in the prologue of the step's generated kernel)" if per_step else
                   "steps 0 and 1 one launch each, steps 2 .. T-1 in ONE launch (gjx_gen_steps: granules instead of kernel boundaries)"),
             hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
             algorithmic_bytes_per_particle_step=8 * dx + 24, achieved_GBs=(8 * dx + 24) * Kf / (dt / T) / 1e9,

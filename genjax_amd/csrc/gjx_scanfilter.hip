@@ -131,7 +131,11 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       for (int u = 2; u < T && same; ++u)
         same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
                steps[u].tab_dev != nullptr && gen_same_kernel(&steps[1], &steps[u], 4);
-      if (same && (int64_t)gen_steps_resident_blocks(&steps[1], 4) >= nt) {
+      // (a grid the device cannot hold at once runs with as many blocks as are resident, each taking several tiles of a step in turn:
+      // a block waits only at the top of a step, for granules every block publishes before it waits itself)
+      const int64_t resident = same ? (int64_t)gen_steps_resident_blocks(&steps[1], 4) : 0;
+      const int64_t grid_steps = resident >= nt ? nt : resident;
+      if (grid_steps > 0 && nt <= 4 * grid_steps) {
         hipStream_t st = (hipStream_t)stream;
         unsigned long long* gran_a = (unsigned long long*)steps_area;           // even steps
         unsigned long long* gran_b = gran_a + nt * kLiveGranulePad;
@@ -164,7 +168,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         sa.logw_a = logw; sa.logw_b = logw2;
         sa.gran_a = gran_a; sa.gran_b = gran_b; sa.part_a = part_a; sa.part_b = part_b;
         sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
-        const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)nt, st);
+        const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)grid_steps, st);
         if (rc2 == GJX_OK)
           return gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st);
         if (rc2 != GJX_EUNSUPPORTED) return rc2;
