@@ -659,8 +659,8 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  * kernel), then the step's kernel (GJX_SCAN_FILTER_TWO_LAUNCH=1 forces this form).  Same ancestors either way, bit for bit.  No
  * co-resident grid, nothing to time out, any K <= 2^26.
  * Every step from the third in ONE launch (the steps kernel gjx_gen_steps) when, beyond that, the step programs 1 .. T-1 are one
- * kernel (same sites: a periodic Scan — tables, keys and comb offsets are per-step arguments), T >= 4, the grid of K / 1024 blocks
- * is co-resident on the device and the workspace has the room below: a step's kernel boundary is replaced by the granules
+ * kernel (same sites: a periodic Scan — tables, keys and comb offsets are per-step arguments), T >= 4, the device holds at least a
+ * quarter of the K / 1024 tiles as co-resident blocks (a block takes several tiles of a step in turn) and the workspace has the room below: a step's kernel boundary is replaced by the granules
  * {tag, e_b, S_b} its blocks publish once their write-through stores have completed, the search of the next step polls them and
  * reads the previous step at agent scope.  Bit-identical to the per-step forms.  A grid that turns out not to be co-resident
  * (another kernel holds compute units) sets GJX_STATUS_POLL_TIMEOUT in the status word of the OP_RESAMPLE part of the workspace
