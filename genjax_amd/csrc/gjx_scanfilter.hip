@@ -144,13 +144,18 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         const float** tabs_dev = (const float**)(part_b + nt);
         uint32_t* keys_dev = (uint32_t*)(tabs_dev + T);
         double* us_dev = (double*)(keys_dev + 2 * (size_t)T);
+        // (host copies that outlive this call: an asynchronous copy from pageable memory may still read them after it returns)
         static thread_local std::vector<const float*> h_tabs;
+        static thread_local std::vector<uint32_t> h_keys;
+        static thread_local std::vector<double> h_us;
+        h_keys = keys;
+        h_us = us;
         h_tabs.assign((size_t)T, nullptr);
         for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
         hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)kLiveGranulePad * (size_t)nt, st);
         if (e == hipSuccess) e = hipMemcpyAsync(tabs_dev, h_tabs.data(), sizeof(float*) * (size_t)T, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(us_dev, us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return gjx_fail_hip(e, "gjx_scan_filter(step arguments)");
         const char* w1 = ws_of(1);
         const uint64_t* tS = (const uint64_t*)(w1 + prev.tiles_offset);
