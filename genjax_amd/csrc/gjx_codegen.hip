@@ -1018,7 +1018,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       o.f("    if (a.rs_logw) {\n      __shared__ TiledSearchShared rs_sh_;\n      __shared__ uint64_t rs_pl_[1026];\n      __shared__ int32_t rs_eb_[1024];\n"
           "      int32_t anc_[4];\n      __syncthreads();\n"
           "      if (live_) tiled_search_tile<false, true>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
-          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_, a.st_rtag, a.st_ready, a.st_step - 1u);\n"
+          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_, a.st_rtag);\n"
           "      else tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
           "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_);\n"
           "      PLOOP src_[p] = (int64_t)anc_[p];\n"
@@ -1056,16 +1056,12 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "        // its granule {tag, e_b, S_b}: the next step of every block waits for it (one tile per block: the launcher checks)\n"
       "        const float tm_ = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));\n"
       "        float se_ = 0.0f;\n        PLOOP se_ += tm_ > -INFINITY ? fast_exp(lw[p] - tm_) : 0.0f;\n        const float wse_ = wave_sum(se_);\n"
-      "        if (lane == 0) red[12 + wid] = wse_;\n        __syncthreads();\n"
-      "        if (threadIdx.x == 0) {   // the granule depends on the weights alone: it goes out at once, the `ready` word behind the stores\n"
-      "          const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3];\n"
-      "          __hip_atomic_store(&a.tile_S[tix * kLiveGranulePad], tile_granule(a.st_tag, tot_ ? e_ : kTileDead, tot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+      "        if (lane == 0) red[12 + wid] = wse_;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n"
+      "        if (threadIdx.x == 0) {\n          const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3];\n"
       "          __hip_atomic_store(&a.partials[tix], pack_f2(tm_, red[12] + red[13] + red[14] + red[15]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-      "        }\n"
-      "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");     // this wave's write-through stores of the step (thread 0: its pair too) have completed\n"
-      "        __syncthreads();\n"
-      "        if (threadIdx.x == 0) __hip_atomic_store(&a.st_ready[tix * kLiveReadyPad], a.st_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-      "      } else {\n      __syncthreads();\n"
+      "          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
+      "          __hip_atomic_store(&a.tile_S[tix * kLiveGranulePad], tile_granule(a.st_tag, tot_ ? e_ : kTileDead, tot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+      "        }\n      } else {\n      __syncthreads();\n"
       "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
       "      }\n    }\n  }\n");
   o.f("  if (a.partials && !live_) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
@@ -1097,7 +1093,6 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
           "    a.rs_S = odd ? s.gran_a : s.gran_b;\n    a.rs_E = nullptr;\n    a.rs_lse = (const float*)(odd ? s.part_a : s.part_b);\n"
           "    a.rs_n_partials = (int)(K >> 10);\n    a.rs_lse_out = s.lse_steps + 4 * (int64_t)(t - 1);\n    a.rs_u = s.us[t];\n"
           "    a.rs_anc_out = s.anc_all ? s.anc_all + (int64_t)(t - 1) * K : s.anc;\n    a.rs_ctrl = s.ctrl;\n"
-          "    a.st_ready = s.ready;\n    a.st_step = (unsigned)t;\n"
           "    a.st_tag = (unsigned long long)((s.epoch + (unsigned)t) %% 15u) + 1ull;\n    a.st_rtag = (unsigned long long)((s.epoch + (unsigned)t - 1u) %% 15u) + 1ull;\n"
           "    gjx_step_<true>(a);\n  }\n}\n");
   }

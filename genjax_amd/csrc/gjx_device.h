@@ -816,8 +816,6 @@ struct GenArgs {
   // are stored write-through at agent scope and the tile's {e_b, S_b} goes out LAST, as a granule tagged st_tag in tile_S[tix]
   // (tile_E unused); the resampling side polls rs_S for granules tagged st_rtag and reads the previous step at agent scope
   unsigned long long st_tag, st_rtag;
-  unsigned* st_ready;     // [K / 1024] (padded): the step number once the tile's block has completed its stores of that step
-  unsigned st_step;
 };
 
 // ---- arguments of `gjx_gen_steps`: steps T0 .. T-1 of a filter whose step programs share one structure (a periodic Scan) ----
@@ -835,7 +833,6 @@ struct GenStepsArgs {
   unsigned long long* part_a; unsigned long long* part_b;   // [K / 1024] block pairs {max, sumexp} of even / odd steps
   float* lse_steps;                   // [T][4]
   int32_t* anc; int32_t* anc_all;     // ancestors of the last resampling / of every resampling [T-1][K]
-  unsigned* ready;                    // [K / 1024] x kLiveReadyPad: step number a tile's block has completed
   unsigned* ctrl;                     // control block of a workspace (status word at [2])
   unsigned epoch;                     // granule tags: (epoch + t) % 15 + 1
 };

@@ -26,14 +26,12 @@ using namespace gjx;
 // tile totals {S_b, e_b} and block pairs of a step that ran as its own launch -> the tagged granules and the pair array the steps
 // kernel's first step polls / reads (gjx_gen_steps)
 __global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_t* __restrict__ E, const unsigned long long* __restrict__ pairs,
-                                    unsigned long long* gran, unsigned long long* part, unsigned* ready, unsigned step, int nt,
-                                    unsigned long long tag) {
+                                    unsigned long long* gran, unsigned long long* part, int nt, unsigned long long tag) {
   const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (b >= nt) return;
   const uint64_t sv = S[b];
   gran[(size_t)b * kLiveGranulePad] = tile_granule(tag, sv ? E[b] : kTileDead, sv);
   part[b] = pairs[b];
-  ready[(size_t)b * kLiveReadyPad] = step;
 }
 
 // rows_of(t): the buffer step t writes its choices into (two alternating buffers, or one per step when the run is recorded)
@@ -53,7 +51,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   // ... and the steps kernel (every step from the third in one launch) an area for its granules, pair arrays and per-step arguments
   const int64_t nt = K / 1024;
   const size_t steps_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
-  const size_t steps_bytes = (16 * (size_t)kLiveGranulePad + 16 + 4 * (size_t)kLiveReadyPad) * (size_t)nt + 24 * (size_t)T + 64;
+  const size_t steps_bytes = (16 * (size_t)kLiveGranulePad + 16) * (size_t)nt + 24 * (size_t)T + 64;
   char* steps_area = (room && K % 1024 == 0 && workspace_bytes >= steps_off + steps_bytes) ? (char*)workspace + steps_off : nullptr;
   const bool no_fuse = getenv("GJX_SCAN_FILTER_TWO_LAUNCH") && atoi(getenv("GJX_SCAN_FILTER_TWO_LAUNCH")) != 0;
   bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
@@ -143,8 +141,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         unsigned long long* gran_b = gran_a + nt * kLiveGranulePad;
         unsigned long long* part_a = gran_b + nt * kLiveGranulePad;
         unsigned long long* part_b = part_a + nt;
-        unsigned* ready_dev = (unsigned*)(part_b + nt);
-        const float** tabs_dev = (const float**)(ready_dev + nt * kLiveReadyPad);
+        const float** tabs_dev = (const float**)(part_b + nt);
         uint32_t* keys_dev = (uint32_t*)(tabs_dev + T);
         double* us_dev = (double*)(keys_dev + 2 * (size_t)T);
         // (host copies that outlive this call: an asynchronous copy from pageable memory may still read them after it returns)
@@ -156,7 +153,6 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         h_tabs.assign((size_t)T, nullptr);
         for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
         hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)kLiveGranulePad * (size_t)nt, st);
-        if (e == hipSuccess) e = hipMemsetAsync(ready_dev, 0, 4 * (size_t)kLiveReadyPad * (size_t)nt, st);
         if (e == hipSuccess) e = hipMemcpyAsync(tabs_dev, h_tabs.data(), sizeof(float*) * (size_t)T, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
@@ -164,7 +160,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         const char* w1 = ws_of(1);
         const uint64_t* tS = (const uint64_t*)(w1 + prev.tiles_offset);
         hipLaunchKernelGGL(k_tiles_to_granules, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tS, (const int32_t*)(tS + nt),
-                           (const unsigned long long*)(w1 + kWsHeaderBytes), gran_b, part_b, ready_dev, 1u, (int)nt, (unsigned long long)(1u % 15u) + 1ull);
+                           (const unsigned long long*)(w1 + kWsHeaderBytes), gran_b, part_b, (int)nt, (unsigned long long)(1u % 15u) + 1ull);
         GJX_CHECK_LAUNCH("gjx_scan_filter(granules of step 1)");
         GenStepsArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -176,7 +172,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         sa.in_row0_first = sa.in_row0 = (int64_t)input_rows(steps[1]) * K;
         sa.logw_a = logw; sa.logw_b = logw2;
         sa.gran_a = gran_a; sa.gran_b = gran_b; sa.part_a = part_a; sa.part_b = part_b;
-        sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ready = ready_dev; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
+        sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
         const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)grid_steps, st);
         if (rc2 == GJX_OK)
           return gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st);

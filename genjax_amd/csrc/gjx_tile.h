@@ -146,7 +146,6 @@ GJX_DEV unsigned long long tile_granule(unsigned long long tag, int e, uint64_t 
 // every tile; !PLANNED: Pl [nt + 2], Ebl [nt] are block-shared scratch (every block reduces all nt totals), PLANNED: Pg, shg
 // hold the prefix and the shifts (k_tiled_plan).  tix == 0 also finishes the LSE record of the producing run (lse_mode 2) and
 // flags a dead collection.  Every thread of the block must call it (block barriers inside).
-constexpr int kLiveReadyPad = 16;          // words between the `ready` words of the steps kernel (one per 64-byte line)
 constexpr int kLiveGranulePad = 8;         // words between the granules of the steps kernel (gjx_gen_steps)
 struct TiledSearchShared {
   float fred[8];
@@ -165,7 +164,7 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
                                const uint64_t* __restrict__ Pg, const int32_t* __restrict__ shg, const int nt, const int tix, uint64_t* const Pl,
                                int32_t* const Ebl, TiledSearchShared& sh, int lse_mode, const float* lse, int n_partials, float* lse_out,
                                float log_k_total, double u, unsigned* ctrl, unsigned long long* timeline, int32_t (&anc)[4],
-                               unsigned long long rtag = 0ull, const unsigned* ready = nullptr, unsigned ready_step = 0u) {
+                               unsigned long long rtag = 0ull) {
   static_assert(!(PLANNED && LIVE), "the live form reduces the granules itself");
 #define GJX_STAMP(n) do { if (timeline && threadIdx.x == 0) timeline[tix * 8 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   constexpr int ITEMS = 4, TILE = 256 * ITEMS, CH = 3;
@@ -219,8 +218,8 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
       Ebl[b] = e;
       em = fmaxf(em, (float)e);
     }
-    // (the granules depend on the weights alone and go out before their blocks' stores have drained; that the previous step is
-    //  readable is signalled by the `ready` words, looked at below — behind the prefix, right in front of the first foreign read)
+    __syncthreads();        // every granule of the step has been seen by some lane of this block: the whole previous step is readable
+    load_window();
   } else {
   for (int b = threadIdx.x; b < nt; b += 256) {
     const uint64_t sv = S[b];
@@ -258,22 +257,6 @@ GJX_DEV void tiled_search_tile(const float* __restrict__ x, int64_t K, const uin
   auto shift_of = [&](int t) { return PLANNED ? shg[t] : Emax - Eb[t]; };   // (a tile shifted out entirely is never a source)
   const uint64_t total = P[nt];
   GJX_STAMP(2);
-  if constexpr (LIVE) {
-    // ready[b] >= ready_step: every store of block b's step (rows, log-weights, block pair) has completed.  Monotone compare: a
-    // block that is a step ahead has completed this one
-    unsigned budget = (ctrl && (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStatusPollTimeout)) ? 0u : kPollBudget;
-    for (int b = threadIdx.x; b < nt; b += 256) {
-      unsigned r = __hip_atomic_load(&ready[(size_t)b * kLiveReadyPad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((int)(r - ready_step) < 0 && budget) {
-        --budget;
-        __builtin_amdgcn_s_sleep(1);
-        r = __hip_atomic_load(&ready[(size_t)b * kLiveReadyPad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if ((int)(r - ready_step) < 0 && ctrl) __hip_atomic_fetch_or(&ctrl[2], kStatusPollTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    load_window();
-  }
   if (tix == 0) {   // block-uniform: the LSE record of the producing run (its block partials), the dead-collection flag
     if (lse_mode == 2 && lse_out) {
       float sm_sum;

@@ -112,7 +112,7 @@ class ScanBootstrapFilter:
             # ... and behind them the area of the steps kernel (every step from the third in ONE launch: granules, pair arrays, the
             # per-step tables / keys / comb offsets); the size of the workspace handed over selects the form (include/gjx.h)
             self._ws_one_launch_per_step = need
-            need += 208 * (K // 1024) + 24 * 4096 + 1024
+            need += 144 * (K // 1024) + 24 * 4096 + 1024
             if getattr(self, "_minimal_workspace", False):        # (tests: the library then runs the two-launch step by itself)
                 need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
                 self._ws_one_launch_per_step = need

@@ -661,8 +661,8 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  * Every step from the third in ONE launch (the steps kernel gjx_gen_steps) when, beyond that, the step programs 1 .. T-1 are one
  * kernel (same sites: a periodic Scan — tables, keys and comb offsets are per-step arguments), T >= 4, the device holds at least a
  * quarter of the K / 1024 tiles as co-resident blocks (a block takes several tiles of a step in turn) and the workspace has the room below: a step's kernel boundary is replaced by the granules
- * {tag, e_b, S_b} its blocks publish (and the `ready` words that follow once their write-through stores have completed); the
- * search of the next step polls them and reads the previous step at agent scope.  Bit-identical to the per-step forms.  A grid that turns out not to be co-resident
+ * {tag, e_b, S_b} its blocks publish once their write-through stores have completed, the search of the next step polls them and
+ * reads the previous step at agent scope.  Bit-identical to the per-step forms.  A grid that turns out not to be co-resident
  * (another kernel holds compute units) sets GJX_STATUS_POLL_TIMEOUT in the status word of the OP_RESAMPLE part of the workspace
  * (workspace + gjx_workspace_bytes(GJX_OP_RUN, K)) and ends the launch: the caller repeats the run with a workspace size below
  * the steps kernel's (the size of the workspace handed over selects the form).  GJX_SCAN_FILTER_PERSISTENT=0 switches it off.
@@ -672,7 +672,7 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  *   lse_steps f32[T][4]: log-ML estimate = sum_t lse_steps[t][3];
  *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once; with
  *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the one-launch step is used (a second run workspace and log-weight buffer); with
- *   208 (K / 1024) + 24 T + 1024 bytes more, the steps kernel. */
+ *   144 (K / 1024) + 24 T + 1024 bytes more, the steps kernel. */
 int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                     float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
                     void* stream);
