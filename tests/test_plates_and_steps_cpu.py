@@ -195,3 +195,47 @@ def test_scan_step_program_on_the_oracle():
     # the same draws as a program WITHOUT the input site would make at site number 1 (INPUT sites take no number)
     o0 = cpu.run_program(progs[0], (1, 2), K)
     np.testing.assert_allclose(o0["choices"][:8], x - Am @ x_in, rtol=0, atol=2e-6)
+
+
+def test_generic_filter_on_the_oracle_alone_matches_kalman():
+    """the whole generic filter restated on the CPU — the host's step programs, the oracle's program runner and its tile-scaled
+    systematic resampler, the filter's key discipline — against the float64 Kalman log-likelihood: checks the lowering of a Scan
+    into step programs (carry as INPUT sites, observations per step) and the key chain without a GPU"""
+    from genjax_amd import workloads
+    from genjax_amd.core import fold_in, split
+    from genjax_amd.inference.pf import _unit_from_key
+    from genjax_amd.inference.scan_filter import ScanBootstrapFilter
+    from oracle import closed_form as cf
+    from oracle import cpu
+    T, K = 12, 8192
+    s = workloads.ssm_problem(dx=4, T=T)
+    Am, q, r = np.asarray(s["A"], np.float32), float(s["q"]), float(s["r"])
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(4, q, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(4, r, np.float32)) @ "y"
+        return x, None
+
+    ys = np.asarray(s["y"], np.float32)
+    progs = ScanBootstrapFilter(step.scan(n=T), K).step_programs(C["y"].set(ys), (np.zeros(4, np.float32), None))
+    assert len(progs) == T and [p.n_input_rows for p in progs] == [0] + [4] * (T - 1)
+    ests = []
+    for seed in (1, 2, 3):
+        k, log_ml, x_prev, lw_prev = genjax.key(seed), 0.0, None, None
+        for t in range(T):
+            k = fold_in(k, t)
+            kp, kr = split(k)
+            ch = np.zeros((progs[t].n_slots, K), np.float32)
+            if t > 0:
+                anc, _, _, dead = cpu.resample_systematic_tiled(lw_prev, _unit_from_key(kr))
+                assert not dead
+                ch[:4] = x_prev[:, anc]
+            o = cpu.run_program(progs[t], kp, K, choices=ch)
+            sl = progs[t].slot_of[("x", t)]
+            x_prev, lw_prev = o["choices"][sl:sl + 4], o["weight"]
+            m = lw_prev.astype(np.float64).max()
+            log_ml += m + np.log(np.exp(lw_prev.astype(np.float64) - m).mean())
+        ests.append(log_ml)
+    exact, _, _ = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"], q0=q)
+    assert abs(np.mean(ests) - exact) < 0.01 * abs(exact) and np.std(ests) < 0.01 * abs(exact), (ests, exact)
