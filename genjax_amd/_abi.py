@@ -126,9 +126,6 @@ PROTOTYPES = {
     "gjx_event_elapsed_us": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "gjx_profile_next_run": (C.c_int, [vp, vp]),
     "gjx_run_partials_count": (C.c_int, [PP, i64, i64]),
-    "gjx_last_run_partials": (C.c_int, []),
-    "gjx_last_run_tiles": (C.c_int64, []),
-    "gjx_run_want_tiles": (C.c_int, [i32]),
     "gjx_resample_gather_tiled": (C.c_int, [vp, i64, vp, vp, i32, vp, i32, f64, vp, i64, i32, vp, i64, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),
     "gjx_resample_indices": (C.c_int, [vp, i64, i32, vp, i32, f64, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp]),

@@ -1231,13 +1231,8 @@ extern "C" int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_
   return plan_engine(prog, K, particle_offset, false).grid;
 }
 
-// ---- deprecated per-thread one-shot state: wrappers around gjx_run_program_ex's explicit options / record ----
-static thread_local gjx_run_info g_last_info = {0, 0, 0};
-extern "C" int gjx_last_run_partials(void) { return g_last_info.n_partials; }
-extern "C" int64_t gjx_last_run_tiles(void) { return g_last_info.tiles_offset; }
-static thread_local int g_want_tiles = 0;
-extern "C" int gjx_run_want_tiles(int32_t on) { g_want_tiles = on ? 1 : 0; return GJX_OK; }
-
+// gjx_run_program: gjx_run_program_ex without options and without a record (the per-thread one-shot setters of ABI 6 —
+// gjx_run_want_tiles, gjx_last_run_partials, gjx_last_run_tiles — are gone: options and record are arguments)
 extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,
                                int64_t particle_offset, float* choices, float* score, float* weight,
                                float* logw, const float* logw_in, const float* sub,
@@ -1245,12 +1240,10 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
                                size_t workspace_bytes, void* stream) {
   gjx_run_opts o;
   memset(&o, 0, sizeof(o));
-  if (g_want_tiles) o.flags |= GJX_RUN_LEAVE_TILES;
-  g_want_tiles = 0;
   if (t_prof_start && t_prof_stop) { o.flags |= GJX_RUN_TIME_DISPATCH; o.start_event = (void*)t_prof_start; o.stop_event = (void*)t_prof_stop; }
   t_prof_start = t_prof_stop = nullptr;
   return gjx_run_program_ex(prog, key0, key1, K, particle_offset, choices, score, weight, logw, logw_in, sub, site_scores, lse, K_total,
-                            workspace, workspace_bytes, stream, &o, &g_last_info);
+                            workspace, workspace_bytes, stream, &o, nullptr);
 }
 
 extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K,

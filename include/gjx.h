@@ -283,8 +283,9 @@ int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64
                     float* lse, int64_t K_total, void* workspace, size_t workspace_bytes,
                     void* stream);
 
-/* The same call with its options and its record as explicit arguments — no per-thread one-shot state (gjx_run_want_tiles,
- * gjx_profile_next_run, gjx_last_run_partials, gjx_last_run_tiles are wrappers around this form and will go away).
+/* The same call with its options and its record as explicit arguments — no per-thread state (the one-shot setters and getters of
+ * ABI 6, gjx_run_want_tiles / gjx_last_run_partials / gjx_last_run_tiles, are gone; gjx_profile_next_run remains as the measurement
+ * hook of gjx_importance_step, which takes no options).
  *   opts (or NULL):
  *     flags  GJX_RUN_LEAVE_TILES   with lse == NULL: leave the {S_b, e_b} of every 1024-particle tile of logw (tile-scaled
  *                                  fixed point, below) behind the block pairs for gjx_resample_gather_tiled
@@ -417,18 +418,9 @@ int gjx_weight_cumsum(const float* x, int64_t K, int32_t is_log, const float* ls
  *                pairs rides in this call's prologue (no serial tail in the producing kernel) and, if lse_out is
  *                not NULL, the finished record {max, sumexp, lse, lse - log K_total} is written there. */
 int gjx_run_partials_count(const gjx_program* prog, int64_t K, int64_t particle_offset);
-/* the number of block pairs the LAST gjx_run_program call of the calling thread left in its workspace (the grid it
- * actually launched): record it right after the call; gjx_run_partials_count re-derives a plan and is for sizing only */
-int gjx_last_run_partials(void);
-/* byte offset, inside the workspace of the LAST gjx_run_program call of the calling thread, of the tile totals that run
- * left for gjx_resample_gather_tiled: uint64 S[nt] followed by int32 E[nt], nt = K / 1024 — or 0 when it left none.  A run
- * leaves them when gjx_run_want_tiles(1) preceded it, it is called with lse == NULL (consumer-finishes mode), K is a multiple
- * of 1024 and a block of its
- * kernel covers whole 1024-particle tiles (the hand-fused mixture kernel with 4 particles per lane). */
-int64_t gjx_last_run_tiles(void);
-/* one-shot: ask the NEXT gjx_run_program call of the calling thread to leave those tile totals (off by default: the
- * per-tile reduction costs the propagate kernel about 1 %, and only gjx_resample_gather_tiled reads them) */
-int gjx_run_want_tiles(int32_t on);
+/* (the block pairs a run left, and the byte offset of its tile totals — uint64 S[nt] followed by int32 E[nt], nt = K / 1024, left
+ * when GJX_RUN_LEAVE_TILES is set, lse == NULL, K % 1024 == 0 and a block of the kernel covers whole 1024-particle tiles — are
+ * reported in gjx_run_info by gjx_run_program_ex; gjx_run_partials_count re-derives a plan and is for sizing only) */
 /* systematic comb over the GLOBAL weight line [0, total_all): local particles cover
  * [base, base + cum[K-1]).  Output slot j (global, 0..N_total-1) sits at (j + u) * total_all / N_total.
  * Writes ancestors for output slots [out_begin, out_begin + n_out) that fall on local particles:
@@ -467,7 +459,7 @@ int gjx_resample_gather(const float* x, int64_t K, int32_t is_log, const float* 
 /* Resampling and the row gather (N = K) under GJX_WEIGHTS_TILE_SCALED (below, at gjx_ssm_filter_scheme) as a PLAIN launch:
  * no block waits for another one, so there is no co-residency requirement, no poll budget and no limit from the device's
  * capacity (K <= 2^22: 4096 tiles).  tile_S / tile_E: the {S_b, e_b} of every 1024-particle tile of logw, as the producing
- * gjx_run_program left them (gjx_last_run_tiles) — both NULL: computed here by one extra small launch into the workspace.
+ * gjx_run_program_ex left them (gjx_run_info.tiles_offset) — both NULL: computed here by one extra small launch into the workspace.
  * lse_mode 2: `lse` points at n_partials block pairs of the producing run and lse_out receives the finished record
  * (reduced by block 0, off the critical path); lse_mode 0: no record.  Ancestors (written to `ancestors` when not NULL)
  * are those of gjx_resample_indices_tiled bit for bit (oracle: gjxo_resample_systematic_tiled).  A dead collection
