@@ -895,17 +895,18 @@ class ScanCombinator(GenerativeFunction):
         return lens[0]
 
     def _unroll(self, t: _Tracer, carry, xs):
-        # a scan inside a vmap instance is a scan of its own (its own id, its own chained keys); a scan inside a scan step
-        # would interleave two key chains within one step's site numbering: not supported
-        if t.in_scan:
-            raise NotSupportedInModelBody("a scan nested inside another scan's step is not supported")
-        outer = t.step
+        # a scan inside a vmap instance is a scan of its own (its own id, its own chained keys).  A scan inside a scan STEP (the
+        # reference nests freely, scan.py:237-294) is a scan of its own as well — a fresh id per instantiation, i.e. per step of
+        # the enclosing scan — and the sites of the enclosing step BEHIND it continue under a fresh id too: the device numbers
+        # sites from 1 within a run of equal tags (include/gjx.h "Scan steps"), so re-entering the enclosing step's tag would
+        # repeat its site numbers, hence its random streams.  Every run of sites thus has its own key chain.
+        outer, outer_scan, nested = t.step, t.scan, t.in_scan
         outs = []
         sid = t.n_scans
         t.n_scans += 1
         n = self._length(xs)
-        if n >= (1 << 20) - 1 or sid >= 2048:
-            raise NotSupportedInModelBody("scan: at most 2^20 - 2 steps and 2048 scans per model")
+        if n >= (1 << 20) - 1 or t.n_scans + (1 if nested else 0) > 2048:
+            raise NotSupportedInModelBody("scan: at most 2^20 - 2 steps and 2048 scan instantiations per model (a scan inside a scan step takes two per step of the enclosing scan)")
         try:
             t.in_scan = True
             for i in range(n):
@@ -915,8 +916,12 @@ class ScanCombinator(GenerativeFunction):
                 outs.append(out)
         finally:
             t.step = outer
-            t.scan = 0
-            t.in_scan = False
+            t.in_scan = nested
+            if nested:                               # the rest of the enclosing step: a run of its own (one step, number 0)
+                t.scan = (t.n_scans << 20) | 1
+                t.n_scans += 1
+            else:
+                t.scan = outer_scan if outer_scan else 0
         return carry, outs
 
     def __call__(self, carry, xs=None):

@@ -461,8 +461,14 @@ class TestNestedCombinators:
         np.testing.assert_allclose(_np(w), want, rtol=3e-4, atol=2e-3)
         assert float(tr.get_choices()[5, 1, "sensors", "y"][0]) == pytest.approx(float(yobs[5, 1]))
 
-    def test_scan_in_scan_is_refused(self):
-        from genjax_amd.gen import NotSupportedInModelBody
+    @pytest.mark.parametrize("rng", [0, 1])
+    def test_scan_in_scan(self, rng, monkeypatch):
+        """a Scan inside a Scan step (the reference nests freely, scan.py:237-294): every instantiation of the inner scan and the
+        rest of the enclosing step behind it are runs of sites with their own chained keys (gen.py ScanCombinator._unroll), so no
+        stream repeats.  HIP == oracle on the packed program; innovations of all sites are independent unit normals; constraints
+        on one inner step of one outer step weigh as its log-density."""
+        from oracle import cpu
+        monkeypatch.setenv("GJX_RNG", "jax32" if rng else "flat")
 
         @genjax.gen
         def inner(x, _):
@@ -471,11 +477,38 @@ class TestNestedCombinators:
 
         @genjax.gen
         def outer(x, _):
-            c, _zs = inner.scan(n=3)(x, None) @ "in"
-            return c, c
+            a = genjax.normal(x, 0.5) @ "a"
+            c, _zs = inner.scan(n=3)(a, None) @ "in"
+            b = genjax.normal(c, 0.25) @ "b"
+            return b, b
 
-        with pytest.raises(NotSupportedInModelBody):
-            outer.scan(n=2).simulate(genjax.key(1), (0.0, None))
+        K, T = 1 << 15, 4
+        model = outer.scan(n=T)
+        tr = model.simulate(genjax.key(1), (0.0, None), K=K)
+        assert tr.prog.rng_mode == rng
+        o = cpu.run_program(tr.prog, genjax.key(1), K)
+        np.testing.assert_allclose(_np(tr.choices), o["choices"], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(_np(tr.score), o["score"], rtol=3e-4, atol=2e-3)
+        chm = tr.get_choices()
+        z = _np(chm[:, :, "in", "z"])                                                # [K][outer step][inner step]
+        a, b = _np(chm[:, "a"]), _np(chm[:, "b"])                                    # [K][T]
+        assert z.shape == (K, T, 3) and a.shape == (K, T)
+        inn = [a[:, 0] / 0.5]
+        for t in range(T):
+            if t:
+                inn.append((a[:, t] - b[:, t - 1]) / 0.5)
+            inn.append(z[:, t, 0] - a[:, t])
+            inn += [z[:, t, i] - z[:, t, i - 1] for i in (1, 2)]
+            inn.append((b[:, t] - z[:, t, 2]) / 0.25)
+        inn = np.stack(inn)
+        assert np.abs(inn.std(axis=1) - 1.0).max() < 0.02
+        assert np.abs(np.corrcoef(inn) - np.eye(len(inn))).max() < 0.03               # (K = 2^15: 1 / sqrt(K) = 0.0055)
+        tr2, w = model.importance(genjax.key(2), C[2, 1, "in", "z"].set(0.75), (0.0, None), K=K)
+        o2 = cpu.run_program(tr2.prog, genjax.key(2), K)
+        np.testing.assert_allclose(_np(w), o2["weight"], rtol=3e-4, atol=3e-4)
+        z2 = _np(tr2.get_choices()[:, :, "in", "z"])
+        assert (z2[:, 2, 1] == 0.75).all()
+        np.testing.assert_allclose(_np(w), -0.5 * (0.75 - z2[:, 2, 0]) ** 2 - 0.5 * np.log(2 * np.pi), rtol=3e-4, atol=3e-4)
 
 
 class TestIterateAccumulateReduceMethods:

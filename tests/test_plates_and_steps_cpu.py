@@ -239,3 +239,34 @@ def test_generic_filter_on_the_oracle_alone_matches_kalman():
         ests.append(log_ml)
     exact, _, _ = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"], q0=q)
     assert abs(np.mean(ests) - exact) < 0.01 * abs(exact) and np.std(ests) < 0.01 * abs(exact), (ests, exact)
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_scan_inside_a_scan_step_lowers_to_runs_with_their_own_keys(rng):
+    """host lowering of a Scan nested in a Scan step (gen.py ScanCombinator._unroll; the reference nests freely, scan.py:237-294):
+    a fresh scan id per instantiation of the inner scan and for the rest of the enclosing step behind it — on the oracle every
+    site's innovation is an independent unit normal (a repeated (key, site number) pair would show as a correlation of 1)"""
+    from genjax_amd.program import PackedProgram
+    from oracle import cpu
+
+    @genjax.gen
+    def inner(x, _):
+        z = genjax.normal(x, 1.0) @ "z"
+        return z, z
+
+    @genjax.gen
+    def outer(x, _):
+        a = genjax.normal(x, 0.5) @ "a"
+        c, _zs = inner.scan(n=3)(a, None) @ "in"
+        b = genjax.normal(c, 0.25) @ "b"
+        return b, b
+
+    sl, _ = outer.scan(n=2).site_list((0.0, None))
+    tags = [s.scan for s in sl.sites]
+    assert len(sl.sites) == 10 and len({t >> 20 for t in tags}) == 5          # outer, 2 x inner, 2 x continuation
+    assert [s.addr for s in sl.sites][1:4] == [(("in", "z"), (0, i)) for i in range(3)]
+    p = PackedProgram(sl, rng_mode=rng)
+    ch = cpu.run_program(p, (3, 4), 100000)["choices"]
+    names, sd = [s.addr for s in sl.sites], [0.5, 1, 1, 1, 0.25] * 2
+    inn = np.stack([(ch[p.slot_of[names[i]]] - (ch[p.slot_of[names[i - 1]]] if i else 0.0)) / sd[i] for i in range(10)])
+    assert np.abs(inn.std(axis=1) - 1.0).max() < 0.02 and np.abs(np.corrcoef(inn) - np.eye(10)).max() < 0.02
