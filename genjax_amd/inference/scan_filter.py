@@ -44,6 +44,8 @@ class ScanBootstrapFilter:
     # -- the T one-step programs -------------------------------------------------------------------------------
     def step_programs(self, constraint: ChoiceMap, args) -> list[PackedProgram]:
         sl, _ = self.scan.site_list(tuple(args))
+        if len({(int(s.scan) & 0xFFFFFFFF) >> 20 for s in sl.sites}) > 1:
+            raise NotImplementedError("ScanBootstrapFilter: the kernel contains a Scan of its own (its steps cannot be told from the filter's)")
         steps: list[list[Site]] = []
         for s in sl.sites:
             t = _step_of(s)
