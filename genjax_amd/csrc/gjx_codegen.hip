@@ -960,7 +960,8 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   o.f("template <int N> GJX_DEV void vec_store_live(float* q, const float (&x)[N]) { _Pragma(\"unroll\") for (int k = 0; k < N; ++k) store_agent(q + k, x[k]); }\n"
       "template <> GJX_DEV void vec_store_live<4>(float* q, const float (&x)[4]) { store_agent_x4(q, x); }\n"
       "#define VSTORE(q, x) do { if (live_) vec_store_live<PPT>(q, x); else VecStore<PPT>::st(q, x); } while (0)\n"
-      "#define LDIN(q) (live_ ? load_agent(q) : *(q))\n");
+      "#define LDIN(q) (live_ ? load_agent(q) : *(q))\n"
+      "#define TSTAMP(n) do { if (live_ && a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)\n");
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
     // (two blocks per CU by launch bounds: with at most 256 VGPRs per lane the compiler keeps the matrix-core accumulators in
     // VGPRs — the elementwise phase reads them there; the AGPR form it picks otherwise ran the loop at HALF the matrix rate)
@@ -970,7 +971,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   else
   o.f("template <bool LIVE_>\nstatic __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
-  o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n");
+  o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n  TSTAMP(0);\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
   // companions: one pass per entry, spread over the block
   for (auto& c : pl.comps) {
@@ -1000,7 +1001,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     }
   }
   if (!pl.comps.empty()) o.f("  __syncthreads();\n");
-  o.f("%s", pl.key_decls.c_str());
+  o.f("  TSTAMP(1);\n%s", pl.key_decls.c_str());
   o.f("  const int64_t K = a.K;\n  const int64_t tile = 256 * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
       "  float tmax = -INFINITY, tsum = 0.0f;\n"
       "  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {\n"
@@ -1018,10 +1019,10 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       o.f("    if (a.rs_logw) {\n      __shared__ TiledSearchShared rs_sh_;\n      __shared__ uint64_t rs_pl_[1026];\n      __shared__ int32_t rs_eb_[1024];\n"
           "      int32_t anc_[4];\n      __syncthreads();\n"
           "      if (live_) tiled_search_tile<false, true>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
-          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_, a.st_rtag);\n"
+          "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, live_ && a.tl ? a.tl + (size_t)blockIdx.x * 16 + 8 - (size_t)tix * 8 : nullptr, anc_, a.st_rtag);\n"
           "      else tiled_search_tile<false>(a.rs_logw, K, (const uint64_t*)a.rs_S, a.rs_E, nullptr, nullptr, (int)ntiles, (int)tix, rs_pl_, rs_eb_, rs_sh_,\n"
           "                               a.rs_lse_out ? 2 : 0, a.rs_lse, a.rs_n_partials, a.rs_lse_out, a.log_k_total, a.rs_u, a.rs_ctrl, nullptr, anc_);\n"
-          "      PLOOP src_[p] = (int64_t)anc_[p];\n"
+          "      TSTAMP(2);\n      PLOOP src_[p] = (int64_t)anc_[p];\n"
           "      if (a.rs_anc_out) *reinterpret_cast<int4*>(a.rs_anc_out + i0) = make_int4(anc_[0], anc_[1], anc_[2], anc_[3]);\n    }\n");
   }
   // rows that already hold values (per-particle constraints, mask flags)
@@ -1038,7 +1039,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   for (int r = 0; r < prog->n_slots; ++r)
     if (pre[r]) o.f("    PLOOP v[%d][p] = a.choices[(int64_t)%d * K + i0 + p];\n", r, r);
   o.s += body.s;
-  o.f("    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
+  o.f("    TSTAMP(3);\n    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
       "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
       "    if (a.logw) VSTORE(a.logw + i0, lw);\n"
       "    float m4 = tmax;\n    PLOOP m4 = fmaxf(m4, lw[p]);\n"
@@ -1056,7 +1057,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "        // its granule {tag, e_b, S_b}: the next step of every block waits for it (one tile per block: the launcher checks)\n"
       "        const float tm_ = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));\n"
       "        float se_ = 0.0f;\n        PLOOP se_ += tm_ > -INFINITY ? fast_exp(lw[p] - tm_) : 0.0f;\n        const float wse_ = wave_sum(se_);\n"
-      "        if (lane == 0) red[12 + wid] = wse_;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n"
+      "        if (lane == 0) red[12 + wid] = wse_;\n        TSTAMP(4);\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n        TSTAMP(5);\n"
       "        if (threadIdx.x == 0) {\n          const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3];\n"
       "          __hip_atomic_store(&a.partials[tix], pack_f2(tm_, red[12] + red[13] + red[14] + red[15]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
       "          asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
@@ -1093,6 +1094,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
           "    a.rs_S = odd ? s.gran_a : s.gran_b;\n    a.rs_E = nullptr;\n    a.rs_lse = (const float*)(odd ? s.part_a : s.part_b);\n"
           "    a.rs_n_partials = (int)(K >> 10);\n    a.rs_lse_out = s.lse_steps + 4 * (int64_t)(t - 1);\n    a.rs_u = s.us[t];\n"
           "    a.rs_anc_out = s.anc_all ? s.anc_all + (int64_t)(t - 1) * K : s.anc;\n    a.rs_ctrl = s.ctrl;\n"
+          "    a.tl = (s.timeline && t == s.T / 2) ? s.timeline : nullptr;\n"
           "    a.st_tag = (unsigned long long)((s.epoch + (unsigned)t) %% 15u) + 1ull;\n    a.st_rtag = (unsigned long long)((s.epoch + (unsigned)t - 1u) %% 15u) + 1ull;\n"
           "    gjx_step_<true>(a);\n  }\n}\n");
   }

@@ -816,6 +816,7 @@ struct GenArgs {
   // are stored write-through at agent scope and the tile's {e_b, S_b} goes out LAST, as a granule tagged st_tag in tile_S[tix]
   // (tile_E unused); the resampling side polls rs_S for granules tagged st_rtag and reads the previous step at agent scope
   unsigned long long st_tag, st_rtag;
+  unsigned long long* tl;    // debug (gjx_debug_timeline): 16 realtime stamps per tile of one step of the steps kernel, or NULL
 };
 
 // ---- arguments of `gjx_gen_steps`: steps T0 .. T-1 of a filter whose step programs share one structure (a periodic Scan) ----
@@ -834,6 +835,7 @@ struct GenStepsArgs {
   float* lse_steps;                   // [T][4]
   int32_t* anc; int32_t* anc_all;     // ancestors of the last resampling / of every resampling [T-1][K]
   unsigned* ctrl;                     // control block of a workspace (status word at [2])
+  unsigned long long* timeline;       // debug: stamps of step T / 2 (profiles/microbench/scan_steps_timeline.py)
   unsigned epoch;                     // granule tags: (epoch + t) % 15 + 1
 };
 

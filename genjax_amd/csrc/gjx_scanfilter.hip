@@ -173,6 +173,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         sa.logw_a = logw; sa.logw_b = logw2;
         sa.gran_a = gran_a; sa.gran_b = gran_b; sa.part_a = part_a; sa.part_b = part_b;
         sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
+        sa.timeline = gjx::debug_timeline(128 * (size_t)grid_steps);
         const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)grid_steps, st);
         if (rc2 == GJX_OK)
           return gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st);

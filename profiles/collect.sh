@@ -77,6 +77,7 @@ python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E "
 SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
 python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
 python $R/profiles/microbench/gather_tiled_timeline.py 2>/dev/null | grep -E " us" > $OUT/${TAG}_resample_gather_tiled_timeline.txt
+python $R/profiles/microbench/scan_steps_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_scan_steps_timeline.txt
 bash $R/profiles/gputests.sh $TAG > /dev/null 2>&1; cp $OUT/gputest_summary.txt $OUT/${TAG}_gputest_summary.txt; rm -f $OUT/gputest_test_*.txt $OUT/gputest_summary.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT
