@@ -994,15 +994,14 @@ def run_round4(dev):
         for i in range(n):
             out = bf.run(genjax.key(10 + i), chm, args)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, float(out["log_ml"])
+        return (time.perf_counter() - t0) / n, float(out["log_ml"]), out.get("info", {})
 
     exact = _kalman_log_lik(s["A"], s["y"], q, r, q)          # float64 closed form (x_0 ~ N(0, q^2 I): the Scan's step 0)
     ys_d = torch.as_tensor(s["y"], device=dev)
-    two_launch = bool(int(os.environ.get("GJX_SCAN_FILTER_TWO_LAUNCH", "0") or 0))
-    per_step = os.environ.get("GJX_SCAN_FILTER_PERSISTENT", "1") == "0"
     for Kf, tag in ((K, "2e18"), (1 << 20, "2e20")):
         bf = BootstrapFilter(lg_step.scan(n=T), Kf)
-        dt, lml = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=5 if Kf == K else 3)
+        bf.alias_outputs = True                      # (the timed loop hands out the filter's own buffers: no copies inside the timing)
+        dt, lml, finfo = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=5 if Kf == K else 3)
         hand = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], q0=q), Kf, weights="tile_scaled")
         for i in range(3):
             hand.run(genjax.key(i), ys_d, device=dev)
@@ -1014,16 +1013,15 @@ def run_round4(dev):
         dth = (time.perf_counter() - t0) / 5
         res[f"scan_filter_lgssm_d8_T256_K{tag}"] = dict(
             us_per_step=dt / T * 1e6, particle_steps_per_sec=Kf * T / dt, log_ml=lml, log_ml_rel_err=abs(lml - exact) / abs(exact),
-            launches_per_step=2 if two_launch else 1,
-            launches_per_run=(2 * T if two_launch else (T + 1 if per_step else 5)),
-            form=("search launch + step launch per step" if two_launch else
-                  "one launch per step (search in the prologue of the step's generated kernel)" if per_step else
-                  "steps 0 and 1 one launch each, steps 2 .. T-1 in ONE launch (gjx_gen_steps: granules instead of kernel boundaries)"),
+            # the form the LIBRARY reports for this run (gjx_filter_info), not what the environment asked for
+            form=finfo.get("form_name"), form_id=finfo.get("form"), launches_per_run=finfo.get("launches"), grid=finfo.get("grid"),
+            tiles_per_block=finfo.get("tiles_per_block"),
             hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
-            algorithmic_bytes_per_particle_step=8 * dx + 24, achieved_GBs=(8 * dx + 24) * Kf / (dt / T) / 1e9,
-            frac_of_hbm=(8 * dx + 24) * Kf / (dt / T) / 1e9 / HBM_PEAK_GBS,
-            engine=("k_resample_gather_tiled<rows = 0> + gjx_gen (generated, INPUT rows through the ancestors)" if two_launch else
-                    "gjx_gen / gjx_gen_steps: the tile-scaled resampler's search in the prologue of the step's generated code, INPUT rows through the ancestors"))
+            roofline=dict(bound="hbm", algorithmic_bytes_per_particle_step=8 * dx + 24, bytes_per_step=(8 * dx + 24) * Kf, us_per_step=dt / T * 1e6,
+                          achieved=(8 * dx + 24) * Kf / (dt / T) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=(8 * dx + 24) * Kf / (dt / T) / 1e9 / HBM_PEAK_GBS, timing="wall clock over whole runs incl. step 0 and the host's calls"),
+            engine=("gjx_gen_pf: the step program's sites as the model of the shared filter skeleton (csrc/gjx_pfcore.h), 16 waves per tile"
+                    if finfo.get("form") == 3 else "gjx_gen / gjx_gen_steps: the tile-scaled resampler's search in the prologue of the step's generated code"))
     with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
         fx = json.load(f)
     phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
@@ -1035,8 +1033,10 @@ def run_round4(dev):
         return x, None
 
     bsv = BootstrapFilter(sv_step.scan(n=len(ysv)), K)
-    dts, lsv = time_filter(bsv, CM["y"].set(ysv), (0.0, None))
+    bsv.alias_outputs = True
+    dts, lsv, sinfo = time_filter(bsv, CM["y"].set(ysv), (0.0, None))
     res["scan_filter_stochastic_volatility_T256_K2e18"] = dict(us_per_step=dts / len(ysv) * 1e6, log_ml=lsv, float64_filter_mean=fx["log_ml_mean"],
+                                                               form=sinfo.get("form_name"), launches_per_run=sinfo.get("launches"),
                                                                float64_filter_std=fx["log_ml_std"], z=(lsv - fx["log_ml_mean"]) / fx["log_ml_std"])
     # (2) the vmapped mixture
     N, Kp = 4096, 1 << 17

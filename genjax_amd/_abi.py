@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -75,6 +75,21 @@ class GjxRunOpts(C.Structure):
 
 class GjxRunInfo(C.Structure):
     _fields_ = [("n_partials", i32), ("engine", i32), ("tiles_offset", i64)]
+
+
+# gjx_scan_filter: flags, forms, options, record (include/gjx.h)
+FILTER_NO_WIDE, FILTER_NO_STEPS, FILTER_NO_ONE_LAUNCH, FILTER_TWO_LAUNCH = 1, 2, 3, 4
+FILTER_FORM_TWO_LAUNCH, FILTER_FORM_PER_STEP, FILTER_FORM_STEPS, FILTER_FORM_WIDE = 0, 1, 2, 3
+FILTER_FORM_NAMES = {0: "two launches per step", 1: "one launch per step", 2: "steps kernel (256 threads x 4 particles)",
+                     3: "filter kernel on the shared skeleton (16 waves per tile)"}
+
+
+class GjxFilterOpts(C.Structure):
+    _fields_ = [("flags", i32), ("coresident_blocks", i32), ("timeline", vp), ("timeline_bytes", i64)]
+
+
+class GjxFilterInfo(C.Structure):
+    _fields_ = [("form", i32), ("launches", i32), ("grid", i32), ("tiles_per_block", i32)]
 
 
 class GjxSsm(C.Structure):
@@ -151,8 +166,10 @@ PROTOTYPES = {
     "gjx_ssm_filter_scheme": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_move": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, vp,
                                       C.c_size_t, vp]),
-    "gjx_scan_filter": (C.c_int, [vp, i32, u32, u32, i64, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
-    "gjx_scan_filter_history": (C.c_int, [vp, i32, u32, u32, i64, vp, i32, vp, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_scan_filter": (C.c_int, [vp, i32, u32, u32, i64, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]),
+    "gjx_scan_filter_history": (C.c_int, [vp, i32, u32, u32, i64, vp, i32, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]),
+    "gjx_program_filter_source": (i64, [PP, i32, C.c_char_p, i64]),
+    "gjx_program_filter_precompile": (C.c_int, [PP, i32]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),

@@ -27,6 +27,7 @@
 
 #include "gjx_device.h"
 #include "gjx_host.h"
+#include "gjx_pfcore.h"
 
 namespace {
 
@@ -41,6 +42,9 @@ const char* kScanHeader =
     ;
 const char* kTileHeader =
 #include "build/gjx_tile_h.inc"
+    ;
+const char* kPfCoreHeader =
+#include "build/gjx_pfcore_h.inc"
     ;
 
 // ---------------------------------------------------------------------------------------------------------
@@ -149,6 +153,11 @@ struct Plan {
   std::string key_decls;            // definitions of the chained step keys, in order
   std::vector<Companion> comps;
   int comp_floats = 0;
+  // filter flavour (generate_pf): standard-normal draws of sampled normal sites are taken ahead of the site — while the step's
+  // granules travel — into Draws::nz; hoist_at[j] = the site's first entry there, or -1
+  std::vector<int> hoist_at;
+  int n_hoist = 0;
+  bool pf = false;
   int find(int kind, int off, int n, int len = 0, int dim = 0) {
     for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n && c.len == len && c.dim == dim) return c.at;
     Companion c{kind, off, n, comp_floats, len, dim};
@@ -661,7 +670,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
   const int np = n_params(kind);
-  if (pl.stream[j].opens) {
+  const int hoist = (!pl.hoist_at.empty() && pl.hoist_at[j] >= 0) ? pl.hoist_at[j] : -1;
+  if (pl.stream[j].opens && hoist < 0) {
     const SiteStream& hs = pl.stream[j];
     o.f("    BitStream<RNG> rs%d[PPT];\n    PLOOP rs%d[p].open(%s, gidx[p], %du);\n", hs.run, hs.run,
         hs.key_var.empty() ? "a.key" : hs.key_var.c_str(), hs.site_no);
@@ -683,6 +693,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // JAX32: site key = fold_in(instance key, position in the body) (static.py:349-352 inside the vmapped kernel)
     if (prog->rng_mode == GJX_RNG_FLAT) o.f("      BitStream<RNG> (&bs)[PPT] = ps%d;\n", j);
     else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open_site_key(fold_in(ik_[p], %du));\n", ri.plate_l + 1);
+  } else if (draws && hoist >= 0) {
+    // (filter flavour: the site's standard normals were drawn ahead, dr_->nz)
   } else if (draws && ss.run >= 0) {
     // member of a scalar-normal run: the run's stream lives OUTSIDE the site's block (declared by the head, in the
     // enclosing scope), members 2k and 2k+1 share one Box-Muller evaluation through its pair cache
@@ -788,7 +800,10 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (logb.empty()) logb = "fast_log(pb)";
         if (rcpb.empty()) rcpb = "fast_rcp(pb)";
         o.f("%sfloat val;\n", in2.c_str());
-        if (mode == GJX_MODE_SAMPLE) {
+        if (mode == GJX_MODE_SAMPLE && hoist >= 0) {
+          o.f("%sconst float n_ = dr_->nz[%d + (%s)];\n", in2.c_str(), hoist, dx.c_str());
+          o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
+        } else if (mode == GJX_MODE_SAMPLE) {
           o.f("%sconst float n_ = stream_normal<RNG>(bs[p], %s + (uint32_t)(%u + (%s)));\n", in2.c_str(), ebase.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
           o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
         } else {
@@ -841,18 +856,29 @@ void emit_site(Emit& o, Plan& pl, int j) {
 
 bool want_roll() { const char* e = getenv("GJX_GEN_ROLL"); return e && atoi(e) != 0; }
 
-std::string generate(const gjx_program* prog_in, int ppt_code) {
-  const int ppt = ppt_code & 255;
-  const bool mfma = (ppt_code >> 8) != 0 && ppt == 1;
-  // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
+// everything the emitter derives from a program before it writes a line: the emitted site list (plates / a rolled Scan remapped to
+// registers), stream keys, site numbers, scalar-normal runs
+struct GenCtx {
   Roll roll;
-  const PlateXf px = plate_program(prog_in);
-  if (!px.any && (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots))) roll = detect_roll(prog_in);
-  gjx_program eprog = *prog_in;
+  PlateXf px;
+  gjx_program eprog;
+  Plan pl;
+};
+
+void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allow_roll = true) {
+  const int ppt = ppt_code & 255;
+  const bool mfma = ((ppt_code >> 8) & 1) != 0 && ppt == 1;
+  Roll& roll = g.roll;
+  Plan& pl = g.pl;
+  // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
+  g.px = plate_program(prog_in);
+  const PlateXf& px = g.px;
+  if (allow_roll && !px.any && (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots))) roll = detect_roll(prog_in);
+  g.eprog = *prog_in;
+  gjx_program& eprog = g.eprog;
   if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_regs; }
   if (px.any) { eprog.sites = px.sites.data(); eprog.n_sites = (int)px.sites.size(); eprog.n_slots = px.n_regs; }
   const gjx_program* prog = &eprog;
-  Plan pl;
   pl.prog = prog;
   pl.ppt = ppt;
   pl.mfma = mfma;
@@ -902,6 +928,13 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     int n_runs = 0;
     assign_runs(prog, pl.stream, 0, prog->n_sites, n_runs);
   }
+}
+
+// the sites of the planned program, in order (a rolled Scan as a loop, a plate as an instance loop)
+std::string emit_body(GenCtx& g) {
+  Roll& roll = g.roll;
+  Plan& pl = g.pl;
+  const gjx_program* prog = pl.prog;
   Emit body;
   if (roll.ok) {
     auto carry = [&]() {   // the step just produced becomes the previous step
@@ -945,6 +978,48 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       j += m;
     }
   }
+  return body.s;
+}
+
+// derived constants (Companion) from the float table: one pass per entry, spread over the block.  The emitted code reads the table
+// through TSRC(i) (the LDS copy, or the step's table in global memory) and strides by BT_ threads
+void emit_companions(Emit& o, Plan& pl) {
+  for (auto& c : pl.comps) {
+    if (c.kind == 0) o.f("  for (int t = threadIdx.x; t < %d; t += BT_) COMP(%d + t) = fast_log(TSRC(%d + t));\n", c.n, c.at, c.off);
+    else if (c.kind == 1) o.f("  for (int t = threadIdx.x; t < %d; t += BT_) COMP(%d + t) = fast_rcp(TSRC(%d + t));\n", c.n, c.at, c.off);
+    else if (c.kind == 4)
+      o.f("  for (int t = threadIdx.x; t < %d; t += BT_) COMP(%d + t) = TSRC(%d + t) * fast_rcp(TSRC(%d + t %% %d));\n", c.n, c.at, c.dim, c.off, c.len);
+    else if (c.kind == 3) {
+      int p2 = 1;
+      while (p2 < c.dim) p2 <<= 1;
+      if (p2 <= 64) {   // one (row, element) per lane, rows are aligned groups of p2 lanes: sum by xor-shuffles
+        o.f("  for (int t0 = 0; t0 < %d; t0 += BT_) {\n    const int t = t0 + threadIdx.x, r_ = t / %d, e_ = t %% %d;\n"
+            "    float s_ = (r_ < %d && e_ < %d) ? kHalfLog2Pi + fast_log(TSRC(%d + r_ * %d + e_ %% %d)) : 0.0f;\n",
+            c.n * p2, p2, p2, c.n, c.dim, c.off, c.len, c.len);
+        for (int o2 = p2 >> 1; o2 >= 1; o2 >>= 1) o.f("    s_ += __shfl_xor(s_, %d, 64);\n", o2);
+        o.f("    if (r_ < %d && e_ == 0) COMP(%d + r_) = s_;\n  }\n", c.n, c.at);
+      } else {
+        o.f("  for (int t = threadIdx.x; t < %d; t += BT_) { float s_ = 0.0f; for (int e_ = 0; e_ < %d; ++e_) s_ += kHalfLog2Pi + fast_log(TSRC(%d + t * %d + e_ %% %d)); COMP(%d + t) = s_; }\n",
+            c.n, c.dim, c.off, c.len, c.len, c.at);
+      }
+    }
+    else {
+      o.f("  if (threadIdx.x == 0) {   // running CDF (float32, category order) and log-sum-exp of constant logits\n"
+          "    float mx = -INFINITY;\n    for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, TSRC(%d + c_));\n"
+          "    float run = 0.0f;\n    for (int c_ = 0; c_ < %d; ++c_) { run += fast_exp(TSRC(%d + c_) - mx); COMP(%d + c_) = run; }\n"
+          "    COMP(%d) = mx + fast_log(run);\n  }\n", c.n, c.off, c.n, c.off, c.at, c.at + c.n);
+    }
+  }
+}
+
+std::string generate(const gjx_program* prog_in, int ppt_code) {
+  const int ppt = ppt_code & 255;
+  GenCtx g;
+  plan_program(prog_in, ppt_code, g);
+  Plan& pl = g.pl;
+  const gjx_program* prog = pl.prog;
+  const bool mfma = pl.mfma;
+  const std::string body_s = emit_body(g);
   Emit o;
   o.f("#include \"gjx_device.h\"\n#include \"gjx_tile.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
@@ -973,33 +1048,9 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
   o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n  TSTAMP(0);\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
-  // companions: one pass per entry, spread over the block
-  for (auto& c : pl.comps) {
-    if (c.kind == 0) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_log(TAB(%d + t));\n", c.n, c.at, c.off);
-    else if (c.kind == 1) o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = fast_rcp(TAB(%d + t));\n", c.n, c.at, c.off);
-    else if (c.kind == 4)
-      o.f("  for (int t = threadIdx.x; t < %d; t += 256) COMP(%d + t) = TAB(%d + t) * fast_rcp(TAB(%d + t %% %d));\n", c.n, c.at, c.dim, c.off, c.len);
-    else if (c.kind == 3) {
-      int p2 = 1;
-      while (p2 < c.dim) p2 <<= 1;
-      if (p2 <= 64) {   // one (row, element) per lane, rows are aligned groups of p2 lanes: sum by xor-shuffles
-        o.f("  for (int t0 = 0; t0 < %d; t0 += 256) {\n    const int t = t0 + threadIdx.x, r_ = t / %d, e_ = t %% %d;\n"
-            "    float s_ = (r_ < %d && e_ < %d) ? kHalfLog2Pi + fast_log(TAB(%d + r_ * %d + e_ %% %d)) : 0.0f;\n",
-            c.n * p2, p2, p2, c.n, c.dim, c.off, c.len, c.len);
-        for (int o2 = p2 >> 1; o2 >= 1; o2 >>= 1) o.f("    s_ += __shfl_xor(s_, %d, 64);\n", o2);
-        o.f("    if (r_ < %d && e_ == 0) COMP(%d + r_) = s_;\n  }\n", c.n, c.at);
-      } else {
-        o.f("  for (int t = threadIdx.x; t < %d; t += 256) { float s_ = 0.0f; for (int e_ = 0; e_ < %d; ++e_) s_ += kHalfLog2Pi + fast_log(TAB(%d + t * %d + e_ %% %d)); COMP(%d + t) = s_; }\n",
-            c.n, c.dim, c.off, c.len, c.len, c.at);
-      }
-    }
-    else {
-      o.f("  if (threadIdx.x == 0) {   // running CDF (float32, category order) and log-sum-exp of constant logits\n"
-          "    float mx = -INFINITY;\n    for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, TAB(%d + c_));\n"
-          "    float run = 0.0f;\n    for (int c_ = 0; c_ < %d; ++c_) { run += fast_exp(TAB(%d + c_) - mx); COMP(%d + c_) = run; }\n"
-          "    COMP(%d) = mx + fast_log(run);\n  }\n", c.n, c.off, c.n, c.off, c.at, c.at + c.n);
-    }
-  }
+  o.f("#define TSRC(i) TAB(i)\n#define BT_ 256\n");
+  emit_companions(o, pl);
+  o.f("#undef TSRC\n#undef BT_\n");
   if (!pl.comps.empty()) o.f("  __syncthreads();\n");
   o.f("  TSTAMP(1);\n%s", pl.key_decls.c_str());
   o.f("  const int64_t K = a.K;\n  const int64_t tile = 256 * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
@@ -1038,7 +1089,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   }
   for (int r = 0; r < prog->n_slots; ++r)
     if (pre[r]) o.f("    PLOOP v[%d][p] = a.choices[(int64_t)%d * K + i0 + p];\n", r, r);
-  o.s += body.s;
+  o.s += body_s;
   o.f("    TSTAMP(3);\n    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
       "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
       "    if (a.logw) VSTORE(a.logw + i0, lw);\n"
@@ -1100,6 +1151,150 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   }
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
   o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
+  return o.s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generated filter kernels (`gjx_gen_pf`): the step program of a Scan kernel as the MODEL of the one-launch filter skeleton
+// pf_core (gjx_pfcore.h) — the skeleton the hand-written linear-Gaussian filter k_pf_persistent runs on.  A tile of 1024
+// particles is one block of 16 waves, ONE particle per lane; the step's table is staged in LDS (with its derived constants)
+// while the granules of the rendezvous travel, the standard-normal draws of the step's sampled normal sites are taken in the same
+// wait (they depend on the key and the particle index only: same streams, same bits), and behind the search a slot gathers
+// its carry from its ancestor's row — on this device or, for a collection sharded over the GPUs of a node, through a peer mapping
+// — and runs the emitted sites.  Reference: Scan.generate's step recursion (combinators/scan.py:237-294); the filter itself is
+// the build's.  SPL = tiles per block (the launcher picks the smallest whose grid is co-resident).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kPfMaxHoist = 32;        // standard normals a lane keeps across the search
+
+bool pf_supported(const gjx_program* p) {
+  if (p->n_sites < 1 || p->n_tab > 16384) return false;
+  bool has_input = false;
+  for (int j = 0; j < p->n_sites; ++j) {
+    const int md = p->sites[j].mode;
+    if (md != GJX_MODE_SAMPLE && md != GJX_MODE_OBS_TAB && md != GJX_MODE_INPUT) return false;
+    if (p->sites[j].scan != 0) return false;
+    has_input = has_input || md == GJX_MODE_INPUT;
+  }
+  return has_input && supported_uncached(p);
+}
+
+std::string generate_pf(const gjx_program* prog_in, int spl) {
+  if (!pf_supported(prog_in)) return "";
+  GenCtx g;
+  plan_program(prog_in, 1, g, false);
+  Plan& pl = g.pl;
+  const gjx_program* prog = pl.prog;
+  pl.pf = true;
+  pl.tab_lds = true;
+  // ---- which draws are taken ahead: sampled normal sites outside plates, whole scalar-normal runs or none of a run ----
+  const int ns = prog->n_sites;
+  pl.hoist_at.assign(ns, -1);
+  if (!getenv("GJX_GEN_NO_HOIST")) {
+    for (int j = 0; j < ns; ++j) {
+      const gjx_site& s = prog->sites[j];
+      const RollInfo& ri = pl.info[j];
+      if (ri.plate || s.mode != GJX_MODE_SAMPLE || !is_normal(s.kind) || s.dim > kMaxExpandDim || pl.hoist_at[j] >= 0) continue;
+      if (pl.stream[j].run >= 0) {
+        if (!pl.stream[j].opens) continue;                       // (a member is decided with its head)
+        int members = 0;
+        for (int l = j; l < ns; ++l) members += pl.stream[l].run == pl.stream[j].run;
+        if (pl.n_hoist + members > kPfMaxHoist) continue;
+        for (int l = j; l < ns; ++l) if (pl.stream[l].run == pl.stream[j].run) pl.hoist_at[l] = pl.n_hoist++;
+      } else if (pl.n_hoist + s.dim <= kPfMaxHoist) {
+        pl.hoist_at[j] = pl.n_hoist;
+        pl.n_hoist += s.dim;
+      }
+    }
+  }
+  const std::string body_s = emit_body(g);
+  int n_in = 0;
+  for (int j = 0; j < ns; ++j) if (prog->sites[j].mode == GJX_MODE_INPUT) n_in += prog->sites[j].dim;
+  Emit o;
+  o.f("#include \"gjx_device.h\"\n#include \"gjx_pfcore.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT 1\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
+      prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT);
+  o.f("#define NTAB %d\n#define NCOMP %d\n#define SPL %d\n#define NHOIST %d\n#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n", prog->n_tab, pl.comp_floats, spl, pl.n_hoist);
+  o.f("template <int N> struct VecStore;\n"
+      "template <> struct VecStore<1> { static GJX_DEV void st(float* q, const float (&x)[1]) { *q = x[0]; } };\n"
+      "typedef float v4f_ __attribute__((ext_vector_type(4)));\n"
+      "#define VSTORE(q, x) do { if (act_) store_scoped((q), (x)[0], sys_); } while (0)\n"
+      "#define LDIN(q) load_scoped((q), sys_)\n");
+  o.f("struct GenPfModel {\n  const GenPfArgs& f;\n  float* const tab_s;\n"
+      "  struct Draws { float nz[NHOIST > 0 ? NHOIST : 1]; };\n"
+      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t) : f(a), tab_s(t) {}\n"
+      "  GJX_DEV float* rows(int t) const { return f.rows_all ? f.rows_all + (int64_t)t * f.rows_step : ((t & 1) ? f.rows_b : f.rows_a); }\n"
+      "  GJX_DEV const float* in_rows(int t) const { return rows(t - 1) + (t == 1 ? f.in_row0_first : f.in_row0); }   // the OWN rows of step t - 1\n"
+      "  GJX_DEV void prologue(int) {}\n"
+      "  GJX_DEV void epilogue(int) {}\n");
+  // ---- stage: the step's table and what derives from it, while the granules travel ----
+  o.f("  GJX_DEV void stage(int t, int tid) {\n    const float* __restrict__ tb_ = f.tabs[t];\n"
+      "    for (int e = tid; e < NTAB; e += %d) tab_s[e] = tb_[e];\n#define TSRC(i) tb_[i]\n#define BT_ %d\n", 1024, 1024);
+  {
+    Emit c;
+    emit_companions(c, pl);
+    o.s += c.s;
+  }
+  o.f("#undef TSRC\n#undef BT_\n  }\n");
+  // ---- draw: the standard normals of the hoisted sites (the statements the sites themselves would run) ----
+  o.f("  GJX_DEV void draw(int, key2 key, uint64_t gidx_, Draws& d) const {\n    (void)key; (void)gidx_; (void)d;\n");
+  for (int j = 0; j < ns; ++j) {
+    if (pl.hoist_at[j] < 0) continue;
+    const SiteStream& ss = pl.stream[j];
+    const gjx_site& s = prog->sites[j];
+    if (ss.run >= 0) {
+      if (!ss.opens) continue;
+      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // scalar-normal run %d\n", ss.site_no, ss.run);
+      for (int l = j; l < ns; ++l)
+        if (pl.stream[l].run == ss.run) o.f("      d.nz[%d] = stream_normal<RNG>(bs, 0u + (uint32_t)(%u + (0)));\n", pl.hoist_at[l], pl.stream[l].elem);
+      o.f("    }\n");
+    } else {
+      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // site %d\n", ss.site_no, j);
+      for (int d = 0; d < s.dim; ++d) o.f("      d.nz[%d] = stream_normal<RNG>(bs, 0u + (uint32_t)(0 + (%d)));\n", pl.hoist_at[j] + d, d);
+      o.f("    }\n");
+    }
+  }
+  o.f("  }\n");
+  // ---- verify mode (GJX_PEER_VERIFY, gjx_peer.hip): the check word of the rows the previous LAUNCH (step 0) wrote ----
+  o.f("  GJX_DEV void seal_prev(int t_prev, int j, uint32_t gslot, const PfSlotCtx& cx) const {\n"
+      "    const float* r_ = in_rows(t_prev + 1);\n    uint32_t h = row_check_init(t_prev, gslot);\n");
+  for (int j = 0; j < ns; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.mode != GJX_MODE_INPUT) continue;
+    for (int d = 0; d < s.dim; ++d) o.f("    h = row_check_mix(h, r_[(int64_t)%d * cx.K + j]);\n", s.obs_off + d);
+  }
+  o.f("    store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? h ^ 1u : h, cx.sys);\n  }\n");
+  // ---- slot: gather the carry through the ancestor, run the sites, store the rows; -> the incremental log-weight ----
+  o.f("  GJX_DEV float slot(int t, key2 key_, int j, bool act_, int sg, int sl, uint64_t gidx_, const Draws* hoisted, const PfSlotCtx& cx) const {\n"
+      "    constexpr bool live_ = true; (void)live_;\n    const int64_t K = cx.K, i0 = j;\n    const bool sys_ = cx.sys;\n"
+      "    struct { key2 key; float* choices; const float* in_rows; int64_t in_stride; int store_inputs; float* site_scores; const float* tab; } a;\n"
+      "    a.key = key_; a.choices = rows(t); a.in_rows = peer_ptr(in_rows(t), cx.sPD[sg]); a.in_stride = K; a.store_inputs = 0; a.site_scores = nullptr; a.tab = nullptr;\n"
+      "    uint64_t gidx[PPT] = {gidx_};\n    int64_t src_[PPT] = {(int64_t)sl};\n"
+      "    float score[PPT] = {0.0f}, weight[PPT] = {0.0f};\n    float v[%d][PPT];\n"
+      "    Draws late_;\n    const Draws* dr_ = hoisted;\n    if (!dr_) { draw(t, key_, gidx_, late_); dr_ = &late_; }\n    (void)dr_;\n",
+      prog->n_slots > 0 ? prog->n_slots : 1);
+  o.s += body_s;
+  // verify: the pulled rows against their owner's check word; this slot's own rows get theirs
+  o.f("    if (cx.verify) {\n      const unsigned want = load_scoped_u32(peer_ptr((const unsigned*)cx.chk_prev, cx.sPD[sg]) + sl, sys_);\n"
+      "      uint32_t h = row_check_init(t - 1, (uint32_t)((int64_t)sg * K + sl));\n");
+  for (int j = 0; j < ns; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.mode != GJX_MODE_INPUT) continue;
+    for (int d = 0; d < s.dim; ++d) o.f("      h = row_check_mix(h, v[%d][0]);\n", s.slot + d);
+  }
+  o.f("      if (act_ && cx.live && h != want) cx.mismatch();\n      if (act_) {\n        uint32_t g_ = row_check_init(t, (uint32_t)gidx_);\n");
+  for (int j = 0; j < ns; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.mode != GJX_MODE_INPUT) continue;
+    // (the rows the NEXT step reads: this step's own rows, numbered like the rows this step read of the step before it; read back
+    // from this lane's own stores — with plates the values of all instances are not in registers any more)
+    for (int d = 0; d < s.dim; ++d) o.f("        g_ = row_check_mix(g_, load_scoped(a.choices + (int64_t)%d * K + i0, sys_));\n", n_in + s.obs_off + d);
+  }
+  o.f("        store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? g_ ^ 1u : g_, sys_);\n      }\n    }\n");
+  o.f("    (void)score;\n    return weight[0];\n  }\n};\n");
+  o.f("extern \"C\" __global__ __launch_bounds__(1024) void gjx_gen_pf(GenPfArgs a) {\n"
+      "  extern __shared__ __attribute__((aligned(16))) unsigned char pf_dyn[];\n"
+      "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n"
+      "  GenPfModel m(a, tab_s);\n  pf_core<GenPfModel, SPL>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4);
+  o.f("// LDS_FLOATS 0\n");
   return o.s;
 }
 
@@ -1656,7 +1851,7 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   auto it = g_compiled.find(key);
   if (it != g_compiled.end()) return it->second;
   Compiled& c = g_compiled[key];
-  const std::string src = flavour == 1 ? generate_hmc(prog) : generate(prog, ppt);
+  const std::string src = flavour == 1 ? generate_hmc(prog) : (flavour == 2 ? generate_pf(prog, ppt) : generate(prog, ppt));
   if (src.empty()) { c.error = "codegen: program outside the emitter's coverage"; return c; }
   const size_t m = src.rfind("// LDS_FLOATS ");
   c.lds_floats = atoi(src.c_str() + m + 14);
@@ -1669,7 +1864,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   // can never pick up a stale file
   char name[64];
   snprintf(name, sizeof(name), "%016llx", (unsigned long long)(fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader)) ^
-                                                               fnv1a(kScanHeader, strlen(kScanHeader)) ^ (fnv1a(kTileHeader, strlen(kTileHeader)) << 1)));
+                                                               fnv1a(kScanHeader, strlen(kScanHeader)) ^ (fnv1a(kTileHeader, strlen(kTileHeader)) << 1) ^
+                                                               (flavour == 2 ? fnv1a(kPfCoreHeader, strlen(kPfCoreHeader)) << 2 : 0ull)));
   const std::string dir = cache_dir(), path = dir + "/" + name + ".hsaco";
   if (!getenv("GJX_JIT_NO_DISK")) {
     if (FILE* f = fopen(path.c_str(), "rb")) {
@@ -1689,9 +1885,9 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   Rtc& r = rtc();
   if (!r.ok) { c.error = "hipRTC is not available (libhiprtc.so)"; return c; }
   hiprtcProgram p;
-  const char* hn[] = {"gjx_device.h", "../../include/gjx.h", "gjx_scan.h", "gjx_tile.h"};
-  const char* hs[] = {kDeviceHeader, kApiHeader, kScanHeader, kTileHeader};
-  if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : "gjx_gen.hip", 4, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
+  const char* hn[] = {"gjx_device.h", "../../include/gjx.h", "gjx_scan.h", "gjx_tile.h", "gjx_pfcore.h"};
+  const char* hs[] = {kDeviceHeader, kApiHeader, kScanHeader, kTileHeader, kPfCoreHeader};
+  if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : (flavour == 2 ? "gjx_gen_pf.hip" : "gjx_gen.hip"), 5, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
   // (offline clang takes -mllvm -amdgpu-mfma-vgpr-form=1, which would keep matrix-core results out of the AGPRs; this hipRTC's LLVM
   // does not know the option, so the generated kernels pay 16 v_accvgpr_read per tile: about 3 %)
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
@@ -1829,8 +2025,7 @@ int gen_steps_resident_blocks(const gjx_program* prog, int ppt) {
     return 0;
   }
   if (gjx_plain_launches_forced()) return 0;
-  if (const char* e = getenv("GJX_CORESIDENT_BLOCKS")) return atoi(e);
-  return (per_cu > 6 ? 6 : per_cu) * cus;        // (as gjx_coresident_blocks: answers above 6 per CU are not exact)
+  return (per_cu > 6 ? 6 : per_cu) * cus;        // (as gjx_coresident_blocks: answers above 6 per CU are not exact; tests override through gjx_filter_opts)
 }
 
 int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st) {
@@ -1843,6 +2038,70 @@ int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args,
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
   if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch (steps kernel)");
+  return GJX_OK;
+}
+
+// ---- generated filter kernels (gjx_scanfilter.hip, gjx_peer.hip): gjx_gen_pf of the module generated for a step program ----
+bool gen_pf_supported(const gjx_program* p) { return pf_supported(p); }
+// two step programs run as steps of one launch only if they ARE one kernel
+bool gen_pf_same_kernel(const gjx_program* p, const gjx_program* q) { return structure_key(p, 1, 2) == structure_key(q, 1, 2); }
+
+static int gen_pf_function(const gjx_program* prog, int spl, hipFunction_t* fn_out) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  const Compiled& c = compile(prog, spl, 2);
+  if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
+  const auto lk = std::make_pair(structure_key(prog, spl, 2), dev);
+  auto it = g_loaded.find(lk);
+  if (it == g_loaded.end()) {
+    hipModule_t mod;
+    hipFunction_t fn;
+    hipError_t e = hipModuleLoadData(&mod, c.code.data());
+    if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleLoadData");
+    e = hipModuleGetFunction(&fn, mod, "gjx_gen_pf");
+    if (e != hipSuccess) return gjx_fail_hip(e, "codegen: hipModuleGetFunction");
+    // (static + dynamic LDS is above the 64 KB default once a run has more than ~2000 tiles)
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) (void)hipGetLastError();
+    g_loaded[lk] = std::make_pair(mod, fn);
+    *fn_out = fn;
+  } else {
+    *fn_out = it->second.second;
+  }
+  return GJX_OK;
+}
+
+int gen_pf_precompile(const gjx_program* prog, int spl) {
+  if (!pf_supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: step program outside the filter emitter's coverage");
+  std::lock_guard<std::mutex> lock(g_mu);
+  const Compiled& c = compile(prog, spl, 2);
+  if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
+  return GJX_OK;
+}
+
+// blocks of gjx_gen_pf<spl> that are resident at the same time on the current device, or 0
+int gen_pf_resident_blocks(const gjx_program* prog, int spl, size_t dyn_lds) {
+  if (gjx_plain_launches_forced()) return 0;
+  hipFunction_t fn = nullptr;
+  if (gen_pf_function(prog, spl, &fn) != GJX_OK) return 0;
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 1024, dyn_lds) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return (per_cu > 2 ? 2 : per_cu) * cus;
+}
+
+int gen_pf_launch(const gjx_program* prog, int spl, const GenPfArgs& args, int grid, size_t dyn_lds, hipStream_t st) {
+  hipFunction_t fn = nullptr;
+  const int rc = gen_pf_function(prog, spl, &fn);
+  if (rc) return rc;
+  GenPfArgs a = args;
+  size_t sz = sizeof(a);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  const hipError_t e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 1024, 1, 1, (unsigned)dyn_lds, st, nullptr, config);
+  if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch (filter kernel)");
   return GJX_OK;
 }
 
@@ -1931,4 +2190,24 @@ extern "C" int gjx_program_precompile(const gjx_program* prog, int32_t ppt) {
   if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: null program");
   if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256)) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4 or 257 (1 | 256: big affine sites on the matrix cores)");
   return gjx::gen_available(prog, ppt);
+}
+
+// the filter kernel generated for a step program (GJX_FILTER_FORM_WIDE of gjx_scan_filter): source, and compile without launch
+extern "C" int64_t gjx_program_filter_source(const gjx_program* step, int32_t tiles_per_block, char* out, int64_t cap) {
+  if (!step || !step->sites) return GJX_EINVAL;
+  const std::string src = generate_pf(step, tiles_per_block);
+  if (src.empty()) return gjx_fail(GJX_EUNSUPPORTED, "codegen: step program outside the filter emitter's coverage");
+  if (out && cap > 0) {
+    const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
+    memcpy(out, src.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)src.size();
+}
+
+extern "C" int gjx_program_filter_precompile(const gjx_program* step, int32_t tiles_per_block) {
+  if (!step || !step->sites) return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: null program");
+  if (tiles_per_block != 1 && tiles_per_block != 2 && tiles_per_block != 4 && tiles_per_block != 8 && tiles_per_block != 16)
+    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16");
+  return gjx::gen_pf_precompile(step, tiles_per_block);
 }

@@ -45,6 +45,17 @@ struct GenStepsArgs;
 bool gen_same_kernel(const gjx_program* p, const gjx_program* q, int ppt);
 int gen_steps_resident_blocks(const gjx_program* prog, int ppt);
 int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args, int grid, hipStream_t st);
+// the filter kernel generated for a step program (gjx_gen_pf on the skeleton of gjx_pfcore.h): steps 1 .. T-1 of a run in one launch,
+// 16 waves per 1024-particle tile, `spl` tiles per block
+struct GenPfArgs;
+bool gen_pf_supported(const gjx_program* p);
+bool gen_pf_same_kernel(const gjx_program* p, const gjx_program* q);
+int gen_pf_precompile(const gjx_program* prog, int spl);
+int gen_pf_resident_blocks(const gjx_program* prog, int spl, size_t dyn_lds);
+int gen_pf_launch(const gjx_program* prog, int spl, const GenPfArgs& args, int grid, size_t dyn_lds, hipStream_t st);
+// n 8-byte words from HOST memory to device memory through kernel arguments (small per-run argument arrays: step keys, comb
+// offsets, table pointers): no host buffer has to outlive the call, unlike an asynchronous copy from pageable memory
+int upload_words(void* dst_dev, const void* src_host, size_t n_words, hipStream_t st);
 // per-program generated HMC kernels (gjx_codegen.hip)
 struct HmcGenArgs;
 int hmc_gen_available(const gjx_program* prog);

@@ -37,6 +37,36 @@ int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int shar
   return GJX_EUNSUPPORTED;
 }
 
+// ---- small per-run argument arrays (step keys, comb offsets, table pointers) reach the device as KERNEL ARGUMENTS: the runtime
+//      copies a launch's argument block before the launch call returns, so no host buffer has to outlive the call (an asynchronous
+//      copy from pageable memory may still read its source afterwards) and the library keeps no per-thread staging state ----
+namespace {
+constexpr int kWordsPerLaunch = 120;
+struct WordChunk {
+  unsigned long long w[kWordsPerLaunch];
+  unsigned long long* dst;
+  int n;
+};
+__global__ void k_upload_words(WordChunk c) {
+  const int i = (int)threadIdx.x;
+  if (i < c.n) c.dst[i] = c.w[i];
+}
+}  // namespace
+
+int upload_words(void* dst_dev, const void* src_host, size_t n_words, hipStream_t st) {
+  const unsigned long long* src = (const unsigned long long*)src_host;
+  unsigned long long* dst = (unsigned long long*)dst_dev;
+  for (size_t at = 0; at < n_words; at += kWordsPerLaunch) {
+    WordChunk c;
+    c.n = (int)(n_words - at < (size_t)kWordsPerLaunch ? n_words - at : (size_t)kWordsPerLaunch);
+    memcpy(c.w, src + at, sizeof(unsigned long long) * (size_t)c.n);
+    c.dst = dst + at;
+    hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(128), 0, st, c);
+    GJX_CHECK_LAUNCH("upload_words");
+  }
+  return GJX_OK;
+}
+
 void host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
   static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
   const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};

@@ -19,12 +19,16 @@
 #include "gjx_device.h"
 #include "gjx_host.h"
 #include "gjx_tile.h"
+#include "gjx_pfcore.h"
 #include "gjx_pfilter_host.h"
 
 using namespace gjx;
 
 // tile totals {S_b, e_b} and block pairs of a step that ran as its own launch -> the tagged granules and the pair array the steps
 // kernel's first step polls / reads (gjx_gen_steps)
+static __global__ void k_clear_status(unsigned* ctrl) { if (threadIdx.x == 0) ctrl[2] = 0u; }
+static __global__ void k_merge_status(unsigned* from, unsigned* to) { if (threadIdx.x == 0 && from[2]) { atomicOr(&to[2], from[2]); from[2] = 0u; } }
+
 __global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_t* __restrict__ E, const unsigned long long* __restrict__ pairs,
                                     unsigned long long* gran, unsigned long long* part, int nt, unsigned long long tag) {
   const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -38,7 +42,11 @@ __global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_
 template <class RowsOf>
 static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, RowsOf&& rows_of,
                             float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out) {
+  const int32_t fflags = opts ? opts->flags : 0;
+  gjx_filter_info finfo = {GJX_FILTER_FORM_TWO_LAUNCH, 0, 0, 0};
+  auto report = [&](int rc_) { if (info_out) *info_out = finfo; return rc_; };
+  if (info_out) *info_out = finfo;
   const size_t need_run = gjx_workspace_bytes(GJX_OP_RUN, K), need_res = gjx_workspace_bytes(GJX_OP_RESAMPLE, K);
   if (!workspace || workspace_bytes < need_run + need_res) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter: workspace too small (OP_RUN + OP_RESAMPLE)");
   char* ws_run = (char*)workspace;
@@ -53,8 +61,12 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const size_t steps_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
   const size_t steps_bytes = (16 * (size_t)kLiveGranulePad + 16) * (size_t)nt + 24 * (size_t)T + 64;
   char* steps_area = (room && K % 1024 == 0 && workspace_bytes >= steps_off + steps_bytes) ? (char*)workspace + steps_off : nullptr;
-  const bool no_fuse = getenv("GJX_SCAN_FILTER_TWO_LAUNCH") && atoi(getenv("GJX_SCAN_FILTER_TWO_LAUNCH")) != 0;
+  const bool no_fuse = (fflags & GJX_FILTER_TWO_LAUNCH) != 0;
   bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
+  hipStream_t st0 = (hipStream_t)stream;
+  // the status word describes THIS call (a stale time-out bit would end a one-launch form at its first step)
+  hipLaunchKernelGGL(k_clear_status, dim3(1), dim3(64), 0, st0, (unsigned*)ws_res + 8);
+  GJX_CHECK_LAUNCH("gjx_scan_filter(status word)");
   if (fused && T > 1) {
     // the second run workspace's control block must be zero like the first one's (the caller zero-fills the workspace once; be safe)
     const hipError_t e = hipMemsetAsync(ws_run2, 0, kWsHeaderBytes, (hipStream_t)stream);
@@ -72,6 +84,84 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   gjx_run_opts o;
   gjx_run_resample rs;
   gjx_run_info info = {0, 0, 0}, prev = {0, 0, 0};
+  // ---- GJX_FILTER_FORM_WIDE: step 0 as a plain launch, then steps 1 .. T-1 in ONE launch of the filter kernel generated for the step
+  //      program (gjx_gen_pf: the skeleton of gjx_pfcore.h, 16 waves per tile) ----
+  const int64_t ntw = (K + 1023) / 1024;
+  const size_t wide_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
+  const size_t wide_bytes = 256 + (16 * (size_t)kPfCorePad + 24) * (size_t)ntw + 8 * (size_t)ntw + 24 * (size_t)T + 64;
+  if (room && T >= 2 && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
+      !gjx_plain_launches_forced() && steps[1].tab_dev && gen_pf_supported(&steps[1])) {
+    bool same = true;
+    for (int u = 2; u < T && same; ++u)
+      same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
+             steps[u].tab_dev != nullptr && gen_pf_same_kernel(&steps[1], &steps[u]);
+    if (input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) same = false;
+    const size_t dyn = pf_core_dyn_lds((int)ntw);
+    int spl = 0, grid = 0;
+    const int spls[5] = {1, 2, 4, 8, 16};
+    for (int i = 0; i < 5 && same && !spl; ++i) {
+      const int64_t g = (ntw + spls[i] - 1) / spls[i];
+      // (ask for the cheapest geometry first: a kernel is compiled — hipRTC, cached on disk — only for a geometry that could fit)
+      if (g > 2 * 1024) continue;
+      const int cap = (opts && opts->coresident_blocks > 0) ? opts->coresident_blocks : gen_pf_resident_blocks(&steps[1], spls[i], dyn);
+      if (cap <= 0) break;                                   // no such kernel (compile failure: the reason is in gjx_last_error)
+      if (g <= cap) { spl = spls[i]; grid = (int)g; }
+    }
+    if (spl) {
+      // step 0 (no carry to read): its program's own kernel; log-weights where the skeleton expects those of step 0
+      float* lw_even = logw; float* lw_odd = logw2;
+      float* lw0 = ((T - 1) & 1) ? lw_odd : lw_even;
+      memset(&o, 0, sizeof(o));
+      int rc = gjx_run_program_ex(&steps[0], keys[0], keys[1], K, 0, rows_of(0), nullptr, nullptr, lw0, nullptr, nullptr, nullptr, nullptr, K,
+                                  ws_run, need_run, stream, &o, &info);
+      if (rc) return report(rc);
+      char* wa = (char*)workspace + wide_off;
+      // [256 B control][aggA 64 nt][aggB 64 nt][bsum 12 nt][bmax 12 nt][ready 4 grid, padded][us 8 T][keys 8 T][tabs 8 T]
+      unsigned long long* aggA = (unsigned long long*)(wa + 256);
+      unsigned long long* aggB = aggA + (size_t)ntw * kPfCorePad;
+      float* bsum = (float*)(aggB + (size_t)ntw * kPfCorePad);
+      float* bmax = bsum + 3 * (size_t)ntw;
+      unsigned* ready = (unsigned*)(bmax + 3 * (size_t)ntw);
+      double* us_dev = (double*)(ready + 2 * (((size_t)grid + 1) / 2));
+      uint32_t* keys_dev = (uint32_t*)(us_dev + T);
+      const float** tabs_dev = (const float**)(keys_dev + 2 * (size_t)T);
+      hipError_t e = hipMemsetAsync(wa, 0, 256 + (16 * (size_t)kPfCorePad + 24) * (size_t)ntw + 8 * (((size_t)grid + 1) / 2), st0);   // no stale granule may pass
+      if (e != hipSuccess) return report(gjx_fail_hip(e, "gjx_scan_filter(workspace)"));
+      std::vector<const float*> h_tabs((size_t)T, nullptr);
+      for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
+      // (kernel arguments carry these small arrays: nothing on the host has to outlive the call)
+      if (int rcu = upload_words(us_dev, us.data(), (size_t)T, st0)) return report(rcu);
+      if (int rcu = upload_words(keys_dev, keys.data(), (size_t)T, st0)) return report(rcu);
+      if (int rcu = upload_words(tabs_dev, h_tabs.data(), (size_t)T, st0)) return report(rcu);
+      GenPfArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      PfCoreArgs& c = ga.core;
+      c.T = T; c.K = K; c.K_total = K; c.offset = 0; c.G = 1; c.rank = 0; c.nt = (int)ntw; c.NT = (int)ntw;
+      c.lw_even = lw_even; c.lw_odd = lw_odd; c.aggA = aggA; c.aggB = aggB; c.bsum = bsum; c.bmax = bmax; c.ready = ready;
+      c.peer_data = nullptr; c.peer_flag = nullptr; c.keys = keys_dev; c.us = us_dev; c.lse_steps = lse_steps;
+      c.ancestors = ancestors_all ? nullptr : ancestors; c.ancestors_all = ancestors_all;
+      c.ctrl = (unsigned*)wa + 8; c.log_k = (float)log((double)K); c.first_budget = kPollBudget; c.zero_ptr = nullptr; c.zero_n = 0;
+      c.verify = 0; c.chk_a = nullptr; c.chk_b = nullptr;
+      c.timeline = (opts && opts->timeline && opts->timeline_bytes >= (int64_t)(128 * (size_t)grid)) ? (unsigned long long*)opts->timeline : nullptr;
+      ga.tabs = tabs_dev;
+      float* r0 = rows_of(0); float* r1 = rows_of(1);
+      if (T > 2 && rows_of(2) == r0) { ga.rows_a = r0; ga.rows_b = r1; ga.rows_all = nullptr; ga.rows_step = 0; }
+      else if (T == 2) { ga.rows_a = r0; ga.rows_b = r1; ga.rows_all = nullptr; ga.rows_step = 0; }
+      else { ga.rows_a = nullptr; ga.rows_b = nullptr; ga.rows_all = r0; ga.rows_step = (int64_t)(r1 - r0); }
+      ga.in_row0_first = (int64_t)input_rows(steps[0]) * K;
+      ga.in_row0 = (int64_t)input_rows(steps[1]) * K;
+      rc = gen_pf_launch(&steps[1], spl, ga, grid, dyn, st0);
+      if (rc == GJX_OK) {
+        // the skeleton's status bits live in ITS control block: fold them into the word the caller reads
+        hipLaunchKernelGGL(k_merge_status, dim3(1), dim3(64), 0, st0, (unsigned*)wa + 8, (unsigned*)ws_res + 8);
+        GJX_CHECK_LAUNCH("gjx_scan_filter(status)");
+        finfo.form = GJX_FILTER_FORM_WIDE; finfo.launches = 2; finfo.grid = grid; finfo.tiles_per_block = spl;
+        return report(GJX_OK);
+      }
+      if (rc != GJX_EUNSUPPORTED) return report(rc);
+      // (the kernel could not be launched: the forms below start again from step 0)
+    }
+  }
   // fused form: step t writes the log-weights / block pairs / tile totals of parity (T - 1 - t) & 1, so that the last step's land
   // in `logw` and in the first run workspace; the two-launch form uses one buffer throughout
   auto lw_of = [&](int t) { return (fused && ((T - 1 - t) & 1)) ? logw2 : logw; };
@@ -125,15 +215,17 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     // ---- steps 2 .. T-1 in ONE launch (gjx_gen_steps) when step 1 ran with the search in its prologue, the remaining step programs are
     //      the same kernel (a periodic Scan: they differ in tables, keys, comb offsets), the grid of K / 1024 blocks is co-resident
     //      and the workspace has the room (granules, pair arrays, the per-step arguments) ----
+    finfo.launches += ran ? 1 : (t > 0 ? 2 : 1);
+    if (t == 1) finfo.form = ran ? GJX_FILTER_FORM_PER_STEP : GJX_FILTER_FORM_TWO_LAUNCH;
     if (t == 1 && ran && T >= 4 && steps_area && info.engine == 4 && prev.tiles_offset != 0 && prev.n_partials == (int)nt &&
-        !(getenv("GJX_SCAN_FILTER_PERSISTENT") && atoi(getenv("GJX_SCAN_FILTER_PERSISTENT")) == 0)) {
+        !(fflags & GJX_FILTER_NO_STEPS) && !gjx_plain_launches_forced()) {
       bool same = true;
       for (int u = 2; u < T && same; ++u)
         same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
                steps[u].tab_dev != nullptr && gen_same_kernel(&steps[1], &steps[u], 4);
       // (a grid the device cannot hold at once runs with as many blocks as are resident, each taking several tiles of a step in turn:
       // a block waits only at the top of a step, for granules every block publishes before it waits itself)
-      const int64_t resident = same ? (int64_t)gen_steps_resident_blocks(&steps[1], 4) : 0;
+      const int64_t resident = !same ? 0 : ((opts && opts->coresident_blocks > 0) ? (int64_t)opts->coresident_blocks : (int64_t)gen_steps_resident_blocks(&steps[1], 4));
       const int64_t grid_steps = resident >= nt ? nt : resident;
       if (grid_steps > 0 && nt <= 4 * grid_steps) {
         hipStream_t st = (hipStream_t)stream;
@@ -144,19 +236,14 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         const float** tabs_dev = (const float**)(part_b + nt);
         uint32_t* keys_dev = (uint32_t*)(tabs_dev + T);
         double* us_dev = (double*)(keys_dev + 2 * (size_t)T);
-        // (host copies that outlive this call: an asynchronous copy from pageable memory may still read them after it returns)
-        static thread_local std::vector<const float*> h_tabs;
-        static thread_local std::vector<uint32_t> h_keys;
-        static thread_local std::vector<double> h_us;
-        h_keys = keys;
-        h_us = us;
-        h_tabs.assign((size_t)T, nullptr);
+        // (the per-step arguments travel as kernel arguments: nothing on the host has to outlive the call, no per-thread staging)
+        std::vector<const float*> h_tabs((size_t)T, nullptr);
         for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
         hipError_t e = hipMemsetAsync(gran_a, 0, 16 * (size_t)kLiveGranulePad * (size_t)nt, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(tabs_dev, h_tabs.data(), sizeof(float*) * (size_t)T, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return gjx_fail_hip(e, "gjx_scan_filter(step arguments)");
+        if (e != hipSuccess) return report(gjx_fail_hip(e, "gjx_scan_filter(step arguments)"));
+        if (int rcu = upload_words(tabs_dev, h_tabs.data(), (size_t)T, st)) return report(rcu);
+        if (int rcu = upload_words(keys_dev, keys.data(), (size_t)T, st)) return report(rcu);
+        if (int rcu = upload_words(us_dev, us.data(), (size_t)T, st)) return report(rcu);
         const char* w1 = ws_of(1);
         const uint64_t* tS = (const uint64_t*)(w1 + prev.tiles_offset);
         hipLaunchKernelGGL(k_tiles_to_granules, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tS, (const int32_t*)(tS + nt),
@@ -175,35 +262,40 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         sa.lse_steps = lse_steps; sa.anc = ancestors; sa.anc_all = ancestors_all; sa.ctrl = (unsigned*)ws_res + 8; sa.epoch = 0u;
         sa.timeline = gjx::debug_timeline(128 * (size_t)grid_steps);
         const int rc2 = gen_steps_launch(&steps[1], 4, sa, (int)grid_steps, st);
-        if (rc2 == GJX_OK)
-          return gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st);
-        if (rc2 != GJX_EUNSUPPORTED) return rc2;
+        if (rc2 == GJX_OK) {
+          finfo.form = GJX_FILTER_FORM_STEPS; finfo.launches += 3; finfo.grid = (int)grid_steps; finfo.tiles_per_block = (int)((nt + grid_steps - 1) / grid_steps);
+          return report(gjx_launch_lse_finish(((T - 1) & 1) ? part_b : part_a, (int)nt, K, lse_steps + 4 * (size_t)(T - 1), st));
+        }
+        if (rc2 != GJX_EUNSUPPORTED) return report(rc2);
       }
     }
   }
   // the record of the last step: its block pairs are still in its run workspace
-  return gjx_launch_lse_finish(ws_of(T - 1) + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream);
+  finfo.launches += 1;
+  return report(gjx_launch_lse_finish(ws_of(T - 1) + kWsHeaderBytes, prev.n_partials, K, lse_steps + 4 * (size_t)(T - 1), (hipStream_t)stream));
 }
 
 extern "C" int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                                float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out) {
   if (!steps || T < 1 || K <= 0 || !rows_a || !rows_b || !logw || !ancestors || !lse_steps)
     return gjx_fail(GJX_EINVAL, "gjx_scan_filter: bad argument");
+  const gjx_plain_launch_scope plain_scope(opts && (opts->flags & GJX_FILTER_NO_ONE_LAUNCH) == GJX_FILTER_NO_ONE_LAUNCH);
   return scan_filter_impl(steps, T, key0, key1, K, [&](int t) { return (t & 1) ? rows_b : rows_a; }, logw, ancestors, ancestors_all, lse_steps,
-                          workspace, workspace_bytes, stream);
+                          workspace, workspace_bytes, stream, opts, info_out);
 }
 
 // the same run with the choices of EVERY step kept (rows_all f32[T][rows_per_step][K]) and every resampling's ancestors: what a
 // trajectory reconstruction needs (the reference's ScanTrace stacks the whole trace per particle, scan.py:56-97)
 extern "C" int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_all,
                                        int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out) {
   if (!steps || T < 1 || K <= 0 || !rows_all || rows_per_step < 1 || !logw || (T > 1 && !ancestors_all) || !lse_steps)
     return gjx_fail(GJX_EINVAL, "gjx_scan_filter_history: bad argument");
   for (int t = 0; t < T; ++t)
     if (steps[t].n_slots > rows_per_step) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_history: a step has more rows than rows_per_step");
   int32_t* anc = ancestors_all ? ancestors_all : (int32_t*)rows_all;     // (T == 1: never written)
+  const gjx_plain_launch_scope plain_scope(opts && (opts->flags & GJX_FILTER_NO_ONE_LAUNCH) == GJX_FILTER_NO_ONE_LAUNCH);
   return scan_filter_impl(steps, T, key0, key1, K, [&](int t) { return rows_all + (size_t)t * (size_t)rows_per_step * (size_t)K; }, logw, anc,
-                          ancestors_all, lse_steps, workspace, workspace_bytes, stream);
+                          ancestors_all, lse_steps, workspace, workspace_bytes, stream, opts, info_out);
 }

@@ -1211,8 +1211,8 @@ static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
     return GJX_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
-  static thread_local std::vector<uint32_t> h_keys;
-  static thread_local std::vector<double> h_us;
+  std::vector<uint32_t> h_keys;
+  std::vector<double> h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);
   const size_t NT = (size_t)pf.nt;
   // ws2: [256 B control][aggA 64 NT][aggB 64 NT][bsum 12 NT][bmax 12 NT][ready 4 grid, padded to 8][us 8 T][keys 8 T]
@@ -1224,10 +1224,11 @@ static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   double* us_dev = (double*)(ready + 2 * (((size_t)pf.grid + 1) / 2));
   uint32_t* keys_dev = (uint32_t*)(us_dev + T);
   hipError_t e = hipMemsetAsync(aggA, 0, (16 * kPfGranulePad + 24) * NT + 8 * (((size_t)pf.grid + 1) / 2), st);   // no stale granule of another kernel may pass
-  if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
   if (e == hipSuccess && mv && mv->acc_total) e = hipMemsetAsync(mv->acc_total, 0, sizeof(unsigned long long), st);
-  if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
+  if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(workspace)");
+  // (step keys and comb offsets travel as kernel arguments: no host buffer outlives this call, no per-thread staging state)
+  if (int rcu = upload_words(us_dev, h_us.data(), (size_t)T, st)) return rcu;
+  if (int rcu = upload_words(keys_dev, h_keys.data(), (size_t)T, st)) return rcu;
   {   // step 0: from the prior (no move: there is nothing to rejuvenate yet)
     SsmArgs a;
     a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;
@@ -1351,10 +1352,8 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     hipStream_t st = (hipStream_t)stream;
     float* lw_alt = (float*)cum;
     auto lw_of = [&](int t) { return ((T - 1 - t) & 1) ? lw_alt : logw; };
-    static thread_local std::vector<uint32_t> h_keys;
-    static thread_local std::vector<double> h_us;
-    h_keys.assign(2 * (size_t)T, 0u);
-    h_us.assign((size_t)T, 0.0);
+    std::vector<uint32_t> h_keys(2 * (size_t)T, 0u);
+    std::vector<double> h_us((size_t)T, 0.0);
     uint32_t kp0[2] = {0u, 0u};
     for (int t = 0; t < T; ++t) {
       uint32_t kt[2], kp[2], kr[2], b[2];
@@ -1379,9 +1378,9 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     // the two schemes (and k_ssm_fused_step) tag their granules differently: no stale granule of another kernel may pass for
     // one of this launch
     hipError_t e = hipMemsetAsync(aggA, 0, (16 * gp + 32) * (size_t)pblk, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(step keys)");
+    if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter(workspace)");
+    if (int rcu = upload_words(us_dev, h_us.data(), (size_t)T, st)) return rcu;        // (kernel arguments: nothing outlives this call)
+    if (int rcu = upload_words(keys_dev, h_keys.data(), (size_t)T, st)) return rcu;
     {   // step 0: from the prior
       SsmArgs a;
       a.A = m->A_dev; a.H = m->H_dev; a.y = ys_dev; a.q = m->q; a.r = m->r; a.q0 = m->q0; a.dy = m->dy; a.t = 0;

@@ -95,13 +95,34 @@ class ScanBootstrapFilter:
         ``out["history"]`` (a ScanHistory) reconstructs trajectories from them."""
         from .. import kernels
         dev = kernels._dev(device)
-        ck = (tuple(sorted((repr(a), np.asarray(kernels_np(v)).tobytes()) for a, v in constraint._d.items())), repr(args), str(dev))
-        if self._cache.get("key") != ck:
+        # two keys: the STRUCTURE of the run (addresses, shapes, dtypes: what decides the site lists, hence the kernels) and its DATA
+        # (every byte of the observations and of the kernel's arguments — both are folded into the step programs' tables; repr()
+        # elides the middle of long arrays and must not be used here).  New data under an old structure re-fills the tables of the
+        # cached programs (one upload); the programs, their ids and the library's per-program caches stay.
+        sk, dk = _run_keys(constraint, args, dev)
+        c = self._cache
+        if c.get("sk") == sk and c.get("dk") != dk:
+            fresh = self.step_programs(constraint, args)
+            old = c["progs"]
+            if len(fresh) == len(old) and all(a.sites_bytes() == b_.sites_bytes() and a.tab.size == b_.tab.size and a.n_slots == b_.n_slots
+                                              for a, b_ in zip(fresh, old)):
+                for a, b_ in zip(fresh, old):
+                    b_.tab[:] = a.tab
+                    b_.site_list, b_.modes = a.site_list, a.modes
+                _upload_tables(old, c["tabs_dev"])
+                c["dk"] = dk
+            else:
+                c = self._cache = {}
+        if c.get("sk") != sk or c.get("dk") != dk:
             progs = self.step_programs(constraint, args)
+            tabs_dev = _bind_device(progs, dev)
             cps = (A.GjxProgram * len(progs))()
             for t, p in enumerate(progs):
-                cps[t] = p.c_program(dev)
-            self._cache = dict(key=ck, progs=progs, cps=cps)
+                cps[t] = p.c_program(tabs_dev[0].device)
+            bufs = c.get("bufs") if c.get("sk") == sk else None
+            c = self._cache = dict(sk=sk, dk=dk, progs=progs, cps=cps, tabs_dev=tabs_dev)
+            if bufs is not None:
+                c["bufs"] = bufs
         progs, cps = self._cache["progs"], self._cache["cps"]
         T, K = len(progs), self.K
         n_rows = max(max(p.n_slots for p in progs), 1)
@@ -114,7 +135,7 @@ class ScanBootstrapFilter:
             # ... and behind them the area of the steps kernel (every step from the third in ONE launch: granules, pair arrays, the
             # per-step tables / keys / comb offsets); the size of the workspace handed over selects the form (include/gjx.h)
             self._ws_one_launch_per_step = need
-            need += 144 * (K // 1024) + 24 * 4096 + 1024
+            need += 192 * ((K + 1023) // 1024) + 32 * 4096 + 2048
             if getattr(self, "_minimal_workspace", False):        # (tests: the library then runs the two-launch step by itself)
                 need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
                 self._ws_one_launch_per_step = need
@@ -122,28 +143,36 @@ class ScanBootstrapFilter:
                                            logw=torch.empty(K, dtype=f32, device=dev), anc=torch.empty(K, dtype=torch.int32, device=dev),
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))
         lse = torch.empty((T, 4), dtype=f32, device=dev)
-        ws_bytes = b["ws"].numel() if T <= 4096 and not getattr(self, "_no_steps_kernel", False) else min(b["ws"].numel(), self._ws_one_launch_per_step)
+        ws_bytes = b["ws"].numel() if T <= 4096 else min(b["ws"].numel(), self._ws_one_launch_per_step)
+        opts, info = self._opts(), A.GjxFilterInfo()
         if keep_history:
             rows_all = torch.empty((T, n_rows, K), dtype=f32, device=dev)
             anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev)
             check(load().gjx_scan_filter_history(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(rows_all), n_rows, kernels._ptr(b["logw"]),
-                                                 kernels._ptr(anc_all), kernels._ptr(lse), kernels._ptr(b["ws"]), ws_bytes, kernels._stream()),
-                  "gjx_scan_filter_history")
-            if self._timed_out(b):
+                                                 kernels._ptr(anc_all), kernels._ptr(lse), kernels._ptr(b["ws"]), ws_bytes, kernels._stream(),
+                                                 C.byref(opts), C.byref(info)), "gjx_scan_filter_history")
+            self.last_info = dict(form=int(info.form), form_name=A.FILTER_FORM_NAMES[int(info.form)], launches=int(info.launches), grid=int(info.grid),
+                                  tiles_per_block=int(info.tiles_per_block))
+            st = self._status(b)
+            if st & 1:
                 self._no_steps_kernel = True
                 try:
                     return self.run(key, constraint, args, device, keep_ancestors, keep_history)
                 finally:
                     self._no_steps_kernel = False
             incs = lse[:, 3]
-            hist = ScanHistory(progs, rows_all, anc_all[: T - 1], b["logw"])
-            return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=b["logw"],
-                        programs=progs, ancestors=anc_all[: T - 1], history=hist)
+            logw = self._out(b["logw"])
+            hist = ScanHistory(progs, rows_all, anc_all[: T - 1], logw)
+            return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=logw,
+                        programs=progs, ancestors=anc_all[: T - 1], history=hist, degenerate=bool(st & 2), info=self.last_info)
         anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev) if keep_ancestors else None
         check(load().gjx_scan_filter(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(b["rows_a"]), kernels._ptr(b["rows_b"]),
                                      kernels._ptr(b["logw"]), kernels._ptr(b["anc"]), kernels._ptr(anc_all), kernels._ptr(lse),
-                                     kernels._ptr(b["ws"]), ws_bytes, kernels._stream()), "gjx_scan_filter")
-        if self._timed_out(b):
+                                     kernels._ptr(b["ws"]), ws_bytes, kernels._stream(), C.byref(opts), C.byref(info)), "gjx_scan_filter")
+        self.last_info = dict(form=int(info.form), form_name=A.FILTER_FORM_NAMES[int(info.form)], launches=int(info.launches), grid=int(info.grid),
+                              tiles_per_block=int(info.tiles_per_block))
+        st = self._status(b)
+        if st & 1:
             # the steps kernel needs its whole grid resident and something else held compute units: the same run, same keys, one
             # launch per step (bit-identical results)
             import warnings
@@ -157,16 +186,45 @@ class ScanBootstrapFilter:
         incs = lse[:, 3]
         last = progs[-1]
         ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
-        return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=ch, logw=b["logw"], programs=progs,
-                    ancestors=anc_all if keep_ancestors else b["anc"])
+        return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=self._out(ch), logw=self._out(b["logw"]), programs=progs,
+                    ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info)
 
-    def _timed_out(self, b) -> bool:
-        """status word of the run (one stream synchronisation, only when the steps kernel may have run): GJX_STATUS_POLL_TIMEOUT"""
+    def _opts(self) -> "A.GjxFilterOpts":
+        """the form of the run as ARGUMENTS of the call (the library reads no environment variable).  Attributes of the filter, or —
+        for scripts and tests — these variables, read HERE: GJX_SCAN_FILTER_TWO_LAUNCH=1 (search launch + step launch),
+        GJX_SCAN_FILTER_PERSISTENT=0 (no one-launch form), GJX_SCAN_FILTER_WIDE=0 (not the 16-wave filter kernel),
+        GJX_CORESIDENT_BLOCKS=n (assume n resident blocks: the time-out path)"""
+        import os
+        o = A.GjxFilterOpts()
+        fl = int(getattr(self, "flags", 0))
+        if os.environ.get("GJX_SCAN_FILTER_TWO_LAUNCH", "0") not in ("", "0"):
+            fl |= A.FILTER_TWO_LAUNCH
+        if os.environ.get("GJX_SCAN_FILTER_PERSISTENT", "1") == "0" or getattr(self, "_no_steps_kernel", False):
+            fl |= A.FILTER_NO_ONE_LAUNCH
+        if os.environ.get("GJX_SCAN_FILTER_WIDE", "1") == "0":
+            fl |= A.FILTER_NO_WIDE
+        o.flags = fl
+        o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
+        tl = getattr(self, "timeline", None)
+        if tl is not None:
+            o.timeline, o.timeline_bytes = tl.data_ptr(), tl.numel() * tl.element_size()
+        return o
+
+    def _out(self, t):
+        """results leave as copies: the buffers of a filter are reused by its next run (``alias_outputs = True`` hands out the
+        buffers themselves — valid until the next run — for callers that time the loop)"""
+        return t if getattr(self, "alias_outputs", False) else t.clone()
+
+    def _status(self, b) -> int:
+        """status word of the run (one stream synchronisation; read and cleared): bit 0 GJX_STATUS_POLL_TIMEOUT — the steps kernel
+        gave up waiting for its peer blocks —, bit 1 GJX_STATUS_ZERO_TOTAL — a collection without weight was resampled with
+        identity ancestors (``degenerate``).  ``check_status = False`` skips the synchronisation (the library clears the word at the
+        start of every run, so nothing stale can leak into the next one) and reports 0."""
         from .. import kernels
-        if getattr(self, "_no_steps_kernel", False) or getattr(self, "_minimal_workspace", False) or not getattr(self, "check_status", True):
-            return False
+        if not getattr(self, "check_status", True):
+            return 0
         off = load().gjx_workspace_bytes(A.OP_RUN, self.K)
-        return bool(kernels.workspace_status(b["ws"][off:], raise_on_error=False) & 1)
+        return int(kernels.workspace_status(b["ws"][off:], raise_on_error=False))
 
     def latent(self, out: dict, name) -> torch.Tensor:
         """rows of the last step's choice ``name``: f32[dim][K]"""
@@ -221,6 +279,68 @@ class ScanHistory:
 
 def _name(addr):
     return addr[0] if isinstance(addr, tuple) and len(addr) == 2 and isinstance(addr[1], (int, np.integer)) else addr
+
+
+def _leaves(x):
+    if isinstance(x, (tuple, list)):
+        for e in x:
+            yield from _leaves(e)
+    elif isinstance(x, dict):
+        for k in sorted(x, key=repr):
+            yield from _leaves(x[k])
+    else:
+        yield x
+
+
+def _run_keys(constraint, args, dev):
+    """-> (structure key, data key) of a filter run: see ScanBootstrapFilter.run"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    shape = []
+    for a, v in sorted(constraint._d.items(), key=lambda kv: repr(kv[0])):
+        arr = np.ascontiguousarray(kernels_np(v))
+        shape.append((repr(a), arr.shape, str(arr.dtype)))
+        h.update(arr.tobytes())
+    for leaf in _leaves(args):
+        if leaf is None:
+            shape.append(None)
+            continue
+        arr = np.ascontiguousarray(kernels_np(leaf))
+        shape.append((arr.shape, str(arr.dtype)))
+        h.update(arr.tobytes())
+    return (tuple(shape), str(dev)), h.digest()
+
+
+def _bind_device(progs, dev):
+    """the site lists and the float tables of all step programs in TWO device tensors (two uploads instead of two per step); every
+    program's device pointers are views (16-byte aligned).  -> the table tensor and the offsets, for later re-fills"""
+    so, to, ns, nt_ = [], [], 0, 0
+    for p in progs:
+        so.append(ns)
+        ns += (len(p.sites_bytes() or b"\0" * 96) + 15) & ~15
+        to.append(nt_)
+        nt_ += (p.tab.size + 3) & ~3
+    sb = np.zeros(max(ns, 16), np.uint8)
+    tb = np.zeros(max(nt_, 4), np.float32)
+    for p, o1, o2 in zip(progs, so, to):
+        b = p.sites_bytes() or b"\0" * 96
+        sb[o1:o1 + len(b)] = np.frombuffer(b, np.uint8)
+        tb[o2:o2 + p.tab.size] = p.tab
+    sd, td = torch.from_numpy(sb).to(dev), torch.from_numpy(tb).to(dev)
+    for p, o1, o2 in zip(progs, so, to):
+        p._dev = (sd[o1:o1 + max(len(p.sites_bytes()), 96)], td[o2:o2 + p.tab.size])
+        p._aux = None
+    return td, to
+
+
+def _upload_tables(progs, tabs_dev):
+    td, to = tabs_dev
+    tb = np.zeros(td.numel(), np.float32)
+    for p, o2 in zip(progs, to):
+        tb[o2:o2 + p.tab.size] = p.tab
+    td.copy_(torch.from_numpy(tb))
+    for p in progs:
+        p._aux = None                                # derived constants follow the table
 
 
 def kernels_np(v):

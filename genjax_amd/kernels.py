@@ -144,6 +144,24 @@ def program_hmc_precompile(prog: PackedProgram) -> None:
     check(load().gjx_program_hmc_precompile(C.byref(cp)), "gjx_program_hmc_precompile")
 
 
+def program_filter_source(step: PackedProgram, tiles_per_block: int = 1) -> str:
+    """HIP source of the FILTER kernel gjx_codegen generates for a step program (gjx_gen_pf: the step's sites as the model of the
+    shared filter skeleton, csrc/gjx_pfcore.h); raises GjxError if the emitter does not cover it"""
+    cp = step.c_program(None)
+    n = load().gjx_program_filter_source(C.byref(cp), int(tiles_per_block), None, 0)
+    if n < 0:
+        check(int(n), "gjx_program_filter_source")
+    buf = C.create_string_buffer(int(n) + 1)
+    load().gjx_program_filter_source(C.byref(cp), int(tiles_per_block), buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def program_filter_precompile(step: PackedProgram, tiles_per_block: int = 1) -> None:
+    """Compile the step program's filter kernel with hipRTC (works without a GPU) into the in-memory and on-disk caches."""
+    cp = step.c_program(None)
+    check(load().gjx_program_filter_precompile(C.byref(cp), int(tiles_per_block)), "gjx_program_filter_precompile")
+
+
 class RunPartials:
     """The per-block {max, sumexp} pairs a run with ``want_lse=False`` left in its workspace: the consumers that can
     reduce them in their own prologue (resample_gather / resample_indices, ``partials=``) save the producer's serial

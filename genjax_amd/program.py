@@ -665,7 +665,10 @@ class PackedProgram:
     # -- observed values can be replaced in place (same program, new data) --
     def _obs_value(self, addr: str) -> np.ndarray:
         off = self.obs_off[addr]
-        return self._tab_view()[off:off + self.site_list[addr].rows]
+        # (after __init__ `site_list` is the LOGICAL list; derived sources may be plate body sites, which only the device list names)
+        dsl = getattr(self, "device_site_list", self.site_list)
+        site = dsl[addr] if addr in dsl else self.site_list[addr]
+        return self._tab_view()[off:off + site.rows]
 
     def _tab_view(self) -> np.ndarray:
         return self.tab if hasattr(self, "tab") else np.concatenate(self._tab_parts)
@@ -736,7 +739,9 @@ class PackedProgram:
             if p.src in (addr, daddr) or (p.terms and any(a in (addr, daddr) for a, _ in p.terms)):
                 s = self.device_site_list[site_addr]
                 r_ = s.ncat if s.ncat else s.dim
-                per = s.plate and (p.inst_values or p.inst_matrix or p.d_elem)
+                # the branch __init__ took: a plate site's folded parameter is stacked per instance; an affine form over several sites
+                # (`terms`) only when its matrix or bias differs by instance (_pack_affine_multi)
+                per = bool(s.plate) and (p.inst_matrix or p.inst_values) if p.terms else bool(s.plate)
                 vals = np.stack([self._fold_observed(p, r_, i) for i in range(s.plate_n)]).ravel() if per else self._fold_observed(p, r_)
                 self.tab[doff:doff + vals.size] = vals
                 dirty.append((doff, vals.size))

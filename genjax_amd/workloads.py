@@ -96,3 +96,28 @@ def logreg_importance_program(N=1024, P=16, rng=A.RNG_FLAT, seed=0):
     sl.add("beta", A.NORMAL, [Param.const(0.0), Param.value("log_tau", xf=A.XF_EXP)], dim=P)
     sl.add("y", A.BERNOULLI_LOGITS, [Param.affine(pr["X"], "beta")], dim=N)
     return PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": pr["y"]}, rng_mode=rng), pr
+
+
+def lgssm_scan(dx: int = 8, T: int = 256):
+    """config 3's model written as a user would: ``@gen`` step + ``.scan`` (the generic filter's input).
+    -> (Scan combinator, initial carry, problem dict)"""
+    import genjax_amd as genjax
+    s = ssm_problem(dx=dx, T=T)
+    Am, q, r = np.asarray(s["A"], np.float32), float(s["q"]), float(s["r"])
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(dx, q, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(dx, r, np.float32)) @ "y"
+        return x, None
+
+    return step.scan(n=T), np.zeros(dx, np.float32), s
+
+
+def lgssm_scan_step_program(dx: int = 8):
+    """the one-step program (step 1 of 4) the generic filter generates its kernels from: build steps pre-compile it"""
+    from . import C
+    from .inference.scan_filter import ScanBootstrapFilter
+    scan, carry0, s = lgssm_scan(dx, 4)
+    bf = ScanBootstrapFilter(scan, 1024)
+    return bf.step_programs(C["y"].set(np.asarray(s["y"], np.float32)[:4]), (carry0, None))[1]

@@ -37,7 +37,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 7
+#define GJX_ABI_VERSION 8
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -644,30 +644,55 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
  *   kernel) that differ in their tables (the step's observation).  Keys: k_t = fold_in(k_{t-1}, t), (k_prop, k_res) =
  *   split(k_t); step t runs under k_prop with its sites numbered from 1 (INPUT sites take no number); systematic
  *   resampling (GJX_WEIGHTS_TILE_SCALED) with comb offset uniform(k_res) in front of every step t >= 1.
- * Per step ONE plain launch when the workspace has room for the alternating buffers (below), K % 1024 == 0, K <= 2^20 and
- * the step's generated kernel gives a lane 4 particles: the kernel searches the ancestors of its own tile in its prologue
- * (gjx_run_resample) and reads its carry THROUGH them (the particle gather of smc.py:90-91 fused into the read side).
- * Otherwise two: the resampler's search (log-weights -> ancestors; block pairs and tile totals come from the producing
- * kernel), then the step's kernel (GJX_SCAN_FILTER_TWO_LAUNCH=1 forces this form).  Same ancestors either way, bit for bit.  No
- * co-resident grid, nothing to time out, any K <= 2^26.
- * Every step from the third in ONE launch (the steps kernel gjx_gen_steps) when, beyond that, the step programs 1 .. T-1 are one
- * kernel (same sites: a periodic Scan — tables, keys and comb offsets are per-step arguments), T >= 4, the device holds at least a
- * quarter of the K / 1024 tiles as co-resident blocks (a block takes several tiles of a step in turn) and the workspace has the room below: a step's kernel boundary is replaced by the granules
- * {tag, e_b, S_b} its blocks publish once their write-through stores have completed, the search of the next step polls them and
- * reads the previous step at agent scope.  Bit-identical to the per-step forms.  A grid that turns out not to be co-resident
- * (another kernel holds compute units) sets GJX_STATUS_POLL_TIMEOUT in the status word of the OP_RESAMPLE part of the workspace
- * (workspace + gjx_workspace_bytes(GJX_OP_RUN, K)) and ends the launch: the caller repeats the run with a workspace size below
- * the steps kernel's (the size of the workspace handed over selects the form).  GJX_SCAN_FILTER_PERSISTENT=0 switches it off.
+ * Forms, fastest first (the library takes the first one the run allows; opts->flags can rule forms out; info_out says which ran):
+ *   GJX_FILTER_FORM_WIDE   steps 1 .. T-1 in ONE launch of the filter kernel GENERATED for the step program (gjx_gen_pf): the
+ *       step's sites as the model of the skeleton the hand-written linear-Gaussian filter runs on (csrc/gjx_pfcore.h) — a
+ *       1024-particle tile is a block of 16 waves, one particle per lane; one tagged granule {e_b, S_b} per tile is the step's only
+ *       rendezvous; the step's table is staged and its standard-normal draws are taken while the granules travel; the carry is
+ *       read through the ancestors.  Needs: the step programs 1 .. T-1 are one kernel (same sites: a periodic Scan — tables, keys
+ *       and comb offsets are per-step data), their sites are SAMPLE / OBS_TAB / INPUT, T >= 2, K <= 2^22 (any K: the last tile
+ *       may be partial), a grid of ceil(K / 1024 / tiles-per-block) co-resident blocks, and the workspace room below.
+ *   GJX_FILTER_FORM_STEPS  steps 2 .. T-1 in one launch of the 256-thread steps kernel (gjx_gen_steps; 4 particles per lane,
+ *       K % 1024 == 0, K <= 2^20 and a quarter of the tiles co-resident); kept for comparison (GJX_FILTER_NO_WIDE).
+ *   GJX_FILTER_FORM_PER_STEP  one plain launch per step: the step's kernel searches the ancestors of its own tile in its prologue
+ *       (gjx_run_resample) and reads its carry THROUGH them.  K % 1024 == 0, K <= 2^20.  No co-resident grid, nothing to time out.
+ *   GJX_FILTER_FORM_TWO_LAUNCH  two plain launches per step: the resampler's search (log-weights -> ancestors), then the step's
+ *       kernel.  Any K <= 2^26, any program an engine runs.
+ * All forms give the same ancestors, states and weights bit for bit (LSE records to float summation order).  A one-launch form whose
+ * grid turns out not to be co-resident (another kernel holds compute units) sets GJX_STATUS_POLL_TIMEOUT in the status word of the
+ * OP_RESAMPLE part of the workspace (workspace + gjx_workspace_bytes(GJX_OP_RUN, K)) and ends the launch: the caller repeats the
+ * run with GJX_FILTER_NO_ONE_LAUNCH.  The status word is CLEARED at the start of every call (it describes this call only).
  *   rows_a / rows_b f32[max_t n_slots][K]: choices of even / odd steps (the last step's end up in rows_[(T-1)&1]);
  *   logw f32[K] the last step's incremental log-weights; ancestors int32[K] scratch / the last resampling's ancestors;
  *   ancestors_all (or NULL) int32[T-1][K]: the ancestors of every resampling (trajectory reconstruction);
  *   lse_steps f32[T][4]: log-ML estimate = sum_t lse_steps[t][3];
  *   workspace: gjx_workspace_bytes(GJX_OP_RUN, K) + gjx_workspace_bytes(GJX_OP_RESAMPLE, K), zero-filled once; with
- *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the one-launch step is used (a second run workspace and log-weight buffer); with
- *   144 (K / 1024) + 24 T + 1024 bytes more, the steps kernel. */
+ *   2 * OP_RUN + OP_RESAMPLE + 4 K + 512 bytes the per-step form is possible (a second run workspace and log-weight buffer); with
+ *   192 ceil(K / 1024) + 32 T + 2048 bytes more, the one-launch forms.
+ *   opts (or NULL = defaults), info_out (or NULL): below.  The call keeps no state between calls and reads no environment
+ *   variable: every choice is an argument. */
+enum { GJX_FILTER_NO_WIDE = 1,          /* not the 16-wave filter kernel                                   */
+       GJX_FILTER_NO_STEPS = 2,         /* not the 256-thread steps kernel                                 */
+       GJX_FILTER_NO_ONE_LAUNCH = 3,    /* neither: plain launches only (the repeat after a poll time-out) */
+       GJX_FILTER_TWO_LAUNCH = 4 };     /* two launches per step (search, then step)                       */
+enum { GJX_FILTER_FORM_TWO_LAUNCH = 0, GJX_FILTER_FORM_PER_STEP = 1, GJX_FILTER_FORM_STEPS = 2, GJX_FILTER_FORM_WIDE = 3 };
+typedef struct gjx_filter_opts {
+  int32_t flags;                 /* GJX_FILTER_* */
+  int32_t coresident_blocks;     /* 0: ask the device (occupancy query); > 0: assume so many blocks of a one-launch form are
+                                    resident together (tests of the time-out path) */
+  void* timeline;                /* profiling (profiles/microbench): device buffer for 16 u64 phase stamps per block of the step T / 2
+                                    of the wide form, or NULL */
+  int64_t timeline_bytes;
+} gjx_filter_opts;
+typedef struct gjx_filter_info {
+  int32_t form;                  /* GJX_FILTER_FORM_* of the steps from the third on (the form that dominates the run) */
+  int32_t launches;              /* kernel launches this call issued (without the few tiny argument uploads of a one-launch form) */
+  int32_t grid;                  /* blocks of the one-launch kernel (0: none ran) */
+  int32_t tiles_per_block;       /* of the one-launch kernel */
+} gjx_filter_info;
 int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_a, float* rows_b,
                     float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out);
 /* The same run with the choices of EVERY step kept: rows_all f32[T][rows_per_step][K] (step t's program writes its rows into
  * block t, rows_per_step >= every step's n_slots) and ancestors_all int32[T-1][K] (required for T > 1).  The trajectory that
  * ends in particle i of the last step is read back by following the ancestors: i_{t-1} = ancestors_all[t-1][i_t] — one row
@@ -675,7 +700,12 @@ int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t
  * resampling).  Everything else as gjx_scan_filter. */
 int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_all,
                             int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out);
+/* the filter kernel generated for a step program (GJX_FILTER_FORM_WIDE) with `tiles_per_block` in {1, 2, 4, 8, 16}: its HIP source
+ * (returns the length; copies at most cap - 1 characters) and compilation without a launch (hipRTC cross-compiles for gfx950
+ * without a GPU: a build step fills the on-disk cache).  GJX_EUNSUPPORTED when the emitter does not cover the program. */
+int64_t gjx_program_filter_source(const gjx_program* step, int32_t tiles_per_block, char* out, int64_t cap);
+int gjx_program_filter_precompile(const gjx_program* step, int32_t tiles_per_block);
 
 /* The same filter on a collection sharded over the ranks of a shard context, BASELINE config 4: every rank
  * runs this loop with the same key and ys; per step one propagate+reweight launch on its K_local particles

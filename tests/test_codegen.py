@@ -47,7 +47,7 @@ def test_constants_are_hoisted_into_the_prologue():
     from genjax_amd import kernels
     src = kernels.program_source(_programs()["gmm"], 2)
     body = src[src.index("for (int64_t tix"):]
-    assert "running CDF" in src and "fast_log(TAB(" in src and "fast_rcp(TAB(" in src
+    assert "running CDF" in src and "#define TSRC(i) TAB(i)" in src and "fast_log(TSRC(" in src and "fast_rcp(TSRC(" in src
     assert "fast_log(" not in body and "fast_rcp(" not in body        # nothing transcendental per particle but the samplers
 
 

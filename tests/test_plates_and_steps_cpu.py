@@ -37,7 +37,10 @@ def test_abi7_structs():
     assert ctypes.sizeof(A.GjxRunOpts) == 56 and ctypes.sizeof(A.GjxRunInfo) == 16 and ctypes.sizeof(A.GjxRunResample) == 72
     assert A.GjxRunResample.u.offset == 48 and A.GjxRunOpts.resample.offset == 48
     hdr = open(__file__.rsplit("/tests/", 1)[0] + "/include/gjx.h").read()
-    assert "#define GJX_ABI_VERSION 7" in hdr and "GJX_MODE_INPUT = 4" in hdr and "GJX_STATUS_VERIFY_MISMATCH = 4" in hdr
+    assert "#define GJX_ABI_VERSION 8" in hdr and "GJX_MODE_INPUT = 4" in hdr and "GJX_STATUS_VERIFY_MISMATCH = 4" in hdr
+    # ABI 8: the generic filter takes its form as arguments and reports the form that ran (no environment, no per-thread state)
+    assert ctypes.sizeof(A.GjxFilterOpts) == 24 and ctypes.sizeof(A.GjxFilterInfo) == 16 and A.GjxFilterOpts.timeline.offset == 8
+    assert "GJX_FILTER_FORM_WIDE = 3" in hdr and "GJX_FILTER_NO_ONE_LAUNCH = 3" in hdr
 
 
 @pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
@@ -270,3 +273,84 @@ def test_scan_inside_a_scan_step_lowers_to_runs_with_their_own_keys(rng):
     names, sd = [s.addr for s in sl.sites], [0.5, 1, 1, 1, 0.25] * 2
     inn = np.stack([(ch[p.slot_of[names[i]]] - (ch[p.slot_of[names[i - 1]]] if i else 0.0)) / sd[i] for i in range(10)])
     assert np.abs(inn.std(axis=1) - 1.0).max() < 0.02 and np.abs(np.corrcoef(inn) - np.eye(10)).max() < 0.02
+
+
+def test_set_obs_on_a_plate_program_equals_a_fresh_pack():
+    """PackedProgram.set_obs restacks every instance of a folded parameter of a plate site — (a) an observed
+    site OUTSIDE the plate read through a gather / an affine form by the body (shared table, d_elem == 0), (b) an observed BODY
+    site read by a later body site (derived source named by the device site list only)"""
+    n = 12
+    rs = np.random.default_rng(2)
+    tab = rs.standard_normal(3).astype(np.float32)
+    xs = rs.standard_normal(n).astype(np.float32)
+
+    @genjax.gen
+    def kernel(x, c, w):
+        m = genjax.normal(genjax.take(tab, c), 1.0) @ "m"
+        v = genjax.normal(2.0 * w + x, 0.5) @ "v"
+        return genjax.normal(3.0 * v + x, 0.3) @ "y"
+
+    @genjax.gen
+    def model():
+        c = genjax.categorical(logits=np.zeros(3, np.float32)) @ "c"
+        w = genjax.normal(0.0, 1.0) @ "w"
+        kernel.vmap(in_axes=(0, None, None))(xs, c, w) @ "k"
+
+    def chm(cv, wv, vs):
+        return C["c"].set(cv) | C["w"].set(np.float32(wv)) | C["k", "v"].set(vs) | C["k", "y"].set(np.zeros(n, np.float32))
+
+    v0, v1 = rs.standard_normal(n).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+    prog, _, _ = model.pack((), chm(0, 0.5, v0), True)
+    fresh, _, _ = model.pack((), chm(2, -1.5, v1), True)
+    assert any(prog.c_sites[j].plate for j in range(prog.n_sites))
+    assert prog.n_sites == fresh.n_sites and prog.tab.size == fresh.tab.size and not np.array_equal(prog.tab, fresh.tab)
+    prog.set_obs("c", 2)
+    prog.set_obs("w", np.float32(-1.5))
+    prog.set_obs(("@plate", ("k", "v")) if ("@plate", ("k", "v")) in prog.obs_off else (("k", "v"), 0), v1)
+    np.testing.assert_array_equal(prog.tab, fresh.tab)
+
+
+def test_filter_kernel_of_a_step_program_is_emitted_and_cross_compiles():
+    """GJX_FILTER_FORM_WIDE (include/gjx.h): the step program of a Scan kernel as the MODEL of the filter skeleton the hand-written
+    linear-Gaussian filter runs on (csrc/gjx_pfcore.h; reference recursion: scan.py:237-294).  On the CPU: the emitted source has the
+    model's pieces — table staged per step, the normal draws of the sampled site hoisted into the granule wait, the carry read
+    through the ancestor with scoped loads, rows stored with scoped stores — and hipRTC compiles it for gfx950."""
+    from genjax_amd import kernels
+    from genjax_amd.inference.scan_filter import ScanBootstrapFilter
+    dx, T = 4, 5
+    rs = np.random.default_rng(1)
+    Am = (0.5 * rs.standard_normal((dx, dx))).astype(np.float32)
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(dx, 0.5, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(dx, 2.0, np.float32)) @ "y"
+        return x, None
+
+    bf = ScanBootstrapFilter(step.scan(n=T), 4096)
+    progs = bf.step_programs(C["y"].set(rs.standard_normal((T, dx)).astype(np.float32)), (np.zeros(dx, np.float32), None))
+    src = kernels.program_filter_source(progs[1], 2)
+    assert "pf_core<GenPfModel, SPL>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src
+    assert "d.nz[3] = stream_normal<RNG>(bs" in src and "const float n_ = dr_->nz[0 + (0)];" in src
+    assert "LDIN(a.in_rows + (int64_t)3 * a.in_stride + src_[p])" in src and "tab_s[e] = tb_[e]" in src
+    assert src.count("stream_normal<RNG>(") == dx                  # the site itself draws nothing any more
+    with pytest.raises(Exception):
+        kernels.program_filter_source(progs[0], 1)                 # step 0 reads no carry: not a filter step
+    kernels.program_filter_precompile(progs[1], 2)                 # hipRTC cross-compiles without a GPU
+    kernels.program_filter_precompile(progs[2], 2)                 # same structure, other table: the same kernel (cache hit)
+
+    # a scalar model with a discrete site in the carry: nothing hoisted for the categorical site, the normal observation is scored
+    P = np.array([[2.0, -1.0], [-1.5, 1.5]], np.float32)
+    sig = np.array([0.3, 1.2], np.float32)
+
+    @genjax.gen
+    def step2(z_prev, _):
+        z = genjax.categorical(logits=genjax.take(P, z_prev) if not isinstance(z_prev, (int, float, np.integer)) else P[int(z_prev)]) @ "z"
+        genjax.normal(0.0, genjax.take(sig, z)) @ "y"
+        return z, None
+
+    bf2 = ScanBootstrapFilter(step2.scan(n=3), 2048)
+    p2 = bf2.step_programs(C["y"].set(np.array([0.1, -0.7, 1.9], np.float32)), (0, None))
+    src2 = kernels.program_filter_source(p2[1], 1)
+    assert "#define NHOIST 0" in src2 and "gjx_gen_pf" in src2
+    kernels.program_filter_precompile(p2[1], 1)
