@@ -657,9 +657,11 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // the carry of a Scan step / an argument: rows that are already there, or the rows of the ancestor the resampling step
     // picked for this slot (gjx_run_program_ex: the particle gather fused into the read side); no draw, no score
     o.f("    { // ---- site %d: INPUT, %d rows, slot %d\n", j, s.dim, s.slot);
-    for (int d = 0; d < s.dim; ++d)
-      o.f("      PLOOP v[%d][p] = a.in_rows ? LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]) : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
-          s.obs_off + d, ri.row + d);
+    for (int d = 0; d < s.dim; ++d) {
+      if (pl.pf) o.f("      PLOOP v[%d][p] = LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]);\n", s.slot + d, s.obs_off + d);   // (always through the ancestor)
+      else o.f("      PLOOP v[%d][p] = a.in_rows ? LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]) : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
+               s.obs_off + d, ri.row + d);
+    }
     o.f("      if (a.in_rows && a.store_inputs) {\n");
     for (int d = 0; d < s.dim; ++d) o.f("        VSTORE(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
     o.f("      }\n      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
@@ -669,6 +671,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const int mode = s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
+  // the filter flavour keeps weights only (no score, no per-site scores): the log-density of a SAMPLED site is never looked at
+  const bool need_lp = !(pl.pf && mode == GJX_MODE_SAMPLE);
   const int np = n_params(kind);
   const int hoist = (!pl.hoist_at.empty() && pl.hoist_at[j] >= 0) ? pl.hoist_at[j] : -1;
   if (pl.stream[j].opens && hoist < 0) {
@@ -778,7 +782,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
     const int at_ys = (comp_scale && mode == GJX_MODE_OBS_TAB && qb.op == GJX_P_CONST && ri.d_obs == 0) ? pl.find(4, qb.off, dim, qb.len, s.obs_off) : -1;
     // diagonal normals accumulate the squared z-scores; the normaliser is one constant per (gathered) row of the
     // scale table, or summed alongside when the scale is not a plain table entry
-    if (norm) o.f("      float q2[PPT], ls[PPT];\n      PLOOP { q2[p] = 0.0f; ls[p] = 0.0f; }\n");
+    if (norm && need_lp) o.f("      float q2[PPT], ls[PPT];\n      PLOOP { q2[p] = 0.0f; ls[p] = 0.0f; }\n");
     auto element = [&](const std::string& dx, const char* ind) {
       o.f("%sPLOOP {\n", ind);
       std::string in2 = std::string(ind) + "  ";
@@ -802,10 +806,12 @@ void emit_site(Emit& o, Plan& pl, int j) {
         o.f("%sfloat val;\n", in2.c_str());
         if (mode == GJX_MODE_SAMPLE && hoist >= 0) {
           o.f("%sconst float n_ = dr_->nz[%d + (%s)];\n", in2.c_str(), hoist, dx.c_str());
-          o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
+          o.f("%sval = fmaf(pb, n_, pa);\n", in2.c_str());
+          if (need_lp) o.f("%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str());
         } else if (mode == GJX_MODE_SAMPLE) {
           o.f("%sconst float n_ = stream_normal<RNG>(bs[p], %s + (uint32_t)(%u + (%s)));\n", in2.c_str(), ebase.c_str(), pl.stream[j].run >= 0 ? pl.stream[j].elem : 0u, dx.c_str());
-          o.f("%sval = fmaf(pb, n_, pa);\n%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str(), in2.c_str());
+          o.f("%sval = fmaf(pb, n_, pa);\n", in2.c_str());
+          if (need_lp) o.f("%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str());
         } else {
           if (masked) o.f("%sval = given[p] ? %s : fmaf(pb, stream_normal<RNG>(bs[p], %s + (uint32_t)(%s)), pa);\n", in2.c_str(), vslot.c_str(), ebase.c_str(), dx.c_str());
           else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
@@ -813,7 +819,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
           if (at_ys >= 0) o.f("%s{ const float z_ = fmaf(-%s, pa, COMP(%d + (%s))); q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str(), at_ys, dx.c_str());
           else o.f("%s{ const float z_ = (val - pa) * %s; q2[p] = fmaf(z_, z_, q2[p]); }\n", in2.c_str(), rcpb.c_str());
         }
-        if (at_sum < 0) o.f("%sls[p] += kHalfLog2Pi + %s;\n", in2.c_str(), logb.c_str());
+        if (at_sum < 0 && need_lp) o.f("%sls[p] += kHalfLog2Pi + %s;\n", in2.c_str(), logb.c_str());
       } else {
         o.f("%sconst float pb = %s, pc = %s, pd = %s;\n%sfloat val;\n", in2.c_str(), pe[1].c_str(), pe[2].c_str(), pe[3].c_str(), in2.c_str());
         const std::string smp = "elem_sample<RNG>(" + std::to_string(kind) + ", bs[p], " + ebase + " + (uint32_t)((" + dx + ") * " + std::to_string(nd) + "), pa, pb, pc, pd)";
@@ -821,7 +827,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
         else if (masked) o.f("%s{ const float smp_ = %s; val = given[p] ? %s : smp_; }\n", in2.c_str(), smp.c_str(), vslot.c_str());
         else if (mode == GJX_MODE_OBS_TAB) o.f("%sval = TAB(%s + (%s));\n", in2.c_str(), toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
         else o.f("%sval = %s;\n", in2.c_str(), vslot.c_str());
-        o.f("%slp[p] += elem_logpdf(%d, val, pa, pb, pc, pd);\n", in2.c_str(), kind);
+        if (need_lp) o.f("%slp[p] += elem_logpdf(%d, val, pa, pb, pc, pd);\n", in2.c_str(), kind);
       }
       if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) o.f("%s%s = val;\n", in2.c_str(), vslot.c_str());
       o.f("%s}\n", ind);
@@ -829,21 +835,22 @@ void emit_site(Emit& o, Plan& pl, int j) {
     if (expand) {
       for (int d = 0; d < dim; ++d) {
         element(std::to_string(d), "      ");
-        if ((d & 1) == 1 && d + 1 < dim) o.f("      PLOOP asm volatile(\"\" : \"+v\"(%s[p]));\n      __builtin_amdgcn_sched_barrier(0);\n", norm ? "q2" : "lp");
+        if ((d & 1) == 1 && d + 1 < dim && need_lp) o.f("      PLOOP asm volatile(\"\" : \"+v\"(%s[p]));\n      __builtin_amdgcn_sched_barrier(0);\n", norm ? "q2" : "lp");
       }
     } else {
       o.f("      for (int d_ = 0; d_ < %d; ++d_) {\n", dim);
       element("d_", "        ");
       o.f("      }\n");
     }
-    if (norm) {
+    if (norm && need_lp) {
       if (at_sum < 0) o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -ls[p]);\n");
       else if (qb.op == GJX_P_CONST) o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -COMP(%d));\n", at_sum);
       else o.f("      PLOOP lp[p] = fmaf(-0.5f, q2[p], -COMP(%d + gi_%d_1[p]));\n", at_sum, j);
     }
   }
   // bookkeeping: score, weight, per-site scores, store the site's rows
-  o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
+  if (pl.pf) { if (mode != GJX_MODE_SAMPLE) o.f("      PLOOP weight[p] += lp[p];\n"); }
+  else o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
   if (ri.plate) o.f("      PLOOP pacc%d[p] += lp[p];\n", j);      // a plate's body site: the sum over its instances
   else o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
            toff(ri.score_row, ri.d_score_row).c_str());
@@ -851,7 +858,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
     for (int d = 0; d < nrow; ++d) o.f("      VSTORE(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
   }
-  o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
+  if (pl.pf) o.f("      PLOOP asm volatile(\"\" : \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
+  else o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
 }
 
 bool want_roll() { const char* e = getenv("GJX_GEN_ROLL"); return e && atoi(e) != 0; }
@@ -1178,8 +1186,11 @@ bool pf_supported(const gjx_program* p) {
   return has_input && supported_uncached(p);
 }
 
-std::string generate_pf(const gjx_program* prog_in, int spl) {
+// spl_code: tiles per block | 256 for the flavour that runs on a collection sharded over peer-mapped windows (gjx_peer.hip)
+std::string generate_pf(const gjx_program* prog_in, int spl_code) {
   if (!pf_supported(prog_in)) return "";
+  const int spl = spl_code & 255;
+  const bool sharded = (spl_code & 256) != 0;
   GenCtx g;
   plan_program(prog_in, 1, g, false);
   Plan& pl = g.pl;
@@ -1220,13 +1231,15 @@ std::string generate_pf(const gjx_program* prog_in, int spl) {
       "#define LDIN(q) load_scoped((q), sys_)\n");
   o.f("struct GenPfModel {\n  const GenPfArgs& f;\n  float* const tab_s;\n"
       "  struct Draws { float nz[NHOIST > 0 ? NHOIST : 1]; };\n"
-      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t) : f(a), tab_s(t) {}\n"
+      "  float* cur_;            // rows of the step being produced, and the OWN rows of the step before it: chosen ONCE per step (stage)\n"
+      "  const float* in_;\n"
+      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t) : f(a), tab_s(t), cur_(nullptr), in_(nullptr) {}\n"
       "  GJX_DEV float* rows(int t) const { return f.rows_all ? f.rows_all + (int64_t)t * f.rows_step : ((t & 1) ? f.rows_b : f.rows_a); }\n"
       "  GJX_DEV const float* in_rows(int t) const { return rows(t - 1) + (t == 1 ? f.in_row0_first : f.in_row0); }   // the OWN rows of step t - 1\n"
       "  GJX_DEV void prologue(int) {}\n"
       "  GJX_DEV void epilogue(int) {}\n");
   // ---- stage: the step's table and what derives from it, while the granules travel ----
-  o.f("  GJX_DEV void stage(int t, int tid) {\n    const float* __restrict__ tb_ = f.tabs[t];\n"
+  o.f("  GJX_DEV void stage(int t, int tid) {\n    cur_ = rows(t);\n    in_ = in_rows(t);\n    const float* __restrict__ tb_ = f.tabs[t];\n"
       "    for (int e = tid; e < NTAB; e += %d) tab_s[e] = tb_[e];\n#define TSRC(i) tb_[i]\n#define BT_ %d\n", 1024, 1024);
   {
     Emit c;
@@ -1266,7 +1279,7 @@ std::string generate_pf(const gjx_program* prog_in, int spl) {
   o.f("  GJX_DEV float slot(int t, key2 key_, int j, bool act_, int sg, int sl, uint64_t gidx_, const Draws* hoisted, const PfSlotCtx& cx) const {\n"
       "    constexpr bool live_ = true; (void)live_;\n    const int64_t K = cx.K, i0 = j;\n    const bool sys_ = cx.sys;\n"
       "    struct { key2 key; float* choices; const float* in_rows; int64_t in_stride; int store_inputs; float* site_scores; const float* tab; } a;\n"
-      "    a.key = key_; a.choices = rows(t); a.in_rows = peer_ptr(in_rows(t), cx.sPD[sg]); a.in_stride = K; a.store_inputs = 0; a.site_scores = nullptr; a.tab = nullptr;\n"
+      "    a.key = key_; a.choices = cur_; a.in_rows = peer_ptr(in_, cx.sPD[sg]); a.in_stride = K; a.store_inputs = 0; a.site_scores = nullptr; a.tab = nullptr;\n"
       "    uint64_t gidx[PPT] = {gidx_};\n    int64_t src_[PPT] = {(int64_t)sl};\n"
       "    float score[PPT] = {0.0f}, weight[PPT] = {0.0f};\n    float v[%d][PPT];\n"
       "    Draws late_;\n    const Draws* dr_ = hoisted;\n    if (!dr_) { draw(t, key_, gidx_, late_); dr_ = &late_; }\n    (void)dr_;\n",
@@ -1290,10 +1303,12 @@ std::string generate_pf(const gjx_program* prog_in, int spl) {
   }
   o.f("        store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? g_ ^ 1u : g_, sys_);\n      }\n    }\n");
   o.f("    (void)score;\n    return weight[0];\n  }\n};\n");
+  // (one rank: agent-scope accesses and no verify mode compiled in; GJX_PF_SHARDED: the peer-sharded flavour decides both at run time)
   o.f("extern \"C\" __global__ __launch_bounds__(1024) void gjx_gen_pf(GenPfArgs a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) unsigned char pf_dyn[];\n"
       "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n"
-      "  GenPfModel m(a, tab_s);\n  pf_core<GenPfModel, SPL>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4);
+      "  GenPfModel m(a, tab_s);\n  pf_core<GenPfModel, SPL, %s>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4,
+      sharded ? "2, 2" : "0, 0");
   o.f("// LDS_FLOATS 0\n");
   return o.s;
 }
@@ -2207,7 +2222,8 @@ extern "C" int64_t gjx_program_filter_source(const gjx_program* step, int32_t ti
 
 extern "C" int gjx_program_filter_precompile(const gjx_program* step, int32_t tiles_per_block) {
   if (!step || !step->sites) return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: null program");
-  if (tiles_per_block != 1 && tiles_per_block != 2 && tiles_per_block != 4 && tiles_per_block != 8 && tiles_per_block != 16)
-    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16");
+  const int tpb = tiles_per_block & 255;
+  if ((tiles_per_block & ~(255 | 256)) || (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16))
+    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16 (| 256: the flavour for sharded collections)");
   return gjx::gen_pf_precompile(step, tiles_per_block);
 }

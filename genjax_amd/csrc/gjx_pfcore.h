@@ -96,8 +96,14 @@ GJX_DEV float pfc_uni_f32(float v) { return __int_as_float(__builtin_amdgcn_read
 inline __host__ __device__ size_t pf_core_dyn_lds(int NT) { return 8 * (size_t)((NT + 2) & ~1) + 8 * (size_t)(kPfCoreThreads / 256) * kPfCoreThreads + 4 * (size_t)NT; }
 
 // SPL: tiles per block (a lane produces one slot of each).  `pf_dyn`: the block's dynamic LDS (pf_core_dyn_lds bytes).
-template <class Model, int SPL>
-GJX_DEV void pf_core(const PfCoreArgs& f, Model& m, unsigned char* pf_dyn) {
+// SYSM: scope of the accesses other blocks / ranks observe — 0 agent (one rank), 1 system (peer-mapped windows), 2 decided at run
+// time by f.G (the hand-written kernels: one instantiation for both).  VERM: 0 verify mode compiled out, 2 decided by f.verify.
+template <class Model, int SPL, int SYSM = 2, int VERM = 2>
+GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
+  struct ArgsView : PfCoreArgs {                 // (compile-time modes fold the fields they fix)
+    GJX_DEV explicit ArgsView(const PfCoreArgs& a) : PfCoreArgs(a) { if (VERM == 0) verify = 0; }
+  };
+  const ArgsView f(f_in);
   constexpr int THREADS = kPfCoreThreads;
   constexpr int NW = THREADS / 64;               // waves per block
   constexpr int WPT = THREADS / 256;             // waves that re-scan one source tile together (256 particles each)
@@ -116,7 +122,7 @@ GJX_DEV void pf_core(const PfCoreArgs& f, Model& m, unsigned char* pf_dyn) {
   __shared__ int s_range[2], s_dead;
   __shared__ long long sPD[GJX_MAX_RANKS], sPF[GJX_MAX_RANKS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const bool sys = f.G > 1;
+  const bool sys = SYSM == 2 ? f.G > 1 : SYSM == 1;
   m.prologue(tid);
   if (tid < GJX_MAX_RANKS) {
     sPD[tid] = (f.peer_data && tid < f.G) ? f.peer_data[tid] : 0;
@@ -472,7 +478,7 @@ GJX_DEV void pf_core(const PfCoreArgs& f, Model& m, unsigned char* pf_dyn) {
       int src = srcs[0];
 #pragma unroll
       for (int k = 1; k < SPL; ++k) if (k == s) src = srcs[k];
-      const int sg = src / kpad, sl = src - sg * kpad;
+      const int sg = SYSM == 0 ? 0 : src / kpad, sl = src - sg * kpad;          // (one rank: no division)
       const int32_t ganc = (int32_t)((int64_t)sg * K + sl);
       if (a && f.ancestors_all) f.ancestors_all[(size_t)(t - 1) * (size_t)K + j] = ganc;
       if (a && t == T - 1 && f.ancestors) f.ancestors[j] = ganc;

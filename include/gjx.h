@@ -701,7 +701,8 @@ int gjx_scan_filter(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t
 int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, int64_t K, float* rows_all,
                             int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
                             size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out);
-/* the filter kernel generated for a step program (GJX_FILTER_FORM_WIDE) with `tiles_per_block` in {1, 2, 4, 8, 16}: its HIP source
+/* the filter kernel generated for a step program (GJX_FILTER_FORM_WIDE) with `tiles_per_block` in {1, 2, 4, 8, 16} (| 256: the flavour
+ * that runs on a collection sharded over peer-mapped windows — system-scope accesses and the verify mode decided at run time): its HIP source
  * (returns the length; copies at most cap - 1 characters) and compilation without a launch (hipRTC cross-compiles for gfx950
  * without a GPU: a build step fills the on-disk cache).  GJX_EUNSUPPORTED when the emitter does not cover the program. */
 int64_t gjx_program_filter_source(const gjx_program* step, int32_t tiles_per_block, char* out, int64_t cap);
