@@ -21,6 +21,7 @@
 #include "gjx_pfilter_host.h"
 #include "gjx_scan.h"
 #include "gjx_tile.h"
+#include "gjx_pfcore.h"
 
 using namespace gjx;
 
@@ -301,6 +302,111 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
   void* args[] = {&f};
   const hipError_t e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);
   if (e != hipSuccess) return gjx_fail_hip(e, "gjx_ssm_filter_peer(k_pf_persistent)");
+  return GJX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The bootstrap filter for ANY Scan kernel (gjx_scan_filter, GJX_FILTER_FORM_WIDE) on a collection sharded over the ranks of the
+// context: step 0 by the step program's own kernel, then steps 1 .. T-1 in ONE launch of the filter kernel generated for the step
+// program (gjx_gen_pf, sharded flavour) — the model of the skeleton k_pf_persistent runs on, so the exchange is that filter's:
+// granules pushed into every rank's flag window, source tiles' log-weights and the ancestors' carry rows pulled from the
+// owner's data window, one rendezvous per step, no host, no collective call.  The context must hold rows >= every step's
+// n_slots; every rank passes its OWN copies of the step programs (same structure, same tables) and the same key.
+// Particles and weights do not depend on the number of ranks (streams and resampling integers are global).
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                                    int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out) {
+  gjx_filter_info finfo = {GJX_FILTER_FORM_WIDE, 0, 0, 0};
+  if (info_out) *info_out = finfo;
+  if (!c || !steps || !lse_steps || T < 2) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: bad argument (T >= 2)");
+  if (!c->connected) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: the context is not connected (gjx_peer_ctx_connect)");
+  auto input_rows = [](const gjx_program& p) {
+    int n = 0;
+    for (int j = 0; j < p.n_sites; ++j) if (p.sites[j].mode == GJX_MODE_INPUT) n += p.sites[j].dim;
+    return n;
+  };
+  for (int t = 0; t < T; ++t)
+    if (steps[t].n_slots > c->rows) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: a step program has more rows than the context (rows >= n_slots of every step)");
+  if (!steps[1].tab_dev || !gen_pf_supported(&steps[1]))
+    return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: the step program is outside the filter emitter's coverage (sites SAMPLE / OBS_TAB / INPUT)");
+  for (int u = 2; u < T; ++u)
+    if (steps[u].n_tab != steps[1].n_tab || steps[u].n_slots != steps[1].n_slots || input_rows(steps[u]) != input_rows(steps[1]) || !steps[u].tab_dev ||
+        !gen_pf_same_kernel(&steps[1], &steps[u]))
+      return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: the step programs 1 .. T-1 must be one kernel (a periodic Scan)");
+  if (input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: step 1 reads more carry rows than step 0 produced");
+  if (c->NT > kPfHostMaxTiles) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: K_total <= 2^22");
+  const size_t need_run = gjx_workspace_bytes(GJX_OP_RUN, c->K);
+  if (!workspace || workspace_bytes < need_run + 8 * (size_t)T + 256) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter_peer: workspace too small (OP_RUN + 8 T + 256)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t K = c->K, K_total = K * c->world;
+  const size_t dyn = pf_core_dyn_lds(c->NT);
+  int spl = 0, grid = 0;
+  const int spls[5] = {1, 2, 4, 8, 16};
+  for (int i = 0; i < 5 && !spl; ++i) {
+    const int64_t g = ((int64_t)c->nt + spls[i] - 1) / spls[i];
+    int cap = gen_pf_resident_blocks(&steps[1], spls[i] | 256, dyn);
+    if (cap <= 0) break;
+    if (c->share > 1) cap /= c->share;               // ranks that share one device (dry runs): every rank's grid must be resident
+    if (g <= cap && g * c->world <= kPfHostMaxTiles) { spl = spls[i]; grid = (int)g; }
+  }
+  if (!spl) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: no co-resident grid for this size (or the kernel could not be generated)");
+  if (T > c->t_cap) {   // longer than the 4096 steps the context was sized for: the scratch grows here, once, outside every loop
+    if (c->us_dev) (void)hipFree(c->us_dev);
+    if (c->keys_dev) (void)hipFree(c->keys_dev);
+    c->us_dev = nullptr; c->keys_dev = nullptr; c->t_cap = 0;
+    GJX_HIP(hipMalloc((void**)&c->us_dev, sizeof(double) * (size_t)T), "gjx_scan_filter_peer: step offsets");
+    GJX_HIP(hipMalloc((void**)&c->keys_dev, sizeof(uint32_t) * 2 * (size_t)T), "gjx_scan_filter_peer: step keys");
+    c->t_cap = T;
+  }
+  std::vector<uint32_t> h_keys;
+  std::vector<double> h_us;
+  pf_step_keys(key0, key1, T, h_keys, h_us);
+  if (int rcu = upload_words(c->us_dev, h_us.data(), (size_t)T, st)) return rcu;
+  if (int rcu = upload_words(c->keys_dev, h_keys.data(), (size_t)T, st)) return rcu;
+  const float** tabs_dev = (const float**)((char*)workspace + ((need_run + 255) & ~(size_t)255));
+  std::vector<const float*> h_tabs((size_t)T, nullptr);
+  for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
+  if (int rcu = upload_words(tabs_dev, h_tabs.data(), (size_t)T, st)) return rcu;
+  float* rows_a = (float*)(c->data + c->off_rows[0]);
+  float* rows_b = (float*)(c->data + c->off_rows[1]);
+  float* lw_even = (float*)(c->data + c->off_lw[0]);
+  float* lw_odd = (float*)(c->data + c->off_lw[1]);
+  float* lw0 = ((T - 1) & 1) ? lw_odd : lw_even;     // log-weights of step 0
+  // step 0 (no carry to read) on this rank's particle range; its global LSE record comes out of the ring like every other step's
+  gjx_run_opts o;
+  memset(&o, 0, sizeof(o));
+  gjx_run_info info = {0, 0, 0};
+  int rc = gjx_run_program_ex(&steps[0], h_keys[0], h_keys[1], K, (int64_t)c->rank * K, rows_a, nullptr, nullptr, lw0, nullptr, nullptr, nullptr, nullptr,
+                              K_total, workspace, need_run, stream, &o, &info);
+  if (rc) return rc;
+  const int region = (int)(c->n_filter & 1), other = region ^ 1;
+  c->n_filter += 1;
+  char* rg = c->flag + c->off_region[region];
+  GenPfArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  PfCoreArgs& f = ga.core;
+  f.T = T; f.K = K; f.K_total = K_total; f.offset = (int64_t)c->rank * K; f.G = c->world; f.rank = c->rank; f.nt = c->nt; f.NT = c->NT;
+  f.lw_even = lw_even; f.lw_odd = lw_odd;
+  f.aggA = (unsigned long long*)(rg + c->r_aggA); f.aggB = (unsigned long long*)(rg + c->r_aggB);
+  f.bsum = (float*)(rg + c->r_bsum); f.bmax = (float*)(rg + c->r_bmax); f.ready = (unsigned*)(rg + c->r_ready);
+  f.peer_data = c->world > 1 ? c->delta_dev : nullptr;
+  f.peer_flag = c->world > 1 ? c->delta_dev + c->world : nullptr;
+  f.keys = c->keys_dev; f.us = c->us_dev; f.lse_steps = lse_steps; f.ancestors = ancestors; f.ancestors_all = nullptr;
+  f.ctrl = (unsigned*)c->flag + 8; f.log_k = (float)log((double)K_total);
+  f.first_budget = c->world > 1 ? (1u << 24) : (1u << 16);
+  f.zero_ptr = (unsigned long long*)(c->flag + c->off_region[other] + c->r_aggA);
+  f.zero_n = (int)((c->r_bsum - c->r_aggA) / 8);
+  f.verify = c->verify ? (c->verify_fault ? 2 : 1) : 0;
+  f.chk_a = (unsigned*)(c->data + c->off_chk[0]); f.chk_b = (unsigned*)(c->data + c->off_chk[1]);
+  f.timeline = nullptr;
+  ga.tabs = tabs_dev;
+  ga.rows_a = rows_a; ga.rows_b = rows_b; ga.rows_all = nullptr; ga.rows_step = 0;
+  ga.in_row0_first = (int64_t)input_rows(steps[0]) * K;
+  ga.in_row0 = (int64_t)input_rows(steps[1]) * K;
+  rc = gen_pf_launch(&steps[1], spl | 256, ga, grid, dyn, st);
+  if (rc) return rc;
+  finfo.launches = 2; finfo.grid = grid; finfo.tiles_per_block = spl;
+  if (info_out) *info_out = finfo;
   return GJX_OK;
 }
 

@@ -189,6 +189,32 @@ class ScanBootstrapFilter:
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=self._out(ch), logw=self._out(b["logw"]), programs=progs,
                     ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info)
 
+    def run_peer(self, ctx, key: Key, constraint: ChoiceMap, args=(None, None), want_ancestors: bool = False):
+        """the same filter on a collection SHARDED over the ranks of a ``kernels.PeerContext`` (one process per GPU; ``self.K`` is the
+        number of particles of THIS rank, the context's K_local; its rows >= the step programs' rows): gjx_scan_filter_peer —
+        two launches per rank whatever T is, granules pushed and carry rows pulled through the peer-mapped windows, no host in the
+        loop.  Every rank calls it with the same key, observations and arguments.  -> dict(log_ml (global), increments, lse_steps,
+        choices (this rank's part of the last step: a view of the window), logw, ancestors? (global indices), programs, info)"""
+        if ctx.K != self.K:
+            raise ValueError("run_peer: the filter's particle count must be the context's K_local")
+        dev = ctx.device
+        sk, dk = _run_keys(constraint, args, dev)
+        c = self._cache
+        if c.get("sk") != sk or c.get("dk") != dk:
+            progs = self.step_programs(constraint, args)
+            tabs_dev = _bind_device(progs, dev)
+            cps = (A.GjxProgram * len(progs))()
+            for t, p in enumerate(progs):
+                cps[t] = p.c_program(tabs_dev[0].device)
+            c = self._cache = dict(sk=sk, dk=dk, progs=progs, cps=cps, tabs_dev=tabs_dev)
+        progs, cps = c["progs"], c["cps"]
+        if max(p.n_slots for p in progs) > ctx.nrows:
+            raise ValueError(f"run_peer: the context has {ctx.nrows} rows, the step programs need {max(p.n_slots for p in progs)}")
+        o = ctx.scan_filter(cps, len(progs), key, want_ancestors=want_ancestors)
+        incs = o["lse_steps"][:, 3]
+        return dict(log_ml=incs.sum(), increments=incs, lse_steps=o["lse_steps"], choices=o["rows"][: max(progs[-1].n_slots, 1)], logw=o["logw"],
+                    ancestors=o["ancestors"], programs=progs, info=o["info"])
+
     def _opts(self) -> "A.GjxFilterOpts":
         """the form of the run as ARGUMENTS of the call (the library reads no environment variable).  Attributes of the filter, or —
         for scripts and tests — these variables, read HERE: GJX_SCAN_FILTER_TWO_LAUNCH=1 (search launch + step launch),

@@ -709,6 +709,21 @@ class PeerContext:
               "gjx_ssm_filter_peer")
         return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
 
+    def scan_filter(self, cps, T: int, key, want_ancestors: bool = False):
+        """gjx_scan_filter_peer: the bootstrap filter for ANY Scan kernel on this sharded collection — ``cps``: the ctypes array of
+        this rank's T step programs (inference/scan_filter.py).  -> dict(lse_steps [T][4] global records, rows (the last step's
+        choices: a view of the window), logw, ancestors?, info)"""
+        lse = torch.empty((T, 4), dtype=torch.float32, device=self.device)
+        anc = torch.empty(self.K, dtype=torch.int32, device=self.device) if want_ancestors else None
+        need = load().gjx_workspace_bytes(A.OP_RUN, self.K) + 8 * int(T) + 512
+        if getattr(self, "_sf_ws", None) is None or self._sf_ws.numel() < need:
+            self._sf_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        info = A.GjxFilterInfo()
+        check(load().gjx_scan_filter_peer(self._h, C.cast(cps, C.c_void_p), int(T), key[0], key[1], _ptr(lse), _ptr(anc), _ptr(self._sf_ws),
+                                          self._sf_ws.numel(), _stream(), C.byref(info)), "gjx_scan_filter_peer")
+        return dict(lse_steps=lse, rows=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc,
+                    info=dict(form=int(info.form), launches=int(info.launches), grid=int(info.grid), tiles_per_block=int(info.tiles_per_block)))
+
     def resample_gather(self, parity: int, u: float, partials=None, out=None, anc=None, lse_out=None):
         """gjx_peer_resample_gather: logw[parity], rows[parity] -> the children of this rank's slots (one launch).
         ``partials=(run_workspace, n)``: the block pairs of the producing run -> lse_out receives the global record."""

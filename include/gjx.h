@@ -786,6 +786,22 @@ int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t 
 int gjx_ssm_filter_peer_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
                              const float* ys_dev, float* lse_steps, int32_t* ancestors, int32_t n_moves, float move_scale,
                              uint64_t* accepted_total, void* stream);
+/* The bootstrap filter for ANY Scan kernel (gjx_scan_filter, form GJX_FILTER_FORM_WIDE) on a collection sharded over the ranks of a
+ * peer context (north_star: particles shard across the GPUs of a node; the recursion is Scan.generate's, combinators/scan.py:237-294).
+ * Every rank calls this with ITS copies of the step programs (same structure and tables on every rank) and the same key; the context
+ * must have rows >= every step's n_slots.  TWO launches per rank whatever T is: step 0 by its program's kernel, then steps 1 .. T-1
+ * in one launch of the filter kernel generated for the step program — the model of the skeleton gjx_ssm_filter_peer's kernel runs on,
+ * hence the same exchange: granules pushed into every rank's flag window, source tiles' log-weights and the ancestors' carry rows
+ * pulled through the peer mappings, one rendezvous per step.  Streams are indexed by the global particle index and every integer of
+ * the resampling comes from the same K_total / 1024 granules on every rank: results do not depend on n_ranks (bit-identical to
+ * gjx_scan_filter on the unsharded collection).  GJX_PEER_VERIFY / GJX_PEER_DATA of the context apply (check words cover the carry
+ * rows a step hands to the next).  The choices of the last step are left in rows[(T - 1) & 1] of the context (row r of the step
+ * program = row r of the window), their log-weights in logw[0]; lse_steps f32[T][4] = the GLOBAL record of every step (every
+ * rank); ancestors (or NULL) int32[K_local] = global index of every slot's ancestor at the last resampling.
+ * workspace: gjx_workspace_bytes(GJX_OP_RUN, K_local) + 8 T + 256 bytes, zero-filled once.  GJX_EUNSUPPORTED: the step programs are
+ * not one kernel the filter emitter covers, or no co-resident grid exists for the size. */
+int gjx_scan_filter_peer(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                         int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out);
 /* BASELINE configs 2 / 4 on a sharded collection — one systematic resampling step over the WHOLE collection in ONE
  * launch per rank (ParticleCollection resampling, the N-of-K form of smc.py:102-109): this rank's log-weights logw[parity]
  * and rows rows[parity] (the buffers of the DATA window the producing kernel wrote) -> the children of this rank's

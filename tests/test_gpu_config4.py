@@ -97,6 +97,68 @@ def test_config4_filter_dry_run(tmp_path, data):
         assert abs(log_ml - exact) <= 1e-4 * abs(exact), (log_ml, exact)
 
 
+def _generic_filter_worker(rank, world, port, K_total, T, dx, out_dir, env):
+    try:
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+        import genjax_amd as genjax
+        from genjax_amd import C, distributed as D, kernels, workloads
+        from genjax_amd.inference import BootstrapFilter
+        D.init_from_env("gloo")
+        torch.cuda.set_device(0)
+        scan, carry0, s = workloads.lgssm_scan(dx, T)
+        ys = np.asarray(s["y"], np.float32)
+        bf = BootstrapFilter(scan, K_total // world)
+        rows = max(p.n_slots for p in bf.step_programs(C["y"].set(ys), (carry0, None)))
+        ctx = kernels.PeerContext(K_total // world, rows, "cuda")
+        o = bf.run_peer(ctx, genjax.key(7), C["y"].set(ys), (carry0, None), want_ancestors=True)
+        torch.cuda.synchronize()
+        st = ctx.status()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=bf.latent(o, "x").cpu().numpy(), logw=o["logw"].cpu().numpy(),
+                 lse=o["lse_steps"].cpu().numpy(), anc=o["ancestors"].cpu().numpy(), status=st, share=ctx.ranks_on_device,
+                 grid=o["info"]["grid"], tpb=o["info"]["tiles_per_block"])
+        ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        with open(os.path.join(out_dir, "rank%d.err" % rank), "w") as f:
+            f.write(traceback.format_exc())
+        raise
+
+
+def test_config4_generic_filter_dry_run(tmp_path):
+    """config 4's workload with the model written as @gen + .scan: 8 ranks x 2^19 particles, T = 256, d_x = 8, GJX_PEER_VERIFY=1 —
+    gjx_scan_filter_peer (the filter kernel GENERATED for the step program on the shared skeleton, sharded flavour).  Required:
+    states, log-weights and ancestors bit-identical to the one-rank generic filter at K = 2^22, log-ML within rtol 1e-4 of the float64
+    Kalman value, status word 0 on every rank"""
+    import genjax_amd as genjax
+    from genjax_amd import C, workloads
+    from genjax_amd.inference import BootstrapFilter
+    from oracle import closed_form as cf
+    world, K_total, T, dx = 8, 1 << 22, 256, 8
+    res = _run_ranks(_generic_filter_worker, world, (K_total, T, dx, str(tmp_path), dict(GJX_PEER_VERIFY="1")), str(tmp_path))
+    assert all(int(r["status"]) == 0 for r in res), [int(r["status"]) for r in res]
+    assert all(int(r["share"]) == world for r in res)
+    scan, carry0, s = workloads.lgssm_scan(dx, T)
+    ys = np.asarray(s["y"], np.float32)
+    bf = BootstrapFilter(scan, K_total)
+    ref = bf.run(genjax.key(7), C["y"].set(ys), (carry0, None))
+    assert not ref["degenerate"]
+    np.testing.assert_array_equal(np.concatenate([r["x"] for r in res], axis=1), bf.latent(ref, "x").cpu().numpy())
+    np.testing.assert_array_equal(np.concatenate([r["logw"] for r in res]), ref["logw"].cpu().numpy())
+    np.testing.assert_array_equal(np.concatenate([r["anc"] for r in res]), ref["ancestors"].cpu().numpy())
+    exact, _, _ = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"], q0=float(s["q"]))
+    for r in res:
+        np.testing.assert_allclose(r["lse"][:, 2:], ref["lse_steps"].cpu().numpy()[:, 2:], rtol=2e-6, atol=2e-6)
+        log_ml = float(r["lse"][:, 3].astype(np.float64).sum())
+        assert abs(log_ml - exact) <= 1e-4 * abs(exact), (log_ml, exact)
+    print("generic filter, config-4 dry run: grid", int(res[0]["grid"]), "x", int(res[0]["tpb"]), "tiles per block; one-rank reference:", ref["info"])
+
+
 def test_verify_mode_catches_a_bad_row(tmp_path):
     """the check itself: with GJX_PEER_VERIFY_FAULT=<rank> that rank publishes check words that do not belong to its rows —
     what a stale or torn row looks like to a reader — and every rank that pulls from it must raise GJX_STATUS_VERIFY_MISMATCH

@@ -134,6 +134,96 @@ def test_peer_move_filter_equals_unsharded(world, K_total, dx):
     assert all(r[2] == 0 for r in res), [r[2] for r in res]
 
 
+def _scan_filter_worker(rank, world, port, K_total, T, dx, q, env):
+    try:
+        import sys
+        import torch
+        import torch.distributed as dist
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+        import genjax_amd as genjax
+        from genjax_amd import C, distributed as D, kernels, workloads
+        from genjax_amd.inference import BootstrapFilter
+        D.init_from_env("gloo")
+        torch.cuda.set_device(0)
+        scan, carry0, s = workloads.lgssm_scan(dx, T)
+        ys = np.asarray(s["y"], np.float32)
+        bf = BootstrapFilter(scan, K_total // world)
+        rows = max(p.n_slots for p in bf.step_programs(C["y"].set(ys), (carry0, None)))
+        ctx = kernels.PeerContext(K_total // world, rows, "cuda")
+        outs = []
+        for rep in range(2):                      # consecutive runs alternate the flag regions of the context
+            o = bf.run_peer(ctx, genjax.key(5 + rep), C["y"].set(ys), (carry0, None), want_ancestors=True)
+            torch.cuda.synchronize()
+            outs.append((bf.latent(o, "x").cpu().numpy().copy(), o["logw"].cpu().numpy().copy(), o["lse_steps"].cpu().numpy().copy(),
+                         o["ancestors"].cpu().numpy().copy(), o["info"]))
+        st = ctx.status()
+        q.put((rank, outs, st, ctx.ranks_on_device))
+        ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+        raise
+
+
+def _run_scan_filter_ranks(world, K_total, T, dx, env):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200) + world
+    procs = [ctx.Process(target=_scan_filter_worker, args=(r, world, port, K_total, T, dx, q, env)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,K_total,dx,verify", [(1, 1 << 14, 8, 0), (2, 1 << 15, 8, 1), (4, 1 << 16, 4, 1), (8, 1 << 19, 8, 1)])
+def test_generic_filter_sharded_over_peer_windows_equals_unsharded(world, K_total, dx, verify):
+    """gjx_scan_filter_peer — the filter kernel GENERATED for config 3's model written as @gen + .scan, on `world` ranks (processes
+    sharing the GPU, windows mapped through hipIpc) — == gjx_scan_filter on one rank: states, log-weights and ancestors bit for bit, the
+    global LSE records to summation order; with GJX_PEER_VERIFY=1 every pulled carry row is checked against its owner's word and every
+    re-scanned tile against its granule, and no status bit may be raised"""
+    import genjax_amd as genjax
+    from genjax_amd import C, workloads
+    from genjax_amd import _abi as A
+    from genjax_amd.inference import BootstrapFilter
+    T = 10
+    res = _run_scan_filter_ranks(world, K_total, T, dx, dict(GJX_PEER_VERIFY=str(verify)))
+    scan, carry0, s = workloads.lgssm_scan(dx, T)
+    ys = np.asarray(s["y"], np.float32)
+    bf = BootstrapFilter(scan, K_total)
+    for rep in range(2):
+        ref = bf.run(genjax.key(5 + rep), C["y"].set(ys), (carry0, None))
+        x = np.concatenate([r[1][rep][0] for r in res], axis=1)
+        lw = np.concatenate([r[1][rep][1] for r in res])
+        anc = np.concatenate([r[1][rep][3] for r in res])
+        np.testing.assert_array_equal(x, bf.latent(ref, "x").cpu().numpy())
+        np.testing.assert_array_equal(lw, ref["logw"].cpu().numpy())
+        np.testing.assert_array_equal(anc, ref["ancestors"].cpu().numpy())
+        for r in res:                             # every rank holds the global records
+            np.testing.assert_allclose(r[1][rep][2][:, 2:], ref["lse_steps"].cpu().numpy()[:, 2:], rtol=2e-6, atol=2e-6)
+            assert r[1][rep][4]["form"] == A.FILTER_FORM_WIDE and r[1][rep][4]["launches"] == 2
+    assert all(r[2] == 0 for r in res), [r[2] for r in res]       # no time-out, no dead step, no verify mismatch
+    assert all(r[3] == world for r in res)
+
+
+def test_generic_filter_verify_mode_detects_a_rank_that_publishes_wrong_check_words():
+    """GJX_PEER_VERIFY_FAULT=<rank>: that rank's check words are wrong on purpose — every rank that pulls one of its carry rows must
+    raise GJX_STATUS_VERIFY_MISMATCH (the detector of the generated filter kernel is itself tested)"""
+    res = _run_scan_filter_ranks(2, 1 << 15, 8, 8, dict(GJX_PEER_VERIFY="1", GJX_PEER_VERIFY_FAULT="1"))
+    assert any(r[2] & 4 for r in res), [r[2] for r in res]
+
+
 def _weights(shape, K, seed=11):
     rs = np.random.default_rng(seed)
     lw = (rs.standard_normal(K) * (5.0 if shape == "wide" else 1.0)).astype(np.float32)
