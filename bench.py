@@ -158,6 +158,28 @@ def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
 
 
 # ---------------------------------------------------------------------------------------------
+
+def _exchange_record(exch, dev, status_word=None):
+    """The first multi-GPU line must diagnose itself: EVERY rank's view — transport chosen, verdict and details of the peer self-check
+    (64 tiles per rank, check words on: genjax_amd/distributed.py), status words, ranks of the communicator — gathered to all ranks
+    (collective: every rank calls it) and put under config.exchange_stats.per_rank by rank 0."""
+    import torch.distributed as dist
+    from genjax_amd import distributed as DD
+    mine = dict(exch)
+    mine["rank"] = dist.get_rank() if dist.is_initialized() else 0
+    mine["device"] = str(dev)
+    mine["status_word"] = status_word
+    mine["peer_self_check"] = DD.peer_report(dev) or "not run (one rank, or GJX_PEER=0 / 1)"
+    if dist.is_initialized():
+        mine["process_group"] = dict(backend=dist.get_backend(), ranks=dist.get_world_size())
+    per_rank = DD.gather_objects(mine)
+    out = dict(exch)
+    out["per_rank"] = per_rank
+    out["transports_agree"] = len({r.get("transport") for r in per_rank}) == 1
+    out["any_status_bit"] = any(bool(r.get("status_word")) for r in per_rank)
+    return out
+
+
 def run_gmm(args, rank, world, dev):
     from genjax_amd import _abi as A
     from genjax_amd import distributed as DD
@@ -289,10 +311,12 @@ def run_gmm(args, rank, world, dev):
     torch.cuda.synchronize()
     dt, lse = timed_loop(args, world, dev, step)
     exch = dict(transport="none")
+    status_word = None
     if peer is not None:
         lse = lse.clone()
         torch.cuda.synchronize()
-        exch = dict(transport="peer", ranks=world, ranks_on_this_device=peer.ranks_on_device, status=peer.status(),
+        status_word = peer.status()
+        exch = dict(transport="peer", ranks=world, ranks_on_this_device=peer.ranks_on_device, status=status_word,
                     note="peer-mapped windows (hipIpc): one resampling launch per rank, two G-word hops, children pulled from their owners")
         peer.close()
     if resampler is not None:
@@ -300,6 +324,8 @@ def run_gmm(args, rank, world, dev):
         torch.cuda.synchronize()
         exch = resampler.stats()
         resampler.close()            # communicator torn down on every rank while the process group is still up
+    if sharded:
+        exch = _exchange_record(exch, dev, status_word)      # (collective: every rank's view travels to rank 0)
     if rank != 0:
         return None
     disp = [timers[j].elapsed_us() for j in range(n_samp) if j % 2 == 0]
@@ -454,13 +480,17 @@ def run_ssm(args, rank, world, dev):
         torch.cuda.synchronize()
         other = dict(weights=o_name, us_per_filter_step=(time.perf_counter() - t0) / 3 / T * 1e6, log_ml=float(lo))
     exch = dict(transport="none")
+    status_word = None
     torch.cuda.synchronize()
     if getattr(bf, "_peer", None) is not None:
-        exch = dict(transport="peer", ranks=world, ranks_on_this_device=bf._peer.ranks_on_device,
+        status_word = bf._peer.status()
+        exch = dict(transport="peer", ranks=world, ranks_on_this_device=bf._peer.ranks_on_device, status=status_word,
                     note="peer-mapped windows (hipIpc): granules pushed, source tiles and ancestors pulled inside one launch; no collective calls")
     elif getattr(bf, "_resampler", None) is not None:
         exch = bf._resampler.stats()
     bf.close()
+    if world > 1:
+        exch = _exchange_record(exch, dev, status_word)      # (collective: every rank's view travels to rank 0)
     if rank != 0:
         return None
     exact = golden("ssm_dx8_T256_seed0")

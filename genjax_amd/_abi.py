@@ -84,6 +84,9 @@ FILTER_FORM_NAMES = {0: "two launches per step", 1: "one launch per step", 2: "s
                      3: "filter kernel on the shared skeleton (16 waves per tile)"}
 
 
+PEER_VERIFY_ON, PEER_DATA_FINE, PEER_VERIFY_FAULTY = 1, 2, 4
+
+
 class GjxFilterOpts(C.Structure):
     _fields_ = [("flags", i32), ("coresident_blocks", i32), ("timeline", vp), ("timeline_bytes", i64)]
 
@@ -178,6 +181,7 @@ PROTOTYPES = {
     "gjx_shard_global_lse": (C.c_int, [vp, vp, vp, vp]),
     "gjx_scan_filter_peer": (C.c_int, [vp, vp, i32, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]),
     "gjx_peer_ctx_create": (C.c_int, [i32, i32, i64, i32, i32, C.POINTER(vp)]),
+    "gjx_peer_ctx_create_ex": (C.c_int, [i32, i32, i64, i32, i32, i32, C.POINTER(vp)]),
     "gjx_peer_ctx_export": (C.c_int, [vp, vp]),
     "gjx_peer_ctx_connect": (C.c_int, [vp, vp]),
     "gjx_peer_ctx_buffers": (C.c_int, [vp, vp]),

@@ -80,8 +80,24 @@ extern "C" int gjx_peer_ctx_destroy(gjx_peer_ctx* c) {
   return GJX_OK;
 }
 
+static int peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device, int32_t flags,
+                           gjx_peer_ctx** out);
+// the switches from the environment (GJX_PEER_VERIFY, GJX_PEER_DATA, GJX_PEER_VERIFY_FAULT), read here and nowhere else
 extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device,
                                    gjx_peer_ctx** out) {
+  int32_t flags = 0;
+  { const char* v = getenv("GJX_PEER_VERIFY"); if (v && atoi(v) != 0) flags |= GJX_PEER_VERIFY_ON; }
+  { const char* v = getenv("GJX_PEER_DATA"); if (v && !strcmp(v, "fine")) flags |= GJX_PEER_DATA_FINE; }
+  { const char* v = getenv("GJX_PEER_VERIFY_FAULT"); if ((flags & GJX_PEER_VERIFY_ON) && v && atoi(v) == rank) flags |= GJX_PEER_VERIFY_FAULTY; }
+  return peer_ctx_create(n_ranks, rank, K_local, rows, ranks_on_this_device, flags, out);
+}
+// the same with the switches as an argument (no environment): GJX_PEER_VERIFY_ON | GJX_PEER_DATA_FINE | GJX_PEER_VERIFY_FAULTY
+extern "C" int gjx_peer_ctx_create_ex(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device,
+                                      int32_t flags, gjx_peer_ctx** out) {
+  return peer_ctx_create(n_ranks, rank, K_local, rows, ranks_on_this_device, flags, out);
+}
+static int peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device, int32_t flags,
+                           gjx_peer_ctx** out) {
   if (!out || n_ranks < 1 || n_ranks > GJX_MAX_RANKS || rank < 0 || rank >= n_ranks || K_local <= 0 || rows < 1 ||
       ranks_on_this_device < 1)
     return gjx_fail(GJX_EINVAL, "gjx_peer_ctx_create: bad argument");
@@ -100,10 +116,10 @@ extern "C" int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_loca
   for (int p = 0; p < 2; ++p) { c->off_m[p] = o; o = align_up(o + sizeof(float) * (size_t)rows * (size_t)K_local); }
   for (int p = 0; p < 2; ++p) { c->off_chk[p] = o; o = align_up(o + sizeof(uint32_t) * (size_t)K_local); }
   c->data_bytes = o;
-  { const char* v = getenv("GJX_PEER_VERIFY"); c->verify = v && atoi(v) != 0; }
-  { const char* v = getenv("GJX_PEER_DATA"); c->data_fine = v && !strcmp(v, "fine"); }
+  c->verify = (flags & GJX_PEER_VERIFY_ON) != 0;
+  c->data_fine = (flags & GJX_PEER_DATA_FINE) != 0;
   // test hook of the verify mode: this rank publishes check words that do not belong to its rows (tests/test_gpu_config4.py)
-  { const char* v = getenv("GJX_PEER_VERIFY_FAULT"); c->verify_fault = c->verify && v && atoi(v) == rank; }
+  c->verify_fault = c->verify && (flags & GJX_PEER_VERIFY_FAULTY) != 0;
   // FLAG window: [256 B control][region 0][region 1]; a region: granules A, B [NT] | ring sum, max [3][NT] | ready words |
   // the words of the one-launch resampling step (twice, for alternating calls: 4 x [MAX_RANKS] u64 + this rank's tile granules [nt])
   const size_t NT = (size_t)c->NT;

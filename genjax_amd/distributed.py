@@ -445,12 +445,16 @@ class ShardedResampler:
 # host in the loop.  Opened once per process after a self-check; the collective transports above stay as the fallback.
 # ---------------------------------------------------------------------------------------------------------------
 _peer_verdict: dict = {}
+_peer_report: dict = {}          # what the self-check saw, per (device, group): bench.py prints it for every rank
+
+SELF_CHECK_TILES = 64            # tiles of 1024 particles per rank in the self-check (enough for rows to cross every pair of ranks)
 
 
 def _peer_self_check(device, group) -> bool:
-    """A small sharded tile-scaled filter through the peer windows against the same filter run unsharded on this rank:
-    this rank's slice of the particles and log-weights must match bit for bit and no rendezvous may time out.  Collective:
-    every rank gets the same verdict."""
+    """First contact with the fabric: a sharded tile-scaled filter through the peer windows — 64 tiles per rank, 6 steps, CHECK WORDS
+    ON (A.PEER_VERIFY_ON: every pulled row against its owner's word, every re-scanned tile against its granule) — against the same
+    filter run unsharded on this rank: this rank's slice of the particles and log-weights must match bit for bit, no rendezvous may
+    time out and no check may fail.  Collective: every rank gets the same verdict; the details stay in ``peer_report``."""
     import numpy as np
     from . import _abi as A
     from . import kernels
@@ -458,43 +462,65 @@ def _peer_self_check(device, group) -> bool:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     host = _host_staged(group) if dist.is_initialized() else True
+    Kl, T = SELF_CHECK_TILES * 1024, 6
+    rep = dict(rank=rank, world=world, verify=True, tiles_per_rank=SELF_CHECK_TILES, steps=T, status=None, bit_identical=None, error=None)
+    _peer_report[(str(torch.device(device)), id(group))] = rep
     ok = 0
     pc = None
     try:
-        pc = kernels.PeerContext(2048, 4, device, group)
+        pc = kernels.PeerContext(Kl, 4, device, group, flags=A.PEER_VERIFY_ON)
     except Exception as e:                 # symmetric: PeerContext raises on every rank or on none
         import warnings
         warnings.warn(f"peer-mapped exchange unavailable: {e}")
+        rep["error"] = repr(e)
         return False
     try:
+        rep["ranks_on_this_device"] = pc.ranks_on_device
         th = 0.3 + 0.1 * np.arange(2)
         Am = np.zeros((4, 4), np.float32)
         for i, t in enumerate(th):
             c, s_ = 0.9 * np.cos(t), 0.9 * np.sin(t)
             Am[2 * i:2 * i + 2, 2 * i:2 * i + 2] = [[c, -s_], [s_, c]]
         ssm = LinearGaussianSSM(Am, 0.5, 2.0)
-        ys = torch.as_tensor(np.random.default_rng(5).standard_normal((5, 4)).astype(np.float32), device=device)
+        ys = torch.as_tensor(np.random.default_rng(5).standard_normal((T, 4)).astype(np.float32), device=device)
         cs = ssm.c_struct(device)
         got = pc.ssm_filter(cs, (0, 77), A.RNG_FLAT, ys)
         torch.cuda.synchronize(device)
         st = pc.status()
-        ref = kernels.ssm_filter(cs, (0, 77), A.RNG_FLAT, ys, 2048 * world, weights=A.WEIGHTS_TILE_SCALED)
-        sl = slice(rank * 2048, (rank + 1) * 2048)
+        ref = kernels.ssm_filter(cs, (0, 77), A.RNG_FLAT, ys, Kl * world, weights=A.WEIGHTS_TILE_SCALED)
+        sl = slice(rank * Kl, (rank + 1) * Kl)
         same = torch.equal(got["x"], ref["x"][:, sl]) and torch.equal(got["logw"], ref["logw"][sl])
+        rep["status"], rep["bit_identical"] = int(st), bool(same)
         ok = 1 if (same and st == 0) else 0
     except Exception as e:
         import warnings
         warnings.warn(f"peer-mapped exchange: self-check raised {e!r}")
+        rep["error"] = repr(e)
         ok = 0
     if world > 1:
         t = torch.tensor([ok], dtype=torch.int32, device="cpu" if host else device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         ok = int(t.item())
+    rep["verdict_all_ranks"] = bool(ok)
     try:
         pc.close()
     except Exception:
         pass
     return bool(ok)
+
+
+def peer_report(device, group=None) -> dict:
+    """what this rank's self-check of the peer-mapped exchange saw ({} when it never ran: GJX_PEER=0 / 1)"""
+    return dict(_peer_report.get((str(torch.device(device)), id(group)), {}))
+
+
+def gather_objects(obj, group=None) -> list:
+    """every rank's (picklable) object on every rank, in rank order — the per-rank diagnostics of a multi-GPU bench line"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
 
 
 def peer_available(device, group=None) -> bool:

@@ -615,7 +615,9 @@ class PeerContext:
     DATA window: kernels write their particles there, other ranks read them through hipIpc mappings.  The handles travel
     through one all-gather on ``group`` (any backend) at construction; nothing else ever goes through the host."""
 
-    def __init__(self, K_local: int, rows: int, device=None, group=None, ranks_on_device: int | None = None):
+    def __init__(self, K_local: int, rows: int, device=None, group=None, ranks_on_device: int | None = None, flags: int | None = None):
+        """``flags`` (A.PEER_VERIFY_ON | A.PEER_DATA_FINE | ...): the context's switches as an argument; None: from the environment
+        (GJX_PEER_VERIFY, GJX_PEER_DATA), read by the library at creation"""
         import torch.distributed as dist
         self.group = group
         self.device = _dev(device)
@@ -660,7 +662,10 @@ class PeerContext:
 
         err = None
         with torch.cuda.device(self.device):
-            rc = load().gjx_peer_ctx_create(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, C.byref(self._h))
+            if flags is None:
+                rc = load().gjx_peer_ctx_create(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, C.byref(self._h))
+            else:
+                rc = load().gjx_peer_ctx_create_ex(self.world, self.rank, self.K, self.nrows, self.ranks_on_device, int(flags), C.byref(self._h))
             buf = (C.c_uint8 * 128)()
             if rc == 0 and self.world > 1:
                 rc = load().gjx_peer_ctx_export(self._h, C.cast(buf, C.c_void_p))

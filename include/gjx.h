@@ -764,6 +764,11 @@ int gjx_shard_global_lse(gjx_shard_ctx* ctx, const float* local_lse, float* lse_
 typedef struct gjx_peer_ctx gjx_peer_ctx;
 int gjx_peer_ctx_create(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device,
                         gjx_peer_ctx** out);
+/* the same with the switches as an argument instead of the environment (a library user that must not touch the process environment;
+ * the self-check of the host layer, which always runs with the check words on) */
+enum { GJX_PEER_VERIFY_ON = 1, GJX_PEER_DATA_FINE = 2, GJX_PEER_VERIFY_FAULTY = 4 /* test hook: THIS rank publishes wrong check words */ };
+int gjx_peer_ctx_create_ex(int32_t n_ranks, int32_t rank, int64_t K_local, int32_t rows, int32_t ranks_on_this_device, int32_t flags,
+                           gjx_peer_ctx** out);
 int gjx_peer_ctx_export(gjx_peer_ctx* ctx, uint8_t* out128);
 int gjx_peer_ctx_connect(gjx_peer_ctx* ctx, const uint8_t* handles);
 int gjx_peer_ctx_buffers(gjx_peer_ctx* ctx, uint64_t* out6);
