@@ -58,6 +58,7 @@ def cpu_baseline_gmm(prog, K, budget_s=12.0):
     """the same step (propagate + reweight + LSE, prefix sum, systematic ancestors, gather) through the C oracle: on all
     host cores (every stage OpenMP-parallel) and on ONE thread"""
     from oracle import cpu
+    flags = cpu.use_fast_build()                # the timed baseline runs the oracle compiled -O3 -march=native on this host (SURVEY.md §8(d))
 
     def run(budget):
         t0 = time.perf_counter()
@@ -82,7 +83,8 @@ def cpu_baseline_gmm(prog, K, budget_s=12.0):
     cpu.gather_rows(o["choices"], cpu.resample_systematic(cum, 0.5, K1))
     dt1 = time.perf_counter() - t0
     cpu.set_threads(threads)
-    return dict(value=K * reps / dt, unit="particle-steps/s", cores=threads, kind="port",
+    cpu.use_checker_build()
+    return dict(value=K * reps / dt, unit="particle-steps/s", cores=threads, kind="port", build=flags,
                 sample=f"{reps} steps of K=2^{int(math.log2(K))} particles of the same workload on {threads} OpenMP threads "
                        f"(all stages parallel; {usable_cpus()} usable CPUs: affinity mask capped by the cgroup quota)",
                 single_thread=dict(value=K1 / dt1, unit="particle-steps/s", cores=1, sample=f"1 step of K=2^{int(math.log2(K1))}"))
@@ -118,6 +120,7 @@ def baseline_threads(cpu) -> int:
 def cpu_baseline_ssm(s, K, T, budget_s=12.0):
     from genjax_amd import core
     from oracle import cpu
+    flags = cpu.use_fast_build()
     threads = baseline_threads(cpu)
     t0 = time.perf_counter()
     key = core.key(1)
@@ -135,12 +138,14 @@ def cpu_baseline_ssm(s, K, T, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return dict(value=K * steps / dt, unit="particle-steps/s", cores=threads, kind="port",
+    cpu.use_checker_build()
+    return dict(value=K * steps / dt, unit="particle-steps/s", cores=threads, kind="port", build=flags,
                 sample=f"first {steps} of {T} filter steps at K=2^{int(math.log2(K))} on {threads} OpenMP threads (all stages parallel)")
 
 
 def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
     from oracle import cpu
+    flags = cpu.use_fast_build()
     threads = baseline_threads(cpu)
     n = max(threads * 4, 256)
     ch = (np.random.default_rng(0).standard_normal((P + 1, n)) * 0.1).astype(np.float32)
@@ -153,7 +158,8 @@ def cpu_baseline_hmc(prog, P, L, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return dict(value=n * Lc * reps / dt, unit="chain-leapfrogs/s", cores=threads, kind="port",
+    cpu.use_checker_build()
+    return dict(value=n * Lc * reps / dt, unit="chain-leapfrogs/s", cores=threads, kind="port", build=flags,
                 sample=f"{reps} moves of {n} chains x {Lc} leapfrog steps on {threads} OpenMP threads")
 
 
@@ -651,9 +657,9 @@ def run_hmc_generated(dev):
     res["hier_logreg_N1024_P16_L100"] = dict(generated=g, hand_written=f)
     sl = H.shape_hierarchy()
     hp = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=("la", "lb"))
-    from oracle import cpu                      # (start states only: a draw from the prior through the CPU checker, outside any timing)
-    base = cpu.run_program(PackedProgram(sl), (3, 4), 4096)["choices"].astype(np.float32)
-    ch = torch.as_tensor(np.tile(base, (1, n // 4096)), device=dev)
+    # start states: a draw from the prior by the DEVICE's own simulate (the CPU checker is not touched outside cpu_baseline_*)
+    base = kernels.run_program(PackedProgram(sl), (3, 4), 4096)["choices"].float()
+    ch = base.repeat(1, n // 4096).contiguous()
     gi, ii = timed(hp, ch, 0.002, 200, "gen"), timed(hp, ch, 0.002, 200, "interp", reps=1)
     res["shape_hierarchy_L200"] = dict(generated=gi, interpreter=ii, speedup=ii["ms_per_move"] / gi["ms_per_move"])
     sp, ys = H.scan_chain(16, carry=True, observe=True, sigma=0.3, r=0.5)
@@ -740,6 +746,9 @@ def run_codegen(dev):
                 os.environ["GJX_ENGINE"] = old
         b = (4 * prog.n_slots + 8) * K
         return dict(engine=eng, kernel_us=us, algorithmic_bytes=b, frac=(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us else None,
+                    roofline=(dict(bound="hbm", algorithmic_bytes_per_launch=b, kernel_us=us, achieved=b / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS,
+                                   unit="GB/s", frac=b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, timing="HIP events attached to the dispatch, median of 5")
+                              if us else None),
                     log_ml=float(out["lse"][3]))
 
     res = {}
@@ -1100,7 +1109,10 @@ def run_round4(dev):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 * 1e3
             row[engine] = dict(engine=o["_engine"], kernel_us=us, particle_instances_per_sec=Kp * N / (us * 1e-6), bytes=4.0 * N * Kp,
-                               achieved_GBs=4.0 * N * Kp / (us * 1e-6) / 1e9)
+                               achieved_GBs=4.0 * N * Kp / (us * 1e-6) / 1e9,
+                               roofline=dict(bound="hbm", algorithmic_bytes_per_launch=4.0 * N * Kp, kernel_us=us, achieved=4.0 * N * Kp / (us * 1e-6) / 1e9,
+                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=4.0 * N * Kp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             timing="event pair around 5 back-to-back launches"))
         finally:
             if old is None:
                 os.environ.pop("GJX_ENGINE", None)

@@ -26,41 +26,76 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_checker_lib = None
+FAST_FLAGS = ["-O3", "-march=native", "-fPIC", "-std=c11", "-fopenmp", "-fno-math-errno"]
+build_flags = "-O2 -ffp-contract=off (the checker build, oracle/Makefile)"
+
+
+def use_fast_build() -> str:
+    """bench.py's cpu_baseline leg ONLY: time the oracle compiled for speed on THIS host (-O3 -march=native: SURVEY.md §8(d)) instead
+    of the checker build (-O2 -ffp-contract=off, which the parity tests use).  Compiled into a temporary directory at run time — a
+    -march=native object built elsewhere could not be trusted to run here.  Falls back to the checker build if no compiler is
+    there.  -> the flags of the build now in use"""
+    global _lib, _checker_lib, build_flags
+    import tempfile
+    if _checker_lib is None:
+        _checker_lib = lib()
+    src = os.path.join(_HERE, "gjx_oracle.c")
+    out = os.path.join(tempfile.mkdtemp(prefix="gjx_oracle_fast_"), "libgjx_oracle_fast.so")
+    try:
+        subprocess.check_call([os.environ.get("CC", "gcc")] + FAST_FLAGS + ["-I", os.path.join(_HERE, "..", "include"), "-shared", "-o", out, src, "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = _bind(C.CDLL(out))
+        build_flags = " ".join(FAST_FLAGS) + " (compiled on this host for the timed baseline)"
+    except Exception:
+        _lib = _checker_lib
+        build_flags = "-O2 -ffp-contract=off (the checker build: the fast build could not be compiled here)"
+    return build_flags
+
+
+def use_checker_build() -> None:
+    global _lib, build_flags
+    if _checker_lib is not None:
+        _lib = _checker_lib
+        build_flags = "-O2 -ffp-contract=off (the checker build, oracle/Makefile)"
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_SO)
-        vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
-        L.gjxo_threefry2x32.argtypes = [u32, u32, u32, u32, vp]
-        L.gjxo_run_program.argtypes = [A.PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64]
-        L.gjxo_logsumexp.argtypes = [vp, i64, i64, vp]
-        L.gjxo_categorical_pick.argtypes = [vp, i64, i64, vp, u32, u32, i32, vp, vp]
-        L.gjxo_weight_cumsum.argtypes = [vp, i64, i32, vp, vp, vp]
-        L.gjxo_resample_systematic.argtypes = [vp, i64, u64, u64, f64, i64, i64, i64, vp]
-        L.gjxo_resample_multinomial.argtypes = [vp, i64, u64, u64, u32, u32, i64, i64, i64, vp]
-        L.gjxo_resample_systematic_tiled.argtypes = [vp, i64, f64, i64, vp, vp, vp, vp]
-        L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
-        L.gjxo_ssm_step.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp,
-                                    i64, vp, vp, vp, vp, vp, i64]
-        L.gjxo_ssm_step_move.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32,
-                                         vp, vp, vp, vp, vp, i64]
-        L.gjxo_score_grad.argtypes = [A.PP, i64, vp, vp, vp]
-        L.gjxo_hmc.argtypes = [A.PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp]
-        for n in ("gjxo_erfinv",):
-            getattr(L, n).argtypes = [f32]
-            getattr(L, n).restype = f32
-        for n in ("gjxo_normal_from_bits", "gjxo_gumbel_from_bits", "gjxo_unit_from_bits"):
-            getattr(L, n).argtypes = [u32]
-            getattr(L, n).restype = f32
-        L.gjxo_set_margin_buffer.argtypes = [vp, i64]
-        L.gjxo_set_momenta_buffer.argtypes = [vp, i64]
-        L.gjxo_num_threads.restype = C.c_int
-        L.gjxo_set_num_threads.argtypes = [C.c_int]
-        _lib = L
+        _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def _bind(L):
+    vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
+    L.gjxo_threefry2x32.argtypes = [u32, u32, u32, u32, vp]
+    L.gjxo_run_program.argtypes = [A.PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64]
+    L.gjxo_logsumexp.argtypes = [vp, i64, i64, vp]
+    L.gjxo_categorical_pick.argtypes = [vp, i64, i64, vp, u32, u32, i32, vp, vp]
+    L.gjxo_weight_cumsum.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.gjxo_resample_systematic.argtypes = [vp, i64, u64, u64, f64, i64, i64, i64, vp]
+    L.gjxo_resample_multinomial.argtypes = [vp, i64, u64, u64, u32, u32, i64, i64, i64, vp]
+    L.gjxo_resample_systematic_tiled.argtypes = [vp, i64, f64, i64, vp, vp, vp, vp]
+    L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
+    L.gjxo_ssm_step.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp,
+                                i64, vp, vp, vp, vp, vp, i64]
+    L.gjxo_ssm_step_move.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, f32,
+                                     vp, vp, vp, vp, vp, i64]
+    L.gjxo_score_grad.argtypes = [A.PP, i64, vp, vp, vp]
+    L.gjxo_hmc.argtypes = [A.PP, u32, u32, i64, i64, f32, i32, i32, i32, vp, vp, vp, vp]
+    for n in ("gjxo_erfinv",):
+        getattr(L, n).argtypes = [f32]
+        getattr(L, n).restype = f32
+    for n in ("gjxo_normal_from_bits", "gjxo_gumbel_from_bits", "gjxo_unit_from_bits"):
+        getattr(L, n).argtypes = [u32]
+        getattr(L, n).restype = f32
+    L.gjxo_set_margin_buffer.argtypes = [vp, i64]
+    L.gjxo_set_momenta_buffer.argtypes = [vp, i64]
+    L.gjxo_num_threads.restype = C.c_int
+    L.gjxo_set_num_threads.argtypes = [C.c_int]
+    return L
 
 
 def _p(a):
