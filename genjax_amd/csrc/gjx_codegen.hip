@@ -158,6 +158,10 @@ struct Plan {
   std::vector<int> hoist_at;
   int n_hoist = 0;
   bool pf = false;
+  // plate flavour "wide" (ppt code | 512): a block is 16 waves that ALL hold the same 64 x PPT particles; the instances of a plate
+  // are dealt to the waves in contiguous chunks and the waves' partial sums meet in LDS (fixed order: deterministic), so a program
+  // with few particles and many instances still fills the SIMDs.  Sites outside plates are computed by every wave, stored by wave 0
+  bool wide = false;
   int find(int kind, int off, int n, int len = 0, int dim = 0) {
     for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n && c.len == len && c.dim == dim) return c.at;
     Companion c{kind, off, n, comp_floats, len, dim};
@@ -644,7 +648,7 @@ void emit_mfma_site(Emit& o, Plan& pl, int j) {
   o.f("      float tot_ = 0.0f;\n      _Pragma(\"unroll\") for (int g_ = 0; g_ < 4; ++g_) {\n        float t_ = part_[g_];\n"
       "        t_ += __shfl_xor(t_, 16, 64);\n        t_ += __shfl_xor(t_, 32, 64);\n        if (q_ == g_) tot_ = t_;\n      }\n      lp[0] = tot_%s;\n", bern ? " * kLn2" : "");
   o.f("      PLOOP { score[p] += lp[p]; weight[p] += lp[p]; }\n");
-  o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n", ri.score_row);
+  o.f("      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n", ri.score_row);
   o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
 }
 
@@ -663,8 +667,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
                s.obs_off + d, ri.row + d);
     }
     o.f("      if (a.in_rows && a.store_inputs) {\n");
-    for (int d = 0; d < s.dim; ++d) o.f("        VSTORE(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
-    o.f("      }\n      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
+    for (int d = 0; d < s.dim; ++d) o.f("        VSTORE1(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
+    o.f("      }\n      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
     return;
   }
   if (pl.mfma && mfma_site_ok(s, ri)) { emit_mfma_site(o, pl, j); return; }
@@ -852,11 +856,12 @@ void emit_site(Emit& o, Plan& pl, int j) {
   if (pl.pf) { if (mode != GJX_MODE_SAMPLE) o.f("      PLOOP weight[p] += lp[p];\n"); }
   else o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
   if (ri.plate) o.f("      PLOOP pacc%d[p] += lp[p];\n", j);      // a plate's body site: the sum over its instances
-  else o.f("      if (a.site_scores) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
+  else o.f("      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
            toff(ri.score_row, ri.d_score_row).c_str());
   if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
-    for (int d = 0; d < nrow; ++d) o.f("      VSTORE(a.choices + (int64_t)%s * K + i0, v[%d]);\n", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
+    // (a plate's instance is stored by the wave that produced it; anything else by the block's first wave: VSTORE1)
+    for (int d = 0; d < nrow; ++d) o.f("      %s(a.choices + (int64_t)%s * K + i0, v[%d]);\n", ri.plate ? "VSTORE" : "VSTORE1", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
   }
   if (pl.pf) o.f("      PLOOP asm volatile(\"\" : \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
   else o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
@@ -890,6 +895,7 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
   pl.prog = prog;
   pl.ppt = ppt;
   pl.mfma = mfma;
+  pl.wide = (ppt_code & 512) != 0 && px.any && !mfma;
   pl.tab_lds = mfma || (prog->n_tab <= kMaxLdsTab && !getenv("GJX_GEN_TAB_GLOBAL"));   // (the variable: profiling variant, part of the cache key)
   if (roll.ok) {
     pl.info = roll.info;
@@ -977,10 +983,24 @@ std::string emit_body(GenCtx& g) {
       }
       // JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J); instance key = split(plate key, n)[i]
       if (!flat) body.f("    key2 pk_[PPT];\n    PLOOP pk_[p] = fold_in(fold_in64(a.key, gidx[p]), %uu);\n", pl.stream[j].site_no);
+      if (pl.wide) {
+        // the instances in 16 contiguous chunks, one per wave of the block (consecutive instances share hash blocks of the FLAT
+        // streams); the plate's contribution to score / weight is summed apart and joined across the waves below
+        body.f("    const int pc_ = (%d + 15) / 16, plo_ = pw_ * pc_, phi_ = plo_ + pc_ < %d ? plo_ + pc_ : %d;\n"
+               "    float psc_[PPT], pwt_[PPT];\n    PLOOP { psc_[p] = score[p]; pwt_[p] = weight[p]; score[p] = 0.0f; weight[p] = 0.0f; }\n"
+               "    _Pragma(\"nounroll\") for (int i_ = plo_; i_ < phi_; ++i_) {\n", pl.info[j].plate_n, pl.info[j].plate_n, pl.info[j].plate_n);
+      } else
       body.f("    _Pragma(\"nounroll\") for (int i_ = 0; i_ < %d; ++i_) {\n", pl.info[j].plate_n);
       if (!flat) body.f("    key2 ik_[PPT];\n    PLOOP ik_[p] = fold_in(pk_[p], (uint32_t)i_);\n");
       for (int l = 0; l < m; ++l) emit_site(body, pl, j + l);
-      body.f("    }\n    if (a.site_scores) {\n");
+      body.f("    }\n");
+      if (pl.wide) {
+        // join: every wave leaves its partial in LDS, every lane adds the 16 partials of its particles in wave order
+        body.f("    PRED_(score, psc_);\n    PRED_(weight, pwt_);\n    if (a.site_scores) {\n      float pz_[PPT];\n      PLOOP pz_[p] = 0.0f;\n");
+        for (int l = 0; l < m; ++l) body.f("      PRED_(pacc%d, pz_);\n", j + l);
+        body.f("    }\n");
+      }
+      body.f("    if (a.site_scores && OWN_) {\n");
       for (int l = 0; l < m; ++l) body.f("      VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, pacc%d);\n", j + l, j + l);
       body.f("    }\n    }\n");
       j += m;
@@ -1027,10 +1047,17 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   Plan& pl = g.pl;
   const gjx_program* prog = pl.prog;
   const bool mfma = pl.mfma;
+  const bool wide = pl.wide;
+  const int BT = wide ? 1024 : 256;
   const std::string body_s = emit_body(g);
   Emit o;
   o.f("#include \"gjx_device.h\"\n#include \"gjx_tile.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
+  if (wide)
+    o.f("#define OWN_ (threadIdx.x < 64u)\n"
+        "#define PRED_(acc_, base_) do { __syncthreads(); PLOOP pred_[(pw_ * 64 + pl_) * PPT + p] = acc_[p]; __syncthreads(); \\\n"
+        "    PLOOP { float t_ = 0.0f; _Pragma(\"unroll\") for (int w_ = 0; w_ < 16; ++w_) t_ += pred_[(w_ * 64 + pl_) * PPT + p]; acc_[p] = base_[p] + t_; } } while (0)\n");
+  else o.f("#define OWN_ true\n");
   o.f("#define NTAB %d\n#define NCOMP %d\n", prog->n_tab, pl.comp_floats);
   if (pl.tab_lds) o.f("#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n");
   else o.f("#define TAB(i) a.tab[i]\n#define COMP(i) tab_s[i]\n");
@@ -1043,6 +1070,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   o.f("template <int N> GJX_DEV void vec_store_live(float* q, const float (&x)[N]) { _Pragma(\"unroll\") for (int k = 0; k < N; ++k) store_agent(q + k, x[k]); }\n"
       "template <> GJX_DEV void vec_store_live<4>(float* q, const float (&x)[4]) { store_agent_x4(q, x); }\n"
       "#define VSTORE(q, x) do { if (live_) vec_store_live<PPT>(q, x); else VecStore<PPT>::st(q, x); } while (0)\n"
+      "#define VSTORE1(q, x) do { if (OWN_) VSTORE(q, x); } while (0)\n"
       "#define LDIN(q) (live_ ? load_agent(q) : *(q))\n"
       "#define TSTAMP(n) do { if (live_ && a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)\n");
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
@@ -1054,19 +1082,20 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   else
   o.f("template <bool LIVE_>\nstatic __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
+  if (wide) o.f("  __shared__ float pred_[1024 * PPT];   // the waves' partial sums of a plate\n  const int pw_ = (int)(threadIdx.x >> 6), pl_ = (int)(threadIdx.x & 63u);\n");
   o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n  TSTAMP(0);\n");
-  if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += 256) tab_s[t] = a.tab[t];\n  __syncthreads();\n");
-  o.f("#define TSRC(i) TAB(i)\n#define BT_ 256\n");
+  if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += %d) tab_s[t] = a.tab[t];\n  __syncthreads();\n", BT);
+  o.f("#define TSRC(i) TAB(i)\n#define BT_ %d\n", BT);
   emit_companions(o, pl);
   o.f("#undef TSRC\n#undef BT_\n");
   if (!pl.comps.empty()) o.f("  __syncthreads();\n");
   o.f("  TSTAMP(1);\n%s", pl.key_decls.c_str());
-  o.f("  const int64_t K = a.K;\n  const int64_t tile = 256 * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
+  o.f("  const int64_t K = a.K;\n  const int64_t tile = %d * (int64_t)PPT;\n  const int64_t ntiles = (K + tile - 1) / tile;\n"
       "  float tmax = -INFINITY, tsum = 0.0f;\n"
       "  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {\n"
-      "    const int64_t i0 = tix * tile + (int64_t)threadIdx.x * PPT;\n    if (i0 >= K) break;   // K %% PPT == 0 (launcher)\n"
+      "    const int64_t i0 = tix * tile + (int64_t)%s * PPT;\n    if (i0 >= K) break;   // K %% PPT == 0 (launcher)\n"
       "    uint64_t gidx[PPT];\n    PLOOP gidx[p] = (uint64_t)(a.offset + i0 + p);\n"
-      "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n");
+      "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n", wide ? 64 : 256, wide ? "pl_" : "threadIdx.x");
   o.f("    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
   {
     bool has_input = false;
@@ -1099,8 +1128,9 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
     if (pre[r]) o.f("    PLOOP v[%d][p] = a.choices[(int64_t)%d * K + i0 + p];\n", r, r);
   o.s += body_s;
   o.f("    TSTAMP(3);\n    float lw[PPT];\n    PLOOP { float l = weight[p]; if (a.logw_in) l += a.logw_in[i0 + p]; if (a.sub) l -= a.sub[i0 + p]; lw[p] = l; }\n"
-      "    if (a.score) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight) VecStore<PPT>::st(a.weight + i0, weight);\n"
-      "    if (a.logw) VSTORE(a.logw + i0, lw);\n"
+      "    if (a.score && OWN_) VecStore<PPT>::st(a.score + i0, score);\n    if (a.weight && OWN_) VecStore<PPT>::st(a.weight + i0, weight);\n"
+      "    if (a.logw) VSTORE1(a.logw + i0, lw);\n"
+      "    if (!OWN_) { PLOOP lw[p] = -INFINITY; }   // (wide flavour: the other waves hold copies — one contribution per particle to the LSE)\n"
       "    float m4 = tmax;\n    PLOOP m4 = fmaxf(m4, lw[p]);\n"
       "    if (m4 > -INFINITY) { float s4 = tsum * fast_exp(tmax - m4); PLOOP s4 += fast_exp(lw[p] - m4); tsum = s4; }\n    tmax = m4;\n");
   // {e_b, S_b} of this block-tile under GJX_WEIGHTS_TILE_SCALED (include/gjx.h) when it IS a quantisation tile (PPT == 4,
@@ -1124,6 +1154,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "        }\n      } else {\n      __syncthreads();\n"
       "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
       "      }\n    }\n  }\n");
+  if (wide) o.f("  if (pw_ >= 4) return;   // (the block's LSE pair is made by 256 threads; waves 1 .. 3 contribute nothing, the rest leave)\n");
   o.f("  if (a.partials && !live_) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
       "    const float wm = wave_max(tmax);\n    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);\n"
       "    if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }\n    __syncthreads();\n"
@@ -1131,11 +1162,11 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
       "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
-  o.f("extern \"C\" __global__ __launch_bounds__(256%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", mfma ? ", 2" : "");
+  o.f("extern \"C\" __global__ __launch_bounds__(%d%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", BT, mfma ? ", 2" : "");
   {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
-    if (has_input && ppt == 4 && !mfma)
+    if (has_input && ppt == 4 && !mfma && !wide)
       // every step t = T0 .. T-1 of a filter in ONE launch: the step programs share this structure and differ in their tables, keys and
       // comb offsets; a step's kernel boundary is replaced by the granules its blocks publish (co-resident grid: the launcher checks)
       o.f("extern \"C\" __global__ __launch_bounds__(256) void gjx_gen_steps(GenStepsArgs s) {\n"
@@ -1158,7 +1189,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
           "    gjx_step_<true>(a);\n  }\n}\n");
   }
   // LDS bytes the kernel needs, as a trailing comment the host parses back (keeps one source of truth)
-  o.f("// LDS_FLOATS %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats);
+  o.f("// LDS_FLOATS %d\n// BT %d\n", mfma ? 0 : (pl.tab_lds ? prog->n_tab : 0) + pl.comp_floats, BT);
   return o.s;
 }
 
@@ -1228,6 +1259,7 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       "template <> struct VecStore<1> { static GJX_DEV void st(float* q, const float (&x)[1]) { *q = x[0]; } };\n"
       "typedef float v4f_ __attribute__((ext_vector_type(4)));\n"
       "#define VSTORE(q, x) do { if (act_) store_scoped((q), (x)[0], sys_); } while (0)\n"
+      "#define VSTORE1(q, x) VSTORE(q, x)\n#define OWN_ true\n"
       "#define LDIN(q) load_scoped((q), sys_)\n");
   o.f("struct GenPfModel {\n  const GenPfArgs& f;\n  float* const tab_s;\n"
       "  struct Draws { float nz[NHOIST > 0 ? NHOIST : 1]; };\n"
@@ -1946,6 +1978,20 @@ int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {
   if (prefer4 && slots <= 40) ppt = 4;     // a block-tile of 1024 particles = one quantisation tile (tile totals, GJX_RUN_LEAVE_TILES)
   // a big affine site goes to the matrix cores: one particle per lane, whole waves (code = ppt | 256: see generate())
   if (K % 256 == 0 && !getenv("GJX_GEN_PPT") && has_mfma_site(prog)) return 1 | 256;
+  // a long plate: the instances dealt to the 16 waves of a block (code = ppt | 512), unless the particles alone fill the machine
+  // many times over (then the plain form's single pass per particle has less overhead); GJX_GEN_WIDE = 0 / 1 forces the choice
+  {
+    int longest = 0;
+    for (int j = 0; j < prog->n_sites; ++j) if (prog->sites[j].plate && prog->sites[j].plate_n > longest) longest = prog->sites[j].plate_n;
+    const char* e = getenv("GJX_GEN_WIDE");
+    const bool want = e ? atoi(e) != 0 : (longest >= 64 && K <= (1 << 21));
+    if (want && longest >= 16 && !prefer4) {
+      int wp = slots <= 4 ? 2 : 1;
+      if (const char* pe = getenv("GJX_GEN_PPT")) { const int q = atoi(pe); if (q == 1 || q == 2) wp = q; }
+      while (wp > 1 && K % wp != 0) wp >>= 1;
+      return wp | 512;
+    }
+  }
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
   if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;
   while (ppt > 1 && K % ppt != 0) ppt >>= 1;
@@ -1964,11 +2010,13 @@ int gen_available(const gjx_program* prog, int ppt) {
 int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   hipFunction_t fn = nullptr;
   int lds_floats = 0;
+  unsigned block = 256;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     const Compiled& c = compile(prog, ppt);
     if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
     lds_floats = c.lds_floats;
+    block = (unsigned)c.block;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
     const auto lk = std::make_pair(structure_key(prog, ppt), dev);
@@ -1988,8 +2036,8 @@ int gen_launch(const gjx_program* prog, int ppt, const GenArgs& args, int grid, 
   size_t sz = sizeof(a);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   hipError_t e;
-  if (ev0 && ev1) e = hipExtModuleLaunchKernel(fn, (uint32_t)grid * 256u, 1, 1, 256, 1, 1, (size_t)lds_floats * 4, st, nullptr, config, ev0, ev1, 0);
-  else e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
+  if (ev0 && ev1) e = hipExtModuleLaunchKernel(fn, (uint32_t)grid * block, 1, 1, block, 1, 1, (size_t)lds_floats * 4, st, nullptr, config, ev0, ev1, 0);
+  else e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, block, 1, 1, (unsigned)(lds_floats * 4), st, nullptr, config);
   if (e != hipSuccess) return gjx_fail_hip(e, "codegen: launch");
   return GJX_OK;
 }
@@ -2189,7 +2237,7 @@ extern "C" int gjx_program_hmc_precompile(const gjx_program* prog) {
 extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   if (!supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the emitter's coverage");
-  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256)) ppt = gjx::gen_pick_ppt(prog, 4);
+  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256) && ppt != (1 | 512) && ppt != (2 | 512)) ppt = gjx::gen_pick_ppt(prog, 4);
   const std::string src = generate(prog, ppt);
   if (out && cap > 0) {
     const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
@@ -2203,7 +2251,8 @@ extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char
 // cache with this on machines without a GPU (hipRTC cross-compiles)
 extern "C" int gjx_program_precompile(const gjx_program* prog, int32_t ppt) {
   if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: null program");
-  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256)) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4 or 257 (1 | 256: big affine sites on the matrix cores)");
+  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256) && ppt != (1 | 512) && ppt != (2 | 512))
+    return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4, 257 (1 | 256: big affine sites on the matrix cores) or 513 / 514 (| 512: the instances of a plate dealt to the 16 waves of a block)");
   return gjx::gen_available(prog, ppt);
 }
 

@@ -1206,13 +1206,16 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
     if (env_int("GJX_NO_CODEGEN", 0)) return false;
     const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);     // (ppt | 256: the matrix-core flavour, gjx_codegen.hip)
     if (gen_available(prog, ppt) != GJX_OK) return false;
-    const int64_t tile = 256 * (int64_t)(ppt & 255), ntiles = (K + tile - 1) / tile;
+    // (ppt | 512: a block of 16 waves shares 64 x ppt particles — the instances of its plates are dealt to the waves)
+    const int64_t tile = ((ppt & 512) ? 64 : 256) * (int64_t)(ppt & 255), ntiles = (K + tile - 1) / tile;
     // the per-block prologue (table copy + derived constants) is paid once per block: no more blocks than can be resident
     // at 4 per CU, each looping over its tiles
     static const int resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * (cus > 0 ? cus : 256); }();
     // (the matrix-core flavour: one block per tile — two 70 KB blocks fit a CU, and 4096 short blocks fill the tail better than
     // 1024 blocks of four tiles: 520 vs 545 us on the config-5 target)
-    const int maxgrid = env_int("GJX_GEN_GRID", (ppt & 256) ? (1 << 20) : resident);
+    int maxgrid = env_int("GJX_GEN_GRID", (ppt & 256) ? (1 << 20) : ((ppt & 512) ? 2 * resident : resident));
+    // (a workspace has room for one {max, sumexp} pair per 256 particles: no more blocks than that, whatever a block's tile is)
+    if ((ppt & 512) && maxgrid > (int)((K + 255) / 256)) maxgrid = (int)((K + 255) / 256);
     e.engine = ENGINE_GEN; e.ppt = ppt; e.grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
     return true;
   };

@@ -330,9 +330,11 @@ def test_filter_kernel_of_a_step_program_is_emitted_and_cross_compiles():
     bf = ScanBootstrapFilter(step.scan(n=T), 4096)
     progs = bf.step_programs(C["y"].set(rs.standard_normal((T, dx)).astype(np.float32)), (np.zeros(dx, np.float32), None))
     src = kernels.program_filter_source(progs[1], 2)
-    assert "pf_core<GenPfModel, SPL>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src
+    assert "pf_core<GenPfModel, SPL, 0, 0>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src      # one rank: agent scope, no verify mode
+    assert "pf_core<GenPfModel, SPL, 2, 2>" in kernels.program_filter_source(progs[1], 2 | 256)                     # sharded flavour: decided at run time
     assert "d.nz[3] = stream_normal<RNG>(bs" in src and "const float n_ = dr_->nz[0 + (0)];" in src
     assert "LDIN(a.in_rows + (int64_t)3 * a.in_stride + src_[p])" in src and "tab_s[e] = tb_[e]" in src
+    assert "score[p] +=" not in src and "q2[p]" in src           # weights only: the sampled site's log-density is not evaluated (the observed one's is)
     assert src.count("stream_normal<RNG>(") == dx                  # the site itself draws nothing any more
     with pytest.raises(Exception):
         kernels.program_filter_source(progs[0], 1)                 # step 0 reads no carry: not a filter step
@@ -354,3 +356,20 @@ def test_filter_kernel_of_a_step_program_is_emitted_and_cross_compiles():
     src2 = kernels.program_filter_source(p2[1], 1)
     assert "#define NHOIST 0" in src2 and "gjx_gen_pf" in src2
     kernels.program_filter_precompile(p2[1], 1)
+
+
+def test_wide_plate_kernel_deals_the_instances_to_the_waves_of_a_block():
+    """the 2-D form of a plate program (gjx_program_precompile ppt | 512; reference: Vmap.generate sums the instances' weights,
+    vmap.py:180-218): a block of 16 waves shares 64 x PPT particles, every wave runs a contiguous chunk of the instances, partial
+    sums meet in LDS in wave order.  On the CPU: the emitted source and its hipRTC compilation"""
+    from genjax_amd import kernels
+    model, chm, ys, mu, logits = _mixture(600)
+    prog, _, _ = model.pack((), chm, True)
+    src = kernels.program_source(prog, 2 | 512)
+    assert "__launch_bounds__(1024)" in src and "#define OWN_ (threadIdx.x < 64u)" in src
+    assert "for (int i_ = plo_; i_ < phi_; ++i_)" in src and "PRED_(score, psc_);" in src and "PRED_(weight, pwt_);" in src
+    assert "const int64_t tile = 64 * (int64_t)PPT;" in src and "if (pw_ >= 4) return;" in src
+    plain = kernels.program_source(prog, 2)
+    assert "__launch_bounds__(256)" in plain and "for (int i_ = 0; i_ < 600; ++i_)" in plain and "PRED_(" not in plain
+    kernels.program_precompile(prog, 2 | 512)
+    kernels.program_precompile(prog, 1 | 512)
