@@ -1077,49 +1077,61 @@ def run_round4(dev):
     res["scan_filter_stochastic_volatility_T256_K2e18"] = dict(us_per_step=dts / len(ysv) * 1e6, log_ml=lsv, float64_filter_mean=fx["log_ml_mean"],
                                                                form=sinfo.get("form_name"), launches_per_run=sinfo.get("launches"),
                                                                float64_filter_std=fx["log_ml_std"], z=(lsv - fx["log_ml_mean"]) / fx["log_ml_std"])
-    # (2) the vmapped mixture
-    N, Kp = 4096, 1 << 17
-    rs = np.random.default_rng(0)
+    # (2) the vmapped mixture: many instances x moderately many particles, and the few-particles / very-many-instances corner
     mu = np.array([-2.0, 0.5, 3.0], np.float32)
-    yv = (mu[rs.integers(0, 3, N)] + 0.7 * rs.standard_normal(N)).astype(np.float32)
 
-    @genjax.gen
-    def mk(lg):
-        z = genjax.categorical(logits=lg) @ "z"
-        return genjax.normal(genjax.take(mu, z), 0.7) @ "x"
+    def plate_row(N, Kp, engines):
+        rs = np.random.default_rng(0)
+        yv = (mu[rs.integers(0, 3, N)] + 0.7 * rs.standard_normal(N)).astype(np.float32)
 
-    @genjax.gen
-    def mix():
-        mk.repeat(n=N)(np.array([0.2, -0.3, 0.1], np.float32)) @ "k"
+        @genjax.gen
+        def mk(lg):
+            z = genjax.categorical(logits=lg) @ "z"
+            return genjax.normal(genjax.take(mu, z), 0.7) @ "x"
 
-    prog, _, _ = mix.pack((), CM["k", "x"].set(yv), True)
-    row = dict(device_sites=prog.n_sites, logical_sites=len(prog.site_list.sites), K=Kp, N=N)
-    for engine in ("gen", "interp"):
-        old = os.environ.get("GJX_ENGINE")
-        os.environ["GJX_ENGINE"] = engine
-        try:
-            ws = kernels.workspace(A.OP_RUN, Kp, dev)
-            o = kernels.run_program(prog, (0, 1), Kp, ws=ws, want_weight=False)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(5):
-                kernels.run_program(prog, (0, 2 + i), Kp, ws=ws, out=o, want_weight=False)
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / 5 * 1e3
-            row[engine] = dict(engine=o["_engine"], kernel_us=us, particle_instances_per_sec=Kp * N / (us * 1e-6), bytes=4.0 * N * Kp,
-                               achieved_GBs=4.0 * N * Kp / (us * 1e-6) / 1e9,
-                               roofline=dict(bound="hbm", algorithmic_bytes_per_launch=4.0 * N * Kp, kernel_us=us, achieved=4.0 * N * Kp / (us * 1e-6) / 1e9,
-                                             peak=HBM_PEAK_GBS, unit="GB/s", frac=4.0 * N * Kp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                             timing="event pair around 5 back-to-back launches"))
-        finally:
-            if old is None:
-                os.environ.pop("GJX_ENGINE", None)
-            else:
-                os.environ["GJX_ENGINE"] = old
+        @genjax.gen
+        def mix():
+            mk.repeat(n=N)(np.array([0.2, -0.3, 0.1], np.float32)) @ "k"
+
+        prog, _, _ = mix.pack((), CM["k", "x"].set(yv), True)
+        row = dict(device_sites=prog.n_sites, logical_sites=len(prog.site_list.sites), K=Kp, N=N)
+        for name, env in engines:
+            old = {k: os.environ.get(k) for k in ("GJX_ENGINE", "GJX_GEN_WIDE")}
+            os.environ.update(env)
+            try:
+                ws = kernels.workspace(A.OP_RUN, Kp, dev)
+                o = kernels.run_program(prog, (0, 1), Kp, ws=ws, want_weight=False)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(5):
+                    kernels.run_program(prog, (0, 2 + i), Kp, ws=ws, out=o, want_weight=False)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / 5 * 1e3
+                row[name] = dict(engine=o["_engine"], kernel_us=us, particle_instances_per_sec=Kp * N / (us * 1e-6), bytes=4.0 * N * Kp,
+                                 achieved_GBs=4.0 * N * Kp / (us * 1e-6) / 1e9,
+                                 roofline=dict(bound="hbm", algorithmic_bytes_per_launch=4.0 * N * Kp, kernel_us=us, achieved=4.0 * N * Kp / (us * 1e-6) / 1e9,
+                                               peak=HBM_PEAK_GBS, unit="GB/s", frac=4.0 * N * Kp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                               timing="event pair around 5 back-to-back launches"))
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return row
+
+    engines = (("gen", dict(GJX_ENGINE="gen")),                                  # the library's own choice: the wide form here
+               ("gen_one_lane_per_particle", dict(GJX_ENGINE="gen", GJX_GEN_WIDE="0")),   # round 4's form: a lane walks all instances
+               ("interp", dict(GJX_ENGINE="interp")))
+    row = plate_row(4096, 1 << 17, engines)
     row["generated_vs_interpreter"] = row["interp"]["kernel_us"] / row["gen"]["kernel_us"]
+    row["wide_vs_one_lane_per_particle"] = row["gen_one_lane_per_particle"]["kernel_us"] / row["gen"]["kernel_us"]
+    row["form"] = ("gjx_gen, ppt | 512: a block of 16 waves shares 64 x PPT particles, the instances of the plate are dealt to the waves in "
+                   "contiguous chunks, partial sums joined in LDS in wave order")
     res["vmapped_mixture_plate"] = row
+    res["vmapped_mixture_plate_K2e12_N2e16"] = plate_row(65536, 1 << 12, engines[:2])
     return res
 
 

@@ -1362,6 +1362,12 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
 constexpr int kHmcMaxSel = 48, kHmcMaxSlots = 96, kHmcMaxTab = 36864;   // 144 KB of LDS for the table
 
 struct HmcPlan {
+  // the EMITTED site list: the program's, or — with plates — plate_program's (every slot a register; a body site owns one instance's
+  // worth, its rows in choices[][] are RollInfo::row + i_ * d_row); n_regs = registers of the chain state
+  std::vector<gjx_site> sites;
+  std::vector<RollInfo> info;
+  int n_regs = 0;
+  bool plates = false;
   int nsel = 0;
   std::vector<int> sel_of_slot;    // slot -> index among the selected slots, or -1
   std::vector<int> slot_of_sel;
@@ -1421,14 +1427,34 @@ int hmc_mfma_param(const gjx_site& s) {
 bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIRICHLET; }
 
 bool hmc_plan(const gjx_program* p, HmcPlan* out) {
-  if (p->n_sites < 1 || p->n_sites > 64 || p->n_slots < 1 || p->n_slots > kHmcMaxSlots || p->n_tab > kHmcMaxTab) return false;
+  if (p->n_sites < 1 || p->n_sites > 64 || p->n_slots < 1 || p->n_tab > kHmcMaxTab) return false;
   HmcPlan pl;
-  pl.sel_of_slot.assign(p->n_slots, -1);
+  {
+    const PlateXf px = plate_program(p);
+    if (px.any) {
+      if (!px.ok) return false;
+      pl.sites = px.sites; pl.info = px.info; pl.n_regs = px.n_regs; pl.plates = true;
+    } else {
+      pl.sites.assign(p->sites, p->sites + p->n_sites);
+      for (int j = 0; j < p->n_sites; ++j) { RollInfo ri; ri.row = p->sites[j].slot; ri.score_row = j; pl.info.push_back(ri); }
+      pl.n_regs = p->n_slots;
+    }
+  }
+  if (pl.n_regs < 1 || pl.n_regs > kHmcMaxSlots) return false;
+  pl.sel_of_slot.assign(pl.n_regs, -1);
   int unrolled = 0;
   for (int j = 0; j < p->n_sites; ++j) {
-    const gjx_site& s = p->sites[j];
-    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET || s.plate != 0) return false;
+    const gjx_site& s = pl.sites[j];
+    const RollInfo& ri = pl.info[j];
+    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
     if (s.mode != GJX_MODE_OBS_TAB && s.mode != GJX_MODE_OBS_SLOT) return false;
+    for (int k = 0; k < 4; ++k) if (ri.mem_slot[k] >= 0) return false;     // (instances of another plate, one instance read from outside: the interpreter)
+    if (ri.plate) {
+      // a plate's body: scored and differentiated instance by instance inside the sweep; what HMC moves lives outside the plate
+      // (a selected per-instance latent would be plate_n x dim chain registers: the site interpreter keeps that state in memory)
+      if ((s.flags & GJX_SITE_HMC_SELECTED) || (!is_categorical(s.kind) && s.dim > kMaxExpandDim)) return false;
+      pl.looped = true;
+    }
     if (is_categorical(s.kind)) {
       if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
       if (s.ncat < 1 || s.ncat > 64 || (s.flags & GJX_SITE_HMC_SELECTED)) return false;
@@ -1455,10 +1481,10 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
   if (pl.looped && !getenv("GJX_HMC_GEN_NO_MFMA")) {
     const int tab_pad = (p->n_tab + 3) & ~3;
     for (int j = 0; j < p->n_sites; ++j) {
-      const gjx_site& s = p->sites[j];
-      const int k = hmc_mfma_param(s);
+      const gjx_site& s = pl.sites[j];
+      const int k = pl.info[j].plate ? -1 : hmc_mfma_param(s);
       if (k < 0) continue;
-      const bool fold = hmc_fold_ok(p, j, k);
+      const bool fold = !pl.plates && hmc_fold_ok(p, j, k);
       const int need = s.p[k].n * (s.dim + 4) + (fold ? s.dim : 0);
       if (tab_pad + pl.xt_floats + need > 40000) continue;           // 160 KB of LDS: table + transposed matrices (+ nothing else)
       pl.mf_k[j] = k;
@@ -1489,6 +1515,8 @@ struct HmcMf { int k; std::string pre, wout, x; };
 void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j, const std::string& dx, bool dyn, const char* acc,
                       const char* sc, const char* ind, const HmcMf* mf = nullptr) {
   const gjx_site& s = prog->sites[j];
+  const RollInfo& ri = hp.info[j];
+  g_loop_var = "i_";                       // (a plate's body site: table offsets advance with the instance)
   const int np = n_params(s.kind);
   o.f("%s{\n", ind);
   for (int k = 0; k < 4; ++k) {
@@ -1500,21 +1528,21 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
       continue;
     }
     switch (q.op) {
-      case GJX_P_CONST: o.f("%s  const float pre_%d = TAB(%d + %s);\n", ind, k, q.off, e.c_str()); break;
-      case GJX_P_GATHER: o.f("%s  const float pre_%d = TAB(%d + gi_%d_%d * %d + %s);\n", ind, k, q.off, j, k, q.len, e.c_str()); break;
+      case GJX_P_CONST: o.f("%s  const float pre_%d = TAB(%s + %s);\n", ind, k, toff(q.off, ri.d_off[k]).c_str(), e.c_str()); break;
+      case GJX_P_GATHER: o.f("%s  const float pre_%d = TAB(%s + gi_%d_%d * %d + %s);\n", ind, k, toff(q.off, ri.d_off[k]).c_str(), j, k, q.len, e.c_str()); break;
       case GJX_P_VALUE:
         if (q.len == 1) o.f("%s  const float pre_%d = v[%d];\n", ind, k, q.slot);
         else o.f("%s  const float pre_%d = v[%d + %s];\n", ind, k, q.slot, e.c_str());   // (unrolled sites only: literal index)
         break;
       default: {   // AFFINE: the row stays in registers for the gradient
         o.f("%s  float row_%d[%d];\n", ind, k, q.n);
-        if (q.moff % 4 == 0 && q.n % 4 == 0)
-          o.f("%s  { const float4* r4_ = (const float4*)&TAB(%d + (%s) * %d); _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) { const float4 t_ = r4_[e_]; "
+        if (q.moff % 4 == 0 && q.n % 4 == 0 && ri.d_moff[k] % 4 == 0)
+          o.f("%s  { const float4* r4_ = (const float4*)&TAB(%s + (%s) * %d); _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) { const float4 t_ = r4_[e_]; "
               "row_%d[4 * e_] = t_.x; row_%d[4 * e_ + 1] = t_.y; row_%d[4 * e_ + 2] = t_.z; row_%d[4 * e_ + 3] = t_.w; } }\n",
-              ind, q.moff, dx.c_str(), q.n, q.n / 4, k, k, k, k);
+              ind, toff(q.moff, ri.d_moff[k]).c_str(), dx.c_str(), q.n, q.n / 4, k, k, k, k);
         else
-          o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) row_%d[e_] = TAB(%d + (%s) * %d + e_);\n", ind, q.n, k, q.moff, dx.c_str(), q.n);
-        o.f("%s  float pre_%d = TAB(%d + %s);\n", ind, k, q.off, e.c_str());
+          o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) row_%d[e_] = TAB(%s + (%s) * %d + e_);\n", ind, q.n, k, toff(q.moff, ri.d_moff[k]).c_str(), dx.c_str(), q.n);
+        o.f("%s  float pre_%d = TAB(%s + %s);\n", ind, k, toff(q.off, ri.d_off[k]).c_str(), e.c_str());
         o.f("%s  _Pragma(\"unroll\") for (int e_ = 0; e_ < %d; ++e_) pre_%d = fmaf(row_%d[e_], v[%d + e_], pre_%d);\n", ind, q.n, k, k, q.slot, k);
       }
     }
@@ -1522,7 +1550,7 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
   }
   if (mf && !mf->x.empty()) o.f("%s  const float x_ = %s;\n", ind, mf->x.c_str());
   else if (s.slot >= 0) o.f("%s  const float x_ = v[%d + %s];\n", ind, s.slot, dx.c_str());
-  else o.f("%s  const float x_ = TAB(%d + %s);\n", ind, s.obs_off, dx.c_str());
+  else o.f("%s  const float x_ = TAB(%s + %s);\n", ind, toff(s.obs_off, ri.d_obs).c_str(), dx.c_str());
   o.f("%s  if (SC) %s += elem_logpdf(%d, x_, par_0, par_1, par_2, par_3);\n", ind, sc, s.kind);
   o.f("%s  float gx_, gp_[4];\n%s  dlogpdf(%d, x_, par_0, par_1, par_2, par_3, gx_, gp_);\n", ind, ind, s.kind);
   if (s.slot >= 0 && !dyn) {
@@ -1636,9 +1664,14 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
   o.f("    if (SC) sc_ += %sQSUM(scp_);\n", fold ? "-kLn2 * " : "");
 }
 
-std::string generate_hmc(const gjx_program* prog) {
+std::string generate_hmc(const gjx_program* prog_in) {
   HmcPlan hp;
-  if (!hmc_plan(prog, &hp)) return "";
+  if (!hmc_plan(prog_in, &hp)) return "";
+  // the emitted program: the plan's site list (plates: every slot a register, a body site owns one instance's worth)
+  gjx_program eprog = *prog_in;
+  eprog.sites = hp.sites.data();
+  eprog.n_slots = hp.n_regs;
+  const gjx_program* prog = &eprog;
   const int cpl = hp.looped ? 4 : 1;
   const int NS = prog->n_slots, NSEL = hp.nsel;
   Emit o;
@@ -1648,13 +1681,19 @@ std::string generate_hmc(const gjx_program* prog) {
   // the lanes of a chain: an aligned quad, or with a matrix-core site the four 16-lane rows of the wave (lane & 15 = chain)
   if (hp.mfma) o.f("GJX_DEV float QSUM(float x) { x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); return x; }\n");
   else o.f("#define QSUM(x) quad_sum(x)\n");
-  // ---- the sweep: score (SC) and gradient of the selected slots
-  o.f("template <bool SC>\nGJX_DEV float sweep(const float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_) {\n"
-      "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
-  for (int j = 0; j < prog->n_sites; ++j) {
+  // ---- the sweep: score (SC) and gradient of the selected slots.  ch_ / n_ / ic_: the chain's column of choices[][] — a plate's
+  //      body sites with per-chain values (OBS_SLOT) read their instance's rows from there, sweep after sweep
+  o.f("template <bool SC>\nGJX_DEV float sweep(float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_,\n"
+      "                  const float* __restrict__ ch_, const int64_t n_, const int64_t ic_) {\n"
+      "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s; (void)ch_; (void)n_; (void)ic_;\n"
+      "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
+  // one site: `acc` / `sc` name the gradient and score accumulators (a plate's body adds to per-lane partials)
+  auto emit_one = [&](int j, const char* acc, const char* sc) {
     const gjx_site& s = prog->sites[j];
+    const RollInfo& ri = hp.info[j];
+    g_loop_var = "i_";
     const int np = n_params(s.kind);
-    o.f("  { // ---- site %d: kind %d, dim %d, slot %d\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot);
+    o.f("  { // ---- site %d: kind %d, dim %d, slot %d%s\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot, ri.plate ? " (plate body)" : "");
     for (int k = 0; k < np; ++k) {
       const gjx_param& q = s.p[k];
       if (q.op == GJX_P_GATHER)
@@ -1663,18 +1702,18 @@ std::string generate_hmc(const gjx_program* prog) {
     if (is_categorical(s.kind)) {   // an integer site: scored, no gradient through it (hmc.py:49-65; k_hmc_generic)
       const gjx_param& q = s.p[0];
       const bool probs = s.kind == GJX_CATEGORICAL_PROBS;
-      std::string L = "TAB(" + std::to_string(q.off) + (q.op == GJX_P_GATHER ? " + gi_" + std::to_string(j) + "_0 * " + std::to_string(q.len) : "") +
+      std::string L = "TAB(" + toff(q.off, ri.d_off[0]) + (q.op == GJX_P_GATHER ? " + gi_" + std::to_string(j) + "_0 * " + std::to_string(q.len) : "") +
                       " + (c_) % " + std::to_string(q.len) + ")";
       L = xf_wrap(q.xf, L);
       if (probs) L = "safe_log(" + L + ")";
       o.f("    if (SC) {\n      float mx = -INFINITY;\n      for (int c_ = 0; c_ < %d; ++c_) mx = fmaxf(mx, %s);\n", s.ncat, L.c_str());
       o.f("      float se = 0.0f;\n      for (int c_ = 0; c_ < %d; ++c_) se += fast_exp(%s - mx);\n", s.ncat, L.c_str());
       if (s.slot >= 0) o.f("      const float val_ = v[%d];\n", s.slot);
-      else o.f("      const float val_ = TAB(%d);\n", s.obs_off);
-      o.f("      int k_ = (int)val_;\n      k_ = k_ < 0 ? 0 : (k_ > %d ? %d : k_);\n      { const int c_ = k_; sc_ += %s - (mx + fast_log(se)); }\n    }\n",
-          s.ncat - 1, s.ncat - 1, L.c_str());
+      else o.f("      const float val_ = TAB(%s);\n", toff(s.obs_off, ri.d_obs).c_str());
+      o.f("      int k_ = (int)val_;\n      k_ = k_ < 0 ? 0 : (k_ > %d ? %d : k_);\n      { const int c_ = k_; %s += %s - (mx + fast_log(se)); }\n    }\n",
+          s.ncat - 1, s.ncat - 1, sc, L.c_str());
     } else if (s.dim <= kMaxExpandDim) {
-      for (int d = 0; d < s.dim; ++d) hmc_emit_element(o, prog, hp, j, std::to_string(d), false, "g", "sc_", "    ");
+      for (int d = 0; d < s.dim; ++d) hmc_emit_element(o, prog, hp, j, std::to_string(d), false, acc, sc, "    ");
     } else if (hp.mf_k[j] >= 0) {
       hmc_emit_mfma_site(o, prog, hp, j);
     } else {
@@ -1694,6 +1733,26 @@ std::string generate_hmc(const gjx_program* prog) {
       o.f("    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n");
     }
     o.f("  }\n");
+  };
+  for (int j = 0; j < prog->n_sites;) {
+    if (!hp.info[j].plate) { emit_one(j, "g", "sc_"); ++j; continue; }
+    // ---- a plate (gjx.h "Plates"; the gradient of assess through a Vmap: hmc.py:70-96, vmap.py:363-376): the instances are dealt
+    //      round-robin to the CPL lanes of the chain; every instance adds its body's score and its gradient terms — into the rows of
+    //      the selected sites OUTSIDE the plate — to per-lane partials, joined across the chain's lanes behind the loop
+    int m = 1;
+    while (j + m < prog->n_sites && hp.info[j + m].plate && hp.info[j + m].plate_j0 == hp.info[j].plate_j0) ++m;
+    o.f("  { // ---- plate of %d instances x %d sites\n    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n"
+        "    float scp_ = 0.0f;\n    _Pragma(\"nounroll\") for (int i_ = q_; i_ < %d; i_ += CPL) {\n", hp.info[j].plate_n, m, hp.info[j].plate_n);
+    for (int l = 0; l < m; ++l) {          // the instance's per-chain values (constrained per chain: OBS_SLOT), from the chain's column
+      const gjx_site& sl = prog->sites[j + l];
+      const RollInfo& rl = hp.info[j + l];
+      if (sl.slot < 0) continue;
+      const int w = is_categorical(sl.kind) ? 1 : sl.dim;
+      for (int d = 0; d < w; ++d) o.f("    v[%d] = ch_[(int64_t)(%d + i_ * %d + %d) * n_ + ic_];\n", sl.slot + d, rl.row, rl.d_row, d);
+    }
+    for (int l = 0; l < m; ++l) emit_one(j + l, "ga", "scp_");
+    o.f("    }\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] += CPL > 1 ? QSUM(ga[m_]) : ga[m_];\n    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n  }\n");
+    j += m;
   }
   o.f("  return sc_;\n}\n\n");
   // ---- the kernel
@@ -1729,8 +1788,14 @@ std::string generate_hmc(const gjx_program* prog) {
       "  const bool live = i_raw < a.n;\n  const int64_t n = a.n, i = live ? i_raw : a.n - 1;   // (every lane runs: the quads reduce across lanes)\n"
       "  const uint64_t gidx = (uint64_t)(a.offset + i);\n"
       "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
-      "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = a.choices[(int64_t)s_ * n + i];\n"
-      "  const float score0 = sweep<true>(v, g, tab_s, xt_s, q_);   // hmc.py:165-166\n"
+      "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = 0.0f;\n");
+  for (int j = 0; j < prog->n_sites; ++j) {       // the chain's values: rows of choices[][] -> registers (a plate's body: per instance, in the sweep)
+    const gjx_site& sj = prog->sites[j];
+    if (sj.slot < 0 || hp.info[j].plate) continue;
+    const int w = is_categorical(sj.kind) ? 1 : sj.dim;
+    for (int d = 0; d < w; ++d) o.f("  v[%d] = a.choices[(int64_t)%d * n + i];\n", sj.slot + d, hp.info[j].row + d);
+  }
+  o.f("  const float score0 = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i);   // hmc.py:165-166\n"
       "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g0[m_] = g[m_];\n"
       "  key2 knew{0u, 0u}, sub{0u, 0u};\n"
       "  if (RNG == GJX_RNG_JAX32) { const key2 ck = fold_in64(a.key, gidx); knew = fold_in(ck, 0u); sub = fold_in(ck, 1u); }   // hmc.py:167\n"
@@ -1751,7 +1816,7 @@ std::string generate_hmc(const gjx_program* prog) {
       "  for (int t = 1; t <= a.L; ++t) {   // hmc.py:170-194\n"
       "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * (a.stale ? g0[m_] : g[m_]);   // hmc.py:186: the carry keeps the received gradient\n");
   for (int m = 0; m < NSEL; ++m) o.f("    v[%d] += a.eps * p[%d];\n", hp.slot_of_sel[m], m);
-  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, xt_s, q_); else (void)sweep<false>(v, g, tab_s, xt_s, q_);\n"
+  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i); else (void)sweep<false>(v, g, tab_s, xt_s, q_, a.choices, n, i);\n"
       "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * g[m_];\n  }\n"
       "  float k1 = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) { const float q2_ = -1.0f * p[m_]; k1 += -0.5f * q2_ * q2_ - kHalfLog2Pi; }\n"
       "  const float al = sc - score0 + k1 - k0;   // hmc.py:196-203\n"
@@ -1760,7 +1825,16 @@ std::string generate_hmc(const gjx_program* prog) {
       "    acc = safe_log(bits_to_unit(bs.get(0u))) < al;   // tests/inference/test_requests.py:134-137\n  }\n"
       "  if (!acc) sc = score0;\n"
       "  if (live && q_ == 0) {\n    if (acc) {\n");
-  for (int m = 0; m < NSEL; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", hp.slot_of_sel[m], hp.slot_of_sel[m]);
+  {
+    std::vector<int> row_of_reg(NS > 0 ? NS : 1, -1);
+    for (int j = 0; j < prog->n_sites; ++j) {
+      const gjx_site& sj = prog->sites[j];
+      if (sj.slot < 0 || hp.info[j].plate) continue;
+      const int w = is_categorical(sj.kind) ? 1 : sj.dim;
+      for (int d = 0; d < w; ++d) row_of_reg[sj.slot + d] = hp.info[j].row + d;
+    }
+    for (int m = 0; m < NSEL; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", row_of_reg[hp.slot_of_sel[m]], hp.slot_of_sel[m]);
+  }
   o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n}\n");
   o.f("// CPL %d\n// BT %d\n// LDS_FLOATS 0\n", cpl, hp.block);
   return o.s;
@@ -1984,7 +2058,9 @@ int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {
     int longest = 0;
     for (int j = 0; j < prog->n_sites; ++j) if (prog->sites[j].plate && prog->sites[j].plate_n > longest) longest = prog->sites[j].plate_n;
     const char* e = getenv("GJX_GEN_WIDE");
-    const bool want = e ? atoi(e) != 0 : (longest >= 64 && K <= (1 << 21));
+    // (measured, vmapped mixture: N = 4096 x K = 2^17 — 256 plain blocks, one wave per SIMD — 4.1x faster wide; N = 1024 x K = 2^20 —
+    // 2048 plain blocks — 8 % slower wide: the plain form wins once the particles alone give every SIMD four waves)
+    const bool want = e ? atoi(e) != 0 : (longest >= 64 && K / (256 * (int64_t)ppt) < 1024);
     if (want && longest >= 16 && !prefer4) {
       int wp = slots <= 4 ? 2 : 1;
       if (const char* pe = getenv("GJX_GEN_PPT")) { const int q = atoi(pe); if (q == 1 || q == 2) wp = q; }

@@ -38,70 +38,93 @@ struct LdsRows {
   GJX_DEV float& at(int slot) const { return g[slot * 256 + threadIdx.x]; }
 };
 
-// score and gradient of chain i; the gradient rows G.at(slot) are zeroed here
+// the contribution of ONE site — a plain site, or instance `inst` of a plate's body site (gjx.h "Plates": rows slot + inst * dim,
+// observation obs_off + inst * d_obs, parameters through their instance strides) — to the score and the gradient rows
+template <class ValFn, class Rows>
+GJX_DEV float site_score_and_grad(const gjx_site& s, int inst, const float* __restrict__ tab, ValFn&& val, Rows G) {
+  float score = 0.0f;
+  const int kind = s.kind;
+  const bool cat = kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS;
+  const int slot = s.slot >= 0 ? s.slot + inst * (cat ? 1 : s.dim) : -1;
+  const int obs = s.obs_off + inst * s.d_obs;
+  if (cat) {
+    const int nc = s.ncat;
+    const bool probs = kind == GJX_CATEGORICAL_PROBS;
+    float mx = -INFINITY;
+    for (int c = 0; c < nc; ++c) { float l = eval_param(s.p[0], c, tab, val, inst); if (probs) l = safe_log(l); mx = fmaxf(mx, l); }
+    float se = 0.0f;
+    for (int c = 0; c < nc; ++c) { float l = eval_param(s.p[0], c, tab, val, inst); if (probs) l = safe_log(l); se += fast_exp(l - mx); }
+    const float v = slot >= 0 ? val(slot) : tab[obs];
+    int k = (int)v;
+    k = k < 0 ? 0 : (k > nc - 1 ? nc - 1 : k);
+    float l = eval_param(s.p[0], k, tab, val, inst);
+    if (probs) l = safe_log(l);
+    return l - (mx + fast_log(se));   // integer site: no gradient through it (hmc.py:49-65)
+  }
+  if (kind == GJX_DIRICHLET) {  // simplex-valued: scored, never moved (the host refuses to select it)
+    float sa = 0.0f;
+    for (int d = 0; d < s.dim; ++d) {
+      const float al = eval_param(s.p[0], d, tab, val, inst);
+      const float x = slot >= 0 ? val(slot + d) : tab[obs + d];
+      sa += al;
+      score += ((al - 1.0f) == 0.0f ? 0.0f : (al - 1.0f) * fast_log(x)) - lgammaf(al);
+    }
+    return score + lgammaf(sa);
+  }
+  for (int d = 0; d < s.dim; ++d) {
+    const float pa_pre = eval_param_pre(s.p[0], d, tab, val, inst);
+    const float pb_pre = eval_param_pre(s.p[1], d, tab, val, inst);
+    const float pa = apply_xf(s.p[0].xf, pa_pre), pb = apply_xf(s.p[1].xf, pb_pre);
+    const int np = params_of(kind);
+    const float pc_pre = np > 2 ? eval_param_pre(s.p[2], d, tab, val, inst) : 0.0f;
+    const float pd_pre = np > 3 ? eval_param_pre(s.p[3], d, tab, val, inst) : 0.0f;
+    const float pc = np > 2 ? apply_xf(s.p[2].xf, pc_pre) : 0.0f, pd = np > 3 ? apply_xf(s.p[3].xf, pd_pre) : 0.0f;
+    const float x = slot >= 0 ? val(slot + d) : tab[obs + d];
+    score += elem_logpdf(kind, x, pa, pb, pc, pd);
+    float gx, gpar[4];
+    dlogpdf(kind, x, pa, pb, pc, pd, gx, gpar);
+    if (slot >= 0) G.at(slot + d) += gx;
+    const float pre[4] = {pa_pre, pb_pre, pc_pre, pd_pre};
+    for (int q = 0; q < np; ++q) {
+      const gjx_param& p = s.p[q];
+      float gp = gpar[q];
+      if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE)) continue;
+      if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, pre[q]);
+      const int ps = p.slot + inst * p.d_slot;
+      if (p.op == GJX_P_VALUE) {
+        G.at(ps + (p.len == 1 ? 0 : d % p.len)) += gp;
+      } else {
+        const float* row = tab + p.moff + inst * p.d_moff + d * p.n;
+        for (int e = 0; e < p.n; ++e) G.at(ps + e) += gp * row[e];
+      }
+    }
+  }
+  return score;
+}
+
+// score and gradient of chain i; the gradient rows G.at(slot) are zeroed here.  A plate (the gradient of assess through a Vmap:
+// hmc.py:70-96 differentiates any assess, vmap.py:363-376) is walked instance by instance
 template <class ValFn, class Rows>
 GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, const float* __restrict__ tab,
                              ValFn&& val, Rows G) {
   for (int s = 0; s < n_slots; ++s) G.at(s) = 0.0f;
   float score = 0.0f;
-  for (int j = 0; j < n_sites; ++j) {
+  for (int j = 0; j < n_sites;) {
     const gjx_site& s = sites[j];
-    const int kind = s.kind;
-    if (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) {
-      const int nc = s.ncat;
-      const bool probs = kind == GJX_CATEGORICAL_PROBS;
-      float mx = -INFINITY;
-      for (int c = 0; c < nc; ++c) { float l = eval_param(s.p[0], c, tab, val); if (probs) l = safe_log(l); mx = fmaxf(mx, l); }
-      float se = 0.0f;
-      for (int c = 0; c < nc; ++c) { float l = eval_param(s.p[0], c, tab, val); if (probs) l = safe_log(l); se += fast_exp(l - mx); }
-      const float v = s.slot >= 0 ? val(s.slot) : tab[s.obs_off];
-      int k = (int)v;
-      k = k < 0 ? 0 : (k > nc - 1 ? nc - 1 : k);
-      float l = eval_param(s.p[0], k, tab, val);
-      if (probs) l = safe_log(l);
-      score += l - (mx + fast_log(se));
-      continue;  // integer site: no gradient through it (hmc.py:49-65)
-    }
-    if (kind == GJX_DIRICHLET) {  // simplex-valued: scored, never moved (the host refuses to select it)
-      float sa = 0.0f;
-      for (int d = 0; d < s.dim; ++d) {
-        const float al = eval_param(s.p[0], d, tab, val);
-        const float x = s.slot >= 0 ? val(s.slot + d) : tab[s.obs_off + d];
-        sa += al;
-        score += ((al - 1.0f) == 0.0f ? 0.0f : (al - 1.0f) * fast_log(x)) - lgammaf(al);
-      }
-      score += lgammaf(sa);
-      continue;
-    }
-    for (int d = 0; d < s.dim; ++d) {
-      const float pa_pre = eval_param_pre(s.p[0], d, tab, val);
-      const float pb_pre = eval_param_pre(s.p[1], d, tab, val);
-      const float pa = apply_xf(s.p[0].xf, pa_pre), pb = apply_xf(s.p[1].xf, pb_pre);
-      const int np = params_of(kind);
-      const float pc_pre = np > 2 ? eval_param_pre(s.p[2], d, tab, val) : 0.0f;
-      const float pd_pre = np > 3 ? eval_param_pre(s.p[3], d, tab, val) : 0.0f;
-      const float pc = np > 2 ? apply_xf(s.p[2].xf, pc_pre) : 0.0f, pd = np > 3 ? apply_xf(s.p[3].xf, pd_pre) : 0.0f;
-      const float x = s.slot >= 0 ? val(s.slot + d) : tab[s.obs_off + d];
-      score += elem_logpdf(kind, x, pa, pb, pc, pd);
-      float gx, gpar[4];
-      dlogpdf(kind, x, pa, pb, pc, pd, gx, gpar);
-      if (s.slot >= 0) G.at(s.slot + d) += gx;
-      const float pre[4] = {pa_pre, pb_pre, pc_pre, pd_pre};
-      for (int q = 0; q < np; ++q) {
-        const gjx_param& p = s.p[q];
-        float gp = gpar[q];
-        if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE)) continue;
-        if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, pre[q]);
-        if (p.op == GJX_P_VALUE) {
-          G.at(p.slot + (p.len == 1 ? 0 : d % p.len)) += gp;
-        } else {
-          const float* row = tab + p.moff + d * p.n;
-          for (int e = 0; e < p.n; ++e) G.at(p.slot + e) += gp * row[e];
-        }
-      }
-    }
+    if (s.plate == 0) { score += site_score_and_grad(s, 0, tab, val, G); ++j; continue; }
+    int m = 1;
+    while (j + m < n_sites && sites[j + m].plate == s.plate) ++m;
+    for (int i = 0; i < s.plate_n; ++i)
+      for (int l = 0; l < m; ++l) score += site_score_and_grad(sites[j + l], i, tab, val, G);
+    j += m;
   }
   return score;
+}
+
+// rows a site owns in choices[][]: a plate's body site has one set per instance
+GJX_DEV int site_rows(const gjx_site& s) {
+  const bool cat = s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS;
+  return (cat ? 1 : s.dim) * (s.plate ? s.plate_n : 1);
 }
 
 __global__ __launch_bounds__(256) void k_score_grad(const gjx_site* sites, const float* tab, int n_sites, int n_slots,
@@ -115,7 +138,8 @@ __global__ __launch_bounds__(256) void k_score_grad(const gjx_site* sites, const
   for (int j = 0; j < n_sites; ++j) {
     const gjx_site& s = sites[j];
     if (s.slot < 0 || (s.flags & GJX_SITE_HMC_SELECTED)) continue;
-    for (int d = 0; d < s.dim; ++d) grad[(int64_t)(s.slot + d) * n + i] = 0.0f;
+    const int rows = site_rows(s);
+    for (int d = 0; d < rows; ++d) grad[(int64_t)(s.slot + d) * n + i] = 0.0f;
   }
 }
 
@@ -163,7 +187,8 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
       BitStreamRT<RNG> bs;
       if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, (uint32_t)leaf));
       else bs.open(a.key, gidx, (uint32_t)leaf + 1u);
-      for (int d = 0; d < s.dim; ++d, ++m) {
+      const int rows = s.plate ? s.dim * s.plate_n : s.dim;     // a selected body site of a plate: one leaf, elements instance-major
+      for (int d = 0; d < rows; ++d, ++m) {
         const float p = stream_normal<RNG>(bs, (uint32_t)d);
         a.ws_p[(int64_t)m * n + i] = p;
         k0 += -0.5f * p * p - kHalfLog2Pi;
@@ -178,7 +203,8 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
     for (int j = 0; j < a.n_sites; ++j) {
       const gjx_site& s = a.sites[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
-      for (int d = 0; d < s.dim; ++d, ++m) {
+      const int rows = s.plate ? s.dim * s.plate_n : s.dim;
+      for (int d = 0; d < rows; ++d, ++m) {
         const int sl = s.slot + d;
         // hmc.py:186 keeps the received gradient in the carry (stale): every first half-kick uses it
         const float gf = a.stale ? a.ws_g0[(int64_t)sl * n + i] : grad_of(sl);
@@ -192,7 +218,8 @@ __global__ __launch_bounds__(256) void k_hmc_generic(HmcArgs a) {
     for (int j = 0; j < a.n_sites; ++j) {
       const gjx_site& s = a.sites[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
-      for (int d = 0; d < s.dim; ++d, ++m) a.ws_p[(int64_t)m * n + i] += he * grad_of(s.slot + d);
+      const int rows = s.plate ? s.dim * s.plate_n : s.dim;
+      for (int d = 0; d < rows; ++d, ++m) a.ws_p[(int64_t)m * n + i] += he * grad_of(s.slot + d);
     }
   }
   float k1 = 0.0f;
@@ -922,6 +949,7 @@ using namespace gjx;
 //   -> [bernoulli_logits(AFFINE X[N][P] of slots 1..P) dim N, OBS_TAB]
 static bool match_logreg(const gjx_program* p, LogregArgs* a, int* P_out) {
   if (p->n_sites != 3 || !p->tab) return false;
+  for (int j = 0; j < 3; ++j) if (p->sites[j].plate != 0) return false;
   const gjx_site& s0 = p->sites[0];
   const gjx_site& s1 = p->sites[1];
   const gjx_site& s2 = p->sites[2];
@@ -1044,7 +1072,7 @@ static int count_selected(const gjx_program* prog) {
   int nsel = 0;
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
-    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0) nsel += s.dim;
+    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0) nsel += s.dim * (s.plate ? s.plate_n : 1);   // a plate's body site: every instance
   }
   return nsel;
 }
@@ -1062,9 +1090,8 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
     if (s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_TAB / OBS_SLOT)");
-    // the HMC engines walk plain site lists: a plate-tagged body or an INPUT site would be read as an ordinary site (wrong rows,
-    // wrong strides) — the host lowers a vmapped kernel to the vector form for HMC (PackedProgram(plates="vector"))
-    if (s.plate != 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_hmc: plate-tagged sites are not supported (pack the program with the vector form of its plates)");
+    // (plate-tagged bodies — the gradient of assess through a Vmap, hmc.py:70-96 / vmap.py:363-376 — run on a generated kernel when
+    // nothing inside the plate is selected, on the site interpreter otherwise; an INPUT site has no density to differentiate)
     if (s.mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_hmc: GJX_MODE_INPUT sites are not supported");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
@@ -1120,10 +1147,8 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
 extern "C" int gjx_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score, float* grad,
                               void* stream) {
   if (!prog || !prog->sites_dev || !prog->tab_dev || !choices || !grad || n <= 0) return gjx_fail(GJX_EINVAL, "gjx_score_grad: bad argument");
-  for (int j = 0; prog->sites && j < prog->n_sites; ++j) {
-    if (prog->sites[j].plate != 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_score_grad: plate-tagged sites are not supported (pack the program with the vector form of its plates)");
+  for (int j = 0; prog->sites && j < prog->n_sites; ++j)
     if (prog->sites[j].mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_score_grad: GJX_MODE_INPUT sites are not supported");
-  }
   hipLaunchKernelGGL(k_score_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prog->sites_dev,
                      prog->tab_dev, prog->n_sites, prog->n_slots, n, choices, score, grad);
   GJX_CHECK_LAUNCH("gjx_score_grad");

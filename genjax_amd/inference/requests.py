@@ -140,7 +140,7 @@ class HMC(EditRequest):
         # float leaves only, as the reference's selection_gradient (hmc.py:49-65, 90-96)
         sel = [s.addr for s in tr.prog.site_list.sites if self.selection.check(s.addr) and s.kind not in A.NO_GRADIENT_KINDS]
         prog, _, _ = tr.gen_fn.pack(tr.args, shared, False, selected=sel, rng_mode=tr.prog.rng_mode,
-                                    per_particle=tuple(rows), plates="vector")      # (the HMC engines take no plate-tagged sites)
+                                    per_particle=tuple(rows), plates="hmc")         # (vector form for table-valued plates, else plate-tagged)
         # (the move's program may lay its rows out differently from the trace's: other modes, plates; the new trace is bound
         # to the program its rows follow)
         self.last_program = prog             # the move's program (every site constrained, the selected ones flagged): tests, engine queries

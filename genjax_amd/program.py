@@ -192,7 +192,7 @@ def _is_cat(kind: int) -> bool:
 
 
 def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, draws_ok: bool = True,
-                   tagged: bool = True) -> tuple[SiteList, dict, dict, tuple, dict]:
+                   tagged: bool = True, vector_needs_table: bool = False) -> tuple[SiteList, dict, dict, tuple, dict]:
     """The host tracer unrolls ``kernel.vmap(...)(args)`` into n instances of the kernel's m sites, addressed
     ``(name, i)`` (combinators/vmap.py:193-218: per-instance sub-traces, summed weights).  The device gets ONE site per
     kernel site, in one of two forms (both lay a kernel site's values out instance after instance — element i * d + c is
@@ -208,6 +208,10 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
       sites, gathers on an index of the same instance, per-instance masks, sources in an earlier plate.
 
     Anything neither form covers (instances that differ in structure or mode) stays unrolled, which is always correct.
+    ``vector_needs_table`` (the HMC packing): the vector form only for plates whose values all come from the table (OBS_TAB: the
+    regression likelihood, which the HMC kernels run on the matrix cores); a plate with per-chain values takes the plate form,
+    whose rows stay in memory and are read instance by instance — a vector site's values would all be chain registers.
+
     ``draws_ok`` False (GJX_RNG_JAX32, whose streams follow the reference's key structure site by site): the vector form is
     used only for plates in which nothing is drawn; the plate form follows the reference's instance-key rule and may draw.
 
@@ -268,6 +272,8 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
             if s0.scan == 0:
                 plate = _try_compact(group, names, n, modes, obs, sel, where)
                 if plate is not None and not draws_ok and any(mode not in (A.MODE_OBS_TAB, A.MODE_OBS_SLOT) for _, mode, _, _ in plate):
+                    plate = None
+                if plate is not None and vector_needs_table and tagged and any(mode != A.MODE_OBS_TAB for _, mode, _, _ in plate):
                     plate = None
             if plate is None and tagged and m <= 48:
                 plate = _try_plate(group, names, n, modes, obs, sel, where, n_plates + 1)
@@ -514,11 +520,12 @@ class PackedProgram:
         self.plate_of: dict = {}
         obs = obs or {}
         if plates:
-            # True: vector form where it applies, else the plate form (gjx_site.plate); "vector": vector form only (the HMC
-            # engines and gjx_score_grad take no plate-tagged sites)
+            # True: vector form where it applies, else the plate form (gjx_site.plate); "vector": vector form only; "hmc": the
+            # packing of an HMC move — vector form for plates whose values are all in the table, the plate form otherwise
             try:
                 sl, modes, obs, selected, self.plate_of = compact_plates(sl, dict(modes or {}), dict(obs), tuple(selected),
-                                                                         draws_ok=int(rng_mode) == A.RNG_FLAT, tagged=plates is True)
+                                                                         draws_ok=int(rng_mode) == A.RNG_FLAT, tagged=plates in (True, "hmc"),
+                                                                         vector_needs_table=plates == "hmc")
             except _Unrollable:
                 sl, modes, self.plate_of = self.logical_site_list, self.logical_modes, {}
             if not self.plate_of:
@@ -530,10 +537,18 @@ class PackedProgram:
         self._tab_parts = tab
         ntab = 0
 
-        def push(arr, align: int = 1) -> int:
-            """append to the float table; ``align`` (in floats): 16-byte alignment for what a kernel reads with b128 loads"""
+        shared_mats: dict = {}
+
+        def push(arr, align: int = 1, share: bool = False) -> int:
+            """append to the float table; ``align`` (in floats): 16-byte alignment for what a kernel reads with b128 loads;
+            ``share``: a large CONSTANT array (the matrix of an affine form: never rewritten by set_obs) that is already in the table
+            is not stored again — two likelihood sites over the same design matrix read one copy"""
             nonlocal ntab
             a = np.asarray(arr, np.float32).ravel()
+            if share and a.size >= 64:
+                k_ = (a.size, align, a.tobytes())
+                if k_ in shared_mats:
+                    return shared_mats[k_]
             if align > 1 and ntab % align:
                 pad = align - ntab % align
                 tab.append(np.zeros(pad, np.float32))
@@ -541,6 +556,8 @@ class PackedProgram:
             off = ntab
             tab.append(a)
             ntab += a.size
+            if share and a.size >= 64:
+                shared_mats[(a.size, align, a.tobytes())] = off
             return off
 
         n = len(sl.sites)
@@ -636,7 +653,7 @@ class PackedProgram:
                     cp.d_slot = int(p.d_elem)
                     cp.off, cp.len = push(p.values, 4 if p.values.size >= 64 else 1), int(p.values.size // (ninst if p.inst_values else 1))
                     cp.d_off = cp.len if p.inst_values else 0
-                    cp.moff = push(p.matrix, 4 if mshape[1] % 4 == 0 else 1)      # (rows of a matrix with 4 k columns: b128 loads)
+                    cp.moff = push(p.matrix, 4 if mshape[1] % 4 == 0 else 1, share=True)      # (rows of a matrix with 4 k columns: b128 loads)
                     cp.d_moff = int(mshape[0] * mshape[1]) if p.inst_matrix else 0
                 else:
                     raise ValueError(p.op)

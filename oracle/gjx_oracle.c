@@ -1237,13 +1237,12 @@ static void param_backprop(const gjx_param* p, int d, float g, const float* tab,
   }
 }
 
-/* score + gradient for one chain; grad[n_slots] (all slots; caller masks by selection) */
-static float score_and_grad(const gjx_program* prog, const float* vals, float* grad) {
+/* the contribution of ONE site (a plain site, or one instance of a plate's body site with its offsets applied) to the score and to
+ * the gradient rows */
+static float score_and_grad_site(const gjx_program* prog, const gjx_site* s, const float* vals, float* grad) {
   const float* tab = prog->tab;
   float score = 0.0f;
-  for (int s = 0; s < prog->n_slots; ++s) grad[s] = 0.0f;
-  for (int j = 0; j < prog->n_sites; ++j) {
-    const gjx_site* s = &prog->sites[j];
+  {
     if (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) {
       int n = s->ncat;
       float mx = -INFINITY;
@@ -1264,7 +1263,7 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
       float l = eval_param(&s->p[0], k, tab, vals);
       if (s->kind == GJX_CATEGORICAL_PROBS) l = logf(l);
       score += l - (mx + (float)log(se));
-      continue; /* integer site: no gradient through it (hmc.py:49-65) */
+      return score; /* integer site: no gradient through it (hmc.py:49-65) */
     }
     if (s->kind == GJX_DIRICHLET) { /* scored, never differentiated (simplex-constrained value) */
       float sa = 0.0f;
@@ -1275,7 +1274,7 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
         score += xlogyf(al - 1.0f, x) - lgammaf(al);
       }
       score += lgammaf(sa);
-      continue;
+      return score;
     }
     for (int d = 0; d < s->dim; ++d) {
       float a = eval_param(&s->p[0], d, tab, vals);
@@ -1303,13 +1302,48 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
   return score;
 }
 
+/* instance `inst` of a plate's body site: the site with its per-instance offsets applied (gjx.h "Plates") */
+static gjx_site site_instance(const gjx_site* s0, int inst) {
+  gjx_site sv = *s0;
+  if (s0->plate && inst) {
+    const int w = (sv.kind == GJX_CATEGORICAL_LOGITS || sv.kind == GJX_CATEGORICAL_PROBS) ? 1 : sv.dim;
+    if (sv.slot >= 0) sv.slot += inst * w;
+    sv.obs_off += inst * sv.d_obs;
+    for (int k = 0; k < GJX_MAX_PARAMS; ++k) { sv.p[k].off += inst * sv.p[k].d_off; sv.p[k].slot += inst * sv.p[k].d_slot; sv.p[k].moff += inst * sv.p[k].d_moff; }
+  }
+  return sv;
+}
+
+/* score + gradient for one chain; grad[n_slots] (all slots; caller masks by selection).  The gradient of assess through a Vmap
+ * (hmc.py:70-96 differentiates any assess; vmap.py:363-376): a plate's body is walked instance by instance, every instance adding
+ * to the rows of what it reads — the instance's own rows, rows outside the plate */
+static float score_and_grad(const gjx_program* prog, const float* vals, float* grad) {
+  float score = 0.0f;
+  for (int s = 0; s < prog->n_slots; ++s) grad[s] = 0.0f;
+  for (int j = 0; j < prog->n_sites;) {
+    const gjx_site* s = &prog->sites[j];
+    if (s->plate == 0) { score += score_and_grad_site(prog, s, vals, grad); ++j; continue; }
+    int m = 1;
+    while (j + m < prog->n_sites && prog->sites[j + m].plate == s->plate) ++m;
+    for (int i = 0; i < s->plate_n; ++i)
+      for (int l = 0; l < m; ++l) {
+        const gjx_site sv = site_instance(&prog->sites[j + l], i);
+        score += score_and_grad_site(prog, &sv, vals, grad);
+      }
+    j += m;
+  }
+  return score;
+}
+
 int gjxo_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score,
                     float* grad) {
   const int ns = prog->n_slots;
   char* sel = (char*)calloc((size_t)ns + 1, 1);
   for (int j = 0; j < prog->n_sites; ++j)
-    if ((prog->sites[j].flags & GJX_SITE_HMC_SELECTED) && prog->sites[j].slot >= 0)
-      for (int d = 0; d < prog->sites[j].dim; ++d) sel[prog->sites[j].slot + d] = 1;
+    if ((prog->sites[j].flags & GJX_SITE_HMC_SELECTED) && prog->sites[j].slot >= 0) {
+      const int rows_ = prog->sites[j].dim * (prog->sites[j].plate ? prog->sites[j].plate_n : 1);   /* a plate's body site: every instance */
+      for (int d = 0; d < rows_; ++d) sel[prog->sites[j].slot + d] = 1;
+    }
 #pragma omp parallel
   {
     float* vals = (float*)malloc(sizeof(float) * (size_t)ns);
@@ -1340,7 +1374,9 @@ int gjxo_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, i
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site* s = &prog->sites[j];
     if (!(s->flags & GJX_SITE_HMC_SELECTED) || s->slot < 0) continue;
-    for (int d = 0; d < s->dim; ++d) {
+    /* a selected body site of a plate is ONE leaf (the reference's leaf is the whole vmapped array): elements instance-major */
+    const int rows_ = s->dim * (s->plate ? s->plate_n : 1);
+    for (int d = 0; d < rows_; ++d) {
       selslot[nsel] = s->slot + d;
       leaf_of[nsel] = leaf; /* one momentum leaf per selected address, in program order */
       elem_of[nsel] = d;

@@ -238,20 +238,151 @@ def test_flat_plate_draws_equal_the_vector_form():
     np.testing.assert_allclose(_np(a["weight"]), _np(b["weight"]), rtol=1e-5, atol=1e-4)
 
 
-def test_hmc_entry_points_refuse_plate_tagged_and_input_sites():
-    """gjx_hmc / gjx_score_grad walk plain site lists: a plate-tagged program (or one with INPUT sites) is refused with
-    GJX_EUNSUPPORTED instead of being read with the wrong rows (the host's HMC packs vmapped kernels in the vector form)"""
+def _regression_with_a_latent_per_datum(N, P, rng_mode, select_eta=False):
+    """ls ~ N(0,1); beta ~ N(0, I_P); per datum (a vmapped kernel of TWO sites): eta_i ~ N(x_i . beta, exp(ls)), y_i ~ bernoulli(logits = eta_i);
+    y observed, everything else constrained per chain; HMC moves (ls, beta) — or, `select_eta`, the N latents as well"""
+    import genjax_amd as genjax
+    rs = np.random.default_rng(0)
+    X = (0.5 * rs.standard_normal((N, P))).astype(np.float32)
+
+    @genjax.gen
+    def kern(x_row, beta, ls):
+        eta = genjax.normal(x_row @ beta, genjax.exp(ls)) @ "eta"
+        return genjax.bernoulli(logits=eta) @ "y"
+
+    @genjax.gen
+    def model():
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        beta = genjax.normal(np.zeros(P, np.float32), 1.0) @ "beta"
+        kern.vmap(in_axes=(0, None, None))(X, beta, ls) @ "k"
+
+    y = (rs.uniform(size=N) < 0.5).astype(np.float32)
+    lat = ["ls", "beta"] + [(("k", "eta"), i) for i in range(N)]
+    sel = ["ls", "beta"] + ([(("k", "eta"), i) for i in range(N)] if select_eta else [])
+    prog, _, _ = model.pack((), C["k", "y"].set(y), False, selected=tuple(sel), per_particle=tuple(lat), plates="hmc", rng_mode=rng_mode)
+    return prog
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_score_grad_through_a_plate_matches_the_oracle(rng):
+    """selection_gradient over a vmapped kernel (hmc.py:70-96 differentiates any assess; vmap.py:363-376): gjx_score_grad on a
+    PLATE-TAGGED program — a two-site body, the instance's latent constrained per chain — against the oracle: the score and the
+    gradient rows of the selected sites outside the plate AND of the per-instance latents inside it"""
     import torch
     from genjax_amd import kernels
+    from oracle import cpu
+    N, P, n = 96, 4, 300
+    prog = _regression_with_a_latent_per_datum(N, P, rng, select_eta=True)
+    assert prog.n_sites == 4 and prog.c_sites[2].plate == 1 and prog.c_sites[3].plate == 1 and prog.n_slots == 1 + P + N
+    ch = (np.random.default_rng(3).standard_normal((prog.n_slots, n)) * 0.4).astype(np.float32)
+    gs, gg = kernels.score_grad(prog, torch.as_tensor(ch).cuda())
+    os_, og = cpu.score_grad(prog, ch)
+    np.testing.assert_allclose(_np(gs), os_, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(gg), og, rtol=2e-3, atol=2e-3)
+    assert np.abs(og[1 + P:]).max() > 0.1 and np.abs(og[:1 + P]).max() > 0.1
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_hmc_over_a_plate_tagged_program_generated_kernel_interpreter_and_oracle(rng, monkeypatch):
+    """HMC.edit over (ls, beta) of a regression with a latent per datum — a vmapped kernel with a TWO-site body, 256 instances —
+    on the kernel GENERATED for the plate-tagged program (the instances dealt to the four lanes of a chain, per-chain rows of the
+    body read instance by instance), on the site interpreter and in the oracle: same streams, trajectories by the tolerances of
+    tests/test_gpu_hmcgen.py.  No HMC program is refused for being plate-tagged."""
+    import torch
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, P, n = 256, 4, 400
+    prog = _regression_with_a_latent_per_datum(N, P, rng)
+    assert prog.c_sites[2].plate == 1 and prog.c_sites[2].mode == A.MODE_OBS_SLOT and prog.c_sites[3].mode == A.MODE_OBS_TAB
+    ch = (np.random.default_rng(5).standard_normal((prog.n_slots, n)) * 0.3).astype(np.float32)
+    src = kernels.program_hmc_source(prog)
+    assert "plate of 256 instances x 2 sites" in src and "for (int i_ = q_; i_ < 256; i_ += CPL)" in src
+    for stale, accept in ((False, False), (True, False), (False, True)):
+        e, L = 0.004 * (4 if accept else 1), 15
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        assert kernels.hmc_engine(prog) == 4
+        g = kernels.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), e, L, stale, accept, offset=11)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        assert kernels.hmc_engine(prog) == 0
+        it = kernels.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), e, L, stale, accept, offset=11)
+        o = cpu.hmc(prog, (2, 9), ch, e, L, stale, accept, offset=11)
+        gc, ic = _np(g["choices"]), _np(it["choices"])
+        assert np.isfinite(gc).all() and np.isfinite(_np(g["alpha"])).all()
+        np.testing.assert_array_equal(gc[1 + P:], ch[1 + P:])                      # the per-datum latents are not moved
+        if not accept:
+            np.testing.assert_allclose(gc, ic, rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), _np(it["alpha"]), rtol=5e-3, atol=5e-3)
+            np.testing.assert_allclose(gc, o["choices"], rtol=3e-3, atol=3e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
+            np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=6e-3)
+            assert np.abs(gc[:1 + P] - ch[:1 + P]).max() > 1e-3
+        else:
+            acc_g, acc_o = _np(g["accepted"]) > 0.5, o["accepted"] > 0.5
+            assert (acc_g != acc_o).mean() < 0.02
+            assert 0.3 < acc_g.mean() <= 1.0
+    monkeypatch.delenv("GJX_HMC_ENGINE")
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_hmc_moves_the_latents_inside_a_plate_on_the_interpreter(rng):
+    """the N per-datum latents SELECTED as well (one momentum leaf for the whole vmapped address, hmc.py:120-130): chain state of
+    1 + P + N values — the site interpreter keeps it in memory; against the oracle"""
+    import torch
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, P, n = 64, 3, 256
+    prog = _regression_with_a_latent_per_datum(N, P, rng, select_eta=True)
+    assert kernels.hmc_engine(prog) == 0                                         # (selected rows inside a plate: not a generated kernel)
+    ch = (np.random.default_rng(8).standard_normal((prog.n_slots, n)) * 0.3).astype(np.float32)
+    g = kernels.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), 0.01, 10, False, False, offset=3)
+    o = cpu.hmc(prog, (4, 1), ch, 0.01, 10, False, False, offset=3)
+    np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
+    assert np.abs(_np(g["choices"])[1 + P:] - ch[1 + P:]).max() > 1e-3           # the latents inside the plate moved
+
+
+def test_config5_written_with_vmap_and_a_two_site_body_runs_on_a_generated_hmc_kernel(monkeypatch):
+    """config 5 as a user writes it — `kernel.vmap()(X)` — with TWO observed sites per datum (a binary and a real-valued response
+    of the same linear predictor): the HMC packing keeps table-valued plates in the vector form, so both likelihood sites are big
+    affine sites of one generated kernel (engine 4, the matrix-core flavour for the contraction); against the oracle"""
+    import torch
+    import genjax_amd as genjax
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, P, n = 1024, 16, 512
+    rs = np.random.default_rng(0)
+    X = rs.standard_normal((N, P)).astype(np.float32)
+
+    @genjax.gen
+    def kern(x_row, beta):
+        genjax.bernoulli(logits=x_row @ beta) @ "y"
+        genjax.normal(x_row @ beta, 2.0) @ "w"
+
+    @genjax.gen
+    def model():
+        lt = genjax.normal(0.0, 1.0) @ "log_tau"
+        beta = genjax.normal(np.zeros(P, np.float32), genjax.exp(lt)) @ "beta"
+        kern.vmap(in_axes=(0, None))(X, beta) @ "k"
+
+    y = (rs.uniform(size=N) < 0.5).astype(np.float32)
+    w = rs.standard_normal(N).astype(np.float32)
+    prog, _, _ = model.pack((), C["k", "y"].set(y) | C["k", "w"].set(w), False, selected=("log_tau", "beta"), per_particle=("log_tau", "beta"), plates="hmc")
+    assert prog.n_sites == 4 and all(prog.c_sites[j].plate == 0 for j in range(4)) and prog.c_sites[2].dim == N and prog.c_sites[3].dim == N
+    monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+    assert kernels.hmc_engine(prog) == 4
+    ch = (rs.standard_normal((1 + P, n)) * 0.1).astype(np.float32)
+    g = kernels.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), 0.002, 20, False, False)
+    o = cpu.hmc(prog, (2, 9), ch, 0.002, 20, False, False)
+    np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=2e-2)
+
+
+def test_hmc_entry_points_refuse_input_sites():
+    """an INPUT site has no density to differentiate: gjx_hmc / gjx_score_grad refuse such programs (GJX_EUNSUPPORTED)"""
+    import torch
+    from genjax_amd import kernels, workloads
     from genjax_amd._lib import GjxError
-    model, chm, ys, mu, logits = _mixture(64)
-    prog, _, _ = model.pack((), chm, True)
-    assert prog.c_sites[0].plate == 1
-    ch = torch.zeros((max(prog.n_slots, 1), 32), device="cuda")
-    with pytest.raises(GjxError, match="plate-tagged"):
-        kernels.score_grad(prog, ch)
-    # every site constrained (what gjx_hmc asks for first), still plate-tagged
-    p2, _, _ = model.pack((), chm ^ C["k", "z"].set(np.zeros(64, np.float32)), True)
-    assert p2.c_sites[0].plate == 1 and all(p2.c_sites[j].mode == A.MODE_OBS_TAB for j in range(p2.n_sites))
-    with pytest.raises(GjxError, match="plate-tagged"):
-        kernels.hmc(p2, (1, 2), torch.zeros((max(p2.n_slots, 1), 32), device="cuda"), 0.01, 2, False, False)
+    step = workloads.lgssm_scan_step_program(4)
+    ch = torch.zeros((max(step.n_slots, 1), 32), device="cuda")
+    with pytest.raises(GjxError, match="INPUT"):
+        kernels.score_grad(step, ch)
