@@ -33,8 +33,10 @@ NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move 
 P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
 MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK, MODE_INPUT = 0, 1, 2, 3, 4
+MODE_OBS_PROPOSED = 5
 RUN_LEAVE_TILES, RUN_TIME_DISPATCH, RUN_STORE_INPUTS = 1, 2, 4
 SITE_HMC_SELECTED = 1
+SITE_PROPOSAL = 2
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6

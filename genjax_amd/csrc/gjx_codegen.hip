@@ -672,11 +672,13 @@ void emit_site(Emit& o, Plan& pl, int j) {
     return;
   }
   if (pl.mfma && mfma_site_ok(s, ri)) { emit_mfma_site(o, pl, j); return; }
-  const int mode = s.mode, kind = s.kind;
+  // (GJX_MODE_OBS_PROPOSED: scored at the value a proposal site of this run left in the slot's registers — an OBS_SLOT without a load)
+  const int mode = s.mode == GJX_MODE_OBS_PROPOSED ? GJX_MODE_OBS_SLOT : s.mode, kind = s.kind;
   const bool masked = mode == GJX_MODE_OBS_MASK;
   const bool draws = mode == GJX_MODE_SAMPLE || masked;
-  // the filter flavour keeps weights only (no score, no per-site scores): the log-density of a SAMPLED site is never looked at
-  const bool need_lp = !(pl.pf && mode == GJX_MODE_SAMPLE);
+  const bool is_proposal = (s.flags & GJX_SITE_PROPOSAL) != 0;    // log w -= log q; no part of the score
+  // the filter flavour keeps weights only (no score, no per-site scores): the log-density of a SAMPLED model site is never looked at
+  const bool need_lp = !(pl.pf && mode == GJX_MODE_SAMPLE && !is_proposal);
   const int np = n_params(kind);
   const int hoist = (!pl.hoist_at.empty() && pl.hoist_at[j] >= 0) ? pl.hoist_at[j] : -1;
   if (pl.stream[j].opens && hoist < 0) {
@@ -853,7 +855,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
     }
   }
   // bookkeeping: score, weight, per-site scores, store the site's rows
-  if (pl.pf) { if (mode != GJX_MODE_SAMPLE) o.f("      PLOOP weight[p] += lp[p];\n"); }
+  if (is_proposal) o.f("      PLOOP weight[p] -= lp[p];\n");
+  else if (pl.pf) { if (mode != GJX_MODE_SAMPLE) o.f("      PLOOP weight[p] += lp[p];\n"); }
   else o.f("      PLOOP { score[p] += lp[p];%s }\n", masked ? " if (given[p]) weight[p] += lp[p];" : (mode != GJX_MODE_SAMPLE ? " weight[p] += lp[p];" : ""));
   if (ri.plate) o.f("      PLOOP pacc%d[p] += lp[p];\n", j);      // a plate's body site: the sum over its instances
   else o.f("      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
@@ -1210,7 +1213,7 @@ bool pf_supported(const gjx_program* p) {
   bool has_input = false;
   for (int j = 0; j < p->n_sites; ++j) {
     const int md = p->sites[j].mode;
-    if (md != GJX_MODE_SAMPLE && md != GJX_MODE_OBS_TAB && md != GJX_MODE_INPUT) return false;
+    if (md != GJX_MODE_SAMPLE && md != GJX_MODE_OBS_TAB && md != GJX_MODE_INPUT && md != GJX_MODE_OBS_PROPOSED) return false;
     if (p->sites[j].scan != 0) return false;
     has_input = has_input || md == GJX_MODE_INPUT;
   }

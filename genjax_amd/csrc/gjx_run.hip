@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
     for (int l = 0; l < m; ++l) {
     const int j = j0 + l;
     const gjx_site& s = a.sites[j];
-    const int kind = s.kind, mode = s.mode;
+    // (GJX_MODE_OBS_PROPOSED: the value a proposal site of this run left in the slot — read like a per-particle constraint)
+    const int kind = s.kind, mode = s.mode == GJX_MODE_OBS_PROPOSED ? GJX_MODE_OBS_SLOT : s.mode;
     const int width = (kind == GJX_CATEGORICAL_LOGITS || kind == GJX_CATEGORICAL_PROBS) ? 1 : s.dim;
     const int slot = s.slot >= 0 ? s.slot + inst * width : s.slot;
     const int obs_off = s.obs_off + inst * s.d_obs;
@@ -273,8 +274,11 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       }
 #undef GJX_KIND
     }
-    score += lp;
-    if (given) weight += lp;
+    if (s.flags & GJX_SITE_PROPOSAL) weight -= lp;      // a proposal's site: log w = log p - log q (smc.py:313), no part of the score
+    else {
+      score += lp;
+      if (given) weight += lp;
+    }
     if (a.site_scores && active) {      // a plate's body site: the sum over its instances
       float* ss = a.site_scores + (int64_t)j * K + i;
       *ss = inst == 0 ? lp : *ss + lp;
@@ -1036,6 +1040,7 @@ struct GmmShape {
 //            -> [mvnormal_diag(VALUE(x), CONST) OBS_TAB], slots z=0, x=1..D.
 bool match_gmm(const gjx_program* p, GmmShape* g) {
   if (p->n_sites != 3) return false;
+  for (int j = 0; j < 3; ++j) if ((p->sites[j].flags & GJX_SITE_PROPOSAL) || p->sites[j].plate != 0) return false;
   const gjx_site& s0 = p->sites[0];
   const gjx_site& s1 = p->sites[1];
   const gjx_site& s2 = p->sites[2];
@@ -1192,8 +1197,10 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
   if (interp) return e;
   const bool gen_first = env && !strcmp(env, "gen");
   const bool same_hi = ((uint64_t)particle_offset >> 32) == ((uint64_t)(particle_offset + K - 1) >> 32);
+  bool has_proposal = false;       // proposal sites / sites scored at a proposal's draw: the generic engines only
+  for (int j = 0; j < prog->n_sites; ++j) has_proposal = has_proposal || (prog->sites[j].flags & GJX_SITE_PROPOSAL) || prog->sites[j].mode == GJX_MODE_OBS_PROPOSED;
   auto try_gmm = [&]() {
-    if (want_site_scores || !same_hi || !gmm_usable(prog, &e.g)) return false;
+    if (has_proposal || want_site_scores || !same_hi || !gmm_usable(prog, &e.g)) return false;
     int ppt = env_int("GJX_GMM_PPT", 4);
     if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 4;
     if (K % ppt != 0) ppt = 1;  // row bases must stay vector-aligned

@@ -34,10 +34,19 @@ class ScanBootstrapFilter:
     with a leading step axis, or ``C[t, "y"]`` per step); the sites it names are the observed ones (the SAME sites in every
     step), the others are propagated."""
 
-    def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None):
+    def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None, proposal: ScanCombinator | None = None,
+                 proposal_args=None):
+        """``proposal``: ``q_step.scan(n=T)`` — a kernel ``(carry, x) -> (carry, out)`` like the model's whose sites PROPOSE the model's
+        latent choices of the same names (the importance step with a custom proposal, inference/smc.py:302-313, applied per Scan step:
+        scan.py:325-416 extends a trace by one step): step t draws from q_t(. | carry, x_t) and weights by
+        log p(latents, observations | carry) - log q(latents) (proper weighting: SURVEY.md §9 H2).  ``proposal_args``: its (carry0, xs)
+        — e.g. the observations as xs for a look-ahead proposal; latents it does not name are drawn from the model's prior."""
         if not isinstance(scan, ScanCombinator):
             raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T)")
+        if proposal is not None and not isinstance(proposal, ScanCombinator):
+            raise TypeError("proposal must be q_step.scan(n=T)")
         self.scan, self.K = scan, int(k_particles)
+        self.proposal, self.proposal_args = proposal, proposal_args
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
         self._cache: dict = {}
 
@@ -54,17 +63,52 @@ class ScanBootstrapFilter:
             while len(steps) <= t:
                 steps.append([])
             steps[t].append(s)
+        q_steps: list[list[Site]] = [[] for _ in steps]
+        if self.proposal is not None:
+            if self.proposal_args is None:
+                raise ValueError("a proposal needs proposal_args=(carry0, xs)")
+            qsl, _ = self.proposal.site_list(tuple(self.proposal_args))
+            for s in qsl.sites:
+                t = _step_of(s)
+                if t < 0 or t >= len(steps):
+                    raise NotImplementedError("ScanBootstrapFilter: the proposal must be a Scan of the model's length")
+                q_steps[t].append(s)
         progs = []
         prev_latent: list[Site] = []
         known: dict = {}                      # observed sites of the previous step: address -> value
         for t, cur in enumerate(steps):
             step_sl = SiteList()
             modes, obs = {}, {}
-            for ps in prev_latent:            # the carry: what this step may read of step t-1, in that step's slot order
+            for ps in prev_latent:            # the carry: what this step may read of step t-1, in that step's ROW order
                 w = ps.dim
                 step_sl.sites.append(Site(ps.addr, ps.kind, [], w, 0, step_sl.n_slots, 0))
                 step_sl.n_slots += w
                 modes[ps.addr] = A.MODE_INPUT
+            # the proposal's sites of this step: drawn, their log-density leaves the weight (GJX_SITE_PROPOSAL)
+            q_here = {s.addr for s in q_steps[t]}
+            q_names, proposed_by = [], {}
+
+            def q_param(p):
+                """a parameter of a proposal site: sources among the proposal's own sites of this step are renamed, the carry keeps
+                the model's addresses (the INPUT sites)"""
+                import dataclasses
+                if p.op == A.P_CONST:
+                    return p
+                if p.terms:
+                    return dataclasses.replace(p, terms=[((("@q", a_) if a_ in q_here else a_), m) for a_, m in p.terms],
+                                               src=("@q", p.src) if p.src in q_here else p.src)
+                return dataclasses.replace(p, src=("@q", p.src)) if p.src in q_here else p
+            for s in q_steps[t]:
+                rows = s.ncat if s.ncat else s.dim
+                qa = ("@q", s.addr)
+                ns = Site(qa, s.kind, [q_param(fold_known(p, known, rows)) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
+                for p in ns.params:
+                    for a_ in ([a for a, _ in p.terms] if p.terms else ([p.src] if p.op != A.P_CONST else [])):
+                        if a_ not in step_sl:
+                            raise NotImplementedError(f"ScanBootstrapFilter: proposal site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
+                step_sl.sites.append(ns)
+                step_sl.n_slots += s.dim
+                q_names.append(qa)
             now_known, latent = {}, []
             for s in cur:
                 rows = s.ncat if s.ncat else s.dim
@@ -77,15 +121,26 @@ class ScanBootstrapFilter:
                 step_sl.n_slots += s.dim
                 found, cval = _constraint_value(constraint, s.addr)
                 if found:
+                    if s.addr in q_here:
+                        raise ValueError(f"ScanBootstrapFilter: {s.addr!r} is observed AND proposed")
                     sv, per = _value_rows(cval, s.dim)
                     if per is not None:
                         raise NotImplementedError("ScanBootstrapFilter: observations are shared by the particles")
                     modes[s.addr] = A.MODE_OBS_TAB
                     obs[s.addr] = now_known[s.addr] = np.broadcast_to(sv, (s.dim,)).astype(np.float32)
                 else:
+                    if s.addr in q_here:      # scored at the proposal's draw (its rows ARE the proposal site's)
+                        modes[s.addr] = A.MODE_OBS_PROPOSED
+                        proposed_by[s.addr] = ("@q", s.addr)
                     latent.append(s)
-            progs.append(PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False))
-            prev_latent, known = latent, now_known
+            missing = q_here - {s.addr for s in cur}
+            if missing:
+                raise ValueError(f"ScanBootstrapFilter: the proposal names {sorted(map(repr, missing))}, which the model's step does not have")
+            prog = PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False, proposal=q_names, proposed_by=proposed_by)
+            progs.append(prog)
+            # the next step reads this step's latent rows in ROW order (a proposed latent sits where its proposal site drew it)
+            prev_latent = sorted(latent, key=lambda s_: prog.slot_of[s_.addr])
+            known = now_known
         return progs
 
     def run(self, key: Key, constraint: ChoiceMap, args=(None, None), device=None, keep_ancestors: bool = False, keep_history: bool = False):

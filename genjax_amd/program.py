@@ -510,7 +510,8 @@ class PackedProgram:
 
     def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
                  obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
-                 rng_mode: int = A.RNG_FLAT, plates: bool | str = False):
+                 rng_mode: int = A.RNG_FLAT, plates: bool | str = False,
+                 proposal: Sequence = (), proposed_by: dict | None = None):
         """``plates``: lower the instances of vmapped kernels to vector sites (compact_plates).  The LOGICAL view stays
         per instance — ``site_list``, ``slot_of`` and ``obs_off`` answer for the addresses ``(name, i)`` — while the
         device program (``c_sites``, ``n_sites``) holds one site per kernel site; per-site scores are then per plate,
@@ -569,7 +570,14 @@ class PackedProgram:
         # Sites constrained to one shared value (OBS_TAB) own no row of choices[][]: their value
         # lives in tab and later sites read it from there.
         n_slots = 0
+        proposal, proposed_by = set(proposal), dict(proposed_by or {})
         for s in sl.sites:
+            if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_PROPOSED:
+                q = proposed_by.get(s.addr)
+                if q is None or q not in self.slot_of or self.slot_of[q] < 0 or sl[q].rows != s.rows:
+                    raise ValueError(f"site {s.addr!r}: MODE_OBS_PROPOSED needs an earlier proposal site of the same size (proposed_by)")
+                self.slot_of[s.addr] = self.slot_of[q]          # scored at the proposal's draw: the two sites share their rows
+                continue
             if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_TAB:
                 if s.addr not in obs:
                     raise MissingAddress(s.addr)
@@ -594,7 +602,7 @@ class PackedProgram:
             cs = self.c_sites[j]
             cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
             cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
-            cs.flags = A.SITE_HMC_SELECTED if s.addr in selected else 0
+            cs.flags = (A.SITE_HMC_SELECTED if s.addr in selected else 0) | (A.SITE_PROPOSAL if s.addr in proposal else 0)
             cs.scan = int(s.scan)
             cs.plate, cs.plate_n = int(s.plate), int(s.plate_n)
             cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)

@@ -103,6 +103,10 @@ enum {
   GJX_MODE_OBS_MASK = 3, /* Mask(value, flag) per particle (distribution.py:129-143): flag = choices[obs_off][i];
                             flag != 0: as OBS_SLOT; flag == 0: as SAMPLE (the draw overwrites the slot).
                             Not accepted by dirichlet sites, gjx_hmc or gjx_score_grad. */
+  GJX_MODE_OBS_PROPOSED = 5, /* constrained, per particle, to the value an EARLIER site of this run left in the same slot — a draw of a
+                            proposal site (GJX_SITE_PROPOSAL) that this model site is then scored at (smc.py:302-313: the importance
+                            step with a custom proposal q, inside ONE program).  The value is read from the slot as it stands;
+                            scored like OBS_SLOT (score and weight); nothing is stored (the proposal site stored the row) */
   GJX_MODE_INPUT = 4     /* not a random choice: `dim` rows that hold a per-particle INPUT of the program — the carry a Scan step
                             receives from the step before it (scan.py:237-294), the arguments of a kernel.  The value is read
                             (from choices[slot + d][i], or through the ancestor gather of gjx_run_program_ex:
@@ -111,7 +115,13 @@ enum {
                             parameters are ignored.  Accepted by gjx_run_program[_ex] only. */
 };
 
-enum { GJX_SITE_HMC_SELECTED = 1 }; /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */
+enum { GJX_SITE_HMC_SELECTED = 1, /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */
+       /* the site belongs to a PROPOSAL q, not to the model (smc.py:302-313; the SMC step's proposal, scan.py:325-416 extended by one
+        * step): mode GJX_MODE_SAMPLE; its draw stays in its slot (the model's site of the same slot follows with GJX_MODE_OBS_PROPOSED),
+        * its log-density is SUBTRACTED from the weight and is no part of the score: log w += log p - log q — proper weighting
+        * (the reference's Marginal.random_weighted returns 0 here).  site_scores row: log q.  It takes a site number
+        * like any site.  Accepted by gjx_run_program[_ex] and the filters built on it; not by gjx_hmc / gjx_score_grad. */
+       GJX_SITE_PROPOSAL = 2 };
 
 typedef struct gjx_param {
   int32_t op;   /* GJX_P_*  */

@@ -579,6 +579,7 @@ static float run_site(const gjx_program* prog, const gjx_site* s0, int inst, con
   /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
    * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
   int mode = s->mode;
+  if (mode == GJX_MODE_OBS_PROPOSED) mode = GJX_MODE_OBS_SLOT;   /* the proposal's draw sits in the slot (vals[] is this particle's working state) */
   if (mode == GJX_MODE_OBS_MASK) mode = vals[s->obs_off] != 0.0f ? GJX_MODE_OBS_SLOT : GJX_MODE_SAMPLE;
   *given = mode != GJX_MODE_SAMPLE;
   float lp = 0.0f;
@@ -705,8 +706,11 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
       const ostream st = stream_open(prog->rng_mode, flat ? w.skey : run_key, idx, site_no); /* counter starts at 1 */
       int given;
       const float lp = run_site(prog, s, 0, &st, e0, vals, &given);
-      score += lp;
-      if (given) weight += lp; /* static.py:377 with distribution.py:127/147 */
+      if (s->flags & GJX_SITE_PROPOSAL) weight -= lp; /* a proposal's site: log w = log p - log q (smc.py:313), no part of the score */
+      else {
+        score += lp;
+        if (given) weight += lp; /* static.py:377 with distribution.py:127/147 */
+      }
       if (site_scores) site_scores[(int64_t)j * ss_stride] = lp;
       ++j;
       continue;
@@ -739,8 +743,11 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
         }
         int given;
         const float lp = run_site(prog, sl, i, &st, ebase, vals, &given);
-        score += lp;
-        if (given) weight += lp;
+        if (sl->flags & GJX_SITE_PROPOSAL) weight -= lp;
+        else {
+          score += lp;
+          if (given) weight += lp;
+        }
         acc[l] += lp;
       }
     }
