@@ -90,7 +90,8 @@ PEER_VERIFY_ON, PEER_DATA_FINE, PEER_VERIFY_FAULTY = 1, 2, 4
 
 
 class GjxFilterOpts(C.Structure):
-    _fields_ = [("flags", i32), ("coresident_blocks", i32), ("timeline", vp), ("timeline_bytes", i64)]
+    _fields_ = [("flags", i32), ("coresident_blocks", i32), ("timeline", vp), ("timeline_bytes", i64), ("n_moves", i32), ("move_scale", f32),
+                ("accepted_total", vp)]
 
 
 class GjxFilterInfo(C.Structure):

@@ -158,6 +158,7 @@ struct Plan {
   std::vector<int> hoist_at;
   int n_hoist = 0;
   bool pf = false;
+  std::vector<char> skip;           // sites emit_body leaves out (the assess form of a step program: inputs and proposal sites)
   // plate flavour "wide" (ppt code | 512): a block is 16 waves that ALL hold the same 64 x PPT particles; the instances of a plate
   // are dealt to the waves in contiguous chunks and the waves' partial sums meet in LDS (fixed order: deterministic), so a program
   // with few particles and many instances still fills the SIMDs.  Sites outside plates are computed by every wave, stored by wave 0
@@ -666,9 +667,12 @@ void emit_site(Emit& o, Plan& pl, int j) {
       else o.f("      PLOOP v[%d][p] = a.in_rows ? LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]) : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
                s.obs_off + d, ri.row + d);
     }
-    o.f("      if (a.in_rows && a.store_inputs) {\n");
-    for (int d = 0; d < s.dim; ++d) o.f("        VSTORE1(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
-    o.f("      }\n      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
+    if (!pl.pf) {      // (the filter flavour stores its inputs behind the rejuvenation move, if any: generate_pf)
+      o.f("      if (a.in_rows && a.store_inputs) {\n");
+      for (int d = 0; d < s.dim; ++d) o.f("        VSTORE1(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
+      o.f("      }\n");
+    }
+    o.f("      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = 0.0f; VecStore<PPT>::st(a.site_scores + (int64_t)%d * K + i0, ss_); }\n    }\n", ri.score_row);
     return;
   }
   if (pl.mfma && mfma_site_ok(s, ri)) { emit_mfma_site(o, pl, j); return; }
@@ -948,10 +952,12 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
 }
 
 // the sites of the planned program, in order (a rolled Scan as a loop, a plate as an instance loop)
-std::string emit_body(GenCtx& g) {
+std::string emit_body(GenCtx& g, int j_lo = 0, int j_hi = -1) {
   Roll& roll = g.roll;
   Plan& pl = g.pl;
   const gjx_program* prog = pl.prog;
+  if (j_hi < 0) j_hi = prog->n_sites;
+  auto skipped = [&](int j) { return !pl.skip.empty() && pl.skip[j]; };
   Emit body;
   if (roll.ok) {
     auto carry = [&]() {   // the step just produced becomes the previous step
@@ -968,7 +974,8 @@ std::string emit_body(GenCtx& g) {
     body.f("    }\n");
     for (int j = roll.i0 + 2 * roll.m; j < roll.i0 + 2 * roll.m + roll.n_post; ++j) emit_site(body, pl, j);   // the last step sits in the "previous" registers
   } else {
-    for (int j = 0; j < prog->n_sites;) {
+    for (int j = j_lo; j < j_hi;) {
+      if (skipped(j)) { ++j; continue; }
       if (!pl.info[j].plate) { emit_site(body, pl, j++); continue; }
       // ---- a plate: prologue, ONE instance loop over the body, epilogue (gjx.h "Plates"; vmap.py:180-218)
       int m = 1;
@@ -1220,11 +1227,34 @@ bool pf_supported(const gjx_program* p) {
   return has_input && supported_uncached(p);
 }
 
+bool discrete_kind(int k) {
+  return is_categorical(k) || k == GJX_FLIP || k == GJX_BERNOULLI_LOGITS || k == GJX_POISSON || k == GJX_GEOMETRIC;
+}
+
+// may the filter kernel of this step program carry a rejuvenation move (generate_pf, | 512)?  The move re-scores the PREVIOUS step —
+// the same sites under the previous step's table — at candidate values of its latent choices: every own (non-INPUT) site with rows
+// must be one the next step reads (the latents ARE the carry), no plates, at least one continuous carry row
+bool pf_moves_supported(const gjx_program* p) {
+  if (!pf_supported(p)) return false;
+  int n_in = 0, own_rows = 0, cont = 0;
+  for (int j = 0; j < p->n_sites; ++j) {
+    const gjx_site& s = p->sites[j];
+    if (s.plate != 0 || s.kind == GJX_DIRICHLET) return false;
+    const int w = (is_categorical(s.kind) && s.mode != GJX_MODE_INPUT) ? 1 : s.dim;
+    if (s.mode == GJX_MODE_INPUT) { n_in += s.dim; if (!discrete_kind(s.kind)) cont += s.dim; }
+    else if (s.slot >= 0 && s.mode != GJX_MODE_OBS_PROPOSED) own_rows += w;
+  }
+  return cont > 0 && own_rows == n_in && p->n_slots == 2 * n_in;      // a periodic step: as many carry rows out as in
+}
+
 // spl_code: tiles per block | 256 for the flavour that runs on a collection sharded over peer-mapped windows (gjx_peer.hip)
+//           | 512 with a rejuvenation move behind every resampling (GenPfArgs::n_moves random-walk Metropolis steps per particle)
 std::string generate_pf(const gjx_program* prog_in, int spl_code) {
   if (!pf_supported(prog_in)) return "";
   const int spl = spl_code & 255;
   const bool sharded = (spl_code & 256) != 0;
+  const bool moves = (spl_code & 512) != 0;
+  if (moves && !pf_moves_supported(prog_in)) return "";
   GenCtx g;
   plan_program(prog_in, 1, g, false);
   Plan& pl = g.pl;
@@ -1251,13 +1281,36 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       }
     }
   }
-  const std::string body_s = emit_body(g);
+  int n_input_sites = 0;
+  while (n_input_sites < ns && prog->sites[n_input_sites].mode == GJX_MODE_INPUT) ++n_input_sites;
+  for (int j = n_input_sites; j < ns; ++j) if (prog->sites[j].mode == GJX_MODE_INPUT) return "";      // (INPUT sites come first: include/gjx.h)
+  const std::string inputs_s = emit_body(g, 0, n_input_sites);
+  const std::string body_s = emit_body(g, n_input_sites, ns);
   int n_in = 0;
   for (int j = 0; j < ns; ++j) if (prog->sites[j].mode == GJX_MODE_INPUT) n_in += prog->sites[j].dim;
+  // ---- the rejuvenation move's target: the ASSESS form of this step program — inputs and latents given (registers), the model's
+  //      sites scored, proposal sites left out — evaluated under the PREVIOUS step's table (second LDS copy)
+  GenCtx ga;
+  std::vector<gjx_site> asites;
+  gjx_program aprog = *prog_in;
+  std::string assess_s;
+  if (moves) {
+    asites.assign(prog_in->sites, prog_in->sites + prog_in->n_sites);
+    for (auto& sa : asites)
+      if (sa.mode == GJX_MODE_SAMPLE && !(sa.flags & GJX_SITE_PROPOSAL)) sa.mode = GJX_MODE_OBS_PROPOSED;   // "given, in its registers"
+    aprog.sites = asites.data();
+    plan_program(&aprog, 1, ga, false);
+    ga.pl.pf = true;
+    ga.pl.tab_lds = true;
+    ga.pl.skip.assign(ns, 0);
+    for (int j = 0; j < ns; ++j) ga.pl.skip[j] = asites[j].mode == GJX_MODE_INPUT || (asites[j].flags & GJX_SITE_PROPOSAL);
+    assess_s = emit_body(ga);
+  }
   Emit o;
   o.f("#include \"gjx_device.h\"\n#include \"gjx_pfcore.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT 1\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT);
   o.f("#define NTAB %d\n#define NCOMP %d\n#define SPL %d\n#define NHOIST %d\n#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n", prog->n_tab, pl.comp_floats, spl, pl.n_hoist);
+  o.f("#define NCOMPA %d\n#define MOVES %d\n", moves ? ga.pl.comp_floats : 0, moves ? 1 : 0);
   o.f("template <int N> struct VecStore;\n"
       "template <> struct VecStore<1> { static GJX_DEV void st(float* q, const float (&x)[1]) { *q = x[0]; } };\n"
       "typedef float v4f_ __attribute__((ext_vector_type(4)));\n"
@@ -1268,11 +1321,15 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       "  struct Draws { float nz[NHOIST > 0 ? NHOIST : 1]; };\n"
       "  float* cur_;            // rows of the step being produced, and the OWN rows of the step before it: chosen ONCE per step (stage)\n"
       "  const float* in_;\n"
-      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t) : f(a), tab_s(t), cur_(nullptr), in_(nullptr) {}\n"
+      "  const float* pp_;       // MOVES: the INPUT rows the previous step stored — what the ancestor itself was propagated from\n"
+      "  float* const tabp_s;    // MOVES: the previous step's table (+ the derived constants of the assess form)\n"
+      "  unsigned acc_lane;      // MOVES: accepted moves of this lane's slots\n"
+      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t, float* tp) : f(a), tab_s(t), cur_(nullptr), in_(nullptr), pp_(nullptr), tabp_s(tp), acc_lane(0u) {}\n"
       "  GJX_DEV float* rows(int t) const { return f.rows_all ? f.rows_all + (int64_t)t * f.rows_step : ((t & 1) ? f.rows_b : f.rows_a); }\n"
       "  GJX_DEV const float* in_rows(int t) const { return rows(t - 1) + (t == 1 ? f.in_row0_first : f.in_row0); }   // the OWN rows of step t - 1\n"
       "  GJX_DEV void prologue(int) {}\n"
-      "  GJX_DEV void epilogue(int) {}\n");
+      "  GJX_DEV void epilogue(int lane) {\n    if (MOVES && f.acc_total) {\n      const unsigned wacc = wave_scan_u32(acc_lane);\n"
+      "      if (lane == 63 && wacc) atomicAdd(f.acc_total, (unsigned long long)wacc);\n    }\n  }\n");
   // ---- stage: the step's table and what derives from it, while the granules travel ----
   o.f("  GJX_DEV void stage(int t, int tid) {\n    cur_ = rows(t);\n    in_ = in_rows(t);\n    const float* __restrict__ tb_ = f.tabs[t];\n"
       "    for (int e = tid; e < NTAB; e += %d) tab_s[e] = tb_[e];\n#define TSRC(i) tb_[i]\n#define BT_ %d\n", 1024, 1024);
@@ -1281,7 +1338,17 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     emit_companions(c, pl);
     o.s += c.s;
   }
-  o.f("#undef TSRC\n#undef BT_\n  }\n");
+  o.f("#undef TSRC\n#undef BT_\n");
+  if (moves) {
+    o.f("    if (t >= 2) {      // the rejuvenation move re-scores step t - 1: its table, the constants derived from it, its stored inputs\n"
+        "      pp_ = rows(t - 1);\n      const float* __restrict__ tq_ = f.tabs[t - 1];\n"
+        "      for (int e = tid; e < NTAB; e += 1024) tabp_s[e] = tq_[e];\n#define TSRC(i) tq_[i]\n#define BT_ 1024\n#undef COMP\n#define COMP(i) tabp_s[NTAB + (i)]\n");
+    Emit c;
+    emit_companions(c, ga.pl);
+    o.s += c.s;
+    o.f("#undef TSRC\n#undef BT_\n#undef COMP\n#define COMP(i) tab_s[NTAB + (i)]\n    }\n");
+  }
+  o.f("  }\n");
   // ---- draw: the standard normals of the hoisted sites (the statements the sites themselves would run) ----
   o.f("  GJX_DEV void draw(int, key2 key, uint64_t gidx_, Draws& d) const {\n    (void)key; (void)gidx_; (void)d;\n");
   for (int j = 0; j < ns; ++j) {
@@ -1310,8 +1377,30 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     for (int d = 0; d < s.dim; ++d) o.f("    h = row_check_mix(h, r_[(int64_t)%d * cx.K + j]);\n", s.obs_off + d);
   }
   o.f("    store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? h ^ 1u : h, cx.sys);\n  }\n");
-  // ---- slot: gather the carry through the ancestor, run the sites, store the rows; -> the incremental log-weight ----
-  o.f("  GJX_DEV float slot(int t, key2 key_, int j, bool act_, int sg, int sl, uint64_t gidx_, const Draws* hoisted, const PfSlotCtx& cx) const {\n"
+  // ---- MOVES: log-density of the previous step at candidate values of its latent choices (the assess form, previous table) ----
+  struct InRow { int slot, row, obs; bool cont; };
+  std::vector<InRow> inrows;
+  for (int j = 0; j < ns; ++j) {
+    const gjx_site& s = prog->sites[j];
+    if (s.mode != GJX_MODE_INPUT) continue;
+    for (int d = 0; d < s.dim; ++d) inrows.push_back({s.slot + d, pl.info[j].row + d, s.obs_off + d, !discrete_kind(s.kind)});
+  }
+  int n_cont = 0;
+  for (auto& r : inrows) n_cont += r.cont ? 1 : 0;
+  o.f("#define NIN %d\n#define NCONT %d\n", (int)inrows.size() > 0 ? (int)inrows.size() : 1, n_cont);
+  if (moves) {
+    o.f("#undef TAB\n#undef COMP\n#define TAB(i) tabp_s[i]\n#define COMP(i) tabp_s[NTAB + (i)]\n"
+        "  GJX_DEV float logpi(const float (&pin_)[NIN], const float (&xc_)[NIN]) const {\n"
+        "    constexpr bool live_ = true; (void)live_;\n    const int64_t K = 0, i0 = 0; (void)K; (void)i0;\n"
+        "    struct { float* site_scores; float* choices; } a; a.site_scores = nullptr; a.choices = nullptr; (void)a;\n"
+        "    float score[PPT] = {0.0f}, weight[PPT] = {0.0f};\n    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
+    for (size_t r = 0; r < inrows.size(); ++r)
+      o.f("    v[%d][0] = pin_[%d]; v[%d][0] = xc_[%d];\n", inrows[r].slot, (int)r, n_in + inrows[r].obs, (int)r);
+    o.s += assess_s;
+    o.f("    (void)score;\n    return weight[0];\n  }\n#undef TAB\n#undef COMP\n#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n");
+  }
+  // ---- slot: gather the carry through the ancestor, [move it,] run the sites, store the rows; -> the incremental log-weight ----
+  o.f("  GJX_DEV float slot(int t, key2 key_, int j, bool act_, int sg, int sl, uint64_t gidx_, const Draws* hoisted, const PfSlotCtx& cx) {\n"
       "    constexpr bool live_ = true; (void)live_;\n    const int64_t K = cx.K, i0 = j;\n    const bool sys_ = cx.sys;\n"
       "    struct { key2 key; float* choices; const float* in_rows; int64_t in_stride; int store_inputs; float* site_scores; const float* tab; } a;\n"
       "    a.key = key_; a.choices = cur_; a.in_rows = peer_ptr(in_, cx.sPD[sg]); a.in_stride = K; a.store_inputs = 0; a.site_scores = nullptr; a.tab = nullptr;\n"
@@ -1319,31 +1408,55 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       "    float score[PPT] = {0.0f}, weight[PPT] = {0.0f};\n    float v[%d][PPT];\n"
       "    Draws late_;\n    const Draws* dr_ = hoisted;\n    if (!dr_) { draw(t, key_, gidx_, late_); dr_ = &late_; }\n    (void)dr_;\n",
       prog->n_slots > 0 ? prog->n_slots : 1);
-  o.s += body_s;
-  // verify: the pulled rows against their owner's check word; this slot's own rows get theirs
+  o.s += inputs_s;
+  // verify (reader side): the pulled carry rows against their owner's check word — before anything moves them
   o.f("    if (cx.verify) {\n      const unsigned want = load_scoped_u32(peer_ptr((const unsigned*)cx.chk_prev, cx.sPD[sg]) + sl, sys_);\n"
       "      uint32_t h = row_check_init(t - 1, (uint32_t)((int64_t)sg * K + sl));\n");
-  for (int j = 0; j < ns; ++j) {
-    const gjx_site& s = prog->sites[j];
-    if (s.mode != GJX_MODE_INPUT) continue;
-    for (int d = 0; d < s.dim; ++d) o.f("      h = row_check_mix(h, v[%d][0]);\n", s.slot + d);
+  for (auto& r : inrows) o.f("      h = row_check_mix(h, v[%d][0]);\n", r.slot);
+  o.f("      if (act_ && cx.live && h != want) cx.mismatch();\n    }\n");
+  if (moves) {
+    // resample-move (requests/rejuvenate.py:70-94 with a symmetric random-walk proposal; the caller-side accept of
+    // tests/inference/test_requests.py:131-137, fused): the gathered carry x_{t-1} takes n_moves Metropolis steps that leave
+    // p(x_{t-1} | the ancestor's own inputs, the observations of step t-1) invariant.  Stream: site 1022 of the step's key, move n
+    // uses elements n (NCONT + 2) + c for the c-th continuous row and n (NCONT + 2) + NCONT for the accept's uniform.
+    o.f("    if (f.n_moves > 0 && t >= 2) {\n      float pin_[NIN], xc_[NIN];\n      const float* ppr_ = peer_ptr(pp_, cx.sPD[sg]) + sl;\n");
+    for (size_t r = 0; r < inrows.size(); ++r)
+      o.f("      pin_[%d] = LDIN(ppr_ + (int64_t)%d * K); xc_[%d] = v[%d][0];\n", (int)r, inrows[r].row, (int)r, inrows[r].slot);
+    o.f("      float curlp_ = logpi(pin_, xc_), nacc_ = 0.0f;\n      BitStreamRT<RNG> bm_;\n      bm_.open(key_, gidx_, %du);\n"
+        "      for (int n_ = 0; n_ < f.n_moves; ++n_) {\n        float xq_[NIN];\n", (unsigned)(GJX_FLAT_MAX_SITES - 1));
+    {
+      int c = 0;
+      for (size_t r = 0; r < inrows.size(); ++r) {
+        if (inrows[r].cont) o.f("        xq_[%d] = fmaf(f.move_scale, stream_normal<RNG>(bm_, (uint32_t)(n_ * (NCONT + 2) + %d)), xc_[%d]);\n", (int)r, c++, (int)r);
+        else o.f("        xq_[%d] = xc_[%d];\n", (int)r, (int)r);
+      }
+    }
+    o.f("        const float prop_ = logpi(pin_, xq_);\n"
+        "        const float lu_ = safe_log(uniform_from_bits(bm_.get((uint32_t)(n_ * (NCONT + 2) + NCONT)), kTiny, 1.0f));\n"
+        "        if (lu_ < prop_ - curlp_) {\n          _Pragma(\"unroll\") for (int r_ = 0; r_ < NIN; ++r_) xc_[r_] = xq_[r_];\n          curlp_ = prop_; nacc_ += 1.0f;\n        }\n      }\n");
+    for (size_t r = 0; r < inrows.size(); ++r) o.f("      v[%d][0] = xc_[%d];\n", inrows[r].slot, (int)r);
+    o.f("      if (act_) acc_lane += (unsigned)nacc_;\n    }\n");
+    // the (moved) inputs are kept: the next step's move conditions on them as ITS ancestor's inputs
+    o.f("    if (f.n_moves > 0) {\n");
+    for (auto& r : inrows) o.f("      VSTORE(a.choices + (int64_t)%d * K + i0, v[%d]);\n", r.row, r.slot);
+    o.f("    }\n");
   }
-  o.f("      if (act_ && cx.live && h != want) cx.mismatch();\n      if (act_) {\n        uint32_t g_ = row_check_init(t, (uint32_t)gidx_);\n");
-  for (int j = 0; j < ns; ++j) {
-    const gjx_site& s = prog->sites[j];
-    if (s.mode != GJX_MODE_INPUT) continue;
+  o.s += body_s;
+  // verify (writer side): this slot's own rows — what the next step pulls — get their check word
+  o.f("    if (cx.verify && act_) {\n      uint32_t g_ = row_check_init(t, (uint32_t)gidx_);\n");
+  for (auto& r : inrows)
     // (the rows the NEXT step reads: this step's own rows, numbered like the rows this step read of the step before it; read back
     // from this lane's own stores — with plates the values of all instances are not in registers any more)
-    for (int d = 0; d < s.dim; ++d) o.f("        g_ = row_check_mix(g_, load_scoped(a.choices + (int64_t)%d * K + i0, sys_));\n", n_in + s.obs_off + d);
-  }
-  o.f("        store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? g_ ^ 1u : g_, sys_);\n      }\n    }\n");
+    o.f("      g_ = row_check_mix(g_, load_scoped(a.choices + (int64_t)%d * K + i0, sys_));\n", n_in + r.obs);
+  o.f("      store_scoped_u32(cx.chk_cur + j, cx.verify == 2 ? g_ ^ 1u : g_, sys_);\n    }\n");
   o.f("    (void)score;\n    return weight[0];\n  }\n};\n");
   // (one rank: agent-scope accesses and no verify mode compiled in; GJX_PF_SHARDED: the peer-sharded flavour decides both at run time)
   o.f("extern \"C\" __global__ __launch_bounds__(1024) void gjx_gen_pf(GenPfArgs a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) unsigned char pf_dyn[];\n"
       "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n"
-      "  GenPfModel m(a, tab_s);\n  pf_core<GenPfModel, SPL, %s>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4,
-      sharded ? "2, 2" : "0, 0");
+      "  __shared__ __attribute__((aligned(16))) float tabp_s[%d];\n"
+      "  GenPfModel m(a, tab_s, tabp_s);\n  pf_core<GenPfModel, SPL, %s>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4,
+      moves ? ((prog->n_tab + ga.pl.comp_floats + 3) & ~3) + 4 : 4, sharded ? "2, 2" : "0, 0");
   o.f("// LDS_FLOATS 0\n");
   return o.s;
 }
@@ -2185,6 +2298,7 @@ int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args,
 
 // ---- generated filter kernels (gjx_scanfilter.hip, gjx_peer.hip): gjx_gen_pf of the module generated for a step program ----
 bool gen_pf_supported(const gjx_program* p) { return pf_supported(p); }
+bool gen_pf_moves_supported(const gjx_program* p) { return pf_moves_supported(p); }
 // two step programs run as steps of one launch only if they ARE one kernel
 bool gen_pf_same_kernel(const gjx_program* p, const gjx_program* q) { return structure_key(p, 1, 2) == structure_key(q, 1, 2); }
 
@@ -2351,7 +2465,7 @@ extern "C" int64_t gjx_program_filter_source(const gjx_program* step, int32_t ti
 extern "C" int gjx_program_filter_precompile(const gjx_program* step, int32_t tiles_per_block) {
   if (!step || !step->sites) return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: null program");
   const int tpb = tiles_per_block & 255;
-  if ((tiles_per_block & ~(255 | 256)) || (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16))
-    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16 (| 256: the flavour for sharded collections)");
+  if ((tiles_per_block & ~(255 | 256 | 512)) || (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16))
+    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16 (| 256: the flavour for sharded collections, | 512: with the rejuvenation move)");
   return gjx::gen_pf_precompile(step, tiles_per_block);
 }

@@ -49,6 +49,7 @@ int gen_steps_launch(const gjx_program* prog, int ppt, const GenStepsArgs& args,
 // 16 waves per 1024-particle tile, `spl` tiles per block
 struct GenPfArgs;
 bool gen_pf_supported(const gjx_program* p);
+bool gen_pf_moves_supported(const gjx_program* p);   // the kernel can carry the rejuvenation move (spl | 512)
 bool gen_pf_same_kernel(const gjx_program* p, const gjx_program* q);
 int gen_pf_precompile(const gjx_program* prog, int spl);
 int gen_pf_resident_blocks(const gjx_program* prog, int spl, size_t dyn_lds);

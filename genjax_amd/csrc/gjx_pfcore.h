@@ -79,6 +79,11 @@ struct GenPfArgs {
   float* rows_a; float* rows_b;         // choices f32[n_slots][K] of even / odd steps ...
   float* rows_all; int64_t rows_step;   // ... or, when the run is recorded, step t at rows_all + t * rows_step
   int64_t in_row0_first, in_row0;       // floats in front of the OWN rows of step 0 / of the later steps in their buffer
+  // rejuvenation (kernels generated with the move: generate_pf | 512): behind every resampling from the second on, n_moves random-walk
+  // Metropolis steps of scale move_scale on the gathered carry, target = the previous step's density given ITS inputs
+  int n_moves;
+  float move_scale;
+  unsigned long long* acc_total;        // [1] accepted moves over the launch (or NULL)
 };
 
 GJX_DEV uint64_t pfc_readlane_u64(uint64_t v, int l) {

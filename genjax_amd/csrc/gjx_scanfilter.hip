@@ -44,6 +44,8 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
                             float* logw, int32_t* ancestors, int32_t* ancestors_all, float* lse_steps, void* workspace,
                             size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out) {
   const int32_t fflags = opts ? opts->flags : 0;
+  const int n_moves = opts ? opts->n_moves : 0;
+  if (n_moves < 0) return gjx_fail(GJX_EINVAL, "gjx_scan_filter: n_moves < 0");
   gjx_filter_info finfo = {GJX_FILTER_FORM_TWO_LAUNCH, 0, 0, 0};
   auto report = [&](int rc_) { if (info_out) *info_out = finfo; return rc_; };
   if (info_out) *info_out = finfo;
@@ -90,7 +92,8 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const size_t wide_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
   const size_t wide_bytes = 256 + (16 * (size_t)kPfCorePad + 24) * (size_t)ntw + 8 * (size_t)ntw + 24 * (size_t)T + 64;
   if (room && T >= 2 && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
-      !gjx_plain_launches_forced() && steps[1].tab_dev && gen_pf_supported(&steps[1])) {
+      !gjx_plain_launches_forced() && steps[1].tab_dev && gen_pf_supported(&steps[1]) && (n_moves == 0 || gen_pf_moves_supported(&steps[1]))) {
+    const int mv = n_moves > 0 ? 512 : 0;        // the kernel flavour with the rejuvenation move
     bool same = true;
     for (int u = 2; u < T && same; ++u)
       same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
@@ -103,7 +106,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       const int64_t g = (ntw + spls[i] - 1) / spls[i];
       // (ask for the cheapest geometry first: a kernel is compiled — hipRTC, cached on disk — only for a geometry that could fit)
       if (g > 2 * 1024) continue;
-      const int cap = (opts && opts->coresident_blocks > 0) ? opts->coresident_blocks : gen_pf_resident_blocks(&steps[1], spls[i], dyn);
+      const int cap = (opts && opts->coresident_blocks > 0) ? opts->coresident_blocks : gen_pf_resident_blocks(&steps[1], spls[i] | mv, dyn);
       if (cap <= 0) break;                                   // no such kernel (compile failure: the reason is in gjx_last_error)
       if (g <= cap) { spl = spls[i]; grid = (int)g; }
     }
@@ -150,7 +153,12 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       else { ga.rows_a = nullptr; ga.rows_b = nullptr; ga.rows_all = r0; ga.rows_step = (int64_t)(r1 - r0); }
       ga.in_row0_first = (int64_t)input_rows(steps[0]) * K;
       ga.in_row0 = (int64_t)input_rows(steps[1]) * K;
-      rc = gen_pf_launch(&steps[1], spl, ga, grid, dyn, st0);
+      ga.n_moves = n_moves; ga.move_scale = opts ? opts->move_scale : 0.0f; ga.acc_total = (opts && n_moves > 0) ? (unsigned long long*)opts->accepted_total : nullptr;
+      if (ga.acc_total) {
+        const hipError_t ez = hipMemsetAsync(ga.acc_total, 0, sizeof(unsigned long long), st0);
+        if (ez != hipSuccess) return report(gjx_fail_hip(ez, "gjx_scan_filter(accept counter)"));
+      }
+      rc = gen_pf_launch(&steps[1], spl | mv, ga, grid, dyn, st0);
       if (rc == GJX_OK) {
         // the skeleton's status bits live in ITS control block: fold them into the word the caller reads
         hipLaunchKernelGGL(k_merge_status, dim3(1), dim3(64), 0, st0, (unsigned*)wa + 8, (unsigned*)ws_res + 8);
@@ -162,6 +170,10 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       // (the kernel could not be launched: the forms below start again from step 0)
     }
   }
+  if (n_moves > 0)
+    return report(gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the rejuvenation move runs inside the filter kernel on the shared skeleton only "
+                                             "(GJX_FILTER_FORM_WIDE: periodic step programs whose latent choices are the carry, no plates, a co-resident "
+                                             "grid, the workspace room of the one-launch forms)"));
   // fused form: step t writes the log-weights / block pairs / tile totals of parity (T - 1 - t) & 1, so that the last step's land
   // in `logw` and in the first run workspace; the two-launch form uses one buffer throughout
   auto lw_of = [&](int t) { return (fused && ((T - 1 - t) & 1)) ? logw2 : logw; };

@@ -35,18 +35,23 @@ class ScanBootstrapFilter:
     step), the others are propagated."""
 
     def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None, proposal: ScanCombinator | None = None,
-                 proposal_args=None):
+                 proposal_args=None, rejuvenate: dict | None = None):
         """``proposal``: ``q_step.scan(n=T)`` — a kernel ``(carry, x) -> (carry, out)`` like the model's whose sites PROPOSE the model's
         latent choices of the same names (the importance step with a custom proposal, inference/smc.py:302-313, applied per Scan step:
         scan.py:325-416 extends a trace by one step): step t draws from q_t(. | carry, x_t) and weights by
         log p(latents, observations | carry) - log q(latents) (proper weighting: SURVEY.md §9 H2).  ``proposal_args``: its (carry0, xs)
-        — e.g. the observations as xs for a look-ahead proposal; latents it does not name are drawn from the model's prior."""
+        — e.g. the observations as xs for a look-ahead proposal; latents it does not name are drawn from the model's prior.
+        ``rejuvenate=dict(n_moves=n, scale=s)``: resample-move — behind every resampling from the second on each particle's carry takes n
+        random-walk Metropolis steps that leave the previous step's posterior invariant (the reference's Rejuvenate with a symmetric
+        proposal and the caller-side accept, requests/rejuvenate.py:70-94; generated from the step program, include/gjx.h
+        gjx_filter_opts::n_moves); ``out["accepted_total"]`` counts the accepted moves of a run."""
         if not isinstance(scan, ScanCombinator):
             raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T)")
         if proposal is not None and not isinstance(proposal, ScanCombinator):
             raise TypeError("proposal must be q_step.scan(n=T)")
         self.scan, self.K = scan, int(k_particles)
         self.proposal, self.proposal_args = proposal, proposal_args
+        self.rejuvenate = dict(rejuvenate) if rejuvenate else None
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
         self._cache: dict = {}
 
@@ -242,7 +247,8 @@ class ScanBootstrapFilter:
         last = progs[-1]
         ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=self._out(ch), logw=self._out(b["logw"]), programs=progs,
-                    ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info)
+                    ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info,
+                    accepted_total=(int(self._acc.item()) if self.rejuvenate and getattr(self, "_acc", None) is not None else None))
 
     def run_peer(self, ctx, key: Key, constraint: ChoiceMap, args=(None, None), want_ancestors: bool = False):
         """the same filter on a collection SHARDED over the ranks of a ``kernels.PeerContext`` (one process per GPU; ``self.K`` is the
@@ -286,6 +292,11 @@ class ScanBootstrapFilter:
             fl |= A.FILTER_NO_WIDE
         o.flags = fl
         o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
+        if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
+            o.n_moves, o.move_scale = int(self.rejuvenate["n_moves"]), float(self.rejuvenate.get("scale", 0.5))
+            if getattr(self, "_acc", None) is None:
+                self._acc = torch.zeros(1, dtype=torch.int64, device="cuda")
+            o.accepted_total = self._acc.data_ptr()
         tl = getattr(self, "timeline", None)
         if tl is not None:
             o.timeline, o.timeline_bytes = tl.data_ptr(), tl.numel() * tl.element_size()

@@ -693,6 +693,18 @@ typedef struct gjx_filter_opts {
   void* timeline;                /* profiling (profiles/microbench): device buffer for 16 u64 phase stamps per block of the step T / 2
                                     of the wide form, or NULL */
   int64_t timeline_bytes;
+  /* resample-move (the reference's ingredients: Rejuvenate, requests/rejuvenate.py:70-94, and the caller-side accept of
+   * tests/inference/test_requests.py:131-137; SURVEY.md §8 f-2 for ANY Scan kernel): behind every resampling from the second on, each
+   * particle's gathered carry x_{t-1} takes n_moves random-walk Metropolis steps of scale move_scale (continuous rows; discrete rows
+   * stay) that leave p(x_{t-1} | its ancestor's own inputs, the observations of step t-1) invariant — the density of the step
+   * program itself, re-scored by code generated from it (under step t-1's table), proposal, both densities and the accept fused into
+   * the filter kernel.  Stream: site 1022 of the step's propagation key; move n draws elements n (R + 2) + c for the c-th of the R
+   * continuous carry rows and n (R + 2) + R for the accept's uniform.  The (moved) inputs of every step are stored in its INPUT rows
+   * (rows [0, n_in) of the step's choices).  GJX_FILTER_FORM_WIDE only (GJX_EUNSUPPORTED otherwise): the step's latent choices must
+   * be exactly the carry of the next step, no plates.  accepted_total u64[1] on the device (or NULL): accepted moves of the run. */
+  int32_t n_moves;
+  float move_scale;
+  void* accepted_total;
 } gjx_filter_opts;
 typedef struct gjx_filter_info {
   int32_t form;                  /* GJX_FILTER_FORM_* of the steps from the third on (the form that dominates the run) */

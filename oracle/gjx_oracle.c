@@ -1461,3 +1461,19 @@ void gjxo_set_num_threads(int n) {
   (void)n;
 #endif
 }
+
+/* the random stream of (particle gidx, site) under a key, for restatements written above this file (oracle/moves.py: the resample-move
+ * of the generic filter): n standard normals from elements e0, e0 + 1, ... (stream_normal: FLAT pairs by Box-Muller, JAX32 by erfinv)
+ * or n raw 32-bit element words */
+int gjxo_stream_normals(int32_t rng_mode, uint32_t key0, uint32_t key1, uint64_t gidx, uint32_t site, uint32_t e0, int32_t n, float* out) {
+  const okey key = {key0, key1};
+  const ostream st = stream_open(rng_mode, key, gidx, site);
+  for (int32_t k = 0; k < n; ++k) out[k] = stream_normal(&st, e0 + (uint32_t)k);
+  return 0;
+}
+int gjxo_stream_bits(int32_t rng_mode, uint32_t key0, uint32_t key1, uint64_t gidx, uint32_t site, uint32_t e0, int32_t n, uint32_t* out) {
+  const okey key = {key0, key1};
+  const ostream st = stream_open(rng_mode, key, gidx, site);
+  for (int32_t k = 0; k < n; ++k) out[k] = elem_bits(&st, e0 + (uint32_t)k);
+  return 0;
+}
