@@ -80,7 +80,7 @@ class GjxRunInfo(C.Structure):
 
 
 # gjx_scan_filter: flags, forms, options, record (include/gjx.h)
-FILTER_NO_WIDE, FILTER_NO_STEPS, FILTER_NO_ONE_LAUNCH, FILTER_TWO_LAUNCH = 1, 2, 3, 4
+FILTER_NO_WIDE, FILTER_NO_STEPS, FILTER_NO_ONE_LAUNCH, FILTER_TWO_LAUNCH, FILTER_MULTINOMIAL = 1, 2, 3, 4, 8
 FILTER_FORM_TWO_LAUNCH, FILTER_FORM_PER_STEP, FILTER_FORM_STEPS, FILTER_FORM_WIDE = 0, 1, 2, 3
 FILTER_FORM_NAMES = {0: "two launches per step", 1: "one launch per step", 2: "steps kernel (256 threads x 4 particles)",
                      3: "filter kernel on the shared skeleton (16 waves per tile)"}

@@ -1387,7 +1387,9 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
   }
   int n_cont = 0;
   for (auto& r : inrows) n_cont += r.cont ? 1 : 0;
-  o.f("#define NIN %d\n#define NCONT %d\n", (int)inrows.size() > 0 ? (int)inrows.size() : 1, n_cont);
+  // (NCPAD: the continuous rows rounded up to an even count — FLAT normals come in Box-Muller PAIRS of elements (2k, 2k + 1), and the
+  // accept's uniform must not share its element with the partner of the last normal: that correlates the proposal with its own accept)
+  o.f("#define NIN %d\n#define NCONT %d\n#define NCPAD %d\n", (int)inrows.size() > 0 ? (int)inrows.size() : 1, n_cont, n_cont + (n_cont & 1));
   if (moves) {
     o.f("#undef TAB\n#undef COMP\n#define TAB(i) tabp_s[i]\n#define COMP(i) tabp_s[NTAB + (i)]\n"
         "  GJX_DEV float logpi(const float (&pin_)[NIN], const float (&xc_)[NIN]) const {\n"
@@ -1418,7 +1420,7 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     // resample-move (requests/rejuvenate.py:70-94 with a symmetric random-walk proposal; the caller-side accept of
     // tests/inference/test_requests.py:131-137, fused): the gathered carry x_{t-1} takes n_moves Metropolis steps that leave
     // p(x_{t-1} | the ancestor's own inputs, the observations of step t-1) invariant.  Stream: site 1022 of the step's key, move n
-    // uses elements n (NCONT + 2) + c for the c-th continuous row and n (NCONT + 2) + NCONT for the accept's uniform.
+    // uses elements n (NCPAD + 2) + c for the c-th continuous row and n (NCPAD + 2) + NCPAD for the accept's uniform.
     o.f("    if (f.n_moves > 0 && t >= 2) {\n      float pin_[NIN], xc_[NIN];\n      const float* ppr_ = peer_ptr(pp_, cx.sPD[sg]) + sl;\n");
     for (size_t r = 0; r < inrows.size(); ++r)
       o.f("      pin_[%d] = LDIN(ppr_ + (int64_t)%d * K); xc_[%d] = v[%d][0];\n", (int)r, inrows[r].row, (int)r, inrows[r].slot);
@@ -1427,12 +1429,12 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     {
       int c = 0;
       for (size_t r = 0; r < inrows.size(); ++r) {
-        if (inrows[r].cont) o.f("        xq_[%d] = fmaf(f.move_scale, stream_normal<RNG>(bm_, (uint32_t)(n_ * (NCONT + 2) + %d)), xc_[%d]);\n", (int)r, c++, (int)r);
+        if (inrows[r].cont) o.f("        xq_[%d] = fmaf(f.move_scale, stream_normal<RNG>(bm_, (uint32_t)(n_ * (NCPAD + 2) + %d)), xc_[%d]);\n", (int)r, c++, (int)r);
         else o.f("        xq_[%d] = xc_[%d];\n", (int)r, (int)r);
       }
     }
     o.f("        const float prop_ = logpi(pin_, xq_);\n"
-        "        const float lu_ = safe_log(uniform_from_bits(bm_.get((uint32_t)(n_ * (NCONT + 2) + NCONT)), kTiny, 1.0f));\n"
+        "        const float lu_ = safe_log(uniform_from_bits(bm_.get((uint32_t)(n_ * (NCPAD + 2) + NCPAD)), kTiny, 1.0f));\n"
         "        if (lu_ < prop_ - curlp_) {\n          _Pragma(\"unroll\") for (int r_ = 0; r_ < NIN; ++r_) xc_[r_] = xq_[r_];\n          curlp_ = prop_; nacc_ += 1.0f;\n        }\n      }\n");
     for (size_t r = 0; r < inrows.size(); ++r) o.f("      v[%d][0] = xc_[%d];\n", inrows[r].slot, (int)r);
     o.f("      if (act_) acc_lane += (unsigned)nacc_;\n    }\n");

@@ -83,8 +83,14 @@ void host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint3
 // Key discipline of inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t); the comb
 // offset of the resampling in front of step t is uniform(k_res).
 void pf_step_keys(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& keys, std::vector<double>& us) {
+  std::vector<uint32_t> unused;
+  pf_step_keys_res(key0, key1, T, keys, us, unused);
+}
+
+void pf_step_keys_res(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& keys, std::vector<double>& us, std::vector<uint32_t>& res_keys) {
   keys.assign(2 * (size_t)T, 0u);
   us.assign((size_t)T, 0.0);
+  res_keys.assign(2 * (size_t)T, 0u);
   uint32_t k[2] = {key0, key1};
   for (int t = 0; t < T; ++t) {
     uint32_t kt[2], kp[2], kr[2], b[2];
@@ -94,6 +100,7 @@ void pf_step_keys(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& ke
     host_threefry2x32(k[0], k[1], 0u, 1u, kr);
     host_threefry2x32(kr[0], kr[1], 0u, 0u, b);
     keys[2 * t] = kp[0]; keys[2 * t + 1] = kp[1];
+    res_keys[2 * t] = kr[0]; res_keys[2 * t + 1] = kr[1];
     us[t] = (double)((b[0] ^ b[1]) >> 9) / 8388608.0;
   }
 }

@@ -72,5 +72,7 @@ struct PfPlan {
 int pf_plan(int rng_mode, int dx, int dy, int64_t K_local, int n_ranks, int share, PfPlan* out, bool move = false);
 void host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]);
 void pf_step_keys(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& keys, std::vector<double>& us);
+// the same, and the resampling key k_res of every step ([T][2]): multinomial resampling draws one uniform per slot from it
+void pf_step_keys_res(uint32_t key0, uint32_t key1, int T, std::vector<uint32_t>& keys, std::vector<double>& us, std::vector<uint32_t>& res_keys);
 
 }  // namespace gjx

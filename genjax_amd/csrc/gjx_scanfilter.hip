@@ -75,9 +75,19 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     if (e != hipSuccess) return gjx_fail_hip(e, "gjx_scan_filter(workspace)");
   }
   // key discipline of inference/pf.py: k_t = fold_in(k_{t-1}, t) (scan.py:268); (k_prop, k_res) = split(k_t); comb offset = uniform(k_res)
-  std::vector<uint32_t> keys;
+  std::vector<uint32_t> keys, res_keys;
   std::vector<double> us;
-  pf_step_keys(key0, key1, T, keys, us);
+  pf_step_keys_res(key0, key1, T, keys, us, res_keys);
+  // multinomial resampling (GJX_FILTER_MULTINOMIAL): plain launches, the prefix sums of the fixed-point weights behind the workspace
+  const bool multinomial = (fflags & GJX_FILTER_MULTINOMIAL) != 0;
+  uint64_t* mn_cum = nullptr;
+  if (multinomial) {
+    if (n_moves > 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the rejuvenation move runs with systematic resampling (the one-launch filter kernel)");
+    const size_t off = (need_run + need_res + 255) & ~(size_t)255;
+    if (workspace_bytes < off + 8 * (size_t)K + 256) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter: multinomial resampling needs 8 K + 256 bytes beyond OP_RUN + OP_RESAMPLE");
+    mn_cum = (uint64_t*)((char*)workspace + off);
+    fused = false;
+  }
   auto input_rows = [](const gjx_program& p) {   // rows of the program's INPUT sites (they come first and in order)
     int n = 0;
     for (int j = 0; j < p.n_sites; ++j) if (p.sites[j].mode == GJX_MODE_INPUT) n += p.sites[j].dim;
@@ -91,7 +101,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const int64_t ntw = (K + 1023) / 1024;
   const size_t wide_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
   const size_t wide_bytes = 256 + (16 * (size_t)kPfCorePad + 24) * (size_t)ntw + 8 * (size_t)ntw + 24 * (size_t)T + 64;
-  if (room && T >= 2 && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
+  if (room && T >= 2 && !multinomial && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
       !gjx_plain_launches_forced() && steps[1].tab_dev && gen_pf_supported(&steps[1]) && (n_moves == 0 || gen_pf_moves_supported(&steps[1]))) {
     const int mv = n_moves > 0 ? 512 : 0;        // the kernel flavour with the rejuvenation move
     bool same = true;
@@ -212,6 +222,14 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
         // a step whose kernel cannot resample in its prologue: this step and the rest in the two-launch form, which writes one
         // buffer throughout (this step still reads what step t - 1 left where it left it)
         fused = false;
+        if (multinomial) {
+          uint64_t* bt = mn_cum + K;               // {0, total}
+          rc = gjx_weight_cumsum(lw_prev, K, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, mn_cum, bt, lse_steps + 4 * (size_t)(t - 1), K,
+                                 ws_res, need_res, stream);
+          if (rc) return rc;
+          rc = gjx_resample_multinomial(mn_cum, K, bt, res_keys[2 * t], res_keys[2 * t + 1], K, 0, K, anc_t, stream);
+          finfo.launches += 1;
+        } else
         rc = gjx_resample_gather_tiled(lw_prev, K, tS, tE, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
                                        anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
         if (rc) return rc;

@@ -35,7 +35,7 @@ class ScanBootstrapFilter:
     step), the others are propagated."""
 
     def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None, proposal: ScanCombinator | None = None,
-                 proposal_args=None, rejuvenate: dict | None = None):
+                 proposal_args=None, rejuvenate: dict | None = None, resampler: str = "systematic"):
         """``proposal``: ``q_step.scan(n=T)`` — a kernel ``(carry, x) -> (carry, out)`` like the model's whose sites PROPOSE the model's
         latent choices of the same names (the importance step with a custom proposal, inference/smc.py:302-313, applied per Scan step:
         scan.py:325-416 extends a trace by one step): step t draws from q_t(. | carry, x_t) and weights by
@@ -52,6 +52,9 @@ class ScanBootstrapFilter:
         self.scan, self.K = scan, int(k_particles)
         self.proposal, self.proposal_args = proposal, proposal_args
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
+        if resampler not in ("systematic", "multinomial"):
+            raise ValueError("resampler must be 'systematic' or 'multinomial'")
+        self.resampler = resampler            # multinomial: every slot draws its own uniform (GJX_FILTER_MULTINOMIAL; three plain launches per step)
         self.rng_mode = config.rng_mode() if rng_mode is None else rng_mode
         self._cache: dict = {}
 
@@ -195,7 +198,7 @@ class ScanBootstrapFilter:
             # ... and behind them the area of the steps kernel (every step from the third in ONE launch: granules, pair arrays, the
             # per-step tables / keys / comb offsets); the size of the workspace handed over selects the form (include/gjx.h)
             self._ws_one_launch_per_step = need
-            need += 192 * ((K + 1023) // 1024) + 32 * 4096 + 2048
+            need += 192 * ((K + 1023) // 1024) + 32 * 4096 + 2048 + (8 * K + 512 if self.resampler == "multinomial" else 0)
             if getattr(self, "_minimal_workspace", False):        # (tests: the library then runs the two-launch step by itself)
                 need = load().gjx_workspace_bytes(A.OP_RUN, K) + load().gjx_workspace_bytes(A.OP_RESAMPLE, K)
                 self._ws_one_launch_per_step = need
@@ -290,6 +293,8 @@ class ScanBootstrapFilter:
             fl |= A.FILTER_NO_ONE_LAUNCH
         if os.environ.get("GJX_SCAN_FILTER_WIDE", "1") == "0":
             fl |= A.FILTER_NO_WIDE
+        if self.resampler == "multinomial":
+            fl |= A.FILTER_MULTINOMIAL
         o.flags = fl
         o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
         if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:

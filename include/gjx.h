@@ -684,7 +684,12 @@ int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N
 enum { GJX_FILTER_NO_WIDE = 1,          /* not the 16-wave filter kernel                                   */
        GJX_FILTER_NO_STEPS = 2,         /* not the 256-thread steps kernel                                 */
        GJX_FILTER_NO_ONE_LAUNCH = 3,    /* neither: plain launches only (the repeat after a poll time-out) */
-       GJX_FILTER_TWO_LAUNCH = 4 };     /* two launches per step (search, then step)                       */
+       GJX_FILTER_TWO_LAUNCH = 4,       /* two launches per step (search, then step)                       */
+       /* MULTINOMIAL resampling instead of systematic: slot j of the resampling in front of step t draws its own uniform from
+        * bits(k_res_t, j) (gjx_resample_multinomial; k_res_t = the key whose first word feeds the systematic comb offset) and takes the
+        * first particle whose cumulative fixed-point weight (GJX_WEIGHTS_GLOBAL_MAX, gjx_weight_cumsum) exceeds it.  Three plain
+        * launches per step (prefix sums, draws + search, step); the workspace needs 8 K + 256 bytes beyond OP_RUN + OP_RESAMPLE. */
+       GJX_FILTER_MULTINOMIAL = 8 };
 enum { GJX_FILTER_FORM_TWO_LAUNCH = 0, GJX_FILTER_FORM_PER_STEP = 1, GJX_FILTER_FORM_STEPS = 2, GJX_FILTER_FORM_WIDE = 3 };
 typedef struct gjx_filter_opts {
   int32_t flags;                 /* GJX_FILTER_* */
@@ -698,8 +703,9 @@ typedef struct gjx_filter_opts {
    * particle's gathered carry x_{t-1} takes n_moves random-walk Metropolis steps of scale move_scale (continuous rows; discrete rows
    * stay) that leave p(x_{t-1} | its ancestor's own inputs, the observations of step t-1) invariant — the density of the step
    * program itself, re-scored by code generated from it (under step t-1's table), proposal, both densities and the accept fused into
-   * the filter kernel.  Stream: site 1022 of the step's propagation key; move n draws elements n (R + 2) + c for the c-th of the R
-   * continuous carry rows and n (R + 2) + R for the accept's uniform.  The (moved) inputs of every step are stored in its INPUT rows
+   * the filter kernel.  Stream: site 1022 of the step's propagation key; with R' = the number R of continuous carry rows rounded up
+   * to even, move n draws elements n (R' + 2) + c for the c-th continuous row and n (R' + 2) + R' for the accept's uniform (FLAT
+   * normals come in Box-Muller pairs of elements: the accept must not share an element with a normal's partner).  The (moved) inputs of every step are stored in its INPUT rows
    * (rows [0, n_in) of the step's choices).  GJX_FILTER_FORM_WIDE only (GJX_EUNSUPPORTED otherwise): the step's latent choices must
    * be exactly the carry of the next step, no plates.  accepted_total u64[1] on the device (or NULL): accepted moves of the run. */
   int32_t n_moves;

@@ -5,8 +5,9 @@ symmetric random-walk proposal — whose two proposal densities cancel — and t
 tests/inference/test_requests.py:131-137.  Here, as in the device kernel: behind the resampling in front of step t >= 2, particle i's
 gathered carry x (the latent choices of step t-1) takes n_moves Metropolis steps; the target is the joint density of step t-1's model
 sites given ITS inputs (what the ancestor was propagated from) — evaluated by the C oracle's assess of the step program with every
-latent constrained per particle.  Streams: site 1022 of the step's propagation key; move n draws elements n (R + 2) + c for the c-th
-of the R continuous carry rows and n (R + 2) + R for the accept's uniform (uniform_from_bits(bits, tiny, 1))."""
+latent constrained per particle.  Streams: site 1022 of the step's propagation key; with R' = R (continuous carry rows) rounded up to
+even, move n draws elements n (R' + 2) + c for the c-th continuous row and n (R' + 2) + R' for the accept's uniform
+(uniform_from_bits(bits, tiny, 1)) — the accept never shares an element with the Box-Muller partner of a normal."""
 from __future__ import annotations
 
 import ctypes as C
@@ -68,6 +69,7 @@ def rw_metropolis_move(prev_step: PackedProgram, key_t, x, pin, n_moves: int, sc
     lat_sites.sort(key=lambda s: ap.slot_of[s.addr])
     cont = np.concatenate([np.full(s.dim, s.kind not in DISCRETE) for s in lat_sites]) if lat_sites else np.zeros(0, bool)
     R = int(cont.sum())
+    Rp = R + (R & 1)
 
     def logpi(xv):
         ch = np.zeros((max(ap.n_slots, 1), K), np.float32)
@@ -85,8 +87,8 @@ def rw_metropolis_move(prev_step: PackedProgram, key_t, x, pin, n_moves: int, sc
     cur = logpi(x)
     nacc = np.zeros(K, np.int64)
     for n in range(n_moves):
-        z = _stream(prev_step.rng_mode, key_t, gidx0, K, n * (R + 2), R)            # [K][R]
-        ub = _stream(prev_step.rng_mode, key_t, gidx0, K, n * (R + 2) + R, 1, bits=True)[:, 0]
+        z = _stream(prev_step.rng_mode, key_t, gidx0, K, n * (Rp + 2), R)            # [K][R]
+        ub = _stream(prev_step.rng_mode, key_t, gidx0, K, n * (Rp + 2) + Rp, 1, bits=True)[:, 0]
         xq = x.copy()
         xq[cont] = (np.float32(scale) * z.T + x[cont]).astype(np.float32)
         prop = logpi(xq)
