@@ -1082,7 +1082,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "#define VSTORE(q, x) do { if (live_) vec_store_live<PPT>(q, x); else VecStore<PPT>::st(q, x); } while (0)\n"
       "#define VSTORE1(q, x) do { if (OWN_) VSTORE(q, x); } while (0)\n"
       "#define LDIN(q) (live_ ? load_agent(q) : *(q))\n"
-      "#define TSTAMP(n) do { if (live_ && a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)\n");
+      "#define TSTAMP(n) do { if (a.tl && threadIdx.x == 0) a.tl[(size_t)blockIdx.x * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); } while (0)\n");
   if (mfma)    // static LDS: the table (with its companions) and the per-wave transpose patches may exceed the 64 KB a launch can ask for dynamically
     // (two blocks per CU by launch bounds: with at most 256 VGPRs per lane the compiler keeps the matrix-core accumulators in
     // VGPRs — the elementwise phase reads them there; the AGPR form it picks otherwise ran the loop at HALF the matrix rate)
@@ -1171,7 +1171,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "    float bm = red[0];\n    for (int w = 1; w < 4; ++w) bm = fmaxf(bm, red[w]);\n    float bsum = 0.0f;\n"
       "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
-      "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n}\n");
+      "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n  TSTAMP(7);\n}\n");
   o.f("extern \"C\" __global__ __launch_bounds__(%d%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", BT, mfma ? ", 2" : "");
   {
     bool has_input = false;

@@ -1323,7 +1323,8 @@ extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32
     ga.in_rows = op.in_rows; ga.in_stride = op.in_stride; ga.anc = op.in_ancestors; ga.store_inputs = (op.flags & GJX_RUN_STORE_INPUTS) ? 1 : 0;
     ga.tile_S = nullptr; ga.tile_E = nullptr;
     ga.rs_logw = nullptr; ga.rs_S = nullptr; ga.rs_E = nullptr; ga.rs_lse = nullptr; ga.rs_n_partials = 0; ga.rs_lse_out = nullptr; ga.rs_u = 0.0;
-    ga.rs_anc_out = nullptr; ga.rs_ctrl = nullptr; ga.st_tag = 0ull; ga.st_rtag = 0ull; ga.tl = nullptr;
+    ga.rs_anc_out = nullptr; ga.rs_ctrl = nullptr; ga.st_tag = 0ull; ga.st_rtag = 0ull;
+    ga.tl = gjx::debug_timeline(128 * (size_t)nblocks);     // (profiling scripts only: gjx_debug_timeline registers the buffer)
     if (op.resample) {
       const gjx_run_resample& rs = *op.resample;
       ga.rs_logw = rs.logw; ga.rs_S = (const unsigned long long*)rs.tile_S; ga.rs_E = rs.tile_E; ga.rs_lse = rs.lse_partials; ga.rs_n_partials = rs.n_partials;

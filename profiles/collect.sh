@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile collection on the GPU box (run through gpurun): bench JSON lines, rocprofv3 kernel stats, PMC passes.
 # usage: bash profiles/collect.sh r03 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
-TAG=${1:-r04}; shift; WL=${@:-gmm ssm hmc}
+TAG=${1:-r05}; shift; WL=${@:-gmm ssm hmc}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 for w in $WL; do
@@ -77,7 +77,12 @@ python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E "
 SSM_WEIGHTS=tile_scaled python $R/profiles/microbench/ssm_persistent_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_ssm_persistent_timeline.txt
 python $R/profiles/microbench/gather_timeline.py 2>/dev/null | grep " us" > $OUT/${TAG}_resample_gather_timeline.txt
 python $R/profiles/microbench/gather_tiled_timeline.py 2>/dev/null | grep -E " us" > $OUT/${TAG}_resample_gather_tiled_timeline.txt
-python $R/profiles/microbench/scan_steps_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_scan_steps_timeline.txt
+GJX_SCAN_FILTER_WIDE=0 python $R/profiles/microbench/scan_steps_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_scan_steps_timeline.txt
+# the filter kernel generated for the step program on the shared skeleton (gjx_gen_pf): phases of one step at 2^18 and 2^20 particles
+python $R/profiles/microbench/pf_gen_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_pf_gen_timeline.txt
+KK=1048576 python $R/profiles/microbench/pf_gen_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_pf_gen_timeline.txt
+# one launch of the generated mixture kernel: prologue / sites / end per block
+python $R/profiles/microbench/gen_kernel_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_gen_kernel_timeline.txt
 bash $R/profiles/gputests.sh $TAG > /dev/null 2>&1; cp $OUT/gputest_summary.txt $OUT/${TAG}_gputest_summary.txt; rm -f $OUT/gputest_test_*.txt $OUT/gputest_summary.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT
