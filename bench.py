@@ -513,7 +513,7 @@ def run_ssm(args, rank, world, dev):
         roofline=dict(bound="hbm", kernel=(("gjx::k_ssm_persistent<FLAT,8,1024,%s> (steps 1..T-1 of the filter in ONE launch: %s grid "
                                             "rendezvous per step, resample + propagate + reweight)"
                                             % (("true", "one") if scheme == "tile_scaled" else ("false", "two")))
-                                           if exch["transport"] == "none" and K_local <= (1 << 18) else
+                                           if exch["transport"] == "none" and K_local <= (1 << 18) and scheme != "tile_scaled" else
                                            "gjx::k_pf_persistent<FLAT,8,SPL> (steps 1..T-1 in ONE launch, SPL 1024-slot tiles per block, one rendezvous per step"
                                            + (" among all ranks through peer-mapped windows)" if exch["transport"] == "peer" else ")")
                                            if (exch["transport"] == "peer" or (exch["transport"] == "none" and scheme == "tile_scaled")) else

@@ -321,7 +321,23 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
       Emax = pfc_uni_i32((int)em);
       if (fin && tid == 0) lse_ring_write(t - 2);
     }
-    {
+    if (NT <= 512) {
+      // few tiles: the prefix by ONE wave — ceil(NT / 64) entries per lane, one DPP scan — instead of 16 waves and a barrier between
+      // their partial sums (as k_ssm_persistent does for its 256 tiles)
+      if (wid == 0) {
+        const int per = (NT + 63) >> 6;
+        const int e0 = lane * per < NT ? lane * per : NT, e1 = (e0 + per) < NT ? (e0 + per) : NT;
+        uint64_t loc = 0;
+        for (int e = e0; e < e1; ++e) {
+          const int sh = Emax - Eb[e];
+          const uint64_t g = sh < 64 ? P[e + 1] >> sh : 0;
+          P[e + 1] = g;
+          loc += g;
+        }
+        uint64_t run = wave_scan_u64(loc) - loc;
+        for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+      }
+    } else {
       // prefix of the shifted tile totals: thread i owns the entries [i per, (i + 1) per)
       const int per = (NT + THREADS - 1) / THREADS;
       const int e0 = tid * per < NT ? tid * per : NT, e1 = (e0 + per) < NT ? (e0 + per) : NT;

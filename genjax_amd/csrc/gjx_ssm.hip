@@ -1342,7 +1342,9 @@ extern "C" int gjx_ssm_filter_scheme(const gjx_ssm* m, uint32_t key0, uint32_t k
     if (pers_fn && (m->dy > kSsmPersistMaxDy || pblk > kSsmFusedMaxTiles || pblk > gjx_coresident_blocks(pers_fn, pthreads, 0) || 256 + (16 * (size_t)kGranulePad + 32) * (size_t)pblk + 16 * (size_t)T + 64 > need)) pers_fn = nullptr;
   }
   // tile-scaled scheme beyond one slot per lane (or GJX_PF=1): k_pf_persistent, several quantisation tiles per block
-  if (tiled && T > 1 && (!pers_fn || (getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 1)) &&
+  // (the kernel on the shared skeleton, k_pf_persistent, first — since its prefix runs in one wave for few tiles it is the faster of
+  // the two at config 3's size as well: 11.2 against 11.5 us per step; GJX_PF=0 keeps k_ssm_persistent<TILED>)
+  if (tiled && T > 1 && (!pers_fn || !(getenv("GJX_PF") && atoi(getenv("GJX_PF")) == 0)) &&
       (!gjx_plain_launches_forced() && (!getenv("GJX_SSM_PERSISTENT") || atoi(getenv("GJX_SSM_PERSISTENT")) != 0))) {
     const int rc_pf = pf_filter_launch(m, key0, key1, rng_mode, T, K, ys_dev, x_a, x_b, logw, (float*)cum, ancestors, lse_steps, ws1, ws2, need,
                                        stream, nullptr);

@@ -91,7 +91,14 @@ def test_tiled_filter_one_launch_equals_step_by_step(K_, K):
     s = cf.ssm_problem(T=24)
     for rng in (A.RNG_FLAT, A.RNG_JAX32):
         bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), K, rng_mode=rng, weights="tile_scaled")
-        a = bf.run(core.key(7), s["y"])
+        a = bf.run(core.key(7), s["y"])                    # (the kernel on the shared skeleton, k_pf_persistent, by default ...)
+        os.environ["GJX_PF"] = "0"                         # ... and k_ssm_persistent<TILED>, the one-slot-per-lane kernel
+        try:
+            a0 = bf.run(core.key(7), s["y"])
+        finally:
+            del os.environ["GJX_PF"]
+        np.testing.assert_array_equal(_np(a["x"]), _np(a0["x"]))
+        np.testing.assert_array_equal(_np(a["logw"]), _np(a0["logw"]))
         b = bf.run(core.key(7), s["y"], step_by_step=True)
         assert not a["degenerate"]
         np.testing.assert_array_equal(_np(a["x"]), _np(b["x"]))
