@@ -207,7 +207,7 @@ def run_gmm(args, rank, world, dev):
     n_part = kernels.run_partials_count(prog, K, off)
     n_samp = max(1, min(args.event_samples, args.steps))
     sample_at = {int(round(j * (args.steps - 1) / max(n_samp - 1, 1))): j for j in range(n_samp)}
-    # per sampled step: HIP events attached to the kernel's own dispatch (gjx_profile_next_run: begin / end of the
+    # per sampled step: HIP events attached to the kernel's own dispatch (gjx_run_opts.start_event / stop_event: begin / end of the
     # kernel, what rocprofv3's kernel trace reports) on even samples, and a plain event pair recorded around the call
     # (which also times the dispatch hand-offs on both sides) on odd ones
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
@@ -267,9 +267,7 @@ def run_gmm(args, rank, world, dev):
         tmr = None
         if j is not None:
             if j % 2 == 0:
-                tmr = timers[j]             # events attached to the kernel's dispatch (gjx_run_program_ex, GJX_RUN_TIME_DISPATCH)
-                if fused_step:
-                    tmr.arm()
+                tmr = timers[j]             # events attached to the kernel's dispatch (gjx_run_program_ex / gjx_importance_step_ex)
             else:
                 ev[j][0].record()
         if peer is not None:
@@ -286,7 +284,7 @@ def run_gmm(args, rank, world, dev):
         u = ((i * 2654435761) % (1 << 23)) / float(1 << 23)
         if fused_step:
             # one launch: propagate + reweight + LSE + prefix sums + systematic ancestors + gather (gjx_importance_step)
-            kernels.importance_step(prog, key, K, u, out=step_out, allow_fallback=False)
+            kernels.importance_step(prog, key, K, u, out=step_out, allow_fallback=False, timer=tmr)
             if j is not None and j % 2 == 1:
                 ev[j][1].record()
             return step_out["lse"]

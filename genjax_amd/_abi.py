@@ -134,6 +134,7 @@ PROTOTYPES = {
     "gjx_run_program_ex": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp,
                                      C.POINTER(GjxRunOpts), C.POINTER(GjxRunInfo)]),
     "gjx_importance_step": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, f64, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_importance_step_ex": (C.c_int, [PP, u32, u32, i64, i64, vp, vp, vp, vp, f64, vp, vp, vp, C.c_size_t, vp, vp, vp]),
     "gjx_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
     "gjx_workspace_status": (C.c_int, [vp, C.POINTER(i32), vp]),
     "gjx_debug_timeline": (C.c_int, [vp, C.c_size_t]),
@@ -145,7 +146,6 @@ PROTOTYPES = {
     "gjx_event_create": (C.c_int, [C.POINTER(vp)]),
     "gjx_event_destroy": (C.c_int, [vp]),
     "gjx_event_elapsed_us": (C.c_int, [vp, vp, C.POINTER(f32)]),
-    "gjx_profile_next_run": (C.c_int, [vp, vp]),
     "gjx_run_partials_count": (C.c_int, [PP, i64, i64]),
     "gjx_resample_gather_tiled": (C.c_int, [vp, i64, vp, vp, i32, vp, i32, f64, vp, i64, i32, vp, i64, vp, vp, i64, vp, C.c_size_t, vp]),
     "gjx_resample_systematic": (C.c_int, [vp, i64, vp, f64, i64, i64, i64, vp, vp]),

@@ -928,7 +928,11 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
       pl.info.push_back(px.any ? px.info[j] : ri);
       const int sc = prog->sites[j].scan;
       if (prog->sites[j].mode == GJX_MODE_INPUT) { pl.stream.push_back({"", 0u}); continue; }      // (takes no site number)
-      if (prog->rng_mode != GJX_RNG_FLAT) { pl.stream.push_back({"", ++jn}); continue; }
+      if (prog->rng_mode != GJX_RNG_FLAT) {   // (a plate is ONE traced site of its caller: its body sites share the first one's number)
+        const bool inner = prog->sites[j].plate != 0 && j > 0 && prog->sites[j - 1].plate == prog->sites[j].plate;
+        pl.stream.push_back({"", inner ? jn : ++jn});
+        continue;
+      }
       if (sc == 0) { tag = 0; pl.stream.push_back({"", ++plain}); continue; }
       if (sc != tag) {
         const unsigned id = (unsigned)sc >> 20;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
     }
     key2 plate_key{0u, 0u};       // JAX32: fold_in(particle key, J), J = 1-based index of the plate's first site
     if (RNG == GJX_RNG_JAX32 && plate != 0) plate_key = fold_in(fold_in64(a.key, gidx), jn + 1u);
-    jn += (uint32_t)m;
+    jn += (RNG == GJX_RNG_JAX32 && plate != 0) ? 1u : (uint32_t)m;   // (the Vmap call is ONE traced site of its caller: static.py:349-352)
     for (int inst = 0; inst < ninst; ++inst) {
     key2 inst_key{0u, 0u};
     if (RNG == GJX_RNG_JAX32 && plate != 0) inst_key = fold_in(plate_key, (uint32_t)inst);     // split(plate key, n)[inst] (vmap.py:186)
@@ -1069,41 +1069,40 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// measurement hook (gjx_profile_next_run): HIP events attached to the DISPATCH of the next propagate kernel launched
-// from this thread — they take the kernel's own begin / end timestamps, not those of markers around it
-thread_local hipEvent_t t_prof_start = nullptr, t_prof_stop = nullptr;
+// the caller's HIP events (gjx_run_opts.start_event / stop_event, gjx_importance_step_ex) are attached to the DISPATCH of the
+// kernel — they take its own begin / end timestamps, not those of markers around it
+struct DispatchEvents { hipEvent_t start = nullptr, stop = nullptr; };
 
 template <class KERN>
-void launch_gmm_kernel(KERN kern, const GmmArgs& a, int grid, size_t lds, hipStream_t st) {
-  if (t_prof_start && t_prof_stop) {
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)lds, st, t_prof_start, t_prof_stop, 0, a);
-    t_prof_start = t_prof_stop = nullptr;
+void launch_gmm_kernel(KERN kern, const GmmArgs& a, int grid, size_t lds, hipStream_t st, DispatchEvents ev) {
+  if (ev.start && ev.stop) {
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)lds, st, ev.start, ev.stop, 0, a);
     return;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
 template <int D>
-void launch_gmm_d(const GmmArgs& a, bool flat, int ppt, int grid, size_t lds, hipStream_t st) {
+void launch_gmm_d(const GmmArgs& a, bool flat, int ppt, int grid, size_t lds, hipStream_t st, DispatchEvents ev) {
   if (flat) {
-    if (ppt == 4 && a.tile_S) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, false, true>, a, grid, lds, st);
-    else if (ppt == 4) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256>, a, grid, lds, st);
-    else if (ppt == 2) launch_gmm_kernel(k_run_gmm_flat<D, 2, 256>, a, grid, lds, st);
-    else launch_gmm_kernel(k_run_gmm_flat<D, 1, 256>, a, grid, lds, st);
+    if (ppt == 4 && a.tile_S) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, false, true>, a, grid, lds, st, ev);
+    else if (ppt == 4) launch_gmm_kernel(k_run_gmm_flat<D, 4, 256>, a, grid, lds, st, ev);
+    else if (ppt == 2) launch_gmm_kernel(k_run_gmm_flat<D, 2, 256>, a, grid, lds, st, ev);
+    else launch_gmm_kernel(k_run_gmm_flat<D, 1, 256>, a, grid, lds, st, ev);
   } else {
-    if (ppt == 4) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 4, 256>, a, grid, lds, st);
-    else if (ppt == 2) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 2, 256>, a, grid, lds, st);
-    else launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 1, 256>, a, grid, lds, st);
+    if (ppt == 4) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 4, 256>, a, grid, lds, st, ev);
+    else if (ppt == 2) launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 2, 256>, a, grid, lds, st, ev);
+    else launch_gmm_kernel(k_run_gmm<GJX_RNG_JAX32, D, 1, 256>, a, grid, lds, st, ev);
   }
 }
-void launch_gmm(const GmmArgs& a, bool flat, int D, int ppt, int grid, size_t lds, hipStream_t st) {
+void launch_gmm(const GmmArgs& a, bool flat, int D, int ppt, int grid, size_t lds, hipStream_t st, DispatchEvents ev) {
   switch (D) {
-    case 1: launch_gmm_d<1>(a, flat, ppt, grid, lds, st); break;
-    case 2: launch_gmm_d<2>(a, flat, ppt, grid, lds, st); break;
-    case 4: launch_gmm_d<4>(a, flat, ppt, grid, lds, st); break;
-    case 8: launch_gmm_d<8>(a, flat, ppt, grid, lds, st); break;
-    case 16: launch_gmm_d<16>(a, flat, ppt, grid, lds, st); break;
-    case 32: launch_gmm_d<32>(a, flat, ppt, grid, lds, st); break;
-    default: launch_gmm_d<64>(a, flat, ppt, grid, lds, st); break;
+    case 1: launch_gmm_d<1>(a, flat, ppt, grid, lds, st, ev); break;
+    case 2: launch_gmm_d<2>(a, flat, ppt, grid, lds, st, ev); break;
+    case 4: launch_gmm_d<4>(a, flat, ppt, grid, lds, st, ev); break;
+    case 8: launch_gmm_d<8>(a, flat, ppt, grid, lds, st, ev); break;
+    case 16: launch_gmm_d<16>(a, flat, ppt, grid, lds, st, ev); break;
+    case 32: launch_gmm_d<32>(a, flat, ppt, grid, lds, st, ev); break;
+    default: launch_gmm_d<64>(a, flat, ppt, grid, lds, st, ev); break;
   }
 }
 
@@ -1150,11 +1149,6 @@ extern "C" int gjx_event_elapsed_us(void* start, void* stop, float* us) {
   r = hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop);
   if (r != hipSuccess) return gjx_fail_hip(r, "gjx_event_elapsed_us");
   *us = ms * 1000.0f;
-  return GJX_OK;
-}
-extern "C" int gjx_profile_next_run(void* start, void* stop) {
-  t_prof_start = (hipEvent_t)start;
-  t_prof_stop = (hipEvent_t)stop;
   return GJX_OK;
 }
 
@@ -1250,8 +1244,6 @@ extern "C" int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t 
                                size_t workspace_bytes, void* stream) {
   gjx_run_opts o;
   memset(&o, 0, sizeof(o));
-  if (t_prof_start && t_prof_stop) { o.flags |= GJX_RUN_TIME_DISPATCH; o.start_event = (void*)t_prof_start; o.stop_event = (void*)t_prof_stop; }
-  t_prof_start = t_prof_stop = nullptr;
   return gjx_run_program_ex(prog, key0, key1, K, particle_offset, choices, score, weight, logw, logw_in, sub, site_scores, lse, K_total,
                             workspace, workspace_bytes, stream, &o, nullptr);
 }
@@ -1365,10 +1357,9 @@ extern "C" int gjx_run_program_ex(const gjx_program* prog, uint32_t key0, uint32
         info.tiles_offset = (int64_t)off;
       }
     }
-    t_prof_start = ev0; t_prof_stop = ev1;      // (consumed by the launch below: transient inside this call)
     const size_t lds = flat ? sizeof(float) * (size_t)gmm_aux_floats(g.C, g.D)
                             : sizeof(float) * (size_t)(3 * g.C * (g.D + 4) + 4 * g.C + 3 * g.D + 32 + 8);
-    launch_gmm(a, flat, g.D, ppt, nblocks, lds, st);
+    launch_gmm(a, flat, g.D, ppt, nblocks, lds, st, DispatchEvents{ev0, ev1});
   } else {
     RunArgs a;
     a.sites = prog->sites_dev; a.tab = prog->tab_dev; a.n_sites = prog->n_sites; a.n_slots = prog->n_slots;
@@ -1412,12 +1403,19 @@ const void* step_kernel_for(int D) {
   }
 }
 template <int D>
-void launch_step_d(const GmmArgs& a, int grid, size_t lds, hipStream_t st) { launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, true>, a, grid, lds, st); }
+void launch_step_d(const GmmArgs& a, int grid, size_t lds, hipStream_t st, DispatchEvents ev) { launch_gmm_kernel(k_run_gmm_flat<D, 4, 256, true>, a, grid, lds, st, ev); }
 }  // namespace
 
 extern "C" int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
                                    float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
                                    int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream) {
+  return gjx_importance_step_ex(prog, key0, key1, K, particle_offset, choices, score, logw, lse, u, rows_out, ancestors, workspace,
+                                workspace_bytes, stream, nullptr, nullptr);
+}
+extern "C" int gjx_importance_step_ex(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
+                                      float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
+                                      int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream,
+                                      void* start_event, void* stop_event) {
   if (!prog || !prog->sites || !prog->sites_dev || !prog->tab_dev) return gjx_fail(GJX_EINVAL, "gjx_importance_step: null program");
   if (K <= 0 || !choices || !logw || !rows_out || !ancestors || !(u >= 0.0 && u < 1.0))
     return gjx_fail(GJX_EINVAL, "gjx_importance_step: bad argument");
@@ -1442,12 +1440,13 @@ extern "C" int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint3
   a.ctrl = (unsigned*)workspace + 8;
   a.timeline = gjx::debug_timeline(64 * (size_t)((K + 1023) / 1024));
   hipStream_t st = (hipStream_t)stream;
+  const DispatchEvents ev{(hipEvent_t)start_event, (hipEvent_t)stop_event};
   switch (g.D) {
-    case 1: launch_step_d<1>(a, (int)nblocks, lds, st); break;
-    case 2: launch_step_d<2>(a, (int)nblocks, lds, st); break;
-    case 4: launch_step_d<4>(a, (int)nblocks, lds, st); break;
-    case 8: launch_step_d<8>(a, (int)nblocks, lds, st); break;
-    default: launch_step_d<16>(a, (int)nblocks, lds, st); break;
+    case 1: launch_step_d<1>(a, (int)nblocks, lds, st, ev); break;
+    case 2: launch_step_d<2>(a, (int)nblocks, lds, st, ev); break;
+    case 4: launch_step_d<4>(a, (int)nblocks, lds, st, ev); break;
+    case 8: launch_step_d<8>(a, (int)nblocks, lds, st, ev); break;
+    default: launch_step_d<16>(a, (int)nblocks, lds, st, ev); break;
   }
   GJX_CHECK_LAUNCH("gjx_importance_step");
   return GJX_OK;

@@ -78,16 +78,12 @@ def threefry2x32(key, n: int, ctr_lo0: int = 0, ctr_hi: int = 0, device=None) ->
 
 
 class DispatchTimer:
-    """A pair of HIP events attached to the dispatch of the next fused propagate kernel (gjx_profile_next_run)."""
+    """A pair of HIP events a call attaches to the dispatch of its kernel (run_program(timer=...), importance_step(timer=...))."""
 
     def __init__(self):
         self.a, self.b = C.c_void_p(), C.c_void_p()
         check(load().gjx_event_create(C.byref(self.a)), "gjx_event_create")
         check(load().gjx_event_create(C.byref(self.b)), "gjx_event_create")
-
-    def arm(self) -> None:
-        """(deprecated form: per-thread one-shot; run_program(timer=...) passes the events explicitly)"""
-        check(load().gjx_profile_next_run(self.a, self.b), "gjx_profile_next_run")
 
     def elapsed_us(self) -> float:
         us = C.c_float()
@@ -240,7 +236,7 @@ def run_program(prog: PackedProgram, key, K: int, offset: int = 0, choices=None,
 
 
 def importance_step(prog: PackedProgram, key, K: int, u: float, offset: int = 0, out=None, ws=None, device=None,
-                    allow_fallback: bool = True):
+                    allow_fallback: bool = True, timer=None):
     """One importance step (propagate + reweight + LSE + systematic resample + gather).  One launch when the program has
     a fused engine and the grid is co-resident (gjx_importance_step), otherwise the three calls it replaces.
     -> dict(choices, score, logw, lse, rows (resampled), ancestors, fused: bool)"""
@@ -259,9 +255,10 @@ def importance_step(prog: PackedProgram, key, K: int, u: float, offset: int = 0,
         ws = workspace(A.OP_RUN, K, dev)
     out["_ws"] = ws
     cp = prog.c_program(dev)
-    rc = load().gjx_importance_step(C.byref(cp), key[0], key[1], K, int(offset), _ptr(out["choices"]), _ptr(out["score"]),
-                                    _ptr(out["logw"]), _ptr(out["lse"]), float(u), _ptr(out["rows"]), _ptr(out["ancestors"]),
-                                    _ptr(ws), ws.numel(), _stream())
+    rc = load().gjx_importance_step_ex(C.byref(cp), key[0], key[1], K, int(offset), _ptr(out["choices"]), _ptr(out["score"]),
+                                       _ptr(out["logw"]), _ptr(out["lse"]), float(u), _ptr(out["rows"]), _ptr(out["ancestors"]),
+                                       _ptr(ws), ws.numel(), _stream(), timer.a if timer is not None else None,
+                                       timer.b if timer is not None else None)
     if rc == A.EUNSUPPORTED and allow_fallback:
         run_program(prog, key, K, offset=offset, ws=ws, out=out, want_weight=False, want_lse=False)
         if out.get("_ws2") is None:

@@ -171,8 +171,9 @@ typedef struct gjx_site {
  * Streams.  GJX_RNG_FLAT: a body site has ONE site number (its position, like any other site) and instance i draws at the
  *     elements a vector site of n * dim elements would use: element (i * dim + c) * draws_per_element + k; categorical
  *     sites: element i.  Body sites never join scalar-normal runs (a drawing body site closes an open run).
- *   GJX_RNG_JAX32 — the reference's key rule:  plate key P = fold_in(particle key, J), J = the (1-based) index of the
- *     plate's first site in the program (the Vmap call is ONE traced site of its caller, static.py:349-352);
+ *   GJX_RNG_JAX32 — the reference's key rule:  plate key P = fold_in(particle key, J), J = the caller's site counter at
+ *     the Vmap call: the number of sites traced before it, plus one, where a whole plate counts as ONE site (the Vmap call
+ *     is one traced site of its caller, static.py:349-352: the site behind a plate of m body sites has counter J + 1);
  *     instance key = Threefry(P, (0, i)) = jax.random.split(P, n)[i] (vmap.py:186, 201);  site key = fold_in(instance key,
  *     l), l = 1-based position of the site in the body (static.py:349-352 inside the kernel); elements from 0 per instance.
  * A plate may sit inside a Scan step (its sites carry both tags); plates do not nest on the device (the host unrolls the
@@ -294,8 +295,8 @@ int gjx_run_program(const gjx_program* prog, uint32_t key0, uint32_t key1, int64
                     void* stream);
 
 /* The same call with its options and its record as explicit arguments — no per-thread state (the one-shot setters and getters of
- * ABI 6, gjx_run_want_tiles / gjx_last_run_partials / gjx_last_run_tiles, are gone; gjx_profile_next_run remains as the measurement
- * hook of gjx_importance_step, which takes no options).
+ * ABI 6, gjx_run_want_tiles / gjx_last_run_partials / gjx_last_run_tiles, are gone, and so is ABI 7's gjx_profile_next_run:
+ * the one-launch step takes its events as arguments, gjx_importance_step_ex).
  *   opts (or NULL):
  *     flags  GJX_RUN_LEAVE_TILES   with lse == NULL: leave the {S_b, e_b} of every 1024-particle tile of logw (tile-scaled
  *                                  fixed point, below) behind the block pairs for gjx_resample_gather_tiled
@@ -375,6 +376,11 @@ int gjx_debug_timeline(void* device_buffer, size_t bytes);
 int gjx_importance_step(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
                         float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
                         int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with a pair of HIP events (or NULLs) attached to the dispatch of the step's kernel: its own begin and end */
+int gjx_importance_step_ex(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t K, int64_t particle_offset,
+                           float* choices, float* score, float* logw, float* lse, double u, float* rows_out,
+                           int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream,
+                           void* start_event, void* stop_event);
 
 /* ---- log-sum-exp (smc.py:97,107,464) -----------------------------------------------------
  * out[4] = {max, sum exp(x-max), logsumexp, logsumexp - log(K_total)} */
@@ -394,14 +400,13 @@ int gjx_lse_combine(const float* pairs /*[G][2]*/, int G, int64_t K_total, float
 int gjx_trials_lse_pick(const float* logw, int64_t n_trials, int64_t K, int64_t particle_offset, uint32_t key0,
                         uint32_t key1, int32_t rng_mode, float* lse_out, int32_t* pick_out, void* stream);
 
-/* ---- measurement aid (bench.py's roofline figure): HIP events attached to the dispatch of the NEXT fused
- * propagate+reweight kernel that gjx_run_program launches from the calling thread, so that the kernel's own begin
- * and end are timed inside a running loop (an event pair recorded around the call also times the dispatch hand-offs
- * on both sides).  Events are created / read / destroyed through the library so that the caller needs no HIP. */
+/* ---- measurement aid (bench.py's roofline figure): HIP events that gjx_run_program_ex (GJX_RUN_TIME_DISPATCH) and
+ * gjx_importance_step_ex attach to the dispatch of their kernel, so that the kernel's own begin and end are timed inside a
+ * running loop (an event pair recorded around the call also times the dispatch hand-offs on both sides).  Events are
+ * created / read / destroyed through the library so that the caller needs no HIP; the library keeps no reference to them. */
 int gjx_event_create(void** event_out);
 int gjx_event_destroy(void* event);
 int gjx_event_elapsed_us(void* start_event, void* stop_event, float* us_out); /* waits for stop_event */
-int gjx_profile_next_run(void* start_event, void* stop_event);
 
 /* ---- 1-of-K categorical draw over the weights: ParticleCollection.sample_particle
  * (smc.py:102-109): idx = argmax_i (logw[i] - lse) + Gumbel(bits(key, i)).

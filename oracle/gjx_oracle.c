@@ -723,6 +723,7 @@ static void run_particle(const gjx_program* prog, okey run_key, uint64_t idx, fl
     float acc[64];
     if (m > 64) m = 64; /* (the host never emits more) */
     for (int l = 0; l < m; ++l) { uint32_t e0; site_no[l] = walk_next(&w, prog, &prog->sites[j + l], j + l, &e0); acc[l] = 0.0f; }
+    if (!flat && prog->sites[j].plate) w.jn -= (uint32_t)(m - 1);   /* JAX32: the Vmap call advances its caller's counter by ONE (static.py:349-352) */
     /* JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J), J = 1-based index of the
      * plate's first site; instance key = split(plate key, n)[i] (vmap.py:186, 201) */
     okey pkey = run_key;

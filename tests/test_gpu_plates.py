@@ -119,10 +119,13 @@ def test_plate_through_the_inference_layer():
 
 
 @pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
-def test_downstream_reader_and_chained_vmaps_match_the_oracle(rng):
+@pytest.mark.parametrize("engine", ["gen", "interp"])
+def test_downstream_reader_and_chained_vmaps_match_the_oracle(rng, engine, monkeypatch):
     """a site outside the plate reads ONE instance (zs[3]); a second vmap reads instance i of the first: both used to fail to
-    pack with plates on; now the reads go to the plate's rows"""
+    pack with plates on; now the reads go to the plate's rows.  (JAX32: the site behind the two-site plate takes the caller's
+    NEXT counter — a Vmap call is one traced site —, in both engines as in the oracle)"""
     from genjax_amd import kernels
+    monkeypatch.setenv("GJX_ENGINE", engine)
     from oracle import cpu
     n = 24
     xs = np.linspace(-1.0, 1.0, n).astype(np.float32)

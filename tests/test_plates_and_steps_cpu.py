@@ -67,6 +67,38 @@ def test_vmapped_mixture_lowers_to_two_plate_sites_and_the_oracle_scores_it(rng)
     assert np.abs(np.bincount(z.ravel(), minlength=3) / z.size - p).max() < 5e-3
 
 
+def test_jax32_a_plate_advances_the_callers_site_counter_by_one():
+    """static.py:349-352: the Vmap call is ONE traced site of its caller — the site behind a plate has counter J + 1 whatever
+    the number of sites in the vmapped kernel's body (the counter used to advance by the body's length)"""
+    from oracle import cpu
+    n, K = 8, 64
+
+    @genjax.gen
+    def one(x):
+        return genjax.normal(x, 1.0) @ "m"
+
+    @genjax.gen
+    def two(x):
+        c = genjax.flip(0.4) @ "c"
+        return genjax.normal(x, 1.0) @ "m"
+
+    def model_of(kernel):
+        @genjax.gen
+        def model():
+            a = genjax.normal(0.0, 1.0) @ "a"
+            kernel.vmap()(np.zeros(n, np.float32)) @ "k"
+            return genjax.normal(0.0, 1.0) @ "t"
+        return model
+
+    draws = []
+    for kernel in (one, two):
+        prog, _, _ = model_of(kernel).pack((), C.n(), True, rng_mode=A.RNG_JAX32)
+        o = cpu.run_program(prog, (3, 4), K)
+        draws.append((o["choices"][prog.slot_of["a"]].copy(), o["choices"][prog.slot_of["t"]].copy()))
+    np.testing.assert_array_equal(draws[0][0], draws[1][0])
+    np.testing.assert_array_equal(draws[0][1], draws[1][1])       # "t" is traced site 3 of its caller in both programs
+
+
 def test_plate_assess_equals_the_unrolled_program():
     """no randomness: a trace's score on the plate lowering == on the unrolled one (per-instance tables, observations, masks,
     an affine row per instance over two latent sites outside the plate)"""
