@@ -349,7 +349,7 @@ def run_gmm(args, rank, world, dev):
     # HBM bytes per launch from the PMC counters are NOT measured in this run (counters need their own rocprofv3 passes):
     # `traffic` stays null and the figure of the committed counter run is reported beside it, labelled as such
     traffic_prof = None
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         tp = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")   # FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/README.md)
         if os.path.exists(tp):                                           # keys: rocprofv3 kernel names without "void " and blanks
             want = "gjx::k_run_gmm_flat<%d,4,256," % D
@@ -1133,6 +1133,138 @@ def run_round4(dev):
     return res
 
 
+def run_round5(dev):
+    """Round-5 paths, short runs: the generic filter (gjx_scan_filter) with a custom proposal per step, with Metropolis moves behind
+    the resampling and with the multinomial resampler; HMC over a plate-tagged program (a regression with a latent per datum: the
+    vmapped kernel's two-site body as a plate loop of the generated kernel) next to the site interpreter."""
+    import genjax_amd as genjax
+    from genjax_amd import C as CM
+    from genjax_amd import kernels, workloads
+    from genjax_amd.inference import BootstrapFilter
+    res = {}
+    T, K, dx = 256, 1 << 18, 8
+    s = workloads.ssm_problem()
+    q, r = float(s["q"]), float(s["r"])
+    Am = np.asarray(s["A"], np.float32)
+    ys = np.asarray(s["y"], np.float32)
+    exact = _kalman_log_lik(s["A"], s["y"], q, r, q)
+    s2 = 1.0 / (1.0 / q ** 2 + 1.0 / r ** 2)
+
+    @genjax.gen
+    def lg_step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(dx, q, np.float32)) @ "x"
+        genjax.mv_normal_diag(x, np.full(dx, r, np.float32)) @ "y"
+        return x, None
+
+    @genjax.gen
+    def q_step(x_prev, y_t):          # the locally optimal proposal of the model (H = I)
+        x = genjax.mv_normal_diag((s2 / q ** 2) * (Am @ x_prev) + (s2 / r ** 2) * y_t, np.full(dx, np.sqrt(s2), np.float32)) @ "x"
+        return x, None
+
+    def time_filter(bf, chm, args, n=4):
+        bf.alias_outputs = True
+        for i in range(2):
+            bf.run(genjax.key(i), chm, args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            out = bf.run(genjax.key(10 + i), chm, args)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, out
+
+    def row(dt, out, Kf, Tn, bytes_per):
+        info = out.get("info", {})
+        return dict(us_per_step=dt / Tn * 1e6, particle_steps_per_sec=Kf * Tn / dt, log_ml=float(out["log_ml"]), form=info.get("form_name"),
+                    launches_per_run=info.get("launches"), grid=info.get("grid"), tiles_per_block=info.get("tiles_per_block"),
+                    roofline=dict(bound="hbm", algorithmic_bytes_per_particle_step=bytes_per, bytes_per_step=bytes_per * Kf, us_per_step=dt / Tn * 1e6,
+                                  achieved=bytes_per * Kf / (dt / Tn) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bytes_per * Kf / (dt / Tn) / 1e9 / HBM_PEAK_GBS,
+                                  timing="wall clock over whole runs incl. step 0 and the host's calls"))
+
+    carry0 = np.zeros(dx, np.float32)
+    chm = CM["y"].set(ys)
+    dtb, ob = time_filter(BootstrapFilter(lg_step.scan(n=T), K), chm, (carry0, None))
+    dtp, op = time_filter(BootstrapFilter(lg_step.scan(n=T), K, proposal=q_step.scan(n=T), proposal_args=(carry0, ys)), chm, (carry0, None))
+    rp = row(dtp, op, K, T, 8 * dx + 24)
+    rp.update(log_ml_rel_err=abs(float(op["log_ml"]) - exact) / abs(exact), bootstrap_proposal_us_per_step=dtb / T * 1e6, ratio_to_bootstrap=dtp / dtb,
+              note="log w = log p(x_t | x_{t-1}) + log p(y_t | x_t) - log q(x_t | x_{t-1}, y_t): proposal sites (GJX_SITE_PROPOSAL) and the model's latent "
+                   "scored at the proposal's draw (GJX_MODE_OBS_PROPOSED) in ONE step program")
+    res["scan_filter_lgssm_optimal_proposal_T256_K2e18"] = rp
+    dtm, om = time_filter(BootstrapFilter(lg_step.scan(n=T), K, resampler="multinomial"), chm, (carry0, None), n=2)
+    rm = row(dtm, om, K, T, 8 * dx + 24)
+    rm.update(log_ml_rel_err=abs(float(om["log_ml"]) - exact) / abs(exact), systematic_us_per_step=dtb / T * 1e6,
+              note="GJX_FILTER_MULTINOMIAL: weight prefix sums + one inverse-CDF search per slot + the step's kernel: three launches per step")
+    res["scan_filter_lgssm_multinomial_T256_K2e18"] = rm
+    with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
+        fx = json.load(f)
+    phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
+
+    @genjax.gen
+    def sv_step(x_prev, _):
+        x = genjax.normal(phi * x_prev, sigma) @ "x"
+        genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+        return x, None
+
+    Tn = len(ysv)
+    dt0, o0 = time_filter(BootstrapFilter(sv_step.scan(n=Tn), K), CM["y"].set(ysv), (0.0, None))
+    dt2, o2 = time_filter(BootstrapFilter(sv_step.scan(n=Tn), K, rejuvenate=dict(n_moves=2, scale=0.3)), CM["y"].set(ysv), (0.0, None))
+    r2 = row(dt2, o2, K, Tn, 8 * 1 + 24 + 8)
+    r2.update(without_moves_us_per_step=dt0 / Tn * 1e6, accept_rate=float(o2["accepted_total"]) / (2.0 * K * (Tn - 2)),
+              float64_filter_mean=fx["log_ml_mean"], float64_filter_std=fx["log_ml_std"], z=(float(o2["log_ml"]) - fx["log_ml_mean"]) / fx["log_ml_std"],
+              note="two random-walk Metropolis moves per particle behind every resampling, target = the previous step's density re-scored by code "
+                   "generated from the step program, inside the filter kernel")
+    res["scan_filter_stochastic_volatility_2_moves_T256_K2e18"] = r2
+
+    # HMC over a plate-tagged program: ls ~ N(0,1), beta ~ N(0, I_P); per datum eta_i ~ N(x_i . beta, exp(ls)), y_i ~ bernoulli(logits = eta_i)
+    N, P, n, L = 256, 4, 1 << 14, 20
+    rs = np.random.default_rng(0)
+    X = (0.5 * rs.standard_normal((N, P))).astype(np.float32)
+
+    @genjax.gen
+    def kern(x_row, beta, ls):
+        eta = genjax.normal(x_row @ beta, genjax.exp(ls)) @ "eta"
+        return genjax.bernoulli(logits=eta) @ "y"
+
+    @genjax.gen
+    def model():
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        beta = genjax.normal(np.zeros(P, np.float32), 1.0) @ "beta"
+        kern.vmap(in_axes=(0, None, None))(X, beta, ls) @ "k"
+
+    y = (rs.uniform(size=N) < 0.5).astype(np.float32)
+    lat = ["ls", "beta"] + [(("k", "eta"), i) for i in range(N)]
+    prog, _, _ = model.pack((), CM["k", "y"].set(y), False, selected=("ls", "beta"), per_particle=tuple(lat), plates="hmc")
+    ch0 = (torch.randn((prog.n_slots, n), device=dev) * 0.3).contiguous()
+    hm = {}
+    for engine in ("gen", "interp"):
+        old = os.environ.get("GJX_HMC_ENGINE")
+        os.environ["GJX_HMC_ENGINE"] = engine
+        try:
+            eng = kernels.hmc_engine(prog)
+            out = kernels.hmc(prog, (1, 2), ch0.clone(), 0.01, L, False, True)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(3):
+                out = kernels.hmc(prog, (1, 3 + i), ch0.clone(), 0.01, L, False, True, ws=out["_ws"])
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 3
+        finally:
+            if old is None:
+                del os.environ["GJX_HMC_ENGINE"]
+            else:
+                os.environ["GJX_HMC_ENGINE"] = old
+        # per chain and gradient sweep: the state rows read once per instance (eta_i: 4 B) — the rest lives in registers / LDS
+        hm[engine] = dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=n * L / (ms * 1e-3), accept_rate=float(out["accepted"].mean()),
+                          roofline=dict(bound="hbm", algorithmic_bytes_per_launch=4.0 * N * n * (L + 1), kernel_us=ms * 1e3,
+                                        achieved=4.0 * N * n * (L + 1) / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=4.0 * N * n * (L + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, timing="event pair around 3 back-to-back moves (incl. a clone of the state)"))
+    hm["speedup"] = hm["interp"]["ms_per_move"] / hm["gen"]["ms_per_move"]
+    hm["device_sites"], hm["plate_instances"], hm["chains"], hm["leapfrog"] = prog.n_sites, N, n, L
+    res["hmc_plate_regression_latent_per_datum_N256"] = hm
+    return res
+
+
 def _config4_worker(rank, world, port, K_total, T, dx, out_dir, verify):
     """one rank of the config-4 dry run (processes sharing ONE device): the sharded filter over peer-mapped windows"""
     import hashlib
@@ -1347,6 +1479,10 @@ def main():
             extra["round4"] = run_round4(dev)
         except Exception as e:
             extra["round4"] = dict(error=repr(e))
+        try:
+            extra["round5"] = run_round5(dev)
+        except Exception as e:
+            extra["round5"] = dict(error=repr(e))
         try:
             extra["config4_dry_run"] = run_config4_dry_run(dev)
         except Exception as e:
