@@ -1262,6 +1262,61 @@ def run_round5(dev):
     hm["speedup"] = hm["interp"]["ms_per_move"] / hm["gen"]["ms_per_move"]
     hm["device_sites"], hm["plate_instances"], hm["chains"], hm["leapfrog"] = prog.n_sites, N, n, L
     res["hmc_plate_regression_latent_per_datum_N256"] = hm
+
+    # HMC over (mu, log sigma) of the 4096-datum vmapped mixture, assignments z fixed per chain: x_i ~ normal(mu[z_i], exp(ls)) reads a
+    # row of a LATENT choice (GJX_P_VGATHER)
+    Nm, nm, Lm = 4096, 1 << 13, 10
+    true_mu = np.array([-2.5, 0.0, 3.0], np.float32)
+    zt = rs.integers(0, 3, Nm)
+    ysm = (true_mu[zt] + 0.6 * rs.standard_normal(Nm)).astype(np.float32)
+    lg = np.array([0.2, -0.3, 0.1], np.float32)
+
+    @genjax.gen
+    def mk(mu, ls, lg_):
+        z = genjax.categorical(logits=lg_) @ "z"
+        return genjax.normal(mu[z], genjax.exp(ls)) @ "x"
+
+    @genjax.gen
+    def mix():
+        mu = genjax.normal(np.zeros(3, np.float32), 3.0) @ "mu"
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        mk.repeat(n=Nm)(mu, ls, lg) @ "k"
+
+    latm = ["mu", "ls"] + [(("k", "z"), i) for i in range(Nm)]
+    pm, _, _ = mix.pack((), CM["k", "x"].set(ysm), False, selected=("mu", "ls"), per_particle=tuple(latm), plates="hmc")
+    chm0 = torch.empty((pm.n_slots, nm), device=dev)
+    chm0[:3] = torch.as_tensor(true_mu, device=dev)[:, None] + 0.03 * torch.randn((3, nm), device=dev)
+    chm0[3] = math.log(0.6) + 0.02 * torch.randn(nm, device=dev)
+    chm0[4:] = torch.as_tensor(zt, device=dev, dtype=torch.float32)[:, None]
+    mm = {}
+    for engine in ("gen", "interp"):
+        old = os.environ.get("GJX_HMC_ENGINE")
+        os.environ["GJX_HMC_ENGINE"] = engine
+        try:
+            eng = kernels.hmc_engine(pm)
+            out = kernels.hmc(pm, (1, 2), chm0, 1e-3, Lm, False, True)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3 if engine == "gen" else 1
+            a.record()
+            for i in range(reps):
+                out = kernels.hmc(pm, (1, 3 + i), chm0, 1e-3, Lm, False, True, ws=out["_ws"])
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / reps
+        finally:
+            if old is None:
+                del os.environ["GJX_HMC_ENGINE"]
+            else:
+                os.environ["GJX_HMC_ENGINE"] = old
+        byt = 4.0 * Nm * nm * (Lm + 1)            # the chain's assignment rows, read once per gradient sweep
+        mm[engine] = dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=nm * Lm / (ms * 1e-3), accept_rate=float(out["accepted"].mean()),
+                          roofline=dict(bound="hbm", algorithmic_bytes_per_launch=byt, kernel_us=ms * 1e3, achieved=byt / (ms * 1e-3) / 1e9,
+                                        peak=HBM_PEAK_GBS, unit="GB/s", frac=byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        timing="event pair around back-to-back moves"))
+    mm["speedup"] = mm["interp"]["ms_per_move"] / mm["gen"]["ms_per_move"]
+    mm["device_sites"], mm["plate_instances"], mm["chains"], mm["leapfrog"] = pm.n_sites, Nm, nm, Lm
+    res["hmc_mixture_latent_means_N4096"] = mm
     return res
 
 

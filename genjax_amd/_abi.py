@@ -30,7 +30,7 @@ DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS,
 NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move (integers; simplex-constrained)
 
 # param forms / transforms / modes / flags / rng
-P_CONST, P_VALUE, P_GATHER, P_AFFINE = 0, 1, 2, 3
+P_CONST, P_VALUE, P_GATHER, P_AFFINE, P_VGATHER = 0, 1, 2, 3, 4
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
 MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK, MODE_INPUT = 0, 1, 2, 3, 4
 MODE_OBS_PROPOSED = 5

@@ -202,13 +202,28 @@ struct Roll {
   std::vector<RollInfo> info;
 };
 
-bool slot_op(int op) { return op == GJX_P_VALUE || op == GJX_P_GATHER || op == GJX_P_AFFINE; }
+bool slot_op(int op) { return op == GJX_P_VALUE || op == GJX_P_GATHER || op == GJX_P_AFFINE || op == GJX_P_VGATHER; }
+bool has_vgather(const gjx_site* sites, int n) {
+  for (int j = 0; j < n; ++j) for (int k = 0; k < GJX_MAX_PARAMS; ++k) if (sites[j].p[k].op == GJX_P_VGATHER) return true;
+  return false;
+}
+// "7" / "(7)" -> 7; -1 when the element index is not a literal (a rolled site's loop variable)
+int literal_index(const std::string& dx) {
+  size_t a = 0, b = dx.size();
+  while (a < b && (dx[a] == '(' || dx[a] == ' ')) ++a;
+  while (b > a && (dx[b - 1] == ')' || dx[b - 1] == ' ')) --b;
+  if (a == b) return -1;
+  int v = 0;
+  for (size_t i = a; i < b; ++i) { if (dx[i] < '0' || dx[i] > '9') return -1; v = v * 10 + (dx[i] - '0'); }
+  return v;
+}
 int ref_span(const gjx_param& q) { return q.op == GJX_P_AFFINE ? q.n : (q.op == GJX_P_VALUE ? q.len : 1); }
 
 Roll detect_roll(const gjx_program* p) {
   Roll r;
   if (p->rng_mode != GJX_RNG_FLAT || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
+  if (has_vgather(p->sites, n)) return r;     // (rows of a choice picked by a discrete choice: not in rolled Scans)
   for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
   int i0 = 0;
   while (i0 < n && p->sites[i0].scan == 0) ++i0;
@@ -420,6 +435,13 @@ PlateXf plate_program(const gjx_program* p) {
     if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = s.plate ? s.d_obs : 0; s.obs_off = flag[j]; }
     for (int k = 0; k < (s.mode == GJX_MODE_INPUT ? 0 : n_params(s.kind)); ++k) {
       gjx_param& q = s.p[k];
+      if (q.op == GJX_P_VGATHER) {
+        // the indexed choice: all its rows in the registers of ONE site outside the plates, the same for every instance
+        const int ov = owner_of(q.moff, j);
+        if (ov < 0 || p->sites[ov].plate != 0 || q.d_moff != 0 || q.moff + q.n * q.len > p->sites[ov].slot + rows(p->sites[ov])) return x;
+        q.moff = reg[ov] + (q.moff - p->sites[ov].slot);
+        if (q.slot < 0) continue;        // (the index comes from the table: RollInfo::d_off is its stride)
+      }
       if (!slot_op(q.op)) continue;
       const int span = ref_span(q);
       const int o = owner_of(q.slot, j);
@@ -472,9 +494,11 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
     if (s.dim > kMaxExpandDim && s.mode != GJX_MODE_OBS_TAB) return false;
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
-      if (q.op < GJX_P_CONST || q.op > GJX_P_AFFINE) return false;
+      if (q.op < GJX_P_CONST || q.op > GJX_P_VGATHER) return false;
       if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
       if (s.dim > kMaxExpandDim && q.op == GJX_P_VALUE && q.len != 1) return false;
+      // a row of a choice in registers picked by a select chain: few rows, and a literal element index unless rows are scalars
+      if (q.op == GJX_P_VGATHER && (q.n < 1 || q.n * q.len > 32 || q.moff < 0 || q.moff + q.n * q.len > n_slots || (q.len != 1 && s.dim > kMaxExpandDim))) return false;
     }
     total += s.dim > kMaxExpandDim ? 8 : s.dim;
   }
@@ -508,6 +532,7 @@ std::string param_expr(const gjx_param& q, const std::string& dx, int site, int 
     case GJX_P_VALUE:
       if (q.len == 1) return src_val(q, ri, k, "0");
       return src_val(q, ri, k, "(" + dx + ") % " + std::to_string(q.len));
+    case GJX_P_VGATHER: snprintf(b, sizeof(b), "vg_%d_%d", site, k); return b;   // (select chain emitted by emit_param_pre)
     default: snprintf(b, sizeof(b), "aff_%d_%d", site, k); return b;   // computed into a local just before use
   }
 }
@@ -522,6 +547,13 @@ std::string xf_wrap(int xf, const std::string& e) {
 
 // statements that must precede the use of param_expr for element dx (affine accumulations)
 void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, const RollInfo& ri) {
+  if (q.op == GJX_P_VGATHER) {
+    // row gi_ of a choice whose rows live in registers: registers cannot be indexed, n - 1 selects can (supported_sites: n len <= 32)
+    const int e = q.len == 1 ? 0 : literal_index(dx) % q.len;
+    o.f("%sfloat vg_%d_%d = v[%d][p];\n", ind, site, k, q.moff + e);
+    for (int c = 1; c < q.n; ++c) o.f("%svg_%d_%d = gi_%d_%d[p] == %d ? v[%d][p] : vg_%d_%d;\n", ind, site, k, site, k, c, q.moff + c * q.len + e, site, k);
+    return;
+  }
   if (q.op != GJX_P_AFFINE) return;
   const std::string e = q.len == 1 ? "0" : ("(" + dx + ") % " + std::to_string(q.len));
   o.f("%sfloat aff_%d_%d = TAB(%s + %s);\n", ind, site, k, toff(q.off, ri.d_off[k]).c_str(), e.c_str());
@@ -533,9 +565,10 @@ void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site
 void emit_gather_index(Emit& o, const gjx_site& s, int site, int np, const RollInfo& ri) {
   for (int k = 0; k < np; ++k) {
     const gjx_param& q = s.p[k];
-    if (q.op != GJX_P_GATHER) continue;
+    if (q.op != GJX_P_GATHER && q.op != GJX_P_VGATHER) continue;
     o.f("      int gi_%d_%d[PPT];\n", site, k);
-    o.f("      PLOOP { int g_ = (int)%s; gi_%d_%d[p] = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", src_val(q, ri, k, "0").c_str(), site, k, q.n - 1, q.n - 1);
+    const std::string from = (q.op == GJX_P_VGATHER && q.slot < 0) ? "TAB(" + toff(q.off, ri.d_off[k]) + ")" : src_val(q, ri, k, "0");
+    o.f("      PLOOP { int g_ = (int)%s; gi_%d_%d[p] = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", from.c_str(), site, k, q.n - 1, q.n - 1);
   }
 }
 
@@ -1228,6 +1261,7 @@ bool pf_supported(const gjx_program* p) {
     if (p->sites[j].scan != 0) return false;
     has_input = has_input || md == GJX_MODE_INPUT;
   }
+  if (has_vgather(p->sites, p->n_sites)) return false;     // (the other forms of the filter run such a step)
   return has_input && supported_uncached(p);
 }
 
@@ -1587,9 +1621,11 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
     if (big && (s.slot >= 0 || (s.flags & GJX_SITE_HMC_SELECTED))) return false;   // a rolled site reads its values from the table
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
-      if (q.op < GJX_P_CONST || q.op > GJX_P_AFFINE) return false;
+      if (q.op < GJX_P_CONST || q.op > GJX_P_VGATHER) return false;
       if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
       if (big && q.op == GJX_P_VALUE && q.len != 1) return false;
+      // a row of a (selected) choice picked by a discrete choice: select chains forwards and backwards, few rows
+      if (q.op == GJX_P_VGATHER && (q.n < 1 || q.n * q.len > 32 || q.moff < 0 || q.moff + q.n * q.len > pl.n_regs || (big && q.len != 1))) return false;
     }
     if (big) pl.looped = true; else unrolled += s.dim;
     if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0)
@@ -1656,6 +1692,12 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         if (q.len == 1) o.f("%s  const float pre_%d = v[%d];\n", ind, k, q.slot);
         else o.f("%s  const float pre_%d = v[%d + %s];\n", ind, k, q.slot, e.c_str());   // (unrolled sites only: literal index)
         break;
+      case GJX_P_VGATHER: {   // row gi_ of a choice in registers: n - 1 selects
+        const int e0 = q.len == 1 ? 0 : literal_index(dx) % q.len;
+        o.f("%s  float pre_%d = v[%d];\n", ind, k, q.moff + e0);
+        for (int c = 1; c < q.n; ++c) o.f("%s  pre_%d = gi_%d_%d == %d ? v[%d] : pre_%d;\n", ind, k, j, k, c, q.moff + c * q.len + e0, k);
+        break;
+      }
       default: {   // AFFINE: the row stays in registers for the gradient
         o.f("%s  float row_%d[%d];\n", ind, k, q.n);
         if (q.moff % 4 == 0 && q.n % 4 == 0 && ri.d_moff[k] % 4 == 0)
@@ -1681,11 +1723,22 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
   }
   for (int k = 0; k < np; ++k) {
     const gjx_param& q = s.p[k];
-    if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE) continue;
+    if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE && q.op != GJX_P_VGATHER) continue;
     const std::string w = q.xf == GJX_XF_NONE ? "gp_[" + std::to_string(k) + "]"
                                               : "(gp_[" + std::to_string(k) + "] * xf_deriv(" + std::to_string(q.xf) + ", pre_" + std::to_string(k) + "))";
     if (mf && k == mf->k) {
       o.f("%s  %s = %s;\n", ind, mf->wout.c_str(), w.c_str());
+    } else if (q.op == GJX_P_VGATHER) {   // the gradient goes to the picked row
+      const int e0 = q.len == 1 ? 0 : literal_index(dx) % q.len;
+      bool any = false;
+      for (int c = 0; c < q.n; ++c) any = any || hp.sel_of_slot[q.moff + c * q.len + e0] >= 0;
+      if (!any) continue;
+      o.f("%s  { const float w_ = %s;\n", ind, w.c_str());
+      for (int c = 0; c < q.n; ++c) {
+        const int m = hp.sel_of_slot[q.moff + c * q.len + e0];
+        if (m >= 0) o.f("%s    %s[%d] += gi_%d_%d == %d ? w_ : 0.0f;\n", ind, acc, m, j, k, c);
+      }
+      o.f("%s  }\n", ind);
     } else if (q.op == GJX_P_VALUE) {
       const int src = q.slot + (q.len == 1 ? 0 : atoi(dx.c_str()) % q.len);
       const int m = hp.sel_of_slot[src];
@@ -1818,8 +1871,10 @@ std::string generate_hmc(const gjx_program* prog_in) {
     o.f("  { // ---- site %d: kind %d, dim %d, slot %d%s\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot, ri.plate ? " (plate body)" : "");
     for (int k = 0; k < np; ++k) {
       const gjx_param& q = s.p[k];
-      if (q.op == GJX_P_GATHER)
+      if (q.op == GJX_P_GATHER || (q.op == GJX_P_VGATHER && q.slot >= 0))
         o.f("    int gi_%d_%d; { const int g_ = (int)v[%d]; gi_%d_%d = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", j, k, q.slot, j, k, q.n - 1, q.n - 1);
+      else if (q.op == GJX_P_VGATHER)     // the index choice is constrained to one value for every chain: read from the table
+        o.f("    int gi_%d_%d; { const int g_ = (int)TAB(%s); gi_%d_%d = g_ < 0 ? 0 : (g_ > %d ? %d : g_); }\n", j, k, toff(q.off, ri.d_off[k]).c_str(), j, k, q.n - 1, q.n - 1);
     }
     if (is_categorical(s.kind)) {   // an integer site: scored, no gradient through it (hmc.py:49-65; k_hmc_generic)
       const gjx_param& q = s.p[0];
@@ -1850,6 +1905,7 @@ std::string generate_hmc(const gjx_program* prog_in) {
         const gjx_param& q = s.p[k];
         if (q.op == GJX_P_VALUE && hp.sel_of_slot[q.slot] >= 0) touched[hp.sel_of_slot[q.slot]] = 1;
         if (q.op == GJX_P_AFFINE) for (int e = 0; e < q.n; ++e) if (hp.sel_of_slot[q.slot + e] >= 0) touched[hp.sel_of_slot[q.slot + e]] = 1;
+        if (q.op == GJX_P_VGATHER) for (int e = 0; e < q.n * q.len; ++e) if (hp.sel_of_slot[q.moff + e] >= 0) touched[hp.sel_of_slot[q.moff + e]] = 1;
       }
       for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? QSUM(ga[%d]) : ga[%d];\n", m, m, m);
       o.f("    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n");

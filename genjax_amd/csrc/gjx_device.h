@@ -385,6 +385,14 @@ GJX_DEV float sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 // ---- parameter evaluation ------------------------------------------------------------------
 // `val(slot)` returns the current particle's value of a slot.
 // `inst`: instance of the site's plate (gjx.h "Plates": off + inst * d_off, slot + inst * d_slot, moff + inst * d_moff); 0 elsewhere
+// GJX_P_VGATHER: the slot the parameter reads (gjx.h): row idx of an earlier vector-valued choice; idx an earlier discrete choice, or
+// (slot < 0) the table value of a choice constrained to one value for every particle
+template <class ValFn>
+GJX_DEV int vgather_row(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst = 0) {
+  int idx = (int)(p.slot >= 0 ? val(p.slot + inst * p.d_slot) : tab[p.off + inst * p.d_off]);
+  idx = idx < 0 ? 0 : (idx > p.n - 1 ? p.n - 1 : idx);
+  return p.moff + inst * p.d_moff + idx * p.len + (p.len == 1 ? 0 : d % p.len);
+}
 template <class ValFn>
 GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst = 0) {
   const int off = p.off + inst * p.d_off, slot = p.slot + inst * p.d_slot;
@@ -402,6 +410,7 @@ GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict_
       for (int e = 0; e < p.n; ++e) acc = fmaf(row[e], val(slot + e), acc);
       return acc;
     }
+    case GJX_P_VGATHER: return val(vgather_row(p, d, tab, val, inst));
     default: return __builtin_nanf("");
   }
 }

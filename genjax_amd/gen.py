@@ -197,6 +197,8 @@ class SiteVal(Sym):
         return Affine(self, np.eye(self.dim), np.zeros(self.dim))
 
     def __getitem__(self, i):
+        if isinstance(i, SiteVal):          # mu[z]: a row of this choice picked by a discrete choice
+            return take(self, i)
         return self._affine()[i]
 
     def as_param(self) -> Param:
@@ -216,6 +218,24 @@ class Gather(Sym):
         return Param.gather(self.table, self.idx.addr, xf=self.xf)
 
 
+class VGather(Sym):
+    """``vec[idx]``: one of the rows of an EARLIER vector-valued choice picked by a discrete choice (GJX_P_VGATHER) — the component
+    mean ``mu[z]`` of a mixture with latent means.  ``rows``: number of rows the choice's elements are read as (default: one
+    element per row)."""
+
+    def __init__(self, vec: SiteVal, idx: SiteVal, rows: int | None = None, xf: int = A.XF_NONE):
+        n = int(rows) if rows else vec.dim
+        if vec.dim % n:
+            raise NotSupportedInModelBody(f"take: {vec.dim} elements do not split into {n} rows")
+        self.vec, self.idx, self.n, self.dim, self.xf = vec, idx, n, vec.dim // n, xf
+
+    def with_xf(self, xf: int) -> "VGather":
+        return VGather(self.vec, self.idx, self.n, xf)
+
+    def as_param(self) -> Param:
+        return Param.vgather(self.vec.addr, self.n, self.idx.addr, vlen=self.dim, xf=self.xf)
+
+
 class const:
     """Wrap a constant table so that it can be indexed by a random choice: ``const(means)[idx]``."""
 
@@ -226,10 +246,13 @@ class const:
         return take(self.table, idx) if isinstance(idx, Sym) else self.table[idx]
 
 
-def take(table, idx) -> Gather:
-    """``table[idx]`` for a categorical / boolean choice ``idx`` (rows of a constant table)."""
+def take(table, idx, rows: int | None = None):
+    """``table[idx]`` for a categorical / boolean choice ``idx``: rows of a constant table, or — ``table`` an earlier vector-valued
+    choice — its element (``rows``: its row of ``dim / rows`` elements) number ``idx``."""
     if not isinstance(idx, SiteVal):
         raise NotSupportedInModelBody("take(table, idx): idx must be a random choice")
+    if isinstance(table, SiteVal):
+        return VGather(table, idx, rows)
     return Gather(np.asarray(table, np.float32), idx)
 
 
@@ -274,6 +297,10 @@ def _xf(x, code: int, fn: Callable):
         if x.xf != A.XF_NONE:
             raise NotSupportedInModelBody("nested transforms")
         return Gather(x.table, x.idx, code)
+    if isinstance(x, VGather):
+        if x.xf != A.XF_NONE:
+            raise NotSupportedInModelBody("nested transforms")
+        return x.with_xf(code)
     if isinstance(x, Sym):
         return x._affine().with_xf(code)
     return fn(np.asarray(x, np.float64))

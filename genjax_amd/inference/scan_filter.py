@@ -105,13 +105,15 @@ class ScanBootstrapFilter:
                 if p.terms:
                     return dataclasses.replace(p, terms=[((("@q", a_) if a_ in q_here else a_), m) for a_, m in p.terms],
                                                src=("@q", p.src) if p.src in q_here else p.src)
+                if p.op == A.P_VGATHER and p.vsrc in q_here:
+                    p = dataclasses.replace(p, vsrc=("@q", p.vsrc))
                 return dataclasses.replace(p, src=("@q", p.src)) if p.src in q_here else p
             for s in q_steps[t]:
                 rows = s.ncat if s.ncat else s.dim
                 qa = ("@q", s.addr)
                 ns = Site(qa, s.kind, [q_param(fold_known(p, known, rows)) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
-                    for a_ in ([a for a, _ in p.terms] if p.terms else ([p.src] if p.op != A.P_CONST else [])):
+                    for a_ in ([a for a, _ in p.terms] if p.terms else (([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src]) if p.op != A.P_CONST else [])):
                         if a_ not in step_sl:
                             raise NotImplementedError(f"ScanBootstrapFilter: proposal site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
                 step_sl.sites.append(ns)
@@ -122,7 +124,7 @@ class ScanBootstrapFilter:
                 rows = s.ncat if s.ncat else s.dim
                 ns = Site(s.addr, s.kind, [fold_known(p, known, rows) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
-                    for a_ in ([a for a, _ in p.terms] if p.terms else ([p.src] if p.op != A.P_CONST else [])):
+                    for a_ in ([a for a, _ in p.terms] if p.terms else (([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src]) if p.op != A.P_CONST else [])):
                         if a_ not in step_sl:
                             raise NotImplementedError(f"ScanBootstrapFilter: site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
                 step_sl.sites.append(ns)

@@ -39,6 +39,11 @@ class Param:
     d_elem: int = 0
     inst_values: bool = False
     inst_matrix: bool = False
+    # VGATHER (gjx.h GJX_P_VGATHER): row `src`-th of the earlier vector-valued choice `vsrc` (from element vsrc_elem: vn rows of vlen values)
+    vsrc: Any = None
+    vsrc_elem: int = 0
+    vn: int = 0
+    vlen: int = 1
 
     @staticmethod
     def const(v, xf=A.XF_NONE) -> "Param":
@@ -54,6 +59,11 @@ class Param:
         if t.ndim == 1:
             t = t[:, None]
         return Param(A.P_GATHER, values=t, src=src, xf=xf)
+
+    @staticmethod
+    def vgather(vsrc, n: int, src: str, vlen: int = 1, xf=A.XF_NONE) -> "Param":
+        """``value(vsrc)[idx]``: one of the n rows (vlen values each) of an earlier choice, picked by the discrete choice ``src``"""
+        return Param(A.P_VGATHER, src=src, vsrc=vsrc, vn=int(n), vlen=int(vlen), xf=xf)
 
     @staticmethod
     def affine(matrix, src: str, bias=0.0, elem: int = 0, xf=A.XF_NONE) -> "Param":
@@ -146,6 +156,8 @@ class SiteList:
                 ncat = int(p0.values.shape[1])
             elif p0.op == A.P_AFFINE:
                 ncat = int((p0.terms[0][1] if p0.terms else p0.matrix).shape[0])
+            elif p0.op == A.P_VGATHER:
+                ncat = int(p0.vlen)
             else:
                 ncat = int(p0.length)
             dim = 1
@@ -158,6 +170,8 @@ class SiteList:
                     dim = max(dim, int(p.length))
                 elif p.op == A.P_GATHER:
                     dim = max(dim, int(p.values.shape[1]))
+                elif p.op == A.P_VGATHER:
+                    dim = max(dim, int(p.vlen))
                 elif p.op == A.P_AFFINE:
                     dim = max(dim, int((p.terms[0][1] if p.terms else p.matrix).shape[0]))
         if kind == A.DIRICHLET and int(dim) > 256:
@@ -235,6 +249,9 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
             if not any(a_ in where for a_, _ in p.terms):
                 return p
             raise _Unrollable()         # (an affine form over several sites, one of them a compacted instance)
+        if p.op == A.P_VGATHER and p.vsrc in where:
+            daddr, off = where[p.vsrc]
+            p = dataclasses.replace(p, vsrc=daddr, vsrc_elem=p.vsrc_elem + off)
         if p.src in where:
             daddr, off = where[p.src]
             return dataclasses.replace(p, src=daddr, src_elem=p.src_elem + off)
@@ -321,6 +338,14 @@ def fold_known(p: Param, known: dict, rows: int) -> Param:
         if not rest:
             return Param.const(bias, xf=p.xf)
         return Param(A.P_AFFINE, values=bias.astype(np.float32), src=rest[0][0], xf=p.xf, terms=rest)
+    if p.op == A.P_VGATHER:
+        if p.vsrc in known:          # the indexed choice is known: an ordinary row gather of a constant table
+            t = np.asarray(known[p.vsrc], np.float32).ravel()[p.vsrc_elem:p.vsrc_elem + p.vn * p.vlen].reshape(p.vn, p.vlen)
+            return fold_known(Param(A.P_GATHER, values=t, src=p.src, src_elem=p.src_elem, xf=p.xf, d_elem=p.d_elem), known, rows)
+        if p.src in known:           # the index is known: a plain read of that row
+            idx = int(np.clip(int(np.asarray(known[p.src]).ravel()[p.src_elem]), 0, p.vn - 1))
+            return Param.value(p.vsrc, length=p.vlen, elem=p.vsrc_elem + idx * p.vlen, xf=p.xf)
+        return p
     if p.src not in known:
         return p
     v = np.asarray(known[p.src], np.float64).ravel()[p.src_elem:]
@@ -404,6 +429,13 @@ def _try_plate(group, names, n: int, modes: dict, obs: dict, sel: set, where: di
                 share = _same(vs)
                 params.append(Param(A.P_GATHER, values=p0.values if share else np.stack(vs), src=src, src_elem=elem0, xf=p0.xf,
                                     d_elem=d_elem, inst_values=not share))
+            elif p0.op == A.P_VGATHER:
+                # the indexed choice lives outside this plate and is the same for every instance; the index advances like a gather's
+                if any(q.vsrc != p0.vsrc or q.vsrc_elem != p0.vsrc_elem or q.vn != p0.vn or q.vlen != p0.vlen for q in ps) or p0.vsrc in inside:
+                    return None
+                vs_, ve_ = where.get(p0.vsrc, (p0.vsrc, 0))
+                params.append(Param(A.P_VGATHER, src=src, src_elem=elem0, xf=p0.xf, d_elem=d_elem, vsrc=vs_, vsrc_elem=p0.vsrc_elem + ve_,
+                                    vn=p0.vn, vlen=p0.vlen))
             elif p0.op == A.P_AFFINE and not p0.terms:
                 if any(q.matrix.shape != p0.matrix.shape or q.values.size != p0.values.size for q in ps):
                     return None
@@ -619,9 +651,12 @@ class PackedProgram:
                 cp = cs.p[k]
                 cp.op, cp.xf = p.op, p.xf
                 if p.op != A.P_CONST:
-                    for a_src in ([t[0] for t in p.terms] if p.terms else [p.src]):
+                    for a_src in ([t[0] for t in p.terms] if p.terms else ([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src])):
                         if a_src not in order or order[a_src] >= j:
                             raise ValueError(f"site {s.addr!r} reads {a_src!r} before it is traced")
+                if p.op == A.P_VGATHER:
+                    self._pack_vgather(cp, p, s)
+                    continue
                 if p.terms:
                     self._pack_affine_multi(cp, p, s, rows, push)
                     continue
@@ -697,6 +732,31 @@ class PackedProgram:
 
     def _tab_view(self) -> np.ndarray:
         return self.tab if hasattr(self, "tab") else np.concatenate(self._tab_parts)
+
+    def _pack_vgather(self, cp, p: Param, s: Site) -> None:
+        """value(vsrc)[idx]: four cases by who owns storage.  A choice constrained to one value for every particle lives in the table:
+        the indexed choice there -> an ordinary GATHER whose table IS the observed value (set_obs keeps working); the index there ->
+        VGATHER with slot = -1 and the index read from the table; both there -> GATHER on the table index is not expressible, so the
+        row is a CONST at the observed offsets only when not in a plate."""
+        v_lat, i_lat = self.slot_of[p.vsrc] >= 0, self.slot_of[p.src] >= 0
+        cp.n, cp.len = int(p.vn), int(p.vlen)
+        if v_lat:
+            cp.op = A.P_VGATHER
+            cp.moff = self.slot_of[p.vsrc] + p.vsrc_elem
+            if i_lat:
+                cp.slot, cp.d_slot = self.slot_of[p.src] + p.src_elem, int(p.d_elem)
+            else:
+                cp.slot, cp.off, cp.d_off = -1, self.obs_off[p.src] + p.src_elem, int(p.d_elem)
+        elif i_lat:
+            cp.op = A.P_GATHER
+            cp.off = self.obs_off[p.vsrc] + p.vsrc_elem
+            cp.slot, cp.d_slot = self.slot_of[p.src] + p.src_elem, int(p.d_elem)
+        else:
+            if s.plate and p.d_elem:
+                raise NotImplementedError("take(observed vector, observed index) inside a plate: constrain one of them per particle")
+            idx = int(np.clip(int(self._obs_value(p.src)[p.src_elem]), 0, p.vn - 1))
+            cp.op = A.P_CONST
+            cp.off, cp.len = self.obs_off[p.vsrc] + p.vsrc_elem + idx * p.vlen, int(p.vlen)
 
     def _pack_affine_multi(self, cp, p: Param, s: Site, rows: int, push) -> None:
         ninst = s.plate_n if s.plate else 1

@@ -89,7 +89,13 @@ enum {
   GJX_P_CONST = 0,  /* tab[off + (d % len)]                                               */
   GJX_P_VALUE = 1,  /* choices[slot + (d % len)][i]                                       */
   GJX_P_GATHER = 2, /* tab[off + clamp((int)choices[slot][i], 0, n-1) * len + (d % len)]  */
-  GJX_P_AFFINE = 3  /* tab[off + (d % len)] + sum_{e<n} tab[moff + d*n + e] * choices[slot+e][i] */
+  GJX_P_AFFINE = 3, /* tab[off + (d % len)] + sum_{e<n} tab[moff + d*n + e] * choices[slot+e][i] */
+  GJX_P_VGATHER = 4 /* choices[moff + clamp(idx, 0, n-1) * len + (d % len)][i]: a row of an EARLIER vector-valued choice (first slot
+                       `moff`, n rows of `len` values: the component means of a mixture with latent means, mu[z]) picked by a discrete
+                       choice — idx = (int)choices[slot][i], or, slot < 0 (the index site is constrained to one value for every
+                       particle and owns no storage), idx = (int)tab[off].  Differentiable in the picked row (gjx_hmc,
+                       gjx_score_grad: the gradient goes to row moff + idx * len + d % len).  Plate strides: slot + i d_slot (or
+                       off + i d_off), moff + i d_moff */
 };
 /* unary transform applied to the evaluated parameter */
 enum { GJX_XF_NONE = 0, GJX_XF_EXP = 1, GJX_XF_SOFTPLUS = 2, GJX_XF_SIGMOID = 3 };
@@ -126,11 +132,11 @@ enum { GJX_SITE_HMC_SELECTED = 1, /* gjx_site.flags: site is moved by gjx_hmc (h
 typedef struct gjx_param {
   int32_t op;   /* GJX_P_*  */
   int32_t xf;   /* GJX_XF_* */
-  int32_t off;  /* CONST: values; GATHER: table base; AFFINE: bias                 (into tab) */
-  int32_t len;  /* CONST/VALUE: vector length (1 = broadcast); GATHER: row length; AFFINE: bias length */
-  int32_t slot; /* VALUE/AFFINE: first source slot; GATHER: slot holding the index             */
-  int32_t n;    /* AFFINE: inner length; GATHER: number of rows                                */
-  int32_t moff; /* AFFINE: matrix [dim][n] row-major                               (into tab) */
+  int32_t off;  /* CONST: values; GATHER: table base; AFFINE: bias; VGATHER with slot < 0: the index (into tab) */
+  int32_t len;  /* CONST/VALUE: vector length (1 = broadcast); GATHER/VGATHER: row length; AFFINE: bias length */
+  int32_t slot; /* VALUE/AFFINE: first source slot; GATHER/VGATHER: slot holding the index     */
+  int32_t n;    /* AFFINE: inner length; GATHER/VGATHER: number of rows                        */
+  int32_t moff; /* AFFINE: matrix [dim][n] row-major (into tab); VGATHER: first SLOT of the indexed choice */
   /* plate strides (sites with gjx_site.plate != 0, see "Plates" below): instance i evaluates the parameter with
    * off + i * d_off, slot + i * d_slot, moff + i * d_moff.  All 0 outside plates and for what the instances share. */
   int32_t d_off, d_slot, d_moff;

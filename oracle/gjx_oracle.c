@@ -272,6 +272,15 @@ static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 static inline float xlogyf(float x, float y) { return x == 0.0f ? 0.0f : x * logf(y); }
 static inline float xlog1pyf(float x, float y) { return x == 0.0f ? 0.0f : x * log1pf(y); }
 
+/* GJX_P_VGATHER: the slot the parameter reads — row idx of an earlier vector-valued choice, idx an earlier discrete choice (or, when
+ * that choice is constrained to one value for every particle, its value in the table) */
+static int vgather_row(const gjx_param* p, int d, const float* tab, const float* vals) {
+  int idx = (int)(p->slot >= 0 ? vals[p->slot] : tab[p->off]);
+  if (idx < 0) idx = 0;
+  if (idx > p->n - 1) idx = p->n - 1;
+  return p->moff + idx * p->len + (d % p->len);
+}
+
 static float eval_param(const gjx_param* p, int d, const float* tab, const float* vals) {
   float v;
   switch (p->op) {
@@ -290,6 +299,7 @@ static float eval_param(const gjx_param* p, int d, const float* tab, const float
       v = acc;
       break;
     }
+    case GJX_P_VGATHER: v = vals[vgather_row(p, d, tab, vals)]; break;
     default: v = NAN;
   }
   switch (p->xf) {
@@ -574,7 +584,10 @@ static float run_site(const gjx_program* prog, const gjx_site* s0, int inst, con
     const int w = (s->kind == GJX_CATEGORICAL_LOGITS || s->kind == GJX_CATEGORICAL_PROBS) ? 1 : s->dim;
     if (s->slot >= 0) s->slot += inst * w;
     s->obs_off += inst * s->d_obs;
-    for (int k = 0; k < GJX_MAX_PARAMS; ++k) { s->p[k].off += inst * s->p[k].d_off; s->p[k].slot += inst * s->p[k].d_slot; s->p[k].moff += inst * s->p[k].d_moff; }
+    for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
+      s->p[k].off += inst * s->p[k].d_off; s->p[k].moff += inst * s->p[k].d_moff;
+      if (s->p[k].slot >= 0) s->p[k].slot += inst * s->p[k].d_slot; /* (VGATHER with slot < 0: the index comes from the table) */
+    }
   }
   /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
    * (distribution.py:129-143): resolve it to one of the two plain modes for THIS particle */
@@ -1241,6 +1254,7 @@ static void param_backprop(const gjx_param* p, int d, float g, const float* tab,
     case GJX_P_AFFINE:
       for (int e = 0; e < p->n; ++e) grad[p->slot + e] += g * tab[p->moff + d * p->n + e];
       break;
+    case GJX_P_VGATHER: grad[vgather_row(p, d, tab, vals)] += g; break;
     default: break; /* CONST, GATHER: no float dependence */
   }
 }
@@ -1317,7 +1331,10 @@ static gjx_site site_instance(const gjx_site* s0, int inst) {
     const int w = (sv.kind == GJX_CATEGORICAL_LOGITS || sv.kind == GJX_CATEGORICAL_PROBS) ? 1 : sv.dim;
     if (sv.slot >= 0) sv.slot += inst * w;
     sv.obs_off += inst * sv.d_obs;
-    for (int k = 0; k < GJX_MAX_PARAMS; ++k) { sv.p[k].off += inst * sv.p[k].d_off; sv.p[k].slot += inst * sv.p[k].d_slot; sv.p[k].moff += inst * sv.p[k].d_moff; }
+    for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
+      sv.p[k].off += inst * sv.p[k].d_off; sv.p[k].moff += inst * sv.p[k].d_moff;
+      if (sv.p[k].slot >= 0) sv.p[k].slot += inst * sv.p[k].d_slot;
+    }
   }
   return sv;
 }

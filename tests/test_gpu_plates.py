@@ -344,6 +344,103 @@ def test_hmc_moves_the_latents_inside_a_plate_on_the_interpreter(rng):
     assert np.abs(_np(g["choices"])[1 + P:] - ch[1 + P:]).max() > 1e-3           # the latents inside the plate moved
 
 
+def _mixture_with_latent_means(N, seed=0):
+    """the Bayesian mixture: mu ~ N(0, 3^2 I_3), ls ~ N(0, 1); per datum z_i ~ categorical(logits), x_i ~ normal(mu[z_i], exp(ls)) — the
+    component mean is a row of a LATENT choice picked by a discrete choice (GJX_P_VGATHER)"""
+    rs = np.random.default_rng(seed)
+    true_mu = np.array([-2.5, 0.0, 3.0], np.float32)
+    ztrue = rs.integers(0, 3, N)
+    ys = (true_mu[ztrue] + 0.6 * rs.standard_normal(N)).astype(np.float32)
+    logits = np.array([0.2, -0.3, 0.1], np.float32)
+
+    @genjax.gen
+    def kern(mu, ls, lg):
+        z = genjax.categorical(logits=lg) @ "z"
+        return genjax.normal(mu[z], genjax.exp(ls)) @ "x"
+
+    @genjax.gen
+    def model():
+        mu = genjax.normal(np.zeros(3, np.float32), 3.0) @ "mu"
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        kern.repeat(n=N)(mu, ls, logits) @ "k"
+
+    return model, ys, logits, ztrue
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+@pytest.mark.parametrize("engine", ["gen", "interp"])
+def test_mixture_with_latent_means_matches_the_oracle(rng, engine, monkeypatch):
+    """importance over (mu, ls, z) with x observed: the x site reads mu[z_i] — one of the rows of an earlier latent choice — in the
+    generated kernel (registers picked by a select chain) and in the interpreter, against the oracle and against numpy"""
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, K = 300, 3000
+    model, ys, logits, _ = _mixture_with_latent_means(N)
+    prog, _, _ = model.pack((), C["k", "x"].set(ys), True, rng_mode=rng)
+    assert prog.n_sites == 4 and prog.c_sites[3].p[0].op == A.P_VGATHER and (prog.c_sites[3].p[0].moff, prog.c_sites[3].p[0].n, prog.c_sites[3].p[0].d_slot) == (0, 3, 1)
+    monkeypatch.setenv("GJX_ENGINE", engine)
+    assert kernels.program_engine(prog) == (4 if engine == "gen" else 0)
+    out = kernels.run_program(prog, (0, 4), K)
+    ora = cpu.run_program(prog, (0, 4), K, want_margin=True)
+    _check_against_oracle(prog, out, ora)
+    ch = _np(out["choices"])
+    mu, ls, z = ch[:3], ch[3], ch[4:4 + N].astype(int)
+    lx = (-0.5 * ((ys[:, None] - np.take_along_axis(mu, z, axis=0)) / np.exp(ls)) ** 2 - ls - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(_np(out["weight"]), lx, rtol=3e-4, atol=3e-2)
+
+
+@pytest.mark.parametrize("z_shared", [False, True])
+def test_hmc_over_the_means_and_log_sigma_of_the_4096_datum_mixture(z_shared, monkeypatch):
+    """HMC.edit over (mu, ls) of the 4096-datum vmapped mixture with the assignments z fixed — per chain (rows of the chain), or one
+    assignment for every chain (the index of the row gather then comes from the table) —: a generated kernel (the plate loop dealt to
+    the lanes of a chain, select chains forwards and for the gradient), the interpreter and the oracle follow the same trajectories;
+    gjx_score_grad's gradient rows against the oracle"""
+    import torch
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, n = 4096, 256
+    model, ys, logits, ztrue = _mixture_with_latent_means(N, seed=3)
+    rs = np.random.default_rng(7)
+    if z_shared:
+        zfix = ztrue.astype(np.float32)
+        prog, _, _ = model.pack((), C["k", "x"].set(ys) | C["k", "z"].set(zfix), False, selected=("mu", "ls"), per_particle=("mu", "ls"), plates="hmc")
+        assert prog.n_slots == 4 and prog.c_sites[3].p[0].op == A.P_VGATHER and prog.c_sites[3].p[0].slot == -1
+    else:
+        lat = ["mu", "ls"] + [(("k", "z"), i) for i in range(N)]
+        prog, _, _ = model.pack((), C["k", "x"].set(ys), False, selected=("mu", "ls"), per_particle=tuple(lat), plates="hmc")
+        assert prog.n_slots == 4 + N and prog.c_sites[3].p[0].slot == 4
+    assert prog.n_sites == 4 and prog.c_sites[2].plate == 1 and prog.c_sites[3].plate == 1
+    ch = np.zeros((prog.n_slots, n), np.float32)
+    # chains start near the mode (the posterior of 4096 data is narrow: sd of a mean about 0.016), a few assignments wrong per chain
+    ch[:3] = np.array([-2.5, 0.0, 3.0], np.float32)[:, None] + 0.03 * rs.standard_normal((3, n))
+    ch[3] = np.log(0.6) + 0.02 * rs.standard_normal(n)
+    if not z_shared:
+        ch[4:] = np.where(rs.uniform(size=(N, n)) < 0.01, rs.integers(0, 3, (N, n)), ztrue[:, None])
+    gs, gg = kernels.score_grad(prog, torch.as_tensor(ch).cuda())
+    os_, og = cpu.score_grad(prog, ch)
+    np.testing.assert_allclose(_np(gs), os_, rtol=3e-4, atol=5e-2)
+    np.testing.assert_allclose(_np(gg)[:4], og[:4], rtol=3e-3, atol=5e-2)
+    assert np.abs(og[:4]).max() > 10.0
+    src = kernels.program_hmc_source(prog)
+    assert "plate of 4096 instances x 2 sites" in src and "gi_3_0 == 2 ? w_ : 0.0f" in src
+    eps, L = 1e-3, 12
+    outs = {}
+    for engine in ("gen", "interp"):
+        monkeypatch.setenv("GJX_HMC_ENGINE", engine)
+        assert kernels.hmc_engine(prog) == (4 if engine == "gen" else 0)
+        outs[engine] = kernels.hmc(prog, (2, 9), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=5)
+    monkeypatch.delenv("GJX_HMC_ENGINE")
+    o = cpu.hmc(prog, (2, 9), ch, eps, L, False, False, offset=5)
+    g, it = _np(outs["gen"]["choices"]), _np(outs["interp"]["choices"])
+    np.testing.assert_allclose(g[:4], it[:4], rtol=1e-3, atol=3e-4)
+    np.testing.assert_allclose(g[:4], o["choices"][:4], rtol=1e-3, atol=3e-4)
+    # (alpha is a difference of two scores of size 4e3: a position error of 3e-4 under a gradient of 1e3 per unit moves it by 0.3)
+    np.testing.assert_allclose(_np(outs["gen"]["alpha"]), o["alpha"], rtol=2e-2, atol=0.3)
+    np.testing.assert_allclose(_np(outs["gen"]["alpha"]), _np(outs["interp"]["alpha"]), rtol=2e-2, atol=0.3)
+    np.testing.assert_array_equal(g[4:], ch[4:])
+    assert np.abs(g[:4] - ch[:4]).max() > 3e-3
+
+
 def test_config5_written_with_vmap_and_a_two_site_body_runs_on_a_generated_hmc_kernel(monkeypatch):
     """config 5 as a user writes it — `kernel.vmap()(X)` — with TWO observed sites per datum (a binary and a real-valued response
     of the same linear predictor): the HMC packing keeps table-valued plates in the vector form, so both likelihood sites are big

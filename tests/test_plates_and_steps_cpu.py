@@ -99,6 +99,81 @@ def test_jax32_a_plate_advances_the_callers_site_counter_by_one():
     np.testing.assert_array_equal(draws[0][1], draws[1][1])       # "t" is traced site 3 of its caller in both programs
 
 
+def test_a_row_of_a_latent_choice_picked_by_a_discrete_choice():
+    """GJX_P_VGATHER (`mu[z]`, the component mean of a mixture with LATENT means): the host lowering in its four storage cases, the
+    oracle's values against numpy, its gradient against central differences, and the emitted kernels (select chains: registers
+    cannot be indexed)"""
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, K, n = 40, 500, 64
+    rs = np.random.default_rng(0)
+    ys = (2.0 * rs.standard_normal(N)).astype(np.float32)
+    logits = np.array([0.2, -0.3, 0.1], np.float32)
+
+    @genjax.gen
+    def kern(mu, ls, lg):
+        z = genjax.categorical(logits=lg) @ "z"
+        return genjax.normal(mu[z], genjax.exp(ls)) @ "x"
+
+    @genjax.gen
+    def model():
+        mu = genjax.normal(np.zeros(3, np.float32), 3.0) @ "mu"
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        kern.repeat(n=N)(mu, ls, logits) @ "k"
+
+    def score(c):
+        mu, ls, z = c[:3], c[3], c[4:].astype(int)
+        lx = (-0.5 * ((ys[:, None] - np.take_along_axis(mu, z, axis=0)) / np.exp(ls)) ** 2 - ls - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+        lz = (logits - np.log(np.exp(logits).sum()))[z].sum(axis=0)
+        lp = (-0.5 * (mu / 3.0) ** 2 - np.log(3.0) - 0.5 * np.log(2 * np.pi)).sum(axis=0) + (-0.5 * ls ** 2 - 0.5 * np.log(2 * np.pi))
+        return lx, lx + lz + lp
+
+    for rng in (A.RNG_FLAT, A.RNG_JAX32):
+        prog, _, _ = model.pack((), C["k", "x"].set(ys), True, rng_mode=rng)
+        q = prog.c_sites[3].p[0]
+        assert prog.n_sites == 4 and (q.op, q.slot, q.moff, q.n, q.len, q.d_slot, q.d_moff) == (A.P_VGATHER, 4, 0, 3, 1, 1, 0)
+        o = cpu.run_program(prog, (0, 5), K)
+        lx, sc = score(o["choices"].astype(np.float64))
+        np.testing.assert_allclose(o["weight"], lx, rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(o["score"], sc, rtol=2e-5, atol=2e-3)
+    assert "vg_3_0 = gi_3_0[p] == 2 ? v[2][p] : vg_3_0" in kernels.program_source(prog, 1)
+    kernels.program_precompile(prog, 1)
+    # the HMC program: z fixed per chain
+    lat = ["mu", "ls"] + [(("k", "z"), i) for i in range(N)]
+    hp, _, _ = model.pack((), C["k", "x"].set(ys), False, selected=("mu", "ls"), per_particle=tuple(lat), plates="hmc")
+    ch = np.zeros((hp.n_slots, n), np.float32)
+    ch[:3], ch[3], ch[4:] = rs.standard_normal((3, n)), 0.1 * rs.standard_normal(n), rs.integers(0, 3, (N, n))
+    sc, g = cpu.score_grad(hp, ch)
+    c64 = ch.astype(np.float64)
+    np.testing.assert_allclose(sc, score(c64)[1], rtol=2e-5, atol=2e-3)
+    for r in range(4):
+        e = np.zeros_like(c64)
+        e[r] = 1e-5
+        num = (score(c64 + e)[1] - score(c64 - e)[1]) / 2e-5
+        np.testing.assert_allclose(g[r], num, rtol=2e-4, atol=2e-4 * np.abs(num).max())
+    assert not g[4:].any()
+    src = kernels.program_hmc_source(hp)
+    assert "ga[2] += gi_3_0 == 2 ? w_ : 0.0f" in src and "pre_0 = gi_3_0 == 1 ? v[1] : pre_0" in src
+    kernels.program_hmc_precompile(hp)
+    # z constrained to ONE assignment for every chain: it owns no storage, the index of the row comes from the table
+    zfix = rs.integers(0, 3, N).astype(np.float32)
+    hp2, _, _ = model.pack((), C["k", "x"].set(ys) | C["k", "z"].set(zfix), False, selected=("mu", "ls"), per_particle=("mu", "ls"), plates="hmc")
+    q = hp2.c_sites[3].p[0]
+    assert (q.op, q.slot, q.d_off, hp2.n_slots) == (A.P_VGATHER, -1, 1, 4) and np.array_equal(hp2.tab[q.off:q.off + N], zfix)
+    sc2, g2 = cpu.score_grad(hp2, ch[:4].copy())
+    full = np.concatenate([ch[:4], np.repeat(zfix[:, None], n, axis=1)]).astype(np.float64)
+    np.testing.assert_allclose(sc2, score(full)[1], rtol=2e-5, atol=2e-3)
+    assert "(int)TAB((" in kernels.program_hmc_source(hp2)
+    # mu constrained for everybody, z latent: an ordinary row gather whose table IS the observed value (set_obs keeps working)
+    p3, _, _ = model.pack((), C["k", "x"].set(ys) | C["mu"].set(np.array([-1.0, 0.5, 2.0], np.float32)), True)
+    q = p3.c_sites[3].p[0]
+    assert q.op == A.P_GATHER and np.array_equal(p3.tab[q.off:q.off + 3], [-1.0, 0.5, 2.0])
+    o3 = cpu.run_program(p3, (0, 5), K)
+    p3.set_obs("mu", np.array([0.0, 0.0, 0.0], np.float32))
+    o4 = cpu.run_program(p3, (0, 5), K)
+    assert np.abs(o3["weight"] - o4["weight"]).max() > 1.0
+
+
 def test_plate_assess_equals_the_unrolled_program():
     """no randomness: a trace's score on the plate lowering == on the unrolled one (per-instance tables, observations, masks,
     an affine row per instance over two latent sites outside the plate)"""
