@@ -1233,19 +1233,24 @@ def run_round5(dev):
     y = (rs.uniform(size=N) < 0.5).astype(np.float32)
     lat = ["ls", "beta"] + [(("k", "eta"), i) for i in range(N)]
     prog, _, _ = model.pack((), CM["k", "y"].set(y), False, selected=("ls", "beta"), per_particle=tuple(lat), plates="hmc")
+    prog_all, _, _ = model.pack((), CM["k", "y"].set(y), False, selected=tuple(lat), per_particle=tuple(lat), plates="hmc")
     ch0 = (torch.randn((prog.n_slots, n), device=dev) * 0.3).contiguous()
     hm = {}
-    for engine in ("gen", "interp"):
+    for engine in ("gen", "interp", "gen_latents_moved_too", "interp_latents_moved_too"):
+        moved = engine.endswith("_too")
+        prog_ = prog_all if moved else prog
+        prog_run, engine_name = prog_, engine
+        engine = engine.split("_")[0]
         old = os.environ.get("GJX_HMC_ENGINE")
         os.environ["GJX_HMC_ENGINE"] = engine
         try:
-            eng = kernels.hmc_engine(prog)
-            out = kernels.hmc(prog, (1, 2), ch0.clone(), 0.01, L, False, True)
+            eng = kernels.hmc_engine(prog_run)
+            out = kernels.hmc(prog_run, (1, 2), ch0.clone(), 0.01, L, False, True)
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for i in range(3):
-                out = kernels.hmc(prog, (1, 3 + i), ch0.clone(), 0.01, L, False, True, ws=out["_ws"])
+                out = kernels.hmc(prog_run, (1, 3 + i), ch0.clone(), 0.01, L, False, True, ws=out["_ws"])
             b.record()
             torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 3
@@ -1254,12 +1259,14 @@ def run_round5(dev):
                 del os.environ["GJX_HMC_ENGINE"]
             else:
                 os.environ["GJX_HMC_ENGINE"] = old
-        # per chain and gradient sweep: the state rows read once per instance (eta_i: 4 B) — the rest lives in registers / LDS
-        hm[engine] = dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=n * L / (ms * 1e-3), accept_rate=float(out["accepted"].mean()),
+        # per chain and gradient sweep: the state rows read once per instance (eta_i: 4 B) — the rest lives in registers / LDS; with the
+        # latents moved too their position, momentum and gradient rows go through the workspace: 10 accesses per row and leapfrog step
+        hm[engine_name] = dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=n * L / (ms * 1e-3), accept_rate=float(out["accepted"].mean()),
                           roofline=dict(bound="hbm", algorithmic_bytes_per_launch=4.0 * N * n * (L + 1), kernel_us=ms * 1e3,
                                         achieved=4.0 * N * n * (L + 1) / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                         frac=4.0 * N * n * (L + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, timing="event pair around 3 back-to-back moves (incl. a clone of the state)"))
     hm["speedup"] = hm["interp"]["ms_per_move"] / hm["gen"]["ms_per_move"]
+    hm["speedup_latents_moved_too"] = hm["interp_latents_moved_too"]["ms_per_move"] / hm["gen_latents_moved_too"]["ms_per_move"]
     hm["device_sites"], hm["plate_instances"], hm["chains"], hm["leapfrog"] = prog.n_sites, N, n, L
     res["hmc_plate_regression_latent_per_datum_N256"] = hm
 

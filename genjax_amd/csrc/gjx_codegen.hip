@@ -1528,6 +1528,13 @@ struct HmcPlan {
   std::vector<int> sel_of_slot;    // slot -> index among the selected slots, or -1
   std::vector<int> slot_of_sel;
   bool looped = false;             // some site is a rolled loop (CPL = 4)
+  // selected sites INSIDE plates (a latent per instance that HMC moves too): their positions, momenta and gradients are rows of the
+  // caller's workspace — [4][prows][n]: q, p, g, g0 — that the lane which owns the instance reads and writes in the sweep and in the
+  // leapfrog updates; the selected indices m >= nout name one instance's worth of them (registers of the plate loop's body)
+  struct PlateSel { int j, reg, dim, row, d_row, plate_n, prow0, leaf, m0; };
+  std::vector<PlateSel> psel;
+  int prows = 0, nout = 0;
+  std::vector<int> leaf_of_site;   // momentum leaf (hmc.py:120-130: one per selected address, in program order) or -1
   // rolled sites whose AFFINE parameter runs on the matrix cores (hmc_emit_mfma_site): parameter index or -1 per site, offset
   // of the site's transposed matrix in the second LDS array, and what the layout needs from the launch
   bool mfma = false;
@@ -1608,7 +1615,8 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
     if (ri.plate) {
       // a plate's body: scored and differentiated instance by instance inside the sweep; what HMC moves lives outside the plate
       // (a selected per-instance latent would be plate_n x dim chain registers: the site interpreter keeps that state in memory)
-      if ((s.flags & GJX_SITE_HMC_SELECTED) || (!is_categorical(s.kind) && s.dim > kMaxExpandDim)) return false;
+      if (!is_categorical(s.kind) && s.dim > kMaxExpandDim) return false;
+      if ((s.flags & GJX_SITE_HMC_SELECTED) && (is_categorical(s.kind) || s.slot < 0 || getenv("GJX_HMC_GEN_NO_PLATE_SEL"))) return false;
       pl.looped = true;
     }
     if (is_categorical(s.kind)) {
@@ -1628,8 +1636,24 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
       if (q.op == GJX_P_VGATHER && (q.n < 1 || q.n * q.len > 32 || q.moff < 0 || q.moff + q.n * q.len > pl.n_regs || (big && q.len != 1))) return false;
     }
     if (big) pl.looped = true; else unrolled += s.dim;
-    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0)
+    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0 && !ri.plate)
       for (int d = 0; d < s.dim; ++d) { pl.sel_of_slot[s.slot + d] = pl.nsel++; pl.slot_of_sel.push_back(s.slot + d); }
+  }
+  pl.nout = pl.nsel;
+  pl.leaf_of_site.assign(p->n_sites, -1);
+  {
+    int leaf = 0;
+    for (int j = 0; j < p->n_sites; ++j) {
+      const gjx_site& s = pl.sites[j];
+      const RollInfo& ri = pl.info[j];
+      if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
+      pl.leaf_of_site[j] = leaf++;
+      if (!ri.plate) continue;
+      HmcPlan::PlateSel ps{j, s.slot, s.dim, ri.row, ri.d_row, ri.plate_n, pl.prows, pl.leaf_of_site[j], pl.nsel};
+      for (int d = 0; d < s.dim; ++d) { pl.sel_of_slot[s.slot + d] = pl.nsel++; pl.slot_of_sel.push_back(s.slot + d); }
+      pl.prows += ri.plate_n * s.dim;
+      pl.psel.push_back(ps);
+    }
   }
   if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
   pl.mf_k.assign(p->n_sites, -1);
@@ -1839,7 +1863,10 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
   o.f("    if (SC) sc_ += %sQSUM(scp_);\n", fold ? "-kLn2 * " : "");
 }
 
-std::string generate_hmc(const gjx_program* prog_in) {
+// cpl_code: lanes per chain of a kernel with loops (plates, rolled sites): 0 = 4; 16 or 64 for FEW chains over LONG loops — the loop's
+// trips are dealt to that many lanes, every lane keeps a copy of the chain's register state (hmc_gen_launch picks it by the number of
+// chains; matrix-core kernels have their own layout)
+std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   HmcPlan hp;
   if (!hmc_plan(prog_in, &hp)) return "";
   // the emitted program: the plan's site list (plates: every slot a register, a body site owns one instance's worth)
@@ -1847,20 +1874,30 @@ std::string generate_hmc(const gjx_program* prog_in) {
   eprog.sites = hp.sites.data();
   eprog.n_slots = hp.n_regs;
   const gjx_program* prog = &eprog;
-  const int cpl = hp.looped ? 4 : 1;
+  int longest = 0;       // the longest loop of the kernel: what more lanes per chain can share
+  for (int j = 0; j < prog_in->n_sites; ++j) {
+    const gjx_site& s = hp.sites[j];
+    const int len = hp.info[j].plate ? hp.info[j].plate_n : (!is_categorical(s.kind) && s.dim > kMaxExpandDim ? s.dim : 0);
+    longest = len > longest ? len : longest;
+  }
+  const int cpl_max = (!hp.looped || hp.mfma) ? (hp.looped ? 4 : 1) : (longest >= 256 ? 64 : (longest >= 64 ? 16 : 4));
+  const int cpl = !hp.looped ? 1 : ((cpl_code == 16 || cpl_code == 64) && cpl_code <= cpl_max ? cpl_code : 4);
   const int NS = prog->n_slots, NSEL = hp.nsel;
   Emit o;
   o.f("#include \"gjx_device.h\"\nusing namespace gjx;\n#define RNG %d\n#define CPL %d\n#define NS %d\n#define NSEL %d\n#define NTAB %d\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, cpl, NS, NSEL, prog->n_tab);
   o.f("#define TAB(i) tab_s[i]\n#define BT %d\n#define XTF %d\ntypedef float v4f_ __attribute__((ext_vector_type(4)));\n", hp.block, hp.xt_floats);
+  // NOUT: selected values outside plates (chain state in registers); PROWS: rows of the selected sites inside plates (state in the workspace)
+  o.f("#define NOUT %d\n#define PROWS %d\n", hp.nout, hp.prows);
   // the lanes of a chain: an aligned quad, or with a matrix-core site the four 16-lane rows of the wave (lane & 15 = chain)
   if (hp.mfma) o.f("GJX_DEV float QSUM(float x) { x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64); return x; }\n");
-  else o.f("#define QSUM(x) quad_sum(x)\n");
+  else if (cpl <= 4) o.f("#define QSUM(x) quad_sum(x)\n");
+  else o.f("GJX_DEV float QSUM(float x) { _Pragma(\"unroll\") for (int o_ = 1; o_ < CPL; o_ <<= 1) x += __shfl_xor(x, o_, 64); return x; }\n");
   // ---- the sweep: score (SC) and gradient of the selected slots.  ch_ / n_ / ic_: the chain's column of choices[][] — a plate's
   //      body sites with per-chain values (OBS_SLOT) read their instance's rows from there, sweep after sweep
   o.f("template <bool SC>\nGJX_DEV float sweep(float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_,\n"
-      "                  const float* __restrict__ ch_, const int64_t n_, const int64_t ic_) {\n"
-      "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s; (void)ch_; (void)n_; (void)ic_;\n"
+      "                  const float* __restrict__ ch_, const int64_t n_, const int64_t ic_, const float* wq_, float* wg_, const bool live_) {\n"
+      "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s; (void)ch_; (void)n_; (void)ic_; (void)wq_; (void)wg_; (void)live_;\n"
       "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
   // one site: `acc` / `sc` name the gradient and score accumulators (a plate's body adds to per-lane partials)
   auto emit_one = [&](int j, const char* acc, const char* sc) {
@@ -1926,10 +1963,19 @@ std::string generate_hmc(const gjx_program* prog_in) {
       const RollInfo& rl = hp.info[j + l];
       if (sl.slot < 0) continue;
       const int w = is_categorical(sl.kind) ? 1 : sl.dim;
-      for (int d = 0; d < w; ++d) o.f("    v[%d] = ch_[(int64_t)(%d + i_ * %d + %d) * n_ + ic_];\n", sl.slot + d, rl.row, rl.d_row, d);
+      const HmcPlan::PlateSel* ps = nullptr;
+      for (const auto& c : hp.psel) if (c.j == j + l) ps = &c;
+      for (int d = 0; d < w; ++d) {
+        // a selected body site: the trajectory's current position of this instance (workspace row), and its gradient row starts at 0
+        if (ps) o.f("    v[%d] = wq_[(int64_t)(%d + i_ * %d + %d) * n_ + ic_];\n    ga[%d] = 0.0f;\n", sl.slot + d, ps->prow0, ps->dim, d, ps->m0 + d);
+        else o.f("    v[%d] = ch_[(int64_t)(%d + i_ * %d + %d) * n_ + ic_];\n", sl.slot + d, rl.row, rl.d_row, d);
+      }
     }
     for (int l = 0; l < m; ++l) emit_one(j + l, "ga", "scp_");
-    o.f("    }\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] += CPL > 1 ? QSUM(ga[m_]) : ga[m_];\n    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n  }\n");
+    for (const auto& c : hp.psel)
+      if (c.j >= j && c.j < j + m)
+        for (int d = 0; d < c.dim; ++d) o.f("    if (live_) wg_[(int64_t)(%d + i_ * %d + %d) * n_ + ic_] = ga[%d];\n", c.prow0, c.dim, d, c.m0 + d);
+    o.f("    }\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) g[m_] += CPL > 1 ? QSUM(ga[m_]) : ga[m_];\n    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n  }\n");
     j += m;
   }
   o.f("  return sc_;\n}\n\n");
@@ -1973,31 +2019,66 @@ std::string generate_hmc(const gjx_program* prog_in) {
     const int w = is_categorical(sj.kind) ? 1 : sj.dim;
     for (int d = 0; d < w; ++d) o.f("  v[%d] = a.choices[(int64_t)%d * n + i];\n", sj.slot + d, hp.info[j].row + d);
   }
-  o.f("  const float score0 = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i);   // hmc.py:165-166\n"
+  // the rows of the selected sites inside plates: working positions, momenta, gradients (and the first gradient for the stale-carry
+  // compatibility mode) in the caller's workspace, [4][PROWS][n]; a lane owns the instances q_, q_ + CPL, ... of its chain
+  auto plate_rows = [&](const char* body) {     // `body` sees idx_ (row * n + chain) and e_ (the element's index within its leaf)
+    for (const auto& c : hp.psel)
+      o.f("  _Pragma(\"nounroll\") for (int i_ = q_; i_ < %d; i_ += CPL) _Pragma(\"unroll\") for (int d_ = 0; d_ < %d; ++d_) {\n"
+          "    const int64_t idx_ = (int64_t)(%d + i_ * %d + d_) * n + i, src_ = (int64_t)(%d + i_ * %d + d_) * n + i; const uint32_t e_ = (uint32_t)(i_ * %d + d_); (void)src_; (void)e_;\n"
+          "    %s\n  }\n", c.plate_n, c.dim, c.prow0, c.dim, c.row, c.d_row, c.dim, body);
+  };
+  if (hp.prows) {
+    o.f("  float* const wq_ = a.ws; float* const wp_ = a.ws + (int64_t)PROWS * n; float* const wg_ = a.ws + 2 * (int64_t)PROWS * n; float* const wg0_ = a.ws + 3 * (int64_t)PROWS * n;\n");
+    plate_rows("if (live) wq_[idx_] = a.choices[src_];");
+  } else {
+    o.f("  float* const wq_ = nullptr; float* const wg_ = nullptr;\n");
+  }
+  o.f("  const float score0 = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i, wq_, wg_, live);   // hmc.py:165-166\n"
       "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g0[m_] = g[m_];\n"
       "  key2 knew{0u, 0u}, sub{0u, 0u};\n"
       "  if (RNG == GJX_RNG_JAX32) { const key2 ck = fold_in64(a.key, gidx); knew = fold_in(ck, 0u); sub = fold_in(ck, 1u); }   // hmc.py:167\n"
       "  float k0 = 0.0f;\n");
+  if (hp.prows) { o.f("  if (a.stale) {\n"); plate_rows("if (live) wg0_[idx_] = wg_[idx_];"); o.f("  }\n"); }
   {   // momenta (hmc.py:120-130): leaf l = l-th selected address in program order
-    int leaf = 0, m = 0;
+    int m = 0;
     for (int j = 0; j < prog->n_sites; ++j) {
       const gjx_site& s = prog->sites[j];
-      if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
+      const int leaf = hp.leaf_of_site[j];
+      if (leaf < 0) continue;
+      if (hp.info[j].plate) {
+        // a selected body site is ONE leaf: element i dim + d for instance i — drawn by the lane that owns the instance
+        for (const auto& c : hp.psel) {
+          if (c.j != j) continue;
+          o.f("  { float kp_ = 0.0f;\n  _Pragma(\"nounroll\") for (int i_ = q_; i_ < %d; i_ += CPL) {\n"
+              "    BitStreamRT<RNG> bs;\n    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, %du)); else bs.open(a.key, gidx, %du);\n", c.plate_n, leaf, leaf + 1);
+          o.f("    _Pragma(\"unroll\") for (int d_ = 0; d_ < %d; ++d_) {\n      const float pm_ = stream_normal<RNG>(bs, (uint32_t)(i_ * %d + d_));\n"
+              "      if (live) wp_[(int64_t)(%d + i_ * %d + d_) * n + i] = pm_;\n      kp_ += -0.5f * pm_ * pm_ - kHalfLog2Pi;\n    }\n  }\n"
+              "  k0 += CPL > 1 ? QSUM(kp_) : kp_; }\n", c.dim, c.dim, c.prow0, c.dim);
+        }
+        continue;
+      }
       o.f("  { BitStreamRT<RNG> bs;\n    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, %du)); else bs.open(a.key, gidx, %du);\n", leaf, leaf + 1);
       for (int d = 0; d < s.dim; ++d, ++m)
         o.f("    p[%d] = stream_normal<RNG>(bs, %du); k0 += -0.5f * p[%d] * p[%d] - kHalfLog2Pi;\n", m, d, m, m);
       o.f("  }\n");
-      ++leaf;
     }
   }
   o.f("  const float he = 0.5f * a.eps;\n  float sc = score0;\n"
       "  for (int t = 1; t <= a.L; ++t) {   // hmc.py:170-194\n"
-      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * (a.stale ? g0[m_] : g[m_]);   // hmc.py:186: the carry keeps the received gradient\n");
-  for (int m = 0; m < NSEL; ++m) o.f("    v[%d] += a.eps * p[%d];\n", hp.slot_of_sel[m], m);
-  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i); else (void)sweep<false>(v, g, tab_s, xt_s, q_, a.choices, n, i);\n"
-      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) p[m_] += he * g[m_];\n  }\n"
-      "  float k1 = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) { const float q2_ = -1.0f * p[m_]; k1 += -0.5f * q2_ * q2_ - kHalfLog2Pi; }\n"
-      "  const float al = sc - score0 + k1 - k0;   // hmc.py:196-203\n"
+      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) p[m_] += he * (a.stale ? g0[m_] : g[m_]);   // hmc.py:186: the carry keeps the received gradient\n");
+  for (int m = 0; m < hp.nout; ++m) o.f("    v[%d] += a.eps * p[%d];\n", hp.slot_of_sel[m], m);
+  if (hp.prows) plate_rows("{ const float pp_ = wp_[idx_] + he * (a.stale ? wg0_[idx_] : wg_[idx_]); if (live) { wp_[idx_] = pp_; wq_[idx_] += a.eps * pp_; } }");
+  o.f("    if (t == a.L) sc = sweep<true>(v, g, tab_s, xt_s, q_, a.choices, n, i, wq_, wg_, live); else (void)sweep<false>(v, g, tab_s, xt_s, q_, a.choices, n, i, wq_, wg_, live);\n"
+      "    _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) p[m_] += he * g[m_];\n");
+  if (hp.prows) plate_rows("if (live) wp_[idx_] += he * wg_[idx_];");
+  o.f("  }\n"
+      "  float k1 = 0.0f;\n  _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) { const float q2_ = -1.0f * p[m_]; k1 += -0.5f * q2_ * q2_ - kHalfLog2Pi; }\n");
+  if (hp.prows) {
+    o.f("  { float kp_ = 0.0f;\n");
+    plate_rows("{ const float q2_ = -1.0f * wp_[idx_]; kp_ += -0.5f * q2_ * q2_ - kHalfLog2Pi; }");
+    o.f("  k1 += CPL > 1 ? QSUM(kp_) : kp_; }\n");
+  }
+  o.f("  const float al = sc - score0 + k1 - k0;   // hmc.py:196-203\n"
       "  bool acc = true;\n"
       "  if (a.accept) {\n    BitStream<RNG> bs;\n    if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(knew, 0x4d48u)); else bs.open(a.key, gidx, GJX_FLAT_MAX_SITES);\n"
       "    acc = safe_log(bits_to_unit(bs.get(0u))) < al;   // tests/inference/test_requests.py:134-137\n  }\n"
@@ -2011,9 +2092,12 @@ std::string generate_hmc(const gjx_program* prog_in) {
       const int w = is_categorical(sj.kind) ? 1 : sj.dim;
       for (int d = 0; d < w; ++d) row_of_reg[sj.slot + d] = hp.info[j].row + d;
     }
-    for (int m = 0; m < NSEL; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", row_of_reg[hp.slot_of_sel[m]], hp.slot_of_sel[m]);
+    for (int m = 0; m < hp.nout; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", row_of_reg[hp.slot_of_sel[m]], hp.slot_of_sel[m]);
   }
-  o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n}\n");
+  o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n");
+  if (hp.prows) { o.f("  if (acc) {\n"); plate_rows("if (live) a.choices[src_] = wq_[idx_];"); o.f("  }\n"); }
+  o.f("}\n");
+  o.f("// PROWS %d\n// CPLMAX %d\n", hp.prows, cpl_max);
   o.f("// CPL %d\n// BT %d\n// LDS_FLOATS 0\n", cpl, hp.block);
   return o.s;
 }
@@ -2079,6 +2163,8 @@ struct Compiled {
   std::vector<char> code;   // code object
   int lds_floats = 0;
   int cpl = 1, block = 256; // generated HMC kernels: lanes per chain, threads per block
+  int prows = 0;            // generated HMC kernels: workspace rows (selected sites inside plates), x 4 x n floats
+  int cpl_max = 1;          // generated HMC kernels: the most lanes per chain the program's loops can use
   std::string error;        // non-empty: this structure cannot be generated / compiled
 };
 
@@ -2150,7 +2236,7 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   auto it = g_compiled.find(key);
   if (it != g_compiled.end()) return it->second;
   Compiled& c = g_compiled[key];
-  const std::string src = flavour == 1 ? generate_hmc(prog) : (flavour == 2 ? generate_pf(prog, ppt) : generate(prog, ppt));
+  const std::string src = flavour == 1 ? generate_hmc(prog, ppt) : (flavour == 2 ? generate_pf(prog, ppt) : generate(prog, ppt));
   if (src.empty()) { c.error = "codegen: program outside the emitter's coverage"; return c; }
   const size_t m = src.rfind("// LDS_FLOATS ");
   c.lds_floats = atoi(src.c_str() + m + 14);
@@ -2158,6 +2244,10 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   if (mc != std::string::npos) c.cpl = atoi(src.c_str() + mc + 7);
   const size_t mb = src.rfind("// BT ");
   if (mb != std::string::npos) c.block = atoi(src.c_str() + mb + 6);
+  const size_t mp = src.rfind("// PROWS ");
+  if (mp != std::string::npos) c.prows = atoi(src.c_str() + mp + 9);
+  const size_t mx = src.rfind("// CPLMAX ");
+  if (mx != std::string::npos) c.cpl_max = atoi(src.c_str() + mx + 10);
   if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
@@ -2438,13 +2528,26 @@ int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t 
   int cpl = 1, block = 256;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    const Compiled& c = compile(prog, 0, 1);
+    const Compiled& c0 = compile(prog, 0, 1);
+    if (!c0.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c0.error.c_str());
+    // few chains over long loops (the usual shape of HMC: hundreds of chains, thousands of data): more lanes per chain, until the
+    // launch has about two waves per SIMD (GJX_HMC_GEN_CPL forces 4, 16 or 64)
+    int variant = 0;
+    {
+      int want = 4;
+      while (want < c0.cpl_max && args.n * want < 131072) want *= 4;
+      if (const char* e = getenv("GJX_HMC_GEN_CPL")) want = atoi(e);
+      if ((want == 16 || want == 64) && want <= c0.cpl_max) variant = want;
+    }
+    const Compiled& c = variant ? compile(prog, variant, 1) : c0;
     if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
     cpl = c.cpl;
     block = c.block;
+    if (c.prows > 0 && (!args.ws || args.ws_floats < 4 * (int64_t)c.prows * args.n))
+      return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small (selected sites inside a plate keep their trajectory state there)");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return gjx_fail(GJX_EHIP, "codegen: no device");
-    const auto lk = std::make_pair(structure_key(prog, 0, 1), dev);
+    const auto lk = std::make_pair(structure_key(prog, variant, 1), dev);
     auto it = g_loaded.find(lk);
     if (it == g_loaded.end()) {
       hipModule_t mod;

@@ -859,6 +859,8 @@ struct HmcGenArgs {
   float* score;     // [n] or NULL
   float* alpha;     // [n] or NULL
   float* accepted;  // [n] or NULL
+  float* ws;        // [4][PROWS][n]: positions, momenta, gradients, first gradients of the selected sites INSIDE plates (else unused)
+  int64_t ws_floats;
 };
 
 // ---- analytic gradients of the element log-densities (gjx_hmc.hip, generated HMC kernels) ----

@@ -1112,11 +1112,14 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
       return GJX_OK;
     }
   }
-  // a kernel generated from the site list (gjx_codegen.hip): chain state in registers, table in LDS, no workspace
+  // a kernel generated from the site list (gjx_codegen.hip): chain state in registers, table in LDS; the workspace only for the rows of
+  // selected sites inside plates
   if ((pref == 0 || pref == 2) && hmc_gen_available(prog) == GJX_OK) {
     HmcGenArgs ga;
     ga.tab = prog->tab_dev; ga.key = key2{key0, key1}; ga.n = n; ga.offset = chain_offset; ga.eps = eps; ga.L = L;
     ga.stale = stale_grad_compat; ga.accept = accept; ga.choices = choices; ga.score = score; ga.alpha = alpha; ga.accepted = accepted;
+    ga.ws = workspace ? (float*)((char*)workspace + 256) : nullptr;          // (used only by programs with selected sites inside plates)
+    ga.ws_floats = workspace && workspace_bytes > 256 ? (int64_t)((workspace_bytes - 256) / sizeof(float)) : 0;
     return hmc_gen_launch(prog, ga, (hipStream_t)stream);
   }
   if (!workspace || workspace_bytes < gjx_hmc_workspace_bytes(prog, n)) return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small");

@@ -327,21 +327,39 @@ def test_hmc_over_a_plate_tagged_program_generated_kernel_interpreter_and_oracle
 
 
 @pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
-def test_hmc_moves_the_latents_inside_a_plate_on_the_interpreter(rng):
+def test_hmc_moves_the_latents_inside_a_plate(rng, monkeypatch):
     """the N per-datum latents SELECTED as well (one momentum leaf for the whole vmapped address, hmc.py:120-130): chain state of
-    1 + P + N values — the site interpreter keeps it in memory; against the oracle"""
+    1 + P + N values.  The generated kernel keeps the plate's rows — positions, momenta, gradients — in the caller's workspace,
+    read and written by the lane that owns the instance; the site interpreter keeps all state in memory; both against the oracle,
+    with the stale-gradient compatibility mode and with the accept step"""
     import torch
     from genjax_amd import kernels
     from oracle import cpu
-    N, P, n = 64, 3, 256
+    N, P, n = 64, 3, 300                                                         # (300 chains: the last block has idle quads)
     prog = _regression_with_a_latent_per_datum(N, P, rng, select_eta=True)
-    assert kernels.hmc_engine(prog) == 0                                         # (selected rows inside a plate: not a generated kernel)
     ch = (np.random.default_rng(8).standard_normal((prog.n_slots, n)) * 0.3).astype(np.float32)
-    g = kernels.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), 0.01, 10, False, False, offset=3)
-    o = cpu.hmc(prog, (4, 1), ch, 0.01, 10, False, False, offset=3)
-    np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3)
-    np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
-    assert np.abs(_np(g["choices"])[1 + P:] - ch[1 + P:]).max() > 1e-3           # the latents inside the plate moved
+    src = kernels.program_hmc_source(prog)
+    assert "// PROWS 64" in src and "wg_[(int64_t)(0 + i_ * 1 + 0) * n_ + ic_] = ga[" in src
+    for stale, accept in ((False, False), (True, False), (False, True)):
+        eps = 0.03 if accept else 0.01
+        o = cpu.hmc(prog, (4, 1), ch, eps, 10, stale, accept, offset=3)
+        for engine, code in (("gen", 4), ("interp", 0)):
+            monkeypatch.setenv("GJX_HMC_ENGINE", engine)
+            assert kernels.hmc_engine(prog) == code
+            g = kernels.hmc(prog, (4, 1), torch.as_tensor(ch).cuda(), eps, 10, stale, accept, offset=3)
+            gc = _np(g["choices"])
+            if not accept:
+                np.testing.assert_allclose(gc, o["choices"], rtol=3e-3, atol=3e-3)
+                np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=6e-3)
+                np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=6e-3)
+                assert np.abs(gc[1 + P:] - ch[1 + P:]).max() > 1e-3             # the latents inside the plate moved
+            else:
+                acc_g, acc_o = _np(g["accepted"]) > 0.5, o["accepted"] > 0.5
+                assert (acc_g != acc_o).mean() < 0.02 and 0.2 < acc_g.mean() < 1.0
+                same = acc_g == acc_o
+                np.testing.assert_allclose(gc[:, same], o["choices"][:, same], rtol=3e-3, atol=3e-3)
+                np.testing.assert_array_equal(gc[:, ~acc_g], ch[:, ~acc_g])      # a rejected chain keeps every row, the plate's included
+    monkeypatch.delenv("GJX_HMC_ENGINE")
 
 
 def _mixture_with_latent_means(N, seed=0):

@@ -154,6 +154,7 @@ def test_a_row_of_a_latent_choice_picked_by_a_discrete_choice():
     assert not g[4:].any()
     src = kernels.program_hmc_source(hp)
     assert "ga[2] += gi_3_0 == 2 ? w_ : 0.0f" in src and "pre_0 = gi_3_0 == 1 ? v[1] : pre_0" in src
+    assert "// PROWS 0" in src and "// CPLMAX 4" in src          # (40 instances: four lanes per chain is all the loop can use)
     kernels.program_hmc_precompile(hp)
     # z constrained to ONE assignment for every chain: it owns no storage, the index of the row comes from the table
     zfix = rs.integers(0, 3, N).astype(np.float32)
