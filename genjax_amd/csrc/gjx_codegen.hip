@@ -145,6 +145,25 @@ std::string src_val(const gjx_param& q, const RollInfo& ri, int k, const std::st
 struct Plan {
   const gjx_program* prog;
   int ppt;
+  // an observation of the site in front of it, element by element (y ~ normal(x, sigma) right behind x: every state-space and mixture
+  // model's last site) is scored INSIDE that site's element loop — the value is used while it is in a register and its row is stored
+  // at once, so that the rows of x are not held until the next site (fused_into[j] = the site whose loop scores site j, or -1)
+  std::vector<int> fused_into;
+  // straight-line programs (no plates, no rolled Scan, no filter flavour) store their rows through ONE running pointer, advanced by
+  // K from row to row — a base address per row is a pair of scalar registers each, hoisted out of the tile loop, and a program of
+  // 17 rows spills the scalar file.  rp_row: the row the pointer stands at (emitter's bookkeeping), -1 = plain addressing
+  bool seq_rows = false;
+  int rp_row = 0;
+  std::string row_store(const char* macro, const std::string& ind, int row, const std::string& val) {
+    char b[512];
+    if (!seq_rows) { snprintf(b, sizeof(b), "%s%s(a.choices + (int64_t)%d * K + i0, %s);\n", ind.c_str(), macro, row, val.c_str()); return b; }
+    std::string s;
+    const int delta = row - rp_row;
+    rp_row = row;
+    if (delta) { snprintf(b, sizeof(b), "%srp_ += (int64_t)%d * K; asm volatile(\"\" : \"+v\"(rp_));\n", ind.c_str(), delta); s += b; }
+    snprintf(b, sizeof(b), "%s%s(rp_, %s);\n", ind.c_str(), macro, val.c_str());
+    return s + b;
+  }
   bool mfma = false;                // flavour: big affine sites on the matrix cores (static LDS, PPT = 1, K % 256 == 0)
   int mfma_floats = 0;              // floats of the transpose patches (4 waves x 64 particles x inner length)
   bool tab_lds;
@@ -686,11 +705,32 @@ void emit_mfma_site(Emit& o, Plan& pl, int j) {
   o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
 }
 
+// may site j + 1 be scored in the element loop of site j?  (see Plan::fused_into)
+bool fusable_observation(const Plan& pl, int j) {
+  const gjx_program* prog = pl.prog;
+  if (getenv("GJX_GEN_NO_FUSE") || pl.pf || pl.mfma || pl.wide || j + 1 >= prog->n_sites) return false;
+  const gjx_site& a = prog->sites[j];
+  const gjx_site& b = prog->sites[j + 1];
+  const RollInfo& ra = pl.info[j];
+  const RollInfo& rb = pl.info[j + 1];
+  if (ra.plate || rb.plate || ra.load_here || rb.load_here || ra.d_row || rb.d_obs || rb.d_off[0] || rb.d_off[1] || rb.mem_slot[0] >= 0 || rb.mem_slot[1] >= 0) return false;
+  if (a.scan != b.scan) return false;
+  if (is_categorical(a.kind) || a.kind == GJX_DIRICHLET || a.slot < 0 || a.dim > kMaxExpandDim || a.mode != GJX_MODE_SAMPLE || (a.flags & GJX_SITE_PROPOSAL)) return false;
+  if (!is_normal(b.kind) || b.mode != GJX_MODE_OBS_TAB || b.dim != a.dim || (b.flags & GJX_SITE_PROPOSAL)) return false;
+  const gjx_param& m = b.p[0];
+  const gjx_param& sc = b.p[1];
+  if (m.op != GJX_P_VALUE || m.xf != GJX_XF_NONE || m.slot != a.slot || m.len != (a.dim == 1 ? 1 : a.dim)) return false;
+  return sc.op == GJX_P_CONST && sc.xf == GJX_XF_NONE;
+}
+
 void emit_site(Emit& o, Plan& pl, int j) {
   const gjx_program* prog = pl.prog;
   const gjx_site& s = prog->sites[j];
   const RollInfo& ri = pl.info[j];
   g_loop_var = ri.plate ? "i_" : "(t_ - 1)";
+  if (pl.fused_into.size() != (size_t)prog->n_sites) pl.fused_into.assign(prog->n_sites, -1);
+  const bool fuse_next = fusable_observation(pl, j);
+  const bool fused_here = pl.fused_into[j] >= 0;       // this site's elements were scored by the site in front of it
   if (s.mode == GJX_MODE_INPUT) {
     // the carry of a Scan step / an argument: rows that are already there, or the rows of the ancestor the resampling step
     // picked for this slot (gjx_run_program_ex: the particle gather fused into the read side); no draw, no score
@@ -720,10 +760,18 @@ void emit_site(Emit& o, Plan& pl, int j) {
   const int hoist = (!pl.hoist_at.empty() && pl.hoist_at[j] >= 0) ? pl.hoist_at[j] : -1;
   if (pl.stream[j].opens && hoist < 0) {
     const SiteStream& hs = pl.stream[j];
-    o.f("    BitStream<RNG> rs%d[PPT];\n    PLOOP rs%d[p].open(%s, gidx[p], %du);\n", hs.run, hs.run,
+    o.f("    BitStream<RNG> rs%d[PPT];\n    PLOOP rs%d[p].open_hi(%s, GHI_, (uint32_t)gidx[p], %du);\n", hs.run, hs.run,
         hs.key_var.empty() ? "a.key" : hs.key_var.c_str(), hs.site_no);
   }
-  o.f("    { // ---- site %d: kind %d, dim %d, mode %d, slot %d\n", j, kind, is_categorical(kind) ? s.ncat : s.dim, mode, s.slot);
+  int fz_rcp = -1, fz_ys = -1;       // companions of the observation scored in this site's loop: 1 / sigma and y / sigma
+  if (fuse_next) {
+    const gjx_site& b = prog->sites[j + 1];
+    pl.fused_into[j + 1] = j;
+    fz_rcp = pl.find(1, b.p[1].off, table_range(b.p[1]));
+    fz_ys = pl.find(4, b.p[1].off, b.dim, b.p[1].len, b.obs_off);
+    o.f("    float q2f%d[PPT];   // squared z-scores of site %d, taken in the element loop of site %d\n    PLOOP q2f%d[p] = 0.0f;\n", j + 1, j + 1, j, j + 1);
+  }
+  o.f("    { // ---- site %d: kind %d, dim %d, mode %d, slot %d%s\n", j, kind, is_categorical(kind) ? s.ncat : s.dim, mode, s.slot, fused_here ? " (scored in the loop of the site in front)" : "");
   o.f("      float lp[PPT];\n      PLOOP lp[p] = 0.0f;\n");
   // stream key and site number (gjx.h "Scan steps"): chained step keys are wave-uniform locals emitted on first use
   const SiteStream& ss = pl.stream[j];
@@ -747,8 +795,8 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // enclosing scope), members 2k and 2k+1 share one Box-Muller evaluation through its pair cache
     o.f("      BitStream<RNG> (&bs)[PPT] = rs%d;\n", ss.run);
   } else if (draws) {
-    if (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(a.key, gidx[p], %du);\n", ss.site_no);
-    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open(%s, gidx[p], %du);\n", ss.key_var.c_str(), ss.site_no);
+    if (prog->rng_mode != GJX_RNG_FLAT || ss.key_var.empty()) o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open_hi(a.key, GHI_, (uint32_t)gidx[p], %du);\n", ss.site_no);
+    else o.f("      BitStream<RNG> bs[PPT];\n      PLOOP bs[p].open_hi(%s, GHI_, (uint32_t)gidx[p], %du);\n", ss.key_var.c_str(), ss.site_no);
   }
   if (ri.load_here) {   // per-particle constraint rows / mask flags whose row moves with t_ or differs from the register number
     const int nrow_ = is_categorical(kind) ? 1 : s.dim;
@@ -826,6 +874,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
     // diagonal normals accumulate the squared z-scores; the normaliser is one constant per (gathered) row of the
     // scale table, or summed alongside when the scale is not a plain table entry
     if (norm && need_lp) o.f("      float q2[PPT], ls[PPT];\n      PLOOP { q2[p] = 0.0f; ls[p] = 0.0f; }\n");
+    const bool store_early = expand && s.slot >= 0 && mode != GJX_MODE_OBS_SLOT && !ri.plate && !pl.pf && !pl.wide && !getenv("GJX_GEN_NO_EARLY_STORE");
     auto element = [&](const std::string& dx, const char* ind) {
       o.f("%sPLOOP {\n", ind);
       std::string in2 = std::string(ind) + "  ";
@@ -873,9 +922,19 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (need_lp) o.f("%slp[p] += elem_logpdf(%d, val, pa, pb, pc, pd);\n", in2.c_str(), kind);
       }
       if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) o.f("%s%s = val;\n", in2.c_str(), vslot.c_str());
+      if (fuse_next) {
+        const gjx_param& sb = prog->sites[j + 1].p[1];
+        const std::string ib = sb.len == 1 ? "0" : "(" + dx + ") % " + std::to_string(sb.len);
+        o.f("%s{ const float z_ = fmaf(-COMP(%d + %s), val, COMP(%d + (%s))); q2f%d[p] = fmaf(z_, z_, q2f%d[p]); }\n", in2.c_str(), fz_rcp, ib.c_str(), fz_ys, dx.c_str(), j + 1, j + 1);
+      }
       o.f("%s}\n", ind);
+      // the row leaves as soon as it exists (registers are not held to the end of the site)
+      if (store_early && pl.seq_rows && literal_index(dx) >= 0) o.f("%s", pl.row_store("VSTORE1", ind, ri.row + literal_index(dx), "v[" + std::to_string(s.slot + literal_index(dx)) + "]").c_str());
+      else if (store_early) o.f("%sVSTORE1(a.choices + (int64_t)(%s + (%s)) * K + i0, v[%d + (%s)]);\n", ind, toff(ri.row, ri.d_row).c_str(), dx.c_str(), s.slot, dx.c_str());
     };
-    if (expand) {
+    if (fused_here) {
+      o.f("      PLOOP q2[p] = q2f%d[p];\n", j);
+    } else if (expand) {
       for (int d = 0; d < dim; ++d) {
         element(std::to_string(d), "      ");
         if ((d & 1) == 1 && d + 1 < dim && need_lp) o.f("      PLOOP asm volatile(\"\" : \"+v\"(%s[p]));\n      __builtin_amdgcn_sched_barrier(0);\n", norm ? "q2" : "lp");
@@ -898,10 +957,14 @@ void emit_site(Emit& o, Plan& pl, int j) {
   if (ri.plate) o.f("      PLOOP pacc%d[p] += lp[p];\n", j);      // a plate's body site: the sum over its instances
   else o.f("      if (a.site_scores && OWN_) { float ss_[PPT]; PLOOP ss_[p] = lp[p]; VecStore<PPT>::st(a.site_scores + (int64_t)%s * K + i0, ss_); }\n",
            toff(ri.score_row, ri.d_score_row).c_str());
-  if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT) {
+  const bool stored_early = !is_categorical(kind) && s.dim <= kMaxExpandDim && s.slot >= 0 && mode != GJX_MODE_OBS_SLOT && !ri.plate && !pl.pf && !pl.wide && !getenv("GJX_GEN_NO_EARLY_STORE");
+  if (s.slot >= 0 && mode != GJX_MODE_OBS_SLOT && !stored_early) {
     const int nrow = is_categorical(kind) ? 1 : s.dim;
     // (a plate's instance is stored by the wave that produced it; anything else by the block's first wave: VSTORE1)
-    for (int d = 0; d < nrow; ++d) o.f("      %s(a.choices + (int64_t)%s * K + i0, v[%d]);\n", ri.plate ? "VSTORE" : "VSTORE1", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
+    for (int d = 0; d < nrow; ++d) {
+      if (pl.seq_rows && !ri.plate) o.f("%s", pl.row_store("VSTORE1", "      ", ri.row + d, "v[" + std::to_string(s.slot + d) + "]").c_str());
+      else o.f("      %s(a.choices + (int64_t)%s * K + i0, v[%d]);\n", ri.plate ? "VSTORE" : "VSTORE1", toff(ri.row + d, ri.d_row).c_str(), s.slot + d);
+    }
   }
   if (pl.pf) o.f("      PLOOP asm volatile(\"\" : \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
   else o.f("      PLOOP asm volatile(\"\" : \"+v\"(score[p]), \"+v\"(weight[p]));\n      __builtin_amdgcn_sched_barrier(0);\n    }\n");
@@ -936,6 +999,7 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
   pl.ppt = ppt;
   pl.mfma = mfma;
   pl.wide = (ppt_code & 512) != 0 && px.any && !mfma;
+  pl.seq_rows = !px.any && !roll.ok && !mfma && !getenv("GJX_GEN_NO_SEQ_ROWS");      // (generate_pf clears it: its rows move with the step)
   pl.tab_lds = mfma || (prog->n_tab <= kMaxLdsTab && !getenv("GJX_GEN_TAB_GLOBAL"));   // (the variable: profiling variant, part of the cache key)
   if (roll.ok) {
     pl.info = roll.info;
@@ -1025,7 +1089,7 @@ std::string emit_body(GenCtx& g, int j_lo = 0, int j_hi = -1) {
         const bool draws = sl.mode == GJX_MODE_SAMPLE || sl.mode == GJX_MODE_OBS_MASK;
         if (flat && draws) {
           const SiteStream& ss = pl.stream[j + l];
-          body.f("    BitStream<RNG> ps%d[PPT];\n    PLOOP ps%d[p].open(%s, gidx[p], %du);\n", j + l, j + l, ss.key_var.empty() ? "a.key" : ss.key_var.c_str(), ss.site_no);
+          body.f("    BitStream<RNG> ps%d[PPT];\n    PLOOP ps%d[p].open_hi(%s, GHI_, (uint32_t)gidx[p], %du);\n", j + l, j + l, ss.key_var.empty() ? "a.key" : ss.key_var.c_str(), ss.site_no);
         }
       }
       // JAX32: the Vmap call is one traced site of its caller: plate key = fold_in(particle key, J); instance key = split(plate key, n)[i]
@@ -1098,6 +1162,8 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   const int BT = wide ? 1024 : 256;
   const std::string body_s = emit_body(g);
   Emit o;
+  // GHI_: the high word of every particle index of the launch (plan_engine keeps a launch inside one 2^32 range): wave-uniform
+  o.f("#define GHI_ ((uint32_t)((uint64_t)a.offset >> 32))\n");
   o.f("#include \"gjx_device.h\"\n#include \"gjx_tile.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
   if (wide)
@@ -1144,6 +1210,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "    uint64_t gidx[PPT];\n    PLOOP gidx[p] = (uint64_t)(a.offset + i0 + p);\n"
       "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n", wide ? 64 : 256, wide ? "pl_" : "threadIdx.x");
   o.f("    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
+  if (pl.seq_rows) { o.f("    float* rp_ = a.choices + i0;   // the running row pointer (Plan::seq_rows)\n"); pl.rp_row = 0; }
   {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
@@ -1298,6 +1365,7 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
   Plan& pl = g.pl;
   const gjx_program* prog = pl.prog;
   pl.pf = true;
+  pl.seq_rows = false;
   pl.tab_lds = true;
   // ---- which draws are taken ahead: sampled normal sites outside plates, whole scalar-normal runs or none of a run ----
   const int ns = prog->n_sites;
@@ -1339,12 +1407,14 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     aprog.sites = asites.data();
     plan_program(&aprog, 1, ga, false);
     ga.pl.pf = true;
+    ga.pl.seq_rows = false;
     ga.pl.tab_lds = true;
     ga.pl.skip.assign(ns, 0);
     for (int j = 0; j < ns; ++j) ga.pl.skip[j] = asites[j].mode == GJX_MODE_INPUT || (asites[j].flags & GJX_SITE_PROPOSAL);
     assess_s = emit_body(ga);
   }
   Emit o;
+  o.f("#define GHI_ 0u   /* a filter's collection: K_total <= 2^25 slots */\n");
   o.f("#include \"gjx_device.h\"\n#include \"gjx_pfcore.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT 1\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT);
   o.f("#define NTAB %d\n#define NCOMP %d\n#define SPL %d\n#define NHOIST %d\n#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n", prog->n_tab, pl.comp_floats, spl, pl.n_hoist);
@@ -2225,7 +2295,8 @@ uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // fl
                             (getenv("GJX_GEN_MFMA_DEBUG") ? atoi(getenv("GJX_GEN_MFMA_DEBUG")) : 0) ^
                                 (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
                                 (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0) ^ (getenv("GJX_GEN_TAB_GLOBAL") ? 1 << 24 : 0) ^
-                                (getenv("GJX_GEN_NO_HOIST") ? 1 << 25 : 0)};
+                                (getenv("GJX_GEN_NO_HOIST") ? 1 << 25 : 0) ^ (getenv("GJX_GEN_NO_FUSE") ? 1 << 26 : 0) ^ (getenv("GJX_GEN_NO_EARLY_STORE") ? 1 << 27 : 0) ^
+                                (getenv("GJX_GEN_NO_SEQ_ROWS") ? 1 << 28 : 0)};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);

@@ -75,6 +75,15 @@ struct BitStream<GJX_RNG_FLAT> {
     npair = 0xFFFFFFFFu;
   }
   GJX_DEV void open_site_key(key2) {}
+  // the same with the index in halves: `hi` wave-uniform (the launcher keeps a launch inside one 2^32 range of indices), so the
+  // stream key and its key schedule stay in scalar registers
+  GJX_DEV void open_hi(key2 run_key, uint32_t hi, uint32_t lo, uint32_t site) {
+    key = hi ? threefry2x32(run_key, 0xFFFFFFFFu, hi) : run_key;
+    c0 = lo;
+    site_hi = site << GJX_FLAT_SITE_SHIFT;
+    h0 = h1 = 0xFFFFFFFFu;
+    npair = 0xFFFFFFFFu;
+  }
   GJX_DEV uint32_t word(uint32_t n) {
     const uint32_t h = n >> 1;
     if (h & 1u) {
@@ -103,6 +112,7 @@ struct BitStream<GJX_RNG_JAX32> {
   key2 sk;
   GJX_DEV BitStream() : sk{0u, 0u} {}
   GJX_DEV void open(key2 run_key, uint64_t idx, uint32_t site) { sk = fold_in(fold_in64(run_key, idx), site); }
+  GJX_DEV void open_hi(key2 run_key, uint32_t hi, uint32_t lo, uint32_t site) { open(run_key, ((uint64_t)hi << 32) | lo, site); }
   GJX_DEV void open_site_key(key2 k) { sk = k; }
   GJX_DEV uint32_t get(uint32_t c) {
     const key2 h = threefry2x32(sk, 0u, c);
@@ -291,7 +301,8 @@ GJX_DEV float normal_from_bits(uint32_t bits) {
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so u2 feeds them directly.
 GJX_DEV void box_muller(uint32_t wa, uint32_t wb, float& n0, float& n1) {
   const float u1 = 2.0f - __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wa, 9));  // 1 - unit, (0,1]
-  const float u2 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9)) - 1.0f;
+  // (the angle stays in [1, 2): v_sin / v_cos are periodic in revolutions and 1 + k 2^-23 is exact, so the -1 is an instruction for nothing)
+  const float u2 = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, wb, 9));
   const float r = fast_sqrt(__builtin_amdgcn_logf(u1) * (-2.0f * kLn2));
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);

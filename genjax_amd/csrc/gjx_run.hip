@@ -1204,7 +1204,7 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
     return true;
   };
   auto try_gen = [&]() {
-    if (env_int("GJX_NO_CODEGEN", 0)) return false;
+    if (env_int("GJX_NO_CODEGEN", 0) || !same_hi) return false;     // (generated kernels take the index's high word as a launch constant)
     const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);     // (ppt | 256: the matrix-core flavour, gjx_codegen.hip)
     if (gen_available(prog, ppt) != GJX_OK) return false;
     // (ppt | 512: a block of 16 waves shares 64 x ppt particles — the instances of its plates are dealt to the waves)

@@ -9,7 +9,7 @@ asm = os.path.join(tempfile.mkdtemp(), "run.s")
 subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", csrc, "-I", os.path.join(ROOT, "include"),
                        "--cuda-device-only", "-S", "-o", asm, os.path.join(csrc, "gjx_run.hip")], stderr=subprocess.DEVNULL)
 txt = open(asm).read()
-name = [n for n in re.findall(r"^(_ZN3gjx14k_run_gmm_flat\w+):", txt, re.M) if "ILi16ELi4ELi256ELb0" in n][0]
+name = [n for n in re.findall(r"^(_ZN3gjx14k_run_gmm_flat\w+):", txt, re.M) if "ILi16ELi4ELi256ELb0ELb0" in n or n.endswith("ILi16ELi4ELi256ELb0EEEvNS_7GmmArgsE")][0]
 i = txt.index(name + ":"); j = txt.index("s_endpgm", i)
 ops = [l.split()[0] for l in (x.strip() for x in txt[i:j].splitlines()) if l and not l.startswith((";", ".", "//")) and not l.endswith(":")]
 FAST = {"v_add_u32_e32", "v_xor_b32_e32", "v_sub_u32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_lshrrev_b32_e32", "v_mov_b32_e32",
