@@ -1324,6 +1324,46 @@ def run_round5(dev):
     mm["speedup"] = mm["interp"]["ms_per_move"] / mm["gen"]["ms_per_move"]
     mm["device_sites"], mm["plate_instances"], mm["chains"], mm["leapfrog"] = pm.n_sites, Nm, nm, Lm
     res["hmc_mixture_latent_means_N4096"] = mm
+
+    # HMC over every state of a T = 256 stochastic-volatility Scan (512 sites, 256 selected values): the generated kernel rolls the Scan
+    Ts, ns_, Ls = len(ysv), 1 << 13, 10
+
+    @genjax.gen
+    def sv_model():
+        sv_step.scan(n=Ts)(0.0, None) @ "s"
+
+    xs_ = [(("s", "x"), t) for t in range(Ts)]
+    ps, _, _ = sv_model.pack((), CM["s", "y"].set(ysv), False, selected=tuple(xs_), per_particle=tuple(xs_))
+    chs = (0.3 * torch.randn((ps.n_slots, ns_), device=dev)).contiguous()
+    sm = {}
+    for engine in ("gen", "interp"):
+        old = os.environ.get("GJX_HMC_ENGINE")
+        os.environ["GJX_HMC_ENGINE"] = engine
+        try:
+            eng = kernels.hmc_engine(ps)
+            out = kernels.hmc(ps, (1, 2), chs.clone(), 0.01, Ls, False, True)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3 if engine == "gen" else 1
+            a.record()
+            for i in range(reps):
+                out = kernels.hmc(ps, (1, 3 + i), chs.clone(), 0.01, Ls, False, True, ws=out["_ws"])
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / reps
+        finally:
+            if old is None:
+                del os.environ["GJX_HMC_ENGINE"]
+            else:
+                os.environ["GJX_HMC_ENGINE"] = old
+        byt = 4.0 * Ts * ns_ * (10 * Ls + 2)       # position, momentum and gradient rows: 10 accesses per row and leapfrog step
+        sm[engine] = dict(engine=eng, ms_per_move=ms, chain_leapfrogs_per_sec=ns_ * Ls / (ms * 1e-3), accept_rate=float(out["accepted"].mean()),
+                          roofline=dict(bound="hbm", algorithmic_bytes_per_launch=byt, kernel_us=ms * 1e3, achieved=byt / (ms * 1e-3) / 1e9,
+                                        peak=HBM_PEAK_GBS, unit="GB/s", frac=byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        timing="event pair around back-to-back moves (incl. a clone of the state)"))
+    sm["speedup"] = sm["interp"]["ms_per_move"] / sm["gen"]["ms_per_move"]
+    sm["device_sites"], sm["steps"], sm["chains"], sm["leapfrog"] = ps.n_sites, Ts, ns_, Ls
+    res["hmc_stochastic_volatility_scan_T256"] = sm
     return res
 
 

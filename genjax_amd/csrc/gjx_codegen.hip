@@ -238,9 +238,9 @@ int literal_index(const std::string& dx) {
 }
 int ref_span(const gjx_param& q) { return q.op == GJX_P_AFFINE ? q.n : (q.op == GJX_P_VALUE ? q.len : 1); }
 
-Roll detect_roll(const gjx_program* p) {
+Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_stream: the HMC emitter (its sweep draws nothing)
   Roll r;
-  if (p->rng_mode != GJX_RNG_FLAT || getenv("GJX_GEN_NO_ROLL")) return r;
+  if ((p->rng_mode != GJX_RNG_FLAT && !any_stream) || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
   if (has_vgather(p->sites, n)) return r;     // (rows of a choice picked by a discrete choice: not in rolled Scans)
   for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
@@ -1605,6 +1605,12 @@ struct HmcPlan {
   std::vector<PlateSel> psel;
   int prows = 0, nout = 0;
   std::vector<int> leaf_of_site;   // momentum leaf (hmc.py:120-130: one per selected address, in program order) or -1
+  // a long periodic Scan (detect_roll): the steps are dealt to the lanes of a chain in contiguous chunks; the values of the previous and
+  // of the current step live in registers, the trajectory state of the steps' selected values in workspace rows t * ssel + k
+  bool rolled = false;
+  Roll roll;
+  int ssel = 0, sl_step = 0, leaf0_scan = 0;
+  std::vector<int> step_ls;        // k -> the selected value's slot within its step (0 .. S - 1)
   // rolled sites whose AFFINE parameter runs on the matrix cores (hmc_emit_mfma_site): parameter index or -1 per site, offset
   // of the site's transposed matrix in the second LDS array, and what the layout needs from the launch
   bool mfma = false;
@@ -1659,10 +1665,15 @@ int hmc_mfma_param(const gjx_site& s) {
 
 bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIRICHLET; }
 
-bool hmc_plan(const gjx_program* p, HmcPlan* out) {
-  if (p->n_sites < 1 || p->n_sites > 64 || p->n_slots < 1 || p->n_tab > kHmcMaxTab) return false;
+// roll: plan the program as a rolled Scan (tried when the straight-line plan does not fit)
+bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
+  if (p->n_sites < 1 || p->n_slots < 1 || p->n_tab > kHmcMaxTab) return false;
   HmcPlan pl;
-  {
+  if (roll) {
+    const Roll r = detect_roll(p, true);
+    if (!r.ok || r.n_post != 0 || getenv("GJX_HMC_GEN_NO_ROLL")) return false;
+    pl.sites = r.sites; pl.info = r.info; pl.n_regs = r.n_regs; pl.rolled = true; pl.roll = r; pl.looped = true;
+  } else {
     const PlateXf px = plate_program(p);
     if (px.any) {
       if (!px.ok) return false;
@@ -1673,10 +1684,11 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
       pl.n_regs = p->n_slots;
     }
   }
-  if (pl.n_regs < 1 || pl.n_regs > kHmcMaxSlots) return false;
+  const int ns = (int)pl.sites.size();
+  if (ns > 64 || pl.n_regs < 1 || pl.n_regs > kHmcMaxSlots) return false;
   pl.sel_of_slot.assign(pl.n_regs, -1);
   int unrolled = 0;
-  for (int j = 0; j < p->n_sites; ++j) {
+  for (int j = 0; j < ns; ++j) {
     const gjx_site& s = pl.sites[j];
     const RollInfo& ri = pl.info[j];
     if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
@@ -1705,15 +1717,36 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
       // a row of a (selected) choice picked by a discrete choice: select chains forwards and backwards, few rows
       if (q.op == GJX_P_VGATHER && (q.n < 1 || q.n * q.len > 32 || q.moff < 0 || q.moff + q.n * q.len > pl.n_regs || (big && q.len != 1))) return false;
     }
+    if (big && pl.rolled) return false;                 // (a rolled site inside a rolled Scan: not emitted)
     if (big) pl.looped = true; else unrolled += s.dim;
-    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0 && !ri.plate)
+    const bool step_site = pl.rolled && j >= pl.roll.i0;      // the Scan's sites: their selected values get indices behind the others'
+    if ((s.flags & GJX_SITE_HMC_SELECTED) && s.slot >= 0 && !ri.plate && !step_site)
       for (int d = 0; d < s.dim; ++d) { pl.sel_of_slot[s.slot + d] = pl.nsel++; pl.slot_of_sel.push_back(s.slot + d); }
   }
   pl.nout = pl.nsel;
-  pl.leaf_of_site.assign(p->n_sites, -1);
-  {
+  pl.leaf_of_site.assign(ns, -1);
+  if (pl.rolled) {
+    // selected values of a step: k = 0 .. ssel - 1 in site order; indices NOUT + k for the PREVIOUS step's registers, NOUT + ssel + k
+    // for the current step's (step 0's sites live in the current step's registers too: detect_roll)
+    const Roll& r = pl.roll;
     int leaf = 0;
-    for (int j = 0; j < p->n_sites; ++j) {
+    for (int j = 0; j < r.i0; ++j) if ((pl.sites[j].flags & GJX_SITE_HMC_SELECTED) && pl.sites[j].slot >= 0) pl.leaf_of_site[j] = leaf++;
+    pl.leaf0_scan = leaf;
+    for (int l = 0; l < r.m; ++l) {
+      const gjx_site& s = pl.sites[r.i0 + r.m + l];          // the loop body's site (registers of the current step)
+      if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
+      if (is_categorical(s.kind)) return false;
+      pl.leaf_of_site[r.i0 + l] = pl.leaf_of_site[r.i0 + r.m + l] = pl.sl_step++;       // (leaf within the step)
+      for (int d = 0; d < s.dim; ++d) pl.step_ls.push_back(s.slot + d - (r.n_pre + r.S));
+    }
+    pl.ssel = (int)pl.step_ls.size();
+    if (pl.ssel < 1) return false;                           // (nothing of the Scan is moved: the straight-line forms cover what fits)
+    for (int k = 0; k < pl.ssel; ++k) { pl.sel_of_slot[r.n_pre + pl.step_ls[k]] = pl.nsel++; pl.slot_of_sel.push_back(r.n_pre + pl.step_ls[k]); }
+    for (int k = 0; k < pl.ssel; ++k) { pl.sel_of_slot[r.n_pre + r.S + pl.step_ls[k]] = pl.nsel++; pl.slot_of_sel.push_back(r.n_pre + r.S + pl.step_ls[k]); }
+    pl.prows = r.T * pl.ssel;
+  } else {
+    int leaf = 0;
+    for (int j = 0; j < ns; ++j) {
       const gjx_site& s = pl.sites[j];
       const RollInfo& ri = pl.info[j];
       if (!(s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) continue;
@@ -1726,13 +1759,13 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
     }
   }
   if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
-  pl.mf_k.assign(p->n_sites, -1);
-  pl.xt_off.assign(p->n_sites, 0);
-  pl.fold.assign(p->n_sites, 0);
-  pl.bs_off.assign(p->n_sites, 0);
-  if (pl.looped && !getenv("GJX_HMC_GEN_NO_MFMA")) {
+  pl.mf_k.assign(ns, -1);
+  pl.xt_off.assign(ns, 0);
+  pl.fold.assign(ns, 0);
+  pl.bs_off.assign(ns, 0);
+  if (pl.looped && !pl.rolled && !getenv("GJX_HMC_GEN_NO_MFMA")) {
     const int tab_pad = (p->n_tab + 3) & ~3;
-    for (int j = 0; j < p->n_sites; ++j) {
+    for (int j = 0; j < ns; ++j) {
       const gjx_site& s = pl.sites[j];
       const int k = pl.info[j].plate ? -1 : hmc_mfma_param(s);
       if (k < 0) continue;
@@ -1758,6 +1791,9 @@ bool hmc_plan(const gjx_program* p, HmcPlan* out) {
   return true;
 }
 
+// the straight-line / plate forms first (chain state in registers); a program they do not fit — a long Scan — as a rolled loop
+bool hmc_plan(const gjx_program* p, HmcPlan* out) { return hmc_plan_form(p, out, false) || hmc_plan_form(p, out, true); }
+
 // one element of site j: parameters, (score,) gradient terms.  dx: element index expression (a literal, or "d_" in a rolled
 // site); acc: name of the gradient accumulator array indexed by SELECTED-slot index ("g" or the site's partial "ga")
 // mf (matrix-core sites): parameter mf->k arrives finished in `pre` (bias + contraction, the tile's C layout) and its
@@ -1768,7 +1804,7 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
                       const char* sc, const char* ind, const HmcMf* mf = nullptr) {
   const gjx_site& s = prog->sites[j];
   const RollInfo& ri = hp.info[j];
-  g_loop_var = "i_";                       // (a plate's body site: table offsets advance with the instance)
+  g_loop_var = hp.rolled ? "(t_ - 1)" : "i_";   // (a plate's body site: table offsets advance with the instance; a rolled Scan's: with the step)
   const int np = n_params(s.kind);
   o.f("%s{\n", ind);
   for (int k = 0; k < 4; ++k) {
@@ -1942,10 +1978,11 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   // the emitted program: the plan's site list (plates: every slot a register, a body site owns one instance's worth)
   gjx_program eprog = *prog_in;
   eprog.sites = hp.sites.data();
+  eprog.n_sites = (int)hp.sites.size();
   eprog.n_slots = hp.n_regs;
   const gjx_program* prog = &eprog;
-  int longest = 0;       // the longest loop of the kernel: what more lanes per chain can share
-  for (int j = 0; j < prog_in->n_sites; ++j) {
+  int longest = hp.rolled ? hp.roll.T : 0;       // the longest loop of the kernel: what more lanes per chain can share
+  for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = hp.sites[j];
     const int len = hp.info[j].plate ? hp.info[j].plate_n : (!is_categorical(s.kind) && s.dim > kMaxExpandDim ? s.dim : 0);
     longest = len > longest ? len : longest;
@@ -1973,7 +2010,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   auto emit_one = [&](int j, const char* acc, const char* sc) {
     const gjx_site& s = prog->sites[j];
     const RollInfo& ri = hp.info[j];
-    g_loop_var = "i_";
+    g_loop_var = hp.rolled ? "(t_ - 1)" : "i_";
     const int np = n_params(s.kind);
     o.f("  { // ---- site %d: kind %d, dim %d, slot %d%s\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot, ri.plate ? " (plate body)" : "");
     for (int k = 0; k < np; ++k) {
@@ -2019,7 +2056,54 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
     }
     o.f("  }\n");
   };
-  for (int j = 0; j < prog->n_sites;) {
+  if (hp.rolled) {
+    // ---- a rolled Scan (scan.py:237-294 differentiated by hmc.py:70-96): the T steps are dealt to the CPL lanes of the chain in
+    //      contiguous chunks [a_, b_).  A lane walks its chunk with the previous and the current step's values in registers; a term of
+    //      step t contributes to the gradient rows of steps t - 1 and t, so the lane carries step t's own part (gcar_) into step
+    //      t + 1's iteration, where the row is complete and stored — and runs ONE extra iteration, t = b_, for its last row only
+    //      (score and outside gradients of that iteration belong to the next lane and are dropped)
+    const Roll& r = hp.roll;
+    const int SS = hp.ssel, S = r.S, np0 = r.n_pre;
+    for (int j = 0; j < r.i0; ++j) emit_one(j, "g", "sc_");        // the sites in front of the Scan: every lane, registers
+    o.f("  { // ---- rolled Scan: %d steps x %d sites, %d selected values per step\n"
+        "    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n    float scp_ = 0.0f, gcar_[%d];\n"
+        "    _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) gcar_[k_] = 0.0f;\n"
+        "    const int L_ = (%d + CPL - 1) / CPL, a_ = q_ * L_, b_ = a_ + L_ < %d ? a_ + L_ : %d;\n"
+        "    if (a_ < %d) {\n", r.T, r.m, SS, SS, SS, r.T, r.T, r.T, r.T);
+    // loads of one step's values into the CURRENT step's registers: selected -> the trajectory's position (workspace), else the chain's column
+    auto load_step = [&](const char* t, const char* ind) {
+      for (int l = 0; l < r.m; ++l) {
+        const gjx_site& sl = prog->sites[r.i0 + r.m + l];
+        if (sl.slot < 0) continue;
+        const int w = is_categorical(sl.kind) ? 1 : sl.dim;
+        for (int d = 0; d < w; ++d) {
+          const int ls = sl.slot + d - (np0 + S), m = hp.sel_of_slot[sl.slot + d];
+          if (m >= 0) o.f("%sv[%d] = wq_[((int64_t)(%s) * %d + %d) * n_ + ic_];\n", ind, sl.slot + d, t, SS, m - hp.nout - SS);
+          else o.f("%sv[%d] = ch_[((int64_t)%d + (int64_t)(%s) * %d + %d) * n_ + ic_];\n", ind, sl.slot + d, np0, t, S, ls);
+        }
+      }
+    };
+    o.f("    int t0_;\n    if (q_ == 0) {   // step 0 (its sites' own parameters: the initial carry)\n");
+    load_step("0", "      ");
+    for (int l = 0; l < r.m; ++l) emit_one(r.i0 + l, "ga", "scp_");
+    o.f("      _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) gcar_[k_] = ga[NOUT + %d + k_];\n      t0_ = 1;\n    } else {\n", SS, SS);
+    load_step("a_ - 1", "      ");
+    o.f("      t0_ = a_;\n    }\n"
+        "    _Pragma(\"nounroll\") for (int t_ = t0_; t_ <= b_ && t_ < %d; ++t_) {\n"
+        "      const bool real_ = t_ < b_;\n", r.T);
+    for (int ls = 0; ls < S; ++ls) o.f("      v[%d] = v[%d];\n", np0 + ls, np0 + S + ls);      // the current step becomes the previous one
+    load_step("t_", "      ");
+    o.f("      float sv_[NOUT > 0 ? NOUT : 1]; const float svs_ = scp_;\n      _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) sv_[m_] = ga[m_];\n"
+        "      _Pragma(\"unroll\") for (int m_ = NOUT; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n");
+    for (int l = 0; l < r.m; ++l) emit_one(r.i0 + r.m + l, "ga", "scp_");
+    o.f("      if (!real_) { scp_ = svs_; _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) ga[m_] = sv_[m_]; }\n"
+        "      if (t_ - 1 >= a_ && live_) { _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) wg_[((int64_t)(t_ - 1) * %d + k_) * n_ + ic_] = gcar_[k_] + ga[NOUT + k_]; }\n"
+        "      _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) gcar_[k_] = ga[NOUT + %d + k_];\n    }\n"
+        "    if (b_ == %d && live_) { _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) wg_[((int64_t)%d * %d + k_) * n_ + ic_] = gcar_[k_]; }\n"
+        "    }\n", SS, SS, SS, SS, r.T, SS, r.T - 1, SS);
+    o.f("    _Pragma(\"unroll\") for (int m_ = 0; m_ < NOUT; ++m_) g[m_] += CPL > 1 ? QSUM(ga[m_]) : ga[m_];\n    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n  }\n");
+  }
+  for (int j = 0; j < (hp.rolled ? 0 : prog->n_sites);) {
     if (!hp.info[j].plate) { emit_one(j, "g", "sc_"); ++j; continue; }
     // ---- a plate (gjx.h "Plates"; the gradient of assess through a Vmap: hmc.py:70-96, vmap.py:363-376): the instances are dealt
     //      round-robin to the CPL lanes of the chain; every instance adds its body's score and its gradient terms — into the rows of
@@ -2083,7 +2167,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
       "  const uint64_t gidx = (uint64_t)(a.offset + i);\n"
       "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
       "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = 0.0f;\n");
-  for (int j = 0; j < prog->n_sites; ++j) {       // the chain's values: rows of choices[][] -> registers (a plate's body: per instance, in the sweep)
+  for (int j = 0; j < (hp.rolled ? hp.roll.i0 : prog->n_sites); ++j) {       // the chain's values: rows of choices[][] -> registers (a plate's body, a rolled Scan's steps: in the sweep)
     const gjx_site& sj = prog->sites[j];
     if (sj.slot < 0 || hp.info[j].plate) continue;
     const int w = is_categorical(sj.kind) ? 1 : sj.dim;
@@ -2092,6 +2176,17 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   // the rows of the selected sites inside plates: working positions, momenta, gradients (and the first gradient for the stale-carry
   // compatibility mode) in the caller's workspace, [4][PROWS][n]; a lane owns the instances q_, q_ + CPL, ... of its chain
   auto plate_rows = [&](const char* body) {     // `body` sees idx_ (row * n + chain) and e_ (the element's index within its leaf)
+    if (hp.rolled) {
+      // a rolled Scan's rows: the lane's chunk of steps (the chunks of the sweep: a row is only ever touched by the lane that owns its step)
+      std::string ls = "{";
+      for (int k = 0; k < hp.ssel; ++k) ls += (k ? ", " : "") + std::to_string(hp.step_ls[k]);
+      ls += "}";
+      o.f("  { const int lsk_[%d] = %s; const int L_ = (%d + CPL - 1) / CPL, a_ = q_ * L_, b_ = a_ + L_ < %d ? a_ + L_ : %d;\n"
+          "  _Pragma(\"nounroll\") for (int t_ = a_; t_ < b_; ++t_) _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) {\n"
+          "    const int64_t idx_ = ((int64_t)t_ * %d + k_) * n + i, src_ = ((int64_t)%d + (int64_t)t_ * %d + lsk_[k_]) * n + i; (void)src_;\n"
+          "    %s\n  } }\n", hp.ssel, ls.c_str(), hp.roll.T, hp.roll.T, hp.roll.T, hp.ssel, hp.ssel, hp.roll.n_pre, hp.roll.S, body);
+      return;
+    }
     for (const auto& c : hp.psel)
       o.f("  _Pragma(\"nounroll\") for (int i_ = q_; i_ < %d; i_ += CPL) _Pragma(\"unroll\") for (int d_ = 0; d_ < %d; ++d_) {\n"
           "    const int64_t idx_ = (int64_t)(%d + i_ * %d + d_) * n + i, src_ = (int64_t)(%d + i_ * %d + d_) * n + i; const uint32_t e_ = (uint32_t)(i_ * %d + d_); (void)src_; (void)e_;\n"
@@ -2111,10 +2206,31 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   if (hp.prows) { o.f("  if (a.stale) {\n"); plate_rows("if (live) wg0_[idx_] = wg_[idx_];"); o.f("  }\n"); }
   {   // momenta (hmc.py:120-130): leaf l = l-th selected address in program order
     int m = 0;
+    bool scan_momenta_done = false;
     for (int j = 0; j < prog->n_sites; ++j) {
       const gjx_site& s = prog->sites[j];
       const int leaf = hp.leaf_of_site[j];
       if (leaf < 0) continue;
+      if (hp.rolled && j >= hp.roll.i0) {
+        if (scan_momenta_done) continue;     // (emitted once: every selected site of every step of the lane's chunk)
+        scan_momenta_done = true;
+        // the momenta of the Scan's selected sites: leaf = (leaves in front of the Scan) + t * (selected sites per step) + position in the step
+        o.f("  { float kp_ = 0.0f; const int L_ = (%d + CPL - 1) / CPL, a_ = q_ * L_, b_ = a_ + L_ < %d ? a_ + L_ : %d;\n"
+            "  _Pragma(\"nounroll\") for (int t_ = a_; t_ < b_; ++t_) {\n", hp.roll.T, hp.roll.T, hp.roll.T);
+        int k = 0;
+        for (int l = 0; l < hp.roll.m; ++l) {
+          const int lf = hp.leaf_of_site[hp.roll.i0 + l];
+          if (lf < 0) continue;
+          const gjx_site& sl = prog->sites[hp.roll.i0 + hp.roll.m + l];
+          o.f("    { BitStreamRT<RNG> bs; const uint32_t lf_ = (uint32_t)(%d + t_ * %d + %d);\n"
+              "      if (RNG == GJX_RNG_JAX32) bs.open_site_key(fold_in(sub, lf_)); else bs.open(a.key, gidx, lf_ + 1u);\n", hp.leaf0_scan, hp.sl_step, lf);
+          for (int d = 0; d < sl.dim; ++d, ++k)
+            o.f("      { const float pm_ = stream_normal<RNG>(bs, %du); if (live) wp_[((int64_t)t_ * %d + %d) * n + i] = pm_; kp_ += -0.5f * pm_ * pm_ - kHalfLog2Pi; }\n", d, hp.ssel, k);
+          o.f("    }\n");
+        }
+        o.f("  }\n  k0 += CPL > 1 ? QSUM(kp_) : kp_; }\n");
+        continue;
+      }
       if (hp.info[j].plate) {
         // a selected body site is ONE leaf: element i dim + d for instance i — drawn by the lane that owns the instance
         for (const auto& c : hp.psel) {
@@ -2156,7 +2272,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
       "  if (live && q_ == 0) {\n    if (acc) {\n");
   {
     std::vector<int> row_of_reg(NS > 0 ? NS : 1, -1);
-    for (int j = 0; j < prog->n_sites; ++j) {
+    for (int j = 0; j < (hp.rolled ? hp.roll.i0 : prog->n_sites); ++j) {
       const gjx_site& sj = prog->sites[j];
       if (sj.slot < 0 || hp.info[j].plate) continue;
       const int w = is_categorical(sj.kind) ? 1 : sj.dim;

@@ -261,3 +261,74 @@ def test_random_programs_generated_hmc_vs_interpreter_and_oracle(K_, oracle, rng
         assert err[w] <= 0, (f"{what} alpha generated vs oracle: chain {np.flatnonzero(well)[w]} generated {ga[well][w]} interpreter {ia[well][w]} "
                              f"oracle {o['alpha'][well][w]} score {o['score'][well][w]} start {ch[:, np.flatnonzero(well)[w]]}")
     assert covered >= trials // 3, f"the emitter covered {covered} of {trials} random programs"
+
+
+def _long_scan_model(T, rng, with_global):
+    """stochastic volatility over T steps: x_t ~ normal(phi x_{t-1}, sigma), y_t ~ normal(0, exp(x_t / 2)) observed, every x_t selected —
+    `with_global`: the transition's scale is exp(ls) with ls ~ normal(-1.2, 0.3) a selected choice in FRONT of the Scan"""
+    import genjax_amd as genjax
+    from genjax_amd import C
+    phi = 0.95
+    ys = np.random.default_rng(1).standard_normal(T).astype(np.float32)
+
+    @genjax.gen
+    def model():
+        ls = (genjax.normal(-1.2, 0.3) @ "ls") if with_global else None
+
+        @genjax.gen
+        def step(x_prev, _):          # (a closure over the choice in front of the Scan: gen.py's closures with keyword arguments)
+            x = genjax.normal(phi * x_prev, genjax.exp(ls) if with_global else 0.3) @ "x"
+            genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+            return x, None
+
+        step.scan(n=T)(0.0, None) @ "s"
+
+    xs = [(("s", "x"), t) for t in range(T)]
+    sel = (["ls"] if with_global else []) + xs
+    prog, _, _ = model.pack((), C["s", "y"].set(ys), False, selected=tuple(sel), per_particle=tuple(sel), rng_mode=rng)
+    return prog
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("T,with_global", [(128, False), (203, False), (96, True)])
+def test_hmc_over_a_long_scan_runs_on_a_rolled_generated_kernel(K_, oracle, rng, T, with_global, monkeypatch):
+    """HMC.edit over every state of a T-step Scan (hmc.py:70-96 differentiates any assess; scan.py:237-294) — 2 T sites, T selected
+    values: more than the straight-line kernel's registers hold.  The generated kernel rolls the Scan: the steps are dealt to the
+    lanes of a chain in contiguous chunks, the trajectory state of the steps' values lives in workspace rows, a lane carries a
+    row's own gradient part into the next step's iteration.  Against the site interpreter and the oracle, with 4, 16 and 64 lanes
+    per chain, the stale-gradient compatibility mode and the accept step; no HMC program goes to the interpreter for its length."""
+    import torch
+    n, L = 300, 8
+    prog = _long_scan_model(T, rng, with_global)
+    assert prog.n_sites == 2 * T + (1 if with_global else 0)
+    src = K_.program_hmc_source(prog)
+    assert "rolled Scan: %d steps x 2 sites, 1 selected values per step" % T in src and "// PROWS %d" % T in src
+    ch = (np.random.default_rng(4).standard_normal((prog.n_slots, n)) * 0.3).astype(np.float32)
+    if with_global:
+        ch[0] = -1.2 + 0.1 * ch[0]
+    for stale, accept, cpl in ((False, False, "4"), (True, False, "16"), (False, True, "64"), (False, False, "64")):
+        eps = 0.02 if accept else 0.005
+        o = oracle.hmc(prog, (6, 2), ch, eps, L, stale, accept, offset=7)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        assert K_.hmc_engine(prog) == 0
+        it = K_.hmc(prog, (6, 2), torch.as_tensor(ch).cuda(), eps, L, stale, accept, offset=7)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        monkeypatch.setenv("GJX_HMC_GEN_CPL", cpl)
+        assert K_.hmc_engine(prog) == 4
+        g = K_.hmc(prog, (6, 2), torch.as_tensor(ch).cuda(), eps, L, stale, accept, offset=7)
+        gc = _np(g["choices"])
+        assert np.isfinite(gc).all()
+        if not accept:
+            np.testing.assert_allclose(gc, o["choices"], rtol=3e-3, atol=3e-3)
+            np.testing.assert_allclose(gc, _np(it["choices"]), rtol=3e-3, atol=3e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=2e-2)
+            np.testing.assert_allclose(_np(g["score"]), o["score"], rtol=1e-3, atol=2e-2)
+            assert np.abs(gc - ch).max() > 1e-3
+        else:
+            acc_g, acc_o = _np(g["accepted"]) > 0.5, o["accepted"] > 0.5
+            assert (acc_g != acc_o).mean() < 0.02 and 0.1 < acc_g.mean() <= 1.0
+            same = acc_g == acc_o
+            np.testing.assert_allclose(gc[:, same], o["choices"][:, same], rtol=3e-3, atol=3e-3)
+            np.testing.assert_array_equal(gc[:, ~acc_g], ch[:, ~acc_g])
+    monkeypatch.delenv("GJX_HMC_ENGINE")
+    monkeypatch.delenv("GJX_HMC_GEN_CPL")
