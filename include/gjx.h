@@ -867,7 +867,10 @@ int gjx_peer_resample_gather(gjx_peer_ctx* ctx, int32_t parity, const float* par
  *   momentum leaf l ~ N(0,1) from fold_in(sub, l) (hmc.py:120-130).  FLAT stream: leaf l is site l+1.
  *   choices f32[n_slots][n] in/out, score f32[n] in/out, alpha f32[n] out (hmc.py:196-203).
  *   stale_grad_compat != 0 reproduces hmc.py:186 (first half-kick always uses the INITIAL gradient).
- *   workspace: gjx_hmc_workspace_bytes(prog, n).
+ *   workspace: gjx_hmc_workspace_bytes(prog, n) — the site interpreter's chain state; a generated kernel uses it for the trajectory
+ *   rows (position, momentum, gradient) of selected sites inside plates and of a rolled Scan's steps, nothing else (its other state
+ *   lives in registers).  Plate-tagged programs and long periodic Scans run on generated kernels: a selected body site of a plate is
+ *   ONE momentum leaf with elements i * dim + d; a Scan's sites are one leaf each, in program order.
  *   accept != 0 additionally applies the caller-side MH rule of tests/inference/test_requests.py:134-137
  *   with log U drawn from fold_in(key', 0x4d48) (FLAT: site 1023) and reverts rejected chains; accepted f32[n] out or NULL.
  */
