@@ -163,37 +163,43 @@ class Rejuvenate(EditRequest):
     propose z' ~ q(. | argument_mapping(old choices)), apply it as an Update (weight w), score the reverse
     proposal, return w + log q(z_old | args(z')) - log q(z' | args(z_old)).  Used through
     ``StaticRequest({addr: Rejuvenate(dist, argument_mapping)})``; ``argument_mapping`` receives a value
-    ChoiceMap (``chm.get_value()`` is the current choice) and is traced symbolically once."""
+    ChoiceMap (``chm.get_value()`` is the current choice, scalar or vector-valued) and is traced symbolically once per event size."""
 
     def __init__(self, proposal, argument_mapping):
         self.proposal, self.argument_mapping = proposal, argument_mapping
-        self._gf = None
+        self._gf = {}
 
-    def _proposal_gf(self):
-        if self._gf is None:
-            from ..gen import StaticGenerativeFunction, normal
+    def _proposal_gf(self, dim: int = 1):
+        """the proposal as a two-site generative function: a carrier of the current value (event size ``dim``; its score is not
+        used) and the proposal distribution on the arguments ``argument_mapping`` makes of it"""
+        if dim not in self._gf:
+            from ..gen import StaticGenerativeFunction, mv_normal_diag, normal
             prop, amap = self.proposal, self.argument_mapping
 
             def body():
-                cur = normal(0.0, 1.0) @ "cur"          # carrier of the current value (its score is not used)
+                cur = (normal(0.0, 1.0) if dim == 1 else mv_normal_diag(np.zeros(dim, np.float32), np.ones(dim, np.float32))) @ "cur"
                 args = amap(ChoiceMap.v(cur))
                 _ = prop(*args) @ "new"
-            self._gf = StaticGenerativeFunction(body)
-        return self._gf
+            self._gf[dim] = StaticGenerativeFunction(body)
+        return self._gf[dim]
 
     def edit_at(self, key: Key, tr: Trace, addr):
         from ..core import split
-        gf = self._proposal_gf()
         site = tr.prog.site_list[addr]
-        if site.dim != 1 or tr.prog.slot_of[addr] < 0:
-            raise NotImplementedError("Rejuvenate is implemented for scalar, unconstrained addresses")
-        old = tr.choices[tr.prog.slot_of[addr]: tr.prog.slot_of[addr] + 1]          # [1][K]
+        d = int(site.dim)
+        if tr.prog.slot_of[addr] < 0:
+            raise NotImplementedError("Rejuvenate: the address is constrained to one value for every particle (nothing to move)")
+        gf = self._proposal_gf(d)
+        old = tr.choices[tr.prog.slot_of[addr]: tr.prog.slot_of[addr] + d]          # [d][K]
         key, sub_key = split(key)
         fwd_tr, fwd_out = gf._run(sub_key, tr.K, (), ChoiceMap.empty(), True, True, prev_rows={"cur": old},
                                   want_site_scores=True)
-        new = fwd_tr.choices[fwd_tr.prog.slot_of["new"]: fwd_tr.prog.slot_of["new"] + 1]
+        if fwd_tr.prog.site_list["new"].dim != d:
+            raise ValueError(f"Rejuvenate: the proposal's event size {fwd_tr.prog.site_list['new'].dim} differs from the address's {d}")
+        new = fwd_tr.choices[fwd_tr.prog.slot_of["new"]: fwd_tr.prog.slot_of["new"] + d]
         fwd = fwd_out["site_scores"][1]
-        new_tr, w, _, bwd_req = Update(ChoiceMap({addr: new[0] if tr.batched else new[0, 0]})).edit(key, tr, None)
+        new_val = (new[0] if tr.batched else new[0, 0]) if d == 1 else (new.T if tr.batched else new[:, 0])
+        new_tr, w, _, bwd_req = Update(ChoiceMap({addr: new_val})).edit(key, tr, None)
         _, bwd_out = gf._run(sub_key, tr.K, (), ChoiceMap.empty(), False, True, prev_rows={"cur": new, "new": old},
                              want_site_scores=True)
         bwd = bwd_out["site_scores"][1]

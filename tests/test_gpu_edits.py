@@ -135,6 +135,57 @@ def test_rejuvenate_against_oracle():
     np.testing.assert_allclose(_np(new_tr.score), score_o, rtol=1e-3, atol=1e-3)
 
 
+def test_rejuvenate_a_vector_valued_address_against_oracle():
+    """Rejuvenate over an arbitrary proposal (rejuvenate.py:70-94) at a VECTOR-valued address: a random-walk proposal
+    mv_normal_diag(current, 0.3) on a 3-vector — proposal draw, Update weight, reverse proposal score, all against the oracle"""
+    import genjax_amd as genjax
+    from genjax_amd import ChoiceMap, Rejuvenate, StaticRequest
+    from genjax_amd.core import fold_in, split
+    from oracle import cpu, edits
+    d, K = 3, 2048
+    sc = np.array([0.3, 0.2, 0.4], np.float32)
+
+    @genjax.gen
+    def model():
+        v = genjax.mv_normal_diag(np.zeros(d, np.float32), np.ones(d, np.float32)) @ "v"
+        genjax.mv_normal_diag(v, np.full(d, 0.5, np.float32)) @ "y"
+        genjax.normal(v[1], 1.0) @ "t"
+
+    tr = model.simulate(genjax.key(5), (), K)
+    old = _np(tr.choices)
+    key = genjax.key(22)
+    req = StaticRequest({"v": Rejuvenate(genjax.mv_normal_diag, lambda chm: (chm.get_value(), sc))})
+    new_tr, w, _, _ = req.edit(key, tr, None)
+
+    @genjax.gen
+    def prop():
+        cur = genjax.mv_normal_diag(np.zeros(d, np.float32), np.ones(d, np.float32)) @ "cur"
+        genjax.mv_normal_diag(cur, sc) @ "new"
+
+    k = fold_in(key, 1)
+    k, sub_key = split(k)
+    vs = tr.prog.slot_of["v"]
+    p_fwd, _, _ = prop.pack((), ChoiceMap.empty(), True, per_particle=("cur",))
+    ch = np.zeros((2 * d, K), np.float32)
+    ch[p_fwd.slot_of["cur"]:p_fwd.slot_of["cur"] + d] = old[vs:vs + d]
+    fwd = cpu.run_program(p_fwd, sub_key, K, choices=ch, want_site_scores=True)
+    z_new = fwd["choices"][p_fwd.slot_of["new"]:p_fwd.slot_of["new"] + d]
+    new = old.copy()
+    new[vs:vs + d] = z_new
+    prog = _assess_prog(model, ())
+    w_upd, _, score_o = edits.update(prog, old, prog, new, K)
+    p_bwd, _, _ = prop.pack((), ChoiceMap.empty(), False, per_particle=("cur", "new"))
+    ch2 = np.zeros((2 * d, K), np.float32)
+    ch2[p_bwd.slot_of["cur"]:p_bwd.slot_of["cur"] + d] = z_new
+    ch2[p_bwd.slot_of["new"]:p_bwd.slot_of["new"] + d] = old[vs:vs + d]
+    bwd_score = cpu.run_program(p_bwd, (0, 0), K, choices=ch2, want_site_scores=True)["site_scores"][1]
+    w_o = edits.rejuvenate(w_upd, fwd["site_scores"][1], bwd_score)
+    np.testing.assert_allclose(_np(new_tr.choices)[vs:vs + d], z_new, rtol=RT, atol=AT)
+    np.testing.assert_allclose(_np(w), w_o, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(_np(new_tr.score), score_o, rtol=1e-3, atol=1e-3)
+    assert np.abs(_np(new_tr.choices)[vs:vs + d] - old[vs:vs + d]).max() > 0.1
+
+
 def test_run_csmc_weights_and_values_against_oracle():
     import genjax_amd as genjax
     from genjax_amd import C, ChoiceMap, ImportanceK, Target
