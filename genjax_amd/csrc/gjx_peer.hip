@@ -42,8 +42,6 @@ struct gjx_peer_ctx {
   bool verify = false;                 // GJX_PEER_VERIFY=1 when the context was created
   bool verify_fault = false;           // GJX_PEER_VERIFY_FAULT=<this rank>: publish wrong check words (test hook)
   bool data_fine = false;              // DATA window in fine-grained memory (GJX_PEER_DATA=fine)
-  std::vector<uint32_t> h_keys;        // host scratch of a filter run (step keys, comb offsets)
-  std::vector<double> h_us;
   size_t off_region[2] = {0, 0}, region_bytes = 0;
   // inside a flag region
   size_t r_aggA = 0, r_aggB = 0, r_bsum = 0, r_bmax = 0, r_ready = 0, r_gmm = 0;
@@ -267,19 +265,14 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
   if (pf_plan(rng_mode, m->dx, m->dy, K, c->world, c->share, &pf, move) != GJX_OK)
     return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_peer: this shape does not fit the one-launch filter (dx in {2,4,8,16}, dy <= 32, "
                                        "K_total <= 2^22, K_local / 1024 tiles co-resident at <= 8 tiles per block)");
-  if (T > c->t_cap) {   // longer than the 4096 steps the context was sized for: the scratch grows here, once, outside every loop
-    if (c->us_dev) (void)hipFree(c->us_dev);
-    if (c->keys_dev) (void)hipFree(c->keys_dev);
-    c->us_dev = nullptr; c->keys_dev = nullptr; c->t_cap = 0;
-    GJX_HIP(hipMalloc((void**)&c->us_dev, sizeof(double) * (size_t)T), "gjx_ssm_filter_peer: step offsets");
-    GJX_HIP(hipMalloc((void**)&c->keys_dev, sizeof(uint32_t) * 2 * (size_t)T), "gjx_ssm_filter_peer: step keys");
-    c->t_cap = T;
-  }
-  std::vector<uint32_t>& h_keys = c->h_keys;
-  std::vector<double>& h_us = c->h_us;
+  // (nothing is allocated after gjx_peer_ctx_create: the context's per-step scratch holds GJX_PEER_MAX_STEPS steps; longer runs are
+  // cut by the caller — the carry of one call is the start of the next)
+  if (T > c->t_cap) return gjx_fail(GJX_EUNSUPPORTED, "gjx_ssm_filter_peer: more steps than a peer context holds (GJX_PEER_MAX_STEPS = 4096 per call)");
+  std::vector<uint32_t> h_keys;        // per-call staging; the words travel as kernel arguments (upload_words): nothing of it is read later
+  std::vector<double> h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);
-  GJX_HIP(hipMemcpyAsync(c->us_dev, h_us.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, st), "gjx_ssm_filter_peer(step offsets)");
-  GJX_HIP(hipMemcpyAsync(c->keys_dev, h_keys.data(), sizeof(uint32_t) * 2 * (size_t)T, hipMemcpyHostToDevice, st), "gjx_ssm_filter_peer(step keys)");
+  if (int rcu = upload_words(c->us_dev, h_us.data(), (size_t)T, st)) return rcu;
+  if (int rck = upload_words(c->keys_dev, h_keys.data(), (size_t)T, st)) return rck;      // (T pairs of 32-bit words)
   float* x_a = (float*)(c->data + c->off_rows[0]);
   float* x_b = (float*)(c->data + c->off_rows[1]);
   float* lw_even = (float*)(c->data + c->off_lw[0]);
@@ -366,14 +359,7 @@ extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, i
     if (g <= cap && g * c->world <= kPfHostMaxTiles) { spl = spls[i]; grid = (int)g; }
   }
   if (!spl) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: no co-resident grid for this size (or the kernel could not be generated)");
-  if (T > c->t_cap) {   // longer than the 4096 steps the context was sized for: the scratch grows here, once, outside every loop
-    if (c->us_dev) (void)hipFree(c->us_dev);
-    if (c->keys_dev) (void)hipFree(c->keys_dev);
-    c->us_dev = nullptr; c->keys_dev = nullptr; c->t_cap = 0;
-    GJX_HIP(hipMalloc((void**)&c->us_dev, sizeof(double) * (size_t)T), "gjx_scan_filter_peer: step offsets");
-    GJX_HIP(hipMalloc((void**)&c->keys_dev, sizeof(uint32_t) * 2 * (size_t)T), "gjx_scan_filter_peer: step keys");
-    c->t_cap = T;
-  }
+  if (T > c->t_cap) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: more steps than a peer context holds (GJX_PEER_MAX_STEPS = 4096 per call)");
   std::vector<uint32_t> h_keys;
   std::vector<double> h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);

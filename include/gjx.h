@@ -9,9 +9,16 @@
  *   - return 0 (GJX_OK) on success, a negative gjx_status otherwise; gjx_last_error() gives the
  *     thread-local message of the last failure.
  *   - the library never allocates or frees caller-visible memory: the caller owns every buffer
- *     (torch tensors in the Python host layer); scratch is sized by gjx_workspace_bytes().
+ *     (torch tensors in the Python host layer); scratch is sized by gjx_workspace_bytes().  The only
+ *     device memory the library itself holds belongs to the two opaque contexts (gjx_shard_ctx,
+ *     gjx_peer_ctx): allocated by their create call, released by their destroy call, never in between.
  *   - every `*_dev` / output pointer is a DEVICE pointer; every call is asynchronous on the
- *     given hipStream_t (passed as void*), re-entrant, and touches no global state.
+ *     given hipStream_t (passed as void*) and re-entrant.  What the library keeps between calls:
+ *     the thread-local error string, the caches of generated kernels (compiled code, keyed by
+ *     program structure) and the buffer registered by gjx_debug_timeline (profiling scripts).
+ *     Options travel as arguments (gjx_run_opts, gjx_filter_opts, the flags of
+ *     gjx_peer_ctx_create_ex); the environment variables that remain select engines for
+ *     experiments (GJX_ENGINE, GJX_HMC_ENGINE, GJX_GEN_*, GJX_HMC_GEN_*) and are read per call.
  *   - particle/chain state is SoA: choices[slot][K] — one contiguous f32[K] row per scalar of a
  *     random choice, so a 64-lane wavefront reads/writes 256 contiguous bytes per row.
  *   - all floating values are float32 (the reference's default, core/typing.py:42); integer and
@@ -821,7 +828,9 @@ int gjx_peer_ctx_destroy(gjx_peer_ctx* ctx);
  * from the same K_total / 1024 granules on every rank, so particles, weights and log-ML do not depend on n_ranks.
  * The particles of the last step are left in rows[(T - 1) & 1], their log-weights in logw[0]; lse_steps f32[T][4] =
  * the GLOBAL record of every step (on every rank); ancestors (or NULL) int32[K_local] = global index of every slot's
- * ancestor at the last resampling. */
+ * ancestor at the last resampling.  T <= GJX_PEER_MAX_STEPS per call (the context's per-step scratch; nothing is allocated after
+ * gjx_peer_ctx_create): a longer run is cut by the caller. */
+#define GJX_PEER_MAX_STEPS 4096
 int gjx_ssm_filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t rng_mode, int32_t T, gjx_peer_ctx* ctx,
                         const float* ys_dev, float* lse_steps, int32_t* ancestors, void* stream);
 /* the sharded filter with resample-move rejuvenation: gjx_ssm_filter_move on a collection sharded over the ranks of a peer
