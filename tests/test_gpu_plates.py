@@ -41,9 +41,12 @@ def _mixture(N, seed=0, mu=(-2.0, 0.5, 3.0)):
     return model, C["k", "x"].set(ys), ys, mu, logits
 
 
-def _check_against_oracle(prog, out, ora, discrete_rows=(), cap_particles=0.08):
+def _check_against_oracle(prog, out, ora, discrete_rows=()):
     """values / scores against the oracle; a particle may differ only where one of the oracle's discrete decisions for it
-    was a near tie (oracle `decide` margins), and discrete ELEMENTS may differ in at most 1e-4 of all elements"""
+    was a near tie (oracle `decide` margins: the smallest margin over ALL of the particle's decisions — thousands, in a plate) — so
+    the fraction that differs is bounded by the fraction of near-tie particles the oracle itself reports, and is expected well below
+    it (a near tie flips only when the two sides' rounding errors straddle it: at most half of them); discrete ELEMENTS may differ
+    in at most 1e-4 of all elements"""
     ch, oc = _np(out["choices"]), ora["choices"]
     close = (np.abs(ch - oc) <= 5e-5 + 2e-4 * np.abs(oc)).all(axis=0)
     for k in ("score", "weight"):
@@ -53,7 +56,8 @@ def _check_against_oracle(prog, out, ora, discrete_rows=(), cap_particles=0.08):
     if bad.any():
         m = ora["margin"][bad]
         assert (m < NEAR_TIE).all(), f"{int((m >= NEAR_TIE).sum())} differing particles are not near ties (max margin {float(m.max()):.3g})"
-        assert bad.mean() <= cap_particles, f"{bad.mean():.4f} of the particles differ"
+        near = float((ora["margin"] < NEAR_TIE).mean())
+        assert bad.mean() <= 0.6 * near + 3.0 / bad.size, f"{bad.mean():.4f} of the particles differ; the oracle has {near:.4f} near-tie particles"
     if len(discrete_rows):
         diff = ch[list(discrete_rows)] != oc[list(discrete_rows)]
         assert diff.mean() <= 1e-4, diff.mean()
