@@ -1127,7 +1127,7 @@ def run_round4(dev):
     row["generated_vs_interpreter"] = row["interp"]["kernel_us"] / row["gen"]["kernel_us"]
     row["wide_vs_one_lane_per_particle"] = row["gen_one_lane_per_particle"]["kernel_us"] / row["gen"]["kernel_us"]
     row["form"] = ("gjx_gen, ppt | 512: a block of 16 waves shares 64 x PPT particles, the instances of the plate are dealt to the waves in "
-                   "contiguous chunks, partial sums joined in LDS in wave order")
+                   "contiguous chunks, partial sums joined in LDS in wave order; few particles: | 1024 / | 2048 = 4 / 16 lanes per particle as well")
     res["vmapped_mixture_plate"] = row
     res["vmapped_mixture_plate_K2e12_N2e16"] = plate_row(65536, 1 << 12, engines[:2])
     return res

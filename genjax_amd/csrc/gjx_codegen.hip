@@ -182,6 +182,8 @@ struct Plan {
   // are dealt to the waves in contiguous chunks and the waves' partial sums meet in LDS (fixed order: deterministic), so a program
   // with few particles and many instances still fills the SIMDs.  Sites outside plates are computed by every wave, stored by wave 0
   bool wide = false;
+  int lpp = 1;                      // wide flavour: lanes per particle (ppt code | 1024: 4, | 2048: 16) — FEW particles over very many instances:
+                                    // a wave holds 64 / lpp particles, the instances are dealt to 16 x lpp chunks (wave, lane within the particle)
   int find(int kind, int off, int n, int len = 0, int dim = 0) {
     for (auto& c : comps) if (c.kind == kind && c.off == off && c.n == n && c.len == len && c.dim == dim) return c.at;
     Companion c{kind, off, n, comp_floats, len, dim};
@@ -999,6 +1001,7 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
   pl.ppt = ppt;
   pl.mfma = mfma;
   pl.wide = (ppt_code & 512) != 0 && px.any && !mfma;
+  pl.lpp = pl.wide ? ((ppt_code & 2048) ? 16 : ((ppt_code & 1024) ? 4 : 1)) : 1;
   pl.seq_rows = !px.any && !roll.ok && !mfma && !getenv("GJX_GEN_NO_SEQ_ROWS");      // (generate_pf clears it: its rows move with the step)
   pl.tab_lds = mfma || (prog->n_tab <= kMaxLdsTab && !getenv("GJX_GEN_TAB_GLOBAL"));   // (the variable: profiling variant, part of the cache key)
   if (roll.ok) {
@@ -1097,7 +1100,7 @@ std::string emit_body(GenCtx& g, int j_lo = 0, int j_hi = -1) {
       if (pl.wide) {
         // the instances in 16 contiguous chunks, one per wave of the block (consecutive instances share hash blocks of the FLAT
         // streams); the plate's contribution to score / weight is summed apart and joined across the waves below
-        body.f("    const int pc_ = (%d + 15) / 16, plo_ = pw_ * pc_, phi_ = plo_ + pc_ < %d ? plo_ + pc_ : %d;\n"
+        body.f("    const int pc_ = (%d + NCH_ - 1) / NCH_, plo_ = pw_ * pc_, phi_ = plo_ + pc_ < %d ? plo_ + pc_ : %d;\n"
                "    float psc_[PPT], pwt_[PPT];\n    PLOOP { psc_[p] = score[p]; pwt_[p] = weight[p]; score[p] = 0.0f; weight[p] = 0.0f; }\n"
                "    _Pragma(\"nounroll\") for (int i_ = plo_; i_ < phi_; ++i_) {\n", pl.info[j].plate_n, pl.info[j].plate_n, pl.info[j].plate_n);
       } else
@@ -1167,9 +1170,12 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   o.f("#include \"gjx_device.h\"\n#include \"gjx_tile.h\"\nusing namespace gjx;\n#define RNG %d\n#define PPT %d\n#define PLOOP _Pragma(\"unroll\") for (int p = 0; p < PPT; ++p)\n",
       prog->rng_mode == GJX_RNG_JAX32 ? GJX_RNG_JAX32 : GJX_RNG_FLAT, ppt);
   if (wide)
-    o.f("#define OWN_ (threadIdx.x < 64u)\n"
-        "#define PRED_(acc_, base_) do { __syncthreads(); PLOOP pred_[(pw_ * 64 + pl_) * PPT + p] = acc_[p]; __syncthreads(); \\\n"
-        "    PLOOP { float t_ = 0.0f; _Pragma(\"unroll\") for (int w_ = 0; w_ < 16; ++w_) t_ += pred_[(w_ * 64 + pl_) * PPT + p]; acc_[p] = base_[p] + t_; } } while (0)\n");
+    // LPP_ lanes per particle: PT_ = 64 / LPP_ particle lanes per wave, NCH_ = 16 LPP_ chunks of instances (wave, lane within the particle);
+    // the chunks' partial sums meet in LDS and are added in chunk order
+    o.f("#define LPP_ %d\n#define PT_ (64 / LPP_)\n#define NCH_ (16 * LPP_)\n"
+        "#define OWN_ (threadIdx.x < 64u && (threadIdx.x %% LPP_) == 0u)\n"
+        "#define PRED_(acc_, base_) do { __syncthreads(); PLOOP pred_[(pw_ * PT_ + pl_) * PPT + p] = acc_[p]; __syncthreads(); \\\n"
+        "    PLOOP { float t_ = 0.0f; _Pragma(\"nounroll\") for (int w_ = 0; w_ < NCH_; ++w_) t_ += pred_[(w_ * PT_ + pl_) * PPT + p]; acc_[p] = base_[p] + t_; } } while (0)\n", pl.lpp);
   else o.f("#define OWN_ true\n");
   o.f("#define NTAB %d\n#define NCOMP %d\n", prog->n_tab, pl.comp_floats);
   if (pl.tab_lds) o.f("#define TAB(i) tab_s[i]\n#define COMP(i) tab_s[NTAB + (i)]\n");
@@ -1195,7 +1201,8 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
   else
   o.f("template <bool LIVE_>\nstatic __device__ __forceinline__ void gjx_step_(const GenArgs& a) {\n"
       "  extern __shared__ __attribute__((aligned(16))) float tab_s[];\n  __shared__ float red[16];\n  __shared__ uint64_t red_q[4];\n");
-  if (wide) o.f("  __shared__ float pred_[1024 * PPT];   // the waves' partial sums of a plate\n  const int pw_ = (int)(threadIdx.x >> 6), pl_ = (int)(threadIdx.x & 63u);\n");
+  if (wide) o.f("  __shared__ float pred_[1024 * PPT];   // the chunks' partial sums of a plate\n"
+                "  const int pw_ = (int)(threadIdx.x >> 6) * LPP_ + (int)((threadIdx.x & 63u) %% LPP_), pl_ = (int)((threadIdx.x & 63u) / LPP_);\n");
   o.f("  constexpr bool live_ = LIVE_;   // steps kernel: agent-scope traffic, granules (compiled out of the one-step kernel)\n  TSTAMP(0);\n");
   if (pl.tab_lds) o.f("  for (int t = threadIdx.x; t < NTAB; t += %d) tab_s[t] = a.tab[t];\n  __syncthreads();\n", BT);
   o.f("#define TSRC(i) TAB(i)\n#define BT_ %d\n", BT);
@@ -1208,7 +1215,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "  for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {\n"
       "    const int64_t i0 = tix * tile + (int64_t)%s * PPT;\n    if (i0 >= K) break;   // K %% PPT == 0 (launcher)\n"
       "    uint64_t gidx[PPT];\n    PLOOP gidx[p] = (uint64_t)(a.offset + i0 + p);\n"
-      "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n", wide ? 64 : 256, wide ? "pl_" : "threadIdx.x");
+      "    float score[PPT], weight[PPT];\n    PLOOP { score[p] = 0.0f; weight[p] = 0.0f; }\n", wide ? 64 / pl.lpp : 256, wide ? "pl_" : "threadIdx.x");
   o.f("    float v[%d][PPT];\n", prog->n_slots > 0 ? prog->n_slots : 1);
   if (pl.seq_rows) { o.f("    float* rp_ = a.choices + i0;   // the running row pointer (Plan::seq_rows)\n"); pl.rp_row = 0; }
   {
@@ -1268,7 +1275,7 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "        }\n      } else {\n      __syncthreads();\n"
       "      if (threadIdx.x == 0) { const uint64_t tot_ = red_q[0] + red_q[1] + red_q[2] + red_q[3]; a.tile_S[tix] = tot_; a.tile_E[tix] = tot_ ? e_ : kTileDead; }\n"
       "      }\n    }\n  }\n");
-  if (wide) o.f("  if (pw_ >= 4) return;   // (the block's LSE pair is made by 256 threads; waves 1 .. 3 contribute nothing, the rest leave)\n");
+  if (wide) o.f("  if ((threadIdx.x >> 6) >= 4u) return;   // (the block's LSE pair is made by 256 threads; waves 1 .. 3 contribute nothing, the rest leave)\n");
   o.f("  if (a.partials && !live_) {\n    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;\n"
       "    const float wm = wave_max(tmax);\n    const float ws = wave_sum(wm > -INFINITY ? tsum * fast_exp(tmax - wm) : 0.0f);\n"
       "    if (lane == 0) { red[wid] = wm; red[4 + wid] = ws; }\n    __syncthreads();\n"
@@ -2520,7 +2527,12 @@ int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {
       int wp = slots <= 4 ? 2 : 1;
       if (const char* pe = getenv("GJX_GEN_PPT")) { const int q = atoi(pe); if (q == 1 || q == 2) wp = q; }
       while (wp > 1 && K % wp != 0) wp >>= 1;
-      return wp | 512;
+      // few particles, very many instances: 4 or 16 lanes per particle (| 1024, | 2048) until the launch has two blocks per CU
+      // (measured, N = 2^16 x K = 2^12: one lane per particle, 64 blocks, 5.36 ms; 4 lanes, 256 blocks, 1.58 ms; 16 lanes, 1024 blocks, 1.28 ms)
+      int lpp = 1;
+      while (lpp < 16 && (K * lpp) / (64 * (int64_t)wp) < 512 && longest >= 16 * (lpp * 4) * 16 && K % (64 * wp / (lpp * 4)) == 0) lpp *= 4;
+      if (const char* le = getenv("GJX_GEN_LPP")) { const int q = atoi(le); if (q == 1 || q == 4 || q == 16) lpp = q; }
+      return wp | 512 | (lpp == 4 ? 1024 : (lpp == 16 ? 2048 : 0));
     }
   }
   if (const char* e = getenv("GJX_GEN_PPT")) ppt = atoi(e);
@@ -2782,7 +2794,11 @@ extern "C" int gjx_program_hmc_precompile(const gjx_program* prog) {
 extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char* out, int64_t cap) {
   if (!prog || !prog->sites) return GJX_EINVAL;
   if (!supported(prog)) return gjx_fail(GJX_EUNSUPPORTED, "codegen: program outside the emitter's coverage");
-  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256) && ppt != (1 | 512) && ppt != (2 | 512)) ppt = gjx::gen_pick_ppt(prog, 4);
+  {
+    const int base = ppt & ~(1024 | 2048);
+    if ((base != 1 && base != 2 && base != 4 && base != (1 | 256) && base != (1 | 512) && base != (2 | 512)) || ((ppt & (1024 | 2048)) && !(base & 512)))
+      ppt = gjx::gen_pick_ppt(prog, 4);
+  }
   const std::string src = generate(prog, ppt);
   if (out && cap > 0) {
     const size_t n = src.size() < (size_t)cap - 1 ? src.size() : (size_t)cap - 1;
@@ -2796,8 +2812,10 @@ extern "C" int64_t gjx_program_source(const gjx_program* prog, int32_t ppt, char
 // cache with this on machines without a GPU (hipRTC cross-compiles)
 extern "C" int gjx_program_precompile(const gjx_program* prog, int32_t ppt) {
   if (!prog || !prog->sites) return gjx_fail(GJX_EINVAL, "gjx_program_precompile: null program");
-  if (ppt != 1 && ppt != 2 && ppt != 4 && ppt != (1 | 256) && ppt != (1 | 512) && ppt != (2 | 512))
-    return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4, 257 (1 | 256: big affine sites on the matrix cores) or 513 / 514 (| 512: the instances of a plate dealt to the 16 waves of a block)");
+  const int wide_lanes = ppt & (1024 | 2048);
+  const int base = ppt & ~(1024 | 2048);
+  if ((base != 1 && base != 2 && base != 4 && base != (1 | 256) && base != (1 | 512) && base != (2 | 512)) || (wide_lanes && !(base & 512)) || wide_lanes == (1024 | 2048))
+    return gjx_fail(GJX_EINVAL, "gjx_program_precompile: ppt must be 1, 2, 4, 257 (1 | 256: big affine sites on the matrix cores) or 513 / 514 (| 512: the instances of a plate dealt to the 16 waves of a block; | 1024 / | 2048: and to 4 / 16 lanes per particle)");
   return gjx::gen_available(prog, ppt);
 }
 

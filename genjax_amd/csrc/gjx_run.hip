@@ -1208,7 +1208,8 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
     const int ppt = gen_pick_ppt(prog, K, want_tiles && K % 1024 == 0);     // (ppt | 256: the matrix-core flavour, gjx_codegen.hip)
     if (gen_available(prog, ppt) != GJX_OK) return false;
     // (ppt | 512: a block of 16 waves shares 64 x ppt particles — the instances of its plates are dealt to the waves)
-    const int64_t tile = ((ppt & 512) ? 64 : 256) * (int64_t)(ppt & 255), ntiles = (K + tile - 1) / tile;
+    const int lpp = (ppt & 2048) ? 16 : ((ppt & 1024) ? 4 : 1);        // (wide flavour: lanes per particle)
+    const int64_t tile = ((ppt & 512) ? 64 / lpp : 256) * (int64_t)(ppt & 255), ntiles = (K + tile - 1) / tile;
     // the per-block prologue (table copy + derived constants) is paid once per block: no more blocks than can be resident
     // at 4 per CU, each looping over its tiles
     static const int resident = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 4 * (cus > 0 ? cus : 256); }();
@@ -1216,7 +1217,8 @@ static EnginePlan plan_engine(const gjx_program* prog, int64_t K, int64_t partic
     // 1024 blocks of four tiles: 520 vs 545 us on the config-5 target)
     int maxgrid = env_int("GJX_GEN_GRID", (ppt & 256) ? (1 << 20) : ((ppt & 512) ? 2 * resident : resident));
     // (a workspace has room for one {max, sumexp} pair per 256 particles: no more blocks than that, whatever a block's tile is)
-    if ((ppt & 512) && maxgrid > (int)((K + 255) / 256)) maxgrid = (int)((K + 255) / 256);
+    // (the wide flavour never leaves tile totals behind the pairs, so its pairs may use the workspace's 64 KB of slack: 4096 of them)
+    if ((ppt & 512) && maxgrid > (int)((K + 255) / 256) && maxgrid > 4096) maxgrid = (int)((K + 255) / 256) > 4096 ? (int)((K + 255) / 256) : 4096;
     e.engine = ENGINE_GEN; e.ppt = ppt; e.grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
     return true;
   };

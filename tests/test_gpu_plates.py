@@ -98,6 +98,35 @@ def test_vmapped_mixture_is_two_device_sites_and_matches_the_oracle(rng, engine,
     assert np.abs(np.bincount(z.ravel(), minlength=3) / z.size - p).max() < 2e-3
 
 
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+@pytest.mark.parametrize("lpp", [4, 16])
+def test_few_particles_over_very_many_instances_take_several_lanes_per_particle(rng, lpp, monkeypatch):
+    """K = 512 particles over N = 8192 data: with one lane per particle the launch has 8 blocks.  The wide flavour deals a particle's
+    instances to 4 or 16 LANES as well as to the 16 waves of its block (a wave holds 64 / lpp particles; 16 x lpp chunks of instances
+    whose partial sums meet in LDS in chunk order): same values as the oracle, every instance's row written by the lane that drew it"""
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, K = 8192, 512
+    model, chm, ys, mu, logits = _mixture(N, seed=2)
+    prog, _, _ = model.pack((), chm, True, rng_mode=rng)
+    monkeypatch.setenv("GJX_ENGINE", "gen")
+    monkeypatch.setenv("GJX_GEN_WIDE", "1")
+    monkeypatch.setenv("GJX_GEN_LPP", str(lpp))
+    out = kernels.run_program(prog, (0, 13), K, want_site_scores=True)
+    assert out["_engine"] == 4
+    ora = cpu.run_program(prog, (0, 13), K, want_margin=True, want_site_scores=True)
+    _check_against_oracle(prog, out, ora, discrete_rows=range(N))
+    z = _np(out["choices"])[:N].astype(int)
+    lw = (-0.5 * ((ys[:, None] - mu[z]) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(_np(out["weight"]), lw, rtol=2e-5, atol=0.03)
+    same = (_np(out["choices"]) == ora["choices"]).all(axis=0)
+    np.testing.assert_allclose(_np(out["site_scores"])[:, same], ora["site_scores"][:, same], rtol=3e-4, atol=4e-3)
+    np.testing.assert_allclose(float(out["lse"][2]), float(np.log(np.exp(ora["weight"].astype(np.float64) - ora["weight"].max()).sum()) + ora["weight"].max()), rtol=1e-5, atol=5e-3)
+    monkeypatch.delenv("GJX_GEN_LPP")
+    monkeypatch.delenv("GJX_GEN_WIDE")
+    assert "#define LPP_ %d" % lpp in kernels.program_source(prog, 1 | 512 | (1024 if lpp == 4 else 2048))
+
+
 def test_plate_through_the_inference_layer():
     """ImportanceK on the vmapped mixture (smc.py:298-315): log-ML against the closed form prod_i sum_c pi_c N(y_i; mu_c, s)"""
     from genjax_amd.inference import ImportanceK, Target
