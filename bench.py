@@ -246,6 +246,12 @@ def run_gmm(args, rank, world, dev):
         # one trial step: the one-launch resampler needs K / 1024 blocks co-resident per rank (ranks that SHARE a device —
         # a dry run of the multi-rank path on one GPU — split its capacity); if any rank cannot, all take the collective transport
         from genjax_amd._lib import GjxError
+        # (the ranks enter their first rendezvous together: kernels are loaded by the warm-up above, the barrier takes the process
+        # start-up skew out — a rank that waits longer than its poll budget for a late peer would report a time-out, and the run
+        # would fall back to the collective transport for no reason)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
         try:
             for _ in range(4):
                 par = peer_calls[0] & 1

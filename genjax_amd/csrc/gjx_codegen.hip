@@ -1698,6 +1698,10 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
   for (int j = 0; j < ns; ++j) {
     const gjx_site& s = pl.sites[j];
     const RollInfo& ri = pl.info[j];
+    if (s.mode == GJX_MODE_INPUT) {      // a per-chain value the other sites read (registers, loaded with the chain's values): no density
+      if (ri.plate || (pl.rolled && j >= pl.roll.i0) || (s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) return false;
+      continue;
+    }
     if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
     if (s.mode != GJX_MODE_OBS_TAB && s.mode != GJX_MODE_OBS_SLOT) return false;
     for (int k = 0; k < 4; ++k) if (ri.mem_slot[k] >= 0) return false;     // (instances of another plate, one instance read from outside: the interpreter)
@@ -2018,6 +2022,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
     const gjx_site& s = prog->sites[j];
     const RollInfo& ri = hp.info[j];
     g_loop_var = hp.rolled ? "(t_ - 1)" : "i_";
+    if (s.mode == GJX_MODE_INPUT) { o.f("  // ---- site %d: INPUT, %d rows from slot %d (a value, no density)\n", j, s.dim, s.slot); return; }
     const int np = n_params(s.kind);
     o.f("  { // ---- site %d: kind %d, dim %d, slot %d%s\n", j, s.kind, is_categorical(s.kind) ? s.ncat : s.dim, s.slot, ri.plate ? " (plate body)" : "");
     for (int k = 0; k < np; ++k) {
@@ -2177,7 +2182,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   for (int j = 0; j < (hp.rolled ? hp.roll.i0 : prog->n_sites); ++j) {       // the chain's values: rows of choices[][] -> registers (a plate's body, a rolled Scan's steps: in the sweep)
     const gjx_site& sj = prog->sites[j];
     if (sj.slot < 0 || hp.info[j].plate) continue;
-    const int w = is_categorical(sj.kind) ? 1 : sj.dim;
+    const int w = (is_categorical(sj.kind) && sj.mode != GJX_MODE_INPUT) ? 1 : sj.dim;
     for (int d = 0; d < w; ++d) o.f("  v[%d] = a.choices[(int64_t)%d * n + i];\n", sj.slot + d, hp.info[j].row + d);
   }
   // the rows of the selected sites inside plates: working positions, momenta, gradients (and the first gradient for the stale-carry
@@ -2282,7 +2287,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
     for (int j = 0; j < (hp.rolled ? hp.roll.i0 : prog->n_sites); ++j) {
       const gjx_site& sj = prog->sites[j];
       if (sj.slot < 0 || hp.info[j].plate) continue;
-      const int w = is_categorical(sj.kind) ? 1 : sj.dim;
+      const int w = (is_categorical(sj.kind) && sj.mode != GJX_MODE_INPUT) ? 1 : sj.dim;
       for (int d = 0; d < w; ++d) row_of_reg[sj.slot + d] = hp.info[j].row + d;
     }
     for (int m = 0; m < hp.nout; ++m) o.f("      a.choices[(int64_t)%d * n + i] = v[%d];\n", row_of_reg[hp.slot_of_sel[m]], hp.slot_of_sel[m]);

@@ -113,11 +113,12 @@ GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, co
   float score = 0.0f;
   for (int j = 0; j < n_sites;) {
     const gjx_site& s = sites[j];
+    if (s.mode == GJX_MODE_INPUT) { ++j; continue; }      // an argument / a carry: a value that is there, no density
     if (s.plate == 0) { score += site_score_and_grad(s, 0, tab, val, G); ++j; continue; }
     int m = 1;
     while (j + m < n_sites && sites[j + m].plate == s.plate) ++m;
     for (int i = 0; i < s.plate_n; ++i)
-      for (int l = 0; l < m; ++l) score += site_score_and_grad(sites[j + l], i, tab, val, G);
+      for (int l = 0; l < m; ++l) if (sites[j + l].mode != GJX_MODE_INPUT) score += site_score_and_grad(sites[j + l], i, tab, val, G);
     j += m;
   }
   return score;
@@ -125,7 +126,7 @@ GJX_DEV float score_and_grad(const gjx_site* sites, int n_sites, int n_slots, co
 
 // rows a site owns in choices[][]: a plate's body site has one set per instance
 GJX_DEV int site_rows(const gjx_site& s) {
-  const bool cat = s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS;
+  const bool cat = (s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS) && s.mode != GJX_MODE_INPUT;
   return (cat ? 1 : s.dim) * (s.plate ? s.plate_n : 1);
 }
 
@@ -1091,10 +1092,10 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     return gjx_fail(GJX_EINVAL, "gjx_hmc: bad argument");
   for (int j = 0; j < prog->n_sites; ++j) {
     const gjx_site& s = prog->sites[j];
-    if (s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_TAB / OBS_SLOT)");
-    // (plate-tagged bodies — the gradient of assess through a Vmap, hmc.py:70-96 / vmap.py:363-376 — run on a generated kernel when
-    // nothing inside the plate is selected, on the site interpreter otherwise; an INPUT site has no density to differentiate)
-    if (s.mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_hmc: GJX_MODE_INPUT sites are not supported");
+    if (s.mode == GJX_MODE_SAMPLE || s.mode == GJX_MODE_OBS_MASK) return gjx_fail(GJX_EINVAL, "gjx_hmc: every site must be constrained (mode OBS_TAB / OBS_SLOT) or an input (GJX_MODE_INPUT)");
+    // (an INPUT site — a kernel's argument, a Scan step's carry — is a per-chain value the other sites read: rows of choices[][],
+    // no density, never moved)
+    if (s.mode == GJX_MODE_INPUT && (s.flags & GJX_SITE_HMC_SELECTED)) return gjx_fail(GJX_EINVAL, "gjx_hmc: an INPUT site cannot be selected");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
                                               s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))
@@ -1152,8 +1153,6 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
 extern "C" int gjx_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score, float* grad,
                               void* stream) {
   if (!prog || !prog->sites_dev || !prog->tab_dev || !choices || !grad || n <= 0) return gjx_fail(GJX_EINVAL, "gjx_score_grad: bad argument");
-  for (int j = 0; prog->sites && j < prog->n_sites; ++j)
-    if (prog->sites[j].mode == GJX_MODE_INPUT) return gjx_fail(GJX_EUNSUPPORTED, "gjx_score_grad: GJX_MODE_INPUT sites are not supported");
   hipLaunchKernelGGL(k_score_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prog->sites_dev,
                      prog->tab_dev, prog->n_sites, prog->n_slots, n, choices, score, grad);
   GJX_CHECK_LAUNCH("gjx_score_grad");

@@ -125,7 +125,9 @@ enum {
                             (from choices[slot + d][i], or through the ancestor gather of gjx_run_program_ex:
                             in_rows[obs_off + d][ancestor(i)]), never drawn and never scored; the site takes NO site number in
                             either stream layout (the sites behind it are numbered as if it were not there); kind and
-                            parameters are ignored.  Accepted by gjx_run_program[_ex] only. */
+                            parameters are ignored.  gjx_hmc / gjx_score_grad read it from choices[slot + d][i] like any per-chain
+                            value (an HMC move of a kernel's latents given its arguments / of a Scan step given its carry): no
+                            density, no gradient row, never selected. */
 };
 
 enum { GJX_SITE_HMC_SELECTED = 1, /* gjx_site.flags: site is moved by gjx_hmc (hmc.py:70-96) */

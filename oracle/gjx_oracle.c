@@ -1347,11 +1347,13 @@ static float score_and_grad(const gjx_program* prog, const float* vals, float* g
   for (int s = 0; s < prog->n_slots; ++s) grad[s] = 0.0f;
   for (int j = 0; j < prog->n_sites;) {
     const gjx_site* s = &prog->sites[j];
+    if (s->mode == GJX_MODE_INPUT) { ++j; continue; } /* an argument / a carry: a value that is there, no density (gjx.h) */
     if (s->plate == 0) { score += score_and_grad_site(prog, s, vals, grad); ++j; continue; }
     int m = 1;
     while (j + m < prog->n_sites && prog->sites[j + m].plate == s->plate) ++m;
     for (int i = 0; i < s->plate_n; ++i)
       for (int l = 0; l < m; ++l) {
+        if (prog->sites[j + l].mode == GJX_MODE_INPUT) continue;
         const gjx_site sv = site_instance(&prog->sites[j + l], i);
         score += score_and_grad_site(prog, &sv, vals, grad);
       }

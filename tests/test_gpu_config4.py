@@ -187,6 +187,9 @@ def _fault_worker(rank, world, port, K_total, dx, out_dir):
         sl = slice(rank * K, (rank + 1) * K)
         ctx.logw[0].copy_(torch.as_tensor(rs.standard_normal(K_total).astype(np.float32)[sl]))
         ctx.rows[0].copy_(torch.as_tensor(rs.standard_normal((dx, K_total)).astype(np.float32)[:, sl]))
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
         ctx.resample_gather(0, 0.3)
         torch.cuda.synchronize()
         st_r = ctx.status()
@@ -231,6 +234,9 @@ def _resample_worker(rank, world, port, K_total, R, out_dir):
             ctx.logw[p].copy_(torch.as_tensor(lw[sl]))
             ctx.rows[p].copy_(torch.as_tensor(rows[:, sl]))
             anc = torch.empty(K, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier()      # the ranks launch together (each spent a different time making its inputs)
             out, _ = ctx.resample_gather(p, 0.41 + 0.2 * call, anc=anc)
             torch.cuda.synchronize()
             outs["rows%d" % call] = out.cpu().numpy()

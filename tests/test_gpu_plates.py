@@ -440,6 +440,30 @@ def test_mixture_with_latent_means_matches_the_oracle(rng, engine, monkeypatch):
     np.testing.assert_allclose(_np(out["weight"]), lx, rtol=3e-4, atol=3e-2)
 
 
+@pytest.mark.parametrize("engine", ["gen", "interp"])
+def test_mixture_with_latent_means_and_one_assignment_for_every_particle(engine, monkeypatch):
+    """importance over (mu, ls) with x AND z observed (one assignment vector for every particle: z owns no storage, the index of the
+    row gather comes from the table, GJX_P_VGATHER with slot = -1) — both engines against the oracle and against numpy"""
+    from genjax_amd import kernels
+    from oracle import cpu
+    N, K = 500, 4096
+    model, ys, logits, ztrue = _mixture_with_latent_means(N, seed=5)
+    prog, _, _ = model.pack((), C["k", "x"].set(ys) | C["k", "z"].set(ztrue.astype(np.float32)), True)
+    q = prog.c_sites[3].p[0]
+    assert prog.n_slots == 4 and (q.op, q.slot, q.d_off) == (A.P_VGATHER, -1, 1)
+    monkeypatch.setenv("GJX_ENGINE", engine)
+    assert kernels.program_engine(prog) == (4 if engine == "gen" else 0)
+    out = kernels.run_program(prog, (0, 6), K)
+    ora = cpu.run_program(prog, (0, 6), K)
+    np.testing.assert_allclose(_np(out["choices"]), ora["choices"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(_np(out["weight"]), ora["weight"], rtol=3e-4, atol=3e-2)
+    ch = _np(out["choices"])
+    mu, ls = ch[:3], ch[3]
+    lz = (logits - np.log(np.exp(logits).sum()))[ztrue].sum()
+    lx = (-0.5 * ((ys[:, None] - mu[ztrue]) / np.exp(ls)) ** 2 - ls - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(_np(out["weight"]), lx + lz, rtol=3e-4, atol=5e-2)
+
+
 @pytest.mark.parametrize("z_shared", [False, True])
 def test_hmc_over_the_means_and_log_sigma_of_the_4096_datum_mixture(z_shared, monkeypatch):
     """HMC.edit over (mu, ls) of the 4096-datum vmapped mixture with the assignments z fixed — per chain (rows of the chain), or one
@@ -528,12 +552,44 @@ def test_config5_written_with_vmap_and_a_two_site_body_runs_on_a_generated_hmc_k
     np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=6e-3, atol=2e-2)
 
 
-def test_hmc_entry_points_refuse_input_sites():
-    """an INPUT site has no density to differentiate: gjx_hmc / gjx_score_grad refuse such programs (GJX_EUNSUPPORTED)"""
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_hmc_and_score_grad_read_input_sites_as_values(rng, monkeypatch):
+    """a kernel's argument / a Scan step's carry as a GJX_MODE_INPUT site in an HMC target: x | x_prev ~ N(A x_prev, q) moved given
+    the per-chain x_prev, y | x observed — the INPUT rows are read like any per-chain value, carry no density and no gradient row.
+    Generated kernel, interpreter and oracle; the same target with x_prev constrained per chain (OBS_SLOT under a flat prior of
+    its own) gives the same gradient of x"""
     import torch
-    from genjax_amd import kernels, workloads
-    from genjax_amd._lib import GjxError
-    step = workloads.lgssm_scan_step_program(4)
-    ch = torch.zeros((max(step.n_slots, 1), 32), device="cuda")
-    with pytest.raises(GjxError, match="INPUT"):
-        kernels.score_grad(step, ch)
+    from genjax_amd import kernels
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    from oracle import cpu
+    dx, n = 4, 300
+    rs = np.random.default_rng(2)
+    Am = (0.5 * rs.standard_normal((dx, dx))).astype(np.float32)
+    y = rs.standard_normal(dx).astype(np.float32)
+    sl = SiteList()
+    sl.add("xp", A.MVNORMAL_DIAG, [np.zeros(dx, np.float32), np.ones(dx, np.float32)])
+    sl.add("x", A.MVNORMAL_DIAG, [Param.affine(Am, "xp"), np.full(dx, 0.7, np.float32)])
+    sl.add("y", A.MVNORMAL_DIAG, [Param.value("x", dx), np.full(dx, 0.5, np.float32)])
+    prog = PackedProgram(sl, {"xp": A.MODE_INPUT, "x": A.MODE_OBS_SLOT, "y": A.MODE_OBS_TAB}, {"y": y}, selected=("x",), rng_mode=rng)
+    assert prog.c_sites[0].mode == A.MODE_INPUT and prog.n_slots == 2 * dx
+    ch = (0.5 * rs.standard_normal((prog.n_slots, n))).astype(np.float32)
+    gs, gg = kernels.score_grad(prog, torch.as_tensor(ch).cuda())
+    os_, og = cpu.score_grad(prog, ch)
+    np.testing.assert_allclose(_np(gs), os_, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(gg), og, rtol=2e-3, atol=2e-3)
+    assert not og[:dx].any() and np.abs(og[dx:]).max() > 0.1                  # the input rows have no gradient row
+    xp, x = ch[:dx].astype(np.float64), ch[dx:].astype(np.float64)
+    want = (-0.5 * ((x - Am.astype(np.float64) @ xp) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi)).sum(axis=0) \
+        + (-0.5 * ((y[:, None] - x) / 0.5) ** 2 - np.log(0.5) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(os_, want, rtol=2e-5, atol=2e-3)               # the input's own "density" is no part of the score
+    for engine, code in (("gen", 4), ("interp", 0)):
+        monkeypatch.setenv("GJX_HMC_ENGINE", engine)
+        assert kernels.hmc_engine(prog) == code
+        g = kernels.hmc(prog, (3, 8), torch.as_tensor(ch).cuda(), 0.05, 10, False, False, offset=2)
+        o = cpu.hmc(prog, (3, 8), ch, 0.05, 10, False, False, offset=2)
+        gc = _np(g["choices"])
+        np.testing.assert_array_equal(gc[:dx], ch[:dx])
+        np.testing.assert_allclose(gc, o["choices"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=5e-3, atol=5e-3)
+        assert np.abs(gc[dx:] - ch[dx:]).max() > 1e-2
+    monkeypatch.delenv("GJX_HMC_ENGINE")
