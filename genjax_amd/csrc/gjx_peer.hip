@@ -323,11 +323,25 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
 // n_slots; every rank passes its OWN copies of the step programs (same structure, same tables) and the same key.
 // Particles and weights do not depend on the number of ranks (streams and resampling integers are global).
 // ------------------------------------------------------------------------------------------------------------
+static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out, bool prepare_only);
+
 extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
                                     int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out) {
+  return scan_filter_peer_impl(c, steps, T, key0, key1, lse_steps, ancestors, workspace, workspace_bytes, stream, info_out, false);
+}
+// everything of the call above that takes unpredictable host time — generating, compiling (hipRTC) and loading the kernels of the
+// step programs, the occupancy queries behind the choice of tiles per block — and no launch: the ranks of a job call it, meet at a
+// HOST barrier, and only then enter the filter together (a rank that waits for a peer still compiling would run out of its poll budget)
+extern "C" int gjx_scan_filter_peer_prepare(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, gjx_filter_info* info_out) {
+  return scan_filter_peer_impl(c, steps, T, 0u, 0u, nullptr, nullptr, nullptr, 0, nullptr, info_out, true);
+}
+
+static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out, bool prepare_only) {
   gjx_filter_info finfo = {GJX_FILTER_FORM_WIDE, 0, 0, 0};
   if (info_out) *info_out = finfo;
-  if (!c || !steps || !lse_steps || T < 2) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: bad argument (T >= 2)");
+  if (!c || !steps || (!lse_steps && !prepare_only) || T < 2) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: bad argument (T >= 2)");
   if (!c->connected) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: the context is not connected (gjx_peer_ctx_connect)");
   auto input_rows = [](const gjx_program& p) {
     int n = 0;
@@ -345,7 +359,7 @@ extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, i
   if (input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: step 1 reads more carry rows than step 0 produced");
   if (c->NT > kPfHostMaxTiles) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: K_total <= 2^22");
   const size_t need_run = gjx_workspace_bytes(GJX_OP_RUN, c->K);
-  if (!workspace || workspace_bytes < need_run + 8 * (size_t)T + 256) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter_peer: workspace too small (OP_RUN + 8 T + 256)");
+  if (!prepare_only && (!workspace || workspace_bytes < need_run + 8 * (size_t)T + 256)) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter_peer: workspace too small (OP_RUN + 8 T + 256)");
   hipStream_t st = (hipStream_t)stream;
   const int64_t K = c->K, K_total = K * c->world;
   const size_t dyn = pf_core_dyn_lds(c->NT);
@@ -360,6 +374,13 @@ extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, i
   }
   if (!spl) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: no co-resident grid for this size (or the kernel could not be generated)");
   if (T > c->t_cap) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: more steps than a peer context holds (GJX_PEER_MAX_STEPS = 4096 per call)");
+  if (prepare_only) {
+    // step 0's own kernel (gjx_run_program_ex picks and compiles it on first use), then nothing is launched
+    finfo.launches = 0; finfo.grid = grid; finfo.tiles_per_block = spl;
+    if (info_out) *info_out = finfo;
+    (void)gjx_program_precompile(&steps[0], gen_pick_ppt(&steps[0], c->K, false));     // (step 0 may run on another engine: not an error)
+    return GJX_OK;
+  }
   std::vector<uint32_t> h_keys;
   std::vector<double> h_us;
   pf_step_keys(key0, key1, T, h_keys, h_us);

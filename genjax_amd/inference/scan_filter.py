@@ -276,6 +276,11 @@ class ScanBootstrapFilter:
         progs, cps = c["progs"], c["cps"]
         if max(p.n_slots for p in progs) > ctx.nrows:
             raise ValueError(f"run_peer: the context has {ctx.nrows} rows, the step programs need {max(p.n_slots for p in progs)}")
+        if c.get("prepared_for") is not ctx or c.get("prepared_sk") != sk:
+            # first run of this structure on this context: kernels generated, compiled and loaded on EVERY rank, then a host barrier —
+            # the ranks enter the filter together (compile times differ by seconds, a rank's poll budget is shorter)
+            ctx.scan_filter_prepare(cps, len(progs))
+            c["prepared_for"], c["prepared_sk"] = ctx, sk
         o = ctx.scan_filter(cps, len(progs), key, want_ancestors=want_ancestors)
         incs = o["lse_steps"][:, 3]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=o["lse_steps"], choices=o["rows"][: max(progs[-1].n_slots, 1)], logw=o["logw"],

@@ -711,6 +711,20 @@ class PeerContext:
               "gjx_ssm_filter_peer")
         return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
 
+    def scan_filter_prepare(self, cps, T: int) -> None:
+        """gjx_scan_filter_peer_prepare + a barrier of the context's group: every rank has generated, compiled and loaded the kernels
+        of the run before any rank launches into the others' windows (call it once per program structure, on every rank)"""
+        info = A.GjxFilterInfo()
+        check(load().gjx_scan_filter_peer_prepare(self._h, C.cast(cps, C.c_void_p), int(T), C.byref(info)), "gjx_scan_filter_peer_prepare")
+        self.barrier()
+
+    def barrier(self) -> None:
+        """host barrier over the context's ranks (a no-op for one rank)"""
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+
     def scan_filter(self, cps, T: int, key, want_ancestors: bool = False):
         """gjx_scan_filter_peer: the bootstrap filter for ANY Scan kernel on this sharded collection — ``cps``: the ctypes array of
         this rank's T step programs (inference/scan_filter.py).  -> dict(lse_steps [T][4] global records, rows (the last step's

@@ -855,6 +855,11 @@ int gjx_ssm_filter_peer_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int
  * rank); ancestors (or NULL) int32[K_local] = global index of every slot's ancestor at the last resampling.
  * workspace: gjx_workspace_bytes(GJX_OP_RUN, K_local) + 8 T + 256 bytes, zero-filled once.  GJX_EUNSUPPORTED: the step programs are
  * not one kernel the filter emitter covers, or no co-resident grid exists for the size. */
+/* what takes unpredictable HOST time in the call below — generating, compiling and loading the kernels of the step programs, the
+ * occupancy queries behind the choice of tiles per block — and no launch: the ranks of a job call it, meet at a host barrier, and only
+ * then enter the filter together (a rank that waits for a peer that is still compiling would run out of its poll budget).  info_out
+ * (or NULL): the grid and tiles per block the run will use. */
+int gjx_scan_filter_peer_prepare(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, gjx_filter_info* info_out);
 int gjx_scan_filter_peer(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
                          int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out);
 /* BASELINE configs 2 / 4 on a sharded collection — one systematic resampling step over the WHOLE collection in ONE

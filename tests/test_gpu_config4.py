@@ -17,6 +17,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -53,10 +61,25 @@ def _filter_worker(rank, world, port, K_total, T, dx, out_dir, env):
         raise
 
 
-def _run_ranks(target, world, args, out_dir, timeout=900):
+def _run_ranks(target, world, args, out_dir, timeout=900, tries=3):
+    """the ranks as processes sharing the ONE device.  A run in which a rendezvous timed out (status bit 0: eight processes' grids have
+    to be resident together, and the device's scheduler may hold one of them back longer than a lane's poll budget) is what the
+    product's host layer repeats (results of such a run are undefined by contract): so does the test, up to `tries` times"""
+    for attempt in range(tries):
+        res = _run_ranks_once(target, world, args, out_dir, timeout)
+        timed_out = any(int(r[k]) & 1 for r in res for k in r.files if k.startswith("status"))
+        if not timed_out or attempt == tries - 1:
+            return res
+        print("a rendezvous timed out (attempt %d): the run is repeated" % (attempt + 1))
+        for f in os.listdir(out_dir):
+            if f.endswith(".npz"):
+                os.remove(os.path.join(out_dir, f))
+
+
+def _run_ranks_once(target, world, args, out_dir, timeout=900):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    port = 29700 + (os.getpid() % 200)
+    port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port) + args) for r in range(world)]
     for p in procs:
         p.start()

@@ -18,6 +18,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -93,7 +101,7 @@ def test_rccl_two_ranks_exchange_equals_unsharded(spread, method):
     K = 200_003
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29300 + os.getpid() % 200
+    port = _free_port()
     procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, K, spread, method, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -183,7 +191,7 @@ def test_peer_filter_on_real_peers_equals_unsharded(move):
     world, K_total, T, dx = min(n, 4), 1 << 17, 12, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 200)
+    port = _free_port()
     procs = [ctx.Process(target=TP._filter_worker, args=(r, world, port, K_total, T, dx, A.RNG_FLAT, q, move, True)) for r in range(world)]
     for p in procs:
         p.start()

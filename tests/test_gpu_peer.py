@@ -9,6 +9,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,7 +74,7 @@ def test_peer_filter_equals_unsharded(world, K_total, dx):
     T = 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29300 + (os.getpid() % 200) + world
+    port = _free_port()
     procs = [ctx.Process(target=_filter_worker, args=(r, world, port, K_total, T, dx, A.RNG_FLAT, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -108,7 +116,7 @@ def test_peer_move_filter_equals_unsharded(world, K_total, dx):
     T, move = 12, (2, 0.4)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 200) + world
+    port = _free_port()
     procs = [ctx.Process(target=_filter_worker, args=(r, world, port, K_total, T, dx, A.RNG_FLAT, q, move)) for r in range(world)]
     for p in procs:
         p.start()
@@ -173,7 +181,7 @@ def _run_scan_filter_ranks(world, K_total, T, dx, env):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 200) + world
+    port = _free_port()
     procs = [ctx.Process(target=_scan_filter_worker, args=(r, world, port, K_total, T, dx, q, env)) for r in range(world)]
     for p in procs:
         p.start()
@@ -294,7 +302,7 @@ def test_peer_resample_gather_equals_unsharded(world, shape):
     K_total, R = 1 << 15, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 200) + world + 10 * ["mild", "wide", "first", "dead_tiles", "spiky"].index(shape)
+    port = _free_port()
     procs = [ctx.Process(target=_resample_worker, args=(r, world, port, K_total, R, shape, q)) for r in range(world)]
     for p in procs:
         p.start()
