@@ -474,9 +474,13 @@ def test_wide_plate_kernel_deals_the_instances_to_the_waves_of_a_block():
     model, chm, ys, mu, logits = _mixture(600)
     prog, _, _ = model.pack((), chm, True)
     src = kernels.program_source(prog, 2 | 512)
-    assert "__launch_bounds__(1024)" in src and "#define OWN_ (threadIdx.x < 64u)" in src
+    assert "__launch_bounds__(1024)" in src and "#define LPP_ 1" in src and "#define OWN_ (threadIdx.x < 64u && (threadIdx.x % LPP_) == 0u)" in src
     assert "for (int i_ = plo_; i_ < phi_; ++i_)" in src and "PRED_(score, psc_);" in src and "PRED_(weight, pwt_);" in src
-    assert "const int64_t tile = 64 * (int64_t)PPT;" in src and "if (pw_ >= 4) return;" in src
+    assert "const int64_t tile = 64 * (int64_t)PPT;" in src and "if ((threadIdx.x >> 6) >= 4u) return;" in src
+    # few particles over very many instances: 4 / 16 lanes per particle as well (| 1024, | 2048): 16 / 4 particles per wave
+    src4 = kernels.program_source(prog, 1 | 512 | 1024)
+    assert "#define LPP_ 4" in src4 and "const int64_t tile = 16 * (int64_t)PPT;" in src4
+    kernels.program_precompile(prog, 1 | 512 | 2048)
     plain = kernels.program_source(prog, 2)
     assert "__launch_bounds__(256)" in plain and "for (int i_ = 0; i_ < 600; ++i_)" in plain and "PRED_(" not in plain
     kernels.program_precompile(prog, 2 | 512)
