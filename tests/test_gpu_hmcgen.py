@@ -332,3 +332,92 @@ def test_hmc_over_a_long_scan_runs_on_a_rolled_generated_kernel(K_, oracle, rng,
             np.testing.assert_array_equal(gc[:, ~acc_g], ch[:, ~acc_g])
     monkeypatch.delenv("GJX_HMC_ENGINE")
     monkeypatch.delenv("GJX_HMC_GEN_CPL")
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_random_long_scans_hmc_generated_interpreter_oracle(K_, oracle, rng, monkeypatch):
+    """differential test of the rolled-Scan path of the HMC emitter: random step kernels — the transition's family, a two-dimensional
+    or scalar state, an optional selected choice in front of the Scan that the steps read, the observation's family, a number of steps
+    that no chunking divides, the lanes per chain — generated kernel == site interpreter == oracle"""
+    import torch
+    import genjax_amd as genjax
+    from genjax_amd import C
+    rs = np.random.default_rng(911 + rng)
+    trials, covered = int(os.environ.get("GJX_FUZZ_TRIALS", "8")), 0
+    for trial in range(trials):
+        T = int(rs.choice([67, 101, 150, 259]))
+        dim = int(rs.choice([1, 2]))
+        trans = str(rs.choice(["normal", "laplace", "student_t", "gumbel"]))
+        obs_kind = str(rs.choice(["normal", "poisson", "bernoulli", "sv"]))
+        with_global = bool(rs.integers(2))
+        cpl = str(rs.choice(["4", "16", "64"]))
+        Am = (0.9 * np.eye(dim) + 0.05 * rs.standard_normal((dim, dim))).astype(np.float32)
+
+        @genjax.gen
+        def model():
+            ls = (genjax.normal(-1.0, 0.3) @ "ls") if with_global else None
+
+            @genjax.gen
+            def step(x_prev, _):
+                sc = genjax.exp(ls) if with_global else 0.4
+                loc = Am @ x_prev if dim > 1 else 0.9 * x_prev
+                if dim > 1:
+                    x = genjax.mv_normal_diag(loc, np.full(dim, 0.4, np.float32)) @ "x"
+                    h = x[0]
+                elif trans == "normal":
+                    x = genjax.normal(loc, sc) @ "x"
+                    h = x
+                elif trans == "laplace":
+                    x = genjax.laplace(loc, sc) @ "x"
+                    h = x
+                elif trans == "student_t":
+                    x = genjax.student_t(5.0, loc, sc) @ "x"
+                    h = x
+                else:
+                    x = genjax.gumbel(loc, sc) @ "x"
+                    h = x
+                if obs_kind == "normal":
+                    genjax.normal(h, 0.6) @ "y"
+                elif obs_kind == "poisson":
+                    genjax.poisson(genjax.exp(0.4 * h)) @ "y"
+                elif obs_kind == "bernoulli":
+                    genjax.bernoulli(logits=h) @ "y"
+                else:
+                    genjax.normal(0.0, genjax.exp(0.5 * h)) @ "y"
+                return x, None
+
+            step.scan(n=T)(np.zeros(dim, np.float32) if dim > 1 else 0.0, None) @ "s"
+
+        ys = (rs.poisson(1.0, T) if obs_kind == "poisson" else (rs.uniform(size=T) < 0.5) if obs_kind == "bernoulli" else rs.standard_normal(T)).astype(np.float32)
+        xs = [(("s", "x"), t) for t in range(T)]
+        sel = (["ls"] if with_global else []) + xs
+        prog, _, _ = model.pack((), C["s", "y"].set(ys), False, selected=tuple(sel), per_particle=tuple(sel), rng_mode=rng)
+        n = 150
+        ch = (0.3 * rs.standard_normal((prog.n_slots, n))).astype(np.float32)
+        if with_global:
+            ch[prog.slot_of["ls"]] = -1.0 + 0.1 * rs.standard_normal(n)
+        what = f"trial {trial}: T={T} dim={dim} transition {trans} obs {obs_kind} global {with_global} lanes {cpl}"
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        monkeypatch.setenv("GJX_HMC_GEN_CPL", cpl)
+        if K_.hmc_engine(prog) != 4:
+            print(what, "-> not on a generated kernel")
+            continue
+        assert "rolled Scan" in K_.program_hmc_source(prog), what
+        covered += 1
+        eps, L = 2e-3, 5
+        g = K_.hmc(prog, (8, trial), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=4)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        it = K_.hmc(prog, (8, trial), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=4)
+        o = oracle.hmc(prog, (8, trial), ch, eps, L, False, False, offset=4)
+        o2 = oracle.hmc(prog, (8, trial), ch, eps * 1.01, L, False, False, offset=4)
+        with np.errstate(invalid="ignore"):
+            well = np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o["alpha"]) < 0.5)
+        assert well.mean() > 0.5, what
+        gc = _np(g["choices"])
+        np.testing.assert_allclose(gc[:, well], _np(it["choices"])[:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs interpreter")
+        np.testing.assert_allclose(gc[:, well], o["choices"][:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs oracle")
+        mag = 2e-5 * np.abs(o["score"])[well]
+        assert (np.abs(_np(g["alpha"])[well] - o["alpha"][well]) <= 2e-2 + mag).all(), what + " alpha"
+    monkeypatch.delenv("GJX_HMC_ENGINE", raising=False)
+    monkeypatch.delenv("GJX_HMC_GEN_CPL", raising=False)
+    assert covered >= trials // 2, covered

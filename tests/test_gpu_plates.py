@@ -593,3 +593,106 @@ def test_hmc_and_score_grad_read_input_sites_as_values(rng, monkeypatch):
         np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=5e-3, atol=5e-3)
         assert np.abs(gc[dx:] - ch[dx:]).max() > 1e-2
     monkeypatch.delenv("GJX_HMC_ENGINE")
+
+
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_random_vmapped_models_hmc_generated_interpreter_oracle(rng, monkeypatch):
+    """differential test of the plate paths of the HMC emitter: random two- and three-site vmapped kernels — the per-datum latent's
+    family, what its location and scale read (an affine form of the outside coefficients and the datum's row, a row of a latent vector
+    picked by a per-datum categorical, a shared log-scale), the observation's family, the number of data (never a multiple of the
+    lanes), whether the per-datum latents are moved too, the lanes per chain — generated kernel == site interpreter == oracle"""
+    import torch
+    from genjax_amd import kernels
+    from oracle import cpu
+    rs = np.random.default_rng(77 + rng)
+    trials, covered = int(os.environ.get("GJX_FUZZ_TRIALS", "10")), 0
+    for trial in range(trials):
+        N = int(rs.choice([13, 37, 70, 131, 300]))
+        P = int(rs.choice([2, 3, 5]))
+        lat_kind = str(rs.choice(["normal", "laplace", "cauchy", "gumbel", "student_t"]))
+        obs_kind = str(rs.choice(["bernoulli", "normal", "poisson", "laplace"]))
+        use_mix = bool(rs.integers(2))                    # location = a row of a latent 3-vector picked by a per-datum categorical
+        move_eta = bool(rs.integers(2))
+        cpl = str(rs.choice(["4", "16", "64"]))
+        X = (0.4 * rs.standard_normal((N, P))).astype(np.float32)
+        lg = np.array([0.3, -0.2, 0.1], np.float32)
+
+        @genjax.gen
+        def kern(x_row, beta, mu, ls):
+            if use_mix:
+                z = genjax.categorical(logits=lg) @ "z"
+                loc = mu[z]
+            else:
+                loc = x_row @ beta
+            sc = genjax.exp(ls)
+            if lat_kind == "normal":
+                eta = genjax.normal(loc, sc) @ "eta"
+            elif lat_kind == "laplace":
+                eta = genjax.laplace(loc, sc) @ "eta"
+            elif lat_kind == "cauchy":
+                eta = genjax.cauchy(loc, sc) @ "eta"
+            elif lat_kind == "gumbel":
+                eta = genjax.gumbel(loc, sc) @ "eta"
+            else:
+                eta = genjax.student_t(4.0, loc, sc) @ "eta"
+            if obs_kind == "bernoulli":
+                genjax.bernoulli(logits=eta) @ "y"
+            elif obs_kind == "normal":
+                genjax.normal(eta, 0.8) @ "y"
+            elif obs_kind == "poisson":
+                genjax.poisson(genjax.exp(0.3 * eta)) @ "y"
+            else:
+                genjax.laplace(eta, 0.7) @ "y"
+
+        @genjax.gen
+        def model():
+            beta = genjax.normal(np.zeros(P, np.float32), 1.0) @ "beta"
+            mu = genjax.normal(np.zeros(3, np.float32), 2.0) @ "mu"
+            ls = genjax.normal(-0.5, 0.3) @ "ls"
+            kern.vmap(in_axes=(0, None, None, None))(X, beta, mu, ls) @ "k"
+
+        y = (rs.poisson(1.0, N) if obs_kind == "poisson" else (rs.uniform(size=N) < 0.5) if obs_kind == "bernoulli" else rs.standard_normal(N)).astype(np.float32)
+        etas = [(("k", "eta"), i) for i in range(N)]
+        zs = [(("k", "z"), i) for i in range(N)] if use_mix else []
+        sel = ["beta", "mu", "ls"] + (etas if move_eta else [])
+        try:
+            prog, _, _ = model.pack((), C["k", "y"].set(y), False, selected=tuple(sel), per_particle=tuple(["beta", "mu", "ls"] + etas + zs), plates="hmc", rng_mode=rng)
+        except Exception as e:                     # (a shape the host lowers differently: not this test's subject)
+            print("trial", trial, "not packed:", type(e).__name__, e)
+            continue
+        if not any(prog.c_sites[j].plate for j in range(prog.n_sites)):
+            continue
+        n = 200
+        ch = np.zeros((prog.n_slots, n), np.float32)
+        ch[:] = 0.3 * rs.standard_normal((prog.n_slots, n))
+        ch[prog.slot_of["ls"]] = -0.5 + 0.1 * rs.standard_normal(n)
+        if use_mix:
+            z0 = prog.slot_of[(("k", "z"), 0)]
+            ch[z0:z0 + N] = rs.integers(0, 3, (N, n))
+        what = f"trial {trial}: N={N} P={P} latent {lat_kind} obs {obs_kind} mix {use_mix} move_eta {move_eta} lanes {cpl}"
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        monkeypatch.setenv("GJX_HMC_GEN_CPL", cpl)
+        if kernels.hmc_engine(prog) != 4:
+            print(what, "-> not on a generated kernel")
+            continue
+        covered += 1
+        eps, L = 2e-3, 6
+        g = kernels.hmc(prog, (5, trial), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=1)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        it = kernels.hmc(prog, (5, trial), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=1)
+        o = cpu.hmc(prog, (5, trial), ch, eps, L, False, False, offset=1)
+        o2 = cpu.hmc(prog, (5, trial), ch, eps * 1.01, L, False, False, offset=1)
+        with np.errstate(invalid="ignore"):
+            well = np.isfinite(o["choices"]).all(0) & np.isfinite(o["alpha"]) & (np.abs(o2["choices"] - o["choices"]).max(0) < 1e-3) & (np.abs(o["alpha"]) < 0.5)
+        assert well.mean() > 0.5, what
+        gc, ic = _np(g["choices"]), _np(it["choices"])
+        np.testing.assert_allclose(gc[:, well], ic[:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs interpreter")
+        np.testing.assert_allclose(gc[:, well], o["choices"][:, well], rtol=3e-3, atol=3e-3, err_msg=what + " generated vs oracle")
+        mag = 2e-5 * np.abs(o["score"])[well]
+        assert (np.abs(_np(g["alpha"])[well] - o["alpha"][well]) <= 2e-2 + mag).all(), what + " alpha"
+        if not move_eta:
+            e0 = prog.slot_of[(("k", "eta"), 0)]
+            np.testing.assert_array_equal(gc[e0:e0 + N], ch[e0:e0 + N])
+    monkeypatch.delenv("GJX_HMC_ENGINE", raising=False)
+    monkeypatch.delenv("GJX_HMC_GEN_CPL", raising=False)
+    assert covered >= trials // 2, covered
