@@ -2424,7 +2424,7 @@ uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // fl
                                 (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
                                 (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0) ^ (getenv("GJX_GEN_TAB_GLOBAL") ? 1 << 24 : 0) ^
                                 (getenv("GJX_GEN_NO_HOIST") ? 1 << 25 : 0) ^ (getenv("GJX_GEN_NO_FUSE") ? 1 << 26 : 0) ^ (getenv("GJX_GEN_NO_EARLY_STORE") ? 1 << 27 : 0) ^
-                                (getenv("GJX_GEN_NO_SEQ_ROWS") ? 1 << 28 : 0)};
+                                (getenv("GJX_GEN_NO_SEQ_ROWS") ? 1 << 28 : 0) ^ (getenv("GJX_JIT_FP_CONTRACT") ? 1 << 29 : 0)};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
@@ -2451,7 +2451,14 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
   char name[64];
-  snprintf(name, sizeof(name), "%016llx", (unsigned long long)(fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader)) ^
+  // generated kernels are compiled WITHOUT implicit fused multiply-adds (the explicit fmaf of the emitters and of gjx_device.h stay):
+  // the same site then rounds the same way in every kernel it is compiled into — the filter kernel with one particle per lane and
+  // gjx_gen with four gave a student-t draw that differed in the last bit — at no measurable cost (mixture kernel 31.6 -> 31.9 us,
+  // filter steps unchanged); GJX_JIT_FP_CONTRACT=fast restores the compiler's default for experiments
+  // — for the propagate and filter kernels; the HMC kernels (one kernel per program: nothing to agree with) keep the default, which is
+  // worth 13 - 25 % on gradient sweeps written without explicit fmaf
+  const bool no_contract = flavour != 1 && !(getenv("GJX_JIT_FP_CONTRACT") && !strcmp(getenv("GJX_JIT_FP_CONTRACT"), "fast"));
+  snprintf(name, sizeof(name), "%016llx", (unsigned long long)((no_contract ? 0x5bd1e995ull : 0ull) ^ fnv1a(src.data(), src.size()) ^ fnv1a(kDeviceHeader, strlen(kDeviceHeader)) ^ fnv1a(kApiHeader, strlen(kApiHeader)) ^
                                                                fnv1a(kScanHeader, strlen(kScanHeader)) ^ (fnv1a(kTileHeader, strlen(kTileHeader)) << 1) ^
                                                                (flavour == 2 ? fnv1a(kPfCoreHeader, strlen(kPfCoreHeader)) << 2 : 0ull)));
   const std::string dir = cache_dir(), path = dir + "/" + name + ".hsaco";
@@ -2478,8 +2485,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   if (r.Create(&p, src.c_str(), flavour == 1 ? "gjx_hmc_gen.hip" : (flavour == 2 ? "gjx_gen_pf.hip" : "gjx_gen.hip"), 5, hs, hn) != HIPRTC_SUCCESS) { c.error = "hiprtcCreateProgram failed"; return c; }
   // (offline clang takes -mllvm -amdgpu-mfma-vgpr-form=1, which would keep matrix-core results out of the AGPRs; this hipRTC's LLVM
   // does not know the option, so the generated kernels pay 16 v_accvgpr_read per tile: about 3 %)
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-  const hiprtcResult rc = r.Compile(p, 3, opts);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const hiprtcResult rc = r.Compile(p, no_contract ? 4 : 3, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
     r.LogSize(p, &ls);
