@@ -734,7 +734,10 @@ def run_codegen(dev):
             eng = kernels.program_engine(prog)
             ws = kernels.workspace(A.OP_RUN, K, dev)
             out = kernels.run_program(prog, (0, 1), K, ws=ws, want_weight=False)
-            for i in range(40 if eng != 0 else 0):          # (a 0.5 ms kernel timed cold runs 12 % slower than inside a train: clocks)
+            # (a kernel timed cold runs up to 12 % slower than inside a train: clocks.  A generated kernel is compiled right before its
+            # first launch — seconds of an idle GPU — so the train is long enough to bring the clocks back for every engine alike:
+            # 400 launches, about 12 ms; with 40 the hand-fused kernel, measured first, came out 6 % faster than in a warm A/B)
+            for i in range(400 if eng != 0 else 0):
                 kernels.run_program(prog, (0, 2 + i), K, ws=ws, out=out, want_weight=False)
             tm = [kernels.DispatchTimer() for _ in range(5)]
             for i, t in enumerate(tm):
