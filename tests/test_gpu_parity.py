@@ -1070,7 +1070,7 @@ def test_masked_constraints_parity(K_, oracle, rng):
 
 
 def _random_program(rs, rng_mode):
-    """A random valid site program: every kind, parameters drawn from the four expression forms over earlier sites
+    """A random valid site program: every kind, parameters drawn from the five expression forms over earlier sites
     (positive / probability parameters go through exp / softplus / sigmoid), random constraint modes."""
     POS, PROB, REAL = "pos", "prob", "real"
     spec = {  # kind -> parameter domains
@@ -1092,7 +1092,7 @@ def _random_program(rs, rng_mode):
                    [(rs.random(n) + 0.1).astype(np.float32)])
             cats.append((addr, n))
             continue
-        kind = int(rs.choice(kinds))
+        kind = A.MVNORMAL_DIAG if rs.random() < 0.12 else int(rs.choice(kinds))      # (vector-valued choices: what a row gather indexes)
         dim = int(rs.integers(2, 5)) if kind == A.MVNORMAL_DIAG else 1
 
         def param(dom):
@@ -1102,6 +1102,11 @@ def _random_program(rs, rng_mode):
             if form < 0.35 or not cont:
                 v = {POS: np.abs(base) + 0.3, PROB: 1 / (1 + np.exp(-base)), REAL: base}[dom]
                 return Param.const(v.astype(np.float32))
+            vecs = [(a_, d_) for a_, d_ in cont if d_ >= 2]
+            if form < 0.5 and cats and vecs:       # a row of an earlier vector-valued choice picked by an earlier categorical (GJX_P_VGATHER)
+                a, _ = cats[int(rs.integers(len(cats)))]
+                v_, d_ = vecs[int(rs.integers(len(vecs)))]
+                return Param.vgather(v_, d_, a, vlen=1, xf=xf)
             if form < 0.6 and cats:
                 a, n = cats[int(rs.integers(len(cats)))]
                 tab = rs.standard_normal((n, dim)).astype(np.float32) * 0.5
