@@ -886,10 +886,16 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
     case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
       const float rc = fast_rcp(c);
       const float y = (x - b) * rc;
-      const float w = (a + 1.0f) * y * fast_rcp(a + y * y);
-      dx = -w * rc; db = w * rc; dc = (w * y - 1.0f) * rc;
-      da = -0.5f * log1p_acc(y * y * fast_rcp(a)) + 0.5f * (a + 1.0f) * y * y * fast_rcp(a * (a + y * y)) - 0.5f * fast_rcp(a) +
-           0.5f * digamma_half_step(0.5f * a);
+      // a draw with df << 1 reaches 1e30 and y^2 leaves float32 (inf / inf below): there y^2 / (df + y^2) is 1 to every bit and
+      // log1p(y^2 / df) is log(y^2 / df), as in the log-density above (found by the differential test: a NaN where the oracle has 1.2)
+      const bool big = fabsf(y) > 1e18f;
+      const float yy = y * y;
+      const float w = big ? (a + 1.0f) * fast_rcp(y) : (a + 1.0f) * y * fast_rcp(a + yy);
+      const float wy = big ? a + 1.0f : w * y;
+      dx = -w * rc; db = w * rc; dc = (wy - 1.0f) * rc;
+      const float l1p = big ? 2.0f * fast_log(fabsf(y)) - fast_log(a) : log1p_acc(yy * fast_rcp(a));
+      const float t2 = big ? 0.5f * (a + 1.0f) * fast_rcp(a) : 0.5f * (a + 1.0f) * yy * fast_rcp(a * (a + yy));
+      da = -0.5f * l1p + t2 - 0.5f * fast_rcp(a) + 0.5f * digamma_half_step(0.5f * a);
       done(); return;
     }
     case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high

@@ -85,8 +85,9 @@ def _run_ranks_once(target, world, args, out_dir, timeout=900):
         p.start()
     for p in procs:
         p.join(timeout=timeout)
-    errs = [open(os.path.join(out_dir, f)).read() for f in sorted(os.listdir(out_dir)) if f.endswith(".err")]
-    assert not errs, errs[0]
+    errs = [f + ": " + open(os.path.join(out_dir, f)).read() for f in sorted(os.listdir(out_dir)) if f.endswith(".err")]
+    # (every rank's report: the first rank to fail takes the others' barriers down with it, and it need not be rank 0)
+    assert not errs, "\n".join(e[-1200:] for e in errs)
     for p in procs:
         assert p.exitcode == 0, [q.exitcode for q in procs]
     return [np.load(os.path.join(out_dir, "rank%d.npz" % r)) for r in range(world)]
