@@ -66,13 +66,22 @@ def _run_ranks(target, world, args, out_dir, timeout=900, tries=3):
     to be resident together, and the device's scheduler may hold one of them back longer than a lane's poll budget) is what the
     product's host layer repeats (results of such a run are undefined by contract): so does the test, up to `tries` times"""
     for attempt in range(tries):
-        res = _run_ranks_once(target, world, args, out_dir, timeout)
-        timed_out = any(int(r[k]) & 1 for r in res for k in r.files if k.startswith("status"))
-        if not timed_out or attempt == tries - 1:
-            return res
-        print("a rendezvous timed out (attempt %d): the run is repeated" % (attempt + 1))
+        try:
+            res = _run_ranks_once(target, world, args, out_dir, timeout)
+        except AssertionError as e:
+            # a rank that dies takes the others' host barriers down with it ("Connection closed by peer"); seen once in a dozen runs
+            # of the whole suite, never twice in a row: one more try, then the error stands
+            if attempt == tries - 1 or "Connection closed by peer" not in str(e):
+                raise
+            print("a rank lost its process group (attempt %d): the run is repeated\n%s" % (attempt + 1, str(e)[-600:]))
+            res = None
+        if res is not None:
+            timed_out = any(int(r[k]) & 1 for r in res for k in r.files if k.startswith("status"))
+            if not timed_out or attempt == tries - 1:
+                return res
+            print("a rendezvous timed out (attempt %d): the run is repeated" % (attempt + 1))
         for f in os.listdir(out_dir):
-            if f.endswith(".npz"):
+            if f.endswith(".npz") or f.endswith(".err"):
                 os.remove(os.path.join(out_dir, f))
 
 
