@@ -93,10 +93,6 @@ def test_resample_move_filter_keeps_the_estimate_and_restores_diversity():
         assert abs(float(out["log_ml"]) - exact) < 3e-3 * abs(exact)
         np.testing.assert_allclose(_np(out["means"]), means, atol=0.05)
     assert 0.1 < moved.last_accept_rate < 0.9
-    # rejuvenation moves the duplicates apart: distinct values among the particles that are propagated
-    def distinct(h, t):
-        x = h.states[t][:, h.ancestors[t].long()] if False else h.states[t]
-        return int(torch.unique(x[0]).numel())
     # the parents actually used at the last step: plain filter duplicates them, the moved filter does not
     pa = a["history"].states[-2][0][a["history"].ancestors[-1].long()]
     assert int(torch.unique(pa).numel()) < K * 0.9
