@@ -485,3 +485,80 @@ def test_wide_plate_kernel_deals_the_instances_to_the_waves_of_a_block():
     assert "__launch_bounds__(256)" in plain and "for (int i_ = 0; i_ < 600; ++i_)" in plain and "PRED_(" not in plain
     kernels.program_precompile(prog, 2 | 512)
     kernels.program_precompile(prog, 1 | 512)
+
+
+def test_hmc_emitter_forms_compile_without_a_gpu():
+    """the forms of the generated HMC kernel that round 5 added — selected sites inside a plate (trajectory rows in the workspace), a
+    long periodic Scan (rolled: steps dealt to the lanes of a chain), INPUT sites read as values — are emitted and cross-compiled here
+    (hipRTC for gfx950); the oracle's score and gradient of the same programs against central differences in float64"""
+    from genjax_amd import kernels
+    from genjax_amd.program import PackedProgram, Param, SiteList
+    from oracle import cpu
+    rs = np.random.default_rng(3)
+    # (1) a regression with a latent per datum, the latents moved too
+    N, P = 40, 3
+    X = (0.5 * rs.standard_normal((N, P))).astype(np.float32)
+
+    @genjax.gen
+    def kern(x_row, beta, ls):
+        eta = genjax.normal(x_row @ beta, genjax.exp(ls)) @ "eta"
+        return genjax.bernoulli(logits=eta) @ "y"
+
+    @genjax.gen
+    def model():
+        ls = genjax.normal(0.0, 1.0) @ "ls"
+        beta = genjax.normal(np.zeros(P, np.float32), 1.0) @ "beta"
+        kern.vmap(in_axes=(0, None, None))(X, beta, ls) @ "k"
+
+    y = (rs.uniform(size=N) < 0.5).astype(np.float32)
+    lat = ["ls", "beta"] + [(("k", "eta"), i) for i in range(N)]
+    prog, _, _ = model.pack((), C["k", "y"].set(y), False, selected=tuple(lat), per_particle=tuple(lat), plates="hmc")
+    src = kernels.program_hmc_source(prog)
+    assert "// PROWS %d" % N in src and "wq_[(int64_t)(0 + i_ * 1 + 0) * n_ + ic_]" in src and "// CPLMAX 4" in src
+    kernels.program_hmc_precompile(prog)
+    # (2) every state of a 150-step stochastic-volatility Scan
+    T = 150
+    ys = rs.standard_normal(T).astype(np.float32)
+
+    @genjax.gen
+    def sv():
+        @genjax.gen
+        def step(x_prev, _):
+            x = genjax.normal(0.95 * x_prev, 0.3) @ "x"
+            genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+            return x, None
+        step.scan(n=T)(0.0, None) @ "s"
+
+    xs = [(("s", "x"), t) for t in range(T)]
+    ps, _, _ = sv.pack((), C["s", "y"].set(ys), False, selected=tuple(xs), per_particle=tuple(xs))
+    assert ps.n_sites == 2 * T and kernels.hmc_engine(ps) == 4
+    src = kernels.program_hmc_source(ps)
+    assert "rolled Scan: %d steps x 2 sites, 1 selected values per step" % T in src and "// PROWS %d" % T in src and "// CPLMAX 16" in src
+    kernels.program_hmc_precompile(ps)
+    ch = (0.3 * rs.standard_normal((ps.n_slots, 5))).astype(np.float32)
+    sc, g = cpu.score_grad(ps, ch)
+
+    def score(x):                      # x [T][n] float64
+        prev = np.vstack([np.zeros((1, x.shape[1])), x[:-1]])
+        lt = -0.5 * ((x - 0.95 * prev) / 0.3) ** 2 - np.log(0.3) - 0.5 * np.log(2 * np.pi)
+        lo = -0.5 * (ys[:, None] / np.exp(0.5 * x)) ** 2 - 0.5 * x - 0.5 * np.log(2 * np.pi)
+        return (lt + lo).sum(axis=0)
+
+    x64 = ch.astype(np.float64)
+    np.testing.assert_allclose(sc, score(x64), rtol=2e-5, atol=2e-3)
+    for t in (0, 1, 77, T - 1):
+        e = np.zeros_like(x64)
+        e[t] = 1e-5
+        np.testing.assert_allclose(g[t], (score(x64 + e) - score(x64 - e)) / 2e-5, rtol=2e-3, atol=2e-3)
+    # (3) an INPUT site: a value the other sites read, no density, never selected
+    sl = SiteList()
+    sl.add("xp", A.MVNORMAL_DIAG, [np.zeros(2, np.float32), np.ones(2, np.float32)])
+    sl.add("x", A.MVNORMAL_DIAG, [Param.affine(np.array([[0.5, 0.1], [0.0, 0.7]], np.float32), "xp"), np.full(2, 0.7, np.float32)])
+    pi_ = PackedProgram(sl, {"xp": A.MODE_INPUT, "x": A.MODE_OBS_SLOT}, selected=("x",))
+    assert "INPUT, 2 rows from slot 0" in kernels.program_hmc_source(pi_)
+    kernels.program_hmc_precompile(pi_)
+    ci = rs.standard_normal((4, 6)).astype(np.float32)
+    si, gi = cpu.score_grad(pi_, ci)
+    want = (-0.5 * ((ci[2:] - np.array([[0.5, 0.1], [0.0, 0.7]]) @ ci[:2]) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    np.testing.assert_allclose(si, want, rtol=2e-5, atol=2e-4)
+    assert not gi[:2].any()
