@@ -1335,7 +1335,6 @@ bool pf_supported(const gjx_program* p) {
     if (p->sites[j].scan != 0) return false;
     has_input = has_input || md == GJX_MODE_INPUT;
   }
-  if (has_vgather(p->sites, p->n_sites)) return false;     // (the other forms of the filter run such a step)
   return has_input && supported_uncached(p);
 }
 
