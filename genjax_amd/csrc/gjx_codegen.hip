@@ -244,7 +244,6 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
   Roll r;
   if ((p->rng_mode != GJX_RNG_FLAT && !any_stream) || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
-  if (has_vgather(p->sites, n)) return r;     // (rows of a choice picked by a discrete choice: not in rolled Scans)
   for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
   int i0 = 0;
   while (i0 < n && p->sites[i0].scan == 0) ++i0;
@@ -316,6 +315,8 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
         if (qa.op != qb.op || qa.xf != qb.xf || qa.len != qb.len || qa.n != qb.n) return r;
         if (qa.op != GJX_P_VALUE && qb.off != qa.off + (t - 1) * st[l].d_off[k]) return r;
         if (qa.op == GJX_P_AFFINE && qb.moff != qa.moff + (t - 1) * st[l].d_moff[k]) return r;
+        // a row gather of a latent vector: the vector lives in front of the Scan (registers that do not move with the step)
+        if (qa.op == GJX_P_VGATHER && (qb.moff != qa.moff || qa.moff < 0 || qa.moff + qa.n * qa.len > n_pre)) return r;
         if (slot_op(qa.op)) {
           const bool pre = qa.slot + ref_span(qa) <= n_pre;
           if (pre ? qb.slot != qa.slot : qb.slot != qa.slot + (t - 1) * S) return r;
@@ -332,6 +333,7 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
   for (int l = 0; l < m; ++l)
     for (int k = 0; k < n_params(at(0, l).kind); ++k) {
       const gjx_param& q = at(0, l).p[k];
+      if (q.op == GJX_P_VGATHER && (q.moff < 0 || q.moff + q.n * q.len > n_pre)) return r;
       if (!slot_op(q.op)) continue;
       const bool pre = q.slot + ref_span(q) <= n_pre;
       const bool own = q.slot >= base(0) && q.slot + ref_span(q) <= base(0) + S;
@@ -345,6 +347,7 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
     if (sj.slot >= 0 && (sj.slot < post0 || sj.slot + width(sj) > F0)) return r;
     for (int k = 0; k < n_params(sj.kind); ++k) {
       const gjx_param& q = sj.p[k];
+      if (q.op == GJX_P_VGATHER && (q.moff < 0 || q.moff + q.n * q.len > n_pre)) return r;
       if (!slot_op(q.op)) continue;
       const bool pre = q.slot + ref_span(q) <= n_pre;
       const bool last = q.slot >= base(T - 1) && q.slot + ref_span(q) <= base(T - 1) + S;
@@ -1749,8 +1752,7 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
       pl.leaf_of_site[r.i0 + l] = pl.leaf_of_site[r.i0 + r.m + l] = pl.sl_step++;       // (leaf within the step)
       for (int d = 0; d < s.dim; ++d) pl.step_ls.push_back(s.slot + d - (r.n_pre + r.S));
     }
-    pl.ssel = (int)pl.step_ls.size();
-    if (pl.ssel < 1) return false;                           // (nothing of the Scan is moved: the straight-line forms cover what fits)
+    pl.ssel = (int)pl.step_ls.size();                        // (0: nothing of the Scan is moved — the loop then only feeds the gradient rows in front of it)
     for (int k = 0; k < pl.ssel; ++k) { pl.sel_of_slot[r.n_pre + pl.step_ls[k]] = pl.nsel++; pl.slot_of_sel.push_back(r.n_pre + pl.step_ls[k]); }
     for (int k = 0; k < pl.ssel; ++k) { pl.sel_of_slot[r.n_pre + r.S + pl.step_ls[k]] = pl.nsel++; pl.slot_of_sel.push_back(r.n_pre + r.S + pl.step_ls[k]); }
     pl.prows = r.T * pl.ssel;
@@ -2080,7 +2082,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
         "    float ga[NSEL];\n    _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) ga[m_] = 0.0f;\n    float scp_ = 0.0f, gcar_[%d];\n"
         "    _Pragma(\"unroll\") for (int k_ = 0; k_ < %d; ++k_) gcar_[k_] = 0.0f;\n"
         "    const int L_ = (%d + CPL - 1) / CPL, a_ = q_ * L_, b_ = a_ + L_ < %d ? a_ + L_ : %d;\n"
-        "    if (a_ < %d) {\n", r.T, r.m, SS, SS, SS, r.T, r.T, r.T, r.T);
+        "    if (a_ < %d) {\n", r.T, r.m, SS, SS > 0 ? SS : 1, SS, r.T, r.T, r.T, r.T);
     // loads of one step's values into the CURRENT step's registers: selected -> the trajectory's position (workspace), else the chain's column
     auto load_step = [&](const char* t, const char* ind) {
       for (int l = 0; l < r.m; ++l) {

@@ -318,3 +318,66 @@ def test_rolled_scan_with_per_particle_masks(K_, oracle, T, post, pre_masked):
     fl = ch[prog.flag_slot_of[a]] != 0
     np.testing.assert_array_equal(_np(g["choices"])[prog.slot_of[a]][fl], ch[prog.slot_of[a]][fl])
     assert (_np(g["choices"])[prog.slot_of[a]][~fl] != ch[prog.slot_of[a]][~fl]).mean() > 0.99
+
+
+@pytest.mark.parametrize("T", [120, 259])
+def test_hidden_markov_model_with_latent_emission_means_rolled(T, monkeypatch):
+    """mu ~ N(0, 4 I_3) in front of a T-step Scan; c_t ~ categorical(P[c_{t-1}]), y_t ~ N(mu[c_t], 0.5) observed: the emission reads a row
+    of a choice in FRONT of the Scan picked by the step's discrete choice (GJX_P_VGATHER in a rolled loop).  ImportanceK on the generated
+    (rolled) kernel and on the interpreter against the oracle; HMC over mu with the states fixed per chain on the rolled generated
+    kernel (nothing of the Scan is selected: the loop only feeds mu's gradient) against interpreter and oracle"""
+    import torch
+    import genjax_amd as genjax
+    from genjax_amd import C, kernels
+    from oracle import cpu
+    rs = np.random.default_rng(1)
+    ys = rs.standard_normal(T).astype(np.float32)
+    P = np.array([[1.0, -1.0, 0.0], [0.0, 1.0, -1.0], [-1.0, 0.0, 1.0]], np.float32)
+
+    @genjax.gen
+    def model():
+        mu = genjax.normal(np.zeros(3, np.float32), 2.0) @ "mu"
+
+        @genjax.gen
+        def step(c_prev, _):
+            c = genjax.categorical(logits=genjax.take(P, c_prev) if not isinstance(c_prev, (int, np.integer)) else P[int(c_prev)]) @ "c"
+            genjax.normal(mu[c], 0.5) @ "y"
+            return c, None
+
+        step.scan(n=T)(0, None) @ "s"
+
+    K = 2000
+    prog, _, _ = model.pack((), C["s", "y"].set(ys), True)
+    assert prog.n_sites == 1 + 2 * T
+    src = kernels.program_source(prog, 1)
+    assert "for (int t_ = 1" in src and "vg_" in src
+    ora = cpu.run_program(prog, (3, 4), K, want_margin=True)
+    for engine in ("gen", "interp"):
+        monkeypatch.setenv("GJX_ENGINE", engine)
+        out = kernels.run_program(prog, (3, 4), K)
+        assert out["_engine"] == (4 if engine == "gen" else 0)
+        ch, oc = out["choices"].cpu().numpy(), ora["choices"]
+        same = (ch == oc).all(axis=0) | (np.abs(ch - oc) <= 5e-5 + 2e-4 * np.abs(oc)).all(axis=0)
+        assert (ora["margin"][~same] < 3e-4).all() and same.mean() > 0.9          # a particle differs only behind a near-tie of a categorical draw
+        np.testing.assert_allclose(out["weight"].cpu().numpy()[same], ora["weight"][same], rtol=3e-4, atol=3e-2)
+    monkeypatch.delenv("GJX_ENGINE")
+    cs = [(("s", "c"), t) for t in range(T)]
+    hp, _, _ = model.pack((), C["s", "y"].set(ys), False, selected=("mu",), per_particle=tuple(["mu"] + cs))
+    n = 200
+    ch = np.zeros((hp.n_slots, n), np.float32)
+    ch[:3] = 0.5 * rs.standard_normal((3, n))
+    ch[3:] = rs.integers(0, 3, (T, n))
+    hs = kernels.program_hmc_source(hp)
+    assert "rolled Scan: %d steps x 2 sites, 0 selected values per step" % T in hs
+    o = cpu.hmc(hp, (5, 6), ch, 0.01, 8, False, False, offset=2)
+    for engine, code, cpl in (("gen", 4, "4"), ("gen", 4, "64"), ("interp", 0, "4")):
+        monkeypatch.setenv("GJX_HMC_ENGINE", engine)
+        monkeypatch.setenv("GJX_HMC_GEN_CPL", cpl)
+        assert kernels.hmc_engine(hp) == code
+        g = kernels.hmc(hp, (5, 6), torch.as_tensor(ch).cuda(), 0.01, 8, False, False, offset=2)
+        gc = g["choices"].cpu().numpy()
+        np.testing.assert_allclose(gc[:3], o["choices"][:3], rtol=3e-3, atol=3e-3)
+        np.testing.assert_array_equal(gc[3:], ch[3:])
+        np.testing.assert_allclose(g["alpha"].cpu().numpy(), o["alpha"], rtol=1e-2, atol=5e-2)
+    monkeypatch.delenv("GJX_HMC_ENGINE")
+    monkeypatch.delenv("GJX_HMC_GEN_CPL")
