@@ -562,3 +562,30 @@ def test_hmc_emitter_forms_compile_without_a_gpu():
     want = (-0.5 * ((ci[2:] - np.array([[0.5, 0.1], [0.0, 0.7]]) @ ci[:2]) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
     np.testing.assert_allclose(si, want, rtol=2e-5, atol=2e-4)
     assert not gi[:2].any()
+
+
+def test_step_programs_fold_row_gathers_of_known_values():
+    """the one-step programs of a filter over a kernel with `vec[idx]`: the row gather of the step's own latent is a GJX_P_VGATHER in every
+    step program (vector and index slots of THAT step); the filter kernel is emitted for it (select chain over the step's registers)
+    and compiles"""
+    from genjax_amd import kernels
+    from genjax_amd.inference.scan_filter import ScanBootstrapFilter
+    Am = np.array([[0.9, 0.1], [-0.1, 0.8]], np.float32)
+
+    @genjax.gen
+    def step(x_prev, _):
+        x = genjax.mv_normal_diag(Am @ x_prev, np.full(2, 0.5, np.float32)) @ "x"
+        c = genjax.flip(0.4) @ "c"
+        genjax.normal(x[c], 0.6) @ "y"
+        return x, None
+
+    bf = ScanBootstrapFilter(step.scan(n=3), 2048)
+    ps = bf.step_programs(C["y"].set(np.array([0.1, -0.7, 1.9], np.float32)), (np.zeros(2, np.float32), None))
+    for t, p in enumerate(ps):
+        ysite = [j for j in range(p.n_sites) if p.c_sites[j].mode == A.MODE_OBS_TAB]
+        assert len(ysite) == 1
+        q = p.c_sites[ysite[0]].p[0]
+        assert q.op == A.P_VGATHER and q.n == 2 and q.len == 1 and q.moff == p.slot_of[("x", t)] and q.slot == p.slot_of[("c", t)]
+    src = kernels.program_filter_source(ps[1], 1)
+    assert "gjx_gen_pf" in src and "vg_" in src
+    kernels.program_filter_precompile(ps[1], 1)
