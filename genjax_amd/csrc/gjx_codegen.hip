@@ -902,7 +902,13 @@ void emit_site(Emit& o, Plan& pl, int j) {
         if (rcpb.empty()) rcpb = "fast_rcp(pb)";
         o.f("%sfloat val;\n", in2.c_str());
         if (mode == GJX_MODE_SAMPLE && hoist >= 0) {
-          o.f("%sconst float n_ = dr_->nz[%d + (%s)];\n", in2.c_str(), hoist, dx.c_str());
+          // the site's standard normal from the words taken ahead (Plan::hoist_at: the base of the site's / the run's words)
+          const int e_ = (pl.stream[j].run >= 0 ? (int)pl.stream[j].elem : 0) + literal_index(dx);
+          if (prog->rng_mode != GJX_RNG_JAX32)
+            o.f("%sfloat hn0_, hn1_;\n%sbox_muller(__float_as_uint(dr_->nz[%d]), __float_as_uint(dr_->nz[%d]), hn0_, hn1_);\n%sconst float n_ = %s;\n", in2.c_str(), in2.c_str(),
+                hoist + (e_ & ~1), hoist + (e_ | 1), in2.c_str(), (e_ & 1) ? "hn1_" : "hn0_");
+          else
+            o.f("%sconst float n_ = normal_from_bits(__float_as_uint(dr_->nz[%d]));\n", in2.c_str(), hoist + e_);
           o.f("%sval = fmaf(pb, n_, pa);\n", in2.c_str());
           if (need_lp) o.f("%sq2[p] = fmaf(n_, n_, q2[p]);\n", in2.c_str());
         } else if (mode == GJX_MODE_SAMPLE) {
@@ -1384,15 +1390,23 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       const gjx_site& s = prog->sites[j];
       const RollInfo& ri = pl.info[j];
       if (ri.plate || s.mode != GJX_MODE_SAMPLE || !is_normal(s.kind) || s.dim > kMaxExpandDim || pl.hoist_at[j] >= 0) continue;
+      // what is taken ahead are the stream's 32-bit WORDS (the hashes: arithmetic that hides nothing); the normals are finished
+      // inside the slot, behind the loads of the carry, as the hand-written model does (its timeline: 1.1 us for this phase
+      // against 2.3 with Box-Muller in it).  FLAT pairs elements (2 k, 2 k + 1): the words of whole pairs are kept
+      const bool flat_ = prog->rng_mode != GJX_RNG_JAX32;
       if (pl.stream[j].run >= 0) {
         if (!pl.stream[j].opens) continue;                       // (a member is decided with its head)
         int members = 0;
         for (int l = j; l < ns; ++l) members += pl.stream[l].run == pl.stream[j].run;
-        if (pl.n_hoist + members > kPfMaxHoist) continue;
-        for (int l = j; l < ns; ++l) if (pl.stream[l].run == pl.stream[j].run) pl.hoist_at[l] = pl.n_hoist++;
-      } else if (pl.n_hoist + s.dim <= kPfMaxHoist) {
+        const int words = flat_ ? 2 * ((members + 1) / 2) : members;
+        if (pl.n_hoist + words > kPfMaxHoist) continue;
+        for (int l = j; l < ns; ++l) if (pl.stream[l].run == pl.stream[j].run) pl.hoist_at[l] = pl.n_hoist;      // (the run's base; a member's element picks its word)
+        pl.n_hoist += words;
+      } else {
+        const int words = flat_ ? 2 * ((s.dim + 1) / 2) : s.dim;
+        if (pl.n_hoist + words > kPfMaxHoist) continue;
         pl.hoist_at[j] = pl.n_hoist;
-        pl.n_hoist += s.dim;
+        pl.n_hoist += words;
       }
     }
   }
@@ -1441,14 +1455,16 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       "  const float* pp_;       // MOVES: the INPUT rows the previous step stored — what the ancestor itself was propagated from\n"
       "  float* const tabp_s;    // MOVES: the previous step's table (+ the derived constants of the assess form)\n"
       "  unsigned acc_lane;      // MOVES: accepted moves of this lane's slots\n"
-      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t, float* tp) : f(a), tab_s(t), cur_(nullptr), in_(nullptr), pp_(nullptr), tabp_s(tp), acc_lane(0u) {}\n"
+      "  const float* tbn_;      // the NEXT step's table: its address is read a step ahead (stage() then waits for ONE dependent load, not two)\n"
+      "  GJX_DEV GenPfModel(const GenPfArgs& a, float* t, float* tp) : f(a), tab_s(t), cur_(nullptr), in_(nullptr), pp_(nullptr), tabp_s(tp), acc_lane(0u), tbn_(nullptr) {}\n"
       "  GJX_DEV float* rows(int t) const { return f.rows_all ? f.rows_all + (int64_t)t * f.rows_step : ((t & 1) ? f.rows_b : f.rows_a); }\n"
       "  GJX_DEV const float* in_rows(int t) const { return rows(t - 1) + (t == 1 ? f.in_row0_first : f.in_row0); }   // the OWN rows of step t - 1\n"
-      "  GJX_DEV void prologue(int) {}\n"
+      "  GJX_DEV void prologue(int) { tbn_ = f.tabs[1]; }\n"
       "  GJX_DEV void epilogue(int lane) {\n    if (MOVES && f.acc_total) {\n      const unsigned wacc = wave_scan_u32(acc_lane);\n"
       "      if (lane == 63 && wacc) atomicAdd(f.acc_total, (unsigned long long)wacc);\n    }\n  }\n");
   // ---- stage: the step's table and what derives from it, while the granules travel ----
-  o.f("  GJX_DEV void stage(int t, int tid) {\n    cur_ = rows(t);\n    in_ = in_rows(t);\n    const float* __restrict__ tb_ = f.tabs[t];\n"
+  o.f("  GJX_DEV void stage(int t, int tid) {\n    cur_ = rows(t);\n    in_ = in_rows(t);\n    const float* __restrict__ tb_ = tbn_;\n"
+      "    if (t + 1 < f.core.T) tbn_ = f.tabs[t + 1];\n"
       "    for (int e = tid; e < NTAB; e += %d) tab_s[e] = tb_[e];\n#define TSRC(i) tb_[i]\n#define BT_ %d\n", 1024, 1024);
   {
     Emit c;
@@ -1474,13 +1490,16 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
     const gjx_site& s = prog->sites[j];
     if (ss.run >= 0) {
       if (!ss.opens) continue;
-      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // scalar-normal run %d\n", ss.site_no, ss.run);
-      for (int l = j; l < ns; ++l)
-        if (pl.stream[l].run == ss.run) o.f("      d.nz[%d] = stream_normal<RNG>(bs, 0u + (uint32_t)(%u + (0)));\n", pl.hoist_at[l], pl.stream[l].elem);
+      int members = 0;
+      for (int l = j; l < ns; ++l) members += pl.stream[l].run == ss.run;
+      const int words = prog->rng_mode != GJX_RNG_JAX32 ? 2 * ((members + 1) / 2) : members;
+      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // scalar-normal run %d: the words of its %d elements\n", ss.site_no, ss.run, members);
+      for (int e = 0; e < words; ++e) o.f("      d.nz[%d] = __uint_as_float(bs.get(%du));\n", pl.hoist_at[j] + e, e);
       o.f("    }\n");
     } else {
-      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // site %d\n", ss.site_no, j);
-      for (int d = 0; d < s.dim; ++d) o.f("      d.nz[%d] = stream_normal<RNG>(bs, 0u + (uint32_t)(0 + (%d)));\n", pl.hoist_at[j] + d, d);
+      const int words = prog->rng_mode != GJX_RNG_JAX32 ? 2 * ((s.dim + 1) / 2) : s.dim;
+      o.f("    { BitStream<RNG> bs; bs.open(key, gidx_, %du);   // site %d: the words of its %d elements\n", ss.site_no, j, s.dim);
+      for (int e = 0; e < words; ++e) o.f("      d.nz[%d] = __uint_as_float(bs.get(%du));\n", pl.hoist_at[j] + e, e);
       o.f("    }\n");
     }
   }

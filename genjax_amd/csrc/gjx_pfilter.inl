@@ -169,7 +169,7 @@ GJX_DEV PfCoreArgs pf_core_args(const PfArgs& f) {
   c.lw_even = f.lw_even; c.lw_odd = f.lw_odd; c.aggA = f.aggA; c.aggB = f.aggB; c.bsum = f.bsum; c.bmax = f.bmax; c.ready = f.ready;
   c.peer_data = f.peer_data; c.peer_flag = f.peer_flag; c.keys = f.keys; c.us = f.us; c.lse_steps = f.lse_steps;
   c.ancestors = f.ancestors; c.ancestors_all = nullptr; c.ctrl = f.ctrl; c.log_k = f.log_k; c.first_budget = f.first_budget;
-  c.zero_ptr = f.zero_ptr; c.zero_n = f.zero_n; c.verify = f.verify; c.chk_a = f.chk_a; c.chk_b = f.chk_b; c.timeline = nullptr;
+  c.zero_ptr = f.zero_ptr; c.zero_n = f.zero_n; c.verify = f.verify; c.chk_a = f.chk_a; c.chk_b = f.chk_b; c.timeline = f.timeline;
   return c;
 }
 

@@ -53,6 +53,7 @@ struct PfArgs {
   // granule.  A mismatch raises GJX_STATUS_VERIFY_MISMATCH.  chk_a / chk_b ping-pong like x_a / x_b (DATA window).
   int verify;
   unsigned* chk_a; unsigned* chk_b;                      // [K]
+  unsigned long long* timeline;                          // debug (gjx_debug_timeline): the skeleton's 16 stamps per block for step T / 2, or NULL
 };
 
 constexpr int kPfHostThreads = kPfThreads;

@@ -1250,6 +1250,7 @@ static int pf_filter_launch(const gjx_ssm* m, uint32_t key0, uint32_t key1, int3
   f.lse_steps = lse_steps; f.ancestors = ancestors; f.ctrl = (unsigned*)ws2 + 8; f.log_k = (float)log((double)K);
   f.first_budget = 1u << 16; f.zero_ptr = nullptr; f.zero_n = 0;
   f.q0 = m->q0;
+  f.timeline = gjx::debug_timeline(128 * (size_t)pf.grid);     // (profiling scripts only: gjx_debug_timeline registers the buffer)
   if (mv) { f.m_a = mv->m_a; f.m_b = mv->m_b; f.n_moves = mv->n_moves; f.move_scale = mv->move_scale; f.acc_total = mv->acc_total; }
   void* args[] = {&f};
   e = hipLaunchKernel(pf.fn, dim3((unsigned)pf.grid), dim3(kPfHostThreads), args, pf.lds, st);

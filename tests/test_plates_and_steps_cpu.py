@@ -440,10 +440,12 @@ def test_filter_kernel_of_a_step_program_is_emitted_and_cross_compiles():
     src = kernels.program_filter_source(progs[1], 2)
     assert "pf_core<GenPfModel, SPL, 0, 0>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src      # one rank: agent scope, no verify mode
     assert "pf_core<GenPfModel, SPL, 2, 2>" in kernels.program_filter_source(progs[1], 2 | 256)                     # sharded flavour: decided at run time
-    assert "d.nz[3] = stream_normal<RNG>(bs" in src and "const float n_ = dr_->nz[0 + (0)];" in src
+    # the step's draws: the stream's words are taken ahead (behind the publish), Box-Muller is finished inside the slot
+    assert "d.nz[3] = __uint_as_float(bs.get(3u));" in src and "box_muller(__float_as_uint(dr_->nz[0]), __float_as_uint(dr_->nz[1]), hn0_, hn1_);" in src
     assert "LDIN(a.in_rows + (int64_t)3 * a.in_stride + src_[p])" in src and "tab_s[e] = tb_[e]" in src
     assert "score[p] +=" not in src and "q2[p]" in src           # weights only: the sampled site's log-density is not evaluated (the observed one's is)
-    assert src.count("stream_normal<RNG>(") == dx                  # the site itself draws nothing any more
+    assert src.count("stream_normal<RNG>(") == 0 and src.count("bs.get(") == dx     # the site itself hashes nothing any more
+    assert "const float* __restrict__ tb_ = tbn_;" in src and "tbn_ = f.tabs[t + 1];" in src     # the table's address is read a step ahead
     with pytest.raises(Exception):
         kernels.program_filter_source(progs[0], 1)                 # step 0 reads no carry: not a filter step
     kernels.program_filter_precompile(progs[1], 2)                 # hipRTC cross-compiles without a GPU
