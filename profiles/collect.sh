@@ -81,6 +81,7 @@ GJX_SCAN_FILTER_WIDE=0 python $R/profiles/microbench/scan_steps_timeline.py 2>/d
 # the filter kernel generated for the step program on the shared skeleton (gjx_gen_pf): phases of one step at 2^18 and 2^20 particles
 python $R/profiles/microbench/pf_gen_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_pf_gen_timeline.txt
 KK=1048576 python $R/profiles/microbench/pf_gen_timeline.py 2>/dev/null | grep -E " us|blocks" >> $OUT/${TAG}_pf_gen_timeline.txt
+python $R/profiles/microbench/pf_hand_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_pf_hand_timeline.txt
 # one launch of the generated mixture kernel: prologue / sites / end per block
 python $R/profiles/microbench/gen_kernel_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_gen_kernel_timeline.txt
 bash $R/profiles/gputests.sh $TAG > /dev/null 2>&1; cp $OUT/gputest_summary.txt $OUT/${TAG}_gputest_summary.txt; rm -f $OUT/gputest_test_*.txt $OUT/gputest_summary.txt
