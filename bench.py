@@ -760,8 +760,11 @@ def run_codegen(dev):
 
     res = {}
     gmm, _ = workloads.gmm_program(D=D, C=C)
-    res["gmm_hand_fused"] = timed(gmm, "auto")
-    res["gmm_generated"] = timed(gmm, "gen")
+    first = (timed(gmm, "auto"), timed(gmm, "gen"))
+    # the pair is timed a second time once both kernels exist, and the second pass is the line: in the first pass the generated kernel is
+    # compiled (seconds, GPU idle) between the two trains, and on a box with a cold kernel cache that alone read 1.24 against 1.15
+    res["gmm_hand_fused"] = dict(timed(gmm, "auto"), first_pass_kernel_us=first[0]["kernel_us"])
+    res["gmm_generated"] = dict(timed(gmm, "gen"), first_pass_kernel_us=first[1]["kernel_us"])
     res["gmm_generated"]["vs_hand_fused"] = res["gmm_generated"]["kernel_us"] / res["gmm_hand_fused"]["kernel_us"]
     sl = SiteList()
     sl.add("p", A.BETA, [np.float32(2.0), np.float32(2.0)])
@@ -1032,37 +1035,42 @@ def run_round4(dev):
         genjax.mv_normal_diag(x, np.full(dx, r, np.float32)) @ "y"
         return x, None
 
+    def time_runs(run, n):
+        # every run timed on its own (host call → device idle) and the MEDIAN reported, all runs listed beside it: a run is 3–10 ms, one
+        # descheduled host thread or a clock step inside a mean of five moved the line by 10 % from box to box
+        ts = []
+        for i in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = run(i)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts, out
+
     def time_filter(bf, chm, args, n=5):
         for i in range(2):
             bf.run(genjax.key(i), chm, args)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n):
-            out = bf.run(genjax.key(10 + i), chm, args)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, float(out["log_ml"]), out.get("info", {})
+        dt, ts, out = time_runs(lambda i: bf.run(genjax.key(10 + i), chm, args), n)
+        return dt, float(out["log_ml"]), dict(out.get("info", {}), runs=ts)
 
     exact = _kalman_log_lik(s["A"], s["y"], q, r, q)          # float64 closed form (x_0 ~ N(0, q^2 I): the Scan's step 0)
     ys_d = torch.as_tensor(s["y"], device=dev)
     for Kf, tag in ((K, "2e18"), (1 << 20, "2e20")):
         bf = BootstrapFilter(lg_step.scan(n=T), Kf)
         bf.alias_outputs = True                      # (the timed loop hands out the filter's own buffers: no copies inside the timing)
-        dt, lml, finfo = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=5 if Kf == K else 3)
+        dt, lml, finfo = time_filter(bf, CM["y"].set(np.asarray(s["y"], np.float32)), (np.zeros(dx, np.float32), None), n=9 if Kf == K else 5)
         hand = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"], q0=q), Kf, weights="tile_scaled")
         for i in range(3):
             hand.run(genjax.key(i), ys_d, device=dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(5):
-            hand.run(genjax.key(10 + i), ys_d, device=dev)
-        torch.cuda.synchronize()
-        dth = (time.perf_counter() - t0) / 5
+        dth, tsh, _ = time_runs(lambda i: hand.run(genjax.key(10 + i), ys_d, device=dev), 9 if Kf == K else 5)
         res[f"scan_filter_lgssm_d8_T256_K{tag}"] = dict(
             us_per_step=dt / T * 1e6, particle_steps_per_sec=Kf * T / dt, log_ml=lml, log_ml_rel_err=abs(lml - exact) / abs(exact),
             # the form the LIBRARY reports for this run (gjx_filter_info), not what the environment asked for
             form=finfo.get("form_name"), form_id=finfo.get("form"), launches_per_run=finfo.get("launches"), grid=finfo.get("grid"),
             tiles_per_block=finfo.get("tiles_per_block"),
             hand_written_one_launch_filter_us_per_step=dth / T * 1e6, ratio=dt / dth,
+            runs_us_per_step=[round(x / T * 1e6, 2) for x in finfo.get("runs", [])], hand_written_runs_us_per_step=[round(x / T * 1e6, 2) for x in tsh],
+            timing="median of the listed whole runs, each from the host's call to an idle device",
             roofline=dict(bound="hbm", algorithmic_bytes_per_particle_step=8 * dx + 24, bytes_per_step=(8 * dx + 24) * Kf, us_per_step=dt / T * 1e6,
                           achieved=(8 * dx + 24) * Kf / (dt / T) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=(8 * dx + 24) * Kf / (dt / T) / 1e9 / HBM_PEAK_GBS, timing="wall clock over whole runs incl. step 0 and the host's calls"),
