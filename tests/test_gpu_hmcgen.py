@@ -342,7 +342,7 @@ def test_random_long_scans_hmc_generated_interpreter_oracle(K_, oracle, rng, mon
     import torch
     import genjax_amd as genjax
     from genjax_amd import C
-    rs = np.random.default_rng(911 + rng)
+    rs = np.random.default_rng(int(os.environ.get("GJX_FUZZ_SEED", "911")) + rng)
     trials, covered = int(os.environ.get("GJX_FUZZ_TRIALS", "8")), 0
     for trial in range(trials):
         T = int(rs.choice([67, 101, 150, 259]))

@@ -604,7 +604,7 @@ def test_random_vmapped_models_hmc_generated_interpreter_oracle(rng, monkeypatch
     import torch
     from genjax_amd import kernels
     from oracle import cpu
-    rs = np.random.default_rng(77 + rng)
+    rs = np.random.default_rng(int(os.environ.get("GJX_FUZZ_SEED", "77")) + rng)
     trials, covered = int(os.environ.get("GJX_FUZZ_TRIALS", "10")), 0
     for trial in range(trials):
         N = int(rs.choice([13, 37, 70, 131, 300]))
