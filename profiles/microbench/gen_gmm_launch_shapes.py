@@ -1,7 +1,7 @@
 """launch shapes of the generated mixture kernel next to the hand-fused one (K = 2^20 by default, KLOG=..): grids (GJX_GEN_GRID) and particles
 per lane (GJX_GEN_PPT); each variant behind a train of 400 launches, median and minimum of 15 dispatch-timed launches, two passes.  DESIGN.md §9."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from genjax_amd import _abi as A, kernels, workloads
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 without moves; prints the log-ML estimates too (an emitter change must not move them).  Used for the A/Bs of DESIGN.md §9."""
 import os, sys, time, json
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import genjax_amd as genjax
 from genjax_amd import C, workloads
 from genjax_amd.inference import BootstrapFilter
@@ -21,7 +21,7 @@ for K in (1 << 18, 1 << 20):
     bf = BootstrapFilter(scan, K); bf.alias_outputs = True
     dt, o = med(bf, C["y"].set(ys), (carry0, None), 9 if K == 1 << 18 else 5)
     res[f"lgssm_K{K}"] = (round(dt / 256 * 1e6, 2), float(o["log_ml"]), o["info"].get("form"))
-fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sv_pf_float64.json")))
+fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "sv_pf_float64.json")))
 phi, sigma, ysv = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
 @genjax.gen
 def sv_step(x_prev, _):
