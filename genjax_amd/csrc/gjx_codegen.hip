@@ -1292,7 +1292,14 @@ std::string generate(const gjx_program* prog_in, int ppt_code) {
       "    for (int w = 0; w < 4; ++w) bsum += bm > -INFINITY ? red[4 + w] * fast_exp(red[w] - bm) : 0.0f;\n"
       "    if (a.lse) lse_publish_and_finish<256>(bm, bsum, a.partials, a.ticket, (int)gridDim.x, a.log_k_total, a.lse, red);\n"
       "    else if (threadIdx.x == 0) a.partials[blockIdx.x] = pack_f2(bm, bsum);\n  }\n  TSTAMP(7);\n}\n");
-  o.f("extern \"C\" __global__ __launch_bounds__(%d%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", BT, mfma ? ", 2" : "");
+  {
+    // GJX_GEN_WAVES_PER_EU=n: the register budget of n waves per SIMD (512 / n VGPRs) instead of the compiler's own choice
+    const char* we = getenv("GJX_GEN_WAVES_PER_EU");
+    const int wpe = we ? atoi(we) : 0;
+    std::string attr;
+    if (wpe >= 1 && wpe <= 8 && !mfma) attr = "__attribute__((amdgpu_waves_per_eu(" + std::to_string(wpe) + ", " + std::to_string(wpe) + "))) ";
+    o.f("extern \"C\" __global__ %s__launch_bounds__(%d%s) void gjx_gen(GenArgs a) { gjx_step_<false>(a); }\n", attr.c_str(), BT, mfma ? ", 2" : "");
+  }
   {
     bool has_input = false;
     for (int j = 0; j < prog->n_sites; ++j) has_input = has_input || prog->sites[j].mode == GJX_MODE_INPUT;
@@ -2444,7 +2451,7 @@ uint64_t structure_key(const gjx_program* p, int ppt, int flavour = 0) {   // fl
                                 (getenv("GJX_HMC_GEN_BT") ? atoi(getenv("GJX_HMC_GEN_BT")) << 8 : 0) ^ (getenv("GJX_HMC_GEN_NO_MFMA") ? 1 << 20 : 0) ^
                                 (getenv("GJX_HMC_GEN_DEBUG") ? atoi(getenv("GJX_HMC_GEN_DEBUG")) << 21 : 0) ^ (getenv("GJX_GEN_TAB_GLOBAL") ? 1 << 24 : 0) ^
                                 (getenv("GJX_GEN_NO_HOIST") ? 1 << 25 : 0) ^ (getenv("GJX_GEN_NO_FUSE") ? 1 << 26 : 0) ^ (getenv("GJX_GEN_NO_EARLY_STORE") ? 1 << 27 : 0) ^
-                                (getenv("GJX_GEN_NO_SEQ_ROWS") ? 1 << 28 : 0) ^ (getenv("GJX_JIT_FP_CONTRACT") ? 1 << 29 : 0)};
+                                (getenv("GJX_GEN_NO_SEQ_ROWS") ? 1 << 28 : 0) ^ (getenv("GJX_JIT_FP_CONTRACT") ? 1 << 29 : 0) ^ (getenv("GJX_GEN_WAVES_PER_EU") ? atoi(getenv("GJX_GEN_WAVES_PER_EU")) << 12 : 0)};
   h = fnv1a(extra, sizeof(extra), h);
   static const uint64_t header_hash = fnv1a(kDeviceHeader, strlen(kDeviceHeader));   // a new device header invalidates the caches
   return h ^ header_hash ^ (0x9E3779B97F4A7C15ull * GJX_ABI_VERSION);
