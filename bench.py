@@ -529,8 +529,18 @@ def run_ssm(args, rank, world, dev):
                            "step, no kernel boundary (phase timeline: profiles/, DESIGN.md section 5); kernel_us = wall time per filter step"),
         log_ml=float(lml), log_ml_exact=exact, log_ml_rel_err=abs(float(lml) - exact) / abs(exact),
     )
+    # rtol 1e-4 is NOT a single-run property at K = 2^18: an ideal float64 bootstrap filter of this size has an rms relative error of
+    # 7.0e-5 over its seeds (tests/golden/ssm_pf_float64.json, make_ssm_pf_float64.py).  The honest single-run figure is the z-score of
+    # this run's log-ML against that filter's single-run distribution (|z| < 3 expected; the tests hold the 32-seed rms to its rms).
+    if K == (1 << 18):
+        with open(os.path.join(ROOT, "tests", "golden", "ssm_pf_float64.json")) as f:
+            ref = np.asarray(json.load(f)["log_ml"], np.float64)
+        res["log_ml_z"] = (float(lml) - float(ref.mean())) / float(ref.std(ddof=1))
+        res["log_ml_z_note"] = "z of this run against the single-run spread of an ideal float64 filter (16 seeds, tests/golden/ssm_pf_float64.json)"
     if other is not None:
         other["log_ml_rel_err"] = abs(other["log_ml"] - exact) / abs(exact)
+        if "log_ml_z" in res:
+            other["log_ml_z"] = (other["log_ml"] - float(ref.mean())) / float(ref.std(ddof=1))
         res["other_weight_scheme"] = other
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_ssm(s, K, T)
@@ -1479,6 +1489,90 @@ def run_config4_dry_run(dev, world=8, K_total=1 << 22, T=256, dx=8):
                 note="all ranks time-share one device: the step time is a correctness-run figure, not a scaling measurement")
 
 
+HEADLINE_MAX_BYTES = 4096
+
+
+def _short(sv, n=140):
+    return sv if not isinstance(sv, str) or len(sv) <= n else sv[:n - 1] + "~"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline_record(res: dict, extra_path=None) -> dict:
+    """The compact object of the driver's line: the contract's keys + roofline + cpu_baseline + parity figures, no prose, no nested
+    `extra` (a 25 KB line could not be parsed).  Everything dropped here is in the side file."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data"))
+    cfg = res.get("config", {})
+    out["config"] = {k: _short(v, 200) for k, v in cfg.items() if k != "exchange_stats"}
+    ex = cfg.get("exchange_stats")
+    if isinstance(ex, dict) and ex.get("transport", "none") != "none":
+        out["config"]["exchange_summary"] = _pick(ex, ("transport", "ranks", "status", "transports_agree", "any_status_bit"))
+    rf = res.get("roofline", {})
+    out["roofline"] = {k: _short(v, 100) for k, v in _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_us",
+                                                                "algorithmic_bytes_per_launch", "launches_per_step")).items()}
+    tp = rf.get("traffic_from_profiles")
+    if isinstance(tp, dict):
+        out["roofline"]["traffic_from_profiles"] = _pick(tp, ("bytes_per_launch", "file"))
+    if isinstance(rf.get("back_to_back"), dict):
+        out["roofline"]["back_to_back_frac"] = rf["back_to_back"].get("frac")
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"]
+        out["cpu_baseline"] = {k: _short(v, 180) for k, v in _pick(cb, ("value", "unit", "cores", "kind", "sample")).items()}
+    for k in ("log_ml", "log_ml_exact", "log_ml_rel_err", "log_ml_z", "accept_rate", "energy_error_rms"):
+        if k in res:
+            out[k] = res[k]
+    if isinstance(res.get("roofline_jax32_stream"), dict):
+        out["roofline_jax32_stream_frac"] = res["roofline_jax32_stream"].get("frac")
+    other = {}
+    for name, r in (res.get("extra") or {}).items():
+        if name in ("ssm", "hmc") and isinstance(r, dict):
+            o = _pick(r, ("value", "unit", "ms_per_step", "log_ml_rel_err", "log_ml_z", "accept_rate"))
+            o["workload"] = _short(r.get("config", {}).get("workload", name), 120)
+            o["roofline"] = {k: _short(v, 60) for k, v in _pick(r.get("roofline", {}), ("bound", "kernel", "frac", "achieved", "unit", "kernel_us")).items()}
+            other[name] = o
+    if other:
+        out["other_configs"] = other
+    if "jit" in res:
+        out["jit_compiles_at_runtime"] = res["jit"]["hiprtc_compiles"]
+    if extra_path:
+        out["full_record"] = os.path.relpath(extra_path, ROOT) if extra_path.startswith(ROOT) else extra_path
+    return out
+
+
+def headline_line(res: dict, extra_path=None) -> str:
+    rec = headline_record(res, extra_path)
+    line = json.dumps(rec, separators=(",", ":"))
+    if len(line) > HEADLINE_MAX_BYTES:          # never let a long string cost the round's measurement: drop the optional blocks
+        for k in ("other_configs", "roofline_jax32_stream_frac", "full_record"):
+            rec.pop(k, None)
+        rec["config"] = _pick(rec["config"], ("workload", "k_particles_per_gpu", "k_particles_total", "sharding", "exchange"))
+        line = json.dumps(rec, separators=(",", ":"))
+    assert len(line) <= 2 * HEADLINE_MAX_BYTES and "\n" not in line
+    return line
+
+
+def write_full_record(res: dict, args) -> str:
+    """everything measured (incl. `extra` and the long notes) as indented JSON beside bench.py — and under gpurun_out/ when that
+    exists, so a GPU-box run brings it home"""
+    path = args.extra_file
+    try:
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError:
+        path = None
+    gp = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(gp) and os.access(gp, os.W_OK):
+        try:
+            with open(os.path.join(gp, "bench_extra_%s.json" % args.workload), "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError:
+            pass
+    return path
+
+
 def respawn(n: int) -> None:
     """Replace this process by `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>`
     (one rank per GPU over RCCL; rendezvous on 127.0.0.1 and a free port)."""
@@ -1549,7 +1643,12 @@ def main():
                     help="ssm on one GPU: fixed-point scheme of the filter's systematic resampler (include/gjx.h)")
     ap.add_argument("--ssm-k-total", type=int, default=0, help="ssm: total number of particles (overrides the config-3/4 sizes)")
     ap.add_argument("--api", action="store_true", help="gmm on one GPU: print only the API-level measurement (extra.api)")
-    ap.add_argument("--no-extra", action="store_true", help="gmm on one GPU: skip the short ssm / hmc / API runs reported under extra")
+    ap.add_argument("--no-extra", action="store_true", help="gmm on one GPU: skip the short ssm / hmc runs summarised under other_configs")
+    ap.add_argument("--extra", action="store_true",
+                    help="gmm on one GPU: also run the round's other measurements (generated kernels, generic filter, plates, HMC engines, "
+                         "config-4 dry run, API step); they are written to the side file (--extra-file), not to the line")
+    ap.add_argument("--extra-file", default=os.environ.get("GJX_BENCH_EXTRA", os.path.join(ROOT, "bench_extra.json")),
+                    help="where the full record (everything measured, incl. long notes) is written; the stdout line stays compact")
     ap.add_argument("--event-samples", type=int, default=16,
                     help="number of timed steps whose propagate+reweight kernel is bracketed with HIP events "
                          "(timing events are not free on ROCm — hundreds of live ones slow every launch — so the "
@@ -1574,48 +1673,35 @@ def main():
         return
     res = {"gmm": run_gmm, "ssm": run_ssm, "hmc": run_hmc}[args.workload](args, rank, world, dev)
     if args.workload == "gmm" and world == 1 and res is not None and not args.no_extra:
-        # the other single-GPU rows of BASELINE.json, short runs, so that the driver's one line carries them too
+        # the other single-GPU rows of BASELINE.json, short runs: their summaries ride in the line under other_configs
         extra = {}
         for name, fn, st in (("ssm", run_ssm, 3), ("hmc", run_hmc, 2)):
             a2 = argparse.Namespace(**vars(args))
             a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline = name, st, 1, True
             r2 = fn(a2, rank, world, dev)
             extra[name] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in r2}
-            for k in ("log_ml_rel_err", "accept_rate", "other_weight_scheme"):
+            for k in ("log_ml_rel_err", "log_ml_z", "accept_rate", "other_weight_scheme"):
                 if k in r2:
                     extra[name][k] = r2[k]
-        try:
-            extra["sharded_one_rank"] = run_sharded_one_rank(dev)
-        except Exception as e:                  # (reported, never fatal for the headline line)
-            extra["sharded_one_rank"] = dict(error=repr(e))
-        extra["codegen"] = run_codegen(dev)
-        extra["hmc_generic"] = run_hmc_generic(dev)
-        try:
-            extra["hmc_generated"] = run_hmc_generated(dev)
-        except Exception as e:
-            extra["hmc_generated"] = dict(error=repr(e))
-        try:
-            extra["round4"] = run_round4(dev)
-        except Exception as e:
-            extra["round4"] = dict(error=repr(e))
-        try:
-            extra["round5"] = run_round5(dev)
-        except Exception as e:
-            extra["round5"] = dict(error=repr(e))
-        try:
-            extra["config4_dry_run"] = run_config4_dry_run(dev)
-        except Exception as e:
-            extra["config4_dry_run"] = dict(error=repr(e))
-        try:
-            extra["round3"] = run_round3(dev)
-        except Exception as e:
-            extra["round3"] = dict(error=repr(e))
-        api = run_api(dev, args.k_per_gpu)
-        api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
-        extra["api"] = api
+        if args.extra:
+            # everything else the round measured (generated kernels, the generic filter, plates, HMC engines, the config-4 dry run,
+            # the API-level step): minutes of work and tens of KB of JSON — they go to the side file, never onto the driver's line
+            for name, fn in (("sharded_one_rank", run_sharded_one_rank), ("codegen", run_codegen), ("hmc_generic", run_hmc_generic),
+                             ("hmc_generated", run_hmc_generated), ("round4", run_round4), ("round5", run_round5),
+                             ("config4_dry_run", run_config4_dry_run), ("round3", run_round3)):
+                try:
+                    extra[name] = fn(dev)
+                except Exception as e:                  # (reported, never fatal for the headline line)
+                    extra[name] = dict(error=repr(e))
+            api = run_api(dev, args.k_per_gpu)
+            api["vs_kernel_level_step"] = api["ms_per_step"] / res["ms_per_step"]
+            extra["api"] = api
         res["extra"] = extra
     if rank == 0 and res is not None:
-        print(json.dumps(res))
+        from genjax_amd import kernels
+        res["jit"] = kernels.jit_stats()
+        path = write_full_record(res, args)
+        print(headline_line(res, path))            # the LAST stdout line: compact, what the driver parses
     if dist.is_initialized():
         dist.destroy_process_group()
 

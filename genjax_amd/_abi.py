@@ -126,6 +126,7 @@ PROTOTYPES = {
     "gjx_program_precompile": (C.c_int, [PP, i32]),
     "gjx_program_hmc_source": (i64, [PP, C.c_char_p, i64]),
     "gjx_program_hmc_precompile": (C.c_int, [PP]),
+    "gjx_jit_stats": (C.c_int, [vp]),
     "gjx_program_aux_floats": (C.c_int, [PP]),
     "gjx_program_prepare": (C.c_int, [PP, vp, i32, vp]),
     "gjx_threefry2x32": (C.c_int, [u32, u32, u32, u32, i64, vp, vp]),

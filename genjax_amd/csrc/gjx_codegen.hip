@@ -19,6 +19,8 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <unordered_map>
 #include <mutex>
@@ -2395,6 +2397,8 @@ struct Compiled {
 
 std::mutex g_mu;
 std::map<uint64_t, Compiled> g_compiled;                                 // by structure key
+// gjx_jit_stats: kernels compiled by hipRTC in this process, code objects taken from the on-disk cache, time spent compiling (us)
+std::atomic<int64_t> g_rtc_compiles{0}, g_disk_hits{0}, g_rtc_us{0};
 std::map<std::pair<uint64_t, int>, std::pair<hipModule_t, hipFunction_t>> g_loaded;   // by (key, device)
 
 // per-program analysis cached under gjx_program.uid (0 = no caching): the site-list hash, the emitter's verdict and the
@@ -2497,7 +2501,7 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
       c.code.resize((size_t)n);
       const size_t got = fread(c.code.data(), 1, (size_t)n, f);
       fclose(f);
-      if (got == (size_t)n && n > 0) return c;
+      if (got == (size_t)n && n > 0) { g_disk_hits++; return c; }
       c.code.clear();
     }
   }
@@ -2513,7 +2517,10 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   // (offline clang takes -mllvm -amdgpu-mfma-vgpr-form=1, which would keep matrix-core results out of the AGPRs; this hipRTC's LLVM
   // does not know the option, so the generated kernels pay 16 v_accvgpr_read per tile: about 3 %)
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const auto t_rtc = std::chrono::steady_clock::now();
   const hiprtcResult rc = r.Compile(p, no_contract ? 4 : 3, opts);
+  g_rtc_compiles++;
+  g_rtc_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_rtc).count();
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
     r.LogSize(p, &ls);
@@ -2545,6 +2552,15 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
 // ---------------------------------------------------------------------------------------------------------
 // interface used by gjx_run.hip
 // ---------------------------------------------------------------------------------------------------------
+extern "C" int gjx_jit_stats(int64_t* out4) {
+  if (!out4) return GJX_EINVAL;
+  out4[0] = g_rtc_compiles.load();
+  out4[1] = g_disk_hits.load();
+  out4[2] = g_rtc_us.load();
+  { std::lock_guard<std::mutex> lock(g_mu); out4[3] = (int64_t)g_compiled.size(); }
+  return GJX_OK;
+}
+
 namespace gjx {
 
 int gen_pick_ppt(const gjx_program* prog, int64_t K, bool prefer4) {

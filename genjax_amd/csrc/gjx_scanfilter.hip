@@ -180,7 +180,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       // (the kernel could not be launched: the forms below start again from step 0)
     }
   }
-  if (n_moves > 0)
+  if (n_moves > 0 && T >= 2)     // (T < 2: there is no resampling, hence nothing to move: the plain forms below are the whole run)
     return report(gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the rejuvenation move runs inside the filter kernel on the shared skeleton only "
                                              "(GJX_FILTER_FORM_WIDE: periodic step programs whose latent choices are the carry, no plates, a co-resident "
                                              "grid, the workspace room of the one-launch forms)"));

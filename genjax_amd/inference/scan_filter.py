@@ -209,7 +209,7 @@ class ScanBootstrapFilter:
                                            ws=torch.zeros(need, dtype=torch.uint8, device=dev))
         lse = torch.empty((T, 4), dtype=f32, device=dev)
         ws_bytes = b["ws"].numel() if T <= 4096 else min(b["ws"].numel(), self._ws_one_launch_per_step)
-        opts, info = self._opts(), A.GjxFilterInfo()
+        opts, info = self._opts(dev), A.GjxFilterInfo()
         if keep_history:
             rows_all = torch.empty((T, n_rows, K), dtype=f32, device=dev)
             anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev)
@@ -220,16 +220,14 @@ class ScanBootstrapFilter:
                                   tiles_per_block=int(info.tiles_per_block))
             st = self._status(b)
             if st & 1:
-                self._no_steps_kernel = True
-                try:
-                    return self.run(key, constraint, args, device, keep_ancestors, keep_history)
-                finally:
-                    self._no_steps_kernel = False
+                return self._repeat_after_timeout(key, constraint, args, device, keep_ancestors, keep_history)
             incs = lse[:, 3]
             logw = self._out(b["logw"])
-            hist = ScanHistory(progs, rows_all, anc_all[: T - 1], logw)
+            moved = bool(self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0)
+            hist = ScanHistory(progs, rows_all, anc_all[: T - 1], logw, moved=moved)
             return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=logw,
-                        programs=progs, ancestors=anc_all[: T - 1], history=hist, degenerate=bool(st & 2), info=self.last_info)
+                        programs=progs, ancestors=anc_all[: T - 1], history=hist, degenerate=bool(st & 2), info=self.last_info,
+                        accepted_total=(int(self._acc.item()) if moved and getattr(self, "_acc", None) is not None else None))
         anc_all = torch.empty((max(T - 1, 1), K), dtype=torch.int32, device=dev) if keep_ancestors else None
         check(load().gjx_scan_filter(C.cast(cps, C.c_void_p), T, key[0], key[1], K, kernels._ptr(b["rows_a"]), kernels._ptr(b["rows_b"]),
                                      kernels._ptr(b["logw"]), kernels._ptr(b["anc"]), kernels._ptr(anc_all), kernels._ptr(lse),
@@ -238,22 +236,40 @@ class ScanBootstrapFilter:
                               tiles_per_block=int(info.tiles_per_block))
         st = self._status(b)
         if st & 1:
-            # the steps kernel needs its whole grid resident and something else held compute units: the same run, same keys, one
-            # launch per step (bit-identical results)
-            import warnings
-            warnings.warn("generic filter: the steps kernel timed out waiting for its peer blocks (another kernel holds compute units); "
-                          "the run was repeated with one launch per step")
-            self._no_steps_kernel = True
-            try:
-                return self.run(key, constraint, args, device, keep_ancestors, keep_history)
-            finally:
-                self._no_steps_kernel = False
+            return self._repeat_after_timeout(key, constraint, args, device, keep_ancestors, keep_history)
         incs = lse[:, 3]
         last = progs[-1]
         ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=self._out(ch), logw=self._out(b["logw"]), programs=progs,
                     ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info,
                     accepted_total=(int(self._acc.item()) if self.rejuvenate and getattr(self, "_acc", None) is not None else None))
+
+    def _repeat_after_timeout(self, key, constraint, args, device, keep_ancestors, keep_history):
+        """GJX_STATUS_POLL_TIMEOUT: the one-launch kernel needs its whole grid resident and something else held compute units.  The
+        same run, same keys, again: with one launch per step (bit-identical results) — or, with resample-move (which exists in the
+        one-launch form only), the one-launch form once more after the device has drained; a second time-out is an error, never a
+        silently different algorithm."""
+        import warnings
+        moved = bool(self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0)
+        if getattr(self, "_repeating", False):
+            raise RuntimeError("generic filter: the one-launch filter kernel timed out twice waiting for its peer blocks; resample-move "
+                               "(rejuvenate=...) needs the one-launch form — free the device of other kernels, or run without rejuvenation")
+        if moved:
+            warnings.warn("generic filter: the one-launch kernel timed out waiting for its peer blocks; the run is repeated once the device "
+                          "is idle (resample-move has no per-step form)")
+            torch.cuda.synchronize()
+            self._repeating = True
+            try:
+                return self.run(key, constraint, args, device, keep_ancestors, keep_history)
+            finally:
+                self._repeating = False
+        warnings.warn("generic filter: the steps kernel timed out waiting for its peer blocks (another kernel holds compute units); "
+                      "the run was repeated with one launch per step")
+        self._no_steps_kernel = True
+        try:
+            return self.run(key, constraint, args, device, keep_ancestors, keep_history)
+        finally:
+            self._no_steps_kernel = False
 
     def run_peer(self, ctx, key: Key, constraint: ChoiceMap, args=(None, None), want_ancestors: bool = False):
         """the same filter on a collection SHARDED over the ranks of a ``kernels.PeerContext`` (one process per GPU; ``self.K`` is the
@@ -263,6 +279,10 @@ class ScanBootstrapFilter:
         choices (this rank's part of the last step: a view of the window), logw, ancestors? (global indices), programs, info)"""
         if ctx.K != self.K:
             raise ValueError("run_peer: the filter's particle count must be the context's K_local")
+        if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
+            raise NotImplementedError("run_peer: the sharded filter kernel has no resample-move yet (rejuvenate=...); run() on one GPU has")
+        if self.resampler != "systematic":
+            raise NotImplementedError("run_peer: the sharded filter kernel resamples systematically; resampler='multinomial' runs on one GPU only")
         dev = ctx.device
         sk, dk = _run_keys(constraint, args, dev)
         c = self._cache
@@ -286,7 +306,7 @@ class ScanBootstrapFilter:
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=o["lse_steps"], choices=o["rows"][: max(progs[-1].n_slots, 1)], logw=o["logw"],
                     ancestors=o["ancestors"], programs=progs, info=o["info"])
 
-    def _opts(self) -> "A.GjxFilterOpts":
+    def _opts(self, dev=None) -> "A.GjxFilterOpts":
         """the form of the run as ARGUMENTS of the call (the library reads no environment variable).  Attributes of the filter, or —
         for scripts and tests — these variables, read HERE: GJX_SCAN_FILTER_TWO_LAUNCH=1 (search launch + step launch),
         GJX_SCAN_FILTER_PERSISTENT=0 (no one-launch form), GJX_SCAN_FILTER_WIDE=0 (not the 16-wave filter kernel),
@@ -306,8 +326,10 @@ class ScanBootstrapFilter:
         o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
         if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
             o.n_moves, o.move_scale = int(self.rejuvenate["n_moves"]), float(self.rejuvenate.get("scale", 0.5))
-            if getattr(self, "_acc", None) is None:
-                self._acc = torch.zeros(1, dtype=torch.int64, device="cuda")
+            if dev is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            if getattr(self, "_acc", None) is None or self._acc.device != dev:       # the counter lives where the filter runs
+                self._acc = torch.zeros(1, dtype=torch.int64, device=dev)
             o.accepted_total = self._acc.data_ptr()
         tl = getattr(self, "timeline", None)
         if tl is not None:
@@ -345,8 +367,11 @@ class ScanHistory:
     (scan.py:56-97); here the trajectory that ends in particle i of the last step is read back lazily: i_{t-1} =
     ancestors[t-1][i_t], one row gather per step."""
 
-    def __init__(self, programs, rows_all, ancestors, logw):
+    def __init__(self, programs, rows_all, ancestors, logw, moved: bool = False):
         self.programs, self.rows_all, self.ancestors, self.logw = programs, rows_all, ancestors, logw
+        # resample-move (gjx_filter_opts.n_moves > 0): the parent a particle of step t+1 was propagated from is the MOVED carry the
+        # kernel stored in step t+1's INPUT rows (at the child's index), not the own rows of step t at the ancestor's index
+        self.moved = bool(moved)
 
     def __len__(self):
         return len(self.programs)
@@ -358,20 +383,38 @@ class ScanHistory:
                 return p.slot_of[s.addr], s.dim
         raise KeyError(name)
 
+    def _input_rows_of(self, t, name):
+        """rows of step t's INPUT site that stands for choice ``name`` of step t-1 (the carry as the step received it), or None"""
+        p = self.programs[t]
+        for s in p.site_list.sites:
+            if _name(s.addr) == name and p.modes.get(s.addr) == A.MODE_INPUT and p.slot_of[s.addr] >= 0:
+                return p.slot_of[s.addr], s.dim
+        return None
+
     def step(self, t, name) -> torch.Tensor:
-        """the particles of step t as propagated (before the next resampling): f32[dim][K]"""
+        """the particles of step t as propagated (before the next resampling and its move): f32[dim][K]"""
         r0, d = self._rows_of(t, name)
         return self.rows_all[t, r0:r0 + d]
 
     def paths(self, name, idx=None) -> torch.Tensor:
-        """-> f32[T][dim][n]: the trajectories of choice ``name`` that end in particles ``idx`` (default: all) of the last step"""
+        """-> f32[T][dim][n]: the trajectories of choice ``name`` that end in particles ``idx`` (default: all) of the last step.
+        With resample-move, x_t (t < T-1) of a trajectory is the value its child at step t+1 was propagated FROM — the moved carry in
+        step t+1's INPUT rows at the child's index — so that every (x_t, x_{t+1}) pair of a path is a transition the filter made."""
         T = len(self.programs)
         K = self.rows_all.shape[2]
         cur = torch.arange(K, device=self.rows_all.device) if idx is None else idx.to(torch.int64)
         out = [None] * T
+        child = None
         for t in range(T - 1, -1, -1):
-            out[t] = self.step(t, name)[:, cur]
+            rin = self._input_rows_of(t + 1, name) if (self.moved and child is not None) else None
+            if rin is not None:
+                out[t] = self.rows_all[t + 1, rin[0]:rin[0] + rin[1]][:, child]
+            else:
+                if self.moved and child is not None:
+                    raise NotImplementedError(f"ScanHistory.paths({name!r}) with resample-move: step {t + 1} does not receive {name!r} as carry")
+                out[t] = self.step(t, name)[:, cur]
             if t > 0:
+                child = cur
                 cur = self.ancestors[t - 1][cur].to(torch.int64)
         return torch.stack(out)
 

@@ -117,6 +117,13 @@ def program_source(prog: PackedProgram, ppt: int = 0) -> str:
     return buf.value.decode()
 
 
+def jit_stats() -> dict:
+    """what the generated-kernel caches did in this process so far (gjx_jit_stats)"""
+    out = (C.c_int64 * 4)()
+    check(load().gjx_jit_stats(out), "gjx_jit_stats")
+    return dict(hiprtc_compiles=int(out[0]), disk_hits=int(out[1]), hiprtc_ms=int(out[2]) / 1e3, structures=int(out[3]))
+
+
 def program_precompile(prog: PackedProgram, ppt: int) -> None:
     """Compile the program's generated kernel with hipRTC (works without a GPU) into the in-memory and on-disk caches."""
     cp = prog.c_program(None)

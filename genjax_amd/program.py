@@ -755,6 +755,8 @@ class PackedProgram:
             if s.plate and p.d_elem:
                 raise NotImplementedError("take(observed vector, observed index) inside a plate: constrain one of them per particle")
             idx = int(np.clip(int(self._obs_value(p.src)[p.src_elem]), 0, p.vn - 1))
+            # the index is baked into the offset: a later set_obs on it could not move the row (set_obs refuses, see there)
+            self._folded_index = getattr(self, "_folded_index", set()) | {p.src}
             cp.op = A.P_CONST
             cp.off, cp.len = self.obs_off[p.vsrc] + p.vsrc_elem + idx * p.vlen, int(p.vlen)
 
@@ -815,6 +817,9 @@ class PackedProgram:
 
     def set_obs(self, addr: str, value) -> None:
         """Replace an observed value in place (same program, new data)."""
+        if addr in getattr(self, "_folded_index", ()):
+            raise NotImplementedError(f"set_obs({addr!r}): this observed index picks a row of an observed vector and was folded into the program "
+                                      "when it was packed (take(observed vector, observed index)); build the program again with the new index")
         off = self.obs_off[addr]
         v = np.asarray(value, np.float32).ravel()
         self.tab[off:off + v.size] = v

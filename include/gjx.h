@@ -277,6 +277,10 @@ int gjx_program_precompile(const gjx_program* prog, int32_t ppt);
  * without launch.  GJX_EUNSUPPORTED when the emitter does not cover the program (the site interpreter runs it). */
 int64_t gjx_program_hmc_source(const gjx_program* prog, char* out, int64_t cap);
 int gjx_program_hmc_precompile(const gjx_program* prog);
+/* what the generated-kernel caches did in this process so far: out4 = {kernels compiled by hipRTC, code objects read from the on-disk
+ * cache, microseconds spent in hipRTC, kernel structures known}.  A deployment (and bench.py's line: jit_compiles_at_runtime) wants the
+ * first to stay 0: build() precompiles the programs of genjax_amd/jit_manifest.py into the cache that ships with the library. */
+int gjx_jit_stats(int64_t* out4);
 int gjx_program_aux_floats(const gjx_program* prog);
 int gjx_program_prepare(const gjx_program* prog, float* aux_dev, int32_t n_aux, void* stream);
 

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Profile collection on the GPU box (run through gpurun): bench JSON lines, rocprofv3 kernel stats, PMC passes.
 # usage: bash profiles/collect.sh r03 [gmm|ssm|hmc ...]      output: gpurun_out/<tag>/, copy what is to be judged into profiles/
-TAG=${1:-r05}; shift; WL=${@:-gmm ssm hmc}
+TAG=${1:-r06}; shift; WL=${@:-gmm ssm hmc}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 for w in $WL; do
-  python bench.py --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
+  # the compact line the driver parses -> <tag>_bench_<w>.json; the full record (incl. --extra's measurements) -> <tag>_bench_<w>_full.json
+  xa=; [ $w = gmm ] && xa=--extra
+  python bench.py --workload $w $xa --extra-file $OUT/${TAG}_bench_${w}_full.json 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 cd /tmp; export TMPDIR=/tmp
 for w in $WL; do
@@ -16,12 +18,12 @@ for w in $WL; do
   cp $(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${w}_kernel_stats.csv
 done
 if echo $WL | grep -q gmm; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extra -o extra -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 1 > $OUT/prof_extra.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extra -o extra -- python $R/bench.py --no-cpu-baseline --extra --extra-file /tmp/bench_extra_prof.json --steps 20 --warmup 1 > $OUT/prof_extra.log 2>&1
   cp $(find $OUT/prof_extra -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_gmm_with_extras_kernel_stats.csv
 fi
 # PMC passes for the default bench (counters only: no tracing domains alongside --pmc); FETCH_SIZE and WRITE_SIZE in separate passes
 if echo $WL | grep -q gmm; then
-  CMD="python $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 --event-samples 2"
+  CMD="python $R/bench.py --no-cpu-baseline --extra --extra-file /tmp/bench_extra_pmc.json --steps 20 --warmup 3 --event-samples 2"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1

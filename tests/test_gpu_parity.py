@@ -567,16 +567,26 @@ def test_ssm_step_parity(K_, oracle, rng):
         np.testing.assert_allclose(_np(l1), l1o, rtol=1e-4, atol=1e-4)
 
 
-def test_bootstrap_filter_full_size(K_, golden):
-    """BASELINE config 3: T=256, K=2^18, systematic resampling every step; log-ML vs the float64 Kalman filter."""
+@pytest.mark.parametrize("weights", ["tile_scaled", "global_max"])
+def test_bootstrap_filter_full_size(K_, golden, weights):
+    """BASELINE config 3: T=256, K=2^18, systematic resampling every step, on BOTH fixed-point schemes (tile_scaled is what the
+    product runs by default).  rtol 1e-4 against the Kalman log-likelihood is not a single-run property at this size — an ideal
+    float64 bootstrap filter has an rms relative error of 7.0e-5 over its seeds and 3 of its 16 seeds exceed 1e-4
+    (tests/golden/ssm_pf_float64.json) — so a single run is held to that filter's single-run distribution (|z| < 4) and to 2.5e-4
+    of the Kalman value; the 32-seed test below holds the rms to the ideal filter's rms and the bias to its standard error."""
+    import json
     from genjax_amd.inference.pf import BootstrapFilter, LinearGaussianSSM
     s = cf.ssm_problem()
     exact = golden["closed_form"]["ssm_dx8_T256_seed0"]
     kl, incs, means = cf.kalman_log_lik(s["A"], s["y"], s["q"], s["r"])
     assert kl == pytest.approx(exact, rel=1e-12)
-    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18, weights="global_max")
+    ref = np.asarray(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ssm_pf_float64.json")))["log_ml"])
+    bf = BootstrapFilter(LinearGaussianSSM(s["A"], s["q"], s["r"]), 1 << 18, weights=weights)
     out = bf.run(core.key(1), s["y"], keep_means=True)
-    assert float(out["log_ml"]) == pytest.approx(exact, rel=1e-4)
+    z = (float(out["log_ml"]) - ref.mean()) / ref.std(ddof=1)
+    print(f"{weights}: log-ML {float(out['log_ml']):.4f}, Kalman {exact:.4f}, rel {abs(float(out['log_ml']) - exact) / abs(exact):.3g}, z {z:.2f}")
+    assert abs(z) < 4.0
+    assert float(out["log_ml"]) == pytest.approx(exact, rel=2.5e-4)
     np.testing.assert_allclose(_np(out["increments"]), incs, atol=0.2)
     # SURVEY.md §8(d) row 3: filtered mean vs Kalman mean at full size (posterior sd ~1, min ESS ~0.05 K: sigma_MC ~0.01)
     np.testing.assert_allclose(_np(out["means"]), means, atol=0.08)
