@@ -13,6 +13,7 @@ from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gum
                   cauchy, cond, const, exp, exponential, flip, gamma, gen, half_normal, laplace, log_normal,
                   iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .gen import Scan, Vmap, accumulate, reduce  # noqa: F401
+from .gen import Expr, NotSupportedInModelBody, cos, dot, log, log1p, maximum, minimum, sin, sqrt, square, tanh  # noqa: F401  (general expressions: GJX_P_EXPR)
 from .inference import requests, smc  # noqa: F401  (the reference's genjax.smc / genjax.requests modules)
 from .inference.smc import SMCAlgorithm as Algorithm  # noqa: F401
 from .inference import (HMC, IndexRequest, BootstrapFilter, ChangeTarget, Importance, ImportanceK, LinearGaussianSSM,  # noqa: F401

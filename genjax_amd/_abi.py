@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -30,7 +30,11 @@ DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS,
 NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move (integers; simplex-constrained)
 
 # param forms / transforms / modes / flags / rng
-P_CONST, P_VALUE, P_GATHER, P_AFFINE, P_VGATHER = 0, 1, 2, 3, 4
+P_CONST, P_VALUE, P_GATHER, P_AFFINE, P_VGATHER, P_EXPR = 0, 1, 2, 3, 4, 5
+# nodes of a GJX_P_EXPR block (include/gjx.h GJX_E_*)
+(E_CONST, E_VALUE, E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_SQRT, E_SQUARE, E_TANH, E_SIGMOID, E_SOFTPLUS, E_ABS, E_SIN, E_COS,
+ E_LOG1P, E_RECIP, E_MAX, E_MIN, E_GT, E_WHERE, E_LINV, E_LINN) = range(25)
+EXPR_MAX_NODES = 96
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
 MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK, MODE_INPUT = 0, 1, 2, 3, 4
 MODE_OBS_PROPOSED = 5

@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <unordered_map>
 #include <mutex>
@@ -225,6 +226,39 @@ struct Roll {
   std::vector<RollInfo> info;
 };
 
+// GJX_P_EXPR (gjx.h): node i of the block of parameter q = {op, a, b, c}, read from the HOST copy of the table at codegen time (the
+// node list is program STRUCTURE: baked into the kernel and hashed into its key; the constants / weights it names are run-time table reads)
+struct ExprNode { int op, a, b, c; };
+ExprNode expr_node(const gjx_program* p, const gjx_param& q, int i) {
+  const float* nd = p->tab + q.off + 4 * i;
+  return ExprNode{(int)nd[0], (int)nd[1], (int)nd[2], (int)nd[3]};
+}
+bool has_expr(const gjx_site* sites, int n) {
+  for (int j = 0; j < n; ++j) if (sites[j].mode != GJX_MODE_INPUT) for (int k = 0; k < GJX_MAX_PARAMS; ++k) if (sites[j].p[k].op == GJX_P_EXPR) return true;
+  return false;
+}
+// a block the emitters take: in range, SSA order, no plate strides (plates with blocks run on the interpreter), leaves in [0, n_slots)
+bool expr_block_ok(const gjx_program* p, const gjx_param& q, int n_slots, int dim) {
+  if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.len < 1 || q.len > q.n || q.off < 0 || q.off + 4 * q.n > p->n_tab) return false;
+  if (q.len != 1 && (q.len != dim || dim > 32)) return false;
+  for (int i = 0; i < q.n; ++i) {
+    const ExprNode e = expr_node(p, q, i);
+    auto nodeok = [&](int x) { return x >= 0 && x < i; };
+    switch (e.op) {
+      case GJX_E_CONST: if (e.a < 0 || e.a >= p->n_tab || e.b != 0) return false; break;
+      case GJX_E_VALUE: if (e.a < 0 || e.a >= n_slots || e.b != 0) return false; break;
+      case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: case GJX_E_GT:
+        if (!nodeok(e.a) || !nodeok(e.b)) return false; break;
+      case GJX_E_WHERE: if (!nodeok(e.a) || !nodeok(e.b) || !nodeok(e.c)) return false; break;
+      case GJX_E_LINV: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || e.b + e.c > n_slots) return false; break;
+      case GJX_E_LINN: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || e.b + e.c > i) return false; break;
+      default: if (e.op < GJX_E_NEG || e.op > GJX_E_RECIP || !nodeok(e.a)) return false; break;
+    }
+  }
+  return true;
+}
+thread_local const gjx_program* g_expr_prog = nullptr;   // the program whose table holds the blocks of the sites being emitted
+
 bool slot_op(int op) { return op == GJX_P_VALUE || op == GJX_P_GATHER || op == GJX_P_AFFINE || op == GJX_P_VGATHER; }
 bool has_vgather(const gjx_site* sites, int n) {
   for (int j = 0; j < n; ++j) for (int k = 0; k < GJX_MAX_PARAMS; ++k) if (sites[j].p[k].op == GJX_P_VGATHER) return true;
@@ -247,6 +281,7 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
   if ((p->rng_mode != GJX_RNG_FLAT && !any_stream) || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
   for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
+  if (has_expr(p->sites, n)) return r;                                   // (the slots inside expression blocks are not remapped to the loop's registers)
   int i0 = 0;
   while (i0 < n && p->sites[i0].scan == 0) ++i0;
   if (i0 == n || GJX_SCAN_STEP(p->sites[i0].scan) != 0) return r;
@@ -432,6 +467,7 @@ PlateXf plate_program(const gjx_program* p) {
   const int n = p->n_sites;
   for (int j = 0; j < n; ++j) x.any = x.any || p->sites[j].plate != 0;
   if (!x.any) return x;
+  if (has_expr(p->sites, n)) return x;      // (ok stays false: expression blocks inside / beside plates run on the site interpreter)
   auto width = [&](const gjx_site& s) { return (is_categorical(s.kind) && s.mode != GJX_MODE_INPUT) ? 1 : s.dim; };
   auto rows = [&](const gjx_site& s) { return width(s) * (s.plate ? s.plate_n : 1); };
   std::vector<int> reg(n, -1), flag(n, -1), first(n, 0), pos(n, 0);
@@ -503,7 +539,7 @@ PlateXf plate_program(const gjx_program* p) {
 }
 
 // what the emitter covers; everything else runs on the interpreter
-bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
+bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_program* prog = nullptr) {   // prog: the program whose table holds expression blocks
   if (n_sites < 1 || n_sites > 48 || n_slots > 160) return false;
   int total = 0;
   for (int j = 0; j < n_sites; ++j) {
@@ -520,6 +556,11 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
     if (s.dim > kMaxExpandDim && s.mode != GJX_MODE_OBS_TAB) return false;
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
+      if (q.op == GJX_P_EXPR) {      // an expression block: emitted inline, one straight-line copy per element that reads it
+        if (!prog || !expr_block_ok(prog, q, n_slots, s.dim) || (s.dim > kMaxExpandDim && q.len != 1)) return false;
+        total += q.n / 2;
+        continue;
+      }
       if (q.op < GJX_P_CONST || q.op > GJX_P_VGATHER) return false;
       if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
       if (s.dim > kMaxExpandDim && q.op == GJX_P_VALUE && q.len != 1) return false;
@@ -534,7 +575,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots) {
 bool supported_uncached(const gjx_program* p) {
   const PlateXf px = plate_program(p);
   if (px.any) return px.ok && supported_sites(px.sites.data(), (int)px.sites.size(), px.n_regs);
-  if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots)) return true;
+  if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots, p)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
   return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs);
 }
@@ -559,6 +600,7 @@ std::string param_expr(const gjx_param& q, const std::string& dx, int site, int 
       if (q.len == 1) return src_val(q, ri, k, "0");
       return src_val(q, ri, k, "(" + dx + ") % " + std::to_string(q.len));
     case GJX_P_VGATHER: snprintf(b, sizeof(b), "vg_%d_%d", site, k); return b;   // (select chain emitted by emit_param_pre)
+    case GJX_P_EXPR: snprintf(b, sizeof(b), "ex_%d_%d", site, k); return b;      // (the block's nodes emitted by emit_param_pre)
     default: snprintf(b, sizeof(b), "aff_%d_%d", site, k); return b;   // computed into a local just before use
   }
 }
@@ -571,8 +613,68 @@ std::string xf_wrap(int xf, const std::string& e) {
   }
 }
 
+// GJX_P_EXPR: the nodes the output `out` depends on, as straight-line statements `const float <pfx><i> = ...;` (the compiler
+// schedules and merges them with the site's own arithmetic; values are in registers: val(slot) is `vfmt` with the slot number).
+// -> the set of emitted nodes.  The unary forms use the device header's helpers (the interpreter's expr_unary computes the same).
+std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_param& q, int out, const std::string& pfx, const char* ind,
+                                  const std::function<std::string(int)>& val) {
+  std::vector<char> need(q.n, 0);
+  need[out] = 1;
+  for (int i = out; i >= 0; --i) {
+    if (!need[i]) continue;
+    const ExprNode e = expr_node(prog, q, i);
+    switch (e.op) {
+      case GJX_E_CONST: case GJX_E_VALUE: case GJX_E_LINV: break;
+      case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: case GJX_E_GT: need[e.a] = need[e.b] = 1; break;
+      case GJX_E_WHERE: need[e.a] = need[e.b] = need[e.c] = 1; break;
+      case GJX_E_LINN: for (int t = 0; t < e.c; ++t) need[e.b + t] = 1; break;
+      default: need[e.a] = 1; break;
+    }
+  }
+  auto N = [&](int i) { return pfx + std::to_string(i); };
+  for (int i = 0; i <= out; ++i) {
+    if (!need[i]) continue;
+    const ExprNode e = expr_node(prog, q, i);
+    std::string r;
+    const std::string A = e.op >= GJX_E_ADD && e.op != GJX_E_LINV && e.op != GJX_E_LINN ? N(e.a) : "", B = N(e.b);
+    switch (e.op) {
+      case GJX_E_CONST: r = "TAB(" + std::to_string(e.a) + ")"; break;
+      case GJX_E_VALUE: r = val(e.a); break;
+      case GJX_E_ADD: r = A + " + " + B; break;
+      case GJX_E_SUB: r = A + " - " + B; break;
+      case GJX_E_MUL: r = A + " * " + B; break;
+      case GJX_E_DIV: r = A + " * fast_rcp(" + B + ")"; break;
+      case GJX_E_MAX: r = A + " >= " + B + " ? " + A + " : " + B; break;
+      case GJX_E_MIN: r = A + " <= " + B + " ? " + A + " : " + B; break;
+      case GJX_E_GT: r = A + " > " + B + " ? 1.0f : 0.0f"; break;
+      case GJX_E_WHERE: r = A + " != 0.0f ? " + B + " : " + N(e.c); break;
+      case GJX_E_LINV: {
+        r = "TAB(" + std::to_string(e.a) + ")";
+        for (int t = 0; t < e.c; ++t) r = "fmaf(TAB(" + std::to_string(e.a + 1 + t) + "), " + val(e.b + t) + ", " + r + ")";
+        break;
+      }
+      case GJX_E_LINN: {
+        r = "TAB(" + std::to_string(e.a) + ")";
+        for (int t = 0; t < e.c; ++t) r = "fmaf(TAB(" + std::to_string(e.a + 1 + t) + "), " + N(e.b + t) + ", " + r + ")";
+        break;
+      }
+      default: r = "expr_unary(" + std::to_string(e.op) + ", " + A + ")"; break;
+    }
+    o.f("%sconst float %s = %s;\n", ind, N(i).c_str(), r.c_str());
+  }
+  return need;
+}
+
 // statements that must precede the use of param_expr for element dx (affine accumulations)
 void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, const RollInfo& ri) {
+  if (q.op == GJX_P_EXPR) {
+    // (supported_sites: a block with several outputs only under literal element indices; no plate / roll remapping of its slots)
+    const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
+    const std::string pfx = "en_" + std::to_string(site) + "_" + std::to_string(k) + "_";
+    emit_expr_nodes(o, g_expr_prog, q, out, pfx, ind, [](int slot) { return "v[" + std::to_string(slot) + "][p]"; });
+    o.f("%sconst float ex_%d_%d = %s%d;\n", ind, site, k, pfx.c_str(), out);
+    return;
+  }
   if (q.op == GJX_P_VGATHER) {
     // row gi_ of a choice whose rows live in registers: registers cannot be indexed, n - 1 selects can (supported_sites: n len <= 32)
     const int e = q.len == 1 ? 0 : literal_index(dx) % q.len;
@@ -999,10 +1101,11 @@ void plan_program(const gjx_program* prog_in, int ppt_code, GenCtx& g, bool allo
   const bool mfma = ((ppt_code >> 8) & 1) != 0 && ppt == 1;
   Roll& roll = g.roll;
   Plan& pl = g.pl;
+  g_expr_prog = prog_in;
   // a Scan too long to unroll (or GJX_GEN_ROLL=1) is emitted as a loop over its steps when its descriptors are periodic
   g.px = plate_program(prog_in);
   const PlateXf& px = g.px;
-  if (allow_roll && !px.any && (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots))) roll = detect_roll(prog_in);
+  if (allow_roll && !px.any && (want_roll() || !supported_sites(prog_in->sites, prog_in->n_sites, prog_in->n_slots, prog_in))) roll = detect_roll(prog_in);
   g.eprog = *prog_in;
   gjx_program& eprog = g.eprog;
   if (roll.ok) { eprog.sites = roll.sites.data(); eprog.n_sites = (int)roll.sites.size(); eprog.n_slots = roll.n_regs; }
@@ -1675,6 +1778,7 @@ bool hmc_fold_ok(const gjx_program* p, int j, int k) {
     if (t.mode == GJX_MODE_OBS_TAB && hits(t.obs_off, is_categorical(t.kind) ? 1 : t.dim)) return false;
     for (int kk = 0; kk < (is_categorical(t.kind) ? 1 : n_params(t.kind)); ++kk) {
       const gjx_param& q = t.p[kk];
+      if (q.op == GJX_P_EXPR) return false;      // (a block may read any table entry: no folding beside it)
       if (q.op == GJX_P_CONST && hits(q.off, q.len)) return false;
       if (q.op == GJX_P_GATHER && hits(q.off, q.n * q.len)) return false;
       if (q.op == GJX_P_AFFINE) {
@@ -1705,6 +1809,7 @@ bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIR
 // roll: plan the program as a rolled Scan (tried when the straight-line plan does not fit)
 bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
   if (p->n_sites < 1 || p->n_slots < 1 || p->n_tab > kHmcMaxTab) return false;
+  g_expr_prog = p;
   HmcPlan pl;
   if (roll) {
     const Roll r = detect_roll(p, true);
@@ -1752,6 +1857,11 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
     if (big && (s.slot >= 0 || (s.flags & GJX_SITE_HMC_SELECTED))) return false;   // a rolled site reads its values from the table
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
+      if (q.op == GJX_P_EXPR) {      // forward nodes and the reverse sweep as straight-line code; straight-line programs only
+        if (ri.plate || pl.rolled || pl.plates || !expr_block_ok(p, q, pl.n_regs, s.dim) || (big && q.len != 1)) return false;
+        unrolled += q.n / 4;
+        continue;
+      }
       if (q.op < GJX_P_CONST || q.op > GJX_P_VGATHER) return false;
       if (q.op == GJX_P_AFFINE && (q.n < 1 || q.n > 64)) return false;
       if (big && q.op == GJX_P_VALUE && q.len != 1) return false;
@@ -1862,6 +1972,13 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         if (q.len == 1) o.f("%s  const float pre_%d = v[%d];\n", ind, k, q.slot);
         else o.f("%s  const float pre_%d = v[%d + %s];\n", ind, k, q.slot, e.c_str());   // (unrolled sites only: literal index)
         break;
+      case GJX_P_EXPR: {      // the block's nodes (kept: the reverse sweep below reads them)
+        const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
+        const std::string pfx = "en_" + std::to_string(k) + "_";
+        emit_expr_nodes(o, g_expr_prog, q, out, pfx, (std::string(ind) + "  ").c_str(), [](int slot) { return "v[" + std::to_string(slot) + "]"; });
+        o.f("%s  const float pre_%d = %s%d;\n", ind, k, pfx.c_str(), out);
+        break;
+      }
       case GJX_P_VGATHER: {   // row gi_ of a choice in registers: n - 1 selects
         const int e0 = q.len == 1 ? 0 : literal_index(dx) % q.len;
         o.f("%s  float pre_%d = v[%d];\n", ind, k, q.moff + e0);
@@ -1893,9 +2010,71 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
   }
   for (int k = 0; k < np; ++k) {
     const gjx_param& q = s.p[k];
-    if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE && q.op != GJX_P_VGATHER) continue;
+    if (q.op != GJX_P_VALUE && q.op != GJX_P_AFFINE && q.op != GJX_P_VGATHER && q.op != GJX_P_EXPR) continue;
     const std::string w = q.xf == GJX_XF_NONE ? "gp_[" + std::to_string(k) + "]"
                                               : "(gp_[" + std::to_string(k) + "] * xf_deriv(" + std::to_string(q.xf) + ", pre_" + std::to_string(k) + "))";
+    if (q.op == GJX_P_EXPR) {
+      // reverse sweep through the block (hmc.py:70-96: selection_gradient differentiates whatever the body computes): one adjoint
+      // per node on a path from a SELECTED leaf to the output, everything else is never emitted
+      const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
+      const std::string pfx = "en_" + std::to_string(k) + "_", ad = "ad_" + std::to_string(k) + "_";
+      std::vector<char> need(q.n, 0), live(q.n, 0);     // need: feeds the output; live: depends on a selected value
+      need[out] = 1;
+      for (int i = out; i >= 0; --i) {
+        if (!need[i]) continue;
+        const ExprNode e = expr_node(g_expr_prog, q, i);
+        switch (e.op) {
+          case GJX_E_CONST: case GJX_E_VALUE: case GJX_E_LINV: break;
+          case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: case GJX_E_GT: need[e.a] = need[e.b] = 1; break;
+          case GJX_E_WHERE: need[e.a] = need[e.b] = need[e.c] = 1; break;
+          case GJX_E_LINN: for (int t = 0; t < e.c; ++t) need[e.b + t] = 1; break;
+          default: need[e.a] = 1; break;
+        }
+      }
+      for (int i = 0; i <= out; ++i) {
+        if (!need[i]) continue;
+        const ExprNode e = expr_node(g_expr_prog, q, i);
+        switch (e.op) {
+          case GJX_E_CONST: case GJX_E_GT: break;
+          case GJX_E_VALUE: live[i] = hp.sel_of_slot[e.a] >= 0; break;
+          case GJX_E_LINV: for (int t = 0; t < e.c; ++t) live[i] = live[i] || hp.sel_of_slot[e.b + t] >= 0; break;
+          case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: live[i] = live[e.a] || live[e.b]; break;
+          case GJX_E_WHERE: live[i] = live[e.b] || live[e.c]; break;
+          case GJX_E_LINN: for (int t = 0; t < e.c; ++t) live[i] = live[i] || live[e.b + t]; break;
+          default: live[i] = live[e.a]; break;
+        }
+      }
+      if (!live[out]) continue;
+      auto N = [&](int i) { return pfx + std::to_string(i); };
+      auto AD = [&](int i) { return ad + std::to_string(i); };
+      o.f("%s  {\n", ind);
+      for (int i = 0; i <= out; ++i) if (need[i] && live[i]) o.f("%s    float %s = %s;\n", ind, AD(i).c_str(), i == out ? w.c_str() : "0.0f");
+      for (int i = out; i >= 0; --i) {
+        if (!need[i] || !live[i]) continue;
+        const ExprNode e = expr_node(g_expr_prog, q, i);
+        const std::string gi = AD(i);
+        auto add = [&](int to, const std::string& term) { if (live[to]) o.f("%s    %s += %s;\n", ind, AD(to).c_str(), term.c_str()); };
+        switch (e.op) {
+          case GJX_E_VALUE: o.f("%s    %s[%d] += %s;\n", ind, acc, hp.sel_of_slot[e.a], gi.c_str()); break;
+          case GJX_E_LINV:
+            for (int t = 0; t < e.c; ++t) if (hp.sel_of_slot[e.b + t] >= 0)
+              o.f("%s    %s[%d] = fmaf(%s, TAB(%d), %s[%d]);\n", ind, acc, hp.sel_of_slot[e.b + t], gi.c_str(), e.a + 1 + t, acc, hp.sel_of_slot[e.b + t]);
+            break;
+          case GJX_E_ADD: add(e.a, gi); add(e.b, gi); break;
+          case GJX_E_SUB: add(e.a, gi); add(e.b, "-" + gi); break;
+          case GJX_E_MUL: add(e.a, gi + " * " + N(e.b)); add(e.b, gi + " * " + N(e.a)); break;
+          case GJX_E_DIV: add(e.a, gi + " * fast_rcp(" + N(e.b) + ")"); add(e.b, "-" + gi + " * " + N(i) + " * fast_rcp(" + N(e.b) + ")"); break;
+          case GJX_E_MAX: add(e.a, N(e.a) + " >= " + N(e.b) + " ? " + gi + " : 0.0f"); add(e.b, N(e.a) + " >= " + N(e.b) + " ? 0.0f : " + gi); break;
+          case GJX_E_MIN: add(e.a, N(e.a) + " <= " + N(e.b) + " ? " + gi + " : 0.0f"); add(e.b, N(e.a) + " <= " + N(e.b) + " ? 0.0f : " + gi); break;
+          case GJX_E_WHERE: add(e.b, N(e.a) + " != 0.0f ? " + gi + " : 0.0f"); add(e.c, N(e.a) + " != 0.0f ? 0.0f : " + gi); break;
+          case GJX_E_LINN: for (int t = 0; t < e.c; ++t) add(e.b + t, gi + " * TAB(" + std::to_string(e.a + 1 + t) + ")"); break;
+          case GJX_E_CONST: case GJX_E_GT: break;
+          default: add(e.a, gi + " * expr_unary_deriv(" + std::to_string(e.op) + ", " + N(e.a) + ", " + N(i) + ")"); break;
+        }
+      }
+      o.f("%s  }\n", ind);
+      continue;
+    }
     if (mf && k == mf->k) {
       o.f("%s  %s = %s;\n", ind, mf->wout.c_str(), w.c_str());
     } else if (q.op == GJX_P_VGATHER) {   // the gradient goes to the picked row
@@ -2015,6 +2194,7 @@ void hmc_emit_mfma_site(Emit& o, const gjx_program* prog, const HmcPlan& hp, int
 std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   HmcPlan hp;
   if (!hmc_plan(prog_in, &hp)) return "";
+  g_expr_prog = prog_in;
   // the emitted program: the plan's site list (plates: every slot a register, a body site owns one instance's worth)
   gjx_program eprog = *prog_in;
   eprog.sites = hp.sites.data();
@@ -2091,6 +2271,12 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
         if (q.op == GJX_P_VALUE && hp.sel_of_slot[q.slot] >= 0) touched[hp.sel_of_slot[q.slot]] = 1;
         if (q.op == GJX_P_AFFINE) for (int e = 0; e < q.n; ++e) if (hp.sel_of_slot[q.slot + e] >= 0) touched[hp.sel_of_slot[q.slot + e]] = 1;
         if (q.op == GJX_P_VGATHER) for (int e = 0; e < q.n * q.len; ++e) if (hp.sel_of_slot[q.moff + e] >= 0) touched[hp.sel_of_slot[q.moff + e]] = 1;
+        if (q.op == GJX_P_EXPR)
+          for (int i = 0; i < q.n; ++i) {
+            const ExprNode e = expr_node(g_expr_prog, q, i);
+            if (e.op == GJX_E_VALUE && hp.sel_of_slot[e.a] >= 0) touched[hp.sel_of_slot[e.a]] = 1;
+            if (e.op == GJX_E_LINV) for (int t = 0; t < e.c; ++t) if (hp.sel_of_slot[e.b + t] >= 0) touched[hp.sel_of_slot[e.b + t]] = 1;
+          }
       }
       for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? QSUM(ga[%d]) : ga[%d];\n", m, m, m);
       o.f("    if (SC) sc_ += CPL > 1 ? QSUM(scp_) : scp_;\n");
@@ -2407,17 +2593,30 @@ struct ProgMeta { bool roll_pref; uint64_t sites_hash; int supported; int slots;
 std::mutex g_meta_mu;
 std::unordered_map<int32_t, ProgMeta> g_meta;
 
+// the site list AND the expression blocks its GJX_P_EXPR parameters name (node lists are structure: gjx.h)
+uint64_t sites_hash_uncached(const gjx_program* p) {
+  uint64_t h = fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites);
+  if (p->tab)
+    for (int j = 0; j < p->n_sites; ++j)
+      for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
+        const gjx_param& q = p->sites[j].p[k];
+        if (p->sites[j].mode != GJX_MODE_INPUT && q.op == GJX_P_EXPR && q.off >= 0 && q.n > 0 && q.off + 4 * q.n <= p->n_tab)
+          h = fnv1a(p->tab + q.off, sizeof(float) * 4 * (size_t)q.n, h);
+      }
+  return h | 1ull;
+}
+
 ProgMeta* meta_of(const gjx_program* p) {      // call with g_meta_mu held; nullptr when the program has no uid
   if (p->uid == 0) return nullptr;
   ProgMeta& m = g_meta[p->uid];
-  if (m.sites_hash == 0 || m.roll_pref != want_roll()) m = ProgMeta{want_roll(), fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites) | 1ull, -1, -1};
+  if (m.sites_hash == 0 || m.roll_pref != want_roll()) m = ProgMeta{want_roll(), sites_hash_uncached(p), -1, -1};
   return &m;
 }
 
 uint64_t sites_hash(const gjx_program* p) {
   std::lock_guard<std::mutex> lock(g_meta_mu);
   if (ProgMeta* m = meta_of(p)) return m->sites_hash;
-  return fnv1a(p->sites, sizeof(gjx_site) * (size_t)p->n_sites) | 1ull;
+  return sites_hash_uncached(p);
 }
 
 bool supported(const gjx_program* p) {
@@ -2436,7 +2635,7 @@ int register_slots(const gjx_program* p) {
   int slots = p->n_slots;
   const PlateXf px = plate_program(p);
   if (px.any) slots = px.n_regs;
-  else if (want_roll() || !supported_sites(p->sites, p->n_sites, p->n_slots)) {
+  else if (want_roll() || !supported_sites(p->sites, p->n_sites, p->n_slots, p)) {
     const Roll r = detect_roll(p);
     if (r.ok) slots = r.n_pre + 2 * r.S;
   }

@@ -404,6 +404,112 @@ GJX_DEV int vgather_row(const gjx_param& p, int d, const float* __restrict__ tab
   idx = idx < 0 ? 0 : (idx > p.n - 1 ? p.n - 1 : idx);
   return p.moff + inst * p.d_moff + idx * p.len + (p.len == 1 ? 0 : d % p.len);
 }
+// ---- GJX_P_EXPR (gjx.h): a block of scalar SSA nodes in the table, node i = tab[off + 4 i ..] = {op, a, b, c}.  The site
+// interpreters evaluate the block into a per-lane array (dynamic indexing: scratch memory — this is the fallback engine; generated
+// kernels emit the nodes as straight-line code, gjx_codegen.hip emit_expr_nodes) and sweep it backwards for gradients.
+GJX_DEV float expr_tanh(float x) {
+  const float e = fast_exp(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * fast_rcp(1.0f + e);
+  return x < 0.0f ? -t : t;
+}
+GJX_DEV float expr_unary(int op, float x) {
+  switch (op) {
+    case GJX_E_NEG: return -x;
+    case GJX_E_EXP: return fast_exp(x);
+    case GJX_E_LOG: return fast_log(x);
+    case GJX_E_SQRT: return fast_sqrt(x);
+    case GJX_E_SQUARE: return x * x;
+    case GJX_E_TANH: return expr_tanh(x);
+    case GJX_E_SIGMOID: return fast_rcp(1.0f + fast_exp(-x));
+    case GJX_E_SOFTPLUS: return fmaxf(x, 0.0f) + log1p_acc(fast_exp(-fabsf(x)));
+    case GJX_E_ABS: return fabsf(x);
+    case GJX_E_SIN: return sinf(x);
+    case GJX_E_COS: return cosf(x);
+    case GJX_E_LOG1P: return log1p_acc(x);
+    default: return fast_rcp(x);   // GJX_E_RECIP
+  }
+}
+// d unary(x) / dx given x and y = unary(x)
+GJX_DEV float expr_unary_deriv(int op, float x, float y) {
+  switch (op) {
+    case GJX_E_NEG: return -1.0f;
+    case GJX_E_EXP: return y;
+    case GJX_E_LOG: return fast_rcp(x);
+    case GJX_E_SQRT: return 0.5f * fast_rcp(y);
+    case GJX_E_SQUARE: return 2.0f * x;
+    case GJX_E_TANH: return 1.0f - y * y;
+    case GJX_E_SIGMOID: return y * (1.0f - y);
+    case GJX_E_SOFTPLUS: return fast_rcp(1.0f + fast_exp(-x));
+    case GJX_E_ABS: return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    case GJX_E_SIN: return cosf(x);
+    case GJX_E_COS: return -sinf(x);
+    case GJX_E_LOG1P: return fast_rcp(1.0f + x);
+    default: return -y * y;        // GJX_E_RECIP
+  }
+}
+template <class ValFn>
+GJX_DEV void expr_forward(const gjx_param& p, const float* __restrict__ tab, ValFn&& val, int inst, float* __restrict__ ev) {
+  const float* __restrict__ nd = tab + p.off;
+  const int n = p.n < GJX_EXPR_MAX_NODES ? p.n : GJX_EXPR_MAX_NODES;
+  for (int i = 0; i < n; ++i) {
+    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    float r;
+    switch (op) {
+      case GJX_E_CONST: r = tab[a + inst * b]; break;
+      case GJX_E_VALUE: r = val(a + inst * b); break;
+      case GJX_E_ADD: r = ev[a] + ev[b]; break;
+      case GJX_E_SUB: r = ev[a] - ev[b]; break;
+      case GJX_E_MUL: r = ev[a] * ev[b]; break;
+      case GJX_E_DIV: r = ev[a] * fast_rcp(ev[b]); break;
+      case GJX_E_MAX: r = ev[a] >= ev[b] ? ev[a] : ev[b]; break;
+      case GJX_E_MIN: r = ev[a] <= ev[b] ? ev[a] : ev[b]; break;
+      case GJX_E_GT: r = ev[a] > ev[b] ? 1.0f : 0.0f; break;
+      case GJX_E_WHERE: r = ev[a] != 0.0f ? ev[b] : ev[c]; break;
+      case GJX_E_LINV: { r = tab[a]; for (int e = 0; e < c; ++e) r = fmaf(tab[a + 1 + e], val(b + e), r); break; }
+      case GJX_E_LINN: { r = tab[a]; for (int e = 0; e < c; ++e) r = fmaf(tab[a + 1 + e], ev[b + e], r); break; }
+      default: r = expr_unary(op, ev[a]); break;
+    }
+    ev[i] = r;
+  }
+}
+// element d of the parameter: output node n - len + d % len
+GJX_DEV int expr_out_node(const gjx_param& p, int d) { return p.n - p.len + (p.len == 1 ? 0 : d % p.len); }
+template <class ValFn>
+GJX_DEV float expr_eval(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst) {
+  float ev[GJX_EXPR_MAX_NODES];
+  expr_forward(p, tab, val, inst, ev);
+  return ev[expr_out_node(p, d)];
+}
+// reverse sweep: adjoint g of output element d flows to the gradient rows G.at(slot) of the block's VALUE / LINV leaves
+template <class ValFn, class Rows>
+GJX_DEV void expr_backward(const gjx_param& p, int d, float g, const float* __restrict__ tab, ValFn&& val, int inst, Rows G) {
+  float ev[GJX_EXPR_MAX_NODES], ad[GJX_EXPR_MAX_NODES];
+  expr_forward(p, tab, val, inst, ev);
+  const float* __restrict__ nd = tab + p.off;
+  const int n = p.n < GJX_EXPR_MAX_NODES ? p.n : GJX_EXPR_MAX_NODES;
+  for (int i = 0; i < n; ++i) ad[i] = 0.0f;
+  ad[expr_out_node(p, d)] = g;
+  for (int i = n - 1; i >= 0; --i) {
+    const float gi = ad[i];
+    if (gi == 0.0f) continue;
+    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    switch (op) {
+      case GJX_E_CONST: case GJX_E_GT: break;
+      case GJX_E_VALUE: G.at(a + inst * b) += gi; break;
+      case GJX_E_ADD: ad[a] += gi; ad[b] += gi; break;
+      case GJX_E_SUB: ad[a] += gi; ad[b] -= gi; break;
+      case GJX_E_MUL: ad[a] = fmaf(gi, ev[b], ad[a]); ad[b] = fmaf(gi, ev[a], ad[b]); break;
+      case GJX_E_DIV: { const float rb = fast_rcp(ev[b]); ad[a] = fmaf(gi, rb, ad[a]); ad[b] = fmaf(-gi * ev[i], rb, ad[b]); break; }
+      case GJX_E_MAX: if (ev[a] >= ev[b]) ad[a] += gi; else ad[b] += gi; break;
+      case GJX_E_MIN: if (ev[a] <= ev[b]) ad[a] += gi; else ad[b] += gi; break;
+      case GJX_E_WHERE: if (ev[a] != 0.0f) ad[b] += gi; else ad[c] += gi; break;
+      case GJX_E_LINV: for (int e = 0; e < c; ++e) G.at(b + e) += gi * tab[a + 1 + e]; break;
+      case GJX_E_LINN: for (int e = 0; e < c; ++e) ad[b + e] = fmaf(gi, tab[a + 1 + e], ad[b + e]); break;
+      default: ad[a] = fmaf(gi, expr_unary_deriv(op, ev[a], ev[i]), ad[a]); break;
+    }
+  }
+}
+
 template <class ValFn>
 GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict__ tab, ValFn&& val, int inst = 0) {
   const int off = p.off + inst * p.d_off, slot = p.slot + inst * p.d_slot;
@@ -422,6 +528,7 @@ GJX_DEV float eval_param_pre(const gjx_param& p, int d, const float* __restrict_
       return acc;
     }
     case GJX_P_VGATHER: return val(vgather_row(p, d, tab, val, inst));
+    case GJX_P_EXPR: return expr_eval(p, d, tab, val, inst);
     default: return __builtin_nanf("");
   }
 }

@@ -88,10 +88,12 @@ GJX_DEV float site_score_and_grad(const gjx_site& s, int inst, const float* __re
     for (int q = 0; q < np; ++q) {
       const gjx_param& p = s.p[q];
       float gp = gpar[q];
-      if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE && p.op != GJX_P_VGATHER)) continue;
+      if (gp == 0.0f || (p.op != GJX_P_VALUE && p.op != GJX_P_AFFINE && p.op != GJX_P_VGATHER && p.op != GJX_P_EXPR)) continue;
       if (p.xf != GJX_XF_NONE) gp *= xf_deriv(p.xf, pre[q]);
       const int ps = p.slot + inst * p.d_slot;
-      if (p.op == GJX_P_VGATHER) {
+      if (p.op == GJX_P_EXPR) {          // reverse sweep through the block to its VALUE leaves (hmc.py:70-96: grad through the body)
+        expr_backward(p, d, gp, tab, val, inst, G);
+      } else if (p.op == GJX_P_VGATHER) {
         G.at(vgather_row(p, d, tab, val, inst)) += gp;
       } else if (p.op == GJX_P_VALUE) {
         G.at(ps + (p.len == 1 ? 0 : d % p.len)) += gp;

@@ -22,12 +22,13 @@ from typing import Any, Callable, Sequence
 import numpy as np
 
 from . import _abi as A
+from . import expr as E
 from .core import ChoiceMap, Key, Masked, Selection, _VALUE, split
 from .program import MissingAddress, PackedProgram, Param, SiteList
 
 __all__ = [
     "gen", "StaticGenerativeFunction", "Trace", "Distribution", "take", "where", "cond", "const", "exp",
-    "softplus", "sigmoid", "normal", "flip", "bernoulli", "beta", "categorical", "uniform", "mv_normal_diag",
+    "softplus", "sigmoid", "tanh", "log", "sqrt", "square", "sin", "cos", "log1p", "maximum", "minimum", "dot", "normal", "flip", "bernoulli", "beta", "categorical", "uniform", "mv_normal_diag",
     "exponential", "half_normal", "laplace", "log_normal", "cauchy", "gamma", "Marginal", "ScanCombinator",
 ]
 
@@ -46,23 +47,116 @@ class Sym:
     def as_param(self) -> Param:  # pragma: no cover - abstract
         raise NotImplementedError
 
-    # arithmetic is defined on Affine; everything else lifts itself first
+    # Arithmetic tries the CLOSED forms first — affine maps of earlier choices, which the engines have fast paths for (Affine) — and
+    # falls back to a general elementwise expression (Expr -> GJX_P_EXPR: any computation between sites, static.py:383-399)
     def _affine(self) -> "Affine":
         raise NotSupportedInModelBody(f"arithmetic on {type(self).__name__} is not supported in a model body")
 
-    def __add__(self, o): return self._affine().add(o)
-    def __radd__(self, o): return self._affine().add(o)
-    def __sub__(self, o): return self._affine().add(_neg(o))
-    def __rsub__(self, o): return self._affine().scale(-1.0).add(o)
-    def __mul__(self, o): return self._affine().mul(o)
-    def __rmul__(self, o): return self._affine().mul(o)
-    def __truediv__(self, o): return self._affine().mul(1.0 / np.asarray(o, np.float64))
-    def __neg__(self): return self._affine().scale(-1.0)
-    def __rmatmul__(self, o): return self._affine().lmatmul(o)
+    def _expr(self) -> "Expr":
+        raise NotSupportedInModelBody(f"arithmetic on {type(self).__name__} is not supported in a model body")
+
+    def _try(self, closed, general):
+        try:
+            return closed()
+        except NotSupportedInModelBody:
+            return general()
+
+    def __add__(self, o): return self._try(lambda: self._affine().add(o), lambda: _ebin("add", self, o))
+    def __radd__(self, o): return self._try(lambda: self._affine().add(o), lambda: _ebin("add", o, self))
+    def __sub__(self, o): return self._try(lambda: self._affine().add(_neg(o)), lambda: _ebin("sub", self, o))
+    def __rsub__(self, o): return self._try(lambda: self._affine().scale(-1.0).add(o), lambda: _ebin("sub", o, self))
+    def __mul__(self, o): return self._try(lambda: self._affine().mul(o), lambda: _ebin("mul", self, o))
+    def __rmul__(self, o): return self._try(lambda: self._affine().mul(o), lambda: _ebin("mul", o, self))
+
+    def __truediv__(self, o):
+        if isinstance(o, Sym):
+            return _ebin("div", self, o)
+        return self._try(lambda: self._affine().mul(1.0 / np.asarray(o, np.float64)), lambda: _ebin("div", self, o))
+
+    def __rtruediv__(self, o): return _ebin("div", o, self)
+    def __neg__(self): return self._try(lambda: self._affine().scale(-1.0), lambda: _eun("neg", self))
+    def __rmatmul__(self, o): return self._try(lambda: self._affine().lmatmul(o), lambda: self._expr().lmatmul(o))
+
+    def __matmul__(self, o):                # x @ w (a dot product); x @ W == W.T @ x
+        o = np.asarray(o, np.float64)
+        return self.__rmatmul__(o if o.ndim == 1 else o.T)
+
+    def __pow__(self, k):
+        k = float(k)
+        if k == 1.0:
+            return self
+        if k == 2.0:
+            return _eun("square", self)
+        if k == 0.5:
+            return _eun("sqrt", self)
+        if k == -1.0:
+            return _eun("recip", self)
+        if k == 3.0:
+            return _ebin("mul", _eun("square", self), self)
+        return _eun("exp", _ebin("mul", _eun("log", self), k))
+
+    # comparisons give 0 / 1 values (for where(...)); no gradient flows through them (jax.grad of a comparison)
+    def __gt__(self, o): return _ebin("gt", self, o)
+    def __lt__(self, o): return _ebin("gt", o, self)
+    def __ge__(self, o): return _ebin("sub", 1.0, _ebin("gt", o, self))
+    def __le__(self, o): return _ebin("sub", 1.0, _ebin("gt", self, o))
 
 
 def _neg(o):
     return -o if isinstance(o, Sym) else -np.asarray(o, np.float64)
+
+
+def _to_expr(x) -> "Expr":
+    if isinstance(x, Sym):
+        return x._expr()
+    return Expr([E.const(v) for v in np.atleast_1d(np.asarray(x, np.float64)).ravel()])
+
+
+def _ebin(op: str, a, b) -> "Expr":
+    """elementwise binary op on general expressions (length-1 operands broadcast)"""
+    a, b = _to_expr(a), _to_expr(b)
+    n = max(a.dim, b.dim)
+    if a.dim not in (1, n) or b.dim not in (1, n):
+        raise NotSupportedInModelBody(f"cannot broadcast expressions of {a.dim} and {b.dim} elements")
+    f = {"add": E.add, "sub": E.sub}.get(op, lambda x, y: E.binary(op, x, y))
+    return Expr([f(a.elems[i % a.dim], b.elems[i % b.dim]) for i in range(n)])
+
+
+def _eun(op: str, a) -> "Expr":
+    a = _to_expr(a)
+    return Expr([E.unary(op, e) for e in a.elems])
+
+
+class Expr(Sym):
+    """A vector of general elementwise expressions of earlier choices and constants (expr.py): products of choices, arithmetic
+    after transforms, tanh / log / sqrt / ..., comparisons and where, matrix products of such vectors.  As a distribution parameter
+    it lowers to GJX_P_EXPR — emitted inline by the generated kernels, evaluated by the interpreters and the oracle, differentiated
+    in reverse by the HMC engines; as a return value it is evaluated from the trace."""
+
+    def __init__(self, elems):
+        self.elems = list(elems)
+        self.dim = len(self.elems)
+
+    def _expr(self) -> "Expr":
+        return self
+
+    def __getitem__(self, i):
+        e = np.asarray(range(self.dim))[i]
+        return Expr([self.elems[int(j)] for j in np.atleast_1d(e)])
+
+    def lmatmul(self, o) -> "Expr":
+        o = np.atleast_2d(np.asarray(o, np.float64))
+        if o.shape[1] != self.dim:
+            raise NotSupportedInModelBody(f"matrix of shape {o.shape} times an expression of {self.dim} elements")
+        return Expr([E.lin(0.0, [(self.elems[c], o[r, c]) for c in range(self.dim)]) for r in range(o.shape[0])])
+
+    def as_param(self) -> Param:
+        if all(E.is_const(e) for e in self.elems):
+            return Param.const([e[1] for e in self.elems])
+        return Param.expr(self.elems)
+
+    def __repr__(self):
+        return f"<expression of {self.dim} element(s) over {E.sources(self.elems)!r}>"
 
 
 class HostExpr(Sym):
@@ -134,6 +228,8 @@ class Affine(Sym):
             if isinstance(o, HostExpr):
                 a0 = self
                 return HostExpr(lambda ev: ev(a0) + ev(o))
+            if isinstance(o, Expr):
+                raise NotSupportedInModelBody("affine + general expression")            # (-> the general expression)
             o = o._affine()
             m = max(self.dim, o.dim)
             a, c = self._bcast(m), o._bcast(m)
@@ -148,10 +244,17 @@ class Affine(Sym):
     def scale(self, s: float):
         return self._map(lambda M: M * s, self.b * s)
 
+    def _expr(self) -> Expr:
+        rows = []
+        for r in range(self.dim):
+            terms = [(E.value(addr, c), M[r, c]) for addr, (sv, M) in self.terms.items() for c in range(M.shape[1]) if M[r, c] != 0.0]
+            rows.append(E.lin(self.b[r], terms))
+        op = {A.XF_EXP: "exp", A.XF_SOFTPLUS: "softplus", A.XF_SIGMOID: "sigmoid"}.get(self.xf)
+        return Expr([E.unary(op, e) for e in rows] if op else rows)
+
     def mul(self, o):
         if isinstance(o, Sym):
-            a0 = self
-            return HostExpr(lambda ev: ev(a0) * ev(o))
+            raise NotSupportedInModelBody("a product of choices is not affine")        # (Sym.__mul__ then takes the general expression)
         o = np.atleast_1d(np.asarray(o, np.float64)).ravel()
         a = self._bcast(max(self.dim, o.size))
         return a._map(lambda M: M * o[:, None], a.b * o)
@@ -196,10 +299,13 @@ class SiteVal(Sym):
             raise NotSupportedInModelBody("arithmetic on a categorical index; use take(table, idx)")
         return Affine(self, np.eye(self.dim), np.zeros(self.dim))
 
+    def _expr(self) -> Expr:
+        return Expr([E.value(self.addr, e) for e in range(self.dim)])
+
     def __getitem__(self, i):
         if isinstance(i, SiteVal):          # mu[z]: a row of this choice picked by a discrete choice
             return take(self, i)
-        return self._affine()[i]
+        return self._try(lambda: self._affine()[i], lambda: self._expr()[i])
 
     def as_param(self) -> Param:
         return Param.value(self.addr, length=self.dim)
@@ -256,59 +362,123 @@ def take(table, idx, rows: int | None = None):
     return Gather(np.asarray(table, np.float32), idx)
 
 
-def where(flag, if_true, if_false) -> Gather:
-    """``jnp.where(flag, a, b)`` / ``jax.lax.cond(flag, lambda: a, lambda: b)`` on constants."""
-    a, b = np.atleast_1d(np.asarray(if_true, np.float32)), np.atleast_1d(np.asarray(if_false, np.float32))
-    return take(np.stack([np.broadcast_to(b, np.broadcast(a, b).shape), np.broadcast_to(a, np.broadcast(a, b).shape)]), flag)
+def where(flag, if_true, if_false):
+    """``jnp.where(flag, a, b)`` / ``jax.lax.cond(flag, lambda: a, lambda: b)``: on constants picked by a boolean choice a table
+    gather (the closed form); with a computed condition (``x > 0``) or branches that depend on choices a general expression"""
+    if isinstance(flag, SiteVal) and not isinstance(if_true, Sym) and not isinstance(if_false, Sym):
+        a, b = np.atleast_1d(np.asarray(if_true, np.float32)), np.atleast_1d(np.asarray(if_false, np.float32))
+        return take(np.stack([np.broadcast_to(b, np.broadcast(a, b).shape), np.broadcast_to(a, np.broadcast(a, b).shape)]), flag)
+    if not isinstance(flag, Sym):
+        c = np.asarray(flag)
+        if c.ndim == 0:
+            return if_true if bool(c) else if_false
+    c, a, b = _to_expr(flag), _to_expr(if_true), _to_expr(if_false)
+    n = max(c.dim, a.dim, b.dim)
+    if any(x.dim not in (1, n) for x in (c, a, b)):
+        raise NotSupportedInModelBody("where: operands do not broadcast")
+    return Expr([E.where(c.elems[i % c.dim], a.elems[i % a.dim], b.elems[i % b.dim]) for i in range(n)])
 
 
-def cond(flag, true_fn, false_fn) -> Gather:
+def cond(flag, true_fn, false_fn):
     t = true_fn() if callable(true_fn) else true_fn
     f = false_fn() if callable(false_fn) else false_fn
     return where(flag, t, f)
 
 
-def array(items) -> "Affine | np.ndarray":
-    """``jnp.array([0.0, y])`` inside a model body: a vector whose entries are numbers and scalar affine
-    expressions of earlier sites."""
+def array(items) -> "Affine | Expr | np.ndarray":
+    """``jnp.array([0.0, y])`` inside a model body: a vector whose entries are numbers and scalar expressions of earlier sites
+    (affine entries keep the closed form; anything else makes it a general expression)"""
     items = list(items)
     if not any(isinstance(it, Sym) for it in items):
         return np.asarray(items, np.float32)
-    n = len(items)
-    terms: dict = {}
-    b = np.zeros(n, np.float64)
-    for r, it in enumerate(items):
-        if not isinstance(it, Sym):
-            b[r] = float(it)
-            continue
-        a = it._affine()
-        if a.dim != 1:
-            raise NotSupportedInModelBody("array([...]): entries must be scalars")
-        b[r] = a.b[0]
-        for addr, (sv, M) in a.terms.items():
-            if addr not in terms:
-                terms[addr] = (sv, np.zeros((n, sv.dim), np.float64))
-            terms[addr][1][r] = M[0]
-    return Affine(terms, b=b)
+    try:
+        n = len(items)
+        terms: dict = {}
+        b = np.zeros(n, np.float64)
+        for r, it in enumerate(items):
+            if not isinstance(it, Sym):
+                b[r] = float(it)
+                continue
+            a = it._affine()
+            if a.dim != 1:
+                raise NotSupportedInModelBody("array([...]): entries must be scalars")
+            b[r] = a.b[0]
+            for addr, (sv, M) in a.terms.items():
+                if addr not in terms:
+                    terms[addr] = (sv, np.zeros((n, sv.dim), np.float64))
+                terms[addr][1][r] = M[0]
+        return Affine(terms, b=b)
+    except NotSupportedInModelBody:
+        es = []
+        for it in items:
+            e = _to_expr(it)
+            if e.dim != 1:
+                raise NotSupportedInModelBody("array([...]): entries must be scalars")
+            es.append(e.elems[0])
+        return Expr(es)
 
 
-def _xf(x, code: int, fn: Callable):
+def _xf(x, code: int, fn: Callable, name: str):
     if isinstance(x, Gather):
         if x.xf != A.XF_NONE:
-            raise NotSupportedInModelBody("nested transforms")
+            raise NotSupportedInModelBody("nested transforms of a table gather")
         return Gather(x.table, x.idx, code)
     if isinstance(x, VGather):
         if x.xf != A.XF_NONE:
-            raise NotSupportedInModelBody("nested transforms")
+            raise NotSupportedInModelBody("nested transforms of a row gather")
         return x.with_xf(code)
     if isinstance(x, Sym):
-        return x._affine().with_xf(code)
+        # one transform on top of an affine map is a closed form (GJX_XF_*); anything else a general expression
+        return x._try(lambda: x._affine().with_xf(code), lambda: _eun(name, x))
     return fn(np.asarray(x, np.float64))
 
 
-def exp(x): return _xf(x, A.XF_EXP, np.exp)
-def softplus(x): return _xf(x, A.XF_SOFTPLUS, lambda v: np.logaddexp(0.0, v))
-def sigmoid(x): return _xf(x, A.XF_SIGMOID, lambda v: 1.0 / (1.0 + np.exp(-v)))
+def _fn(name: str, fn: Callable):
+    def f(x):
+        return _eun(name, x) if isinstance(x, Sym) else fn(np.asarray(x, np.float64))
+    f.__name__ = name
+    f.__doc__ = f"``jnp.{name}`` of numbers or of expressions of earlier choices (a general expression: GJX_P_EXPR)"
+    return f
+
+
+def exp(x): return _xf(x, A.XF_EXP, np.exp, "exp")
+def softplus(x): return _xf(x, A.XF_SOFTPLUS, lambda v: np.logaddexp(0.0, v), "softplus")
+def sigmoid(x): return _xf(x, A.XF_SIGMOID, lambda v: 1.0 / (1.0 + np.exp(-v)), "sigmoid")
+
+
+tanh = _fn("tanh", np.tanh)
+log = _fn("log", np.log)
+sqrt = _fn("sqrt", np.sqrt)
+square = _fn("square", np.square)
+sin = _fn("sin", np.sin)
+cos = _fn("cos", np.cos)
+log1p = _fn("log1p", np.log1p)
+abs_ = _fn("abs", np.abs)
+
+
+def maximum(a, b):
+    return _ebin("max", a, b) if isinstance(a, Sym) or isinstance(b, Sym) else np.maximum(a, b)
+
+
+def minimum(a, b):
+    return _ebin("min", a, b) if isinstance(a, Sym) or isinstance(b, Sym) else np.minimum(a, b)
+
+
+def dot(a, b):
+    """``jnp.dot`` of a constant vector / matrix and a vector of expressions (either order), or of two expression vectors"""
+    if isinstance(a, Sym) and isinstance(b, Sym):
+        ea, eb = _to_expr(a), _to_expr(b)
+        if ea.dim != eb.dim:
+            raise NotSupportedInModelBody("dot: lengths differ")
+        acc = E.binary("mul", ea.elems[0], eb.elems[0])
+        for x, y in zip(ea.elems[1:], eb.elems[1:]):
+            acc = E.add(acc, E.binary("mul", x, y))
+        return Expr([acc])
+    if isinstance(b, Sym):
+        return np.asarray(a, np.float64) @ b
+    if isinstance(a, Sym):
+        return a @ np.asarray(b, np.float64)
+    return np.dot(a, b)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -510,6 +680,13 @@ class Trace:
                 idx = self._site_value(x.idx.addr).long()
                 out = torch.as_tensor(x.table, device=idx.device)[idx]
                 return out[..., 0] if x.dim == 1 else out
+            if isinstance(x, Expr):
+                def leaf(addr, elem):
+                    v = self._site_value(addr).float()
+                    return v if self.prog.site_list[addr].dim == 1 else v[..., elem]
+                outs = [E._as_arr(o, torch, self.score) * torch.ones_like(self.score if self.batched else self.score[0])
+                        for o in E.evaluate(x.elems, leaf, torch)]
+                return outs[0] if x.dim == 1 else torch.stack(outs, dim=-1)
             if isinstance(x, HostExpr):
                 return x.fn(ev)
             if isinstance(x, (tuple, list)):

@@ -102,6 +102,9 @@ class ScanBootstrapFilter:
                 import dataclasses
                 if p.op == A.P_CONST:
                     return p
+                if p.op == A.P_EXPR:
+                    from .. import expr as E
+                    return dataclasses.replace(p, outs=tuple(E.rewrite_leaves(p.outs, lambda a_, e_: E.value(("@q", a_), e_) if a_ in q_here else None)))
                 if p.terms:
                     return dataclasses.replace(p, terms=[((("@q", a_) if a_ in q_here else a_), m) for a_, m in p.terms],
                                                src=("@q", p.src) if p.src in q_here else p.src)
@@ -113,7 +116,7 @@ class ScanBootstrapFilter:
                 qa = ("@q", s.addr)
                 ns = Site(qa, s.kind, [q_param(fold_known(p, known, rows)) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
-                    for a_ in ([a for a, _ in p.terms] if p.terms else (([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src]) if p.op != A.P_CONST else [])):
+                    for a_ in p.sources():
                         if a_ not in step_sl:
                             raise NotImplementedError(f"ScanBootstrapFilter: proposal site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
                 step_sl.sites.append(ns)
@@ -124,7 +127,7 @@ class ScanBootstrapFilter:
                 rows = s.ncat if s.ncat else s.dim
                 ns = Site(s.addr, s.kind, [fold_known(p, known, rows) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
-                    for a_ in ([a for a, _ in p.terms] if p.terms else (([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src]) if p.op != A.P_CONST else [])):
+                    for a_ in p.sources():
                         if a_ not in step_sl:
                             raise NotImplementedError(f"ScanBootstrapFilter: site {s.addr!r} reads {a_!r}, which is neither of this step nor of the one before")
                 step_sl.sites.append(ns)

@@ -44,6 +44,24 @@ class Param:
     vsrc_elem: int = 0
     vn: int = 0
     vlen: int = 1
+    # EXPR (gjx.h GJX_P_EXPR): the output nodes of a general elementwise expression (expr.py); len(outs) = 1 or the site's dim
+    outs: tuple | None = None
+
+    @staticmethod
+    def expr(outs, xf=A.XF_NONE) -> "Param":
+        """a general elementwise expression of earlier choices and constants: ``outs`` = its output nodes (expr.py)"""
+        return Param(A.P_EXPR, outs=tuple(outs), xf=xf)
+
+    def sources(self) -> list:
+        """addresses of the choices this parameter reads"""
+        if self.op == A.P_CONST:
+            return []
+        if self.op == A.P_EXPR:
+            from . import expr as E
+            return E.sources(self.outs)
+        if self.terms:
+            return [a for a, _ in self.terms]
+        return [self.src, self.vsrc] if self.op == A.P_VGATHER else [self.src]
 
     @staticmethod
     def const(v, xf=A.XF_NONE) -> "Param":
@@ -158,6 +176,8 @@ class SiteList:
                 ncat = int((p0.terms[0][1] if p0.terms else p0.matrix).shape[0])
             elif p0.op == A.P_VGATHER:
                 ncat = int(p0.vlen)
+            elif p0.op == A.P_EXPR:
+                ncat = len(p0.outs)
             else:
                 ncat = int(p0.length)
             dim = 1
@@ -172,6 +192,8 @@ class SiteList:
                     dim = max(dim, int(p.values.shape[1]))
                 elif p.op == A.P_VGATHER:
                     dim = max(dim, int(p.vlen))
+                elif p.op == A.P_EXPR:
+                    dim = max(dim, len(p.outs))
                 elif p.op == A.P_AFFINE:
                     dim = max(dim, int((p.terms[0][1] if p.terms else p.matrix).shape[0]))
         if kind == A.DIRICHLET and int(dim) > 256:
@@ -245,6 +267,11 @@ def compact_plates(sl: SiteList, modes: dict, obs: dict, selected: Sequence, dra
         """a parameter of a site OUTSIDE the plates that reads a compacted instance: read the device site at the instance's offset"""
         if p.op == A.P_CONST:
             return p
+        if p.op == A.P_EXPR:            # leaves that name a compacted instance: the device site at the instance's offset
+            from . import expr as E
+            if not any(a_ in where for a_ in p.sources()):
+                return p
+            return dataclasses.replace(p, outs=tuple(E.rewrite_leaves(p.outs, lambda a_, e_: E.value(where[a_][0], e_ + where[a_][1]) if a_ in where else None)))
         if p.terms:
             if not any(a_ in where for a_, _ in p.terms):
                 return p
@@ -325,6 +352,14 @@ def fold_known(p: Param, known: dict, rows: int) -> Param:
     terms.  ``rows``: the reading site's event size."""
     if p.op == A.P_CONST:
         return p
+    if p.op == A.P_EXPR:
+        from . import expr as E
+        if not any(a_ in known for a_ in p.sources()):
+            return p
+        outs = E.rewrite_leaves(p.outs, lambda a_, e_: E.const(np.asarray(known[a_], np.float64).ravel()[e_]) if a_ in known else None)
+        if all(E.is_const(n) for n in outs):
+            return Param.const([n[1] for n in outs], xf=p.xf)
+        return dataclasses.replace(p, outs=tuple(outs))
     if p.terms:
         if not any(a_ in known for a_, _ in p.terms):
             return p
@@ -405,6 +440,8 @@ def _try_plate(group, names, n: int, modes: dict, obs: dict, sel: set, where: di
             ps = [s.params[k] for s in col]
             if any(q.op != p0.op or q.xf != p0.xf or bool(q.terms) != bool(p0.terms) for q in ps):
                 return None
+            if p0.op == A.P_EXPR:
+                return None                 # (a vmapped kernel with expression blocks stays unrolled: always correct)
             d_elem, src, elem0 = 0, None, 0
             if p0.op != A.P_CONST and not p0.terms:
                 rs = [source(q.src, l, i) for i, q in enumerate(ps)]
@@ -477,6 +514,8 @@ def _try_compact(group, names, n: int, modes: dict, obs: dict, sel: set, where: 
         d = s0.dim
         if s0.kind in (A.CATEGORICAL_LOGITS, A.CATEGORICAL_PROBS, A.DIRICHLET) or s0.ncat:
             return None
+        if any(q.op == A.P_EXPR for s in col for q in s.params):
+            return None                     # (expression blocks: instances stay unrolled or take the plate form)
         if any(q.op != A.P_CONST and (q.src in where or (q.terms and any(a_ in where for a_, _ in q.terms))) for s in col for q in s.params):
             return None                     # reads instances of an earlier plate: the plate form expresses that
         mode0 = modes.get(s0.addr)
@@ -651,9 +690,12 @@ class PackedProgram:
                 cp = cs.p[k]
                 cp.op, cp.xf = p.op, p.xf
                 if p.op != A.P_CONST:
-                    for a_src in ([t[0] for t in p.terms] if p.terms else ([p.src, p.vsrc] if p.op == A.P_VGATHER else [p.src])):
+                    for a_src in p.sources():
                         if a_src not in order or order[a_src] >= j:
                             raise ValueError(f"site {s.addr!r} reads {a_src!r} before it is traced")
+                if p.op == A.P_EXPR:
+                    self._pack_expr(cp, p, s, rows, push)
+                    continue
                 if p.op == A.P_VGATHER:
                     self._pack_vgather(cp, p, s)
                     continue
@@ -759,6 +801,21 @@ class PackedProgram:
             self._folded_index = getattr(self, "_folded_index", set()) | {p.src}
             cp.op = A.P_CONST
             cp.off, cp.len = self.obs_off[p.vsrc] + p.vsrc_elem + idx * p.vlen, int(p.vlen)
+
+    def _pack_expr(self, cp, p: Param, s: Site, rows: int, push) -> None:
+        """GJX_P_EXPR: the expression's nodes as a block of float quadruples in the table (include/gjx.h).  Latent sources are read
+        from their rows; a source constrained to one shared value is read from ITS table entries (set_obs is seen without repacking)."""
+        from . import expr as E
+        if s.plate:
+            raise NotImplementedError("an expression block inside a plate site")        # (compact_plates keeps such kernels unrolled)
+        if len(p.outs) not in (1, rows):
+            raise ValueError(f"site {s.addr!r}: an expression parameter with {len(p.outs)} elements for an event of {rows}")
+
+        def place(addr, elem):
+            sl_ = self.slot_of[addr]
+            return ("slot", sl_ + elem) if sl_ >= 0 else ("tab", self.obs_off[addr] + elem)
+        nodes, n = E.lower(p.outs, place, push)
+        cp.op, cp.off, cp.n, cp.len = A.P_EXPR, push(nodes), int(n), len(p.outs)
 
     def _pack_affine_multi(self, cp, p: Param, s: Site, rows: int, push) -> None:
         ninst = s.plate_n if s.plate else 1

@@ -44,7 +44,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 8
+#define GJX_ABI_VERSION 9
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -57,8 +57,9 @@ typedef enum gjx_status {
 /* ---- model program ---------------------------------------------------------------------
  * A generative function in the reference is a Python function traced to a Jaxpr and
  * interpreted site by site (generative_functions/static.py:340-399).  Here it is an explicit
- * straight-line list of sites; "user code between sites" is restricted to the parameter
- * expression forms below (enough for every configuration in BASELINE.json).
+ * straight-line list of sites; "user code between sites" is one of the parameter
+ * expression forms below: five closed forms the engines have fast paths for, and
+ * GJX_P_EXPR, a general elementwise expression block.
  */
 
 /* primitive distribution kinds — generative_functions/distributions/tensorflow_probability/__init__.py */
@@ -97,13 +98,45 @@ enum {
   GJX_P_VALUE = 1,  /* choices[slot + (d % len)][i]                                       */
   GJX_P_GATHER = 2, /* tab[off + clamp((int)choices[slot][i], 0, n-1) * len + (d % len)]  */
   GJX_P_AFFINE = 3, /* tab[off + (d % len)] + sum_{e<n} tab[moff + d*n + e] * choices[slot+e][i] */
-  GJX_P_VGATHER = 4 /* choices[moff + clamp(idx, 0, n-1) * len + (d % len)][i]: a row of an EARLIER vector-valued choice (first slot
+  GJX_P_VGATHER = 4,/* choices[moff + clamp(idx, 0, n-1) * len + (d % len)][i]: a row of an EARLIER vector-valued choice (first slot
                        `moff`, n rows of `len` values: the component means of a mixture with latent means, mu[z]) picked by a discrete
                        choice — idx = (int)choices[slot][i], or, slot < 0 (the index site is constrained to one value for every
                        particle and owns no storage), idx = (int)tab[off].  Differentiable in the picked row (gjx_hmc,
                        gjx_score_grad: the gradient goes to row moff + idx * len + d % len).  Plate strides: slot + i d_slot (or
                        off + i d_off), moff + i d_moff */
+  GJX_P_EXPR = 5    /* an expression block in the table: see "GJX_P_EXPR" below */
 };
+/* GJX_P_EXPR (ABI 9) — ANY elementwise computation between sites.  The reference stages the whole @gen body and interprets whatever
+ * JAX computes between two trace sites (generative_functions/static.py:383-399, core/compiler/staging.py:286-298), and
+ * selection_gradient differentiates through it (inference/requests/hmc.py:70-96).  Here such a computation is a small SSA BLOCK of
+ * scalar nodes stored in the program's float table: node i is the four floats tab[off + 4 i .. off + 4 i + 3] = {op, a, b, c} (small
+ * integers held exactly in float32; a / b / c are node indices WITHIN the block — always smaller than i —, slots, table offsets or
+ * counts, by op).  gjx_param: op = GJX_P_EXPR, off = the block, n = its number of nodes (1 .. GJX_EXPR_MAX_NODES), len = number of
+ * outputs: the LAST len nodes (len = 1: one value for every element; else len = the site's dim and element d reads output d % len).
+ * xf still applies on top.  The node list is part of the program's STRUCTURE (generated kernels bake it in and the structure key
+ * hashes it); the constants and weights it refers to are ordinary table entries and may change like any table value.
+ * Plate instance i (gjx.h "Plates"): VALUE nodes read slot a + i * b, CONST nodes tab[a + i * b]; LIN nodes are not strided.
+ * Reverse mode (gjx_hmc, gjx_score_grad): the adjoint of the output flows back through the block to its VALUE leaves; CONST leaves,
+ * comparisons and the condition of a WHERE carry no gradient (jax.grad of jnp.where / lax.select, comparisons). */
+enum {
+  GJX_E_CONST = 0,    /* tab[a + inst * b]                                                              */
+  GJX_E_VALUE = 1,    /* choices[a + inst * b][i]                                                       */
+  GJX_E_ADD = 2,      /* node a + node b                                                                */
+  GJX_E_SUB = 3,      /* node a - node b                                                                */
+  GJX_E_MUL = 4,      /* node a * node b                                                                */
+  GJX_E_DIV = 5,      /* node a / node b                                                                */
+  GJX_E_NEG = 6,      /* -node a                                                                        */
+  GJX_E_EXP = 7, GJX_E_LOG = 8, GJX_E_SQRT = 9, GJX_E_SQUARE = 10, GJX_E_TANH = 11, GJX_E_SIGMOID = 12, GJX_E_SOFTPLUS = 13,
+  GJX_E_ABS = 14, GJX_E_SIN = 15, GJX_E_COS = 16, GJX_E_LOG1P = 17, GJX_E_RECIP = 18,   /* unary, of node a                */
+  GJX_E_MAX = 19,     /* max(node a, node b)   (gradient to the larger; to a at a tie)                   */
+  GJX_E_MIN = 20,     /* min(node a, node b)                                                            */
+  GJX_E_GT = 21,      /* node a > node b ? 1 : 0                                                        */
+  GJX_E_WHERE = 22,   /* node a != 0 ? node b : node c                                                  */
+  GJX_E_LINV = 23,    /* tab[a] + sum_{e < c} tab[a + 1 + e] * choices[b + e][i]: bias and weights contiguous in the table */
+  GJX_E_LINN = 24,    /* tab[a] + sum_{e < c} tab[a + 1 + e] * node (b + e)                              */
+  GJX_E_OP_MAX = 25
+};
+#define GJX_EXPR_MAX_NODES 96
 /* unary transform applied to the evaluated parameter */
 enum { GJX_XF_NONE = 0, GJX_XF_EXP = 1, GJX_XF_SOFTPLUS = 2, GJX_XF_SIGMOID = 3 };
 
@@ -141,10 +174,10 @@ enum { GJX_SITE_HMC_SELECTED = 1, /* gjx_site.flags: site is moved by gjx_hmc (h
 typedef struct gjx_param {
   int32_t op;   /* GJX_P_*  */
   int32_t xf;   /* GJX_XF_* */
-  int32_t off;  /* CONST: values; GATHER: table base; AFFINE: bias; VGATHER with slot < 0: the index (into tab) */
-  int32_t len;  /* CONST/VALUE: vector length (1 = broadcast); GATHER/VGATHER: row length; AFFINE: bias length */
+  int32_t off;  /* CONST: values; GATHER: table base; AFFINE: bias; VGATHER with slot < 0: the index (into tab); EXPR: the node block */
+  int32_t len;  /* CONST/VALUE: vector length (1 = broadcast); GATHER/VGATHER: row length; AFFINE: bias length; EXPR: outputs */
   int32_t slot; /* VALUE/AFFINE: first source slot; GATHER/VGATHER: slot holding the index     */
-  int32_t n;    /* AFFINE: inner length; GATHER/VGATHER: number of rows                        */
+  int32_t n;    /* AFFINE: inner length; GATHER/VGATHER: number of rows; EXPR: number of nodes */
   int32_t moff; /* AFFINE: matrix [dim][n] row-major (into tab); VGATHER: first SLOT of the indexed choice */
   /* plate strides (sites with gjx_site.plate != 0, see "Plates" below): instance i evaluates the parameter with
    * off + i * d_off, slot + i * d_slot, moff + i * d_moff.  All 0 outside plates and for what the instances share. */

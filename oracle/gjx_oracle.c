@@ -281,6 +281,98 @@ static int vgather_row(const gjx_param* p, int d, const float* tab, const float*
   return p->moff + idx * p->len + (d % p->len);
 }
 
+/* GJX_P_EXPR (gjx.h): the block of scalar SSA nodes tab[off + 4 i ..] = {op, a, b, c}; the reference interprets whatever JAX computes
+ * between two sites in float32 (static.py:383-399, staging.py:286-298) — every node here is evaluated in double and rounded to
+ * float32 once (a correctly rounded float32 operation).  `inst`: the plate instance (site_instance leaves it in pad_[0]). */
+static double expr_unary_d(int op, double x) {
+  switch (op) {
+    case GJX_E_NEG: return -x;
+    case GJX_E_EXP: return exp(x);
+    case GJX_E_LOG: return log(x);
+    case GJX_E_SQRT: return sqrt(x);
+    case GJX_E_SQUARE: return x * x;
+    case GJX_E_TANH: return tanh(x);
+    case GJX_E_SIGMOID: return 1.0 / (1.0 + exp(-x));
+    case GJX_E_SOFTPLUS: return (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x)));
+    case GJX_E_ABS: return fabs(x);
+    case GJX_E_SIN: return sin(x);
+    case GJX_E_COS: return cos(x);
+    case GJX_E_LOG1P: return log1p(x);
+    default: return 1.0 / x; /* GJX_E_RECIP */
+  }
+}
+static double expr_unary_deriv_d(int op, double x, double y) {
+  switch (op) {
+    case GJX_E_NEG: return -1.0;
+    case GJX_E_EXP: return y;
+    case GJX_E_LOG: return 1.0 / x;
+    case GJX_E_SQRT: return 0.5 / y;
+    case GJX_E_SQUARE: return 2.0 * x;
+    case GJX_E_TANH: return 1.0 - y * y;
+    case GJX_E_SIGMOID: return y * (1.0 - y);
+    case GJX_E_SOFTPLUS: return 1.0 / (1.0 + exp(-x));
+    case GJX_E_ABS: return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
+    case GJX_E_SIN: return cos(x);
+    case GJX_E_COS: return -sin(x);
+    case GJX_E_LOG1P: return 1.0 / (1.0 + x);
+    default: return -y * y; /* GJX_E_RECIP */
+  }
+}
+static void expr_forward(const gjx_param* p, const float* tab, const float* vals, float* ev) {
+  const float* nd = tab + p->off;
+  const int inst = p->pad_[0];
+  for (int i = 0; i < p->n && i < GJX_EXPR_MAX_NODES; ++i) {
+    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    double r;
+    switch (op) {
+      case GJX_E_CONST: r = tab[a + inst * b]; break;
+      case GJX_E_VALUE: r = vals[a + inst * b]; break;
+      case GJX_E_ADD: r = (double)ev[a] + ev[b]; break;
+      case GJX_E_SUB: r = (double)ev[a] - ev[b]; break;
+      case GJX_E_MUL: r = (double)ev[a] * ev[b]; break;
+      case GJX_E_DIV: r = (double)ev[a] / ev[b]; break;
+      case GJX_E_MAX: r = ev[a] >= ev[b] ? ev[a] : ev[b]; break;
+      case GJX_E_MIN: r = ev[a] <= ev[b] ? ev[a] : ev[b]; break;
+      case GJX_E_GT: decide(ev[a], ev[b]); r = ev[a] > ev[b] ? 1.0 : 0.0; break;   /* (a comparison: a near-tie may go the other way on the device) */
+      case GJX_E_WHERE: r = ev[a] != 0.0f ? ev[b] : ev[c]; break;
+      case GJX_E_LINV: r = tab[a]; for (int e = 0; e < c; ++e) r += (double)tab[a + 1 + e] * vals[b + e]; break;
+      case GJX_E_LINN: r = tab[a]; for (int e = 0; e < c; ++e) r += (double)tab[a + 1 + e] * ev[b + e]; break;
+      default: r = expr_unary_d(op, ev[a]); break;
+    }
+    ev[i] = (float)r;
+  }
+}
+static int expr_out_node(const gjx_param* p, int d) { return p->n - p->len + (d % p->len); }
+static void expr_backward(const gjx_param* p, int d, float g, const float* tab, const float* vals, float* grad) {
+  float ev[GJX_EXPR_MAX_NODES];
+  double ad[GJX_EXPR_MAX_NODES];
+  expr_forward(p, tab, vals, ev);
+  const float* nd = tab + p->off;
+  const int inst = p->pad_[0];
+  const int n = p->n < GJX_EXPR_MAX_NODES ? p->n : GJX_EXPR_MAX_NODES;
+  for (int i = 0; i < n; ++i) ad[i] = 0.0;
+  ad[expr_out_node(p, d)] = g;
+  for (int i = n - 1; i >= 0; --i) {
+    const double gi = ad[i];
+    if (gi == 0.0) continue;
+    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    switch (op) {
+      case GJX_E_CONST: case GJX_E_GT: break;
+      case GJX_E_VALUE: grad[a + inst * b] += (float)gi; break;
+      case GJX_E_ADD: ad[a] += gi; ad[b] += gi; break;
+      case GJX_E_SUB: ad[a] += gi; ad[b] -= gi; break;
+      case GJX_E_MUL: ad[a] += gi * ev[b]; ad[b] += gi * ev[a]; break;
+      case GJX_E_DIV: ad[a] += gi / ev[b]; ad[b] -= gi * ev[i] / ev[b]; break;
+      case GJX_E_MAX: if (ev[a] >= ev[b]) ad[a] += gi; else ad[b] += gi; break;
+      case GJX_E_MIN: if (ev[a] <= ev[b]) ad[a] += gi; else ad[b] += gi; break;
+      case GJX_E_WHERE: if (ev[a] != 0.0f) ad[b] += gi; else ad[c] += gi; break;
+      case GJX_E_LINV: for (int e = 0; e < c; ++e) grad[b + e] += (float)(gi * tab[a + 1 + e]); break;
+      case GJX_E_LINN: for (int e = 0; e < c; ++e) ad[b + e] += gi * tab[a + 1 + e]; break;
+      default: ad[a] += gi * expr_unary_deriv_d(op, ev[a], ev[i]); break;
+    }
+  }
+}
+
 static float eval_param(const gjx_param* p, int d, const float* tab, const float* vals) {
   float v;
   switch (p->op) {
@@ -300,6 +392,7 @@ static float eval_param(const gjx_param* p, int d, const float* tab, const float
       break;
     }
     case GJX_P_VGATHER: v = vals[vgather_row(p, d, tab, vals)]; break;
+    case GJX_P_EXPR: { float ev[GJX_EXPR_MAX_NODES]; expr_forward(p, tab, vals, ev); v = ev[expr_out_node(p, d)]; break; }
     default: v = NAN;
   }
   switch (p->xf) {
@@ -587,6 +680,7 @@ static float run_site(const gjx_program* prog, const gjx_site* s0, int inst, con
     for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
       s->p[k].off += inst * s->p[k].d_off; s->p[k].moff += inst * s->p[k].d_moff;
       if (s->p[k].slot >= 0) s->p[k].slot += inst * s->p[k].d_slot; /* (VGATHER with slot < 0: the index comes from the table) */
+      if (s->p[k].op == GJX_P_EXPR) { s->p[k].off = s0->p[k].off; s->p[k].pad_[0] = inst; }   /* a block's nodes carry their own strides */
     }
   }
   /* Mask(value, flag) is a per-particle lax.cond between the constrained and the unconstrained rule
@@ -1255,6 +1349,7 @@ static void param_backprop(const gjx_param* p, int d, float g, const float* tab,
       for (int e = 0; e < p->n; ++e) grad[p->slot + e] += g * tab[p->moff + d * p->n + e];
       break;
     case GJX_P_VGATHER: grad[vgather_row(p, d, tab, vals)] += g; break;
+    case GJX_P_EXPR: expr_backward(p, d, g, tab, vals, grad); break;
     default: break; /* CONST, GATHER: no float dependence */
   }
 }
@@ -1334,6 +1429,7 @@ static gjx_site site_instance(const gjx_site* s0, int inst) {
     for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
       sv.p[k].off += inst * sv.p[k].d_off; sv.p[k].moff += inst * sv.p[k].d_moff;
       if (sv.p[k].slot >= 0) sv.p[k].slot += inst * sv.p[k].d_slot;
+      if (sv.p[k].op == GJX_P_EXPR) { sv.p[k].off = s0->p[k].off; sv.p[k].pad_[0] = inst; }   /* the block's VALUE / CONST nodes carry their own strides (expr_forward) */
     }
   }
   return sv;

@@ -134,3 +134,65 @@ def scan_chain(T, rng=A.RNG_FLAT, carry=True, observe=False, sigma=0.1, r=0.5, s
             modes[("y", t)] = A.MODE_OBS_TAB
             obs[("y", t)] = ys[t]
     return PackedProgram(sl, modes, obs, rng_mode=rng), ys
+
+
+# ---------------------------------------------------------------------------------------------
+# random general expressions (GJX_P_EXPR): shared by the CPU tests of the oracle and the GPU differential tests
+# ---------------------------------------------------------------------------------------------
+def random_expr_outs(rs, cont, dim, dom="real", depth=3):
+    """`dim` output nodes (genjax_amd/expr.py) of a random elementwise expression over the elements of the earlier continuous sites
+    ``cont`` = [(addr, dim), ...] and constants.  Magnitudes stay bounded (every branch passes through tanh / sigmoid / sin or a
+    bounded rational form before it is combined), the final value lands in the domain the parameter needs: "real", "pos", "prob"."""
+    from genjax_amd import expr as E
+
+    def leaf():
+        if rs.random() < 0.25 or not cont:
+            return E.const(float(rs.standard_normal() * 0.7))
+        a, d = cont[int(rs.integers(len(cont)))]
+        return E.value(a, int(rs.integers(d)))
+
+    def bounded(n):          # any node -> (-1, 1)-ish
+        r = rs.random()
+        if r < 0.4:
+            return E.unary("tanh", n)
+        if r < 0.6:
+            return E.unary("sin", n)
+        if r < 0.8:
+            return E.lin(-1.0, [(E.unary("sigmoid", n), 2.0)])
+        return E.binary("div", n, E.lin(1.0, [(E.unary("square", n), 1.0)]))      # x / (1 + x^2)
+
+    def tree(d):
+        if d == 0:
+            return bounded(leaf())
+        r = rs.random()
+        a = tree(d - 1)
+        if r < 0.18:
+            return E.add(a, tree(d - 1))
+        if r < 0.3:
+            return E.sub(a, tree(d - 1))
+        if r < 0.5:
+            return E.binary("mul", a, tree(d - 1))
+        if r < 0.58:
+            return E.binary("max" if rs.random() < 0.5 else "min", a, tree(d - 1))
+        if r < 0.66:
+            return E.where(E.binary("gt", a, tree(d - 1)), tree(d - 1), a)
+        if r < 0.74:          # a small linear layer over several sub-expressions
+            k = int(rs.integers(2, 4))
+            return bounded(E.lin(float(rs.standard_normal() * 0.3), [(tree(d - 1), float(rs.standard_normal() * 0.8)) for _ in range(k)]))
+        if r < 0.8:
+            return E.unary("abs", a)
+        if r < 0.86:
+            return E.unary("log1p", E.unary("square", a))
+        if r < 0.92:
+            return E.unary("sqrt", E.lin(0.5, [(E.unary("square", a), 1.0)]))
+        return bounded(E.unary("exp", a))
+
+    outs = []
+    for _ in range(dim):
+        n = tree(int(rs.integers(1, depth + 1)))
+        if dom == "pos":
+            n = E.lin(0.25, [(E.unary("softplus", n), 1.0)]) if rs.random() < 0.5 else E.unary("exp", E.lin(0.0, [(bounded(n), 0.8)]))
+        elif dom == "prob":
+            n = E.lin(0.02, [(E.unary("sigmoid", n), 0.96)])
+        outs.append(n)
+    return outs

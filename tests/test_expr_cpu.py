@@ -1,0 +1,194 @@
+"""General expressions between sites (GJX_P_EXPR, include/gjx.h) — CPU tests: the tracer records them, the packer lowers them to
+valid node blocks, the oracle's restatement evaluates them like float64 NumPy and differentiates them like finite differences.
+(The device engines are compared with the oracle in tests/test_gpu_expr.py.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.stats as st
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import helpers as H                       # noqa: E402
+import genjax_amd as genjax               # noqa: E402
+from genjax_amd import _abi as A          # noqa: E402
+from genjax_amd import expr as E          # noqa: E402
+from genjax_amd.program import PackedProgram, Param, SiteList      # noqa: E402
+
+
+def _blocks(prog):
+    """[(site index, parameter index, nodes int[n][4], len)] of every expression block of a packed program"""
+    out = []
+    for j in range(prog.n_sites):
+        for k in range(A.MAX_PARAMS):
+            cp = prog.c_sites[j].p[k]
+            if cp.op == A.P_EXPR:
+                out.append((j, k, prog.tab[cp.off:cp.off + 4 * cp.n].reshape(-1, 4).astype(int), int(cp.len)))
+    return out
+
+
+def _check_block(prog, nodes, n_out):
+    """the invariants include/gjx.h states: SSA order, operands in range, LINN operands consecutive and earlier, outputs last"""
+    n = len(nodes)
+    assert 1 <= n <= A.EXPR_MAX_NODES and 1 <= n_out <= n
+    for i, (op, a, b, c) in enumerate(nodes):
+        assert 0 <= op < 25
+        if op == A.E_CONST:
+            assert 0 <= a < prog.tab.size and b == 0
+        elif op == A.E_VALUE:
+            assert 0 <= a < prog.n_slots and b == 0
+        elif op == A.E_LINV:
+            assert 1 <= c <= 64 and a + 1 + c <= prog.tab.size and 0 <= b and b + c <= prog.n_slots
+        elif op == A.E_LINN:
+            assert 1 <= c <= 64 and a + 1 + c <= prog.tab.size and 0 <= b and b + c <= i
+        elif op == A.E_WHERE:
+            assert 0 <= a < i and 0 <= b < i and 0 <= c < i
+        elif op in (A.E_ADD, A.E_SUB, A.E_MUL, A.E_DIV, A.E_MAX, A.E_MIN, A.E_GT):
+            assert 0 <= a < i and 0 <= b < i
+        else:
+            assert 0 <= a < i
+
+
+def test_tracer_records_general_expressions_and_keeps_the_closed_forms():
+    """VERDICT r05 'missing 1': normal(a * b, 1) and normal(0, exp(a) + 1) used to raise NotSupportedInModelBody.  Affine arithmetic
+    still lowers to the closed forms (the engines' fast paths); everything else to an expression block."""
+    W1, w2 = np.random.default_rng(0).standard_normal((8, 16)), np.random.default_rng(1).standard_normal(8)
+
+    @genjax.gen
+    def model():
+        a = genjax.normal(0.0, 1.0) @ "a"
+        b = genjax.normal(0.0, 1.0) @ "b"
+        x = genjax.mv_normal_diag(np.zeros(16, np.float32), np.ones(16, np.float32)) @ "x"
+        genjax.normal(a * b, 1.0) @ "prod"
+        genjax.normal(0.0, genjax.exp(a) + genjax.exp(b)) @ "sumexp"
+        genjax.normal(0.0, genjax.exp(a) + 1.0) @ "after_xf"
+        genjax.bernoulli(logits=w2 @ genjax.tanh(W1 @ x)) @ "mlp"
+        genjax.normal(genjax.where(a > b, a, b * b), genjax.sqrt(a * a + 1.0)) @ "where"
+        genjax.mv_normal_diag(x * x[0], np.ones(16, np.float32)) @ "vec"
+        genjax.normal(2.0 * a - b + 0.5, genjax.exp(0.3 * a)) @ "affine"           # closed forms: AFFINE, VALUE + GJX_XF_EXP
+        genjax.normal(a / 2.0, 1.0) @ "scaled"
+        return a * b
+
+    sl, ret = model.site_list(())
+    ops = {s.addr: [p.op for p in s.params] for s in sl.sites}
+    assert ops["prod"] == [A.P_EXPR, A.P_CONST] and ops["sumexp"] == [A.P_CONST, A.P_EXPR] and ops["after_xf"] == [A.P_CONST, A.P_EXPR]
+    assert ops["mlp"] == [A.P_EXPR] and ops["where"] == [A.P_EXPR, A.P_EXPR] and ops["vec"] == [A.P_EXPR, A.P_CONST]
+    assert ops["affine"] == [A.P_AFFINE, A.P_AFFINE] and sl["affine"].params[1].xf == A.XF_EXP and ops["scaled"][0] in (A.P_AFFINE, A.P_VALUE)
+    assert isinstance(ret, genjax.Expr) and E.sources(ret.elems) == ["a", "b"]
+    assert sl["vec"].dim == 16 and len(sl["vec"].params[0].outs) == 16
+    prog = PackedProgram(sl, {}, {})
+    blocks = _blocks(prog)
+    assert len(blocks) == 7
+    for j, k, nodes, n_out in blocks:
+        _check_block(prog, nodes, n_out)
+    by_site = {sl.sites[j].addr: nodes for j, k, nodes, n_out in blocks}
+    # the 16 -> 8 -> 1 network: 8 rows over the choice's 16 slots, 8 tanh, one row over those 8 nodes
+    mlp = by_site["mlp"]
+    assert len(mlp) == 17 and (mlp[:8, 0] == A.E_LINV).all() and (mlp[8:16, 0] == A.E_TANH).all() and tuple(mlp[16][[0, 2, 3]]) == (A.E_LINN, 8, 8)
+    np.testing.assert_allclose(prog.tab[mlp[0][1] + 1: mlp[0][1] + 17], W1[0].astype(np.float32))
+    assert len(by_site["prod"]) == 3
+
+
+def test_sources_constrained_to_a_shared_value_are_read_from_the_table_and_follow_set_obs():
+    @genjax.gen
+    def model():
+        a = genjax.normal(0.0, 1.0) @ "a"
+        b = genjax.normal(0.0, 1.0) @ "b"
+        genjax.normal(a * b, 1.0) @ "y"
+
+    sl, _ = model.site_list(())
+    prog = PackedProgram(sl, {"a": A.MODE_OBS_SLOT, "b": A.MODE_OBS_TAB, "y": A.MODE_OBS_TAB}, {"b": 2.0, "y": 1.0})
+    (j, k, nodes, n_out), = _blocks(prog)
+    assert sorted(nodes[:, 0].tolist()) == sorted([A.E_CONST, A.E_VALUE, A.E_MUL])                               # b is a table read
+    const_nodes = [nd for nd in nodes if nd[0] == A.E_CONST]
+    assert any(nd[1] == prog.obs_off["b"] for nd in const_nodes)
+    from oracle import cpu
+    ch = np.array([[0.7]], np.float32)
+    s1 = cpu.run_program(prog, (0, 1), 1, choices=ch)["score"][0]
+    prog.set_obs("b", 3.0)
+    s2 = cpu.run_program(prog, (0, 1), 1, choices=ch)["score"][0]
+    want = lambda bv: st.norm.logpdf(0.7) + st.norm.logpdf(bv) + st.norm.logpdf(1.0, 0.7 * bv, 1.0)       # noqa: E731
+    assert s1 == pytest.approx(want(2.0), rel=1e-5) and s2 == pytest.approx(want(3.0), rel=1e-5)
+
+
+def test_too_large_a_block_is_refused_with_a_message():
+    sl = SiteList()
+    sl.add("a", A.NORMAL, [0.0, 1.0])
+    n = E.value("a", 0)
+    for i in range(120):
+        n = E.unary("tanh", E.binary("mul", n, E.value("a", 0)))
+    sl.add("y", A.NORMAL, [Param.expr([n]), 1.0])
+    with pytest.raises(E.ExprTooLarge, match="more than"):
+        PackedProgram(sl, {}, {})
+
+
+def _program_with_random_expressions(rs, n_latent=3):
+    sl = SiteList()
+    cont = []
+    for j in range(n_latent):
+        d = int(rs.integers(1, 4))
+        if d == 1:
+            sl.add(f"x{j}", A.NORMAL, [0.0, 1.0])
+        else:
+            sl.add(f"x{j}", A.MVNORMAL_DIAG, [np.zeros(d, np.float32), np.ones(d, np.float32)], dim=d)
+        cont.append((f"x{j}", d))
+    d = int(rs.integers(1, 4))
+    loc = H.random_expr_outs(rs, cont, d if rs.random() < 0.6 else 1, "real")
+    sc = H.random_expr_outs(rs, cont, 1, "pos")
+    if d == 1:
+        sl.add("y", A.NORMAL, [Param.expr(loc[:1]), Param.expr(sc)])
+    else:
+        sl.add("y", A.MVNORMAL_DIAG, [Param.expr(loc), Param.expr(sc)], dim=d)
+    pr = H.random_expr_outs(rs, cont, 1, "prob")
+    sl.add("f", A.FLIP, [Param.expr(pr)])
+    return sl, cont, (loc, sc, pr, d)
+
+
+def _score64(sl, cont, parts, vals):
+    """float64 NumPy log-density of the program above at `vals` {addr: [dim][K]}: the reference the oracle is held to"""
+    loc, sc, pr, d = parts
+    leaf = lambda a, e: vals[a][e]                                     # noqa: E731
+    tot = sum(st.norm.logpdf(vals[a]).sum(axis=0) for a, _ in cont)
+    mu = np.stack([np.broadcast_to(m, vals["f"][0].shape) for m in E.evaluate(loc, leaf)])
+    sg = np.broadcast_to(E.evaluate(sc, leaf)[0], vals["f"][0].shape)
+    p = np.broadcast_to(E.evaluate(pr, leaf)[0], vals["f"][0].shape)
+    for e in range(d):
+        tot = tot + st.norm.logpdf(vals["y"][e], mu[e % len(loc)], sg)
+    return tot + np.where(vals["f"][0] != 0, np.log(p), np.log1p(-p))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_evaluates_blocks_like_float64_numpy_and_differentiates_them_like_finite_differences(seed):
+    from oracle import cpu
+    rs = np.random.default_rng(1000 + seed)
+    sl, cont, parts = _program_with_random_expressions(rs)
+    modes = {s.addr: A.MODE_OBS_SLOT for s in sl.sites}
+    prog = PackedProgram(sl, modes, {}, selected=tuple(a for a, _ in cont) + ("y",))
+    for j, k, nodes, n_out in _blocks(prog):
+        _check_block(prog, nodes, n_out)
+    K = 64
+    ch = (rs.standard_normal((prog.n_slots, K)) * 0.8).astype(np.float32)
+    ch[prog.slot_of["f"]] = rs.integers(0, 2, K)
+    vals = {s.addr: ch[prog.slot_of[s.addr]: prog.slot_of[s.addr] + s.dim].astype(np.float64) for s in sl.sites}
+    want = _score64(sl, cont, parts, vals)
+    got = cpu.run_program(prog, (0, 1), K, choices=ch)["score"]
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    # gradient rows of the selected sites: central differences of the float64 density (comparisons / where / max / min are piecewise:
+    # a particle that sits within the step of a switch is left out)
+    sc, g = cpu.score_grad(prog, ch)
+    np.testing.assert_allclose(sc, want, rtol=2e-5, atol=2e-5)
+    h = 1e-5
+    for a, d in cont + [("y", parts[3])]:
+        for e in range(d):
+            vp = {k_: v.copy() for k_, v in vals.items()}
+            vm = {k_: v.copy() for k_, v in vals.items()}
+            vp[a][e] += h
+            vm[a][e] -= h
+            fd = (_score64(sl, cont, parts, vp) - _score64(sl, cont, parts, vm)) / (2 * h)
+            vp[a][e] += 20 * h
+            vm[a][e] -= 20 * h
+            fd_wide = (_score64(sl, cont, parts, vp) - _score64(sl, cont, parts, vm)) / (42 * h)
+            smooth = np.abs(fd - fd_wide) < 1e-3 * (1.0 + np.abs(fd))
+            assert smooth.mean() > 0.9
+            np.testing.assert_allclose(g[prog.slot_of[a] + e][smooth], fd[smooth], rtol=2e-3, atol=2e-3)

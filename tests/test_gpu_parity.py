@@ -1080,7 +1080,8 @@ def test_masked_constraints_parity(K_, oracle, rng):
 
 
 def _random_program(rs, rng_mode):
-    """A random valid site program: every kind, parameters drawn from the five expression forms over earlier sites
+    """A random valid site program: every kind, parameters drawn from the six expression forms over earlier sites — the five closed
+    forms and general expression blocks (GJX_P_EXPR) —
     (positive / probability parameters go through exp / softplus / sigmoid), random constraint modes."""
     POS, PROB, REAL = "pos", "prob", "real"
     spec = {  # kind -> parameter domains
@@ -1122,9 +1123,12 @@ def _random_program(rs, rng_mode):
                 tab = rs.standard_normal((n, dim)).astype(np.float32) * 0.5
                 return Param.gather(tab, a, xf=xf)
             a, d = cont[int(rs.integers(len(cont)))]
-            if form < 0.8:
+            if form < 0.74:
                 return Param.value(a, length=1, elem=int(rs.integers(d)), xf=xf)
-            return Param.affine((rs.standard_normal((dim, d)) * 0.3).astype(np.float32), a, bias=base * 0.2, xf=xf)
+            if form < 0.87:
+                return Param.affine((rs.standard_normal((dim, d)) * 0.3).astype(np.float32), a, bias=base * 0.2, xf=xf)
+            # a general expression block over the earlier continuous sites (GJX_P_EXPR), the domain's transform on top of it
+            return Param.expr(H.random_expr_outs(rs, cont, dim if rs.random() < 0.5 else 1, "real", depth=2), xf=xf)
 
         sl.add(addr, kind, [param(dom) for dom in spec[kind]], dim=dim)
         # bounded-magnitude continuous values only feed later parameters (heavy tails would overflow exp())

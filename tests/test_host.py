@@ -167,8 +167,18 @@ def test_errors_mirror_the_reference():
         b = genjax.normal(0.0, 1.0) @ "b"
         _ = genjax.normal(a * b, 1.0) @ "c"
 
+    # (rounds 1-5 refused a product of choices; since ABI 9 it is a general expression block: tests/test_expr_cpu.py)
+    sl_, _ = nonlinear.site_list(())
+    assert sl_["c"].params[0].op == A.P_EXPR
+
+    @genjax.gen
+    def gather_arith():
+        z = genjax.categorical(np.zeros(3, np.float32)) @ "z"
+        a = genjax.normal(0.0, 1.0) @ "a"
+        _ = genjax.normal(genjax.take(np.arange(3.0), z) * a, 1.0) @ "c"     # arithmetic on a table gather: still not expressible
+
     with pytest.raises(TypeError):
-        nonlinear.site_list(())
+        gather_arith.site_list(())
     with pytest.warns(DeprecationWarning):                   # distribution.py:479-500
         genjax.categorical([0.0, 1.0])
     with pytest.raises(RuntimeError):
