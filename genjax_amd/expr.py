@@ -70,6 +70,13 @@ def binary(op: str, a: tuple, b: tuple) -> tuple:
         with np.errstate(all="ignore"):
             r = {"add": x + y, "sub": x - y, "mul": x * y, "div": x / y, "max": max(x, y), "min": min(x, y), "gt": float(x > y)}[op]
         return const(r)
+    if a == b:                      # the same node on both sides: decided here, not by a float comparison of a value with itself
+        if op in ("max", "min"):
+            return a
+        if op == "gt":
+            return const(0.0)
+        if op == "sub":
+            return const(0.0)
     if op == "add":
         if is_const(a) and a[1] == 0.0:
             return b

@@ -5,7 +5,7 @@ TAG=${1:-r03}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -
 : > $OUT/gputest_summary.txt
 for f in tests/test_gpu_*.py; do
   b=$(basename $f .py)
-  timeout 1200 python -m pytest $f -m gpu -q -x -s > $OUT/gputest_$b.txt 2>&1
+  timeout 1200 python -m pytest $f -m gpu -q -s > $OUT/gputest_$b.txt 2>&1
   echo "$b rc=$? $(grep -E "passed|failed|error|no tests ran" $OUT/gputest_$b.txt | tail -1)" >> $OUT/gputest_summary.txt
 done
 cat $OUT/gputest_summary.txt

@@ -151,12 +151,12 @@ def random_expr_outs(rs, cont, dim, dom="real", depth=3):
         a, d = cont[int(rs.integers(len(cont)))]
         return E.value(a, int(rs.integers(d)))
 
-    def bounded(n):          # any node -> (-1, 1)-ish
-        r = rs.random()
+    def bounded(n):          # any node -> (-1, 1)-ish, WELL CONDITIONED: no periodic or exploding function of an unbounded argument
+        r = rs.random()      # (sin(exp(a)) amplifies the last bit of the device's v_exp_f32 into an O(1) difference: not a parity question)
         if r < 0.4:
             return E.unary("tanh", n)
         if r < 0.6:
-            return E.unary("sin", n)
+            return E.unary("sin", E.lin(0.0, [(E.unary("tanh", n), 2.0)]))
         if r < 0.8:
             return E.lin(-1.0, [(E.unary("sigmoid", n), 2.0)])
         return E.binary("div", n, E.lin(1.0, [(E.unary("square", n), 1.0)]))      # x / (1 + x^2)
@@ -185,7 +185,7 @@ def random_expr_outs(rs, cont, dim, dom="real", depth=3):
             return E.unary("log1p", E.unary("square", a))
         if r < 0.92:
             return E.unary("sqrt", E.lin(0.5, [(E.unary("square", a), 1.0)]))
-        return bounded(E.unary("exp", a))
+        return bounded(E.unary("exp", bounded(a)))
 
     outs = []
     for _ in range(dim):

@@ -121,6 +121,11 @@ def test_rccl_two_ranks_exchange_equals_unsharded(spread, method):
 
 
 def _run_bench(extra_args, env_extra=None, timeout=900):
+    """-> the compact line bench.py prints LAST (what the driver parses: < 4 KB, parseable, roofline inside), with the full record it
+    points to (the side file) under "_full" """
+    import tempfile
+    side = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
+    extra_args = list(extra_args) + ["--extra-file", side]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -129,8 +134,14 @@ def _run_bench(extra_args, env_extra=None, timeout=900):
                          timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0], out.stdout[-2000:]
+    assert len(lines[0]) < 4096
+    rec = json.loads(lines[0])
+    assert rec["roofline"]["frac"] > 0 and "exchange_stats" not in rec["config"] and "extra" not in rec
+    with open(side) as f:
+        rec["_full"] = json.load(f)
+    os.unlink(side)
+    return rec
 
 
 def test_bench_launcher_spawns_its_own_ranks():
@@ -143,10 +154,14 @@ def test_bench_launcher_spawns_its_own_ranks():
     assert two["n_gpus"] == 2 and two["config"]["k_particles_total"] == 1 << 17
     # peer-mapped windows when the ranks can map each other's memory (always on one shared GPU), else the collective transport
     assert two["config"]["exchange"] in (("peer", "rccl") if multi else ("peer",))
+    # the line carries the summary of the exchange; every rank's view is in the full record
+    assert two["config"]["exchange_summary"]["transports_agree"] is True and two["config"]["exchange_summary"]["any_status_bit"] is False
+    full = two["_full"]["config"]["exchange_stats"]
+    assert len(full["per_rank"]) == 2
     if two["config"]["exchange"] == "rccl":
-        assert two["config"]["exchange_stats"]["rccl_ranks"] == 2
+        assert full["rccl_ranks"] == 2
     else:
-        assert two["config"]["exchange_stats"]["status"] == 0
+        assert full["status"] == 0
     # same global collection, same global stream: the log-ML estimates agree to LSE rounding
     assert abs(two["log_ml"] - one["log_ml"]) <= 2e-5 * abs(one["log_ml"])
 
