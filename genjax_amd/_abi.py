@@ -41,6 +41,7 @@ MODE_OBS_PROPOSED = 5
 RUN_LEAVE_TILES, RUN_TIME_DISPATCH, RUN_STORE_INPUTS = 1, 2, 4
 SITE_HMC_SELECTED = 1
 SITE_PROPOSAL = 2
+SITE_CARRIED = 4
 RNG_FLAT, RNG_JAX32 = 0, 1
 FLAT_SITE_SHIFT, FLAT_MAX_SITES = 22, 1023
 OP_RUN, OP_LSE, OP_PICK, OP_RESAMPLE, OP_HMC, OP_SSM = 1, 2, 3, 4, 5, 6
@@ -84,7 +85,7 @@ class GjxRunInfo(C.Structure):
 
 
 # gjx_scan_filter: flags, forms, options, record (include/gjx.h)
-FILTER_NO_WIDE, FILTER_NO_STEPS, FILTER_NO_ONE_LAUNCH, FILTER_TWO_LAUNCH, FILTER_MULTINOMIAL = 1, 2, 3, 4, 8
+FILTER_NO_WIDE, FILTER_NO_STEPS, FILTER_NO_ONE_LAUNCH, FILTER_TWO_LAUNCH, FILTER_MULTINOMIAL, FILTER_ABSOLUTE_INPUTS = 1, 2, 3, 4, 8, 16
 FILTER_FORM_TWO_LAUNCH, FILTER_FORM_PER_STEP, FILTER_FORM_STEPS, FILTER_FORM_WIDE = 0, 1, 2, 3
 FILTER_FORM_NAMES = {0: "two launches per step", 1: "one launch per step", 2: "steps kernel (256 threads x 4 particles)",
                      3: "filter kernel on the shared skeleton (16 waves per tile)"}

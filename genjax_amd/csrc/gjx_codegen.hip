@@ -849,8 +849,10 @@ void emit_site(Emit& o, Plan& pl, int j) {
       else o.f("      PLOOP v[%d][p] = a.in_rows ? LDIN(a.in_rows + (int64_t)%d * a.in_stride + src_[p]) : a.choices[(int64_t)%d * K + i0 + p];\n", s.slot + d,
                s.obs_off + d, ri.row + d);
     }
-    if (!pl.pf) {      // (the filter flavour stores its inputs behind the rejuvenation move, if any: generate_pf)
-      o.f("      if (a.in_rows && a.store_inputs) {\n");
+    if (pl.pf) {       // (the filter flavour stores its inputs behind the rejuvenation move, if any: generate_pf) — a CARRIED input here
+      if (s.flags & GJX_SITE_CARRIED) for (int d = 0; d < s.dim; ++d) o.f("      VSTORE(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
+    } else {
+      o.f("      if (a.in_rows && (a.store_inputs || %d)) {\n", (s.flags & GJX_SITE_CARRIED) ? 1 : 0);
       for (int d = 0; d < s.dim; ++d) o.f("        VSTORE1(a.choices + (int64_t)%d * K + i0, v[%d]);\n", ri.row + d, s.slot + d);
       o.f("      }\n");
     }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       for (int d = 0; d < s.dim; ++d) {
         const float v = a.in_rows ? a.in_rows[(int64_t)(s.obs_off + d) * a.in_stride + src_i] : ch[(int64_t)(s.slot + d) * K + ii];
         if (LDSV) vals_s[(s.slot + d) * 256 + threadIdx.x] = v;
-        if (a.in_rows && active && (!LDSV || a.store_inputs)) ch[(int64_t)(s.slot + d) * K + i] = v;
+        if (a.in_rows && active && (!LDSV || a.store_inputs || (s.flags & GJX_SITE_CARRIED))) ch[(int64_t)(s.slot + d) * K + i] = v;
       }
       if (a.site_scores && active) a.site_scores[(int64_t)j0 * K + i] = 0.0f;
       ++j0;

@@ -93,6 +93,11 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     for (int j = 0; j < p.n_sites; ++j) if (p.sites[j].mode == GJX_MODE_INPUT) n += p.sites[j].dim;
     return n;
   };
+  // GJX_FILTER_ABSOLUTE_INPUTS: an INPUT site's obs_off is the row of the previous step's WHOLE buffer (carried statics are read from
+  // its INPUT rows, the carry from its own rows); otherwise the row among the previous step's own rows, which sit behind its inputs
+  const bool abs_in = (fflags & GJX_FILTER_ABSOLUTE_INPUTS) != 0;
+  auto in_base = [&](const gjx_program& p) { return abs_in ? 0 : input_rows(p); };
+  if (abs_in && n_moves > 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: no rejuvenation move with carried static inputs (GJX_FILTER_ABSOLUTE_INPUTS)");
   gjx_run_opts o;
   gjx_run_resample rs;
   gjx_run_info info = {0, 0, 0}, prev = {0, 0, 0};
@@ -108,7 +113,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     for (int u = 2; u < T && same; ++u)
       same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
              steps[u].tab_dev != nullptr && gen_pf_same_kernel(&steps[1], &steps[u]);
-    if (input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) same = false;
+    if (!abs_in && input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) same = false;
     const size_t dyn = pf_core_dyn_lds((int)ntw);
     int spl = 0, grid = 0;
     const int spls[5] = {1, 2, 4, 8, 16};
@@ -161,8 +166,8 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       if (T > 2 && rows_of(2) == r0) { ga.rows_a = r0; ga.rows_b = r1; ga.rows_all = nullptr; ga.rows_step = 0; }
       else if (T == 2) { ga.rows_a = r0; ga.rows_b = r1; ga.rows_all = nullptr; ga.rows_step = 0; }
       else { ga.rows_a = nullptr; ga.rows_b = nullptr; ga.rows_all = r0; ga.rows_step = (int64_t)(r1 - r0); }
-      ga.in_row0_first = (int64_t)input_rows(steps[0]) * K;
-      ga.in_row0 = (int64_t)input_rows(steps[1]) * K;
+      ga.in_row0_first = (int64_t)in_base(steps[0]) * K;
+      ga.in_row0 = (int64_t)in_base(steps[1]) * K;
       ga.n_moves = n_moves; ga.move_scale = opts ? opts->move_scale : 0.0f; ga.acc_total = (opts && n_moves > 0) ? (unsigned long long*)opts->accepted_total : nullptr;
       if (ga.acc_total) {
         const hipError_t ez = hipMemsetAsync(ga.acc_total, 0, sizeof(unsigned long long), st0);
@@ -197,7 +202,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     int rc = GJX_EUNSUPPORTED;
     bool ran = false;
     if (t > 0) {
-      if (input_rows(pr) > steps[t - 1].n_slots - input_rows(steps[t - 1]))
+      if (!abs_in && input_rows(pr) > steps[t - 1].n_slots - input_rows(steps[t - 1]))
         return gjx_fail(GJX_EINVAL, "gjx_scan_filter: a step reads more carry rows than the step before it produced");
       const char* pws = ws_of(t - 1);
       const float* lw_prev = lw_of(t - 1);
@@ -205,7 +210,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       const uint64_t* tS = tiles ? (const uint64_t*)(pws + prev.tiles_offset) : nullptr;
       const int32_t* tE = tiles ? (const int32_t*)(tS + (K / 1024)) : nullptr;
       int32_t* anc_t = ancestors_all ? ancestors_all + (size_t)(t - 1) * (size_t)K : ancestors;
-      o.in_rows = in + (size_t)input_rows(steps[t - 1]) * (size_t)K;      // the rows the previous step's OWN sites wrote
+      o.in_rows = in + (size_t)in_base(steps[t - 1]) * (size_t)K;      // the rows the previous step's OWN sites wrote (abs_in: its whole buffer)
       o.in_stride = K;
       if (fused && tiles) {
         memset(&rs, 0, sizeof(rs));
@@ -248,7 +253,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
     finfo.launches += ran ? 1 : (t > 0 ? 2 : 1);
     if (t == 1) finfo.form = ran ? GJX_FILTER_FORM_PER_STEP : GJX_FILTER_FORM_TWO_LAUNCH;
     if (t == 1 && ran && T >= 4 && steps_area && info.engine == 4 && prev.tiles_offset != 0 && prev.n_partials == (int)nt &&
-        !(fflags & GJX_FILTER_NO_STEPS) && !gjx_plain_launches_forced()) {
+        !(fflags & GJX_FILTER_NO_STEPS) && !abs_in && !gjx_plain_launches_forced()) {
       bool same = true;
       for (int u = 2; u < T && same; ++u)
         same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&

@@ -189,11 +189,13 @@ class ParticleHistory:
 class BootstrapFilter:
     """SMC with the prior as proposal and systematic resampling before every propagate step.
     ``BootstrapFilter(LinearGaussianSSM(...), K)``: the hand-written kernels of BASELINE configs 3 / 4;
-    ``BootstrapFilter(kernel.scan(n=T), K)``: any Scan kernel (inference/scan_filter.py, gjx_scan_filter)."""
+    ``BootstrapFilter(kernel.scan(n=T), K)``: any Scan kernel (inference/scan_filter.py, gjx_scan_filter);
+    ``BootstrapFilter(model, K)`` with a ``@gen`` model whose body draws static parameters and then calls ONE ``kernel.scan(n=T)(...)``:
+    the parameters are drawn with step 0 and travel with the particles (``run(key, constraint, model_args)``)."""
 
     def __new__(cls, model, *args, **kwargs):
-        from ..gen import ScanCombinator
-        if isinstance(model, ScanCombinator):
+        from ..gen import ScanCombinator, StaticGenerativeFunction
+        if isinstance(model, (ScanCombinator, StaticGenerativeFunction)):      # (a @gen model whose body is sites in front of ONE Scan)
             from .scan_filter import ScanBootstrapFilter
             return ScanBootstrapFilter(model, *args, **kwargs)
         return super().__new__(cls)

@@ -45,8 +45,9 @@ class ScanBootstrapFilter:
         random-walk Metropolis steps that leave the previous step's posterior invariant (the reference's Rejuvenate with a symmetric
         proposal and the caller-side accept, requests/rejuvenate.py:70-94; generated from the step program, include/gjx.h
         gjx_filter_opts::n_moves); ``out["accepted_total"]`` counts the accepted moves of a run."""
-        if not isinstance(scan, ScanCombinator):
-            raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T)")
+        from ..gen import StaticGenerativeFunction
+        if not isinstance(scan, (ScanCombinator, StaticGenerativeFunction)):
+            raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T), or a @gen model whose body is sites in front of one kernel.scan(n=T)(...) call")
         if proposal is not None and not isinstance(proposal, ScanCombinator):
             raise TypeError("proposal must be q_step.scan(n=T)")
         self.scan, self.K = scan, int(k_particles)
@@ -64,10 +65,14 @@ class ScanBootstrapFilter:
         if len({(int(s.scan) & 0xFFFFFFFF) >> 20 for s in sl.sites}) > 1:
             raise NotImplementedError("ScanBootstrapFilter: the kernel contains a Scan of its own (its steps cannot be told from the filter's)")
         steps: list[list[Site]] = []
+        pre: list[Site] = []                  # sites in FRONT of the Scan: static parameters (Scan.generate is a callee of any @gen body, scan.py:237-294)
         for s in sl.sites:
             t = _step_of(s)
             if t < 0:
-                raise NotImplementedError("ScanBootstrapFilter: the model must be the Scan itself (no sites outside it)")
+                if steps:
+                    raise NotImplementedError("ScanBootstrapFilter: sites BEHIND the Scan are not filtered (sites in front of it are)")
+                pre.append(s)
+                continue
             while len(steps) <= t:
                 steps.append([])
             steps[t].append(s)
@@ -84,9 +89,44 @@ class ScanBootstrapFilter:
         progs = []
         prev_latent: list[Site] = []
         known: dict = {}                      # observed sites of the previous step: address -> value
+        # the sites in front of the Scan: observed ones are constants of every step; latent ones are drawn by step 0 and travel with
+        # the particle (GJX_SITE_CARRIED inputs of every later step, GJX_FILTER_ABSOLUTE_INPUTS)
+        known_static: dict = {}
+        statics: list[Site] = []
+        for s in pre:
+            found, cval = _constraint_value(constraint, s.addr)
+            if found:
+                sv, per = _value_rows(cval, s.dim)
+                if per is not None:
+                    raise NotImplementedError("ScanBootstrapFilter: observations are shared by the particles")
+                known_static[s.addr] = np.broadcast_to(sv, (s.dim,)).astype(np.float32)
+            else:
+                statics.append(s)
+        self._has_statics = bool(statics)
+        if statics and (self.proposal is not None or self.rejuvenate):
+            raise NotImplementedError("ScanBootstrapFilter: a model with latent sites in front of the Scan runs with the prior proposal and without moves")
+        n_lat0 = sum(s.dim for s in steps[0] if not _constraint_value(constraint, s.addr)[0]) if steps else 0
         for t, cur in enumerate(steps):
             step_sl = SiteList()
             modes, obs = {}, {}
+            if t == 0:
+                # step 0 runs the sites in front of the Scan as they are; with statics its rows are laid out like a later step's —
+                # [statics | as many unused rows as a step has carry rows | own] — so that ONE kernel serves steps 1 .. T-1
+                for s in pre:
+                    step_sl.sites.append(Site(s.addr, s.kind, list(s.params), s.dim, s.ncat, step_sl.n_slots, 0))
+                    step_sl.n_slots += s.dim
+                    if s.addr in known_static:
+                        modes[s.addr] = A.MODE_OBS_TAB
+                        obs[s.addr] = known_static[s.addr]
+                if statics and n_lat0:
+                    step_sl.sites.append(Site("@pad", A.NORMAL, [], n_lat0, 0, step_sl.n_slots, 0))
+                    step_sl.n_slots += n_lat0
+                    modes["@pad"] = A.MODE_INPUT
+            else:
+                for ps in statics:            # the statics first, then the carry: what this step may read, in ROW order of the step before
+                    step_sl.sites.append(Site(ps.addr, ps.kind, [], ps.dim, 0, step_sl.n_slots, 0))
+                    step_sl.n_slots += ps.dim
+                    modes[ps.addr] = A.MODE_INPUT
             for ps in prev_latent:            # the carry: what this step may read of step t-1, in that step's ROW order
                 w = ps.dim
                 step_sl.sites.append(Site(ps.addr, ps.kind, [], w, 0, step_sl.n_slots, 0))
@@ -95,6 +135,7 @@ class ScanBootstrapFilter:
             # the proposal's sites of this step: drawn, their log-density leaves the weight (GJX_SITE_PROPOSAL)
             q_here = {s.addr for s in q_steps[t]}
             q_names, proposed_by = [], {}
+            kn = {**known_static, **known}
 
             def q_param(p):
                 """a parameter of a proposal site: sources among the proposal's own sites of this step are renamed, the carry keeps
@@ -114,7 +155,7 @@ class ScanBootstrapFilter:
             for s in q_steps[t]:
                 rows = s.ncat if s.ncat else s.dim
                 qa = ("@q", s.addr)
-                ns = Site(qa, s.kind, [q_param(fold_known(p, known, rows)) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
+                ns = Site(qa, s.kind, [q_param(fold_known(p, kn, rows)) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
                     for a_ in p.sources():
                         if a_ not in step_sl:
@@ -125,7 +166,7 @@ class ScanBootstrapFilter:
             now_known, latent = {}, []
             for s in cur:
                 rows = s.ncat if s.ncat else s.dim
-                ns = Site(s.addr, s.kind, [fold_known(p, known, rows) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
+                ns = Site(s.addr, s.kind, [fold_known(p, kn, rows) for p in s.params], s.dim, s.ncat, step_sl.n_slots, 0)
                 for p in ns.params:
                     for a_ in p.sources():
                         if a_ not in step_sl:
@@ -149,7 +190,14 @@ class ScanBootstrapFilter:
             missing = q_here - {s.addr for s in cur}
             if missing:
                 raise ValueError(f"ScanBootstrapFilter: the proposal names {sorted(map(repr, missing))}, which the model's step does not have")
-            prog = PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False, proposal=q_names, proposed_by=proposed_by)
+            extra = {}
+            if statics and t > 0:
+                # absolute rows of the step before: a static sits where THAT step keeps it (its own rows in step 0, its stored INPUT
+                # rows later), the carry in that step's own rows
+                prev_prog = progs[-1]
+                extra = dict(carried=[ps.addr for ps in statics],
+                             input_row_of={ps.addr: prev_prog.slot_of[ps.addr] for ps in list(statics) + list(prev_latent)})
+            prog = PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False, proposal=q_names, proposed_by=proposed_by, **extra)
             progs.append(prog)
             # the next step reads this step's latent rows in ROW order (a proposed latent sits where its proposal site drew it)
             prev_latent = sorted(latent, key=lambda s_: prog.slot_of[s_.addr])
@@ -286,6 +334,8 @@ class ScanBootstrapFilter:
             raise NotImplementedError("run_peer: the sharded filter kernel has no resample-move yet (rejuvenate=...); run() on one GPU has")
         if self.resampler != "systematic":
             raise NotImplementedError("run_peer: the sharded filter kernel resamples systematically; resampler='multinomial' runs on one GPU only")
+        if getattr(self, "_has_statics", False):
+            raise NotImplementedError("run_peer: a model with latent sites in front of the Scan runs on one GPU")
         dev = ctx.device
         sk, dk = _run_keys(constraint, args, dev)
         c = self._cache
@@ -325,6 +375,8 @@ class ScanBootstrapFilter:
             fl |= A.FILTER_NO_WIDE
         if self.resampler == "multinomial":
             fl |= A.FILTER_MULTINOMIAL
+        if getattr(self, "_has_statics", False):
+            fl |= A.FILTER_ABSOLUTE_INPUTS
         o.flags = fl
         o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
         if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
@@ -356,11 +408,15 @@ class ScanBootstrapFilter:
         return int(kernels.workspace_status(b["ws"][off:], raise_on_error=False))
 
     def latent(self, out: dict, name) -> torch.Tensor:
-        """rows of the last step's choice ``name``: f32[dim][K]"""
+        """rows of the last step's choice ``name`` — or of the latent site ``name`` in FRONT of the Scan as the last step's particles
+        carry it (their weights are out["logw"]): f32[dim][K]"""
         p = out["programs"][-1]
-        for s in p.site_list.sites:
-            if _name(s.addr) == name and p.modes.get(s.addr) != A.MODE_INPUT and p.slot_of[s.addr] >= 0:
-                return out["choices"][p.slot_of[s.addr]: p.slot_of[s.addr] + s.dim]
+        for own in (True, False):
+            for s in p.site_list.sites:
+                is_in = p.modes.get(s.addr) == A.MODE_INPUT
+                carried = is_in and bool(p.c_sites[p.site_list._pos(s.addr)].flags & A.SITE_CARRIED)
+                if _name(s.addr) == name and p.slot_of[s.addr] >= 0 and ((own and not is_in) or (not own and carried)):
+                    return out["choices"][p.slot_of[s.addr]: p.slot_of[s.addr] + s.dim]
         raise KeyError(name)
 
 
@@ -383,6 +439,9 @@ class ScanHistory:
         p = self.programs[t]
         for s in p.site_list.sites:
             if _name(s.addr) == name and p.modes.get(s.addr) != A.MODE_INPUT and p.slot_of[s.addr] >= 0:
+                return p.slot_of[s.addr], s.dim
+        for s in p.site_list.sites:      # a static in front of the Scan: the step's stored (GJX_SITE_CARRIED) input rows
+            if _name(s.addr) == name and p.slot_of[s.addr] >= 0 and (p.c_sites[p.site_list._pos(s.addr)].flags & A.SITE_CARRIED):
                 return p.slot_of[s.addr], s.dim
         raise KeyError(name)
 

@@ -582,8 +582,12 @@ class PackedProgram:
     def __init__(self, sl: SiteList, modes: dict[str, int] | None = None,
                  obs: dict[str, Any] | None = None, selected: Sequence[str] = (),
                  rng_mode: int = A.RNG_FLAT, plates: bool | str = False,
-                 proposal: Sequence = (), proposed_by: dict | None = None):
-        """``plates``: lower the instances of vmapped kernels to vector sites (compact_plates).  The LOGICAL view stays
+                 proposal: Sequence = (), proposed_by: dict | None = None,
+                 carried: Sequence = (), input_row_of: dict | None = None):
+        """``carried``: GJX_MODE_INPUT sites flagged GJX_SITE_CARRIED (their gathered value is stored into their own rows: a value that
+        travels with the particle through a filter's steps); ``input_row_of``: address -> the row an INPUT site reads (gjx_site.obs_off;
+        default: the inputs' rows in site order, from 0) — with GJX_FILTER_ABSOLUTE_INPUTS the absolute row of the previous step's buffer.
+        ``plates``: lower the instances of vmapped kernels to vector sites (compact_plates).  The LOGICAL view stays
         per instance — ``site_list``, ``slot_of`` and ``obs_off`` answer for the addresses ``(name, i)`` — while the
         device program (``c_sites``, ``n_sites``) holds one site per kernel site; per-site scores are then per plate,
         so callers that need one score per instance pack without it."""
@@ -641,7 +645,7 @@ class PackedProgram:
         # Sites constrained to one shared value (OBS_TAB) own no row of choices[][]: their value
         # lives in tab and later sites read it from there.
         n_slots = 0
-        proposal, proposed_by = set(proposal), dict(proposed_by or {})
+        proposal, proposed_by, carried = set(proposal), dict(proposed_by or {}), set(carried)
         for s in sl.sites:
             if self.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_OBS_PROPOSED:
                 q = proposed_by.get(s.addr)
@@ -673,13 +677,14 @@ class PackedProgram:
             cs = self.c_sites[j]
             cs.kind, cs.dim, cs.slot, cs.ncat = s.kind, s.dim, self.slot_of[s.addr], s.ncat
             cs.mode = self.modes.get(s.addr, A.MODE_SAMPLE)
-            cs.flags = (A.SITE_HMC_SELECTED if s.addr in selected else 0) | (A.SITE_PROPOSAL if s.addr in proposal else 0)
+            cs.flags = ((A.SITE_HMC_SELECTED if s.addr in selected else 0) | (A.SITE_PROPOSAL if s.addr in proposal else 0)
+                        | (A.SITE_CARRIED if s.addr in carried else 0))
             cs.scan = int(s.scan)
             cs.plate, cs.plate_n = int(s.plate), int(s.plate_n)
             cs.obs_off = self.flag_slot_of[s.addr] if s.addr in self.flag_slot_of else self.obs_off.get(s.addr, 0)
             if cs.mode == A.MODE_INPUT:          # row of the site in the INPUT rows of gjx_run_program_ex (in_rows): inputs in site order
-                cs.obs_off = self.n_input_rows
-                self.input_row[s.addr] = self.n_input_rows
+                cs.obs_off = self.n_input_rows if not input_row_of or s.addr not in input_row_of else int(input_row_of[s.addr])
+                self.input_row[s.addr] = int(cs.obs_off)
                 self.n_input_rows += s.dim
             if s.plate:
                 cs.d_obs = 1 if cs.mode == A.MODE_OBS_MASK else (s.dim if cs.mode == A.MODE_OBS_TAB else 0)

@@ -169,7 +169,11 @@ enum { GJX_SITE_HMC_SELECTED = 1, /* gjx_site.flags: site is moved by gjx_hmc (h
         * its log-density is SUBTRACTED from the weight and is no part of the score: log w += log p - log q — proper weighting
         * (the reference's Marginal.random_weighted returns 0 here).  site_scores row: log q.  It takes a site number
         * like any site.  Accepted by gjx_run_program[_ex] and the filters built on it; not by gjx_hmc / gjx_score_grad. */
-       GJX_SITE_PROPOSAL = 2 };
+       GJX_SITE_PROPOSAL = 2,
+       /* a GJX_MODE_INPUT site whose gathered value is STORED into the site's own rows whenever it was read through in_rows
+        * (as GJX_RUN_STORE_INPUTS does for every input): a value that travels with the particle from step to step of a filter — a
+        * static parameter drawn in front of the Scan (GJX_FILTER_ABSOLUTE_INPUTS) */
+       GJX_SITE_CARRIED = 4 };
 
 typedef struct gjx_param {
   int32_t op;   /* GJX_P_*  */
@@ -746,7 +750,15 @@ enum { GJX_FILTER_NO_WIDE = 1,          /* not the 16-wave filter kernel        
         * bits(k_res_t, j) (gjx_resample_multinomial; k_res_t = the key whose first word feeds the systematic comb offset) and takes the
         * first particle whose cumulative fixed-point weight (GJX_WEIGHTS_GLOBAL_MAX, gjx_weight_cumsum) exceeds it.  Three plain
         * launches per step (prefix sums, draws + search, step); the workspace needs 8 K + 256 bytes beyond OP_RUN + OP_RESAMPLE. */
-       GJX_FILTER_MULTINOMIAL = 8 };
+       GJX_FILTER_MULTINOMIAL = 8,
+       /* A model that is MORE than the Scan: latent sites in front of it (static parameters, `phi ~ beta(...)` before the state-space
+        * Scan; Scan.generate is a callee of any @gen body, scan.py:237-294) are drawn by step 0 and travel with the particle: every
+        * later step receives them as GJX_MODE_INPUT sites flagged GJX_SITE_CARRIED — gathered through the ancestors like the carry,
+        * STORED into the step's own INPUT rows, from where the next step gathers them again.  With this flag an INPUT site's obs_off
+        * is the ABSOLUTE row of the previous step's buffer it reads (without it: the row among the previous step's OWN rows, which sit
+        * behind its INPUT rows).  Forms: the wide filter kernel, one launch per step, two launches per step (not the 256-thread
+        * steps kernel, no moves, one GPU). */
+       GJX_FILTER_ABSOLUTE_INPUTS = 16 };
 enum { GJX_FILTER_FORM_TWO_LAUNCH = 0, GJX_FILTER_FORM_PER_STEP = 1, GJX_FILTER_FORM_STEPS = 2, GJX_FILTER_FORM_WIDE = 3 };
 typedef struct gjx_filter_opts {
   int32_t flags;                 /* GJX_FILTER_* */
