@@ -35,6 +35,7 @@ P_CONST, P_VALUE, P_GATHER, P_AFFINE, P_VGATHER, P_EXPR = 0, 1, 2, 3, 4, 5
 (E_CONST, E_VALUE, E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_SQRT, E_SQUARE, E_TANH, E_SIGMOID, E_SOFTPLUS, E_ABS, E_SIN, E_COS,
  E_LOG1P, E_RECIP, E_MAX, E_MIN, E_GT, E_WHERE, E_LINV, E_LINN) = range(25)
 EXPR_MAX_NODES = 96
+EXPR_NODE_FLOATS = 6        # {op, a, b, c, da, db}
 XF_NONE, XF_EXP, XF_SOFTPLUS, XF_SIGMOID = 0, 1, 2, 3
 MODE_SAMPLE, MODE_OBS_TAB, MODE_OBS_SLOT, MODE_OBS_MASK, MODE_INPUT = 0, 1, 2, 3, 4
 MODE_OBS_PROPOSED = 5

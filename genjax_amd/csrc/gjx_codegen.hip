@@ -128,6 +128,11 @@ struct RollInfo {
   // a parameter whose source rows are not in registers (instances of ANOTHER plate, one instance of a plate read from outside
   // it): read from choices[][] — rows mem_slot + i_ * d_mem + element; -1: a register source
   int mem_slot[4] = {-1, -1, -1, -1}, d_mem[4] = {0, 0, 0, 0};
+  // GJX_P_EXPR parameter k of a PLATE program: where each leaf of its block really is (plate_program resolves them like the sources
+  // of the closed forms): eleaf[k][eleaf_at[k][node] + e] for element e of the node's leaf span (VALUE: 1, LINV: its count)
+  struct ExprLeaf { int reg = -1; int mem_row = -1, mem_stride = 0; };
+  std::vector<ExprLeaf> eleaf[4];
+  std::vector<int> eleaf_at[4];
 };
 
 // loop variable of the site being emitted: steps of a rolled Scan, or instances of a plate
@@ -228,30 +233,30 @@ struct Roll {
 
 // GJX_P_EXPR (gjx.h): node i of the block of parameter q = {op, a, b, c}, read from the HOST copy of the table at codegen time (the
 // node list is program STRUCTURE: baked into the kernel and hashed into its key; the constants / weights it names are run-time table reads)
-struct ExprNode { int op, a, b, c; };
+struct ExprNode { int op, a, b, c, da, db; };
 ExprNode expr_node(const gjx_program* p, const gjx_param& q, int i) {
-  const float* nd = p->tab + q.off + 4 * i;
-  return ExprNode{(int)nd[0], (int)nd[1], (int)nd[2], (int)nd[3]};
+  const float* nd = p->tab + q.off + GJX_EXPR_NODE_FLOATS * i;
+  return ExprNode{(int)nd[0], (int)nd[1], (int)nd[2], (int)nd[3], (int)nd[4], (int)nd[5]};
 }
 bool has_expr(const gjx_site* sites, int n) {
   for (int j = 0; j < n; ++j) if (sites[j].mode != GJX_MODE_INPUT) for (int k = 0; k < GJX_MAX_PARAMS; ++k) if (sites[j].p[k].op == GJX_P_EXPR) return true;
   return false;
 }
 // a block the emitters take: in range, SSA order, no plate strides (plates with blocks run on the interpreter), leaves in [0, n_slots)
-bool expr_block_ok(const gjx_program* p, const gjx_param& q, int n_slots, int dim) {
-  if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.len < 1 || q.len > q.n || q.off < 0 || q.off + 4 * q.n > p->n_tab) return false;
+bool expr_block_ok(const gjx_program* p, const gjx_param& q, int n_slots, int dim, bool plate = false) {   // plate: strides allowed, leaves resolved by plate_program
+  if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.len < 1 || q.len > q.n || q.off < 0 || q.off + GJX_EXPR_NODE_FLOATS * q.n > p->n_tab) return false;
   if (q.len != 1 && (q.len != dim || dim > 32)) return false;
   for (int i = 0; i < q.n; ++i) {
     const ExprNode e = expr_node(p, q, i);
     auto nodeok = [&](int x) { return x >= 0 && x < i; };
     switch (e.op) {
-      case GJX_E_CONST: if (e.a < 0 || e.a >= p->n_tab || e.b != 0) return false; break;
-      case GJX_E_VALUE: if (e.a < 0 || e.a >= n_slots || e.b != 0) return false; break;
+      case GJX_E_CONST: if (e.a < 0 || e.a >= p->n_tab || (e.da != 0 && !plate)) return false; break;
+      case GJX_E_VALUE: if (e.a < 0 || (!plate && (e.a >= n_slots || e.da != 0))) return false; break;
       case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: case GJX_E_GT:
         if (!nodeok(e.a) || !nodeok(e.b)) return false; break;
       case GJX_E_WHERE: if (!nodeok(e.a) || !nodeok(e.b) || !nodeok(e.c)) return false; break;
-      case GJX_E_LINV: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || e.b + e.c > n_slots) return false; break;
-      case GJX_E_LINN: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || e.b + e.c > i) return false; break;
+      case GJX_E_LINV: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || (!plate && (e.b + e.c > n_slots || e.da || e.db))) return false; break;
+      case GJX_E_LINN: if (e.c < 1 || e.c > 64 || e.a < 0 || e.a + 1 + e.c > p->n_tab || e.b < 0 || e.b + e.c > i || (e.da && !plate)) return false; break;
       default: if (e.op < GJX_E_NEG || e.op > GJX_E_RECIP || !nodeok(e.a)) return false; break;
     }
   }
@@ -467,7 +472,6 @@ PlateXf plate_program(const gjx_program* p) {
   const int n = p->n_sites;
   for (int j = 0; j < n; ++j) x.any = x.any || p->sites[j].plate != 0;
   if (!x.any) return x;
-  if (has_expr(p->sites, n)) return x;      // (ok stays false: expression blocks inside / beside plates run on the site interpreter)
   auto width = [&](const gjx_site& s) { return (is_categorical(s.kind) && s.mode != GJX_MODE_INPUT) ? 1 : s.dim; };
   auto rows = [&](const gjx_site& s) { return width(s) * (s.plate ? s.plate_n : 1); };
   std::vector<int> reg(n, -1), flag(n, -1), first(n, 0), pos(n, 0);
@@ -497,6 +501,31 @@ PlateXf plate_program(const gjx_program* p) {
     if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = s.plate ? s.d_obs : 0; s.obs_off = flag[j]; }
     for (int k = 0; k < (s.mode == GJX_MODE_INPUT ? 0 : n_params(s.kind)); ++k) {
       gjx_param& q = s.p[k];
+      if (q.op == GJX_P_EXPR) {
+        // every leaf of the block like a source of the closed forms: a register (a site outside the plates; an earlier site of the
+        // SAME instance) or rows of choices[][] (instances of another plate, elements of a vector site picked by the instance)
+        if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.off < 0 || q.off + GJX_EXPR_NODE_FLOATS * q.n > p->n_tab) return x;
+        ri.eleaf_at[k].assign(q.n, -1);
+        for (int i = 0; i < q.n; ++i) {
+          const ExprNode e = expr_node(p, q, i);
+          if (e.op != GJX_E_VALUE && e.op != GJX_E_LINV) continue;
+          const int base = e.op == GJX_E_VALUE ? e.a : e.b, dsl = e.op == GJX_E_VALUE ? e.da : e.db, cnt = e.op == GJX_E_VALUE ? 1 : e.c;
+          if (!s.plate && dsl != 0) return x;
+          ri.eleaf_at[k][i] = (int)ri.eleaf[k].size();
+          for (int t = 0; t < cnt; ++t) {
+            RollInfo::ExprLeaf lf;
+            const int o = owner_of(base + t, j);
+            if (o < 0) return x;
+            const gjx_site& so = p->sites[o];
+            const int off = base + t - so.slot;
+            if (so.plate == 0 && dsl == 0) lf.reg = reg[o] + off;
+            else if (so.plate != 0 && s.plate == so.plate && dsl == width(so) && off < width(so)) lf.reg = reg[o] + off;
+            else { lf.mem_row = base + t; lf.mem_stride = s.plate ? dsl : 0; }
+            ri.eleaf[k].push_back(lf);
+          }
+        }
+        continue;
+      }
       if (q.op == GJX_P_VGATHER) {
         // the indexed choice: all its rows in the registers of ONE site outside the plates, the same for every instance
         const int ov = owner_of(q.moff, j);
@@ -539,7 +568,7 @@ PlateXf plate_program(const gjx_program* p) {
 }
 
 // what the emitter covers; everything else runs on the interpreter
-bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_program* prog = nullptr) {   // prog: the program whose table holds expression blocks
+bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_program* prog = nullptr, bool plate_prog = false) {   // prog: the program whose table holds expression blocks
   if (n_sites < 1 || n_sites > 48 || n_slots > 160) return false;
   int total = 0;
   for (int j = 0; j < n_sites; ++j) {
@@ -557,7 +586,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
       if (q.op == GJX_P_EXPR) {      // an expression block: emitted inline, one straight-line copy per element that reads it
-        if (!prog || !expr_block_ok(prog, q, n_slots, s.dim) || (s.dim > kMaxExpandDim && q.len != 1)) return false;
+        if (!prog || !expr_block_ok(prog, q, n_slots, s.dim, plate_prog) || (s.dim > kMaxExpandDim && q.len != 1)) return false;
         total += q.n / 2;
         continue;
       }
@@ -574,7 +603,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_
 
 bool supported_uncached(const gjx_program* p) {
   const PlateXf px = plate_program(p);
-  if (px.any) return px.ok && supported_sites(px.sites.data(), (int)px.sites.size(), px.n_regs);
+  if (px.any) return px.ok && supported_sites(px.sites.data(), (int)px.sites.size(), px.n_regs, p, true);
   if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots, p)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
   return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs);
@@ -617,7 +646,7 @@ std::string xf_wrap(int xf, const std::string& e) {
 // schedules and merges them with the site's own arithmetic; values are in registers: val(slot) is `vfmt` with the slot number).
 // -> the set of emitted nodes.  The unary forms use the device header's helpers (the interpreter's expr_unary computes the same).
 std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_param& q, int out, const std::string& pfx, const char* ind,
-                                  const std::function<std::string(int)>& val) {
+                                  const std::function<std::string(int, int)>& val) {   // val(node, element of the node's leaf span)
   std::vector<char> need(q.n, 0);
   need[out] = 1;
   for (int i = out; i >= 0; --i) {
@@ -632,14 +661,16 @@ std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_pa
     }
   }
   auto N = [&](int i) { return pfx + std::to_string(i); };
+  // table entry `at` of a node whose table base advances by `stride` per plate instance / rolled step (toff: the loop variable)
+  auto T = [&](int base, int stride, int at) { return "TAB(" + toff(base, stride) + (at ? " + " + std::to_string(at) : "") + ")"; };
   for (int i = 0; i <= out; ++i) {
     if (!need[i]) continue;
     const ExprNode e = expr_node(prog, q, i);
     std::string r;
     const std::string A = e.op >= GJX_E_ADD && e.op != GJX_E_LINV && e.op != GJX_E_LINN ? N(e.a) : "", B = N(e.b);
     switch (e.op) {
-      case GJX_E_CONST: r = "TAB(" + std::to_string(e.a) + ")"; break;
-      case GJX_E_VALUE: r = val(e.a); break;
+      case GJX_E_CONST: r = T(e.a, e.da, 0); break;
+      case GJX_E_VALUE: r = val(i, 0); break;
       case GJX_E_ADD: r = A + " + " + B; break;
       case GJX_E_SUB: r = A + " - " + B; break;
       case GJX_E_MUL: r = A + " * " + B; break;
@@ -649,13 +680,13 @@ std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_pa
       case GJX_E_GT: r = A + " > " + B + " ? 1.0f : 0.0f"; break;
       case GJX_E_WHERE: r = A + " != 0.0f ? " + B + " : " + N(e.c); break;
       case GJX_E_LINV: {
-        r = "TAB(" + std::to_string(e.a) + ")";
-        for (int t = 0; t < e.c; ++t) r = "fmaf(TAB(" + std::to_string(e.a + 1 + t) + "), " + val(e.b + t) + ", " + r + ")";
+        r = T(e.a, e.da, 0);
+        for (int t = 0; t < e.c; ++t) r = "fmaf(" + T(e.a, e.da, 1 + t) + ", " + val(i, t) + ", " + r + ")";
         break;
       }
       case GJX_E_LINN: {
-        r = "TAB(" + std::to_string(e.a) + ")";
-        for (int t = 0; t < e.c; ++t) r = "fmaf(TAB(" + std::to_string(e.a + 1 + t) + "), " + N(e.b + t) + ", " + r + ")";
+        r = T(e.a, e.da, 0);
+        for (int t = 0; t < e.c; ++t) r = "fmaf(" + T(e.a, e.da, 1 + t) + ", " + N(e.b + t) + ", " + r + ")";
         break;
       }
       default: r = "expr_unary(" + std::to_string(e.op) + ", " + A + ")"; break;
@@ -665,13 +696,25 @@ std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_pa
   return need;
 }
 
+// the leaf reader of parameter k's block for the propagate emitters: registers by slot number, or — a plate program — what
+// plate_program resolved (RollInfo::eleaf): a register, or rows of choices[][] that advance with the instance
+std::function<std::string(int, int)> expr_leaf_reader(const gjx_program* prog, const gjx_param& q, const RollInfo& ri, int k) {
+  return [prog, &q, &ri, k](int node, int t) -> std::string {
+    const ExprNode e = expr_node(prog, q, node);
+    if (ri.eleaf_at[k].empty()) return "v[" + std::to_string((e.op == GJX_E_VALUE ? e.a : e.b) + t) + "][p]";
+    const RollInfo::ExprLeaf& lf = ri.eleaf[k][ri.eleaf_at[k][node] + t];
+    if (lf.reg >= 0) return "v[" + std::to_string(lf.reg) + "][p]";
+    return "a.choices[(int64_t)" + toff(lf.mem_row, lf.mem_stride) + " * K + i0 + p]";
+  };
+}
+
 // statements that must precede the use of param_expr for element dx (affine accumulations)
 void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site, int k, const char* ind, const RollInfo& ri) {
   if (q.op == GJX_P_EXPR) {
     // (supported_sites: a block with several outputs only under literal element indices; no plate / roll remapping of its slots)
     const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
     const std::string pfx = "en_" + std::to_string(site) + "_" + std::to_string(k) + "_";
-    emit_expr_nodes(o, g_expr_prog, q, out, pfx, ind, [](int slot) { return "v[" + std::to_string(slot) + "][p]"; });
+    emit_expr_nodes(o, g_expr_prog, q, out, pfx, ind, expr_leaf_reader(g_expr_prog, q, ri, k));
     o.f("%sconst float ex_%d_%d = %s%d;\n", ind, site, k, pfx.c_str(), out);
     return;
   }
@@ -1977,7 +2020,8 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
       case GJX_P_EXPR: {      // the block's nodes (kept: the reverse sweep below reads them)
         const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
         const std::string pfx = "en_" + std::to_string(k) + "_";
-        emit_expr_nodes(o, g_expr_prog, q, out, pfx, (std::string(ind) + "  ").c_str(), [](int slot) { return "v[" + std::to_string(slot) + "]"; });
+        emit_expr_nodes(o, g_expr_prog, q, out, pfx, (std::string(ind) + "  ").c_str(),
+                        [&q](int node, int t) { const ExprNode e = expr_node(g_expr_prog, q, node); return "v[" + std::to_string((e.op == GJX_E_VALUE ? e.a : e.b) + t) + "]"; });
         o.f("%s  const float pre_%d = %s%d;\n", ind, k, pfx.c_str(), out);
         break;
       }
@@ -2602,8 +2646,8 @@ uint64_t sites_hash_uncached(const gjx_program* p) {
     for (int j = 0; j < p->n_sites; ++j)
       for (int k = 0; k < GJX_MAX_PARAMS; ++k) {
         const gjx_param& q = p->sites[j].p[k];
-        if (p->sites[j].mode != GJX_MODE_INPUT && q.op == GJX_P_EXPR && q.off >= 0 && q.n > 0 && q.off + 4 * q.n <= p->n_tab)
-          h = fnv1a(p->tab + q.off, sizeof(float) * 4 * (size_t)q.n, h);
+        if (p->sites[j].mode != GJX_MODE_INPUT && q.op == GJX_P_EXPR && q.off >= 0 && q.n > 0 && q.off + GJX_EXPR_NODE_FLOATS * q.n <= p->n_tab)
+          h = fnv1a(p->tab + q.off, sizeof(float) * GJX_EXPR_NODE_FLOATS * (size_t)q.n, h);
       }
   return h | 1ull;
 }

@@ -404,7 +404,7 @@ GJX_DEV int vgather_row(const gjx_param& p, int d, const float* __restrict__ tab
   idx = idx < 0 ? 0 : (idx > p.n - 1 ? p.n - 1 : idx);
   return p.moff + inst * p.d_moff + idx * p.len + (p.len == 1 ? 0 : d % p.len);
 }
-// ---- GJX_P_EXPR (gjx.h): a block of scalar SSA nodes in the table, node i = tab[off + 4 i ..] = {op, a, b, c}.  The site
+// ---- GJX_P_EXPR (gjx.h): a block of scalar SSA nodes in the table, node i = tab[off + 6 i ..] = {op, a, b, c, da, db}.  The site
 // interpreters evaluate the block into a per-lane array (dynamic indexing: scratch memory — this is the fallback engine; generated
 // kernels emit the nodes as straight-line code, gjx_codegen.hip emit_expr_nodes) and sweep it backwards for gradients.
 GJX_DEV float expr_tanh(float x) {
@@ -452,11 +452,13 @@ GJX_DEV void expr_forward(const gjx_param& p, const float* __restrict__ tab, Val
   const float* __restrict__ nd = tab + p.off;
   const int n = p.n < GJX_EXPR_MAX_NODES ? p.n : GJX_EXPR_MAX_NODES;
   for (int i = 0; i < n; ++i) {
-    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    const float* __restrict__ q6 = nd + GJX_EXPR_NODE_FLOATS * i;
+    const int op = (int)q6[0], c = (int)q6[3];
+    const int a = (int)q6[1] + inst * (int)q6[4], b = (int)q6[2] + inst * (int)q6[5];     // (plate strides: 0 outside plates)
     float r;
     switch (op) {
-      case GJX_E_CONST: r = tab[a + inst * b]; break;
-      case GJX_E_VALUE: r = val(a + inst * b); break;
+      case GJX_E_CONST: r = tab[a]; break;
+      case GJX_E_VALUE: r = val(a); break;
       case GJX_E_ADD: r = ev[a] + ev[b]; break;
       case GJX_E_SUB: r = ev[a] - ev[b]; break;
       case GJX_E_MUL: r = ev[a] * ev[b]; break;
@@ -492,10 +494,12 @@ GJX_DEV void expr_backward(const gjx_param& p, int d, float g, const float* __re
   for (int i = n - 1; i >= 0; --i) {
     const float gi = ad[i];
     if (gi == 0.0f) continue;
-    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    const float* __restrict__ q6 = nd + GJX_EXPR_NODE_FLOATS * i;
+    const int op = (int)q6[0], c = (int)q6[3];
+    const int a = (int)q6[1] + inst * (int)q6[4], b = (int)q6[2] + inst * (int)q6[5];
     switch (op) {
       case GJX_E_CONST: case GJX_E_GT: break;
-      case GJX_E_VALUE: G.at(a + inst * b) += gi; break;
+      case GJX_E_VALUE: G.at(a) += gi; break;
       case GJX_E_ADD: ad[a] += gi; ad[b] += gi; break;
       case GJX_E_SUB: ad[a] += gi; ad[b] -= gi; break;
       case GJX_E_MUL: ad[a] = fmaf(gi, ev[b], ad[a]); ad[b] = fmaf(gi, ev[a], ad[b]); break;

@@ -272,7 +272,7 @@ def _as_arr(x, xp, like=None):
 # lowering to the device block
 # ---------------------------------------------------------------------------------------------
 def lower(outs: Sequence[tuple], leaf_place: Callable, push: Callable) -> tuple[np.ndarray, int]:
-    """-> (float32 [n][4] node list {op, a, b, c}, n) for include/gjx.h GJX_P_EXPR; the LAST len(outs) nodes are the outputs.
+    """-> (float32 [n][6] node list {op, a, b, c, da, db}, n) for include/gjx.h GJX_P_EXPR; the LAST len(outs) nodes are the outputs.
 
     ``leaf_place(addr, elem)`` -> ("slot", s) for a latent choice (a row of choices[][]) or ("tab", off) for a choice constrained
     to one shared value (it lives in the table: a later set_obs is seen without repacking); ``push(arr) -> off`` appends floats
@@ -280,9 +280,18 @@ def lower(outs: Sequence[tuple], leaf_place: Callable, push: Callable) -> tuple[
     nodes: list[list[int]] = []
     index: dict = {}                 # host node -> device node (first emission)
     const_off: dict = {}
+    pushed: dict = {}                # equal float arrays are stored once per block (the 8 rows of W1 @ x all carry the weights x)
+    push_raw = push
+
+    def push(arr):
+        a_ = np.asarray(arr, np.float32).ravel()
+        k_ = a_.tobytes()
+        if k_ not in pushed:
+            pushed[k_] = push_raw(a_)
+        return pushed[k_]
 
     def emit(op, a=0, b=0, c=0) -> int:
-        nodes.append([int(op), int(a), int(b), int(c)])
+        nodes.append([int(op), int(a), int(b), int(c), 0, 0])           # (da, db: plate strides, filled by lower_plate)
         if len(nodes) > A.EXPR_MAX_NODES:
             raise ExprTooLarge(f"a distribution parameter's expression needs more than {A.EXPR_MAX_NODES} nodes: give an intermediate result a "
                                "site of its own, or use the closed forms (affine maps, gathers) where they apply")
@@ -380,7 +389,7 @@ def lower(outs: Sequence[tuple], leaf_place: Callable, push: Callable) -> tuple[
         for n, p_ in zip(outs, pre):
             i = emit(A.E_MAX, p_, p_) if p_ is not None else top(n, fresh=True)     # max(x, x): the identity, gradient to x
             first_out = i if first_out is None else first_out
-    return np.asarray(nodes, np.float32).reshape(-1, 4), len(nodes)
+    return np.asarray(nodes, np.float32).reshape(-1, A.EXPR_NODE_FLOATS), len(nodes)
 
 
 def count_nodes(outs: Sequence[tuple]) -> int:
@@ -394,3 +403,66 @@ def count_nodes(outs: Sequence[tuple]) -> int:
         seen.add(n)
         stack.extend(_children(n))
     return len(seen)
+
+
+POOL_BASE = 1 << 22      # lower_plate: table offsets at or above it are relative to the instance's own constant pool
+
+
+class IrregularPlate(ValueError):
+    """the instances of a vmapped kernel do not lower to ONE node list with linear strides"""
+
+
+def lower_plate(inst_outs: Sequence[Sequence[tuple]], leaf_place: Callable, push: Callable | None) -> tuple[np.ndarray, int]:
+    """The expression of a parameter of a PLATE body site (include/gjx.h "Plates"): ``inst_outs[i]`` = its output nodes in instance i
+    (leaves already name device sites: ("v", device addr, element incl. the instance's offset)).  Every instance is lowered on its
+    own into a private constant pool; the instances must give the SAME node list up to fields that advance linearly with i — the
+    strides da / db of the device nodes: VALUE / CONST leaves and LINV slots by what the leaves say, everything that points into the
+    pool by the pool's length (the pools are stored one after the other) — else IrregularPlate (the caller keeps the plate unrolled).
+    ``push`` None: a dry run (regularity check only)."""
+    lowered = []
+    for outs in inst_outs:
+        pool: list = []
+
+        def lpush(arr, pool=pool):
+            off = len(pool)
+            pool.extend(np.asarray(arr, np.float32).ravel().tolist())
+            return POOL_BASE + off
+        nodes, n = lower(outs, leaf_place, lpush)
+        lowered.append((nodes.astype(np.int64), pool))
+    nd0, pool0 = lowered[0]
+    L = len(pool0)
+    n = nd0.shape[0]
+    if any(nd.shape != nd0.shape or len(pool) != L for nd, pool in lowered):
+        raise IrregularPlate("instances lower to different node lists")
+    out = nd0.copy()
+    n_inst = len(lowered)
+    for i_node in range(n):
+        op = int(nd0[i_node, 0])
+        for nd, _ in lowered:
+            if int(nd[i_node, 0]) != op or int(nd[i_node, 3]) != int(nd0[i_node, 3]):
+                raise IrregularPlate("instances differ in an operation")
+        strided = {A.E_CONST: (1,), A.E_VALUE: (1,), A.E_LINV: (1, 2), A.E_LINN: (1,)}.get(op, ())
+        for f in (1, 2):
+            col = [int(nd[i_node, f]) for nd, _ in lowered]
+            if f not in strided:
+                if any(c != col[0] for c in col):
+                    raise IrregularPlate("instances differ in an operand")
+                continue
+            if col[0] >= POOL_BASE:                 # into the instance's pool: same relative entry, stride = pool length
+                if any(c != col[0] for c in col):
+                    raise IrregularPlate("instances use different pool entries")
+                out[i_node, f] = col[0]             # (rebased below)
+                out[i_node, 3 + f] = L
+            else:
+                d = col[1] - col[0] if n_inst > 1 else 0
+                if any(col[i] != col[0] + i * d for i in range(n_inst)):
+                    raise IrregularPlate("a source does not advance linearly with the instance")
+                out[i_node, 3 + f] = d
+    if push is None:
+        return out.astype(np.float32), n
+    base = push(np.asarray([v for _, pool in lowered for v in pool], np.float32)) if L else 0
+    for i_node in range(n):
+        for f in (1, 2):
+            if out[i_node, f] >= POOL_BASE:
+                out[i_node, f] = base + (out[i_node, f] - POOL_BASE)
+    return out.astype(np.float32), n

@@ -46,6 +46,7 @@ class Param:
     vlen: int = 1
     # EXPR (gjx.h GJX_P_EXPR): the output nodes of a general elementwise expression (expr.py); len(outs) = 1 or the site's dim
     outs: tuple | None = None
+    inst_outs: list | None = None      # EXPR parameter of a plate body site: the output nodes of every instance (expr.lower_plate)
 
     @staticmethod
     def expr(outs, xf=A.XF_NONE) -> "Param":
@@ -441,7 +442,32 @@ def _try_plate(group, names, n: int, modes: dict, obs: dict, sel: set, where: di
             if any(q.op != p0.op or q.xf != p0.xf or bool(q.terms) != bool(p0.terms) for q in ps):
                 return None
             if p0.op == A.P_EXPR:
-                return None                 # (a vmapped kernel with expression blocks stays unrolled: always correct)
+                # every instance's expression with its leaves renamed to the DEVICE sites (an earlier site of the same instance, a site
+                # outside the plate, an instance of an earlier plate); one node list with linear strides, or the plate stays unrolled
+                from . import expr as E
+                inst_outs = []
+                for i, q in enumerate(ps):
+                    if len(q.outs) != len(p0.outs):
+                        return None
+                    bad = []
+
+                    def ren(a_, e_, i=i, bad=bad):
+                        r = source(a_, l, i)
+                        if r is None:
+                            bad.append(a_)
+                            return None
+                        return E.value(r[0], e_ + r[1])
+                    outs_i = E.rewrite_leaves(q.outs, ren)
+                    if bad:
+                        return None
+                    inst_outs.append(tuple(outs_i))
+                try:
+                    fake = {}
+                    E.lower_plate(inst_outs, lambda a_, e_: ("slot", fake.setdefault(a_, 100000 * (len(fake) + 1)) + e_), None)
+                except (E.IrregularPlate, E.ExprTooLarge):
+                    return None
+                params.append(Param(A.P_EXPR, outs=inst_outs[0], xf=p0.xf, inst_outs=inst_outs))
+                continue
             d_elem, src, elem0 = 0, None, 0
             if p0.op != A.P_CONST and not p0.terms:
                 rs = [source(q.src, l, i) for i, q in enumerate(ps)]
@@ -808,18 +834,19 @@ class PackedProgram:
             cp.off, cp.len = self.obs_off[p.vsrc] + p.vsrc_elem + idx * p.vlen, int(p.vlen)
 
     def _pack_expr(self, cp, p: Param, s: Site, rows: int, push) -> None:
-        """GJX_P_EXPR: the expression's nodes as a block of float quadruples in the table (include/gjx.h).  Latent sources are read
+        """GJX_P_EXPR: the expression's nodes as a block of 6-float records in the table (include/gjx.h).  Latent sources are read
         from their rows; a source constrained to one shared value is read from ITS table entries (set_obs is seen without repacking)."""
         from . import expr as E
-        if s.plate:
-            raise NotImplementedError("an expression block inside a plate site")        # (compact_plates keeps such kernels unrolled)
         if len(p.outs) not in (1, rows):
             raise ValueError(f"site {s.addr!r}: an expression parameter with {len(p.outs)} elements for an event of {rows}")
 
         def place(addr, elem):
             sl_ = self.slot_of[addr]
             return ("slot", sl_ + elem) if sl_ >= 0 else ("tab", self.obs_off[addr] + elem)
-        nodes, n = E.lower(p.outs, place, push)
+        if s.plate:                            # ONE node list for the plate's instances, strides in the nodes (include/gjx.h)
+            nodes, n = E.lower_plate(p.inst_outs, place, push)
+        else:
+            nodes, n = E.lower(p.outs, place, push)
         cp.op, cp.off, cp.n, cp.len = A.P_EXPR, push(nodes), int(n), len(p.outs)
 
     def _pack_affine_multi(self, cp, p: Param, s: Site, rows: int, push) -> None:

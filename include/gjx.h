@@ -109,18 +109,20 @@ enum {
 /* GJX_P_EXPR (ABI 9) — ANY elementwise computation between sites.  The reference stages the whole @gen body and interprets whatever
  * JAX computes between two trace sites (generative_functions/static.py:383-399, core/compiler/staging.py:286-298), and
  * selection_gradient differentiates through it (inference/requests/hmc.py:70-96).  Here such a computation is a small SSA BLOCK of
- * scalar nodes stored in the program's float table: node i is the four floats tab[off + 4 i .. off + 4 i + 3] = {op, a, b, c} (small
- * integers held exactly in float32; a / b / c are node indices WITHIN the block — always smaller than i —, slots, table offsets or
- * counts, by op).  gjx_param: op = GJX_P_EXPR, off = the block, n = its number of nodes (1 .. GJX_EXPR_MAX_NODES), len = number of
+ * scalar nodes stored in the program's float table: node i is the GJX_EXPR_NODE_FLOATS = 6 floats tab[off + 6 i ..] = {op, a, b, c, da,
+ * db} (small integers held exactly in float32; a / b / c are node indices WITHIN the block — always smaller than i —, slots, table
+ * offsets or counts, by op; da / db are the plate strides of a / b, 0 outside plates).  gjx_param: op = GJX_P_EXPR, off = the block, n = its number of nodes (1 .. GJX_EXPR_MAX_NODES), len = number of
  * outputs: the LAST len nodes (len = 1: one value for every element; else len = the site's dim and element d reads output d % len).
  * xf still applies on top.  The node list is part of the program's STRUCTURE (generated kernels bake it in and the structure key
  * hashes it); the constants and weights it refers to are ordinary table entries and may change like any table value.
- * Plate instance i (gjx.h "Plates"): VALUE nodes read slot a + i * b, CONST nodes tab[a + i * b]; LIN nodes are not strided.
+ * Plate instance i (gjx.h "Plates"): VALUE nodes read slot a + i da, CONST nodes tab[a + i da]; LINV reads its [bias, weights] at
+ * tab[a + i da ...] and its slots from b + i db; LINN its [bias, weights] at tab[a + i da ...] — per-instance data (the covariates of a
+ * regression with a nonlinear link, vmapped over the observations) and per-instance latents, with ONE node list for the plate.
  * Reverse mode (gjx_hmc, gjx_score_grad): the adjoint of the output flows back through the block to its VALUE leaves; CONST leaves,
  * comparisons and the condition of a WHERE carry no gradient (jax.grad of jnp.where / lax.select, comparisons). */
 enum {
-  GJX_E_CONST = 0,    /* tab[a + inst * b]                                                              */
-  GJX_E_VALUE = 1,    /* choices[a + inst * b][i]                                                       */
+  GJX_E_CONST = 0,    /* tab[a + inst * da]                                                             */
+  GJX_E_VALUE = 1,    /* choices[a + inst * da][i]                                                      */
   GJX_E_ADD = 2,      /* node a + node b                                                                */
   GJX_E_SUB = 3,      /* node a - node b                                                                */
   GJX_E_MUL = 4,      /* node a * node b                                                                */
@@ -137,6 +139,7 @@ enum {
   GJX_E_OP_MAX = 25
 };
 #define GJX_EXPR_MAX_NODES 96
+#define GJX_EXPR_NODE_FLOATS 6
 /* unary transform applied to the evaluated parameter */
 enum { GJX_XF_NONE = 0, GJX_XF_EXP = 1, GJX_XF_SOFTPLUS = 2, GJX_XF_SIGMOID = 3 };
 

@@ -281,7 +281,7 @@ static int vgather_row(const gjx_param* p, int d, const float* tab, const float*
   return p->moff + idx * p->len + (d % p->len);
 }
 
-/* GJX_P_EXPR (gjx.h): the block of scalar SSA nodes tab[off + 4 i ..] = {op, a, b, c}; the reference interprets whatever JAX computes
+/* GJX_P_EXPR (gjx.h): the block of scalar SSA nodes tab[off + 6 i ..] = {op, a, b, c, da, db}; the reference interprets whatever JAX computes
  * between two sites in float32 (static.py:383-399, staging.py:286-298) — every node here is evaluated in double and rounded to
  * float32 once (a correctly rounded float32 operation).  `inst`: the plate instance (site_instance leaves it in pad_[0]). */
 static double expr_unary_d(int op, double x) {
@@ -322,11 +322,13 @@ static void expr_forward(const gjx_param* p, const float* tab, const float* vals
   const float* nd = tab + p->off;
   const int inst = p->pad_[0];
   for (int i = 0; i < p->n && i < GJX_EXPR_MAX_NODES; ++i) {
-    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    const float* q6 = nd + GJX_EXPR_NODE_FLOATS * i;
+    const int op = (int)q6[0], c = (int)q6[3];
+    const int a = (int)q6[1] + inst * (int)q6[4], b = (int)q6[2] + inst * (int)q6[5];
     double r;
     switch (op) {
-      case GJX_E_CONST: r = tab[a + inst * b]; break;
-      case GJX_E_VALUE: r = vals[a + inst * b]; break;
+      case GJX_E_CONST: r = tab[a]; break;
+      case GJX_E_VALUE: r = vals[a]; break;
       case GJX_E_ADD: r = (double)ev[a] + ev[b]; break;
       case GJX_E_SUB: r = (double)ev[a] - ev[b]; break;
       case GJX_E_MUL: r = (double)ev[a] * ev[b]; break;
@@ -355,10 +357,12 @@ static void expr_backward(const gjx_param* p, int d, float g, const float* tab, 
   for (int i = n - 1; i >= 0; --i) {
     const double gi = ad[i];
     if (gi == 0.0) continue;
-    const int op = (int)nd[4 * i], a = (int)nd[4 * i + 1], b = (int)nd[4 * i + 2], c = (int)nd[4 * i + 3];
+    const float* q6 = nd + GJX_EXPR_NODE_FLOATS * i;
+    const int op = (int)q6[0], c = (int)q6[3];
+    const int a = (int)q6[1] + inst * (int)q6[4], b = (int)q6[2] + inst * (int)q6[5];
     switch (op) {
       case GJX_E_CONST: case GJX_E_GT: break;
-      case GJX_E_VALUE: grad[a + inst * b] += (float)gi; break;
+      case GJX_E_VALUE: grad[a] += (float)gi; break;
       case GJX_E_ADD: ad[a] += gi; ad[b] += gi; break;
       case GJX_E_SUB: ad[a] += gi; ad[b] -= gi; break;
       case GJX_E_MUL: ad[a] += gi * ev[b]; ad[b] += gi * ev[a]; break;

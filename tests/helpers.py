@@ -196,3 +196,33 @@ def random_expr_outs(rs, cont, dim, dom="real", depth=3):
             n = E.lin(0.02, [(E.unary("sigmoid", n), 0.96)])
         outs.append(n)
     return outs
+
+
+def bnn_model(N=64, DI=16, DH=8, seed=0, first_is_one=False):
+    """a small Bayesian network classifier, the canonical model of general expressions inside a vmapped kernel: latent weights outside
+    the plate (one site per hidden unit's row, one for the output layer), the observations vmapped over the data —
+    y_n ~ bernoulli(logits = w2 . tanh(W1 x_n)).  -> (model, X, Y, float64 log-likelihood function of (W1 [DH][DI][K], w2 [DH][K]))"""
+    import genjax_amd as genjax
+    rs = np.random.default_rng(seed)
+    X = rs.standard_normal((N, DI)).astype(np.float32)
+    if first_is_one:
+        X[3, 0] = 1.0          # (a covariate that constant-folds differently in ONE instance: the plate is irregular and stays unrolled)
+    Y = (rs.random(N) < 0.5).astype(np.float32)
+
+    @genjax.gen
+    def kern(x_row, W1, w2):
+        h = genjax.tanh(genjax.array([genjax.dot(W1[j], x_row) for j in range(DH)]))
+        return genjax.bernoulli(logits=genjax.dot(w2, h)) @ "y"
+
+    @genjax.gen
+    def bnn():
+        W1 = [genjax.normal(np.zeros(DI, np.float32), 0.5) @ f"W1_{j}" for j in range(DH)]
+        w2 = genjax.normal(np.zeros(DH, np.float32), 1.0) @ "w2"
+        kern.vmap(in_axes=(0, None, None))(X, W1, w2) @ "obs"
+
+    def loglik(W1, w2):
+        h = np.tanh(np.einsum("jik,ni->njk", W1, X.astype(np.float64)))
+        lg = np.einsum("jk,njk->nk", w2, h)
+        return (Y[:, None] * -np.logaddexp(0, -lg) + (1 - Y[:, None]) * -np.logaddexp(0, lg)).sum(0)
+
+    return bnn, X, Y, loglik

@@ -24,7 +24,7 @@ def _blocks(prog):
         for k in range(A.MAX_PARAMS):
             cp = prog.c_sites[j].p[k]
             if cp.op == A.P_EXPR:
-                out.append((j, k, prog.tab[cp.off:cp.off + 4 * cp.n].reshape(-1, 4).astype(int), int(cp.len)))
+                out.append((j, k, prog.tab[cp.off:cp.off + A.EXPR_NODE_FLOATS * cp.n].reshape(-1, A.EXPR_NODE_FLOATS).astype(int), int(cp.len)))
     return out
 
 
@@ -32,7 +32,7 @@ def _check_block(prog, nodes, n_out):
     """the invariants include/gjx.h states: SSA order, operands in range, LINN operands consecutive and earlier, outputs last"""
     n = len(nodes)
     assert 1 <= n <= A.EXPR_MAX_NODES and 1 <= n_out <= n
-    for i, (op, a, b, c) in enumerate(nodes):
+    for i, (op, a, b, c, da, db) in enumerate(nodes):
         assert 0 <= op < 25
         if op == A.E_CONST:
             assert 0 <= a < prog.tab.size and b == 0
@@ -192,3 +192,66 @@ def test_oracle_evaluates_blocks_like_float64_numpy_and_differentiates_them_like
             smooth = np.abs(fd - fd_wide) < 1e-3 * (1.0 + np.abs(fd))
             assert smooth.mean() > 0.9
             np.testing.assert_allclose(g[prog.slot_of[a] + e][smooth], fd[smooth], rtol=2e-3, atol=2e-3)
+
+
+def test_a_vmapped_kernel_with_expressions_is_one_device_plate():
+    """general expressions INSIDE a vmapped kernel (a network classifier over N observations): the N instances lower to ONE plate
+    site whose block carries strides (include/gjx.h: VALUE / CONST / LINV / LINN nodes advance by da / db per instance; the covariates
+    are per-instance table entries), the oracle scores it like float64 NumPy and differentiates it like finite differences; a plate
+    whose instances do NOT lower to one node list stays unrolled and is just as right"""
+    from genjax_amd import C
+    from oracle import cpu
+    N, DI, DH, K = 64, 16, 8, 128
+    model, X, Y, loglik = H.bnn_model(N, DI, DH)
+    prog, _, _ = model.pack((), C["obs", "y"].set(Y), True)
+    assert prog.n_sites == DH + 2 and prog.n_slots == DI * DH + DH
+    body = prog.c_sites[prog.n_sites - 1]
+    assert (body.plate, body.plate_n, body.mode) == (1, N, A.MODE_OBS_TAB) and body.p[0].op == A.P_EXPR
+    (j, k, nodes, n_out), = _blocks(prog)
+    linv = nodes[nodes[:, 0] == A.E_LINV]
+    assert len(linv) == DH and (linv[:, 3] == DI).all() and (linv[:, 4] == DI + 1).all() and (linv[:, 5] == 0).all()      # x_n: 1 + DI floats per instance
+    assert len(set(linv[:, 1])) == 1                                   # the DH rows of W1 @ x_n share ONE copy of x_n
+    np.testing.assert_allclose(prog.tab[linv[0, 1] + 1 + (DI + 1) * 5: linv[0, 1] + 1 + (DI + 1) * 5 + DI], X[5])
+    o = cpu.run_program(prog, (1, 2), K)
+    W1 = o["choices"][:DI * DH].astype(np.float64).reshape(DH, DI, K)
+    w2 = o["choices"][DI * DH:].astype(np.float64)
+    np.testing.assert_allclose(o["weight"], loglik(W1, w2), rtol=2e-5, atol=2e-4)
+    # gradient through the plate
+    sel = tuple(f"W1_{j}" for j in range(DH)) + ("w2",)
+    hp, _, _ = model.pack((), C["obs", "y"].set(Y), False, selected=sel, per_particle=sel, plates="hmc")
+    assert hp.n_sites == DH + 2
+    ch = o["choices"].astype(np.float64)
+    sc, g = cpu.score_grad(hp, o["choices"])
+
+    def dens(c):
+        return loglik(c[:DI * DH].reshape(DH, DI, -1), c[DI * DH:]) + (-0.5 * (c[:DI * DH] / 0.5) ** 2).sum(0) + (-0.5 * c[DI * DH:] ** 2).sum(0)
+    for r in (0, 17, 100, DI * DH + 3):
+        cp_, cm_ = ch.copy(), ch.copy()
+        cp_[r] += 1e-5
+        cm_[r] -= 1e-5
+        np.testing.assert_allclose(g[r], (dens(cp_) - dens(cm_)) / 2e-5, rtol=2e-3, atol=2e-3)
+    # an irregular plate — one instance's factor is exactly 1 and folds away, so that instance has a node less — stays unrolled
+    import scipy.stats as st_
+    ys = np.random.default_rng(2).standard_normal(16).astype(np.float32)
+
+    def scaled(xs):
+        _a = [None]
+
+        @genjax.gen
+        def kern(x):
+            return genjax.normal(genjax.tanh(_a[0]) * x, 1.0) @ "y"
+
+        @genjax.gen
+        def m2():
+            _a[0] = genjax.normal(0.0, 1.0) @ "a"
+            kern.vmap()(xs) @ "obs"
+        return m2
+
+    for x3, n_sites in ((1.0, 17), (1.25, 2)):
+        xs = np.linspace(0.55, 2.05, 16).astype(np.float32)
+        xs[3] = x3
+        prog2, _, _ = scaled(xs).pack((), C["obs", "y"].set(ys), True)
+        assert prog2.n_sites == n_sites and (n_sites == 2) == bool(prog2.c_sites[prog2.n_sites - 1].plate)
+        o2 = cpu.run_program(prog2, (1, 2), K)
+        a = o2["choices"][prog2.slot_of["a"]].astype(np.float64)
+        np.testing.assert_allclose(o2["weight"], st_.norm.logpdf(ys[:, None], np.tanh(a)[None, :] * xs[:, None], 1.0).sum(0), rtol=2e-5, atol=2e-4)

@@ -318,3 +318,66 @@ def test_generic_filter_on_a_nonlinear_model_written_with_expressions(K_, oracle
     print(f"nonlinear model, T={Tf}, K=2^16: device log-ML {dev.mean():.4f} +- {dev.std(ddof=1):.4f}, float64 filter {ref.mean():.4f} +- {ref.std(ddof=1):.4f}")
     assert abs(dev.mean() - ref.mean()) < 4 * se + 1e-3
     assert 0.4 < dev.std(ddof=1) / ref.std(ddof=1) < 2.5
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_network_classifier_vmapped_over_the_data_runs_as_a_generated_plate_kernel(K_, oracle, rng, monkeypatch):
+    """general expressions INSIDE a vmapped kernel — y_n ~ bernoulli(logits = w2 . tanh(W1 x_n)), latent weights, N observations: one
+    plate site whose block advances through the covariates by its strides.  The generated kernel (plate loop, nodes emitted inline,
+    table offsets with the instance stride) and the interpreter against the oracle; the log-ML of a tiny instance against quadrature."""
+    from genjax_amd import C as CM
+    N, DI, DH, K = 64, 16, 8, 3001
+    model, X, Y, loglik = H.bnn_model(N, DI, DH)
+    prog, _, _ = model.pack((), CM["obs", "y"].set(Y), True, rng_mode=rng)
+    assert prog.n_sites == DH + 2 and prog.c_sites[prog.n_sites - 1].plate_n == N
+    monkeypatch.delenv("GJX_ENGINE", raising=False)
+    assert K_.program_engine(prog) == 4
+    o = oracle.run_program(prog, (4, 5), K, want_site_scores=True)
+    for eng in ("gen", "interp"):
+        monkeypatch.setenv("GJX_ENGINE", eng)
+        g = K_.run_program(prog, (4, 5), K, want_site_scores=True)
+        np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=RT, atol=AT, err_msg=eng)
+        np.testing.assert_allclose(_np(g["logw"]), o["logw"], rtol=5e-4, atol=2e-3, err_msg=eng)
+        np.testing.assert_allclose(_np(g["site_scores"])[-1], o["site_scores"][-1], rtol=5e-4, atol=2e-3, err_msg=eng)
+    W1 = o["choices"][:DI * DH].astype(np.float64).reshape(DH, DI, K)
+    np.testing.assert_allclose(_np(g["logw"]), loglik(W1, o["choices"][DI * DH:].astype(np.float64)), rtol=5e-4, atol=2e-3)
+    # few particles over many observations: the wide flavour (instances dealt to the 16 waves of a block) gives the same numbers
+    monkeypatch.setenv("GJX_ENGINE", "gen")
+    Kw = 512
+    model2, X2, Y2, _ = H.bnn_model(1024, 8, 4, seed=3)
+    prog2, _, _ = model2.pack((), CM["obs", "y"].set(Y2), True, rng_mode=rng)
+    assert K_.program_engine(prog2) == 4
+    g2, o2 = K_.run_program(prog2, (6, 7), Kw), oracle.run_program(prog2, (6, 7), Kw)
+    np.testing.assert_allclose(_np(g2["logw"]), o2["logw"], rtol=5e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_hmc_over_the_weights_of_a_small_network_through_the_plate(K_, oracle, rng, monkeypatch):
+    """HMC over the latent weights of a network classifier whose likelihood is a plate with an expression block (hmc.py:70-96
+    differentiates assess through the Vmap and through whatever the body computes): gradient and move, generated HMC kernel and
+    interpreter, against the oracle"""
+    import torch
+    from genjax_amd import C as CM
+    N, DI, DH, n = 96, 4, 3, 512
+    model, X, Y, loglik = H.bnn_model(N, DI, DH, seed=2)
+    sel = tuple(f"W1_{j}" for j in range(DH)) + ("w2",)
+    hp, _, _ = model.pack((), CM["obs", "y"].set(Y), False, selected=sel, per_particle=sel, plates="hmc", rng_mode=rng)
+    assert hp.n_sites == DH + 2
+    ch = (np.random.default_rng(5).standard_normal((hp.n_slots, n)) * 0.5).astype(np.float32)
+    so, go = oracle.score_grad(hp, ch)
+    sg, gg = K_.score_grad(hp, torch.as_tensor(ch).cuda())
+    np.testing.assert_allclose(_np(sg), so, rtol=5e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(gg), go, rtol=2e-3, atol=2e-3)
+    eps, L = 5e-3, 6
+    o = oracle.hmc(hp, (2, 9), ch, eps, L, False, False, offset=5)
+    engines = []
+    for eng in ("gen", "interp"):
+        monkeypatch.setenv("GJX_HMC_ENGINE", eng)
+        if eng == "gen" and K_.hmc_engine(hp) != 4:
+            continue
+        engines.append(eng)
+        g = K_.hmc(hp, (2, 9), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=5)
+        np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3, err_msg=eng)
+        np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=1e-2, atol=1e-2, err_msg=eng)
+    print("HMC engines that ran the plate with an expression block:", engines)
+    assert "interp" in engines
