@@ -696,6 +696,14 @@ std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_pa
   return need;
 }
 
+// register that holds element t of the leaf span of `node` (VALUE: t = 0; LINV: t < count) of parameter k's block: the slot number, or —
+// a plate program — what plate_program resolved; -1: the leaf lives in memory (rows of another plate)
+int expr_leaf_reg(const gjx_program* prog, const gjx_param& q, const RollInfo& ri, int k, int node, int t) {
+  const ExprNode e = expr_node(prog, q, node);
+  if (ri.eleaf_at[k].empty()) return (e.op == GJX_E_VALUE ? e.a : e.b) + t;
+  return ri.eleaf[k][ri.eleaf_at[k][node] + t].reg;
+}
+
 // the leaf reader of parameter k's block for the propagate emitters: registers by slot number, or — a plate program — what
 // plate_program resolved (RollInfo::eleaf): a register, or rows of choices[][] that advance with the instance
 std::function<std::string(int, int)> expr_leaf_reader(const gjx_program* prog, const gjx_param& q, const RollInfo& ri, int k) {
@@ -1903,7 +1911,8 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
       if (q.op == GJX_P_EXPR) {      // forward nodes and the reverse sweep as straight-line code; straight-line programs only
-        if (ri.plate || pl.rolled || pl.plates || !expr_block_ok(p, q, pl.n_regs, s.dim) || (big && q.len != 1)) return false;
+        if (pl.rolled || !expr_block_ok(p, q, pl.n_regs, s.dim, pl.plates) || (big && q.len != 1)) return false;
+        for (const auto& lf : ri.eleaf[k]) if (lf.reg < 0) return false;      // (a leaf in another plate's rows: the interpreter)
         unrolled += q.n / 4;
         continue;
       }
@@ -2021,7 +2030,7 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
         const std::string pfx = "en_" + std::to_string(k) + "_";
         emit_expr_nodes(o, g_expr_prog, q, out, pfx, (std::string(ind) + "  ").c_str(),
-                        [&q](int node, int t) { const ExprNode e = expr_node(g_expr_prog, q, node); return "v[" + std::to_string((e.op == GJX_E_VALUE ? e.a : e.b) + t) + "]"; });
+                        [&q, &ri, k](int node, int t) { return "v[" + std::to_string(expr_leaf_reg(g_expr_prog, q, ri, k, node, t)) + "]"; });
         o.f("%s  const float pre_%d = %s%d;\n", ind, k, pfx.c_str(), out);
         break;
       }
@@ -2082,8 +2091,8 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         const ExprNode e = expr_node(g_expr_prog, q, i);
         switch (e.op) {
           case GJX_E_CONST: case GJX_E_GT: break;
-          case GJX_E_VALUE: live[i] = hp.sel_of_slot[e.a] >= 0; break;
-          case GJX_E_LINV: for (int t = 0; t < e.c; ++t) live[i] = live[i] || hp.sel_of_slot[e.b + t] >= 0; break;
+          case GJX_E_VALUE: live[i] = hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, 0)] >= 0; break;
+          case GJX_E_LINV: for (int t = 0; t < e.c; ++t) live[i] = live[i] || hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, t)] >= 0; break;
           case GJX_E_ADD: case GJX_E_SUB: case GJX_E_MUL: case GJX_E_DIV: case GJX_E_MAX: case GJX_E_MIN: live[i] = live[e.a] || live[e.b]; break;
           case GJX_E_WHERE: live[i] = live[e.b] || live[e.c]; break;
           case GJX_E_LINN: for (int t = 0; t < e.c; ++t) live[i] = live[i] || live[e.b + t]; break;
@@ -2101,10 +2110,12 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         const std::string gi = AD(i);
         auto add = [&](int to, const std::string& term) { if (live[to]) o.f("%s    %s += %s;\n", ind, AD(to).c_str(), term.c_str()); };
         switch (e.op) {
-          case GJX_E_VALUE: o.f("%s    %s[%d] += %s;\n", ind, acc, hp.sel_of_slot[e.a], gi.c_str()); break;
+          case GJX_E_VALUE: o.f("%s    %s[%d] += %s;\n", ind, acc, hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, 0)], gi.c_str()); break;
           case GJX_E_LINV:
-            for (int t = 0; t < e.c; ++t) if (hp.sel_of_slot[e.b + t] >= 0)
-              o.f("%s    %s[%d] = fmaf(%s, TAB(%d), %s[%d]);\n", ind, acc, hp.sel_of_slot[e.b + t], gi.c_str(), e.a + 1 + t, acc, hp.sel_of_slot[e.b + t]);
+            for (int t = 0; t < e.c; ++t) {
+              const int m_ = hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, t)];
+              if (m_ >= 0) o.f("%s    %s[%d] = fmaf(%s, TAB(%s + %d), %s[%d]);\n", ind, acc, m_, gi.c_str(), toff(e.a, e.da).c_str(), 1 + t, acc, m_);
+            }
             break;
           case GJX_E_ADD: add(e.a, gi); add(e.b, gi); break;
           case GJX_E_SUB: add(e.a, gi); add(e.b, "-" + gi); break;
@@ -2113,7 +2124,7 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
           case GJX_E_MAX: add(e.a, N(e.a) + " >= " + N(e.b) + " ? " + gi + " : 0.0f"); add(e.b, N(e.a) + " >= " + N(e.b) + " ? 0.0f : " + gi); break;
           case GJX_E_MIN: add(e.a, N(e.a) + " <= " + N(e.b) + " ? " + gi + " : 0.0f"); add(e.b, N(e.a) + " <= " + N(e.b) + " ? 0.0f : " + gi); break;
           case GJX_E_WHERE: add(e.b, N(e.a) + " != 0.0f ? " + gi + " : 0.0f"); add(e.c, N(e.a) + " != 0.0f ? 0.0f : " + gi); break;
-          case GJX_E_LINN: for (int t = 0; t < e.c; ++t) add(e.b + t, gi + " * TAB(" + std::to_string(e.a + 1 + t) + ")"); break;
+          case GJX_E_LINN: for (int t = 0; t < e.c; ++t) add(e.b + t, gi + " * TAB(" + toff(e.a, e.da) + " + " + std::to_string(1 + t) + ")"); break;
           case GJX_E_CONST: case GJX_E_GT: break;
           default: add(e.a, gi + " * expr_unary_deriv(" + std::to_string(e.op) + ", " + N(e.a) + ", " + N(i) + ")"); break;
         }
@@ -2320,8 +2331,8 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
         if (q.op == GJX_P_EXPR)
           for (int i = 0; i < q.n; ++i) {
             const ExprNode e = expr_node(g_expr_prog, q, i);
-            if (e.op == GJX_E_VALUE && hp.sel_of_slot[e.a] >= 0) touched[hp.sel_of_slot[e.a]] = 1;
-            if (e.op == GJX_E_LINV) for (int t = 0; t < e.c; ++t) if (hp.sel_of_slot[e.b + t] >= 0) touched[hp.sel_of_slot[e.b + t]] = 1;
+            if (e.op == GJX_E_VALUE && hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, 0)] >= 0) touched[hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, 0)]] = 1;
+            if (e.op == GJX_E_LINV) for (int t = 0; t < e.c; ++t) { const int m_ = hp.sel_of_slot[expr_leaf_reg(g_expr_prog, q, ri, k, i, t)]; if (m_ >= 0) touched[m_] = 1; }
           }
       }
       for (int m = 0; m < NSEL; ++m) if (touched[m]) o.f("    g[%d] += CPL > 1 ? QSUM(ga[%d]) : ga[%d];\n", m, m, m);
