@@ -1394,6 +1394,158 @@ def run_round5(dev):
     return res
 
 
+def run_round6(dev):
+    """Round-6 paths, short runs: general expressions (GJX_P_EXPR) — a 16 -> 8 -> 1 network likelihood under ImportanceK on the
+    generated kernel and on the interpreter; a network classifier vmapped over the data as ONE plate (generated plate kernel vs
+    interpreter; HMC over its weights, generated vs interpreter); the generic filter on a nonlinear model whose step means are
+    expression blocks; the generic filter over a model with latent parameters in front of the Scan."""
+    import math as m_
+    import genjax_amd as genjax
+    from genjax_amd import C as CM
+    from genjax_amd import _abi as A
+    from genjax_amd import kernels
+    from genjax_amd.inference import BootstrapFilter
+    from genjax_amd.program import PackedProgram
+    res = {}
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+
+    def with_engine(var, val, fn):
+        old = os.environ.get(var)
+        os.environ[var] = val
+        try:
+            return fn()
+        finally:
+            if old is None:
+                del os.environ[var]
+            else:
+                os.environ[var] = old
+
+    # (1) bernoulli(logits = w2 . tanh(W1 x)), x latent (16): ImportanceK at K = 2^20
+    W1 = np.random.default_rng(0).standard_normal((8, 16)) * 0.4
+    w2 = np.random.default_rng(1).standard_normal(8)
+
+    @genjax.gen
+    def mlp():
+        x = genjax.mv_normal_diag(np.zeros(16, np.float32), np.ones(16, np.float32)) @ "x"
+        genjax.bernoulli(logits=w2 @ genjax.tanh(W1 @ x)) @ "y"
+
+    sl, _ = mlp.site_list(())
+    prog = PackedProgram(sl, {"y": A.MODE_OBS_TAB}, {"y": np.float32(1.0)})
+    K = 1 << 20
+    row = {}
+    for eng in ("gen", "interp"):
+        out = with_engine("GJX_ENGINE", eng, lambda: kernels.run_program(prog, (0, 1), K, want_weight=False, want_lse=False))
+        us = with_engine("GJX_ENGINE", eng, lambda: timed(lambda: kernels.run_program(prog, (0, 1), K, out=out, want_weight=False, want_lse=False), 20 if eng == "gen" else 5))
+        row[eng] = dict(kernel_us=us, engine=with_engine("GJX_ENGINE", eng, lambda: kernels.program_engine(prog)))
+    algo = (4 * 16 + 8) * K
+    row["gen"].update(achieved=algo / (row["gen"]["kernel_us"] * 1e-6) / 1e9, unit="GB/s", frac=algo / (row["gen"]["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                      algorithmic_bytes_per_launch=algo)
+    row["generated_vs_interpreter"] = row["interp"]["kernel_us"] / row["gen"]["kernel_us"]
+    row["note"] = "the 17-node block (8 LINV rows over the 16 latent values, 8 tanh, one LINN row) emitted inline; 72 B written per particle"
+    res["mlp_16_8_1_importance_K2e20"] = row
+
+    # (2) a network classifier vmapped over N = 1024 observations (one plate site, strided block), K = 2^14 particles
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    N, DI, DH, Kp = 1024, 16, 8, 1 << 14
+    model, X, Y, _ = H.bnn_model(N, DI, DH)
+    bprog, _, _ = model.pack((), CM["obs", "y"].set(Y), True)
+    row = dict(device_sites=bprog.n_sites, instances=N, particles=Kp)
+    for eng in ("gen", "interp"):
+        out = with_engine("GJX_ENGINE", eng, lambda: kernels.run_program(bprog, (0, 1), Kp, want_weight=False, want_lse=False))
+        us = with_engine("GJX_ENGINE", eng, lambda: timed(lambda: kernels.run_program(bprog, (0, 1), Kp, out=out, want_weight=False, want_lse=False), 10 if eng == "gen" else 3))
+        row[eng] = dict(kernel_us=us)
+    flops = Kp * N * (2 * DI * DH + 2 * DH + 12 * DH)
+    row["gen"]["tflops"] = flops / (row["gen"]["kernel_us"] * 1e-6) / 1e12
+    row["generated_vs_interpreter"] = row["interp"]["kernel_us"] / row["gen"]["kernel_us"]
+    res["network_classifier_plate_N1024_K2e14"] = row
+    # HMC over the weights of a smaller network through the plate (generated HMC kernel vs interpreter)
+    N2, n_ch = 512, 1 << 13
+    model2, X2, Y2, _ = H.bnn_model(N2, 4, 3, seed=2)
+    sel = tuple(f"W1_{j}" for j in range(3)) + ("w2",)
+    hp, _, _ = model2.pack((), CM["obs", "y"].set(Y2), False, selected=sel, per_particle=sel, plates="hmc")
+    ch0 = torch.as_tensor((np.random.default_rng(5).standard_normal((hp.n_slots, n_ch)) * 0.3).astype(np.float32), device=dev)
+    row = dict(observations=N2, chains=n_ch, leapfrog=10)
+    for eng in ("gen", "interp"):
+        e_ = with_engine("GJX_HMC_ENGINE", eng, lambda: kernels.hmc_engine(hp))
+        ms = with_engine("GJX_HMC_ENGINE", eng, lambda: timed(lambda: kernels.hmc(hp, (1, 2), ch0, 0.01, 10, False, True), 5 if eng == "gen" else 2)) * 1e-3
+        row[eng] = dict(ms_per_move=ms, engine=e_)
+    row["generated_vs_interpreter"] = row["interp"]["ms_per_move"] / row["gen"]["ms_per_move"]
+    res["hmc_network_weights_through_plate"] = row
+
+    # (3) the generic filter on the nonlinear benchmark model (both step means are expression blocks of the carry)
+    def time_filter(bf, chm, args, n=5):
+        bf.alias_outputs = True
+        for i in range(2):
+            bf.run(genjax.key(i), chm, args)
+        runs = []
+        for i in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = bf.run(genjax.key(10 + i), chm, args)
+            torch.cuda.synchronize()
+            runs.append(time.perf_counter() - t0)
+        return sorted(runs)[len(runs) // 2], out
+
+    T, Kf = 256, 1 << 18
+
+    @genjax.gen
+    def nl_step(x_prev, c_t):
+        x = genjax.normal(0.5 * x_prev + 25.0 * x_prev / (1.0 + x_prev * x_prev) + c_t, m_.sqrt(10.0)) @ "x"
+        genjax.normal(x * x / 20.0, 1.0) @ "y"
+        return x, None
+
+    rs = np.random.default_rng(0)
+    cs = (8.0 * np.cos(1.2 * np.arange(T))).astype(np.float32)
+    xv, ysl = 0.1, []
+    for t in range(T):
+        xv = 0.5 * xv + 25.0 * xv / (1 + xv * xv) + cs[t] + m_.sqrt(10.0) * rs.standard_normal()
+        ysl.append(xv * xv / 20.0 + rs.standard_normal())
+    ys = np.asarray(ysl, np.float32)
+    bf = BootstrapFilter(nl_step.scan(n=T), Kf)
+    dt, out = time_filter(bf, CM["y"].set(ys), (np.float32(0.1), cs))
+    res["scan_filter_nonlinear_expressions_T256_K2e18"] = dict(us_per_step=dt / T * 1e6, form=bf.last_info["form_name"], launches=bf.last_info["launches"],
+                                                              log_ml=float(out["log_ml"]), particle_steps_per_sec=Kf * T / dt,
+                                                              note="x_t ~ normal(x/2 + 25 x / (1 + x^2) + 8 cos(1.2 t), sqrt 10), y_t ~ normal(x^2 / 20, 1): GJX_P_EXPR blocks inside gjx_gen_pf")
+    # (4) latent parameters in front of the Scan (stochastic volatility with latent phi and log sigma)
+    from genjax_amd.inference import BootstrapFilter as BF
+
+    @genjax.gen
+    def sv_step(carry, _):
+        x_prev, phi, ls = carry
+        x = genjax.normal(phi * x_prev, genjax.exp(ls)) @ "x"
+        genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+        return (x, phi, ls), None
+
+    @genjax.gen
+    def sv_model():
+        phi = genjax.uniform(0.8, 0.99) @ "phi"
+        ls = genjax.normal(m_.log(0.3), 0.3) @ "log_sigma"
+        sv_step.scan(n=T)((0.0, phi, ls), None) @ "chain"
+
+    ysv = (np.random.default_rng(3).standard_normal(T) * 1.2).astype(np.float32)
+    bf2 = BF(sv_model, Kf)
+    dt2, out2 = time_filter(bf2, CM["chain", "y"].set(ysv), ())
+    lw = out2["logw"].double()
+    w = torch.exp(lw - lw.max())
+    res["scan_filter_latent_parameters_T256_K2e18"] = dict(us_per_step=dt2 / T * 1e6, form=bf2.last_info["form_name"], launches=bf2.last_info["launches"],
+                                                          log_ml=float(out2["log_ml"]),
+                                                          posterior_mean_phi=float((w * bf2.latent(out2, "phi")[0].double()).sum() / w.sum()),
+                                                          note="phi and log sigma drawn in front of the Scan travel with the particles (GJX_SITE_CARRIED inputs)")
+    return res
+
+
 def _config4_worker(rank, world, port, K_total, T, dx, out_dir, verify):
     """one rank of the config-4 dry run (processes sharing ONE device): the sharded filter over peer-mapped windows"""
     import hashlib
@@ -1687,7 +1839,7 @@ def main():
             # everything else the round measured (generated kernels, the generic filter, plates, HMC engines, the config-4 dry run,
             # the API-level step): minutes of work and tens of KB of JSON — they go to the side file, never onto the driver's line
             for name, fn in (("sharded_one_rank", run_sharded_one_rank), ("codegen", run_codegen), ("hmc_generic", run_hmc_generic),
-                             ("hmc_generated", run_hmc_generated), ("round4", run_round4), ("round5", run_round5),
+                             ("hmc_generated", run_hmc_generated), ("round4", run_round4), ("round5", run_round5), ("round6", run_round6),
                              ("config4_dry_run", run_config4_dry_run), ("round3", run_round3)):
                 try:
                     extra[name] = fn(dev)

@@ -133,6 +133,9 @@ struct RollInfo {
   struct ExprLeaf { int reg = -1; int mem_row = -1, mem_stride = 0; };
   std::vector<ExprLeaf> eleaf[4];
   std::vector<int> eleaf_at[4];
+  // ... of a ROLLED Scan's loop body: how far the table entries a node names (CONST; the [bias, weights] of LINV / LINN) advance per
+  // step (detect_roll checked that every step's block is step 1's with these strides); empty: the nodes' own plate strides
+  std::vector<int> enode_dtab[4];
 };
 
 // loop variable of the site being emitted: steps of a rolled Scan, or instances of a plate
@@ -286,7 +289,6 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
   if ((p->rng_mode != GJX_RNG_FLAT && !any_stream) || getenv("GJX_GEN_NO_ROLL")) return r;
   const int n = p->n_sites;
   for (int j = 0; j < n; ++j) if (p->sites[j].plate != 0) return r;      // (a rolled Scan and a plate loop in one kernel: not emitted)
-  if (has_expr(p->sites, n)) return r;                                   // (the slots inside expression blocks are not remapped to the loop's registers)
   int i0 = 0;
   while (i0 < n && p->sites[i0].scan == 0) ++i0;
   if (i0 == n || GJX_SCAN_STEP(p->sites[i0].scan) != 0) return r;
@@ -355,6 +357,39 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
       for (int k = 0; k < n_params(a.kind); ++k) {
         const gjx_param &qa = a.p[k], &qb = b.p[k];
         if (qa.op != qb.op || qa.xf != qb.xf || qa.len != qb.len || qa.n != qb.n) return r;
+        if (qa.op == GJX_P_EXPR) {
+          // an expression block: step t's node list is step 1's with the leaves that read Scan slots moved by (t - 1) S and the table
+          // entries moved by a fixed stride per node (taken from steps 1 and 2)
+          if (!p->tab || qa.n < 1 || qa.n > GJX_EXPR_MAX_NODES || qa.off < 0 || qa.off + GJX_EXPR_NODE_FLOATS * qa.n > p->n_tab ||
+              qb.off < 0 || qb.off + GJX_EXPR_NODE_FLOATS * qb.n > p->n_tab) return r;
+          if (t == 1) {
+            const gjx_param& q2 = at(2, l).p[k];
+            if (q2.op != GJX_P_EXPR || q2.n != qa.n || q2.off < 0 || q2.off + GJX_EXPR_NODE_FLOATS * q2.n > p->n_tab) return r;
+            st[l].enode_dtab[k].assign(qa.n, 0);
+            for (int i = 0; i < qa.n; ++i) {
+              const ExprNode ea = expr_node(p, qa, i), e2 = expr_node(p, q2, i);
+              if (ea.op == GJX_E_CONST || ea.op == GJX_E_LINV || ea.op == GJX_E_LINN) st[l].enode_dtab[k][i] = e2.a - ea.a;
+            }
+          }
+          for (int i = 0; i < qa.n; ++i) {
+            const ExprNode ea = expr_node(p, qa, i), eb = expr_node(p, qb, i);
+            if (ea.op != eb.op || ea.c != eb.c || ea.da || ea.db || eb.da || eb.db) return r;
+            auto moves_ok = [&](int sa, int sb, int span) {     // a slot reference of step 1 (sa) and of step t (sb)
+              const bool pre = sa + span <= n_pre;
+              if (pre ? sb != sa : sb != sa + (t - 1) * S) return false;
+              if (pre) return true;
+              return (sa >= base(0) && sa + span <= base(0) + S) || (sa >= base(1) && sa + span <= base(1) + S);
+            };
+            switch (ea.op) {
+              case GJX_E_CONST: if (eb.a != ea.a + (t - 1) * st[l].enode_dtab[k][i]) return r; break;
+              case GJX_E_VALUE: if (!moves_ok(ea.a, eb.a, 1)) return r; break;
+              case GJX_E_LINV: if (eb.a != ea.a + (t - 1) * st[l].enode_dtab[k][i] || !moves_ok(ea.b, eb.b, ea.c)) return r; break;
+              case GJX_E_LINN: if (eb.a != ea.a + (t - 1) * st[l].enode_dtab[k][i] || eb.b != ea.b) return r; break;
+              default: if (eb.a != ea.a || eb.b != ea.b) return r; break;
+            }
+          }
+          continue;
+        }
         if (qa.op != GJX_P_VALUE && qb.off != qa.off + (t - 1) * st[l].d_off[k]) return r;
         if (qa.op == GJX_P_AFFINE && qb.moff != qa.moff + (t - 1) * st[l].d_moff[k]) return r;
         // a row gather of a latent vector: the vector lives in front of the Scan (registers that do not move with the step)
@@ -375,6 +410,17 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
   for (int l = 0; l < m; ++l)
     for (int k = 0; k < n_params(at(0, l).kind); ++k) {
       const gjx_param& q = at(0, l).p[k];
+      if (q.op == GJX_P_EXPR) {
+        if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.off < 0 || q.off + GJX_EXPR_NODE_FLOATS * q.n > p->n_tab) return r;
+        for (int i = 0; i < q.n; ++i) {
+          const ExprNode e = expr_node(p, q, i);
+          if (e.da || e.db) return r;
+          if (e.op != GJX_E_VALUE && e.op != GJX_E_LINV) continue;
+          const int sa = e.op == GJX_E_VALUE ? e.a : e.b, span = e.op == GJX_E_VALUE ? 1 : e.c;
+          if (!(sa + span <= n_pre) && !(sa >= base(0) && sa + span <= base(0) + S)) return r;
+        }
+        continue;
+      }
       if (q.op == GJX_P_VGATHER && (q.moff < 0 || q.moff + q.n * q.len > n_pre)) return r;
       if (!slot_op(q.op)) continue;
       const bool pre = q.slot + ref_span(q) <= n_pre;
@@ -389,6 +435,17 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
     if (sj.slot >= 0 && (sj.slot < post0 || sj.slot + width(sj) > F0)) return r;
     for (int k = 0; k < n_params(sj.kind); ++k) {
       const gjx_param& q = sj.p[k];
+      if (q.op == GJX_P_EXPR) {
+        if (!p->tab || q.n < 1 || q.n > GJX_EXPR_MAX_NODES || q.off < 0 || q.off + GJX_EXPR_NODE_FLOATS * q.n > p->n_tab) return r;
+        for (int i = 0; i < q.n; ++i) {
+          const ExprNode e = expr_node(p, q, i);
+          if (e.da || e.db) return r;
+          if (e.op != GJX_E_VALUE && e.op != GJX_E_LINV) continue;
+          const int sa = e.op == GJX_E_VALUE ? e.a : e.b, span = e.op == GJX_E_VALUE ? 1 : e.c;
+          if (!(sa + span <= n_pre) && !(sa >= base(T - 1) && sa + span <= base(T - 1) + S) && !(sa >= post0 && sa + span <= F0)) return r;
+        }
+        continue;
+      }
       if (q.op == GJX_P_VGATHER && (q.moff < 0 || q.moff + q.n * q.len > n_pre)) return r;
       if (!slot_op(q.op)) continue;
       const bool pre = q.slot + ref_span(q) <= n_pre;
@@ -410,12 +467,29 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
     if (ref >= post0) return reg_post0 + (ref - post0);
     return n_pre + (ref - base(T - 1));           // the last step: the loop's final carry left it in the "previous" registers
   };
+  // the leaves of a site's expression blocks -> the registers of the emitted program (RollInfo::eleaf)
+  auto expr_leaves = [&](const gjx_site& s, RollInfo& ri, const std::function<int(int)>& map) {
+    if (s.mode == GJX_MODE_INPUT) return;
+    for (int k = 0; k < n_params(s.kind); ++k) {
+      const gjx_param& q = s.p[k];
+      if (q.op != GJX_P_EXPR) continue;
+      ri.eleaf[k].clear();
+      ri.eleaf_at[k].assign(q.n, -1);
+      for (int i = 0; i < q.n; ++i) {
+        const ExprNode e = expr_node(p, q, i);
+        if (e.op != GJX_E_VALUE && e.op != GJX_E_LINV) continue;
+        ri.eleaf_at[k][i] = (int)ri.eleaf[k].size();
+        for (int t2 = 0; t2 < (e.op == GJX_E_VALUE ? 1 : e.c); ++t2) { RollInfo::ExprLeaf lf; lf.reg = map((e.op == GJX_E_VALUE ? e.a : e.b) + t2); ri.eleaf[k].push_back(lf); }
+      }
+    }
+  };
   {
     int fi = 0;
     for (int j = 0; j < i0; ++j) {
       gjx_site s = p->sites[j];
       RollInfo ri; ri.row = s.slot; ri.score_row = j;
       if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; s.obs_off = reg_f0 + fi++; ri.load_here = true; }
+      expr_leaves(s, ri, [](int ref) { return ref; });
       r.sites.push_back(s);
       r.info.push_back(ri);
     }
@@ -431,6 +505,8 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
       if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; ri.d_flag_row = tau ? mk : 0; s.obs_off = reg_f0 + nf_pre + fi++; }
       if (s.slot >= 0) s.slot = remap(s.slot, tau);
       for (int k = 0; k < n_params(s.kind); ++k) if (slot_op(s.p[k].op)) s.p[k].slot = remap(s.p[k].slot, tau);
+      expr_leaves(s, ri, [&](int ref) { return remap(ref, tau); });
+      if (!tau) for (int k = 0; k < 4; ++k) ri.enode_dtab[k].clear();        // (step 0 is emitted outside the loop: nothing strides)
       r.sites.push_back(s);
       r.info.push_back(ri);
     }
@@ -444,6 +520,7 @@ Roll detect_roll(const gjx_program* p, bool any_stream = false) {     // any_str
       if (s.mode == GJX_MODE_OBS_MASK) { ri.flag_row = s.obs_off; s.obs_off = reg_f0 + nf_pre + mk + fi++; }
       if (s.slot >= 0) s.slot = remap_post(s.slot);
       for (int k = 0; k < n_params(s.kind); ++k) if (slot_op(s.p[k].op)) s.p[k].slot = remap_post(s.p[k].slot);
+      expr_leaves(s, ri, [&](int ref) { return remap_post(ref); });
       r.sites.push_back(s);
       r.info.push_back(ri);
     }
@@ -606,7 +683,7 @@ bool supported_uncached(const gjx_program* p) {
   if (px.any) return px.ok && supported_sites(px.sites.data(), (int)px.sites.size(), px.n_regs, p, true);
   if (p->n_sites >= 1 && supported_sites(p->sites, p->n_sites, p->n_slots, p)) return true;
   const Roll r = detect_roll(p);      // a long periodic Scan is emitted as a loop
-  return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs);
+  return r.ok && supported_sites(r.sites.data(), (int)r.sites.size(), r.n_regs, p, true);
 }
 
 // index into the float table of parameter q at element `d` (a C expression; `dx` is the element index expression)
@@ -646,7 +723,8 @@ std::string xf_wrap(int xf, const std::string& e) {
 // schedules and merges them with the site's own arithmetic; values are in registers: val(slot) is `vfmt` with the slot number).
 // -> the set of emitted nodes.  The unary forms use the device header's helpers (the interpreter's expr_unary computes the same).
 std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_param& q, int out, const std::string& pfx, const char* ind,
-                                  const std::function<std::string(int, int)>& val) {   // val(node, element of the node's leaf span)
+                                  const std::function<std::string(int, int)>& val,      // val(node, element of the node's leaf span)
+                                  const std::vector<int>* dtab = nullptr) {              // a rolled Scan's per-node table strides (RollInfo::enode_dtab)
   std::vector<char> need(q.n, 0);
   need[out] = 1;
   for (int i = out; i >= 0; --i) {
@@ -665,7 +743,8 @@ std::vector<char> emit_expr_nodes(Emit& o, const gjx_program* prog, const gjx_pa
   auto T = [&](int base, int stride, int at) { return "TAB(" + toff(base, stride) + (at ? " + " + std::to_string(at) : "") + ")"; };
   for (int i = 0; i <= out; ++i) {
     if (!need[i]) continue;
-    const ExprNode e = expr_node(prog, q, i);
+    ExprNode e = expr_node(prog, q, i);
+    if (dtab && !dtab->empty()) e.da = (*dtab)[i];
     std::string r;
     const std::string A = e.op >= GJX_E_ADD && e.op != GJX_E_LINV && e.op != GJX_E_LINN ? N(e.a) : "", B = N(e.b);
     switch (e.op) {
@@ -722,7 +801,7 @@ void emit_param_pre(Emit& o, const gjx_param& q, const std::string& dx, int site
     // (supported_sites: a block with several outputs only under literal element indices; no plate / roll remapping of its slots)
     const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
     const std::string pfx = "en_" + std::to_string(site) + "_" + std::to_string(k) + "_";
-    emit_expr_nodes(o, g_expr_prog, q, out, pfx, ind, expr_leaf_reader(g_expr_prog, q, ri, k));
+    emit_expr_nodes(o, g_expr_prog, q, out, pfx, ind, expr_leaf_reader(g_expr_prog, q, ri, k), &ri.enode_dtab[k]);
     o.f("%sconst float ex_%d_%d = %s%d;\n", ind, site, k, pfx.c_str(), out);
     return;
   }
@@ -1911,7 +1990,7 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
     for (int k = 0; k < n_params(s.kind); ++k) {
       const gjx_param& q = s.p[k];
       if (q.op == GJX_P_EXPR) {      // forward nodes and the reverse sweep as straight-line code; straight-line programs only
-        if (pl.rolled || !expr_block_ok(p, q, pl.n_regs, s.dim, pl.plates) || (big && q.len != 1)) return false;
+        if (!expr_block_ok(p, q, pl.n_regs, s.dim, pl.plates || pl.rolled) || (big && q.len != 1)) return false;
         for (const auto& lf : ri.eleaf[k]) if (lf.reg < 0) return false;      // (a leaf in another plate's rows: the interpreter)
         unrolled += q.n / 4;
         continue;
@@ -2030,7 +2109,7 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
         const int out = q.n - q.len + (q.len == 1 ? 0 : literal_index(dx) % q.len);
         const std::string pfx = "en_" + std::to_string(k) + "_";
         emit_expr_nodes(o, g_expr_prog, q, out, pfx, (std::string(ind) + "  ").c_str(),
-                        [&q, &ri, k](int node, int t) { return "v[" + std::to_string(expr_leaf_reg(g_expr_prog, q, ri, k, node, t)) + "]"; });
+                        [&q, &ri, k](int node, int t) { return "v[" + std::to_string(expr_leaf_reg(g_expr_prog, q, ri, k, node, t)) + "]"; }, &ri.enode_dtab[k]);
         o.f("%s  const float pre_%d = %s%d;\n", ind, k, pfx.c_str(), out);
         break;
       }
@@ -2106,7 +2185,8 @@ void hmc_emit_element(Emit& o, const gjx_program* prog, const HmcPlan& hp, int j
       for (int i = 0; i <= out; ++i) if (need[i] && live[i]) o.f("%s    float %s = %s;\n", ind, AD(i).c_str(), i == out ? w.c_str() : "0.0f");
       for (int i = out; i >= 0; --i) {
         if (!need[i] || !live[i]) continue;
-        const ExprNode e = expr_node(g_expr_prog, q, i);
+        ExprNode e = expr_node(g_expr_prog, q, i);
+        if (!ri.enode_dtab[k].empty()) e.da = ri.enode_dtab[k][i];
         const std::string gi = AD(i);
         auto add = [&](int to, const std::string& term) { if (live[to]) o.f("%s    %s += %s;\n", ind, AD(to).c_str(), term.c_str()); };
         switch (e.op) {

@@ -380,3 +380,51 @@ def test_hmc_over_the_weights_of_a_small_network_through_the_plate(K_, oracle, r
         np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3, err_msg=eng)
         np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=1e-2, atol=1e-2, err_msg=eng)
     assert engines == ["gen", "interp"], engines        # (the HMC emitter covers the plate: leaves in registers, table offsets by instance)
+
+
+@pytest.mark.parametrize("rng", RNGS)
+def test_a_long_scan_with_expression_blocks_is_rolled_and_its_states_are_moved_by_hmc(K_, oracle, rng, monkeypatch):
+    """the nonlinear model as ONE program of T = 120 steps (240 sites): the propagate emitter rolls the periodic Scan — the block of
+    step t is step 1's with its leaves moved to the loop's registers and its table entries strided — and the HMC emitter rolls it too
+    (HMC over all 120 states: smoothing); generated == interpreter == oracle"""
+    import torch
+    T, K, n = 120, 2000, 256
+    ys, cs = _nonlinear_data(T, seed=4)
+    scan = _nonlinear_scan(T)
+    prog, _, _ = scan.pack((np.float32(0.1), cs), C["y"].set(ys), True, rng_mode=rng)
+    assert prog.n_sites == 2 * T
+    if rng == A.RNG_FLAT:                      # (the propagate emitter rolls FLAT streams; JAX32 long Scans take the interpreter)
+        monkeypatch.delenv("GJX_ENGINE", raising=False)
+        assert K_.program_engine(prog) == 4, "a periodic Scan with expression blocks must roll"
+    o = oracle.run_program(prog, (8, 9), K)
+    for eng in (("gen", "interp") if rng == A.RNG_FLAT else ("interp",)):
+        monkeypatch.setenv("GJX_ENGINE", eng)
+        g = K_.run_program(prog, (8, 9), K)
+        # (the recursion x -> x/2 + 25 x / (1 + x^2) amplifies rounding differences near its unstable points: compare where the
+        # oracle's own trajectory is insensitive to a perturbation of a few ulps)
+        np.testing.assert_allclose(_np(g["choices"])[:3], o["choices"][:3], rtol=5e-4, atol=5e-4, err_msg=eng)
+        close = np.abs(_np(g["choices"]) - o["choices"]).max(axis=0) < 2e-2
+        assert close.mean() > 0.9, (eng, close.mean())
+        np.testing.assert_allclose(_np(g["logw"])[close], o["logw"][close], rtol=2e-3, atol=5e-2, err_msg=eng)
+    monkeypatch.delenv("GJX_ENGINE", raising=False)
+    # HMC over every state, a short trajectory with a small step
+    sel = tuple(("x", t) for t in range(T))
+    hp, _, _ = scan.pack((np.float32(0.1), cs), C["y"].set(ys), False, selected=sel, per_particle=sel, plates="hmc", rng_mode=rng)
+    ch = o["choices"][:, :n].astype(np.float32)
+    so, go = oracle.score_grad(hp, ch)
+    sg, gg = K_.score_grad(hp, torch.as_tensor(ch).cuda())
+    np.testing.assert_allclose(_np(sg), so, rtol=5e-4, atol=5e-2)
+    np.testing.assert_allclose(_np(gg), go, rtol=3e-3, atol=3e-3)
+    eps, L = 1e-3, 5
+    oh = oracle.hmc(hp, (2, 9), ch, eps, L, False, False, offset=3)
+    ran = []
+    for eng in ("gen", "interp"):
+        monkeypatch.setenv("GJX_HMC_ENGINE", eng)
+        if eng == "gen":
+            assert K_.hmc_engine(hp) == 4, "the HMC emitter must roll the Scan with its expression blocks"
+        ran.append(eng)
+        g = K_.hmc(hp, (2, 9), torch.as_tensor(ch).cuda(), eps, L, False, False, offset=3)
+        np.testing.assert_allclose(_np(g["choices"]), oh["choices"], rtol=3e-3, atol=3e-3, err_msg=eng)
+        mag = 5e-6 * np.maximum(np.abs(oh["score"]), np.abs(oh["score"] - oh["alpha"]))
+        assert (np.abs(_np(g["alpha"]) - oh["alpha"]) <= 1e-2 + 1e-2 * np.abs(oh["alpha"]) + mag).all(), eng
+    assert ran == ["gen", "interp"]
