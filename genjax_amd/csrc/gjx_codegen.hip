@@ -1858,6 +1858,7 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
 // float summation order.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kHmcMaxSel = 48, kHmcMaxSlots = 96, kHmcMaxTab = 36864;   // 144 KB of LDS for the table
+constexpr int kHmcBigSlots = 512;   // chain values of the LDS-state flavour (HmcPlan::big)
 
 struct HmcPlan {
   // the EMITTED site list: the program's, or — with plates — plate_program's (every slot a register; a body site owns one instance's
@@ -1888,6 +1889,11 @@ struct HmcPlan {
   bool mfma = false;
   std::vector<int> mf_k, xt_off;
   int xt_floats = 0, block = 256;
+  // chain state beyond the register budget (more than kHmcMaxSlots values or kHmcMaxSel selected ones: a network's weights, a model
+  // written as a hundred scalar sites): values, gradient, momenta (and the first gradient when it fits: nostale otherwise) live in
+  // LDS COLUMNS of a one-wave block — slot s of lane l at st[s * 64 + l]: conflict-free, indexed like the register arrays by the
+  // same emitted code —, the table is read from memory (the lanes of a wave read the same entry)
+  bool big = false, nostale = false;
   // bernoulli(logits = X v + b) with every observation 0 or 1: rows of X (both copies) and the bias are folded with the sign
   // s = 2 y - 1 and log2 e in the kernel's prologue — log p = log sigmoid(s a), d/da = s sigmoid(-s a): the element costs
   // exp2, add, rcp and needs neither y nor a subtraction (what the hand-written k_hmc_logreg_mfma2 does for its one shape)
@@ -1940,7 +1946,7 @@ bool hmc_elementwise(int kind) { return !is_categorical(kind) && kind != GJX_DIR
 
 // roll: plan the program as a rolled Scan (tried when the straight-line plan does not fit)
 bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
-  if (p->n_sites < 1 || p->n_slots < 1 || p->n_tab > kHmcMaxTab) return false;
+  if (p->n_sites < 1 || p->n_slots < 1) return false;
   g_expr_prog = p;
   HmcPlan pl;
   if (roll) {
@@ -1959,7 +1965,8 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
     }
   }
   const int ns = (int)pl.sites.size();
-  if (ns > 64 || pl.n_regs < 1 || pl.n_regs > kHmcMaxSlots) return false;
+  if (ns > 64 || pl.n_regs < 1) return false;
+  if (pl.n_regs > kHmcMaxSlots) { if (pl.rolled || pl.n_regs > kHmcBigSlots) return false; pl.big = true; }
   pl.sel_of_slot.assign(pl.n_regs, -1);
   int unrolled = 0;
   for (int j = 0; j < ns; ++j) {
@@ -2041,12 +2048,21 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
       pl.psel.push_back(ps);
     }
   }
-  if (pl.nsel < 1 || pl.nsel > kHmcMaxSel || unrolled > 256) return false;
+  if (pl.nsel < 1) return false;
+  if (pl.nsel > kHmcMaxSel || unrolled > 256 || p->n_tab > kHmcMaxTab) { if (pl.rolled) return false; pl.big = true; }   // (a table beyond the LDS: read from memory)
+  if (pl.big) {
+    // LDS columns of a 64-lane block: v, g, p (+ g0 for the stale-carry compatibility mode when it still fits 152 KB)
+    if (unrolled > 1024 || getenv("GJX_HMC_GEN_NO_BIG")) return false;
+    const int need3 = pl.n_regs + 2 * pl.nsel, need4 = need3 + pl.nsel;
+    if (need3 * 256 > 152 * 1024) return false;
+    pl.nostale = need4 * 256 > 152 * 1024;
+    pl.block = 64;
+  }
   pl.mf_k.assign(ns, -1);
   pl.xt_off.assign(ns, 0);
   pl.fold.assign(ns, 0);
   pl.bs_off.assign(ns, 0);
-  if (pl.looped && !pl.rolled && !getenv("GJX_HMC_GEN_NO_MFMA")) {
+  if (pl.looped && !pl.rolled && !pl.big && !getenv("GJX_HMC_GEN_NO_MFMA")) {
     const int tab_pad = (p->n_tab + 3) & ~3;
     for (int j = 0; j < ns; ++j) {
       const gjx_site& s = pl.sites[j];
@@ -2359,7 +2375,9 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   else o.f("GJX_DEV float QSUM(float x) { _Pragma(\"unroll\") for (int o_ = 1; o_ < CPL; o_ <<= 1) x += __shfl_xor(x, o_, 64); return x; }\n");
   // ---- the sweep: score (SC) and gradient of the selected slots.  ch_ / n_ / ic_: the chain's column of choices[][] — a plate's
   //      body sites with per-chain values (OBS_SLOT) read their instance's rows from there, sweep after sweep
-  o.f("template <bool SC>\nGJX_DEV float sweep(float (&v)[NS], float (&g)[NSEL], const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_,\n"
+  // (the chain state as register arrays, or — HmcPlan::big — as LDS columns behind the same indexing syntax)
+  o.f("struct LdsCol { float* b; GJX_DEV float& operator[](int i) const { return b[i * BT]; } };\n"
+      "template <bool SC, class VA, class GA>\nGJX_DEV float sweep(VA& v, GA& g, const float* __restrict__ tab_s, const float* __restrict__ xt_s, const int q_,\n"
       "                  const float* __restrict__ ch_, const int64_t n_, const int64_t ic_, const float* wq_, float* wg_, const bool live_) {\n"
       "  float sc_ = 0.0f;\n  const int c16_ = (int)(threadIdx.x & 15u); (void)c16_; (void)xt_s; (void)ch_; (void)n_; (void)ic_; (void)wq_; (void)wg_; (void)live_;\n"
       "  _Pragma(\"unroll\") for (int m_ = 0; m_ < NSEL; ++m_) g[m_] = 0.0f;\n");
@@ -2498,6 +2516,12 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   }
   o.f("  return sc_;\n}\n\n");
   // ---- the kernel
+  if (hp.big)
+    o.f("extern \"C\" __global__ __launch_bounds__(BT) void gjx_hmc_gen(HmcGenArgs a) {\n"
+        "  const float* __restrict__ tab_s = a.tab;     // (the table stays in memory: the LDS holds the chains' state)\n"
+        "  __shared__ __attribute__((aligned(16))) float xt_s[4];\n"
+        "  __shared__ __attribute__((aligned(16))) float st_s[(NS + %d * NSEL) * BT];\n", hp.nostale ? 2 : 3);
+  else
   o.f("extern \"C\" __global__ __launch_bounds__(BT) void gjx_hmc_gen(HmcGenArgs a) {\n"
       "  __shared__ __attribute__((aligned(16))) float tab_s[NTAB > 0 ? ((NTAB + 3) & ~3) : 4];\n"
       "  __shared__ __attribute__((aligned(16))) float xt_s[XTF > 0 ? XTF : 4];\n"
@@ -2529,8 +2553,11 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   o.f(
       "  const bool live = i_raw < a.n;\n  const int64_t n = a.n, i = live ? i_raw : a.n - 1;   // (every lane runs: the quads reduce across lanes)\n"
       "  const uint64_t gidx = (uint64_t)(a.offset + i);\n"
-      "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
-      "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = 0.0f;\n");
+      "%s"
+      "  _Pragma(\"unroll\") for (int s_ = 0; s_ < NS; ++s_) v[s_] = 0.0f;\n",
+      !hp.big ? "  float v[NS], g[NSEL], g0[NSEL], p[NSEL];\n"
+      : (hp.nostale ? "  LdsCol v{st_s + threadIdx.x}, g{st_s + NS * BT + threadIdx.x}, p{st_s + (NS + NSEL) * BT + threadIdx.x}, g0{st_s + NS * BT + threadIdx.x};   // (no room for the first gradient: the launcher refuses the stale-carry mode)\n"
+                    : "  LdsCol v{st_s + threadIdx.x}, g{st_s + NS * BT + threadIdx.x}, p{st_s + (NS + NSEL) * BT + threadIdx.x}, g0{st_s + (NS + 2 * NSEL) * BT + threadIdx.x};\n"));
   for (int j = 0; j < (hp.rolled ? hp.roll.i0 : prog->n_sites); ++j) {       // the chain's values: rows of choices[][] -> registers (a plate's body, a rolled Scan's steps: in the sweep)
     const gjx_site& sj = prog->sites[j];
     if (sj.slot < 0 || hp.info[j].plate) continue;
@@ -2647,7 +2674,7 @@ std::string generate_hmc(const gjx_program* prog_in, int cpl_code = 0) {
   o.f("    }\n    if (a.score) a.score[i] = sc;\n    if (a.alpha) a.alpha[i] = al;\n    if (a.accepted) a.accepted[i] = acc ? 1.0f : 0.0f;\n  }\n");
   if (hp.prows) { o.f("  if (acc) {\n"); plate_rows("if (live) a.choices[src_] = wq_[idx_];"); o.f("  }\n"); }
   o.f("}\n");
-  o.f("// PROWS %d\n// CPLMAX %d\n", hp.prows, cpl_max);
+  o.f("// PROWS %d\n// CPLMAX %d\n// NOSTALE %d\n", hp.prows, cpl_max, hp.nostale ? 1 : 0);
   o.f("// CPL %d\n// BT %d\n// LDS_FLOATS 0\n", cpl, hp.block);
   return o.s;
 }
@@ -2715,6 +2742,7 @@ struct Compiled {
   int cpl = 1, block = 256; // generated HMC kernels: lanes per chain, threads per block
   int prows = 0;            // generated HMC kernels: workspace rows (selected sites inside plates), x 4 x n floats
   int cpl_max = 1;          // generated HMC kernels: the most lanes per chain the program's loops can use
+  int nostale = 0;          // generated HMC kernels, LDS-state flavour without room for the first gradient: no stale-carry mode
   std::string error;        // non-empty: this structure cannot be generated / compiled
 };
 
@@ -2814,6 +2842,8 @@ const Compiled& compile(const gjx_program* prog, int ppt, int flavour = 0) {
   if (mp != std::string::npos) c.prows = atoi(src.c_str() + mp + 9);
   const size_t mx = src.rfind("// CPLMAX ");
   if (mx != std::string::npos) c.cpl_max = atoi(src.c_str() + mx + 10);
+  const size_t mn = src.rfind("// NOSTALE ");
+  if (mn != std::string::npos) c.nostale = atoi(src.c_str() + mn + 11);
   if ((size_t)c.lds_floats * 4 + 256 > 64 * 1024) { c.error = "the program's table does not fit the LDS budget"; return c; }
   // the code object on disk is named by the SOURCE it was compiled from (and the headers): a changed emitter or header
   // can never pick up a stale file
@@ -3133,6 +3163,7 @@ int hmc_gen_launch(const gjx_program* prog, const HmcGenArgs& args, hipStream_t 
     if (!c.error.empty()) return gjx_fail(GJX_EUNSUPPORTED, c.error.c_str());
     cpl = c.cpl;
     block = c.block;
+    if (c.nostale && args.stale) return gjx_fail(GJX_EUNSUPPORTED, "codegen: the LDS-state HMC kernel of this program has no room for the stale-carry compatibility mode");
     if (c.prows > 0 && (!args.ws || args.ws_floats < 4 * (int64_t)c.prows * args.n))
       return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small (selected sites inside a plate keep their trajectory state there)");
     int dev = 0;

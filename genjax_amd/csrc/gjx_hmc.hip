@@ -1123,7 +1123,8 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     ga.stale = stale_grad_compat; ga.accept = accept; ga.choices = choices; ga.score = score; ga.alpha = alpha; ga.accepted = accepted;
     ga.ws = workspace ? (float*)((char*)workspace + 256) : nullptr;          // (used only by programs with selected sites inside plates)
     ga.ws_floats = workspace && workspace_bytes > 256 ? (int64_t)((workspace_bytes - 256) / sizeof(float)) : 0;
-    return hmc_gen_launch(prog, ga, (hipStream_t)stream);
+    const int rc_gen = hmc_gen_launch(prog, ga, (hipStream_t)stream);
+    if (rc_gen != GJX_EUNSUPPORTED) return rc_gen;      // (a mode this program's generated kernel does not carry: the site interpreter below)
   }
   if (!workspace || workspace_bytes < gjx_hmc_workspace_bytes(prog, n)) return gjx_fail(GJX_EWORKSPACE, "gjx_hmc: workspace too small");
   HmcArgs a;

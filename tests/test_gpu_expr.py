@@ -352,13 +352,16 @@ def test_network_classifier_vmapped_over_the_data_runs_as_a_generated_plate_kern
 
 
 @pytest.mark.parametrize("rng", RNGS)
-def test_hmc_over_the_weights_of_a_small_network_through_the_plate(K_, oracle, rng, monkeypatch):
+@pytest.mark.parametrize("shape", [(96, 4, 3), (128, 16, 8)])
+def test_hmc_over_the_weights_of_a_small_network_through_the_plate(K_, oracle, rng, shape, monkeypatch):
     """HMC over the latent weights of a network classifier whose likelihood is a plate with an expression block (hmc.py:70-96
     differentiates assess through the Vmap and through whatever the body computes): gradient and move, generated HMC kernel and
     interpreter, against the oracle"""
     import torch
     from genjax_amd import C as CM
-    N, DI, DH, n = 96, 4, 3, 512
+    # (16 -> 8 -> 1: 136 selected values — beyond the register budget of the generated HMC kernel, whose LDS-state flavour keeps the
+    # chain's values, gradient and momenta in LDS columns of a one-wave block: HmcPlan::big)
+    (N, DI, DH), n = shape, 512
     model, X, Y, loglik = H.bnn_model(N, DI, DH, seed=2)
     sel = tuple(f"W1_{j}" for j in range(DH)) + ("w2",)
     hp, _, _ = model.pack((), CM["obs", "y"].set(Y), False, selected=sel, per_particle=sel, plates="hmc", rng_mode=rng)
@@ -368,7 +371,7 @@ def test_hmc_over_the_weights_of_a_small_network_through_the_plate(K_, oracle, r
     sg, gg = K_.score_grad(hp, torch.as_tensor(ch).cuda())
     np.testing.assert_allclose(_np(sg), so, rtol=5e-4, atol=2e-3)
     np.testing.assert_allclose(_np(gg), go, rtol=2e-3, atol=2e-3)
-    eps, L = 5e-3, 6
+    eps, L = (5e-3 if DI == 4 else 2e-3), 6
     o = oracle.hmc(hp, (2, 9), ch, eps, L, False, False, offset=5)
     engines = []
     for eng in ("gen", "interp"):

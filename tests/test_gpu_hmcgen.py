@@ -421,3 +421,48 @@ def test_random_long_scans_hmc_generated_interpreter_oracle(K_, oracle, rng, mon
     monkeypatch.delenv("GJX_HMC_ENGINE", raising=False)
     monkeypatch.delenv("GJX_HMC_GEN_CPL", raising=False)
     assert covered >= trials // 2, covered
+
+
+@pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("groups,dim", [(10, 12), (12, 16)])
+def test_generated_hmc_with_the_chain_state_in_lds(K_, oracle, rng, groups, dim, monkeypatch):
+    """straight-line programs beyond the register budget of the generated HMC kernel (more than 96 values / 48 selected ones: here 120
+    and 192 selected scalars in 10 / 12 vector sites under a common scale) run on its LDS-state flavour (HmcPlan::big: values,
+    gradient and momenta as LDS columns of a one-wave block) instead of the site interpreter.  Generated ==
+    interpreter == oracle, with and without the accept; the stale-carry compatibility mode where the first gradient still fits the
+    LDS, and through the interpreter (silently, same results) where it does not."""
+    import torch
+    rs = np.random.default_rng(3)
+    sl = SiteList()
+    sl.add("ls", A.NORMAL, [0.0, 0.5])
+    for j in range(groups):
+        sl.add(f"m{j}", A.MVNORMAL_DIAG, [np.zeros(dim, np.float32), Param.value("ls", xf=A.XF_EXP)], dim=dim)
+        sl.add(f"y{j}", A.MVNORMAL_DIAG, [Param.value(f"m{j}", dim), np.full(dim, 0.7, np.float32)], dim=dim)
+    modes = {s.addr: (A.MODE_OBS_TAB if s.addr.startswith("y") else A.MODE_OBS_SLOT) for s in sl.sites}
+    obs = {f"y{j}": rs.standard_normal(dim).astype(np.float32) for j in range(groups)}
+    sel = ("ls",) + tuple(f"m{j}" for j in range(groups))
+    prog = PackedProgram(sl, modes, obs, selected=sel, rng_mode=rng)
+    assert prog.n_slots == 1 + groups * dim
+    n = 300
+    ch = (rs.standard_normal((prog.n_slots, n)) * 0.4).astype(np.float32)
+    monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+    assert K_.hmc_engine(prog) == 4, "the LDS-state flavour must take this program"
+    assert "LdsCol v{" in K_.program_hmc_source(prog)
+    nostale = "// NOSTALE 1" in K_.program_hmc_source(prog)
+    assert nostale == (groups * dim + 1 > 150)
+    for stale, accept in ((False, False), (True, False), (False, True)):
+        eps, L = (0.02 if accept else 0.005), 8
+        o = oracle.hmc(prog, (4, 5), ch, eps, L, stale, accept, offset=2)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "gen")
+        g = K_.hmc(prog, (4, 5), torch.as_tensor(ch).cuda(), eps, L, stale, accept, offset=2)
+        monkeypatch.setenv("GJX_HMC_ENGINE", "interp")
+        it = K_.hmc(prog, (4, 5), torch.as_tensor(ch).cuda(), eps, L, stale, accept, offset=2)
+        if not accept:
+            np.testing.assert_allclose(_np(g["choices"]), o["choices"], rtol=3e-3, atol=3e-3)
+            np.testing.assert_allclose(_np(g["choices"]), _np(it["choices"]), rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(_np(g["alpha"]), o["alpha"], rtol=1e-2, atol=1e-2)
+        else:
+            flip = _np(g["accepted"]) != o["accepted"]
+            assert flip.mean() < 0.03 and (o["margin"][flip] < 1e-2 + 1e-2 * np.abs(o["alpha"][flip])).all()
+            rej = _np(g["accepted"]) == 0
+            np.testing.assert_array_equal(_np(g["choices"])[:, rej], ch[:, rej])
