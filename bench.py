@@ -1483,6 +1483,22 @@ def run_round6(dev):
         row[eng] = dict(ms_per_move=ms, engine=e_)
     row["generated_vs_interpreter"] = row["interp"]["ms_per_move"] / row["gen"]["ms_per_move"]
     res["hmc_network_weights_through_plate"] = row
+    # ... and the 16 -> 8 -> 1 network's 136 weights over 1024 observations: beyond the register budget, the generated kernel keeps the
+    # chain state in LDS columns (HmcPlan::big)
+    model3, X3, Y3, _ = H.bnn_model(1024, 16, 8, seed=2)
+    sel3 = tuple(f"W1_{j}" for j in range(8)) + ("w2",)
+    hp3, _, _ = model3.pack((), CM["obs", "y"].set(Y3), False, selected=sel3, per_particle=sel3, plates="hmc")
+    n3 = 1 << 12
+    ch3 = torch.as_tensor((np.random.default_rng(6).standard_normal((hp3.n_slots, n3)) * 0.3).astype(np.float32), device=dev)
+    row = dict(observations=1024, weights=136, chains=n3, leapfrog=10)
+    for eng in ("gen", "interp"):
+        e_ = with_engine("GJX_HMC_ENGINE", eng, lambda: kernels.hmc_engine(hp3))
+        ms = with_engine("GJX_HMC_ENGINE", eng, lambda: timed(lambda: kernels.hmc(hp3, (1, 2), ch3, 0.005, 10, False, True), 3 if eng == "gen" else 1)) * 1e-3
+        row[eng] = dict(ms_per_move=ms, engine=e_)
+    fl = n3 * 11 * 1024 * (4 * 16 * 8 + 4 * 8 + 30 * 8)            # forward + reverse sweep of the block per observation, 11 sweeps
+    row["gen"]["tflops"] = fl / (row["gen"]["ms_per_move"] * 1e-3) / 1e12
+    row["generated_vs_interpreter"] = row["interp"]["ms_per_move"] / row["gen"]["ms_per_move"]
+    res["hmc_network_16_8_1_weights_lds_state"] = row
 
     # (3) the generic filter on the nonlinear benchmark model (both step means are expression blocks of the carry)
     def time_filter(bf, chm, args, n=5):
