@@ -1507,6 +1507,49 @@ def run_round6(dev):
     row["generated_vs_interpreter"] = row["interp"]["ms_per_move"] / row["gen"]["ms_per_move"]
     res["hmc_network_16_8_1_weights_lds_state"] = row
 
+    # (2b) two INDEPENDENT ImportanceK steps in flight on two HIP streams (config 2's steps are independent runs: different keys): the
+    #      VALU-bound propagate kernel of one step overlaps the HBM-bound gather of the other.  Plain launches only (the tile-scaled
+    #      resampler: no co-resident grid beside another kernel).  NOT the headline: a kernel's own duration stretches when it shares the
+    #      device, so roofline.frac is quoted on the unpipelined step; this is what a caller with independent batches gets.
+    from genjax_amd import workloads
+    gprog, _ = workloads.gmm_program(D=D, C=C)
+    Kg = 1 << 20
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    bufs = []
+    for _ in range(2):
+        ws_a, ws_b = kernels.workspace(A.OP_RUN, Kg, dev), kernels.workspace(A.OP_RESAMPLE, Kg, dev)
+        o_ = kernels.run_program(gprog, (0, 1), Kg, ws=ws_a, want_weight=False, want_lse=False, want_tiles=True)
+        bufs.append(dict(ws=ws_a, ws2=ws_b, out=o_, rows=torch.empty_like(o_["choices"]), lse=torch.empty(4, dtype=torch.float32, device=dev)))
+    torch.cuda.synchronize()
+
+    def one_step(i, b):
+        kernels.run_program(gprog, (0, 1 + i), Kg, ws=b["ws"], out=b["out"], want_weight=False, want_lse=False, want_tiles=True)
+        pr = b["out"]["_partials"]
+        kernels.resample_gather_tiled(b["out"]["logw"], 0.37, b["out"]["choices"], partials=(b["ws"], pr.count()), tiles=pr.tiles, lse_out=b["lse"],
+                                      K_total=Kg, out=b["rows"], ws=b["ws2"])
+
+    def run_steps(n, pipelined):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            if pipelined:
+                with torch.cuda.stream(streams[i & 1]):
+                    one_step(i, bufs[i & 1])
+            else:
+                one_step(i, bufs[0])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    for pip in (False, True):
+        run_steps(50, pip)
+    serial = sorted(run_steps(400, False) for _ in range(3))[1]
+    piped = sorted(run_steps(400, True) for _ in range(3))[1]
+    res["two_independent_steps_in_flight"] = dict(
+        us_per_step_one_stream=serial * 1e6, us_per_step_two_streams=piped * 1e6, particle_steps_per_sec_two_streams=Kg / piped, speedup=serial / piped,
+        log_ml=float(bufs[1]["lse"][3]),
+        note="gjx_run_program_ex (tile totals left) + gjx_resample_gather_tiled per step; independent steps alternate between two streams and two "
+             "sets of buffers; not the headline (see the comment in bench.py)")
+
     # (3) the generic filter on the nonlinear benchmark model (both step means are expression blocks of the carry)
     def time_filter(bf, chm, args, n=5):
         bf.alias_outputs = True
