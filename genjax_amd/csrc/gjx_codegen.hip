@@ -1612,12 +1612,14 @@ bool pf_moves_supported(const gjx_program* p) {
 }
 
 // spl_code: tiles per block | 256 for the flavour that runs on a collection sharded over peer-mapped windows (gjx_peer.hip)
+//           | 1024 multinomial resampling by sorted uniforms instead of the systematic comb (pf_core's MULTI flavour)
 //           | 512 with a rejuvenation move behind every resampling (GenPfArgs::n_moves random-walk Metropolis steps per particle)
 std::string generate_pf(const gjx_program* prog_in, int spl_code) {
   if (!pf_supported(prog_in)) return "";
   const int spl = spl_code & 255;
   const bool sharded = (spl_code & 256) != 0;
   const bool moves = (spl_code & 512) != 0;
+  const bool multi = (spl_code & 1024) != 0;         // multinomial resampling by sorted uniforms (pf_core<..., MULTI>)
   if (moves && !pf_moves_supported(prog_in)) return "";
   GenCtx g;
   plan_program(prog_in, 1, g, false);
@@ -1837,8 +1839,8 @@ std::string generate_pf(const gjx_program* prog_in, int spl_code) {
       "  extern __shared__ __attribute__((aligned(16))) unsigned char pf_dyn[];\n"
       "  __shared__ __attribute__((aligned(16))) float tab_s[%d];\n"
       "  __shared__ __attribute__((aligned(16))) float tabp_s[%d];\n"
-      "  GenPfModel m(a, tab_s, tabp_s);\n  pf_core<GenPfModel, SPL, %s>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4,
-      moves ? ((prog->n_tab + ga.pl.comp_floats + 3) & ~3) + 4 : 4, sharded ? "2, 2" : "0, 0");
+      "  GenPfModel m(a, tab_s, tabp_s);\n  pf_core<GenPfModel, SPL, %s, %s>(a.core, m, pf_dyn);\n}\n", ((prog->n_tab + pl.comp_floats + 3) & ~3) + 4,
+      moves ? ((prog->n_tab + ga.pl.comp_floats + 3) & ~3) + 4 : 4, sharded ? "2, 2" : "0, 0", multi ? "true" : "false");
   o.f("// LDS_FLOATS 0\n");
   return o.s;
 }
@@ -3257,7 +3259,7 @@ extern "C" int64_t gjx_program_filter_source(const gjx_program* step, int32_t ti
 extern "C" int gjx_program_filter_precompile(const gjx_program* step, int32_t tiles_per_block) {
   if (!step || !step->sites) return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: null program");
   const int tpb = tiles_per_block & 255;
-  if ((tiles_per_block & ~(255 | 256 | 512)) || (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16))
-    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16 (| 256: the flavour for sharded collections, | 512: with the rejuvenation move)");
+  if ((tiles_per_block & ~(255 | 256 | 512 | 1024)) || (tpb != 1 && tpb != 2 && tpb != 4 && tpb != 8 && tpb != 16) || (tiles_per_block & (256 | 512 | 1024)) > 1024)
+    return gjx_fail(GJX_EINVAL, "gjx_program_filter_precompile: tiles_per_block must be 1, 2, 4, 8 or 16 (| 256: the flavour for sharded collections, | 512: with the rejuvenation move, | 1024: multinomial resampling by sorted uniforms, on its own)");
   return gjx::gen_pf_precompile(step, tiles_per_block);
 }

@@ -1108,6 +1108,36 @@ GJX_DEV uint64_t comb_threshold(int64_t j, double u, double step, uint64_t total
   return T;
 }
 
+// ---- multinomial resampling by SORTED uniforms (include/gjx.h GJX_FILTER_MULTINOMIAL in the one-launch filter): the j-th smallest of N
+// independent uniforms is S_j / S_{N+1}, S_j = e_0 + ... + e_j, for independent exponential spacings e_i.  A spacing is -log2(u_i) in
+// units of 2^-20, u_i = (2 m + 1) / 2^24 with m the top 23 bits of the slot's word — computed in float32 steps that round identically
+// on the device and in the oracle (integer -> float, a power-of-two scale, a Horner chain of fmaf, float -> integer): the sums are
+// exact integers, so the sorted uniforms and with them the ancestors do not depend on launch geometry, sharding or the math library.
+GJX_DEV uint64_t exp_spacing(uint32_t word) {
+  const uint32_t x = ((word >> 9) << 1) | 1u;                    // odd, < 2^24: exact in float32
+  int k = 31 - __builtin_clz(x);                                 // x = 2^k f, f in [1, 2)
+  float f = ldexpf((float)x, -k);
+  if (f > 1.41421354f) { f *= 0.5f; k += 1; }                    // f in (sqrt 1/2, sqrt 2]
+  const float t = f - 1.0f;
+  float q = 0.12614846229553223f;                                // log2(1 + t) = t Q(t), |error| < 7e-8 on the interval
+  q = fmaf(q, t, -0.20742103457450867f);
+  q = fmaf(q, t, 0.21566985547542572f);
+  q = fmaf(q, t, -0.23892034590244293f);
+  q = fmaf(q, t, 0.2879183292388916f);
+  q = fmaf(q, t, -0.36070483922958374f);
+  q = fmaf(q, t, 0.48091059923171997f);
+  q = fmaf(q, t, -0.7213473320007324f);
+  q = fmaf(q, t, 1.4426950216293335f);
+  const float e = fmaf(-q, t, (float)(24 - k));                  // -log2(x / 2^24) >= 0
+  return e > 0.0f ? (uint64_t)(e * 1048576.0f) : 0ull;
+}
+// threshold of the slot whose inclusive spacing sum is Sj: floor(U_(j) total) on the weight line, non-decreasing in j
+GJX_DEV uint64_t sorted_threshold(uint64_t Sj, uint64_t Sall, uint64_t total) {
+  uint64_t T = (uint64_t)((double)Sj * ((double)total / (double)Sall));
+  if (total > 0 && T > total - 1) T = total - 1;
+  return T;
+}
+
 // number of output slots whose comb threshold lies strictly below c (0 <= c <= total):
 // J(c) = #{j in [0, N) : T_j < c}.  T_j is non-decreasing in j, so J is found from the real-valued guess
 // ceil(c/step - u) and corrected with the EXACT integer predicate (the same T_j the per-slot search uses).

@@ -98,12 +98,22 @@ GJX_DEV double pfc_uni_f64(double v) { return __longlong_as_double((long long)pf
 GJX_DEV float pfc_uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // dynamic LDS of pf_core for NT tiles: prefix [NT + 1] u64 (padded to even), cumulative q [4][1024] u64, exponents [NT] i32
-inline __host__ __device__ size_t pf_core_dyn_lds(int NT) { return 8 * (size_t)((NT + 2) & ~1) + 8 * (size_t)(kPfCoreThreads / 256) * kPfCoreThreads + 4 * (size_t)NT; }
+// (+ MULTI: the prefix of the tiles' spacing sums, [NT + 1] u64 behind the exponents)
+inline __host__ __device__ size_t pf_core_dyn_lds(int NT, bool multi = false) {
+  return 8 * (size_t)((NT + 2) & ~1) + 8 * (size_t)(kPfCoreThreads / 256) * kPfCoreThreads + 4 * (size_t)((NT + 1) & ~1) + (multi ? 8 * (size_t)((NT + 2) & ~1) : 0);
+}
 
 // SPL: tiles per block (a lane produces one slot of each).  `pf_dyn`: the block's dynamic LDS (pf_core_dyn_lds bytes).
 // SYSM: scope of the accesses other blocks / ranks observe — 0 agent (one rank), 1 system (peer-mapped windows), 2 decided at run
 // time by f.G (the hand-written kernels: one instantiation for both).  VERM: 0 verify mode compiled out, 2 decided by f.verify.
-template <class Model, int SPL, int SYSM = 2, int VERM = 2>
+// MULTI: MULTINOMIAL resampling by sorted uniforms instead of the systematic comb (include/gjx.h GJX_FILTER_MULTINOMIAL): slot j's
+// threshold is floor(U_(j) total), U_(j) = S_j / S_{N+1} the j-th smallest of N uniforms built from exponential spacings of the
+// slots' words under the step's resampling key (exp_spacing, gjx_device.h: exact integers).  A lane draws its slots' spacings (they
+// depend on the key only), the in-tile running sums ride on the barrier of the tile maxima, a tile's spacing total travels in the
+// second word of its granule, the prefix over the tiles' totals is taken beside the prefix of the weights; everything behind the
+// threshold — tile search, re-scan of the source tiles, in-tile search — is the comb's.  f.us[t] then holds the resampling KEY of
+// step t (its two words as one 64-bit pattern), not a comb offset.
+template <class Model, int SPL, int SYSM = 2, int VERM = 2, bool MULTI = false>
 GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
   struct ArgsView : PfCoreArgs {                 // (compile-time modes fold the fields they fix)
     GJX_DEV explicit ArgsView(const PfCoreArgs& a) : PfCoreArgs(a) { if (VERM == 0) verify = 0; }
@@ -119,6 +129,9 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
   uint64_t* const P = (uint64_t*)pf_dyn;                               // [NT + 1] prefix of the shifted tile totals
   uint64_t* const cumL = P + ((f.NT + 2) & ~1);                        // [kChunk][THREADS] cumulative q of the tiles being searched
   int32_t* const Eb = (int32_t*)(cumL + kChunk * THREADS);             // [NT] tile exponents
+  uint64_t* const P2 = (uint64_t*)(Eb + ((f.NT + 1) & ~1));            // MULTI: [NT + 1] prefix of the tiles' spacing sums
+  __shared__ uint64_t wexp[MULTI ? SPL : 1][NW];                       // MULTI: the waves' spacing sums of the block's tiles
+  __shared__ uint32_t sRes[2][2];                                      // MULTI: resampling key of the step (staged a step ahead)
   __shared__ float fred[SPL][NW], fsum[SPL][NW], fmx[NW];
   __shared__ uint64_t wtot[SPL][NW], wq[NW];
   __shared__ float lse_pm[NW], lse_ps[NW];
@@ -203,10 +216,12 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
     if (t < T && wid == 1) {
       if (lane == 63) sU = f.us[t];
       if (lane >= 61 && lane < 63 && t + 1 < T) sKey[(t + 1) & 1][lane - 61] = f.keys[2 * (t + 1) + (lane - 61)];
+      if (MULTI && lane >= 59 && lane < 61 && t + 1 < T) sRes[(t + 1) & 1][lane - 59] = ((const uint32_t*)f.us)[2 * (t + 1) + (lane - 59)];
     }
     if (t < T) m.stage(t, tid);
   };
   if (tid < 2) sKey[1][tid] = f.keys[2 + tid];   // step 1's key (T > 1)
+  if (MULTI && tid >= 2 && tid < 4) sRes[1][tid - 2] = ((const uint32_t*)f.us)[2 + (tid - 2)];
   __syncthreads();
   for (int t = 1; t <= T; ++t) {
     GJX_CSTAMP(0);
@@ -240,7 +255,32 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
       const float wm = wave_max_dpp(act(s) ? lw_own[s] : -INFINITY);
       if (lane == 0) fred[s][wid] = wm;          // (last read two barriers ago)
     }
+    // MULTI: the spacings of this lane's slots (key and slot index only) and their running sum within the wave
+    uint64_t ex_incl[SPL];
+    key2 kres{0u, 0u};
+    if constexpr (MULTI) {
+      if (t < T) {
+        kres = key2{(uint32_t)pfc_uni_i32((int)sRes[t & 1][0]), (uint32_t)pfc_uni_i32((int)sRes[t & 1][1])};
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          const uint64_t e = act(s) ? exp_spacing(fold_in64(kres, (uint64_t)(f.offset + jl(s))).a) : 0ull;
+          ex_incl[s] = wave_scan_u64(e);
+          if (lane == 63) wexp[s][wid] = ex_incl[s];
+        }
+      }
+    }
     __syncthreads();
+    uint64_t ex_tile[SPL];
+    if constexpr (MULTI) {
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        uint64_t below = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const uint64_t v = wexp[s][w]; tot += v; below += w < wid ? v : 0; }
+        ex_incl[s] += below;
+        ex_tile[s] = tot;
+      }
+    }
     // ---- the ONE rendezvous: {e_b, S_b} of every tile, to every rank ----
     const unsigned long long tag = (unsigned long long)((epoch + (unsigned)t) % 15u) + 1ull;
     unsigned long long* agg = (t & 1) ? f.aggA : f.aggB;   // alternate: a slow block may still poll step t-1's granules
@@ -267,6 +307,7 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
         const float bs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_sum_to_lane15(lane < NW ? fsum[s][lane] : 0.0f)), 15));
         if (ton(s) && lane < G) {
           const long long d = sPF[lane];
+          if constexpr (MULTI) store_scoped_u64(peer_ptr(agg + (size_t)(gt0 + s) * kPfCorePad + 1, d), (tag << 60) | (ex_tile[s] & ((1ull << 60) - 1)), sys);
           store_scoped_u64(peer_ptr(agg + (size_t)(gt0 + s) * kPfCorePad, d), tile_granule(tag, eb[s], tt), sys);
           const size_t slot = (size_t)((t - 1) % 3) * NT + gt0 + s;
           store_scoped(peer_ptr(f.bsum + slot, d), bs, sys);
@@ -305,13 +346,23 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
         P[b + 1] = S;
         Eb[b] = e;
         em = fmaxf(em, (float)e);
+        if constexpr (MULTI) {                   // the tile's spacing total: the second word of its granule, under the same tag
+          unsigned long long v2 = load_scoped_u64(&agg[(size_t)b * kPfCorePad + 1], sys);
+          while ((v2 >> 60) != tag && step_budget) {
+            --step_budget;
+            __builtin_amdgcn_s_sleep(1);
+            v2 = load_scoped_u64(&agg[(size_t)b * kPfCorePad + 1], sys);
+          }
+          if ((v2 >> 60) != tag) { timed_out(); v2 = 0; }
+          P2[b + 1] = v2 & ((1ull << 60) - 1);
+        }
       }
       // the `ready` words: the first load is issued now and looked at after the tile search
       rdy0 = tid < nready ? load_scoped_u32(&f.ready[tid], sys) : rtag;
       em = wave_max_dpp(em);
       if (lane == 0) fmx[wid] = em;
     }
-    if (tid == 0) P[0] = 0;
+    if (tid == 0) { P[0] = 0; if (MULTI) P2[0] = 0; }
     __syncthreads();
     GJX_CSTAMP(3);
     {
@@ -337,6 +388,14 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
         uint64_t run = wave_scan_u64(loc) - loc;
         for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
       }
+      if (MULTI && wid == 1) {                   // the prefix of the spacing totals, by the next wave at the same time
+        const int per = (NT + 63) >> 6;
+        const int e0 = lane * per < NT ? lane * per : NT, e1 = (e0 + per) < NT ? (e0 + per) : NT;
+        uint64_t loc = 0;
+        for (int e = e0; e < e1; ++e) loc += P2[e + 1];
+        uint64_t run = wave_scan_u64(loc) - loc;
+        for (int e = e0; e < e1; ++e) { run += P2[e + 1]; P2[e + 1] = run; }
+      }
     } else {
       // prefix of the shifted tile totals: thread i owns the entries [i per, (i + 1) per)
       const int per = (NT + THREADS - 1) / THREADS;
@@ -354,6 +413,17 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
       uint64_t run = inc - loc;
       for (int w = 0; w < wid; ++w) run += wq[w];
       for (int e = e0; e < e1; ++e) { run += P[e + 1]; P[e + 1] = run; }
+      if constexpr (MULTI) {                     // ... and of the spacing totals (a second pass: wq is reused)
+        __syncthreads();
+        uint64_t loc2 = 0;
+        for (int e = e0; e < e1; ++e) loc2 += P2[e + 1];
+        const uint64_t inc2 = wave_scan_u64(loc2);
+        if (lane == 63) wq[wid] = inc2;
+        __syncthreads();
+        uint64_t run2 = inc2 - loc2;
+        for (int w = 0; w < wid; ++w) run2 += wq[w];
+        for (int e = e0; e < e1; ++e) { run2 += P2[e + 1]; P2[e + 1] = run2; }
+      }
     }
     __syncthreads();
     GJX_CSTAMP(4);
@@ -394,7 +464,14 @@ GJX_DEV void pf_core(const PfCoreArgs& f_in, Model& m, unsigned char* pf_dyn) {
         tiles[s] = 0; Tjs[s] = 0;
         if (!ton(s)) continue;
         // slots past the rank's last particle search that particle's threshold (thresholds stay non-decreasing in the tile)
-        uint64_t Tj = comb_threshold(f.offset + (act(s) ? (int64_t)jl(s) : K - 1), u_t, step, total);
+        uint64_t Tj;
+        if constexpr (MULTI) {
+          // the slot's sorted uniform: spacings of all the slots up to and including it, over all N + 1 spacings (slots past the
+          // rank's last particle drew no spacing: they repeat that particle's threshold)
+          const uint64_t s_all = P2[NT] + exp_spacing(fold_in64(kres, (uint64_t)f.K_total).a);
+          Tj = sorted_threshold(P2[gt0 + s] + ex_incl[s], s_all, total);
+        } else
+        Tj = comb_threshold(f.offset + (act(s) ? (int64_t)jl(s) : K - 1), u_t, step, total);
         // a tile's slots draw from tiles near its own index: the nine boundaries around it are read together (one LDS
         // latency, the same addresses in every lane); a threshold outside that window takes the fixed-trip descent
         const int own = gt0 + s;

@@ -106,15 +106,16 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const int64_t ntw = (K + 1023) / 1024;
   const size_t wide_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
   const size_t wide_bytes = 256 + (16 * (size_t)kPfCorePad + 24) * (size_t)ntw + 8 * (size_t)ntw + 24 * (size_t)T + 64;
-  if (room && T >= 2 && !multinomial && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
+  if (room && T >= 2 && !(multinomial && n_moves > 0) && !(fflags & GJX_FILTER_NO_WIDE) && !no_fuse && ntw <= kPfHostMaxTiles && workspace_bytes >= wide_off + wide_bytes &&
       !gjx_plain_launches_forced() && steps[1].tab_dev && gen_pf_supported(&steps[1]) && (n_moves == 0 || gen_pf_moves_supported(&steps[1]))) {
-    const int mv = n_moves > 0 ? 512 : 0;        // the kernel flavour with the rejuvenation move
+    // the kernel flavour: | 512 with the rejuvenation move, | 1024 multinomial resampling by sorted uniforms (pf_core's MULTI)
+    const int mv = (n_moves > 0 ? 512 : 0) | (multinomial ? 1024 : 0);
     bool same = true;
     for (int u = 2; u < T && same; ++u)
       same = steps[u].n_tab == steps[1].n_tab && steps[u].n_slots == steps[1].n_slots && input_rows(steps[u]) == input_rows(steps[1]) &&
              steps[u].tab_dev != nullptr && gen_pf_same_kernel(&steps[1], &steps[u]);
     if (!abs_in && input_rows(steps[1]) > steps[0].n_slots - input_rows(steps[0])) same = false;
-    const size_t dyn = pf_core_dyn_lds((int)ntw);
+    const size_t dyn = pf_core_dyn_lds((int)ntw, multinomial);
     int spl = 0, grid = 0;
     const int spls[5] = {1, 2, 4, 8, 16};
     for (int i = 0; i < 5 && same && !spl; ++i) {
@@ -148,6 +149,13 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
       std::vector<const float*> h_tabs((size_t)T, nullptr);
       for (int u = 0; u < T; ++u) h_tabs[u] = steps[u].tab_dev;
       // (kernel arguments carry these small arrays: nothing on the host has to outlive the call)
+      if (multinomial) {
+        // (the sorted-uniform resampler takes the resampling KEY of every step where the comb takes its offset: f.us[t] = the key's
+        // two words as one 64-bit pattern)
+        std::vector<double> kb((size_t)T, 0.0);
+        for (int u = 0; u < T; ++u) { const uint64_t w = (uint64_t)res_keys[2 * u] | ((uint64_t)res_keys[2 * u + 1] << 32); memcpy(&kb[u], &w, 8); }
+        if (int rcu = upload_words(us_dev, kb.data(), (size_t)T, st0)) return report(rcu);
+      } else
       if (int rcu = upload_words(us_dev, us.data(), (size_t)T, st0)) return report(rcu);
       if (int rcu = upload_words(keys_dev, keys.data(), (size_t)T, st0)) return report(rcu);
       if (int rcu = upload_words(tabs_dev, h_tabs.data(), (size_t)T, st0)) return report(rcu);
@@ -232,8 +240,9 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
           rc = gjx_weight_cumsum(lw_prev, K, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, mn_cum, bt, lse_steps + 4 * (size_t)(t - 1), K,
                                  ws_res, need_res, stream);
           if (rc) return rc;
-          rc = gjx_resample_multinomial(mn_cum, K, bt, res_keys[2 * t], res_keys[2 * t + 1], K, 0, K, anc_t, stream);
-          finfo.launches += 1;
+          // (the call above: the finished LSE record of step t - 1 from the run's block pairs; its prefix sums are overwritten)
+          rc = gjx_resample_sorted_multinomial_tiled(lw_prev, K, res_keys[2 * t], res_keys[2 * t + 1], K, anc_t, mn_cum, nullptr, nullptr, ws_res, need_res, stream);
+          finfo.launches += 5;
         } else
         rc = gjx_resample_gather_tiled(lw_prev, K, tS, tE, 2, (const float*)(pws + kWsHeaderBytes), prev.n_partials, us[t], nullptr, 0, 0, nullptr, 0,
                                        anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);

@@ -1058,6 +1058,76 @@ __global__ __launch_bounds__(256) void k_tiled_ancestors(const uint64_t* P, cons
   anc[j] = (int32_t)((int64_t)lo * kTileQ + l2);
 }
 
+// ---- multinomial resampling by SORTED uniforms on the tile-scaled weight line (gjx_resample_sorted_multinomial_tiled): slot j's
+//      threshold is floor(total * S_j / S_N+1) with S_j the running sum of the exponential spacings exp_spacing(bits(key, j)) — the
+//      order statistics of N iid uniforms, so the ancestors are a multinomial draw delivered in non-decreasing order.  The spacings
+//      are exact integers (gjx_device.h): their sums do not depend on how the slots are cut into tiles. ----
+__global__ __launch_bounds__(kTileQ) void k_spacing_totals(key2 key, int64_t N, uint64_t* SS) {
+  constexpr int NW = kTileQ / 64;
+  __shared__ uint64_t wsum[NW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * kTileQ + threadIdx.x;
+  uint64_t e = j <= N ? exp_spacing(fold_in64(key, (uint64_t)j).a) : 0ull;     // (slot N: the spacing that closes the unit interval)
+  e = wave_scan_u64(e);
+  if (lane == 63) wsum[wid] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t tot = 0;
+    for (int w = 0; w < NW; ++w) tot += wsum[w];
+    SS[blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_spacing_plan(const uint64_t* SS, int nb, uint64_t* SP) {
+  __shared__ uint64_t wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint64_t carry = 0;
+  if (threadIdx.x == 0) SP[0] = 0;
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    const uint64_t inc = wave_scan_u64(b < nb ? SS[b] : 0ull);
+    __syncthreads();
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint64_t base = carry, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wid) base += wsum[w]; tot += wsum[w]; }
+    if (b < nb) SP[b + 1] = base + inc;
+    carry += tot;
+  }
+}
+
+__global__ __launch_bounds__(kTileQ) void k_sorted_ancestors(const uint64_t* P, const int32_t* sh, const uint64_t* cq, int nt, int64_t K, key2 key,
+                                                             const uint64_t* SP, int nb, int64_t N, int32_t* anc) {
+  constexpr int NW = kTileQ / 64;
+  __shared__ uint64_t wsum[NW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * kTileQ + threadIdx.x;
+  uint64_t e = j < N ? exp_spacing(fold_in64(key, (uint64_t)j).a) : 0ull;
+  e = wave_scan_u64(e);
+  if (lane == 63) wsum[wid] = e;
+  __syncthreads();
+  uint64_t Sj = SP[blockIdx.x] + e;
+  for (int w = 0; w < wid; ++w) Sj += wsum[w];
+  if (j >= N) return;
+  const uint64_t total = P[nt];
+  if (total == 0) { anc[j] = (int32_t)(j < K ? j : K - 1); return; }   // dead collection: identity, flagged by the plan
+  const uint64_t Tj = sorted_threshold(Sj, SP[nb], total);
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (P[mid + 1] > Tj) hi = mid; else lo = mid + 1;
+  }
+  const uint64_t r = (Tj - P[lo]) << sh[lo];
+  const uint64_t* cm = cq + (int64_t)lo * kTileQ;
+  const int64_t left = K - (int64_t)lo * kTileQ;
+  int l2 = 0, h2 = (int)(left < kTileQ ? left : kTileQ) - 1;
+  while (l2 < h2) {
+    const int mid = (l2 + h2) >> 1;
+    if (cm[mid] > r) h2 = mid; else l2 = mid + 1;
+  }
+  anc[j] = (int32_t)((int64_t)lo * kTileQ + l2);
+}
+
 int launch_tiled_plan(const uint64_t* S, const int32_t* E, int nt, uint64_t* P, int32_t* sh, unsigned* ctrl, hipStream_t st) {
   hipLaunchKernelGGL(k_tiled_plan, dim3(1), dim3(1024), 0, st, S, E, nt, P, sh, ctrl);
   GJX_CHECK_LAUNCH("k_tiled_plan");
@@ -1194,6 +1264,35 @@ extern "C" int gjx_resample_indices_tiled(const float* logw, int64_t K, double u
   hipLaunchKernelGGL(k_tiled_ancestors, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const uint64_t*)P, (const int32_t*)sh,
                      (const uint64_t*)cum, (int)nt, K, u, N, ancestors);
   GJX_CHECK_LAUNCH("gjx_resample_indices_tiled");
+  return GJX_OK;
+}
+
+extern "C" int gjx_resample_sorted_multinomial_tiled(const float* logw, int64_t K, uint32_t key0, uint32_t key1, int64_t N, int32_t* ancestors,
+                                                     uint64_t* cum, uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes,
+                                                     void* stream) {
+  if (!logw || !ancestors || !cum || K <= 0 || N <= 0 || K > (int64_t)1 << 31 || N > (int64_t)1 << 31)
+    return gjx_fail(GJX_EINVAL, "gjx_resample_sorted_multinomial_tiled: bad argument");
+  const int64_t nt = (K + kTileQ - 1) / kTileQ;
+  const int64_t nb = (N + 1 + kTileQ - 1) / kTileQ;        // tiles of SLOTS (N + 1 spacings)
+  // workspace: [256 B control][S u64 nt][P u64 nt + 1][E i32 nt][shift i32 nt][SS u64 nb][SP u64 nb + 1]
+  const size_t off_ss = (256 + 24 * (size_t)nt + 8 + 7) & ~(size_t)7;
+  if (!workspace || workspace_bytes < gjx_workspace_bytes(GJX_OP_RESAMPLE, K) || off_ss + 16 * (size_t)nb + 8 > workspace_bytes)
+    return gjx_fail(GJX_EWORKSPACE, "gjx_resample_sorted_multinomial_tiled: workspace too small (OP_RESAMPLE of K, and 288 + 24 ceil(K / 1024) + 16 ceil((N + 1) / 1024) bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t* S = (uint64_t*)((char*)workspace + kWsHeaderBytes);
+  uint64_t* P = S + nt;
+  int32_t* E = (int32_t*)(P + nt + 1);
+  int32_t* sh = E + nt;
+  uint64_t* SS = (uint64_t*)((char*)workspace + off_ss);
+  uint64_t* SP = SS + nb;
+  const key2 key{key0, key1};
+  hipLaunchKernelGGL(k_tiled_quantise, dim3((unsigned)nt), dim3(kTileQ), 0, st, logw, K, cum, S, E, q_out, e_out);
+  hipLaunchKernelGGL(k_tiled_plan, dim3(1), dim3(1024), 0, st, (const uint64_t*)S, (const int32_t*)E, (int)nt, P, sh, (unsigned*)workspace + 8);
+  hipLaunchKernelGGL(k_spacing_totals, dim3((unsigned)nb), dim3(kTileQ), 0, st, key, N, SS);
+  hipLaunchKernelGGL(k_spacing_plan, dim3(1), dim3(1024), 0, st, (const uint64_t*)SS, (int)nb, SP);
+  hipLaunchKernelGGL(k_sorted_ancestors, dim3((unsigned)((N + kTileQ - 1) / kTileQ)), dim3(kTileQ), 0, st, (const uint64_t*)P, (const int32_t*)sh,
+                     (const uint64_t*)cum, (int)nt, K, key, (const uint64_t*)SP, (int)nb, N, ancestors);
+  GJX_CHECK_LAUNCH("gjx_resample_sorted_multinomial_tiled");
   return GJX_OK;
 }
 

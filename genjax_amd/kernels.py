@@ -388,6 +388,25 @@ def resample_indices_tiled(logw: torch.Tensor, u: float, N: int | None = None, a
     return (anc, q, e) if want_q else anc
 
 
+def resample_sorted_multinomial_tiled(logw: torch.Tensor, key, N: int | None = None, anc=None, cum=None, ws=None, want_q=False):
+    """gjx_resample_sorted_multinomial_tiled: log-weights -> MULTINOMIAL ancestors (sorted uniforms from exponential spacings under
+    `key`, tile-scaled fixed point), non-decreasing.  -> ancestors int32[N], or (ancestors, q, e) with want_q"""
+    K = logw.numel()
+    N = int(N or K)
+    dev = logw.device
+    if anc is None:
+        anc = torch.empty(N, dtype=torch.int32, device=dev)
+    if cum is None:
+        cum = torch.empty(K, dtype=torch.int64, device=dev)
+    if ws is None:
+        ws = workspace(A.OP_RESAMPLE, K, dev)
+    q = torch.empty(K, dtype=torch.int32, device=dev) if want_q else None
+    e = torch.empty((K + 1023) // 1024, dtype=torch.int32, device=dev) if want_q else None
+    check(load().gjx_resample_sorted_multinomial_tiled(_ptr(logw), K, key[0], key[1], N, _ptr(anc), _ptr(cum), _ptr(q), _ptr(e), _ptr(ws),
+                                                       ws.numel(), _stream()), "gjx_resample_sorted_multinomial_tiled")
+    return (anc, q, e) if want_q else anc
+
+
 def resample_gather(x: torch.Tensor, u: float, rows: torch.Tensor, is_log=True, lse=None, partials=None, lse_out=None,
                     K_total=None, out=None, anc=None, ws=None, allow_fallback=True) -> torch.Tensor:
     """gjx_resample_gather: weights -> systematic ancestors -> out[r, j] = rows[r, ancestor(j)] in ONE launch (N = K);

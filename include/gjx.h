@@ -708,6 +708,26 @@ int gjx_ssm_filter_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t 
  * in the reference (its SMC does not resample); the comb is that of gjx_resample_systematic. */
 int gjx_resample_indices_tiled(const float* logw, int64_t K, double u, int64_t N, int32_t* ancestors, uint64_t* cum,
                                uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes, void* stream);
+/* MULTINOMIAL resampling on the same tile-scaled weight line, by SORTED uniforms (what the generic filter's GJX_FILTER_MULTINOMIAL
+ * computes between two steps, bit for bit; five plain launches here).  The reference's SMC cookbook resamples with
+ * jax.random.categorical(key, log_weights, shape=(N,)) (docs/cookbook/inactive/inference/importance_sampling.ipynb): N iid draws
+ * from the normalised weights.  The N draws as a SET are the images of N iid uniforms under the inverse CDF; this call produces the
+ * uniforms already SORTED — U_(j) = S_j / S_{N+1}, S_j = e_0 + ... + e_j the running sum of N + 1 iid standard exponentials
+ * (Devroye 1986, V.3.1) — so that slot j's ancestor needs no sort and no second pass, the ancestors come out non-decreasing (the
+ * gather that follows reads forward), and the resampled collection is the same multinomial draw as the cookbook's up to the order of
+ * its members, which no estimator over the collection depends on.
+ *   e_j = floor(2^20 * -log2(x_j / 2^24)), x_j = 2 (w_j >> 9) + 1 for w_j the first word of Threefry(key, (j >> 32, j)) (the common
+ *   scale 2^20 / ln 2 cancels in S_j / S_{N+1}) — log2 by a fixed float32 polynomial (integer -> float, a power-of-two scale, a Horner chain of fmaf), the same integers on
+ *   the device and in the oracle (gjxo_exp_spacing); S_j are exact integer sums (independent of the launch geometry);
+ *   T_j = min(floor((double)S_j * ((double)total / (double)S_{N+1})), total - 1) on the tile-scaled weight line; ancestor(j) = the
+ *   particle under T_j exactly as in gjx_resample_indices_tiled.
+ * cum, q_out, e_out, the dead collection and the workspace as gjx_resample_indices_tiled; the workspace also holds
+ * 16 ceil((N + 1) / 1024) + 8 bytes of slot-tile sums behind the 288 + 24 ceil(K / 1024) bytes of the weight tiles (GJX_EWORKSPACE
+ * when N is so much larger than K that gjx_workspace_bytes(GJX_OP_RESAMPLE, K) does not hold them).  Oracle:
+ * gjxo_resample_sorted_multinomial_tiled. */
+int gjx_resample_sorted_multinomial_tiled(const float* logw, int64_t K, uint32_t key0, uint32_t key1, int64_t N, int32_t* ancestors,
+                                          uint64_t* cum, uint32_t* q_out, int32_t* e_out, void* workspace, size_t workspace_bytes,
+                                          void* stream);
 
 /* ---- bootstrap filter for ANY Scan kernel (SURVEY.md §8 R-2 beyond the linear-Gaussian model).  The reference's
  * ingredients: Scan.generate's step recursion (combinators/scan.py:237-294 — step t receives the carry of step t-1, weights
@@ -749,10 +769,12 @@ enum { GJX_FILTER_NO_WIDE = 1,          /* not the 16-wave filter kernel        
        GJX_FILTER_NO_STEPS = 2,         /* not the 256-thread steps kernel                                 */
        GJX_FILTER_NO_ONE_LAUNCH = 3,    /* neither: plain launches only (the repeat after a poll time-out) */
        GJX_FILTER_TWO_LAUNCH = 4,       /* two launches per step (search, then step)                       */
-       /* MULTINOMIAL resampling instead of systematic: slot j of the resampling in front of step t draws its own uniform from
-        * bits(k_res_t, j) (gjx_resample_multinomial; k_res_t = the key whose first word feeds the systematic comb offset) and takes the
-        * first particle whose cumulative fixed-point weight (GJX_WEIGHTS_GLOBAL_MAX, gjx_weight_cumsum) exceeds it.  Three plain
-        * launches per step (prefix sums, draws + search, step); the workspace needs 8 K + 256 bytes beyond OP_RUN + OP_RESAMPLE. */
+       /* MULTINOMIAL resampling instead of systematic: the resampling in front of step t is gjx_resample_sorted_multinomial_tiled
+        * under k_res_t (the key whose first word feeds the systematic comb offset) — N = K sorted uniforms from exponential spacings,
+        * on the tile-scaled weight line.  Runs INSIDE the one-launch filter kernel (GJX_FILTER_FORM_WIDE: the spacing sums ride the
+        * tile granules of the step's one rendezvous as a second word, no extra barrier) when the run has no rejuvenation move; the
+        * other forms resample with the standalone call between two step launches — the same ancestors bit for bit.  The workspace
+        * needs 8 K + 256 bytes beyond OP_RUN + OP_RESAMPLE (the plain-launch forms' cumulative weights). */
        GJX_FILTER_MULTINOMIAL = 8,
        /* A model that is MORE than the Scan: latent sites in front of it (static parameters, `phi ~ beta(...)` before the state-space
         * Scan; Scan.generate is a callee of any @gen body, scan.py:237-294) are drawn by step 0 and travel with the particle: every
@@ -802,7 +824,8 @@ int gjx_scan_filter_history(const gjx_program* steps, int32_t T, uint32_t key0, 
                             int32_t rows_per_step, float* logw, int32_t* ancestors_all, float* lse_steps, void* workspace,
                             size_t workspace_bytes, void* stream, const gjx_filter_opts* opts, gjx_filter_info* info_out);
 /* the filter kernel generated for a step program (GJX_FILTER_FORM_WIDE) with `tiles_per_block` in {1, 2, 4, 8, 16} (| 256: the flavour
- * that runs on a collection sharded over peer-mapped windows — system-scope accesses and the verify mode decided at run time): its HIP source
+ * that runs on a collection sharded over peer-mapped windows — system-scope accesses and the verify mode decided at run time; | 512: with
+ * the rejuvenation move; | 1024, on its own: multinomial resampling by sorted uniforms): its HIP source
  * (returns the length; copies at most cap - 1 characters) and compilation without a launch (hipRTC cross-compiles for gfx950
  * without a GPU: a build step fills the on-disk cache).  GJX_EUNSUPPORTED when the emitter does not cover the program. */
 int64_t gjx_program_filter_source(const gjx_program* step, int32_t tiles_per_block, char* out, int64_t cap);

@@ -78,6 +78,9 @@ def _bind(L):
     L.gjxo_resample_systematic.argtypes = [vp, i64, u64, u64, f64, i64, i64, i64, vp]
     L.gjxo_resample_multinomial.argtypes = [vp, i64, u64, u64, u32, u32, i64, i64, i64, vp]
     L.gjxo_resample_systematic_tiled.argtypes = [vp, i64, f64, i64, vp, vp, vp, vp]
+    L.gjxo_resample_sorted_multinomial_tiled.argtypes = [vp, i64, u32, u32, i64, vp, vp]
+    L.gjxo_exp_spacing.argtypes = [u32]
+    L.gjxo_exp_spacing.restype = C.c_uint64
     L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
     L.gjxo_ssm_step.argtypes = [i32, i32, vp, vp, f32, f32, f32, u32, u32, i32, i32, i64, i64, vp,
                                 i64, vp, vp, vp, vp, vp, i64]
@@ -206,6 +209,22 @@ def resample_systematic_tiled(logw, u, N=None, q=None):
     qi = None if q is None else np.ascontiguousarray(q, np.uint32)
     rc = lib().gjxo_resample_systematic_tiled(_p(logw), K, float(u), N, _p(qi), _p(anc), _p(q_out), _p(e_out))
     return anc, q_out, e_out, bool(rc)
+
+
+def resample_sorted_multinomial_tiled(logw, key, N=None, q=None):
+    """-> (ancestors int32[N], dead): multinomial resampling by SORTED uniforms (exponential spacings of the slots' words) under the
+    tile-scaled fixed point; ``q``: quantised weights to use instead of the oracle's own exp2f (the device's)"""
+    logw = np.ascontiguousarray(logw, np.float32)
+    K = logw.size
+    N = int(K if N is None else N)
+    anc = np.zeros(N, np.int32)
+    qi = None if q is None else np.ascontiguousarray(q, np.uint32)
+    rc = lib().gjxo_resample_sorted_multinomial_tiled(_p(logw), K, key[0], key[1], N, _p(qi), _p(anc))
+    return anc, bool(rc)
+
+
+def exp_spacing(word: int) -> int:
+    return int(lib().gjxo_exp_spacing(int(word) & 0xFFFFFFFF))
 
 
 def resample_multinomial(cum, key, N_total, base=0, total_all=None, out_begin=0, n_out=None):

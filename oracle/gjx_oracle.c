@@ -1106,6 +1106,103 @@ int gjxo_resample_systematic_tiled(const float* logw, int64_t K, double u, int64
   return rc;
 }
 
+/* Multinomial resampling by SORTED uniforms under the tile-scaled fixed point (include/gjx.h: GJX_FILTER_MULTINOMIAL inside the
+ * one-launch filter; the cookbook's jax.random.categorical over the log-weights draws N independent ancestors — their sorted order is
+ * what a filter may use, the collection is exchangeable).  The j-th smallest of N uniforms = S_j / S_{N+1} with exponential spacings
+ * e_i = -log2(u_i) in units of 2^-20, u_i = (2 m_i + 1) / 2^24, m_i = the top 23 bits of word 0 of Threefry(key, (0, i)); every float32
+ * step below rounds as on the device (csrc/gjx_device.h exp_spacing). */
+static uint64_t exp_spacing(uint32_t word) {
+  const uint32_t x = ((word >> 9) << 1) | 1u;
+  int k = 31 - __builtin_clz(x);
+  float f = ldexpf((float)x, -k);
+  if (f > 1.41421354f) { f *= 0.5f; k += 1; }
+  const float t = f - 1.0f;
+  float q = 0.12614846229553223f;
+  q = fmaf(q, t, -0.20742103457450867f);
+  q = fmaf(q, t, 0.21566985547542572f);
+  q = fmaf(q, t, -0.23892034590244293f);
+  q = fmaf(q, t, 0.2879183292388916f);
+  q = fmaf(q, t, -0.36070483922958374f);
+  q = fmaf(q, t, 0.48091059923171997f);
+  q = fmaf(q, t, -0.7213473320007324f);
+  q = fmaf(q, t, 1.4426950216293335f);
+  const float e = fmaf(-q, t, (float)(24 - k));
+  return e > 0.0f ? (uint64_t)(e * 1048576.0f) : 0ull;
+}
+uint64_t gjxo_exp_spacing(uint32_t word) { return exp_spacing(word); }
+
+int gjxo_resample_sorted_multinomial_tiled(const float* logw, int64_t K, uint32_t key0, uint32_t key1, int64_t N, const uint32_t* q_in,
+                                           int32_t* ancestors) {
+  const float log2e = 1.44269504f;
+  const int64_t nt = (K + GJXO_TILE_Q - 1) / GJXO_TILE_Q;
+  uint64_t* S = (uint64_t*)calloc((size_t)nt + 1, sizeof(uint64_t));
+  uint64_t* P = (uint64_t*)calloc((size_t)nt + 1, sizeof(uint64_t));
+  int32_t* E = (int32_t*)calloc((size_t)nt, sizeof(int32_t));
+  uint32_t* q = (uint32_t*)calloc((size_t)K, sizeof(uint32_t));
+  int Emax = GJXO_TILE_DEAD;
+  for (int64_t b = 0; b < nt; ++b) {
+    const int64_t lo = b * GJXO_TILE_Q, hi = lo + GJXO_TILE_Q < K ? lo + GJXO_TILE_Q : K;
+    float m = -INFINITY;
+    for (int64_t i = lo; i < hi; ++i) if (logw[i] > m) m = logw[i];
+    int e = GJXO_TILE_DEAD;
+    if (m > -INFINITY) {
+      const float t = ceilf(m * log2e);
+      e = t < -524287.0f ? -524287 : (t > 524287.0f ? 524287 : (int)t);
+    }
+    uint64_t acc = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      uint32_t qi = 0;
+      if (q_in) qi = q_in[i];
+      else if (e != GJXO_TILE_DEAD) {
+        float w = exp2f(fmaf(logw[i], log2e, -(float)e));
+        if (!(w > 0.0f)) w = 0.0f;
+        if (!(w < 1.0f)) w = 1.0f;
+        qi = (uint32_t)(w * 536870912.0f);
+      }
+      q[i] = qi;
+      acc += qi;
+    }
+    S[b] = acc;
+    E[b] = acc ? e : GJXO_TILE_DEAD;
+    if (acc && e > Emax) Emax = e;
+  }
+  for (int64_t b = 0; b < nt; ++b) {
+    const int sh = Emax - E[b];
+    P[b + 1] = P[b] + (sh < 64 ? S[b] >> sh : 0);
+  }
+  const uint64_t total = P[nt];
+  int rc = 0;
+  if (total == 0) {
+    for (int64_t j = 0; j < N; ++j) ancestors[j] = (int32_t)(j < K ? j : K - 1);
+    rc = 1;
+  } else {
+    uint64_t Sall = 0;
+    for (int64_t j = 0; j <= N; ++j) {          /* N + 1 spacings: the last one closes the unit interval */
+      uint32_t o[2];
+      gjxo_threefry2x32(key0, key1, (uint32_t)((uint64_t)j >> 32), (uint32_t)j, o);
+      Sall += exp_spacing(o[0]);
+    }
+    uint64_t Sj = 0;
+    int64_t b = 0;
+    for (int64_t j = 0; j < N; ++j) {
+      uint32_t o[2];
+      gjxo_threefry2x32(key0, key1, (uint32_t)((uint64_t)j >> 32), (uint32_t)j, o);
+      Sj += exp_spacing(o[0]);
+      uint64_t T = (uint64_t)((double)Sj * ((double)total / (double)Sall));
+      if (T > total - 1) T = total - 1;
+      while (!(P[b + 1] > T)) ++b;
+      const uint64_t r = (T - P[b]) << (Emax - E[b]);
+      const int64_t lo = b * GJXO_TILE_Q, hi = lo + GJXO_TILE_Q < K ? lo + GJXO_TILE_Q : K;
+      uint64_t c = 0;
+      int64_t i = lo;
+      for (; i < hi - 1; ++i) { c += q[i]; if (c > r) break; }
+      ancestors[j] = (int32_t)i;
+    }
+  }
+  free(S); free(P); free(E); free(q);
+  return rc;
+}
+
 int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uint64_t total_all,
                               uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
                               int64_t n_out, int32_t* ancestors) {

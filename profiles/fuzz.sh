@@ -6,7 +6,8 @@ TR=${1:-150}; shift; SEEDS=${@:-1001 1002}
 for sd in $SEEDS; do
   GJX_FUZZ_TRIALS=$TR GJX_FUZZ_SEED=$sd timeout 1500 python -m pytest -m gpu -q \
     "tests/test_gpu_parity.py::test_random_programs_against_oracle" "tests/test_gpu_parity.py::test_resampling_fuzz_against_oracle" \
-    "tests/test_gpu_hmcgen.py::test_random_programs_generated_hmc_vs_interpreter_and_oracle" > $OUT/seed_$sd.txt 2>&1
+    "tests/test_gpu_hmcgen.py::test_random_programs_generated_hmc_vs_interpreter_and_oracle" \
+    "tests/test_gpu_expr.py::test_random_expression_programs_against_oracle" > $OUT/seed_$sd.txt 2>&1
   echo "seed $sd trials $TR: $(grep -E "passed|failed" $OUT/seed_$sd.txt | tail -1)" >> $OUT/summary.txt
   grep -E "^E  " $OUT/seed_$sd.txt | head -12 >> $OUT/summary.txt
 done

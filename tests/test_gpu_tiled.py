@@ -73,6 +73,49 @@ def test_tiled_resampler_against_oracle(K_, oracle, K, N):
             assert q.max() <= (1 << 29)
 
 
+@pytest.mark.parametrize("K,N", [(1, 1), (777, 777), (1023, 1024), (1024, 1023), (1025, 3000), (10_000, 10_000), (1 << 18, 1 << 18), ((1 << 20) + 5, 1 << 19)])
+def test_sorted_multinomial_resampler_against_oracle(K_, oracle, K, N):
+    """gjx_resample_sorted_multinomial_tiled: multinomial resampling by sorted uniforms (exponential spacings) on the tile-scaled
+    weight line.  The spacings and their sums are integers on both sides, the threshold one double multiply: the oracle on the
+    device's quantised weights gives the same ancestors BIT FOR BIT; the ancestors are non-decreasing; and they are a multinomial
+    draw — the counts of a flat collection have the multinomial's variance 1 - 1/K (a systematic comb would have 0)"""
+    import torch
+    rs = np.random.default_rng(K + 1)
+    for name, lw in _weight_shapes(K, rs):
+        for key in ((0, 0), (0x12345678, 0x9ABCDEF0)):
+            anc, q, e = K_.resample_sorted_multinomial_tiled(torch.as_tensor(lw).cuda(), key, N, want_q=True)
+            anc, q, e = _np(anc), _np(q).view(np.uint32), _np(e)
+            anc_o, dead = oracle.resample_sorted_multinomial_tiled(lw, key, N, q=q)
+            np.testing.assert_array_equal(anc, anc_o, err_msg=f"{name} key={key}")
+            assert dead == (not q.any()), name           # (a 1-particle collection whose particle is a hole: identity on both sides)
+            assert (np.diff(anc) >= 0).all() and (dead or (q[anc] > 0).all()), name
+    if K >= 10_000:
+        flat = torch.zeros(K, device="cuda")
+        var = []
+        for k in range(6):
+            cnt = np.bincount(_np(K_.resample_sorted_multinomial_tiled(flat, (77, k), K)), minlength=K)
+            var.append(cnt.var())
+        assert abs(np.mean(var) - 1.0) < 6.0 * np.sqrt(3.0 / (6 * K)) + 2.0 / K, np.mean(var)      # (Poisson-like counts: var of a sample variance ~ 3 / K)
+        # and the draws follow the weights: the mass of the collection's heavier half
+        lw = rs.standard_normal(K).astype(np.float32)
+        w = np.exp(lw.astype(np.float64)); w /= w.sum()
+        heavy = lw > 0
+        got = np.mean([heavy[_np(K_.resample_sorted_multinomial_tiled(torch.as_tensor(lw).cuda(), (5, k), K))].mean() for k in range(8)])
+        p = w[heavy].sum()
+        assert abs(got - p) < 5.0 * np.sqrt(p * (1 - p) / (8 * K)), (got, p)
+
+
+def test_sorted_multinomial_dead_collection_and_workspace(K_):
+    import torch
+    lw = torch.full((5000,), float("-inf"), device="cuda")
+    ws = K_.workspace(A.OP_RESAMPLE, 5000, lw.device)
+    anc = K_.resample_sorted_multinomial_tiled(lw, (1, 2), ws=ws)
+    assert (_np(anc) == np.arange(5000)).all()
+    assert K_.workspace_status(ws, raise_on_error=False) & 2
+    with pytest.raises(K_.GjxError, match="workspace too small"):        # N far beyond K: the slot-tile sums do not fit
+        K_.resample_sorted_multinomial_tiled(torch.zeros(8, device="cuda"), (1, 2), N=1 << 24)
+
+
 def test_tiled_dead_collection_sets_status(K_):
     import torch
     lw = torch.full((5000,), float("-inf"), device="cuda")

@@ -90,3 +90,69 @@ def test_tiled_uses_given_quantisation():
     q2[:] = 1 << 20                            # flat weights given: every particle once
     a2, _, _, _ = oracle.resample_systematic_tiled(lw, 0.9, 4000, q=q2)
     assert (a2 == np.arange(4000)).all()
+
+
+# ---- multinomial resampling by sorted uniforms (gjxo_resample_sorted_multinomial_tiled; include/gjx.h,
+#      gjx_resample_sorted_multinomial_tiled) ----
+def test_exp_spacing_is_the_fixed_point_negative_log2():
+    """e(w) = floor(2^20 * -log2(x / 2^24)), x = 2 (w >> 9) + 1: against float64 within the polynomial's error (7e-8 in log2 ->
+    under 1 count of 2^-20 ... a few counts after the float32 chain), exact at the ends, monotone in x"""
+    rs = np.random.default_rng(0)
+    words = np.concatenate([rs.integers(0, 1 << 32, 20000, dtype=np.uint64), [0, 511, 512, (1 << 32) - 1, 1 << 31, (1 << 31) - 1]]).astype(np.uint64)
+    got = np.array([oracle.exp_spacing(int(w)) for w in words], np.float64)
+    x = 2.0 * (words >> np.uint64(9)).astype(np.float64) + 1.0
+    want = -np.log2(x / 2.0 ** 24) * 2.0 ** 20
+    assert np.abs(got - want).max() < 8.0, np.abs(got - want).max()
+    assert oracle.exp_spacing(0) == oracle.exp_spacing(511) == 24 << 20          # x = 1
+    assert oracle.exp_spacing((1 << 32) - 1) in (0, 1)                            # x = 2^24 - 1: -log2 = 8.6e-8 -> 0.09 counts
+    order = np.argsort(x, kind="stable")
+    assert (np.diff(got[order]) <= 0).all()
+
+
+def _exact_sorted_multinomial(lw, key, N):
+    """the same sorted uniforms (from the oracle's own spacings), float64 inverse CDF on the exact normalised weights"""
+    from oracle.cpu import threefry2x32
+    sp = np.array([oracle.exp_spacing(int(threefry2x32(key[0], key[1], 0, j)[0])) for j in range(N + 1)], np.float64)
+    u = np.cumsum(sp)[:N] / sp.sum()
+    w = np.exp(lw.astype(np.float64) - np.nanmax(lw[np.isfinite(lw)]))
+    w[~np.isfinite(w)] = 0.0
+    c = np.cumsum(w)
+    return np.minimum(np.searchsorted(c, u * c[-1], side="right"), lw.size - 1)
+
+
+@pytest.mark.parametrize("K,N", [(1, 1), (5, 5), (1024, 1024), (1025, 1025), (5000, 5000), (4096, 1000), (3000, 9001)])
+def test_sorted_multinomial_matches_float64_inverse_cdf(K, N):
+    rs = np.random.default_rng(K + N)
+    lw = (rs.standard_normal(K) * 3.0 - 40.0).astype(np.float32)
+    anc, dead = oracle.resample_sorted_multinomial_tiled(lw, (11, 13), N)
+    assert not dead and anc.min() >= 0 and anc.max() < K and (np.diff(anc) >= 0).all()
+    ref = _exact_sorted_multinomial(lw, (11, 13), N)
+    bad = anc != ref                 # a threshold within the quantisation step of a particle boundary: rare, then a neighbour
+    assert bad.mean() <= 2e-3 + 2.0 / N
+    assert (np.abs(anc[bad].astype(np.int64) - ref[bad]) <= 2).all() or K < 16
+
+
+def test_sorted_multinomial_is_a_multinomial_draw():
+    """counts over repeated draws: mean N p_i and the multinomial's variance N p_i (1 - p_i) — a systematic comb would show a variance
+    below 1/4; the uniforms are order statistics of iid draws: the FIRST one is Beta(1, N), mean 1 / (N + 1)"""
+    K = 64
+    rs = np.random.default_rng(5)
+    lw = rs.standard_normal(K).astype(np.float32)
+    p = np.exp(lw.astype(np.float64)); p /= p.sum()
+    N, R = 256, 600
+    counts = np.stack([np.bincount(oracle.resample_sorted_multinomial_tiled(lw, (3, r), N)[0], minlength=K) for r in range(R)])
+    se = np.sqrt(N * p * (1 - p) / R)
+    assert (np.abs(counts.mean(0) - N * p) < 4.5 * se).all()
+    ratio = counts.var(0, ddof=1) / (N * p * (1 - p))
+    assert 0.85 < ratio.mean() < 1.15 and ratio.min() > 0.6, (ratio.mean(), ratio.min())
+
+
+def test_sorted_multinomial_dead_collection_and_given_quantisation():
+    lw = np.full(3000, -np.inf, np.float32)
+    anc, dead = oracle.resample_sorted_multinomial_tiled(lw, (1, 2))
+    assert dead and (anc == np.arange(3000)).all()
+    q = np.zeros(3000, np.uint32)
+    q[[7, 2999]] = 5
+    anc, dead = oracle.resample_sorted_multinomial_tiled(np.zeros(3000, np.float32), (1, 2), 4000, q=q)
+    assert not dead and set(np.unique(anc)) == {7, 2999} and (np.diff(anc) >= 0).all()
+    assert abs((anc == 7).mean() - 0.5) < 0.05
