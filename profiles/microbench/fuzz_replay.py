@@ -29,9 +29,9 @@ for trial in range(want + 1):
     prog = PackedProgram(sl, rng_mode=rng)
     print("engine", K_.program_engine(prog), "key", key)
     for s in sl.sites:
-        print(" site", s.addr, A.KIND_NAMES[s.kind], "dim", s.dim, [(p.op, getattr(p, "src", None), getattr(p, "value", None)) for p in s.params])
+        print(" site", s.addr, A.KIND_NAMES[s.kind], "dim", s.dim, [(p.op, p.src, p.src_elem, p.length, p.xf, None if p.values is None else np.asarray(p.values).ravel()[:6]) for p in s.params])
     g = K_.run_program(prog, key, K, want_site_scores=True)
-    o = oracle.run_program(prog, key, K, want_site_scores=True)
+    o = oracle.run_program(prog, key, K, want_site_scores=True, want_margin=True)
     gc, gs = g["choices"].cpu().numpy(), g["score"].cpu().numpy()
     ok = P._close_cols(gc, o["choices"], rt=1e-3, at=5e-4) & P._close_cols(gs[None], o["score"][None], rt=2e-3, at=2e-3)
     bad = np.nonzero(~ok)[0]
