@@ -1103,7 +1103,7 @@ def run_round4(dev):
                                                                form=sinfo.get("form_name"), launches_per_run=sinfo.get("launches"),
                                                                float64_filter_std=fx["log_ml_std"], z=(lsv - fx["log_ml_mean"]) / fx["log_ml_std"])
     # a single run's z says little (rounds 4 / 5 timed ONE seed twice: +2.8, +3.7 against the 16-seed fixture's sd): 16 seeds against the
-    # 64-seed fixture — mean difference in standard errors (tests/test_gpu_scan_filter.py holds 32 seeds to 3 SE; profiles/r06_sv_bias.txt)
+    # 256-seed fixture — mean difference in standard errors (tests/test_gpu_scan_filter.py holds 32 seeds to 3 SE; profiles/r06_sv_bias.txt)
     ests = np.array([float(bsv.run(genjax.key(300 + i), CM["y"].set(ysv), (0.0, None))["log_ml"]) for i in range(16)])
     ref64 = np.asarray(fx["log_ml"], np.float64)
     se_ = float(np.sqrt(ests.var(ddof=1) / ests.size + ref64.var(ddof=1) / ref64.size))

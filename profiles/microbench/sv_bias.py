@@ -1,5 +1,5 @@
 """Stochastic-volatility filter: is the device's log-ML estimate biased against the ideal float64 filter?  (two single
-runs sat at z = +2.8 and +3.7.)  N device seeds x {FLAT, JAX32} x {0, 2 Metropolis moves per step} against the 64-seed float64
+runs sat at z = +2.8 and +3.7.)  N device seeds x {FLAT, JAX32} x {0, 2 Metropolis moves per step}, and the multinomial resampler, against the 256-seed float64
 fixture (tests/golden/sv_pf_float64.json): mean difference +- standard error, and the ratio of the spreads.
 usage: python profiles/microbench/sv_bias.py [n_seeds=64]"""
 import json
@@ -41,4 +41,12 @@ for rng, rn in ((A.RNG_FLAT, "flat"), (A.RNG_JAX32, "jax32")):
         out[f"{rn}_moves{moves}"] = dict(mean=float(est.mean()), sd=float(est.std(ddof=1)), bias=float(d), se=float(se), bias_over_se=float(d / se),
                                          spread_ratio=float(est.std(ddof=1) / ref.std(ddof=1)), form=bf.last_info["form_name"])
         print(f"{rn:6s} moves={moves}: mean {est.mean():.5f} sd {est.std(ddof=1):.5f}  bias {d:+.5f} +- {se:.5f} ({d / se:+.2f} SE)  spread ratio {est.std(ddof=1) / ref.std(ddof=1):.2f}  [{bf.last_info['form_name']}]")
+for rng, rn in ((A.RNG_FLAT, "flat"), (A.RNG_JAX32, "jax32")):
+    bf = BootstrapFilter(step.scan(n=T), K, rng_mode=rng, resampler="multinomial")
+    est = np.array([float(bf.run(genjax.key(1000 + i), C["y"].set(ys), (0.0, None))["log_ml"]) for i in range(n)])
+    d = est.mean() - ref.mean()
+    se = math.sqrt(est.var(ddof=1) / est.size + ref.var(ddof=1) / ref.size)
+    out[f"{rn}_multinomial"] = dict(mean=float(est.mean()), sd=float(est.std(ddof=1)), bias=float(d), se=float(se), bias_over_se=float(d / se),
+                                    spread_ratio=float(est.std(ddof=1) / ref.std(ddof=1)), form=bf.last_info["form_name"])
+    print(f"{rn:6s} multinomial: mean {est.mean():.5f} sd {est.std(ddof=1):.5f}  bias {d:+.5f} +- {se:.5f} ({d / se:+.2f} SE)  spread ratio {est.std(ddof=1) / ref.std(ddof=1):.2f}  [{bf.last_info['form_name']}]")
 print(json.dumps(out))
