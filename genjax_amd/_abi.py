@@ -192,6 +192,8 @@ PROTOTYPES = {
     "gjx_shard_global_lse": (C.c_int, [vp, vp, vp, vp]),
     "gjx_scan_filter_peer": (C.c_int, [vp, vp, i32, u32, u32, vp, vp, vp, C.c_size_t, vp, vp]),
     "gjx_scan_filter_peer_prepare": (C.c_int, [vp, vp, i32, vp]),
+    "gjx_scan_filter_peer_opts": (C.c_int, [vp, vp, i32, u32, u32, vp, vp, vp, C.c_size_t, vp, vp, vp]),
+    "gjx_scan_filter_peer_prepare_opts": (C.c_int, [vp, vp, i32, vp, vp]),
     "gjx_peer_ctx_create": (C.c_int, [i32, i32, i64, i32, i32, C.POINTER(vp)]),
     "gjx_peer_ctx_create_ex": (C.c_int, [i32, i32, i64, i32, i32, i32, C.POINTER(vp)]),
     "gjx_peer_ctx_export": (C.c_int, [vp, vp]),

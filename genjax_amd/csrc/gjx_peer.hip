@@ -324,23 +324,40 @@ static int filter_peer(const gjx_ssm* m, uint32_t key0, uint32_t key1, int32_t r
 // Particles and weights do not depend on the number of ranks (streams and resampling integers are global).
 // ------------------------------------------------------------------------------------------------------------
 static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
-                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out, bool prepare_only);
+                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, const gjx_filter_opts* opts,
+                                 gjx_filter_info* info_out, bool prepare_only);
 
 extern "C" int gjx_scan_filter_peer(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
                                     int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out) {
-  return scan_filter_peer_impl(c, steps, T, key0, key1, lse_steps, ancestors, workspace, workspace_bytes, stream, info_out, false);
+  return scan_filter_peer_impl(c, steps, T, key0, key1, lse_steps, ancestors, workspace, workspace_bytes, stream, nullptr, info_out, false);
+}
+// ... with the options of gjx_scan_filter that the sharded kernel carries: GJX_FILTER_MULTINOMIAL (resampling by sorted uniforms — the
+// spacing sums of every tile travel to every rank as the second word of its granule, no exchange beyond the systematic filter's)
+extern "C" int gjx_scan_filter_peer_opts(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                                         int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, const gjx_filter_opts* opts,
+                                         gjx_filter_info* info_out) {
+  return scan_filter_peer_impl(c, steps, T, key0, key1, lse_steps, ancestors, workspace, workspace_bytes, stream, opts, info_out, false);
+}
+extern "C" int gjx_scan_filter_peer_prepare_opts(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, const gjx_filter_opts* opts, gjx_filter_info* info_out) {
+  return scan_filter_peer_impl(c, steps, T, 0u, 0u, nullptr, nullptr, nullptr, 0, nullptr, opts, info_out, true);
 }
 // everything of the call above that takes unpredictable host time — generating, compiling (hipRTC) and loading the kernels of the
 // step programs, the occupancy queries behind the choice of tiles per block — and no launch: the ranks of a job call it, meet at a
 // HOST barrier, and only then enter the filter together (a rank that waits for a peer still compiling would run out of its poll budget)
 extern "C" int gjx_scan_filter_peer_prepare(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, gjx_filter_info* info_out) {
-  return scan_filter_peer_impl(c, steps, T, 0u, 0u, nullptr, nullptr, nullptr, 0, nullptr, info_out, true);
+  return scan_filter_peer_impl(c, steps, T, 0u, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, info_out, true);
 }
 
 static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
-                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out, bool prepare_only) {
+                                 int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, const gjx_filter_opts* opts,
+                                 gjx_filter_info* info_out, bool prepare_only) {
   gjx_filter_info finfo = {GJX_FILTER_FORM_WIDE, 0, 0, 0};
   if (info_out) *info_out = finfo;
+  const int fflags = opts ? opts->flags : 0;
+  if (opts && opts->n_moves > 0) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: the sharded filter kernel has no rejuvenation move (gjx_scan_filter on one GPU has)");
+  if (fflags & ~(GJX_FILTER_MULTINOMIAL)) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter_peer: of gjx_filter_opts.flags the sharded kernel takes GJX_FILTER_MULTINOMIAL only (it has one form)");
+  const bool multinomial = (fflags & GJX_FILTER_MULTINOMIAL) != 0;
+  const int flavour = 256 | (multinomial ? 1024 : 0);
   if (!c || !steps || (!lse_steps && !prepare_only) || T < 2) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: bad argument (T >= 2)");
   if (!c->connected) return gjx_fail(GJX_EINVAL, "gjx_scan_filter_peer: the context is not connected (gjx_peer_ctx_connect)");
   auto input_rows = [](const gjx_program& p) {
@@ -362,12 +379,12 @@ static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int3
   if (!prepare_only && (!workspace || workspace_bytes < need_run + 8 * (size_t)T + 256)) return gjx_fail(GJX_EWORKSPACE, "gjx_scan_filter_peer: workspace too small (OP_RUN + 8 T + 256)");
   hipStream_t st = (hipStream_t)stream;
   const int64_t K = c->K, K_total = K * c->world;
-  const size_t dyn = pf_core_dyn_lds(c->NT);
+  const size_t dyn = pf_core_dyn_lds(c->NT, multinomial);
   int spl = 0, grid = 0;
   const int spls[5] = {1, 2, 4, 8, 16};
   for (int i = 0; i < 5 && !spl; ++i) {
     const int64_t g = ((int64_t)c->nt + spls[i] - 1) / spls[i];
-    int cap = gen_pf_resident_blocks(&steps[1], spls[i] | 256, dyn);
+    int cap = gen_pf_resident_blocks(&steps[1], spls[i] | flavour, dyn);
     if (cap <= 0) break;
     if (c->share > 1) cap /= c->share;               // ranks that share one device (dry runs): every rank's grid must be resident
     if (g <= cap && g * c->world <= kPfHostMaxTiles) { spl = spls[i]; grid = (int)g; }
@@ -381,9 +398,11 @@ static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int3
     (void)gjx_program_precompile(&steps[0], gen_pick_ppt(&steps[0], c->K, false));     // (step 0 may run on another engine: not an error)
     return GJX_OK;
   }
-  std::vector<uint32_t> h_keys;
+  std::vector<uint32_t> h_keys, h_res;
   std::vector<double> h_us;
-  pf_step_keys(key0, key1, T, h_keys, h_us);
+  pf_step_keys_res(key0, key1, T, h_keys, h_us, h_res);
+  if (multinomial)      // (the sorted-uniform resampler takes the resampling KEY of a step where the comb takes its offset: two words as one 64-bit pattern)
+    for (int u = 0; u < T; ++u) { const uint64_t w = (uint64_t)h_res[2 * u] | ((uint64_t)h_res[2 * u + 1] << 32); memcpy(&h_us[u], &w, 8); }
   if (int rcu = upload_words(c->us_dev, h_us.data(), (size_t)T, st)) return rcu;
   if (int rcu = upload_words(c->keys_dev, h_keys.data(), (size_t)T, st)) return rcu;
   const float** tabs_dev = (const float**)((char*)workspace + ((need_run + 255) & ~(size_t)255));
@@ -426,7 +445,7 @@ static int scan_filter_peer_impl(gjx_peer_ctx* c, const gjx_program* steps, int3
   ga.rows_a = rows_a; ga.rows_b = rows_b; ga.rows_all = nullptr; ga.rows_step = 0;
   ga.in_row0_first = (int64_t)input_rows(steps[0]) * K;
   ga.in_row0 = (int64_t)input_rows(steps[1]) * K;
-  rc = gen_pf_launch(&steps[1], spl | 256, ga, grid, dyn, st);
+  rc = gen_pf_launch(&steps[1], spl | flavour, ga, grid, dyn, st);
   if (rc) return rc;
   finfo.launches = 2; finfo.grid = grid; finfo.tiles_per_block = spl;
   if (info_out) *info_out = finfo;

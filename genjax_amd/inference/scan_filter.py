@@ -326,14 +326,12 @@ class ScanBootstrapFilter:
         """the same filter on a collection SHARDED over the ranks of a ``kernels.PeerContext`` (one process per GPU; ``self.K`` is the
         number of particles of THIS rank, the context's K_local; its rows >= the step programs' rows): gjx_scan_filter_peer —
         two launches per rank whatever T is, granules pushed and carry rows pulled through the peer-mapped windows, no host in the
-        loop.  Every rank calls it with the same key, observations and arguments.  -> dict(log_ml (global), increments, lse_steps,
+        loop; ``resampler="multinomial"``: sorted uniforms over the whole sharded collection, no exchange beyond the systematic filter's.  Every rank calls it with the same key, observations and arguments.  -> dict(log_ml (global), increments, lse_steps,
         choices (this rank's part of the last step: a view of the window), logw, ancestors? (global indices), programs, info)"""
         if ctx.K != self.K:
             raise ValueError("run_peer: the filter's particle count must be the context's K_local")
         if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
             raise NotImplementedError("run_peer: the sharded filter kernel has no resample-move yet (rejuvenate=...); run() on one GPU has")
-        if self.resampler != "systematic":
-            raise NotImplementedError("run_peer: the sharded filter kernel resamples systematically; resampler='multinomial' runs on one GPU only")
         if getattr(self, "_has_statics", False):
             raise NotImplementedError("run_peer: a model with latent sites in front of the Scan runs on one GPU")
         dev = ctx.device
@@ -352,12 +350,20 @@ class ScanBootstrapFilter:
         if c.get("prepared_for") is not ctx or c.get("prepared_sk") != sk:
             # first run of this structure on this context: kernels generated, compiled and loaded on EVERY rank, then a host barrier —
             # the ranks enter the filter together (compile times differ by seconds, a rank's poll budget is shorter)
-            ctx.scan_filter_prepare(cps, len(progs))
+            ctx.scan_filter_prepare(cps, len(progs), opts=self._peer_opts())
             c["prepared_for"], c["prepared_sk"] = ctx, sk
-        o = ctx.scan_filter(cps, len(progs), key, want_ancestors=want_ancestors)
+        o = ctx.scan_filter(cps, len(progs), key, want_ancestors=want_ancestors, opts=self._peer_opts())
         incs = o["lse_steps"][:, 3]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=o["lse_steps"], choices=o["rows"][: max(progs[-1].n_slots, 1)], logw=o["logw"],
                     ancestors=o["ancestors"], programs=progs, info=o["info"])
+
+    def _peer_opts(self):
+        """of the run's options, what the sharded kernel carries (gjx_scan_filter_peer_opts): the multinomial resampler"""
+        if self.resampler != "multinomial":
+            return None
+        o = A.GjxFilterOpts()
+        o.flags = A.FILTER_MULTINOMIAL
+        return o
 
     def _opts(self, dev=None) -> "A.GjxFilterOpts":
         """the form of the run as ARGUMENTS of the call (the library reads no environment variable).  Attributes of the filter, or —

@@ -737,11 +737,12 @@ class PeerContext:
               "gjx_ssm_filter_peer")
         return dict(lse_steps=lse, x=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc)
 
-    def scan_filter_prepare(self, cps, T: int) -> None:
+    def scan_filter_prepare(self, cps, T: int, opts=None) -> None:
         """gjx_scan_filter_peer_prepare + a barrier of the context's group: every rank has generated, compiled and loaded the kernels
         of the run before any rank launches into the others' windows (call it once per program structure, on every rank)"""
         info = A.GjxFilterInfo()
-        check(load().gjx_scan_filter_peer_prepare(self._h, C.cast(cps, C.c_void_p), int(T), C.byref(info)), "gjx_scan_filter_peer_prepare")
+        check(load().gjx_scan_filter_peer_prepare_opts(self._h, C.cast(cps, C.c_void_p), int(T), C.byref(opts) if opts is not None else None, C.byref(info)),
+              "gjx_scan_filter_peer_prepare")
         self.barrier()
 
     def barrier(self) -> None:
@@ -751,7 +752,7 @@ class PeerContext:
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
 
-    def scan_filter(self, cps, T: int, key, want_ancestors: bool = False):
+    def scan_filter(self, cps, T: int, key, want_ancestors: bool = False, opts=None):
         """gjx_scan_filter_peer: the bootstrap filter for ANY Scan kernel on this sharded collection — ``cps``: the ctypes array of
         this rank's T step programs (inference/scan_filter.py).  -> dict(lse_steps [T][4] global records, rows (the last step's
         choices: a view of the window), logw, ancestors?, info)"""
@@ -761,8 +762,9 @@ class PeerContext:
         if getattr(self, "_sf_ws", None) is None or self._sf_ws.numel() < need:
             self._sf_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         info = A.GjxFilterInfo()
-        check(load().gjx_scan_filter_peer(self._h, C.cast(cps, C.c_void_p), int(T), key[0], key[1], _ptr(lse), _ptr(anc), _ptr(self._sf_ws),
-                                          self._sf_ws.numel(), _stream(), C.byref(info)), "gjx_scan_filter_peer")
+        check(load().gjx_scan_filter_peer_opts(self._h, C.cast(cps, C.c_void_p), int(T), key[0], key[1], _ptr(lse), _ptr(anc), _ptr(self._sf_ws),
+                                               self._sf_ws.numel(), _stream(), C.byref(opts) if opts is not None else None, C.byref(info)),
+              "gjx_scan_filter_peer")
         return dict(lse_steps=lse, rows=self.rows[(T - 1) & 1], logw=self.logw[0], ancestors=anc,
                     info=dict(form=int(info.form), launches=int(info.launches), grid=int(info.grid), tiles_per_block=int(info.tiles_per_block)))
 

@@ -937,6 +937,16 @@ int gjx_ssm_filter_peer_move(const gjx_ssm* m, uint32_t key0, uint32_t key1, int
 int gjx_scan_filter_peer_prepare(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, gjx_filter_info* info_out);
 int gjx_scan_filter_peer(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
                          int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, gjx_filter_info* info_out);
+/* the two calls above with the options of gjx_scan_filter that the sharded kernel carries (opts NULL: the calls above):
+ * GJX_FILTER_MULTINOMIAL — multinomial resampling by sorted uniforms over the WHOLE sharded collection ("multinomial
+ * resampling uses the same exchange with sorted uniforms"): slot j's spacing comes from its GLOBAL index, every tile's spacing total
+ * travels to every rank as the second word of the tile's granule, so the ranks exchange nothing beyond the systematic filter's granules
+ * and pulled carry rows; ancestors == gjx_resample_sorted_multinomial_tiled on the unsharded collection, bit for bit.  Any other flag,
+ * or n_moves > 0: GJX_EUNSUPPORTED.  prepare_opts must be given the opts of the run (the flavour is another kernel). */
+int gjx_scan_filter_peer_prepare_opts(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, const gjx_filter_opts* opts, gjx_filter_info* info_out);
+int gjx_scan_filter_peer_opts(gjx_peer_ctx* ctx, const gjx_program* steps, int32_t T, uint32_t key0, uint32_t key1, float* lse_steps,
+                              int32_t* ancestors, void* workspace, size_t workspace_bytes, void* stream, const gjx_filter_opts* opts,
+                              gjx_filter_info* info_out);
 /* BASELINE configs 2 / 4 on a sharded collection — one systematic resampling step over the WHOLE collection in ONE
  * launch per rank (ParticleCollection resampling, the N-of-K form of smc.py:102-109): this rank's log-weights logw[parity]
  * and rows rows[parity] (the buffers of the DATA window the producing kernel wrote) -> the children of this rank's

@@ -157,7 +157,7 @@ def _scan_filter_worker(rank, world, port, K_total, T, dx, q, env):
         torch.cuda.set_device(0)
         scan, carry0, s = workloads.lgssm_scan(dx, T)
         ys = np.asarray(s["y"], np.float32)
-        bf = BootstrapFilter(scan, K_total // world)
+        bf = BootstrapFilter(scan, K_total // world, resampler=env.get("GJX_TEST_RESAMPLER", "systematic"))
         rows = max(p.n_slots for p in bf.step_programs(C["y"].set(ys), (carry0, None)))
         ctx = kernels.PeerContext(K_total // world, rows, "cuda")
         outs = []
@@ -195,21 +195,24 @@ def _run_scan_filter_ranks(world, K_total, T, dx, env):
     return res
 
 
-@pytest.mark.parametrize("world,K_total,dx,verify", [(1, 1 << 14, 8, 0), (2, 1 << 15, 8, 1), (4, 1 << 16, 4, 1), (8, 1 << 19, 8, 1)])
-def test_generic_filter_sharded_over_peer_windows_equals_unsharded(world, K_total, dx, verify):
+@pytest.mark.parametrize("world,K_total,dx,verify,resampler", [(1, 1 << 14, 8, 0, "systematic"), (2, 1 << 15, 8, 1, "systematic"), (4, 1 << 16, 4, 1, "systematic"),
+                                                               (8, 1 << 19, 8, 1, "systematic"), (1, 1 << 14, 8, 0, "multinomial"),
+                                                               (2, 1 << 15, 8, 1, "multinomial"), (4, 1 << 17, 4, 1, "multinomial"), (8, 1 << 19, 8, 0, "multinomial")])
+def test_generic_filter_sharded_over_peer_windows_equals_unsharded(world, K_total, dx, verify, resampler):
     """gjx_scan_filter_peer — the filter kernel GENERATED for config 3's model written as @gen + .scan, on `world` ranks (processes
     sharing the GPU, windows mapped through hipIpc) — == gjx_scan_filter on one rank: states, log-weights and ancestors bit for bit, the
     global LSE records to summation order; with GJX_PEER_VERIFY=1 every pulled carry row is checked against its owner's word and every
-    re-scanned tile against its granule, and no status bit may be raised"""
+    re-scanned tile against its granule, and no status bit may be raised.  resampler="multinomial" (gjx_scan_filter_peer_opts, SURVEY.md
+    §8(e): sorted uniforms over the whole sharded collection): the spacing sums of every tile travel with its granule"""
     import genjax_amd as genjax
     from genjax_amd import C, workloads
     from genjax_amd import _abi as A
     from genjax_amd.inference import BootstrapFilter
     T = 10
-    res = _run_scan_filter_ranks(world, K_total, T, dx, dict(GJX_PEER_VERIFY=str(verify)))
+    res = _run_scan_filter_ranks(world, K_total, T, dx, dict(GJX_PEER_VERIFY=str(verify), GJX_TEST_RESAMPLER=resampler))
     scan, carry0, s = workloads.lgssm_scan(dx, T)
     ys = np.asarray(s["y"], np.float32)
-    bf = BootstrapFilter(scan, K_total)
+    bf = BootstrapFilter(scan, K_total, resampler=resampler)
     for rep in range(2):
         ref = bf.run(genjax.key(5 + rep), C["y"].set(ys), (carry0, None))
         x = np.concatenate([r[1][rep][0] for r in res], axis=1)
