@@ -1610,6 +1610,33 @@ def run_round6(dev):
                                                           log_ml=float(out2["log_ml"]),
                                                           posterior_mean_phi=float((w * bf2.latent(out2, "phi")[0].double()).sum() / w.sum()),
                                                           note="phi and log sigma drawn in front of the Scan travel with the particles (GJX_SITE_CARRIED inputs)")
+    # (5) moves that are the library's own requests (inference/filter_moves.py): the filter step by step as device calls, an HMC move
+    # (gjx_hmc on the step-local target, accept fused) and a Rejuvenate proposal move behind every resampling; stochastic volatility
+    from genjax_amd import S
+    from genjax_amd.inference import HMC, Rejuvenate
+    with open(os.path.join(ROOT, "tests", "golden", "sv_pf_float64.json")) as f:
+        fx = json.load(f)
+    phi_, sig_, yfx = fx["phi"], fx["sigma"], np.asarray(fx["y"], np.float32)
+
+    @genjax.gen
+    def sv1(x_prev, _):
+        x = genjax.normal(phi_ * x_prev, sig_) @ "x"
+        genjax.normal(0.0, genjax.exp(0.5 * x)) @ "y"
+        return x, None
+
+    Km = 1 << 16
+    for name, mv in (("hmc_L3", [HMC(S["x"], 0.25, 3)]), ("rejuvenate_proposal", [{"x": Rejuvenate(genjax.normal, lambda chm: (chm.get_value(), 0.2))}]),
+                     ("no_move_step_by_step", None)):
+        bfm = BootstrapFilter(sv1.scan(n=len(yfx)), Km, moves=mv)
+        if mv is None:
+            from genjax_amd.inference.filter_moves import run_with_moves
+            bfm.run = lambda k_, c_, a_, _b=bfm, _none=[]: run_with_moves(_b, k_, c_, a_, _none)
+        dtm, om = time_filter(bfm, CM["y"].set(yfx), (0.0, None), n=3)
+        acc = om.get("accepted") or []
+        res[f"scan_filter_sv_moves_{name}_T256_K2e16"] = dict(
+            us_per_step=dtm / len(yfx) * 1e6, log_ml=float(om["log_ml"]), z=(float(om["log_ml"]) - fx["log_ml_mean"]) / (fx["log_ml_std"] * 2.0),
+            accept_rate=[a / (Km * (len(yfx) - 1)) for a in acc], distinct_carry=int(torch.unique(om["choices"][0]).numel()),
+            note="step-by-step form: resample, gather, moves, propagate as device calls per step; z against the float64 fixture's spread scaled to K = 2^16")
     return res
 
 

@@ -35,7 +35,7 @@ class ScanBootstrapFilter:
     step), the others are propagated."""
 
     def __init__(self, scan: ScanCombinator, k_particles: int, rng_mode: int | None = None, proposal: ScanCombinator | None = None,
-                 proposal_args=None, rejuvenate: dict | None = None, resampler: str = "systematic"):
+                 proposal_args=None, rejuvenate: dict | None = None, resampler: str = "systematic", moves=None):
         """``proposal``: ``q_step.scan(n=T)`` — a kernel ``(carry, x) -> (carry, out)`` like the model's whose sites PROPOSE the model's
         latent choices of the same names (the importance step with a custom proposal, inference/smc.py:302-313, applied per Scan step:
         scan.py:325-416 extends a trace by one step): step t draws from q_t(. | carry, x_t) and weights by
@@ -44,7 +44,11 @@ class ScanBootstrapFilter:
         ``rejuvenate=dict(n_moves=n, scale=s)``: resample-move — behind every resampling from the second on each particle's carry takes n
         random-walk Metropolis steps that leave the previous step's posterior invariant (the reference's Rejuvenate with a symmetric
         proposal and the caller-side accept, requests/rejuvenate.py:70-94; generated from the step program, include/gjx.h
-        gjx_filter_opts::n_moves); ``out["accepted_total"]`` counts the accepted moves of a run."""
+        gjx_filter_opts::n_moves); ``out["accepted_total"]`` counts the accepted moves of a run.
+        ``moves=[...]``: ANY of the library's move requests behind every resampling — ``HMC(S["x"], eps, L)`` over the step's continuous
+        latents (hmc.py:138-211), ``{"x": Rejuvenate(dist, argument_mapping)}`` with an arbitrary proposal (rejuvenate.py:70-94) — each
+        with the caller-side accept (test_requests.py:131-137) on the step-local target; the filter then runs step by step as device
+        calls (inference/filter_moves.py) instead of in the one-launch kernel; ``out["accepted"]`` counts per move."""
         from ..gen import StaticGenerativeFunction
         if not isinstance(scan, (ScanCombinator, StaticGenerativeFunction)):
             raise TypeError("ScanBootstrapFilter needs kernel.scan(n=T), or a @gen model whose body is sites in front of one kernel.scan(n=T)(...) call")
@@ -53,6 +57,12 @@ class ScanBootstrapFilter:
         self.scan, self.K = scan, int(k_particles)
         self.proposal, self.proposal_args = proposal, proposal_args
         self.rejuvenate = dict(rejuvenate) if rejuvenate else None
+        self.moves = list(moves) if moves else None
+        if self.moves and self.rejuvenate:
+            raise ValueError("give the random-walk move (rejuvenate=...: inside the one-launch kernel) or moves=[...] (step by step), not both")
+        if self.moves:
+            from .filter_moves import normalise_moves
+            normalise_moves(self.moves)       # (raises on what is not a move)
         if resampler not in ("systematic", "multinomial"):
             raise ValueError("resampler must be 'systematic' or 'multinomial'")
         self.resampler = resampler            # multinomial: every slot draws its own uniform (GJX_FILTER_MULTINOMIAL; three plain launches per step)
@@ -198,6 +208,7 @@ class ScanBootstrapFilter:
                 extra = dict(carried=[ps.addr for ps in statics],
                              input_row_of={ps.addr: prev_prog.slot_of[ps.addr] for ps in list(statics) + list(prev_latent)})
             prog = PackedProgram(step_sl, modes, obs, rng_mode=self.rng_mode, plates=False, proposal=q_names, proposed_by=proposed_by, **extra)
+            prog.filter_obs = dict(obs)       # (inference/filter_moves.py builds the step's assess form from them)
             progs.append(prog)
             # the next step reads this step's latent rows in ROW order (a proposed latent sits where its proposal site drew it)
             prev_latent = sorted(latent, key=lambda s_: prog.slot_of[s_.addr])
@@ -211,6 +222,11 @@ class ScanBootstrapFilter:
         ``out["history"]`` (a ScanHistory) reconstructs trajectories from them."""
         from .. import kernels
         dev = kernels._dev(device)
+        if self.moves:
+            if keep_history:
+                raise NotImplementedError("filter moves: keep_history is kept by the one-launch forms (gjx_scan_filter_history)")
+            from .filter_moves import run_with_moves
+            return run_with_moves(self, key, constraint, args, self.moves, device=dev, keep_ancestors=keep_ancestors)
         # two keys: the STRUCTURE of the run (addresses, shapes, dtypes: what decides the site lists, hence the kernels) and its DATA
         # (every byte of the observations and of the kernel's arguments — both are folded into the step programs' tables; repr()
         # elides the middle of long arrays and must not be used here).  New data under an old structure re-fills the tables of the
@@ -330,8 +346,8 @@ class ScanBootstrapFilter:
         choices (this rank's part of the last step: a view of the window), logw, ancestors? (global indices), programs, info)"""
         if ctx.K != self.K:
             raise ValueError("run_peer: the filter's particle count must be the context's K_local")
-        if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
-            raise NotImplementedError("run_peer: the sharded filter kernel has no resample-move yet (rejuvenate=...); run() on one GPU has")
+        if self.moves or (self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0):
+            raise NotImplementedError("run_peer: the sharded filter kernel has no resample-move yet (rejuvenate=..., moves=...); run() on one GPU has")
         if getattr(self, "_has_statics", False):
             raise NotImplementedError("run_peer: a model with latent sites in front of the Scan runs on one GPU")
         dev = ctx.device

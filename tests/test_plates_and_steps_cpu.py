@@ -438,8 +438,10 @@ def test_filter_kernel_of_a_step_program_is_emitted_and_cross_compiles():
     bf = ScanBootstrapFilter(step.scan(n=T), 4096)
     progs = bf.step_programs(C["y"].set(rs.standard_normal((T, dx)).astype(np.float32)), (np.zeros(dx, np.float32), None))
     src = kernels.program_filter_source(progs[1], 2)
-    assert "pf_core<GenPfModel, SPL, 0, 0>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src      # one rank: agent scope, no verify mode
-    assert "pf_core<GenPfModel, SPL, 2, 2>" in kernels.program_filter_source(progs[1], 2 | 256)                     # sharded flavour: decided at run time
+    assert "pf_core<GenPfModel, SPL, 0, 0, false>" in src and "#define SPL 2" in src and "#define NHOIST 4" in src      # one rank: agent scope, no verify mode
+    assert "pf_core<GenPfModel, SPL, 2, 2, false>" in kernels.program_filter_source(progs[1], 2 | 256)              # sharded flavour: decided at run time
+    assert "pf_core<GenPfModel, SPL, 0, 0, true>" in kernels.program_filter_source(progs[1], 2 | 1024)              # multinomial resampling by sorted uniforms
+    assert "pf_core<GenPfModel, SPL, 2, 2, true>" in kernels.program_filter_source(progs[1], 1 | 256 | 1024)        # ... on a sharded collection
     # the step's draws: the stream's words are taken ahead (behind the publish), Box-Muller is finished inside the slot
     assert "d.nz[3] = __uint_as_float(bs.get(3u));" in src and "box_muller(__float_as_uint(dr_->nz[0]), __float_as_uint(dr_->nz[1]), hn0_, hn1_);" in src
     assert "LDIN(a.in_rows + (int64_t)3 * a.in_stride + src_[p])" in src and "tab_s[e] = tb_[e]" in src
