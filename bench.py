@@ -1636,7 +1636,9 @@ def run_round6(dev):
         res[f"scan_filter_sv_moves_{name}_T256_K2e16"] = dict(
             us_per_step=dtm / len(yfx) * 1e6, log_ml=float(om["log_ml"]), z=(float(om["log_ml"]) - fx["log_ml_mean"]) / (fx["log_ml_std"] * 2.0),
             accept_rate=[a / (Km * (len(yfx) - 1)) for a in acc], distinct_carry=int(torch.unique(om["choices"][0]).numel()),
-            note="step-by-step form: resample, gather, moves, propagate as device calls per step; z against the float64 fixture's spread scaled to K = 2^16")
+            form=(om.get("info") or {}).get("form_name"),
+            note="ONE HMC move: inside the library's step loop (gjx_filter_opts::hmc_targets: gather, gjx_hmc, propagate per step); proposal moves "
+                 "and the no-move reference: the same calls composed from the host (inference/filter_moves.py); z against the float64 fixture's spread scaled to K = 2^16")
     return res
 
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # status
 OK, EINVAL, EUNSUPPORTED, EHIP, EWORKSPACE = 0, -1, -2, -3, -4
@@ -97,7 +97,8 @@ PEER_VERIFY_ON, PEER_DATA_FINE, PEER_VERIFY_FAULTY = 1, 2, 4
 
 class GjxFilterOpts(C.Structure):
     _fields_ = [("flags", i32), ("coresident_blocks", i32), ("timeline", vp), ("timeline_bytes", i64), ("n_moves", i32), ("move_scale", f32),
-                ("accepted_total", vp)]
+                ("accepted_total", vp), ("hmc_targets", vp), ("hmc_eps", f32), ("hmc_L", i32), ("hmc_rows", vp), ("hmc_out", vp),
+                ("hmc_workspace", vp), ("hmc_workspace_bytes", C.c_size_t)]
 
 
 class GjxFilterInfo(C.Structure):

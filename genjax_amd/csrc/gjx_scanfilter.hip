@@ -27,6 +27,13 @@ using namespace gjx;
 // tile totals {S_b, e_b} and block pairs of a step that ran as its own launch -> the tagged granules and the pair array the steps
 // kernel's first step polls / reads (gjx_gen_steps)
 static __global__ void k_clear_status(unsigned* ctrl) { if (threadIdx.x == 0) ctrl[2] = 0u; }
+// accepted chains of one HMC move (gjx_hmc's flags f32[K]) added to the run's counter
+static __global__ __launch_bounds__(256) void k_count_flags(const float* flags, int64_t K, unsigned long long* total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(i < K && flags[i] > 0.5f);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+}
+
 static __global__ void k_merge_status(unsigned* from, unsigned* to) { if (threadIdx.x == 0 && from[2]) { atomicOr(&to[2], from[2]); from[2] = 0u; } }
 
 __global__ void k_tiles_to_granules(const uint64_t* __restrict__ S, const int32_t* __restrict__ E, const unsigned long long* __restrict__ pairs,
@@ -63,7 +70,17 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
   const size_t steps_off = (logw_off + sizeof(float) * (size_t)K + 255) & ~(size_t)255;
   const size_t steps_bytes = (16 * (size_t)kLiveGranulePad + 16) * (size_t)nt + 24 * (size_t)T + 64;
   char* steps_area = (room && K % 1024 == 0 && workspace_bytes >= steps_off + steps_bytes) ? (char*)workspace + steps_off : nullptr;
-  const bool no_fuse = (fflags & GJX_FILTER_TWO_LAUNCH) != 0;
+  // an HMC move behind every resampling (gjx_filter_opts::hmc_targets): the plain two-launch step with a gather and one gjx_hmc between them
+  const gjx_program* hmc_t = opts ? opts->hmc_targets : nullptr;
+  if (hmc_t) {
+    if (n_moves > 0 || (fflags & GJX_FILTER_ABSOLUTE_INPUTS)) return gjx_fail(GJX_EUNSUPPORTED, "gjx_scan_filter: the HMC move runs without n_moves and without carried static inputs");
+    if (!opts->hmc_rows || !opts->hmc_out || !opts->hmc_workspace || opts->hmc_L < 1 || !(opts->hmc_eps > 0.0f))
+      return gjx_fail(GJX_EINVAL, "gjx_scan_filter: hmc_targets needs hmc_rows, hmc_out, hmc_workspace, hmc_L >= 1, hmc_eps > 0");
+    for (int t = 0; t + 1 < T; ++t)
+      if (hmc_t[t].n_slots != steps[t].n_slots || opts->hmc_workspace_bytes < gjx_hmc_workspace_bytes(&hmc_t[t], K))
+        return gjx_fail(GJX_EINVAL, "gjx_scan_filter: hmc_targets[t] must have the rows of step t, and hmc_workspace must hold gjx_hmc_workspace_bytes of every target");
+  }
+  const bool no_fuse = (fflags & GJX_FILTER_TWO_LAUNCH) != 0 || hmc_t != nullptr;
   bool fused = room && !no_fuse && K % 1024 == 0 && K <= (1 << 20);
   hipStream_t st0 = (hipStream_t)stream;
   // the status word describes THIS call (a stale time-out bit would end a one-launch form at its first step)
@@ -248,6 +265,27 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
                                        anc_t, lse_steps + 4 * (size_t)(t - 1), K, ws_res, need_res, stream);
         if (rc) return rc;
         o.in_ancestors = anc_t;
+        if (hmc_t) {
+          // the resampled particle of step t - 1 — [its ancestor's inputs | its latent choices] — gathered, moved, and handed to the step
+          const gjx_program& tg = hmc_t[t - 1];
+          rc = gjx_gather_rows(in, K, anc_t, K, tg.n_slots, opts->hmc_rows, K, stream);
+          if (rc) return rc;
+          uint32_t k1[2], k2[2];
+          host_threefry2x32(keys[2 * t], keys[2 * t + 1], 0u, 0x6d6f7665u, k1);
+          host_threefry2x32(k1[0], k1[1], 0u, 0u, k2);
+          rc = gjx_hmc(&tg, k2[0], k2[1], K, 0, opts->hmc_eps, opts->hmc_L, 0, 1, opts->hmc_rows, opts->hmc_out, opts->hmc_out + K, opts->hmc_out + 2 * (size_t)K,
+                       opts->hmc_workspace, opts->hmc_workspace_bytes, stream);
+          if (rc) return rc;
+          if (opts->accepted_total) {
+            hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st0, (const float*)(opts->hmc_out + 2 * (size_t)K), K,
+                               (unsigned long long*)opts->accepted_total);
+            GJX_CHECK_LAUNCH("gjx_scan_filter(accepted chains)");
+          }
+          o.in_rows = opts->hmc_rows + (size_t)input_rows(steps[t - 1]) * (size_t)K;
+          o.in_ancestors = nullptr;
+          o.flags |= GJX_RUN_STORE_INPUTS;
+          finfo.launches += 3;
+        }
       }
     }
     if (!ran) {

@@ -116,6 +116,20 @@ def target_program(step_prog: PackedProgram, selected=(), rng_mode=None) -> Pack
     return p
 
 
+def hmc_selection(step_prog: PackedProgram, req) -> list:
+    """the latent choices of a step that an HMC request's selection names (float leaves only, as hmc.py:49-65)"""
+    sel = [s.addr for s in step_prog.site_list.sites if step_prog.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_SAMPLE
+           and req.selection.check(_bare(s.addr)) and s.kind not in A.NO_GRADIENT_KINDS]
+    if not sel:
+        raise ValueError("filter moves: the HMC selection names no continuous latent of the step")
+    return sel
+
+
+def hmc_targets(progs, req) -> list:
+    """gjx_filter_opts::hmc_targets of a run: the assess forms of steps 0 .. T-2 with the request's selection flagged"""
+    return [target_program(p, hmc_selection(p, req)) for p in progs[:-1]]
+
+
 def proposal_programs(rej, dim: int, rng_mode: int):
     """(forward, backward) programs of a Rejuvenate proposal on a value of event size ``dim``: sites "cur" (the current value, given)
     and "new" (drawn from / scored under proposal(*argument_mapping(cur)))"""
@@ -232,10 +246,7 @@ def run_with_moves(bf, key: Key, constraint: ChoiceMap, args, moves, device=None
                 km = move_key(k_prop, m)
                 if spec[0] == "hmc":
                     req = spec[1]
-                    sel = [s.addr for s in pp.site_list.sites if pp.modes.get(s.addr, A.MODE_SAMPLE) == A.MODE_SAMPLE
-                           and req.selection.check(_bare(s.addr)) and s.kind not in A.NO_GRADIENT_KINDS]
-                    if not sel:
-                        raise ValueError("filter moves: the HMC selection names no continuous latent of the step")
+                    sel = hmc_selection(pp, req)
                     tk = ("target", t - 1, tuple(sel))
                     if tk not in cache:
                         cache[tk] = _bind(target_program(pp, sel), dev)

@@ -222,11 +222,18 @@ class ScanBootstrapFilter:
         ``out["history"]`` (a ScanHistory) reconstructs trajectories from them."""
         from .. import kernels
         dev = kernels._dev(device)
+        hmc_move = None
         if self.moves:
             if keep_history:
-                raise NotImplementedError("filter moves: keep_history is kept by the one-launch forms (gjx_scan_filter_history)")
-            from .filter_moves import run_with_moves
-            return run_with_moves(self, key, constraint, args, self.moves, device=dev, keep_ancestors=keep_ancestors)
+                raise NotImplementedError("filter moves: keep_history is kept by the forms without moves= (gjx_scan_filter_history)")
+            from .filter_moves import normalise_moves, run_with_moves
+            specs = normalise_moves(self.moves)
+            # ONE HMC move: inside the library's own step loop (gjx_filter_opts::hmc_targets: gather, gjx_hmc, propagate per step, no
+            # host between the launches); anything else — proposals, several moves — step by step from here
+            if len(specs) == 1 and specs[0][0] == "hmc" and not getattr(self, "_moves_step_by_step", False):
+                hmc_move = specs[0][1]
+            else:
+                return run_with_moves(self, key, constraint, args, self.moves, device=dev, keep_ancestors=keep_ancestors)
         # two keys: the STRUCTURE of the run (addresses, shapes, dtypes: what decides the site lists, hence the kernels) and its DATA
         # (every byte of the observations and of the kernel's arguments — both are folded into the step programs' tables; repr()
         # elides the middle of long arrays and must not be used here).  New data under an old structure re-fills the tables of the
@@ -240,9 +247,10 @@ class ScanBootstrapFilter:
                                               for a, b_ in zip(fresh, old)):
                 for a, b_ in zip(fresh, old):
                     b_.tab[:] = a.tab
-                    b_.site_list, b_.modes = a.site_list, a.modes
+                    b_.site_list, b_.modes, b_.filter_obs = a.site_list, a.modes, a.filter_obs
                 _upload_tables(old, c["tabs_dev"])
                 c["dk"] = dk
+                c.pop("hmc", None)            # (the move's targets hold the observations too: rebuilt)
             else:
                 c = self._cache = {}
         if c.get("sk") != sk or c.get("dk") != dk:
@@ -259,6 +267,20 @@ class ScanBootstrapFilter:
         T, K = len(progs), self.K
         n_rows = max(max(p.n_slots for p in progs), 1)
         f32 = torch.float32
+        self._hmc_state = None
+        if hmc_move is not None and T >= 2:
+            hs = self._cache.get("hmc")
+            if hs is None or hs["move"] is not hmc_move:
+                from .filter_moves import hmc_targets
+                tg = hmc_targets(progs, hmc_move)
+                tdev = _bind_device(tg, dev)
+                tcps = (A.GjxProgram * len(tg))()
+                for t, p in enumerate(tg):
+                    tcps[t] = p.c_program(tdev[0].device)
+                wsb = max(int(load().gjx_hmc_workspace_bytes(C.byref(tcps[t]), K)) for t in range(len(tg)))
+                hs = self._cache["hmc"] = dict(move=hmc_move, progs=tg, cps=tcps, tabs_dev=tdev, rows=torch.empty((n_rows, K), dtype=f32, device=dev),
+                                               out=torch.empty((3, K), dtype=f32, device=dev), ws=torch.zeros(max(wsb, 256), dtype=torch.uint8, device=dev))
+            self._hmc_state = hs
         b = self._cache.get("bufs")
         if b is None or b["rows_a"].shape != (n_rows, K):
             # two run workspaces and a second log-weight buffer: the one-launch step (resampling in the generated kernel's
@@ -309,7 +331,8 @@ class ScanBootstrapFilter:
         ch = (b["rows_b"] if (T - 1) & 1 else b["rows_a"])[: max(last.n_slots, 1)]
         return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=self._out(ch), logw=self._out(b["logw"]), programs=progs,
                     ancestors=anc_all if keep_ancestors else self._out(b["anc"]), degenerate=bool(st & 2), info=self.last_info,
-                    accepted_total=(int(self._acc.item()) if self.rejuvenate and getattr(self, "_acc", None) is not None else None))
+                    accepted_total=(int(self._acc.item()) if (self.rejuvenate or self._hmc_state) and getattr(self, "_acc", None) is not None else None),
+                    accepted=([int(self._acc.item())] if self._hmc_state else None))
 
     def _repeat_after_timeout(self, key, constraint, args, device, keep_ancestors, keep_history):
         """GJX_STATUS_POLL_TIMEOUT: the one-launch kernel needs its whole grid resident and something else held compute units.  The
@@ -401,13 +424,21 @@ class ScanBootstrapFilter:
             fl |= A.FILTER_ABSOLUTE_INPUTS
         o.flags = fl
         o.coresident_blocks = int(os.environ.get("GJX_CORESIDENT_BLOCKS", "0") or 0)
-        if self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0:
-            o.n_moves, o.move_scale = int(self.rejuvenate["n_moves"]), float(self.rejuvenate.get("scale", 0.5))
+        hs = getattr(self, "_hmc_state", None)
+        if (self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0) or hs is not None:
+            if hs is None:
+                o.n_moves, o.move_scale = int(self.rejuvenate["n_moves"]), float(self.rejuvenate.get("scale", 0.5))
             if dev is None:
                 dev = torch.device("cuda", torch.cuda.current_device())
             if getattr(self, "_acc", None) is None or self._acc.device != dev:       # the counter lives where the filter runs
                 self._acc = torch.zeros(1, dtype=torch.int64, device=dev)
             o.accepted_total = self._acc.data_ptr()
+        if hs is not None:
+            self._acc.zero_()
+            o.hmc_targets = C.cast(hs["cps"], C.c_void_p)
+            o.hmc_eps, o.hmc_L = float(hs["move"].eps), int(hs["move"].L)
+            o.hmc_rows, o.hmc_out = hs["rows"].data_ptr(), hs["out"].data_ptr()
+            o.hmc_workspace, o.hmc_workspace_bytes = hs["ws"].data_ptr(), hs["ws"].numel()
         tl = getattr(self, "timeline", None)
         if tl is not None:
             o.timeline, o.timeline_bytes = tl.data_ptr(), tl.numel() * tl.element_size()

@@ -44,7 +44,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define GJX_ABI_VERSION 9
+#define GJX_ABI_VERSION 10
 
 typedef enum gjx_status {
   GJX_OK = 0,
@@ -805,6 +805,24 @@ typedef struct gjx_filter_opts {
   int32_t n_moves;
   float move_scale;
   void* accepted_total;
+  /* (ABI 10) an HMC move behind every resampling — the reference's HMC edit request used as a rejuvenation move (hmc.py:138-211) with
+   * the caller-side accept of tests/inference/test_requests.py:134-137 fused (gjx_hmc(..., accept = 1)) — in the plain-launch form of
+   * the filter.  hmc_targets[t] (t = 0 .. T-2), or NULL: step t's program in ASSESS form — its GJX_MODE_INPUT sites as they are, its
+   * latent choices GJX_MODE_OBS_SLOT with the moved ones flagged GJX_SITE_SELECTED, its observations in the table, the SAME rows as
+   * step t.  Behind the resampling in front of step t + 1 the particle [its ancestor's own inputs | its latent choices] is gathered
+   * into hmc_rows, moved by ONE gjx_hmc launch over all K particles (L leapfrog steps of size hmc_eps; key
+   * fold_in(fold_in(k_prop of step t + 1, 0x6d6f7665), 0)), and step t + 1 propagates from the moved rows, which it stores as its
+   * inputs.  The target is p(x_t | inputs) p(y_t | x_t), the law of the resampled particle: the filter stays proper.
+   * hmc_rows f32[max n_slots][K], hmc_out f32[3][K] (score, alpha, accepted flags of the last move), hmc_workspace /
+   * hmc_workspace_bytes (>= gjx_hmc_workspace_bytes of every target): device scratch of the caller; accepted_total counts the accepted
+   * chains of the run.  Forces GJX_FILTER_FORM_TWO_LAUNCH; GJX_EUNSUPPORTED with n_moves > 0 or GJX_FILTER_ABSOLUTE_INPUTS. */
+  const gjx_program* hmc_targets;
+  float hmc_eps;
+  int32_t hmc_L;
+  float* hmc_rows;
+  float* hmc_out;
+  void* hmc_workspace;
+  size_t hmc_workspace_bytes;
 } gjx_filter_opts;
 typedef struct gjx_filter_info {
   int32_t form;                  /* GJX_FILTER_FORM_* of the steps from the third on (the form that dominates the run) */
@@ -981,7 +999,7 @@ size_t gjx_hmc_workspace_bytes(const gjx_program* prog, int64_t n);
  * A generated kernel runs both contractions of a rolled site with an affine parameter (n = 16 .. 64 inputs, rows a multiple of
  * 16: the likelihood of a regression) on the matrix cores, and folds 0 / 1 observations of a bernoulli-logits site into its
  * copies of the matrix; profiling variants of the emitter: GJX_HMC_GEN_NO_MFMA=1 (scalar rolled loop), GJX_HMC_GEN_NO_FOLD=1,
- * GJX_HMC_GEN_BT=256|512|1024 (threads per block).  Plate-tagged and GJX_MODE_INPUT sites: GJX_EUNSUPPORTED (gjx_score_grad too). */
+ * GJX_HMC_GEN_BT=256|512|1024 (threads per block).  GJX_MODE_INPUT sites are read as given values (never selected). */
 int gjx_hmc_engine(const gjx_program* prog);
 int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, int64_t chain_offset,
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,

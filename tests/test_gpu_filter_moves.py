@@ -197,6 +197,34 @@ def test_filter_with_hmc_and_proposal_moves_keeps_the_log_ml_and_diversifies_the
     assert abs(float(o["log_ml"]) - exact) < 2e-3 * abs(exact), (float(o["log_ml"]), exact)
 
 
+@pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
+def test_one_hmc_move_runs_inside_the_library_loop_and_equals_the_step_by_step_form(resampler):
+    """moves=[HMC(...)] alone: gjx_scan_filter with gjx_filter_opts::hmc_targets — gather, ONE gjx_hmc launch, propagate per step, issued
+    by the library without the host in between — gives the states, log-weights, ancestors and accept count of the step-by-step form
+    (the same kernels under the same keys), bit for bit"""
+    from genjax_amd.inference import BootstrapFilter, HMC
+    from genjax_amd.inference.filter_moves import run_with_moves
+    dx, T, K = 4, 9, (1 << 13) + 3
+    scan, carry0, s, ys = _lgssm(dx, T)
+    mv = [HMC(S["x"], 0.15, 3)]
+    bf = BootstrapFilter(scan, K, moves=mv, resampler=resampler)
+    a = bf.run(genjax.key(21), C["y"].set(ys), (carry0, None), keep_ancestors=True)
+    assert a["info"]["form"] == A.FILTER_FORM_TWO_LAUNCH and a["accepted"][0] == a["accepted_total"] > 0.5 * K * (T - 1)
+    a = {k: (_np(v).copy() if hasattr(v, "cpu") else v) for k, v in a.items()}
+    b = run_with_moves(bf, genjax.key(21), C["y"].set(ys), (carry0, None), mv, keep_ancestors=True)
+    np.testing.assert_array_equal(a["ancestors"], _np(b["ancestors"]))
+    np.testing.assert_array_equal(a["logw"], _np(b["logw"]))
+    np.testing.assert_array_equal(a["choices"], _np(b["choices"]))
+    assert a["accepted"] == b["accepted"]
+    np.testing.assert_allclose(a["lse_steps"][:, 2:], _np(b["lse_steps"])[:, 2:], rtol=2e-6, atol=2e-6)
+    # a second run with other observations under the same structure: the targets are rebuilt with the tables
+    ys2 = ys + 0.25
+    a2 = bf.run(genjax.key(21), C["y"].set(ys2), (carry0, None))
+    b2 = run_with_moves(bf, genjax.key(21), C["y"].set(ys2), (carry0, None), mv)
+    np.testing.assert_array_equal(_np(a2["logw"]), _np(b2["logw"]))
+    assert float(a2["log_ml"]) != float(a["log_ml"])
+
+
 def test_moves_argument_is_checked():
     from genjax_amd.inference import BootstrapFilter, HMC, Regenerate, Rejuvenate
     scan, carry0, s, ys = _lgssm(2, 3)

@@ -39,7 +39,7 @@ def test_abi7_structs():
     hdr = open(__file__.rsplit("/tests/", 1)[0] + "/include/gjx.h").read()
     assert "#define GJX_ABI_VERSION %d" % A.ABI_VERSION in hdr and A.ABI_VERSION >= 9 and "GJX_P_EXPR = 5" in hdr and "GJX_E_LINN = 24" in hdr and "GJX_MODE_INPUT = 4" in hdr and "GJX_STATUS_VERIFY_MISMATCH = 4" in hdr
     # ABI 8: the generic filter takes its form as arguments and reports the form that ran (no environment, no per-thread state)
-    assert ctypes.sizeof(A.GjxFilterOpts) == 40 and ctypes.sizeof(A.GjxFilterInfo) == 16 and A.GjxFilterOpts.timeline.offset == 8 and A.GjxFilterOpts.n_moves.offset == 24 and A.GjxFilterOpts.accepted_total.offset == 32
+    assert ctypes.sizeof(A.GjxFilterOpts) == 88 and A.GjxFilterOpts.hmc_targets.offset == 40 and A.GjxFilterOpts.hmc_L.offset == 52 and A.GjxFilterOpts.hmc_workspace_bytes.offset == 80 and ctypes.sizeof(A.GjxFilterInfo) == 16 and A.GjxFilterOpts.timeline.offset == 8 and A.GjxFilterOpts.n_moves.offset == 24 and A.GjxFilterOpts.accepted_total.offset == 32
     assert "GJX_FILTER_FORM_WIDE = 3" in hdr and "GJX_FILTER_NO_ONE_LAUNCH = 3" in hdr
 
 
