@@ -17,6 +17,8 @@ NORMAL, FLIP, BERNOULLI_LOGITS, BETA, CATEGORICAL_LOGITS, CATEGORICAL_PROBS = 1,
 UNIFORM, MVNORMAL_DIAG, EXPONENTIAL, HALF_NORMAL, LAPLACE, LOG_NORMAL, CAUCHY, GAMMA = 7, 8, 9, 10, 11, 12, 13, 14
 STUDENT_T, TRUNCATED_NORMAL, POISSON, GEOMETRIC, DIRICHLET, GUMBEL, HALF_CAUCHY, INVERSE_GAMMA = 15, 16, 17, 18, 19, 20, 21, 22
 WEIBULL, LOGIT_NORMAL, CHI2 = 23, 24, 25
+CHI, EXP_GAMMA, EXP_INVERSE_GAMMA, HALF_STUDENT_T, KUMARASWAMY, MOYAL, TRUNCATED_CAUCHY, DOUBLESIDED_MAXWELL, INVERSE_GAUSSIAN = 26, 27, 28, 29, 30, 31, 32, 33, 34
+KIND_MAX = 35
 KIND_NAMES = {
     NORMAL: "normal", FLIP: "flip", BERNOULLI_LOGITS: "bernoulli", BETA: "beta",
     CATEGORICAL_LOGITS: "categorical", CATEGORICAL_PROBS: "categorical(probs)", UNIFORM: "uniform",
@@ -25,6 +27,8 @@ KIND_NAMES = {
     STUDENT_T: "student_t", TRUNCATED_NORMAL: "truncated_normal", POISSON: "poisson", GEOMETRIC: "geometric",
     DIRICHLET: "dirichlet", GUMBEL: "gumbel", HALF_CAUCHY: "half_cauchy", INVERSE_GAMMA: "inverse_gamma",
     WEIBULL: "weibull", LOGIT_NORMAL: "logit_normal", CHI2: "chi2",
+    CHI: "chi", EXP_GAMMA: "exp_gamma", EXP_INVERSE_GAMMA: "exp_inverse_gamma", HALF_STUDENT_T: "half_student_t", KUMARASWAMY: "kumaraswamy",
+    MOYAL: "moyal", TRUNCATED_CAUCHY: "truncated_cauchy", DOUBLESIDED_MAXWELL: "double_sided_maxwell", INVERSE_GAUSSIAN: "inverse_gaussian",
 }
 DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS, POISSON, GEOMETRIC)
 NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move (integers; simplex-constrained)

@@ -212,7 +212,7 @@ bool is_categorical(int k) { return k == GJX_CATEGORICAL_LOGITS || k == GJX_CATE
 bool table_param(const gjx_param& p) { return (p.op == GJX_P_CONST || p.op == GJX_P_GATHER) && p.xf == GJX_XF_NONE; }
 int table_range(const gjx_param& p) { return p.op == GJX_P_CONST ? p.len : p.n * p.len; }
 
-int n_params(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : (is_categorical(kind) ? 1 : 2)); }
+int n_params(int kind) { return is_categorical(kind) ? 1 : gjx::kind_params(kind); }
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -651,7 +651,7 @@ bool supported_sites(const gjx_site* sites, int n_sites, int n_slots, const gjx_
   for (int j = 0; j < n_sites; ++j) {
     const gjx_site& s = sites[j];
     if (s.mode == GJX_MODE_INPUT) { if (s.dim < 1 || s.dim > kMaxExpandDim || s.slot < 0) return false; total += s.dim; continue; }
-    if (s.kind == GJX_DIRICHLET || s.kind < 1 || s.kind > GJX_CHI2) return false;
+    if (s.kind == GJX_DIRICHLET || s.kind < 1 || s.kind >= GJX_KIND_MAX) return false;
     if (is_categorical(s.kind)) {
       if (s.p[0].op != GJX_P_CONST && s.p[0].op != GJX_P_GATHER) return false;
       if (s.ncat < 1 || s.ncat > 64) return false;
@@ -1019,9 +1019,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
   // element at which this (site, instance) starts drawing (gjx.h "Plates": the elements of a vector site of n * dim elements)
   std::string ebase = "0u";
   if (ri.plate && prog->rng_mode == GJX_RNG_FLAT) {
-    const int per = is_categorical(kind) ? 1 : s.dim * (kind == GJX_BETA ? 2 * gjx::kGammaNDraw
-                   : (kind == GJX_GAMMA || kind == GJX_INVERSE_GAMMA || kind == GJX_CHI2) ? gjx::kGammaNDraw
-                   : kind == GJX_STUDENT_T ? gjx::kGammaNDraw + 2 : kind == GJX_POISSON ? 2 * gjx::kPoissonTries + 2 : 1);
+    const int per = is_categorical(kind) ? 1 : s.dim * gjx::kind_draws(kind);
     ebase = "(uint32_t)(i_ * " + std::to_string(per) + ")";
   }
   if (draws && ri.plate) {
@@ -1097,10 +1095,7 @@ void emit_site(Emit& o, Plan& pl, int j) {
   } else {
     const int dim = s.dim;
     const bool expand = dim <= kMaxExpandDim;
-    const int nd = kind == GJX_BETA ? 2 * gjx::kGammaNDraw
-                   : (kind == GJX_GAMMA || kind == GJX_INVERSE_GAMMA || kind == GJX_CHI2) ? gjx::kGammaNDraw
-                   : kind == GJX_STUDENT_T ? gjx::kGammaNDraw + 2
-                   : kind == GJX_POISSON ? 2 * gjx::kPoissonTries + 2 : 1;
+    const int nd = gjx::kind_draws(kind);
     // the scale of a normal that comes straight from the table has its log and reciprocal in the prologue's companions
     const bool norm = is_normal(kind);
     const gjx_param& qb = s.p[1];
@@ -1978,7 +1973,7 @@ bool hmc_plan_form(const gjx_program* p, HmcPlan* out, bool roll) {
       if (ri.plate || (pl.rolled && j >= pl.roll.i0) || (s.flags & GJX_SITE_HMC_SELECTED) || s.slot < 0) return false;
       continue;
     }
-    if (s.kind < 1 || s.kind > GJX_CHI2 || s.kind == GJX_DIRICHLET) return false;
+    if (s.kind < 1 || s.kind >= GJX_KIND_MAX || s.kind == GJX_DIRICHLET) return false;
     if (s.mode != GJX_MODE_OBS_TAB && s.mode != GJX_MODE_OBS_SLOT) return false;
     for (int k = 0; k < 4; ++k) if (ri.mem_slot[k] >= 0) return false;     // (instances of another plate, one instance read from outside: the interpreter)
     if (ri.plate) {

@@ -564,16 +564,74 @@ GJX_DEV float normal_interval_mass(float lo, float hi) {
   return normal_cdf(hi) - normal_cdf(lo);
 }
 
-GJX_DEV int params_of(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : 2); }
+// parameters a (non-categorical) kind reads, and stream elements one scalar of it may draw (host and device: the emitters use them too)
+constexpr int kGammaMaxIt = 32;
+constexpr int kGammaNDraw = 4 * kGammaMaxIt + 2;  // draw schedule: see GAMMA_NDRAW in the oracle
+constexpr int kPoissonTries = 16;
+constexpr int kind_params(int kind) {
+  return (kind == GJX_TRUNCATED_NORMAL || kind == GJX_TRUNCATED_CAUCHY) ? 4 : ((kind == GJX_STUDENT_T || kind == GJX_HALF_STUDENT_T) ? 3 : 2);
+}
+constexpr int kind_draws(int kind) {
+  return kind == GJX_BETA ? 2 * kGammaNDraw
+         : (kind == GJX_GAMMA || kind == GJX_DIRICHLET || kind == GJX_INVERSE_GAMMA || kind == GJX_CHI2 || kind == GJX_CHI || kind == GJX_EXP_GAMMA ||
+            kind == GJX_EXP_INVERSE_GAMMA) ? kGammaNDraw
+         : (kind == GJX_STUDENT_T || kind == GJX_HALF_STUDENT_T || kind == GJX_DOUBLESIDED_MAXWELL) ? kGammaNDraw + 2
+         : kind == GJX_POISSON ? 2 * kPoissonTries + 2
+         : kind == GJX_INVERSE_GAUSSIAN ? 4 : 1;
+}
+GJX_DEV int params_of(int kind) { return kind_params(kind); }
 
 GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, float d = 0.0f) {
   switch (kind) {
+    case GJX_HALF_STUDENT_T:   // a = df, b = loc, c = scale: the student-t folded at its location
+      if (x < b) return -INFINITY;
+      [[fallthrough]];
     case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
       const float y = (x - b) * fast_rcp(c);
       // log1p(y^2 / df): a draw with df << 1 reaches 1e30 and y^2 leaves float32 — there log(y^2 / df) stands for it (the 1 is below 1e-30 of it)
       const float q = y * y * fast_rcp(a);
       const float l1p = q < 1e30f ? log1p_acc(q) : 2.0f * fast_log(fabsf(y)) - fast_log(a);
-      return -0.5f * (a + 1.0f) * l1p - fast_log(c) - 0.5f * fast_log(a) - 0.5f * kLogPi + lgamma_half_step(0.5f * a);
+      return -0.5f * (a + 1.0f) * l1p - fast_log(c) - 0.5f * fast_log(a) - 0.5f * kLogPi + lgamma_half_step(0.5f * a) + (kind == GJX_HALF_STUDENT_T ? kLn2 : 0.0f);
+    }
+    case GJX_TRUNCATED_CAUCHY: {  // a = loc, b = scale, c = low, d = high: 1 / (b (1 + z^2) (atan z_high - atan z_low))
+      if (x < c || x > d) return -INFINITY;
+      const float rs = fast_rcp(b);
+      const float z = (x - a) * rs;
+      return -fast_log(b) - log1p_acc(z * z) - fast_log(atanf((d - a) * rs) - atanf((c - a) * rs));
+    }
+    case GJX_CHI: {  // a = df: sqrt of a chi2(df) variate
+      if (x <= 0.0f) return -INFINITY;
+      const float h = 0.5f * a;
+      if (h >= 8.0f) return gamma_kernel_big(h, 0.5f * fmaf(x, x, -a)) + kLn2 - fast_log(x);      // chi2's density at x^2, times 2 x
+      return (1.0f - h) * kLn2 + ((a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * fast_log(x)) - 0.5f * x * x - lgammaf(h);
+    }
+    case GJX_EXP_GAMMA: {  // a = concentration, b = rate: y = log of a gamma variate; with z = b e^y: a log z - z - lgamma(a)
+      const float z = b * fast_exp(x);
+      if (a >= 8.0f) return gamma_kernel_big(a, z - a);
+      return a * (fast_log(b) + x) - z - lgammaf(a);
+    }
+    case GJX_EXP_INVERSE_GAMMA: {  // a = concentration, b = scale: y = log of an inverse-gamma variate; z = b e^-y
+      const float z = b * fast_exp(-x);
+      if (a >= 8.0f) return gamma_kernel_big(a, z - a);
+      return a * (fast_log(b) - x) - z - lgammaf(a);
+    }
+    case GJX_KUMARASWAMY: {  // a = concentration1, b = concentration0
+      if (!(x > 0.0f && x < 1.0f)) return -INFINITY;
+      const float lx = fast_log(x);
+      return fast_log(a * b) + ((a - 1.0f) == 0.0f ? 0.0f : (a - 1.0f) * lx) + ((b - 1.0f) == 0.0f ? 0.0f : (b - 1.0f) * log1p_acc(-fast_exp(a * lx)));
+    }
+    case GJX_MOYAL: {  // a = loc, b = scale
+      const float z = (x - a) * fast_rcp(b);
+      return -0.5f * (z + fast_exp(-z)) - fast_log(b) - 0.918938533f /* log sqrt(2 pi) */;
+    }
+    case GJX_DOUBLESIDED_MAXWELL: {  // a = loc, b = scale: z^2 exp(-z^2 / 2) / (b sqrt(2 pi))
+      const float z = (x - a) * fast_rcp(b);
+      return 2.0f * fast_log(fabsf(z)) - 0.5f * z * z - fast_log(b) - 0.918938533f;
+    }
+    case GJX_INVERSE_GAUSSIAN: {  // a = loc (mean), b = concentration
+      if (x <= 0.0f) return -INFINITY;
+      const float r = (x - a) * fast_rcp(a);
+      return 0.5f * (fast_log(b) - 1.83787707f /* log 2 pi */ - 3.0f * fast_log(x)) - 0.5f * b * r * r * fast_rcp(x);
     }
     case GJX_TRUNCATED_NORMAL: {  // a = loc, b = scale, c = low, d = high
       if (x < c || x > d) return -INFINITY;
@@ -660,23 +718,7 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
 }
 
 // ---- samplers ----------------------------------------------------------------------------------
-constexpr int kGammaMaxIt = 32;
-constexpr int kGammaNDraw = 4 * kGammaMaxIt + 2;  // draw schedule: see GAMMA_NDRAW in the oracle
-
-constexpr int kPoissonTries = 16;
-
-GJX_DEV int draws_per_elem(int kind) {
-  switch (kind) {
-    case GJX_BETA: return 2 * kGammaNDraw;
-    case GJX_GAMMA:
-    case GJX_DIRICHLET:
-    case GJX_INVERSE_GAMMA:
-    case GJX_CHI2: return kGammaNDraw;
-    case GJX_STUDENT_T: return kGammaNDraw + 2;
-    case GJX_POISSON: return 2 * kPoissonTries + 2;
-    default: return 1;
-  }
-}
+GJX_DEV int draws_per_elem(int kind) { return kind_draws(kind); }
 
 // Marsaglia & Tsang (2000), log space, fixed draw budget (same element schedule as the oracle)
 template <int RNG, class BS>
@@ -738,10 +780,41 @@ GJX_DEV float poisson_variate(BS& bs, uint32_t c, float lam) {
 template <int RNG, class BS>
 GJX_DEV float elem_sample(int kind, BS& bs, uint32_t c, float a, float b, float p3 = 0.0f, float p4 = 0.0f) {
   switch (kind) {
+    case GJX_HALF_STUDENT_T:
     case GJX_STUDENT_T: {  // a = df, b = loc, p3 = scale: z * sqrt(df / chi2_df), chi2_df = 2 * Gamma(df/2)
       const float z = stream_normal<RNG>(bs, c);
       const float lg = log_gamma_variate<RNG>(bs, c + 2, 0.5f * a);
-      return fmaf(p3 * z, fast_exp(0.5f * (fast_log(0.5f * a) - lg)), b);
+      const float t = p3 * z * fast_exp(0.5f * (fast_log(0.5f * a) - lg));
+      return b + (kind == GJX_HALF_STUDENT_T ? fabsf(t) : t);
+    }
+    case GJX_TRUNCATED_CAUCHY: {  // inverse CDF on the arctangent scale
+      const float rs = fast_rcp(b);
+      const float lo = atanf((p3 - a) * rs), hi = atanf((p4 - a) * rs);
+      return fminf(fmaxf(fmaf(b, tanf(fmaf(bits_to_unit(bs.get(c)), hi - lo, lo)), a), p3), p4);
+    }
+    case GJX_CHI: return fast_exp(0.5f * (kLn2 + log_gamma_variate<RNG>(bs, c, 0.5f * a)));
+    case GJX_EXP_GAMMA: return log_gamma_variate<RNG>(bs, c, a) - fast_log(b);
+    case GJX_EXP_INVERSE_GAMMA: return fast_log(b) - log_gamma_variate<RNG>(bs, c, a);
+    case GJX_KUMARASWAMY: {  // x = (1 - (1 - u)^(1 / b))^(1 / a)
+      const float t = log1p_acc(-bits_to_unit(bs.get(c))) * fast_rcp(b);
+      return fast_exp(safe_log(-expm1f(t)) * fast_rcp(a));
+    }
+    case GJX_MOYAL: {  // -log of a chi2(1) variate: loc - scale log(n^2)
+      const float n = stream_normal<RNG>(bs, c);
+      return fmaf(-2.0f * b, safe_log(fabsf(n)), a);
+    }
+    case GJX_DOUBLESIDED_MAXWELL: {  // a random sign times the root of a chi2(3) variate
+      const float sgn = bits_to_unit(bs.get(c)) < 0.5f ? -1.0f : 1.0f;
+      const float r = fast_exp(0.5f * (kLn2 + log_gamma_variate<RNG>(bs, c + 2, 1.5f)));
+      return fmaf(b * sgn, r, a);
+    }
+    case GJX_INVERSE_GAUSSIAN: {  // Michael, Schucany & Haas (1976): a = mean, b = concentration
+      const float n = stream_normal<RNG>(bs, c);
+      const float y = n * n;
+      const float m2 = a * fast_rcp(2.0f * b);                                   // mu / (2 lambda)
+      const float x1 = a + m2 * (a * y - sqrtf(fmaf(a * y, a * y, 4.0f * a * b * y)));
+      const float u = bits_to_unit(bs.get(c + 2));
+      return u * (a + x1) <= a ? x1 : a * a * fast_rcp(x1);
     }
     case GJX_TRUNCATED_NORMAL: {  // inverse CDF inside [low, high], in the tail that keeps precision
       const float rs = fast_rcp(b);
@@ -994,6 +1067,57 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
   dx = 0.0f;
   auto done = [&]() { gpar[0] = da; gpar[1] = db; gpar[2] = dc; gpar[3] = dd; };
   switch (kind) {
+    case GJX_TRUNCATED_CAUCHY: {  // a = loc, b = scale, c = low, d = high
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb, lo = (c - a) * rb, hi = (d - a) * rb;
+      const float rA = fast_rcp(atanf(hi) - atanf(lo)) * rb;
+      const float wl = fast_rcp(fmaf(lo, lo, 1.0f)) * rA, wh = fast_rcp(fmaf(hi, hi, 1.0f)) * rA;
+      const float w = 2.0f * z * fast_rcp(fmaf(z, z, 1.0f)) * rb;
+      dx = -w; da = w + (wh - wl); db = fmaf(w, z, -rb) + (hi * wh - lo * wl); dc = wl; dd = -wh;
+      done(); return;
+    }
+    case GJX_CHI: dx = (a - 1.0f) * fast_rcp(x) - x; da = fast_log(x) - 0.5f * kLn2 - 0.5f * digamma_f(0.5f * a); done(); return;
+    case GJX_EXP_GAMMA: {
+      const float e = fast_exp(x);
+      dx = fmaf(-b, e, a); da = fast_log(b) + x - digamma_f(a); db = a * fast_rcp(b) - e;
+      done(); return;
+    }
+    case GJX_EXP_INVERSE_GAMMA: {
+      const float e = fast_exp(-x);
+      dx = fmaf(b, e, -a); da = fast_log(b) - x - digamma_f(a); db = a * fast_rcp(b) - e;
+      done(); return;
+    }
+    case GJX_KUMARASWAMY: {
+      const float lx = fast_log(x), xa = fast_exp(a * lx);
+      const float r = xa * fast_rcp(1.0f - xa);                                  // x^a / (1 - x^a)
+      dx = ((a - 1.0f) - (b - 1.0f) * a * r) * fast_rcp(x);
+      da = fast_rcp(a) + lx * (1.0f - (b - 1.0f) * r);
+      db = fast_rcp(b) + log1p_acc(-xa);
+      done(); return;
+    }
+    case GJX_MOYAL: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float e1 = 0.5f * (1.0f - fast_exp(-z));
+      dx = -e1 * rb; da = e1 * rb; db = (e1 * z - 1.0f) * rb;
+      done(); return;
+    }
+    case GJX_DOUBLESIDED_MAXWELL: {
+      const float rb = fast_rcp(b);
+      const float z = (x - a) * rb;
+      const float w = (2.0f * fast_rcp(z) - z) * rb;
+      dx = w; da = -w; db = (z * z - 3.0f) * rb;
+      done(); return;
+    }
+    case GJX_INVERSE_GAUSSIAN: {
+      const float ra = fast_rcp(a), rx = fast_rcp(x);
+      const float r = (x - a) * ra;
+      dx = -1.5f * rx - 0.5f * b * (x * x - a * a) * ra * ra * rx * rx;
+      da = b * r * ra * ra;
+      db = 0.5f * fast_rcp(b) - 0.5f * r * r * rx;
+      done(); return;
+    }
+    case GJX_HALF_STUDENT_T:
     case GJX_STUDENT_T: {  // a = df, b = loc, c = scale
       const float rc = fast_rcp(c);
       const float y = (x - b) * rc;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
       // the element loop is instantiated per distribution kind so that the sampler / density switches fold away
       auto elems = [&](auto kind_c) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
-        constexpr int NP = KIND == GJX_TRUNCATED_NORMAL ? 4 : (KIND == GJX_STUDENT_T ? 3 : 2);
+        constexpr int NP = kind_params(KIND);
         const int nd = draws_per_elem(KIND);
         const int dim = s.dim;
         const bool b_inv = s.p[1].op == GJX_P_CONST && s.p[1].len == 1 && s.p[1].xf == GJX_XF_NONE && s.p[1].d_off == 0;  // wave-uniform
@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         GJX_KIND(GJX_UNIFORM) GJX_KIND(GJX_EXPONENTIAL) GJX_KIND(GJX_HALF_NORMAL) GJX_KIND(GJX_LAPLACE) GJX_KIND(GJX_LOG_NORMAL)
         GJX_KIND(GJX_CAUCHY) GJX_KIND(GJX_GAMMA) GJX_KIND(GJX_STUDENT_T) GJX_KIND(GJX_TRUNCATED_NORMAL) GJX_KIND(GJX_POISSON)
         GJX_KIND(GJX_GEOMETRIC) GJX_KIND(GJX_GUMBEL) GJX_KIND(GJX_HALF_CAUCHY) GJX_KIND(GJX_INVERSE_GAMMA) GJX_KIND(GJX_WEIBULL)
-        GJX_KIND(GJX_LOGIT_NORMAL) GJX_KIND(GJX_CHI2)
+        GJX_KIND(GJX_LOGIT_NORMAL) GJX_KIND(GJX_CHI2) GJX_KIND(GJX_CHI) GJX_KIND(GJX_EXP_GAMMA) GJX_KIND(GJX_EXP_INVERSE_GAMMA)
+        GJX_KIND(GJX_HALF_STUDENT_T) GJX_KIND(GJX_KUMARASWAMY) GJX_KIND(GJX_MOYAL) GJX_KIND(GJX_TRUNCATED_CAUCHY)
+        GJX_KIND(GJX_DOUBLESIDED_MAXWELL) GJX_KIND(GJX_INVERSE_GAUSSIAN)
         default: lp = __builtin_nanf(""); break;
       }
 #undef GJX_KIND

@@ -1547,3 +1547,13 @@ inverse_gamma = _VectorDist("inverse_gamma", A.INVERSE_GAMMA, ("concentration", 
 weibull = _VectorDist("weibull", A.WEIBULL, ("concentration", "scale"))
 logit_normal = _VectorDist("logit_normal", A.LOGIT_NORMAL, ("loc", "scale"))
 chi2 = _VectorDist("chi2", A.CHI2, ("df",))
+# (round 6: nine more of the reference's TFP wrappers, tensorflow_probability/__init__.py:115-284)
+chi = _VectorDist("chi", A.CHI, ("df",))
+exp_gamma = _VectorDist("exp_gamma", A.EXP_GAMMA, ("concentration", "rate"))
+exp_inverse_gamma = _VectorDist("exp_inverse_gamma", A.EXP_INVERSE_GAMMA, ("concentration", "scale"))
+half_student_t = _VectorDist("half_student_t", A.HALF_STUDENT_T, ("df", "loc", "scale"))
+kumaraswamy = _VectorDist("kumaraswamy", A.KUMARASWAMY, ("concentration1", "concentration0"))
+moyal = _VectorDist("moyal", A.MOYAL, ("loc", "scale"))
+truncated_cauchy = _VectorDist("truncated_cauchy", A.TRUNCATED_CAUCHY, ("loc", "scale", "low", "high"))
+double_sided_maxwell = _VectorDist("double_sided_maxwell", A.DOUBLESIDED_MAXWELL, ("loc", "scale"))
+inverse_gaussian = _VectorDist("inverse_gaussian", A.INVERSE_GAUSSIAN, ("loc", "concentration"))

@@ -893,6 +893,8 @@ def ssm_filter_sharded(ssm: A.GjxSsm, key, rng_mode, ys: torch.Tensor, ctx: "Sha
 def hmc(prog: PackedProgram, key, choices: torch.Tensor, eps: float, L: int, stale=False, accept=False, offset=0,
         ws=None):
     """gjx_hmc: in-place HMC move of every chain column.  Returns dict(choices, score, alpha, accepted)."""
+    if not choices.is_contiguous():
+        raise ValueError("hmc: choices must be a contiguous f32[n_slots][n] tensor (it is moved in place)")
     n = choices.shape[1]
     dev = choices.device
     cp = prog.c_program(dev)

@@ -89,7 +89,16 @@ enum {
   GJX_WEIBULL = 23,           /* weibull(concentration, scale) :309                         */
   GJX_LOGIT_NORMAL = 24,      /* logit_normal(loc, scale)      :224                         */
   GJX_CHI2 = 25,              /* chi2(df)                      :120                         */
-  GJX_KIND_MAX = 26
+  GJX_CHI = 26,               /* chi(df)                       :115                         */
+  GJX_EXP_GAMMA = 27,         /* exp_gamma(concentration, rate): log of a gamma variate :140  */
+  GJX_EXP_INVERSE_GAMMA = 28, /* exp_inverse_gamma(concentration, scale): log of an inverse-gamma variate :145 */
+  GJX_HALF_STUDENT_T = 29,    /* half_student_t(df, loc, scale) :189                        */
+  GJX_KUMARASWAMY = 30,       /* kumaraswamy(concentration1, concentration0) :204           */
+  GJX_MOYAL = 31,             /* moyal(loc, scale)             :229                         */
+  GJX_TRUNCATED_CAUCHY = 32,  /* truncated_cauchy(loc, scale, low, high) :284               */
+  GJX_DOUBLESIDED_MAXWELL = 33, /* double_sided_maxwell(loc, scale) :135                    */
+  GJX_INVERSE_GAUSSIAN = 34,  /* inverse_gaussian(loc, concentration) :199                  */
+  GJX_KIND_MAX = 35
 };
 
 /* parameter expression forms (what the model body computes between sites) */

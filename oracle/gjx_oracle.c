@@ -415,7 +415,9 @@ static float normal_interval_mass(float lo, float hi) {
   if (lo > 0.0f) return std_normal_cdf(-lo) - std_normal_cdf(-hi);
   return std_normal_cdf(hi) - std_normal_cdf(lo);
 }
-static int params_of(int kind) { return kind == GJX_TRUNCATED_NORMAL ? 4 : (kind == GJX_STUDENT_T ? 3 : 2); }
+static int params_of(int kind) {
+  return (kind == GJX_TRUNCATED_NORMAL || kind == GJX_TRUNCATED_CAUCHY) ? 4 : ((kind == GJX_STUDENT_T || kind == GJX_HALF_STUDENT_T) ? 3 : 2);
+}
 
 /* parameter order follows the reference's constructor arguments (tfp wrappers, tensorflow_probability/__init__.py) */
 /* The closed-form log-densities are evaluated in DOUBLE from the float32 inputs and rounded once: the oracle is the
@@ -430,13 +432,45 @@ static inline double softplus_d(double x) { return (x > 0.0 ? x : 0.0) + log1p(e
 static float elem_logpdf4(int kind, float xf, float af, float bf, float cf, float df) {
   const double x = xf, a = af, b = bf, c = cf, d = df;
   switch (kind) {
+    case GJX_TRUNCATED_CAUCHY: { /* tfd.TruncatedCauchy(loc=a, scale=b, low=c, high=d) */
+      if (x < c || x > d) return -INFINITY;
+      double z = (x - a) / b;
+      return (float)(-log(b) - log1p(z * z) - log(atan((d - a) / b) - atan((c - a) / b)));
+    }
+    case GJX_CHI: { /* tfd.Chi(df=a): the root of a chi2(a) variate */
+      double h = 0.5 * a;
+      return x <= 0.0 ? -INFINITY : (float)((1.0 - h) * log(2.0) + xlogy_d(a - 1.0, x) - 0.5 * x * x - lgamma(h));
+    }
+    case GJX_EXP_GAMMA: /* tfd.ExpGamma(concentration=a, rate=b): log of a gamma variate */
+      return (float)(a * (log(b) + x) - b * exp(x) - lgamma(a));
+    case GJX_EXP_INVERSE_GAMMA: /* tfd.ExpInverseGamma(concentration=a, scale=b): log of an inverse-gamma variate */
+      return (float)(a * (log(b) - x) - b * exp(-x) - lgamma(a));
+    case GJX_KUMARASWAMY: /* tfd.Kumaraswamy(concentration1=a, concentration0=b) */
+      if (!(x > 0.0 && x < 1.0)) return -INFINITY;
+      return (float)(log(a) + log(b) + xlogy_d(a - 1.0, x) + xlog1py_d(b - 1.0, -pow(x, a)));
+    case GJX_MOYAL: { /* tfd.Moyal(loc=a, scale=b) */
+      double z = (x - a) / b;
+      return (float)(-0.5 * (z + exp(-z)) - log(b) - (double)HALF_LOG_2PI);
+    }
+    case GJX_DOUBLESIDED_MAXWELL: { /* tfd.DoublesidedMaxwell(loc=a, scale=b): z^2 exp(-z^2 / 2) / (b sqrt(2 pi)) */
+      double z = (x - a) / b;
+      return (float)(2.0 * log(fabs(z)) - 0.5 * z * z - log(b) - (double)HALF_LOG_2PI);
+    }
+    case GJX_INVERSE_GAUSSIAN: { /* tfd.InverseGaussian(loc=a, concentration=b) */
+      if (x <= 0.0) return -INFINITY;
+      double r = (x - a) / a;
+      return (float)(0.5 * (log(b) - 2.0 * (double)HALF_LOG_2PI - 3.0 * log(x)) - 0.5 * b * r * r / x);
+    }
+    case GJX_HALF_STUDENT_T: /* tfd.HalfStudentT(df=a, loc=b, scale=c): the student-t folded at its location */
+      if (x < b) return -INFINITY;
+      /* fall through */
     case GJX_STUDENT_T: { /* tfd.StudentT(df=a, loc=b, scale=c) */
       double y = (x - b) / c, h = 0.5 * a, lgd;
       /* lgamma(h + 1/2) - lgamma(h) on its own (added to the small terms one lgamma at a time, a df of 1e20 absorbs them: the result
        * was exactly 0), and from the asymptotic series where the two values agree to within their own rounding */
       if (h < 1e6) lgd = lgamma(h + 0.5) - lgamma(h);
       else { double r = 1.0 / h; lgd = 0.5 * log(h) - r * (0.125 - r * r / 192.0); }
-      return (float)(-0.5 * (a + 1.0) * log1p(y * y / a) - log(c) - 0.5 * log(a) - 0.5 * (double)LOG_PI + lgd);
+      return (float)(-0.5 * (a + 1.0) * log1p(y * y / a) - log(c) - 0.5 * log(a) - 0.5 * (double)LOG_PI + lgd + (kind == GJX_HALF_STUDENT_T ? log(2.0) : 0.0));
     }
     case GJX_TRUNCATED_NORMAL: { /* tfd.TruncatedNormal(loc=a, scale=b, low=c, high=d) */
       if (x < c || x > d) return -INFINITY;
@@ -522,9 +556,15 @@ static int draws_per_elem(int kind) {
     case GJX_GAMMA:
     case GJX_DIRICHLET:
     case GJX_INVERSE_GAMMA:
-    case GJX_CHI2: return GAMMA_NDRAW;
-    case GJX_STUDENT_T: return GAMMA_NDRAW + 2;
+    case GJX_CHI2:
+    case GJX_CHI:
+    case GJX_EXP_GAMMA:
+    case GJX_EXP_INVERSE_GAMMA: return GAMMA_NDRAW;
+    case GJX_STUDENT_T:
+    case GJX_HALF_STUDENT_T:
+    case GJX_DOUBLESIDED_MAXWELL: return GAMMA_NDRAW + 2;
     case GJX_POISSON: return 2 * POISSON_TRIES + 2;
+    case GJX_INVERSE_GAUSSIAN: return 4;
     default: return 1;
   }
 }
@@ -566,10 +606,44 @@ static float poisson_variate(const ostream* sk, uint32_t c, float lam) {
 
 static float elem_sample4(int kind, const ostream* sk, uint32_t c, float a, float b, float p3, float p4) {
   switch (kind) {
+    case GJX_HALF_STUDENT_T:
     case GJX_STUDENT_T: { /* z * sqrt(df / chi2_df), chi2_df = 2 Gamma(df/2, 1) */
       float z = stream_normal(sk, c);
       float lg = log_gamma_variate(sk, c + 2, 0.5f * a);
-      return b + p3 * z * expf(0.5f * (logf(0.5f * a) - lg));
+      float t = p3 * z * expf(0.5f * (logf(0.5f * a) - lg));
+      return b + (kind == GJX_HALF_STUDENT_T ? fabsf(t) : t);
+    }
+    case GJX_TRUNCATED_CAUCHY: { /* inverse CDF on the arctangent scale */
+      float lo = atanf((p3 - a) / b), hi = atanf((p4 - a) / b);
+      float x = a + b * tanf(lo + bits_to_unit(elem_bits(sk, c)) * (hi - lo));
+      return x < p3 ? p3 : (x > p4 ? p4 : x);
+    }
+    case GJX_CHI: return expf(0.5f * (0.69314718f + log_gamma_variate(sk, c, 0.5f * a)));
+    case GJX_EXP_GAMMA: return log_gamma_variate(sk, c, a) - logf(b);
+    case GJX_EXP_INVERSE_GAMMA: return logf(b) - log_gamma_variate(sk, c, a);
+    case GJX_KUMARASWAMY: { /* x = (1 - (1 - u)^(1 / b))^(1 / a) */
+      float t = log1pf(-bits_to_unit(elem_bits(sk, c))) / b;
+      float m = -expm1f(t);
+      return expf(logf(m) / a);
+    }
+    case GJX_MOYAL: { /* -log of a chi2(1) variate: loc - scale log(n^2) */
+      float n = fabsf(stream_normal(sk, c));
+      return a - 2.0f * b * logf(n);
+    }
+    case GJX_DOUBLESIDED_MAXWELL: { /* a random sign times the root of a chi2(3) variate */
+      const float u = bits_to_unit(elem_bits(sk, c));
+      decide(u, 0.5f);
+      float sgn = u < 0.5f ? -1.0f : 1.0f;
+      float r = expf(0.5f * (0.69314718f + log_gamma_variate(sk, c + 2, 1.5f)));
+      return a + b * sgn * r;
+    }
+    case GJX_INVERSE_GAUSSIAN: { /* Michael, Schucany & Haas (1976): a = mean, b = concentration */
+      float n = stream_normal(sk, c);
+      float y = n * n;
+      float x1 = a + (a / (2.0f * b)) * (a * y - sqrtf(a * y * a * y + 4.0f * a * b * y));
+      float u = bits_to_unit(elem_bits(sk, c + 2));
+      decide(u * (a + x1), a);
+      return u * (a + x1) <= a ? x1 : a * a / x1;
     }
     case GJX_TRUNCATED_NORMAL: {
       float lo = (p3 - a) / b, hi = (p4 - a) / b;
@@ -1400,6 +1474,29 @@ static void dlogpdf4(int kind, float x, float a, float b, float c, float d, floa
   g[0] = g[1] = g[2] = g[3] = 0.0f;
   *dx = 0.0f;
   switch (kind) {
+    case GJX_TRUNCATED_CAUCHY: {
+      double z = ((double)x - a) / b, lo = ((double)c - a) / b, hi = ((double)d - a) / b;
+      double rA = 1.0 / ((atan(hi) - atan(lo)) * b), wl = rA / (1.0 + lo * lo), wh = rA / (1.0 + hi * hi), w = 2.0 * z / ((1.0 + z * z) * b);
+      *dx = (float)-w; g[0] = (float)(w + (wh - wl)); g[1] = (float)(w * z - 1.0 / b + (hi * wh - lo * wl)); g[2] = (float)wl; g[3] = (float)-wh;
+      return;
+    }
+    case GJX_CHI: *dx = (a - 1.0f) / x - x; g[0] = (float)(log((double)x) - 0.5 * 0.6931471805599453 - 0.5 * digamma_d(0.5 * a)); return;
+    case GJX_EXP_GAMMA: { double e = exp((double)x); *dx = (float)(a - b * e); g[0] = (float)(log((double)b) + x - digamma_d(a)); g[1] = (float)(a / b - e); return; }
+    case GJX_EXP_INVERSE_GAMMA: { double e = exp(-(double)x); *dx = (float)(b * e - a); g[0] = (float)(log((double)b) - x - digamma_d(a)); g[1] = (float)(a / b - e); return; }
+    case GJX_KUMARASWAMY: {
+      double lx = log((double)x), xa = exp(a * lx), r = xa / (1.0 - xa);
+      *dx = (float)(((a - 1.0) - (b - 1.0) * a * r) / x); g[0] = (float)(1.0 / a + lx * (1.0 - (b - 1.0) * r)); g[1] = (float)(1.0 / b + log1p(-xa));
+      return;
+    }
+    case GJX_MOYAL: { double z = ((double)x - a) / b, e1 = 0.5 * (1.0 - exp(-z)); *dx = (float)(-e1 / b); g[0] = (float)(e1 / b); g[1] = (float)((e1 * z - 1.0) / b); return; }
+    case GJX_DOUBLESIDED_MAXWELL: { double z = ((double)x - a) / b, w = (2.0 / z - z) / b; *dx = (float)w; g[0] = (float)-w; g[1] = (float)((z * z - 3.0) / b); return; }
+    case GJX_INVERSE_GAUSSIAN: {
+      double r = ((double)x - a) / a;
+      *dx = (float)(-1.5 / x - 0.5 * b * ((double)x * x - (double)a * a) / ((double)a * a * (double)x * x));
+      g[0] = (float)(b * r / ((double)a * a)); g[1] = (float)(0.5 / b - 0.5 * r * r / x);
+      return;
+    }
+    case GJX_HALF_STUDENT_T:
     case GJX_STUDENT_T: {
       float y = (x - b) / c;
       float w = (a + 1.0f) * y / (a + y * y);

@@ -9,10 +9,14 @@ KIND = dict(normal=A.NORMAL, flip=A.FLIP, bernoulli_logits=A.BERNOULLI_LOGITS, b
             exponential=A.EXPONENTIAL, half_normal=A.HALF_NORMAL, laplace=A.LAPLACE, log_normal=A.LOG_NORMAL,
             cauchy=A.CAUCHY, gamma=A.GAMMA, mv_normal_diag=A.MVNORMAL_DIAG, student_t=A.STUDENT_T,
             truncated_normal=A.TRUNCATED_NORMAL, poisson=A.POISSON, geometric=A.GEOMETRIC, dirichlet=A.DIRICHLET, gumbel=A.GUMBEL,
-            half_cauchy=A.HALF_CAUCHY, inverse_gamma=A.INVERSE_GAMMA, weibull=A.WEIBULL, logit_normal=A.LOGIT_NORMAL, chi2=A.CHI2)
+            half_cauchy=A.HALF_CAUCHY, inverse_gamma=A.INVERSE_GAMMA, weibull=A.WEIBULL, logit_normal=A.LOGIT_NORMAL, chi2=A.CHI2,
+            chi=A.CHI, exp_gamma=A.EXP_GAMMA, exp_inverse_gamma=A.EXP_INVERSE_GAMMA, half_student_t=A.HALF_STUDENT_T, kumaraswamy=A.KUMARASWAMY,
+            moyal=A.MOYAL, truncated_cauchy=A.TRUNCATED_CAUCHY, double_sided_maxwell=A.DOUBLESIDED_MAXWELL, inverse_gaussian=A.INVERSE_GAUSSIAN)
 NPAR = dict(normal=2, flip=1, bernoulli_logits=1, beta=2, uniform=2, exponential=1, half_normal=1, laplace=2,
             log_normal=2, cauchy=2, gamma=2, mv_normal_diag=2, student_t=3, truncated_normal=4, poisson=1, geometric=1,
-            dirichlet=1, gumbel=2, half_cauchy=2, inverse_gamma=2, weibull=2, logit_normal=2, chi2=1)
+            dirichlet=1, gumbel=2, half_cauchy=2, inverse_gamma=2, weibull=2, logit_normal=2, chi2=1,
+            chi=1, exp_gamma=2, exp_inverse_gamma=2, half_student_t=3, kumaraswamy=2, moyal=2, truncated_cauchy=4, double_sided_maxwell=2,
+            inverse_gaussian=2)
 
 
 def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT, c=None, d=None):
@@ -96,6 +100,35 @@ def zoo2(rng=A.RNG_FLAT, observed=()):
     sl.add("tr", A.TRUNCATED_NORMAL, [0.0, 1.0, 2.5, 6.0])            # far upper tail
     sl.add("n9", A.NORMAL, [Param.value("t1", xf=A.XF_SIGMOID), 0.3])
     obs_vals = dict(n9=0.4, di=[0.2, 0.3, 0.5], po=2.0, tn=0.7)
+    modes = {a: A.MODE_OBS_TAB for a in observed}
+    return PackedProgram(sl, modes, {a: obs_vals[a] for a in observed}, rng_mode=rng)
+
+
+def zoo3(rng=A.RNG_FLAT, observed=()):
+    """Nine more of the reference's TFP wrappers (round 6: chi, exp_gamma, exp_inverse_gamma, half_student_t, kumaraswamy, moyal,
+    truncated_cauchy, double_sided_maxwell, inverse_gaussian), one site per kind plus chained copies through parameter forms."""
+    sl = SiteList()
+    sl.add("ch", A.CHI, [3.0])
+    sl.add("eg", A.EXP_GAMMA, [2.5, 1.5])
+    sl.add("ei", A.EXP_INVERSE_GAMMA, [3.0, 2.0])
+    sl.add("hs", A.HALF_STUDENT_T, [5.0, 0.5, 1.5])
+    sl.add("ku", A.KUMARASWAMY, [2.0, 3.0])
+    sl.add("mo", A.MOYAL, [0.3, 0.8])
+    sl.add("tc", A.TRUNCATED_CAUCHY, [0.2, 1.5, -2.0, 3.0])
+    sl.add("dm", A.DOUBLESIDED_MAXWELL, [0.4, 0.7])
+    sl.add("ig", A.INVERSE_GAUSSIAN, [1.5, 4.0])
+    # chained: parameters that are values of earlier choices (under transforms that keep them in their domains)
+    sl.add("ch2", A.CHI, [Param.value("ig", xf=A.XF_SOFTPLUS)])
+    sl.add("eg2", A.EXP_GAMMA, [Param.value("ch"), Param.value("eg", xf=A.XF_EXP)])
+    sl.add("ei2", A.EXP_INVERSE_GAMMA, [9.5, Param.value("ku", xf=A.XF_EXP)])                 # (concentration >= 8: the big-shape branch)
+    sl.add("hs2", A.HALF_STUDENT_T, [Param.value("ch", xf=A.XF_SOFTPLUS), Param.value("mo"), Param.value("ig")])
+    sl.add("ku2", A.KUMARASWAMY, [Param.value("ch"), Param.value("hs")])
+    sl.add("mo2", A.MOYAL, [Param.value("dm"), Param.value("ku", xf=A.XF_SOFTPLUS)])
+    sl.add("tc2", A.TRUNCATED_CAUCHY, [Param.value("mo", xf=A.XF_SIGMOID), Param.value("ch"), -1.0, 4.0])
+    sl.add("dm2", A.DOUBLESIDED_MAXWELL, [Param.value("tc"), Param.value("ku", xf=A.XF_EXP)])
+    sl.add("ig2", A.INVERSE_GAUSSIAN, [Param.value("ch"), Param.value("eg", xf=A.XF_EXP)])
+    sl.add("n9", A.NORMAL, [Param.value("ig2", xf=A.XF_SIGMOID), 0.3])
+    obs_vals = dict(n9=0.4, ku=0.35, mo=0.9, ig=1.1)
     modes = {a: A.MODE_OBS_TAB for a in observed}
     return PackedProgram(sl, modes, {a: obs_vals[a] for a in observed}, rng_mode=rng)
 

@@ -119,6 +119,56 @@ def test_zoo_parity(K_, oracle, rng, observed):
 
 
 @pytest.mark.parametrize("rng", RNGS)
+@pytest.mark.parametrize("engine", ["interp", "gen"])
+@pytest.mark.parametrize("observed", [(), ("n9", "ku", "mo", "ig")])
+def test_zoo3_parity(K_, oracle, rng, observed, engine, monkeypatch):
+    """nine more of the reference's TFP wrappers (round 6: chi, exp_gamma, exp_inverse_gamma, half_student_t, kumaraswamy, moyal,
+    truncated_cauchy, double_sided_maxwell, inverse_gaussian; the oracle is held to scipy by tests/test_oracle.py) on the site
+    interpreter and on the generated kernel: samples, scores, weights; a rejection sampler or a sign may part ways with the oracle only
+    at a near tie"""
+    monkeypatch.setenv("GJX_ENGINE", engine)
+    prog = H.zoo3(rng, observed)
+    assert K_.program_engine(prog) == (4 if engine == "gen" else 0)
+    for K in (1, 77, 3000):
+        g, o = _run_both(K_, oracle, prog, (41, 42), K, want_site_scores=True)
+        ok = _close_cols(g["choices"], o["choices"], rt=5e-4, at=2e-4)
+        for k in ("score", "weight", "logw"):
+            ok &= _close_cols(g[k][None], o[k][None], rt=5e-4, at=5e-4)
+        # (a draw at 1e-4 of a pole of the density — |z| -> 0 of the double-sided Maxwell, x -> 1 of kumaraswamy — is float32 ill-conditioned)
+        ok |= ~np.isfinite(o["score"]) | (np.abs(o["site_scores"]) > 12.0).any(axis=0)
+        assert_near_ties_only(~ok, o, f"zoo3 K={K}", cap=0.01)
+        np.testing.assert_allclose(g["site_scores"][:, ok], o["site_scores"][:, ok], rtol=1e-3, atol=5e-4)
+        if not observed:
+            assert (g["weight"] == 0).all()
+        else:
+            assert np.isfinite(g["logw"]).all()
+
+
+def test_zoo3_gradient_parity(K_, oracle):
+    """analytic gradients of the nine kinds: device == oracle (the oracle's against finite differences: tests/test_oracle.py), through
+    gjx_score_grad; and an HMC move over all of them runs on a generated kernel with the oracle's alpha"""
+    import torch
+    sl = H.zoo3().site_list
+    cont = tuple(s.addr for s in sl.sites)
+    prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=cont)
+    base = oracle.run_program(H.zoo3(), (9, 9), 512)["choices"].astype(np.float32)
+    sg, gg = K_.score_grad(prog, torch.as_tensor(base).cuda())
+    so, go = oracle.score_grad(prog, base)
+    fin = np.isfinite(so) & (np.abs(go).max(axis=0) < 1e3)
+    np.testing.assert_allclose(_np(sg)[fin], so[fin], rtol=2e-4, atol=1e-3)
+    np.testing.assert_allclose(_np(gg)[:, fin], go[:, fin], rtol=3e-3, atol=3e-3)
+    assert fin.mean() > 0.8
+    assert K_.hmc_engine(prog) == 4
+    sub_ = np.ascontiguousarray(base[:, fin])
+    out = K_.hmc(prog, (1, 2), torch.as_tensor(sub_).cuda(), 0.002, 5, False, False)
+    oo = oracle.hmc(prog, (1, 2), sub_, 0.002, 5)
+    al, alo = _np(out["alpha"]), oo["alpha"]
+    good = np.isfinite(alo) & (np.abs(alo) < 1.0)
+    assert good.mean() > 0.7
+    np.testing.assert_allclose(al[good], alo[good], rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("rng", RNGS)
 @pytest.mark.parametrize("observed", [(), ("n9", "di", "po", "tn")])
 def test_zoo2_parity(K_, oracle, rng, observed):
     """the wider distribution set (student_t, truncated_normal, poisson, geometric, dirichlet, gumbel, half_cauchy,
@@ -1093,6 +1143,8 @@ def _random_program(rs, rng_mode):
         A.GAMMA: (POS, POS), A.STUDENT_T: (POS, REAL, POS), A.POISSON: (POS,), A.GEOMETRIC: (PROB,), A.GUMBEL: (REAL, POS),
         A.HALF_CAUCHY: (REAL, POS), A.INVERSE_GAMMA: (POS, POS), A.WEIBULL: (POS, POS), A.LOGIT_NORMAL: (REAL, POS), A.CHI2: (POS,),
         A.MVNORMAL_DIAG: (REAL, POS),
+        A.CHI: (POS,), A.EXP_GAMMA: (POS, POS), A.EXP_INVERSE_GAMMA: (POS, POS), A.HALF_STUDENT_T: (POS, REAL, POS), A.KUMARASWAMY: (POS, POS),
+        A.MOYAL: (REAL, POS), A.DOUBLESIDED_MAXWELL: (REAL, POS), A.INVERSE_GAUSSIAN: (POS, POS),
     }
     kinds = [k for k in spec if spec[k] is not None]
     sl = SiteList()

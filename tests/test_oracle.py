@@ -562,14 +562,69 @@ def test_wider_samplers_match_scipy_moments(oracle, rng):
     assert (out["weight"] == 0).all()
 
 
-def test_wider_gradients_by_finite_differences(oracle):
+@pytest.mark.parametrize("rng", [A.RNG_FLAT, A.RNG_JAX32])
+def test_round6_distributions_match_scipy(oracle, rng):
+    """chi, exp_gamma, exp_inverse_gamma, half_student_t, kumaraswamy, moyal, truncated_cauchy, double_sided_maxwell, inverse_gaussian
+    (the reference wraps TFP's: tensorflow_probability/__init__.py:115-284): the oracle's samplers against scipy.stats by a
+    Kolmogorov-Smirnov distance, its log-densities against scipy's logpdf at the oracle's own draws"""
+    import scipy.stats as st
+    K = 100_000
+    prog = H.zoo3(rng)
+    out = oracle.run_program(prog, (5, 6), K, want_site_scores=True)
+    idx = {s.addr: j for j, s in enumerate(prog.site_list.sites)}
+    v = {s.addr: out["choices"][prog.slot_of[s.addr]].astype(np.float64) for s in prog.site_list.sites}
+
+    class dsm:                               # z^2 exp(-z^2 / 2) / sqrt(2 pi): |z| is Maxwell
+        cdf = staticmethod(lambda z: 0.5 + 0.5 * np.sign(z) * st.maxwell.cdf(np.abs(z)))
+        logpdf = staticmethod(lambda z: 2.0 * np.log(np.abs(z)) - 0.5 * z * z - 0.5 * np.log(2 * np.pi))
+
+    class kuma:
+        cdf = staticmethod(lambda x, a, b: 1.0 - (1.0 - x ** a) ** b)
+        logpdf = staticmethod(lambda x, a, b: np.log(a * b) + (a - 1) * np.log(x) + (b - 1) * np.log1p(-x ** a))
+
+    class tca:
+        cdf = staticmethod(lambda x, lo, hi: (np.arctan(x) - np.arctan(lo)) / (np.arctan(hi) - np.arctan(lo)))
+        logpdf = staticmethod(lambda x, lo, hi: -np.log1p(x * x) - np.log(np.arctan(hi) - np.arctan(lo)))
+
+    ref = dict(ch=st.chi(3.0), eg=st.loggamma(2.5, loc=-math.log(1.5)), hs=st.halfnorm,          # (hs: below)
+               mo=st.moyal(0.3, 0.8), ig=st.invgauss(1.5 / 4.0, scale=4.0))
+    ks = lambda x, cdf: np.abs(np.arange(1, x.size + 1) / x.size - cdf(np.sort(x))).max()
+    tol = 2.2 / math.sqrt(K)                                                                       # KS critical value at ~1e-4
+    assert ks(v["ch"], ref["ch"].cdf) < tol and ks(v["eg"], ref["eg"].cdf) < tol and ks(v["mo"], ref["mo"].cdf) < tol and ks(v["ig"], ref["ig"].cdf) < tol
+    assert ks(-v["ei"], st.loggamma(3.0, loc=-math.log(2.0)).cdf) < tol                            # -log inverse-gamma(a, b) = log gamma(a, rate b)
+    t5 = st.t(5.0)
+    assert (v["hs"] >= 0.5).all() and ks((v["hs"] - 0.5) / 1.5, lambda z: 2.0 * t5.cdf(z) - 1.0) < tol
+    assert ks(v["ku"], lambda x: kuma.cdf(x, 2.0, 3.0)) < tol
+    lo, hi = (-2.0 - 0.2) / 1.5, (3.0 - 0.2) / 1.5
+    assert (v["tc"] >= -2.0).all() and (v["tc"] <= 3.0).all() and ks((v["tc"] - 0.2) / 1.5, lambda z: tca.cdf(z, lo, hi)) < tol
+    assert ks((v["dm"] - 0.4) / 0.7, dsm.cdf) < tol and 0.48 < (v["dm"] > 0.4).mean() < 0.52
+    ss = out["site_scores"].astype(np.float64)
+    lp = dict(ch=ref["ch"].logpdf(v["ch"]), eg=ref["eg"].logpdf(v["eg"]), ei=st.loggamma(3.0, loc=-math.log(2.0)).logpdf(-v["ei"]),
+              hs=math.log(2.0) + st.t.logpdf(v["hs"], 5.0, 0.5, 1.5), ku=kuma.logpdf(v["ku"], 2.0, 3.0), mo=ref["mo"].logpdf(v["mo"]),
+              tc=tca.logpdf((v["tc"] - 0.2) / 1.5, lo, hi) - math.log(1.5), dm=dsm.logpdf((v["dm"] - 0.4) / 0.7) - math.log(0.7),
+              ig=ref["ig"].logpdf(v["ig"]))
+    for a_, want in lp.items():
+        np.testing.assert_allclose(ss[idx[a_]], want, rtol=2e-5, atol=2e-5, err_msg=a_)
+    # the chained copies, at their per-particle parameters
+    sp = lambda x: np.logaddexp(0.0, x)
+    np.testing.assert_allclose(ss[idx["ch2"]], st.chi.logpdf(v["ch2"], sp(v["ig"])), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ss[idx["eg2"]], st.loggamma.logpdf(v["eg2"], v["ch"], loc=-v["eg"]), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ss[idx["ei2"]], st.loggamma.logpdf(-v["ei2"], 9.5, loc=-v["ku"]), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ss[idx["mo2"]], st.moyal.logpdf(v["mo2"], v["dm"], sp(v["ku"])), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ss[idx["ig2"]], st.invgauss.logpdf(v["ig2"], v["ch"] / np.exp(v["eg"]), scale=np.exp(v["eg"])), rtol=2e-4, atol=5e-4)
+    np.testing.assert_allclose(ss[idx["hs2"]], math.log(2.0) + st.t.logpdf(v["hs2"], sp(v["ch"]), v["mo"], v["ig"]), rtol=1e-4, atol=2e-4)
+    assert (v["hs2"] >= v["mo"]).all() and (v["tc2"] >= -1.0).all() and (v["tc2"] <= 4.0).all() and (v["ku2"] > 0).all() and (v["ku2"] <= 1).all()
+
+
+@pytest.mark.parametrize("zoo", ["zoo2", "zoo3"])
+def test_wider_gradients_by_finite_differences(oracle, zoo):
     """dlogpdf of the wider set (value and parameter gradients through VALUE / xf chains) against central differences
     of the oracle's own score in float64-ish steps."""
-    prog0 = H.zoo2()
+    prog0 = getattr(H, zoo)()
     sl = prog0.site_list
     cont = [s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS]
     prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=tuple(cont))
-    base = oracle.run_program(H.zoo2(), (9, 9), 64)["choices"].astype(np.float32)
+    base = oracle.run_program(getattr(H, zoo)(), (9, 9), 64)["choices"].astype(np.float32)
     sc, gr = oracle.score_grad(prog, base)
     n_checked = 0
     for s in sl.sites:
