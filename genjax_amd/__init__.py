@@ -14,7 +14,7 @@ from .gen import (Distribution, Marginal, array, chi2, dirichlet, geometric, gum
                   iterate, iterate_final, mv_normal_diag, normal, repeat, scan, sigmoid, softplus, take, uniform, vmap, where)
 from .gen import Scan, Vmap, accumulate, reduce  # noqa: F401
 from .gen import (chi, double_sided_maxwell, exp_gamma, exp_inverse_gamma, half_student_t, inverse_gaussian, kumaraswamy, moyal,  # noqa: F401
-                  truncated_cauchy)
+                  negative_binomial, truncated_cauchy, von_mises)
 from .gen import Expr, NotSupportedInModelBody, cos, dot, log, log1p, maximum, minimum, sin, sqrt, square, tanh  # noqa: F401  (general expressions: GJX_P_EXPR)
 from .inference import requests, smc  # noqa: F401  (the reference's genjax.smc / genjax.requests modules)
 from .inference.smc import SMCAlgorithm as Algorithm  # noqa: F401

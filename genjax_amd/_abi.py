@@ -18,7 +18,8 @@ UNIFORM, MVNORMAL_DIAG, EXPONENTIAL, HALF_NORMAL, LAPLACE, LOG_NORMAL, CAUCHY, G
 STUDENT_T, TRUNCATED_NORMAL, POISSON, GEOMETRIC, DIRICHLET, GUMBEL, HALF_CAUCHY, INVERSE_GAMMA = 15, 16, 17, 18, 19, 20, 21, 22
 WEIBULL, LOGIT_NORMAL, CHI2 = 23, 24, 25
 CHI, EXP_GAMMA, EXP_INVERSE_GAMMA, HALF_STUDENT_T, KUMARASWAMY, MOYAL, TRUNCATED_CAUCHY, DOUBLESIDED_MAXWELL, INVERSE_GAUSSIAN = 26, 27, 28, 29, 30, 31, 32, 33, 34
-KIND_MAX = 35
+NEGATIVE_BINOMIAL, VON_MISES = 35, 36
+KIND_MAX = 37
 KIND_NAMES = {
     NORMAL: "normal", FLIP: "flip", BERNOULLI_LOGITS: "bernoulli", BETA: "beta",
     CATEGORICAL_LOGITS: "categorical", CATEGORICAL_PROBS: "categorical(probs)", UNIFORM: "uniform",
@@ -29,8 +30,9 @@ KIND_NAMES = {
     WEIBULL: "weibull", LOGIT_NORMAL: "logit_normal", CHI2: "chi2",
     CHI: "chi", EXP_GAMMA: "exp_gamma", EXP_INVERSE_GAMMA: "exp_inverse_gamma", HALF_STUDENT_T: "half_student_t", KUMARASWAMY: "kumaraswamy",
     MOYAL: "moyal", TRUNCATED_CAUCHY: "truncated_cauchy", DOUBLESIDED_MAXWELL: "double_sided_maxwell", INVERSE_GAUSSIAN: "inverse_gaussian",
+    NEGATIVE_BINOMIAL: "negative_binomial", VON_MISES: "von_mises",
 }
-DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS, POISSON, GEOMETRIC)
+DISCRETE_KINDS = (FLIP, BERNOULLI_LOGITS, CATEGORICAL_LOGITS, CATEGORICAL_PROBS, POISSON, GEOMETRIC, NEGATIVE_BINOMIAL)
 NO_GRADIENT_KINDS = DISCRETE_KINDS + (DIRICHLET,)      # values HMC cannot move (integers; simplex-constrained)
 
 # param forms / transforms / modes / flags / rng

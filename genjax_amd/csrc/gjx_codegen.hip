@@ -1587,7 +1587,7 @@ bool pf_supported(const gjx_program* p) {
 }
 
 bool discrete_kind(int k) {
-  return is_categorical(k) || k == GJX_FLIP || k == GJX_BERNOULLI_LOGITS || k == GJX_POISSON || k == GJX_GEOMETRIC;
+  return is_categorical(k) || k == GJX_FLIP || k == GJX_BERNOULLI_LOGITS || k == GJX_POISSON || k == GJX_GEOMETRIC || k == GJX_NEGATIVE_BINOMIAL;
 }
 
 // may the filter kernel of this step program carry a rejuvenation move (generate_pf, | 512)?  The move re-scores the PREVIOUS step —

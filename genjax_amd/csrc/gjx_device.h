@@ -564,10 +564,35 @@ GJX_DEV float normal_interval_mass(float lo, float hi) {
   return normal_cdf(hi) - normal_cdf(lo);
 }
 
+// exp(-x) I0(x) and I1(x) / I0(x), x >= 0: Abramowitz & Stegun 9.8.1 - 9.8.4 (|relative error| < 2e-7)
+GJX_DEV float bessel_i0e(float x) {
+  if (x < 3.75f) {
+    const float t = x * (1.0f / 3.75f), t2 = t * t;
+    const float p = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.0045813f, t2, 0.0360768f), t2, 0.2659732f), t2, 1.2067492f), t2, 3.0899424f), t2, 3.5156229f), t2, 1.0f);
+    return p * fast_exp(-x);
+  }
+  const float u = 3.75f * fast_rcp(x);
+  const float p = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.00392377f, u, -0.01647633f), u, 0.02635537f), u, -0.02057706f), u, 0.00916281f), u, -0.00157565f), u, 0.00225319f), u, 0.01328592f), u, 0.39894228f);
+  return p * rsqrtf(x);
+}
+GJX_DEV float bessel_i1_over_i0(float x) {
+  if (x < 3.75f) {
+    const float t = x * (1.0f / 3.75f), t2 = t * t;
+    const float p1 = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.00032411f, t2, 0.00301532f), t2, 0.02658733f), t2, 0.15084934f), t2, 0.51498869f), t2, 0.87890594f), t2, 0.5f);
+    const float p0 = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.0045813f, t2, 0.0360768f), t2, 0.2659732f), t2, 1.2067492f), t2, 3.0899424f), t2, 3.5156229f), t2, 1.0f);
+    return x * p1 * fast_rcp(p0);
+  }
+  const float u = 3.75f * fast_rcp(x);
+  const float p1 = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(-0.00420059f, u, 0.01787654f), u, -0.02895312f), u, 0.02282967f), u, -0.01031555f), u, 0.00163801f), u, -0.00362018f), u, -0.03988024f), u, 0.39894228f);
+  const float p0 = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.00392377f, u, -0.01647633f), u, 0.02635537f), u, -0.02057706f), u, 0.00916281f), u, -0.00157565f), u, 0.00225319f), u, 0.01328592f), u, 0.39894228f);
+  return p1 * fast_rcp(p0);
+}
+
 // parameters a (non-categorical) kind reads, and stream elements one scalar of it may draw (host and device: the emitters use them too)
 constexpr int kGammaMaxIt = 32;
 constexpr int kGammaNDraw = 4 * kGammaMaxIt + 2;  // draw schedule: see GAMMA_NDRAW in the oracle
 constexpr int kPoissonTries = 16;
+constexpr int kVonMisesTries = 16;
 constexpr int kind_params(int kind) {
   return (kind == GJX_TRUNCATED_NORMAL || kind == GJX_TRUNCATED_CAUCHY) ? 4 : ((kind == GJX_STUDENT_T || kind == GJX_HALF_STUDENT_T) ? 3 : 2);
 }
@@ -577,6 +602,8 @@ constexpr int kind_draws(int kind) {
             kind == GJX_EXP_INVERSE_GAMMA) ? kGammaNDraw
          : (kind == GJX_STUDENT_T || kind == GJX_HALF_STUDENT_T || kind == GJX_DOUBLESIDED_MAXWELL) ? kGammaNDraw + 2
          : kind == GJX_POISSON ? 2 * kPoissonTries + 2
+         : kind == GJX_NEGATIVE_BINOMIAL ? kGammaNDraw + 2 * kPoissonTries + 2
+         : kind == GJX_VON_MISES ? 2 * kVonMisesTries + 2
          : kind == GJX_INVERSE_GAUSSIAN ? 4 : 1;
 }
 GJX_DEV int params_of(int kind) { return kind_params(kind); }
@@ -598,6 +625,13 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
       const float rs = fast_rcp(b);
       const float z = (x - a) * rs;
       return -fast_log(b) - log1p_acc(z * z) - fast_log(atanf((d - a) * rs) - atanf((c - a) * rs));
+    }
+    case GJX_NEGATIVE_BINOMIAL: {  // a = total_count r, b = logits l of the success probability: C(x + r - 1, x) p^x (1 - p)^r
+      if (x < 0.0f || x != floorf(x)) return -INFINITY;
+      return lgammaf(x + a) - lgammaf(x + 1.0f) - lgammaf(a) - (x == 0.0f ? 0.0f : x * softplus(-b)) - a * softplus(b);
+    }
+    case GJX_VON_MISES: {  // a = loc, b = concentration: exp(k cos(x - loc)) / (2 pi I0(k)), with I0(k) = e^k i0e(k)
+      return b * (cosf(x - a) - 1.0f) - 1.83787707f - fast_log(bessel_i0e(b));
     }
     case GJX_CHI: {  // a = df: sqrt of a chi2(df) variate
       if (x <= 0.0f) return -INFINITY;
@@ -791,6 +825,27 @@ GJX_DEV float elem_sample(int kind, BS& bs, uint32_t c, float a, float b, float 
       const float rs = fast_rcp(b);
       const float lo = atanf((p3 - a) * rs), hi = atanf((p4 - a) * rs);
       return fminf(fmaxf(fmaf(b, tanf(fmaf(bits_to_unit(bs.get(c)), hi - lo, lo)), a), p3), p4);
+    }
+    case GJX_NEGATIVE_BINOMIAL: {  // a gamma(r, rate e^-l) mixture of Poissons: rate = exp(log gamma(r, 1) + l)
+      const float lg = log_gamma_variate<RNG>(bs, c, a);
+      return poisson_variate<RNG>(bs, c + kGammaNDraw, fast_exp(lg + b));
+    }
+    case GJX_VON_MISES: {  // Best & Fisher (1979): a wrapped-Cauchy envelope, fixed budget of tries (elements 2 t, 2 t + 1; the sign: the last one)
+      if (b < 1e-6f) return fmaf(kPi, fmaf(2.0f, bits_to_unit(bs.get(c)), -1.0f), a);          // (no concentration: uniform on the circle)
+      const double kd = (double)b;
+      const double tau = 1.0 + sqrt(1.0 + 4.0 * kd * kd);
+      const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * kd);
+      const float r = (float)((1.0 + rho * rho) / (2.0 * rho));
+      float f = 1.0f;
+      for (int t = 0; t < kVonMisesTries; ++t) {
+        const float z = cosf(kPi * bits_to_unit(bs.get(c + 2 * t)));
+        const float u2 = uniform_from_bits(bs.get(c + 2 * t + 1), kTiny, 1.0f);
+        f = fmaf(r, z, 1.0f) * fast_rcp(r + z);
+        const float cc = b * (r - f);
+        if (u2 < cc * (2.0f - cc) || fast_log(cc * fast_rcp(u2)) + 1.0f - cc >= 0.0f) break;
+      }
+      const float th = acosf(fminf(fmaxf(f, -1.0f), 1.0f));
+      return a + (bits_to_unit(bs.get(c + 2 * kVonMisesTries)) < 0.5f ? -th : th);
     }
     case GJX_CHI: return fast_exp(0.5f * (kLn2 + log_gamma_variate<RNG>(bs, c, 0.5f * a)));
     case GJX_EXP_GAMMA: return log_gamma_variate<RNG>(bs, c, a) - fast_log(b);
@@ -1074,6 +1129,16 @@ GJX_DEV void dlogpdf(int kind, float x, float a, float b, float c, float d, floa
       const float wl = fast_rcp(fmaf(lo, lo, 1.0f)) * rA, wh = fast_rcp(fmaf(hi, hi, 1.0f)) * rA;
       const float w = 2.0f * z * fast_rcp(fmaf(z, z, 1.0f)) * rb;
       dx = -w; da = w + (wh - wl); db = fmaf(w, z, -rb) + (hi * wh - lo * wl); dc = wl; dd = -wh;
+      done(); return;
+    }
+    case GJX_NEGATIVE_BINOMIAL: {
+      const float p = sigmoid(b);
+      da = digamma_f(x + a) - digamma_f(a) - softplus(b); db = x * (1.0f - p) - a * p;
+      done(); return;
+    }
+    case GJX_VON_MISES: {
+      const float sn = sinf(x - a);
+      dx = -b * sn; da = b * sn; db = cosf(x - a) - bessel_i1_over_i0(b);
       done(); return;
     }
     case GJX_CHI: dx = (a - 1.0f) * fast_rcp(x) - x; da = fast_log(x) - 0.5f * kLn2 - 0.5f * digamma_f(0.5f * a); done(); return;

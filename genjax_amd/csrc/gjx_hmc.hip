@@ -1100,7 +1100,7 @@ extern "C" int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, in
     if (s.mode == GJX_MODE_INPUT && (s.flags & GJX_SITE_HMC_SELECTED)) return gjx_fail(GJX_EINVAL, "gjx_hmc: an INPUT site cannot be selected");
     if ((s.flags & GJX_SITE_HMC_SELECTED) && (s.kind == GJX_FLIP || s.kind == GJX_BERNOULLI_LOGITS ||
                                               s.kind == GJX_CATEGORICAL_LOGITS || s.kind == GJX_CATEGORICAL_PROBS ||
-                                              s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET))
+                                              s.kind == GJX_POISSON || s.kind == GJX_GEOMETRIC || s.kind == GJX_DIRICHLET || s.kind == GJX_NEGATIVE_BINOMIAL))
       return gjx_fail(GJX_EINVAL, "gjx_hmc: only unconstrained float32 sites can be selected (hmc.py:49-65)");
   }
   const int pref = hmc_engine_pref();

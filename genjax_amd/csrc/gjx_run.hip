@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_run_generic(RunArgs a) {
         GJX_KIND(GJX_GEOMETRIC) GJX_KIND(GJX_GUMBEL) GJX_KIND(GJX_HALF_CAUCHY) GJX_KIND(GJX_INVERSE_GAMMA) GJX_KIND(GJX_WEIBULL)
         GJX_KIND(GJX_LOGIT_NORMAL) GJX_KIND(GJX_CHI2) GJX_KIND(GJX_CHI) GJX_KIND(GJX_EXP_GAMMA) GJX_KIND(GJX_EXP_INVERSE_GAMMA)
         GJX_KIND(GJX_HALF_STUDENT_T) GJX_KIND(GJX_KUMARASWAMY) GJX_KIND(GJX_MOYAL) GJX_KIND(GJX_TRUNCATED_CAUCHY)
-        GJX_KIND(GJX_DOUBLESIDED_MAXWELL) GJX_KIND(GJX_INVERSE_GAUSSIAN)
+        GJX_KIND(GJX_DOUBLESIDED_MAXWELL) GJX_KIND(GJX_INVERSE_GAUSSIAN) GJX_KIND(GJX_NEGATIVE_BINOMIAL) GJX_KIND(GJX_VON_MISES)
         default: lp = __builtin_nanf(""); break;
       }
 #undef GJX_KIND

@@ -1523,6 +1523,23 @@ class _Poisson(_VectorDist):
         return super()._params(args, kwargs)
 
 
+class _NegativeBinomial(_VectorDist):
+    """tfd.NegativeBinomial(total_count, logits=None, probs=None): a bare second argument is LOGITS (the reference passes the TFP
+    distribution through unwrapped, tensorflow_probability/__init__.py:249)"""
+
+    def _params(self, args, kwargs):
+        tc = kwargs["total_count"] if "total_count" in kwargs else (args[0] if args else None)
+        if tc is None:
+            raise TypeError("negative_binomial(total_count, logits) / negative_binomial(total_count, probs=...)")
+        if "probs" in kwargs:
+            p = kwargs["probs"]
+            return self.kind, [tc, log(p) - log1p(-p)]
+        l = kwargs["logits"] if "logits" in kwargs else (args[1] if len(args) == 2 else None)
+        if l is None:
+            raise TypeError("negative_binomial(total_count, logits) / negative_binomial(total_count, probs=...)")
+        return self.kind, [tc, l]
+
+
 normal = _VectorDist("normal", A.NORMAL, ("loc", "scale"))
 mv_normal_diag = _VectorDist("mv_normal_diag", A.MVNORMAL_DIAG, ("loc", "scale_diag"))
 flip = _VectorDist("flip", A.FLIP, ("p",))
@@ -1557,3 +1574,5 @@ moyal = _VectorDist("moyal", A.MOYAL, ("loc", "scale"))
 truncated_cauchy = _VectorDist("truncated_cauchy", A.TRUNCATED_CAUCHY, ("loc", "scale", "low", "high"))
 double_sided_maxwell = _VectorDist("double_sided_maxwell", A.DOUBLESIDED_MAXWELL, ("loc", "scale"))
 inverse_gaussian = _VectorDist("inverse_gaussian", A.INVERSE_GAUSSIAN, ("loc", "concentration"))
+negative_binomial = _NegativeBinomial("negative_binomial", A.NEGATIVE_BINOMIAL, ("total_count", "logits"))
+von_mises = _VectorDist("von_mises", A.VON_MISES, ("loc", "concentration"))

@@ -224,10 +224,10 @@ class ScanBootstrapFilter:
         dev = kernels._dev(device)
         hmc_move = None
         if self.moves:
-            if keep_history:
-                raise NotImplementedError("filter moves: keep_history is kept by the forms without moves= (gjx_scan_filter_history)")
             from .filter_moves import normalise_moves, run_with_moves
             specs = normalise_moves(self.moves)
+            if keep_history and not (len(specs) == 1 and specs[0][0] == "hmc"):
+                raise NotImplementedError("filter moves: keep_history is kept by the library's own loops (no moves, the random-walk move, ONE HMC move)")
             # ONE HMC move: inside the library's own step loop (gjx_filter_opts::hmc_targets: gather, gjx_hmc, propagate per step, no
             # host between the launches); anything else — proposals, several moves — step by step from here
             if len(specs) == 1 and specs[0][0] == "hmc" and not getattr(self, "_moves_step_by_step", False):
@@ -312,7 +312,7 @@ class ScanBootstrapFilter:
                 return self._repeat_after_timeout(key, constraint, args, device, keep_ancestors, keep_history)
             incs = lse[:, 3]
             logw = self._out(b["logw"])
-            moved = bool(self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0)
+            moved = bool(self.rejuvenate and int(self.rejuvenate.get("n_moves", 0)) > 0) or self._hmc_state is not None
             hist = ScanHistory(progs, rows_all, anc_all[: T - 1], logw, moved=moved)
             return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows_all[T - 1][: max(progs[-1].n_slots, 1)], logw=logw,
                         programs=progs, ancestors=anc_all[: T - 1], history=hist, degenerate=bool(st & 2), info=self.last_info,

@@ -134,7 +134,7 @@ N_PARAMS = {
     A.STUDENT_T: 3, A.TRUNCATED_NORMAL: 4, A.POISSON: 1, A.GEOMETRIC: 1, A.DIRICHLET: 1, A.GUMBEL: 2, A.HALF_CAUCHY: 2,
     A.INVERSE_GAMMA: 2, A.WEIBULL: 2, A.LOGIT_NORMAL: 2, A.CHI2: 1,
     A.CHI: 1, A.EXP_GAMMA: 2, A.EXP_INVERSE_GAMMA: 2, A.HALF_STUDENT_T: 3, A.KUMARASWAMY: 2, A.MOYAL: 2, A.TRUNCATED_CAUCHY: 4,
-    A.DOUBLESIDED_MAXWELL: 2, A.INVERSE_GAUSSIAN: 2,
+    A.DOUBLESIDED_MAXWELL: 2, A.INVERSE_GAUSSIAN: 2, A.NEGATIVE_BINOMIAL: 2, A.VON_MISES: 2,
 }
 
 

@@ -98,7 +98,9 @@ enum {
   GJX_TRUNCATED_CAUCHY = 32,  /* truncated_cauchy(loc, scale, low, high) :284               */
   GJX_DOUBLESIDED_MAXWELL = 33, /* double_sided_maxwell(loc, scale) :135                    */
   GJX_INVERSE_GAUSSIAN = 34,  /* inverse_gaussian(loc, concentration) :199                  */
-  GJX_KIND_MAX = 35
+  GJX_NEGATIVE_BINOMIAL = 35, /* negative_binomial(total_count, logits) :249  (successes before total_count failures; value stored as float) */
+  GJX_VON_MISES = 36,         /* von_mises(loc, concentration) :299                         */
+  GJX_KIND_MAX = 37
 };
 
 /* parameter expression forms (what the model body computes between sites) */

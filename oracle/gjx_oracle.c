@@ -231,6 +231,7 @@ float gjxo_unit_from_bits(uint32_t bits) { return bits_to_unit(bits); }
 /* Marsaglia & Tsang (2000) gamma sampler in log space; the draw budget per gamma variate is
  * fixed so that element indices are a pure function of (variate, iteration). */
 #define POISSON_TRIES 16
+#define VON_MISES_TRIES 16
 #define GAMMA_MAXIT 32
 #define GAMMA_NDRAW (4 * GAMMA_MAXIT + 2)
 /* draw schedule of one gamma variate (element indices relative to `base`): iteration t takes its normal
@@ -429,6 +430,20 @@ static inline double xlogy_d(double x, double y) { return x == 0.0 ? 0.0 : x * l
 static inline double xlog1py_d(double x, double y) { return x == 0.0 ? 0.0 : x * log1p(y); }
 static inline double softplus_d(double x) { return (x > 0.0 ? x : 0.0) + log1p(exp(-fabs(x))); }
 
+/* exp(-x) I0(x) and I1(x) / I0(x), x >= 0: Abramowitz & Stegun 9.8.1 - 9.8.4, the polynomials the device evaluates (in double here) */
+static double bessel_i0_poly(double x, int one) {
+  if (x < 3.75) {
+    double t2 = (x / 3.75) * (x / 3.75);
+    if (one) return x * (0.5 + t2 * (0.87890594 + t2 * (0.51498869 + t2 * (0.15084934 + t2 * (0.02658733 + t2 * (0.00301532 + t2 * 0.00032411))))));
+    return 1.0 + t2 * (3.5156229 + t2 * (3.0899424 + t2 * (1.2067492 + t2 * (0.2659732 + t2 * (0.0360768 + t2 * 0.0045813)))));
+  }
+  double u = 3.75 / x;
+  if (one) return 0.39894228 + u * (-0.03988024 + u * (-0.00362018 + u * (0.00163801 + u * (-0.01031555 + u * (0.02282967 + u * (-0.02895312 + u * (0.01787654 + u * -0.00420059)))))));
+  return 0.39894228 + u * (0.01328592 + u * (0.00225319 + u * (-0.00157565 + u * (0.00916281 + u * (-0.02057706 + u * (0.02635537 + u * (-0.01647633 + u * 0.00392377)))))));
+}
+static double bessel_i0e_d(double x) { return x < 3.75 ? bessel_i0_poly(x, 0) * exp(-x) : bessel_i0_poly(x, 0) / sqrt(x); }
+static double bessel_i1_over_i0_d(double x) { return bessel_i0_poly(x, 1) / bessel_i0_poly(x, 0); }
+
 static float elem_logpdf4(int kind, float xf, float af, float bf, float cf, float df) {
   const double x = xf, a = af, b = bf, c = cf, d = df;
   switch (kind) {
@@ -437,6 +452,11 @@ static float elem_logpdf4(int kind, float xf, float af, float bf, float cf, floa
       double z = (x - a) / b;
       return (float)(-log(b) - log1p(z * z) - log(atan((d - a) / b) - atan((c - a) / b)));
     }
+    case GJX_NEGATIVE_BINOMIAL: /* tfd.NegativeBinomial(total_count=a, logits=b): successes before a failures, success probability sigmoid(b) */
+      if (x < 0.0 || x != floor(x)) return -INFINITY;
+      return (float)(lgamma(x + a) - lgamma(x + 1.0) - lgamma(a) - (x == 0.0 ? 0.0 : x * softplus_d(-b)) - a * softplus_d(b));
+    case GJX_VON_MISES: /* tfd.VonMises(loc=a, concentration=b) */
+      return (float)(b * (cos(x - a) - 1.0) - 2.0 * (double)HALF_LOG_2PI - log(bessel_i0e_d(b)));
     case GJX_CHI: { /* tfd.Chi(df=a): the root of a chi2(a) variate */
       double h = 0.5 * a;
       return x <= 0.0 ? -INFINITY : (float)((1.0 - h) * log(2.0) + xlogy_d(a - 1.0, x) - 0.5 * x * x - lgamma(h));
@@ -564,6 +584,8 @@ static int draws_per_elem(int kind) {
     case GJX_HALF_STUDENT_T:
     case GJX_DOUBLESIDED_MAXWELL: return GAMMA_NDRAW + 2;
     case GJX_POISSON: return 2 * POISSON_TRIES + 2;
+    case GJX_NEGATIVE_BINOMIAL: return GAMMA_NDRAW + 2 * POISSON_TRIES + 2;
+    case GJX_VON_MISES: return 2 * VON_MISES_TRIES + 2;
     case GJX_INVERSE_GAUSSIAN: return 4;
     default: return 1;
   }
@@ -617,6 +639,30 @@ static float elem_sample4(int kind, const ostream* sk, uint32_t c, float a, floa
       float lo = atanf((p3 - a) / b), hi = atanf((p4 - a) / b);
       float x = a + b * tanf(lo + bits_to_unit(elem_bits(sk, c)) * (hi - lo));
       return x < p3 ? p3 : (x > p4 ? p4 : x);
+    }
+    case GJX_NEGATIVE_BINOMIAL: { /* a gamma(r, rate e^-l) mixture of Poissons */
+      float lg = log_gamma_variate(sk, c, a);
+      return poisson_variate(sk, c + GAMMA_NDRAW, expf(lg + b));
+    }
+    case GJX_VON_MISES: { /* Best & Fisher (1979), fixed budget of tries (elements 2 t, 2 t + 1; the sign: the last one) */
+      if (b < 1e-6f) return a + 3.14159265f * (2.0f * bits_to_unit(elem_bits(sk, c)) - 1.0f);
+      double kd = b, tau = 1.0 + sqrt(1.0 + 4.0 * kd * kd), rho = (tau - sqrt(2.0 * tau)) / (2.0 * kd);
+      float r = (float)((1.0 + rho * rho) / (2.0 * rho));
+      float f = 1.0f;
+      for (int t = 0; t < VON_MISES_TRIES; ++t) {
+        float z = cosf(3.14159265f * bits_to_unit(elem_bits(sk, c + 2 * t)));
+        float u2 = uniform_from_bits(elem_bits(sk, c + 2 * t + 1), F32_TINY, 1.0f);
+        f = (r * z + 1.0f) / (r + z);
+        float cc = b * (r - f);
+        decide(u2, cc * (2.0f - cc));
+        if (u2 < cc * (2.0f - cc)) break;
+        decide(logf(cc / u2) + 1.0f - cc, 0.0f);
+        if (logf(cc / u2) + 1.0f - cc >= 0.0f) break;
+      }
+      float th = acosf(f < -1.0f ? -1.0f : (f > 1.0f ? 1.0f : f));
+      float us = bits_to_unit(elem_bits(sk, c + 2 * VON_MISES_TRIES));
+      decide(us, 0.5f);
+      return a + (us < 0.5f ? -th : th);
     }
     case GJX_CHI: return expf(0.5f * (0.69314718f + log_gamma_variate(sk, c, 0.5f * a)));
     case GJX_EXP_GAMMA: return log_gamma_variate(sk, c, a) - logf(b);
@@ -1480,6 +1526,8 @@ static void dlogpdf4(int kind, float x, float a, float b, float c, float d, floa
       *dx = (float)-w; g[0] = (float)(w + (wh - wl)); g[1] = (float)(w * z - 1.0 / b + (hi * wh - lo * wl)); g[2] = (float)wl; g[3] = (float)-wh;
       return;
     }
+    case GJX_NEGATIVE_BINOMIAL: { double p = 1.0 / (1.0 + exp(-(double)b)); g[0] = (float)(digamma_d((double)x + a) - digamma_d(a) - softplus_d(b)); g[1] = (float)(x * (1.0 - p) - a * p); return; }
+    case GJX_VON_MISES: { double sn = sin((double)x - a); *dx = (float)(-b * sn); g[0] = (float)(b * sn); g[1] = (float)(cos((double)x - a) - bessel_i1_over_i0_d(b)); return; }
     case GJX_CHI: *dx = (a - 1.0f) / x - x; g[0] = (float)(log((double)x) - 0.5 * 0.6931471805599453 - 0.5 * digamma_d(0.5 * a)); return;
     case GJX_EXP_GAMMA: { double e = exp((double)x); *dx = (float)(a - b * e); g[0] = (float)(log((double)b) + x - digamma_d(a)); g[1] = (float)(a / b - e); return; }
     case GJX_EXP_INVERSE_GAMMA: { double e = exp(-(double)x); *dx = (float)(b * e - a); g[0] = (float)(log((double)b) - x - digamma_d(a)); g[1] = (float)(a / b - e); return; }

@@ -87,7 +87,7 @@ python $R/profiles/microbench/pf_hand_timeline.py 2>/dev/null | grep -E " us|blo
 # one launch of the generated mixture kernel: prologue / sites / end per block
 python $R/profiles/microbench/gen_kernel_timeline.py 2>/dev/null | grep -E " us|blocks" > $OUT/${TAG}_gen_kernel_timeline.txt
 bash $R/profiles/microbench/pf_traffic.sh $TAG > /dev/null 2>&1     # filter kernels' HBM traffic, generated and hand-written, one size per pass
-python $R/profiles/microbench/sv_bias.py 64 > $OUT/${TAG}_sv_bias.txt 2>/dev/null
+python $R/profiles/microbench/sv_bias.py 256 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_sv_bias.txt
 bash $R/profiles/gputests.sh $TAG > /dev/null 2>&1; cp $OUT/gputest_summary.txt $OUT/${TAG}_gputest_summary.txt; rm -f $OUT/gputest_test_*.txt $OUT/gputest_summary.txt
 rm -rf $OUT/prof_*/ $OUT/pmc_*/
 ls $OUT

@@ -11,12 +11,13 @@ KIND = dict(normal=A.NORMAL, flip=A.FLIP, bernoulli_logits=A.BERNOULLI_LOGITS, b
             truncated_normal=A.TRUNCATED_NORMAL, poisson=A.POISSON, geometric=A.GEOMETRIC, dirichlet=A.DIRICHLET, gumbel=A.GUMBEL,
             half_cauchy=A.HALF_CAUCHY, inverse_gamma=A.INVERSE_GAMMA, weibull=A.WEIBULL, logit_normal=A.LOGIT_NORMAL, chi2=A.CHI2,
             chi=A.CHI, exp_gamma=A.EXP_GAMMA, exp_inverse_gamma=A.EXP_INVERSE_GAMMA, half_student_t=A.HALF_STUDENT_T, kumaraswamy=A.KUMARASWAMY,
-            moyal=A.MOYAL, truncated_cauchy=A.TRUNCATED_CAUCHY, double_sided_maxwell=A.DOUBLESIDED_MAXWELL, inverse_gaussian=A.INVERSE_GAUSSIAN)
+            moyal=A.MOYAL, truncated_cauchy=A.TRUNCATED_CAUCHY, double_sided_maxwell=A.DOUBLESIDED_MAXWELL, inverse_gaussian=A.INVERSE_GAUSSIAN,
+            negative_binomial=A.NEGATIVE_BINOMIAL, von_mises=A.VON_MISES)
 NPAR = dict(normal=2, flip=1, bernoulli_logits=1, beta=2, uniform=2, exponential=1, half_normal=1, laplace=2,
             log_normal=2, cauchy=2, gamma=2, mv_normal_diag=2, student_t=3, truncated_normal=4, poisson=1, geometric=1,
             dirichlet=1, gumbel=2, half_cauchy=2, inverse_gamma=2, weibull=2, logit_normal=2, chi2=1,
             chi=1, exp_gamma=2, exp_inverse_gamma=2, half_student_t=3, kumaraswamy=2, moyal=2, truncated_cauchy=4, double_sided_maxwell=2,
-            inverse_gaussian=2)
+            inverse_gaussian=2, negative_binomial=2, von_mises=2)
 
 
 def one_site(kind: str, a, b=None, obs=None, rng=A.RNG_FLAT, c=None, d=None):
@@ -127,6 +128,11 @@ def zoo3(rng=A.RNG_FLAT, observed=()):
     sl.add("tc2", A.TRUNCATED_CAUCHY, [Param.value("mo", xf=A.XF_SIGMOID), Param.value("ch"), -1.0, 4.0])
     sl.add("dm2", A.DOUBLESIDED_MAXWELL, [Param.value("tc"), Param.value("ku", xf=A.XF_EXP)])
     sl.add("ig2", A.INVERSE_GAUSSIAN, [Param.value("ch"), Param.value("eg", xf=A.XF_EXP)])
+    sl.add("nb", A.NEGATIVE_BINOMIAL, [4.5, 0.3])
+    sl.add("vm", A.VON_MISES, [0.7, 2.5])
+    sl.add("vs", A.VON_MISES, [-0.4, 0.3])                                                     # (small concentration: nearly uniform)
+    sl.add("vb", A.VON_MISES, [Param.value("mo", xf=A.XF_SIGMOID), Param.value("ch", xf=A.XF_EXP)])   # (concentration up to exp(3))
+    sl.add("nb2", A.NEGATIVE_BINOMIAL, [Param.value("ch"), Param.value("vm")])
     sl.add("n9", A.NORMAL, [Param.value("ig2", xf=A.XF_SIGMOID), 0.3])
     obs_vals = dict(n9=0.4, ku=0.35, mo=0.9, ig=1.1)
     modes = {a: A.MODE_OBS_TAB for a in observed}

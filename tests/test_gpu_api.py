@@ -680,7 +680,8 @@ class TestWiderDistributions:
             (genjax.logit_normal, (0.0, 1.0)), (genjax.chi2, (5.0,)), (genjax.gamma, (2.0, 1.5)), (genjax.exponential, (1.5,)),
             (genjax.chi, (3.0,)), (genjax.exp_gamma, (2.5, 1.5)), (genjax.exp_inverse_gamma, (3.0, 2.0)), (genjax.half_student_t, (5.0, 0.5, 1.5)),
             (genjax.kumaraswamy, (2.0, 3.0)), (genjax.moyal, (0.3, 0.8)), (genjax.truncated_cauchy, (0.2, 1.5, -2.0, 3.0)),
-            (genjax.double_sided_maxwell, (0.4, 0.7)), (genjax.inverse_gaussian, (1.5, 4.0)),
+            (genjax.double_sided_maxwell, (0.4, 0.7)), (genjax.inverse_gaussian, (1.5, 4.0)), (genjax.negative_binomial, (4.5, 0.3)),
+            (genjax.von_mises, (0.7, 2.5)),
         ]
         for i, (dist, args) in enumerate(cases):
             tr = dist.simulate(genjax.key(10 + i), args)

@@ -149,7 +149,7 @@ def test_zoo3_gradient_parity(K_, oracle):
     gjx_score_grad; and an HMC move over all of them runs on a generated kernel with the oracle's alpha"""
     import torch
     sl = H.zoo3().site_list
-    cont = tuple(s.addr for s in sl.sites)
+    cont = tuple(s.addr for s in sl.sites if s.kind not in A.NO_GRADIENT_KINDS)
     prog = PackedProgram(sl, {s.addr: A.MODE_OBS_SLOT for s in sl.sites}, selected=cont)
     base = oracle.run_program(H.zoo3(), (9, 9), 512)["choices"].astype(np.float32)
     sg, gg = K_.score_grad(prog, torch.as_tensor(base).cuda())
@@ -1144,7 +1144,8 @@ def _random_program(rs, rng_mode):
         A.HALF_CAUCHY: (REAL, POS), A.INVERSE_GAMMA: (POS, POS), A.WEIBULL: (POS, POS), A.LOGIT_NORMAL: (REAL, POS), A.CHI2: (POS,),
         A.MVNORMAL_DIAG: (REAL, POS),
         A.CHI: (POS,), A.EXP_GAMMA: (POS, POS), A.EXP_INVERSE_GAMMA: (POS, POS), A.HALF_STUDENT_T: (POS, REAL, POS), A.KUMARASWAMY: (POS, POS),
-        A.MOYAL: (REAL, POS), A.DOUBLESIDED_MAXWELL: (REAL, POS), A.INVERSE_GAUSSIAN: (POS, POS),
+        A.MOYAL: (REAL, POS), A.DOUBLESIDED_MAXWELL: (REAL, POS), A.INVERSE_GAUSSIAN: (POS, POS), A.NEGATIVE_BINOMIAL: (POS, REAL),
+        A.VON_MISES: (REAL, POS),
     }
     kinds = [k for k in spec if spec[k] is not None]
     sl = SiteList()

@@ -759,3 +759,31 @@ def test_tracing_of_inline_methods_closures_and_scan_lengths():
         return acc + genjax.normal(v, 1.0) @ "n"
 
     assert addrs(add.accumulate(), (0.0, xs)) == [("n", 0), ("n", 1), ("n", 2)] == addrs(add.reduce(), (0.0, xs))
+
+
+def test_round6_distribution_wrappers_follow_the_tfp_signatures():
+    """negative_binomial(total_count, logits) — a bare second argument is LOGITS, probs= is folded to logits on the host (the
+    reference passes tfd.NegativeBinomial through unwrapped, tensorflow_probability/__init__.py:249) — and the two-parameter forms of
+    the other round-6 wrappers"""
+    import genjax_amd as genjax
+    from genjax_amd import _abi as A
+
+    @genjax.gen
+    def m():
+        r = genjax.gamma(2.0, 1.0) @ "r"
+        genjax.negative_binomial(r, probs=0.57) @ "k"
+        genjax.negative_binomial(3.0, 0.2) @ "k2"
+        genjax.negative_binomial(total_count=3.0, logits=r) @ "k3"
+        genjax.von_mises(0.1, r) @ "th"
+        genjax.half_student_t(4.0, 0.0, r) @ "h"
+        genjax.truncated_cauchy(0.0, 1.0, -2.0, r) @ "tc"
+
+    sl, _ = m.site_list(())
+    assert sl["k"].kind == A.NEGATIVE_BINOMIAL and sl["k"].params[0].src == "r"
+    np.testing.assert_allclose(sl["k"].params[1].values, [np.log(0.57 / 0.43)], rtol=1e-6)
+    np.testing.assert_allclose(sl["k2"].params[1].values, [0.2])
+    assert sl["k3"].params[1].src == "r" and sl["th"].kind == A.VON_MISES and sl["th"].params[1].src == "r"
+    assert len(sl["h"].params) == 3 and len(sl["tc"].params) == 4 and sl["tc"].params[3].src == "r"
+    with pytest.raises(TypeError):
+        genjax.negative_binomial(3.0) @ "x"
+    assert A.NEGATIVE_BINOMIAL in A.NO_GRADIENT_KINDS and A.VON_MISES not in A.NO_GRADIENT_KINDS and A.KIND_MAX == 37

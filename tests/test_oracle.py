@@ -613,6 +613,24 @@ def test_round6_distributions_match_scipy(oracle, rng):
     np.testing.assert_allclose(ss[idx["mo2"]], st.moyal.logpdf(v["mo2"], v["dm"], sp(v["ku"])), rtol=1e-4, atol=2e-4)
     np.testing.assert_allclose(ss[idx["ig2"]], st.invgauss.logpdf(v["ig2"], v["ch"] / np.exp(v["eg"]), scale=np.exp(v["eg"])), rtol=2e-4, atol=5e-4)
     np.testing.assert_allclose(ss[idx["hs2"]], math.log(2.0) + st.t.logpdf(v["hs2"], sp(v["ch"]), v["mo"], v["ig"]), rtol=1e-4, atol=2e-4)
+    # negative_binomial(total_count, logits) and von_mises(loc, concentration) (scipy: nbinom counts FAILURES before n successes with
+    # success probability p: our "successes before r failures with success probability sigmoid(l)" is nbinom(r, 1 - sigmoid(l)))
+    p_ = 1.0 / (1.0 + math.exp(-0.3))
+    nb = st.nbinom(4.5, 1.0 - p_)
+    assert (v["nb"] == np.floor(v["nb"])).all() and (v["nb"] >= 0).all()
+    assert abs(v["nb"].mean() - nb.mean()) < 5.0 * nb.std() / math.sqrt(K) and abs(v["nb"].var() / nb.var() - 1.0) < 0.05
+    cnt = np.bincount(v["nb"].astype(np.int64), minlength=40)[:40]
+    assert np.abs(cnt / K - nb.pmf(np.arange(40))).max() < 4.5 * math.sqrt(0.25 / K)
+    np.testing.assert_allclose(ss[idx["nb"]], nb.logpmf(v["nb"]), rtol=2e-5, atol=2e-5)
+    wrap = lambda t: (t + np.pi) % (2 * np.pi) - np.pi
+    for a_, (mu_, kap_) in dict(vm=(0.7, 2.5), vs=(-0.4, 0.3)).items():
+        d_ = wrap(v[a_] - mu_)
+        assert (np.abs(v[a_] - mu_) <= np.pi + 1e-6).all()
+        assert ks(d_, st.vonmises(kap_).cdf) < tol, a_
+        np.testing.assert_allclose(ss[idx[a_]], st.vonmises.logpdf(v[a_], kap_, loc=mu_), rtol=2e-5, atol=2e-5, err_msg=a_)
+    sg = lambda x: 1.0 / (1.0 + np.exp(-x))
+    np.testing.assert_allclose(ss[idx["vb"]], st.vonmises.logpdf(v["vb"], np.exp(v["ch"]), loc=sg(v["mo"])), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ss[idx["nb2"]], st.nbinom.logpmf(v["nb2"], v["ch"], 1.0 - sg(v["vm"])), rtol=2e-4, atol=5e-4)
     assert (v["hs2"] >= v["mo"]).all() and (v["tc2"] >= -1.0).all() and (v["tc2"] <= 4.0).all() and (v["ku2"] > 0).all() and (v["ku2"] <= 1).all()
 
 
