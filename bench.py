@@ -355,7 +355,7 @@ def run_gmm(args, rank, world, dev):
     # HBM bytes per launch from the PMC counters are NOT measured in this run (counters need their own rocprofv3 passes):
     # `traffic` stays null and the figure of the committed counter run is reported beside it, labelled as such
     traffic_prof = None
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         tp = os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")   # FETCH_SIZE x 2 + WRITE_SIZE per launch (profiles/README.md)
         if os.path.exists(tp):                                           # keys: rocprofv3 kernel names without "void " and blanks
             want = "gjx::k_run_gmm_flat<%d,4,256," % D

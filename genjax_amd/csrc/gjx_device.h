@@ -628,7 +628,9 @@ GJX_DEV float elem_logpdf(int kind, float x, float a, float b, float c = 0.0f, f
     }
     case GJX_NEGATIVE_BINOMIAL: {  // a = total_count r, b = logits l of the success probability: C(x + r - 1, x) p^x (1 - p)^r
       if (x < 0.0f || x != floorf(x)) return -INFINITY;
-      return lgammaf(x + a) - lgammaf(x + 1.0f) - lgammaf(a) - (x == 0.0f ? 0.0f : x * softplus(-b)) - a * softplus(b);
+      // log C(x + r - 1, x) = lgamma(hi + lo - 1) - lgamma(hi) - lgamma(lo), {hi, lo} = {r, x + 1}: the two large values cancel inside lgamma_step
+      const float hi = fmaxf(a, x + 1.0f), lo = fminf(a, x + 1.0f);
+      return lgamma_step(hi, lo - 1.0f) - lgammaf(lo) - (x == 0.0f ? 0.0f : x * softplus(-b)) - a * softplus(b);
     }
     case GJX_VON_MISES: {  // a = loc, b = concentration: exp(k cos(x - loc)) / (2 pi I0(k)), with I0(k) = e^k i0e(k)
       return b * (cosf(x - a) - 1.0f) - 1.83787707f - fast_log(bessel_i0e(b));
@@ -866,8 +868,9 @@ GJX_DEV float elem_sample(int kind, BS& bs, uint32_t c, float a, float b, float 
     case GJX_INVERSE_GAUSSIAN: {  // Michael, Schucany & Haas (1976): a = mean, b = concentration
       const float n = stream_normal<RNG>(bs, c);
       const float y = n * n;
-      const float m2 = a * fast_rcp(2.0f * b);                                   // mu / (2 lambda)
-      const float x1 = a + m2 * (a * y - sqrtf(fmaf(a * y, a * y, 4.0f * a * b * y)));
+      // the smaller root mu (1 + w - sqrt(w (w + 2))), w = mu y / (2 lambda), in the form without the cancellation: (1 + w)^2 - w (w + 2) = 1
+      const float w = a * y * fast_rcp(2.0f * b);
+      const float x1 = a * fast_rcp(1.0f + w + sqrtf(w * (w + 2.0f)));
       const float u = bits_to_unit(bs.get(c + 2));
       return u * (a + x1) <= a ? x1 : a * a * fast_rcp(x1);
     }

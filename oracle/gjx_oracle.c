@@ -686,7 +686,8 @@ static float elem_sample4(int kind, const ostream* sk, uint32_t c, float a, floa
     case GJX_INVERSE_GAUSSIAN: { /* Michael, Schucany & Haas (1976): a = mean, b = concentration */
       float n = stream_normal(sk, c);
       float y = n * n;
-      float x1 = a + (a / (2.0f * b)) * (a * y - sqrtf(a * y * a * y + 4.0f * a * b * y));
+      float w = a * y / (2.0f * b);                          /* the smaller root mu (1 + w - sqrt(w (w + 2))) without its cancellation */
+      float x1 = a / (1.0f + w + sqrtf(w * (w + 2.0f)));
       float u = bits_to_unit(elem_bits(sk, c + 2));
       decide(u * (a + x1), a);
       return u * (a + x1) <= a ? x1 : a * a / x1;

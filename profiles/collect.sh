@@ -21,13 +21,15 @@ if echo $WL | grep -q gmm; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_extra -o extra -- python $R/bench.py --no-cpu-baseline --extra --extra-file /tmp/bench_extra_prof.json --steps 20 --warmup 1 > $OUT/prof_extra.log 2>&1
   cp $(find $OUT/prof_extra -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_gmm_with_extras_kernel_stats.csv
 fi
-# PMC passes for the default bench (counters only: no tracing domains alongside --pmc); FETCH_SIZE and WRITE_SIZE in separate passes
+# PMC passes for the default bench (counters only: no tracing domains alongside --pmc); FETCH_SIZE and WRITE_SIZE in separate passes.
+# Every pass under its own timeout: in the round-6 re-collection one counter pass died inside the tool at its first dispatch (SIGSEGV in
+# rocprofv3's dispatch interception) and the next one hung for 58 minutes with "1838 incomplete dispatches" until the call's limit.
 if echo $WL | grep -q gmm; then
   CMD="python $R/bench.py --no-cpu-baseline --extra --extra-file /tmp/bench_extra_pmc.json --steps 20 --warmup 3 --event-samples 2"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
-  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_sq2 -o pmc -- $CMD > $OUT/pmc_sq2.log 2>&1
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
+  timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
+  timeout 900 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_sq2 -o pmc -- $CMD > $OUT/pmc_sq2.log 2>&1
   python - <<PY
 import csv, glob, collections, json
 res = collections.defaultdict(dict)

@@ -15,13 +15,14 @@ from genjax_amd.program import PackedProgram     # noqa: E402
 from oracle import cpu as oracle                 # noqa: E402
 
 seed, rng, want = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+K_PART = int(os.environ.get("FUZZ_K", "600"))
 rs = np.random.default_rng(seed + rng)
-K = 600
+K = K_PART
 for trial in range(want + 1):
     sl = P._random_program(rs, rng)
     key = (int(rs.integers(1 << 30)), int(rs.integers(1 << 30)))
+    subdraw = [rs.random() for _ in sl.sites]
     if trial < want:
-        [rs.random() for _ in sl.sites]
         continue
     os.environ["GJX_ENGINE"] = "interp" if trial & 1 else ""
     if not (trial & 1):
@@ -44,3 +45,19 @@ for trial in range(want + 1):
         print("  dev score", gs[i], "ora score", o["score"][i])
         print("  dev site scores", g["site_scores"].cpu().numpy()[:, i])
         print("  ora site scores", o["site_scores"][:, i])
+
+    # the second half of the test: a random subset of sites constrained to the oracle's own draws, site scores compared
+    sub = [s_.addr for s_, u in zip(sl.sites, subdraw) if u < 0.5]
+    if sub:
+        prog2 = PackedProgram(sl, {a: A.MODE_OBS_SLOT for a in sub}, rng_mode=rng)
+        ch = o["choices"].copy()
+        g2 = K_.run_program(prog2, key, K, choices=torch.as_tensor(ch).cuda(), want_site_scores=True)
+        o2 = oracle.run_program(prog2, key, K, choices=ch.copy(), want_site_scores=True)
+        idx = [j for j, s_ in enumerate(sl.sites) if s_.addr in sub]
+        gs, os_ = g2["site_scores"].cpu().numpy()[idx], o2["site_scores"][idx]
+        with np.errstate(invalid="ignore"):
+            off = ~(np.abs(gs - os_) <= 2e-3 + 2e-3 * np.abs(os_)) & np.isfinite(os_) & (np.abs(os_) < 1e4)
+        for r, i in zip(*np.nonzero(off)):
+            s_ = sl.sites[idx[r]]
+            print("constrained site", s_.addr, A.KIND_NAMES[s_.kind], "particle", i, "dev", gs[r, i], "ora", os_[r, i], "value", ch[prog2.slot_of[s_.addr], i])
+            print("   all choices of the particle", ch[:, i])

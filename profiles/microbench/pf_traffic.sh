@@ -18,8 +18,8 @@ for i in range(6):
 torch.cuda.synchronize()
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pf_gen_$c -o pmc -- python $R/profiles/microbench/scan_filter_run.py > /dev/null 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pf_hand_$c -o pmc -- python /tmp/pf_hand_run.py > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pf_gen_$c -o pmc -- python $R/profiles/microbench/scan_filter_run.py > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pf_hand_$c -o pmc -- python /tmp/pf_hand_run.py > /dev/null 2>&1
 done
 python - <<PY
 import csv, glob, collections, json

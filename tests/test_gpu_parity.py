@@ -1290,6 +1290,12 @@ def test_random_programs_against_oracle(K_, oracle, rng, monkeypatch):
         idx = [j for j, s in enumerate(sl.sites) if s.addr in sub]
         gs, os_ = _np(g2["site_scores"])[idx], o2["site_scores"][idx]
         good = np.isfinite(os_) & (np.abs(os_) < 1e4) & fin[None, :]
+        # conditioning of the SITE score (the probe above holds the particle's total score, which a large neighbour can dominate): an
+        # element the oracle itself moves by a good part of the tolerance when the continuous inputs move by a few ulps — exp_gamma at a
+        # concentration of 1e5 and a value of 20: a (log b + x) - b e^x - lgamma(a) = 9.35 from terms of 1e6 — is not a parity question
+        os_p = oracle.run_program(prog2, key, K, choices=ch_p.copy(), want_site_scores=True)["site_scores"][idx]
+        with np.errstate(invalid="ignore"):
+            good &= np.abs(os_p - os_) <= 5e-4 + 5e-4 * np.abs(os_)
         if loose:
             with np.errstate(invalid="ignore"):
                 off = ~(np.abs(gs - os_) <= 2e-3 + 2e-3 * np.abs(os_)) & good
