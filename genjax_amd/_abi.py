@@ -191,6 +191,7 @@ PROTOTYPES = {
     "gjx_program_filter_source": (i64, [PP, i32, C.c_char_p, i64]),
     "gjx_program_filter_precompile": (C.c_int, [PP, i32]),
     "gjx_resample_indices_tiled": (C.c_int, [vp, i64, f64, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "gjx_mh_accept": (C.c_int, [vp, i64, u32, u32, vp, vp, i64, i32, vp, vp, vp]),
     "gjx_resample_sorted_multinomial_tiled": (C.c_int, [vp, i64, u32, u32, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_ssm_filter_sharded": (C.c_int, [C.POINTER(GjxSsm), u32, u32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "gjx_shard_ctx_shape": (C.c_int, [vp, vp]),

@@ -114,6 +114,36 @@ __global__ __launch_bounds__(256) void k_threefry(key2 key, uint32_t ctr_hi, uin
 }
 }  // namespace gjx
 
+namespace gjx {
+__global__ __launch_bounds__(256) void k_mh_accept(const float* __restrict__ log_alpha, int64_t K, key2 key, float* rows_cur, const float* __restrict__ rows_prop,
+                                                   int64_t stride, int rows, float* accepted, unsigned long long* total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool acc = false;
+  if (i < K) {
+    const key2 h = threefry2x32(key, (uint32_t)((uint64_t)i >> 32), (uint32_t)i);
+    const float lu = safe_log(uniform_from_bits(h.a ^ h.b, kTiny, 1.0f));
+    acc = lu < log_alpha[i];                      // (NaN: false)
+    if (acc)
+      for (int r = 0; r < rows; ++r) rows_cur[(int64_t)r * stride + i] = rows_prop[(int64_t)r * stride + i];
+    if (accepted) accepted[i] = acc ? 1.0f : 0.0f;
+  }
+  if (total) {
+    const unsigned long long m = __ballot(acc);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+  }
+}
+}  // namespace gjx
+
+extern "C" int gjx_mh_accept(const float* log_alpha, int64_t K, uint32_t key0, uint32_t key1, float* rows_cur, const float* rows_prop,
+                             int64_t row_stride, int32_t rows, float* accepted, void* accepted_total, void* stream) {
+  if (!log_alpha || K < 0 || rows < 0 || (rows > 0 && (!rows_cur || !rows_prop || row_stride < K))) return gjx_fail(GJX_EINVAL, "gjx_mh_accept: bad argument");
+  if (K == 0) return GJX_OK;
+  hipLaunchKernelGGL(gjx::k_mh_accept, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_alpha, K, gjx::key2{key0, key1},
+                     rows_cur, rows_prop, row_stride, (int)rows, accepted, (unsigned long long*)accepted_total);
+  GJX_CHECK_LAUNCH("gjx_mh_accept");
+  return GJX_OK;
+}
+
 extern "C" int gjx_threefry2x32(uint32_t key0, uint32_t key1, uint32_t ctr_hi, uint32_t ctr_lo0, int64_t n,
                                 uint32_t* out_dev, void* stream) {
   if (n < 0 || (n > 0 && !out_dev)) return gjx_fail(GJX_EINVAL, "gjx_threefry2x32: bad argument");

@@ -19,7 +19,8 @@ which the filter's particles are distributed as at that point, so any pi-invaria
     (rejuvenate.py:70-94).
 
 Everything that computes is a call of the HIP library (gjx_run_program_ex, gjx_hmc, gjx_gather_rows, the tile-scaled resamplers,
-gjx_threefry2x32); the accept's compare-and-select is elementwise plumbing.  Without moves the loop reproduces gjx_scan_filter bit
+gjx_mh_accept: the reference's caller-side accept as a device call); what the host adds are the row copies between the calls and the
+four-term sum of the acceptance ratio.  Without moves the loop reproduces gjx_scan_filter bit
 for bit (same step keys, comb offsets / resampling keys, resamplers): tests/test_gpu_filter_moves.py holds it to that, and holds every
 move step-locally to the same composition over the oracle.
 """
@@ -74,11 +75,11 @@ class DeviceBackend:
         from .. import kernels
         return kernels.hmc(prog, key, rows, eps, L, stale=False, accept=True)
 
-    def log_uniform(self, key: Key, K: int):
-        """log of K uniforms in (0, 1): the top 23 bits of the first word of Threefry(key, (0, i)), centred"""
+    def accept(self, log_alpha, key: Key, rows_cur, rows_prop):
+        """gjx_mh_accept: the caller-side accept (log u < alpha) in place on rows_cur; -> accepted chains (a device scalar: the run
+        reads its counters once, at its end)"""
         from .. import kernels
-        bits = kernels.threefry2x32(key, K, device=self.dev)[:, 0].to(torch.int64) & 0xFFFFFFFF
-        return torch.log(((bits >> 9).to(torch.float32) + 0.5) * np.float32(2.0 ** -23))
+        return kernels.mh_accept(log_alpha, key, rows_cur, rows_prop).sum()
 
     def empty(self, rows: int, K: int):
         return torch.empty((max(rows, 1), K), dtype=torch.float32, device=self.dev)
@@ -86,11 +87,8 @@ class DeviceBackend:
     def clone(self, x):
         return x.clone()
 
-    def select(self, mask, a, b):
-        return torch.where(mask, a, b)
-
     def count(self, mask):
-        return mask.sum()                    # (a device scalar: the run reads the counters once, at its end)
+        return mask.sum()
 
 
 def target_program(step_prog: PackedProgram, selected=(), rng_mode=None) -> PackedProgram:
@@ -167,9 +165,8 @@ def apply_proposal(b, target: PackedProgram, addr, progs_q, key: Key, R, K: int)
     Rn[s0:s0 + d] = new
     lp_new = b.run(target, k_draw, K, Rn)["score"]
     alpha = (lp_new - lp_old) + (bwd - fwd)
-    acc = b.log_uniform(k_acc, K) < alpha
-    R[s0:s0 + d] = b.select(acc, new, old)
-    return R, b.count(acc)
+    na = b.accept(alpha, k_acc, R[s0:s0 + d], new)
+    return R, na
 
 
 def step_rows(prog: PackedProgram):

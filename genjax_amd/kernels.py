@@ -910,6 +910,19 @@ def hmc(prog: PackedProgram, key, choices: torch.Tensor, eps: float, L: int, sta
     return dict(choices=choices, score=score, alpha=alpha, accepted=acc, _ws=ws)
 
 
+def mh_accept(log_alpha: torch.Tensor, key, rows_cur: torch.Tensor, rows_prop: torch.Tensor, accepted=None, total=None):
+    """gjx_mh_accept: the caller-side accept of the reference's move requests (log u < alpha) in place on rows_cur f32[rows][K];
+    ``total``: an int64[1] device counter that receives the number of accepted chains.  -> accepted f32[K] (1 / 0)"""
+    K = log_alpha.numel()
+    if rows_cur.shape != rows_prop.shape or rows_cur.shape[-1] != K or rows_cur.stride(-1) != 1 or rows_prop.stride(-1) != 1 or rows_cur.stride(0) != rows_prop.stride(0):
+        raise ValueError("mh_accept: rows_cur / rows_prop must be f32[rows][K] of one layout")
+    if accepted is None:
+        accepted = torch.empty(K, dtype=torch.float32, device=log_alpha.device)
+    check(load().gjx_mh_accept(_ptr(log_alpha), K, key[0], key[1], _ptr(rows_cur), _ptr(rows_prop), rows_cur.stride(0), rows_cur.shape[0],
+                               _ptr(accepted), _ptr(total), _stream()), "gjx_mh_accept")
+    return accepted
+
+
 def hmc_engine(prog: PackedProgram) -> int:
     cp = prog.c_program(None)
     return int(load().gjx_hmc_engine(C.byref(cp)))

@@ -1016,6 +1016,13 @@ int gjx_hmc(const gjx_program* prog, uint32_t key0, uint32_t key1, int64_t n, in
             float eps, int32_t L, int32_t stale_grad_compat, int32_t accept, float* choices,
             float* score, float* alpha, float* accepted, void* workspace, size_t workspace_bytes,
             void* stream);
+/* The caller-side Metropolis-Hastings accept of the reference's move requests — `log(uniform(key)) < w` behind Rejuvenate.edit / HMC.edit
+ * (tests/inference/test_requests.py:131-137) — as a device call: chain i draws log u_i from the bits x0 ^ x1 of Threefry(key, (i >> 32, i))
+ * (23 bits, u in [tiny, 1)), and where log u_i < log_alpha[i] it takes the proposal: rows_cur[r][i] = rows_prop[r][i] for r < rows
+ * (row_stride in floats, both arrays).  A NaN log_alpha never accepts.  accepted f32[K] receives 1 / 0 (or NULL); accepted_total, a u64
+ * on the device, is incremented by the number of accepted chains (or NULL). */
+int gjx_mh_accept(const float* log_alpha, int64_t K, uint32_t key0, uint32_t key1, float* rows_cur, const float* rows_prop,
+                  int64_t row_stride, int32_t rows, float* accepted, void* accepted_total, void* stream);
 /* d score / d choices for the selected slots: selection_gradient (hmc.py:70-96).
  * grad f32[n_slots][n] (rows of unselected slots are written as 0). */
 int gjx_score_grad(const gjx_program* prog, int64_t n, const float* choices, float* score,

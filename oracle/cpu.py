@@ -79,6 +79,8 @@ def _bind(L):
     L.gjxo_resample_multinomial.argtypes = [vp, i64, u64, u64, u32, u32, i64, i64, i64, vp]
     L.gjxo_resample_systematic_tiled.argtypes = [vp, i64, f64, i64, vp, vp, vp, vp]
     L.gjxo_resample_sorted_multinomial_tiled.argtypes = [vp, i64, u32, u32, i64, vp, vp]
+    L.gjxo_mh_accept.argtypes = [vp, i64, u32, u32, vp, vp, i64, i32, vp]
+    L.gjxo_mh_accept.restype = C.c_int64
     L.gjxo_exp_spacing.argtypes = [u32]
     L.gjxo_exp_spacing.restype = C.c_uint64
     L.gjxo_gather_rows.argtypes = [vp, i64, vp, i64, i32, vp, i64]
@@ -221,6 +223,22 @@ def resample_sorted_multinomial_tiled(logw, key, N=None, q=None):
     qi = None if q is None else np.ascontiguousarray(q, np.uint32)
     rc = lib().gjxo_resample_sorted_multinomial_tiled(_p(logw), K, key[0], key[1], N, _p(qi), _p(anc))
     return anc, bool(rc)
+
+
+def mh_accept(log_alpha, key, rows_cur, rows_prop):
+    """gjx_mh_accept: -> (rows after the accept f32[rows][K], accepted f32[K], margin f32[K] = |log u - alpha| of every chain)"""
+    la = np.ascontiguousarray(log_alpha, np.float32)
+    K = la.size
+    cur = np.ascontiguousarray(rows_cur, np.float32).copy().reshape(-1, K)
+    prop = np.ascontiguousarray(rows_prop, np.float32).reshape(-1, K)
+    acc = np.zeros(K, np.float32)
+    margin = np.full(K, 3.0e38, np.float32)
+    lib().gjxo_set_margin_buffer(_p(margin), K)
+    try:
+        lib().gjxo_mh_accept(_p(la), K, key[0], key[1], _p(cur), _p(prop), K, cur.shape[0], _p(acc))
+    finally:
+        lib().gjxo_set_margin_buffer(None, 0)
+    return cur, acc, margin
 
 
 def exp_spacing(word: int) -> int:

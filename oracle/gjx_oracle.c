@@ -1324,6 +1324,25 @@ int gjxo_resample_sorted_multinomial_tiled(const float* logw, int64_t K, uint32_
   return rc;
 }
 
+/* gjx_mh_accept (include/gjx.h): the caller-side accept of tests/inference/test_requests.py:131-137.  -> accepted chains; the decision
+ * margin |log u - alpha| of every chain goes to the margin buffer (gjxo_set_margin_buffer) */
+int64_t gjxo_mh_accept(const float* log_alpha, int64_t K, uint32_t key0, uint32_t key1, float* rows_cur, const float* rows_prop,
+                       int64_t row_stride, int32_t rows, float* accepted) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < K; ++i) {
+    uint32_t o[2];
+    gjxo_threefry2x32(key0, key1, (uint32_t)((uint64_t)i >> 32), (uint32_t)i, o);
+    float lu = logf(uniform_from_bits(o[0] ^ o[1], F32_TINY, 1.0f));
+    int acc = lu < log_alpha[i];
+    if (g_margin_buf && i < g_margin_n) g_margin_buf[i] = fabsf(lu - log_alpha[i]);
+    if (acc)
+      for (int r = 0; r < rows; ++r) rows_cur[(int64_t)r * row_stride + i] = rows_prop[(int64_t)r * row_stride + i];
+    if (accepted) accepted[i] = (float)acc;
+    n += acc;
+  }
+  return n;
+}
+
 int gjxo_resample_multinomial(const uint64_t* cum, int64_t K, uint64_t base, uint64_t total_all,
                               uint32_t key0, uint32_t key1, int64_t N_total, int64_t out_begin,
                               int64_t n_out, int32_t* ancestors) {

@@ -45,19 +45,17 @@ class OracleBackend:
         from oracle import cpu
         return cpu.hmc(prog, key, rows, eps, L, accept=True)
 
-    def log_uniform(self, key, K):
-        from genjax_amd import kernels
-        bits = _np(kernels.threefry2x32(key, K))[:, 0].astype(np.int64) & 0xFFFFFFFF       # (the hash is bit-exact by its own tests)
-        return np.log(((bits >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)).astype(np.float32)
+    def accept(self, log_alpha, key, rows_cur, rows_prop):
+        from oracle import cpu
+        new, acc, _ = cpu.mh_accept(log_alpha, key, rows_cur, rows_prop)
+        rows_cur[...] = new
+        return int(acc.sum())
 
     def empty(self, rows, K):
         return np.zeros((max(rows, 1), K), np.float32)
 
     def clone(self, x):
         return np.array(x, np.float32)
-
-    def select(self, m, a, b):
-        return np.where(m, a, b)
 
     def count(self, m):
         return int(np.sum(m))
@@ -223,6 +221,35 @@ def test_one_hmc_move_runs_inside_the_library_loop_and_equals_the_step_by_step_f
     b2 = run_with_moves(bf, genjax.key(21), C["y"].set(ys2), (carry0, None), mv)
     np.testing.assert_array_equal(_np(a2["logw"]), _np(b2["logw"]))
     assert float(a2["log_ml"]) != float(a["log_ml"])
+
+
+def test_mh_accept_against_the_oracle():
+    """gjx_mh_accept — the caller-side accept of the reference's move requests as a device call: the same chains accept as in the
+    oracle (a flip only where |log u - alpha| is at the last bit of a float32 log), accepted rows are the proposal's, the others
+    untouched, NaN never accepts, the counter counts"""
+    import torch
+    from genjax_amd import kernels
+    from oracle import cpu
+    rs = np.random.default_rng(3)
+    for K, rows in ((1, 1), (77, 3), (100_003, 5)):
+        al = (rs.standard_normal(K) * 2.0 - 0.7).astype(np.float32)
+        al[rs.random(K) < 0.01] = np.nan
+        al[rs.random(K) < 0.01] = np.inf
+        cur = rs.standard_normal((rows, K)).astype(np.float32)
+        prop = rs.standard_normal((rows, K)).astype(np.float32)
+        want, acc_o, margin = cpu.mh_accept(al, (5, K), cur, prop)
+        c = torch.as_tensor(cur).cuda()
+        tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+        acc = _np(kernels.mh_accept(torch.as_tensor(al).cuda(), (5, K), c, torch.as_tensor(prop).cuda(), total=tot))
+        flip = acc != acc_o
+        assert flip.sum() <= 2 and (margin[flip] < 1e-5).all(), (flip.sum(), margin[flip])
+        got = _np(c)
+        np.testing.assert_array_equal(got[:, ~flip], want[:, ~flip])
+        np.testing.assert_array_equal(got[:, acc > 0.5], prop[:, acc > 0.5])
+        np.testing.assert_array_equal(got[:, acc < 0.5], cur[:, acc < 0.5])
+        assert int(tot.item()) == int(acc.sum()) and not acc[np.isnan(al)].any() and acc[np.isposinf(al)].all()
+        if K > 1000:
+            assert abs(acc.mean() - acc_o.mean()) < 1e-4 and 0.2 < acc.mean() < 0.6
 
 
 def test_moves_argument_is_checked():

@@ -766,3 +766,25 @@ def test_scalar_normal_run_is_the_stream_of_a_vector_site_at_its_head_oracle():
     ja = cpu.run_program(PackedProgram(a, modes, obs, rng_mode=A.RNG_JAX32), (0, 5), K)["choices"]
     jb = cpu.run_program(PackedProgram(b, rng_mode=A.RNG_JAX32), (0, 5), K)["choices"]
     assert not np.array_equal(ja[1:], jb[1:])
+
+
+def test_mh_accept_is_the_callers_rule(oracle):
+    """gjxo_mh_accept (the oracle of gjx_mh_accept; tests/inference/test_requests.py:131-137: log(uniform(key)) < w): the accept rate
+    of a chain with log-ratio a is min(1, e^a); accepted chains take the proposal's rows, the others keep theirs; NaN never accepts"""
+    K = 200_000
+    for a in (-2.0, -0.3, 0.0, 1.5):
+        al = np.full(K, a, np.float32)
+        cur, prop = np.zeros((2, K), np.float32), np.ones((2, K), np.float32)
+        new, acc, margin = oracle.mh_accept(al, (7, 11), cur, prop)
+        p = min(1.0, math.exp(a))
+        assert abs(acc.mean() - p) < 5.0 * math.sqrt(max(p * (1 - p), 1e-9) / K) + 1e-6, (a, acc.mean())
+        np.testing.assert_array_equal(new[0], acc)
+        np.testing.assert_array_equal(new[1], acc)
+        assert (margin >= 0).all()
+    new, acc, _ = oracle.mh_accept(np.array([np.nan, np.inf, -np.inf], np.float32), (1, 2), np.zeros((1, 3)), np.ones((1, 3)))
+    assert acc.tolist() == [0.0, 1.0, 0.0]
+    # the uniforms are those of the key: another key, other decisions; the same key, the same
+    a1 = oracle.mh_accept(np.full(1000, -0.7, np.float32), (1, 2), np.zeros((1, 1000)), np.ones((1, 1000)))[1]
+    a2 = oracle.mh_accept(np.full(1000, -0.7, np.float32), (1, 3), np.zeros((1, 1000)), np.ones((1, 1000)))[1]
+    a3 = oracle.mh_accept(np.full(1000, -0.7, np.float32), (1, 2), np.zeros((1, 1000)), np.ones((1, 1000)))[1]
+    assert (a1 != a2).any() and (a1 == a3).all()
