@@ -271,8 +271,10 @@ def run_with_moves(bf, key: Key, constraint: ChoiceMap, args, moves, device=None
                                 ancestors=anc, store_inputs=True)
     incs = lse[:, 3]
     last = progs[-1]
+    # (the resamplers flag a collection without weight — identity ancestors — in their workspace's status word: read once, here)
+    st = kernels.workspace_status(ws_res, raise_on_error=False) if T > 1 else 0
     return dict(log_ml=incs.sum(), increments=incs, lse_steps=lse, choices=rows[(T - 1) & 1][: max(last.n_slots, 1)], logw=logw[(T - 1) & 1],
-                programs=progs, ancestors=anc_all if keep_ancestors else anc, degenerate=False, accepted=[int(a) for a in accepted],
+                programs=progs, ancestors=anc_all if keep_ancestors else anc, degenerate=bool(st & 2), accepted=[int(a) for a in accepted],
                 info=dict(form=A.FILTER_FORM_TWO_LAUNCH, form_name="step by step with moves (device calls per step)", launches=None, grid=0,
                           tiles_per_block=0))
 
