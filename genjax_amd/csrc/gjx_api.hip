@@ -117,19 +117,27 @@ __global__ __launch_bounds__(256) void k_threefry(key2 key, uint32_t ctr_hi, uin
 namespace gjx {
 __global__ __launch_bounds__(256) void k_mh_accept(const float* __restrict__ log_alpha, int64_t K, key2 key, float* rows_cur, const float* __restrict__ rows_prop,
                                                    int64_t stride, int rows, float* accepted, unsigned long long* total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool acc = false;
-  if (i < K) {
+  // (grid-stride over at most 512 blocks and ONE atomic per block: per-wave atomics on one address cost more than the accept itself)
+  __shared__ unsigned wcount[4];
+  unsigned n = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < K; i += (int64_t)gridDim.x * 256) {
     const key2 h = threefry2x32(key, (uint32_t)((uint64_t)i >> 32), (uint32_t)i);
     const float lu = safe_log(uniform_from_bits(h.a ^ h.b, kTiny, 1.0f));
-    acc = lu < log_alpha[i];                      // (NaN: false)
+    const bool acc = lu < log_alpha[i];           // (NaN: false)
     if (acc)
       for (int r = 0; r < rows; ++r) rows_cur[(int64_t)r * stride + i] = rows_prop[(int64_t)r * stride + i];
     if (accepted) accepted[i] = acc ? 1.0f : 0.0f;
+    n += acc ? 1u : 0u;
   }
   if (total) {
-    const unsigned long long m = __ballot(acc);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+      if (t) atomicAdd(total, (unsigned long long)t);
+    }
   }
 }
 }  // namespace gjx
@@ -138,7 +146,8 @@ extern "C" int gjx_mh_accept(const float* log_alpha, int64_t K, uint32_t key0, u
                              int64_t row_stride, int32_t rows, float* accepted, void* accepted_total, void* stream) {
   if (!log_alpha || K < 0 || rows < 0 || (rows > 0 && (!rows_cur || !rows_prop || row_stride < K))) return gjx_fail(GJX_EINVAL, "gjx_mh_accept: bad argument");
   if (K == 0) return GJX_OK;
-  hipLaunchKernelGGL(gjx::k_mh_accept, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_alpha, K, gjx::key2{key0, key1},
+  const int64_t nb = (K + 255) / 256;
+  hipLaunchKernelGGL(gjx::k_mh_accept, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(256), 0, (hipStream_t)stream, log_alpha, K, gjx::key2{key0, key1},
                      rows_cur, rows_prop, row_stride, (int)rows, accepted, (unsigned long long*)accepted_total);
   GJX_CHECK_LAUNCH("gjx_mh_accept");
   return GJX_OK;

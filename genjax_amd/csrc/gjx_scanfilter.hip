@@ -28,10 +28,20 @@ using namespace gjx;
 // kernel's first step polls / reads (gjx_gen_steps)
 static __global__ void k_clear_status(unsigned* ctrl) { if (threadIdx.x == 0) ctrl[2] = 0u; }
 // accepted chains of one HMC move (gjx_hmc's flags f32[K]) added to the run's counter
+// (a grid-stride loop over at most 64 blocks, ONE atomic per block: a wave-level atomic per 64 chains — 1024 of them on one address at
+// K = 2^16 — took 13 us, four times the HMC kernel it counts for; rocprofv3, profiles/r06_moves_kernel_stats.csv)
 static __global__ __launch_bounds__(256) void k_count_flags(const float* flags, int64_t K, unsigned long long* total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long m = __ballot(i < K && flags[i] > 0.5f);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+  __shared__ unsigned wcount[4];
+  unsigned n = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < K; i += (int64_t)gridDim.x * 256) n += flags[i] > 0.5f ? 1u : 0u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+  if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (t) atomicAdd(total, (unsigned long long)t);
+  }
 }
 
 static __global__ void k_merge_status(unsigned* from, unsigned* to) { if (threadIdx.x == 0 && from[2]) { atomicOr(&to[2], from[2]); from[2] = 0u; } }
@@ -277,7 +287,7 @@ static int scan_filter_impl(const gjx_program* steps, int32_t T, uint32_t key0, 
                        opts->hmc_workspace, opts->hmc_workspace_bytes, stream);
           if (rc) return rc;
           if (opts->accepted_total) {
-            hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st0, (const float*)(opts->hmc_out + 2 * (size_t)K), K,
+            hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((K + 255) / 256 < 64 ? (K + 255) / 256 : 64)), dim3(256), 0, st0, (const float*)(opts->hmc_out + 2 * (size_t)K), K,
                                (unsigned long long*)opts->accepted_total);
             GJX_CHECK_LAUNCH("gjx_scan_filter(accepted chains)");
           }
