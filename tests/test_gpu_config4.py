@@ -144,7 +144,7 @@ def _generic_filter_worker(rank, world, port, K_total, T, dx, out_dir, env):
         torch.cuda.set_device(0)
         scan, carry0, s = workloads.lgssm_scan(dx, T)
         ys = np.asarray(s["y"], np.float32)
-        bf = BootstrapFilter(scan, K_total // world)
+        bf = BootstrapFilter(scan, K_total // world, resampler=env.get("GJX_TEST_RESAMPLER", "systematic"))
         rows = max(p.n_slots for p in bf.step_programs(C["y"].set(ys), (carry0, None)))
         ctx = kernels.PeerContext(K_total // world, rows, "cuda")
         o = bf.run_peer(ctx, genjax.key(7), C["y"].set(ys), (carry0, None), want_ancestors=True)
@@ -163,22 +163,24 @@ def _generic_filter_worker(rank, world, port, K_total, T, dx, out_dir, env):
         raise
 
 
-def test_config4_generic_filter_dry_run(tmp_path):
+@pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
+def test_config4_generic_filter_dry_run(tmp_path, resampler):
     """config 4's workload with the model written as @gen + .scan: 8 ranks x 2^19 particles, T = 256, d_x = 8, GJX_PEER_VERIFY=1 —
     gjx_scan_filter_peer (the filter kernel GENERATED for the step program on the shared skeleton, sharded flavour).  Required:
     states, log-weights and ancestors bit-identical to the one-rank generic filter at K = 2^22, log-ML within rtol 1e-4 of the float64
-    Kalman value, status word 0 on every rank"""
+    Kalman value, status word 0 on every rank.  resampler="multinomial": north_star's "multinomial resampling" over the sharded
+    collection by sorted uniforms (gjx_scan_filter_peer_opts) at the full size of config 4"""
     import genjax_amd as genjax
     from genjax_amd import C, workloads
     from genjax_amd.inference import BootstrapFilter
     from oracle import closed_form as cf
     world, K_total, T, dx = 8, 1 << 22, 256, 8
-    res = _run_ranks(_generic_filter_worker, world, (K_total, T, dx, str(tmp_path), dict(GJX_PEER_VERIFY="1")), str(tmp_path))
+    res = _run_ranks(_generic_filter_worker, world, (K_total, T, dx, str(tmp_path), dict(GJX_PEER_VERIFY="1", GJX_TEST_RESAMPLER=resampler)), str(tmp_path))
     assert all(int(r["status"]) == 0 for r in res), [int(r["status"]) for r in res]
     assert all(int(r["share"]) == world for r in res)
     scan, carry0, s = workloads.lgssm_scan(dx, T)
     ys = np.asarray(s["y"], np.float32)
-    bf = BootstrapFilter(scan, K_total)
+    bf = BootstrapFilter(scan, K_total, resampler=resampler)
     ref = bf.run(genjax.key(7), C["y"].set(ys), (carry0, None))
     assert not ref["degenerate"]
     np.testing.assert_array_equal(np.concatenate([r["x"] for r in res], axis=1), bf.latent(ref, "x").cpu().numpy())
